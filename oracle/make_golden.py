@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the
+UNMODIFIED reference compiled into oracle/_ref (run `make -C oracle` first).
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs oracle/_ref and
+therefore /root/reference); the fixtures it writes are what travels.
+
+Fixtures:
+  en_us_ptm_tables.npz     model tables as the reference holds them after init
+  ptm_<case>.npz           PTM scorer goldens (compallsen) for several inputs
+  senlog_default.npz       every frame_eval call of a default-mode decode
+  decode_<mode>.npz        hypothesis + segmentation goldens
+
+Large per-frame outputs are stored as 64-bit FNV-1a row hashes for every frame
+plus the full rows of a frame sample (tests recompute the hashes).
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from psgb import read_psgb  # noqa: E402
+from pso import row_hash  # noqa: E402
+
+REF = os.path.join(HERE, "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+MODEL = os.path.join(REF, "model", "en-us")
+LM = os.path.join(REF, "data", "turtle.lm.bin")
+DIC = os.path.join(REF, "data", "turtle.dic")
+RAW = os.path.join(REF, "data", "goforward.raw")
+SEED = 20260921
+
+
+def ref_dump(cmd, *args, extra=()):
+    with tempfile.NamedTemporaryFile(suffix=".psgb", delete=False) as fh:
+        out = fh.name
+    argv = [os.path.join(REF, "ref_dump"), cmd, out, MODEL, LM, DIC] + [str(a) for a in args]
+    if extra:
+        argv += ["--"] + [str(e) for e in extra]
+    subprocess.check_call(argv)
+    d = read_psgb(out)
+    os.unlink(out)
+    return d
+
+
+def synth_feats(t, n, rng):
+    """x[t][d] ~ N(mu_d, sigma_d^2) with mu/sigma the
+    per-dimension mean/std of the model means."""
+    n_mgau, n_feat, n_den = int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0])
+    fl = int(t["featlen"][0])
+    mean = t["mean"].reshape(n_mgau, n_feat, n_den, fl)
+    mu = mean.mean(axis=(0, 2)).reshape(-1)
+    sd = mean.std(axis=(0, 2)).reshape(-1)
+    return (mu + sd * rng.standard_normal((n, mu.size))).astype(np.float32)
+
+
+def adversarial_feats(t, n, rng):
+    """(C): every stream sits on (or a hair off) a codeword mean of a random
+    codebook, so distances land on/near det values and near-ties appear."""
+    n_mgau, n_feat, n_den = int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0])
+    fl = int(t["featlen"][0])
+    mean = t["mean"].reshape(n_mgau, n_feat, n_den, fl)
+    x = np.empty((n, n_feat, fl), np.float32)
+    for i in range(n):
+        for f in range(n_feat):
+            cb = rng.integers(n_mgau); cw = rng.integers(n_den)
+            eps = (0.0 if i % 3 == 0 else 1e-3 * rng.standard_normal(fl))
+            x[i, f] = mean[cb, f, cw] + eps
+    return x.reshape(n, n_feat * fl)
+
+
+def ptm_case(name, feats, seglen, carry, dup=0, full_topn=False, sample=16):
+    with tempfile.NamedTemporaryFile(suffix=".f32", delete=False) as fh:
+        feats.astype(np.float32).tofile(fh)
+        fpath = fh.name
+    d = ref_dump("ptm", fpath, seglen, carry, dup)
+    os.unlink(fpath)
+    T = feats.shape[0]
+    idx = np.unique(np.linspace(0, T - 1, sample).astype(np.int64))
+    topn = np.concatenate([d["topn_cw"].reshape(T, -1).astype(np.int32),
+                           d["topn_raw"].reshape(T, -1)], axis=1)
+    out = dict(feat=feats.astype(np.float32), seglen=np.int32(seglen), carry=np.int32(carry),
+               dup=np.int32(dup),
+               senscr_hash=row_hash(d["senscr"]), topn_hash=row_hash(topn),
+               sample_idx=idx, senscr_sample=d["senscr"][idx],
+               topn_cw_sample=d["topn_cw"][idx], topn_raw_sample=d["topn_raw"][idx],
+               topn_norm_sample=d["topn_norm"][idx])
+    if full_topn:
+        out["topn_cw"] = d["topn_cw"]; out["topn_raw"] = d["topn_raw"]
+    np.savez_compressed(os.path.join(GOLD, "ptm_%s.npz" % name), **out)
+    print("ptm_%s: T=%d" % (name, T))
+    return d
+
+
+def senlog_case(name, nrep, extra=()):
+    d = ref_dump("senlog", RAW, nrep, extra=extra)
+    n = int(d["n_calls"][0])
+    idx = np.unique(np.linspace(0, n - 1, 24).astype(np.int64))
+    out = {k: v for k, v in d.items() if k.startswith("utt") or k.startswith("call_")}
+    scr = out.pop("call_scr")
+    out["call_scr_hash"] = row_hash(scr)
+    out["sample_idx"] = idx
+    out["call_scr_sample"] = scr[idx]
+    out["extra"] = np.array(list(extra), dtype="U")
+    np.savez_compressed(os.path.join(GOLD, "senlog_%s.npz" % name), **out)
+    print("senlog_%s: %d calls, hyp=%r" % (name, n, bytes(d["utt0_hyp"]).decode()))
+
+
+def decode_case(name, extra=()):
+    d = ref_dump("decode", RAW, extra=extra)
+    d["extra"] = np.array(list(extra), dtype="U")
+    np.savez_compressed(os.path.join(GOLD, "decode_%s.npz" % name), **d)
+    print("decode_%s: hyp=%r score=%d" % (name, bytes(d["hyp"]).decode(), int(d["hyp_score"][0])))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    t = ref_dump("tables")
+    np.savez_compressed(os.path.join(GOLD, "en_us_ptm_tables.npz"), **t)
+    print("tables:", {k: v.shape for k, v in t.items() if v.size > 1})
+
+    gof = ref_dump("feats", RAW)["feat"]
+    rng = np.random.default_rng(SEED)
+    ptm_case("goforward", gof, gof.shape[0], 0, full_topn=True)
+    ptm_case("goforward_x2_carry", np.concatenate([gof, gof]), gof.shape[0], 1)
+    ptm_case("synth", synth_feats(t, 1500, rng), 1500, 0)
+    ptm_case("synth_utts", synth_feats(t, 6 * 100, rng), 100, 0)
+    ptm_case("adversarial", adversarial_feats(t, 512, rng), 512, 0)
+    ptm_case("dup_ties", adversarial_feats(t, 384, rng), 128, 1, dup=1)
+
+    senlog_case("default", 2)
+    senlog_case("fwdtree_only", 1, extra=("fwdflat", "no", "bestpath", "no"))
+    decode_case("default")
+    decode_case("fwdtree_only", extra=("fwdflat", "no", "bestpath", "no"))
+    decode_case("compallsen_plw0", extra=("compallsen", "yes", "pl_window", "0"))
+
+
+if __name__ == "__main__":
+    main()

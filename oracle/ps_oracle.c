@@ -1,0 +1,637 @@
+/* oracle/ps_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the PocketSphinx acoustic-scoring / Viterbi-step
+ * arithmetic, written from the behaviour specified in SURVEY.md section 8(a)
+ * and checked against the compiled reference (see ps_oracle.h for the parity
+ * statement).  Compile with -ffp-contract=off: the Gaussian distance is a
+ * strictly sequential fp32 sub/mul/mul/sub chain with no fused multiply-add
+ * (SURVEY F5).
+ *
+ * Citations are to files under /root/reference/src.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include "ps_oracle.h"
+
+/* ================================================================== */
+/* PTM scorer                                                          */
+/* ================================================================== */
+
+struct pso_ptm_s {
+    int n_mgau, n_feat, n_density, n_sen, topn, ds_ratio, n_hist;
+    int32_t *featlen;
+    int32_t *featoff;        /* offset of stream f inside a frame vector */
+    int64_t *cboff;          /* float offset of (mgau, feat) block in mean/var */
+    int veclen;
+    const float *mean, *var, *det;
+    const uint8_t *mixw, *mixw_cb, *sen2cb, *logadd8;
+    int logadd8_size;
+    /* history ring (ptm_mgau.h:68-71, ptm_mgau.c:884-890) */
+    pso_topn_t *hist;        /* [n_hist][n_mgau][n_feat][topn] */
+    uint8_t *hist_active;    /* [n_hist][n_mgau] */
+    int cur;                 /* current slot (s->f) */
+    int frame_idx;           /* ps_mgau_t.frame_idx (acmod.h:113-116) */
+};
+
+static size_t
+slot_len(const pso_ptm_t *s)
+{
+    return (size_t)s->n_mgau * s->n_feat * s->topn;
+}
+
+pso_ptm_t *
+pso_ptm_new(int n_mgau, int n_feat, int n_density, const int32_t *featlen,
+            int n_sen, int topn, int ds_ratio, int n_fast_hist,
+            const float *mean, const float *var, const float *det,
+            const uint8_t *mixw, const uint8_t *mixw_cb, const uint8_t *sen2cb,
+            const uint8_t *logadd8, int logadd8_size)
+{
+    pso_ptm_t *s = calloc(1, sizeof(*s));
+    int m, f;
+    int64_t o = 0;
+    s->n_mgau = n_mgau; s->n_feat = n_feat; s->n_density = n_density;
+    s->n_sen = n_sen; s->topn = topn; s->ds_ratio = ds_ratio; s->n_hist = n_fast_hist;
+    s->featlen = malloc(sizeof(int32_t) * n_feat);
+    s->featoff = malloc(sizeof(int32_t) * n_feat);
+    s->cboff = malloc(sizeof(int64_t) * n_mgau * n_feat);
+    for (f = 0; f < n_feat; ++f) {
+        s->featlen[f] = featlen[f];
+        s->featoff[f] = s->veclen;
+        s->veclen += featlen[f];
+    }
+    for (m = 0; m < n_mgau; ++m)
+        for (f = 0; f < n_feat; ++f) {
+            s->cboff[m * n_feat + f] = o;
+            o += (int64_t)n_density * featlen[f];
+        }
+    s->mean = mean; s->var = var; s->det = det;
+    s->mixw = mixw; s->mixw_cb = mixw_cb; s->sen2cb = sen2cb;
+    s->logadd8 = logadd8; s->logadd8_size = logadd8_size;
+    s->hist = malloc(sizeof(pso_topn_t) * slot_len(s) * n_fast_hist);
+    s->hist_active = malloc((size_t)n_fast_hist * n_mgau);
+    pso_ptm_reset_hist(s);
+    return s;
+}
+
+void
+pso_ptm_free(pso_ptm_t *s)
+{
+    if (!s) return;
+    free(s->featlen); free(s->featoff); free(s->cboff);
+    free(s->hist); free(s->hist_active);
+    free(s);
+}
+
+/* ptm_mgau.c:777-802: every list starts as cw = 0..N-1, score = WORST_DIST,
+ * every codebook flagged active. */
+void
+pso_ptm_reset_hist(pso_ptm_t *s)
+{
+    size_t i, n = slot_len(s) * s->n_hist;
+    for (i = 0; i < n; ++i) {
+        s->hist[i].cw = (int32_t)(i % s->topn);
+        s->hist[i].score = PSO_WORST_DIST;
+    }
+    memset(s->hist_active, 1, (size_t)s->n_hist * s->n_mgau);
+    s->cur = 0;
+}
+
+void pso_ptm_set_frame_idx(pso_ptm_t *s, int v) { s->frame_idx = v; }
+int pso_ptm_get_frame_idx(const pso_ptm_t *s) { return s->frame_idx; }
+
+const pso_topn_t *
+pso_ptm_cur_topn(const pso_ptm_t *s)
+{
+    return s->hist + slot_len(s) * s->cur;
+}
+
+/* The Gaussian "distance": d = det - sum_j ((x_j - m_j)^2 * v_j), evaluated
+ * left to right in fp32 (ptm_mgau.c:64-69 macros, :102-128, :182-209; the
+ * reference's 1-then-4x grouping is the same left-to-right order). */
+static float
+gau_dist(float d, const float *x, const float *m, const float *v, int len)
+{
+    int j;
+    for (j = 0; j < len; ++j) {
+        float diff = x[j] - m[j];
+        float sq = diff * diff;
+        float c = sq * v[j];
+        d = d - c;
+    }
+    return d;
+}
+
+/* float -> int32 as the reference does it (ptm_mgau.c:129-132, :220-223) */
+static int32_t
+dist_to_int(float d)
+{
+    if (d < (float)PSO_MAX_NEG_INT32)
+        return PSO_MAX_NEG_INT32;
+    return (int32_t)d;
+}
+
+/* eval_topn (ptm_mgau.c:87-136) with insertion_sort_topn (:71-85) */
+static void
+rescore_seed_list(const pso_ptm_t *s, pso_topn_t *tl, int cb, int f, const float *x)
+{
+    int len = s->featlen[f], i;
+    int64_t base = s->cboff[cb * s->n_feat + f];
+    const float *det = s->det + ((size_t)cb * s->n_feat + f) * s->n_density;
+    for (i = 0; i < s->topn; ++i) {
+        int cw = tl[i].cw, j;
+        float d = gau_dist(det[cw], x, s->mean + base + (int64_t)cw * len,
+                           s->var + base + (int64_t)cw * len, len);
+        int32_t sc = dist_to_int(d);
+        pso_topn_t e;
+        e.cw = cw; e.score = sc;
+        /* bubble entry i upward past strictly worse entries */
+        for (j = i - 1; j >= 0 && sc > tl[j].score; --j)
+            tl[j + 1] = tl[j];
+        tl[j + 1] = e;
+    }
+}
+
+/* eval_cb (ptm_mgau.c:151-226) with insertion_sort_cb (:140-149).  The
+ * reference abandons a codeword as soon as the partial distance drops below
+ * the threshold; since every subtracted term is >= 0 that is equivalent to
+ * testing the completed distance, which is what is done here. */
+static void
+scan_codebook(const pso_ptm_t *s, pso_topn_t *tl, int cb, int f, const float *x)
+{
+    int len = s->featlen[f], N = s->topn, cw;
+    int64_t base = s->cboff[cb * s->n_feat + f];
+    const float *det = s->det + ((size_t)cb * s->n_feat + f) * s->n_density;
+    for (cw = 0; cw < s->n_density; ++cw) {
+        float thresh = (float)tl[N - 1].score;
+        float d = gau_dist(det[cw], x, s->mean + base + (int64_t)cw * len,
+                           s->var + base + (int64_t)cw * len, len);
+        int i, p;
+        int32_t sc;
+        if (d < thresh)
+            continue;
+        for (i = 0; i < N; ++i)
+            if (tl[i].cw == cw)
+                break;
+        if (i < N)
+            continue;
+        sc = dist_to_int(d);
+        /* goes ahead of equal scores; the old worst entry falls off */
+        for (p = N - 1; p > 0 && sc >= tl[p - 1].score; --p)
+            tl[p] = tl[p - 1];
+        tl[p].cw = cw;
+        tl[p].score = sc;
+    }
+}
+
+/* fast_logmath_add (tied_mgau_common.h:106-125); operands are negated logs.
+ * The reference indexes the table without a bound check; the table is
+ * "never smaller than 256 entries" and its tail is zero, so an index beyond
+ * it is treated as zero here. */
+static int
+logadd8(const pso_ptm_t *s, int x, int y)
+{
+    int d, r;
+    if (x > y) { d = x - y; r = y; }
+    else       { d = y - x; r = x; }
+    return r - (d < s->logadd8_size ? s->logadd8[d] : 0);
+}
+
+int
+pso_ptm_frame_eval(pso_ptm_t *s, int16_t *senscr,
+                   const uint8_t *senone_active, int32_t n_senone_active,
+                   const float *feat, int32_t frame, int32_t compallsen,
+                   pso_topn_t *raw_topn)
+{
+    int N = s->topn, evaluated = 0;
+    int slot = frame % s->n_hist;               /* ptm_mgau.c:425-426 */
+    pso_topn_t *cur = s->hist + slot_len(s) * slot;
+    uint8_t *active = s->hist_active + (size_t)slot * s->n_mgau;
+    int cb, f, k, i, lastsen, best;
+
+    s->cur = slot;
+    if (frame >= s->frame_idx) {                /* ptm_mgau.c:430 */
+        int prev = (slot == 0) ? s->n_hist - 1 : slot - 1;
+        evaluated = 1;
+        memcpy(cur, s->hist + slot_len(s) * prev, sizeof(pso_topn_t) * slot_len(s));
+        /* ptm_mgau_calc_cb_active (:297-321) */
+        if (compallsen)
+            memset(active, 1, s->n_mgau);
+        else {
+            memset(active, 0, s->n_mgau);
+            for (lastsen = i = 0; i < n_senone_active; ++i) {
+                int sen = senone_active[i] + lastsen;
+                active[s->sen2cb[sen]] = 1;
+                lastsen = sen;
+            }
+        }
+        /* ptm_mgau_codebook_eval (:231-254): seeds of EVERY codebook are
+         * re-scored, only active ones are scanned, and only on frames that
+         * are multiples of the downsampling ratio. */
+        for (cb = 0; cb < s->n_mgau; ++cb)
+            for (f = 0; f < s->n_feat; ++f)
+                rescore_seed_list(s, cur + ((size_t)cb * s->n_feat + f) * N, cb, f,
+                                  feat + s->featoff[f]);
+        if (frame % s->ds_ratio == 0) {
+            for (cb = 0; cb < s->n_mgau; ++cb) {
+                if (!active[cb]) continue;
+                for (f = 0; f < s->n_feat; ++f)
+                    scan_codebook(s, cur + ((size_t)cb * s->n_feat + f) * N, cb, f,
+                                  feat + s->featoff[f]);
+            }
+        }
+        if (raw_topn)
+            memcpy(raw_topn, cur, sizeof(pso_topn_t) * slot_len(s));
+        /* ptm_mgau_codebook_norm (:265-295) */
+        for (f = 0; f < s->n_feat; ++f) {
+            int32_t norm = PSO_WORST_SCORE;
+            for (cb = 0; cb < s->n_mgau; ++cb) {
+                int32_t top;
+                if (!active[cb]) continue;
+                top = cur[((size_t)cb * s->n_feat + f) * N].score >> PSO_SENSCR_SHIFT;
+                if (norm < top) norm = top;
+            }
+            for (cb = 0; cb < s->n_mgau; ++cb) {
+                pso_topn_t *tl = cur + ((size_t)cb * s->n_feat + f) * N;
+                if (!active[cb]) continue;
+                for (k = 0; k < N; ++k) {
+                    int32_t v = tl[k].score >> PSO_SENSCR_SHIFT;
+                    v = v - norm;   /* wraps like the reference's int arithmetic */
+                    v = -v;
+                    if (v > PSO_MAX_NEG_ASCR) v = PSO_MAX_NEG_ASCR;
+                    tl[k].score = v;
+                }
+            }
+        }
+    }
+
+    /* ptm_mgau_senone_eval (:326-403) */
+    memset(senscr, 0, sizeof(int16_t) * s->n_sen);
+    if (compallsen)
+        n_senone_active = s->n_sen;
+    best = 0x7fffffff;
+    for (lastsen = i = 0; i < n_senone_active; ++i) {
+        int sen = compallsen ? i : senone_active[i] + lastsen;
+        int ascore = 0;
+        lastsen = sen;
+        cb = s->sen2cb[sen];
+        if (!active[cb]) {
+            /* persistent overwrite of the slot (:353-364) */
+            for (f = 0; f < s->n_feat; ++f)
+                for (k = 0; k < N; ++k)
+                    cur[((size_t)cb * s->n_feat + f) * N + k].score = PSO_MAX_NEG_ASCR;
+        }
+        for (f = 0; f < s->n_feat; ++f) {
+            const pso_topn_t *tl = cur + ((size_t)cb * s->n_feat + f) * N;
+            int fden = 0;
+            for (k = 0; k < N; ++k) {
+                int w;
+                if (s->mixw_cb) {
+                    /* 4-bit clustered weights; the nibble is selected by the
+                     * low bit of the packed byte itself, as in the reference
+                     * (:375-379), not by the senone's parity. */
+                    size_t row = (size_t)(s->n_sen + 1) / 2;
+                    int dcw = s->mixw[((size_t)f * s->n_density + tl[k].cw) * row + sen / 2];
+                    dcw = (dcw & 1) ? dcw >> 4 : dcw & 0x0f;
+                    w = s->mixw_cb[dcw];
+                }
+                else
+                    w = s->mixw[((size_t)f * s->n_density + tl[k].cw) * s->n_sen + sen];
+                if (k == 0)
+                    fden = w + tl[k].score;
+                else
+                    fden = logadd8(s, fden, w + tl[k].score);
+            }
+            ascore += fden;
+        }
+        if (ascore < best) best = ascore;
+        senscr[sen] = (int16_t)ascore;
+    }
+    for (i = 0; i < s->n_sen; ++i)              /* :398-400, int16 store */
+        senscr[i] = (int16_t)(senscr[i] - best);
+    return evaluated;
+}
+
+void
+pso_ptm_score_utt(pso_ptm_t *s, const float *feats, int T, int reset_hist,
+                  int16_t *senscr, uint8_t *topn_cw, int32_t *topn_raw)
+{
+    size_t L = slot_len(s), i;
+    pso_topn_t *raw = malloc(sizeof(pso_topn_t) * L);
+    int16_t *row = malloc(sizeof(int16_t) * s->n_sen);
+    int t;
+    if (reset_hist) pso_ptm_reset_hist(s);
+    s->frame_idx = 0;                            /* acmod_start_utt, acmod.c:419 */
+    for (t = 0; t < T; ++t) {
+        pso_ptm_frame_eval(s, senscr ? senscr + (size_t)t * s->n_sen : row, NULL, 0,
+                           feats + (size_t)t * s->veclen, t, 1, raw);
+        for (i = 0; i < L; ++i) {
+            if (topn_cw) topn_cw[(size_t)t * L + i] = (uint8_t)raw[i].cw;
+            if (topn_raw) topn_raw[(size_t)t * L + i] = raw[i].score;
+        }
+        s->frame_idx++;                          /* acmod_advance, acmod.c:874 */
+    }
+    free(raw); free(row);
+}
+
+/* ================================================================== */
+/* acmod_flags2list (acmod.c:1223-1275)                                */
+/* ================================================================== */
+int
+pso_flags2list(const uint8_t *flags, int n_sen, uint8_t *deltas)
+{
+    int n = 0, last = 0, sen;
+    for (sen = 0; sen < n_sen; ++sen) {
+        int delta;
+        if (!flags[sen]) continue;
+        delta = sen - last;
+        while (delta > 255) {       /* lossy bridge: the bridging entries get scored too */
+            deltas[n++] = 255;
+            delta -= 255;
+        }
+        deltas[n++] = (uint8_t)delta;
+        last = sen;
+    }
+    return n;
+}
+
+/* ================================================================== */
+/* HMM Viterbi step (hmm.c:222-805)                                    */
+/* ================================================================== */
+
+#define W PSO_WORST_SCORE
+
+static inline int32_t clampw(int32_t v) { return v < W ? W : v; }
+
+/* hmm_vit_eval_3st_lr (hmm.c:529-607) */
+static int32_t
+vit3(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
+{
+    const uint8_t *tp = ctx->tp + (size_t)h->tmatid * 3 * 4;
+    const int16_t *ss = ctx->senscore;
+#define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
+    int32_t s2 = h->score[2] - ss[h->senid[2]];
+    int32_t s1 = h->score[1] - ss[h->senid[1]];
+    int32_t s0 = h->score[0] - ss[h->senid[0]];
+    int32_t best = W, t0, t1, t2 = INT_MIN, s3;
+
+    if (s1 > W) {
+        t1 = s2 + TP(2, 3);
+        if (TP(1, 3) > -PSO_TMAT_WORST)
+            t2 = s1 + TP(1, 3);
+        if (t1 > t2) { s3 = t1; h->out_history = h->history[2]; }
+        else         { s3 = t2; h->out_history = h->history[1]; }
+        s3 = clampw(s3);
+        h->out_score = s3;
+        best = s3;
+    }
+    t0 = s2 + TP(2, 2);
+    t1 = s1 + TP(1, 2);
+    if (TP(0, 2) > -PSO_TMAT_WORST)
+        t2 = s0 + TP(0, 2);         /* otherwise t2 keeps its previous value */
+    if (t0 > t1) {
+        if (t2 > t0) { s2 = t2; h->history[2] = h->history[0]; }
+        else s2 = t0;
+    }
+    else {
+        if (t2 > t1) { s2 = t2; h->history[2] = h->history[0]; }
+        else { s2 = t1; h->history[2] = h->history[1]; }
+    }
+    s2 = clampw(s2);
+    if (s2 > best) best = s2;
+    h->score[2] = s2;
+
+    t0 = s1 + TP(1, 1);
+    t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h->history[1] = h->history[0]; }
+    s1 = clampw(s1);
+    if (s1 > best) best = s1;
+    h->score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    if (s0 > best) best = s0;
+    h->score[0] = s0;
+    h->bestscore = best;
+    return best;
+#undef TP
+}
+
+/* hmm_vit_eval_3st_lr_mpx (hmm.c:609-707) */
+static int32_t
+vit3_mpx(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
+{
+    const uint8_t *tp = ctx->tp + (size_t)h->tmatid * 3 * 4;
+    const int16_t *ss = ctx->senscore;
+    uint16_t *ssid = h->senid;
+#define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
+#define SEN(st) (-(int32_t)ss[ctx->sseq[(size_t)ssid[st] * 3 + (st)]])
+    int32_t s3, s2, s1, s0, t0, t1, t2 = INT_MIN, best;
+
+    if (ssid[2] == PSO_BAD_SSID) s2 = t1 = W;
+    else { s2 = h->score[2] + SEN(2); t1 = s2 + TP(2, 3); }
+    if (ssid[1] == PSO_BAD_SSID) s1 = t2 = W;
+    else {
+        s1 = h->score[1] + SEN(1);
+        if (TP(1, 3) > -PSO_TMAT_WORST) t2 = s1 + TP(1, 3);
+    }
+    if (t1 > t2) { s3 = t1; h->out_history = h->history[2]; }
+    else         { s3 = t2; h->out_history = h->history[1]; }
+    s3 = clampw(s3);
+    h->out_score = s3;
+    best = s3;
+
+    s0 = h->score[0] + SEN(0);
+    t0 = t1 = W;
+    if (s2 != W) t0 = s2 + TP(2, 2);
+    if (s1 != W) t1 = s1 + TP(1, 2);
+    if (TP(0, 2) > -PSO_TMAT_WORST) t2 = s0 + TP(0, 2);
+    if (t0 > t1) {
+        if (t2 > t0) { s2 = t2; h->history[2] = h->history[0]; ssid[2] = ssid[0]; }
+        else s2 = t0;
+    }
+    else {
+        if (t2 > t1) { s2 = t2; h->history[2] = h->history[0]; ssid[2] = ssid[0]; }
+        else { s2 = t1; h->history[2] = h->history[1]; ssid[2] = ssid[1]; }
+    }
+    s2 = clampw(s2);
+    if (s2 > best) best = s2;
+    h->score[2] = s2;
+
+    t0 = W;
+    if (s1 != W) t0 = s1 + TP(1, 1);
+    t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h->history[1] = h->history[0]; ssid[1] = ssid[0]; }
+    s1 = clampw(s1);
+    if (s1 > best) best = s1;
+    h->score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    if (s0 > best) best = s0;
+    h->score[0] = s0;
+    h->bestscore = best;
+    return best;
+#undef TP
+#undef SEN
+}
+
+/* three-way arg-max used for states 2..4 of the 5-state topologies: the
+ * self loop t0, the neighbour t1 (from `nb`), the skip t2 (from `sk`). */
+#define PICK3(dst, T0, T1, T2, nb, sk, MPX)                                  \
+    do {                                                                     \
+        if ((T0) > (T1)) {                                                   \
+            if ((T2) > (T0)) { dst = (T2); h->history[(nb) + 1] = h->history[sk]; \
+                               if (MPX) ssid[(nb) + 1] = ssid[sk]; }         \
+            else dst = (T0);                                                 \
+        } else {                                                             \
+            if ((T2) > (T1)) { dst = (T2); h->history[(nb) + 1] = h->history[sk]; \
+                               if (MPX) ssid[(nb) + 1] = ssid[sk]; }         \
+            else { dst = (T1); h->history[(nb) + 1] = h->history[nb];        \
+                   if (MPX) ssid[(nb) + 1] = ssid[nb]; }                     \
+        }                                                                    \
+    } while (0)
+
+/* hmm_vit_eval_5st_lr (hmm.c:222-350) */
+static int32_t
+vit5(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
+{
+    const uint8_t *tp = ctx->tp + (size_t)h->tmatid * 5 * 6;
+    const int16_t *ss = ctx->senscore;
+    uint16_t *ssid = h->senid; /* unused by the non-mpx PICK3 expansion */
+#define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
+#define SEN(st) (-(int32_t)ss[h->senid[st]])
+    int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best = W;
+
+    s4 = h->score[4] + SEN(4);
+    s3 = h->score[3] + SEN(3);
+    if (s3 > W) {
+        t1 = s4 + TP(4, 5);
+        t2 = s3 + TP(3, 5);
+        if (t1 > t2) { s5 = t1; h->out_history = h->history[4]; }
+        else         { s5 = t2; h->out_history = h->history[3]; }
+        s5 = clampw(s5);
+        h->out_score = s5;
+        best = s5;
+    }
+    s2 = h->score[2] + SEN(2);
+    if (s2 > W) {
+        t0 = s4 + TP(4, 4); t1 = s3 + TP(3, 4); t2 = s2 + TP(2, 4);
+        PICK3(s4, t0, t1, t2, 3, 2, 0);
+        s4 = clampw(s4);
+        if (s4 > best) best = s4;
+        h->score[4] = s4;
+    }
+    s1 = h->score[1] + SEN(1);
+    if (s1 > W) {
+        t0 = s3 + TP(3, 3); t1 = s2 + TP(2, 3); t2 = s1 + TP(1, 3);
+        PICK3(s3, t0, t1, t2, 2, 1, 0);
+        s3 = clampw(s3);
+        if (s3 > best) best = s3;
+        h->score[3] = s3;
+    }
+    s0 = h->score[0] + SEN(0);
+    t0 = s2 + TP(2, 2); t1 = s1 + TP(1, 2); t2 = s0 + TP(0, 2);
+    PICK3(s2, t0, t1, t2, 1, 0, 0);
+    s2 = clampw(s2);
+    if (s2 > best) best = s2;
+    h->score[2] = s2;
+
+    t0 = s1 + TP(1, 1); t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h->history[1] = h->history[0]; }
+    s1 = clampw(s1);
+    if (s1 > best) best = s1;
+    h->score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    if (s0 > best) best = s0;
+    h->score[0] = s0;
+    h->bestscore = best;
+    (void)ssid;
+    return best;
+#undef TP
+#undef SEN
+}
+
+/* hmm_vit_eval_5st_lr_mpx (hmm.c:355-525) */
+static int32_t
+vit5_mpx(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
+{
+    const uint8_t *tp = ctx->tp + (size_t)h->tmatid * 5 * 6;
+    const int16_t *ss = ctx->senscore;
+    uint16_t *ssid = h->senid;
+#define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
+#define SEN(st) (-(int32_t)ss[ctx->sseq[(size_t)ssid[st] * 5 + (st)]])
+    int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best;
+
+    if (ssid[4] == PSO_BAD_SSID) s4 = t1 = W;
+    else { s4 = h->score[4] + SEN(4); t1 = s4 + TP(4, 5); }
+    if (ssid[3] == PSO_BAD_SSID) s3 = t2 = W;
+    else { s3 = h->score[3] + SEN(3); t2 = s3 + TP(3, 5); }
+    if (t1 > t2) { s5 = t1; h->out_history = h->history[4]; }
+    else         { s5 = t2; h->out_history = h->history[3]; }
+    s5 = clampw(s5);
+    h->out_score = s5;
+    best = s5;
+
+    if (ssid[2] == PSO_BAD_SSID) s2 = t2 = W;
+    else { s2 = h->score[2] + SEN(2); t2 = s2 + TP(2, 4); }
+    t0 = t1 = W;
+    if (s4 != W) t0 = s4 + TP(4, 4);
+    if (s3 != W) t1 = s3 + TP(3, 4);
+    PICK3(s4, t0, t1, t2, 3, 2, 1);
+    s4 = clampw(s4);
+    if (s4 > best) best = s4;
+    h->score[4] = s4;
+
+    if (ssid[1] == PSO_BAD_SSID) s1 = t2 = W;
+    else { s1 = h->score[1] + SEN(1); t2 = s1 + TP(1, 3); }
+    t0 = t1 = W;
+    if (s3 != W) t0 = s3 + TP(3, 3);
+    if (s2 != W) t1 = s2 + TP(2, 3);
+    PICK3(s3, t0, t1, t2, 2, 1, 1);
+    s3 = clampw(s3);
+    if (s3 > best) best = s3;
+    h->score[3] = s3;
+
+    s0 = h->score[0] + SEN(0);
+    t0 = t1 = W;
+    if (s2 != W) t0 = s2 + TP(2, 2);
+    if (s1 != W) t1 = s1 + TP(1, 2);
+    t2 = s0 + TP(0, 2);
+    PICK3(s2, t0, t1, t2, 1, 0, 1);
+    s2 = clampw(s2);
+    if (s2 > best) best = s2;
+    h->score[2] = s2;
+
+    t0 = W;
+    if (s1 != W) t0 = s1 + TP(1, 1);
+    t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h->history[1] = h->history[0]; ssid[1] = ssid[0]; }
+    s1 = clampw(s1);
+    if (s1 > best) best = s1;
+    h->score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    if (s0 > best) best = s0;
+    h->score[0] = s0;
+    h->bestscore = best;
+    return best;
+#undef TP
+#undef SEN
+}
+
+/* hmm_vit_eval (hmm.c:786-805).  Only the hard-wired 3- and 5-state
+ * topologies are restated; no bundled model reaches hmm_vit_eval_anytopo
+ * (SURVEY section 4). */
+int32_t
+pso_hmm_vit_eval(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
+{
+    if (h->n_emit_state == 3)
+        return h->mpx ? vit3_mpx(ctx, h) : vit3(ctx, h);
+    if (h->n_emit_state == 5)
+        return h->mpx ? vit5_mpx(ctx, h) : vit5(ctx, h);
+    return W;
+}

@@ -1,0 +1,121 @@
+/* oracle/ps_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the PocketSphinx hot path (acoustic scoring and
+ * the per-HMM Viterbi step) used as the checker for the HIP kernels and as the
+ * "port" CPU baseline of bench.py.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * here against fixtures under tests/golden/ that were produced by the
+ * unmodified reference compiled into oracle/_ref (generator:
+ * oracle/make_golden.py + oracle/ref_dump.c), and, when oracle/_ref is
+ * present, against the live reference library.
+ *
+ * Every function cites the reference file:line it restates
+ * (paths relative to /root/reference/src).
+ */
+#ifndef PS_ORACLE_H
+#define PS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSO_MAX_NEG_INT32 ((int32_t)0x80000000)   /* prim_type.h:168 */
+#define PSO_WORST_DIST    PSO_MAX_NEG_INT32       /* tied_mgau_common.h:60 */
+#define PSO_WORST_SCORE   ((int32_t)0xE0000000)   /* hmm.h:84 */
+#define PSO_SENSCR_SHIFT  10                      /* hmm.h:73 */
+#define PSO_MAX_NEG_ASCR  96                      /* tied_mgau_common.h:82 */
+#define PSO_BAD_SSID      0xffff                  /* hmm.h:89 */
+#define PSO_TMAT_WORST    255                     /* tmat.h: 8-bit floor */
+
+/* ---------------- PTM scorer (ptm_mgau.c) ---------------- */
+
+typedef struct pso_topn_s {
+    int32_t cw;
+    int32_t score;
+} pso_topn_t;
+
+typedef struct pso_ptm_s pso_ptm_t;
+
+/* Tables are borrowed (not copied); they must outlive the object.
+ *  mean/var : packed [n_mgau][n_feat][n_density][featlen[f]]  (ms_gauden.c:211-221)
+ *  det      : [n_mgau][n_feat][n_density]
+ *  mixw     : [n_feat][n_density][n_sen] (8-bit) or [..][(n_sen+1)/2] with a
+ *             16-entry mixw_cb (4-bit)                         (ptm_mgau.c:456-661)
+ *  logadd8  : uint8 table of logmath_init(base, 10, 1)          (logmath.c:62-162)
+ */
+pso_ptm_t *pso_ptm_new(int n_mgau, int n_feat, int n_density, const int32_t *featlen,
+                       int n_sen, int topn, int ds_ratio, int n_fast_hist,
+                       const float *mean, const float *var, const float *det,
+                       const uint8_t *mixw, const uint8_t *mixw_cb,
+                       const uint8_t *sen2cb,
+                       const uint8_t *logadd8, int logadd8_size);
+void pso_ptm_free(pso_ptm_t *s);
+/* ptm_mgau_reset_fast_hist (ptm_mgau.c:777-802) */
+void pso_ptm_reset_hist(pso_ptm_t *s);
+/* acmod writes mgau->frame_idx directly (acmod.c:419,862,874) */
+void pso_ptm_set_frame_idx(pso_ptm_t *s, int frame_idx);
+int  pso_ptm_get_frame_idx(const pso_ptm_t *s);
+
+/* ptm_mgau_frame_eval (ptm_mgau.c:408-454).  feat = the frame's dynamic
+ * feature vector, streams concatenated (sum featlen floats).  If raw_topn is
+ * non-NULL it receives the [n_mgau][n_feat][topn] lists as they stand after
+ * codebook evaluation and BEFORE normalisation (only written when the
+ * codebooks are actually evaluated, i.e. frame >= frame_idx; returns 1 then,
+ * 0 when the history slot was reused). */
+int pso_ptm_frame_eval(pso_ptm_t *s, int16_t *senscr,
+                       const uint8_t *senone_active, int32_t n_senone_active,
+                       const float *feat, int32_t frame, int32_t compallsen,
+                       pso_topn_t *raw_topn);
+
+/* current slot's (normalised) top-N, [n_mgau][n_feat][topn] */
+const pso_topn_t *pso_ptm_cur_topn(const pso_ptm_t *s);
+
+/* Convenience driver: score T frames of one utterance with compallsen,
+ * doing what acmod_start_utt/acmod_advance do to frame_idx.  If
+ * reset_hist != 0 the top-N history is reset first (fresh decoder).
+ * Outputs (any may be NULL): senscr [T][n_sen]; topn_cw uint8
+ * [T][n_mgau][n_feat][topn]; topn_raw int32 same shape. */
+void pso_ptm_score_utt(pso_ptm_t *s, const float *feats, int T, int reset_hist,
+                       int16_t *senscr, uint8_t *topn_cw, int32_t *topn_raw);
+
+/* ---------------- shared helpers ---------------- */
+
+/* acmod_flags2list (acmod.c:1223-1275): bit flags -> uint8 delta list.
+ * flags: one byte per senone (non-zero = active).  Returns n_active and
+ * writes the deltas (at most n_sen entries). */
+int pso_flags2list(const uint8_t *flags, int n_sen, uint8_t *deltas);
+
+/* ---------------- HMM Viterbi step (hmm.c) ---------------- */
+
+typedef struct pso_hmm_s {
+    int32_t score[5];
+    int32_t history[5];
+    int32_t out_score;
+    int32_t out_history;
+    uint16_t ssid;          /* non-mpx: senone sequence id */
+    uint16_t senid[5];      /* non-mpx: senone ids; mpx: per-state ssids */
+    int32_t bestscore;
+    int16_t tmatid;
+    int32_t frame;
+    uint8_t mpx;
+    uint8_t n_emit_state;
+} pso_hmm_t;
+
+typedef struct pso_hmm_ctx_s {
+    int n_emit_state;
+    const uint8_t *tp;        /* [n_tmat][n_emit][n_emit+1] (tmat.h:60-66) */
+    const int16_t *senscore;  /* current frame's senone scores */
+    const uint16_t *sseq;     /* [n_sseq][n_emit] */
+} pso_hmm_ctx_t;
+
+/* hmm_vit_eval (hmm.c:786-805) and its 3/5-state (mpx) variants */
+int32_t pso_hmm_vit_eval(const pso_hmm_ctx_t *ctx, pso_hmm_t *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,511 @@
+/* oracle/ref_dump.c -- TEST INFRASTRUCTURE (golden generator), not product.
+ *
+ * Links against the UNMODIFIED reference built by oracle/Makefile into
+ * oracle/_ref/libpocketsphinx.so and uses the reference's internal headers to
+ *   tables  : dump the model tables exactly as the reference holds them after
+ *             ps_init() (mean, precomputed var, det, mixw, sen2cb, 8-bit
+ *             log-add table, tmat tp, sseq ...)
+ *   feats   : run the reference front end over a raw PCM file and dump the
+ *             39-dim dynamic features acmod would hand to frame_eval()
+ *   ptm     : drive the reference's ptm_mgau_frame_eval() over a feature
+ *             matrix (compallsen) and dump int16 senone scores + raw int32
+ *             top-N densities + normalised top-N per frame
+ *   senlog  : full ps_decode_raw() with the reference's frame_eval wrapped
+ *             by a recorder: every (frame, active list, scores) call is logged
+ *   decode  : hypothesis + segmentation of ps_decode_raw()
+ *
+ * The file #includes the reference's ptm_mgau.c *from where it lies* so the
+ * static stages (eval_topn/eval_cb/codebook_norm/senone_eval) can be called
+ * one by one to capture the raw (pre-normalisation) top-N lists.  No
+ * reference source is copied into this repository.
+ *
+ * Output container ("PSGB1"): a flat sequence of named n-d arrays, read by
+ * oracle/psgb.py.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include <pocketsphinx.h>
+#include "pocketsphinx_internal.h"
+#include "ptm_mgau.c"           /* reference source, included in place */
+#include "s2_semi_mgau.h"
+#include "ms_mgau.h"
+#include "tmat.h"
+#include "bin_mdef.h"
+#include "hmm.h"
+
+/* ------------------------------------------------------------------ */
+static FILE *g_out;
+
+static void
+psgb_open(const char *path)
+{
+    g_out = fopen(path, "wb");
+    if (!g_out) { perror(path); exit(2); }
+    fwrite("PSGB1\n", 1, 6, g_out);
+}
+
+/* dtype codes: 'f' float32, 'i' int32, 'h' int16, 'B' uint8, 'H' uint16, 'q' int64 */
+static void
+psgb_put(const char *name, char dtype, int ndim, const int64_t *dims, const void *data)
+{
+    uint32_t nl = (uint32_t)strlen(name), dt = (uint32_t)dtype, nd = (uint32_t)ndim;
+    size_t esz = (dtype == 'f' || dtype == 'i') ? 4 : (dtype == 'h' || dtype == 'H') ? 2
+               : (dtype == 'q') ? 8 : 1;
+    size_t n = 1;
+    int i;
+    for (i = 0; i < ndim; ++i) n *= (size_t)dims[i];
+    fwrite(&nl, 4, 1, g_out); fwrite(name, 1, nl, g_out);
+    fwrite(&dt, 4, 1, g_out); fwrite(&nd, 4, 1, g_out);
+    fwrite(dims, 8, ndim, g_out);
+    fwrite(data, esz, n, g_out);
+}
+static void put1(const char *name, char dt, int64_t a, const void *d)
+{ int64_t dims[1] = {a}; psgb_put(name, dt, 1, dims, d); }
+static void put2(const char *name, char dt, int64_t a, int64_t b, const void *d)
+{ int64_t dims[2] = {a, b}; psgb_put(name, dt, 2, dims, d); }
+static void put3(const char *name, char dt, int64_t a, int64_t b, int64_t c, const void *d)
+{ int64_t dims[3] = {a, b, c}; psgb_put(name, dt, 3, dims, d); }
+static void put4(const char *name, char dt, int64_t a, int64_t b, int64_t c, int64_t e, const void *d)
+{ int64_t dims[4] = {a, b, c, e}; psgb_put(name, dt, 4, dims, d); }
+static void puti(const char *name, int32_t v) { put1(name, 'i', 1, &v); }
+
+/* ------------------------------------------------------------------ */
+static ps_decoder_t *
+make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, char **argv)
+{
+    ps_config_t *config = ps_config_init(NULL);
+    ps_decoder_t *ps;
+    int i;
+    ps_config_set_str(config, "hmm", modeldir);
+    if (lm) ps_config_set_str(config, "lm", lm);
+    if (dict) ps_config_set_str(config, "dict", dict);
+    ps_config_set_str(config, "loglevel", "ERROR");
+    /* extra key=value settings */
+    for (i = 0; i + 1 < argc; i += 2) {
+        const char *k = argv[i], *v = argv[i + 1];
+        if (k[0] == '-') ++k;
+        if (ps_config_set_str(config, k, v) == NULL) {
+            fprintf(stderr, "bad config %s=%s\n", k, v); exit(2);
+        }
+    }
+    ps = ps_init(config);
+    if (!ps) { fprintf(stderr, "ps_init failed\n"); exit(2); }
+    return ps;
+}
+
+static float *
+read_f32(const char *path, int64_t *n)
+{
+    FILE *fp = fopen(path, "rb");
+    long sz; float *buf;
+    if (!fp) { perror(path); exit(2); }
+    fseek(fp, 0, SEEK_END); sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+    buf = malloc(sz);
+    if (fread(buf, 1, sz, fp) != (size_t)sz) { perror("read"); exit(2); }
+    fclose(fp);
+    *n = sz / 4;
+    return buf;
+}
+
+static int16 *
+read_pcm(const char *path, size_t *n)
+{
+    FILE *fp = fopen(path, "rb");
+    long sz; int16 *buf;
+    if (!fp) { perror(path); exit(2); }
+    fseek(fp, 0, SEEK_END); sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+    buf = malloc(sz);
+    if (fread(buf, 1, sz, fp) != (size_t)sz) { perror("read"); exit(2); }
+    fclose(fp);
+    *n = sz / 2;
+    return buf;
+}
+
+/* ------------------------------------------------------------------ */
+static int
+cmd_tables(ps_decoder_t *ps)
+{
+    acmod_t *acmod = ps->acmod;
+    ptm_mgau_t *s = (ptm_mgau_t *)acmod->mgau;
+    gauden_t *g = s->g;
+    bin_mdef_t *mdef = acmod->mdef;
+    tmat_t *tmat = acmod->tmat;
+    int32_t i, f;
+    int64_t tot;
+
+    if (strcmp(acmod->mgau->vt->name, "ptm") != 0) {
+        fprintf(stderr, "not a PTM model\n"); return 2;
+    }
+    puti("n_mgau", g->n_mgau); puti("n_feat", g->n_feat); puti("n_density", g->n_density);
+    put1("featlen", 'i', g->n_feat, g->featlen);
+    puti("n_sen", s->n_sen); puti("max_topn", s->max_topn); puti("ds_ratio", s->ds_ratio);
+    puti("n_fast_hist", s->n_fast_hist);
+    puti("mixw_is_4bit", s->mixw_cb != NULL);
+    /* mean/var are [mgau][feat][density][featlen[f]]: contiguous per (mgau, feat)
+     * (ms_gauden.c gauden_param_read); with equal featlen the whole block is
+     * one contiguous buffer starting at mean[0][0][0]. */
+    tot = 0;
+    for (f = 0; f < g->n_feat; ++f) tot += g->featlen[f];
+    {
+        float *mean = malloc(sizeof(float) * g->n_mgau * g->n_density * tot);
+        float *var = malloc(sizeof(float) * g->n_mgau * g->n_density * tot);
+        float *det = malloc(sizeof(float) * g->n_mgau * g->n_feat * g->n_density);
+        int64_t o = 0, od = 0;
+        int32_t m, d;
+        /* packed as [mgau][feat][density][featlen[f]] in that loop order */
+        for (m = 0; m < g->n_mgau; ++m)
+            for (f = 0; f < g->n_feat; ++f) {
+                for (d = 0; d < g->n_density; ++d) {
+                    memcpy(mean + o, g->mean[m][f][d], sizeof(float) * g->featlen[f]);
+                    memcpy(var + o, g->var[m][f][d], sizeof(float) * g->featlen[f]);
+                    o += g->featlen[f];
+                    det[od++] = g->det[m][f][d];
+                }
+            }
+        put1("mean", 'f', o, mean);
+        put1("var", 'f', o, var);
+        put3("det", 'f', g->n_mgau, g->n_feat, g->n_density, det);
+        free(mean); free(var); free(det);
+    }
+    {
+        int32_t cw;
+        int64_t rowlen = s->mixw_cb ? (s->n_sen + 1) / 2 : s->n_sen;
+        uint8 *mixw = malloc((size_t)g->n_feat * g->n_density * rowlen);
+        for (f = 0; f < g->n_feat; ++f)
+            for (cw = 0; cw < g->n_density; ++cw)
+                memcpy(mixw + ((size_t)f * g->n_density + cw) * rowlen, s->mixw[f][cw], rowlen);
+        put3("mixw", 'B', g->n_feat, g->n_density, rowlen, mixw);
+        if (s->mixw_cb) put1("mixw_cb", 'B', 16, s->mixw_cb);
+        free(mixw);
+    }
+    put1("sen2cb", 'B', s->n_sen, s->sen2cb);
+    {
+        logadd_t *t = LOGMATH_TABLE(s->lmath_8b);
+        puti("logadd8_size", (int32_t)t->table_size);
+        puti("logadd8_width", t->width);
+        puti("logadd8_shift", t->shift);
+        put1("logadd8", 'B', t->table_size, t->table);
+        {
+            double base = logmath_get_base(s->lmath_8b);
+            int64_t one = 1;
+            FILE *o = g_out; (void)o;
+            psgb_put("logbase_f64bits", 'q', 1, &one, &base);
+        }
+    }
+    /* transition matrices: tp[tmat][from][to] uint8, n_state x (n_state+1)... */
+    puti("n_tmat", tmat->n_tmat); puti("tmat_n_state", tmat->n_state);
+    {
+        int32_t n = tmat->n_tmat, ns = tmat->n_state, t, a;
+        uint8 *tp = malloc((size_t)n * ns * (ns + 1));
+        for (t = 0; t < n; ++t)
+            for (a = 0; a < ns; ++a)
+                memcpy(tp + ((size_t)t * ns + a) * (ns + 1), tmat->tp[t][a], ns + 1);
+        put3("tp", 'B', n, ns, ns + 1, tp);
+        free(tp);
+    }
+    /* senone sequences */
+    {
+        int32_t n_sseq = bin_mdef_n_sseq(mdef), ne = bin_mdef_n_emit_state(mdef);
+        uint16 *sseq = malloc(sizeof(uint16) * n_sseq * ne);
+        for (i = 0; i < n_sseq; ++i)
+            memcpy(sseq + (size_t)i * ne, mdef->sseq[i], sizeof(uint16) * ne);
+        puti("n_sseq", n_sseq); puti("n_emit_state", ne);
+        put2("sseq", 'H', n_sseq, ne, sseq);
+        puti("n_ciphone", bin_mdef_n_ciphone(mdef));
+        puti("n_ci_sen", mdef->n_ci_sen);
+        free(sseq);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+static int
+cmd_feats(ps_decoder_t *ps, const char *rawpath)
+{
+    acmod_t *acmod = ps->acmod;
+    size_t n; int16 *pcm = read_pcm(rawpath, &n);
+    int16 const *p = pcm;
+    int nfr, dim = feat_dimension(acmod->fcb);
+    acmod_start_utt(acmod);
+    acmod_process_raw(acmod, &p, &n, TRUE);
+    acmod_end_utt(acmod);
+    nfr = acmod->n_feat_frame;
+    /* full-utterance mode: feat_buf[feat_outidx][0] is contiguous [nfr][dim] */
+    {
+        float *out = malloc(sizeof(float) * nfr * dim);
+        int t;
+        for (t = 0; t < nfr; ++t) {
+            int idx = (acmod->feat_outidx + t) % acmod->n_feat_alloc;
+            memcpy(out + (size_t)t * dim, acmod->feat_buf[idx][0], sizeof(float) * dim);
+        }
+        put2("feat", 'f', nfr, dim, out);
+        free(out);
+    }
+    free(pcm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Drive the reference PTM scorer over a feature matrix, compallsen.
+ * Two instances: A = the real ptm_mgau_frame_eval (pure reference call);
+ * B = the same stages called one by one (reference statics) so the raw
+ * top-N can be captured before ptm_mgau_codebook_norm overwrites it.
+ * A and B are asserted identical.  `carry` != 0 keeps the top-N history of
+ * a previous segment; segments are given by seglen (frames). */
+/* Force exact score ties: overwrite codeword d (d >= n_density/2) of every
+ * (codebook, stream) with the parameters of codeword d - n_density/2, in the
+ * reference's own in-memory tables. */
+static void
+dup_codewords(ptm_mgau_t *s)
+{
+    gauden_t *g = s->g;
+    int m, f, d, half = g->n_density / 2;
+    for (m = 0; m < g->n_mgau; ++m)
+        for (f = 0; f < g->n_feat; ++f)
+            for (d = half; d < g->n_density; ++d) {
+                memcpy(g->mean[m][f][d], g->mean[m][f][d - half], sizeof(mfcc_t) * g->featlen[f]);
+                memcpy(g->var[m][f][d], g->var[m][f][d - half], sizeof(mfcc_t) * g->featlen[f]);
+                g->det[m][f][d] = g->det[m][f][d - half];
+            }
+}
+
+static int
+cmd_ptm(ps_decoder_t *psA, ps_decoder_t *psB, const char *featpath, int seglen, int carry, int dup)
+{
+    ptm_mgau_t *a = (ptm_mgau_t *)psA->acmod->mgau;
+    ptm_mgau_t *b = (ptm_mgau_t *)psB->acmod->mgau;
+    gauden_t *g = a->g;
+    int64_t nfl; float *feat = read_f32(featpath, &nfl);
+    int dim = 0, f, nfr, t, cb, k, n_sen = a->n_sen, N = a->max_topn;
+    int16 *scrA, *scrB, *allscr;
+    int32 *raw_sc, *norm_sc; uint8 *cws;
+    mfcc_t *fp[16];
+    int nlist = g->n_mgau * g->n_feat;
+
+    if (dup) { dup_codewords(a); dup_codewords(b); }
+    for (f = 0; f < g->n_feat; ++f) dim += g->featlen[f];
+    nfr = (int)(nfl / dim);
+    if (seglen <= 0) seglen = nfr;
+    scrA = malloc(sizeof(int16) * n_sen); scrB = malloc(sizeof(int16) * n_sen);
+    allscr = malloc(sizeof(int16) * (size_t)n_sen * nfr);
+    raw_sc = malloc(sizeof(int32) * (size_t)nfr * nlist * N);
+    norm_sc = malloc(sizeof(int32) * (size_t)nfr * nlist * N);
+    cws = malloc((size_t)nfr * nlist * N);
+
+    for (t = 0; t < nfr; ++t) {
+        int frame = t % seglen;     /* frame index inside the utterance */
+        int o = 0, slot;
+        ptm_fast_eval_t *lastf;
+        for (f = 0; f < g->n_feat; ++f) { fp[f] = feat + (size_t)t * dim + o; o += g->featlen[f]; }
+        if (frame == 0) {
+            /* acmod_start_utt(): mgau->frame_idx = 0 (acmod.c:419) */
+            ps_mgau_base(a)->frame_idx = 0; ps_mgau_base(b)->frame_idx = 0;
+            if (!carry) { ptm_mgau_reset_fast_hist(ps_mgau_base(a)); ptm_mgau_reset_fast_hist(ps_mgau_base(b)); }
+        }
+        /* A: the real thing */
+        ptm_mgau_frame_eval(ps_mgau_base(a), scrA, NULL, 0, fp, frame, TRUE);
+        /* B: staged (same statements as ptm_mgau_frame_eval, ptm_mgau.c:425-451) */
+        slot = frame % b->n_fast_hist;
+        b->f = b->hist + slot;
+        lastf = (slot == 0) ? b->hist + b->n_fast_hist - 1 : b->hist + slot - 1;
+        memcpy(b->f->topn[0][0], lastf->topn[0][0], g->n_mgau * g->n_feat * N * sizeof(ptm_topn_t));
+        ptm_mgau_calc_cb_active(b, NULL, 0, TRUE);
+        ptm_mgau_codebook_eval(b, fp, frame);
+        for (cb = 0; cb < g->n_mgau; ++cb) for (f = 0; f < g->n_feat; ++f) for (k = 0; k < N; ++k) {
+            size_t ix = (((size_t)t * g->n_mgau + cb) * g->n_feat + f) * N + k;
+            raw_sc[ix] = b->f->topn[cb][f][k].score;
+            cws[ix] = (uint8)b->f->topn[cb][f][k].cw;
+        }
+        ptm_mgau_codebook_norm(b, fp, frame);
+        for (cb = 0; cb < g->n_mgau; ++cb) for (f = 0; f < g->n_feat; ++f) for (k = 0; k < N; ++k) {
+            size_t ix = (((size_t)t * g->n_mgau + cb) * g->n_feat + f) * N + k;
+            norm_sc[ix] = b->f->topn[cb][f][k].score;
+        }
+        ptm_mgau_senone_eval(b, scrB, NULL, 0, TRUE);
+        if (memcmp(scrA, scrB, sizeof(int16) * n_sen) != 0) {
+            fprintf(stderr, "staged != frame_eval at frame %d\n", t); return 3;
+        }
+        for (cb = 0; cb < g->n_mgau; ++cb) for (f = 0; f < g->n_feat; ++f) for (k = 0; k < N; ++k)
+            if (a->f->topn[cb][f][k].cw != b->f->topn[cb][f][k].cw ||
+                a->f->topn[cb][f][k].score != b->f->topn[cb][f][k].score) {
+                fprintf(stderr, "staged topn != frame_eval topn at frame %d\n", t); return 3;
+            }
+        memcpy(allscr + (size_t)t * n_sen, scrA, sizeof(int16) * n_sen);
+        /* acmod_advance(): ++mgau->frame_idx (acmod.c:874) */
+        ps_mgau_base(a)->frame_idx++; ps_mgau_base(b)->frame_idx++;
+    }
+    puti("seglen", seglen); puti("carry", carry);
+    put2("senscr", 'h', nfr, n_sen, allscr);
+    put4("topn_cw", 'B', nfr, g->n_mgau, g->n_feat, N, cws);
+    put4("topn_raw", 'i', nfr, g->n_mgau, g->n_feat, N, raw_sc);
+    put4("topn_norm", 'i', nfr, g->n_mgau, g->n_feat, N, norm_sc);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* senlog: record every frame_eval call made during ps_decode_raw */
+static ps_mgaufuncs_t rec_funcs;
+static ps_mgaufuncs_t *orig_funcs;
+static int rec_n, rec_cap;
+static int32 *rec_frame, *rec_nact, *rec_fidx;
+static int64_t *rec_off;           /* offsets into rec_act / rec_scr */
+static uint8 *rec_act; static size_t rec_act_n, rec_act_cap;
+static int16 *rec_scr; static size_t rec_scr_n, rec_scr_cap;
+static int rec_nsen, rec_dim;
+static float *rec_feat; static size_t rec_feat_n, rec_feat_cap;
+
+static int
+rec_frame_eval(ps_mgau_t *mg, int16 *senscr, uint8 *act, int32 nact,
+               mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    int r = orig_funcs->frame_eval(mg, senscr, act, nact, feat, frame, compallsen);
+    if (rec_n == rec_cap) {
+        rec_cap = rec_cap ? rec_cap * 2 : 1024;
+        rec_frame = realloc(rec_frame, sizeof(int32) * rec_cap);
+        rec_nact = realloc(rec_nact, sizeof(int32) * rec_cap);
+        rec_fidx = realloc(rec_fidx, sizeof(int32) * rec_cap);
+        rec_off = realloc(rec_off, sizeof(int64_t) * rec_cap);
+    }
+    rec_frame[rec_n] = frame; rec_nact[rec_n] = compallsen ? -1 : nact;
+    rec_fidx[rec_n] = mg->frame_idx;
+    rec_off[rec_n] = (int64_t)rec_act_n;
+    if (!compallsen) {
+        if (rec_act_n + nact > rec_act_cap) {
+            rec_act_cap = (rec_act_n + nact) * 2;
+            rec_act = realloc(rec_act, rec_act_cap);
+        }
+        memcpy(rec_act + rec_act_n, act, nact); rec_act_n += nact;
+    }
+    if (rec_scr_n + rec_nsen > rec_scr_cap) {
+        rec_scr_cap = (rec_scr_n + rec_nsen) * 2;
+        rec_scr = realloc(rec_scr, sizeof(int16) * rec_scr_cap);
+    }
+    memcpy(rec_scr + rec_scr_n, senscr, sizeof(int16) * rec_nsen); rec_scr_n += rec_nsen;
+    if (rec_feat_n + rec_dim > rec_feat_cap) {
+        rec_feat_cap = (rec_feat_n + rec_dim) * 2;
+        rec_feat = realloc(rec_feat, sizeof(float) * rec_feat_cap);
+    }
+    /* streams are contiguous inside one frame vector (feat.c:356-384) */
+    memcpy(rec_feat + rec_feat_n, feat[0], sizeof(float) * rec_dim); rec_feat_n += rec_dim;
+    ++rec_n;
+    return r;
+}
+
+static void
+dump_hyp(ps_decoder_t *ps, const char *prefix)
+{
+    int32 score = 0; char name[128];
+    const char *hyp = ps_get_hyp(ps, &score);
+    ps_seg_t *seg;
+    int n = 0, cap = 256;
+    int32 *segs = malloc(sizeof(int32) * 5 * cap);
+    char words[8192]; size_t wl = 0;
+    if (!hyp) hyp = "";
+    snprintf(name, sizeof name, "%shyp", prefix);
+    put1(name, 'B', (int64_t)strlen(hyp), hyp);
+    snprintf(name, sizeof name, "%shyp_score", prefix);
+    puti(name, score);
+    words[0] = 0;
+    for (seg = ps_seg_iter(ps); seg; seg = ps_seg_next(seg)) {
+        int sf, ef; int32 ascr, lscr, lback;
+        const char *w = ps_seg_word(seg);
+        ps_seg_frames(seg, &sf, &ef);
+        ps_seg_prob(seg, &ascr, &lscr, &lback);
+        if (n == cap) { cap *= 2; segs = realloc(segs, sizeof(int32) * 5 * cap); }
+        segs[n * 5 + 0] = sf; segs[n * 5 + 1] = ef; segs[n * 5 + 2] = ascr;
+        segs[n * 5 + 3] = lscr; segs[n * 5 + 4] = lback;
+        wl += snprintf(words + wl, sizeof words - wl, "%s\n", w);
+        ++n;
+    }
+    snprintf(name, sizeof name, "%sseg", prefix);
+    put2(name, 'i', n, 5, segs);
+    snprintf(name, sizeof name, "%sseg_words", prefix);
+    put1(name, 'B', (int64_t)wl, words);
+    free(segs);
+}
+
+static int
+cmd_senlog(ps_decoder_t *ps, const char *rawpath, int nrep)
+{
+    size_t n; int16 *pcm = read_pcm(rawpath, &n);
+    int r;
+    rec_nsen = bin_mdef_n_sen(ps->acmod->mdef);
+    rec_dim = feat_dimension(ps->acmod->fcb);
+    orig_funcs = ps->acmod->mgau->vt;
+    rec_funcs = *orig_funcs;
+    rec_funcs.frame_eval = rec_frame_eval;
+    ps->acmod->mgau->vt = &rec_funcs;
+    for (r = 0; r < nrep; ++r) {
+        char pfx[32];
+        ps_start_utt(ps);
+        ps_process_raw(ps, pcm, n, FALSE, TRUE);
+        ps_end_utt(ps);
+        snprintf(pfx, sizeof pfx, "utt%d_", r);
+        dump_hyp(ps, pfx);
+    }
+    ps->acmod->mgau->vt = orig_funcs;
+    puti("n_calls", rec_n); puti("n_sen", rec_nsen);
+    put1("call_frame", 'i', rec_n, rec_frame);
+    put1("call_nact", 'i', rec_n, rec_nact);
+    put1("call_frame_idx", 'i', rec_n, rec_fidx);
+    put1("call_act_off", 'q', rec_n, rec_off);
+    put1("call_act", 'B', (int64_t)rec_act_n, rec_act ? rec_act : (uint8 *)"");
+    put2("call_scr", 'h', rec_n, rec_nsen, rec_scr);
+    put2("call_feat", 'f', rec_n, rec_dim, rec_feat);
+    free(pcm);
+    return 0;
+}
+
+static int
+cmd_decode(ps_decoder_t *ps, const char *rawpath)
+{
+    size_t n; int16 *pcm = read_pcm(rawpath, &n);
+    ps_start_utt(ps);
+    ps_process_raw(ps, pcm, n, FALSE, TRUE);
+    ps_end_utt(ps);
+    dump_hyp(ps, "");
+    puti("n_frames", ps_get_n_frames(ps));
+    free(pcm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+int
+main(int argc, char **argv)
+{
+    /* usage: ref_dump CMD OUT MODELDIR LM DICT [cmd args...] [-- key val ...] */
+    const char *cmd, *out, *modeldir, *lm, *dict;
+    int rc = 2, i, xa = argc;
+    char **extra = NULL; int nextra = 0;
+    if (argc < 6) {
+        fprintf(stderr, "usage: ref_dump CMD OUT MODELDIR LM|- DICT|- [args] [-- key val ...]\n");
+        return 2;
+    }
+    cmd = argv[1]; out = argv[2]; modeldir = argv[3];
+    lm = strcmp(argv[4], "-") ? argv[4] : NULL;
+    dict = strcmp(argv[5], "-") ? argv[5] : NULL;
+    for (i = 6; i < argc; ++i)
+        if (strcmp(argv[i], "--") == 0) { xa = i; extra = argv + i + 1; nextra = argc - i - 1; break; }
+    err_set_loglevel(ERR_ERROR);
+    psgb_open(out);
+    if (!strcmp(cmd, "tables")) {
+        rc = cmd_tables(make_decoder(modeldir, lm, dict, nextra, extra));
+    } else if (!strcmp(cmd, "feats") && xa > 6) {
+        rc = cmd_feats(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+    } else if (!strcmp(cmd, "ptm") && xa > 8) {
+        ps_decoder_t *a = make_decoder(modeldir, lm, dict, nextra, extra);
+        ps_decoder_t *b = make_decoder(modeldir, lm, dict, nextra, extra);
+        rc = cmd_ptm(a, b, argv[6], atoi(argv[7]), atoi(argv[8]), xa > 9 ? atoi(argv[9]) : 0);
+    } else if (!strcmp(cmd, "senlog") && xa > 7) {
+        rc = cmd_senlog(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]));
+    } else if (!strcmp(cmd, "decode") && xa > 6) {
+        rc = cmd_decode(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+    } else {
+        fprintf(stderr, "unknown/short command %s\n", cmd);
+    }
+    fclose(g_out);
+    return rc;
+}

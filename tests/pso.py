@@ -1,0 +1,164 @@
+"""ctypes binding of oracle/libpsoracle.so (the CPU checker).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+
+_lib = None
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libpsoracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "libpsoracle.so")
+        src = os.path.join(ORACLE_DIR, "ps_oracle.c")
+        if (not os.path.exists(path)) or os.path.getmtime(path) < os.path.getmtime(src):
+            build_oracle()
+        L = C.CDLL(path)
+        vp, i32 = C.c_void_p, C.c_int32
+        L.pso_ptm_new.restype = vp
+        L.pso_ptm_new.argtypes = [i32, i32, i32, vp, i32, i32, i32, i32,
+                                  vp, vp, vp, vp, vp, vp, vp, i32]
+        L.pso_ptm_free.argtypes = [vp]
+        L.pso_ptm_reset_hist.argtypes = [vp]
+        L.pso_ptm_set_frame_idx.argtypes = [vp, i32]
+        L.pso_ptm_get_frame_idx.argtypes = [vp]
+        L.pso_ptm_get_frame_idx.restype = i32
+        L.pso_ptm_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
+        L.pso_ptm_frame_eval.restype = i32
+        L.pso_ptm_cur_topn.argtypes = [vp]
+        L.pso_ptm_cur_topn.restype = vp
+        L.pso_ptm_score_utt.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.pso_flags2list.argtypes = [vp, i32, vp]
+        L.pso_flags2list.restype = i32
+        L.pso_hmm_vit_eval.argtypes = [vp, vp]
+        L.pso_hmm_vit_eval.restype = i32
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def load_tables(name="en_us_ptm_tables.npz"):
+    z = np.load(os.path.join(GOLDEN_DIR, name))
+    return {k: z[k] for k in z.files}
+
+
+class OraclePTM:
+    """Stateful wrapper around pso_ptm_t (restates ptm_mgau.c)."""
+
+    def __init__(self, t, n_fast_hist=None, topn=None, ds_ratio=None):
+        L = lib()
+        self.t = t
+        self.n_mgau = int(t["n_mgau"][0]); self.n_feat = int(t["n_feat"][0])
+        self.n_density = int(t["n_density"][0]); self.n_sen = int(t["n_sen"][0])
+        self.topn = int(topn if topn is not None else t["max_topn"][0])
+        self.ds = int(ds_ratio if ds_ratio is not None else t["ds_ratio"][0])
+        self.n_hist = int(n_fast_hist if n_fast_hist is not None else t["n_fast_hist"][0])
+        self.veclen = int(t["featlen"].sum())
+        # keep contiguous copies alive for the lifetime of the C object
+        self._keep = dict(
+            featlen=np.ascontiguousarray(t["featlen"], np.int32),
+            mean=np.ascontiguousarray(t["mean"], np.float32),
+            var=np.ascontiguousarray(t["var"], np.float32),
+            det=np.ascontiguousarray(t["det"], np.float32),
+            mixw=np.ascontiguousarray(t["mixw"], np.uint8),
+            sen2cb=np.ascontiguousarray(t["sen2cb"], np.uint8),
+            logadd8=np.ascontiguousarray(t["logadd8"], np.uint8),
+            mixw_cb=(np.ascontiguousarray(t["mixw_cb"], np.uint8) if "mixw_cb" in t else None),
+        )
+        k = self._keep
+        self.h = L.pso_ptm_new(self.n_mgau, self.n_feat, self.n_density, _p(k["featlen"]),
+                               self.n_sen, self.topn, self.ds, self.n_hist,
+                               _p(k["mean"]), _p(k["var"]), _p(k["det"]), _p(k["mixw"]),
+                               _p(k["mixw_cb"]), _p(k["sen2cb"]), _p(k["logadd8"]),
+                               int(k["logadd8"].size))
+
+    def __del__(self):
+        try:
+            lib().pso_ptm_free(self.h)
+        except Exception:
+            pass
+
+    def reset_hist(self):
+        lib().pso_ptm_reset_hist(self.h)
+
+    def set_frame_idx(self, v):
+        lib().pso_ptm_set_frame_idx(self.h, int(v))
+
+    def frame_eval(self, feat, frame, active=None, compallsen=True, want_raw=False):
+        feat = np.ascontiguousarray(feat, np.float32)
+        scr = np.empty(self.n_sen, np.int16)
+        raw = np.empty((self.n_mgau, self.n_feat, self.topn, 2), np.int32) if want_raw else None
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        ev = lib().pso_ptm_frame_eval(self.h, _p(scr), _p(act),
+                                      0 if act is None else act.size, _p(feat),
+                                      int(frame), int(bool(compallsen)), _p(raw))
+        if want_raw:
+            return scr, raw, ev
+        return scr
+
+    def cur_topn(self):
+        p = lib().pso_ptm_cur_topn(self.h)
+        n = self.n_mgau * self.n_feat * self.topn * 2
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n,)).copy()
+        return a.reshape(self.n_mgau, self.n_feat, self.topn, 2)
+
+    def score_utt(self, feats, reset_hist=True, want_topn=True):
+        feats = np.ascontiguousarray(feats, np.float32)
+        T = feats.shape[0]
+        scr = np.empty((T, self.n_sen), np.int16)
+        cw = np.empty((T, self.n_mgau, self.n_feat, self.topn), np.uint8) if want_topn else None
+        raw = np.empty((T, self.n_mgau, self.n_feat, self.topn), np.int32) if want_topn else None
+        lib().pso_ptm_score_utt(self.h, _p(feats), T, int(bool(reset_hist)), _p(scr), _p(cw), _p(raw))
+        return scr, cw, raw
+
+
+def flags2list(flags):
+    flags = np.ascontiguousarray(flags, np.uint8)
+    out = np.empty(flags.size + flags.size // 255 + 8, np.uint8)
+    n = lib().pso_flags2list(_p(flags), flags.size, _p(out))
+    return out[:n].copy()
+
+
+# ---- HMM step ---------------------------------------------------------
+class PsoHmm(C.Structure):
+    _fields_ = [("score", C.c_int32 * 5), ("history", C.c_int32 * 5),
+                ("out_score", C.c_int32), ("out_history", C.c_int32),
+                ("ssid", C.c_uint16), ("senid", C.c_uint16 * 5),
+                ("bestscore", C.c_int32), ("tmatid", C.c_int16),
+                ("frame", C.c_int32), ("mpx", C.c_uint8), ("n_emit_state", C.c_uint8)]
+
+
+class PsoHmmCtx(C.Structure):
+    _fields_ = [("n_emit_state", C.c_int), ("tp", C.c_void_p),
+                ("senscore", C.c_void_p), ("sseq", C.c_void_p)]
+
+
+def row_hash(a):
+    """64-bit FNV-1a over each row of a 2-D (or flattened-per-first-axis) array."""
+    a = np.ascontiguousarray(a)
+    b = a.reshape(a.shape[0], -1).view(np.uint8)
+    h = np.full(b.shape[0], 0xcbf29ce484222325, np.uint64)
+    prime = np.uint64(0x100000001b3)
+    with np.errstate(over="ignore"):
+        for j in range(b.shape[1]):
+            h ^= b[:, j].astype(np.uint64)
+            h *= prime
+    return h

@@ -1,0 +1,117 @@
+"""Pin oracle/ps_oracle.c (the CPU checker) to goldens produced by the
+unmodified reference (oracle/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import pso
+
+G = pso.GOLDEN_DIR
+
+
+def _load(name):
+    z = np.load(os.path.join(G, name))
+    return {k: z[k] for k in z.files}
+
+
+def dup_tables(t):
+    """Same in-memory edit as ref_dump.c dup_codewords()."""
+    t = dict(t)
+    n_mgau, n_feat, n_den = int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0])
+    fl = int(t["featlen"][0])
+    half = n_den // 2
+    for k in ("mean", "var"):
+        a = t[k].reshape(n_mgau, n_feat, n_den, fl).copy()
+        a[:, :, half:] = a[:, :, :half]
+        t[k] = a.reshape(-1)
+    d = t["det"].copy()
+    d[:, :, half:] = d[:, :, :half]
+    t["det"] = d
+    return t
+
+
+def run_case(o, g):
+    feats, seglen, carry = g["feat"], int(g["seglen"]), int(g["carry"])
+    T = feats.shape[0]
+    scr = np.empty((T, o.n_sen), np.int16)
+    cw = np.empty((T, o.n_mgau, o.n_feat, o.topn), np.uint8)
+    raw = np.empty((T, o.n_mgau, o.n_feat, o.topn), np.int32)
+    o.reset_hist()
+    for s0 in range(0, T, seglen):
+        a, b, c = o.score_utt(feats[s0:s0 + seglen], reset_hist=not carry)
+        scr[s0:s0 + seglen], cw[s0:s0 + seglen], raw[s0:s0 + seglen] = a, b, c
+    return scr, cw, raw
+
+
+CASES = ["goforward", "goforward_x2_carry", "synth", "synth_utts", "adversarial", "dup_ties"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_ptm_oracle_matches_reference(tables, case):
+    g = _load("ptm_%s.npz" % case)
+    t = dup_tables(tables) if int(g["dup"]) else tables
+    o = pso.OraclePTM(t)
+    scr, cw, raw = run_case(o, g)
+    T = scr.shape[0]
+    idx = g["sample_idx"]
+    assert np.array_equal(cw[idx], g["topn_cw_sample"])
+    assert np.array_equal(raw[idx], g["topn_raw_sample"])
+    assert np.array_equal(scr[idx], g["senscr_sample"])
+    topn = np.concatenate([cw.reshape(T, -1).astype(np.int32), raw.reshape(T, -1)], axis=1)
+    assert np.array_equal(pso.row_hash(topn), g["topn_hash"])
+    assert np.array_equal(pso.row_hash(scr), g["senscr_hash"])
+    if "topn_cw" in g:
+        assert np.array_equal(cw, g["topn_cw"])
+        assert np.array_equal(raw, g["topn_raw"])
+
+
+def test_history_dependence_is_real(tables):
+    """a stateless top-N differs from the reference's stateful one
+    somewhere (otherwise the carry fixtures pin nothing)."""
+    g = _load("ptm_goforward_x2_carry.npz")
+    o = pso.OraclePTM(tables)
+    n = int(g["seglen"])
+    a, _, _ = o.score_utt(g["feat"][:n], reset_hist=True)
+    b, _, _ = o.score_utt(g["feat"][n:], reset_hist=False)
+    # same features, different seed state: almost all frames equal
+    assert a.shape == b.shape
+    assert (a != b).any(axis=1).sum() < n // 4
+
+
+@pytest.mark.parametrize("case", ["default", "fwdtree_only"])
+def test_senlog_replay(tables, case):
+    """Replay every frame_eval call the reference made during a real decode
+    (active lists, history-slot reuse, pass-2 codebook masking)."""
+    g = _load("senlog_%s.npz" % case)
+    feats = g["call_feat"]      # the vector the reference handed to each call
+    o = pso.OraclePTM(tables)
+    n = int(g["call_frame"].size)
+    off = g["call_act_off"]
+    hashes = np.empty(n, np.uint64)
+    rows = {}
+    sample = set(int(i) for i in g["sample_idx"])
+    for c in range(n):
+        fr, na = int(g["call_frame"][c]), int(g["call_nact"][c])
+        o.set_frame_idx(int(g["call_frame_idx"][c]))
+        act = None if na < 0 else g["call_act"][off[c]:off[c] + na]
+        scr = o.frame_eval(feats[c], fr, active=act, compallsen=(na < 0))
+        hashes[c] = pso.row_hash(scr[None, :])[0]
+        if c in sample:
+            rows[c] = scr
+    bad = np.nonzero(hashes != g["call_scr_hash"])[0]
+    assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
+    for k, c in enumerate(g["sample_idx"]):
+        assert np.array_equal(rows[int(c)], g["call_scr_sample"][k])
+
+
+def test_flags2list_bridges_gaps():
+    flags = np.zeros(5126, np.uint8)
+    flags[[0, 3, 300, 301, 1000, 5125]] = 1
+    d = pso.flags2list(flags)
+    sens = np.cumsum(d.astype(np.int64))
+    # every flagged senone is listed; bridging entries are extra senones
+    assert set([0, 3, 300, 301, 1000, 5125]) <= set(sens.tolist())
+    assert d.max() <= 255 and d[0] == 0
+    # acmod.c:1246-1249: a gap of 297 becomes 255 + 42
+    assert list(d[:4]) == [0, 3, 255, 42]
