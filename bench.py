@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- senone-scoring throughput of the HIP path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE
+JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run, one
+rank per GPU; utterances shard across ranks with no data-path collective
+(weak scaling: every rank scores its own batch), the only collective is the
+timing reduction.
+
+Workload (BASELINE.json configs[1]): en-us PTM (42 codebooks x 3 streams x
+128 Gaussians x 13 dims, 5126 senones, top-4), senone-score-only, 10,000
+synthetic 39-dim frames per GPU organised as 40 utterances x 250 frames,
+compallsen semantics, fresh top-N state per utterance.  A "step" is one pass
+of the hot path (top-N chain kernel + senone kernel) over that batch, inputs
+already resident in HBM.  value = frames/s over all ranks.
+
+Extra objects on the line:
+  roofline     HBM roofline of the dominant kernel (this path
+               is VALU-bound by construction, the HBM fraction is small)
+  cpu_baseline the unmodified reference (oracle/_ref, kind "reference") or
+               the C restatement (kind "port") timed single-thread on this
+               host over a bounded sample of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_UTT, UTT_LEN = 40, 250
+SEED = 20260921
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_GOPS = 78643.2         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-FMA fp32 op rate)
+BYTES_PER_FRAME = 39 * 4 + 5126 * 2          # compulsory HBM bytes per frame
+FLOP_PER_FRAME = 16128 * 13 * 4
+
+
+def load_tables():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "en_us_ptm_tables.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def synth_feats(t, n, seed):
+    """N(mu_d, sigma_d) from the model means' statistics."""
+    n_mgau, n_feat, n_den = int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0])
+    fl = int(t["featlen"][0])
+    mean = t["mean"].reshape(n_mgau, n_feat, n_den, fl)
+    mu = mean.mean(axis=(0, 2)).reshape(-1)
+    sd = mean.std(axis=(0, 2)).reshape(-1)
+    rng = np.random.default_rng(seed)
+    return (mu + sd * rng.standard_normal((n, mu.size))).astype(np.float32)
+
+
+def cpu_baseline(t, feats):
+    """Single-thread CPU time over a bounded sample (the full 10k-frame batch, once)."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_score_bench")
+    model = os.path.join(ROOT, "oracle", "_ref", "model", "en-us")
+    sample = "%d utterances x %d frames (the full step batch, one pass)" % (N_UTT, UTT_LEN)
+    if os.path.exists(ref_bin) and os.path.exists(os.path.join(model, "means")):
+        with tempfile.NamedTemporaryFile(suffix=".f32", delete=False) as fh:
+            feats.tofile(fh)
+            path = fh.name
+        try:
+            out = subprocess.run([ref_bin, model, path, str(UTT_LEN)], capture_output=True,
+                                 text=True, timeout=600)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            return {"value": round(r["frames_per_s"], 2), "unit": "frames/s", "cores": 1,
+                    "kind": "reference", "sample": sample,
+                    "what": "unmodified reference ptm_mgau_frame_eval(compallsen), gcc -O2"}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write("reference baseline failed (%s); using the port\n" % e)
+        finally:
+            os.unlink(path)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pso
+    o = pso.OraclePTM(t)
+    t0 = time.perf_counter()
+    for u in range(N_UTT):
+        o.score_utt(feats[u * UTT_LEN:(u + 1) * UTT_LEN], reset_hist=True, want_topn=False)
+    dt = time.perf_counter() - t0
+    return {"value": round(feats.shape[0] / dt, 2), "unit": "frames/s", "cores": 1,
+            "kind": "port", "sample": sample, "what": "oracle/ps_oracle.c restatement, gcc -O2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    L = capi.lib()
+    capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
+    t = load_tables()
+    model = P.PtmModel(t)
+
+    T = N_UTT * UTT_LEN
+    feats_h = synth_feats(t, T, SEED + rank)
+    feats = torch.from_numpy(feats_h).to(dev)
+    off = torch.arange(0, T + 1, UTT_LEN, dtype=torch.int32, device=dev)
+    n_chain, topn, n_sen = model.n_chain, model.topn, model.n_sen
+    topn_sc = torch.empty((T, n_chain, topn), dtype=torch.int32, device=dev)
+    topn_cw = torch.empty((T, n_chain, topn), dtype=torch.uint8, device=dev)
+    senscr = torch.empty((T, n_sen), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    sp = C.c_void_p(stream)
+
+    def p(x):
+        return C.c_void_p(x.data_ptr())
+
+    def step_topn():
+        capi.check(L.psgpu_ptm_topn_dev(model.h, p(feats), p(off), N_UTT, T, None,
+                                        p(topn_sc), p(topn_cw), sp), "topn")
+
+    def step_senone():
+        capi.check(L.psgpu_ptm_senone_dev(model.h, T, p(topn_sc), p(topn_cw), p(senscr),
+                                          None, 0, sp), "senone")
+
+    for _ in range(args.warmup):
+        step_topn(); step_senone()
+    torch.cuda.synchronize()
+
+    # per-kernel HIP events on the launch stream (inside the timed region)
+    evs = []
+    for _ in range(3 * args.steps):
+        e = C.c_void_p(); capi.check(L.psgpu_event_create(C.byref(e))); evs.append(e)
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        L.psgpu_event_record(evs[3 * k], sp)
+        step_topn()
+        L.psgpu_event_record(evs[3 * k + 1], sp)
+        step_senone()
+        L.psgpu_event_record(evs[3 * k + 2], sp)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms = C.c_float()
+    k_topn, k_sen = [], []
+    for k in range(args.steps):
+        L.psgpu_event_elapsed_ms(evs[3 * k], evs[3 * k + 1], C.byref(ms)); k_topn.append(ms.value)
+        L.psgpu_event_elapsed_ms(evs[3 * k + 1], evs[3 * k + 2], C.byref(ms)); k_sen.append(ms.value)
+    for e in evs:
+        L.psgpu_event_destroy(e)
+    topn_ms, sen_ms = float(np.mean(k_topn)), float(np.mean(k_sen))
+
+    # sanity: the benchmarked output is the parity-tested one (cheap spot check)
+    chk = int(senscr[:UTT_LEN].to(torch.int32).min(dim=1).values.abs().sum().item())
+    if chk != 0:
+        raise SystemExit("bench output failed the normalisation invariant")
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    frames_total = T * world * args.steps
+    fps = frames_total / dt
+    dom_name, dom_ms = (("ptm_chain_kernel", topn_ms) if topn_ms >= sen_ms
+                        else ("ptm_senone_kernel", sen_ms))
+    achieved = BYTES_PER_FRAME * T / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom_name)
+        except Exception:
+            traffic = None
+    line = {
+        "metric": "frames/sec senone scoring, en-us PTM 5126 senones (bit-exact int16)",
+        "value": round(fps, 1), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32->i32/i16", "data": "synthetic features; en-us PTM model tables (reference init dump)",
+        "config": {"workload": "configs[1]: en-us PTM senone-score-only, 10,000 synthetic frames/GPU "
+                               "= 40 utterances x 250 frames, compallsen, topn 4",
+                   "frames_per_step_per_gpu": T, "utterances": N_UTT, "parallelism": "utt-shard x%d" % world},
+        "xrt": round((dt / args.steps) / (T * world / 100.0), 8),
+        "kernels_ms": {"ptm_chain_kernel": round(topn_ms, 4), "ptm_senone_kernel": round(sen_ms, 4)},
+        "roofline": {"bound": "hbm", "kernel": dom_name,
+                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "note": "VALU/LDS-bound by construction (SURVEY 8d); fp32-VALU fraction of the "
+                             "distance work = %.4f" % (FLOP_PER_FRAME * T / (topn_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS)},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(t, feats_h)
+        line["speedup_vs_cpu_1thread"] = round(fps / world / line["cpu_baseline"]["value"], 1)
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+/* psgpu.h -- C ABI of the MI355X-native acoustic-scoring / Viterbi engine.
+ *
+ * This is the drop-in boundary for PocketSphinx's one data-parallel hot path
+ * (SURVEY.md section 8b).  Plain pointers and sizes only; no reference types,
+ * no torch types.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference's src/).  The reference-side
+ * binding that plugs these into `ps_mgau_t` / `acmod_t` is shown in
+ * INTEGRATION.md and lives in integration/.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative PSGPU_E* code on
+ *    failure (the reference's convention: `int`, negative = failure,
+ *    acmod.h:98-111); psgpu_last_error() gives the message.
+ *  - `*_dev` arguments are device (HBM) pointers; everything else is host.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *  - there is NO CPU fallback: without a usable gfx950 device every call
+ *    fails with PSGPU_ENODEV.
+ */
+#ifndef PSGPU_H
+#define PSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSGPU_OK        0
+#define PSGPU_ENODEV   -1   /* no HIP device / wrong architecture */
+#define PSGPU_EINVAL   -2   /* bad argument / unsupported model shape */
+#define PSGPU_ENOMEM   -3   /* device or host allocation failed */
+#define PSGPU_EHIP     -4   /* a HIP runtime call failed */
+#define PSGPU_ESTATE   -5   /* call sequence violates the frame_eval contract */
+
+#define PSGPU_MAX_TOPN  8
+
+/* ---- library / device ------------------------------------------------ */
+const char *psgpu_version(void);
+const char *psgpu_last_error(void);          /* thread-local message */
+int psgpu_device_count(void);                /* >=0, or PSGPU_ENODEV */
+int psgpu_set_device(int device);
+/* device memory helpers so that a C host needs no HIP headers */
+int psgpu_malloc(void **dev_ptr, size_t bytes);
+int psgpu_free(void *dev_ptr);
+int psgpu_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
+int psgpu_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
+int psgpu_stream_sync(void *stream);
+
+/* ---- PTM acoustic model ------------------------------------------------
+ * Replaces the table set built by ptm_mgau_init() (ptm_mgau.c:804-896):
+ *   mean/var  packed [n_mgau][n_feat][n_density][featlen[f]] floats, `var`
+ *             already precomputed by gauden_dist_precompute (ms_gauden.c:263-308)
+ *   det       [n_mgau][n_feat][n_density]
+ *   mixw      [n_feat][n_density][n_sen] uint8 (read_sendump / read_mixw,
+ *             ptm_mgau.c:456-774); 4-bit clustered sendumps are not accepted
+ *   sen2cb    [n_sen] (ptm_mgau.c:877-879)
+ *   logadd8   the uint8 table of logmath_init(base, SENSCR_SHIFT, 1)
+ *             (ptm_mgau.c:817-825, util/logmath.c:62-162), logadd8_size >= 256
+ * The tables are copied to the current device. */
+typedef struct psgpu_ptm_model_s psgpu_ptm_model_t;
+
+int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
+                           int32_t n_mgau, int32_t n_feat, int32_t n_density,
+                           const int32_t *featlen, int32_t n_sen, int32_t topn,
+                           int32_t ds_ratio,
+                           const float *mean, const float *var, const float *det,
+                           const uint8_t *mixw, const uint8_t *sen2cb,
+                           const uint8_t *logadd8, int32_t logadd8_size);
+void psgpu_ptm_model_free(psgpu_ptm_model_t *m);
+int32_t psgpu_ptm_n_sen(const psgpu_ptm_model_t *m);
+int32_t psgpu_ptm_n_chain(const psgpu_ptm_model_t *m);   /* n_mgau * n_feat */
+int32_t psgpu_ptm_veclen(const psgpu_ptm_model_t *m);    /* sum of featlen */
+int32_t psgpu_ptm_topn(const psgpu_ptm_model_t *m);
+
+/* ---- batched scoring (the throughput path) ------------------------------
+ * Replaces, for every frame of every utterance of a batch, one
+ * ptm_mgau_frame_eval(..., compallsen=TRUE) call (ptm_mgau.c:408-454) made in
+ * frame order: eval_topn + eval_cb (top-N selection with frame-to-frame
+ * seeding, :87-226), ptm_mgau_codebook_norm (:265-295) and
+ * ptm_mgau_senone_eval (:326-403).
+ *
+ *  feats_dev     [total_frames][veclen] fp32, utterances back to back
+ *  utt_off_dev   [n_utt + 1] int32 frame offsets (utt u = frames
+ *                utt_off[u] .. utt_off[u+1]-1); total_frames = utt_off[n_utt]
+ *  seed_cw_dev   NULL, or [n_utt][n_chain][topn] uint8, in/out: the top-N
+ *                codeword lists carried into frame 0 of each utterance and
+ *                out of its last frame (the reference never resets them
+ *                between utterances, acmod.c:407-421).  NULL =
+ *                fresh state, cw = 0..topn-1 (ptm_mgau_reset_fast_hist,
+ *                ptm_mgau.c:777-802).
+ *  topn_score_dev [total_frames][n_chain][topn] int32  raw (pre-norm) scores
+ *  topn_cw_dev    [total_frames][n_chain][topn] uint8  codewords
+ *                both are outputs AND the workspace between the two kernels.
+ *  senscr_dev    [total_frames][n_sen] int16 senone scores, or NULL to stop
+ *                after top-N selection.
+ *  flags         PSGPU_PTM_RAW_SCORES: skip the final per-frame
+ *                best-score subtraction (ptm_mgau.c:398-400) and store the
+ *                un-normalised sums; the per-frame minimum goes to
+ *                best_dev[total_frames] (int32) if non-NULL.
+ */
+#define PSGPU_PTM_RAW_SCORES 1u
+
+int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
+                              const float *feats_dev, const int32_t *utt_off_dev,
+                              int32_t n_utt, int32_t total_frames,
+                              uint8_t *seed_cw_dev,
+                              int32_t *topn_score_dev, uint8_t *topn_cw_dev,
+                              int16_t *senscr_dev, int32_t *best_dev,
+                              uint32_t flags, void *stream);
+
+/* Host-buffer convenience wrapper around the call above (allocates device
+ * buffers, copies in, runs, copies out, synchronises).  Any of the output
+ * pointers may be NULL. */
+int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
+                          const float *feats, const int32_t *utt_off, int32_t n_utt,
+                          uint8_t *seed_cw,
+                          int32_t *topn_score, uint8_t *topn_cw,
+                          int16_t *senscr, int32_t *best, uint32_t flags);
+
+/* Per-kernel timing of the most recent psgpu_ptm_score_batch_dev call on
+ * this model is NOT kept here; benchmarks bracket the call with HIP events
+ * through the helpers below (events are recorded on the given stream). */
+int psgpu_event_create(void **ev);
+int psgpu_event_destroy(void *ev);
+int psgpu_event_record(void *ev, void *stream);
+int psgpu_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* syncs on stop */
+
+/* Launch only one of the two kernels (used by bench.py to time the dominant
+ * kernel in isolation with HIP events; same arguments as the batch call). */
+int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
+                       const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                       uint8_t *seed_cw_dev, int32_t *topn_score_dev,
+                       uint8_t *topn_cw_dev, void *stream);
+int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
+                         const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
+                         int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSGPU_H */

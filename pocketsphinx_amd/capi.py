@@ -1,0 +1,85 @@
+"""ctypes binding of libpsgpu.so (include/psgpu.h)."""
+import ctypes as C
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip"]
+
+# every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "psgpu_version", "psgpu_last_error", "psgpu_device_count", "psgpu_set_device",
+    "psgpu_malloc", "psgpu_free", "psgpu_memcpy_h2d", "psgpu_memcpy_d2h", "psgpu_stream_sync",
+    "psgpu_ptm_model_create", "psgpu_ptm_model_free", "psgpu_ptm_n_sen", "psgpu_ptm_n_chain",
+    "psgpu_ptm_veclen", "psgpu_ptm_topn", "psgpu_ptm_score_batch_dev", "psgpu_ptm_score_batch",
+    "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",
+    "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev",
+]
+
+
+class PsgpuError(RuntimeError):
+    pass
+
+
+def build_library(force=False):
+    """Compile the HIP sources for gfx950 into pocketsphinx_amd/libpsgpu.so
+    (in-tree, so it travels to the GPU box).  hipcc cross-compiles without a GPU."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "psgpu_internal.h"), os.path.join(ROOT, "include", "psgpu.h")]
+    if (not force) and os.path.exists(LIB_PATH) and \
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+           "-Wno-unused-value", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+           "-o", LIB_PATH] + srcs
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libpsgpu.so; fail loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsgpuError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32 = C.c_void_p, C.c_int32, C.c_uint32
+    L.psgpu_version.restype = C.c_char_p
+    L.psgpu_last_error.restype = C.c_char_p
+    L.psgpu_set_device.argtypes = [C.c_int]
+    L.psgpu_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.psgpu_free.argtypes = [vp]
+    L.psgpu_memcpy_h2d.argtypes = [vp, vp, C.c_size_t, vp]
+    L.psgpu_memcpy_d2h.argtypes = [vp, vp, C.c_size_t, vp]
+    L.psgpu_stream_sync.argtypes = [vp]
+    L.psgpu_ptm_model_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp, i32, i32, i32,
+                                         vp, vp, vp, vp, vp, vp, i32]
+    L.psgpu_ptm_model_free.argtypes = [vp]
+    L.psgpu_ptm_model_free.restype = None
+    for f in ("psgpu_ptm_n_sen", "psgpu_ptm_n_chain", "psgpu_ptm_veclen", "psgpu_ptm_topn"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = i32
+    L.psgpu_ptm_score_batch_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, u32, vp]
+    L.psgpu_ptm_score_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, u32]
+    L.psgpu_ptm_topn_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.psgpu_ptm_senone_dev.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
+    L.psgpu_event_create.argtypes = [C.POINTER(vp)]
+    L.psgpu_event_destroy.argtypes = [vp]
+    L.psgpu_event_record.argtypes = [vp, vp]
+    L.psgpu_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    _lib = L
+    return L
+
+
+def check(rc, what="psgpu call"):
+    if rc != 0:
+        raise PsgpuError("%s failed (%d): %s" % (what, rc, lib().psgpu_last_error().decode()))

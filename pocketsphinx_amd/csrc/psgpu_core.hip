@@ -1,0 +1,121 @@
+// psgpu_core.hip -- device / memory / event plumbing of the C ABI (include/psgpu.h).
+#include "psgpu_internal.h"
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void psgpu_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int psgpu_check_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        psgpu_set_error("no HIP device visible (%s); libpsgpu has no CPU fallback",
+                        e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return PSGPU_ENODEV;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        psgpu_set_error("hipGetDevice failed");
+        return PSGPU_ENODEV;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) {
+        psgpu_set_error("hipGetDeviceProperties failed");
+        return PSGPU_ENODEV;
+    }
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+        psgpu_set_error("device %d is %s; libpsgpu is built for gfx950 only", dev, p.gcnArchName);
+        return PSGPU_ENODEV;
+    }
+    return PSGPU_OK;
+}
+
+extern "C" {
+
+const char *psgpu_version(void) { return "psgpu 0.1 (gfx950)"; }
+const char *psgpu_last_error(void) { return g_err; }
+
+int psgpu_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        psgpu_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return PSGPU_ENODEV;
+    }
+    return n;
+}
+
+int psgpu_set_device(int device)
+{
+    PSGPU_HIP(hipSetDevice(device));
+    return psgpu_check_device();
+}
+
+int psgpu_malloc(void **p, size_t bytes)
+{
+    PSGPU_REQUIRE(p != nullptr, "psgpu_malloc: NULL out pointer");
+    PSGPU_HIP(hipMalloc(p, bytes ? bytes : 1));
+    return PSGPU_OK;
+}
+
+int psgpu_free(void *p)
+{
+    if (p) PSGPU_HIP(hipFree(p));
+    return PSGPU_OK;
+}
+
+int psgpu_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    PSGPU_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return PSGPU_OK;
+}
+
+int psgpu_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    PSGPU_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PSGPU_OK;
+}
+
+int psgpu_stream_sync(void *stream)
+{
+    PSGPU_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PSGPU_OK;
+}
+
+int psgpu_event_create(void **ev)
+{
+    hipEvent_t e;
+    PSGPU_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return PSGPU_OK;
+}
+
+int psgpu_event_destroy(void *ev)
+{
+    PSGPU_HIP(hipEventDestroy((hipEvent_t)ev));
+    return PSGPU_OK;
+}
+
+int psgpu_event_record(void *ev, void *stream)
+{
+    PSGPU_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return PSGPU_OK;
+}
+
+int psgpu_event_elapsed_ms(void *a, void *b, float *ms)
+{
+    PSGPU_HIP(hipEventSynchronize((hipEvent_t)b));
+    PSGPU_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return PSGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+"""Host-side mirror of the reference's PTM scorer interface.
+
+``PtmModel`` owns the device copy of the tables ptm_mgau_init() builds
+(reference src/ptm_mgau.c:804-896).  ``PtmMgau.score_utts`` is the batched
+equivalent of calling ptm_mgau_frame_eval(..., compallsen=TRUE)
+(src/ptm_mgau.c:408-454) for every frame of every utterance in order.
+All arithmetic happens in the HIP kernels of libpsgpu.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+RAW_SCORES = 1
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PtmModel:
+    def __init__(self, tables, topn=None, ds_ratio=None):
+        L = capi.lib()
+        t = tables
+        if "mixw_cb" in t or int(np.asarray(t.get("mixw_is_4bit", [0])).ravel()[0]):
+            raise capi.PsgpuError("4-bit clustered sendumps are not supported by libpsgpu")
+        self.n_mgau = int(t["n_mgau"][0]); self.n_feat = int(t["n_feat"][0])
+        self.n_density = int(t["n_density"][0]); self.n_sen = int(t["n_sen"][0])
+        self.topn = int(topn if topn is not None else t["max_topn"][0])
+        self.ds_ratio = int(ds_ratio if ds_ratio is not None else t["ds_ratio"][0])
+        featlen = np.ascontiguousarray(t["featlen"], np.int32)
+        self.veclen = int(featlen.sum())
+        self.n_chain = self.n_mgau * self.n_feat
+        h = C.c_void_p()
+        capi.check(L.psgpu_ptm_model_create(
+            C.byref(h), self.n_mgau, self.n_feat, self.n_density, _p(featlen), self.n_sen,
+            self.topn, self.ds_ratio,
+            _p(np.ascontiguousarray(t["mean"], np.float32)),
+            _p(np.ascontiguousarray(t["var"], np.float32)),
+            _p(np.ascontiguousarray(t["det"], np.float32)),
+            _p(np.ascontiguousarray(t["mixw"], np.uint8)),
+            _p(np.ascontiguousarray(t["sen2cb"], np.uint8)),
+            _p(np.ascontiguousarray(t["logadd8"], np.uint8)), int(t["logadd8"].size)),
+            "psgpu_ptm_model_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().psgpu_ptm_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PtmMgau:
+    """Batched PTM scorer (compallsen semantics) over host numpy buffers."""
+
+    def __init__(self, model):
+        self.m = model
+
+    def score_utts(self, feats, utt_lens, seed_cw=None, raw_scores=False,
+                   want_topn=True, want_scores=True):
+        """feats [total_frames][veclen] fp32; utt_lens: frames per utterance.
+        Returns dict(senscr int16 [T][n_sen], topn_cw uint8 [T][n_chain][topn],
+        topn_score int32 same, best int32 [T], seed_cw)."""
+        m = self.m
+        feats = np.ascontiguousarray(feats, np.float32)
+        off = np.zeros(len(utt_lens) + 1, np.int32)
+        off[1:] = np.cumsum(np.asarray(utt_lens, np.int64))
+        T = int(off[-1])
+        if feats.shape != (T, m.veclen):
+            raise ValueError("feats shape %r != (%d, %d)" % (feats.shape, T, m.veclen))
+        scr = np.empty((T, m.n_sen), np.int16) if want_scores else None
+        cw = np.empty((T, m.n_chain, m.topn), np.uint8) if want_topn else None
+        sc = np.empty((T, m.n_chain, m.topn), np.int32) if want_topn else None
+        best = np.empty(T, np.int32) if want_scores else None
+        if seed_cw is not None:
+            seed_cw = np.ascontiguousarray(seed_cw, np.uint8).copy()
+            assert seed_cw.shape == (len(utt_lens), m.n_chain, m.topn)
+        capi.check(capi.lib().psgpu_ptm_score_batch(
+            m.h, _p(feats), _p(off), len(utt_lens), _p(seed_cw), _p(sc), _p(cw), _p(scr),
+            _p(best), RAW_SCORES if raw_scores else 0), "psgpu_ptm_score_batch")
+        return dict(senscr=scr, topn_cw=cw, topn_score=sc, best=best, seed_cw=seed_cw)
