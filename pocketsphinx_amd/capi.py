@@ -48,6 +48,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64; load it FIRST so libpsgpu binds to
+        # the same runtime (two HIP runtimes in one process lose the device).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise PsgpuError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(there is no CPU fallback)" % LIB_PATH)

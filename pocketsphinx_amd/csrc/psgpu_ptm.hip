@@ -82,6 +82,22 @@ __device__ __forceinline__ float lane_value(float v, int lane)
         __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// max over the 64 lanes of a wavefront, returned wave-uniform.  Quad
+// butterflies and row rotations run on the DPP path (no LDS traffic); the four
+// 16-lane rows are combined on the scalar unit.
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));  // row_ror:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));  // row_ror:8
+    const int32_t r0 = __builtin_amdgcn_readlane(v, 0);
+    const int32_t r1 = __builtin_amdgcn_readlane(v, 16);
+    const int32_t r2 = __builtin_amdgcn_readlane(v, 32);
+    const int32_t r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
 // Wave-uniform top-N list.
 template <int N>
 struct TopN {
@@ -161,6 +177,35 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
             d1 = gau_step(d1, x[j], m1[j], v1[j]);
         }
 
+        const bool scan_frame = (p.ds_ratio == 1) || ((t % p.ds_ratio) == 0);
+
+        // ---- fast path.  If the four largest truncated scores of the
+        // codebook are pairwise distinct and strictly above the fifth, the
+        // reference's seed/scan procedure ends with exactly those four in
+        // descending order whatever the seeds were ("top-N
+        // closed form"), so they are extracted with four wave-wide
+        // unique-maximum rounds.  Any tie falls through to the exact
+        // emulation below.
+        bool exact = !scan_frame;
+        if (scan_frame) {
+            int32_t s0 = dist_to_int(d0), s1 = dist_to_int(d1);
+            TopN<N> F;
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                const int32_t mx = wave_max_i32(max(s0, s1));
+                const bool e0 = (s0 == mx), e1 = (s1 == mx);
+                const unsigned long long b0 = __ballot(e0), b1 = __ballot(e1);
+                if (__popcll(b0) + __popcll(b1) != 1)
+                    exact = true;
+                F.sc[r] = mx;
+                F.cw[r] = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+                s0 = e0 ? kMaxNegInt32 : s0;
+                s1 = e1 ? kMaxNegInt32 : s1;
+            }
+            if (!exact) L = F;
+        }
+
+        if (exact) {
         // ---- eval_topn: re-score the carried codewords, stable insertion
         // sort, descending, strict '>' (ptm_mgau.c:71-85, :87-136)
 #pragma unroll
@@ -180,7 +225,7 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
         // ---- eval_cb: scan codewords in index order against the moving
         // threshold (ptm_mgau.c:151-226).  Only frames that are multiples of
         // the downsampling ratio are scanned (:242).
-        if (p.ds_ratio == 1 || (t % p.ds_ratio) == 0) {
+        if (scan_frame) {
             int pos = 0;                        // next codeword index to look at
             for (;;) {
                 const float th = (float)L.sc[N - 1];
@@ -221,6 +266,7 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
                 pos = c + 1;
             }
         }
+        }   // exact
 
         // ---- publish the raw list of this frame
         if (lane == 0) {
