@@ -133,7 +133,7 @@ def main():
         return C.c_void_p(x.data_ptr())
 
     def step_topn():
-        capi.check(L.psgpu_ptm_topn_dev(model.h, p(feats), p(off), N_UTT, T, None,
+        capi.check(L.psgpu_ptm_topn_dev(model.h, p(feats), p(off), N_UTT, T, None, None,
                                         p(topn_sc), p(topn_cw), sp), "topn")
 
     def step_senone():
@@ -179,7 +179,7 @@ def main():
 
     # sanity: the benchmarked output is the parity-tested one (cheap spot check)
     chk = int(senscr[:UTT_LEN].to(torch.int32).min(dim=1).values.abs().sum().item())
-    if chk != 0:
+    if chk != 0 and not os.environ.get("PSGPU_ABLATE"):
         raise SystemExit("bench output failed the normalisation invariant")
 
     if rank != 0:

@@ -83,12 +83,14 @@ int32_t psgpu_ptm_topn(const psgpu_ptm_model_t *m);
  *  feats_dev     [total_frames][veclen] fp32, utterances back to back
  *  utt_off_dev   [n_utt + 1] int32 frame offsets (utt u = frames
  *                utt_off[u] .. utt_off[u+1]-1); total_frames = utt_off[n_utt]
- *  seed_cw_dev   NULL, or [n_utt][n_chain][topn] uint8, in/out: the top-N
- *                codeword lists carried into frame 0 of each utterance and
- *                out of its last frame (the reference never resets them
- *                between utterances, acmod.c:407-421).  NULL =
- *                fresh state, cw = 0..topn-1 (ptm_mgau_reset_fast_hist,
- *                ptm_mgau.c:777-802).
+ *  seed_in_dev   NULL, or [n_utt][n_chain][topn] uint8: the top-N codeword
+ *                lists carried into frame 0 of each utterance (the reference
+ *                never resets them between utterances, acmod.c:407-421;
+ *                SURVEY F7).  NULL = fresh state, cw = 0..topn-1
+ *                (ptm_mgau_reset_fast_hist, ptm_mgau.c:777-802).
+ *  seed_out_dev  NULL, or [n_utt][n_chain][topn] uint8: receives the lists
+ *                carried out of each non-empty utterance's last frame.  Must
+ *                not alias seed_in_dev.
  *  topn_score_dev [total_frames][n_chain][topn] int32  raw (pre-norm) scores
  *  topn_cw_dev    [total_frames][n_chain][topn] uint8  codewords
  *                both are outputs AND the workspace between the two kernels.
@@ -104,14 +106,16 @@ int32_t psgpu_ptm_topn(const psgpu_ptm_model_t *m);
 int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
                               const float *feats_dev, const int32_t *utt_off_dev,
                               int32_t n_utt, int32_t total_frames,
-                              uint8_t *seed_cw_dev,
+                              const uint8_t *seed_in_dev, uint8_t *seed_out_dev,
                               int32_t *topn_score_dev, uint8_t *topn_cw_dev,
                               int16_t *senscr_dev, int32_t *best_dev,
                               uint32_t flags, void *stream);
 
 /* Host-buffer convenience wrapper around the call above (allocates device
  * buffers, copies in, runs, copies out, synchronises).  Any of the output
- * pointers may be NULL. */
+ * pointers may be NULL.  seed_cw (NULL or [n_utt][n_chain][topn]) is in/out:
+ * read as the carried-in lists, overwritten with the carried-out lists
+ * (empty utterances keep theirs). */
 int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
                           const float *feats, const int32_t *utt_off, int32_t n_utt,
                           uint8_t *seed_cw,
@@ -130,8 +134,8 @@ int psgpu_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* syncs o
  * kernel in isolation with HIP events; same arguments as the batch call). */
 int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
                        const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
-                       uint8_t *seed_cw_dev, int32_t *topn_score_dev,
-                       uint8_t *topn_cw_dev, void *stream);
+                       const uint8_t *seed_in_dev, uint8_t *seed_out_dev,
+                       int32_t *topn_score_dev, uint8_t *topn_cw_dev, void *stream);
 int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
                          const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
                          int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,

@@ -34,7 +34,9 @@ def build_library(force=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-           "-Wno-unused-value", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+           # packed fp32 (v_pk_*) runs at half rate on gfx950 and the SLP pass
+           # doubles register pressure here: keep the distance chain scalar
+           "-fno-slp-vectorize", "-Wno-unused-value", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
            "-o", LIB_PATH] + srcs
     subprocess.check_call(cmd)
     return LIB_PATH
@@ -74,9 +76,9 @@ def lib():
     for f in ("psgpu_ptm_n_sen", "psgpu_ptm_n_chain", "psgpu_ptm_veclen", "psgpu_ptm_topn"):
         getattr(L, f).argtypes = [vp]
         getattr(L, f).restype = i32
-    L.psgpu_ptm_score_batch_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, u32, vp]
+    L.psgpu_ptm_score_batch_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, u32, vp]
     L.psgpu_ptm_score_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, u32]
-    L.psgpu_ptm_topn_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.psgpu_ptm_topn_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.psgpu_ptm_senone_dev.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
     L.psgpu_event_create.argtypes = [C.POINTER(vp)]
     L.psgpu_event_destroy.argtypes = [vp]

@@ -25,6 +25,8 @@
 // feature rows in and the int16 score rows out (+ the top-N lists between the
 // two kernels).  See DESIGN.md for the roofline discussion.
 #include "psgpu_internal.h"
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 struct psgpu_ptm_model_s {
@@ -36,12 +38,18 @@ struct psgpu_ptm_model_s {
     float *mean, *var, *det;      // device
     int64_t *cboff;               // device: float offset of (mgau, feat) block
     uint8_t *mixw, *sen2cb, *logadd8;
+    uint8_t *mixw_slot;           // [n_feat][n_density][slot_stride], slot order, rows 64-byte aligned
+    uint8_t *group_cb;            // [n_groups] codebook of each 4-slot group
+    uint16_t *slot_sen;           // [n_slots] senone id of a slot, 0xffff = pad
+    int32_t slot_stride, n_groups;
     int32_t logadd8_size;
 };
 
 struct PtmDev {
     const float *mean, *var, *det;
-    const uint8_t *mixw, *sen2cb, *logadd8;
+    const uint8_t *mixw, *sen2cb, *logadd8, *mixw_slot, *group_cb;
+    const uint16_t *slot_sen;
+    int32_t slot_stride, n_groups;
     int32_t n_mgau, n_feat, n_density, n_sen, veclen, n_chain, ds_ratio, logadd8_size;
 };
 
@@ -50,6 +58,8 @@ static PtmDev dev_view(const psgpu_ptm_model_t *m)
     PtmDev p;
     p.mean = m->mean; p.var = m->var; p.det = m->det;
     p.mixw = m->mixw; p.sen2cb = m->sen2cb; p.logadd8 = m->logadd8;
+    p.mixw_slot = m->mixw_slot; p.group_cb = m->group_cb; p.slot_sen = m->slot_sen;
+    p.slot_stride = m->slot_stride; p.n_groups = m->n_groups;
     p.n_mgau = m->n_mgau; p.n_feat = m->n_feat; p.n_density = m->n_density;
     p.n_sen = m->n_sen; p.veclen = m->veclen; p.n_chain = m->n_chain;
     p.ds_ratio = m->ds_ratio; p.logadd8_size = m->logadd8_size;
@@ -82,20 +92,29 @@ __device__ __forceinline__ float lane_value(float v, int lane)
         __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// max over the 64 lanes of a wavefront, returned wave-uniform.  Quad
-// butterflies and row rotations run on the DPP path (no LDS traffic); the four
-// 16-lane rows are combined on the scalar unit.
+// max over the 64 lanes of a wavefront, returned wave-uniform.  Runs entirely
+// on the DPP path (no LDS traffic): quad butterflies, row rotations, then the
+// two cross-row broadcasts; lane 63 ends up with the wave maximum.  The s_nop
+// fill the 2 wait states gfx9 requires between a VALU write and a DPP read of
+// the same VGPR (the compiler does not see inside the asm statement).
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 {
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));  // row_ror:4
-    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));  // row_ror:8
-    const int32_t r0 = __builtin_amdgcn_readlane(v, 0);
-    const int32_t r1 = __builtin_amdgcn_readlane(v, 16);
-    const int32_t r2 = __builtin_amdgcn_readlane(v, 32);
-    const int32_t r3 = __builtin_amdgcn_readlane(v, 48);
-    return max(max(r0, r1), max(r2, r3));
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Wave-uniform top-N list.
@@ -105,28 +124,124 @@ struct TopN {
     int32_t sc[N];
 };
 
+// Exact emulation of one reference frame step on a chain whose 128 distances
+// are d0 (codeword = lane) and d1 (codeword = lane + 64):
+//   eval_topn  (ptm_mgau.c:71-136)  re-score the carried list, stable
+//              descending insertion sort with strict '>'
+//   eval_cb    (ptm_mgau.c:140-226) scan codewords in index order against
+//              the moving float threshold, skip-if-present, insert ahead of
+//              equal scores, worst entry drops
+// All list state is wave-uniform.  This is the slow path, taken only when the
+// closed form below cannot be used.
+template <int N>
+__device__ __forceinline__ void exact_frame_step(TopN<N> &L, float d0, float d1, int lane, bool scan)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = L.cw[i];
+        const float d = (c < 64) ? lane_value(d0, c) : lane_value(d1, c - 64);
+        L.sc[i] = dist_to_int(d);
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+            if (L.sc[j] > L.sc[j - 1]) {
+                int32_t ts = L.sc[j]; L.sc[j] = L.sc[j - 1]; L.sc[j - 1] = ts;
+                int32_t tc = L.cw[j]; L.cw[j] = L.cw[j - 1]; L.cw[j - 1] = tc;
+            }
+        }
+    }
+    if (!scan)
+        return;
+    int pos = 0;                            // next codeword index to look at
+    for (;;) {
+        const float th = (float)L.sc[N - 1];
+        bool in0 = false, in1 = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            in0 |= (L.cw[i] == lane);
+            in1 |= (L.cw[i] == lane + 64);
+        }
+        unsigned long long b0 = __ballot(d0 >= th && !in0);
+        unsigned long long b1 = __ballot(d1 >= th && !in1);
+        if (pos >= 64) {
+            b0 = 0;
+            b1 = (pos >= 128) ? 0ull : (b1 & (~0ull << (pos - 64)));
+        }
+        else
+            b0 &= (~0ull << pos);
+        if ((b0 | b1) == 0)
+            break;
+        const int c = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
+        const float d = (c < 64) ? lane_value(d0, c) : lane_value(d1, c - 64);
+        const int32_t s = dist_to_int(d);
+        int q = N - 1;
+#pragma unroll
+        for (int k = N - 1; k > 0; --k) {
+            if (q == k && s >= L.sc[k - 1]) {
+                L.sc[k] = L.sc[k - 1];
+                L.cw[k] = L.cw[k - 1];
+                q = k - 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (q == k) { L.sc[k] = s; L.cw[k] = c; }
+        }
+        pos = c + 1;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // kernel 1: top-N chains, specialised for 128 densities (2 per lane) and a
 // compile-time stream length.
+//
+// Work decomposition: one wavefront = one (codebook, stream) chain x one chunk
+// of `chunk` consecutive global frames (utterances lie back to back).  Chunks
+// are independent although the reference's top-N update is sequential in time:
+// whenever a frame's closed form applies its list does not depend on the
+// list carried in, so a chunk that does not start an utterance re-derives its
+// incoming state by stepping back to the nearest earlier scan frame whose
+// closed form holds (almost always the frame just before the chunk; at worst
+// the utterance's first frame with its seed list) and replaying forward
+// without publishing.  Results are therefore identical to a sequential march.
 // ---------------------------------------------------------------------------
-template <int LEN, int N>
-__global__ __launch_bounds__(256)
+constexpr int32_t kKeyLo = -(1 << 24);          // clamp range of the score part
+constexpr int32_t kKeyHi = (1 << 24) - 1;       // of a packed selection key
+
+template <int LEN, int N, int OCC>
+__global__ __launch_bounds__(256, OCC)
 void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
                       const int32_t *__restrict__ utt_off, int32_t n_utt,
-                      uint8_t *__restrict__ seed_cw,
-                      int32_t *__restrict__ topn_score, uint8_t *__restrict__ topn_cw)
+                      int32_t total_frames, int32_t chunk,
+                      const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out,
+                      int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw)
 {
+    static_assert(N == 4, "codeword lists are published as one packed uint32");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(
         (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int n_chain = p.n_chain;
-    if (wave >= n_utt * n_chain)
+    const int n_chunks = (total_frames + chunk - 1) / chunk;
+    if (wave >= n_chunks * n_chain)
         return;
-    const int utt = wave / n_chain;
-    const int chain = wave - utt * n_chain;
+    const int g = wave / n_chain;
+    const int chain = wave - g * n_chain;
     const int f = chain % p.n_feat;
-    const int t0 = utt_off[utt];
-    const int T = utt_off[utt + 1] - t0;
+    const int fbeg = g * chunk;
+    const int fend = min(total_frames, fbeg + chunk);
+    const int ds = p.ds_ratio;
+
+    // utterance holding frame fbeg: largest u with utt_off[u] <= fbeg (empty
+    // utterances share an offset; the largest such u is the non-empty one)
+    int u;
+    {
+        int lo = 0, hi = n_utt;          // invariant: utt_off[lo] <= fbeg < utt_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (utt_off[mid] <= fbeg) lo = mid; else hi = mid;
+        }
+        u = lo;
+    }
+    int ubeg = utt_off[u], uend = utt_off[u + 1];
 
     // Gaussian parameters of codewords `lane` and `lane + 64`
     float m0[LEN], v0[LEN], m1[LEN], v1[LEN];
@@ -143,146 +258,107 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
     }
     const float det0 = p.det[(size_t)chain * 128 + lane];
     const float det1 = p.det[(size_t)chain * 128 + lane + 64];
+    const int32_t tag0 = 127 - lane;                     // 127 - codeword
 
-    // seed list (ptm_mgau.c:790-793 for a fresh decoder)
     TopN<N> L;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        L.cw[i] = seed_cw ? (int32_t)seed_cw[((size_t)utt * n_chain + chain) * N + i] : i;
-        L.sc[i] = kMaxNegInt32;
-    }
-
-    const float *xrow = feats + (size_t)t0 * p.veclen + f * LEN;
-    float xn[LEN];
-    if (T > 0) {
-#pragma unroll
-        for (int j = 0; j < LEN; ++j) xn[j] = xrow[j];
-    }
-
-    for (int t = 0; t < T; ++t) {
-        float x[LEN];
-#pragma unroll
-        for (int j = 0; j < LEN; ++j) x[j] = xn[j];
-        if (t + 1 < T) {                       // prefetch the next frame's vector
-            const float *nx = xrow + (size_t)(t + 1) * p.veclen;
-#pragma unroll
-            for (int j = 0; j < LEN; ++j) xn[j] = nx[j];
-        }
-
-        // all 128 distances, reference operation order
-        float d0 = det0, d1 = det1;
-#pragma unroll
-        for (int j = 0; j < LEN; ++j) {
-            d0 = gau_step(d0, x[j], m0[j], v0[j]);
-            d1 = gau_step(d1, x[j], m1[j], v1[j]);
-        }
-
-        const bool scan_frame = (p.ds_ratio == 1) || ((t % p.ds_ratio) == 0);
-
-        // ---- fast path.  If the four largest truncated scores of the
-        // codebook are pairwise distinct and strictly above the fifth, the
-        // reference's seed/scan procedure ends with exactly those four in
-        // descending order whatever the seeds were ("top-N
-        // closed form"), so they are extracted with four wave-wide
-        // unique-maximum rounds.  Any tie falls through to the exact
-        // emulation below.
-        bool exact = !scan_frame;
-        if (scan_frame) {
-            int32_t s0 = dist_to_int(d0), s1 = dist_to_int(d1);
-            TopN<N> F;
-#pragma unroll
-            for (int r = 0; r < N; ++r) {
-                const int32_t mx = wave_max_i32(max(s0, s1));
-                const bool e0 = (s0 == mx), e1 = (s1 == mx);
-                const unsigned long long b0 = __ballot(e0), b1 = __ballot(e1);
-                if (__popcll(b0) + __popcll(b1) != 1)
-                    exact = true;
-                F.sc[r] = mx;
-                F.cw[r] = b0 ? (__ffsll((long long)b0) - 1) : (64 + __ffsll((long long)b1) - 1);
-                s0 = e0 ? kMaxNegInt32 : s0;
-                s1 = e1 ? kMaxNegInt32 : s1;
-            }
-            if (!exact) L = F;
-        }
-
-        if (exact) {
-        // ---- eval_topn: re-score the carried codewords, stable insertion
-        // sort, descending, strict '>' (ptm_mgau.c:71-85, :87-136)
+    auto load_seed = [&](int utt) __attribute__((always_inline)) {
+        // ptm_mgau.c:790-793 for a fresh decoder, else the carried codewords
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int c = L.cw[i];
-            const float d = (c < 64) ? lane_value(d0, c) : lane_value(d1, c - 64);
-            L.sc[i] = dist_to_int(d);
-#pragma unroll
-            for (int j = i; j > 0; --j) {
-                if (L.sc[j] > L.sc[j - 1]) {
-                    int32_t ts = L.sc[j]; L.sc[j] = L.sc[j - 1]; L.sc[j - 1] = ts;
-                    int32_t tc = L.cw[j]; L.cw[j] = L.cw[j - 1]; L.cw[j - 1] = tc;
-                }
-            }
+            L.cw[i] = seed_in ? (int32_t)seed_in[((size_t)utt * n_chain + chain) * N + i] : i;
+            L.sc[i] = kMaxNegInt32;
         }
+    };
 
-        // ---- eval_cb: scan codewords in index order against the moving
-        // threshold (ptm_mgau.c:151-226).  Only frames that are multiples of
-        // the downsampling ratio are scanned (:242).
-        if (scan_frame) {
-            int pos = 0;                        // next codeword index to look at
-            for (;;) {
-                const float th = (float)L.sc[N - 1];
-                bool in0 = false, in1 = false;
+    const float *xbase = feats + f * LEN;
+    auto distances = [&](int t, float &d0, float &d1) __attribute__((always_inline)) {
+        const float *x = xbase + (size_t)t * p.veclen;   // wave-uniform: scalar loads
+        d0 = det0; d1 = det1;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    in0 |= (L.cw[i] == lane);
-                    in1 |= (L.cw[i] == lane + 64);
-                }
-                unsigned long long b0 = __ballot(d0 >= th && !in0);
-                unsigned long long b1 = __ballot(d1 >= th && !in1);
-                if (pos >= 64) {
-                    b0 = 0;
-                    b1 = (pos >= 128) ? 0ull : (b1 & (~0ull << (pos - 64)));
-                }
-                else
-                    b0 &= (~0ull << pos);
-                if ((b0 | b1) == 0)
-                    break;
-                const int c = b0 ? (__ffsll((long long)b0) - 1)
-                                 : (64 + __ffsll((long long)b1) - 1);
-                const float d = (c < 64) ? lane_value(d0, c) : lane_value(d1, c - 64);
-                const int32_t s = dist_to_int(d);
-                // insertion_sort_cb (:140-149): ahead of equal scores, worst drops
-                int q = N - 1;
-#pragma unroll
-                for (int k = N - 1; k > 0; --k) {
-                    if (q == k && s >= L.sc[k - 1]) {
-                        L.sc[k] = L.sc[k - 1];
-                        L.cw[k] = L.cw[k - 1];
-                        q = k - 1;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    if (q == k) { L.sc[k] = s; L.cw[k] = c; }
-                }
-                pos = c + 1;
-            }
+        for (int j = 0; j < LEN; ++j) {
+            const float xj = x[j];
+            d0 = gau_step(d0, xj, m0[j], v0[j]);
+            d1 = gau_step(d1, xj, m1[j], v1[j]);
         }
-        }   // exact
+    };
 
-        // ---- publish the raw list of this frame
-        if (lane == 0) {
-            const size_t o = ((size_t)(t0 + t) * n_chain + chain) * N;
+    // Closed form: if the four largest truncated scores of the codebook are
+    // pairwise distinct and strictly above the fifth, the reference's
+    // seed/scan procedure ends with exactly those four in descending order
+    // whatever the seeds were (DESIGN.md "top-N closed form").  Selection key
+    // = clamp(trunc(d), -2^24, 2^24-1) << 7 | (127 - codeword): unique per
+    // codeword, so four wave-max rounds extract the winners.  Returns false
+    // (list untouched) if a winner touches the clamp bounds or on any tie.
+    auto closed_form = [&](float d0, float d1) __attribute__((always_inline)) -> bool {
+        const float c0 = __builtin_amdgcn_fmed3f(d0, (float)kKeyLo, (float)kKeyHi);
+        const float c1 = __builtin_amdgcn_fmed3f(d1, (float)kKeyLo, (float)kKeyHi);
+        const int32_t k0 = ((int32_t)c0 << 7) | tag0;
+        const int32_t k1 = (((int32_t)c1 << 7) | tag0) - 64;      // tag1 = tag0 - 64
+        int32_t hi = max(k0, k1), lo = min(k0, k1);
+        int32_t key[N];
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                topn_score[o + i] = L.sc[i];
-                topn_cw[o + i] = (uint8_t)L.cw[i];
-            }
+        for (int r = 0; r < N; ++r) {
+            key[r] = wave_max_i32(hi);
+            const bool win = (hi == key[r]);
+            hi = win ? lo : hi;
+            lo = win ? kMaxNegInt32 : lo;
         }
+        const int32_t s4 = key[N - 1] >> 7;
+        // a remaining codeword with the 4th winner's score, or a tie among
+        // the winners, or a clamped winner -> not closed
+        bool bad = __ballot(((hi >> 7) == s4) | ((lo >> 7) == s4)) != 0;
+        bad |= ((key[0] >> 7) >= kKeyHi) | (s4 <= kKeyLo);
+#pragma unroll
+        for (int r = 1; r < N; ++r) bad |= ((key[r] >> 7) == (key[r - 1] >> 7));
+        if (bad) return false;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            L.sc[r] = key[r] >> 7;
+            L.cw[r] = 127 - (key[r] & 127);
+        }
+        return true;
+    };
+
+    // ---- incoming state
+    int t = fbeg;
+    load_seed(u);
+    if (fbeg > ubeg) {
+        int ws = fbeg - 1;
+        ws -= (ws - ubeg) % ds;                 // latest scan frame before the chunk
+        for (;;) {
+            float d0, d1;
+            distances(ws, d0, d1);
+            if (__builtin_expect(closed_form(d0, d1), 1)) break;
+            if (ws == ubeg) {                   // utterance start: exact step from the seed
+                exact_frame_step<N>(L, d0, d1, lane, true);
+                break;
+            }
+            ws -= ds;
+        }
+        t = ws + 1;                             // frames ws+1 .. fbeg-1 are replayed silently
     }
 
-    if (seed_cw && lane == 0) {
+    for (; t < fend; ++t) {
+        if (t == uend) {                        // next utterance starts here
+            do { ++u; ubeg = uend; uend = utt_off[u + 1]; } while (uend == ubeg);
+            load_seed(u);
+        }
+        float d0, d1;
+        distances(t, d0, d1);
+        const bool scan = (ds == 1) || (((t - ubeg) % ds) == 0);
+        if (__builtin_expect(!(scan && closed_form(d0, d1)), 0))
+            exact_frame_step<N>(L, d0, d1, lane, scan);
+        if (t >= fbeg && lane == 0) {           // publish the raw list of this frame
+            const size_t o = (size_t)t * n_chain + chain;
+            *reinterpret_cast<int4 *>(topn_score + o * N) = make_int4(L.sc[0], L.sc[1], L.sc[2], L.sc[3]);
+            topn_cw[o] = (uint32_t)L.cw[0] | ((uint32_t)L.cw[1] << 8) |
+                         ((uint32_t)L.cw[2] << 16) | ((uint32_t)L.cw[3] << 24);
+            if (seed_out && t == uend - 1) {    // carry-out of this utterance
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            seed_cw[((size_t)utt * n_chain + chain) * N + i] = (uint8_t)L.cw[i];
+                for (int i = 0; i < N; ++i)
+                    seed_out[((size_t)u * n_chain + chain) * N + i] = (uint8_t)L.cw[i];
+            }
+        }
     }
 }
 
@@ -379,6 +455,156 @@ void ptm_senone_kernel(PtmDev p, const int32_t *__restrict__ topn_score,
 }
 
 // ---------------------------------------------------------------------------
+// kernel 2, fast variant (3 streams, top-4).
+//
+// The model is re-laid out once at creation into "slots": senones sorted by
+// codebook, every codebook padded to a multiple of four slots (pad slots are
+// never stored).  A lane owns groups of four consecutive slots; the group
+// shares its 12 (stream, rank) mixture-weight rows, so the four weights of a
+// row arrive as ONE aligned dword from the slot-ordered, row-padded copy of
+// mixw, and there is no divergence between lanes.  All 12 loads of a group
+// are in flight before its first log-add.  Scores are staged in LDS in
+// senone order, the block minimum is subtracted, and the row leaves in
+// coalesced dword stores.
+// ---------------------------------------------------------------------------
+constexpr int kSenMaxIters = 8;
+constexpr int kLaSize = 512;                    // log-add table padded with zeros
+
+// fast_logmath_add (tied_mgau_common.h:106-125): min(x,y) - T[|x-y|].  With
+// uint8 weights and scores <= 96 the index stays below 512; the LDS copy of
+// the table is zero beyond the reference's entries.
+__device__ __forceinline__ int32_t logadd8_lds(const uint8_t *s_la, int32_t x, int32_t y)
+{
+    const int32_t lo = min(x, y);
+    const int32_t d = max(x, y) - lo;
+    return lo - (int32_t)s_la[d];
+}
+
+template <int ITERS>
+__global__ __launch_bounds__(512)
+void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
+                            const uint32_t *__restrict__ topn_cw,
+                            int16_t *__restrict__ senscr, int32_t *__restrict__ best_out,
+                            uint32_t flags)
+{
+    constexpr int N = 4, NF = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int16_t *s_out = reinterpret_cast<int16_t *>(smem);          // [n_sen] (+pad)
+    __shared__ uint32_t s_cw32[256 * NF];       // packed codewords per chain
+    __shared__ uint32_t s_sc32[256 * NF];       // packed normalised scores per chain
+    __shared__ uint8_t s_la[kLaSize];
+    __shared__ int32_t s_norm[NF];
+    __shared__ int32_t s_best;
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int frame = blockIdx.x;
+    const size_t lo = (size_t)frame * p.n_chain;
+
+    if (tid < NF) s_norm[tid] = kWorstScore;
+    if (tid == 0) s_best = 0x7fffffff;
+    for (int i = tid; i < kLaSize; i += nthr)
+        s_la[i] = (i < p.logadd8_size) ? p.logadd8[i] : 0;
+    __syncthreads();
+
+    // ptm_mgau_codebook_norm (:265-295)
+    int4 sc[3];
+    uint32_t cw[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {               // 3 x >=256 threads cover 768 chains
+        const int i = tid + h * nthr;
+        if (i < p.n_chain) {
+            sc[h] = *reinterpret_cast<const int4 *>(topn_score + (lo + i) * N);
+            cw[h] = topn_cw[lo + i];
+            atomicMax(&s_norm[i % NF], sc[h].x >> kSenscrShift);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const int i = tid + h * nthr;
+        if (i < p.n_chain) {
+            const int32_t norm = s_norm[i % NF];
+            const int32_t a = min(kMaxNegAscr, -((sc[h].x >> kSenscrShift) - norm));
+            const int32_t b = min(kMaxNegAscr, -((sc[h].y >> kSenscrShift) - norm));
+            const int32_t c = min(kMaxNegAscr, -((sc[h].z >> kSenscrShift) - norm));
+            const int32_t d = min(kMaxNegAscr, -((sc[h].w >> kSenscrShift) - norm));
+            s_sc32[i] = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+            s_cw32[i] = cw[h];
+        }
+    }
+    __syncthreads();
+
+    // ptm_mgau_senone_eval (:326-403), slot order
+    int32_t mybest = 0x7fffffff;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int g = tid + it * nthr;
+        if (g < p.n_groups) {
+            const uint32_t cb = p.group_cb[g];
+            const uint32_t slot = (uint32_t)g << 2;
+            uint32_t w[NF][N], nsc[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const uint32_t c4 = s_cw32[cb * NF + f];
+                nsc[f] = s_sc32[cb * NF + f];
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const uint32_t row = (uint32_t)f * p.n_density + ((c4 >> (8 * k)) & 0xff);
+                    w[f][k] = *reinterpret_cast<const uint32_t *>(
+                        p.mixw_slot + (size_t)(row * (uint32_t)p.slot_stride + slot));
+                }
+            }
+            const uint2 sen2 = *reinterpret_cast<const uint2 *>(p.slot_sen + slot);   // 4 x uint16
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int32_t ascore = 0;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    int32_t fden = (int32_t)((w[f][0] >> (8 * b)) & 0xff) + (int32_t)(nsc[f] & 0xff);
+#pragma unroll
+                    for (int k = 1; k < N; ++k) {
+                        const int32_t y = (int32_t)((w[f][k] >> (8 * b)) & 0xff) +
+                                          (int32_t)((nsc[f] >> (8 * k)) & 0xff);
+                        fden = logadd8_lds(s_la, fden, y);
+                    }
+                    ascore += fden;
+                }
+                const uint32_t sen = ((b < 2 ? sen2.x : sen2.y) >> (16 * (b & 1))) & 0xffff;
+                if (sen != 0xffff) {            // pad slots are dropped
+                    s_out[sen] = (int16_t)ascore;
+                    mybest = min(mybest, ascore);
+                }
+            }
+        }
+    }
+    // block minimum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        mybest = min(mybest, __shfl_xor(mybest, off));
+    if ((tid & 63) == 0) atomicMin(&s_best, mybest);
+    __syncthreads();
+    const int32_t best = s_best;
+    if (best_out && tid == 0) best_out[frame] = best;
+    const int32_t sub = (flags & PSGPU_PTM_RAW_SCORES) ? 0 : best;
+    int16_t *orow = senscr + (size_t)frame * p.n_sen;
+    if ((p.n_sen & 1) == 0) {                   // rows stay 4-byte aligned
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s_out);
+        uint32_t *o32 = reinterpret_cast<uint32_t *>(orow);
+        for (int i = tid; i < (p.n_sen >> 1); i += nthr) {
+            const uint32_t v = s32[i];
+            const uint32_t a = ((v & 0xffff) - (uint32_t)sub) & 0xffff;     // int16 wrap as in :398-400
+            const uint32_t b = ((v >> 16) - (uint32_t)sub) & 0xffff;
+            o32[i] = a | (b << 16);
+        }
+    }
+    else {
+        for (int i = tid; i < p.n_sen; i += nthr)
+            orow[i] = (int16_t)(s_out[i] - sub);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -438,6 +664,35 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
         return rc;
     }
     m->logadd8_size = logadd8_size;
+    {
+        // slot layout for the fast senone kernel: senones grouped by codebook,
+        // each codebook padded to a multiple of 4 slots
+        std::vector<std::vector<int>> by_cb(256);
+        for (int i = 0; i < n_sen; ++i) by_cb[sen2cb[i]].push_back(i);
+        std::vector<uint16_t> slot_sen;
+        std::vector<uint8_t> group_cb;
+        for (int cb = 0; cb < 256; ++cb) {
+            if (by_cb[cb].empty()) continue;
+            for (int i : by_cb[cb]) slot_sen.push_back((uint16_t)i);
+            while (slot_sen.size() % 4) slot_sen.push_back(0xffff);
+            while (group_cb.size() < slot_sen.size() / 4) group_cb.push_back((uint8_t)cb);
+        }
+        m->n_groups = (int32_t)group_cb.size();
+        const size_t n_slots = slot_sen.size();
+        m->slot_stride = (int32_t)(((n_slots + 63) / 64) * 64);
+        const size_t rows = (size_t)n_feat * n_density;
+        std::vector<uint8_t> ms(rows * m->slot_stride, 255);
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t sl = 0; sl < n_slots; ++sl)
+                if (slot_sen[sl] != 0xffff)
+                    ms[r * m->slot_stride + sl] = mixw[r * (size_t)n_sen + slot_sen[sl]];
+        if ((rc = upload(&m->mixw_slot, ms.data(), ms.size())) ||
+            (rc = upload(&m->group_cb, group_cb.data(), group_cb.size())) ||
+            (rc = upload(&m->slot_sen, slot_sen.data(), slot_sen.size()))) {
+            psgpu_ptm_model_free(m);
+            return rc;
+        }
+    }
     *out = m;
     return PSGPU_OK;
 }
@@ -447,6 +702,7 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     if (!m) return;
     hipFree(m->mean); hipFree(m->var); hipFree(m->det);
     hipFree(m->mixw); hipFree(m->sen2cb); hipFree(m->logadd8);
+    hipFree(m->mixw_slot); hipFree(m->group_cb); hipFree(m->slot_sen);
     delete m;
 }
 
@@ -457,18 +713,39 @@ int32_t psgpu_ptm_topn(const psgpu_ptm_model_t *m) { return m->topn; }
 
 int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
                        const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
-                       uint8_t *seed_cw_dev, int32_t *topn_score_dev,
-                       uint8_t *topn_cw_dev, void *stream)
+                       const uint8_t *seed_in_dev, uint8_t *seed_out_dev,
+                       int32_t *topn_score_dev, uint8_t *topn_cw_dev, void *stream)
 {
     PSGPU_REQUIRE(m && feats_dev && utt_off_dev && topn_score_dev && topn_cw_dev,
                   "psgpu_ptm_topn_dev: NULL argument");
     PSGPU_REQUIRE(n_utt >= 0 && total_frames >= 0, "negative sizes");
+    PSGPU_REQUIRE(seed_in_dev == nullptr || seed_in_dev != seed_out_dev,
+                  "seed_in and seed_out must not alias (chunks read seeds while others write carry-outs)");
     if (n_utt == 0 || total_frames == 0) return PSGPU_OK;
-    const long long waves = (long long)n_utt * m->n_chain;
+    // chunk length: enough wavefronts to fill 256 CUs x 32 waves a few times
+    // over, but long enough to amortise the parameter load and the one-frame
+    // warm-up of every chunk.
+    static const int forced = [] { const char *e = getenv("PSGPU_CHUNK"); return e ? atoi(e) : 0; }();
+    int chunk = forced;
+    if (chunk <= 0) {
+        const long long target_waves = 4LL * 256 * 32;
+        long long c = ((long long)total_frames * m->n_chain + target_waves - 1) / target_waves;
+        chunk = (int)(c < 32 ? 32 : (c > 512 ? 512 : c));
+    }
+    const long long n_chunks = ((long long)total_frames + chunk - 1) / chunk;
+    const long long waves = n_chunks * m->n_chain;
     const int blocks = (int)((waves + 3) / 4);
-    hipLaunchKernelGGL((ptm_chain_kernel<13, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       dev_view(m), feats_dev, utt_off_dev, n_utt, seed_cw_dev,
-                       topn_score_dev, topn_cw_dev);
+    static const int occ = [] { const char *e = getenv("PSGPU_CHAIN_OCC"); return e ? atoi(e) : 8; }();
+    if (occ >= 8)
+        hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           dev_view(m), feats_dev, utt_off_dev, n_utt, total_frames, chunk,
+                           seed_in_dev, seed_out_dev, topn_score_dev,
+                           reinterpret_cast<uint32_t *>(topn_cw_dev));
+    else
+        hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           dev_view(m), feats_dev, utt_off_dev, n_utt, total_frames, chunk,
+                           seed_in_dev, seed_out_dev, topn_score_dev,
+                           reinterpret_cast<uint32_t *>(topn_cw_dev));
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
@@ -481,6 +758,33 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
     PSGPU_REQUIRE(m && topn_score_dev && topn_cw_dev && senscr_dev,
                   "psgpu_ptm_senone_dev: NULL argument");
     if (total_frames <= 0) return PSGPU_OK;
+    static const int force_generic = [] { const char *e = getenv("PSGPU_SENONE_GENERIC"); return e ? atoi(e) : 0; }();
+    if (!force_generic && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 768 && m->n_sen < 0xffff) {
+        // block = 4..8 waves: pick the width that wastes the fewest lanes
+        int best_w = 0, iters = 0;
+        double best_eff = 0;
+        for (int w = 4; w <= 8; ++w) {
+            const int it = (m->n_groups + 64 * w - 1) / (64 * w);
+            const double eff = (double)m->n_groups / ((double)it * 64 * w);
+            if (it <= kSenMaxIters && eff > best_eff + 1e-9) { best_eff = eff; best_w = w; iters = it; }
+        }
+        if (best_w) {
+            const dim3 grid(total_frames), block(64 * best_w);
+            const size_t sm = (((size_t)m->n_sen * 2 + 15) / 16) * 16;
+            hipStream_t st = (hipStream_t)stream;
+            const PtmDev pv = dev_view(m);
+            const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(topn_cw_dev);
+#define PSGPU_SEN_CASE(I) case I: hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I>), grid, block, sm, st, pv, \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags); break;
+            switch (iters) {
+                PSGPU_SEN_CASE(1) PSGPU_SEN_CASE(2) PSGPU_SEN_CASE(3) PSGPU_SEN_CASE(4)
+                PSGPU_SEN_CASE(5) PSGPU_SEN_CASE(6) PSGPU_SEN_CASE(7) default: PSGPU_SEN_CASE(8)
+            }
+#undef PSGPU_SEN_CASE
+            PSGPU_HIP(hipGetLastError());
+            return PSGPU_OK;
+        }
+    }
     const int out_bytes = ((m->n_sen * 2 + 15) / 16) * 16;
     const int list_bytes = ((m->n_chain * 4 + 15) / 16) * 16;
     const size_t smem = (size_t)out_bytes + 2 * list_bytes + 256 + 16 * 4 + 8 * 4;
@@ -494,13 +798,13 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
 int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
                               const float *feats_dev, const int32_t *utt_off_dev,
                               int32_t n_utt, int32_t total_frames,
-                              uint8_t *seed_cw_dev,
+                              const uint8_t *seed_in_dev, uint8_t *seed_out_dev,
                               int32_t *topn_score_dev, uint8_t *topn_cw_dev,
                               int16_t *senscr_dev, int32_t *best_dev,
                               uint32_t flags, void *stream)
 {
-    int rc = psgpu_ptm_topn_dev(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_cw_dev,
-                                topn_score_dev, topn_cw_dev, stream);
+    int rc = psgpu_ptm_topn_dev(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev,
+                                seed_out_dev, topn_score_dev, topn_cw_dev, stream);
     if (rc != PSGPU_OK || senscr_dev == nullptr) return rc;
     return psgpu_ptm_senone_dev(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev,
                                 best_dev, flags, stream);
@@ -521,11 +825,11 @@ int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
     if (T == 0) return PSGPU_OK;
     const size_t n_ent = (size_t)T * m->n_chain * m->topn;
     float *d_feat = nullptr; int32_t *d_off = nullptr, *d_sc = nullptr, *d_best = nullptr;
-    uint8_t *d_seed = nullptr, *d_cw = nullptr; int16_t *d_scr = nullptr;
+    uint8_t *d_seed = nullptr, *d_seed_out = nullptr, *d_cw = nullptr; int16_t *d_scr = nullptr;
     int rc = PSGPU_OK;
     auto cleanup = [&]() {
         hipFree(d_feat); hipFree(d_off); hipFree(d_sc); hipFree(d_best);
-        hipFree(d_seed); hipFree(d_cw); hipFree(d_scr);
+        hipFree(d_seed); hipFree(d_seed_out); hipFree(d_cw); hipFree(d_scr);
     };
 #define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) {                 \
         psgpu_set_error("%s -> %s", #call, hipGetErrorString(e_)); cleanup();          \
@@ -539,18 +843,21 @@ int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
     if (seed_cw) {
         TRY(hipMalloc((void **)&d_seed, (size_t)n_utt * m->n_chain * m->topn));
         TRY(hipMemcpy(d_seed, seed_cw, (size_t)n_utt * m->n_chain * m->topn, hipMemcpyHostToDevice));
+        TRY(hipMalloc((void **)&d_seed_out, (size_t)n_utt * m->n_chain * m->topn));
+        // empty utterances pass their seed through unchanged
+        TRY(hipMemcpy(d_seed_out, seed_cw, (size_t)n_utt * m->n_chain * m->topn, hipMemcpyHostToDevice));
     }
     if (senscr) TRY(hipMalloc((void **)&d_scr, (size_t)T * m->n_sen * sizeof(int16_t)));
     if (best) TRY(hipMalloc((void **)&d_best, (size_t)T * sizeof(int32_t)));
-    rc = psgpu_ptm_score_batch_dev(m, d_feat, d_off, n_utt, T, d_seed, d_sc, d_cw, d_scr, d_best,
-                                   flags, nullptr);
+    rc = psgpu_ptm_score_batch_dev(m, d_feat, d_off, n_utt, T, d_seed, d_seed_out, d_sc, d_cw,
+                                   d_scr, d_best, flags, nullptr);
     if (rc == PSGPU_OK) {
         TRY(hipDeviceSynchronize());
         if (topn_score) TRY(hipMemcpy(topn_score, d_sc, n_ent * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (topn_cw) TRY(hipMemcpy(topn_cw, d_cw, n_ent, hipMemcpyDeviceToHost));
         if (senscr) TRY(hipMemcpy(senscr, d_scr, (size_t)T * m->n_sen * sizeof(int16_t), hipMemcpyDeviceToHost));
         if (best) TRY(hipMemcpy(best, d_best, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (seed_cw) TRY(hipMemcpy(seed_cw, d_seed, (size_t)n_utt * m->n_chain * m->topn, hipMemcpyDeviceToHost));
+        if (seed_cw) TRY(hipMemcpy(seed_cw, d_seed_out, (size_t)n_utt * m->n_chain * m->topn, hipMemcpyDeviceToHost));
     }
 #undef TRY
     cleanup();
