@@ -193,12 +193,15 @@ def main():
                         else ("ptm_senone_kernel", sen_ms))
     achieved = BYTES_PER_FRAME * T / (dom_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(dom_name)
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:       # newest committed PMC pass (tools/gpu_round.sh + tools/prof_collect.py)
+            k = [v for n, v in json.load(open(tpath)).items() if dom_name.startswith(n) or n.startswith(dom_name)]
+            if k and k[0].get("hbm_bytes_per_launch"):
+                traffic = round(k[0]["hbm_bytes_per_launch"])
+                break
         except Exception:
-            traffic = None
+            continue
     line = {
         "metric": "frames/sec senone scoring, en-us PTM 5126 senones (bit-exact int16)",
         "value": round(fps, 1), "unit": "frames/s",

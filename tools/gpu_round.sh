@@ -1,0 +1,32 @@
+#!/bin/bash
+# tools/gpu_round.sh -- one gpurun call: GPU parity tests, bench line, rocprofv3
+# kernel-trace stats and the two PMC passes (FETCH_SIZE / WRITE_SIZE cannot
+# share a pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").  Everything lands
+# under gpurun_out/<tag>/; tools/prof_collect.py condenses it for profiles/.
+#   usage: tools/gpu_round.sh TAG [skip-tests]
+set -u
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+
+if [ "${2:-}" != "skip-tests" ]; then
+  (timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15) > "$OUT/pytest_gpu.log"
+  cat "$OUT/pytest_gpu.log"
+  (timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3) > "$OUT/smoke.log"
+  cat "$OUT/smoke.log"
+fi
+
+timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -1 "$OUT/bench.json"; tail -3 "$OUT/bench.err"
+
+BENCH="python $PWD/bench.py --no-cpu-baseline --steps 20 --warmup 3"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -T -f csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -T -f csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -T -f csv -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/pmc_write.log" 2>&1
+cd - > /dev/null
+# keep only what is small enough to merge back
+find "$OUT" -name '*_kernel_trace.csv' -size +8M -delete
+python tools/prof_collect.py "$OUT" "$TAG" 2>&1 | tail -40
