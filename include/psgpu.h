@@ -141,6 +141,42 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
                          int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,
                          void *stream);
 
+/* ---- per-call scoring state: the ps_mgau_t::frame_eval replacement -------
+ * One object per decoder.  Replaces the mutable part of ptm_mgau_t
+ * (ptm_mgau.h:68-97): the history ring hist[n_fast_hist] of top-N lists and
+ * active-codebook sets (ptm_mgau.c:884-890), kept in HBM.
+ *
+ * psgpu_ptm_frame_eval() is ptm_mgau_frame_eval() (ptm_mgau.c:408-454) with
+ * the reference's exact call contract (acmod.h:98-111):
+ *   senscr          [n_sen] int16 out (host), fully written: listed senones
+ *                   get their score, every other entry becomes -best
+ *                   (ptm_mgau.c:398-400)
+ *   senone_active   uint8 DELTAS as built by acmod_flags2list
+ *                   (acmod.c:1223-1275); ignored when compallsen != 0
+ *   feat            the frame's feature vector, streams concatenated
+ *                   (veclen floats; the reference's mfcc_t** points at the
+ *                   same contiguous floats, feat/feat.c:356-384)
+ *   frame           frame number; slot = frame % n_fast_hist
+ *   frame_idx       the caller's ps_mgau_t.frame_idx (acmod.h:113-116, written
+ *                   by acmod_start_utt / acmod_advance / acmod_rewind,
+ *                   acmod.c:419,862,874): codebooks are evaluated only when
+ *                   frame >= frame_idx, otherwise the slot is reused.
+ * The call is synchronous (returns with senscr filled).
+ * psgpu_ptm_state_reset() is ptm_mgau_reset_fast_hist() (ptm_mgau.c:777-802).
+ * psgpu_ptm_state_get_topn() copies one slot's lists out ([n_chain][topn]
+ * int32 each; slot -1 = the slot of the last call) -- the reference exposes
+ * the same data as s->f->topn. */
+typedef struct psgpu_ptm_state_s psgpu_ptm_state_t;
+
+int psgpu_ptm_state_create(psgpu_ptm_state_t **out, psgpu_ptm_model_t *m, int32_t n_fast_hist);
+void psgpu_ptm_state_free(psgpu_ptm_state_t *s);
+int psgpu_ptm_state_reset(psgpu_ptm_state_t *s);
+int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
+                         const uint8_t *senone_active, int32_t n_senone_active,
+                         const float *feat, int32_t frame, int32_t frame_idx,
+                         int32_t compallsen);
+int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score);
+
 #ifdef __cplusplus
 }
 #endif

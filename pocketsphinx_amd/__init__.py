@@ -10,6 +10,6 @@ raises ``PsgpuError`` unless the HIP library is built and a gfx950 device is
 present.
 """
 from .capi import PsgpuError, lib, build_library, LIB_PATH  # noqa: F401
-from .ptm import PtmModel, PtmMgau  # noqa: F401
+from .ptm import PtmModel, PtmMgau, PtmState  # noqa: F401
 
-__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau"]
+__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState"]

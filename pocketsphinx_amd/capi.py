@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip"]
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip"]
 
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -17,6 +17,8 @@ SYMBOLS = [
     "psgpu_ptm_veclen", "psgpu_ptm_topn", "psgpu_ptm_score_batch_dev", "psgpu_ptm_score_batch",
     "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",
     "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev",
+    "psgpu_ptm_state_create", "psgpu_ptm_state_free", "psgpu_ptm_state_reset",
+    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn",
 ]
 
 
@@ -28,7 +30,7 @@ def build_library(force=False):
     """Compile the HIP sources for gfx950 into pocketsphinx_amd/libpsgpu.so
     (in-tree, so it travels to the GPU box).  hipcc cross-compiles without a GPU."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "psgpu_internal.h"), os.path.join(ROOT, "include", "psgpu.h")]
+    deps = srcs + [os.path.join(CSRC, "psgpu_internal.h"), os.path.join(CSRC, "psgpu_ptm_dev.h"), os.path.join(ROOT, "include", "psgpu.h")]
     if (not force) and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -80,6 +82,12 @@ def lib():
     L.psgpu_ptm_score_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, u32]
     L.psgpu_ptm_topn_dev.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.psgpu_ptm_senone_dev.argtypes = [vp, i32, vp, vp, vp, vp, u32, vp]
+    L.psgpu_ptm_state_create.argtypes = [C.POINTER(vp), vp, i32]
+    L.psgpu_ptm_state_free.argtypes = [vp]
+    L.psgpu_ptm_state_free.restype = None
+    L.psgpu_ptm_state_reset.argtypes = [vp]
+    L.psgpu_ptm_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32]
+    L.psgpu_ptm_state_get_topn.argtypes = [vp, i32, vp, vp]
     L.psgpu_event_create.argtypes = [C.POINTER(vp)]
     L.psgpu_event_destroy.argtypes = [vp]
     L.psgpu_event_record.argtypes = [vp, vp]

@@ -1,0 +1,354 @@
+// psgpu_ptm_frame.hip -- the stateful, per-call PTM scorer: a literal device
+// replacement of ptm_mgau_frame_eval() (reference src/ptm_mgau.c:408-454)
+// including everything the batched path may ignore: the history ring
+// hist[n_fast_hist] (:884-890), the `frame >= frame_idx` rule (:430), the
+// active-codebook subset derived from the active senone list (:297-321),
+// seeds-only re-scoring of inactive codebooks (:237-239 vs :246-251), the
+// in-place normalisation of active codebooks only (:265-295), the persistent
+// overwrite with MAX_NEG_ASCR (:353-364) and the best-score subtraction over
+// ALL n_sen entries (:398-400).  This is what the ps_mgau_t vtable shim
+// (integration/psgpu_mgau_shim.c) calls once per acmod_score().
+//
+// All state lives in HBM; a call is 1-2 kernel launches on the state's own
+// stream, the scores leave through a host-mapped (pinned) buffer.
+#include "psgpu_ptm_dev.h"
+#include <cstring>
+#include <cstdlib>
+
+constexpr int kMaxVec = 64;            // feature vector travels as a kernel argument
+struct FeatArg { float x[kMaxVec]; };
+struct MaskArg { uint32_t w[8]; };     // active codebooks, n_mgau <= 256 (ptm_mgau.c:838)
+
+struct psgpu_ptm_state_s {
+    psgpu_ptm_model_t *m;
+    int32_t n_hist;
+    int32_t *hist_cw;        // [n_hist][n_chain][topn]
+    int32_t *hist_sc;        // [n_hist][n_chain][topn]  raw or normalised, as the reference's slot
+    uint32_t *hist_active;   // [n_hist][8]
+    uint16_t *h_list;        // pinned + mapped: absolute senone ids of the active list
+    uint16_t *d_list;        // device alias of h_list
+    int16_t *h_out;          // pinned + mapped: n_sen scores
+    int16_t *d_out;
+    hipStream_t stream;
+    int32_t cur;             // slot of the most recent call (s->f)
+};
+
+// ---------------------------------------------------------------------------
+// kernel A: one wavefront per (codebook, stream) chain, one frame.
+//   copy the previous slot's codewords (ptm_mgau.c:435-441), eval_topn for
+//   every chain (:237-239), eval_cb for chains of active codebooks on scan
+//   frames (:242-251).  Raw lists go to the current slot.
+// ---------------------------------------------------------------------------
+template <int LEN>
+__global__ __launch_bounds__(256)
+void ptm_frame_topn_kernel(PtmDev p, FeatArg fa, MaskArg mask, int32_t do_scan,
+                           const int32_t *__restrict__ prev_cw,
+                           int32_t *__restrict__ cur_cw, int32_t *__restrict__ cur_sc,
+                           uint32_t *__restrict__ cur_active)
+{
+    constexpr int N = 4;
+    const int lane = threadIdx.x & 63;
+    const int chain = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (blockIdx.x == 0 && threadIdx.x < 8)
+        cur_active[threadIdx.x] = mask.w[threadIdx.x];
+    if (chain >= p.n_chain)
+        return;
+    const int cb = chain / p.n_feat;
+    const int f = chain - cb * p.n_feat;
+    const bool active = (mask.w[cb >> 5] >> (cb & 31)) & 1u;
+
+    const float *mp = p.mean + ((size_t)chain * 128 + lane) * LEN;
+    const float *vp = p.var + ((size_t)chain * 128 + lane) * LEN;
+    float d0 = p.det[(size_t)chain * 128 + lane];
+    float d1 = p.det[(size_t)chain * 128 + lane + 64];
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+        const float xj = fa.x[f * LEN + j];
+        d0 = gau_step(d0, xj, mp[j], vp[j]);
+        d1 = gau_step(d1, xj, mp[64 * LEN + j], vp[64 * LEN + j]);
+    }
+    TopN<N> L;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        L.cw[i] = __builtin_amdgcn_readfirstlane(prev_cw[(size_t)chain * N + i]);
+        L.sc[i] = kMaxNegInt32;
+    }
+    const bool scan = active && do_scan;
+    if (!(scan && closed_form_top4(L, d0, d1, 127 - lane)))
+        exact_frame_step<N>(L, d0, d1, lane, scan);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            cur_cw[(size_t)chain * N + i] = L.cw[i];
+            cur_sc[(size_t)chain * N + i] = L.sc[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel B: one workgroup.  ptm_mgau_codebook_norm (only when the slot was
+// just evaluated) + ptm_mgau_senone_eval over the listed senones.
+// ---------------------------------------------------------------------------
+constexpr int kFrameThreads = 1024;
+constexpr int kFrameLa = 512;
+
+__global__ __launch_bounds__(kFrameThreads)
+void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n_list,
+                             const uint16_t *__restrict__ list,
+                             const int32_t *__restrict__ cur_cw, int32_t *__restrict__ cur_sc,
+                             const uint32_t *__restrict__ cur_active,
+                             int16_t *__restrict__ out)
+{
+    constexpr int N = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int16_t *s_out = reinterpret_cast<int16_t *>(smem);                    // [n_sen]
+    const int out_bytes = ((p.n_sen * 2 + 15) / 16) * 16;
+    int32_t *s_sc = reinterpret_cast<int32_t *>(smem + out_bytes);         // [n_chain * N]
+    uint8_t *s_cw = reinterpret_cast<uint8_t *>(s_sc + p.n_chain * N);     // [n_chain * N]
+    __shared__ uint8_t s_la[kFrameLa];
+    __shared__ int32_t s_norm[16];
+    __shared__ uint32_t s_active[8], s_touch[8];
+    __shared__ int32_t s_best;
+
+    const int tid = threadIdx.x;
+    const int n_ent = p.n_chain * N;
+    if (tid < 16) s_norm[tid] = kWorstScore;
+    if (tid < 8) { s_active[tid] = cur_active[tid]; s_touch[tid] = 0; }
+    if (tid == 0) s_best = 0x7fffffff;
+    for (int i = tid; i < kFrameLa; i += kFrameThreads)
+        s_la[i] = (i < p.logadd8_size) ? p.logadd8[i] : 0;
+    for (int i = tid; i < n_ent; i += kFrameThreads) {
+        s_sc[i] = cur_sc[i];
+        s_cw[i] = (uint8_t)cur_cw[i];
+    }
+    for (int i = tid; i < p.n_sen; i += kFrameThreads)
+        s_out[i] = 0;                                      // memset (:333)
+    __syncthreads();
+
+    if (fresh) {
+        // ptm_mgau_codebook_norm (:265-295), active codebooks only
+        for (int c = tid; c < p.n_chain; c += kFrameThreads) {
+            const int cb = c / p.n_feat, f = c - cb * p.n_feat;
+            if ((s_active[cb >> 5] >> (cb & 31)) & 1u)
+                atomicMax(&s_norm[f], s_sc[c * N] >> kSenscrShift);
+        }
+        __syncthreads();
+        for (int i = tid; i < n_ent; i += kFrameThreads) {
+            const int c = i / N;
+            const int cb = c / p.n_feat, f = c - cb * p.n_feat;
+            if ((s_active[cb >> 5] >> (cb & 31)) & 1u) {
+                // int arithmetic wraps exactly as the reference's
+                int32_t v = (int32_t)((uint32_t)(s_sc[i] >> kSenscrShift) - (uint32_t)s_norm[f]);
+                v = (int32_t)(0u - (uint32_t)v);
+                if (v > kMaxNegAscr) v = kMaxNegAscr;
+                s_sc[i] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // listed senones of inactive codebooks force that codebook's scores to
+    // MAX_NEG_ASCR, persistently in the slot (:353-364)
+    const int n = compall ? p.n_sen : n_list;
+    for (int i = tid; i < n; i += kFrameThreads) {
+        const int sen = compall ? i : list[i];
+        const int cb = p.sen2cb[sen];
+        if (!((s_active[cb >> 5] >> (cb & 31)) & 1u))
+            atomicOr(&s_touch[cb >> 5], 1u << (cb & 31));
+    }
+    __syncthreads();
+    for (int i = tid; i < n_ent; i += kFrameThreads) {
+        const int cb = (i / N) / p.n_feat;
+        if ((s_touch[cb >> 5] >> (cb & 31)) & 1u)
+            s_sc[i] = kMaxNegAscr;
+    }
+    __syncthreads();
+    // the slot keeps what the reference would leave in it
+    for (int i = tid; i < n_ent; i += kFrameThreads)
+        cur_sc[i] = s_sc[i];
+
+    // ptm_mgau_senone_eval (:326-403)
+    int32_t mybest = 0x7fffffff;
+    for (int i = tid; i < n; i += kFrameThreads) {
+        const int sen = compall ? i : list[i];
+        const int cb = p.sen2cb[sen];
+        int32_t ascore = 0;
+        for (int f = 0; f < p.n_feat; ++f) {
+            const int li = (cb * p.n_feat + f) * N;
+            const uint8_t *wrow = p.mixw + (size_t)f * p.n_density * p.n_sen + sen;
+            int32_t w[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                w[k] = wrow[(size_t)s_cw[li + k] * p.n_sen];
+            int32_t fden = w[0] + s_sc[li];
+#pragma unroll
+            for (int k = 1; k < N; ++k) {
+                // fast_logmath_add (tied_mgau_common.h:106-125)
+                const int32_t y = w[k] + s_sc[li + k];
+                const int32_t lo_ = min(fden, y);
+                const uint32_t d = (uint32_t)(max(fden, y) - lo_);
+                fden = lo_ - (d < (uint32_t)kFrameLa ? (int32_t)s_la[d] : 0);
+            }
+            ascore += fden;
+        }
+        s_out[sen] = (int16_t)ascore;
+        mybest = min(mybest, ascore);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        mybest = min(mybest, __shfl_xor(mybest, off));
+    if ((tid & 63) == 0) atomicMin(&s_best, mybest);
+    __syncthreads();
+    const uint32_t best = (uint32_t)s_best;
+    for (int i = tid; i < p.n_sen; i += kFrameThreads)
+        out[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)s_out[i] - best);   // int16 -= int (:398-400)
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int psgpu_ptm_state_reset(psgpu_ptm_state_t *s)
+{
+    PSGPU_REQUIRE(s != nullptr, "psgpu_ptm_state_reset: NULL state");
+    // ptm_mgau_reset_fast_hist (ptm_mgau.c:777-802): cw = 0..N-1,
+    // score = WORST_DIST, every codebook active, in every slot
+    const psgpu_ptm_model_t *m = s->m;
+    const size_t n = (size_t)s->n_hist * m->n_chain * m->topn;
+    int32_t *cw = (int32_t *)malloc(n * sizeof(int32_t));
+    int32_t *sc = (int32_t *)malloc(n * sizeof(int32_t));
+    if (!cw || !sc) { free(cw); free(sc); psgpu_set_error("out of host memory"); return PSGPU_ENOMEM; }
+    for (size_t i = 0; i < n; ++i) { cw[i] = (int32_t)(i % m->topn); sc[i] = kMaxNegInt32; }
+    uint32_t act[64 * 8];
+    memset(act, 0xff, sizeof act);
+    hipError_t e1 = hipMemcpy(s->hist_cw, cw, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(s->hist_sc, sc, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipError_t e3 = hipMemcpy(s->hist_active, act, (size_t)s->n_hist * 8 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    free(cw); free(sc);
+    PSGPU_HIP(e1); PSGPU_HIP(e2); PSGPU_HIP(e3);
+    s->cur = 0;
+    return PSGPU_OK;
+}
+
+int psgpu_ptm_state_create(psgpu_ptm_state_t **out, psgpu_ptm_model_t *m, int32_t n_fast_hist)
+{
+    PSGPU_REQUIRE(out && m, "psgpu_ptm_state_create: NULL argument");
+    PSGPU_REQUIRE(n_fast_hist >= 1 && n_fast_hist <= 64, "n_fast_hist %d outside 1..64", n_fast_hist);
+    PSGPU_REQUIRE(m->veclen <= kMaxVec, "feature vector of %d floats exceeds %d", m->veclen, kMaxVec);
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    psgpu_ptm_state_t *s = new psgpu_ptm_state_t();
+    memset(s, 0, sizeof *s);
+    s->m = m; s->n_hist = n_fast_hist;
+    const size_t n = (size_t)n_fast_hist * m->n_chain * m->topn;
+    hipError_t e = hipMalloc((void **)&s->hist_cw, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->hist_sc, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->hist_active, (size_t)n_fast_hist * 8 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_list, (size_t)m->n_sen * sizeof(uint16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, (size_t)m->n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_list, s->h_list, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_out, s->h_out, 0);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        psgpu_set_error("psgpu_ptm_state_create: %s", hipGetErrorString(e));
+        psgpu_ptm_state_free(s);
+        return e == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP;
+    }
+    rc = psgpu_ptm_state_reset(s);
+    if (rc != PSGPU_OK) { psgpu_ptm_state_free(s); return rc; }
+    *out = s;
+    return PSGPU_OK;
+}
+
+void psgpu_ptm_state_free(psgpu_ptm_state_t *s)
+{
+    if (!s) return;
+    if (s->stream) hipStreamDestroy(s->stream);
+    hipFree(s->hist_cw); hipFree(s->hist_sc); hipFree(s->hist_active);
+    if (s->h_list) hipHostFree(s->h_list);
+    if (s->h_out) hipHostFree(s->h_out);
+    delete s;
+}
+
+int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
+                         const uint8_t *senone_active, int32_t n_senone_active,
+                         const float *feat, int32_t frame, int32_t frame_idx,
+                         int32_t compallsen)
+{
+    PSGPU_REQUIRE(s && senscr && feat, "psgpu_ptm_frame_eval: NULL argument");
+    PSGPU_REQUIRE(frame >= 0, "negative frame %d", frame);
+    PSGPU_REQUIRE(compallsen || n_senone_active == 0 || senone_active,
+                  "active list missing (compallsen is off)");
+    psgpu_ptm_model_t *m = s->m;
+    const PtmDev pv = dev_view(m);
+    const int slot = frame % s->n_hist;                      // ptm_mgau.c:425-426
+    const size_t slot_len = (size_t)m->n_chain * m->topn;
+    int32_t *cur_cw = s->hist_cw + slot * slot_len;
+    int32_t *cur_sc = s->hist_sc + slot * slot_len;
+    uint32_t *cur_act = s->hist_active + (size_t)slot * 8;
+    const int fresh = frame >= frame_idx;                    // :430
+    s->cur = slot;
+
+    // active list: uint8 deltas -> absolute ids (the list acmod_flags2list
+    // built, acmod.c:1223-1275), and the codebooks it touches (:297-321)
+    MaskArg mask;
+    memset(&mask, 0, sizeof mask);
+    int n_list = 0;
+    if (compallsen) {
+        memset(&mask, 0xff, sizeof mask);
+    }
+    else {
+        int sen = 0;
+        for (int i = 0; i < n_senone_active; ++i) {
+            sen += senone_active[i];
+            if (sen >= m->n_sen) {
+                psgpu_set_error("active list runs past n_sen (%d >= %d)", sen, m->n_sen);
+                return PSGPU_EINVAL;
+            }
+            s->h_list[n_list++] = (uint16_t)sen;
+        }
+    }
+    if (fresh) {
+        if (!compallsen) {
+            // sen2cb lookups happen on the device copy; the host only needs the
+            // codebook set, which the model keeps a host mirror of
+            for (int i = 0; i < n_list; ++i) {
+                const int cb = m->h_sen2cb[s->h_list[i]];
+                mask.w[cb >> 5] |= 1u << (cb & 31);
+            }
+        }
+        const int prev = (slot == 0) ? s->n_hist - 1 : slot - 1;
+        FeatArg fa;
+        memset(&fa, 0, sizeof fa);
+        memcpy(fa.x, feat, (size_t)m->veclen * sizeof(float));
+        const int blocks = (m->n_chain + 3) / 4;
+        hipLaunchKernelGGL((ptm_frame_topn_kernel<13>), dim3(blocks), dim3(256), 0, s->stream,
+                           pv, fa, mask, (int32_t)(frame % m->ds_ratio == 0),
+                           (const int32_t *)(s->hist_cw + prev * slot_len), cur_cw, cur_sc, cur_act);
+        PSGPU_HIP(hipGetLastError());
+    }
+    const size_t smem = (((size_t)m->n_sen * 2 + 15) / 16) * 16 + slot_len * 5;
+    hipLaunchKernelGGL(ptm_frame_senone_kernel, dim3(1), dim3(kFrameThreads), smem, s->stream,
+                       pv, (int32_t)fresh, (int32_t)(compallsen != 0), (int32_t)n_list,
+                       (const uint16_t *)s->d_list, (const int32_t *)cur_cw, cur_sc,
+                       (const uint32_t *)cur_act, s->d_out);
+    PSGPU_HIP(hipGetLastError());
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    memcpy(senscr, s->h_out, (size_t)m->n_sen * sizeof(int16_t));
+    return PSGPU_OK;
+}
+
+int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score)
+{
+    PSGPU_REQUIRE(s != nullptr, "psgpu_ptm_state_get_topn: NULL state");
+    if (slot < 0) slot = s->cur;
+    PSGPU_REQUIRE(slot < s->n_hist, "slot %d outside the %d-slot ring", slot, s->n_hist);
+    const size_t slot_len = (size_t)s->m->n_chain * s->m->topn;
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    if (cw) PSGPU_HIP(hipMemcpy(cw, s->hist_cw + slot * slot_len, slot_len * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (score) PSGPU_HIP(hipMemcpy(score, s->hist_sc + slot * slot_len, slot_len * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return PSGPU_OK;
+}
+
+}  // extern "C"

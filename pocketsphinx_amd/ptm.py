@@ -86,3 +86,51 @@ class PtmMgau:
             m.h, _p(feats), _p(off), len(utt_lens), _p(seed_cw), _p(sc), _p(cw), _p(scr),
             _p(best), RAW_SCORES if raw_scores else 0), "psgpu_ptm_score_batch")
         return dict(senscr=scr, topn_cw=cw, topn_score=sc, best=best, seed_cw=seed_cw)
+
+
+class PtmState:
+    """Per-decoder scorer state: mirrors ptm_mgau_t's mutable part (history
+    ring of top-N lists, src/ptm_mgau.h:68-97).  ``frame_eval`` has the
+    argument meaning of ptm_mgau_frame_eval (src/ptm_mgau.c:408-454) plus the
+    caller's ``frame_idx`` (ps_mgau_t.frame_idx, src/acmod.h:113-116)."""
+
+    def __init__(self, model, n_fast_hist):
+        self.m = model
+        self.n_hist = int(n_fast_hist)
+        h = C.c_void_p()
+        capi.check(capi.lib().psgpu_ptm_state_create(C.byref(h), model.h, self.n_hist),
+                   "psgpu_ptm_state_create")
+        self.h = h
+        self.frame_idx = 0
+
+    def reset_hist(self):
+        capi.check(capi.lib().psgpu_ptm_state_reset(self.h), "psgpu_ptm_state_reset")
+
+    def frame_eval(self, feat, frame, active=None, compallsen=True, frame_idx=None):
+        feat = np.ascontiguousarray(feat, np.float32).reshape(-1)
+        assert feat.size == self.m.veclen
+        scr = np.empty(self.m.n_sen, np.int16)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        capi.check(capi.lib().psgpu_ptm_frame_eval(
+            self.h, _p(scr), _p(act), 0 if act is None else act.size, _p(feat), int(frame),
+            int(self.frame_idx if frame_idx is None else frame_idx), int(bool(compallsen))),
+            "psgpu_ptm_frame_eval")
+        return scr
+
+    def cur_topn(self, slot=-1):
+        cw = np.empty((self.m.n_chain, self.m.topn), np.int32)
+        sc = np.empty((self.m.n_chain, self.m.topn), np.int32)
+        capi.check(capi.lib().psgpu_ptm_state_get_topn(self.h, int(slot), _p(cw), _p(sc)),
+                   "psgpu_ptm_state_get_topn")
+        return cw, sc
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().psgpu_ptm_state_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,122 @@
+"""GPU parity of the stateful per-call scorer (psgpu_ptm_frame_eval, the
+ps_mgau_t::frame_eval replacement) against (a) every frame_eval call the
+unmodified reference made during real decodes (senlog fixtures: active lists,
+history-slot reuse by the fwdtree search 5 frames behind the phone loop,
+pass-2 codebook masking after acmod_rewind) and (b) the pinned oracle on
+adversarial call sequences.  Bit-exact int16 scores and int32 top-N lists."""
+import numpy as np
+import pytest
+
+import pso
+from test_oracle_golden import _load, dup_tables
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_model(tables):
+    import pocketsphinx_amd as P
+    m = P.PtmModel(tables)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("case", ["default", "fwdtree_only"])
+def test_senlog_replay_gpu(tables, gpu_model, case):
+    import pocketsphinx_amd as P
+    g = _load("senlog_%s.npz" % case)
+    st = P.PtmState(gpu_model, int(tables["n_fast_hist"][0]))
+    n = int(g["call_frame"].size)
+    off = g["call_act_off"]
+    scr = np.empty((n, gpu_model.n_sen), np.int16)
+    for c in range(n):
+        na = int(g["call_nact"][c])
+        act = None if na < 0 else g["call_act"][off[c]:off[c] + na]
+        scr[c] = st.frame_eval(g["call_feat"][c], int(g["call_frame"][c]), active=act,
+                               compallsen=(na < 0), frame_idx=int(g["call_frame_idx"][c]))
+    bad = np.nonzero(pso.row_hash(scr) != g["call_scr_hash"])[0]
+    assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
+    assert np.array_equal(scr[g["sample_idx"]], g["call_scr_sample"])
+    st.close()
+
+
+def _random_list(rng, n_sen, sen2cb, mode):
+    """uint8 delta list (acmod_flags2list) of a random active set."""
+    flags = np.zeros(n_sen, np.uint8)
+    if mode == 0:                                   # CI senones only (phone loop)
+        flags[:126] = 1
+    elif mode == 1:                                 # a few codebooks, sparse
+        cbs = rng.choice(int(sen2cb.max()) + 1, size=rng.integers(1, 6), replace=False)
+        cand = np.nonzero(np.isin(sen2cb, cbs))[0]
+        flags[rng.choice(cand, size=min(cand.size, rng.integers(1, 200)), replace=False)] = 1
+    elif mode == 2:                                 # wide random set with big gaps
+        flags[rng.choice(n_sen, size=rng.integers(1, 600), replace=False)] = 1
+    else:                                           # a single far senone: bridging entries
+        flags[n_sen - 1 - rng.integers(0, 50)] = 1
+    return pso.flags2list(flags)
+
+
+@pytest.mark.parametrize("dup", [0, 1])
+def test_vs_oracle_call_patterns(tables, dup):
+    """Random mixes of the reference's three call patterns, HIP vs oracle, every
+    call memcmp'd (scores + the slot's top-N lists).  dup=1 duplicates
+    codewords so that exact ties and the sequential fallback are exercised
+    with partially active codebooks."""
+    import pocketsphinx_amd as P
+    t = dup_tables(tables) if dup else tables
+    rng = np.random.default_rng(11 + dup)
+    base = _load("ptm_adversarial.npz" if dup else "ptm_goforward.npz")["feat"]
+    H = int(tables["n_fast_hist"][0])
+    m = P.PtmModel(t)
+    st = P.PtmState(m, H)
+    o = pso.OraclePTM(t, n_fast_hist=H)
+    sen2cb = tables["sen2cb"]
+    n_sen = m.n_sen
+
+    def both(feat, frame, act, call, frame_idx):
+        o.set_frame_idx(frame_idx)
+        a = o.frame_eval(feat, frame, active=act, compallsen=call)
+        b = st.frame_eval(feat, frame, active=act, compallsen=call, frame_idx=frame_idx)
+        assert np.array_equal(a, b), "scores differ at frame %d (frame_idx %d)" % (frame, frame_idx)
+        ocur = o.cur_topn().reshape(m.n_chain, m.topn, 2)
+        cw, sc = st.cur_topn()
+        assert np.array_equal(ocur[..., 0], cw), "top-N codewords differ at frame %d" % frame
+        assert np.array_equal(ocur[..., 1], sc), "top-N slot scores differ at frame %d" % frame
+
+    T = 60
+    feats = base[rng.integers(0, base.shape[0], T)]
+    # pass 1: phone loop at t (fresh), search at t-5 (slot reuse, arbitrary list)
+    for t_ in range(T):
+        both(feats[t_], t_, _random_list(rng, n_sen, sen2cb, 0), False, t_)
+        if t_ >= 5:
+            both(feats[t_ - 5], t_ - 5, _random_list(rng, n_sen, sen2cb, int(rng.integers(1, 4))), False, t_)
+    # pass 2 after acmod_rewind: fresh evaluation with a codebook subset, no reset
+    for t_ in range(T):
+        mode = int(rng.integers(1, 4))
+        both(feats[t_], t_, _random_list(rng, n_sen, sen2cb, mode), False, t_)
+        if t_ % 7 == 3:                              # same frame again: reuse + 96-overwrite path
+            both(feats[t_], t_, _random_list(rng, n_sen, sen2cb, 2), False, t_ + 1)
+    # compallsen calls interleaved with an empty list
+    for t_ in range(10):
+        both(feats[t_], t_, None, True, t_)
+        both(feats[t_], t_, np.zeros(0, np.uint8), False, t_ + 1)
+    st.close()
+    m.close()
+
+
+def test_reset_hist(tables, gpu_model):
+    """psgpu_ptm_state_reset == ptm_mgau_reset_fast_hist: scores after a reset
+    equal those of a fresh state."""
+    import pocketsphinx_amd as P
+    g = _load("ptm_goforward.npz")
+    H = int(tables["n_fast_hist"][0])
+    a = P.PtmState(gpu_model, H)
+    for t_ in range(20):
+        a.frame_eval(g["feat"][t_ + 100], t_, compallsen=True, frame_idx=t_)
+    a.reset_hist()
+    b = P.PtmState(gpu_model, H)
+    for t_ in range(12):
+        x = a.frame_eval(g["feat"][t_], t_, compallsen=True, frame_idx=t_)
+        y = b.frame_eval(g["feat"][t_], t_, compallsen=True, frame_idx=t_)
+        assert np.array_equal(x, y)
+    a.close(); b.close()
