@@ -164,8 +164,9 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
  * The call is synchronous (returns with senscr filled).
  * psgpu_ptm_state_reset() is ptm_mgau_reset_fast_hist() (ptm_mgau.c:777-802).
  * psgpu_ptm_state_get_topn() copies one slot's lists out ([n_chain][topn]
- * int32 each; slot -1 = the slot of the last call) -- the reference exposes
- * the same data as s->f->topn. */
+ * int32 each, mgau_active one byte per codebook, any may be NULL; slot -1 =
+ * the slot of the last call) -- the reference exposes the same data as
+ * s->f->topn / s->f->mgau_active. */
 typedef struct psgpu_ptm_state_s psgpu_ptm_state_t;
 
 int psgpu_ptm_state_create(psgpu_ptm_state_t **out, psgpu_ptm_model_t *m, int32_t n_fast_hist);
@@ -175,7 +176,14 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
                          const uint8_t *senone_active, int32_t n_senone_active,
                          const float *feat, int32_t frame, int32_t frame_idx,
                          int32_t compallsen);
-int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score);
+int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score,
+                             uint8_t *mgau_active);
+/* Load one slot of the ring from a host image of ptm_fast_eval_t
+ * (ptm_mgau.h:68-71): cw/score [n_chain][topn] int32, mgau_active one byte
+ * per codebook (NULL = all active).  Lets a shim attached to a decoder that
+ * has already decoded with the CPU scorer continue from its exact state. */
+int psgpu_ptm_state_set_topn(psgpu_ptm_state_t *s, int32_t slot, const int32_t *cw,
+                             const int32_t *score, const uint8_t *mgau_active);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,264 @@
+/* integration/psgpu_mgau_shim.c -- REFERENCE-SIDE BINDING.
+ *
+ * What a PocketSphinx maintainer adds to plug the MI355X scorer in behind the
+ * existing GMM plugin vtable: a `ps_mgau_t` implementation (acmod.h:98-116)
+ * whose frame_eval / transform / free forward to the psgpu C ABI
+ * (include/psgpu.h).  It is compiled against the reference's own internal
+ * headers (-I src) and linked with the reference library; nothing here
+ * computes scores -- all arithmetic happens in libpsgpu.so's HIP kernels.
+ *
+ * Installation is the post-init pointer swap of SURVEY.md 8(b): the reference
+ * has no plugin registry (acmod.c:100-119 is a hard-coded if-chain), so
+ *
+ *     ps_decoder_t *ps = ps_init(config);
+ *     psgpu_mgau_attach(ps);            // ps->acmod->mgau := GPU scorer
+ *     ps_decode_raw(ps, fh, -1);        // unchanged
+ *
+ * The wrapped CPU `ptm_mgau_t` is kept: it is the source of the model tables
+ * (means, precomputed variances, dets, mixture weights, sen2cb, the 8-bit
+ * log-add table) and still serves MLLR transforms, after which the device
+ * tables are re-uploaded.  Its top-N history is imported so that attaching in
+ * the middle of a session continues bit-exactly.
+ */
+#include <string.h>
+
+#include <pocketsphinx.h>
+#include "pocketsphinx_internal.h"
+#include "acmod.h"
+#include "ptm_mgau.h"
+#include "ms_gauden.h"
+#include "tied_mgau_common.h"
+
+#include "psgpu.h"
+#include "psgpu_mgau_shim.h"
+
+typedef struct psgpu_mgau_s {
+    ps_mgau_t base;               /* vt + frame_idx: MUST be first (acmod.h:113-116) */
+    ptm_mgau_t *cpu;              /* the reference scorer this one replaces */
+    psgpu_ptm_model_t *model;
+    psgpu_ptm_state_t *state;
+    float *vec;                   /* one frame, streams concatenated */
+    int n_feat;
+    int veclen;
+    int32 n_calls;
+} psgpu_mgau_t;
+
+static int shim_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
+                           int32 n_senone_active, mfcc_t **feat, int32 frame,
+                           int32 compallsen);
+static int shim_transform(ps_mgau_t *ps, ps_mllr_t *mllr);
+static void shim_free(ps_mgau_t *ps);
+
+static ps_mgaufuncs_t psgpu_mgau_funcs = {
+    "ptm-psgpu",                  /* name */
+    shim_frame_eval,
+    shim_transform,
+    shim_free
+};
+
+/* Upload the tables ptm_mgau_init() built (ptm_mgau.c:804-896). */
+static int
+upload_model(psgpu_mgau_t *g)
+{
+    ptm_mgau_t *s = g->cpu;
+    gauden_t *gd = s->g;
+    logadd_t *la = LOGMATH_TABLE(s->lmath_8b);
+    size_t rows = (size_t)gd->n_feat * gd->n_density, r;
+    uint8 *mixw;
+    int f, d, rc;
+
+    if (s->mixw_cb) {
+        E_ERROR("psgpu: 4-bit clustered sendumps are not supported on the device\n");
+        return -1;
+    }
+    if (la->width != 1) {
+        E_ERROR("psgpu: 8-bit log-add table expected (width %d)\n", la->width);
+        return -1;
+    }
+    /* mixw[f][d] rows may live in an mmap of sendump: gather them */
+    mixw = ckd_malloc(rows * (size_t)s->n_sen);
+    for (r = 0, f = 0; f < gd->n_feat; ++f)
+        for (d = 0; d < gd->n_density; ++d, ++r)
+            memcpy(mixw + r * (size_t)s->n_sen, s->mixw[f][d], (size_t)s->n_sen);
+    if (g->model)
+        psgpu_ptm_model_free(g->model);
+    g->model = NULL;
+    /* mean/var are one contiguous block [mgau][feat][density][featlen]
+     * (gauden_param_read, ms_gauden.c:211-221); det likewise (ckd_calloc_3d) */
+    rc = psgpu_ptm_model_create(&g->model, gd->n_mgau, gd->n_feat, gd->n_density,
+                                gd->featlen, s->n_sen, s->max_topn, s->ds_ratio,
+                                gd->mean[0][0][0], gd->var[0][0][0], gd->det[0][0],
+                                mixw, s->sen2cb, (const uint8_t *)la->table,
+                                (int32_t)la->table_size);
+    ckd_free(mixw);
+    if (rc != PSGPU_OK) {
+        E_ERROR("psgpu_ptm_model_create failed (%d): %s\n", rc, psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+/* Copy the CPU scorer's history ring (ptm_mgau.h:68-71) into the device state. */
+static int
+import_history(psgpu_mgau_t *g)
+{
+    ptm_mgau_t *s = g->cpu;
+    gauden_t *gd = s->g;
+    int n_chain = gd->n_mgau * gd->n_feat, N = s->max_topn;
+    int32 *cw = ckd_calloc((size_t)n_chain * N, sizeof(int32));
+    int32 *sc = ckd_calloc((size_t)n_chain * N, sizeof(int32));
+    uint8 *act = ckd_calloc(gd->n_mgau, 1);
+    int slot, i, rc = 0;
+
+    for (slot = 0; slot < s->n_fast_hist && rc == 0; ++slot) {
+        ptm_topn_t *tl = s->hist[slot].topn[0][0];
+        for (i = 0; i < n_chain * N; ++i) {
+            cw[i] = tl[i].cw;
+            sc[i] = tl[i].score;
+        }
+        for (i = 0; i < gd->n_mgau; ++i)
+            act[i] = bitvec_is_set(s->hist[slot].mgau_active, i) ? 1 : 0;
+        if (psgpu_ptm_state_set_topn(g->state, slot, cw, sc, act) != PSGPU_OK) {
+            E_ERROR("psgpu_ptm_state_set_topn failed: %s\n", psgpu_last_error());
+            rc = -1;
+        }
+    }
+    ckd_free(cw); ckd_free(sc); ckd_free(act);
+    return rc;
+}
+
+ps_mgau_t *
+psgpu_mgau_wrap(ps_mgau_t *cpu_mgau)
+{
+    psgpu_mgau_t *g;
+    ptm_mgau_t *s = (ptm_mgau_t *)cpu_mgau;
+    int f;
+
+    if (cpu_mgau == NULL || strcmp(cpu_mgau->vt->name, "ptm") != 0) {
+        E_ERROR("psgpu: only the \"ptm\" scorer can be wrapped (got \"%s\")\n",
+                cpu_mgau ? cpu_mgau->vt->name : "(null)");
+        return NULL;
+    }
+    g = ckd_calloc(1, sizeof(*g));
+    g->base.vt = &psgpu_mgau_funcs;
+    g->base.frame_idx = cpu_mgau->frame_idx;
+    g->cpu = s;
+    g->n_feat = s->g->n_feat;
+    for (f = 0; f < g->n_feat; ++f)
+        g->veclen += s->g->featlen[f];
+    g->vec = ckd_calloc(g->veclen, sizeof(float));
+    if (upload_model(g) < 0
+        || psgpu_ptm_state_create(&g->state, g->model, s->n_fast_hist) != PSGPU_OK
+        || import_history(g) < 0) {
+        if (g->model && !g->state)
+            E_ERROR("psgpu_ptm_state_create failed: %s\n", psgpu_last_error());
+        if (g->state) psgpu_ptm_state_free(g->state);
+        if (g->model) psgpu_ptm_model_free(g->model);
+        ckd_free(g->vec);
+        ckd_free(g);
+        return NULL;
+    }
+    return (ps_mgau_t *)g;
+}
+
+int
+psgpu_mgau_attach(ps_decoder_t *ps)
+{
+    ps_mgau_t *gpu;
+
+    if (ps == NULL || ps->acmod == NULL || ps->acmod->mgau == NULL)
+        return -1;
+    gpu = psgpu_mgau_wrap(ps->acmod->mgau);
+    if (gpu == NULL)
+        return -1;
+    ps->acmod->mgau = gpu;        /* freed through vt->free by acmod_free (acmod.c:315) */
+    return 0;
+}
+
+int32
+psgpu_mgau_n_calls(ps_mgau_t *ps)
+{
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
+        return -1;
+    return ((psgpu_mgau_t *)ps)->n_calls;
+}
+
+/* ps_mgaufuncs_t.frame_eval (acmod.h:101-107), called by acmod_score (acmod.c:1108) */
+static int
+shim_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
+                int32 n_senone_active, mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    gauden_t *gd = g->cpu->g;
+    int f, o = 0, rc;
+
+    for (f = 0; f < g->n_feat; ++f) {
+        memcpy(g->vec + o, feat[f], sizeof(float) * gd->featlen[f]);
+        o += gd->featlen[f];
+    }
+    rc = psgpu_ptm_frame_eval(g->state, senscr, senone_active, n_senone_active, g->vec,
+                              frame, ps->frame_idx, compallsen);
+    ++g->n_calls;
+    if (rc != PSGPU_OK) {
+        E_ERROR("psgpu_ptm_frame_eval(frame %d) failed (%d): %s\n", frame, rc,
+                psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+/* ps_mgaufuncs_t.transform (acmod.h:108-109), called by acmod_update_mllr (acmod.c:329):
+ * the reference re-reads and transforms means/variances on the host
+ * (ptm_mgau_mllr_transform -> gauden_mllr_transform, ms_gauden.c:511-572);
+ * the device copy is then refreshed. */
+static int
+shim_transform(ps_mgau_t *ps, ps_mllr_t *mllr)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    psgpu_ptm_state_t *old = g->state;
+    int rc = ps_mgau_transform(ps_mgau_base(g->cpu), mllr);
+    if (rc < 0)
+        return rc;
+    /* keep the history: read it back into the CPU object's ring first */
+    {
+        gauden_t *gd = g->cpu->g;
+        int n_chain = gd->n_mgau * gd->n_feat, N = g->cpu->max_topn, slot, i;
+        int32 *cw = ckd_calloc((size_t)n_chain * N, sizeof(int32));
+        int32 *sc = ckd_calloc((size_t)n_chain * N, sizeof(int32));
+        uint8 *act = ckd_calloc(gd->n_mgau, 1);
+        for (slot = 0; slot < g->cpu->n_fast_hist; ++slot) {
+            ptm_topn_t *tl = g->cpu->hist[slot].topn[0][0];
+            if (psgpu_ptm_state_get_topn(old, slot, cw, sc, act) != PSGPU_OK)
+                break;
+            for (i = 0; i < n_chain * N; ++i) {
+                tl[i].cw = cw[i];
+                tl[i].score = sc[i];
+            }
+            for (i = 0; i < gd->n_mgau; ++i) {
+                if (act[i]) bitvec_set(g->cpu->hist[slot].mgau_active, i);
+                else bitvec_clear(g->cpu->hist[slot].mgau_active, i);
+            }
+        }
+        ckd_free(cw); ckd_free(sc); ckd_free(act);
+    }
+    g->state = NULL;
+    psgpu_ptm_state_free(old);
+    if (upload_model(g) < 0)
+        return -1;
+    if (psgpu_ptm_state_create(&g->state, g->model, g->cpu->n_fast_hist) != PSGPU_OK) {
+        E_ERROR("psgpu_ptm_state_create failed: %s\n", psgpu_last_error());
+        return -1;
+    }
+    return import_history(g);
+}
+
+static void
+shim_free(ps_mgau_t *ps)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    if (g->state) psgpu_ptm_state_free(g->state);
+    if (g->model) psgpu_ptm_model_free(g->model);
+    if (g->cpu) ps_mgau_free(ps_mgau_base(g->cpu));
+    ckd_free(g->vec);
+    ckd_free(g);
+}

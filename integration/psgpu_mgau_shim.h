@@ -1,0 +1,29 @@
+/* integration/psgpu_mgau_shim.h -- reference-side binding of the psgpu scorer
+ * behind PocketSphinx's ps_mgau_t vtable (acmod.h:98-116).  See INTEGRATION.md. */
+#ifndef PSGPU_MGAU_SHIM_H
+#define PSGPU_MGAU_SHIM_H
+
+#include <pocketsphinx.h>
+#include "acmod.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Wrap the decoder's CPU "ptm" scorer: returns a ps_mgau_t whose frame_eval
+ * runs on the MI355X, or NULL (message through E_ERROR) if the model shape is
+ * unsupported or no gfx950 device is usable.  The returned object owns
+ * `cpu_mgau` and frees it in its vt->free. */
+ps_mgau_t *psgpu_mgau_wrap(ps_mgau_t *cpu_mgau);
+
+/* ps->acmod->mgau := psgpu_mgau_wrap(ps->acmod->mgau).  0 on success, -1 on
+ * failure (the decoder is left untouched and keeps its CPU scorer). */
+int psgpu_mgau_attach(ps_decoder_t *ps);
+
+/* number of frame_eval calls served by the device (-1 if not a psgpu scorer) */
+int32 psgpu_mgau_n_calls(ps_mgau_t *mgau);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,213 @@
+/* oracle/dropin_decode.c -- TEST INFRASTRUCTURE (checker), not product.
+ *
+ * Drop-in proof for the GMM boundary: decode the same PCM with two decoders
+ * built from the UNMODIFIED reference library (oracle/_ref/libpocketsphinx.so)
+ *   A: untouched (CPU ptm_mgau_t)
+ *   B: after psgpu_mgau_attach() (integration/psgpu_mgau_shim.c -> libpsgpu.so)
+ * through the public ps_start_utt / ps_process_raw / ps_end_utt path
+ * (ps_decode_raw does exactly this, pocketsphinx.c:1030-1070) and compare
+ *   - every frame_eval call's full int16 senone score vector (FNV-1a hash per
+ *     call; both passes, phone-loop and search calls alike)
+ *   - hypothesis string and path score
+ *   - segmentation (word, start frame, end frame, ascr, lscr, lback)
+ * Prints one JSON line; exit status 0 iff everything is identical.
+ *
+ * usage: dropin_decode MODELDIR LM DICT RAW NREP [key val ...]
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <time.h>
+
+#include <pocketsphinx.h>
+#include "pocketsphinx_internal.h"
+#include "bin_mdef.h"
+#include "psgpu_mgau_shim.h"
+
+typedef struct rec_s {
+    ps_mgaufuncs_t funcs;          /* wrapper vtable */
+    ps_mgaufuncs_t *orig;
+    uint64_t *hash;
+    int32 *frame;
+    int n, cap, n_sen;
+} rec_t;
+
+static rec_t *g_rec;               /* the recorder of the decoder being run */
+
+static uint64_t
+fnv1a(const void *p, size_t n)
+{
+    const unsigned char *b = p;
+    uint64_t h = 0xcbf29ce484222325ull;
+    size_t i;
+    for (i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+static int
+rec_frame_eval(ps_mgau_t *mg, int16 *senscr, uint8 *act, int32 nact,
+               mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    rec_t *r = g_rec;
+    int rc = r->orig->frame_eval(mg, senscr, act, nact, feat, frame, compallsen);
+    if (r->n == r->cap) {
+        r->cap = r->cap ? r->cap * 2 : 4096;
+        r->hash = realloc(r->hash, sizeof(uint64_t) * r->cap);
+        r->frame = realloc(r->frame, sizeof(int32) * r->cap);
+    }
+    r->hash[r->n] = fnv1a(senscr, sizeof(int16) * r->n_sen);
+    r->frame[r->n] = frame;
+    ++r->n;
+    return rc;
+}
+
+static void
+rec_install(rec_t *r, ps_decoder_t *ps)
+{
+    memset(r, 0, sizeof *r);
+    r->orig = ps->acmod->mgau->vt;
+    r->funcs = *r->orig;
+    r->funcs.frame_eval = rec_frame_eval;
+    r->n_sen = bin_mdef_n_sen(ps->acmod->mdef);
+    ps->acmod->mgau->vt = &r->funcs;
+}
+
+static ps_decoder_t *
+make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, char **argv)
+{
+    ps_config_t *config = ps_config_init(NULL);
+    ps_decoder_t *ps;
+    int i;
+    ps_config_set_str(config, "hmm", modeldir);
+    if (strcmp(lm, "-")) ps_config_set_str(config, "lm", lm);
+    if (strcmp(dict, "-")) ps_config_set_str(config, "dict", dict);
+    ps_config_set_str(config, "loglevel", "ERROR");
+    for (i = 0; i + 1 < argc; i += 2) {
+        const char *k = argv[i];
+        if (k[0] == '-') ++k;
+        if (!strcmp(k, "mllr_after")) continue;       /* handled by main() */
+        if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
+            fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
+        }
+    }
+    ps = ps_init(config);
+    if (!ps) { fprintf(stderr, "ps_init failed\n"); exit(2); }
+    return ps;
+}
+
+typedef struct result_s {
+    char hyp[4096];
+    int32 score;
+    char seg[65536];               /* "word sf ef ascr lscr lback\n" ... */
+    int n_frames;
+} result_t;
+
+static double
+now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void
+decode(ps_decoder_t *ps, const int16 *pcm, size_t n, result_t *res)
+{
+    const char *hyp;
+    ps_seg_t *seg;
+    size_t o = 0;
+    ps_start_utt(ps);
+    ps_process_raw(ps, pcm, n, FALSE, TRUE);
+    ps_end_utt(ps);
+    hyp = ps_get_hyp(ps, &res->score);
+    snprintf(res->hyp, sizeof res->hyp, "%s", hyp ? hyp : "");
+    res->seg[0] = 0;
+    for (seg = ps_seg_iter(ps); seg; seg = ps_seg_next(seg)) {
+        int sf, ef; int32 ascr, lscr, lback;
+        ps_seg_frames(seg, &sf, &ef);
+        ps_seg_prob(seg, &ascr, &lscr, &lback);
+        o += snprintf(res->seg + o, sizeof res->seg - o, "%s %d %d %d %d %d\n",
+                      ps_seg_word(seg), sf, ef, ascr, lscr, lback);
+    }
+    res->n_frames = ps_get_n_frames(ps);
+}
+
+int
+main(int argc, char **argv)
+{
+    ps_decoder_t *cpu, *gpu;
+    rec_t rc_cpu, rc_gpu;
+    result_t *ra, *rb;
+    FILE *fp; long sz; int16 *pcm; size_t n;
+    int nrep, r, i, ok = 1, bad_calls = 0, first_bad = -1, hyp_equal = 1, seg_equal = 1;
+    double t_cpu = 0, t_gpu = 0, t0;
+
+    if (argc < 6) {
+        fprintf(stderr, "usage: dropin_decode MODELDIR LM|- DICT|- RAW NREP [key val ...]\n");
+        return 2;
+    }
+    nrep = atoi(argv[5]);
+    fp = fopen(argv[4], "rb");
+    if (!fp) { perror(argv[4]); return 2; }
+    fseek(fp, 0, SEEK_END); sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+    pcm = malloc(sz);
+    if (fread(pcm, 1, sz, fp) != (size_t)sz) { perror("read"); return 2; }
+    fclose(fp);
+    n = sz / 2;
+    err_set_loglevel(ERR_ERROR);
+
+    cpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
+    gpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
+    if (psgpu_mgau_attach(gpu) < 0) {
+        fprintf(stderr, "psgpu_mgau_attach failed\n");
+        return 3;
+    }
+    /* "mllr_after FILE": apply an MLLR transform AFTER attaching, so that the
+     * shim's vt->transform (acmod_update_mllr, acmod.c:329) is what runs */
+    for (i = 6; i + 1 < argc; i += 2)
+        if (!strcmp(argv[i], "mllr_after") || !strcmp(argv[i], "-mllr_after")) {
+            ps_mllr_t *ma = ps_mllr_read(argv[i + 1]), *mb = ps_mllr_read(argv[i + 1]);
+            if (!ma || !mb) { fprintf(stderr, "cannot read MLLR %s\n", argv[i + 1]); return 2; }
+            ps_update_mllr(cpu, ma);
+            ps_update_mllr(gpu, mb);
+        }
+    rec_install(&rc_cpu, cpu);
+    rec_install(&rc_gpu, gpu);
+    ra = calloc(nrep, sizeof *ra);
+    rb = calloc(nrep, sizeof *rb);
+    for (r = 0; r < nrep; ++r) {
+        g_rec = &rc_cpu; t0 = now_s(); decode(cpu, pcm, n, &ra[r]); t_cpu += now_s() - t0;
+        g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, &rb[r]); t_gpu += now_s() - t0;
+        if (strcmp(ra[r].hyp, rb[r].hyp) || ra[r].score != rb[r].score) hyp_equal = 0;
+        if (strcmp(ra[r].seg, rb[r].seg)) seg_equal = 0;
+    }
+    if (rc_cpu.n != rc_gpu.n) { ok = 0; bad_calls = -1; }
+    else
+        for (i = 0; i < rc_cpu.n; ++i)
+            if (rc_cpu.hash[i] != rc_gpu.hash[i] || rc_cpu.frame[i] != rc_gpu.frame[i]) {
+                if (first_bad < 0) first_bad = i;
+                ++bad_calls;
+            }
+    if (bad_calls || !hyp_equal || !seg_equal) ok = 0;
+    /* detach recorders before the decoders free their scorers */
+    cpu->acmod->mgau->vt = rc_cpu.orig;
+    gpu->acmod->mgau->vt = rc_gpu.orig;
+    {
+        int n_seg = 0; const char *p;
+        for (p = ra[0].seg; *p; ++p) n_seg += (*p == '\n');
+        printf("{\"ok\": %s, \"nrep\": %d, \"n_frames\": %d, \"calls_cpu\": %d, \"calls_gpu\": %d, "
+               "\"device_calls\": %d, \"mismatching_calls\": %d, \"first_bad_call\": %d, "
+               "\"hyp_equal\": %s, \"seg_equal\": %s, \"hyp_cpu\": \"%s\", \"hyp_gpu\": \"%s\", "
+               "\"score_cpu\": %d, \"score_gpu\": %d, \"n_seg\": %d, "
+               "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\"}\n",
+               ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
+               (int)psgpu_mgau_n_calls(gpu->acmod->mgau), bad_calls, first_bad,
+               hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
+               ra[nrep - 1].hyp, rb[nrep - 1].hyp, ra[nrep - 1].score, rb[nrep - 1].score,
+               n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name);
+    }
+    ps_free(cpu);
+    ps_free(gpu);
+    return ok ? 0 : 1;
+}

@@ -18,7 +18,7 @@ SYMBOLS = [
     "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",
     "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev",
     "psgpu_ptm_state_create", "psgpu_ptm_state_free", "psgpu_ptm_state_reset",
-    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn",
+    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn",
 ]
 
 
@@ -87,7 +87,8 @@ def lib():
     L.psgpu_ptm_state_free.restype = None
     L.psgpu_ptm_state_reset.argtypes = [vp]
     L.psgpu_ptm_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32]
-    L.psgpu_ptm_state_get_topn.argtypes = [vp, i32, vp, vp]
+    L.psgpu_ptm_state_get_topn.argtypes = [vp, i32, vp, vp, vp]
+    L.psgpu_ptm_state_set_topn.argtypes = [vp, i32, vp, vp, vp]
     L.psgpu_event_create.argtypes = [C.POINTER(vp)]
     L.psgpu_event_destroy.argtypes = [vp]
     L.psgpu_event_record.argtypes = [vp, vp]

@@ -339,7 +339,8 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
     return PSGPU_OK;
 }
 
-int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score)
+int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score,
+                             uint8_t *mgau_active)
 {
     PSGPU_REQUIRE(s != nullptr, "psgpu_ptm_state_get_topn: NULL state");
     if (slot < 0) slot = s->cur;
@@ -348,6 +349,33 @@ int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, in
     PSGPU_HIP(hipStreamSynchronize(s->stream));
     if (cw) PSGPU_HIP(hipMemcpy(cw, s->hist_cw + slot * slot_len, slot_len * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (score) PSGPU_HIP(hipMemcpy(score, s->hist_sc + slot * slot_len, slot_len * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (mgau_active) {
+        uint32_t act[8];
+        PSGPU_HIP(hipMemcpy(act, s->hist_active + (size_t)slot * 8, sizeof act, hipMemcpyDeviceToHost));
+        for (int cb = 0; cb < s->m->n_mgau; ++cb)
+            mgau_active[cb] = (act[cb >> 5] >> (cb & 31)) & 1u;
+    }
+    return PSGPU_OK;
+}
+
+int psgpu_ptm_state_set_topn(psgpu_ptm_state_t *s, int32_t slot, const int32_t *cw,
+                             const int32_t *score, const uint8_t *mgau_active)
+{
+    PSGPU_REQUIRE(s && cw && score, "psgpu_ptm_state_set_topn: NULL argument");
+    PSGPU_REQUIRE(slot >= 0 && slot < s->n_hist, "slot %d outside the %d-slot ring", slot, s->n_hist);
+    const psgpu_ptm_model_t *m = s->m;
+    const size_t slot_len = (size_t)m->n_chain * m->topn;
+    for (size_t i = 0; i < slot_len; ++i)
+        PSGPU_REQUIRE(cw[i] >= 0 && cw[i] < m->n_density, "codeword %d outside the codebook", cw[i]);
+    uint32_t act[8];
+    memset(act, mgau_active ? 0 : 0xff, sizeof act);
+    if (mgau_active)
+        for (int cb = 0; cb < m->n_mgau; ++cb)
+            if (mgau_active[cb]) act[cb >> 5] |= 1u << (cb & 31);
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    PSGPU_HIP(hipMemcpy(s->hist_cw + slot * slot_len, cw, slot_len * sizeof(int32_t), hipMemcpyHostToDevice));
+    PSGPU_HIP(hipMemcpy(s->hist_sc + slot * slot_len, score, slot_len * sizeof(int32_t), hipMemcpyHostToDevice));
+    PSGPU_HIP(hipMemcpy(s->hist_active + (size_t)slot * 8, act, sizeof act, hipMemcpyHostToDevice));
     return PSGPU_OK;
 }
 

@@ -120,7 +120,7 @@ class PtmState:
     def cur_topn(self, slot=-1):
         cw = np.empty((self.m.n_chain, self.m.topn), np.int32)
         sc = np.empty((self.m.n_chain, self.m.topn), np.int32)
-        capi.check(capi.lib().psgpu_ptm_state_get_topn(self.h, int(slot), _p(cw), _p(sc)),
+        capi.check(capi.lib().psgpu_ptm_state_get_topn(self.h, int(slot), _p(cw), _p(sc), None),
                    "psgpu_ptm_state_get_topn")
         return cw, sc
 

@@ -1,0 +1,97 @@
+"""Drop-in proof on the GPU box: the UNMODIFIED reference decoder
+(oracle/_ref/libpocketsphinx.so) with its GMM scorer swapped for the psgpu
+shim (integration/psgpu_mgau_shim.c -> libpsgpu.so) must produce, for whole
+ps_decode_raw-style decodes, bit-identical senone scores on every
+frame_eval call of every pass, the same hypothesis + path score and the same
+segmentation as the same decoder with its CPU scorer.  The comparison is done
+by oracle/dropin_decode.c (test infrastructure)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import pso
+
+REF = pso.REF_DIR
+BIN = os.path.join(REF, "dropin_decode")
+MODEL = os.path.join(REF, "model", "en-us")
+DATA = os.path.join(REF, "data")
+
+
+def run(raw, nrep, *extra, lm="turtle.lm.bin", dic="turtle.dic"):
+    if not os.path.exists(BIN):
+        pytest.fail("oracle/_ref/dropin_decode is missing: run __graft_entry__.build() where "
+                    "/root/reference is present (the built oracle/_ref travels with gpurun)")
+    argv = [BIN, MODEL, os.path.join(DATA, lm), os.path.join(DATA, dic),
+            os.path.join(DATA, raw), str(nrep)] + [str(e) for e in extra]
+    p = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    assert p.stdout.strip(), "no output (rc %d): %s" % (p.returncode, p.stderr[-2000:])
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    r["rc"] = p.returncode
+    return r
+
+
+def _write_mllr(tmp_path, n_feat=3, veclen=13, seed=5):
+    """ps_mllr_read format (ps_mllr.c:57-125): n_class, n_feat, then per stream
+    veclen, A (veclen x veclen), b, h."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lines = ["1", str(n_feat)]
+    for _ in range(n_feat):
+        lines.append(str(veclen))
+        A = np.eye(veclen) + 0.02 * rng.standard_normal((veclen, veclen))
+        for row in A:
+            lines.append(" ".join("%.6f" % v for v in row))
+        lines.append(" ".join("%.6f" % v for v in 0.05 * rng.standard_normal(veclen)))
+        lines.append(" ".join("%.6f" % v for v in 1.0 + 0.05 * rng.random(veclen)))
+    p = tmp_path / "mllr_3x13"
+    p.write_text("\n".join(lines) + "\n")
+    return str(p)
+
+
+CASES = {
+    # name: (raw, nrep, extra config)
+    "default_3pass_x2": ("goforward.raw", 2, ()),                 # fwdtree + fwdflat + bestpath, carry-over (F7)
+    "fwdtree_only": ("goforward.raw", 1, ("fwdflat", "no", "bestpath", "no")),
+    "compallsen_plw0": ("goforward.raw", 1, ("compallsen", "yes", "pl_window", "0")),
+    "ds2": ("goforward.raw", 1, ("ds", "2")),                     # codebook scan every 2nd frame
+    "fwdflat_only": ("goforward.raw", 1, ("fwdtree", "no")),      # pass-2 codebook masking without pass 1
+    "numbers": ("numbers.raw", 1, ()),
+    "something": ("something.raw", 1, ()),
+    "librivox_0870": ("librivox-0870.raw", 1, ()),
+    # vt->transform through the shim: 1-class MLLR for 3 streams x 13 written below (the bundled
+    # test/data/mllr_matrices is 1 x 39 for an4_ci_cont and crashes the reference itself on en-us)
+    "mllr_after_attach": ("goforward.raw", 1, ("mllr_after", "@MLLR@")),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_dropin_decode_identical(case, tmp_path):
+    raw, nrep, extra = CASES[case]
+    if "@MLLR@" in extra:
+        extra = tuple(_write_mllr(tmp_path) if e == "@MLLR@" else e for e in extra)
+    r = run(raw, nrep, *extra)
+    assert r["mgau"] == "ptm-psgpu"
+    assert r["device_calls"] == r["calls_gpu"] > 0
+    assert r["calls_cpu"] == r["calls_gpu"]
+    assert r["mismatching_calls"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"], r
+    assert r["ok"] and r["rc"] == 0, r
+    if raw == "goforward.raw" and "mllr_after" not in extra:
+        assert r["hyp_gpu"] == "go forward ten meters"
+
+
+def test_attach_fails_loudly_without_gpu():
+    """No CPU fallback inside the product: on a box without a gfx950 device the
+    attach fails and the checker exits 3."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    if not os.path.exists(BIN):
+        pytest.skip("oracle/_ref not built")
+    p = subprocess.run([BIN, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"),
+                        os.path.join(DATA, "goforward.raw"), "1"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3
+    assert "psgpu_mgau_attach failed" in p.stderr
