@@ -185,6 +185,64 @@ int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, in
 int psgpu_ptm_state_set_topn(psgpu_ptm_state_t *s, int32_t slot, const int32_t *cw,
                              const int32_t *score, const uint8_t *mgau_active);
 
+/* ---- HMM Viterbi step ----------------------------------------------------
+ * Replaces hmm_vit_eval() (hmm.c:786-805) and its hard-wired variants
+ * hmm_vit_eval_3st_lr[_mpx] (:529-707) / _5st_lr[_mpx] (:222-525) for whole
+ * active lists, i.e. the loops of evaluate_channels()
+ * (ngram_search_fwdtree.c:605-715), fwdflat_eval_chan()
+ * (ngram_search_fwdflat.c:444-480) and evaluate_hmms()
+ * (phone_loop_search.c:202-222).
+ *
+ * psgpu_hmm_ctx_t replaces hmm_context_t (hmm.h:145-154): the shared tables
+ *   tp    uint8 [n_tmat][n_emit][n_emit+1]  (tmat_t.tp flattened, tmat.h:60-66)
+ *   sseq  uint16 [n_sseq][n_emit]           (bin_mdef_t.sseq, bin_mdef.h:119)
+ * psgpu_hmm_rec_t carries the per-HMM fields of hmm_t (hmm.h:169-182) in one
+ * 64-byte line.  senid[] holds senone ids for a non-multiplex HMM and
+ * per-state ssids (BAD_SSID 0xffff = state not yet entered) for a multiplex
+ * one, exactly as hmm_t.senid; tmatid_mpx = tmatid | PSGPU_HMM_MPX for
+ * multiplex HMMs.  Unused states of a 3-state record are ignored. */
+#define PSGPU_HMM_MPX 0x8000u
+
+typedef struct psgpu_hmm_rec_s {
+    int32_t score[5];       /* hmm_t.score      */
+    int32_t history[5];     /* hmm_t.history    */
+    int32_t out_score;      /* hmm_t.out_score  */
+    int32_t out_history;    /* hmm_t.out_history */
+    int32_t bestscore;      /* hmm_t.bestscore (written) */
+    uint16_t senid[5];      /* hmm_t.senid      */
+    uint16_t tmatid_mpx;    /* hmm_t.tmatid | (hmm_t.mpx ? PSGPU_HMM_MPX : 0) */
+} psgpu_hmm_rec_t;          /* 64 bytes */
+
+typedef struct psgpu_hmm_ctx_s psgpu_hmm_ctx_t;
+
+int psgpu_hmm_ctx_create(psgpu_hmm_ctx_t **out, int32_t n_emit_state, int32_t n_tmat,
+                         const uint8_t *tp, int32_t n_sseq, const uint16_t *sseq, int32_t n_sen);
+void psgpu_hmm_ctx_free(psgpu_hmm_ctx_t *c);
+int32_t psgpu_hmm_n_emit_state(const psgpu_hmm_ctx_t *c);
+
+/* One Viterbi step for n_active HMMs resident in HBM.
+ *  recs_dev        record arena
+ *  active_idx_dev  NULL (records 0..n_active-1) or [n_active] indices into the
+ *                  arena: the active HMM list of the frame
+ *  utt_of_hmm_dev  NULL (one utterance) or [arena] utterance number of every
+ *                  record: selects the senone-score row and the best[] slot
+ *  senscr_dev      int16 rows of senone scores (acmod_score output,
+ *                  acmod.h:165), row u at senscr_dev + u * senscr_stride
+ *  best_dev        NULL or int32 [n_utt]: max-folded with every HMM's returned
+ *                  best score (the caller presets it, normally to WORST_SCORE
+ *                  0xE0000000, hmm.h:84) */
+int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
+                           const int32_t *active_idx_dev, int32_t n_active,
+                           const uint16_t *utt_of_hmm_dev,
+                           const int16_t *senscr_dev, int32_t senscr_stride,
+                           int32_t *best_dev, void *stream);
+
+/* Host-buffer form used by the search-side shim: n records in, the same n
+ * records updated in place, *best = max(WORST_SCORE, returned best scores).
+ * senscr is the frame's n_sen int16 scores.  Synchronous. */
+int psgpu_hmm_vit_eval(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs, int32_t n,
+                       const int16_t *senscr, int32_t *best);
+
 #ifdef __cplusplus
 }
 #endif

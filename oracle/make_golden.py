@@ -10,6 +10,7 @@ Fixtures:
   ptm_<case>.npz           PTM scorer goldens (compallsen) for several inputs
   senlog_default.npz       every frame_eval call of a default-mode decode
   decode_<mode>.npz        hypothesis + segmentation goldens
+  hmm_<model>.npz          hmm_vit_eval state before/after each step (3- and 5-state, mpx and not)
 
 Large per-frame outputs are stored as 64-bit FNV-1a row hashes for every frame
 plus the full rows of a frame sample (tests recompute the hashes).
@@ -119,6 +120,17 @@ def decode_case(name, extra=()):
     print("decode_%s: hyp=%r score=%d" % (name, bytes(d["hyp"]).decode(), int(d["hyp_score"][0])))
 
 
+def hmm_case(name, model, lm, dic, n_hmm, n_steps, seed):
+    with tempfile.NamedTemporaryFile(suffix=".psgb", delete=False) as fh:
+        out = fh.name
+    subprocess.check_call([os.path.join(REF, "ref_dump"), "hmm", out, model, lm, dic,
+                           str(n_hmm), str(n_steps), str(seed)])
+    d = read_psgb(out)
+    os.unlink(out)
+    np.savez_compressed(os.path.join(GOLD, "hmm_%s.npz" % name), **d)
+    print("hmm_%s: n_emit=%d n_hmm=%d steps=%d" % (name, int(d["n_emit"][0]), n_hmm, n_steps))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     t = ref_dump("tables")
@@ -139,7 +151,21 @@ def main():
     decode_case("default")
     decode_case("fwdtree_only", extra=("fwdflat", "no", "bestpath", "no"))
     decode_case("compallsen_plw0", extra=("compallsen", "yes", "pl_window", "0"))
+    hmm_only()
+
+
+def hmm_only():
+    # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
+    hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
+    tdm = os.path.join(REF, "model", "tidigits")
+    tdl = os.path.join(REF, "data", "tidigits")
+    hmm_case("tidigits_5st", tdm, os.path.join(tdl, "tidigits.lm.bin"), os.path.join(tdl, "tidigits.dic"),
+             1536, 12, 20260923)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "hmm":
+        os.makedirs(GOLD, exist_ok=True)
+        hmm_only()
+    else:
+        main()

@@ -13,6 +13,8 @@
  *   senlog  : full ps_decode_raw() with the reference's frame_eval wrapped
  *             by a recorder: every (frame, active list, scores) call is logged
  *   decode  : hypothesis + segmentation of ps_decode_raw()
+ *   hmm     : hmm_vit_eval() over a seeded random HMM population using the
+ *             model's real tmat/sseq tables; state before/after every step
  *
  * The file #includes the reference's ptm_mgau.c *from where it lies* so the
  * static stages (eval_topn/eval_cb/codebook_norm/senone_eval) can be called
@@ -473,6 +475,94 @@ cmd_decode(ps_decoder_t *ps, const char *rawpath)
 }
 
 /* ------------------------------------------------------------------ */
+/* hmm: drive the reference's hmm_vit_eval() (hmm.c:786-805) over a seeded
+ * random population of HMMs that uses the decoder's real tmat / sseq tables;
+ * dump the complete state before and after every step. */
+static uint32_t g_rng;
+static uint32_t rnd(void) { g_rng = g_rng * 1664525u + 1013904223u; return g_rng >> 8; }
+
+#define HF 19   /* score[5] history[5] out_score out_history senid[5] bestscore tmatid */
+static void
+hmm_pack(const hmm_t *h, int32 *o)
+{
+    int i;
+    for (i = 0; i < 5; ++i) { o[i] = h->score[i]; o[5 + i] = h->history[i]; o[12 + i] = h->senid[i]; }
+    o[10] = h->out_score; o[11] = h->out_history;
+    o[17] = h->bestscore; o[18] = h->tmatid;
+}
+
+static int
+cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
+{
+    bin_mdef_t *mdef = ps->acmod->mdef;
+    tmat_t *tmat = ps->acmod->tmat;
+    int n_emit = bin_mdef_n_emit_state(mdef), n_sseq = bin_mdef_n_sseq(mdef);
+    int n_sen = bin_mdef_n_sen(mdef), n_tmat = tmat->n_tmat;
+    int16 *senscr = calloc(n_sen, sizeof(int16));
+    hmm_context_t *ctx = hmm_context_init(n_emit, tmat->tp, senscr, mdef->sseq);
+    hmm_t *h = calloc(n_hmm, sizeof(hmm_t));
+    int32 *before = malloc(sizeof(int32) * (size_t)n_steps * n_hmm * HF);
+    int32 *after = malloc(sizeof(int32) * (size_t)n_steps * n_hmm * HF);
+    int32 *ret = malloc(sizeof(int32) * (size_t)n_steps * n_hmm);
+    int16 *allscr = malloc(sizeof(int16) * (size_t)n_steps * n_sen);
+    uint8 *mpx = malloc(n_hmm);
+    uint8 *tpflat = malloc((size_t)n_tmat * n_emit * (n_emit + 1));
+    uint16 *sseqflat = malloc(sizeof(uint16) * (size_t)n_sseq * n_emit);
+    int i, t, st, a, b;
+
+    g_rng = (uint32_t)seed;
+    for (i = 0; i < n_tmat; ++i) for (a = 0; a < n_emit; ++a) for (b = 0; b <= n_emit; ++b)
+        tpflat[((size_t)i * n_emit + a) * (n_emit + 1) + b] = tmat->tp[i][a][b];
+    for (i = 0; i < n_sseq; ++i) for (a = 0; a < n_emit; ++a)
+        sseqflat[(size_t)i * n_emit + a] = mdef->sseq[i][a];
+    for (i = 0; i < n_hmm; ++i) {
+        mpx[i] = (uint8)(rnd() & 1);
+        hmm_init(ctx, &h[i], mpx[i], rnd() % n_sseq, rnd() % n_tmat);
+    }
+    for (t = 0; t < n_steps; ++t) {
+        /* senone scores: mostly speech-like, some saturated */
+        for (i = 0; i < n_sen; ++i) {
+            uint32_t r = rnd();
+            senscr[i] = (int16)((r & 15) == 0 ? 32767 - (r >> 8) % 100 : (r >> 4) % 4000);
+        }
+        memcpy(allscr + (size_t)t * n_sen, senscr, sizeof(int16) * n_sen);
+        for (i = 0; i < n_hmm; ++i) {
+            uint32_t r = rnd();
+            /* (re-)enter a third of them; push a few towards the WORST_SCORE clamp */
+            if (t == 0 || r % 3 == 0)
+                hmm_enter(&h[i], -(int32)(rnd() % 200000), (int32)(rnd() % 5000), t);
+            if (r % 53 == 0)
+                for (st = 0; st < n_emit; ++st)
+                    h[i].score[st] = WORST_SCORE + (int32)(rnd() % 3000) - 200;
+            if (r % 41 == 0)
+                hmm_clear(&h[i]);
+            if (mpx[i] && r % 7 == 0) {          /* mpx: states carry their own ssids */
+                st = 1 + rnd() % (n_emit - 1);
+                h[i].senid[st] = (rnd() % 5 == 0) ? 0xffff : (uint16)(rnd() % n_sseq);
+            }
+            if (t == 0 && r % 2)                   /* start some with populated inner states */
+                for (st = 1; st < n_emit; ++st) {
+                    h[i].score[st] = -(int32)(rnd() % 300000);
+                    h[i].history[st] = (int32)(rnd() % 5000);
+                    if (mpx[i]) h[i].senid[st] = (uint16)(rnd() % n_sseq);
+                }
+            hmm_pack(&h[i], before + ((size_t)t * n_hmm + i) * HF);
+            ret[(size_t)t * n_hmm + i] = hmm_vit_eval(&h[i]);
+            hmm_pack(&h[i], after + ((size_t)t * n_hmm + i) * HF);
+        }
+    }
+    puti("n_emit", n_emit); puti("n_sseq", n_sseq); puti("n_tmat", n_tmat); puti("n_sen", n_sen);
+    put3("tp", 'B', n_tmat, n_emit, n_emit + 1, tpflat);
+    put2("sseq", 'H', n_sseq, n_emit, sseqflat);
+    put1("mpx", 'B', n_hmm, mpx);
+    put2("senscr", 'h', n_steps, n_sen, allscr);
+    put3("before", 'i', n_steps, n_hmm, HF, before);
+    put3("after", 'i', n_steps, n_hmm, HF, after);
+    put2("ret", 'i', n_steps, n_hmm, ret);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 int
 main(int argc, char **argv)
 {
@@ -501,6 +591,8 @@ main(int argc, char **argv)
         rc = cmd_ptm(a, b, argv[6], atoi(argv[7]), atoi(argv[8]), xa > 9 ? atoi(argv[9]) : 0);
     } else if (!strcmp(cmd, "senlog") && xa > 7) {
         rc = cmd_senlog(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]));
+    } else if (!strcmp(cmd, "hmm") && xa > 8) {
+        rc = cmd_hmm(make_decoder(modeldir, lm, dict, nextra, extra), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
     } else if (!strcmp(cmd, "decode") && xa > 6) {
         rc = cmd_decode(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
     } else {

@@ -11,5 +11,6 @@ present.
 """
 from .capi import PsgpuError, lib, build_library, LIB_PATH  # noqa: F401
 from .ptm import PtmModel, PtmMgau, PtmState  # noqa: F401
+from .hmm import HmmContext, HMM_REC  # noqa: F401
 
-__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState"]
+__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC"]

@@ -1,0 +1,461 @@
+// psgpu_hmm.hip -- the per-frame Viterbi step of hmm_vit_eval() (reference
+// src/hmm.c:786-805) for batches of active HMMs on gfx950.
+//
+// Replaces hmm_vit_eval_3st_lr (:529-607), _3st_lr_mpx (:609-707), _5st_lr
+// (:222-350) and _5st_lr_mpx (:355-525) bit-exactly (int32 path scores, the
+// reference's arg-max tie rules, WORST_SCORE clamps, stale-t2 behaviour of the
+// 3-state form, BAD_SSID handling and ssid propagation of the multiplex form).
+//
+// Layout: one 64-byte record per HMM (psgpu_hmm_rec_t: the fields of hmm_t,
+// hmm.h:169-182, minus the context pointer and frame stamp), so that a lane
+// working on an arbitrary member of the active list moves exactly one aligned
+// 64-byte line in and one out -- the access pattern is a gather/scatter over
+// the active list and nothing else is worth staging.  Transition matrices
+// (uint8 tp[tmat][from][to], tmat.h:60-66) are tiny and sit in LDS; senone
+// scores are gathered from the frame's int16 row of the HMM's utterance; the
+// multiplex form goes through sseq[ssid][state] (bin_mdef.h:119) first.
+// One lane = one HMM; the block max of the returned best scores is folded into
+// best[utt] with one atomic per wavefront (evaluate_channels keeps the same
+// maximum, ngram_search_fwdtree.c:701-715).
+#include "psgpu_internal.h"
+#include <cstring>
+#include <cstdlib>
+#include <climits>
+
+static_assert(sizeof(psgpu_hmm_rec_t) == 64, "HMM record must be one 64-byte line");
+
+struct psgpu_hmm_ctx_s {
+    int32_t n_emit, n_tmat, n_sseq, n_sen;
+    uint8_t *tp;             // device [n_tmat][n_emit][n_emit+1]
+    uint16_t *sseq;          // device [n_sseq][n_emit]
+    // staging for the host-buffer entry point
+    hipStream_t stream;
+    psgpu_hmm_rec_t *h_recs, *d_recs;
+    int16_t *h_scr, *d_scr;
+    int32_t *h_best, *d_best;
+    int32_t cap;
+};
+
+constexpr int32_t kW = kWorstScore;
+constexpr int kTmatWorst = 255;            // tmat.h: 8-bit floor; "tp > -255" gates skip arcs
+constexpr uint16_t kBadSsid = 0xffff;      // hmm.h:89
+
+__device__ __forceinline__ int32_t clampw(int32_t v) { return v < kW ? kW : v; }
+
+struct HmmRegs {
+    int32_t score[5], history[5], out_score, out_history, bestscore;
+    uint16_t senid[5];
+};
+
+// ---- 3-state, non-multiplex (hmm.c:529-607) --------------------------------
+__device__ __forceinline__ int32_t vit3(HmmRegs &h, const uint8_t *tp, const int16_t *ss)
+{
+#define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
+    int32_t s2 = h.score[2] - ss[h.senid[2]];
+    int32_t s1 = h.score[1] - ss[h.senid[1]];
+    int32_t s0 = h.score[0] - ss[h.senid[0]];
+    int32_t best = kW, t0, t1, t2 = INT_MIN;
+    if (s1 > kW) {
+        t1 = s2 + TP(2, 3);
+        if (TP(1, 3) > -kTmatWorst) t2 = s1 + TP(1, 3);
+        int32_t s3;
+        if (t1 > t2) { s3 = t1; h.out_history = h.history[2]; }
+        else         { s3 = t2; h.out_history = h.history[1]; }
+        s3 = clampw(s3);
+        h.out_score = s3;
+        best = s3;
+    }
+    t0 = s2 + TP(2, 2);
+    t1 = s1 + TP(1, 2);
+    if (TP(0, 2) > -kTmatWorst) t2 = s0 + TP(0, 2);     // else t2 keeps its value (stale, as the reference)
+    if (t0 > t1) {
+        if (t2 > t0) { s2 = t2; h.history[2] = h.history[0]; }
+        else s2 = t0;
+    }
+    else {
+        if (t2 > t1) { s2 = t2; h.history[2] = h.history[0]; }
+        else { s2 = t1; h.history[2] = h.history[1]; }
+    }
+    s2 = clampw(s2);
+    best = max(best, s2);
+    h.score[2] = s2;
+    t0 = s1 + TP(1, 1);
+    t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h.history[1] = h.history[0]; }
+    s1 = clampw(s1);
+    best = max(best, s1);
+    h.score[1] = s1;
+    s0 = clampw(s0 + TP(0, 0));
+    best = max(best, s0);
+    h.score[0] = s0;
+    h.bestscore = best;
+    return best;
+#undef TP
+}
+
+// ---- 3-state, multiplex (hmm.c:609-707) -------------------------------------
+__device__ __forceinline__ int32_t vit3_mpx(HmmRegs &h, const uint8_t *tp, const int16_t *ss,
+                                            const uint16_t *sseq)
+{
+#define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
+#define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 3 + (st)]])
+    int32_t s3, s2, s1, s0, t0, t1, t2 = INT_MIN, best;
+    if (h.senid[2] == kBadSsid) s2 = t1 = kW;
+    else { s2 = h.score[2] + SEN(2); t1 = s2 + TP(2, 3); }
+    if (h.senid[1] == kBadSsid) s1 = t2 = kW;
+    else {
+        s1 = h.score[1] + SEN(1);
+        if (TP(1, 3) > -kTmatWorst) t2 = s1 + TP(1, 3);
+    }
+    if (t1 > t2) { s3 = t1; h.out_history = h.history[2]; }
+    else         { s3 = t2; h.out_history = h.history[1]; }
+    s3 = clampw(s3);
+    h.out_score = s3;
+    best = s3;
+
+    s0 = h.score[0] + SEN(0);
+    t0 = t1 = kW;
+    if (s2 != kW) t0 = s2 + TP(2, 2);
+    if (s1 != kW) t1 = s1 + TP(1, 2);
+    if (TP(0, 2) > -kTmatWorst) t2 = s0 + TP(0, 2);
+    if (t0 > t1) {
+        if (t2 > t0) { s2 = t2; h.history[2] = h.history[0]; h.senid[2] = h.senid[0]; }
+        else s2 = t0;
+    }
+    else {
+        if (t2 > t1) { s2 = t2; h.history[2] = h.history[0]; h.senid[2] = h.senid[0]; }
+        else { s2 = t1; h.history[2] = h.history[1]; h.senid[2] = h.senid[1]; }
+    }
+    s2 = clampw(s2);
+    best = max(best, s2);
+    h.score[2] = s2;
+
+    t0 = kW;
+    if (s1 != kW) t0 = s1 + TP(1, 1);
+    t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h.history[1] = h.history[0]; h.senid[1] = h.senid[0]; }
+    s1 = clampw(s1);
+    best = max(best, s1);
+    h.score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    best = max(best, s0);
+    h.score[0] = s0;
+    h.bestscore = best;
+    return best;
+#undef TP
+#undef SEN
+}
+
+// three-way arg-max of the 5-state forms: self loop T0, neighbour T1 (state
+// nb), skip T2 (state sk); destination state nb + 1
+template <bool MPX>
+__device__ __forceinline__ int32_t pick3(HmmRegs &h, int32_t T0, int32_t T1, int32_t T2, int nb, int sk)
+{
+    int32_t dst;
+    if (T0 > T1) {
+        if (T2 > T0) { dst = T2; h.history[nb + 1] = h.history[sk]; if (MPX) h.senid[nb + 1] = h.senid[sk]; }
+        else dst = T0;
+    }
+    else {
+        if (T2 > T1) { dst = T2; h.history[nb + 1] = h.history[sk]; if (MPX) h.senid[nb + 1] = h.senid[sk]; }
+        else { dst = T1; h.history[nb + 1] = h.history[nb]; if (MPX) h.senid[nb + 1] = h.senid[nb]; }
+    }
+    return dst;
+}
+
+// ---- 5-state, non-multiplex (hmm.c:222-350) ---------------------------------
+__device__ __forceinline__ int32_t vit5(HmmRegs &h, const uint8_t *tp, const int16_t *ss)
+{
+#define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
+#define SEN(st) (-(int32_t)ss[h.senid[st]])
+    int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best = kW;
+    s4 = h.score[4] + SEN(4);
+    s3 = h.score[3] + SEN(3);
+    if (s3 > kW) {
+        t1 = s4 + TP(4, 5);
+        t2 = s3 + TP(3, 5);
+        if (t1 > t2) { s5 = t1; h.out_history = h.history[4]; }
+        else         { s5 = t2; h.out_history = h.history[3]; }
+        s5 = clampw(s5);
+        h.out_score = s5;
+        best = s5;
+    }
+    s2 = h.score[2] + SEN(2);
+    if (s2 > kW) {
+        t0 = s4 + TP(4, 4); t1 = s3 + TP(3, 4); t2 = s2 + TP(2, 4);
+        s4 = clampw(pick3<false>(h, t0, t1, t2, 3, 2));
+        best = max(best, s4);
+        h.score[4] = s4;
+    }
+    s1 = h.score[1] + SEN(1);
+    if (s1 > kW) {
+        t0 = s3 + TP(3, 3); t1 = s2 + TP(2, 3); t2 = s1 + TP(1, 3);
+        s3 = clampw(pick3<false>(h, t0, t1, t2, 2, 1));
+        best = max(best, s3);
+        h.score[3] = s3;
+    }
+    s0 = h.score[0] + SEN(0);
+    t0 = s2 + TP(2, 2); t1 = s1 + TP(1, 2); t2 = s0 + TP(0, 2);
+    s2 = clampw(pick3<false>(h, t0, t1, t2, 1, 0));
+    best = max(best, s2);
+    h.score[2] = s2;
+
+    t0 = s1 + TP(1, 1); t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h.history[1] = h.history[0]; }
+    s1 = clampw(s1);
+    best = max(best, s1);
+    h.score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    best = max(best, s0);
+    h.score[0] = s0;
+    h.bestscore = best;
+    return best;
+#undef TP
+#undef SEN
+}
+
+// ---- 5-state, multiplex (hmm.c:355-525) -------------------------------------
+__device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const int16_t *ss,
+                                            const uint16_t *sseq)
+{
+#define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
+#define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 5 + (st)]])
+    int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best;
+    if (h.senid[4] == kBadSsid) s4 = t1 = kW;
+    else { s4 = h.score[4] + SEN(4); t1 = s4 + TP(4, 5); }
+    if (h.senid[3] == kBadSsid) s3 = t2 = kW;
+    else { s3 = h.score[3] + SEN(3); t2 = s3 + TP(3, 5); }
+    if (t1 > t2) { s5 = t1; h.out_history = h.history[4]; }
+    else         { s5 = t2; h.out_history = h.history[3]; }
+    s5 = clampw(s5);
+    h.out_score = s5;
+    best = s5;
+
+    if (h.senid[2] == kBadSsid) s2 = t2 = kW;
+    else { s2 = h.score[2] + SEN(2); t2 = s2 + TP(2, 4); }
+    t0 = t1 = kW;
+    if (s4 != kW) t0 = s4 + TP(4, 4);
+    if (s3 != kW) t1 = s3 + TP(3, 4);
+    s4 = clampw(pick3<true>(h, t0, t1, t2, 3, 2));
+    best = max(best, s4);
+    h.score[4] = s4;
+
+    if (h.senid[1] == kBadSsid) s1 = t2 = kW;
+    else { s1 = h.score[1] + SEN(1); t2 = s1 + TP(1, 3); }
+    t0 = t1 = kW;
+    if (s3 != kW) t0 = s3 + TP(3, 3);
+    if (s2 != kW) t1 = s2 + TP(2, 3);
+    s3 = clampw(pick3<true>(h, t0, t1, t2, 2, 1));
+    best = max(best, s3);
+    h.score[3] = s3;
+
+    s0 = h.score[0] + SEN(0);
+    t0 = t1 = kW;
+    if (s2 != kW) t0 = s2 + TP(2, 2);
+    if (s1 != kW) t1 = s1 + TP(1, 2);
+    t2 = s0 + TP(0, 2);
+    s2 = clampw(pick3<true>(h, t0, t1, t2, 1, 0));
+    best = max(best, s2);
+    h.score[2] = s2;
+
+    t0 = kW;
+    if (s1 != kW) t0 = s1 + TP(1, 1);
+    t1 = s0 + TP(0, 1);
+    if (t0 > t1) s1 = t0;
+    else { s1 = t1; h.history[1] = h.history[0]; h.senid[1] = h.senid[0]; }
+    s1 = clampw(s1);
+    best = max(best, s1);
+    h.score[1] = s1;
+
+    s0 = clampw(s0 + TP(0, 0));
+    best = max(best, s0);
+    h.score[0] = s0;
+    h.bestscore = best;
+    return best;
+#undef TP
+#undef SEN
+}
+
+// ---------------------------------------------------------------------------
+// kernel: one lane per active HMM
+// ---------------------------------------------------------------------------
+constexpr int kHmmThreads = 256;
+constexpr int kTpLdsMax = 16384;
+
+template <int NE>
+__global__ __launch_bounds__(kHmmThreads)
+void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restrict__ active,
+                    int32_t n_active, const uint16_t *__restrict__ utt_of_hmm,
+                    const int16_t *__restrict__ senscr, int32_t senscr_stride,
+                    const uint8_t *__restrict__ tp_g, int32_t tp_bytes,
+                    const uint16_t *__restrict__ sseq, int32_t *__restrict__ best_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_tp[kTpLdsMax];
+    const bool tp_in_lds = tp_bytes <= kTpLdsMax;
+    if (tp_in_lds) {
+        for (int i = threadIdx.x; i < tp_bytes; i += kHmmThreads) s_tp[i] = tp_g[i];
+        __syncthreads();
+    }
+    const int i = blockIdx.x * kHmmThreads + threadIdx.x;
+    int32_t best = kMaxNegInt32;
+    int utt = 0;
+    if (i < n_active) {
+        const int idx = active ? active[i] : i;
+        utt = utt_of_hmm ? utt_of_hmm[idx] : 0;
+        // one 64-byte line in
+        const int4 *rp = reinterpret_cast<const int4 *>(recs + idx);
+        int4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        HmmRegs h;
+        h.score[0] = q0.x; h.score[1] = q0.y; h.score[2] = q0.z; h.score[3] = q0.w;
+        h.score[4] = q1.x; h.history[0] = q1.y; h.history[1] = q1.z; h.history[2] = q1.w;
+        h.history[3] = q2.x; h.history[4] = q2.y; h.out_score = q2.z; h.out_history = q2.w;
+        h.bestscore = q3.x;
+        h.senid[0] = (uint16_t)(q3.y & 0xffff); h.senid[1] = (uint16_t)((uint32_t)q3.y >> 16);
+        h.senid[2] = (uint16_t)(q3.z & 0xffff); h.senid[3] = (uint16_t)((uint32_t)q3.z >> 16);
+        h.senid[4] = (uint16_t)(q3.w & 0xffff);
+        const uint32_t tm = (uint32_t)q3.w >> 16;
+        const bool mpx = (tm & PSGPU_HMM_MPX) != 0;
+        const uint32_t tmatid = tm & 0x7fffu;
+        const uint8_t *tp = (tp_in_lds ? s_tp : tp_g) + (size_t)tmatid * NE * (NE + 1);
+        const int16_t *ss = senscr + (size_t)utt * senscr_stride;
+        if (NE == 3)
+            best = mpx ? vit3_mpx(h, tp, ss, sseq) : vit3(h, tp, ss);
+        else
+            best = mpx ? vit5_mpx(h, tp, ss, sseq) : vit5(h, tp, ss);
+        // one 64-byte line out
+        q0 = make_int4(h.score[0], h.score[1], h.score[2], h.score[3]);
+        q1 = make_int4(h.score[4], h.history[0], h.history[1], h.history[2]);
+        q2 = make_int4(h.history[3], h.history[4], h.out_score, h.out_history);
+        q3 = make_int4(h.bestscore, (int32_t)((uint32_t)h.senid[0] | ((uint32_t)h.senid[1] << 16)),
+                       (int32_t)((uint32_t)h.senid[2] | ((uint32_t)h.senid[3] << 16)),
+                       (int32_t)((uint32_t)h.senid[4] | (tm << 16)));
+        int4 *wp = reinterpret_cast<int4 *>(recs + idx);
+        wp[0] = q0; wp[1] = q1; wp[2] = q2; wp[3] = q3;
+    }
+    if (best_out) {
+        // fold the wave's maximum into best[utt]; lanes of one wave may belong
+        // to different utterances, so reduce only when the wave is uniform
+        const int utt0 = __builtin_amdgcn_readfirstlane(utt);
+        if (__ballot(utt != utt0 && i < n_active) == 0) {
+            int32_t m = best;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+            if ((threadIdx.x & 63) == 0 && m != kMaxNegInt32) atomicMax(&best_out[utt0], m);
+        }
+        else if (i < n_active)
+            atomicMax(&best_out[utt], best);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int psgpu_hmm_ctx_create(psgpu_hmm_ctx_t **out, int32_t n_emit_state, int32_t n_tmat,
+                         const uint8_t *tp, int32_t n_sseq, const uint16_t *sseq, int32_t n_sen)
+{
+    PSGPU_REQUIRE(out && tp && sseq, "psgpu_hmm_ctx_create: NULL argument");
+    PSGPU_REQUIRE(n_emit_state == 3 || n_emit_state == 5,
+                  "n_emit_state %d: the hard-wired 3- and 5-state topologies are supported "
+                  "(hmm_vit_eval_anytopo, hmm.c:709-784, is reached by no bundled model)", n_emit_state);
+    PSGPU_REQUIRE(n_tmat > 0 && n_tmat < 32768 && n_sseq > 0 && n_sseq < 65535 && n_sen > 0,
+                  "bad table sizes (n_tmat %d, n_sseq %d, n_sen %d)", n_tmat, n_sseq, n_sen);
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    psgpu_hmm_ctx_t *c = new psgpu_hmm_ctx_t();
+    memset(c, 0, sizeof *c);
+    c->n_emit = n_emit_state; c->n_tmat = n_tmat; c->n_sseq = n_sseq; c->n_sen = n_sen;
+    const size_t tpb = (size_t)n_tmat * n_emit_state * (n_emit_state + 1);
+    hipError_t e = hipMalloc((void **)&c->tp, tpb);
+    if (e == hipSuccess) e = hipMemcpy(c->tp, tp, tpb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->sseq, (size_t)n_sseq * n_emit_state * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(c->sseq, sseq, (size_t)n_sseq * n_emit_state * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_scr, (size_t)n_sen * sizeof(int16_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_scr, (size_t)n_sen * sizeof(int16_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, sizeof(int32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, sizeof(int32_t));
+    if (e != hipSuccess) {
+        psgpu_set_error("psgpu_hmm_ctx_create: %s", hipGetErrorString(e));
+        psgpu_hmm_ctx_free(c);
+        return e == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP;
+    }
+    *out = c;
+    return PSGPU_OK;
+}
+
+void psgpu_hmm_ctx_free(psgpu_hmm_ctx_t *c)
+{
+    if (!c) return;
+    if (c->stream) hipStreamDestroy(c->stream);
+    hipFree(c->tp); hipFree(c->sseq); hipFree(c->d_recs); hipFree(c->d_scr); hipFree(c->d_best);
+    if (c->h_recs) hipHostFree(c->h_recs);
+    if (c->h_scr) hipHostFree(c->h_scr);
+    if (c->h_best) hipHostFree(c->h_best);
+    delete c;
+}
+
+int32_t psgpu_hmm_n_emit_state(const psgpu_hmm_ctx_t *c) { return c->n_emit; }
+
+int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
+                           const int32_t *active_idx_dev, int32_t n_active,
+                           const uint16_t *utt_of_hmm_dev,
+                           const int16_t *senscr_dev, int32_t senscr_stride,
+                           int32_t *best_dev, void *stream)
+{
+    PSGPU_REQUIRE(c && recs_dev && senscr_dev, "psgpu_hmm_vit_eval_dev: NULL argument");
+    PSGPU_REQUIRE(n_active >= 0, "negative n_active");
+    if (n_active == 0) return PSGPU_OK;
+    const int blocks = (n_active + kHmmThreads - 1) / kHmmThreads;
+    const int32_t tpb = c->n_tmat * c->n_emit * (c->n_emit + 1);
+    if (c->n_emit == 3)
+        hipLaunchKernelGGL((hmm_vit_kernel<3>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
+                           recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
+                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev);
+    else
+        hipLaunchKernelGGL((hmm_vit_kernel<5>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
+                           recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
+                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev);
+    PSGPU_HIP(hipGetLastError());
+    return PSGPU_OK;
+}
+
+int psgpu_hmm_vit_eval(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs, int32_t n,
+                       const int16_t *senscr, int32_t *best)
+{
+    PSGPU_REQUIRE(c && senscr && (recs || n == 0), "psgpu_hmm_vit_eval: NULL argument");
+    PSGPU_REQUIRE(n >= 0, "negative n");
+    if (best) *best = kWorstScore;
+    if (n == 0) return PSGPU_OK;
+    if (n > c->cap) {
+        const int32_t cap = n < 1024 ? 1024 : n + n / 2;
+        if (c->h_recs) hipHostFree(c->h_recs);
+        hipFree(c->d_recs);
+        c->h_recs = nullptr; c->d_recs = nullptr; c->cap = 0;
+        PSGPU_HIP(hipHostMalloc((void **)&c->h_recs, (size_t)cap * sizeof(psgpu_hmm_rec_t), hipHostMallocDefault));
+        PSGPU_HIP(hipMalloc((void **)&c->d_recs, (size_t)cap * sizeof(psgpu_hmm_rec_t)));
+        c->cap = cap;
+    }
+    memcpy(c->h_recs, recs, (size_t)n * sizeof(psgpu_hmm_rec_t));
+    memcpy(c->h_scr, senscr, (size_t)c->n_sen * sizeof(int16_t));
+    *c->h_best = kWorstScore;       // hmm.h:84: the evaluate loops start from WORST_SCORE
+    PSGPU_HIP(hipMemcpyAsync(c->d_recs, c->h_recs, (size_t)n * sizeof(psgpu_hmm_rec_t), hipMemcpyHostToDevice, c->stream));
+    PSGPU_HIP(hipMemcpyAsync(c->d_scr, c->h_scr, (size_t)c->n_sen * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    PSGPU_HIP(hipMemcpyAsync(c->d_best, c->h_best, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    int rc = psgpu_hmm_vit_eval_dev(c, c->d_recs, nullptr, n, nullptr, c->d_scr, c->n_sen, c->d_best, c->stream);
+    if (rc != PSGPU_OK) return rc;
+    PSGPU_HIP(hipMemcpyAsync(c->h_recs, c->d_recs, (size_t)n * sizeof(psgpu_hmm_rec_t), hipMemcpyDeviceToHost, c->stream));
+    PSGPU_HIP(hipMemcpyAsync(c->h_best, c->d_best, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    PSGPU_HIP(hipStreamSynchronize(c->stream));
+    memcpy(recs, c->h_recs, (size_t)n * sizeof(psgpu_hmm_rec_t));
+    if (best) *best = *c->h_best;
+    return PSGPU_OK;
+}
+
+}  // extern "C"

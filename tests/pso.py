@@ -162,3 +162,35 @@ def row_hash(a):
             h ^= b[:, j].astype(np.uint64)
             h *= prime
     return h
+
+
+HMM_FIELDS = 19   # score[5] history[5] out_score out_history senid[5] bestscore tmatid (ref_dump.c hmm_pack)
+
+
+def hmm_step_oracle(g, t):
+    """Run pso_hmm_vit_eval over every HMM of step t of an hmm_*.npz fixture
+    (state `before` -> returns (after [n_hmm][19], ret [n_hmm]))."""
+    L = lib()
+    n_emit = int(g["n_emit"][0])
+    tp = np.ascontiguousarray(g["tp"], np.uint8)
+    sseq = np.ascontiguousarray(g["sseq"], np.uint16)
+    scr = np.ascontiguousarray(g["senscr"][t], np.int16)
+    ctx = PsoHmmCtx(n_emit, tp.ctypes.data, scr.ctypes.data, sseq.ctypes.data)
+    before = g["before"][t]
+    n = before.shape[0]
+    after = np.empty_like(before)
+    ret = np.empty(n, np.int32)
+    h = PsoHmm()
+    for i in range(n):
+        b = before[i]
+        for s in range(5):
+            h.score[s] = int(b[s]); h.history[s] = int(b[5 + s]); h.senid[s] = int(b[12 + s])
+        h.out_score = int(b[10]); h.out_history = int(b[11])
+        h.bestscore = int(b[17]); h.tmatid = int(b[18])
+        h.mpx = int(g["mpx"][i]); h.n_emit_state = n_emit; h.ssid = int(b[12])
+        ret[i] = L.pso_hmm_vit_eval(C.byref(ctx), C.byref(h))
+        a = after[i]
+        for s in range(5):
+            a[s] = h.score[s]; a[5 + s] = h.history[s]; a[12 + s] = h.senid[s]
+        a[10] = h.out_score; a[11] = h.out_history; a[17] = h.bestscore; a[18] = h.tmatid
+    return after, ret

@@ -1,0 +1,115 @@
+"""GPU parity of the HMM Viterbi step (psgpu_hmm_vit_eval*, the hmm_vit_eval
+replacement) against state dumps of the unmodified reference (hmm_*.npz:
+3-state en-us and 5-state tidigits, multiplex and not) and the pinned oracle.
+Bit-exact int32 scores, history pointers, propagated ssids, best scores."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pso
+from test_oracle_golden import _load
+
+pytestmark = pytest.mark.gpu
+
+
+def to_recs(P, before, mpx):
+    r = np.zeros(before.shape[0], P.HMM_REC)
+    r["score"] = before[:, 0:5]; r["history"] = before[:, 5:10]
+    r["out_score"] = before[:, 10]; r["out_history"] = before[:, 11]
+    r["senid"] = before[:, 12:17].astype(np.uint16); r["bestscore"] = before[:, 17]
+    r["tmatid_mpx"] = (before[:, 18].astype(np.uint16) | np.where(mpx != 0, 0x8000, 0).astype(np.uint16))
+    return r
+
+
+def from_recs(r):
+    out = np.empty((r.size, pso.HMM_FIELDS), np.int32)
+    out[:, 0:5] = r["score"]; out[:, 5:10] = r["history"]
+    out[:, 10] = r["out_score"]; out[:, 11] = r["out_history"]
+    out[:, 12:17] = r["senid"]; out[:, 17] = r["bestscore"]
+    out[:, 18] = r["tmatid_mpx"] & 0x7fff
+    return out
+
+
+@pytest.mark.parametrize("case", ["en_us_3st", "tidigits_5st"])
+def test_hmm_steps_match_reference(case):
+    import pocketsphinx_amd as P
+    g = _load("hmm_%s.npz" % case)
+    ne = int(g["n_emit"][0])
+    ctx = P.HmmContext(g["tp"], g["sseq"], int(g["n_sen"][0]))
+    for t in range(g["before"].shape[0]):
+        recs = to_recs(P, g["before"][t], g["mpx"])
+        best = ctx.vit_eval(recs, g["senscr"][t])
+        got, want = from_recs(recs), g["after"][t].copy()
+        # states beyond n_emit are not part of a 3-state HMM
+        if ne == 3:
+            for a in (got, want):
+                a[:, 3:5] = 0; a[:, 8:10] = 0; a[:, 15:17] = 0
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, "step %d HMM %d (mpx %d)\nbefore %s\nref    %s\ngpu    %s" % (
+            t, bad[0], g["mpx"][bad[0]], g["before"][t][bad[0]], want[bad[0]], got[bad[0]])
+        assert np.array_equal(recs["bestscore"], g["ret"][t])
+        assert best == max(int(g["ret"][t].max()), -0x20000000)
+    ctx.close()
+
+
+def test_active_list_multi_utt_dev():
+    """Device entry point: sparse active list over an arena that holds HMMs of
+    several utterances, each scored against its own senone-score row; inactive
+    records must stay untouched and best[] is a per-utterance maximum."""
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    g = _load("hmm_en_us_3st.npz")
+    n_sen = int(g["n_sen"][0])
+    ctx = P.HmmContext(g["tp"], g["sseq"], n_sen)
+    n_utt, T = 4, g["before"].shape[0]
+    n = g["before"].shape[1]
+    rng = np.random.default_rng(3)
+    # arena = step-0 states; utterance u scored with senone row u
+    recs = to_recs(P, g["before"][0], g["mpx"])
+    utt = rng.integers(0, n_utt, n).astype(np.uint16)
+    active = np.sort(rng.choice(n, n // 3, replace=False)).astype(np.int32)
+    scr = np.ascontiguousarray(g["senscr"][:n_utt])
+    dev = torch.device("cuda", 0)
+    d_recs = torch.from_numpy(recs.view(np.uint8).reshape(n, 64).copy()).to(dev)
+    d_act = torch.from_numpy(active).to(dev)
+    d_utt = torch.from_numpy(utt.view(np.int16).copy()).to(dev)
+    d_scr = torch.from_numpy(scr).to(dev)
+    d_best = torch.full((n_utt,), -0x20000000, dtype=torch.int32, device=dev)
+    L = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(L.psgpu_hmm_vit_eval_dev(ctx.h, C.c_void_p(d_recs.data_ptr()), C.c_void_p(d_act.data_ptr()),
+                                        int(active.size), C.c_void_p(d_utt.data_ptr()),
+                                        C.c_void_p(d_scr.data_ptr()), n_sen,
+                                        C.c_void_p(d_best.data_ptr()), st), "hmm_vit_eval_dev")
+    torch.cuda.synchronize()
+    got = d_recs.cpu().numpy().reshape(-1).view(P.HMM_REC)
+    # oracle: same thing per utterance row
+    want = recs.copy()
+    best = np.full(n_utt, -0x20000000, np.int64)
+    for u in range(n_utt):
+        gg = dict(g); gg["senscr"] = scr[u][None, :].repeat(T, axis=0)
+        after, ret = pso.hmm_step_oracle(gg, 0)
+        sel = active[utt[active] == u]
+        w = to_recs(P, after, g["mpx"])
+        want[sel] = w[sel]
+        want["bestscore"][sel] = ret[sel]
+        if sel.size:
+            best[u] = max(best[u], int(ret[sel].max()))
+    for f in ("score", "history", "senid"):
+        assert np.array_equal(got[f][:, :3], want[f][:, :3]), f
+    for f in ("out_score", "out_history", "bestscore", "tmatid_mpx"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(d_best.cpu().numpy().astype(np.int64), best)
+    ctx.close()
+
+
+def test_empty_and_errors():
+    import pocketsphinx_amd as P
+    g = _load("hmm_en_us_3st.npz")
+    ctx = P.HmmContext(g["tp"], g["sseq"], int(g["n_sen"][0]))
+    assert ctx.vit_eval(np.zeros(0, P.HMM_REC), g["senscr"][0]) == -0x20000000
+    with pytest.raises(P.PsgpuError):
+        P.HmmContext(np.zeros((2, 4, 5), np.uint8), np.zeros((3, 4), np.uint16), 10)   # 4-state: unsupported
+    ctx.close()

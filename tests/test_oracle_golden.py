@@ -115,3 +115,17 @@ def test_flags2list_bridges_gaps():
     assert d.max() <= 255 and d[0] == 0
     # acmod.c:1246-1249: a gap of 297 becomes 255 + 42
     assert list(d[:4]) == [0, 3, 255, 42]
+
+
+@pytest.mark.parametrize("case", ["en_us_3st", "tidigits_5st"])
+def test_hmm_oracle_matches_reference(case):
+    """pso_hmm_vit_eval vs the reference's hmm_vit_eval (hmm.c:786-805) on the
+    state dumps of oracle/ref_dump.c `hmm`: 3-state (en-us) and 5-state
+    (tidigits) topologies, multiplex and not, incl. WORST_SCORE clamps,
+    BAD_SSID states and saturated senone scores."""
+    g = _load("hmm_%s.npz" % case)
+    for t in range(g["before"].shape[0]):
+        after, ret = pso.hmm_step_oracle(g, t)
+        bad = np.nonzero((after != g["after"][t]).any(axis=1) | (ret != g["ret"][t]))[0]
+        assert bad.size == 0, "step %d: first mismatching HMM %d (mpx %d)\nbefore %s\nref    %s\noracle %s" % (
+            t, bad[0], g["mpx"][bad[0]], g["before"][t][bad[0]], g["after"][t][bad[0]], after[bad[0]])
