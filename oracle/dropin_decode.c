@@ -12,7 +12,15 @@
  *   - segmentation (word, start frame, end frame, ascr, lscr, lback)
  * Prints one JSON line; exit status 0 iff everything is identical.
  *
+ * Built twice by oracle/Makefile:
+ *   dropin_decode       against the plain reference library + the GMM shim
+ *   dropin_decode_full  (-DPSGPU_SEARCH_HOOKS) against libpocketsphinx_psgpu.so,
+ *                       the reference with its three hmm_vit_eval loops routed
+ *                       through integration/psgpu_search_hooks.h; decoder B
+ *                       then also runs every Viterbi step on the device
+ *
  * usage: dropin_decode MODELDIR LM DICT RAW NREP [key val ...]
+ *   pseudo keys: mllr_after FILE | psgpu_mgau yes|no | psgpu_search yes|no
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +32,9 @@
 #include "pocketsphinx_internal.h"
 #include "bin_mdef.h"
 #include "psgpu_mgau_shim.h"
+#ifdef PSGPU_SEARCH_HOOKS
+#include "psgpu_search_hooks.h"
+#endif
 
 typedef struct rec_s {
     ps_mgaufuncs_t funcs;          /* wrapper vtable */
@@ -86,7 +97,8 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
     for (i = 0; i + 1 < argc; i += 2) {
         const char *k = argv[i];
         if (k[0] == '-') ++k;
-        if (!strcmp(k, "mllr_after")) continue;       /* handled by main() */
+        if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search"))
+            continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
         }
@@ -142,6 +154,13 @@ main(int argc, char **argv)
     FILE *fp; long sz; int16 *pcm; size_t n;
     int nrep, r, i, ok = 1, bad_calls = 0, first_bad = -1, hyp_equal = 1, seg_equal = 1;
     double t_cpu = 0, t_gpu = 0, t0;
+    int use_mgau = 1;
+#ifdef PSGPU_SEARCH_HOOKS
+    int use_search = 1;
+#else
+    int use_search = 0;
+#endif
+    long hmm_batches = 0, hmm_evals = 0;
 
     if (argc < 6) {
         fprintf(stderr, "usage: dropin_decode MODELDIR LM|- DICT|- RAW NREP [key val ...]\n");
@@ -159,10 +178,22 @@ main(int argc, char **argv)
 
     cpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
     gpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
-    if (psgpu_mgau_attach(gpu) < 0) {
+    for (i = 6; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "psgpu_mgau")) use_mgau = !strcmp(argv[i + 1], "yes");
+        if (!strcmp(argv[i], "psgpu_search")) use_search = !strcmp(argv[i + 1], "yes");
+    }
+    if (use_mgau && psgpu_mgau_attach(gpu) < 0) {
         fprintf(stderr, "psgpu_mgau_attach failed\n");
         return 3;
     }
+#ifdef PSGPU_SEARCH_HOOKS
+    if (use_search && psgpu_search_attach(gpu) < 0) {
+        fprintf(stderr, "psgpu_search_attach failed\n");
+        return 3;
+    }
+#else
+    if (use_search) { fprintf(stderr, "built without the search hooks\n"); return 2; }
+#endif
     /* "mllr_after FILE": apply an MLLR transform AFTER attaching, so that the
      * shim's vt->transform (acmod_update_mllr, acmod.c:329) is what runs */
     for (i = 6; i + 1 < argc; i += 2)
@@ -190,6 +221,10 @@ main(int argc, char **argv)
                 ++bad_calls;
             }
     if (bad_calls || !hyp_equal || !seg_equal) ok = 0;
+#ifdef PSGPU_SEARCH_HOOKS
+    psgpu_search_stats(gpu, &hmm_batches, &hmm_evals);
+    psgpu_search_detach(gpu);
+#endif
     /* detach recorders before the decoders free their scorers */
     cpu->acmod->mgau->vt = rc_cpu.orig;
     gpu->acmod->mgau->vt = rc_gpu.orig;
@@ -200,12 +235,14 @@ main(int argc, char **argv)
                "\"device_calls\": %d, \"mismatching_calls\": %d, \"first_bad_call\": %d, "
                "\"hyp_equal\": %s, \"seg_equal\": %s, \"hyp_cpu\": \"%s\", \"hyp_gpu\": \"%s\", "
                "\"score_cpu\": %d, \"score_gpu\": %d, \"n_seg\": %d, "
-               "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\"}\n",
+               "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
+               "\"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld}\n",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
-               (int)psgpu_mgau_n_calls(gpu->acmod->mgau), bad_calls, first_bad,
+               use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
                ra[nrep - 1].hyp, rb[nrep - 1].hyp, ra[nrep - 1].score, rb[nrep - 1].score,
-               n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name);
+               n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
+               use_search ? "true" : "false", hmm_batches, hmm_evals);
     }
     ps_free(cpu);
     ps_free(gpu);

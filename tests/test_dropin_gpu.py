@@ -19,7 +19,11 @@ MODEL = os.path.join(REF, "model", "en-us")
 DATA = os.path.join(REF, "data")
 
 
-def run(raw, nrep, *extra, lm="turtle.lm.bin", dic="turtle.dic"):
+BIN_FULL = os.path.join(REF, "dropin_decode_full")
+
+
+def run(raw, nrep, *extra, lm="turtle.lm.bin", dic="turtle.dic", binary=None):
+    BIN = binary or globals()["BIN"]
     if not os.path.exists(BIN):
         pytest.fail("oracle/_ref/dropin_decode is missing: run __graft_entry__.build() where "
                     "/root/reference is present (the built oracle/_ref travels with gpurun)")
@@ -81,6 +85,40 @@ def test_dropin_decode_identical(case, tmp_path):
     assert r["ok"] and r["rc"] == 0, r
     if raw == "goforward.raw" and "mllr_after" not in extra:
         assert r["hyp_gpu"] == "go forward ten meters"
+
+
+FULL_CASES = {
+    # name: (raw, nrep, extra) -- decoder B runs GMM scoring AND every hmm_vit_eval loop on the device
+    "default_3pass_x2": ("goforward.raw", 2, ()),
+    "fwdtree_only": ("goforward.raw", 1, ("fwdflat", "no", "bestpath", "no")),
+    "fwdflat_only": ("goforward.raw", 1, ("fwdtree", "no")),
+    "plw0": ("goforward.raw", 1, ("pl_window", "0")),
+    "search_only_cpu_gmm": ("goforward.raw", 1, ("psgpu_mgau", "no")),
+    "numbers": ("numbers.raw", 1, ()),
+    "librivox_0870": ("librivox-0870.raw", 1, ()),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(FULL_CASES))
+def test_dropin_full_decode_identical(case):
+    """GMM shim + the three hmm_vit_eval loops (fwdtree evaluate_channels,
+    fwdflat_eval_chan, phone-loop evaluate_hmms) on the device: identical
+    senone-score calls (=> identical active sets, i.e. identical search
+    trajectories), hypothesis, path score and segmentation."""
+    raw, nrep, extra = FULL_CASES[case]
+    r = run(raw, nrep, *extra, binary=BIN_FULL)
+    assert r["search_hooks"] and r["hmm_batches"] > 0 and r["hmm_evals"] > r["hmm_batches"]
+    assert r["calls_cpu"] == r["calls_gpu"] and r["mismatching_calls"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"], r
+    assert r["ok"] and r["rc"] == 0, r
+    if raw == "goforward.raw":
+        assert r["hyp_gpu"] == "go forward ten meters"
+    if case == "default_3pass_x2":
+        # decoder A of the hooked library (hooks idle) still equals the unmodified reference
+        import numpy as np
+        g = np.load(os.path.join(pso.GOLDEN_DIR, "decode_default.npz"))
+        assert r["hyp_cpu"] == bytes(g["hyp"]).decode()
 
 
 def test_attach_fails_loudly_without_gpu():
