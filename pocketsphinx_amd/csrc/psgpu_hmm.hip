@@ -287,6 +287,14 @@ __device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const
 constexpr int kHmmThreads = 256;
 constexpr int kTpLdsMax = 16384;
 
+// fold a wave's running maximum into best[utt] (one atomic per wave per flush)
+__device__ __forceinline__ void flush_best(int32_t *best_out, int utt, int32_t m)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m != kMaxNegInt32) atomicMax(&best_out[utt], m);
+}
+
 template <int NE>
 __global__ __launch_bounds__(kHmmThreads)
 void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restrict__ active,
@@ -296,59 +304,94 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
                     const uint16_t *__restrict__ sseq, int32_t *__restrict__ best_out)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tp[kTpLdsMax];
+    __shared__ int32_t s_wbest[kHmmThreads / 64], s_wutt[kHmmThreads / 64];
     const bool tp_in_lds = tp_bytes <= kTpLdsMax;
     if (tp_in_lds) {
-        for (int i = threadIdx.x; i < tp_bytes; i += kHmmThreads) s_tp[i] = tp_g[i];
+        for (int i = threadIdx.x * 4; i < tp_bytes; i += kHmmThreads * 4) {
+            if (i + 4 <= tp_bytes) *reinterpret_cast<uint32_t *>(s_tp + i) = *reinterpret_cast<const uint32_t *>(tp_g + i);
+            else for (int j = i; j < tp_bytes; ++j) s_tp[j] = tp_g[j];
+        }
         __syncthreads();
     }
-    const int i = blockIdx.x * kHmmThreads + threadIdx.x;
-    int32_t best = kMaxNegInt32;
-    int utt = 0;
-    if (i < n_active) {
-        const int idx = active ? active[i] : i;
-        utt = utt_of_hmm ? utt_of_hmm[idx] : 0;
-        // one 64-byte line in
-        const int4 *rp = reinterpret_cast<const int4 *>(recs + idx);
-        int4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-        HmmRegs h;
-        h.score[0] = q0.x; h.score[1] = q0.y; h.score[2] = q0.z; h.score[3] = q0.w;
-        h.score[4] = q1.x; h.history[0] = q1.y; h.history[1] = q1.z; h.history[2] = q1.w;
-        h.history[3] = q2.x; h.history[4] = q2.y; h.out_score = q2.z; h.out_history = q2.w;
-        h.bestscore = q3.x;
-        h.senid[0] = (uint16_t)(q3.y & 0xffff); h.senid[1] = (uint16_t)((uint32_t)q3.y >> 16);
-        h.senid[2] = (uint16_t)(q3.z & 0xffff); h.senid[3] = (uint16_t)((uint32_t)q3.z >> 16);
-        h.senid[4] = (uint16_t)(q3.w & 0xffff);
-        const uint32_t tm = (uint32_t)q3.w >> 16;
-        const bool mpx = (tm & PSGPU_HMM_MPX) != 0;
-        const uint32_t tmatid = tm & 0x7fffu;
-        const uint8_t *tp = (tp_in_lds ? s_tp : tp_g) + (size_t)tmatid * NE * (NE + 1);
-        const int16_t *ss = senscr + (size_t)utt * senscr_stride;
-        if (NE == 3)
-            best = mpx ? vit3_mpx(h, tp, ss, sseq) : vit3(h, tp, ss);
-        else
-            best = mpx ? vit5_mpx(h, tp, ss, sseq) : vit5(h, tp, ss);
-        // one 64-byte line out
-        q0 = make_int4(h.score[0], h.score[1], h.score[2], h.score[3]);
-        q1 = make_int4(h.score[4], h.history[0], h.history[1], h.history[2]);
-        q2 = make_int4(h.history[3], h.history[4], h.out_score, h.out_history);
-        q3 = make_int4(h.bestscore, (int32_t)((uint32_t)h.senid[0] | ((uint32_t)h.senid[1] << 16)),
-                       (int32_t)((uint32_t)h.senid[2] | ((uint32_t)h.senid[3] << 16)),
-                       (int32_t)((uint32_t)h.senid[4] | (tm << 16)));
-        int4 *wp = reinterpret_cast<int4 *>(recs + idx);
-        wp[0] = q0; wp[1] = q1; wp[2] = q2; wp[3] = q3;
+    // persistent blocks: the grid is sized to the machine, every lane walks
+    // the active list with a grid stride.  The running best of a wave is kept
+    // in a register together with the utterance it belongs to and flushed
+    // when the utterance changes (active lists are grouped by utterance).
+    int32_t acc = kMaxNegInt32;
+    int acc_utt = -1;
+    const int stride = gridDim.x * kHmmThreads;
+    for (int base = blockIdx.x * kHmmThreads; base < n_active; base += stride) {
+        const int i = base + threadIdx.x;
+        const bool live = i < n_active;
+        int32_t best = kMaxNegInt32;
+        int utt = 0;
+        if (live) {
+            const int idx = active ? active[i] : i;
+            // one 64-byte line in
+            const int4 *rp = reinterpret_cast<const int4 *>(recs + idx);
+            int4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            utt = utt_of_hmm ? utt_of_hmm[idx] : 0;
+            HmmRegs h;
+            h.score[0] = q0.x; h.score[1] = q0.y; h.score[2] = q0.z; h.score[3] = q0.w;
+            h.score[4] = q1.x; h.history[0] = q1.y; h.history[1] = q1.z; h.history[2] = q1.w;
+            h.history[3] = q2.x; h.history[4] = q2.y; h.out_score = q2.z; h.out_history = q2.w;
+            h.bestscore = q3.x;
+            h.senid[0] = (uint16_t)(q3.y & 0xffff); h.senid[1] = (uint16_t)((uint32_t)q3.y >> 16);
+            h.senid[2] = (uint16_t)(q3.z & 0xffff); h.senid[3] = (uint16_t)((uint32_t)q3.z >> 16);
+            h.senid[4] = (uint16_t)(q3.w & 0xffff);
+            const uint32_t tm = (uint32_t)q3.w >> 16;
+            const bool mpx = (tm & PSGPU_HMM_MPX) != 0;
+            const uint32_t tmatid = tm & 0x7fffu;
+            const uint8_t *tp = (tp_in_lds ? s_tp : tp_g) + (size_t)tmatid * NE * (NE + 1);
+            const int16_t *ss = senscr + (size_t)utt * senscr_stride;
+            if (NE == 3)
+                best = mpx ? vit3_mpx(h, tp, ss, sseq) : vit3(h, tp, ss);
+            else
+                best = mpx ? vit5_mpx(h, tp, ss, sseq) : vit5(h, tp, ss);
+            // one 64-byte line out
+            q0 = make_int4(h.score[0], h.score[1], h.score[2], h.score[3]);
+            q1 = make_int4(h.score[4], h.history[0], h.history[1], h.history[2]);
+            q2 = make_int4(h.history[3], h.history[4], h.out_score, h.out_history);
+            q3 = make_int4(h.bestscore, (int32_t)((uint32_t)h.senid[0] | ((uint32_t)h.senid[1] << 16)),
+                           (int32_t)((uint32_t)h.senid[2] | ((uint32_t)h.senid[3] << 16)),
+                           (int32_t)((uint32_t)h.senid[4] | (tm << 16)));
+            int4 *wp = reinterpret_cast<int4 *>(recs + idx);
+            wp[0] = q0; wp[1] = q1; wp[2] = q2; wp[3] = q3;
+        }
+        if (best_out) {
+            const unsigned long long lv = __ballot(live);
+            if (lv) {
+                const int first = __ffsll((long long)lv) - 1;
+                const int utt0 = __builtin_amdgcn_readlane(utt, first);
+                if (__ballot(live && utt != utt0) == 0) {       // wave-uniform utterance (the usual case)
+                    if (utt0 != acc_utt) {
+                        if (acc_utt >= 0) flush_best(best_out, acc_utt, acc);
+                        acc = kMaxNegInt32;
+                        acc_utt = utt0;
+                    }
+                    acc = max(acc, best);
+                }
+                else if (live)
+                    atomicMax(&best_out[utt], best);
+            }
+        }
     }
     if (best_out) {
-        // fold the wave's maximum into best[utt]; lanes of one wave may belong
-        // to different utterances, so reduce only when the wave is uniform
-        const int utt0 = __builtin_amdgcn_readfirstlane(utt);
-        if (__ballot(utt != utt0 && i < n_active) == 0) {
-            int32_t m = best;
+        // combine the block's waves when they agree on the utterance
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-            if ((threadIdx.x & 63) == 0 && m != kMaxNegInt32) atomicMax(&best_out[utt0], m);
+        for (int off = 32; off > 0; off >>= 1) acc = max(acc, __shfl_xor(acc, off));
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_wbest[w] = acc; s_wutt[w] = acc_utt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int a = 0; a < kHmmThreads / 64; ++a) {
+                if (s_wutt[a] < 0) continue;
+                int32_t m = s_wbest[a];
+                for (int b2 = a + 1; b2 < kHmmThreads / 64; ++b2)
+                    if (s_wutt[b2] == s_wutt[a]) { m = max(m, s_wbest[b2]); s_wutt[b2] = -1; }
+                if (m != kMaxNegInt32) atomicMax(&best_out[s_wutt[a]], m);
+            }
         }
-        else if (i < n_active)
-            atomicMax(&best_out[utt], best);
     }
 }
 
@@ -412,7 +455,9 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
     PSGPU_REQUIRE(c && recs_dev && senscr_dev, "psgpu_hmm_vit_eval_dev: NULL argument");
     PSGPU_REQUIRE(n_active >= 0, "negative n_active");
     if (n_active == 0) return PSGPU_OK;
-    const int blocks = (n_active + kHmmThreads - 1) / kHmmThreads;
+    // persistent grid: at most 8 workgroups of 4 waves per CU on 256 CUs
+    int blocks = (n_active + kHmmThreads - 1) / kHmmThreads;
+    if (blocks > 2048) blocks = 2048;
     const int32_t tpb = c->n_tmat * c->n_emit * (c->n_emit + 1);
     if (c->n_emit == 3)
         hipLaunchKernelGGL((hmm_vit_kernel<3>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
