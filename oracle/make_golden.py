@@ -38,10 +38,10 @@ RAW = os.path.join(REF, "data", "goforward.raw")
 SEED = 20260921
 
 
-def ref_dump(cmd, *args, extra=()):
+def ref_dump(cmd, *args, extra=(), model=None, lm=None, dic=None):
     with tempfile.NamedTemporaryFile(suffix=".psgb", delete=False) as fh:
         out = fh.name
-    argv = [os.path.join(REF, "ref_dump"), cmd, out, MODEL, LM, DIC] + [str(a) for a in args]
+    argv = [os.path.join(REF, "ref_dump"), cmd, out, model or MODEL, lm or LM, dic or DIC] + [str(a) for a in args]
     if extra:
         argv += ["--"] + [str(e) for e in extra]
     subprocess.check_call(argv)
@@ -99,8 +99,8 @@ def ptm_case(name, feats, seglen, carry, dup=0, full_topn=False, sample=16):
     return d
 
 
-def senlog_case(name, nrep, extra=()):
-    d = ref_dump("senlog", RAW, nrep, extra=extra)
+def senlog_case(name, nrep, extra=(), inp=None, **kw):
+    d = ref_dump("senlog", inp or RAW, nrep, extra=extra, **kw)
     n = int(d["n_calls"][0])
     idx = np.unique(np.linspace(0, n - 1, 24).astype(np.int64))
     out = {k: v for k, v in d.items() if k.startswith("utt") or k.startswith("call_")}
@@ -154,6 +154,26 @@ def main():
     hmm_only()
 
 
+TD_MODEL = os.path.join(REF, "model", "tidigits")
+TD_DATA = os.path.join(REF, "data", "tidigits")
+TD = dict(model=TD_MODEL, lm=os.path.join(TD_DATA, "tidigits.lm.bin"), dic=os.path.join(TD_DATA, "tidigits.dic"))
+
+
+def semi_only():
+    """s2_semi scorer (tidigits: 4 streams x 256 densities, 4-bit clustered mixw,
+    5-state HMMs): tables + every frame_eval call of real decodes."""
+    t = ref_dump("tables_semi", **TD)
+    np.savez_compressed(os.path.join(GOLD, "semi_tidigits_tables.npz"), **t)
+    print("semi tables:", {k: v.shape for k, v in t.items() if v.size > 1})
+    a = os.path.join(TD_DATA, "man.ah.111a.mfc")
+    b = os.path.join(TD_DATA, "woman.ak.276317oa.mfc")
+    senlog_case("tidigits_default", 2, inp=a, **TD)
+    senlog_case("tidigits_beam", 1, inp=b, extra=("topn_beam", "20,35,10,20"), **TD)
+    senlog_case("tidigits_topn6_ds2", 1, inp=a, extra=("topn", "6", "ds", "2"), **TD)
+    senlog_case("tidigits_topn7_call", 1, inp=a, extra=("topn", "7", "compallsen", "yes"), **TD)
+    senlog_case("tidigits_topn2", 1, inp=b, extra=("topn", "2", "pl_window", "0"), **TD)
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -167,5 +187,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hmm":
         os.makedirs(GOLD, exist_ok=True)
         hmm_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "semi":
+        semi_only()
     else:
         main()

@@ -335,6 +335,237 @@ pso_ptm_score_utt(pso_ptm_t *s, const float *feats, int T, int reset_hist,
 }
 
 /* ================================================================== */
+/* semi-continuous scorer (s2_semi_mgau.c)                             */
+/* ================================================================== */
+
+struct pso_semi_s {
+    int n_feat, n_density, n_sen, topn, ds_ratio, n_hist, veclen;
+    int32_t *featlen, *featoff;
+    int64_t *foff;                 /* float offset of stream f in mean/var */
+    uint8_t *beam;
+    const float *mean, *var, *det;
+    const uint8_t *mixw, *mixw_cb, *logadd8;
+    int logadd8_size;
+    pso_topn_t *hist;              /* [n_hist][n_feat][topn]  (topn_hist, s2_semi_mgau.h:83) */
+    uint8_t *hist_n;               /* [n_hist][n_feat]        (topn_hist_n, :84) */
+    int cur, frame_idx;
+};
+
+pso_semi_t *
+pso_semi_new(int n_feat, int n_density, const int32_t *featlen, int n_sen,
+             int topn, int ds_ratio, int n_hist, const uint8_t *topn_beam,
+             const float *mean, const float *var, const float *det,
+             const uint8_t *mixw, const uint8_t *mixw_cb,
+             const uint8_t *logadd8, int logadd8_size)
+{
+    pso_semi_t *s = calloc(1, sizeof(*s));
+    int f; int64_t o = 0;
+    s->n_feat = n_feat; s->n_density = n_density; s->n_sen = n_sen; s->topn = topn;
+    s->ds_ratio = ds_ratio; s->n_hist = n_hist;
+    s->featlen = malloc(sizeof(int32_t) * n_feat);
+    s->featoff = malloc(sizeof(int32_t) * n_feat);
+    s->foff = malloc(sizeof(int64_t) * n_feat);
+    s->beam = malloc(n_feat);
+    for (f = 0; f < n_feat; ++f) {
+        s->featlen[f] = featlen[f]; s->featoff[f] = s->veclen; s->veclen += featlen[f];
+        s->foff[f] = o; o += (int64_t)n_density * featlen[f];
+        s->beam[f] = topn_beam ? topn_beam[f] : 0;
+    }
+    s->mean = mean; s->var = var; s->det = det; s->mixw = mixw; s->mixw_cb = mixw_cb;
+    s->logadd8 = logadd8; s->logadd8_size = logadd8_size;
+    s->hist = malloc(sizeof(pso_topn_t) * (size_t)n_hist * n_feat * topn);
+    s->hist_n = malloc((size_t)n_hist * n_feat);
+    pso_semi_reset_hist(s);
+    return s;
+}
+
+void
+pso_semi_free(pso_semi_t *s)
+{
+    if (!s) return;
+    free(s->featlen); free(s->featoff); free(s->foff); free(s->beam);
+    free(s->hist); free(s->hist_n); free(s);
+}
+
+/* s2_semi_mgau.c:1305-1322: topn_hist_n comes from ckd_calloc_2d (zeros),
+ * every list is codeword k / WORST_DIST */
+void
+pso_semi_reset_hist(pso_semi_t *s)
+{
+    size_t i, n = (size_t)s->n_hist * s->n_feat * s->topn;
+    for (i = 0; i < n; ++i) {
+        s->hist[i].cw = (int32_t)(i % s->topn);
+        s->hist[i].score = PSO_WORST_DIST;
+    }
+    memset(s->hist_n, 0, (size_t)s->n_hist * s->n_feat);
+    s->cur = 0;
+}
+
+void pso_semi_set_frame_idx(pso_semi_t *s, int v) { s->frame_idx = v; }
+
+const pso_topn_t *
+pso_semi_cur_topn(const pso_semi_t *s, uint8_t *n_used)
+{
+    if (n_used) memcpy(n_used, s->hist_n + (size_t)s->cur * s->n_feat, s->n_feat);
+    return s->hist + (size_t)s->cur * s->n_feat * s->topn;
+}
+
+static int
+semi_logadd8(const pso_semi_t *s, int x, int y)
+{
+    int d, r;
+    if (x > y) { d = x - y; r = y; } else { d = y - x; r = x; }
+    return r - ((d >= 0 && d < s->logadd8_size) ? s->logadd8[d] : 0);
+}
+
+/* eval_topn (s2_semi_mgau.c:69-109): same as the PTM one */
+static void
+semi_rescore(const pso_semi_t *s, pso_topn_t *tl, int f, const float *x)
+{
+    int len = s->featlen[f], i;
+    const float *mean = s->mean + s->foff[f], *var = s->var + s->foff[f];
+    const float *det = s->det + (size_t)f * s->n_density;
+    for (i = 0; i < s->topn; ++i) {
+        int cw = tl[i].cw, j;
+        float d = gau_dist(det[cw], x, mean + (int64_t)cw * len, var + (int64_t)cw * len, len);
+        pso_topn_t e;
+        e.cw = cw; e.score = dist_to_int(d);
+        for (j = i - 1; j >= 0 && e.score > tl[j].score; --j)
+            tl[j + 1] = tl[j];
+        tl[j + 1] = e;
+    }
+}
+
+/* eval_cb (s2_semi_mgau.c:111-170).  Unlike the PTM scan, the acceptance test
+ * is NOT a function of the finished distance alone: the float test
+ * `d >= worst->score` guards every dimension but is not applied to the
+ * finished sum (the loop ends on j == ceplen), which is then compared as a
+ * TRUNCATED int (`d_int < worst->score`).  Since every term is >= 0 the
+ * partial sums fall monotonically, so "all guards passed" is "the partial sum
+ * before the last dimension passed". */
+static void
+semi_scan(const pso_semi_t *s, pso_topn_t *tl, int f, const float *x)
+{
+    int len = s->featlen[f], N = s->topn, cw;
+    const float *mean = s->mean + s->foff[f], *var = s->var + s->foff[f];
+    const float *det = s->det + (size_t)f * s->n_density;
+    for (cw = 0; cw < s->n_density; ++cw) {
+        const float *m = mean + (int64_t)cw * len, *v = var + (int64_t)cw * len;
+        float worst = (float)tl[N - 1].score;   /* int -> float for the comparison */
+        float d = det[cw];
+        int j, i, p;
+        int32_t di;
+        for (j = 0; j < len && d >= worst; ++j) {
+            float diff = x[j] - m[j];
+            float sq = diff * diff;
+            float c = sq * v[j];
+            d = d - c;
+        }
+        if (j < len)
+            continue;
+        di = dist_to_int(d);
+        if (di < tl[N - 1].score)
+            continue;
+        for (i = 0; i < N; ++i)
+            if (tl[i].cw == cw) break;
+        if (i < N)
+            continue;
+        for (p = N - 1; p > 0 && di >= tl[p - 1].score; --p)
+            tl[p] = tl[p - 1];
+        tl[p].cw = cw; tl[p].score = di;
+    }
+}
+
+/* mgau_norm (s2_semi_mgau.c:185-203): entries past the beam cut stay raw */
+static int
+semi_norm(const pso_semi_t *s, pso_topn_t *tl, int f)
+{
+    int32_t norm = tl[0].score >> PSO_SENSCR_SHIFT;
+    int j;
+    for (j = 0; j < s->topn; ++j) {
+        tl[j].score = -((tl[j].score >> PSO_SENSCR_SHIFT) - norm);
+        if (tl[j].score > PSO_MAX_NEG_ASCR) tl[j].score = PSO_MAX_NEG_ASCR;
+        if (s->beam[f] && tl[j].score > s->beam[f]) break;
+    }
+    return j;
+}
+
+int
+pso_semi_frame_eval(pso_semi_t *s, int16_t *senscr,
+                    const uint8_t *senone_active, int32_t n_senone_active,
+                    const float *feat, int32_t frame, int32_t compallsen)
+{
+    int slot = frame % s->n_hist, f, evaluated = 0;   /* :849-850 */
+    pso_topn_t *cur = s->hist + (size_t)slot * s->n_feat * s->topn;
+    uint8_t *cur_n = s->hist_n + (size_t)slot * s->n_feat;
+    size_t row4 = (size_t)(s->n_sen + 1) / 2;
+
+    memset(senscr, 0, sizeof(int16_t) * s->n_sen);     /* :846 */
+    s->cur = slot;
+    for (f = 0; f < s->n_feat; ++f) {
+        pso_topn_t *tl = cur + (size_t)f * s->topn;
+        int n, i, k, l;
+        if (frame >= s->frame_idx) {                   /* :853-862 */
+            int prev = (slot == 0) ? s->n_hist - 1 : slot - 1;
+            evaluated = 1;
+            memcpy(tl, s->hist + ((size_t)prev * s->n_feat + f) * s->topn, sizeof(pso_topn_t) * s->topn);
+            semi_rescore(s, tl, f, feat + s->featoff[f]);
+            if (frame % s->ds_ratio == 0)              /* mgau_dist :172-183 */
+                semi_scan(s, tl, f, feat + s->featoff[f]);
+            cur_n[f] = (uint8_t)semi_norm(s, tl, f);
+        }
+        n = cur_n[f];
+        if (compallsen) {
+            /* get_scores_{8b,4b}_feat_all (:431-444, :792-831): int arithmetic */
+            int last = s->mixw_cb ? (s->n_sen & ~1) : s->n_sen;
+            for (i = 0; i < last; ++i) {
+                int tmp = 0;
+                for (k = 0; k < n || k == 0; ++k) {
+                    int w;
+                    if (s->mixw_cb) {
+                        int b = s->mixw[((size_t)f * s->n_density + tl[k].cw) * row4 + i / 2];
+                        w = s->mixw_cb[(i & 1) ? (b >> 4) : (b & 0x0f)];
+                    }
+                    else
+                        w = s->mixw[((size_t)f * s->n_density + tl[k].cw) * s->n_sen + i];
+                    tmp = (k == 0) ? w + tl[k].score : semi_logadd8(s, tmp, w + tl[k].score);
+                    if (n == 0) break;
+                }
+                senscr[i] = (int16_t)(senscr[i] + tmp);
+            }
+        }
+        else {
+            /* get_scores_8b_feat_N / _any (:205-394), get_scores_4b_feat_N / _any
+             * (:446-790).  The unrolled 4-bit kernels (N = 1..6) precompute
+             * w_den as uint8, i.e. mixw_cb + score wraps mod 256; _any and the
+             * 8-bit kernels add in int.  N = 0 cannot happen after mgau_norm;
+             * a never-evaluated slot (count 0) scores like the `_any` loop
+             * with zero iterations: first codeword only. */
+            int wrap = (s->mixw_cb != NULL) && n >= 1 && n <= 6;
+            for (l = i = 0; i < n_senone_active; ++i) {
+                int sen = senone_active[i] + l, tmp = 0;
+                for (k = 0; k < n || k == 0; ++k) {
+                    int w, y;
+                    if (s->mixw_cb) {
+                        int b = s->mixw[((size_t)f * s->n_density + tl[k].cw) * row4 + sen / 2];
+                        w = s->mixw_cb[(sen & 1) ? (b >> 4) : (b & 0x0f)];
+                    }
+                    else
+                        w = s->mixw[((size_t)f * s->n_density + tl[k].cw) * s->n_sen + sen];
+                    y = w + tl[k].score;
+                    if (wrap) y &= 0xff;
+                    tmp = (k == 0) ? y : semi_logadd8(s, tmp, y);
+                    if (n == 0) break;
+                }
+                senscr[sen] = (int16_t)(senscr[sen] + tmp);
+                l = sen;
+            }
+        }
+    }
+    return evaluated;
+}
+
+/* ================================================================== */
 /* acmod_flags2list (acmod.c:1223-1275)                                */
 /* ================================================================== */
 int

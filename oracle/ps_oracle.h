@@ -82,6 +82,31 @@ const pso_topn_t *pso_ptm_cur_topn(const pso_ptm_t *s);
 void pso_ptm_score_utt(pso_ptm_t *s, const float *feats, int T, int reset_hist,
                        int16_t *senscr, uint8_t *topn_cw, int32_t *topn_raw);
 
+/* ---------------- semi-continuous scorer (s2_semi_mgau.c) ---------------- */
+
+typedef struct pso_semi_s pso_semi_t;
+
+/* One shared codebook, n_feat streams.
+ *  mean/var : packed [n_feat][n_density][featlen[f]]
+ *  det      : [n_feat][n_density]
+ *  mixw     : [n_feat][n_density][n_sen] (8-bit) or [..][(n_sen+1)/2] with a
+ *             16-entry mixw_cb (4-bit clustered)            (s2_semi_mgau.c:885-1080)
+ *  topn_beam: [n_feat] per-stream beam, 0 = none             (:1296-1299) */
+pso_semi_t *pso_semi_new(int n_feat, int n_density, const int32_t *featlen, int n_sen,
+                         int topn, int ds_ratio, int n_hist, const uint8_t *topn_beam,
+                         const float *mean, const float *var, const float *det,
+                         const uint8_t *mixw, const uint8_t *mixw_cb,
+                         const uint8_t *logadd8, int logadd8_size);
+void pso_semi_free(pso_semi_t *s);
+void pso_semi_reset_hist(pso_semi_t *s);             /* state after s2_semi_mgau_init (:1311-1322) */
+void pso_semi_set_frame_idx(pso_semi_t *s, int frame_idx);
+/* s2_semi_mgau_frame_eval (s2_semi_mgau.c:836-883) */
+int pso_semi_frame_eval(pso_semi_t *s, int16_t *senscr,
+                        const uint8_t *senone_active, int32_t n_senone_active,
+                        const float *feat, int32_t frame, int32_t compallsen);
+/* current slot: lists [n_feat][topn] and the per-stream counts topn_hist_n */
+const pso_topn_t *pso_semi_cur_topn(const pso_semi_t *s, uint8_t *n_used);
+
 /* ---------------- shared helpers ---------------- */
 
 /* acmod_flags2list (acmod.c:1223-1275): bit flags -> uint8 delta list.

@@ -127,6 +127,49 @@ read_pcm(const char *path, size_t *n)
 }
 
 /* ------------------------------------------------------------------ */
+/* one utterance through the public API: raw PCM (ps_process_raw) or, for a
+ * path ending in .mfc, Sphinx cepstra (ps_process_cep) as pocketsphinx_batch
+ * does for its -cepdir inputs (programs/pocketsphinx_batch.c:195-250,478-488) */
+static void
+run_utt(ps_decoder_t *ps, const char *path)
+{
+    size_t len = strlen(path);
+    if (len > 4 && strcmp(path + len - 4, ".mfc") == 0) {
+        int ceplen = ps_config_int(ps_get_config(ps), "ceplen");
+        FILE *fp = fopen(path, "rb");
+        long flen; int32 nmfc; int nfr, i, swap = 0;
+        float32 **mfcs;
+        if (!fp) { perror(path); exit(2); }
+        fseek(fp, 0, SEEK_END); flen = ftell(fp); fseek(fp, 0, SEEK_SET);
+        if (fread(&nmfc, 4, 1, fp) != 1) { perror("mfc"); exit(2); }
+        if (nmfc != flen / 4 - 1) {
+            nmfc = (int32)__builtin_bswap32((uint32_t)nmfc); swap = 1;
+            if (nmfc != flen / 4 - 1) { fprintf(stderr, "%s: not an MFCC file\n", path); exit(2); }
+        }
+        nfr = nmfc / ceplen;
+        mfcs = (float32 **)ckd_calloc_2d(nfr, ceplen, sizeof(float32));
+        if (fread(mfcs[0], 4, (size_t)nfr * ceplen, fp) != (size_t)nfr * ceplen) { perror("mfc"); exit(2); }
+        fclose(fp);
+        if (swap)
+            for (i = 0; i < nfr * ceplen; ++i) {
+                uint32_t *u = (uint32_t *)&mfcs[0][i];
+                *u = __builtin_bswap32(*u);
+            }
+        ps_start_utt(ps);
+        ps_process_cep(ps, mfcs, nfr, FALSE, TRUE);
+        ps_end_utt(ps);
+        ckd_free_2d(mfcs);
+    }
+    else {
+        size_t n; int16 *pcm = read_pcm(path, &n);
+        ps_start_utt(ps);
+        ps_process_raw(ps, pcm, n, FALSE, TRUE);
+        ps_end_utt(ps);
+        free(pcm);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 static int
 cmd_tables(ps_decoder_t *ps)
 {
@@ -219,6 +262,58 @@ cmd_tables(ps_decoder_t *ps)
         puti("n_ciphone", bin_mdef_n_ciphone(mdef));
         puti("n_ci_sen", mdef->n_ci_sen);
         free(sseq);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* model tables of the semi-continuous scorer as s2_semi_mgau_init left them */
+static int
+cmd_tables_semi(ps_decoder_t *ps)
+{
+    acmod_t *acmod = ps->acmod;
+    s2_semi_mgau_t *s = (s2_semi_mgau_t *)acmod->mgau;
+    gauden_t *g;
+    int32_t f, d;
+    int64_t tot = 0, o = 0, od = 0;
+    float *mean, *var, *det;
+
+    if (strcmp(acmod->mgau->vt->name, "s2_semi") != 0) {
+        fprintf(stderr, "not an s2_semi model (%s)\n", acmod->mgau->vt->name); return 2;
+    }
+    g = s->g;
+    puti("n_mgau", g->n_mgau); puti("n_feat", g->n_feat); puti("n_density", g->n_density);
+    put1("featlen", 'i', g->n_feat, g->featlen);
+    puti("n_sen", s->n_sen); puti("max_topn", s->max_topn); puti("ds_ratio", s->ds_ratio);
+    puti("n_fast_hist", s->n_topn_hist);
+    put1("topn_beam", 'B', g->n_feat, s->topn_beam);
+    for (f = 0; f < g->n_feat; ++f) tot += g->featlen[f];
+    mean = malloc(sizeof(float) * g->n_density * tot);
+    var = malloc(sizeof(float) * g->n_density * tot);
+    det = malloc(sizeof(float) * g->n_feat * g->n_density);
+    for (f = 0; f < g->n_feat; ++f)
+        for (d = 0; d < g->n_density; ++d) {
+            memcpy(mean + o, g->mean[0][f][d], sizeof(float) * g->featlen[f]);
+            memcpy(var + o, g->var[0][f][d], sizeof(float) * g->featlen[f]);
+            o += g->featlen[f];
+            det[od++] = g->det[0][f][d];
+        }
+    put1("mean", 'f', o, mean); put1("var", 'f', o, var);
+    put2("det", 'f', g->n_feat, g->n_density, det);
+    free(mean); free(var); free(det);
+    {
+        int64_t rowlen = s->mixw_cb ? (s->n_sen + 1) / 2 : s->n_sen;
+        uint8 *mixw = malloc((size_t)g->n_feat * g->n_density * rowlen);
+        for (f = 0; f < g->n_feat; ++f)
+            for (d = 0; d < g->n_density; ++d)
+                memcpy(mixw + ((size_t)f * g->n_density + d) * rowlen, s->mixw[f][d], rowlen);
+        put3("mixw", 'B', g->n_feat, g->n_density, rowlen, mixw);
+        if (s->mixw_cb) put1("mixw_cb", 'B', 16, s->mixw_cb);
+        free(mixw);
+    }
+    {
+        logadd_t *t = LOGMATH_TABLE(s->lmath_8b);
+        put1("logadd8", 'B', t->table_size, t->table);
     }
     return 0;
 }
@@ -432,7 +527,6 @@ dump_hyp(ps_decoder_t *ps, const char *prefix)
 static int
 cmd_senlog(ps_decoder_t *ps, const char *rawpath, int nrep)
 {
-    size_t n; int16 *pcm = read_pcm(rawpath, &n);
     int r;
     rec_nsen = bin_mdef_n_sen(ps->acmod->mdef);
     rec_dim = feat_dimension(ps->acmod->fcb);
@@ -442,9 +536,7 @@ cmd_senlog(ps_decoder_t *ps, const char *rawpath, int nrep)
     ps->acmod->mgau->vt = &rec_funcs;
     for (r = 0; r < nrep; ++r) {
         char pfx[32];
-        ps_start_utt(ps);
-        ps_process_raw(ps, pcm, n, FALSE, TRUE);
-        ps_end_utt(ps);
+        run_utt(ps, rawpath);
         snprintf(pfx, sizeof pfx, "utt%d_", r);
         dump_hyp(ps, pfx);
     }
@@ -457,20 +549,15 @@ cmd_senlog(ps_decoder_t *ps, const char *rawpath, int nrep)
     put1("call_act", 'B', (int64_t)rec_act_n, rec_act ? rec_act : (uint8 *)"");
     put2("call_scr", 'h', rec_n, rec_nsen, rec_scr);
     put2("call_feat", 'f', rec_n, rec_dim, rec_feat);
-    free(pcm);
     return 0;
 }
 
 static int
 cmd_decode(ps_decoder_t *ps, const char *rawpath)
 {
-    size_t n; int16 *pcm = read_pcm(rawpath, &n);
-    ps_start_utt(ps);
-    ps_process_raw(ps, pcm, n, FALSE, TRUE);
-    ps_end_utt(ps);
+    run_utt(ps, rawpath);
     dump_hyp(ps, "");
     puti("n_frames", ps_get_n_frames(ps));
-    free(pcm);
     return 0;
 }
 
@@ -581,7 +668,9 @@ main(int argc, char **argv)
         if (strcmp(argv[i], "--") == 0) { xa = i; extra = argv + i + 1; nextra = argc - i - 1; break; }
     err_set_loglevel(ERR_ERROR);
     psgb_open(out);
-    if (!strcmp(cmd, "tables")) {
+    if (!strcmp(cmd, "tables_semi")) {
+        rc = cmd_tables_semi(make_decoder(modeldir, lm, dict, nextra, extra));
+    } else if (!strcmp(cmd, "tables")) {
         rc = cmd_tables(make_decoder(modeldir, lm, dict, nextra, extra));
     } else if (!strcmp(cmd, "feats") && xa > 6) {
         rc = cmd_feats(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);

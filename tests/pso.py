@@ -194,3 +194,66 @@ def hmm_step_oracle(g, t):
             a[s] = h.score[s]; a[5 + s] = h.history[s]; a[12 + s] = h.senid[s]
         a[10] = h.out_score; a[11] = h.out_history; a[17] = h.bestscore; a[18] = h.tmatid
     return after, ret
+
+
+class OracleSemi:
+    """Stateful wrapper around pso_semi_t (restates s2_semi_mgau.c)."""
+
+    def __init__(self, t, topn=None, ds_ratio=None, topn_beam=None):
+        L = lib()
+        vp, i32 = C.c_void_p, C.c_int32
+        L.pso_semi_new.restype = vp
+        L.pso_semi_new.argtypes = [i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]
+        L.pso_semi_free.argtypes = [vp]
+        L.pso_semi_reset_hist.argtypes = [vp]
+        L.pso_semi_set_frame_idx.argtypes = [vp, i32]
+        L.pso_semi_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32]
+        L.pso_semi_cur_topn.argtypes = [vp, vp]
+        L.pso_semi_cur_topn.restype = vp
+        self.n_feat = int(t["n_feat"][0]); self.n_density = int(t["n_density"][0])
+        self.n_sen = int(t["n_sen"][0])
+        self.topn = int(topn if topn is not None else t["max_topn"][0])
+        self.ds = int(ds_ratio if ds_ratio is not None else t["ds_ratio"][0])
+        self.n_hist = int(t["n_fast_hist"][0])
+        self.veclen = int(t["featlen"].sum())
+        beam = np.asarray(topn_beam if topn_beam is not None else t["topn_beam"], np.uint8)
+        self._keep = dict(
+            featlen=np.ascontiguousarray(t["featlen"], np.int32), beam=np.ascontiguousarray(beam),
+            mean=np.ascontiguousarray(t["mean"], np.float32), var=np.ascontiguousarray(t["var"], np.float32),
+            det=np.ascontiguousarray(t["det"], np.float32), mixw=np.ascontiguousarray(t["mixw"], np.uint8),
+            mixw_cb=(np.ascontiguousarray(t["mixw_cb"], np.uint8) if "mixw_cb" in t else None),
+            logadd8=np.ascontiguousarray(t["logadd8"], np.uint8))
+        k = self._keep
+        self.h = L.pso_semi_new(self.n_feat, self.n_density, _p(k["featlen"]), self.n_sen, self.topn,
+                                self.ds, self.n_hist, _p(k["beam"]), _p(k["mean"]), _p(k["var"]),
+                                _p(k["det"]), _p(k["mixw"]), _p(k["mixw_cb"]), _p(k["logadd8"]),
+                                int(k["logadd8"].size))
+
+    def __del__(self):
+        try:
+            lib().pso_semi_free(self.h)
+        except Exception:
+            pass
+
+    def set_frame_idx(self, v):
+        lib().pso_semi_set_frame_idx(self.h, int(v))
+
+    def frame_eval(self, feat, frame, active=None, compallsen=True):
+        feat = np.ascontiguousarray(feat, np.float32)
+        scr = np.empty(self.n_sen, np.int16)
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        lib().pso_semi_frame_eval(self.h, _p(scr), _p(act), 0 if act is None else act.size,
+                                  _p(feat), int(frame), int(bool(compallsen)))
+        return scr
+
+    def cur_topn(self):
+        n = np.empty(self.n_feat, np.uint8)
+        p = lib().pso_semi_cur_topn(self.h, _p(n))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(self.n_feat * self.topn * 2,)).copy()
+        return a.reshape(self.n_feat, self.topn, 2), n
+
+
+def senlog_params(g):
+    """topn / ds / topn_beam / ... overrides a senlog fixture was recorded with."""
+    e = [str(x) for x in g["extra"]]
+    return dict(zip(e[0::2], e[1::2]))

@@ -129,3 +129,37 @@ def test_hmm_oracle_matches_reference(case):
         bad = np.nonzero((after != g["after"][t]).any(axis=1) | (ret != g["ret"][t]))[0]
         assert bad.size == 0, "step %d: first mismatching HMM %d (mpx %d)\nbefore %s\nref    %s\noracle %s" % (
             t, bad[0], g["mpx"][bad[0]], g["before"][t][bad[0]], g["after"][t][bad[0]], after[bad[0]])
+
+
+SEMI_CASES = ["tidigits_default", "tidigits_beam", "tidigits_topn6_ds2", "tidigits_topn7_call", "tidigits_topn2"]
+
+
+def semi_oracle_for(g, t):
+    p = pso.senlog_params(g)
+    beam = None
+    if "topn_beam" in p:
+        b = [int(x) for x in p["topn_beam"].split(",")]
+        beam = (b + [max(b)] * 4)[:int(t["n_feat"][0])]
+    return pso.OracleSemi(t, topn=int(p["topn"]) if "topn" in p else None,
+                          ds_ratio=int(p["ds"]) if "ds" in p else None, topn_beam=beam)
+
+
+@pytest.mark.parametrize("case", SEMI_CASES)
+def test_semi_senlog_replay(case):
+    """pso_semi_frame_eval vs every s2_semi_mgau_frame_eval call of real tidigits
+    decodes (4 streams x 256 densities, 4-bit clustered weights): default, per-stream
+    top-N beams, topn 6 + ds 2, topn 7 (the `_any` kernels) with compallsen, topn 2."""
+    g = _load("senlog_%s.npz" % case)
+    t = _load("semi_tidigits_tables.npz")
+    o = semi_oracle_for(g, t)
+    off = g["call_act_off"]
+    n = int(g["call_frame"].size)
+    hashes = np.empty(n, np.uint64)
+    for c in range(n):
+        na = int(g["call_nact"][c])
+        o.set_frame_idx(int(g["call_frame_idx"][c]))
+        act = None if na < 0 else g["call_act"][off[c]:off[c] + na]
+        scr = o.frame_eval(g["call_feat"][c], int(g["call_frame"][c]), active=act, compallsen=(na < 0))
+        hashes[c] = pso.row_hash(scr[None, :])[0]
+    bad = np.nonzero(hashes != g["call_scr_hash"])[0]
+    assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
