@@ -185,6 +185,42 @@ int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, in
 int psgpu_ptm_state_set_topn(psgpu_ptm_state_t *s, int32_t slot, const int32_t *cw,
                              const int32_t *score, const uint8_t *mgau_active);
 
+/* ---- semi-continuous scorer ("s2_semi") -------------------------------------
+ * Replaces s2_semi_mgau_frame_eval() (s2_semi_mgau.c:836-883) with the same
+ * call contract as psgpu_ptm_frame_eval above.  Model tables as
+ * s2_semi_mgau_init() holds them (:1235-1332):
+ *   mean/var  packed [n_feat][n_density][featlen[f]] floats (one shared
+ *             codebook, var precomputed by gauden_dist_precompute)
+ *   det       [n_feat][n_density]
+ *   mixw      [n_feat][n_density][n_sen] uint8, or, when mixw_cb != NULL,
+ *             4-bit clustered: [n_feat][n_density][(n_sen+1)/2] nibbles indexing
+ *             the 16-entry mixw_cb (read_sendump, :885-1080)
+ *   topn_beam [n_feat] per-stream top-N beam, 0 = none (:1296-1299), or NULL
+ * State = the ring topn_hist[n_topn_hist] / topn_hist_n (s2_semi_mgau.h:83-86). */
+typedef struct psgpu_semi_model_s psgpu_semi_model_t;
+typedef struct psgpu_semi_state_s psgpu_semi_state_t;
+
+int psgpu_semi_model_create(psgpu_semi_model_t **out, int32_t n_feat, int32_t n_density,
+                            const int32_t *featlen, int32_t n_sen, int32_t topn, int32_t ds_ratio,
+                            const uint8_t *topn_beam,
+                            const float *mean, const float *var, const float *det,
+                            const uint8_t *mixw, const uint8_t *mixw_cb,
+                            const uint8_t *logadd8, int32_t logadd8_size);
+void psgpu_semi_model_free(psgpu_semi_model_t *m);
+int psgpu_semi_state_create(psgpu_semi_state_t **out, psgpu_semi_model_t *m, int32_t n_topn_hist);
+void psgpu_semi_state_free(psgpu_semi_state_t *s);
+int psgpu_semi_state_reset(psgpu_semi_state_t *s);
+int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
+                          const uint8_t *senone_active, int32_t n_senone_active,
+                          const float *feat, int32_t frame, int32_t frame_idx,
+                          int32_t compallsen);
+/* one slot of the ring: cw/score [n_feat][topn] int32, n_used [n_feat] int32
+ * (topn_hist_n); slot -1 = the slot of the last call */
+int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, int32_t *score,
+                              int32_t *n_used);
+int psgpu_semi_state_set_topn(psgpu_semi_state_t *s, int32_t slot, const int32_t *cw,
+                              const int32_t *score, const int32_t *n_used);
+
 /* ---- HMM Viterbi step ----------------------------------------------------
  * Replaces hmm_vit_eval() (hmm.c:786-805) and its hard-wired variants
  * hmm_vit_eval_3st_lr[_mpx] (:529-707) / _5st_lr[_mpx] (:222-525) for whole

@@ -26,17 +26,27 @@
 #include "pocketsphinx_internal.h"
 #include "acmod.h"
 #include "ptm_mgau.h"
+#include "s2_semi_mgau.h"
 #include "ms_gauden.h"
 #include "tied_mgau_common.h"
 
 #include "psgpu.h"
 #include "psgpu_mgau_shim.h"
 
+/* vqFeature_t is private to s2_semi_mgau.c (:64-67); same two int32 fields */
+struct vqFeature_s {
+    int32 score;
+    int32 codeword;
+};
+
 typedef struct psgpu_mgau_s {
     ps_mgau_t base;               /* vt + frame_idx: MUST be first (acmod.h:113-116) */
-    ptm_mgau_t *cpu;              /* the reference scorer this one replaces */
+    ptm_mgau_t *cpu;              /* the reference scorer this one replaces ("ptm") ... */
+    s2_semi_mgau_t *cpu_semi;     /* ... or ("s2_semi") */
     psgpu_ptm_model_t *model;
     psgpu_ptm_state_t *state;
+    psgpu_semi_model_t *smodel;
+    psgpu_semi_state_t *sstate;
     float *vec;                   /* one frame, streams concatenated */
     int n_feat;
     int veclen;
@@ -54,6 +64,19 @@ static ps_mgaufuncs_t psgpu_mgau_funcs = {
     shim_frame_eval,
     shim_transform,
     shim_free
+};
+
+static int semi_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
+                           int32 n_senone_active, mfcc_t **feat, int32 frame,
+                           int32 compallsen);
+static int semi_transform(ps_mgau_t *ps, ps_mllr_t *mllr);
+static void semi_free(ps_mgau_t *ps);
+
+static ps_mgaufuncs_t psgpu_semi_funcs = {
+    "s2_semi-psgpu",
+    semi_frame_eval,
+    semi_transform,
+    semi_free
 };
 
 /* Upload the tables ptm_mgau_init() built (ptm_mgau.c:804-896). */
@@ -127,6 +150,164 @@ import_history(psgpu_mgau_t *g)
     return rc;
 }
 
+/* ---- "s2_semi": tables of s2_semi_mgau_init() (s2_semi_mgau.c:1235-1332) ---- */
+static int
+semi_upload_model(psgpu_mgau_t *g)
+{
+    s2_semi_mgau_t *s = g->cpu_semi;
+    gauden_t *gd = s->g;
+    logadd_t *la = LOGMATH_TABLE(s->lmath_8b);
+    size_t rowlen = s->mixw_cb ? (size_t)(s->n_sen + 1) / 2 : (size_t)s->n_sen;
+    size_t rows = (size_t)gd->n_feat * gd->n_density, r, tot = 0, o = 0;
+    uint8 *mixw;
+    float *mean, *var, *det;
+    int f, d, rc;
+
+    for (f = 0; f < gd->n_feat; ++f)
+        tot += (size_t)gd->featlen[f] * gd->n_density;
+    mean = ckd_calloc(tot, sizeof(float));
+    var = ckd_calloc(tot, sizeof(float));
+    det = ckd_calloc(rows, sizeof(float));
+    mixw = ckd_malloc(rows * rowlen);
+    for (r = 0, f = 0; f < gd->n_feat; ++f)
+        for (d = 0; d < gd->n_density; ++d, ++r) {
+            memcpy(mean + o, gd->mean[0][f][d], sizeof(float) * gd->featlen[f]);
+            memcpy(var + o, gd->var[0][f][d], sizeof(float) * gd->featlen[f]);
+            o += gd->featlen[f];
+            det[r] = gd->det[0][f][d];
+            memcpy(mixw + r * rowlen, s->mixw[f][d], rowlen);
+        }
+    if (g->smodel)
+        psgpu_semi_model_free(g->smodel);
+    g->smodel = NULL;
+    rc = psgpu_semi_model_create(&g->smodel, gd->n_feat, gd->n_density, gd->featlen, s->n_sen,
+                                 s->max_topn, s->ds_ratio, s->topn_beam, mean, var, det, mixw,
+                                 s->mixw_cb, (const uint8_t *)la->table, (int32_t)la->table_size);
+    ckd_free(mean); ckd_free(var); ckd_free(det); ckd_free(mixw);
+    if (rc != PSGPU_OK) {
+        E_ERROR("psgpu_semi_model_create failed (%d): %s\n", rc, psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+/* topn_hist / topn_hist_n (s2_semi_mgau.h:83-84) <-> device ring */
+static int
+semi_sync_history(psgpu_mgau_t *g, int to_device)
+{
+    s2_semi_mgau_t *s = g->cpu_semi;
+    int nf = s->g->n_feat, N = s->max_topn, slot, f, k, rc = 0;
+    int32 *cw = ckd_calloc((size_t)nf * N, sizeof(int32));
+    int32 *sc = ckd_calloc((size_t)nf * N, sizeof(int32));
+    int32 *nu = ckd_calloc(nf, sizeof(int32));
+
+    for (slot = 0; slot < s->n_topn_hist && rc == 0; ++slot) {
+        if (!to_device && psgpu_semi_state_get_topn(g->sstate, slot, cw, sc, nu) != PSGPU_OK)
+            rc = -1;
+        for (f = 0; f < nf && rc == 0; ++f) {
+            for (k = 0; k < N; ++k) {
+                if (to_device) {
+                    cw[f * N + k] = s->topn_hist[slot][f][k].codeword;
+                    sc[f * N + k] = s->topn_hist[slot][f][k].score;
+                }
+                else {
+                    s->topn_hist[slot][f][k].codeword = cw[f * N + k];
+                    s->topn_hist[slot][f][k].score = sc[f * N + k];
+                }
+            }
+            if (to_device) nu[f] = s->topn_hist_n[slot][f];
+            else s->topn_hist_n[slot][f] = (uint8)nu[f];
+        }
+        if (to_device && psgpu_semi_state_set_topn(g->sstate, slot, cw, sc, nu) != PSGPU_OK)
+            rc = -1;
+    }
+    if (rc < 0)
+        E_ERROR("psgpu semi history transfer failed: %s\n", psgpu_last_error());
+    ckd_free(cw); ckd_free(sc); ckd_free(nu);
+    return rc;
+}
+
+static ps_mgau_t *
+semi_wrap(ps_mgau_t *cpu_mgau)
+{
+    psgpu_mgau_t *g = ckd_calloc(1, sizeof(*g));
+    s2_semi_mgau_t *s = (s2_semi_mgau_t *)cpu_mgau;
+    int f;
+
+    g->base.vt = &psgpu_semi_funcs;
+    g->base.frame_idx = cpu_mgau->frame_idx;
+    g->cpu_semi = s;
+    g->n_feat = s->g->n_feat;
+    for (f = 0; f < g->n_feat; ++f)
+        g->veclen += s->g->featlen[f];
+    g->vec = ckd_calloc(g->veclen, sizeof(float));
+    if (semi_upload_model(g) < 0
+        || psgpu_semi_state_create(&g->sstate, g->smodel, s->n_topn_hist) != PSGPU_OK
+        || semi_sync_history(g, 1) < 0) {
+        if (g->smodel && !g->sstate)
+            E_ERROR("psgpu_semi_state_create failed: %s\n", psgpu_last_error());
+        if (g->sstate) psgpu_semi_state_free(g->sstate);
+        if (g->smodel) psgpu_semi_model_free(g->smodel);
+        ckd_free(g->vec);
+        ckd_free(g);
+        return NULL;
+    }
+    return (ps_mgau_t *)g;
+}
+
+static int
+semi_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
+                int32 n_senone_active, mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    gauden_t *gd = g->cpu_semi->g;
+    int f, o = 0, rc;
+
+    for (f = 0; f < g->n_feat; ++f) {
+        memcpy(g->vec + o, feat[f], sizeof(float) * gd->featlen[f]);
+        o += gd->featlen[f];
+    }
+    rc = psgpu_semi_frame_eval(g->sstate, senscr, senone_active, n_senone_active, g->vec,
+                               frame, ps->frame_idx, compallsen);
+    ++g->n_calls;
+    if (rc != PSGPU_OK) {
+        E_ERROR("psgpu_semi_frame_eval(frame %d) failed (%d): %s\n", frame, rc, psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+static int
+semi_transform(ps_mgau_t *ps, ps_mllr_t *mllr)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    int rc = ps_mgau_transform(ps_mgau_base(g->cpu_semi), mllr);
+    if (rc < 0)
+        return rc;
+    if (semi_sync_history(g, 0) < 0)
+        return -1;
+    psgpu_semi_state_free(g->sstate);
+    g->sstate = NULL;
+    if (semi_upload_model(g) < 0)
+        return -1;
+    if (psgpu_semi_state_create(&g->sstate, g->smodel, g->cpu_semi->n_topn_hist) != PSGPU_OK) {
+        E_ERROR("psgpu_semi_state_create failed: %s\n", psgpu_last_error());
+        return -1;
+    }
+    return semi_sync_history(g, 1);
+}
+
+static void
+semi_free(ps_mgau_t *ps)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    if (g->sstate) psgpu_semi_state_free(g->sstate);
+    if (g->smodel) psgpu_semi_model_free(g->smodel);
+    if (g->cpu_semi) ps_mgau_free(ps_mgau_base(g->cpu_semi));
+    ckd_free(g->vec);
+    ckd_free(g);
+}
+
 ps_mgau_t *
 psgpu_mgau_wrap(ps_mgau_t *cpu_mgau)
 {
@@ -134,8 +315,10 @@ psgpu_mgau_wrap(ps_mgau_t *cpu_mgau)
     ptm_mgau_t *s = (ptm_mgau_t *)cpu_mgau;
     int f;
 
+    if (cpu_mgau != NULL && strcmp(cpu_mgau->vt->name, "s2_semi") == 0)
+        return semi_wrap(cpu_mgau);
     if (cpu_mgau == NULL || strcmp(cpu_mgau->vt->name, "ptm") != 0) {
-        E_ERROR("psgpu: only the \"ptm\" scorer can be wrapped (got \"%s\")\n",
+        E_ERROR("psgpu: only the \"ptm\" and \"s2_semi\" scorers can be wrapped (got \"%s\")\n",
                 cpu_mgau ? cpu_mgau->vt->name : "(null)");
         return NULL;
     }
@@ -178,7 +361,7 @@ psgpu_mgau_attach(ps_decoder_t *ps)
 int32
 psgpu_mgau_n_calls(ps_mgau_t *ps)
 {
-    if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
+    if (ps == NULL || (ps->vt != &psgpu_mgau_funcs && ps->vt != &psgpu_semi_funcs))
         return -1;
     return ((psgpu_mgau_t *)ps)->n_calls;
 }

@@ -67,6 +67,12 @@ rec_frame_eval(ps_mgau_t *mg, int16 *senscr, uint8 *act, int32 nact,
         r->hash = realloc(r->hash, sizeof(uint64_t) * r->cap);
         r->frame = realloc(r->frame, sizeof(int32) * r->cap);
     }
+    if (r->n == 0 && getenv("PSGPU_DEBUG_DUMP")) {
+        int i;
+        fprintf(stderr, "call0 frame %d nact %d compall %d:", frame, nact, compallsen);
+        for (i = 0; i < 24 && i < r->n_sen; ++i) fprintf(stderr, " %d", senscr[i]);
+        fprintf(stderr, "\n");
+    }
     r->hash[r->n] = fnv1a(senscr, sizeof(int16) * r->n_sen);
     r->frame[r->n] = frame;
     ++r->n;
@@ -123,14 +129,45 @@ now_s(void)
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
 
+/* Sphinx cepstra file, as pocketsphinx_batch reads its -cepdir inputs
+ * (programs/pocketsphinx_batch.c:195-250) */
+static float32 **
+read_mfc(const char *path, int ceplen, int *out_nfr)
+{
+    FILE *fp = fopen(path, "rb");
+    long flen; int32 nmfc; int nfr, i, swap = 0;
+    float32 **mfcs;
+    if (!fp) { perror(path); exit(2); }
+    fseek(fp, 0, SEEK_END); flen = ftell(fp); fseek(fp, 0, SEEK_SET);
+    if (fread(&nmfc, 4, 1, fp) != 1) { perror(path); exit(2); }
+    if (nmfc != flen / 4 - 1) {
+        nmfc = (int32)__builtin_bswap32((uint32_t)nmfc); swap = 1;
+        if (nmfc != flen / 4 - 1) { fprintf(stderr, "%s: not an MFCC file\n", path); exit(2); }
+    }
+    nfr = nmfc / ceplen;
+    mfcs = (float32 **)ckd_calloc_2d(nfr, ceplen, sizeof(float32));
+    if (fread(mfcs[0], 4, (size_t)nfr * ceplen, fp) != (size_t)nfr * ceplen) { perror(path); exit(2); }
+    fclose(fp);
+    if (swap)
+        for (i = 0; i < nfr * ceplen; ++i) {
+            uint32_t *u = (uint32_t *)&mfcs[0][i];
+            *u = __builtin_bswap32(*u);
+        }
+    *out_nfr = nfr;
+    return mfcs;
+}
+
 static void
-decode(ps_decoder_t *ps, const int16 *pcm, size_t n, result_t *res)
+decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, result_t *res)
 {
     const char *hyp;
     ps_seg_t *seg;
     size_t o = 0;
     ps_start_utt(ps);
-    ps_process_raw(ps, pcm, n, FALSE, TRUE);
+    if (mfcs)
+        ps_process_cep(ps, mfcs, nfr, FALSE, TRUE);
+    else
+        ps_process_raw(ps, pcm, n, FALSE, TRUE);
     ps_end_utt(ps);
     hyp = ps_get_hyp(ps, &res->score);
     snprintf(res->hyp, sizeof res->hyp, "%s", hyp ? hyp : "");
@@ -152,6 +189,9 @@ main(int argc, char **argv)
     rec_t rc_cpu, rc_gpu;
     result_t *ra, *rb;
     FILE *fp; long sz; int16 *pcm; size_t n;
+    enum { MAX_IN = 512 };
+    char *in_id[MAX_IN], *in_path[MAX_IN];
+    int n_in = 0, n_res, u, total_frames = 0;
     int nrep, r, i, ok = 1, bad_calls = 0, first_bad = -1, hyp_equal = 1, seg_equal = 1;
     double t_cpu = 0, t_gpu = 0, t0;
     int use_mgau = 1;
@@ -167,13 +207,27 @@ main(int argc, char **argv)
         return 2;
     }
     nrep = atoi(argv[5]);
-    fp = fopen(argv[4], "rb");
-    if (!fp) { perror(argv[4]); return 2; }
-    fseek(fp, 0, SEEK_END); sz = ftell(fp); fseek(fp, 0, SEEK_SET);
-    pcm = malloc(sz);
-    if (fread(pcm, 1, sz, fp) != (size_t)sz) { perror("read"); return 2; }
-    fclose(fp);
-    n = sz / 2;
+    /* inputs: one raw/.mfc file, or "@CTLFILE:DIR" = every id of CTLFILE as DIR/id.mfc
+     * (pocketsphinx_batch -ctl/-cepdir, test/regression/test-tidigits-simple.sh) */
+    if (argv[4][0] == '@') {
+        char *spec = strdup(argv[4] + 1), *dir = strchr(spec, ':'), line[512];
+        if (!dir) { fprintf(stderr, "bad ctl spec\n"); return 2; }
+        *dir++ = 0;
+        fp = fopen(spec, "r");
+        if (!fp) { perror(spec); return 2; }
+        while (fgets(line, sizeof line, fp)) {
+            line[strcspn(line, "\r\n")] = 0;
+            if (!line[0]) continue;
+            in_id[n_in] = strdup(line);
+            in_path[n_in] = malloc(strlen(dir) + strlen(line) + 8);
+            sprintf(in_path[n_in], "%s/%s.mfc", dir, line);
+            if (++n_in == MAX_IN) break;
+        }
+        fclose(fp);
+    }
+    else {
+        in_id[0] = "utt"; in_path[0] = argv[4]; n_in = 1;
+    }
     err_set_loglevel(ERR_ERROR);
 
     cpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
@@ -205,13 +259,39 @@ main(int argc, char **argv)
         }
     rec_install(&rc_cpu, cpu);
     rec_install(&rc_gpu, gpu);
-    ra = calloc(nrep, sizeof *ra);
-    rb = calloc(nrep, sizeof *rb);
+    n_res = nrep * n_in;
+    ra = calloc(n_res, sizeof *ra);
+    rb = calloc(n_res, sizeof *rb);
     for (r = 0; r < nrep; ++r) {
-        g_rec = &rc_cpu; t0 = now_s(); decode(cpu, pcm, n, &ra[r]); t_cpu += now_s() - t0;
-        g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, &rb[r]); t_gpu += now_s() - t0;
-        if (strcmp(ra[r].hyp, rb[r].hyp) || ra[r].score != rb[r].score) hyp_equal = 0;
-        if (strcmp(ra[r].seg, rb[r].seg)) seg_equal = 0;
+        for (u = 0; u < n_in; ++u) {
+            const char *path = in_path[u];
+            size_t len = strlen(path);
+            int k = r * n_in + u, nfr = 0;
+            float32 **mfcs = NULL;
+            pcm = NULL; n = 0;
+            if (len > 4 && !strcmp(path + len - 4, ".mfc"))
+                mfcs = read_mfc(path, ps_config_int(ps_get_config(cpu), "ceplen"), &nfr);
+            else {
+                fp = fopen(path, "rb");
+                if (!fp) { perror(path); return 2; }
+                fseek(fp, 0, SEEK_END); sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+                pcm = malloc(sz);
+                if (fread(pcm, 1, sz, fp) != (size_t)sz) { perror("read"); return 2; }
+                fclose(fp);
+                n = sz / 2;
+            }
+            g_rec = &rc_cpu; t0 = now_s(); decode(cpu, pcm, n, mfcs, nfr, &ra[k]); t_cpu += now_s() - t0;
+            if (mfcs) {     /* ps_process_cep normalises its input in place (CMN): reload for B */
+                ckd_free_2d(mfcs);
+                mfcs = read_mfc(path, ps_config_int(ps_get_config(cpu), "ceplen"), &nfr);
+            }
+            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k]); t_gpu += now_s() - t0;
+            if (strcmp(ra[k].hyp, rb[k].hyp) || ra[k].score != rb[k].score) hyp_equal = 0;
+            if (strcmp(ra[k].seg, rb[k].seg)) seg_equal = 0;
+            total_frames += ra[k].n_frames;
+            if (mfcs) ckd_free_2d(mfcs);
+            free(pcm);
+        }
     }
     if (rc_cpu.n != rc_gpu.n) { ok = 0; bad_calls = -1; }
     else
@@ -236,13 +316,18 @@ main(int argc, char **argv)
                "\"hyp_equal\": %s, \"seg_equal\": %s, \"hyp_cpu\": \"%s\", \"hyp_gpu\": \"%s\", "
                "\"score_cpu\": %d, \"score_gpu\": %d, \"n_seg\": %d, "
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
-               "\"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld}\n",
+               "\"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
+               "\"total_frames\": %d, \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
-               ra[nrep - 1].hyp, rb[nrep - 1].hyp, ra[nrep - 1].score, rb[nrep - 1].score,
+               ra[n_res - 1].hyp, rb[n_res - 1].hyp, ra[n_res - 1].score, rb[n_res - 1].score,
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
-               use_search ? "true" : "false", hmm_batches, hmm_evals);
+               use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames);
+        for (u = 0; u < n_res; ++u)
+            printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",
+                   in_id[u % n_in], rb[u].hyp, rb[u].score);
+        printf("]}\n");
     }
     ps_free(cpu);
     ps_free(gpu);

@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip"]
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip"]
 
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -19,6 +19,9 @@ SYMBOLS = [
     "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev",
     "psgpu_ptm_state_create", "psgpu_ptm_state_free", "psgpu_ptm_state_reset",
     "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn",
+    "psgpu_semi_model_create", "psgpu_semi_model_free", "psgpu_semi_state_create",
+    "psgpu_semi_state_free", "psgpu_semi_state_reset", "psgpu_semi_frame_eval",
+    "psgpu_semi_state_get_topn", "psgpu_semi_state_set_topn",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval",
 ]
@@ -91,6 +94,16 @@ def lib():
     L.psgpu_ptm_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32]
     L.psgpu_ptm_state_get_topn.argtypes = [vp, i32, vp, vp, vp]
     L.psgpu_ptm_state_set_topn.argtypes = [vp, i32, vp, vp, vp]
+    L.psgpu_semi_model_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.psgpu_semi_model_free.argtypes = [vp]
+    L.psgpu_semi_model_free.restype = None
+    L.psgpu_semi_state_create.argtypes = [C.POINTER(vp), vp, i32]
+    L.psgpu_semi_state_free.argtypes = [vp]
+    L.psgpu_semi_state_free.restype = None
+    L.psgpu_semi_state_reset.argtypes = [vp]
+    L.psgpu_semi_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32]
+    L.psgpu_semi_state_get_topn.argtypes = [vp, i32, vp, vp, vp]
+    L.psgpu_semi_state_set_topn.argtypes = [vp, i32, vp, vp, vp]
     L.psgpu_hmm_ctx_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, vp, i32]
     L.psgpu_hmm_ctx_free.argtypes = [vp]
     L.psgpu_hmm_ctx_free.restype = None

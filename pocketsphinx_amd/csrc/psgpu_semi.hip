@@ -1,0 +1,444 @@
+// psgpu_semi.hip -- the semi-continuous scorer: device replacement of
+// s2_semi_mgau_frame_eval() (reference src/s2_semi_mgau.c:836-883) with its
+// full call contract (one shared codebook, n_feat streams of different
+// lengths, top-N with frame-to-frame seeding, per-stream top-N beams, history
+// ring topn_hist[pl_window+2] (:1301-1322), 8-bit and 4-bit clustered mixture
+// weights, int16 accumulation without final normalisation).
+//
+// One launch per call: one workgroup of 8 wavefronts.  Wave f < n_feat owns
+// stream f: up to 256 Gaussians, 4 codewords per lane (cw = k*64 + lane), the
+// fp32 distances in the reference's exact op order, then the history-dependent
+// top-N update emulated on wave-uniform state with ballots.  After a barrier
+// all lanes score the listed senones (mixture weights from L2, 8-bit log-add
+// table in LDS) and store int16 scores into a host-mapped buffer.
+#include "psgpu_ptm_dev.h"
+#include <cstring>
+#include <cstdlib>
+
+constexpr int kSemiMaxFeat = 8;
+constexpr int kSemiMaxTopn = 8;
+constexpr int kSemiK = 4;                 // codewords per lane -> n_density <= 256
+constexpr int kSemiMaxVec = 64;
+constexpr int kSemiThreads = 512;
+constexpr int kSemiLa = 512;
+
+struct SemiFeat { float x[kSemiMaxVec]; };
+
+struct SemiDev {
+    const float *mean, *var, *det;
+    const uint8_t *mixw, *mixw_cb, *logadd8;       // mixw_cb == nullptr: 8-bit weights
+    int32_t n_feat, n_density, n_sen, topn, ds_ratio, logadd8_size, row;   // row = bytes per mixw row
+    int32_t featlen[kSemiMaxFeat], featoff[kSemiMaxFeat], foff[kSemiMaxFeat];
+    int32_t beam[kSemiMaxFeat];
+};
+
+struct psgpu_semi_model_s {
+    SemiDev d;
+    float *mean, *var, *det;
+    uint8_t *mixw, *mixw_cb, *logadd8;
+    int32_t veclen;
+};
+
+struct psgpu_semi_state_s {
+    psgpu_semi_model_t *m;
+    int32_t n_hist;
+    int32_t *hist_cw, *hist_sc;      // [n_hist][n_feat][topn]
+    int32_t *hist_n;                 // [n_hist][n_feat]   (topn_hist_n)
+    uint16_t *h_list, *d_list;
+    int16_t *h_out, *d_out;
+    hipStream_t stream;
+    int32_t cur;
+};
+
+__device__ __forceinline__ float pick4(const float (&d)[kSemiK], int c)
+{
+    const int k = c >> 6, l = c & 63;
+    float v = lane_value(d[0], l);
+    if (k == 1) v = lane_value(d[1], l);
+    if (k == 2) v = lane_value(d[2], l);
+    if (k == 3) v = lane_value(d[3], l);
+    return v;
+}
+
+// eval_topn (s2_semi_mgau.c:69-109) + eval_cb (:111-170) on wave-uniform list
+// state.  d[k] / dp[k] = finished distance / partial sum before the last
+// dimension of codeword k*64 + lane.  A codeword is accepted iff every float
+// guard `d >= worst->score` passed (<=> dp >= (float)worst) AND the truncated
+// finished distance is not below worst (`d_int < worst->score`), it is not in
+// the list, and it goes ahead of equal scores.
+template <int N>
+__device__ __forceinline__ void semi_frame_step(TopN<N> &L, const float (&d)[kSemiK], const float (&dp)[kSemiK],
+                                                int lane, int n_density, bool scan)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        L.sc[i] = dist_to_int(pick4(d, L.cw[i]));
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+            if (L.sc[j] > L.sc[j - 1]) {
+                int32_t ts = L.sc[j]; L.sc[j] = L.sc[j - 1]; L.sc[j - 1] = ts;
+                int32_t tc = L.cw[j]; L.cw[j] = L.cw[j - 1]; L.cw[j - 1] = tc;
+            }
+        }
+    }
+    if (!scan)
+        return;
+    int32_t di[kSemiK];
+#pragma unroll
+    for (int k = 0; k < kSemiK; ++k) di[k] = dist_to_int(d[k]);
+    int pos = 0;
+    for (;;) {
+        const int32_t W = L.sc[N - 1];
+        const float th = (float)W;
+        int found = -1;
+#pragma unroll
+        for (int k = 0; k < kSemiK; ++k) {
+            const int cw = k * 64 + lane;
+            bool inl = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) inl |= (L.cw[i] == cw);
+            const bool ok = (cw < n_density) && (cw >= pos) && (dp[k] >= th) && (di[k] >= W) && !inl;
+            const unsigned long long b = __ballot(ok);
+            if (found < 0 && b) found = k * 64 + __ffsll((long long)b) - 1;
+        }
+        if (found < 0)
+            break;
+        const int32_t s = dist_to_int(pick4(d, found));
+        int q = N - 1;
+#pragma unroll
+        for (int k = N - 1; k > 0; --k) {
+            if (q == k && s >= L.sc[k - 1]) {
+                L.sc[k] = L.sc[k - 1];
+                L.cw[k] = L.cw[k - 1];
+                q = k - 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (q == k) { L.sc[k] = s; L.cw[k] = found; }
+        pos = found + 1;
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(kSemiThreads)
+void semi_frame_kernel(SemiDev p, SemiFeat fa, int32_t fresh, int32_t do_scan, int32_t compall,
+                       int32_t n_list, const uint16_t *__restrict__ list,
+                       const int32_t *__restrict__ prev_cw,
+                       int32_t *__restrict__ cur_cw, int32_t *__restrict__ cur_sc,
+                       int32_t *__restrict__ cur_n, int16_t *__restrict__ out)
+{
+    __shared__ uint8_t s_la[kSemiLa];
+    __shared__ int32_t s_cw[kSemiMaxFeat * N], s_sc[kSemiMaxFeat * N], s_n[kSemiMaxFeat];
+    __shared__ uint8_t s_cb[16];
+    extern __shared__ __attribute__((aligned(16))) int16_t s_out[];       // [n_sen]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int i = tid; i < kSemiLa; i += kSemiThreads)
+        s_la[i] = (i < p.logadd8_size) ? p.logadd8[i] : 0;
+    if (tid < 16) s_cb[tid] = p.mixw_cb ? p.mixw_cb[tid] : 0;
+
+    if (wave < p.n_feat) {
+        const int f = wave;
+        TopN<N> L;
+        int32_t cnt;
+        if (fresh) {
+            const int len = p.featlen[f];
+            const float *mean = p.mean + p.foff[f], *var = p.var + p.foff[f];
+            const float *det = p.det + (size_t)f * p.n_density;
+            const float *x = fa.x + p.featoff[f];
+            float d[kSemiK], dp[kSemiK];
+#pragma unroll
+            for (int k = 0; k < kSemiK; ++k) {
+                const int cw = min(k * 64 + lane, p.n_density - 1);     // clamp; masked in the scan
+                const float *m = mean + (size_t)cw * len, *v = var + (size_t)cw * len;
+                float acc = det[cw], prev = acc;
+                for (int j = 0; j < len; ++j) {
+                    prev = acc;
+                    acc = gau_step(acc, x[j], m[j], v[j]);
+                }
+                d[k] = acc; dp[k] = prev;
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                L.cw[i] = __builtin_amdgcn_readfirstlane(prev_cw[f * N + i]);
+                L.sc[i] = kMaxNegInt32;
+            }
+            semi_frame_step<N>(L, d, dp, lane, p.n_density, do_scan != 0);
+            // mgau_norm (:185-203): own best as the norm, beam cut leaves the tail raw
+            const int32_t norm = L.sc[0] >> kSenscrShift;
+            cnt = N;
+            bool cut = false;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (!cut) {
+                    int32_t v = (int32_t)(0u - ((uint32_t)(L.sc[j] >> kSenscrShift) - (uint32_t)norm));
+                    if (v > kMaxNegAscr) v = kMaxNegAscr;
+                    L.sc[j] = v;
+                    if (p.beam[f] && v > p.beam[f]) { cnt = j; cut = true; }
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) { cur_cw[f * N + i] = L.cw[i]; cur_sc[f * N + i] = L.sc[i]; }
+                cur_n[f] = cnt;
+            }
+        }
+        else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { L.cw[i] = cur_cw[f * N + i]; L.sc[i] = cur_sc[f * N + i]; }
+            cnt = cur_n[f];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { s_cw[f * N + i] = L.cw[i]; s_sc[f * N + i] = L.sc[i]; }
+            s_n[f] = cnt;
+        }
+    }
+    // memset(senone_scores, 0) (:846)
+    for (int i = tid; i < p.n_sen; i += kSemiThreads) s_out[i] = 0;
+    __syncthreads();
+
+    const bool four = p.mixw_cb != nullptr;
+    const int n = compall ? (four ? (p.n_sen & ~1) : p.n_sen) : n_list;
+    for (int i = tid; i < n; i += kSemiThreads) {
+        const int sen = compall ? i : list[i];
+        int32_t acc = 0;
+        for (int f = 0; f < p.n_feat; ++f) {
+            const int cnt = s_n[f];
+            // the unrolled 4-bit kernels (:446-741) keep mixw_cb + score in uint8
+            const bool wrap = four && !compall && cnt >= 1 && cnt <= 6;
+            int32_t tmp = 0;
+            for (int k = 0; k < max(cnt, 1); ++k) {
+                const int cw = s_cw[f * N + k];
+                int32_t w;
+                if (four) {
+                    const int b = p.mixw[((size_t)f * p.n_density + cw) * p.row + (sen >> 1)];
+                    w = s_cb[(sen & 1) ? (b >> 4) : (b & 0x0f)];
+                }
+                else
+                    w = p.mixw[((size_t)f * p.n_density + cw) * p.row + sen];
+                int32_t y = w + s_sc[f * N + k];
+                if (wrap) y &= 0xff;
+                if (k == 0) tmp = y;
+                else {
+                    // fast_logmath_add (tied_mgau_common.h:106-125)
+                    const int32_t lo_ = min(tmp, y);
+                    const uint32_t dd = (uint32_t)(max(tmp, y) - lo_);
+                    tmp = lo_ - (dd < (uint32_t)kSemiLa ? (int32_t)s_la[dd] : 0);
+                }
+            }
+            acc = (int32_t)(int16_t)(acc + tmp);          // senone_scores[sen] += tmp, int16
+        }
+        s_out[sen] = (int16_t)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < p.n_sen; i += kSemiThreads) out[i] = s_out[i];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T>
+static int up(T **dst, const T *src, size_t n)
+{
+    PSGPU_HIP(hipMalloc((void **)dst, n * sizeof(T) ? n * sizeof(T) : 1));
+    PSGPU_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PSGPU_OK;
+}
+
+extern "C" {
+
+int psgpu_semi_model_create(psgpu_semi_model_t **out, int32_t n_feat, int32_t n_density,
+                            const int32_t *featlen, int32_t n_sen, int32_t topn, int32_t ds_ratio,
+                            const uint8_t *topn_beam,
+                            const float *mean, const float *var, const float *det,
+                            const uint8_t *mixw, const uint8_t *mixw_cb,
+                            const uint8_t *logadd8, int32_t logadd8_size)
+{
+    PSGPU_REQUIRE(out && featlen && mean && var && det && mixw && logadd8,
+                  "psgpu_semi_model_create: NULL argument");
+    PSGPU_REQUIRE(n_feat >= 1 && n_feat <= kSemiMaxFeat, "n_feat %d outside 1..%d", n_feat, kSemiMaxFeat);
+    PSGPU_REQUIRE(n_density >= 1 && n_density <= 64 * kSemiK, "n_density %d outside 1..%d", n_density, 64 * kSemiK);
+    PSGPU_REQUIRE(topn >= 1 && topn <= kSemiMaxTopn && topn <= n_density, "topn %d outside 1..%d", topn, kSemiMaxTopn);
+    PSGPU_REQUIRE(ds_ratio >= 1, "ds_ratio %d < 1", ds_ratio);
+    PSGPU_REQUIRE(n_sen > 0 && n_sen < 65535, "n_sen %d outside 1..65534", n_sen);
+    PSGPU_REQUIRE(logadd8_size >= 256, "log-add table has %d < 256 entries", logadd8_size);
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    psgpu_semi_model_t *m = new psgpu_semi_model_t();
+    memset(m, 0, sizeof *m);
+    SemiDev &d = m->d;
+    d.n_feat = n_feat; d.n_density = n_density; d.n_sen = n_sen; d.topn = topn;
+    d.ds_ratio = ds_ratio; d.logadd8_size = logadd8_size;
+    d.row = mixw_cb ? (n_sen + 1) / 2 : n_sen;
+    int32_t o = 0;
+    for (int f = 0; f < n_feat; ++f) {
+        PSGPU_REQUIRE(featlen[f] >= 1, "stream %d has length %d", f, featlen[f]);
+        d.featlen[f] = featlen[f]; d.featoff[f] = m->veclen; m->veclen += featlen[f];
+        d.foff[f] = o; o += n_density * featlen[f];
+        d.beam[f] = topn_beam ? topn_beam[f] : 0;
+    }
+    if (m->veclen > kSemiMaxVec) {
+        psgpu_set_error("feature vector of %d floats exceeds %d", m->veclen, kSemiMaxVec);
+        delete m;
+        return PSGPU_EINVAL;
+    }
+    if ((rc = up(&m->mean, mean, (size_t)o)) || (rc = up(&m->var, var, (size_t)o)) ||
+        (rc = up(&m->det, det, (size_t)n_feat * n_density)) ||
+        (rc = up(&m->mixw, mixw, (size_t)n_feat * n_density * d.row)) ||
+        (rc = up(&m->logadd8, logadd8, (size_t)logadd8_size)) ||
+        (mixw_cb && (rc = up(&m->mixw_cb, mixw_cb, (size_t)16)))) {
+        psgpu_semi_model_free(m);
+        return rc;
+    }
+    d.mean = m->mean; d.var = m->var; d.det = m->det; d.mixw = m->mixw;
+    d.mixw_cb = m->mixw_cb; d.logadd8 = m->logadd8;
+    *out = m;
+    return PSGPU_OK;
+}
+
+void psgpu_semi_model_free(psgpu_semi_model_t *m)
+{
+    if (!m) return;
+    hipFree(m->mean); hipFree(m->var); hipFree(m->det);
+    hipFree(m->mixw); hipFree(m->mixw_cb); hipFree(m->logadd8);
+    delete m;
+}
+
+int psgpu_semi_state_reset(psgpu_semi_state_t *s)
+{
+    PSGPU_REQUIRE(s != nullptr, "psgpu_semi_state_reset: NULL state");
+    // s2_semi_mgau_init (:1305-1322): codeword k / WORST_DIST, counts 0
+    const SemiDev &d = s->m->d;
+    const size_t n = (size_t)s->n_hist * d.n_feat * d.topn;
+    int32_t *cw = (int32_t *)malloc(n * sizeof(int32_t)), *sc = (int32_t *)malloc(n * sizeof(int32_t));
+    if (!cw || !sc) { free(cw); free(sc); psgpu_set_error("out of host memory"); return PSGPU_ENOMEM; }
+    for (size_t i = 0; i < n; ++i) { cw[i] = (int32_t)(i % d.topn); sc[i] = kMaxNegInt32; }
+    hipError_t e1 = hipMemcpy(s->hist_cw, cw, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipError_t e2 = hipMemcpy(s->hist_sc, sc, n * sizeof(int32_t), hipMemcpyHostToDevice);
+    hipError_t e3 = hipMemset(s->hist_n, 0, (size_t)s->n_hist * d.n_feat * sizeof(int32_t));
+    free(cw); free(sc);
+    PSGPU_HIP(e1); PSGPU_HIP(e2); PSGPU_HIP(e3);
+    s->cur = 0;
+    return PSGPU_OK;
+}
+
+int psgpu_semi_state_create(psgpu_semi_state_t **out, psgpu_semi_model_t *m, int32_t n_topn_hist)
+{
+    PSGPU_REQUIRE(out && m, "psgpu_semi_state_create: NULL argument");
+    PSGPU_REQUIRE(n_topn_hist >= 1 && n_topn_hist <= 64, "n_topn_hist %d outside 1..64", n_topn_hist);
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    psgpu_semi_state_t *s = new psgpu_semi_state_t();
+    memset(s, 0, sizeof *s);
+    s->m = m; s->n_hist = n_topn_hist;
+    const SemiDev &d = m->d;
+    const size_t n = (size_t)n_topn_hist * d.n_feat * d.topn;
+    hipError_t e = hipMalloc((void **)&s->hist_cw, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->hist_sc, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&s->hist_n, (size_t)n_topn_hist * d.n_feat * sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_list, (size_t)d.n_sen * sizeof(uint16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, (size_t)d.n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_list, s->h_list, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_out, s->h_out, 0);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        psgpu_set_error("psgpu_semi_state_create: %s", hipGetErrorString(e));
+        psgpu_semi_state_free(s);
+        return e == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP;
+    }
+    rc = psgpu_semi_state_reset(s);
+    if (rc != PSGPU_OK) { psgpu_semi_state_free(s); return rc; }
+    *out = s;
+    return PSGPU_OK;
+}
+
+void psgpu_semi_state_free(psgpu_semi_state_t *s)
+{
+    if (!s) return;
+    if (s->stream) hipStreamDestroy(s->stream);
+    hipFree(s->hist_cw); hipFree(s->hist_sc); hipFree(s->hist_n);
+    if (s->h_list) hipHostFree(s->h_list);
+    if (s->h_out) hipHostFree(s->h_out);
+    delete s;
+}
+
+int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
+                          const uint8_t *senone_active, int32_t n_senone_active,
+                          const float *feat, int32_t frame, int32_t frame_idx, int32_t compallsen)
+{
+    PSGPU_REQUIRE(s && senscr && feat, "psgpu_semi_frame_eval: NULL argument");
+    PSGPU_REQUIRE(frame >= 0, "negative frame %d", frame);
+    PSGPU_REQUIRE(compallsen || n_senone_active == 0 || senone_active, "active list missing");
+    psgpu_semi_model_t *m = s->m;
+    const SemiDev &d = m->d;
+    const int slot = frame % s->n_hist;                        // s2_semi_mgau.c:849-850
+    const int prev = (slot == 0) ? s->n_hist - 1 : slot - 1;
+    const size_t sl = (size_t)d.n_feat * d.topn;
+    const int fresh = frame >= frame_idx;                      // :853
+    s->cur = slot;
+    int n_list = 0;
+    if (!compallsen) {
+        int sen = 0;
+        for (int i = 0; i < n_senone_active; ++i) {
+            sen += senone_active[i];
+            if (sen >= d.n_sen) {
+                psgpu_set_error("active list runs past n_sen (%d >= %d)", sen, d.n_sen);
+                return PSGPU_EINVAL;
+            }
+            s->h_list[n_list++] = (uint16_t)sen;
+        }
+    }
+    SemiFeat fa;
+    memset(&fa, 0, sizeof fa);
+    memcpy(fa.x, feat, (size_t)m->veclen * sizeof(float));
+    const size_t smem = (((size_t)d.n_sen * 2 + 15) / 16) * 16;
+#define PSGPU_SEMI_CASE(NN) case NN: hipLaunchKernelGGL((semi_frame_kernel<NN>), dim3(1), dim3(kSemiThreads), smem, s->stream, \
+        d, fa, (int32_t)fresh, (int32_t)(frame % d.ds_ratio == 0), (int32_t)(compallsen != 0), (int32_t)n_list,          \
+        (const uint16_t *)s->d_list, (const int32_t *)(s->hist_cw + prev * sl), s->hist_cw + slot * sl,                  \
+        s->hist_sc + slot * sl, s->hist_n + (size_t)slot * d.n_feat, s->d_out); break;
+    switch (d.topn) {
+        PSGPU_SEMI_CASE(1) PSGPU_SEMI_CASE(2) PSGPU_SEMI_CASE(3) PSGPU_SEMI_CASE(4)
+        PSGPU_SEMI_CASE(5) PSGPU_SEMI_CASE(6) PSGPU_SEMI_CASE(7) default: PSGPU_SEMI_CASE(8)
+    }
+#undef PSGPU_SEMI_CASE
+    PSGPU_HIP(hipGetLastError());
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    memcpy(senscr, s->h_out, (size_t)d.n_sen * sizeof(int16_t));
+    return PSGPU_OK;
+}
+
+int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, int32_t *score, int32_t *n_used)
+{
+    PSGPU_REQUIRE(s != nullptr, "psgpu_semi_state_get_topn: NULL state");
+    if (slot < 0) slot = s->cur;
+    PSGPU_REQUIRE(slot < s->n_hist, "slot %d outside the %d-slot ring", slot, s->n_hist);
+    const SemiDev &d = s->m->d;
+    const size_t sl = (size_t)d.n_feat * d.topn;
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    if (cw) PSGPU_HIP(hipMemcpy(cw, s->hist_cw + slot * sl, sl * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (score) PSGPU_HIP(hipMemcpy(score, s->hist_sc + slot * sl, sl * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_used) PSGPU_HIP(hipMemcpy(n_used, s->hist_n + (size_t)slot * d.n_feat, d.n_feat * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return PSGPU_OK;
+}
+
+int psgpu_semi_state_set_topn(psgpu_semi_state_t *s, int32_t slot, const int32_t *cw, const int32_t *score,
+                              const int32_t *n_used)
+{
+    PSGPU_REQUIRE(s && cw && score && n_used, "psgpu_semi_state_set_topn: NULL argument");
+    PSGPU_REQUIRE(slot >= 0 && slot < s->n_hist, "slot %d outside the %d-slot ring", slot, s->n_hist);
+    const SemiDev &d = s->m->d;
+    const size_t sl = (size_t)d.n_feat * d.topn;
+    for (size_t i = 0; i < sl; ++i)
+        PSGPU_REQUIRE(cw[i] >= 0 && cw[i] < d.n_density, "codeword %d outside the codebook", cw[i]);
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    PSGPU_HIP(hipMemcpy(s->hist_cw + slot * sl, cw, sl * sizeof(int32_t), hipMemcpyHostToDevice));
+    PSGPU_HIP(hipMemcpy(s->hist_sc + slot * sl, score, sl * sizeof(int32_t), hipMemcpyHostToDevice));
+    PSGPU_HIP(hipMemcpy(s->hist_n + (size_t)slot * d.n_feat, n_used, d.n_feat * sizeof(int32_t), hipMemcpyHostToDevice));
+    return PSGPU_OK;
+}
+
+}  // extern "C"

@@ -22,13 +22,14 @@ DATA = os.path.join(REF, "data")
 BIN_FULL = os.path.join(REF, "dropin_decode_full")
 
 
-def run(raw, nrep, *extra, lm="turtle.lm.bin", dic="turtle.dic", binary=None):
+def run(raw, nrep, *extra, lm="turtle.lm.bin", dic="turtle.dic", binary=None, model=None):
     BIN = binary or globals()["BIN"]
     if not os.path.exists(BIN):
         pytest.fail("oracle/_ref/dropin_decode is missing: run __graft_entry__.build() where "
                     "/root/reference is present (the built oracle/_ref travels with gpurun)")
-    argv = [BIN, MODEL, os.path.join(DATA, lm), os.path.join(DATA, dic),
-            os.path.join(DATA, raw), str(nrep)] + [str(e) for e in extra]
+    inp = raw if raw.startswith("@") else os.path.join(DATA, raw)
+    argv = [BIN, model or MODEL, os.path.join(DATA, lm), os.path.join(DATA, dic),
+            inp, str(nrep)] + [str(e) for e in extra]
     p = subprocess.run(argv, capture_output=True, text=True, timeout=600)
     assert p.stdout.strip(), "no output (rc %d): %s" % (p.returncode, p.stderr[-2000:])
     r = json.loads(p.stdout.strip().splitlines()[-1])
@@ -119,6 +120,56 @@ def test_dropin_full_decode_identical(case):
         import numpy as np
         g = np.load(os.path.join(pso.GOLDEN_DIR, "decode_default.npz"))
         assert r["hyp_cpu"] == bytes(g["hyp"]).decode()
+
+
+TD = os.path.join(DATA, "tidigits")
+TD_KW = dict(model=os.path.join(REF, "model", "tidigits"), lm="tidigits/tidigits.lm.bin",
+             dic="tidigits/tidigits.dic")
+
+
+def _match_file():
+    out = []
+    for line in open(os.path.join(TD, "test-tidigits-simple.match")):
+        line = line.strip()
+        if line:
+            hyp, tail = line.rsplit("(", 1)
+            uid, score = tail.rstrip(")").split()
+            out.append((uid, hyp.strip(), int(score)))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("binary", ["mgau", "full"])
+def test_tidigits_regression_vs_reference_match_file(binary):
+    """The reference's own regression (test/regression/test-tidigits-simple.sh):
+    40 tidigits utterances, s2_semi scorer (4-bit weights) + n-gram fwdtree /
+    fwdflat / bestpath over 5-state HMMs, hypotheses AND path scores pinned by
+    test/data/tidigits/test-tidigits-simple.match.  Decoder B runs the scorer
+    (and, for "full", every 5-state Viterbi step) on the device; it must equal
+    decoder A call for call and reproduce the match file exactly."""
+    r = run("@%s:%s" % (os.path.join(TD, "tidigits.ctl"), TD), 1, **TD_KW,
+            binary=BIN_FULL if binary == "full" else BIN)
+    assert r["mgau"] == "s2_semi-psgpu" and r["device_calls"] == r["calls_gpu"] > 0
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
+    if binary == "full":
+        assert r["hmm_evals"] > 0
+    want = _match_file()
+    assert len(r["utts"]) == len(want) == 40
+    for u, (uid, hyp, score) in zip(r["utts"], want):
+        assert u["id"] == uid
+        assert u["hyp"] == hyp, u
+        assert u["score"] == score, u            # the reference's compare_table tolerance is 100000; we are exact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [("topn_beam", "20,35,10,20"), ("topn", "6", "ds", "2"),
+                                   ("topn", "7", "compallsen", "yes"), ("topn", "2", "pl_window", "0")])
+def test_tidigits_scorer_options(extra):
+    r = run("tidigits/woman.ak.276317oa.mfc", 2, *extra, **TD_KW, binary=BIN_FULL)
+    assert r["mgau"] == "s2_semi-psgpu"
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
 
 
 def test_attach_fails_loudly_without_gpu():
