@@ -174,6 +174,53 @@ def semi_only():
     senlog_case("tidigits_topn2", 1, inp=b, extra=("topn", "2", "pl_window", "0"), **TD)
 
 
+def write_s3_mixw(path, w):
+    """S3 mixture_weights file (senone_mixw_read, ms_senone.c:134-267):
+    text header, byte-order magic, n_sen n_feat n_cw n_total, float32 [sen][feat][cw]."""
+    import struct
+    w = np.ascontiguousarray(w, np.float32)
+    with open(path, "wb") as fh:
+        fh.write(b"s3\nversion 1.0\nendhdr\n")
+        fh.write(struct.pack("<I4i", 0x11223344, w.shape[0], w.shape[1], w.shape[2], w.size))
+        fh.write(w.tobytes())
+
+
+def stage_en_us_ms():
+    """A multi-density model for the ms scorer (the only bundled continuous
+    model, an4_ci_cont, has ONE density per codebook): the en-us means /
+    variances / mdef with a float mixture_weights file de-quantised from the
+    en-us sendump, used with `-senmgau .ptm.`."""
+    src, dst = MODEL, os.path.join(REF, "model", "en-us-ms")
+    os.makedirs(dst, exist_ok=True)
+    for f in ("mdef", "means", "variances", "transition_matrices", "feat.params", "noisedict"):
+        subprocess.check_call(["cp", "-u", os.path.join(src, f), dst])
+    mw = os.path.join(dst, "mixture_weights")
+    if not os.path.exists(mw):
+        t = np.load(os.path.join(GOLD, "en_us_ptm_tables.npz"))
+        q = t["mixw"].astype(np.float64)                       # [feat][cw][sen], -log_{1.0001}(w) >> 10
+        w = np.power(1.0001, -(q * 1024.0))                     # back to probabilities
+        write_s3_mixw(mw, np.transpose(w, (2, 0, 1)))
+    return dst
+
+
+def ms_only():
+    """ms scorer: an4_ci_cont (102 codebooks x 1 density x 39 dims, compute_dist_all
+    path) and en-us-ms (42 codebooks x 3 streams x 128 densities, top-N scan path)."""
+    an4 = os.path.join(REF, "model", "an4_ci_cont")
+    t = ref_dump("tables_ms", model=an4)
+    np.savez_compressed(os.path.join(GOLD, "ms_an4_tables.npz"), **t)
+    print("ms an4 tables:", {k: v.shape for k, v in t.items() if v.size > 1})
+    senlog_case("ms_an4_default", 1, model=an4)
+    senlog_case("ms_an4_compall_aw2", 1, model=an4, extra=("compallsen", "yes", "aw", "2"))
+    ems = stage_en_us_ms()
+    x = ("senmgau", ".ptm.")
+    t = ref_dump("tables_ms", model=ems, extra=x)
+    np.savez_compressed(os.path.join(GOLD, "ms_en_us_tables.npz"), **t)
+    print("ms en-us tables:", {k: v.shape for k, v in t.items() if v.size > 1})
+    senlog_case("ms_en_us_default", 1, model=ems, extra=x)
+    senlog_case("ms_en_us_topn2_call", 1, model=ems, extra=x + ("topn", "2", "compallsen", "yes", "fwdflat", "no"))
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -189,5 +236,7 @@ if __name__ == "__main__":
         hmm_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "semi":
         semi_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ms":
+        ms_only()
     else:
         main()

@@ -566,6 +566,157 @@ pso_semi_frame_eval(pso_semi_t *s, int16_t *senscr,
 }
 
 /* ================================================================== */
+/* multi-stream / continuous scorer (ms_mgau.c, ms_gauden.c, ms_senone.c) */
+/* ================================================================== */
+
+typedef struct { int32_t id; float dist; } pso_gdist_t;      /* gauden_dist_t, ms_gauden.h:70-75 */
+
+struct pso_ms_s {
+    int n_mgau, n_feat, n_density, n_sen, topn, aw, veclen;
+    int32_t *featlen, *featoff;
+    int64_t *cboff;
+    const float *mean, *var, *det;
+    const uint8_t *pdf;
+    const uint32_t *sen2mgau;
+    const void *logadd; int logadd_size, logadd_width; int32_t log_zero;
+    pso_gdist_t *dist;             /* [n_mgau][n_feat][topn], persistent like msg->dist (ms_mgau.c:150-152) */
+    uint8_t *active;
+};
+
+pso_ms_t *
+pso_ms_new(int n_mgau, int n_feat, int n_density, const int32_t *featlen,
+           int n_sen, int topn, int aw,
+           const float *mean, const float *var, const float *det,
+           const uint8_t *pdf, const uint32_t *sen2mgau,
+           const void *logadd, int logadd_size, int logadd_width, int32_t log_zero)
+{
+    pso_ms_t *s = calloc(1, sizeof(*s));
+    int m, f; int64_t o = 0;
+    s->n_mgau = n_mgau; s->n_feat = n_feat; s->n_density = n_density; s->n_sen = n_sen;
+    s->topn = topn; s->aw = aw;
+    s->featlen = malloc(sizeof(int32_t) * n_feat);
+    s->featoff = malloc(sizeof(int32_t) * n_feat);
+    s->cboff = malloc(sizeof(int64_t) * n_mgau * n_feat);
+    for (f = 0; f < n_feat; ++f) { s->featlen[f] = featlen[f]; s->featoff[f] = s->veclen; s->veclen += featlen[f]; }
+    for (m = 0; m < n_mgau; ++m)
+        for (f = 0; f < n_feat; ++f) { s->cboff[m * n_feat + f] = o; o += (int64_t)n_density * featlen[f]; }
+    s->mean = mean; s->var = var; s->det = det; s->pdf = pdf; s->sen2mgau = sen2mgau;
+    s->logadd = logadd; s->logadd_size = logadd_size; s->logadd_width = logadd_width; s->log_zero = log_zero;
+    s->dist = calloc((size_t)n_mgau * n_feat * topn, sizeof(pso_gdist_t));   /* ckd_calloc_3d: ids start at 0 */
+    s->active = calloc(n_mgau, 1);
+    return s;
+}
+
+void
+pso_ms_free(pso_ms_t *s)
+{
+    if (!s) return;
+    free(s->featlen); free(s->featoff); free(s->cboff); free(s->dist); free(s->active); free(s);
+}
+
+/* compute_dist / compute_dist_all (ms_gauden.c:377-483).  The early exit on
+ * `dval >= worst->dist` is result-neutral here (the finished value is tested
+ * in float as well, :461), so the finished distance decides. */
+static void
+ms_topn(const pso_ms_t *s, int m, int f, const float *x, pso_gdist_t *out)
+{
+    int len = s->featlen[f], N = s->topn, d, i, j;
+    int64_t base = s->cboff[m * s->n_feat + f];
+    const float *det = s->det + ((size_t)m * s->n_feat + f) * s->n_density;
+    if (N >= s->n_density) {                       /* compute_dist_all: unsorted, every density */
+        for (d = 0; d < s->n_density; ++d) {
+            out[d].dist = gau_dist(det[d], x, s->mean + base + (int64_t)d * len, s->var + base + (int64_t)d * len, len);
+            out[d].id = d;
+        }
+        return;
+    }
+    for (i = 0; i < N; ++i)
+        out[i].dist = (float)PSO_WORST_DIST;       /* ids keep their previous contents */
+    for (d = 0; d < s->n_density; ++d) {
+        float dval = gau_dist(det[d], x, s->mean + base + (int64_t)d * len, s->var + base + (int64_t)d * len, len);
+        if (!(dval >= out[N - 1].dist))
+            continue;
+        for (i = 0; i < N && dval < out[i].dist; ++i) ;
+        for (j = N - 1; j > i; --j) out[j] = out[j - 1];
+        out[i].dist = dval; out[i].id = d;
+    }
+}
+
+/* logmath_add (util/logmath.c:401-446) on the senone log-math object */
+static int
+ms_logadd(const pso_ms_t *s, int x, int y)
+{
+    int d, r;
+    if (x <= s->log_zero) return y;
+    if (y <= s->log_zero) return x;
+    if (x > y) { d = x - y; r = x; } else { d = y - x; r = y; }
+    if (d < 0 || d >= s->logadd_size) return r;
+    switch (s->logadd_width) {
+    case 1: return r + ((const uint8_t *)s->logadd)[d];
+    case 2: return r + ((const uint16_t *)s->logadd)[d];
+    case 4: return r + (int)((const uint32_t *)s->logadd)[d];
+    }
+    return r;
+}
+
+/* senone_eval (ms_senone.c:357-407) */
+static int32_t
+ms_senone(const pso_ms_t *s, int id, const pso_gdist_t *dist)
+{
+    int f, t, scr = 0;
+    for (f = 0; f < s->n_feat; ++f) {
+        const pso_gdist_t *fd = dist + (size_t)f * s->topn;
+        const uint8_t *pdf = s->pdf + ((size_t)id * s->n_feat + f) * s->n_density;
+        int fscr = 0;
+        for (t = 0; t < s->topn; ++t) {
+            int fden, fw;
+            if (fd[t].dist < (float)PSO_MAX_NEG_INT32) fden = PSO_MAX_NEG_INT32 >> PSO_SENSCR_SHIFT;
+            else fden = ((int32_t)fd[t].dist + ((1 << PSO_SENSCR_SHIFT) - 1)) >> PSO_SENSCR_SHIFT;
+            fw = fden - pdf[fd[t].id];
+            fscr = (t == 0) ? fw : ms_logadd(s, fscr, fw);
+        }
+        scr -= fscr;
+    }
+    scr /= s->aw;
+    if (scr > 32767) scr = 32767;
+    if (scr < -32768) scr = -32768;
+    return scr;
+}
+
+int
+pso_ms_frame_eval(pso_ms_t *s, int16_t *senscr,
+                  const uint8_t *senone_active, int32_t n_senone_active,
+                  const float *feat, int32_t compallsen)
+{
+    int m, f, i, n, best = 0x7fffffff;
+    size_t L = (size_t)s->n_feat * s->topn;
+    if (compallsen)
+        memset(s->active, 1, s->n_mgau);
+    else {
+        memset(s->active, 0, s->n_mgau);
+        for (n = 0, i = 0; i < n_senone_active; ++i) { n += senone_active[i]; s->active[s->sen2mgau[n]] = 1; }
+    }
+    for (m = 0; m < s->n_mgau; ++m)
+        if (s->active[m])
+            for (f = 0; f < s->n_feat; ++f)
+                ms_topn(s, m, f, feat + s->featoff[f], s->dist + m * L + (size_t)f * s->topn);
+    if (compallsen) n_senone_active = s->n_sen;
+    for (n = 0, i = 0; i < n_senone_active; ++i) {
+        int sen = compallsen ? i : (n += senone_active[i]);
+        senscr[sen] = (int16_t)ms_senone(s, sen, s->dist + s->sen2mgau[sen] * L);
+        if (best > senscr[sen]) best = senscr[sen];
+    }
+    for (n = 0, i = 0; i < n_senone_active; ++i) {
+        int sen = compallsen ? i : (n += senone_active[i]);
+        int bs = senscr[sen] - best;
+        if (bs > 32767) bs = 32767;
+        if (bs < -32768) bs = -32768;
+        senscr[sen] = (int16_t)bs;
+    }
+    return 0;
+}
+
+/* ================================================================== */
 /* acmod_flags2list (acmod.c:1223-1275)                                */
 /* ================================================================== */
 int

@@ -107,6 +107,30 @@ int pso_semi_frame_eval(pso_semi_t *s, int16_t *senscr,
 /* current slot: lists [n_feat][topn] and the per-stream counts topn_hist_n */
 const pso_topn_t *pso_semi_cur_topn(const pso_semi_t *s, uint8_t *n_used);
 
+/* ---------------- multi-stream / continuous scorer (ms_mgau.c, ms_gauden.c, ms_senone.c) ------ */
+
+typedef struct pso_ms_s pso_ms_t;
+
+/*  mean/var : packed [n_mgau][n_feat][n_density][featlen[f]]   (ms_gauden.c:211-221)
+ *  det      : [n_mgau][n_feat][n_density]
+ *  pdf      : senone mixture weights in the canonical order [n_sen][n_feat][n_density]
+ *             (the reference keeps [feat][cw][sen] when there is one codebook,
+ *             ms_senone.c:198-209; the caller transposes)
+ *  sen2mgau : [n_sen] codebook of each senone                   (ms_senone.c:283-320)
+ *  logadd   : the add table of senone_t.lmath = logmath_init(base, SENSCR_SHIFT, 1)
+ *             (ms_senone.c:276), entries of `logadd_width` bytes; log_zero = lmath->zero */
+pso_ms_t *pso_ms_new(int n_mgau, int n_feat, int n_density, const int32_t *featlen,
+                     int n_sen, int topn, int aw,
+                     const float *mean, const float *var, const float *det,
+                     const uint8_t *pdf, const uint32_t *sen2mgau,
+                     const void *logadd, int logadd_size, int logadd_width, int32_t log_zero);
+void pso_ms_free(pso_ms_t *s);
+/* ms_cont_mgau_frame_eval (ms_mgau.c:191-282).  senscr is IN/OUT: entries of
+ * unlisted senones keep their previous contents, as in the reference. */
+int pso_ms_frame_eval(pso_ms_t *s, int16_t *senscr,
+                      const uint8_t *senone_active, int32_t n_senone_active,
+                      const float *feat, int32_t compallsen);
+
 /* ---------------- shared helpers ---------------- */
 
 /* acmod_flags2list (acmod.c:1223-1275): bit flags -> uint8 delta list.

@@ -319,6 +319,66 @@ cmd_tables_semi(ps_decoder_t *ps)
 }
 
 /* ------------------------------------------------------------------ */
+/* model tables of the multi-stream / continuous scorer (ms_mgau_init) */
+static int
+cmd_tables_ms(ps_decoder_t *ps)
+{
+    acmod_t *acmod = ps->acmod;
+    ms_mgau_model_t *msg = (ms_mgau_model_t *)acmod->mgau;
+    gauden_t *g;
+    senone_t *sn;
+    int32_t m, f, d, i;
+    int64_t tot = 0, o = 0, od = 0;
+    float *mean, *var, *det;
+
+    if (strcmp(acmod->mgau->vt->name, "ms") != 0) {
+        fprintf(stderr, "not an ms model (%s)\n", acmod->mgau->vt->name); return 2;
+    }
+    g = msg->g; sn = msg->s;
+    puti("n_mgau", g->n_mgau); puti("n_feat", g->n_feat); puti("n_density", g->n_density);
+    put1("featlen", 'i', g->n_feat, g->featlen);
+    puti("n_sen", (int32_t)sn->n_sen); puti("max_topn", msg->topn); puti("aw", sn->aw);
+    puti("n_gauden", (int32_t)sn->n_gauden);
+    for (f = 0; f < g->n_feat; ++f) tot += g->featlen[f];
+    mean = malloc(sizeof(float) * g->n_mgau * g->n_density * tot);
+    var = malloc(sizeof(float) * g->n_mgau * g->n_density * tot);
+    det = malloc(sizeof(float) * g->n_mgau * g->n_feat * g->n_density);
+    for (m = 0; m < g->n_mgau; ++m)
+        for (f = 0; f < g->n_feat; ++f)
+            for (d = 0; d < g->n_density; ++d) {
+                memcpy(mean + o, g->mean[m][f][d], sizeof(float) * g->featlen[f]);
+                memcpy(var + o, g->var[m][f][d], sizeof(float) * g->featlen[f]);
+                o += g->featlen[f];
+                det[od++] = g->det[m][f][d];
+            }
+    put1("mean", 'f', o, mean); put1("var", 'f', o, var);
+    put3("det", 'f', g->n_mgau, g->n_feat, g->n_density, det);
+    free(mean); free(var); free(det);
+    {
+        /* canonical [sen][feat][cw], whatever the in-memory transposition (ms_senone.c:198-209) */
+        uint8 *pdf = malloc((size_t)sn->n_sen * sn->n_feat * sn->n_cw);
+        uint32_t *map = malloc(sizeof(uint32_t) * sn->n_sen);
+        for (i = 0; (uint32)i < sn->n_sen; ++i) {
+            for (f = 0; (uint32)f < sn->n_feat; ++f)
+                for (d = 0; (uint32)d < sn->n_cw; ++d)
+                    pdf[((size_t)i * sn->n_feat + f) * sn->n_cw + d] =
+                        (sn->n_gauden > 1) ? sn->pdf[i][f][d] : sn->pdf[f][d][i];
+            map[i] = sn->mgau[i];
+        }
+        put3("pdf", 'B', sn->n_sen, sn->n_feat, sn->n_cw, pdf);
+        put1("sen2mgau", 'i', sn->n_sen, map);
+        free(pdf); free(map);
+    }
+    {
+        logadd_t *t = LOGMATH_TABLE(sn->lmath);
+        puti("logadd_width", t->width); puti("logadd_size", (int32_t)t->table_size);
+        put1("logadd", 'B', (int64_t)t->table_size * t->width, t->table);
+        puti("log_zero", logmath_get_zero(sn->lmath));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 static int
 cmd_feats(ps_decoder_t *ps, const char *rawpath)
 {
@@ -668,7 +728,9 @@ main(int argc, char **argv)
         if (strcmp(argv[i], "--") == 0) { xa = i; extra = argv + i + 1; nextra = argc - i - 1; break; }
     err_set_loglevel(ERR_ERROR);
     psgb_open(out);
-    if (!strcmp(cmd, "tables_semi")) {
+    if (!strcmp(cmd, "tables_ms")) {
+        rc = cmd_tables_ms(make_decoder(modeldir, lm, dict, nextra, extra));
+    } else if (!strcmp(cmd, "tables_semi")) {
         rc = cmd_tables_semi(make_decoder(modeldir, lm, dict, nextra, extra));
     } else if (!strcmp(cmd, "tables")) {
         rc = cmd_tables(make_decoder(modeldir, lm, dict, nextra, extra));

@@ -257,3 +257,44 @@ def senlog_params(g):
     """topn / ds / topn_beam / ... overrides a senlog fixture was recorded with."""
     e = [str(x) for x in g["extra"]]
     return dict(zip(e[0::2], e[1::2]))
+
+
+class OracleMs:
+    """Wrapper around pso_ms_t (restates ms_mgau.c / ms_gauden.c / ms_senone.c).
+    `senscr` is a persistent in/out buffer like acmod->senone_scores."""
+
+    def __init__(self, t, topn=None, aw=None):
+        L = lib()
+        vp, i32 = C.c_void_p, C.c_int32
+        L.pso_ms_new.restype = vp
+        L.pso_ms_new.argtypes = [i32, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32]
+        L.pso_ms_free.argtypes = [vp]
+        L.pso_ms_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32]
+        self.n_mgau = int(t["n_mgau"][0]); self.n_feat = int(t["n_feat"][0])
+        self.n_density = int(t["n_density"][0]); self.n_sen = int(t["n_sen"][0])
+        self.topn = min(int(topn if topn is not None else t["max_topn"][0]), self.n_density)
+        self.aw = int(aw if aw is not None else t["aw"][0])
+        self._keep = dict(
+            featlen=np.ascontiguousarray(t["featlen"], np.int32),
+            mean=np.ascontiguousarray(t["mean"], np.float32), var=np.ascontiguousarray(t["var"], np.float32),
+            det=np.ascontiguousarray(t["det"], np.float32), pdf=np.ascontiguousarray(t["pdf"], np.uint8),
+            map=np.ascontiguousarray(t["sen2mgau"], np.uint32), logadd=np.ascontiguousarray(t["logadd"], np.uint8))
+        k = self._keep
+        self.h = L.pso_ms_new(self.n_mgau, self.n_feat, self.n_density, _p(k["featlen"]), self.n_sen,
+                              self.topn, self.aw, _p(k["mean"]), _p(k["var"]), _p(k["det"]), _p(k["pdf"]),
+                              _p(k["map"]), _p(k["logadd"]), int(t["logadd_size"][0]),
+                              int(t["logadd_width"][0]), int(t["log_zero"][0]))
+        self.senscr = np.zeros(self.n_sen, np.int16)
+
+    def __del__(self):
+        try:
+            lib().pso_ms_free(self.h)
+        except Exception:
+            pass
+
+    def frame_eval(self, feat, active=None, compallsen=True):
+        feat = np.ascontiguousarray(feat, np.float32)
+        act = np.ascontiguousarray(active, np.uint8) if active is not None else None
+        lib().pso_ms_frame_eval(self.h, _p(self.senscr), _p(act), 0 if act is None else act.size,
+                                _p(feat), int(bool(compallsen)))
+        return self.senscr.copy()

@@ -163,3 +163,30 @@ def test_semi_senlog_replay(case):
         hashes[c] = pso.row_hash(scr[None, :])[0]
     bad = np.nonzero(hashes != g["call_scr_hash"])[0]
     assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
+
+
+MS_CASES = [("ms_an4_default", "ms_an4_tables"), ("ms_an4_compall_aw2", "ms_an4_tables"),
+            ("ms_en_us_default", "ms_en_us_tables"), ("ms_en_us_topn2_call", "ms_en_us_tables")]
+
+
+@pytest.mark.parametrize("case,tab", MS_CASES)
+def test_ms_senlog_replay(case, tab):
+    """pso_ms_frame_eval vs every ms_cont_mgau_frame_eval call of real decodes:
+    an4_ci_cont (1 density/codebook: compute_dist_all) and en-us forced through the
+    ms scorer (42 codebooks x 3 streams x 128 densities: the top-N scan), incl.
+    aw 2, topn 2, compallsen.  The score buffer persists between calls (unlisted
+    senones keep stale values in the reference)."""
+    g = _load("senlog_%s.npz" % case)
+    t = _load("%s.npz" % tab)
+    p = pso.senlog_params(g)
+    o = pso.OracleMs(t, topn=int(p["topn"]) if "topn" in p else None, aw=int(p["aw"]) if "aw" in p else None)
+    off = g["call_act_off"]
+    n = int(g["call_frame"].size)
+    hashes = np.empty(n, np.uint64)
+    for c in range(n):
+        na = int(g["call_nact"][c])
+        act = None if na < 0 else g["call_act"][off[c]:off[c] + na]
+        scr = o.frame_eval(g["call_feat"][c], active=act, compallsen=(na < 0))
+        hashes[c] = pso.row_hash(scr[None, :])[0]
+    bad = np.nonzero(hashes != g["call_scr_hash"])[0]
+    assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
