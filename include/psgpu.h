@@ -221,6 +221,55 @@ int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, 
 int psgpu_semi_state_set_topn(psgpu_semi_state_t *s, int32_t slot, const int32_t *cw,
                               const int32_t *score, const int32_t *n_used);
 
+/* ---- multi-stream / continuous scorer ("ms") ----------------------------------
+ * Replaces ms_cont_mgau_frame_eval() (ms_mgau.c:191-282): gauden_dist() /
+ * compute_dist() (ms_gauden.c:424-509) + senone_eval() (ms_senone.c:357-407).
+ * Tables as ms_mgau_init() holds them (ms_mgau.c:80-160):
+ *   mean/var  packed [n_mgau][n_feat][n_density][featlen[f]], var precomputed
+ *   det       [n_mgau][n_feat][n_density]
+ *   pdf       senone weights (senprob_t) in the canonical order
+ *             [n_sen][n_feat][n_density]; the reference keeps [feat][cw][sen] when
+ *             there is a single codebook (ms_senone.c:198-209) -- transpose first
+ *   sen2mgau  [n_sen] senone_t.mgau (ms_senone.c:283-320)
+ *   logadd    add table of senone_t.lmath (= logmath_init(base, SENSCR_SHIFT, 1),
+ *             ms_senone.c:276): logadd_size entries of logadd_width (1|2|4) bytes;
+ *             log_zero = logmath_get_zero() of the same object
+ *   topn      msg->topn (already clamped to n_density, ms_mgau.c:141-147); aw = senone_t.aw
+ * The model object also carries the per-decoder state of the per-call entry
+ * (msg->dist: list ids persist between calls, ms_gauden.c:438-440).
+ *
+ * psgpu_ms_frame_eval: senscr is IN/OUT -- only listed senones are written,
+ * exactly as the reference leaves stale values in unlisted entries.  There is no
+ * frame / frame_idx: the scorer is stateless in time (ms_mgau.c:207). */
+typedef struct psgpu_ms_model_s psgpu_ms_model_t;
+
+int psgpu_ms_model_create(psgpu_ms_model_t **out, int32_t n_mgau, int32_t n_feat, int32_t n_density,
+                          const int32_t *featlen, int32_t n_sen, int32_t topn, int32_t aw,
+                          const float *mean, const float *var, const float *det,
+                          const uint8_t *pdf, const uint32_t *sen2mgau,
+                          const void *logadd, int32_t logadd_size, int32_t logadd_width,
+                          int32_t log_zero);
+void psgpu_ms_model_free(psgpu_ms_model_t *m);
+int32_t psgpu_ms_n_sen(const psgpu_ms_model_t *m);
+int32_t psgpu_ms_veclen(const psgpu_ms_model_t *m);
+int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
+                        const uint8_t *senone_active, int32_t n_senone_active,
+                        const float *feat, int32_t compallsen);
+/* Batched compallsen scoring of total_frames independent frames (frames of any
+ * number of utterances back to back: the scorer has no time dependence).
+ *  list_id_dev / list_dist_dev  [total_frames][n_mgau][n_feat][topn] int32 / fp32:
+ *                               the top-N lists (output and workspace)
+ *  senscr_dev                   [total_frames][n_sen] int16, or NULL to stop after
+ *                               the top-N kernel
+ * psgpu_ms_batch_check() synchronises `stream` and returns PSGPU_ESTATE if some
+ * frame had fewer than topn densities above WORST_DIST (see above). */
+int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
+                             int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
+                             void *stream);
+int psgpu_ms_batch_check(psgpu_ms_model_t *m, void *stream);
+/* host-buffer convenience wrapper (allocates, copies, runs, checks, copies back) */
+int psgpu_ms_score_batch(psgpu_ms_model_t *m, const float *feats, int32_t total_frames, int16_t *senscr);
+
 /* ---- HMM Viterbi step ----------------------------------------------------
  * Replaces hmm_vit_eval() (hmm.c:786-805) and its hard-wired variants
  * hmm_vit_eval_3st_lr[_mpx] (:529-707) / _5st_lr[_mpx] (:222-525) for whole

@@ -27,7 +27,9 @@
 #include "acmod.h"
 #include "ptm_mgau.h"
 #include "s2_semi_mgau.h"
+#include "ms_mgau.h"
 #include "ms_gauden.h"
+#include "ms_senone.h"
 #include "tied_mgau_common.h"
 
 #include "psgpu.h"
@@ -47,6 +49,8 @@ typedef struct psgpu_mgau_s {
     psgpu_ptm_state_t *state;
     psgpu_semi_model_t *smodel;
     psgpu_semi_state_t *sstate;
+    ms_mgau_model_t *cpu_ms;      /* ... or ("ms") */
+    psgpu_ms_model_t *mmodel;
     float *vec;                   /* one frame, streams concatenated */
     int n_feat;
     int veclen;
@@ -308,6 +312,131 @@ semi_free(ps_mgau_t *ps)
     ckd_free(g);
 }
 
+/* ---- "ms": tables of ms_mgau_init() (ms_mgau.c:80-160) ---- */
+static int ms_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
+                         int32 n_senone_active, mfcc_t **feat, int32 frame, int32 compallsen);
+static int ms_transform(ps_mgau_t *ps, ps_mllr_t *mllr);
+static void ms_free(ps_mgau_t *ps);
+
+static ps_mgaufuncs_t psgpu_ms_funcs = {
+    "ms-psgpu",
+    ms_frame_eval,
+    ms_transform,
+    ms_free
+};
+
+static int
+ms_upload_model(psgpu_mgau_t *g)
+{
+    ms_mgau_model_t *msg = g->cpu_ms;
+    gauden_t *gd = msg->g;
+    senone_t *sn = msg->s;
+    logadd_t *la = LOGMATH_TABLE(sn->lmath);
+    size_t tot = 0, o = 0, od = 0;
+    float *mean, *var, *det;
+    uint8 *pdf;
+    int m, f, d, rc;
+    uint32 i;
+
+    for (f = 0; f < gd->n_feat; ++f)
+        tot += (size_t)gd->featlen[f];
+    tot *= (size_t)gd->n_mgau * gd->n_density;
+    mean = ckd_calloc(tot, sizeof(float));
+    var = ckd_calloc(tot, sizeof(float));
+    det = ckd_calloc((size_t)gd->n_mgau * gd->n_feat * gd->n_density, sizeof(float));
+    for (m = 0; m < gd->n_mgau; ++m)
+        for (f = 0; f < gd->n_feat; ++f)
+            for (d = 0; d < gd->n_density; ++d) {
+                memcpy(mean + o, gd->mean[m][f][d], sizeof(float) * gd->featlen[f]);
+                memcpy(var + o, gd->var[m][f][d], sizeof(float) * gd->featlen[f]);
+                o += gd->featlen[f];
+                det[od++] = gd->det[m][f][d];
+            }
+    /* canonical [sen][feat][cw] whatever the in-memory transposition (ms_senone.c:198-209) */
+    pdf = ckd_malloc((size_t)sn->n_sen * sn->n_feat * sn->n_cw);
+    for (i = 0; i < sn->n_sen; ++i)
+        for (f = 0; (uint32)f < sn->n_feat; ++f)
+            for (d = 0; (uint32)d < sn->n_cw; ++d)
+                pdf[((size_t)i * sn->n_feat + f) * sn->n_cw + d] =
+                    (sn->n_gauden > 1) ? sn->pdf[i][f][d] : sn->pdf[f][d][i];
+    if (g->mmodel)
+        psgpu_ms_model_free(g->mmodel);
+    g->mmodel = NULL;
+    rc = psgpu_ms_model_create(&g->mmodel, gd->n_mgau, gd->n_feat, gd->n_density, gd->featlen,
+                               (int32_t)sn->n_sen, msg->topn, sn->aw, mean, var, det, pdf, sn->mgau,
+                               la->table, (int32_t)la->table_size, la->width,
+                               logmath_get_zero(sn->lmath));
+    ckd_free(mean); ckd_free(var); ckd_free(det); ckd_free(pdf);
+    if (rc != PSGPU_OK) {
+        E_ERROR("psgpu_ms_model_create failed (%d): %s\n", rc, psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+static ps_mgau_t *
+ms_wrap(ps_mgau_t *cpu_mgau)
+{
+    psgpu_mgau_t *g = ckd_calloc(1, sizeof(*g));
+    int f;
+
+    g->base.vt = &psgpu_ms_funcs;
+    g->base.frame_idx = cpu_mgau->frame_idx;
+    g->cpu_ms = (ms_mgau_model_t *)cpu_mgau;
+    g->n_feat = g->cpu_ms->g->n_feat;
+    for (f = 0; f < g->n_feat; ++f)
+        g->veclen += g->cpu_ms->g->featlen[f];
+    g->vec = ckd_calloc(g->veclen, sizeof(float));
+    if (ms_upload_model(g) < 0) {
+        ckd_free(g->vec);
+        ckd_free(g);
+        return NULL;
+    }
+    return (ps_mgau_t *)g;
+}
+
+static int
+ms_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
+              int32 n_senone_active, mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    gauden_t *gd = g->cpu_ms->g;
+    int f, o = 0, rc;
+
+    (void)frame;                                     /* ms_mgau.c:207 */
+    for (f = 0; f < g->n_feat; ++f) {
+        memcpy(g->vec + o, feat[f], sizeof(float) * gd->featlen[f]);
+        o += gd->featlen[f];
+    }
+    rc = psgpu_ms_frame_eval(g->mmodel, senscr, senone_active, n_senone_active, g->vec, compallsen);
+    ++g->n_calls;
+    if (rc != PSGPU_OK) {
+        E_ERROR("psgpu_ms_frame_eval failed (%d): %s\n", rc, psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+static int
+ms_transform(ps_mgau_t *ps, ps_mllr_t *mllr)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    int rc = ps_mgau_transform(ps_mgau_base(g->cpu_ms), mllr);
+    if (rc < 0)
+        return rc;
+    return ms_upload_model(g);       /* list ids restart at 0 like a fresh msg->dist */
+}
+
+static void
+ms_free(ps_mgau_t *ps)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    if (g->mmodel) psgpu_ms_model_free(g->mmodel);
+    if (g->cpu_ms) ps_mgau_free(ps_mgau_base(g->cpu_ms));
+    ckd_free(g->vec);
+    ckd_free(g);
+}
+
 ps_mgau_t *
 psgpu_mgau_wrap(ps_mgau_t *cpu_mgau)
 {
@@ -317,8 +446,10 @@ psgpu_mgau_wrap(ps_mgau_t *cpu_mgau)
 
     if (cpu_mgau != NULL && strcmp(cpu_mgau->vt->name, "s2_semi") == 0)
         return semi_wrap(cpu_mgau);
+    if (cpu_mgau != NULL && strcmp(cpu_mgau->vt->name, "ms") == 0)
+        return ms_wrap(cpu_mgau);
     if (cpu_mgau == NULL || strcmp(cpu_mgau->vt->name, "ptm") != 0) {
-        E_ERROR("psgpu: only the \"ptm\" and \"s2_semi\" scorers can be wrapped (got \"%s\")\n",
+        E_ERROR("psgpu: only the \"ptm\", \"s2_semi\" and \"ms\" scorers can be wrapped (got \"%s\")\n",
                 cpu_mgau ? cpu_mgau->vt->name : "(null)");
         return NULL;
     }
@@ -361,7 +492,7 @@ psgpu_mgau_attach(ps_decoder_t *ps)
 int32
 psgpu_mgau_n_calls(ps_mgau_t *ps)
 {
-    if (ps == NULL || (ps->vt != &psgpu_mgau_funcs && ps->vt != &psgpu_semi_funcs))
+    if (ps == NULL || (ps->vt != &psgpu_mgau_funcs && ps->vt != &psgpu_semi_funcs && ps->vt != &psgpu_ms_funcs))
         return -1;
     return ((psgpu_mgau_t *)ps)->n_calls;
 }

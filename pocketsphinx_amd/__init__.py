@@ -13,5 +13,6 @@ from .capi import PsgpuError, lib, build_library, LIB_PATH  # noqa: F401
 from .ptm import PtmModel, PtmMgau, PtmState  # noqa: F401
 from .hmm import HmmContext, HMM_REC  # noqa: F401
 from .semi import SemiMgau  # noqa: F401
+from .ms import MsMgau  # noqa: F401
 
-__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau"]
+__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau"]

@@ -1,0 +1,464 @@
+// psgpu_ms.hip -- the multi-stream / continuous-density scorer: device
+// replacement of ms_cont_mgau_frame_eval() (reference src/ms_mgau.c:191-282)
+// = gauden_dist()/compute_dist() (ms_gauden.c:424-509) + senone_eval()
+// (ms_senone.c:357-407) + the best-score normalisation.
+//
+// Differences from the tied-mixture scorers that shape the kernels:
+//   * top-N is STATELESS per frame (list reset to WORST_DIST, ms_gauden.c:438)
+//     and keeps FLOAT distances; the sequential scan's result is the N largest
+//     (dist, id) pairs in descending lexicographic order among densities with
+//     dist >= WORST_DIST, so it is selected with N wave-wide arg-max rounds on
+//     an order-preserving 64-bit key -- no history, frames are independent;
+//   * unfilled list slots keep WORST_DIST and whatever id the slot held before
+//     (the reference never clears ids): the per-call state keeps the lists in
+//     HBM between calls; the batch entry reports such frames instead of
+//     guessing (PSGPU_ESTATE);
+//   * n_top >= n_density skips selection: every density, in index order
+//     (compute_dist_all, :377-417);
+//   * senone scores: fden = ((int32)dist + 1023) >> 10, 16-bit-domain
+//     logmath_add through the senone log-add table (util/logmath.c:401-446),
+//     `/ aw`, int16 clamp BEFORE and AFTER the best-score subtraction, and only
+//     LISTED senones are written (unlisted entries of senscr keep stale values).
+//
+// Kernel 1: one wavefront per (frame, codebook, stream); densities on lanes
+// (k*64 + lane, n_density <= 256).  Kernel 2: one workgroup per frame.
+#include "psgpu_internal.h"
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+
+constexpr int kMsMaxFeat = 8;
+constexpr int kMsMaxTopn = 8;
+constexpr int kMsK = 4;
+constexpr int kMsLaLds = 4096;           // log-add entries kept in LDS (int32)
+
+struct MsDev {
+    const float *mean, *var, *det;
+    const uint8_t *pdf;                  // [n_sen][n_feat][n_density]
+    const int32_t *sen2mgau;
+    const int32_t *logadd;               // widened to int32
+    int32_t n_mgau, n_feat, n_density, n_sen, topn, aw, veclen, logadd_size, log_zero;
+    int32_t featlen[kMsMaxFeat], featoff[kMsMaxFeat];
+    const int64_t *cboff;                // [n_mgau * n_feat] float offset into mean/var
+};
+
+struct psgpu_ms_model_s {
+    MsDev d;
+    float *mean, *var, *det;
+    uint8_t *pdf;
+    int32_t *sen2mgau, *logadd;
+    int64_t *cboff;
+    int32_t *h_sen2mgau;
+    // per-call state (persistent lists, ms_mgau.c:150-152 msg->dist)
+    int32_t *list_id; float *list_dist;  // [n_mgau][n_feat][topn]
+    uint8_t *h_active, *d_active;        // mapped: active codebooks
+    float *h_feat, *d_feat;              // mapped: one frame
+    uint16_t *h_list, *d_list;           // mapped: listed senone ids
+    int16_t *h_out, *d_out;              // mapped: scores of listed senones (list order) / all
+    int32_t *d_flag;
+    hipStream_t stream;
+};
+
+// order-preserving map float -> uint32 (larger float = larger key)
+__device__ __forceinline__ uint32_t fkey(float f)
+{
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1: top-N float distances of one (frame, codebook, stream)
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256)
+void ms_topn_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
+                    const uint8_t *__restrict__ active,           // [n_mgau] or nullptr (all)
+                    int32_t *__restrict__ list_id, float *__restrict__ list_dist,
+                    int64_t frame_stride,                         // entries between frames (0: per-call state)
+                    int32_t *__restrict__ flag)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6));
+    const int per_frame = p.n_mgau * p.n_feat;
+    if (wave >= (long long)n_frames * per_frame)
+        return;
+    const int t = (int)(wave / per_frame);
+    const int c = (int)(wave - (long long)t * per_frame);
+    const int m = c / p.n_feat, f = c - m * p.n_feat;
+    if (active && !active[m])
+        return;
+    const int len = p.featlen[f];
+    const float *mean = p.mean + p.cboff[c], *var = p.var + p.cboff[c];
+    const float *det = p.det + (size_t)c * p.n_density;
+    const float *x = feats + (size_t)t * p.veclen + p.featoff[f];
+    float d[kMsK];
+#pragma unroll
+    for (int k = 0; k < kMsK; ++k) {
+        const int cw = min(k * 64 + lane, p.n_density - 1);
+        const float *mp = mean + (size_t)cw * len, *vp = var + (size_t)cw * len;
+        float acc = det[cw];
+        for (int j = 0; j < len; ++j) {
+            // dval -= diff * diff * v[i]  (ms_gauden.c:405-408, :452-455): every op rounded, no FMA
+            const float diff = __fsub_rn(x[j], mp[j]);
+            acc = __fsub_rn(acc, __fmul_rn(__fmul_rn(diff, diff), vp[j]));
+        }
+        d[k] = acc;
+    }
+    int32_t *oid = list_id + (size_t)t * frame_stride + (size_t)c * N;
+    float *odist = list_dist + (size_t)t * frame_stride + (size_t)c * N;
+    if (N >= p.n_density) {
+        // compute_dist_all: every density in index order (n_density <= N <= 8 lanes)
+        if (lane < p.n_density) { oid[lane] = lane; odist[lane] = d[0]; }
+        return;
+    }
+    // eligible: dval >= WORST_DIST (NaN never is)
+    unsigned long long key[kMsK];
+#pragma unroll
+    for (int k = 0; k < kMsK; ++k) {
+        const int cw = k * 64 + lane;
+        const bool ok = (cw < p.n_density) && (d[k] >= (float)kMaxNegInt32);
+        key[k] = ok ? (((unsigned long long)fkey(d[k]) << 32) | (uint32_t)cw) : 0ull;
+    }
+    int filled = 0;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        unsigned long long loc = key[0];
+#pragma unroll
+        for (int k = 1; k < kMsK; ++k) loc = key[k] > loc ? key[k] : loc;
+        const unsigned long long w = wave_max_u64(loc);
+        if (w != 0ull) {
+            const int cw = (int)(w & 0xffffffffu);
+            // the owner publishes the exact float and retires the candidate
+#pragma unroll
+            for (int k = 0; k < kMsK; ++k)
+                if (key[k] == w) { odist[r] = d[k]; oid[r] = cw; key[k] = 0ull; }
+            ++filled;
+        }
+        else if (lane == 0)
+            odist[r] = (float)kMaxNegInt32;          // id keeps its previous contents (ms_gauden.c:438-440)
+    }
+    if (filled < N && frame_stride != 0 && lane == 0 && flag)
+        atomicOr(flag, 1);                           // batch mode cannot know the stale ids
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2: senone_eval over the listed senones of one frame + normalisation
+// ---------------------------------------------------------------------------
+constexpr int kMsSenThreads = 1024;
+
+template <int N>
+__global__ __launch_bounds__(kMsSenThreads)
+void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *__restrict__ list,
+                      const int32_t *__restrict__ list_id, const float *__restrict__ list_dist,
+                      int64_t frame_stride, int16_t *__restrict__ out, int64_t out_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t s_scr[];      // [n]
+    __shared__ int32_t s_la[kMsLaLds];
+    __shared__ int32_t s_best;
+    const int tid = threadIdx.x;
+    const int frame = blockIdx.x;
+    const bool la_lds = p.logadd_size <= kMsLaLds;
+    if (la_lds)
+        for (int i = tid; i < p.logadd_size; i += kMsSenThreads) s_la[i] = p.logadd[i];
+    if (tid == 0) s_best = 0x7fffffff;
+    __syncthreads();
+    const int32_t *la = la_lds ? s_la : p.logadd;
+    const int n = compall ? p.n_sen : n_list;
+    const int L = p.n_feat * N;
+    const int ntop = min(N, p.n_density);
+    int32_t mybest = 0x7fffffff;
+    for (int i = tid; i < n; i += kMsSenThreads) {
+        const int sen = compall ? i : list[i];
+        const int cb = p.sen2mgau[sen];
+        const int32_t *ids = list_id + (size_t)frame * frame_stride + (size_t)cb * L;
+        const float *ds = list_dist + (size_t)frame * frame_stride + (size_t)cb * L;
+        int32_t scr = 0;
+        for (int f = 0; f < p.n_feat; ++f) {
+            const uint8_t *pdf = p.pdf + ((size_t)sen * p.n_feat + f) * p.n_density;
+            int32_t fscr = 0;
+            for (int t = 0; t < ntop; ++t) {
+                const float dv = ds[f * N + t];
+                const int32_t fden = (dv < (float)kMaxNegInt32)
+                    ? (kMaxNegInt32 >> kSenscrShift)
+                    : (((int32_t)dv + ((1 << kSenscrShift) - 1)) >> kSenscrShift);
+                const int32_t fw = fden - (int32_t)pdf[ids[f * N + t]];
+                if (t == 0) fscr = fw;
+                else {
+                    // logmath_add (util/logmath.c:401-446)
+                    if (fscr <= p.log_zero) fscr = fw;
+                    else if (fw > p.log_zero) {
+                        const int32_t r = max(fscr, fw);
+                        const int32_t dd = r - min(fscr, fw);
+                        fscr = (dd < 0 || dd >= p.logadd_size) ? r : r + la[dd];
+                    }
+                }
+            }
+            scr -= fscr;
+        }
+        scr /= p.aw;                                     // C division, truncates toward zero
+        scr = max(-32768, min(32767, scr));              // senone_eval's clamp + int16 store (ms_mgau.c:219)
+        s_scr[i] = scr;
+        mybest = min(mybest, scr);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mybest = min(mybest, __shfl_xor(mybest, off));
+    if ((tid & 63) == 0) atomicMin(&s_best, mybest);
+    __syncthreads();
+    const int32_t best = s_best;
+    int16_t *o = out + (size_t)frame * out_stride;
+    for (int i = tid; i < n; i += kMsSenThreads) {
+        int32_t bs = s_scr[i] - best;
+        bs = max(-32768, min(32767, bs));
+        o[i] = (int16_t)bs;                              // list order (per-call) / senone order (compall)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T>
+static int upl(T **dst, const T *src, size_t n)
+{
+    PSGPU_HIP(hipMalloc((void **)dst, n * sizeof(T) ? n * sizeof(T) : 1));
+    PSGPU_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PSGPU_OK;
+}
+
+static void launch_topn(const MsDev &d, const float *feats, int32_t T, const uint8_t *active,
+                        int32_t *ids, float *dist, int64_t stride, int32_t *flag, hipStream_t st)
+{
+    const long long waves = (long long)T * d.n_mgau * d.n_feat;
+    const int blocks = (int)((waves + 3) / 4);
+#define PSGPU_MS_TOPN(NN) case NN: hipLaunchKernelGGL((ms_topn_kernel<NN>), dim3(blocks), dim3(256), 0, st, \
+        d, feats, T, active, ids, dist, stride, flag); break;
+    switch (d.topn) {
+        PSGPU_MS_TOPN(1) PSGPU_MS_TOPN(2) PSGPU_MS_TOPN(3) PSGPU_MS_TOPN(4)
+        PSGPU_MS_TOPN(5) PSGPU_MS_TOPN(6) PSGPU_MS_TOPN(7) default: PSGPU_MS_TOPN(8)
+    }
+#undef PSGPU_MS_TOPN
+}
+
+static void launch_senone(const MsDev &d, int32_t T, int32_t compall, int32_t n_list, const uint16_t *list,
+                          const int32_t *ids, const float *dist, int64_t stride, int16_t *out,
+                          int64_t out_stride, hipStream_t st)
+{
+    const int n = compall ? d.n_sen : n_list;
+    const size_t smem = ((size_t)(n > 0 ? n : 1) * 4 + 15) / 16 * 16;
+#define PSGPU_MS_SEN(NN) case NN: hipLaunchKernelGGL((ms_senone_kernel<NN>), dim3(T), dim3(kMsSenThreads), smem, st, \
+        d, compall, n_list, list, ids, dist, stride, out, out_stride); break;
+    switch (d.topn) {
+        PSGPU_MS_SEN(1) PSGPU_MS_SEN(2) PSGPU_MS_SEN(3) PSGPU_MS_SEN(4)
+        PSGPU_MS_SEN(5) PSGPU_MS_SEN(6) PSGPU_MS_SEN(7) default: PSGPU_MS_SEN(8)
+    }
+#undef PSGPU_MS_SEN
+}
+
+extern "C" {
+
+int psgpu_ms_model_create(psgpu_ms_model_t **out, int32_t n_mgau, int32_t n_feat, int32_t n_density,
+                          const int32_t *featlen, int32_t n_sen, int32_t topn, int32_t aw,
+                          const float *mean, const float *var, const float *det,
+                          const uint8_t *pdf, const uint32_t *sen2mgau,
+                          const void *logadd, int32_t logadd_size, int32_t logadd_width, int32_t log_zero)
+{
+    PSGPU_REQUIRE(out && featlen && mean && var && det && pdf && sen2mgau && logadd,
+                  "psgpu_ms_model_create: NULL argument");
+    PSGPU_REQUIRE(n_mgau >= 1 && n_feat >= 1 && n_feat <= kMsMaxFeat, "n_mgau %d / n_feat %d unsupported", n_mgau, n_feat);
+    PSGPU_REQUIRE(n_density >= 1 && n_density <= 64 * kMsK, "n_density %d outside 1..%d", n_density, 64 * kMsK);
+    PSGPU_REQUIRE(topn >= 1 && (topn <= kMsMaxTopn), "topn %d outside 1..%d", topn, kMsMaxTopn);
+    PSGPU_REQUIRE(topn <= n_density, "topn %d > n_density %d (ms_mgau_init clamps it, ms_mgau.c:141-147)", topn, n_density);
+    PSGPU_REQUIRE(aw >= 1, "aw %d < 1", aw);
+    PSGPU_REQUIRE(n_sen > 0 && n_sen <= 32768, "n_sen %d outside 1..32768", n_sen);
+    PSGPU_REQUIRE(logadd_size >= 1 && (logadd_width == 1 || logadd_width == 2 || logadd_width == 4),
+                  "bad log-add table (size %d, width %d)", logadd_size, logadd_width);
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    psgpu_ms_model_t *m = new psgpu_ms_model_t();
+    memset(m, 0, sizeof *m);
+    MsDev &d = m->d;
+    d.n_mgau = n_mgau; d.n_feat = n_feat; d.n_density = n_density; d.n_sen = n_sen;
+    d.topn = topn; d.aw = aw; d.logadd_size = logadd_size; d.log_zero = log_zero;
+    std::vector<int64_t> cboff((size_t)n_mgau * n_feat);
+    int64_t o = 0;
+    for (int f = 0; f < n_feat; ++f) { d.featlen[f] = featlen[f]; d.featoff[f] = d.veclen; d.veclen += featlen[f]; }
+    for (int g = 0; g < n_mgau; ++g)
+        for (int f = 0; f < n_feat; ++f) { cboff[(size_t)g * n_feat + f] = o; o += (int64_t)n_density * featlen[f]; }
+    std::vector<int32_t> la((size_t)logadd_size), map((size_t)n_sen);
+    for (int i = 0; i < logadd_size; ++i)
+        la[i] = logadd_width == 1 ? ((const uint8_t *)logadd)[i]
+              : logadd_width == 2 ? ((const uint16_t *)logadd)[i] : (int32_t)((const uint32_t *)logadd)[i];
+    for (int i = 0; i < n_sen; ++i) {
+        if (sen2mgau[i] >= (uint32_t)n_mgau) {
+            psgpu_set_error("senone %d maps to codebook %u >= n_mgau %d", i, sen2mgau[i], n_mgau);
+            delete m;
+            return PSGPU_EINVAL;
+        }
+        map[i] = (int32_t)sen2mgau[i];
+    }
+    const size_t nlist = (size_t)n_mgau * n_feat * topn;
+    hipError_t e = hipSuccess;
+    if ((rc = upl(&m->mean, mean, (size_t)o)) || (rc = upl(&m->var, var, (size_t)o)) ||
+        (rc = upl(&m->det, det, (size_t)n_mgau * n_feat * n_density)) ||
+        (rc = upl(&m->pdf, pdf, (size_t)n_sen * n_feat * n_density)) ||
+        (rc = upl(&m->sen2mgau, map.data(), map.size())) ||
+        (rc = upl(&m->logadd, la.data(), la.size())) ||
+        (rc = upl(&m->cboff, cboff.data(), cboff.size()))) {
+        psgpu_ms_model_free(m);
+        return rc;
+    }
+    m->h_sen2mgau = (int32_t *)malloc(sizeof(int32_t) * n_sen);
+    memcpy(m->h_sen2mgau, map.data(), sizeof(int32_t) * n_sen);
+    e = hipMalloc((void **)&m->list_id, nlist * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(m->list_id, 0, nlist * sizeof(int32_t));     // ckd_calloc_3d (ms_mgau.c:150)
+    if (e == hipSuccess) e = hipMalloc((void **)&m->list_dist, nlist * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(m->list_dist, 0, nlist * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_flag, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(m->d_flag, 0, sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_active, (size_t)n_mgau, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_feat, (size_t)d.veclen * sizeof(float), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_list, (size_t)n_sen * sizeof(uint16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_out, (size_t)n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_active, m->h_active, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_feat, m->h_feat, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_list, m->h_list, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_out, m->h_out, 0);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        psgpu_set_error("psgpu_ms_model_create: %s", hipGetErrorString(e));
+        psgpu_ms_model_free(m);
+        return e == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP;
+    }
+    d.mean = m->mean; d.var = m->var; d.det = m->det; d.pdf = m->pdf;
+    d.sen2mgau = m->sen2mgau; d.logadd = m->logadd; d.cboff = m->cboff;
+    *out = m;
+    return PSGPU_OK;
+}
+
+void psgpu_ms_model_free(psgpu_ms_model_t *m)
+{
+    if (!m) return;
+    if (m->stream) hipStreamDestroy(m->stream);
+    hipFree(m->mean); hipFree(m->var); hipFree(m->det); hipFree(m->pdf);
+    hipFree(m->sen2mgau); hipFree(m->logadd); hipFree(m->cboff);
+    hipFree(m->list_id); hipFree(m->list_dist); hipFree(m->d_flag);
+    if (m->h_active) hipHostFree(m->h_active);
+    if (m->h_feat) hipHostFree(m->h_feat);
+    if (m->h_list) hipHostFree(m->h_list);
+    if (m->h_out) hipHostFree(m->h_out);
+    free(m->h_sen2mgau);
+    delete m;
+}
+
+int32_t psgpu_ms_n_sen(const psgpu_ms_model_t *m) { return m->d.n_sen; }
+int32_t psgpu_ms_veclen(const psgpu_ms_model_t *m) { return m->d.veclen; }
+
+int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
+                        const uint8_t *senone_active, int32_t n_senone_active,
+                        const float *feat, int32_t compallsen)
+{
+    PSGPU_REQUIRE(m && senscr && feat, "psgpu_ms_frame_eval: NULL argument");
+    PSGPU_REQUIRE(compallsen || n_senone_active == 0 || senone_active, "active list missing");
+    const MsDev &d = m->d;
+    int n_list = 0;
+    if (compallsen)
+        memset(m->h_active, 1, (size_t)d.n_mgau);
+    else {
+        memset(m->h_active, 0, (size_t)d.n_mgau);        // ms_mgau.c:238-249
+        int sen = 0;
+        for (int i = 0; i < n_senone_active; ++i) {
+            sen += senone_active[i];
+            if (sen >= d.n_sen) {
+                psgpu_set_error("active list runs past n_sen (%d >= %d)", sen, d.n_sen);
+                return PSGPU_EINVAL;
+            }
+            m->h_list[n_list++] = (uint16_t)sen;
+            m->h_active[m->h_sen2mgau[sen]] = 1;
+        }
+        if (n_list == 0)
+            return PSGPU_OK;                             // nothing listed: senscr untouched
+    }
+    memcpy(m->h_feat, feat, (size_t)d.veclen * sizeof(float));
+    launch_topn(d, m->d_feat, 1, m->d_active, m->list_id, m->list_dist, 0, nullptr, m->stream);
+    PSGPU_HIP(hipGetLastError());
+    launch_senone(d, 1, compallsen != 0, n_list, m->d_list, m->list_id, m->list_dist, 0, m->d_out, 0, m->stream);
+    PSGPU_HIP(hipGetLastError());
+    PSGPU_HIP(hipStreamSynchronize(m->stream));
+    if (compallsen)
+        memcpy(senscr, m->h_out, (size_t)d.n_sen * sizeof(int16_t));
+    else
+        for (int i = 0; i < n_list; ++i)                 // only listed senones are written (ms_mgau.c:252-277)
+            senscr[m->h_list[i]] = m->h_out[i];
+    return PSGPU_OK;
+}
+
+int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
+                             int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
+                             void *stream)
+{
+    PSGPU_REQUIRE(m && feats_dev && list_id_dev && list_dist_dev, "psgpu_ms_score_batch_dev: NULL argument");
+    PSGPU_REQUIRE(total_frames >= 0, "negative frame count");
+    if (total_frames == 0) return PSGPU_OK;
+    const MsDev &d = m->d;
+    const int64_t stride = (int64_t)d.n_mgau * d.n_feat * d.topn;
+    hipStream_t st = (hipStream_t)stream;
+    PSGPU_HIP(hipMemsetAsync(m->d_flag, 0, sizeof(int32_t), st));
+    launch_topn(d, feats_dev, total_frames, nullptr, list_id_dev, list_dist_dev, stride, m->d_flag, st);
+    PSGPU_HIP(hipGetLastError());
+    if (senscr_dev) {
+        launch_senone(d, total_frames, 1, 0, nullptr, list_id_dev, list_dist_dev, stride, senscr_dev, d.n_sen, st);
+        PSGPU_HIP(hipGetLastError());
+    }
+    return PSGPU_OK;
+}
+
+int psgpu_ms_batch_check(psgpu_ms_model_t *m, void *stream)
+{
+    PSGPU_REQUIRE(m != nullptr, "psgpu_ms_batch_check: NULL model");
+    int32_t flag = 0;
+    PSGPU_HIP(hipMemcpyAsync(&flag, m->d_flag, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PSGPU_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        psgpu_set_error("a frame had fewer than topn densities above WORST_DIST: the reference then reuses "
+                        "list ids of the previous call (ms_gauden.c:438-440), which only the per-call "
+                        "entry psgpu_ms_frame_eval reproduces");
+        return PSGPU_ESTATE;
+    }
+    return PSGPU_OK;
+}
+
+int psgpu_ms_score_batch(psgpu_ms_model_t *m, const float *feats, int32_t total_frames, int16_t *senscr)
+{
+    PSGPU_REQUIRE(m && feats && senscr && total_frames >= 0, "psgpu_ms_score_batch: bad argument");
+    if (total_frames == 0) return PSGPU_OK;
+    const MsDev &d = m->d;
+    const size_t nl = (size_t)total_frames * d.n_mgau * d.n_feat * d.topn;
+    float *df = nullptr, *dd = nullptr; int32_t *di = nullptr; int16_t *ds = nullptr;
+    auto cleanup = [&]() { hipFree(df); hipFree(dd); hipFree(di); hipFree(ds); };
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) {                 \
+        psgpu_set_error("%s -> %s", #call, hipGetErrorString(e_)); cleanup();          \
+        return e_ == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP; } } while (0)
+    TRY(hipMalloc((void **)&df, (size_t)total_frames * d.veclen * sizeof(float)));
+    TRY(hipMalloc((void **)&dd, nl * sizeof(float)));
+    TRY(hipMalloc((void **)&di, nl * sizeof(int32_t)));
+    TRY(hipMalloc((void **)&ds, (size_t)total_frames * d.n_sen * sizeof(int16_t)));
+    TRY(hipMemcpy(df, feats, (size_t)total_frames * d.veclen * sizeof(float), hipMemcpyHostToDevice));
+    int rc = psgpu_ms_score_batch_dev(m, df, total_frames, di, dd, ds, m->stream);
+    if (rc == PSGPU_OK) rc = psgpu_ms_batch_check(m, m->stream);
+    if (rc == PSGPU_OK)
+        TRY(hipMemcpy(senscr, ds, (size_t)total_frames * d.n_sen * sizeof(int16_t), hipMemcpyDeviceToHost));
+#undef TRY
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"
