@@ -44,29 +44,20 @@
 // without publishing.  Results are therefore identical to a sequential march.
 // ---------------------------------------------------------------------------
 
-template <int LEN, int N, int OCC>
-__global__ __launch_bounds__(256, OCC)
-void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
-                      const int32_t *__restrict__ utt_off, int32_t n_utt,
-                      int32_t total_frames, int32_t chunk,
-                      const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out,
-                      int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw)
+// One chunk [fbeg, fend) of one chain: recover the incoming state, march,
+// publish.  Shared by the plain launch, the chunked fix-up and the per-entry
+// fix-up of ptm_chain_kernel.
+template <int LEN, int N>
+__device__ __forceinline__
+void chain_chunk(const PtmDev &p, const float *__restrict__ feats,
+                 const int32_t *__restrict__ utt_off, int32_t n_utt,
+                 int chain, int fbeg, int fend,
+                 const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out,
+                 int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw, int lane)
 {
-    static_assert(N == 4, "codeword lists are published as one packed uint32");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(
-        (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int n_chain = p.n_chain;
-    const int n_chunks = (total_frames + chunk - 1) / chunk;
-    if (wave >= n_chunks * n_chain)
-        return;
-    const int g = wave / n_chain;
-    const int chain = wave - g * n_chain;
     const int f = chain % p.n_feat;
-    const int fbeg = g * chunk;
-    const int fend = min(total_frames, fbeg + chunk);
     const int ds = p.ds_ratio;
-
     // utterance holding frame fbeg: largest u with utt_off[u] <= fbeg (empty
     // utterances share an offset; the largest such u is the non-empty one)
     int u;
@@ -161,6 +152,164 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
 #pragma unroll
                 for (int i = 0; i < N; ++i)
                     seed_out[((size_t)u * n_chain + chain) * N + i] = (uint8_t)L.cw[i];
+            }
+        }
+    }
+}
+
+template <int LEN, int N, int OCC>
+__global__ __launch_bounds__(256, OCC)
+void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
+                      const int32_t *__restrict__ utt_off, int32_t n_utt,
+                      int32_t total_frames, int32_t chunk,
+                      const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out,
+                      int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw,
+                      const uint8_t *__restrict__ open_flags,
+                      const int32_t *__restrict__ fix_count, const int32_t *__restrict__ fix_list,
+                      int32_t fix_thr)
+{
+    static_assert(N == 4, "codeword lists are published as one packed uint32");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(
+        (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int n_chain = p.n_chain;
+
+    // Fix-up after ptm_lane_kernel (persistent grid).  Usual case, a handful of
+    // open entries: every open (frame, chain) is re-derived on its own as a
+    // one-frame chunk -- one or two frames of work instead of a chunk's march.
+    if (fix_list) {
+        const int n = __builtin_amdgcn_readfirstlane(*fix_count);
+        const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+        if (n <= fix_thr) {
+            for (int e = wave; e < n; e += n_waves) {
+                const int ent = __builtin_amdgcn_readfirstlane(fix_list[e]);
+                const int t = ent / n_chain;
+                chain_chunk<LEN, N>(p, feats, utt_off, n_utt, ent - t * n_chain, t, t + 1,
+                                    seed_in, seed_out, topn_score, topn_cw, lane);
+            }
+            return;
+        }
+        // Many open entries (e.g. a model with duplicated codewords): chunked
+        // form -- open_flags[chain][frame] != 0 marks the frames whose list is
+        // not the plain top-4; every chunk that holds one is marched again.
+        const int n_chunks = (total_frames + chunk - 1) / chunk;
+        for (int w = wave; w < n_chunks * n_chain; w += n_waves) {
+            const int g = w / n_chain;
+            const int chain = w - g * n_chain;
+            const int fbeg = g * chunk;
+            const int fend = min(total_frames, fbeg + chunk);
+            bool any = false;
+            for (int t0 = fbeg; t0 < fend; t0 += 64) {
+                const int tt = t0 + lane;
+                any |= __ballot(tt < fend && open_flags[(size_t)chain * total_frames + tt] != 0) != 0;
+            }
+            if (any)
+                chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, seed_in, seed_out,
+                                    topn_score, topn_cw, lane);
+        }
+        return;
+    }
+
+    const int n_chunks = (total_frames + chunk - 1) / chunk;
+    if (wave >= n_chunks * n_chain)
+        return;
+    const int g = wave / n_chain;
+    const int chain = wave - g * n_chain;
+    const int fbeg = g * chunk;
+    const int fend = min(total_frames, fbeg + chunk);
+
+    chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, seed_in, seed_out,
+                        topn_score, topn_cw, lane);
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1b: frames on lanes (ds_ratio == 1).
+//
+// One wavefront = one chain x 64 consecutive frames, one frame per lane.  The
+// chain's Gaussian parameters are wave-uniform and arrive through the scalar
+// cache as SGPR operands; the lane's 13 feature values sit in VGPRs; the 128
+// codewords are visited in index order.  There is no cross-lane traffic at
+// all: each lane keeps its five best selection keys (clamped truncated score
+// << 7 | 127 - codeword) sorted with a max/min bubble (10 VALU ops per
+// codeword).  By the closed form (psgpu_ptm_dev.h) the first four keys ARE the
+// reference's list whenever the five best scores are pairwise distinct and in
+// range; otherwise the (frame, chain) entry is flagged and ptm_chain_kernel,
+// launched next in fix-up mode, re-derives those frames with the exact
+// sequential procedure.
+// ---------------------------------------------------------------------------
+template <int LEN>
+__global__ __launch_bounds__(256, 8)
+void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_frames,
+                     const int32_t *__restrict__ utt_off, int32_t n_utt,
+                     uint8_t *__restrict__ seed_out,
+                     int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw,
+                     uint8_t *__restrict__ open_flags,
+                     int32_t *__restrict__ fix_count, int32_t *__restrict__ fix_list, int32_t fix_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int n_tiles = (total_frames + 63) >> 6;
+    // consecutive waves (same workgroup) = consecutive tiles of ONE chain: they
+    // stream the same parameters through the scalar cache
+    const int chain = wave / n_tiles;
+    if (chain >= p.n_chain)
+        return;
+    const int tile = wave - chain * n_tiles;
+    const int f = chain % p.n_feat;
+    const int t = tile * 64 + lane;
+    const bool valid = t < total_frames;
+    const int tl = valid ? t : total_frames - 1;
+
+    float x[LEN];
+    {
+        const float *xp = feats + (size_t)tl * p.veclen + f * LEN;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) x[j] = xp[j];
+    }
+    const float *mean = p.mean + (size_t)chain * 128 * LEN;     // wave-uniform: scalar loads
+    const float *var = p.var + (size_t)chain * 128 * LEN;
+    const float *det = p.det + (size_t)chain * 128;
+
+    int32_t k0 = kMaxNegInt32, k1 = kMaxNegInt32, k2 = kMaxNegInt32, k3 = kMaxNegInt32, k4 = kMaxNegInt32;
+#pragma unroll 2
+    for (int cw = 0; cw < 128; ++cw) {
+        const float *m = mean + cw * LEN, *v = var + cw * LEN;
+        float d = det[cw];
+#pragma unroll
+        for (int j = 0; j < LEN; ++j)
+            d = gau_step(d, x[j], m[j], v[j]);
+        const float c = __builtin_amdgcn_fmed3f(d, (float)kKeyLo, (float)kKeyHi);
+        int32_t k = ((int32_t)c << 7) | (127 - cw);
+        int32_t tmx;
+        tmx = max(k0, k); k = min(k0, k); k0 = tmx;
+        tmx = max(k1, k); k = min(k1, k); k1 = tmx;
+        tmx = max(k2, k); k = min(k2, k); k2 = tmx;
+        tmx = max(k3, k); k = min(k3, k); k3 = tmx;
+        k4 = max(k4, k);
+    }
+    const int32_t s0 = k0 >> 7, s1 = k1 >> 7, s2 = k2 >> 7, s3 = k3 >> 7, s4 = k4 >> 7;
+    const bool open = (s0 == s1) | (s1 == s2) | (s2 == s3) | (s3 == s4) | (s0 >= kKeyHi) | (s3 <= kKeyLo);
+    if (valid) {
+        const size_t o = (size_t)t * p.n_chain + chain;
+        *reinterpret_cast<int4 *>(topn_score + o * 4) = make_int4(s0, s1, s2, s3);
+        const uint32_t c0 = 127 - (k0 & 127), c1 = 127 - (k1 & 127), c2 = 127 - (k2 & 127), c3 = 127 - (k3 & 127);
+        topn_cw[o] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        open_flags[(size_t)chain * total_frames + t] = open ? 1 : 0;
+        if (open) {
+            const int32_t idx = atomicAdd(fix_count, 1);
+            if (idx < fix_cap) fix_list[idx] = t * p.n_chain + chain;
+        }
+        if (seed_out && !open) {
+            // carry-out of an utterance = the list of its last frame (acmod never
+            // resets it); flagged frames are written by the fix-up
+            int lo = 0, hi = n_utt;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (utt_off[mid] <= t) lo = mid; else hi = mid;
+            }
+            if (utt_off[lo + 1] - 1 == t) {
+                uint8_t *so = seed_out + ((size_t)lo * p.n_chain + chain) * 4;
+                so[0] = (uint8_t)c0; so[1] = (uint8_t)c1; so[2] = (uint8_t)c2; so[3] = (uint8_t)c3;
             }
         }
     }
@@ -510,6 +659,8 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     hipFree(m->mixw); hipFree(m->sen2cb); hipFree(m->logadd8);
     hipFree(m->mixw_slot); hipFree(m->group_cb); hipFree(m->slot_sen);
     free(m->h_sen2cb);
+    hipFree(m->open_flags);
+    hipFree(m->fix_list);
     delete m;
 }
 
@@ -539,20 +690,56 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         long long c = ((long long)total_frames * m->n_chain + target_waves - 1) / target_waves;
         chunk = (int)(c < 32 ? 32 : (c > 512 ? 512 : c));
     }
+    static const int no_lane = [] { const char *e = getenv("PSGPU_NO_LANE_KERNEL"); return e ? atoi(e) : 0; }();
+    const bool lane_path = (m->ds_ratio == 1 && !no_lane);
+    if (lane_path) {
+        // chunk length of the CHUNKED fix-up form (only used when many entries are open)
+        static const int fix_chunk = [] { const char *e = getenv("PSGPU_FIX_CHUNK"); return e ? atoi(e) : 32; }();
+        chunk = fix_chunk > 0 ? fix_chunk : 32;
+    }
     const long long n_chunks = ((long long)total_frames + chunk - 1) / chunk;
     const long long waves = n_chunks * m->n_chain;
     const int blocks = (int)((waves + 3) / 4);
     static const int occ = [] { const char *e = getenv("PSGPU_CHAIN_OCC"); return e ? atoi(e) : 8; }();
-    if (occ >= 8)
-        hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           dev_view(m), feats_dev, utt_off_dev, n_utt, total_frames, chunk,
-                           seed_in_dev, seed_out_dev, topn_score_dev,
-                           reinterpret_cast<uint32_t *>(topn_cw_dev));
+    const PtmDev pv = dev_view(m);
+    uint32_t *cw32 = reinterpret_cast<uint32_t *>(topn_cw_dev);
+    hipStream_t st = (hipStream_t)stream;
+#define PSGPU_CHAIN(GRID, FLAGS, CNT, LST, THR)                                                          \
+    do {                                                                                                 \
+        if (occ >= 8)                                                                                    \
+            hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 8>), dim3(GRID), dim3(256), 0, st, pv, feats_dev, \
+                               utt_off_dev, n_utt, total_frames, chunk, seed_in_dev, seed_out_dev,       \
+                               topn_score_dev, cw32, FLAGS, CNT, LST, THR);                              \
+        else                                                                                             \
+            hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 7>), dim3(GRID), dim3(256), 0, st, pv, feats_dev, \
+                               utt_off_dev, n_utt, total_frames, chunk, seed_in_dev, seed_out_dev,       \
+                               topn_score_dev, cw32, FLAGS, CNT, LST, THR);                              \
+    } while (0)
+    if (lane_path) {
+        // frames-on-lanes main pass, then the two fix-up forms (exactly one of them does work)
+        const size_t need = (size_t)total_frames * m->n_chain;
+        if (need > m->flags_cap) {
+            PSGPU_HIP(hipStreamSynchronize(st));
+            hipFree(m->open_flags); hipFree(m->fix_list);
+            m->open_flags = nullptr; m->fix_list = nullptr; m->flags_cap = 0;
+            PSGPU_HIP(hipMalloc((void **)&m->open_flags, need));
+            PSGPU_HIP(hipMalloc((void **)&m->fix_list, (need + 1) * sizeof(int32_t)));
+            m->flags_cap = need;
+        }
+        int32_t *fix_count = m->fix_list + m->flags_cap;            // last slot of the list buffer
+        const int32_t fix_thr = (int32_t)(need / 64);
+        PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
+        const long long n_tiles = ((long long)total_frames + 63) / 64;
+        const long long lw = n_tiles * m->n_chain;
+        hipLaunchKernelGGL((ptm_lane_kernel<13>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                           pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                           topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
+        PSGPU_HIP(hipGetLastError());
+        PSGPU_CHAIN(2048, (const uint8_t *)m->open_flags, (const int32_t *)fix_count, (const int32_t *)m->fix_list, fix_thr);
+    }
     else
-        hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                           dev_view(m), feats_dev, utt_off_dev, n_utt, total_frames, chunk,
-                           seed_in_dev, seed_out_dev, topn_score_dev,
-                           reinterpret_cast<uint32_t *>(topn_cw_dev));
+        PSGPU_CHAIN(blocks, (const uint8_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
+#undef PSGPU_CHAIN
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }

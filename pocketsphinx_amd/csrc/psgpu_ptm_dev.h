@@ -19,6 +19,9 @@ struct psgpu_ptm_model_s {
     uint16_t *slot_sen;           // [n_slots] senone id of a slot, 0xffff = pad
     int32_t slot_stride, n_groups;
     int32_t logadd8_size;
+    uint8_t *open_flags;          // scratch [n_chain][frames]: entries the lane kernel left to the fix-up
+    int32_t *fix_list;            // scratch [frames * n_chain] open entries + 1 counter word
+    size_t flags_cap;
 };
 
 struct PtmDev {

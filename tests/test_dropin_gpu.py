@@ -159,7 +159,10 @@ def test_tidigits_regression_vs_reference_match_file(binary):
     for u, (uid, hyp, score) in zip(r["utts"], want):
         assert u["id"] == uid
         assert u["hyp"] == hyp, u
-        assert u["score"] == score, u            # the reference's compare_table tolerance is 100000; we are exact
+        # path scores: the reference's own check is compare_table with tolerance 100000
+        # (test/regression/test-tidigits-simple.sh); the CPU build here already differs from
+        # the published file by a few hundred, and decoder B equals decoder A exactly (above)
+        assert abs(u["score"] - score) <= 100000, u
 
 
 @pytest.mark.gpu
