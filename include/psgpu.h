@@ -122,9 +122,13 @@ int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
                           int32_t *topn_score, uint8_t *topn_cw,
                           int16_t *senscr, int32_t *best, uint32_t flags);
 
-/* Per-kernel timing of the most recent psgpu_ptm_score_batch_dev call on
- * this model is NOT kept here; benchmarks bracket the call with HIP events
- * through the helpers below (events are recorded on the given stream). */
+/* Per-kernel timing of psgpu_ptm_score_batch_dev: when enabled, HIP events are
+ * recorded on the launch stream around the main top-N kernel, the exact
+ * fix-up launch and the senone kernel; psgpu_ptm_last_kernel_ms() waits for the
+ * most recent call and returns the three durations (ms).  Generic event
+ * helpers follow. */
+int psgpu_ptm_kernel_timing(psgpu_ptm_model_t *m, int32_t enable);
+int psgpu_ptm_last_kernel_ms(psgpu_ptm_model_t *m, float *ms3);
 int psgpu_event_create(void **ev);
 int psgpu_event_destroy(void *ev);
 int psgpu_event_record(void *ev, void *stream);

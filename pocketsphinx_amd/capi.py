@@ -16,7 +16,7 @@ SYMBOLS = [
     "psgpu_ptm_model_create", "psgpu_ptm_model_free", "psgpu_ptm_n_sen", "psgpu_ptm_n_chain",
     "psgpu_ptm_veclen", "psgpu_ptm_topn", "psgpu_ptm_score_batch_dev", "psgpu_ptm_score_batch",
     "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",
-    "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev",
+    "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev", "psgpu_ptm_kernel_timing", "psgpu_ptm_last_kernel_ms",
     "psgpu_ptm_state_create", "psgpu_ptm_state_free", "psgpu_ptm_state_reset",
     "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn",
     "psgpu_semi_model_create", "psgpu_semi_model_free", "psgpu_semi_state_create",
@@ -122,6 +122,8 @@ def lib():
     L.psgpu_hmm_n_emit_state.argtypes = [vp]
     L.psgpu_hmm_vit_eval_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp]
     L.psgpu_hmm_vit_eval.argtypes = [vp, vp, i32, vp, C.POINTER(i32)]
+    L.psgpu_ptm_kernel_timing.argtypes = [vp, i32]
+    L.psgpu_ptm_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.psgpu_event_create.argtypes = [C.POINTER(vp)]
     L.psgpu_event_destroy.argtypes = [vp]
     L.psgpu_event_record.argtypes = [vp, vp]

@@ -661,6 +661,7 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     free(m->h_sen2cb);
     hipFree(m->open_flags);
     hipFree(m->fix_list);
+    for (int i = 0; i < 4; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
     delete m;
 }
 
@@ -731,15 +732,20 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
         const long long n_tiles = ((long long)total_frames + 63) / 64;
         const long long lw = n_tiles * m->n_chain;
+        if (m->timing) hipEventRecord(m->ev[0], st);
         hipLaunchKernelGGL((ptm_lane_kernel<13>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
                            pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
                            topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
         PSGPU_HIP(hipGetLastError());
+        if (m->timing) hipEventRecord(m->ev[1], st);
         PSGPU_CHAIN(2048, (const uint8_t *)m->open_flags, (const int32_t *)fix_count, (const int32_t *)m->fix_list, fix_thr);
     }
-    else
+    else {
+        if (m->timing) { hipEventRecord(m->ev[0], st); hipEventRecord(m->ev[1], st); }
         PSGPU_CHAIN(blocks, (const uint8_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
+    }
 #undef PSGPU_CHAIN
+    if (m->timing) hipEventRecord(m->ev[2], st);
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
@@ -789,6 +795,25 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
     return PSGPU_OK;
 }
 
+int psgpu_ptm_kernel_timing(psgpu_ptm_model_t *m, int32_t enable)
+{
+    PSGPU_REQUIRE(m != nullptr, "psgpu_ptm_kernel_timing: NULL model");
+    if (enable && !m->ev[0])
+        for (int i = 0; i < 4; ++i) PSGPU_HIP(hipEventCreate(&m->ev[i]));
+    m->timing = enable ? 1 : 0;
+    return PSGPU_OK;
+}
+
+int psgpu_ptm_last_kernel_ms(psgpu_ptm_model_t *m, float *ms3)
+{
+    PSGPU_REQUIRE(m && ms3 && m->timing, "psgpu_ptm_last_kernel_ms: timing is not enabled");
+    PSGPU_HIP(hipEventSynchronize(m->ev[3]));
+    PSGPU_HIP(hipEventElapsedTime(&ms3[0], m->ev[0], m->ev[1]));    // main top-N kernel
+    PSGPU_HIP(hipEventElapsedTime(&ms3[1], m->ev[1], m->ev[2]));    // exact fix-up launch
+    PSGPU_HIP(hipEventElapsedTime(&ms3[2], m->ev[2], m->ev[3]));    // senone kernel
+    return PSGPU_OK;
+}
+
 int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
                               const float *feats_dev, const int32_t *utt_off_dev,
                               int32_t n_utt, int32_t total_frames,
@@ -800,8 +825,10 @@ int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
     int rc = psgpu_ptm_topn_dev(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev,
                                 seed_out_dev, topn_score_dev, topn_cw_dev, stream);
     if (rc != PSGPU_OK || senscr_dev == nullptr) return rc;
-    return psgpu_ptm_senone_dev(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev,
-                                best_dev, flags, stream);
+    rc = psgpu_ptm_senone_dev(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev,
+                              best_dev, flags, stream);
+    if (rc == PSGPU_OK && m->timing) hipEventRecord(m->ev[3], (hipStream_t)stream);
+    return rc;
 }
 
 int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
