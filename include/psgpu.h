@@ -91,9 +91,12 @@ int32_t psgpu_ptm_topn(const psgpu_ptm_model_t *m);
  *  seed_out_dev  NULL, or [n_utt][n_chain][topn] uint8: receives the lists
  *                carried out of each non-empty utterance's last frame.  Must
  *                not alias seed_in_dev.
- *  topn_score_dev [total_frames][n_chain][topn] int32  raw (pre-norm) scores
- *  topn_cw_dev    [total_frames][n_chain][topn] uint8  codewords
- *                both are outputs AND the workspace between the two kernels.
+ *  topn_score_dev [n_chain][total_frames][topn] int32  raw (pre-norm) scores
+ *  topn_cw_dev    [n_chain][total_frames][topn] uint8  codewords
+ *                CHAIN-MAJOR (a wavefront owns one chain x 64 frames and stores
+ *                1 KB contiguous); both are outputs AND the workspace between
+ *                the kernels.  The host-buffer wrapper below returns them
+ *                frame-major, [total_frames][n_chain][topn].
  *  senscr_dev    [total_frames][n_sen] int16 senone scores, or NULL to stop
  *                after top-N selection.
  *  flags         PSGPU_PTM_RAW_SCORES: skip the final per-frame

@@ -51,7 +51,7 @@ template <int LEN, int N>
 __device__ __forceinline__
 void chain_chunk(const PtmDev &p, const float *__restrict__ feats,
                  const int32_t *__restrict__ utt_off, int32_t n_utt,
-                 int chain, int fbeg, int fend,
+                 int chain, int fbeg, int fend, int total_frames,
                  const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out,
                  int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw, int lane)
 {
@@ -144,7 +144,7 @@ void chain_chunk(const PtmDev &p, const float *__restrict__ feats,
         if (__builtin_expect(!(scan && closed_form(d0, d1)), 0))
             exact_frame_step<N>(L, d0, d1, lane, scan);
         if (t >= fbeg && lane == 0) {           // publish the raw list of this frame
-            const size_t o = (size_t)t * n_chain + chain;
+            const size_t o = (size_t)chain * total_frames + t;      // chain-major: [chain][frame]
             *reinterpret_cast<int4 *>(topn_score + o * N) = make_int4(L.sc[0], L.sc[1], L.sc[2], L.sc[3]);
             topn_cw[o] = (uint32_t)L.cw[0] | ((uint32_t)L.cw[1] << 8) |
                          ((uint32_t)L.cw[2] << 16) | ((uint32_t)L.cw[3] << 24);
@@ -184,7 +184,7 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
             for (int e = wave; e < n; e += n_waves) {
                 const int ent = __builtin_amdgcn_readfirstlane(fix_list[e]);
                 const int t = ent / n_chain;
-                chain_chunk<LEN, N>(p, feats, utt_off, n_utt, ent - t * n_chain, t, t + 1,
+                chain_chunk<LEN, N>(p, feats, utt_off, n_utt, ent - t * n_chain, t, t + 1, total_frames,
                                     seed_in, seed_out, topn_score, topn_cw, lane);
             }
             return;
@@ -204,7 +204,7 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
                 any |= __ballot(tt < fend && open_flags[(size_t)chain * total_frames + tt] != 0) != 0;
             }
             if (any)
-                chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, seed_in, seed_out,
+                chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, total_frames, seed_in, seed_out,
                                     topn_score, topn_cw, lane);
         }
         return;
@@ -218,7 +218,7 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
     const int fbeg = g * chunk;
     const int fend = min(total_frames, fbeg + chunk);
 
-    chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, seed_in, seed_out,
+    chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, total_frames, seed_in, seed_out,
                         topn_score, topn_cw, lane);
 }
 
@@ -290,7 +290,7 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
     const int32_t s0 = k0 >> 7, s1 = k1 >> 7, s2 = k2 >> 7, s3 = k3 >> 7, s4 = k4 >> 7;
     const bool open = (s0 == s1) | (s1 == s2) | (s2 == s3) | (s3 == s4) | (s0 >= kKeyHi) | (s3 <= kKeyLo);
     if (valid) {
-        const size_t o = (size_t)t * p.n_chain + chain;
+        const size_t o = (size_t)chain * total_frames + t;          // chain-major: a wave stores 1 KB contiguous
         *reinterpret_cast<int4 *>(topn_score + o * 4) = make_int4(s0, s1, s2, s3);
         const uint32_t c0 = 127 - (k0 & 127), c1 = 127 - (k1 & 127), c2 = 127 - (k2 & 127), c3 = 127 - (k3 & 127);
         topn_cw[o] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kSenThreads)
 void ptm_senone_kernel(PtmDev p, const int32_t *__restrict__ topn_score,
                        const uint8_t *__restrict__ topn_cw,
                        int16_t *__restrict__ senscr, int32_t *__restrict__ best_out,
-                       uint32_t flags)
+                       uint32_t flags, int32_t total_frames)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: [n_sen] int16 scores | [n_chain*N] cw | [n_chain*N] norm score |
@@ -342,7 +342,8 @@ void ptm_senone_kernel(PtmDev p, const int32_t *__restrict__ topn_score,
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
     const int n_ent = p.n_chain * N;
-    const size_t lo = (size_t)frame * n_ent;
+    // lists are chain-major: entry (chain c, rank k) of this frame
+    auto ent = [&](int i) { return ((size_t)(i / N) * total_frames + frame) * N + (i % N); };
 
     if (tid < p.n_feat) s_norm[tid] = kWorstScore;
     if (tid < 8) s_red[tid] = 0x7fffffff;
@@ -354,16 +355,16 @@ void ptm_senone_kernel(PtmDev p, const int32_t *__restrict__ topn_score,
     // (best score >> 10)
     for (int i = tid; i < p.n_chain; i += kSenThreads) {
         const int f = i % p.n_feat;
-        atomicMax(&s_norm[f], topn_score[lo + (size_t)i * N] >> kSenscrShift);
+        atomicMax(&s_norm[f], topn_score[ent(i * N)] >> kSenscrShift);
     }
     __syncthreads();
     for (int i = tid; i < n_ent; i += kSenThreads) {
         const int f = (i / N) % p.n_feat;
-        int32_t v = topn_score[lo + i] >> kSenscrShift;
+        int32_t v = topn_score[ent(i)] >> kSenscrShift;
         v = -(v - s_norm[f]);
         if (v > kMaxNegAscr) v = kMaxNegAscr;
         s_sc[i] = (uint8_t)v;
-        s_cw[i] = topn_cw[lo + i];
+        s_cw[i] = topn_cw[ent(i)];
     }
     __syncthreads();
 
@@ -433,127 +434,148 @@ __device__ __forceinline__ int32_t logadd8_lds(const uint8_t *s_la, int32_t x, i
     return lo - (int32_t)s_la[d];
 }
 
-template <int ITERS>
+template <int ITERS, int kSenFr>                // kSenFr = frames per workgroup
 __global__ __launch_bounds__(512)
 void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                             const uint32_t *__restrict__ topn_cw,
                             int16_t *__restrict__ senscr, int32_t *__restrict__ best_out,
-                            uint32_t flags)
+                            uint32_t flags, int32_t total_frames)
 {
-    constexpr int N = 4, NF = 3;
+    constexpr int N = 4, NF = 3, MAXC = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int16_t *s_out = reinterpret_cast<int16_t *>(smem);          // [n_sen] (+pad)
-    __shared__ uint32_t s_cw32[256 * NF];       // packed codewords per chain
-    __shared__ uint32_t s_sc32[256 * NF];       // packed normalised scores per chain
+    const int out_stride = ((p.n_sen * 2 + 15) / 16) * 8;         // int16 entries per staged row
+    int16_t *s_out = reinterpret_cast<int16_t *>(smem);          // [kSenFr][out_stride]
+    __shared__ uint32_t s_cw32[kSenFr][MAXC];        // packed codewords per chain (n_chain <= MAXC)
+    __shared__ uint32_t s_sc32[kSenFr][MAXC];        // packed normalised scores per chain
     __shared__ uint8_t s_la[kLaSize];
-    __shared__ int32_t s_norm[NF];
-    __shared__ int32_t s_best;
+    __shared__ int32_t s_norm[kSenFr][NF];
+    __shared__ int32_t s_best[kSenFr];
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const int frame = blockIdx.x;
-    const size_t lo = (size_t)frame * p.n_chain;
+    const int f0 = blockIdx.x * kSenFr;
+    const int nf = min(kSenFr, total_frames - f0);
 
-    if (tid < NF) s_norm[tid] = kWorstScore;
-    if (tid == 0) s_best = 0x7fffffff;
+    if (tid < kSenFr * NF) s_norm[tid / NF][tid % NF] = kWorstScore;
+    if (tid < kSenFr) s_best[tid] = 0x7fffffff;
     for (int i = tid; i < kLaSize; i += nthr)
         s_la[i] = (i < p.logadd8_size) ? p.logadd8[i] : 0;
     __syncthreads();
 
-    // ptm_mgau_codebook_norm (:265-295)
-    int4 sc[3];
-    uint32_t cw[3];
+    // ptm_mgau_codebook_norm (:265-295).  Lists are chain-major, so the kSenFr
+    // frames of one chain are 64 contiguous bytes of scores + 16 of codewords.
+    int4 sc[kSenFr];
+    uint32_t cw[kSenFr];
+    const int i = tid;
+    if (i < p.n_chain) {
+        const size_t lo = (size_t)i * total_frames + f0;
 #pragma unroll
-    for (int h = 0; h < 3; ++h) {               // 3 x >=256 threads cover 768 chains
-        const int i = tid + h * nthr;
-        if (i < p.n_chain) {
-            sc[h] = *reinterpret_cast<const int4 *>(topn_score + (lo + i) * N);
-            cw[h] = topn_cw[lo + i];
-            atomicMax(&s_norm[i % NF], sc[h].x >> kSenscrShift);
+        for (int fr = 0; fr < kSenFr; ++fr) {
+            if (fr < nf) {
+                sc[fr] = *reinterpret_cast<const int4 *>(topn_score + (lo + fr) * N);
+                cw[fr] = topn_cw[lo + fr];
+                atomicMax(&s_norm[fr][i % NF], sc[fr].x >> kSenscrShift);
+            }
         }
     }
     __syncthreads();
+    if (i < p.n_chain) {
 #pragma unroll
-    for (int h = 0; h < 3; ++h) {
-        const int i = tid + h * nthr;
-        if (i < p.n_chain) {
-            const int32_t norm = s_norm[i % NF];
-            const int32_t a = min(kMaxNegAscr, -((sc[h].x >> kSenscrShift) - norm));
-            const int32_t b = min(kMaxNegAscr, -((sc[h].y >> kSenscrShift) - norm));
-            const int32_t c = min(kMaxNegAscr, -((sc[h].z >> kSenscrShift) - norm));
-            const int32_t d = min(kMaxNegAscr, -((sc[h].w >> kSenscrShift) - norm));
-            s_sc32[i] = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
-            s_cw32[i] = cw[h];
+        for (int fr = 0; fr < kSenFr; ++fr) {
+            if (fr < nf) {
+                const int32_t norm = s_norm[fr][i % NF];
+                const int32_t a = min(kMaxNegAscr, -((sc[fr].x >> kSenscrShift) - norm));
+                const int32_t b = min(kMaxNegAscr, -((sc[fr].y >> kSenscrShift) - norm));
+                const int32_t c = min(kMaxNegAscr, -((sc[fr].z >> kSenscrShift) - norm));
+                const int32_t d = min(kMaxNegAscr, -((sc[fr].w >> kSenscrShift) - norm));
+                s_sc32[fr][i] = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+                s_cw32[fr][i] = cw[fr];
+            }
         }
     }
     __syncthreads();
 
-    // ptm_mgau_senone_eval (:326-403), slot order
-    int32_t mybest = 0x7fffffff;
+    // ptm_mgau_senone_eval (:326-403), slot order, kSenFr frames back to back
+    int32_t mybest[kSenFr];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int g = tid + it * nthr;
-        if (g < p.n_groups) {
-            const uint32_t cb = p.group_cb[g];
-            const uint32_t slot = (uint32_t)g << 2;
-            uint32_t w[NF][N], nsc[NF];
+    for (int fr = 0; fr < kSenFr; ++fr) {
+        mybest[fr] = 0x7fffffff;
+        if (fr < nf) {
+            int16_t *orow_s = s_out + fr * out_stride;
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const uint32_t c4 = s_cw32[cb * NF + f];
-                nsc[f] = s_sc32[cb * NF + f];
+            for (int it = 0; it < ITERS; ++it) {
+                const int g = tid + it * nthr;
+                if (g < p.n_groups) {
+                    const uint32_t cb = p.group_cb[g];
+                    const uint32_t slot = (uint32_t)g << 2;
+                    uint32_t w[NF][N], nsc[NF];
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    const uint32_t row = (uint32_t)f * p.n_density + ((c4 >> (8 * k)) & 0xff);
-                    w[f][k] = *reinterpret_cast<const uint32_t *>(
-                        p.mixw_slot + (size_t)(row * (uint32_t)p.slot_stride + slot));
-                }
-            }
-            const uint2 sen2 = *reinterpret_cast<const uint2 *>(p.slot_sen + slot);   // 4 x uint16
+                    for (int f = 0; f < NF; ++f) {
+                        const uint32_t c4 = s_cw32[fr][cb * NF + f];
+                        nsc[f] = s_sc32[fr][cb * NF + f];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                int32_t ascore = 0;
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    int32_t fden = (int32_t)((w[f][0] >> (8 * b)) & 0xff) + (int32_t)(nsc[f] & 0xff);
-#pragma unroll
-                    for (int k = 1; k < N; ++k) {
-                        const int32_t y = (int32_t)((w[f][k] >> (8 * b)) & 0xff) +
-                                          (int32_t)((nsc[f] >> (8 * k)) & 0xff);
-                        fden = logadd8_lds(s_la, fden, y);
+                        for (int k = 0; k < N; ++k) {
+                            const uint32_t row = (uint32_t)f * p.n_density + ((c4 >> (8 * k)) & 0xff);
+                            w[f][k] = *reinterpret_cast<const uint32_t *>(
+                                p.mixw_slot + (size_t)(row * (uint32_t)p.slot_stride + slot));
+                        }
                     }
-                    ascore += fden;
-                }
-                const uint32_t sen = ((b < 2 ? sen2.x : sen2.y) >> (16 * (b & 1))) & 0xffff;
-                if (sen != 0xffff) {            // pad slots are dropped
-                    s_out[sen] = (int16_t)ascore;
-                    mybest = min(mybest, ascore);
+                    const uint2 sen2 = *reinterpret_cast<const uint2 *>(p.slot_sen + slot);   // 4 x uint16
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        int32_t ascore = 0;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            int32_t fden = (int32_t)((w[f][0] >> (8 * b)) & 0xff) + (int32_t)(nsc[f] & 0xff);
+#pragma unroll
+                            for (int k = 1; k < N; ++k) {
+                                const int32_t y = (int32_t)((w[f][k] >> (8 * b)) & 0xff) +
+                                                  (int32_t)((nsc[f] >> (8 * k)) & 0xff);
+                                fden = logadd8_lds(s_la, fden, y);
+                            }
+                            ascore += fden;
+                        }
+                        const uint32_t sen = ((b < 2 ? sen2.x : sen2.y) >> (16 * (b & 1))) & 0xffff;
+                        if (sen != 0xffff) {            // pad slots are dropped
+                            orow_s[sen] = (int16_t)ascore;
+                            mybest[fr] = min(mybest[fr], ascore);
+                        }
+                    }
                 }
             }
         }
     }
-    // block minimum
+    // per-frame block minimum
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        mybest = min(mybest, __shfl_xor(mybest, off));
-    if ((tid & 63) == 0) atomicMin(&s_best, mybest);
-    __syncthreads();
-    const int32_t best = s_best;
-    if (best_out && tid == 0) best_out[frame] = best;
-    const int32_t sub = (flags & PSGPU_PTM_RAW_SCORES) ? 0 : best;
-    int16_t *orow = senscr + (size_t)frame * p.n_sen;
-    if ((p.n_sen & 1) == 0) {                   // rows stay 4-byte aligned
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s_out);
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(orow);
-        for (int i = tid; i < (p.n_sen >> 1); i += nthr) {
-            const uint32_t v = s32[i];
-            const uint32_t a = ((v & 0xffff) - (uint32_t)sub) & 0xffff;     // int16 wrap as in :398-400
-            const uint32_t b = ((v >> 16) - (uint32_t)sub) & 0xffff;
-            o32[i] = a | (b << 16);
-        }
+    for (int fr = 0; fr < kSenFr; ++fr) {
+        int32_t mb = mybest[fr];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            mb = min(mb, __shfl_xor(mb, off));
+        if ((tid & 63) == 0 && fr < nf) atomicMin(&s_best[fr], mb);
     }
-    else {
-        for (int i = tid; i < p.n_sen; i += nthr)
-            orow[i] = (int16_t)(s_out[i] - sub);
+    __syncthreads();
+    for (int fr = 0; fr < nf; ++fr) {
+        const int frame = f0 + fr;
+        const int32_t best = s_best[fr];
+        if (best_out && tid == 0) best_out[frame] = best;
+        const int32_t sub = (flags & PSGPU_PTM_RAW_SCORES) ? 0 : best;
+        int16_t *orow = senscr + (size_t)frame * p.n_sen;
+        const int16_t *srow = s_out + fr * out_stride;
+        if ((p.n_sen & 1) == 0) {                   // rows stay 4-byte aligned
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(srow);
+            uint32_t *o32 = reinterpret_cast<uint32_t *>(orow);
+            for (int j = tid; j < (p.n_sen >> 1); j += nthr) {
+                const uint32_t v = s32[j];
+                const uint32_t a = ((v & 0xffff) - (uint32_t)sub) & 0xffff;     // int16 wrap as in :398-400
+                const uint32_t b = ((v >> 16) - (uint32_t)sub) & 0xffff;
+                o32[j] = a | (b << 16);
+            }
+        }
+        else {
+            for (int j = tid; j < p.n_sen; j += nthr)
+                orow[j] = (int16_t)(srow[j] - sub);
+        }
     }
 }
 
@@ -759,23 +781,35 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
                   "psgpu_ptm_senone_dev: NULL argument");
     if (total_frames <= 0) return PSGPU_OK;
     static const int force_generic = [] { const char *e = getenv("PSGPU_SENONE_GENERIC"); return e ? atoi(e) : 0; }();
-    if (!force_generic && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 768 && m->n_sen < 0xffff) {
+    if (!force_generic && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 256 && m->n_sen < 0xffff) {
         // block = 4..8 waves: pick the width that wastes the fewest lanes
         int best_w = 0, iters = 0;
         double best_eff = 0;
-        for (int w = 4; w <= 8; ++w) {
+        static const int force_w = [] { const char *e = getenv("PSGPU_SEN_W"); return e ? atoi(e) : 0; }();
+        static const int sen_fr = [] { const char *e = getenv("PSGPU_SEN_FR"); return e ? atoi(e) : 1; }();
+        // measured on MI355X (tools/sensweep.sh): the kernel is latency-bound and runs best with the
+        // most workgroups in flight per CU, i.e. the narrowest workgroup that covers a frame's
+        // groups in <= kSenMaxIters passes (en-us: 4 waves x 6 passes, 8 workgroups per CU)
+        for (int w = (force_w ? force_w : 4); w <= (force_w ? force_w : 8) && !best_w; ++w) {
             const int it = (m->n_groups + 64 * w - 1) / (64 * w);
             const double eff = (double)m->n_groups / ((double)it * 64 * w);
             if (it <= kSenMaxIters && eff > best_eff + 1e-9) { best_eff = eff; best_w = w; iters = it; }
         }
         if (best_w) {
-            const dim3 grid(total_frames), block(64 * best_w);
-            const size_t sm = (((size_t)m->n_sen * 2 + 15) / 16) * 16;
+            const int kSenFr = (sen_fr == 1 || sen_fr == 4) ? sen_fr : 2;
+            const dim3 grid((total_frames + kSenFr - 1) / kSenFr), block(64 * best_w);
+            const size_t sm = (((size_t)m->n_sen * 2 + 15) / 16) * 16 * kSenFr;
             hipStream_t st = (hipStream_t)stream;
             const PtmDev pv = dev_view(m);
             const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(topn_cw_dev);
-#define PSGPU_SEN_CASE(I) case I: hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I>), grid, block, sm, st, pv, \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags); break;
+#define PSGPU_SEN_CASE(I) case I:                                                                              \
+                if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1>), grid, block, sm, st, pv,        \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames);           \
+                else if (kSenFr == 4) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 4>), grid, block, sm, st, pv,   \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames);           \
+                else hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 2>), grid, block, sm, st, pv,                    \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames);           \
+                break;
             switch (iters) {
                 PSGPU_SEN_CASE(1) PSGPU_SEN_CASE(2) PSGPU_SEN_CASE(3) PSGPU_SEN_CASE(4)
                 PSGPU_SEN_CASE(5) PSGPU_SEN_CASE(6) PSGPU_SEN_CASE(7) default: PSGPU_SEN_CASE(8)
@@ -790,7 +824,7 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
     const size_t smem = (size_t)out_bytes + 2 * list_bytes + 256 + 16 * 4 + 8 * 4;
     hipLaunchKernelGGL((ptm_senone_kernel<4>), dim3(total_frames), dim3(kSenThreads), smem,
                        (hipStream_t)stream, dev_view(m), topn_score_dev, topn_cw_dev,
-                       senscr_dev, best_dev, flags);
+                       senscr_dev, best_dev, flags, total_frames);
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
@@ -874,8 +908,24 @@ int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,
                                    d_scr, d_best, flags, nullptr);
     if (rc == PSGPU_OK) {
         TRY(hipDeviceSynchronize());
-        if (topn_score) TRY(hipMemcpy(topn_score, d_sc, n_ent * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (topn_cw) TRY(hipMemcpy(topn_cw, d_cw, n_ent, hipMemcpyDeviceToHost));
+        // device lists are chain-major ([chain][frame][topn]); the host interface keeps the
+        // reference's frame-major view (s->f->topn[cb][feat][k] per frame)
+        if (topn_score) {
+            std::vector<int32_t> tmp(n_ent);
+            TRY(hipMemcpy(tmp.data(), d_sc, n_ent * sizeof(int32_t), hipMemcpyDeviceToHost));
+            const size_t N_ = (size_t)m->topn, C_ = (size_t)m->n_chain;
+            for (size_t c = 0; c < C_; ++c)
+                for (size_t t = 0; t < (size_t)T; ++t)
+                    memcpy(topn_score + (t * C_ + c) * N_, tmp.data() + (c * (size_t)T + t) * N_, N_ * sizeof(int32_t));
+        }
+        if (topn_cw) {
+            std::vector<uint8_t> tmp(n_ent);
+            TRY(hipMemcpy(tmp.data(), d_cw, n_ent, hipMemcpyDeviceToHost));
+            const size_t N_ = (size_t)m->topn, C_ = (size_t)m->n_chain;
+            for (size_t c = 0; c < C_; ++c)
+                for (size_t t = 0; t < (size_t)T; ++t)
+                    memcpy(topn_cw + (t * C_ + c) * N_, tmp.data() + (c * (size_t)T + t) * N_, N_);
+        }
         if (senscr) TRY(hipMemcpy(senscr, d_scr, (size_t)T * m->n_sen * sizeof(int16_t), hipMemcpyDeviceToHost));
         if (best) TRY(hipMemcpy(best, d_best, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (seed_cw) TRY(hipMemcpy(seed_cw, d_seed_out, (size_t)n_utt * m->n_chain * m->topn, hipMemcpyDeviceToHost));
