@@ -264,8 +264,8 @@ int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
                         const float *feat, int32_t compallsen);
 /* Batched compallsen scoring of total_frames independent frames (frames of any
  * number of utterances back to back: the scorer has no time dependence).
- *  list_id_dev / list_dist_dev  [total_frames][n_mgau][n_feat][topn] int32 / fp32:
- *                               the top-N lists (output and workspace)
+ *  list_id_dev / list_dist_dev  [n_mgau][n_feat][total_frames][topn] int32 / fp32:
+ *                               the top-N lists, codebook-major (output and workspace)
  *  senscr_dev                   [total_frames][n_sen] int16, or NULL to stop after
  *                               the top-N kernel
  * psgpu_ms_batch_check() synchronises `stream` and returns PSGPU_ESTATE if some

@@ -35,6 +35,7 @@ constexpr int kMsLaLds = 4096;           // log-add entries kept in LDS (int32)
 struct MsDev {
     const float *mean, *var, *det;
     const uint8_t *pdf;                  // [n_sen][n_feat][n_density]
+    const uint8_t *pdf_t;                // [n_feat][n_density][n_sen] when senones share codebooks, else nullptr
     const int32_t *sen2mgau;
     const int32_t *logadd;               // widened to int32
     int32_t n_mgau, n_feat, n_density, n_sen, topn, aw, veclen, logadd_size, log_zero;
@@ -45,7 +46,7 @@ struct MsDev {
 struct psgpu_ms_model_s {
     MsDev d;
     float *mean, *var, *det;
-    uint8_t *pdf;
+    uint8_t *pdf, *pdf_t;
     int32_t *sen2mgau, *logadd;
     int64_t *cboff;
     int32_t *h_sen2mgau;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256)
 void ms_topn_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
                     const uint8_t *__restrict__ active,           // [n_mgau] or nullptr (all)
                     int32_t *__restrict__ list_id, float *__restrict__ list_dist,
-                    int64_t frame_stride,                         // entries between frames (0: per-call state)
+                    int32_t batch,                                // 0: per-call state (stale ids are meaningful)
                     int32_t *__restrict__ flag)
 {
     const int lane = threadIdx.x & 63;
@@ -114,8 +115,9 @@ void ms_topn_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
         }
         d[k] = acc;
     }
-    int32_t *oid = list_id + (size_t)t * frame_stride + (size_t)c * N;
-    float *odist = list_dist + (size_t)t * frame_stride + (size_t)c * N;
+    // lists are codebook-major: [codebook*stream][frame][N]
+    int32_t *oid = list_id + ((size_t)c * n_frames + t) * N;
+    float *odist = list_dist + ((size_t)c * n_frames + t) * N;
     if (N >= p.n_density) {
         // compute_dist_all: every density in index order (n_density <= N <= 8 lanes)
         if (lane < p.n_density) { oid[lane] = lane; odist[lane] = d[0]; }
@@ -147,51 +149,56 @@ void ms_topn_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
         else if (lane == 0)
             odist[r] = (float)kMaxNegInt32;          // id keeps its previous contents (ms_gauden.c:438-440)
     }
-    if (filled < N && frame_stride != 0 && lane == 0 && flag)
+    if (filled < N && batch && lane == 0 && flag)
         atomicOr(flag, 1);                           // batch mode cannot know the stale ids
 }
 
 // ---------------------------------------------------------------------------
 // kernel 2: senone_eval over the listed senones of one frame + normalisation
 // ---------------------------------------------------------------------------
-constexpr int kMsSenThreads = 1024;
+constexpr int kMsSenThreads = 256;
 
 template <int N>
 __global__ __launch_bounds__(kMsSenThreads)
 void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *__restrict__ list,
                       const int32_t *__restrict__ list_id, const float *__restrict__ list_dist,
-                      int64_t frame_stride, int16_t *__restrict__ out, int64_t out_stride)
+                      int32_t n_frames, int16_t *__restrict__ out, int64_t out_stride)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t s_scr[];      // [n]
-    __shared__ int32_t s_la[kMsLaLds];
+    extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];      // [la entries] int32 | [n] int16
     __shared__ int32_t s_best;
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
     const bool la_lds = p.logadd_size <= kMsLaLds;
+    int32_t *s_la = s_dyn;
+    int16_t *s_scr = reinterpret_cast<int16_t *>(s_dyn + (la_lds ? p.logadd_size : 0));
     if (la_lds)
         for (int i = tid; i < p.logadd_size; i += kMsSenThreads) s_la[i] = p.logadd[i];
     if (tid == 0) s_best = 0x7fffffff;
     __syncthreads();
     const int32_t *la = la_lds ? s_la : p.logadd;
     const int n = compall ? p.n_sen : n_list;
-    const int L = p.n_feat * N;
     const int ntop = min(N, p.n_density);
     int32_t mybest = 0x7fffffff;
     for (int i = tid; i < n; i += kMsSenThreads) {
         const int sen = compall ? i : list[i];
         const int cb = p.sen2mgau[sen];
-        const int32_t *ids = list_id + (size_t)frame * frame_stride + (size_t)cb * L;
-        const float *ds = list_dist + (size_t)frame * frame_stride + (size_t)cb * L;
+        // lists are codebook-major: entry (cb, f) of this frame at ((cb * n_feat + f) * n_frames + frame) * N
+        const size_t lbase = ((size_t)cb * p.n_feat * n_frames + frame) * N;
+        const size_t lstep = (size_t)n_frames * N;          // next stream
         int32_t scr = 0;
         for (int f = 0; f < p.n_feat; ++f) {
-            const uint8_t *pdf = p.pdf + ((size_t)sen * p.n_feat + f) * p.n_density;
+            // senone weights: [sen][f][cw] (own codebook per senone: one 16-byte row) or, when
+            // senones share codebooks, the transposed copy [f][cw][sen] (coalesced along senones)
+            const uint8_t *pdf = p.pdf_t ? p.pdf_t + (size_t)f * p.n_density * p.n_sen + sen
+                                         : p.pdf + ((size_t)sen * p.n_feat + f) * p.n_density;
+            const size_t pstep = p.pdf_t ? (size_t)p.n_sen : 1;
             int32_t fscr = 0;
             for (int t = 0; t < ntop; ++t) {
-                const float dv = ds[f * N + t];
+                const float dv = list_dist[lbase + f * lstep + t];
                 const int32_t fden = (dv < (float)kMaxNegInt32)
                     ? (kMaxNegInt32 >> kSenscrShift)
                     : (((int32_t)dv + ((1 << kSenscrShift) - 1)) >> kSenscrShift);
-                const int32_t fw = fden - (int32_t)pdf[ids[f * N + t]];
+                const int32_t fw = fden - (int32_t)pdf[(size_t)list_id[lbase + f * lstep + t] * pstep];
                 if (t == 0) fscr = fw;
                 else {
                     // logmath_add (util/logmath.c:401-446)
@@ -207,7 +214,7 @@ void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *
         }
         scr /= p.aw;                                     // C division, truncates toward zero
         scr = max(-32768, min(32767, scr));              // senone_eval's clamp + int16 store (ms_mgau.c:219)
-        s_scr[i] = scr;
+        s_scr[i] = (int16_t)scr;
         mybest = min(mybest, scr);
     }
 #pragma unroll
@@ -217,7 +224,7 @@ void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *
     const int32_t best = s_best;
     int16_t *o = out + (size_t)frame * out_stride;
     for (int i = tid; i < n; i += kMsSenThreads) {
-        int32_t bs = s_scr[i] - best;
+        int32_t bs = (int32_t)s_scr[i] - best;
         bs = max(-32768, min(32767, bs));
         o[i] = (int16_t)bs;                              // list order (per-call) / senone order (compall)
     }
@@ -235,12 +242,12 @@ static int upl(T **dst, const T *src, size_t n)
 }
 
 static void launch_topn(const MsDev &d, const float *feats, int32_t T, const uint8_t *active,
-                        int32_t *ids, float *dist, int64_t stride, int32_t *flag, hipStream_t st)
+                        int32_t *ids, float *dist, int32_t batch, int32_t *flag, hipStream_t st)
 {
     const long long waves = (long long)T * d.n_mgau * d.n_feat;
     const int blocks = (int)((waves + 3) / 4);
 #define PSGPU_MS_TOPN(NN) case NN: hipLaunchKernelGGL((ms_topn_kernel<NN>), dim3(blocks), dim3(256), 0, st, \
-        d, feats, T, active, ids, dist, stride, flag); break;
+        d, feats, T, active, ids, dist, batch, flag); break;
     switch (d.topn) {
         PSGPU_MS_TOPN(1) PSGPU_MS_TOPN(2) PSGPU_MS_TOPN(3) PSGPU_MS_TOPN(4)
         PSGPU_MS_TOPN(5) PSGPU_MS_TOPN(6) PSGPU_MS_TOPN(7) default: PSGPU_MS_TOPN(8)
@@ -249,18 +256,139 @@ static void launch_topn(const MsDev &d, const float *feats, int32_t T, const uin
 }
 
 static void launch_senone(const MsDev &d, int32_t T, int32_t compall, int32_t n_list, const uint16_t *list,
-                          const int32_t *ids, const float *dist, int64_t stride, int16_t *out,
+                          const int32_t *ids, const float *dist, int16_t *out,
                           int64_t out_stride, hipStream_t st)
 {
     const int n = compall ? d.n_sen : n_list;
-    const size_t smem = ((size_t)(n > 0 ? n : 1) * 4 + 15) / 16 * 16;
+    const size_t smem = ((size_t)(d.logadd_size <= kMsLaLds ? d.logadd_size : 0) * 4 +
+                         (size_t)(n > 0 ? n : 1) * 2 + 15) / 16 * 16;
 #define PSGPU_MS_SEN(NN) case NN: hipLaunchKernelGGL((ms_senone_kernel<NN>), dim3(T), dim3(kMsSenThreads), smem, st, \
-        d, compall, n_list, list, ids, dist, stride, out, out_stride); break;
+        d, compall, n_list, list, ids, dist, T, out, out_stride); break;
     switch (d.topn) {
         PSGPU_MS_SEN(1) PSGPU_MS_SEN(2) PSGPU_MS_SEN(3) PSGPU_MS_SEN(4)
         PSGPU_MS_SEN(5) PSGPU_MS_SEN(6) PSGPU_MS_SEN(7) default: PSGPU_MS_SEN(8)
     }
 #undef PSGPU_MS_SEN
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1b (batched entry): frames on lanes.  One wavefront = one
+// (codebook, stream) x 64 consecutive frames; the codebook's parameters are
+// wave-uniform (scalar cache -> SGPR operands), the lane's feature values sit
+// in VGPRs, densities are visited in index order and each lane keeps its N
+// best 64-bit keys (order-preserving float bits << 32 | density) sorted with a
+// max/min bubble.  No cross-lane traffic, no history: exact by construction.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long umax64(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned long long umin64(unsigned long long a, unsigned long long b) { return a > b ? b : a; }
+
+template <int N, int LEN>
+__global__ __launch_bounds__(256)
+void ms_lane_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
+                    int32_t *__restrict__ list_id, float *__restrict__ list_dist,
+                    int32_t *__restrict__ flag)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6));
+    const int n_tiles = (n_frames + 63) >> 6;
+    const int c = (int)(wave / n_tiles);                       // consecutive waves: tiles of ONE codebook
+    if (c >= p.n_mgau * p.n_feat)
+        return;
+    const int tile = (int)(wave - (long long)c * n_tiles);
+    const int f = c % p.n_feat;
+    const int t = tile * 64 + lane;
+    const bool valid = t < n_frames;
+    const int tl = valid ? t : n_frames - 1;
+    float x[LEN];
+    {
+        const float *xp = feats + (size_t)tl * p.veclen + p.featoff[f];
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) x[j] = xp[j];
+    }
+    const float *mean = p.mean + p.cboff[c], *var = p.var + p.cboff[c];
+    const float *det = p.det + (size_t)c * p.n_density;
+    int32_t *oid = list_id + ((size_t)c * n_frames + t) * N;
+    float *odist = list_dist + ((size_t)c * n_frames + t) * N;
+
+    if (N >= p.n_density) {                                    // compute_dist_all: index order, no selection
+        for (int dn = 0; dn < p.n_density; ++dn) {
+            const float *m = mean + dn * LEN, *v = var + dn * LEN;
+            float acc = det[dn];
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const float diff = __fsub_rn(x[j], m[j]);
+                acc = __fsub_rn(acc, __fmul_rn(__fmul_rn(diff, diff), v[j]));
+            }
+            if (valid) { oid[dn] = dn; odist[dn] = acc; }
+        }
+        return;
+    }
+    unsigned long long key[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) key[r] = 0ull;
+    for (int dn = 0; dn < p.n_density; ++dn) {
+        const float *m = mean + dn * LEN, *v = var + dn * LEN;
+        float acc = det[dn];
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) {
+            const float diff = __fsub_rn(x[j], m[j]);
+            acc = __fsub_rn(acc, __fmul_rn(__fmul_rn(diff, diff), v[j]));
+        }
+        unsigned long long k = (acc >= (float)kMaxNegInt32)
+            ? (((unsigned long long)fkey(acc) << 32) | (uint32_t)dn) : 0ull;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const unsigned long long hi = umax64(key[r], k);
+            k = umin64(key[r], k);
+            key[r] = hi;
+        }
+    }
+    if (valid) {
+        bool unfilled = false;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            if (key[r] != 0ull) {
+                const uint32_t fk = (uint32_t)(key[r] >> 32);
+                const uint32_t u = (fk & 0x80000000u) ? (fk & 0x7fffffffu) : ~fk;   // inverse of fkey
+                odist[r] = __builtin_bit_cast(float, u);
+                oid[r] = (int32_t)(key[r] & 0xffffffffu);
+            }
+            else { odist[r] = (float)kMaxNegInt32; oid[r] = 0; unfilled = true; }
+        }
+        if (unfilled) atomicOr(flag, 1);                       // stale ids: only the per-call entry knows them
+    }
+}
+
+template <int N>
+static bool launch_lane_n(const MsDev &d, const float *feats, int32_t T, int32_t *ids, float *dist,
+                          int32_t *flag, hipStream_t st)
+{
+    int len = d.featlen[0];
+    for (int f = 1; f < d.n_feat; ++f) if (d.featlen[f] != len) return false;
+    const long long waves = (long long)((T + 63) / 64) * d.n_mgau * d.n_feat;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    if (len == 13)
+        hipLaunchKernelGGL((ms_lane_kernel<N, 13>), dim3(blocks), dim3(256), 0, st, d, feats, T, ids, dist, flag);
+    else if (len == 39)
+        hipLaunchKernelGGL((ms_lane_kernel<N, 39>), dim3(blocks), dim3(256), 0, st, d, feats, T, ids, dist, flag);
+    else
+        return false;
+    return true;
+}
+
+static bool launch_lane(const MsDev &d, const float *feats, int32_t T, int32_t *ids, float *dist,
+                        int32_t *flag, hipStream_t st)
+{
+    switch (d.topn) {
+    case 1: return launch_lane_n<1>(d, feats, T, ids, dist, flag, st);
+    case 2: return launch_lane_n<2>(d, feats, T, ids, dist, flag, st);
+    case 3: return launch_lane_n<3>(d, feats, T, ids, dist, flag, st);
+    case 4: return launch_lane_n<4>(d, feats, T, ids, dist, flag, st);
+    case 5: return launch_lane_n<5>(d, feats, T, ids, dist, flag, st);
+    case 6: return launch_lane_n<6>(d, feats, T, ids, dist, flag, st);
+    case 7: return launch_lane_n<7>(d, feats, T, ids, dist, flag, st);
+    default: return launch_lane_n<8>(d, feats, T, ids, dist, flag, st);
+    }
 }
 
 extern "C" {
@@ -316,6 +444,14 @@ int psgpu_ms_model_create(psgpu_ms_model_t **out, int32_t n_mgau, int32_t n_feat
         psgpu_ms_model_free(m);
         return rc;
     }
+    if (n_mgau * 2 <= n_sen) {
+        std::vector<uint8_t> pt((size_t)n_sen * n_feat * n_density);
+        for (int i = 0; i < n_sen; ++i)
+            for (int f = 0; f < n_feat; ++f)
+                for (int c = 0; c < n_density; ++c)
+                    pt[((size_t)f * n_density + c) * n_sen + i] = pdf[((size_t)i * n_feat + f) * n_density + c];
+        if ((rc = upl(&m->pdf_t, pt.data(), pt.size()))) { psgpu_ms_model_free(m); return rc; }
+    }
     m->h_sen2mgau = (int32_t *)malloc(sizeof(int32_t) * n_sen);
     memcpy(m->h_sen2mgau, map.data(), sizeof(int32_t) * n_sen);
     e = hipMalloc((void **)&m->list_id, nlist * sizeof(int32_t));
@@ -338,7 +474,7 @@ int psgpu_ms_model_create(psgpu_ms_model_t **out, int32_t n_mgau, int32_t n_feat
         psgpu_ms_model_free(m);
         return e == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP;
     }
-    d.mean = m->mean; d.var = m->var; d.det = m->det; d.pdf = m->pdf;
+    d.mean = m->mean; d.var = m->var; d.det = m->det; d.pdf = m->pdf; d.pdf_t = m->pdf_t;
     d.sen2mgau = m->sen2mgau; d.logadd = m->logadd; d.cboff = m->cboff;
     *out = m;
     return PSGPU_OK;
@@ -348,7 +484,7 @@ void psgpu_ms_model_free(psgpu_ms_model_t *m)
 {
     if (!m) return;
     if (m->stream) hipStreamDestroy(m->stream);
-    hipFree(m->mean); hipFree(m->var); hipFree(m->det); hipFree(m->pdf);
+    hipFree(m->mean); hipFree(m->var); hipFree(m->det); hipFree(m->pdf); hipFree(m->pdf_t);
     hipFree(m->sen2mgau); hipFree(m->logadd); hipFree(m->cboff);
     hipFree(m->list_id); hipFree(m->list_dist); hipFree(m->d_flag);
     if (m->h_active) hipHostFree(m->h_active);
@@ -390,7 +526,7 @@ int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
     memcpy(m->h_feat, feat, (size_t)d.veclen * sizeof(float));
     launch_topn(d, m->d_feat, 1, m->d_active, m->list_id, m->list_dist, 0, nullptr, m->stream);
     PSGPU_HIP(hipGetLastError());
-    launch_senone(d, 1, compallsen != 0, n_list, m->d_list, m->list_id, m->list_dist, 0, m->d_out, 0, m->stream);
+    launch_senone(d, 1, compallsen != 0, n_list, m->d_list, m->list_id, m->list_dist, m->d_out, 0, m->stream);
     PSGPU_HIP(hipGetLastError());
     PSGPU_HIP(hipStreamSynchronize(m->stream));
     if (compallsen)
@@ -409,13 +545,14 @@ int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_
     PSGPU_REQUIRE(total_frames >= 0, "negative frame count");
     if (total_frames == 0) return PSGPU_OK;
     const MsDev &d = m->d;
-    const int64_t stride = (int64_t)d.n_mgau * d.n_feat * d.topn;
     hipStream_t st = (hipStream_t)stream;
     PSGPU_HIP(hipMemsetAsync(m->d_flag, 0, sizeof(int32_t), st));
-    launch_topn(d, feats_dev, total_frames, nullptr, list_id_dev, list_dist_dev, stride, m->d_flag, st);
+    static const int no_lane = [] { const char *e = getenv("PSGPU_NO_LANE_KERNEL"); return e ? atoi(e) : 0; }();
+    if (no_lane || !launch_lane(d, feats_dev, total_frames, list_id_dev, list_dist_dev, m->d_flag, st))
+        launch_topn(d, feats_dev, total_frames, nullptr, list_id_dev, list_dist_dev, 1, m->d_flag, st);
     PSGPU_HIP(hipGetLastError());
     if (senscr_dev) {
-        launch_senone(d, total_frames, 1, 0, nullptr, list_id_dev, list_dist_dev, stride, senscr_dev, d.n_sen, st);
+        launch_senone(d, total_frames, 1, 0, nullptr, list_id_dev, list_dist_dev, senscr_dev, d.n_sen, st);
         PSGPU_HIP(hipGetLastError());
     }
     return PSGPU_OK;
