@@ -148,6 +148,7 @@ def main():
 
     senlog_case("default", 2)
     senlog_case("fwdtree_only", 1, extra=("fwdflat", "no", "bestpath", "no"))
+    ptm_topn_only()
     decode_case("default")
     decode_case("fwdtree_only", extra=("fwdflat", "no", "bestpath", "no"))
     decode_case("compallsen_plw0", extra=("compallsen", "yes", "pl_window", "0"))
@@ -221,6 +222,12 @@ def ms_only():
     senlog_case("ms_en_us_topn2_call", 1, model=ems, extra=x + ("topn", "2", "compallsen", "yes", "fwdflat", "no"))
 
 
+def ptm_topn_only():
+    # PTM with other top-N sizes (the any-shape per-call path)
+    senlog_case("ptm_topn2", 1, extra=("topn", "2", "fwdflat", "no"))
+    senlog_case("ptm_topn6_ds2", 1, extra=("topn", "6", "ds", "2", "fwdflat", "no"))
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -238,5 +245,7 @@ if __name__ == "__main__":
         semi_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ms":
         ms_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ptm_topn":
+        ptm_topn_only()
     else:
         main()

@@ -604,8 +604,8 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
                   "psgpu_ptm_model_create: NULL argument");
     PSGPU_REQUIRE(n_mgau > 0 && n_mgau <= 256, "n_mgau %d outside 1..256 (ptm_mgau.c:838)", n_mgau);
     PSGPU_REQUIRE(n_feat > 0 && n_feat <= 16, "n_feat %d outside 1..16", n_feat);
-    PSGPU_REQUIRE(n_density == 128, "n_density %d: this build handles 128-density PTM codebooks", n_density);
-    PSGPU_REQUIRE(topn == 4, "topn %d: this build handles topn = 4", topn);
+    PSGPU_REQUIRE(n_density >= 1 && n_density <= 256, "n_density %d outside 1..256", n_density);
+    PSGPU_REQUIRE(topn >= 1 && topn <= PSGPU_MAX_TOPN && topn <= n_density, "topn %d outside 1..%d", topn, PSGPU_MAX_TOPN);
     PSGPU_REQUIRE(ds_ratio >= 1, "ds_ratio %d < 1", ds_ratio);
     PSGPU_REQUIRE(n_sen > 0 && n_sen < 32768, "n_sen %d outside 1..32767", n_sen);
     PSGPU_REQUIRE(logadd8_size >= 256, "log-add table has %d < 256 entries (logmath.c:112)", logadd8_size);
@@ -623,11 +623,13 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
         m->veclen += featlen[f];
         if (featlen[f] != featlen[0]) m->uniform_len = 0;
     }
-    if (m->uniform_len != 13) {
-        psgpu_set_error("stream lengths must all be 13 in this build (got %d...)", featlen[0]);
+    if (m->veclen > 64) {
+        psgpu_set_error("feature vector of %d floats exceeds 64", m->veclen);
         delete m;
         return PSGPU_EINVAL;
     }
+    // the batched kernels are specialised; every other shape is served by the per-call entry
+    m->fast_shape = (n_density == 128 && topn == 4 && m->uniform_len == 13);
     hipGetDevice(&m->device);
     const size_t npar = (size_t)n_mgau * n_density * m->veclen;
     if ((rc = upload(&m->mean, mean, npar)) || (rc = upload(&m->var, var, npar)) ||
@@ -700,6 +702,8 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
     PSGPU_REQUIRE(m && feats_dev && utt_off_dev && topn_score_dev && topn_cw_dev,
                   "psgpu_ptm_topn_dev: NULL argument");
     PSGPU_REQUIRE(n_utt >= 0 && total_frames >= 0, "negative sizes");
+    PSGPU_REQUIRE(m->fast_shape, "the batched entry handles 128-density / top-4 / 13-dim PTM models; this one "
+                  "(n_density %d, topn %d) is served by psgpu_ptm_frame_eval", m->n_density, m->topn);
     PSGPU_REQUIRE(seed_in_dev == nullptr || seed_in_dev != seed_out_dev,
                   "seed_in and seed_out must not alias (chunks read seeds while others write carry-outs)");
     if (n_utt == 0 || total_frames == 0) return PSGPU_OK;
@@ -779,6 +783,7 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
 {
     PSGPU_REQUIRE(m && topn_score_dev && topn_cw_dev && senscr_dev,
                   "psgpu_ptm_senone_dev: NULL argument");
+    PSGPU_REQUIRE(m->fast_shape, "the batched entry handles 128-density / top-4 / 13-dim PTM models");
     if (total_frames <= 0) return PSGPU_OK;
     static const int force_generic = [] { const char *e = getenv("PSGPU_SENONE_GENERIC"); return e ? atoi(e) : 0; }();
     if (!force_generic && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 256 && m->n_sen < 0xffff) {

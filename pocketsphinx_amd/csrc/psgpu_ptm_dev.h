@@ -9,6 +9,7 @@ struct psgpu_ptm_model_s {
     int32_t featlen[16];
     int32_t featoff[16];
     int32_t uniform_len;          // featlen if all streams are equal, else 0
+    int32_t fast_shape;           // 128 densities, top-4, 13-dim streams: the batched kernels' shape
     int device;
     float *mean, *var, *det;      // device
     int64_t *cboff;               // device: float offset of (mgau, feat) block
@@ -31,7 +32,8 @@ struct PtmDev {
     const uint8_t *mixw, *sen2cb, *logadd8, *mixw_slot, *group_cb;
     const uint16_t *slot_sen;
     int32_t slot_stride, n_groups;
-    int32_t n_mgau, n_feat, n_density, n_sen, veclen, n_chain, ds_ratio, logadd8_size;
+    int32_t n_mgau, n_feat, n_density, n_sen, veclen, n_chain, ds_ratio, logadd8_size, topn;
+    int32_t featlen[16], featoff[16];
 };
 
 static inline PtmDev dev_view(const psgpu_ptm_model_t *m)
@@ -43,7 +45,8 @@ static inline PtmDev dev_view(const psgpu_ptm_model_t *m)
     p.slot_stride = m->slot_stride; p.n_groups = m->n_groups;
     p.n_mgau = m->n_mgau; p.n_feat = m->n_feat; p.n_density = m->n_density;
     p.n_sen = m->n_sen; p.veclen = m->veclen; p.n_chain = m->n_chain;
-    p.ds_ratio = m->ds_ratio; p.logadd8_size = m->logadd8_size;
+    p.ds_ratio = m->ds_ratio; p.logadd8_size = m->logadd8_size; p.topn = m->topn;
+    for (int f = 0; f < 16; ++f) { p.featlen[f] = m->featlen[f]; p.featoff[f] = m->featoff[f]; }
     return p;
 }
 
@@ -215,3 +218,78 @@ __device__ __forceinline__ bool closed_form_top4(TopN<4> &L, float d0, float d1,
     }
     return true;
 }
+
+constexpr int kGenK = 4;                        // codewords per lane of the any-shape path
+
+__device__ __forceinline__ float pick4(const float (&d)[kGenK], int c)
+{
+    const int k = c >> 6, l = c & 63;
+    float v = lane_value(d[0], l);
+    if (k == 1) v = lane_value(d[1], l);
+    if (k == 2) v = lane_value(d[2], l);
+    if (k == 3) v = lane_value(d[3], l);
+    return v;
+}
+
+// Any-shape exact frame step (up to 256 codewords, 4 per lane: cw = k*64 + lane).
+// SEMI = true: eval_topn (s2_semi_mgau.c:69-109) + eval_cb (:111-170).
+// SEMI = false: the PTM pair (ptm_mgau.c:87-226), whose acceptance test is the
+// finished float distance alone (pass dp = d).  Wave-uniform list state.  d[k] / dp[k] = finished distance / partial sum before the last
+// dimension of codeword k*64 + lane.  A codeword is accepted iff every float
+// guard `d >= worst->score` passed (<=> dp >= (float)worst) AND the truncated
+// finished distance is not below worst (`d_int < worst->score`), it is not in
+// the list, and it goes ahead of equal scores.
+template <int N, bool SEMI>
+__device__ __forceinline__ void generic_frame_step(TopN<N> &L, const float (&d)[kGenK], const float (&dp)[kGenK],
+                                                int lane, int n_density, bool scan)
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        L.sc[i] = dist_to_int(pick4(d, L.cw[i]));
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+            if (L.sc[j] > L.sc[j - 1]) {
+                int32_t ts = L.sc[j]; L.sc[j] = L.sc[j - 1]; L.sc[j - 1] = ts;
+                int32_t tc = L.cw[j]; L.cw[j] = L.cw[j - 1]; L.cw[j - 1] = tc;
+            }
+        }
+    }
+    if (!scan)
+        return;
+    int32_t di[kGenK];
+#pragma unroll
+    for (int k = 0; k < kGenK; ++k) di[k] = dist_to_int(d[k]);
+    int pos = 0;
+    for (;;) {
+        const int32_t W = L.sc[N - 1];
+        const float th = (float)W;
+        int found = -1;
+#pragma unroll
+        for (int k = 0; k < kGenK; ++k) {
+            const int cw = k * 64 + lane;
+            bool inl = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) inl |= (L.cw[i] == cw);
+            const bool ok = (cw < n_density) && (cw >= pos) && (dp[k] >= th) && (!SEMI || di[k] >= W) && !inl;
+            const unsigned long long b = __ballot(ok);
+            if (found < 0 && b) found = k * 64 + __ffsll((long long)b) - 1;
+        }
+        if (found < 0)
+            break;
+        const int32_t s = dist_to_int(pick4(d, found));
+        int q = N - 1;
+#pragma unroll
+        for (int k = N - 1; k > 0; --k) {
+            if (q == k && s >= L.sc[k - 1]) {
+                L.sc[k] = L.sc[k - 1];
+                L.cw[k] = L.cw[k - 1];
+                q = k - 1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (q == k) { L.sc[k] = s; L.cw[k] = found; }
+        pos = found + 1;
+    }
+}
+

@@ -85,6 +85,56 @@ void ptm_frame_topn_kernel(PtmDev p, FeatArg fa, MaskArg mask, int32_t do_scan,
     }
 }
 
+// kernel A, any shape: n_density <= 256 (4 codewords per lane), any stream
+// lengths, top-N 1..8 -- the exact sequential procedure only (no closed form).
+template <int N>
+__global__ __launch_bounds__(256)
+void ptm_frame_topn_generic(PtmDev p, FeatArg fa, MaskArg mask, int32_t do_scan,
+                            const int32_t *__restrict__ prev_cw,
+                            int32_t *__restrict__ cur_cw, int32_t *__restrict__ cur_sc,
+                            uint32_t *__restrict__ cur_active)
+{
+    const int lane = threadIdx.x & 63;
+    const int chain = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (blockIdx.x == 0 && threadIdx.x < 8)
+        cur_active[threadIdx.x] = mask.w[threadIdx.x];
+    if (chain >= p.n_chain)
+        return;
+    const int cb = chain / p.n_feat;
+    const int f = chain - cb * p.n_feat;
+    const bool active = (mask.w[cb >> 5] >> (cb & 31)) & 1u;
+    const int len = p.featlen[f];
+    // packed [mgau][feat][density][featlen[f]] (ms_gauden.c:211-221)
+    const size_t base = (size_t)cb * p.n_density * p.veclen + (size_t)p.n_density * p.featoff[f];
+    const float *mean = p.mean + base, *var = p.var + base;
+    const float *det = p.det + (size_t)chain * p.n_density;
+    const float *x = fa.x + p.featoff[f];
+    float d[kGenK];
+#pragma unroll
+    for (int k = 0; k < kGenK; ++k) {
+        const int cw = min(k * 64 + lane, p.n_density - 1);
+        const float *m = mean + (size_t)cw * len, *v = var + (size_t)cw * len;
+        float acc = det[cw];
+        for (int j = 0; j < len; ++j)
+            acc = gau_step(acc, x[j], m[j], v[j]);
+        d[k] = acc;
+    }
+    TopN<N> L;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        L.cw[i] = __builtin_amdgcn_readfirstlane(prev_cw[(size_t)chain * N + i]);
+        L.sc[i] = kMaxNegInt32;
+    }
+    generic_frame_step<N, false>(L, d, d, lane, p.n_density, active && do_scan);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            cur_cw[(size_t)chain * N + i] = L.cw[i];
+            cur_sc[(size_t)chain * N + i] = L.sc[i];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // kernel B: one workgroup.  ptm_mgau_codebook_norm (only when the slot was
 // just evaluated) + ptm_mgau_senone_eval over the listed senones.
@@ -92,6 +142,7 @@ void ptm_frame_topn_kernel(PtmDev p, FeatArg fa, MaskArg mask, int32_t do_scan,
 constexpr int kFrameThreads = 1024;
 constexpr int kFrameLa = 512;
 
+template <int N>
 __global__ __launch_bounds__(kFrameThreads)
 void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n_list,
                              const uint16_t *__restrict__ list,
@@ -99,7 +150,6 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
                              const uint32_t *__restrict__ cur_active,
                              int16_t *__restrict__ out)
 {
-    constexpr int N = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int16_t *s_out = reinterpret_cast<int16_t *>(smem);                    // [n_sen]
     const int out_bytes = ((p.n_sen * 2 + 15) / 16) * 16;
@@ -323,16 +373,31 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
         memset(&fa, 0, sizeof fa);
         memcpy(fa.x, feat, (size_t)m->veclen * sizeof(float));
         const int blocks = (m->n_chain + 3) / 4;
-        hipLaunchKernelGGL((ptm_frame_topn_kernel<13>), dim3(blocks), dim3(256), 0, s->stream,
-                           pv, fa, mask, (int32_t)(frame % m->ds_ratio == 0),
-                           (const int32_t *)(s->hist_cw + prev * slot_len), cur_cw, cur_sc, cur_act);
+        const int32_t do_scan = (int32_t)(frame % m->ds_ratio == 0);
+        const int32_t *prev_cw = s->hist_cw + prev * slot_len;
+        if (m->fast_shape)
+            hipLaunchKernelGGL((ptm_frame_topn_kernel<13>), dim3(blocks), dim3(256), 0, s->stream,
+                               pv, fa, mask, do_scan, prev_cw, cur_cw, cur_sc, cur_act);
+        else {
+#define PSGPU_GEN_CASE(NN) case NN: hipLaunchKernelGGL((ptm_frame_topn_generic<NN>), dim3(blocks), dim3(256), 0, \
+                s->stream, pv, fa, mask, do_scan, prev_cw, cur_cw, cur_sc, cur_act); break;
+            switch (m->topn) {
+                PSGPU_GEN_CASE(1) PSGPU_GEN_CASE(2) PSGPU_GEN_CASE(3) PSGPU_GEN_CASE(4)
+                PSGPU_GEN_CASE(5) PSGPU_GEN_CASE(6) PSGPU_GEN_CASE(7) default: PSGPU_GEN_CASE(8)
+            }
+#undef PSGPU_GEN_CASE
+        }
         PSGPU_HIP(hipGetLastError());
     }
     const size_t smem = (((size_t)m->n_sen * 2 + 15) / 16) * 16 + slot_len * 5;
-    hipLaunchKernelGGL(ptm_frame_senone_kernel, dim3(1), dim3(kFrameThreads), smem, s->stream,
-                       pv, (int32_t)fresh, (int32_t)(compallsen != 0), (int32_t)n_list,
-                       (const uint16_t *)s->d_list, (const int32_t *)cur_cw, cur_sc,
-                       (const uint32_t *)cur_act, s->d_out);
+#define PSGPU_SENF_CASE(NN) case NN: hipLaunchKernelGGL((ptm_frame_senone_kernel<NN>), dim3(1), dim3(kFrameThreads), \
+        smem, s->stream, pv, (int32_t)fresh, (int32_t)(compallsen != 0), (int32_t)n_list,                         \
+        (const uint16_t *)s->d_list, (const int32_t *)cur_cw, cur_sc, (const uint32_t *)cur_act, s->d_out); break;
+    switch (m->topn) {
+        PSGPU_SENF_CASE(1) PSGPU_SENF_CASE(2) PSGPU_SENF_CASE(3) PSGPU_SENF_CASE(4)
+        PSGPU_SENF_CASE(5) PSGPU_SENF_CASE(6) PSGPU_SENF_CASE(7) default: PSGPU_SENF_CASE(8)
+    }
+#undef PSGPU_SENF_CASE
     PSGPU_HIP(hipGetLastError());
     PSGPU_HIP(hipStreamSynchronize(s->stream));
     memcpy(senscr, s->h_out, (size_t)m->n_sen * sizeof(int16_t));

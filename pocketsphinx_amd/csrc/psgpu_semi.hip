@@ -17,7 +17,7 @@
 
 constexpr int kSemiMaxFeat = 8;
 constexpr int kSemiMaxTopn = 8;
-constexpr int kSemiK = 4;                 // codewords per lane -> n_density <= 256
+constexpr int kSemiK = kGenK;             // codewords per lane -> n_density <= 256
 constexpr int kSemiMaxVec = 64;
 constexpr int kSemiThreads = 512;
 constexpr int kSemiLa = 512;
@@ -49,76 +49,6 @@ struct psgpu_semi_state_s {
     hipStream_t stream;
     int32_t cur;
 };
-
-__device__ __forceinline__ float pick4(const float (&d)[kSemiK], int c)
-{
-    const int k = c >> 6, l = c & 63;
-    float v = lane_value(d[0], l);
-    if (k == 1) v = lane_value(d[1], l);
-    if (k == 2) v = lane_value(d[2], l);
-    if (k == 3) v = lane_value(d[3], l);
-    return v;
-}
-
-// eval_topn (s2_semi_mgau.c:69-109) + eval_cb (:111-170) on wave-uniform list
-// state.  d[k] / dp[k] = finished distance / partial sum before the last
-// dimension of codeword k*64 + lane.  A codeword is accepted iff every float
-// guard `d >= worst->score` passed (<=> dp >= (float)worst) AND the truncated
-// finished distance is not below worst (`d_int < worst->score`), it is not in
-// the list, and it goes ahead of equal scores.
-template <int N>
-__device__ __forceinline__ void semi_frame_step(TopN<N> &L, const float (&d)[kSemiK], const float (&dp)[kSemiK],
-                                                int lane, int n_density, bool scan)
-{
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        L.sc[i] = dist_to_int(pick4(d, L.cw[i]));
-#pragma unroll
-        for (int j = i; j > 0; --j) {
-            if (L.sc[j] > L.sc[j - 1]) {
-                int32_t ts = L.sc[j]; L.sc[j] = L.sc[j - 1]; L.sc[j - 1] = ts;
-                int32_t tc = L.cw[j]; L.cw[j] = L.cw[j - 1]; L.cw[j - 1] = tc;
-            }
-        }
-    }
-    if (!scan)
-        return;
-    int32_t di[kSemiK];
-#pragma unroll
-    for (int k = 0; k < kSemiK; ++k) di[k] = dist_to_int(d[k]);
-    int pos = 0;
-    for (;;) {
-        const int32_t W = L.sc[N - 1];
-        const float th = (float)W;
-        int found = -1;
-#pragma unroll
-        for (int k = 0; k < kSemiK; ++k) {
-            const int cw = k * 64 + lane;
-            bool inl = false;
-#pragma unroll
-            for (int i = 0; i < N; ++i) inl |= (L.cw[i] == cw);
-            const bool ok = (cw < n_density) && (cw >= pos) && (dp[k] >= th) && (di[k] >= W) && !inl;
-            const unsigned long long b = __ballot(ok);
-            if (found < 0 && b) found = k * 64 + __ffsll((long long)b) - 1;
-        }
-        if (found < 0)
-            break;
-        const int32_t s = dist_to_int(pick4(d, found));
-        int q = N - 1;
-#pragma unroll
-        for (int k = N - 1; k > 0; --k) {
-            if (q == k && s >= L.sc[k - 1]) {
-                L.sc[k] = L.sc[k - 1];
-                L.cw[k] = L.cw[k - 1];
-                q = k - 1;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-            if (q == k) { L.sc[k] = s; L.cw[k] = found; }
-        pos = found + 1;
-    }
-}
 
 template <int N>
 __global__ __launch_bounds__(kSemiThreads)
@@ -166,7 +96,7 @@ void semi_frame_kernel(SemiDev p, SemiFeat fa, int32_t fresh, int32_t do_scan, i
                 L.cw[i] = __builtin_amdgcn_readfirstlane(prev_cw[f * N + i]);
                 L.sc[i] = kMaxNegInt32;
             }
-            semi_frame_step<N>(L, d, dp, lane, p.n_density, do_scan != 0);
+            generic_frame_step<N, true>(L, d, dp, lane, p.n_density, do_scan != 0);
             // mgau_norm (:185-203): own best as the norm, beam cut leaves the tail raw
             const int32_t norm = L.sc[0] >> kSenscrShift;
             cnt = N;

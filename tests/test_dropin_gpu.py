@@ -63,6 +63,8 @@ CASES = {
     "ds2": ("goforward.raw", 1, ("ds", "2")),                     # codebook scan every 2nd frame
     "fwdflat_only": ("goforward.raw", 1, ("fwdtree", "no")),      # pass-2 codebook masking without pass 1
     "numbers": ("numbers.raw", 1, ()),
+    "topn2": ("goforward.raw", 1, ("topn", "2")),                 # any-shape per-call kernels
+    "topn6": ("goforward.raw", 1, ("topn", "6")),
     "something": ("something.raw", 1, ()),
     "librivox_0870": ("librivox-0870.raw", 1, ()),
     # vt->transform through the shim: 1-class MLLR for 3 streams x 13 written below (the bundled

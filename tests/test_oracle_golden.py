@@ -79,13 +79,15 @@ def test_history_dependence_is_real(tables):
     assert (a != b).any(axis=1).sum() < n // 4
 
 
-@pytest.mark.parametrize("case", ["default", "fwdtree_only"])
+@pytest.mark.parametrize("case", ["default", "fwdtree_only", "ptm_topn2", "ptm_topn6_ds2"])
 def test_senlog_replay(tables, case):
     """Replay every frame_eval call the reference made during a real decode
     (active lists, history-slot reuse, pass-2 codebook masking)."""
     g = _load("senlog_%s.npz" % case)
     feats = g["call_feat"]      # the vector the reference handed to each call
-    o = pso.OraclePTM(tables)
+    pr = pso.senlog_params(g)
+    o = pso.OraclePTM(tables, topn=int(pr["topn"]) if "topn" in pr else None,
+                      ds_ratio=int(pr["ds"]) if "ds" in pr else None)
     n = int(g["call_frame"].size)
     off = g["call_act_off"]
     hashes = np.empty(n, np.uint64)

@@ -21,10 +21,16 @@ def gpu_model(tables):
     m.close()
 
 
-@pytest.mark.parametrize("case", ["default", "fwdtree_only"])
+@pytest.mark.parametrize("case", ["default", "fwdtree_only", "ptm_topn2", "ptm_topn6_ds2"])
 def test_senlog_replay_gpu(tables, gpu_model, case):
+    """topn 2 / topn 6 + ds 2 go through the any-shape kernels (exact sequential
+    procedure only); the default shape through the specialised ones."""
     import pocketsphinx_amd as P
     g = _load("senlog_%s.npz" % case)
+    pr = pso.senlog_params(g)
+    own = None
+    if "topn" in pr or "ds" in pr:
+        own = gpu_model = P.PtmModel(tables, topn=int(pr.get("topn", 4)), ds_ratio=int(pr.get("ds", 1)))
     st = P.PtmState(gpu_model, int(tables["n_fast_hist"][0]))
     n = int(g["call_frame"].size)
     off = g["call_act_off"]
@@ -38,6 +44,10 @@ def test_senlog_replay_gpu(tables, gpu_model, case):
     assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
     assert np.array_equal(scr[g["sample_idx"]], g["call_scr_sample"])
     st.close()
+    if own is not None:
+        with pytest.raises(P.PsgpuError):        # the batched entry is specialised and says so
+            P.PtmMgau(own).score_utts(g["call_feat"][:4], [4])
+        own.close()
 
 
 def _random_list(rng, n_sen, sen2cb, mode):
