@@ -434,6 +434,14 @@ __device__ __forceinline__ int32_t logadd8_lds(const uint8_t *s_la, int32_t x, i
     return lo - (int32_t)s_la[d];
 }
 
+// |a - b| in one VALU op (v_sad_u32 with a zero accumulator)
+__device__ __forceinline__ int32_t abs_diff_u32(int32_t a, int32_t b)
+{
+    int32_t d;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <int ITERS, int kSenFr>                // kSenFr = frames per workgroup
 __global__ __launch_bounds__(512)
 void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
@@ -521,20 +529,36 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                         }
                     }
                     const uint2 sen2 = *reinterpret_cast<const uint2 *>(p.slot_sen + slot);   // 4 x uint16
+                    // the 4 slots x 3 streams are 12 independent log-add chains: advance them in
+                    // lock-step so that 12 table reads are in flight per wait (pad slots are
+                    // computed too -- their weights are valid bytes -- and dropped at the store)
+                    int32_t fden[4][NF];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        int32_t ascore = 0;
+                    for (int b = 0; b < 4; ++b)
 #pragma unroll
-                        for (int f = 0; f < NF; ++f) {
-                            int32_t fden = (int32_t)((w[f][0] >> (8 * b)) & 0xff) + (int32_t)(nsc[f] & 0xff);
+                        for (int f = 0; f < NF; ++f)
+                            fden[b][f] = (int32_t)((w[f][0] >> (8 * b)) & 0xff) + (int32_t)(nsc[f] & 0xff);
 #pragma unroll
-                            for (int k = 1; k < N; ++k) {
+                    for (int k = 1; k < N; ++k) {
+                        int32_t lo_[4][NF], dd[4][NF];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+#pragma unroll
+                            for (int f = 0; f < NF; ++f) {
                                 const int32_t y = (int32_t)((w[f][k] >> (8 * b)) & 0xff) +
                                                   (int32_t)((nsc[f] >> (8 * k)) & 0xff);
-                                fden = logadd8_lds(s_la, fden, y);
+                                lo_[b][f] = min(fden[b][f], y);
+                                dd[b][f] = abs_diff_u32(fden[b][f], y);
                             }
-                            ascore += fden;
-                        }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+#pragma unroll
+                            for (int f = 0; f < NF; ++f)
+                                fden[b][f] = lo_[b][f] - (int32_t)s_la[dd[b][f]];   // fast_logmath_add (tied_mgau_common.h:106-125)
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int32_t ascore = fden[b][0] + fden[b][1] + fden[b][2];
                         const uint32_t sen = ((b < 2 ? sen2.x : sen2.y) >> (16 * (b & 1))) & 0xffff;
                         if (sen != 0xffff) {            // pad slots are dropped
                             orow_s[sen] = (int16_t)ascore;
