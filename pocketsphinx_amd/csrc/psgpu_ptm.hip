@@ -447,9 +447,11 @@ __global__ __launch_bounds__(512)
 void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                             const uint32_t *__restrict__ topn_cw,
                             int16_t *__restrict__ senscr, int32_t *__restrict__ best_out,
-                            uint32_t flags, int32_t total_frames)
+                            uint32_t flags, int32_t total_frames, int32_t *__restrict__ zero_word)
 {
     constexpr int N = 4, NF = 3, MAXC = 256;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0)
+        *zero_word = 0;                         // open-entry counter of the top-N pass, for the next call
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int out_stride = ((p.n_sen * 2 + 15) / 16) * 8;         // int16 entries per staged row
     int16_t *s_out = reinterpret_cast<int16_t *>(smem);          // [kSenFr][out_stride]
@@ -776,10 +778,14 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
             PSGPU_HIP(hipMalloc((void **)&m->open_flags, need));
             PSGPU_HIP(hipMalloc((void **)&m->fix_list, (need + 1) * sizeof(int32_t)));
             m->flags_cap = need;
+            m->count_dirty = 1;
         }
         int32_t *fix_count = m->fix_list + m->flags_cap;            // last slot of the list buffer
         const int32_t fix_thr = (int32_t)(need / 64);
-        PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
+        static const int fix_grid = [] { const char *e = getenv("PSGPU_FIX_GRID"); return e ? atoi(e) : 512; }();
+        if (m->count_dirty)                  // normally the senone kernel of the previous call zeroed it
+            PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
+        m->count_dirty = 1;
         const long long n_tiles = ((long long)total_frames + 63) / 64;
         const long long lw = n_tiles * m->n_chain;
         if (m->timing) hipEventRecord(m->ev[0], st);
@@ -788,7 +794,7 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
                            topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
         PSGPU_HIP(hipGetLastError());
         if (m->timing) hipEventRecord(m->ev[1], st);
-        PSGPU_CHAIN(2048, (const uint8_t *)m->open_flags, (const int32_t *)fix_count, (const int32_t *)m->fix_list, fix_thr);
+        PSGPU_CHAIN(fix_grid, (const uint8_t *)m->open_flags, (const int32_t *)fix_count, (const int32_t *)m->fix_list, fix_thr);
     }
     else {
         if (m->timing) { hipEventRecord(m->ev[0], st); hipEventRecord(m->ev[1], st); }
@@ -831,13 +837,14 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
             hipStream_t st = (hipStream_t)stream;
             const PtmDev pv = dev_view(m);
             const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(topn_cw_dev);
+            int32_t *zw = m->fix_list ? m->fix_list + m->flags_cap : nullptr;
 #define PSGPU_SEN_CASE(I) case I:                                                                              \
                 if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1>), grid, block, sm, st, pv,        \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames);           \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
                 else if (kSenFr == 4) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 4>), grid, block, sm, st, pv,   \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames);           \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
                 else hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 2>), grid, block, sm, st, pv,                    \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames);           \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
                 break;
             switch (iters) {
                 PSGPU_SEN_CASE(1) PSGPU_SEN_CASE(2) PSGPU_SEN_CASE(3) PSGPU_SEN_CASE(4)
@@ -845,6 +852,7 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
             }
 #undef PSGPU_SEN_CASE
             PSGPU_HIP(hipGetLastError());
+            if (zw) m->count_dirty = 0;
             return PSGPU_OK;
         }
     }

@@ -23,6 +23,7 @@ struct psgpu_ptm_model_s {
     uint8_t *open_flags;          // scratch [n_chain][frames]: entries the lane kernel left to the fix-up
     int32_t *fix_list;            // scratch [frames * n_chain] open entries + 1 counter word
     size_t flags_cap;
+    int count_dirty;              // the open-entry counter must be zeroed before the next lane pass
     hipEvent_t ev[4];             // optional per-kernel timing: lane | fix-up | (gap) | senone
     int timing;
 };
