@@ -188,6 +188,21 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
                          int32_t compallsen);
 int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, int32_t *score,
                              uint8_t *mgau_active);
+/* Look-ahead (additive; the reference scores one frame per call).  Announces
+ * the feature vectors of frames frame0 .. frame0+n_frames-1 ([n_frames][veclen])
+ * that later psgpu_ptm_frame_eval calls will present -- in full-utterance decoding
+ * acmod holds them all before the search starts (acmod.c:496-528).  When the first
+ * of them is asked for as a fresh evaluation with every codebook active, all of
+ * them are scored in ONE batched pass (the kernels of psgpu_ptm_score_batch_dev,
+ * seeded with the ring) and the un-normalised rows come to the host; each later
+ * call whose frame, feature vector and call pattern match is then answered from
+ * that row (score - min over the active list, ptm_mgau.c:393-400) with no device
+ * work.  Anything else -- a codebook subset on a fresh call (pass 2), frames out of
+ * order, a different vector -- falls back to the per-call kernels after the ring has
+ * been brought up to date, so results are identical either way.  A call with
+ * n_frames == 0 drops the cache.  Models outside the batched kernels' shape ignore it. */
+int psgpu_ptm_state_lookahead(psgpu_ptm_state_t *s, const float *feats, int32_t frame0, int32_t n_frames);
+int psgpu_ptm_state_lookahead_stats(psgpu_ptm_state_t *s, int64_t *calls_served, int64_t *batches);
 /* Load one slot of the ring from a host image of ptm_fast_eval_t
  * (ptm_mgau.h:68-71): cw/score [n_chain][topn] int32, mgau_active one byte
  * per codebook (NULL = all active).  Lets a shim attached to a decoder that

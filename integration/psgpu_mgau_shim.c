@@ -51,6 +51,11 @@ typedef struct psgpu_mgau_s {
     psgpu_semi_state_t *sstate;
     ms_mgau_model_t *cpu_ms;      /* ... or ("ms") */
     psgpu_ms_model_t *mmodel;
+    acmod_t *acmod;               /* set by psgpu_mgau_attach: lets frame_eval look ahead */
+    int la_c0, la_cn;             /* frames announced to psgpu_ptm_state_lookahead */
+    int la_expect;                /* next fresh frame if the caller keeps marching */
+    float *la_buf;
+    int la_cap;
     float *vec;                   /* one frame, streams concatenated */
     int n_feat;
     int veclen;
@@ -485,8 +490,20 @@ psgpu_mgau_attach(ps_decoder_t *ps)
     gpu = psgpu_mgau_wrap(ps->acmod->mgau);
     if (gpu == NULL)
         return -1;
+    if (gpu->vt == &psgpu_mgau_funcs)
+        ((psgpu_mgau_t *)gpu)->acmod = ps->acmod;
     ps->acmod->mgau = gpu;        /* freed through vt->free by acmod_free (acmod.c:315) */
     return 0;
+}
+
+long
+psgpu_mgau_n_cache_served(ps_mgau_t *ps)
+{
+    int64_t a = 0, b = 0;
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
+        return 0;
+    psgpu_ptm_state_lookahead_stats(((psgpu_mgau_t *)ps)->state, &a, &b);
+    return (long)a;
 }
 
 int32
@@ -495,6 +512,46 @@ psgpu_mgau_n_calls(ps_mgau_t *ps)
     if (ps == NULL || (ps->vt != &psgpu_mgau_funcs && ps->vt != &psgpu_semi_funcs && ps->vt != &psgpu_ms_funcs))
         return -1;
     return ((psgpu_mgau_t *)ps)->n_calls;
+}
+
+/* Full-utterance decoding puts every frame's features into acmod->feat_buf before
+ * the search starts (acmod_process_full_cep, acmod.c:496-528); streaming leaves a
+ * few frames there.  Announce whatever lies ahead of `frame` so that the library
+ * can score it in one batched pass (psgpu_ptm_state_lookahead). */
+static void
+shim_announce(psgpu_mgau_t *g, int32 frame)
+{
+    acmod_t *a = g->acmod;
+    int avail, i;
+
+    if (a == NULL || a->feat_buf == NULL)
+        return;
+    if (frame == g->la_expect && frame >= g->la_c0 && frame < g->la_c0 + g->la_cn) {
+        ++g->la_expect;                               /* announced, and arriving in order */
+        return;
+    }
+    g->la_expect = frame + 1;                         /* new utterance / new pass / a jump */
+    g->la_c0 = g->la_cn = 0;
+    if (frame < a->output_frame)
+        return;
+    avail = a->output_frame + a->n_feat_frame - frame;
+    if (avail < 8) {
+        psgpu_ptm_state_lookahead(g->state, NULL, frame, 0);   /* drop a stale cache */
+        return;
+    }
+    if (avail > g->la_cap) {
+        g->la_buf = ckd_realloc(g->la_buf, sizeof(float) * (size_t)avail * g->veclen);
+        g->la_cap = avail;
+    }
+    for (i = 0; i < avail; ++i) {
+        int idx = (a->feat_outidx + (frame - a->output_frame) + i) % a->n_feat_alloc;
+        /* streams of one frame are contiguous (feat_array_alloc, feat/feat.c:356-384) */
+        memcpy(g->la_buf + (size_t)i * g->veclen, a->feat_buf[idx][0], sizeof(float) * g->veclen);
+    }
+    if (psgpu_ptm_state_lookahead(g->state, g->la_buf, frame, avail) == PSGPU_OK) {
+        g->la_c0 = frame;
+        g->la_cn = avail;
+    }
 }
 
 /* ps_mgaufuncs_t.frame_eval (acmod.h:101-107), called by acmod_score (acmod.c:1108) */
@@ -510,6 +567,8 @@ shim_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
         memcpy(g->vec + o, feat[f], sizeof(float) * gd->featlen[f]);
         o += gd->featlen[f];
     }
+    if (frame >= ps->frame_idx)
+        shim_announce(g, frame);
     rc = psgpu_ptm_frame_eval(g->state, senscr, senone_active, n_senone_active, g->vec,
                               frame, ps->frame_idx, compallsen);
     ++g->n_calls;
@@ -556,6 +615,7 @@ shim_transform(ps_mgau_t *ps, ps_mllr_t *mllr)
         ckd_free(cw); ckd_free(sc); ckd_free(act);
     }
     g->state = NULL;
+    g->la_c0 = g->la_cn = 0;
     psgpu_ptm_state_free(old);
     if (upload_model(g) < 0)
         return -1;
@@ -573,6 +633,7 @@ shim_free(ps_mgau_t *ps)
     if (g->state) psgpu_ptm_state_free(g->state);
     if (g->model) psgpu_ptm_model_free(g->model);
     if (g->cpu) ps_mgau_free(ps_mgau_base(g->cpu));
+    ckd_free(g->la_buf);
     ckd_free(g->vec);
     ckd_free(g);
 }

@@ -22,6 +22,8 @@ int psgpu_mgau_attach(ps_decoder_t *ps);
 
 /* number of frame_eval calls served by the device (-1 if not a psgpu scorer) */
 int32 psgpu_mgau_n_calls(ps_mgau_t *mgau);
+/* of which answered from the look-ahead cache (one batched pass per utterance pass) */
+long psgpu_mgau_n_cache_served(ps_mgau_t *mgau);
 
 #ifdef __cplusplus
 }

@@ -316,13 +316,14 @@ main(int argc, char **argv)
                "\"hyp_equal\": %s, \"seg_equal\": %s, \"hyp_cpu\": \"%s\", \"hyp_gpu\": \"%s\", "
                "\"score_cpu\": %d, \"score_gpu\": %d, \"n_seg\": %d, "
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
-               "\"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
+               "\"cache_served\": %ld, \"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
                "\"total_frames\": %d, \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
                ra[n_res - 1].hyp, rb[n_res - 1].hyp, ra[n_res - 1].score, rb[n_res - 1].score,
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
+               use_mgau ? psgpu_mgau_n_cache_served(gpu->acmod->mgau) : 0L,
                use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames);
         for (u = 0; u < n_res; ++u)
             printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",

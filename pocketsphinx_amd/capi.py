@@ -18,7 +18,7 @@ SYMBOLS = [
     "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",
     "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev", "psgpu_ptm_kernel_timing", "psgpu_ptm_last_kernel_ms",
     "psgpu_ptm_state_create", "psgpu_ptm_state_free", "psgpu_ptm_state_reset",
-    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn",
+    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn", "psgpu_ptm_state_lookahead", "psgpu_ptm_state_lookahead_stats",
     "psgpu_semi_model_create", "psgpu_semi_model_free", "psgpu_semi_state_create",
     "psgpu_semi_state_free", "psgpu_semi_state_reset", "psgpu_semi_frame_eval",
     "psgpu_semi_state_get_topn", "psgpu_semi_state_set_topn",
@@ -96,6 +96,8 @@ def lib():
     L.psgpu_ptm_frame_eval.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32]
     L.psgpu_ptm_state_get_topn.argtypes = [vp, i32, vp, vp, vp]
     L.psgpu_ptm_state_set_topn.argtypes = [vp, i32, vp, vp, vp]
+    L.psgpu_ptm_state_lookahead.argtypes = [vp, vp, i32, i32]
+    L.psgpu_ptm_state_lookahead_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.psgpu_semi_model_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32]
     L.psgpu_semi_model_free.argtypes = [vp]
     L.psgpu_semi_model_free.restype = None

@@ -31,7 +31,65 @@ struct psgpu_ptm_state_s {
     int16_t *d_out;
     hipStream_t stream;
     int32_t cur;             // slot of the most recent call (s->f)
+    // ---- look-ahead cache (psgpu_ptm_state_lookahead): the frames the caller
+    // announced, scored in ONE batched pass when the first of them is asked for
+    struct {
+        int valid, computed, flushed;
+        int c0, cn, cap;         // announced frames c0 .. c0+cn-1
+        int next_fresh;          // next frame the cache may serve as a fresh evaluation
+        int max_fresh;           // last frame served fresh from the cache (c0-1: none)
+        int limit;               // frames >= limit are no longer covered (history diverged)
+        float *h_feat, *d_feat;  // [cn][veclen] (pinned / device)
+        int32_t *d_off, *d_sc, *d_best, *h_best;
+        uint8_t *d_cw, *d_seed;
+        int16_t *d_raw, *h_raw;  // [cn][n_sen] un-normalised scores (pinned host copy)
+    } la;
+    long la_served, la_batches;
 };
+
+// look-ahead: seed lists of the batched pass = codewords of a ring slot
+__global__ void la_seed_kernel(const int32_t *__restrict__ slot_cw, uint8_t *__restrict__ seed, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) seed[i] = (uint8_t)slot_cw[i];
+}
+
+// look-ahead: write the lists of cache frame t (chain-major batch buffers) into
+// ring slot t % n_hist exactly as a fresh all-codebooks-active evaluation would
+// leave them: codewords, scores normalised by ptm_mgau_codebook_norm
+// (ptm_mgau.c:265-295), every codebook active.  One workgroup per frame.
+__global__ __launch_bounds__(256)
+void la_flush_kernel(PtmDev p, const int32_t *__restrict__ sc, const uint32_t *__restrict__ cw,
+                     int32_t cn, int32_t c0, int32_t t_first, int32_t n_hist,
+                     int32_t *__restrict__ hist_cw, int32_t *__restrict__ hist_sc,
+                     uint32_t *__restrict__ hist_active)
+{
+    __shared__ int32_t s_norm[16];
+    const int t = t_first + blockIdx.x;
+    const int slot = t % n_hist;
+    const int rel = t - c0;
+    if (threadIdx.x < 16) s_norm[threadIdx.x] = kWorstScore;
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.n_chain; c += blockDim.x)
+        atomicMax(&s_norm[c % p.n_feat], sc[((size_t)c * cn + rel) * 4] >> kSenscrShift);
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.n_chain; c += blockDim.x) {
+        const int4 v = *reinterpret_cast<const int4 *>(sc + ((size_t)c * cn + rel) * 4);
+        const uint32_t w = cw[(size_t)c * cn + rel];
+        const int32_t norm = s_norm[c % p.n_feat];
+        const int32_t raw[4] = {v.x, v.y, v.z, v.w};
+        int32_t *ocw = hist_cw + ((size_t)slot * p.n_chain + c) * 4;
+        int32_t *osc = hist_sc + ((size_t)slot * p.n_chain + c) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int32_t x = (int32_t)(0u - ((uint32_t)(raw[k] >> kSenscrShift) - (uint32_t)norm));
+            if (x > kMaxNegAscr) x = kMaxNegAscr;
+            ocw[k] = (int32_t)((w >> (8 * k)) & 0xff);
+            osc[k] = x;
+        }
+    }
+    if (threadIdx.x < 8) hist_active[(size_t)slot * 8 + threadIdx.x] = 0xffffffffu;
+}
 
 // ---------------------------------------------------------------------------
 // kernel A: one wavefront per (codebook, stream) chain, one frame.
@@ -257,6 +315,84 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+static void la_release(psgpu_ptm_state_t *s)
+{
+    if (s->la.h_feat) hipHostFree(s->la.h_feat);
+    if (s->la.h_raw) hipHostFree(s->la.h_raw);
+    if (s->la.h_best) hipHostFree(s->la.h_best);
+    hipFree(s->la.d_feat); hipFree(s->la.d_off); hipFree(s->la.d_sc); hipFree(s->la.d_cw);
+    hipFree(s->la.d_seed); hipFree(s->la.d_raw); hipFree(s->la.d_best);
+    memset(&s->la, 0, sizeof s->la);
+}
+
+// Bring the ring up to date with the frames the cache served as fresh
+// evaluations (the reference writes slot t % H on every fresh call).
+static int la_flush(psgpu_ptm_state_t *s)
+{
+    if (!s->la.valid || s->la.flushed || s->la.max_fresh < s->la.c0)
+        return PSGPU_OK;
+    const int t_last = s->la.max_fresh;
+    int t_first = t_last - s->n_hist + 1;
+    if (t_first < s->la.c0) t_first = s->la.c0;
+    hipLaunchKernelGGL(la_flush_kernel, dim3(t_last - t_first + 1), dim3(256), 0, s->stream, dev_view(s->m),
+                       (const int32_t *)s->la.d_sc, reinterpret_cast<const uint32_t *>(s->la.d_cw),
+                       s->la.cn, s->la.c0, t_first, s->n_hist, s->hist_cw, s->hist_sc, s->hist_active);
+    PSGPU_HIP(hipGetLastError());
+    s->la.flushed = 1;
+    return PSGPU_OK;
+}
+
+// One batched pass over the announced frames, seeded with the ring slot of frame c0 - 1.
+static int la_compute(psgpu_ptm_state_t *s)
+{
+    psgpu_ptm_model_t *m = s->m;
+    const int cn = s->la.cn, prev = (s->la.c0 % s->n_hist == 0) ? s->n_hist - 1 : (s->la.c0 % s->n_hist) - 1;
+    const size_t slot_len = (size_t)m->n_chain * m->topn;
+    const int32_t off[2] = {0, cn};
+    PSGPU_HIP(hipMemcpyAsync(s->la.d_feat, s->la.h_feat, (size_t)cn * m->veclen * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    PSGPU_HIP(hipMemcpyAsync(s->la.d_off, off, sizeof off, hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(la_seed_kernel, dim3((unsigned)((slot_len + 255) / 256)), dim3(256), 0, s->stream,
+                       (const int32_t *)(s->hist_cw + prev * slot_len), s->la.d_seed, (int)slot_len);
+    PSGPU_HIP(hipGetLastError());
+    int rc = psgpu_ptm_score_batch_dev(m, s->la.d_feat, s->la.d_off, 1, cn, s->la.d_seed, nullptr, s->la.d_sc,
+                                       s->la.d_cw, s->la.d_raw, s->la.d_best, PSGPU_PTM_RAW_SCORES, s->stream);
+    if (rc != PSGPU_OK) return rc;
+    PSGPU_HIP(hipMemcpyAsync(s->la.h_raw, s->la.d_raw, (size_t)cn * m->n_sen * sizeof(int16_t), hipMemcpyDeviceToHost, s->stream));
+    PSGPU_HIP(hipMemcpyAsync(s->la.h_best, s->la.d_best, (size_t)cn * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    s->la.computed = 1;
+    ++s->la_batches;
+    return PSGPU_OK;
+}
+
+// Scores of one call from the cached un-normalised row: listed senones get
+// raw - min over the list, every other entry -min (ptm_mgau.c:393-400).
+static void la_serve(psgpu_ptm_state_t *s, int frame, int16_t *senscr, int compallsen, int n_list)
+{
+    const psgpu_ptm_model_t *m = s->m;
+    const int16_t *raw = s->la.h_raw + (size_t)(frame - s->la.c0) * m->n_sen;
+    if (compallsen) {
+        const uint32_t best = (uint32_t)s->la.h_best[frame - s->la.c0];
+        for (int i = 0; i < m->n_sen; ++i)
+            senscr[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)raw[i] - best);
+    }
+    else {
+        int32_t bs = 0x7fffffff;
+        for (int i = 0; i < n_list; ++i) {
+            const int32_t v = raw[s->h_list[i]];
+            if (v < bs) bs = v;
+        }
+        const uint32_t best = (uint32_t)bs;
+        const int16_t rest = (int16_t)(uint16_t)(0u - best);
+        for (int i = 0; i < m->n_sen; ++i) senscr[i] = rest;
+        for (int i = 0; i < n_list; ++i) {
+            const int sen = s->h_list[i];
+            senscr[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)raw[sen] - best);
+        }
+    }
+    ++s->la_served;
+}
+
 extern "C" {
 
 int psgpu_ptm_state_reset(psgpu_ptm_state_t *s)
@@ -278,6 +414,7 @@ int psgpu_ptm_state_reset(psgpu_ptm_state_t *s)
     free(cw); free(sc);
     PSGPU_HIP(e1); PSGPU_HIP(e2); PSGPU_HIP(e3);
     s->cur = 0;
+    s->la.valid = 0;
     return PSGPU_OK;
 }
 
@@ -318,7 +455,55 @@ void psgpu_ptm_state_free(psgpu_ptm_state_t *s)
     hipFree(s->hist_cw); hipFree(s->hist_sc); hipFree(s->hist_active);
     if (s->h_list) hipHostFree(s->h_list);
     if (s->h_out) hipHostFree(s->h_out);
+    la_release(s);
     delete s;
+}
+
+int psgpu_ptm_state_lookahead(psgpu_ptm_state_t *s, const float *feats, int32_t frame0, int32_t n_frames)
+{
+    PSGPU_REQUIRE(s && (feats || n_frames == 0) && frame0 >= 0 && n_frames >= 0,
+                  "psgpu_ptm_state_lookahead: bad argument");
+    psgpu_ptm_model_t *m = s->m;
+    int rc = la_flush(s);                // the ring must be exact before the cache is replaced
+    if (rc != PSGPU_OK) return rc;
+    s->la.valid = 0;
+    // the batched kernels are specialised (en-us shape) and count down-sampling from the
+    // first frame of the pass, the reference from absolute frame numbers (ptm_mgau.c:242)
+    if (n_frames == 0 || !m->fast_shape || frame0 % m->ds_ratio != 0)
+        return PSGPU_OK;
+    if (n_frames > s->la.cap) {
+        la_release(s);
+        const size_t n = (size_t)n_frames, ne = n * m->n_chain * m->topn;
+        hipError_t e = hipHostMalloc((void **)&s->la.h_feat, n * m->veclen * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_feat, n * m->veclen * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_off, 2 * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_sc, ne * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_cw, ne);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_seed, (size_t)m->n_chain * m->topn);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_raw, n * m->n_sen * sizeof(int16_t));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->la.h_raw, n * m->n_sen * sizeof(int16_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->la.d_best, n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->la.h_best, n * sizeof(int32_t), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            la_release(s);
+            psgpu_set_error("psgpu_ptm_state_lookahead: %s", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP;
+        }
+        s->la.cap = n_frames;
+    }
+    memcpy(s->la.h_feat, feats, (size_t)n_frames * m->veclen * sizeof(float));
+    s->la.valid = 1; s->la.computed = 0; s->la.flushed = 1;
+    s->la.c0 = frame0; s->la.cn = n_frames;
+    s->la.next_fresh = frame0; s->la.max_fresh = frame0 - 1; s->la.limit = frame0 + n_frames;
+    return PSGPU_OK;
+}
+
+int psgpu_ptm_state_lookahead_stats(psgpu_ptm_state_t *s, int64_t *served, int64_t *batches)
+{
+    PSGPU_REQUIRE(s != nullptr, "psgpu_ptm_state_lookahead_stats: NULL state");
+    if (served) *served = s->la_served;
+    if (batches) *batches = s->la_batches;
+    return PSGPU_OK;
 }
 
 int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
@@ -357,6 +542,46 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
                 return PSGPU_EINVAL;
             }
             s->h_list[n_list++] = (uint16_t)sen;
+        }
+    }
+    if (s->la.valid) {
+        // Look-ahead cache.  A frame may be served from it when it is one of the
+        // announced frames, its feature vector is the announced one, and -- for
+        // a fresh evaluation -- every codebook is active and frames arrive in
+        // order: then the slot the reference would compute is the all-active
+        // list of the batched pass, whose history is the same sequential one.
+        const int rel = frame - s->la.c0;
+        const bool in_range = rel >= 0 && frame < s->la.limit &&
+            memcmp(feat, s->la.h_feat + (size_t)rel * m->veclen, (size_t)m->veclen * sizeof(float)) == 0;
+        bool all_cb = compallsen != 0;
+        if (!all_cb && in_range && fresh) {
+            uint32_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int cnt = 0;
+            for (int i = 0; i < n_list && cnt < m->n_mgau; ++i) {
+                const int cb = m->h_sen2cb[s->h_list[i]];
+                if (!((seen[cb >> 5] >> (cb & 31)) & 1u)) { seen[cb >> 5] |= 1u << (cb & 31); ++cnt; }
+            }
+            all_cb = (cnt == m->n_mgau);
+        }
+        if (in_range && fresh && all_cb && frame == s->la.next_fresh) {
+            if (!s->la.computed) {
+                const int rc = la_compute(s);
+                if (rc != PSGPU_OK) return rc;
+            }
+            la_serve(s, frame, senscr, compallsen, n_list);
+            s->la.max_fresh = frame; s->la.next_fresh = frame + 1; s->la.flushed = 0;
+            return PSGPU_OK;
+        }
+        if (in_range && !fresh && frame <= s->la.max_fresh && frame > s->la.max_fresh - s->n_hist) {
+            la_serve(s, frame, senscr, compallsen, n_list);     // slot reuse: any list
+            return PSGPU_OK;
+        }
+        // per-call from here: the ring must hold what the cache stood for
+        const int rc = la_flush(s);
+        if (rc != PSGPU_OK) return rc;
+        if (fresh) {                      // the history diverges from the batched pass at this frame
+            if (frame < s->la.limit) s->la.limit = frame;
+            s->la.next_fresh = 0x7fffffff;
         }
     }
     if (fresh) {
@@ -411,6 +636,7 @@ int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, in
     if (slot < 0) slot = s->cur;
     PSGPU_REQUIRE(slot < s->n_hist, "slot %d outside the %d-slot ring", slot, s->n_hist);
     const size_t slot_len = (size_t)s->m->n_chain * s->m->topn;
+    { const int rc = la_flush(s); if (rc != PSGPU_OK) return rc; }
     PSGPU_HIP(hipStreamSynchronize(s->stream));
     if (cw) PSGPU_HIP(hipMemcpy(cw, s->hist_cw + slot * slot_len, slot_len * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (score) PSGPU_HIP(hipMemcpy(score, s->hist_sc + slot * slot_len, slot_len * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -432,6 +658,8 @@ int psgpu_ptm_state_set_topn(psgpu_ptm_state_t *s, int32_t slot, const int32_t *
     const size_t slot_len = (size_t)m->n_chain * m->topn;
     for (size_t i = 0; i < slot_len; ++i)
         PSGPU_REQUIRE(cw[i] >= 0 && cw[i] < m->n_density, "codeword %d outside the codebook", cw[i]);
+    { const int rc = la_flush(s); if (rc != PSGPU_OK) return rc; }
+    s->la.valid = 0;
     uint32_t act[8];
     memset(act, mgau_active ? 0 : 0xff, sizeof act);
     if (mgau_active)

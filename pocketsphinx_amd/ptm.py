@@ -117,6 +117,17 @@ class PtmState:
             "psgpu_ptm_frame_eval")
         return scr
 
+    def lookahead(self, feats, frame0):
+        """Announce upcoming frames (psgpu_ptm_state_lookahead)."""
+        feats = np.ascontiguousarray(feats, np.float32).reshape(-1, self.m.veclen)
+        capi.check(capi.lib().psgpu_ptm_state_lookahead(self.h, _p(feats), int(frame0), int(feats.shape[0])),
+                   "psgpu_ptm_state_lookahead")
+
+    def lookahead_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        capi.check(capi.lib().psgpu_ptm_state_lookahead_stats(self.h, C.byref(a), C.byref(b)), "lookahead_stats")
+        return int(a.value), int(b.value)
+
     def cur_topn(self, slot=-1):
         cw = np.empty((self.m.n_chain, self.m.topn), np.int32)
         sc = np.empty((self.m.n_chain, self.m.topn), np.int32)

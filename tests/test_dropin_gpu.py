@@ -81,6 +81,9 @@ def test_dropin_decode_identical(case, tmp_path):
         extra = tuple(_write_mllr(tmp_path) if e == "@MLLR@" else e for e in extra)
     r = run(raw, nrep, *extra)
     assert r["mgau"] == "ptm-psgpu"
+    if case in ("default_3pass_x2", "fwdtree_only", "numbers", "librivox_0870"):
+        # pass-1 calls are answered from the look-ahead cache (one batched pass per utterance)
+        assert r["cache_served"] > r["calls_gpu"] // 2, r
     assert r["device_calls"] == r["calls_gpu"] > 0
     assert r["calls_cpu"] == r["calls_gpu"]
     assert r["mismatching_calls"] == 0, r

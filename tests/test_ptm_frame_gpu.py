@@ -130,3 +130,41 @@ def test_reset_hist(tables, gpu_model):
         y = b.frame_eval(g["feat"][t_], t_, compallsen=True, frame_idx=t_)
         assert np.array_equal(x, y)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", ["default", "fwdtree_only"])
+def test_lookahead_cache_is_invisible(tables, gpu_model, case):
+    """psgpu_ptm_state_lookahead: announce every pass's frames up front (what the
+    shim does from acmod's feature buffer).  Pass-1 calls (phone loop: all
+    codebooks, search: slot reuse) must be answered from the batched pass,
+    pass-2 calls (codebook subsets) must fall back to the per-call kernels on a
+    ring brought up to date -- and every score vector must still equal the
+    reference's, call for call."""
+    import pocketsphinx_amd as P
+    g = _load("senlog_%s.npz" % case)
+    st = P.PtmState(gpu_model, int(tables["n_fast_hist"][0]))
+    n = int(g["call_frame"].size)
+    off = g["call_act_off"]
+    fr, fi = g["call_frame"], g["call_frame_idx"]
+    scr = np.empty((n, gpu_model.n_sen), np.int16)
+    c = 0
+    while c < n:
+        if fr[c] == 0 and fi[c] == 0:
+            # start of a pass: collect the feature vector of every frame up to the next pass start
+            e = c + 1
+            while e < n and not (fr[e] == 0 and fi[e] == 0):
+                e += 1
+            T = int(fr[c:e].max()) + 1
+            feats = np.zeros((T, gpu_model.veclen), np.float32)
+            for k in range(c, e):
+                feats[fr[k]] = g["call_feat"][k]
+            st.lookahead(feats, 0)
+        na = int(g["call_nact"][c])
+        act = None if na < 0 else g["call_act"][off[c]:off[c] + na]
+        scr[c] = st.frame_eval(g["call_feat"][c], int(fr[c]), active=act, compallsen=(na < 0), frame_idx=int(fi[c]))
+        c += 1
+    bad = np.nonzero(pso.row_hash(scr) != g["call_scr_hash"])[0]
+    assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], fr[bad[0]])
+    served, batches = st.lookahead_stats()
+    assert served > n // 3 and batches >= 1, (served, batches, n)
+    st.close()
