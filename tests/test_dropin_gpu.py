@@ -202,6 +202,21 @@ def test_ms_dropin_decode_identical(name, kw, extra):
     assert r["hyp_gpu"] == "go forward ten meters"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("fwdflat", "no", "bestpath", "no")])
+def test_large_vocabulary_dropin(extra):
+    """126,052-word vocabulary (every base word of cmudict-en-us.dict, synthetic
+    Zipf LM: the reference ships no large LM): ~250k lextree
+    channels and thousands of active HMMs per frame go through the Viterbi
+    kernel each frame; scores, hypothesis and segmentation stay identical."""
+    r = run("goforward.raw", 1, *extra, lm="big.arpa", dic="cmudict-en-us.dict", binary=BIN_FULL)
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
+    assert r["hyp_gpu"] == "go forward ten meters"
+    assert r["hmm_evals"] > 1000 * r["n_frames"], r      # > 1000 HMMs per frame on average
+    assert r["cache_served"] > 0
+
+
 def test_attach_fails_loudly_without_gpu():
     """No CPU fallback inside the product: on a box without a gfx950 device the
     attach fails and the checker exits 3."""
