@@ -210,17 +210,19 @@ main(int argc, char **argv)
     /* inputs: one raw/.mfc file, or "@CTLFILE:DIR" = every id of CTLFILE as DIR/id.mfc
      * (pocketsphinx_batch -ctl/-cepdir, test/regression/test-tidigits-simple.sh) */
     if (argv[4][0] == '@') {
-        char *spec = strdup(argv[4] + 1), *dir = strchr(spec, ':'), line[512];
+        char *spec = strdup(argv[4] + 1), *dir = strchr(spec, ':'), *ext, line[512];
         if (!dir) { fprintf(stderr, "bad ctl spec\n"); return 2; }
         *dir++ = 0;
+        ext = strchr(dir, ':');                       /* optional third field: file extension */
+        if (ext) *ext++ = 0; else ext = "mfc";
         fp = fopen(spec, "r");
         if (!fp) { perror(spec); return 2; }
         while (fgets(line, sizeof line, fp)) {
             line[strcspn(line, "\r\n")] = 0;
             if (!line[0]) continue;
             in_id[n_in] = strdup(line);
-            in_path[n_in] = malloc(strlen(dir) + strlen(line) + 8);
-            sprintf(in_path[n_in], "%s/%s.mfc", dir, line);
+            in_path[n_in] = malloc(strlen(dir) + strlen(line) + strlen(ext) + 8);
+            sprintf(in_path[n_in], "%s/%s.%s", dir, line, ext);
             if (++n_in == MAX_IN) break;
         }
         fclose(fp);

@@ -28,8 +28,8 @@ def run(raw, nrep, *extra, lm="turtle.lm.bin", dic="turtle.dic", binary=None, mo
         pytest.fail("oracle/_ref/dropin_decode is missing: run __graft_entry__.build() where "
                     "/root/reference is present (the built oracle/_ref travels with gpurun)")
     inp = raw if raw.startswith("@") else os.path.join(DATA, raw)
-    argv = [BIN, model or MODEL, os.path.join(DATA, lm), os.path.join(DATA, dic),
-            inp, str(nrep)] + [str(e) for e in extra]
+    argv = [BIN, model or MODEL, "-" if lm == "-" else os.path.join(DATA, lm),
+            "-" if dic == "-" else os.path.join(DATA, dic), inp, str(nrep)] + [str(e) for e in extra]
     p = subprocess.run(argv, capture_output=True, text=True, timeout=600)
     assert p.stdout.strip(), "no output (rc %d): %s" % (p.returncode, p.stderr[-2000:])
     r = json.loads(p.stdout.strip().splitlines()[-1])
@@ -215,6 +215,58 @@ def test_large_vocabulary_dropin(extra):
     assert r["hyp_gpu"] == "go forward ten meters"
     assert r["hmm_evals"] > 1000 * r["n_frames"], r      # > 1000 HMMs per frame on average
     assert r["cache_served"] > 0
+
+
+OTHER_SEARCHES = {
+    # the other consumers of the same boundary: they call acmod_score()
+    # exactly like the n-gram search, so the GMM shim serves them unchanged
+    "fsg": dict(lm="-", extra=("fsg", os.path.join(DATA, "goforward.fsg")), hyp="go forward ten meters"),
+    "jsgf": dict(lm="-", extra=("jsgf", os.path.join(DATA, "goforward.gram")), hyp="go forward ten meters"),
+    "keyphrase": dict(lm="-", extra=("keyphrase", "forward", "kws_threshold", "1e-20"), hyp=None),
+    "allphone": dict(lm="-", dic="-", extra=("allphone", os.path.join(DATA, "en-us-phone.lm.bin"), "beam", "1e-20",
+                                            "pbeam", "1e-10", "allphone_ci", "false", "lw", "2.0"),
+                     hyp="SIL G OW F AO R W ER D T AE N M IY IH ZH ER Z S V SIL"),    # test/unit/test_allphone.c
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(OTHER_SEARCHES))
+def test_other_searches_through_the_gmm_shim(name):
+    c = OTHER_SEARCHES[name]
+    r = run("goforward.raw", 2, *c["extra"], lm=c["lm"], dic=c.get("dic", "turtle.dic"))
+    assert r["mgau"] == "ptm-psgpu" and r["device_calls"] == r["calls_gpu"] > 0
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
+    if c["hyp"] is not None:
+        assert r["utts"][0]["hyp"] == c["hyp"]      # first utterance (the second starts from updated CMN state)
+
+
+@pytest.mark.gpu
+def test_cards_regression_jsgf():
+    """test/regression/test-cards.sh: en-us PTM + JSGF grammar (fsg search), 5 utterances,
+    hypotheses pinned by test/data/cards/cards.hyp."""
+    cards = os.path.join(DATA, "cards")
+    r = run("@%s:%s:raw" % (os.path.join(cards, "cards.fileids"), cards), 1,
+            "jsgf", os.path.join(cards, "cards.gram"), "bestpath", "no",
+            lm="-", dic="cmudict-en-us.dict")
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
+    want = [l.rsplit("(", 1)[0].strip() for l in open(os.path.join(cards, "cards.hyp")) if l.strip()]
+    assert [u["hyp"] for u in r["utts"]] == want
+
+
+@pytest.mark.gpu
+def test_tidigits_fsg_regression():
+    """test/regression/test-tidigits-fsg.sh: s2_semi + FSG search, hypotheses pinned by
+    test/data/tidigits/test-tidigits-fsg.match."""
+    r = run("@%s:%s" % (os.path.join(TD, "tidigits.ctl"), TD), 1,
+            "fsg", os.path.join(TD, "tidigits.fsg"), "wbeam", "1e-48", "bestpath", "no",
+            model=TD_KW["model"], lm="-", dic=TD_KW["dic"])
+    assert r["mgau"] == "s2_semi-psgpu"
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
+    want = [l.rsplit("(", 1)[0].strip() for l in open(os.path.join(TD, "test-tidigits-fsg.match")) if l.strip()]
+    assert [u["hyp"] for u in r["utts"]] == want
 
 
 def test_attach_fails_loudly_without_gpu():
