@@ -1,0 +1,7 @@
+/* The reference's kws_search.c compiled with its hmm_vit_eval loop routed through psgpu
+ * (see psgpu_search_hooks.h).  The source is included from where it lies. */
+#include "psgpu_search_hooks.h"
+#undef hmm_context_set_senscore
+#define hmm_context_set_senscore(ctx, scr) psgpu_kws_pre_evaluate(kwss, (scr))
+#define hmm_vit_eval(h) psgpu_hmm_vit_result(h)
+#include "kws_search.c"

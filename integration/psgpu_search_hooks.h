@@ -37,6 +37,10 @@
 #include "hmm.h"
 #include "ngram_search.h"
 #include "phone_loop_search.h"
+#include "fsg_search_internal.h"
+#include "allphone_search.h"
+#include "kws_search.h"
+#include "state_align_search.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -44,8 +48,9 @@ extern "C" {
 
 /* Attach device HMM contexts to the decoder's n-gram search (fwdtree and
  * fwdflat share one hmm_context_t, ngram_search.h:203) and to its phone-loop
- * search (phone_loop_search.h:79).  0 on success, -1 on failure (decoder
- * untouched). */
+ * search (phone_loop_search.h:79); or, when the active search is an fsg / allphone
+ * / kws / state_align search, to that search's hmm_context_t.  0 on success, -1 on
+ * failure (decoder untouched). */
 int psgpu_search_attach(ps_decoder_t *ps);
 /* Detach and free them (also safe on a decoder that was never attached). */
 void psgpu_search_detach(ps_decoder_t *ps);
@@ -55,6 +60,15 @@ void psgpu_search_stats(ps_decoder_t *ps, long *n_batches, long *n_hmms);
 void psgpu_fwdtree_pre_evaluate(ngram_search_t *ngs, int16 const *senscr, int frame_idx);
 void psgpu_fwdflat_pre_evaluate(ngram_search_t *ngs, int16 const *senscr, int frame_idx);
 void psgpu_phone_loop_pre_evaluate(phone_loop_search_t *pls, int16 const *senscr, int frame_idx);
+/* the other consumers of hmm_vit_eval, same two-statement patch:
+ *   fsg_search_step / fsg_search_hmm_eval   fsg_search.c:706, :335-385
+ *   phmm_eval_all                           allphone_search.c:346-375
+ *   kws_search_hmm_eval                     kws_search.c:194-226
+ *   evaluate_hmms                           state_align_search.c:64-84 */
+void psgpu_fsg_pre_evaluate(fsg_search_t *fsgs, int16 const *senscr);
+void psgpu_allphone_pre_evaluate(allphone_search_t *allphs, int16 const *senscr);
+void psgpu_kws_pre_evaluate(kws_search_t *kwss, int16 const *senscr);
+void psgpu_state_align_pre_evaluate(state_align_search_t *sas, int16 const *senscr, int frame_idx);
 
 /* hmm_vit_eval as seen by the hooked loops */
 static inline int32

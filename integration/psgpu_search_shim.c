@@ -193,11 +193,99 @@ psgpu_phone_loop_pre_evaluate(phone_loop_search_t *pls, int16 const *senscr, int
     ctx_run(c, senscr);
 }
 
+/* fsg_search_hmm_eval (fsg_search.c:335-385): the active pnode list */
+void
+psgpu_fsg_pre_evaluate(fsg_search_t *fsgs, int16 const *senscr)
+{
+    psgpu_search_ctx_t *c = fsgs->hmmctx->udata;
+    gnode_t *gn;
+
+    fsgs->hmmctx->senscore = senscr;
+    if (c == NULL)
+        return;
+    for (gn = fsgs->pnode_active; gn; gn = gnode_next(gn))
+        ctx_add(c, fsg_pnode_hmmptr((fsg_pnode_t *) gnode_ptr(gn)));
+    ctx_run(c, senscr);
+}
+
+/* phmm_eval_all (allphone_search.c:346-375) */
+void
+psgpu_allphone_pre_evaluate(allphone_search_t *allphs, int16 const *senscr)
+{
+    psgpu_search_ctx_t *c = allphs->hmmctx->udata;
+    bin_mdef_t *mdef = ((ps_search_t *) allphs)->acmod->mdef;
+    s3cipid_t ci;
+    phmm_t *p;
+
+    allphs->hmmctx->senscore = senscr;
+    if (c == NULL)
+        return;
+    for (ci = 0; ci < mdef->n_ciphone; ci++)
+        for (p = allphs->ci_phmm[(unsigned) ci]; p; p = p->next)
+            if (hmm_frame(&(p->hmm)) == allphs->frame)
+                ctx_add(c, &p->hmm);
+    ctx_run(c, senscr);
+}
+
+/* kws_search_hmm_eval (kws_search.c:194-226): the phone loop, then active keyphrase HMMs */
+void
+psgpu_kws_pre_evaluate(kws_search_t *kwss, int16 const *senscr)
+{
+    psgpu_search_ctx_t *c = kwss->hmmctx->udata;
+    gnode_t *gn;
+    int32 i;
+
+    kwss->hmmctx->senscore = senscr;
+    if (c == NULL)
+        return;
+    for (i = 0; i < kwss->n_pl; ++i)
+        ctx_add(c, &kwss->pl_hmms[i]);
+    for (gn = kwss->keyphrases; gn; gn = gnode_next(gn)) {
+        kws_keyphrase_t *keyphrase = gnode_ptr(gn);
+        for (i = 0; i < keyphrase->n_hmms; i++)
+            if (keyphrase->hmms[i].frame > 0)            /* hmm_is_active, kws_search.c:52 */
+                ctx_add(c, &keyphrase->hmms[i]);
+    }
+    ctx_run(c, senscr);
+}
+
+/* evaluate_hmms (state_align_search.c:64-84) */
+void
+psgpu_state_align_pre_evaluate(state_align_search_t *sas, int16 const *senscr, int frame_idx)
+{
+    psgpu_search_ctx_t *c = sas->hmmctx->udata;
+    int i;
+
+    sas->hmmctx->senscore = senscr;
+    if (c == NULL)
+        return;
+    for (i = 0; i < sas->n_phones; ++i) {
+        hmm_t *hmm = sas->hmms + i;
+        if (hmm_frame(hmm) < frame_idx)
+            continue;
+        ctx_add(c, hmm);
+    }
+    ctx_run(c, senscr);
+}
+
+/* the hmm_context_t of the active search (n-gram: shared by fwdtree and fwdflat) */
 static hmm_context_t *
 ngram_hmmctx(ps_decoder_t *ps)
 {
-    if (ps->search && 0 == strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM))
+    const char *type;
+    if (ps->search == NULL)
+        return NULL;
+    type = ps_search_type(ps->search);
+    if (0 == strcmp(type, PS_SEARCH_TYPE_NGRAM))
         return ((ngram_search_t *)ps->search)->hmmctx;
+    if (0 == strcmp(type, PS_SEARCH_TYPE_FSG))
+        return ((fsg_search_t *)ps->search)->hmmctx;
+    if (0 == strcmp(type, PS_SEARCH_TYPE_ALLPHONE))
+        return ((allphone_search_t *)ps->search)->hmmctx;
+    if (0 == strcmp(type, PS_SEARCH_TYPE_KWS))
+        return ((kws_search_t *)ps->search)->hmmctx;
+    if (0 == strcmp(type, PS_SEARCH_TYPE_STATE_ALIGN))
+        return ((state_align_search_t *)ps->search)->hmmctx;
     return NULL;
 }
 
@@ -217,8 +305,10 @@ psgpu_search_attach(ps_decoder_t *ps)
         return -1;
     nc = ngram_hmmctx(ps);
     pc = pl_hmmctx(ps);
+    if (pc == nc)
+        pc = NULL;
     if (nc == NULL) {
-        E_ERROR("psgpu: the active search is not an n-gram search\n");
+        E_ERROR("psgpu: the active search has no hmm_vit_eval loop known to the hooks\n");
         return -1;
     }
     if (nc->udata || (pc && pc->udata))

@@ -20,7 +20,7 @@
  *                       then also runs every Viterbi step on the device
  *
  * usage: dropin_decode MODELDIR LM DICT RAW NREP [key val ...]
- *   pseudo keys: mllr_after FILE | psgpu_mgau yes|no | psgpu_search yes|no
+ *   pseudo keys: mllr_after FILE | psgpu_mgau yes|no | psgpu_search yes|no | align_text "WORDS"
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -103,7 +103,8 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
     for (i = 0; i + 1 < argc; i += 2) {
         const char *k = argv[i];
         if (k[0] == '-') ++k;
-        if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search"))
+        if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search")
+            || !strcmp(k, "align_text"))
             continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
@@ -235,6 +236,11 @@ main(int argc, char **argv)
     cpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
     gpu = make_decoder(argv[1], argv[2], argv[3], argc - 6, argv + 6);
     for (i = 6; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "align_text")) {        /* forced alignment: state_align_search */
+            if (ps_set_align_text(cpu, argv[i + 1]) < 0 || ps_set_align_text(gpu, argv[i + 1]) < 0) {
+                fprintf(stderr, "ps_set_align_text failed\n"); return 2;
+            }
+        }
         if (!strcmp(argv[i], "psgpu_mgau")) use_mgau = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_search")) use_search = !strcmp(argv[i + 1], "yes");
     }

@@ -242,6 +242,24 @@ def test_other_searches_through_the_gmm_shim(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(OTHER_SEARCHES) + ["align"])
+def test_other_searches_viterbi_hooks(name):
+    """The same searches with their own hmm_vit_eval loops (fsg_search_hmm_eval,
+    phmm_eval_all, kws_search_hmm_eval, state_align evaluate_hmms) routed to the
+    Viterbi kernel through integration/hook_*.c."""
+    if name == "align":
+        c = dict(lm="-", extra=("align_text", "go forward ten meters"), hyp="go forward ten meters")
+    else:
+        c = OTHER_SEARCHES[name]
+    r = run("goforward.raw", 2, *c["extra"], lm=c["lm"], dic=c.get("dic", "turtle.dic"), binary=BIN_FULL)
+    assert r["search_hooks"] and r["hmm_batches"] > 0 and r["hmm_evals"] > r["hmm_batches"], r
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"] and r["ok"], \
+        {k: v for k, v in r.items() if k != "utts"}
+    if c["hyp"] is not None:
+        assert r["utts"][0]["hyp"] == c["hyp"]
+
+
+@pytest.mark.gpu
 def test_cards_regression_jsgf():
     """test/regression/test-cards.sh: en-us PTM + JSGF grammar (fsg search), 5 utterances,
     hypotheses pinned by test/data/cards/cards.hyp."""
