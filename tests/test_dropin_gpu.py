@@ -287,6 +287,19 @@ def test_tidigits_fsg_regression():
     assert [u["hyp"] for u in r["utts"]] == want
 
 
+@pytest.mark.gpu
+def test_batch_decode_threads_share_the_gpu():
+    """integration/psgpu_batch_decode.c: one decoder per host thread, each with its own
+    psgpu model/state/stream on the same device: hypotheses stay identical."""
+    exe = os.path.join(REF, "psgpu_batch_decode")
+    p = subprocess.run([exe, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"),
+                        os.path.join(DATA, "goforward.raw"), "12", "4", "gpu"],
+                       capture_output=True, text=True, timeout=600)
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0 and r["hyp_mismatches"] == 0 and r["mgau"] == "ptm-psgpu", r
+    assert r["hyp"] == "go forward ten meters" and r["frames"] == 12 * 279
+
+
 def test_attach_fails_loudly_without_gpu():
     """No CPU fallback inside the product: on a box without a gfx950 device the
     attach fails and the checker exits 3."""
