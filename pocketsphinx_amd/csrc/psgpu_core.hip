@@ -40,7 +40,7 @@ int psgpu_check_device()
 
 extern "C" {
 
-const char *psgpu_version(void) { return "psgpu 0.1 (gfx950)"; }
+const char *psgpu_version(void) { return "psgpu 0.3 (gfx950): ptm, s2_semi, ms scorers + hmm_vit_eval"; }
 const char *psgpu_last_error(void) { return g_err; }
 
 int psgpu_device_count(void)

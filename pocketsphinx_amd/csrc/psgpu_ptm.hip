@@ -1,37 +1,42 @@
-// psgpu_ptm.hip -- phonetically-tied-mixture senone scoring on gfx950.
+// psgpu_ptm.hip -- phonetically-tied-mixture senone scoring on gfx950, batched entry.
 //
 // Replaces, bit-exactly, the per-frame work of ptm_mgau_frame_eval()
-// (reference src/ptm_mgau.c:408-454) for whole batches of utterances:
+// (reference src/ptm_mgau.c:408-454, compallsen) for whole batches of utterances:
 //
-//   kernel 1  ptm_chain_kernel     eval_topn + eval_cb (ptm_mgau.c:87-226)
-//       One 64-lane wavefront owns one (utterance, codebook, stream) "chain"
-//       and marches over the utterance's frames.  The chain's 128 Gaussians
-//       live in VGPRs for the whole utterance (2 codewords per lane), the
-//       frame's 13-float stream vector arrives through the scalar cache, the
-//       128 fp32 distances are computed with the reference's exact
-//       sub/mul/mul/sub order (no FMA contraction: SURVEY F5), and the
-//       history-dependent top-N update (seed re-score, threshold scan in
-//       codeword order, insert-ahead-of-equals, skip-if-present) is emulated
-//       with wave ballots on wave-uniform (scalar) list state.
+//   ptm_lane_kernel    eval_topn + eval_cb (ptm_mgau.c:87-226), frames on lanes:
+//       one wavefront = one (codebook, stream) chain x 64 consecutive frames.
+//       The chain's 128 Gaussians are wave-uniform and arrive through the
+//       scalar cache as SGPR operands, the lane's 13 feature values sit in
+//       VGPRs, the fp32 distances are computed with the reference's exact
+//       sub/mul/mul/sub order (no FMA contraction: SURVEY F5) and each lane
+//       keeps its five best selection keys in a max/min bubble -- no cross-lane
+//       traffic.  By the closed form (psgpu_ptm_dev.h) the first four keys are
+//       the reference's list unless scores tie; tied entries are flagged.
 //
-//   kernel 2  ptm_senone_kernel    ptm_mgau_codebook_norm + ptm_mgau_senone_eval
-//       (ptm_mgau.c:265-295, :326-403).  One workgroup per frame: normalise
-//       the 126 top-N lists in LDS, then each lane gathers the uint8 mixture
-//       weights of its senones (coalesced along the senone axis), log-adds
-//       them through the 256-entry table in LDS, and the block min-reduces
-//       and stores int16 scores.
+//   ptm_chain_kernel   the exact sequential procedure, codewords on lanes:
+//       seed re-score, threshold scan in codeword order, insert-ahead-of-equals,
+//       skip-if-present, emulated with wave ballots on wave-uniform list state.
+//       Repairs the flagged entries after the lane kernel (persistent grid), and
+//       scores whole batches when ds_ratio > 1 (frames that only re-score seeds).
+//
+//   ptm_senone_kernel_f3n4 / ptm_senone_kernel
+//       ptm_mgau_codebook_norm + ptm_mgau_senone_eval (ptm_mgau.c:265-295,
+//       :326-403).  One workgroup per frame: normalise the 126 top-N lists in
+//       LDS, gather the uint8 mixture weights (slot layout: one aligned dword =
+//       the four slots of a lane), log-add through the table in LDS, block
+//       minimum, coalesced int16 row out.
 //
 // The model (3.7 MB) stays resident in L2 / Infinity Cache; HBM traffic is the
-// feature rows in and the int16 score rows out (+ the top-N lists between the
-// two kernels).  See DESIGN.md for the roofline discussion.
+// feature rows in and the int16 score rows out (+ the chain-major top-N lists
+// between the kernels).  See DESIGN.md for the roofline discussion.
 #include "psgpu_ptm_dev.h"
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 // ---------------------------------------------------------------------------
-// kernel 1: top-N chains, specialised for 128 densities (2 per lane) and a
-// compile-time stream length.
+// ptm_chain_kernel: top-N chains, codewords on lanes (128 densities, 2 per
+// lane; compile-time stream length).
 //
 // Work decomposition: one wavefront = one (codebook, stream) chain x one chunk
 // of `chunk` consecutive global frames (utterances lie back to back).  Chunks

@@ -12,7 +12,6 @@ struct psgpu_ptm_model_s {
     int32_t fast_shape;           // 128 densities, top-4, 13-dim streams: the batched kernels' shape
     int device;
     float *mean, *var, *det;      // device
-    int64_t *cboff;               // device: float offset of (mgau, feat) block
     uint8_t *mixw, *sen2cb, *logadd8;
     uint8_t *h_sen2cb;            // host mirror (active list -> codebook set, ptm_mgau.c:297-321)
     uint8_t *mixw_slot;           // [n_feat][n_density][slot_stride], slot order, rows 64-byte aligned
