@@ -242,7 +242,7 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
 // launched next in fix-up mode, re-derives those frames with the exact
 // sequential procedure.
 // ---------------------------------------------------------------------------
-template <int LEN>
+template <int LEN, int FPL>                     // FPL = frames per lane
 __global__ __launch_bounds__(256, 8)
 void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_frames,
                      const int32_t *__restrict__ utt_off, int32_t n_utt,
@@ -253,7 +253,7 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const int n_tiles = (total_frames + 63) >> 6;
+    const int n_tiles = (total_frames + 64 * FPL - 1) / (64 * FPL);
     // consecutive waves (same workgroup) = consecutive tiles of ONE chain: they
     // stream the same parameters through the scalar cache
     const int chain = wave / n_tiles;
@@ -261,60 +261,74 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
         return;
     const int tile = wave - chain * n_tiles;
     const int f = chain % p.n_feat;
-    const int t = tile * 64 + lane;
-    const bool valid = t < total_frames;
-    const int tl = valid ? t : total_frames - 1;
 
-    float x[LEN];
-    {
+    int t[FPL];
+    bool valid[FPL];
+    float x[FPL][LEN];
+#pragma unroll
+    for (int q = 0; q < FPL; ++q) {
+        t[q] = (tile * FPL + q) * 64 + lane;
+        valid[q] = t[q] < total_frames;
+        const int tl = valid[q] ? t[q] : total_frames - 1;
         const float *xp = feats + (size_t)tl * p.veclen + f * LEN;
 #pragma unroll
-        for (int j = 0; j < LEN; ++j) x[j] = xp[j];
+        for (int j = 0; j < LEN; ++j) x[q][j] = xp[j];
     }
     const float *mean = p.mean + (size_t)chain * 128 * LEN;     // wave-uniform: scalar loads
     const float *var = p.var + (size_t)chain * 128 * LEN;
     const float *det = p.det + (size_t)chain * 128;
 
-    int32_t k0 = kMaxNegInt32, k1 = kMaxNegInt32, k2 = kMaxNegInt32, k3 = kMaxNegInt32, k4 = kMaxNegInt32;
+    int32_t k0[FPL], k1[FPL], k2[FPL], k3[FPL], k4[FPL];
+#pragma unroll
+    for (int q = 0; q < FPL; ++q) k0[q] = k1[q] = k2[q] = k3[q] = k4[q] = kMaxNegInt32;
 #pragma unroll 2
     for (int cw = 0; cw < 128; ++cw) {
         const float *m = mean + cw * LEN, *v = var + cw * LEN;
-        float d = det[cw];
+        const float dt = det[cw];
 #pragma unroll
-        for (int j = 0; j < LEN; ++j)
-            d = gau_step(d, x[j], m[j], v[j]);
-        const float c = __builtin_amdgcn_fmed3f(d, (float)kKeyLo, (float)kKeyHi);
-        int32_t k = ((int32_t)c << 7) | (127 - cw);
-        int32_t tmx;
-        tmx = max(k0, k); k = min(k0, k); k0 = tmx;
-        tmx = max(k1, k); k = min(k1, k); k1 = tmx;
-        tmx = max(k2, k); k = min(k2, k); k2 = tmx;
-        tmx = max(k3, k); k = min(k3, k); k3 = tmx;
-        k4 = max(k4, k);
-    }
-    const int32_t s0 = k0 >> 7, s1 = k1 >> 7, s2 = k2 >> 7, s3 = k3 >> 7, s4 = k4 >> 7;
-    const bool open = (s0 == s1) | (s1 == s2) | (s2 == s3) | (s3 == s4) | (s0 >= kKeyHi) | (s3 <= kKeyLo);
-    if (valid) {
-        const size_t o = (size_t)chain * total_frames + t;          // chain-major: a wave stores 1 KB contiguous
-        *reinterpret_cast<int4 *>(topn_score + o * 4) = make_int4(s0, s1, s2, s3);
-        const uint32_t c0 = 127 - (k0 & 127), c1 = 127 - (k1 & 127), c2 = 127 - (k2 & 127), c3 = 127 - (k3 & 127);
-        topn_cw[o] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
-        open_flags[(size_t)chain * total_frames + t] = open ? 1 : 0;
-        if (open) {
-            const int32_t idx = atomicAdd(fix_count, 1);
-            if (idx < fix_cap) fix_list[idx] = t * p.n_chain + chain;
+        for (int q = 0; q < FPL; ++q) {
+            float d = dt;
+#pragma unroll
+            for (int j = 0; j < LEN; ++j)
+                d = gau_step(d, x[q][j], m[j], v[j]);
+            const float c = __builtin_amdgcn_fmed3f(d, (float)kKeyLo, (float)kKeyHi);
+            int32_t k = ((int32_t)c << 7) | (127 - cw);
+            int32_t tmx;
+            tmx = max(k0[q], k); k = min(k0[q], k); k0[q] = tmx;
+            tmx = max(k1[q], k); k = min(k1[q], k); k1[q] = tmx;
+            tmx = max(k2[q], k); k = min(k2[q], k); k2[q] = tmx;
+            tmx = max(k3[q], k); k = min(k3[q], k); k3[q] = tmx;
+            k4[q] = max(k4[q], k);
         }
-        if (seed_out && !open) {
-            // carry-out of an utterance = the list of its last frame (acmod never
-            // resets it); flagged frames are written by the fix-up
-            int lo = 0, hi = n_utt;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (utt_off[mid] <= t) lo = mid; else hi = mid;
+    }
+#pragma unroll
+    for (int q = 0; q < FPL; ++q) {
+        const int32_t s0 = k0[q] >> 7, s1 = k1[q] >> 7, s2 = k2[q] >> 7, s3 = k3[q] >> 7, s4 = k4[q] >> 7;
+        const bool open = (s0 == s1) | (s1 == s2) | (s2 == s3) | (s3 == s4) | (s0 >= kKeyHi) | (s3 <= kKeyLo);
+        if (valid[q]) {
+            const int tt = t[q];
+            const size_t o = (size_t)chain * total_frames + tt;         // chain-major: a wave stores 1 KB contiguous
+            *reinterpret_cast<int4 *>(topn_score + o * 4) = make_int4(s0, s1, s2, s3);
+            const uint32_t c0 = 127 - (k0[q] & 127), c1 = 127 - (k1[q] & 127), c2 = 127 - (k2[q] & 127),
+                           c3 = 127 - (k3[q] & 127);
+            topn_cw[o] = c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+            open_flags[(size_t)chain * total_frames + tt] = open ? 1 : 0;
+            if (open) {
+                const int32_t idx = atomicAdd(fix_count, 1);
+                if (idx < fix_cap) fix_list[idx] = tt * p.n_chain + chain;
             }
-            if (utt_off[lo + 1] - 1 == t) {
-                uint8_t *so = seed_out + ((size_t)lo * p.n_chain + chain) * 4;
-                so[0] = (uint8_t)c0; so[1] = (uint8_t)c1; so[2] = (uint8_t)c2; so[3] = (uint8_t)c3;
+            if (seed_out && !open) {
+                // carry-out of an utterance = the list of its last frame (acmod never
+                // resets it); flagged frames are written by the fix-up
+                int lo = 0, hi = n_utt;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (utt_off[mid] <= tt) lo = mid; else hi = mid;
+                }
+                if (utt_off[lo + 1] - 1 == tt) {
+                    uint8_t *so = seed_out + ((size_t)lo * p.n_chain + chain) * 4;
+                    so[0] = (uint8_t)c0; so[1] = (uint8_t)c1; so[2] = (uint8_t)c2; so[3] = (uint8_t)c3;
+                }
             }
         }
     }
@@ -791,12 +805,18 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         if (m->count_dirty)                  // normally the senone kernel of the previous call zeroed it
             PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
         m->count_dirty = 1;
-        const long long n_tiles = ((long long)total_frames + 63) / 64;
+        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 1; }();
+        const long long n_tiles = ((long long)total_frames + 64 * fpl - 1) / (64 * fpl);
         const long long lw = n_tiles * m->n_chain;
         if (m->timing) hipEventRecord(m->ev[0], st);
-        hipLaunchKernelGGL((ptm_lane_kernel<13>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
-                           pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
-                           topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
+        if (fpl == 2)
+            hipLaunchKernelGGL((ptm_lane_kernel<13, 2>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                               topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
+        else
+            hipLaunchKernelGGL((ptm_lane_kernel<13, 1>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                               topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
         PSGPU_HIP(hipGetLastError());
         if (m->timing) hipEventRecord(m->ev[1], st);
         PSGPU_CHAIN(fix_grid, (const uint8_t *)m->open_flags, (const int32_t *)fix_count, (const int32_t *)m->fix_list, fix_thr);
