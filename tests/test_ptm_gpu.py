@@ -131,3 +131,42 @@ def test_full_size_properties(tables, gpu_model):
         assert np.array_equal(r["senscr"][u * 250:(u + 1) * 250], scr)
         alone = sc.score_utts(feats[u * 250:(u + 1) * 250], [250], want_topn=False)
         assert np.array_equal(alone["senscr"], scr)
+
+
+def test_config5_size_device_batch(tables, gpu_model):
+    """BASELINE configs[4] size: 512 utterances x 3,000 frames = 1,536,000 frames in
+    ONE call of the device entry (features 240 MB, int16 scores 15.7 GB, all
+    resident in HBM).  Size-independent properties on the whole output (every
+    row's minimum is 0, no negative score) and full memcmp against the oracle for
+    two whole utterances."""
+    import ctypes as C
+    import torch
+    from pocketsphinx_amd import capi
+    n_utt, ulen = 512, 3000
+    T = n_utt * ulen
+    rng = np.random.default_rng(5)
+    base = _load("ptm_synth.npz")["feat"]
+    mu, sd = base.mean(0), base.std(0)
+    dev = torch.device("cuda", 0)
+    feats_h = (mu + sd * rng.standard_normal((T, base.shape[1]), dtype=np.float32)).astype(np.float32)
+    feats = torch.from_numpy(feats_h).to(dev)
+    off = torch.arange(0, T + 1, ulen, dtype=torch.int32, device=dev)
+    m = gpu_model
+    sc = torch.empty((m.n_chain, T, m.topn), dtype=torch.int32, device=dev)
+    cw = torch.empty((m.n_chain, T, m.topn), dtype=torch.uint8, device=dev)
+    scr = torch.empty((T, m.n_sen), dtype=torch.int16, device=dev)
+    L = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    capi.check(L.psgpu_ptm_score_batch_dev(m.h, p(feats), p(off), n_utt, T, None, None, p(sc), p(cw), p(scr),
+                                           None, 0, st), "score_batch_dev")
+    torch.cuda.synchronize()
+    mins = torch.empty(T, dtype=torch.int16, device=dev)
+    for a in range(0, T, 65536):                       # chunked: amin over a 15 GB tensor
+        mins[a:a + 65536] = scr[a:a + 65536].amin(dim=1)
+    assert int(mins.abs().max().item()) == 0
+    o = pso.OraclePTM(tables)
+    for u in (0, 377):
+        want, _, _ = o.score_utt(feats_h[u * ulen:(u + 1) * ulen], reset_hist=True, want_topn=False)
+        got = scr[u * ulen:(u + 1) * ulen].cpu().numpy()
+        assert np.array_equal(got, want), "utterance %d" % u
