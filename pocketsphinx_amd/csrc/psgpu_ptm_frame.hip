@@ -27,8 +27,9 @@ struct psgpu_ptm_state_s {
     uint32_t *hist_active;   // [n_hist][8]
     uint16_t *h_list;        // pinned + mapped: absolute senone ids of the active list
     uint16_t *d_list;        // device alias of h_list
-    int16_t *h_out;          // pinned + mapped: n_sen scores
+    int16_t *h_out;          // pinned + mapped: n_sen scores, then a completion word
     int16_t *d_out;
+    uint32_t seq;            // call counter: the kernel stores it behind the scores when done
     hipStream_t stream;
     int32_t cur;             // slot of the most recent call (s->f)
     // ---- look-ahead cache (psgpu_ptm_state_lookahead): the frames the caller
@@ -206,7 +207,7 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
                              const uint16_t *__restrict__ list,
                              const int32_t *__restrict__ cur_cw, int32_t *__restrict__ cur_sc,
                              const uint32_t *__restrict__ cur_active,
-                             int16_t *__restrict__ out)
+                             int16_t *__restrict__ out, uint32_t *__restrict__ done_word, uint32_t seq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int16_t *s_out = reinterpret_cast<int16_t *>(smem);                    // [n_sen]
@@ -310,6 +311,12 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
     const uint32_t best = (uint32_t)s_best;
     for (int i = tid; i < p.n_sen; i += kFrameThreads)
         out[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)s_out[i] - best);   // int16 -= int (:398-400)
+    // completion word behind the scores (host-mapped memory): the host polls it
+    // instead of paying for a stream synchronisation per call
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -433,7 +440,7 @@ int psgpu_ptm_state_create(psgpu_ptm_state_t **out, psgpu_ptm_model_t *m, int32_
     if (e == hipSuccess) e = hipMalloc((void **)&s->hist_sc, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->hist_active, (size_t)n_fast_hist * 8 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_list, (size_t)m->n_sen * sizeof(uint16_t), hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, (size_t)m->n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, ((size_t)m->n_sen * sizeof(int16_t) + 15) / 16 * 16 + 16, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_list, s->h_list, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_out, s->h_out, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -615,16 +622,35 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
         PSGPU_HIP(hipGetLastError());
     }
     const size_t smem = (((size_t)m->n_sen * 2 + 15) / 16) * 16 + slot_len * 5;
+    const size_t done_off = ((size_t)m->n_sen * sizeof(int16_t) + 15) / 16 * 16;
+    volatile uint32_t *h_done = reinterpret_cast<volatile uint32_t *>(reinterpret_cast<char *>(s->h_out) + done_off);
+    uint32_t *d_done = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s->d_out) + done_off);
+    const uint32_t seq = ++s->seq ? s->seq : ++s->seq;          // never 0
 #define PSGPU_SENF_CASE(NN) case NN: hipLaunchKernelGGL((ptm_frame_senone_kernel<NN>), dim3(1), dim3(kFrameThreads), \
         smem, s->stream, pv, (int32_t)fresh, (int32_t)(compallsen != 0), (int32_t)n_list,                         \
-        (const uint16_t *)s->d_list, (const int32_t *)cur_cw, cur_sc, (const uint32_t *)cur_act, s->d_out); break;
+        (const uint16_t *)s->d_list, (const int32_t *)cur_cw, cur_sc, (const uint32_t *)cur_act, s->d_out,           \
+        d_done, seq); break;
     switch (m->topn) {
         PSGPU_SENF_CASE(1) PSGPU_SENF_CASE(2) PSGPU_SENF_CASE(3) PSGPU_SENF_CASE(4)
         PSGPU_SENF_CASE(5) PSGPU_SENF_CASE(6) PSGPU_SENF_CASE(7) default: PSGPU_SENF_CASE(8)
     }
 #undef PSGPU_SENF_CASE
     PSGPU_HIP(hipGetLastError());
-    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    {
+        // wait for the completion word; fall back to a stream sync (which also reports
+        // launch failures) if it does not show up within a generous spin budget
+        static const int spin_only = [] { const char *e = getenv("PSGPU_NO_POLL"); return e ? !atoi(e) : 1; }();
+        bool done = false;
+        if (spin_only) {
+            for (long i = 0; i < 200000000L; ++i) {
+                if (*h_done == seq) { done = true; break; }
+                __builtin_ia32_pause();
+            }
+        }
+        if (!done)
+            PSGPU_HIP(hipStreamSynchronize(s->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     memcpy(senscr, s->h_out, (size_t)m->n_sen * sizeof(int16_t));
     return PSGPU_OK;
 }
