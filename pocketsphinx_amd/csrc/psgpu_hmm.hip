@@ -34,7 +34,18 @@ struct psgpu_hmm_ctx_s {
     int16_t *h_scr, *d_scr;
     int32_t *h_best, *d_best;
     int32_t cap;
+    // zero-copy path of the host-buffer entry (small batches): host-mapped buffers + completion word
+    psgpu_hmm_rec_t *z_recs, *zd_recs;     // [kZeroCopyMax]
+    int16_t *z_scr, *zd_scr;
+    uint32_t *z_word, *zd_word;            // [0] completion word, [1] best score
+    uint32_t *d_count;
+    uint32_t seq;
+    // per-launch completion arguments (nullptr for the plain device entry)
+    uint32_t *launch_done_count, *launch_done_word;
+    uint32_t launch_seq;
 };
+
+constexpr int32_t kZeroCopyMax = 2048;
 
 constexpr int32_t kW = kWorstScore;
 constexpr int kTmatWorst = 255;            // tmat.h: 8-bit floor; "tp > -255" gates skip arcs
@@ -301,7 +312,8 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
                     int32_t n_active, const uint16_t *__restrict__ utt_of_hmm,
                     const int16_t *__restrict__ senscr, int32_t senscr_stride,
                     const uint8_t *__restrict__ tp_g, int32_t tp_bytes,
-                    const uint16_t *__restrict__ sseq, int32_t *__restrict__ best_out)
+                    const uint16_t *__restrict__ sseq, int32_t *__restrict__ best_out,
+                    uint32_t *__restrict__ done_count, uint32_t *__restrict__ done_word, uint32_t seq)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tp[kTpLdsMax];
     __shared__ int32_t s_wbest[kHmmThreads / 64], s_wutt[kHmmThreads / 64];
@@ -393,6 +405,20 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
             }
         }
     }
+    if (done_word) {
+        // zero-copy host entry: records / best live in host-mapped memory; the last
+        // workgroup to finish publishes the call's sequence number for the polling host
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t k = atomicAdd(done_count, 1u);
+            if (k == gridDim.x - 1) {
+                *done_count = 0;
+                __threadfence_system();
+                __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -424,6 +450,14 @@ int psgpu_hmm_ctx_create(psgpu_hmm_ctx_t **out, int32_t n_emit_state, int32_t n_
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_scr, (size_t)n_sen * sizeof(int16_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_best, sizeof(int32_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_best, sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->z_recs, (size_t)kZeroCopyMax * sizeof(psgpu_hmm_rec_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->z_scr, (size_t)n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->z_word, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->zd_recs, c->z_recs, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->zd_scr, c->z_scr, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&c->zd_word, c->z_word, 0);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_count, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_count, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
         psgpu_set_error("psgpu_hmm_ctx_create: %s", hipGetErrorString(e));
         psgpu_hmm_ctx_free(c);
@@ -441,6 +475,10 @@ void psgpu_hmm_ctx_free(psgpu_hmm_ctx_t *c)
     if (c->h_recs) hipHostFree(c->h_recs);
     if (c->h_scr) hipHostFree(c->h_scr);
     if (c->h_best) hipHostFree(c->h_best);
+    if (c->z_recs) hipHostFree(c->z_recs);
+    if (c->z_scr) hipHostFree(c->z_scr);
+    if (c->z_word) hipHostFree(c->z_word);
+    hipFree(c->d_count);
     delete c;
 }
 
@@ -462,11 +500,13 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
     if (c->n_emit == 3)
         hipLaunchKernelGGL((hmm_vit_kernel<3>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
                            recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
-                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev);
+                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,
+                           c->launch_done_count, c->launch_done_word, c->launch_seq);
     else
         hipLaunchKernelGGL((hmm_vit_kernel<5>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
                            recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
-                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev);
+                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,
+                           c->launch_done_count, c->launch_done_word, c->launch_seq);
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
@@ -478,6 +518,31 @@ int psgpu_hmm_vit_eval(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs, int32_t n,
     PSGPU_REQUIRE(n >= 0, "negative n");
     if (best) *best = kWorstScore;
     if (n == 0) return PSGPU_OK;
+    static const int no_zero_copy = [] { const char *e = getenv("PSGPU_NO_POLL"); return e ? atoi(e) : 0; }();
+    if (n <= kZeroCopyMax && !no_zero_copy) {
+        // small batch (a single decoder's active list): the kernel works on host-mapped
+        // records and scores over PCIe and publishes a completion word; no copies, no sync call
+        memcpy(c->z_recs, recs, (size_t)n * sizeof(psgpu_hmm_rec_t));
+        memcpy(c->z_scr, senscr, (size_t)c->n_sen * sizeof(int16_t));
+        c->z_word[1] = (uint32_t)kWorstScore;
+        const uint32_t seq = ++c->seq ? c->seq : ++c->seq;
+        c->launch_done_count = c->d_count; c->launch_done_word = c->zd_word; c->launch_seq = seq;
+        int rc = psgpu_hmm_vit_eval_dev(c, c->zd_recs, nullptr, n, nullptr, c->zd_scr, c->n_sen,
+                                        reinterpret_cast<int32_t *>(c->zd_word + 1), c->stream);
+        c->launch_done_count = nullptr; c->launch_done_word = nullptr;
+        if (rc != PSGPU_OK) return rc;
+        bool done = false;
+        volatile uint32_t *w = c->z_word;
+        for (long i = 0; i < 200000000L; ++i) {
+            if (w[0] == seq) { done = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!done) PSGPU_HIP(hipStreamSynchronize(c->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        memcpy(recs, c->z_recs, (size_t)n * sizeof(psgpu_hmm_rec_t));
+        if (best) *best = (int32_t)w[1];
+        return PSGPU_OK;
+    }
     if (n > c->cap) {
         const int32_t cap = n < 1024 ? 1024 : n + n / 2;
         if (c->h_recs) hipHostFree(c->h_recs);
