@@ -175,33 +175,9 @@ def semi_only():
     senlog_case("tidigits_topn2", 1, inp=b, extra=("topn", "2", "pl_window", "0"), **TD)
 
 
-def write_s3_mixw(path, w):
-    """S3 mixture_weights file (senone_mixw_read, ms_senone.c:134-267):
-    text header, byte-order magic, n_sen n_feat n_cw n_total, float32 [sen][feat][cw]."""
-    import struct
-    w = np.ascontiguousarray(w, np.float32)
-    with open(path, "wb") as fh:
-        fh.write(b"s3\nversion 1.0\nendhdr\n")
-        fh.write(struct.pack("<I4i", 0x11223344, w.shape[0], w.shape[1], w.shape[2], w.size))
-        fh.write(w.tobytes())
-
-
 def stage_en_us_ms():
-    """A multi-density model for the ms scorer (the only bundled continuous
-    model, an4_ci_cont, has ONE density per codebook): the en-us means /
-    variances / mdef with a float mixture_weights file de-quantised from the
-    en-us sendump, used with `-senmgau .ptm.`."""
-    src, dst = MODEL, os.path.join(REF, "model", "en-us-ms")
-    os.makedirs(dst, exist_ok=True)
-    for f in ("mdef", "means", "variances", "transition_matrices", "feat.params", "noisedict"):
-        subprocess.check_call(["cp", "-u", os.path.join(src, f), dst])
-    mw = os.path.join(dst, "mixture_weights")
-    if not os.path.exists(mw):
-        t = np.load(os.path.join(GOLD, "en_us_ptm_tables.npz"))
-        q = t["mixw"].astype(np.float64)                       # [feat][cw][sen], -log_{1.0001}(w) >> 10
-        w = np.power(1.0001, -(q * 1024.0))                     # back to probabilities
-        write_s3_mixw(mw, np.transpose(w, (2, 0, 1)))
-    return dst
+    from stage_ms_model import stage
+    return stage(MODEL, os.path.join(GOLD, "en_us_ptm_tables.npz"), os.path.join(REF, "model", "en-us-ms"))
 
 
 def ms_only():
