@@ -58,6 +58,7 @@ struct psgpu_ms_model_s {
     int16_t *h_out, *d_out;              // mapped: scores of listed senones (list order) / all
     int32_t *d_flag;
     hipStream_t stream;
+    uint32_t seq;
 };
 
 // order-preserving map float -> uint32 (larger float = larger key)
@@ -162,7 +163,8 @@ template <int N>
 __global__ __launch_bounds__(kMsSenThreads)
 void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *__restrict__ list,
                       const int32_t *__restrict__ list_id, const float *__restrict__ list_dist,
-                      int32_t n_frames, int16_t *__restrict__ out, int64_t out_stride)
+                      int32_t n_frames, int16_t *__restrict__ out, int64_t out_stride,
+                      uint32_t *__restrict__ done_word, uint32_t seq)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];      // [la entries] int32 | [n] int16
     __shared__ int32_t s_best;
@@ -228,6 +230,12 @@ void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *
         bs = max(-32768, min(32767, bs));
         o[i] = (int16_t)bs;                              // list order (per-call) / senone order (compall)
     }
+    if (done_word) {                                     // per-call entry: completion word for the polling host
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -257,13 +265,13 @@ static void launch_topn(const MsDev &d, const float *feats, int32_t T, const uin
 
 static void launch_senone(const MsDev &d, int32_t T, int32_t compall, int32_t n_list, const uint16_t *list,
                           const int32_t *ids, const float *dist, int16_t *out,
-                          int64_t out_stride, hipStream_t st)
+                          int64_t out_stride, hipStream_t st, uint32_t *done_word = nullptr, uint32_t seq = 0)
 {
     const int n = compall ? d.n_sen : n_list;
     const size_t smem = ((size_t)(d.logadd_size <= kMsLaLds ? d.logadd_size : 0) * 4 +
                          (size_t)(n > 0 ? n : 1) * 2 + 15) / 16 * 16;
 #define PSGPU_MS_SEN(NN) case NN: hipLaunchKernelGGL((ms_senone_kernel<NN>), dim3(T), dim3(kMsSenThreads), smem, st, \
-        d, compall, n_list, list, ids, dist, T, out, out_stride); break;
+        d, compall, n_list, list, ids, dist, T, out, out_stride, done_word, seq); break;
     switch (d.topn) {
         PSGPU_MS_SEN(1) PSGPU_MS_SEN(2) PSGPU_MS_SEN(3) PSGPU_MS_SEN(4)
         PSGPU_MS_SEN(5) PSGPU_MS_SEN(6) PSGPU_MS_SEN(7) default: PSGPU_MS_SEN(8)
@@ -463,7 +471,7 @@ int psgpu_ms_model_create(psgpu_ms_model_t **out, int32_t n_mgau, int32_t n_feat
     if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_active, (size_t)n_mgau, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_feat, (size_t)d.veclen * sizeof(float), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_list, (size_t)n_sen * sizeof(uint16_t), hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_out, (size_t)n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_out, ((size_t)n_sen * sizeof(int16_t) + 15) / 16 * 16 + 16, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_active, m->h_active, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_feat, m->h_feat, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&m->d_list, m->h_list, 0);
@@ -526,9 +534,22 @@ int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
     memcpy(m->h_feat, feat, (size_t)d.veclen * sizeof(float));
     launch_topn(d, m->d_feat, 1, m->d_active, m->list_id, m->list_dist, 0, nullptr, m->stream);
     PSGPU_HIP(hipGetLastError());
-    launch_senone(d, 1, compallsen != 0, n_list, m->d_list, m->list_id, m->list_dist, m->d_out, 0, m->stream);
+    const size_t done_off = ((size_t)d.n_sen * sizeof(int16_t) + 15) / 16 * 16;
+    volatile uint32_t *h_done = reinterpret_cast<volatile uint32_t *>(reinterpret_cast<char *>(m->h_out) + done_off);
+    uint32_t *d_done = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(m->d_out) + done_off);
+    const uint32_t seq = ++m->seq ? m->seq : ++m->seq;
+    launch_senone(d, 1, compallsen != 0, n_list, m->d_list, m->list_id, m->list_dist, m->d_out, 0, m->stream,
+                  d_done, seq);
     PSGPU_HIP(hipGetLastError());
-    PSGPU_HIP(hipStreamSynchronize(m->stream));
+    {
+        bool done = false;
+        for (long i = 0; i < 200000000L; ++i) {
+            if (*h_done == seq) { done = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!done) PSGPU_HIP(hipStreamSynchronize(m->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     if (compallsen)
         memcpy(senscr, m->h_out, (size_t)d.n_sen * sizeof(int16_t));
     else

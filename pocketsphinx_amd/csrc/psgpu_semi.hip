@@ -48,6 +48,7 @@ struct psgpu_semi_state_s {
     int16_t *h_out, *d_out;
     hipStream_t stream;
     int32_t cur;
+    uint32_t seq;
 };
 
 template <int N>
@@ -56,7 +57,8 @@ void semi_frame_kernel(SemiDev p, SemiFeat fa, int32_t fresh, int32_t do_scan, i
                        int32_t n_list, const uint16_t *__restrict__ list,
                        const int32_t *__restrict__ prev_cw,
                        int32_t *__restrict__ cur_cw, int32_t *__restrict__ cur_sc,
-                       int32_t *__restrict__ cur_n, int16_t *__restrict__ out)
+                       int32_t *__restrict__ cur_n, int16_t *__restrict__ out,
+                       uint32_t *__restrict__ done_word, uint32_t seq)
 {
     __shared__ uint8_t s_la[kSemiLa];
     __shared__ int32_t s_cw[kSemiMaxFeat * N], s_sc[kSemiMaxFeat * N], s_n[kSemiMaxFeat];
@@ -166,6 +168,11 @@ void semi_frame_kernel(SemiDev p, SemiFeat fa, int32_t fresh, int32_t do_scan, i
     }
     __syncthreads();
     for (int i = tid; i < p.n_sen; i += kSemiThreads) out[i] = s_out[i];
+    // completion word behind the scores (host-mapped memory), polled by the host
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -271,7 +278,7 @@ int psgpu_semi_state_create(psgpu_semi_state_t **out, psgpu_semi_model_t *m, int
     if (e == hipSuccess) e = hipMalloc((void **)&s->hist_sc, n * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&s->hist_n, (size_t)n_topn_hist * d.n_feat * sizeof(int32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_list, (size_t)d.n_sen * sizeof(uint16_t), hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, (size_t)d.n_sen * sizeof(int16_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, ((size_t)d.n_sen * sizeof(int16_t) + 15) / 16 * 16 + 16, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_list, s->h_list, 0);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&s->d_out, s->h_out, 0);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
@@ -326,17 +333,29 @@ int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
     memset(&fa, 0, sizeof fa);
     memcpy(fa.x, feat, (size_t)m->veclen * sizeof(float));
     const size_t smem = (((size_t)d.n_sen * 2 + 15) / 16) * 16;
+    const size_t done_off = ((size_t)d.n_sen * sizeof(int16_t) + 15) / 16 * 16;
+    volatile uint32_t *h_done = reinterpret_cast<volatile uint32_t *>(reinterpret_cast<char *>(s->h_out) + done_off);
+    uint32_t *d_done = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s->d_out) + done_off);
+    const uint32_t seq = ++s->seq ? s->seq : ++s->seq;
 #define PSGPU_SEMI_CASE(NN) case NN: hipLaunchKernelGGL((semi_frame_kernel<NN>), dim3(1), dim3(kSemiThreads), smem, s->stream, \
         d, fa, (int32_t)fresh, (int32_t)(frame % d.ds_ratio == 0), (int32_t)(compallsen != 0), (int32_t)n_list,          \
         (const uint16_t *)s->d_list, (const int32_t *)(s->hist_cw + prev * sl), s->hist_cw + slot * sl,                  \
-        s->hist_sc + slot * sl, s->hist_n + (size_t)slot * d.n_feat, s->d_out); break;
+        s->hist_sc + slot * sl, s->hist_n + (size_t)slot * d.n_feat, s->d_out, d_done, seq); break;
     switch (d.topn) {
         PSGPU_SEMI_CASE(1) PSGPU_SEMI_CASE(2) PSGPU_SEMI_CASE(3) PSGPU_SEMI_CASE(4)
         PSGPU_SEMI_CASE(5) PSGPU_SEMI_CASE(6) PSGPU_SEMI_CASE(7) default: PSGPU_SEMI_CASE(8)
     }
 #undef PSGPU_SEMI_CASE
     PSGPU_HIP(hipGetLastError());
-    PSGPU_HIP(hipStreamSynchronize(s->stream));
+    {
+        bool done = false;
+        for (long i = 0; i < 200000000L; ++i) {
+            if (*h_done == seq) { done = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!done) PSGPU_HIP(hipStreamSynchronize(s->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     memcpy(senscr, s->h_out, (size_t)d.n_sen * sizeof(int16_t));
     return PSGPU_OK;
 }
