@@ -151,6 +151,20 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
                          int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,
                          void *stream);
 
+/* ---- dynamic features (caller side of the scorer) -------------------------------
+ * Replaces feat_s2mfc2feat_live(begin = end = TRUE) (feat/feat.c:1310, :1275-1306)
+ * for the "1s_c_d_dd" feature type with batch CMN and no AGC / LDA (the en-us
+ * configuration, model/en-us/en-us/feat.params): cmn() (feat/cmn.c:166-208),
+ * first/last frame replicated over a window of 3, feat_1s_c_d_dd_cep2feat
+ * (feat.c:579-622).  cep [total_frames][cepsize] MFCC vectors of n_utt utterances
+ * back to back (utt_off as above; NOT modified, unlike the reference, which
+ * normalises its input in place); feat [total_frames][3*cepsize], directly usable
+ * as feats_dev of psgpu_ptm_score_batch_dev.  Bit-exact. */
+int psgpu_feat_1s_c_d_dd_dev(const float *cep_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                             int32_t cepsize, float *feat_dev, void *stream);
+int psgpu_feat_1s_c_d_dd(const float *cep, const int32_t *utt_off, int32_t n_utt, int32_t cepsize,
+                         float *feat);
+
 /* ---- per-call scoring state: the ps_mgau_t::frame_eval replacement -------
  * One object per decoder.  Replaces the mutable part of ptm_mgau_t
  * (ptm_mgau.h:68-97): the history ring hist[n_fast_hist] of top-N lists and

@@ -173,6 +173,7 @@ def semi_only():
     senlog_case("tidigits_topn6_ds2", 1, inp=a, extra=("topn", "6", "ds", "2"), **TD)
     senlog_case("tidigits_topn7_call", 1, inp=a, extra=("topn", "7", "compallsen", "yes"), **TD)
     senlog_case("tidigits_topn2", 1, inp=b, extra=("topn", "2", "pl_window", "0"), **TD)
+    senlog_case("tidigits_topn8_list", 1, inp=a, extra=("topn", "8", "fwdflat", "no"), **TD)   # 4-bit `_any` kernel, active lists
 
 
 def stage_en_us_ms():
@@ -204,6 +205,12 @@ def ptm_topn_only():
     senlog_case("ptm_topn6_ds2", 1, extra=("topn", "6", "ds", "2", "fwdflat", "no"))
 
 
+def dynfeat_only():
+    d = ref_dump("dynfeat", os.path.join(REF, "data", "goforward.mfc"))
+    np.savez_compressed(os.path.join(GOLD, "dynfeat_goforward.npz"), **d)
+    print("dynfeat_goforward:", d["cep"].shape, "->", d["feat"].shape)
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -221,6 +228,8 @@ if __name__ == "__main__":
         semi_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ms":
         ms_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":
+        dynfeat_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ptm_topn":
         ptm_topn_only()
     else:

@@ -717,6 +717,44 @@ pso_ms_frame_eval(pso_ms_t *s, int16_t *senscr,
 }
 
 /* ================================================================== */
+/* dynamic features (feat/feat.c, feat/cmn.c)                          */
+/* ================================================================== */
+void
+pso_dynfeat_1s_c_d_dd(const float *cep, int T, int cepsize, float *out)
+{
+    float *n = malloc(sizeof(float) * (size_t)(T + 6) * cepsize);   /* normalised + padded by 3 on each side */
+    float *sum = calloc(cepsize, sizeof(float));
+    int t, i, nframe = 0;
+    if (T <= 0) { free(n); free(sum); return; }
+    for (t = 0; t < T; ++t) {                       /* cmn.c:182-194 */
+        if (cep[(size_t)t * cepsize] < 0) continue;
+        for (i = 0; i < cepsize; ++i) sum[i] += cep[(size_t)t * cepsize + i];
+        ++nframe;
+    }
+    for (i = 0; i < cepsize; ++i) sum[i] = sum[i] / nframe;           /* :196-198 */
+    for (t = 0; t < T; ++t)
+        for (i = 0; i < cepsize; ++i)
+            n[(size_t)(t + 3) * cepsize + i] = cep[(size_t)t * cepsize + i] - sum[i];
+    for (t = 0; t < 3; ++t) {                       /* feat.c:1295-1302 */
+        memcpy(n + (size_t)t * cepsize, n + (size_t)3 * cepsize, sizeof(float) * cepsize);
+        memcpy(n + (size_t)(T + 3 + t) * cepsize, n + (size_t)(T + 2) * cepsize, sizeof(float) * cepsize);
+    }
+    for (t = 0; t < T; ++t) {                       /* feat.c:579-622, FEAT_DCEP_WIN = 2 */
+        const float *m = n + (size_t)(t + 3) * cepsize;
+        float *f = out + (size_t)t * 3 * cepsize;
+        for (i = 0; i < cepsize; ++i) {
+            float d1, d2;
+            f[i] = m[i];
+            f[cepsize + i] = m[2 * cepsize + i] - m[-2 * cepsize + i];
+            d1 = m[3 * cepsize + i] - m[-1 * cepsize + i];
+            d2 = m[1 * cepsize + i] - m[-3 * cepsize + i];
+            f[2 * cepsize + i] = d1 - d2;
+        }
+    }
+    free(n); free(sum);
+}
+
+/* ================================================================== */
 /* acmod_flags2list (acmod.c:1223-1275)                                */
 /* ================================================================== */
 int

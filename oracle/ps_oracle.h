@@ -131,6 +131,18 @@ int pso_ms_frame_eval(pso_ms_t *s, int16_t *senscr,
                       const uint8_t *senone_active, int32_t n_senone_active,
                       const float *feat, int32_t compallsen);
 
+/* ---------------- dynamic features (feat/feat.c, feat/cmn.c) ---------------- */
+
+/* Whole-utterance feature computation of the "1s_c_d_dd" type with batch CMN and
+ * no AGC, as feat_s2mfc2feat_live(begin = end = TRUE) does it (feat.c:1310 ->
+ * feat_s2mfc2feat_block_utt :1275-1306): cmn() (cmn.c:166-208: mean over frames
+ * whose c0 >= 0, summed in frame order, subtracted from every frame), the first
+ * and last frame replicated over a window of 3, then per frame
+ * [cep | cep[t+2]-cep[t-2] | (cep[t+3]-cep[t-1]) - (cep[t+1]-cep[t-3])]
+ * (feat_1s_c_d_dd_cep2feat, feat.c:579-622).  cep [T][cepsize] is not modified;
+ * out [T][3*cepsize]. */
+void pso_dynfeat_1s_c_d_dd(const float *cep, int T, int cepsize, float *out);
+
 /* ---------------- shared helpers ---------------- */
 
 /* acmod_flags2list (acmod.c:1223-1275): bit flags -> uint8 delta list.

@@ -710,6 +710,42 @@ cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
 }
 
 /* ------------------------------------------------------------------ */
+/* dynfeat: cepstra file (.mfc) -> the decoder's dynamic feature computation
+ * for a whole utterance (feat_s2mfc2feat_live(begin, end), feat/feat.c:1310:
+ * batch CMN + window padding + 1s_c_d_dd deltas + subvector split) */
+static int
+cmd_dynfeat(ps_decoder_t *ps, const char *mfcpath)
+{
+    feat_t *fcb = ps->acmod->fcb;
+    int ceplen = feat_cepsize(fcb), dim = feat_dimension(fcb);
+    FILE *fp = fopen(mfcpath, "rb");
+    long flen; int32 nmfc; int nfr, i, swap = 0, nout;
+    float32 **mfcs, *copy;
+    mfcc_t ***feat;
+
+    if (!fp) { perror(mfcpath); return 2; }
+    fseek(fp, 0, SEEK_END); flen = ftell(fp); fseek(fp, 0, SEEK_SET);
+    if (fread(&nmfc, 4, 1, fp) != 1) return 2;
+    if (nmfc != flen / 4 - 1) { nmfc = (int32)__builtin_bswap32((uint32_t)nmfc); swap = 1; }
+    nfr = nmfc / ceplen;
+    mfcs = (float32 **)ckd_calloc_2d(nfr, ceplen, sizeof(float32));
+    if (fread(mfcs[0], 4, (size_t)nfr * ceplen, fp) != (size_t)nfr * ceplen) return 2;
+    fclose(fp);
+    if (swap)
+        for (i = 0; i < nfr * ceplen; ++i) { uint32_t *u = (uint32_t *)&mfcs[0][i]; *u = __builtin_bswap32(*u); }
+    copy = malloc(sizeof(float) * (size_t)nfr * ceplen);
+    memcpy(copy, mfcs[0], sizeof(float) * (size_t)nfr * ceplen);
+    feat = feat_array_alloc(fcb, nfr);
+    nout = nfr;
+    nout = feat_s2mfc2feat_live(fcb, mfcs, &nout, TRUE, TRUE, feat);
+    puti("cepsize", ceplen); puti("n_out", nout);
+    put2("cep", 'f', nfr, ceplen, copy);
+    put2("feat", 'f', nout, dim, feat[0][0]);
+    free(copy);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 int
 main(int argc, char **argv)
 {
@@ -742,6 +778,8 @@ main(int argc, char **argv)
         rc = cmd_ptm(a, b, argv[6], atoi(argv[7]), atoi(argv[8]), xa > 9 ? atoi(argv[9]) : 0);
     } else if (!strcmp(cmd, "senlog") && xa > 7) {
         rc = cmd_senlog(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]));
+    } else if (!strcmp(cmd, "dynfeat") && xa > 6) {
+        rc = cmd_dynfeat(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
     } else if (!strcmp(cmd, "hmm") && xa > 8) {
         rc = cmd_hmm(make_decoder(modeldir, lm, dict, nextra, extra), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
     } else if (!strcmp(cmd, "decode") && xa > 6) {

@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip"]
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip"]
 
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -24,6 +24,7 @@ SYMBOLS = [
     "psgpu_semi_state_get_topn", "psgpu_semi_state_set_topn",
     "psgpu_ms_model_create", "psgpu_ms_model_free", "psgpu_ms_n_sen", "psgpu_ms_veclen",
     "psgpu_ms_frame_eval", "psgpu_ms_score_batch_dev", "psgpu_ms_batch_check", "psgpu_ms_score_batch",
+    "psgpu_feat_1s_c_d_dd_dev", "psgpu_feat_1s_c_d_dd",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval",
 ]
@@ -118,6 +119,8 @@ def lib():
     L.psgpu_ms_score_batch_dev.argtypes = [vp, vp, i32, vp, vp, vp, vp]
     L.psgpu_ms_batch_check.argtypes = [vp, vp]
     L.psgpu_ms_score_batch.argtypes = [vp, vp, i32, vp]
+    L.psgpu_feat_1s_c_d_dd_dev.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.psgpu_feat_1s_c_d_dd.argtypes = [vp, vp, i32, i32, vp]
     L.psgpu_hmm_ctx_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, vp, i32]
     L.psgpu_hmm_ctx_free.argtypes = [vp]
     L.psgpu_hmm_ctx_free.restype = None

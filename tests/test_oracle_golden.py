@@ -133,7 +133,8 @@ def test_hmm_oracle_matches_reference(case):
             t, bad[0], g["mpx"][bad[0]], g["before"][t][bad[0]], g["after"][t][bad[0]], after[bad[0]])
 
 
-SEMI_CASES = ["tidigits_default", "tidigits_beam", "tidigits_topn6_ds2", "tidigits_topn7_call", "tidigits_topn2"]
+SEMI_CASES = ["tidigits_default", "tidigits_beam", "tidigits_topn6_ds2", "tidigits_topn7_call", "tidigits_topn2",
+              "tidigits_topn8_list"]
 
 
 def semi_oracle_for(g, t):
@@ -192,3 +193,16 @@ def test_ms_senlog_replay(case, tab):
         hashes[c] = pso.row_hash(scr[None, :])[0]
     bad = np.nonzero(hashes != g["call_scr_hash"])[0]
     assert bad.size == 0, "first mismatching call %d (frame %d)" % (bad[0], g["call_frame"][bad[0]])
+
+
+def test_dynfeat_oracle_matches_reference():
+    """pso_dynfeat_1s_c_d_dd vs feat_s2mfc2feat_live(begin, end) of the reference on the
+    bundled cepstra test/data/goforward.mfc (batch CMN, padding, deltas): memcmp."""
+    import ctypes as C
+    g = _load("dynfeat_goforward.npz")
+    cep = np.ascontiguousarray(g["cep"], np.float32)
+    out = np.empty((cep.shape[0], 3 * cep.shape[1]), np.float32)
+    L = pso.lib()
+    L.pso_dynfeat_1s_c_d_dd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.pso_dynfeat_1s_c_d_dd(cep.ctypes.data, cep.shape[0], cep.shape[1], out.ctypes.data)
+    assert out.tobytes() == np.ascontiguousarray(g["feat"], np.float32).tobytes()
