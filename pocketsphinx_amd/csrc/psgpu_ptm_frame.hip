@@ -230,8 +230,9 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
         s_sc[i] = cur_sc[i];
         s_cw[i] = (uint8_t)cur_cw[i];
     }
-    for (int i = tid; i < p.n_sen; i += kFrameThreads)
-        s_out[i] = 0;                                      // memset (:333)
+    if (compall)
+        for (int i = tid; i < p.n_sen; i += kFrameThreads)
+            s_out[i] = 0;                                  // memset (:333); list mode: the host fills the rest
     __syncthreads();
 
     if (fresh) {
@@ -300,7 +301,7 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
             }
             ascore += fden;
         }
-        s_out[sen] = (int16_t)ascore;
+        s_out[compall ? sen : i] = (int16_t)ascore;       // list mode: list order, compact
         mybest = min(mybest, ascore);
     }
 #pragma unroll
@@ -309,8 +310,12 @@ void ptm_frame_senone_kernel(PtmDev p, int32_t fresh, int32_t compall, int32_t n
     if ((tid & 63) == 0) atomicMin(&s_best, mybest);
     __syncthreads();
     const uint32_t best = (uint32_t)s_best;
-    for (int i = tid; i < p.n_sen; i += kFrameThreads)
+    // compallsen: the whole row; list mode: the n listed scores in list order -- every other
+    // entry of senone_scores is 0 - best (:398-400), which the host fills in from done_word[1]
+    const int n_out = compall ? p.n_sen : n;
+    for (int i = tid; i < n_out; i += kFrameThreads)
         out[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)s_out[i] - best);   // int16 -= int (:398-400)
+    if (tid == 0) done_word[1] = best;
     // completion word behind the scores (host-mapped memory): the host polls it
     // instead of paying for a stream synchronisation per call
     __threadfence_system();
@@ -651,7 +656,13 @@ int psgpu_ptm_frame_eval(psgpu_ptm_state_t *s, int16_t *senscr,
             PSGPU_HIP(hipStreamSynchronize(s->stream));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
-    memcpy(senscr, s->h_out, (size_t)m->n_sen * sizeof(int16_t));
+    if (compallsen)
+        memcpy(senscr, s->h_out, (size_t)m->n_sen * sizeof(int16_t));
+    else {
+        const int16_t rest = (int16_t)(uint16_t)(0u - h_done[1]);
+        for (int i = 0; i < m->n_sen; ++i) senscr[i] = rest;
+        for (int i = 0; i < n_list; ++i) senscr[s->h_list[i]] = s->h_out[i];
+    }
     return PSGPU_OK;
 }
 
