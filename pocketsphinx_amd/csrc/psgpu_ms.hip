@@ -31,6 +31,7 @@ constexpr int kMsMaxFeat = 8;
 constexpr int kMsMaxTopn = 8;
 constexpr int kMsK = 4;
 constexpr int kMsLaLds = 4096;           // log-add entries kept in LDS (int32)
+constexpr int kMsStage = 4096;           // (codebook, stream, rank) entries staged per frame
 
 struct MsDev {
     const float *mean, *var, *det;
@@ -176,10 +177,28 @@ void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *
     if (la_lds)
         for (int i = tid; i < p.logadd_size; i += kMsSenThreads) s_la[i] = p.logadd[i];
     if (tid == 0) s_best = 0x7fffffff;
+    const int ntop = min(N, p.n_density);
+    // Senones that share codebooks (pdf_t): the frame's (codebook, stream, rank) entries are
+    // few, so their density scores fden and ids are computed ONCE into LDS instead of once
+    // per senone.
+    __shared__ int32_t s_fd[kMsStage];
+    __shared__ uint8_t s_idb[kMsStage];
+    const int n_ent = p.n_mgau * p.n_feat * N;
+    const bool staged = p.pdf_t != nullptr && n_ent <= kMsStage;
+    if (staged) {
+        for (int e = tid; e < n_ent; e += kMsSenThreads) {
+            const int c = e / N, t = e - c * N;
+            const size_t li = ((size_t)c * n_frames + frame) * N + t;
+            const float dv = list_dist[li];
+            s_fd[e] = (dv < (float)kMaxNegInt32)
+                ? (kMaxNegInt32 >> kSenscrShift)
+                : (((int32_t)dv + ((1 << kSenscrShift) - 1)) >> kSenscrShift);
+            s_idb[e] = (uint8_t)list_id[li];
+        }
+    }
     __syncthreads();
     const int32_t *la = la_lds ? s_la : p.logadd;
     const int n = compall ? p.n_sen : n_list;
-    const int ntop = min(N, p.n_density);
     int32_t mybest = 0x7fffffff;
     for (int i = tid; i < n; i += kMsSenThreads) {
         const int sen = compall ? i : list[i];
@@ -196,11 +215,19 @@ void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *
             const size_t pstep = p.pdf_t ? (size_t)p.n_sen : 1;
             int32_t fscr = 0;
             for (int t = 0; t < ntop; ++t) {
-                const float dv = list_dist[lbase + f * lstep + t];
-                const int32_t fden = (dv < (float)kMaxNegInt32)
-                    ? (kMaxNegInt32 >> kSenscrShift)
-                    : (((int32_t)dv + ((1 << kSenscrShift) - 1)) >> kSenscrShift);
-                const int32_t fw = fden - (int32_t)pdf[(size_t)list_id[lbase + f * lstep + t] * pstep];
+                int32_t fden, id;
+                if (staged) {
+                    const int e = (cb * p.n_feat + f) * N + t;
+                    fden = s_fd[e]; id = s_idb[e];
+                }
+                else {
+                    const float dv = list_dist[lbase + f * lstep + t];
+                    fden = (dv < (float)kMaxNegInt32)
+                        ? (kMaxNegInt32 >> kSenscrShift)
+                        : (((int32_t)dv + ((1 << kSenscrShift) - 1)) >> kSenscrShift);
+                    id = list_id[lbase + f * lstep + t];
+                }
+                const int32_t fw = fden - (int32_t)pdf[(size_t)id * pstep];
                 if (t == 0) fscr = fw;
                 else {
                     // logmath_add (util/logmath.c:401-446)
