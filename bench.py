@@ -178,6 +178,53 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         ms.close()
     except Exception as e:
         out["ms_scorer"] = {"error": str(e)}
+    # (4) a fully continuous model of en-us size (BASELINE configs[3]: the only bundled continuous model,
+    #     an4_ci_cont, has 102 one-density codebooks): 5126 senones x 16 densities x 39 dims, top-4,
+    #     random parameters with the value ranges of real precomputed tables, 32 utterances x 50 frames
+    try:
+        rng = np.random.default_rng(9)
+        n_sen, n_den, LL = 5126, 16, 39
+        mt = dict(n_mgau=np.array([n_sen]), n_feat=np.array([1]), n_density=np.array([n_den]),
+                  n_sen=np.array([n_sen]), max_topn=np.array([4]), aw=np.array([1]),
+                  featlen=np.array([LL], np.int32),
+                  mean=rng.standard_normal(n_sen * n_den * LL).astype(np.float32),
+                  var=np.floor(np.exp(rng.uniform(0, 12, n_sen * n_den * LL))).astype(np.float32),
+                  det=np.floor(rng.uniform(-500000, 400000, (n_sen, 1, n_den))).astype(np.float32),
+                  pdf=rng.integers(0, 256, (n_sen, 1, n_den)).astype(np.uint8),
+                  sen2mgau=np.arange(n_sen, dtype=np.uint32), logadd=t["logadd8"],
+                  logadd_size=np.array([int(t["logadd8"].size)]), logadd_width=np.array([1]),
+                  log_zero=np.array([-524288]))
+        ms = P.MsMgau(mt)
+        n_fr = 32 * 50
+        f = torch.from_numpy(rng.standard_normal((n_fr, LL)).astype(np.float32)).to(dev)
+        nl = n_fr * ms.n_mgau * ms.n_feat * ms.topn
+        ids = torch.empty(nl, dtype=torch.int32, device=dev)
+        dist = torch.empty(nl, dtype=torch.float32, device=dev)
+        scr = torch.empty((n_fr, ms.n_sen), dtype=torch.int16, device=dev)
+
+        def cstep():
+            capi.check(L.psgpu_ms_score_batch_dev(ms.h, C.c_void_p(f.data_ptr()), n_fr, C.c_void_p(ids.data_ptr()),
+                                                  C.c_void_p(dist.data_ptr()), C.c_void_p(scr.data_ptr()), sp), "ms")
+        cstep()
+        capi.check(L.psgpu_ms_batch_check(ms.h, sp), "ms check")
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
+        K = 5
+        L.psgpu_event_record(e0, sp)
+        for _ in range(K):
+            cstep()
+        L.psgpu_event_record(e1, sp)
+        ms_ = C.c_float()
+        L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
+        flop = n_sen * n_den * LL * 4
+        out["ms_continuous"] = {"frames_per_s": round(n_fr * K / (ms_.value * 1e-3), 1), "frames": n_fr,
+                                "model": "synthetic .cont. 5126 senones x 16 densities x 39 dims, topn 4",
+                                "ms_per_launch_pair": round(ms_.value / K, 4),
+                                "distance_tflops": round(flop * n_fr * K / (ms_.value * 1e-3) / 1e12, 2)}
+        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
+        ms.close()
+    except Exception as e:
+        out["ms_continuous"] = {"error": str(e)}
     return out
 
 

@@ -195,3 +195,25 @@ def test_ptm_random_model(seed):
         if frame == fi:
             fi += 1
     st.close(); m.close()
+
+
+def test_ms_continuous_model_batch():
+    """A fully continuous model (.cont. mapping: every senone its own codebook,
+    ms_senone.c:305-315): 700 senones x 8 densities x 39 dims, top-4 -- the
+    frames-on-lanes kernel with LEN 39 and the [sen][feat][cw] weight layout."""
+    import pocketsphinx_amd as P
+    rng = np.random.default_rng(42)
+    n_sen, n_den, L = 700, 8, 39
+    featlen = np.array([L], np.int32)
+    mean, var, det = _gauss(rng, n_sen, 1, n_den, featlen)
+    t = dict(n_mgau=np.array([n_sen]), n_feat=np.array([1]), n_density=np.array([n_den]),
+             n_sen=np.array([n_sen]), max_topn=np.array([4]), aw=np.array([1]), featlen=featlen,
+             mean=mean, var=var, det=det, pdf=rng.integers(0, 256, (n_sen, 1, n_den)).astype(np.uint8),
+             sen2mgau=np.arange(n_sen, dtype=np.uint32), logadd=_logadd8(), logadd_size=np.array([256]),
+             logadd_width=np.array([1]), log_zero=np.array([-524288]))
+    g, o = P.MsMgau(t), pso.OracleMs(t)
+    feats = rng.standard_normal((150, L)).astype(np.float32)
+    got = g.score_frames(feats)
+    for i in range(feats.shape[0]):
+        assert np.array_equal(got[i], o.frame_eval(feats[i], compallsen=True)), "frame %d" % i
+    g.close()
