@@ -151,6 +151,55 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
                          int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,
                          void *stream);
 
+/* ---- MFCC front end (caller side of the scorer) ------------------
+ * Replaces fe_start_utt + fe_process_frames(all samples) + fe_end_utt
+ * (fe/fe_interface.c:318-327, 352-495, 526-541) as acmod_process_full_raw runs them
+ * (acmod.c:552-557), i.e. fe_process_utt (fe_interface.c:505-524) plus the tail
+ * frame, for batches of whole utterances; floating-point build of the reference
+ * (fe/fe_type.h:58-60).  The object holds the reference's own precomputed tables
+ * (fe_t / melfb_t, fe/fe_internal.h:70-161), which the caller reads out of its
+ * fe_t; nothing is regenerated on the device.  Bit-identical to the reference up
+ * to the double-precision log() of the mel spectrum (see csrc/psgpu_fe.hip). */
+typedef struct psgpu_fe_s psgpu_fe_t;
+typedef struct psgpu_fe_params_s {
+    int32_t frame_size, frame_shift, fft_size;   /* fe_t.frame_size, frame_shift, fft_size */
+    int32_t n_filt, num_cepstra, out_dim;        /* melfb_t.num_filters, fe_t.num_cepstra, feature_dimension */
+    int32_t transform;                           /* fe_t.transform: 0 legacy, 1 dct, 2 htk */
+    int32_t log_spec;                            /* fe_t.log_spec: 0, 1 raw, 2 smooth */
+    int32_t remove_dc, remove_noise;             /* fe_t.remove_dc, fe_t.noise_stats != NULL */
+    int32_t swap, dither;                        /* fe_t.swap; dither must be 0 (PSGPU_EINVAL otherwise) */
+    float alpha;                                 /* fe_t.pre_emphasis_alpha */
+    float sqrt_inv_n, sqrt_inv_2n;               /* melfb_t.sqrt_inv_n, sqrt_inv_2n */
+} psgpu_fe_params_t;
+
+/* hamming [frame_size/2], ccc/sss [fft_size/4] (float64); spec_start / filt_start /
+ * filt_width [n_filt]; filt_coeffs flattened (sum of widths); mel_cosine
+ * [num_cepstra][n_filt]; lifter [num_cepstra] or NULL when lifter_val == 0. */
+int psgpu_fe_create(psgpu_fe_t **out, const psgpu_fe_params_t *p, const double *hamming,
+                    const double *ccc, const double *sss, const int16_t *spec_start,
+                    const int16_t *filt_start, const int16_t *filt_width, const float *filt_coeffs,
+                    const float *mel_cosine, const float *lifter);
+void psgpu_fe_free(psgpu_fe_t *fe);
+int32_t psgpu_fe_out_dim(const psgpu_fe_t *fe);
+/* frames produced for an utterance of n_samples: full frames + the zero-padded tail
+ * frame of fe_end_utt (always present when n_samples > 0) */
+int64_t psgpu_fe_n_frames(const psgpu_fe_t *fe, int64_t n_samples);
+
+/* pcm_dev: samples of n_utt utterances back to back; samp_off [n_utt + 1] HOST array of
+ * sample offsets.  cep_dev [total_frames][out_dim]; frame_off_dev [n_utt + 1] receives the
+ * frame offsets (the utt_off_dev of psgpu_feat_1s_c_d_dd_dev / psgpu_ptm_score_batch_dev),
+ * frame_off (host, optional) the same.  noise_dev [n_utt][4][n_filt] float64 (power, noise,
+ * floor, peak of noise_stats_t, fe_noise.c:70-101) and undefined_dev [n_utt] are the noise
+ * tracker carried into and out of each utterance (the reference keeps it per decoder until
+ * ps_start_stream); both NULL = every utterance starts from reset statistics.  Asynchronous
+ * on `stream`; one call in flight per front-end object (it owns the scratch spectrum). */
+int psgpu_fe_process_utts_dev(psgpu_fe_t *fe, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt,
+                              double *noise_dev, int32_t *undefined_dev, float *cep_dev,
+                              int32_t *frame_off_dev, int32_t *frame_off, void *stream);
+/* host buffers, synchronous */
+int psgpu_fe_process_utts(psgpu_fe_t *fe, const int16_t *pcm, const int64_t *samp_off, int32_t n_utt,
+                          double *noise, int32_t *undefined, float *cep, int32_t *frame_off);
+
 /* ---- dynamic features (caller side of the scorer) -------------------------------
  * Replaces feat_s2mfc2feat_live(begin = end = TRUE) (feat/feat.c:1310, :1275-1306)
  * for the "1s_c_d_dd" feature type with batch CMN and no AGC / LDA (the en-us

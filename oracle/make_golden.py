@@ -211,6 +211,36 @@ def dynfeat_only():
     print("dynfeat_goforward:", d["cep"].shape, "->", d["feat"].shape)
 
 
+def mfcc_only():
+    """Front-end goldens: the reference's tables + cepstra.  `mfcc` uses the en-us decoder's
+    front end; the variants a stand-alone fe_t (ref_dump mfcc_cfg) configured by key/value."""
+    def clip(src, n0, n1):
+        pcm = np.fromfile(os.path.join(REF, "data", src), dtype=np.int16)[n0:n1]
+        fh = tempfile.NamedTemporaryFile(suffix=".raw", delete=False)
+        pcm.tofile(fh); fh.close()
+        return fh.name
+
+    d = ref_dump("mfcc", os.path.join(REF, "data", "goforward.raw"), 2)
+    np.savez_compressed(os.path.join(GOLD, "mfcc_en_us_goforward.npz"), **d)
+    print("mfcc_en_us_goforward:", d["cep"].shape)
+    en = ("lowerf", "130", "upperf", "6800", "nfilt", "25", "transform", "dct", "lifter", "22", "remove_noise", "yes")
+    cases = {
+        "legacy_dc": (("remove_dc", "yes"), (0, 12000)),                     # built-in defaults: 40 filters, legacy transform
+        "htk_40": (("transform", "htk", "lifter", "22", "remove_noise", "yes"), (3000, 14000)),
+        "logspec": (en + ("nfilt", "31", "logspec", "yes"), (0, 9000)),
+        "smoothspec": (en + ("smoothspec", "yes"), (0, 9000)),
+        "nfft1024": (en + ("nfft", "1024", "wlen", "0.032", "frate", "125", "alpha", "0"), (1000, 13000)),
+        "short": (en, (5000, 5300)),                    # fewer samples than one frame: only the fe_end_utt frame
+        "exact": (en, (5000, 5000 + 410 + 160 * 7)),    # no left-over samples beyond the last full frame
+    }
+    for name, (extra, (n0, n1)) in cases.items():
+        raw = clip("numbers.raw", n0, n1)
+        d = ref_dump("mfcc_cfg", raw, 2, lm="-", dic="-", extra=extra)
+        os.unlink(raw)
+        np.savez_compressed(os.path.join(GOLD, "mfcc_%s.npz" % name), **d)
+        print("mfcc_%s:" % name, [int(v) for v in d["par"][:12]], d["cep"].shape)
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -228,6 +258,8 @@ if __name__ == "__main__":
         semi_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ms":
         ms_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mfcc":
+        mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":
         dynfeat_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ptm_topn":

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <math.h>
 #include "ps_oracle.h"
 
 /* ================================================================== */
@@ -1054,4 +1055,209 @@ pso_hmm_vit_eval(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
     if (h->n_emit_state == 5)
         return h->mpx ? vit5_mpx(ctx, h) : vit5(ctx, h);
     return W;
+}
+
+/* ====================================================================== */
+/* MFCC front end                                                         */
+/* ====================================================================== */
+
+int
+pso_fe_n_frames(const pso_fe_t *fe, long n)
+{
+    /* fe_interface.c:398-403 (full frames), :526-541 (fe_end_utt: one more frame
+     * from the overflow samples; after the full frames the overflow buffer holds
+     * frame_size - frame_shift + (left-over < frame_shift) > 0 samples, :452-466;
+     * with fewer than frame_size samples it holds all of them, :375-381) */
+    if (n <= 0) return 0;
+    if (n < fe->frame_size) return 1;
+    return 1 + (int)((n - fe->frame_size) / fe->frame_shift) + 1;
+}
+
+/* in-place real FFT of fe_fft_real (fe_sigproc.c:1052-1149): bit reversal, one
+ * stage of 2-point butterflies, then stages k = 1..m-1 over blocks of 2^(k+1)
+ * points.  Output: x[j] real part, x[n-j] imaginary part. */
+static void
+fe_rfft(const pso_fe_t *fe, double *x)
+{
+    int n = fe->fft_size, m = fe->fft_order, i, j, k;
+    for (i = 0; i < n; ++i) {                       /* :1062-1075 as a permutation */
+        int r = 0, b;
+        for (b = 0; b < m; ++b) r |= ((i >> b) & 1) << (m - 1 - b);
+        if (i < r) { double t = x[i]; x[i] = x[r]; x[r] = t; }
+    }
+    for (i = 0; i < n; i += 2) {                    /* :1081-1085 */
+        double a = x[i], b = x[i + 1];
+        x[i] = a + b;
+        x[i + 1] = a - b;
+    }
+    for (k = 1; k < m; ++k) {                       /* :1088-1144 */
+        int half = 1 << k, quarter = half >> 1, blk = half << 1, base;
+        for (base = 0; base < n; base += blk) {
+            double a = x[base], b = x[base + half];
+            x[base] = a + b;
+            x[base + half] = a - b;
+            x[base + half + quarter] = -x[base + half + quarter];
+            for (j = 1; j < quarter; ++j) {
+                int i1 = base + j, i2 = base + half - j, i3 = base + half + j, i4 = base + blk - j;
+                double cc = fe->ccc[j << (m - k - 1)], ss = fe->sss[j << (m - k - 1)];
+                double p = x[i3] * cc, q = x[i4] * ss, r = x[i3] * ss, s = x[i4] * cc;
+                double t1 = p + q, t2 = r - s;
+                double x1 = x[i1], x2 = x[i2];
+                x[i4] = x2 - t2;
+                x[i3] = -x2 - t2;
+                x[i2] = x1 - t1;
+                x[i1] = x1 + t1;
+            }
+        }
+    }
+}
+
+/* fe_remove_noise (fe_noise.c:268-364), floating-point branches. */
+static void
+fe_denoise(const pso_fe_t *fe, double *mf, double *st, int32_t *undefined)
+{
+    const double l_pow = 0.7, c_pow = 1 - 0.7, l_a = 0.995, c_a = 1 - 0.995, l_b = 0.5, c_b = 1 - 0.5;
+    const double l_t = 0.85, mu_t = 0.2, max_gain = 20, inv_max_gain = 1.0 / 20;   /* :59-68, :203-213 */
+    int nf = fe->n_filt, i, j;
+    double *power = st, *noise = st + nf, *floor_ = st + 2 * nf, *peak = st + 3 * nf;
+    double signal[256], gain[256];
+    if (*undefined) {                               /* :282-298 */
+        for (i = 0; i < nf; ++i) {
+            power[i] = mf[i];
+            noise[i] = mf[i] / max_gain;
+            floor_[i] = mf[i] / max_gain;
+            peak[i] = 0.0;
+        }
+        *undefined = 0;
+    }
+    for (i = 0; i < nf; ++i) {
+        double in;
+        power[i] = l_pow * power[i] + c_pow * mf[i];                      /* :301-309 */
+        if (power[i] >= noise[i]) noise[i] = l_a * noise[i] + c_a * power[i];      /* fe_lower_envelope :109-127 */
+        else                      noise[i] = l_b * noise[i] + c_b * power[i];
+        signal[i] = power[i] - noise[i];                                   /* :315-323 */
+        if (signal[i] < 1.0) signal[i] = 1.0;
+        if (signal[i] >= floor_[i]) floor_[i] = l_a * floor_[i] + c_a * signal[i]; /* :327 */
+        else                        floor_[i] = l_b * floor_[i] + c_b * signal[i];
+        in = signal[i];                                                    /* fe_temp_masking :131-152 */
+        peak[i] *= l_t;
+        if (signal[i] < l_t * peak[i]) signal[i] = peak[i] * mu_t;
+        if (in > peak[i]) peak[i] = in;
+        if (signal[i] < floor_[i]) signal[i] = floor_[i];                  /* :331-334 */
+        if (signal[i] < max_gain * power[i]) gain[i] = signal[i] / power[i];       /* :337-345 */
+        else                                 gain[i] = max_gain;
+        if (gain[i] < inv_max_gain) gain[i] = inv_max_gain;
+    }
+    for (i = 0; i < nf; ++i) {                      /* fe_weight_smooth :155-184, window 4 */
+        int l1 = i - 4 > 0 ? i - 4 : 0, l2 = i + 4 < nf - 1 ? i + 4 : nf - 1;
+        double c = 0;
+        for (j = l1; j <= l2; ++j) c += gain[j];
+        mf[i] = mf[i] * (c / (l2 - l1 + 1));
+    }
+}
+
+/* fe_mel_cep + fe_lifter (fe_sigproc.c:1217-1342): mfcc_t (float32) accumulators,
+ * float64 log spectrum. */
+static void
+fe_cepstrum(const pso_fe_t *fe, double *mf, float *cep)
+{
+    int nf = fe->n_filt, nc = fe->num_cepstra, i, j;
+    for (i = 0; i < nf; ++i)
+        mf[i] = log(mf[i] + 1e-4);                  /* LOG_FLOOR :1215, :1228 */
+    if (fe->log_spec == 1) {                        /* RAW_LOG_SPEC :1233-1237 */
+        for (i = 0; i < fe->out_dim; ++i) cep[i] = (float)mf[i];
+        return;
+    }
+    if (fe->log_spec == 2 || fe->transform == 1 || fe->transform == 2) {
+        int htk = (fe->log_spec != 2 && fe->transform == 2);
+        float c[256];
+        float *o = fe->log_spec == 2 ? c : cep;
+        o[0] = (float)mf[0];                        /* fe_dct2 :1288-1310 */
+        for (j = 1; j < nf; ++j) o[0] = (float)(o[0] + mf[j]);
+        o[0] = o[0] * (htk ? fe->sqrt_inv_2n : fe->sqrt_inv_n);
+        for (i = 1; i < nc; ++i) {
+            o[i] = 0;
+            for (j = 0; j < nf; ++j)
+                o[i] = (float)(o[i] + mf[j] * fe->mel_cosine[i * nf + j]);
+            o[i] = o[i] * fe->sqrt_inv_2n;
+        }
+        if (fe->log_spec == 2) {                    /* SMOOTH_LOG_SPEC :1240-1248: fe_dct3 :1326-1338 */
+            for (i = 0; i < nf; ++i) {
+                mf[i] = c[0] * 0.707106781186548;   /* SQRT_HALF is a double constant, fe_internal.h:106 */
+                for (j = 1; j < nc; ++j)
+                    mf[i] += c[j] * fe->mel_cosine[j * nf + i];
+                mf[i] = mf[i] * fe->sqrt_inv_2n;
+            }
+            for (i = 0; i < fe->out_dim; ++i) cep[i] = (float)mf[i];
+            return;                                 /* fe_lifter is still applied by the caller */
+        }
+    }
+    else {                                          /* fe_spec2cep :1257-1285 */
+        cep[0] = (float)(mf[0] / 2);
+        for (j = 1; j < nf; ++j) cep[0] = (float)(cep[0] + mf[j]);
+        cep[0] = (float)(cep[0] / (double)nf);
+        for (i = 1; i < nc; ++i) {
+            cep[i] = 0;
+            for (j = 0; j < nf; ++j) {
+                int beta = j == 0 ? 1 : 2;
+                cep[i] = (float)(cep[i] + mf[j] * fe->mel_cosine[i * nf + j] * beta);
+            }
+            cep[i] = (float)(cep[i] / ((double)nf * 2));
+        }
+    }
+}
+
+int
+pso_fe_process_utt(const pso_fe_t *fe, const int16_t *pcm, long n, float *cep,
+                   double *noise, int32_t *undefined)
+{
+    int nfr = pso_fe_n_frames(fe, n), t, i, j;
+    int fs = fe->frame_size, N = fe->fft_size;
+    double *x = malloc(sizeof(double) * N), *spec = malloc(sizeof(double) * (N / 2 + 1));
+    double mf[256];
+    for (t = 0; t < nfr; ++t) {
+        long start = (long)t * fe->frame_shift;
+        int len = (int)(n - start < fs ? n - start : fs);
+        float *out = cep + (size_t)t * fe->out_dim;
+        /* fe_spch_to_frame (fe_sigproc.c:839-860): pre-emphasis with the sample
+         * before the frame (fe_pre_emphasis_int16 :745-749; prior = 0 at the
+         * utterance start, fe_interface.c:325), zero padding, window */
+        if (fe->alpha != 0.0f) {
+            double prior = start > 0 ? (double)pcm[start - 1] : 0.0;
+            x[0] = (double)pcm[start] - prior * fe->alpha;
+            for (i = 1; i < len; ++i)
+                x[i] = (double)pcm[start + i] - (double)pcm[start + i - 1] * fe->alpha;
+        }
+        else
+            for (i = 0; i < len; ++i) x[i] = (double)pcm[start + i];
+        for (i = len; i < N; ++i) x[i] = 0;
+        if (fe->remove_dc) {                        /* fe_hamming_window :802-815 */
+            double mean = 0;
+            for (i = 0; i < fs; ++i) mean += x[i];
+            mean /= fs;
+            for (i = 0; i < fs; ++i) x[i] -= mean;
+        }
+        for (i = 0; i < fs / 2; ++i) {              /* :826-829 */
+            x[i] = x[i] * fe->hamming[i];
+            x[fs - 1 - i] = x[fs - 1 - i] * fe->hamming[i];
+        }
+        fe_rfft(fe, x);
+        spec[0] = x[0] * x[0];                      /* fe_spec_magnitude :1171-1191 */
+        for (j = 1; j <= N / 2; ++j)
+            spec[j] = x[j] * x[j] + x[N - j] * x[N - j];
+        for (i = 0; i < fe->n_filt; ++i) {          /* fe_mel_spec :1194-1213 */
+            const float *co = fe->filt_coeffs + fe->filt_start[i];
+            const double *sp = spec + fe->spec_start[i];
+            double a = 0;
+            for (j = 0; j < fe->filt_width[i]; ++j) a += sp[j] * co[j];
+            mf[i] = a;
+        }
+        if (fe->remove_noise)
+            fe_denoise(fe, mf, noise, undefined);
+        fe_cepstrum(fe, mf, out);
+        if (fe->has_lifter)                         /* fe_lifter :1313-1323 */
+            for (i = 0; i < fe->num_cepstra; ++i) out[i] = out[i] * fe->lifter[i];
+    }
+    free(x); free(spec);
+    return nfr;
 }

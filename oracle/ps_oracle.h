@@ -143,6 +143,42 @@ int pso_ms_frame_eval(pso_ms_t *s, int16_t *senscr,
  * out [T][3*cepsize]. */
 void pso_dynfeat_1s_c_d_dd(const float *cep, int T, int cepsize, float *out);
 
+/* ---------------- MFCC front end (fe/fe_sigproc.c, fe/fe_noise.c, fe/fe_interface.c) ---------------- */
+
+/* Floating-point build of the reference front end (frame_t = powspec_t =
+ * window_t = float64, mfcc_t = float32; fe/fe_type.h:58-60).  All tables are the
+ * reference's own precomputed ones (fe_create_hamming, fe_create_twiddle,
+ * fe_build_melfilters, fe_compute_melcosine; fe_sigproc.c:552-722,780-795,
+ * 886-903) and are passed in, never regenerated. */
+typedef struct pso_fe_s {
+    int32_t frame_size, frame_shift, fft_size, fft_order;
+    int32_t n_filt, num_cepstra, out_dim;      /* out_dim = fe_t.feature_dimension */
+    int32_t transform;                         /* 0 legacy, 1 dct, 2 htk (fe_internal.h:65-69) */
+    int32_t log_spec;                          /* 0, 1 raw, 2 smooth (fe_internal.h:59-62) */
+    int32_t remove_dc, remove_noise, has_lifter;
+    float alpha, sqrt_inv_n, sqrt_inv_2n;
+    const double *hamming;                     /* [frame_size/2] */
+    const double *ccc, *sss;                   /* [fft_size/4] */
+    const int16_t *spec_start, *filt_start, *filt_width;   /* [n_filt] */
+    const float *filt_coeffs;                  /* flattened */
+    const float *mel_cosine;                   /* [num_cepstra][n_filt] */
+    const float *lifter;                       /* [num_cepstra] or NULL */
+} pso_fe_t;
+
+/* Number of cepstral frames fe_start_utt + fe_process_frames(all samples) +
+ * fe_end_utt produce for n samples (fe_interface.c:398-403, 526-541):
+ * 1 + (n - frame_size)/frame_shift full frames when n >= frame_size, plus the
+ * zero-padded tail frame whenever any sample is left over (always, for n > 0). */
+int pso_fe_n_frames(const pso_fe_t *fe, long n);
+
+/* One utterance, acmod_process_full_raw order (acmod.c:552-557).  noise
+ * [4][n_filt] = power, noise, floor, peak of noise_stats_t, *undefined = its
+ * "initialise on next frame" flag; both are read and updated (the reference
+ * keeps them across utterances until ps_start_stream, pocketsphinx.c:1081).
+ * cep [pso_fe_n_frames][out_dim].  Returns the number of frames. */
+int pso_fe_process_utt(const pso_fe_t *fe, const int16_t *pcm, long n, float *cep,
+                       double *noise, int32_t *undefined);
+
 /* ---------------- shared helpers ---------------- */
 
 /* acmod_flags2list (acmod.c:1223-1275): bit flags -> uint8 delta list.

@@ -6,7 +6,8 @@ import struct
 import numpy as np
 
 _DT = {ord('f'): np.float32, ord('i'): np.int32, ord('h'): np.int16,
-       ord('B'): np.uint8, ord('H'): np.uint16, ord('q'): np.int64}
+       ord('B'): np.uint8, ord('H'): np.uint16, ord('q'): np.int64,
+       ord('d'): np.float64}
 
 
 def read_psgb(path):

@@ -49,13 +49,13 @@ psgb_open(const char *path)
     fwrite("PSGB1\n", 1, 6, g_out);
 }
 
-/* dtype codes: 'f' float32, 'i' int32, 'h' int16, 'B' uint8, 'H' uint16, 'q' int64 */
+/* dtype codes: 'f' float32, 'i' int32, 'h' int16, 'B' uint8, 'H' uint16, 'q' int64, 'd' float64 */
 static void
 psgb_put(const char *name, char dtype, int ndim, const int64_t *dims, const void *data)
 {
     uint32_t nl = (uint32_t)strlen(name), dt = (uint32_t)dtype, nd = (uint32_t)ndim;
     size_t esz = (dtype == 'f' || dtype == 'i') ? 4 : (dtype == 'h' || dtype == 'H') ? 2
-               : (dtype == 'q') ? 8 : 1;
+               : (dtype == 'q' || dtype == 'd') ? 8 : 1;
     size_t n = 1;
     int i;
     for (i = 0; i < ndim; ++i) n *= (size_t)dims[i];
@@ -745,6 +745,65 @@ cmd_dynfeat(ps_decoder_t *ps, const char *mfcpath)
     return 0;
 }
 
+
+/* ------------------------------------------------------------------ */
+/* mfcc: the front end's precomputed tables (fe_t / melfb_t, fe_internal.h:70-161)
+ * and the cepstra of one recording computed exactly as acmod_process_full_raw
+ * does (acmod.c:552-557: fe_start_utt, fe_process_frames, fe_end_utt), starting
+ * from reset noise statistics (what ps_start_stream leaves, pocketsphinx.c:1081).
+ * With nrep > 1 the recording is processed again WITHOUT a reset, so the second
+ * block shows the noise tracker carried across utterances. */
+#include "fe/fe_internal.h"
+#include "fe/fe_noise.h"
+static int
+cmd_mfcc(fe_t *fe, const char *rawpath, int nrep)
+{
+    melfb_t *mel = fe->mel_fb;
+    size_t n; int16 *pcm = read_pcm(rawpath, &n);
+    int32 par[16];
+    int i, r, ncoef = 0, outdim = fe_get_output_size(fe);
+    float *cos_flat;
+    if (!pcm) return 2;
+    par[0] = fe->frame_size; par[1] = fe->frame_shift; par[2] = fe->fft_size; par[3] = fe->fft_order;
+    par[4] = mel->num_filters; par[5] = fe->num_cepstra; par[6] = fe->feature_dimension;
+    par[7] = fe->transform; par[8] = fe->log_spec; par[9] = fe->remove_dc; par[10] = fe->noise_stats != NULL;
+    par[11] = mel->lifter_val; par[12] = fe->swap; par[13] = fe->dither; par[14] = 0; par[15] = 0;
+    put1("par", 'i', 16, par);
+    put1("alpha", 'f', 1, &fe->pre_emphasis_alpha);
+    put1("sqrt_inv_n", 'f', 1, &mel->sqrt_inv_n);
+    put1("sqrt_inv_2n", 'f', 1, &mel->sqrt_inv_2n);
+    put1("hamming", 'd', fe->frame_size / 2, fe->hamming_window);
+    put1("ccc", 'd', fe->fft_size / 4, fe->ccc);
+    put1("sss", 'd', fe->fft_size / 4, fe->sss);
+    put1("spec_start", 'h', mel->num_filters, mel->spec_start);
+    put1("filt_start", 'h', mel->num_filters, mel->filt_start);
+    put1("filt_width", 'h', mel->num_filters, mel->filt_width);
+    for (i = 0; i < mel->num_filters; ++i) ncoef += mel->filt_width[i];
+    put1("filt_coeffs", 'f', ncoef, mel->filt_coeffs);
+    cos_flat = malloc(sizeof(float) * fe->num_cepstra * mel->num_filters);
+    for (i = 0; i < fe->num_cepstra; ++i)
+        memcpy(cos_flat + i * mel->num_filters, mel->mel_cosine[i], sizeof(float) * mel->num_filters);
+    put2("mel_cosine", 'f', fe->num_cepstra, mel->num_filters, cos_flat);
+    if (mel->lifter_val) put1("lifter", 'f', fe->num_cepstra, mel->lifter);
+    put1("pcm", 'h', (int64_t)n, pcm);
+    fe_reset_noisestats(fe->noise_stats);
+    for (r = 0; r < nrep; ++r) {
+        int16 const *p = pcm; size_t ns = n; int32 nfr, ntail; char name[32];
+        mfcc_t **cep;
+        fe_process_frames(fe, NULL, &ns, NULL, &nfr);
+        cep = (mfcc_t **)ckd_calloc_2d(nfr + 1, outdim, sizeof(mfcc_t));
+        fe_start_utt(fe);
+        fe_process_frames(fe, &p, &ns, cep, &nfr);
+        fe_end_utt(fe, cep[nfr], &ntail);
+        nfr += ntail;
+        snprintf(name, sizeof name, r ? "cep%d" : "cep", r);
+        put2(name, 'f', nfr, outdim, cep[0]);
+        ckd_free_2d(cep);
+    }
+    free(cos_flat); free(pcm);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 int
 main(int argc, char **argv)
@@ -780,6 +839,20 @@ main(int argc, char **argv)
         rc = cmd_senlog(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]));
     } else if (!strcmp(cmd, "dynfeat") && xa > 6) {
         rc = cmd_dynfeat(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+    } else if (!strcmp(cmd, "mfcc") && xa > 7) {
+        rc = cmd_mfcc(make_decoder(modeldir, lm, dict, nextra, extra)->acmod->fe, argv[6], atoi(argv[7]));
+    } else if (!strcmp(cmd, "mfcc_cfg") && xa > 7) {
+        /* a front end of its own (fe_init_auto_r, fe_interface.c:198), configured only by the
+         * key/value pairs: reaches settings no bundled acoustic model accepts (logspec, ...) */
+        ps_config_t *config = ps_config_init(NULL);
+        fe_t *fe;
+        err_set_loglevel(ERR_ERROR);
+        for (i = 0; i + 1 < nextra; i += 2)
+            if (ps_config_set_str(config, extra[i], extra[i + 1]) == NULL) {
+                fprintf(stderr, "bad config %s\n", extra[i]); return 2;
+            }
+        fe = fe_init_auto_r(config);
+        rc = fe ? cmd_mfcc(fe, argv[6], atoi(argv[7])) : 2;
     } else if (!strcmp(cmd, "hmm") && xa > 8) {
         rc = cmd_hmm(make_decoder(modeldir, lm, dict, nextra, extra), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
     } else if (!strcmp(cmd, "decode") && xa > 6) {

@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip"]
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip"]
 
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -25,6 +25,8 @@ SYMBOLS = [
     "psgpu_ms_model_create", "psgpu_ms_model_free", "psgpu_ms_n_sen", "psgpu_ms_veclen",
     "psgpu_ms_frame_eval", "psgpu_ms_score_batch_dev", "psgpu_ms_batch_check", "psgpu_ms_score_batch",
     "psgpu_feat_1s_c_d_dd_dev", "psgpu_feat_1s_c_d_dd",
+    "psgpu_fe_create", "psgpu_fe_free", "psgpu_fe_out_dim", "psgpu_fe_n_frames",
+    "psgpu_fe_process_utts_dev", "psgpu_fe_process_utts",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval",
 ]

@@ -298,3 +298,61 @@ class OracleMs:
         lib().pso_ms_frame_eval(self.h, _p(self.senscr), _p(act), 0 if act is None else act.size,
                                 _p(feat), int(bool(compallsen)))
         return self.senscr.copy()
+
+
+class OracleFe:
+    """Wrapper around pso_fe_t / pso_fe_process_utt (restates fe_sigproc.c,
+    fe_noise.c, fe_interface.c).  `t` = the arrays of an mfcc_*.npz fixture
+    (the reference's own precomputed front-end tables).  The noise tracker is
+    kept across process() calls like the reference's noise_stats_t; reset()
+    = fe_reset_noisestats."""
+
+    class _S(C.Structure):
+        _fields_ = [(n, C.c_int32) for n in ("frame_size", "frame_shift", "fft_size", "fft_order", "n_filt",
+                                             "num_cepstra", "out_dim", "transform", "log_spec", "remove_dc",
+                                             "remove_noise", "has_lifter")] + \
+                   [(n, C.c_float) for n in ("alpha", "sqrt_inv_n", "sqrt_inv_2n")] + \
+                   [(n, C.c_void_p) for n in ("hamming", "ccc", "sss", "spec_start", "filt_start", "filt_width",
+                                              "filt_coeffs", "mel_cosine", "lifter")]
+
+    def __init__(self, t):
+        par = [int(v) for v in t["par"]]
+        self._keep = dict(
+            hamming=np.ascontiguousarray(t["hamming"], np.float64), ccc=np.ascontiguousarray(t["ccc"], np.float64),
+            sss=np.ascontiguousarray(t["sss"], np.float64), spec_start=np.ascontiguousarray(t["spec_start"], np.int16),
+            filt_start=np.ascontiguousarray(t["filt_start"], np.int16),
+            filt_width=np.ascontiguousarray(t["filt_width"], np.int16),
+            filt_coeffs=np.ascontiguousarray(t["filt_coeffs"], np.float32),
+            mel_cosine=np.ascontiguousarray(t["mel_cosine"], np.float32))
+        if "lifter" in t:
+            self._keep["lifter"] = np.ascontiguousarray(t["lifter"], np.float32)
+        k = self._keep
+        s = self._S()
+        (s.frame_size, s.frame_shift, s.fft_size, s.fft_order, s.n_filt, s.num_cepstra, s.out_dim, s.transform,
+         s.log_spec, s.remove_dc, s.remove_noise) = par[:11]
+        s.has_lifter = int("lifter" in k)
+        s.alpha = float(t["alpha"][0]); s.sqrt_inv_n = float(t["sqrt_inv_n"][0]); s.sqrt_inv_2n = float(t["sqrt_inv_2n"][0])
+        for n in ("hamming", "ccc", "sss", "spec_start", "filt_start", "filt_width", "filt_coeffs", "mel_cosine", "lifter"):
+            setattr(s, n, _p(k[n]) if n in k else None)
+        self.s = s
+        self.out_dim = s.out_dim
+        self.noise = np.zeros((4, s.n_filt), np.float64)
+        self.undefined = C.c_int32(1)
+        L = lib()
+        L.pso_fe_n_frames.argtypes = [C.c_void_p, C.c_long]
+        L.pso_fe_process_utt.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def reset(self):
+        self.undefined = C.c_int32(1)
+
+    def n_frames(self, n):
+        return int(lib().pso_fe_n_frames(C.byref(self.s), n))
+
+    def process(self, pcm):
+        pcm = np.ascontiguousarray(pcm, np.int16)
+        nfr = self.n_frames(pcm.size)
+        cep = np.empty((nfr, self.out_dim), np.float32)
+        got = lib().pso_fe_process_utt(C.byref(self.s), _p(pcm), pcm.size, _p(cep), _p(self.noise),
+                                       C.byref(self.undefined))
+        assert got == nfr
+        return cep

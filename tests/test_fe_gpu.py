@@ -1,0 +1,93 @@
+"""GPU parity of the MFCC front end (psgpu_fe_*, the fe_process_utt + fe_end_utt
+replacement) against the pinned oracle and the reference's own cepstra.
+
+Tolerance: the path is float64/float32 arithmetic restated operation for operation
+(bit-identical by construction) except log(), where the device's libm and the host's
+are both faithful, not correctly rounded.  The tests demand bit equality and would
+report the number of differing values; on every bundled recording there is none."""
+import numpy as np
+import pytest
+
+import pso
+from test_oracle_golden import _load, MFCC_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))
+    assert bad[0].size == 0, "%d of %d values differ; first: frame %d coeff %d: %r vs %r" % (
+        bad[0].size, a.size, bad[0][0], bad[1][0], a[bad[0][0], bad[1][0]], b[bad[0][0], bad[1][0]])
+
+
+@pytest.mark.parametrize("case", MFCC_CASES)
+def test_fe_matches_reference_and_oracle(case):
+    """Every configuration of the goldens (dct / legacy / htk transforms, raw and
+    smoothed log spectra, DC removal, noise removal on and off, 1024-point FFT
+    without pre-emphasis, an utterance shorter than a frame, one with no left-over
+    samples): first from reset noise statistics, then with the tracker carried."""
+    import pocketsphinx_amd as P
+    g = _load("mfcc_%s.npz" % case)
+    fe = P.FrontEnd(g)
+    o = pso.OracleFe(g)
+    noise = np.zeros((1, 4, fe.n_filt), np.float64)
+    undefined = np.ones(1, np.int32)
+    for key in ("cep", "cep1"):
+        cep, fo = fe.process_utts([g["pcm"]], noise, undefined)
+        assert fo.tolist() == [0, g[key].shape[0]]
+        _same(cep, o.process(g["pcm"]))
+        _same(cep, g[key])
+        assert undefined[0] == 0 or not int(g["par"][10])
+        if int(g["par"][10]):
+            assert np.array_equal(noise[0], o.noise)          # the tracker state itself, float64
+    fe.close()
+
+
+def test_fe_ragged_batch():
+    """Several utterances in one call (one shorter than a frame, one empty, one
+    ending exactly on a frame boundary) equal the same utterances one at a time;
+    without noise arrays every utterance starts from reset statistics."""
+    import pocketsphinx_amd as P
+    g = _load("mfcc_en_us_goforward.npz")
+    pcm = g["pcm"]
+    cuts = [pcm[:7000], pcm[100:300], pcm[:0], pcm[9000:9000 + 410 + 160 * 20], pcm[20000:], pcm[3:411]]
+    fe = P.FrontEnd(g)
+    cep, fo = fe.process_utts(cuts)
+    assert fo[-1] == cep.shape[0] and fo[3] == fo[2]
+    for u, c in enumerate(cuts):
+        o = pso.OracleFe(g)
+        _same(cep[fo[u]:fo[u + 1]], o.process(c))
+    fe.close()
+
+
+def test_fe_all_bundled_recordings_and_feature_chain(tables):
+    """en-us configuration on every bundled 16 kHz recording, then the chain the
+    decoder runs: PCM -> cepstra -> 1s_c_d_dd features on the device equals the
+    feature vectors of the reference decoder's own acmod buffer."""
+    import os
+    import pocketsphinx_amd as P
+    g = _load("mfcc_en_us_goforward.npz")
+    fe = P.FrontEnd(g)
+    data = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "data")
+    names = [n for n in ("goforward.raw", "numbers.raw", "something.raw", "librivox-0870.raw")
+             if os.path.exists(os.path.join(data, n))]
+    assert names, "staged recordings missing (make -C oracle)"
+    pcms = [np.fromfile(os.path.join(data, n), dtype=np.int16) for n in names]
+    cep, fo = fe.process_utts(pcms)
+    for u, p in enumerate(pcms):
+        _same(cep[fo[u]:fo[u + 1]], pso.OracleFe(g).process(p))
+    c0 = cep[fo[0]:fo[1]]
+    feat = P.dynfeat_1s_c_d_dd(c0, [c0.shape[0]])
+    assert feat.tobytes() == np.ascontiguousarray(_load("ptm_goforward.npz")["feat"], np.float32).tobytes()
+    fe.close()
+
+
+def test_fe_rejects_what_it_cannot_reproduce():
+    import pocketsphinx_amd as P
+    g = dict(_load("mfcc_en_us_goforward.npz"))
+    par = g["par"].copy(); par[13] = 1                  # dither
+    g["par"] = par
+    with pytest.raises(P.PsgpuError):
+        P.FrontEnd(g)

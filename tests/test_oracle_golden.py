@@ -206,3 +206,37 @@ def test_dynfeat_oracle_matches_reference():
     L.pso_dynfeat_1s_c_d_dd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.pso_dynfeat_1s_c_d_dd(cep.ctypes.data, cep.shape[0], cep.shape[1], out.ctypes.data)
     assert out.tobytes() == np.ascontiguousarray(g["feat"], np.float32).tobytes()
+
+
+MFCC_CASES = ["en_us_goforward", "legacy_dc", "htk_40", "logspec", "smoothspec", "nfft1024", "short", "exact"]
+
+
+@pytest.mark.parametrize("case", MFCC_CASES)
+def test_fe_oracle_matches_reference(case):
+    """pso_fe_process_utt vs the reference front end (fe_start_utt / fe_process_frames /
+    fe_end_utt on its own fe_t, ref_dump mfcc): cepstra memcmp, first from reset noise
+    statistics, then a second pass with the noise tracker carried over.  The only libm
+    call on the path is log(); oracle and reference use the same libm here."""
+    g = _load("mfcc_%s.npz" % case)
+    fe = pso.OracleFe(g)
+    for key in ("cep", "cep1"):
+        got = fe.process(g["pcm"])
+        ref = np.ascontiguousarray(g[key], np.float32)
+        assert got.shape == ref.shape
+        bad = np.nonzero(got.view(np.uint32) != ref.view(np.uint32))
+        assert bad[0].size == 0, "%s: %d values differ, first at frame %d coeff %d" % (
+            key, bad[0].size, bad[0][0], bad[1][0])
+
+
+def test_fe_plus_dynfeat_oracle_reproduces_decoder_features():
+    """PCM -> pso_fe_process_utt -> pso_dynfeat_1s_c_d_dd equals, bit for bit, the feature
+    vectors the reference decoder itself computed for goforward.raw (ref_dump feats: the
+    contents of acmod->feat_buf during a real decode)."""
+    import ctypes as C
+    g = _load("mfcc_en_us_goforward.npz")
+    cep = pso.OracleFe(g).process(g["pcm"])
+    out = np.empty((cep.shape[0], 3 * cep.shape[1]), np.float32)
+    L = pso.lib()
+    L.pso_dynfeat_1s_c_d_dd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.pso_dynfeat_1s_c_d_dd(cep.ctypes.data, cep.shape[0], cep.shape[1], out.ctypes.data)
+    assert out.tobytes() == np.ascontiguousarray(_load("ptm_goforward.npz")["feat"], np.float32).tobytes()
