@@ -225,6 +225,67 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         ms.close()
     except Exception as e:
         out["ms_continuous"] = {"error": str(e)}
+    # (5) the whole device-side chain from audio: synthetic 16 kHz PCM (white noise
+    #     plus a tiled tone burst, int16) -> MFCC front end -> 1s_c_d_dd features with batch CMN -> PTM
+    #     senone scores, same batch shape as the headline (40 utterances x 250 frames)
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "mfcc_en_us_goforward.npz"))
+        fe = P.FrontEnd({k: g[k] for k in g.files})
+        par = [int(v) for v in g["par"]]
+        fsz, fsh = par[0], par[1]
+        n_samp = fsz + fsh * (UTT_LEN - 2)                  # UTT_LEN frames including the tail frame
+        rng = np.random.default_rng(11)
+        tt = np.arange(n_samp)
+        pcm_h = np.concatenate([(2000 * rng.standard_normal(n_samp) + 6000 * np.sin(2 * np.pi * (200 + 37 * u) * tt / 16000.0)
+                                 * (np.sin(2 * np.pi * 3 * tt / 16000.0) > 0)).astype(np.int16) for u in range(N_UTT)])
+        soff = (np.arange(N_UTT + 1, dtype=np.int64) * n_samp)
+        assert fe.n_frames(n_samp) == UTT_LEN
+        Tn = N_UTT * UTT_LEN
+        pcm = torch.from_numpy(pcm_h).to(dev)
+        cep = torch.empty((Tn, fe.out_dim), dtype=torch.float32, device=dev)
+        ft = torch.empty((Tn, 3 * fe.out_dim), dtype=torch.float32, device=dev)
+        foff = torch.empty(N_UTT + 1, dtype=torch.int32, device=dev)
+        tsc = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.int32, device=dev)
+        tcw = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.uint8, device=dev)
+        scr = torch.empty((Tn, model.n_sen), dtype=torch.int16, device=dev)
+        L.psgpu_fe_process_utts_dev.argtypes = [C.c_void_p] * 10
+        sarr = soff.ctypes.data_as(C.c_void_p)
+
+        def fe_step():
+            capi.check(L.psgpu_fe_process_utts_dev(fe.h, C.c_void_p(pcm.data_ptr()), sarr, N_UTT, None, None,
+                                                   C.c_void_p(cep.data_ptr()), C.c_void_p(foff.data_ptr()), None, sp), "fe")
+
+        def chain_step():
+            fe_step()
+            capi.check(L.psgpu_feat_1s_c_d_dd_dev(C.c_void_p(cep.data_ptr()), C.c_void_p(foff.data_ptr()), N_UTT,
+                                                  fe.out_dim, C.c_void_p(ft.data_ptr()), sp), "feat")
+            capi.check(L.psgpu_ptm_score_batch_dev(model.h, C.c_void_p(ft.data_ptr()), C.c_void_p(foff.data_ptr()), N_UTT, Tn,
+                                                   None, None, C.c_void_p(tsc.data_ptr()), C.c_void_p(tcw.data_ptr()),
+                                                   C.c_void_p(scr.data_ptr()), None, 0, sp), "score")
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
+        res = {}
+        for name, fn in (("front_end", fe_step), ("pcm_to_scores", chain_step)):
+            fn(); fn()
+            K = 20
+            L.psgpu_event_record(e0, sp)
+            for _ in range(K):
+                fn()
+            L.psgpu_event_record(e1, sp)
+            ms_ = C.c_float()
+            L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
+            res[name] = ms_.value / K
+        out["pcm_pipeline"] = {"frames": Tn, "audio_s": round(N_UTT * n_samp / 16000.0, 2),
+                               "front_end_ms": round(res["front_end"], 4),
+                               "front_end_frames_per_s": round(Tn / (res["front_end"] * 1e-3), 1),
+                               "pcm_to_scores_ms": round(res["pcm_to_scores"], 4),
+                               "pcm_to_scores_frames_per_s": round(Tn / (res["pcm_to_scores"] * 1e-3), 1),
+                               "xrt": round(res["pcm_to_scores"] * 1e-3 / (N_UTT * n_samp / 16000.0), 9),
+                               "data": "synthetic 16 kHz int16 PCM (noise + gated tone), en-us front-end tables"}
+        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
+        fe.close()
+    except Exception as e:
+        out["pcm_pipeline"] = {"error": str(e)}
     return out
 
 

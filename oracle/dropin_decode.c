@@ -21,6 +21,7 @@
  *
  * usage: dropin_decode MODELDIR LM DICT RAW NREP [key val ...]
  *   pseudo keys: mllr_after FILE | psgpu_mgau yes|no | psgpu_search yes|no | align_text "WORDS"
+ *                | psgpu_fe yes (decoder B: PCM -> cepstra on the device, integration/psgpu_fe_shim.c)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,6 +33,7 @@
 #include "pocketsphinx_internal.h"
 #include "bin_mdef.h"
 #include "psgpu_mgau_shim.h"
+#include "psgpu_fe_shim.h"
 #ifdef PSGPU_SEARCH_HOOKS
 #include "psgpu_search_hooks.h"
 #endif
@@ -104,7 +106,7 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
         const char *k = argv[i];
         if (k[0] == '-') ++k;
         if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search")
-            || !strcmp(k, "align_text"))
+            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe"))
             continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
@@ -158,8 +160,10 @@ read_mfc(const char *path, int ceplen, int *out_nfr)
     return mfcs;
 }
 
+static psgpu_fe_shim_t *g_fe;      /* "psgpu_fe yes": decoder B's cepstra come from the device */
+
 static void
-decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, result_t *res)
+decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, result_t *res, int dev_fe)
 {
     const char *hyp;
     ps_seg_t *seg;
@@ -167,6 +171,9 @@ decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, re
     ps_start_utt(ps);
     if (mfcs)
         ps_process_cep(ps, mfcs, nfr, FALSE, TRUE);
+    else if (dev_fe) {
+        if (psgpu_process_raw_full(ps, g_fe, pcm, n) < 0) { fprintf(stderr, "device front end failed\n"); exit(3); }
+    }
     else
         ps_process_raw(ps, pcm, n, FALSE, TRUE);
     ps_end_utt(ps);
@@ -243,6 +250,10 @@ main(int argc, char **argv)
         }
         if (!strcmp(argv[i], "psgpu_mgau")) use_mgau = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_search")) use_search = !strcmp(argv[i + 1], "yes");
+        if (!strcmp(argv[i], "psgpu_fe") && !strcmp(argv[i + 1], "yes")) {
+            g_fe = psgpu_fe_wrap(gpu->acmod->fe);
+            if (!g_fe) { fprintf(stderr, "psgpu_fe_wrap failed\n"); return 3; }
+        }
     }
     if (use_mgau && psgpu_mgau_attach(gpu) < 0) {
         fprintf(stderr, "psgpu_mgau_attach failed\n");
@@ -288,12 +299,12 @@ main(int argc, char **argv)
                 fclose(fp);
                 n = sz / 2;
             }
-            g_rec = &rc_cpu; t0 = now_s(); decode(cpu, pcm, n, mfcs, nfr, &ra[k]); t_cpu += now_s() - t0;
+            g_rec = &rc_cpu; t0 = now_s(); decode(cpu, pcm, n, mfcs, nfr, &ra[k], 0); t_cpu += now_s() - t0;
             if (mfcs) {     /* ps_process_cep normalises its input in place (CMN): reload for B */
                 ckd_free_2d(mfcs);
                 mfcs = read_mfc(path, ps_config_int(ps_get_config(cpu), "ceplen"), &nfr);
             }
-            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k]); t_gpu += now_s() - t0;
+            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k], g_fe != NULL); t_gpu += now_s() - t0;
             if (strcmp(ra[k].hyp, rb[k].hyp) || ra[k].score != rb[k].score) hyp_equal = 0;
             if (strcmp(ra[k].seg, rb[k].seg)) seg_equal = 0;
             total_frames += ra[k].n_frames;
@@ -325,19 +336,20 @@ main(int argc, char **argv)
                "\"score_cpu\": %d, \"score_gpu\": %d, \"n_seg\": %d, "
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
                "\"cache_served\": %ld, \"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
-               "\"total_frames\": %d, \"utts\": [",
+               "\"total_frames\": %d, \"device_fe\": %s, \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
                ra[n_res - 1].hyp, rb[n_res - 1].hyp, ra[n_res - 1].score, rb[n_res - 1].score,
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
                use_mgau ? psgpu_mgau_n_cache_served(gpu->acmod->mgau) : 0L,
-               use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames);
+               use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames, g_fe ? "true" : "false");
         for (u = 0; u < n_res; ++u)
             printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",
                    in_id[u % n_in], rb[u].hyp, rb[u].score);
         printf("]}\n");
     }
+    psgpu_fe_shim_free(g_fe);
     ps_free(cpu);
     ps_free(gpu);
     return ok ? 0 : 1;

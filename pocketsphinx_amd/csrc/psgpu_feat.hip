@@ -7,8 +7,7 @@
 // of the first and last frame over a window of 3, feat_1s_c_d_dd_cep2feat
 // (feat.c:579-622).  The subvector split of en-us (-svspec 0-12/13-25/26-38) is
 // the identity on this layout.  This is the caller-side row SURVEY 8f-1; the
-// MFCC front end itself (src/fe) is NOT reproduced: it takes log() of the mel
-// spectrum through libm, which a device log cannot match bit for bit.
+// MFCC front end in front of it is csrc/psgpu_fe.hip.
 //
 // One workgroup per utterance.  The mean must be summed in frame order in fp32
 // to match the reference, so lane i (< cepsize) walks its coefficient over the

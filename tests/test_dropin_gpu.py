@@ -312,3 +312,22 @@ def test_attach_fails_loudly_without_gpu():
                         os.path.join(DATA, "goforward.raw"), "1"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 3
     assert "psgpu_mgau_attach failed" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw,nrep,extra,binary", [
+    ("goforward.raw", 3, (), None),                         # noise tracker carried over three utterances
+    ("numbers.raw", 1, (), None),
+    ("librivox-0870.raw", 1, ("psgpu_search", "yes"), "full"),   # front end + GMM + Viterbi all on the device
+])
+def test_dropin_device_front_end(raw, nrep, extra, binary):
+    """psgpu_fe yes: decoder B gets its cepstra from the device front end
+    (integration/psgpu_fe_shim.c: tables read out of the decoder's own fe_t,
+    psgpu_process_raw_full = ps_process_raw(full_utt)), decoder A runs the reference's
+    fe on the host.  Same features => every frame_eval call hashes equal, same
+    hypothesis, score and segmentation."""
+    r = run(raw, nrep, "psgpu_fe", "yes", *extra, binary=BIN_FULL if binary == "full" else None)
+    assert r["device_fe"] is True
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"], r
+    assert r["hyp_gpu"], r
