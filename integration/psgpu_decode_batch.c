@@ -1,0 +1,284 @@
+/* integration/psgpu_decode_batch.c -- REFERENCE-SIDE code.
+ *
+ * The additive batch call of SURVEY 8(b).  The reference decodes on one thread
+ * and has no batched entry; its decoder objects are independent, so a batch is
+ * B utterances handed to n_workers decoders, each on its own host thread with
+ * its own psgpu scorer (model + state + HIP stream) on the same MI355X.  With
+ * PSGPU_BATCH_DEVICE_FE the cepstra of the WHOLE batch come out of one device
+ * call before the workers start.  Utterances are independent: no
+ * shared mutable state, no collective; the work queue is one atomic counter. */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <pocketsphinx.h>
+#include "pocketsphinx_internal.h"
+#include "util/ckd_alloc.h"
+#include "ptm_mgau.h"
+#include "ngram_search.h"
+#include "hmm.h"
+#include "fe/fe_noise.h"
+#include "fe/fe_internal.h"
+
+#include "psgpu.h"
+#include "psgpu_mgau_shim.h"
+#include "psgpu_fe_shim.h"
+#include "psgpu_decode_batch.h"
+#ifdef PSGPU_SEARCH_HOOKS
+#include "psgpu_search_hooks.h"
+#endif
+
+struct psgpu_batch_s {
+    int n_workers;
+    unsigned flags;
+    ps_decoder_t **ps;
+    psgpu_fe_t *fe;                /* batch front end (tables of worker 0's fe_t) */
+    int out_dim;
+    /* one call's work */
+    const int16 *const *pcm;
+    const size_t *n;
+    int B;
+    psgpu_batch_result_t *out;
+    float *cep;                    /* [total frames][out_dim] when the device front end is on */
+    int32_t *frame_off;
+    int next;                      /* work queue */
+    int failed;
+};
+
+typedef struct worker_arg_s {
+    psgpu_batch_t *b;
+    int w;
+} worker_arg_t;
+
+static char *
+dup_str(const char *s)
+{
+    size_t n = strlen(s) + 1;
+    char *d = malloc(n);
+    memcpy(d, s, n);
+    return d;
+}
+
+void
+psgpu_batch_result_clear(psgpu_batch_result_t *r)
+{
+    int i;
+    if (!r) return;
+    for (i = 0; i < r->n_seg; ++i) free(r->seg[i].word);
+    free(r->seg); free(r->hyp);
+    memset(r, 0, sizeof *r);
+}
+
+/* hmm_clear (hmm.c:181-196) resets scores, histories and the frame stamp of an HMM but
+ * not the per-state senone-sequence ids a multiplex HMM picked up along the winning arcs
+ * (hmm.c:609-707); hmm_init (hmm.c:146-168) starts them at BAD_SSID.  The lexicon tree's
+ * permanently allocated multiplex HMMs (root channels, single-phone words) therefore keep
+ * the ids of the previous utterance, which puts extra senones on the active list of the
+ * first frames (acmod_activate_hmm, acmod.c:1179-1221) and so moves the per-frame
+ * normalisation -- a decoder's scores depend on what it decoded before.  A batch call
+ * must not: put them back to what hmm_init leaves. */
+static void
+fresh_mpx_ssids(hmm_t *h)
+{
+    int i;
+    if (hmm_is_mpx(h))
+        for (i = 1; i < hmm_n_emit_state(h); ++i)
+            h->senid[i] = BAD_SSID;
+}
+
+static void
+reset_search(ps_decoder_t *ps)
+{
+    ps_search_t *search = ps->search;
+    if (search && !strcmp(ps_search_type(search), PS_SEARCH_TYPE_NGRAM)) {
+        ngram_search_t *ngs = (ngram_search_t *)search;
+        int i;
+        if (ngs->fwdtree && ngs->root_chan)
+            for (i = 0; i < ngs->n_root_chan; ++i)
+                fresh_mpx_ssids(&ngs->root_chan[i].hmm);
+        if (ngs->word_chan && ngs->single_phone_wid)       /* fwdtree and fwdflat share these (ngram_search_fwdflat.c:160-190) */
+            for (i = 0; i < ngs->n_1ph_words; ++i)
+                if (ngs->word_chan[ngs->single_phone_wid[i]])
+                    fresh_mpx_ssids(&((root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]])->hmm);
+    }
+}
+
+/* the state a decoder has after ps_start_stream() on its first utterance */
+static int
+reset_decoder(psgpu_batch_t *b, ps_decoder_t *ps)
+{
+    ps_start_stream(ps);                                   /* fe_reset_noisestats (pocketsphinx.c:1081) */
+    reset_search(ps);
+    if (b->flags & PSGPU_BATCH_CPU_ONLY) {
+        if (!strcmp(ps->acmod->mgau->vt->name, "ptm"))
+            ptm_mgau_reset_fast_hist(ps->acmod->mgau);
+        return 0;
+    }
+    return psgpu_mgau_reset(ps->acmod->mgau);
+}
+
+static int
+decode_one(psgpu_batch_t *b, ps_decoder_t *ps, int u)
+{
+    psgpu_batch_result_t *r = &b->out[u];
+    const char *hyp;
+    ps_seg_t *seg;
+    int cap = 0, rv;
+
+    memset(r, 0, sizeof *r);
+    if (reset_decoder(b, ps) < 0) return -1;
+    if (ps_start_utt(ps) < 0) return -1;
+    if (b->cep) {
+        /* rows of the batch's cepstra; ps_process_cep normalises them in place (CMN), they are ours */
+        int nfr = b->frame_off[u + 1] - b->frame_off[u], t;
+        mfcc_t **rows = ckd_calloc(nfr ? nfr : 1, sizeof *rows);
+        for (t = 0; t < nfr; ++t)
+            rows[t] = b->cep + (size_t)(b->frame_off[u] + t) * b->out_dim;
+        rv = ps_process_cep(ps, rows, nfr, FALSE, TRUE);
+        ckd_free(rows);
+    }
+    else
+        rv = ps_process_raw(ps, b->pcm[u], b->n[u], FALSE, TRUE);
+    if (rv < 0) { ps_end_utt(ps); return -1; }
+    if (ps_end_utt(ps) < 0) return -1;
+    hyp = ps_get_hyp(ps, &r->score);
+    r->hyp = dup_str(hyp ? hyp : "");
+    r->n_frames = ps_get_n_frames(ps);
+    for (seg = ps_seg_iter(ps); seg; seg = ps_seg_next(seg)) {
+        psgpu_batch_seg_t *s;
+        if (r->n_seg == cap) {
+            cap = cap ? 2 * cap : 16;
+            r->seg = realloc(r->seg, cap * sizeof *r->seg);
+        }
+        s = &r->seg[r->n_seg++];
+        s->word = dup_str(ps_seg_word(seg));
+        ps_seg_frames(seg, &s->sf, &s->ef);
+        ps_seg_prob(seg, &s->ascr, &s->lscr, &s->lback);
+    }
+    return 0;
+}
+
+static void *
+worker(void *arg)
+{
+    worker_arg_t *a = arg;
+    psgpu_batch_t *b = a->b;
+    for (;;) {
+        int u = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
+        if (u >= b->B) break;
+        if (decode_one(b, b->ps[a->w], u) < 0)
+            __atomic_store_n(&b->failed, 1, __ATOMIC_RELAXED);
+    }
+    return NULL;
+}
+
+psgpu_batch_t *
+psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
+{
+    psgpu_batch_t *b;
+    int w;
+
+    if (config == NULL || n_workers < 1) return NULL;
+#ifndef PSGPU_SEARCH_HOOKS
+    if (flags & PSGPU_BATCH_DEVICE_SEARCH) {
+        E_ERROR("PSGPU_BATCH_DEVICE_SEARCH needs the library built with the search hooks\n");
+        return NULL;
+    }
+#endif
+    b = calloc(1, sizeof *b);
+    b->n_workers = n_workers; b->flags = flags;
+    b->ps = calloc(n_workers, sizeof *b->ps);
+    for (w = 0; w < n_workers; ++w) {
+        b->ps[w] = ps_init(config);                        /* ps_init retains the config */
+        if (b->ps[w] == NULL) goto fail;
+        if (flags & PSGPU_BATCH_CPU_ONLY) continue;
+        if (psgpu_mgau_attach(b->ps[w]) < 0) {
+            E_ERROR("psgpu_mgau_attach failed: %s\n", psgpu_last_error());
+            goto fail;
+        }
+#ifdef PSGPU_SEARCH_HOOKS
+        if ((flags & PSGPU_BATCH_DEVICE_SEARCH) && psgpu_search_attach(b->ps[w]) < 0) goto fail;
+#endif
+    }
+    if ((flags & PSGPU_BATCH_DEVICE_FE) && !(flags & PSGPU_BATCH_CPU_ONLY)) {
+        /* one front end for the batch: psgpu_fe_wrap's table read-out, kept as the raw object */
+        psgpu_fe_shim_t *s = psgpu_fe_wrap(b->ps[0]->acmod->fe);
+        if (s == NULL) goto fail;
+        b->fe = psgpu_fe_shim_release(s);
+        b->out_dim = psgpu_fe_out_dim(b->fe);
+    }
+    return b;
+fail:
+    psgpu_batch_free(b);
+    return NULL;
+}
+
+void
+psgpu_batch_free(psgpu_batch_t *b)
+{
+    int w;
+    if (!b) return;
+    for (w = 0; w < b->n_workers; ++w) {
+        if (!b->ps[w]) continue;
+#ifdef PSGPU_SEARCH_HOOKS
+        if (b->flags & PSGPU_BATCH_DEVICE_SEARCH) psgpu_search_detach(b->ps[w]);
+#endif
+        ps_free(b->ps[w]);
+    }
+    psgpu_fe_free(b->fe);
+    free(b->ps);
+    free(b);
+}
+
+int
+psgpu_decode_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t n[], int B,
+                   psgpu_batch_result_t out[])
+{
+    pthread_t *tid;
+    worker_arg_t *args;
+    int w, nw, rc = 0;
+
+    if (b == NULL || B < 0 || (B > 0 && (!pcm || !n || !out))) return -1;
+    if (B == 0) return 0;
+    b->pcm = pcm; b->n = n; b->B = B; b->out = out; b->next = 0; b->failed = 0;
+    b->cep = NULL; b->frame_off = NULL;
+    if (b->fe) {
+        /* the whole batch through the device front end in one call, every utterance from
+         * reset noise statistics (noise arrays NULL) */
+        int64_t *soff = malloc(sizeof *soff * ((size_t)B + 1));
+        int64_t total = 0, frames = 0;
+        int16 *all;
+        int u;
+        soff[0] = 0;
+        for (u = 0; u < B; ++u) {
+            soff[u + 1] = soff[u] + (int64_t)n[u];
+            frames += psgpu_fe_n_frames(b->fe, (int64_t)n[u]);
+        }
+        total = soff[B];
+        all = malloc(sizeof *all * (size_t)(total ? total : 1));
+        for (u = 0; u < B; ++u) memcpy(all + soff[u], pcm[u], sizeof *all * n[u]);
+        b->cep = malloc(sizeof(float) * (size_t)(frames ? frames : 1) * b->out_dim);
+        b->frame_off = malloc(sizeof(int32_t) * ((size_t)B + 1));
+        if (psgpu_fe_process_utts(b->fe, all, soff, B, NULL, NULL, b->cep, b->frame_off) != PSGPU_OK) {
+            E_ERROR("psgpu_fe_process_utts: %s\n", psgpu_last_error());
+            rc = -1;
+        }
+        free(all); free(soff);
+    }
+    if (rc == 0) {
+        nw = b->n_workers < B ? b->n_workers : B;
+        tid = calloc(nw, sizeof *tid);
+        args = calloc(nw, sizeof *args);
+        for (w = 0; w < nw; ++w) {
+            args[w].b = b; args[w].w = w;
+            if (w == nw - 1) worker(&args[w]);             /* the caller's thread is the last worker */
+            else pthread_create(&tid[w], NULL, worker, &args[w]);
+        }
+        for (w = 0; w + 1 < nw; ++w) pthread_join(tid[w], NULL);
+        free(tid); free(args);
+        if (b->failed) rc = -1;
+    }
+    free(b->cep); free(b->frame_off);
+    b->cep = NULL; b->frame_off = NULL;
+    return rc;
+}

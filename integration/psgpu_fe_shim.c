@@ -60,6 +60,15 @@ psgpu_fe_shim_free(psgpu_fe_shim_t *s)
     ckd_free(s);
 }
 
+struct psgpu_fe_s *
+psgpu_fe_shim_release(psgpu_fe_shim_t *s)
+{
+    psgpu_fe_t *dev = s->dev;
+    ckd_free(s->noise);
+    ckd_free(s);
+    return dev;
+}
+
 void
 psgpu_fe_shim_reset_noise(psgpu_fe_shim_t *s)
 {

@@ -18,6 +18,8 @@ typedef struct psgpu_fe_shim_s psgpu_fe_shim_t;
  * device is usable or the configuration cannot be reproduced (dither). */
 psgpu_fe_shim_t *psgpu_fe_wrap(fe_t *fe);
 void psgpu_fe_shim_free(psgpu_fe_shim_t *s);
+/* hand over the underlying device object (psgpu.h) and drop the wrapper */
+struct psgpu_fe_s *psgpu_fe_shim_release(psgpu_fe_shim_t *s);
 
 /* = fe_reset_noisestats(fe->noise_stats) (what ps_start_stream does, pocketsphinx.c:1081) */
 void psgpu_fe_shim_reset_noise(psgpu_fe_shim_t *s);

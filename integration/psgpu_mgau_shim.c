@@ -496,6 +496,25 @@ psgpu_mgau_attach(ps_decoder_t *ps)
     return 0;
 }
 
+/* = ptm_mgau_reset_fast_hist (ptm_mgau.c:777-802) for whichever scorer is wrapped:
+ * the top-N history a freshly initialised scorer has (the multi-stream scorer is stateless) */
+int
+psgpu_mgau_reset(ps_mgau_t *ps)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    if (ps == NULL)
+        return -1;
+    if (ps->vt == &psgpu_mgau_funcs) {
+        g->la_c0 = g->la_cn = 0; g->la_expect = -1;
+        return psgpu_ptm_state_reset(g->state) == PSGPU_OK ? 0 : -1;
+    }
+    if (ps->vt == &psgpu_semi_funcs)
+        return psgpu_semi_state_reset(g->sstate) == PSGPU_OK ? 0 : -1;
+    if (ps->vt == &psgpu_ms_funcs)
+        return 0;
+    return -1;
+}
+
 long
 psgpu_mgau_n_cache_served(ps_mgau_t *ps)
 {

@@ -20,6 +20,10 @@ ps_mgau_t *psgpu_mgau_wrap(ps_mgau_t *cpu_mgau);
  * failure (the decoder is left untouched and keeps its CPU scorer). */
 int psgpu_mgau_attach(ps_decoder_t *ps);
 
+/* Back to the top-N history of a freshly initialised scorer (ptm_mgau_reset_fast_hist,
+ * ptm_mgau.c:777-802).  0, or -1 if `mgau` is not a psgpu scorer. */
+int psgpu_mgau_reset(ps_mgau_t *mgau);
+
 /* number of frame_eval calls served by the device (-1 if not a psgpu scorer) */
 int32 psgpu_mgau_n_calls(ps_mgau_t *mgau);
 /* of which answered from the look-ahead cache (one batched pass per utterance pass) */

@@ -331,3 +331,67 @@ def test_dropin_device_front_end(raw, nrep, extra, binary):
     assert r["ok"] and r["rc"] == 0, r
     assert r["mismatching_calls"] == 0 and r["hyp_equal"] and r["seg_equal"], r
     assert r["hyp_gpu"], r
+
+
+def _batch_api(workers, flags, files, *extra, full=False, lm="turtle.lm.bin", dic="turtle.dic"):
+    binary = os.path.join(REF, "batch_api_check_full" if full else "batch_api_check")
+    if not os.path.exists(binary):
+        pytest.fail("oracle/_ref/batch_api_check is missing (make -C oracle where /root/reference is present)")
+    argv = [binary, MODEL, os.path.join(DATA, lm), os.path.join(DATA, dic), str(workers), str(flags)] + \
+           [os.path.join(DATA, f) for f in files]
+    if extra:
+        argv += ["--"] + [str(e) for e in extra]
+    p = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    assert p.stdout.strip(), "no output (rc %d): %s" % (p.returncode, p.stderr[-2000:])
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    r["rc"] = p.returncode
+    return r
+
+
+FILES = ["goforward.raw", "numbers.raw", "something.raw", "librivox-0870.raw", "goforward.raw", "numbers.raw"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers,flags,full,extra", [
+    (1, 0, False, ()),        # GMM on the device, one worker
+    (3, 0, False, ()),        # more utterances than workers: work queue, per-utterance reset
+    (3, 1, False, ()),        # + cepstra of the whole batch from one device front-end call
+    (4, 3, True, ()),         # + hmm_vit_eval loops on the device (hooked library)
+    (3, 1, False, ("fwdflat", "no", "bestpath", "no")),   # pass 1 only: its scores are not masked by later passes
+    (2, 1, False, ("fwdtree", "no")),                     # pass 2 only
+])
+def test_decode_batch_api(workers, flags, full, extra):
+    """psgpu_decode_batch (the additive batch call): every utterance's
+    hypothesis, path score, frame count and full segmentation equal what a fresh
+    unmodified CPU decoder gives for it -- for the batch in order, reversed, and one
+    utterance at a time (B = 1 is the drop-in path)."""
+    r = _batch_api(workers, flags, FILES, *extra, full=full)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["B"] == len(FILES) and r["mismatch_batch"] == r["mismatch_reversed"] == r["mismatch_single"] == 0
+    assert r["hyps"][0] == "go forward ten meters"
+
+
+@pytest.mark.parametrize("extra", [(), ("fwdflat", "no", "bestpath", "no")])
+def test_decode_batch_api_cpu_only_is_order_independent(extra):
+    """PSGPU_BATCH_CPU_ONLY (flag 4, no device involved): the per-utterance reset of the
+    batch call makes the REFERENCE's own decoders order-independent -- without it a
+    decoder's path scores depend on what it decoded before (multiplex HMMs of the lexicon
+    tree keep their senone-sequence ids across utterances; see psgpu_decode_batch.c)."""
+    if not os.path.exists(os.path.join(REF, "batch_api_check")):
+        pytest.skip("oracle/_ref not built")
+    r = _batch_api(2, 4, ["goforward.raw", "numbers.raw", "goforward.raw"], *extra)
+    assert r["ok"] and r["rc"] == 0, r
+
+
+def test_decode_batch_api_refuses_without_device():
+    """No silent CPU fallback: without a usable device psgpu_batch_init fails (exit code 3)
+    unless PSGPU_BATCH_CPU_ONLY is asked for."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    binary = os.path.join(REF, "batch_api_check")
+    if not os.path.exists(binary):
+        pytest.skip("oracle/_ref not built")
+    p = subprocess.run([binary, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"), "1", "0",
+                        os.path.join(DATA, "goforward.raw")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stdout, p.stderr[-500:])
