@@ -180,7 +180,7 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         out["ms_scorer"] = {"error": str(e)}
     # (4) a fully continuous model of en-us size (BASELINE configs[3]: the only bundled continuous model,
     #     an4_ci_cont, has 102 one-density codebooks): 5126 senones x 16 densities x 39 dims, top-4,
-    #     random parameters with the value ranges of real precomputed tables, 32 utterances x 50 frames
+    #     random parameters with the value ranges of real precomputed tables, 64 utterances x 250 frames
     try:
         rng = np.random.default_rng(9)
         n_sen, n_den, LL = 5126, 16, 39
@@ -195,7 +195,7 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
                   logadd_size=np.array([int(t["logadd8"].size)]), logadd_width=np.array([1]),
                   log_zero=np.array([-524288]))
         ms = P.MsMgau(mt)
-        n_fr = 32 * 50
+        n_fr = 64 * 250                                      # BASELINE configs[3]: a batch of 64 utterances
         f = torch.from_numpy(rng.standard_normal((n_fr, LL)).astype(np.float32)).to(dev)
         nl = n_fr * ms.n_mgau * ms.n_feat * ms.topn
         ids = torch.empty(nl, dtype=torch.int32, device=dev)
@@ -203,8 +203,8 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         scr = torch.empty((n_fr, ms.n_sen), dtype=torch.int16, device=dev)
 
         def cstep():
-            capi.check(L.psgpu_ms_score_batch_dev(ms.h, C.c_void_p(f.data_ptr()), n_fr, C.c_void_p(ids.data_ptr()),
-                                                  C.c_void_p(dist.data_ptr()), C.c_void_p(scr.data_ptr()), sp), "ms")
+            capi.check(L.psgpu_ms_score_batch_dev(ms.h, C.c_void_p(f.data_ptr()), n_fr, None, None,
+                                                  C.c_void_p(scr.data_ptr()), sp), "ms")
         cstep()
         capi.check(L.psgpu_ms_batch_check(ms.h, sp), "ms check")
         e0, e1 = C.c_void_p(), C.c_void_p()

@@ -346,7 +346,11 @@ int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
 /* Batched compallsen scoring of total_frames independent frames (frames of any
  * number of utterances back to back: the scorer has no time dependence).
  *  list_id_dev / list_dist_dev  [n_mgau][n_feat][total_frames][topn] int32 / fp32:
- *                               the top-N lists, codebook-major (output and workspace)
+ *                               the top-N lists, codebook-major (output and workspace).
+ *                               May both be NULL for a fully continuous model (one
+ *                               stream, senone i owns codebook i, topn < n_density):
+ *                               its fused kernel goes from the densities to the senone
+ *                               score without the lists; PSGPU_EINVAL for other shapes
  *  senscr_dev                   [total_frames][n_sen] int16, or NULL to stop after
  *                               the top-N kernel
  * psgpu_ms_batch_check() synchronises `stream` and returns PSGPU_ESTATE if some

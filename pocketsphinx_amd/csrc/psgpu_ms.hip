@@ -58,9 +58,19 @@ struct psgpu_ms_model_s {
     uint16_t *h_list, *d_list;           // mapped: listed senone ids
     int16_t *h_out, *d_out;              // mapped: scores of listed senones (list order) / all
     int32_t *d_flag;
+    int32_t *d_best; int32_t cap_best;   // per-frame minima of the fused continuous path
+    bool cont;                           // one stream, senone i owns codebook i, topn < n_density
     hipStream_t stream;
     uint32_t seq;
 };
+
+// Wave-uniform model parameters read through the constant address space: the backend
+// then issues scalar loads (SGPR operands, no VGPRs, no vector-memory traffic) even when
+// the kernel has stores in flight that it cannot prove disjoint from the tables.
+typedef const float __attribute__((address_space(4))) kfloat;
+typedef const uint8_t __attribute__((address_space(4))) kbyte;
+__device__ __forceinline__ kfloat *as_k(const float *p) { return (kfloat *)(uintptr_t)p; }
+__device__ __forceinline__ kbyte *as_k(const uint8_t *p) { return (kbyte *)(uintptr_t)p; }
 
 // order-preserving map float -> uint32 (larger float = larger key)
 __device__ __forceinline__ uint32_t fkey(float f)
@@ -340,14 +350,14 @@ void ms_lane_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
 #pragma unroll
         for (int j = 0; j < LEN; ++j) x[j] = xp[j];
     }
-    const float *mean = p.mean + p.cboff[c], *var = p.var + p.cboff[c];
-    const float *det = p.det + (size_t)c * p.n_density;
+    kfloat *mean = as_k(p.mean + p.cboff[c]), *var = as_k(p.var + p.cboff[c]);
+    kfloat *det = as_k(p.det + (size_t)c * p.n_density);
     int32_t *oid = list_id + ((size_t)c * n_frames + t) * N;
     float *odist = list_dist + ((size_t)c * n_frames + t) * N;
 
     if (N >= p.n_density) {                                    // compute_dist_all: index order, no selection
         for (int dn = 0; dn < p.n_density; ++dn) {
-            const float *m = mean + dn * LEN, *v = var + dn * LEN;
+            kfloat *m = mean + dn * LEN, *v = var + dn * LEN;
             float acc = det[dn];
 #pragma unroll
             for (int j = 0; j < LEN; ++j) {
@@ -362,7 +372,7 @@ void ms_lane_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
 #pragma unroll
     for (int r = 0; r < N; ++r) key[r] = 0ull;
     for (int dn = 0; dn < p.n_density; ++dn) {
-        const float *m = mean + dn * LEN, *v = var + dn * LEN;
+        kfloat *m = mean + dn * LEN, *v = var + dn * LEN;
         float acc = det[dn];
 #pragma unroll
         for (int j = 0; j < LEN; ++j) {
@@ -423,6 +433,172 @@ static bool launch_lane(const MsDev &d, const float *feats, int32_t T, int32_t *
     case 6: return launch_lane_n<6>(d, feats, T, ids, dist, flag, st);
     case 7: return launch_lane_n<7>(d, feats, T, ids, dist, flag, st);
     default: return launch_lane_n<8>(d, feats, T, ids, dist, flag, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused kernel for fully continuous models (batched entry): every senone owns
+// its codebook (".cont." mapping, ms_senone.c:305-315) and there is one stream.
+// Frames on lanes as in ms_lane_kernel, but the wave goes straight on from the
+// N best densities of (senone c, frame t) to the senone's score -- the list
+// never round-trips through HBM (32 B per senone-frame against 2 B of output;
+// the list buffers are still filled when the caller passes them).  A workgroup
+// = 64 frames x kContG consecutive senones (4 waves x kContG/4 senones each,
+// the lane's feature vector loaded once); scores are transposed through LDS so
+// that a frame's kContG scores leave as one contiguous segment; the per-frame
+// minimum goes to best[t] with one atomicMin per (workgroup, frame), and
+// ms_cont_norm_kernel applies ms_cont_mgau_frame_eval's second clamp
+// (ms_mgau.c:229-234).
+// ---------------------------------------------------------------------------
+constexpr int kContG = 64;
+
+template <int N, int LEN>
+__global__ __launch_bounds__(256)
+void ms_cont_kernel(MsDev p, const float *__restrict__ feats, int32_t n_frames,
+                    int32_t *__restrict__ list_id, float *__restrict__ list_dist,
+                    int16_t *__restrict__ out, int64_t out_stride, int32_t *__restrict__ best,
+                    int32_t *__restrict__ flag)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];      // [la entries] int32
+    __shared__ int16_t s_tile[64][kContG + 2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n_tiles = (n_frames + 63) >> 6;
+    const int tile = blockIdx.x % n_tiles, grp = blockIdx.x / n_tiles;   // consecutive workgroups: same senones
+    const int g0 = grp * kContG;
+    const int t = tile * 64 + lane;
+    const bool valid = t < n_frames;
+    const int tl = valid ? t : n_frames - 1;
+    const bool la_lds = p.logadd_size <= kMsLaLds;
+    if (la_lds)
+        for (int i = threadIdx.x; i < p.logadd_size; i += 256) s_dyn[i] = p.logadd[i];
+    __syncthreads();
+    const int32_t *la = la_lds ? s_dyn : p.logadd;
+    float x[LEN];
+    {
+        const float *xp = feats + (size_t)tl * p.veclen;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) x[j] = xp[j];
+    }
+    for (int k = 0; k < kContG / 4; ++k) {
+        const int c = __builtin_amdgcn_readfirstlane(g0 + w * (kContG / 4) + k);
+        if (c >= p.n_sen) break;
+        kfloat *mean = as_k(p.mean + p.cboff[c]), *var = as_k(p.var + p.cboff[c]);
+        kfloat *det = as_k(p.det + (size_t)c * p.n_density);
+        unsigned long long key[N];
+#pragma unroll
+        for (int r = 0; r < N; ++r) key[r] = 0ull;
+        for (int dn = 0; dn < p.n_density; ++dn) {
+            kfloat *m = mean + dn * LEN, *v = var + dn * LEN;
+            float acc = det[dn];
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const float diff = __fsub_rn(x[j], m[j]);
+                acc = __fsub_rn(acc, __fmul_rn(__fmul_rn(diff, diff), v[j]));
+            }
+            unsigned long long kk = (acc >= (float)kMaxNegInt32)
+                ? (((unsigned long long)fkey(acc) << 32) | (uint32_t)dn) : 0ull;
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                const unsigned long long hi = umax64(key[r], kk);
+                kk = umin64(key[r], kk);
+                key[r] = hi;
+            }
+        }
+        // senone_eval (ms_senone.c:357-407) on the list, best first
+        const uint8_t *pdf = p.pdf + (size_t)c * p.n_density;
+        int32_t fscr = 0;
+        bool unfilled = false;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            float dv; int32_t id;
+            if (key[r] != 0ull) {
+                const uint32_t fk = (uint32_t)(key[r] >> 32);
+                const uint32_t u = (fk & 0x80000000u) ? (fk & 0x7fffffffu) : ~fk;   // inverse of fkey
+                dv = __builtin_bit_cast(float, u);
+                id = (int32_t)(key[r] & 0xffffffffu);
+            }
+            else { dv = (float)kMaxNegInt32; id = 0; unfilled = true; }
+            if (list_id && valid) {
+                const size_t li = ((size_t)c * n_frames + t) * N + r;
+                list_id[li] = id; list_dist[li] = dv;
+            }
+            const int32_t fden = (dv < (float)kMaxNegInt32)
+                ? (kMaxNegInt32 >> kSenscrShift)
+                : (((int32_t)dv + ((1 << kSenscrShift) - 1)) >> kSenscrShift);
+            const int32_t fw = fden - (int32_t)pdf[id];
+            if (r == 0) fscr = fw;
+            else if (fscr <= p.log_zero) fscr = fw;                 // logmath_add (util/logmath.c:401-446)
+            else if (fw > p.log_zero) {
+                const int32_t hi = max(fscr, fw);
+                const int32_t dd = hi - min(fscr, fw);
+                fscr = (dd < 0 || dd >= p.logadd_size) ? hi : hi + la[dd];
+            }
+        }
+        if (unfilled && valid) atomicOr(flag, 1);
+        int32_t scr = -fscr;
+        scr /= p.aw;
+        scr = max(-32768, min(32767, scr));
+        s_tile[lane][c - g0] = (int16_t)scr;
+    }
+    __syncthreads();
+    const int ng = min(kContG, p.n_sen - g0);
+    if (threadIdx.x < 64 && valid) {                               // per-frame minimum of this group
+        int32_t mn = 0x7fffffff;
+        for (int i = 0; i < ng; ++i) mn = min(mn, (int32_t)s_tile[lane][(i + lane) % ng]);
+        atomicMin(&best[t], mn);
+    }
+    // rows out: 4 threads per frame, 16 senones each (32 contiguous bytes per thread)
+    {
+        const int fr = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const int tt = tile * 64 + fr;
+        if (tt < n_frames) {
+            int16_t *o = out + (size_t)tt * out_stride + g0;
+            for (int i = part * (kContG / 4); i < (part + 1) * (kContG / 4) && i < ng; ++i) o[i] = s_tile[fr][i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void ms_cont_norm_kernel(int16_t *__restrict__ out, int64_t out_stride, int32_t n_sen, const int32_t *__restrict__ best)
+{
+    const int t = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_sen) return;
+    int16_t *o = out + (size_t)t * out_stride;
+    int32_t bs = (int32_t)o[i] - best[t];
+    bs = max(-32768, min(32767, bs));
+    o[i] = (int16_t)bs;
+}
+
+template <int N>
+static bool launch_cont_n(const MsDev &d, const float *feats, int32_t T, int32_t *ids, float *dist,
+                          int16_t *out, int64_t out_stride, int32_t *best, int32_t *flag, hipStream_t st)
+{
+    const int n_tiles = (T + 63) / 64, n_grp = (d.n_sen + kContG - 1) / kContG;
+    const size_t smem = (size_t)(d.logadd_size <= kMsLaLds ? d.logadd_size : 0) * 4;
+    const dim3 grid((unsigned)(n_tiles * (long long)n_grp));
+    if (d.featlen[0] == 13)
+        hipLaunchKernelGGL((ms_cont_kernel<N, 13>), grid, dim3(256), smem, st, d, feats, T, ids, dist, out, out_stride, best, flag);
+    else if (d.featlen[0] == 39)
+        hipLaunchKernelGGL((ms_cont_kernel<N, 39>), grid, dim3(256), smem, st, d, feats, T, ids, dist, out, out_stride, best, flag);
+    else
+        return false;
+    hipLaunchKernelGGL(ms_cont_norm_kernel, dim3((d.n_sen + 255) / 256, T), dim3(256), 0, st, out, out_stride, d.n_sen, best);
+    return true;
+}
+
+static bool launch_cont(const MsDev &d, const float *feats, int32_t T, int32_t *ids, float *dist,
+                        int16_t *out, int64_t out_stride, int32_t *best, int32_t *flag, hipStream_t st)
+{
+    switch (d.topn) {
+    case 1: return launch_cont_n<1>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 2: return launch_cont_n<2>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 3: return launch_cont_n<3>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 4: return launch_cont_n<4>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 5: return launch_cont_n<5>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 6: return launch_cont_n<6>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 7: return launch_cont_n<7>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    default: return launch_cont_n<8>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
     }
 }
 
@@ -489,6 +665,8 @@ int psgpu_ms_model_create(psgpu_ms_model_t **out, int32_t n_mgau, int32_t n_feat
     }
     m->h_sen2mgau = (int32_t *)malloc(sizeof(int32_t) * n_sen);
     memcpy(m->h_sen2mgau, map.data(), sizeof(int32_t) * n_sen);
+    m->cont = n_feat == 1 && n_mgau == n_sen && topn < n_density;
+    for (int i = 0; i < n_sen && m->cont; ++i) m->cont = map[i] == i;
     e = hipMalloc((void **)&m->list_id, nlist * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(m->list_id, 0, nlist * sizeof(int32_t));     // ckd_calloc_3d (ms_mgau.c:150)
     if (e == hipSuccess) e = hipMalloc((void **)&m->list_dist, nlist * sizeof(float));
@@ -521,7 +699,7 @@ void psgpu_ms_model_free(psgpu_ms_model_t *m)
     if (m->stream) hipStreamDestroy(m->stream);
     hipFree(m->mean); hipFree(m->var); hipFree(m->det); hipFree(m->pdf); hipFree(m->pdf_t);
     hipFree(m->sen2mgau); hipFree(m->logadd); hipFree(m->cboff);
-    hipFree(m->list_id); hipFree(m->list_dist); hipFree(m->d_flag);
+    hipFree(m->list_id); hipFree(m->list_dist); hipFree(m->d_flag); hipFree(m->d_best);
     if (m->h_active) hipHostFree(m->h_active);
     if (m->h_feat) hipHostFree(m->h_feat);
     if (m->h_list) hipHostFree(m->h_list);
@@ -589,12 +767,27 @@ int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_
                              int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
                              void *stream)
 {
-    PSGPU_REQUIRE(m && feats_dev && list_id_dev && list_dist_dev, "psgpu_ms_score_batch_dev: NULL argument");
+    PSGPU_REQUIRE(m && feats_dev, "psgpu_ms_score_batch_dev: NULL argument");
+    PSGPU_REQUIRE((list_id_dev == nullptr) == (list_dist_dev == nullptr), "list buffers: both or neither");
     PSGPU_REQUIRE(total_frames >= 0, "negative frame count");
     if (total_frames == 0) return PSGPU_OK;
     const MsDev &d = m->d;
     hipStream_t st = (hipStream_t)stream;
     PSGPU_HIP(hipMemsetAsync(m->d_flag, 0, sizeof(int32_t), st));
+    static const int no_cont = [] { const char *e = getenv("PSGPU_MS_NO_FUSED"); return e ? atoi(e) : 0; }();
+    if (m->cont && senscr_dev && !no_cont && (d.featlen[0] == 13 || d.featlen[0] == 39)) {
+        if (total_frames > m->cap_best) {
+            PSGPU_HIP(hipFree(m->d_best)); m->d_best = nullptr; m->cap_best = 0;
+            PSGPU_HIP(hipMalloc((void **)&m->d_best, sizeof(int32_t) * (size_t)total_frames));
+            m->cap_best = total_frames;
+        }
+        PSGPU_HIP(hipMemsetAsync(m->d_best, 0x7f, sizeof(int32_t) * (size_t)total_frames, st));
+        launch_cont(d, feats_dev, total_frames, list_id_dev, list_dist_dev, senscr_dev, d.n_sen, m->d_best, m->d_flag, st);
+        PSGPU_HIP(hipGetLastError());
+        return PSGPU_OK;
+    }
+    PSGPU_REQUIRE(list_id_dev != nullptr, "this model shape needs the list buffers (only fully continuous models "
+                  "are scored without them)");
     static const int no_lane = [] { const char *e = getenv("PSGPU_NO_LANE_KERNEL"); return e ? atoi(e) : 0; }();
     if (no_lane || !launch_lane(d, feats_dev, total_frames, list_id_dev, list_dist_dev, m->d_flag, st))
         launch_topn(d, feats_dev, total_frames, nullptr, list_id_dev, list_dist_dev, 1, m->d_flag, st);

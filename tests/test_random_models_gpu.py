@@ -197,23 +197,60 @@ def test_ptm_random_model(seed):
     st.close(); m.close()
 
 
-def test_ms_continuous_model_batch():
+@pytest.mark.parametrize("L,n_den,topn,aw,T", [(39, 8, 4, 1, 150), (13, 16, 2, 3, 70), (39, 4, 3, 1, 64)])
+def test_ms_continuous_model_batch(L, n_den, topn, aw, T):
     """A fully continuous model (.cont. mapping: every senone its own codebook,
-    ms_senone.c:305-315): 700 senones x 8 densities x 39 dims, top-4 -- the
-    frames-on-lanes kernel with LEN 39 and the [sen][feat][cw] weight layout."""
+    ms_senone.c:305-315): 700 senones, one stream -- the fused frames-on-lanes kernel
+    (densities -> top-N -> senone score without the lists in between), with the list
+    buffers (host wrapper) and without them (device entry, NULL lists); senone and
+    frame counts that are not multiples of the 64 x 64 tiles."""
+    import ctypes as C
+    import torch
     import pocketsphinx_amd as P
-    rng = np.random.default_rng(42)
-    n_sen, n_den, L = 700, 8, 39
+    from pocketsphinx_amd import capi
+    rng = np.random.default_rng(42 + L + topn)
+    n_sen = 700
     featlen = np.array([L], np.int32)
     mean, var, det = _gauss(rng, n_sen, 1, n_den, featlen)
     t = dict(n_mgau=np.array([n_sen]), n_feat=np.array([1]), n_density=np.array([n_den]),
-             n_sen=np.array([n_sen]), max_topn=np.array([4]), aw=np.array([1]), featlen=featlen,
+             n_sen=np.array([n_sen]), max_topn=np.array([topn]), aw=np.array([aw]), featlen=featlen,
              mean=mean, var=var, det=det, pdf=rng.integers(0, 256, (n_sen, 1, n_den)).astype(np.uint8),
              sen2mgau=np.arange(n_sen, dtype=np.uint32), logadd=_logadd8(), logadd_size=np.array([256]),
              logadd_width=np.array([1]), log_zero=np.array([-524288]))
     g, o = P.MsMgau(t), pso.OracleMs(t)
-    feats = rng.standard_normal((150, L)).astype(np.float32)
+    feats = rng.standard_normal((T, L)).astype(np.float32)
     got = g.score_frames(feats)
     for i in range(feats.shape[0]):
         assert np.array_equal(got[i], o.frame_eval(feats[i], compallsen=True)), "frame %d" % i
+    dev = torch.device("cuda", 0)
+    f = torch.from_numpy(feats).to(dev)
+    scr = torch.zeros((T, n_sen), dtype=torch.int16, device=dev)
+    L_ = capi.lib()
+    capi.check(L_.psgpu_ms_score_batch_dev(g.h, C.c_void_p(f.data_ptr()), T, None, None, C.c_void_p(scr.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "no lists")
+    capi.check(L_.psgpu_ms_batch_check(g.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "check")
+    assert np.array_equal(scr.cpu().numpy(), got)
+    g.close()
+
+
+def test_ms_shared_codebooks_need_lists():
+    """The list-less call is only for fully continuous models; any other shape says so."""
+    import ctypes as C
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    rng = np.random.default_rng(5)
+    featlen = np.array([13], np.int32)
+    mean, var, det = _gauss(rng, 4, 1, 8, featlen)
+    t = dict(n_mgau=np.array([4]), n_feat=np.array([1]), n_density=np.array([8]), n_sen=np.array([40]),
+             max_topn=np.array([4]), aw=np.array([1]), featlen=featlen, mean=mean, var=var, det=det,
+             pdf=rng.integers(0, 256, (40, 1, 8)).astype(np.uint8),
+             sen2mgau=(np.arange(40) % 4).astype(np.uint32), logadd=_logadd8(), logadd_size=np.array([256]),
+             logadd_width=np.array([1]), log_zero=np.array([-524288]))
+    g = P.MsMgau(t)
+    dev = torch.device("cuda", 0)
+    f = torch.zeros((8, 13), dtype=torch.float32, device=dev)
+    scr = torch.zeros((8, 40), dtype=torch.int16, device=dev)
+    rc = capi.lib().psgpu_ms_score_batch_dev(g.h, C.c_void_p(f.data_ptr()), 8, None, None, C.c_void_p(scr.data_ptr()), None)
+    assert rc == -2
     g.close()
