@@ -343,6 +343,20 @@ int32_t psgpu_ms_veclen(const psgpu_ms_model_t *m);
 int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
                         const uint8_t *senone_active, int32_t n_senone_active,
                         const float *feat, int32_t compallsen);
+/* Look-ahead (optional): announce the feature vectors of frames frame0 .. frame0+n_frames-1
+ * ([n_frames][veclen]); they are scored in one batched pass, and psgpu_ms_frame_eval_at()
+ * answers every later call for one of them -- any pass, any active list, as long as the
+ * vector handed in is the announced one -- from the host copy, with the reference's
+ * active-list normalisation (ms_mgau.c:219-234) and its list-id side effect
+ * (ms_gauden.c:438-440) preserved.  Results are identical with or without it.  n_frames 0
+ * drops the cache.  psgpu_ms_frame_eval_at with a frame outside the cache (or -1) is
+ * psgpu_ms_frame_eval. */
+int psgpu_ms_lookahead(psgpu_ms_model_t *m, const float *feats, int32_t frame0, int32_t n_frames);
+int psgpu_ms_lookahead_covers(const psgpu_ms_model_t *m, const float *feat, int32_t frame);
+int psgpu_ms_lookahead_stats(const psgpu_ms_model_t *m, int64_t *served, int64_t *batches);
+int psgpu_ms_frame_eval_at(psgpu_ms_model_t *m, int16_t *senscr, const uint8_t *senone_active,
+                           int32_t n_senone_active, const float *feat, int32_t frame,
+                           int32_t compallsen);
 /* Batched compallsen scoring of total_frames independent frames (frames of any
  * number of utterances back to back: the scorer has no time dependence).
  *  list_id_dev / list_dist_dev  [n_mgau][n_feat][total_frames][topn] int32 / fp32:

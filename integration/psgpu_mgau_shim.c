@@ -408,12 +408,30 @@ ms_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
     gauden_t *gd = g->cpu_ms->g;
     int f, o = 0, rc;
 
-    (void)frame;                                     /* ms_mgau.c:207 */
     for (f = 0; f < g->n_feat; ++f) {
         memcpy(g->vec + o, feat[f], sizeof(float) * gd->featlen[f]);
         o += gd->featlen[f];
     }
-    rc = psgpu_ms_frame_eval(g->mmodel, senscr, senone_active, n_senone_active, g->vec, compallsen);
+    /* The scorer itself ignores `frame` (ms_mgau.c:207); here it keys the look-ahead cache.
+     * Full-utterance decoding has every frame's features in acmod->feat_buf before the search
+     * starts: announce what lies ahead once, every pass is then answered from that one batch. */
+    if (g->acmod && g->acmod->feat_buf && !psgpu_ms_lookahead_covers(g->mmodel, g->vec, frame)
+        && frame >= g->acmod->output_frame) {
+        acmod_t *a = g->acmod;
+        int avail = a->output_frame + a->n_feat_frame - frame, i;
+        if (avail >= 8) {
+            if (avail > g->la_cap) {
+                g->la_buf = ckd_realloc(g->la_buf, sizeof(float) * (size_t)avail * g->veclen);
+                g->la_cap = avail;
+            }
+            for (i = 0; i < avail; ++i) {
+                int idx = (a->feat_outidx + (frame - a->output_frame) + i) % a->n_feat_alloc;
+                memcpy(g->la_buf + (size_t)i * g->veclen, a->feat_buf[idx][0], sizeof(float) * g->veclen);
+            }
+            psgpu_ms_lookahead(g->mmodel, g->la_buf, frame, avail);
+        }
+    }
+    rc = psgpu_ms_frame_eval_at(g->mmodel, senscr, senone_active, n_senone_active, g->vec, frame, compallsen);
     ++g->n_calls;
     if (rc != PSGPU_OK) {
         E_ERROR("psgpu_ms_frame_eval failed (%d): %s\n", rc, psgpu_last_error());
@@ -439,6 +457,7 @@ ms_free(ps_mgau_t *ps)
     if (g->mmodel) psgpu_ms_model_free(g->mmodel);
     if (g->cpu_ms) ps_mgau_free(ps_mgau_base(g->cpu_ms));
     ckd_free(g->vec);
+    ckd_free(g->la_buf);
     ckd_free(g);
 }
 
@@ -490,7 +509,7 @@ psgpu_mgau_attach(ps_decoder_t *ps)
     gpu = psgpu_mgau_wrap(ps->acmod->mgau);
     if (gpu == NULL)
         return -1;
-    if (gpu->vt == &psgpu_mgau_funcs)
+    if (gpu->vt == &psgpu_mgau_funcs || gpu->vt == &psgpu_ms_funcs)
         ((psgpu_mgau_t *)gpu)->acmod = ps->acmod;
     ps->acmod->mgau = gpu;        /* freed through vt->free by acmod_free (acmod.c:315) */
     return 0;
@@ -519,6 +538,10 @@ long
 psgpu_mgau_n_cache_served(ps_mgau_t *ps)
 {
     int64_t a = 0, b = 0;
+    if (ps != NULL && ps->vt == &psgpu_ms_funcs) {
+        psgpu_ms_lookahead_stats(((psgpu_mgau_t *)ps)->mmodel, &a, &b);
+        return (long)a;
+    }
     if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
         return 0;
     psgpu_ptm_state_lookahead_stats(((psgpu_mgau_t *)ps)->state, &a, &b);

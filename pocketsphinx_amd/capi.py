@@ -23,7 +23,8 @@ SYMBOLS = [
     "psgpu_semi_state_free", "psgpu_semi_state_reset", "psgpu_semi_frame_eval",
     "psgpu_semi_state_get_topn", "psgpu_semi_state_set_topn",
     "psgpu_ms_model_create", "psgpu_ms_model_free", "psgpu_ms_n_sen", "psgpu_ms_veclen",
-    "psgpu_ms_frame_eval", "psgpu_ms_score_batch_dev", "psgpu_ms_batch_check", "psgpu_ms_score_batch",
+    "psgpu_ms_frame_eval", "psgpu_ms_lookahead", "psgpu_ms_lookahead_covers", "psgpu_ms_lookahead_stats",
+    "psgpu_ms_frame_eval_at", "psgpu_ms_score_batch_dev", "psgpu_ms_batch_check", "psgpu_ms_score_batch",
     "psgpu_feat_1s_c_d_dd_dev", "psgpu_feat_1s_c_d_dd",
     "psgpu_fe_create", "psgpu_fe_free", "psgpu_fe_out_dim", "psgpu_fe_n_frames",
     "psgpu_fe_process_utts_dev", "psgpu_fe_process_utts",

@@ -60,6 +60,16 @@ struct psgpu_ms_model_s {
     int32_t *d_flag;
     int32_t *d_best; int32_t cap_best;   // per-frame minima of the fused continuous path
     bool cont;                           // one stream, senone i owns codebook i, topn < n_density
+    // look-ahead (psgpu_ms_lookahead): raw rows of announced frames on the host, their lists on the device
+    struct {
+        int valid, frame0, n, cap;
+        bool dirty;                      // calls were served: the per-call lists lag behind
+        float *h_feats, *d_feats;        // [cap][veclen]
+        int16_t *h_rows, *d_rows;        // [cap][n_sen] raw (first clamp only); h_rows pinned
+        int32_t *d_ids; float *d_dist;   // [n_mgau][n_feat][n][topn]
+        int32_t *h_last, *d_last;        // [n_mgau]: frame whose list a served call left in codebook c, or -1
+        int64_t served, batches;
+    } la;
     hipStream_t stream;
     uint32_t seq;
 };
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(kMsSenThreads)
 void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *__restrict__ list,
                       const int32_t *__restrict__ list_id, const float *__restrict__ list_dist,
                       int32_t n_frames, int16_t *__restrict__ out, int64_t out_stride,
-                      uint32_t *__restrict__ done_word, uint32_t seq)
+                      uint32_t *__restrict__ done_word, uint32_t seq, int32_t raw)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t s_dyn[];      // [la entries] int32 | [n] int16
     __shared__ int32_t s_best;
@@ -260,7 +270,7 @@ void ms_senone_kernel(MsDev p, int32_t compall, int32_t n_list, const uint16_t *
     for (int off = 32; off > 0; off >>= 1) mybest = min(mybest, __shfl_xor(mybest, off));
     if ((tid & 63) == 0) atomicMin(&s_best, mybest);
     __syncthreads();
-    const int32_t best = s_best;
+    const int32_t best = raw ? 0 : s_best;               // raw: stop after senone_eval's own clamp (look-ahead rows)
     int16_t *o = out + (size_t)frame * out_stride;
     for (int i = tid; i < n; i += kMsSenThreads) {
         int32_t bs = (int32_t)s_scr[i] - best;
@@ -302,13 +312,14 @@ static void launch_topn(const MsDev &d, const float *feats, int32_t T, const uin
 
 static void launch_senone(const MsDev &d, int32_t T, int32_t compall, int32_t n_list, const uint16_t *list,
                           const int32_t *ids, const float *dist, int16_t *out,
-                          int64_t out_stride, hipStream_t st, uint32_t *done_word = nullptr, uint32_t seq = 0)
+                          int64_t out_stride, hipStream_t st, uint32_t *done_word = nullptr, uint32_t seq = 0,
+                          int32_t raw = 0)
 {
     const int n = compall ? d.n_sen : n_list;
     const size_t smem = ((size_t)(d.logadd_size <= kMsLaLds ? d.logadd_size : 0) * 4 +
                          (size_t)(n > 0 ? n : 1) * 2 + 15) / 16 * 16;
 #define PSGPU_MS_SEN(NN) case NN: hipLaunchKernelGGL((ms_senone_kernel<NN>), dim3(T), dim3(kMsSenThreads), smem, st, \
-        d, compall, n_list, list, ids, dist, T, out, out_stride, done_word, seq); break;
+        d, compall, n_list, list, ids, dist, T, out, out_stride, done_word, seq, raw); break;
     switch (d.topn) {
         PSGPU_MS_SEN(1) PSGPU_MS_SEN(2) PSGPU_MS_SEN(3) PSGPU_MS_SEN(4)
         PSGPU_MS_SEN(5) PSGPU_MS_SEN(6) PSGPU_MS_SEN(7) default: PSGPU_MS_SEN(8)
@@ -572,7 +583,7 @@ void ms_cont_norm_kernel(int16_t *__restrict__ out, int64_t out_stride, int32_t 
 
 template <int N>
 static bool launch_cont_n(const MsDev &d, const float *feats, int32_t T, int32_t *ids, float *dist,
-                          int16_t *out, int64_t out_stride, int32_t *best, int32_t *flag, hipStream_t st)
+                          int16_t *out, int64_t out_stride, int32_t *best, int32_t *flag, hipStream_t st, bool raw)
 {
     const int n_tiles = (T + 63) / 64, n_grp = (d.n_sen + kContG - 1) / kContG;
     const size_t smem = (size_t)(d.logadd_size <= kMsLaLds ? d.logadd_size : 0) * 4;
@@ -583,24 +594,27 @@ static bool launch_cont_n(const MsDev &d, const float *feats, int32_t T, int32_t
         hipLaunchKernelGGL((ms_cont_kernel<N, 39>), grid, dim3(256), smem, st, d, feats, T, ids, dist, out, out_stride, best, flag);
     else
         return false;
-    hipLaunchKernelGGL(ms_cont_norm_kernel, dim3((d.n_sen + 255) / 256, T), dim3(256), 0, st, out, out_stride, d.n_sen, best);
+    if (!raw)
+        hipLaunchKernelGGL(ms_cont_norm_kernel, dim3((d.n_sen + 255) / 256, T), dim3(256), 0, st, out, out_stride, d.n_sen, best);
     return true;
 }
 
 static bool launch_cont(const MsDev &d, const float *feats, int32_t T, int32_t *ids, float *dist,
-                        int16_t *out, int64_t out_stride, int32_t *best, int32_t *flag, hipStream_t st)
+                        int16_t *out, int64_t out_stride, int32_t *best, int32_t *flag, hipStream_t st, bool raw = false)
 {
     switch (d.topn) {
-    case 1: return launch_cont_n<1>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    case 2: return launch_cont_n<2>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    case 3: return launch_cont_n<3>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    case 4: return launch_cont_n<4>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    case 5: return launch_cont_n<5>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    case 6: return launch_cont_n<6>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    case 7: return launch_cont_n<7>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
-    default: return launch_cont_n<8>(d, feats, T, ids, dist, out, out_stride, best, flag, st);
+    case 1: return launch_cont_n<1>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    case 2: return launch_cont_n<2>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    case 3: return launch_cont_n<3>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    case 4: return launch_cont_n<4>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    case 5: return launch_cont_n<5>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    case 6: return launch_cont_n<6>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    case 7: return launch_cont_n<7>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
+    default: return launch_cont_n<8>(d, feats, T, ids, dist, out, out_stride, best, flag, st, raw);
     }
 }
+
+static void ms_la_release(psgpu_ms_model_t *m);
 
 extern "C" {
 
@@ -700,6 +714,7 @@ void psgpu_ms_model_free(psgpu_ms_model_t *m)
     hipFree(m->mean); hipFree(m->var); hipFree(m->det); hipFree(m->pdf); hipFree(m->pdf_t);
     hipFree(m->sen2mgau); hipFree(m->logadd); hipFree(m->cboff);
     hipFree(m->list_id); hipFree(m->list_dist); hipFree(m->d_flag); hipFree(m->d_best);
+    ms_la_release(m);
     if (m->h_active) hipHostFree(m->h_active);
     if (m->h_feat) hipHostFree(m->h_feat);
     if (m->h_list) hipHostFree(m->h_list);
@@ -711,6 +726,159 @@ void psgpu_ms_model_free(psgpu_ms_model_t *m)
 int32_t psgpu_ms_n_sen(const psgpu_ms_model_t *m) { return m->d.n_sen; }
 int32_t psgpu_ms_veclen(const psgpu_ms_model_t *m) { return m->d.veclen; }
 
+
+static int ms_batch(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames, int32_t *list_id_dev,
+                    float *list_dist_dev, int16_t *senscr_dev, void *stream, bool raw);
+
+// ---- look-ahead -----------------------------------------------------------
+// The scorer has no time dependence (ms_mgau.c:207), so the frames a caller announces can
+// be scored in one batched pass (compallsen, stopping after senone_eval's own clamp) and
+// every later frame_eval call on one of them -- any pass, any active list -- is answered on
+// the host from the raw row: best over the listed senones, subtract, clamp
+// (ms_mgau.c:219-234).  The only thing a call leaves behind is the list of ids of each
+// active codebook (msg->dist, ms_gauden.c:438-440: unfilled slots of a later call keep
+// them); served calls record which frame's list that is (la.h_last) and the per-call lists
+// are brought up to date from the batch's lists before the per-call kernels run again.
+__global__ void ms_la_sync_kernel(MsDev p, const int32_t *__restrict__ last, int32_t frame0, int32_t n,
+                                  const int32_t *__restrict__ b_id, const float *__restrict__ b_dist,
+                                  int32_t *__restrict__ list_id, float *__restrict__ list_dist)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;        // (codebook, stream, rank)
+    const int per = p.n_feat * p.topn;
+    if (e >= p.n_mgau * per) return;
+    const int g = e / per;
+    const int fr = last[g];
+    if (fr < 0) return;
+    const int chain = e / p.topn, r = e - chain * p.topn;
+    const size_t src = ((size_t)chain * n + (fr - frame0)) * p.topn + r;
+    list_id[e] = b_id[src];
+    list_dist[e] = b_dist[src];
+}
+
+static void ms_la_release(psgpu_ms_model_t *m)
+{
+    free(m->la.h_feats); hipFree(m->la.d_feats); hipFree(m->la.d_rows); hipFree(m->la.d_ids); hipFree(m->la.d_dist);
+    if (m->la.h_rows) hipHostFree(m->la.h_rows);
+    if (m->la.h_last) hipHostFree(m->la.h_last);
+    memset(&m->la, 0, sizeof m->la);
+}
+
+// per-call lists := what the served calls would have left
+static int ms_la_sync(psgpu_ms_model_t *m)
+{
+    if (!m->la.dirty) return PSGPU_OK;
+    const MsDev &d = m->d;
+    const int n_ent = d.n_mgau * d.n_feat * d.topn;
+    hipLaunchKernelGGL(ms_la_sync_kernel, dim3((n_ent + 255) / 256), dim3(256), 0, m->stream, d, m->la.d_last,
+                       m->la.frame0, m->la.n, m->la.d_ids, m->la.d_dist, m->list_id, m->list_dist);
+    PSGPU_HIP(hipGetLastError());
+    PSGPU_HIP(hipStreamSynchronize(m->stream));
+    for (int g = 0; g < d.n_mgau; ++g) m->la.h_last[g] = -1;
+    m->la.dirty = false;
+    return PSGPU_OK;
+}
+
+int psgpu_ms_lookahead(psgpu_ms_model_t *m, const float *feats, int32_t frame0, int32_t n_frames)
+{
+    PSGPU_REQUIRE(m && (feats || n_frames == 0) && frame0 >= 0 && n_frames >= 0, "psgpu_ms_lookahead: bad argument");
+    const MsDev &d = m->d;
+    int rc = ms_la_sync(m);                                      // the old cache's lists are still needed for this
+    if (rc != PSGPU_OK) return rc;
+    m->la.valid = 0;
+    if (n_frames == 0) return PSGPU_OK;
+    if (n_frames > m->la.cap) {
+        int64_t served = m->la.served, batches = m->la.batches;
+        ms_la_release(m);
+        m->la.served = served; m->la.batches = batches;
+        const size_t nl = (size_t)d.n_mgau * d.n_feat * n_frames * d.topn;
+        m->la.h_feats = (float *)malloc(sizeof(float) * (size_t)n_frames * d.veclen);
+        if (!m->la.h_feats) { psgpu_set_error("out of host memory"); return PSGPU_ENOMEM; }
+        PSGPU_HIP(hipMalloc((void **)&m->la.d_feats, sizeof(float) * (size_t)n_frames * d.veclen));
+        PSGPU_HIP(hipMalloc((void **)&m->la.d_rows, sizeof(int16_t) * (size_t)n_frames * d.n_sen));
+        PSGPU_HIP(hipMalloc((void **)&m->la.d_ids, sizeof(int32_t) * nl));
+        PSGPU_HIP(hipMalloc((void **)&m->la.d_dist, sizeof(float) * nl));
+        PSGPU_HIP(hipHostMalloc((void **)&m->la.h_rows, sizeof(int16_t) * (size_t)n_frames * d.n_sen, hipHostMallocDefault));
+        PSGPU_HIP(hipHostMalloc((void **)&m->la.h_last, sizeof(int32_t) * (size_t)d.n_mgau, hipHostMallocMapped));
+        PSGPU_HIP(hipHostGetDevicePointer((void **)&m->la.d_last, m->la.h_last, 0));
+        for (int g = 0; g < d.n_mgau; ++g) m->la.h_last[g] = -1;
+        m->la.cap = n_frames;
+    }
+    memcpy(m->la.h_feats, feats, sizeof(float) * (size_t)n_frames * d.veclen);
+    PSGPU_HIP(hipMemcpyAsync(m->la.d_feats, m->la.h_feats, sizeof(float) * (size_t)n_frames * d.veclen,
+                             hipMemcpyHostToDevice, m->stream));
+    rc = ms_batch(m, m->la.d_feats, n_frames, m->la.d_ids, m->la.d_dist, m->la.d_rows, m->stream, true);
+    if (rc != PSGPU_OK) return rc;
+    int32_t flag = 0;
+    PSGPU_HIP(hipMemcpyAsync(&flag, m->d_flag, sizeof flag, hipMemcpyDeviceToHost, m->stream));
+    PSGPU_HIP(hipMemcpyAsync(m->la.h_rows, m->la.d_rows, sizeof(int16_t) * (size_t)n_frames * d.n_sen,
+                             hipMemcpyDeviceToHost, m->stream));
+    PSGPU_HIP(hipStreamSynchronize(m->stream));
+    if (flag) return PSGPU_OK;             // a list with unfilled slots: only the per-call path knows its stale ids
+    m->la.frame0 = frame0; m->la.n = n_frames; m->la.valid = 1;
+    ++m->la.batches;
+    return PSGPU_OK;
+}
+
+int psgpu_ms_lookahead_covers(const psgpu_ms_model_t *m, const float *feat, int32_t frame)
+{
+    if (!m || !feat || !m->la.valid || frame < m->la.frame0 || frame >= m->la.frame0 + m->la.n) return 0;
+    return memcmp(feat, m->la.h_feats + (size_t)(frame - m->la.frame0) * m->d.veclen, sizeof(float) * m->d.veclen) == 0;
+}
+
+int psgpu_ms_lookahead_stats(const psgpu_ms_model_t *m, int64_t *served, int64_t *batches)
+{
+    PSGPU_REQUIRE(m != nullptr, "psgpu_ms_lookahead_stats: NULL model");
+    if (served) *served = m->la.served;
+    if (batches) *batches = m->la.batches;
+    return PSGPU_OK;
+}
+
+int psgpu_ms_frame_eval_at(psgpu_ms_model_t *m, int16_t *senscr, const uint8_t *senone_active,
+                           int32_t n_senone_active, const float *feat, int32_t frame, int32_t compallsen)
+{
+    PSGPU_REQUIRE(m && senscr && feat, "psgpu_ms_frame_eval_at: NULL argument");
+    PSGPU_REQUIRE(compallsen || n_senone_active == 0 || senone_active, "active list missing");
+    const MsDev &d = m->d;
+    if (!psgpu_ms_lookahead_covers(m, feat, frame)) {
+        int rc = ms_la_sync(m);
+        if (rc != PSGPU_OK) return rc;
+        return psgpu_ms_frame_eval(m, senscr, senone_active, n_senone_active, feat, compallsen);
+    }
+    const int16_t *row = m->la.h_rows + (size_t)(frame - m->la.frame0) * d.n_sen;
+    if (compallsen) {
+        int32_t best = 0x7fffffff;
+        for (int i = 0; i < d.n_sen; ++i) best = row[i] < best ? row[i] : best;
+        for (int i = 0; i < d.n_sen; ++i) {
+            int32_t bs = (int32_t)row[i] - best;
+            senscr[i] = (int16_t)(bs > 32767 ? 32767 : bs < -32768 ? -32768 : bs);
+        }
+        for (int g = 0; g < d.n_mgau; ++g) m->la.h_last[g] = frame;
+    }
+    else {
+        int32_t best = 0x7fffffff;
+        int sen = 0;
+        for (int i = 0; i < n_senone_active; ++i) {
+            sen += senone_active[i];
+            if (sen >= d.n_sen) {
+                psgpu_set_error("active list runs past n_sen (%d >= %d)", sen, d.n_sen);
+                return PSGPU_EINVAL;
+            }
+            best = row[sen] < best ? row[sen] : best;
+        }
+        sen = 0;
+        for (int i = 0; i < n_senone_active; ++i) {
+            sen += senone_active[i];
+            int32_t bs = (int32_t)row[sen] - best;
+            senscr[sen] = (int16_t)(bs > 32767 ? 32767 : bs < -32768 ? -32768 : bs);
+            m->la.h_last[m->h_sen2mgau[sen]] = frame;
+        }
+        if (n_senone_active == 0) return PSGPU_OK;              // nothing listed, nothing evaluated
+    }
+    m->la.dirty = true;
+    ++m->la.served;
+    return PSGPU_OK;
+}
+
 int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
                         const uint8_t *senone_active, int32_t n_senone_active,
                         const float *feat, int32_t compallsen)
@@ -718,6 +886,10 @@ int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
     PSGPU_REQUIRE(m && senscr && feat, "psgpu_ms_frame_eval: NULL argument");
     PSGPU_REQUIRE(compallsen || n_senone_active == 0 || senone_active, "active list missing");
     const MsDev &d = m->d;
+    if (m->la.dirty) {                                   // served calls first: their lists are this call's stale ids
+        int rc = ms_la_sync(m);
+        if (rc != PSGPU_OK) return rc;
+    }
     int n_list = 0;
     if (compallsen)
         memset(m->h_active, 1, (size_t)d.n_mgau);
@@ -763,9 +935,9 @@ int psgpu_ms_frame_eval(psgpu_ms_model_t *m, int16_t *senscr,
     return PSGPU_OK;
 }
 
-int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
-                             int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
-                             void *stream)
+static int ms_batch(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
+                    int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
+                    void *stream, bool raw)
 {
     PSGPU_REQUIRE(m && feats_dev, "psgpu_ms_score_batch_dev: NULL argument");
     PSGPU_REQUIRE((list_id_dev == nullptr) == (list_dist_dev == nullptr), "list buffers: both or neither");
@@ -782,7 +954,7 @@ int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_
             m->cap_best = total_frames;
         }
         PSGPU_HIP(hipMemsetAsync(m->d_best, 0x7f, sizeof(int32_t) * (size_t)total_frames, st));
-        launch_cont(d, feats_dev, total_frames, list_id_dev, list_dist_dev, senscr_dev, d.n_sen, m->d_best, m->d_flag, st);
+        launch_cont(d, feats_dev, total_frames, list_id_dev, list_dist_dev, senscr_dev, d.n_sen, m->d_best, m->d_flag, st, raw);
         PSGPU_HIP(hipGetLastError());
         return PSGPU_OK;
     }
@@ -793,10 +965,17 @@ int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_
         launch_topn(d, feats_dev, total_frames, nullptr, list_id_dev, list_dist_dev, 1, m->d_flag, st);
     PSGPU_HIP(hipGetLastError());
     if (senscr_dev) {
-        launch_senone(d, total_frames, 1, 0, nullptr, list_id_dev, list_dist_dev, senscr_dev, d.n_sen, st);
+        launch_senone(d, total_frames, 1, 0, nullptr, list_id_dev, list_dist_dev, senscr_dev, d.n_sen, st, nullptr, 0, raw);
         PSGPU_HIP(hipGetLastError());
     }
     return PSGPU_OK;
+}
+
+int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
+                             int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
+                             void *stream)
+{
+    return ms_batch(m, feats_dev, total_frames, list_id_dev, list_dist_dev, senscr_dev, stream, false);
 }
 
 int psgpu_ms_batch_check(psgpu_ms_model_t *m, void *stream)

@@ -34,14 +34,27 @@ class MsMgau:
         self.h = h
         self.senscr = np.zeros(self.n_sen, np.int16)      # acmod->senone_scores: persists between calls
 
-    def frame_eval(self, feat, active=None, compallsen=True):
+    def frame_eval(self, feat, active=None, compallsen=True, frame=-1):
+        """One ms_cont_mgau_frame_eval call.  `frame` >= 0 lets the call be answered from
+        the look-ahead cache when that frame was announced with this very vector."""
         feat = np.ascontiguousarray(feat, np.float32).reshape(-1)
         assert feat.size == self.veclen
         act = None if active is None else np.ascontiguousarray(active, np.uint8)
-        capi.check(capi.lib().psgpu_ms_frame_eval(self.h, _p(self.senscr), _p(act),
-                                                  0 if act is None else act.size, _p(feat),
-                                                  int(bool(compallsen))), "psgpu_ms_frame_eval")
+        capi.check(capi.lib().psgpu_ms_frame_eval_at(self.h, _p(self.senscr), _p(act),
+                                                     0 if act is None else act.size, _p(feat), int(frame),
+                                                     int(bool(compallsen))), "psgpu_ms_frame_eval_at")
         return self.senscr.copy()
+
+    def lookahead(self, feats, frame0=0):
+        feats = np.ascontiguousarray(feats, np.float32)
+        assert feats.ndim == 2 and feats.shape[1] == self.veclen
+        capi.check(capi.lib().psgpu_ms_lookahead(self.h, _p(feats), int(frame0), int(feats.shape[0])),
+                   "psgpu_ms_lookahead")
+
+    def lookahead_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        capi.check(capi.lib().psgpu_ms_lookahead_stats(self.h, C.byref(a), C.byref(b)), "psgpu_ms_lookahead_stats")
+        return a.value, b.value
 
     def score_frames(self, feats):
         feats = np.ascontiguousarray(feats, np.float32)
