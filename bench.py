@@ -286,6 +286,39 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         fe.close()
     except Exception as e:
         out["pcm_pipeline"] = {"error": str(e)}
+    # (6) semi-continuous scorer, batched entry: tidigits model (4 streams x 256 densities, 4-bit clustered
+    #     weights), 512 utterances x 100 frames (one wave per (utterance, stream) walks its frames in order)
+    try:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "semi_tidigits_tables.npz"))
+        g = np.load(os.path.join(ROOT, "tests", "golden", "senlog_tidigits_default.npz"))
+        sm = P.SemiMgau({k: z[k] for k in z.files})
+        n_u, u_len = 512, 100
+        rng = np.random.default_rng(4)
+        fh = np.ascontiguousarray(g["call_feat"][rng.integers(0, g["call_feat"].shape[0], n_u * u_len)], np.float32)
+        f = torch.from_numpy(fh).to(dev)
+        so = torch.arange(0, n_u * u_len + 1, u_len, dtype=torch.int32, device=dev)
+        scr = torch.empty((n_u * u_len, sm.n_sen), dtype=torch.int16, device=dev)
+
+        def sstep():
+            capi.check(L.psgpu_semi_score_batch_dev(sm.m, C.c_void_p(f.data_ptr()), C.c_void_p(so.data_ptr()), n_u,
+                                                    n_u * u_len, C.c_void_p(scr.data_ptr()), sp), "semi")
+        sstep(); sstep()
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
+        K = 5
+        L.psgpu_event_record(e0, sp)
+        for _ in range(K):
+            sstep()
+        L.psgpu_event_record(e1, sp)
+        ms_ = C.c_float()
+        L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
+        out["semi_scorer"] = {"frames_per_s": round(n_u * u_len * K / (ms_.value * 1e-3), 1), "frames": n_u * u_len,
+                              "utterances": n_u, "model": "tidigits s2_semi (4 x 256, 4-bit weights, %d senones)" % sm.n_sen,
+                              "ms_per_launch_pair": round(ms_.value / K, 4)}
+        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
+        sm.close()
+    except Exception as e:
+        out["semi_scorer"] = {"error": str(e)}
     return out
 
 

@@ -304,6 +304,16 @@ int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
                           int32_t compallsen);
 /* one slot of the ring: cw/score [n_feat][topn] int32, n_used [n_feat] int32
  * (topn_hist_n); slot -1 = the slot of the last call */
+/* Batched compallsen scoring of whole utterances (additive, like psgpu_ptm_score_batch_dev):
+ * feats [total_frames][veclen], utt_off [n_utt + 1] frame offsets, senscr [total_frames][n_sen].
+ * = one s2_semi_mgau_frame_eval(compallsen) per frame in frame order, every utterance starting
+ * from the lists of a freshly initialised scorer, frames numbered from 0 within the utterance
+ * (down-sampling rule, s2_semi_mgau.c:173-175).  The frame-to-frame dependence of the top-N
+ * lists is kept: one wavefront per (utterance, stream) walks its frames in order. */
+int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, const int32_t *utt_off_dev,
+                               int32_t n_utt, int32_t total_frames, int16_t *senscr_dev, void *stream);
+int psgpu_semi_score_batch(psgpu_semi_model_t *m, const float *feats, const int32_t *utt_off, int32_t n_utt,
+                           int16_t *senscr);
 int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, int32_t *score,
                               int32_t *n_used);
 int psgpu_semi_state_set_topn(psgpu_semi_state_t *s, int32_t slot, const int32_t *cw,

@@ -21,6 +21,7 @@ SYMBOLS = [
     "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn", "psgpu_ptm_state_lookahead", "psgpu_ptm_state_lookahead_stats",
     "psgpu_semi_model_create", "psgpu_semi_model_free", "psgpu_semi_state_create",
     "psgpu_semi_state_free", "psgpu_semi_state_reset", "psgpu_semi_frame_eval",
+    "psgpu_semi_score_batch_dev", "psgpu_semi_score_batch",
     "psgpu_semi_state_get_topn", "psgpu_semi_state_set_topn",
     "psgpu_ms_model_create", "psgpu_ms_model_free", "psgpu_ms_n_sen", "psgpu_ms_veclen",
     "psgpu_ms_frame_eval", "psgpu_ms_lookahead", "psgpu_ms_lookahead_covers", "psgpu_ms_lookahead_stats",

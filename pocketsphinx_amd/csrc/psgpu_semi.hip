@@ -37,6 +37,8 @@ struct psgpu_semi_model_s {
     float *mean, *var, *det;
     uint8_t *mixw, *mixw_cb, *logadd8;
     int32_t veclen;
+    // batched entry scratch: lists of every frame
+    uint8_t *b_cw, *b_n; int32_t *b_sc; int64_t b_cap;
 };
 
 struct psgpu_semi_state_s {
@@ -175,6 +177,130 @@ void semi_frame_kernel(SemiDev p, SemiFeat fa, int32_t fresh, int32_t do_scan, i
         __hip_atomic_store(done_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+
+// ---------------------------------------------------------------------------
+// batched entry: whole utterances, compallsen.  The top-N of a stream depends on
+// the previous frame's list (eval_topn re-scores the carried codewords, eval_cb's
+// acceptance threshold starts from them), so the unit of parallelism is the
+// (utterance, stream) chain: one wavefront walks its frames in order with exactly
+// the per-call procedure (generic_frame_step: codewords on lanes, wave-uniform
+// list state), n_utt x n_feat waves in flight.  Lists (normalised, with the
+// per-stream beam count) go to HBM; a second kernel, one workgroup per frame,
+// scores all senones.  Each utterance starts from the lists of a freshly
+// initialised scorer (s2_semi_mgau_init, s2_semi_mgau.c:1305-1322); frames count
+// from 0 within the utterance for the down-sampling rule (:173-175).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256)
+void semi_chain_kernel(SemiDev p, const float *__restrict__ feats, int32_t veclen,
+                       const int32_t *__restrict__ utt_off, int32_t n_utt,
+                       uint8_t *__restrict__ l_cw, int32_t *__restrict__ l_sc, uint8_t *__restrict__ l_n)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wave >= n_utt * p.n_feat) return;
+    const int u = wave / p.n_feat, f = wave - u * p.n_feat;
+    const int t0 = utt_off[u], T = utt_off[u + 1] - t0;
+    const int len = p.featlen[f];
+    const float *mean = p.mean + p.foff[f], *var = p.var + p.foff[f];
+    const float *det = p.det + (size_t)f * p.n_density;
+    TopN<N> L;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { L.cw[i] = i; L.sc[i] = kMaxNegInt32; }
+    float dt[kSemiK];
+#pragma unroll
+    for (int k = 0; k < kSemiK; ++k) dt[k] = det[min(k * 64 + lane, p.n_density - 1)];
+    for (int t = 0; t < T; ++t) {
+        const float *x = feats + (size_t)(t0 + t) * veclen + p.featoff[f];
+        float d[kSemiK], dp[kSemiK];
+#pragma unroll
+        for (int k = 0; k < kSemiK; ++k) {
+            const int cw = min(k * 64 + lane, p.n_density - 1);         // clamp; masked in the scan
+            const float *m = mean + (size_t)cw * len, *v = var + (size_t)cw * len;
+            float acc = dt[k], prev = acc;
+            for (int j = 0; j < len; ++j) {
+                prev = acc;
+                acc = gau_step(acc, x[j], m[j], v[j]);
+            }
+            d[k] = acc; dp[k] = prev;
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) L.sc[i] = kMaxNegInt32;             // carried codewords, scores re-derived
+        generic_frame_step<N, true>(L, d, dp, lane, p.n_density, (t % p.ds_ratio) == 0);
+        // mgau_norm (:185-203)
+        const int32_t norm = L.sc[0] >> kSenscrShift;
+        int cnt = N;
+        bool cut = false;
+        int32_t v_[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            v_[j] = L.sc[j];
+            if (!cut) {
+                int32_t v = (int32_t)(0u - ((uint32_t)(L.sc[j] >> kSenscrShift) - (uint32_t)norm));
+                if (v > kMaxNegAscr) v = kMaxNegAscr;
+                v_[j] = v;
+                if (p.beam[f] && v > p.beam[f]) { cnt = j; cut = true; }
+            }
+        }
+        if (lane == 0) {
+            const size_t o = ((size_t)(t0 + t) * p.n_feat + f) * N;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { l_cw[o + i] = (uint8_t)L.cw[i]; l_sc[o + i] = v_[i]; }
+            l_n[(size_t)(t0 + t) * p.n_feat + f] = (uint8_t)cnt;
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256)
+void semi_senone_batch_kernel(SemiDev p, const uint8_t *__restrict__ l_cw, const int32_t *__restrict__ l_sc,
+                              const uint8_t *__restrict__ l_n, int16_t *__restrict__ out)
+{
+    __shared__ uint8_t s_la[kSemiLa];
+    __shared__ int32_t s_cw[kSemiMaxFeat * N], s_sc[kSemiMaxFeat * N], s_n[kSemiMaxFeat];
+    __shared__ uint8_t s_cb[16];
+    const int tid = threadIdx.x, frame = blockIdx.x;
+    for (int i = tid; i < kSemiLa; i += 256)
+        s_la[i] = (i < p.logadd8_size) ? p.logadd8[i] : 0;
+    if (tid < 16) s_cb[tid] = p.mixw_cb ? p.mixw_cb[tid] : 0;
+    if (tid < p.n_feat * N) {
+        s_cw[tid] = l_cw[(size_t)frame * p.n_feat * N + tid];
+        s_sc[tid] = l_sc[(size_t)frame * p.n_feat * N + tid];
+    }
+    if (tid < p.n_feat) s_n[tid] = l_n[(size_t)frame * p.n_feat + tid];
+    __syncthreads();
+    const bool four = p.mixw_cb != nullptr;
+    const int n = four ? (p.n_sen & ~1) : p.n_sen;                       // compallsen loops (:446-741)
+    int16_t *o = out + (size_t)frame * p.n_sen;
+    for (int sen = tid; sen < p.n_sen; sen += 256) {
+        int32_t acc = 0;
+        if (sen < n)
+            for (int f = 0; f < p.n_feat; ++f) {
+                const int cnt = s_n[f];
+                int32_t tmp = 0;
+                for (int k = 0; k < max(cnt, 1); ++k) {
+                    const int cw = s_cw[f * N + k];
+                    int32_t w;
+                    if (four) {
+                        const int b = p.mixw[((size_t)f * p.n_density + cw) * p.row + (sen >> 1)];
+                        w = s_cb[(sen & 1) ? (b >> 4) : (b & 0x0f)];
+                    }
+                    else
+                        w = p.mixw[((size_t)f * p.n_density + cw) * p.row + sen];
+                    const int32_t y = w + s_sc[f * N + k];
+                    if (k == 0) tmp = y;
+                    else {
+                        const int32_t lo_ = min(tmp, y);
+                        const uint32_t dd = (uint32_t)(max(tmp, y) - lo_);
+                        tmp = lo_ - (dd < (uint32_t)kSemiLa ? (int32_t)s_la[dd] : 0);
+                    }
+                }
+                acc = (int32_t)(int16_t)(acc + tmp);
+            }
+        o[sen] = (int16_t)acc;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -242,6 +368,7 @@ void psgpu_semi_model_free(psgpu_semi_model_t *m)
     if (!m) return;
     hipFree(m->mean); hipFree(m->var); hipFree(m->det);
     hipFree(m->mixw); hipFree(m->mixw_cb); hipFree(m->logadd8);
+    hipFree(m->b_cw); hipFree(m->b_n); hipFree(m->b_sc);
     delete m;
 }
 
@@ -358,6 +485,70 @@ int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
     }
     memcpy(senscr, s->h_out, (size_t)d.n_sen * sizeof(int16_t));
     return PSGPU_OK;
+}
+
+int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, const int32_t *utt_off_dev,
+                               int32_t n_utt, int32_t total_frames, int16_t *senscr_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && n_utt >= 0 && total_frames >= 0, "psgpu_semi_score_batch_dev: bad argument");
+    if (n_utt == 0 || total_frames == 0) return PSGPU_OK;
+    PSGPU_REQUIRE(feats_dev && utt_off_dev && senscr_dev, "psgpu_semi_score_batch_dev: NULL device buffer");
+    const SemiDev &d = m->d;
+    hipStream_t st = (hipStream_t)stream;
+    if (total_frames > m->b_cap) {
+        PSGPU_HIP(hipFree(m->b_cw)); PSGPU_HIP(hipFree(m->b_sc)); PSGPU_HIP(hipFree(m->b_n));
+        m->b_cw = nullptr; m->b_sc = nullptr; m->b_n = nullptr; m->b_cap = 0;
+        const size_t ne = (size_t)total_frames * d.n_feat * d.topn;
+        PSGPU_HIP(hipMalloc((void **)&m->b_cw, ne));
+        PSGPU_HIP(hipMalloc((void **)&m->b_sc, ne * sizeof(int32_t)));
+        PSGPU_HIP(hipMalloc((void **)&m->b_n, (size_t)total_frames * d.n_feat));
+        m->b_cap = total_frames;
+    }
+    const int waves = n_utt * d.n_feat;
+#define PSGPU_SEMI_B(NN) case NN:                                                                                     \
+        hipLaunchKernelGGL((semi_chain_kernel<NN>), dim3((waves + 3) / 4), dim3(256), 0, st, d, feats_dev, m->veclen, \
+                           utt_off_dev, n_utt, m->b_cw, m->b_sc, m->b_n);                                             \
+        hipLaunchKernelGGL((semi_senone_batch_kernel<NN>), dim3(total_frames), dim3(256), 0, st, d,                   \
+                           (const uint8_t *)m->b_cw, (const int32_t *)m->b_sc, (const uint8_t *)m->b_n, senscr_dev);  \
+        break;
+    switch (d.topn) {
+        PSGPU_SEMI_B(1) PSGPU_SEMI_B(2) PSGPU_SEMI_B(3) PSGPU_SEMI_B(4)
+        PSGPU_SEMI_B(5) PSGPU_SEMI_B(6) PSGPU_SEMI_B(7) default: PSGPU_SEMI_B(8)
+    }
+#undef PSGPU_SEMI_B
+    PSGPU_HIP(hipGetLastError());
+    return PSGPU_OK;
+}
+
+int psgpu_semi_score_batch(psgpu_semi_model_t *m, const float *feats, const int32_t *utt_off, int32_t n_utt,
+                           int16_t *senscr)
+{
+    PSGPU_REQUIRE(m && utt_off && n_utt >= 0, "psgpu_semi_score_batch: bad argument");
+    if (n_utt == 0) return PSGPU_OK;
+    const int32_t T = utt_off[n_utt];
+    PSGPU_REQUIRE(utt_off[0] == 0 && T >= 0, "utt_off must start at 0");
+    for (int u = 0; u < n_utt; ++u) PSGPU_REQUIRE(utt_off[u + 1] >= utt_off[u], "utt_off must be non-decreasing");
+    if (T == 0) return PSGPU_OK;
+    PSGPU_REQUIRE(feats && senscr, "psgpu_semi_score_batch: NULL buffer");
+    const SemiDev &d = m->d;
+    float *df = nullptr; int32_t *doff = nullptr; int16_t *ds = nullptr;
+    auto cleanup = [&]() { hipFree(df); hipFree(doff); hipFree(ds); };
+#define TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) {                 \
+        psgpu_set_error("%s -> %s", #call, hipGetErrorString(e_)); cleanup();          \
+        return e_ == hipErrorOutOfMemory ? PSGPU_ENOMEM : PSGPU_EHIP; } } while (0)
+    TRY(hipMalloc((void **)&df, sizeof(float) * (size_t)T * m->veclen));
+    TRY(hipMalloc((void **)&doff, sizeof(int32_t) * ((size_t)n_utt + 1)));
+    TRY(hipMalloc((void **)&ds, sizeof(int16_t) * (size_t)T * d.n_sen));
+    TRY(hipMemcpy(df, feats, sizeof(float) * (size_t)T * m->veclen, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(doff, utt_off, sizeof(int32_t) * ((size_t)n_utt + 1), hipMemcpyHostToDevice));
+    int rc = psgpu_semi_score_batch_dev(m, df, doff, n_utt, T, ds, nullptr);
+    if (rc == PSGPU_OK) {
+        TRY(hipDeviceSynchronize());
+        TRY(hipMemcpy(senscr, ds, sizeof(int16_t) * (size_t)T * d.n_sen, hipMemcpyDeviceToHost));
+    }
+#undef TRY
+    cleanup();
+    return rc;
 }
 
 int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, int32_t *score, int32_t *n_used)

@@ -51,6 +51,17 @@ class SemiMgau:
             "psgpu_semi_frame_eval")
         return scr
 
+    def score_utts(self, feats, utt_lens):
+        """Batched compallsen scoring of whole utterances (each from a fresh top-N state)."""
+        feats = np.ascontiguousarray(feats, np.float32)
+        off = np.zeros(len(utt_lens) + 1, np.int32)
+        off[1:] = np.cumsum(np.asarray(utt_lens, np.int64))
+        assert feats.ndim == 2 and feats.shape == (int(off[-1]), self.veclen)
+        out = np.empty((feats.shape[0], self.n_sen), np.int16)
+        capi.check(capi.lib().psgpu_semi_score_batch(self.m, _p(feats), _p(off), len(utt_lens), _p(out)),
+                   "psgpu_semi_score_batch")
+        return out
+
     def cur_topn(self, slot=-1):
         cw = np.empty((self.n_feat, self.topn), np.int32)
         sc = np.empty((self.n_feat, self.topn), np.int32)

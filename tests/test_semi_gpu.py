@@ -78,3 +78,52 @@ def test_semi_8bit_weights_vs_oracle():
         b = s.frame_eval(g["call_feat"][c], fr, active=act, compallsen=(na < 0), frame_idx=fi)
         assert np.array_equal(a, b), "call %d" % c
     s.close()
+
+
+@pytest.mark.parametrize("variant", ["4bit_default", "8bit", "4bit_beam_topn6_ds2", "dup_codewords_topn2"])
+def test_semi_batch_vs_oracle(variant):
+    """psgpu_semi_score_batch (one wave per (utterance, stream) walking its frames in
+    order + one workgroup per frame for the senones) == the oracle's compallsen
+    frame_eval frame by frame, every utterance from a fresh state: ragged utterances
+    (one frame, empty), 4-bit and 8-bit weights, per-stream beams, down-sampling,
+    duplicated codewords (exact ties through the sequential acceptance rule)."""
+    import pocketsphinx_amd as P
+    t = dict(_load("semi_tidigits_tables.npz"))
+    kw = {}
+    if variant == "8bit":
+        n_sen = int(t["n_sen"][0])
+        cb = t.pop("mixw_cb")
+        packed = t["mixw"]
+        full = np.empty(packed.shape[:2] + (n_sen,), np.uint8)
+        full[..., 0::2] = cb[packed & 0x0f][..., :(n_sen + 1) // 2]
+        full[..., 1::2] = cb[packed >> 4][..., :n_sen // 2]
+        t["mixw"] = full
+    elif variant == "4bit_beam_topn6_ds2":
+        kw = dict(topn=6, ds_ratio=2, topn_beam=[40, 30, 0, 60])
+    elif variant == "dup_codewords_topn2":
+        # codeword 2k+1 := codeword 2k in every stream: exact score ties everywhere
+        kw = dict(topn=2)
+        fl = t["featlen"]
+        nd = int(t["n_density"][0])
+        mean, var, det = t["mean"].copy(), t["var"].copy(), t["det"].copy().reshape(len(fl), nd)
+        o = 0
+        for f, ln in enumerate(fl):
+            m = mean[o:o + nd * ln].reshape(nd, ln); v = var[o:o + nd * ln].reshape(nd, ln)
+            m[1::2] = m[0::2]; v[1::2] = v[0::2]; det[f, 1::2] = det[f, 0::2]
+            o += nd * ln
+        t["mean"], t["var"], t["det"] = mean, var, det.reshape(t["det"].shape)
+    g = _load("senlog_tidigits_default.npz")
+    rng = np.random.default_rng(9)
+    lens = [37, 1, 0, 90, 12]
+    feats = np.ascontiguousarray(g["call_feat"][rng.integers(0, g["call_feat"].shape[0], sum(lens))])
+    s = P.SemiMgau(t, **kw)
+    got = s.score_utts(feats, lens)
+    pos = 0
+    for n in lens:
+        o = pso.OracleSemi(t, **kw)
+        for i in range(n):
+            o.set_frame_idx(i)
+            want = o.frame_eval(feats[pos + i], i, compallsen=True)
+            assert np.array_equal(got[pos + i], want), "utterance frame %d (batch row %d)" % (i, pos + i)
+        pos += n
+    s.close()
