@@ -1,4 +1,4 @@
-/* integration/psgpu_fe_shim.c -- REFERENCE-SIDE code (INTEGRATION.md section 5).
+/* integration/psgpu_fe_shim.c -- REFERENCE-SIDE code (INTEGRATION.md section 4).
  * Reads the precomputed tables out of a fe_t and hands whole utterances to
  * psgpu_fe_process_utts(); compiled against the unmodified reference. */
 #include <string.h>

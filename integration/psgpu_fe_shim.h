@@ -1,6 +1,6 @@
 /* integration/psgpu_fe_shim.h -- reference-side binding of the psgpu MFCC front
  * end: fe_process_utt + fe_end_utt (fe/fe_interface.c:505-541) computed on the
- * MI355X from the tables of the decoder's own fe_t.  See INTEGRATION.md section 5. */
+ * MI355X from the tables of the decoder's own fe_t.  See INTEGRATION.md section 4. */
 #ifndef PSGPU_FE_SHIM_H
 #define PSGPU_FE_SHIM_H
 
