@@ -43,6 +43,9 @@ int psgpu_set_device(int device);
 /* device memory helpers so that a C host needs no HIP headers */
 int psgpu_malloc(void **dev_ptr, size_t bytes);
 int psgpu_free(void *dev_ptr);
+/* page-locked host memory: asynchronous copies into it do not go through a shared staging buffer */
+int psgpu_host_alloc(void **host_ptr, size_t bytes);
+int psgpu_host_free(void *host_ptr);
 int psgpu_memcpy_h2d(void *dst_dev, const void *src, size_t bytes, void *stream);
 int psgpu_memcpy_d2h(void *dst, const void *src_dev, size_t bytes, void *stream);
 int psgpu_stream_sync(void *stream);
@@ -266,6 +269,15 @@ int psgpu_ptm_state_get_topn(psgpu_ptm_state_t *s, int32_t slot, int32_t *cw, in
  * n_frames == 0 drops the cache.  Models outside the batched kernels' shape ignore it. */
 int psgpu_ptm_state_lookahead(psgpu_ptm_state_t *s, const float *feats, int32_t frame0, int32_t n_frames);
 int psgpu_ptm_state_lookahead_stats(psgpu_ptm_state_t *s, int64_t *calls_served, int64_t *batches);
+/* For a search component that lives on the device as well (psgpu_phone_loop_run_dev): the
+ * cache's un-normalised rows [n_frames][n_sen] and all-senone minima [n_frames] on the device
+ * (computing them now if the announcement has not been used yet; PSGPU_ESTATE when there is no
+ * cache positioned at its first frame), and the bookkeeping of a fresh all-codebook
+ * frame_eval call that such a component no longer makes: psgpu_ptm_state_mark_fresh(frame)
+ * is that call without its scores (PSGPU_ESTATE unless `frame` is the cache's next fresh frame). */
+int psgpu_ptm_state_lookahead_rows(psgpu_ptm_state_t *s, const int16_t **raw_dev, const int32_t **best_dev,
+                                   int32_t *frame0, int32_t *n_frames);
+int psgpu_ptm_state_mark_fresh(psgpu_ptm_state_t *s, int32_t frame);
 /* Load one slot of the ring from a host image of ptm_fast_eval_t
  * (ptm_mgau.h:68-71): cw/score [n_chain][topn] int32, mgau_active one byte
  * per codebook (NULL = all active).  Lets a shim attached to a decoder that
@@ -437,6 +449,43 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
                            const uint16_t *utt_of_hmm_dev,
                            const int16_t *senscr_dev, int32_t senscr_stride,
                            int32_t *best_dev, void *stream);
+
+
+/* ---- phone-loop search of whole utterances -----------------------
+ * Replaces phone_loop_search_start (phone_loop_search.c:165-184) + phone_loop_search_step
+ * (:302-340) for every frame of n_utt utterances: the per-frame normalisation acmod_score
+ * applies for the all-phones-active senone list, evaluate_hmms, store_scores, prune_hmms,
+ * phone_transition, renormalisation.  One wavefront per utterance, lane = CI phone.
+ *  c             tp / sseq tables (psgpu_hmm_ctx_create), 3 or 5 emitting states, non-multiplex
+ *  ssid_dev, tmatid_dev [n_phones]   the CI phones' senone-sequence and transition-matrix ids
+ *                                    (hmm_init(ctx, hmm, FALSE, pid2ssid, pid2tmatid), :113-117)
+ *  raw_dev [total][raw_stride] int16 un-normalised senone scores (PSGPU_PTM_RAW_SCORES rows)
+ *  ci_list_dev [n_list]              senone ids of the list acmod_flags2list builds when every CI
+ *                                    phone is active (incl. its bridging entries): a frame's scores
+ *                                    are raw - min over this list (ptm_mgau.c:393-400); OR
+ *  best_dev [total]                  the all-senone minima when the decoder runs with -compallsen
+ *  penalties_dev [total][n_phones]   pls->penalties after each step (what fwdtree reads through
+ *                                    phone_loop_search_score, phone_loop_search.h:99)
+ *  pen_now_dev   [total][n_phones]   the step's own ring entry (pen_buf), and
+ *  state_dev     [total][n_phones][8] score[0..4], out_score, bestscore, frame of each HMM after
+ *                                    the step: enough to continue stepping on the host from any frame
+ * total_frames = utt_off[n_utt].  Two launches: every frame's normaliser and the CI phones'
+ * normalised scores, packed, in parallel; then one wavefront per utterance marching through its
+ * frames with the next four frames' scores always in registers. */
+typedef struct psgpu_phone_loop_params_s {
+    int32_t n_phones;            /* <= 64 */
+    int32_t window;              /* pl_window, 1..32 */
+    int32_t beam, pbeam, pip;    /* phone_loop_search_t.beam / pbeam / pip */
+    double penalty_weight;       /* pl_weight */
+} psgpu_phone_loop_params_t;
+int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *p, const uint16_t *ssid_dev,
+                             const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                             const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
+                             const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                             int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream);
+/* the context's own (non-blocking) stream, which the call above uses when `stream` is NULL;
+ * usable with psgpu_memcpy_* / psgpu_stream_sync */
+void *psgpu_hmm_ctx_stream(psgpu_hmm_ctx_t *c);
 
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).

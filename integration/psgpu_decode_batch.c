@@ -23,6 +23,7 @@
 #include "psgpu.h"
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
+#include "psgpu_phone_loop_shim.h"
 #include "psgpu_decode_batch.h"
 #ifdef PSGPU_SEARCH_HOOKS
 #include "psgpu_search_hooks.h"
@@ -199,6 +200,10 @@ psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
 #ifdef PSGPU_SEARCH_HOOKS
         if ((flags & PSGPU_BATCH_DEVICE_SEARCH) && psgpu_search_attach(b->ps[w]) < 0) goto fail;
 #endif
+        if ((flags & PSGPU_BATCH_DEVICE_PHONE_LOOP) && psgpu_phone_loop_attach(b->ps[w]) < 0) {
+            E_ERROR("psgpu_phone_loop_attach failed\n");
+            goto fail;
+        }
     }
     if ((flags & PSGPU_BATCH_DEVICE_FE) && !(flags & PSGPU_BATCH_CPU_ONLY)) {
         /* one front end for the batch: psgpu_fe_wrap's table read-out, kept as the raw object */
@@ -223,6 +228,7 @@ psgpu_batch_free(psgpu_batch_t *b)
 #ifdef PSGPU_SEARCH_HOOKS
         if (b->flags & PSGPU_BATCH_DEVICE_SEARCH) psgpu_search_detach(b->ps[w]);
 #endif
+        psgpu_phone_loop_detach(b->ps[w]);
         ps_free(b->ps[w]);
     }
     psgpu_fe_free(b->fe);

@@ -15,6 +15,7 @@ extern "C" {
 #define PSGPU_BATCH_DEVICE_FE     1u   /* cepstra of the whole batch in one device call (psgpu_fe_shim) */
 #define PSGPU_BATCH_DEVICE_SEARCH 2u   /* hmm_vit_eval loops on the device (needs the hooked library) */
 #define PSGPU_BATCH_CPU_ONLY      4u   /* no device at all: the reference as it is (for A/B runs) */
+#define PSGPU_BATCH_DEVICE_PHONE_LOOP 8u /* each utterance's phone-loop search in one device launch (psgpu_phone_loop_shim) */
 
 typedef struct psgpu_batch_seg_s {
     char *word;

@@ -62,6 +62,7 @@ typedef struct psgpu_mgau_s {
     int32 n_calls;
 } psgpu_mgau_t;
 
+static void shim_announce(struct psgpu_mgau_s *g, int32 frame);
 static int shim_frame_eval(ps_mgau_t *ps, int16 *senscr, uint8 *senone_active,
                            int32 n_senone_active, mfcc_t **feat, int32 frame,
                            int32 compallsen);
@@ -532,6 +533,39 @@ psgpu_mgau_reset(ps_mgau_t *ps)
     if (ps->vt == &psgpu_ms_funcs)
         return 0;
     return -1;
+}
+
+/* For a search component that consumes scores on the device (psgpu_phone_loop_shim.c):
+ * announce what lies ahead of `frame` now, have it scored, and hand out the device rows. */
+int
+psgpu_mgau_prefetch(ps_mgau_t *ps, int frame, const int16_t **raw_dev, const int32_t **best_dev,
+                    int *frame0, int *n_frames, int *n_sen)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    int32_t f0 = 0, n = 0;
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs || g->acmod == NULL)
+        return -1;
+    g->la_expect = -1;                                  /* force a fresh announcement */
+    shim_announce(g, frame);
+    if (g->la_cn == 0 || g->la_c0 != frame)
+        return -1;
+    if (psgpu_ptm_state_lookahead_rows(g->state, raw_dev, best_dev, &f0, &n) != PSGPU_OK)
+        return -1;
+    *frame0 = f0; *n_frames = n; *n_sen = psgpu_ptm_n_sen(g->model);
+    return 0;
+}
+
+/* the bookkeeping of the fresh all-codebook frame_eval call a device-side phone loop no longer makes */
+int
+psgpu_mgau_mark_fresh(ps_mgau_t *ps, int frame)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
+        return -1;
+    if (psgpu_ptm_state_mark_fresh(g->state, frame) != PSGPU_OK)
+        return -1;
+    g->la_expect = frame + 1;
+    return 0;
 }
 
 long

@@ -3,6 +3,7 @@
 #ifndef PSGPU_MGAU_SHIM_H
 #define PSGPU_MGAU_SHIM_H
 
+#include <stdint.h>
 #include <pocketsphinx.h>
 #include "acmod.h"
 
@@ -23,6 +24,14 @@ int psgpu_mgau_attach(ps_decoder_t *ps);
 /* Back to the top-N history of a freshly initialised scorer (ptm_mgau_reset_fast_hist,
  * ptm_mgau.c:777-802).  0, or -1 if `mgau` is not a psgpu scorer. */
 int psgpu_mgau_reset(ps_mgau_t *mgau);
+
+/* Hooks for a device-side search component (integration/psgpu_phone_loop_shim.c): score what
+ * lies ahead of `frame` now and return the device rows; account for a fresh frame_eval call
+ * that component no longer makes.  0, or -1 when the scorer is not the psgpu PTM scorer with
+ * an attached acmod or the request does not fit the cache. */
+int psgpu_mgau_prefetch(ps_mgau_t *mgau, int frame, const int16_t **raw_dev, const int32_t **best_dev,
+                        int *frame0, int *n_frames, int *n_sen);
+int psgpu_mgau_mark_fresh(ps_mgau_t *mgau, int frame);
 
 /* number of frame_eval calls served by the device (-1 if not a psgpu scorer) */
 int32 psgpu_mgau_n_calls(ps_mgau_t *mgau);

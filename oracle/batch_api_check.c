@@ -58,7 +58,7 @@ same(const psgpu_batch_result_t *a, const psgpu_batch_result_t *b)
 int
 main(int argc, char **argv)
 {
-    enum { MAXU = 64 };
+    enum { MAXU = 2048 };
     int16 *pcm[MAXU]; size_t n[MAXU];
     const int16 *cp[MAXU], *rp[MAXU]; size_t rn[MAXU];
     psgpu_batch_result_t ref[MAXU], got[MAXU], rev[MAXU], one[MAXU];
@@ -88,9 +88,10 @@ main(int argc, char **argv)
     }
     err_set_loglevel(ERR_ERROR);
 
-    /* 1. the definition: every utterance on its own fresh CPU decoder */
+    /* 1. the definition: every utterance on its own fresh CPU decoder
+     *    (BATCH_CHECK_TIMING_ONLY=1 skips it and every comparison: throughput runs on big batches) */
     t0 = now_s();
-    for (i = 0; i < B; ++i) {
+    for (i = 0; i < B && !getenv("BATCH_CHECK_TIMING_ONLY"); ++i) {
         cpu = psgpu_batch_init(make_config(argv, nx, extra), 1, PSGPU_BATCH_CPU_ONLY);
         if (!cpu || psgpu_decode_batch(cpu, &cp[i], &n[i], 1, &ref[i]) < 0) { fprintf(stderr, "cpu decode failed\n"); return 2; }
         psgpu_batch_free(cpu);
@@ -106,6 +107,13 @@ main(int argc, char **argv)
     t0 = now_s();
     if (psgpu_decode_batch(dev, cp, n, B, got) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }
     t_batch = now_s() - t0;
+    if (getenv("BATCH_CHECK_TIMING_ONLY")) {
+        for (i = 0; i < B; ++i) frames += got[i].n_frames;
+        printf("{\"timing_only\": true, \"B\": %d, \"workers\": %d, \"flags\": %u, \"frames\": %d, \"batch_s\": %.4f, "
+               "\"frames_per_s\": %.1f, \"hyp0\": \"%s\"}\n", B, n_workers, flags, frames, t_batch, frames / t_batch, got[0].hyp);
+        psgpu_batch_free(dev);
+        return 0;
+    }
     for (i = 0; i < B; ++i) { rp[i] = cp[B - 1 - i]; rn[i] = n[B - 1 - i]; }
     if (psgpu_decode_batch(dev, rp, rn, B, rev) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }
     for (i = 0; i < B; ++i)

@@ -34,6 +34,8 @@
 #include "bin_mdef.h"
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
+#include "psgpu_phone_loop_shim.h"
+#include "phone_loop_search.h"
 #ifdef PSGPU_SEARCH_HOOKS
 #include "psgpu_search_hooks.h"
 #endif
@@ -106,7 +108,7 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
         const char *k = argv[i];
         if (k[0] == '-') ++k;
         if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search")
-            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe"))
+            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop"))
             continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
@@ -160,6 +162,27 @@ read_mfc(const char *path, int ceplen, int *out_nfr)
     return mfcs;
 }
 
+/* "psgpu_phone_loop yes": decoder B's phone-loop steps come from one device launch per utterance
+ * (integration/psgpu_phone_loop_shim.c).  Both decoders' steps are wrapped to record a hash of
+ * pls->penalties after every step: the only thing the phone loop hands to the n-gram search. */
+enum { MAX_PL = 1 << 18 };
+static ps_searchfuncs_t g_plvt[2], *g_plorig[2];
+static uint64_t *g_plhash[2];
+static int g_pln[2];
+static int
+pl_record(int which, ps_search_t *s, int frame_idx)
+{
+    phone_loop_search_t *pls = (phone_loop_search_t *)s;
+    int rv = g_plorig[which]->step(s, frame_idx), i;
+    uint64_t h = 1469598103934665603ULL;
+    const unsigned char *b = (const unsigned char *)pls->penalties;
+    for (i = 0; i < (int)(pls->n_phones * sizeof(int32)); ++i) { h ^= b[i]; h *= 1099511628211ULL; }
+    if (g_pln[which] < MAX_PL) g_plhash[which][g_pln[which]++] = h;
+    return rv;
+}
+static int pl_record_a(ps_search_t *s, int f) { return pl_record(0, s, f); }
+static int pl_record_b(ps_search_t *s, int f) { return pl_record(1, s, f); }
+
 static psgpu_fe_shim_t *g_fe;      /* "psgpu_fe yes": decoder B's cepstra come from the device */
 
 static void
@@ -208,7 +231,8 @@ main(int argc, char **argv)
 #else
     int use_search = 0;
 #endif
-    long hmm_batches = 0, hmm_evals = 0;
+    long hmm_batches = 0, hmm_evals = 0, pl_dev = 0, pl_host = 0;
+    int use_pl = 0, pl_bad = 0;
 
     if (argc < 6) {
         fprintf(stderr, "usage: dropin_decode MODELDIR LM|- DICT|- RAW NREP [key val ...]\n");
@@ -250,6 +274,7 @@ main(int argc, char **argv)
         }
         if (!strcmp(argv[i], "psgpu_mgau")) use_mgau = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_search")) use_search = !strcmp(argv[i + 1], "yes");
+        if (!strcmp(argv[i], "psgpu_phone_loop")) use_pl = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_fe") && !strcmp(argv[i + 1], "yes")) {
             g_fe = psgpu_fe_wrap(gpu->acmod->fe);
             if (!g_fe) { fprintf(stderr, "psgpu_fe_wrap failed\n"); return 3; }
@@ -267,6 +292,16 @@ main(int argc, char **argv)
 #else
     if (use_search) { fprintf(stderr, "built without the search hooks\n"); return 2; }
 #endif
+    if (use_pl) {
+        if (psgpu_phone_loop_attach(gpu) < 0) { fprintf(stderr, "psgpu_phone_loop_attach failed\n"); return 3; }
+        if (cpu->phone_loop && gpu->phone_loop) {
+            g_plhash[0] = malloc(sizeof(uint64_t) * MAX_PL); g_plhash[1] = malloc(sizeof(uint64_t) * MAX_PL);
+            g_plorig[0] = cpu->phone_loop->vt; g_plvt[0] = *g_plorig[0]; g_plvt[0].step = pl_record_a;
+            cpu->phone_loop->vt = &g_plvt[0];
+            g_plorig[1] = gpu->phone_loop->vt; g_plvt[1] = *g_plorig[1]; g_plvt[1].step = pl_record_b;
+            gpu->phone_loop->vt = &g_plvt[1];
+        }
+    }
     /* "mllr_after FILE": apply an MLLR transform AFTER attaching, so that the
      * shim's vt->transform (acmod_update_mllr, acmod.c:329) is what runs */
     for (i = 6; i + 1 < argc; i += 2)
@@ -276,8 +311,10 @@ main(int argc, char **argv)
             ps_update_mllr(cpu, ma);
             ps_update_mllr(gpu, mb);
         }
-    rec_install(&rc_cpu, cpu);
-    rec_install(&rc_gpu, gpu);
+    if (!use_pl) {       /* (the recorder replaces vt, which hides the psgpu scorer from the phone-loop shim) */
+        rec_install(&rc_cpu, cpu);
+        rec_install(&rc_gpu, gpu);
+    }
     n_res = nrep * n_in;
     ra = calloc(n_res, sizeof *ra);
     rb = calloc(n_res, sizeof *rb);
@@ -312,7 +349,17 @@ main(int argc, char **argv)
             free(pcm);
         }
     }
-    if (rc_cpu.n != rc_gpu.n) { ok = 0; bad_calls = -1; }
+    if (use_pl) {
+        /* the device phone loop makes no frame_eval calls of its own: the call sequences differ by
+         * construction; what must agree is every step's penalties vector and the decode results */
+        if (g_pln[0] != g_pln[1]) pl_bad = -1;
+        else for (i = 0; i < g_pln[0]; ++i) pl_bad += g_plhash[0][i] != g_plhash[1][i];
+        if (pl_bad) ok = 0;
+        cpu->phone_loop->vt = g_plorig[0]; gpu->phone_loop->vt = g_plorig[1];
+        psgpu_phone_loop_stats(gpu, &pl_dev, &pl_host);
+        psgpu_phone_loop_detach(gpu);
+    }
+    else if (rc_cpu.n != rc_gpu.n) { ok = 0; bad_calls = -1; }
     else
         for (i = 0; i < rc_cpu.n; ++i)
             if (rc_cpu.hash[i] != rc_gpu.hash[i] || rc_cpu.frame[i] != rc_gpu.frame[i]) {
@@ -325,8 +372,10 @@ main(int argc, char **argv)
     psgpu_search_detach(gpu);
 #endif
     /* detach recorders before the decoders free their scorers */
-    cpu->acmod->mgau->vt = rc_cpu.orig;
-    gpu->acmod->mgau->vt = rc_gpu.orig;
+    if (!use_pl) {
+        cpu->acmod->mgau->vt = rc_cpu.orig;
+        gpu->acmod->mgau->vt = rc_gpu.orig;
+    }
     {
         int n_seg = 0; const char *p;
         for (p = ra[0].seg; *p; ++p) n_seg += (*p == '\n');
@@ -336,14 +385,16 @@ main(int argc, char **argv)
                "\"score_cpu\": %d, \"score_gpu\": %d, \"n_seg\": %d, "
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
                "\"cache_served\": %ld, \"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
-               "\"total_frames\": %d, \"device_fe\": %s, \"utts\": [",
+               "\"total_frames\": %d, \"device_fe\": %s, \"pl_steps\": %d, \"pl_mismatch\": %d, \"pl_device_steps\": %ld, "
+               "\"pl_host_steps\": %ld, \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
                ra[n_res - 1].hyp, rb[n_res - 1].hyp, ra[n_res - 1].score, rb[n_res - 1].score,
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
                use_mgau ? psgpu_mgau_n_cache_served(gpu->acmod->mgau) : 0L,
-               use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames, g_fe ? "true" : "false");
+               use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames, g_fe ? "true" : "false",
+               g_pln[0], pl_bad, pl_dev, pl_host);
         for (u = 0; u < n_res; ++u)
             printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",
                    in_id[u % n_in], rb[u].hyp, rb[u].score);

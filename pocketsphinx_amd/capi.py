@@ -12,13 +12,13 @@ SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "psgpu_version", "psgpu_last_error", "psgpu_device_count", "psgpu_set_device",
-    "psgpu_malloc", "psgpu_free", "psgpu_memcpy_h2d", "psgpu_memcpy_d2h", "psgpu_stream_sync",
+    "psgpu_malloc", "psgpu_free", "psgpu_host_alloc", "psgpu_host_free", "psgpu_memcpy_h2d", "psgpu_memcpy_d2h", "psgpu_stream_sync",
     "psgpu_ptm_model_create", "psgpu_ptm_model_free", "psgpu_ptm_n_sen", "psgpu_ptm_n_chain",
     "psgpu_ptm_veclen", "psgpu_ptm_topn", "psgpu_ptm_score_batch_dev", "psgpu_ptm_score_batch",
     "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",
     "psgpu_ptm_topn_dev", "psgpu_ptm_senone_dev", "psgpu_ptm_kernel_timing", "psgpu_ptm_last_kernel_ms",
     "psgpu_ptm_state_create", "psgpu_ptm_state_free", "psgpu_ptm_state_reset",
-    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn", "psgpu_ptm_state_lookahead", "psgpu_ptm_state_lookahead_stats",
+    "psgpu_ptm_frame_eval", "psgpu_ptm_state_get_topn", "psgpu_ptm_state_set_topn", "psgpu_ptm_state_lookahead", "psgpu_ptm_state_lookahead_stats", "psgpu_ptm_state_lookahead_rows", "psgpu_ptm_state_mark_fresh",
     "psgpu_semi_model_create", "psgpu_semi_model_free", "psgpu_semi_state_create",
     "psgpu_semi_state_free", "psgpu_semi_state_reset", "psgpu_semi_frame_eval",
     "psgpu_semi_score_batch_dev", "psgpu_semi_score_batch",
@@ -30,7 +30,7 @@ SYMBOLS = [
     "psgpu_fe_create", "psgpu_fe_free", "psgpu_fe_out_dim", "psgpu_fe_n_frames",
     "psgpu_fe_process_utts_dev", "psgpu_fe_process_utts",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
-    "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval",
+    "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval", "psgpu_phone_loop_run_dev", "psgpu_hmm_ctx_stream",
 ]
 
 

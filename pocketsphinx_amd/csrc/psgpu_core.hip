@@ -73,6 +73,19 @@ int psgpu_free(void *p)
     return PSGPU_OK;
 }
 
+int psgpu_host_alloc(void **p, size_t bytes)
+{
+    PSGPU_REQUIRE(p != nullptr, "psgpu_host_alloc: NULL argument");
+    PSGPU_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return PSGPU_OK;
+}
+
+int psgpu_host_free(void *p)
+{
+    if (p) PSGPU_HIP(hipHostFree(p));
+    return PSGPU_OK;
+}
+
 int psgpu_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
     PSGPU_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));

@@ -43,6 +43,8 @@ struct psgpu_hmm_ctx_s {
     // per-launch completion arguments (nullptr for the plain device entry)
     uint32_t *launch_done_count, *launch_done_word;
     uint32_t launch_seq;
+    // phone-loop scratch
+    int16_t *pl_css; int32_t pl_cap;        // [frames][64][4 or 8] normalised CI state scores
 };
 
 constexpr int32_t kZeroCopyMax = 2048;
@@ -421,6 +423,178 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// The phone-loop search of a whole utterance in one launch:
+// phone_loop_search_start (phone_loop_search.c:165-184) followed by
+// phone_loop_search_step (:302-340) for every frame -- evaluate_hmms,
+// store_scores, prune_hmms, phone_transition (:201-300) and the renormalisation
+// test (:320-325) -- on un-normalised senone score rows that are already on the
+// device.  One wavefront per utterance, lane = CI phone (n_phones <= 64): the
+// search is a recurrence over frames, its per-frame work is 42 HMMs.  Histories
+// are not tracked: nothing reads them (the search produces no back-pointers,
+// only pls->penalties).  Per frame the kernel leaves the penalties, the ring
+// value behind them and the HMM state, so that a host decoder can take any
+// frame's vector as pls->penalties and resume stepping on the host from any
+// frame.
+// ---------------------------------------------------------------------------
+struct PlDev {
+    int32_t n_phones, window, beam, pbeam, pip, n_list, norm_mode;
+    double weight;
+    const uint16_t *ssid;      // [n_phones]
+    const int16_t *tmatid;     // [n_phones]
+    const uint16_t *ci_list;   // [n_list] senones the all-phones-active list holds (acmod_flags2list incl. bridges)
+};
+
+constexpr int kPlMaxWindow = 32;
+
+// DPP wave maximum (same sequence as psgpu_ptm_dev.h): ~20 cycles instead of six
+// dependent ds_bpermute round trips -- the search below is one wave marching through
+// the frames, its step latency is the whole cost.
+__device__ __forceinline__ int32_t pl_wave_max(int32_t v)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Pre-pass, parallel over frames (one wave per frame): the frame's normaliser -- what
+// acmod_score subtracts for the all-phones-active list (ptm_mgau.c:393-400), or the
+// all-senone minimum under -compallsen -- and every CI phone's normalised state scores
+// packed as 4 x int16 per phone, so that the sequential kernel reads 8 contiguous bytes
+// per lane per frame.
+template <int NE>
+__global__ __launch_bounds__(256)
+void phone_loop_prep_kernel(PlDev p, const uint16_t *__restrict__ sseq, const int16_t *__restrict__ raw,
+                            int64_t raw_stride, const int32_t *__restrict__ best_all, int32_t total,
+                            int16_t *__restrict__ css)                 // [total][64][NE <= 3 ? 4 : 8]
+{
+    constexpr int W = NE <= 3 ? 4 : 8;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= total) return;
+    const int16_t *row = raw + (size_t)t * raw_stride;
+    int32_t nb;
+    if (p.norm_mode == 2) nb = best_all[t];
+    else {
+        nb = 0x7fffffff;
+        for (int i = lane; i < p.n_list; i += 64) nb = min(nb, (int32_t)row[p.ci_list[i]]);
+        nb = -pl_wave_max(-nb);
+    }
+    int16_t v[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = 0;
+    if (lane < p.n_phones) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            v[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)row[sseq[(size_t)p.ssid[lane] * NE + i]] - (uint32_t)nb);
+    }
+    int16_t *o = css + ((size_t)t * 64 + lane) * W;
+#pragma unroll
+    for (int i = 0; i < W; ++i) o[i] = v[i];
+}
+
+template <int NE>
+__global__ __launch_bounds__(64)
+void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t *__restrict__ css,
+                       const int32_t *__restrict__ utt_off, int32_t *__restrict__ penalties,
+                       int32_t *__restrict__ pen_now, int32_t *__restrict__ state)
+{
+    constexpr int W = NE <= 3 ? 4 : 8;
+    constexpr int kAhead = 4;                                     // frames fetched ahead of the one being searched
+    __shared__ int32_t s_ring[kPlMaxWindow][64];
+    const int lane = threadIdx.x, u = blockIdx.x;
+    const int t0 = utt_off[u], T = utt_off[u + 1] - t0;
+    if (T <= 0) return;
+    const bool on = lane < p.n_phones;
+    const int ph = on ? lane : 0;
+    HmmRegs h;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { h.score[i] = kW; h.history[i] = -1; h.senid[i] = (uint16_t)i; }
+    h.out_score = kW; h.out_history = -1; h.bestscore = kW;
+    // hmm_clear + hmm_enter(hmm, 0, -1, 0) (:170-175)
+    h.score[0] = 0;
+    int frame = 0;
+    // this phone's transition matrix in registers
+    uint8_t tpl[NE * (NE + 1)];
+#pragma unroll
+    for (int i = 0; i < NE * (NE + 1); ++i) tpl[i] = tp_g[(size_t)p.tmatid[ph] * NE * (NE + 1) + i];
+    for (int w = 0; w < p.window; ++w) s_ring[w][lane] = 0;       // memset(pen_buf, 0) (:177-178)
+    int ptr = 0;
+    int32_t best_score = 0;                                       // pls->best_score (:180)
+    // a small register queue of upcoming frames' scores: the march never waits for memory
+    typedef int16_t vec_t __attribute__((ext_vector_type(W)));
+    const vec_t *in = reinterpret_cast<const vec_t *>(css) + (size_t)t0 * 64 + lane;
+    vec_t q[kAhead];
+#pragma unroll
+    for (int a = 0; a < kAhead; ++a) q[a] = in[(size_t)min(a, T - 1) * 64];
+    for (int t = 0; t < T; ++t) {
+        int16_t ss[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) ss[i] = q[0][i];
+#pragma unroll
+        for (int a = 0; a + 1 < kAhead; ++a) q[a] = q[a + 1];
+        q[kAhead - 1] = in[(size_t)min(t + kAhead, T - 1) * 64];
+        // renormalize_hmms (:186-199): every phone, whether active or not
+        if (best_score + 2 * p.beam < kW) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) if (h.score[i] > kW) h.score[i] -= best_score;
+            if (h.out_score > kW) h.out_score -= best_score;
+        }
+        // evaluate_hmms (:201-221)
+        int32_t sc = kW;
+        const bool act = on && frame >= t;
+        if (act) sc = (NE == 3) ? vit3(h, tpl, ss) : vit5(h, tpl, ss);
+        const int32_t bs = pl_wave_max(act ? max(sc, kW) : kW);
+        best_score = bs;
+        // store_scores (:223-245): (int32)((bestscore - best) * pl_weight), then the window maximum
+        const int32_t pen = (int32_t)((double)(h.bestscore - bs) * p.weight);
+        s_ring[ptr][lane] = pen;
+        ptr = (ptr + 1 == p.window) ? 0 : ptr + 1;
+        int32_t mx = kW;
+        for (int w = 0; w < p.window; ++w) mx = max(mx, s_ring[w][lane]);
+        if (on) {
+            penalties[(size_t)(t0 + t) * p.n_phones + lane] = mx;
+            pen_now[(size_t)(t0 + t) * p.n_phones + lane] = pen;
+        }
+        // prune_hmms (:247-266)
+        if (act) {
+            if (h.bestscore > bs + p.beam) frame = t + 1;
+            else {                                                // hmm_clear_scores
+#pragma unroll
+                for (int i = 0; i < NE; ++i) h.score[i] = kW;
+                h.out_score = kW; h.bestscore = kW;
+            }
+        }
+        // phone_transition (:268-300): every phone is entered by the best exiting phone
+        const int32_t np = (on && frame == t + 1) ? h.out_score + p.pip : kMaxNegInt32;
+        const bool exits = on && frame == t + 1 && np > bs + p.pbeam;
+        const int32_t m = pl_wave_max(exits ? np : kMaxNegInt32);
+        if (m != kMaxNegInt32 && on) {
+            if (frame < t || m > h.score[0]) { h.score[0] = m; frame = t + 1; }
+        }
+        if (on) {
+            int32_t *st = state + ((size_t)(t0 + t) * p.n_phones + lane) * 8;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) st[i] = h.score[i];
+            st[5] = h.out_score; st[6] = h.bestscore; st[7] = frame;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -478,7 +652,7 @@ void psgpu_hmm_ctx_free(psgpu_hmm_ctx_t *c)
     if (c->z_recs) hipHostFree(c->z_recs);
     if (c->z_scr) hipHostFree(c->z_scr);
     if (c->z_word) hipHostFree(c->z_word);
-    hipFree(c->d_count);
+    hipFree(c->d_count); hipFree(c->pl_css);
     delete c;
 }
 
@@ -507,6 +681,52 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
                            recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
                            (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,
                            c->launch_done_count, c->launch_done_word, c->launch_seq);
+    PSGPU_HIP(hipGetLastError());
+    return PSGPU_OK;
+}
+
+void *psgpu_hmm_ctx_stream(psgpu_hmm_ctx_t *c) { return c ? (void *)c->stream : nullptr; }
+
+int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
+                             const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                             const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
+                             const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                             int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream)
+{
+    PSGPU_REQUIRE(c && pp && n_utt >= 0, "psgpu_phone_loop_run_dev: bad argument");
+    if (n_utt == 0) return PSGPU_OK;
+    PSGPU_REQUIRE(ssid_dev && tmatid_dev && raw_dev && utt_off_dev && penalties_dev && pen_now_dev && state_dev,
+                  "psgpu_phone_loop_run_dev: NULL device buffer");
+    PSGPU_REQUIRE(pp->n_phones >= 1 && pp->n_phones <= 64, "n_phones %d outside 1..64", pp->n_phones);
+    PSGPU_REQUIRE(pp->window >= 1 && pp->window <= kPlMaxWindow, "window %d outside 1..%d", pp->window, kPlMaxWindow);
+    PSGPU_REQUIRE((best_dev != nullptr) != (ci_list_dev != nullptr && n_list > 0),
+                  "exactly one of best_dev (compallsen) and ci_list_dev (active-list normalisation) is needed");
+    PlDev p;
+    p.n_phones = pp->n_phones; p.window = pp->window; p.beam = pp->beam; p.pbeam = pp->pbeam; p.pip = pp->pip;
+    p.n_list = n_list; p.norm_mode = best_dev ? 2 : 1; p.weight = pp->penalty_weight;
+    p.ssid = ssid_dev; p.tmatid = tmatid_dev; p.ci_list = ci_list_dev;
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;     // NULL: the context's own stream
+    PSGPU_REQUIRE(total_frames >= 0, "negative frame count");
+    if (total_frames == 0) return PSGPU_OK;
+    const int W = c->n_emit <= 3 ? 4 : 8;
+    if (total_frames > c->pl_cap) {
+        PSGPU_HIP(hipFree(c->pl_css)); c->pl_css = nullptr; c->pl_cap = 0;
+        PSGPU_HIP(hipMalloc((void **)&c->pl_css, sizeof(int16_t) * (size_t)total_frames * 64 * W));
+        c->pl_cap = total_frames;
+    }
+    const dim3 pg((total_frames + 3) / 4);
+    if (c->n_emit == 3) {
+        hipLaunchKernelGGL((phone_loop_prep_kernel<3>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, raw_dev, raw_stride,
+                           best_dev, total_frames, c->pl_css);
+        hipLaunchKernelGGL((phone_loop_kernel<3>), dim3(n_utt), dim3(64), 0, st, p, (const uint8_t *)c->tp,
+                           (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev);
+    }
+    else {
+        hipLaunchKernelGGL((phone_loop_prep_kernel<5>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, raw_dev, raw_stride,
+                           best_dev, total_frames, c->pl_css);
+        hipLaunchKernelGGL((phone_loop_kernel<5>), dim3(n_utt), dim3(64), 0, st, p, (const uint8_t *)c->tp,
+                           (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev);
+    }
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }

@@ -510,6 +510,34 @@ int psgpu_ptm_state_lookahead(psgpu_ptm_state_t *s, const float *feats, int32_t 
     return PSGPU_OK;
 }
 
+int psgpu_ptm_state_lookahead_rows(psgpu_ptm_state_t *s, const int16_t **raw_dev, const int32_t **best_dev,
+                                   int32_t *frame0, int32_t *n_frames)
+{
+    PSGPU_REQUIRE(s && raw_dev && best_dev && frame0 && n_frames, "psgpu_ptm_state_lookahead_rows: NULL argument");
+    if (!s->la.valid || s->la.next_fresh != s->la.c0) {
+        psgpu_set_error("no look-ahead cache at its first frame");
+        return PSGPU_ESTATE;
+    }
+    if (!s->la.computed) {
+        const int rc = la_compute(s);
+        if (rc != PSGPU_OK) return rc;
+    }
+    *raw_dev = s->la.d_raw; *best_dev = s->la.d_best; *frame0 = s->la.c0; *n_frames = s->la.cn;
+    return PSGPU_OK;
+}
+
+int psgpu_ptm_state_mark_fresh(psgpu_ptm_state_t *s, int32_t frame)
+{
+    PSGPU_REQUIRE(s != nullptr, "psgpu_ptm_state_mark_fresh: NULL state");
+    if (!(s->la.valid && s->la.computed && frame >= s->la.c0 && frame < s->la.limit && frame == s->la.next_fresh)) {
+        psgpu_set_error("frame %d is not the next fresh frame of a computed look-ahead cache", frame);
+        return PSGPU_ESTATE;
+    }
+    s->cur = frame % s->n_hist;
+    s->la.max_fresh = frame; s->la.next_fresh = frame + 1; s->la.flushed = 0;
+    return PSGPU_OK;
+}
+
 int psgpu_ptm_state_lookahead_stats(psgpu_ptm_state_t *s, int64_t *served, int64_t *batches)
 {
     PSGPU_REQUIRE(s != nullptr, "psgpu_ptm_state_lookahead_stats: NULL state");

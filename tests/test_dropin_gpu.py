@@ -359,6 +359,8 @@ FILES = ["goforward.raw", "numbers.raw", "something.raw", "librivox-0870.raw", "
     (4, 3, True, ()),         # + hmm_vit_eval loops on the device (hooked library)
     (3, 1, False, ("fwdflat", "no", "bestpath", "no")),   # pass 1 only: its scores are not masked by later passes
     (2, 1, False, ("fwdtree", "no")),                     # pass 2 only
+    (3, 9, False, ("fwdflat", "no", "bestpath", "no")),   # + each utterance's phone loop in one device launch
+    (3, 9, False, ()),
 ])
 def test_decode_batch_api(workers, flags, full, extra):
     """psgpu_decode_batch (the additive batch call): every utterance's
@@ -395,3 +397,36 @@ def test_decode_batch_api_refuses_without_device():
     p = subprocess.run([binary, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"), "1", "0",
                         os.path.join(DATA, "goforward.raw")], capture_output=True, text=True, timeout=300)
     assert p.returncode == 3, (p.returncode, p.stdout, p.stderr[-500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw,nrep,extra,full", [
+    ("goforward.raw", 2, (), False),                                   # 3-pass, two utterances
+    ("numbers.raw", 1, ("fwdflat", "no", "bestpath", "no"), False),    # pass 1 alone: nothing masks its scores
+    ("librivox-0870.raw", 1, ("compallsen", "yes"), False),            # normaliser = the all-senone minimum
+    ("something.raw", 1, ("pl_window", "2", "pl_weight", "1.5"), False),
+    ("goforward.raw", 1, ("psgpu_search", "yes", "psgpu_fe", "yes"), True),   # with every other device component
+])
+def test_dropin_device_phone_loop(raw, nrep, extra, full):
+    """psgpu_phone_loop yes: the whole phone-loop search of an utterance is one
+    device launch on the scorer's device-resident rows; the decoder's phone_loop_search_t only
+    receives pls->penalties per step and makes no frame_eval calls of its own.  Every step's
+    penalties vector must equal the CPU decoder's, and hypothesis, path score and segmentation
+    (whose acoustic scores depend on every frame's normalisation) must be identical."""
+    r = run(raw, nrep, "psgpu_phone_loop", "yes", *extra, binary=BIN_FULL if full else None)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["pl_mismatch"] == 0 and r["pl_steps"] > 0 and r["hyp_equal"] and r["seg_equal"], r
+    assert r["pl_device_steps"] == r["pl_steps"] and r["pl_host_steps"] == 0, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("break_at", [1, 7, 123])
+def test_dropin_device_phone_loop_resumes_on_host(break_at, monkeypatch):
+    """Leaving the device path in the middle of an utterance (test hook PSGPU_PL_BREAK_AT): the
+    reference's HMMs and penalty ring are loaded with the device's state of the previous frame and
+    the reference's own step carries on -- penalties and results still identical."""
+    monkeypatch.setenv("PSGPU_PL_BREAK_AT", str(break_at))
+    r = run("goforward.raw", 1, "psgpu_phone_loop", "yes", "fwdflat", "no", "bestpath", "no")
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["pl_mismatch"] == 0 and r["hyp_equal"] and r["seg_equal"], r
+    assert r["pl_device_steps"] == break_at and r["pl_host_steps"] == r["pl_steps"] - break_at, r
