@@ -40,6 +40,7 @@ const char *psgpu_version(void);
 const char *psgpu_last_error(void);          /* thread-local message */
 int psgpu_device_count(void);                /* >=0, or PSGPU_ENODEV */
 int psgpu_set_device(int device);
+int psgpu_get_device(void);                  /* the calling thread's current device, or PSGPU_ENODEV */
 /* device memory helpers so that a C host needs no HIP headers */
 int psgpu_malloc(void **dev_ptr, size_t bytes);
 int psgpu_free(void *dev_ptr);

@@ -32,6 +32,7 @@
 struct psgpu_batch_s {
     int n_workers;
     unsigned flags;
+    int device;                    /* the device the decoders' psgpu objects live on */
     ps_decoder_t **ps;
     psgpu_fe_t *fe;                /* batch front end (tables of worker 0's fe_t) */
     int out_dim;
@@ -164,6 +165,10 @@ worker(void *arg)
 {
     worker_arg_t *a = arg;
     psgpu_batch_t *b = a->b;
+    /* HIP's current device is per thread: a worker must be on the device its decoder's
+     * model, state and stream were created on (one process per GPU, or psgpu_set_device
+     * before psgpu_batch_init in a multi-GPU process) */
+    if (b->device >= 0) psgpu_set_device(b->device);
     for (;;) {
         int u = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED);
         if (u >= b->B) break;
@@ -188,6 +193,7 @@ psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
 #endif
     b = calloc(1, sizeof *b);
     b->n_workers = n_workers; b->flags = flags;
+    b->device = (flags & PSGPU_BATCH_CPU_ONLY) ? -1 : psgpu_get_device();
     b->ps = calloc(n_workers, sizeof *b->ps);
     for (w = 0; w < n_workers; ++w) {
         b->ps[w] = ps_init(config);                        /* ps_init retains the config */

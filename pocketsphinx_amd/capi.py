@@ -12,7 +12,7 @@ SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "psgpu_version", "psgpu_last_error", "psgpu_device_count", "psgpu_set_device",
-    "psgpu_malloc", "psgpu_free", "psgpu_host_alloc", "psgpu_host_free", "psgpu_memcpy_h2d", "psgpu_memcpy_d2h", "psgpu_stream_sync",
+    "psgpu_get_device", "psgpu_malloc", "psgpu_free", "psgpu_host_alloc", "psgpu_host_free", "psgpu_memcpy_h2d", "psgpu_memcpy_d2h", "psgpu_stream_sync",
     "psgpu_ptm_model_create", "psgpu_ptm_model_free", "psgpu_ptm_n_sen", "psgpu_ptm_n_chain",
     "psgpu_ptm_veclen", "psgpu_ptm_topn", "psgpu_ptm_score_batch_dev", "psgpu_ptm_score_batch",
     "psgpu_event_create", "psgpu_event_destroy", "psgpu_event_record", "psgpu_event_elapsed_ms",

@@ -73,6 +73,13 @@ int psgpu_free(void *p)
     return PSGPU_OK;
 }
 
+int psgpu_get_device(void)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return PSGPU_ENODEV;
+    return d;
+}
+
 int psgpu_host_alloc(void **p, size_t bytes)
 {
     PSGPU_REQUIRE(p != nullptr, "psgpu_host_alloc: NULL argument");
