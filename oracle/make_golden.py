@@ -241,6 +241,39 @@ def mfcc_only():
         print("mfcc_%s:" % name, [int(v) for v in d["par"][:12]], d["cep"].shape)
 
 
+FT_STATIC = ["node_ci", "node_ci2", "node_ssid", "node_tmat", "node_child", "node_sib", "node_penult_wid",
+             "homophone_set", "w1_wid", "w1_ci", "w1_ci2", "w1_ssid", "w1_tmat", "w1_mpx", "dict_pronlen", "dict_first",
+             "dict_last", "dict_last2", "dict_basewid", "dict_filler", "dict_real", "rssid_n", "rssid_ssid", "rssid_cimap",
+             "ldiph_lc", "tp", "sseq", "ci_tmat", "lm"]
+
+
+def fwdtree_only():
+    """Lexicon-tree search goldens (ref_dump fwdtree): the static search tables of a (model, dictionary,
+    LM) triple once, and per decode the trace the search consumed (senone scores, phone-loop
+    penalties) with the back-pointer table it produced."""
+    tdm = os.path.join(REF, "model", "tidigits")
+    tdl = os.path.join(REF, "data", "tidigits")
+    base = ("fwdflat", "no", "bestpath", "no")
+    cases = [
+        ("en_us_turtle", "goforward", dict(), "goforward.raw", base),
+        ("en_us_turtle", "numbers", dict(), "numbers.raw", base),
+        ("en_us_turtle", "goforward_maxhmmpf60_maxwpf3", dict(), "goforward.raw", base + ("maxhmmpf", "60", "maxwpf", "3")),
+        ("en_us_turtle", "something_plwindow0", dict(), "something.raw", base + ("pl_window", "0")),
+        ("tidigits", "man_ah_2934za", dict(model=tdm, lm=os.path.join(tdl, "tidigits.lm.bin"), dic=os.path.join(tdl, "tidigits.dic")),
+         os.path.join("tidigits", "man.ah.2934za.mfc"), base),
+    ]
+    done = set()
+    for static, name, kw, audio, extra in cases:
+        d = ref_dump("fwdtree", os.path.join(REF, "data", audio), extra=extra, **kw)
+        if static not in done:
+            np.savez_compressed(os.path.join(GOLD, "fwdtree_static_%s.npz" % static), **{k: d[k] for k in FT_STATIC})
+            done.add(static)
+        tr = {k: v for k, v in d.items() if k not in FT_STATIC}
+        tr["static"] = np.frombuffer(static.encode(), np.uint8)
+        np.savez_compressed(os.path.join(GOLD, "fwdtree_trace_%s.npz" % name), **tr)
+        print("fwdtree", name, "steps", int(d["n_steps"][0]), "bp", d["bp"].shape[0])
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -258,6 +291,8 @@ if __name__ == "__main__":
         semi_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ms":
         ms_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree":
+        fwdtree_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "mfcc":
         mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":

@@ -1,0 +1,54 @@
+/* oracle/ps_oracle_search.h -- TEST INFRASTRUCTURE: the lexicon-tree search oracle
+ * (see ps_oracle_search.c).  Only tests/ may use it. */
+#ifndef PS_ORACLE_SEARCH_H
+#define PS_ORACLE_SEARCH_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* bptbl_t (ngram_search.h:112-124), every field widened to int32 */
+typedef struct pso_bp_s {
+    int32_t frame, valid, wid, bp, score, s_idx, real_wid, prev_real_wid, last_phone, last2_phone;
+} pso_bp_t;
+
+/* the arrays `ref_dump fwdtree` writes (same names) */
+typedef struct pso_ft_tables_s {
+    const int32_t *par;                       /* [32], see ref_dump.c cmd_fwdtree */
+    const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_child, *node_sib, *node_penult_wid;   /* [R + M] */
+    const int32_t *homophone_set;             /* [n_w] */
+    const int32_t *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx;                                    /* [n_1ph] */
+    const int32_t *dict_pronlen, *dict_first, *dict_last, *dict_last2, *dict_basewid, *dict_filler;        /* [n_w] */
+    const int32_t *rssid_n;                   /* [n_ci][n_ci] */
+    const int32_t *rssid_ssid, *rssid_cimap;  /* [n_ci][n_ci][n_ci] */
+    const int32_t *ldiph_lc;                  /* [n_ci][n_ci][n_ci] */
+    const uint8_t *tp;                        /* [n_tmat][n_emit][n_emit + 1] */
+    const uint16_t *sseq;                     /* [n_sseq][n_emit] */
+    const int32_t *ci_tmat;                   /* [n_ci] */
+    const int32_t *lm;                        /* [n_w][n_w + 1][n_w + 1] */
+} pso_ft_tables_t;
+
+typedef struct pso_ft_s pso_ft_t;
+
+pso_ft_t *pso_ft_new(const pso_ft_tables_t *t);     /* the tables must outlive the object */
+void pso_ft_free(pso_ft_t *s);
+void pso_ft_start(pso_ft_t *s);
+/* the senone ids compute_sen_active + acmod_flags2list would list for `frame` (bridging entries
+ * included); out has room for n_sen entries */
+int pso_ft_active_list(pso_ft_t *s, int frame, int32_t *out);
+int pso_ft_step(pso_ft_t *s, int frame, const int32_t *ids, const int16_t *scr, int n, int16_t rest,
+                const int32_t *penalties);
+void pso_ft_finish(pso_ft_t *s, int n_frames);
+int32_t pso_ft_best_score(const pso_ft_t *s);
+int32_t pso_ft_last_phone_best_score(const pso_ft_t *s);
+int32_t pso_ft_bpidx(const pso_ft_t *s);
+int32_t pso_ft_bss_head(const pso_ft_t *s);
+const pso_bp_t *pso_ft_bp(const pso_ft_t *s);
+const int32_t *pso_ft_bss(const pso_ft_t *s);
+const int32_t *pso_ft_bp_table_idx(const pso_ft_t *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -805,6 +805,264 @@ cmd_mfcc(fe_t *fe, const char *rawpath, int nrep)
 }
 
 /* ------------------------------------------------------------------ */
+/* fwdtree: everything the lexicon-tree search of one utterance consumes and
+ * produces (ngram_search_fwdtree.c), for pinning oracle/ps_oracle_search.c:
+ *   static  the tree as create_search_channels built it, flattened (roots first,
+ *           then the other nodes in depth-first order), single-phone word
+ *           channels, dictionary and dict2pid tables, beams and penalties, and
+ *           the language model as a dense table over dictionary word ids
+ *           (ngram_tg_score(w3, w2, w1) >> SENSCR_SHIFT for every triple, -1 =
+ *           no history) -- small vocabularies only;
+ *   trace   per fwdtree frame: the senone scores acmod_score handed to the
+ *           search (active ids + scores + the value of every other entry) and the
+ *           phone-loop penalties it read;
+ *   result  the back-pointer table and score stack after ngram_fwdtree_finish,
+ *           per-frame marks, best scores, hypothesis.
+ * Run with fwdflat/bestpath off so that nothing else touches the tables. */
+#include "ngram_search.h"
+#include "phone_loop_search.h"
+#include "dict2pid.h"
+#include "lm/ngram_model.h"
+
+static ps_searchfuncs_t ft_vt, *ft_orig;
+static int ft_in_step = -1;                 /* frame of the fwdtree step in progress */
+static ps_decoder_t *ft_ps;
+static int32 *ft_pen; static size_t ft_pen_n, ft_pen_cap;
+static int32 *ft_step_frame, *ft_best, *ft_bpidx, *ft_lpbest; static size_t ft_n, ft_cap;
+static int32 *ft_act; static int16 *ft_scr; static size_t ft_act_n, ft_act_cap;
+static int64_t *ft_act_off; static int16 *ft_rest;
+static ps_mgaufuncs_t ft_mvt, *ft_morig;
+
+static int
+ft_frame_eval(ps_mgau_t *mg, int16 *senscr, uint8 *act, int32 nact, mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    int r = ft_morig->frame_eval(mg, senscr, act, nact, feat, frame, compallsen);
+    if (ft_in_step >= 0 && frame == ft_in_step) {
+        /* the search's own call: absolute ids of the listed senones and their scores */
+        int i, sen = 0, n_sen = bin_mdef_n_sen(ft_ps->acmod->mdef);
+        uint8 *listed = calloc(n_sen, 1);
+        if (compallsen) nact = n_sen;                  /* every senone is "listed" */
+        if (ft_act_n + nact > ft_act_cap) {
+            ft_act_cap = (ft_act_n + nact) * 2 + 1024;
+            ft_act = realloc(ft_act, sizeof(int32) * ft_act_cap);
+            ft_scr = realloc(ft_scr, sizeof(int16) * ft_act_cap);
+        }
+        ft_act_off[ft_n] = (int64_t)ft_act_n;
+        for (i = 0; i < nact; ++i) {
+            sen = compallsen ? i : sen + act[i];
+            ft_act[ft_act_n] = sen; ft_scr[ft_act_n] = senscr[sen]; ++ft_act_n;
+            listed[sen] = 1;
+        }
+        ft_rest[ft_n] = 0;
+        for (i = 0; i < n_sen; ++i) if (!listed[i]) { ft_rest[ft_n] = senscr[i]; break; }
+        free(listed);
+    }
+    return r;
+}
+
+static int
+ft_step(ps_search_t *search, int frame_idx)
+{
+    ngram_search_t *ngs = (ngram_search_t *)search;
+    phone_loop_search_t *pls = (phone_loop_search_t *)ps_search_lookahead(search);
+    int n_ci = bin_mdef_n_ciphone(ps_search_acmod(search)->mdef), rv, i;
+    if (ft_n == ft_cap) {
+        ft_cap = ft_cap ? ft_cap * 2 : 1024;
+        ft_step_frame = realloc(ft_step_frame, sizeof(int32) * ft_cap);
+        ft_best = realloc(ft_best, sizeof(int32) * ft_cap);
+        ft_lpbest = realloc(ft_lpbest, sizeof(int32) * ft_cap);
+        ft_bpidx = realloc(ft_bpidx, sizeof(int32) * ft_cap);
+        ft_act_off = realloc(ft_act_off, sizeof(int64_t) * (ft_cap + 1));
+        ft_rest = realloc(ft_rest, sizeof(int16) * ft_cap);
+    }
+    if (ft_pen_n + n_ci > ft_pen_cap) {
+        ft_pen_cap = (ft_pen_n + n_ci) * 2;
+        ft_pen = realloc(ft_pen, sizeof(int32) * ft_pen_cap);
+    }
+    for (i = 0; i < n_ci; ++i) ft_pen[ft_pen_n + i] = pls ? pls->penalties[i] : 0;
+    ft_pen_n += n_ci;
+    ft_act_off[ft_n] = (int64_t)ft_act_n;
+    ft_rest[ft_n] = 0;
+    ft_in_step = frame_idx;
+    rv = ft_orig->step(search, frame_idx);
+    ft_in_step = -1;
+    ft_step_frame[ft_n] = frame_idx; ft_best[ft_n] = ngs->best_score; ft_lpbest[ft_n] = ngs->last_phone_best_score;
+    ft_bpidx[ft_n] = ngs->bpidx;
+    ++ft_n;
+    ft_act_off[ft_n] = (int64_t)ft_act_n;
+    return rv;
+}
+
+/* depth-first numbering of the non-root tree nodes */
+static int
+ft_number(chan_t *first, chan_t **nodes, int n)
+{
+    chan_t *h;
+    for (h = first; h; h = h->alt) {
+        nodes[n++] = h;
+        n = ft_number(h->next, nodes, n);
+    }
+    return n;
+}
+static int ft_index(chan_t **nodes, int n, chan_t *h, int base)
+{
+    int i;
+    if (h == NULL) return -1;
+    for (i = 0; i < n; ++i) if (nodes[i] == h) return base + i;
+    return -2;
+}
+
+static int
+cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
+{
+    ngram_search_t *ngs = (ngram_search_t *)ps->search;
+    acmod_t *acmod = ps->acmod;
+    bin_mdef_t *mdef = acmod->mdef;
+    dict_t *dict = ps_search_dict(ngs);
+    dict2pid_t *d2p = ps_search_dict2pid(ngs);
+    int n_ci = bin_mdef_n_ciphone(mdef), n_emit = bin_mdef_n_emit_state(mdef), n_w = dict_size(dict);
+    int R = ngs->n_root_chan, M, i, j, k, w;
+    chan_t **nodes;
+    int32 par[32];
+
+    if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM) || !ngs->fwdtree || ngs->fwdflat || ngs->bestpath) {
+        fprintf(stderr, "fwdtree dump needs an n-gram search with -fwdflat no -bestpath no\n");
+        return 2;
+    }
+    /* ---- the tree */
+    nodes = calloc(ngs->n_nonroot_chan + 16, sizeof *nodes);
+    for (M = 0, i = 0; i < R; ++i) M = ft_number(ngs->root_chan[i].next, nodes, M);
+    {
+        int N = R + M;
+        int32 *ci = calloc(N, 4), *ci2 = calloc(N, 4), *ssid = calloc(N, 4), *tm = calloc(N, 4), *child = calloc(N, 4),
+              *sib = calloc(N, 4), *pw = calloc(N, 4);
+        for (i = 0; i < R; ++i) {
+            root_chan_t *r = &ngs->root_chan[i];
+            ci[i] = r->ciphone; ci2[i] = r->ci2phone; ssid[i] = hmm_mpx_ssid(&r->hmm, 0); tm[i] = r->hmm.tmatid;
+            child[i] = ft_index(nodes, M, r->next, R); sib[i] = -1; pw[i] = r->penult_phn_wid;
+        }
+        for (i = 0; i < M; ++i) {
+            chan_t *h = nodes[i];
+            ci[R + i] = h->ciphone; ci2[R + i] = -1; ssid[R + i] = hmm_nonmpx_ssid(&h->hmm); tm[R + i] = h->hmm.tmatid;
+            child[R + i] = ft_index(nodes, M, h->next, R); sib[R + i] = ft_index(nodes, M, h->alt, R);
+            pw[R + i] = h->info.penult_phn_wid;
+        }
+        put1("node_ci", 'i', N, ci); put1("node_ci2", 'i', N, ci2); put1("node_ssid", 'i', N, ssid);
+        put1("node_tmat", 'i', N, tm); put1("node_child", 'i', N, child); put1("node_sib", 'i', N, sib);
+        put1("node_penult_wid", 'i', N, pw);
+    }
+    put1("homophone_set", 'i', n_w, ngs->homophone_set);
+    {   /* single-phone words (permanent channels) */
+        int n1 = ngs->n_1ph_words;
+        int32 *sw = calloc(n1 + 1, 4), *sci = calloc(n1 + 1, 4), *sci2 = calloc(n1 + 1, 4), *sss = calloc(n1 + 1, 4),
+              *stm = calloc(n1 + 1, 4), *smpx = calloc(n1 + 1, 4);
+        for (i = 0; i < n1; ++i) {
+            root_chan_t *r = (root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]];
+            sw[i] = ngs->single_phone_wid[i]; sci[i] = r->ciphone; sci2[i] = r->ci2phone;
+            smpx[i] = hmm_is_mpx(&r->hmm);
+            sss[i] = smpx[i] ? hmm_mpx_ssid(&r->hmm, 0) : hmm_nonmpx_ssid(&r->hmm);
+            stm[i] = r->hmm.tmatid;
+        }
+        put1("w1_wid", 'i', n1, sw); put1("w1_ci", 'i', n1, sci); put1("w1_ci2", 'i', n1, sci2);
+        put1("w1_ssid", 'i', n1, sss); put1("w1_tmat", 'i', n1, stm); put1("w1_mpx", 'i', n1, smpx);
+    }
+    {   /* dictionary */
+        int32 *pl = calloc(n_w, 4), *p0 = calloc(n_w, 4), *pz = calloc(n_w, 4), *py = calloc(n_w, 4), *bw = calloc(n_w, 4),
+              *fl = calloc(n_w, 4), *real = calloc(n_w, 4);
+        for (w = 0; w < n_w; ++w) {
+            pl[w] = dict_pronlen(dict, w); p0[w] = dict_first_phone(dict, w); pz[w] = dict_last_phone(dict, w);
+            py[w] = pl[w] > 1 ? dict_second_last_phone(dict, w) : -1; bw[w] = dict_basewid(dict, w);
+            fl[w] = dict_filler_word(dict, w); real[w] = dict_real_word(dict, w);
+        }
+        put1("dict_pronlen", 'i', n_w, pl); put1("dict_first", 'i', n_w, p0); put1("dict_last", 'i', n_w, pz);
+        put1("dict_last2", 'i', n_w, py); put1("dict_basewid", 'i', n_w, bw); put1("dict_filler", 'i', n_w, fl);
+        put1("dict_real", 'i', n_w, real);
+    }
+    {   /* dict2pid: right-context tables for every (last phone, second-last phone), root entry ssids */
+        int32 *rn = calloc((size_t)n_ci * n_ci, 4), *rs = calloc((size_t)n_ci * n_ci * n_ci, 4), *rm = calloc((size_t)n_ci * n_ci * n_ci, 4);
+        int32 *ld = calloc((size_t)n_ci * n_ci * n_ci, 4);
+        for (i = 0; i < n_ci; ++i)
+            for (j = 0; j < n_ci; ++j) {
+                xwdssid_t *x = dict2pid_rssid(d2p, i, j);
+                rn[i * n_ci + j] = x->n_ssid;
+                for (k = 0; k < n_ci; ++k) {
+                    rs[((size_t)i * n_ci + j) * n_ci + k] = (x->ssid && k < x->n_ssid) ? x->ssid[k] : -1;
+                    rm[((size_t)i * n_ci + j) * n_ci + k] = x->cimap ? x->cimap[k] : -1;
+                    ld[((size_t)i * n_ci + j) * n_ci + k] = d2p->ldiph_lc[i][j][k];
+                }
+            }
+        put2("rssid_n", 'i', n_ci, n_ci, rn); put3("rssid_ssid", 'i', n_ci, n_ci, n_ci, rs);
+        put3("rssid_cimap", 'i', n_ci, n_ci, n_ci, rm); put3("ldiph_lc", 'i', n_ci, n_ci, n_ci, ld);
+    }
+    {   /* HMM topology */
+        int n_tmat = acmod->tmat->n_tmat, n_sseq = bin_mdef_n_sseq(mdef), a, b;
+        uint8 *tp = calloc((size_t)n_tmat * n_emit * (n_emit + 1), 1);
+        uint16 *sq = calloc((size_t)n_sseq * n_emit, 2);
+        int32 *ptm = calloc(n_ci, 4);
+        for (i = 0; i < n_tmat; ++i) for (a = 0; a < n_emit; ++a) for (b = 0; b <= n_emit; ++b)
+            tp[((size_t)i * n_emit + a) * (n_emit + 1) + b] = acmod->tmat->tp[i][a][b];
+        for (i = 0; i < n_sseq; ++i) for (a = 0; a < n_emit; ++a) sq[(size_t)i * n_emit + a] = mdef->sseq[i][a];
+        for (i = 0; i < n_ci; ++i) ptm[i] = bin_mdef_pid2tmatid(mdef, i);
+        put3("tp", 'B', n_tmat, n_emit, n_emit + 1, tp); put2("sseq", 'H', n_sseq, n_emit, sq);
+        put1("ci_tmat", 'i', n_ci, ptm);
+    }
+    memset(par, 0, sizeof par);
+    par[0] = n_ci; par[1] = n_emit; par[2] = bin_mdef_n_sen(mdef); par[3] = n_w; par[4] = R; par[5] = M;
+    par[6] = ngs->n_1ph_words; par[7] = ngs->n_1ph_LMwords; par[8] = ngs->beam; par[9] = ngs->pbeam; par[10] = ngs->lpbeam;
+    par[11] = ngs->lponlybeam; par[12] = ngs->wbeam; par[13] = ngs->pip; par[14] = ngs->nwpen; par[15] = ngs->silpen;
+    par[16] = ngs->fillpen; par[17] = ngs->maxhmmpf; par[18] = ngs->maxwpf; par[19] = dict_startwid(dict);
+    par[20] = dict_finishwid(dict); par[21] = dict_silwid(dict); par[22] = dict_filler_start(dict);
+    par[23] = dict_filler_end(dict); par[24] = mdef->sil; par[25] = ps_search_lookahead(ngs) != NULL;
+    par[26] = acmod->compallsen;
+    put1("par", 'i', 32, par);
+    {   /* the language model over dictionary word ids */
+        size_t n1 = (size_t)n_w + 1;
+        int32 *lm;
+        if (n_w > 400) { fprintf(stderr, "vocabulary too large for a dense LM table\n"); return 2; }
+        lm = malloc(sizeof(int32) * n_w * n1 * n1);
+        for (i = 0; i < n_w; ++i)
+            for (j = -1; j < n_w; ++j)
+                for (k = -1; k < n_w; ++k) {
+                    int32 nu, v = 0;
+                    if (!dict_filler_word(dict, i) && dict_basewid(dict, i) == i)
+                        v = ngram_tg_score(ngs->lmset, i, j, k, &nu) >> SENSCR_SHIFT;
+                    lm[((size_t)i * n1 + (j + 1)) * n1 + (k + 1)] = v;
+                }
+        put3("lm", 'i', n_w, (int64_t)n1, (int64_t)n1, lm);
+        free(lm);
+    }
+    /* ---- the decode, traced */
+    ft_ps = ps;
+    ft_orig = ps->search->vt; ft_vt = *ft_orig; ft_vt.step = ft_step; ps->search->vt = &ft_vt;
+    ft_morig = acmod->mgau->vt; ft_mvt = *ft_morig; ft_mvt.frame_eval = ft_frame_eval; acmod->mgau->vt = &ft_mvt;
+    run_utt(ps, rawpath);
+    ps->search->vt = ft_orig; acmod->mgau->vt = ft_morig;
+    dump_hyp(ps, "");
+    puti("n_steps", (int32)ft_n);
+    put1("step_frame", 'i', ft_n, ft_step_frame); put1("step_best", 'i', ft_n, ft_best);
+    put1("step_lpbest", 'i', ft_n, ft_lpbest); put1("step_bpidx", 'i', ft_n, ft_bpidx);
+    put2("step_pen", 'i', ft_n, n_ci, ft_pen);
+    put1("step_act_off", 'q', ft_n + 1, ft_act_off);
+    put1("step_act", 'i', (int64_t)ft_act_n, ft_act); put1("step_scr", 'h', (int64_t)ft_act_n, ft_scr);
+    put1("step_rest", 'h', ft_n, ft_rest);
+    {   /* ---- the result */
+        int nb = ngs->bpidx;
+        int32 *b = calloc((size_t)nb * 10 + 1, 4);
+        for (i = 0; i < nb; ++i) {
+            bptbl_t *e = &ngs->bp_table[i];
+            b[i * 10 + 0] = e->frame; b[i * 10 + 1] = e->valid; b[i * 10 + 2] = e->wid; b[i * 10 + 3] = e->bp;
+            b[i * 10 + 4] = e->score; b[i * 10 + 5] = e->s_idx; b[i * 10 + 6] = e->real_wid; b[i * 10 + 7] = e->prev_real_wid;
+            b[i * 10 + 8] = e->last_phone; b[i * 10 + 9] = e->last2_phone;
+        }
+        put2("bp", 'i', nb, 10, b);
+        put1("bscore_stack", 'i', ngs->bss_head, ngs->bscore_stack);
+        put1("bp_table_idx", 'i', ngs->n_frame + 1, ngs->bp_table_idx);
+        puti("n_frame", ngs->n_frame);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 int
 main(int argc, char **argv)
 {
@@ -853,6 +1111,8 @@ main(int argc, char **argv)
             }
         fe = fe_init_auto_r(config);
         rc = fe ? cmd_mfcc(fe, argv[6], atoi(argv[7])) : 2;
+    } else if (!strcmp(cmd, "fwdtree") && xa > 6) {
+        rc = cmd_fwdtree(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
     } else if (!strcmp(cmd, "hmm") && xa > 8) {
         rc = cmd_hmm(make_decoder(modeldir, lm, dict, nextra, extra), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
     } else if (!strcmp(cmd, "decode") && xa > 6) {

@@ -356,3 +356,82 @@ class OracleFe:
                                        C.byref(self.undefined))
         assert got == nfr
         return cep
+
+
+class OracleFwdtree:
+    """Wrapper around pso_ft_t (oracle/ps_oracle_search.c: restates ngram_search_fwdtree.c and the
+    back-pointer helpers of ngram_search.c on flat tables).  `static` = a fwdtree_static_*.npz,
+    `par` = the trace's parameter vector (beams, penalties, word ids)."""
+
+    NAMES = ["par", "node_ci", "node_ci2", "node_ssid", "node_tmat", "node_child", "node_sib", "node_penult_wid",
+             "homophone_set", "w1_wid", "w1_ci", "w1_ci2", "w1_ssid", "w1_tmat", "w1_mpx", "dict_pronlen", "dict_first",
+             "dict_last", "dict_last2", "dict_basewid", "dict_filler", "rssid_n", "rssid_ssid", "rssid_cimap", "ldiph_lc",
+             "tp", "sseq", "ci_tmat", "lm"]
+    DT = {"tp": np.uint8, "sseq": np.uint16}
+
+    def __init__(self, static, par):
+        L = lib()
+        src = dict(static); src["par"] = par
+        self._keep = {n: np.ascontiguousarray(src[n], self.DT.get(n, np.int32)) for n in self.NAMES}
+
+        class T(C.Structure):
+            _fields_ = [(n, C.c_void_p) for n in self.NAMES]
+        self._t = T(*[self._keep[n].ctypes.data for n in self.NAMES])
+        vp = C.c_void_p
+        L.pso_ft_new.restype = vp; L.pso_ft_new.argtypes = [vp]
+        L.pso_ft_free.argtypes = [vp]; L.pso_ft_start.argtypes = [vp]
+        L.pso_ft_active_list.argtypes = [vp, C.c_int, vp]
+        L.pso_ft_step.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int16, vp]
+        L.pso_ft_finish.argtypes = [vp, C.c_int]
+        for f in ("pso_ft_best_score", "pso_ft_last_phone_best_score", "pso_ft_bpidx", "pso_ft_bss_head"):
+            getattr(L, f).argtypes = [vp]; getattr(L, f).restype = C.c_int32
+        for f in ("pso_ft_bp", "pso_ft_bss", "pso_ft_bp_table_idx"):
+            getattr(L, f).argtypes = [vp]; getattr(L, f).restype = vp
+        self.n_sen = int(par[2])
+        self.h = L.pso_ft_new(C.byref(self._t))
+        self._buf = np.zeros(self.n_sen, np.int32)
+
+    def __del__(self):
+        try:
+            lib().pso_ft_free(self.h)
+        except Exception:
+            pass
+
+    def start(self):
+        lib().pso_ft_start(self.h)
+
+    def active_list(self, frame):
+        n = lib().pso_ft_active_list(self.h, int(frame), _p(self._buf))
+        return self._buf[:n].copy()
+
+    def step(self, frame, ids, scr, rest, penalties):
+        ids = np.ascontiguousarray(ids, np.int32); scr = np.ascontiguousarray(scr, np.int16)
+        pen = np.ascontiguousarray(penalties, np.int32)
+        return lib().pso_ft_step(self.h, int(frame), _p(ids), _p(scr), int(ids.size), int(rest), _p(pen))
+
+    def finish(self, n_frames):
+        lib().pso_ft_finish(self.h, int(n_frames))
+
+    def best_score(self):
+        return int(lib().pso_ft_best_score(self.h))
+
+    def last_phone_best_score(self):
+        return int(lib().pso_ft_last_phone_best_score(self.h))
+
+    def bpidx(self):
+        return int(lib().pso_ft_bpidx(self.h))
+
+    def bp_table(self):
+        L = lib()
+        n = L.pso_ft_bpidx(self.h)
+        return np.ctypeslib.as_array(C.cast(L.pso_ft_bp(self.h), C.POINTER(C.c_int32)), shape=(n, 10)).copy()
+
+    def bscore_stack(self):
+        L = lib()
+        n = L.pso_ft_bss_head(self.h)
+        return np.ctypeslib.as_array(C.cast(L.pso_ft_bss(self.h), C.POINTER(C.c_int32)), shape=(max(n, 1),)).copy()[:n]
+
+    def bp_table_idx(self, n_frames):
+        L = lib()
+        return np.ctypeslib.as_array(C.cast(L.pso_ft_bp_table_idx(self.h), C.POINTER(C.c_int32)),
+                                     shape=(n_frames + 1,)).copy()

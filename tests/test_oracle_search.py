@@ -1,0 +1,45 @@
+"""The lexicon-tree search oracle (oracle/ps_oracle_search.c: prune / transitions / back-pointer
+table) pinned against the unmodified reference.
+
+`ref_dump fwdtree` recorded, for real decodes, the static search tables the reference built, the
+senone scores and phone-loop penalties its search was handed frame by frame, and what it
+produced.  The oracle, fed the same inputs, must reproduce per frame the active senone list
+(compute_sen_active + acmod_flags2list, bridging entries included), the best score, the
+last-phone best score and the back-pointer count, and at the end the complete back-pointer
+table (frame, valid, wid, bp, score, s_idx, real_wid, prev_real_wid, last_phone, last2_phone),
+the right-context score stack and the per-frame marks -- bit for bit.  Cases: en-us + turtle LM
+(3-state HMMs, PTM scores) on two recordings, with histogram pruning (maxhmmpf) and absolute
+word-exit pruning (maxwpf) forced on, without the phone-loop look-ahead, and tidigits
+(5-state HMMs, semi-continuous scores, its own LM and dictionary)."""
+import numpy as np
+import pytest
+
+import pso
+from test_oracle_golden import _load
+
+CASES = ["goforward", "numbers", "goforward_maxhmmpf60_maxwpf3", "something_plwindow0", "man_ah_2934za"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fwdtree_oracle_matches_reference(case):
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    o = pso.OracleFwdtree(st, g["par"])
+    o.start()
+    off, act, scr = g["step_act_off"], g["step_act"], g["step_scr"]
+    n = int(g["n_steps"][0])
+    for i in range(n):
+        fr = int(g["step_frame"][i])
+        a0, a1 = int(off[i]), int(off[i + 1])
+        assert np.array_equal(o.active_list(fr), act[a0:a1]), "frame %d: active senone list" % fr
+        o.step(fr, act[a0:a1], scr[a0:a1], int(g["step_rest"][i]), g["step_pen"][i])
+        assert (o.best_score(), o.last_phone_best_score(), o.bpidx()) == \
+            (int(g["step_best"][i]), int(g["step_lpbest"][i]), int(g["step_bpidx"][i])), "frame %d" % fr
+    nfr = int(g["n_frame"][0])
+    o.finish(nfr)
+    bp = o.bp_table()
+    assert bp.shape == g["bp"].shape
+    bad = np.nonzero((bp != g["bp"]).any(axis=1))[0]
+    assert bad.size == 0, "first differing back-pointer %d: %r vs %r" % (bad[0], bp[bad[0]], g["bp"][bad[0]])
+    assert np.array_equal(o.bscore_stack(), g["bscore_stack"])
+    assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
