@@ -242,6 +242,13 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
 // launched next in fix-up mode, re-derives those frames with the exact
 // sequential procedure.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t med3_i32(int32_t a, int32_t b, int32_t c)
+{
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int LEN, int FPL>                     // FPL = frames per lane
 __global__ __launch_bounds__(256, 8)
 void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_frames,
@@ -292,13 +299,12 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
             for (int j = 0; j < LEN; ++j)
                 d = gau_step(d, x[q][j], m[j], v[j]);
             const float c = __builtin_amdgcn_fmed3f(d, (float)kKeyLo, (float)kKeyHi);
-            int32_t k = ((int32_t)c << 7) | (127 - cw);
-            int32_t tmx;
-            tmx = max(k0[q], k); k = min(k0[q], k); k0[q] = tmx;
-            tmx = max(k1[q], k); k = min(k1[q], k); k1[q] = tmx;
-            tmx = max(k2[q], k); k = min(k2[q], k); k2[q] = tmx;
-            tmx = max(k3[q], k); k = min(k3[q], k); k3[q] = tmx;
-            k4[q] = max(k4[q], k);
+            const int32_t k = ((int32_t)c << 7) | (127 - cw);
+            // insertion into the sorted five: new_i = med3(old_{i-1}, old_i, k), all five from the
+            // OLD values -- one max and four v_med3_i32, independent of each other
+            const int32_t n4 = med3_i32(k3[q], k4[q], k), n3 = med3_i32(k2[q], k3[q], k),
+                          n2 = med3_i32(k1[q], k2[q], k), n1 = med3_i32(k0[q], k1[q], k);
+            k0[q] = max(k0[q], k); k1[q] = n1; k2[q] = n2; k3[q] = n3; k4[q] = n4;
         }
     }
 #pragma unroll
