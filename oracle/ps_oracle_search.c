@@ -57,6 +57,11 @@ struct pso_ft_s {
     int32_t best_score, last_phone_best_score, dynamic_beam, n_frame;
     int64_t n_root_eval, n_nonroot_eval;       /* ngram_search_stats_t counters the histogram pruning looks at */
     uint8_t *sen_active;               /* compute_sen_active flags */
+    /* data-parallel formulation of the tree pruning (pso_ft_set_parallel) */
+    int par_mode;
+    int32_t *parent;                   /* [N] tree parent of a non-root node */
+    int32_t *pos, *o_frame, *o_s0, *o_best, *o_out, *o_outh, *cnt, *offs;
+    uint8_t *fire, *selfapp, *ret;
 };
 
 /* ---- hmm.c helpers on pso_hmm_t ---- */
@@ -239,6 +244,15 @@ pso_ft_t *pso_ft_new(const pso_ft_tables_t *t)
     s->word_lat_idx = calloc(s->n_w, sizeof(int32_t));
     s->n_frame_alloc = 256; s->bp_table_idx = calloc(s->n_frame_alloc + 1, sizeof(int32_t));
     s->sen_active = calloc(s->n_sen, 1);
+    s->parent = calloc(s->N, sizeof(int32_t));
+    for (i = 0; i < s->N; ++i) s->parent[i] = -1;
+    for (i = 0; i < s->N; ++i) {
+        int c;
+        for (c = t->node_child[i]; c >= 0; c = t->node_sib[c]) s->parent[c] = i;
+    }
+    s->pos = calloc(s->N, 4); s->o_frame = calloc(s->N, 4); s->o_s0 = calloc(s->N, 4); s->o_best = calloc(s->N, 4);
+    s->o_out = calloc(s->N, 4); s->o_outh = calloc(s->N, 4); s->cnt = calloc(s->N + 1, 4); s->offs = calloc(s->N + 2, 4);
+    s->fire = calloc(s->N, 1); s->selfapp = calloc(s->N, 1); s->ret = calloc(s->N, 1);
     return s;
 }
 
@@ -250,6 +264,8 @@ void pso_ft_free(pso_ft_t *s)
     for (i = 0; i < 2; ++i) { free(s->acl[i]); free(s->awl[i]); }
     free(s->word_active); free(s->cand); free(s->ltrans); free(s->candsf); free(s->bestrc);
     free(s->bp); free(s->bss); free(s->word_lat_idx); free(s->bp_table_idx); free(s->sen_active);
+    free(s->parent); free(s->pos); free(s->o_frame); free(s->o_s0); free(s->o_best); free(s->o_out); free(s->o_outh);
+    free(s->cnt); free(s->offs); free(s->fire); free(s->selfapp); free(s->ret);
     free(s);
 }
 
@@ -438,6 +454,99 @@ static void prune_nonroot(pso_ft_t *s, int frame, const int32_t *pp)
     s->n_acl[nf & 1] = (int32_t)(nacl - s->acl[nf & 1]);
 }
 
+
+/* ---------------------------------------------------------------------------------------
+ * The same tree pruning (prune_root_chan + prune_nonroot_chan) written as independent
+ * per-node computations on a snapshot of the state after evaluation, plus prefix sums for
+ * the list positions -- the form a device kernel can run with one lane per node.  The
+ * reference walks the active list sequentially; what that order decides is enumerable,
+ * because a tree node has exactly one parent:
+ *   - a node goes on the next active list either by its own retention or by its parent's
+ *     transition into it, whichever comes first in list order (roots come before everything);
+ *   - a node that fails the beam is cleared at its own turn unless its parent entered it
+ *     earlier; if the parent comes later it enters a cleared node unconditionally.
+ * Equivalence with the sequential walk is what tests/test_oracle_search.py checks
+ * (pso_ft_set_parallel(1): identical back-pointer tables on every golden decode).
+ * --------------------------------------------------------------------------------------- */
+static void prune_tree_parallel(pso_ft_t *s, int frame, const int32_t *pp)
+{
+    const int nf = frame + 1, N = s->N, R = s->R;
+    const int32_t thresh = s->best_score + s->dynamic_beam;
+    const int32_t npt = s->best_score + s->pbeam, lpt = s->best_score + s->lpbeam;
+    const int32_t *acl = s->acl[frame & 1];
+    const int n_acl = s->n_acl[frame & 1];
+    int32_t *nacl = s->acl[nf & 1];
+    int i, p, c, w, total;
+
+    /* snapshot + positions */
+    for (i = 0; i < N; ++i) {
+        const pso_hmm_t *h = &s->node[i];
+        s->pos[i] = -1; s->o_frame[i] = h->frame; s->o_s0[i] = h->score[0]; s->o_best[i] = h->bestscore;
+        s->o_out[i] = h->out_score; s->o_outh[i] = h->out_history;
+    }
+    for (p = 0; p < n_acl; ++p) s->pos[acl[p]] = p;
+    /* retention of every node (roots: active this frame; others: on the list) */
+    for (i = 0; i < N; ++i) {
+        const int active = i < R ? s->o_frame[i] >= frame : s->pos[i] >= 0;
+        s->ret[i] = (uint8_t)(active && s->o_best[i] > thresh);
+    }
+    /* every non-root node decides its own fate from its own and its parent's snapshot */
+    for (c = R; c < N; ++c) {
+        pso_hmm_t *h = &s->node[c];
+        const int P = s->parent[c], pc = s->pos[c], in_acl = pc >= 0;
+        const int32_t news = s->o_out[P] + s->pip;
+        const int par_active = P < R ? 1 : s->pos[P] >= 0;
+        const int parent_can = par_active && s->ret[P] && (s->has_pl || news > npt) && (news + pen(s, pp, s->t.node_ci[c]) > npt);
+        const int parent_first = P < R || (in_acl && s->pos[P] < pc) || !in_acl;
+        int fire, entered_first = 0, cleared = 0;
+        if (!in_acl)                       fire = parent_can && (s->o_frame[c] < frame || news > s->o_s0[c]);
+        else if (parent_first)             fire = parent_can && (s->o_frame[c] < frame || news > s->o_s0[c]);
+        else if (s->ret[c])                fire = parent_can && news > s->o_s0[c];
+        else                               fire = parent_can;          /* cleared at its own, earlier turn */
+        if (fire && parent_first) entered_first = 1;
+        s->selfapp[c] = (uint8_t)(in_acl && s->ret[c] && !entered_first);
+        /* listed by the parent unless it put itself on the list earlier; a root's transition lists always */
+        s->fire[c] = (uint8_t)(fire ? ((P < R || !(in_acl && !parent_first && s->ret[c])) ? 1 : 2) : 0);
+        if (in_acl && !s->ret[c] && !entered_first) cleared = 1;
+        /* new state */
+        if (cleared) h_clear(h);
+        if (in_acl && s->ret[c]) h->frame = nf;
+        if (fire) h_enter(h, news, s->o_outh[P], nf);
+    }
+    for (i = 0; i < R; ++i) if (s->ret[i]) s->node[i].frame = nf;
+    /* list positions: the root phase, then one segment per list position */
+    total = 0;
+    for (i = 0; i < R; ++i)
+        for (c = s->t.node_child[i]; c >= 0; c = s->t.node_sib[c])
+            if (s->fire[c]) nacl[total++] = c;              /* roots list every child they enter (:756-759) */
+    for (p = 0; p < n_acl; ++p) {
+        int k = s->selfapp[acl[p]];
+        for (c = s->t.node_child[acl[p]]; c >= 0; c = s->t.node_sib[c]) k += (s->fire[c] == 1);
+        s->cnt[p] = k;
+    }
+    s->offs[0] = total;
+    for (p = 0; p < n_acl; ++p) s->offs[p + 1] = s->offs[p] + s->cnt[p];     /* exclusive prefix sum */
+    for (p = 0; p < n_acl; ++p) {
+        int o = s->offs[p];
+        if (s->selfapp[acl[p]]) nacl[o++] = acl[p];
+        for (c = s->t.node_child[acl[p]]; c >= 0; c = s->t.node_sib[c]) if (s->fire[c] == 1) nacl[o++] = c;
+    }
+    s->n_acl[nf & 1] = s->offs[n_acl];
+    /* last-phone candidates: list order, homophone chain inside (order-free given the snapshot) */
+    for (i = 0; i < R + n_acl; ++i) {
+        const int node = i < R ? i : acl[i - R];
+        const int32_t news = s->o_out[node] + s->pip;
+        if (!s->ret[node] || !(s->has_pl || news > lpt)) continue;
+        for (w = s->t.node_penult_wid[node]; w >= 0; w = s->t.homophone_set[w])
+            if (news + pen(s, pp, s->t.dict_last[w]) > lpt) {
+                cand_t *cp = &s->cand[s->n_cand++];
+                cp->wid = w; cp->score = news - s->nwpen; cp->bp = s->o_outh[node];
+            }
+    }
+}
+
+void pso_ft_set_parallel(pso_ft_t *s, int on) { s->par_mode = on; }
+
 /* last_phone_transition, :884-1032 */
 static void last_phone_transition(pso_ft_t *s, int frame)
 {
@@ -560,8 +669,8 @@ static void prune_channels(pso_ft_t *s, int frame, const int32_t *pp)
         for (i = 0; i < 256; ++i) { nh += bins[i]; if (nh > s->maxhmmpf) break; }
         s->dynamic_beam = -(i * bw);
     }
-    prune_root(s, frame, pp);
-    prune_nonroot(s, frame, pp);
+    if (s->par_mode) prune_tree_parallel(s, frame, pp);
+    else { prune_root(s, frame, pp); prune_nonroot(s, frame, pp); }
     last_phone_transition(s, frame);
     prune_word(s, frame);
 }

@@ -34,6 +34,9 @@ typedef struct pso_ft_s pso_ft_t;
 pso_ft_t *pso_ft_new(const pso_ft_tables_t *t);     /* the tables must outlive the object */
 void pso_ft_free(pso_ft_t *s);
 void pso_ft_start(pso_ft_t *s);
+/* 1: run the tree pruning in its data-parallel formulation (per-node decisions on a snapshot +
+ * prefix sums for list positions) instead of the reference's sequential walk; same results */
+void pso_ft_set_parallel(pso_ft_t *s, int on);
 /* the senone ids compute_sen_active + acmod_flags2list would list for `frame` (bridging entries
  * included); out has room for n_sen entries */
 int pso_ft_active_list(pso_ft_t *s, int frame, int32_t *out);

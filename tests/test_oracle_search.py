@@ -20,11 +20,18 @@ from test_oracle_golden import _load
 CASES = ["goforward", "numbers", "goforward_maxhmmpf60_maxwpf3", "something_plwindow0", "man_ah_2934za"]
 
 
+@pytest.mark.parametrize("parallel", [0, 1])
 @pytest.mark.parametrize("case", CASES)
-def test_fwdtree_oracle_matches_reference(case):
+def test_fwdtree_oracle_matches_reference(case, parallel):
+    """parallel = 1: the tree pruning in its data-parallel formulation (per-node decisions on a
+    snapshot of the evaluated state + prefix sums for the list positions, prune_tree_parallel) --
+    the form the device kernel uses -- must give the same tables as the sequential walk."""
+    import ctypes as C
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
     o = pso.OracleFwdtree(st, g["par"])
+    pso.lib().pso_ft_set_parallel.argtypes = [C.c_void_p, C.c_int]
+    pso.lib().pso_ft_set_parallel(o.h, parallel)
     o.start()
     off, act, scr = g["step_act_off"], g["step_act"], g["step_scr"]
     n = int(g["n_steps"][0])
