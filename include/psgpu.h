@@ -488,6 +488,47 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
  * usable with psgpu_memcpy_* / psgpu_stream_sync */
 void *psgpu_hmm_ctx_stream(psgpu_hmm_ctx_t *c);
 
+/* ---- lexicon-tree search of whole utterances, first version ----------
+ * Replaces ngram_fwdtree_start + ngram_fwdtree_search per frame + ngram_fwdtree_finish
+ * (ngram_search_fwdtree.c:469-520, 1452-1495, 1497-1533) with the back-pointer helpers of
+ * ngram_search.c (:301-498, 583-674).  The tables are the reference's own search structures
+ * flattened to index arrays (what oracle/ref_dump.c `fwdtree` writes: the tree
+ * create_search_channels built with roots first, single-phone word channels, dictionary and
+ * dict2pid tables, `par` = sizes, beams, penalties, special word ids) and the language model as
+ * a dense table lm[w3][w2 + 1][w1 + 1] = ngram_tg_score(w3, w2, w1) >> SENSCR_SHIFT over
+ * dictionary word ids (-1 = no history): small vocabularies only (<= 1024 words, <= 4096 tree
+ * nodes, <= 64 CI phones) in this version. */
+typedef struct psgpu_fwdtree_s psgpu_fwdtree_t;
+typedef struct psgpu_fwdtree_tables_s {
+    const int32_t *par;                       /* [32] */
+    const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_child, *node_sib, *node_penult_wid;
+    const int32_t *homophone_set;
+    const int32_t *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx;
+    const int32_t *dict_pronlen, *dict_first, *dict_last, *dict_last2, *dict_basewid, *dict_filler;
+    const int32_t *rssid_n, *rssid_ssid, *rssid_cimap, *ldiph_lc;
+    const uint8_t *tp;
+    const uint16_t *sseq;
+    const int32_t *ci_tmat;
+    const int32_t *lm;
+    int32_t n_tmat, n_sseq;
+} psgpu_fwdtree_tables_t;
+int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t);
+void psgpu_fwdtree_free(psgpu_fwdtree_t *m);
+/* n_utt utterances, one workgroup each, every frame inside the kernel.  senscr_dev
+ * [total][scr_stride] int16 = the scores acmod_score hands the search for each frame;
+ * penalties_dev [total][n_ci] = pls->penalties as the search reads them at that frame;
+ * utt_off_dev [n_utt + 1].  Per utterance u: the ten columns of the back-pointer table
+ * (frame, valid, wid, bp, score, s_idx, real_wid, prev_real_wid, last_phone, last2_phone:
+ * bptbl_t, ngram_search.h:112-124) at bp_dev + u*10*bp_cap, the right-context score stack at
+ * bss_dev + u*bss_cap, bp_table_idx at idx_dev + u*(max_frames + 2), per-frame
+ * {best_score, last_phone_best_score, bpidx, n_active_chan} at step_dev + u*max_frames*4, and
+ * result_dev + u*8 = {n back-pointers, score-stack length, frames searched, status (1: a table
+ * was full)}.  Synchronous on `stream`. */
+int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                             const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                             int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                             int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream);
+
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).
  * senscr is the frame's n_sen int16 scores.  Synchronous. */

@@ -49,254 +49,8 @@ struct psgpu_hmm_ctx_s {
 
 constexpr int32_t kZeroCopyMax = 2048;
 
-constexpr int32_t kW = kWorstScore;
-constexpr int kTmatWorst = 255;            // tmat.h: 8-bit floor; "tp > -255" gates skip arcs
-constexpr uint16_t kBadSsid = 0xffff;      // hmm.h:89
+#include "psgpu_hmm_dev.h"
 
-__device__ __forceinline__ int32_t clampw(int32_t v) { return v < kW ? kW : v; }
-
-struct HmmRegs {
-    int32_t score[5], history[5], out_score, out_history, bestscore;
-    uint16_t senid[5];
-};
-
-// ---- 3-state, non-multiplex (hmm.c:529-607) --------------------------------
-__device__ __forceinline__ int32_t vit3(HmmRegs &h, const uint8_t *tp, const int16_t *ss)
-{
-#define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
-    int32_t s2 = h.score[2] - ss[h.senid[2]];
-    int32_t s1 = h.score[1] - ss[h.senid[1]];
-    int32_t s0 = h.score[0] - ss[h.senid[0]];
-    int32_t best = kW, t0, t1, t2 = INT_MIN;
-    if (s1 > kW) {
-        t1 = s2 + TP(2, 3);
-        if (TP(1, 3) > -kTmatWorst) t2 = s1 + TP(1, 3);
-        int32_t s3;
-        if (t1 > t2) { s3 = t1; h.out_history = h.history[2]; }
-        else         { s3 = t2; h.out_history = h.history[1]; }
-        s3 = clampw(s3);
-        h.out_score = s3;
-        best = s3;
-    }
-    t0 = s2 + TP(2, 2);
-    t1 = s1 + TP(1, 2);
-    if (TP(0, 2) > -kTmatWorst) t2 = s0 + TP(0, 2);     // else t2 keeps its value (stale, as the reference)
-    if (t0 > t1) {
-        if (t2 > t0) { s2 = t2; h.history[2] = h.history[0]; }
-        else s2 = t0;
-    }
-    else {
-        if (t2 > t1) { s2 = t2; h.history[2] = h.history[0]; }
-        else { s2 = t1; h.history[2] = h.history[1]; }
-    }
-    s2 = clampw(s2);
-    best = max(best, s2);
-    h.score[2] = s2;
-    t0 = s1 + TP(1, 1);
-    t1 = s0 + TP(0, 1);
-    if (t0 > t1) s1 = t0;
-    else { s1 = t1; h.history[1] = h.history[0]; }
-    s1 = clampw(s1);
-    best = max(best, s1);
-    h.score[1] = s1;
-    s0 = clampw(s0 + TP(0, 0));
-    best = max(best, s0);
-    h.score[0] = s0;
-    h.bestscore = best;
-    return best;
-#undef TP
-}
-
-// ---- 3-state, multiplex (hmm.c:609-707) -------------------------------------
-__device__ __forceinline__ int32_t vit3_mpx(HmmRegs &h, const uint8_t *tp, const int16_t *ss,
-                                            const uint16_t *sseq)
-{
-#define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
-#define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 3 + (st)]])
-    int32_t s3, s2, s1, s0, t0, t1, t2 = INT_MIN, best;
-    if (h.senid[2] == kBadSsid) s2 = t1 = kW;
-    else { s2 = h.score[2] + SEN(2); t1 = s2 + TP(2, 3); }
-    if (h.senid[1] == kBadSsid) s1 = t2 = kW;
-    else {
-        s1 = h.score[1] + SEN(1);
-        if (TP(1, 3) > -kTmatWorst) t2 = s1 + TP(1, 3);
-    }
-    if (t1 > t2) { s3 = t1; h.out_history = h.history[2]; }
-    else         { s3 = t2; h.out_history = h.history[1]; }
-    s3 = clampw(s3);
-    h.out_score = s3;
-    best = s3;
-
-    s0 = h.score[0] + SEN(0);
-    t0 = t1 = kW;
-    if (s2 != kW) t0 = s2 + TP(2, 2);
-    if (s1 != kW) t1 = s1 + TP(1, 2);
-    if (TP(0, 2) > -kTmatWorst) t2 = s0 + TP(0, 2);
-    if (t0 > t1) {
-        if (t2 > t0) { s2 = t2; h.history[2] = h.history[0]; h.senid[2] = h.senid[0]; }
-        else s2 = t0;
-    }
-    else {
-        if (t2 > t1) { s2 = t2; h.history[2] = h.history[0]; h.senid[2] = h.senid[0]; }
-        else { s2 = t1; h.history[2] = h.history[1]; h.senid[2] = h.senid[1]; }
-    }
-    s2 = clampw(s2);
-    best = max(best, s2);
-    h.score[2] = s2;
-
-    t0 = kW;
-    if (s1 != kW) t0 = s1 + TP(1, 1);
-    t1 = s0 + TP(0, 1);
-    if (t0 > t1) s1 = t0;
-    else { s1 = t1; h.history[1] = h.history[0]; h.senid[1] = h.senid[0]; }
-    s1 = clampw(s1);
-    best = max(best, s1);
-    h.score[1] = s1;
-
-    s0 = clampw(s0 + TP(0, 0));
-    best = max(best, s0);
-    h.score[0] = s0;
-    h.bestscore = best;
-    return best;
-#undef TP
-#undef SEN
-}
-
-// three-way arg-max of the 5-state forms: self loop T0, neighbour T1 (state
-// nb), skip T2 (state sk); destination state nb + 1
-template <bool MPX>
-__device__ __forceinline__ int32_t pick3(HmmRegs &h, int32_t T0, int32_t T1, int32_t T2, int nb, int sk)
-{
-    int32_t dst;
-    if (T0 > T1) {
-        if (T2 > T0) { dst = T2; h.history[nb + 1] = h.history[sk]; if (MPX) h.senid[nb + 1] = h.senid[sk]; }
-        else dst = T0;
-    }
-    else {
-        if (T2 > T1) { dst = T2; h.history[nb + 1] = h.history[sk]; if (MPX) h.senid[nb + 1] = h.senid[sk]; }
-        else { dst = T1; h.history[nb + 1] = h.history[nb]; if (MPX) h.senid[nb + 1] = h.senid[nb]; }
-    }
-    return dst;
-}
-
-// ---- 5-state, non-multiplex (hmm.c:222-350) ---------------------------------
-__device__ __forceinline__ int32_t vit5(HmmRegs &h, const uint8_t *tp, const int16_t *ss)
-{
-#define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
-#define SEN(st) (-(int32_t)ss[h.senid[st]])
-    int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best = kW;
-    s4 = h.score[4] + SEN(4);
-    s3 = h.score[3] + SEN(3);
-    if (s3 > kW) {
-        t1 = s4 + TP(4, 5);
-        t2 = s3 + TP(3, 5);
-        if (t1 > t2) { s5 = t1; h.out_history = h.history[4]; }
-        else         { s5 = t2; h.out_history = h.history[3]; }
-        s5 = clampw(s5);
-        h.out_score = s5;
-        best = s5;
-    }
-    s2 = h.score[2] + SEN(2);
-    if (s2 > kW) {
-        t0 = s4 + TP(4, 4); t1 = s3 + TP(3, 4); t2 = s2 + TP(2, 4);
-        s4 = clampw(pick3<false>(h, t0, t1, t2, 3, 2));
-        best = max(best, s4);
-        h.score[4] = s4;
-    }
-    s1 = h.score[1] + SEN(1);
-    if (s1 > kW) {
-        t0 = s3 + TP(3, 3); t1 = s2 + TP(2, 3); t2 = s1 + TP(1, 3);
-        s3 = clampw(pick3<false>(h, t0, t1, t2, 2, 1));
-        best = max(best, s3);
-        h.score[3] = s3;
-    }
-    s0 = h.score[0] + SEN(0);
-    t0 = s2 + TP(2, 2); t1 = s1 + TP(1, 2); t2 = s0 + TP(0, 2);
-    s2 = clampw(pick3<false>(h, t0, t1, t2, 1, 0));
-    best = max(best, s2);
-    h.score[2] = s2;
-
-    t0 = s1 + TP(1, 1); t1 = s0 + TP(0, 1);
-    if (t0 > t1) s1 = t0;
-    else { s1 = t1; h.history[1] = h.history[0]; }
-    s1 = clampw(s1);
-    best = max(best, s1);
-    h.score[1] = s1;
-
-    s0 = clampw(s0 + TP(0, 0));
-    best = max(best, s0);
-    h.score[0] = s0;
-    h.bestscore = best;
-    return best;
-#undef TP
-#undef SEN
-}
-
-// ---- 5-state, multiplex (hmm.c:355-525) -------------------------------------
-__device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const int16_t *ss,
-                                            const uint16_t *sseq)
-{
-#define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
-#define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 5 + (st)]])
-    int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best;
-    if (h.senid[4] == kBadSsid) s4 = t1 = kW;
-    else { s4 = h.score[4] + SEN(4); t1 = s4 + TP(4, 5); }
-    if (h.senid[3] == kBadSsid) s3 = t2 = kW;
-    else { s3 = h.score[3] + SEN(3); t2 = s3 + TP(3, 5); }
-    if (t1 > t2) { s5 = t1; h.out_history = h.history[4]; }
-    else         { s5 = t2; h.out_history = h.history[3]; }
-    s5 = clampw(s5);
-    h.out_score = s5;
-    best = s5;
-
-    if (h.senid[2] == kBadSsid) s2 = t2 = kW;
-    else { s2 = h.score[2] + SEN(2); t2 = s2 + TP(2, 4); }
-    t0 = t1 = kW;
-    if (s4 != kW) t0 = s4 + TP(4, 4);
-    if (s3 != kW) t1 = s3 + TP(3, 4);
-    s4 = clampw(pick3<true>(h, t0, t1, t2, 3, 2));
-    best = max(best, s4);
-    h.score[4] = s4;
-
-    if (h.senid[1] == kBadSsid) s1 = t2 = kW;
-    else { s1 = h.score[1] + SEN(1); t2 = s1 + TP(1, 3); }
-    t0 = t1 = kW;
-    if (s3 != kW) t0 = s3 + TP(3, 3);
-    if (s2 != kW) t1 = s2 + TP(2, 3);
-    s3 = clampw(pick3<true>(h, t0, t1, t2, 2, 1));
-    best = max(best, s3);
-    h.score[3] = s3;
-
-    s0 = h.score[0] + SEN(0);
-    t0 = t1 = kW;
-    if (s2 != kW) t0 = s2 + TP(2, 2);
-    if (s1 != kW) t1 = s1 + TP(1, 2);
-    t2 = s0 + TP(0, 2);
-    s2 = clampw(pick3<true>(h, t0, t1, t2, 1, 0));
-    best = max(best, s2);
-    h.score[2] = s2;
-
-    t0 = kW;
-    if (s1 != kW) t0 = s1 + TP(1, 1);
-    t1 = s0 + TP(0, 1);
-    if (t0 > t1) s1 = t0;
-    else { s1 = t1; h.history[1] = h.history[0]; h.senid[1] = h.senid[0]; }
-    s1 = clampw(s1);
-    best = max(best, s1);
-    h.score[1] = s1;
-
-    s0 = clampw(s0 + TP(0, 0));
-    best = max(best, s0);
-    h.score[0] = s0;
-    h.bestscore = best;
-    return best;
-#undef TP
-#undef SEN
-}
-
-// ---------------------------------------------------------------------------
-// kernel: one lane per active HMM
-// ---------------------------------------------------------------------------
 constexpr int kHmmThreads = 256;
 constexpr int kTpLdsMax = 16384;
 

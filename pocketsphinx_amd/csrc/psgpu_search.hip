@@ -1,0 +1,705 @@
+// psgpu_search.hip -- the lexicon-tree search on gfx950, first
+// version: whole utterances, one workgroup per utterance, every frame inside the kernel.
+//
+// Replaces ngram_fwdtree_start + ngram_fwdtree_search x T + ngram_fwdtree_finish
+// (reference src/ngram_search_fwdtree.c:469-520, 1452-1495, 1497-1533) and the
+// back-pointer helpers they call (src/ngram_search.c:301-498, 583-674): evaluate_channels,
+// histogram / beam pruning with phone and last-phone transitions, language-model scores at
+// word entry, right-context channel allocation, save_bp, bptable_maxwpf, word_transition,
+// deactivate_channels.  Output: the back-pointer table in the reference's own columns
+// (bptbl_t, ngram_search.h:112-124), the right-context score stack and the per-frame marks.
+//
+// Inputs are what the other kernels leave on the device: per-frame senone scores
+// (normalised rows here; the un-normalised rows + active-list normaliser come next) and
+// the phone-loop penalties.  Static tables are the reference's own (tree, dictionary,
+// dict2pid, beams) flattened to index arrays; the language model is a dense table over
+// dictionary word ids, so this version is for small vocabularies (turtle, tidigits).
+//
+// Parallelism in this version: utterances across workgroups; inside a frame the HMM
+// evaluation and the tree pruning run across the 256 threads (the pruning in the
+// order-free per-node formulation that oracle/ps_oracle_search.c proves equivalent to the
+// reference's sequential walk: decisions on a snapshot, prefix sums for list positions);
+// the word-level bookkeeping (tens of items per frame) is still one thread.  Results are
+// the reference's, bit for bit (tests/test_search_gpu.py against reference dumps).
+#include "psgpu_hmm_dev.h"
+#include <cstring>
+#include <vector>
+
+constexpr int kFtThreads = 256;
+constexpr int kFtMaxN = 4096;          // tree nodes (LDS scratch of the pruning)
+constexpr int kFtMaxCi = 64;
+
+struct FtDev {
+    int32_t n_ci, n_emit, n_sen, n_w, R, M, N, n1, n1lm, TOT;
+    int32_t beam, pbeam, lpbeam, lponlybeam, wbeam, pip, nwpen, silpen, fillpen, maxhmmpf, maxwpf;
+    int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci, has_pl;
+    const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_child, *node_sib, *node_pw, *parent;
+    const int32_t *homophone, *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx, *w1_of_word;
+    const int32_t *d_pronlen, *d_first, *d_last, *d_last2, *d_base, *d_filler;
+    const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
+    const uint8_t *tp;
+    const uint16_t *sseq;
+};
+
+// per-utterance state (one slab per utterance; all int32 unless noted)
+struct FtUtt {
+    // channels: [0, N) tree nodes, [N, N + n1) single-phone words, [N + n1, N + n1 + TOT) last-phone slots
+    int32_t *score, *hist;               // [C][5]
+    int32_t *out, *outh, *best, *frame;  // [C]
+    int32_t *senid;                      // [C][5]  senone ids, or per-state ssids of multiplex HMMs
+    int32_t *tmat, *mpx;                 // [C]
+    int32_t *present;                    // [TOT]
+    int32_t *acl[2], *awl[2];            // [N], [n_w]
+    int32_t *word_active, *word_lat_idx; // [n_w]
+    int32_t *cand_wid, *cand_score, *cand_bp, *cand_next;   // [n_w + 1]
+    int32_t *lt_sf, *lt_dscr, *lt_bp;    // [n_w]
+    int32_t *csf_ef, *csf_cand;          // [n_w + 1]
+    int32_t *bp;                         // [10][bp_cap] columns: frame valid wid bp score s_idx real_wid prev_real_wid last last2
+    int32_t *bss;                        // [bss_cap]
+    int32_t *bp_table_idx;               // [T + 2]
+    int32_t *o_frame, *o_s0, *o_best, *o_out, *o_outh, *pos, *flag;   // [N] pruning snapshot / decisions
+    int32_t *step;                       // [T][4] best_score, last_phone_best_score, bpidx, n_active_chan (diagnostics)
+    int32_t *result;                     // [8] bpidx, bss_head, n_frame, status
+    int32_t bp_cap, bss_cap;
+};
+
+struct psgpu_fwdtree_s {
+    FtDev d;
+    std::vector<void *> allocs;
+    int32_t C;
+};
+
+#define BPC(u, col, i) ((u).bp[(size_t)(col) * (u).bp_cap + (i)])
+enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2 };
+
+__device__ __forceinline__ void ch_clear(const FtDev &p, FtUtt &u, int c)      // hmm_clear, hmm.c:181-196
+{
+    for (int i = 0; i < p.n_emit; ++i) { u.score[c * 5 + i] = kW; u.hist[c * 5 + i] = -1; }
+    u.out[c] = kW; u.outh[c] = -1; u.best[c] = kW; u.frame[c] = -1;
+}
+__device__ __forceinline__ void ch_init(const FtDev &p, FtUtt &u, int c, int mpx, int ssid, int tmatid)   // hmm_init :146-168
+{
+    u.mpx[c] = mpx; u.tmat[c] = tmatid;
+    if (mpx) {
+        u.senid[c * 5] = ssid;
+        for (int i = 1; i < p.n_emit; ++i) u.senid[c * 5 + i] = kBadSsid;
+    }
+    else
+        for (int i = 0; i < p.n_emit; ++i) u.senid[c * 5 + i] = p.sseq[(size_t)ssid * p.n_emit + i];
+    ch_clear(p, u, c);
+}
+__device__ __forceinline__ void ch_enter(FtUtt &u, int c, int32_t score, int32_t hist, int frame)   // hmm_enter :198-204
+{
+    u.score[c * 5] = score; u.hist[c * 5] = hist; u.frame[c] = frame;
+}
+__device__ __forceinline__ void ch_normalize(const FtDev &p, FtUtt &u, int c, int32_t norm)      // hmm_normalize :206-217
+{
+    for (int i = 0; i < p.n_emit; ++i) if (u.score[c * 5 + i] > kW) u.score[c * 5 + i] -= norm;
+    if (u.out[c] > kW) u.out[c] -= norm;
+}
+
+// hmm_vit_eval on channel c with the frame's score row
+template <int NE>
+__device__ __forceinline__ int32_t ch_eval(const FtDev &p, FtUtt &u, int c, const int16_t *row)
+{
+    HmmRegs h;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        h.score[i] = i < NE ? u.score[c * 5 + i] : kW;
+        h.history[i] = i < NE ? u.hist[c * 5 + i] : -1;
+        h.senid[i] = i < NE ? (uint16_t)u.senid[c * 5 + i] : 0;
+    }
+    h.out_score = u.out[c]; h.out_history = u.outh[c]; h.bestscore = u.best[c];
+    const uint8_t *tp = p.tp + (size_t)u.tmat[c] * NE * (NE + 1);
+    int32_t b;
+    if (NE == 3) b = u.mpx[c] ? vit3_mpx(h, tp, row, p.sseq) : vit3(h, tp, row);
+    else         b = u.mpx[c] ? vit5_mpx(h, tp, row, p.sseq) : vit5(h, tp, row);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { u.score[c * 5 + i] = h.score[i]; u.hist[c * 5 + i] = h.history[i]; u.senid[c * 5 + i] = h.senid[i]; }
+    u.out[c] = h.out_score; u.outh[c] = h.out_history; u.best[c] = h.bestscore;
+    return b;
+}
+
+__device__ __forceinline__ int32_t ft_pen(const FtDev &p, const int32_t *pp, int ci) { return p.has_pl ? pp[ci] : 0; }
+__device__ __forceinline__ int32_t ft_lm(const FtDev &p, int w3, int w2, int w1)
+{
+    const size_t n1 = (size_t)p.n_w + 1;
+    return p.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
+}
+// ngram_search_exit_score, ngram_search.c:653-674
+__device__ __forceinline__ int32_t ft_exit_score(const FtDev &p, const FtUtt &u, int bp, int rcphone)
+{
+    const int l2 = BPC(u, B_LAST2, bp);
+    if (l2 == -1) return BPC(u, B_SCORE, bp);
+    const int l1 = BPC(u, B_LAST, bp);
+    return u.bss[BPC(u, B_SIDX, bp) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + rcphone]];
+}
+// set_real_wid, ngram_search.c:341-372
+__device__ void ft_set_real_wid(const FtDev &p, FtUtt &u, int bp)
+{
+    const int prev = BPC(u, B_BP, bp), wid = BPC(u, B_WID, bp);
+    if (p.d_filler[wid]) {
+        if (prev != -1) { BPC(u, B_REAL, bp) = BPC(u, B_REAL, prev); BPC(u, B_PREAL, bp) = BPC(u, B_PREAL, prev); }
+        else { BPC(u, B_REAL, bp) = p.d_base[wid]; BPC(u, B_PREAL, bp) = -1; }
+    }
+    else {
+        BPC(u, B_REAL, bp) = p.d_base[wid];
+        BPC(u, B_PREAL, bp) = prev != -1 ? BPC(u, B_REAL, prev) : -1;
+    }
+}
+// ngram_search_save_bp, ngram_search.c:376-498 (single thread).  Returns false when a table is full.
+__device__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bss_head, int frame, int w, int32_t score,
+                           int32_t path, int rc)
+{
+    const int bp = u.word_lat_idx[w];
+    if (bp != -1) {
+        if (BPC(u, B_SCORE, bp) < score) {
+            const int ob = BPC(u, B_BP, bp);
+            if (ob != path) {
+                const int32_t b0 = ob == -1 ? -1 : BPC(u, B_PREAL, ob), b1 = ob == -1 ? -1 : BPC(u, B_REAL, ob);
+                const int32_t n0 = path == -1 ? -1 : BPC(u, B_PREAL, path), n1 = path == -1 ? -1 : BPC(u, B_REAL, path);
+                if (b0 != n0 || b1 != n1) ft_set_real_wid(p, u, bp);      // with the old bp still in place, as the reference
+                BPC(u, B_BP, bp) = path;
+            }
+            BPC(u, B_SCORE, bp) = score;
+        }
+        if (BPC(u, B_SIDX, bp) != -1) u.bss[BPC(u, B_SIDX, bp) + rc] = score;
+        return true;
+    }
+    if (bpidx >= u.bp_cap || bss_head + p.n_ci >= u.bss_cap) return false;
+    u.word_lat_idx[w] = bpidx;
+    BPC(u, B_WID, bpidx) = w; BPC(u, B_FRAME, bpidx) = frame; BPC(u, B_BP, bpidx) = path; BPC(u, B_SCORE, bpidx) = score;
+    BPC(u, B_SIDX, bpidx) = bss_head; BPC(u, B_VALID, bpidx) = 1;
+    BPC(u, B_LAST, bpidx) = p.d_last[w];
+    int rcsize = 0;
+    if (p.d_pronlen[w] == 1) { BPC(u, B_LAST2, bpidx) = -1; BPC(u, B_SIDX, bpidx) = -1; }
+    else {
+        BPC(u, B_LAST2, bpidx) = p.d_last2[w];
+        rcsize = p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]];
+    }
+    for (int i = 0; i < rcsize; ++i) u.bss[bss_head + i] = kW;
+    if (rcsize) u.bss[bss_head + rc] = score;
+    ft_set_real_wid(p, u, bpidx);
+    ++bpidx;
+    bss_head += rcsize;
+    return true;
+}
+
+template <int NE>
+__global__ __launch_bounds__(kFtThreads)
+void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
+                    const int32_t *__restrict__ penalties, const int32_t *__restrict__ utt_off)
+{
+    __shared__ int32_t s_cnt[kFtMaxN + 1];
+    __shared__ int32_t s_red[8];
+    __shared__ int32_t s_bins[256];
+    __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
+    __shared__ unsigned long long s_evals;
+    const int tid = threadIdx.x;
+    FtUtt u = utts[blockIdx.x];
+    const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
+    const int N = p.N, R = p.R, W1 = N, WC = N + p.n1;
+    int n_acl[2] = {0, 0}, n_awl[2] = {0, 0};           // uniform copies (every thread tracks them identically)
+
+    // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
+    for (int c = tid; c < N; c += kFtThreads) ch_init(p, u, c, c < R, p.node_ssid[c], p.node_tmat[c]);
+    for (int i = tid; i < p.n1; i += kFtThreads) ch_init(p, u, W1 + i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i]);
+    for (int i = tid; i < p.TOT; i += kFtThreads) u.present[i] = 0;
+    for (int w = tid; w < p.n_w; w += kFtThreads) { u.word_lat_idx[w] = -1; u.lt_sf[w] = -1; u.word_active[w] = 0; }
+    if (tid == 0) {
+        s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
+        s_evals = 0ull;
+    }
+    __syncthreads();
+    if (tid == 0) ch_enter(u, W1 + p.w1_of_word[p.startwid], 0, -1, 0);
+    __syncthreads();
+
+    for (int f = 0; f < T; ++f) {
+        const int cur = f & 1, nxt = cur ^ 1, nf = f + 1;
+        const int16_t *row = senscr + (size_t)(t0 + f) * scr_stride;
+        const int32_t *pp = penalties + (size_t)(t0 + f) * p.n_ci;
+        // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
+        if (tid == 0) u.bp_table_idx[f] = s_sc[3];
+        const int32_t best_in = s_sc[0];
+        if (best_in == kW || best_in < kW) break;
+        if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
+            for (int i = tid; i < R; i += kFtThreads) if (u.frame[i] == f) ch_normalize(p, u, i, best_in);
+            for (int i = tid; i < n_acl[cur]; i += kFtThreads) ch_normalize(p, u, u.acl[cur][i], best_in);
+            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+                const int w = u.awl[cur][i];
+                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) ch_normalize(p, u, WC + k, best_in);
+            }
+            for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) ch_normalize(p, u, W1 + i, best_in);
+        }
+        if (tid < 8) s_red[tid] = kW;
+        __syncthreads();
+        // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..5] counts
+        {
+            int32_t b0 = kW, b1 = kW, b2 = kW; int n0 = 0, n2 = 0;
+            for (int i = tid; i < R; i += kFtThreads)
+                if (u.frame[i] == f) { b0 = max(b0, ch_eval<NE>(p, u, i, row)); ++n0; }
+            for (int i = tid; i < n_acl[cur]; i += kFtThreads) b1 = max(b1, ch_eval<NE>(p, u, u.acl[cur][i], row));
+            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+                const int w = u.awl[cur][i];
+                u.word_active[w] = 0;
+                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
+                    if (u.present[k]) { b2 = max(b2, ch_eval<NE>(p, u, WC + k, row)); ++n2; }
+            }
+            for (int i = tid; i < p.n1; i += kFtThreads) {
+                if (u.frame[W1 + i] < f) continue;
+                const int32_t sc = ch_eval<NE>(p, u, W1 + i, row);
+                if (p.w1_wid[i] != p.finishwid) b2 = max(b2, sc);
+                ++n2;
+            }
+            atomicMax(&s_red[0], b0); atomicMax(&s_red[1], b1); atomicMax(&s_red[2], b2);
+            if (n0) atomicAdd(&s_red[3], n0 - 0);            // (s_red[3..4] start at kW: corrected below)
+            if (n2) atomicAdd(&s_red[4], n2);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int32_t bs = max(max(s_red[0], s_red[1]), s_red[2]);
+            s_sc[0] = bs; s_sc[1] = s_red[2];
+            s_evals += (unsigned long long)((s_red[3] - kW) + n_acl[cur] + (s_red[4] - kW));
+            s_sc[5] = 0;                                        // n_lastphn_cand
+            // dynamic beam (:1133-1181)
+            s_sc[2] = p.beam;
+        }
+        for (int i = tid; i < 256; i += kFtThreads) s_bins[i] = 0;
+        __syncthreads();
+        const int32_t best_score = s_sc[0];
+        if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
+            const int32_t bw = -p.beam / 256;
+            for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+                const int c = i < R ? i : u.acl[cur][i - R];
+                int32_t b = (best_score - u.best[c]) / bw;
+                if (b >= 256) b = 255;
+                atomicAdd(&s_bins[b], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int i, nh = 0;
+                for (i = 0; i < 256; ++i) { nh += s_bins[i]; if (nh > p.maxhmmpf) break; }
+                s_sc[2] = -(i * bw);
+            }
+            __syncthreads();
+        }
+        const int32_t thresh = best_score + s_sc[2];
+        const int32_t npt = best_score + p.pbeam, lpt = best_score + p.lpbeam;
+
+        // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation
+        for (int i = tid; i < N; i += kFtThreads) {
+            u.pos[i] = -1; u.o_frame[i] = u.frame[i]; u.o_s0[i] = u.score[i * 5]; u.o_best[i] = u.best[i];
+            u.o_out[i] = u.out[i]; u.o_outh[i] = u.outh[i];
+        }
+        __syncthreads();
+        for (int q = tid; q < n_acl[cur]; q += kFtThreads) u.pos[u.acl[cur][q]] = q;
+        __syncthreads();
+        // flag bits: 1 retained, 2 fire (listed by parent), 4 fire (not listed), 8 self-append
+        for (int c = tid; c < N; c += kFtThreads) {
+            const bool active = c < R ? u.o_frame[c] >= f : u.pos[c] >= 0;
+            u.flag[c] = (active && u.o_best[c] > thresh) ? 1 : 0;
+        }
+        __syncthreads();
+        for (int c = R + tid; c < N; c += kFtThreads) {
+            const int P = p.parent[c], pc = u.pos[c];
+            const bool in_acl = pc >= 0, retc = u.flag[c] & 1;
+            const int32_t news = u.o_out[P] + p.pip;
+            const bool par_active = P < R ? true : u.pos[P] >= 0;
+            const bool parent_can = par_active && (u.flag[P] & 1) && (p.has_pl || news > npt)
+                                    && (news + ft_pen(p, pp, p.node_ci[c]) > npt);
+            const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
+            bool fire;
+            if (!in_acl || parent_first) fire = parent_can && (u.o_frame[c] < f || news > u.o_s0[c]);
+            else if (retc)               fire = parent_can && news > u.o_s0[c];
+            else                         fire = parent_can;
+            const bool entered_first = fire && parent_first;
+            const bool selfapp = in_acl && retc && !entered_first;
+            const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
+            const bool cleared = in_acl && !retc && !entered_first;
+            if (cleared) ch_clear(p, u, c);
+            if (in_acl && retc) u.frame[c] = nf;
+            if (fire) ch_enter(u, c, news, u.o_outh[P], nf);
+            // decision word for the list phase; o_frame[c] is read by this thread only, so it can be reused
+            u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | (selfapp ? 8 : 0);
+        }
+        for (int i = tid; i < R; i += kFtThreads) if (u.flag[i] & 1) u.frame[i] = nf;
+        __syncthreads();
+        // list positions: root phase (segment per root), then one segment per list position
+        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+            const int node = i < R ? i : u.acl[cur][i - R];
+            int k = (i >= R && (u.o_frame[node] & 8)) ? 1 : 0;
+            for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) k += (u.o_frame[c] & 2) ? 1 : 0;
+            s_cnt[i] = k;
+        }
+        __syncthreads();
+        if (tid == 0) {                                          // exclusive prefix sum (small)
+            int run = 0;
+            for (int i = 0; i < R + n_acl[cur]; ++i) { const int k = s_cnt[i]; s_cnt[i] = run; run += k; }
+            s_cnt[R + n_acl[cur]] = run;
+        }
+        __syncthreads();
+        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+            const int node = i < R ? i : u.acl[cur][i - R];
+            int o = s_cnt[i];
+            if (i >= R && (u.o_frame[node] & 8)) u.acl[nxt][o++] = node;
+            for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.o_frame[c] & 2) u.acl[nxt][o++] = c;
+        }
+        n_acl[nxt] = s_cnt[R + n_acl[cur]];
+        __syncthreads();
+        // last-phone candidates: list order, homophone chain inside
+        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+            const int node = i < R ? i : u.acl[cur][i - R];
+            const int32_t news = u.o_out[node] + p.pip;
+            int k = 0;
+            if ((u.flag[node] & 1) && (p.has_pl || news > lpt))
+                for (int w = p.node_pw[node]; w >= 0; w = p.homophone[w]) k += (news + ft_pen(p, pp, p.d_last[w]) > lpt) ? 1 : 0;
+            s_cnt[i] = k;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int i = 0; i < R + n_acl[cur]; ++i) { const int k = s_cnt[i]; s_cnt[i] = run; run += k; }
+            s_sc[5] = run;
+        }
+        __syncthreads();
+        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+            const int node = i < R ? i : u.acl[cur][i - R];
+            const int32_t news = u.o_out[node] + p.pip;
+            int o = s_cnt[i];
+            if ((u.flag[node] & 1) && (p.has_pl || news > lpt))
+                for (int w = p.node_pw[node]; w >= 0; w = p.homophone[w])
+                    if (news + ft_pen(p, pp, p.d_last[w]) > lpt) {
+                        u.cand_wid[o] = w; u.cand_score[o] = news - p.nwpen; u.cand_bp[o] = u.o_outh[node]; ++o;
+                    }
+        }
+        __syncthreads();
+
+        // ---- word level: last_phone_transition, prune_word_chan, bptable_maxwpf (:884-1241); one thread
+        if (tid == 0) {
+            const int n_cand = s_sc[5];
+            int32_t bpidx = s_sc[3], bss_head = s_sc[4];
+            int n_csf = 0, nawl = 0;
+            bool ok = true;
+            for (int i = 0; i < n_cand; ++i) {
+                const int cb = u.cand_bp[i], w = u.cand_wid[i];
+                if (cb == -1) continue;
+                u.cand_score[i] -= ft_exit_score(p, u, cb, p.d_first[w]);
+                const int ef = BPC(u, B_FRAME, cb);
+                if (u.lt_sf[w] != ef + 1) {
+                    int j;
+                    for (j = 0; j < n_csf; ++j) if (u.csf_ef[j] == ef) break;
+                    if (j < n_csf) u.cand_next[i] = u.csf_cand[j];
+                    else { j = n_csf++; u.cand_next[i] = -1; u.csf_ef[j] = ef; }
+                    u.csf_cand[j] = i;
+                    u.lt_dscr[w] = kW;
+                    u.lt_sf[w] = ef + 1;
+                }
+            }
+            for (int i = 0; i < n_csf; ++i) {
+                const int b1 = u.bp_table_idx[u.csf_ef[i] + 1];
+                for (int bp = u.bp_table_idx[u.csf_ef[i]]; bp < b1; ++bp) {
+                    if (!BPC(u, B_VALID, bp)) continue;
+                    for (int j = u.csf_cand[i]; j >= 0; j = u.cand_next[j]) {
+                        const int w = u.cand_wid[j];
+                        int32_t dscr = ft_exit_score(p, u, bp, p.d_first[w]);
+                        if (dscr > kW) dscr += ft_lm(p, p.d_base[w], BPC(u, B_REAL, bp), BPC(u, B_PREAL, bp));
+                        if (dscr > u.lt_dscr[w]) { u.lt_dscr[w] = dscr; u.lt_bp[w] = bp; }
+                    }
+                }
+            }
+            int32_t bestscore = s_sc[1];
+            for (int i = 0; i < n_cand; ++i) {
+                const int w = u.cand_wid[i];
+                u.cand_score[i] += u.lt_dscr[w];
+                u.cand_bp[i] = u.lt_bp[w];
+                if (u.cand_score[i] > bestscore) bestscore = u.cand_score[i];
+            }
+            s_sc[1] = bestscore;
+            const int32_t cthresh = bestscore + p.lponlybeam;
+            for (int i = 0; i < n_cand; ++i) {
+                if (!(u.cand_score[i] > cthresh)) continue;
+                const int w = u.cand_wid[i];
+                // ngram_search_alloc_all_rc (ngram_search.c:583-633)
+                const int last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
+                for (int r = 0; r < nrc; ++r) {
+                    const int slot = p.wc_off[w] + r;
+                    if (!u.present[slot]) {
+                        ch_init(p, u, WC + slot, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last]);
+                        u.present[slot] = 1;
+                    }
+                }
+                int k = 0;
+                for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
+                    if (!u.present[slot]) continue;
+                    const int c = WC + slot;
+                    if (u.frame[c] < f || u.cand_score[i] > u.score[c * 5]) { ch_enter(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
+                }
+                if (k > 0) { u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
+            }
+            // prune_word_chan (:1038-1128)
+            const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
+            for (int i = 0; i < n_awl[cur] && ok; ++i) {
+                const int w = u.awl[cur][i];
+                int k = 0;
+                for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1] && ok; ++slot) {
+                    if (!u.present[slot]) continue;
+                    const int c = WC + slot;
+                    if (u.best[c] > lpth) {
+                        u.frame[c] = nf; ++k;
+                        if (u.out[c] > nwt) ok = ft_save_bp(p, u, bpidx, bss_head, f, w, u.out[c], u.outh[c], slot - p.wc_off[w]);
+                    }
+                    else if (u.frame[c] != nf) u.present[slot] = 0;
+                }
+                if (k > 0 && !u.word_active[w]) { u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
+            }
+            for (int i = 0; i < p.n1 && ok; ++i) {
+                const int c = W1 + i;
+                if (u.frame[c] < f) continue;
+                if (u.best[c] > lpth) {
+                    u.frame[c] = nf;
+                    if (u.out[c] > nwt) ok = ft_save_bp(p, u, bpidx, bss_head, f, p.w1_wid[i], u.out[c], u.outh[c], 0);
+                }
+            }
+            // bptable_maxwpf (:1193-1241)
+            if (!(p.maxwpf == -1 || p.maxwpf == p.n_w)) {
+                const int b0 = u.bp_table_idx[f];
+                int32_t bestscr = kMaxNegInt32; int bestbp = -1, n = 0;
+                for (int bp = b0; bp < bpidx; ++bp)
+                    if (p.d_filler[BPC(u, B_WID, bp)]) {
+                        if (BPC(u, B_SCORE, bp) > bestscr) { bestscr = BPC(u, B_SCORE, bp); bestbp = bp; }
+                        BPC(u, B_VALID, bp) = 0; ++n;
+                    }
+                if (bestbp >= 0) { BPC(u, B_VALID, bestbp) = 1; --n; }
+                n = (bpidx - b0) - n;
+                for (; n > p.maxwpf; --n) {
+                    int32_t worst = 0x7fffffff; int wbp = -1;
+                    for (int bp = b0; bp < bpidx; ++bp)
+                        if (BPC(u, B_VALID, bp) && BPC(u, B_SCORE, bp) < worst) { worst = BPC(u, B_SCORE, bp); wbp = bp; }
+                    if (wbp < 0) break;
+                    BPC(u, B_VALID, wbp) = 0;
+                }
+            }
+            s_sc[3] = bpidx; s_sc[4] = bss_head; s_red[5] = nawl; if (!ok) s_sc[6] = 1;
+        }
+        __syncthreads();
+        n_awl[nxt] = s_red[5];
+        if (s_sc[6]) break;
+
+        // ---- word_transition (:1243-1427)
+        const int bp0 = u.bp_table_idx[f], bp1 = s_sc[3];
+        int32_t *brc_score = s_bins, *brc_path = s_bins + kFtMaxCi, *brc_lc = s_bins + 2 * kFtMaxCi;
+        if (tid == 0) s_red[6] = 0;
+        __syncthreads();
+        for (int bp = bp0 + tid; bp < bp1; bp += kFtThreads) {
+            u.word_lat_idx[BPC(u, B_WID, bp)] = -1;
+            if (BPC(u, B_WID, bp) != p.finishwid) atomicAdd(&s_red[6], 1);
+        }
+        for (int rc = tid; rc < p.n_ci; rc += kFtThreads) {     // best exit per right-context phone, earliest bp on ties
+            int32_t bs = kW; int path = 0, lc = 0;
+            for (int bp = bp0; bp < bp1; ++bp) {
+                if (BPC(u, B_WID, bp) == p.finishwid) continue;
+                const int l2 = BPC(u, B_LAST2, bp), l1 = BPC(u, B_LAST, bp);
+                const int32_t sc = l2 == -1 ? BPC(u, B_SCORE, bp)
+                    : u.bss[BPC(u, B_SIDX, bp) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + rc]];
+                if (sc > bs) { bs = sc; path = bp; lc = l1; }
+            }
+            brc_score[rc] = bs; brc_path[rc] = path; brc_lc[rc] = lc;
+        }
+        __syncthreads();
+        if (s_red[6] > 0) {
+            for (int i = tid; i < R; i += kFtThreads) {          // tree roots (:1306-1325)
+                const int ci = p.node_ci[i];
+                const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
+                if (ns + ft_pen(p, pp, ci) > thresh && (u.frame[i] < f || ns > u.score[i * 5])) {
+                    ch_enter(u, i, ns, brc_path[ci], nf);
+                    u.senid[i * 5] = p.ldiph[((size_t)ci * p.n_ci + p.node_ci2[i]) * p.n_ci + brc_lc[ci]];
+                }
+            }
+            for (int i = tid; i < p.n1lm; i += kFtThreads) {     // in-LM single-phone words (:1331-1388)
+                const int w = p.w1_wid[i];
+                int32_t ds = kMaxNegInt32; int dbp = 0;
+                for (int bp = bp0; bp < bp1; ++bp) {
+                    if (!BPC(u, B_VALID, bp)) continue;
+                    int32_t ns = ft_exit_score(p, u, bp, p.d_first[w]);
+                    if (ns != kW) ns += ft_lm(p, p.d_base[w], BPC(u, B_REAL, bp), BPC(u, B_PREAL, bp));
+                    if (ns > ds) { ds = ns; dbp = bp; }
+                }
+                u.lt_dscr[w] = ds; u.lt_bp[w] = dbp;
+                if (w == p.startwid) continue;
+                const int c = W1 + i;
+                const int32_t ns = ds + p.pip;
+                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[c] < f || ns > u.score[c * 5])) {
+                    ch_enter(u, c, ns, dbp, nf);
+                    u.senid[c * 5] = p.ldiph[((size_t)p.w1_ci[i] * p.n_ci + p.w1_ci2[i]) * p.n_ci + p.d_last[BPC(u, B_WID, dbp)]];
+                }
+            }
+            for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += kFtThreads) {    // <sil> and noise words (:1390-1426)
+                // slot filler_start - 1 stands for <sil>, which is handled whatever its place in the dictionary
+                const bool is_sil = w == p.filler_start - 1;
+                if (!is_sil && (w == p.startwid || w == p.silwid)) continue;
+                const int i = p.w1_of_word[is_sil ? p.silwid : w];
+                if (i < 0) continue;
+                const int c = W1 + i;
+                const int32_t ns = brc_score[p.sil_ci] + (is_sil ? p.silpen : p.fillpen) + p.pip;
+                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[c] < f || ns > u.score[c * 5]))
+                    ch_enter(u, c, ns, brc_path[p.sil_ci], nf);
+            }
+        }
+        __syncthreads();
+        // ---- deactivate_channels (:1429-1450)
+        for (int i = tid; i < R; i += kFtThreads) if (u.frame[i] == f) ch_clear(p, u, i);
+        for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) ch_clear(p, u, W1 + i);
+        if (tid == 0) {
+            u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = s_sc[1]; u.step[f * 4 + 2] = s_sc[3]; u.step[f * 4 + 3] = n_acl[nxt];
+            ++s_sc[7];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        u.bp_table_idx[s_sc[7]] = s_sc[3];                       // ngram_fwdtree_finish: mark one past the last frame
+        u.result[0] = s_sc[3]; u.result[1] = s_sc[4]; u.result[2] = s_sc[7]; u.result[3] = s_sc[6];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T>
+static const T *ft_up(psgpu_fwdtree_s *m, const T *src, size_t n, int *rc)
+{
+    void *d = nullptr;
+    if (*rc != PSGPU_OK) return nullptr;
+    if (hipMalloc(&d, n * sizeof(T) ? n * sizeof(T) : 1) != hipSuccess ||
+        hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        psgpu_set_error("fwdtree model upload failed");
+        *rc = PSGPU_ENOMEM;
+        hipFree(d);
+        return nullptr;
+    }
+    m->allocs.push_back(d);
+    return (const T *)d;
+}
+
+extern "C" {
+
+int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
+{
+    PSGPU_REQUIRE(out && t && t->par, "psgpu_fwdtree_create: NULL argument");
+    *out = nullptr;
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    const int32_t *q = t->par;
+    psgpu_fwdtree_s *m = new psgpu_fwdtree_s();
+    FtDev &d = m->d;
+    memset(&d, 0, sizeof d);
+    d.n_ci = q[0]; d.n_emit = q[1]; d.n_sen = q[2]; d.n_w = q[3]; d.R = q[4]; d.M = q[5]; d.N = d.R + d.M; d.n1 = q[6];
+    d.n1lm = q[7]; d.beam = q[8]; d.pbeam = q[9]; d.lpbeam = q[10]; d.lponlybeam = q[11]; d.wbeam = q[12]; d.pip = q[13];
+    d.nwpen = q[14]; d.silpen = q[15]; d.fillpen = q[16]; d.maxhmmpf = q[17]; d.maxwpf = q[18]; d.startwid = q[19];
+    d.finishwid = q[20]; d.silwid = q[21]; d.filler_start = q[22]; d.filler_end = q[23]; d.sil_ci = q[24]; d.has_pl = q[25];
+    if (!(d.n_emit == 3 || d.n_emit == 5) || d.n_ci < 1 || d.n_ci > kFtMaxCi || d.N < 1 || d.N + d.R > kFtMaxN || d.n_w < 1 || d.n_w > 1024) {
+        psgpu_set_error("fwdtree: unsupported shape (n_emit %d, n_ci %d, tree nodes %d, words %d)", d.n_emit, d.n_ci, d.N, d.n_w);
+        delete m;
+        return PSGPU_EINVAL;
+    }
+    const size_t nci3 = (size_t)d.n_ci * d.n_ci * d.n_ci, n1 = (size_t)d.n_w + 1;
+    std::vector<int32_t> parent(d.N, -1), w1_of(d.n_w, -1), wc_off(d.n_w + 1, 0);
+    for (int i = 0; i < d.N; ++i)
+        for (int c = t->node_child[i]; c >= 0; c = t->node_sib[c]) parent[c] = i;
+    for (int i = 0; i < d.n1; ++i) w1_of[t->w1_wid[i]] = i;
+    int tot = 0;
+    for (int w = 0; w < d.n_w; ++w) {
+        wc_off[w] = tot;
+        if (t->dict_pronlen[w] > 1) tot += t->rssid_n[t->dict_last[w] * d.n_ci + t->dict_last2[w]];
+    }
+    wc_off[d.n_w] = tot;
+    d.TOT = tot;
+    m->C = d.N + d.n1 + tot;
+    d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
+    d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
+    d.node_child = ft_up(m, t->node_child, d.N, &rc); d.node_sib = ft_up(m, t->node_sib, d.N, &rc);
+    d.node_pw = ft_up(m, t->node_penult_wid, d.N, &rc); d.parent = ft_up(m, parent.data(), d.N, &rc);
+    d.homophone = ft_up(m, t->homophone_set, d.n_w, &rc);
+    d.w1_wid = ft_up(m, t->w1_wid, d.n1, &rc); d.w1_ci = ft_up(m, t->w1_ci, d.n1, &rc); d.w1_ci2 = ft_up(m, t->w1_ci2, d.n1, &rc);
+    d.w1_ssid = ft_up(m, t->w1_ssid, d.n1, &rc); d.w1_tmat = ft_up(m, t->w1_tmat, d.n1, &rc); d.w1_mpx = ft_up(m, t->w1_mpx, d.n1, &rc);
+    d.w1_of_word = ft_up(m, w1_of.data(), d.n_w, &rc);
+    d.d_pronlen = ft_up(m, t->dict_pronlen, d.n_w, &rc); d.d_first = ft_up(m, t->dict_first, d.n_w, &rc);
+    d.d_last = ft_up(m, t->dict_last, d.n_w, &rc); d.d_last2 = ft_up(m, t->dict_last2, d.n_w, &rc);
+    d.d_base = ft_up(m, t->dict_basewid, d.n_w, &rc); d.d_filler = ft_up(m, t->dict_filler, d.n_w, &rc);
+    d.rs_n = ft_up(m, t->rssid_n, (size_t)d.n_ci * d.n_ci, &rc); d.rs_ssid = ft_up(m, t->rssid_ssid, nci3, &rc);
+    d.rs_cimap = ft_up(m, t->rssid_cimap, nci3, &rc); d.ldiph = ft_up(m, t->ldiph_lc, nci3, &rc);
+    d.ci_tmat = ft_up(m, t->ci_tmat, d.n_ci, &rc); d.lm = ft_up(m, t->lm, (size_t)d.n_w * n1 * n1, &rc);
+    d.wc_off = ft_up(m, wc_off.data(), (size_t)d.n_w + 1, &rc);
+    d.tp = ft_up(m, t->tp, (size_t)t->n_tmat * d.n_emit * (d.n_emit + 1), &rc);
+    d.sseq = ft_up(m, t->sseq, (size_t)t->n_sseq * d.n_emit, &rc);
+    if (rc != PSGPU_OK) { psgpu_fwdtree_free(m); return rc; }
+    *out = m;
+    return PSGPU_OK;
+}
+
+void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
+{
+    if (!m) return;
+    for (void *p : m->allocs) hipFree(p);
+    delete m;
+}
+
+// Search n_utt utterances.  senscr_dev [total][scr_stride] int16: the scores acmod_score hands the search for each
+// frame; penalties_dev [total][n_ci]; utt_off_dev [n_utt + 1].  Per utterance u the columns of the back-pointer
+// table go to bp_dev + u * 10 * bp_cap, the score stack to bss_dev + u * bss_cap, the frame marks to
+// idx_dev + u * (max_frames + 2), per-frame diagnostics to step_dev + u * max_frames * 4, and
+// result_dev + u * 8 = {n back-pointers, score-stack length, frames searched, status (1 = a table was full)}.
+int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                             const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                             int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                             int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0, "psgpu_fwdtree_search_dev: bad argument");
+    if (n_utt == 0) return PSGPU_OK;
+    PSGPU_REQUIRE(senscr_dev && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
+                  "psgpu_fwdtree_search_dev: NULL device buffer");
+    const FtDev &d = m->d;
+    hipStream_t st = (hipStream_t)stream;
+    // per-utterance work slab
+    const size_t C = m->C;
+    const size_t per = C * (5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
+                     + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64;
+    int32_t *slab = nullptr;
+    FtUtt *d_utts = nullptr;
+    PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * per * n_utt));
+    std::vector<FtUtt> hu(n_utt);
+    for (int i = 0; i < n_utt; ++i) {
+        int32_t *q = slab + per * i;
+        FtUtt &u = hu[i];
+        auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
+        u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
+        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.present = take(d.TOT);
+        u.acl[0] = take(d.N); u.acl[1] = take(d.N); u.awl[0] = take(d.n_w); u.awl[1] = take(d.n_w);
+        u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
+        u.cand_wid = take(d.n_w + 1); u.cand_score = take(d.n_w + 1); u.cand_bp = take(d.n_w + 1); u.cand_next = take(d.n_w + 1);
+        u.lt_sf = take(d.n_w); u.lt_dscr = take(d.n_w); u.lt_bp = take(d.n_w);
+        u.csf_ef = take(d.n_w + 1); u.csf_cand = take(d.n_w + 1);
+        u.o_frame = take(d.N); u.o_s0 = take(d.N); u.o_best = take(d.N); u.o_out = take(d.N); u.o_outh = take(d.N);
+        u.pos = take(d.N); u.flag = take(d.N);
+        u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
+        u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
+        u.result = result_dev + (size_t)i * 8;
+        u.bp_cap = bp_cap; u.bss_cap = bss_cap;
+    }
+    hipError_t e = hipMalloc((void **)&d_utts, sizeof(FtUtt) * n_utt);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FtUtt) * n_utt, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          // hu is about to go out of scope
+    if (e != hipSuccess) { hipFree(slab); hipFree(d_utts); PSGPU_HIP(e); }
+    if (d.n_emit == 3)
+        hipLaunchKernelGGL((fwdtree_kernel<3>), dim3(n_utt), dim3(kFtThreads), 0, st, d, d_utts, senscr_dev, scr_stride,
+                           penalties_dev, utt_off_dev);
+    else
+        hipLaunchKernelGGL((fwdtree_kernel<5>), dim3(n_utt), dim3(kFtThreads), 0, st, d, d_utts, senscr_dev, scr_stride,
+                           penalties_dev, utt_off_dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
+    hipFree(slab); hipFree(d_utts);
+    PSGPU_HIP(e);
+    return PSGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+"""Host-side mirror of the lexicon-tree search object (ngram_search_t's fwdtree half, reference
+src/ngram_search_fwdtree.c); arithmetic in csrc/psgpu_search.hip."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_NAMES = ["par", "node_ci", "node_ci2", "node_ssid", "node_tmat", "node_child", "node_sib", "node_penult_wid",
+          "homophone_set", "w1_wid", "w1_ci", "w1_ci2", "w1_ssid", "w1_tmat", "w1_mpx", "dict_pronlen", "dict_first",
+          "dict_last", "dict_last2", "dict_basewid", "dict_filler", "rssid_n", "rssid_ssid", "rssid_cimap", "ldiph_lc",
+          "tp", "sseq", "ci_tmat", "lm"]
+_DT = {"tp": np.uint8, "sseq": np.uint16}
+
+
+class _Tables(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _NAMES] + [("n_tmat", C.c_int32), ("n_sseq", C.c_int32)]
+
+
+class FwdtreeSearch:
+    """`static` = the flattened search tables (what `ref_dump fwdtree` writes / an integration reads out
+    of its ngram_search_t), `par` = sizes, beams, penalties and special word ids."""
+
+    BP_COLS = ("frame", "valid", "wid", "bp", "score", "s_idx", "real_wid", "prev_real_wid", "last_phone", "last2_phone")
+
+    def __init__(self, static, par):
+        src = dict(static); src["par"] = par
+        self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES}
+        t = _Tables(*[self._keep[n].ctypes.data for n in _NAMES], int(self._keep["tp"].shape[0]), int(self._keep["sseq"].shape[0]))
+        self.h = C.c_void_p()
+        capi.check(capi.lib().psgpu_fwdtree_create(C.byref(self.h), C.byref(t)), "psgpu_fwdtree_create")
+        self.n_sen = int(par[2]); self.n_ci = int(par[0])
+
+    def close(self):
+        if self.h:
+            capi.lib().psgpu_fwdtree_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19):
+        """senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back.  Returns a list of
+        dicts (bp [n][10], bscore_stack, bp_table_idx, step [frames][4], status) per utterance."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        senscr = np.ascontiguousarray(senscr, np.int16); penalties = np.ascontiguousarray(penalties, np.int32)
+        off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
+        T = int(off[-1]); n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
+        assert senscr.shape == (T, self.n_sen) and penalties.shape == (T, self.n_ci)
+        d_s = torch.from_numpy(senscr).to(dev); d_p = torch.from_numpy(penalties).to(dev); d_o = torch.from_numpy(off).to(dev)
+        bp = torch.zeros((n, 10, bp_cap), dtype=torch.int32, device=dev)
+        bss = torch.zeros((n, bss_cap), dtype=torch.int32, device=dev)
+        idx = torch.zeros((n, mf + 2), dtype=torch.int32, device=dev)
+        step = torch.zeros((n, max(mf, 1), 4), dtype=torch.int32, device=dev)
+        res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+        p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        capi.check(capi.lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap,
+                                                       bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "psgpu_fwdtree_search_dev")
+        out = []
+        res_h = res.cpu().numpy()
+        for u in range(n):
+            nb, nh, nfr, status = [int(v) for v in res_h[u, :4]]
+            out.append(dict(bp=bp[u, :, :nb].cpu().numpy().T.copy(), bscore_stack=bss[u, :nh].cpu().numpy(),
+                            bp_table_idx=idx[u, :nfr + 1].cpu().numpy(), step=step[u, :nfr].cpu().numpy(),
+                            n_frame=nfr, status=status))
+        return out
