@@ -377,9 +377,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         // ---- word level: last_phone_transition, prune_word_chan, bptable_maxwpf (:884-1241); one thread
         if (tid == 0) {
             const int n_cand = s_sc[5];
-            int32_t bpidx = s_sc[3], bss_head = s_sc[4];
-            int n_csf = 0, nawl = 0;
-            bool ok = true;
+            int n_csf = 0;
             for (int i = 0; i < n_cand; ++i) {
                 const int cb = u.cand_bp[i], w = u.cand_wid[i];
                 if (cb == -1) continue;
@@ -415,43 +413,101 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 if (u.cand_score[i] > bestscore) bestscore = u.cand_score[i];
             }
             s_sc[1] = bestscore;
-            const int32_t cthresh = bestscore + p.lponlybeam;
-            for (int i = 0; i < n_cand; ++i) {
-                if (!(u.cand_score[i] > cthresh)) continue;
+            s_sc[5] = n_cand;
+        }
+        __syncthreads();
+        {
+            // ---- last_phone_transition's entering loop (:1004-1030), one thread per candidate.  Candidates of
+            //      one frame name distinct words (a word has one penultimate tree node) -- if that ever fails the
+            //      loop is run by one thread in candidate order.
+            const int n_cand = s_sc[5];
+            const int32_t cthresh = s_sc[1] + p.lponlybeam;
+            if (tid == 0) s_red[7] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_cand; i += kFtThreads) {
                 const int w = u.cand_wid[i];
-                // ngram_search_alloc_all_rc (ngram_search.c:583-633)
-                const int last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
-                for (int r = 0; r < nrc; ++r) {
-                    const int slot = p.wc_off[w] + r;
-                    if (!u.present[slot]) {
-                        ch_init(p, u, WC + slot, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last]);
-                        u.present[slot] = 1;
+                for (int j = 0; j < i; ++j) if (u.cand_wid[j] == w) s_red[7] = 1;
+            }
+            __syncthreads();
+            const bool dup = s_red[7] != 0;
+            for (int i = (dup ? (tid == 0 ? 0 : n_cand) : tid); i < n_cand; i += (dup ? 1 : kFtThreads)) {
+                int k = 0;
+                if (u.cand_score[i] > cthresh) {
+                    const int w = u.cand_wid[i];
+                    // ngram_search_alloc_all_rc (ngram_search.c:583-633)
+                    const int last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
+                    for (int r = 0; r < nrc; ++r) {
+                        const int slot = p.wc_off[w] + r;
+                        if (!u.present[slot]) {
+                            ch_init(p, u, WC + slot, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last]);
+                            u.present[slot] = 1;
+                        }
+                    }
+                    for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
+                        if (!u.present[slot]) continue;
+                        const int c = WC + slot;
+                        if (u.frame[c] < f || u.cand_score[i] > u.score[c * 5]) { ch_enter(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
                     }
                 }
-                int k = 0;
+                s_cnt[i] = k > 0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int nawl = 0;
+                for (int i = 0; i < n_cand; ++i)
+                    if (s_cnt[i]) { const int w = u.cand_wid[i]; u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
+                s_red[5] = nawl;
+            }
+            __syncthreads();
+            // ---- prune_word_chan (:1038-1128): pass A, one thread per active word -- keep / free the
+            //      right-context channels, count the survivors, note whether the word exits
+            const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
+            int32_t *w_k = s_cnt, *w_exit = s_cnt + 1024, *w_bp = s_cnt + 2048, *w_bss = s_cnt + 3072;   // n_awl <= n_w <= 1024
+            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+                const int w = u.awl[cur][i];
+                int k = 0, ex = 0;
                 for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
                     if (!u.present[slot]) continue;
                     const int c = WC + slot;
-                    if (u.frame[c] < f || u.cand_score[i] > u.score[c * 5]) { ch_enter(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
-                }
-                if (k > 0) { u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
-            }
-            // prune_word_chan (:1038-1128)
-            const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            for (int i = 0; i < n_awl[cur] && ok; ++i) {
-                const int w = u.awl[cur][i];
-                int k = 0;
-                for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1] && ok; ++slot) {
-                    if (!u.present[slot]) continue;
-                    const int c = WC + slot;
-                    if (u.best[c] > lpth) {
-                        u.frame[c] = nf; ++k;
-                        if (u.out[c] > nwt) ok = ft_save_bp(p, u, bpidx, bss_head, f, w, u.out[c], u.outh[c], slot - p.wc_off[w]);
-                    }
+                    if (u.best[c] > lpth) { u.frame[c] = nf; ++k; ex |= (u.out[c] > nwt); }
                     else if (u.frame[c] != nf) u.present[slot] = 0;
                 }
-                if (k > 0 && !u.word_active[w]) { u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
+                w_k[i] = k; w_exit[i] = ex;
             }
+            __syncthreads();
+            if (tid == 0) {                                     // positions: back-pointers, score stack, next active words
+                int32_t bpidx = s_sc[3], bss_head = s_sc[4];
+                int nawl = s_red[5];
+                for (int i = 0; i < n_awl[cur]; ++i) {
+                    const int w = u.awl[cur][i];
+                    w_bp[i] = bpidx; w_bss[i] = bss_head;
+                    if (w_exit[i]) { ++bpidx; bss_head += p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]]; }
+                    if (w_k[i] > 0 && !u.word_active[w]) { u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
+                }
+                if (bpidx + p.n1 >= u.bp_cap || bss_head + p.n_ci >= u.bss_cap) s_sc[6] = 1;
+                s_sc[3] = bpidx; s_sc[4] = bss_head; s_red[5] = nawl;
+            }
+            __syncthreads();
+            if (!s_sc[6]) {
+                // pass B: every exiting word writes its own back-pointer (first exit creates, the others update)
+                for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+                    if (!w_exit[i]) continue;
+                    const int w = u.awl[cur][i];
+                    int32_t bpi = w_bp[i], bsh = w_bss[i];
+                    for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
+                        if (!u.present[slot]) continue;
+                        const int c = WC + slot;
+                        if (u.frame[c] == nf && u.best[c] > lpth && u.out[c] > nwt)
+                            ft_save_bp(p, u, bpi, bsh, f, w, u.out[c], u.outh[c], slot - p.wc_off[w]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0 && !s_sc[6]) {
+            int32_t bpidx = s_sc[3], bss_head = s_sc[4];
+            bool ok = true;
+            const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
             for (int i = 0; i < p.n1 && ok; ++i) {
                 const int c = W1 + i;
                 if (u.frame[c] < f) continue;
@@ -479,7 +535,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     BPC(u, B_VALID, wbp) = 0;
                 }
             }
-            s_sc[3] = bpidx; s_sc[4] = bss_head; s_red[5] = nawl; if (!ok) s_sc[6] = 1;
+            s_sc[3] = bpidx; s_sc[4] = bss_head; if (!ok) s_sc[6] = 1;
         }
         __syncthreads();
         n_awl[nxt] = s_red[5];

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Throughput of the device lexicon-tree search (psgpu_fwdtree_search_dev) on replicas of a golden
+trace: B utterances in one launch (one workgroup each).  Prints frames/s and the per-utterance time."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import pocketsphinx_amd as P
+    from test_search_gpu import _inputs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_goforward.npz"))
+    st = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_en_us_turtle.npz"))
+    s = P.FwdtreeSearch({k: st[k] for k in st.files}, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    import ctypes as C
+    from pocketsphinx_amd import capi
+    dev = torch.device("cuda", 0)
+    T = rows.shape[0]
+    d_rows = torch.from_numpy(rows).to(dev); d_pen1 = torch.from_numpy(pen).to(dev)
+    for B in [int(x) for x in os.environ.get("SB_BATCHES", "1,64,512").split(",")]:
+        # every utterance reads the same device rows (scr offsets repeat): inputs resident, as in a pipeline
+        d_s = d_rows.repeat(B, 1); d_p = d_pen1.repeat(B, 1)
+        nb = B
+        uo = torch.from_numpy((np.arange(nb + 1) * T).astype(np.int32)).to(dev)
+        bp_cap, bss_cap = 4096, 65536
+        bp = torch.zeros((nb, 10, bp_cap), dtype=torch.int32, device=dev); bss = torch.zeros((nb, bss_cap), dtype=torch.int32, device=dev)
+        idx = torch.zeros((nb, T + 2), dtype=torch.int32, device=dev); step = torch.zeros((nb, T, 4), dtype=torch.int32, device=dev)
+        res = torch.zeros((nb, 8), dtype=torch.int32, device=dev)
+        p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def run():
+            capi.check(capi.lib().psgpu_fwdtree_search_dev(s.h, p(d_s), C.c_int64(s.n_sen), p(d_p), p(uo), nb, T, bp_cap, bss_cap,
+                                                           p(bp), p(bss), p(idx), p(step), p(res), sp), "search")
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        nbp = int(res[0, 0].item())
+        ok = nbp == g["bp"].shape[0] and np.array_equal(bp[0, :, :nbp].cpu().numpy().T, g["bp"])
+        print("B=%d (%d launches of %d): %.4f s, %.0f frames/s, %.2f ms per launch, tables ok: %s" % (
+            nb * reps, reps, nb, dt, nb * reps * T / dt, 1e3 * dt / reps, ok))
+
+
+if __name__ == "__main__":
+    main()
