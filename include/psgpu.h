@@ -523,11 +523,18 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m);
  * bss_dev + u*bss_cap, bp_table_idx at idx_dev + u*(max_frames + 2), per-frame
  * {best_score, last_phone_best_score, bpidx, n_active_chan} at step_dev + u*max_frames*4, and
  * result_dev + u*8 = {n back-pointers, score-stack length, frames searched, status (1: a table
- * was full)}.  Synchronous on `stream`. */
+ * was full)}.  Synchronous on `stream`.
+ * raw_scores = 1: senscr_dev holds the scorer's UN-normalised rows (PSGPU_PTM_RAW_SCORES) and
+ * penalties_dev the phone loop's output per phone-loop frame (psgpu_phone_loop_run_dev): the kernel
+ * then builds each frame's active senone list itself (compute_sen_active + acmod_flags2list,
+ * bridging entries included), subtracts its minimum as the scorer would (ptm_mgau.c:393-400), and
+ * reads the penalties of frame min(f + pl_window, T - 1) -- i.e. it is fed directly by the other
+ * kernels, nothing passes through the host. */
 int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
                              const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
                              int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
-                             int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream);
+                             int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
+                             int32_t pl_window, void *stream);
 
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).

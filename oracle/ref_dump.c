@@ -1015,6 +1015,14 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
     par[23] = dict_filler_end(dict); par[24] = mdef->sil; par[25] = ps_search_lookahead(ngs) != NULL;
     par[26] = acmod->compallsen;
     put1("par", 'i', 32, par);
+    if (ps->phone_loop) {   /* the phone-loop search feeding the look-ahead penalties (phone_loop_search.h:75-94) */
+        phone_loop_search_t *pls = (phone_loop_search_t *)ps->phone_loop;
+        int32 pp[8] = { pls->n_phones, pls->window, pls->beam, pls->pbeam, pls->pip, ps->pl_window, 0, 0 };
+        int32 *ss = calloc(pls->n_phones, 4), *tm = calloc(pls->n_phones, 4);
+        for (i = 0; i < pls->n_phones; ++i) { ss[i] = hmm_nonmpx_ssid(&pls->hmms[i]); tm[i] = pls->hmms[i].tmatid; }
+        put1("pl_par", 'i', 8, pp); put1("pl_weight", 'd', 1, &pls->penalty_weight);
+        put1("pl_ssid", 'i', pls->n_phones, ss); put1("pl_tmat", 'i', pls->n_phones, tm);
+    }
     {   /* the language model over dictionary word ids */
         size_t n1 = (size_t)n_w + 1;
         int32 *lm;

@@ -28,6 +28,7 @@
 constexpr int kFtThreads = 256;
 constexpr int kFtMaxN = 4096;          // tree nodes (LDS scratch of the pruning)
 constexpr int kFtMaxCi = 64;
+constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
 
 struct FtDev {
     int32_t n_ci, n_emit, n_sen, n_w, R, M, N, n1, n1lm, TOT;
@@ -60,6 +61,7 @@ struct FtUtt {
     int32_t *o_frame, *o_s0, *o_best, *o_out, *o_outh, *pos, *flag;   // [N] pruning snapshot / decisions
     int32_t *step;                       // [T][4] best_score, last_phone_best_score, bpidx, n_active_chan (diagnostics)
     int32_t *result;                     // [8] bpidx, bss_head, n_frame, status
+    int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
     int32_t bp_cap, bss_cap;
 };
 
@@ -188,8 +190,12 @@ __device__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bs
 template <int NE>
 __global__ __launch_bounds__(kFtThreads)
 void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
-                    const int32_t *__restrict__ penalties, const int32_t *__restrict__ utt_off)
+                    const int32_t *__restrict__ penalties, const int32_t *__restrict__ utt_off, int32_t raw_mode,
+                    int32_t pl_window)
 {
+    __shared__ uint32_t s_bits[kFtMaxSen / 32];
+    __shared__ int32_t s_prev[kFtMaxSen / 32];
+    __shared__ int32_t s_nb;
     __shared__ int32_t s_cnt[kFtMaxN + 1];
     __shared__ int32_t s_red[8];
     __shared__ int32_t s_bins[256];
@@ -217,7 +223,65 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1;
         const int16_t *row = senscr + (size_t)(t0 + f) * scr_stride;
-        const int32_t *pp = penalties + (size_t)(t0 + f) * p.n_ci;
+        // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
+        const int32_t *pp = penalties + (size_t)(t0 + (raw_mode ? min(f + pl_window, T - 1) : f)) * p.n_ci;
+        if (raw_mode) {
+            // ---- compute_sen_active (:526-564) + acmod_flags2list (acmod.c:1223-1275) + the scorer's
+            //      active-list normalisation (ptm_mgau.c:393-400) on un-normalised rows: the frame's scores
+            //      are raw - min over the listed senones, bridging entries included
+            const int nwords = (p.n_sen + 31) >> 5;
+            for (int i = tid; i < nwords; i += kFtThreads) s_bits[i] = 0u;
+            if (tid == 0) s_nb = 0x7fffffff;
+            __syncthreads();
+            auto mark = [&](int c) {
+                for (int k = 0; k < NE; ++k) {
+                    int sen = u.senid[c * 5 + k];
+                    if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + k]; }
+                    atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
+                }
+            };
+            for (int i = tid; i < R; i += kFtThreads) if (u.frame[i] == f) mark(i);
+            for (int i = tid; i < n_acl[cur]; i += kFtThreads) mark(u.acl[cur][i]);
+            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+                const int w = u.awl[cur][i];
+                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) mark(WC + k);
+            }
+            for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) mark(W1 + i);
+            __syncthreads();
+            if (tid == 0) {
+                int last = -1;
+                for (int w = 0; w < nwords; ++w) {
+                    s_prev[w] = last;
+                    if (s_bits[w]) last = w * 32 + 31 - __clz((int)s_bits[w]);
+                }
+            }
+            __syncthreads();
+            int32_t mn = 0x7fffffff;
+            for (int w = tid; w < nwords; w += kFtThreads) {
+                uint32_t b = s_bits[w];
+                int prev = s_prev[w];
+                while (b) {
+                    const int sen = w * 32 + __ffs((int)b) - 1;
+                    b &= b - 1;
+                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; mn = min(mn, (int32_t)row[last]); }
+                    mn = min(mn, (int32_t)row[sen]);
+                    prev = sen;
+                }
+            }
+            atomicMin(&s_nb, mn);
+            __syncthreads();
+            const int32_t nb = s_nb;
+            for (int w = tid; w < nwords; w += kFtThreads) {
+                uint32_t b = s_bits[w];
+                while (b) {
+                    const int sen = w * 32 + __ffs((int)b) - 1;
+                    b &= b - 1;
+                    u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)row[sen] - (uint32_t)nb);
+                }
+            }
+            __syncthreads();
+            row = u.nrow;
+        }
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
         if (tid == 0) u.bp_table_idx[f] = s_sc[3];
         const int32_t best_in = s_sc[0];
@@ -707,9 +771,12 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
 int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
                              const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
                              int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
-                             int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream)
+                             int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
+                             int32_t pl_window, void *stream)
 {
     PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0, "psgpu_fwdtree_search_dev: bad argument");
+    PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
+                  m->d.n_sen, kFtMaxSen);
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE(senscr_dev && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdtree_search_dev: NULL device buffer");
@@ -718,7 +785,8 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     // per-utterance work slab
     const size_t C = m->C;
     const size_t per = C * (5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
-                     + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64;
+                     + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
+                     + ((size_t)d.n_sen + 1) / 2 + 1;
     int32_t *slab = nullptr;
     FtUtt *d_utts = nullptr;
     PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * per * n_utt));
@@ -736,6 +804,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.csf_ef = take(d.n_w + 1); u.csf_cand = take(d.n_w + 1);
         u.o_frame = take(d.N); u.o_s0 = take(d.N); u.o_best = take(d.N); u.o_out = take(d.N); u.o_outh = take(d.N);
         u.pos = take(d.N); u.flag = take(d.N);
+        u.nrow = reinterpret_cast<int16_t *>(take(((size_t)d.n_sen + 1) / 2 + 1));
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
         u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
         u.result = result_dev + (size_t)i * 8;
@@ -747,10 +816,10 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     if (e != hipSuccess) { hipFree(slab); hipFree(d_utts); PSGPU_HIP(e); }
     if (d.n_emit == 3)
         hipLaunchKernelGGL((fwdtree_kernel<3>), dim3(n_utt), dim3(kFtThreads), 0, st, d, d_utts, senscr_dev, scr_stride,
-                           penalties_dev, utt_off_dev);
+                           penalties_dev, utt_off_dev, raw_scores, pl_window);
     else
         hipLaunchKernelGGL((fwdtree_kernel<5>), dim3(n_utt), dim3(kFtThreads), 0, st, d, d_utts, senscr_dev, scr_stride,
-                           penalties_dev, utt_off_dev);
+                           penalties_dev, utt_off_dev, raw_scores, pl_window);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
     hipFree(slab); hipFree(d_utts);

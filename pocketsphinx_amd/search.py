@@ -42,16 +42,21 @@ class FwdtreeSearch:
         except Exception:
             pass
 
-    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19):
-        """senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back.  Returns a list of
-        dicts (bp [n][10], bscore_stack, bp_table_idx, step [frames][4], status) per utterance."""
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0):
+        """senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back (numpy arrays, or
+        torch tensors already on the device).  raw_scores: un-normalised rows + phone-loop output, see psgpu.h.
+        Returns a list of dicts (bp [n][10], bscore_stack, bp_table_idx, step [frames][4], status) per utterance."""
         import torch
         dev = torch.device("cuda", torch.cuda.current_device())
-        senscr = np.ascontiguousarray(senscr, np.int16); penalties = np.ascontiguousarray(penalties, np.int32)
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
         T = int(off[-1]); n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
-        assert senscr.shape == (T, self.n_sen) and penalties.shape == (T, self.n_ci)
-        d_s = torch.from_numpy(senscr).to(dev); d_p = torch.from_numpy(penalties).to(dev); d_o = torch.from_numpy(off).to(dev)
+        if not torch.is_tensor(senscr):
+            senscr = torch.from_numpy(np.ascontiguousarray(senscr, np.int16)).to(dev)
+        if not torch.is_tensor(penalties):
+            penalties = torch.from_numpy(np.ascontiguousarray(penalties, np.int32)).to(dev)
+        assert tuple(senscr.shape) == (T, self.n_sen) and tuple(penalties.shape) == (T, self.n_ci)
+        assert senscr.dtype == torch.int16 and penalties.dtype == torch.int32
+        d_s, d_p, d_o = senscr.contiguous(), penalties.contiguous(), torch.from_numpy(off).to(dev)
         bp = torch.zeros((n, 10, bp_cap), dtype=torch.int32, device=dev)
         bss = torch.zeros((n, bss_cap), dtype=torch.int32, device=dev)
         idx = torch.zeros((n, mf + 2), dtype=torch.int32, device=dev)
@@ -59,8 +64,8 @@ class FwdtreeSearch:
         res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
         capi.check(capi.lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap,
-                                                       bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
-                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                       bss_cap, p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)),
+                                                       int(pl_window), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                    "psgpu_fwdtree_search_dev")
         out = []
         res_h = res.cpu().numpy()

@@ -63,3 +63,80 @@ def test_fwdtree_kernel_batch_of_utterances():
     for r, g, n in zip(out, gs, names):
         _check(r, g, n)
     s.close()
+
+
+@pytest.mark.parametrize("name", ["goforward", "numbers"])
+def test_device_decode_chain_audio_to_backpointers(name, tables):
+    """The whole first pass on the device, nothing through the host in between: 16-bit PCM -> MFCC front
+    end -> 1s_c_d_dd features -> PTM senone scores (un-normalised rows) -> phone-loop search of the
+    utterance -> lexicon-tree search reading those rows and penalties directly (it builds each frame's
+    active senone list and normaliser itself).  The back-pointer table, score stack and frame marks must be
+    the reference decoder's for the same recording (ref_dump fwdtree), and the phone-loop penalties the
+    ones its search read."""
+    import ctypes as C
+    import os
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    import pso
+    g = _load("fwdtree_trace_%s.npz" % name)
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    raw = os.path.join(pso.REF_DIR, "data", name + ".raw")
+    assert os.path.exists(raw), "staged recordings missing (make -C oracle)"
+    pcm = np.fromfile(raw, dtype=np.int16)
+    dev = torch.device("cuda", 0)
+    L = capi.lib()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    # front end + dynamic features
+    fe = P.FrontEnd(_load("mfcc_en_us_goforward.npz"))
+    cep, fo = fe.process_utts([pcm])
+    feats = P.dynfeat_1s_c_d_dd(cep, [cep.shape[0]])
+    T = feats.shape[0]
+    assert T == int(g["n_frame"][0])
+    # senone scores, un-normalised, resident
+    model = P.PtmModel(tables)
+    d_f = torch.from_numpy(feats).to(dev)
+    d_off = torch.tensor([0, T], dtype=torch.int32, device=dev)
+    tsc = torch.empty((T, model.n_chain, model.topn), dtype=torch.int32, device=dev)
+    tcw = torch.empty((T, model.n_chain, model.topn), dtype=torch.uint8, device=dev)
+    rows = torch.empty((T, model.n_sen), dtype=torch.int16, device=dev)
+    best = torch.empty(T, dtype=torch.int32, device=dev)
+    capi.check(L.psgpu_ptm_score_batch_dev(model.h, p(d_f), p(d_off), 1, T, None, None, p(tsc), p(tcw), p(rows), p(best),
+                                           1, sp), "score (PSGPU_PTM_RAW_SCORES)")
+    # phone loop of the utterance
+    n_ci, window = int(g["pl_par"][0]), int(g["pl_par"][1])
+    ctx = P.HmmContext(st["tp"], st["sseq"], model.n_sen)
+
+    class PlPar(C.Structure):
+        _fields_ = [("n_phones", C.c_int32), ("window", C.c_int32), ("beam", C.c_int32), ("pbeam", C.c_int32),
+                    ("pip", C.c_int32), ("penalty_weight", C.c_double)]
+    par = PlPar(n_ci, window, int(g["pl_par"][2]), int(g["pl_par"][3]), int(g["pl_par"][4]), float(g["pl_weight"][0]))
+    flags = np.zeros(model.n_sen, bool)
+    flags[st["sseq"][g["pl_ssid"]].reshape(-1)] = True
+    ci_list, last = [], 0
+    for s_ in np.nonzero(flags)[0]:
+        while s_ - last > 255:
+            last += 255; ci_list.append(last)
+        ci_list.append(int(s_)); last = int(s_)
+    d_ssid = torch.from_numpy(g["pl_ssid"].astype(np.uint16).view(np.int16)).to(dev)
+    d_tm = torch.from_numpy(g["pl_tmat"].astype(np.int16)).to(dev)
+    d_ci = torch.from_numpy(np.array(ci_list, np.uint16).view(np.int16)).to(dev)
+    pen = torch.empty((T, n_ci), dtype=torch.int32, device=dev)
+    now = torch.empty((T, n_ci), dtype=torch.int32, device=dev)
+    state = torch.empty((T, n_ci, 8), dtype=torch.int32, device=dev)
+    L.psgpu_phone_loop_run_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
+    capi.check(L.psgpu_phone_loop_run_dev(ctx.h, C.byref(par), p(d_ssid), p(d_tm), p(d_ci), len(ci_list), p(rows),
+                                          model.n_sen, None, p(d_off), 1, T, p(pen), p(now), p(state), sp), "phone loop")
+    torch.cuda.synchronize()
+    pen_h = pen.cpu().numpy()
+    want = g["step_pen"]
+    got = pen_h[np.minimum(np.arange(T) + int(g["pl_par"][5]), T - 1)]
+    assert np.array_equal(got, want), "phone-loop penalties differ from what the reference search read"
+    # tree search on the raw rows and the phone loop's output
+    s = P.FwdtreeSearch(st, g["par"])
+    r = s.search(rows, pen, [T], raw_scores=True, pl_window=int(g["pl_par"][5]))[0]
+    _check(r, g, name + " (device chain)")
+    s.close(); ctx.close(); model.close(); fe.close()

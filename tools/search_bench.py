@@ -38,7 +38,7 @@ def main():
 
         def run():
             capi.check(capi.lib().psgpu_fwdtree_search_dev(s.h, p(d_s), C.c_int64(s.n_sen), p(d_p), p(uo), nb, T, bp_cap, bss_cap,
-                                                           p(bp), p(bss), p(idx), p(step), p(res), sp), "search")
+                                                           p(bp), p(bss), p(idx), p(step), p(res), 0, 0, sp), "search")
         run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
