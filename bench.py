@@ -319,6 +319,96 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         sm.close()
     except Exception as e:
         out["semi_scorer"] = {"error": str(e)}
+    # (7) the whole first pass on the device: PCM -> MFCC -> features -> PTM scores (un-normalised) -> phone-loop
+    #     search -> lexicon-tree search -> back-pointer tables, 512 utterances (the bundled goforward recording,
+    #     2.8 s each, with a different gain per utterance) in one batch; turtle LM / dictionary as the reference built them
+    try:
+        gm = np.load(os.path.join(ROOT, "tests", "golden", "mfcc_en_us_goforward.npz"))
+        gt = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_goforward.npz"))
+        gs = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_en_us_turtle.npz"))
+        st = {k: gs[k] for k in gs.files}
+        B = 512
+        fe = P.FrontEnd({k: gm[k] for k in gm.files})
+        srch = P.FwdtreeSearch(st, gt["par"])
+        ctx = P.HmmContext(st["tp"], st["sseq"], model.n_sen)
+        pcm1 = gm["pcm"].astype(np.float32)
+        rng = np.random.default_rng(3)
+        pcm_h = np.concatenate([(pcm1 * g_).astype(np.int16) for g_ in rng.uniform(0.6, 1.0, B)])
+        ns = pcm1.size
+        Tu = fe.n_frames(ns); Tn = B * Tu
+        soff = (np.arange(B + 1, dtype=np.int64) * ns)
+        pcm = torch.from_numpy(pcm_h).to(dev)
+        cep = torch.empty((Tn, fe.out_dim), dtype=torch.float32, device=dev)
+        ft = torch.empty((Tn, 3 * fe.out_dim), dtype=torch.float32, device=dev)
+        foff = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        tsc = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.int32, device=dev)
+        tcw = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.uint8, device=dev)
+        rows = torch.empty((Tn, model.n_sen), dtype=torch.int16, device=dev)
+        bst = torch.empty(Tn, dtype=torch.int32, device=dev)
+        n_ci, window = int(gt["pl_par"][0]), int(gt["pl_par"][1])
+
+        class PlPar(C.Structure):
+            _fields_ = [("n_phones", C.c_int32), ("window", C.c_int32), ("beam", C.c_int32), ("pbeam", C.c_int32),
+                        ("pip", C.c_int32), ("penalty_weight", C.c_double)]
+        ppar = PlPar(n_ci, window, int(gt["pl_par"][2]), int(gt["pl_par"][3]), int(gt["pl_par"][4]), float(gt["pl_weight"][0]))
+        fl = np.zeros(model.n_sen, bool); fl[st["sseq"][gt["pl_ssid"]].reshape(-1)] = True
+        cil, last = [], 0
+        for s_ in np.nonzero(fl)[0]:
+            while s_ - last > 255:
+                last += 255; cil.append(last)
+            cil.append(int(s_)); last = int(s_)
+        d_ssid = torch.from_numpy(gt["pl_ssid"].astype(np.uint16).view(np.int16)).to(dev)
+        d_tm = torch.from_numpy(gt["pl_tmat"].astype(np.int16)).to(dev)
+        d_ci = torch.from_numpy(np.array(cil, np.uint16).view(np.int16)).to(dev)
+        pen = torch.empty((Tn, n_ci), dtype=torch.int32, device=dev)
+        now = torch.empty((Tn, n_ci), dtype=torch.int32, device=dev)
+        pstate = torch.empty((Tn, n_ci, 8), dtype=torch.int32, device=dev)
+        bp_cap, bss_cap = 4096, 65536
+        bp = torch.zeros((B, 10, bp_cap), dtype=torch.int32, device=dev); bss = torch.zeros((B, bss_cap), dtype=torch.int32, device=dev)
+        idx = torch.zeros((B, Tu + 2), dtype=torch.int32, device=dev); stp = torch.zeros((B, Tu, 4), dtype=torch.int32, device=dev)
+        res = torch.zeros((B, 8), dtype=torch.int32, device=dev)
+        L.psgpu_fe_process_utts_dev.argtypes = [C.c_void_p] * 10
+        L.psgpu_phone_loop_run_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
+        q = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        tm = {}
+
+        def decode_step():
+            capi.check(L.psgpu_fe_process_utts_dev(fe.h, q(pcm), soff.ctypes.data_as(C.c_void_p), B, None, None, q(cep), q(foff),
+                                                   None, sp), "fe")
+            capi.check(L.psgpu_feat_1s_c_d_dd_dev(q(cep), q(foff), B, fe.out_dim, q(ft), sp), "feat")
+            capi.check(L.psgpu_ptm_score_batch_dev(model.h, q(ft), q(foff), B, Tn, None, None, q(tsc), q(tcw), q(rows), q(bst),
+                                                   1, sp), "score")
+            capi.check(L.psgpu_phone_loop_run_dev(ctx.h, C.byref(ppar), q(d_ssid), q(d_tm), q(d_ci), len(cil), q(rows),
+                                                  model.n_sen, None, q(foff), B, Tn, q(pen), q(now), q(pstate), sp), "phone loop")
+            capi.check(L.psgpu_fwdtree_search_dev(srch.h, q(rows), C.c_int64(model.n_sen), q(pen), q(foff), B, Tu, bp_cap, bss_cap,
+                                                  q(bp), q(bss), q(idx), q(stp), q(res), 1, int(gt["pl_par"][5]), sp), "search")
+        decode_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = 3
+        for _ in range(K):
+            decode_step()
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / K
+        rh = res.cpu().numpy()
+        # every utterance must come out as the same sentence (gain does not change the words)
+        r0 = dict(bp=bp[0, :, :int(rh[0, 0])].cpu().numpy().T, bp_table_idx=idx[0].cpu().numpy(), n_frame=int(rh[0, 2]))
+        _, words0 = P.backtrace(r0, int(gt["par"][20]))
+        same = 0
+        for u_ in range(0, B, 37):
+            ru = dict(bp=bp[u_, :, :int(rh[u_, 0])].cpu().numpy().T, bp_table_idx=idx[u_].cpu().numpy(), n_frame=int(rh[u_, 2]))
+            same += [w for w, _, _ in P.backtrace(ru, int(gt["par"][20]))[1]] == [w for w, _, _ in words0]
+        out["device_decode"] = {"utterances": B, "frames": Tn, "audio_s": round(B * ns / 16000.0, 1), "seconds": round(dts, 5),
+                                "frames_per_s": round(Tn / dts, 1), "xrt": round(dts / (B * ns / 16000.0), 8),
+                                "status_nonzero": int((rh[:, 3] != 0).sum()), "words_in_hyp": len(words0),
+                                "sampled_hyps_equal_first": "%d/%d" % (same, len(range(0, B, 37))),
+                                "what": "PCM -> MFCC -> features -> PTM scores -> phone loop -> lexicon-tree search -> "
+                                        "back-pointer tables, all on the device (turtle LM, 512 x goforward)"}
+        srch.close(); ctx.close(); fe.close()
+    except Exception as e:
+        out["device_decode"] = {"error": str(e)}
     return out
 
 

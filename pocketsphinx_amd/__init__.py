@@ -16,6 +16,6 @@ from .semi import SemiMgau  # noqa: F401
 from .ms import MsMgau  # noqa: F401
 from .feat import dynfeat_1s_c_d_dd  # noqa: F401
 from .fe import FrontEnd  # noqa: F401
-from .search import FwdtreeSearch  # noqa: F401
+from .search import FwdtreeSearch, backtrace  # noqa: F401
 
 __all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch"]

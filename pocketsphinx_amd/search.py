@@ -75,3 +75,34 @@ class FwdtreeSearch:
                             bp_table_idx=idx[u, :nfr + 1].cpu().numpy(), step=step[u, :nfr].cpu().numpy(),
                             n_frame=nfr, status=status))
         return out
+
+
+def backtrace(result, finish_wid):
+    """Best exit and its word sequence from a back-pointer table, as ngram_search_find_exit
+    (reference src/ngram_search.c:500-544: the </s> entry of the last frame that has entries, else the
+    best-scoring one) and ngram_search_bp_hyp / the segment iterator (:546-581, 903-1010) walk it.
+    Returns (path score, [(wid, start_frame, end_frame), ...])."""
+    bp, idx = result["bp"], result["bp_table_idx"]
+    n_frame = result["n_frame"]
+    if n_frame == 0 or bp.shape[0] == 0:
+        return None, []
+    f = n_frame - 1
+    end = int(idx[f])
+    while f >= 0 and int(idx[f]) == end:
+        f -= 1
+    if f < 0:
+        return None, []
+    best, best_score = -1, -(1 << 29)
+    for b in range(int(idx[f]), end):
+        if int(bp[b, 2]) == finish_wid or int(bp[b, 4]) > best_score:
+            best, best_score = b, int(bp[b, 4])
+        if int(bp[b, 2]) == finish_wid:
+            break
+    words = []
+    b = best
+    while b != -1:
+        prev = int(bp[b, 3])
+        sf = 0 if prev == -1 else int(bp[prev, 0]) + 1
+        words.append((int(bp[b, 2]), sf, int(bp[b, 0])))
+        b = prev
+    return best_score, words[::-1]

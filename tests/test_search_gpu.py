@@ -139,4 +139,8 @@ def test_device_decode_chain_audio_to_backpointers(name, tables):
     s = P.FwdtreeSearch(st, g["par"])
     r = s.search(rows, pen, [T], raw_scores=True, pl_window=int(g["pl_par"][5]))[0]
     _check(r, g, name + " (device chain)")
+    # the hypothesis the host reads off the table: same path score and word boundaries as ps_get_hyp / ps_seg_iter
+    score, words = P.backtrace(r, int(g["par"][20]))
+    assert score == int(g["hyp_score"][0])
+    assert [(sf, ef) for _, sf, ef in words] == [(int(a), int(b)) for a, b in g["seg"][:, :2]]
     s.close(); ctx.close(); model.close(); fe.close()
