@@ -418,6 +418,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only (clean per-kernel profiles)")
     args = ap.parse_args()
 
     import torch
@@ -533,7 +534,7 @@ def main():
                      "note": "VALU/LDS-bound by construction (SURVEY 8d); fp32-VALU fraction of the "
                              "distance work = %.4f" % (FLOP_PER_FRAME * T / (topn_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS)},
     }
-    line["extra"] = extras(P, capi, L, model, t, feats_h, dev, sp)
+    line["extra"] = {} if args.no_extras else extras(P, capi, L, model, t, feats_h, dev, sp)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(t, feats_h)
         line["speedup_vs_cpu_1thread"] = round(fps / world / line["cpu_baseline"]["value"], 1)
