@@ -535,6 +535,15 @@ psgpu_mgau_reset(ps_mgau_t *ps)
     return -1;
 }
 
+/* the device model of the wrapped PTM scorer (for components that score whole utterances themselves) */
+struct psgpu_ptm_model_s *
+psgpu_mgau_ptm_model(ps_mgau_t *ps)
+{
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
+        return NULL;
+    return ((psgpu_mgau_t *)ps)->model;
+}
+
 /* For a search component that consumes scores on the device (psgpu_phone_loop_shim.c):
  * announce what lies ahead of `frame` now, have it scored, and hand out the device rows. */
 int

@@ -32,6 +32,8 @@ int psgpu_mgau_reset(ps_mgau_t *mgau);
 int psgpu_mgau_prefetch(ps_mgau_t *mgau, int frame, const int16_t **raw_dev, const int32_t **best_dev,
                         int *frame0, int *n_frames, int *n_sen);
 int psgpu_mgau_mark_fresh(ps_mgau_t *mgau, int frame);
+/* the device model behind a wrapped PTM scorer, or NULL */
+struct psgpu_ptm_model_s *psgpu_mgau_ptm_model(ps_mgau_t *mgau);
 
 /* number of frame_eval calls served by the device (-1 if not a psgpu scorer) */
 int32 psgpu_mgau_n_calls(ps_mgau_t *mgau);

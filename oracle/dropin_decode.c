@@ -35,6 +35,7 @@
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
 #include "psgpu_phone_loop_shim.h"
+#include "psgpu_device_decode.h"
 #include "phone_loop_search.h"
 #ifdef PSGPU_SEARCH_HOOKS
 #include "psgpu_search_hooks.h"
@@ -108,7 +109,7 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
         const char *k = argv[i];
         if (k[0] == '-') ++k;
         if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search")
-            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop"))
+            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop") || !strcmp(k, "psgpu_device_search"))
             continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
@@ -183,6 +184,8 @@ pl_record(int which, ps_search_t *s, int frame_idx)
 static int pl_record_a(ps_search_t *s, int f) { return pl_record(0, s, f); }
 static int pl_record_b(ps_search_t *s, int f) { return pl_record(1, s, f); }
 
+static psgpu_device_decode_t *g_dd;   /* "psgpu_device_search yes": decoder B's whole first pass runs on the device */
+static long g_dd_frames;
 static psgpu_fe_shim_t *g_fe;      /* "psgpu_fe yes": decoder B's cepstra come from the device */
 
 static void
@@ -191,6 +194,12 @@ decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, re
     const char *hyp;
     ps_seg_t *seg;
     size_t o = 0;
+    if (dev_fe == 2) {
+        int nf = psgpu_device_decode_utt(g_dd, pcm, n);
+        if (nf < 0) { fprintf(stderr, "device decode failed\n"); exit(3); }
+        g_dd_frames += nf;
+        goto results;
+    }
     ps_start_utt(ps);
     if (mfcs)
         ps_process_cep(ps, mfcs, nfr, FALSE, TRUE);
@@ -200,6 +209,7 @@ decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, re
     else
         ps_process_raw(ps, pcm, n, FALSE, TRUE);
     ps_end_utt(ps);
+results:
     hyp = ps_get_hyp(ps, &res->score);
     snprintf(res->hyp, sizeof res->hyp, "%s", hyp ? hyp : "");
     res->seg[0] = 0;
@@ -232,7 +242,7 @@ main(int argc, char **argv)
     int use_search = 0;
 #endif
     long hmm_batches = 0, hmm_evals = 0, pl_dev = 0, pl_host = 0;
-    int use_pl = 0, pl_bad = 0;
+    int use_pl = 0, pl_bad = 0, use_dd = 0;
 
     if (argc < 6) {
         fprintf(stderr, "usage: dropin_decode MODELDIR LM|- DICT|- RAW NREP [key val ...]\n");
@@ -275,6 +285,7 @@ main(int argc, char **argv)
         if (!strcmp(argv[i], "psgpu_mgau")) use_mgau = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_search")) use_search = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_phone_loop")) use_pl = !strcmp(argv[i + 1], "yes");
+        if (!strcmp(argv[i], "psgpu_device_search")) use_dd = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_fe") && !strcmp(argv[i + 1], "yes")) {
             g_fe = psgpu_fe_wrap(gpu->acmod->fe);
             if (!g_fe) { fprintf(stderr, "psgpu_fe_wrap failed\n"); return 3; }
@@ -292,6 +303,10 @@ main(int argc, char **argv)
 #else
     if (use_search) { fprintf(stderr, "built without the search hooks\n"); return 2; }
 #endif
+    if (use_dd) {
+        g_dd = psgpu_device_decode_attach(gpu);
+        if (!g_dd) { fprintf(stderr, "psgpu_device_decode_attach failed\n"); return 3; }
+    }
     if (use_pl) {
         if (psgpu_phone_loop_attach(gpu) < 0) { fprintf(stderr, "psgpu_phone_loop_attach failed\n"); return 3; }
         if (cpu->phone_loop && gpu->phone_loop) {
@@ -311,7 +326,7 @@ main(int argc, char **argv)
             ps_update_mllr(cpu, ma);
             ps_update_mllr(gpu, mb);
         }
-    if (!use_pl) {       /* (the recorder replaces vt, which hides the psgpu scorer from the phone-loop shim) */
+    if (!use_pl && !use_dd) {       /* (the recorder replaces vt, which hides the psgpu scorer from the other shims) */
         rec_install(&rc_cpu, cpu);
         rec_install(&rc_gpu, gpu);
     }
@@ -341,7 +356,7 @@ main(int argc, char **argv)
                 ckd_free_2d(mfcs);
                 mfcs = read_mfc(path, ps_config_int(ps_get_config(cpu), "ceplen"), &nfr);
             }
-            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k], g_fe != NULL); t_gpu += now_s() - t0;
+            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k], g_dd ? 2 : (g_fe != NULL)); t_gpu += now_s() - t0;
             if (strcmp(ra[k].hyp, rb[k].hyp) || ra[k].score != rb[k].score) hyp_equal = 0;
             if (strcmp(ra[k].seg, rb[k].seg)) seg_equal = 0;
             total_frames += ra[k].n_frames;
@@ -359,6 +374,7 @@ main(int argc, char **argv)
         psgpu_phone_loop_stats(gpu, &pl_dev, &pl_host);
         psgpu_phone_loop_detach(gpu);
     }
+    else if (use_dd) { /* the device search makes no frame_eval calls at all: results only */ }
     else if (rc_cpu.n != rc_gpu.n) { ok = 0; bad_calls = -1; }
     else
         for (i = 0; i < rc_cpu.n; ++i)
@@ -372,7 +388,7 @@ main(int argc, char **argv)
     psgpu_search_detach(gpu);
 #endif
     /* detach recorders before the decoders free their scorers */
-    if (!use_pl) {
+    if (!use_pl && !use_dd) {
         cpu->acmod->mgau->vt = rc_cpu.orig;
         gpu->acmod->mgau->vt = rc_gpu.orig;
     }
@@ -386,7 +402,7 @@ main(int argc, char **argv)
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
                "\"cache_served\": %ld, \"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
                "\"total_frames\": %d, \"device_fe\": %s, \"pl_steps\": %d, \"pl_mismatch\": %d, \"pl_device_steps\": %ld, "
-               "\"pl_host_steps\": %ld, \"utts\": [",
+               "\"pl_host_steps\": %ld, \"device_search_frames\": %ld, \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
@@ -394,13 +410,14 @@ main(int argc, char **argv)
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
                use_mgau ? psgpu_mgau_n_cache_served(gpu->acmod->mgau) : 0L,
                use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames, g_fe ? "true" : "false",
-               g_pln[0], pl_bad, pl_dev, pl_host);
+               g_pln[0], pl_bad, pl_dev, pl_host, g_dd_frames);
         for (u = 0; u < n_res; ++u)
             printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",
                    in_id[u % n_in], rb[u].hyp, rb[u].score);
         printf("]}\n");
     }
     psgpu_fe_shim_free(g_fe);
+    psgpu_device_decode_detach(g_dd);
     ps_free(cpu);
     ps_free(gpu);
     return ok ? 0 : 1;

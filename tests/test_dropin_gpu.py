@@ -430,3 +430,33 @@ def test_dropin_device_phone_loop_resumes_on_host(break_at, monkeypatch):
     assert r["ok"] and r["rc"] == 0, r
     assert r["pl_mismatch"] == 0 and r["hyp_equal"] and r["seg_equal"], r
     assert r["pl_device_steps"] == break_at and r["pl_host_steps"] == r["pl_steps"] - break_at, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("raw,nrep,extra,lm,dic,model", [
+    ("goforward.raw", 1, (), "turtle.lm.bin", "turtle.dic", None),
+    ("numbers.raw", 1, (), "turtle.lm.bin", "turtle.dic", None),
+    ("something.raw", 1, ("pl_window", "2", "pl_weight", "1.5"), "turtle.lm.bin", "turtle.dic", None),
+    ("goforward.raw", 1, ("maxhmmpf", "100", "maxwpf", "5"), "turtle.lm.bin", "turtle.dic", None),   # histogram + word pruning
+])
+def test_dropin_device_first_pass(raw, nrep, extra, lm, dic, model):
+    """psgpu_device_search yes (integration/psgpu_device_decode.c): decoder B's whole first
+    pass -- front end, features, senone scores, phone loop, lexicon-tree Viterbi search -- runs on the
+    MI355X; the back-pointer table it produces is copied into the live ngram_search_t in the
+    reference's layout and the REFERENCE's own ps_get_hyp / ps_seg_iter read it.  Hypothesis, path
+    score and every segment (word, frames, acoustic / language score, back-off) must be identical to
+    the CPU decoder's on the same audio."""
+    r = run(raw, nrep, "psgpu_device_search", "yes", "fwdflat", "no", "bestpath", "no", *extra, lm=lm, dic=dic, model=model)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    # (ps_get_n_frames() reports acmod->output_frame + 1: one more than the frames searched)
+    assert r["device_search_frames"] == r["total_frames"] - r["n_utts"] and r["n_seg"] > 0, r
+
+
+@pytest.mark.gpu
+def test_dropin_device_first_pass_refuses_other_setups():
+    """attach fails loudly (exit code 3 of the harness) when the decoder is not a pass-1-only n-gram setup."""
+    argv = [BIN, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"),
+            os.path.join(DATA, "goforward.raw"), "1", "psgpu_device_search", "yes"]
+    p = subprocess.run(argv, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
