@@ -523,7 +523,7 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m);
  * bss_dev + u*bss_cap, bp_table_idx at idx_dev + u*(max_frames + 2), per-frame
  * {best_score, last_phone_best_score, bpidx, n_active_chan} at step_dev + u*max_frames*4, and
  * result_dev + u*8 = {n back-pointers, score-stack length, frames searched, status (1: a table
- * was full)}.  Synchronous on `stream`.
+ * was full), best_score of the last frame (ngs->best_score)}.  Synchronous on `stream`.
  * raw_scores = 1: senscr_dev holds the scorer's UN-normalised rows (PSGPU_PTM_RAW_SCORES) and
  * penalties_dev the phone loop's output per phone-loop frame (psgpu_phone_loop_run_dev): the kernel
  * then builds each frame's active senone list itself (compute_sen_active + acmod_flags2list,

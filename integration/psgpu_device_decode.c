@@ -13,7 +13,8 @@
  * and beams, and the language model as a dense table over dictionary word ids
  * (ngram_tg_score for every triple) -- which limits this binding to small vocabularies
  * until the trie lookup itself is on the device.  Requires the n-gram search with
- * -fwdflat no -bestpath no (pass 1 only), the PTM scorer (psgpu_mgau_attach first) and
+ * -fwdflat no (pass 1 on the device; -bestpath yes builds the word lattice from the
+ * injected table on the host, ngram_search.c:1212, and searches it as usual), the PTM scorer (psgpu_mgau_attach first) and
  * the 1s_c_d_dd feature type. */
 #include <string.h>
 
@@ -87,8 +88,8 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     if (ps == NULL || ps->search == NULL || ps->acmod == NULL) return NULL;
     if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM)) { E_ERROR("psgpu device decode: not an n-gram search\n"); return NULL; }
     ngs = (ngram_search_t *)ps->search;
-    if (!ngs->fwdtree || ngs->fwdflat || ngs->bestpath) {
-        E_ERROR("psgpu device decode: needs -fwdtree yes -fwdflat no -bestpath no\n");
+    if (!ngs->fwdtree || ngs->fwdflat) {
+        E_ERROR("psgpu device decode: needs -fwdtree yes -fwdflat no (pass 1 on the device, the lattice pass on the host)\n");
         return NULL;
     }
     acmod = ps->acmod; mdef = acmod->mdef; dict = ps_search_dict(ngs); d2p = ps_search_dict2pid(ngs);
@@ -335,5 +336,6 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
     memcpy(ngs->bscore_stack, d->h_bss, sizeof(int32) * nh);
     memcpy(ngs->bp_table_idx, d->h_idx, sizeof(int32) * (nfr + 1));
     ngs->bpidx = nb; ngs->bss_head = nh; ngs->n_frame = nfr;
+    ngs->best_score = res[4];        /* ngram_search_lattice (ngram_search.c:1226) refuses an utterance whose best score is WORST_SCORE */
     return nfr;
 }

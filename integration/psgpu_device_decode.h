@@ -13,7 +13,7 @@ typedef struct psgpu_device_decode_s psgpu_device_decode_t;
 
 /* Reads the decoder's search structures (tree, dictionary, dict2pid, beams, phone loop, language model
  * as a dense table: small vocabularies) and uploads them.  Needs psgpu_mgau_attach(ps) first, the n-gram
- * search with -fwdflat no -bestpath no, the 1s_c_d_dd feature type, pl_window > 0.  NULL on failure. */
+ * search with -fwdflat no (-bestpath yes then runs on the host over the injected table), the 1s_c_d_dd feature type, pl_window > 0.  NULL on failure. */
 psgpu_device_decode_t *psgpu_device_decode_attach(ps_decoder_t *ps);
 void psgpu_device_decode_detach(psgpu_device_decode_t *d);
 

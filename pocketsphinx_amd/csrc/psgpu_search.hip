@@ -678,6 +678,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     if (tid == 0) {
         u.bp_table_idx[s_sc[7]] = s_sc[3];                       // ngram_fwdtree_finish: mark one past the last frame
         u.result[0] = s_sc[3]; u.result[1] = s_sc[4]; u.result[2] = s_sc[7]; u.result[3] = s_sc[6];
+        u.result[4] = s_sc[0];                                   // ngs->best_score as the last frame left it
     }
 }
 

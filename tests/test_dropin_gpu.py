@@ -438,6 +438,9 @@ def test_dropin_device_phone_loop_resumes_on_host(break_at, monkeypatch):
     ("numbers.raw", 1, (), "turtle.lm.bin", "turtle.dic", None),
     ("something.raw", 1, ("pl_window", "2", "pl_weight", "1.5"), "turtle.lm.bin", "turtle.dic", None),
     ("goforward.raw", 1, ("maxhmmpf", "100", "maxwpf", "5"), "turtle.lm.bin", "turtle.dic", None),   # histogram + word pruning
+    # pass 3 on the host over the injected table: ngram_search_lattice + ps_lattice_bestpath (SURVEY f-2)
+    ("goforward.raw", 1, ("bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
+    ("numbers.raw", 1, ("bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
 ])
 def test_dropin_device_first_pass(raw, nrep, extra, lm, dic, model):
     """psgpu_device_search yes (integration/psgpu_device_decode.c): decoder B's whole first
@@ -446,7 +449,8 @@ def test_dropin_device_first_pass(raw, nrep, extra, lm, dic, model):
     reference's layout and the REFERENCE's own ps_get_hyp / ps_seg_iter read it.  Hypothesis, path
     score and every segment (word, frames, acoustic / language score, back-off) must be identical to
     the CPU decoder's on the same audio."""
-    r = run(raw, nrep, "psgpu_device_search", "yes", "fwdflat", "no", "bestpath", "no", *extra, lm=lm, dic=dic, model=model)
+    flags = ("fwdflat", "no") + (() if "bestpath" in extra else ("bestpath", "no"))
+    r = run(raw, nrep, "psgpu_device_search", "yes", *flags, *extra, lm=lm, dic=dic, model=model)
     assert r["ok"] and r["rc"] == 0, r
     assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
     # (ps_get_n_frames() reports acmod->output_frame + 1: one more than the frames searched)
