@@ -536,6 +536,49 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
                              int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
                              int32_t pl_window, void *stream);
 
+
+/* ---- the trigram language model on the device -----------------------
+ * Replaces ngram_tg_score(ngs->lmset, w3, w2, w1, &n_used) (lm/ngram_model.c:451 ->
+ * ngram_model_set_score, lm/ngram_model_set.c:685 -> ngram_ng_score, ngram_model.c:388 ->
+ * ngram_model_trie_score / weight_score, lm/ngram_model_trie.c:710-742 -> lm_trie_score,
+ * lm/lm_trie.c:813) for a model set holding ONE trie model without word classes: the
+ * bit-packed reverse trie (lm/lm_trie.c:549-650, lm/bitarr.c:74), the 16-bit quantisation
+ * tables (lm/lm_trie_quant.c:330-354), interpolation search included, bit-exact (float32
+ * additions in the reference's order, weight_score's float multiply-add unfused).
+ *
+ * Tables, as integration/psgpu_lm_tables.c reads them out of a live ngram_model_t:
+ *   unigrams   [n_unigrams + 1][3] uint32: {prob (float bits), backoff (float bits), next}
+ *   ngram_mem  lm_trie_t.ngram_mem, the middle arrays then the longest one; level l < order - 2
+ *              is middle l, level order - 2 the longest array
+ *   quant      [2 * (order - 2) + 1][65536] float: middle l probabilities at row 2l, back-offs
+ *              at row 2l + 1, the longest order's probabilities in the last row
+ *   widmap     [n_words] dictionary word id -> model word id (ngram_model_set_t.widmap[w][0];
+ *              -1 = not in the model) */
+#define PSGPU_LM_MAX_LEVELS 4
+typedef struct psgpu_lm_s psgpu_lm_t;
+typedef struct psgpu_lm_tables_s {
+    int32_t order, n_unigrams, n_words;
+    const uint32_t *unigrams;
+    const uint8_t *ngram_mem;
+    uint64_t ngram_mem_size;
+    uint32_t level_offset[PSGPU_LM_MAX_LEVELS];     /* byte offset of each level inside ngram_mem */
+    uint32_t total_bits[PSGPU_LM_MAX_LEVELS], word_bits[PSGPU_LM_MAX_LEVELS], word_mask[PSGPU_LM_MAX_LEVELS];
+    uint32_t max_vocab[PSGPU_LM_MAX_LEVELS], next_bits[PSGPU_LM_MAX_LEVELS], next_mask[PSGPU_LM_MAX_LEVELS];
+    const float *quant;
+    float lw;
+    int32_t log_wip, log_zero;
+    const int32_t *widmap;
+} psgpu_lm_tables_t;
+int psgpu_lm_create(psgpu_lm_t **out, const psgpu_lm_tables_t *t);
+void psgpu_lm_free(psgpu_lm_t *lm);
+/* n independent look-ups: score_dev[i] = ngram_tg_score(lmset, w3[i], w2[i], w1[i], &n_used[i]);
+ * w2 / w1 may be -1 (no history, as the search passes it); n_used_dev may be NULL. */
+int psgpu_lm_tg_score_dev(const psgpu_lm_t *lm, const int32_t *w3_dev, const int32_t *w2_dev, const int32_t *w1_dev,
+                          int64_t n, int32_t *score_dev, int32_t *n_used_dev, void *stream);
+/* Makes the tree search look its language scores up in `lm` (which must outlive it) instead of
+ * the dense table of psgpu_fwdtree_tables_t.lm (which may then be NULL at create). */
+int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
+
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).
  * senscr is the frame's n_sen int16 scores.  Synchronous. */

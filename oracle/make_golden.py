@@ -274,6 +274,122 @@ def fwdtree_only():
         print("fwdtree", name, "steps", int(d["n_steps"][0]), "bp", d["bp"].shape[0])
 
 
+
+def read_arpa(path):
+    """n-grams of an ARPA file as lists of word tuples per order"""
+    import bz2
+    op = bz2.open if path.endswith(".bz2") else open
+    grams, order = {}, 0
+    with op(path, "rt") as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith("\\") and line.endswith("-grams:"):
+                order = int(line[1:line.index("-")])
+                grams[order] = []
+            elif line.startswith("\\end\\"):
+                break
+            elif order and line:
+                f = line.split()
+                grams[order].append(tuple(f[1:1 + order]))
+    return grams
+
+
+def write_synthetic_arpa(path, n_words, n_bg, n_tg, seed):
+    """a consistent random trigram model (every trigram's two bigrams and every bigram's unigrams exist):
+    large enough that the interpolation search of the trie takes several steps"""
+    rng = np.random.default_rng(seed)
+    words = ["<s>", "</s>"] + ["w%05d" % i for i in range(n_words - 2)]
+    bg = set()
+    while len(bg) < n_bg:
+        a, b = (int(x) for x in rng.integers(0, n_words, 2))
+        if a != 1 and b != 0:
+            bg.add((a, b))
+    succ = {}
+    for a, b in bg:
+        succ.setdefault(a, []).append(b)
+    bgl = sorted(bg)
+    tg = set()
+    while len(tg) < n_tg:
+        a, b = bgl[int(rng.integers(0, len(bgl)))]
+        if b in succ:
+            tg.add((a, b, succ[b][int(rng.integers(0, len(succ[b])))]))
+    with open(path, "w") as fh:
+        fh.write("\\data\\\nngram 1=%d\nngram 2=%d\nngram 3=%d\n" % (n_words, len(bg), len(tg)))
+        fh.write("\n\\1-grams:\n")
+        for w in words:
+            fh.write("%.4f %s %.4f\n" % (-99.0 if w == "<s>" else -rng.uniform(1.0, 5.0), w, -rng.uniform(0.0, 1.5)))
+        fh.write("\n\\2-grams:\n")
+        for a, b in bgl:
+            fh.write("%.4f %s %s %.4f\n" % (-rng.uniform(0.05, 4.0), words[a], words[b], -rng.uniform(0.0, 1.0)))
+        fh.write("\n\\3-grams:\n")
+        for a, b, c in sorted(tg):
+            fh.write("%.4f %s %s %s\n" % (-rng.uniform(0.05, 3.0), words[a], words[b], words[c]))
+        fh.write("\n\\end\\\n")
+    return [tuple(words[i] for i in g) for g in bgl], [tuple(words[i] for i in g) for g in sorted(tg)]
+
+
+def lm_case(name, cmd, args, grams, seed, n_random=4000, n_scan=24, max_listed=100000, **kw):
+    """two runs of `ref_dump lm`: the first for the word list, the second with the queries:
+    every listed n-gram (in look-up order: ARPA "a b c" = ngram_tg_score(c, b, a)), shortened and
+    perturbed variants, random triples, -1 histories, and full successor scans of a few histories"""
+    d = ref_dump(cmd, "-", *args, **kw)
+    words = bytes(d["words"]).decode().split("\n")[:-1]
+    n = len(words)
+    wid = {}
+    for i, w in enumerate(words):
+        wid.setdefault(w, i)
+        wid.setdefault(w.upper(), i)       # (test_ngram/turtle.lm is upper case, the dictionary is not)
+    rng = np.random.default_rng(seed)
+    q = []
+    grams = {o: ([g[int(i)] for i in rng.choice(len(g), max_listed, replace=False)] if len(g) > max_listed else g)
+             for o, g in grams.items()}
+    for g in grams.get(3, []):
+        if all(w in wid for w in g):
+            a, b, c = (wid[w] for w in g)
+            q += [(c, b, a), (c, b, int(rng.integers(0, n))), (c, b, -1), (int(rng.integers(0, n)), b, a)]
+    for g in grams.get(2, []):
+        if all(w in wid for w in g):
+            a, b = (wid[w] for w in g)
+            q += [(b, a, -1), (b, a, int(rng.integers(0, n))), (b, -1, a)]
+    for i in range(n):
+        q.append((i, -1, -1))
+    r = rng.integers(-1, n, (n_random, 3)); r[:, 0] = np.abs(r[:, 0])
+    q += [tuple(int(x) for x in t) for t in r]
+    tgs = [g for g in grams.get(3, []) if all(w in wid for w in g)]
+    for k in range(n_scan):
+        if tgs and k % 2 == 0:
+            g = tgs[int(rng.integers(0, len(tgs)))]; h = (wid[g[1]], wid[g[0]])
+        else:
+            h = (int(rng.integers(0, n)), int(rng.integers(-1, n)))
+        w3 = np.arange(n) if n <= 512 else rng.integers(0, n, 512)
+        q += [(int(w), h[0], h[1]) for w in w3]
+    qa = np.asarray(q, np.int32)
+    with tempfile.NamedTemporaryFile(suffix=".q", delete=False) as fh:
+        fh.write(qa.tobytes()); qf = fh.name
+    d = ref_dump(cmd, qf, *args, **kw)
+    os.unlink(qf)
+    assert np.array_equal(d["queries"], qa)
+    np.savez_compressed(os.path.join(GOLD, "lm_%s.npz" % name), **d)
+    print("lm", name, "order", int(d["order"][0]), "words", n, "queries", len(qa),
+          "n_used histogram", np.bincount(d["n_used"], minlength=4).tolist(),
+          "bytes", os.path.getsize(os.path.join(GOLD, "lm_%s.npz" % name)))
+
+
+def lm_only():
+    """Language-model goldens: the trie's tables and the reference's ngram_tg_score answers."""
+    tn = "/root/reference/test/unit/test_ngram"
+    # the model of test/unit/test_ngram/test_lm_score.c, with the weights that test applies (7.5, 0.5)
+    lm_case("100", "lm_file", (7.5, 0.5), read_arpa(os.path.join(tn, "100.lm.bz2")), 11,
+            lm=os.path.join(tn, "100.lm.bin"), model="-", dic="-")
+    # the decoder's own model set: dictionary word ids, -lw / -wip of the default configuration
+    lm_case("turtle_decoder", "lm", (), read_arpa(os.path.join(tn, "turtle.lm")), 12)
+    # a random consistent trigram model, read from ARPA text: deeper interpolation searches
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "synth.arpa")
+        bg, tg = write_synthetic_arpa(path, 3000, 30000, 40000, 13)
+        lm_case("synthetic", "lm_file", (6.5, 0.65), {2: bg, 3: tg}, 14, n_scan=8, max_listed=4000, lm=path, model="-", dic="-")
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -293,6 +409,8 @@ if __name__ == "__main__":
         ms_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree":
         fwdtree_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lm":
+        lm_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "mfcc":
         mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":

@@ -1071,6 +1071,61 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
 }
 
 /* ------------------------------------------------------------------ */
+
+/* ---- language model: the trie's tables + the reference's answers to a list of
+ * (w3, w2, w1) queries in the word ids of the model SET (= dictionary word ids inside a decoder) */
+#include "lm/ngram_model_set.h"
+#include "psgpu_lm_tables.h"
+static int
+cmd_lm(ngram_model_t *lmset, const char *qfile)
+{
+    psgpu_lm_tables_t t;
+    uint32_t lev[PSGPU_LM_MAX_LEVELS * 7];
+    int l, w;
+    size_t nb = 0;
+    char *words;
+    if (psgpu_lm_tables_read(lmset, &t) < 0) return 2;
+    puti("order", t.order); puti("n_unigrams", t.n_unigrams); puti("n_words", t.n_words);
+    put2("unigrams", 'i', t.n_unigrams + 1, 3, t.unigrams);
+    put1("ngram_mem", 'B', (int64_t)t.ngram_mem_size, t.ngram_mem ? (const void *)t.ngram_mem : (const void *)"");
+    for (l = 0; l < t.order - 1; ++l) {
+        lev[7 * l] = t.level_offset[l]; lev[7 * l + 1] = t.total_bits[l]; lev[7 * l + 2] = t.word_bits[l];
+        lev[7 * l + 3] = t.word_mask[l]; lev[7 * l + 4] = t.max_vocab[l]; lev[7 * l + 5] = t.next_bits[l];
+        lev[7 * l + 6] = t.next_mask[l];
+    }
+    put2("levels", 'i', t.order - 1, 7, lev);
+    if (t.order > 1) put2("quant", 'f', 2 * (t.order - 2) + 1, 65536, t.quant);
+    put1("lw", 'f', 1, &t.lw); puti("log_wip", t.log_wip); puti("log_zero", t.log_zero);
+    put1("widmap", 'i', t.n_words, t.widmap);
+    for (w = 0; w < t.n_words; ++w) nb += strlen(ngram_word(lmset, w)) + 1;
+    words = ckd_calloc(nb + 1, 1);
+    for (w = 0, nb = 0; w < t.n_words; ++w) {
+        const char *s = ngram_word(lmset, w);
+        memcpy(words + nb, s, strlen(s)); nb += strlen(s); words[nb++] = '\n';
+    }
+    put1("words", 'B', (int64_t)nb, words);
+    if (qfile && strcmp(qfile, "-")) {
+        FILE *fp = fopen(qfile, "rb");
+        long n; int32 *q, *sc, *nu, i, a = -1, b = -1;
+        if (!fp) { perror(qfile); return 2; }
+        fseek(fp, 0, SEEK_END); n = ftell(fp) / 12; fseek(fp, 0, SEEK_SET);
+        q = ckd_calloc(3 * n + 1, 4); sc = ckd_calloc(n + 1, 4); nu = ckd_calloc(n + 1, 4);
+        if (fread(q, 12, n, fp) != (size_t)n) { perror(qfile); return 2; }
+        fclose(fp);
+        /* lm_trie_t starts with an all-zero history cache that a first query with model history
+         * (0, 0) would match without filling the back-offs (lm_trie.c:775-828): make one query with
+         * another history first, as any decoder will have done */
+        for (w = 0; w < t.n_words && b < 0; ++w)
+            if (t.widmap[w] > 0) { if (a < 0) a = w; else b = w; }
+        if (b >= 0) ngram_tg_score(lmset, a, a, b, &i);
+        for (i = 0; i < n; ++i)
+            sc[i] = ngram_tg_score(lmset, q[3 * i], q[3 * i + 1], q[3 * i + 2], &nu[i]);
+        put2("queries", 'i', n, 3, q); put1("scores", 'i', n, sc); put1("n_used", 'i', n, nu);
+    }
+    psgpu_lm_tables_release(&t);
+    return 0;
+}
+
 int
 main(int argc, char **argv)
 {
@@ -1121,6 +1176,19 @@ main(int argc, char **argv)
         rc = fe ? cmd_mfcc(fe, argv[6], atoi(argv[7])) : 2;
     } else if (!strcmp(cmd, "fwdtree") && xa > 6) {
         rc = cmd_fwdtree(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+    } else if (!strcmp(cmd, "lm") && xa > 6) {
+        /* the decoder's own model set: word ids are dictionary word ids */
+        rc = cmd_lm(((ngram_search_t *)make_decoder(modeldir, lm, dict, nextra, extra)->search)->lmset, argv[6]);
+    } else if (!strcmp(cmd, "lm_file") && xa > 8 && lm) {
+        /* a model file on its own, as test/unit/test_ngram/test_lm_score.c loads it (logmath 1.0001),
+         * wrapped in a one-model set; QUERIES LW WIP */
+        logmath_t *lmath = logmath_init(1.0001, 0, 0);
+        ngram_model_t *m = ngram_model_read(NULL, lm, NGRAM_AUTO, lmath), *set;
+        char *name = "default";
+        if (!m) { fprintf(stderr, "cannot read %s\n", lm); return 2; }
+        set = ngram_model_set_init(NULL, &m, &name, NULL, 1);
+        ngram_model_apply_weights(set, (float32)atof(argv[7]), (float32)atof(argv[8]));
+        rc = cmd_lm(set, argv[6]);
     } else if (!strcmp(cmd, "hmm") && xa > 8) {
         rc = cmd_hmm(make_decoder(modeldir, lm, dict, nextra, extra), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
     } else if (!strcmp(cmd, "decode") && xa > 6) {

@@ -435,3 +435,51 @@ class OracleFwdtree:
         L = lib()
         return np.ctypeslib.as_array(C.cast(L.pso_ft_bp_table_idx(self.h), C.POINTER(C.c_int32)),
                                      shape=(n_frames + 1,)).copy()
+
+
+class OracleLm:
+    """Wrapper around pso_lm_t (oracle/ps_oracle_lm.c: restates ngram_tg_score through the model set,
+    the trie and its quantisation tables).  `g` = an lm_*.npz fixture (`ref_dump lm`);
+    lw / log_wip override the weights the fixture was dumped with."""
+
+    def __init__(self, g, lw=None, log_wip=None):
+        L = lib()
+        vp = C.c_void_p
+        L.pso_lm_new.restype = vp
+        L.pso_lm_new.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, C.c_uint64, vp, vp, C.c_float, C.c_int32,
+                                 C.c_int32, vp]
+        L.pso_lm_free.argtypes = [vp]
+        L.pso_lm_tg_score.restype = C.c_int32
+        L.pso_lm_tg_score.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.pso_lm_tg_score_batch.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp]
+        self.order = int(g["order"][0]); self.n_words = int(g["n_words"][0])
+        mem = np.concatenate([np.asarray(g["ngram_mem"], np.uint8), np.zeros(8, np.uint8)])
+        quant = g["quant"] if "quant" in g else np.zeros((1, 65536), np.float32)
+        self._keep = [np.ascontiguousarray(g["unigrams"]).view(np.uint32), mem,
+                      np.ascontiguousarray(g["levels"]).view(np.uint32), np.ascontiguousarray(quant, np.float32),
+                      np.ascontiguousarray(g["widmap"], np.int32)]
+        self.lw = float(g["lw"][0]) if lw is None else lw
+        self.log_wip = int(g["log_wip"][0]) if log_wip is None else log_wip
+        self.h = L.pso_lm_new(self.order, int(g["n_unigrams"][0]), self.n_words, self._keep[0].ctypes.data,
+                              mem.ctypes.data, len(g["ngram_mem"]), self._keep[2].ctypes.data, self._keep[3].ctypes.data,
+                              self.lw, self.log_wip, int(g["log_zero"][0]), self._keep[4].ctypes.data)
+        assert self.h
+
+    def __del__(self):
+        try:
+            lib().pso_lm_free(self.h)
+        except Exception:
+            pass
+
+    def tg_score(self, w3, w2=-1, w1=-1):
+        nu = C.c_int32(0)
+        s = lib().pso_lm_tg_score(self.h, w3, w2, w1, C.byref(nu))
+        return s, nu.value
+
+    def tg_score_batch(self, q):
+        q = np.ascontiguousarray(q, np.int32)
+        w3, w2, w1 = (np.ascontiguousarray(q[:, i]) for i in range(3))
+        sc = np.zeros(len(q), np.int32); nu = np.zeros(len(q), np.int32)
+        lib().pso_lm_tg_score_batch(self.h, w3.ctypes.data, w2.ctypes.data, w1.ctypes.data, len(q), sc.ctypes.data,
+                                    nu.ctypes.data)
+        return sc, nu
