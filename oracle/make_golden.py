@@ -383,6 +383,10 @@ def lm_only():
             lm=os.path.join(tn, "100.lm.bin"), model="-", dic="-")
     # the decoder's own model set: dictionary word ids, -lw / -wip of the default configuration
     lm_case("turtle_decoder", "lm", (), read_arpa(os.path.join(tn, "turtle.lm")), 12)
+    # the second search fixture's model (tests cross-check the whole dense table of fwdtree_static_tidigits)
+    tdl = os.path.join(REF, "data", "tidigits")
+    lm_case("tidigits_decoder", "lm", (), {}, 15, model=os.path.join(REF, "model", "tidigits"),
+            lm=os.path.join(tdl, "tidigits.lm.bin"), dic=os.path.join(tdl, "tidigits.dic"))
     # a random consistent trigram model, read from ARPA text: deeper interpolation searches
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "synth.arpa")

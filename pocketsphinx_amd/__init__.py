@@ -17,5 +17,6 @@ from .ms import MsMgau  # noqa: F401
 from .feat import dynfeat_1s_c_d_dd  # noqa: F401
 from .fe import FrontEnd  # noqa: F401
 from .search import FwdtreeSearch, backtrace  # noqa: F401
+from .lm import NGramTrieLM  # noqa: F401
 
-__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch"]
+__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch", "backtrace", "NGramTrieLM"]

@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip", "psgpu_search.hip"]
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip", "psgpu_search.hip", "psgpu_lm.hip"]
 
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -31,7 +31,8 @@ SYMBOLS = [
     "psgpu_fe_process_utts_dev", "psgpu_fe_process_utts",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval", "psgpu_phone_loop_run_dev", "psgpu_hmm_ctx_stream",
-    "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev",
+    "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_set_lm",
+    "psgpu_lm_create", "psgpu_lm_free", "psgpu_lm_tg_score_dev",
 ]
 
 
@@ -43,7 +44,7 @@ def build_library(force=False):
     """Compile the HIP sources for gfx950 into pocketsphinx_amd/libpsgpu.so
     (in-tree, so it travels to the GPU box).  hipcc cross-compiles without a GPU."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "psgpu_internal.h"), os.path.join(CSRC, "psgpu_ptm_dev.h"), os.path.join(CSRC, "psgpu_hmm_dev.h"), os.path.join(ROOT, "include", "psgpu.h")]
+    deps = srcs + [os.path.join(CSRC, "psgpu_internal.h"), os.path.join(CSRC, "psgpu_ptm_dev.h"), os.path.join(CSRC, "psgpu_hmm_dev.h"), os.path.join(CSRC, "psgpu_lm_dev.h"), os.path.join(ROOT, "include", "psgpu.h")]
     if (not force) and os.path.exists(LIB_PATH) and \
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH

@@ -1,0 +1,181 @@
+// psgpu_lm_dev.h -- the trigram look-up as device code, shared by the batch look-up kernel
+// (psgpu_lm.hip) and the lexicon-tree search (psgpu_search.hip).
+//
+// ngram_tg_score as the n-gram search calls it (lm/ngram_model.c:451 -> ngram_model_set_score,
+// lm/ngram_model_set.c:685 -> ngram_ng_score, ngram_model.c:388 -> ngram_model_trie_score,
+// lm/ngram_model_trie.c:710-742 -> lm_trie_score, lm/lm_trie.c:549-828): one model without
+// classes; a bit-packed reverse trie searched by interpolation (uniform_find), 16-bit
+// quantised probabilities and back-offs.  All integer arithmetic in uint32 with the
+// reference's wrap-around, float sums in its order and unfused.
+//
+// One look-up is a chain of dependent loads (3-6 per trie level); the tables of a small model sit
+// in L2, so a look-up costs a few microseconds of latency and no bandwidth to speak of: callers
+// issue many look-ups in parallel (one per lane), never a loop over words in one lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct LmLevel { uint32_t off, total_bits, word_bits, word_mask, max_vocab, next_bits, next_mask; };
+struct LmDev {
+    int32_t order, n_unigrams, n_words;
+    const uint32_t *ug;       // [n_unigrams + 1][3]: prob bits, back-off bits, next
+    const uint8_t *mem;       // ngram_mem (4-byte aligned, 8 bytes of padding)
+    LmLevel lev[4];
+    const float *quant;       // [2 * (order - 2) + 1][65536]
+    float lw;
+    int32_t log_wip, log_zero;
+    const int32_t *widmap;    // [n_words]
+};
+
+struct LmRange { uint32_t begin, end; };
+
+// bitarr_read_int25 (lm/bitarr.c:74-82): 32 bits little-endian from the byte holding bit `offset`
+__device__ __forceinline__ uint32_t lm_read25(const uint8_t *level, uint32_t offset, uint32_t mask)
+{
+    const uintptr_t a = (uintptr_t)level + (offset >> 3);
+    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+    const uint64_t v = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    return (uint32_t)(v >> (8 * (uint32_t)(a & 3) + (offset & 7))) & mask;
+}
+__device__ __forceinline__ float lm_ug_prob(const LmDev &m, uint32_t w) { return __uint_as_float(m.ug[3 * (size_t)w]); }
+__device__ __forceinline__ float lm_ug_bo(const LmDev &m, uint32_t w) { return __uint_as_float(m.ug[3 * (size_t)w + 1]); }
+__device__ __forceinline__ void lm_ug_range(const LmDev &m, uint32_t w, LmRange &r)      // unigram_find, lm_trie.c:549
+{
+    r.begin = m.ug[3 * (size_t)w + 2]; r.end = m.ug[3 * (size_t)w + 5];
+}
+
+// uniform_find, lm_trie.c:564-600
+__device__ __forceinline__ bool lm_uniform_find(const uint8_t *level, uint32_t total_bits, uint32_t key_mask,
+                                                uint32_t before_it, uint32_t before_v, uint32_t after_it, uint32_t after_v,
+                                                uint32_t key, uint32_t &out)
+{
+    if (key > after_v) return false;
+    while (after_it - before_it > 1) {
+        const uint32_t pivot = before_it + (1u + ((key - before_v) * (after_it - before_it - 1u)) / (after_v - before_v + 1u));
+        const uint32_t mid = lm_read25(level, pivot * total_bits, key_mask);
+        if (mid < key) { before_it = pivot; before_v = mid; }
+        else if (mid > key) { after_it = pivot; after_v = mid; }
+        else { out = pivot; return true; }
+    }
+    return false;
+}
+// middle_find, lm_trie.c:602-631: bit offset just after the word field; r becomes the entry's child range
+__device__ __forceinline__ bool lm_middle_find(const LmDev &m, int l, uint32_t word, LmRange &r, uint32_t &o)
+{
+    const LmLevel &v = m.lev[l];
+    const uint8_t *level = m.mem + v.off;
+    uint32_t at;
+    if (!lm_uniform_find(level, v.total_bits, v.word_mask, r.begin - 1u, 0u, r.end, v.max_vocab, word, at)) return false;
+    at = at * v.total_bits + v.word_bits;
+    r.begin = lm_read25(level, at + 32u, v.next_mask);
+    r.end = lm_read25(level, at + 32u + v.total_bits, v.next_mask);
+    o = at;
+    return true;
+}
+// longest_find, lm_trie.c:633-651
+__device__ __forceinline__ bool lm_longest_find(const LmDev &m, uint32_t word, const LmRange &r, uint32_t &o)
+{
+    const LmLevel &v = m.lev[m.order - 2];
+    uint32_t at;
+    if (!lm_uniform_find(m.mem + v.off, v.total_bits, v.word_mask, r.begin - 1u, 0u, r.end, v.max_vocab, word, at)) return false;
+    o = at * v.total_bits + v.word_bits;
+    return true;
+}
+// lm_trie_quant_mboread / _mpread / _lpread, lm_trie_quant.c:330-354
+__device__ __forceinline__ float lm_mid_bo(const LmDev &m, int l, uint32_t o)
+{ return m.quant[(size_t)(2 * l + 1) * 65536 + lm_read25(m.mem + m.lev[l].off, o, 0xffffu)]; }
+__device__ __forceinline__ float lm_mid_prob(const LmDev &m, int l, uint32_t o)
+{ return m.quant[(size_t)(2 * l) * 65536 + lm_read25(m.mem + m.lev[l].off, o + 16u, 0xffffu)]; }
+__device__ __forceinline__ float lm_long_prob(const LmDev &m, uint32_t o)
+{ return m.quant[(size_t)(2 * (m.order - 2)) * 65536 + lm_read25(m.mem + m.lev[m.order - 2].off, o, 0xffffu)]; }
+
+// get_available_prob, lm_trie.c:653-704 (reached with n_hist < order - 1 only)
+__device__ inline float lm_available_prob(const LmDev &m, int32_t wid, const int32_t *hist, int n_hist, int &n_used)
+{
+    LmRange node;
+    float prob = lm_ug_prob(m, wid);
+    uint32_t o = 0;
+    n_used = 1;
+    lm_ug_range(m, wid, node);
+    if (n_hist == 0) return prob;
+    bool indep = node.begin == node.end;
+    int k = 0;
+    for (;; ++k) {
+        if (k == n_hist) return prob;
+        if (indep) return prob;
+        if (k == m.order - 2) break;
+        const bool found = lm_middle_find(m, k, hist[k], node, o);
+        indep = !found || node.begin == node.end;
+        if (!found) return prob;
+        prob = lm_mid_prob(m, k, o);
+        n_used = k + 2;
+    }
+    if (lm_longest_find(m, hist[k], node, o)) { prob = lm_long_prob(m, o); n_used = m.order; }
+    return prob;
+}
+// get_available_backoff, lm_trie.c:706-731
+__device__ inline float lm_available_backoff(const LmDev &m, int start, const int32_t *hist, int n_hist)
+{
+    float backoff = 0.0f;
+    LmRange node;
+    uint32_t o = 0;
+    lm_ug_range(m, hist[0], node);
+    if (start <= 1) { backoff = __fadd_rn(backoff, lm_ug_bo(m, hist[0])); start = 2; }
+    for (int k = start - 1; k < n_hist; ++k) {
+        if (!lm_middle_find(m, k - 1, hist[k], node, o)) break;
+        backoff = __fadd_rn(backoff, lm_mid_bo(m, k - 1, o));
+    }
+    return backoff;
+}
+// lm_trie_hist_score with the back-off cache of update_backoff computed in place, lm_trie.c:744-811
+__device__ inline float lm_hist_score(const LmDev &m, int32_t wid, const int32_t *hist, int n_hist, int &n_used)
+{
+    float cache[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    LmRange node;
+    uint32_t o = 0;
+    if (n_hist > 0) {
+        cache[0] = lm_ug_bo(m, hist[0]);
+        lm_ug_range(m, hist[0], node);
+        for (int i = 1; i < n_hist; ++i) {
+            if (!lm_middle_find(m, i - 1, hist[i], node, o)) break;
+            cache[i] = lm_mid_bo(m, i - 1, o);
+        }
+    }
+    n_used = 1;
+    float prob = lm_ug_prob(m, wid);
+    lm_ug_range(m, wid, node);
+    if (n_hist == 0) return prob;
+    for (int i = 0; i < n_hist - 1; ++i) {
+        if (!lm_middle_find(m, i, hist[i], node, o)) {
+            for (int j = i; j < n_hist; ++j) prob = __fadd_rn(prob, cache[j]);
+            return prob;
+        }
+        ++n_used;
+        prob = lm_mid_prob(m, i, o);
+    }
+    if (!lm_longest_find(m, hist[n_hist - 1], node, o)) return __fadd_rn(prob, cache[n_hist - 1]);
+    ++n_used;
+    return lm_long_prob(m, o);
+}
+
+// ngram_tg_score(lmset, w3, w2, w1, &n_used) with dictionary word ids; w2 / w1 may be -1
+__device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, int32_t w1, int &n_used)
+{
+    int32_t hist[2];
+    int n_hist = min(2, m.order - 1);                       // ngram_model_set.c:693
+    const int32_t wid = m.widmap[w3];
+    hist[0] = w2 < 0 ? -1 : m.widmap[w2];
+    hist[1] = w1 < 0 ? -1 : m.widmap[w1];
+    n_used = 0;
+    if (wid == -1) return m.log_zero;                       // ngram_model.c:394
+    for (int i = 0; i < n_hist; ++i) if (hist[i] < 0) { n_hist = i; break; }    // ngram_model_trie.c:724-731
+    float s;
+    if (n_hist < m.order - 1) {                             // lm_trie.c:813-828, :733-742
+        s = lm_available_prob(m, wid, hist, n_hist, n_used);
+        if (!(n_hist < n_used)) s = __fadd_rn(s, lm_available_backoff(m, n_used, hist, n_hist));
+    }
+    else
+        s = lm_hist_score(m, wid, hist, n_hist, n_used);
+    const int32_t raw = (int32_t)s;
+    return (int32_t)__fadd_rn(__fmul_rn((float)raw, m.lw), (float)m.log_wip);    // weight_score, ngram_model_trie.c:710
+}

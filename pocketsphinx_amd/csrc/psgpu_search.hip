@@ -22,6 +22,7 @@
 // the word-level bookkeeping (tens of items per frame) is still one thread.  Results are
 // the reference's, bit for bit (tests/test_search_gpu.py against reference dumps).
 #include "psgpu_hmm_dev.h"
+#include "psgpu_lm_dev.h"
 #include <cstring>
 #include <vector>
 
@@ -40,6 +41,8 @@ struct FtDev {
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
     const uint8_t *tp;
     const uint16_t *sseq;
+    int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
+    LmDev trie;
 };
 
 // per-utterance state (one slab per utterance; all int32 unless noted)
@@ -125,6 +128,10 @@ __device__ __forceinline__ int32_t ch_eval(const FtDev &p, FtUtt &u, int c, cons
 __device__ __forceinline__ int32_t ft_pen(const FtDev &p, const int32_t *pp, int ci) { return p.has_pl ? pp[ci] : 0; }
 __device__ __forceinline__ int32_t ft_lm(const FtDev &p, int w3, int w2, int w1)
 {
+    if (p.use_trie) {                    // ngram_tg_score(...) >> SENSCR_SHIFT, ngram_search_fwdtree.c:1118, :1342
+        int nu;
+        return lm_tg_score(p.trie, w3, w2, w1, nu) >> 10;
+    }
     const size_t n1 = (size_t)p.n_w + 1;
     return p.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
@@ -748,12 +755,25 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.d_base = ft_up(m, t->dict_basewid, d.n_w, &rc); d.d_filler = ft_up(m, t->dict_filler, d.n_w, &rc);
     d.rs_n = ft_up(m, t->rssid_n, (size_t)d.n_ci * d.n_ci, &rc); d.rs_ssid = ft_up(m, t->rssid_ssid, nci3, &rc);
     d.rs_cimap = ft_up(m, t->rssid_cimap, nci3, &rc); d.ldiph = ft_up(m, t->ldiph_lc, nci3, &rc);
-    d.ci_tmat = ft_up(m, t->ci_tmat, d.n_ci, &rc); d.lm = ft_up(m, t->lm, (size_t)d.n_w * n1 * n1, &rc);
+    d.ci_tmat = ft_up(m, t->ci_tmat, d.n_ci, &rc);
+    d.lm = t->lm ? ft_up(m, t->lm, (size_t)d.n_w * n1 * n1, &rc) : nullptr;     // NULL: psgpu_fwdtree_set_lm supplies the trie
     d.wc_off = ft_up(m, wc_off.data(), (size_t)d.n_w + 1, &rc);
     d.tp = ft_up(m, t->tp, (size_t)t->n_tmat * d.n_emit * (d.n_emit + 1), &rc);
     d.sseq = ft_up(m, t->sseq, (size_t)t->n_sseq * d.n_emit, &rc);
     if (rc != PSGPU_OK) { psgpu_fwdtree_free(m); return rc; }
     *out = m;
+    return PSGPU_OK;
+}
+
+const LmDev *psgpu_lm_dev(const psgpu_lm_t *lm);     // psgpu_lm.hip
+
+int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm)
+{
+    PSGPU_REQUIRE(m && lm, "psgpu_fwdtree_set_lm: NULL argument");
+    const LmDev *d = psgpu_lm_dev(lm);
+    PSGPU_REQUIRE(d->n_words == m->d.n_w, "psgpu_fwdtree_set_lm: the model maps %d dictionary words, the search has %d", d->n_words, m->d.n_w);
+    m->d.trie = *d;
+    m->d.use_trie = 1;
     return PSGPU_OK;
 }
 
@@ -778,6 +798,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0, "psgpu_fwdtree_search_dev: bad argument");
     PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
                   m->d.n_sen, kFtMaxSen);
+    PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdtree_search_dev: no language model (dense table or psgpu_fwdtree_set_lm)");
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE(senscr_dev && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdtree_search_dev: NULL device buffer");

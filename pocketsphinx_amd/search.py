@@ -23,12 +23,18 @@ class FwdtreeSearch:
 
     BP_COLS = ("frame", "valid", "wid", "bp", "score", "s_idx", "real_wid", "prev_real_wid", "last_phone", "last2_phone")
 
-    def __init__(self, static, par):
+    def __init__(self, static, par, lm=None):
+        """lm: an NGramTrieLM over the same dictionary -- language scores are then looked up in the trie on
+        the device and the dense table static["lm"] is not needed (any vocabulary the tree fits)."""
         src = dict(static); src["par"] = par
-        self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES}
-        t = _Tables(*[self._keep[n].ctypes.data for n in _NAMES], int(self._keep["tp"].shape[0]), int(self._keep["sseq"].shape[0]))
+        self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES if not (n == "lm" and lm is not None)}
+        t = _Tables(*[self._keep[n].ctypes.data if n in self._keep else None for n in _NAMES],
+                    int(self._keep["tp"].shape[0]), int(self._keep["sseq"].shape[0]))
         self.h = C.c_void_p()
         capi.check(capi.lib().psgpu_fwdtree_create(C.byref(self.h), C.byref(t)), "psgpu_fwdtree_create")
+        self.lm = lm
+        if lm is not None:
+            capi.check(capi.lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
         self.n_sen = int(par[2]); self.n_ci = int(par[0])
 
     def close(self):

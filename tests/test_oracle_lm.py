@@ -10,7 +10,7 @@ import pytest
 from pso import OracleLm
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["100", "turtle_decoder", "synthetic"]
+CASES = ["100", "turtle_decoder", "tidigits_decoder", "synthetic"]
 
 
 def load(name):
@@ -30,7 +30,7 @@ def test_lm_oracle_equals_reference_on_every_query(name):
     assert bad.size == 0, (bad[:5], g["queries"][bad[:5]], sc[bad[:5]], g["scores"][bad[:5]])
     assert np.array_equal(nu, g["n_used"])
     # the fixture exercises every depth of the look-up
-    assert set(np.unique(g["n_used"])) >= {1, 2, 3}
+    assert set(np.unique(g["n_used"])) >= set(range(1, int(g["order"][0]) + 1))
 
 
 def test_lm_oracle_known_answers_of_the_reference_unit_test():
@@ -59,3 +59,19 @@ def test_lm_oracle_words_outside_the_model_score_log_zero():
     assert out.size > 0            # filler words of the dictionary are not in the model
     s, nu = lm.tg_score(int(out[0]), 3, 4)
     assert s == int(g["log_zero"][0]) and nu == 0
+
+
+@pytest.mark.parametrize("static,name", [("en_us_turtle", "turtle_decoder"), ("tidigits", "tidigits_decoder")])
+def test_lm_oracle_reproduces_the_whole_dense_table_of_the_search_fixture(static, name):
+    """fwdtree_static_*.npz holds ngram_tg_score >> 10 of the reference for EVERY (w3, w2, w1) the search can ask
+    (w3 a non-filler base word; -1 = no history): the trie oracle must give the same number for each."""
+    st = np.load(os.path.join(GOLD, "fwdtree_static_%s.npz" % static))
+    dense = st["lm"]
+    n_w = dense.shape[0]
+    lm = OracleLm(load(name))
+    assert lm.n_words == n_w
+    w3 = np.flatnonzero((st["dict_filler"] == 0) & (st["dict_basewid"] == np.arange(n_w)))
+    grid = np.stack(np.meshgrid(w3, np.arange(-1, n_w), np.arange(-1, n_w), indexing="ij"), -1).reshape(-1, 3)
+    sc, _ = lm.tg_score_batch(grid)
+    want = dense[grid[:, 0], grid[:, 1] + 1, grid[:, 2] + 1]
+    assert np.array_equal(sc >> 10, want)
