@@ -31,11 +31,13 @@
 #include "psgpu.h"
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
+#include "psgpu_lm_tables.h"
 #include "psgpu_device_decode.h"
 
 struct psgpu_device_decode_s {
     ps_decoder_t *ps;
     psgpu_fwdtree_t *ft;
+    psgpu_lm_t *lm;                    /* the trie on the device (NULL: dense table inside ft) */
     psgpu_hmm_ctx_t *ctx;
     psgpu_fe_t *fe;
     psgpu_ptm_model_t *model;          /* borrowed from the attached scorer */
@@ -78,12 +80,13 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     phone_loop_search_t *pls;
     psgpu_fwdtree_tables_t t;
     chan_t **nodes;
-    int n_ci, n_emit, n_w, R, M, N, n1, i, j, k, w, n_tmat, n_sseq;
+    int n_ci, n_emit, n_w, R, M, N, n1, i, j, k, w, n_tmat, n_sseq, lm_ok;
     int32 par[32];
     int32 *ci, *ci2, *ssid, *tm, *child, *sib, *pw, *sw, *sci, *sci2, *sss, *stm, *smpx;
     int32 *pl, *p0, *pz, *py, *bw, *fl, *rn, *rs, *rm, *ld, *ptm, *lm;
     uint8 *tp; uint16 *sq;
     psgpu_fe_shim_t *fes;
+    psgpu_lm_tables_t lt;
 
     if (ps == NULL || ps->search == NULL || ps->acmod == NULL) return NULL;
     if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM)) { E_ERROR("psgpu device decode: not an n-gram search\n"); return NULL; }
@@ -94,7 +97,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     }
     acmod = ps->acmod; mdef = acmod->mdef; dict = ps_search_dict(ngs); d2p = ps_search_dict2pid(ngs);
     n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(dict);
-    if (n_w > 400) { E_ERROR("psgpu device decode: %d words -- the dense LM table is for small vocabularies\n", n_w); return NULL; }
+    if (n_w > 1024) { E_ERROR("psgpu device decode: %d words -- the tree search kernel holds up to 1024\n", n_w); return NULL; }
     if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->compallsen || acmod->fcb->cmn != CMN_BATCH
         || acmod->fcb->agc != AGC_NONE || acmod->fcb->varnorm) {
         E_ERROR("psgpu device decode: needs the 1s_c_d_dd feature type with -cmn batch, no AGC / variance normalisation / LDA, "
@@ -167,7 +170,20 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     par[17] = ngs->maxhmmpf; par[18] = ngs->maxwpf; par[19] = dict_startwid(dict); par[20] = dict_finishwid(dict);
     par[21] = dict_silwid(dict); par[22] = dict_filler_start(dict); par[23] = dict_filler_end(dict); par[24] = mdef->sil;
     par[25] = ps_search_lookahead(ngs) != NULL; par[26] = acmod->compallsen;
-    {
+    /* language scores: the model's own trie on the device when it is one trie model without classes
+     * (psgpu_lm_tables.c), else -- small vocabularies only -- every ngram_tg_score in a dense table */
+    lm = NULL;
+    if (psgpu_lm_tables_read(ngs->lmset, &lt) == 0) {
+        if (psgpu_lm_create(&d->lm, &lt) != PSGPU_OK) {
+            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+            d->lm = NULL;
+        }
+        psgpu_lm_tables_release(&lt);
+    }
+    lm_ok = d->lm != NULL || n_w <= 400;
+    if (!lm_ok)
+        E_ERROR("psgpu device decode: %d words and no trie model -- the dense LM table is for small vocabularies\n", n_w);
+    else if (d->lm == NULL) {
         size_t nn = (size_t)n_w + 1;
         lm = ckd_calloc((size_t)n_w * nn * nn, 4);
         for (i = 0; i < n_w; ++i)
@@ -184,7 +200,8 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     t.w1_tmat = stm; t.w1_mpx = smpx; t.dict_pronlen = pl; t.dict_first = p0; t.dict_last = pz; t.dict_last2 = py;
     t.dict_basewid = bw; t.dict_filler = fl; t.rssid_n = rn; t.rssid_ssid = rs; t.rssid_cimap = rm; t.ldiph_lc = ld;
     t.tp = tp; t.sseq = sq; t.ci_tmat = ptm; t.lm = lm; t.n_tmat = n_tmat; t.n_sseq = n_sseq;
-    i = psgpu_fwdtree_create(&d->ft, &t);
+    i = lm_ok ? psgpu_fwdtree_create(&d->ft, &t) : PSGPU_EINVAL;
+    if (i == PSGPU_OK && d->lm) i = psgpu_fwdtree_set_lm(d->ft, d->lm);
     if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, n_tmat, tp, n_sseq, sq, d->n_sen);
     /* ---- the phone loop (cf. psgpu_phone_loop_shim.c) */
     pls = (phone_loop_search_t *)ps->phone_loop;
@@ -239,7 +256,7 @@ void
 psgpu_device_decode_detach(psgpu_device_decode_t *d)
 {
     if (!d) return;
-    psgpu_fwdtree_free(d->ft); psgpu_hmm_ctx_free(d->ctx); psgpu_fe_free(d->fe);
+    psgpu_fwdtree_free(d->ft); psgpu_lm_free(d->lm); psgpu_hmm_ctx_free(d->ctx); psgpu_fe_free(d->fe);
     psgpu_free(d->d_ssid); psgpu_free(d->d_tmatid); psgpu_free(d->d_ci);
     psgpu_free(d->d_pcm); psgpu_free(d->d_cep); psgpu_free(d->d_feat); psgpu_free(d->d_off); psgpu_free(d->d_tsc); psgpu_free(d->d_tcw);
     psgpu_free(d->d_rows); psgpu_free(d->d_best); psgpu_free(d->d_pen); psgpu_free(d->d_now); psgpu_free(d->d_state);

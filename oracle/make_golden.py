@@ -394,6 +394,30 @@ def lm_only():
         lm_case("synthetic", "lm_file", (6.5, 0.65), {2: bg, 3: tg}, 14, n_scan=8, max_listed=4000, lm=path, model="-", dic="-")
 
 
+LM_KEYS = ["order", "n_unigrams", "n_words", "unigrams", "ngram_mem", "levels", "quant", "lw", "log_wip", "log_zero",
+           "widmap", "words"]
+
+
+def fwdtree_medium_only():
+    """The same goldens for a 715-word task (oracle/make_medium_task.py, staged by `make -C oracle`): too many
+    words for the dense LM table, so the static file carries the model's trie tables (LM_KEYS) instead."""
+    base = ("fwdflat", "no", "bestpath", "no")
+    kw = dict(lm=os.path.join(REF, "data", "medium.arpa"), dic=os.path.join(REF, "data", "medium.dic"))
+    static = "en_us_medium"
+    for i, (name, audio, extra) in enumerate([("medium_goforward", "goforward.raw", base),
+                                              ("medium_numbers_maxwpf8", "numbers.raw", base + ("maxwpf", "8", "maxhmmpf", "1500"))]):
+        d = ref_dump("fwdtree", os.path.join(REF, "data", audio), extra=extra, **kw)
+        keys = [k for k in FT_STATIC if k != "lm"] + LM_KEYS
+        if i == 0:
+            np.savez_compressed(os.path.join(GOLD, "fwdtree_static_%s.npz" % static), **{k: d[k] for k in keys})
+        tr = {k: v for k, v in d.items() if k not in keys}
+        tr["static"] = np.frombuffer(static.encode(), np.uint8)
+        np.savez_compressed(os.path.join(GOLD, "fwdtree_trace_%s.npz" % name), **tr)
+        print("fwdtree", name, "steps", int(d["n_steps"][0]), "bp", d["bp"].shape[0], "hyp", bytes(d["hyp"]).decode(),
+              os.path.getsize(os.path.join(GOLD, "fwdtree_trace_%s.npz" % name)))
+    print("static", os.path.getsize(os.path.join(GOLD, "fwdtree_static_%s.npz" % static)))
+
+
 def hmm_only():
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
@@ -413,6 +437,8 @@ if __name__ == "__main__":
         ms_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree":
         fwdtree_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree_medium":
+        fwdtree_medium_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "lm":
         lm_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "mfcc":

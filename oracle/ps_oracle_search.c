@@ -19,6 +19,7 @@
 #include <limits.h>
 #include "ps_oracle.h"
 #include "ps_oracle_search.h"
+#include "ps_oracle_lm.h"
 
 #define WORST ((int32_t)0xE0000000)     /* WORST_SCORE, hmm.h:84 */
 #define NO_BP (-1)
@@ -31,6 +32,7 @@ typedef struct { int32_t score, path, lc; } bestrc_t;             /* bestbp_rc_t
 
 struct pso_ft_s {
     pso_ft_tables_t t;
+    const pso_lm_t *trie;              /* optional: language scores from ps_oracle_lm.c instead of t.lm */
     int n_ci, n_emit, n_sen, n_w, R, M, N, n1, n1lm;
     int32_t beam, pbeam, lpbeam, lponlybeam, wbeam, pip, nwpen, silpen, fillpen, maxhmmpf, maxwpf;
     int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci, has_pl;
@@ -105,10 +107,12 @@ static const int32_t *rs_cimap(const pso_ft_t *s, int last, int last2)
 static int rs_n(const pso_ft_t *s, int last, int last2) { return s->t.rssid_n[last * s->n_ci + last2]; }
 static int32_t pen(const pso_ft_t *s, const int32_t *p, int ci) { return s->has_pl ? p[ci] : 0; }   /* phone_loop_search_score */
 
-/* ngram_tg_score(lmset, w3, w2, w1) >> SENSCR_SHIFT from the dense table */
+/* ngram_tg_score(lmset, w3, w2, w1) >> SENSCR_SHIFT: from the trie oracle (pso_ft_set_lm), else the dense table */
 static int32_t lm_score(const pso_ft_t *s, int w3, int w2, int w1)
 {
     const size_t n1 = (size_t)s->n_w + 1;
+    if (s->trie)
+        return pso_lm_tg_score(s->trie, w3, w2, w1, NULL) >> 10;
     return s->t.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
 
@@ -544,6 +548,8 @@ static void prune_tree_parallel(pso_ft_t *s, int frame, const int32_t *pp)
             }
     }
 }
+
+void pso_ft_set_lm(pso_ft_t *s, const pso_lm_t *lm) { s->trie = lm; }
 
 void pso_ft_set_parallel(pso_ft_t *s, int on) { s->par_mode = on; }
 

@@ -34,6 +34,9 @@ typedef struct pso_ft_s pso_ft_t;
 pso_ft_t *pso_ft_new(const pso_ft_tables_t *t);     /* the tables must outlive the object */
 void pso_ft_free(pso_ft_t *s);
 void pso_ft_start(pso_ft_t *s);
+/* language scores from a trie model (ps_oracle_lm.h) instead of the dense table, which may then be NULL */
+struct pso_lm_s;
+void pso_ft_set_lm(pso_ft_t *s, const struct pso_lm_s *lm);
 /* 1: run the tree pruning in its data-parallel formulation (per-node decisions on a snapshot +
  * prefix sums for list positions) instead of the reference's sequential walk; same results */
 void pso_ft_set_parallel(pso_ft_t *s, int on);

@@ -912,6 +912,7 @@ static int ft_index(chan_t **nodes, int n, chan_t *h, int base)
     return -2;
 }
 
+static int cmd_lm(ngram_model_t *lmset, const char *qfile);
 static int
 cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
 {
@@ -1026,7 +1027,10 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
     {   /* the language model over dictionary word ids */
         size_t n1 = (size_t)n_w + 1;
         int32 *lm;
-        if (n_w > 400) { fprintf(stderr, "vocabulary too large for a dense LM table\n"); return 2; }
+        if (n_w > 400) {       /* too many words for the dense table: the model's trie tables instead (`lm` command) */
+            if (cmd_lm(ngs->lmset, NULL) != 0) { fprintf(stderr, "vocabulary too large for a dense LM table and no trie model\n"); return 2; }
+            goto traced;
+        }
         lm = malloc(sizeof(int32) * n_w * n1 * n1);
         for (i = 0; i < n_w; ++i)
             for (j = -1; j < n_w; ++j)
@@ -1039,6 +1043,7 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
         put3("lm", 'i', n_w, (int64_t)n1, (int64_t)n1, lm);
         free(lm);
     }
+traced:
     /* ---- the decode, traced */
     ft_ps = ps;
     ft_orig = ps->search->vt; ft_vt = *ft_orig; ft_vt.step = ft_step; ps->search->vt = &ft_vt;

@@ -369,14 +369,17 @@ class OracleFwdtree:
              "tp", "sseq", "ci_tmat", "lm"]
     DT = {"tp": np.uint8, "sseq": np.uint16}
 
-    def __init__(self, static, par):
+    def __init__(self, static, par, lm=None):
+        """lm: an OracleLm -- language scores from the trie oracle instead of the dense table static["lm"]"""
         L = lib()
         src = dict(static); src["par"] = par
-        self._keep = {n: np.ascontiguousarray(src[n], self.DT.get(n, np.int32)) for n in self.NAMES}
+        self._keep = {n: np.ascontiguousarray(src[n], self.DT.get(n, np.int32)) for n in self.NAMES
+                      if not (n == "lm" and lm is not None)}
 
         class T(C.Structure):
             _fields_ = [(n, C.c_void_p) for n in self.NAMES]
-        self._t = T(*[self._keep[n].ctypes.data for n in self.NAMES])
+        self._t = T(*[self._keep[n].ctypes.data if n in self._keep else None for n in self.NAMES])
+        self._lm = lm
         vp = C.c_void_p
         L.pso_ft_new.restype = vp; L.pso_ft_new.argtypes = [vp]
         L.pso_ft_free.argtypes = [vp]; L.pso_ft_start.argtypes = [vp]
@@ -389,6 +392,9 @@ class OracleFwdtree:
             getattr(L, f).argtypes = [vp]; getattr(L, f).restype = vp
         self.n_sen = int(par[2])
         self.h = L.pso_ft_new(C.byref(self._t))
+        if lm is not None:
+            L.pso_ft_set_lm.argtypes = [vp, vp]
+            L.pso_ft_set_lm(self.h, lm.h)
         self._buf = np.zeros(self.n_sen, np.int32)
 
     def __del__(self):

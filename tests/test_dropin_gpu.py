@@ -441,6 +441,9 @@ def test_dropin_device_phone_loop_resumes_on_host(break_at, monkeypatch):
     # pass 3 on the host over the injected table: ngram_search_lattice + ps_lattice_bestpath (SURVEY f-2)
     ("goforward.raw", 1, ("bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
     ("numbers.raw", 1, ("bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
+    # 715 words (oracle/make_medium_task.py): the language scores come from the model's trie on the device
+    ("goforward.raw", 1, (), "medium.arpa", "medium.dic", None),
+    ("numbers.raw", 1, ("bestpath", "yes", "maxwpf", "8"), "medium.arpa", "medium.dic", None),
 ])
 def test_dropin_device_first_pass(raw, nrep, extra, lm, dic, model):
     """psgpu_device_search yes (integration/psgpu_device_decode.c): decoder B's whole first

@@ -9,7 +9,7 @@ import pytest
 
 from test_oracle_golden import _load
 from test_oracle_lm import CASES, load
-from test_oracle_search import CASES as SEARCH_CASES
+from test_oracle_search import CASES as SEARCH_CASES, MEDIUM_CASES
 from test_search_gpu import _check, _inputs
 
 pytestmark = pytest.mark.gpu
@@ -88,15 +88,16 @@ def test_device_lm_create_rejects_inconsistent_tables():
         P.NGramTrieLM(bad)
 
 
-@pytest.mark.parametrize("case", SEARCH_CASES)
+@pytest.mark.parametrize("case", SEARCH_CASES + MEDIUM_CASES)
 def test_fwdtree_kernel_with_the_trie_lm_matches_reference(case):
     """The lexicon-tree search with its language scores looked up in the trie on the device (no dense table
-    uploaded): back-pointer table, score stack and per-frame scores are still the reference's."""
+    uploaded): back-pointer table, score stack and per-frame scores are still the reference's.  The medium
+    cases (715 words, 2820 tree nodes, forced word-exit pruning) cannot run any other way."""
     import pocketsphinx_amd as P
     g = _load("fwdtree_trace_%s.npz" % case)
     static = bytes(g["static"]).decode()
     st = _load("fwdtree_static_%s.npz" % static)
-    lm = P.NGramTrieLM(load({"en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
+    lm = P.NGramTrieLM(st if "lm" not in st else load({"en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
     s = P.FwdtreeSearch(st, g["par"], lm=lm)
     rows, pen = _inputs(g, s.n_sen)
     _check(s.search(rows, pen, [rows.shape[0]])[0], g, case)

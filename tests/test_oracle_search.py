@@ -18,10 +18,13 @@ import pso
 from test_oracle_golden import _load
 
 CASES = ["goforward", "numbers", "goforward_maxhmmpf60_maxwpf3", "something_plwindow0", "man_ah_2934za"]
+# a 715-word task (oracle/make_medium_task.py): no dense LM table, the static fixture carries the model's trie
+# tables and the language scores come from the trie oracle (ps_oracle_lm.c) / the device trie
+MEDIUM_CASES = ["medium_goforward", "medium_numbers_maxwpf8"]
 
 
 @pytest.mark.parametrize("parallel", [0, 1])
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
 def test_fwdtree_oracle_matches_reference(case, parallel):
     """parallel = 1: the tree pruning in its data-parallel formulation (per-node decisions on a
     snapshot of the evaluated state + prefix sums for the list positions, prune_tree_parallel) --
@@ -29,7 +32,7 @@ def test_fwdtree_oracle_matches_reference(case, parallel):
     import ctypes as C
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
-    o = pso.OracleFwdtree(st, g["par"])
+    o = pso.OracleFwdtree(st, g["par"], lm=pso.OracleLm(st) if "lm" not in st else None)
     pso.lib().pso_ft_set_parallel.argtypes = [C.c_void_p, C.c_int]
     pso.lib().pso_ft_set_parallel(o.h, parallel)
     o.start()
