@@ -11,6 +11,8 @@ the right-context score stack and the per-frame marks -- bit for bit.  Cases: en
 (3-state HMMs, PTM scores) on two recordings, with histogram pruning (maxhmmpf) and absolute
 word-exit pruning (maxwpf) forced on, without the phone-loop look-ahead, and tidigits
 (5-state HMMs, semi-continuous scores, its own LM and dictionary)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -51,5 +53,44 @@ def test_fwdtree_oracle_matches_reference(case, parallel):
     assert bp.shape == g["bp"].shape
     bad = np.nonzero((bp != g["bp"]).any(axis=1))[0]
     assert bad.size == 0, "first differing back-pointer %d: %r vs %r" % (bad[0], bp[bad[0]], g["bp"][bad[0]])
+    assert np.array_equal(o.bscore_stack(), g["bscore_stack"])
+    assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
+
+
+@pytest.mark.parametrize("parallel", [0, 1])
+def test_fwdtree_oracle_large_vocabulary(parallel, tmp_path):
+    """The search oracle at full scale: every base word of cmudict (134,865 dictionary entries, a lexicon tree
+    of 248 k channels, ~9,000 active HMMs per frame) with the synthetic large LM of SURVEY F9b (oracle/make_biglm.py).
+    The fixture is too large to commit, so it is produced here by the compiled reference (`ref_dump fwdtree`,
+    ~10 s) -- which travels with the repository as oracle/_ref; language scores come from the trie oracle."""
+    import ctypes as C
+    import subprocess
+    import sys
+    ref = pso.REF_DIR
+    need = [os.path.join(ref, "ref_dump"), os.path.join(ref, "data", "big.arpa"), os.path.join(ref, "data", "cmudict-en-us.dict")]
+    if not all(os.path.exists(p) for p in need):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    out = str(tmp_path / "big.psgb")
+    subprocess.check_call([need[0], "fwdtree", out, os.path.join(ref, "model", "en-us"), need[1], need[2],
+                           os.path.join(ref, "data", "goforward.raw"), "--", "fwdflat", "no", "bestpath", "no"], timeout=600)
+    sys.path.insert(0, os.path.join(os.path.dirname(pso.__file__), "..", "oracle"))
+    from psgb import read_psgb
+    g = read_psgb(out)
+    assert bytes(g["hyp"]).decode() == "go forward ten meters" and int(g["par"][3]) > 100000
+    o = pso.OracleFwdtree(g, g["par"], lm=pso.OracleLm(g))
+    pso.lib().pso_ft_set_parallel.argtypes = [C.c_void_p, C.c_int]
+    pso.lib().pso_ft_set_parallel(o.h, parallel)
+    o.start()
+    off, act, scr = g["step_act_off"], g["step_act"], g["step_scr"]
+    for i in range(int(g["n_steps"][0])):
+        fr = int(g["step_frame"][i])
+        a0, a1 = int(off[i]), int(off[i + 1])
+        assert np.array_equal(o.active_list(fr), act[a0:a1]), "frame %d: active senone list" % fr
+        o.step(fr, act[a0:a1], scr[a0:a1], int(g["step_rest"][i]), g["step_pen"][i])
+        assert (o.best_score(), o.last_phone_best_score(), o.bpidx()) == \
+            (int(g["step_best"][i]), int(g["step_lpbest"][i]), int(g["step_bpidx"][i])), "frame %d" % fr
+    nfr = int(g["n_frame"][0])
+    o.finish(nfr)
+    assert np.array_equal(o.bp_table(), g["bp"])
     assert np.array_equal(o.bscore_stack(), g["bscore_stack"])
     assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
