@@ -15,9 +15,20 @@ def main():
     import torch
     import pocketsphinx_amd as P
     from test_search_gpu import _inputs
-    g = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_goforward.npz"))
-    st = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_en_us_turtle.npz"))
-    s = P.FwdtreeSearch({k: st[k] for k in st.files}, g["par"])
+    # SB_CASE: a golden trace; SB_LM = trie: language scores from the model's trie on the device (the only way for
+    # the medium_* traces) instead of the dense table
+    case = os.environ.get("SB_CASE", "goforward")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_%s.npz" % case))
+    static = bytes(g["static"]).decode()
+    st = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_%s.npz" % static))
+    st = {k: st[k] for k in st.files}
+    lm = None
+    if os.environ.get("SB_LM", "dense") == "trie" or "lm" not in st:
+        lmsrc = st if "lm" not in st else np.load(os.path.join(ROOT, "tests", "golden", "lm_%s.npz" % {
+            "en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
+        lm = P.NGramTrieLM({k: lmsrc[k] for k in (lmsrc.files if hasattr(lmsrc, "files") else lmsrc)})
+    print("case %s, %d words, %d tree nodes, LM: %s" % (case, int(g["par"][3]), int(g["par"][4] + g["par"][5]), "trie" if lm else "dense"))
+    s = P.FwdtreeSearch(st, g["par"], lm=lm)
     rows, pen = _inputs(g, s.n_sen)
     import ctypes as C
     from pocketsphinx_amd import capi
@@ -29,7 +40,7 @@ def main():
         d_s = d_rows.repeat(B, 1); d_p = d_pen1.repeat(B, 1)
         nb = B
         uo = torch.from_numpy((np.arange(nb + 1) * T).astype(np.int32)).to(dev)
-        bp_cap, bss_cap = 4096, 65536
+        bp_cap, bss_cap = 8192, 1 << 17
         bp = torch.zeros((nb, 10, bp_cap), dtype=torch.int32, device=dev); bss = torch.zeros((nb, bss_cap), dtype=torch.int32, device=dev)
         idx = torch.zeros((nb, T + 2), dtype=torch.int32, device=dev); step = torch.zeros((nb, T, 4), dtype=torch.int32, device=dev)
         res = torch.zeros((nb, 8), dtype=torch.int32, device=dev)
