@@ -194,6 +194,44 @@ __device__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bs
     return true;
 }
 
+// Exclusive prefix sum of a[0..n) in place by the whole workgroup (a in LDS, written before a barrier);
+// returns the total to every thread.  tmp: kFtThreads / 64 words of LDS.  Ends with a barrier.
+__device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int per = (n + kFtThreads - 1) / kFtThreads;
+    const int b = min(n, tid * per), e = min(n, b + per);
+    int32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += a[i];
+    int32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) tmp[tid >> 6] = incl;
+    __syncthreads();
+    int32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kFtThreads / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
+    int32_t run = base + incl - sum;
+    for (int i = b; i < e; ++i) { const int32_t k = a[i]; a[i] = run; run += k; }
+    __syncthreads();
+    return total;
+}
+// out[t] = max of v over threads 0 .. t - 1 (-1 for thread 0): one value per thread.  Ends with a barrier.
+__device__ __forceinline__ int32_t ft_block_excl_max(int32_t v, int32_t *tmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    int32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
+    if (lane == 63) tmp[tid >> 6] = incl;
+    int32_t excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = -1;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); ++w) excl = max(excl, tmp[w]);
+    __syncthreads();
+    return excl;
+}
+
 template <int NE>
 __global__ __launch_bounds__(kFtThreads)
 void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
@@ -205,6 +243,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     __shared__ int32_t s_nb;
     __shared__ int32_t s_cnt[kFtMaxN + 1];
     __shared__ int32_t s_red[8];
+    __shared__ int32_t s_scan[kFtThreads / 64];
     __shared__ int32_t s_bins[256];
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
@@ -255,12 +294,11 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             }
             for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) mark(W1 + i);
             __syncthreads();
-            if (tid == 0) {
-                int last = -1;
-                for (int w = 0; w < nwords; ++w) {
-                    s_prev[w] = last;
-                    if (s_bits[w]) last = w * 32 + 31 - __clz((int)s_bits[w]);
-                }
+            {   // s_prev[w] = the highest senone listed in the words before w (one bitmap word per thread)
+                static_assert(kFtMaxSen / 32 <= kFtThreads, "one bitmap word per thread");
+                const uint32_t bw = tid < nwords ? s_bits[tid] : 0u;
+                const int32_t pv = ft_block_excl_max(bw ? tid * 32 + 31 - __clz((int)bw) : -1, s_scan);
+                if (tid < nwords) s_prev[tid] = pv;
             }
             __syncthreads();
             int32_t mn = 0x7fffffff;
@@ -403,19 +441,14 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             s_cnt[i] = k;
         }
         __syncthreads();
-        if (tid == 0) {                                          // exclusive prefix sum (small)
-            int run = 0;
-            for (int i = 0; i < R + n_acl[cur]; ++i) { const int k = s_cnt[i]; s_cnt[i] = run; run += k; }
-            s_cnt[R + n_acl[cur]] = run;
-        }
-        __syncthreads();
+        const int32_t n_listed = ft_block_scan(s_cnt, R + n_acl[cur], s_scan);      // exclusive prefix sum
         for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
             const int node = i < R ? i : u.acl[cur][i - R];
             int o = s_cnt[i];
             if (i >= R && (u.o_frame[node] & 8)) u.acl[nxt][o++] = node;
             for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.o_frame[c] & 2) u.acl[nxt][o++] = c;
         }
-        n_acl[nxt] = s_cnt[R + n_acl[cur]];
+        n_acl[nxt] = n_listed;
         __syncthreads();
         // last-phone candidates: list order, homophone chain inside
         for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
@@ -427,10 +460,9 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             s_cnt[i] = k;
         }
         __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int i = 0; i < R + n_acl[cur]; ++i) { const int k = s_cnt[i]; s_cnt[i] = run; run += k; }
-            s_sc[5] = run;
+        {
+            const int32_t n_cand_all = ft_block_scan(s_cnt, R + n_acl[cur], s_scan);
+            if (tid == 0) s_sc[5] = n_cand_all;
         }
         __syncthreads();
         for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
@@ -445,7 +477,52 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         }
         __syncthreads();
 
-        // ---- word level: last_phone_transition, prune_word_chan, bptable_maxwpf (:884-1241); one thread
+        // ---- word level: last_phone_transition (:884-1035).  Candidates of one frame name distinct words (a word has
+        //      one penultimate tree node, a node one place in the active list), so each candidate's best
+        //      predecessor -- exit score + language score over the back-pointers of its start frame, the
+        //      look-ups that dominate this step -- is found by its own thread; last_ltrans (lt_*) is the
+        //      reference's per-word cache keyed by start frame.  Should two candidates ever share a word, the
+        //      reference's loops are run as written by one thread.
+        {
+            const int n_cand = s_sc[5];
+            if (tid == 0) s_red[7] = 0;
+            __syncthreads();
+            for (int i = tid; i < n_cand; i += kFtThreads) {
+                const int w = u.cand_wid[i];
+                for (int j = 0; j < i; ++j) if (u.cand_wid[j] == w) s_red[7] = 1;
+            }
+            __syncthreads();
+        }
+        if (s_red[7] == 0) {
+            const int n_cand = s_sc[5];
+            int32_t bestscore = kW;
+            for (int i = tid; i < n_cand; i += kFtThreads) {
+                const int cb = u.cand_bp[i], w = u.cand_wid[i];
+                int32_t score = u.cand_score[i];
+                if (cb != -1) {
+                    const int first = p.d_first[w];
+                    score -= ft_exit_score(p, u, cb, first);
+                    const int ef = BPC(u, B_FRAME, cb);
+                    if (u.lt_sf[w] != ef + 1) {
+                        int32_t best = kW, bestbp = u.lt_bp[w];
+                        const int b1 = u.bp_table_idx[ef + 1], base = p.d_base[w];
+                        for (int bp = u.bp_table_idx[ef]; bp < b1; ++bp) {
+                            if (!BPC(u, B_VALID, bp)) continue;
+                            int32_t dscr = ft_exit_score(p, u, bp, first);
+                            if (dscr > kW) dscr += ft_lm(p, base, BPC(u, B_REAL, bp), BPC(u, B_PREAL, bp));
+                            if (dscr > best) { best = dscr; bestbp = bp; }
+                        }
+                        u.lt_dscr[w] = best; u.lt_bp[w] = bestbp; u.lt_sf[w] = ef + 1;
+                    }
+                }
+                score += u.lt_dscr[w];
+                u.cand_score[i] = score;
+                u.cand_bp[i] = u.lt_bp[w];
+                bestscore = max(bestscore, score);
+            }
+            if (bestscore > kW) atomicMax(&s_sc[1], bestscore);
+        }
+        else
         if (tid == 0) {
             const int n_cand = s_sc[5];
             int n_csf = 0;
@@ -493,14 +570,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             //      loop is run by one thread in candidate order.
             const int n_cand = s_sc[5];
             const int32_t cthresh = s_sc[1] + p.lponlybeam;
-            if (tid == 0) s_red[7] = 0;
-            __syncthreads();
-            for (int i = tid; i < n_cand; i += kFtThreads) {
-                const int w = u.cand_wid[i];
-                for (int j = 0; j < i; ++j) if (u.cand_wid[j] == w) s_red[7] = 1;
-            }
-            __syncthreads();
-            const bool dup = s_red[7] != 0;
+            const bool dup = s_red[7] != 0;                     // (found above)
             for (int i = (dup ? (tid == 0 ? 0 : n_cand) : tid); i < n_cand; i += (dup ? 1 : kFtThreads)) {
                 int k = 0;
                 if (u.cand_score[i] > cthresh) {
