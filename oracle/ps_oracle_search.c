@@ -291,6 +291,7 @@ void pso_ft_start(pso_ft_t *s)
     for (i = 0; i < s->n_w; ++i) s->ltrans[i].sf = -1;
     s->n_frame = 0;
     s->n_root_eval = s->n_nonroot_eval = 0;
+    for (i = 0; i < s->N; ++i) s->pos[i] = -1;               /* (prune_tree_list keeps it so between frames) */
     for (i = 0; i < s->n1; ++i) h_clear(&s->w1[i]);
     i = w1_index(s, s->startwid);
     h_clear(&s->w1[i]);
@@ -549,6 +550,93 @@ static void prune_tree_parallel(pso_ft_t *s, int frame, const int32_t *pp)
     }
 }
 
+/* The same decisions with work proportional to the ACTIVE part of the tree (pso_ft_set_parallel(2)): the form a
+ * large-vocabulary kernel needs (248 k channels, ~9 k active per frame).  Work items are the nodes on the active
+ * list (own retention / clearing, in_acl = 1) and the children of roots and of listed nodes that are not listed
+ * themselves (entered by the parent or left alone, in_acl = 0; a node has one parent, so no item is visited
+ * twice).  The per-node arrays (pos, snapshot, ret, fire, selfapp) are sized for the whole tree but touched only
+ * at these items; pos is reset at the end.  Every read of another node's state goes to the snapshot of an
+ * active node or root, every write to the item's own node, so the items are independent. */
+static void decide_node(pso_ft_t *s, int c, int frame, const int32_t *pp, int32_t npt)
+{
+    const int nf = frame + 1, R = s->R;
+    pso_hmm_t *h = &s->node[c];
+    const int P = s->parent[c], pc = s->pos[c], in_acl = pc >= 0;
+    const int par_active = P < R ? 1 : s->pos[P] >= 0;
+    const int32_t news = (par_active ? s->o_out[P] : WORST) + s->pip;
+    const int parent_can = par_active && s->ret[P] && (s->has_pl || news > npt) && (news + pen(s, pp, s->t.node_ci[c]) > npt);
+    const int parent_first = P < R || (in_acl && s->pos[P] < pc) || !in_acl;
+    const int retc = in_acl && s->ret[c];
+    int fire, entered_first;
+    if (!in_acl || parent_first) fire = parent_can && (h->frame < frame || news > h->score[0]);   /* own state: live */
+    else if (retc)               fire = parent_can && news > h->score[0];
+    else                         fire = parent_can;
+    entered_first = fire && parent_first;
+    s->selfapp[c] = (uint8_t)(retc && !entered_first);
+    s->fire[c] = (uint8_t)(fire ? ((P < R || !(in_acl && !parent_first && retc)) ? 1 : 2) : 0);
+    if (in_acl && !retc && !entered_first) h_clear(h);
+    if (retc) h->frame = nf;
+    if (fire) h_enter(h, news, s->o_outh[P], nf);
+}
+
+static void prune_tree_list(pso_ft_t *s, int frame, const int32_t *pp)
+{
+    const int nf = frame + 1, R = s->R;
+    const int32_t thresh = s->best_score + s->dynamic_beam;
+    const int32_t npt = s->best_score + s->pbeam, lpt = s->best_score + s->lpbeam;
+    const int32_t *acl = s->acl[frame & 1];
+    const int n_acl = s->n_acl[frame & 1];
+    int32_t *nacl = s->acl[nf & 1];
+    int i, p, c, w, total;
+
+    /* positions, snapshot and retention of roots and listed nodes */
+    for (p = 0; p < n_acl; ++p) s->pos[acl[p]] = p;
+    for (i = 0; i < R + n_acl; ++i) {
+        const int node = i < R ? i : acl[i - R];
+        const pso_hmm_t *h = &s->node[node];
+        const int active = node < R ? h->frame >= frame : 1;
+        s->o_out[node] = h->out_score; s->o_outh[node] = h->out_history;
+        s->ret[node] = (uint8_t)(active && h->bestscore > thresh);
+    }
+    /* decisions: listed nodes, then the unlisted children of roots and listed nodes */
+    for (p = 0; p < n_acl; ++p) decide_node(s, acl[p], frame, pp, npt);
+    for (i = 0; i < R + n_acl; ++i) {
+        const int node = i < R ? i : acl[i - R];
+        for (c = s->t.node_child[node]; c >= 0; c = s->t.node_sib[c])
+            if (s->pos[c] < 0) decide_node(s, c, frame, pp, npt);
+    }
+    for (i = 0; i < R; ++i) if (s->ret[i]) s->node[i].frame = nf;
+    /* list positions, as in prune_tree_parallel */
+    total = 0;
+    for (i = 0; i < R; ++i)
+        for (c = s->t.node_child[i]; c >= 0; c = s->t.node_sib[c])
+            if (s->fire[c]) nacl[total++] = c;
+    for (p = 0; p < n_acl; ++p) {
+        int k = s->selfapp[acl[p]];
+        for (c = s->t.node_child[acl[p]]; c >= 0; c = s->t.node_sib[c]) k += (s->fire[c] == 1);
+        s->cnt[p] = k;
+    }
+    s->offs[0] = total;
+    for (p = 0; p < n_acl; ++p) s->offs[p + 1] = s->offs[p] + s->cnt[p];
+    for (p = 0; p < n_acl; ++p) {
+        int o = s->offs[p];
+        if (s->selfapp[acl[p]]) nacl[o++] = acl[p];
+        for (c = s->t.node_child[acl[p]]; c >= 0; c = s->t.node_sib[c]) if (s->fire[c] == 1) nacl[o++] = c;
+    }
+    s->n_acl[nf & 1] = s->offs[n_acl];
+    for (i = 0; i < R + n_acl; ++i) {
+        const int node = i < R ? i : acl[i - R];
+        const int32_t news = s->o_out[node] + s->pip;
+        if (!s->ret[node] || !(s->has_pl || news > lpt)) continue;
+        for (w = s->t.node_penult_wid[node]; w >= 0; w = s->t.homophone_set[w])
+            if (news + pen(s, pp, s->t.dict_last[w]) > lpt) {
+                cand_t *cp = &s->cand[s->n_cand++];
+                cp->wid = w; cp->score = news - s->nwpen; cp->bp = s->o_outh[node];
+            }
+    }
+    for (p = 0; p < n_acl; ++p) s->pos[acl[p]] = -1;
+}
+
 void pso_ft_set_lm(pso_ft_t *s, const pso_lm_t *lm) { s->trie = lm; }
 
 void pso_ft_set_parallel(pso_ft_t *s, int on) { s->par_mode = on; }
@@ -675,7 +763,8 @@ static void prune_channels(pso_ft_t *s, int frame, const int32_t *pp)
         for (i = 0; i < 256; ++i) { nh += bins[i]; if (nh > s->maxhmmpf) break; }
         s->dynamic_beam = -(i * bw);
     }
-    if (s->par_mode) prune_tree_parallel(s, frame, pp);
+    if (s->par_mode == 2) prune_tree_list(s, frame, pp);
+    else if (s->par_mode) prune_tree_parallel(s, frame, pp);
     else { prune_root(s, frame, pp); prune_nonroot(s, frame, pp); }
     last_phone_transition(s, frame);
     prune_word(s, frame);

@@ -38,7 +38,9 @@ void pso_ft_start(pso_ft_t *s);
 struct pso_lm_s;
 void pso_ft_set_lm(pso_ft_t *s, const struct pso_lm_s *lm);
 /* 1: run the tree pruning in its data-parallel formulation (per-node decisions on a snapshot +
- * prefix sums for list positions) instead of the reference's sequential walk; same results */
+ * prefix sums for list positions) instead of the reference's sequential walk; same results.
+ * 2: the same decisions with work proportional to the active part of the tree (listed nodes and their
+ * children) -- the form for large vocabularies */
 void pso_ft_set_parallel(pso_ft_t *s, int on);
 /* the senone ids compute_sen_active + acmod_flags2list would list for `frame` (bridging entries
  * included); out has room for n_sen entries */

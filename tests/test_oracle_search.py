@@ -25,12 +25,13 @@ CASES = ["goforward", "numbers", "goforward_maxhmmpf60_maxwpf3", "something_plwi
 MEDIUM_CASES = ["medium_goforward", "medium_numbers_maxwpf8"]
 
 
-@pytest.mark.parametrize("parallel", [0, 1])
+@pytest.mark.parametrize("parallel", [0, 1, 2])
 @pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
 def test_fwdtree_oracle_matches_reference(case, parallel):
     """parallel = 1: the tree pruning in its data-parallel formulation (per-node decisions on a
     snapshot of the evaluated state + prefix sums for the list positions, prune_tree_parallel) --
-    the form the device kernel uses -- must give the same tables as the sequential walk."""
+    the form the device kernel uses -- must give the same tables as the sequential walk.
+    parallel = 2: the same with work proportional to the active part of the tree (prune_tree_list)."""
     import ctypes as C
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
@@ -57,25 +58,32 @@ def test_fwdtree_oracle_matches_reference(case, parallel):
     assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
 
 
-@pytest.mark.parametrize("parallel", [0, 1])
-def test_fwdtree_oracle_large_vocabulary(parallel, tmp_path):
-    """The search oracle at full scale: every base word of cmudict (134,865 dictionary entries, a lexicon tree
-    of 248 k channels, ~9,000 active HMMs per frame) with the synthetic large LM of SURVEY F9b (oracle/make_biglm.py).
-    The fixture is too large to commit, so it is produced here by the compiled reference (`ref_dump fwdtree`,
-    ~10 s) -- which travels with the repository as oracle/_ref; language scores come from the trie oracle."""
-    import ctypes as C
+@pytest.fixture(scope="module")
+def big_trace(tmp_path_factory):
+    """`ref_dump fwdtree` of the compiled reference on the large-vocabulary task (too large to commit, ~10 s to make)"""
     import subprocess
     import sys
     ref = pso.REF_DIR
     need = [os.path.join(ref, "ref_dump"), os.path.join(ref, "data", "big.arpa"), os.path.join(ref, "data", "cmudict-en-us.dict")]
     if not all(os.path.exists(p) for p in need):
         pytest.skip("oracle/_ref (compiled reference + staged data) not built")
-    out = str(tmp_path / "big.psgb")
+    out = str(tmp_path_factory.mktemp("big") / "big.psgb")
     subprocess.check_call([need[0], "fwdtree", out, os.path.join(ref, "model", "en-us"), need[1], need[2],
                            os.path.join(ref, "data", "goforward.raw"), "--", "fwdflat", "no", "bestpath", "no"], timeout=600)
     sys.path.insert(0, os.path.join(os.path.dirname(pso.__file__), "..", "oracle"))
     from psgb import read_psgb
-    g = read_psgb(out)
+    return read_psgb(out)
+
+
+@pytest.mark.parametrize("parallel", [0, 1, 2])
+def test_fwdtree_oracle_large_vocabulary(parallel, big_trace):
+    """The search oracle at full scale: every base word of cmudict (134,865 dictionary entries, a lexicon tree
+    of 248 k channels, ~9,000 active HMMs per frame) with the synthetic large LM of SURVEY F9b (oracle/make_biglm.py).
+    The fixture is produced at test time by the compiled reference, which travels with the repository as
+    oracle/_ref; language scores come from the trie oracle.  parallel = 2 is the formulation whose work per frame
+    is proportional to the active channels, not the tree."""
+    import ctypes as C
+    g = big_trace
     assert bytes(g["hyp"]).decode() == "go forward ten meters" and int(g["par"][3]) > 100000
     o = pso.OracleFwdtree(g, g["par"], lm=pso.OracleLm(g))
     pso.lib().pso_ft_set_parallel.argtypes = [C.c_void_p, C.c_int]
