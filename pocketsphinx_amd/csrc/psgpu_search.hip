@@ -23,6 +23,7 @@
 // the reference's, bit for bit (tests/test_search_gpu.py against reference dumps).
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct FtDev {
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
     const uint8_t *tp;
     const uint16_t *sseq;
+    int32_t big;                         // tree or vocabulary beyond the LDS scratch: list / word scratch in the utterance's slab
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
     LmDev trie;
 };
@@ -64,6 +66,7 @@ struct FtUtt {
     int32_t *o_frame, *o_s0, *o_best, *o_out, *o_outh, *pos, *flag;   // [N] pruning snapshot / decisions
     int32_t *step;                       // [T][4] best_score, last_phone_best_score, bpidx, n_active_chan (diagnostics)
     int32_t *result;                     // [8] bpidx, bss_head, n_frame, status
+    int32_t *g_cnt, *g_w;                // [max(R + N, n_w) + 1], [4][n_w]: scratch for large trees / vocabularies (FtDev.big)
     int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
     int32_t bp_cap, bss_cap;
 };
@@ -249,6 +252,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     __shared__ unsigned long long s_evals;
     const int tid = threadIdx.x;
     FtUtt u = utts[blockIdx.x];
+    // list-position / candidate / word scratch: LDS when the tree and the vocabulary fit (kFtMaxN entries), else the slab
+    int32_t *const cnt = p.big ? u.g_cnt : s_cnt;
     const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
     const int N = p.N, R = p.R, W1 = N, WC = N + p.n1;
     int n_acl[2] = {0, 0}, n_awl[2] = {0, 0};           // uniform copies (every thread tracks them identically)
@@ -438,13 +443,13 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int node = i < R ? i : u.acl[cur][i - R];
             int k = (i >= R && (u.o_frame[node] & 8)) ? 1 : 0;
             for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) k += (u.o_frame[c] & 2) ? 1 : 0;
-            s_cnt[i] = k;
+            cnt[i] = k;
         }
         __syncthreads();
-        const int32_t n_listed = ft_block_scan(s_cnt, R + n_acl[cur], s_scan);      // exclusive prefix sum
+        const int32_t n_listed = ft_block_scan(cnt, R + n_acl[cur], s_scan);      // exclusive prefix sum
         for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
             const int node = i < R ? i : u.acl[cur][i - R];
-            int o = s_cnt[i];
+            int o = cnt[i];
             if (i >= R && (u.o_frame[node] & 8)) u.acl[nxt][o++] = node;
             for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.o_frame[c] & 2) u.acl[nxt][o++] = c;
         }
@@ -457,18 +462,18 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             int k = 0;
             if ((u.flag[node] & 1) && (p.has_pl || news > lpt))
                 for (int w = p.node_pw[node]; w >= 0; w = p.homophone[w]) k += (news + ft_pen(p, pp, p.d_last[w]) > lpt) ? 1 : 0;
-            s_cnt[i] = k;
+            cnt[i] = k;
         }
         __syncthreads();
         {
-            const int32_t n_cand_all = ft_block_scan(s_cnt, R + n_acl[cur], s_scan);
+            const int32_t n_cand_all = ft_block_scan(cnt, R + n_acl[cur], s_scan);
             if (tid == 0) s_sc[5] = n_cand_all;
         }
         __syncthreads();
         for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
             const int node = i < R ? i : u.acl[cur][i - R];
             const int32_t news = u.o_out[node] + p.pip;
-            int o = s_cnt[i];
+            int o = cnt[i];
             if ((u.flag[node] & 1) && (p.has_pl || news > lpt))
                 for (int w = p.node_pw[node]; w >= 0; w = p.homophone[w])
                     if (news + ft_pen(p, pp, p.d_last[w]) > lpt) {
@@ -590,20 +595,21 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                         if (u.frame[c] < f || u.cand_score[i] > u.score[c * 5]) { ch_enter(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
                     }
                 }
-                s_cnt[i] = k > 0;
+                cnt[i] = k > 0;
             }
             __syncthreads();
             if (tid == 0) {
                 int nawl = 0;
                 for (int i = 0; i < n_cand; ++i)
-                    if (s_cnt[i]) { const int w = u.cand_wid[i]; u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
+                    if (cnt[i]) { const int w = u.cand_wid[i]; u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
                 s_red[5] = nawl;
             }
             __syncthreads();
             // ---- prune_word_chan (:1038-1128): pass A, one thread per active word -- keep / free the
             //      right-context channels, count the survivors, note whether the word exits
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            int32_t *w_k = s_cnt, *w_exit = s_cnt + 1024, *w_bp = s_cnt + 2048, *w_bss = s_cnt + 3072;   // n_awl <= n_w <= 1024
+            const int wst = p.big ? p.n_w : 1024;                // n_awl <= n_w
+            int32_t *w_k = p.big ? u.g_w : cnt, *w_exit = w_k + wst, *w_bp = w_k + 2 * wst, *w_bss = w_k + 3 * wst;
             for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
                 const int w = u.awl[cur][i];
                 int k = 0, ex = 0;
@@ -794,7 +800,8 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.n1lm = q[7]; d.beam = q[8]; d.pbeam = q[9]; d.lpbeam = q[10]; d.lponlybeam = q[11]; d.wbeam = q[12]; d.pip = q[13];
     d.nwpen = q[14]; d.silpen = q[15]; d.fillpen = q[16]; d.maxhmmpf = q[17]; d.maxwpf = q[18]; d.startwid = q[19];
     d.finishwid = q[20]; d.silwid = q[21]; d.filler_start = q[22]; d.filler_end = q[23]; d.sil_ci = q[24]; d.has_pl = q[25];
-    if (!(d.n_emit == 3 || d.n_emit == 5) || d.n_ci < 1 || d.n_ci > kFtMaxCi || d.N < 1 || d.N + d.R > kFtMaxN || d.n_w < 1 || d.n_w > 1024) {
+    d.big = (d.N + d.R > kFtMaxN || d.n_w > 1024) ? 1 : 0;
+    if (!(d.n_emit == 3 || d.n_emit == 5) || d.n_ci < 1 || d.n_ci > kFtMaxCi || d.N < 1 || d.n_w < 1) {
         psgpu_set_error("fwdtree: unsupported shape (n_emit %d, n_ci %d, tree nodes %d, words %d)", d.n_emit, d.n_ci, d.N, d.n_w);
         delete m;
         return PSGPU_EINVAL;
@@ -878,7 +885,8 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     const size_t C = m->C;
     const size_t per = C * (5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
                      + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
-                     + ((size_t)d.n_sen + 1) / 2 + 1;
+                     + ((size_t)d.n_sen + 1) / 2 + 1
+                     + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
     int32_t *slab = nullptr;
     FtUtt *d_utts = nullptr;
     PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * per * n_utt));
@@ -897,6 +905,8 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.o_frame = take(d.N); u.o_s0 = take(d.N); u.o_best = take(d.N); u.o_out = take(d.N); u.o_outh = take(d.N);
         u.pos = take(d.N); u.flag = take(d.N);
         u.nrow = reinterpret_cast<int16_t *>(take(((size_t)d.n_sen + 1) / 2 + 1));
+        u.g_cnt = d.big ? take((size_t)std::max(d.N + d.R, d.n_w) + 1) : nullptr;
+        u.g_w = d.big ? take(4 * (size_t)d.n_w) : nullptr;
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
         u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
         u.result = result_dev + (size_t)i * 8;

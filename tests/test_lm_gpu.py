@@ -9,7 +9,7 @@ import pytest
 
 from test_oracle_golden import _load
 from test_oracle_lm import CASES, load
-from test_oracle_search import CASES as SEARCH_CASES, MEDIUM_CASES
+from test_oracle_search import CASES as SEARCH_CASES, MEDIUM_CASES, big_trace  # noqa: F401 (fixture)
 from test_search_gpu import _check, _inputs
 
 pytestmark = pytest.mark.gpu
@@ -110,3 +110,19 @@ def test_fwdtree_set_lm_checks_the_vocabulary():
     st = _load("fwdtree_static_en_us_turtle.npz")
     with pytest.raises(P.PsgpuError):
         P.FwdtreeSearch(st, g["par"], lm=P.NGramTrieLM(load("tidigits_decoder")))
+
+
+def test_fwdtree_kernel_full_cmudict_vocabulary(big_trace):  # noqa: F811
+    """The search kernel at the scale of SURVEY 8d config 3's large-vocabulary decode: 134,865 dictionary entries,
+    a lexicon tree of 248 k channels, 3.7 M (word, right context) last-phone slots, language scores from the
+    device trie (126 k unigrams).  Beyond the LDS scratch (4096 tree nodes / 1024 words) the list and word scratch
+    live in the utterance's slab; the algorithm is the same, so the back-pointer table, score stack, frame marks
+    and per-frame best scores must again be the reference's (fixture made at test time by the compiled reference).
+    This version still walks the whole tree every frame: correct, not yet fast."""
+    import pocketsphinx_amd as P
+    g = big_trace
+    lm = P.NGramTrieLM(g)
+    s = P.FwdtreeSearch(g, g["par"], lm=lm)
+    rows, pen = _inputs(g, s.n_sen)
+    _check(s.search(rows, pen, [rows.shape[0]])[0], g, "cmudict")
+    s.close()
