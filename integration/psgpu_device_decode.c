@@ -16,6 +16,7 @@
  * -fwdflat no (pass 1 on the device; -bestpath yes builds the word lattice from the
  * injected table on the host, ngram_search.c:1212, and searches it as usual), the PTM scorer (psgpu_mgau_attach first) and
  * the 1s_c_d_dd feature type. */
+#include <stdlib.h>
 #include <string.h>
 
 #include <pocketsphinx.h>
@@ -59,13 +60,25 @@ number_nodes(chan_t *first, chan_t **nodes, int n)
     for (h = first; h; h = h->alt) { nodes[n++] = h; n = number_nodes(h->next, nodes, n); }
     return n;
 }
+/* index of a tree channel in the flattened numbering: the pointers are sorted once (the tree of a large
+ * dictionary has a quarter of a million channels) */
+typedef struct { chan_t *h; int idx; } node_ref_t;
+static int
+node_ref_cmp(const void *a, const void *b)
+{
+    const chan_t *x = ((const node_ref_t *)a)->h, *y = ((const node_ref_t *)b)->h;
+    return x < y ? -1 : x > y;
+}
+static node_ref_t *g_refs;       /* set for the duration of one attach (single-threaded, like ps_init) */
 static int
 node_index(chan_t **nodes, int n, chan_t *h, int base)
 {
-    int i;
+    node_ref_t key, *r;
+    (void)nodes;
     if (h == NULL) return -1;
-    for (i = 0; i < n; ++i) if (nodes[i] == h) return base + i;
-    return -1;
+    key.h = h; key.idx = 0;
+    r = bsearch(&key, g_refs, n, sizeof *g_refs, node_ref_cmp);
+    return r ? base + r->idx : -1;
 }
 
 psgpu_device_decode_t *
@@ -97,7 +110,6 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     }
     acmod = ps->acmod; mdef = acmod->mdef; dict = ps_search_dict(ngs); d2p = ps_search_dict2pid(ngs);
     n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(dict);
-    if (n_w > 1024) { E_ERROR("psgpu device decode: %d words -- the tree search kernel holds up to 1024\n", n_w); return NULL; }
     if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->compallsen || acmod->fcb->cmn != CMN_BATCH
         || acmod->fcb->agc != AGC_NONE || acmod->fcb->varnorm) {
         E_ERROR("psgpu device decode: needs the 1s_c_d_dd feature type with -cmn batch, no AGC / variance normalisation / LDA, "
@@ -116,6 +128,9 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     nodes = ckd_calloc(ngs->n_nonroot_chan + 16, sizeof *nodes);
     for (M = 0, i = 0; i < R; ++i) M = number_nodes(ngs->root_chan[i].next, nodes, M);
     N = R + M; n1 = ngs->n_1ph_words;
+    g_refs = ckd_calloc(M + 1, sizeof *g_refs);
+    for (i = 0; i < M; ++i) { g_refs[i].h = nodes[i]; g_refs[i].idx = i; }
+    qsort(g_refs, M, sizeof *g_refs, node_ref_cmp);
     ci = ckd_calloc(N, 4); ci2 = ckd_calloc(N, 4); ssid = ckd_calloc(N, 4); tm = ckd_calloc(N, 4); child = ckd_calloc(N, 4);
     sib = ckd_calloc(N, 4); pw = ckd_calloc(N, 4);
     for (i = 0; i < R; ++i) {
@@ -129,6 +144,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         child[R + i] = node_index(nodes, M, h->next, R); sib[R + i] = node_index(nodes, M, h->alt, R);
         pw[R + i] = h->info.penult_phn_wid;
     }
+    ckd_free(g_refs); g_refs = NULL;
     sw = ckd_calloc(n1 + 1, 4); sci = ckd_calloc(n1 + 1, 4); sci2 = ckd_calloc(n1 + 1, 4); sss = ckd_calloc(n1 + 1, 4);
     stm = ckd_calloc(n1 + 1, 4); smpx = ckd_calloc(n1 + 1, 4);
     for (i = 0; i < n1; ++i) {

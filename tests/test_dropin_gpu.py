@@ -444,6 +444,8 @@ def test_dropin_device_phone_loop_resumes_on_host(break_at, monkeypatch):
     # 715 words (oracle/make_medium_task.py): the language scores come from the model's trie on the device
     ("goforward.raw", 1, (), "medium.arpa", "medium.dic", None),
     ("numbers.raw", 1, ("bestpath", "yes", "maxwpf", "8"), "medium.arpa", "medium.dic", None),
+    # the full cmudict vocabulary (134,865 words, 248 k tree channels, SURVEY F9b's synthetic large LM)
+    ("goforward.raw", 1, (), "big.arpa", "cmudict-en-us.dict", None),
 ])
 def test_dropin_device_first_pass(raw, nrep, extra, lm, dic, model):
     """psgpu_device_search yes (integration/psgpu_device_decode.c): decoder B's whole first

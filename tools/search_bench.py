@@ -18,10 +18,23 @@ def main():
     # SB_CASE: a golden trace; SB_LM = trie: language scores from the model's trie on the device (the only way for
     # the medium_* traces) instead of the dense table
     case = os.environ.get("SB_CASE", "goforward")
-    g = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_%s.npz" % case))
-    static = bytes(g["static"]).decode()
-    st = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_%s.npz" % static))
-    st = {k: st[k] for k in st.files}
+    if case == "cmudict":
+        # the full-vocabulary task (134,865 words): trace made on the spot by the compiled reference (oracle/_ref)
+        import subprocess
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from psgb import read_psgb
+        ref = os.path.join(ROOT, "oracle", "_ref")
+        out = os.path.join(tempfile.mkdtemp(), "big.psgb")
+        subprocess.check_call([os.path.join(ref, "ref_dump"), "fwdtree", out, os.path.join(ref, "model", "en-us"),
+                               os.path.join(ref, "data", "big.arpa"), os.path.join(ref, "data", "cmudict-en-us.dict"),
+                               os.path.join(ref, "data", "goforward.raw"), "--", "fwdflat", "no", "bestpath", "no"])
+        g = st = read_psgb(out)
+    else:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_%s.npz" % case))
+        static = bytes(g["static"]).decode()
+        st = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_%s.npz" % static))
+        st = {k: st[k] for k in st.files}
     lm = None
     if os.environ.get("SB_LM", "dense") == "trie" or "lm" not in st:
         lmsrc = st if "lm" not in st else np.load(os.path.join(ROOT, "tests", "golden", "lm_%s.npz" % {
@@ -53,7 +66,7 @@ def main():
         run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 2
+        reps = int(os.environ.get("SB_REPS", "2"))
         for _ in range(reps):
             run()
         torch.cuda.synchronize()
