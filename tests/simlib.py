@@ -1,0 +1,117 @@
+"""TEST INFRASTRUCTURE: builds and drives tests/hostsim -- the search and language-model kernel SOURCES of
+pocketsphinx_amd/csrc compiled with g++ against a workgroup simulator (one fiber per work-item) -- so that
+the kernels' logic (barrier structure, prefix sums, list orders, table contents) is checked against the
+reference goldens on machines without a GPU.  "Device" buffers are numpy arrays.  Not a product path:
+pocketsphinx_amd never loads this library."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pocketsphinx_amd.lm import NGramTrieLM
+from pocketsphinx_amd.search import _DT, _NAMES, _Tables
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SIM_DIR = os.path.join(HERE, "hostsim")
+CSRC = os.path.join(ROOT, "pocketsphinx_amd", "csrc")
+LIB = os.path.join(SIM_DIR, "_build", "libpsgpu_hostsim.so")
+SOURCES = [os.path.join(SIM_DIR, "hipsim.cc"), os.path.join(CSRC, "psgpu_search.hip"), os.path.join(CSRC, "psgpu_lm.hip")]
+DEPS = SOURCES + [os.path.join(SIM_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "psgpu.h")] + \
+    [os.path.join(CSRC, h) for h in ("psgpu_internal.h", "psgpu_hmm_dev.h", "psgpu_lm_dev.h")]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wall", "-Wno-unused-variable", "-Wno-unknown-pragmas", "-Wno-int-in-bool-context",
+                               "-I" + SIM_DIR, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + SOURCES)
+    L = C.CDLL(LIB)
+    L.psgpu_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().psgpu_last_error().decode()))
+
+
+class SimLm(NGramTrieLM):
+    """NGramTrieLM on the simulator (same table marshalling, the other library)."""
+
+    def __init__(self, g, lw=None, log_wip=None):
+        import pocketsphinx_amd.lm as lm_mod
+        real = lm_mod.capi
+        lm_mod.capi = _SimCapi
+        try:
+            NGramTrieLM.__init__(self, g, lw, log_wip)
+        finally:
+            lm_mod.capi = real
+
+    def close(self):
+        if self.h:
+            lib().psgpu_lm_free(self.h)
+            self.h = C.c_void_p()
+
+    def tg_score(self, queries):
+        q = np.ascontiguousarray(queries, np.int32)
+        w3, w2, w1 = (np.ascontiguousarray(q[:, i]) for i in range(3))
+        n = q.shape[0]
+        sc = np.empty(n, np.int32); nu = np.empty(n, np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        check(lib().psgpu_lm_tg_score_dev(self.h, p(w3), p(w2), p(w1), C.c_int64(n), p(sc), p(nu), None), "psgpu_lm_tg_score_dev")
+        return sc, nu
+
+
+class _SimCapi:
+    lib = staticmethod(lib)
+    check = staticmethod(check)
+
+
+class SimFwdtreeSearch:
+    """pocketsphinx_amd.search.FwdtreeSearch on the simulator."""
+
+    def __init__(self, static, par, lm=None, list_mode=None):
+        src = dict(static); src["par"] = par
+        self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES if not (n == "lm" and lm is not None)}
+        t = _Tables(*[self._keep[n].ctypes.data if n in self._keep else None for n in _NAMES],
+                    int(self._keep["tp"].shape[0]), int(self._keep["sseq"].shape[0]))
+        self.h = C.c_void_p()
+        check(lib().psgpu_fwdtree_create(C.byref(self.h), C.byref(t)), "psgpu_fwdtree_create")
+        self.lm = lm
+        if lm is not None:
+            check(lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
+        if list_mode is not None:
+            check(lib().psgpu_fwdtree_set_mode(self.h, int(list_mode)), "psgpu_fwdtree_set_mode")
+        self.n_sen = int(par[2]); self.n_ci = int(par[0])
+
+    def close(self):
+        if self.h:
+            lib().psgpu_fwdtree_free(self.h)
+            self.h = C.c_void_p()
+
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0):
+        off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
+        n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
+        d_s = np.ascontiguousarray(senscr, np.int16); d_p = np.ascontiguousarray(penalties, np.int32)
+        assert d_s.shape == (int(off[-1]), self.n_sen) and d_p.shape == (int(off[-1]), self.n_ci)
+        bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
+        idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        check(lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
+                                             p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window), None),
+              "psgpu_fwdtree_search_dev")
+        out = []
+        for u in range(n):
+            nb, nh, nfr, status = [int(v) for v in res[u, :4]]
+            out.append(dict(bp=bp[u, :, :nb].T.copy(), bscore_stack=bss[u, :nh].copy(), bp_table_idx=idx[u, :nfr + 1].copy(),
+                            step=step[u, :nfr].copy(), n_frame=nfr, status=status))
+        return out

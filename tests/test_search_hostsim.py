@@ -1,0 +1,70 @@
+"""CPU check of the lexicon-tree search KERNEL SOURCE (pocketsphinx_amd/csrc/psgpu_search.hip + the device
+trie of psgpu_lm_dev.h) without a GPU: the unmodified sources are compiled with g++ against the workgroup
+simulator of tests/hostsim (one fiber per work-item, cooperative switches at barriers and cross-lane
+operations) and must reproduce the reference's back-pointer tables on the same goldens as the GPU parity
+tests (tests/test_search_gpu.py, tests/test_lm_gpu.py).  The order in which the work-items of a workgroup
+run between barriers is varied: a result that depends on it is a missing barrier.  This checks logic only --
+the GPU tests remain the parity tests proper."""
+import os
+
+import numpy as np
+import pytest
+
+import simlib
+from test_oracle_golden import _load
+from test_oracle_lm import CASES as LM_CASES, load as lm_load
+from test_oracle_search import CASES, MEDIUM_CASES, big_trace  # noqa: F401
+from test_search_gpu import _check, _inputs
+
+
+class _order:
+    def __init__(self, order):
+        self.order = order
+
+    def __enter__(self):
+        self.old = os.environ.get("PSGPU_SIM_ORDER")
+        os.environ["PSGPU_SIM_ORDER"] = self.order
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["PSGPU_SIM_ORDER"]
+        else:
+            os.environ["PSGPU_SIM_ORDER"] = self.old
+
+
+def _run(case, order, trie=False, **kw):
+    g = _load("fwdtree_trace_%s.npz" % case)
+    static = bytes(g["static"]).decode()
+    st = _load("fwdtree_static_%s.npz" % static)
+    lm = None
+    if "lm" not in st:
+        lm = simlib.SimLm(st)
+    elif trie:
+        lm = simlib.SimLm(lm_load({"en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
+    with _order(order):
+        s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm, **kw)
+        rows, pen = _inputs(g, s.n_sen)
+        _check(s.search(rows, pen, [rows.shape[0]])[0], g, "%s (%s)" % (case, order))
+        s.close()
+
+
+@pytest.mark.parametrize("order", ["fwd", "rev", "shuffle:7"])
+@pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
+def test_search_kernel_source_on_the_simulator(case, order):
+    _run(case, order)
+
+
+@pytest.mark.parametrize("case", ["goforward", "man_ah_2934za"])
+def test_search_kernel_source_with_the_trie_lm(case):
+    _run(case, "rev", trie=True)
+
+
+@pytest.mark.parametrize("name", LM_CASES)
+def test_simulated_device_trie_equals_reference_look_ups(name):
+    """psgpu_lm_dev.h through the simulator against the reference's recorded look-ups"""
+    g = lm_load(name)
+    lm = simlib.SimLm(g)
+    q = g["queries"][:20000]
+    sc, nu = lm.tg_score(q)
+    assert np.array_equal(sc, g["scores"][:q.shape[0]]) and np.array_equal(nu, g["n_used"][:q.shape[0]])
+    lm.close()
