@@ -578,6 +578,16 @@ int psgpu_lm_tg_score_dev(const psgpu_lm_t *lm, const int32_t *w3_dev, const int
 /* Makes the tree search look its language scores up in `lm` (which must outlive it) instead of
  * the dense table of psgpu_fwdtree_tables_t.lm (which may then be NULL at create). */
 int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
+/* How the per-frame passes of the tree search are formulated; the tables produced are the same, bit for bit.
+ *   PER_NODE     (default) prune_root_chan / prune_nonroot_chan (ngram_search_fwdtree.c:722-877) decided for every
+ *                node of the tree: work per frame ~ tree size.  The form verified on the MI355X.
+ *   ACTIVE_LIST  the same decisions made only for the roots, the nodes on the active list and their children
+ *                (work per frame ~ active channels), word-level positions (next active words, back-pointer and
+ *                score-stack slots, prune_word_chan :1038-1128) by workgroup prefix sums; trees beyond the LDS
+ *                scratch run with 1024 work-items per utterance.  The form for large vocabularies. */
+#define PSGPU_FWDTREE_PER_NODE 0
+#define PSGPU_FWDTREE_ACTIVE_LIST 1
+int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode);
 
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).

@@ -21,13 +21,21 @@
 // reference's sequential walk: decisions on a snapshot, prefix sums for list positions);
 // the word-level bookkeeping (tens of items per frame) is still one thread.  Results are
 // the reference's, bit for bit (tests/test_search_gpu.py against reference dumps).
+//
+// Two formulations of the per-frame passes (psgpu_fwdtree_set_mode):
+//   PER_NODE    (default) the pruning decides every node of the tree (work ~ tree size), 256 work-items;
+//   ACTIVE_LIST the pruning visits only the roots, the listed nodes and their children (work ~ active
+//               channels, oracle prune_tree_list), the word-level positions come from workgroup prefix sums
+//               instead of single-thread loops, and a large tree gets a 1024-work-item workgroup: the form
+//               for large vocabularies.  Same tables, bit for bit.
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
 #include <algorithm>
 #include <cstring>
 #include <vector>
 
-constexpr int kFtThreads = 256;
+constexpr int kFtThreads = 256;        // work-items per utterance (PER_NODE, and ACTIVE_LIST on small trees)
+constexpr int kFtThreadsBig = 1024;    // ACTIVE_LIST on trees beyond the LDS scratch
 constexpr int kFtMaxN = 4096;          // tree nodes (LDS scratch of the pruning)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
@@ -44,6 +52,7 @@ struct FtDev {
     const uint16_t *sseq;
     int32_t big;                         // tree or vocabulary beyond the LDS scratch: list / word scratch in the utterance's slab
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
+    int32_t list_mode;                   // PSGPU_FWDTREE_ACTIVE_LIST: per-frame work proportional to the active channels
     LmDev trie;
 };
 
@@ -68,6 +77,7 @@ struct FtUtt {
     int32_t *result;                     // [8] bpidx, bss_head, n_frame, status
     int32_t *g_cnt, *g_w;                // [max(R + N, n_w) + 1], [4][n_w]: scratch for large trees / vocabularies (FtDev.big)
     int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
+    int32_t *cand_mark;                  // [n_w] frame in which the word was last a last-phone candidate (ACTIVE_LIST)
     int32_t bp_cap, bss_cap;
 };
 
@@ -198,11 +208,12 @@ __device__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bs
 }
 
 // Exclusive prefix sum of a[0..n) in place by the whole workgroup (a in LDS, written before a barrier);
-// returns the total to every thread.  tmp: kFtThreads / 64 words of LDS.  Ends with a barrier.
+// returns the total to every thread.  tmp: NT / 64 words of LDS.  Ends with a barrier.
+template <int NT>
 __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int per = (n + kFtThreads - 1) / kFtThreads;
+    const int per = (n + NT - 1) / NT;
     const int b = min(n, tid * per), e = min(n, b + per);
     int32_t sum = 0;
     for (int i = b; i < e; ++i) sum += a[i];
@@ -213,7 +224,7 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
     __syncthreads();
     int32_t base = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < kFtThreads / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
+    for (int w = 0; w < NT / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
     int32_t run = base + incl - sum;
     for (int i = b; i < e; ++i) { const int32_t k = a[i]; a[i] = run; run += k; }
     __syncthreads();
@@ -235,8 +246,8 @@ __device__ __forceinline__ int32_t ft_block_excl_max(int32_t v, int32_t *tmp)
     return excl;
 }
 
-template <int NE>
-__global__ __launch_bounds__(kFtThreads)
+template <int NE, int NT, bool LIST>
+__global__ __launch_bounds__(NT)
 void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
                     const int32_t *__restrict__ penalties, const int32_t *__restrict__ utt_off, int32_t raw_mode,
                     int32_t pl_window)
@@ -246,7 +257,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     __shared__ int32_t s_nb;
     __shared__ int32_t s_cnt[kFtMaxN + 1];
     __shared__ int32_t s_red[8];
-    __shared__ int32_t s_scan[kFtThreads / 64];
+    __shared__ int32_t s_scan[NT / 64];
     __shared__ int32_t s_bins[256];
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
@@ -259,10 +270,14 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     int n_acl[2] = {0, 0}, n_awl[2] = {0, 0};           // uniform copies (every thread tracks them identically)
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
-    for (int c = tid; c < N; c += kFtThreads) ch_init(p, u, c, c < R, p.node_ssid[c], p.node_tmat[c]);
-    for (int i = tid; i < p.n1; i += kFtThreads) ch_init(p, u, W1 + i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i]);
-    for (int i = tid; i < p.TOT; i += kFtThreads) u.present[i] = 0;
-    for (int w = tid; w < p.n_w; w += kFtThreads) { u.word_lat_idx[w] = -1; u.lt_sf[w] = -1; u.word_active[w] = 0; }
+    for (int c = tid; c < N; c += NT) ch_init(p, u, c, c < R, p.node_ssid[c], p.node_tmat[c]);
+    for (int i = tid; i < p.n1; i += NT) ch_init(p, u, W1 + i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i]);
+    for (int i = tid; i < p.TOT; i += NT) u.present[i] = 0;
+    for (int w = tid; w < p.n_w; w += NT) { u.word_lat_idx[w] = -1; u.lt_sf[w] = -1; u.word_active[w] = 0; }
+    if (LIST) {                                  // pos is kept at -1 between frames; no word has been a candidate yet
+        for (int c = tid; c < N; c += NT) u.pos[c] = -1;
+        for (int w = tid; w < p.n_w; w += NT) u.cand_mark[w] = -1;
+    }
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
         s_evals = 0ull;
@@ -281,7 +296,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             //      active-list normalisation (ptm_mgau.c:393-400) on un-normalised rows: the frame's scores
             //      are raw - min over the listed senones, bridging entries included
             const int nwords = (p.n_sen + 31) >> 5;
-            for (int i = tid; i < nwords; i += kFtThreads) s_bits[i] = 0u;
+            for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
             if (tid == 0) s_nb = 0x7fffffff;
             __syncthreads();
             auto mark = [&](int c) {
@@ -291,23 +306,23 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
                 }
             };
-            for (int i = tid; i < R; i += kFtThreads) if (u.frame[i] == f) mark(i);
-            for (int i = tid; i < n_acl[cur]; i += kFtThreads) mark(u.acl[cur][i]);
-            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+            for (int i = tid; i < R; i += NT) if (u.frame[i] == f) mark(i);
+            for (int i = tid; i < n_acl[cur]; i += NT) mark(u.acl[cur][i]);
+            for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) mark(WC + k);
             }
-            for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) mark(W1 + i);
+            for (int i = tid; i < p.n1; i += NT) if (u.frame[W1 + i] == f) mark(W1 + i);
             __syncthreads();
             {   // s_prev[w] = the highest senone listed in the words before w (one bitmap word per thread)
-                static_assert(kFtMaxSen / 32 <= kFtThreads, "one bitmap word per thread");
+                static_assert(kFtMaxSen / 32 <= NT, "one bitmap word per thread");
                 const uint32_t bw = tid < nwords ? s_bits[tid] : 0u;
                 const int32_t pv = ft_block_excl_max(bw ? tid * 32 + 31 - __clz((int)bw) : -1, s_scan);
                 if (tid < nwords) s_prev[tid] = pv;
             }
             __syncthreads();
             int32_t mn = 0x7fffffff;
-            for (int w = tid; w < nwords; w += kFtThreads) {
+            for (int w = tid; w < nwords; w += NT) {
                 uint32_t b = s_bits[w];
                 int prev = s_prev[w];
                 while (b) {
@@ -321,7 +336,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             atomicMin(&s_nb, mn);
             __syncthreads();
             const int32_t nb = s_nb;
-            for (int w = tid; w < nwords; w += kFtThreads) {
+            for (int w = tid; w < nwords; w += NT) {
                 uint32_t b = s_bits[w];
                 while (b) {
                     const int sen = w * 32 + __ffs((int)b) - 1;
@@ -337,29 +352,29 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
-            for (int i = tid; i < R; i += kFtThreads) if (u.frame[i] == f) ch_normalize(p, u, i, best_in);
-            for (int i = tid; i < n_acl[cur]; i += kFtThreads) ch_normalize(p, u, u.acl[cur][i], best_in);
-            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+            for (int i = tid; i < R; i += NT) if (u.frame[i] == f) ch_normalize(p, u, i, best_in);
+            for (int i = tid; i < n_acl[cur]; i += NT) ch_normalize(p, u, u.acl[cur][i], best_in);
+            for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) ch_normalize(p, u, WC + k, best_in);
             }
-            for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) ch_normalize(p, u, W1 + i, best_in);
+            for (int i = tid; i < p.n1; i += NT) if (u.frame[W1 + i] == f) ch_normalize(p, u, W1 + i, best_in);
         }
         if (tid < 8) s_red[tid] = kW;
         __syncthreads();
         // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..5] counts
         {
             int32_t b0 = kW, b1 = kW, b2 = kW; int n0 = 0, n2 = 0;
-            for (int i = tid; i < R; i += kFtThreads)
+            for (int i = tid; i < R; i += NT)
                 if (u.frame[i] == f) { b0 = max(b0, ch_eval<NE>(p, u, i, row)); ++n0; }
-            for (int i = tid; i < n_acl[cur]; i += kFtThreads) b1 = max(b1, ch_eval<NE>(p, u, u.acl[cur][i], row));
-            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+            for (int i = tid; i < n_acl[cur]; i += NT) b1 = max(b1, ch_eval<NE>(p, u, u.acl[cur][i], row));
+            for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 u.word_active[w] = 0;
                 for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
                     if (u.present[k]) { b2 = max(b2, ch_eval<NE>(p, u, WC + k, row)); ++n2; }
             }
-            for (int i = tid; i < p.n1; i += kFtThreads) {
+            for (int i = tid; i < p.n1; i += NT) {
                 if (u.frame[W1 + i] < f) continue;
                 const int32_t sc = ch_eval<NE>(p, u, W1 + i, row);
                 if (p.w1_wid[i] != p.finishwid) b2 = max(b2, sc);
@@ -378,12 +393,12 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             // dynamic beam (:1133-1181)
             s_sc[2] = p.beam;
         }
-        for (int i = tid; i < 256; i += kFtThreads) s_bins[i] = 0;
+        for (int i = tid; i < 256; i += NT) s_bins[i] = 0;
         __syncthreads();
         const int32_t best_score = s_sc[0];
         if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
             const int32_t bw = -p.beam / 256;
-            for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+            for (int i = tid; i < R + n_acl[cur]; i += NT) {
                 const int c = i < R ? i : u.acl[cur][i - R];
                 int32_t b = (best_score - u.best[c]) / bw;
                 if (b >= 256) b = 255;
@@ -401,53 +416,96 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         const int32_t npt = best_score + p.pbeam, lpt = best_score + p.lpbeam;
 
         // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation
-        for (int i = tid; i < N; i += kFtThreads) {
-            u.pos[i] = -1; u.o_frame[i] = u.frame[i]; u.o_s0[i] = u.score[i * 5]; u.o_best[i] = u.best[i];
-            u.o_out[i] = u.out[i]; u.o_outh[i] = u.outh[i];
+        if (LIST) {
+            // work proportional to the active channels (oracle prune_tree_list): the items are the roots, the listed
+            // nodes and their children.  Reads of another node's state go to the snapshot (o_out, o_outh, flag, pos) of
+            // a root or listed node, writes to the item's own channel and decision word, so the items are independent.
+            const int na = n_acl[cur];
+            for (int q = tid; q < na; q += NT) u.pos[u.acl[cur][q]] = q;
+            for (int i = tid; i < R + na; i += NT) {
+                const int node = i < R ? i : u.acl[cur][i - R];
+                const bool active = i < R ? u.frame[node] >= f : true;
+                u.o_out[node] = u.out[node]; u.o_outh[node] = u.outh[node];
+                u.flag[node] = (active && u.best[node] > thresh) ? 1 : 0;
+            }
+            __syncthreads();
+            auto decide = [&](int c) {
+                const int P = p.parent[c], pc = u.pos[c];
+                const bool in_acl = pc >= 0, par_active = P < R || u.pos[P] >= 0;
+                const int32_t news = (par_active ? u.o_out[P] : kW) + p.pip;
+                const bool parent_can = par_active && (u.flag[P] & 1) && (p.has_pl || news > npt)
+                                        && (news + ft_pen(p, pp, p.node_ci[c]) > npt);
+                const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
+                const bool retc = in_acl && (u.flag[c] & 1);
+                bool fire;
+                if (!in_acl || parent_first) fire = parent_can && (u.frame[c] < f || news > u.score[c * 5]);
+                else if (retc)               fire = parent_can && news > u.score[c * 5];
+                else                         fire = parent_can;
+                const bool entered_first = fire && parent_first;
+                const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
+                if (in_acl && !retc && !entered_first) ch_clear(p, u, c);
+                if (retc) u.frame[c] = nf;
+                if (fire) ch_enter(u, c, news, u.o_outh[P], nf);
+                u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
+            };
+            for (int i = tid; i < R + na; i += NT) {
+                const int node = i < R ? i : u.acl[cur][i - R];
+                if (i >= R) decide(node);
+                for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.pos[c] < 0) decide(c);
+            }
+            __syncthreads();
+            for (int q = tid; q < na; q += NT) u.pos[u.acl[cur][q]] = -1;        // (nothing below reads pos or a root's frame
+            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[i] = nf;  //  before the next barrier)
         }
-        __syncthreads();
-        for (int q = tid; q < n_acl[cur]; q += kFtThreads) u.pos[u.acl[cur][q]] = q;
-        __syncthreads();
-        // flag bits: 1 retained, 2 fire (listed by parent), 4 fire (not listed), 8 self-append
-        for (int c = tid; c < N; c += kFtThreads) {
-            const bool active = c < R ? u.o_frame[c] >= f : u.pos[c] >= 0;
-            u.flag[c] = (active && u.o_best[c] > thresh) ? 1 : 0;
+        else {
+            for (int i = tid; i < N; i += NT) {
+                u.pos[i] = -1; u.o_frame[i] = u.frame[i]; u.o_s0[i] = u.score[i * 5]; u.o_best[i] = u.best[i];
+                u.o_out[i] = u.out[i]; u.o_outh[i] = u.outh[i];
+            }
+            __syncthreads();
+            for (int q = tid; q < n_acl[cur]; q += NT) u.pos[u.acl[cur][q]] = q;
+            __syncthreads();
+            // flag bits: 1 retained, 2 fire (listed by parent), 4 fire (not listed), 8 self-append
+            for (int c = tid; c < N; c += NT) {
+                const bool active = c < R ? u.o_frame[c] >= f : u.pos[c] >= 0;
+                u.flag[c] = (active && u.o_best[c] > thresh) ? 1 : 0;
+            }
+            __syncthreads();
+            for (int c = R + tid; c < N; c += NT) {
+                const int P = p.parent[c], pc = u.pos[c];
+                const bool in_acl = pc >= 0, retc = u.flag[c] & 1;
+                const int32_t news = u.o_out[P] + p.pip;
+                const bool par_active = P < R ? true : u.pos[P] >= 0;
+                const bool parent_can = par_active && (u.flag[P] & 1) && (p.has_pl || news > npt)
+                                        && (news + ft_pen(p, pp, p.node_ci[c]) > npt);
+                const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
+                bool fire;
+                if (!in_acl || parent_first) fire = parent_can && (u.o_frame[c] < f || news > u.o_s0[c]);
+                else if (retc)               fire = parent_can && news > u.o_s0[c];
+                else                         fire = parent_can;
+                const bool entered_first = fire && parent_first;
+                const bool selfapp = in_acl && retc && !entered_first;
+                const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
+                const bool cleared = in_acl && !retc && !entered_first;
+                if (cleared) ch_clear(p, u, c);
+                if (in_acl && retc) u.frame[c] = nf;
+                if (fire) ch_enter(u, c, news, u.o_outh[P], nf);
+                // decision word for the list phase; o_frame[c] is read by this thread only, so it can be reused
+                u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | (selfapp ? 8 : 0);
+            }
+            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[i] = nf;
+            __syncthreads();
         }
-        __syncthreads();
-        for (int c = R + tid; c < N; c += kFtThreads) {
-            const int P = p.parent[c], pc = u.pos[c];
-            const bool in_acl = pc >= 0, retc = u.flag[c] & 1;
-            const int32_t news = u.o_out[P] + p.pip;
-            const bool par_active = P < R ? true : u.pos[P] >= 0;
-            const bool parent_can = par_active && (u.flag[P] & 1) && (p.has_pl || news > npt)
-                                    && (news + ft_pen(p, pp, p.node_ci[c]) > npt);
-            const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
-            bool fire;
-            if (!in_acl || parent_first) fire = parent_can && (u.o_frame[c] < f || news > u.o_s0[c]);
-            else if (retc)               fire = parent_can && news > u.o_s0[c];
-            else                         fire = parent_can;
-            const bool entered_first = fire && parent_first;
-            const bool selfapp = in_acl && retc && !entered_first;
-            const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
-            const bool cleared = in_acl && !retc && !entered_first;
-            if (cleared) ch_clear(p, u, c);
-            if (in_acl && retc) u.frame[c] = nf;
-            if (fire) ch_enter(u, c, news, u.o_outh[P], nf);
-            // decision word for the list phase; o_frame[c] is read by this thread only, so it can be reused
-            u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | (selfapp ? 8 : 0);
-        }
-        for (int i = tid; i < R; i += kFtThreads) if (u.flag[i] & 1) u.frame[i] = nf;
-        __syncthreads();
         // list positions: root phase (segment per root), then one segment per list position
-        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+        for (int i = tid; i < R + n_acl[cur]; i += NT) {
             const int node = i < R ? i : u.acl[cur][i - R];
             int k = (i >= R && (u.o_frame[node] & 8)) ? 1 : 0;
             for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) k += (u.o_frame[c] & 2) ? 1 : 0;
             cnt[i] = k;
         }
         __syncthreads();
-        const int32_t n_listed = ft_block_scan(cnt, R + n_acl[cur], s_scan);      // exclusive prefix sum
-        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+        const int32_t n_listed = ft_block_scan<NT>(cnt, R + n_acl[cur], s_scan);      // exclusive prefix sum
+        for (int i = tid; i < R + n_acl[cur]; i += NT) {
             const int node = i < R ? i : u.acl[cur][i - R];
             int o = cnt[i];
             if (i >= R && (u.o_frame[node] & 8)) u.acl[nxt][o++] = node;
@@ -456,7 +514,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         n_acl[nxt] = n_listed;
         __syncthreads();
         // last-phone candidates: list order, homophone chain inside
-        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+        for (int i = tid; i < R + n_acl[cur]; i += NT) {
             const int node = i < R ? i : u.acl[cur][i - R];
             const int32_t news = u.o_out[node] + p.pip;
             int k = 0;
@@ -466,11 +524,11 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         }
         __syncthreads();
         {
-            const int32_t n_cand_all = ft_block_scan(cnt, R + n_acl[cur], s_scan);
+            const int32_t n_cand_all = ft_block_scan<NT>(cnt, R + n_acl[cur], s_scan);
             if (tid == 0) s_sc[5] = n_cand_all;
         }
         __syncthreads();
-        for (int i = tid; i < R + n_acl[cur]; i += kFtThreads) {
+        for (int i = tid; i < R + n_acl[cur]; i += NT) {
             const int node = i < R ? i : u.acl[cur][i - R];
             const int32_t news = u.o_out[node] + p.pip;
             int o = cnt[i];
@@ -492,7 +550,12 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int n_cand = s_sc[5];
             if (tid == 0) s_red[7] = 0;
             __syncthreads();
-            for (int i = tid; i < n_cand; i += kFtThreads) {
+            if (LIST) {                                  // O(1) per candidate: the frame stamp of the word
+                for (int i = tid; i < n_cand; i += NT)
+                    if (atomicExch(&u.cand_mark[u.cand_wid[i]], f) == f) s_red[7] = 1;
+            }
+            else
+            for (int i = tid; i < n_cand; i += NT) {
                 const int w = u.cand_wid[i];
                 for (int j = 0; j < i; ++j) if (u.cand_wid[j] == w) s_red[7] = 1;
             }
@@ -501,7 +564,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         if (s_red[7] == 0) {
             const int n_cand = s_sc[5];
             int32_t bestscore = kW;
-            for (int i = tid; i < n_cand; i += kFtThreads) {
+            for (int i = tid; i < n_cand; i += NT) {
                 const int cb = u.cand_bp[i], w = u.cand_wid[i];
                 int32_t score = u.cand_score[i];
                 if (cb != -1) {
@@ -576,7 +639,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int n_cand = s_sc[5];
             const int32_t cthresh = s_sc[1] + p.lponlybeam;
             const bool dup = s_red[7] != 0;                     // (found above)
-            for (int i = (dup ? (tid == 0 ? 0 : n_cand) : tid); i < n_cand; i += (dup ? 1 : kFtThreads)) {
+            for (int i = (dup ? (tid == 0 ? 0 : n_cand) : tid); i < n_cand; i += (dup ? 1 : NT)) {
                 int k = 0;
                 if (u.cand_score[i] > cthresh) {
                     const int w = u.cand_wid[i];
@@ -598,6 +661,16 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 cnt[i] = k > 0;
             }
             __syncthreads();
+            if (LIST) {                                  // stable compaction by a prefix sum
+                const int32_t nawl = ft_block_scan<NT>(cnt, n_cand, s_scan);
+                for (int i = tid; i < n_cand; i += NT)
+                    if ((i + 1 < n_cand ? cnt[i + 1] : nawl) != cnt[i]) {
+                        const int w = u.cand_wid[i];
+                        u.awl[nxt][cnt[i]] = w; u.word_active[w] = 1;
+                    }
+                if (tid == 0) s_red[5] = nawl;
+            }
+            else
             if (tid == 0) {
                 int nawl = 0;
                 for (int i = 0; i < n_cand; ++i)
@@ -610,7 +683,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
             const int wst = p.big ? p.n_w : 1024;                // n_awl <= n_w
             int32_t *w_k = p.big ? u.g_w : cnt, *w_exit = w_k + wst, *w_bp = w_k + 2 * wst, *w_bss = w_k + 3 * wst;
-            for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+            for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 int k = 0, ex = 0;
                 for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
@@ -620,8 +693,32 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     else if (u.frame[c] != nf) u.present[slot] = 0;
                 }
                 w_k[i] = k; w_exit[i] = ex;
+                if (LIST) {                              // inputs of the three prefix sums below
+                    w_k[i] = (k > 0 && !u.word_active[w]) ? 1 : 0;
+                    w_bp[i] = ex ? 1 : 0;
+                    w_bss[i] = ex ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+                }
             }
             __syncthreads();
+            if (LIST) {                                  // positions by workgroup prefix sums
+                const int na = n_awl[cur];
+                const int32_t bpidx = s_sc[3], bss_head = s_sc[4], nawl = s_red[5];    // (rewritten below, after the scans' barriers)
+                const int32_t n_exit = ft_block_scan<NT>(w_bp, na, s_scan);
+                const int32_t n_bss = ft_block_scan<NT>(w_bss, na, s_scan);
+                const int32_t n_app = ft_block_scan<NT>(w_k, na, s_scan);
+                for (int i = tid; i < na; i += NT) {
+                    w_bp[i] += bpidx; w_bss[i] += bss_head;
+                    if ((i + 1 < na ? w_k[i + 1] : n_app) != w_k[i]) {
+                        const int w = u.awl[cur][i];
+                        u.awl[nxt][nawl + w_k[i]] = w; u.word_active[w] = 1;
+                    }
+                }
+                if (tid == 0) {
+                    if (bpidx + n_exit + p.n1 >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap) s_sc[6] = 1;
+                    s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; s_red[5] = nawl + n_app;
+                }
+            }
+            else
             if (tid == 0) {                                     // positions: back-pointers, score stack, next active words
                 int32_t bpidx = s_sc[3], bss_head = s_sc[4];
                 int nawl = s_red[5];
@@ -637,7 +734,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             __syncthreads();
             if (!s_sc[6]) {
                 // pass B: every exiting word writes its own back-pointer (first exit creates, the others update)
-                for (int i = tid; i < n_awl[cur]; i += kFtThreads) {
+                for (int i = tid; i < n_awl[cur]; i += NT) {
                     if (!w_exit[i]) continue;
                     const int w = u.awl[cur][i];
                     int32_t bpi = w_bp[i], bsh = w_bss[i];
@@ -651,11 +748,44 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             }
             __syncthreads();
         }
+        if (LIST && !s_sc[6]) {
+            // single-phone words (:1100-1127), one work-item per word; back-pointer positions in list order by prefix sums
+            const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
+            const int wst = p.big ? p.n_w : 1024;                // n1 <= n_w
+            int32_t *f_ex = p.big ? u.g_w : cnt, *f_new = f_ex + wst, *f_rc = f_ex + 2 * wst;
+            for (int i = tid; i < p.n1; i += NT) {
+                const int c = W1 + i;
+                int ex = 0, nw = 0, rcn = 0;
+                if (u.frame[c] >= f && u.best[c] > lpth) {
+                    u.frame[c] = nf;
+                    if (u.out[c] > nwt) {
+                        const int w = p.w1_wid[i];
+                        ex = 1;
+                        if (u.word_lat_idx[w] == -1) {
+                            nw = 1;
+                            rcn = p.d_pronlen[w] == 1 ? 0 : p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]];
+                        }
+                    }
+                }
+                f_ex[i] = ex; f_new[i] = nw; f_rc[i] = rcn;
+            }
+            __syncthreads();
+            const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
+            const int32_t n_new = ft_block_scan<NT>(f_new, p.n1, s_scan);
+            const int32_t n_rc = ft_block_scan<NT>(f_rc, p.n1, s_scan);
+            for (int i = tid; i < p.n1; i += NT)
+                if (f_ex[i]) {
+                    int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
+                    if (!ft_save_bp(p, u, bpi, bsh, f, p.w1_wid[i], u.out[W1 + i], u.outh[W1 + i], 0)) s_sc[6] = 1;
+                }
+            __syncthreads();
+            if (tid == 0) { s_sc[3] = bpidx0 + n_new; s_sc[4] = bss0 + n_rc; }
+        }
         if (tid == 0 && !s_sc[6]) {
             int32_t bpidx = s_sc[3], bss_head = s_sc[4];
             bool ok = true;
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            for (int i = 0; i < p.n1 && ok; ++i) {
+            for (int i = 0; i < p.n1 && ok && !LIST; ++i) {
                 const int c = W1 + i;
                 if (u.frame[c] < f) continue;
                 if (u.best[c] > lpth) {
@@ -693,11 +823,11 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         int32_t *brc_score = s_bins, *brc_path = s_bins + kFtMaxCi, *brc_lc = s_bins + 2 * kFtMaxCi;
         if (tid == 0) s_red[6] = 0;
         __syncthreads();
-        for (int bp = bp0 + tid; bp < bp1; bp += kFtThreads) {
+        for (int bp = bp0 + tid; bp < bp1; bp += NT) {
             u.word_lat_idx[BPC(u, B_WID, bp)] = -1;
             if (BPC(u, B_WID, bp) != p.finishwid) atomicAdd(&s_red[6], 1);
         }
-        for (int rc = tid; rc < p.n_ci; rc += kFtThreads) {     // best exit per right-context phone, earliest bp on ties
+        for (int rc = tid; rc < p.n_ci; rc += NT) {     // best exit per right-context phone, earliest bp on ties
             int32_t bs = kW; int path = 0, lc = 0;
             for (int bp = bp0; bp < bp1; ++bp) {
                 if (BPC(u, B_WID, bp) == p.finishwid) continue;
@@ -710,7 +840,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         }
         __syncthreads();
         if (s_red[6] > 0) {
-            for (int i = tid; i < R; i += kFtThreads) {          // tree roots (:1306-1325)
+            for (int i = tid; i < R; i += NT) {          // tree roots (:1306-1325)
                 const int ci = p.node_ci[i];
                 const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
                 if (ns + ft_pen(p, pp, ci) > thresh && (u.frame[i] < f || ns > u.score[i * 5])) {
@@ -718,7 +848,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     u.senid[i * 5] = p.ldiph[((size_t)ci * p.n_ci + p.node_ci2[i]) * p.n_ci + brc_lc[ci]];
                 }
             }
-            for (int i = tid; i < p.n1lm; i += kFtThreads) {     // in-LM single-phone words (:1331-1388)
+            for (int i = tid; i < p.n1lm; i += NT) {     // in-LM single-phone words (:1331-1388)
                 const int w = p.w1_wid[i];
                 int32_t ds = kMaxNegInt32; int dbp = 0;
                 for (int bp = bp0; bp < bp1; ++bp) {
@@ -736,7 +866,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     u.senid[c * 5] = p.ldiph[((size_t)p.w1_ci[i] * p.n_ci + p.w1_ci2[i]) * p.n_ci + p.d_last[BPC(u, B_WID, dbp)]];
                 }
             }
-            for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += kFtThreads) {    // <sil> and noise words (:1390-1426)
+            for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += NT) {    // <sil> and noise words (:1390-1426)
                 // slot filler_start - 1 stands for <sil>, which is handled whatever its place in the dictionary
                 const bool is_sil = w == p.filler_start - 1;
                 if (!is_sil && (w == p.startwid || w == p.silwid)) continue;
@@ -750,8 +880,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         }
         __syncthreads();
         // ---- deactivate_channels (:1429-1450)
-        for (int i = tid; i < R; i += kFtThreads) if (u.frame[i] == f) ch_clear(p, u, i);
-        for (int i = tid; i < p.n1; i += kFtThreads) if (u.frame[W1 + i] == f) ch_clear(p, u, W1 + i);
+        for (int i = tid; i < R; i += NT) if (u.frame[i] == f) ch_clear(p, u, i);
+        for (int i = tid; i < p.n1; i += NT) if (u.frame[W1 + i] == f) ch_clear(p, u, W1 + i);
         if (tid == 0) {
             u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = s_sc[1]; u.step[f * 4 + 2] = s_sc[3]; u.step[f * 4 + 3] = n_acl[nxt];
             ++s_sc[7];
@@ -854,6 +984,13 @@ int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm)
     return PSGPU_OK;
 }
 
+int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode)
+{
+    PSGPU_REQUIRE(m && (mode == PSGPU_FWDTREE_PER_NODE || mode == PSGPU_FWDTREE_ACTIVE_LIST), "psgpu_fwdtree_set_mode: bad argument");
+    m->d.list_mode = mode;
+    return PSGPU_OK;
+}
+
 void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
 {
     if (!m) return;
@@ -885,7 +1022,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     const size_t C = m->C;
     const size_t per = C * (5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
                      + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
-                     + ((size_t)d.n_sen + 1) / 2 + 1
+                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w
                      + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
     int32_t *slab = nullptr;
     FtUtt *d_utts = nullptr;
@@ -905,6 +1042,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.o_frame = take(d.N); u.o_s0 = take(d.N); u.o_best = take(d.N); u.o_out = take(d.N); u.o_outh = take(d.N);
         u.pos = take(d.N); u.flag = take(d.N);
         u.nrow = reinterpret_cast<int16_t *>(take(((size_t)d.n_sen + 1) / 2 + 1));
+        u.cand_mark = take(d.n_w);
         u.g_cnt = d.big ? take((size_t)std::max(d.N + d.R, d.n_w) + 1) : nullptr;
         u.g_w = d.big ? take(4 * (size_t)d.n_w) : nullptr;
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
@@ -916,12 +1054,22 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FtUtt) * n_utt, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // hu is about to go out of scope
     if (e != hipSuccess) { hipFree(slab); hipFree(d_utts); PSGPU_HIP(e); }
-    if (d.n_emit == 3)
-        hipLaunchKernelGGL((fwdtree_kernel<3>), dim3(n_utt), dim3(kFtThreads), 0, st, d, d_utts, senscr_dev, scr_stride,
-                           penalties_dev, utt_off_dev, raw_scores, pl_window);
-    else
-        hipLaunchKernelGGL((fwdtree_kernel<5>), dim3(n_utt), dim3(kFtThreads), 0, st, d, d_utts, senscr_dev, scr_stride,
-                           penalties_dev, utt_off_dev, raw_scores, pl_window);
+    // ACTIVE_LIST on a tree beyond the LDS scratch: ~10^4 active channels per frame, 16 waves per utterance
+    const int nt = (d.list_mode && d.big) ? kFtThreadsBig : kFtThreads;
+#define FT_LAUNCH(NE, NT, LIST)                                                                                          \
+    hipLaunchKernelGGL((fwdtree_kernel<NE, NT, LIST>), dim3(n_utt), dim3(NT), 0, st, d, d_utts, senscr_dev, scr_stride, \
+                       penalties_dev, utt_off_dev, raw_scores, pl_window)
+    if (d.n_emit == 3) {
+        if (!d.list_mode) FT_LAUNCH(3, kFtThreads, false);
+        else if (nt == kFtThreads) FT_LAUNCH(3, kFtThreads, true);
+        else FT_LAUNCH(3, kFtThreadsBig, true);
+    }
+    else {
+        if (!d.list_mode) FT_LAUNCH(5, kFtThreads, false);
+        else if (nt == kFtThreads) FT_LAUNCH(5, kFtThreads, true);
+        else FT_LAUNCH(5, kFtThreadsBig, true);
+    }
+#undef FT_LAUNCH
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
     hipFree(slab); hipFree(d_utts);

@@ -23,9 +23,12 @@ class FwdtreeSearch:
 
     BP_COLS = ("frame", "valid", "wid", "bp", "score", "s_idx", "real_wid", "prev_real_wid", "last_phone", "last2_phone")
 
-    def __init__(self, static, par, lm=None):
+    PER_NODE, ACTIVE_LIST = 0, 1          # psgpu_fwdtree_set_mode (include/psgpu.h)
+
+    def __init__(self, static, par, lm=None, mode=None):
         """lm: an NGramTrieLM over the same dictionary -- language scores are then looked up in the trie on
-        the device and the dense table static["lm"] is not needed (any vocabulary the tree fits)."""
+        the device and the dense table static["lm"] is not needed (any vocabulary the tree fits).
+        mode: PER_NODE (default) or ACTIVE_LIST (per-frame work proportional to the active channels)."""
         src = dict(static); src["par"] = par
         self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES if not (n == "lm" and lm is not None)}
         t = _Tables(*[self._keep[n].ctypes.data if n in self._keep else None for n in _NAMES],
@@ -35,6 +38,8 @@ class FwdtreeSearch:
         self.lm = lm
         if lm is not None:
             capi.check(capi.lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
+        if mode is not None:
+            capi.check(capi.lib().psgpu_fwdtree_set_mode(self.h, int(mode)), "psgpu_fwdtree_set_mode")
         self.n_sen = int(par[2]); self.n_ci = int(par[0])
 
     def close(self):

@@ -2,24 +2,52 @@
 // of this directory, plus the three symbols the kernel sources expect from psgpu_core.hip.
 //
 // A launch runs its workgroups one after the other.  Inside a workgroup every work-item is a fiber
-// (ucontext); a fiber runs until it waits -- at __syncthreads() or inside a cross-lane operation --
+// (own stack, hand-written switch); a fiber runs until it waits -- at __syncthreads() or inside a cross-lane operation --
 // and then hands over to the next fiber of the workgroup in the chosen order.  Waiting is a
 // generation counter per barrier object (one for the workgroup, one per wavefront), so a fiber that
 // is resumed early simply hands over again; if a whole round goes by without progress the kernel
 // has divergent barriers and the run aborts with a message.
 #include <hip/hip_runtime.h>
 #include <cstdarg>
-#include <ucontext.h>
 #include <vector>
 
 #include "psgpu.h"
+
+// The fiber switch: callee-saved registers and the stack pointer (System V x86-64).  ucontext's swapcontext
+// would do, but it makes two signal-mask system calls per switch and a search of one utterance is ~10^7 switches.
+#if !defined(__x86_64__)
+#error "tests/hostsim needs x86-64 (the fiber switch below)"
+#endif
+extern "C" void hipsim_switch(void **save_sp, void *load_sp);
+asm(R"(
+    .text
+    .globl hipsim_switch
+    .type hipsim_switch,@function
+hipsim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipsim_switch, .-hipsim_switch
+)");
 
 namespace hipsim {
 
 struct Barrier { int count = 0, size = 0; unsigned gen = 0; };
 
 struct Fiber {
-    ucontext_t ctx;
+    void *sp = nullptr;
     char *stack = nullptr;
     int tid = 0, done = 0;
 };
@@ -37,7 +65,7 @@ struct Block {
     std::vector<int> where;          // tid -> position
     Barrier bar;
     int n = 0, n_done = 0, idle = 0;
-    ucontext_t main_ctx;
+    void *main_sp = nullptr;
     const std::function<void()> *body = nullptr;
     dim3 bdim;
 };
@@ -63,11 +91,11 @@ static void switch_to_next()
         if (f == me) return;
         cur = f;
         set_ids(b, f->tid);
-        swapcontext(&me->ctx, &f->ctx);
+        hipsim_switch(&me->sp, f->sp);
         return;
     }
     // every other fiber has finished
-    if (me->done) { cur = nullptr; swapcontext(&me->ctx, &b->main_ctx); }
+    if (me->done) { cur = nullptr; hipsim_switch(&me->sp, b->main_sp); }
 }
 
 static void wait_on(Barrier &bar)
@@ -156,14 +184,17 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body)
         for (int i = 0; i < n; ++i) {
             Fiber &f = b.fib[i];
             f.tid = i; f.done = 0;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = nullptr;
-            makecontext(&f.ctx, fiber_main, 0);
+            // first switch "returns" into fiber_main with the stack aligned as after a call
+            uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+            void **q = (void **)(top - 64);
+            for (int k = 0; k < 6; ++k) q[k] = nullptr;
+            q[6] = (void *)fiber_main;
+            f.sp = q;
         }
         g_blk = &b;
         cur = &b.fib[b.order[0]];
         set_ids(&b, cur->tid);
-        swapcontext(&b.main_ctx, &cur->ctx);
+        hipsim_switch(&b.main_sp, cur->sp);
         g_blk = nullptr;
     }
     for (int i = 0; i < n; ++i) free(b.fib[i].stack);

@@ -49,14 +49,45 @@ def _run(case, order, trie=False, **kw):
 
 
 @pytest.mark.parametrize("order", ["fwd", "rev", "shuffle:7"])
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
-def test_search_kernel_source_on_the_simulator(case, order):
-    _run(case, order)
+def test_search_kernel_source_on_the_simulator(case, mode, order):
+    """mode 0 = PSGPU_FWDTREE_PER_NODE, 1 = PSGPU_FWDTREE_ACTIVE_LIST (include/psgpu.h)"""
+    _run(case, order, list_mode=mode)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("case", ["goforward", "man_ah_2934za"])
-def test_search_kernel_source_with_the_trie_lm(case):
-    _run(case, "rev", trie=True)
+def test_search_kernel_source_with_the_trie_lm(case, mode):
+    _run(case, "rev", trie=True, list_mode=mode)
+
+
+def test_search_kernel_source_batch_of_utterances():
+    """several workgroups in one launch, ACTIVE_LIST: every utterance equals its own golden"""
+    names = ["goforward", "numbers", "goforward"]
+    gs = [_load("fwdtree_trace_%s.npz" % n) for n in names]
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    s = simlib.SimFwdtreeSearch(st, gs[0]["par"], list_mode=1)
+    ins = [_inputs(g, s.n_sen) for g in gs]
+    out = s.search(np.concatenate([i[0] for i in ins]), np.concatenate([i[1] for i in ins]), [i[0].shape[0] for i in ins])
+    for r, g, n in zip(out, gs, names):
+        _check(r, g, n)
+    s.close()
+
+
+@pytest.mark.parametrize("order", ["fwd", "rev"])
+def test_search_kernel_source_full_cmudict_vocabulary_active_list(big_trace, order):  # noqa: F811
+    """The large-vocabulary form of the kernel (ACTIVE_LIST, 1024 work-items, list / word scratch in the
+    utterance's slab) on the full cmudict task: 134,865 words, 248 k tree channels, ~8 k (up to 33 k) active
+    channels per frame, language scores from the simulated device trie.  Tables identical to the reference's."""
+    g = big_trace
+    lm = simlib.SimLm(g)
+    with _order(order):
+        s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm, list_mode=1)
+        rows, pen = _inputs(g, s.n_sen)
+        _check(s.search(rows, pen, [rows.shape[0]])[0], g, "cmudict (%s)" % order)
+        s.close()
+    lm.close()
 
 
 @pytest.mark.parametrize("name", LM_CASES)
