@@ -275,6 +275,47 @@ def fwdtree_only():
 
 
 
+FF_STATIC = ["pron_off", "pron_ci", "pron_ssid", "ci_ssid", "lm_known"]
+FF_DROP = ["step_frame", "step_best", "step_lpbest", "step_bpidx", "step_pen", "step_act_off", "step_act", "step_scr", "step_rest",
+           "n_steps"]
+
+
+def fwdflat_only():
+    """Second-pass goldens (ref_dump fwdflat): what the flat-lexicon search adds to a fixture's static tables
+    (pronunciations as word-internal ssids, CI ssids, LM membership), and per two-pass decode what pass 1 handed
+    over (its back-pointer table, the single-phone channels' ssids), the senone scores every pass-2 frame was
+    handed, and the back-pointer table pass 2 produced."""
+    tdm = os.path.join(REF, "model", "tidigits")
+    tdl = os.path.join(REF, "data", "tidigits")
+    base = ("fwdflat", "yes", "bestpath", "no")
+    med = dict(lm=os.path.join(REF, "data", "medium.arpa"), dic=os.path.join(REF, "data", "medium.dic"))
+    cases = [
+        ("en_us_turtle", "goforward", dict(), "goforward.raw", base),
+        ("en_us_turtle", "numbers", dict(), "numbers.raw", base),
+        ("en_us_turtle", "something_efwid2_sfwin8", dict(), "something.raw",
+         base + ("fwdflatefwid", "2", "fwdflatsfwin", "8", "fwdflatbeam", "1e-40", "fwdflatwbeam", "1e-5", "fwdflatlw", "6.0")),
+        ("tidigits", "man_ah_2934za", dict(model=tdm, lm=os.path.join(tdl, "tidigits.lm.bin"), dic=os.path.join(tdl, "tidigits.dic")),
+         os.path.join("tidigits", "man.ah.2934za.mfc"), base),
+        ("en_us_medium", "medium_numbers", med, "numbers.raw", base),
+    ]
+    done = set()
+    for static, name, kw, audio, extra in cases:
+        d = ref_dump("fwdflat", os.path.join(REF, "data", audio), extra=extra, **kw)
+        if static not in done:
+            # a fixture without a dense LM table carries the trie tables of the model THIS decode used (the staged
+            # medium.arpa need not be the one fwdtree_static_en_us_medium.npz was made from)
+            keys = FF_STATIC + ([k for k in LM_KEYS if k in d] if "lm" not in d else [])
+            np.savez_compressed(os.path.join(GOLD, "fwdflat_static_%s.npz" % static), **{k: d[k] for k in keys})
+            done.add(static)
+        drop = set(FT_STATIC) | set(LM_KEYS) | set(FF_STATIC) | set(FF_DROP)
+        tr = {k: v for k, v in d.items() if k not in drop}
+        tr["static"] = np.frombuffer(static.encode(), np.uint8)
+        path = os.path.join(GOLD, "fwdflat_trace_%s.npz" % name)
+        np.savez_compressed(path, **tr)
+        print("fwdflat", name, "frames", int(d["flat_n_steps"][0]), "bp1", d["bp1"].shape[0], "bp", d["bp"].shape[0],
+              "hyp", bytes(d["hyp"]).decode(), os.path.getsize(path))
+
+
 def read_arpa(path):
     """n-grams of an ARPA file as lists of word tuples per order"""
     import bz2
@@ -439,6 +480,8 @@ if __name__ == "__main__":
         fwdtree_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree_medium":
         fwdtree_medium_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fwdflat":
+        fwdflat_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "lm":
         lm_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "mfcc":

@@ -40,10 +40,10 @@ def main():
         a, b = vocab[rnd.randrange(n)], vocab[rnd.randrange(n)]
         if a != "</s>" and b != "<s>":
             bg.add((a, b))
-    succ = {}
-    for a, b in bg:
-        succ.setdefault(a, []).append(b)
     bgl = sorted(bg)
+    succ = {}
+    for a, b in bgl:                   # (sorted: iterating the set itself made the model depend on PYTHONHASHSEED)
+        succ.setdefault(a, []).append(b)
     tg = {("<s>", "go", "forward"), ("go", "forward", "ten"), ("forward", "ten", "meters"), ("ten", "meters", "</s>")}
     while len(tg) < 5 * n:
         a, b = bgl[rnd.randrange(len(bgl))]

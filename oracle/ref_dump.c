@@ -912,9 +912,95 @@ static int ft_index(chan_t **nodes, int n, chan_t *h, int base)
     return -2;
 }
 
+/* ---- fwdflat (`fwdflat` command): the second pass (ngram_search_fwdflat.c) runs inside the search's finish();
+ * the wrapper snapshots what pass 1 left (back-pointer table, score stack, the multiplex ssids of the permanent
+ * single-phone channels: hmm_clear does not reset them), the scorer hook records the scores each pass-2 frame was
+ * handed and, one call later, the best score / back-pointer count that frame ended with. */
+static int ff_on, ff_phase;                 /* tracing a two-pass decode; inside finish() */
+static int32 *ff_bp1, *ff_bss1, *ff_idx1, *ff_w1ssid; static int ff_nb1, ff_nbss1, ff_nfr1;
+static int32 *ff_best, *ff_bpidx; static size_t ff_n, ff_cap;
+static int32 *ff_wordlist; static int ff_nwd;
+static int32 *ff_act; static int16 *ff_scr, *ff_rest; static size_t ff_act_n, ff_act_cap; static int64_t *ff_act_off;
+
+static void
+ff_record_frame(ps_mgau_t *mg, int16 *senscr, uint8 *act, int32 nact, int32 frame, int32 compallsen)
+{
+    ngram_search_t *ngs = (ngram_search_t *)ft_ps->search;
+    int i, sen = 0, n_sen = bin_mdef_n_sen(ft_ps->acmod->mdef);
+    uint8 *listed = calloc(n_sen, 1);
+    (void)mg;
+    if ((size_t)frame != ff_n) { fprintf(stderr, "fwdflat trace: frame %d out of order (%zu recorded)\n", frame, ff_n); exit(2); }
+    if (ff_n + 2 > ff_cap) {
+        ff_cap = ff_cap ? ff_cap * 2 : 1024;
+        ff_best = realloc(ff_best, sizeof(int32) * ff_cap); ff_bpidx = realloc(ff_bpidx, sizeof(int32) * ff_cap);
+        ff_act_off = realloc(ff_act_off, sizeof(int64_t) * (ff_cap + 1)); ff_rest = realloc(ff_rest, sizeof(int16) * ff_cap);
+    }
+    if (frame > 0) { ff_best[frame - 1] = ngs->best_score; ff_bpidx[frame - 1] = ngs->bpidx; }   /* what frame - 1 ended with */
+    else {                                              /* the utterance's vocabulary as build_fwdflat_wordlist left it */
+        for (ff_nwd = 0; ngs->fwdflat_wordlist[ff_nwd] >= 0; ++ff_nwd);
+        ff_wordlist = calloc(ff_nwd + 1, 4);
+        memcpy(ff_wordlist, ngs->fwdflat_wordlist, sizeof(int32) * ff_nwd);
+    }
+    if (compallsen) nact = n_sen;
+    if (ff_act_n + nact > ff_act_cap) {
+        ff_act_cap = (ff_act_n + nact) * 2 + 1024;
+        ff_act = realloc(ff_act, sizeof(int32) * ff_act_cap); ff_scr = realloc(ff_scr, sizeof(int16) * ff_act_cap);
+    }
+    ff_act_off[ff_n] = (int64_t)ff_act_n;
+    for (i = 0; i < nact; ++i) {
+        sen = compallsen ? i : sen + act[i];
+        ff_act[ff_act_n] = sen; ff_scr[ff_act_n] = senscr[sen]; ++ff_act_n;
+        listed[sen] = 1;
+    }
+    ff_rest[ff_n] = 0;
+    for (i = 0; i < n_sen; ++i) if (!listed[i]) { ff_rest[ff_n] = senscr[i]; break; }
+    free(listed);
+    ++ff_n;
+    ff_act_off[ff_n] = (int64_t)ff_act_n;
+}
+
+static int
+ff_frame_eval(ps_mgau_t *mg, int16 *senscr, uint8 *act, int32 nact, mfcc_t **feat, int32 frame, int32 compallsen)
+{
+    int r;
+    if (!ff_phase) return ft_frame_eval(mg, senscr, act, nact, feat, frame, compallsen);
+    r = ft_morig->frame_eval(mg, senscr, act, nact, feat, frame, compallsen);
+    ff_record_frame(mg, senscr, act, nact, frame, compallsen);
+    return r;
+}
+
+static int
+ff_finish(ps_search_t *search)
+{
+    ngram_search_t *ngs = (ngram_search_t *)search;
+    int n_emit = bin_mdef_n_emit_state(ps_search_acmod(search)->mdef), i, k, rv;
+    ff_nb1 = ngs->bpidx; ff_nbss1 = ngs->bss_head; ff_nfr1 = ngs->n_frame;
+    ff_bp1 = calloc((size_t)ff_nb1 * 10 + 1, 4); ff_bss1 = calloc(ff_nbss1 + 1, 4); ff_idx1 = calloc(ff_nfr1 + 2, 4);
+    for (i = 0; i < ff_nb1; ++i) {
+        bptbl_t *e = &ngs->bp_table[i];
+        int32 *b = ff_bp1 + (size_t)i * 10;
+        b[0] = e->frame; b[1] = e->valid; b[2] = e->wid; b[3] = e->bp; b[4] = e->score; b[5] = e->s_idx;
+        b[6] = e->real_wid; b[7] = e->prev_real_wid; b[8] = e->last_phone; b[9] = e->last2_phone;
+    }
+    memcpy(ff_bss1, ngs->bscore_stack, sizeof(int32) * ff_nbss1);
+    memcpy(ff_idx1, ngs->bp_table_idx, sizeof(int32) * ff_nfr1);
+    ff_idx1[ff_nfr1] = ngs->bpidx;                       /* the mark ngram_fwdtree_finish adds */
+    ff_w1ssid = calloc((size_t)ngs->n_1ph_words * n_emit + 1, 4);
+    for (i = 0; i < ngs->n_1ph_words; ++i) {
+        root_chan_t *r = (root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]];
+        for (k = 0; k < n_emit; ++k)
+            ff_w1ssid[i * n_emit + k] = hmm_is_mpx(&r->hmm) ? hmm_mpx_ssid(&r->hmm, k) : hmm_nonmpx_ssid(&r->hmm);
+    }
+    ff_phase = 1;
+    rv = ft_orig->finish(search);
+    ff_phase = 0;
+    if (ff_n > 0) { ff_best[ff_n - 1] = ngs->best_score; ff_bpidx[ff_n - 1] = ngs->bpidx; }
+    return rv;
+}
+
 static int cmd_lm(ngram_model_t *lmset, const char *qfile);
 static int
-cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
+cmd_fwdtree(ps_decoder_t *ps, const char *rawpath, int flat)
 {
     ngram_search_t *ngs = (ngram_search_t *)ps->search;
     acmod_t *acmod = ps->acmod;
@@ -926,10 +1012,11 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
     chan_t **nodes;
     int32 par[32];
 
-    if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM) || !ngs->fwdtree || ngs->fwdflat || ngs->bestpath) {
-        fprintf(stderr, "fwdtree dump needs an n-gram search with -fwdflat no -bestpath no\n");
+    if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM) || !ngs->fwdtree || (!ngs->fwdflat) != !flat || ngs->bestpath) {
+        fprintf(stderr, "fwdtree dump needs an n-gram search with -fwdflat no -bestpath no, fwdflat dump one with -fwdflat yes -bestpath no\n");
         return 2;
     }
+    ff_on = flat;
     /* ---- the tree */
     nodes = calloc(ngs->n_nonroot_chan + 16, sizeof *nodes);
     for (M = 0, i = 0; i < R; ++i) M = ft_number(ngs->root_chan[i].next, nodes, M);
@@ -1016,6 +1103,29 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
     par[23] = dict_filler_end(dict); par[24] = mdef->sil; par[25] = ps_search_lookahead(ngs) != NULL;
     par[26] = acmod->compallsen;
     put1("par", 'i', 32, par);
+    if (flat) {   /* what the second pass adds: pronunciations as word-internal ssids, CI ssids, LM membership, its beams */
+        int64_t tot = 0, o = 0;
+        int32 *off = calloc(n_w + 1, 4), *pci, *pss, *cis = calloc(n_ci, 4), *known = calloc(n_w, 4), fpar[16];
+        float lwf = ngs->fwdflat_fwdtree_lw_ratio;
+        for (w = 0; w < n_w; ++w) tot += dict_pronlen(dict, w);
+        pci = calloc(tot + 1, 4); pss = calloc(tot + 1, 4);
+        for (w = 0; w < n_w; ++w) {
+            int len = dict_pronlen(dict, w);
+            off[w] = (int32)o;
+            for (k = 0; k < len; ++k, ++o) {
+                pci[o] = dict_pron(dict, w, k);
+                pss[o] = (k >= 1 && k < len - 1) ? dict2pid_internal(d2p, w, k) : -1;
+            }
+            known[w] = ngram_model_set_known_wid(ngs->lmset, dict_basewid(dict, w)) ? 1 : 0;
+        }
+        off[n_w] = (int32)o;
+        for (i = 0; i < n_ci; ++i) cis[i] = bin_mdef_pid2ssid(mdef, i);
+        put1("pron_off", 'i', n_w + 1, off); put1("pron_ci", 'i', tot, pci); put1("pron_ssid", 'i', tot, pss);
+        put1("ci_ssid", 'i', n_ci, cis); put1("lm_known", 'i', n_w, known);
+        memset(fpar, 0, sizeof fpar);
+        fpar[0] = ngs->fwdflatbeam; fpar[1] = ngs->fwdflatwbeam; fpar[2] = ngs->min_ef_width; fpar[3] = ngs->max_sf_win;
+        put1("flat_par", 'i', 16, fpar); put1("flat_lwf", 'f', 1, &lwf);
+    }
     if (ps->phone_loop) {   /* the phone-loop search feeding the look-ahead penalties (phone_loop_search.h:75-94) */
         phone_loop_search_t *pls = (phone_loop_search_t *)ps->phone_loop;
         int32 pp[8] = { pls->n_phones, pls->window, pls->beam, pls->pbeam, pls->pip, ps->pl_window, 0, 0 };
@@ -1046,8 +1156,8 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath)
 traced:
     /* ---- the decode, traced */
     ft_ps = ps;
-    ft_orig = ps->search->vt; ft_vt = *ft_orig; ft_vt.step = ft_step; ps->search->vt = &ft_vt;
-    ft_morig = acmod->mgau->vt; ft_mvt = *ft_morig; ft_mvt.frame_eval = ft_frame_eval; acmod->mgau->vt = &ft_mvt;
+    ft_orig = ps->search->vt; ft_vt = *ft_orig; ft_vt.step = ft_step; if (flat) ft_vt.finish = ff_finish; ps->search->vt = &ft_vt;
+    ft_morig = acmod->mgau->vt; ft_mvt = *ft_morig; ft_mvt.frame_eval = flat ? ff_frame_eval : ft_frame_eval; acmod->mgau->vt = &ft_mvt;
     run_utt(ps, rawpath);
     ps->search->vt = ft_orig; acmod->mgau->vt = ft_morig;
     dump_hyp(ps, "");
@@ -1058,7 +1168,18 @@ traced:
     put1("step_act_off", 'q', ft_n + 1, ft_act_off);
     put1("step_act", 'i', (int64_t)ft_act_n, ft_act); put1("step_scr", 'h', (int64_t)ft_act_n, ft_scr);
     put1("step_rest", 'h', ft_n, ft_rest);
-    {   /* ---- the result */
+    if (flat) {   /* ---- what pass 1 handed over, and the second pass's trace */
+        put2("bp1", 'i', ff_nb1, 10, ff_bp1); put1("bscore_stack1", 'i', ff_nbss1, ff_bss1);
+        put1("bp_table_idx1", 'i', ff_nfr1 + 1, ff_idx1);
+        put2("flat_w1_ssid", 'i', ngs->n_1ph_words, n_emit, ff_w1ssid);
+        put1("flat_wordlist", 'i', ff_nwd, ff_wordlist);
+        puti("flat_n_steps", (int32)ff_n);
+        put1("flat_best", 'i', ff_n, ff_best); put1("flat_bpidx", 'i', ff_n, ff_bpidx);
+        put1("flat_act_off", 'q', ff_n + 1, ff_act_off);
+        put1("flat_act", 'i', (int64_t)ff_act_n, ff_act); put1("flat_scr", 'h', (int64_t)ff_act_n, ff_scr);
+        put1("flat_rest", 'h', ff_n, ff_rest);
+    }
+    {   /* ---- the result (of the last pass run) */
         int nb = ngs->bpidx;
         int32 *b = calloc((size_t)nb * 10 + 1, 4);
         for (i = 0; i < nb; ++i) {
@@ -1180,7 +1301,9 @@ main(int argc, char **argv)
         fe = fe_init_auto_r(config);
         rc = fe ? cmd_mfcc(fe, argv[6], atoi(argv[7])) : 2;
     } else if (!strcmp(cmd, "fwdtree") && xa > 6) {
-        rc = cmd_fwdtree(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+        rc = cmd_fwdtree(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], 0);
+    } else if (!strcmp(cmd, "fwdflat") && xa > 6) {
+        rc = cmd_fwdtree(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], 1);
     } else if (!strcmp(cmd, "lm") && xa > 6) {
         /* the decoder's own model set: word ids are dictionary word ids */
         rc = cmd_lm(((ngram_search_t *)make_decoder(modeldir, lm, dict, nextra, extra)->search)->lmset, argv[6]);

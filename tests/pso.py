@@ -489,3 +489,91 @@ class OracleLm:
         lib().pso_lm_tg_score_batch(self.h, w3.ctypes.data, w2.ctypes.data, w1.ctypes.data, len(q), sc.ctypes.data,
                                     nu.ctypes.data)
         return sc, nu
+
+
+class OracleFwdflat:
+    """Wrapper around pso_ff_t (oracle/ps_oracle_flat.c: restates ngram_search_fwdflat.c on flat tables).
+    `static` = a fwdtree_static_*.npz, `fstatic` = the matching fwdflat_static_*.npz, `g` = a fwdflat trace
+    (par, flat_par, flat_lwf)."""
+
+    EXTRA = ["pron_off", "pron_ci", "pron_ssid", "ci_ssid", "lm_known", "flat_par"]
+
+    def __init__(self, static, fstatic, g, lm=None):
+        L = lib()
+        names = OracleFwdtree.NAMES
+        src = dict(static); src.update(dict(fstatic)); src["par"] = g["par"]; src["flat_par"] = g["flat_par"]
+        self._keep = {n: np.ascontiguousarray(src[n], OracleFwdtree.DT.get(n, np.int32)) for n in names + self.EXTRA
+                      if not (n == "lm" and lm is not None)}
+
+        class T(C.Structure):
+            _fields_ = [(n, C.c_void_p) for n in names + self.EXTRA] + [("lwf", C.c_float)]
+        self._t = T(*([self._keep[n].ctypes.data if n in self._keep else None for n in names + self.EXTRA] +
+                      [float(np.asarray(g["flat_lwf"], np.float32).ravel()[0])]))
+        self._lm = lm
+        vp = C.c_void_p
+        L.pso_ff_new.restype = vp; L.pso_ff_new.argtypes = [vp]
+        L.pso_ff_free.argtypes = [vp]
+        L.pso_ff_set_lm.argtypes = [vp, vp]
+        L.pso_ff_start.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+        L.pso_ff_active_list.argtypes = [vp, C.c_int, vp]
+        L.pso_ff_step.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int16]
+        L.pso_ff_finish.argtypes = [vp, C.c_int]
+        for f in ("pso_ff_best_score", "pso_ff_bpidx", "pso_ff_bss_head", "pso_ff_n_words", "pso_ff_n_chan"):
+            getattr(L, f).argtypes = [vp]; getattr(L, f).restype = C.c_int32
+        for f in ("pso_ff_bp", "pso_ff_bss", "pso_ff_bp_table_idx", "pso_ff_wordlist"):
+            getattr(L, f).argtypes = [vp]; getattr(L, f).restype = vp
+        self.n_sen = int(g["par"][2])
+        self.h = L.pso_ff_new(C.byref(self._t))
+        if lm is not None:
+            L.pso_ff_set_lm(self.h, lm.h)
+        self._buf = np.zeros(self.n_sen, np.int32)
+
+    def __del__(self):
+        try:
+            lib().pso_ff_free(self.h)
+        except Exception:
+            pass
+
+    def start(self, bp1, n_frame, w1_ssid):
+        bp1 = np.ascontiguousarray(bp1, np.int32); w1 = np.ascontiguousarray(w1_ssid, np.int32)
+        lib().pso_ff_start(self.h, _p(bp1), int(bp1.shape[0]), int(n_frame), _p(w1))
+
+    def active_list(self, frame):
+        n = lib().pso_ff_active_list(self.h, int(frame), _p(self._buf))
+        return self._buf[:n].copy()
+
+    def step(self, frame, ids, scr, rest):
+        ids = np.ascontiguousarray(ids, np.int32); scr = np.ascontiguousarray(scr, np.int16)
+        return lib().pso_ff_step(self.h, int(frame), _p(ids), _p(scr), int(ids.size), int(rest))
+
+    def finish(self, n_frames):
+        lib().pso_ff_finish(self.h, int(n_frames))
+
+    def best_score(self):
+        return int(lib().pso_ff_best_score(self.h))
+
+    def bpidx(self):
+        return int(lib().pso_ff_bpidx(self.h))
+
+    def wordlist(self):
+        L = lib()
+        n = L.pso_ff_n_words(self.h)
+        return np.ctypeslib.as_array(C.cast(L.pso_ff_wordlist(self.h), C.POINTER(C.c_int32)), shape=(max(n, 1),)).copy()[:n]
+
+    def n_chan(self):
+        return int(lib().pso_ff_n_chan(self.h))
+
+    def bp_table(self):
+        L = lib()
+        n = L.pso_ff_bpidx(self.h)
+        return np.ctypeslib.as_array(C.cast(L.pso_ff_bp(self.h), C.POINTER(C.c_int32)), shape=(max(n, 1), 10)).copy()[:n]
+
+    def bscore_stack(self):
+        L = lib()
+        n = L.pso_ff_bss_head(self.h)
+        return np.ctypeslib.as_array(C.cast(L.pso_ff_bss(self.h), C.POINTER(C.c_int32)), shape=(max(n, 1),)).copy()[:n]
+
+    def bp_table_idx(self, n_frames):
+        L = lib()
+        return np.ctypeslib.as_array(C.cast(L.pso_ff_bp_table_idx(self.h), C.POINTER(C.c_int32)),
+                                     shape=(n_frames + 1,)).copy()
