@@ -589,6 +589,43 @@ int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
 #define PSGPU_FWDTREE_ACTIVE_LIST 1
 int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode);
 
+/* ---- flat-lexicon second pass of whole utterances, first version ----------
+ * Replaces ngram_fwdflat_start + ngram_fwdflat_search per frame + ngram_fwdflat_finish
+ * (ngram_search_fwdflat.c:223-414, 416-877, 925-960).  `ft` are the first pass's static tables (the tree arrays
+ * are not used); on top of them the second pass needs the pronunciations as word-internal ssids
+ * (dict2pid_internal; -1 at the first and last position), the CI phones' ssids (bin_mdef_pid2ssid), which words
+ * the language model knows (ngram_model_set_known_wid(lmset, dict_basewid(w)): build_fwdflat_wordlist :240-243),
+ * its two beams, the end-point filter and start-frame window (-fwdflatefwid, -fwdflatsfwin) and
+ * fwdflat_fwdtree_lw_ratio (ngram_search.c:122-125) -- what oracle/ref_dump.c `fwdflat` writes. */
+typedef struct psgpu_fwdflat_s psgpu_fwdflat_t;
+typedef struct psgpu_fwdflat_tables_s {
+    const psgpu_fwdtree_tables_t *ft;
+    const int32_t *pron_off;                  /* [n_w + 1] */
+    const int32_t *pron_ci, *pron_ssid;       /* [pron_off[n_w]] */
+    const int32_t *ci_ssid;                   /* [n_ci] */
+    const int32_t *lm_known;                  /* [n_w] */
+    int32_t fwdflatbeam, fwdflatwbeam, min_ef_width, max_sf_win;
+    float lwf;
+} psgpu_fwdflat_tables_t;
+int psgpu_fwdflat_create(psgpu_fwdflat_t **out, const psgpu_fwdflat_tables_t *t);
+void psgpu_fwdflat_free(psgpu_fwdflat_t *m);
+/* language scores from the device trie instead of ft->lm (which may then be NULL at create) */
+int psgpu_fwdflat_set_lm(psgpu_fwdflat_t *m, const psgpu_lm_t *lm);
+/* n_utt utterances, one workgroup each, every frame inside the kernel.  senscr_dev [total][scr_stride] int16 =
+ * the scores acmod_score hands the second pass for each frame; utt_off_dev [n_utt + 1].  The first pass is taken
+ * over as psgpu_fwdtree_search_dev left it: bp1_dev (ten columns per utterance at u*10*bp1_cap) and result1_dev
+ * (u*8: back-pointer count, .., frames searched); w1_ssid_dev [n_utt][n_1ph][n_emit] (may be NULL) = the per-state
+ * ssids its permanent single-phone channels ended with (hmm_clear at ngram_fwdflat_start keeps them).  The
+ * utterance's vocabulary (build_fwdflat_wordlist) is built on the host from three columns of that table.
+ * Outputs as psgpu_fwdtree_search_dev's: back-pointer columns, score stack, bp_table_idx, per-frame
+ * {best_score, 0, bpidx, n_active_words}, result {n back-pointers, score-stack length, frames searched, status,
+ * best_score}.  Synchronous on `stream`. */
+int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                             const int32_t *utt_off_dev, int32_t n_utt, int32_t max_frames,
+                             int32_t bp1_cap, const int32_t *bp1_dev, const int32_t *result1_dev,
+                             const int32_t *w1_ssid_dev, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev,
+                             int32_t *bss_dev, int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream);
+
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).
  * senscr is the frame's n_sen int16 scores.  Synchronous. */

@@ -18,5 +18,6 @@ from .feat import dynfeat_1s_c_d_dd  # noqa: F401
 from .fe import FrontEnd  # noqa: F401
 from .search import FwdtreeSearch, backtrace  # noqa: F401
 from .lm import NGramTrieLM  # noqa: F401
+from .flat import FwdflatSearch  # noqa: F401
 
-__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch", "backtrace", "NGramTrieLM"]
+__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch", "backtrace", "NGramTrieLM", "FwdflatSearch"]

@@ -1,0 +1,675 @@
+// psgpu_flat.hip -- the flat-lexicon second pass on gfx950, first version: whole
+// utterances, one workgroup per utterance, every frame inside the kernel.
+//
+// Replaces ngram_fwdflat_start + ngram_fwdflat_search x T + ngram_fwdflat_finish (reference
+// src/ngram_search_fwdflat.c:223-414, 416-877, 925-960) and the back-pointer helpers they share with the first
+// pass (src/ngram_search.c:301-498): the utterance's vocabulary from the first pass's back-pointer table, one HMM
+// chain per word ([multiplex root][word-internal phones][right-context fan-out], contiguous), evaluation, beam
+// pruning with phone transitions inside the chain, word exits into the back-pointer table, word transitions
+// with the float-weighted language score (:700-706), silence / filler entry, the next active word list.
+// Output: back-pointer table, score stack and frame marks in the reference's columns, as the first pass's kernel.
+//
+// Parallelism in this version: utterances across workgroups; inside a frame one work-item per active word
+// (a chain is short and its pruning is sequential along the chain by construction: a phone entered this frame
+// is looked at later in the same walk), one per vocabulary word for the word transitions (each loops over the
+// frame's exits in order, so "first best wins" is kept), workgroup prefix sums for back-pointer positions and the
+// next active word list (vocabulary order, then fillers: ngram_search_fwdflat.c:853-869).  The utterance's
+// vocabulary and chain layout are built on the host from the first pass's table (a few hundred entries) --
+// build_fwdflat_wordlist's list surgery is sequential; an on-device build can replace it behind the same entry.
+// Oracle: oracle/ps_oracle_flat.c (pinned to the reference); checked on the CPU through tests/hostsim.
+#include "psgpu_hmm_dev.h"
+#include "psgpu_lm_dev.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+constexpr int kFfThreads = 256;
+constexpr int kFfMaxCi = 64;
+
+struct FfDev {
+    int32_t n_ci, n_emit, n_sen, n_w, n1;
+    int32_t beam, pip, silpen, fillpen, fwdflatbeam, fwdflatwbeam, min_ef_width, max_sf_win;
+    int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci;
+    float lwf;
+    const int32_t *w1_wid, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx, *w1_of_word;
+    const int32_t *d_pronlen, *d_first, *d_last, *d_last2, *d_base, *d_filler;
+    const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm;
+    const int32_t *pron_off, *pron_ci, *pron_ssid, *ci_ssid;
+    const uint8_t *tp;
+    const uint16_t *sseq;
+    int32_t use_trie;
+    LmDev trie;
+};
+
+// per-utterance state; channels [0, n1) are the permanent single-phone words, then the chains of the vocabulary
+struct FfUtt {
+    int32_t nwd, n_chan, n_frame, awl_cap;
+    const int32_t *wl_wid, *wl_chain, *wl_len, *wl_node_off, *node_sf;     // [nwd] (+1), [n nodes]: vocabulary, host-built
+    int32_t *score, *hist;               // [C][5]
+    int32_t *out, *outh, *best, *frame;  // [C]
+    int32_t *senid;                      // [C][5]
+    int32_t *tmat, *mpx, *rcid, *xflag;  // [C]
+    int32_t *wchain, *wlen;              // [n_w] chain offset (channel index) or -1, chain length
+    int32_t *word_active, *word_lat_idx; // [n_w] (word_active: frame stamp)
+    int32_t *awl[2];                     // [awl_cap]
+    int32_t *cnt_a, *cnt_b, *cnt_c;      // [max(awl_cap, nwd + fillers) + 1] scan scratch
+    int32_t *bp, *bss, *bp_table_idx, *step, *result;
+    const int32_t *w1_ssid_in;           // [n1][n_emit] or NULL
+    int32_t bp_cap, bss_cap;
+};
+
+struct psgpu_fwdflat_s {
+    FfDev d;
+    std::vector<void *> allocs;
+    std::vector<int32_t> h_pronlen, h_last, h_last2, h_rs_n, h_known;   // host copies for the vocabulary build
+};
+
+#define FBP(u, col, i) ((u).bp[(size_t)(col) * (u).bp_cap + (i)])
+enum { F_FRAME, F_VALID, F_WID, F_BP, F_SCORE, F_SIDX, F_REAL, F_PREAL, F_LAST, F_LAST2 };
+
+__device__ __forceinline__ void ff_clear(const FfDev &p, FfUtt &u, int c)             // hmm_clear, hmm.c:181-198
+{
+    for (int i = 0; i < p.n_emit; ++i) { u.score[c * 5 + i] = kW; u.hist[c * 5 + i] = -1; }
+    u.out[c] = kW; u.outh[c] = -1; u.best[c] = kW; u.frame[c] = -1;
+}
+__device__ __forceinline__ void ff_clear_scores(const FfDev &p, FfUtt &u, int c)      // hmm_clear_scores, hmm.c:167-179
+{
+    for (int i = 0; i < p.n_emit; ++i) u.score[c * 5 + i] = kW;
+    u.out[c] = kW; u.best[c] = kW;
+}
+__device__ __forceinline__ void ff_init(const FfDev &p, FfUtt &u, int c, int mpx, int ssid, int tmatid, int rcid)
+{
+    u.mpx[c] = mpx; u.tmat[c] = tmatid; u.rcid[c] = rcid; u.xflag[c] = 0;
+    if (mpx) {
+        u.senid[c * 5] = ssid;
+        for (int i = 1; i < p.n_emit; ++i) u.senid[c * 5 + i] = kBadSsid;
+    }
+    else
+        for (int i = 0; i < p.n_emit; ++i) u.senid[c * 5 + i] = p.sseq[(size_t)ssid * p.n_emit + i];
+    ff_clear(p, u, c);
+}
+__device__ __forceinline__ void ff_enter(FfUtt &u, int c, int32_t score, int32_t hist, int frame)
+{
+    u.score[c * 5] = score; u.hist[c * 5] = hist; u.frame[c] = frame;
+}
+__device__ __forceinline__ void ff_enter_if_better(FfUtt &u, int c, int32_t score, int32_t hist, int cf)
+{
+    if (u.frame[c] < cf || score > u.score[c * 5]) ff_enter(u, c, score, hist, cf + 1);
+}
+__device__ __forceinline__ void ff_normalize(const FfDev &p, FfUtt &u, int c, int32_t norm)
+{
+    for (int i = 0; i < p.n_emit; ++i) if (u.score[c * 5 + i] > kW) u.score[c * 5 + i] -= norm;
+    if (u.out[c] > kW) u.out[c] -= norm;
+}
+
+template <int NE>
+__device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, const int16_t *row)
+{
+    HmmRegs h;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        h.score[i] = i < NE ? u.score[c * 5 + i] : kW;
+        h.history[i] = i < NE ? u.hist[c * 5 + i] : -1;
+        h.senid[i] = i < NE ? (uint16_t)u.senid[c * 5 + i] : 0;
+    }
+    h.out_score = u.out[c]; h.out_history = u.outh[c]; h.bestscore = u.best[c];
+    const uint8_t *tp = p.tp + (size_t)u.tmat[c] * NE * (NE + 1);
+    int32_t b;
+    if (NE == 3) b = u.mpx[c] ? vit3_mpx(h, tp, row, p.sseq) : vit3(h, tp, row);
+    else         b = u.mpx[c] ? vit5_mpx(h, tp, row, p.sseq) : vit5(h, tp, row);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { u.score[c * 5 + i] = h.score[i]; u.hist[c * 5 + i] = h.history[i]; u.senid[c * 5 + i] = h.senid[i]; }
+    u.out[c] = h.out_score; u.outh[c] = h.out_history; u.best[c] = h.bestscore;
+    return b;
+}
+
+__device__ __forceinline__ int32_t ff_lm(const FfDev &p, int w3, int w2, int w1)      // ngram_tg_score(...) >> SENSCR_SHIFT
+{
+    if (p.use_trie) { int nu; return lm_tg_score(p.trie, w3, w2, w1, nu) >> 10; }
+    const size_t n1 = (size_t)p.n_w + 1;
+    return p.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
+}
+// set_real_wid, ngram_search.c:341-372
+__device__ void ff_set_real_wid(const FfDev &p, FfUtt &u, int bp)
+{
+    const int prev = FBP(u, F_BP, bp), wid = FBP(u, F_WID, bp);
+    if (p.d_filler[wid]) {
+        if (prev != -1) { FBP(u, F_REAL, bp) = FBP(u, F_REAL, prev); FBP(u, F_PREAL, bp) = FBP(u, F_PREAL, prev); }
+        else { FBP(u, F_REAL, bp) = p.d_base[wid]; FBP(u, F_PREAL, bp) = -1; }
+    }
+    else {
+        FBP(u, F_REAL, bp) = p.d_base[wid];
+        FBP(u, F_PREAL, bp) = prev != -1 ? FBP(u, F_REAL, prev) : -1;
+    }
+}
+// ngram_search_save_bp, ngram_search.c:376-498, with the position of a new entry (bpidx, bss_head) given by the caller
+__device__ void ff_save_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score,
+                           int32_t path, int rc)
+{
+    const int bp = u.word_lat_idx[w];
+    if (bp != -1) {
+        if (FBP(u, F_SCORE, bp) < score) {
+            const int ob = FBP(u, F_BP, bp);
+            if (ob != path) {
+                const int32_t b0 = ob == -1 ? -1 : FBP(u, F_PREAL, ob), b1 = ob == -1 ? -1 : FBP(u, F_REAL, ob);
+                const int32_t n0 = path == -1 ? -1 : FBP(u, F_PREAL, path), n1 = path == -1 ? -1 : FBP(u, F_REAL, path);
+                if (b0 != n0 || b1 != n1) ff_set_real_wid(p, u, bp);      // with the old bp still in place, as the reference
+                FBP(u, F_BP, bp) = path;
+            }
+            FBP(u, F_SCORE, bp) = score;
+        }
+        if (FBP(u, F_SIDX, bp) != -1) u.bss[FBP(u, F_SIDX, bp) + rc] = score;
+        return;
+    }
+    u.word_lat_idx[w] = bpidx;
+    FBP(u, F_WID, bpidx) = w; FBP(u, F_FRAME, bpidx) = frame; FBP(u, F_BP, bpidx) = path; FBP(u, F_SCORE, bpidx) = score;
+    FBP(u, F_SIDX, bpidx) = bss_head; FBP(u, F_VALID, bpidx) = 1;
+    FBP(u, F_LAST, bpidx) = p.d_last[w];
+    int rcsize = 0;
+    if (p.d_pronlen[w] == 1) { FBP(u, F_LAST2, bpidx) = -1; FBP(u, F_SIDX, bpidx) = -1; }
+    else {
+        FBP(u, F_LAST2, bpidx) = p.d_last2[w];
+        rcsize = p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]];
+    }
+    for (int i = 0; i < rcsize; ++i) u.bss[bss_head + i] = kW;
+    if (rcsize) u.bss[bss_head + rc] = score;
+    ff_set_real_wid(p, u, bpidx);
+}
+
+// exclusive prefix sum of a[0..n) in place by the whole workgroup; returns the total.  Ends with a barrier.
+__device__ __forceinline__ int32_t ff_block_scan(int32_t *a, int n, int32_t *tmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int per = (n + kFfThreads - 1) / kFfThreads;
+    const int b = min(n, tid * per), e = min(n, b + per);
+    int32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += a[i];
+    int32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    if (lane == 63) tmp[tid >> 6] = incl;
+    __syncthreads();
+    int32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kFfThreads / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
+    int32_t run = base + incl - sum;
+    for (int i = b; i < e; ++i) { const int32_t k = a[i]; a[i] = run; run += k; }
+    __syncthreads();
+    return total;
+}
+
+// first channel and chain length of word w (a vocabulary word's chain, else its permanent single-phone channel)
+__device__ __forceinline__ int ff_root(const FfDev &p, const FfUtt &u, int w, int &len)
+{
+    const int c = u.wchain[w];
+    if (c >= 0) { len = u.wlen[w]; return c; }
+    len = 1;
+    return p.w1_of_word[w];
+}
+
+template <int NE>
+__global__ __launch_bounds__(kFfThreads)
+void fwdflat_kernel(FfDev p, const FfUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
+                    const int32_t *__restrict__ utt_off)
+{
+    __shared__ int32_t s_scan[kFfThreads / 64];
+    __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, best sil score, best sil bp, n real exits
+    __shared__ unsigned long long s_key;
+    const int tid = threadIdx.x;
+    FfUtt u = utts[blockIdx.x];
+    const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
+    int n_awl[2] = {0, 0};
+
+    // ---- build_fwdflat_chan (:305-368) on the host-made layout, ngram_fwdflat_start (:370-414)
+    for (int i = tid; i < p.n1; i += kFfThreads) {
+        ff_init(p, u, i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i], -1);
+        if (u.w1_ssid_in && p.w1_mpx[i])        // what the first pass left in the permanent channels (hmm_clear keeps the ssids)
+            for (int k = 0; k < p.n_emit; ++k) u.senid[i * 5 + k] = u.w1_ssid_in[i * p.n_emit + k];
+    }
+    for (int w = tid; w < p.n_w; w += kFfThreads) { u.wchain[w] = -1; u.wlen[w] = 0; u.word_active[w] = -1; u.word_lat_idx[w] = -1; }
+    __syncthreads();
+    for (int k = tid; k < u.nwd; k += kFfThreads) {
+        const int w = u.wl_wid[k], c0 = u.wl_chain[k];
+        if (c0 < 0) continue;
+        const int len = p.d_pronlen[w], last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
+        int c = c0;
+        u.wchain[w] = c0; u.wlen[w] = u.wl_len[k];
+        ff_init(p, u, c++, 1, p.ci_ssid[p.d_first[w]], p.ci_tmat[p.d_first[w]], -1);
+        for (int q = 1; q < len - 1; ++q) {
+            const int o = p.pron_off[w] + q;
+            ff_init(p, u, c++, 0, p.pron_ssid[o], p.ci_tmat[p.pron_ci[o]], -1);
+        }
+        for (int r = 0; r < nrc; ++r)
+            ff_init(p, u, c++, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last], r);
+    }
+    if (tid == 0) {
+        s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = 0; s_sc[3] = 0; s_sc[4] = 0;
+        ff_enter(u, p.w1_of_word[p.startwid], 0, -1, 0);
+        u.awl[0][0] = p.startwid;
+    }
+    n_awl[0] = 1;
+    __syncthreads();
+
+    for (int f = 0; f < T; ++f) {
+        const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = n_awl[cur];
+        const int16_t *row = senscr + (size_t)(t0 + f) * scr_stride;
+        // ---- ngram_search_mark_bptable, failure test, renormalisation (:825-838)
+        if (tid == 0) u.bp_table_idx[f] = s_sc[1];
+        const int32_t best_in = s_sc[0];
+        if (best_in == kW || best_in < kW) break;
+        if (best_in + 2 * p.beam < kW)                       // fwdflat_renormalize_scores (:784-810)
+            for (int i = tid; i < na; i += kFfThreads) {
+                int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
+                for (int k = 0; k < len; ++k) if (u.frame[c0 + k] == f) ff_normalize(p, u, c0 + k, best_in);
+            }
+        __syncthreads();
+        if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_sc[7] = 0; s_key = 0ull; }
+        __syncthreads();
+        // ---- fwdflat_eval_chan (:444-480)
+        {
+            int32_t b = kW;
+            for (int i = tid; i < na; i += kFfThreads) {
+                const int w = u.awl[cur][i];
+                int len; const int c0 = ff_root(p, u, w, len);
+                for (int k = 0; k < len; ++k) {
+                    if (u.frame[c0 + k] != f) continue;
+                    const int32_t sc = ff_eval<NE>(p, u, c0 + k, row);
+                    if (!(k == 0 && w == p.finishwid)) b = max(b, sc);
+                }
+            }
+            if (b > kW) atomicMax(&s_sc[0], b);
+        }
+        __syncthreads();
+        const int32_t best_score = s_sc[0];
+        const int32_t thresh = best_score + p.fwdflatbeam, wordthresh = best_score + p.fwdflatwbeam;
+        // ---- fwdflat_prune_chan (:482-607), one work-item per active word; exits are flagged, their back-pointer
+        //      positions come from the prefix sums below (one entry per exiting word, in active-list order)
+        for (int i = tid; i < na; i += kFfThreads) {
+            const int w = u.awl[cur][i];
+            int len; const int c0 = ff_root(p, u, w, len);
+            int ex = 0, act = 0;
+            if (u.frame[c0] == f && u.best[c0] > thresh) {
+                int32_t newscore = u.out[c0];
+                u.frame[c0] = nf; act = 1;
+                if (len > 1) {
+                    newscore += p.pip;
+                    if (newscore > thresh) {
+                        if (u.rcid[c0 + 1] >= 0) for (int j = 1; j < len; ++j) ff_enter_if_better(u, c0 + j, newscore, u.outh[c0], f);
+                        else ff_enter_if_better(u, c0 + 1, newscore, u.outh[c0], f);
+                    }
+                }
+                else if (newscore > wordthresh) { u.xflag[c0] = 1; ex = 1; }
+            }
+            for (int k = 1; k < len; ++k) {
+                const int c = c0 + k;
+                if (u.frame[c] < f) continue;
+                if (u.best[c] > thresh) {
+                    int32_t newscore = u.out[c];
+                    u.frame[c] = nf; act = 1;
+                    if (u.rcid[c] < 0) {
+                        newscore += p.pip;
+                        if (newscore > thresh) {
+                            if (u.rcid[c + 1] >= 0) for (int j = k + 1; j < len; ++j) ff_enter_if_better(u, c0 + j, newscore, u.outh[c], f);
+                            else ff_enter_if_better(u, c + 1, newscore, u.outh[c], f);
+                        }
+                    }
+                    else if (newscore > wordthresh) { u.xflag[c] = 1; ex = 1; }
+                }
+                else if (u.frame[c] != nf) ff_clear_scores(p, u, c);
+            }
+            if (act) u.word_active[w] = nf;
+            u.cnt_a[i] = ex;
+            u.cnt_b[i] = (ex && p.d_pronlen[w] > 1) ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+        }
+        __syncthreads();
+        {
+            const int32_t bpidx = s_sc[1], bss_head = s_sc[2];
+            const int32_t n_exit = ff_block_scan(u.cnt_a, na, s_scan);
+            const int32_t n_bss = ff_block_scan(u.cnt_b, na, s_scan);
+            const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
+            if (!full)
+                for (int i = tid; i < na; i += kFfThreads) {
+                    if ((i + 1 < na ? u.cnt_a[i + 1] : n_exit) == u.cnt_a[i]) continue;
+                    const int w = u.awl[cur][i];
+                    int len; const int c0 = ff_root(p, u, w, len);
+                    const int32_t bpi = bpidx + u.cnt_a[i], bsh = bss_head + u.cnt_b[i];
+                    for (int k = 0; k < len; ++k) {
+                        const int c = c0 + k;
+                        if (!u.xflag[c]) continue;
+                        u.xflag[c] = 0;
+                        ff_save_bp(p, u, bpi, bsh, f, w, u.out[c], u.outh[c], k == 0 ? 0 : u.rcid[c]);
+                    }
+                }
+            __syncthreads();
+            if (tid == 0) { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; if (full) s_sc[3] = 1; }
+        }
+        __syncthreads();
+        if (s_sc[3]) break;
+
+        // ---- fwdflat_word_transition (:642-782)
+        const int bp0 = u.bp_table_idx[f], bp1 = s_sc[1];
+        for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
+            const int wid = FBP(u, F_WID, b);
+            u.word_lat_idx[wid] = -1;
+            if (wid == p.finishwid) continue;
+            const int l2 = FBP(u, F_LAST2, b), l1 = FBP(u, F_LAST, b);
+            const int32_t sil = l2 == -1 ? FBP(u, F_SCORE, b)
+                : u.bss[FBP(u, F_SIDX, b) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + p.sil_ci]];
+            // best exit into silence, the earliest on ties (:745-753): key = (score, -index)
+            if (sil > kW)
+                atomicMax(&s_key, ((unsigned long long)(uint32_t)(sil - kW) << 32) | (uint32_t)(0x7fffffff - b));
+        }
+        // successors: the vocabulary words that start within the window of this frame (get_expand_wordlist :609-640)
+        {
+            int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
+            if (sf0 < 0) sf0 = 0;
+            if (ef0 > u.n_frame) ef0 = u.n_frame;
+            for (int k = tid; k < u.nwd; k += kFfThreads) {
+                bool in = false;
+                for (int q = u.wl_node_off[k]; q < u.wl_node_off[k + 1] && !in; ++q) in = u.node_sf[q] >= sf0 && u.node_sf[q] < ef0;
+                if (!in) continue;
+                const int w = u.wl_wid[k];
+                int len; const int c0 = ff_root(p, u, w, len);
+                const int first = p.d_first[w], base = p.d_base[w];
+                const int ci2 = u.wl_chain[k] >= 0 ? p.pron_ci[p.pron_off[w] + 1] : p.w1_ci2[p.w1_of_word[w]];
+                for (int b = bp0; b < bp1; ++b) {              // exits in order: the first best one wins, as in the reference
+                    if (FBP(u, F_WID, b) == p.finishwid) continue;
+                    const int l2 = FBP(u, F_LAST2, b), l1 = FBP(u, F_LAST, b);
+                    int32_t newscore = l2 == -1 ? FBP(u, F_SCORE, b)
+                        : u.bss[FBP(u, F_SIDX, b) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + first]];
+                    if (newscore == kW) continue;
+                    // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
+                    const float prod = __fmul_rn(p.lwf, (float)ff_lm(p, base, FBP(u, F_REAL, b), FBP(u, F_PREAL, b)));
+                    newscore = (int32_t)__fadd_rn((float)newscore, prod);
+                    newscore += p.pip;
+                    if (newscore > thresh && (u.frame[c0] < f || newscore > u.score[c0 * 5])) {
+                        ff_enter(u, c0, newscore, b, nf);
+                        u.senid[c0 * 5] = p.ldiph[((size_t)first * p.n_ci + ci2) * p.n_ci + l1];
+                        u.word_active[w] = nf;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            // <sil> and the noise words (:755-769)
+            const unsigned long long key = s_key;
+            const int32_t silscore = key ? (int32_t)(uint32_t)(key >> 32) + kW : kW;
+            const int32_t silbp = key ? 0x7fffffff - (int32_t)(uint32_t)(key & 0xffffffffu) : 0;
+            for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += kFfThreads) {
+                const bool is_sil = w == p.filler_start - 1;       // slot filler_start - 1 stands for <sil>
+                if (!is_sil && w == p.silwid) continue;
+                const int ww = is_sil ? p.silwid : w;
+                const int c = p.w1_of_word[ww];
+                if (c < 0) continue;                               // noise words that are not a single phone have no channel
+                const int32_t ns = silscore + (is_sil ? p.silpen : p.fillpen) + p.pip;
+                if (ns > thresh && ns > kW && (u.frame[c] < f || ns > u.score[c * 5])) {
+                    ff_enter(u, c, ns, silbp, nf);
+                    u.word_active[ww] = nf;
+                }
+            }
+        }
+        __syncthreads();
+        // initial channels of words that stayed inactive (:771-781)
+        for (int i = tid; i < na; i += kFfThreads) {
+            int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
+            if (u.frame[c0] == f) ff_clear_scores(p, u, c0);
+        }
+        // ---- next active word list (:853-869): the vocabulary in its order (words below <s>), then <s> and above by id
+        const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
+        for (int i = tid; i < n_all; i += kFfThreads) {
+            const int w = i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd);
+            u.cnt_c[i] = (u.word_active[w] == nf && (i < u.nwd ? w < p.startwid : true)) ? 1 : 0;
+        }
+        __syncthreads();
+        const int32_t n_next = ff_block_scan(u.cnt_c, n_all, s_scan);
+        for (int i = tid; i < n_all; i += kFfThreads)
+            if ((i + 1 < n_all ? u.cnt_c[i + 1] : n_next) != u.cnt_c[i])
+                u.awl[nxt][u.cnt_c[i]] = i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd);
+        n_awl[nxt] = n_next;
+        if (tid == 0) {
+            u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = 0; u.step[f * 4 + 2] = s_sc[1]; u.step[f * 4 + 3] = n_next;
+            ++s_sc[4];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        u.bp_table_idx[s_sc[4]] = s_sc[1];                       // ngram_fwdflat_finish: mark one past the last frame
+        u.result[0] = s_sc[1]; u.result[1] = s_sc[2]; u.result[2] = s_sc[4]; u.result[3] = s_sc[3]; u.result[4] = s_sc[0];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T>
+static const T *ff_up(psgpu_fwdflat_s *m, const T *src, size_t n, int *rc)
+{
+    void *d = nullptr;
+    if (*rc != PSGPU_OK) return nullptr;
+    const size_t bytes = n * sizeof(T);
+    if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess || hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        psgpu_set_error("fwdflat model upload failed");
+        *rc = PSGPU_ENOMEM;
+        hipFree(d);
+        return nullptr;
+    }
+    m->allocs.push_back(d);
+    return (const T *)d;
+}
+
+extern "C" {
+
+int psgpu_fwdflat_create(psgpu_fwdflat_t **out, const psgpu_fwdflat_tables_t *t)
+{
+    PSGPU_REQUIRE(out && t && t->ft && t->ft->par && t->pron_off && t->pron_ci && t->pron_ssid && t->ci_ssid && t->lm_known,
+                  "psgpu_fwdflat_create: NULL argument");
+    *out = nullptr;
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    const psgpu_fwdtree_tables_t *ft = t->ft;
+    const int32_t *q = ft->par;
+    psgpu_fwdflat_s *m = new psgpu_fwdflat_s();
+    FfDev &d = m->d;
+    memset(&d, 0, sizeof d);
+    d.n_ci = q[0]; d.n_emit = q[1]; d.n_sen = q[2]; d.n_w = q[3]; d.n1 = q[6];
+    d.beam = q[8]; d.pip = q[13]; d.silpen = q[15]; d.fillpen = q[16];
+    d.startwid = q[19]; d.finishwid = q[20]; d.silwid = q[21]; d.filler_start = q[22]; d.filler_end = q[23]; d.sil_ci = q[24];
+    d.fwdflatbeam = t->fwdflatbeam; d.fwdflatwbeam = t->fwdflatwbeam; d.min_ef_width = t->min_ef_width; d.max_sf_win = t->max_sf_win;
+    d.lwf = t->lwf;
+    if (!(d.n_emit == 3 || d.n_emit == 5) || d.n_ci < 1 || d.n_ci > kFfMaxCi || d.n_w < 1 || d.n1 < 1 ||
+        d.startwid < 0 || d.startwid >= d.n_w) {
+        psgpu_set_error("fwdflat: unsupported shape (n_emit %d, n_ci %d, words %d, single-phone words %d)", d.n_emit, d.n_ci, d.n_w, d.n1);
+        delete m;
+        return PSGPU_EINVAL;
+    }
+    const size_t nci3 = (size_t)d.n_ci * d.n_ci * d.n_ci, n1 = (size_t)d.n_w + 1;
+    std::vector<int32_t> w1_of(d.n_w, -1);
+    for (int i = 0; i < d.n1; ++i) w1_of[ft->w1_wid[i]] = i;
+    if (w1_of[d.startwid] < 0 || w1_of[d.silwid] < 0) {
+        psgpu_set_error("fwdflat: <s> and <sil> must be single-phone words");
+        delete m;
+        return PSGPU_EINVAL;
+    }
+    const size_t n_pron = (size_t)t->pron_off[d.n_w];
+    d.w1_wid = ff_up(m, ft->w1_wid, d.n1, &rc); d.w1_ci2 = ff_up(m, ft->w1_ci2, d.n1, &rc);
+    d.w1_ssid = ff_up(m, ft->w1_ssid, d.n1, &rc); d.w1_tmat = ff_up(m, ft->w1_tmat, d.n1, &rc); d.w1_mpx = ff_up(m, ft->w1_mpx, d.n1, &rc);
+    d.w1_of_word = ff_up(m, w1_of.data(), d.n_w, &rc);
+    d.d_pronlen = ff_up(m, ft->dict_pronlen, d.n_w, &rc); d.d_first = ff_up(m, ft->dict_first, d.n_w, &rc);
+    d.d_last = ff_up(m, ft->dict_last, d.n_w, &rc); d.d_last2 = ff_up(m, ft->dict_last2, d.n_w, &rc);
+    d.d_base = ff_up(m, ft->dict_basewid, d.n_w, &rc); d.d_filler = ff_up(m, ft->dict_filler, d.n_w, &rc);
+    d.rs_n = ff_up(m, ft->rssid_n, (size_t)d.n_ci * d.n_ci, &rc); d.rs_ssid = ff_up(m, ft->rssid_ssid, nci3, &rc);
+    d.rs_cimap = ff_up(m, ft->rssid_cimap, nci3, &rc); d.ldiph = ff_up(m, ft->ldiph_lc, nci3, &rc);
+    d.ci_tmat = ff_up(m, ft->ci_tmat, d.n_ci, &rc);
+    d.lm = ft->lm ? ff_up(m, ft->lm, (size_t)d.n_w * n1 * n1, &rc) : nullptr;
+    d.pron_off = ff_up(m, t->pron_off, (size_t)d.n_w + 1, &rc); d.pron_ci = ff_up(m, t->pron_ci, n_pron, &rc);
+    d.pron_ssid = ff_up(m, t->pron_ssid, n_pron, &rc); d.ci_ssid = ff_up(m, t->ci_ssid, d.n_ci, &rc);
+    d.tp = ff_up(m, ft->tp, (size_t)ft->n_tmat * d.n_emit * (d.n_emit + 1), &rc);
+    d.sseq = ff_up(m, ft->sseq, (size_t)ft->n_sseq * d.n_emit, &rc);
+    m->h_pronlen.assign(ft->dict_pronlen, ft->dict_pronlen + d.n_w);
+    m->h_last.assign(ft->dict_last, ft->dict_last + d.n_w); m->h_last2.assign(ft->dict_last2, ft->dict_last2 + d.n_w);
+    m->h_rs_n.assign(ft->rssid_n, ft->rssid_n + (size_t)d.n_ci * d.n_ci);
+    m->h_known.assign(t->lm_known, t->lm_known + d.n_w);
+    if (rc != PSGPU_OK) { psgpu_fwdflat_free(m); return rc; }
+    *out = m;
+    return PSGPU_OK;
+}
+
+const LmDev *psgpu_lm_dev(const psgpu_lm_t *lm);     // psgpu_lm.hip
+
+int psgpu_fwdflat_set_lm(psgpu_fwdflat_t *m, const psgpu_lm_t *lm)
+{
+    PSGPU_REQUIRE(m && lm, "psgpu_fwdflat_set_lm: NULL argument");
+    const LmDev *d = psgpu_lm_dev(lm);
+    PSGPU_REQUIRE(d->n_words == m->d.n_w, "psgpu_fwdflat_set_lm: the model maps %d dictionary words, the search has %d", d->n_words, m->d.n_w);
+    m->d.trie = *d;
+    m->d.use_trie = 1;
+    return PSGPU_OK;
+}
+
+void psgpu_fwdflat_free(psgpu_fwdflat_t *m)
+{
+    if (!m) return;
+    for (void *p : m->allocs) hipFree(p);
+    delete m;
+}
+
+}  // extern "C"
+
+// build_fwdflat_wordlist (:223-300) for one utterance from the first pass's back-pointer columns (frame, wid, bp):
+// one node per (start frame, word), new nodes at the head of their start frame's list, nodes with too few end points
+// (and </s> not ending in the last frame) dropped, the vocabulary in order of first appearance walking the frames.
+struct FfVocab { std::vector<int32_t> wid, chain, len, node_off, node_sf; int32_t n_chan = 0; };
+
+static void ff_build_vocab(const psgpu_fwdflat_s *m, const int32_t *fr, const int32_t *wid, const int32_t *bpc, int nb,
+                           int n_frame, int32_t chan_base, FfVocab &v)
+{
+    const FfDev &d = m->d;
+    std::vector<int32_t> n_sf, n_wid, n_fef, n_lef, n_next, head(n_frame + 2, -1);
+    for (int i = 0; i < nb; ++i) {
+        const int sf = bpc[i] < 0 ? 0 : fr[bpc[i]] + 1, ef = fr[i], w = wid[i];
+        if (w < 0 || w >= d.n_w || sf > n_frame || !m->h_known[w]) continue;
+        int nd;
+        for (nd = head[sf]; nd >= 0 && n_wid[nd] != w; nd = n_next[nd]);
+        if (nd >= 0) n_lef[nd] = ef;
+        else {
+            n_sf.push_back(sf); n_wid.push_back(w); n_fef.push_back(ef); n_lef.push_back(ef);
+            n_next.push_back(head[sf]); head[sf] = (int32_t)n_sf.size() - 1;
+        }
+    }
+    for (int f = 0; f < n_frame; ++f) {
+        int prev = -1, next;
+        for (int nd = head[f]; nd >= 0; nd = next) {
+            next = n_next[nd];
+            if (n_lef[nd] - n_fef[nd] < d.min_ef_width || (n_wid[nd] == d.finishwid && n_lef[nd] < n_frame - 1)) {
+                if (prev < 0) head[f] = next; else n_next[prev] = next;
+            }
+            else prev = nd;
+        }
+    }
+    std::vector<int32_t> slot(d.n_w, -1);
+    std::vector<std::vector<int32_t>> sfs;
+    for (int f = 0; f < n_frame; ++f)
+        for (int nd = head[f]; nd >= 0; nd = n_next[nd]) {
+            const int w = n_wid[nd];
+            if (slot[w] < 0) { slot[w] = (int32_t)v.wid.size(); v.wid.push_back(w); sfs.emplace_back(); }
+            sfs[slot[w]].push_back(f);
+        }
+    int32_t c = chan_base;
+    v.node_off.push_back(0);
+    for (size_t k = 0; k < v.wid.size(); ++k) {
+        const int w = v.wid[k];
+        if (m->h_pronlen[w] == 1) { v.chain.push_back(-1); v.len.push_back(1); }
+        else {
+            const int len = 1 + (m->h_pronlen[w] - 2) + m->h_rs_n[m->h_last[w] * d.n_ci + m->h_last2[w]];
+            v.chain.push_back(c); v.len.push_back(len); c += len;
+        }
+        v.node_sf.insert(v.node_sf.end(), sfs[k].begin(), sfs[k].end());
+        v.node_off.push_back((int32_t)v.node_sf.size());
+    }
+    v.n_chan = c - chan_base;
+}
+
+extern "C" int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                                        const int32_t *utt_off_dev, int32_t n_utt, int32_t max_frames,
+                                        int32_t bp1_cap, const int32_t *bp1_dev, const int32_t *result1_dev,
+                                        const int32_t *w1_ssid_dev, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev,
+                                        int32_t *bss_dev, int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0 && bp1_cap > 0, "psgpu_fwdflat_search_dev: bad argument");
+    PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdflat_search_dev: no language model (dense table or psgpu_fwdflat_set_lm)");
+    if (n_utt == 0) return PSGPU_OK;
+    PSGPU_REQUIRE(senscr_dev && utt_off_dev && bp1_dev && result1_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
+                  "psgpu_fwdflat_search_dev: NULL device buffer");
+    const FfDev &d = m->d;
+    hipStream_t st = (hipStream_t)stream;
+    // ---- the first pass's tables to the host: counts, then the three columns the vocabulary needs
+    std::vector<int32_t> res1((size_t)n_utt * 8);
+    PSGPU_HIP(hipMemcpyAsync(res1.data(), result1_dev, sizeof(int32_t) * res1.size(), hipMemcpyDeviceToHost, st));
+    PSGPU_HIP(hipStreamSynchronize(st));
+    std::vector<std::vector<int32_t>> cols((size_t)n_utt * 3);
+    for (int u = 0; u < n_utt; ++u) {
+        const int nb = res1[(size_t)u * 8];
+        PSGPU_REQUIRE(nb >= 0 && nb <= bp1_cap, "psgpu_fwdflat_search_dev: utterance %d: %d first-pass back-pointers, capacity %d", u, nb, bp1_cap);
+        static const int kCol[3] = {F_FRAME, F_WID, F_BP};
+        for (int k = 0; k < 3; ++k) {
+            cols[(size_t)u * 3 + k].resize(nb);
+            if (nb) PSGPU_HIP(hipMemcpyAsync(cols[(size_t)u * 3 + k].data(), bp1_dev + ((size_t)u * 10 + kCol[k]) * bp1_cap,
+                                             sizeof(int32_t) * nb, hipMemcpyDeviceToHost, st));
+        }
+    }
+    PSGPU_HIP(hipStreamSynchronize(st));
+    // ---- vocabulary + chain layout per utterance, slab sizes
+    std::vector<FfVocab> voc(n_utt);
+    std::vector<size_t> slab_off(n_utt + 1, 0), voc_off(n_utt + 1, 0);
+    const int n_tail = d.n_w - d.startwid;
+    for (int u = 0; u < n_utt; ++u) {
+        const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
+        ff_build_vocab(m, cols[(size_t)u * 3].data(), cols[(size_t)u * 3 + 1].data(), cols[(size_t)u * 3 + 2].data(), nb, nfr, d.n1, voc[u]);
+        const size_t C = (size_t)d.n1 + voc[u].n_chan, nwd = voc[u].wid.size(), cap = nwd + n_tail + 1;
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 4) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16;
+        voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
+    }
+    int32_t *slab = nullptr, *vdev = nullptr;
+    FfUtt *d_utts = nullptr;
+    PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * slab_off[n_utt]));
+    hipError_t e = hipMalloc((void **)&vdev, sizeof(int32_t) * voc_off[n_utt]);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_utts, sizeof(FfUtt) * n_utt);
+    std::vector<int32_t> vhost(voc_off[n_utt]);
+    std::vector<FfUtt> hu(n_utt);
+    for (int i = 0; i < n_utt && e == hipSuccess; ++i) {
+        FfUtt &u = hu[i];
+        const FfVocab &v = voc[i];
+        const size_t nwd = v.wid.size(), C = (size_t)d.n1 + v.n_chan, cap = nwd + n_tail + 1;
+        int32_t *vh = vhost.data() + voc_off[i], *vd = vdev + voc_off[i];
+        auto put = [&](const std::vector<int32_t> &a, size_t n) { const int32_t *r = vd; if (n) memcpy(vh, a.data(), sizeof(int32_t) * n); vh += n; vd += n; return r; };
+        u.nwd = (int32_t)nwd; u.n_chan = v.n_chan; u.n_frame = res1[(size_t)i * 8 + 2]; u.awl_cap = (int32_t)cap;
+        u.wl_wid = put(v.wid, nwd); u.wl_chain = put(v.chain, nwd); u.wl_len = put(v.len, nwd);
+        u.wl_node_off = put(v.node_off, nwd + 1); u.node_sf = put(v.node_sf, v.node_sf.size());
+        int32_t *q = slab + slab_off[i];
+        auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
+        u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
+        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C);
+        u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
+        u.awl[0] = take(cap); u.awl[1] = take(cap);
+        u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
+        u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
+        u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
+        u.result = result_dev + (size_t)i * 8;
+        u.w1_ssid_in = w1_ssid_dev ? w1_ssid_dev + (size_t)i * d.n1 * d.n_emit : nullptr;
+        u.bp_cap = bp_cap; u.bss_cap = bss_cap;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(vdev, vhost.data(), sizeof(int32_t) * vhost.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FfUtt) * n_utt, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          // the host vectors are about to go out of scope
+    if (e != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); PSGPU_HIP(e); }
+    if (d.n_emit == 3)
+        hipLaunchKernelGGL((fwdflat_kernel<3>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev);
+    else
+        hipLaunchKernelGGL((fwdflat_kernel<5>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
+    hipFree(slab); hipFree(vdev); hipFree(d_utts);
+    PSGPU_HIP(e);
+    return PSGPU_OK;
+}

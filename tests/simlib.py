@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 SIM_DIR = os.path.join(HERE, "hostsim")
 CSRC = os.path.join(ROOT, "pocketsphinx_amd", "csrc")
 LIB = os.path.join(SIM_DIR, "_build", "libpsgpu_hostsim.so")
-SOURCES = [os.path.join(SIM_DIR, "hipsim.cc"), os.path.join(CSRC, "psgpu_search.hip"), os.path.join(CSRC, "psgpu_lm.hip")]
+SOURCES = [os.path.join(SIM_DIR, "hipsim.cc"), os.path.join(CSRC, "psgpu_search.hip"), os.path.join(CSRC, "psgpu_lm.hip"), os.path.join(CSRC, "psgpu_flat.hip")]
 DEPS = SOURCES + [os.path.join(SIM_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "psgpu.h")] + \
     [os.path.join(CSRC, h) for h in ("psgpu_internal.h", "psgpu_hmm_dev.h", "psgpu_lm_dev.h")]
 
@@ -109,6 +109,48 @@ class SimFwdtreeSearch:
         check(lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
                                              p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window), None),
               "psgpu_fwdtree_search_dev")
+        out = []
+        for u in range(n):
+            nb, nh, nfr, status = [int(v) for v in res[u, :4]]
+            out.append(dict(bp=bp[u, :, :nb].T.copy(), bscore_stack=bss[u, :nh].copy(), bp_table_idx=idx[u, :nfr + 1].copy(),
+                            step=step[u, :nfr].copy(), n_frame=nfr, status=status))
+        return out
+
+
+class SimFwdflatSearch:
+    """pocketsphinx_amd.flat.FwdflatSearch on the simulator."""
+
+    def __init__(self, static, fstatic, par, flat_par, lwf, lm=None):
+        from pocketsphinx_amd.flat import marshal
+        self._keep, self._ft, t = marshal(static, fstatic, par, flat_par, lwf, lm)
+        self.h = C.c_void_p()
+        check(lib().psgpu_fwdflat_create(C.byref(self.h), C.byref(t)), "psgpu_fwdflat_create")
+        self.lm = lm
+        if lm is not None:
+            check(lib().psgpu_fwdflat_set_lm(self.h, lm.h), "psgpu_fwdflat_set_lm")
+        self.n_sen = int(par[2]); self.n1 = int(par[6]); self.n_emit = int(par[1])
+
+    def close(self):
+        if self.h:
+            lib().psgpu_fwdflat_free(self.h)
+            self.h = C.c_void_p()
+
+    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19):
+        off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
+        n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
+        d_s = np.ascontiguousarray(senscr, np.int16)
+        assert d_s.shape == (int(off[-1]), self.n_sen)
+        cap1 = max(1, max(int(b.shape[0]) for b in bp1))
+        h_bp1 = np.zeros((n, 10, cap1), np.int32); h_res1 = np.zeros((n, 8), np.int32)
+        for u, b in enumerate(bp1):
+            h_bp1[u, :, :b.shape[0]] = np.asarray(b, np.int32).T
+            h_res1[u, 0] = b.shape[0]; h_res1[u, 2] = utt_lens[u]
+        d_w1 = None if w1_ssid is None else np.ascontiguousarray(np.stack([np.asarray(w, np.int32) for w in w1_ssid]), np.int32)
+        bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
+        idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
+        check(lib().psgpu_fwdflat_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(off), n, mf, cap1, p(h_bp1), p(h_res1), p(d_w1),
+                                             bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), None), "psgpu_fwdflat_search_dev")
         out = []
         for u in range(n):
             nb, nh, nfr, status = [int(v) for v in res[u, :4]]

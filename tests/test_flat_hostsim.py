@@ -1,0 +1,61 @@
+"""CPU check of the flat-lexicon second-pass KERNEL SOURCE (pocketsphinx_amd/csrc/psgpu_flat.hip) on the
+workgroup simulator of tests/hostsim: given what the reference's first pass handed over and the senone scores
+its second pass was handed, the kernel must reproduce the second pass's back-pointer table, score stack, frame
+marks and per-frame best score / back-pointer count (goldens of tests/test_oracle_flat.py), in any work-item
+order.  Logic only -- tests/test_zz_flat_gpu.py is the parity test proper."""
+import numpy as np
+import pytest
+
+import simlib
+from test_oracle_flat import FLAT_CASES, load_flat
+from test_search_hostsim import _order
+
+
+def flat_rows(g, n_sen):
+    n = int(g["flat_n_steps"][0])
+    off, act, scr = g["flat_act_off"], g["flat_act"], g["flat_scr"]
+    rows = np.empty((n, n_sen), np.int16)
+    for i in range(n):
+        rows[i] = g["flat_rest"][i]
+        rows[i, act[off[i]:off[i + 1]]] = scr[off[i]:off[i + 1]]
+    return rows
+
+
+def check_flat(r, g, what):
+    n = int(g["flat_n_steps"][0])
+    assert r["status"] == 0 and r["n_frame"] == n, what
+    ref = np.stack([g["flat_best"], g["flat_bpidx"]], axis=1)
+    got = r["step"][:, [0, 2]]
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, "%s: first diverging frame %d: kernel %r reference %r" % (what, bad[0], got[bad[0]], ref[bad[0]])
+    assert r["bp"].shape == g["bp"].shape, what
+    badbp = np.nonzero((r["bp"] != g["bp"]).any(axis=1))[0]
+    assert badbp.size == 0, "%s: back-pointer %d: %r vs %r" % (what, badbp[0], r["bp"][badbp[0]], g["bp"][badbp[0]])
+    assert np.array_equal(r["bscore_stack"], g["bscore_stack"]), what
+    assert np.array_equal(r["bp_table_idx"], g["bp_table_idx"]), what
+
+
+@pytest.mark.parametrize("order", ["fwd", "rev", "shuffle:11"])
+@pytest.mark.parametrize("case", FLAT_CASES)
+def test_flat_kernel_source_on_the_simulator(case, order):
+    g, st, fst = load_flat(case)
+    lm = simlib.SimLm(fst) if "lm" not in st else None
+    with _order(order):
+        s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"], lm=lm)
+        r = s.search(flat_rows(g, s.n_sen), [int(g["flat_n_steps"][0])], [g["bp1"]], [g["flat_w1_ssid"]])[0]
+        check_flat(r, g, "%s (%s)" % (case, order))
+        s.close()
+
+
+def test_flat_kernel_source_batch_of_utterances():
+    """several workgroups per launch, each with its own vocabulary and chain layout"""
+    names = ["goforward", "numbers"]
+    loaded = [load_flat(n) for n in names]
+    g0, st, fst = loaded[0]
+    s = simlib.SimFwdflatSearch(st, fst, g0["par"], g0["flat_par"], g0["flat_lwf"])
+    gs = [loaded[0][0], loaded[1][0], loaded[0][0]]
+    rows = [flat_rows(g, s.n_sen) for g in gs]
+    out = s.search(np.concatenate(rows), [r.shape[0] for r in rows], [g["bp1"] for g in gs], [g["flat_w1_ssid"] for g in gs])
+    for r, g in zip(out, gs):
+        check_flat(r, g, "batch")
+    s.close()
