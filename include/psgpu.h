@@ -588,6 +588,12 @@ int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
 #define PSGPU_FWDTREE_PER_NODE 0
 #define PSGPU_FWDTREE_ACTIVE_LIST 1
 int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode);
+/* Hand-over to the second pass: subsequent searches also write, per utterance u, the per-state ssids (multiplex
+ * HMMs: hmm_mpx_ssid) their permanent single-phone word channels ended with to w1_ssid_dev + u*n_1ph*n_emit --
+ * ngram_fwdflat_start clears those channels' scores but not their ssids (ngram_search_fwdflat.c:385-392), so they
+ * are part of what psgpu_fwdflat_search_dev takes over.  NULL switches it off.  The buffer must hold n_utt
+ * utterances of the next call. */
+int psgpu_fwdtree_set_w1_ssid_out(psgpu_fwdtree_t *m, int32_t *w1_ssid_dev);
 
 /* ---- flat-lexicon second pass of whole utterances, first version ----------
  * Replaces ngram_fwdflat_start + ngram_fwdflat_search per frame + ngram_fwdflat_finish

@@ -53,6 +53,7 @@ struct FtDev {
     int32_t big;                         // tree or vocabulary beyond the LDS scratch: list / word scratch in the utterance's slab
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
     int32_t list_mode;                   // PSGPU_FWDTREE_ACTIVE_LIST: per-frame work proportional to the active channels
+    int32_t *w1_out;                     // optional [n_utt][n1][n_emit]: the single-phone channels' ssids when the pass ends
     LmDev trie;
 };
 
@@ -893,6 +894,11 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         u.result[0] = s_sc[3]; u.result[1] = s_sc[4]; u.result[2] = s_sc[7]; u.result[3] = s_sc[6];
         u.result[4] = s_sc[0];                                   // ngs->best_score as the last frame left it
     }
+    // what the second pass inherits besides the tables: the permanent single-phone channels keep their per-state ssids
+    // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)
+    if (p.w1_out)
+        for (int i = tid; i < p.n1 * NE; i += NT)
+            p.w1_out[((size_t)blockIdx.x * p.n1 + i / NE) * NE + i % NE] = u.senid[(W1 + i / NE) * 5 + i % NE];
 }
 
 // ---------------------------------------------------------------------------
@@ -988,6 +994,13 @@ int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode)
 {
     PSGPU_REQUIRE(m && (mode == PSGPU_FWDTREE_PER_NODE || mode == PSGPU_FWDTREE_ACTIVE_LIST), "psgpu_fwdtree_set_mode: bad argument");
     m->d.list_mode = mode;
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_set_w1_ssid_out(psgpu_fwdtree_t *m, int32_t *w1_ssid_dev)
+{
+    PSGPU_REQUIRE(m, "psgpu_fwdtree_set_w1_ssid_out: NULL argument");
+    m->d.w1_out = w1_ssid_dev;
     return PSGPU_OK;
 }
 

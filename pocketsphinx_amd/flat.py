@@ -55,7 +55,7 @@ class FwdflatSearch:
 
     def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19):
         """senscr [T][n_sen] int16 for utterances back to back; bp1: per utterance the first pass's back-pointer
-        table [n][10] (numpy; or a tuple of device tensors (bp_dev [n_utt][10][cap], result_dev [n_utt][8]) as
+        table [n][10] (numpy), or the `handover` dict FwdtreeSearch.search filled (device buffers as
         psgpu_fwdtree_search_dev left them); w1_ssid: per utterance [n_1ph][n_emit] or None.
         Returns a list of dicts like FwdtreeSearch.search."""
         import torch
@@ -65,8 +65,9 @@ class FwdflatSearch:
         if not torch.is_tensor(senscr):
             senscr = torch.from_numpy(np.ascontiguousarray(senscr, np.int16)).to(dev)
         assert tuple(senscr.shape) == (T, self.n_sen) and senscr.dtype == torch.int16
-        if isinstance(bp1, tuple):
-            d_bp1, d_res1 = bp1
+        d_w1 = None
+        if isinstance(bp1, dict):                 # FwdtreeSearch.search(handover=...): everything stays on the device
+            d_bp1, d_res1, d_w1 = bp1["bp"], bp1["result"], bp1["w1_ssid"]
             cap1 = int(d_bp1.shape[2])
         else:
             cap1 = max(1, max(int(b.shape[0]) for b in bp1))
@@ -75,7 +76,6 @@ class FwdflatSearch:
                 h_bp1[u, :, :b.shape[0]] = np.asarray(b, np.int32).T
                 h_res1[u, 0] = b.shape[0]; h_res1[u, 2] = utt_lens[u]
             d_bp1 = torch.from_numpy(h_bp1).to(dev); d_res1 = torch.from_numpy(h_res1).to(dev)
-        d_w1 = None
         if w1_ssid is not None:
             d_w1 = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(w, np.int32) for w in w1_ssid]), np.int32)).to(dev)
             assert tuple(d_w1.shape) == (n, self.n1, self.n_emit)

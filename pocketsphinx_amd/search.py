@@ -53,9 +53,10 @@ class FwdtreeSearch:
         except Exception:
             pass
 
-    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0):
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None):
         """senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back (numpy arrays, or
         torch tensors already on the device).  raw_scores: un-normalised rows + phone-loop output, see psgpu.h.
+        handover: a dict that receives the device buffers a second pass takes over (FwdflatSearch.search(bp1=...)).
         Returns a list of dicts (bp [n][10], bscore_stack, bp_table_idx, step [frames][4], status) per utterance."""
         import torch
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -74,6 +75,10 @@ class FwdtreeSearch:
         step = torch.zeros((n, max(mf, 1), 4), dtype=torch.int32, device=dev)
         res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        if handover is not None:
+            w1 = torch.zeros((n, int(self._keep["par"][6]), int(self._keep["par"][1])), dtype=torch.int32, device=dev)
+            capi.check(capi.lib().psgpu_fwdtree_set_w1_ssid_out(self.h, p(w1)), "psgpu_fwdtree_set_w1_ssid_out")
+            handover.update(bp=bp, result=res, w1_ssid=w1)
         capi.check(capi.lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap,
                                                        bss_cap, p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)),
                                                        int(pl_window), C.c_void_p(torch.cuda.current_stream().cuda_stream)),

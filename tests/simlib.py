@@ -91,14 +91,15 @@ class SimFwdtreeSearch:
             check(lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
         if list_mode is not None:
             check(lib().psgpu_fwdtree_set_mode(self.h, int(list_mode)), "psgpu_fwdtree_set_mode")
-        self.n_sen = int(par[2]); self.n_ci = int(par[0])
+        self.n_sen = int(par[2]); self.n_ci = int(par[0]); self.n1 = int(par[6]); self.n_emit = int(par[1])
 
     def close(self):
         if self.h:
             lib().psgpu_fwdtree_free(self.h)
             self.h = C.c_void_p()
 
-    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0):
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None):
+        """handover: a dict that receives the buffers a second pass takes over (bp [n][10][cap], result [n][8], w1_ssid)"""
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
         n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
         d_s = np.ascontiguousarray(senscr, np.int16); d_p = np.ascontiguousarray(penalties, np.int32)
@@ -106,6 +107,10 @@ class SimFwdtreeSearch:
         bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
         idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
         p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        if handover is not None:
+            w1 = np.zeros((n, self.n1, self.n_emit), np.int32)
+            check(lib().psgpu_fwdtree_set_w1_ssid_out(self.h, p(w1)), "psgpu_fwdtree_set_w1_ssid_out")
+            handover.update(bp=bp, result=res, w1_ssid=w1, bp_cap=bp_cap)
         check(lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
                                              p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window), None),
               "psgpu_fwdtree_search_dev")
@@ -136,16 +141,20 @@ class SimFwdflatSearch:
             self.h = C.c_void_p()
 
     def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19):
+        """bp1: per utterance the first pass's table [n][10], or the `handover` dict of SimFwdtreeSearch.search"""
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
         n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
         d_s = np.ascontiguousarray(senscr, np.int16)
         assert d_s.shape == (int(off[-1]), self.n_sen)
-        cap1 = max(1, max(int(b.shape[0]) for b in bp1))
-        h_bp1 = np.zeros((n, 10, cap1), np.int32); h_res1 = np.zeros((n, 8), np.int32)
-        for u, b in enumerate(bp1):
-            h_bp1[u, :, :b.shape[0]] = np.asarray(b, np.int32).T
-            h_res1[u, 0] = b.shape[0]; h_res1[u, 2] = utt_lens[u]
-        d_w1 = None if w1_ssid is None else np.ascontiguousarray(np.stack([np.asarray(w, np.int32) for w in w1_ssid]), np.int32)
+        if isinstance(bp1, dict):
+            h_bp1, h_res1, cap1, d_w1 = bp1["bp"], bp1["result"], bp1["bp_cap"], bp1["w1_ssid"]
+        else:
+            cap1 = max(1, max(int(b.shape[0]) for b in bp1))
+            h_bp1 = np.zeros((n, 10, cap1), np.int32); h_res1 = np.zeros((n, 8), np.int32)
+            for u, b in enumerate(bp1):
+                h_bp1[u, :, :b.shape[0]] = np.asarray(b, np.int32).T
+                h_res1[u, 0] = b.shape[0]; h_res1[u, 2] = utt_lens[u]
+            d_w1 = None if w1_ssid is None else np.ascontiguousarray(np.stack([np.asarray(w, np.int32) for w in w1_ssid]), np.int32)
         bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
         idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
         p = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731

@@ -59,3 +59,24 @@ def test_flat_kernel_source_batch_of_utterances():
     for r, g in zip(out, gs):
         check_flat(r, g, "batch")
     s.close()
+
+
+@pytest.mark.parametrize("case", ["goforward", "numbers", "man_ah_2934za"])
+def test_two_passes_chained_on_the_simulator(case):
+    """First-pass kernel -> second-pass kernel with nothing but the kernels' own buffers in between: the tree search
+    on the first pass's trace leaves its back-pointer table, result record and the single-phone channels' ssids
+    (psgpu_fwdtree_set_w1_ssid_out); the flat search takes them over and must end with the reference's pass-2
+    tables.  The hand-over itself is checked against what the reference's first pass left."""
+    from test_oracle_golden import _load
+    from test_search_gpu import _inputs
+    g, st, fst = load_flat(case)
+    g1 = _load("fwdtree_trace_%s.npz" % case)
+    s1 = simlib.SimFwdtreeSearch(st, g1["par"], list_mode=1)
+    rows1, pen1 = _inputs(g1, s1.n_sen)
+    h = {}
+    r1 = s1.search(rows1, pen1, [rows1.shape[0]], handover=h)[0]
+    assert np.array_equal(r1["bp"], g["bp1"]) and np.array_equal(h["w1_ssid"][0], g["flat_w1_ssid"])
+    s2 = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+    r2 = s2.search(flat_rows(g, s2.n_sen), [int(g["flat_n_steps"][0])], h)[0]
+    check_flat(r2, g, case)
+    s1.close(); s2.close()

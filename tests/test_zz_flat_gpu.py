@@ -36,3 +36,23 @@ def test_fwdflat_kernel_batch_of_utterances():
     for r, g in zip(out, gs):
         check_flat(r, g, "batch")
     s.close()
+
+
+@pytest.mark.parametrize("case", ["goforward", "numbers", "man_ah_2934za"])
+def test_two_passes_chained_on_the_device(case):
+    """tree search -> flat search, the hand-over (back-pointer table, result record, single-phone ssids) staying in
+    device buffers; the second pass must end with the reference's pass-2 tables"""
+    import pocketsphinx_amd as P
+    from test_oracle_golden import _load
+    from test_search_gpu import _inputs
+    g, st, fst = load_flat(case)
+    g1 = _load("fwdtree_trace_%s.npz" % case)
+    s1 = P.FwdtreeSearch(st, g1["par"])
+    rows1, pen1 = _inputs(g1, s1.n_sen)
+    h = {}
+    r1 = s1.search(rows1, pen1, [rows1.shape[0]], handover=h)[0]
+    assert np.array_equal(r1["bp"], g["bp1"]) and np.array_equal(h["w1_ssid"][0].cpu().numpy(), g["flat_w1_ssid"])
+    s2 = P.FwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+    r2 = s2.search(flat_rows(g, s2.n_sen), [int(g["flat_n_steps"][0])], h)[0]
+    check_flat(r2, g, case)
+    s1.close(); s2.close()
