@@ -218,6 +218,10 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     t.tp = tp; t.sseq = sq; t.ci_tmat = ptm; t.lm = lm; t.n_tmat = n_tmat; t.n_sseq = n_sseq;
     i = lm_ok ? psgpu_fwdtree_create(&d->ft, &t) : PSGPU_EINVAL;
     if (i == PSGPU_OK && d->lm) i = psgpu_fwdtree_set_lm(d->ft, d->lm);
+    /* PSGPU_FWDTREE_MODE=active_list: the large-vocabulary formulation of the kernel (psgpu.h, psgpu_fwdtree_set_mode);
+     * same tables, per-frame work proportional to the active channels */
+    if (i == PSGPU_OK && getenv("PSGPU_FWDTREE_MODE") && !strcmp(getenv("PSGPU_FWDTREE_MODE"), "active_list"))
+        i = psgpu_fwdtree_set_mode(d->ft, PSGPU_FWDTREE_ACTIVE_LIST);
     if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, n_tmat, tp, n_sseq, sq, d->n_sen);
     /* ---- the phone loop (cf. psgpu_phone_loop_shim.c) */
     pls = (phone_loop_search_t *)ps->phone_loop;

@@ -41,7 +41,10 @@ def main():
             "en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
         lm = P.NGramTrieLM({k: lmsrc[k] for k in (lmsrc.files if hasattr(lmsrc, "files") else lmsrc)})
     print("case %s, %d words, %d tree nodes, LM: %s" % (case, int(g["par"][3]), int(g["par"][4] + g["par"][5]), "trie" if lm else "dense"))
-    s = P.FwdtreeSearch(st, g["par"], lm=lm)
+    # SB_MODE = active_list: psgpu_fwdtree_set_mode(PSGPU_FWDTREE_ACTIVE_LIST)
+    mode = P.FwdtreeSearch.ACTIVE_LIST if os.environ.get("SB_MODE", "") == "active_list" else None
+    print("mode:", "ACTIVE_LIST" if mode else "PER_NODE")
+    s = P.FwdtreeSearch(st, g["par"], lm=lm, mode=mode)
     rows, pen = _inputs(g, s.n_sen)
     import ctypes as C
     from pocketsphinx_amd import capi
