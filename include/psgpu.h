@@ -631,6 +631,26 @@ int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int6
                              int32_t bp1_cap, const int32_t *bp1_dev, const int32_t *result1_dev,
                              const int32_t *w1_ssid_dev, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev,
                              int32_t *bss_dev, int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream);
+/* The same with the scores produced inside the kernel (PTM models), so that the second pass needs nothing from the host
+ * but its launch: feats_dev [total][veclen] float (psgpu_feat_1s_c_d_dd_dev's output), `ptm` = device pointers to the
+ * scorer's tables (psgpu_ptm_model_view), topn_seed_dev [n_utt][n_mgau * n_feat][topn] = the codewords of the history
+ * slot pass-2 frame 0 is seeded from (ptm_mgau.c:425-441: slot n_fast_hist - 1 as the first pass left it, i.e. the lists
+ * of the last first-pass frame t with t % n_fast_hist == n_fast_hist - 1; psgpu_ptm_score_batch_dev's topn_cw rows).
+ * Per frame the kernel restates ptm_mgau_frame_eval as the second pass calls it: its own active senone list, only the
+ * codebooks that list touches scanned and normalised (which is why these scores are not a shift of the first pass's rows). */
+typedef struct psgpu_ptm_view_s {
+    const float *mean, *var, *det;            /* as psgpu_ptm_model_create took them */
+    const uint8_t *mixw, *sen2cb, *logadd8;
+    int32_t n_mgau, n_feat, n_density, n_sen, veclen, topn, logadd8_size;
+    int32_t featlen[16], featoff[16];
+} psgpu_ptm_view_t;
+int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out);
+int psgpu_fwdflat_search_feats_dev(psgpu_fwdflat_t *m, const psgpu_ptm_view_t *ptm, const float *feats_dev,
+                                   const int32_t *topn_seed_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                   int32_t max_frames, int32_t bp1_cap, const int32_t *bp1_dev,
+                                   const int32_t *result1_dev, const int32_t *w1_ssid_dev, int32_t bp_cap,
+                                   int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev, int32_t *idx_dev,
+                                   int32_t *step_dev, int32_t *result_dev, void *stream);
 
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).

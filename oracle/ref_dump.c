@@ -920,6 +920,7 @@ static int ff_on, ff_phase;                 /* tracing a two-pass decode; inside
 static int32 *ff_bp1, *ff_bss1, *ff_idx1, *ff_w1ssid; static int ff_nb1, ff_nbss1, ff_nfr1;
 static int32 *ff_best, *ff_bpidx; static size_t ff_n, ff_cap;
 static int32 *ff_wordlist; static int ff_nwd;
+static int32 *ff_seed; static int ff_seed_dims[3]; static float *ff_feat; static int ff_feat_dim;
 static int32 *ff_act; static int16 *ff_scr, *ff_rest; static size_t ff_act_n, ff_act_cap; static int64_t *ff_act_off;
 
 static void
@@ -990,6 +991,25 @@ ff_finish(ps_search_t *search)
         root_chan_t *r = (root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]];
         for (k = 0; k < n_emit; ++k)
             ff_w1ssid[i * n_emit + k] = hmm_is_mpx(&r->hmm) ? hmm_mpx_ssid(&r->hmm, k) : hmm_nonmpx_ssid(&r->hmm);
+    }
+    /* what a second pass that scores its own senones needs on top: the feature rows, and -- PTM scorer -- the
+     * codeword lists the first pass left in the history slot pass-2 frame 0 starts from (ptm_mgau.c:425-441: slot 0
+     * is seeded from slot n_fast_hist - 1) */
+    {
+        acmod_t *acmod = ps_search_acmod(search);
+        int dim = feat_dimension(acmod->fcb), t;
+        ff_feat_dim = dim;
+        ff_feat = malloc(sizeof(float) * (size_t)(ff_nfr1 + 1) * dim);
+        for (t = 0; t < ff_nfr1; ++t) memcpy(ff_feat + (size_t)t * dim, acmod->feat_buf[t % acmod->n_feat_alloc][0], sizeof(float) * dim);
+        if (!strcmp(ft_morig->name, "ptm")) {
+            ptm_mgau_t *pm = (ptm_mgau_t *)acmod->mgau;
+            int m, f, k2, nm = pm->g->n_mgau, nf = pm->g->n_feat, tn = pm->max_topn;
+            ptm_fast_eval_t *fe = &pm->hist[pm->n_fast_hist - 1];
+            ff_seed = calloc((size_t)nm * nf * tn + 1, 4);
+            ff_seed_dims[0] = nm; ff_seed_dims[1] = nf; ff_seed_dims[2] = tn;
+            for (m = 0; m < nm; ++m) for (f = 0; f < nf; ++f) for (k2 = 0; k2 < tn; ++k2)
+                ff_seed[((size_t)m * nf + f) * tn + k2] = fe->topn[m][f][k2].cw;
+        }
     }
     ff_phase = 1;
     rv = ft_orig->finish(search);
@@ -1173,6 +1193,8 @@ traced:
         put1("bp_table_idx1", 'i', ff_nfr1 + 1, ff_idx1);
         put2("flat_w1_ssid", 'i', ngs->n_1ph_words, n_emit, ff_w1ssid);
         put1("flat_wordlist", 'i', ff_nwd, ff_wordlist);
+        put2("flat_feat", 'f', ff_nfr1, ff_feat_dim, ff_feat);
+        if (ff_seed) put3("flat_ptm_seed", 'i', ff_seed_dims[0], ff_seed_dims[1], ff_seed_dims[2], ff_seed);
         puti("flat_n_steps", (int32)ff_n);
         put1("flat_best", 'i', ff_n, ff_best); put1("flat_bpidx", 'i', ff_n, ff_bpidx);
         put1("flat_act_off", 'q', ff_n + 1, ff_act_off);

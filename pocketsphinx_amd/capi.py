@@ -32,7 +32,7 @@ SYMBOLS = [
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval", "psgpu_phone_loop_run_dev", "psgpu_hmm_ctx_stream",
     "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_set_lm", "psgpu_fwdtree_set_mode", "psgpu_fwdtree_set_w1_ssid_out",
-    "psgpu_fwdflat_create", "psgpu_fwdflat_free", "psgpu_fwdflat_set_lm", "psgpu_fwdflat_search_dev",
+    "psgpu_fwdflat_create", "psgpu_fwdflat_free", "psgpu_fwdflat_set_lm", "psgpu_fwdflat_search_dev", "psgpu_fwdflat_search_feats_dev", "psgpu_ptm_model_view",
     "psgpu_lm_create", "psgpu_lm_free", "psgpu_lm_tg_score_dev",
 ]
 

@@ -25,6 +25,24 @@
 
 constexpr int kFfThreads = 256;
 constexpr int kFfMaxCi = 64;
+constexpr int kFfMaxSen = 8192;        // senones (LDS bitmap of the frame's active list, scoring mode)
+constexpr int kFfMaxEnt = 1024;        // (codebook, stream) chains x top-N entries held in LDS (en-us PTM: 126 x 4)
+constexpr int kFfMaxCb = 256;          // codebooks
+constexpr int kFfMaxTopn = 8;
+
+// Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
+// each frame's senone scores itself, as ptm_mgau_frame_eval does when the second pass calls it (ptm_mgau.c:408-454 with
+// compallsen off): the frame's active senone list from the active channels (compute_fwdflat_sen_active +
+// acmod_flags2list, bridging entries included), the codebooks those senones touch (:297-321), every carried list
+// re-scored (eval_topn :87-136), the touched codebooks scanned exactly as the reference scans them (eval_cb :151-226,
+// one work-item per (codebook, stream), sequential in codeword order -- the acceptance rule depends on it), the
+// per-stream normaliser over the touched codebooks only (:265-295), the listed senones (:326-403).  This is why pass-2
+// scores are not a shift of pass-1 rows: in pass 1 the phone loop keeps every codebook touched, here nothing does.
+struct FfRaw {
+    psgpu_ptm_view_t pm;
+    const float *feats;                  // [total][veclen]
+    const int32_t *seed;                 // [n_utt][n_chain][topn] codewords of the history slot pass-2 frame 0 starts from
+};
 
 struct FfDev {
     int32_t n_ci, n_emit, n_sen, n_w, n1;
@@ -55,6 +73,7 @@ struct FfUtt {
     int32_t *cnt_a, *cnt_b, *cnt_c;      // [max(awl_cap, nwd + fillers) + 1] scan scratch
     int32_t *bp, *bss, *bp_table_idx, *step, *result;
     const int32_t *w1_ssid_in;           // [n1][n_emit] or NULL
+    int16_t *nrow; int32_t *nrow32;      // [n_sen] the frame's scores (scoring mode)
     int32_t bp_cap, bss_cap;
 };
 
@@ -207,11 +226,45 @@ __device__ __forceinline__ int ff_root(const FfDev &p, const FfUtt &u, int w, in
     return p.w1_of_word[w];
 }
 
-template <int NE>
+// float -> int32 as the reference does (ptm_mgau.c:129-132, :220-223)
+__device__ __forceinline__ int32_t ff_dist_to_int(float d) { return (d < (float)kMaxNegInt32) ? kMaxNegInt32 : (int32_t)d; }
+// the diagonal-Gaussian distance of ptm_mgau.c:102-128: fp32, one rounding per operation, dimensions in order
+__device__ __forceinline__ float ff_density(const psgpu_ptm_view_t &pm, const float *x, size_t base, int chain, int cw, int len)
+{
+    float d = pm.det[(size_t)chain * pm.n_density + cw];
+    const float *m = pm.mean + base + (size_t)cw * len, *v = pm.var + base + (size_t)cw * len;
+    for (int j = 0; j < len; ++j) {
+        const float diff = __fsub_rn(x[j], m[j]);
+        d = __fsub_rn(d, __fmul_rn(__fmul_rn(diff, diff), v[j]));
+    }
+    return d;
+}
+// out[t] = max of v over work-items 0 .. t - 1 (-1 for work-item 0).  Ends with a barrier.
+__device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    int32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
+    if (lane == 63) tmp[tid >> 6] = incl;
+    int32_t excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = -1;
+    __syncthreads();
+    for (int w = 0; w < (tid >> 6); ++w) excl = max(excl, tmp[w]);
+    __syncthreads();
+    return excl;
+}
+
+template <int NE, bool RAW>
 __global__ __launch_bounds__(kFfThreads)
 void fwdflat_kernel(FfDev p, const FfUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
-                    const int32_t *__restrict__ utt_off)
+                    const int32_t *__restrict__ utt_off, FfRaw rw)
 {
+    __shared__ uint32_t s_bits[RAW ? kFfMaxSen / 32 : 1];
+    __shared__ int32_t s_prev[RAW ? kFfMaxSen / 32 : 1];
+    __shared__ int32_t s_lcw[RAW ? kFfMaxEnt : 1], s_lsc[RAW ? kFfMaxEnt : 1];   // the scorer's lists: codeword, score
+    __shared__ uint8_t s_cbact[RAW ? kFfMaxCb : 1], s_la[RAW ? 256 : 1];
+    __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64];
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, best sil score, best sil bp, n real exits
     __shared__ unsigned long long s_key;
@@ -248,11 +301,142 @@ void fwdflat_kernel(FfDev p, const FfUtt *__restrict__ utts, const int16_t *__re
         u.awl[0][0] = p.startwid;
     }
     n_awl[0] = 1;
+    const int n_chain = RAW ? rw.pm.n_mgau * rw.pm.n_feat : 0, topn = RAW ? rw.pm.topn : 0;
+    if (RAW) {
+        for (int i = tid; i < n_chain * topn; i += kFfThreads) { s_lcw[i] = rw.seed[(size_t)blockIdx.x * n_chain * topn + i]; s_lsc[i] = 0; }
+        for (int i = tid; i < 256; i += kFfThreads) s_la[i] = i < rw.pm.logadd8_size ? rw.pm.logadd8[i] : 0;
+    }
     __syncthreads();
 
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = n_awl[cur];
-        const int16_t *row = senscr + (size_t)(t0 + f) * scr_stride;
+        const int16_t *row = RAW ? nullptr : senscr + (size_t)(t0 + f) * scr_stride;
+        if (RAW) {
+            const psgpu_ptm_view_t &pm = rw.pm;
+            const float *x = rw.feats + (size_t)(t0 + f) * pm.veclen;
+            const int nwords = (pm.n_sen + 31) >> 5;
+            // ---- compute_fwdflat_sen_active (:416-442): senones of the channels that are active in this frame
+            for (int i = tid; i < nwords; i += kFfThreads) s_bits[i] = 0u;
+            for (int i = tid; i < pm.n_mgau; i += kFfThreads) s_cbact[i] = 0;
+            if (tid < 16) s_norm[tid] = kW;
+            if (tid == 0) s_nb = 0x7fffffff;
+            __syncthreads();
+            for (int i = tid; i < na; i += kFfThreads) {
+                int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
+                for (int k = 0; k < len; ++k) {
+                    const int c = c0 + k;
+                    if (u.frame[c] != f) continue;
+                    for (int q = 0; q < NE; ++q) {
+                        int sen = u.senid[c * 5 + q];
+                        if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
+                        atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
+                    }
+                }
+            }
+            __syncthreads();
+            {   // s_prev[w] = the highest senone listed in the words before w: where acmod_flags2list's bridging entries go
+                static_assert(kFfMaxSen / 32 <= kFfThreads, "one bitmap word per work-item");
+                const uint32_t bw = tid < nwords ? s_bits[tid] : 0u;
+                const int32_t pv = ff_block_excl_max(bw ? tid * 32 + 31 - __clz((int)bw) : -1, s_scan);
+                if (tid < nwords) s_prev[tid] = pv;
+            }
+            __syncthreads();
+            // every listed senone (bridging entries included) touches its codebook: ptm_mgau_calc_cb_active (:297-321)
+            for (int w = tid; w < nwords; w += kFfThreads) {
+                uint32_t b = s_bits[w];
+                int prev = s_prev[w];
+                while (b) {
+                    const int sen = w * 32 + __ffs((int)b) - 1;
+                    b &= b - 1;
+                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; s_cbact[pm.sen2cb[last]] = 1; }
+                    s_cbact[pm.sen2cb[sen]] = 1;
+                    prev = sen;
+                }
+            }
+            __syncthreads();
+            // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain
+            for (int ch = tid; ch < n_chain; ch += kFfThreads) {
+                const int cb = ch / pm.n_feat, fs = ch % pm.n_feat, len = pm.featlen[fs];
+                const size_t base = (size_t)cb * pm.n_density * pm.veclen + (size_t)pm.n_density * pm.featoff[fs];
+                const float *xs = x + pm.featoff[fs];
+                int32_t cw[kFfMaxTopn], sc[kFfMaxTopn];
+                for (int i = 0; i < topn; ++i) cw[i] = s_lcw[ch * topn + i];
+                for (int i = 0; i < topn; ++i) {                 // re-score, stable descending insertion with strict '>' (:71-85)
+                    const int c = cw[i];
+                    const int32_t v = ff_dist_to_int(ff_density(pm, xs, base, ch, c, len));
+                    int j = i;
+                    for (; j > 0 && v > sc[j - 1]; --j) { sc[j] = sc[j - 1]; cw[j] = cw[j - 1]; }
+                    sc[j] = v; cw[j] = c;
+                }
+                if (s_cbact[cb])
+                    for (int c = 0; c < pm.n_density; ++c) {     // codewords in index order against the moving threshold (:151-226)
+                        const float th = (float)sc[topn - 1];
+                        const float d = ff_density(pm, xs, base, ch, c, len);
+                        if (d < th) continue;
+                        bool in = false;
+                        for (int i = 0; i < topn; ++i) in |= cw[i] == c;
+                        if (in) continue;
+                        const int32_t v = ff_dist_to_int(d);
+                        int q = topn - 1;                        // ahead of equal scores, the old worst drops (:140-149)
+                        for (; q > 0 && v >= sc[q - 1]; --q) { sc[q] = sc[q - 1]; cw[q] = cw[q - 1]; }
+                        sc[q] = v; cw[q] = c;
+                    }
+                for (int i = 0; i < topn; ++i) { s_lcw[ch * topn + i] = cw[i]; s_lsc[ch * topn + i] = sc[i]; }
+                if (s_cbact[cb]) atomicMax(&s_norm[fs], sc[0] >> 10);        // ptm_mgau_codebook_norm (:272-279)
+            }
+            __syncthreads();
+            for (int i = tid; i < n_chain * topn; i += kFfThreads) {          // (:280-291), touched codebooks only
+                const int ch = i / topn;
+                if (!s_cbact[ch / pm.n_feat]) continue;
+                const int32_t v = s_norm[ch % pm.n_feat] - (s_lsc[i] >> 10);
+                s_lsc[i] = v > kMaxNegAscr ? kMaxNegAscr : v;
+            }
+            __syncthreads();
+            // ---- ptm_mgau_senone_eval (:326-403) for the listed senones; the frame's scores are those minus their minimum
+            int32_t mn = 0x7fffffff;
+            auto senone = [&](int sen) {
+                const int cb = pm.sen2cb[sen];
+                int32_t a = 0;
+                for (int fs = 0; fs < pm.n_feat; ++fs) {
+                    const int li = (cb * pm.n_feat + fs) * topn;
+                    const uint8_t *mw = pm.mixw + (size_t)fs * pm.n_density * pm.n_sen + sen;
+                    int32_t fden = (int32_t)mw[(size_t)s_lcw[li] * pm.n_sen] + s_lsc[li];
+                    for (int k = 1; k < topn; ++k) {             // fast_logmath_add (tied_mgau_common.h:106-125)
+                        const int32_t y = (int32_t)mw[(size_t)s_lcw[li + k] * pm.n_sen] + s_lsc[li + k];
+                        const int32_t lo = min(fden, y);
+                        const uint32_t dd = (uint32_t)(max(fden, y) - lo);
+                        fden = lo - (dd < 256u ? (int32_t)s_la[dd] : 0);
+                    }
+                    a += fden;
+                }
+                u.nrow32[sen] = a;
+                mn = min(mn, a);
+            };
+            for (int w = tid; w < nwords; w += kFfThreads) {
+                uint32_t b = s_bits[w];
+                int prev = s_prev[w];
+                while (b) {
+                    const int sen = w * 32 + __ffs((int)b) - 1;
+                    b &= b - 1;
+                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; senone(last); }
+                    senone(sen);
+                    prev = sen;
+                }
+            }
+            atomicMin(&s_nb, mn);
+            __syncthreads();
+            const int32_t nb = s_nb;
+            for (int w = tid; w < nwords; w += kFfThreads) {
+                uint32_t b = s_bits[w];
+                while (b) {
+                    const int sen = w * 32 + __ffs((int)b) - 1;
+                    b &= b - 1;
+                    u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
+                }
+            }
+            __syncthreads();
+            row = u.nrow;
+        }
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:825-838)
         if (tid == 0) u.bp_table_idx[f] = s_sc[1];
         const int32_t best_in = s_sc[0];
@@ -590,17 +774,18 @@ static void ff_build_vocab(const psgpu_fwdflat_s *m, const int32_t *fr, const in
     v.n_chan = c - chan_base;
 }
 
-extern "C" int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_stride,
-                                        const int32_t *utt_off_dev, int32_t n_utt, int32_t max_frames,
-                                        int32_t bp1_cap, const int32_t *bp1_dev, const int32_t *result1_dev,
-                                        const int32_t *w1_ssid_dev, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev,
-                                        int32_t *bss_dev, int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream)
+// raw == NULL: the frames' scores are given (senscr_dev); else the kernel scores its own senones from raw->feats
+static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_stride, const FfRaw *raw,
+                     const int32_t *utt_off_dev, int32_t n_utt, int32_t max_frames,
+                     int32_t bp1_cap, const int32_t *bp1_dev, const int32_t *result1_dev,
+                     const int32_t *w1_ssid_dev, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev,
+                     int32_t *bss_dev, int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream)
 {
-    PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0 && bp1_cap > 0, "psgpu_fwdflat_search_dev: bad argument");
-    PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdflat_search_dev: no language model (dense table or psgpu_fwdflat_set_lm)");
+    PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0 && bp1_cap > 0, "psgpu_fwdflat_search: bad argument");
+    PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdflat_search: no language model (dense table or psgpu_fwdflat_set_lm)");
     if (n_utt == 0) return PSGPU_OK;
-    PSGPU_REQUIRE(senscr_dev && utt_off_dev && bp1_dev && result1_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
-                  "psgpu_fwdflat_search_dev: NULL device buffer");
+    PSGPU_REQUIRE((senscr_dev || raw) && utt_off_dev && bp1_dev && result1_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
+                  "psgpu_fwdflat_search: NULL device buffer");
     const FfDev &d = m->d;
     hipStream_t st = (hipStream_t)stream;
     // ---- the first pass's tables to the host: counts, then the three columns the vocabulary needs
@@ -627,7 +812,8 @@ extern "C" int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *sensc
         const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
         ff_build_vocab(m, cols[(size_t)u * 3].data(), cols[(size_t)u * 3 + 1].data(), cols[(size_t)u * 3 + 2].data(), nb, nfr, d.n1, voc[u]);
         const size_t C = (size_t)d.n1 + voc[u].n_chan, nwd = voc[u].wid.size(), cap = nwd + n_tail + 1;
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 4) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16;
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 4) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
+                        + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
     }
     int32_t *slab = nullptr, *vdev = nullptr;
@@ -653,6 +839,8 @@ extern "C" int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *sensc
         u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
         u.awl[0] = take(cap); u.awl[1] = take(cap);
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
+        u.nrow32 = raw ? take(d.n_sen) : nullptr;
+        u.nrow = raw ? reinterpret_cast<int16_t *>(take((size_t)d.n_sen / 2 + 1)) : nullptr;
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
         u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
         u.result = result_dev + (size_t)i * 8;
@@ -663,13 +851,51 @@ extern "C" int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *sensc
     if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FfUtt) * n_utt, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the host vectors are about to go out of scope
     if (e != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); PSGPU_HIP(e); }
-    if (d.n_emit == 3)
-        hipLaunchKernelGGL((fwdflat_kernel<3>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev);
+    FfRaw rw;
+    memset(&rw, 0, sizeof rw);
+    if (raw) rw = *raw;
+    if (d.n_emit == 3 && raw)
+        hipLaunchKernelGGL((fwdflat_kernel<3, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
+    else if (d.n_emit == 3)
+        hipLaunchKernelGGL((fwdflat_kernel<3, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
+    else if (raw)
+        hipLaunchKernelGGL((fwdflat_kernel<5, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
     else
-        hipLaunchKernelGGL((fwdflat_kernel<5>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev);
+        hipLaunchKernelGGL((fwdflat_kernel<5, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
     hipFree(slab); hipFree(vdev); hipFree(d_utts);
     PSGPU_HIP(e);
     return PSGPU_OK;
+}
+
+extern "C" int psgpu_fwdflat_search_dev(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                                        const int32_t *utt_off_dev, int32_t n_utt, int32_t max_frames,
+                                        int32_t bp1_cap, const int32_t *bp1_dev, const int32_t *result1_dev,
+                                        const int32_t *w1_ssid_dev, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev,
+                                        int32_t *bss_dev, int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, void *stream)
+{
+    PSGPU_REQUIRE(senscr_dev, "psgpu_fwdflat_search_dev: NULL score rows");
+    return ff_search(m, senscr_dev, scr_stride, nullptr, utt_off_dev, n_utt, max_frames, bp1_cap, bp1_dev, result1_dev, w1_ssid_dev,
+                     bp_cap, bss_cap, bp_dev, bss_dev, idx_dev, step_dev, result_dev, stream);
+}
+
+extern "C" int psgpu_fwdflat_search_feats_dev(psgpu_fwdflat_t *m, const psgpu_ptm_view_t *ptm, const float *feats_dev,
+                                              const int32_t *topn_seed_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                              int32_t max_frames, int32_t bp1_cap, const int32_t *bp1_dev,
+                                              const int32_t *result1_dev, const int32_t *w1_ssid_dev, int32_t bp_cap,
+                                              int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev, int32_t *idx_dev,
+                                              int32_t *step_dev, int32_t *result_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && ptm && feats_dev && topn_seed_dev, "psgpu_fwdflat_search_feats_dev: NULL argument");
+    PSGPU_REQUIRE(ptm->n_sen == m->d.n_sen && ptm->n_sen <= kFfMaxSen && ptm->n_mgau >= 1 && ptm->n_mgau <= kFfMaxCb &&
+                  ptm->n_feat >= 1 && ptm->n_feat <= 16 && ptm->topn >= 1 && ptm->topn <= kFfMaxTopn &&
+                  (int64_t)ptm->n_mgau * ptm->n_feat * ptm->topn <= kFfMaxEnt && ptm->logadd8_size <= 256 && ptm->n_density >= ptm->topn,
+                  "psgpu_fwdflat_search_feats_dev: model shape outside this version (senones %d, codebooks %d, streams %d, top-N %d)",
+                  ptm->n_sen, ptm->n_mgau, ptm->n_feat, ptm->topn);
+    PSGPU_REQUIRE(ptm->mean && ptm->var && ptm->det && ptm->mixw && ptm->sen2cb && ptm->logadd8, "psgpu_fwdflat_search_feats_dev: NULL model table");
+    FfRaw rw;
+    rw.pm = *ptm; rw.feats = feats_dev; rw.seed = topn_seed_dev;
+    return ff_search(m, nullptr, 0, &rw, utt_off_dev, n_utt, max_frames, bp1_cap, bp1_dev, result1_dev, w1_ssid_dev,
+                     bp_cap, bss_cap, bp_dev, bss_dev, idx_dev, step_dev, result_dev, stream);
 }

@@ -740,6 +740,20 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     delete m;
 }
 
+// device pointers to the tables, for kernels outside this file that score senones themselves (psgpu_flat.hip)
+int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out)
+{
+    PSGPU_REQUIRE(m && out, "psgpu_ptm_model_view: NULL argument");
+    PSGPU_REQUIRE(m->ds_ratio == 1, "psgpu_ptm_model_view: a model with -ds %d re-scores carried lists on most frames; not supported by the in-kernel scorer", m->ds_ratio);
+    memset(out, 0, sizeof *out);
+    out->mean = m->mean; out->var = m->var; out->det = m->det;
+    out->mixw = m->mixw; out->sen2cb = m->sen2cb; out->logadd8 = m->logadd8;
+    out->n_mgau = m->n_mgau; out->n_feat = m->n_feat; out->n_density = m->n_density; out->n_sen = m->n_sen;
+    out->veclen = m->veclen; out->topn = m->topn; out->logadd8_size = m->logadd8_size;
+    for (int f = 0; f < 16; ++f) { out->featlen[f] = m->featlen[f]; out->featoff[f] = m->featoff[f]; }
+    return PSGPU_OK;
+}
+
 int32_t psgpu_ptm_n_sen(const psgpu_ptm_model_t *m) { return m->n_sen; }
 int32_t psgpu_ptm_n_chain(const psgpu_ptm_model_t *m) { return m->n_chain; }
 int32_t psgpu_ptm_veclen(const psgpu_ptm_model_t *m) { return m->veclen; }

@@ -28,6 +28,14 @@ def marshal(static, fstatic, par, flat_par, lwf, lm):
     return keep, ft, t
 
 
+class PtmView(C.Structure):
+    """psgpu_ptm_view_t (include/psgpu.h)"""
+    _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("det", C.c_void_p), ("mixw", C.c_void_p), ("sen2cb", C.c_void_p),
+                ("logadd8", C.c_void_p), ("n_mgau", C.c_int32), ("n_feat", C.c_int32), ("n_density", C.c_int32),
+                ("n_sen", C.c_int32), ("veclen", C.c_int32), ("topn", C.c_int32), ("logadd8_size", C.c_int32),
+                ("featlen", C.c_int32 * 16), ("featoff", C.c_int32 * 16)]
+
+
 class FwdflatSearch:
     """`static` = the first pass's flattened tables (FwdtreeSearch), `fstatic` = what the second pass adds
     (pron_off, pron_ci, pron_ssid, ci_ssid, lm_known), `par` the first pass's parameter vector, `flat_par` =
@@ -53,8 +61,10 @@ class FwdflatSearch:
         except Exception:
             pass
 
-    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19):
-        """senscr [T][n_sen] int16 for utterances back to back; bp1: per utterance the first pass's back-pointer
+    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19, ptm=None, topn_seed=None):
+        """senscr [T][n_sen] int16 for utterances back to back (or, with ptm = a PtmModel and topn_seed
+        [n_utt][n_chain][topn] codewords, the FEATURE rows [T][veclen] float32: the kernel then scores its own senones,
+        psgpu_fwdflat_search_feats_dev); bp1: per utterance the first pass's back-pointer
         table [n][10] (numpy), or the `handover` dict FwdtreeSearch.search filled (device buffers as
         psgpu_fwdtree_search_dev left them); w1_ssid: per utterance [n_1ph][n_emit] or None.
         Returns a list of dicts like FwdtreeSearch.search."""
@@ -62,9 +72,19 @@ class FwdflatSearch:
         dev = torch.device("cuda", torch.cuda.current_device())
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
         T = int(off[-1]); n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
-        if not torch.is_tensor(senscr):
-            senscr = torch.from_numpy(np.ascontiguousarray(senscr, np.int16)).to(dev)
-        assert tuple(senscr.shape) == (T, self.n_sen) and senscr.dtype == torch.int16
+        if ptm is not None:
+            if not torch.is_tensor(senscr):
+                senscr = torch.from_numpy(np.ascontiguousarray(senscr, np.float32)).to(dev)
+            assert senscr.dtype == torch.float32 and senscr.dim() == 2 and senscr.shape[0] == T
+            view = PtmView()
+            capi.check(capi.lib().psgpu_ptm_model_view(ptm.h, C.byref(view)), "psgpu_ptm_model_view")
+            assert senscr.shape[1] == view.veclen
+            d_seed = topn_seed if torch.is_tensor(topn_seed) else torch.from_numpy(np.ascontiguousarray(topn_seed, np.int32)).to(dev)
+            assert d_seed.dtype == torch.int32 and d_seed.numel() == n * view.n_mgau * view.n_feat * view.topn
+        else:
+            if not torch.is_tensor(senscr):
+                senscr = torch.from_numpy(np.ascontiguousarray(senscr, np.int16)).to(dev)
+            assert tuple(senscr.shape) == (T, self.n_sen) and senscr.dtype == torch.int16
         d_w1 = None
         if isinstance(bp1, dict):                 # FwdtreeSearch.search(handover=...): everything stays on the device
             d_bp1, d_res1, d_w1 = bp1["bp"], bp1["result"], bp1["w1_ssid"]
@@ -86,10 +106,15 @@ class FwdflatSearch:
         step = torch.zeros((n, max(mf, 1), 4), dtype=torch.int32, device=dev)
         res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None  # noqa: E731
-        capi.check(capi.lib().psgpu_fwdflat_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_o), n, mf, cap1, p(d_bp1), p(d_res1),
-                                                       p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
-                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   "psgpu_fwdflat_search_dev")
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if ptm is not None:
+            capi.check(capi.lib().psgpu_fwdflat_search_feats_dev(self.h, C.byref(view), p(d_s), p(d_seed.contiguous()), p(d_o), n, mf, cap1,
+                                                                 p(d_bp1), p(d_res1), p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx),
+                                                                 p(step), p(res), sp), "psgpu_fwdflat_search_feats_dev")
+        else:
+            capi.check(capi.lib().psgpu_fwdflat_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_o), n, mf, cap1, p(d_bp1), p(d_res1),
+                                                           p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), sp),
+                       "psgpu_fwdflat_search_dev")
         out = []
         res_h = res.cpu().numpy()
         for u in range(n):

@@ -140,12 +140,31 @@ class SimFwdflatSearch:
             lib().psgpu_fwdflat_free(self.h)
             self.h = C.c_void_p()
 
-    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19):
-        """bp1: per utterance the first pass's table [n][10], or the `handover` dict of SimFwdtreeSearch.search"""
+    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19, ptm_tables=None, topn_seed=None):
+        """bp1: per utterance the first pass's table [n][10], or the `handover` dict of SimFwdtreeSearch.search.
+        ptm_tables (a tests/golden/*_ptm_tables.npz) + topn_seed: senscr holds the FEATURE rows and the kernel scores
+        its own senones (psgpu_fwdflat_search_feats_dev)."""
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
         n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
-        d_s = np.ascontiguousarray(senscr, np.int16)
-        assert d_s.shape == (int(off[-1]), self.n_sen)
+        view = None
+        if ptm_tables is not None:
+            from pocketsphinx_amd.flat import PtmView
+            t = ptm_tables
+            k = dict(mean=np.ascontiguousarray(t["mean"], np.float32), var=np.ascontiguousarray(t["var"], np.float32),
+                     det=np.ascontiguousarray(t["det"], np.float32), mixw=np.ascontiguousarray(t["mixw"], np.uint8),
+                     sen2cb=np.ascontiguousarray(t["sen2cb"], np.uint8), logadd8=np.ascontiguousarray(t["logadd8"], np.uint8))
+            fl = [int(v) for v in t["featlen"]]
+            view = PtmView(*[k[x].ctypes.data for x in ("mean", "var", "det", "mixw", "sen2cb", "logadd8")],
+                           int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0]), int(t["n_sen"][0]), sum(fl),
+                           int(t["max_topn"][0]), int(k["logadd8"].size))
+            for i, v in enumerate(fl):
+                view.featlen[i] = v; view.featoff[i] = sum(fl[:i])
+            d_s = np.ascontiguousarray(senscr, np.float32)
+            d_seed = np.ascontiguousarray(topn_seed, np.int32)
+            assert d_s.shape == (int(off[-1]), view.veclen) and d_seed.size == n * view.n_mgau * view.n_feat * view.topn
+        else:
+            d_s = np.ascontiguousarray(senscr, np.int16)
+            assert d_s.shape == (int(off[-1]), self.n_sen)
         if isinstance(bp1, dict):
             h_bp1, h_res1, cap1, d_w1 = bp1["bp"], bp1["result"], bp1["bp_cap"], bp1["w1_ssid"]
         else:
@@ -158,8 +177,13 @@ class SimFwdflatSearch:
         bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
         idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
         p = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
-        check(lib().psgpu_fwdflat_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(off), n, mf, cap1, p(h_bp1), p(h_res1), p(d_w1),
-                                             bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), None), "psgpu_fwdflat_search_dev")
+        if view is not None:
+            check(lib().psgpu_fwdflat_search_feats_dev(self.h, C.byref(view), p(d_s), p(d_seed), p(off), n, mf, cap1, p(h_bp1), p(h_res1),
+                                                       p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), None),
+                  "psgpu_fwdflat_search_feats_dev")
+        else:
+            check(lib().psgpu_fwdflat_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(off), n, mf, cap1, p(h_bp1), p(h_res1), p(d_w1),
+                                                 bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), None), "psgpu_fwdflat_search_dev")
         out = []
         for u in range(n):
             nb, nh, nfr, status = [int(v) for v in res[u, :4]]

@@ -80,3 +80,42 @@ def test_two_passes_chained_on_the_simulator(case):
     r2 = s2.search(flat_rows(g, s2.n_sen), [int(g["flat_n_steps"][0])], h)[0]
     check_flat(r2, g, case)
     s1.close(); s2.close()
+
+
+@pytest.mark.parametrize("order", ["fwd", "rev"])
+@pytest.mark.parametrize("case", ["goforward", "numbers", "something_efwid2_sfwin8"])
+def test_flat_kernel_source_scoring_its_own_senones(case, order):
+    """psgpu_fwdflat_search_feats_dev: handed the FEATURE rows and the PTM tables instead of scores, the kernel restates
+    ptm_mgau_frame_eval as the second pass calls it (own active list, only the touched codebooks scanned and
+    normalised) and must still end with the reference's pass-2 tables."""
+    import pso
+    g, st, fst = load_flat(case)
+    with _order(order):
+        s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+        r = s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=pso.load_tables(),
+                     topn_seed=g["flat_ptm_seed"])[0]
+        check_flat(r, g, "%s (%s)" % (case, order))
+        s.close()
+
+
+@pytest.mark.parametrize("case", ["goforward", "numbers", "something_efwid2_sfwin8"])
+def test_second_pass_seed_is_a_first_pass_list(case):
+    """What psgpu_fwdflat_search_feats_dev documents about topn_seed_dev: the history slot pass-2 frame 0 starts from
+    holds the lists of the last first-pass frame t with t % n_fast_hist == n_fast_hist - 1 (every codebook is
+    touched in pass 1, so these are the batch scorer's lists); and the oracle of the per-call scorer, rewound and
+    called with the second pass's active lists, gives the scores the reference's second pass was handed."""
+    import pso
+    t = pso.load_tables()
+    g, st, fst = load_flat(case)
+    H = int(t["n_fast_hist"][0])
+    o = pso.OraclePTM(t)
+    feats = g["flat_feat"]
+    _, cw, _ = o.score_utt(feats, reset_hist=True)
+    ts = max(x for x in range(feats.shape[0]) if x % H == H - 1)
+    assert np.array_equal(cw[ts].astype(np.int32), g["flat_ptm_seed"])
+    off, act, scr = g["flat_act_off"], g["flat_act"], g["flat_scr"]
+    for i in range(0, feats.shape[0]):
+        a = act[off[i]:off[i + 1]].astype(np.int64)
+        o.set_frame_idx(i)
+        sc = o.frame_eval(feats[i], i, active=np.diff(np.concatenate([[0], a])).astype(np.uint8), compallsen=False)
+        assert np.array_equal(sc[a], scr[off[i]:off[i + 1]]), "frame %d" % i

@@ -56,3 +56,92 @@ def test_two_passes_chained_on_the_device(case):
     r2 = s2.search(flat_rows(g, s2.n_sen), [int(g["flat_n_steps"][0])], h)[0]
     check_flat(r2, g, case)
     s1.close(); s2.close()
+
+
+@pytest.mark.parametrize("case", ["goforward", "numbers", "something_efwid2_sfwin8"])
+def test_fwdflat_kernel_scoring_its_own_senones(case, tables):
+    """psgpu_fwdflat_search_feats_dev: features and PTM tables in, the reference's pass-2 tables out"""
+    import pocketsphinx_amd as P
+    g, st, fst = load_flat(case)
+    model = P.PtmModel(tables)
+    s = P.FwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+    r = s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm=model, topn_seed=g["flat_ptm_seed"][None])[0]
+    check_flat(r, g, case)
+    s.close(); model.close()
+
+
+@pytest.mark.parametrize("name", ["goforward", "numbers"])
+def test_two_pass_decode_chain_audio_to_second_pass_backpointers(name, tables):
+    """Both search passes on the device with nothing through the host in between but the launch parameters: PCM ->
+    MFCC -> features -> PTM scores (un-normalised rows + top-N lists) -> phone loop -> tree search (own active
+    lists) -> flat search scoring its own senones from the features, seeded from the batch scorer's lists.  The
+    second pass's back-pointer table must be the reference decoder's for the same recording (-fwdflat yes)."""
+    import ctypes as C
+    import os
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    import pso
+    from test_oracle_golden import _load
+    g, st, fst = load_flat(name)
+    g1 = _load("fwdtree_trace_%s.npz" % name)
+    raw = os.path.join(pso.REF_DIR, "data", name + ".raw")
+    assert os.path.exists(raw), "staged recordings missing (make -C oracle)"
+    pcm = np.fromfile(raw, dtype=np.int16)
+    dev = torch.device("cuda", 0)
+    L = capi.lib()
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    fe = P.FrontEnd(_load("mfcc_en_us_goforward.npz"))
+    cep, _ = fe.process_utts([pcm])
+    feats = P.dynfeat_1s_c_d_dd(cep, [cep.shape[0]])
+    T = feats.shape[0]
+    assert T == int(g["n_frame"][0]) and np.array_equal(feats, g["flat_feat"])
+    model = P.PtmModel(tables)
+    d_f = torch.from_numpy(feats).to(dev)
+    d_off = torch.tensor([0, T], dtype=torch.int32, device=dev)
+    tsc = torch.empty((model.n_chain, T, model.topn), dtype=torch.int32, device=dev)
+    tcw = torch.empty((model.n_chain, T, model.topn), dtype=torch.uint8, device=dev)
+    rows = torch.empty((T, model.n_sen), dtype=torch.int16, device=dev)
+    best = torch.empty(T, dtype=torch.int32, device=dev)
+    capi.check(L.psgpu_ptm_score_batch_dev(model.h, p(d_f), p(d_off), 1, T, None, None, p(tsc), p(tcw), p(rows), p(best),
+                                           1, sp), "score (PSGPU_PTM_RAW_SCORES)")
+    # phone loop of the utterance (as tests/test_search_gpu.py)
+    n_ci, window = int(g1["pl_par"][0]), int(g1["pl_par"][1])
+    ctx = P.HmmContext(st["tp"], st["sseq"], model.n_sen)
+
+    class PlPar(C.Structure):
+        _fields_ = [("n_phones", C.c_int32), ("window", C.c_int32), ("beam", C.c_int32), ("pbeam", C.c_int32),
+                    ("pip", C.c_int32), ("penalty_weight", C.c_double)]
+    par = PlPar(n_ci, window, int(g1["pl_par"][2]), int(g1["pl_par"][3]), int(g1["pl_par"][4]), float(g1["pl_weight"][0]))
+    flags = np.zeros(model.n_sen, bool)
+    flags[st["sseq"][g1["pl_ssid"]].reshape(-1)] = True
+    ci_list, last = [], 0
+    for s_ in np.nonzero(flags)[0]:
+        while s_ - last > 255:
+            last += 255; ci_list.append(last)
+        ci_list.append(int(s_)); last = int(s_)
+    d_ssid = torch.from_numpy(g1["pl_ssid"].astype(np.uint16).view(np.int16)).to(dev)
+    d_tm = torch.from_numpy(g1["pl_tmat"].astype(np.int16)).to(dev)
+    d_ci = torch.from_numpy(np.array(ci_list, np.uint16).view(np.int16)).to(dev)
+    pen = torch.empty((T, n_ci), dtype=torch.int32, device=dev)
+    now = torch.empty((T, n_ci), dtype=torch.int32, device=dev)
+    state = torch.empty((T, n_ci, 8), dtype=torch.int32, device=dev)
+    L.psgpu_phone_loop_run_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]
+    capi.check(L.psgpu_phone_loop_run_dev(ctx.h, C.byref(par), p(d_ssid), p(d_tm), p(d_ci), len(ci_list), p(rows),
+                                          model.n_sen, None, p(d_off), 1, T, p(pen), p(now), p(state), sp), "phone loop")
+    # first pass on the raw rows, second pass on the features
+    s1 = P.FwdtreeSearch(st, g1["par"])
+    h = {}
+    r1 = s1.search(rows, pen, [T], raw_scores=True, pl_window=int(g1["pl_par"][5]), handover=h)[0]
+    assert np.array_equal(r1["bp"], g["bp1"])
+    H = int(tables["n_fast_hist"][0])
+    ts = max(x for x in range(T) if x % H == H - 1)
+    seed = tcw[:, ts, :].to(torch.int32).contiguous()
+    assert np.array_equal(seed.cpu().numpy().reshape(g["flat_ptm_seed"].shape), g["flat_ptm_seed"])
+    s2 = P.FwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+    r2 = s2.search(d_f, [T], h, ptm=model, topn_seed=seed)[0]
+    check_flat(r2, g, name)
+    s1.close(); s2.close(); model.close()
