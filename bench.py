@@ -409,6 +409,31 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         srch.close(); ctx.close(); fe.close()
     except Exception as e:
         out["device_decode"] = {"error": str(e)}
+    # (8), (9): kernels written after the round's GPU minutes were spent (checked on the CPU only, tests/hostsim): each runs
+    #     in a CHILD process with a time limit, so that a fault in one of them cannot take this process -- and the headline
+    #     line -- with it.  PSGPU_BENCH_NO_CHILD=1 skips them.
+    if not os.environ.get("PSGPU_BENCH_NO_CHILD"):
+        import subprocess
+
+        def child(key, argv, env, limit):
+            try:
+                r = subprocess.run([sys.executable] + argv, env=dict(os.environ, **env), capture_output=True, text=True, timeout=limit)
+                lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+                if r.returncode != 0 or not lines:
+                    out[key] = {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+                elif lines[-1].lstrip().startswith("{"):
+                    out[key] = json.loads(lines[-1])
+                else:
+                    out[key] = {"lines": lines[-6:]}
+            except Exception as e:
+                out[key] = {"error": str(e)[-400:]}
+        # (8) both search passes on the device, 256 utterances from PCM
+        child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 150)
+        # (9) the tree search on the full cmudict task (134,865 words), large-vocabulary formulation;
+        #     the default formulation measured 1.19 s for one utterance, 5.5 k frames/s at 32 per launch (profiles/r01i_*)
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
+            child("search_cmudict_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
+                  {"SB_CASE": "cmudict", "SB_MODE": "active_list", "SB_BATCHES": "1,32", "SB_REPS": "1"}, 200)
     return out
 
 
@@ -534,6 +559,8 @@ def main():
                      "note": "VALU/LDS-bound by construction (SURVEY 8d); fp32-VALU fraction of the "
                              "distance work = %.4f" % (FLOP_PER_FRAME * T / (topn_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS)},
     }
+    if world > 1:
+        os.environ["PSGPU_BENCH_NO_CHILD"] = "1"        # the child-process extras are single-GPU measurements: N = 1 only
     line["extra"] = {} if args.no_extras else extras(P, capi, L, model, t, feats_h, dev, sp)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(t, feats_h)

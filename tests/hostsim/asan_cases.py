@@ -1,0 +1,35 @@
+"""Driven by tools/hostsim_asan.sh: search kernels on the simulator, built with AddressSanitizer, output buffers sized
+to what each golden needs (+ the kernels' documented head-room)."""
+import os
+
+import simlib
+simlib.LIB = os.environ["PSGPU_SIM_LIB"]; simlib.DEPS = []
+
+import pso  # noqa: E402
+from test_flat_hostsim import check_flat, flat_rows  # noqa: E402
+from test_oracle_flat import load_flat  # noqa: E402
+from test_oracle_golden import _load  # noqa: E402
+from test_search_gpu import _check, _inputs  # noqa: E402
+
+
+def caps(g):
+    return dict(bp_cap=int(g["bp"].shape[0]) + 64, bss_cap=int(g["bscore_stack"].shape[0]) + 128)
+
+
+for case, mode in [("goforward", 0), ("goforward", 1), ("goforward_maxhmmpf60_maxwpf3", 1), ("man_ah_2934za", 1), ("medium_numbers_maxwpf8", 1)]:
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    s = simlib.SimFwdtreeSearch(st, g["par"], lm=simlib.SimLm(st) if "lm" not in st else None, list_mode=mode)
+    rows, pen = _inputs(g, s.n_sen)
+    _check(s.search(rows, pen, [rows.shape[0]], handover={}, **caps(g))[0], g, case)
+    print("tree search", case, "mode", mode, "clean")
+for case in ["goforward", "man_ah_2934za", "medium_numbers"]:
+    g, st, fst = load_flat(case)
+    s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"], lm=simlib.SimLm(fst) if "lm" not in st else None)
+    check_flat(s.search(flat_rows(g, s.n_sen), [int(g["flat_n_steps"][0])], [g["bp1"]], [g["flat_w1_ssid"]], **caps(g))[0], g, case)
+    print("flat search", case, "clean")
+g, st, fst = load_flat("numbers")
+s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+check_flat(s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=pso.load_tables(),
+                    topn_seed=g["flat_ptm_seed"], **caps(g))[0], g, "numbers")
+print("flat search scoring its own senones clean")
