@@ -58,21 +58,29 @@ def test_fwdtree_oracle_matches_reference(case, parallel):
     assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
 
 
-@pytest.fixture(scope="module")
-def big_trace(tmp_path_factory):
-    """`ref_dump fwdtree` of the compiled reference on the large-vocabulary task (too large to commit, ~10 s to make)"""
+def make_big_trace(out_dir):
+    """`ref_dump fwdtree` of the compiled reference on the large-vocabulary task (too large to commit, ~10 s to make);
+    None when oracle/_ref is not built"""
     import subprocess
     import sys
     ref = pso.REF_DIR
     need = [os.path.join(ref, "ref_dump"), os.path.join(ref, "data", "big.arpa"), os.path.join(ref, "data", "cmudict-en-us.dict")]
     if not all(os.path.exists(p) for p in need):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
-    out = str(tmp_path_factory.mktemp("big") / "big.psgb")
+        return None
+    out = os.path.join(str(out_dir), "big.psgb")
     subprocess.check_call([need[0], "fwdtree", out, os.path.join(ref, "model", "en-us"), need[1], need[2],
                            os.path.join(ref, "data", "goforward.raw"), "--", "fwdflat", "no", "bestpath", "no"], timeout=600)
     sys.path.insert(0, os.path.join(os.path.dirname(pso.__file__), "..", "oracle"))
     from psgb import read_psgb
     return read_psgb(out)
+
+
+@pytest.fixture(scope="module")
+def big_trace(tmp_path_factory):
+    g = make_big_trace(tmp_path_factory.mktemp("big"))
+    if g is None:
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    return g
 
 
 @pytest.mark.parametrize("parallel", [0, 1, 2])

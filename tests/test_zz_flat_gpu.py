@@ -8,14 +8,20 @@ the kernel source is checked on the CPU by tests/test_flat_hostsim.py.)"""
 import numpy as np
 import pytest
 
+from conftest import run_isolated
 from test_flat_hostsim import check_flat, flat_rows
 from test_oracle_flat import FLAT_CASES, load_flat
 
 pytestmark = pytest.mark.gpu
+ME = "test_zz_flat_gpu"                    # every test body runs in a child process (conftest.run_isolated)
 
 
 @pytest.mark.parametrize("case", FLAT_CASES)
 def test_fwdflat_kernel_matches_reference(case):
+    run_isolated(ME, "impl_matches_reference", case)
+
+
+def impl_matches_reference(case):
     import pocketsphinx_amd as P
     g, st, fst = load_flat(case)
     lm = P.NGramTrieLM(fst) if "lm" not in st else None
@@ -26,6 +32,10 @@ def test_fwdflat_kernel_matches_reference(case):
 
 
 def test_fwdflat_kernel_batch_of_utterances():
+    run_isolated(ME, "impl_batch_of_utterances")
+
+
+def impl_batch_of_utterances():
     import pocketsphinx_amd as P
     loaded = [load_flat(n) for n in ("goforward", "numbers")]
     g0, st, fst = loaded[0]
@@ -42,6 +52,10 @@ def test_fwdflat_kernel_batch_of_utterances():
 def test_two_passes_chained_on_the_device(case):
     """tree search -> flat search, the hand-over (back-pointer table, result record, single-phone ssids) staying in
     device buffers; the second pass must end with the reference's pass-2 tables"""
+    run_isolated(ME, "impl_two_passes_chained", case)
+
+
+def impl_two_passes_chained(case):
     import pocketsphinx_amd as P
     from test_oracle_golden import _load
     from test_search_gpu import _inputs
@@ -59,9 +73,15 @@ def test_two_passes_chained_on_the_device(case):
 
 
 @pytest.mark.parametrize("case", ["goforward", "numbers", "something_efwid2_sfwin8"])
-def test_fwdflat_kernel_scoring_its_own_senones(case, tables):
+def test_fwdflat_kernel_scoring_its_own_senones(case):
     """psgpu_fwdflat_search_feats_dev: features and PTM tables in, the reference's pass-2 tables out"""
+    run_isolated(ME, "impl_scoring_its_own_senones", case)
+
+
+def impl_scoring_its_own_senones(case):
     import pocketsphinx_amd as P
+    import pso
+    tables = pso.load_tables()
     g, st, fst = load_flat(case)
     model = P.PtmModel(tables)
     s = P.FwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
@@ -71,11 +91,15 @@ def test_fwdflat_kernel_scoring_its_own_senones(case, tables):
 
 
 @pytest.mark.parametrize("name", ["goforward", "numbers"])
-def test_two_pass_decode_chain_audio_to_second_pass_backpointers(name, tables):
+def test_two_pass_decode_chain_audio_to_second_pass_backpointers(name):
     """Both search passes on the device with nothing through the host in between but the launch parameters: PCM ->
     MFCC -> features -> PTM scores (un-normalised rows + top-N lists) -> phone loop -> tree search (own active
     lists) -> flat search scoring its own senones from the features, seeded from the batch scorer's lists.  The
     second pass's back-pointer table must be the reference decoder's for the same recording (-fwdflat yes)."""
+    run_isolated(ME, "impl_two_pass_chain_from_audio", name)
+
+
+def impl_two_pass_chain_from_audio(name):
     import ctypes as C
     import os
     import torch
@@ -83,6 +107,7 @@ def test_two_pass_decode_chain_audio_to_second_pass_backpointers(name, tables):
     from pocketsphinx_amd import capi
     import pso
     from test_oracle_golden import _load
+    tables = pso.load_tables()
     g, st, fst = load_flat(name)
     g1 = _load("fwdtree_trace_%s.npz" % name)
     raw = os.path.join(pso.REF_DIR, "data", name + ".raw")

@@ -8,16 +8,22 @@ opt-in and was written in a session that had no GPU minutes left)."""
 import numpy as np
 import pytest
 
+from conftest import run_isolated
 from test_oracle_golden import _load
 from test_oracle_lm import load as lm_load
-from test_oracle_search import CASES, MEDIUM_CASES, big_trace  # noqa: F401 (fixture)
+from test_oracle_search import CASES, MEDIUM_CASES, make_big_trace
 from test_search_gpu import _check, _inputs
 
 pytestmark = pytest.mark.gpu
+ME = "test_zz_search_active_list_gpu"      # every test body runs in a child process (conftest.run_isolated)
 
 
 @pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
 def test_fwdtree_kernel_active_list_matches_reference(case):
+    run_isolated(ME, "impl_matches_reference", case)
+
+
+def impl_matches_reference(case):
     import pocketsphinx_amd as P
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
@@ -30,6 +36,10 @@ def test_fwdtree_kernel_active_list_matches_reference(case):
 
 def test_fwdtree_kernel_active_list_batch_and_trie():
     """several utterances per launch, language scores from the device trie"""
+    run_isolated(ME, "impl_batch_and_trie")
+
+
+def impl_batch_and_trie():
     import pocketsphinx_amd as P
     names = ["goforward", "numbers", "goforward"]
     gs = [_load("fwdtree_trace_%s.npz" % n) for n in names]
@@ -42,10 +52,18 @@ def test_fwdtree_kernel_active_list_batch_and_trie():
     s.close()
 
 
-def test_fwdtree_kernel_active_list_full_cmudict_vocabulary(big_trace):  # noqa: F811
+def test_fwdtree_kernel_active_list_full_cmudict_vocabulary(tmp_path):
     """134,865 words, 248 k tree channels, ~8 k active channels per frame: the task the mode exists for"""
+    import pso
+    import os
+    if not os.path.exists(os.path.join(pso.REF_DIR, "ref_dump")):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    run_isolated(ME, "impl_full_cmudict", str(tmp_path), timeout=1200)
+
+
+def impl_full_cmudict(tmp):
     import pocketsphinx_amd as P
-    g = big_trace
+    g = make_big_trace(tmp)
     s = P.FwdtreeSearch(g, g["par"], lm=P.NGramTrieLM(g), mode=P.FwdtreeSearch.ACTIVE_LIST)
     rows, pen = _inputs(g, s.n_sen)
     _check(s.search(rows, pen, [rows.shape[0]])[0], g, "cmudict")
@@ -54,6 +72,10 @@ def test_fwdtree_kernel_active_list_full_cmudict_vocabulary(big_trace):  # noqa:
 
 
 def test_fwdtree_set_mode_rejects_unknown_modes():
+    run_isolated(ME, "impl_rejects_unknown_modes")
+
+
+def impl_rejects_unknown_modes():
     import pocketsphinx_amd as P
     g = _load("fwdtree_trace_goforward.npz")
     with pytest.raises(P.PsgpuError):
