@@ -80,6 +80,7 @@ class FwdflatSearch:
             capi.check(capi.lib().psgpu_ptm_model_view(ptm.h, C.byref(view)), "psgpu_ptm_model_view")
             assert senscr.shape[1] == view.veclen
             d_seed = topn_seed if torch.is_tensor(topn_seed) else torch.from_numpy(np.ascontiguousarray(topn_seed, np.int32)).to(dev)
+            d_seed = d_seed.contiguous()              # (kept in a name: the launch below reads it)
             assert d_seed.dtype == torch.int32 and d_seed.numel() == n * view.n_mgau * view.n_feat * view.topn
         else:
             if not torch.is_tensor(senscr):
@@ -108,7 +109,7 @@ class FwdflatSearch:
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None  # noqa: E731
         sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         if ptm is not None:
-            capi.check(capi.lib().psgpu_fwdflat_search_feats_dev(self.h, C.byref(view), p(d_s), p(d_seed.contiguous()), p(d_o), n, mf, cap1,
+            capi.check(capi.lib().psgpu_fwdflat_search_feats_dev(self.h, C.byref(view), p(d_s), p(d_seed), p(d_o), n, mf, cap1,
                                                                  p(d_bp1), p(d_res1), p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx),
                                                                  p(step), p(res), sp), "psgpu_fwdflat_search_feats_dev")
         else:
