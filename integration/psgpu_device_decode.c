@@ -51,6 +51,12 @@ struct psgpu_device_decode_s {
     int32_t *d_pen, *d_now, *d_state, *d_bp, *d_bss, *d_idx, *d_step, *d_res;
     int32_t *h_bp, *h_bss, *h_idx;
     int bp_cap, bss_cap;
+    /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
+    psgpu_fwdflat_t *ff;
+    psgpu_ptm_view_t view;
+    int n_fast_hist, n1, n_emit;
+    int32_t *d_w1, *d_seed, *d_bp2, *d_bss2, *d_idx2, *d_step2, *d_res2, *h_seed;
+    uint8_t *h_tcw;
 };
 
 static int
@@ -104,8 +110,9 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     if (ps == NULL || ps->search == NULL || ps->acmod == NULL) return NULL;
     if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM)) { E_ERROR("psgpu device decode: not an n-gram search\n"); return NULL; }
     ngs = (ngram_search_t *)ps->search;
-    if (!ngs->fwdtree || ngs->fwdflat) {
-        E_ERROR("psgpu device decode: needs -fwdtree yes -fwdflat no (pass 1 on the device, the lattice pass on the host)\n");
+    if (!ngs->fwdtree || (ngs->fwdflat && !(getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS"))))) {
+        E_ERROR("psgpu device decode: needs -fwdtree yes -fwdflat no (pass 1 on the device, the lattice pass on the host); "
+                "-fwdflat yes with PSGPU_DEVICE_SECOND_PASS=1 in the environment runs the second pass on the device too\n");
         return NULL;
     }
     acmod = ps->acmod; mdef = acmod->mdef; dict = ps_search_dict(ngs); d2p = ps_search_dict2pid(ngs);
@@ -218,6 +225,40 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     t.tp = tp; t.sseq = sq; t.ci_tmat = ptm; t.lm = lm; t.n_tmat = n_tmat; t.n_sseq = n_sseq;
     i = lm_ok ? psgpu_fwdtree_create(&d->ft, &t) : PSGPU_EINVAL;
     if (i == PSGPU_OK && d->lm) i = psgpu_fwdtree_set_lm(d->ft, d->lm);
+    if (i == PSGPU_OK && ngs->fwdflat) {
+        /* ---- what the second pass adds (cf. oracle/ref_dump.c cmd_fwdtree(.., flat = 1)): pronunciations as word-internal
+         *      ssids, the CI phones' ssids, which words the language model knows, its beams and windows */
+        psgpu_fwdflat_tables_t t2;
+        int64_t tot = 0, o = 0;
+        int32 *off = ckd_calloc(n_w + 1, 4), *pci, *pss, *cis = ckd_calloc(n_ci, 4), *known = ckd_calloc(n_w, 4);
+        for (w = 0; w < n_w; ++w) tot += dict_pronlen(dict, w);
+        pci = ckd_calloc(tot + 1, 4); pss = ckd_calloc(tot + 1, 4);
+        for (w = 0; w < n_w; ++w) {
+            int len = dict_pronlen(dict, w);
+            off[w] = (int32)o;
+            for (k = 0; k < len; ++k, ++o) {
+                pci[o] = dict_pron(dict, w, k);
+                pss[o] = (k >= 1 && k < len - 1) ? dict2pid_internal(d2p, w, k) : -1;
+            }
+            known[w] = ngram_model_set_known_wid(ngs->lmset, dict_basewid(dict, w)) ? 1 : 0;
+        }
+        off[n_w] = (int32)o;
+        for (j = 0; j < n_ci; ++j) cis[j] = bin_mdef_pid2ssid(mdef, j);
+        memset(&t2, 0, sizeof t2);
+        t2.ft = &t; t2.pron_off = off; t2.pron_ci = pci; t2.pron_ssid = pss; t2.ci_ssid = cis; t2.lm_known = known;
+        t2.fwdflatbeam = ngs->fwdflatbeam; t2.fwdflatwbeam = ngs->fwdflatwbeam; t2.min_ef_width = ngs->min_ef_width;
+        t2.max_sf_win = ngs->max_sf_win; t2.lwf = ngs->fwdflat_fwdtree_lw_ratio;
+        i = psgpu_fwdflat_create(&d->ff, &t2);
+        if (i == PSGPU_OK && d->lm) i = psgpu_fwdflat_set_lm(d->ff, d->lm);
+        if (i == PSGPU_OK) i = psgpu_ptm_model_view(d->model, &d->view);
+        d->n_fast_hist = ps->pl_window + 2;               /* ptm_mgau.c:884 */
+        d->n1 = ngs->n_1ph_words; d->n_emit = n_emit;
+        if (i == PSGPU_OK && (psgpu_malloc((void **)&d->d_w1, 4 * (size_t)d->n1 * n_emit + 4)
+                              || psgpu_malloc((void **)&d->d_seed, 4 * (size_t)d->n_chain * d->topn + 4)))
+            i = PSGPU_ENOMEM;
+        d->h_seed = ckd_calloc((size_t)d->n_chain * d->topn + 1, 4);
+        ckd_free(off); ckd_free(pci); ckd_free(pss); ckd_free(cis); ckd_free(known);
+    }
     /* PSGPU_FWDTREE_MODE=active_list: the large-vocabulary formulation of the kernel (psgpu.h, psgpu_fwdtree_set_mode);
      * same tables, per-frame work proportional to the active channels */
     if (i == PSGPU_OK && getenv("PSGPU_FWDTREE_MODE") && !strcmp(getenv("PSGPU_FWDTREE_MODE"), "active_list"))
@@ -276,6 +317,8 @@ void
 psgpu_device_decode_detach(psgpu_device_decode_t *d)
 {
     if (!d) return;
+    psgpu_fwdflat_free(d->ff); psgpu_free(d->d_w1); psgpu_free(d->d_seed); psgpu_free(d->d_bp2); psgpu_free(d->d_bss2);
+    psgpu_free(d->d_idx2); psgpu_free(d->d_step2); psgpu_free(d->d_res2); ckd_free(d->h_seed); ckd_free(d->h_tcw);
     psgpu_fwdtree_free(d->ft); psgpu_lm_free(d->lm); psgpu_hmm_ctx_free(d->ctx); psgpu_fe_free(d->fe);
     psgpu_free(d->d_ssid); psgpu_free(d->d_tmatid); psgpu_free(d->d_ci);
     psgpu_free(d->d_pcm); psgpu_free(d->d_cep); psgpu_free(d->d_feat); psgpu_free(d->d_off); psgpu_free(d->d_tsc); psgpu_free(d->d_tcw);
@@ -299,6 +342,16 @@ grow(psgpu_device_decode_t *d, size_t n_samples, int T)
         psgpu_free(d->d_best); psgpu_free(d->d_pen); psgpu_free(d->d_now); psgpu_free(d->d_state); psgpu_free(d->d_idx);
         psgpu_free(d->d_step); psgpu_free(d->d_off); psgpu_free(d->d_bp); psgpu_free(d->d_bss); psgpu_free(d->d_res);
         ckd_free(d->h_bp); ckd_free(d->h_bss); ckd_free(d->h_idx);
+        if (d->ff) {
+            psgpu_free(d->d_bp2); psgpu_free(d->d_bss2); psgpu_free(d->d_idx2); psgpu_free(d->d_step2); psgpu_free(d->d_res2);
+            ckd_free(d->h_tcw);
+            d->d_bp2 = d->d_bss2 = d->d_idx2 = d->d_step2 = d->d_res2 = NULL; d->h_tcw = NULL;
+            if (psgpu_malloc((void **)&d->d_bp2, 4 * (size_t)10 * d->bp_cap) || psgpu_malloc((void **)&d->d_bss2, 4 * (size_t)d->bss_cap)
+                || psgpu_malloc((void **)&d->d_idx2, 4 * (t + 2)) || psgpu_malloc((void **)&d->d_step2, 4 * t * 4)
+                || psgpu_malloc((void **)&d->d_res2, 32))
+                return -1;
+            d->h_tcw = ckd_calloc(ne + 1, 1);
+        }
         d->cap_frames = 0;
         if (psgpu_malloc((void **)&d->d_cep, 4 * t * d->cepsize) || psgpu_malloc((void **)&d->d_feat, 4 * t * 3 * d->cepsize)
             || psgpu_malloc((void **)&d->d_tsc, 4 * ne) || psgpu_malloc((void **)&d->d_tcw, ne)
@@ -330,6 +383,7 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
     if (ps_start_utt(ps) < 0) return -1;
     if (ps_end_utt(ps) < 0) return -1;
     if (T == 0) return 0;
+    if (d->ff && psgpu_fwdtree_set_w1_ssid_out(d->ft, d->d_w1)) { E_ERROR("psgpu device decode: %s\n", psgpu_last_error()); return -1; }
     if (psgpu_memcpy_h2d(d->d_pcm, pcm, 2 * n_samples, st)
         || psgpu_fe_process_utts_dev(d->fe, d->d_pcm, soff, 1, NULL, NULL, d->d_cep, d->d_off, fo, st)
         || psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, 1, d->cepsize, d->d_feat, st)
@@ -343,10 +397,34 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
-    nb = res[0]; nh = res[1]; nfr = res[2];
     if (res[3]) { E_ERROR("psgpu device decode: back-pointer table or score stack full\n"); return -1; }
-    if (psgpu_memcpy_d2h(d->h_bp, d->d_bp, 4 * (size_t)10 * d->bp_cap, st) || psgpu_memcpy_d2h(d->h_bss, d->d_bss, 4 * (size_t)(nh ? nh : 1), st)
-        || psgpu_memcpy_d2h(d->h_idx, d->d_idx, 4 * ((size_t)nfr + 1), st) || psgpu_stream_sync(st)) {
+    if (d->ff) {
+        /* ---- the second pass (ngram_search_finish, ngram_search.c:791-808, does it inside ps_end_utt on the host): the
+         *      flat-lexicon search over the first pass's device-resident table, scoring its own senones from the feature
+         *      rows; its scorer state starts from the lists pass 1 left in history slot n_fast_hist - 1 (ptm_mgau.c:425-441),
+         *      i.e. the batch scorer's lists (chain-major [n_chain][T][topn]) of the last frame ts with ts % H == H - 1 */
+        int H = d->n_fast_hist, ts = T - 1, c;
+        while (ts >= 0 && ts % H != H - 1) --ts;
+        if (psgpu_memcpy_d2h(d->h_tcw, d->d_tcw, (size_t)d->n_chain * T * d->topn, st) || psgpu_stream_sync(st)) {
+            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+            return -1;
+        }
+        for (c = 0; c < d->n_chain; ++c)
+            for (i = 0; i < d->topn; ++i)      /* a shorter utterance than H frames never wrote that slot: ptm_mgau_init's i-th codeword */
+                d->h_seed[c * d->topn + i] = ts >= 0 ? d->h_tcw[((size_t)c * T + ts) * d->topn + i] : i;
+        if (psgpu_memcpy_h2d(d->d_seed, d->h_seed, 4 * (size_t)d->n_chain * d->topn, st)
+            || psgpu_fwdflat_search_feats_dev(d->ff, &d->view, d->d_feat, d->d_seed, d->d_off, 1, T, d->bp_cap, d->d_bp, d->d_res,
+                                              d->d_w1, d->bp_cap, d->bss_cap, d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)
+            || psgpu_memcpy_d2h(res, d->d_res2, sizeof res, st) || psgpu_stream_sync(st)) {
+            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+            return -1;
+        }
+        if (res[3]) { E_ERROR("psgpu device decode: second pass: back-pointer table or score stack full\n"); return -1; }
+    }
+    nb = res[0]; nh = res[1]; nfr = res[2];
+    if (psgpu_memcpy_d2h(d->h_bp, d->ff ? d->d_bp2 : d->d_bp, 4 * (size_t)10 * d->bp_cap, st)
+        || psgpu_memcpy_d2h(d->h_bss, d->ff ? d->d_bss2 : d->d_bss, 4 * (size_t)(nh ? nh : 1), st)
+        || psgpu_memcpy_d2h(d->h_idx, d->ff ? d->d_idx2 : d->d_idx, 4 * ((size_t)nfr + 1), st) || psgpu_stream_sync(st)) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }

@@ -170,3 +170,24 @@ def impl_two_pass_chain_from_audio(name):
     r2 = s2.search(d_f, [T], h, ptm=model, topn_seed=seed)[0]
     check_flat(r2, g, name)
     s1.close(); s2.close(); model.close()
+
+
+@pytest.mark.parametrize("raw,extra,lm,dic", [
+    ("goforward.raw", ("bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
+    ("numbers.raw", ("bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
+    ("goforward.raw", (), "turtle.lm.bin", "turtle.dic"),                       # + the lattice pass on the injected table
+    ("goforward.raw", ("bestpath", "no"), "medium.arpa", "medium.dic"),        # trie language scores
+])
+def test_dropin_device_two_passes(raw, extra, lm, dic, monkeypatch):
+    """Decoder B's first AND second pass on the MI355X (integration/psgpu_device_decode.c with
+    PSGPU_DEVICE_SECOND_PASS=1 and -fwdflat yes): front end, features, scores, phone loop, lexicon-tree search, then
+    the flat-lexicon search scoring its own senones; the second pass's back-pointer table is copied into the live
+    ngram_search_t and the REFERENCE's ps_get_hyp / ps_seg_iter (and, with -bestpath yes, its lattice pass) read it.
+    Hypothesis, path score and every segment must equal the CPU decoder's three-/two-pass decode of the same audio.
+    (The harness is a child process.)"""
+    from test_dropin_gpu import run
+    monkeypatch.setenv("PSGPU_DEVICE_SECOND_PASS", "1")
+    r = run(raw, 1, "psgpu_device_search", "yes", "fwdflat", "yes", *extra, lm=lm, dic=dic)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert r["n_seg"] > 0, r
