@@ -452,6 +452,9 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             for (int i = tid; i < R + na; i += NT) {
                 const int node = i < R ? i : u.acl[cur][i - R];
                 if (i >= R) decide(node);
+                // a node that is not retained enters none of its children: their (stale) decision words are not
+                // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
+                if (!(u.flag[node] & 1)) continue;
                 for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.pos[c] < 0) decide(c);
             }
             __syncthreads();
@@ -501,7 +504,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         for (int i = tid; i < R + n_acl[cur]; i += NT) {
             const int node = i < R ? i : u.acl[cur][i - R];
             int k = (i >= R && (u.o_frame[node] & 8)) ? 1 : 0;
-            for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) k += (u.o_frame[c] & 2) ? 1 : 0;
+            if (!LIST || (u.flag[node] & 1))
+                for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) k += (u.o_frame[c] & 2) ? 1 : 0;
             cnt[i] = k;
         }
         __syncthreads();
@@ -510,7 +514,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int node = i < R ? i : u.acl[cur][i - R];
             int o = cnt[i];
             if (i >= R && (u.o_frame[node] & 8)) u.acl[nxt][o++] = node;
-            for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.o_frame[c] & 2) u.acl[nxt][o++] = c;
+            if (!LIST || (u.flag[node] & 1))
+                for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.o_frame[c] & 2) u.acl[nxt][o++] = c;
         }
         n_acl[nxt] = n_listed;
         __syncthreads();
