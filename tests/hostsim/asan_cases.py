@@ -33,3 +33,20 @@ s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
 check_flat(s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=pso.load_tables(),
                     topn_seed=g["flat_ptm_seed"], **caps(g))[0], g, "numbers")
 print("flat search scoring its own senones clean")
+
+# tables too small: the kernels must stop with status 1 and stay inside the buffers
+g = _load("fwdtree_trace_numbers.npz")
+st = _load("fwdtree_static_en_us_turtle.npz")
+for mode in (0, 1):
+    s = simlib.SimFwdtreeSearch(st, g["par"], list_mode=mode)
+    rows, pen = _inputs(g, s.n_sen)
+    for kw in (dict(bp_cap=300, bss_cap=1 << 16), dict(bp_cap=4096, bss_cap=900)):
+        r = s.search(rows, pen, [rows.shape[0]], **kw)[0]
+        assert r["status"] == 1 and r["n_frame"] < rows.shape[0], (mode, kw, r["status"], r["n_frame"])
+    print("tree search mode", mode, "full tables: status 1, clean")
+g, st, fst = load_flat("numbers")
+s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+for kw in (dict(bp_cap=300, bss_cap=1 << 16), dict(bp_cap=4096, bss_cap=900)):
+    r = s.search(flat_rows(g, s.n_sen), [int(g["flat_n_steps"][0])], [g["bp1"]], [g["flat_w1_ssid"]], **kw)[0]
+    assert r["status"] == 1 and r["n_frame"] < int(g["flat_n_steps"][0]), (kw, r["status"], r["n_frame"])
+print("flat search full tables: status 1, clean")
