@@ -118,9 +118,13 @@ class FwdflatSearch:
                        "psgpu_fwdflat_search_dev")
         out = []
         res_h = res.cpu().numpy()
+        # one transfer per table for the whole batch (cut to the longest utterance's entries), sliced on the host
+        mb, mh = max(1, int(res_h[:, 0].max())), max(1, int(res_h[:, 1].max()))
+        bp_h = bp[:, :, :mb].contiguous().cpu().numpy(); bss_h = bss[:, :mh].contiguous().cpu().numpy()
+        idx_h = idx.cpu().numpy(); step_h = step.cpu().numpy()
         for u in range(n):
             nb, nh, nfr, status = [int(v) for v in res_h[u, :4]]
-            out.append(dict(bp=bp[u, :, :nb].cpu().numpy().T.copy(), bscore_stack=bss[u, :nh].cpu().numpy(),
-                            bp_table_idx=idx[u, :nfr + 1].cpu().numpy(), step=step[u, :nfr].cpu().numpy(),
+            out.append(dict(bp=bp_h[u, :, :nb].T.copy(), bscore_stack=bss_h[u, :nh].copy(),
+                            bp_table_idx=idx_h[u, :nfr + 1].copy(), step=step_h[u, :nfr].copy(),
                             n_frame=nfr, status=status))
         return out
