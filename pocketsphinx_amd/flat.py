@@ -117,6 +117,8 @@ class FwdflatSearch:
                                                            p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), sp),
                        "psgpu_fwdflat_search_dev")
         out = []
+        if n == 0:
+            return out
         res_h = res.cpu().numpy()
         # one transfer per table for the whole batch (cut to the longest utterance's entries), sliced on the host
         mb, mh = max(1, int(res_h[:, 0].max())), max(1, int(res_h[:, 1].max()))

@@ -84,6 +84,8 @@ class FwdtreeSearch:
                                                        int(pl_window), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                    "psgpu_fwdtree_search_dev")
         out = []
+        if n == 0:
+            return out
         res_h = res.cpu().numpy()
         # one transfer per table for the whole batch (cut to the longest utterance's entries), sliced on the host
         mb, mh = max(1, int(res_h[:, 0].max())), max(1, int(res_h[:, 1].max()))
