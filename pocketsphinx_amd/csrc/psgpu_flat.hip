@@ -792,16 +792,20 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     std::vector<int32_t> res1((size_t)n_utt * 8);
     PSGPU_HIP(hipMemcpyAsync(res1.data(), result1_dev, sizeof(int32_t) * res1.size(), hipMemcpyDeviceToHost, st));
     PSGPU_HIP(hipStreamSynchronize(st));
-    std::vector<std::vector<int32_t>> cols((size_t)n_utt * 3);
+    // three strided copies for the whole batch: column k of every utterance's table, cut to the longest table
+    int max_nb = 1;
     for (int u = 0; u < n_utt; ++u) {
         const int nb = res1[(size_t)u * 8];
-        PSGPU_REQUIRE(nb >= 0 && nb <= bp1_cap, "psgpu_fwdflat_search_dev: utterance %d: %d first-pass back-pointers, capacity %d", u, nb, bp1_cap);
+        PSGPU_REQUIRE(nb >= 0 && nb <= bp1_cap, "psgpu_fwdflat_search: utterance %d: %d first-pass back-pointers, capacity %d", u, nb, bp1_cap);
+        max_nb = std::max(max_nb, nb);
+    }
+    std::vector<int32_t> cols((size_t)3 * n_utt * max_nb);
+    {
         static const int kCol[3] = {F_FRAME, F_WID, F_BP};
-        for (int k = 0; k < 3; ++k) {
-            cols[(size_t)u * 3 + k].resize(nb);
-            if (nb) PSGPU_HIP(hipMemcpyAsync(cols[(size_t)u * 3 + k].data(), bp1_dev + ((size_t)u * 10 + kCol[k]) * bp1_cap,
-                                             sizeof(int32_t) * nb, hipMemcpyDeviceToHost, st));
-        }
+        for (int k = 0; k < 3; ++k)
+            PSGPU_HIP(hipMemcpy2DAsync(cols.data() + (size_t)k * n_utt * max_nb, sizeof(int32_t) * max_nb,
+                                       bp1_dev + (size_t)kCol[k] * bp1_cap, sizeof(int32_t) * 10 * bp1_cap,
+                                       sizeof(int32_t) * max_nb, n_utt, hipMemcpyDeviceToHost, st));
     }
     PSGPU_HIP(hipStreamSynchronize(st));
     // ---- vocabulary + chain layout per utterance, slab sizes
@@ -810,7 +814,8 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     const int n_tail = d.n_w - d.startwid;
     for (int u = 0; u < n_utt; ++u) {
         const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
-        ff_build_vocab(m, cols[(size_t)u * 3].data(), cols[(size_t)u * 3 + 1].data(), cols[(size_t)u * 3 + 2].data(), nb, nfr, d.n1, voc[u]);
+        const int32_t *cu = cols.data() + (size_t)u * max_nb;
+        ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
         const size_t C = (size_t)d.n1 + voc[u].n_chan, nwd = voc[u].wid.size(), cap = nwd + n_tail + 1;
         slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 4) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);

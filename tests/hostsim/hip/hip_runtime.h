@@ -1,7 +1,7 @@
 // tests/hostsim/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
 //
 // A workgroup simulator for CPU-only checks of kernel LOGIC: the unmodified kernel sources of
-// pocketsphinx_amd/csrc (psgpu_search.hip, psgpu_lm.hip) are compiled with g++ against this header
+// pocketsphinx_amd/csrc (psgpu_search.hip, psgpu_flat.hip, psgpu_lm.hip) are compiled with g++ against this header
 // instead of the HIP runtime, and a launch runs every workgroup on the host: one fiber per
 // work-item, cooperative switches at __syncthreads() and at the cross-lane operations, so the
 // barrier structure, prefix sums, list orders and table contents a kernel produces can be compared
@@ -105,6 +105,11 @@ inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t)
+{
+    for (size_t r = 0; r < height; ++r) memcpy((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
