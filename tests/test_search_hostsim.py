@@ -99,3 +99,42 @@ def test_simulated_device_trie_equals_reference_look_ups(name):
     sc, nu = lm.tg_score(q)
     assert np.array_equal(sc, g["scores"][:q.shape[0]]) and np.array_equal(nu, g["n_used"][:q.shape[0]])
     lm.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("case", ["goforward", "numbers", "medium_goforward"])
+def test_search_kernel_source_building_its_own_active_lists(case, mode):
+    """raw-score mode (the kernel builds each frame's active senone list, bridging entries included, and subtracts the
+    list's minimum itself, as the PTM scorer does): fed the reference's normalised scores plus an arbitrary per-frame
+    offset -- the listed senones' minimum is 0 in the PTM scorer's rows, so the kernel must recover them exactly --
+    and garbage in every senone the search does not ask for.  (PTM traces only: the semi-continuous scorer of the
+    tidigits trace does not normalise by the minimum.)"""
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    lm = simlib.SimLm(st) if "lm" not in st else None
+    s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm, list_mode=mode)
+    rows, pen = _inputs(g, s.n_sen)
+    rng = np.random.default_rng(5)
+    off, act = g["step_act_off"], g["step_act"]
+    raw = rng.integers(-30000, 30000, rows.shape).astype(np.int16)          # what nobody should read
+    for i in range(rows.shape[0]):
+        a = act[off[i]:off[i + 1]]
+        raw[i, a] = (rows[i, a].astype(np.int32) + int(rng.integers(-2000, 2000))).astype(np.int16)
+    with _order("rev"):
+        _check(s.search(raw, pen, [rows.shape[0]], raw_scores=True, pl_window=0)[0], g, case)
+    s.close()
+
+
+def test_search_kernel_source_full_cmudict_own_active_lists(big_trace):  # noqa: F811
+    """the same at full scale: ACTIVE_LIST, 1024 work-items, the tree search building its own active lists"""
+    g = big_trace
+    lm = simlib.SimLm(g)
+    s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm, list_mode=1)
+    rows, pen = _inputs(g, s.n_sen)
+    off, act = g["step_act_off"], g["step_act"]
+    raw = np.full(rows.shape, 12345, np.int16)
+    for i in range(rows.shape[0]):
+        a = act[off[i]:off[i + 1]]
+        raw[i, a] = (rows[i, a].astype(np.int32) + 777 - 5 * (i % 50)).astype(np.int16)
+    _check(s.search(raw, pen, [rows.shape[0]], raw_scores=True, pl_window=0)[0], g, "cmudict raw")
+    s.close(); lm.close()
