@@ -119,3 +119,21 @@ def test_second_pass_seed_is_a_first_pass_list(case):
         o.set_frame_idx(i)
         sc = o.frame_eval(feats[i], i, active=np.diff(np.concatenate([[0], a])).astype(np.uint8), compallsen=False)
         assert np.array_equal(sc[a], scr[off[i]:off[i + 1]]), "frame %d" % i
+
+
+@pytest.mark.parametrize("scoring", [False, True])
+def test_flat_kernel_source_full_cmudict_vocabulary(big_flat_trace, scoring):
+    """the second-pass kernel at full scale (134,865-word dictionary, trie language scores, per-word arrays sized for the
+    dictionary, an utterance vocabulary of ~150 words in ~4,400 chain channels), with the scores given and scoring its
+    own senones from the feature rows"""
+    import pso
+    g = big_flat_trace
+    lm = simlib.SimLm(g)
+    s = simlib.SimFwdflatSearch(g, g, g["par"], g["flat_par"], g["flat_lwf"], lm=lm)
+    nfr = int(g["n_frame"][0])
+    if scoring:
+        r = s.search(g["flat_feat"], [nfr], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=pso.load_tables(), topn_seed=g["flat_ptm_seed"])[0]
+    else:
+        r = s.search(flat_rows(g, s.n_sen), [nfr], [g["bp1"]], [g["flat_w1_ssid"]])[0]
+    check_flat(r, g, "cmudict")
+    s.close(); lm.close()

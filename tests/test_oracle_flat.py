@@ -46,3 +46,25 @@ def test_fwdflat_oracle_matches_reference(case):
     assert bad.size == 0, "first differing back-pointer %d: %r vs %r" % (bad[0], bp[bad[0]], g["bp"][bad[0]])
     assert np.array_equal(o.bscore_stack(), g["bscore_stack"])
     assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
+
+
+def test_fwdflat_oracle_large_vocabulary(big_flat_trace):
+    """The second-pass oracle at full scale: every base word of cmudict in the dictionary (134,865 entries), the
+    synthetic large LM (trie language scores), the first pass's 2,613-entry table; the fixture is produced at test
+    time by the compiled reference.  Vocabulary, per-frame active lists / best scores / back-pointer counts and the
+    final tables must be the reference's."""
+    g = big_flat_trace
+    assert bytes(g["hyp"]).decode() == "go forward ten meters" and int(g["par"][3]) > 100000
+    o = pso.OracleFwdflat(g, g, g, lm=pso.OracleLm(g))
+    nfr = int(g["n_frame"][0])
+    o.start(g["bp1"], nfr, g["flat_w1_ssid"])
+    assert np.array_equal(o.wordlist(), g["flat_wordlist"])
+    off, act, scr = g["flat_act_off"], g["flat_act"], g["flat_scr"]
+    for i in range(nfr):
+        a0, a1 = int(off[i]), int(off[i + 1])
+        assert np.array_equal(o.active_list(i), act[a0:a1]), "frame %d: active senone list" % i
+        o.step(i, act[a0:a1], scr[a0:a1], int(g["flat_rest"][i]))
+        assert (o.best_score(), o.bpidx()) == (int(g["flat_best"][i]), int(g["flat_bpidx"][i])), "frame %d" % i
+    o.finish(nfr)
+    assert np.array_equal(o.bp_table(), g["bp"]) and np.array_equal(o.bscore_stack(), g["bscore_stack"])
+    assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])

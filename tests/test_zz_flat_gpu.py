@@ -191,3 +191,26 @@ def test_dropin_device_two_passes(raw, extra, lm, dic, monkeypatch):
     assert r["ok"] and r["rc"] == 0, r
     assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
     assert r["n_seg"] > 0, r
+
+
+def test_fwdflat_kernel_full_cmudict_vocabulary(tmp_path):
+    """134,865-word dictionary, trie language scores: the second pass on the first pass's 2,613-entry table"""
+    import os
+    import pso
+    if not os.path.exists(os.path.join(pso.REF_DIR, "ref_dump")):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    run_isolated(ME, "impl_full_cmudict", str(tmp_path), timeout=1500)
+
+
+def impl_full_cmudict(tmp):
+    import pocketsphinx_amd as P
+    import pso
+    from conftest import make_big_flat_trace
+    g = make_big_flat_trace(tmp)
+    lm = P.NGramTrieLM(g)
+    s = P.FwdflatSearch(g, g, g["par"], g["flat_par"], g["flat_lwf"], lm=lm)
+    nfr = int(g["n_frame"][0])
+    check_flat(s.search(flat_rows(g, s.n_sen), [nfr], [g["bp1"]], [g["flat_w1_ssid"]])[0], g, "cmudict")
+    model = P.PtmModel(pso.load_tables())
+    check_flat(s.search(g["flat_feat"], [nfr], [g["bp1"]], [g["flat_w1_ssid"]], ptm=model, topn_seed=g["flat_ptm_seed"][None])[0], g, "cmudict, scoring")
+    s.close(); model.close()
