@@ -137,3 +137,19 @@ def test_flat_kernel_source_full_cmudict_vocabulary(big_flat_trace, scoring):
         r = s.search(flat_rows(g, s.n_sen), [nfr], [g["bp1"]], [g["flat_w1_ssid"]])[0]
     check_flat(r, g, "cmudict")
     s.close(); lm.close()
+
+
+def test_two_passes_chained_full_cmudict_vocabulary(big_flat_trace):
+    """both kernels at full scale, chained through their own buffers: the tree search (ACTIVE_LIST, 1024 work-items) on the
+    first pass's trace of the same two-pass decode, then the flat search on what it left"""
+    from test_search_gpu import _inputs
+    g = big_flat_trace
+    lm = simlib.SimLm(g)
+    s1 = simlib.SimFwdtreeSearch(g, g["par"], lm=lm, list_mode=1)
+    rows1, pen1 = _inputs(g, s1.n_sen)
+    h = {}
+    r1 = s1.search(rows1, pen1, [rows1.shape[0]], handover=h)[0]
+    assert np.array_equal(r1["bp"], g["bp1"]) and np.array_equal(h["w1_ssid"][0], g["flat_w1_ssid"])
+    s2 = simlib.SimFwdflatSearch(g, g, g["par"], g["flat_par"], g["flat_lwf"], lm=lm)
+    check_flat(s2.search(flat_rows(g, s2.n_sen), [int(g["flat_n_steps"][0])], h)[0], g, "cmudict chained")
+    s1.close(); s2.close(); lm.close()
