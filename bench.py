@@ -415,7 +415,14 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
     if not os.environ.get("PSGPU_BENCH_NO_CHILD"):
         import subprocess
 
+        t_children = time.perf_counter()
+
         def child(key, argv, env, limit):
+            left = 300.0 - (time.perf_counter() - t_children)        # all children together: five minutes at most
+            if left < 20.0:
+                out[key] = {"skipped": "time budget of the child-process extras used up"}
+                return
+            limit = min(limit, left)
             try:
                 r = subprocess.run([sys.executable] + argv, env=dict(os.environ, **env), capture_output=True, text=True, timeout=limit)
                 lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
