@@ -438,15 +438,15 @@ def extras(P, capi, L, model, t, feats_h, dev, sp):
         child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 150)
         # (9) the tree search on the full cmudict task (134,865 words), large-vocabulary formulation;
         #     the default formulation measured 1.19 s for one utterance, 5.5 k frames/s at 32 per launch (profiles/r01i_*)
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
+            child("search_cmudict_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
+                  {"SB_CASE": "cmudict", "SB_MODE": "active_list", "SB_BATCHES": "1,32", "SB_REPS": "1"}, 200)
         # (9a) the same formulation on the tasks the default one was measured on (3.6 M frames/s at 512 utterances,
         #      turtle; 1.5 M on the 715-word task): the A/B that decides which becomes the default
         child("search_turtle_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
               {"SB_CASE": "goforward", "SB_MODE": "active_list", "SB_BATCHES": "512,1024", "SB_REPS": "2"}, 120)
         child("search_medium_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
               {"SB_CASE": "medium_goforward", "SB_MODE": "active_list", "SB_BATCHES": "512", "SB_REPS": "2"}, 120)
-        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
-            child("search_cmudict_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
-                  {"SB_CASE": "cmudict", "SB_MODE": "active_list", "SB_BATCHES": "1,32", "SB_REPS": "1"}, 200)
     return out
 
 
