@@ -91,51 +91,55 @@ struct psgpu_fwdtree_s {
 #define BPC(u, col, i) ((u).bp[(size_t)(col) * (u).bp_cap + (i)])
 enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2 };
 
+template <int CS, int C1>
 __device__ __forceinline__ void ch_clear(const FtDev &p, FtUtt &u, int c)      // hmm_clear, hmm.c:181-196
 {
-    for (int i = 0; i < p.n_emit; ++i) { u.score[c * 5 + i] = kW; u.hist[c * 5 + i] = -1; }
-    u.out[c] = kW; u.outh[c] = -1; u.best[c] = kW; u.frame[c] = -1;
+    for (int i = 0; i < p.n_emit; ++i) { u.score[c * CS + i] = kW; u.hist[c * CS + i] = -1; }
+    u.out[(c) * C1] = kW; u.outh[(c) * C1] = -1; u.best[(c) * C1] = kW; u.frame[(c) * C1] = -1;
 }
+template <int CS, int C1>
 __device__ __forceinline__ void ch_init(const FtDev &p, FtUtt &u, int c, int mpx, int ssid, int tmatid)   // hmm_init :146-168
 {
-    u.mpx[c] = mpx; u.tmat[c] = tmatid;
+    u.mpx[(c) * C1] = mpx; u.tmat[(c) * C1] = tmatid;
     if (mpx) {
-        u.senid[c * 5] = ssid;
-        for (int i = 1; i < p.n_emit; ++i) u.senid[c * 5 + i] = kBadSsid;
+        u.senid[c * CS] = ssid;
+        for (int i = 1; i < p.n_emit; ++i) u.senid[c * CS + i] = kBadSsid;
     }
     else
-        for (int i = 0; i < p.n_emit; ++i) u.senid[c * 5 + i] = p.sseq[(size_t)ssid * p.n_emit + i];
-    ch_clear(p, u, c);
+        for (int i = 0; i < p.n_emit; ++i) u.senid[c * CS + i] = p.sseq[(size_t)ssid * p.n_emit + i];
+    ch_clear<CS, C1>(p, u, c);
 }
+template <int CS, int C1>
 __device__ __forceinline__ void ch_enter(FtUtt &u, int c, int32_t score, int32_t hist, int frame)   // hmm_enter :198-204
 {
-    u.score[c * 5] = score; u.hist[c * 5] = hist; u.frame[c] = frame;
+    u.score[c * CS] = score; u.hist[c * CS] = hist; u.frame[(c) * C1] = frame;
 }
+template <int CS, int C1>
 __device__ __forceinline__ void ch_normalize(const FtDev &p, FtUtt &u, int c, int32_t norm)      // hmm_normalize :206-217
 {
-    for (int i = 0; i < p.n_emit; ++i) if (u.score[c * 5 + i] > kW) u.score[c * 5 + i] -= norm;
-    if (u.out[c] > kW) u.out[c] -= norm;
+    for (int i = 0; i < p.n_emit; ++i) if (u.score[c * CS + i] > kW) u.score[c * CS + i] -= norm;
+    if (u.out[(c) * C1] > kW) u.out[(c) * C1] -= norm;
 }
 
 // hmm_vit_eval on channel c with the frame's score row
-template <int NE>
+template <int NE, int CS, int C1>
 __device__ __forceinline__ int32_t ch_eval(const FtDev &p, FtUtt &u, int c, const int16_t *row)
 {
     HmmRegs h;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        h.score[i] = i < NE ? u.score[c * 5 + i] : kW;
-        h.history[i] = i < NE ? u.hist[c * 5 + i] : -1;
-        h.senid[i] = i < NE ? (uint16_t)u.senid[c * 5 + i] : 0;
+        h.score[i] = i < NE ? u.score[c * CS + i] : kW;
+        h.history[i] = i < NE ? u.hist[c * CS + i] : -1;
+        h.senid[i] = i < NE ? (uint16_t)u.senid[c * CS + i] : 0;
     }
-    h.out_score = u.out[c]; h.out_history = u.outh[c]; h.bestscore = u.best[c];
-    const uint8_t *tp = p.tp + (size_t)u.tmat[c] * NE * (NE + 1);
+    h.out_score = u.out[(c) * C1]; h.out_history = u.outh[(c) * C1]; h.bestscore = u.best[(c) * C1];
+    const uint8_t *tp = p.tp + (size_t)u.tmat[(c) * C1] * NE * (NE + 1);
     int32_t b;
-    if (NE == 3) b = u.mpx[c] ? vit3_mpx(h, tp, row, p.sseq) : vit3(h, tp, row);
-    else         b = u.mpx[c] ? vit5_mpx(h, tp, row, p.sseq) : vit5(h, tp, row);
+    if (NE == 3) b = u.mpx[(c) * C1] ? vit3_mpx(h, tp, row, p.sseq) : vit3(h, tp, row);
+    else         b = u.mpx[(c) * C1] ? vit5_mpx(h, tp, row, p.sseq) : vit5(h, tp, row);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) { u.score[c * 5 + i] = h.score[i]; u.hist[c * 5 + i] = h.history[i]; u.senid[c * 5 + i] = h.senid[i]; }
-    u.out[c] = h.out_score; u.outh[c] = h.out_history; u.best[c] = h.bestscore;
+    for (int i = 0; i < NE; ++i) { u.score[c * CS + i] = h.score[i]; u.hist[c * CS + i] = h.history[i]; u.senid[c * CS + i] = h.senid[i]; }
+    u.out[(c) * C1] = h.out_score; u.outh[(c) * C1] = h.out_history; u.best[(c) * C1] = h.bestscore;
     return b;
 }
 
@@ -262,6 +266,10 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     __shared__ int32_t s_bins[256];
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
+    // channel state: PER_NODE keeps one array per field ([C][5] / [C]); ACTIVE_LIST one record of CS ints per channel (score,
+    // hist, out, outh, best, frame, senid, tmat, mpx: 64 bytes for 3-state models) -- its passes gather by channel id, and a
+    // record is one cache line where the arrays are nine
+    constexpr int CS = LIST ? (NE == 3 ? 16 : 24) : 5, C1 = LIST ? CS : 1;
     const int tid = threadIdx.x;
     FtUtt u = utts[blockIdx.x];
     // list-position / candidate / word scratch: LDS when the tree and the vocabulary fit (kFtMaxN entries), else the slab
@@ -271,8 +279,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     int n_acl[2] = {0, 0}, n_awl[2] = {0, 0};           // uniform copies (every thread tracks them identically)
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
-    for (int c = tid; c < N; c += NT) ch_init(p, u, c, c < R, p.node_ssid[c], p.node_tmat[c]);
-    for (int i = tid; i < p.n1; i += NT) ch_init(p, u, W1 + i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i]);
+    for (int c = tid; c < N; c += NT) ch_init<CS, C1>(p, u, c, c < R, p.node_ssid[c], p.node_tmat[c]);
+    for (int i = tid; i < p.n1; i += NT) ch_init<CS, C1>(p, u, W1 + i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i]);
     for (int i = tid; i < p.TOT; i += NT) u.present[i] = 0;
     for (int w = tid; w < p.n_w; w += NT) { u.word_lat_idx[w] = -1; u.lt_sf[w] = -1; u.word_active[w] = 0; }
     if (LIST) {                                  // pos is kept at -1 between frames; no word has been a candidate yet
@@ -284,7 +292,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         s_evals = 0ull;
     }
     __syncthreads();
-    if (tid == 0) ch_enter(u, W1 + p.w1_of_word[p.startwid], 0, -1, 0);
+    if (tid == 0) ch_enter<CS, C1>(u, W1 + p.w1_of_word[p.startwid], 0, -1, 0);
     __syncthreads();
 
     for (int f = 0; f < T; ++f) {
@@ -302,18 +310,18 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             __syncthreads();
             auto mark = [&](int c) {
                 for (int k = 0; k < NE; ++k) {
-                    int sen = u.senid[c * 5 + k];
-                    if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + k]; }
+                    int sen = u.senid[c * CS + k];
+                    if (u.mpx[(c) * C1]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + k]; }
                     atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
                 }
             };
-            for (int i = tid; i < R; i += NT) if (u.frame[i] == f) mark(i);
+            for (int i = tid; i < R; i += NT) if (u.frame[(i) * C1] == f) mark(i);
             for (int i = tid; i < n_acl[cur]; i += NT) mark(u.acl[cur][i]);
             for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) mark(WC + k);
             }
-            for (int i = tid; i < p.n1; i += NT) if (u.frame[W1 + i] == f) mark(W1 + i);
+            for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) mark(W1 + i);
             __syncthreads();
             {   // s_prev[w] = the highest senone listed in the words before w (one bitmap word per thread)
                 static_assert(kFtMaxSen / 32 <= NT, "one bitmap word per thread");
@@ -353,13 +361,13 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
-            for (int i = tid; i < R; i += NT) if (u.frame[i] == f) ch_normalize(p, u, i, best_in);
-            for (int i = tid; i < n_acl[cur]; i += NT) ch_normalize(p, u, u.acl[cur][i], best_in);
+            for (int i = tid; i < R; i += NT) if (u.frame[(i) * C1] == f) ch_normalize<CS, C1>(p, u, i, best_in);
+            for (int i = tid; i < n_acl[cur]; i += NT) ch_normalize<CS, C1>(p, u, u.acl[cur][i], best_in);
             for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
-                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) ch_normalize(p, u, WC + k, best_in);
+                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) ch_normalize<CS, C1>(p, u, WC + k, best_in);
             }
-            for (int i = tid; i < p.n1; i += NT) if (u.frame[W1 + i] == f) ch_normalize(p, u, W1 + i, best_in);
+            for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) ch_normalize<CS, C1>(p, u, W1 + i, best_in);
         }
         if (tid < 8) s_red[tid] = kW;
         __syncthreads();
@@ -367,17 +375,17 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         {
             int32_t b0 = kW, b1 = kW, b2 = kW; int n0 = 0, n2 = 0;
             for (int i = tid; i < R; i += NT)
-                if (u.frame[i] == f) { b0 = max(b0, ch_eval<NE>(p, u, i, row)); ++n0; }
-            for (int i = tid; i < n_acl[cur]; i += NT) b1 = max(b1, ch_eval<NE>(p, u, u.acl[cur][i], row));
+                if (u.frame[(i) * C1] == f) { b0 = max(b0, ch_eval<NE, CS, C1>(p, u, i, row)); ++n0; }
+            for (int i = tid; i < n_acl[cur]; i += NT) b1 = max(b1, ch_eval<NE, CS, C1>(p, u, u.acl[cur][i], row));
             for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 u.word_active[w] = 0;
                 for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
-                    if (u.present[k]) { b2 = max(b2, ch_eval<NE>(p, u, WC + k, row)); ++n2; }
+                    if (u.present[k]) { b2 = max(b2, ch_eval<NE, CS, C1>(p, u, WC + k, row)); ++n2; }
             }
             for (int i = tid; i < p.n1; i += NT) {
-                if (u.frame[W1 + i] < f) continue;
-                const int32_t sc = ch_eval<NE>(p, u, W1 + i, row);
+                if (u.frame[(W1 + i) * C1] < f) continue;
+                const int32_t sc = ch_eval<NE, CS, C1>(p, u, W1 + i, row);
                 if (p.w1_wid[i] != p.finishwid) b2 = max(b2, sc);
                 ++n2;
             }
@@ -401,7 +409,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int32_t bw = -p.beam / 256;
             for (int i = tid; i < R + n_acl[cur]; i += NT) {
                 const int c = i < R ? i : u.acl[cur][i - R];
-                int32_t b = (best_score - u.best[c]) / bw;
+                int32_t b = (best_score - u.best[(c) * C1]) / bw;
                 if (b >= 256) b = 255;
                 atomicAdd(&s_bins[b], 1);
             }
@@ -425,9 +433,9 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             for (int q = tid; q < na; q += NT) u.pos[u.acl[cur][q]] = q;
             for (int i = tid; i < R + na; i += NT) {
                 const int node = i < R ? i : u.acl[cur][i - R];
-                const bool active = i < R ? u.frame[node] >= f : true;
-                u.o_out[node] = u.out[node]; u.o_outh[node] = u.outh[node];
-                u.flag[node] = (active && u.best[node] > thresh) ? 1 : 0;
+                const bool active = i < R ? u.frame[(node) * C1] >= f : true;
+                u.o_out[node] = u.out[(node) * C1]; u.o_outh[node] = u.outh[(node) * C1];
+                u.flag[node] = (active && u.best[(node) * C1] > thresh) ? 1 : 0;
             }
             __syncthreads();
             auto decide = [&](int c) {
@@ -439,14 +447,14 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
                 const bool retc = in_acl && (u.flag[c] & 1);
                 bool fire;
-                if (!in_acl || parent_first) fire = parent_can && (u.frame[c] < f || news > u.score[c * 5]);
-                else if (retc)               fire = parent_can && news > u.score[c * 5];
+                if (!in_acl || parent_first) fire = parent_can && (u.frame[(c) * C1] < f || news > u.score[c * CS]);
+                else if (retc)               fire = parent_can && news > u.score[c * CS];
                 else                         fire = parent_can;
                 const bool entered_first = fire && parent_first;
                 const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
-                if (in_acl && !retc && !entered_first) ch_clear(p, u, c);
-                if (retc) u.frame[c] = nf;
-                if (fire) ch_enter(u, c, news, u.o_outh[P], nf);
+                if (in_acl && !retc && !entered_first) ch_clear<CS, C1>(p, u, c);
+                if (retc) u.frame[(c) * C1] = nf;
+                if (fire) ch_enter<CS, C1>(u, c, news, u.o_outh[P], nf);
                 u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
             };
             for (int i = tid; i < R + na; i += NT) {
@@ -459,12 +467,12 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             }
             __syncthreads();
             for (int q = tid; q < na; q += NT) u.pos[u.acl[cur][q]] = -1;        // (nothing below reads pos or a root's frame
-            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[i] = nf;  //  before the next barrier)
+            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[(i) * C1] = nf;  //  before the next barrier)
         }
         else {
             for (int i = tid; i < N; i += NT) {
-                u.pos[i] = -1; u.o_frame[i] = u.frame[i]; u.o_s0[i] = u.score[i * 5]; u.o_best[i] = u.best[i];
-                u.o_out[i] = u.out[i]; u.o_outh[i] = u.outh[i];
+                u.pos[i] = -1; u.o_frame[i] = u.frame[(i) * C1]; u.o_s0[i] = u.score[i * CS]; u.o_best[i] = u.best[(i) * C1];
+                u.o_out[i] = u.out[(i) * C1]; u.o_outh[i] = u.outh[(i) * C1];
             }
             __syncthreads();
             for (int q = tid; q < n_acl[cur]; q += NT) u.pos[u.acl[cur][q]] = q;
@@ -491,13 +499,13 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 const bool selfapp = in_acl && retc && !entered_first;
                 const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
                 const bool cleared = in_acl && !retc && !entered_first;
-                if (cleared) ch_clear(p, u, c);
-                if (in_acl && retc) u.frame[c] = nf;
-                if (fire) ch_enter(u, c, news, u.o_outh[P], nf);
+                if (cleared) ch_clear<CS, C1>(p, u, c);
+                if (in_acl && retc) u.frame[(c) * C1] = nf;
+                if (fire) ch_enter<CS, C1>(u, c, news, u.o_outh[P], nf);
                 // decision word for the list phase; o_frame[c] is read by this thread only, so it can be reused
                 u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | (selfapp ? 8 : 0);
             }
-            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[i] = nf;
+            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[(i) * C1] = nf;
             __syncthreads();
         }
         // list positions: root phase (segment per root), then one segment per list position
@@ -654,14 +662,14 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     for (int r = 0; r < nrc; ++r) {
                         const int slot = p.wc_off[w] + r;
                         if (!u.present[slot]) {
-                            ch_init(p, u, WC + slot, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last]);
+                            ch_init<CS, C1>(p, u, WC + slot, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last]);
                             u.present[slot] = 1;
                         }
                     }
                     for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
                         if (!u.present[slot]) continue;
                         const int c = WC + slot;
-                        if (u.frame[c] < f || u.cand_score[i] > u.score[c * 5]) { ch_enter(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
+                        if (u.frame[(c) * C1] < f || u.cand_score[i] > u.score[c * CS]) { ch_enter<CS, C1>(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
                     }
                 }
                 cnt[i] = k > 0;
@@ -695,8 +703,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
                     if (!u.present[slot]) continue;
                     const int c = WC + slot;
-                    if (u.best[c] > lpth) { u.frame[c] = nf; ++k; ex |= (u.out[c] > nwt); }
-                    else if (u.frame[c] != nf) u.present[slot] = 0;
+                    if (u.best[(c) * C1] > lpth) { u.frame[(c) * C1] = nf; ++k; ex |= (u.out[(c) * C1] > nwt); }
+                    else if (u.frame[(c) * C1] != nf) u.present[slot] = 0;
                 }
                 w_k[i] = k; w_exit[i] = ex;
                 if (LIST) {                              // inputs of the three prefix sums below
@@ -747,8 +755,8 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
                         if (!u.present[slot]) continue;
                         const int c = WC + slot;
-                        if (u.frame[c] == nf && u.best[c] > lpth && u.out[c] > nwt)
-                            ft_save_bp(p, u, bpi, bsh, f, w, u.out[c], u.outh[c], slot - p.wc_off[w]);
+                        if (u.frame[(c) * C1] == nf && u.best[(c) * C1] > lpth && u.out[(c) * C1] > nwt)
+                            ft_save_bp(p, u, bpi, bsh, f, w, u.out[(c) * C1], u.outh[(c) * C1], slot - p.wc_off[w]);
                     }
                 }
             }
@@ -762,9 +770,9 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             for (int i = tid; i < p.n1; i += NT) {
                 const int c = W1 + i;
                 int ex = 0, nw = 0, rcn = 0;
-                if (u.frame[c] >= f && u.best[c] > lpth) {
-                    u.frame[c] = nf;
-                    if (u.out[c] > nwt) {
+                if (u.frame[(c) * C1] >= f && u.best[(c) * C1] > lpth) {
+                    u.frame[(c) * C1] = nf;
+                    if (u.out[(c) * C1] > nwt) {
                         const int w = p.w1_wid[i];
                         ex = 1;
                         if (u.word_lat_idx[w] == -1) {
@@ -782,7 +790,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             for (int i = tid; i < p.n1; i += NT)
                 if (f_ex[i]) {
                     int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
-                    if (!ft_save_bp(p, u, bpi, bsh, f, p.w1_wid[i], u.out[W1 + i], u.outh[W1 + i], 0)) s_sc[6] = 1;
+                    if (!ft_save_bp(p, u, bpi, bsh, f, p.w1_wid[i], u.out[(W1 + i) * C1], u.outh[(W1 + i) * C1], 0)) s_sc[6] = 1;
                 }
             __syncthreads();
             if (tid == 0) { s_sc[3] = bpidx0 + n_new; s_sc[4] = bss0 + n_rc; }
@@ -793,10 +801,10 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
             for (int i = 0; i < p.n1 && ok && !LIST; ++i) {
                 const int c = W1 + i;
-                if (u.frame[c] < f) continue;
-                if (u.best[c] > lpth) {
-                    u.frame[c] = nf;
-                    if (u.out[c] > nwt) ok = ft_save_bp(p, u, bpidx, bss_head, f, p.w1_wid[i], u.out[c], u.outh[c], 0);
+                if (u.frame[(c) * C1] < f) continue;
+                if (u.best[(c) * C1] > lpth) {
+                    u.frame[(c) * C1] = nf;
+                    if (u.out[(c) * C1] > nwt) ok = ft_save_bp(p, u, bpidx, bss_head, f, p.w1_wid[i], u.out[(c) * C1], u.outh[(c) * C1], 0);
                 }
             }
             // bptable_maxwpf (:1193-1241)
@@ -849,9 +857,9 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             for (int i = tid; i < R; i += NT) {          // tree roots (:1306-1325)
                 const int ci = p.node_ci[i];
                 const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
-                if (ns + ft_pen(p, pp, ci) > thresh && (u.frame[i] < f || ns > u.score[i * 5])) {
-                    ch_enter(u, i, ns, brc_path[ci], nf);
-                    u.senid[i * 5] = p.ldiph[((size_t)ci * p.n_ci + p.node_ci2[i]) * p.n_ci + brc_lc[ci]];
+                if (ns + ft_pen(p, pp, ci) > thresh && (u.frame[(i) * C1] < f || ns > u.score[i * CS])) {
+                    ch_enter<CS, C1>(u, i, ns, brc_path[ci], nf);
+                    u.senid[i * CS] = p.ldiph[((size_t)ci * p.n_ci + p.node_ci2[i]) * p.n_ci + brc_lc[ci]];
                 }
             }
             for (int i = tid; i < p.n1lm; i += NT) {     // in-LM single-phone words (:1331-1388)
@@ -867,9 +875,9 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 if (w == p.startwid) continue;
                 const int c = W1 + i;
                 const int32_t ns = ds + p.pip;
-                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[c] < f || ns > u.score[c * 5])) {
-                    ch_enter(u, c, ns, dbp, nf);
-                    u.senid[c * 5] = p.ldiph[((size_t)p.w1_ci[i] * p.n_ci + p.w1_ci2[i]) * p.n_ci + p.d_last[BPC(u, B_WID, dbp)]];
+                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[(c) * C1] < f || ns > u.score[c * CS])) {
+                    ch_enter<CS, C1>(u, c, ns, dbp, nf);
+                    u.senid[c * CS] = p.ldiph[((size_t)p.w1_ci[i] * p.n_ci + p.w1_ci2[i]) * p.n_ci + p.d_last[BPC(u, B_WID, dbp)]];
                 }
             }
             for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += NT) {    // <sil> and noise words (:1390-1426)
@@ -880,14 +888,14 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 if (i < 0) continue;
                 const int c = W1 + i;
                 const int32_t ns = brc_score[p.sil_ci] + (is_sil ? p.silpen : p.fillpen) + p.pip;
-                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[c] < f || ns > u.score[c * 5]))
-                    ch_enter(u, c, ns, brc_path[p.sil_ci], nf);
+                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[(c) * C1] < f || ns > u.score[c * CS]))
+                    ch_enter<CS, C1>(u, c, ns, brc_path[p.sil_ci], nf);
             }
         }
         __syncthreads();
         // ---- deactivate_channels (:1429-1450)
-        for (int i = tid; i < R; i += NT) if (u.frame[i] == f) ch_clear(p, u, i);
-        for (int i = tid; i < p.n1; i += NT) if (u.frame[W1 + i] == f) ch_clear(p, u, W1 + i);
+        for (int i = tid; i < R; i += NT) if (u.frame[(i) * C1] == f) ch_clear<CS, C1>(p, u, i);
+        for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) ch_clear<CS, C1>(p, u, W1 + i);
         if (tid == 0) {
             u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = s_sc[1]; u.step[f * 4 + 2] = s_sc[3]; u.step[f * 4 + 3] = n_acl[nxt];
             ++s_sc[7];
@@ -903,7 +911,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)
     if (p.w1_out)
         for (int i = tid; i < p.n1 * NE; i += NT)
-            p.w1_out[((size_t)blockIdx.x * p.n1 + i / NE) * NE + i % NE] = u.senid[(W1 + i / NE) * 5 + i % NE];
+            p.w1_out[((size_t)blockIdx.x * p.n1 + i / NE) * NE + i % NE] = u.senid[(W1 + i / NE) * CS + i % NE];
 }
 
 // ---------------------------------------------------------------------------
@@ -1038,7 +1046,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     hipStream_t st = (hipStream_t)stream;
     // per-utterance work slab
     const size_t C = m->C;
-    const size_t per = C * (5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
+    const size_t per = C * (d.list_mode ? 24 : 5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
                      + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
                      + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w
                      + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
@@ -1050,8 +1058,17 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         int32_t *q = slab + per * i;
         FtUtt &u = hu[i];
         auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
-        u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
-        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.present = take(d.TOT);
+        if (d.list_mode) {                                      // one record per channel (see the kernel)
+            const int ne = d.n_emit, rs = ne == 3 ? 16 : 24;
+            int32_t *rec = take(C * rs);
+            u.score = rec; u.hist = rec + ne; u.out = rec + 2 * ne; u.outh = u.out + 1; u.best = u.out + 2; u.frame = u.out + 3;
+            u.senid = u.out + 4; u.tmat = u.senid + ne; u.mpx = u.tmat + 1;
+        }
+        else {
+            u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
+            u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C);
+        }
+        u.present = take(d.TOT);
         u.acl[0] = take(d.N); u.acl[1] = take(d.N); u.awl[0] = take(d.n_w); u.awl[1] = take(d.n_w);
         u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
         u.cand_wid = take(d.n_w + 1); u.cand_score = take(d.n_w + 1); u.cand_bp = take(d.n_w + 1); u.cand_next = take(d.n_w + 1);
