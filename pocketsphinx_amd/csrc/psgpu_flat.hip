@@ -77,6 +77,24 @@ struct FfUtt {
     int32_t bp_cap, bss_cap;
 };
 
+// What the kernel is actually handed per utterance: the same fields as offsets (in int32 units) from buffers that are
+// kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
+// wait counters); pointers formed from a kernel argument are global.
+#define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(wchain) \
+    X(wlen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
+#define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf)
+struct FfOff {
+#define X(f) int64_t f;
+    FF_SLAB_FIELDS(X) FF_VOC_FIELDS(X)
+#undef X
+    int64_t awl0, awl1, nrow32, nrow;    // nrow32 / nrow: -1 when the scores are given
+    int32_t nwd, n_chan, n_frame, awl_cap;
+};
+struct FfBufs {
+    int32_t *slab; const int32_t *voc; int32_t *bp, *bss, *idx, *step, *res; const int32_t *w1_ssid;
+    int32_t bp_cap, bss_cap, max_frames;
+};
+
 struct psgpu_fwdflat_s {
     FfDev d;
     std::vector<void *> allocs;
@@ -257,7 +275,7 @@ __device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
 
 template <int NE, bool RAW>
 __global__ __launch_bounds__(kFfThreads)
-void fwdflat_kernel(FfDev p, const FfUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
+void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const int16_t *__restrict__ senscr, int64_t scr_stride,
                     const int32_t *__restrict__ utt_off, FfRaw rw)
 {
     __shared__ uint32_t s_bits[RAW ? kFfMaxSen / 32 : 1];
@@ -269,7 +287,25 @@ void fwdflat_kernel(FfDev p, const FfUtt *__restrict__ utts, const int16_t *__re
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, best sil score, best sil bp, n real exits
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
-    FfUtt u = utts[blockIdx.x];
+    FfUtt u;
+    {
+        const FfOff o = offs[blockIdx.x];
+#define X(f) u.f = bf.slab + o.f;
+        FF_SLAB_FIELDS(X)
+#undef X
+#define X(f) u.f = bf.voc + o.f;
+        FF_VOC_FIELDS(X)
+#undef X
+        u.awl[0] = bf.slab + o.awl0; u.awl[1] = bf.slab + o.awl1;
+        u.nrow32 = RAW ? bf.slab + o.nrow32 : nullptr;
+        u.nrow = RAW ? reinterpret_cast<int16_t *>(bf.slab + o.nrow) : nullptr;
+        u.nwd = o.nwd; u.n_chan = o.n_chan; u.n_frame = o.n_frame; u.awl_cap = o.awl_cap;
+        u.bp = bf.bp + (size_t)blockIdx.x * 10 * bf.bp_cap; u.bss = bf.bss + (size_t)blockIdx.x * bf.bss_cap;
+        u.bp_table_idx = bf.idx + (size_t)blockIdx.x * (bf.max_frames + 2); u.step = bf.step + (size_t)blockIdx.x * bf.max_frames * 4;
+        u.result = bf.res + (size_t)blockIdx.x * 8;
+        u.w1_ssid_in = bf.w1_ssid ? bf.w1_ssid + (size_t)blockIdx.x * p.n1 * p.n_emit : nullptr;
+        u.bp_cap = bf.bp_cap; u.bss_cap = bf.bss_cap;
+    }
     const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
     int n_awl[2] = {0, 0};
 
@@ -822,14 +858,15 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
     }
     int32_t *slab = nullptr, *vdev = nullptr;
-    FfUtt *d_utts = nullptr;
+    FfOff *d_utts = nullptr;
     PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * slab_off[n_utt]));
     hipError_t e = hipMalloc((void **)&vdev, sizeof(int32_t) * voc_off[n_utt]);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_utts, sizeof(FfUtt) * n_utt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_utts, sizeof(FfOff) * n_utt);
     std::vector<int32_t> vhost(voc_off[n_utt]);
-    std::vector<FfUtt> hu(n_utt);
+    std::vector<FfOff> ho(n_utt);
     for (int i = 0; i < n_utt && e == hipSuccess; ++i) {
-        FfUtt &u = hu[i];
+        FfUtt u;
+        memset(&u, 0, sizeof u);
         const FfVocab &v = voc[i];
         const size_t nwd = v.wid.size(), C = (size_t)d.n1 + v.n_chan, cap = nwd + n_tail + 1;
         int32_t *vh = vhost.data() + voc_off[i], *vd = vdev + voc_off[i];
@@ -846,27 +883,35 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
         u.nrow32 = raw ? take(d.n_sen) : nullptr;
         u.nrow = raw ? reinterpret_cast<int16_t *>(take((size_t)d.n_sen / 2 + 1)) : nullptr;
-        u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
-        u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
-        u.result = result_dev + (size_t)i * 8;
-        u.w1_ssid_in = w1_ssid_dev ? w1_ssid_dev + (size_t)i * d.n1 * d.n_emit : nullptr;
-        u.bp_cap = bp_cap; u.bss_cap = bss_cap;
+        FfOff &o = ho[i];
+#define X(f) o.f = u.f - slab;
+        FF_SLAB_FIELDS(X)
+#undef X
+#define X(f) o.f = u.f - vdev;
+        FF_VOC_FIELDS(X)
+#undef X
+        o.awl0 = u.awl[0] - slab; o.awl1 = u.awl[1] - slab;
+        o.nrow32 = raw ? u.nrow32 - slab : -1; o.nrow = raw ? reinterpret_cast<int32_t *>(u.nrow) - slab : -1;
+        o.nwd = u.nwd; o.n_chan = u.n_chan; o.n_frame = u.n_frame; o.awl_cap = u.awl_cap;
     }
     if (e == hipSuccess) e = hipMemcpyAsync(vdev, vhost.data(), sizeof(int32_t) * vhost.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FfUtt) * n_utt, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_utts, ho.data(), sizeof(FfOff) * n_utt, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the host vectors are about to go out of scope
     if (e != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); PSGPU_HIP(e); }
     FfRaw rw;
     memset(&rw, 0, sizeof rw);
     if (raw) rw = *raw;
+    FfBufs bf;
+    bf.slab = slab; bf.voc = vdev; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
+    bf.w1_ssid = w1_ssid_dev; bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     if (d.n_emit == 3 && raw)
-        hipLaunchKernelGGL((fwdflat_kernel<3, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
+        hipLaunchKernelGGL((fwdflat_kernel<3, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
     else if (d.n_emit == 3)
-        hipLaunchKernelGGL((fwdflat_kernel<3, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
+        hipLaunchKernelGGL((fwdflat_kernel<3, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
     else if (raw)
-        hipLaunchKernelGGL((fwdflat_kernel<5, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
+        hipLaunchKernelGGL((fwdflat_kernel<5, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
     else
-        hipLaunchKernelGGL((fwdflat_kernel<5, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, senscr_dev, scr_stride, utt_off_dev, rw);
+        hipLaunchKernelGGL((fwdflat_kernel<5, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
     hipFree(slab); hipFree(vdev); hipFree(d_utts);
