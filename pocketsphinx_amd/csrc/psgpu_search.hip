@@ -82,6 +82,23 @@ struct FtUtt {
     int32_t bp_cap, bss_cap;
 };
 
+// ACTIVE_LIST is handed the per-utterance fields as offsets (int32 units) from buffers that are kernel arguments: a pointer
+// loaded from memory is generic to the compiler (every access a flat_load / flat_store, both wait counters), a pointer formed
+// from a kernel argument is global.  (The default formulation keeps reading FtUtt, as measured.)
+#define FT_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(present) X(word_active) \
+    X(word_lat_idx) X(cand_wid) X(cand_score) X(cand_bp) X(cand_next) X(lt_sf) X(lt_dscr) X(lt_bp) X(csf_ef) X(csf_cand) \
+    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark)
+struct FtOff {
+#define X(f) int64_t f;
+    FT_SLAB_FIELDS(X)
+#undef X
+    int64_t acl0, acl1, awl0, awl1, g_cnt, g_w, nrow;
+};
+struct FtBufs {
+    int32_t *slab, *bp, *bss, *idx, *step, *res;
+    int32_t bp_cap, bss_cap, max_frames;
+};
+
 struct psgpu_fwdtree_s {
     FtDev d;
     std::vector<void *> allocs;
@@ -255,7 +272,7 @@ template <int NE, int NT, bool LIST>
 __global__ __launch_bounds__(NT)
 void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
                     const int32_t *__restrict__ penalties, const int32_t *__restrict__ utt_off, int32_t raw_mode,
-                    int32_t pl_window)
+                    int32_t pl_window, const FtOff *__restrict__ offs, FtBufs bf)
 {
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_prev[kFtMaxSen / 32];
@@ -271,7 +288,22 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     // record is one cache line where the arrays are nine
     constexpr int CS = LIST ? (NE == 3 ? 16 : 24) : 5, C1 = LIST ? CS : 1;
     const int tid = threadIdx.x;
-    FtUtt u = utts[blockIdx.x];
+    FtUtt u;
+    if (LIST) {
+        const FtOff o = offs[blockIdx.x];
+#define X(f) u.f = bf.slab + o.f;
+        FT_SLAB_FIELDS(X)
+#undef X
+        u.acl[0] = bf.slab + o.acl0; u.acl[1] = bf.slab + o.acl1; u.awl[0] = bf.slab + o.awl0; u.awl[1] = bf.slab + o.awl1;
+        u.g_cnt = bf.slab + o.g_cnt; u.g_w = bf.slab + o.g_w;           // (offset 0 when unused: never dereferenced then)
+        u.nrow = reinterpret_cast<int16_t *>(bf.slab + o.nrow);
+        u.bp = bf.bp + (size_t)blockIdx.x * 10 * bf.bp_cap; u.bss = bf.bss + (size_t)blockIdx.x * bf.bss_cap;
+        u.bp_table_idx = bf.idx + (size_t)blockIdx.x * (bf.max_frames + 2); u.step = bf.step + (size_t)blockIdx.x * bf.max_frames * 4;
+        u.result = bf.res + (size_t)blockIdx.x * 8;
+        u.bp_cap = bf.bp_cap; u.bss_cap = bf.bss_cap;
+    }
+    else
+        u = utts[blockIdx.x];
     // list-position / candidate / word scratch: LDS when the tree and the vocabulary fit (kFtMaxN entries), else the slab
     int32_t *const cnt = p.big ? u.g_cnt : s_cnt;
     const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
@@ -1085,15 +1117,32 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.result = result_dev + (size_t)i * 8;
         u.bp_cap = bp_cap; u.bss_cap = bss_cap;
     }
+    std::vector<FtOff> ho(d.list_mode ? n_utt : 0);
+    for (size_t i = 0; i < ho.size(); ++i) {
+        const FtUtt &u = hu[i];
+        FtOff &o = ho[i];
+#define X(f) o.f = u.f - slab;
+        FT_SLAB_FIELDS(X)
+#undef X
+        o.acl0 = u.acl[0] - slab; o.acl1 = u.acl[1] - slab; o.awl0 = u.awl[0] - slab; o.awl1 = u.awl[1] - slab;
+        o.g_cnt = u.g_cnt ? u.g_cnt - slab : 0; o.g_w = u.g_w ? u.g_w - slab : 0;
+        o.nrow = reinterpret_cast<int32_t *>(u.nrow) - slab;
+    }
+    FtOff *d_offs = nullptr;
+    FtBufs bf;
+    bf.slab = slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
+    bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     hipError_t e = hipMalloc((void **)&d_utts, sizeof(FtUtt) * n_utt);
+    if (e == hipSuccess && d.list_mode) e = hipMalloc((void **)&d_offs, sizeof(FtOff) * n_utt);
+    if (e == hipSuccess && d.list_mode) e = hipMemcpyAsync(d_offs, ho.data(), sizeof(FtOff) * n_utt, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FtUtt) * n_utt, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // hu is about to go out of scope
-    if (e != hipSuccess) { hipFree(slab); hipFree(d_utts); PSGPU_HIP(e); }
+    if (e != hipSuccess) { hipFree(slab); hipFree(d_utts); hipFree(d_offs); PSGPU_HIP(e); }
     // ACTIVE_LIST on a tree beyond the LDS scratch: ~10^4 active channels per frame, 16 waves per utterance
     const int nt = (d.list_mode && d.big) ? kFtThreadsBig : kFtThreads;
 #define FT_LAUNCH(NE, NT, LIST)                                                                                          \
     hipLaunchKernelGGL((fwdtree_kernel<NE, NT, LIST>), dim3(n_utt), dim3(NT), 0, st, d, d_utts, senscr_dev, scr_stride, \
-                       penalties_dev, utt_off_dev, raw_scores, pl_window)
+                       penalties_dev, utt_off_dev, raw_scores, pl_window, d_offs, bf)
     if (d.n_emit == 3) {
         if (!d.list_mode) FT_LAUNCH(3, kFtThreads, false);
         else if (nt == kFtThreads) FT_LAUNCH(3, kFtThreads, true);
@@ -1107,7 +1156,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
 #undef FT_LAUNCH
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
-    hipFree(slab); hipFree(d_utts);
+    hipFree(slab); hipFree(d_utts); hipFree(d_offs);
     PSGPU_HIP(e);
     return PSGPU_OK;
 }
