@@ -179,7 +179,7 @@ __device__ __forceinline__ int32_t ft_exit_score(const FtDev &p, const FtUtt &u,
     return u.bss[BPC(u, B_SIDX, bp) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + rcphone]];
 }
 // set_real_wid, ngram_search.c:341-372
-__device__ void ft_set_real_wid(const FtDev &p, FtUtt &u, int bp)
+__device__ __forceinline__ void ft_set_real_wid(const FtDev &p, FtUtt &u, int bp)
 {
     const int prev = BPC(u, B_BP, bp), wid = BPC(u, B_WID, bp);
     if (p.d_filler[wid]) {
@@ -192,7 +192,7 @@ __device__ void ft_set_real_wid(const FtDev &p, FtUtt &u, int bp)
     }
 }
 // ngram_search_save_bp, ngram_search.c:376-498 (single thread).  Returns false when a table is full.
-__device__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bss_head, int frame, int w, int32_t score,
+__device__ __forceinline__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bss_head, int frame, int w, int32_t score,
                            int32_t path, int rc)
 {
     const int bp = u.word_lat_idx[w];
