@@ -1,0 +1,65 @@
+"""Compile-time guards for the search kernels (no GPU needed: hipcc cross-compiles gfx950): register budget /
+occupancy of each instantiation as reported by -Rpass-analysis=kernel-resource-usage, and the address class of their
+memory instructions.  The default tree-search formulation for 3-state models is the one measured on the MI355X
+(profiles/r01g-r01i): it must keep compiling to the same budget while the other formulations change around it."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-Wno-unused-value",
+         "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
+
+
+def usage(src, tmp_path):
+    p = subprocess.run([HIPCC] + FLAGS + ["-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"),
+                        os.path.join(ROOT, "pocketsphinx_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out, cur = {}, None
+    for line in p.stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" ")[0] if not m.group(1).startswith("VGPRs Spill") else "Spill"] = int(m.group(2))
+    return out
+
+
+def test_tree_search_kernels_register_budget(tmp_path):
+    u = usage("psgpu_search.hip", tmp_path)
+    k = {n: v for n, v in u.items() if "fwdtree_kernel" in n}
+    assert len(k) == 6, sorted(k)
+    default3 = [v for n, v in k.items() if "ILi3ELi256ELb0E" in n][0]
+    assert default3["VGPRs"] <= 142 and default3["Occupancy"] >= 3 and default3["Spill"] == 0, default3   # as measured in round 1
+    for n, v in k.items():
+        if "Li1024E" in n:
+            assert v["VGPRs"] <= 128 and v["Occupancy"] >= 4, (n, v)          # 16 waves of one workgroup on a CU
+        else:
+            assert v["Occupancy"] >= 3 and v["Spill"] == 0, (n, v)
+        assert v["LDS"] <= 64 * 1024, (n, v)
+
+
+def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):
+    u = usage("psgpu_flat.hip", tmp_path)
+    k = {n: v for n, v in u.items() if "fwdflat_kernel" in n}
+    assert len(k) == 4, sorted(k)
+    for n, v in k.items():
+        assert v["Occupancy"] >= 3 and v["Spill"] == 0, (n, v)
+    # the per-utterance state is addressed from kernel-argument buffers: its accesses must be provably global
+    s = tmp_path / "flat.s"
+    p = subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-S", "-o", str(s), os.path.join(ROOT, "pocketsphinx_amd", "csrc", "psgpu_flat.hip")],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    txt = s.read_text()
+    for n in re.findall(r"\n(_Z14fwdflat_kernel\w+):", txt):
+        body = txt[txt.index("\n" + n + ":"):txt.index(".Lfunc_end", txt.index("\n" + n + ":"))]
+        g = len(re.findall(r"global_(load|store)_", body)); f = len(re.findall(r"flat_(load|store)_", body))
+        assert g > 8 * f, (n, g, f)
