@@ -67,6 +67,7 @@ struct FfUtt {
     int32_t *out, *outh, *best, *frame;  // [C]
     int32_t *senid;                      // [C][5]
     int32_t *tmat, *mpx, *rcid, *xflag;  // [C]
+    int32_t *elist;                      // [C] the frame's active channels (evaluation work list)
     int32_t *wchain, *wlen;              // [n_w] chain offset (channel index) or -1, chain length
     int32_t *word_active, *word_lat_idx; // [n_w] (word_active: frame stamp)
     int32_t *awl[2];                     // [awl_cap]
@@ -80,7 +81,7 @@ struct FfUtt {
 // What the kernel is actually handed per utterance: the same fields as offsets (in int32 units) from buffers that are
 // kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
 // wait counters); pointers formed from a kernel argument are global.
-#define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(wchain) \
+#define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(wchain) \
     X(wlen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
 #define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf)
 struct FfOff {
@@ -284,7 +285,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ uint8_t s_cbact[RAW ? kFfMaxCb : 1], s_la[RAW ? 256 : 1];
     __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64];
-    __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, best sil score, best sil bp, n real exits
+    __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, -, -, length of the evaluation list
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
     FfUtt u;
@@ -485,17 +486,25 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         __syncthreads();
         if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_sc[7] = 0; s_key = 0ull; }
         __syncthreads();
-        // ---- fwdflat_eval_chan (:444-480)
+        // ---- fwdflat_eval_chan (:444-480).  A word near its end has its whole right-context fan-out (20-40 channels) active at
+        //      once: the active channels are first gathered into one list (one work-item per word, order irrelevant -- the
+        //      evaluations are independent and the best score is a maximum), then evaluated one work-item per channel
+        //      (s_sc[7], the list length, was zeroed before the barrier above)
+        for (int i = tid; i < na; i += kFfThreads) {
+            const int w = u.awl[cur][i];
+            int len; const int c0 = ff_root(p, u, w, len);
+            for (int k = 0; k < len; ++k)
+                if (u.frame[c0 + k] == f)                     // bit 30: the root of </s>, which does not count towards the best score
+                    u.elist[atomicAdd(&s_sc[7], 1)] = (c0 + k) | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
+        }
+        __syncthreads();
         {
             int32_t b = kW;
-            for (int i = tid; i < na; i += kFfThreads) {
-                const int w = u.awl[cur][i];
-                int len; const int c0 = ff_root(p, u, w, len);
-                for (int k = 0; k < len; ++k) {
-                    if (u.frame[c0 + k] != f) continue;
-                    const int32_t sc = ff_eval<NE>(p, u, c0 + k, row);
-                    if (!(k == 0 && w == p.finishwid)) b = max(b, sc);
-                }
+            const int n_eval = s_sc[7];
+            for (int i = tid; i < n_eval; i += kFfThreads) {
+                const int e = u.elist[i];
+                const int32_t sc = ff_eval<NE>(p, u, e & ~(1 << 30), row);
+                if (!(e & (1 << 30))) b = max(b, sc);
             }
             if (b > kW) atomicMax(&s_sc[0], b);
         }
@@ -853,7 +862,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         const int32_t *cu = cols.data() + (size_t)u * max_nb;
         ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
         const size_t C = (size_t)d.n1 + voc[u].n_chan, nwd = voc[u].wid.size(), cap = nwd + n_tail + 1;
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 4) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 5) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
     }
@@ -877,7 +886,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         int32_t *q = slab + slab_off[i];
         auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
         u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
-        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C);
+        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C);
         u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
         u.awl[0] = take(cap); u.awl[1] = take(cap);
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
