@@ -79,6 +79,7 @@ struct FtUtt {
     int32_t *g_cnt, *g_w;                // [max(R + N, n_w) + 1], [4][n_w]: scratch for large trees / vocabularies (FtDev.big)
     int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
     int32_t *cand_mark;                  // [n_w] frame in which the word was last a last-phone candidate (ACTIVE_LIST)
+    int32_t *elist;                      // [TOT] the frame's present last-phone channels (ACTIVE_LIST: evaluation work list)
     int32_t bp_cap, bss_cap;
 };
 
@@ -87,7 +88,7 @@ struct FtUtt {
 // from a kernel argument is global.  (The default formulation keeps reading FtUtt, as measured.)
 #define FT_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(present) X(word_active) \
     X(word_lat_idx) X(cand_wid) X(cand_score) X(cand_bp) X(cand_next) X(lt_sf) X(lt_dscr) X(lt_bp) X(csf_ef) X(csf_cand) \
-    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark)
+    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark) X(elist)
 struct FtOff {
 #define X(f) int64_t f;
     FT_SLAB_FIELDS(X)
@@ -283,6 +284,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     __shared__ int32_t s_bins[256];
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
+    __shared__ int32_t s_nwc;            // ACTIVE_LIST: length of the word level's evaluation list
     // channel state: PER_NODE keeps one array per field ([C][5] / [C]); ACTIVE_LIST one record of CS ints per channel (score,
     // hist, out, outh, best, frame, senid, tmat, mpx: 64 bytes for 3-state models) -- its passes gather by channel id, and a
     // record is one cache line where the arrays are nine
@@ -402,13 +404,29 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) ch_normalize<CS, C1>(p, u, W1 + i, best_in);
         }
         if (tid < 8) s_red[tid] = kW;
+        if (LIST && tid == 0) s_nwc = 0;
         __syncthreads();
+        if (LIST) {
+            // a word near its end has its whole right-context fan-out (20-40 channels) present at once: the word level's
+            // channels are gathered into one list first (order irrelevant: independent evaluations, a maximum and a count)
+            // and evaluated one work-item per channel below
+            for (int i = tid; i < n_awl[cur]; i += NT) {
+                const int w = u.awl[cur][i];
+                u.word_active[w] = 0;
+                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
+                    if (u.present[k]) u.elist[atomicAdd(&s_nwc, 1)] = WC + k;
+            }
+            __syncthreads();
+        }
         // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..5] counts
         {
             int32_t b0 = kW, b1 = kW, b2 = kW; int n0 = 0, n2 = 0;
             for (int i = tid; i < R; i += NT)
                 if (u.frame[(i) * C1] == f) { b0 = max(b0, ch_eval<NE, CS, C1>(p, u, i, row)); ++n0; }
             for (int i = tid; i < n_acl[cur]; i += NT) b1 = max(b1, ch_eval<NE, CS, C1>(p, u, u.acl[cur][i], row));
+            if (LIST)
+                for (int i = tid; i < s_nwc; i += NT) { b2 = max(b2, ch_eval<NE, CS, C1>(p, u, u.elist[i], row)); ++n2; }
+            else
             for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
                 u.word_active[w] = 0;
@@ -1080,7 +1098,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     const size_t C = m->C;
     const size_t per = C * (d.list_mode ? 24 : 5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
                      + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
-                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w
+                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w + (d.list_mode ? (size_t)d.TOT + 1 : 0)
                      + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
     int32_t *slab = nullptr;
     FtUtt *d_utts = nullptr;
@@ -1110,6 +1128,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.pos = take(d.N); u.flag = take(d.N);
         u.nrow = reinterpret_cast<int16_t *>(take(((size_t)d.n_sen + 1) / 2 + 1));
         u.cand_mark = take(d.n_w);
+        u.elist = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
         u.g_cnt = d.big ? take((size_t)std::max(d.N + d.R, d.n_w) + 1) : nullptr;
         u.g_w = d.big ? take(4 * (size_t)d.n_w) : nullptr;
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
