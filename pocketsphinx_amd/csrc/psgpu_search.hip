@@ -79,7 +79,8 @@ struct FtUtt {
     int32_t *g_cnt, *g_w;                // [max(R + N, n_w) + 1], [4][n_w]: scratch for large trees / vocabularies (FtDev.big)
     int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
     int32_t *cand_mark;                  // [n_w] frame in which the word was last a last-phone candidate (ACTIVE_LIST)
-    int32_t *elist;                      // [TOT] the frame's present last-phone channels (ACTIVE_LIST: evaluation work list)
+    int32_t *elist, *eword;              // [TOT] the frame's present last-phone channels and the index of their word in the
+                                         //       active word list (ACTIVE_LIST: evaluation / pruning work list)
     int32_t bp_cap, bss_cap;
 };
 
@@ -88,7 +89,7 @@ struct FtUtt {
 // from a kernel argument is global.  (The default formulation keeps reading FtUtt, as measured.)
 #define FT_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(present) X(word_active) \
     X(word_lat_idx) X(cand_wid) X(cand_score) X(cand_bp) X(cand_next) X(lt_sf) X(lt_dscr) X(lt_bp) X(csf_ef) X(csf_cand) \
-    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark) X(elist)
+    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark) X(elist) X(eword)
 struct FtOff {
 #define X(f) int64_t f;
     FT_SLAB_FIELDS(X)
@@ -414,7 +415,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                 const int w = u.awl[cur][i];
                 u.word_active[w] = 0;
                 for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
-                    if (u.present[k]) u.elist[atomicAdd(&s_nwc, 1)] = WC + k;
+                    if (u.present[k]) { const int q = atomicAdd(&s_nwc, 1); u.elist[q] = WC + k; u.eword[q] = i; }
             }
             __syncthreads();
         }
@@ -747,9 +748,27 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
             const int wst = p.big ? p.n_w : 1024;                // n_awl <= n_w
             int32_t *w_k = p.big ? u.g_w : cnt, *w_exit = w_k + wst, *w_bp = w_k + 2 * wst, *w_bss = w_k + 3 * wst;
+            if (LIST) {
+                // one work-item per channel of the evaluation list (the channels present when the frame was evaluated; the ones
+                // this frame's candidates have just allocated were all entered for the next frame and have no score yet: the
+                // word-at-a-time walk below would neither count nor free them), survivors counted per word by atomics
+                for (int i = tid; i < n_awl[cur]; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
+                __syncthreads();
+                for (int j = tid; j < s_nwc; j += NT) {
+                    const int c = u.elist[j], i = u.eword[j];
+                    if (u.best[(c) * C1] > lpth) {
+                        u.frame[(c) * C1] = nf;
+                        atomicAdd(&w_k[i], 1);
+                        if (u.out[(c) * C1] > nwt) atomicOr(&w_exit[i], 1);
+                    }
+                    else if (u.frame[(c) * C1] != nf) u.present[c - WC] = 0;
+                }
+                __syncthreads();
+            }
             for (int i = tid; i < n_awl[cur]; i += NT) {
                 const int w = u.awl[cur][i];
-                int k = 0, ex = 0;
+                int k = LIST ? w_k[i] : 0, ex = LIST ? w_exit[i] : 0;
+                if (!LIST)
                 for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
                     if (!u.present[slot]) continue;
                     const int c = WC + slot;
@@ -1098,7 +1117,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     const size_t C = m->C;
     const size_t per = C * (d.list_mode ? 24 : 5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
                      + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
-                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w + (d.list_mode ? (size_t)d.TOT + 1 : 0)
+                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w + (d.list_mode ? 2 * ((size_t)d.TOT + 1) : 0)
                      + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
     int32_t *slab = nullptr;
     FtUtt *d_utts = nullptr;
@@ -1129,6 +1148,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.nrow = reinterpret_cast<int16_t *>(take(((size_t)d.n_sen + 1) / 2 + 1));
         u.cand_mark = take(d.n_w);
         u.elist = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
+        u.eword = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
         u.g_cnt = d.big ? take((size_t)std::max(d.N + d.R, d.n_w) + 1) : nullptr;
         u.g_w = d.big ? take(4 * (size_t)d.n_w) : nullptr;
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
