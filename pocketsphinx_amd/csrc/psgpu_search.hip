@@ -79,6 +79,7 @@ struct FtUtt {
     int32_t *g_cnt, *g_w;                // [max(R + N, n_w) + 1], [4][n_w]: scratch for large trees / vocabularies (FtDev.big)
     int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
     int32_t *cand_mark;                  // [n_w] frame in which the word was last a last-phone candidate (ACTIVE_LIST)
+    int32_t *xlist, *xslot;              // [TOT] (candidate, slot) pairs of the entering loop (ACTIVE_LIST)
     int32_t *elist, *eword;              // [TOT] the frame's present last-phone channels and the index of their word in the
                                          //       active word list (ACTIVE_LIST: evaluation / pruning work list)
     int32_t bp_cap, bss_cap;
@@ -89,7 +90,7 @@ struct FtUtt {
 // from a kernel argument is global.  (The default formulation keeps reading FtUtt, as measured.)
 #define FT_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(present) X(word_active) \
     X(word_lat_idx) X(cand_wid) X(cand_score) X(cand_bp) X(cand_next) X(lt_sf) X(lt_dscr) X(lt_bp) X(csf_ef) X(csf_cand) \
-    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark) X(elist) X(eword)
+    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark) X(elist) X(eword) X(xlist) X(xslot)
 struct FtOff {
 #define X(f) int64_t f;
     FT_SLAB_FIELDS(X)
@@ -285,7 +286,7 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
     __shared__ int32_t s_bins[256];
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
-    __shared__ int32_t s_nwc;            // ACTIVE_LIST: length of the word level's evaluation list
+    __shared__ int32_t s_nwc, s_nwc2;    // ACTIVE_LIST: lengths of the word level's evaluation list and of the entering list
     // channel state: PER_NODE keeps one array per field ([C][5] / [C]); ACTIVE_LIST one record of CS ints per channel (score,
     // hist, out, outh, best, frame, senid, tmat, mpx: 64 bytes for 3-state models) -- its passes gather by channel id, and a
     // record is one cache line where the arrays are nine
@@ -704,6 +705,33 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             const int n_cand = s_sc[5];
             const int32_t cthresh = s_sc[1] + p.lponlybeam;
             const bool dup = s_red[7] != 0;                     // (found above)
+            if (LIST && !dup) {
+                // one work-item per (entering candidate, right context): the word's slots are exactly its right contexts, so
+                // "allocate the missing ones, then enter every present one" is, per slot, "create if missing, then enter"
+                if (tid == 0) s_nwc2 = 0;
+                for (int i = tid; i < n_cand; i += NT) cnt[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < n_cand; i += NT) {
+                    if (!(u.cand_score[i] > cthresh)) continue;
+                    const int w = u.cand_wid[i], nrc = p.wc_off[w + 1] - p.wc_off[w];
+                    const int q = atomicAdd(&s_nwc2, nrc);
+                    for (int r = 0; r < nrc; ++r) { u.xlist[q + r] = i; u.xslot[q + r] = p.wc_off[w] + r; }
+                }
+                __syncthreads();
+                for (int j = tid; j < s_nwc2; j += NT) {
+                    const int i = u.xlist[j], slot = u.xslot[j], w = u.cand_wid[i], c = WC + slot;
+                    if (!u.present[slot]) {                     // ngram_search_alloc_all_rc (ngram_search.c:583-633)
+                        const int last = p.d_last[w], last2 = p.d_last2[w];
+                        ch_init<CS, C1>(p, u, c, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + (slot - p.wc_off[w])], p.ci_tmat[last]);
+                        u.present[slot] = 1;
+                    }
+                    if (u.frame[(c) * C1] < f || u.cand_score[i] > u.score[c * CS]) {
+                        ch_enter<CS, C1>(u, c, u.cand_score[i], u.cand_bp[i], nf);
+                        cnt[i] = 1;
+                    }
+                }
+            }
+            else
             for (int i = (dup ? (tid == 0 ? 0 : n_cand) : tid); i < n_cand; i += (dup ? 1 : NT)) {
                 int k = 0;
                 if (u.cand_score[i] > cthresh) {
@@ -1117,7 +1145,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     const size_t C = m->C;
     const size_t per = C * (d.list_mode ? 24 : 5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
                      + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
-                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w + (d.list_mode ? 2 * ((size_t)d.TOT + 1) : 0)
+                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w + (d.list_mode ? 4 * ((size_t)d.TOT + 1) : 0)
                      + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
     int32_t *slab = nullptr;
     FtUtt *d_utts = nullptr;
@@ -1149,6 +1177,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
         u.cand_mark = take(d.n_w);
         u.elist = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
         u.eword = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
+        u.xlist = d.list_mode ? take((size_t)d.TOT + 1) : nullptr; u.xslot = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
         u.g_cnt = d.big ? take((size_t)std::max(d.N + d.R, d.n_w) + 1) : nullptr;
         u.g_w = d.big ? take(4 * (size_t)d.n_w) : nullptr;
         u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
