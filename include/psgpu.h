@@ -470,6 +470,7 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
  *  pen_now_dev   [total][n_phones]   the step's own ring entry (pen_buf), and
  *  state_dev     [total][n_phones][8] score[0..4], out_score, bestscore, frame of each HMM after
  *                                    the step: enough to continue stepping on the host from any frame
+ *                                    (either may be NULL: a device-only pipeline needs the penalties alone)
  * total_frames = utt_off[n_utt].  Two launches: every frame's normaliser and the CI phones'
  * normalised scores, packed, in parallel; then one wavefront per utterance marching through its
  * frames with the next four frames' scores always in registers. */
@@ -488,16 +489,18 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
  * usable with psgpu_memcpy_* / psgpu_stream_sync */
 void *psgpu_hmm_ctx_stream(psgpu_hmm_ctx_t *c);
 
-/* ---- lexicon-tree search of whole utterances, first version ----------
+/* ---- lexicon-tree search of whole utterances --------------------------
  * Replaces ngram_fwdtree_start + ngram_fwdtree_search per frame + ngram_fwdtree_finish
  * (ngram_search_fwdtree.c:469-520, 1452-1495, 1497-1533) with the back-pointer helpers of
  * ngram_search.c (:301-498, 583-674).  The tables are the reference's own search structures
  * flattened to index arrays (what oracle/ref_dump.c `fwdtree` writes: the tree
  * create_search_channels built with roots first, single-phone word channels, dictionary and
- * dict2pid tables, `par` = sizes, beams, penalties, special word ids) and the language model as
- * a dense table lm[w3][w2 + 1][w1 + 1] = ngram_tg_score(w3, w2, w1) >> SENSCR_SHIFT over
- * dictionary word ids (-1 = no history): small vocabularies only (<= 1024 words, <= 4096 tree
- * nodes, <= 64 CI phones) in this version. */
+ * dict2pid tables, `par` = sizes, beams, penalties, special word ids) and the language model
+ * either as a dense table lm[w3][w2 + 1][w1 + 1] = ngram_tg_score(w3, w2, w1) >> SENSCR_SHIFT
+ * over dictionary word ids (-1 = no history; small vocabularies) or as the model's own trie
+ * (psgpu_fwdtree_set_lm).  Any tree size (<= 64 CI phones); per-frame work follows the active
+ * channels.  Where the tree-level state fits (en-us with a few hundred words) it is kept in LDS
+ * for the whole utterance, otherwise in a per-utterance slab in device memory -- same tables. */
 typedef struct psgpu_fwdtree_s psgpu_fwdtree_t;
 typedef struct psgpu_fwdtree_tables_s {
     const int32_t *par;                       /* [32] */
@@ -523,18 +526,39 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m);
  * bss_dev + u*bss_cap, bp_table_idx at idx_dev + u*(max_frames + 2), per-frame
  * {best_score, last_phone_best_score, bpidx, n_active_chan} at step_dev + u*max_frames*4, and
  * result_dev + u*8 = {n back-pointers, score-stack length, frames searched, status (1: a table
- * was full), best_score of the last frame (ngs->best_score)}.  Synchronous on `stream`.
+ * was full), best_score of the last frame (ngs->best_score)}.  Asynchronous on `stream`; the work
+ * slab belongs to the handle, so one search at a time per handle.
  * raw_scores = 1: senscr_dev holds the scorer's UN-normalised rows (PSGPU_PTM_RAW_SCORES) and
  * penalties_dev the phone loop's output per phone-loop frame (psgpu_phone_loop_run_dev): the kernel
  * then builds each frame's active senone list itself (compute_sen_active + acmod_flags2list,
  * bridging entries included), subtracts its minimum as the scorer would (ptm_mgau.c:393-400), and
  * reads the penalties of frame min(f + pl_window, T - 1) -- i.e. it is fed directly by the other
- * kernels, nothing passes through the host. */
+ * kernels, nothing passes through the host.
+ * w1_ssid_out_dev (may be NULL) is the hand-over to the second pass: per utterance u the per-state
+ * ssids (multiplex HMMs: hmm_mpx_ssid) its permanent single-phone word channels ended with, at
+ * w1_ssid_out_dev + u*n_1ph*n_emit -- ngram_fwdflat_start clears those channels' scores but not
+ * their ssids (ngram_search_fwdflat.c:385-392), so they are part of what psgpu_fwdflat_search_dev
+ * takes over. */
 int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
                              const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
                              int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
                              int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
-                             int32_t pl_window, void *stream);
+                             int32_t pl_window, int32_t *w1_ssid_out_dev, void *stream);
+/* ngram_search_find_exit (ngram_search.c:500-544) + the backtrace of ngram_search_bp_hyp / the segment
+ * iterator (:546-581, 903-1010) for every utterance of a batch, on the tables as the search left them:
+ * hyp_dev + u*max_words*4 = {word id, start frame, end frame, path score at the word's end} per word in
+ * spoken order; hyp_n_dev + u*4 = {number of words (when > max_words only the last max_words are
+ * stored), path score of the exit, its back-pointer index (-1: no hypothesis), 0}. */
+int psgpu_fwdtree_backtrace_dev(const psgpu_fwdtree_t *m, const int32_t *bp_dev, const int32_t *idx_dev,
+                                const int32_t *result_dev, int32_t n_utt, int32_t max_frames, int32_t bp_cap,
+                                int32_t max_words, int32_t *hyp_dev, int32_t *hyp_n_dev, void *stream);
+/* number of permanently allocated single-phone word channels (ngs->n_1ph_words): the w1_ssid_out_dev row length is
+ * this times the number of emitting states */
+int32_t psgpu_fwdtree_n_single_phone_words(const psgpu_fwdtree_t *m);
+/* *lds_layout = 1 when the tree-level state of this search lives in LDS; *slab_bytes_per_utt = device memory
+ * the handle keeps per utterance of a batch.  Either pointer may be NULL.  (PSGPU_FWDTREE_LAYOUT=slab in the
+ * environment at create forces the device-memory layout: the parity tests run both.) */
+int psgpu_fwdtree_layout(const psgpu_fwdtree_t *m, int32_t *lds_layout, int64_t *slab_bytes_per_utt);
 
 
 /* ---- the trigram language model on the device -----------------------
@@ -578,22 +602,61 @@ int psgpu_lm_tg_score_dev(const psgpu_lm_t *lm, const int32_t *w3_dev, const int
 /* Makes the tree search look its language scores up in `lm` (which must outlive it) instead of
  * the dense table of psgpu_fwdtree_tables_t.lm (which may then be NULL at create). */
 int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
-/* How the per-frame passes of the tree search are formulated; the tables produced are the same, bit for bit.
- *   PER_NODE     (default) prune_root_chan / prune_nonroot_chan (ngram_search_fwdtree.c:722-877) decided for every
- *                node of the tree: work per frame ~ tree size.  The form verified on the MI355X.
- *   ACTIVE_LIST  the same decisions made only for the roots, the nodes on the active list and their children
- *                (work per frame ~ active channels), word-level positions (next active words, back-pointer and
- *                score-stack slots, prune_word_chan :1038-1128) by workgroup prefix sums; trees beyond the LDS
- *                scratch run with 1024 work-items per utterance.  The form for large vocabularies. */
-#define PSGPU_FWDTREE_PER_NODE 0
-#define PSGPU_FWDTREE_ACTIVE_LIST 1
-int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode);
-/* Hand-over to the second pass: subsequent searches also write, per utterance u, the per-state ssids (multiplex
- * HMMs: hmm_mpx_ssid) their permanent single-phone word channels ended with to w1_ssid_dev + u*n_1ph*n_emit --
- * ngram_fwdflat_start clears those channels' scores but not their ssids (ngram_search_fwdflat.c:385-392), so they
- * are part of what psgpu_fwdflat_search_dev takes over.  NULL switches it off.  The buffer must hold n_utt
- * utterances of the next call. */
-int psgpu_fwdtree_set_w1_ssid_out(psgpu_fwdtree_t *m, int32_t *w1_ssid_dev);
+
+/* ---- the first pass of a batch of utterances as one device pipeline ---------------------------
+ * 16-bit PCM -> MFCC -> 1s_c_d_dd features -> PTM senone scores (un-normalised rows) -> phone-loop
+ * search -> lexicon-tree search -> back-pointer tables -> best exit and backtrace: the device side of
+ * ps_decode_raw() (pocketsphinx.c:1030-1070) with -fwdflat no -bestpath no, followed by
+ * ngram_search_bp_hyp (ngram_search.c:546-581), for n_utt utterances per call.  Every utterance is
+ * decoded from the state a decoder has after ps_start_stream() on its first utterance (noise tracker
+ * and top-N history reset), so results do not depend on the batch.  The object owns the buffers
+ * between the stages; the stages are the handles of `cfg` (borrowed: they must outlive it). */
+typedef struct psgpu_decode_s psgpu_decode_t;
+typedef struct psgpu_decode_config_s {
+    psgpu_fe_t *fe;                    /* front end (psgpu_fe_create) */
+    psgpu_ptm_model_t *model;          /* scorer (psgpu_ptm_model_create) */
+    psgpu_hmm_ctx_t *ctx;              /* tp / sseq (psgpu_hmm_ctx_create) */
+    psgpu_fwdtree_t *ft;               /* the search (psgpu_fwdtree_create [+ psgpu_fwdtree_set_lm]) */
+    psgpu_phone_loop_params_t pl;      /* phone_loop_search_t: n_phones, window, beams, pip, penalty weight */
+    const uint16_t *pl_ssid;           /* HOST [pl.n_phones]: the CI phones' senone-sequence ids ... */
+    const int16_t *pl_tmatid;          /* ... and transition-matrix ids */
+    const uint16_t *ci_list;           /* HOST [n_ci_list]: the senone list acmod_flags2list builds when every CI */
+    int32_t n_ci_list;                 /*   phone is active, bridging entries included (psgpu_phone_loop_run_dev) */
+    int32_t pl_window;                 /* ps->pl_window: frames the phone loop runs ahead of the search (>= 1) */
+    int32_t max_words;                 /* hypothesis records per utterance (0: 512) */
+} psgpu_decode_config_t;
+int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
+void psgpu_decode_free(psgpu_decode_t *d);
+/* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */
+int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
+/* pcm_dev: the samples of n_utt utterances back to back, resident on the device; samp_off [n_utt + 1]
+ * HOST array of sample offsets.  Asynchronous on `stream`; one call at a time per object.  Results stay on
+ * the device (psgpu_decode_view) until fetched. */
+int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt,
+                                void *stream);
+/* the same from host buffers: pcm[u][0..n[u]) are staged and copied to the device first */
+int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const size_t n[], int32_t n_utt, void *stream);
+/* what the last call left on the device (valid until the next call), for a second pass or a custom read-out:
+ * tables as psgpu_fwdtree_search_dev writes them with the strides bp_cap / bss_cap / max_frames + 2,
+ * hypotheses as psgpu_fwdtree_backtrace_dev writes them */
+typedef struct psgpu_decode_view_s {
+    int32_t n_utt, total_frames, max_frames, bp_cap, bss_cap, max_words;
+    const int32_t *frame_off;          /* HOST [n_utt + 1] */
+    const int32_t *frame_off_dev;
+    const float *feat_dev;             /* [total][3 * cepsize] */
+    const uint8_t *topn_cw_dev;        /* [n_chain][total][topn] */
+    const int16_t *rows_dev;           /* [total][n_sen] un-normalised scores */
+    const int32_t *penalties_dev;      /* [total][n_phones] */
+    int32_t *bp_dev, *bss_dev, *idx_dev, *step_dev, *result_dev, *hyp_dev, *hyp_n_dev, *w1_ssid_dev;
+} psgpu_decode_view_t;
+int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v);
+/* hyp_n [n_utt][4], hyp [n_utt][max_words][4], result [n_utt][8] (any may be NULL) to the host; waits for the
+ * stream.  This is the only transfer a caller that wants word sequences needs. */
+int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int32_t *result, void *stream);
+/* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
+ * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array. */
+int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp,
+                              int32_t *bss, int32_t *idx, void *stream);
 
 /* ---- flat-lexicon second pass of whole utterances, first version ----------
  * Replaces ngram_fwdflat_start + ngram_fwdflat_search per frame + ngram_fwdflat_finish

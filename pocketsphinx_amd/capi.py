@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
 CSRC = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip", "psgpu_search.hip", "psgpu_lm.hip", "psgpu_flat.hip"]
+SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip", "psgpu_search.hip", "psgpu_lm.hip", "psgpu_flat.hip", "psgpu_decode.hip"]
 
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -31,7 +31,9 @@ SYMBOLS = [
     "psgpu_fe_process_utts_dev", "psgpu_fe_process_utts",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval", "psgpu_phone_loop_run_dev", "psgpu_hmm_ctx_stream",
-    "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_set_lm", "psgpu_fwdtree_set_mode", "psgpu_fwdtree_set_w1_ssid_out",
+    "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_set_lm", "psgpu_fwdtree_backtrace_dev", "psgpu_fwdtree_layout", "psgpu_fwdtree_n_single_phone_words",
+    "psgpu_decode_create", "psgpu_decode_free", "psgpu_decode_set_model", "psgpu_decode_first_pass_dev", "psgpu_decode_first_pass",
+    "psgpu_decode_view", "psgpu_decode_fetch_hyps", "psgpu_decode_fetch_tables",
     "psgpu_fwdflat_create", "psgpu_fwdflat_free", "psgpu_fwdflat_set_lm", "psgpu_fwdflat_search_dev", "psgpu_fwdflat_search_feats_dev", "psgpu_ptm_model_view",
     "psgpu_lm_create", "psgpu_lm_free", "psgpu_lm_tg_score_dev",
 ]

@@ -1,0 +1,240 @@
+// psgpu_decode.hip -- the first pass of a batch of utterances as ONE device pipeline:
+// 16-bit PCM -> MFCC (psgpu_fe) -> 1s_c_d_dd features -> PTM senone scores (un-normalised rows) -> phone-loop search
+// -> lexicon-tree search -> back-pointer tables -> best exit + backtrace, nothing through the host in between.
+//
+// This is the device side of what ps_decode_raw() does per utterance with -fwdflat no -bestpath no
+// (pocketsphinx.c:1030-1070: ps_start_utt, ps_process_raw(full_utt), ps_end_utt, then ps_get_hyp's
+// ngram_search_bp_hyp), for n_utt utterances at once.  The object owns only the buffers between the stages; the stages
+// are the handles it is given (front end, scorer model, HMM context, tree search), so the reference-side binding
+// (integration/psgpu_device_decode.c: tables read out of a live decoder) and a table-driven caller (bench.py: tables from
+// a dump) run the same code.
+#include "psgpu_internal.h"
+#include <cstring>
+#include <vector>
+
+struct psgpu_decode_s {
+    psgpu_decode_config_t cfg;
+    uint16_t *d_ssid = nullptr, *d_ci = nullptr;
+    int16_t *d_tmatid = nullptr;
+    int32_t n_sen = 0, n_chain = 0, topn = 0, cepsize = 0, n_ci = 0, n1 = 0, n_emit = 0, max_words = 0;
+    // work buffers, grown on demand
+    size_t cap_samples = 0, cap_frames = 0, cap_utt = 0, cap_bp = 0, cap_bss = 0, cap_mf = 0;
+    int16_t *d_pcm = nullptr;
+    float *d_cep = nullptr, *d_feat = nullptr;
+    int32_t *d_off = nullptr, *d_tsc = nullptr, *d_best = nullptr, *d_pen = nullptr;
+    uint8_t *d_tcw = nullptr;
+    int16_t *d_rows = nullptr;
+    int32_t *d_bp = nullptr, *d_bss = nullptr, *d_idx = nullptr, *d_step = nullptr, *d_res = nullptr, *d_hyp = nullptr, *d_hn = nullptr,
+            *d_w1 = nullptr;
+    // the last call
+    int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
+    std::vector<int32_t> frame_off;
+    std::vector<int64_t> soff;
+    std::vector<int16_t> stage;
+};
+
+#define DFREE(p) do { if (p) { hipFree(p); (p) = nullptr; } } while (0)
+
+static int dec_alloc(void **p, size_t bytes)
+{
+    *p = nullptr;
+    PSGPU_HIP(hipMalloc(p, bytes ? bytes : 4));
+    return PSGPU_OK;
+}
+
+extern "C" {
+
+int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg)
+{
+    PSGPU_REQUIRE(out && cfg && cfg->fe && cfg->model && cfg->ctx && cfg->ft, "psgpu_decode_create: NULL argument");
+    PSGPU_REQUIRE(cfg->pl_ssid && cfg->pl_tmatid && cfg->ci_list && cfg->n_ci_list > 0 && cfg->pl.n_phones >= 1 && cfg->pl.n_phones <= 64
+                  && cfg->pl_window >= 1, "psgpu_decode_create: the pipeline needs the phone-loop look-ahead (tables, pl_window >= 1)");
+    *out = nullptr;
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    psgpu_decode_s *d = new psgpu_decode_s();
+    d->cfg = *cfg;
+    d->n_sen = psgpu_ptm_n_sen(cfg->model); d->n_chain = psgpu_ptm_n_chain(cfg->model); d->topn = psgpu_ptm_topn(cfg->model);
+    d->cepsize = psgpu_fe_out_dim(cfg->fe); d->n_ci = cfg->pl.n_phones;
+    d->n_emit = psgpu_hmm_n_emit_state(cfg->ctx); d->n1 = psgpu_fwdtree_n_single_phone_words(cfg->ft);
+    d->max_words = cfg->max_words > 0 ? cfg->max_words : 512;
+    if (psgpu_ptm_veclen(cfg->model) != 3 * d->cepsize) {
+        psgpu_set_error("psgpu_decode_create: the scorer takes %d-dimensional vectors, 1s_c_d_dd of %d cepstra gives %d",
+                        psgpu_ptm_veclen(cfg->model), d->cepsize, 3 * d->cepsize);
+        delete d;
+        return PSGPU_EINVAL;
+    }
+    const size_t np = (size_t)cfg->pl.n_phones;
+    if (dec_alloc((void **)&d->d_ssid, 2 * np) || dec_alloc((void **)&d->d_tmatid, 2 * np) || dec_alloc((void **)&d->d_ci, 2 * (size_t)cfg->n_ci_list)
+        || hipMemcpy(d->d_ssid, cfg->pl_ssid, 2 * np, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(d->d_tmatid, cfg->pl_tmatid, 2 * np, hipMemcpyHostToDevice) != hipSuccess
+        || hipMemcpy(d->d_ci, cfg->ci_list, 2 * (size_t)cfg->n_ci_list, hipMemcpyHostToDevice) != hipSuccess) {
+        psgpu_set_error("psgpu_decode_create: table upload failed");
+        psgpu_decode_free(d);
+        return PSGPU_EHIP;
+    }
+    d->cfg.pl_ssid = nullptr; d->cfg.pl_tmatid = nullptr; d->cfg.ci_list = nullptr;      // (host tables are not kept)
+    *out = d;
+    return PSGPU_OK;
+}
+
+void psgpu_decode_free(psgpu_decode_t *d)
+{
+    if (!d) return;
+    DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
+    DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
+    DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
+    delete d;
+}
+
+int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model)
+{
+    PSGPU_REQUIRE(d && model, "psgpu_decode_set_model: NULL argument");
+    PSGPU_REQUIRE(psgpu_ptm_n_sen(model) == d->n_sen && psgpu_ptm_n_chain(model) == d->n_chain && psgpu_ptm_topn(model) == d->topn,
+                  "psgpu_decode_set_model: the model has another shape");
+    d->cfg.model = model;
+    return PSGPU_OK;
+}
+
+// buffers for n_utt utterances of `total` frames in all, the longest `mf` frames
+static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hipStream_t st)
+{
+    // table capacities follow the longest utterance: the bundled recordings write 4-6 back-pointers and 30-80 score-stack
+    // entries per frame (tests/golden/fwdtree_trace_*); a full table ends the utterance with status 1
+    const size_t bp_cap = 16 * mf + 2048, bss_cap = 320 * mf + 8192;
+    bool waited = false;
+    auto wait = [&]() { if (!waited) { hipStreamSynchronize(st); waited = true; } };
+    if (total > d->cap_frames) {
+        wait();
+        const size_t t = total + total / 8 + 64, ne = t * d->n_chain * d->topn;
+        DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_tsc); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_best); DFREE(d->d_pen);
+        d->cap_frames = 0;
+        int rc;
+        if ((rc = dec_alloc((void **)&d->d_cep, 4 * t * d->cepsize)) || (rc = dec_alloc((void **)&d->d_feat, 4 * t * 3 * d->cepsize))
+            || (rc = dec_alloc((void **)&d->d_tsc, 4 * ne)) || (rc = dec_alloc((void **)&d->d_tcw, ne))
+            || (rc = dec_alloc((void **)&d->d_rows, 2 * t * d->n_sen)) || (rc = dec_alloc((void **)&d->d_best, 4 * t))
+            || (rc = dec_alloc((void **)&d->d_pen, 4 * t * d->n_ci)))
+            return rc;
+        d->cap_frames = t;
+    }
+    if (n_utt > d->cap_utt || bp_cap > d->cap_bp || bss_cap > d->cap_bss || mf > d->cap_mf) {
+        wait();
+        const size_t nu = std::max(n_utt, d->cap_utt), cb = std::max(bp_cap, d->cap_bp), cs = std::max(bss_cap, d->cap_bss),
+                     cm = std::max(mf, d->cap_mf);
+        DFREE(d->d_off); DFREE(d->d_bp); DFREE(d->d_bss); DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn);
+        DFREE(d->d_w1);
+        d->cap_utt = 0;
+        int rc;
+        if ((rc = dec_alloc((void **)&d->d_off, 4 * (nu + 1))) || (rc = dec_alloc((void **)&d->d_bp, 4 * nu * 10 * cb))
+            || (rc = dec_alloc((void **)&d->d_bss, 4 * nu * cs)) || (rc = dec_alloc((void **)&d->d_idx, 4 * nu * (cm + 2)))
+            || (rc = dec_alloc((void **)&d->d_step, 4 * nu * (cm ? cm : 1) * 4)) || (rc = dec_alloc((void **)&d->d_res, 4 * nu * 8))
+            || (rc = dec_alloc((void **)&d->d_hyp, 4 * nu * d->max_words * 4)) || (rc = dec_alloc((void **)&d->d_hn, 4 * nu * 4))
+            || (rc = dec_alloc((void **)&d->d_w1, 4 * nu * (size_t)std::max(1, d->n1) * d->n_emit)))
+            return rc;
+        d->cap_utt = nu; d->cap_bp = cb; d->cap_bss = cs; d->cap_mf = cm;
+    }
+    return PSGPU_OK;
+}
+
+int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, void *stream)
+{
+    PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm_dev && samp_off)), "psgpu_decode_first_pass_dev: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0;
+    d->frame_off.assign((size_t)n_utt + 1, 0);
+    if (n_utt == 0) return PSGPU_OK;
+    size_t total = 0, mf = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        PSGPU_REQUIRE(samp_off[u + 1] >= samp_off[u], "psgpu_decode_first_pass_dev: sample offsets must not decrease");
+        const size_t t = (size_t)psgpu_fe_n_frames(d->cfg.fe, samp_off[u + 1] - samp_off[u]);
+        total += t; mf = std::max(mf, t);
+    }
+    PSGPU_REQUIRE(total < 0x7fffff00u, "psgpu_decode_first_pass_dev: %zu frames in one call", total);
+    int rc = dec_grow(d, (size_t)n_utt, total ? total : 1, mf, st);
+    if (rc != PSGPU_OK) return rc;
+    d->total = (int32_t)total; d->max_frames = (int32_t)mf;
+    d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
+    if ((rc = psgpu_fe_process_utts_dev(d->cfg.fe, pcm_dev, samp_off, n_utt, nullptr, nullptr, d->d_cep, d->d_off, d->frame_off.data(), st)))
+        return rc;
+    if (total == 0) {                                   // nothing but empty utterances: empty results
+        PSGPU_HIP(hipMemsetAsync(d->d_res, 0, 4 * (size_t)n_utt * 8, st));
+        PSGPU_HIP(hipMemsetAsync(d->d_hn, 0, 4 * (size_t)n_utt * 4, st));
+        return PSGPU_OK;
+    }
+    if ((rc = psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, n_utt, d->cepsize, d->d_feat, st))) return rc;
+    if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, nullptr, nullptr, d->d_tsc, d->d_tcw,
+                                        d->d_rows, d->d_best, PSGPU_PTM_RAW_SCORES, st)))
+        return rc;
+    if ((rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
+                                       nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st)))
+        return rc;
+    // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
+    if ((rc = psgpu_fwdtree_search_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
+                                       d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1, st)))
+        return rc;
+    return psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp, d->d_idx, d->d_res, n_utt, (int32_t)mf, d->bp_cap, d->max_words, d->d_hyp,
+                                       d->d_hn, st);
+}
+
+int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const size_t n[], int32_t n_utt, void *stream)
+{
+    PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm && n)), "psgpu_decode_first_pass: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    d->soff.assign((size_t)n_utt + 1, 0);
+    for (int u = 0; u < n_utt; ++u) d->soff[u + 1] = d->soff[u] + (int64_t)n[u];
+    const size_t ns = (size_t)d->soff[n_utt];
+    if (ns > d->cap_samples) {
+        PSGPU_HIP(hipStreamSynchronize(st));
+        DFREE(d->d_pcm); d->cap_samples = 0;
+        int rc = dec_alloc((void **)&d->d_pcm, 2 * (ns + ns / 8 + 64));
+        if (rc != PSGPU_OK) return rc;
+        d->cap_samples = ns + ns / 8 + 64;
+    }
+    PSGPU_HIP(hipStreamSynchronize(st));                 // the staging buffer of the previous call may still be in flight
+    d->stage.resize(ns ? ns : 1);
+    for (int u = 0; u < n_utt; ++u) if (n[u]) memcpy(d->stage.data() + d->soff[u], pcm[u], 2 * n[u]);
+    if (ns) PSGPU_HIP(hipMemcpyAsync(d->d_pcm, d->stage.data(), 2 * ns, hipMemcpyHostToDevice, st));
+    return psgpu_decode_first_pass_dev(d, d->d_pcm, d->soff.data(), n_utt, st);
+}
+
+int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v)
+{
+    PSGPU_REQUIRE(d && v, "psgpu_decode_view: NULL argument");
+    v->n_utt = d->n_utt; v->total_frames = d->total; v->max_frames = d->max_frames; v->bp_cap = d->bp_cap; v->bss_cap = d->bss_cap;
+    v->max_words = d->max_words; v->frame_off = d->frame_off.data();
+    v->frame_off_dev = d->d_off; v->feat_dev = d->d_feat; v->topn_cw_dev = d->d_tcw; v->rows_dev = d->d_rows; v->penalties_dev = d->d_pen;
+    v->bp_dev = d->d_bp; v->bss_dev = d->d_bss; v->idx_dev = d->d_idx; v->step_dev = d->d_step; v->result_dev = d->d_res;
+    v->hyp_dev = d->d_hyp; v->hyp_n_dev = d->d_hn; v->w1_ssid_dev = d->d_w1;
+    return PSGPU_OK;
+}
+
+int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int32_t *result, void *stream)
+{
+    PSGPU_REQUIRE(d, "psgpu_decode_fetch_hyps: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nu = (size_t)d->n_utt;
+    if (nu) {
+        if (hyp_n) PSGPU_HIP(hipMemcpyAsync(hyp_n, d->d_hn, 4 * nu * 4, hipMemcpyDeviceToHost, st));
+        if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
+        if (result) PSGPU_HIP(hipMemcpyAsync(result, d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+    }
+    PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp, int32_t *bss,
+                              int32_t *idx, void *stream)
+{
+    PSGPU_REQUIRE(d && u >= 0 && u < d->n_utt && n_bp >= 0 && n_bp <= d->bp_cap && n_bss >= 0 && n_bss <= d->bss_cap
+                  && n_idx >= 0 && n_idx <= d->max_frames + 2, "psgpu_decode_fetch_tables: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (bp && n_bp)       // ten columns, bp_cap apart on the device, n_bp apart on the host
+        PSGPU_HIP(hipMemcpy2DAsync(bp, 4 * (size_t)n_bp, d->d_bp + (size_t)u * 10 * d->bp_cap, 4 * (size_t)d->bp_cap, 4 * (size_t)n_bp, 10,
+                                   hipMemcpyDeviceToHost, st));
+    if (bss && n_bss) PSGPU_HIP(hipMemcpyAsync(bss, d->d_bss + (size_t)u * d->bss_cap, 4 * (size_t)n_bss, hipMemcpyDeviceToHost, st));
+    if (idx && n_idx) PSGPU_HIP(hipMemcpyAsync(idx, d->d_idx + (size_t)u * (d->max_frames + 2), 4 * (size_t)n_idx, hipMemcpyDeviceToHost, st));
+    PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
+}
+
+}  // extern "C"

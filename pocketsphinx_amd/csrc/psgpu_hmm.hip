@@ -322,7 +322,7 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
         for (int w = 0; w < p.window; ++w) mx = max(mx, s_ring[w][lane]);
         if (on) {
             penalties[(size_t)(t0 + t) * p.n_phones + lane] = mx;
-            pen_now[(size_t)(t0 + t) * p.n_phones + lane] = pen;
+            if (pen_now) pen_now[(size_t)(t0 + t) * p.n_phones + lane] = pen;
         }
         // prune_hmms (:247-266)
         if (act) {
@@ -340,7 +340,7 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
         if (m != kMaxNegInt32 && on) {
             if (frame < t || m > h.score[0]) { h.score[0] = m; frame = t + 1; }
         }
-        if (on) {
+        if (on && state) {
             int32_t *st = state + ((size_t)(t0 + t) * p.n_phones + lane) * 8;
 #pragma unroll
             for (int i = 0; i < NE; ++i) st[i] = h.score[i];
@@ -449,8 +449,7 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
 {
     PSGPU_REQUIRE(c && pp && n_utt >= 0, "psgpu_phone_loop_run_dev: bad argument");
     if (n_utt == 0) return PSGPU_OK;
-    PSGPU_REQUIRE(ssid_dev && tmatid_dev && raw_dev && utt_off_dev && penalties_dev && pen_now_dev && state_dev,
-                  "psgpu_phone_loop_run_dev: NULL device buffer");
+    PSGPU_REQUIRE(ssid_dev && tmatid_dev && raw_dev && utt_off_dev && penalties_dev, "psgpu_phone_loop_run_dev: NULL device buffer");
     PSGPU_REQUIRE(pp->n_phones >= 1 && pp->n_phones <= 64, "n_phones %d outside 1..64", pp->n_phones);
     PSGPU_REQUIRE(pp->window >= 1 && pp->window <= kPlMaxWindow, "window %d outside 1..%d", pp->window, kPlMaxWindow);
     PSGPU_REQUIRE((best_dev != nullptr) != (ci_list_dev != nullptr && n_list > 0),

@@ -16,8 +16,19 @@ struct HmmRegs {
     uint16_t senid[5];
 };
 
+// The frame's senone scores as the Viterbi step reads them: `ss[senone]`.  A plain `const int16_t *` row, or a row of
+// un-normalised scores with the active list's normaliser applied on the fly (ptm_mgau.c:393-400: score - best in int16
+// arithmetic).
+struct SenRowNorm {
+    const int16_t *row;
+    int32_t nb;
+    __device__ __forceinline__ int16_t operator[](int s) const
+    { return (int16_t)(uint16_t)((uint32_t)(int32_t)row[s] - (uint32_t)nb); }
+};
+
 // ---- 3-state, non-multiplex (hmm.c:529-607) --------------------------------
-__device__ __forceinline__ int32_t vit3(HmmRegs &h, const uint8_t *tp, const int16_t *ss)
+template <typename S>
+__device__ __forceinline__ int32_t vit3(HmmRegs &h, const uint8_t *tp, const S &ss)
 {
 #define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
     int32_t s2 = h.score[2] - ss[h.senid[2]];
@@ -64,8 +75,8 @@ __device__ __forceinline__ int32_t vit3(HmmRegs &h, const uint8_t *tp, const int
 }
 
 // ---- 3-state, multiplex (hmm.c:609-707) -------------------------------------
-__device__ __forceinline__ int32_t vit3_mpx(HmmRegs &h, const uint8_t *tp, const int16_t *ss,
-                                            const uint16_t *sseq)
+template <typename S>
+__device__ __forceinline__ int32_t vit3_mpx(HmmRegs &h, const uint8_t *tp, const S &ss, const uint16_t *sseq)
 {
 #define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
 #define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 3 + (st)]])
@@ -136,7 +147,8 @@ __device__ __forceinline__ int32_t pick3(HmmRegs &h, int32_t T0, int32_t T1, int
 }
 
 // ---- 5-state, non-multiplex (hmm.c:222-350) ---------------------------------
-__device__ __forceinline__ int32_t vit5(HmmRegs &h, const uint8_t *tp, const int16_t *ss)
+template <typename S>
+__device__ __forceinline__ int32_t vit5(HmmRegs &h, const uint8_t *tp, const S &ss)
 {
 #define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
 #define SEN(st) (-(int32_t)ss[h.senid[st]])
@@ -189,8 +201,8 @@ __device__ __forceinline__ int32_t vit5(HmmRegs &h, const uint8_t *tp, const int
 }
 
 // ---- 5-state, multiplex (hmm.c:355-525) -------------------------------------
-__device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const int16_t *ss,
-                                            const uint16_t *sseq)
+template <typename S>
+__device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const S &ss, const uint16_t *sseq)
 {
 #define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
 #define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 5 + (st)]])

@@ -33,3 +33,17 @@ constexpr int32_t kMaxNegInt32 = (int32_t)0x80000000;
 constexpr int32_t kWorstScore = (int32_t)0xE0000000;
 constexpr int kSenscrShift = 10;
 constexpr int kMaxNegAscr = 96;
+
+// A pointer that arrives inside a by-value kernel-argument struct (or is loaded from memory) is a generic pointer to the
+// compiler: every access through it becomes flat_load / flat_store, which wait on both memory counters.  Device memory
+// handed over by the host is global: saying so (generic -> address space 1 -> generic) lets the address-space inference
+// turn those accesses into global_load / global_store.
+template <typename T>
+__device__ __forceinline__ T *psgpu_as_global(T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (T *)(__attribute__((address_space(1))) T *)p;
+#else
+    return p;
+#endif
+}

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "psgpu_internal.h"
 
 struct LmLevel { uint32_t off, total_bits, word_bits, word_mask, max_vocab, next_bits, next_mask; };
 struct LmDev {
@@ -32,16 +33,18 @@ struct LmRange { uint32_t begin, end; };
 // bitarr_read_int25 (lm/bitarr.c:74-82): 32 bits little-endian from the byte holding bit `offset`
 __device__ __forceinline__ uint32_t lm_read25(const uint8_t *level, uint32_t offset, uint32_t mask)
 {
-    const uintptr_t a = (uintptr_t)level + (offset >> 3);
-    const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+    // (the aligned address is formed by pointer arithmetic on `level`, not by a round trip through an integer: that
+    //  keeps the address space the caller established, psgpu_as_global)
+    const uint32_t byte = offset >> 3, mis = (uint32_t)(((uintptr_t)level + byte) & 3);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(level + byte - mis);
     const uint64_t v = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    return (uint32_t)(v >> (8 * (uint32_t)(a & 3) + (offset & 7))) & mask;
+    return (uint32_t)(v >> (8 * mis + (offset & 7))) & mask;
 }
-__device__ __forceinline__ float lm_ug_prob(const LmDev &m, uint32_t w) { return __uint_as_float(m.ug[3 * (size_t)w]); }
-__device__ __forceinline__ float lm_ug_bo(const LmDev &m, uint32_t w) { return __uint_as_float(m.ug[3 * (size_t)w + 1]); }
+__device__ __forceinline__ float lm_ug_prob(const LmDev &m, uint32_t w) { return __uint_as_float(psgpu_as_global(m.ug)[3 * (size_t)w]); }
+__device__ __forceinline__ float lm_ug_bo(const LmDev &m, uint32_t w) { return __uint_as_float(psgpu_as_global(m.ug)[3 * (size_t)w + 1]); }
 __device__ __forceinline__ void lm_ug_range(const LmDev &m, uint32_t w, LmRange &r)      // unigram_find, lm_trie.c:549
 {
-    r.begin = m.ug[3 * (size_t)w + 2]; r.end = m.ug[3 * (size_t)w + 5];
+    r.begin = psgpu_as_global(m.ug)[3 * (size_t)w + 2]; r.end = psgpu_as_global(m.ug)[3 * (size_t)w + 5];
 }
 
 // uniform_find, lm_trie.c:564-600
@@ -63,7 +66,7 @@ __device__ __forceinline__ bool lm_uniform_find(const uint8_t *level, uint32_t t
 __device__ __forceinline__ bool lm_middle_find(const LmDev &m, int l, uint32_t word, LmRange &r, uint32_t &o)
 {
     const LmLevel &v = m.lev[l];
-    const uint8_t *level = m.mem + v.off;
+    const uint8_t *level = psgpu_as_global(m.mem) + v.off;
     uint32_t at;
     if (!lm_uniform_find(level, v.total_bits, v.word_mask, r.begin - 1u, 0u, r.end, v.max_vocab, word, at)) return false;
     at = at * v.total_bits + v.word_bits;
@@ -77,17 +80,17 @@ __device__ __forceinline__ bool lm_longest_find(const LmDev &m, uint32_t word, c
 {
     const LmLevel &v = m.lev[m.order - 2];
     uint32_t at;
-    if (!lm_uniform_find(m.mem + v.off, v.total_bits, v.word_mask, r.begin - 1u, 0u, r.end, v.max_vocab, word, at)) return false;
+    if (!lm_uniform_find(psgpu_as_global(m.mem) + v.off, v.total_bits, v.word_mask, r.begin - 1u, 0u, r.end, v.max_vocab, word, at)) return false;
     o = at * v.total_bits + v.word_bits;
     return true;
 }
 // lm_trie_quant_mboread / _mpread / _lpread, lm_trie_quant.c:330-354
 __device__ __forceinline__ float lm_mid_bo(const LmDev &m, int l, uint32_t o)
-{ return m.quant[(size_t)(2 * l + 1) * 65536 + lm_read25(m.mem + m.lev[l].off, o, 0xffffu)]; }
+{ return psgpu_as_global(m.quant)[(size_t)(2 * l + 1) * 65536 + lm_read25(psgpu_as_global(m.mem) + m.lev[l].off, o, 0xffffu)]; }
 __device__ __forceinline__ float lm_mid_prob(const LmDev &m, int l, uint32_t o)
-{ return m.quant[(size_t)(2 * l) * 65536 + lm_read25(m.mem + m.lev[l].off, o + 16u, 0xffffu)]; }
+{ return psgpu_as_global(m.quant)[(size_t)(2 * l) * 65536 + lm_read25(psgpu_as_global(m.mem) + m.lev[l].off, o + 16u, 0xffffu)]; }
 __device__ __forceinline__ float lm_long_prob(const LmDev &m, uint32_t o)
-{ return m.quant[(size_t)(2 * (m.order - 2)) * 65536 + lm_read25(m.mem + m.lev[m.order - 2].off, o, 0xffffu)]; }
+{ return psgpu_as_global(m.quant)[(size_t)(2 * (m.order - 2)) * 65536 + lm_read25(psgpu_as_global(m.mem) + m.lev[m.order - 2].off, o, 0xffffu)]; }
 
 // get_available_prob, lm_trie.c:653-704 (reached with n_hist < order - 1 only)
 __device__ inline float lm_available_prob(const LmDev &m, int32_t wid, const int32_t *hist, int n_hist, int &n_used)
@@ -163,9 +166,9 @@ __device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, in
 {
     int32_t hist[2];
     int n_hist = min(2, m.order - 1);                       // ngram_model_set.c:693
-    const int32_t wid = m.widmap[w3];
-    hist[0] = w2 < 0 ? -1 : m.widmap[w2];
-    hist[1] = w1 < 0 ? -1 : m.widmap[w1];
+    const int32_t wid = psgpu_as_global(m.widmap)[w3];
+    hist[0] = w2 < 0 ? -1 : psgpu_as_global(m.widmap)[w2];
+    hist[1] = w1 < 0 ? -1 : psgpu_as_global(m.widmap)[w1];
     n_used = 0;
     if (wid == -1) return m.log_zero;                       // ngram_model.c:394
     for (int i = 0; i < n_hist; ++i) if (hist[i] < 0) { n_hist = i; break; }    // ngram_model_trie.c:724-731

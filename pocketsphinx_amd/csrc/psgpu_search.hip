@@ -1,5 +1,5 @@
-// psgpu_search.hip -- the lexicon-tree search on gfx950, first
-// version: whole utterances, one workgroup per utterance, every frame inside the kernel.
+// psgpu_search.hip -- the lexicon-tree search on gfx950: whole utterances, one workgroup per
+// utterance, every frame inside the kernel.
 //
 // Replaces ngram_fwdtree_start + ngram_fwdtree_search x T + ngram_fwdtree_finish
 // (reference src/ngram_search_fwdtree.c:469-520, 1452-1495, 1497-1533) and the
@@ -9,231 +9,246 @@
 // deactivate_channels.  Output: the back-pointer table in the reference's own columns
 // (bptbl_t, ngram_search.h:112-124), the right-context score stack and the per-frame marks.
 //
-// Inputs are what the other kernels leave on the device: per-frame senone scores
-// (normalised rows here; the un-normalised rows + active-list normaliser come next) and
-// the phone-loop penalties.  Static tables are the reference's own (tree, dictionary,
-// dict2pid, beams) flattened to index arrays; the language model is a dense table over
-// dictionary word ids, so this version is for small vocabularies (turtle, tidigits).
+// Inputs are what the other kernels leave on the device: per-frame senone scores (normalised rows, or the scorer's
+// un-normalised rows, in which case the kernel builds each frame's active senone list and normaliser itself) and the
+// phone-loop penalties.  Static tables are the reference's own (tree, dictionary, dict2pid, beams) flattened to index
+// arrays; language scores come from a dense table over dictionary word ids or from the model's trie (psgpu_lm_dev.h).
 //
-// Parallelism in this version: utterances across workgroups; inside a frame the HMM
-// evaluation and the tree pruning run across the 256 threads (the pruning in the
-// order-free per-node formulation that oracle/ps_oracle_search.c proves equivalent to the
-// reference's sequential walk: decisions on a snapshot, prefix sums for list positions);
-// the word-level bookkeeping (tens of items per frame) is still one thread.  Results are
+// Formulation: per-frame work proportional to the active channels (oracle/ps_oracle_search.c `prune_tree_list`): the
+// pruning visits the roots, the listed nodes and their children; decisions are taken on a snapshot and list positions
+// come from workgroup prefix sums, which the oracle proves equivalent to the reference's sequential walk.  Results are
 // the reference's, bit for bit (tests/test_search_gpu.py against reference dumps).
 //
-// Two formulations of the per-frame passes (psgpu_fwdtree_set_mode):
-//   PER_NODE    (default) the pruning decides every node of the tree (work ~ tree size), 256 work-items;
-//   ACTIVE_LIST the pruning visits only the roots, the listed nodes and their children (work ~ active
-//               channels, oracle prune_tree_list), the word-level positions come from workgroup prefix sums
-//               instead of single-thread loops, and a large tree gets a 1024-work-item workgroup: the form
-//               for large vocabularies.  Same tables, bit for bit.
+// Memory: a recurrence over frames is bound by the latency of its dependent accesses, so where the tree is small enough
+// (FtDev.small: en-us + a few hundred words) everything the tree level touches per frame lives in LDS -- channel state
+// (structure of arrays: consecutive channels in consecutive banks), the pruning snapshot, the active lists, the per-word
+// tables, the children lists of the tree (CSR), the frame's score row (copied in one frame ahead) -- and only the
+// right-context fan-out of the words' last phones, the back-pointer table and the language model stay in global memory.
+// Larger trees keep the same arrays in a per-utterance slab in global memory (same source lines, other base pointers)
+// and run 1024 work-items per utterance.
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
-constexpr int kFtThreads = 256;        // work-items per utterance (PER_NODE, and ACTIVE_LIST on small trees)
-constexpr int kFtThreadsBig = 1024;    // ACTIVE_LIST on trees beyond the LDS scratch
-constexpr int kFtMaxN = 4096;          // tree nodes (LDS scratch of the pruning)
+constexpr int kFtThreads = 256;        // work-items per utterance
+constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
+constexpr int kFtBigNodes = 4096;
+constexpr int kFtLdsWords = 15104;     // LDS layout: 59 KB of arrays (+ 2.5 KB fixed) per workgroup, two workgroups per CU
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
 
+// word offsets of the per-utterance arrays the tree level works on ("fast" arrays: LDS in the small layout, the
+// utterance's slab otherwise)
+struct FtLay {
+    int32_t rec;                         // [CH][..] channel records of the tree nodes and the single-phone words
+    int32_t acl0, acl1, awl0, awl1;      // [N], [n_w] active lists (this frame / next frame)
+    int32_t word_active, word_lat_idx, lt_sf, lt_dscr, lt_bp, cand_mark;    // [n_w]
+    int32_t cand_wid, cand_score, cand_bp;                                  // [n_w + 1]
+    int32_t o_out, o_outh, pos, flag, o_frame;                              // [N] pruning snapshot / decisions
+    int32_t cnt;                         // [cnt_words] scan scratch
+    int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
+    int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
+    int32_t total;
+};
+
 struct FtDev {
-    int32_t n_ci, n_emit, n_sen, n_w, R, M, N, n1, n1lm, TOT;
+    int32_t n_ci, n_emit, n_sen, n_w, R, M, N, n1, n1lm, TOT, CH;
     int32_t beam, pbeam, lpbeam, lponlybeam, wbeam, pip, nwpen, silpen, fillpen, maxhmmpf, maxwpf;
     int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci, has_pl;
-    const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_child, *node_sib, *node_pw, *parent;
+    const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_pw, *parent, *kid_off, *kids;
     const int32_t *homophone, *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx, *w1_of_word;
     const int32_t *d_pronlen, *d_first, *d_last, *d_last2, *d_base, *d_filler;
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
     const uint8_t *tp;
     const uint16_t *sseq;
-    int32_t big;                         // tree or vocabulary beyond the LDS scratch: list / word scratch in the utterance's slab
+    int32_t small;                       // the fast arrays fit the LDS pool
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
-    int32_t list_mode;                   // PSGPU_FWDTREE_ACTIVE_LIST: per-frame work proportional to the active channels
-    int32_t *w1_out;                     // optional [n_utt][n1][n_emit]: the single-phone channels' ssids when the pass ends
+    int32_t cnt_words;
+    FtLay lay;
+    // always in the utterance's slab (int32 units from its start): last-phone channel records, their presence flags,
+    // the evaluation / entering work lists, the rarely used duplicate-candidate scratch; `fast`: the FtLay arrays
+    // when they are not in LDS
+    int64_t g_wrec, g_present, g_elist, g_eword, g_xlist, g_xslot, g_cand_next, g_csf_ef, g_csf_cand, g_fast, per;
     LmDev trie;
 };
 
-// per-utterance state (one slab per utterance; all int32 unless noted)
-struct FtUtt {
-    // channels: [0, N) tree nodes, [N, N + n1) single-phone words, [N + n1, N + n1 + TOT) last-phone slots
-    int32_t *score, *hist;               // [C][5]
-    int32_t *out, *outh, *best, *frame;  // [C]
-    int32_t *senid;                      // [C][5]  senone ids, or per-state ssids of multiplex HMMs
-    int32_t *tmat, *mpx;                 // [C]
-    int32_t *present;                    // [TOT]
-    int32_t *acl[2], *awl[2];            // [N], [n_w]
-    int32_t *word_active, *word_lat_idx; // [n_w]
-    int32_t *cand_wid, *cand_score, *cand_bp, *cand_next;   // [n_w + 1]
-    int32_t *lt_sf, *lt_dscr, *lt_bp;    // [n_w]
-    int32_t *csf_ef, *csf_cand;          // [n_w + 1]
-    int32_t *bp;                         // [10][bp_cap] columns: frame valid wid bp score s_idx real_wid prev_real_wid last last2
-    int32_t *bss;                        // [bss_cap]
-    int32_t *bp_table_idx;               // [T + 2]
-    int32_t *o_frame, *o_s0, *o_best, *o_out, *o_outh, *pos, *flag;   // [N] pruning snapshot / decisions
-    int32_t *step;                       // [T][4] best_score, last_phone_best_score, bpidx, n_active_chan (diagnostics)
-    int32_t *result;                     // [8] bpidx, bss_head, n_frame, status
-    int32_t *g_cnt, *g_w;                // [max(R + N, n_w) + 1], [4][n_w]: scratch for large trees / vocabularies (FtDev.big)
-    int16_t *nrow;                       // [n_sen] the frame's normalised scores (raw-score mode)
-    int32_t *cand_mark;                  // [n_w] frame in which the word was last a last-phone candidate (ACTIVE_LIST)
-    int32_t *xlist, *xslot;              // [TOT] (candidate, slot) pairs of the entering loop (ACTIVE_LIST)
-    int32_t *elist, *eword;              // [TOT] the frame's present last-phone channels and the index of their word in the
-                                         //       active word list (ACTIVE_LIST: evaluation / pruning work list)
-    int32_t bp_cap, bss_cap;
-};
-
-// ACTIVE_LIST is handed the per-utterance fields as offsets (int32 units) from buffers that are kernel arguments: a pointer
-// loaded from memory is generic to the compiler (every access a flat_load / flat_store, both wait counters), a pointer formed
-// from a kernel argument is global.  (The default formulation keeps reading FtUtt, as measured.)
-#define FT_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(present) X(word_active) \
-    X(word_lat_idx) X(cand_wid) X(cand_score) X(cand_bp) X(cand_next) X(lt_sf) X(lt_dscr) X(lt_bp) X(csf_ef) X(csf_cand) \
-    X(o_frame) X(o_s0) X(o_best) X(o_out) X(o_outh) X(pos) X(flag) X(cand_mark) X(elist) X(eword) X(xlist) X(xslot)
-struct FtOff {
-#define X(f) int64_t f;
-    FT_SLAB_FIELDS(X)
-#undef X
-    int64_t acl0, acl1, awl0, awl1, g_cnt, g_w, nrow;
-};
 struct FtBufs {
-    int32_t *slab, *bp, *bss, *idx, *step, *res;
+    int32_t *slab, *bp, *bss, *idx, *step, *res, *w1_out;
     int32_t bp_cap, bss_cap, max_frames;
 };
 
 struct psgpu_fwdtree_s {
     FtDev d;
     std::vector<void *> allocs;
-    int32_t C;
+    int32_t *slab = nullptr;             // work slab, kept between calls (grown on demand)
+    size_t slab_words = 0;
 };
 
-#define BPC(u, col, i) ((u).bp[(size_t)(col) * (u).bp_cap + (i)])
-enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2 };
+// ---- channel records ---------------------------------------------------------------------------------------------
+// One record per HMM instance = the fields of hmm_t (hmm.h:169-182).  Addressed as base[c * cst + field * fst]: the
+// last-phone channels (global memory) are arrays of records (cst = record size, fst = 1: a record is one cache line);
+// the tree's channels in LDS are a structure of arrays (cst = 1, fst = number of channels: work-items on consecutive
+// channels hit consecutive banks).
+template <int NE> struct ChF {
+    static constexpr int SCORE = 0, HIST = NE, OUT = 2 * NE, OUTH = 2 * NE + 1, BEST = 2 * NE + 2, FRAME = 2 * NE + 3,
+                         SENID = 2 * NE + 4, TMAT = 3 * NE + 4, MPX = 3 * NE + 5, WORDS = 3 * NE + 6,
+                         REC = NE == 3 ? 16 : 24;
+};
+struct ChView {
+    int32_t *b;
+    int cst, fst;
+    __device__ __forceinline__ int32_t &at(int c, int field) const { return b[c * cst + field * fst]; }
+};
 
-template <int CS, int C1>
-__device__ __forceinline__ void ch_clear(const FtDev &p, FtUtt &u, int c)      // hmm_clear, hmm.c:181-196
+template <int NE>
+__device__ __forceinline__ void ch_clear(const ChView &v, int c)                 // hmm_clear, hmm.c:181-196
 {
-    for (int i = 0; i < p.n_emit; ++i) { u.score[c * CS + i] = kW; u.hist[c * CS + i] = -1; }
-    u.out[(c) * C1] = kW; u.outh[(c) * C1] = -1; u.best[(c) * C1] = kW; u.frame[(c) * C1] = -1;
+    using F = ChF<NE>;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { v.at(c, F::SCORE + i) = kW; v.at(c, F::HIST + i) = -1; }
+    v.at(c, F::OUT) = kW; v.at(c, F::OUTH) = -1; v.at(c, F::BEST) = kW; v.at(c, F::FRAME) = -1;
 }
-template <int CS, int C1>
-__device__ __forceinline__ void ch_init(const FtDev &p, FtUtt &u, int c, int mpx, int ssid, int tmatid)   // hmm_init :146-168
+template <int NE>
+__device__ __forceinline__ void ch_init(const ChView &v, int c, int mpx, int ssid, int tmatid, const uint16_t *sseq)   // hmm_init :146-168
 {
-    u.mpx[(c) * C1] = mpx; u.tmat[(c) * C1] = tmatid;
+    using F = ChF<NE>;
+    v.at(c, F::MPX) = mpx; v.at(c, F::TMAT) = tmatid;
     if (mpx) {
-        u.senid[c * CS] = ssid;
-        for (int i = 1; i < p.n_emit; ++i) u.senid[c * CS + i] = kBadSsid;
+        v.at(c, F::SENID) = ssid;
+#pragma unroll
+        for (int i = 1; i < NE; ++i) v.at(c, F::SENID + i) = kBadSsid;
     }
-    else
-        for (int i = 0; i < p.n_emit; ++i) u.senid[c * CS + i] = p.sseq[(size_t)ssid * p.n_emit + i];
-    ch_clear<CS, C1>(p, u, c);
+    else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v.at(c, F::SENID + i) = sseq[(size_t)ssid * NE + i];
+    }
+    ch_clear<NE>(v, c);
 }
-template <int CS, int C1>
-__device__ __forceinline__ void ch_enter(FtUtt &u, int c, int32_t score, int32_t hist, int frame)   // hmm_enter :198-204
+template <int NE>
+__device__ __forceinline__ void ch_enter(const ChView &v, int c, int32_t score, int32_t hist, int frame)   // hmm_enter :198-204
 {
-    u.score[c * CS] = score; u.hist[c * CS] = hist; u.frame[(c) * C1] = frame;
+    using F = ChF<NE>;
+    v.at(c, F::SCORE) = score; v.at(c, F::HIST) = hist; v.at(c, F::FRAME) = frame;
 }
-template <int CS, int C1>
-__device__ __forceinline__ void ch_normalize(const FtDev &p, FtUtt &u, int c, int32_t norm)      // hmm_normalize :206-217
+template <int NE>
+__device__ __forceinline__ void ch_normalize(const ChView &v, int c, int32_t norm)      // hmm_normalize :206-217
 {
-    for (int i = 0; i < p.n_emit; ++i) if (u.score[c * CS + i] > kW) u.score[c * CS + i] -= norm;
-    if (u.out[(c) * C1] > kW) u.out[(c) * C1] -= norm;
+    using F = ChF<NE>;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) if (v.at(c, F::SCORE + i) > kW) v.at(c, F::SCORE + i) -= norm;
+    if (v.at(c, F::OUT) > kW) v.at(c, F::OUT) -= norm;
 }
-
-// hmm_vit_eval on channel c with the frame's score row
-template <int NE, int CS, int C1>
-__device__ __forceinline__ int32_t ch_eval(const FtDev &p, FtUtt &u, int c, const int16_t *row)
+// hmm_vit_eval on channel c with the frame's scores
+template <int NE, typename S>
+__device__ __forceinline__ int32_t ch_eval(const ChView &v, int c, const S &row, const uint8_t *tpall, const uint16_t *sseq)
 {
+    using F = ChF<NE>;
     HmmRegs h;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        h.score[i] = i < NE ? u.score[c * CS + i] : kW;
-        h.history[i] = i < NE ? u.hist[c * CS + i] : -1;
-        h.senid[i] = i < NE ? (uint16_t)u.senid[c * CS + i] : 0;
+        h.score[i] = i < NE ? v.at(c, F::SCORE + i) : kW;
+        h.history[i] = i < NE ? v.at(c, F::HIST + i) : -1;
+        h.senid[i] = i < NE ? (uint16_t)v.at(c, F::SENID + i) : 0;
     }
-    h.out_score = u.out[(c) * C1]; h.out_history = u.outh[(c) * C1]; h.bestscore = u.best[(c) * C1];
-    const uint8_t *tp = p.tp + (size_t)u.tmat[(c) * C1] * NE * (NE + 1);
+    h.out_score = v.at(c, F::OUT); h.out_history = v.at(c, F::OUTH); h.bestscore = v.at(c, F::BEST);
+    const uint8_t *tp = tpall + (size_t)v.at(c, F::TMAT) * NE * (NE + 1);
+    const int mpx = v.at(c, F::MPX);
     int32_t b;
-    if (NE == 3) b = u.mpx[(c) * C1] ? vit3_mpx(h, tp, row, p.sseq) : vit3(h, tp, row);
-    else         b = u.mpx[(c) * C1] ? vit5_mpx(h, tp, row, p.sseq) : vit5(h, tp, row);
+    if (NE == 3) b = mpx ? vit3_mpx(h, tp, row, sseq) : vit3(h, tp, row);
+    else         b = mpx ? vit5_mpx(h, tp, row, sseq) : vit5(h, tp, row);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) { u.score[c * CS + i] = h.score[i]; u.hist[c * CS + i] = h.history[i]; u.senid[c * CS + i] = h.senid[i]; }
-    u.out[(c) * C1] = h.out_score; u.outh[(c) * C1] = h.out_history; u.best[(c) * C1] = h.bestscore;
+    for (int i = 0; i < NE; ++i) { v.at(c, F::SCORE + i) = h.score[i]; v.at(c, F::HIST + i) = h.history[i]; }
+    if (mpx) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v.at(c, F::SENID + i) = h.senid[i];
+    }
+    v.at(c, F::OUT) = h.out_score; v.at(c, F::OUTH) = h.out_history; v.at(c, F::BEST) = h.bestscore;
     return b;
 }
 
-__device__ __forceinline__ int32_t ft_pen(const FtDev &p, const int32_t *pp, int ci) { return p.has_pl ? pp[ci] : 0; }
-__device__ __forceinline__ int32_t ft_lm(const FtDev &p, int w3, int w2, int w1)
+// ---- the back-pointer table ------------------------------------------------------------------------------------------
+struct FtTab {
+    int32_t *bp, *bss, *idx;
+    int32_t bp_cap, bss_cap;
+};
+#define BPC(t, col, i) ((t).bp[(size_t)(col) * (t).bp_cap + (i)])
+enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2 };
+
+__device__ __forceinline__ int32_t ft_lm(const FtDev &p, const LmDev &trie, const int32_t *lmtab, int w3, int w2, int w1)
 {
     if (p.use_trie) {                    // ngram_tg_score(...) >> SENSCR_SHIFT, ngram_search_fwdtree.c:1118, :1342
         int nu;
-        return lm_tg_score(p.trie, w3, w2, w1, nu) >> 10;
+        return lm_tg_score(trie, w3, w2, w1, nu) >> 10;
     }
     const size_t n1 = (size_t)p.n_w + 1;
-    return p.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
+    return lmtab[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
 // ngram_search_exit_score, ngram_search.c:653-674
-__device__ __forceinline__ int32_t ft_exit_score(const FtDev &p, const FtUtt &u, int bp, int rcphone)
+__device__ __forceinline__ int32_t ft_exit_score(const FtTab &t, const int32_t *rs_cimap, int n_ci, int bp, int rcphone)
 {
-    const int l2 = BPC(u, B_LAST2, bp);
-    if (l2 == -1) return BPC(u, B_SCORE, bp);
-    const int l1 = BPC(u, B_LAST, bp);
-    return u.bss[BPC(u, B_SIDX, bp) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + rcphone]];
+    const int l2 = BPC(t, B_LAST2, bp);
+    if (l2 == -1) return BPC(t, B_SCORE, bp);
+    const int l1 = BPC(t, B_LAST, bp);
+    return t.bss[BPC(t, B_SIDX, bp) + rs_cimap[((size_t)l1 * n_ci + l2) * n_ci + rcphone]];
 }
 // set_real_wid, ngram_search.c:341-372
-__device__ __forceinline__ void ft_set_real_wid(const FtDev &p, FtUtt &u, int bp)
+__device__ __forceinline__ void ft_set_real_wid(const FtTab &t, const int32_t *d_filler, const int32_t *d_base, int bp)
 {
-    const int prev = BPC(u, B_BP, bp), wid = BPC(u, B_WID, bp);
-    if (p.d_filler[wid]) {
-        if (prev != -1) { BPC(u, B_REAL, bp) = BPC(u, B_REAL, prev); BPC(u, B_PREAL, bp) = BPC(u, B_PREAL, prev); }
-        else { BPC(u, B_REAL, bp) = p.d_base[wid]; BPC(u, B_PREAL, bp) = -1; }
+    const int prev = BPC(t, B_BP, bp), wid = BPC(t, B_WID, bp);
+    if (d_filler[wid]) {
+        if (prev != -1) { BPC(t, B_REAL, bp) = BPC(t, B_REAL, prev); BPC(t, B_PREAL, bp) = BPC(t, B_PREAL, prev); }
+        else { BPC(t, B_REAL, bp) = d_base[wid]; BPC(t, B_PREAL, bp) = -1; }
     }
     else {
-        BPC(u, B_REAL, bp) = p.d_base[wid];
-        BPC(u, B_PREAL, bp) = prev != -1 ? BPC(u, B_REAL, prev) : -1;
+        BPC(t, B_REAL, bp) = d_base[wid];
+        BPC(t, B_PREAL, bp) = prev != -1 ? BPC(t, B_REAL, prev) : -1;
     }
 }
+// the static per-word tables save_bp reads
+struct FtDict { const int32_t *d_pronlen, *d_last, *d_last2, *d_base, *d_filler, *rs_n; int n_ci; };
 // ngram_search_save_bp, ngram_search.c:376-498 (single thread).  Returns false when a table is full.
-__device__ __forceinline__ bool ft_save_bp(const FtDev &p, FtUtt &u, int32_t &bpidx, int32_t &bss_head, int frame, int w, int32_t score,
-                           int32_t path, int rc)
+__device__ __forceinline__ bool ft_save_bp(const FtTab &t, const FtDict &d, int32_t *word_lat_idx, int32_t &bpidx, int32_t &bss_head,
+                                           int frame, int w, int32_t score, int32_t path, int rc)
 {
-    const int bp = u.word_lat_idx[w];
+    const int bp = word_lat_idx[w];
     if (bp != -1) {
-        if (BPC(u, B_SCORE, bp) < score) {
-            const int ob = BPC(u, B_BP, bp);
+        if (BPC(t, B_SCORE, bp) < score) {
+            const int ob = BPC(t, B_BP, bp);
             if (ob != path) {
-                const int32_t b0 = ob == -1 ? -1 : BPC(u, B_PREAL, ob), b1 = ob == -1 ? -1 : BPC(u, B_REAL, ob);
-                const int32_t n0 = path == -1 ? -1 : BPC(u, B_PREAL, path), n1 = path == -1 ? -1 : BPC(u, B_REAL, path);
-                if (b0 != n0 || b1 != n1) ft_set_real_wid(p, u, bp);      // with the old bp still in place, as the reference
-                BPC(u, B_BP, bp) = path;
+                const int32_t b0 = ob == -1 ? -1 : BPC(t, B_PREAL, ob), b1 = ob == -1 ? -1 : BPC(t, B_REAL, ob);
+                const int32_t n0 = path == -1 ? -1 : BPC(t, B_PREAL, path), n1 = path == -1 ? -1 : BPC(t, B_REAL, path);
+                if (b0 != n0 || b1 != n1) ft_set_real_wid(t, d.d_filler, d.d_base, bp);      // with the old bp still in place, as the reference
+                BPC(t, B_BP, bp) = path;
             }
-            BPC(u, B_SCORE, bp) = score;
+            BPC(t, B_SCORE, bp) = score;
         }
-        if (BPC(u, B_SIDX, bp) != -1) u.bss[BPC(u, B_SIDX, bp) + rc] = score;
+        if (BPC(t, B_SIDX, bp) != -1) t.bss[BPC(t, B_SIDX, bp) + rc] = score;
         return true;
     }
-    if (bpidx >= u.bp_cap || bss_head + p.n_ci >= u.bss_cap) return false;
-    u.word_lat_idx[w] = bpidx;
-    BPC(u, B_WID, bpidx) = w; BPC(u, B_FRAME, bpidx) = frame; BPC(u, B_BP, bpidx) = path; BPC(u, B_SCORE, bpidx) = score;
-    BPC(u, B_SIDX, bpidx) = bss_head; BPC(u, B_VALID, bpidx) = 1;
-    BPC(u, B_LAST, bpidx) = p.d_last[w];
+    if (bpidx >= t.bp_cap || bss_head + d.n_ci >= t.bss_cap) return false;
+    word_lat_idx[w] = bpidx;
+    BPC(t, B_WID, bpidx) = w; BPC(t, B_FRAME, bpidx) = frame; BPC(t, B_BP, bpidx) = path; BPC(t, B_SCORE, bpidx) = score;
+    BPC(t, B_SIDX, bpidx) = bss_head; BPC(t, B_VALID, bpidx) = 1;
+    BPC(t, B_LAST, bpidx) = d.d_last[w];
     int rcsize = 0;
-    if (p.d_pronlen[w] == 1) { BPC(u, B_LAST2, bpidx) = -1; BPC(u, B_SIDX, bpidx) = -1; }
+    if (d.d_pronlen[w] == 1) { BPC(t, B_LAST2, bpidx) = -1; BPC(t, B_SIDX, bpidx) = -1; }
     else {
-        BPC(u, B_LAST2, bpidx) = p.d_last2[w];
-        rcsize = p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]];
+        BPC(t, B_LAST2, bpidx) = d.d_last2[w];
+        rcsize = d.rs_n[d.d_last[w] * d.n_ci + d.d_last2[w]];
     }
-    for (int i = 0; i < rcsize; ++i) u.bss[bss_head + i] = kW;
-    if (rcsize) u.bss[bss_head + rc] = score;
-    ft_set_real_wid(p, u, bpidx);
+    for (int i = 0; i < rcsize; ++i) t.bss[bss_head + i] = kW;
+    if (rcsize) t.bss[bss_head + rc] = score;
+    ft_set_real_wid(t, d.d_filler, d.d_base, bpidx);
     ++bpidx;
     bss_head += rcsize;
     return true;
 }
 
-// Exclusive prefix sum of a[0..n) in place by the whole workgroup (a in LDS, written before a barrier);
-// returns the total to every thread.  tmp: NT / 64 words of LDS.  Ends with a barrier.
+// Exclusive prefix sum of a[0..n) in place by the whole workgroup (a written before a barrier); returns the total to
+// every thread.  tmp: NT / 64 words of LDS.  Ends with a barrier.
 template <int NT>
 __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp)
 {
@@ -255,121 +270,177 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
     __syncthreads();
     return total;
 }
-// out[t] = max of v over threads 0 .. t - 1 (-1 for thread 0): one value per thread.  Ends with a barrier.
-__device__ __forceinline__ int32_t ft_block_excl_max(int32_t v, int32_t *tmp)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    int32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
-    if (lane == 63) tmp[tid >> 6] = incl;
-    int32_t excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = -1;
-    __syncthreads();
-    for (int w = 0; w < (tid >> 6); ++w) excl = max(excl, tmp[w]);
-    __syncthreads();
-    return excl;
-}
 
-template <int NE, int NT, bool LIST>
+template <int NE, int NT, bool SMALL>
 __global__ __launch_bounds__(NT)
-void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__restrict__ senscr, int64_t scr_stride,
-                    const int32_t *__restrict__ penalties, const int32_t *__restrict__ utt_off, int32_t raw_mode,
-                    int32_t pl_window, const FtOff *__restrict__ offs, FtBufs bf)
+void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_stride, const int32_t *__restrict__ penalties_,
+                    const int32_t *__restrict__ utt_off_, int32_t raw_mode, int32_t pl_window, FtBufs bf)
 {
+    using F = ChF<NE>;
+    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 4];
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
-    __shared__ int32_t s_prev[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
-    __shared__ int32_t s_cnt[kFtMaxN + 1];
     __shared__ int32_t s_red[8];
     __shared__ int32_t s_scan[NT / 64];
     __shared__ int32_t s_bins[256];
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
-    __shared__ int32_t s_nwc, s_nwc2;    // ACTIVE_LIST: lengths of the word level's evaluation list and of the entering list
-    // channel state: PER_NODE keeps one array per field ([C][5] / [C]); ACTIVE_LIST one record of CS ints per channel (score,
-    // hist, out, outh, best, frame, senid, tmat, mpx: 64 bytes for 3-state models) -- its passes gather by channel id, and a
-    // record is one cache line where the arrays are nine
-    constexpr int CS = LIST ? (NE == 3 ? 16 : 24) : 5, C1 = LIST ? CS : 1;
+    __shared__ int32_t s_nwc, s_nwc2;    // lengths of the word level's evaluation list and of the entering list
     const int tid = threadIdx.x;
-    FtUtt u;
-    if (LIST) {
-        const FtOff o = offs[blockIdx.x];
-#define X(f) u.f = bf.slab + o.f;
-        FT_SLAB_FIELDS(X)
-#undef X
-        u.acl[0] = bf.slab + o.acl0; u.acl[1] = bf.slab + o.acl1; u.awl[0] = bf.slab + o.awl0; u.awl[1] = bf.slab + o.awl1;
-        u.g_cnt = bf.slab + o.g_cnt; u.g_w = bf.slab + o.g_w;           // (offset 0 when unused: never dereferenced then)
-        u.nrow = reinterpret_cast<int16_t *>(bf.slab + o.nrow);
-        u.bp = bf.bp + (size_t)blockIdx.x * 10 * bf.bp_cap; u.bss = bf.bss + (size_t)blockIdx.x * bf.bss_cap;
-        u.bp_table_idx = bf.idx + (size_t)blockIdx.x * (bf.max_frames + 2); u.step = bf.step + (size_t)blockIdx.x * bf.max_frames * 4;
-        u.result = bf.res + (size_t)blockIdx.x * 8;
-        u.bp_cap = bf.bp_cap; u.bss_cap = bf.bss_cap;
+    const int N = p.N, R = p.R, n1 = p.n1, n_ci = p.n_ci;
+    const FtLay &L = p.lay;
+
+    // ---- pointers.  Everything the host handed over is global memory (psgpu_as_global: see psgpu_internal.h).
+    const int16_t *const senscr = psgpu_as_global(senscr_);
+    const int32_t *const penalties = psgpu_as_global(penalties_);
+    const int32_t *const utt_off = psgpu_as_global(utt_off_);
+    int32_t *const gs = psgpu_as_global(bf.slab) + (size_t)blockIdx.x * p.per;
+    int32_t *const fb = SMALL ? s_pool : gs + p.g_fast;
+    const ChView tv = { fb + L.rec, SMALL ? 1 : F::REC, SMALL ? p.CH : 1 };       // tree nodes [0, N), single-phone words [N, N + n1)
+    const ChView wv = { gs + p.g_wrec, F::REC, 1 };                               // last-phone slots [0, TOT)
+    int32_t *const word_active = fb + L.word_active, *const word_lat_idx = fb + L.word_lat_idx, *const lt_sf = fb + L.lt_sf,
+            *const lt_dscr = fb + L.lt_dscr, *const lt_bp = fb + L.lt_bp, *const cand_mark = fb + L.cand_mark,
+            *const cand_wid = fb + L.cand_wid, *const cand_score = fb + L.cand_score, *const cand_bp = fb + L.cand_bp,
+            *const o_out = fb + L.o_out, *const o_outh = fb + L.o_outh, *const pos = fb + L.pos, *const flag = fb + L.flag,
+            *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt;
+    int32_t *const present = gs + p.g_present, *const elist = gs + p.g_elist, *const eword = gs + p.g_eword,
+            *const xlist = gs + p.g_xlist, *const xslot = gs + p.g_xslot, *const cand_next = gs + p.g_cand_next,
+            *const csf_ef = gs + p.g_csf_ef, *const csf_cand = gs + p.g_csf_cand;
+    FtTab tb;
+    tb.bp = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * 10 * bf.bp_cap; tb.bss = psgpu_as_global(bf.bss) + (size_t)blockIdx.x * bf.bss_cap;
+    tb.idx = psgpu_as_global(bf.idx) + (size_t)blockIdx.x * (bf.max_frames + 2);
+    tb.bp_cap = bf.bp_cap; tb.bss_cap = bf.bss_cap;
+    int32_t *const step = psgpu_as_global(bf.step) + (size_t)blockIdx.x * bf.max_frames * 4;
+    int32_t *const result = psgpu_as_global(bf.res) + (size_t)blockIdx.x * 8;
+    // static tables
+    const int32_t *const node_ci2 = psgpu_as_global(p.node_ci2), *const node_ssid = psgpu_as_global(p.node_ssid),
+                  *const node_tmat = psgpu_as_global(p.node_tmat), *const homophone = psgpu_as_global(p.homophone),
+                  *const w1_wid = psgpu_as_global(p.w1_wid), *const w1_ci = psgpu_as_global(p.w1_ci), *const w1_ci2 = psgpu_as_global(p.w1_ci2),
+                  *const w1_ssid = psgpu_as_global(p.w1_ssid), *const w1_tmat = psgpu_as_global(p.w1_tmat), *const w1_mpx = psgpu_as_global(p.w1_mpx),
+                  *const w1_of_word = psgpu_as_global(p.w1_of_word), *const d_first = psgpu_as_global(p.d_first),
+                  *const d_last = psgpu_as_global(p.d_last), *const d_last2 = psgpu_as_global(p.d_last2), *const d_base = psgpu_as_global(p.d_base),
+                  *const d_filler = psgpu_as_global(p.d_filler), *const rs_n = psgpu_as_global(p.rs_n), *const rs_ssid = psgpu_as_global(p.rs_ssid),
+                  *const rs_cimap = psgpu_as_global(p.rs_cimap), *const ldiph = psgpu_as_global(p.ldiph), *const ci_tmat = psgpu_as_global(p.ci_tmat),
+                  *const lmtab = psgpu_as_global(p.lm), *const wc_off = psgpu_as_global(p.wc_off);
+    const uint8_t *const tpall = psgpu_as_global(p.tp);
+    const uint16_t *const sseq = psgpu_as_global(p.sseq);
+    const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
+    const LmDev &trie = p.trie;                          // (its pointers are cast where they are used: psgpu_lm_dev.h)
+    // the tree's structure: LDS copies in the small layout
+    const int32_t *const kid_off = SMALL ? fb + L.kid_off : psgpu_as_global(p.kid_off), *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids),
+                  *const parent = SMALL ? fb + L.parent : psgpu_as_global(p.parent), *const node_ci = SMALL ? fb + L.ci : psgpu_as_global(p.node_ci),
+                  *const node_pw = SMALL ? fb + L.pw : psgpu_as_global(p.node_pw);
+    if (SMALL) {
+        const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_k = psgpu_as_global(p.kids), *const g_p = psgpu_as_global(p.parent),
+                      *const g_c = psgpu_as_global(p.node_ci), *const g_w = psgpu_as_global(p.node_pw);
+        for (int i = tid; i <= N; i += NT) fb[L.kid_off + i] = g_ko[i];
+        for (int i = tid; i < p.M; i += NT) fb[L.kids + i] = g_k[i];
+        for (int i = tid; i < N; i += NT) { fb[L.parent + i] = g_p[i]; fb[L.ci + i] = g_c[i]; fb[L.pw + i] = g_w[i]; }
     }
-    else
-        u = utts[blockIdx.x];
-    // list-position / candidate / word scratch: LDS when the tree and the vocabulary fit (kFtMaxN entries), else the slab
-    int32_t *const cnt = p.big ? u.g_cnt : s_cnt;
+    int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // small layout only
+    int32_t *const s_pen = fb + L.pen;                                      // small layout only: [2][n_ci]
+
     const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
-    const int N = p.N, R = p.R, W1 = N, WC = N + p.n1;
-    int n_acl[2] = {0, 0}, n_awl[2] = {0, 0};           // uniform copies (every thread tracks them identically)
+    const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
+    int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
-    for (int c = tid; c < N; c += NT) ch_init<CS, C1>(p, u, c, c < R, p.node_ssid[c], p.node_tmat[c]);
-    for (int i = tid; i < p.n1; i += NT) ch_init<CS, C1>(p, u, W1 + i, p.w1_mpx[i], p.w1_ssid[i], p.w1_tmat[i]);
-    for (int i = tid; i < p.TOT; i += NT) u.present[i] = 0;
-    for (int w = tid; w < p.n_w; w += NT) { u.word_lat_idx[w] = -1; u.lt_sf[w] = -1; u.word_active[w] = 0; }
-    if (LIST) {                                  // pos is kept at -1 between frames; no word has been a candidate yet
-        for (int c = tid; c < N; c += NT) u.pos[c] = -1;
-        for (int w = tid; w < p.n_w; w += NT) u.cand_mark[w] = -1;
-    }
+    for (int c = tid; c < N; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
+    for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
+    for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
+    for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
+    for (int c = tid; c < N; c += NT) pos[c] = -1;       // pos is kept at -1 between frames
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
-        s_evals = 0ull;
+        s_evals = 0ull; s_nb = 0x7fffffff;
+    }
+    {
+        const int nwords = (p.n_sen + 31) >> 5;
+        for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
+    }
+    // the small layout reads scores and penalties from LDS: frame 0's rows now, every later frame's one frame ahead
+    constexpr int kPre = SMALL ? (kFtMaxSen / 2 + NT - 1) / NT : 1;
+    const int row_dw = (p.n_sen + 1) >> 1;              // dwords per score row (the host checked the alignment)
+    auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T - 1) : f); };
+    if (SMALL && T > 0) {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
+        uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+        for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
+        if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[i] = penalties[(size_t)pen_frame(0) * n_ci + i];
     }
     __syncthreads();
-    if (tid == 0) ch_enter<CS, C1>(u, W1 + p.w1_of_word[p.startwid], 0, -1, 0);
+    if (tid == 0) ch_enter<NE>(tv, W1 + w1_of_word[p.startwid], 0, -1, 0);
     __syncthreads();
 
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1;
-        const int16_t *row = senscr + (size_t)(t0 + f) * scr_stride;
+        int32_t *const aclc = fb + (cur ? L.acl1 : L.acl0), *const acln = fb + (cur ? L.acl0 : L.acl1);
+        int32_t *const awlc = fb + (cur ? L.awl1 : L.awl0), *const awln = fb + (cur ? L.awl0 : L.awl1);
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
-        const int32_t *pp = penalties + (size_t)(t0 + (raw_mode ? min(f + pl_window, T - 1) : f)) * p.n_ci;
+        const int32_t *const pp = SMALL ? s_pen + cur * n_ci : penalties + (size_t)pen_frame(f) * n_ci;
+        const int16_t *const row = SMALL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
+        auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
+        // small layout: the next frame's score row and penalties start their way from HBM now
+        uint32_t pre[kPre];
+        int32_t pre_pen = 0;
+        if (SMALL && nf < T) {
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + nf) * scr_stride);
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; pre[k] = i < row_dw ? __builtin_nontemporal_load(g + i) : 0u; }
+            if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
+        }
+        // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
+        if (tid == 0) tb.idx[f] = s_sc[3];
+        const int32_t best_in = s_sc[0];
+        if (best_in == kW || best_in < kW) break;
+        if (tid < 8) s_red[tid] = kW;
+        if (tid == 0) s_nwc = 0;
+        __syncthreads();
+        // a word near its end has its whole right-context fan-out (20-40 channels) present at once: the word level's
+        // channels are gathered into one list first (order irrelevant: independent evaluations, a maximum and a count)
+        // and marked / evaluated / pruned one work-item per channel below
+        for (int i = tid; i < n_awl_cur; i += NT) {
+            const int w = awlc[i];
+            word_active[w] = 0;
+            for (int k = wc_off[w]; k < wc_off[w + 1]; ++k)
+                if (present[k]) { const int q = atomicAdd(&s_nwc, 1); elist[q] = k; eword[q] = i; }
+        }
+        __syncthreads();
+        const int nwc = s_nwc;
+        if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
+            for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_normalize<NE>(tv, i, best_in);
+            for (int i = tid; i < n_acl_cur; i += NT) ch_normalize<NE>(tv, aclc[i], best_in);
+            for (int i = tid; i < nwc; i += NT) ch_normalize<NE>(wv, elist[i], best_in);
+            for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_normalize<NE>(tv, W1 + i, best_in);
+            __syncthreads();
+        }
+        int32_t nb = 0;
         if (raw_mode) {
             // ---- compute_sen_active (:526-564) + acmod_flags2list (acmod.c:1223-1275) + the scorer's
             //      active-list normalisation (ptm_mgau.c:393-400) on un-normalised rows: the frame's scores
             //      are raw - min over the listed senones, bridging entries included
             const int nwords = (p.n_sen + 31) >> 5;
-            for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
-            if (tid == 0) s_nb = 0x7fffffff;
-            __syncthreads();
-            auto mark = [&](int c) {
+            auto mark = [&](const ChView &v, int c) {
+                const int mpx = v.at(c, F::MPX);
+#pragma unroll
                 for (int k = 0; k < NE; ++k) {
-                    int sen = u.senid[c * CS + k];
-                    if (u.mpx[(c) * C1]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + k]; }
+                    int sen = v.at(c, F::SENID + k);
+                    if (mpx) { if (sen == kBadSsid) continue; sen = sseq[(size_t)sen * NE + k]; }
                     atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
                 }
             };
-            for (int i = tid; i < R; i += NT) if (u.frame[(i) * C1] == f) mark(i);
-            for (int i = tid; i < n_acl[cur]; i += NT) mark(u.acl[cur][i]);
-            for (int i = tid; i < n_awl[cur]; i += NT) {
-                const int w = u.awl[cur][i];
-                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) mark(WC + k);
-            }
-            for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) mark(W1 + i);
-            __syncthreads();
-            {   // s_prev[w] = the highest senone listed in the words before w (one bitmap word per thread)
-                static_assert(kFtMaxSen / 32 <= NT, "one bitmap word per thread");
-                const uint32_t bw = tid < nwords ? s_bits[tid] : 0u;
-                const int32_t pv = ft_block_excl_max(bw ? tid * 32 + 31 - __clz((int)bw) : -1, s_scan);
-                if (tid < nwords) s_prev[tid] = pv;
-            }
+            for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) mark(tv, i);
+            for (int i = tid; i < n_acl_cur; i += NT) mark(tv, aclc[i]);
+            for (int i = tid; i < nwc; i += NT) mark(wv, elist[i]);
+            for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) mark(tv, W1 + i);
             __syncthreads();
             int32_t mn = 0x7fffffff;
             for (int w = tid; w < nwords; w += NT) {
                 uint32_t b = s_bits[w];
-                int prev = s_prev[w];
+                if (!b) continue;
+                // the highest senone listed before this bitmap word (acmod_flags2list bridges gaps > 255 from it)
+                int prev = -1;
+                for (int q = w - 1; q >= 0; --q) { const uint32_t pb = s_bits[q]; if (pb) { prev = q * 32 + 31 - __clz((int)pb); break; } }
                 while (b) {
                     const int sen = w * 32 + __ffs((int)b) - 1;
                     b &= b - 1;
@@ -378,90 +449,57 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
                     prev = sen;
                 }
             }
-            atomicMin(&s_nb, mn);
+            if (mn != 0x7fffffff) atomicMin(&s_nb, mn);
             __syncthreads();
-            const int32_t nb = s_nb;
-            for (int w = tid; w < nwords; w += NT) {
-                uint32_t b = s_bits[w];
-                while (b) {
-                    const int sen = w * 32 + __ffs((int)b) - 1;
-                    b &= b - 1;
-                    u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)row[sen] - (uint32_t)nb);
-                }
-            }
-            __syncthreads();
-            row = u.nrow;
+            nb = s_nb;
         }
-        // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
-        if (tid == 0) u.bp_table_idx[f] = s_sc[3];
-        const int32_t best_in = s_sc[0];
-        if (best_in == kW || best_in < kW) break;
-        if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
-            for (int i = tid; i < R; i += NT) if (u.frame[(i) * C1] == f) ch_normalize<CS, C1>(p, u, i, best_in);
-            for (int i = tid; i < n_acl[cur]; i += NT) ch_normalize<CS, C1>(p, u, u.acl[cur][i], best_in);
-            for (int i = tid; i < n_awl[cur]; i += NT) {
-                const int w = u.awl[cur][i];
-                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k) if (u.present[k]) ch_normalize<CS, C1>(p, u, WC + k, best_in);
-            }
-            for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) ch_normalize<CS, C1>(p, u, W1 + i, best_in);
-        }
-        if (tid < 8) s_red[tid] = kW;
-        if (LIST && tid == 0) s_nwc = 0;
-        __syncthreads();
-        if (LIST) {
-            // a word near its end has its whole right-context fan-out (20-40 channels) present at once: the word level's
-            // channels are gathered into one list first (order irrelevant: independent evaluations, a maximum and a count)
-            // and evaluated one work-item per channel below
-            for (int i = tid; i < n_awl[cur]; i += NT) {
-                const int w = u.awl[cur][i];
-                u.word_active[w] = 0;
-                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
-                    if (u.present[k]) { const int q = atomicAdd(&s_nwc, 1); u.elist[q] = WC + k; u.eword[q] = i; }
-            }
-            __syncthreads();
-        }
-        // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..5] counts
+        // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..4] counts
         {
+            const SenRowNorm sr = { row, nb };
             int32_t b0 = kW, b1 = kW, b2 = kW; int n0 = 0, n2 = 0;
             for (int i = tid; i < R; i += NT)
-                if (u.frame[(i) * C1] == f) { b0 = max(b0, ch_eval<NE, CS, C1>(p, u, i, row)); ++n0; }
-            for (int i = tid; i < n_acl[cur]; i += NT) b1 = max(b1, ch_eval<NE, CS, C1>(p, u, u.acl[cur][i], row));
-            if (LIST)
-                for (int i = tid; i < s_nwc; i += NT) { b2 = max(b2, ch_eval<NE, CS, C1>(p, u, u.elist[i], row)); ++n2; }
-            else
-            for (int i = tid; i < n_awl[cur]; i += NT) {
-                const int w = u.awl[cur][i];
-                u.word_active[w] = 0;
-                for (int k = p.wc_off[w]; k < p.wc_off[w + 1]; ++k)
-                    if (u.present[k]) { b2 = max(b2, ch_eval<NE, CS, C1>(p, u, WC + k, row)); ++n2; }
-            }
-            for (int i = tid; i < p.n1; i += NT) {
-                if (u.frame[(W1 + i) * C1] < f) continue;
-                const int32_t sc = ch_eval<NE, CS, C1>(p, u, W1 + i, row);
-                if (p.w1_wid[i] != p.finishwid) b2 = max(b2, sc);
+                if (tv.at(i, F::FRAME) == f) { b0 = max(b0, ch_eval<NE>(tv, i, sr, tpall, sseq)); ++n0; }
+            for (int i = tid; i < n_acl_cur; i += NT) b1 = max(b1, ch_eval<NE>(tv, aclc[i], sr, tpall, sseq));
+            for (int i = tid; i < nwc; i += NT) { b2 = max(b2, ch_eval<NE>(wv, elist[i], sr, tpall, sseq)); ++n2; }
+            for (int i = tid; i < n1; i += NT) {
+                if (tv.at(W1 + i, F::FRAME) < f) continue;
+                const int32_t sc = ch_eval<NE>(tv, W1 + i, sr, tpall, sseq);
+                if (w1_wid[i] != p.finishwid) b2 = max(b2, sc);
                 ++n2;
             }
-            atomicMax(&s_red[0], b0); atomicMax(&s_red[1], b1); atomicMax(&s_red[2], b2);
-            if (n0) atomicAdd(&s_red[3], n0 - 0);            // (s_red[3..4] start at kW: corrected below)
+            if (b0 > kW) atomicMax(&s_red[0], b0);
+            if (b1 > kW) atomicMax(&s_red[1], b1);
+            if (b2 > kW) atomicMax(&s_red[2], b2);
+            if (n0) atomicAdd(&s_red[3], n0);                // (s_red[3..4] start at kW: corrected below)
             if (n2) atomicAdd(&s_red[4], n2);
+            if (raw_mode) {                                  // the bitmap is free again: cleared for the next frame
+                const int nwords = (p.n_sen + 31) >> 5;
+                for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
+            }
         }
         __syncthreads();
+        if (SMALL && nf < T) {                               // the score row has been read: the next frame's takes its place
+            uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+#pragma unroll
+            for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; if (i < row_dw) d[i] = pre[k]; }
+            if (p.has_pl && tid < n_ci) s_pen[nxt * n_ci + tid] = pre_pen;
+        }
         if (tid == 0) {
             const int32_t bs = max(max(s_red[0], s_red[1]), s_red[2]);
             s_sc[0] = bs; s_sc[1] = s_red[2];
-            s_evals += (unsigned long long)((s_red[3] - kW) + n_acl[cur] + (s_red[4] - kW));
+            s_evals += (unsigned long long)((s_red[3] - kW) + n_acl_cur + (s_red[4] - kW));
             s_sc[5] = 0;                                        // n_lastphn_cand
-            // dynamic beam (:1133-1181)
-            s_sc[2] = p.beam;
+            s_sc[2] = p.beam;                                   // dynamic beam (:1133-1181)
+            s_nb = 0x7fffffff;
         }
         for (int i = tid; i < 256; i += NT) s_bins[i] = 0;
         __syncthreads();
         const int32_t best_score = s_sc[0];
         if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
             const int32_t bw = -p.beam / 256;
-            for (int i = tid; i < R + n_acl[cur]; i += NT) {
-                const int c = i < R ? i : u.acl[cur][i - R];
-                int32_t b = (best_score - u.best[(c) * C1]) / bw;
+            for (int i = tid; i < R + n_acl_cur; i += NT) {
+                const int c = i < R ? i : aclc[i - R];
+                int32_t b = (best_score - tv.at(c, F::BEST)) / bw;
                 if (b >= 256) b = 255;
                 atomicAdd(&s_bins[b], 1);
             }
@@ -476,132 +514,94 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         const int32_t thresh = best_score + s_sc[2];
         const int32_t npt = best_score + p.pbeam, lpt = best_score + p.lpbeam;
 
-        // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation
-        if (LIST) {
-            // work proportional to the active channels (oracle prune_tree_list): the items are the roots, the listed
-            // nodes and their children.  Reads of another node's state go to the snapshot (o_out, o_outh, flag, pos) of
-            // a root or listed node, writes to the item's own channel and decision word, so the items are independent.
-            const int na = n_acl[cur];
-            for (int q = tid; q < na; q += NT) u.pos[u.acl[cur][q]] = q;
-            for (int i = tid; i < R + na; i += NT) {
-                const int node = i < R ? i : u.acl[cur][i - R];
-                const bool active = i < R ? u.frame[(node) * C1] >= f : true;
-                u.o_out[node] = u.out[(node) * C1]; u.o_outh[node] = u.outh[(node) * C1];
-                u.flag[node] = (active && u.best[(node) * C1] > thresh) ? 1 : 0;
-            }
-            __syncthreads();
-            auto decide = [&](int c) {
-                const int P = p.parent[c], pc = u.pos[c];
-                const bool in_acl = pc >= 0, par_active = P < R || u.pos[P] >= 0;
-                const int32_t news = (par_active ? u.o_out[P] : kW) + p.pip;
-                const bool parent_can = par_active && (u.flag[P] & 1) && (p.has_pl || news > npt)
-                                        && (news + ft_pen(p, pp, p.node_ci[c]) > npt);
-                const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
-                const bool retc = in_acl && (u.flag[c] & 1);
-                bool fire;
-                if (!in_acl || parent_first) fire = parent_can && (u.frame[(c) * C1] < f || news > u.score[c * CS]);
-                else if (retc)               fire = parent_can && news > u.score[c * CS];
-                else                         fire = parent_can;
-                const bool entered_first = fire && parent_first;
-                const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
-                if (in_acl && !retc && !entered_first) ch_clear<CS, C1>(p, u, c);
-                if (retc) u.frame[(c) * C1] = nf;
-                if (fire) ch_enter<CS, C1>(u, c, news, u.o_outh[P], nf);
-                u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
-            };
-            for (int i = tid; i < R + na; i += NT) {
-                const int node = i < R ? i : u.acl[cur][i - R];
-                if (i >= R) decide(node);
-                // a node that is not retained enters none of its children: their (stale) decision words are not
-                // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
-                if (!(u.flag[node] & 1)) continue;
-                for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.pos[c] < 0) decide(c);
-            }
-            __syncthreads();
-            for (int q = tid; q < na; q += NT) u.pos[u.acl[cur][q]] = -1;        // (nothing below reads pos or a root's frame
-            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[(i) * C1] = nf;  //  before the next barrier)
+        // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation.  Work proportional to the active
+        //      channels (oracle prune_tree_list): the items are the roots, the listed nodes and their children.  Reads of
+        //      another node's state go to the snapshot (o_out, o_outh, flag, pos) of a root or listed node, writes to the
+        //      item's own channel and decision word, so the items are independent.
+        const int na = n_acl_cur;
+        for (int q = tid; q < na; q += NT) pos[aclc[q]] = q;
+        for (int i = tid; i < R + na; i += NT) {
+            const int node = i < R ? i : aclc[i - R];
+            const bool active = i < R ? tv.at(node, F::FRAME) >= f : true;
+            o_out[node] = tv.at(node, F::OUT); o_outh[node] = tv.at(node, F::OUTH);
+            flag[node] = (active && tv.at(node, F::BEST) > thresh) ? 1 : 0;
         }
-        else {
-            for (int i = tid; i < N; i += NT) {
-                u.pos[i] = -1; u.o_frame[i] = u.frame[(i) * C1]; u.o_s0[i] = u.score[i * CS]; u.o_best[i] = u.best[(i) * C1];
-                u.o_out[i] = u.out[(i) * C1]; u.o_outh[i] = u.outh[(i) * C1];
-            }
-            __syncthreads();
-            for (int q = tid; q < n_acl[cur]; q += NT) u.pos[u.acl[cur][q]] = q;
-            __syncthreads();
-            // flag bits: 1 retained, 2 fire (listed by parent), 4 fire (not listed), 8 self-append
-            for (int c = tid; c < N; c += NT) {
-                const bool active = c < R ? u.o_frame[c] >= f : u.pos[c] >= 0;
-                u.flag[c] = (active && u.o_best[c] > thresh) ? 1 : 0;
-            }
-            __syncthreads();
-            for (int c = R + tid; c < N; c += NT) {
-                const int P = p.parent[c], pc = u.pos[c];
-                const bool in_acl = pc >= 0, retc = u.flag[c] & 1;
-                const int32_t news = u.o_out[P] + p.pip;
-                const bool par_active = P < R ? true : u.pos[P] >= 0;
-                const bool parent_can = par_active && (u.flag[P] & 1) && (p.has_pl || news > npt)
-                                        && (news + ft_pen(p, pp, p.node_ci[c]) > npt);
-                const bool parent_first = P < R || !in_acl || u.pos[P] < pc;
-                bool fire;
-                if (!in_acl || parent_first) fire = parent_can && (u.o_frame[c] < f || news > u.o_s0[c]);
-                else if (retc)               fire = parent_can && news > u.o_s0[c];
-                else                         fire = parent_can;
-                const bool entered_first = fire && parent_first;
-                const bool selfapp = in_acl && retc && !entered_first;
-                const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
-                const bool cleared = in_acl && !retc && !entered_first;
-                if (cleared) ch_clear<CS, C1>(p, u, c);
-                if (in_acl && retc) u.frame[(c) * C1] = nf;
-                if (fire) ch_enter<CS, C1>(u, c, news, u.o_outh[P], nf);
-                // decision word for the list phase; o_frame[c] is read by this thread only, so it can be reused
-                u.o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | (selfapp ? 8 : 0);
-            }
-            for (int i = tid; i < R; i += NT) if (u.flag[i] & 1) u.frame[(i) * C1] = nf;
-            __syncthreads();
+        __syncthreads();
+        auto decide = [&](int c) {
+            const int P = parent[c], pc = pos[c];
+            const bool in_acl = pc >= 0, par_active = P < R || pos[P] >= 0;
+            const int32_t news = (par_active ? o_out[P] : kW) + p.pip;
+            const bool parent_can = par_active && (flag[P] & 1) && (p.has_pl || news > npt)
+                                    && (news + ft_pen(node_ci[c]) > npt);
+            const bool parent_first = P < R || !in_acl || pos[P] < pc;
+            const bool retc = in_acl && (flag[c] & 1);
+            bool fire;
+            if (!in_acl || parent_first) fire = parent_can && (tv.at(c, F::FRAME) < f || news > tv.at(c, F::SCORE));
+            else if (retc)               fire = parent_can && news > tv.at(c, F::SCORE);
+            else                         fire = parent_can;
+            const bool entered_first = fire && parent_first;
+            const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
+            if (in_acl && !retc && !entered_first) ch_clear<NE>(tv, c);
+            if (retc) tv.at(c, F::FRAME) = nf;
+            if (fire) ch_enter<NE>(tv, c, news, o_outh[P], nf);
+            o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
+        };
+        for (int i = tid; i < R + na; i += NT) {
+            const int node = i < R ? i : aclc[i - R];
+            if (i >= R) decide(node);
+            // a node that is not retained enters none of its children: their (stale) decision words are not
+            // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
+            if (!(flag[node] & 1)) continue;
+            const int k1 = kid_off[node + 1];
+            for (int k = kid_off[node]; k < k1; ++k) { const int c = kids[k]; if (pos[c] < 0) decide(c); }
         }
+        __syncthreads();
+        for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
+        for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
         // list positions: root phase (segment per root), then one segment per list position
-        for (int i = tid; i < R + n_acl[cur]; i += NT) {
-            const int node = i < R ? i : u.acl[cur][i - R];
-            int k = (i >= R && (u.o_frame[node] & 8)) ? 1 : 0;
-            if (!LIST || (u.flag[node] & 1))
-                for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) k += (u.o_frame[c] & 2) ? 1 : 0;
+        for (int i = tid; i < R + na; i += NT) {
+            const int node = i < R ? i : aclc[i - R];
+            int k = (i >= R && (o_frame[node] & 8)) ? 1 : 0;
+            if (flag[node] & 1) {
+                const int k1 = kid_off[node + 1];
+                for (int q = kid_off[node]; q < k1; ++q) k += (o_frame[kids[q]] & 2) ? 1 : 0;
+            }
             cnt[i] = k;
         }
         __syncthreads();
-        const int32_t n_listed = ft_block_scan<NT>(cnt, R + n_acl[cur], s_scan);      // exclusive prefix sum
-        for (int i = tid; i < R + n_acl[cur]; i += NT) {
-            const int node = i < R ? i : u.acl[cur][i - R];
+        const int32_t n_listed = ft_block_scan<NT>(cnt, R + na, s_scan);      // exclusive prefix sum
+        for (int i = tid; i < R + na; i += NT) {
+            const int node = i < R ? i : aclc[i - R];
             int o = cnt[i];
-            if (i >= R && (u.o_frame[node] & 8)) u.acl[nxt][o++] = node;
-            if (!LIST || (u.flag[node] & 1))
-                for (int c = p.node_child[node]; c >= 0; c = p.node_sib[c]) if (u.o_frame[c] & 2) u.acl[nxt][o++] = c;
+            if (i >= R && (o_frame[node] & 8)) acln[o++] = node;
+            if (flag[node] & 1) {
+                const int k1 = kid_off[node + 1];
+                for (int q = kid_off[node]; q < k1; ++q) { const int c = kids[q]; if (o_frame[c] & 2) acln[o++] = c; }
+            }
         }
-        n_acl[nxt] = n_listed;
         __syncthreads();
         // last-phone candidates: list order, homophone chain inside
-        for (int i = tid; i < R + n_acl[cur]; i += NT) {
-            const int node = i < R ? i : u.acl[cur][i - R];
-            const int32_t news = u.o_out[node] + p.pip;
+        for (int i = tid; i < R + na; i += NT) {
+            const int node = i < R ? i : aclc[i - R];
+            const int32_t news = o_out[node] + p.pip;
             int k = 0;
-            if ((u.flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = p.node_pw[node]; w >= 0; w = p.homophone[w]) k += (news + ft_pen(p, pp, p.d_last[w]) > lpt) ? 1 : 0;
+            if ((flag[node] & 1) && (p.has_pl || news > lpt))
+                for (int w = node_pw[node]; w >= 0; w = homophone[w]) k += (news + ft_pen(d_last[w]) > lpt) ? 1 : 0;
             cnt[i] = k;
         }
         __syncthreads();
         {
-            const int32_t n_cand_all = ft_block_scan<NT>(cnt, R + n_acl[cur], s_scan);
-            if (tid == 0) s_sc[5] = n_cand_all;
+            const int32_t n_cand_all = ft_block_scan<NT>(cnt, R + na, s_scan);
+            if (tid == 0) { s_sc[5] = n_cand_all; s_red[7] = 0; }
         }
-        __syncthreads();
-        for (int i = tid; i < R + n_acl[cur]; i += NT) {
-            const int node = i < R ? i : u.acl[cur][i - R];
-            const int32_t news = u.o_out[node] + p.pip;
+        for (int i = tid; i < R + na; i += NT) {
+            const int node = i < R ? i : aclc[i - R];
+            const int32_t news = o_out[node] + p.pip;
             int o = cnt[i];
-            if ((u.flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = p.node_pw[node]; w >= 0; w = p.homophone[w])
-                    if (news + ft_pen(p, pp, p.d_last[w]) > lpt) {
-                        u.cand_wid[o] = w; u.cand_score[o] = news - p.nwpen; u.cand_bp[o] = u.o_outh[node]; ++o;
+            if ((flag[node] & 1) && (p.has_pl || news > lpt))
+                for (int w = node_pw[node]; w >= 0; w = homophone[w])
+                    if (news + ft_pen(d_last[w]) > lpt) {
+                        cand_wid[o] = w; cand_score[o] = news - p.nwpen; cand_bp[o] = o_outh[node]; ++o;
                     }
         }
         __syncthreads();
@@ -612,269 +612,218 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         //      look-ups that dominate this step -- is found by its own thread; last_ltrans (lt_*) is the
         //      reference's per-word cache keyed by start frame.  Should two candidates ever share a word, the
         //      reference's loops are run as written by one thread.
-        {
-            const int n_cand = s_sc[5];
-            if (tid == 0) s_red[7] = 0;
-            __syncthreads();
-            if (LIST) {                                  // O(1) per candidate: the frame stamp of the word
-                for (int i = tid; i < n_cand; i += NT)
-                    if (atomicExch(&u.cand_mark[u.cand_wid[i]], f) == f) s_red[7] = 1;
-            }
-            else
-            for (int i = tid; i < n_cand; i += NT) {
-                const int w = u.cand_wid[i];
-                for (int j = 0; j < i; ++j) if (u.cand_wid[j] == w) s_red[7] = 1;
-            }
-            __syncthreads();
-        }
-        if (s_red[7] == 0) {
-            const int n_cand = s_sc[5];
+        const int n_cand = s_sc[5];
+        for (int i = tid; i < n_cand; i += NT)               // O(1) per candidate: the frame stamp of the word
+            if (atomicExch(&cand_mark[cand_wid[i]], f) == f) s_red[7] = 1;
+        __syncthreads();
+        const bool dup = s_red[7] != 0;
+        if (!dup) {
             int32_t bestscore = kW;
             for (int i = tid; i < n_cand; i += NT) {
-                const int cb = u.cand_bp[i], w = u.cand_wid[i];
-                int32_t score = u.cand_score[i];
+                const int cb = cand_bp[i], w = cand_wid[i];
+                int32_t score = cand_score[i];
                 if (cb != -1) {
-                    const int first = p.d_first[w];
-                    score -= ft_exit_score(p, u, cb, first);
-                    const int ef = BPC(u, B_FRAME, cb);
-                    if (u.lt_sf[w] != ef + 1) {
-                        int32_t best = kW, bestbp = u.lt_bp[w];
-                        const int b1 = u.bp_table_idx[ef + 1], base = p.d_base[w];
-                        for (int bp = u.bp_table_idx[ef]; bp < b1; ++bp) {
-                            if (!BPC(u, B_VALID, bp)) continue;
-                            int32_t dscr = ft_exit_score(p, u, bp, first);
-                            if (dscr > kW) dscr += ft_lm(p, base, BPC(u, B_REAL, bp), BPC(u, B_PREAL, bp));
+                    const int first = d_first[w];
+                    score -= ft_exit_score(tb, rs_cimap, n_ci, cb, first);
+                    const int ef = BPC(tb, B_FRAME, cb);
+                    if (lt_sf[w] != ef + 1) {
+                        int32_t best = kW, bestbp = lt_bp[w];
+                        const int b1 = tb.idx[ef + 1], base = d_base[w];
+                        for (int bp = tb.idx[ef]; bp < b1; ++bp) {
+                            if (!BPC(tb, B_VALID, bp)) continue;
+                            int32_t dscr = ft_exit_score(tb, rs_cimap, n_ci, bp, first);
+                            if (dscr > kW) dscr += ft_lm(p, trie, lmtab, base, BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
                             if (dscr > best) { best = dscr; bestbp = bp; }
                         }
-                        u.lt_dscr[w] = best; u.lt_bp[w] = bestbp; u.lt_sf[w] = ef + 1;
+                        lt_dscr[w] = best; lt_bp[w] = bestbp; lt_sf[w] = ef + 1;
                     }
                 }
-                score += u.lt_dscr[w];
-                u.cand_score[i] = score;
-                u.cand_bp[i] = u.lt_bp[w];
+                score += lt_dscr[w];
+                cand_score[i] = score;
+                cand_bp[i] = lt_bp[w];
                 bestscore = max(bestscore, score);
             }
             if (bestscore > kW) atomicMax(&s_sc[1], bestscore);
         }
-        else
-        if (tid == 0) {
-            const int n_cand = s_sc[5];
+        else if (tid == 0) {
             int n_csf = 0;
             for (int i = 0; i < n_cand; ++i) {
-                const int cb = u.cand_bp[i], w = u.cand_wid[i];
+                const int cb = cand_bp[i], w = cand_wid[i];
                 if (cb == -1) continue;
-                u.cand_score[i] -= ft_exit_score(p, u, cb, p.d_first[w]);
-                const int ef = BPC(u, B_FRAME, cb);
-                if (u.lt_sf[w] != ef + 1) {
+                cand_score[i] -= ft_exit_score(tb, rs_cimap, n_ci, cb, d_first[w]);
+                const int ef = BPC(tb, B_FRAME, cb);
+                if (lt_sf[w] != ef + 1) {
                     int j;
-                    for (j = 0; j < n_csf; ++j) if (u.csf_ef[j] == ef) break;
-                    if (j < n_csf) u.cand_next[i] = u.csf_cand[j];
-                    else { j = n_csf++; u.cand_next[i] = -1; u.csf_ef[j] = ef; }
-                    u.csf_cand[j] = i;
-                    u.lt_dscr[w] = kW;
-                    u.lt_sf[w] = ef + 1;
+                    for (j = 0; j < n_csf; ++j) if (csf_ef[j] == ef) break;
+                    if (j < n_csf) cand_next[i] = csf_cand[j];
+                    else { j = n_csf++; cand_next[i] = -1; csf_ef[j] = ef; }
+                    csf_cand[j] = i;
+                    lt_dscr[w] = kW;
+                    lt_sf[w] = ef + 1;
                 }
             }
             for (int i = 0; i < n_csf; ++i) {
-                const int b1 = u.bp_table_idx[u.csf_ef[i] + 1];
-                for (int bp = u.bp_table_idx[u.csf_ef[i]]; bp < b1; ++bp) {
-                    if (!BPC(u, B_VALID, bp)) continue;
-                    for (int j = u.csf_cand[i]; j >= 0; j = u.cand_next[j]) {
-                        const int w = u.cand_wid[j];
-                        int32_t dscr = ft_exit_score(p, u, bp, p.d_first[w]);
-                        if (dscr > kW) dscr += ft_lm(p, p.d_base[w], BPC(u, B_REAL, bp), BPC(u, B_PREAL, bp));
-                        if (dscr > u.lt_dscr[w]) { u.lt_dscr[w] = dscr; u.lt_bp[w] = bp; }
+                const int b1 = tb.idx[csf_ef[i] + 1];
+                for (int bp = tb.idx[csf_ef[i]]; bp < b1; ++bp) {
+                    if (!BPC(tb, B_VALID, bp)) continue;
+                    for (int j = csf_cand[i]; j >= 0; j = cand_next[j]) {
+                        const int w = cand_wid[j];
+                        int32_t dscr = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
+                        if (dscr > kW) dscr += ft_lm(p, trie, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
+                        if (dscr > lt_dscr[w]) { lt_dscr[w] = dscr; lt_bp[w] = bp; }
                     }
                 }
             }
             int32_t bestscore = s_sc[1];
             for (int i = 0; i < n_cand; ++i) {
-                const int w = u.cand_wid[i];
-                u.cand_score[i] += u.lt_dscr[w];
-                u.cand_bp[i] = u.lt_bp[w];
-                if (u.cand_score[i] > bestscore) bestscore = u.cand_score[i];
+                const int w = cand_wid[i];
+                cand_score[i] += lt_dscr[w];
+                cand_bp[i] = lt_bp[w];
+                if (cand_score[i] > bestscore) bestscore = cand_score[i];
             }
             s_sc[1] = bestscore;
-            s_sc[5] = n_cand;
         }
+        if (tid == 0) s_nwc2 = 0;
+        for (int i = tid; i < n_cand; i += NT) cnt[i] = 0;
         __syncthreads();
         {
-            // ---- last_phone_transition's entering loop (:1004-1030), one thread per candidate.  Candidates of
-            //      one frame name distinct words (a word has one penultimate tree node) -- if that ever fails the
-            //      loop is run by one thread in candidate order.
-            const int n_cand = s_sc[5];
+            // ---- last_phone_transition's entering loop (:1004-1030).  Candidates of one frame name distinct words (a word
+            //      has one penultimate tree node) -- if that ever fails the loop is run by one thread in candidate order.
             const int32_t cthresh = s_sc[1] + p.lponlybeam;
-            const bool dup = s_red[7] != 0;                     // (found above)
-            if (LIST && !dup) {
+            if (!dup) {
                 // one work-item per (entering candidate, right context): the word's slots are exactly its right contexts, so
                 // "allocate the missing ones, then enter every present one" is, per slot, "create if missing, then enter"
-                if (tid == 0) s_nwc2 = 0;
-                for (int i = tid; i < n_cand; i += NT) cnt[i] = 0;
-                __syncthreads();
                 for (int i = tid; i < n_cand; i += NT) {
-                    if (!(u.cand_score[i] > cthresh)) continue;
-                    const int w = u.cand_wid[i], nrc = p.wc_off[w + 1] - p.wc_off[w];
+                    if (!(cand_score[i] > cthresh)) continue;
+                    const int w = cand_wid[i], nrc = wc_off[w + 1] - wc_off[w];
                     const int q = atomicAdd(&s_nwc2, nrc);
-                    for (int r = 0; r < nrc; ++r) { u.xlist[q + r] = i; u.xslot[q + r] = p.wc_off[w] + r; }
+                    for (int r = 0; r < nrc; ++r) { xlist[q + r] = i; xslot[q + r] = wc_off[w] + r; }
                 }
                 __syncthreads();
                 for (int j = tid; j < s_nwc2; j += NT) {
-                    const int i = u.xlist[j], slot = u.xslot[j], w = u.cand_wid[i], c = WC + slot;
-                    if (!u.present[slot]) {                     // ngram_search_alloc_all_rc (ngram_search.c:583-633)
-                        const int last = p.d_last[w], last2 = p.d_last2[w];
-                        ch_init<CS, C1>(p, u, c, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + (slot - p.wc_off[w])], p.ci_tmat[last]);
-                        u.present[slot] = 1;
+                    const int i = xlist[j], slot = xslot[j], w = cand_wid[i];
+                    if (!present[slot]) {                       // ngram_search_alloc_all_rc (ngram_search.c:583-633)
+                        const int last = d_last[w], last2 = d_last2[w];
+                        ch_init<NE>(wv, slot, 0, rs_ssid[((size_t)last * n_ci + last2) * n_ci + (slot - wc_off[w])], ci_tmat[last], sseq);
+                        present[slot] = 1;
                     }
-                    if (u.frame[(c) * C1] < f || u.cand_score[i] > u.score[c * CS]) {
-                        ch_enter<CS, C1>(u, c, u.cand_score[i], u.cand_bp[i], nf);
+                    if (wv.at(slot, F::FRAME) < f || cand_score[i] > wv.at(slot, F::SCORE)) {
+                        ch_enter<NE>(wv, slot, cand_score[i], cand_bp[i], nf);
                         cnt[i] = 1;
                     }
                 }
             }
-            else
-            for (int i = (dup ? (tid == 0 ? 0 : n_cand) : tid); i < n_cand; i += (dup ? 1 : NT)) {
-                int k = 0;
-                if (u.cand_score[i] > cthresh) {
-                    const int w = u.cand_wid[i];
-                    // ngram_search_alloc_all_rc (ngram_search.c:583-633)
-                    const int last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
-                    for (int r = 0; r < nrc; ++r) {
-                        const int slot = p.wc_off[w] + r;
-                        if (!u.present[slot]) {
-                            ch_init<CS, C1>(p, u, WC + slot, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last]);
-                            u.present[slot] = 1;
+            else if (tid == 0)
+                for (int i = 0; i < n_cand; ++i) {
+                    int k = 0;
+                    if (cand_score[i] > cthresh) {
+                        const int w = cand_wid[i];
+                        // ngram_search_alloc_all_rc (ngram_search.c:583-633)
+                        const int last = d_last[w], last2 = d_last2[w], nrc = rs_n[last * n_ci + last2];
+                        for (int r = 0; r < nrc; ++r) {
+                            const int slot = wc_off[w] + r;
+                            if (!present[slot]) {
+                                ch_init<NE>(wv, slot, 0, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq);
+                                present[slot] = 1;
+                            }
+                        }
+                        for (int slot = wc_off[w]; slot < wc_off[w + 1]; ++slot) {
+                            if (!present[slot]) continue;
+                            if (wv.at(slot, F::FRAME) < f || cand_score[i] > wv.at(slot, F::SCORE)) { ch_enter<NE>(wv, slot, cand_score[i], cand_bp[i], nf); ++k; }
                         }
                     }
-                    for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
-                        if (!u.present[slot]) continue;
-                        const int c = WC + slot;
-                        if (u.frame[(c) * C1] < f || u.cand_score[i] > u.score[c * CS]) { ch_enter<CS, C1>(u, c, u.cand_score[i], u.cand_bp[i], nf); ++k; }
-                    }
+                    cnt[i] = k > 0;
                 }
-                cnt[i] = k > 0;
-            }
             __syncthreads();
-            if (LIST) {                                  // stable compaction by a prefix sum
+            {                                            // stable compaction by a prefix sum
                 const int32_t nawl = ft_block_scan<NT>(cnt, n_cand, s_scan);
                 for (int i = tid; i < n_cand; i += NT)
                     if ((i + 1 < n_cand ? cnt[i + 1] : nawl) != cnt[i]) {
-                        const int w = u.cand_wid[i];
-                        u.awl[nxt][cnt[i]] = w; u.word_active[w] = 1;
+                        const int w = cand_wid[i];
+                        awln[cnt[i]] = w; word_active[w] = 1;
                     }
                 if (tid == 0) s_red[5] = nawl;
             }
-            else
-            if (tid == 0) {
-                int nawl = 0;
-                for (int i = 0; i < n_cand; ++i)
-                    if (cnt[i]) { const int w = u.cand_wid[i]; u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
-                s_red[5] = nawl;
-            }
             __syncthreads();
-            // ---- prune_word_chan (:1038-1128): pass A, one thread per active word -- keep / free the
-            //      right-context channels, count the survivors, note whether the word exits
+            // ---- prune_word_chan (:1038-1128): keep / free the right-context channels, count the survivors per word,
+            //      note whether the word exits.  One work-item per channel of the evaluation list (the channels present when
+            //      the frame was evaluated; the ones this frame's candidates have just allocated were all entered for the next
+            //      frame and have no score yet: a word-at-a-time walk would neither count nor free them), survivors counted
+            //      per word by atomics
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            const int wst = p.big ? p.n_w : 1024;                // n_awl <= n_w
-            int32_t *w_k = p.big ? u.g_w : cnt, *w_exit = w_k + wst, *w_bp = w_k + 2 * wst, *w_bss = w_k + 3 * wst;
-            if (LIST) {
-                // one work-item per channel of the evaluation list (the channels present when the frame was evaluated; the ones
-                // this frame's candidates have just allocated were all entered for the next frame and have no score yet: the
-                // word-at-a-time walk below would neither count nor free them), survivors counted per word by atomics
-                for (int i = tid; i < n_awl[cur]; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
-                __syncthreads();
-                for (int j = tid; j < s_nwc; j += NT) {
-                    const int c = u.elist[j], i = u.eword[j];
-                    if (u.best[(c) * C1] > lpth) {
-                        u.frame[(c) * C1] = nf;
-                        atomicAdd(&w_k[i], 1);
-                        if (u.out[(c) * C1] > nwt) atomicOr(&w_exit[i], 1);
-                    }
-                    else if (u.frame[(c) * C1] != nf) u.present[c - WC] = 0;
+            const int wst = p.n_w;                                // n_awl <= n_w
+            int32_t *w_k = cnt, *w_exit = w_k + wst, *w_bp = w_k + 2 * wst, *w_bss = w_k + 3 * wst;
+            const int naw = n_awl_cur;
+            for (int i = tid; i < naw; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
+            __syncthreads();
+            for (int j = tid; j < nwc; j += NT) {
+                const int k = elist[j], i = eword[j];
+                if (wv.at(k, F::BEST) > lpth) {
+                    wv.at(k, F::FRAME) = nf;
+                    atomicAdd(&w_k[i], 1);
+                    if (wv.at(k, F::OUT) > nwt) atomicOr(&w_exit[i], 1);
                 }
-                __syncthreads();
-            }
-            for (int i = tid; i < n_awl[cur]; i += NT) {
-                const int w = u.awl[cur][i];
-                int k = LIST ? w_k[i] : 0, ex = LIST ? w_exit[i] : 0;
-                if (!LIST)
-                for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
-                    if (!u.present[slot]) continue;
-                    const int c = WC + slot;
-                    if (u.best[(c) * C1] > lpth) { u.frame[(c) * C1] = nf; ++k; ex |= (u.out[(c) * C1] > nwt); }
-                    else if (u.frame[(c) * C1] != nf) u.present[slot] = 0;
-                }
-                w_k[i] = k; w_exit[i] = ex;
-                if (LIST) {                              // inputs of the three prefix sums below
-                    w_k[i] = (k > 0 && !u.word_active[w]) ? 1 : 0;
-                    w_bp[i] = ex ? 1 : 0;
-                    w_bss[i] = ex ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
-                }
+                else if (wv.at(k, F::FRAME) != nf) present[k] = 0;
             }
             __syncthreads();
-            if (LIST) {                                  // positions by workgroup prefix sums
-                const int na = n_awl[cur];
+            for (int i = tid; i < naw; i += NT) {
+                const int w = awlc[i];
+                const int k = w_k[i], ex = w_exit[i];
+                // inputs of the three prefix sums below
+                w_k[i] = (k > 0 && !word_active[w]) ? 1 : 0;
+                w_bp[i] = ex ? 1 : 0;
+                w_bss[i] = ex ? rs_n[d_last[w] * n_ci + d_last2[w]] : 0;
+            }
+            __syncthreads();
+            {                                            // positions by workgroup prefix sums
                 const int32_t bpidx = s_sc[3], bss_head = s_sc[4], nawl = s_red[5];    // (rewritten below, after the scans' barriers)
-                const int32_t n_exit = ft_block_scan<NT>(w_bp, na, s_scan);
-                const int32_t n_bss = ft_block_scan<NT>(w_bss, na, s_scan);
-                const int32_t n_app = ft_block_scan<NT>(w_k, na, s_scan);
-                for (int i = tid; i < na; i += NT) {
+                const int32_t n_exit = ft_block_scan<NT>(w_bp, naw, s_scan);
+                const int32_t n_bss = ft_block_scan<NT>(w_bss, naw, s_scan);
+                const int32_t n_app = ft_block_scan<NT>(w_k, naw, s_scan);
+                for (int i = tid; i < naw; i += NT) {
                     w_bp[i] += bpidx; w_bss[i] += bss_head;
-                    if ((i + 1 < na ? w_k[i + 1] : n_app) != w_k[i]) {
-                        const int w = u.awl[cur][i];
-                        u.awl[nxt][nawl + w_k[i]] = w; u.word_active[w] = 1;
+                    if ((i + 1 < naw ? w_k[i + 1] : n_app) != w_k[i]) {
+                        const int w = awlc[i];
+                        awln[nawl + w_k[i]] = w; word_active[w] = 1;
                     }
                 }
                 if (tid == 0) {
-                    if (bpidx + n_exit + p.n1 >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap) s_sc[6] = 1;
+                    if (bpidx + n_exit + n1 >= tb.bp_cap || bss_head + n_bss + n_ci >= tb.bss_cap) s_sc[6] = 1;
                     s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; s_red[5] = nawl + n_app;
                 }
-            }
-            else
-            if (tid == 0) {                                     // positions: back-pointers, score stack, next active words
-                int32_t bpidx = s_sc[3], bss_head = s_sc[4];
-                int nawl = s_red[5];
-                for (int i = 0; i < n_awl[cur]; ++i) {
-                    const int w = u.awl[cur][i];
-                    w_bp[i] = bpidx; w_bss[i] = bss_head;
-                    if (w_exit[i]) { ++bpidx; bss_head += p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]]; }
-                    if (w_k[i] > 0 && !u.word_active[w]) { u.awl[nxt][nawl++] = w; u.word_active[w] = 1; }
-                }
-                if (bpidx + p.n1 >= u.bp_cap || bss_head + p.n_ci >= u.bss_cap) s_sc[6] = 1;
-                s_sc[3] = bpidx; s_sc[4] = bss_head; s_red[5] = nawl;
             }
             __syncthreads();
             if (!s_sc[6]) {
                 // pass B: every exiting word writes its own back-pointer (first exit creates, the others update)
-                for (int i = tid; i < n_awl[cur]; i += NT) {
+                for (int i = tid; i < naw; i += NT) {
                     if (!w_exit[i]) continue;
-                    const int w = u.awl[cur][i];
+                    const int w = awlc[i];
                     int32_t bpi = w_bp[i], bsh = w_bss[i];
-                    for (int slot = p.wc_off[w]; slot < p.wc_off[w + 1]; ++slot) {
-                        if (!u.present[slot]) continue;
-                        const int c = WC + slot;
-                        if (u.frame[(c) * C1] == nf && u.best[(c) * C1] > lpth && u.out[(c) * C1] > nwt)
-                            ft_save_bp(p, u, bpi, bsh, f, w, u.out[(c) * C1], u.outh[(c) * C1], slot - p.wc_off[w]);
+                    for (int slot = wc_off[w]; slot < wc_off[w + 1]; ++slot) {
+                        if (!present[slot]) continue;
+                        if (wv.at(slot, F::FRAME) == nf && wv.at(slot, F::BEST) > lpth && wv.at(slot, F::OUT) > nwt)
+                            ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w, wv.at(slot, F::OUT), wv.at(slot, F::OUTH), slot - wc_off[w]);
                     }
                 }
             }
             __syncthreads();
         }
-        if (LIST && !s_sc[6]) {
+        if (!s_sc[6]) {
             // single-phone words (:1100-1127), one work-item per word; back-pointer positions in list order by prefix sums
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            const int wst = p.big ? p.n_w : 1024;                // n1 <= n_w
-            int32_t *f_ex = p.big ? u.g_w : cnt, *f_new = f_ex + wst, *f_rc = f_ex + 2 * wst;
-            for (int i = tid; i < p.n1; i += NT) {
+            const int wst = p.n_w;                                // n1 <= n_w
+            int32_t *f_ex = cnt, *f_new = f_ex + wst, *f_rc = f_ex + 2 * wst;
+            for (int i = tid; i < n1; i += NT) {
                 const int c = W1 + i;
                 int ex = 0, nw = 0, rcn = 0;
-                if (u.frame[(c) * C1] >= f && u.best[(c) * C1] > lpth) {
-                    u.frame[(c) * C1] = nf;
-                    if (u.out[(c) * C1] > nwt) {
-                        const int w = p.w1_wid[i];
+                if (tv.at(c, F::FRAME) >= f && tv.at(c, F::BEST) > lpth) {
+                    tv.at(c, F::FRAME) = nf;
+                    if (tv.at(c, F::OUT) > nwt) {
+                        const int w = w1_wid[i];
                         ex = 1;
-                        if (u.word_lat_idx[w] == -1) {
+                        if (word_lat_idx[w] == -1) {
                             nw = 1;
-                            rcn = p.d_pronlen[w] == 1 ? 0 : p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]];
+                            rcn = dict.d_pronlen[w] == 1 ? 0 : rs_n[d_last[w] * n_ci + d_last2[w]];
                         }
                     }
                 }
@@ -882,69 +831,58 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
             }
             __syncthreads();
             const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
-            const int32_t n_new = ft_block_scan<NT>(f_new, p.n1, s_scan);
-            const int32_t n_rc = ft_block_scan<NT>(f_rc, p.n1, s_scan);
-            for (int i = tid; i < p.n1; i += NT)
+            const int32_t n_new = ft_block_scan<NT>(f_new, n1, s_scan);
+            const int32_t n_rc = ft_block_scan<NT>(f_rc, n1, s_scan);
+            for (int i = tid; i < n1; i += NT)
                 if (f_ex[i]) {
                     int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
-                    if (!ft_save_bp(p, u, bpi, bsh, f, p.w1_wid[i], u.out[(W1 + i) * C1], u.outh[(W1 + i) * C1], 0)) s_sc[6] = 1;
+                    if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
                 }
             __syncthreads();
             if (tid == 0) { s_sc[3] = bpidx0 + n_new; s_sc[4] = bss0 + n_rc; }
         }
         if (tid == 0 && !s_sc[6]) {
-            int32_t bpidx = s_sc[3], bss_head = s_sc[4];
-            bool ok = true;
-            const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            for (int i = 0; i < p.n1 && ok && !LIST; ++i) {
-                const int c = W1 + i;
-                if (u.frame[(c) * C1] < f) continue;
-                if (u.best[(c) * C1] > lpth) {
-                    u.frame[(c) * C1] = nf;
-                    if (u.out[(c) * C1] > nwt) ok = ft_save_bp(p, u, bpidx, bss_head, f, p.w1_wid[i], u.out[(c) * C1], u.outh[(c) * C1], 0);
-                }
-            }
+            const int32_t bpidx = s_sc[3];
             // bptable_maxwpf (:1193-1241)
             if (!(p.maxwpf == -1 || p.maxwpf == p.n_w)) {
-                const int b0 = u.bp_table_idx[f];
+                const int b0 = tb.idx[f];
                 int32_t bestscr = kMaxNegInt32; int bestbp = -1, n = 0;
                 for (int bp = b0; bp < bpidx; ++bp)
-                    if (p.d_filler[BPC(u, B_WID, bp)]) {
-                        if (BPC(u, B_SCORE, bp) > bestscr) { bestscr = BPC(u, B_SCORE, bp); bestbp = bp; }
-                        BPC(u, B_VALID, bp) = 0; ++n;
+                    if (d_filler[BPC(tb, B_WID, bp)]) {
+                        if (BPC(tb, B_SCORE, bp) > bestscr) { bestscr = BPC(tb, B_SCORE, bp); bestbp = bp; }
+                        BPC(tb, B_VALID, bp) = 0; ++n;
                     }
-                if (bestbp >= 0) { BPC(u, B_VALID, bestbp) = 1; --n; }
+                if (bestbp >= 0) { BPC(tb, B_VALID, bestbp) = 1; --n; }
                 n = (bpidx - b0) - n;
                 for (; n > p.maxwpf; --n) {
                     int32_t worst = 0x7fffffff; int wbp = -1;
                     for (int bp = b0; bp < bpidx; ++bp)
-                        if (BPC(u, B_VALID, bp) && BPC(u, B_SCORE, bp) < worst) { worst = BPC(u, B_SCORE, bp); wbp = bp; }
+                        if (BPC(tb, B_VALID, bp) && BPC(tb, B_SCORE, bp) < worst) { worst = BPC(tb, B_SCORE, bp); wbp = bp; }
                     if (wbp < 0) break;
-                    BPC(u, B_VALID, wbp) = 0;
+                    BPC(tb, B_VALID, wbp) = 0;
                 }
             }
-            s_sc[3] = bpidx; s_sc[4] = bss_head; if (!ok) s_sc[6] = 1;
         }
         __syncthreads();
-        n_awl[nxt] = s_red[5];
+        const int n_awl_nxt = s_red[5];
         if (s_sc[6]) break;
 
         // ---- word_transition (:1243-1427)
-        const int bp0 = u.bp_table_idx[f], bp1 = s_sc[3];
+        const int bp0 = tb.idx[f], bp1 = s_sc[3];
         int32_t *brc_score = s_bins, *brc_path = s_bins + kFtMaxCi, *brc_lc = s_bins + 2 * kFtMaxCi;
         if (tid == 0) s_red[6] = 0;
         __syncthreads();
         for (int bp = bp0 + tid; bp < bp1; bp += NT) {
-            u.word_lat_idx[BPC(u, B_WID, bp)] = -1;
-            if (BPC(u, B_WID, bp) != p.finishwid) atomicAdd(&s_red[6], 1);
+            word_lat_idx[BPC(tb, B_WID, bp)] = -1;
+            if (BPC(tb, B_WID, bp) != p.finishwid) atomicAdd(&s_red[6], 1);
         }
-        for (int rc = tid; rc < p.n_ci; rc += NT) {     // best exit per right-context phone, earliest bp on ties
+        for (int rc = tid; rc < n_ci; rc += NT) {     // best exit per right-context phone, earliest bp on ties
             int32_t bs = kW; int path = 0, lc = 0;
             for (int bp = bp0; bp < bp1; ++bp) {
-                if (BPC(u, B_WID, bp) == p.finishwid) continue;
-                const int l2 = BPC(u, B_LAST2, bp), l1 = BPC(u, B_LAST, bp);
-                const int32_t sc = l2 == -1 ? BPC(u, B_SCORE, bp)
-                    : u.bss[BPC(u, B_SIDX, bp) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + rc]];
+                if (BPC(tb, B_WID, bp) == p.finishwid) continue;
+                const int l2 = BPC(tb, B_LAST2, bp), l1 = BPC(tb, B_LAST, bp);
+                const int32_t sc = l2 == -1 ? BPC(tb, B_SCORE, bp)
+                    : tb.bss[BPC(tb, B_SIDX, bp) + rs_cimap[((size_t)l1 * n_ci + l2) * n_ci + rc]];
                 if (sc > bs) { bs = sc; path = bp; lc = l1; }
             }
             brc_score[rc] = bs; brc_path[rc] = path; brc_lc[rc] = lc;
@@ -952,63 +890,106 @@ void fwdtree_kernel(FtDev p, const FtUtt *__restrict__ utts, const int16_t *__re
         __syncthreads();
         if (s_red[6] > 0) {
             for (int i = tid; i < R; i += NT) {          // tree roots (:1306-1325)
-                const int ci = p.node_ci[i];
+                const int ci = node_ci[i];
                 const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
-                if (ns + ft_pen(p, pp, ci) > thresh && (u.frame[(i) * C1] < f || ns > u.score[i * CS])) {
-                    ch_enter<CS, C1>(u, i, ns, brc_path[ci], nf);
-                    u.senid[i * CS] = p.ldiph[((size_t)ci * p.n_ci + p.node_ci2[i]) * p.n_ci + brc_lc[ci]];
+                if (ns + ft_pen(ci) > thresh && (tv.at(i, F::FRAME) < f || ns > tv.at(i, F::SCORE))) {
+                    ch_enter<NE>(tv, i, ns, brc_path[ci], nf);
+                    tv.at(i, F::SENID) = ldiph[((size_t)ci * n_ci + node_ci2[i]) * n_ci + brc_lc[ci]];
                 }
             }
             for (int i = tid; i < p.n1lm; i += NT) {     // in-LM single-phone words (:1331-1388)
-                const int w = p.w1_wid[i];
+                const int w = w1_wid[i];
                 int32_t ds = kMaxNegInt32; int dbp = 0;
                 for (int bp = bp0; bp < bp1; ++bp) {
-                    if (!BPC(u, B_VALID, bp)) continue;
-                    int32_t ns = ft_exit_score(p, u, bp, p.d_first[w]);
-                    if (ns != kW) ns += ft_lm(p, p.d_base[w], BPC(u, B_REAL, bp), BPC(u, B_PREAL, bp));
+                    if (!BPC(tb, B_VALID, bp)) continue;
+                    int32_t ns = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
+                    if (ns != kW) ns += ft_lm(p, trie, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
                     if (ns > ds) { ds = ns; dbp = bp; }
                 }
-                u.lt_dscr[w] = ds; u.lt_bp[w] = dbp;
+                lt_dscr[w] = ds; lt_bp[w] = dbp;
                 if (w == p.startwid) continue;
                 const int c = W1 + i;
                 const int32_t ns = ds + p.pip;
-                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[(c) * C1] < f || ns > u.score[c * CS])) {
-                    ch_enter<CS, C1>(u, c, ns, dbp, nf);
-                    u.senid[c * CS] = p.ldiph[((size_t)p.w1_ci[i] * p.n_ci + p.w1_ci2[i]) * p.n_ci + p.d_last[BPC(u, B_WID, dbp)]];
+                if (ns + ft_pen(w1_ci[i]) > thresh && (tv.at(c, F::FRAME) < f || ns > tv.at(c, F::SCORE))) {
+                    ch_enter<NE>(tv, c, ns, dbp, nf);
+                    tv.at(c, F::SENID) = ldiph[((size_t)w1_ci[i] * n_ci + w1_ci2[i]) * n_ci + d_last[BPC(tb, B_WID, dbp)]];
                 }
             }
             for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += NT) {    // <sil> and noise words (:1390-1426)
                 // slot filler_start - 1 stands for <sil>, which is handled whatever its place in the dictionary
                 const bool is_sil = w == p.filler_start - 1;
                 if (!is_sil && (w == p.startwid || w == p.silwid)) continue;
-                const int i = p.w1_of_word[is_sil ? p.silwid : w];
+                const int i = w1_of_word[is_sil ? p.silwid : w];
                 if (i < 0) continue;
                 const int c = W1 + i;
                 const int32_t ns = brc_score[p.sil_ci] + (is_sil ? p.silpen : p.fillpen) + p.pip;
-                if (ns + ft_pen(p, pp, p.w1_ci[i]) > thresh && (u.frame[(c) * C1] < f || ns > u.score[c * CS]))
-                    ch_enter<CS, C1>(u, c, ns, brc_path[p.sil_ci], nf);
+                if (ns + ft_pen(w1_ci[i]) > thresh && (tv.at(c, F::FRAME) < f || ns > tv.at(c, F::SCORE)))
+                    ch_enter<NE>(tv, c, ns, brc_path[p.sil_ci], nf);
             }
         }
         __syncthreads();
         // ---- deactivate_channels (:1429-1450)
-        for (int i = tid; i < R; i += NT) if (u.frame[(i) * C1] == f) ch_clear<CS, C1>(p, u, i);
-        for (int i = tid; i < p.n1; i += NT) if (u.frame[(W1 + i) * C1] == f) ch_clear<CS, C1>(p, u, W1 + i);
+        for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_clear<NE>(tv, i);
+        for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_clear<NE>(tv, W1 + i);
         if (tid == 0) {
-            u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = s_sc[1]; u.step[f * 4 + 2] = s_sc[3]; u.step[f * 4 + 3] = n_acl[nxt];
+            step[f * 4] = s_sc[0]; step[f * 4 + 1] = s_sc[1]; step[f * 4 + 2] = s_sc[3]; step[f * 4 + 3] = n_listed;
             ++s_sc[7];
         }
+        n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
         __syncthreads();
     }
     if (tid == 0) {
-        u.bp_table_idx[s_sc[7]] = s_sc[3];                       // ngram_fwdtree_finish: mark one past the last frame
-        u.result[0] = s_sc[3]; u.result[1] = s_sc[4]; u.result[2] = s_sc[7]; u.result[3] = s_sc[6];
-        u.result[4] = s_sc[0];                                   // ngs->best_score as the last frame left it
+        tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
+        result[0] = s_sc[3]; result[1] = s_sc[4]; result[2] = s_sc[7]; result[3] = s_sc[6];
+        result[4] = s_sc[0];                                     // ngs->best_score as the last frame left it
     }
     // what the second pass inherits besides the tables: the permanent single-phone channels keep their per-state ssids
     // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)
-    if (p.w1_out)
-        for (int i = tid; i < p.n1 * NE; i += NT)
-            p.w1_out[((size_t)blockIdx.x * p.n1 + i / NE) * NE + i % NE] = u.senid[(W1 + i / NE) * CS + i % NE];
+    if (bf.w1_out) {
+        int32_t *const w1o = psgpu_as_global(bf.w1_out);
+        for (int i = tid; i < n1 * NE; i += NT)
+            w1o[((size_t)blockIdx.x * n1 + i / NE) * NE + i % NE] = tv.at(W1 + i / NE, F::SENID + i % NE);
+    }
+}
+
+// ngram_search_find_exit (ngram_search.c:500-544, frame_idx = -1) + the walk of ngram_search_bp_hyp / the segment iterator
+// (:546-581, 903-1010) over an utterance's table: one work-item per utterance.  hyp [max_words][4] = wid, start frame, end
+// frame, path score at the word's end, in spoken order; hyp_n [4] = number of words (may exceed max_words: then only the
+// LAST max_words are stored), path score of the exit, exit back-pointer, 0.
+__global__ void fwdtree_backtrace_kernel(const int32_t *__restrict__ bp_all, const int32_t *__restrict__ idx_all,
+                                         const int32_t *__restrict__ res_all, int32_t n_utt, int32_t max_frames, int32_t bp_cap,
+                                         int32_t finish_wid, int32_t max_words, int32_t *__restrict__ hyp_all, int32_t *__restrict__ hyp_n_all)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_utt) return;
+    FtTab tb;
+    tb.bp = const_cast<int32_t *>(bp_all) + (size_t)u * 10 * bp_cap; tb.bp_cap = bp_cap;
+    const int32_t *idx = idx_all + (size_t)u * (max_frames + 2);
+    int32_t *hyp = hyp_all + (size_t)u * max_words * 4, *hn = hyp_n_all + (size_t)u * 4;
+    const int n_frame = res_all[(size_t)u * 8 + 2];
+    hn[0] = 0; hn[1] = kW; hn[2] = -1; hn[3] = 0;
+    if (n_frame == 0) return;
+    int f = n_frame - 1;
+    const int end = idx[f];
+    while (f >= 0 && idx[f] == end) --f;
+    if (f < 0) return;
+    int best = -1; int32_t best_score = kW;
+    for (int bp = idx[f]; bp < end; ++bp) {
+        const int wid = BPC(tb, B_WID, bp);
+        if (wid == finish_wid || BPC(tb, B_SCORE, bp) > best_score) { best_score = BPC(tb, B_SCORE, bp); best = bp; }
+        if (wid == finish_wid) break;
+    }
+    int n = 0;
+    for (int b = best; b != -1; b = BPC(tb, B_BP, b)) ++n;
+    hn[0] = n; hn[1] = best_score; hn[2] = best;
+    int k = n - 1;
+    const int skip = n > max_words ? n - max_words : 0;
+    for (int b = best; b != -1 && k >= skip; --k) {
+        const int prev = BPC(tb, B_BP, b);
+        int32_t *h = hyp + (size_t)(k - skip) * 4;
+        h[0] = BPC(tb, B_WID, b); h[1] = prev == -1 ? 0 : BPC(tb, B_FRAME, prev) + 1; h[2] = BPC(tb, B_FRAME, b); h[3] = BPC(tb, B_SCORE, b);
+        b = prev;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1030,6 +1011,37 @@ static const T *ft_up(psgpu_fwdtree_s *m, const T *src, size_t n, int *rc)
     return (const T *)d;
 }
 
+// the per-utterance arrays: offsets of the fast arrays (LDS pool or slab) and of the slab
+static void ft_layout(FtDev &d, bool small)
+{
+    const int ne = d.n_emit, rec = ne == 3 ? 16 : 24, words = 3 * ne + 6;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t r = o; o += (n + 3) & ~(int64_t)3; return (int32_t)r; };
+    FtLay &L = d.lay;
+    memset(&L, 0, sizeof L);
+    L.rec = take((int64_t)d.CH * (small ? words : rec));
+    L.acl0 = take(d.N); L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
+    L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
+    L.cand_mark = take(d.n_w);
+    L.cand_wid = take(d.n_w + 1); L.cand_score = take(d.n_w + 1); L.cand_bp = take(d.n_w + 1);
+    L.o_out = take(d.N); L.o_outh = take(d.N); L.pos = take(d.N); L.flag = take(d.N); L.o_frame = take(d.N);
+    L.cnt = take(d.cnt_words);
+    if (small) {
+        L.row = take(((int64_t)d.n_sen + 1) / 2 + 4); L.pen = take(2 * (int64_t)d.n_ci);
+        L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
+    }
+    L.total = (int32_t)std::min<int64_t>(o, 0x7fffffff);
+    d.small = small ? 1 : 0;
+    int64_t g = 0;
+    auto gtake = [&](int64_t n) { const int64_t r = g; g += (n + 31) & ~(int64_t)31; return r; };       // 128-byte lines
+    d.g_wrec = gtake((int64_t)d.TOT * rec); d.g_present = gtake(d.TOT);
+    d.g_elist = gtake((int64_t)d.TOT + 1); d.g_eword = gtake((int64_t)d.TOT + 1);
+    d.g_xlist = gtake((int64_t)d.TOT + 1); d.g_xslot = gtake((int64_t)d.TOT + 1);
+    d.g_cand_next = gtake(d.n_w + 1); d.g_csf_ef = gtake(d.n_w + 1); d.g_csf_cand = gtake(d.n_w + 1);
+    d.g_fast = small ? 0 : gtake(o);
+    d.per = g;
+}
+
 extern "C" {
 
 int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
@@ -1046,28 +1058,44 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.n1lm = q[7]; d.beam = q[8]; d.pbeam = q[9]; d.lpbeam = q[10]; d.lponlybeam = q[11]; d.wbeam = q[12]; d.pip = q[13];
     d.nwpen = q[14]; d.silpen = q[15]; d.fillpen = q[16]; d.maxhmmpf = q[17]; d.maxwpf = q[18]; d.startwid = q[19];
     d.finishwid = q[20]; d.silwid = q[21]; d.filler_start = q[22]; d.filler_end = q[23]; d.sil_ci = q[24]; d.has_pl = q[25];
-    d.big = (d.N + d.R > kFtMaxN || d.n_w > 1024) ? 1 : 0;
     if (!(d.n_emit == 3 || d.n_emit == 5) || d.n_ci < 1 || d.n_ci > kFtMaxCi || d.N < 1 || d.n_w < 1) {
         psgpu_set_error("fwdtree: unsupported shape (n_emit %d, n_ci %d, tree nodes %d, words %d)", d.n_emit, d.n_ci, d.N, d.n_w);
         delete m;
         return PSGPU_EINVAL;
     }
     const size_t nci3 = (size_t)d.n_ci * d.n_ci * d.n_ci, n1 = (size_t)d.n_w + 1;
-    std::vector<int32_t> parent(d.N, -1), w1_of(d.n_w, -1), wc_off(d.n_w + 1, 0);
-    for (int i = 0; i < d.N; ++i)
-        for (int c = t->node_child[i]; c >= 0; c = t->node_sib[c]) parent[c] = i;
+    std::vector<int32_t> parent(d.N, -1), w1_of(d.n_w, -1), wc_off(d.n_w + 1, 0), kid_off(d.N + 1, 0), kids(d.M > 0 ? d.M : 1, 0);
+    // the children of every node, in sibling order, as one array (CSR): a walk along the sibling pointers is a chain of
+    // dependent loads, a range of an array is not
+    {
+        int k = 0;
+        for (int i = 0; i < d.N; ++i) {
+            kid_off[i] = k;
+            for (int c = t->node_child[i]; c >= 0; c = t->node_sib[c]) {
+                if (k >= d.M || c < d.R || c >= d.N || parent[c] != -1) {
+                    psgpu_set_error("fwdtree: the tree tables are not a tree (node %d, child %d)", i, c);
+                    delete m;
+                    return PSGPU_EINVAL;
+                }
+                parent[c] = i; kids[k++] = c;
+            }
+        }
+        kid_off[d.N] = k;
+    }
     for (int i = 0; i < d.n1; ++i) w1_of[t->w1_wid[i]] = i;
-    int tot = 0;
+    int64_t tot = 0;
     for (int w = 0; w < d.n_w; ++w) {
-        wc_off[w] = tot;
+        wc_off[w] = (int32_t)tot;
         if (t->dict_pronlen[w] > 1) tot += t->rssid_n[t->dict_last[w] * d.n_ci + t->dict_last2[w]];
     }
-    wc_off[d.n_w] = tot;
-    d.TOT = tot;
-    m->C = d.N + d.n1 + tot;
+    if (tot > 0x7ffffff0) { psgpu_set_error("fwdtree: %lld last-phone channels", (long long)tot); delete m; return PSGPU_EINVAL; }
+    wc_off[d.n_w] = (int32_t)tot;
+    d.TOT = (int32_t)tot;
+    d.CH = d.N + d.n1;
+    d.cnt_words = std::max(d.R + d.N + 1, 4 * d.n_w + 4);
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
     d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
-    d.node_child = ft_up(m, t->node_child, d.N, &rc); d.node_sib = ft_up(m, t->node_sib, d.N, &rc);
+    d.kid_off = ft_up(m, kid_off.data(), (size_t)d.N + 1, &rc); d.kids = ft_up(m, kids.data(), kids.size(), &rc);
     d.node_pw = ft_up(m, t->node_penult_wid, d.N, &rc); d.parent = ft_up(m, parent.data(), d.N, &rc);
     d.homophone = ft_up(m, t->homophone_set, d.n_w, &rc);
     d.w1_wid = ft_up(m, t->w1_wid, d.n1, &rc); d.w1_ci = ft_up(m, t->w1_ci, d.n1, &rc); d.w1_ci2 = ft_up(m, t->w1_ci2, d.n1, &rc);
@@ -1084,6 +1112,11 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.tp = ft_up(m, t->tp, (size_t)t->n_tmat * d.n_emit * (d.n_emit + 1), &rc);
     d.sseq = ft_up(m, t->sseq, (size_t)t->n_sseq * d.n_emit, &rc);
     if (rc != PSGPU_OK) { psgpu_fwdtree_free(m); return rc; }
+    // layout: LDS when everything the tree level touches fits the pool (PSGPU_FWDTREE_LAYOUT=slab forces the other one: the
+    // parity tests run both)
+    const char *force = getenv("PSGPU_FWDTREE_LAYOUT");
+    ft_layout(d, true);
+    if (d.lay.total > kFtLdsWords || d.n_sen > kFtMaxSen || (force && !strcmp(force, "slab"))) ft_layout(d, false);
     *out = m;
     return PSGPU_OK;
 }
@@ -1100,17 +1133,13 @@ int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm)
     return PSGPU_OK;
 }
 
-int psgpu_fwdtree_set_mode(psgpu_fwdtree_t *m, int32_t mode)
-{
-    PSGPU_REQUIRE(m && (mode == PSGPU_FWDTREE_PER_NODE || mode == PSGPU_FWDTREE_ACTIVE_LIST), "psgpu_fwdtree_set_mode: bad argument");
-    m->d.list_mode = mode;
-    return PSGPU_OK;
-}
+int32_t psgpu_fwdtree_n_single_phone_words(const psgpu_fwdtree_t *m) { return m ? m->d.n1 : 0; }
 
-int psgpu_fwdtree_set_w1_ssid_out(psgpu_fwdtree_t *m, int32_t *w1_ssid_dev)
+int psgpu_fwdtree_layout(const psgpu_fwdtree_t *m, int32_t *lds_layout, int64_t *slab_bytes_per_utt)
 {
-    PSGPU_REQUIRE(m, "psgpu_fwdtree_set_w1_ssid_out: NULL argument");
-    m->d.w1_out = w1_ssid_dev;
+    PSGPU_REQUIRE(m, "psgpu_fwdtree_layout: NULL argument");
+    if (lds_layout) *lds_layout = m->d.small;
+    if (slab_bytes_per_utt) *slab_bytes_per_utt = 4 * m->d.per;
     return PSGPU_OK;
 }
 
@@ -1118,6 +1147,7 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
 {
     if (!m) return;
     for (void *p : m->allocs) hipFree(p);
+    hipFree(m->slab);
     delete m;
 }
 
@@ -1126,11 +1156,12 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
 // table go to bp_dev + u * 10 * bp_cap, the score stack to bss_dev + u * bss_cap, the frame marks to
 // idx_dev + u * (max_frames + 2), per-frame diagnostics to step_dev + u * max_frames * 4, and
 // result_dev + u * 8 = {n back-pointers, score-stack length, frames searched, status (1 = a table was full)}.
+// Asynchronous on `stream` (the work slab belongs to the handle: one search at a time per handle).
 int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
                              const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
                              int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
                              int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
-                             int32_t pl_window, void *stream)
+                             int32_t pl_window, int32_t *w1_ssid_out_dev, void *stream)
 {
     PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0, "psgpu_fwdtree_search_dev: bad argument");
     PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
@@ -1139,93 +1170,50 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE(senscr_dev && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdtree_search_dev: NULL device buffer");
-    const FtDev &d = m->d;
+    FtDev d = m->d;
+    // the LDS layout copies score rows as dwords: rows must start on 4-byte boundaries
+    if (d.small && ((scr_stride & 1) || ((uintptr_t)senscr_dev & 3))) ft_layout(d, false);
     hipStream_t st = (hipStream_t)stream;
-    // per-utterance work slab
-    const size_t C = m->C;
-    const size_t per = C * (d.list_mode ? 24 : 5 + 5 + 4 + 5 + 2) + d.TOT + 2 * (size_t)d.N + 2 * (size_t)d.n_w + 2 * (size_t)d.n_w
-                     + 4 * ((size_t)d.n_w + 1) + 3 * (size_t)d.n_w + 2 * ((size_t)d.n_w + 1) + 7 * (size_t)d.N + 64
-                     + ((size_t)d.n_sen + 1) / 2 + 1 + (size_t)d.n_w + (d.list_mode ? 4 * ((size_t)d.TOT + 1) : 0)
-                     + (d.big ? (size_t)std::max(d.N + d.R, d.n_w) + 1 + 4 * (size_t)d.n_w : 0);
-    int32_t *slab = nullptr;
-    FtUtt *d_utts = nullptr;
-    PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * per * n_utt));
-    std::vector<FtUtt> hu(n_utt);
-    for (int i = 0; i < n_utt; ++i) {
-        int32_t *q = slab + per * i;
-        FtUtt &u = hu[i];
-        auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
-        if (d.list_mode) {                                      // one record per channel (see the kernel)
-            const int ne = d.n_emit, rs = ne == 3 ? 16 : 24;
-            int32_t *rec = take(C * rs);
-            u.score = rec; u.hist = rec + ne; u.out = rec + 2 * ne; u.outh = u.out + 1; u.best = u.out + 2; u.frame = u.out + 3;
-            u.senid = u.out + 4; u.tmat = u.senid + ne; u.mpx = u.tmat + 1;
-        }
-        else {
-            u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
-            u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C);
-        }
-        u.present = take(d.TOT);
-        u.acl[0] = take(d.N); u.acl[1] = take(d.N); u.awl[0] = take(d.n_w); u.awl[1] = take(d.n_w);
-        u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
-        u.cand_wid = take(d.n_w + 1); u.cand_score = take(d.n_w + 1); u.cand_bp = take(d.n_w + 1); u.cand_next = take(d.n_w + 1);
-        u.lt_sf = take(d.n_w); u.lt_dscr = take(d.n_w); u.lt_bp = take(d.n_w);
-        u.csf_ef = take(d.n_w + 1); u.csf_cand = take(d.n_w + 1);
-        u.o_frame = take(d.N); u.o_s0 = take(d.N); u.o_best = take(d.N); u.o_out = take(d.N); u.o_outh = take(d.N);
-        u.pos = take(d.N); u.flag = take(d.N);
-        u.nrow = reinterpret_cast<int16_t *>(take(((size_t)d.n_sen + 1) / 2 + 1));
-        u.cand_mark = take(d.n_w);
-        u.elist = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
-        u.eword = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
-        u.xlist = d.list_mode ? take((size_t)d.TOT + 1) : nullptr; u.xslot = d.list_mode ? take((size_t)d.TOT + 1) : nullptr;
-        u.g_cnt = d.big ? take((size_t)std::max(d.N + d.R, d.n_w) + 1) : nullptr;
-        u.g_w = d.big ? take(4 * (size_t)d.n_w) : nullptr;
-        u.bp = bp_dev + (size_t)i * 10 * bp_cap; u.bss = bss_dev + (size_t)i * bss_cap;
-        u.bp_table_idx = idx_dev + (size_t)i * (max_frames + 2); u.step = step_dev + (size_t)i * max_frames * 4;
-        u.result = result_dev + (size_t)i * 8;
-        u.bp_cap = bp_cap; u.bss_cap = bss_cap;
+    const size_t need = (size_t)d.per * n_utt;
+    if (need > m->slab_words) {
+        if (m->slab) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->slab); m->slab = nullptr; m->slab_words = 0; }
+        PSGPU_HIP(hipMalloc((void **)&m->slab, sizeof(int32_t) * need));
+        m->slab_words = need;
     }
-    std::vector<FtOff> ho(d.list_mode ? n_utt : 0);
-    for (size_t i = 0; i < ho.size(); ++i) {
-        const FtUtt &u = hu[i];
-        FtOff &o = ho[i];
-#define X(f) o.f = u.f - slab;
-        FT_SLAB_FIELDS(X)
-#undef X
-        o.acl0 = u.acl[0] - slab; o.acl1 = u.acl[1] - slab; o.awl0 = u.awl[0] - slab; o.awl1 = u.awl[1] - slab;
-        o.g_cnt = u.g_cnt ? u.g_cnt - slab : 0; o.g_w = u.g_w ? u.g_w - slab : 0;
-        o.nrow = reinterpret_cast<int32_t *>(u.nrow) - slab;
-    }
-    FtOff *d_offs = nullptr;
     FtBufs bf;
-    bf.slab = slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
+    bf.slab = m->slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
+    bf.w1_out = w1_ssid_out_dev;
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
-    hipError_t e = hipMalloc((void **)&d_utts, sizeof(FtUtt) * n_utt);
-    if (e == hipSuccess && d.list_mode) e = hipMalloc((void **)&d_offs, sizeof(FtOff) * n_utt);
-    if (e == hipSuccess && d.list_mode) e = hipMemcpyAsync(d_offs, ho.data(), sizeof(FtOff) * n_utt, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_utts, hu.data(), sizeof(FtUtt) * n_utt, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);          // hu is about to go out of scope
-    if (e != hipSuccess) { hipFree(slab); hipFree(d_utts); hipFree(d_offs); PSGPU_HIP(e); }
-    // ACTIVE_LIST on a tree beyond the LDS scratch: ~10^4 active channels per frame, 16 waves per utterance
-    const int nt = (d.list_mode && d.big) ? kFtThreadsBig : kFtThreads;
-#define FT_LAUNCH(NE, NT, LIST)                                                                                          \
-    hipLaunchKernelGGL((fwdtree_kernel<NE, NT, LIST>), dim3(n_utt), dim3(NT), 0, st, d, d_utts, senscr_dev, scr_stride, \
-                       penalties_dev, utt_off_dev, raw_scores, pl_window, d_offs, bf)
+    // ~10^4 active channels per frame on a large tree: 16 waves per utterance
+    const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
+#define FT_LAUNCH(NE, NT, SMALL)                                                                                      \
+    hipLaunchKernelGGL((fwdtree_kernel<NE, NT, SMALL>), dim3(n_utt), dim3(NT), 0, st, d, senscr_dev, scr_stride,     \
+                       penalties_dev, utt_off_dev, raw_scores, pl_window, bf)
     if (d.n_emit == 3) {
-        if (!d.list_mode) FT_LAUNCH(3, kFtThreads, false);
-        else if (nt == kFtThreads) FT_LAUNCH(3, kFtThreads, true);
-        else FT_LAUNCH(3, kFtThreadsBig, true);
+        if (d.small) FT_LAUNCH(3, kFtThreads, true);
+        else if (!big) FT_LAUNCH(3, kFtThreads, false);
+        else FT_LAUNCH(3, kFtThreadsBig, false);
     }
     else {
-        if (!d.list_mode) FT_LAUNCH(5, kFtThreads, false);
-        else if (nt == kFtThreads) FT_LAUNCH(5, kFtThreads, true);
-        else FT_LAUNCH(5, kFtThreadsBig, true);
+        if (d.small) FT_LAUNCH(5, kFtThreads, true);
+        else if (!big) FT_LAUNCH(5, kFtThreads, false);
+        else FT_LAUNCH(5, kFtThreadsBig, false);
     }
 #undef FT_LAUNCH
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
-    hipFree(slab); hipFree(d_utts); hipFree(d_offs);
-    PSGPU_HIP(e);
+    PSGPU_HIP(hipGetLastError());
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_backtrace_dev(const psgpu_fwdtree_t *m, const int32_t *bp_dev, const int32_t *idx_dev, const int32_t *result_dev,
+                                int32_t n_utt, int32_t max_frames, int32_t bp_cap, int32_t max_words, int32_t *hyp_dev,
+                                int32_t *hyp_n_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && max_words > 0, "psgpu_fwdtree_backtrace_dev: bad argument");
+    if (n_utt == 0) return PSGPU_OK;
+    PSGPU_REQUIRE(bp_dev && idx_dev && result_dev && hyp_dev && hyp_n_dev, "psgpu_fwdtree_backtrace_dev: NULL device buffer");
+    hipLaunchKernelGGL(fwdtree_backtrace_kernel, dim3((n_utt + 63) / 64), dim3(64), 0, (hipStream_t)stream, bp_dev, idx_dev, result_dev,
+                       n_utt, max_frames, bp_cap, m->d.finishwid, max_words, hyp_dev, hyp_n_dev);
+    PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
 

@@ -23,12 +23,9 @@ class FwdtreeSearch:
 
     BP_COLS = ("frame", "valid", "wid", "bp", "score", "s_idx", "real_wid", "prev_real_wid", "last_phone", "last2_phone")
 
-    PER_NODE, ACTIVE_LIST = 0, 1          # psgpu_fwdtree_set_mode (include/psgpu.h)
-
-    def __init__(self, static, par, lm=None, mode=None):
+    def __init__(self, static, par, lm=None):
         """lm: an NGramTrieLM over the same dictionary -- language scores are then looked up in the trie on
-        the device and the dense table static["lm"] is not needed (any vocabulary the tree fits).
-        mode: PER_NODE (default) or ACTIVE_LIST (per-frame work proportional to the active channels)."""
+        the device and the dense table static["lm"] is not needed (any vocabulary the tree fits)."""
         src = dict(static); src["par"] = par
         self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES if not (n == "lm" and lm is not None)}
         t = _Tables(*[self._keep[n].ctypes.data if n in self._keep else None for n in _NAMES],
@@ -38,9 +35,13 @@ class FwdtreeSearch:
         self.lm = lm
         if lm is not None:
             capi.check(capi.lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
-        if mode is not None:
-            capi.check(capi.lib().psgpu_fwdtree_set_mode(self.h, int(mode)), "psgpu_fwdtree_set_mode")
-        self.n_sen = int(par[2]); self.n_ci = int(par[0])
+        self.n_sen = int(par[2]); self.n_ci = int(par[0]); self.finish_wid = int(par[20])
+
+    def lds_layout(self):
+        """True when the tree-level state of this search lives in LDS (psgpu_fwdtree_layout)."""
+        v = C.c_int32()
+        capi.check(capi.lib().psgpu_fwdtree_layout(self.h, C.byref(v), None), "psgpu_fwdtree_layout")
+        return bool(v.value)
 
     def close(self):
         if self.h:
@@ -52,6 +53,20 @@ class FwdtreeSearch:
             self.close()
         except Exception:
             pass
+
+    def backtrace_dev(self, bp, idx, result, max_frames, max_words=512):
+        """psgpu_fwdtree_backtrace_dev on the device tensors a search left (handover["bp"], ["idx"], ["result"]):
+        returns (hyp [n][max_words][4] = wid, sf, ef, path score; hyp_n [n][4] = n words, exit score, exit bp, 0) as numpy."""
+        import torch
+        n = int(result.shape[0])
+        hyp = torch.zeros((n, max_words, 4), dtype=torch.int32, device=bp.device)
+        hn = torch.zeros((n, 4), dtype=torch.int32, device=bp.device)
+        p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        capi.check(capi.lib().psgpu_fwdtree_backtrace_dev(self.h, p(bp), p(idx), p(result), n, int(max_frames), int(bp.shape[2]),
+                                                          int(max_words), p(hyp), p(hn),
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "psgpu_fwdtree_backtrace_dev")
+        return hyp.cpu().numpy(), hn.cpu().numpy()
 
     def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None):
         """senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back (numpy arrays, or
@@ -75,14 +90,16 @@ class FwdtreeSearch:
         step = torch.zeros((n, max(mf, 1), 4), dtype=torch.int32, device=dev)
         res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+        w1 = None
         if handover is not None:
             w1 = torch.zeros((n, int(self._keep["par"][6]), int(self._keep["par"][1])), dtype=torch.int32, device=dev)
-            capi.check(capi.lib().psgpu_fwdtree_set_w1_ssid_out(self.h, p(w1)), "psgpu_fwdtree_set_w1_ssid_out")
-            handover.update(bp=bp, result=res, w1_ssid=w1)
+            handover.update(bp=bp, result=res, w1_ssid=w1, idx=idx, bp_cap=bp_cap, max_frames=mf)
         capi.check(capi.lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap,
                                                        bss_cap, p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)),
-                                                       int(pl_window), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                                                       int(pl_window), p(w1) if w1 is not None else None,
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                    "psgpu_fwdtree_search_dev")
+        torch.cuda.current_stream().synchronize()       # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel
         out = []
         if n == 0:
             return out

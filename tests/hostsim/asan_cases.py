@@ -16,10 +16,11 @@ def caps(g):
     return dict(bp_cap=int(g["bp"].shape[0]) + 64, bss_cap=int(g["bscore_stack"].shape[0]) + 128)
 
 
-for case, mode in [("goforward", 0), ("goforward", 1), ("goforward_maxhmmpf60_maxwpf3", 1), ("man_ah_2934za", 1), ("medium_numbers_maxwpf8", 1)]:
+for case, mode in [("goforward", "slab"), ("goforward", "lds"), ("goforward_maxhmmpf60_maxwpf3", "lds"), ("man_ah_2934za", "lds"), ("medium_numbers_maxwpf8", "lds")]:
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
-    s = simlib.SimFwdtreeSearch(st, g["par"], lm=simlib.SimLm(st) if "lm" not in st else None, list_mode=mode)
+    os.environ["PSGPU_FWDTREE_LAYOUT"] = mode
+    s = simlib.SimFwdtreeSearch(st, g["par"], lm=simlib.SimLm(st) if "lm" not in st else None)
     rows, pen = _inputs(g, s.n_sen)
     _check(s.search(rows, pen, [rows.shape[0]], handover={}, **caps(g))[0], g, case)
     print("tree search", case, "mode", mode, "clean")
@@ -37,8 +38,9 @@ print("flat search scoring its own senones clean")
 # tables too small: the kernels must stop with status 1 and stay inside the buffers
 g = _load("fwdtree_trace_numbers.npz")
 st = _load("fwdtree_static_en_us_turtle.npz")
-for mode in (0, 1):
-    s = simlib.SimFwdtreeSearch(st, g["par"], list_mode=mode)
+for mode in ("slab", "lds"):
+    os.environ["PSGPU_FWDTREE_LAYOUT"] = mode
+    s = simlib.SimFwdtreeSearch(st, g["par"])
     rows, pen = _inputs(g, s.n_sen)
     for kw in (dict(bp_cap=300, bss_cap=1 << 16), dict(bp_cap=4096, bss_cap=900)):
         r = s.search(rows, pen, [rows.shape[0]], **kw)[0]

@@ -86,6 +86,7 @@ inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 using std::max;
 using std::min;
+template <typename T> inline T __builtin_nontemporal_load(const T *p) { return *p; }
 
 // ---- atomics (one host thread runs all fibers: plain read-modify-write) ----------------------------
 template <typename T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }

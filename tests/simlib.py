@@ -79,7 +79,7 @@ class _SimCapi:
 class SimFwdtreeSearch:
     """pocketsphinx_amd.search.FwdtreeSearch on the simulator."""
 
-    def __init__(self, static, par, lm=None, list_mode=None):
+    def __init__(self, static, par, lm=None):
         src = dict(static); src["par"] = par
         self._keep = {n: np.ascontiguousarray(src[n], _DT.get(n, np.int32)) for n in _NAMES if not (n == "lm" and lm is not None)}
         t = _Tables(*[self._keep[n].ctypes.data if n in self._keep else None for n in _NAMES],
@@ -89,8 +89,6 @@ class SimFwdtreeSearch:
         self.lm = lm
         if lm is not None:
             check(lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
-        if list_mode is not None:
-            check(lib().psgpu_fwdtree_set_mode(self.h, int(list_mode)), "psgpu_fwdtree_set_mode")
         self.n_sen = int(par[2]); self.n_ci = int(par[0]); self.n1 = int(par[6]); self.n_emit = int(par[1])
 
     def close(self):
@@ -107,13 +105,15 @@ class SimFwdtreeSearch:
         bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
         idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
         p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        w1 = None
         if handover is not None:
             w1 = np.zeros((n, self.n1, self.n_emit), np.int32)
-            check(lib().psgpu_fwdtree_set_w1_ssid_out(self.h, p(w1)), "psgpu_fwdtree_set_w1_ssid_out")
             handover.update(bp=bp, result=res, w1_ssid=w1, bp_cap=bp_cap)
         check(lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
-                                             p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window), None),
+                                             p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window),
+                                             p(w1) if w1 is not None else None, None),
               "psgpu_fwdtree_search_dev")
+        self.last = dict(bp=bp, idx=idx, res=res, mf=mf, bp_cap=bp_cap)
         out = []
         for u in range(n):
             nb, nh, nfr, status = [int(v) for v in res[u, :4]]

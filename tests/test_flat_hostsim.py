@@ -71,7 +71,7 @@ def test_two_passes_chained_on_the_simulator(case):
     from test_search_gpu import _inputs
     g, st, fst = load_flat(case)
     g1 = _load("fwdtree_trace_%s.npz" % case)
-    s1 = simlib.SimFwdtreeSearch(st, g1["par"], list_mode=1)
+    s1 = simlib.SimFwdtreeSearch(st, g1["par"])
     rows1, pen1 = _inputs(g1, s1.n_sen)
     h = {}
     r1 = s1.search(rows1, pen1, [rows1.shape[0]], handover=h)[0]
@@ -145,7 +145,7 @@ def test_two_passes_chained_full_cmudict_vocabulary(big_flat_trace):
     from test_search_gpu import _inputs
     g = big_flat_trace
     lm = simlib.SimLm(g)
-    s1 = simlib.SimFwdtreeSearch(g, g["par"], lm=lm, list_mode=1)
+    s1 = simlib.SimFwdtreeSearch(g, g["par"], lm=lm)
     rows1, pen1 = _inputs(g, s1.n_sen)
     h = {}
     r1 = s1.search(rows1, pen1, [rows1.shape[0]], handover=h)[0]

@@ -17,22 +17,32 @@ from test_oracle_search import CASES, MEDIUM_CASES, big_trace  # noqa: F401
 from test_search_gpu import _check, _inputs
 
 
-class _order:
-    def __init__(self, order):
-        self.order = order
+class _env:
+    def __init__(self, name, value):
+        self.name, self.value = name, value
 
     def __enter__(self):
-        self.old = os.environ.get("PSGPU_SIM_ORDER")
-        os.environ["PSGPU_SIM_ORDER"] = self.order
+        self.old = os.environ.get(self.name)
+        os.environ[self.name] = self.value
 
     def __exit__(self, *a):
         if self.old is None:
-            del os.environ["PSGPU_SIM_ORDER"]
+            del os.environ[self.name]
         else:
-            os.environ["PSGPU_SIM_ORDER"] = self.old
+            os.environ[self.name] = self.old
 
 
-def _run(case, order, trie=False, **kw):
+def _order(order):
+    return _env("PSGPU_SIM_ORDER", order)
+
+
+def _layout(layout):
+    """"lds": the tree-level state in the workgroup's LDS pool where it fits (structure of arrays, copies of the static
+    tree tables, score rows copied in a frame ahead); "slab": everything in the utterance's slab (psgpu_fwdtree_layout)."""
+    return _env("PSGPU_FWDTREE_LAYOUT", layout)
+
+
+def _run(case, order, trie=False, layout="lds"):
     g = _load("fwdtree_trace_%s.npz" % case)
     static = bytes(g["static"]).decode()
     st = _load("fwdtree_static_%s.npz" % static)
@@ -41,32 +51,31 @@ def _run(case, order, trie=False, **kw):
         lm = simlib.SimLm(st)
     elif trie:
         lm = simlib.SimLm(lm_load({"en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
-    with _order(order):
-        s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm, **kw)
+    with _order(order), _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm)
         rows, pen = _inputs(g, s.n_sen)
         _check(s.search(rows, pen, [rows.shape[0]])[0], g, "%s (%s)" % (case, order))
         s.close()
 
 
-@pytest.mark.parametrize("mode,order", [(0, "fwd"), (0, "rev"), (1, "fwd"), (1, "rev"), (1, "shuffle:7")])
+@pytest.mark.parametrize("layout,order", [("slab", "fwd"), ("slab", "rev"), ("lds", "fwd"), ("lds", "rev"), ("lds", "shuffle:7")])
 @pytest.mark.parametrize("case", CASES + MEDIUM_CASES)
-def test_search_kernel_source_on_the_simulator(case, mode, order):
-    """mode 0 = PSGPU_FWDTREE_PER_NODE (verified on the MI355X), 1 = PSGPU_FWDTREE_ACTIVE_LIST (include/psgpu.h)"""
-    _run(case, order, list_mode=mode)
+def test_search_kernel_source_on_the_simulator(case, layout, order):
+    _run(case, order, layout=layout)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("layout", ["slab", "lds"])
 @pytest.mark.parametrize("case", ["goforward", "man_ah_2934za"])
-def test_search_kernel_source_with_the_trie_lm(case, mode):
-    _run(case, "rev", trie=True, list_mode=mode)
+def test_search_kernel_source_with_the_trie_lm(case, layout):
+    _run(case, "rev", trie=True, layout=layout)
 
 
 def test_search_kernel_source_batch_of_utterances():
-    """several workgroups in one launch, ACTIVE_LIST: every utterance equals its own golden"""
+    """several workgroups in one launch: every utterance equals its own golden"""
     names = ["goforward", "numbers", "goforward"]
     gs = [_load("fwdtree_trace_%s.npz" % n) for n in names]
     st = _load("fwdtree_static_en_us_turtle.npz")
-    s = simlib.SimFwdtreeSearch(st, gs[0]["par"], list_mode=1)
+    s = simlib.SimFwdtreeSearch(st, gs[0]["par"])
     ins = [_inputs(g, s.n_sen) for g in gs]
     out = s.search(np.concatenate([i[0] for i in ins]), np.concatenate([i[1] for i in ins]), [i[0].shape[0] for i in ins])
     for r, g, n in zip(out, gs, names):
@@ -75,14 +84,13 @@ def test_search_kernel_source_batch_of_utterances():
 
 
 @pytest.mark.parametrize("order", ["fwd", "rev"])
-def test_search_kernel_source_full_cmudict_vocabulary_active_list(big_trace, order):  # noqa: F811
-    """The large-vocabulary form of the kernel (ACTIVE_LIST, 1024 work-items, list / word scratch in the
-    utterance's slab) on the full cmudict task: 134,865 words, 248 k tree channels, ~8 k (up to 33 k) active
+def test_search_kernel_source_full_cmudict_vocabulary(big_trace, order):  # noqa: F811
+    """The large-vocabulary form of the kernel (1024 work-items, everything in the utterance's slab) on the full cmudict task: 134,865 words, 248 k tree channels, ~8 k (up to 33 k) active
     channels per frame, language scores from the simulated device trie.  Tables identical to the reference's."""
     g = big_trace
     lm = simlib.SimLm(g)
     with _order(order):
-        s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm, list_mode=1)
+        s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm)
         rows, pen = _inputs(g, s.n_sen)
         _check(s.search(rows, pen, [rows.shape[0]])[0], g, "cmudict (%s)" % order)
         s.close()
@@ -100,9 +108,9 @@ def test_simulated_device_trie_equals_reference_look_ups(name):
     lm.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("layout", ["slab", "lds"])
 @pytest.mark.parametrize("case", ["goforward", "numbers", "medium_goforward"])
-def test_search_kernel_source_building_its_own_active_lists(case, mode):
+def test_search_kernel_source_building_its_own_active_lists(case, layout):
     """raw-score mode (the kernel builds each frame's active senone list, bridging entries included, and subtracts the
     list's minimum itself, as the PTM scorer does): fed the reference's normalised scores plus an arbitrary per-frame
     offset -- the listed senones' minimum is 0 in the PTM scorer's rows, so the kernel must recover them exactly --
@@ -111,7 +119,8 @@ def test_search_kernel_source_building_its_own_active_lists(case, mode):
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
     lm = simlib.SimLm(st) if "lm" not in st else None
-    s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm, list_mode=mode)
+    with _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm)
     rows, pen = _inputs(g, s.n_sen)
     rng = np.random.default_rng(5)
     off, act = g["step_act_off"], g["step_act"]
@@ -125,10 +134,10 @@ def test_search_kernel_source_building_its_own_active_lists(case, mode):
 
 
 def test_search_kernel_source_full_cmudict_own_active_lists(big_trace):  # noqa: F811
-    """the same at full scale: ACTIVE_LIST, 1024 work-items, the tree search building its own active lists"""
+    """the same at full scale: 1024 work-items, the tree search building its own active lists"""
     g = big_trace
     lm = simlib.SimLm(g)
-    s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm, list_mode=1)
+    s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm)
     rows, pen = _inputs(g, s.n_sen)
     off, act = g["step_act_off"], g["step_act"]
     raw = np.full(rows.shape, 12345, np.int16)

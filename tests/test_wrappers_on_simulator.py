@@ -18,6 +18,9 @@ from test_search_gpu import _check, _inputs
 class _Stream:
     cuda_stream = 0
 
+    def synchronize(self):
+        pass
+
 
 class _SimLibWithPtmView:
     """the simulator's library + psgpu_ptm_model_view (which lives in psgpu_ptm.hip, not compiled by the simulator)"""
@@ -64,12 +67,14 @@ def on_simulator(monkeypatch):
     return torch
 
 
-@pytest.mark.parametrize("mode", [None, 1])
-def test_tree_search_wrapper_and_handover(on_simulator, mode):
+@pytest.mark.parametrize("layout", ["lds", "slab"])
+def test_tree_search_wrapper_and_handover(on_simulator, layout, monkeypatch):
     import pocketsphinx_amd as P
     g1 = _load("fwdtree_trace_goforward.npz")
     g, st, fst = load_flat("goforward")
-    s1 = P.FwdtreeSearch(st, g1["par"], mode=mode)
+    monkeypatch.setenv("PSGPU_FWDTREE_LAYOUT", layout)
+    s1 = P.FwdtreeSearch(st, g1["par"])
+    assert s1.lds_layout() == (layout == "lds")
     rows1, pen1 = _inputs(g1, s1.n_sen)
     # a batch of two, so that the bulk read-back slices per utterance
     h = {}

@@ -41,10 +41,9 @@ def main():
             "en_us_turtle": "turtle_decoder", "tidigits": "tidigits_decoder"}[static]))
         lm = P.NGramTrieLM({k: lmsrc[k] for k in (lmsrc.files if hasattr(lmsrc, "files") else lmsrc)})
     print("case %s, %d words, %d tree nodes, LM: %s" % (case, int(g["par"][3]), int(g["par"][4] + g["par"][5]), "trie" if lm else "dense"))
-    # SB_MODE = active_list: psgpu_fwdtree_set_mode(PSGPU_FWDTREE_ACTIVE_LIST)
-    mode = P.FwdtreeSearch.ACTIVE_LIST if os.environ.get("SB_MODE", "") == "active_list" else None
-    print("mode:", "ACTIVE_LIST" if mode else "PER_NODE")
-    s = P.FwdtreeSearch(st, g["par"], lm=lm, mode=mode)
+    # PSGPU_FWDTREE_LAYOUT=slab in the environment forces the device-memory layout (psgpu_fwdtree_layout)
+    s = P.FwdtreeSearch(st, g["par"], lm=lm)
+    print("layout:", "LDS" if s.lds_layout() else "slab")
     rows, pen = _inputs(g, s.n_sen)
     import ctypes as C
     from pocketsphinx_amd import capi
@@ -65,7 +64,7 @@ def main():
 
         def run():
             capi.check(capi.lib().psgpu_fwdtree_search_dev(s.h, p(d_s), C.c_int64(s.n_sen), p(d_p), p(uo), nb, T, bp_cap, bss_cap,
-                                                           p(bp), p(bss), p(idx), p(step), p(res), 0, 0, sp), "search")
+                                                           p(bp), p(bss), p(idx), p(step), p(res), 0, 0, None, sp), "search")
         run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
