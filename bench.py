@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- senone-scoring throughput of the HIP path on MI355X.
+"""bench.py -- decode throughput of the device first pass on MI355X (BASELINE.json metric: frames/sec + xRT decode,
+en-us PTM, n-gram fwdtree).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE
-JSON line on rank 0.  For N > 1 it is launched by torch.distributed.run, one
-rank per GPU; utterances shard across ranks with no data-path collective
-(weak scaling: every rank scores its own batch), the only collective is the
-timing reduction.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  For N > 1 it is
+launched by torch.distributed.run, one rank per GPU.
 
-Workload (BASELINE.json configs[1]): en-us PTM (42 codebooks x 3 streams x
-128 Gaussians x 13 dims, 5126 senones, top-4), senone-score-only, 10,000
-synthetic 39-dim frames per GPU organised as 40 utterances x 250 frames,
-compallsen semantics, fresh top-N state per utterance.  A "step" is one pass
-of the hot path (top-N chain kernel + senone kernel) over that batch, inputs
-already resident in HBM.  value = frames/s over all ranks.
+Workload (BASELINE.json configs[4], the per-GPU share): 512 utterances x 30 s of synthetic 16 kHz PCM (the bundled
+recordings tiled with random gains and pauses over a noise floor, pocketsphinx_amd/synth.py; utterance id = seed),
+en-us PTM acoustic model (5126 senones), turtle n-gram LM + dictionary as the reference built them
+(tests/golden/fwdtree_static_en_us_turtle.npz), `-fwdflat no -bestpath no` ("fwdtree only").  A "step" is one
+pass of the whole hot path over that batch, PCM already resident in HBM:
+    PCM -> MFCC -> 1s_c_d_dd features -> PTM senone scores -> phone-loop search -> lexicon-tree Viterbi search
+        -> back-pointer tables -> best exit + backtrace -> hypothesis records (word id, start, end, score) on the host
+through ONE C-ABI call per step (psgpu_decode_first_pass_dev, include/psgpu.h) plus the fetch of the hypothesis records.
+value = frames/s over all ranks; xrt = seconds of compute per second of audio.
+
+N > 1 (weak scaling, utterances shard with no data-path collective inside the decode): rank 0 owns the PCM of the whole
+job, scatters each rank's 512 utterances over RCCL before the timed region; every timed step ends with the gather of the
+fixed-size hypothesis records to rank 0 (pocketsphinx_amd/batch.py).
 
 Extra objects on the line:
-  roofline     HBM roofline of the dominant kernel (this path
-               is VALU-bound by construction, the HBM fraction is small)
-  cpu_baseline the unmodified reference (oracle/_ref, kind "reference") or
-               the C restatement (kind "port") timed single-thread on this
-               host over a bounded sample of the same workload
+  roofline     HBM roofline of the dominant kernel (fwdtree_kernel): algorithmic bytes per launch = sum over frames of
+               156 + 2 * listed senones + 86 * HMM evaluations (SURVEY 8d "full decode, per frame"), counted by the kernel
+               itself, over the kernel's duration from HIP events on its launch stream inside the library
+  cpu_baseline the UNMODIFIED reference (oracle/_ref/ref_decode_bench, kind "reference") decoding a bounded sample of the
+               SAME utterances on one host thread; the same run is the parity check: every sampled utterance's words and
+               frame boundaries from the device must equal the reference's
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import subprocess
@@ -35,434 +42,159 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_UTT, UTT_LEN = 40, 250
-SEED = 20260921
+B_UTT, UTT_SECONDS = 512, 30.0
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GOPS = 78643.2         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-FMA fp32 op rate)
-BYTES_PER_FRAME = 39 * 4 + 5126 * 2          # compulsory HBM bytes per frame
-FLOP_PER_FRAME = 16128 * 13 * 4
+N_SAMPLE = 16                    # utterances decoded by the reference for cpu_baseline + parity
 
 
-def load_tables():
-    z = np.load(os.path.join(ROOT, "tests", "golden", "en_us_ptm_tables.npz"))
+def _npz(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", name))
     return {k: z[k] for k in z.files}
 
 
-def synth_feats(t, n, seed):
-    """N(mu_d, sigma_d) from the model means' statistics."""
-    n_mgau, n_feat, n_den = int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0])
-    fl = int(t["featlen"][0])
-    mean = t["mean"].reshape(n_mgau, n_feat, n_den, fl)
-    mu = mean.mean(axis=(0, 2)).reshape(-1)
-    sd = mean.std(axis=(0, 2)).reshape(-1)
-    rng = np.random.default_rng(seed)
-    return (mu + sd * rng.standard_normal((n, mu.size))).astype(np.float32)
+def _synth_range(args):
+    from pocketsphinx_amd import synth
+    first, n, seconds = args
+    return synth.batch(first, n, seconds)[0]
 
 
-def cpu_baseline(t, feats):
-    """Single-thread CPU time over a bounded sample (the full 10k-frame batch, once)."""
-    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_score_bench")
-    model = os.path.join(ROOT, "oracle", "_ref", "model", "en-us")
-    sample = "%d utterances x %d frames (the full step batch, one pass)" % (N_UTT, UTT_LEN)
-    if os.path.exists(ref_bin) and os.path.exists(os.path.join(model, "means")):
-        with tempfile.NamedTemporaryFile(suffix=".f32", delete=False) as fh:
-            feats.tofile(fh)
-            path = fh.name
-        try:
-            out = subprocess.run([ref_bin, model, path, str(UTT_LEN)], capture_output=True,
-                                 text=True, timeout=600)
-            r = json.loads(out.stdout.strip().splitlines()[-1])
-            return {"value": round(r["frames_per_s"], 2), "unit": "frames/s", "cores": 1,
-                    "kind": "reference", "sample": sample,
-                    "what": "unmodified reference ptm_mgau_frame_eval(compallsen), gcc -O2"}
-        except Exception as e:  # fall through to the port
-            sys.stderr.write("reference baseline failed (%s); using the port\n" % e)
-        finally:
-            os.unlink(path)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import pso
-    o = pso.OraclePTM(t)
-    t0 = time.perf_counter()
-    for u in range(N_UTT):
-        o.score_utt(feats[u * UTT_LEN:(u + 1) * UTT_LEN], reset_hist=True, want_topn=False)
-    dt = time.perf_counter() - t0
-    return {"value": round(feats.shape[0] / dt, 2), "unit": "frames/s", "cores": 1,
-            "kind": "port", "sample": sample, "what": "oracle/ps_oracle.c restatement, gcc -O2"}
+def synth_pcm(first_id, n_utt, seconds):
+    """PCM of utterances first_id .. first_id + n_utt - 1, int16, back to back (a process pool above 64 utterances;
+    called before torch / HIP are initialised)"""
+    from pocketsphinx_amd import synth
+    if n_utt <= 64:
+        return synth.batch(first_id, n_utt, seconds)[0]
+    from concurrent.futures import ProcessPoolExecutor
+    nw = min(32, os.cpu_count() or 1)
+    per = (n_utt + nw - 1) // nw
+    jobs = [(first_id + i, min(per, n_utt - i), seconds) for i in range(0, n_utt, per)]
+    with ProcessPoolExecutor(max_workers=nw) as ex:
+        return np.concatenate(list(ex.map(_synth_range, jobs)))
 
 
-def extras(P, capi, L, model, t, feats_h, dev, sp):
-    """Secondary measurements (never `value`): the PCIe-inclusive rate of the
-    host-buffer entry point and the Viterbi-step kernel's own roofline."""
+def reference_decode(pcm, n_samples, ids):
+    """the compiled reference on the same PCM: [(utt id, json)] + totals; None when oracle/_ref is absent"""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    exe = os.path.join(ref, "ref_decode_bench")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as fh:
+        for i in ids:
+            pcm[i * n_samples:(i + 1) * n_samples].tofile(fh)
+        path = fh.name
+    try:
+        out = subprocess.run([exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", "turtle.lm.bin"),
+                              os.path.join(ref, "data", "turtle.dic"), path, str(n_samples)], capture_output=True, text=True,
+                             timeout=900)
+        lines = [json.loads(ln) for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or not lines or "total" not in lines[-1]:
+            raise RuntimeError("ref_decode_bench rc %d: %s" % (out.returncode, out.stderr[-300:]))
+        return lines[:-1], lines[-1]
+    finally:
+        os.unlink(path)
+
+
+class _DevArray:
+    """a device buffer of the library as a zero-copy torch tensor (torch.as_tensor on __cuda_array_interface__)"""
+
+    def __init__(self, ptr, shape, typestr="<i4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def scorer_extra(P, capi, L, dev, sp, tables):
+    """the senone scorer alone (BASELINE configs[1]: 10,000 synthetic frames, compallsen): round 1's headline"""
     import torch
-    out = {}
-    # (1) host buffers in, host buffers out: psgpu_ptm_score_batch (H2D + 2 kernels + D2H of 102 MB)
-    sc = P.PtmMgau(model)
-    lens = [UTT_LEN] * N_UTT
-    sc.score_utts(feats_h, lens, want_topn=False)
-    t0 = time.perf_counter()
+    n_utt, utt_len = 40, 250
+    T = n_utt * utt_len
+    mean = tables["mean"].reshape(int(tables["n_mgau"][0]), int(tables["n_feat"][0]), int(tables["n_density"][0]), -1)
+    mu = mean.mean(axis=(0, 2)).reshape(-1); sd = mean.std(axis=(0, 2)).reshape(-1)
+    feats_h = (mu + sd * np.random.default_rng(20260921).standard_normal((T, mu.size))).astype(np.float32)
+    model = P.PtmModel(tables)
+    feats = torch.from_numpy(feats_h).to(dev)
+    off = torch.arange(0, T + 1, utt_len, dtype=torch.int32, device=dev)
+    tsc = torch.empty((T, model.n_chain, model.topn), dtype=torch.int32, device=dev)
+    tcw = torch.empty((T, model.n_chain, model.topn), dtype=torch.uint8, device=dev)
+    scr = torch.empty((T, model.n_sen), dtype=torch.int16, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+
+    def step():
+        capi.check(L.psgpu_ptm_score_batch_dev(model.h, p(feats), p(off), n_utt, T, None, None, p(tsc), p(tcw), p(scr), None, 0, sp),
+                   "score_batch_dev")
+    capi.check(L.psgpu_ptm_kernel_timing(model.h, 1), "kernel_timing")
     for _ in range(3):
-        sc.score_utts(feats_h, lens, want_topn=False)
-    out["pcie_inclusive_frames_per_s"] = round(3 * feats_h.shape[0] / (time.perf_counter() - t0), 1)
-    # (2) hmm_vit_kernel over a dense arena larger than L2+MALL: B_v = 86 B per HMM-frame (SURVEY 8d)
-    try:
-        g = np.load(os.path.join(ROOT, "tests", "golden", "hmm_en_us_3st.npz"))
-        n_sen = int(g["n_sen"][0])
-        ctx = P.HmmContext(g["tp"], g["sseq"], n_sen)
-        n_hmm, rng = 8 * 1024 * 1024, np.random.default_rng(1)
-        recs = np.zeros(n_hmm, P.HMM_REC)
-        recs["score"][:, :3] = -rng.integers(0, 200000, (n_hmm, 3))
-        recs["history"][:, :3] = rng.integers(0, 5000, (n_hmm, 3))
-        recs["senid"][:, :3] = rng.integers(0, n_sen, (n_hmm, 3))
-        recs["tmatid_mpx"] = rng.integers(0, g["tp"].shape[0], n_hmm)
-        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(n_hmm, 64)).to(dev)
-        d_scr = torch.from_numpy(np.ascontiguousarray(g["senscr"][0])).to(dev)
-        d_best = torch.full((1,), -0x20000000, dtype=torch.int32, device=dev)
+        step()
+    torch.cuda.synchronize()
+    K = 20
+    ms3 = (C.c_float * 3)()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    capi.check(L.psgpu_ptm_last_kernel_ms(model.h, ms3), "last_kernel_ms")
+    lane, fix, sen = float(ms3[0]), float(ms3[1]), float(ms3[2])
+    bpf, fpf = 39 * 4 + model.n_sen * 2, 16128 * 13 * 4
+    out = {"frames_per_s": round(T * K / dt, 1), "frames": T, "ms_per_step": round(1e3 * dt / K, 4),
+           "kernels_ms": {"ptm_lane_kernel": round(lane, 4), "ptm_chain_kernel(fix-up)": round(fix, 4), "ptm_senone_kernel_f3n4": round(sen, 4)},
+           "roofline": {"bound": "hbm", "kernel": "ptm_lane_kernel", "achieved": round(bpf * T / (lane * 1e-3) / 1e9, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bpf * T / (lane * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "note": "VALU-bound by construction; fp32-VALU fraction of the distance work = %.4f"
+                                % (fpf * T / (lane * 1e-3) / 1e9 / VALU_PEAK_GOPS)},
+           "what": "configs[1]: en-us PTM senone-score-only, 10,000 synthetic frames = 40 utterances x 250, compallsen, topn 4"}
+    return out, model, feats_h
 
-        def step():
-            capi.check(L.psgpu_hmm_vit_eval_dev(ctx.h, C.c_void_p(d_recs.data_ptr()), None, n_hmm, None,
-                                                C.c_void_p(d_scr.data_ptr()), n_sen,
-                                                C.c_void_p(d_best.data_ptr()), sp), "hmm")
-        for _ in range(2):
-            step()
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
-        K = 10
-        L.psgpu_event_record(e0, sp)
-        for _ in range(K):
-            step()
-        L.psgpu_event_record(e1, sp)
-        ms = C.c_float()
-        L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms))
-        per = ms.value / K * 1e-3
-        out["hmm_vit_kernel"] = {
-            "hmm_frames_per_s": round(n_hmm / per, 1), "n_hmm": n_hmm, "ms_per_launch": round(per * 1e3, 4),
-            "roofline": {"bound": "hbm", "achieved": round(86 * n_hmm / per / 1e9, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(86 * n_hmm / per / 1e9 / HBM_PEAK_GBS, 5),
-                         "line_traffic_GBs": round(128 * n_hmm / per / 1e9, 2)}}
-        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
-        ctx.close()
-    except Exception as e:          # secondary measurement: report, do not hide
-        out["hmm_vit_kernel"] = {"error": str(e)}
-    # (3) ms (multi-stream / continuous) scorer, BASELINE configs[3] flavour: en-us forced through the
-    #     ms path (42 codebooks x 3 streams x 128 densities, float mixture weights re-quantised by the
-    #     reference), 64 utterances x 50 frames, compallsen
-    try:
-        z = np.load(os.path.join(ROOT, "tests", "golden", "ms_en_us_tables.npz"))
-        mt = {k: z[k] for k in z.files}
-        ms = P.MsMgau(mt)
-        n_fr = 64 * 50
-        f = torch.from_numpy(np.ascontiguousarray(feats_h[:n_fr])).to(dev)
-        nl = n_fr * ms.n_mgau * ms.n_feat * ms.topn
-        ids = torch.empty(nl, dtype=torch.int32, device=dev)
-        dist = torch.empty(nl, dtype=torch.float32, device=dev)
-        scr = torch.empty((n_fr, ms.n_sen), dtype=torch.int16, device=dev)
 
-        def mstep():
-            capi.check(L.psgpu_ms_score_batch_dev(ms.h, C.c_void_p(f.data_ptr()), n_fr, C.c_void_p(ids.data_ptr()),
-                                                  C.c_void_p(dist.data_ptr()), C.c_void_p(scr.data_ptr()), sp), "ms")
-        mstep()
-        capi.check(L.psgpu_ms_batch_check(ms.h, sp), "ms check")
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
-        K = 5
-        L.psgpu_event_record(e0, sp)
-        for _ in range(K):
-            mstep()
-        L.psgpu_event_record(e1, sp)
-        ms_ = C.c_float()
-        L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
-        out["ms_scorer"] = {"frames_per_s": round(n_fr * K / (ms_.value * 1e-3), 1), "frames": n_fr,
-                            "model": "en-us via ms (42 cb x 3 x 128, topn %d)" % ms.topn,
-                            "ms_per_launch_pair": round(ms_.value / K, 4)}
-        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
-        ms.close()
-    except Exception as e:
-        out["ms_scorer"] = {"error": str(e)}
-    # (4) a fully continuous model of en-us size (BASELINE configs[3]: the only bundled continuous model,
-    #     an4_ci_cont, has 102 one-density codebooks): 5126 senones x 16 densities x 39 dims, top-4,
-    #     random parameters with the value ranges of real precomputed tables, 64 utterances x 250 frames
-    try:
-        rng = np.random.default_rng(9)
-        n_sen, n_den, LL = 5126, 16, 39
-        mt = dict(n_mgau=np.array([n_sen]), n_feat=np.array([1]), n_density=np.array([n_den]),
-                  n_sen=np.array([n_sen]), max_topn=np.array([4]), aw=np.array([1]),
-                  featlen=np.array([LL], np.int32),
-                  mean=rng.standard_normal(n_sen * n_den * LL).astype(np.float32),
-                  var=np.floor(np.exp(rng.uniform(0, 12, n_sen * n_den * LL))).astype(np.float32),
-                  det=np.floor(rng.uniform(-500000, 400000, (n_sen, 1, n_den))).astype(np.float32),
-                  pdf=rng.integers(0, 256, (n_sen, 1, n_den)).astype(np.uint8),
-                  sen2mgau=np.arange(n_sen, dtype=np.uint32), logadd=t["logadd8"],
-                  logadd_size=np.array([int(t["logadd8"].size)]), logadd_width=np.array([1]),
-                  log_zero=np.array([-524288]))
-        ms = P.MsMgau(mt)
-        n_fr = 64 * 250                                      # BASELINE configs[3]: a batch of 64 utterances
-        f = torch.from_numpy(rng.standard_normal((n_fr, LL)).astype(np.float32)).to(dev)
-        nl = n_fr * ms.n_mgau * ms.n_feat * ms.topn
-        ids = torch.empty(nl, dtype=torch.int32, device=dev)
-        dist = torch.empty(nl, dtype=torch.float32, device=dev)
-        scr = torch.empty((n_fr, ms.n_sen), dtype=torch.int16, device=dev)
+def child_extras(out):
+    """measurements that run in CHILD processes with a time limit (a fault or a slow case cannot take the headline with it)"""
+    t_children = time.perf_counter()
 
-        def cstep():
-            capi.check(L.psgpu_ms_score_batch_dev(ms.h, C.c_void_p(f.data_ptr()), n_fr, None, None,
-                                                  C.c_void_p(scr.data_ptr()), sp), "ms")
-        cstep()
-        capi.check(L.psgpu_ms_batch_check(ms.h, sp), "ms check")
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
-        K = 5
-        L.psgpu_event_record(e0, sp)
-        for _ in range(K):
-            cstep()
-        L.psgpu_event_record(e1, sp)
-        ms_ = C.c_float()
-        L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
-        flop = n_sen * n_den * LL * 4
-        out["ms_continuous"] = {"frames_per_s": round(n_fr * K / (ms_.value * 1e-3), 1), "frames": n_fr,
-                                "model": "synthetic .cont. 5126 senones x 16 densities x 39 dims, topn 4",
-                                "ms_per_launch_pair": round(ms_.value / K, 4),
-                                "distance_tflops": round(flop * n_fr * K / (ms_.value * 1e-3) / 1e12, 2)}
-        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
-        ms.close()
-    except Exception as e:
-        out["ms_continuous"] = {"error": str(e)}
-    # (5) the whole device-side chain from audio: synthetic 16 kHz PCM (SURVEY 8d config 5: white noise
-    #     plus a tiled tone burst, int16) -> MFCC front end -> 1s_c_d_dd features with batch CMN -> PTM
-    #     senone scores, same batch shape as the headline (40 utterances x 250 frames)
-    try:
-        g = np.load(os.path.join(ROOT, "tests", "golden", "mfcc_en_us_goforward.npz"))
-        fe = P.FrontEnd({k: g[k] for k in g.files})
-        par = [int(v) for v in g["par"]]
-        fsz, fsh = par[0], par[1]
-        n_samp = fsz + fsh * (UTT_LEN - 2)                  # UTT_LEN frames including the tail frame
-        rng = np.random.default_rng(11)
-        tt = np.arange(n_samp)
-        pcm_h = np.concatenate([(2000 * rng.standard_normal(n_samp) + 6000 * np.sin(2 * np.pi * (200 + 37 * u) * tt / 16000.0)
-                                 * (np.sin(2 * np.pi * 3 * tt / 16000.0) > 0)).astype(np.int16) for u in range(N_UTT)])
-        soff = (np.arange(N_UTT + 1, dtype=np.int64) * n_samp)
-        assert fe.n_frames(n_samp) == UTT_LEN
-        Tn = N_UTT * UTT_LEN
-        pcm = torch.from_numpy(pcm_h).to(dev)
-        cep = torch.empty((Tn, fe.out_dim), dtype=torch.float32, device=dev)
-        ft = torch.empty((Tn, 3 * fe.out_dim), dtype=torch.float32, device=dev)
-        foff = torch.empty(N_UTT + 1, dtype=torch.int32, device=dev)
-        tsc = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.int32, device=dev)
-        tcw = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.uint8, device=dev)
-        scr = torch.empty((Tn, model.n_sen), dtype=torch.int16, device=dev)
-        L.psgpu_fe_process_utts_dev.argtypes = [C.c_void_p] * 10
-        sarr = soff.ctypes.data_as(C.c_void_p)
-
-        def fe_step():
-            capi.check(L.psgpu_fe_process_utts_dev(fe.h, C.c_void_p(pcm.data_ptr()), sarr, N_UTT, None, None,
-                                                   C.c_void_p(cep.data_ptr()), C.c_void_p(foff.data_ptr()), None, sp), "fe")
-
-        def chain_step():
-            fe_step()
-            capi.check(L.psgpu_feat_1s_c_d_dd_dev(C.c_void_p(cep.data_ptr()), C.c_void_p(foff.data_ptr()), N_UTT,
-                                                  fe.out_dim, C.c_void_p(ft.data_ptr()), sp), "feat")
-            capi.check(L.psgpu_ptm_score_batch_dev(model.h, C.c_void_p(ft.data_ptr()), C.c_void_p(foff.data_ptr()), N_UTT, Tn,
-                                                   None, None, C.c_void_p(tsc.data_ptr()), C.c_void_p(tcw.data_ptr()),
-                                                   C.c_void_p(scr.data_ptr()), None, 0, sp), "score")
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
-        res = {}
-        for name, fn in (("front_end", fe_step), ("pcm_to_scores", chain_step)):
-            fn(); fn()
-            K = 20
-            L.psgpu_event_record(e0, sp)
-            for _ in range(K):
-                fn()
-            L.psgpu_event_record(e1, sp)
-            ms_ = C.c_float()
-            L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
-            res[name] = ms_.value / K
-        out["pcm_pipeline"] = {"frames": Tn, "audio_s": round(N_UTT * n_samp / 16000.0, 2),
-                               "front_end_ms": round(res["front_end"], 4),
-                               "front_end_frames_per_s": round(Tn / (res["front_end"] * 1e-3), 1),
-                               "pcm_to_scores_ms": round(res["pcm_to_scores"], 4),
-                               "pcm_to_scores_frames_per_s": round(Tn / (res["pcm_to_scores"] * 1e-3), 1),
-                               "xrt": round(res["pcm_to_scores"] * 1e-3 / (N_UTT * n_samp / 16000.0), 9),
-                               "data": "synthetic 16 kHz int16 PCM (noise + gated tone), en-us front-end tables"}
-        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
-        fe.close()
-    except Exception as e:
-        out["pcm_pipeline"] = {"error": str(e)}
-    # (6) semi-continuous scorer, batched entry: tidigits model (4 streams x 256 densities, 4-bit clustered
-    #     weights), 512 utterances x 100 frames (one wave per (utterance, stream) walks its frames in order)
-    try:
-        z = np.load(os.path.join(ROOT, "tests", "golden", "semi_tidigits_tables.npz"))
-        g = np.load(os.path.join(ROOT, "tests", "golden", "senlog_tidigits_default.npz"))
-        sm = P.SemiMgau({k: z[k] for k in z.files})
-        n_u, u_len = 512, 100
-        rng = np.random.default_rng(4)
-        fh = np.ascontiguousarray(g["call_feat"][rng.integers(0, g["call_feat"].shape[0], n_u * u_len)], np.float32)
-        f = torch.from_numpy(fh).to(dev)
-        so = torch.arange(0, n_u * u_len + 1, u_len, dtype=torch.int32, device=dev)
-        scr = torch.empty((n_u * u_len, sm.n_sen), dtype=torch.int16, device=dev)
-
-        def sstep():
-            capi.check(L.psgpu_semi_score_batch_dev(sm.m, C.c_void_p(f.data_ptr()), C.c_void_p(so.data_ptr()), n_u,
-                                                    n_u * u_len, C.c_void_p(scr.data_ptr()), sp), "semi")
-        sstep(); sstep()
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        L.psgpu_event_create(C.byref(e0)); L.psgpu_event_create(C.byref(e1))
-        K = 5
-        L.psgpu_event_record(e0, sp)
-        for _ in range(K):
-            sstep()
-        L.psgpu_event_record(e1, sp)
-        ms_ = C.c_float()
-        L.psgpu_event_elapsed_ms(e0, e1, C.byref(ms_))
-        out["semi_scorer"] = {"frames_per_s": round(n_u * u_len * K / (ms_.value * 1e-3), 1), "frames": n_u * u_len,
-                              "utterances": n_u, "model": "tidigits s2_semi (4 x 256, 4-bit weights, %d senones)" % sm.n_sen,
-                              "ms_per_launch_pair": round(ms_.value / K, 4)}
-        L.psgpu_event_destroy(e0); L.psgpu_event_destroy(e1)
-        sm.close()
-    except Exception as e:
-        out["semi_scorer"] = {"error": str(e)}
-    # (7) the whole first pass on the device: PCM -> MFCC -> features -> PTM scores (un-normalised) -> phone-loop
-    #     search -> lexicon-tree search -> back-pointer tables, 512 utterances (the bundled goforward recording,
-    #     2.8 s each, with a different gain per utterance) in one batch; turtle LM / dictionary as the reference built them
-    try:
-        gm = np.load(os.path.join(ROOT, "tests", "golden", "mfcc_en_us_goforward.npz"))
-        gt = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_trace_goforward.npz"))
-        gs = np.load(os.path.join(ROOT, "tests", "golden", "fwdtree_static_en_us_turtle.npz"))
-        st = {k: gs[k] for k in gs.files}
-        B = 512
-        fe = P.FrontEnd({k: gm[k] for k in gm.files})
-        srch = P.FwdtreeSearch(st, gt["par"])
-        ctx = P.HmmContext(st["tp"], st["sseq"], model.n_sen)
-        pcm1 = gm["pcm"].astype(np.float32)
-        rng = np.random.default_rng(3)
-        pcm_h = np.concatenate([(pcm1 * g_).astype(np.int16) for g_ in rng.uniform(0.6, 1.0, B)])
-        ns = pcm1.size
-        Tu = fe.n_frames(ns); Tn = B * Tu
-        soff = (np.arange(B + 1, dtype=np.int64) * ns)
-        pcm = torch.from_numpy(pcm_h).to(dev)
-        cep = torch.empty((Tn, fe.out_dim), dtype=torch.float32, device=dev)
-        ft = torch.empty((Tn, 3 * fe.out_dim), dtype=torch.float32, device=dev)
-        foff = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        tsc = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.int32, device=dev)
-        tcw = torch.empty((Tn, model.n_chain, model.topn), dtype=torch.uint8, device=dev)
-        rows = torch.empty((Tn, model.n_sen), dtype=torch.int16, device=dev)
-        bst = torch.empty(Tn, dtype=torch.int32, device=dev)
-        n_ci, window = int(gt["pl_par"][0]), int(gt["pl_par"][1])
-
-        class PlPar(C.Structure):
-            _fields_ = [("n_phones", C.c_int32), ("window", C.c_int32), ("beam", C.c_int32), ("pbeam", C.c_int32),
-                        ("pip", C.c_int32), ("penalty_weight", C.c_double)]
-        ppar = PlPar(n_ci, window, int(gt["pl_par"][2]), int(gt["pl_par"][3]), int(gt["pl_par"][4]), float(gt["pl_weight"][0]))
-        fl = np.zeros(model.n_sen, bool); fl[st["sseq"][gt["pl_ssid"]].reshape(-1)] = True
-        cil, last = [], 0
-        for s_ in np.nonzero(fl)[0]:
-            while s_ - last > 255:
-                last += 255; cil.append(last)
-            cil.append(int(s_)); last = int(s_)
-        d_ssid = torch.from_numpy(gt["pl_ssid"].astype(np.uint16).view(np.int16)).to(dev)
-        d_tm = torch.from_numpy(gt["pl_tmat"].astype(np.int16)).to(dev)
-        d_ci = torch.from_numpy(np.array(cil, np.uint16).view(np.int16)).to(dev)
-        pen = torch.empty((Tn, n_ci), dtype=torch.int32, device=dev)
-        now = torch.empty((Tn, n_ci), dtype=torch.int32, device=dev)
-        pstate = torch.empty((Tn, n_ci, 8), dtype=torch.int32, device=dev)
-        bp_cap, bss_cap = 4096, 65536
-        bp = torch.zeros((B, 10, bp_cap), dtype=torch.int32, device=dev); bss = torch.zeros((B, bss_cap), dtype=torch.int32, device=dev)
-        idx = torch.zeros((B, Tu + 2), dtype=torch.int32, device=dev); stp = torch.zeros((B, Tu, 4), dtype=torch.int32, device=dev)
-        res = torch.zeros((B, 8), dtype=torch.int32, device=dev)
-        L.psgpu_fe_process_utts_dev.argtypes = [C.c_void_p] * 10
-        L.psgpu_phone_loop_run_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_void_p]
-        q = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
-        tm = {}
-
-        def decode_step():
-            capi.check(L.psgpu_fe_process_utts_dev(fe.h, q(pcm), soff.ctypes.data_as(C.c_void_p), B, None, None, q(cep), q(foff),
-                                                   None, sp), "fe")
-            capi.check(L.psgpu_feat_1s_c_d_dd_dev(q(cep), q(foff), B, fe.out_dim, q(ft), sp), "feat")
-            capi.check(L.psgpu_ptm_score_batch_dev(model.h, q(ft), q(foff), B, Tn, None, None, q(tsc), q(tcw), q(rows), q(bst),
-                                                   1, sp), "score")
-            capi.check(L.psgpu_phone_loop_run_dev(ctx.h, C.byref(ppar), q(d_ssid), q(d_tm), q(d_ci), len(cil), q(rows),
-                                                  model.n_sen, None, q(foff), B, Tn, q(pen), q(now), q(pstate), sp), "phone loop")
-            capi.check(L.psgpu_fwdtree_search_dev(srch.h, q(rows), C.c_int64(model.n_sen), q(pen), q(foff), B, Tu, bp_cap, bss_cap,
-                                                  q(bp), q(bss), q(idx), q(stp), q(res), 1, int(gt["pl_par"][5]), sp), "search")
-        decode_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        K = 3
-        for _ in range(K):
-            decode_step()
-        torch.cuda.synchronize()
-        dts = (time.perf_counter() - t0) / K
-        rh = res.cpu().numpy()
-        # every utterance must come out as the same sentence (gain does not change the words)
-        r0 = dict(bp=bp[0, :, :int(rh[0, 0])].cpu().numpy().T, bp_table_idx=idx[0].cpu().numpy(), n_frame=int(rh[0, 2]))
-        _, words0 = P.backtrace(r0, int(gt["par"][20]))
-        same = 0
-        for u_ in range(0, B, 37):
-            ru = dict(bp=bp[u_, :, :int(rh[u_, 0])].cpu().numpy().T, bp_table_idx=idx[u_].cpu().numpy(), n_frame=int(rh[u_, 2]))
-            same += [w for w, _, _ in P.backtrace(ru, int(gt["par"][20]))[1]] == [w for w, _, _ in words0]
-        out["device_decode"] = {"utterances": B, "frames": Tn, "audio_s": round(B * ns / 16000.0, 1), "seconds": round(dts, 5),
-                                "frames_per_s": round(Tn / dts, 1), "xrt": round(dts / (B * ns / 16000.0), 8),
-                                "status_nonzero": int((rh[:, 3] != 0).sum()), "words_in_hyp": len(words0),
-                                "sampled_hyps_equal_first": "%d/%d" % (same, len(range(0, B, 37))),
-                                "what": "PCM -> MFCC -> features -> PTM scores -> phone loop -> lexicon-tree search -> "
-                                        "back-pointer tables, all on the device (turtle LM, 512 x goforward)"}
-        srch.close(); ctx.close(); fe.close()
-    except Exception as e:
-        out["device_decode"] = {"error": str(e)}
-    # (8), (9): kernels written after the round's GPU minutes were spent (checked on the CPU only, tests/hostsim): each runs
-    #     in a CHILD process with a time limit, so that a fault in one of them cannot take this process -- and the headline
-    #     line -- with it.  PSGPU_BENCH_NO_CHILD=1 skips them.
-    if not os.environ.get("PSGPU_BENCH_NO_CHILD"):
-        import subprocess
-
-        t_children = time.perf_counter()
-
-        def child(key, argv, env, limit):
-            left = 300.0 - (time.perf_counter() - t_children)        # all children together: five minutes at most
-            if left < 20.0:
-                out[key] = {"skipped": "time budget of the child-process extras used up"}
-                return
-            limit = min(limit, left)
-            try:
-                r = subprocess.run([sys.executable] + argv, env=dict(os.environ, **env), capture_output=True, text=True, timeout=limit)
-                lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
-                if r.returncode != 0 or not lines:
-                    out[key] = {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
-                elif lines[-1].lstrip().startswith("{"):
-                    out[key] = json.loads(lines[-1])
-                else:
-                    out[key] = {"lines": lines[-6:]}
-            except Exception as e:
-                out[key] = {"error": str(e)[-400:]}
-        # (8) both search passes on the device, 256 utterances from PCM
-        child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 150)
-        # (9) the tree search on the full cmudict task (134,865 words), large-vocabulary formulation (DESIGN 7.2);
-        #     the default formulation measured 1.19 s for one utterance, 5.5 k frames/s at 32 per launch (profiles/r01i_*)
-        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
-            child("search_cmudict_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
-                  {"SB_CASE": "cmudict", "SB_MODE": "active_list", "SB_BATCHES": "1,32", "SB_REPS": "1"}, 200)
-        # (9a) the same formulation on the tasks the default one was measured on (DESIGN 4: 3.6 M frames/s at 512 utterances,
-        #      turtle; 1.5 M on the 715-word task): the A/B that decides which becomes the default
-        child("search_turtle_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
-              {"SB_CASE": "goforward", "SB_MODE": "active_list", "SB_BATCHES": "512,1024", "SB_REPS": "2"}, 120)
-        child("search_medium_active_list", [os.path.join(ROOT, "tools", "search_bench.py")],
-              {"SB_CASE": "medium_goforward", "SB_MODE": "active_list", "SB_BATCHES": "512", "SB_REPS": "2"}, 120)
-    return out
+    def child(key, argv, env, limit):
+        left = 240.0 - (time.perf_counter() - t_children)        # all children together: four minutes at most
+        if left < 20.0:
+            out[key] = {"skipped": "time budget of the child-process extras used up"}
+            return
+        try:
+            r = subprocess.run([sys.executable] + argv, env=dict(os.environ, **env), capture_output=True, text=True,
+                               timeout=min(limit, left))
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+            if r.returncode != 0 or not lines:
+                out[key] = {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+            elif lines[-1].lstrip().startswith("{"):
+                out[key] = json.loads(lines[-1])
+            else:
+                out[key] = {"lines": lines[-6:]}
+        except Exception as e:
+            out[key] = {"error": str(e)[-400:]}
+    sb = os.path.join(ROOT, "tools", "search_bench.py")
+    child("search_only_turtle", [sb], {"SB_CASE": "goforward", "SB_BATCHES": "512,1024", "SB_REPS": "2"}, 100)
+    child("search_only_medium", [sb], {"SB_CASE": "medium_goforward", "SB_BATCHES": "512", "SB_REPS": "2"}, 100)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
+        # the full cmudict task (134,865 words): single-thread reference ~1.2 k frames/s on this decode (profiles/r01i_*)
+        child("search_only_cmudict", [sb], {"SB_CASE": "cmudict", "SB_BATCHES": "1,32,256", "SB_REPS": "1"}, 200)
+    child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 120)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--utts", type=int, default=B_UTT, help="utterances per GPU (default: the configs[4] share, 512)")
+    ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (clean per-kernel profiles)")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    B, n_samp = args.utts, int(round(args.seconds * 16000))
+
+    # rank 0 owns the PCM of the whole job (synthesised before torch / HIP start: the pool forks)
+    pcm_all = synth_pcm(0, B * world, args.seconds) if rank == 0 else None
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -473,111 +205,181 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import pocketsphinx_amd as P
-    from pocketsphinx_amd import capi
+    from pocketsphinx_amd import capi, batch as pbatch
     L = capi.lib()
     capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
-    t = load_tables()
-    model = P.PtmModel(t)
-
-    T = N_UTT * UTT_LEN
-    feats_h = synth_feats(t, T, SEED + rank)
-    feats = torch.from_numpy(feats_h).to(dev)
-    off = torch.arange(0, T + 1, UTT_LEN, dtype=torch.int32, device=dev)
-    n_chain, topn, n_sen = model.n_chain, model.topn, model.n_sen
-    topn_sc = torch.empty((T, n_chain, topn), dtype=torch.int32, device=dev)
-    topn_cw = torch.empty((T, n_chain, topn), dtype=torch.uint8, device=dev)
-    senscr = torch.empty((T, n_sen), dtype=torch.int16, device=dev)
+    tables = _npz("en_us_ptm_tables.npz")
+    gt = _npz("fwdtree_trace_goforward.npz")
+    pipe = P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+    pipe.stage_timing(True)
     stream = torch.cuda.current_stream().cuda_stream
     sp = C.c_void_p(stream)
 
-    def p(x):
-        return C.c_void_p(x.data_ptr())
+    # ---- inputs resident in HBM: this rank's 512 utterances (scattered from rank 0 over RCCL when N > 1)
+    pcm = torch.empty(B * n_samp, dtype=torch.int16, device=dev)
+    if dist is None:
+        pcm.copy_(torch.from_numpy(pcm_all))
+    else:
+        pbatch.scatter_pcm(pcm, pcm_all, B * n_samp, device=dev)
+    soff = np.arange(B + 1, dtype=np.int64) * n_samp
+    torch.cuda.synchronize()
+
+    hyp_rec = None
 
     def step():
-        capi.check(L.psgpu_ptm_score_batch_dev(model.h, p(feats), p(off), N_UTT, T, None, None,
-                                               p(topn_sc), p(topn_cw), p(senscr), None, 0, sp), "score_batch_dev")
+        """one pass of the hot path over the batch + the hypothesis records on the host (rank 0: of every rank)"""
+        pipe.run_dev(pcm, soff, stream)
+        if dist is None:
+            return pipe.fetch()
+        v = pipe.view()
+        hn = torch.as_tensor(_DevArray(v.hyp_n_dev, (B, 4)), device=dev)
+        hy = torch.as_tensor(_DevArray(v.hyp_dev, (B, pipe.max_words, 4)), device=dev)
+        g_hn = pbatch.gather_records(hn, device=dev)
+        g_hy = pbatch.gather_records(hy, device=dev)
+        if rank == 0:
+            return g_hn.cpu().numpy(), g_hy.cpu().numpy(), None
+        torch.cuda.synchronize()
+        return None
 
-    # per-kernel HIP events are recorded inside the library on the launch stream
-    # (main top-N kernel | exact fix-up launch | senone kernel)
-    capi.check(L.psgpu_ptm_kernel_timing(model.h, 1), "kernel_timing")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    k_ms = np.zeros((args.steps, 3), np.float64)
-    ms3 = (C.c_float * 3)()
+    stage = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step()
-        if k % 8 == 7 or k == args.steps - 1:
-            # read the events of the latest step (a sample of the timed steps; waits only on
-            # work that is already queued, nothing extra is launched)
-            capi.check(L.psgpu_ptm_last_kernel_ms(model.h, ms3), "last_kernel_ms")
-            k_ms[k] = (ms3[0], ms3[1], ms3[2])
+        hyp_rec = step()
+        stage.append(pipe.last_stage_ms())      # events of this step's launches (already complete: step() waited)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        from pocketsphinx_amd import batch as _batch
-        dt = _batch.max_over_ranks(dt, device=dev)
-    sampled = k_ms[k_ms.sum(axis=1) > 0]
-    lane_ms, fix_ms, sen_ms = [float(x) for x in sampled.mean(axis=0)]
-    topn_ms = lane_ms
+        dt = pbatch.max_over_ranks(dt, device=dev)
 
-    # sanity: the benchmarked output is the parity-tested one (cheap spot check)
-    chk = int(senscr[:UTT_LEN].to(torch.int32).min(dim=1).values.abs().sum().item())
-    if chk != 0 and not os.environ.get("PSGPU_ABLATE"):
-        raise SystemExit("bench output failed the normalisation invariant")
-
+    # this rank's own results (tables' sizes, status, workload counters)
+    hn_l, hyp_l, res_l = pipe.fetch()
+    if int((res_l[:, 3] != 0).sum()):
+        raise SystemExit("bench: %d utterances ended with a full back-pointer table / score stack" % int((res_l[:, 3] != 0).sum()))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    frames_total = T * world * args.steps
-    fps = frames_total / dt
-    dom_name, dom_ms = (("ptm_lane_kernel", topn_ms) if topn_ms >= sen_ms
-                        else ("ptm_senone_kernel", sen_ms))
-    achieved = BYTES_PER_FRAME * T / (dom_ms * 1e-3) / 1e9
+    frames_rank = int(res_l[:, 2].sum())
+    frames_step = frames_rank * world             # every rank decodes the same number of equally long utterances
+    fps = frames_step * args.steps / dt
+    audio_s = B * world * args.seconds
+    st_mean = {k: float(np.mean([s[k] for s in stage])) for k in stage[0]}
+    evals = int(res_l[:, 5].astype(np.int64).sum() + (res_l[:, 6].astype(np.int64) << 32).sum())
+    senones = int(res_l[:, 7].astype(np.int64).sum())
+    alg_bytes = 156 * frames_rank + 2 * senones + 86 * evals
+    search_s = st_mean["search"] * 1e-3
+    workload = ("configs[4] per-GPU share: %d utterances x %g s synthetic 16 kHz PCM, en-us PTM (5126 senones) + turtle n-gram LM, "
+                "fwdtree only (-fwdflat no -bestpath no), PCM -> hypotheses on the device" % (B, args.seconds))
     traffic = None
-    import glob
     for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
-        try:       # newest committed PMC pass (tools/gpu_round.sh + tools/prof_collect.py)
-            k = [v for n, v in json.load(open(tpath)).items() if dom_name.startswith(n) or n.startswith(dom_name)]
-            if k and k[0].get("hbm_bytes_per_launch"):
-                traffic = round(k[0]["hbm_bytes_per_launch"])
+        try:       # the newest committed PMC pass OF THIS WORKLOAD (tools/prof_collect.py records what it profiled)
+            j = json.load(open(tpath))
+            k = j.get("fwdtree_kernel")
+            if k and j.get("_workload", {}).get("utterances") == B and j["_workload"].get("seconds") == args.seconds \
+                    and k.get("hbm_bytes_per_launch"):
+                traffic = round(k["hbm_bytes_per_launch"])
                 break
         except Exception:
             continue
     line = {
-        "metric": "frames/sec senone scoring, en-us PTM 5126 senones (bit-exact int16)",
+        "metric": "frames/sec + xRT decode, en-us PTM 5126-senone n-gram fwdtree (device first pass, PCM -> hypotheses)",
         "value": round(fps, 1), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic features; en-us PTM model tables (reference init dump)",
-        "config": {"workload": "configs[1]: en-us PTM senone-score-only, 10,000 synthetic frames/GPU "
-                               "= 40 utterances x 250 frames, compallsen, topn 4",
-                   "frames_per_step_per_gpu": T, "utterances": N_UTT, "parallelism": "utt-shard x%d" % world},
-        "xrt": round((dt / args.steps) / (T * world / 100.0), 8),
-        "kernels_ms": {"ptm_lane_kernel": round(lane_ms, 4), "ptm_chain_kernel(fix-up)": round(fix_ms, 4),
-                       "ptm_senone_kernel_f3n4": round(sen_ms, 4)},
-        "roofline": {"bound": "hbm", "kernel": dom_name,
-                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "note": "VALU/LDS-bound by construction (SURVEY 8d); fp32-VALU fraction of the "
-                             "distance work = %.4f" % (FLOP_PER_FRAME * T / (topn_ms * 1e-3) / 1e9 / VALU_PEAK_GOPS)},
+        "dtype": "f32 (Gaussian distances) + int32 (log-domain scores, Viterbi)",
+        "data": "synthetic: bundled recordings tiled with random gains / pauses over a noise floor; model, LM and dictionary tables "
+                "as the reference built them",
+        "config": {"workload": workload, "utterances_per_gpu": B, "seconds_per_utterance": args.seconds,
+                   "frames_per_step_per_gpu": frames_rank, "lm": "turtle.lm.bin (115 dictionary words)",
+                   "parallelism": "utt-shard x%d (rank 0 scatters PCM, gathers hypothesis records)" % world},
+        "xrt": round((dt / args.steps) / audio_s, 9),
+        "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
+        "workload_counts": {"hmm_evals_per_frame": round(evals / max(frames_rank, 1), 2),
+                            "listed_senones_per_frame": round(senones / max(frames_rank, 1), 2),
+                            "back_pointers_per_utt": round(float(res_l[:, 0].mean()), 1),
+                            "words_per_hyp": round(float(hn_l[:, 0].mean()), 1),
+                            "lds_layout": bool(pipe.search.lds_layout())},
+        "roofline": {"bound": "hbm", "kernel": "fwdtree_kernel", "achieved": round(alg_bytes / search_s / 1e9, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(alg_bytes / search_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(st_mean["search"], 3),
+                     "note": "a recurrence over frames: one workgroup per utterance, bound by the latency of one frame's dependent "
+                             "steps, not by bytes (DESIGN.md 4); bytes = sum over frames of 156 + 2 x listed senones + 86 x HMM "
+                             "evaluations (SURVEY 8d), counted by the kernel"},
     }
-    if world > 1:
-        os.environ["PSGPU_BENCH_NO_CHILD"] = "1"        # the child-process extras are single-GPU measurements: N = 1 only
-    line["extra"] = {} if args.no_extras else extras(P, capi, L, model, t, feats_h, dev, sp)
+    # ---- cpu_baseline + parity: the compiled reference on a sample of the same utterances
     if not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(t, feats_h)
-        line["speedup_vs_cpu_1thread"] = round(fps / world / line["cpu_baseline"]["value"], 1)
+        ids = sorted(set(int(i) for i in np.linspace(0, B - 1, min(N_SAMPLE, B))))
+        ref = reference_decode(pcm_all, n_samp, ids)
+        if ref is None:
+            line["cpu_baseline"] = None
+            line["parity"] = {"checked": 0, "note": "oracle/_ref/ref_decode_bench not built: parity unchecked in this run"}
+        else:
+            utts, tot = ref
+            bad = []
+            for i, r in zip(ids, utts):
+                got = [tuple(int(v) for v in hyp_l[i, k, :3]) for k in range(int(hn_l[i, 0]))]
+                want = [(s[1], s[2], s[3]) for s in r["seg"]]
+                if got != want or int(hn_l[i, 1]) != r["score"] or int(res_l[i, 2]) != r["frames"]:
+                    bad.append(i)
+            line["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                    "xrt": tot["xrt"],
+                                    "sample": "%d of the step's %d utterances (%d frames, %.1f s of CPU): ps_start_utt / "
+                                              "ps_process_raw(full_utt) / ps_end_utt per utterance, -fwdflat no -bestpath no"
+                                              % (len(ids), B, tot["frames"], tot["cpu_s"]),
+                                    "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2), one thread"}
+            line["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad,
+                              "what": "word ids, start / end frames, path score and frame count of each sampled utterance: device vs "
+                                      "the reference decoding the same PCM"}
+            line["speedup_vs_cpu_1thread"] = round(fps / world / tot["frames_per_s"], 1)
+            if bad:
+                print(json.dumps(line))
+                raise SystemExit("bench: device hypotheses differ from the reference's on utterances %r" % bad)
+    # ---- extras (N = 1 only)
+    extra = {}
+    if not args.no_extras and world == 1:
+        pipe.close()
+        del pcm
+        torch.cuda.empty_cache()
+        try:
+            # configs[2]: one 60 s utterance
+            p1 = P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+            from pocketsphinx_amd import synth
+            u60 = torch.from_numpy(synth.utterance(7, 60.0)).to(dev)
+            o60 = np.array([0, u60.numel()], np.int64)
+            p1.run_dev(u60, o60, stream); p1.fetch()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                p1.run_dev(u60, o60, stream); hn1, _, res1 = p1.fetch()
+            d1 = (time.perf_counter() - t1) / 3
+            extra["single_utterance_60s"] = {"frames": int(res1[0, 2]), "seconds": round(d1, 5), "frames_per_s": round(int(res1[0, 2]) / d1, 1),
+                                             "xrt": round(d1 / 60.0, 7), "words": int(hn1[0, 0]),
+                                             "what": "configs[2]: one 60 s utterance through the same pipeline (latency of one workgroup's "
+                                                     "recurrence over 6000 frames)"}
+            p1.close()
+        except Exception as e:
+            extra["single_utterance_60s"] = {"error": str(e)[-300:]}
+        try:
+            sc, model, feats_h = scorer_extra(P, capi, L, dev, sp, tables)
+            extra["senone_scoring"] = sc
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_extras
+            extra.update(bench_extras.extras(P, capi, L, model, tables, feats_h, dev, sp))
+            model.close()
+        except Exception as e:
+            extra["senone_scoring_error"] = str(e)[-300:]
+        if not os.environ.get("PSGPU_BENCH_NO_CHILD"):
+            child_extras(extra)
+    line["extra"] = extra
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -526,7 +526,8 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m);
  * bss_dev + u*bss_cap, bp_table_idx at idx_dev + u*(max_frames + 2), per-frame
  * {best_score, last_phone_best_score, bpidx, n_active_chan} at step_dev + u*max_frames*4, and
  * result_dev + u*8 = {n back-pointers, score-stack length, frames searched, status (1: a table
- * was full), best_score of the last frame (ngs->best_score)}.  Asynchronous on `stream`; the work
+ * was full), best_score of the last frame (ngs->best_score), HMM evaluations of the utterance (low, high
+ * word), listed senones summed over its frames (raw_scores mode)}.  Asynchronous on `stream`; the work
  * slab belongs to the handle, so one search at a time per handle.
  * raw_scores = 1: senscr_dev holds the scorer's UN-normalised rows (PSGPU_PTM_RAW_SCORES) and
  * penalties_dev the phone loop's output per phone-loop frame (psgpu_phone_loop_run_dev): the kernel
@@ -636,6 +637,15 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
                                 void *stream);
 /* the same from host buffers: pcm[u][0..n[u]) are staged and copied to the device first */
 int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const size_t n[], int32_t n_utt, void *stream);
+/* entering after the front end: feat [total][3 * cepsize] HOST feature vectors as feat_s2mfc2feat_live leaves them
+ * (acmod->feat_buf), frame_off [n_utt + 1] HOST.  For a binding whose host has already run the reference's own
+ * front end (ps_process_raw -> ps_search_step per frame): both arrays are copied before the call returns. */
+int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int32_t *frame_off, int32_t n_utt, void *stream);
+/* Per-stage timing of psgpu_decode_first_pass_dev / psgpu_decode_first_pass: when enabled, HIP events are recorded on
+ * the launch stream between the stages; ms[6] = front end, dynamic features, scorer (its three kernels), phone loop
+ * (two kernels), lexicon-tree search kernel, backtrace kernel of the latest call (waits for it). */
+int psgpu_decode_stage_timing(psgpu_decode_t *d, int32_t enable);
+int psgpu_decode_last_stage_ms(psgpu_decode_t *d, float ms[6]);
 /* what the last call left on the device (valid until the next call), for a second pass or a custom read-out:
  * tables as psgpu_fwdtree_search_dev writes them with the strides bp_cap / bss_cap / max_frames + 2,
  * hypotheses as psgpu_fwdtree_backtrace_dev writes them */

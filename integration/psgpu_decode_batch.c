@@ -24,6 +24,7 @@
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
 #include "psgpu_phone_loop_shim.h"
+#include "psgpu_device_decode.h"
 #include "psgpu_decode_batch.h"
 #ifdef PSGPU_SEARCH_HOOKS
 #include "psgpu_search_hooks.h"
@@ -35,6 +36,7 @@ struct psgpu_batch_s {
     int device;                    /* the device the decoders' psgpu objects live on */
     ps_decoder_t **ps;
     psgpu_fe_t *fe;                /* batch front end (tables of worker 0's fe_t) */
+    psgpu_device_decode_t *dd;     /* PSGPU_BATCH_DEVICE_FIRST_PASS: the device pipeline, bound to worker 0's decoder */
     int out_dim;
     /* one call's work */
     const int16 *const *pcm;
@@ -120,12 +122,32 @@ reset_decoder(psgpu_batch_t *b, ps_decoder_t *ps)
 }
 
 static int
+collect(ps_decoder_t *ps, psgpu_batch_result_t *r)
+{
+    const char *hyp;
+    ps_seg_t *seg;
+    int cap = 0;
+    hyp = ps_get_hyp(ps, &r->score);
+    r->hyp = dup_str(hyp ? hyp : "");
+    for (seg = ps_seg_iter(ps); seg; seg = ps_seg_next(seg)) {
+        psgpu_batch_seg_t *s;
+        if (r->n_seg == cap) {
+            cap = cap ? 2 * cap : 16;
+            r->seg = realloc(r->seg, cap * sizeof *r->seg);
+        }
+        s = &r->seg[r->n_seg++];
+        s->word = dup_str(ps_seg_word(seg));
+        ps_seg_frames(seg, &s->sf, &s->ef);
+        ps_seg_prob(seg, &s->ascr, &s->lscr, &s->lback);
+    }
+    return 0;
+}
+
+static int
 decode_one(psgpu_batch_t *b, ps_decoder_t *ps, int u)
 {
     psgpu_batch_result_t *r = &b->out[u];
-    const char *hyp;
-    ps_seg_t *seg;
-    int cap = 0, rv;
+    int rv;
 
     memset(r, 0, sizeof *r);
     if (reset_decoder(b, ps) < 0) return -1;
@@ -143,21 +165,8 @@ decode_one(psgpu_batch_t *b, ps_decoder_t *ps, int u)
         rv = ps_process_raw(ps, b->pcm[u], b->n[u], FALSE, TRUE);
     if (rv < 0) { ps_end_utt(ps); return -1; }
     if (ps_end_utt(ps) < 0) return -1;
-    hyp = ps_get_hyp(ps, &r->score);
-    r->hyp = dup_str(hyp ? hyp : "");
     r->n_frames = ps_get_n_frames(ps);
-    for (seg = ps_seg_iter(ps); seg; seg = ps_seg_next(seg)) {
-        psgpu_batch_seg_t *s;
-        if (r->n_seg == cap) {
-            cap = cap ? 2 * cap : 16;
-            r->seg = realloc(r->seg, cap * sizeof *r->seg);
-        }
-        s = &r->seg[r->n_seg++];
-        s->word = dup_str(ps_seg_word(seg));
-        ps_seg_frames(seg, &s->sf, &s->ef);
-        ps_seg_prob(seg, &s->ascr, &s->lscr, &s->lback);
-    }
-    return 0;
+    return collect(ps, r);
 }
 
 static void *
@@ -211,7 +220,13 @@ psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
             goto fail;
         }
     }
-    if ((flags & PSGPU_BATCH_DEVICE_FE) && !(flags & PSGPU_BATCH_CPU_ONLY)) {
+    if ((flags & PSGPU_BATCH_DEVICE_FIRST_PASS) && !(flags & PSGPU_BATCH_CPU_ONLY)) {
+        /* the pipeline reads the search tables out of worker 0's decoder; results are injected into that decoder one
+         * utterance at a time (the read-out is a table walk: one host thread is plenty) */
+        b->dd = psgpu_device_decode_attach(b->ps[0]);
+        if (b->dd == NULL) goto fail;
+    }
+    if ((flags & PSGPU_BATCH_DEVICE_FE) && !(flags & PSGPU_BATCH_CPU_ONLY) && !(flags & PSGPU_BATCH_DEVICE_FIRST_PASS)) {
         /* one front end for the batch: psgpu_fe_wrap's table read-out, kept as the raw object */
         psgpu_fe_shim_t *s = psgpu_fe_wrap(b->ps[0]->acmod->fe);
         if (s == NULL) goto fail;
@@ -229,6 +244,7 @@ psgpu_batch_free(psgpu_batch_t *b)
 {
     int w;
     if (!b) return;
+    psgpu_device_decode_detach(b->dd);
     for (w = 0; w < b->n_workers; ++w) {
         if (!b->ps[w]) continue;
 #ifdef PSGPU_SEARCH_HOOKS
@@ -248,12 +264,26 @@ psgpu_decode_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t n[],
 {
     pthread_t *tid;
     worker_arg_t *args;
-    int w, nw, rc = 0;
+    int w, nw, rc = 0, *started;
 
     if (b == NULL || B < 0 || (B > 0 && (!pcm || !n || !out))) return -1;
     if (B == 0) return 0;
     b->pcm = pcm; b->n = n; b->B = B; b->out = out; b->next = 0; b->failed = 0;
     b->cep = NULL; b->frame_off = NULL;
+    if (b->dd) {
+        /* the whole first pass of the batch in one launch set; then the reference's own read-out per utterance */
+        int u;
+        if (psgpu_device_decode_batch_run(b->dd, pcm, n, B) < 0) return -1;
+        for (u = 0; u < B; ++u) {
+            psgpu_batch_result_t *r = &out[u];
+            int nfr;
+            memset(r, 0, sizeof *r);
+            if ((nfr = psgpu_device_decode_batch_select(b->dd, u)) < 0) { r->hyp = dup_str(""); rc = -1; continue; }
+            r->n_frames = psgpu_device_decode_batch_n_frames(b->dd, u) + 1;    /* ps_get_n_frames: output_frame + 1 */
+            collect(b->ps[0], r);
+        }
+        return rc;
+    }
     if (b->fe) {
         /* the whole batch through the device front end in one call, every utterance from
          * reset noise statistics (noise arrays NULL) */
@@ -280,13 +310,17 @@ psgpu_decode_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t n[],
     if (rc == 0) {
         nw = b->n_workers < B ? b->n_workers : B;
         tid = calloc(nw, sizeof *tid);
+        started = calloc(nw, sizeof *started);
         args = calloc(nw, sizeof *args);
         for (w = 0; w < nw; ++w) {
             args[w].b = b; args[w].w = w;
+            started[w] = 0;
             if (w == nw - 1) worker(&args[w]);             /* the caller's thread is the last worker */
-            else pthread_create(&tid[w], NULL, worker, &args[w]);
+            else if (pthread_create(&tid[w], NULL, worker, &args[w]) == 0) started[w] = 1;
+            else worker(&args[w]);                         /* no thread to be had: its share runs here */
         }
-        for (w = 0; w + 1 < nw; ++w) pthread_join(tid[w], NULL);
+        for (w = 0; w + 1 < nw; ++w) if (started[w]) pthread_join(tid[w], NULL);
+        free(started);
         free(tid); free(args);
         if (b->failed) rc = -1;
     }

@@ -16,6 +16,11 @@ extern "C" {
 #define PSGPU_BATCH_DEVICE_SEARCH 2u   /* hmm_vit_eval loops on the device (needs the hooked library) */
 #define PSGPU_BATCH_CPU_ONLY      4u   /* no device at all: the reference as it is (for A/B runs) */
 #define PSGPU_BATCH_DEVICE_PHONE_LOOP 8u /* each utterance's phone-loop search in one device launch (psgpu_phone_loop_shim) */
+#define PSGPU_BATCH_DEVICE_FIRST_PASS 16u /* the WHOLE first pass of the batch on the device in one launch set: front end,
+                                          * features, scores, phone loop, lexicon-tree search (psgpu_device_decode.h); the
+                                          * workers only read the results out (ps_get_hyp / ps_seg_iter on the injected
+                                          * tables; with -fwdflat yes / -bestpath yes the reference's later passes run on
+                                          * them on the worker's host thread) */
 
 typedef struct psgpu_batch_seg_s {
     char *word;

@@ -1,21 +1,28 @@
 /* integration/psgpu_device_decode.c -- REFERENCE-SIDE code.
  *
- * The first pass of an utterance entirely on the MI355X, behind the reference's own
- * result API: PCM -> MFCC (psgpu_fe) -> 1s_c_d_dd features -> PTM senone scores
- * (un-normalised rows) -> phone-loop search -> lexicon-tree search, then the
- * back-pointer table, right-context score stack and frame marks are copied into the
- * decoder's ngram_search_t in the reference's own layout (bptbl_t, ngram_search.h:112-124;
- * SURVEY 8f-2), so that ps_get_hyp(), ps_seg_iter() and friends run unchanged on them.
+ * The first pass of the n-gram search entirely on the MI355X, behind the reference's own
+ * interfaces.  Three ways in, one device pipeline (psgpu_decode_*, include/psgpu.h):
  *
- * What is read out of the decoder, once (psgpu_device_decode_attach): the search tree
- * create_search_channels built (flattened: roots, then depth-first), single-phone word
- * channels, dictionary and dict2pid tables, beams and penalties, the phone loop's HMMs
- * and beams, and the language model as a dense table over dictionary word ids
- * (ngram_tg_score for every triple) -- which limits this binding to small vocabularies
- * until the trie lookup itself is on the device.  Requires the n-gram search with
- * -fwdflat no (pass 1 on the device; -bestpath yes builds the word lattice from the
- * injected table on the host, ngram_search.c:1212, and searches it as usual), the PTM scorer (psgpu_mgau_attach first) and
- * the 1s_c_d_dd feature type. */
+ *  1. psgpu_device_search_attach(ps): the decoder's n-gram search gets a ps_searchfuncs_t
+ *     (pocketsphinx_internal.h:86-97) whose step() only buffers the frame's feature vector and
+ *     whose finish() runs scorer -> phone loop -> lexicon-tree search on the device and copies the
+ *     back-pointer table, right-context score stack and frame marks into the ngram_search_t in the
+ *     reference's own layout (bptbl_t, ngram_search.h:112-124).  The search object IS
+ *     the reference's ngram_search_t (type "ngram", ps_get_lm() keeps working), so
+ *     unmodified ps_decode_raw() / ps_process_raw() + ps_end_utt() / ps_get_hyp() / ps_seg_iter() /
+ *     ps_get_lattice() reach it; with -fwdflat yes the reference's own second pass then runs on the
+ *     injected table (ngram_search.c:791-808), with -bestpath yes its lattice pass.
+ *  2. psgpu_device_decode_utt(d, pcm, n): one utterance from PCM, front end on the device too.
+ *  3. psgpu_device_decode_batch_run(d, pcm[], n[], B) + _select(d, u): B utterances through ONE
+ *     launch set (what psgpu_decode_batch uses with PSGPU_BATCH_DEVICE_FIRST_PASS).
+ *
+ * What is read out of the decoder, once (attach): the search tree create_search_channels built
+ * (flattened: roots, then depth-first), single-phone word channels, dictionary and dict2pid
+ * tables, beams and penalties, the phone loop's HMMs and beams, and the language model -- the
+ * model's own trie when it is one trie model without classes (psgpu_lm_tables.c), else, for small
+ * vocabularies, every ngram_tg_score in a dense table.  Requires the n-gram search with -fwdtree
+ * yes, the PTM scorer (psgpu_mgau_attach first), the 1s_c_d_dd feature type with batch CMN,
+ * -compallsen no and the phone-loop look-ahead (pl_window > 0). */
 #include <stdlib.h>
 #include <string.h>
 
@@ -24,6 +31,8 @@
 #include "util/ckd_alloc.h"
 #include "acmod.h"
 #include "ngram_search.h"
+#include "ngram_search_fwdtree.h"
+#include "ngram_search_fwdflat.h"
 #include "phone_loop_search.h"
 #include "dict2pid.h"
 #include "lm/ngram_model.h"
@@ -41,23 +50,44 @@ struct psgpu_device_decode_s {
     psgpu_lm_t *lm;                    /* the trie on the device (NULL: dense table inside ft) */
     psgpu_hmm_ctx_t *ctx;
     psgpu_fe_t *fe;
-    psgpu_ptm_model_t *model;          /* borrowed from the attached scorer */
-    psgpu_phone_loop_params_t plpar;
-    int pl_window, n_ci, n_sen, n_chain, topn, cepsize, n_list;
-    uint16_t *d_ssid, *d_ci; int16_t *d_tmatid;
-    /* per-utterance device buffers, grown on demand */
-    int cap_frames; size_t cap_samples;
-    int16_t *d_pcm; float *d_cep, *d_feat; int32_t *d_off, *d_tsc; uint8_t *d_tcw; int16_t *d_rows; int32_t *d_best;
-    int32_t *d_pen, *d_now, *d_state, *d_bp, *d_bss, *d_idx, *d_step, *d_res;
+    psgpu_decode_t *dec;               /* the pipeline (borrows the four above and the attached scorer's model) */
+    int n_ci, n_sen, n_chain, topn, cepsize, veclen;
+    int n_words_at_attach;
+    ngram_model_t *lmset_at_attach;
+    /* host side of the results */
+    int32_t *h_res, *h_hn;             /* [B][8], [B][4] of the last run */
+    int B, cap_B;
     int32_t *h_bp, *h_bss, *h_idx;
-    int bp_cap, bss_cap;
+    size_t cap_bp, cap_bss, cap_idx;
+    /* ps_search_t binding: the frames of the utterance in progress */
+    ps_searchfuncs_t vt, pl_vt;
+    ps_searchfuncs_t *orig_vt, *orig_pl_vt;
+    float *h_feat; int n_feat, cap_feat;
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
     psgpu_ptm_view_t view;
-    int n_fast_hist, n1, n_emit;
-    int32_t *d_w1, *d_seed, *d_bp2, *d_bss2, *d_idx2, *d_step2, *d_res2, *h_seed;
-    uint8_t *h_tcw;
+    int n_fast_hist, n1, n_emit, cap_t2, bp_cap2, bss_cap2;
+    int32_t *d_seed, *d_bp2, *d_bss2, *d_idx2, *d_step2, *d_res2, *h_seed;
+    uint8_t *h_tcw; size_t cap_tcw;
 };
+
+#define FREE_DEV(p) do { psgpu_free(p); (p) = NULL; } while (0)
+#define FREE_HOST(p) do { ckd_free(p); (p) = NULL; } while (0)
+
+/* one attachment per decoder: the vtable functions find it through this (the reference has no user pointer in
+ * ps_search_t; decoders are few) */
+#define MAX_ATTACHED 64
+static psgpu_device_decode_t *g_attached[MAX_ATTACHED];
+
+static psgpu_device_decode_t *
+find_attached(ps_search_t *search)
+{
+    int i;
+    for (i = 0; i < MAX_ATTACHED; ++i)
+        if (g_attached[i] && (g_attached[i]->ps->search == search || g_attached[i]->ps->phone_loop == search))
+            return g_attached[i];
+    return NULL;
+}
 
 static int
 number_nodes(chan_t *first, chan_t **nodes, int n)
@@ -75,15 +105,13 @@ node_ref_cmp(const void *a, const void *b)
     const chan_t *x = ((const node_ref_t *)a)->h, *y = ((const node_ref_t *)b)->h;
     return x < y ? -1 : x > y;
 }
-static node_ref_t *g_refs;       /* set for the duration of one attach (single-threaded, like ps_init) */
 static int
-node_index(chan_t **nodes, int n, chan_t *h, int base)
+node_index(node_ref_t *refs, int n, chan_t *h, int base)
 {
     node_ref_t key, *r;
-    (void)nodes;
     if (h == NULL) return -1;
     key.h = h; key.idx = 0;
-    r = bsearch(&key, g_refs, n, sizeof *g_refs, node_ref_cmp);
+    r = bsearch(&key, refs, n, sizeof *refs, node_ref_cmp);
     return r ? base + r->idx : -1;
 }
 
@@ -98,8 +126,11 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     dict2pid_t *d2p;
     phone_loop_search_t *pls;
     psgpu_fwdtree_tables_t t;
+    psgpu_decode_config_t cfg;
+    psgpu_ptm_model_t *model;
     chan_t **nodes;
-    int n_ci, n_emit, n_w, R, M, N, n1, i, j, k, w, n_tmat, n_sseq, lm_ok;
+    node_ref_t *refs;
+    int n_ci, n_emit, n_w, R, M, N, n1, i, j, k, w, n_tmat, n_sseq, lm_ok, want_ff;
     int32 par[32];
     int32 *ci, *ci2, *ssid, *tm, *child, *sib, *pw, *sw, *sci, *sci2, *sss, *stm, *smpx;
     int32 *pl, *p0, *pz, *py, *bw, *fl, *rn, *rs, *rm, *ld, *ptm, *lm;
@@ -110,11 +141,8 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     if (ps == NULL || ps->search == NULL || ps->acmod == NULL) return NULL;
     if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM)) { E_ERROR("psgpu device decode: not an n-gram search\n"); return NULL; }
     ngs = (ngram_search_t *)ps->search;
-    if (!ngs->fwdtree || (ngs->fwdflat && !(getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS"))))) {
-        E_ERROR("psgpu device decode: needs -fwdtree yes -fwdflat no (pass 1 on the device, the lattice pass on the host); "
-                "-fwdflat yes with PSGPU_DEVICE_SECOND_PASS=1 in the environment runs the second pass on the device too\n");
-        return NULL;
-    }
+    if (!ngs->fwdtree) { E_ERROR("psgpu device decode: needs -fwdtree yes (pass 1 is what runs on the device)\n"); return NULL; }
+    want_ff = ngs->fwdflat && getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS"));
     acmod = ps->acmod; mdef = acmod->mdef; dict = ps_search_dict(ngs); d2p = ps_search_dict2pid(ngs);
     n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(dict);
     if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->compallsen || acmod->fcb->cmn != CMN_BATCH
@@ -123,35 +151,36 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
                 "and -compallsen no\n");
         return NULL;
     }
+    model = psgpu_mgau_ptm_model(acmod->mgau);
+    if (model == NULL) { E_ERROR("psgpu device decode: attach the psgpu PTM scorer first\n"); return NULL; }
     d = ckd_calloc(1, sizeof *d);
     d->ps = ps;
-    d->model = psgpu_mgau_ptm_model(acmod->mgau);
-    if (d->model == NULL) { E_ERROR("psgpu device decode: attach the psgpu PTM scorer first\n"); ckd_free(d); return NULL; }
     d->n_ci = n_ci; d->n_sen = bin_mdef_n_sen(mdef);
-    d->n_chain = psgpu_ptm_n_chain(d->model); d->topn = psgpu_ptm_topn(d->model);
-    d->cepsize = feat_cepsize(acmod->fcb);
+    d->n_chain = psgpu_ptm_n_chain(model); d->topn = psgpu_ptm_topn(model);
+    d->cepsize = feat_cepsize(acmod->fcb); d->veclen = 3 * d->cepsize;
+    d->n_words_at_attach = n_w; d->lmset_at_attach = ngs->lmset;
     /* ---- the search tables (cf. oracle/ref_dump.c cmd_fwdtree, which writes the same arrays to a file) */
     R = ngs->n_root_chan;
     nodes = ckd_calloc(ngs->n_nonroot_chan + 16, sizeof *nodes);
     for (M = 0, i = 0; i < R; ++i) M = number_nodes(ngs->root_chan[i].next, nodes, M);
     N = R + M; n1 = ngs->n_1ph_words;
-    g_refs = ckd_calloc(M + 1, sizeof *g_refs);
-    for (i = 0; i < M; ++i) { g_refs[i].h = nodes[i]; g_refs[i].idx = i; }
-    qsort(g_refs, M, sizeof *g_refs, node_ref_cmp);
+    refs = ckd_calloc(M + 1, sizeof *refs);
+    for (i = 0; i < M; ++i) { refs[i].h = nodes[i]; refs[i].idx = i; }
+    qsort(refs, M, sizeof *refs, node_ref_cmp);
     ci = ckd_calloc(N, 4); ci2 = ckd_calloc(N, 4); ssid = ckd_calloc(N, 4); tm = ckd_calloc(N, 4); child = ckd_calloc(N, 4);
     sib = ckd_calloc(N, 4); pw = ckd_calloc(N, 4);
     for (i = 0; i < R; ++i) {
         root_chan_t *r = &ngs->root_chan[i];
         ci[i] = r->ciphone; ci2[i] = r->ci2phone; ssid[i] = hmm_mpx_ssid(&r->hmm, 0); tm[i] = r->hmm.tmatid;
-        child[i] = node_index(nodes, M, r->next, R); sib[i] = -1; pw[i] = r->penult_phn_wid;
+        child[i] = node_index(refs, M, r->next, R); sib[i] = -1; pw[i] = r->penult_phn_wid;
     }
     for (i = 0; i < M; ++i) {
         chan_t *h = nodes[i];
         ci[R + i] = h->ciphone; ci2[R + i] = -1; ssid[R + i] = hmm_nonmpx_ssid(&h->hmm); tm[R + i] = h->hmm.tmatid;
-        child[R + i] = node_index(nodes, M, h->next, R); sib[R + i] = node_index(nodes, M, h->alt, R);
+        child[R + i] = node_index(refs, M, h->next, R); sib[R + i] = node_index(refs, M, h->alt, R);
         pw[R + i] = h->info.penult_phn_wid;
     }
-    ckd_free(g_refs); g_refs = NULL;
+    ckd_free(refs);
     sw = ckd_calloc(n1 + 1, 4); sci = ckd_calloc(n1 + 1, 4); sci2 = ckd_calloc(n1 + 1, 4); sss = ckd_calloc(n1 + 1, 4);
     stm = ckd_calloc(n1 + 1, 4); smpx = ckd_calloc(n1 + 1, 4);
     for (i = 0; i < n1; ++i) {
@@ -225,7 +254,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     t.tp = tp; t.sseq = sq; t.ci_tmat = ptm; t.lm = lm; t.n_tmat = n_tmat; t.n_sseq = n_sseq;
     i = lm_ok ? psgpu_fwdtree_create(&d->ft, &t) : PSGPU_EINVAL;
     if (i == PSGPU_OK && d->lm) i = psgpu_fwdtree_set_lm(d->ft, d->lm);
-    if (i == PSGPU_OK && ngs->fwdflat) {
+    if (i == PSGPU_OK && want_ff) {
         /* ---- what the second pass adds (cf. oracle/ref_dump.c cmd_fwdtree(.., flat = 1)): pronunciations as word-internal
          *      ssids, the CI phones' ssids, which words the language model knows, its beams and windows */
         psgpu_fwdflat_tables_t t2;
@@ -250,21 +279,18 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         t2.max_sf_win = ngs->max_sf_win; t2.lwf = ngs->fwdflat_fwdtree_lw_ratio;
         i = psgpu_fwdflat_create(&d->ff, &t2);
         if (i == PSGPU_OK && d->lm) i = psgpu_fwdflat_set_lm(d->ff, d->lm);
-        if (i == PSGPU_OK) i = psgpu_ptm_model_view(d->model, &d->view);
         d->n_fast_hist = ps->pl_window + 2;               /* ptm_mgau.c:884 */
         d->n1 = ngs->n_1ph_words; d->n_emit = n_emit;
-        if (i == PSGPU_OK && (psgpu_malloc((void **)&d->d_w1, 4 * (size_t)d->n1 * n_emit + 4)
-                              || psgpu_malloc((void **)&d->d_seed, 4 * (size_t)d->n_chain * d->topn + 4)))
-            i = PSGPU_ENOMEM;
+        if (i == PSGPU_OK && psgpu_malloc((void **)&d->d_seed, 4 * (size_t)d->n_chain * d->topn + 4)) i = PSGPU_ENOMEM;
         d->h_seed = ckd_calloc((size_t)d->n_chain * d->topn + 1, 4);
         ckd_free(off); ckd_free(pci); ckd_free(pss); ckd_free(cis); ckd_free(known);
     }
-    /* PSGPU_FWDTREE_MODE=active_list: the large-vocabulary formulation of the kernel (psgpu.h, psgpu_fwdtree_set_mode);
-     * same tables, per-frame work proportional to the active channels */
-    if (i == PSGPU_OK && getenv("PSGPU_FWDTREE_MODE") && !strcmp(getenv("PSGPU_FWDTREE_MODE"), "active_list"))
-        i = psgpu_fwdtree_set_mode(d->ft, PSGPU_FWDTREE_ACTIVE_LIST);
     if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, n_tmat, tp, n_sseq, sq, d->n_sen);
-    /* ---- the phone loop (cf. psgpu_phone_loop_shim.c) */
+    if (i == PSGPU_OK) {
+        fes = psgpu_fe_wrap(acmod->fe);
+        if (fes) d->fe = psgpu_fe_shim_release(fes); else i = PSGPU_EINVAL;
+    }
+    /* ---- the phone loop (cf. psgpu_phone_loop_shim.c) and the pipeline object */
     pls = (phone_loop_search_t *)ps->phone_loop;
     if (i == PSGPU_OK && pls && ps->pl_window > 0 && pls->n_phones <= 64) {
         uint16_t *ps_ssid = ckd_calloc(pls->n_phones, 2), *cil = ckd_calloc(d->n_sen, 2);
@@ -281,15 +307,13 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
             while (j - last > 255) { last += 255; cil[nl++] = (uint16_t)last; }
             cil[nl++] = (uint16_t)j; last = j;
         }
-        d->n_list = nl;
-        d->plpar.n_phones = pls->n_phones; d->plpar.window = pls->window; d->plpar.beam = pls->beam; d->plpar.pbeam = pls->pbeam;
-        d->plpar.pip = pls->pip; d->plpar.penalty_weight = pls->penalty_weight;
-        d->pl_window = ps->pl_window;
-        if (psgpu_malloc((void **)&d->d_ssid, 2 * pls->n_phones) || psgpu_malloc((void **)&d->d_tmatid, 2 * pls->n_phones)
-            || psgpu_malloc((void **)&d->d_ci, 2 * (nl ? nl : 1)) || psgpu_memcpy_h2d(d->d_ssid, ps_ssid, 2 * pls->n_phones, NULL)
-            || psgpu_memcpy_h2d(d->d_tmatid, ps_tm, 2 * pls->n_phones, NULL) || psgpu_memcpy_h2d(d->d_ci, cil, 2 * nl, NULL)
-            || psgpu_stream_sync(NULL))
-            i = PSGPU_EHIP;
+        memset(&cfg, 0, sizeof cfg);
+        cfg.fe = d->fe; cfg.model = model; cfg.ctx = d->ctx; cfg.ft = d->ft;
+        cfg.pl.n_phones = pls->n_phones; cfg.pl.window = pls->window; cfg.pl.beam = pls->beam; cfg.pl.pbeam = pls->pbeam;
+        cfg.pl.pip = pls->pip; cfg.pl.penalty_weight = pls->penalty_weight;
+        cfg.pl_ssid = ps_ssid; cfg.pl_tmatid = ps_tm; cfg.ci_list = cil; cfg.n_ci_list = nl; cfg.pl_window = ps->pl_window;
+        cfg.max_words = 0;
+        i = psgpu_decode_create(&d->dec, &cfg);
         ckd_free(ps_ssid); ckd_free(cil); ckd_free(ps_tm); ckd_free(flags);
     }
     else if (i == PSGPU_OK) {
@@ -300,72 +324,185 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     ckd_free(sw); ckd_free(sci); ckd_free(sci2); ckd_free(sss); ckd_free(stm); ckd_free(smpx);
     ckd_free(pl); ckd_free(p0); ckd_free(pz); ckd_free(py); ckd_free(bw); ckd_free(fl); ckd_free(rn); ckd_free(rs); ckd_free(rm);
     ckd_free(ld); ckd_free(tp); ckd_free(sq); ckd_free(ptm); ckd_free(lm);
-    if (i == PSGPU_OK) {
-        fes = psgpu_fe_wrap(acmod->fe);
-        if (fes) d->fe = psgpu_fe_shim_release(fes); else i = PSGPU_EINVAL;
-    }
     if (i != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         psgpu_device_decode_detach(d);
         return NULL;
     }
-    d->bp_cap = 16384; d->bss_cap = 1 << 19;
+    for (i = 0; i < MAX_ATTACHED; ++i) if (g_attached[i] == NULL) { g_attached[i] = d; break; }
     return d;
 }
 
 void
 psgpu_device_decode_detach(psgpu_device_decode_t *d)
 {
+    int i;
     if (!d) return;
-    psgpu_fwdflat_free(d->ff); psgpu_free(d->d_w1); psgpu_free(d->d_seed); psgpu_free(d->d_bp2); psgpu_free(d->d_bss2);
-    psgpu_free(d->d_idx2); psgpu_free(d->d_step2); psgpu_free(d->d_res2); ckd_free(d->h_seed); ckd_free(d->h_tcw);
+    psgpu_device_search_detach(d);
+    for (i = 0; i < MAX_ATTACHED; ++i) if (g_attached[i] == d) g_attached[i] = NULL;
+    psgpu_decode_free(d->dec);
+    psgpu_fwdflat_free(d->ff); FREE_DEV(d->d_seed); FREE_DEV(d->d_bp2); FREE_DEV(d->d_bss2); FREE_DEV(d->d_idx2); FREE_DEV(d->d_step2);
+    FREE_DEV(d->d_res2); FREE_HOST(d->h_seed); FREE_HOST(d->h_tcw);
     psgpu_fwdtree_free(d->ft); psgpu_lm_free(d->lm); psgpu_hmm_ctx_free(d->ctx); psgpu_fe_free(d->fe);
-    psgpu_free(d->d_ssid); psgpu_free(d->d_tmatid); psgpu_free(d->d_ci);
-    psgpu_free(d->d_pcm); psgpu_free(d->d_cep); psgpu_free(d->d_feat); psgpu_free(d->d_off); psgpu_free(d->d_tsc); psgpu_free(d->d_tcw);
-    psgpu_free(d->d_rows); psgpu_free(d->d_best); psgpu_free(d->d_pen); psgpu_free(d->d_now); psgpu_free(d->d_state);
-    psgpu_free(d->d_bp); psgpu_free(d->d_bss); psgpu_free(d->d_idx); psgpu_free(d->d_step); psgpu_free(d->d_res);
-    ckd_free(d->h_bp); ckd_free(d->h_bss); ckd_free(d->h_idx);
+    FREE_HOST(d->h_res); FREE_HOST(d->h_hn); FREE_HOST(d->h_bp); FREE_HOST(d->h_bss); FREE_HOST(d->h_idx); FREE_HOST(d->h_feat);
     ckd_free(d);
 }
 
+/* the decoder may have changed since attach: MLLR re-uploads the scorer's tables (psgpu_mgau_shim.c, a new model handle);
+ * a dictionary or language-model change invalidates the flattened tables, which is refused */
 static int
-grow(psgpu_device_decode_t *d, size_t n_samples, int T)
+refresh(psgpu_device_decode_t *d)
 {
-    if (n_samples > d->cap_samples) {
-        psgpu_free(d->d_pcm); d->d_pcm = NULL;
-        if (psgpu_malloc((void **)&d->d_pcm, 2 * n_samples)) return -1;
-        d->cap_samples = n_samples;
+    ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
+    psgpu_ptm_model_t *model = psgpu_mgau_ptm_model(d->ps->acmod->mgau);
+    if (model == NULL) { E_ERROR("psgpu device decode: the psgpu PTM scorer is no longer attached\n"); return -1; }
+    if (dict_size(ps_search_dict(ngs)) != d->n_words_at_attach || ngs->lmset != d->lmset_at_attach) {
+        E_ERROR("psgpu device decode: the dictionary or the language model changed after attach (ps_add_word / ps_set_lm): "
+                "detach and attach again\n");
+        return -1;
     }
-    if (T > d->cap_frames) {
-        size_t t = (size_t)T + T / 2 + 64, ne = t * d->n_chain * d->topn;
-        psgpu_free(d->d_cep); psgpu_free(d->d_feat); psgpu_free(d->d_tsc); psgpu_free(d->d_tcw); psgpu_free(d->d_rows);
-        psgpu_free(d->d_best); psgpu_free(d->d_pen); psgpu_free(d->d_now); psgpu_free(d->d_state); psgpu_free(d->d_idx);
-        psgpu_free(d->d_step); psgpu_free(d->d_off); psgpu_free(d->d_bp); psgpu_free(d->d_bss); psgpu_free(d->d_res);
-        ckd_free(d->h_bp); ckd_free(d->h_bss); ckd_free(d->h_idx);
-        if (d->ff) {
-            psgpu_free(d->d_bp2); psgpu_free(d->d_bss2); psgpu_free(d->d_idx2); psgpu_free(d->d_step2); psgpu_free(d->d_res2);
-            ckd_free(d->h_tcw);
-            d->d_bp2 = d->d_bss2 = d->d_idx2 = d->d_step2 = d->d_res2 = NULL; d->h_tcw = NULL;
-            if (psgpu_malloc((void **)&d->d_bp2, 4 * (size_t)10 * d->bp_cap) || psgpu_malloc((void **)&d->d_bss2, 4 * (size_t)d->bss_cap)
-                || psgpu_malloc((void **)&d->d_idx2, 4 * (t + 2)) || psgpu_malloc((void **)&d->d_step2, 4 * t * 4)
-                || psgpu_malloc((void **)&d->d_res2, 32))
-                return -1;
-            d->h_tcw = ckd_calloc(ne + 1, 1);
-        }
-        d->cap_frames = 0;
-        if (psgpu_malloc((void **)&d->d_cep, 4 * t * d->cepsize) || psgpu_malloc((void **)&d->d_feat, 4 * t * 3 * d->cepsize)
-            || psgpu_malloc((void **)&d->d_tsc, 4 * ne) || psgpu_malloc((void **)&d->d_tcw, ne)
-            || psgpu_malloc((void **)&d->d_rows, 2 * t * d->n_sen) || psgpu_malloc((void **)&d->d_best, 4 * t)
-            || psgpu_malloc((void **)&d->d_pen, 4 * t * d->n_ci) || psgpu_malloc((void **)&d->d_now, 4 * t * d->n_ci)
-            || psgpu_malloc((void **)&d->d_state, 4 * t * d->n_ci * 8) || psgpu_malloc((void **)&d->d_idx, 4 * (t + 2))
-            || psgpu_malloc((void **)&d->d_step, 4 * t * 4) || psgpu_malloc((void **)&d->d_off, 8)
-            || psgpu_malloc((void **)&d->d_bp, 4 * (size_t)10 * d->bp_cap) || psgpu_malloc((void **)&d->d_bss, 4 * (size_t)d->bss_cap)
-            || psgpu_malloc((void **)&d->d_res, 32))
-            return -1;
-        d->h_bp = ckd_calloc((size_t)10 * d->bp_cap, 4); d->h_bss = ckd_calloc(d->bss_cap, 4); d->h_idx = ckd_calloc(t + 2, 4);
-        d->cap_frames = (int)t;
+    if (psgpu_decode_set_model(d->dec, model) != PSGPU_OK || (d->ff && psgpu_ptm_model_view(model, &d->view) != PSGPU_OK)) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
     }
     return 0;
+}
+
+static int
+fetch_summary(psgpu_device_decode_t *d, int B)
+{
+    if (B > d->cap_B) {
+        FREE_HOST(d->h_res); FREE_HOST(d->h_hn);
+        d->h_res = ckd_calloc((size_t)B * 8, 4); d->h_hn = ckd_calloc((size_t)B * 4, 4);
+        d->cap_B = B;
+    }
+    d->B = B;
+    if (psgpu_decode_fetch_hyps(d->dec, d->h_hn, NULL, d->h_res, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+/* ngram_search_mark_bptable's growth (ngram_search.c:323-340): the frame marks and, when the second pass exists, its
+ * per-frame word lists grow together */
+static void
+grow_frames(ngram_search_t *ngs, int need)
+{
+    while (need >= ngs->n_frame_alloc) {
+        int old = ngs->n_frame_alloc;
+        ngs->n_frame_alloc *= 2;
+        ngs->bp_table_idx = (int32 *)ckd_realloc(ngs->bp_table_idx - 1, (ngs->n_frame_alloc + 1) * sizeof(*ngs->bp_table_idx)) + 1;
+        if (ngs->frm_wordlist) {
+            ngs->frm_wordlist = ckd_realloc(ngs->frm_wordlist, ngs->n_frame_alloc * sizeof(*ngs->frm_wordlist));
+            memset(ngs->frm_wordlist + old, 0, (ngs->n_frame_alloc - old) * sizeof(*ngs->frm_wordlist));
+        }
+    }
+}
+
+/* ---- tables in the reference's layout (ngram_search.h:112-124, ngram_search.c:301-339, 445-497).
+ *      bp [10][nb] column-major, bss [nh], idx [nfr + 1] on the host. */
+static void
+inject(ngram_search_t *ngs, int n_ci, const int32_t *bp, int nb, const int32_t *bss, int nh, const int32_t *idx, int nfr, int32 best_score)
+{
+    int i;
+    if (nb > ngs->bp_table_size) {
+        ngs->bp_table_size = nb + nb / 2;
+        ngs->bp_table = ckd_realloc(ngs->bp_table, ngs->bp_table_size * sizeof(*ngs->bp_table));
+    }
+    if (nh + n_ci >= ngs->bscore_stack_size) {
+        ngs->bscore_stack_size = nh + n_ci + nh / 2 + 1;
+        ngs->bscore_stack = ckd_realloc(ngs->bscore_stack, ngs->bscore_stack_size * sizeof(*ngs->bscore_stack));
+    }
+    grow_frames(ngs, nfr + 1);
+    for (i = 0; i < nb; ++i) {
+        bptbl_t *e = &ngs->bp_table[i];
+#define COL(c) bp[(size_t)(c) * nb + i]
+        e->frame = COL(0); e->valid = (uint8)COL(1); e->refcnt = 0; e->wid = COL(2); e->bp = COL(3); e->score = COL(4);
+        e->s_idx = COL(5); e->real_wid = COL(6); e->prev_real_wid = COL(7); e->last_phone = (int16)COL(8); e->last2_phone = (int16)COL(9);
+#undef COL
+    }
+    memcpy(ngs->bscore_stack, bss, sizeof(int32) * nh);
+    memcpy(ngs->bp_table_idx, idx, sizeof(int32) * (nfr + 1));
+    ngs->bpidx = nb; ngs->bss_head = nh; ngs->n_frame = nfr;
+    ngs->best_score = best_score;    /* ngram_search_lattice (ngram_search.c:1226) refuses an utterance whose best score is WORST_SCORE */
+}
+
+static int
+fetch_and_inject(psgpu_device_decode_t *d, int u)
+{
+    ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
+    const int32_t *res = d->h_res + (size_t)u * 8;
+    int nb = res[0], nh = res[1], nfr = res[2];
+    if (res[3]) { E_ERROR("psgpu device decode: utterance %d: back-pointer table or score stack full\n", u); return -1; }
+    if ((size_t)nb * 10 > d->cap_bp) { FREE_HOST(d->h_bp); d->cap_bp = (size_t)nb * 15 + 640; d->h_bp = ckd_calloc(d->cap_bp, 4); }
+    if ((size_t)nh > d->cap_bss) { FREE_HOST(d->h_bss); d->cap_bss = (size_t)nh + nh / 2 + 64; d->h_bss = ckd_calloc(d->cap_bss, 4); }
+    if ((size_t)nfr + 1 > d->cap_idx) { FREE_HOST(d->h_idx); d->cap_idx = (size_t)nfr + nfr / 2 + 64; d->h_idx = ckd_calloc(d->cap_idx, 4); }
+    if (psgpu_decode_fetch_tables(d->dec, u, nb, nh, nfr + 1, d->h_bp, d->h_bss, d->h_idx, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    inject(ngs, d->n_ci, d->h_bp, nb, d->h_bss, nh, d->h_idx, nfr, res[4]);
+    return nfr;
+}
+
+/* ---- the second pass on the device (one utterance): the flat-lexicon search over the first pass's device-resident
+ *      table, scoring its own senones from the feature rows; its scorer state starts from the lists pass 1 left in
+ *      history slot n_fast_hist - 1 (ptm_mgau.c:425-441), i.e. the batch scorer's lists (chain-major
+ *      [n_chain][T][topn]) of the last frame ts with ts % H == H - 1 */
+static int
+second_pass_one(psgpu_device_decode_t *d, int T)
+{
+    ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
+    psgpu_decode_view_t v;
+    void *st = psgpu_hmm_ctx_stream(d->ctx);
+    int32_t res[8];
+    int H = d->n_fast_hist, ts = T - 1, c, i, nb, nh, nfr;
+    size_t ne = (size_t)d->n_chain * T * d->topn;
+
+    if (psgpu_decode_view(d->dec, &v) != PSGPU_OK || v.n_utt != 1) return -1;
+    if (T > d->cap_t2 || v.bp_cap > d->bp_cap2 || v.bss_cap > d->bss_cap2) {
+        size_t t = (size_t)T + T / 2 + 64;
+        FREE_DEV(d->d_bp2); FREE_DEV(d->d_bss2); FREE_DEV(d->d_idx2); FREE_DEV(d->d_step2); FREE_DEV(d->d_res2);
+        d->cap_t2 = 0;
+        if (psgpu_malloc((void **)&d->d_bp2, 4 * (size_t)10 * v.bp_cap) || psgpu_malloc((void **)&d->d_bss2, 4 * (size_t)v.bss_cap)
+            || psgpu_malloc((void **)&d->d_idx2, 4 * (t + 2)) || psgpu_malloc((void **)&d->d_step2, 4 * t * 4)
+            || psgpu_malloc((void **)&d->d_res2, 32)) {
+            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+            return -1;
+        }
+        d->cap_t2 = (int)t; d->bp_cap2 = v.bp_cap; d->bss_cap2 = v.bss_cap;
+    }
+    if (ne > d->cap_tcw) { FREE_HOST(d->h_tcw); d->cap_tcw = ne + ne / 2 + 64; d->h_tcw = ckd_calloc(d->cap_tcw, 1); }
+    while (ts >= 0 && ts % H != H - 1) --ts;
+    if (psgpu_memcpy_d2h(d->h_tcw, v.topn_cw_dev, ne, st) || psgpu_stream_sync(st)) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    for (c = 0; c < d->n_chain; ++c)
+        for (i = 0; i < d->topn; ++i)      /* a shorter utterance than H frames never wrote that slot: ptm_mgau_init's i-th codeword */
+            d->h_seed[c * d->topn + i] = ts >= 0 ? d->h_tcw[((size_t)c * T + ts) * d->topn + i] : i;
+    if (psgpu_memcpy_h2d(d->d_seed, d->h_seed, 4 * (size_t)d->n_chain * d->topn, st)
+        || psgpu_fwdflat_search_feats_dev(d->ff, &d->view, v.feat_dev, d->d_seed, v.frame_off_dev, 1, T, v.bp_cap, v.bp_dev, v.result_dev,
+                                          v.w1_ssid_dev, d->bp_cap2, d->bss_cap2, d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)
+        || psgpu_memcpy_d2h(res, d->d_res2, sizeof res, st) || psgpu_stream_sync(st)) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    if (res[3]) { E_ERROR("psgpu device decode: second pass: back-pointer table or score stack full\n"); return -1; }
+    nb = res[0]; nh = res[1]; nfr = res[2];
+    if ((size_t)nb * 10 > d->cap_bp) { FREE_HOST(d->h_bp); d->cap_bp = (size_t)nb * 15 + 640; d->h_bp = ckd_calloc(d->cap_bp, 4); }
+    if ((size_t)nh > d->cap_bss) { FREE_HOST(d->h_bss); d->cap_bss = (size_t)nh + nh / 2 + 64; d->h_bss = ckd_calloc(d->cap_bss, 4); }
+    if ((size_t)nfr + 1 > d->cap_idx) { FREE_HOST(d->h_idx); d->cap_idx = (size_t)nfr + nfr / 2 + 64; d->h_idx = ckd_calloc(d->cap_idx, 4); }
+    for (i = 0; i < 10 && nb; ++i)
+        if (psgpu_memcpy_d2h(d->h_bp + (size_t)i * nb, d->d_bp2 + (size_t)i * d->bp_cap2, 4 * (size_t)nb, st)) return -1;
+    if ((nh && psgpu_memcpy_d2h(d->h_bss, d->d_bss2, 4 * (size_t)nh, st)) || psgpu_memcpy_d2h(d->h_idx, d->d_idx2, 4 * ((size_t)nfr + 1), st)
+        || psgpu_stream_sync(st)) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    inject(ngs, d->n_ci, d->h_bp, nb, d->h_bss, nh, d->h_idx, nfr, res[4]);
+    return nfr;
 }
 
 int
@@ -373,84 +510,243 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
 {
     ps_decoder_t *ps = d->ps;
     ngram_search_t *ngs = (ngram_search_t *)ps->search;
-    int64_t soff[2] = { 0, (int64_t)n_samples };
-    int32_t fo[2], res[8];
-    int T = (int)psgpu_fe_n_frames(d->fe, (int64_t)n_samples), i, nb, nh, nfr;
-    void *st = psgpu_hmm_ctx_stream(d->ctx);       /* one stream for the whole chain */
+    const int16 *one[1]; size_t n1[1];
+    int nfr;
 
-    if (grow(d, n_samples ? n_samples : 1, T ? T : 1) < 0) { E_ERROR("psgpu device decode: %s\n", psgpu_last_error()); return -1; }
+    if (ngs->fwdflat && !d->ff) {
+        E_ERROR("psgpu device decode: -fwdflat yes needs PSGPU_DEVICE_SECOND_PASS=1 at attach for this entry (or use "
+                "psgpu_device_search_attach + ps_decode_raw: the reference's second pass then runs on the host)\n");
+        return -1;
+    }
+    if (refresh(d) < 0) return -1;
     /* the reference's own start / end-of-utterance housekeeping, without any frame going through its search */
     if (ps_start_utt(ps) < 0) return -1;
     if (ps_end_utt(ps) < 0) return -1;
-    if (T == 0) return 0;
-    if (d->ff && psgpu_fwdtree_set_w1_ssid_out(d->ft, d->d_w1)) { E_ERROR("psgpu device decode: %s\n", psgpu_last_error()); return -1; }
-    if (psgpu_memcpy_h2d(d->d_pcm, pcm, 2 * n_samples, st)
-        || psgpu_fe_process_utts_dev(d->fe, d->d_pcm, soff, 1, NULL, NULL, d->d_cep, d->d_off, fo, st)
-        || psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, 1, d->cepsize, d->d_feat, st)
-        || psgpu_ptm_score_batch_dev(d->model, d->d_feat, d->d_off, 1, T, NULL, NULL, d->d_tsc, d->d_tcw, d->d_rows, d->d_best,
-                                     PSGPU_PTM_RAW_SCORES, st)
-        || psgpu_phone_loop_run_dev(d->ctx, &d->plpar, d->d_ssid, d->d_tmatid, d->d_ci, d->n_list, d->d_rows, d->n_sen, NULL,
-                                    d->d_off, 1, T, d->d_pen, d->d_now, d->d_state, st)
-        || psgpu_fwdtree_search_dev(d->ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, 1, T, d->bp_cap, d->bss_cap, d->d_bp, d->d_bss,
-                                    d->d_idx, d->d_step, d->d_res, 1, d->pl_window, st)
-        || psgpu_memcpy_d2h(res, d->d_res, sizeof res, st) || psgpu_stream_sync(st)) {
+    one[0] = pcm; n1[0] = n_samples;
+    if (psgpu_decode_first_pass(d->dec, one, n1, 1, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
-    if (res[3]) { E_ERROR("psgpu device decode: back-pointer table or score stack full\n"); return -1; }
-    if (d->ff) {
-        /* ---- the second pass (ngram_search_finish, ngram_search.c:791-808, does it inside ps_end_utt on the host): the
-         *      flat-lexicon search over the first pass's device-resident table, scoring its own senones from the feature
-         *      rows; its scorer state starts from the lists pass 1 left in history slot n_fast_hist - 1 (ptm_mgau.c:425-441),
-         *      i.e. the batch scorer's lists (chain-major [n_chain][T][topn]) of the last frame ts with ts % H == H - 1 */
-        int H = d->n_fast_hist, ts = T - 1, c;
-        while (ts >= 0 && ts % H != H - 1) --ts;
-        if (psgpu_memcpy_d2h(d->h_tcw, d->d_tcw, (size_t)d->n_chain * T * d->topn, st) || psgpu_stream_sync(st)) {
-            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-            return -1;
-        }
-        for (c = 0; c < d->n_chain; ++c)
-            for (i = 0; i < d->topn; ++i)      /* a shorter utterance than H frames never wrote that slot: ptm_mgau_init's i-th codeword */
-                d->h_seed[c * d->topn + i] = ts >= 0 ? d->h_tcw[((size_t)c * T + ts) * d->topn + i] : i;
-        if (psgpu_memcpy_h2d(d->d_seed, d->h_seed, 4 * (size_t)d->n_chain * d->topn, st)
-            || psgpu_fwdflat_search_feats_dev(d->ff, &d->view, d->d_feat, d->d_seed, d->d_off, 1, T, d->bp_cap, d->d_bp, d->d_res,
-                                              d->d_w1, d->bp_cap, d->bss_cap, d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)
-            || psgpu_memcpy_d2h(res, d->d_res2, sizeof res, st) || psgpu_stream_sync(st)) {
-            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-            return -1;
-        }
-        if (res[3]) { E_ERROR("psgpu device decode: second pass: back-pointer table or score stack full\n"); return -1; }
-    }
-    nb = res[0]; nh = res[1]; nfr = res[2];
-    if (psgpu_memcpy_d2h(d->h_bp, d->ff ? d->d_bp2 : d->d_bp, 4 * (size_t)10 * d->bp_cap, st)
-        || psgpu_memcpy_d2h(d->h_bss, d->ff ? d->d_bss2 : d->d_bss, 4 * (size_t)(nh ? nh : 1), st)
-        || psgpu_memcpy_d2h(d->h_idx, d->ff ? d->d_idx2 : d->d_idx, 4 * ((size_t)nfr + 1), st) || psgpu_stream_sync(st)) {
-        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-        return -1;
-    }
-    /* ---- the tables in the reference's layout (ngram_search.h:112-124, ngram_search.c:301-339, 445-497) */
-    if (nb > ngs->bp_table_size) {
-        ngs->bp_table_size = nb + nb / 2;
-        ngs->bp_table = ckd_realloc(ngs->bp_table, ngs->bp_table_size * sizeof(*ngs->bp_table));
-    }
-    if (nh + d->n_ci >= ngs->bscore_stack_size) {
-        ngs->bscore_stack_size = nh + d->n_ci + nh / 2 + 1;
-        ngs->bscore_stack = ckd_realloc(ngs->bscore_stack, ngs->bscore_stack_size * sizeof(*ngs->bscore_stack));
-    }
-    if (nfr + 1 >= ngs->n_frame_alloc) {
-        ngs->n_frame_alloc = nfr + 2;
-        ngs->bp_table_idx = (int32 *)ckd_realloc(ngs->bp_table_idx - 1, (ngs->n_frame_alloc + 1) * sizeof(*ngs->bp_table_idx)) + 1;
-    }
-    for (i = 0; i < nb; ++i) {
-        bptbl_t *e = &ngs->bp_table[i];
-#define COL(c) d->h_bp[(size_t)(c) * d->bp_cap + i]
-        e->frame = COL(0); e->valid = (uint8)COL(1); e->refcnt = 0; e->wid = COL(2); e->bp = COL(3); e->score = COL(4);
-        e->s_idx = COL(5); e->real_wid = COL(6); e->prev_real_wid = COL(7); e->last_phone = (int16)COL(8); e->last2_phone = (int16)COL(9);
-#undef COL
-    }
-    memcpy(ngs->bscore_stack, d->h_bss, sizeof(int32) * nh);
-    memcpy(ngs->bp_table_idx, d->h_idx, sizeof(int32) * (nfr + 1));
-    ngs->bpidx = nb; ngs->bss_head = nh; ngs->n_frame = nfr;
-    ngs->best_score = res[4];        /* ngram_search_lattice (ngram_search.c:1226) refuses an utterance whose best score is WORST_SCORE */
+    if (fetch_summary(d, 1) < 0) return -1;
+    if (d->h_res[3]) { E_ERROR("psgpu device decode: back-pointer table or score stack full\n"); return -1; }
+    if (d->h_res[2] == 0) return 0;
+    if (d->ff) nfr = second_pass_one(d, d->h_res[2]);
+    else nfr = fetch_and_inject(d, 0);
     return nfr;
+}
+
+int
+psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[], const size_t n[], int B)
+{
+    if (d == NULL || B < 0 || (B > 0 && (!pcm || !n))) return -1;
+    if (d->ff) { E_ERROR("psgpu device decode: the device second pass takes one utterance per call (psgpu_device_decode_utt)\n"); return -1; }
+    if (((ngram_search_t *)d->ps->search)->fwdflat) {
+        E_ERROR("psgpu device decode: the batch entry runs pass 1 (-fwdflat no; -bestpath yes searches the injected table per "
+                "utterance); for the reference's second pass use psgpu_device_search_attach + ps_decode_raw\n");
+        return -1;
+    }
+    if (refresh(d) < 0) return -1;
+    d->B = 0;
+    if (psgpu_decode_first_pass(d->dec, pcm, n, B, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    return fetch_summary(d, B);
+}
+
+int
+psgpu_device_decode_batch_select(psgpu_device_decode_t *d, int u)
+{
+    ps_decoder_t *ps;
+    if (d == NULL || u < 0 || u >= d->B) return -1;
+    ps = d->ps;
+    /* the reference's own start / end-of-utterance housekeeping (hypothesis, lattice, timers), no frame through its search */
+    if (ps_start_utt(ps) < 0) return -1;
+    if (ps_end_utt(ps) < 0) return -1;
+    if (d->h_res[(size_t)u * 8 + 2] == 0) return 0;
+    return fetch_and_inject(d, u);
+}
+
+int
+psgpu_device_decode_batch_n_frames(psgpu_device_decode_t *d, int u)
+{
+    psgpu_decode_view_t v;
+    if (d == NULL || u < 0 || u >= d->B || psgpu_decode_view(d->dec, &v) != PSGPU_OK) return -1;
+    return v.frame_off[u + 1] - v.frame_off[u];
+}
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The ps_search_t binding (SURVEY 8b "Search side"): ps_decode_raw() and friends reach the device search.
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* acmod.c:1035-1056 (calc_feat_idx is static there): ring position of a frame's feature vector */
+static int
+feat_ring_index(acmod_t *acmod, int frame_idx)
+{
+    int n_backfr = acmod->n_feat_alloc - acmod->n_feat_frame, feat_idx;
+    if (frame_idx < 0 || acmod->output_frame - frame_idx > n_backfr) return -1;
+    feat_idx = (acmod->feat_outidx + frame_idx - acmod->output_frame) % acmod->n_feat_alloc;
+    if (feat_idx < 0) feat_idx += acmod->n_feat_alloc;
+    return feat_idx;
+}
+
+static int
+dev_search_start(ps_search_t *search)
+{
+    psgpu_device_decode_t *d = find_attached(search);
+    if (d == NULL) return -1;
+    d->n_feat = 0;
+    return d->orig_vt->start(search);          /* ngram_search_start: tables, timers, <s> entered (ngram_search_fwdtree.c:469-520) */
+}
+
+/* called by ps_search_forward (pocketsphinx.c:1173-1197) for frame output_frame - pl_window and by ps_end_utt's drain
+ * loop (:1329-1333): the frame's feature vector is kept, nothing is searched yet */
+static int
+dev_search_step(ps_search_t *search, int frame_idx)
+{
+    psgpu_device_decode_t *d = find_attached(search);
+    acmod_t *acmod = ps_search_acmod(search);
+    int fi, s;
+    float *dst;
+    if (d == NULL) return -1;
+    if (frame_idx != d->n_feat) { E_ERROR("psgpu device search: frame %d after %d frames\n", frame_idx, d->n_feat); return -1; }
+    fi = feat_ring_index(acmod, frame_idx);
+    if (fi < 0) { E_ERROR("psgpu device search: frame %d fell out of the feature window\n", frame_idx); return -1; }
+    if (d->n_feat == d->cap_feat) {
+        d->cap_feat = d->cap_feat ? 2 * d->cap_feat : 1024;
+        d->h_feat = ckd_realloc(d->h_feat, (size_t)d->cap_feat * d->veclen * sizeof(float));
+    }
+    dst = d->h_feat + (size_t)d->n_feat * d->veclen;
+    for (s = 0; s < feat_dimension1(acmod->fcb); ++s) {
+        memcpy(dst, acmod->feat_buf[fi][s], feat_dimension2(acmod->fcb, s) * sizeof(float));
+        dst += feat_dimension2(acmod->fcb, s);
+    }
+    ++d->n_feat;
+    return 1;
+}
+
+static int
+dev_search_finish(ps_search_t *search)
+{
+    psgpu_device_decode_t *d = find_attached(search);
+    ngram_search_t *ngs = (ngram_search_t *)search;
+    int32_t off[2];
+    int nfr = 0;
+    if (d == NULL) return -1;
+    /* the reference's end-of-pass housekeeping on its own (idle) channels and timers; its mark of "one past the last
+     * frame" is overwritten by the injected marks below */
+    ngram_fwdtree_finish(ngs);
+    if (d->n_feat > 0) {
+        if (refresh(d) < 0) return -1;
+        off[0] = 0; off[1] = d->n_feat;
+        if (psgpu_decode_first_pass_feat(d->dec, d->h_feat, off, 1, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+            E_ERROR("psgpu device search: %s\n", psgpu_last_error());
+            return -1;
+        }
+        if (fetch_summary(d, 1) < 0) return -1;
+        if (d->h_res[2] > 0 && (nfr = fetch_and_inject(d, 0)) < 0) return -1;
+    }
+    ngs->n_tot_frame += nfr;
+    if (ngs->fwdflat && nfr > 0) {
+        /* part of what the second pass inherits (ngram_fwdflat_start's hmm_clear keeps them, ngram_search_fwdflat.c:385-392):
+         * the per-state ssids the permanent single-phone word channels ended the first pass with */
+        psgpu_decode_view_t v;
+        int n1 = ngs->n_1ph_words, ne = hmm_n_emit_state(&ngs->root_chan[0].hmm), i, k;
+        int32_t *w1 = ckd_calloc((size_t)n1 * ne + 1, 4);
+        if (psgpu_decode_view(d->dec, &v) != PSGPU_OK
+            || psgpu_memcpy_d2h(w1, v.w1_ssid_dev, 4 * (size_t)n1 * ne, psgpu_hmm_ctx_stream(d->ctx))
+            || psgpu_stream_sync(psgpu_hmm_ctx_stream(d->ctx))) {
+            E_ERROR("psgpu device search: %s\n", psgpu_last_error());
+            ckd_free(w1);
+            return -1;
+        }
+        for (i = 0; i < n1; ++i) {
+            hmm_t *h = &((root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]])->hmm;
+            if (hmm_is_mpx(h))
+                for (k = 0; k < ne; ++k) h->senid[k] = (uint16)w1[(size_t)i * ne + k];
+        }
+        ckd_free(w1);
+        /* ... and the scorer's history: pass 2's first frame re-scores the lists pass 1 left in slot n_fast_hist - 1
+         * (ptm_mgau.c:425-441), i.e. those of the last frame ts with ts % H == H - 1; the batch scorer has them
+         * (chain-major [n_chain][T][topn]) */
+        {
+            int H = d->ps->pl_window + 2, T = v.total_frames, ts = T - 1, c;
+            size_t ne_all = (size_t)d->n_chain * T * d->topn;
+            while (ts >= 0 && ts % H != H - 1) --ts;
+            if (ts >= 0) {
+                int32 *cw = ckd_calloc((size_t)d->n_chain * d->topn + 1, 4);
+                if (ne_all > d->cap_tcw) { FREE_HOST(d->h_tcw); d->cap_tcw = ne_all + ne_all / 2 + 64; d->h_tcw = ckd_calloc(d->cap_tcw, 1); }
+                if (psgpu_memcpy_d2h(d->h_tcw, v.topn_cw_dev, ne_all, psgpu_hmm_ctx_stream(d->ctx))
+                    || psgpu_stream_sync(psgpu_hmm_ctx_stream(d->ctx))) {
+                    E_ERROR("psgpu device search: %s\n", psgpu_last_error());
+                    ckd_free(cw);
+                    return -1;
+                }
+                for (c = 0; c < d->n_chain; ++c)
+                    for (i = 0; i < d->topn; ++i) cw[c * d->topn + i] = d->h_tcw[((size_t)c * T + ts) * d->topn + i];
+                if (psgpu_mgau_seed_history(ps_search_acmod(ngs)->mgau, H - 1, cw) < 0) {
+                    E_ERROR("psgpu device search: could not hand the scorer's history over to the second pass\n");
+                    ckd_free(cw);
+                    return -1;
+                }
+                ckd_free(cw);
+            }
+        }
+    }
+    if (ngs->fwdflat) {
+        /* the reference's second pass over the injected table, exactly as ngram_search_finish runs it (ngram_search.c:791-808) */
+        int i = 0;
+        if (acmod_rewind(ps_search_acmod(ngs)) < 0) return -1;
+        ngram_fwdflat_start(ngs);
+        while (ps_search_acmod(ngs)->n_feat_frame > 0) {
+            int k;
+            if ((k = ngram_fwdflat_search(ngs, i)) < 0) return k;
+            acmod_advance(ps_search_acmod(ngs));
+            ++i;
+        }
+        ngram_fwdflat_finish(ngs);
+    }
+    ngs->done = TRUE;
+    return 0;
+}
+
+/* the look-ahead search of the host has nothing to do: the device pipeline runs its own (psgpu_phone_loop_run_dev) */
+static int
+dev_phone_loop_step(ps_search_t *search, int frame_idx)
+{
+    (void)search; (void)frame_idx;
+    return 1;
+}
+
+int
+psgpu_device_search_attach(psgpu_device_decode_t *d)
+{
+    ps_search_t *s, *pl;
+    ngram_search_t *ngs;
+    if (d == NULL || d->orig_vt) return -1;
+    s = d->ps->search; pl = d->ps->phone_loop;
+    ngs = (ngram_search_t *)s;
+    if (ngs->fwdflat && d->ff) {
+        E_ERROR("psgpu device search: with PSGPU_DEVICE_SECOND_PASS=1 use psgpu_device_decode_utt (the vtable binding runs the "
+                "reference's own second pass)\n");
+        return -1;
+    }
+    d->orig_vt = s->vt; d->vt = *s->vt;
+    d->vt.start = dev_search_start; d->vt.step = dev_search_step; d->vt.finish = dev_search_finish;
+    s->vt = &d->vt;                              /* reinit / free / lattice / hyp / prob / seg_iter stay the reference's */
+    if (pl) {
+        d->orig_pl_vt = pl->vt; d->pl_vt = *pl->vt;
+        d->pl_vt.step = dev_phone_loop_step;
+        pl->vt = &d->pl_vt;
+    }
+    return 0;
+}
+
+void
+psgpu_device_search_detach(psgpu_device_decode_t *d)
+{
+    if (d == NULL || d->orig_vt == NULL) return;
+    if (d->ps->search && d->ps->search->vt == &d->vt) d->ps->search->vt = d->orig_vt;
+    if (d->ps->phone_loop && d->orig_pl_vt && d->ps->phone_loop->vt == &d->pl_vt) d->ps->phone_loop->vt = d->orig_pl_vt;
+    d->orig_vt = NULL; d->orig_pl_vt = NULL;
 }

@@ -1,5 +1,5 @@
-/* integration/psgpu_device_decode.h -- the first pass of an utterance entirely on the MI355X behind
- * the reference's own result API (ps_get_hyp, ps_seg_iter, ...).  See INTEGRATION.md section 2d. */
+/* integration/psgpu_device_decode.h -- the first pass of the n-gram search entirely on the MI355X behind
+ * the reference's own interfaces (ps_search_t vtable, ps_get_hyp, ps_seg_iter, ...).  See INTEGRATION.md section 2d. */
 #ifndef PSGPU_DEVICE_DECODE_H
 #define PSGPU_DEVICE_DECODE_H
 
@@ -11,17 +11,41 @@ extern "C" {
 
 typedef struct psgpu_device_decode_s psgpu_device_decode_t;
 
-/* Reads the decoder's search structures (tree, dictionary, dict2pid, beams, phone loop, language model
- * as a dense table: small vocabularies) and uploads them.  Needs psgpu_mgau_attach(ps) first, the n-gram
- * search with -fwdflat no (-bestpath yes then runs on the host over the injected table), the 1s_c_d_dd feature type, pl_window > 0.  NULL on failure. */
+/* Reads the decoder's search structures (tree, dictionary, dict2pid, beams, phone loop; the language model as
+ * its own trie, or as a dense table for small vocabularies) and uploads them.  Needs psgpu_mgau_attach(ps) first,
+ * the n-gram search with -fwdtree yes, the 1s_c_d_dd feature type, pl_window > 0.  NULL on failure.
+ * Detach BEFORE ps_free(ps).  Dictionary / language-model changes after attach are refused at decode time
+ * (detach and attach again); MLLR updates are picked up. */
 psgpu_device_decode_t *psgpu_device_decode_attach(ps_decoder_t *ps);
 void psgpu_device_decode_detach(psgpu_device_decode_t *d);
+
+/* ---- the ps_search_t binding (pocketsphinx_internal.h:86-127) ------------------------------------------
+ * After this, the decoder's own n-gram search object runs its first pass on the device: start() as the
+ * reference, step() buffers the frame's feature vector, finish() runs scorer -> phone loop -> lexicon-tree
+ * search for the utterance on the MI355X and puts the back-pointer table, score stack and frame marks into the
+ * ngram_search_t in the reference's layout; the host's phone-loop search step becomes a no-op (the device
+ * pipeline runs its own).  Unmodified ps_decode_raw(), ps_process_raw() + ps_end_utt(), ps_get_hyp(),
+ * ps_seg_iter(), ps_get_lattice() work on top; with -fwdflat yes / -bestpath yes the reference's own later
+ * passes run on the injected table.  0 on success. */
+int psgpu_device_search_attach(psgpu_device_decode_t *d);
+void psgpu_device_search_detach(psgpu_device_decode_t *d);
 
 /* = ps_start_utt; ps_process_raw(pcm, n, FALSE, TRUE); ps_end_utt -- with front end, features, senone
  * scores, phone loop and lexicon-tree search on the device; afterwards the decoder's back-pointer
  * table, score stack and frame marks hold the result in the reference's layout, so ps_get_hyp(),
- * ps_seg_iter() etc. work as after a host decode.  Returns the number of frames searched, or -1. */
+ * ps_seg_iter() etc. work as after a host decode.  Returns the number of frames searched, or -1.
+ * (Not to be mixed with psgpu_device_search_attach on the same decoder.) */
 int psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_samples);
+
+/* B utterances through ONE launch set (front end ... search for the whole batch); then, per utterance,
+ * _select(u) does the reference's start/end-of-utterance housekeeping and puts utterance u's tables into the
+ * decoder, after which ps_get_hyp() / ps_seg_iter() / ps_get_lattice() read them.  Every utterance is decoded
+ * from the state a decoder has after ps_start_stream() on its first utterance, so results do not depend on B
+ * or on the order.  _run returns 0 or -1; _select the number of frames searched, or -1. */
+int psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[], const size_t n[], int B);
+int psgpu_device_decode_batch_select(psgpu_device_decode_t *d, int u);
+/* frames the front end produced for utterance u of the last run */
+int psgpu_device_decode_batch_n_frames(psgpu_device_decode_t *d, int u);
 
 #ifdef __cplusplus
 }

@@ -516,6 +516,27 @@ psgpu_mgau_attach(ps_decoder_t *ps)
     return 0;
 }
 
+/* One slot of the PTM scorer's history ring := the given codeword lists (cw [n_chain][topn]; their scores are re-computed
+ * by eval_topn before they are used, ptm_mgau.c:435-441 + :87-136, so only the codewords and their order matter).  For a
+ * search component that scored a pass somewhere else (integration/psgpu_device_decode.c) and hands the scorer back in
+ * the state the reference's own pass would have left. */
+int
+psgpu_mgau_seed_history(ps_mgau_t *ps, int slot, const int32 *cw)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    int32 *sc;
+    int rc, n;
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs || cw == NULL || slot < 0 || slot >= g->cpu->n_fast_hist)
+        return -1;
+    n = g->cpu->g->n_mgau * g->cpu->g->n_feat * g->cpu->max_topn;
+    sc = ckd_calloc(n, sizeof *sc);
+    g->la_c0 = g->la_cn = 0; g->la_expect = -1;
+    psgpu_ptm_state_lookahead(g->state, NULL, 0, 0);           /* drop a stale look-ahead cache */
+    rc = psgpu_ptm_state_set_topn(g->state, slot, cw, sc, NULL);
+    ckd_free(sc);
+    return rc == PSGPU_OK ? 0 : -1;
+}
+
 /* = ptm_mgau_reset_fast_hist (ptm_mgau.c:777-802) for whichever scorer is wrapped:
  * the top-N history a freshly initialised scorer has (the multi-stream scorer is stateless) */
 int

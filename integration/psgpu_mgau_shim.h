@@ -25,6 +25,9 @@ int psgpu_mgau_attach(ps_decoder_t *ps);
  * ptm_mgau.c:777-802).  0, or -1 if `mgau` is not a psgpu scorer. */
 int psgpu_mgau_reset(ps_mgau_t *mgau);
 
+/* history slot `slot` of a wrapped PTM scorer := the codeword lists cw [n_chain][topn] (see psgpu_mgau_shim.c) */
+int psgpu_mgau_seed_history(ps_mgau_t *mgau, int slot, const int32 *cw);
+
 /* Hooks for a device-side search component (integration/psgpu_phone_loop_shim.c): score what
  * lies ahead of `frame` now and return the device rows; account for a fresh frame_eval call
  * that component no longer makes.  0, or -1 when the scorer is not the psgpu PTM scorer with

@@ -35,6 +35,7 @@
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
 #include "psgpu_phone_loop_shim.h"
+#include "ngram_search.h"
 #include "psgpu_device_decode.h"
 #include "phone_loop_search.h"
 #ifdef PSGPU_SEARCH_HOOKS
@@ -109,7 +110,7 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
         const char *k = argv[i];
         if (k[0] == '-') ++k;
         if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search")
-            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop") || !strcmp(k, "psgpu_device_search"))
+            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop") || !strcmp(k, "psgpu_device_search") || !strcmp(k, "psgpu_device_vtable"))
             continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
@@ -242,7 +243,7 @@ main(int argc, char **argv)
     int use_search = 0;
 #endif
     long hmm_batches = 0, hmm_evals = 0, pl_dev = 0, pl_host = 0;
-    int use_pl = 0, pl_bad = 0, use_dd = 0;
+    int use_pl = 0, pl_bad = 0, use_dd = 0, use_dv = 0;
 
     if (argc < 6) {
         fprintf(stderr, "usage: dropin_decode MODELDIR LM|- DICT|- RAW NREP [key val ...]\n");
@@ -286,6 +287,9 @@ main(int argc, char **argv)
         if (!strcmp(argv[i], "psgpu_search")) use_search = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_phone_loop")) use_pl = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_device_search")) use_dd = !strcmp(argv[i + 1], "yes");
+        /* "psgpu_device_vtable yes": decoder B's n-gram search gets the device ps_searchfuncs_t (psgpu_device_search_attach)
+         * and is then driven by the UNMODIFIED public calls below (ps_start_utt / ps_process_raw / ps_end_utt) */
+        if (!strcmp(argv[i], "psgpu_device_vtable")) use_dv = use_dd = !strcmp(argv[i + 1], "yes");
         if (!strcmp(argv[i], "psgpu_fe") && !strcmp(argv[i + 1], "yes")) {
             g_fe = psgpu_fe_wrap(gpu->acmod->fe);
             if (!g_fe) { fprintf(stderr, "psgpu_fe_wrap failed\n"); return 3; }
@@ -306,6 +310,7 @@ main(int argc, char **argv)
     if (use_dd) {
         g_dd = psgpu_device_decode_attach(gpu);
         if (!g_dd) { fprintf(stderr, "psgpu_device_decode_attach failed\n"); return 3; }
+        if (use_dv && psgpu_device_search_attach(g_dd) < 0) { fprintf(stderr, "psgpu_device_search_attach failed\n"); return 3; }
     }
     if (use_pl) {
         if (psgpu_phone_loop_attach(gpu) < 0) { fprintf(stderr, "psgpu_phone_loop_attach failed\n"); return 3; }
@@ -356,7 +361,8 @@ main(int argc, char **argv)
                 ckd_free_2d(mfcs);
                 mfcs = read_mfc(path, ps_config_int(ps_get_config(cpu), "ceplen"), &nfr);
             }
-            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k], g_dd ? 2 : (g_fe != NULL)); t_gpu += now_s() - t0;
+            g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k], (g_dd && !use_dv) ? 2 : (g_fe != NULL)); t_gpu += now_s() - t0;
+            if (use_dv) { g_dd_frames += ((ngram_search_t *)gpu->search)->n_frame; }
             if (strcmp(ra[k].hyp, rb[k].hyp) || ra[k].score != rb[k].score) hyp_equal = 0;
             if (strcmp(ra[k].seg, rb[k].seg)) seg_equal = 0;
             total_frames += ra[k].n_frames;

@@ -19,5 +19,6 @@ from .fe import FrontEnd  # noqa: F401
 from .search import FwdtreeSearch, backtrace  # noqa: F401
 from .lm import NGramTrieLM  # noqa: F401
 from .flat import FwdflatSearch  # noqa: F401
+from .decode import DecodePipeline  # noqa: F401
 
-__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch", "backtrace", "NGramTrieLM", "FwdflatSearch"]
+__all__ = ["PsgpuError", "lib", "build_library", "LIB_PATH", "PtmModel", "PtmMgau", "PtmState", "HmmContext", "HMM_REC", "SemiMgau", "MsMgau", "dynfeat_1s_c_d_dd", "FrontEnd", "FwdtreeSearch", "backtrace", "NGramTrieLM", "FwdflatSearch", "DecodePipeline"]

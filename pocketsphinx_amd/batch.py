@@ -102,3 +102,40 @@ def max_over_ranks(seconds, group=None, device="cpu"):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def scatter_pcm(recv, pcm_all, n_per_rank, group=None, src=0, device="cpu"):
+    """Rank `src` holds the 16-bit samples of the whole job back to back (numpy int16, world * n_per_rank); every rank's
+    share lands in `recv` (torch int16 [n_per_rank] on `device`).  One rank's share at a time is staged on `src`'s
+    device, so the source never needs more than two shares resident."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert recv.dtype == torch.int16 and recv.numel() == n_per_rank
+    if rank == src:
+        pcm_all = np.ascontiguousarray(pcm_all, np.int16).reshape(-1)
+        assert pcm_all.size == world * n_per_rank
+        recv.copy_(torch.from_numpy(pcm_all[src * n_per_rank:(src + 1) * n_per_rank]))
+        for r in range(world):
+            if r == src:
+                continue
+            stage = torch.from_numpy(pcm_all[r * n_per_rank:(r + 1) * n_per_rank]).to(device)
+            dist.send(stage, dst=r, group=group)
+    else:
+        dist.recv(recv, src=src, group=group)
+    return recv
+
+
+def gather_records(local, group=None, dst=0, device="cpu"):
+    """Fixed-size result records (torch tensor, same shape on every rank) of every rank to `dst`: returns
+    [world * n][...] there (rank order = utterance order of a block-sharded job), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local = local.contiguous()
+    if rank == dst:
+        bufs = [torch.empty_like(local) for _ in range(world)]
+        dist.gather(local, bufs, dst=dst, group=group)
+        return torch.cat(bufs, dim=0)
+    dist.gather(local, None, dst=dst, group=group)
+    return None

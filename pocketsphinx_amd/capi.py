@@ -32,8 +32,8 @@ SYMBOLS = [
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval", "psgpu_phone_loop_run_dev", "psgpu_hmm_ctx_stream",
     "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_set_lm", "psgpu_fwdtree_backtrace_dev", "psgpu_fwdtree_layout", "psgpu_fwdtree_n_single_phone_words",
-    "psgpu_decode_create", "psgpu_decode_free", "psgpu_decode_set_model", "psgpu_decode_first_pass_dev", "psgpu_decode_first_pass",
-    "psgpu_decode_view", "psgpu_decode_fetch_hyps", "psgpu_decode_fetch_tables",
+    "psgpu_decode_create", "psgpu_decode_free", "psgpu_decode_set_model", "psgpu_decode_first_pass_dev", "psgpu_decode_first_pass", "psgpu_decode_first_pass_feat",
+    "psgpu_decode_view", "psgpu_decode_fetch_hyps", "psgpu_decode_fetch_tables", "psgpu_decode_stage_timing", "psgpu_decode_last_stage_ms",
     "psgpu_fwdflat_create", "psgpu_fwdflat_free", "psgpu_fwdflat_set_lm", "psgpu_fwdflat_search_dev", "psgpu_fwdflat_search_feats_dev", "psgpu_ptm_model_view",
     "psgpu_lm_create", "psgpu_lm_free", "psgpu_lm_tg_score_dev",
 ]
@@ -45,19 +45,33 @@ class PsgpuError(RuntimeError):
 
 def build_library(force=False):
     """Compile the HIP sources for gfx950 into pocketsphinx_amd/libpsgpu.so
-    (in-tree, so it travels to the GPU box).  hipcc cross-compiles without a GPU."""
+    (in-tree, so it travels to the GPU box).  hipcc cross-compiles without a GPU.
+    One object per source under pocketsphinx_amd/_build/ (recompiled when the source or a header is newer),
+    compiled in parallel, then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "psgpu_internal.h"), os.path.join(CSRC, "psgpu_ptm_dev.h"), os.path.join(CSRC, "psgpu_hmm_dev.h"), os.path.join(CSRC, "psgpu_lm_dev.h"), os.path.join(ROOT, "include", "psgpu.h")]
+    hdrs = [os.path.join(CSRC, h) for h in ("psgpu_internal.h", "psgpu_ptm_dev.h", "psgpu_hmm_dev.h", "psgpu_lm_dev.h")] + \
+        [os.path.join(ROOT, "include", "psgpu.h")]
     if (not force) and os.path.exists(LIB_PATH) and \
-            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-           # packed fp32 (v_pk_*) runs at half rate on gfx950 and the SLP pass
-           # doubles register pressure here: keep the distance chain scalar
-           "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-unused-result", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
-           "-o", LIB_PATH] + srcs
-    subprocess.check_call(cmd)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+             # packed fp32 (v_pk_*) runs at half rate on gfx950 and the SLP pass
+             # doubles register pressure here: keep the distance chain scalar
+             "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-unused-result", "-fPIC", "-I" + os.path.join(ROOT, "include")]
+    bdir = os.path.join(PKG_DIR, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+
+    def compile_one(src):
+        obj = os.path.join(bdir, os.path.basename(src) + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
+            subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
     return LIB_PATH
 
 

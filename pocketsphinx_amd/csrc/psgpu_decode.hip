@@ -31,7 +31,13 @@ struct psgpu_decode_s {
     std::vector<int32_t> frame_off;
     std::vector<int64_t> soff;
     std::vector<int16_t> stage;
+    // optional per-stage timing: events on the launch stream around front end | features | scorer | phone loop | search | backtrace
+    bool timing = false;
+    hipEvent_t ev[7] = {};
+    bool ev_valid = false;
 };
+
+static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
 
 #define DFREE(p) do { if (p) { hipFree(p); (p) = nullptr; } } while (0)
 
@@ -84,6 +90,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
+    for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     delete d;
 }
 
@@ -136,6 +143,30 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
     return PSGPU_OK;
 }
 
+// scores -> phone loop -> tree search -> backtrace on the features in d_feat / the frame offsets in d_off
+static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t mf, hipStream_t st)
+{
+    int rc;
+    dec_mark(d, 2, st);
+    if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, nullptr, nullptr, d->d_tsc, d->d_tcw,
+                                        d->d_rows, d->d_best, PSGPU_PTM_RAW_SCORES, st)))
+        return rc;
+    dec_mark(d, 3, st);
+    if ((rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
+                                       nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st)))
+        return rc;
+    dec_mark(d, 4, st);
+    // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
+    if ((rc = psgpu_fwdtree_search_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
+                                       d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1, st)))
+        return rc;
+    dec_mark(d, 5, st);
+    rc = psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp, d->d_idx, d->d_res, n_utt, (int32_t)mf, d->bp_cap, d->max_words, d->d_hyp,
+                                     d->d_hn, st);
+    dec_mark(d, 6, st);
+    return rc;
+}
+
 int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, void *stream)
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm_dev && samp_off)), "psgpu_decode_first_pass_dev: bad argument");
@@ -154,26 +185,52 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
     if (rc != PSGPU_OK) return rc;
     d->total = (int32_t)total; d->max_frames = (int32_t)mf;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
+    d->ev_valid = false;
+    dec_mark(d, 0, st);
     if ((rc = psgpu_fe_process_utts_dev(d->cfg.fe, pcm_dev, samp_off, n_utt, nullptr, nullptr, d->d_cep, d->d_off, d->frame_off.data(), st)))
         return rc;
+    dec_mark(d, 1, st);
     if (total == 0) {                                   // nothing but empty utterances: empty results
         PSGPU_HIP(hipMemsetAsync(d->d_res, 0, 4 * (size_t)n_utt * 8, st));
         PSGPU_HIP(hipMemsetAsync(d->d_hn, 0, 4 * (size_t)n_utt * 4, st));
         return PSGPU_OK;
     }
     if ((rc = psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, n_utt, d->cepsize, d->d_feat, st))) return rc;
-    if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, nullptr, nullptr, d->d_tsc, d->d_tcw,
-                                        d->d_rows, d->d_best, PSGPU_PTM_RAW_SCORES, st)))
-        return rc;
-    if ((rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
-                                       nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st)))
-        return rc;
-    // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
-    if ((rc = psgpu_fwdtree_search_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
-                                       d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1, st)))
-        return rc;
-    return psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp, d->d_idx, d->d_res, n_utt, (int32_t)mf, d->bp_cap, d->max_words, d->d_hyp,
-                                       d->d_hn, st);
+    if ((rc = dec_from_feat(d, n_utt, total, mf, st))) return rc;
+    d->ev_valid = d->timing;
+    return PSGPU_OK;
+}
+
+// feature vectors in, from the host: feat [total][3 * cepsize] as feat_s2mfc2feat_live leaves them (acmod->feat_buf),
+// frame_off [n_utt + 1].  For a binding whose host has already run the reference's own front end (ps_process_raw).
+int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int32_t *frame_off, int32_t n_utt, void *stream)
+{
+    PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (feat && frame_off)), "psgpu_decode_first_pass_feat: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0;
+    d->frame_off.assign(frame_off, frame_off + (n_utt ? n_utt + 1 : 0));
+    if (n_utt == 0) { d->frame_off.assign(1, 0); return PSGPU_OK; }
+    PSGPU_REQUIRE(frame_off[0] == 0, "psgpu_decode_first_pass_feat: frame offsets start at 0");
+    size_t mf = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        PSGPU_REQUIRE(frame_off[u + 1] >= frame_off[u], "psgpu_decode_first_pass_feat: frame offsets must not decrease");
+        mf = std::max(mf, (size_t)(frame_off[u + 1] - frame_off[u]));
+    }
+    const size_t total = (size_t)frame_off[n_utt];
+    int rc = dec_grow(d, (size_t)n_utt, total ? total : 1, mf, st);
+    if (rc != PSGPU_OK) return rc;
+    d->total = (int32_t)total; d->max_frames = (int32_t)mf;
+    d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
+    PSGPU_HIP(hipStreamSynchronize(st));                 // frame_off / feat are the caller's: copied before returning
+    PSGPU_HIP(hipMemcpyAsync(d->d_off, frame_off, 4 * ((size_t)n_utt + 1), hipMemcpyHostToDevice, st));
+    if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * 3 * d->cepsize, hipMemcpyHostToDevice, st));
+    PSGPU_HIP(hipStreamSynchronize(st));
+    if (total == 0) {
+        PSGPU_HIP(hipMemsetAsync(d->d_res, 0, 4 * (size_t)n_utt * 8, st));
+        PSGPU_HIP(hipMemsetAsync(d->d_hn, 0, 4 * (size_t)n_utt * 4, st));
+        return PSGPU_OK;
+    }
+    return dec_from_feat(d, n_utt, total, mf, st);
 }
 
 int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const size_t n[], int32_t n_utt, void *stream)
@@ -195,6 +252,25 @@ int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const
     for (int u = 0; u < n_utt; ++u) if (n[u]) memcpy(d->stage.data() + d->soff[u], pcm[u], 2 * n[u]);
     if (ns) PSGPU_HIP(hipMemcpyAsync(d->d_pcm, d->stage.data(), 2 * ns, hipMemcpyHostToDevice, st));
     return psgpu_decode_first_pass_dev(d, d->d_pcm, d->soff.data(), n_utt, st);
+}
+
+int psgpu_decode_stage_timing(psgpu_decode_t *d, int32_t enable)
+{
+    PSGPU_REQUIRE(d, "psgpu_decode_stage_timing: NULL argument");
+    if (enable && !d->ev[0])
+        for (int i = 0; i < 7; ++i) PSGPU_HIP(hipEventCreate(&d->ev[i]));
+    d->timing = enable != 0;
+    d->ev_valid = false;
+    return PSGPU_OK;
+}
+
+int psgpu_decode_last_stage_ms(psgpu_decode_t *d, float ms[6])
+{
+    PSGPU_REQUIRE(d && ms, "psgpu_decode_last_stage_ms: NULL argument");
+    PSGPU_REQUIRE(d->ev_valid, "psgpu_decode_last_stage_ms: no timed psgpu_decode_first_pass_dev call yet");
+    PSGPU_HIP(hipEventSynchronize(d->ev[6]));
+    for (int i = 0; i < 6; ++i) PSGPU_HIP(hipEventElapsedTime(&ms[i], d->ev[i], d->ev[i + 1]));
+    return PSGPU_OK;
 }
 
 int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v)

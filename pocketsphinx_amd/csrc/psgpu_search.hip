@@ -286,6 +286,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
     __shared__ int32_t s_nwc, s_nwc2;    // lengths of the word level's evaluation list and of the entering list
+    __shared__ int32_t s_nsen;           // listed senones, summed over the frames (raw-score mode)
     const int tid = threadIdx.x;
     const int N = p.N, R = p.R, n1 = p.n1, n_ci = p.n_ci;
     const FtLay &L = p.lay;
@@ -340,7 +341,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // small layout only
     int32_t *const s_pen = fb + L.pen;                                      // small layout only: [2][n_ci]
 
-    const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
+    // an utterance shorter than the look-ahead window is never searched by the reference: ps_end_utt steps the main search
+    // over the last pl_window frames only `if (output_frame >= pl_window)` (pocketsphinx.c:1329-1333)
+    const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0, T = (raw_mode && T_in < pl_window) ? 0 : T_in;
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
 
@@ -352,7 +355,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     for (int c = tid; c < N; c += NT) pos[c] = -1;       // pos is kept at -1 between frames
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
-        s_evals = 0ull; s_nb = 0x7fffffff;
+        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0;
     }
     {
         const int nwords = (p.n_sen + 31) >> 5;
@@ -438,6 +441,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             for (int w = tid; w < nwords; w += NT) {
                 uint32_t b = s_bits[w];
                 if (!b) continue;
+                atomicAdd(&s_nsen, __popc(b));
                 // the highest senone listed before this bitmap word (acmod_flags2list bridges gaps > 255 from it)
                 int prev = -1;
                 for (int q = w - 1; q >= 0; --q) { const uint32_t pb = s_bits[q]; if (pb) { prev = q * 32 + 31 - __clz((int)pb); break; } }
@@ -942,6 +946,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
         result[0] = s_sc[3]; result[1] = s_sc[4]; result[2] = s_sc[7]; result[3] = s_sc[6];
         result[4] = s_sc[0];                                     // ngs->best_score as the last frame left it
+        result[5] = (int32_t)(s_evals & 0xffffffffull); result[6] = (int32_t)(s_evals >> 32); result[7] = s_nsen;
     }
     // what the second pass inherits besides the tables: the permanent single-phone channels keep their per-state ssids
     // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)

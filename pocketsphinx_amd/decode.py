@@ -1,0 +1,135 @@
+"""Host-side mirror of the batch first pass (include/psgpu.h, psgpu_decode_*): PCM of a batch of utterances ->
+hypotheses, every stage on the MI355X (csrc/psgpu_decode.hip).  The device side of ps_decode_raw() with
+-fwdflat no -bestpath no (reference src/pocketsphinx.c:1030-1070) followed by ngram_search_bp_hyp
+(src/ngram_search.c:546-581) for a batch."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .fe import FrontEnd
+from .hmm import HmmContext
+from .ptm import PtmModel
+from .search import FwdtreeSearch
+
+
+class _PlPar(C.Structure):
+    _fields_ = [("n_phones", C.c_int32), ("window", C.c_int32), ("beam", C.c_int32), ("pbeam", C.c_int32),
+                ("pip", C.c_int32), ("penalty_weight", C.c_double)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("fe", C.c_void_p), ("model", C.c_void_p), ("ctx", C.c_void_p), ("ft", C.c_void_p), ("pl", _PlPar),
+                ("pl_ssid", C.c_void_p), ("pl_tmatid", C.c_void_p), ("ci_list", C.c_void_p), ("n_ci_list", C.c_int32),
+                ("pl_window", C.c_int32), ("max_words", C.c_int32)]
+
+
+class DecodeView(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_utt", "total_frames", "max_frames", "bp_cap", "bss_cap", "max_words")] + \
+               [(n, C.c_void_p) for n in ("frame_off", "frame_off_dev", "feat_dev", "topn_cw_dev", "rows_dev", "penalties_dev",
+                                          "bp_dev", "bss_dev", "idx_dev", "step_dev", "result_dev", "hyp_dev", "hyp_n_dev",
+                                          "w1_ssid_dev")]
+
+
+def ci_senone_list(sseq, pl_ssid, n_sen):
+    """the senone list acmod_flags2list (reference src/acmod.c:1223-1275) builds when every CI phone is active: the
+    listed senones in order, gaps > 255 bridged by extra entries"""
+    fl = np.zeros(n_sen, bool)
+    fl[np.asarray(sseq)[np.asarray(pl_ssid)].reshape(-1)] = True
+    out, last = [], 0
+    for s in np.nonzero(fl)[0]:
+        while s - last > 255:
+            last += 255; out.append(last)
+        out.append(int(s)); last = int(s)
+    return np.array(out, np.uint16)
+
+
+class DecodePipeline:
+    """fe_tables: FrontEnd tables; ptm_tables: PtmModel tables; static / par: FwdtreeSearch tables; trace: the phone
+    loop's parameters as `ref_dump fwdtree` writes them (pl_par = n_phones, window, beam, pbeam, pip, pl_window;
+    pl_weight; pl_ssid; pl_tmat); lm: an NGramTrieLM or None (dense table in `static`)."""
+
+    def __init__(self, fe_tables, ptm_tables, static, par, trace, lm=None, max_words=512):
+        self.fe = FrontEnd(fe_tables)
+        self.model = PtmModel(ptm_tables)
+        self.search = FwdtreeSearch(static, par, lm=lm)
+        self.ctx = HmmContext(static["tp"], static["sseq"], self.model.n_sen)
+        self.max_words = int(max_words)
+        pl = [int(v) for v in trace["pl_par"]]
+        ssid = np.ascontiguousarray(trace["pl_ssid"], np.uint16)
+        tmat = np.ascontiguousarray(trace["pl_tmat"], np.int16)
+        cil = ci_senone_list(static["sseq"], trace["pl_ssid"], self.model.n_sen)
+        cfg = _Config(self.fe.h, self.model.h, self.ctx.h, self.search.h,
+                      _PlPar(pl[0], pl[1], pl[2], pl[3], pl[4], float(trace["pl_weight"][0])),
+                      ssid.ctypes.data, tmat.ctypes.data, cil.ctypes.data, int(cil.size), pl[5], self.max_words)
+        self.h = C.c_void_p()
+        capi.check(capi.lib().psgpu_decode_create(C.byref(self.h), C.byref(cfg)), "psgpu_decode_create")
+        self.n_utt = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().psgpu_decode_free(self.h)
+            self.h = None
+            self.search.close(); self.ctx.close(); self.model.close(); self.fe.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stage_timing(self, on=True):
+        capi.check(capi.lib().psgpu_decode_stage_timing(self.h, int(bool(on))), "psgpu_decode_stage_timing")
+
+    def last_stage_ms(self):
+        ms = (C.c_float * 6)()
+        capi.check(capi.lib().psgpu_decode_last_stage_ms(self.h, ms), "psgpu_decode_last_stage_ms")
+        return dict(zip(("front_end", "features", "scorer", "phone_loop", "search", "backtrace"), [float(v) for v in ms]))
+
+    def run_dev(self, pcm_dev, samp_off, stream=None):
+        """pcm_dev: torch int16 tensor on the device (utterances back to back), samp_off: int64 numpy [n_utt + 1].
+        Asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        samp_off = np.ascontiguousarray(samp_off, np.int64)
+        self._keep = (pcm_dev, samp_off)
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        self.n_utt = int(samp_off.size - 1)
+        capi.check(capi.lib().psgpu_decode_first_pass_dev(self.h, C.c_void_p(pcm_dev.data_ptr()), samp_off.ctypes.data_as(C.c_void_p),
+                                                          self.n_utt, st), "psgpu_decode_first_pass_dev")
+        self._stream = st
+
+    def run(self, pcms, stream=None):
+        """pcms: list of int16 numpy arrays (host)."""
+        import torch
+        pcms = [np.ascontiguousarray(p, np.int16).reshape(-1) for p in pcms]
+        n = len(pcms)
+        ptrs = (C.c_void_p * max(n, 1))(*[p.ctypes.data for p in pcms])
+        lens = (C.c_size_t * max(n, 1))(*[p.size for p in pcms])
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        self.n_utt = n
+        capi.check(capi.lib().psgpu_decode_first_pass(self.h, ptrs, lens, n, st), "psgpu_decode_first_pass")
+        self._stream = st
+
+    def fetch(self, want_hyp=True):
+        """(hyp_n [n][4], hyp [n][max_words][4] or None, result [n][8]) on the host; waits for the pipeline."""
+        n = self.n_utt
+        hn = np.zeros((n, 4), np.int32); res = np.zeros((n, 8), np.int32)
+        hyp = np.zeros((n, self.max_words, 4), np.int32) if want_hyp else None
+        capi.check(capi.lib().psgpu_decode_fetch_hyps(self.h, hn.ctypes.data_as(C.c_void_p),
+                                                      hyp.ctypes.data_as(C.c_void_p) if want_hyp else None,
+                                                      res.ctypes.data_as(C.c_void_p), self._stream), "psgpu_decode_fetch_hyps")
+        return hn, hyp, res
+
+    def view(self):
+        v = DecodeView()
+        capi.check(capi.lib().psgpu_decode_view(self.h, C.byref(v)), "psgpu_decode_view")
+        return v
+
+    def tables(self, u, res):
+        """utterance u's back-pointer table [n][10], score stack and frame marks on the host"""
+        nb, nh, nfr = int(res[u, 0]), int(res[u, 1]), int(res[u, 2])
+        bp = np.zeros((10, max(nb, 1)), np.int32); bss = np.zeros(max(nh, 1), np.int32); idx = np.zeros(nfr + 1, np.int32)
+        capi.check(capi.lib().psgpu_decode_fetch_tables(self.h, int(u), nb, nh, nfr + 1, bp.ctypes.data_as(C.c_void_p),
+                                                        bss.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), self._stream),
+                   "psgpu_decode_fetch_tables")
+        return dict(bp=bp[:, :nb].T.copy(), bscore_stack=bss[:nh].copy(), bp_table_idx=idx, n_frame=nfr, status=int(res[u, 3]))

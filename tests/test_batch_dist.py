@@ -79,3 +79,42 @@ def test_sharded_scoring_gloo_world2():
     ok, tmax, nrows = q.get(timeout=10)
     assert ok and nrows == 68
     assert tmax == 2.0
+
+
+def _worker_pcm(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 1000
+        pcm_all = (np.arange(world * n) % 30011 - 15000).astype(np.int16) if rank == 0 else None
+        mine = batch.scatter_pcm(torch.empty(n, dtype=torch.int16), pcm_all, n)
+        want = (np.arange(rank * n, (rank + 1) * n) % 30011 - 15000).astype(np.int16)
+        ok = bool(np.array_equal(mine.numpy(), want))
+        # every rank's "hypothesis records": [4 utterances][3 words][4] int32, tagged with the rank
+        rec = torch.full((4, 3, 4), rank, dtype=torch.int32) + torch.arange(4, dtype=torch.int32).reshape(4, 1, 1)
+        full = batch.gather_records(rec)
+        if rank == 0:
+            ok = ok and tuple(full.shape) == (4 * world, 3, 4) and all(int(full[4 * r + u, 0, 0]) == r + u for r in range(world) for u in range(4))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pcm_scatter_and_record_gather_gloo_world2():
+    """what bench.py --gpus N moves: rank 0's PCM to the ranks before the timed region, the ranks' fixed-size hypothesis
+    records back to rank 0 inside it"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_pcm, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=10) for _ in range(2))
+    assert got == {0: True, 1: True}

@@ -1,0 +1,89 @@
+"""GPU parity of the batch first pass as one device pipeline (psgpu_decode_*, csrc/psgpu_decode.hip; the device side
+of ps_decode_raw with -fwdflat no -bestpath no, reference src/pocketsphinx.c:1030-1070): PCM in, back-pointer tables
+and hypotheses out, against (a) the reference decoder's recorded tables for the bundled recordings (ref_dump fwdtree
+goldens) and (b) the compiled reference decoding the SAME synthetic 30 s utterances the benchmark uses
+(oracle/_ref/ref_decode_bench), word ids and frame boundaries."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pso
+from test_oracle_golden import _load
+from test_search_gpu import _check
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipeline(tables):
+    import pocketsphinx_amd as P
+    gt = _load("fwdtree_trace_goforward.npz")
+    return P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), tables, _load("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+
+
+def test_pipeline_tables_equal_the_reference_decoders(tables):
+    """a ragged batch with an empty utterance and one shorter than the look-ahead window (which the reference never
+    searches: ps_end_utt, pocketsphinx.c:1329-1333): every utterance's tables are the reference's for that recording"""
+    import torch
+    import pocketsphinx_amd as P
+    clips = _load("speech_clips.npz")
+    p = _pipeline(tables)
+    names = ["goforward", "numbers", None, "short", "goforward"]
+    pcms = [clips[n] if n in ("goforward", "numbers") else (np.zeros(0, np.int16) if n is None else clips["goforward"][:700]) for n in names]
+    p.stage_timing(True)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    assert p.last_stage_ms()["search"] > 0
+    for u, n in enumerate(names):
+        if n in ("goforward", "numbers"):
+            g = _load("fwdtree_trace_%s.npz" % n)
+            r = p.tables(u, res)
+            r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)     # (the pipeline keeps no per-frame trace)
+            _check(r, g, "%s in a batch" % n)
+            score, words = P.backtrace(r, int(g["par"][20]))
+            assert int(hn[u, 0]) == len(words) and int(hn[u, 1]) == score == int(g["hyp_score"][0])
+            assert [tuple(int(v) for v in hyp[u, i, :3]) for i in range(len(words))] == words
+            assert [(int(a), int(b)) for a, b in g["seg"][:, :2]] == [(sf, ef) for _, sf, ef in words]
+            assert int(res[u, 5]) > 0 and int(res[u, 7]) > 0            # workload counters: HMM evaluations, listed senones
+        else:
+            assert int(res[u, 2]) == 0 and int(hn[u, 0]) == 0 and int(res[u, 3]) == 0, (n, res[u], hn[u])
+    # the same batch again, from device-resident PCM, gives the same words (buffers are re-used)
+    off = np.zeros(len(pcms) + 1, np.int64); off[1:] = np.cumsum([x.size for x in pcms])
+    d_pcm = torch.from_numpy(np.concatenate(pcms)).cuda()
+    p.run_dev(d_pcm, off)
+    hn2, hyp2, res2 = p.fetch()
+    assert np.array_equal(hn, hn2) and np.array_equal(res[:, :5], res2[:, :5])
+    for u in range(len(names)):
+        assert np.array_equal(hyp[u, :hn[u, 0]], hyp2[u, :hn2[u, 0]])
+    p.close()
+
+
+@pytest.mark.parametrize("seconds,ids", [(30.0, (0, 3, 511)), (60.0, (7,))])
+def test_pipeline_equals_the_reference_on_synthetic_utterances(tables, tmp_path, seconds, ids):
+    """BASELINE configs[4] / configs[2] material: the benchmark's synthetic utterances, decoded by the compiled reference
+    on the host and by the pipeline on the device: same words (dictionary ids), same frame boundaries, same path score"""
+    ref = os.path.join(pso.REF_DIR, "ref_decode_bench")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    from pocketsphinx_amd import synth
+    pcms = [synth.utterance(i, seconds) for i in ids]
+    raw = tmp_path / "utts.raw"
+    np.concatenate(pcms).tofile(raw)
+    data = os.path.join(pso.REF_DIR, "data")
+    out = subprocess.run([ref, os.path.join(pso.REF_DIR, "model", "en-us"), os.path.join(data, "turtle.lm.bin"),
+                          os.path.join(data, "turtle.dic"), str(raw), str(pcms[0].size)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    refs = [json.loads(ln) for ln in out.stdout.strip().splitlines()][:-1]
+    p = _pipeline(tables)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    for u, r in enumerate(refs):
+        assert int(res[u, 3]) == 0 and int(res[u, 2]) == r["frames"], (res[u], r["frames"])
+        assert int(res[u, 0]) == r["n_bp"] and int(res[u, 1]) == r["n_bss"]
+        got = [tuple(int(v) for v in hyp[u, i, :3]) for i in range(int(hn[u, 0]))]
+        want = [(s[1], s[2], s[3]) for s in r["seg"]]
+        assert got == want, "utterance %d: %r vs %r" % (ids[u], got[:6], want[:6])
+        assert int(hn[u, 1]) == r["score"]
+    p.close()

@@ -463,9 +463,47 @@ def test_dropin_device_first_pass(raw, nrep, extra, lm, dic, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("raw,nrep,extra,lm,dic", [
+    ("goforward.raw", 2, ("fwdflat", "no", "bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
+    ("numbers.raw", 1, ("fwdflat", "no", "bestpath", "yes"), "turtle.lm.bin", "turtle.dic"),     # lattice pass over the injected table
+    ("goforward.raw", 1, (), "turtle.lm.bin", "turtle.dic"),                                      # the default three passes
+    ("numbers.raw", 1, (), "turtle.lm.bin", "turtle.dic"),
+    ("something.raw", 1, ("fwdflat", "no", "bestpath", "no", "pl_window", "2", "pl_weight", "1.5"), "turtle.lm.bin", "turtle.dic"),
+    ("goforward.raw", 1, ("fwdflat", "no", "bestpath", "no"), "medium.arpa", "medium.dic"),      # trie language model on the device
+])
+def test_dropin_device_search_vtable(raw, nrep, extra, lm, dic):
+    """psgpu_device_vtable yes (integration/psgpu_device_decode.c, psgpu_device_search_attach): decoder B's n-gram search
+    object carries the device ps_searchfuncs_t and is driven by the UNMODIFIED public calls -- ps_start_utt,
+    ps_process_raw(full_utt), ps_end_utt, ps_get_hyp, ps_seg_iter: step() buffers feature vectors, finish() runs scorer ->
+    phone loop -> lexicon-tree search on the MI355X and injects the tables; with -fwdflat yes / -bestpath yes the
+    reference's own later passes run on them.  Hypothesis, path score and every segment equal the CPU decoder's."""
+    r = run(raw, nrep, "psgpu_device_vtable", "yes", *extra, lm=lm, dic=dic)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert r["n_seg"] > 0 and r["device_search_frames"] > 0, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers,extra,reps", [
+    (1, ("fwdflat", "no", "bestpath", "no"), 1),
+    (2, ("fwdflat", "no", "bestpath", "yes"), 1),          # each utterance's lattice pass on the host over its injected table
+    (1, ("fwdflat", "no", "bestpath", "no"), 11),          # B = 66
+])
+def test_decode_batch_api_device_first_pass(workers, extra, reps):
+    """psgpu_decode_batch(..., PSGPU_BATCH_DEVICE_FIRST_PASS = 16): B utterances through ONE launch set of the device
+    pipeline (front end, features, scores, phone loop, lexicon-tree search), the reference's own ps_get_hyp / ps_seg_iter
+    reading each utterance's injected tables.  Every result equals a fresh unmodified CPU decoder's -- batch in order,
+    reversed, and one utterance at a time."""
+    r = _batch_api(workers, 16, FILES * reps, *extra)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["B"] == len(FILES) * reps and r["mismatch_batch"] == r["mismatch_reversed"] == r["mismatch_single"] == 0
+    assert r["hyps"][0] == "go forward ten meters"
+
+
+@pytest.mark.gpu
 def test_dropin_device_first_pass_refuses_other_setups():
     """attach fails loudly (exit code 3 of the harness) when the decoder is not a pass-1-only n-gram setup."""
     argv = [BIN, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"),
-            os.path.join(DATA, "goforward.raw"), "1", "psgpu_device_search", "yes"]
+            os.path.join(DATA, "goforward.raw"), "1", "psgpu_device_search", "yes", "fwdtree", "no"]
     p = subprocess.run(argv, capture_output=True, text=True, timeout=300)
     assert p.returncode == 3, (p.returncode, p.stderr[-500:])

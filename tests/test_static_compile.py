@@ -1,7 +1,6 @@
 """Compile-time guards for the search kernels (no GPU needed: hipcc cross-compiles gfx950): register budget /
 occupancy of each instantiation as reported by -Rpass-analysis=kernel-resource-usage, and the address class of their
-memory instructions.  The default tree-search formulation for 3-state models is the one measured on the MI355X
-(profiles/r01g-r01i): it must keep compiling to the same budget while the other formulations change around it."""
+memory instructions."""
 import os
 import re
 import shutil
@@ -33,18 +32,36 @@ def usage(src, tmp_path):
     return out
 
 
-def test_tree_search_kernels_register_budget(tmp_path):
+def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
     u = usage("psgpu_search.hip", tmp_path)
     k = {n: v for n, v in u.items() if "fwdtree_kernel" in n}
-    assert len(k) == 6, sorted(k)
-    default3 = [v for n, v in k.items() if "ILi3ELi256ELb0E" in n][0]
-    assert default3["VGPRs"] <= 142 and default3["Occupancy"] >= 3 and default3["Spill"] == 0, default3   # as measured in round 1
+    assert len(k) == 6, sorted(k)             # {3, 5 states} x {LDS layout, slab with 256 work-items, slab with 1024}
     for n, v in k.items():
         if "Li1024E" in n:
             assert v["VGPRs"] <= 128 and v["Occupancy"] >= 4, (n, v)          # 16 waves of one workgroup on a CU
+        elif "ELb1E" in n:
+            # the LDS layout: two workgroups per CU by LDS (2 x ~61 KB of 160 KB), i.e. two waves per SIMD
+            assert v["Occupancy"] >= 2 and v["Spill"] == 0 and v["VGPRs"] <= 256, (n, v)
+            assert 56 * 1024 <= v["LDS"] <= 64 * 1024, (n, v)
         else:
             assert v["Occupancy"] >= 3 and v["Spill"] == 0, (n, v)
         assert v["LDS"] <= 64 * 1024, (n, v)
+    # every pointer of the kernel is either derived from its LDS pool or declared global (psgpu_as_global): no access may be
+    # left generic (flat_*: waits on both memory counters), and the 256-work-item forms keep nothing in scratch memory
+    s = tmp_path / "search.s"
+    p = subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-S", "-o", str(s), os.path.join(ROOT, "pocketsphinx_amd", "csrc", "psgpu_search.hip")],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    txt = s.read_text()
+    names = re.findall(r"\n(_Z14fwdtree_kernel\w+):", txt)
+    assert len(names) == 6
+    for n in names:
+        body = txt[txt.index("\n" + n + ":"):txt.index(".Lfunc_end", txt.index("\n" + n + ":"))]
+        assert len(re.findall(r"\bflat_(load|store|atomic)", body)) == 0, n
+        if "Li1024E" not in n:
+            assert len(re.findall(r"\bscratch_(load|store)", body)) == 0, n
+        if "ELb1E" in n:        # tree-level state in LDS: most accesses are ds_*
+            assert len(re.findall(r"\bds_(read|write|load|store)", body)) > 500, n
 
 
 def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):

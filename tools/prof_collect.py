@@ -11,7 +11,11 @@ files that are committed under profiles/:
                                     coalesced reads -> x2; WRITE_SIZE
                                     uncalibrated, reported as is)
 
-usage: prof_collect.py gpurun_out/<tag> <tag>
+The PMC averages are taken over the dispatches of ONE workload only (the bench is profiled with --no-extras, and
+dispatches are filtered by grid size where a kernel is launched with several): the file records which workload
+(`_workload`), and bench.py uses a file's number only for that workload.
+
+usage: prof_collect.py gpurun_out/<tag> <tag> [utterances seconds]
 """
 import csv
 import glob
@@ -47,7 +51,7 @@ def main():
     os.makedirs(prof, exist_ok=True)
 
     # ---- kernel stats
-    lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 20 --warmup 3",
+    lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1",
              "# (durations in microseconds)",
              "%-8s %-14s %-12s %-8s %-10s %-10s %s" % ("calls", "total_us", "avg_us", "pct", "min_us", "max_us", "kernel")]
     stats = {}
@@ -82,17 +86,25 @@ def main():
     # ---- PMC traffic
     res = {}
     for sub, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        acc = {}
+        acc, grids = {}, {}
         for f in find(os.path.join(root, sub), "*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if (col(r, "Counter_Name") or "") != cname:
                     continue
                 k = short(col(r, "Kernel_Name") or "")
                 acc.setdefault(k, []).append(float(col(r, "Counter_Value")))
+                grids.setdefault(k, []).append(col(r, "Grid_Size"))
         for k, v in acc.items():
             if not (k.startswith("ptm_") or k.startswith("hmm_") or k.startswith("psgpu") or k.startswith("semi_")
-                    or k.startswith("ms_")):
+                    or k.startswith("ms_") or k.startswith("fwdtree_") or k.startswith("phone_loop") or k.startswith("fe_")
+                    or k.startswith("feat_") or k.startswith("fwdflat_")):
                 continue
+            # one workload only: the dispatches with the most common grid size
+            gs = grids.get(k, [])
+            if gs and len(set(gs)) > 1:
+                top = max(set(gs), key=gs.count)
+                v = [x for x, g_ in zip(v, gs) if g_ == top]
+                res.setdefault(k, {})["grid_size_kept"] = top
             # steady state: drop the first (cold) dispatch
             vv = v[1:] if len(v) > 1 else v
             res.setdefault(k, {})[cname + "_KB_avg_per_launch"] = sum(vv) / len(vv)
@@ -104,6 +116,9 @@ def main():
         d["hbm_write_bytes"] = None if w_kb is None else w_kb * 1024.0
         if f_kb is not None and w_kb is not None:
             d["hbm_bytes_per_launch"] = d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"]
+    if len(sys.argv) >= 5:
+        res["_workload"] = {"utterances": int(sys.argv[3]), "seconds": float(sys.argv[4]),
+                            "command": "bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1"}
     res["_note"] = ("FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KB; read bytes doubled per "
                     "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated")
     json.dump(res, open(os.path.join(prof, "%s_pmc_traffic.json" % tag), "w"), indent=1, sort_keys=True)
