@@ -485,8 +485,9 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
                              const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
                              const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
                              int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream);
-/* the context's own (non-blocking) stream, which the call above uses when `stream` is NULL;
- * usable with psgpu_memcpy_* / psgpu_stream_sync */
+/* the context's own (non-blocking) stream: a stream a binding can run one decoder's chain of calls on without
+ * serialising with other decoders; usable with psgpu_memcpy_* / psgpu_stream_sync.  (`stream` = NULL in the call
+ * above is the default stream, as everywhere.) */
 void *psgpu_hmm_ctx_stream(psgpu_hmm_ctx_t *c);
 
 /* ---- lexicon-tree search of whole utterances --------------------------

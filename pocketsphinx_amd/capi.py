@@ -5,7 +5,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libpsgpu.so")
+LIB_PATH = os.environ.get("PSGPU_LIB_PATH") or os.path.join(PKG_DIR, "libpsgpu.so")     # (PSGPU_LIB_PATH: a measuring build, tools/build_prof_lib.py)
 CSRC = os.path.join(PKG_DIR, "csrc")
 SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip", "psgpu_search.hip", "psgpu_lm.hip", "psgpu_flat.hip", "psgpu_decode.hip"]
 
@@ -43,24 +43,25 @@ class PsgpuError(RuntimeError):
     pass
 
 
-def build_library(force=False):
+def build_library(force=False, extra_flags=(), lib_path=None, build_dir=None):
     """Compile the HIP sources for gfx950 into pocketsphinx_amd/libpsgpu.so
     (in-tree, so it travels to the GPU box).  hipcc cross-compiles without a GPU.
     One object per source under pocketsphinx_amd/_build/ (recompiled when the source or a header is newer),
     compiled in parallel, then linked."""
     from concurrent.futures import ThreadPoolExecutor
+    lib_path = lib_path or os.path.join(PKG_DIR, "libpsgpu.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, h) for h in ("psgpu_internal.h", "psgpu_ptm_dev.h", "psgpu_hmm_dev.h", "psgpu_lm_dev.h")] + \
         [os.path.join(ROOT, "include", "psgpu.h")]
-    if (not force) and os.path.exists(LIB_PATH) and \
-            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in srcs + hdrs):
-        return LIB_PATH
+    if (not force) and os.path.exists(lib_path) and \
+            all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in srcs + hdrs):
+        return lib_path
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
              # packed fp32 (v_pk_*) runs at half rate on gfx950 and the SLP pass
              # doubles register pressure here: keep the distance chain scalar
-             "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-unused-result", "-fPIC", "-I" + os.path.join(ROOT, "include")]
-    bdir = os.path.join(PKG_DIR, "_build")
+             "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-unused-result", "-fPIC", "-I" + os.path.join(ROOT, "include")] + list(extra_flags)
+    bdir = build_dir or os.path.join(PKG_DIR, "_build")
     os.makedirs(bdir, exist_ok=True)
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
 
@@ -71,8 +72,8 @@ def build_library(force=False):
         return obj
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 _lib = None

@@ -458,7 +458,9 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
     p.n_phones = pp->n_phones; p.window = pp->window; p.beam = pp->beam; p.pbeam = pp->pbeam; p.pip = pp->pip;
     p.n_list = n_list; p.norm_mode = best_dev ? 2 : 1; p.weight = pp->penalty_weight;
     p.ssid = ssid_dev; p.tmatid = tmatid_dev; p.ci_list = ci_list_dev;
-    hipStream_t st = stream ? (hipStream_t)stream : c->stream;     // NULL: the context's own stream
+    // (NULL is the default stream, as for every other entry point.  It used to select the context's own non-blocking stream:
+    //  a caller that ran the scorer before and the search after this call on the default stream then raced with it.)
+    hipStream_t st = (hipStream_t)stream;
     PSGPU_REQUIRE(total_frames >= 0, "negative frame count");
     if (total_frames == 0) return PSGPU_OK;
     const int W = c->n_emit <= 3 ? 4 : 8;

@@ -10,11 +10,13 @@
 
 struct psgpu_lm_s {
     LmDev d;
+    LmDev *d_dev = nullptr;          // the same descriptor in device memory (lm_tg_score_call)
     std::vector<void *> allocs;
 };
 
-// internal: the search copies the descriptor (psgpu_fwdtree_set_lm)
+// internal: the searches copy the descriptor (psgpu_fwdtree_set_lm / psgpu_fwdflat_set_lm) or use its device copy
 extern "C" const LmDev *psgpu_lm_dev(const psgpu_lm_t *lm) { return lm ? &lm->d : nullptr; }
+extern "C" const LmDev *psgpu_lm_dev_ptr(const psgpu_lm_t *lm) { return lm ? lm->d_dev : nullptr; }
 
 static int psgpu_fail(int code, const char *msg) { psgpu_set_error("%s", msg); return code; }
 
@@ -58,6 +60,7 @@ extern "C" int psgpu_lm_create(psgpu_lm_t **out, const psgpu_lm_tables_t *t)
         d.lev[l].next_mask = t->next_mask[l];
     }
     d.lw = t->lw; d.log_wip = t->log_wip; d.log_zero = t->log_zero;
+    if (rc == PSGPU_OK) m->d_dev = (LmDev *)const_cast<void *>(lm_up(m, &d, sizeof d, 0, &rc));
     if (rc != PSGPU_OK) { psgpu_lm_free(m); return rc; }
     *out = m;
     return PSGPU_OK;

@@ -161,7 +161,8 @@ __device__ inline float lm_hist_score(const LmDev &m, int32_t wid, const int32_t
     return lm_long_prob(m, o);
 }
 
-// ngram_tg_score(lmset, w3, w2, w1, &n_used) with dictionary word ids; w2 / w1 may be -1
+// ngram_tg_score(lmset, w3, w2, w1, &n_used) with dictionary word ids; w2 / w1 may be -1.  (lm_tg_score_call below is the
+// out-of-line form for kernels with several call sites.)
 __device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, int32_t w1, int &n_used)
 {
     int32_t hist[2];
@@ -181,4 +182,13 @@ __device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, in
         s = lm_hist_score(m, wid, hist, n_hist, n_used);
     const int32_t raw = (int32_t)s;
     return (int32_t)__fadd_rn(__fmul_rn((float)raw, m.lw), (float)m.log_wip);    // weight_score, ngram_model_trie.c:710
+}
+
+// Out of line, the descriptor read from device memory: ONE copy of the trie walk (~1,400 instructions) per kernel however
+// many call sites it has.  A frame loop that outgrows the instruction cache (64 KB per pair of CUs) refetches itself from
+// L2 every frame; the search kernel calls this from three places.
+static __device__ __attribute__((noinline, unused)) int32_t lm_tg_score_call(const LmDev *m_dev, int32_t w3, int32_t w2, int32_t w1)
+{
+    int nu;
+    return lm_tg_score(*psgpu_as_global(m_dev), w3, w2, w1, nu);
 }

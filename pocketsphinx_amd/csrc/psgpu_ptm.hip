@@ -734,8 +734,7 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     hipFree(m->mixw); hipFree(m->sen2cb); hipFree(m->logadd8);
     hipFree(m->mixw_slot); hipFree(m->group_cb); hipFree(m->slot_sen);
     free(m->h_sen2cb);
-    hipFree(m->open_flags);
-    hipFree(m->fix_list);
+    for (PtmWorkspace &w : m->ws) { hipFree(w.open_flags); hipFree(w.fix_list); }
     for (int i = 0; i < 4; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
     delete m;
 }
@@ -810,21 +809,22 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
     if (lane_path) {
         // frames-on-lanes main pass, then the two fix-up forms (exactly one of them does work)
         const size_t need = (size_t)total_frames * m->n_chain;
-        if (need > m->flags_cap) {
+        PtmWorkspace *ws = ptm_workspace(m, st, true);               // this stream's scratch (two host threads scoring on one
+        if (need > ws->flags_cap) {                                  //  model use two streams, hence two workspaces)
             PSGPU_HIP(hipStreamSynchronize(st));
-            hipFree(m->open_flags); hipFree(m->fix_list);
-            m->open_flags = nullptr; m->fix_list = nullptr; m->flags_cap = 0;
-            PSGPU_HIP(hipMalloc((void **)&m->open_flags, need));
-            PSGPU_HIP(hipMalloc((void **)&m->fix_list, (need + 1) * sizeof(int32_t)));
-            m->flags_cap = need;
-            m->count_dirty = 1;
+            hipFree(ws->open_flags); hipFree(ws->fix_list);
+            ws->open_flags = nullptr; ws->fix_list = nullptr; ws->flags_cap = 0;
+            PSGPU_HIP(hipMalloc((void **)&ws->open_flags, need));
+            PSGPU_HIP(hipMalloc((void **)&ws->fix_list, (need + 1) * sizeof(int32_t)));
+            ws->flags_cap = need;
+            ws->count_dirty = 1;
         }
-        int32_t *fix_count = m->fix_list + m->flags_cap;            // last slot of the list buffer
+        int32_t *fix_count = ws->fix_list + ws->flags_cap;          // last slot of the list buffer
         const int32_t fix_thr = (int32_t)(need / 64);
         static const int fix_grid = [] { const char *e = getenv("PSGPU_FIX_GRID"); return e ? atoi(e) : 512; }();
-        if (m->count_dirty)                  // normally the senone kernel of the previous call zeroed it
+        if (ws->count_dirty)                 // normally the senone kernel of the previous call zeroed it
             PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
-        m->count_dirty = 1;
+        ws->count_dirty = 1;
         static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 1; }();
         const long long n_tiles = ((long long)total_frames + 64 * fpl - 1) / (64 * fpl);
         const long long lw = n_tiles * m->n_chain;
@@ -832,14 +832,14 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         if (fpl == 2)
             hipLaunchKernelGGL((ptm_lane_kernel<13, 2>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
                                pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
-                               topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
+                               topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);
         else
             hipLaunchKernelGGL((ptm_lane_kernel<13, 1>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
                                pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
-                               topn_score_dev, cw32, m->open_flags, fix_count, m->fix_list, (int32_t)need);
+                               topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);
         PSGPU_HIP(hipGetLastError());
         if (m->timing) hipEventRecord(m->ev[1], st);
-        PSGPU_CHAIN(fix_grid, (const uint8_t *)m->open_flags, (const int32_t *)fix_count, (const int32_t *)m->fix_list, fix_thr);
+        PSGPU_CHAIN(fix_grid, (const uint8_t *)ws->open_flags, (const int32_t *)fix_count, (const int32_t *)ws->fix_list, fix_thr);
     }
     else {
         if (m->timing) { hipEventRecord(m->ev[0], st); hipEventRecord(m->ev[1], st); }
@@ -882,7 +882,8 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
             hipStream_t st = (hipStream_t)stream;
             const PtmDev pv = dev_view(m);
             const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(topn_cw_dev);
-            int32_t *zw = m->fix_list ? m->fix_list + m->flags_cap : nullptr;
+            PtmWorkspace *ws = ptm_workspace(m, st, false);
+            int32_t *zw = (ws && ws->fix_list) ? ws->fix_list + ws->flags_cap : nullptr;
 #define PSGPU_SEN_CASE(I) case I:                                                                              \
                 if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1>), grid, block, sm, st, pv,        \
                                        topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
@@ -897,7 +898,7 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
             }
 #undef PSGPU_SEN_CASE
             PSGPU_HIP(hipGetLastError());
-            if (zw) m->count_dirty = 0;
+            if (zw) ws->count_dirty = 0;
             return PSGPU_OK;
         }
     }

@@ -3,6 +3,19 @@
 // in psgpu_ptm_frame.hip).
 #pragma once
 #include "psgpu_internal.h"
+#include <list>
+#include <mutex>
+
+// Scratch of one batched scoring call (the hand-over between its kernels).  One per stream the model is used on: calls on
+// one stream are ordered on the device and may share it; calls from different host threads on different streams run
+// concurrently and must not.
+struct PtmWorkspace {
+    hipStream_t stream;
+    uint8_t *open_flags;          // [n_chain][frames]: entries the lane kernel left to the fix-up
+    int32_t *fix_list;            // [frames * n_chain] open entries + 1 counter word
+    size_t flags_cap;
+    int count_dirty;              // the open-entry counter must be zeroed before the next lane pass
+};
 
 struct psgpu_ptm_model_s {
     int32_t n_mgau, n_feat, n_density, n_sen, topn, ds_ratio, veclen, n_chain;
@@ -19,13 +32,21 @@ struct psgpu_ptm_model_s {
     uint16_t *slot_sen;           // [n_slots] senone id of a slot, 0xffff = pad
     int32_t slot_stride, n_groups;
     int32_t logadd8_size;
-    uint8_t *open_flags;          // scratch [n_chain][frames]: entries the lane kernel left to the fix-up
-    int32_t *fix_list;            // scratch [frames * n_chain] open entries + 1 counter word
-    size_t flags_cap;
-    int count_dirty;              // the open-entry counter must be zeroed before the next lane pass
-    hipEvent_t ev[4];             // optional per-kernel timing: lane | fix-up | (gap) | senone
+    std::mutex ws_mu;             // guards the list below (not the workspaces: those belong to their stream)
+    std::list<PtmWorkspace> ws;
+    hipEvent_t ev[4];             // optional per-kernel timing: lane | fix-up | (gap) | senone (one timed caller at a time)
     int timing;
 };
+
+// the workspace of `st` (created on first use; list nodes never move)
+static inline PtmWorkspace *ptm_workspace(psgpu_ptm_model_t *m, hipStream_t st, bool create)
+{
+    std::lock_guard<std::mutex> lock(m->ws_mu);
+    for (PtmWorkspace &w : m->ws) if (w.stream == st) return &w;
+    if (!create) return nullptr;
+    m->ws.push_back(PtmWorkspace{st, nullptr, nullptr, 0, 1});
+    return &m->ws.back();
+}
 
 struct PtmDev {
     const float *mean, *var, *det;

@@ -36,7 +36,8 @@
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
-constexpr int kFtLdsWords = 15104;     // LDS layout: 59 KB of arrays (+ 2.5 KB fixed) per workgroup, two workgroups per CU
+constexpr int kFtLdsWords = 15488;     // LDS layout: 60.5 KB of arrays (+ 2.4 KB fixed) per workgroup, two workgroups per CU
+constexpr int kFtMinStage = 128;       // exits staged in LDS per frame, at least (LDS layout)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
 
@@ -49,8 +50,14 @@ struct FtLay {
     int32_t cand_wid, cand_score, cand_bp;                                  // [n_w + 1]
     int32_t o_out, o_outh, pos, flag, o_frame;                              // [N] pruning snapshot / decisions
     int32_t cnt;                         // [cnt_words] scan scratch
+    int32_t cnt2, cnt3, woff;            // [n_w + 2] per-candidate / per-active-word scratch; first slot index of each active word
+    int32_t ckey;                        // [n_w + 2] 64-bit (score, back-pointer) keys of the pair searches
+    int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
+    int32_t stage, stage_cap;            // [stage_cap][4] the frame's exiting channels: out score, history, its real / prev_real wid
+    int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
+    int32_t tp;                          // small layout: copy of the transition matrices (bytes)
     int32_t total;
 };
 
@@ -64,19 +71,20 @@ struct FtDev {
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
     const uint8_t *tp;
     const uint16_t *sseq;
+    int32_t n_tmat;
     int32_t small;                       // the fast arrays fit the LDS pool
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
     int32_t cnt_words;
     FtLay lay;
-    // always in the utterance's slab (int32 units from its start): last-phone channel records, their presence flags,
-    // the evaluation / entering work lists, the rarely used duplicate-candidate scratch; `fast`: the FtLay arrays
+    // always in the utterance's slab (int32 units from its start): last-phone channel records; `fast`: the FtLay arrays
     // when they are not in LDS
-    int64_t g_wrec, g_present, g_elist, g_eword, g_xlist, g_xslot, g_cand_next, g_csf_ef, g_csf_cand, g_fast, per;
-    LmDev trie;
+    int64_t g_wrec, g_fast, per;
+    const LmDev *trie_dev;               // the trie's descriptor in device memory
 };
 
 struct FtBufs {
     int32_t *slab, *bp, *bss, *idx, *step, *res, *w1_out;
+    long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][32] cycles per phase (tools/build_prof_lib.py)
     int32_t bp_cap, bss_cap, max_frames;
 };
 
@@ -177,12 +185,10 @@ struct FtTab {
 #define BPC(t, col, i) ((t).bp[(size_t)(col) * (t).bp_cap + (i)])
 enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2 };
 
-__device__ __forceinline__ int32_t ft_lm(const FtDev &p, const LmDev &trie, const int32_t *lmtab, int w3, int w2, int w1)
+__device__ __forceinline__ int32_t ft_lm(const FtDev &p, const int32_t *lmtab, int w3, int w2, int w1)
 {
-    if (p.use_trie) {                    // ngram_tg_score(...) >> SENSCR_SHIFT, ngram_search_fwdtree.c:1118, :1342
-        int nu;
-        return lm_tg_score(trie, w3, w2, w1, nu) >> 10;
-    }
+    // ngram_tg_score(...) >> SENSCR_SHIFT, ngram_search_fwdtree.c:1118, :1342
+    if (p.use_trie) return lm_tg_score_call(p.trie_dev, w3, w2, w1) >> 10;
     const size_t n1 = (size_t)p.n_w + 1;
     return lmtab[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
@@ -253,6 +259,18 @@ template <int NT>
 __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp)
 {
     const int tid = threadIdx.x, lane = tid & 63;
+    if (n <= 64) {                       // one wavefront, one barrier (most of the word level's lists are this short)
+        if (tid < 64) {
+            const int32_t v = lane < n ? a[lane] : 0;
+            int32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            if (lane < n) a[lane] = incl - v;
+            if (lane == 63) tmp[0] = incl;
+        }
+        __syncthreads();
+        return tmp[0];
+    }
     const int per = (n + NT - 1) / NT;
     const int b = min(n, tid * per), e = min(n, b + per);
     int32_t sum = 0;
@@ -271,6 +289,84 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
     return total;
 }
 
+// K exclusive prefix sums at once (same barriers as one)
+template <int NT, int K>
+__device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, int32_t *tmp, int32_t (&total)[K])
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (n <= 64) {
+        if (tid < 64) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int32_t v = lane < n ? a[k][lane] : 0;
+                int32_t incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                if (lane < n) a[k][lane] = incl - v;
+                if (lane == 63) tmp[k] = incl;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) total[k] = tmp[k];
+        return;
+    }
+    const int per = (n + NT - 1) / NT;
+    const int b = min(n, tid * per), e = min(n, b + per);
+    int32_t sum[K], incl[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { sum[k] = 0; for (int i = b; i < e; ++i) sum[k] += a[k][i]; incl[k] = sum[k]; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const int32_t v = __shfl_up(incl[k], d); if (lane >= d) incl[k] += v; }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) tmp[k * (NT / 64) + (tid >> 6)] = incl[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int32_t base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { const int32_t t = tmp[k * (NT / 64) + w]; tot += t; if (w < (tid >> 6)) base += t; }
+        total[k] = tot;
+        int32_t run = base + incl[k] - sum[k];
+        for (int i = b; i < e; ++i) { const int32_t v = a[k][i]; a[k][i] = run; run += v; }
+    }
+    __syncthreads();
+}
+// the segment of item j in the exclusive prefix sums off[0..n] (off[0] = 0 <= j < off[n]): the largest i with off[i] <= j
+// (empty segments are skipped)
+__device__ __forceinline__ int ft_seg_find(const int32_t *off, int n, int j)
+{
+    int lo = 0, hi = n;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= j) lo = mid; else hi = mid; }
+    return lo;
+}
+// "best score, earliest back-pointer among equals" as one 64-bit maximum: the searches over (item, back-pointer) pairs
+// below reduce with atomicMax where the reference keeps `if (score > best) { best = score; bestbp = bp; }` in a loop
+// over ascending back-pointers
+__device__ __forceinline__ unsigned long long ft_key(int32_t score, int bp)
+{
+    return ((unsigned long long)((uint32_t)score ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - bp);
+}
+__device__ __forceinline__ unsigned long long ft_key_floor(int32_t floor)        // "nothing better than `floor` seen"
+{
+    return ((unsigned long long)((uint32_t)floor ^ 0x80000000u) << 32) | 0xffffffffull;
+}
+__device__ __forceinline__ bool ft_key_none(unsigned long long k) { return (uint32_t)k == 0xffffffffu; }
+__device__ __forceinline__ int32_t ft_key_score(unsigned long long k) { return (int32_t)((uint32_t)(k >> 32) ^ 0x80000000u); }
+__device__ __forceinline__ int ft_key_bp(unsigned long long k) { return 0x7fffffff - (int)(uint32_t)k; }
+
+// per-phase cycle counts of work-item 0 (a profiling build only: -DPSGPU_FT_PROFILE; the product kernel has none of it)
+#ifdef PSGPU_FT_PROFILE
+#define FT_PROF(i) do { if (tid == 0) { const long long t_ = clock64(); s_prof[i] += t_ - s_last; s_last = t_; } } while (0)
+#else
+#define FT_PROF(i) do { } while (0)
+#endif
+
 template <int NE, int NT, bool SMALL>
 __global__ __launch_bounds__(NT)
 void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_stride, const int32_t *__restrict__ penalties_,
@@ -281,13 +377,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
     __shared__ int32_t s_red[8];
-    __shared__ int32_t s_scan[NT / 64];
-    __shared__ int32_t s_bins[256];
+    __shared__ int32_t s_scan[3 * NT / 64];
+    __shared__ int32_t s_bins[320];      // histogram of the maxhmmpf beam; word_transition: 64 keys (64-bit) + 3 x 64 decoded
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
-    __shared__ int32_t s_nwc, s_nwc2;    // lengths of the word level's evaluation list and of the entering list
     __shared__ int32_t s_nsen;           // listed senones, summed over the frames (raw-score mode)
     const int tid = threadIdx.x;
+#ifdef PSGPU_FT_PROFILE
+    __shared__ long long s_prof[32], s_last;
+    if (tid == 0) { for (int i = 0; i < 32; ++i) s_prof[i] = 0; s_last = clock64(); }
+#endif
     const int N = p.N, R = p.R, n1 = p.n1, n_ci = p.n_ci;
     const FtLay &L = p.lay;
 
@@ -303,10 +402,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const lt_dscr = fb + L.lt_dscr, *const lt_bp = fb + L.lt_bp, *const cand_mark = fb + L.cand_mark,
             *const cand_wid = fb + L.cand_wid, *const cand_score = fb + L.cand_score, *const cand_bp = fb + L.cand_bp,
             *const o_out = fb + L.o_out, *const o_outh = fb + L.o_outh, *const pos = fb + L.pos, *const flag = fb + L.flag,
-            *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt;
-    int32_t *const present = gs + p.g_present, *const elist = gs + p.g_elist, *const eword = gs + p.g_eword,
-            *const xlist = gs + p.g_xlist, *const xslot = gs + p.g_xslot, *const cand_next = gs + p.g_cand_next,
-            *const csf_ef = gs + p.g_csf_ef, *const csf_cand = gs + p.g_csf_cand;
+            *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3,
+            *const woff = fb + L.woff, *const stage = fb + L.stage;
+    unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
+    uint8_t *const present = reinterpret_cast<uint8_t *>(fb + L.present);
     FtTab tb;
     tb.bp = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * 10 * bf.bp_cap; tb.bss = psgpu_as_global(bf.bss) + (size_t)blockIdx.x * bf.bss_cap;
     tb.idx = psgpu_as_global(bf.idx) + (size_t)blockIdx.x * (bf.max_frames + 2);
@@ -322,21 +421,26 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                   *const d_last = psgpu_as_global(p.d_last), *const d_last2 = psgpu_as_global(p.d_last2), *const d_base = psgpu_as_global(p.d_base),
                   *const d_filler = psgpu_as_global(p.d_filler), *const rs_n = psgpu_as_global(p.rs_n), *const rs_ssid = psgpu_as_global(p.rs_ssid),
                   *const rs_cimap = psgpu_as_global(p.rs_cimap), *const ldiph = psgpu_as_global(p.ldiph), *const ci_tmat = psgpu_as_global(p.ci_tmat),
-                  *const lmtab = psgpu_as_global(p.lm), *const wc_off = psgpu_as_global(p.wc_off);
-    const uint8_t *const tpall = psgpu_as_global(p.tp);
+                  *const lmtab = psgpu_as_global(p.lm);
+    const uint8_t *const tpall = SMALL ? reinterpret_cast<const uint8_t *>(fb + L.tp) : psgpu_as_global(p.tp);
     const uint16_t *const sseq = psgpu_as_global(p.sseq);
     const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
-    const LmDev &trie = p.trie;                          // (its pointers are cast where they are used: psgpu_lm_dev.h)
     // the tree's structure: LDS copies in the small layout
     const int32_t *const kid_off = SMALL ? fb + L.kid_off : psgpu_as_global(p.kid_off), *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids),
                   *const parent = SMALL ? fb + L.parent : psgpu_as_global(p.parent), *const node_ci = SMALL ? fb + L.ci : psgpu_as_global(p.node_ci),
-                  *const node_pw = SMALL ? fb + L.pw : psgpu_as_global(p.node_pw);
+                  *const node_pw = SMALL ? fb + L.pw : psgpu_as_global(p.node_pw),
+                  *const wc_off = SMALL ? fb + L.wc_off : psgpu_as_global(p.wc_off);
     if (SMALL) {
         const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_k = psgpu_as_global(p.kids), *const g_p = psgpu_as_global(p.parent),
                       *const g_c = psgpu_as_global(p.node_ci), *const g_w = psgpu_as_global(p.node_pw);
         for (int i = tid; i <= N; i += NT) fb[L.kid_off + i] = g_ko[i];
         for (int i = tid; i < p.M; i += NT) fb[L.kids + i] = g_k[i];
         for (int i = tid; i < N; i += NT) { fb[L.parent + i] = g_p[i]; fb[L.ci + i] = g_c[i]; fb[L.pw + i] = g_w[i]; }
+        const int32_t *const g_o = psgpu_as_global(p.wc_off);
+        for (int i = tid; i <= p.n_w; i += NT) fb[L.wc_off + i] = g_o[i];
+        const uint8_t *const g_tp = psgpu_as_global(p.tp);
+        uint8_t *const l_tp = reinterpret_cast<uint8_t *>(fb + L.tp);
+        for (int i = tid; i < p.n_tmat * NE * (NE + 1); i += NT) l_tp[i] = g_tp[i];
     }
     int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // small layout only
     int32_t *const s_pen = fb + L.pen;                                      // small layout only: [2][n_ci]
@@ -396,24 +500,27 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) tb.idx[f] = s_sc[3];
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
+        const int32_t bp0 = s_sc[3];                          // this frame's first back-pointer
         if (tid < 8) s_red[tid] = kW;
-        if (tid == 0) s_nwc = 0;
+        // a word near its end has its whole right-context fan-out (20-40 channels) allocated at once: the word level is
+        // worked on one work-item per channel.  The channels of the active words are the segments [woff[i], woff[i + 1])
+        // of one index range; an item finds its word by bisection (ft_seg_find) and skips slots that are not allocated.
+        const int naw = n_awl_cur;
+        for (int i = tid; i < naw; i += NT) { const int w = awlc[i]; word_active[w] = 0; woff[i] = wc_off[w + 1] - wc_off[w]; }
+        if (tid == 0) woff[naw] = 0;
         __syncthreads();
-        // a word near its end has its whole right-context fan-out (20-40 channels) present at once: the word level's
-        // channels are gathered into one list first (order irrelevant: independent evaluations, a maximum and a count)
-        // and marked / evaluated / pruned one work-item per channel below
-        for (int i = tid; i < n_awl_cur; i += NT) {
-            const int w = awlc[i];
-            word_active[w] = 0;
-            for (int k = wc_off[w]; k < wc_off[w + 1]; ++k)
-                if (present[k]) { const int q = atomicAdd(&s_nwc, 1); elist[q] = k; eword[q] = i; }
-        }
-        __syncthreads();
-        const int nwc = s_nwc;
+        const int nwc = ft_block_scan<NT>(woff, naw + 1, s_scan);
+        FT_PROF(0);
+        auto for_word_channels = [&](auto &&fn) {
+            for (int j = tid; j < nwc; j += NT) {
+                const int i = ft_seg_find(woff, naw, j), slot = wc_off[awlc[i]] + (j - woff[i]);
+                if (present[slot]) fn(i, slot);
+            }
+        };
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
             for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_normalize<NE>(tv, i, best_in);
             for (int i = tid; i < n_acl_cur; i += NT) ch_normalize<NE>(tv, aclc[i], best_in);
-            for (int i = tid; i < nwc; i += NT) ch_normalize<NE>(wv, elist[i], best_in);
+            for_word_channels([&](int, int slot) { ch_normalize<NE>(wv, slot, best_in); });
             for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_normalize<NE>(tv, W1 + i, best_in);
             __syncthreads();
         }
@@ -434,9 +541,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             };
             for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) mark(tv, i);
             for (int i = tid; i < n_acl_cur; i += NT) mark(tv, aclc[i]);
-            for (int i = tid; i < nwc; i += NT) mark(wv, elist[i]);
+            for_word_channels([&](int, int slot) { mark(wv, slot); });
             for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) mark(tv, W1 + i);
             __syncthreads();
+            FT_PROF(1);
             int32_t mn = 0x7fffffff;
             for (int w = tid; w < nwords; w += NT) {
                 uint32_t b = s_bits[w];
@@ -456,6 +564,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (mn != 0x7fffffff) atomicMin(&s_nb, mn);
             __syncthreads();
             nb = s_nb;
+            FT_PROF(2);
         }
         // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..4] counts
         {
@@ -464,7 +573,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             for (int i = tid; i < R; i += NT)
                 if (tv.at(i, F::FRAME) == f) { b0 = max(b0, ch_eval<NE>(tv, i, sr, tpall, sseq)); ++n0; }
             for (int i = tid; i < n_acl_cur; i += NT) b1 = max(b1, ch_eval<NE>(tv, aclc[i], sr, tpall, sseq));
-            for (int i = tid; i < nwc; i += NT) { b2 = max(b2, ch_eval<NE>(wv, elist[i], sr, tpall, sseq)); ++n2; }
+            for_word_channels([&](int, int slot) { b2 = max(b2, ch_eval<NE>(wv, slot, sr, tpall, sseq)); ++n2; });
             for (int i = tid; i < n1; i += NT) {
                 if (tv.at(W1 + i, F::FRAME) < f) continue;
                 const int32_t sc = ch_eval<NE>(tv, W1 + i, sr, tpall, sseq);
@@ -498,6 +607,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         }
         for (int i = tid; i < 256; i += NT) s_bins[i] = 0;
         __syncthreads();
+        FT_PROF(3);
         const int32_t best_score = s_sc[0];
         if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
             const int32_t bw = -p.beam / 256;
@@ -531,6 +641,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             flag[node] = (active && tv.at(node, F::BEST) > thresh) ? 1 : 0;
         }
         __syncthreads();
+        FT_PROF(4);
         auto decide = [&](int c) {
             const int P = parent[c], pc = pos[c];
             const bool in_acl = pc >= 0, par_active = P < R || pos[P] >= 0;
@@ -552,14 +663,17 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         };
         for (int i = tid; i < R + na; i += NT) {
             const int node = i < R ? i : aclc[i - R];
-            if (i >= R) decide(node);
             // a node that is not retained enters none of its children: their (stale) decision words are not
             // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
-            if (!(flag[node] & 1)) continue;
-            const int k1 = kid_off[node + 1];
-            for (int k = kid_off[node]; k < k1; ++k) { const int c = kids[k]; if (pos[c] < 0) decide(c); }
+            const int k0 = kid_off[node], nk = (flag[node] & 1) ? kid_off[node + 1] - k0 : 0;
+            for (int q = i >= R ? -1 : 0; q < nk; ++q) {         // q = -1: the listed node itself, then its unlisted children
+                const int c = q < 0 ? node : kids[k0 + q];
+                if (q >= 0 && pos[c] >= 0) continue;
+                decide(c);
+            }
         }
         __syncthreads();
+        FT_PROF(5);
         for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
         for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
         // list positions: root phase (segment per root), then one segment per list position
@@ -584,6 +698,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
         }
         __syncthreads();
+        FT_PROF(6);
         // last-phone candidates: list order, homophone chain inside
         for (int i = tid; i < R + na; i += NT) {
             const int node = i < R ? i : aclc[i - R];
@@ -609,225 +724,230 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     }
         }
         __syncthreads();
+        FT_PROF(7);
 
         // ---- word level: last_phone_transition (:884-1035).  Candidates of one frame name distinct words (a word has
-        //      one penultimate tree node, a node one place in the active list), so each candidate's best
-        //      predecessor -- exit score + language score over the back-pointers of its start frame, the
-        //      look-ups that dominate this step -- is found by its own thread; last_ltrans (lt_*) is the
-        //      reference's per-word cache keyed by start frame.  Should two candidates ever share a word, the
-        //      reference's loops are run as written by one thread.
+        //      one penultimate tree node, a node one place in the active list).  Each candidate's best predecessor --
+        //      exit score + language score over the back-pointers of its start frame, the look-ups that dominate this
+        //      step -- is searched one work-item per (candidate, back-pointer) pair: a loop over the back-pointers in one
+        //      work-item is a chain of dependent loads per iteration.  last_ltrans (lt_*) is the reference's per-word
+        //      cache keyed by start frame.  Should two candidates ever share a word, the reference's loops are run as
+        //      written by one thread.
         const int n_cand = s_sc[5];
         for (int i = tid; i < n_cand; i += NT)               // O(1) per candidate: the frame stamp of the word
             if (atomicExch(&cand_mark[cand_wid[i]], f) == f) s_red[7] = 1;
         __syncthreads();
-        const bool dup = s_red[7] != 0;
-        if (!dup) {
-            int32_t bestscore = kW;
+        // (two candidates naming one word would need two paths to that word in the tree: create_search_channels builds
+        //  one per dictionary entry.  The reference's loops would cope; here it ends the utterance with status 3.)
+        if (s_red[7] != 0) { if (tid == 0) s_sc[6] = 3; __syncthreads(); break; }
+        {
             for (int i = tid; i < n_cand; i += NT) {
                 const int cb = cand_bp[i], w = cand_wid[i];
-                int32_t score = cand_score[i];
+                int need = 0, b0 = 0, sf = -1;
                 if (cb != -1) {
-                    const int first = d_first[w];
-                    score -= ft_exit_score(tb, rs_cimap, n_ci, cb, first);
+                    cand_score[i] -= ft_exit_score(tb, rs_cimap, n_ci, cb, d_first[w]);
                     const int ef = BPC(tb, B_FRAME, cb);
-                    if (lt_sf[w] != ef + 1) {
-                        int32_t best = kW, bestbp = lt_bp[w];
-                        const int b1 = tb.idx[ef + 1], base = d_base[w];
-                        for (int bp = tb.idx[ef]; bp < b1; ++bp) {
-                            if (!BPC(tb, B_VALID, bp)) continue;
-                            int32_t dscr = ft_exit_score(tb, rs_cimap, n_ci, bp, first);
-                            if (dscr > kW) dscr += ft_lm(p, trie, lmtab, base, BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
-                            if (dscr > best) { best = dscr; bestbp = bp; }
-                        }
-                        lt_dscr[w] = best; lt_bp[w] = bestbp; lt_sf[w] = ef + 1;
-                    }
+                    if (lt_sf[w] != ef + 1) { b0 = tb.idx[ef]; need = tb.idx[ef + 1] - b0; sf = ef + 1; }
                 }
-                score += lt_dscr[w];
+                cnt[i] = need; cnt2[i] = b0; cnt3[i] = sf;
+                ckey[i] = ft_key_floor(kW);
+            }
+            if (tid == 0) cnt[n_cand] = 0;
+            __syncthreads();
+            const int n_pair = ft_block_scan<NT>(cnt, n_cand + 1, s_scan);
+            for (int j = tid; j < n_pair; j += NT) {
+                const int i = ft_seg_find(cnt, n_cand, j), bp = cnt2[i] + (j - cnt[i]), w = cand_wid[i];
+                if (!BPC(tb, B_VALID, bp)) continue;
+                int32_t dscr = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
+                if (dscr > kW) dscr += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
+                atomicMax(&ckey[i], ft_key(dscr, bp));
+            }
+            __syncthreads();
+            int32_t bestscore = kW;
+            for (int i = tid; i < n_cand; i += NT) {
+                const int w = cand_wid[i];
+                if (cnt3[i] >= 0) {                          // searched: best = WORST_SCORE keeps the old back-pointer
+                    const unsigned long long k = ckey[i];
+                    if (ft_key_none(k)) lt_dscr[w] = kW;
+                    else { lt_dscr[w] = ft_key_score(k); lt_bp[w] = ft_key_bp(k); }
+                    lt_sf[w] = cnt3[i];
+                }
+                const int32_t score = cand_score[i] + lt_dscr[w];
                 cand_score[i] = score;
                 cand_bp[i] = lt_bp[w];
                 bestscore = max(bestscore, score);
             }
             if (bestscore > kW) atomicMax(&s_sc[1], bestscore);
         }
-        else if (tid == 0) {
-            int n_csf = 0;
-            for (int i = 0; i < n_cand; ++i) {
-                const int cb = cand_bp[i], w = cand_wid[i];
-                if (cb == -1) continue;
-                cand_score[i] -= ft_exit_score(tb, rs_cimap, n_ci, cb, d_first[w]);
-                const int ef = BPC(tb, B_FRAME, cb);
-                if (lt_sf[w] != ef + 1) {
-                    int j;
-                    for (j = 0; j < n_csf; ++j) if (csf_ef[j] == ef) break;
-                    if (j < n_csf) cand_next[i] = csf_cand[j];
-                    else { j = n_csf++; cand_next[i] = -1; csf_ef[j] = ef; }
-                    csf_cand[j] = i;
-                    lt_dscr[w] = kW;
-                    lt_sf[w] = ef + 1;
-                }
-            }
-            for (int i = 0; i < n_csf; ++i) {
-                const int b1 = tb.idx[csf_ef[i] + 1];
-                for (int bp = tb.idx[csf_ef[i]]; bp < b1; ++bp) {
-                    if (!BPC(tb, B_VALID, bp)) continue;
-                    for (int j = csf_cand[i]; j >= 0; j = cand_next[j]) {
-                        const int w = cand_wid[j];
-                        int32_t dscr = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
-                        if (dscr > kW) dscr += ft_lm(p, trie, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
-                        if (dscr > lt_dscr[w]) { lt_dscr[w] = dscr; lt_bp[w] = bp; }
-                    }
-                }
-            }
-            int32_t bestscore = s_sc[1];
-            for (int i = 0; i < n_cand; ++i) {
-                const int w = cand_wid[i];
-                cand_score[i] += lt_dscr[w];
-                cand_bp[i] = lt_bp[w];
-                if (cand_score[i] > bestscore) bestscore = cand_score[i];
-            }
-            s_sc[1] = bestscore;
-        }
-        if (tid == 0) s_nwc2 = 0;
-        for (int i = tid; i < n_cand; i += NT) cnt[i] = 0;
         __syncthreads();
+        FT_PROF(8);
         {
-            // ---- last_phone_transition's entering loop (:1004-1030).  Candidates of one frame name distinct words (a word
-            //      has one penultimate tree node) -- if that ever fails the loop is run by one thread in candidate order.
+            // ---- last_phone_transition's entering loop (:1004-1030).  One work-item per (entering candidate, right context):
+            //      the word's slots are exactly its right contexts, so "allocate the missing ones, then enter every present
+            //      one" is, per slot, "create if missing, then enter".
             const int32_t cthresh = s_sc[1] + p.lponlybeam;
-            if (!dup) {
-                // one work-item per (entering candidate, right context): the word's slots are exactly its right contexts, so
-                // "allocate the missing ones, then enter every present one" is, per slot, "create if missing, then enter"
+            {
                 for (int i = tid; i < n_cand; i += NT) {
-                    if (!(cand_score[i] > cthresh)) continue;
-                    const int w = cand_wid[i], nrc = wc_off[w + 1] - wc_off[w];
-                    const int q = atomicAdd(&s_nwc2, nrc);
-                    for (int r = 0; r < nrc; ++r) { xlist[q + r] = i; xslot[q + r] = wc_off[w] + r; }
+                    const int w = cand_wid[i];
+                    cnt[i] = cand_score[i] > cthresh ? wc_off[w + 1] - wc_off[w] : 0;
+                    cnt2[i] = 0;                                // "entered a channel"
                 }
+                if (tid == 0) cnt[n_cand] = 0;
                 __syncthreads();
-                for (int j = tid; j < s_nwc2; j += NT) {
-                    const int i = xlist[j], slot = xslot[j], w = cand_wid[i];
+                const int n_ent = ft_block_scan<NT>(cnt, n_cand + 1, s_scan);
+                for (int j = tid; j < n_ent; j += NT) {
+                    const int i = ft_seg_find(cnt, n_cand, j), w = cand_wid[i], r = j - cnt[i], slot = wc_off[w] + r;
                     if (!present[slot]) {                       // ngram_search_alloc_all_rc (ngram_search.c:583-633)
                         const int last = d_last[w], last2 = d_last2[w];
-                        ch_init<NE>(wv, slot, 0, rs_ssid[((size_t)last * n_ci + last2) * n_ci + (slot - wc_off[w])], ci_tmat[last], sseq);
+                        ch_init<NE>(wv, slot, 0, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq);
                         present[slot] = 1;
                     }
                     if (wv.at(slot, F::FRAME) < f || cand_score[i] > wv.at(slot, F::SCORE)) {
                         ch_enter<NE>(wv, slot, cand_score[i], cand_bp[i], nf);
-                        cnt[i] = 1;
+                        cnt2[i] = 1;
                     }
                 }
             }
-            else if (tid == 0)
-                for (int i = 0; i < n_cand; ++i) {
-                    int k = 0;
-                    if (cand_score[i] > cthresh) {
-                        const int w = cand_wid[i];
-                        // ngram_search_alloc_all_rc (ngram_search.c:583-633)
-                        const int last = d_last[w], last2 = d_last2[w], nrc = rs_n[last * n_ci + last2];
-                        for (int r = 0; r < nrc; ++r) {
-                            const int slot = wc_off[w] + r;
-                            if (!present[slot]) {
-                                ch_init<NE>(wv, slot, 0, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq);
-                                present[slot] = 1;
-                            }
-                        }
-                        for (int slot = wc_off[w]; slot < wc_off[w + 1]; ++slot) {
-                            if (!present[slot]) continue;
-                            if (wv.at(slot, F::FRAME) < f || cand_score[i] > wv.at(slot, F::SCORE)) { ch_enter<NE>(wv, slot, cand_score[i], cand_bp[i], nf); ++k; }
-                        }
-                    }
-                    cnt[i] = k > 0;
-                }
             __syncthreads();
+            FT_PROF(9);
             {                                            // stable compaction by a prefix sum
-                const int32_t nawl = ft_block_scan<NT>(cnt, n_cand, s_scan);
+                const int32_t nawl = ft_block_scan<NT>(cnt2, n_cand, s_scan);
                 for (int i = tid; i < n_cand; i += NT)
-                    if ((i + 1 < n_cand ? cnt[i + 1] : nawl) != cnt[i]) {
+                    if ((i + 1 < n_cand ? cnt2[i + 1] : nawl) != cnt2[i]) {
                         const int w = cand_wid[i];
-                        awln[cnt[i]] = w; word_active[w] = 1;
+                        awln[cnt2[i]] = w; word_active[w] = 1;
                     }
                 if (tid == 0) s_red[5] = nawl;
             }
             __syncthreads();
+            FT_PROF(10);
             // ---- prune_word_chan (:1038-1128): keep / free the right-context channels, count the survivors per word,
-            //      note whether the word exits.  One work-item per channel of the evaluation list (the channels present when
-            //      the frame was evaluated; the ones this frame's candidates have just allocated were all entered for the next
-            //      frame and have no score yet: a word-at-a-time walk would neither count nor free them), survivors counted
-            //      per word by atomics
+            //      note whether the word exits.  One work-item per allocated channel of the active words (the ones this
+            //      frame's candidates have just allocated were entered for the next frame and have no score yet: they are
+            //      neither counted nor freed, exactly as the reference's walk treats them), survivors counted per word by atomics
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            const int wst = p.n_w;                                // n_awl <= n_w
-            int32_t *w_k = cnt, *w_exit = w_k + wst, *w_bp = w_k + 2 * wst, *w_bss = w_k + 3 * wst;
-            const int naw = n_awl_cur;
+            const int wst = p.n_w + 1;                            // naw <= n_w
+            int32_t *const w_k = cnt, *const w_exit = cnt + wst, *const w_bp = cnt + 2 * wst, *const w_bss = cnt + 3 * wst;
             for (int i = tid; i < naw; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
             __syncthreads();
-            for (int j = tid; j < nwc; j += NT) {
-                const int k = elist[j], i = eword[j];
-                if (wv.at(k, F::BEST) > lpth) {
-                    wv.at(k, F::FRAME) = nf;
+            for_word_channels([&](int i, int slot) {
+                if (wv.at(slot, F::BEST) > lpth) {
+                    wv.at(slot, F::FRAME) = nf;
                     atomicAdd(&w_k[i], 1);
-                    if (wv.at(k, F::OUT) > nwt) atomicOr(&w_exit[i], 1);
+                    if (wv.at(slot, F::OUT) > nwt) atomicOr(&w_exit[i], 1);
                 }
-                else if (wv.at(k, F::FRAME) != nf) present[k] = 0;
-            }
+                else if (wv.at(slot, F::FRAME) != nf) present[slot] = 0;
+            });
             __syncthreads();
-            for (int i = tid; i < naw; i += NT) {
-                const int w = awlc[i];
-                const int k = w_k[i], ex = w_exit[i];
-                // inputs of the three prefix sums below
+            FT_PROF(11);
+            for (int i = tid; i <= naw; i += NT) {
+                // inputs of the three prefix sums below: next active word list, back-pointers, score-stack entries
+                const int w = i < naw ? awlc[i] : 0;
+                const int k = i < naw ? w_k[i] : 0, ex = i < naw ? w_exit[i] : 0;
                 w_k[i] = (k > 0 && !word_active[w]) ? 1 : 0;
                 w_bp[i] = ex ? 1 : 0;
-                w_bss[i] = ex ? rs_n[d_last[w] * n_ci + d_last2[w]] : 0;
+                w_bss[i] = ex ? wc_off[w + 1] - wc_off[w] : 0;     // = rssid n_ssid of the word's last two phones
             }
             __syncthreads();
-            {                                            // positions by workgroup prefix sums
-                const int32_t bpidx = s_sc[3], bss_head = s_sc[4], nawl = s_red[5];    // (rewritten below, after the scans' barriers)
-                const int32_t n_exit = ft_block_scan<NT>(w_bp, naw, s_scan);
-                const int32_t n_bss = ft_block_scan<NT>(w_bss, naw, s_scan);
-                const int32_t n_app = ft_block_scan<NT>(w_k, naw, s_scan);
-                for (int i = tid; i < naw; i += NT) {
-                    w_bp[i] += bpidx; w_bss[i] += bss_head;
-                    if ((i + 1 < naw ? w_k[i + 1] : n_app) != w_k[i]) {
-                        const int w = awlc[i];
-                        awln[nawl + w_k[i]] = w; word_active[w] = 1;
-                    }
+            const int32_t bpidx = s_sc[3], bss_head = s_sc[4], nawl0 = s_red[5];     // (rewritten below, after the scans' barriers)
+            int32_t tot[3];
+            {
+                int32_t *const arr[3] = { w_bp, w_bss, w_k };
+                ft_block_scan_k<NT, 3>(arr, naw + 1, s_scan, tot);
+            }
+            const int32_t n_exit = tot[0], n_bss = tot[1], n_app = tot[2];
+            for (int i = tid; i < naw; i += NT)
+                if (w_k[i + 1] != w_k[i]) {
+                    const int w = awlc[i];
+                    awln[nawl0 + w_k[i]] = w; word_active[w] = 1;
                 }
-                if (tid == 0) {
-                    if (bpidx + n_exit + n1 >= tb.bp_cap || bss_head + n_bss + n_ci >= tb.bss_cap) s_sc[6] = 1;
-                    s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; s_red[5] = nawl + n_app;
-                }
+            if (tid == 0) {
+                if (bpidx + n_exit + n1 >= tb.bp_cap || bss_head + n_bss + n_ci >= tb.bss_cap) s_sc[6] = 1;
+                s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; s_red[5] = nawl0 + n_app;
             }
             __syncthreads();
+            FT_PROF(12);
             if (!s_sc[6]) {
-                // pass B: every exiting word writes its own back-pointer (first exit creates, the others update)
+                // ---- the exits' back-pointers (ngram_search_save_bp, ngram_search.c:376-498).  An exiting word owns one
+                //      new entry and wc_off-many score-stack slots; its exiting channels are merged into the entry in
+                //      right-context order (first creates, a better one updates).  Two steps: one work-item per (exiting
+                //      word, right context) writes the score stack and stages what the merge needs -- out score, history,
+                //      the language-model state of that history -- then one work-item per word merges from the staged
+                //      items, no dependent device-memory load in its loop.
+                auto exit_item = [&](int slot, int32_t (&it)[4]) {
+                    it[0] = kW; it[1] = -1; it[2] = -1; it[3] = -1;
+                    if (present[slot] && wv.at(slot, F::FRAME) == nf && wv.at(slot, F::BEST) > lpth && wv.at(slot, F::OUT) > nwt) {
+                        const int32_t path = wv.at(slot, F::OUTH);
+                        it[0] = wv.at(slot, F::OUT); it[1] = path;
+                        if (path != -1) { it[2] = BPC(tb, B_REAL, path); it[3] = BPC(tb, B_PREAL, path); }
+                    }
+                };
+                const int scap = L.stage_cap;
+                for (int j = tid; j < n_bss; j += NT) {
+                    const int i = ft_seg_find(w_bss, naw, j), w = awlc[i], slot = wc_off[w] + (j - w_bss[i]);
+                    int32_t it[4];
+                    exit_item(slot, it);
+                    tb.bss[bss_head + j] = it[0];                // (no exit: WORST_SCORE, as the creation fills it)
+                    if (j < scap) { stage[4 * j] = it[0]; stage[4 * j + 1] = it[1]; stage[4 * j + 2] = it[2]; stage[4 * j + 3] = it[3]; }
+                }
+                __syncthreads();
+                FT_PROF(13);
                 for (int i = tid; i < naw; i += NT) {
                     if (!w_exit[i]) continue;
-                    const int w = awlc[i];
-                    int32_t bpi = w_bp[i], bsh = w_bss[i];
-                    for (int slot = wc_off[w]; slot < wc_off[w + 1]; ++slot) {
-                        if (!present[slot]) continue;
-                        if (wv.at(slot, F::FRAME) == nf && wv.at(slot, F::BEST) > lpth && wv.at(slot, F::OUT) > nwt)
-                            ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w, wv.at(slot, F::OUT), wv.at(slot, F::OUTH), slot - wc_off[w]);
+                    const int w = awlc[i], j0 = w_bss[i], nrc = w_bss[i + 1] - j0, bpi = bpidx + w_bp[i];
+                    bool created = false;
+                    int32_t S = kW, P = -1, p_real = -1, p_preal = -1, rw_real = -1, rw_preal = -1;
+                    for (int r = 0; r < nrc; ++r) {
+                        int32_t it[4];
+                        if (j0 + r < scap) { it[0] = stage[4 * (j0 + r)]; it[1] = stage[4 * (j0 + r) + 1]; it[2] = stage[4 * (j0 + r) + 2]; it[3] = stage[4 * (j0 + r) + 3]; }
+                        else exit_item(wc_off[w] + r, it);
+                        // an exit has out > nwt > WORST_SCORE; a staged non-exit carries WORST_SCORE
+                        if (!(it[0] > kW)) continue;
+                        if (!created) { created = true; S = it[0]; P = it[1]; p_real = rw_real = it[2]; p_preal = rw_preal = it[3]; }
+                        else if (S < it[0]) {
+                            if (P != it[1]) {
+                                // "if (bplh != newlh) set_real_wid(bp)" runs with the OLD path still in the entry (:420-436):
+                                // the entry's real word ids are then those its previous path gives
+                                if (p_preal != it[3] || p_real != it[2]) { rw_real = p_real; rw_preal = p_preal; }
+                                P = it[1]; p_real = it[2]; p_preal = it[3];
+                            }
+                            S = it[0];
+                        }
                     }
+                    if (!created) continue;                      // (cannot happen: w_exit says one channel exits)
+                    word_lat_idx[w] = bpi;
+                    BPC(tb, B_WID, bpi) = w; BPC(tb, B_FRAME, bpi) = f; BPC(tb, B_BP, bpi) = P; BPC(tb, B_SCORE, bpi) = S;
+                    BPC(tb, B_SIDX, bpi) = bss_head + j0; BPC(tb, B_VALID, bpi) = 1;
+                    BPC(tb, B_LAST, bpi) = d_last[w]; BPC(tb, B_LAST2, bpi) = d_last2[w];
+                    // set_real_wid (:341-372) from the path it was last evaluated with (real ids are >= 0: -1 = no path)
+                    if (d_filler[w]) {
+                        BPC(tb, B_REAL, bpi) = rw_real != -1 ? rw_real : d_base[w];
+                        BPC(tb, B_PREAL, bpi) = rw_real != -1 ? rw_preal : -1;
+                    }
+                    else { BPC(tb, B_REAL, bpi) = d_base[w]; BPC(tb, B_PREAL, bpi) = rw_real; }
                 }
             }
             __syncthreads();
+            FT_PROF(14);
         }
         if (!s_sc[6]) {
             // single-phone words (:1100-1127), one work-item per word; back-pointer positions in list order by prefix sums
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            const int wst = p.n_w;                                // n1 <= n_w
-            int32_t *f_ex = cnt, *f_new = f_ex + wst, *f_rc = f_ex + 2 * wst;
-            for (int i = tid; i < n1; i += NT) {
-                const int c = W1 + i;
+            const int wst = p.n_w + 1;                            // n1 <= n_w
+            int32_t *const f_ex = cnt, *const f_new = cnt + wst, *const f_rc = cnt + 2 * wst;
+            for (int i = tid; i <= n1; i += NT) {
                 int ex = 0, nw = 0, rcn = 0;
-                if (tv.at(c, F::FRAME) >= f && tv.at(c, F::BEST) > lpth) {
-                    tv.at(c, F::FRAME) = nf;
-                    if (tv.at(c, F::OUT) > nwt) {
-                        const int w = w1_wid[i];
-                        ex = 1;
-                        if (word_lat_idx[w] == -1) {
-                            nw = 1;
-                            rcn = dict.d_pronlen[w] == 1 ? 0 : rs_n[d_last[w] * n_ci + d_last2[w]];
+                if (i < n1) {
+                    const int c = W1 + i;
+                    if (tv.at(c, F::FRAME) >= f && tv.at(c, F::BEST) > lpth) {
+                        tv.at(c, F::FRAME) = nf;
+                        if (tv.at(c, F::OUT) > nwt) {
+                            const int w = w1_wid[i];
+                            ex = 1;
+                            if (word_lat_idx[w] == -1) {
+                                nw = 1;
+                                rcn = dict.d_pronlen[w] == 1 ? 0 : rs_n[d_last[w] * n_ci + d_last2[w]];
+                            }
                         }
                     }
                 }
@@ -835,61 +955,76 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             __syncthreads();
             const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
-            const int32_t n_new = ft_block_scan<NT>(f_new, n1, s_scan);
-            const int32_t n_rc = ft_block_scan<NT>(f_rc, n1, s_scan);
+            int32_t tot[2];
+            {
+                int32_t *const arr[2] = { f_new, f_rc };
+                ft_block_scan_k<NT, 2>(arr, n1 + 1, s_scan, tot);
+            }
             for (int i = tid; i < n1; i += NT)
                 if (f_ex[i]) {
                     int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
                     if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
                 }
             __syncthreads();
-            if (tid == 0) { s_sc[3] = bpidx0 + n_new; s_sc[4] = bss0 + n_rc; }
+            if (tid == 0) { s_sc[3] = bpidx0 + tot[0]; s_sc[4] = bss0 + tot[1]; }
         }
         if (tid == 0 && !s_sc[6]) {
             const int32_t bpidx = s_sc[3];
             // bptable_maxwpf (:1193-1241)
             if (!(p.maxwpf == -1 || p.maxwpf == p.n_w)) {
-                const int b0 = tb.idx[f];
                 int32_t bestscr = kMaxNegInt32; int bestbp = -1, n = 0;
-                for (int bp = b0; bp < bpidx; ++bp)
+                for (int bp = bp0; bp < bpidx; ++bp)
                     if (d_filler[BPC(tb, B_WID, bp)]) {
                         if (BPC(tb, B_SCORE, bp) > bestscr) { bestscr = BPC(tb, B_SCORE, bp); bestbp = bp; }
                         BPC(tb, B_VALID, bp) = 0; ++n;
                     }
                 if (bestbp >= 0) { BPC(tb, B_VALID, bestbp) = 1; --n; }
-                n = (bpidx - b0) - n;
+                n = (bpidx - bp0) - n;
                 for (; n > p.maxwpf; --n) {
                     int32_t worst = 0x7fffffff; int wbp = -1;
-                    for (int bp = b0; bp < bpidx; ++bp)
+                    for (int bp = bp0; bp < bpidx; ++bp)
                         if (BPC(tb, B_VALID, bp) && BPC(tb, B_SCORE, bp) < worst) { worst = BPC(tb, B_SCORE, bp); wbp = bp; }
                     if (wbp < 0) break;
                     BPC(tb, B_VALID, wbp) = 0;
                 }
             }
         }
+        FT_PROF(15);
+        // ---- word_transition (:1243-1427).  The best exit per right-context phone (earliest back-pointer among equals) and
+        //      the single-phone words' best predecessors are maxima over (back-pointer, phone) / (word, back-pointer)
+        //      pairs: one work-item per pair.
+        unsigned long long *const brc_key = reinterpret_cast<unsigned long long *>(s_bins);      // [kFtMaxCi]
+        int32_t *const brc_score = s_bins + 2 * kFtMaxCi, *const brc_path = s_bins + 3 * kFtMaxCi, *const brc_lc = s_bins + 4 * kFtMaxCi;
+        for (int rc = tid; rc < n_ci; rc += NT) brc_key[rc] = ft_key_floor(kW);
+        for (int i = tid; i < p.n1lm; i += NT) ckey[i] = ft_key_floor(kMaxNegInt32);
+        if (tid == 0) s_red[6] = 0;
         __syncthreads();
         const int n_awl_nxt = s_red[5];
         if (s_sc[6]) break;
-
-        // ---- word_transition (:1243-1427)
-        const int bp0 = tb.idx[f], bp1 = s_sc[3];
-        int32_t *brc_score = s_bins, *brc_path = s_bins + kFtMaxCi, *brc_lc = s_bins + 2 * kFtMaxCi;
-        if (tid == 0) s_red[6] = 0;
-        __syncthreads();
-        for (int bp = bp0 + tid; bp < bp1; bp += NT) {
-            word_lat_idx[BPC(tb, B_WID, bp)] = -1;
-            if (BPC(tb, B_WID, bp) != p.finishwid) atomicAdd(&s_red[6], 1);
+        const int bp1 = s_sc[3], nbp = bp1 - bp0;
+        for (int j = tid; j < nbp * n_ci; j += NT) {
+            const int bp = bp0 + j / n_ci, rc = j % n_ci, wid = BPC(tb, B_WID, bp);
+            if (rc == 0) { word_lat_idx[wid] = -1; if (wid != p.finishwid) atomicAdd(&s_red[6], 1); }
+            if (wid == p.finishwid) continue;
+            const int l2 = BPC(tb, B_LAST2, bp);
+            const int32_t sc = l2 == -1 ? BPC(tb, B_SCORE, bp)
+                : tb.bss[BPC(tb, B_SIDX, bp) + rs_cimap[((size_t)BPC(tb, B_LAST, bp) * n_ci + l2) * n_ci + rc]];
+            if (sc > kW) atomicMax(&brc_key[rc], ft_key(sc, bp));
         }
-        for (int rc = tid; rc < n_ci; rc += NT) {     // best exit per right-context phone, earliest bp on ties
-            int32_t bs = kW; int path = 0, lc = 0;
-            for (int bp = bp0; bp < bp1; ++bp) {
-                if (BPC(tb, B_WID, bp) == p.finishwid) continue;
-                const int l2 = BPC(tb, B_LAST2, bp), l1 = BPC(tb, B_LAST, bp);
-                const int32_t sc = l2 == -1 ? BPC(tb, B_SCORE, bp)
-                    : tb.bss[BPC(tb, B_SIDX, bp) + rs_cimap[((size_t)l1 * n_ci + l2) * n_ci + rc]];
-                if (sc > bs) { bs = sc; path = bp; lc = l1; }
-            }
-            brc_score[rc] = bs; brc_path[rc] = path; brc_lc[rc] = lc;
+        for (int j = tid; j < p.n1lm * nbp; j += NT) {             // in-LM single-phone words (:1331-1388): best predecessor
+            const int i = j / nbp, bp = bp0 + j % nbp, w = w1_wid[i];
+            if (!BPC(tb, B_VALID, bp)) continue;
+            int32_t ns = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
+            if (ns != kW) ns += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
+            atomicMax(&ckey[i], ft_key(ns, bp));
+        }
+        __syncthreads();
+        FT_PROF(16);
+        for (int rc = tid; rc < n_ci; rc += NT) {
+            const unsigned long long k = brc_key[rc];
+            const bool none = ft_key_none(k);
+            const int path = none ? 0 : ft_key_bp(k);
+            brc_score[rc] = none ? kW : ft_key_score(k); brc_path[rc] = path; brc_lc[rc] = none ? 0 : BPC(tb, B_LAST, path);
         }
         __syncthreads();
         if (s_red[6] > 0) {
@@ -903,13 +1038,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             for (int i = tid; i < p.n1lm; i += NT) {     // in-LM single-phone words (:1331-1388)
                 const int w = w1_wid[i];
-                int32_t ds = kMaxNegInt32; int dbp = 0;
-                for (int bp = bp0; bp < bp1; ++bp) {
-                    if (!BPC(tb, B_VALID, bp)) continue;
-                    int32_t ns = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
-                    if (ns != kW) ns += ft_lm(p, trie, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
-                    if (ns > ds) { ds = ns; dbp = bp; }
-                }
+                const unsigned long long k = ckey[i];
+                const int32_t ds = ft_key_none(k) ? kMaxNegInt32 : ft_key_score(k);
+                const int dbp = ft_key_none(k) ? 0 : ft_key_bp(k);
                 lt_dscr[w] = ds; lt_bp[w] = dbp;
                 if (w == p.startwid) continue;
                 const int c = W1 + i;
@@ -941,7 +1072,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         }
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
         __syncthreads();
+        FT_PROF(17);
     }
+#ifdef PSGPU_FT_PROFILE
+    if (tid == 0 && bf.prof) for (int i = 0; i < 32; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 32 + i] = s_prof[i];
+#endif
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
         result[0] = s_sc[3]; result[1] = s_sc[4]; result[2] = s_sc[7]; result[3] = s_sc[6];
@@ -1016,8 +1151,9 @@ static const T *ft_up(psgpu_fwdtree_s *m, const T *src, size_t n, int *rc)
     return (const T *)d;
 }
 
-// the per-utterance arrays: offsets of the fast arrays (LDS pool or slab) and of the slab
-static void ft_layout(FtDev &d, bool small)
+// the per-utterance arrays: offsets of the fast arrays (LDS pool or slab) and of the slab.  Returns false when the LDS layout
+// was asked for and does not fit.
+static bool ft_layout(FtDev &d, bool small)
 {
     const int ne = d.n_emit, rec = ne == 3 ? 16 : 24, words = 3 * ne + 6;
     int64_t o = 0;
@@ -1031,20 +1167,30 @@ static void ft_layout(FtDev &d, bool small)
     L.cand_wid = take(d.n_w + 1); L.cand_score = take(d.n_w + 1); L.cand_bp = take(d.n_w + 1);
     L.o_out = take(d.N); L.o_outh = take(d.N); L.pos = take(d.N); L.flag = take(d.N); L.o_frame = take(d.N);
     L.cnt = take(d.cnt_words);
+    L.cnt2 = take(d.n_w + 2); L.cnt3 = take(d.n_w + 2); L.woff = take(d.n_w + 2); L.ckey = take(2 * ((int64_t)d.n_w + 2));
+    L.present = take(((int64_t)d.TOT + 3) / 4);
     if (small) {
         L.row = take(((int64_t)d.n_sen + 1) / 2 + 4); L.pen = take(2 * (int64_t)d.n_ci);
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
+        L.wc_off = take(d.n_w + 1);
+        L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
+        // what is left of the pool stages the frame's exits
+        const int64_t left = ((int64_t)kFtLdsWords - o) / 4;
+        if (left < kFtMinStage || d.n_sen > kFtMaxSen) return false;
+        L.stage_cap = (int32_t)std::min<int64_t>(left, 2048);
     }
-    L.total = (int32_t)std::min<int64_t>(o, 0x7fffffff);
+    else
+        L.stage_cap = (int32_t)std::min<int64_t>(std::max<int64_t>(d.TOT, 64), 8192);
+    L.stage = take(4 * (int64_t)L.stage_cap);
+    if (o > 0x7fffff00) return false;
+    L.total = (int32_t)o;
     d.small = small ? 1 : 0;
     int64_t g = 0;
     auto gtake = [&](int64_t n) { const int64_t r = g; g += (n + 31) & ~(int64_t)31; return r; };       // 128-byte lines
-    d.g_wrec = gtake((int64_t)d.TOT * rec); d.g_present = gtake(d.TOT);
-    d.g_elist = gtake((int64_t)d.TOT + 1); d.g_eword = gtake((int64_t)d.TOT + 1);
-    d.g_xlist = gtake((int64_t)d.TOT + 1); d.g_xslot = gtake((int64_t)d.TOT + 1);
-    d.g_cand_next = gtake(d.n_w + 1); d.g_csf_ef = gtake(d.n_w + 1); d.g_csf_cand = gtake(d.n_w + 1);
+    d.g_wrec = gtake((int64_t)d.TOT * rec);
     d.g_fast = small ? 0 : gtake(o);
     d.per = g;
+    return true;
 }
 
 extern "C" {
@@ -1097,6 +1243,7 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     wc_off[d.n_w] = (int32_t)tot;
     d.TOT = (int32_t)tot;
     d.CH = d.N + d.n1;
+    d.n_tmat = t->n_tmat;
     d.cnt_words = std::max(d.R + d.N + 1, 4 * d.n_w + 4);
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
     d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
@@ -1120,20 +1267,22 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     // layout: LDS when everything the tree level touches fits the pool (PSGPU_FWDTREE_LAYOUT=slab forces the other one: the
     // parity tests run both)
     const char *force = getenv("PSGPU_FWDTREE_LAYOUT");
-    ft_layout(d, true);
-    if (d.lay.total > kFtLdsWords || d.n_sen > kFtMaxSen || (force && !strcmp(force, "slab"))) ft_layout(d, false);
+    if ((force && !strcmp(force, "slab")) || !ft_layout(d, true)) {
+        if (!ft_layout(d, false)) { psgpu_set_error("fwdtree: the search's per-utterance arrays exceed 8 GB"); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
+    }
     *out = m;
     return PSGPU_OK;
 }
 
 const LmDev *psgpu_lm_dev(const psgpu_lm_t *lm);     // psgpu_lm.hip
+const LmDev *psgpu_lm_dev_ptr(const psgpu_lm_t *lm);
 
 int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm)
 {
     PSGPU_REQUIRE(m && lm, "psgpu_fwdtree_set_lm: NULL argument");
     const LmDev *d = psgpu_lm_dev(lm);
     PSGPU_REQUIRE(d->n_words == m->d.n_w, "psgpu_fwdtree_set_lm: the model maps %d dictionary words, the search has %d", d->n_words, m->d.n_w);
-    m->d.trie = *d;
+    m->d.trie_dev = psgpu_lm_dev_ptr(lm);
     m->d.use_trie = 1;
     return PSGPU_OK;
 }
@@ -1188,6 +1337,10 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     FtBufs bf;
     bf.slab = m->slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
     bf.w1_out = w1_ssid_out_dev;
+    bf.prof = nullptr;
+#ifdef PSGPU_FT_PROFILE
+    PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 32 * (size_t)n_utt));
+#endif
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
@@ -1206,6 +1359,24 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     }
 #undef FT_LAUNCH
     PSGPU_HIP(hipGetLastError());
+#ifdef PSGPU_FT_PROFILE
+    {   // a profiling build: wait, average the per-phase cycle counts over the utterances, print them per frame
+        static const char *const names[18] = { "top: active words' channel ranges", "senone bitmap", "normaliser", "evaluate", "prune: snapshot", "prune: decide",
+            "next active list", "last-phone candidates", "predecessor search (LM)", "entering", "active words", "prune_word_chan",
+            "positions (scans)", "exits: stage", "exits: merge", "single-phone words", "word_transition: pairs", "word_transition: enter + deactivate" };
+        std::vector<long long> h((size_t)32 * n_utt);
+        std::vector<int32_t> r((size_t)8 * n_utt);
+        PSGPU_HIP(hipStreamSynchronize(st));
+        PSGPU_HIP(hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+        PSGPU_HIP(hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost));
+        hipFree(bf.prof);
+        double frames = 0, tot = 0, acc[18] = {};
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 18; ++i) acc[i] += (double)h[(size_t)u * 32 + i]; }
+        for (int i = 0; i < 18; ++i) tot += acc[i];
+        fprintf(stderr, "fwdtree_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
+        for (int i = 0; i < 18; ++i) fprintf(stderr, "  %2d %-38s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
+    }
+#endif
     return PSGPU_OK;
 }
 

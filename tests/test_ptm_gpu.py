@@ -170,3 +170,59 @@ def test_config5_size_device_batch(tables, gpu_model):
         want, _, _ = o.score_utt(feats_h[u * ulen:(u + 1) * ulen], reset_hist=True, want_topn=False)
         got = scr[u * ulen:(u + 1) * ulen].cpu().numpy()
         assert np.array_equal(got, want), "utterance %d" % u
+
+
+def test_two_host_threads_score_concurrently_on_one_model(tables):
+    """The scratch between the batched scorer's kernels (open-entry flags / list / counter) belongs to the stream a
+    call is issued on, not to the model: two host threads scoring different batches on ONE psgpu_ptm_model_t at the
+    same time (each on its own stream) must both get the oracle's scores.  Duplicated codewords force the fix-up
+    path, the part that reads that scratch."""
+    import ctypes as C
+    import threading
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    g = _golden("ptm_dup_ties") if "_golden" in globals() else None
+    z = np.load(os.path.join(pso.GOLDEN_DIR, "ptm_dup_ties.npz"))
+    t2 = dict(tables)
+    for k in ("mean", "var", "det"):
+        if k in z.files:
+            t2[k] = z[k]
+    feats = np.ascontiguousarray(z["feat"], np.float32)
+    o = pso.OraclePTM(t2)
+    n = feats.shape[0]
+    halves = [feats[: n // 2], feats[n // 2:][::-1].copy()]
+    want = [o.score_utt(h, reset_hist=True, want_topn=False)[0] for h in halves]
+    m = P.PtmModel(t2)
+    L = capi.lib()
+    dev = torch.device("cuda", 0)
+    out, errs = [None, None], []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                T = halves[i].shape[0]
+                f = torch.from_numpy(halves[i]).to(dev)
+                off = torch.tensor([0, T], dtype=torch.int32, device=dev)
+                tsc = torch.empty((T, m.n_chain, m.topn), dtype=torch.int32, device=dev)
+                tcw = torch.empty((T, m.n_chain, m.topn), dtype=torch.uint8, device=dev)
+                scr = torch.empty((T, m.n_sen), dtype=torch.int16, device=dev)
+                p = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+                for _ in range(20):
+                    capi.check(L.psgpu_ptm_score_batch_dev(m.h, p(f), p(off), 1, T, None, None, p(tsc), p(tcw), p(scr), None, 0,
+                                                           C.c_void_p(st.cuda_stream)), "score")
+                st.synchronize()
+                out[i] = scr.cpu().numpy()
+        except Exception as e:     # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for i in range(2):
+        assert np.array_equal(out[i], want[i]), "thread %d" % i
+    m.close()
