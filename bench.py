@@ -210,8 +210,15 @@ def main():
     capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
     tables = _npz("en_us_ptm_tables.npz")
     gt = _npz("fwdtree_trace_goforward.npz")
-    pipe = P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
-    pipe.stage_timing(True)
+    # two pipeline objects on two streams: consecutive steps overlap (step k + 1's front end and scorer -- VALU-bound, no LDS
+    # to speak of -- run beside step k's search, a latency-bound recurrence that leaves most of every SIMD idle)
+    n_pipe = 1 if os.environ.get("PSGPU_BENCH_NO_OVERLAP") else 2
+    pipes = [P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+             for _ in range(n_pipe)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
+    for q in pipes:
+        q.stage_timing(True)
+    pipe = pipes[0]
     stream = torch.cuda.current_stream().cuda_stream
     sp = C.c_void_p(stream)
 
@@ -224,34 +231,45 @@ def main():
     soff = np.arange(B + 1, dtype=np.int64) * n_samp
     torch.cuda.synchronize()
 
-    hyp_rec = None
+    stage = []
 
-    def step():
-        """one pass of the hot path over the batch + the hypothesis records on the host (rank 0: of every rank)"""
-        pipe.run_dev(pcm, soff, stream)
+    def launch(k):
+        """one pass of the hot path over the batch: everything enqueued on the step's stream"""
+        pipes[k % n_pipe].run_dev(pcm, soff, streams[k % n_pipe].cuda_stream)
+
+    def finish(k, timed):
+        """the step's hypothesis records on the host (rank 0: of every rank)"""
+        q, st = pipes[k % n_pipe], streams[k % n_pipe]
         if dist is None:
-            return pipe.fetch()
-        v = pipe.view()
-        hn = torch.as_tensor(_DevArray(v.hyp_n_dev, (B, 4)), device=dev)
-        hy = torch.as_tensor(_DevArray(v.hyp_dev, (B, pipe.max_words, 4)), device=dev)
-        g_hn = pbatch.gather_records(hn, device=dev)
-        g_hy = pbatch.gather_records(hy, device=dev)
-        if rank == 0:
-            return g_hn.cpu().numpy(), g_hy.cpu().numpy(), None
-        torch.cuda.synchronize()
-        return None
+            out = q.fetch()
+        else:
+            v = q.view()
+            with torch.cuda.stream(st):
+                hn = torch.as_tensor(_DevArray(v.hyp_n_dev, (B, 4)), device=dev)
+                hy = torch.as_tensor(_DevArray(v.hyp_dev, (B, q.max_words, 4)), device=dev)
+                g_hn = pbatch.gather_records(hn, device=dev)
+                g_hy = pbatch.gather_records(hy, device=dev)
+                out = (g_hn.cpu().numpy(), g_hy.cpu().numpy(), None) if rank == 0 else None
+            st.synchronize()
+        if timed:
+            stage.append(q.last_stage_ms())     # events of this step's launches (complete: the records are here)
+        return out
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n, timed):
+        for k in range(n):
+            launch(k)
+            if k >= n_pipe - 1:
+                finish(k - (n_pipe - 1), timed)
+        for k in range(max(n - (n_pipe - 1), 0), n):
+            finish(k, timed)
+
+    run_steps(args.warmup, False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    stage = []
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        hyp_rec = step()
-        stage.append(pipe.last_stage_ms())      # events of this step's launches (already complete: step() waited)
+    run_steps(args.steps, True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -260,6 +278,7 @@ def main():
         dt = pbatch.max_over_ranks(dt, device=dev)
 
     # this rank's own results (tables' sizes, status, workload counters)
+    pipe.run_dev(pcm, soff, streams[0].cuda_stream)
     hn_l, hyp_l, res_l = pipe.fetch()
     if int((res_l[:, 3] != 0).sum()):
         raise SystemExit("bench: %d utterances ended with a full back-pointer table / score stack" % int((res_l[:, 3] != 0).sum()))
@@ -303,6 +322,7 @@ def main():
                    "frames_per_step_per_gpu": frames_rank, "lm": "turtle.lm.bin (115 dictionary words)",
                    "parallelism": "utt-shard x%d (rank 0 scatters PCM, gathers hypothesis records)" % world},
         "xrt": round((dt / args.steps) / audio_s, 9),
+        "steps_in_flight": n_pipe,
         "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
         "workload_counts": {"hmm_evals_per_frame": round(evals / max(frames_rank, 1), 2),
                             "listed_senones_per_frame": round(senones / max(frames_rank, 1), 2),
@@ -347,7 +367,8 @@ def main():
     # ---- extras (N = 1 only)
     extra = {}
     if not args.no_extras and world == 1:
-        pipe.close()
+        for q in pipes:
+            q.close()
         del pcm
         torch.cuda.empty_cache()
         try:

@@ -40,6 +40,7 @@ constexpr int kFtLdsWords = 15488;     // LDS layout: 60.5 KB of arrays (+ 2.4 K
 constexpr int kFtMinStage = 128;       // exits staged in LDS per frame, at least (LDS layout)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
+constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
 
 // word offsets of the per-utterance arrays the tree level works on ("fast" arrays: LDS in the small layout, the
 // utterance's slab otherwise)
@@ -54,6 +55,7 @@ struct FtLay {
     int32_t ckey;                        // [n_w + 2] 64-bit (score, back-pointer) keys of the pair searches
     int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
     int32_t stage, stage_cap;            // [stage_cap][4] the frame's exiting channels: out score, history, its real / prev_real wid
+    int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: the staging area doubles as it)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
@@ -253,9 +255,25 @@ __device__ __forceinline__ bool ft_save_bp(const FtTab &t, const FtDict &d, int3
     return true;
 }
 
+// Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, not for its outstanding
+// device-memory loads and stores (which __syncthreads() drains: the score-row prefetch would never survive a phase, and
+// every store would be waited for ~50 times a frame).  Where work-items exchange data through DEVICE memory (the
+// right-context channels' records, the back-pointer table) the kernel keeps __syncthreads().  LDS = false: everything
+// is in device memory (slab layout), every barrier is a full one.
+template <bool LDS>
+__device__ __forceinline__ void ft_sync()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+#else
+    __syncthreads();
+#endif
+}
+
 // Exclusive prefix sum of a[0..n) in place by the whole workgroup (a written before a barrier); returns the total to
 // every thread.  tmp: NT / 64 words of LDS.  Ends with a barrier.
-template <int NT>
+template <int NT, bool LDS>
 __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp)
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -268,7 +286,7 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
             if (lane < n) a[lane] = incl - v;
             if (lane == 63) tmp[0] = incl;
         }
-        __syncthreads();
+        ft_sync<LDS>();
         return tmp[0];
     }
     const int per = (n + NT - 1) / NT;
@@ -279,18 +297,18 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
     if (lane == 63) tmp[tid >> 6] = incl;
-    __syncthreads();
+    ft_sync<LDS>();
     int32_t base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
     int32_t run = base + incl - sum;
     for (int i = b; i < e; ++i) { const int32_t k = a[i]; a[i] = run; run += k; }
-    __syncthreads();
+    ft_sync<LDS>();
     return total;
 }
 
 // K exclusive prefix sums at once (same barriers as one)
-template <int NT, int K>
+template <int NT, int K, bool LDS>
 __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, int32_t *tmp, int32_t (&total)[K])
 {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -306,7 +324,7 @@ __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, i
                 if (lane == 63) tmp[k] = incl;
             }
         }
-        __syncthreads();
+        ft_sync<LDS>();
 #pragma unroll
         for (int k = 0; k < K; ++k) total[k] = tmp[k];
         return;
@@ -325,7 +343,7 @@ __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, i
 #pragma unroll
         for (int k = 0; k < K; ++k) tmp[k * (NT / 64) + (tid >> 6)] = incl[k];
     }
-    __syncthreads();
+    ft_sync<LDS>();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         int32_t base = 0, tot = 0;
@@ -335,7 +353,7 @@ __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, i
         int32_t run = base + incl[k] - sum[k];
         for (int i = b; i < e; ++i) { const int32_t v = a[k][i]; a[k][i] = run; run += v; }
     }
-    __syncthreads();
+    ft_sync<LDS>();
 }
 // the segment of item j in the exclusive prefix sums off[0..n] (off[0] = 0 <= j < off[n]): the largest i with off[i] <= j
 // (empty segments are skipped)
@@ -367,6 +385,19 @@ __device__ __forceinline__ int ft_key_bp(unsigned long long k) { return 0x7fffff
 #define FT_PROF(i) do { } while (0)
 #endif
 
+// measuring builds: PSGPU_FT_ROW_DIRECT reads the frame's scores straight from device memory (no copy through LDS, no
+// prefetch); PSGPU_FT_PLAIN_PREFETCH uses ordinary instead of non-temporal loads for the copy
+#ifdef PSGPU_FT_ROW_DIRECT
+constexpr bool kFtRowLds = false;
+#else
+constexpr bool kFtRowLds = true;
+#endif
+#ifdef PSGPU_FT_PLAIN_PREFETCH
+#define FT_ROW_LOAD(p) (*(p))
+#else
+#define FT_ROW_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 template <int NE, int NT, bool SMALL>
 __global__ __launch_bounds__(NT)
 void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_stride, const int32_t *__restrict__ penalties_,
@@ -382,6 +413,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
     __shared__ int32_t s_nsen;           // listed senones, summed over the frames (raw-score mode)
+    __shared__ int32_t s_nev;            // length of the frame's evaluation list
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
     __shared__ long long s_prof[32], s_last;
@@ -403,7 +435,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const cand_wid = fb + L.cand_wid, *const cand_score = fb + L.cand_score, *const cand_bp = fb + L.cand_bp,
             *const o_out = fb + L.o_out, *const o_outh = fb + L.o_outh, *const pos = fb + L.pos, *const flag = fb + L.flag,
             *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3,
-            *const woff = fb + L.woff, *const stage = fb + L.stage;
+            *const woff = fb + L.woff, *const stage = fb + L.stage, *const evl = fb + L.evl;
     unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
     uint8_t *const present = reinterpret_cast<uint8_t *>(fb + L.present);
     FtTab tb;
@@ -466,13 +498,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
     }
     // the small layout reads scores and penalties from LDS: frame 0's rows now, every later frame's one frame ahead
-    constexpr int kPre = SMALL ? (kFtMaxSen / 2 + NT - 1) / NT : 1;
+    constexpr bool ROWL = SMALL && kFtRowLds;           // the frame's score row is read from its LDS copy
+    constexpr int kPre = ROWL ? (kFtMaxSen / 2 + NT - 1) / NT : 1;
     const int row_dw = (p.n_sen + 1) >> 1;              // dwords per score row (the host checked the alignment)
     auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T - 1) : f); };
     if (SMALL && T > 0) {
-        const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
-        uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
-        for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
+        if (ROWL) {
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
+            uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+            for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
+        }
         if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[i] = penalties[(size_t)pen_frame(0) * n_ci + i];
     }
     __syncthreads();
@@ -485,43 +520,57 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         int32_t *const awlc = fb + (cur ? L.awl1 : L.awl0), *const awln = fb + (cur ? L.awl0 : L.awl1);
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : penalties + (size_t)pen_frame(f) * n_ci;
-        const int16_t *const row = SMALL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
+        const int16_t *const row = ROWL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
-        // small layout: the next frame's score row and penalties start their way from HBM now
-        uint32_t pre[kPre];
-        int32_t pre_pen = 0;
-        if (SMALL && nf < T) {
-            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + nf) * scr_stride);
-#pragma unroll
-            for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; pre[k] = i < row_dw ? __builtin_nontemporal_load(g + i) : 0u; }
-            if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
-        }
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
-        if (tid == 0) tb.idx[f] = s_sc[3];
+        if (tid == 0) { tb.idx[f] = s_sc[3]; s_nev = 0; }
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
         const int32_t bp0 = s_sc[3];                          // this frame's first back-pointer
         if (tid < 8) s_red[tid] = kW;
         // a word near its end has its whole right-context fan-out (20-40 channels) allocated at once: the word level is
         // worked on one work-item per channel.  The channels of the active words are the segments [woff[i], woff[i + 1])
-        // of one index range; an item finds its word by bisection (ft_seg_find) and skips slots that are not allocated.
-        const int naw = n_awl_cur;
+        // of one index range; an item finds its word by bisection (ft_seg_find).
+        const int naw = n_awl_cur, na = n_acl_cur;
         for (int i = tid; i < naw; i += NT) { const int w = awlc[i]; word_active[w] = 0; woff[i] = wc_off[w + 1] - wc_off[w]; }
         if (tid == 0) woff[naw] = 0;
-        __syncthreads();
-        const int nwc = ft_block_scan<NT>(woff, naw + 1, s_scan);
-        FT_PROF(0);
-        auto for_word_channels = [&](auto &&fn) {
-            for (int j = tid; j < nwc; j += NT) {
-                const int i = ft_seg_find(woff, naw, j), slot = wc_off[awlc[i]] + (j - woff[i]);
-                if (present[slot]) fn(i, slot);
+        ft_sync<SMALL>();
+        const int nwc = ft_block_scan<NT, SMALL>(woff, naw + 1, s_scan);
+        // ---- the frame's evaluation list: every HMM instance evaluate_channels (:605-715) visits -- roots entered for this
+        //      frame, the listed tree nodes, the allocated right-context channels of the active words, the single-phone
+        //      words entered for this frame -- compacted into one list (order irrelevant: independent evaluations, maxima
+        //      and counts), so that marking the senones, the evaluation and the renormalisation each are ONE pass of the
+        //      workgroup instead of four loops each paying its own latency.  Tree channels: their channel index;
+        //      right-context channels: kFtWordCh | index of the word in the active list << 8 | right context.
+        {
+            const int n_items = R + na + n1 + nwc, lane = tid & 63;
+            for (int k0 = 0; k0 < n_items; k0 += NT) {
+                int k = k0 + tid, code = -1;
+                if (k < R) { if (tv.at(k, F::FRAME) == f) code = k; }
+                else if ((k -= R) < na) code = aclc[k];
+                else if ((k -= na) < n1) { if (tv.at(W1 + k, F::FRAME) == f) code = W1 + k; }
+                else if ((k -= n1) < nwc) {
+                    const int i = ft_seg_find(woff, naw, k), r = k - woff[i];
+                    if (present[wc_off[awlc[i]] + r]) code = kFtWordCh | (i << 8) | r;
+                }
+                const unsigned long long m = __ballot(code >= 0);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_nev, __popcll(m));
+                base = __shfl(base, 0);
+                const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (code >= 0 && at < L.evl_cap) evl[at] = code;
             }
-        };
+        }
+        ft_sync<SMALL>();
+        const int n_ev = s_nev;
+        if (n_ev > L.evl_cap) { if (tid == 0) s_sc[6] = 2; ft_sync<SMALL>(); break; }      // status 2: the LDS layout's list is full
+        FT_PROF(0);
+        auto word_slot = [&](int code) { return wc_off[awlc[(code >> 8) & 0x3fffff]] + (code & 255); };
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
-            for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_normalize<NE>(tv, i, best_in);
-            for (int i = tid; i < n_acl_cur; i += NT) ch_normalize<NE>(tv, aclc[i], best_in);
-            for_word_channels([&](int, int slot) { ch_normalize<NE>(wv, slot, best_in); });
-            for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_normalize<NE>(tv, W1 + i, best_in);
+            for (int e = tid; e < n_ev; e += NT) {
+                const int c = evl[e];
+                if (c & kFtWordCh) ch_normalize<NE>(wv, word_slot(c), best_in); else ch_normalize<NE>(tv, c, best_in);
+            }
             __syncthreads();
         }
         int32_t nb = 0;
@@ -539,11 +588,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
                 }
             };
-            for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) mark(tv, i);
-            for (int i = tid; i < n_acl_cur; i += NT) mark(tv, aclc[i]);
-            for_word_channels([&](int, int slot) { mark(wv, slot); });
-            for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) mark(tv, W1 + i);
-            __syncthreads();
+            for (int e = tid; e < n_ev; e += NT) {
+                const int c = evl[e];
+                if (c & kFtWordCh) mark(wv, word_slot(c)); else mark(tv, c);
+            }
+            ft_sync<SMALL>();
             FT_PROF(1);
             int32_t mn = 0x7fffffff;
             for (int w = tid; w < nwords; w += NT) {
@@ -562,51 +611,57 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
             }
             if (mn != 0x7fffffff) atomicMin(&s_nb, mn);
-            __syncthreads();
+            ft_sync<SMALL>();
             nb = s_nb;
             FT_PROF(2);
         }
-        // ---- evaluate_channels (:605-715): s_red[0] roots, [1] tree, [2] word level; [3..4] counts
+        // ---- evaluate_channels (:605-715): s_red[0] every channel, [2] word level (ngs->last_phone_best_score: the
+        //      right-context channels and the single-phone words but </s>)
         {
             const SenRowNorm sr = { row, nb };
-            int32_t b0 = kW, b1 = kW, b2 = kW; int n0 = 0, n2 = 0;
-            for (int i = tid; i < R; i += NT)
-                if (tv.at(i, F::FRAME) == f) { b0 = max(b0, ch_eval<NE>(tv, i, sr, tpall, sseq)); ++n0; }
-            for (int i = tid; i < n_acl_cur; i += NT) b1 = max(b1, ch_eval<NE>(tv, aclc[i], sr, tpall, sseq));
-            for_word_channels([&](int, int slot) { b2 = max(b2, ch_eval<NE>(wv, slot, sr, tpall, sseq)); ++n2; });
-            for (int i = tid; i < n1; i += NT) {
-                if (tv.at(W1 + i, F::FRAME) < f) continue;
-                const int32_t sc = ch_eval<NE>(tv, W1 + i, sr, tpall, sseq);
-                if (w1_wid[i] != p.finishwid) b2 = max(b2, sc);
-                ++n2;
+            int32_t b_all = kW, b_word = kW;
+            for (int e = tid; e < n_ev; e += NT) {
+                const int c = evl[e];
+                if (c & kFtWordCh) {
+                    const int32_t sc = ch_eval<NE>(wv, word_slot(c), sr, tpall, sseq);
+                    b_all = max(b_all, sc); b_word = max(b_word, sc);
+                }
+                else {
+                    const int32_t sc = ch_eval<NE>(tv, c, sr, tpall, sseq);
+                    if (c < W1) b_all = max(b_all, sc);
+                    else if (w1_wid[c - W1] != p.finishwid) { b_all = max(b_all, sc); b_word = max(b_word, sc); }   // (:688-694: </s> never sets the best score)
+                }
             }
-            if (b0 > kW) atomicMax(&s_red[0], b0);
-            if (b1 > kW) atomicMax(&s_red[1], b1);
-            if (b2 > kW) atomicMax(&s_red[2], b2);
-            if (n0) atomicAdd(&s_red[3], n0);                // (s_red[3..4] start at kW: corrected below)
-            if (n2) atomicAdd(&s_red[4], n2);
+            if (b_all > kW) atomicMax(&s_red[0], b_all);
+            if (b_word > kW) atomicMax(&s_red[2], b_word);
             if (raw_mode) {                                  // the bitmap is free again: cleared for the next frame
                 const int nwords = (p.n_sen + 31) >> 5;
                 for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
             }
         }
-        __syncthreads();
-        if (SMALL && nf < T) {                               // the score row has been read: the next frame's takes its place
-            uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+        __syncthreads();                                     // (device memory: the right-context channels' records, tb.idx[f])
+        // small layout: the next frame's score row and penalties start their way from HBM now -- the barriers from here to
+        // the language-model look-ups wait for LDS only, so the loads stay in flight across them; they are written to LDS
+        // at the end of the frame (this frame's row has been read: evaluation is over)
+        uint32_t pre[kPre];
+        int32_t pre_pen = 0;
+        if (SMALL && nf < T) {
+            if (ROWL) {
+                const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + nf) * scr_stride);
 #pragma unroll
-            for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; if (i < row_dw) d[i] = pre[k]; }
-            if (p.has_pl && tid < n_ci) s_pen[nxt * n_ci + tid] = pre_pen;
+                for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; pre[k] = i < row_dw ? FT_ROW_LOAD(g + i) : 0u; }
+            }
+            if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
         }
         if (tid == 0) {
-            const int32_t bs = max(max(s_red[0], s_red[1]), s_red[2]);
-            s_sc[0] = bs; s_sc[1] = s_red[2];
-            s_evals += (unsigned long long)((s_red[3] - kW) + n_acl_cur + (s_red[4] - kW));
+            s_sc[0] = s_red[0]; s_sc[1] = s_red[2];
+            s_evals += (unsigned long long)n_ev;
             s_sc[5] = 0;                                        // n_lastphn_cand
             s_sc[2] = p.beam;                                   // dynamic beam (:1133-1181)
             s_nb = 0x7fffffff;
         }
         for (int i = tid; i < 256; i += NT) s_bins[i] = 0;
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(3);
         const int32_t best_score = s_sc[0];
         if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
@@ -617,13 +672,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 if (b >= 256) b = 255;
                 atomicAdd(&s_bins[b], 1);
             }
-            __syncthreads();
+            ft_sync<SMALL>();
             if (tid == 0) {
                 int i, nh = 0;
                 for (i = 0; i < 256; ++i) { nh += s_bins[i]; if (nh > p.maxhmmpf) break; }
                 s_sc[2] = -(i * bw);
             }
-            __syncthreads();
+            ft_sync<SMALL>();
         }
         const int32_t thresh = best_score + s_sc[2];
         const int32_t npt = best_score + p.pbeam, lpt = best_score + p.lpbeam;
@@ -632,7 +687,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //      channels (oracle prune_tree_list): the items are the roots, the listed nodes and their children.  Reads of
         //      another node's state go to the snapshot (o_out, o_outh, flag, pos) of a root or listed node, writes to the
         //      item's own channel and decision word, so the items are independent.
-        const int na = n_acl_cur;
         for (int q = tid; q < na; q += NT) pos[aclc[q]] = q;
         for (int i = tid; i < R + na; i += NT) {
             const int node = i < R ? i : aclc[i - R];
@@ -640,7 +694,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             o_out[node] = tv.at(node, F::OUT); o_outh[node] = tv.at(node, F::OUTH);
             flag[node] = (active && tv.at(node, F::BEST) > thresh) ? 1 : 0;
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(4);
         auto decide = [&](int c) {
             const int P = parent[c], pc = pos[c];
@@ -672,7 +726,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 decide(c);
             }
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(5);
         for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
         for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
@@ -686,8 +740,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             cnt[i] = k;
         }
-        __syncthreads();
-        const int32_t n_listed = ft_block_scan<NT>(cnt, R + na, s_scan);      // exclusive prefix sum
+        ft_sync<SMALL>();
+        const int32_t n_listed = ft_block_scan<NT, SMALL>(cnt, R + na, s_scan);      // exclusive prefix sum
         for (int i = tid; i < R + na; i += NT) {
             const int node = i < R ? i : aclc[i - R];
             int o = cnt[i];
@@ -697,7 +751,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int q = kid_off[node]; q < k1; ++q) { const int c = kids[q]; if (o_frame[c] & 2) acln[o++] = c; }
             }
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(6);
         // last-phone candidates: list order, homophone chain inside
         for (int i = tid; i < R + na; i += NT) {
@@ -708,9 +762,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int w = node_pw[node]; w >= 0; w = homophone[w]) k += (news + ft_pen(d_last[w]) > lpt) ? 1 : 0;
             cnt[i] = k;
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         {
-            const int32_t n_cand_all = ft_block_scan<NT>(cnt, R + na, s_scan);
+            const int32_t n_cand_all = ft_block_scan<NT, SMALL>(cnt, R + na, s_scan);
             if (tid == 0) { s_sc[5] = n_cand_all; s_red[7] = 0; }
         }
         for (int i = tid; i < R + na; i += NT) {
@@ -723,7 +777,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         cand_wid[o] = w; cand_score[o] = news - p.nwpen; cand_bp[o] = o_outh[node]; ++o;
                     }
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(7);
 
         // ---- word level: last_phone_transition (:884-1035).  Candidates of one frame name distinct words (a word has
@@ -736,10 +790,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int n_cand = s_sc[5];
         for (int i = tid; i < n_cand; i += NT)               // O(1) per candidate: the frame stamp of the word
             if (atomicExch(&cand_mark[cand_wid[i]], f) == f) s_red[7] = 1;
-        __syncthreads();
+        ft_sync<SMALL>();
         // (two candidates naming one word would need two paths to that word in the tree: create_search_channels builds
         //  one per dictionary entry.  The reference's loops would cope; here it ends the utterance with status 3.)
-        if (s_red[7] != 0) { if (tid == 0) s_sc[6] = 3; __syncthreads(); break; }
+        if (s_red[7] != 0) { if (tid == 0) s_sc[6] = 3; ft_sync<SMALL>(); break; }
         {
             for (int i = tid; i < n_cand; i += NT) {
                 const int cb = cand_bp[i], w = cand_wid[i];
@@ -753,8 +807,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 ckey[i] = ft_key_floor(kW);
             }
             if (tid == 0) cnt[n_cand] = 0;
-            __syncthreads();
-            const int n_pair = ft_block_scan<NT>(cnt, n_cand + 1, s_scan);
+            ft_sync<SMALL>();
+            const int n_pair = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
             for (int j = tid; j < n_pair; j += NT) {
                 const int i = ft_seg_find(cnt, n_cand, j), bp = cnt2[i] + (j - cnt[i]), w = cand_wid[i];
                 if (!BPC(tb, B_VALID, bp)) continue;
@@ -762,7 +816,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 if (dscr > kW) dscr += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
                 atomicMax(&ckey[i], ft_key(dscr, bp));
             }
-            __syncthreads();
+            ft_sync<SMALL>();
             int32_t bestscore = kW;
             for (int i = tid; i < n_cand; i += NT) {
                 const int w = cand_wid[i];
@@ -779,7 +833,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             if (bestscore > kW) atomicMax(&s_sc[1], bestscore);
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(8);
         {
             // ---- last_phone_transition's entering loop (:1004-1030).  One work-item per (entering candidate, right context):
@@ -793,8 +847,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     cnt2[i] = 0;                                // "entered a channel"
                 }
                 if (tid == 0) cnt[n_cand] = 0;
-                __syncthreads();
-                const int n_ent = ft_block_scan<NT>(cnt, n_cand + 1, s_scan);
+                ft_sync<SMALL>();
+                const int n_ent = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
                 for (int j = tid; j < n_ent; j += NT) {
                     const int i = ft_seg_find(cnt, n_cand, j), w = cand_wid[i], r = j - cnt[i], slot = wc_off[w] + r;
                     if (!present[slot]) {                       // ngram_search_alloc_all_rc (ngram_search.c:583-633)
@@ -808,10 +862,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads();                                     // (device memory is exchanged here)
             FT_PROF(9);
             {                                            // stable compaction by a prefix sum
-                const int32_t nawl = ft_block_scan<NT>(cnt2, n_cand, s_scan);
+                const int32_t nawl = ft_block_scan<NT, SMALL>(cnt2, n_cand, s_scan);
                 for (int i = tid; i < n_cand; i += NT)
                     if ((i + 1 < n_cand ? cnt2[i + 1] : nawl) != cnt2[i]) {
                         const int w = cand_wid[i];
@@ -819,26 +873,29 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     }
                 if (tid == 0) s_red[5] = nawl;
             }
-            __syncthreads();
+            ft_sync<SMALL>();
             FT_PROF(10);
             // ---- prune_word_chan (:1038-1128): keep / free the right-context channels, count the survivors per word,
-            //      note whether the word exits.  One work-item per allocated channel of the active words (the ones this
-            //      frame's candidates have just allocated were entered for the next frame and have no score yet: they are
-            //      neither counted nor freed, exactly as the reference's walk treats them), survivors counted per word by atomics
+            //      note whether the word exits.  One work-item per right-context channel of the evaluation list (the channels
+            //      this frame's candidates have just allocated were entered for the next frame and have no score yet: the
+            //      reference's walk neither counts nor frees them), survivors counted per word by atomics
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
             const int wst = p.n_w + 1;                            // naw <= n_w
             int32_t *const w_k = cnt, *const w_exit = cnt + wst, *const w_bp = cnt + 2 * wst, *const w_bss = cnt + 3 * wst;
             for (int i = tid; i < naw; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
-            __syncthreads();
-            for_word_channels([&](int i, int slot) {
+            ft_sync<SMALL>();
+            for (int e = tid; e < n_ev; e += NT) {
+                const int c = evl[e];
+                if (!(c & kFtWordCh)) continue;
+                const int i = (c >> 8) & 0x3fffff, slot = word_slot(c);
                 if (wv.at(slot, F::BEST) > lpth) {
                     wv.at(slot, F::FRAME) = nf;
                     atomicAdd(&w_k[i], 1);
                     if (wv.at(slot, F::OUT) > nwt) atomicOr(&w_exit[i], 1);
                 }
                 else if (wv.at(slot, F::FRAME) != nf) present[slot] = 0;
-            });
-            __syncthreads();
+            }
+            __syncthreads();                                     // (device memory is exchanged here)
             FT_PROF(11);
             for (int i = tid; i <= naw; i += NT) {
                 // inputs of the three prefix sums below: next active word list, back-pointers, score-stack entries
@@ -848,12 +905,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 w_bp[i] = ex ? 1 : 0;
                 w_bss[i] = ex ? wc_off[w + 1] - wc_off[w] : 0;     // = rssid n_ssid of the word's last two phones
             }
-            __syncthreads();
+            ft_sync<SMALL>();
             const int32_t bpidx = s_sc[3], bss_head = s_sc[4], nawl0 = s_red[5];     // (rewritten below, after the scans' barriers)
             int32_t tot[3];
             {
                 int32_t *const arr[3] = { w_bp, w_bss, w_k };
-                ft_block_scan_k<NT, 3>(arr, naw + 1, s_scan, tot);
+                ft_block_scan_k<NT, 3, SMALL>(arr, naw + 1, s_scan, tot);
             }
             const int32_t n_exit = tot[0], n_bss = tot[1], n_app = tot[2];
             for (int i = tid; i < naw; i += NT)
@@ -865,7 +922,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 if (bpidx + n_exit + n1 >= tb.bp_cap || bss_head + n_bss + n_ci >= tb.bss_cap) s_sc[6] = 1;
                 s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; s_red[5] = nawl0 + n_app;
             }
-            __syncthreads();
+            ft_sync<SMALL>();
             FT_PROF(12);
             if (!s_sc[6]) {
                 // ---- the exits' back-pointers (ngram_search_save_bp, ngram_search.c:376-498).  An exiting word owns one
@@ -890,7 +947,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     tb.bss[bss_head + j] = it[0];                // (no exit: WORST_SCORE, as the creation fills it)
                     if (j < scap) { stage[4 * j] = it[0]; stage[4 * j + 1] = it[1]; stage[4 * j + 2] = it[2]; stage[4 * j + 3] = it[3]; }
                 }
-                __syncthreads();
+                ft_sync<SMALL>();
                 FT_PROF(13);
                 for (int i = tid; i < naw; i += NT) {
                     if (!w_exit[i]) continue;
@@ -927,7 +984,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     else { BPC(tb, B_REAL, bpi) = d_base[w]; BPC(tb, B_PREAL, bpi) = rw_real; }
                 }
             }
-            __syncthreads();
+            __syncthreads();                                     // (device memory is exchanged here)
             FT_PROF(14);
         }
         if (!s_sc[6]) {
@@ -953,19 +1010,19 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
                 f_ex[i] = ex; f_new[i] = nw; f_rc[i] = rcn;
             }
-            __syncthreads();
+            ft_sync<SMALL>();
             const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
             int32_t tot[2];
             {
                 int32_t *const arr[2] = { f_new, f_rc };
-                ft_block_scan_k<NT, 2>(arr, n1 + 1, s_scan, tot);
+                ft_block_scan_k<NT, 2, SMALL>(arr, n1 + 1, s_scan, tot);
             }
             for (int i = tid; i < n1; i += NT)
                 if (f_ex[i]) {
                     int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
                     if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
                 }
-            __syncthreads();
+            __syncthreads();                                     // (device memory is exchanged here)
             if (tid == 0) { s_sc[3] = bpidx0 + tot[0]; s_sc[4] = bss0 + tot[1]; }
         }
         if (tid == 0 && !s_sc[6]) {
@@ -998,7 +1055,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         for (int rc = tid; rc < n_ci; rc += NT) brc_key[rc] = ft_key_floor(kW);
         for (int i = tid; i < p.n1lm; i += NT) ckey[i] = ft_key_floor(kMaxNegInt32);
         if (tid == 0) s_red[6] = 0;
-        __syncthreads();
+        __syncthreads();                                     // (device memory is exchanged here)
         const int n_awl_nxt = s_red[5];
         if (s_sc[6]) break;
         const int bp1 = s_sc[3], nbp = bp1 - bp0;
@@ -1018,7 +1075,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (ns != kW) ns += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
             atomicMax(&ckey[i], ft_key(ns, bp));
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         FT_PROF(16);
         for (int rc = tid; rc < n_ci; rc += NT) {
             const unsigned long long k = brc_key[rc];
@@ -1026,7 +1083,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const int path = none ? 0 : ft_key_bp(k);
             brc_score[rc] = none ? kW : ft_key_score(k); brc_path[rc] = path; brc_lc[rc] = none ? 0 : BPC(tb, B_LAST, path);
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         if (s_red[6] > 0) {
             for (int i = tid; i < R; i += NT) {          // tree roots (:1306-1325)
                 const int ci = node_ci[i];
@@ -1062,7 +1119,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     ch_enter<NE>(tv, c, ns, brc_path[p.sil_ci], nf);
             }
         }
-        __syncthreads();
+        ft_sync<SMALL>();
         // ---- deactivate_channels (:1429-1450)
         for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_clear<NE>(tv, i);
         for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_clear<NE>(tv, W1 + i);
@@ -1071,7 +1128,15 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             ++s_sc[7];
         }
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
-        __syncthreads();
+        if (SMALL && nf < T) {                               // the next frame's score row and penalties take their place
+            if (ROWL) {
+                uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+#pragma unroll
+                for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; if (i < row_dw) d[i] = pre[k]; }
+            }
+            if (p.has_pl && tid < n_ci) s_pen[nxt * n_ci + tid] = pre_pen;
+        }
+        ft_sync<SMALL>();
         FT_PROF(17);
     }
 #ifdef PSGPU_FT_PROFILE
@@ -1182,6 +1247,12 @@ static bool ft_layout(FtDev &d, bool small)
     else
         L.stage_cap = (int32_t)std::min<int64_t>(std::max<int64_t>(d.TOT, 64), 8192);
     L.stage = take(4 * (int64_t)L.stage_cap);
+    if (small) { L.evl = L.stage; L.evl_cap = 4 * L.stage_cap; }       // (the list is dead before the exits are staged)
+    else {
+        const int64_t n = (int64_t)d.R + d.N + d.n1 + d.TOT + 64;
+        L.evl_cap = (int32_t)std::min<int64_t>(n, 0x7ffffff0);
+        L.evl = take(L.evl_cap);
+    }
     if (o > 0x7fffff00) return false;
     L.total = (int32_t)o;
     d.small = small ? 1 : 0;

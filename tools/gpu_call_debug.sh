@@ -1,5 +1,9 @@
 set -u
-OUT=$PWD/gpurun_out/r02d; mkdir -p $OUT
+OUT=$PWD/gpurun_out/r02f; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-(DBG_REPS=16 timeout 400 python tools/debug_long_utt.py 2>&1 | tail -30) > $OUT/debug_long_1.txt; cat $OUT/debug_long_1.txt
-(DBG_REPS=10 DBG_COPIES=3 timeout 400 python tools/debug_long_utt.py 2>&1 | tail -24) > $OUT/debug_long_3.txt; cat $OUT/debug_long_3.txt
+for v in "" _plain _direct; do
+  echo "=== variant libpsgpu$v"
+  (PSGPU_LIB_PATH=$PWD/pocketsphinx_amd/libpsgpu$v.so SB_BATCHES=1,512 timeout 200 python tools/search_bench.py 2>&1 | tail -2) | tee $OUT/search_turtle$v.txt
+  (PSGPU_LIB_PATH=$PWD/pocketsphinx_amd/libpsgpu$v.so PSGPU_BENCH_NO_OVERLAP=1 timeout 600 python bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1 2>&1 | tail -c 1500 | grep -o '"value": [0-9.]*\|"stage_ms": {[^}]*}') | tee $OUT/bench$v.txt
+done
+(PSGPU_LIB_PATH=$PWD/pocketsphinx_amd/libpsgpu_prof_direct.so SB_BATCHES=512 SB_REPS=1 timeout 200 python tools/search_bench.py 2>&1 | tail -21) | tee $OUT/search_turtle_prof_direct.txt
