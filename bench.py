@@ -210,9 +210,9 @@ def main():
     capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
     tables = _npz("en_us_ptm_tables.npz")
     gt = _npz("fwdtree_trace_goforward.npz")
-    # two pipeline objects on two streams: consecutive steps overlap (step k + 1's front end and scorer -- VALU-bound, no LDS
-    # to speak of -- run beside step k's search, a latency-bound recurrence that leaves most of every SIMD idle)
-    n_pipe = 1 if os.environ.get("PSGPU_BENCH_NO_OVERLAP") else 2
+    # PSGPU_BENCH_PIPES=2: two pipeline objects on two streams, consecutive steps overlapping.  Measured (r02, profiles/):
+    # 225.5 vs 225.9 ms per step, i.e. no gain (and twice the buffers), so one pipeline is the default.
+    n_pipe = max(1, int(os.environ.get("PSGPU_BENCH_PIPES", "1")))
     pipes = [P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
              for _ in range(n_pipe)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]

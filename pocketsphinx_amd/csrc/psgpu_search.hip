@@ -37,7 +37,7 @@ constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
 constexpr int kFtLdsWords = 15488;     // LDS layout: 60.5 KB of arrays (+ 2.4 KB fixed) per workgroup, two workgroups per CU
-constexpr int kFtMinStage = 128;       // exits staged in LDS per frame, at least (LDS layout)
+constexpr int kFtMinEvl = 512;         // the frame's evaluation list holds at least this many entries (LDS layout)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
 constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
@@ -54,8 +54,7 @@ struct FtLay {
     int32_t cnt2, cnt3, woff;            // [n_w + 2] per-candidate / per-active-word scratch; first slot index of each active word
     int32_t ckey;                        // [n_w + 2] 64-bit (score, back-pointer) keys of the pair searches
     int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
-    int32_t stage, stage_cap;            // [stage_cap][4] the frame's exiting channels: out score, history, its real / prev_real wid
-    int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: the staging area doubles as it)
+    int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
@@ -103,10 +102,14 @@ struct psgpu_fwdtree_s {
 // the tree's channels in LDS are a structure of arrays (cst = 1, fst = number of channels: work-items on consecutive
 // channels hit consecutive banks).
 template <int NE> struct ChF {
-    static constexpr int SCORE = 0, HIST = NE, OUT = 2 * NE, OUTH = 2 * NE + 1, BEST = 2 * NE + 2, FRAME = 2 * NE + 3,
-                         SENID = 2 * NE + 4, TMAT = 3 * NE + 4, MPX = 3 * NE + 5, WORDS = 3 * NE + 6,
+    // records in device memory are read and written four words at a time: what an evaluation rewrites is [0, FRAME], what the
+    // pruning and the exits look at is the quad [OUT, FRAME], the senone ids are the last quad(s)
+    static constexpr int SCORE = 0, HIST = NE, TMAT = 2 * NE, MPX = 2 * NE + 1, OUT = 2 * NE + 2, OUTH = 2 * NE + 3,
+                         BEST = 2 * NE + 4, FRAME = 2 * NE + 5, SENID = 2 * NE + 6, WORDS = 3 * NE + 6,
                          REC = NE == 3 ? 16 : 24;
+    static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
+struct alignas(16) FtQuad { int32_t x, y, z, w; };
 struct ChView {
     int32_t *b;
     int cst, fst;
@@ -136,6 +139,23 @@ __device__ __forceinline__ void ch_init(const ChView &v, int c, int mpx, int ssi
         for (int i = 0; i < NE; ++i) v.at(c, F::SENID + i) = sseq[(size_t)ssid * NE + i];
     }
     ch_clear<NE>(v, c);
+}
+// hmm_init of a plain (not multiplexed) channel followed by hmm_enter, on a record in device memory: written as quads
+template <int NE>
+__device__ __forceinline__ void ch_init_enter_rec(int32_t *rec, int ssid, int tmatid, const uint16_t *sseq, int32_t score, int32_t hist, int frame)
+{
+    using F = ChF<NE>;
+    constexpr int NQ = (F::WORDS + 3) / 4;
+    int32_t w[4 * NQ];
+#pragma unroll
+    for (int i = 0; i < 4 * NQ; ++i) w[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { w[F::SCORE + i] = kW; w[F::HIST + i] = -1; w[F::SENID + i] = sseq[(size_t)ssid * NE + i]; }
+    w[F::OUT] = kW; w[F::OUTH] = -1; w[F::BEST] = kW; w[F::MPX] = 0; w[F::TMAT] = tmatid;
+    w[F::SCORE] = score; w[F::HIST] = hist; w[F::FRAME] = frame;
+    FtQuad *dst = reinterpret_cast<FtQuad *>(rec);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) dst[k] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
 }
 template <int NE>
 __device__ __forceinline__ void ch_enter(const ChView &v, int c, int32_t score, int32_t hist, int frame)   // hmm_enter :198-204
@@ -178,6 +198,45 @@ __device__ __forceinline__ int32_t ch_eval(const ChView &v, int c, const S &row,
     v.at(c, F::OUT) = h.out_score; v.at(c, F::OUTH) = h.out_history; v.at(c, F::BEST) = h.bestscore;
     return b;
 }
+// the same on a record in device memory (16-byte aligned, ChF<NE>::REC words): the record comes in and goes out as quads
+// -- a work-item's record is one or two cache lines, and 64 work-items asking for it word by word are 64 requests per word
+template <int NE, typename S>
+__device__ __forceinline__ int32_t ch_eval_rec(int32_t *rec, const S &row, const uint8_t *tpall, const uint16_t *sseq)
+{
+    using F = ChF<NE>;
+    constexpr int NQ = (F::WORDS + 3) / 4, NW = F::SENID / 4;       // quads read; quads an evaluation rewrites ([0, FRAME])
+    int32_t w[4 * NQ];
+    const FtQuad *src = reinterpret_cast<const FtQuad *>(rec);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) { const FtQuad q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    HmmRegs h;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        h.score[i] = i < NE ? w[F::SCORE + i] : kW;
+        h.history[i] = i < NE ? w[F::HIST + i] : -1;
+        h.senid[i] = i < NE ? (uint16_t)w[F::SENID + i] : 0;
+    }
+    h.out_score = w[F::OUT]; h.out_history = w[F::OUTH]; h.bestscore = w[F::BEST];
+    const uint8_t *tp = tpall + (size_t)w[F::TMAT] * NE * (NE + 1);
+    const int mpx = w[F::MPX];
+    int32_t b;
+    if (NE == 3) b = mpx ? vit3_mpx(h, tp, row, sseq) : vit3(h, tp, row);
+    else         b = mpx ? vit5_mpx(h, tp, row, sseq) : vit5(h, tp, row);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { w[F::SCORE + i] = h.score[i]; w[F::HIST + i] = h.history[i]; }
+    w[F::OUT] = h.out_score; w[F::OUTH] = h.out_history; w[F::BEST] = h.bestscore;
+    FtQuad *dst = reinterpret_cast<FtQuad *>(rec);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dst[k] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+    if (mpx) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) rec[F::SENID + i] = h.senid[i];
+    }
+    return b;
+}
+// [OUT, OUTH, BEST, FRAME] of a record in device memory
+template <int NE>
+__device__ __forceinline__ FtQuad ch_summary(const int32_t *rec) { return *reinterpret_cast<const FtQuad *>(rec + ChF<NE>::OUT); }
 
 // ---- the back-pointer table ------------------------------------------------------------------------------------------
 struct FtTab {
@@ -271,6 +330,53 @@ __device__ __forceinline__ void ft_sync()
 #endif
 }
 
+// ---- wavefront scans ------------------------------------------------------------------------------------------------
+// Inclusive scans over the 64 lanes by data-parallel-primitive moves (row shifts within 16 lanes, then the two row broadcasts):
+// six VALU operations instead of six trips through the LDS crossbar (__shfl_up is ds_bpermute, an LDS-latency operation, and
+// a frame runs some eighty of them in sequence).  EVERY lane of the wavefront must be active.  The host build (the workgroup
+// simulator) keeps the shuffle form.
+struct FtAdd { static constexpr int32_t id = 0; static __device__ __forceinline__ int32_t op(int32_t a, int32_t b) { return a + b; } };
+struct FtMax { static constexpr int32_t id = (int32_t)0x80000000; static __device__ __forceinline__ int32_t op(int32_t a, int32_t b) { return a > b ? a : b; } };
+struct FtMin { static constexpr int32_t id = 0x7fffffff; static __device__ __forceinline__ int32_t op(int32_t a, int32_t b) { return a < b ? a : b; } };
+template <typename OP>
+__device__ __forceinline__ int32_t ft_wave_incl(int32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = OP::op(v, __builtin_amdgcn_update_dpp(OP::id, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+    v = OP::op(v, __builtin_amdgcn_update_dpp(OP::id, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+    v = OP::op(v, __builtin_amdgcn_update_dpp(OP::id, v, 0x114, 0xf, 0xf, false));      // row_shr:4
+    v = OP::op(v, __builtin_amdgcn_update_dpp(OP::id, v, 0x118, 0xf, 0xf, false));      // row_shr:8
+    v = OP::op(v, __builtin_amdgcn_update_dpp(OP::id, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+    v = OP::op(v, __builtin_amdgcn_update_dpp(OP::id, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
+    return v;
+#else
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(v, d); if (lane >= d) v = OP::op(v, o); }
+    return v;
+#endif
+}
+// the scan of the lanes BEFORE this one (lane 0: the identity)
+template <typename OP>
+__device__ __forceinline__ int32_t ft_wave_excl(int32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ft_wave_incl<OP>(__builtin_amdgcn_update_dpp(OP::id, v, 0x138, 0xf, 0xf, false));   // wave_shr:1
+#else
+    int32_t s = __shfl_up(v, 1);
+    if ((threadIdx.x & 63) == 0) s = OP::id;
+    return ft_wave_incl<OP>(s);
+#endif
+}
+// lane `l`'s value (l uniform over the wavefront)
+__device__ __forceinline__ int32_t ft_lane(int32_t v, int l)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readlane(v, l);
+#else
+    return __shfl(v, l);
+#endif
+}
+
 // Exclusive prefix sum of a[0..n) in place by the whole workgroup (a written before a barrier); returns the total to
 // every thread.  tmp: NT / 64 words of LDS.  Ends with a barrier.
 template <int NT, bool LDS>
@@ -280,9 +386,7 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
     if (n <= 64) {                       // one wavefront, one barrier (most of the word level's lists are this short)
         if (tid < 64) {
             const int32_t v = lane < n ? a[lane] : 0;
-            int32_t incl = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const int32_t incl = ft_wave_incl<FtAdd>(v);
             if (lane < n) a[lane] = incl - v;
             if (lane == 63) tmp[0] = incl;
         }
@@ -293,9 +397,7 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
     const int b = min(n, tid * per), e = min(n, b + per);
     int32_t sum = 0;
     for (int i = b; i < e; ++i) sum += a[i];
-    int32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    const int32_t incl = ft_wave_incl<FtAdd>(sum);
     if (lane == 63) tmp[tid >> 6] = incl;
     ft_sync<LDS>();
     int32_t base = 0, total = 0;
@@ -317,9 +419,7 @@ __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, i
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const int32_t v = lane < n ? a[k][lane] : 0;
-                int32_t incl = v;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                const int32_t incl = ft_wave_incl<FtAdd>(v);
                 if (lane < n) a[k][lane] = incl - v;
                 if (lane == 63) tmp[k] = incl;
             }
@@ -335,10 +435,7 @@ __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, i
 #pragma unroll
     for (int k = 0; k < K; ++k) { sum[k] = 0; for (int i = b; i < e; ++i) sum[k] += a[k][i]; incl[k] = sum[k]; }
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { const int32_t v = __shfl_up(incl[k], d); if (lane >= d) incl[k] += v; }
-    }
+    for (int k = 0; k < K; ++k) incl[k] = ft_wave_incl<FtAdd>(incl[k]);
     if (lane == 63) {
 #pragma unroll
         for (int k = 0; k < K; ++k) tmp[k * (NT / 64) + (tid >> 6)] = incl[k];
@@ -435,7 +532,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const cand_wid = fb + L.cand_wid, *const cand_score = fb + L.cand_score, *const cand_bp = fb + L.cand_bp,
             *const o_out = fb + L.o_out, *const o_outh = fb + L.o_outh, *const pos = fb + L.pos, *const flag = fb + L.flag,
             *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3,
-            *const woff = fb + L.woff, *const stage = fb + L.stage, *const evl = fb + L.evl;
+            *const woff = fb + L.woff, *const evl = fb + L.evl;
     unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
     uint8_t *const present = reinterpret_cast<uint8_t *>(fb + L.present);
     FtTab tb;
@@ -544,21 +641,48 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //      right-context channels: kFtWordCh | index of the word in the active list << 8 | right context.
         {
             const int n_items = R + na + n1 + nwc, lane = tid & 63;
+            // raw-score mode: the senones of the listed channels are marked (compute_sen_active, :526-564) and the minimum of
+            // their raw scores taken in the same pass
+            int32_t mn = 0x7fffffff;
+            auto mark_sen = [&](int sen) { atomicOr(&s_bits[sen >> 5], 1u << (sen & 31)); mn = min(mn, (int32_t)row[sen]); };
+            auto mark = [&](const ChView &v, int c) {
+                const int mpx = v.at(c, F::MPX);
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    int sen = v.at(c, F::SENID + k);
+                    if (mpx) { if (sen == kBadSsid) continue; sen = sseq[(size_t)sen * NE + k]; }
+                    atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
+                    mn = min(mn, (int32_t)row[sen]);
+                }
+            };
             for (int k0 = 0; k0 < n_items; k0 += NT) {
                 int k = k0 + tid, code = -1;
                 if (k < R) { if (tv.at(k, F::FRAME) == f) code = k; }
                 else if ((k -= R) < na) code = aclc[k];
                 else if ((k -= na) < n1) { if (tv.at(W1 + k, F::FRAME) == f) code = W1 + k; }
                 else if ((k -= n1) < nwc) {
-                    const int i = ft_seg_find(woff, naw, k), r = k - woff[i];
-                    if (present[wc_off[awlc[i]] + r]) code = kFtWordCh | (i << 8) | r;
+                    const int i = ft_seg_find(woff, naw, k), r = k - woff[i], slot = wc_off[awlc[i]] + r;
+                    if (present[slot]) {
+                        code = kFtWordCh | (i << 8) | r;
+                        if (raw_mode) {                          // (never multiplexed: the senone ids are the record's last quad(s))
+                            const FtQuad *q = reinterpret_cast<const FtQuad *>(wv.b + (size_t)slot * F::REC + F::SENID);
+                            const FtQuad a = q[0];
+                            mark_sen(a.x); mark_sen(a.y); mark_sen(a.z);
+                            if (NE == 5) { mark_sen(a.w); mark_sen(q[1].x); }
+                        }
+                    }
                 }
+                if (raw_mode && code >= 0 && !(code & kFtWordCh)) mark(tv, code);
                 const unsigned long long m = __ballot(code >= 0);
                 int base = 0;
                 if (lane == 0 && m) base = atomicAdd(&s_nev, __popcll(m));
-                base = __shfl(base, 0);
+                base = ft_lane(base, 0);
                 const int at = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (code >= 0 && at < L.evl_cap) evl[at] = code;
+            }
+            if (raw_mode) {
+                mn = ft_wave_incl<FtMin>(mn);                 // (lane 63: the wavefront's minimum)
+                if (lane == 63 && mn != 0x7fffffff) atomicMin(&s_nb, mn);
             }
         }
         ft_sync<SMALL>();
@@ -578,38 +702,25 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             // ---- compute_sen_active (:526-564) + acmod_flags2list (acmod.c:1223-1275) + the scorer's
             //      active-list normalisation (ptm_mgau.c:393-400) on un-normalised rows: the frame's scores
             //      are raw - min over the listed senones, bridging entries included
-            const int nwords = (p.n_sen + 31) >> 5;
-            auto mark = [&](const ChView &v, int c) {
-                const int mpx = v.at(c, F::MPX);
-#pragma unroll
-                for (int k = 0; k < NE; ++k) {
-                    int sen = v.at(c, F::SENID + k);
-                    if (mpx) { if (sen == kBadSsid) continue; sen = sseq[(size_t)sen * NE + k]; }
-                    atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
-                }
-            };
-            for (int e = tid; e < n_ev; e += NT) {
-                const int c = evl[e];
-                if (c & kFtWordCh) mark(wv, word_slot(c)); else mark(tv, c);
-            }
-            ft_sync<SMALL>();
-            FT_PROF(1);
-            int32_t mn = 0x7fffffff;
-            for (int w = tid; w < nwords; w += NT) {
-                uint32_t b = s_bits[w];
+            //      (acmod_flags2list walks the flags in senone order and bridges a gap of more than 255 with entries of its
+            //      own: last + 255, last + 510, ...  Only the first senone of a bitmap word can be that far from its
+            //      predecessor; the predecessor is the highest bit of the words before -- a running maximum across the lanes,
+            //      continued by a backward walk by the first lane of a wavefront that holds a senone)
+            const int nwords = (p.n_sen + 31) >> 5, lane = tid & 63;
+            int32_t mn = 0x7fffffff, n_listed_sen = 0;
+            for (int w0 = 0; w0 < nwords; w0 += NT) {
+                const int w = w0 + tid;
+                const uint32_t b = w < nwords ? s_bits[w] : 0u;
+                const int hi = b ? w * 32 + 31 - __clz((int)b) : -1;
+                int prev = ft_wave_excl<FtMax>(hi);          // (none: the identity, negative)
                 if (!b) continue;
-                atomicAdd(&s_nsen, __popc(b));
-                // the highest senone listed before this bitmap word (acmod_flags2list bridges gaps > 255 from it)
-                int prev = -1;
-                for (int q = w - 1; q >= 0; --q) { const uint32_t pb = s_bits[q]; if (pb) { prev = q * 32 + 31 - __clz((int)pb); break; } }
-                while (b) {
-                    const int sen = w * 32 + __ffs((int)b) - 1;
-                    b &= b - 1;
-                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; mn = min(mn, (int32_t)row[last]); }
-                    mn = min(mn, (int32_t)row[sen]);
-                    prev = sen;
-                }
+                n_listed_sen += __popc(b);
+                if (prev < 0)
+                    for (int q = w - lane - 1; q >= 0; --q) { const uint32_t pb = s_bits[q]; if (pb) { prev = q * 32 + 31 - __clz((int)pb); break; } }
+                const int sen = w * 32 + __ffs((int)b) - 1;
+                for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; mn = min(mn, (int32_t)row[last]); }
             }
+            if (n_listed_sen) atomicAdd(&s_nsen, n_listed_sen);
             if (mn != 0x7fffffff) atomicMin(&s_nb, mn);
             ft_sync<SMALL>();
             nb = s_nb;
@@ -623,15 +734,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             for (int e = tid; e < n_ev; e += NT) {
                 const int c = evl[e];
                 if (c & kFtWordCh) {
-                    const int32_t sc = ch_eval<NE>(wv, word_slot(c), sr, tpall, sseq);
+                    const int32_t sc = ch_eval_rec<NE>(wv.b + (size_t)word_slot(c) * F::REC, sr, tpall, sseq);
                     b_all = max(b_all, sc); b_word = max(b_word, sc);
                 }
                 else {
-                    const int32_t sc = ch_eval<NE>(tv, c, sr, tpall, sseq);
+                    const int32_t sc = SMALL ? ch_eval<NE>(tv, c, sr, tpall, sseq) : ch_eval_rec<NE>(tv.b + (size_t)c * F::REC, sr, tpall, sseq);
                     if (c < W1) b_all = max(b_all, sc);
                     else if (w1_wid[c - W1] != p.finishwid) { b_all = max(b_all, sc); b_word = max(b_word, sc); }   // (:688-694: </s> never sets the best score)
                 }
             }
+            FT_PROF(18);
             if (b_all > kW) atomicMax(&s_red[0], b_all);
             if (b_word > kW) atomicMax(&s_red[2], b_word);
             if (raw_mode) {                                  // the bitmap is free again: cleared for the next frame
@@ -640,6 +752,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
         }
         __syncthreads();                                     // (device memory: the right-context channels' records, tb.idx[f])
+        FT_PROF(19);
         // small layout: the next frame's score row and penalties start their way from HBM now -- the barriers from here to
         // the language-model look-ups wait for LDS only, so the loads stay in flight across them; they are written to LDS
         // at the end of the frame (this frame's row has been read: evaluation is over)
@@ -660,27 +773,37 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             s_sc[2] = p.beam;                                   // dynamic beam (:1133-1181)
             s_nb = 0x7fffffff;
         }
-        for (int i = tid; i < 256; i += NT) s_bins[i] = 0;
         ft_sync<SMALL>();
         FT_PROF(3);
         const int32_t best_score = s_sc[0];
+        // dynamic beam (ngram_search_fwdtree.c:1133-1181): the reference compares the utterance's CUMULATIVE evaluation count
+        // with maxhmmpf, so from some frame on the histogram is consulted every frame.  It counts every root and every
+        // listed node; when there are no more than maxhmmpf of them the running sum never passes it and the loop leaves
+        // i == 256 -- known without building the histogram.  Otherwise: 256 bins, one prefix sum, the first bin whose
+        // running sum passes maxhmmpf.
+        int32_t dyn_beam = p.beam;
         if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
             const int32_t bw = -p.beam / 256;
-            for (int i = tid; i < R + n_acl_cur; i += NT) {
-                const int c = i < R ? i : aclc[i - R];
-                int32_t b = (best_score - tv.at(c, F::BEST)) / bw;
-                if (b >= 256) b = 255;
-                atomicAdd(&s_bins[b], 1);
+            if (R + na <= p.maxhmmpf) dyn_beam = -(256 * bw);
+            else {
+                for (int i = tid; i < 257; i += NT) s_bins[i] = 0;
+                if (tid == 0) s_bins[257] = 256;
+                ft_sync<true>();
+                for (int i = tid; i < R + na; i += NT) {
+                    const int c = i < R ? i : aclc[i - R];
+                    int32_t b = (best_score - tv.at(c, F::BEST)) / bw;
+                    if (b >= 256) b = 255;
+                    atomicAdd(&s_bins[b], 1);
+                }
+                ft_sync<true>();
+                ft_block_scan<NT, true>(s_bins, 257, s_scan);              // s_bins[i + 1] = bins[0] + .. + bins[i]
+                for (int i = tid; i < 256; i += NT) if (s_bins[i + 1] > p.maxhmmpf) atomicMin(&s_bins[257], i);
+                ft_sync<true>();
+                dyn_beam = -(s_bins[257] * bw);
+                ft_sync<true>();                                           // (s_bins is reused by the word transitions)
             }
-            ft_sync<SMALL>();
-            if (tid == 0) {
-                int i, nh = 0;
-                for (i = 0; i < 256; ++i) { nh += s_bins[i]; if (nh > p.maxhmmpf) break; }
-                s_sc[2] = -(i * bw);
-            }
-            ft_sync<SMALL>();
         }
-        const int32_t thresh = best_score + s_sc[2];
+        const int32_t thresh = best_score + dyn_beam;
         const int32_t npt = best_score + p.pbeam, lpt = best_score + p.lpbeam;
 
         // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation.  Work proportional to the active
@@ -726,6 +849,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 decide(c);
             }
         }
+        FT_PROF(28);
         ft_sync<SMALL>();
         FT_PROF(5);
         for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
@@ -809,6 +933,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (tid == 0) cnt[n_cand] = 0;
             ft_sync<SMALL>();
             const int n_pair = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
+            FT_PROF(29);
             for (int j = tid; j < n_pair; j += NT) {
                 const int i = ft_seg_find(cnt, n_cand, j), bp = cnt2[i] + (j - cnt[i]), w = cand_wid[i];
                 if (!BPC(tb, B_VALID, bp)) continue;
@@ -817,6 +942,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 atomicMax(&ckey[i], ft_key(dscr, bp));
             }
             ft_sync<SMALL>();
+            FT_PROF(30);
             int32_t bestscore = kW;
             for (int i = tid; i < n_cand; i += NT) {
                 const int w = cand_wid[i];
@@ -851,12 +977,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int n_ent = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
                 for (int j = tid; j < n_ent; j += NT) {
                     const int i = ft_seg_find(cnt, n_cand, j), w = cand_wid[i], r = j - cnt[i], slot = wc_off[w] + r;
-                    if (!present[slot]) {                       // ngram_search_alloc_all_rc (ngram_search.c:583-633)
+                    int32_t *const rec = wv.b + (size_t)slot * F::REC;
+                    if (!present[slot]) {
+                        // ngram_search_alloc_all_rc (ngram_search.c:583-633), then hmm_enter into the cleared channel (its frame
+                        // is -1: the test below always passes): the whole record is written at once
                         const int last = d_last[w], last2 = d_last2[w];
-                        ch_init<NE>(wv, slot, 0, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq);
+                        ch_init_enter_rec<NE>(rec, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq, cand_score[i], cand_bp[i], nf);
                         present[slot] = 1;
+                        cnt2[i] = 1;
                     }
-                    if (wv.at(slot, F::FRAME) < f || cand_score[i] > wv.at(slot, F::SCORE)) {
+                    else if (rec[F::FRAME] < f || cand_score[i] > rec[F::SCORE]) {
                         ch_enter<NE>(wv, slot, cand_score[i], cand_bp[i], nf);
                         cnt2[i] = 1;
                     }
@@ -888,12 +1018,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int c = evl[e];
                 if (!(c & kFtWordCh)) continue;
                 const int i = (c >> 8) & 0x3fffff, slot = word_slot(c);
-                if (wv.at(slot, F::BEST) > lpth) {
+                const FtQuad q = ch_summary<NE>(wv.b + (size_t)slot * F::REC);      // out, out history, best, frame
+                if (q.z > lpth) {
                     wv.at(slot, F::FRAME) = nf;
                     atomicAdd(&w_k[i], 1);
-                    if (wv.at(slot, F::OUT) > nwt) atomicOr(&w_exit[i], 1);
+                    if (q.x > nwt) atomicOr(&w_exit[i], 1);
                 }
-                else if (wv.at(slot, F::FRAME) != nf) present[slot] = 0;
+                else if (q.w != nf) present[slot] = 0;
             }
             __syncthreads();                                     // (device memory is exchanged here)
             FT_PROF(11);
@@ -926,62 +1057,54 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             FT_PROF(12);
             if (!s_sc[6]) {
                 // ---- the exits' back-pointers (ngram_search_save_bp, ngram_search.c:376-498).  An exiting word owns one
-                //      new entry and wc_off-many score-stack slots; its exiting channels are merged into the entry in
-                //      right-context order (first creates, a better one updates).  Two steps: one work-item per (exiting
-                //      word, right context) writes the score stack and stages what the merge needs -- out score, history,
-                //      the language-model state of that history -- then one work-item per word merges from the staged
-                //      items, no dependent device-memory load in its loop.
-                auto exit_item = [&](int slot, int32_t (&it)[4]) {
-                    it[0] = kW; it[1] = -1; it[2] = -1; it[3] = -1;
-                    if (present[slot] && wv.at(slot, F::FRAME) == nf && wv.at(slot, F::BEST) > lpth && wv.at(slot, F::OUT) > nwt) {
-                        const int32_t path = wv.at(slot, F::OUTH);
-                        it[0] = wv.at(slot, F::OUT); it[1] = path;
-                        if (path != -1) { it[2] = BPC(tb, B_REAL, path); it[3] = BPC(tb, B_PREAL, path); }
-                    }
-                };
-                const int scap = L.stage_cap;
-                for (int j = tid; j < n_bss; j += NT) {
-                    const int i = ft_seg_find(w_bss, naw, j), w = awlc[i], slot = wc_off[w] + (j - w_bss[i]);
-                    int32_t it[4];
-                    exit_item(slot, it);
-                    tb.bss[bss_head + j] = it[0];                // (no exit: WORST_SCORE, as the creation fills it)
-                    if (j < scap) { stage[4 * j] = it[0]; stage[4 * j + 1] = it[1]; stage[4 * j + 2] = it[2]; stage[4 * j + 3] = it[3]; }
-                }
-                ft_sync<SMALL>();
-                FT_PROF(13);
-                for (int i = tid; i < naw; i += NT) {
-                    if (!w_exit[i]) continue;
-                    const int w = awlc[i], j0 = w_bss[i], nrc = w_bss[i + 1] - j0, bpi = bpidx + w_bp[i];
-                    bool created = false;
-                    int32_t S = kW, P = -1, p_real = -1, p_preal = -1, rw_real = -1, rw_preal = -1;
-                    for (int r = 0; r < nrc; ++r) {
-                        int32_t it[4];
-                        if (j0 + r < scap) { it[0] = stage[4 * (j0 + r)]; it[1] = stage[4 * (j0 + r) + 1]; it[2] = stage[4 * (j0 + r) + 2]; it[3] = stage[4 * (j0 + r) + 3]; }
-                        else exit_item(wc_off[w] + r, it);
-                        // an exit has out > nwt > WORST_SCORE; a staged non-exit carries WORST_SCORE
-                        if (!(it[0] > kW)) continue;
-                        if (!created) { created = true; S = it[0]; P = it[1]; p_real = rw_real = it[2]; p_preal = rw_preal = it[3]; }
-                        else if (S < it[0]) {
-                            if (P != it[1]) {
-                                // "if (bplh != newlh) set_real_wid(bp)" runs with the OLD path still in the entry (:420-436):
-                                // the entry's real word ids are then those its previous path gives
-                                if (p_preal != it[3] || p_real != it[2]) { rw_real = p_real; rw_preal = p_preal; }
-                                P = it[1]; p_real = it[2]; p_preal = it[3];
-                            }
-                            S = it[0];
+                //      new entry and wc_off-many score-stack slots; the reference merges its exiting channels into the entry
+                //      in right-context order (the first creates it, a better one updates it).  One wavefront per exiting
+                //      word, one lane per right context (n_ci <= 64): a lane reads its channel, writes its score-stack slot
+                //      and fetches the language-model state of its history; the merge is a running maximum across lanes.
+                //        entry score / path = those of the last lane that raised the running maximum (strictly);
+                //        real word ids      = set_real_wid's, which the reference runs BEFORE it stores a new path
+                //                             (:420-436): the ids of the path the entry held before the last update that
+                //                             changed them -- or the creating path's when no update did.
+                const int lane = tid & 63;
+                for (int e = tid >> 6; e < n_exit; e += NT / 64) {
+                    const int i = ft_seg_find(w_bp, naw, e), w = awlc[i], j0 = w_bss[i], nrc = w_bss[i + 1] - j0, bpi = bpidx + e;
+                    int32_t it[4] = { kW, -1, -1, -1 };          // out score, history, its real / prev_real wid
+                    if (lane < nrc) {
+                        const int slot = wc_off[w] + lane;
+                        const FtQuad q = ch_summary<NE>(wv.b + (size_t)slot * F::REC);      // out, out history, best, frame
+                        if (present[slot] && q.w == nf && q.z > lpth && q.x > nwt) {
+                            const int32_t path = q.y;
+                            it[0] = q.x; it[1] = path;
+                            if (path != -1) { it[2] = BPC(tb, B_REAL, path); it[3] = BPC(tb, B_PREAL, path); }
                         }
+                        tb.bss[bss_head + j0 + lane] = it[0];    // (no exit: WORST_SCORE, as the creation fills it)
                     }
-                    if (!created) continue;                      // (cannot happen: w_exit says one channel exits)
-                    word_lat_idx[w] = bpi;
-                    BPC(tb, B_WID, bpi) = w; BPC(tb, B_FRAME, bpi) = f; BPC(tb, B_BP, bpi) = P; BPC(tb, B_SCORE, bpi) = S;
-                    BPC(tb, B_SIDX, bpi) = bss_head + j0; BPC(tb, B_VALID, bpi) = 1;
-                    BPC(tb, B_LAST, bpi) = d_last[w]; BPC(tb, B_LAST2, bpi) = d_last2[w];
-                    // set_real_wid (:341-372) from the path it was last evaluated with (real ids are >= 0: -1 = no path)
-                    if (d_filler[w]) {
-                        BPC(tb, B_REAL, bpi) = rw_real != -1 ? rw_real : d_base[w];
-                        BPC(tb, B_PREAL, bpi) = rw_real != -1 ? rw_preal : -1;
+                    // an exit has out > nwt > WORST_SCORE
+                    const int32_t pm = ft_wave_excl<FtMax>(it[0]);     // maximum over the lanes before this one (none: below WORST_SCORE)
+                    const bool rec = it[0] > kW && it[0] > pm;   // this lane creates or updates the entry
+                    const unsigned long long m = __ballot(rec);
+                    if (m == 0) continue;                        // (cannot happen: w_exit says one channel exits)
+                    const int first = __ffsll(m) - 1, last = 63 - __clzll((long long)m);
+                    const unsigned long long below = m & ((1ull << lane) - 1ull);
+                    const int prev = below ? 63 - __clzll((long long)below) : first;
+                    const int32_t pr = __shfl(it[2], prev), pp = __shfl(it[3], prev);      // (prev differs per lane)
+                    const unsigned long long dm = __ballot(rec && below != 0 && (pr != it[2] || pp != it[3]));
+                    int src = first;
+                    if (dm) src = 63 - __clzll((long long)(m & ((1ull << (63 - __clzll((long long)dm))) - 1ull)));
+                    const int32_t S = ft_lane(it[0], last), P = ft_lane(it[1], last);
+                    const int32_t rw_real = ft_lane(it[2], src), rw_preal = ft_lane(it[3], src);
+                    if (lane == 0) {
+                        word_lat_idx[w] = bpi;
+                        BPC(tb, B_WID, bpi) = w; BPC(tb, B_FRAME, bpi) = f; BPC(tb, B_BP, bpi) = P; BPC(tb, B_SCORE, bpi) = S;
+                        BPC(tb, B_SIDX, bpi) = bss_head + j0; BPC(tb, B_VALID, bpi) = 1;
+                        BPC(tb, B_LAST, bpi) = d_last[w]; BPC(tb, B_LAST2, bpi) = d_last2[w];
+                        // set_real_wid (:341-372) from the path it was last evaluated with (real ids are >= 0: -1 = no path)
+                        if (d_filler[w]) {
+                            BPC(tb, B_REAL, bpi) = rw_real != -1 ? rw_real : d_base[w];
+                            BPC(tb, B_PREAL, bpi) = rw_real != -1 ? rw_preal : -1;
+                        }
+                        else { BPC(tb, B_REAL, bpi) = d_base[w]; BPC(tb, B_PREAL, bpi) = rw_real; }
                     }
-                    else { BPC(tb, B_REAL, bpi) = d_base[w]; BPC(tb, B_PREAL, bpi) = rw_real; }
                 }
             }
             __syncthreads();                                     // (device memory is exchanged here)
@@ -1017,11 +1140,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 int32_t *const arr[2] = { f_new, f_rc };
                 ft_block_scan_k<NT, 2, SMALL>(arr, n1 + 1, s_scan, tot);
             }
+            FT_PROF(20);
             for (int i = tid; i < n1; i += NT)
                 if (f_ex[i]) {
                     int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
                     if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
                 }
+            FT_PROF(21);
             __syncthreads();                                     // (device memory is exchanged here)
             if (tid == 0) { s_sc[3] = bpidx0 + tot[0]; s_sc[4] = bss0 + tot[1]; }
         }
@@ -1057,6 +1182,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) s_red[6] = 0;
         __syncthreads();                                     // (device memory is exchanged here)
         const int n_awl_nxt = s_red[5];
+        FT_PROF(23);
         if (s_sc[6]) break;
         const int bp1 = s_sc[3], nbp = bp1 - bp0;
         for (int j = tid; j < nbp * n_ci; j += NT) {
@@ -1075,6 +1201,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (ns != kW) ns += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
             atomicMax(&ckey[i], ft_key(ns, bp));
         }
+        FT_PROF(24);
         ft_sync<SMALL>();
         FT_PROF(16);
         for (int rc = tid; rc < n_ci; rc += NT) {
@@ -1084,6 +1211,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             brc_score[rc] = none ? kW : ft_key_score(k); brc_path[rc] = path; brc_lc[rc] = none ? 0 : BPC(tb, B_LAST, path);
         }
         ft_sync<SMALL>();
+        FT_PROF(25);
         if (s_red[6] > 0) {
             for (int i = tid; i < R; i += NT) {          // tree roots (:1306-1325)
                 const int ci = node_ci[i];
@@ -1120,6 +1248,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
         }
         ft_sync<SMALL>();
+        FT_PROF(26);
         // ---- deactivate_channels (:1429-1450)
         for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_clear<NE>(tv, i);
         for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_clear<NE>(tv, W1 + i);
@@ -1127,6 +1256,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             step[f * 4] = s_sc[0]; step[f * 4 + 1] = s_sc[1]; step[f * 4 + 2] = s_sc[3]; step[f * 4 + 3] = n_listed;
             ++s_sc[7];
         }
+        FT_PROF(27);
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
         if (SMALL && nf < T) {                               // the next frame's score row and penalties take their place
             if (ROWL) {
@@ -1239,20 +1369,14 @@ static bool ft_layout(FtDev &d, bool small)
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
-        // what is left of the pool stages the frame's exits
-        const int64_t left = ((int64_t)kFtLdsWords - o) / 4;
-        if (left < kFtMinStage || d.n_sen > kFtMaxSen) return false;
-        L.stage_cap = (int32_t)std::min<int64_t>(left, 2048);
+        // what is left of the pool holds the frame's evaluation list
+        const int64_t left = (int64_t)kFtLdsWords - o;
+        if (left < kFtMinEvl || d.n_sen > kFtMaxSen) return false;
+        L.evl_cap = (int32_t)std::min<int64_t>(left & ~(int64_t)3, 8192);
     }
     else
-        L.stage_cap = (int32_t)std::min<int64_t>(std::max<int64_t>(d.TOT, 64), 8192);
-    L.stage = take(4 * (int64_t)L.stage_cap);
-    if (small) { L.evl = L.stage; L.evl_cap = 4 * L.stage_cap; }       // (the list is dead before the exits are staged)
-    else {
-        const int64_t n = (int64_t)d.R + d.N + d.n1 + d.TOT + 64;
-        L.evl_cap = (int32_t)std::min<int64_t>(n, 0x7ffffff0);
-        L.evl = take(L.evl_cap);
-    }
+        L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
+    L.evl = take(L.evl_cap);
     if (o > 0x7fffff00) return false;
     L.total = (int32_t)o;
     d.small = small ? 1 : 0;
@@ -1432,20 +1556,25 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     PSGPU_HIP(hipGetLastError());
 #ifdef PSGPU_FT_PROFILE
     {   // a profiling build: wait, average the per-phase cycle counts over the utterances, print them per frame
-        static const char *const names[18] = { "top: active words' channel ranges", "senone bitmap", "normaliser", "evaluate", "prune: snapshot", "prune: decide",
-            "next active list", "last-phone candidates", "predecessor search (LM)", "entering", "active words", "prune_word_chan",
-            "positions (scans)", "exits: stage", "exits: merge", "single-phone words", "word_transition: pairs", "word_transition: enter + deactivate" };
+        // (an interval ends at its marker: "x: to barrier" = work-item 0's own work, the next interval = its wait at the barrier + the rest)
+        static const char *const names[32] = { "top: lists, senone marks", "-", "normaliser", "evaluate: after barrier (prefetch issue, beam)", "prune: snapshot", "prune: decide, barrier",
+            "next active list", "last-phone candidates", "predecessor search: decode + max", "entering", "active words", "prune_word_chan",
+            "positions (scans)", "-", "exits", "single-phone: barrier + counters", "word_transition: pairs, barrier", "frame end: row to LDS",
+            "evaluate: loop", "evaluate: barrier", "single-phone: flags + scan", "single-phone: save", "-", "word_transition: init + barrier",
+            "word_transition: pair loops", "word_transition: decode keys", "word_transition: enter", "deactivate + step", "prune: decide loop",
+            "predecessor search: exit scores + scan", "predecessor search: pairs", "-" };
         std::vector<long long> h((size_t)32 * n_utt);
         std::vector<int32_t> r((size_t)8 * n_utt);
         PSGPU_HIP(hipStreamSynchronize(st));
         PSGPU_HIP(hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
         PSGPU_HIP(hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost));
         hipFree(bf.prof);
-        double frames = 0, tot = 0, acc[18] = {};
-        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 18; ++i) acc[i] += (double)h[(size_t)u * 32 + i]; }
-        for (int i = 0; i < 18; ++i) tot += acc[i];
+        double frames = 0, tot = 0, acc[32] = {};
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 32; ++i) acc[i] += (double)h[(size_t)u * 32 + i]; }
+        for (int i = 0; i < 32; ++i) tot += acc[i];
         fprintf(stderr, "fwdtree_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
-        for (int i = 0; i < 18; ++i) fprintf(stderr, "  %2d %-38s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
+        static const int order[] = { 0, 2, 18, 19, 3, 4, 28, 5, 6, 7, 29, 30, 8, 9, 10, 11, 12, 14, 20, 21, 15, 23, 24, 16, 25, 26, 27, 17 };
+        for (int i : order) fprintf(stderr, "  %2d %-48s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
     }
 #endif
     return PSGPU_OK;

@@ -76,6 +76,8 @@ inline unsigned long long __ballot(int p) { return hipsim::ballot_wave(p != 0); 
 // ---- integer / float intrinsics ------------------------------------------------------------------
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

@@ -28,11 +28,19 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
+    def stale():
+        return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+    if stale():
+        import fcntl
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-Wall", "-Wno-unused-variable", "-Wno-unknown-pragmas", "-Wno-int-in-bool-context",
-                               "-I" + SIM_DIR, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + SOURCES)
+        with open(LIB + ".lock", "w") as lk:            # parallel test workers: one builds, the others wait
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                tmp = "%s.%d.tmp" % (LIB, os.getpid())
+                subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-ffp-contract=off",
+                                       "-Wall", "-Wno-unused-variable", "-Wno-unknown-pragmas", "-Wno-int-in-bool-context",
+                                       "-I" + SIM_DIR, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", tmp] + SOURCES)
+                os.replace(tmp, LIB)
     L = C.CDLL(LIB)
     L.psgpu_last_error.restype = C.c_char_p
     _lib = L

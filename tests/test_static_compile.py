@@ -44,7 +44,8 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             assert v["Occupancy"] >= 2 and v["Spill"] == 0 and v["VGPRs"] <= 256, (n, v)
             assert 56 * 1024 <= v["LDS"] <= 64 * 1024, (n, v)
         else:
-            assert v["Occupancy"] >= 3 and v["Spill"] == 0, (n, v)
+            # slab layout, 256 work-items: at least two workgroups per CU (512 utterances = one round on 256 CUs)
+            assert v["Occupancy"] >= 2 and v["Spill"] == 0, (n, v)
         assert v["LDS"] <= 64 * 1024, (n, v)
     # every pointer of the kernel is either derived from its LDS pool or declared global (psgpu_as_global): no access may be
     # left generic (flat_*: waits on both memory counters), and the 256-work-item forms keep nothing in scratch memory
