@@ -478,8 +478,17 @@ __device__ __forceinline__ int ft_key_bp(unsigned long long k) { return 0x7fffff
 // per-phase cycle counts of work-item 0 (a profiling build only: -DPSGPU_FT_PROFILE; the product kernel has none of it)
 #ifdef PSGPU_FT_PROFILE
 #define FT_PROF(i) do { if (tid == 0) { const long long t_ = clock64(); s_prof[i] += t_ - s_last; s_last = t_; } } while (0)
+// distribution of the evaluation's duration over the frames: [44] frames over 16k cycles, [45] their cycles, [46] the longest,
+// [47] evaluations in the frames over 16k
+#define FT_PROFD0() do { if (tid == 0) s_d0 = clock64(); } while (0)
+#define FT_PROFD1(n) do { if (tid == 0) { const long long d_ = clock64() - s_d0; if (d_ > 16000) { s_prof[44] += 1; s_prof[45] += d_; s_prof[47] += (n); } if (d_ > s_prof[46]) s_prof[46] = d_; } } while (0)
+// the other wavefronts' view of one phase: k = 0 marks its start, k = 1, 2 end intervals (slots 32 + 4 * wavefront + k)
+#define FT_PROFW(k) do { if ((tid & 63) == 0 && tid > 0 && tid < 256) { const long long t_ = clock64(); if (k) s_prof[32 + 4 * (tid >> 6) + (k)] += t_ - s_lastw[tid >> 6]; s_lastw[tid >> 6] = t_; } } while (0)
 #else
 #define FT_PROF(i) do { } while (0)
+#define FT_PROFW(k) do { } while (0)
+#define FT_PROFD0() do { } while (0)
+#define FT_PROFD1(n) do { } while (0)
 #endif
 
 // measuring builds: PSGPU_FT_ROW_DIRECT reads the frame's scores straight from device memory (no copy through LDS, no
@@ -513,8 +522,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     __shared__ int32_t s_nev;            // length of the frame's evaluation list
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
-    __shared__ long long s_prof[32], s_last;
-    if (tid == 0) { for (int i = 0; i < 32; ++i) s_prof[i] = 0; s_last = clock64(); }
+    __shared__ long long s_prof[48], s_last, s_lastw[4], s_d0;
+    if (tid == 0) { for (int i = 0; i < 48; ++i) s_prof[i] = 0; s_last = clock64(); }
 #endif
     const int N = p.N, R = p.R, n1 = p.n1, n_ci = p.n_ci;
     const FtLay &L = p.lay;
@@ -720,8 +729,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int sen = w * 32 + __ffs((int)b) - 1;
                 for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; mn = min(mn, (int32_t)row[last]); }
             }
-            if (n_listed_sen) atomicAdd(&s_nsen, n_listed_sen);
-            if (mn != 0x7fffffff) atomicMin(&s_nb, mn);
+            n_listed_sen = ft_wave_incl<FtAdd>(n_listed_sen); mn = ft_wave_incl<FtMin>(mn);     // (lane 63: the wavefront's)
+            if (lane == 63 && n_listed_sen) atomicAdd(&s_nsen, n_listed_sen);
+            if (lane == 63 && mn != 0x7fffffff) atomicMin(&s_nb, mn);
             ft_sync<SMALL>();
             nb = s_nb;
             FT_PROF(2);
@@ -731,6 +741,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         {
             const SenRowNorm sr = { row, nb };
             int32_t b_all = kW, b_word = kW;
+            FT_PROFW(0);
+            FT_PROFD0();
             for (int e = tid; e < n_ev; e += NT) {
                 const int c = evl[e];
                 if (c & kFtWordCh) {
@@ -744,15 +756,27 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
             }
             FT_PROF(18);
-            if (b_all > kW) atomicMax(&s_red[0], b_all);
-            if (b_word > kW) atomicMax(&s_red[2], b_word);
+            FT_PROFW(1);
+            // (one atomic per wavefront: a per-lane atomicMax on one address is compiled to a serial loop over the lanes)
+            b_all = ft_wave_incl<FtMax>(b_all); b_word = ft_wave_incl<FtMax>(b_word);
+            if ((tid & 63) == 63) {
+                if (b_all > kW) atomicMax(&s_red[0], b_all);
+                if (b_word > kW) atomicMax(&s_red[2], b_word);
+            }
             if (raw_mode) {                                  // the bitmap is free again: cleared for the next frame
                 const int nwords = (p.n_sen + 31) >> 5;
                 for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
             }
         }
-        __syncthreads();                                     // (device memory: the right-context channels' records, tb.idx[f])
+        // (LDS only.  The evaluation's stores to the right-context channels' records are still on their way -- the records of
+        //  512 utterances do not fit the L2, a store is acknowledged microseconds later -- and nothing needs them yet: the
+        //  next reader of a record is the work-item that wrote it (prune_word_chan walks the evaluation list as the evaluation
+        //  did), the next writer from another work-item is last_phone_transition, behind the full barrier that ends the
+        //  candidates' step.)
+        ft_sync<SMALL>();
         FT_PROF(19);
+        FT_PROFW(2);
+        FT_PROFD1(n_ev);
         // small layout: the next frame's score row and penalties start their way from HBM now -- the barriers from here to
         // the language-model look-ups wait for LDS only, so the loads stay in flight across them; they are written to LDS
         // at the end of the frame (this frame's row has been read: evaluation is over)
@@ -797,7 +821,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
                 ft_sync<true>();
                 ft_block_scan<NT, true>(s_bins, 257, s_scan);              // s_bins[i + 1] = bins[0] + .. + bins[i]
-                for (int i = tid; i < 256; i += NT) if (s_bins[i + 1] > p.maxhmmpf) atomicMin(&s_bins[257], i);
+                {
+                    int32_t first = (tid < 256 && s_bins[tid + 1] > p.maxhmmpf) ? tid : 256;
+                    first = ft_wave_incl<FtMin>(first);
+                    if ((tid & 63) == 63 && first < 256) atomicMin(&s_bins[257], first);
+                }
                 ft_sync<true>();
                 dyn_beam = -(s_bins[257] * bw);
                 ft_sync<true>();                                           // (s_bins is reused by the word transitions)
@@ -901,7 +929,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         cand_wid[o] = w; cand_score[o] = news - p.nwpen; cand_bp[o] = o_outh[node]; ++o;
                     }
         }
-        ft_sync<SMALL>();
+        __syncthreads();                                     // (device memory: the evaluation's records, tb.idx[f] -- see above)
         FT_PROF(7);
 
         // ---- word level: last_phone_transition (:884-1035).  Candidates of one frame name distinct words (a word has
@@ -957,7 +985,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 cand_bp[i] = lt_bp[w];
                 bestscore = max(bestscore, score);
             }
-            if (bestscore > kW) atomicMax(&s_sc[1], bestscore);
+            bestscore = ft_wave_incl<FtMax>(bestscore);
+            if ((tid & 63) == 63 && bestscore > kW) atomicMax(&s_sc[1], bestscore);
         }
         ft_sync<SMALL>();
         FT_PROF(8);
@@ -1026,7 +1055,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
                 else if (q.w != nf) present[slot] = 0;
             }
-            __syncthreads();                                     // (device memory is exchanged here)
+            ft_sync<SMALL>();                                    // (its store -- the frame stamp -- is read by nobody this frame)
             FT_PROF(11);
             for (int i = tid; i <= naw; i += NT) {
                 // inputs of the three prefix sums below: next active word list, back-pointers, score-stack entries
@@ -1072,7 +1101,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (lane < nrc) {
                         const int slot = wc_off[w] + lane;
                         const FtQuad q = ch_summary<NE>(wv.b + (size_t)slot * F::REC);      // out, out history, best, frame
-                        if (present[slot] && q.w == nf && q.z > lpth && q.x > nwt) {
+                        if (present[slot] && q.z > lpth && q.x > nwt) {     // (best > lpth: prune_word_chan has stamped it)
                             const int32_t path = q.y;
                             it[0] = q.x; it[1] = path;
                             if (path != -1) { it[2] = BPC(tb, B_REAL, path); it[3] = BPC(tb, B_PREAL, path); }
@@ -1107,7 +1136,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     }
                 }
             }
-            __syncthreads();                                     // (device memory is exchanged here)
+            ft_sync<SMALL>();                                    // (the new entries are first read behind word_transition's full barrier)
             FT_PROF(14);
         }
         if (!s_sc[6]) {
@@ -1147,7 +1176,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
                 }
             FT_PROF(21);
-            __syncthreads();                                     // (device memory is exchanged here)
+            if (p.maxwpf == -1 || p.maxwpf == p.n_w) ft_sync<SMALL>(); else __syncthreads();     // (bptable_maxwpf reads the frame's entries)
             if (tid == 0) { s_sc[3] = bpidx0 + tot[0]; s_sc[4] = bss0 + tot[1]; }
         }
         if (tid == 0 && !s_sc[6]) {
@@ -1270,7 +1299,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         FT_PROF(17);
     }
 #ifdef PSGPU_FT_PROFILE
-    if (tid == 0 && bf.prof) for (int i = 0; i < 32; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 32 + i] = s_prof[i];
+    if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
@@ -1534,7 +1563,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     bf.w1_out = w1_ssid_out_dev;
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
-    PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 32 * (size_t)n_utt));
+    PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));
 #endif
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
@@ -1563,17 +1592,27 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
             "evaluate: loop", "evaluate: barrier", "single-phone: flags + scan", "single-phone: save", "-", "word_transition: init + barrier",
             "word_transition: pair loops", "word_transition: decode keys", "word_transition: enter", "deactivate + step", "prune: decide loop",
             "predecessor search: exit scores + scan", "predecessor search: pairs", "-" };
-        std::vector<long long> h((size_t)32 * n_utt);
+        std::vector<long long> h((size_t)48 * n_utt);
         std::vector<int32_t> r((size_t)8 * n_utt);
         PSGPU_HIP(hipStreamSynchronize(st));
         PSGPU_HIP(hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
         PSGPU_HIP(hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost));
         hipFree(bf.prof);
         double frames = 0, tot = 0, acc[32] = {};
-        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 32; ++i) acc[i] += (double)h[(size_t)u * 32 + i]; }
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 32; ++i) acc[i] += (double)h[(size_t)u * 48 + i]; }
         for (int i = 0; i < 32; ++i) tot += acc[i];
         fprintf(stderr, "fwdtree_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
         static const int order[] = { 0, 2, 18, 19, 3, 4, 28, 5, 6, 7, 29, 30, 8, 9, 10, 11, 12, 14, 20, 21, 15, 23, 24, 16, 25, 26, 27, 17 };
+        for (int w = 1; w < 4; ++w) {
+            double a1 = 0, a2 = 0;
+            for (int u = 0; u < n_utt; ++u) { a1 += (double)h[(size_t)u * 48 + 32 + 4 * w + 1]; a2 += (double)h[(size_t)u * 48 + 32 + 4 * w + 2]; }
+            fprintf(stderr, "  wavefront %d: evaluate loop %9.0f, its barrier %9.0f cycles/frame\n", w, a1 / (frames > 0 ? frames : 1), a2 / (frames > 0 ? frames : 1));
+        }
+        {
+            double n16 = 0, c16 = 0, mx = 0, e16 = 0;
+            for (int u = 0; u < n_utt; ++u) { n16 += (double)h[(size_t)u * 48 + 44]; c16 += (double)h[(size_t)u * 48 + 45]; mx = std::max(mx, (double)h[(size_t)u * 48 + 46]); e16 += (double)h[(size_t)u * 48 + 47]; }
+            fprintf(stderr, "  evaluation over 16k cycles: %.0f of %.0f frames, %.0f cycles and %.1f evaluations each on average; longest %.0f\n", n16, frames, c16 / (n16 > 0 ? n16 : 1), e16 / (n16 > 0 ? n16 : 1), mx);
+        }
         for (int i : order) fprintf(stderr, "  %2d %-48s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
     }
 #endif
