@@ -414,7 +414,11 @@ int psgpu_ms_score_batch(psgpu_ms_model_t *m, const float *feats, int32_t total_
  * 64-byte line.  senid[] holds senone ids for a non-multiplex HMM and
  * per-state ssids (BAD_SSID 0xffff = state not yet entered) for a multiplex
  * one, exactly as hmm_t.senid; tmatid_mpx = tmatid | PSGPU_HMM_MPX for
- * multiplex HMMs.  Unused states of a 3-state record are ignored. */
+ * multiplex HMMs.  Unused states of a record are ignored.  n_emit_state is
+ * 1..5 (HMM_MAX_NSTATE): 3 and 5 run the hard-wired left-to-right forms
+ * (hmm.c:222-707), 1, 2 and 4 the any-topology form hmm_vit_eval_anytopo
+ * (hmm.c:710-784) -- the dispatch of hmm_vit_eval (hmm.c:786-805).  The phone
+ * loop and the searches are built for 3 and 5. */
 #define PSGPU_HMM_MPX 0x8000u
 
 typedef struct psgpu_hmm_rec_s {
@@ -546,6 +550,23 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
                              int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
                              int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
                              int32_t pl_window, int32_t *w1_ssid_out_dev, void *stream);
+/* The same with a decoder session's carry-over.  The reference's permanent channels -- the lexicon tree's roots and the
+ * single-phone words, multiplexed HMMs -- are cleared between utterances by hmm_clear (hmm.c:181-196), which resets scores
+ * and histories but not the per-state ssids (hmm_mpx_ssid): utterance k + 1 of one ps_decoder_t starts with the ssids
+ * utterance k left, and since a state's ssid decides which senone the search lists for it (compute_sen_active,
+ * ngram_search_fwdtree.c:526-564), the active lists and with them every score's normaliser depend on it.
+ * mpx_ssid_in_dev (NULL: freshly initialised channels, a new decoder) / mpx_ssid_out_dev (NULL: not wanted): per utterance
+ * u at + u*n_mpx*n_emit, n_mpx = psgpu_fwdtree_n_mpx_channels = roots then single-phone words, [n_mpx][n_emit] int32
+ * (entries of a non-multiplexed single-phone word are ignored / carry its senone ids).  The two may be one buffer.  A
+ * caller that decodes a session's utterances one after another passes each call's output as the next call's input;
+ * utterances of one call are independent of each other. */
+int32_t psgpu_fwdtree_n_mpx_channels(const psgpu_fwdtree_t *m);
+int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                                     const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                     int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                                     int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
+                                     int32_t pl_window, int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev,
+                                     int32_t *mpx_ssid_out_dev, void *stream);
 /* ngram_search_find_exit (ngram_search.c:500-544) + the backtrace of ngram_search_bp_hyp / the segment
  * iterator (:546-581, 903-1010) for every utterance of a batch, on the tables as the search left them:
  * hyp_dev + u*max_words*4 = {word id, start frame, end frame, path score at the word's end} per word in
@@ -631,6 +652,22 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
 void psgpu_decode_free(psgpu_decode_t *d);
 /* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
+/* Session mode.  The utterances of ONE call are decoded as by so many new reference decoders.  A reference decoder that
+ * decodes utterances one after another carries state from each into the next: the PTM scorer's top-N lists (the first
+ * frame of utterance k + 1 is seeded with the last lists of utterance k) and the per-state ssids of the
+ * search's permanent multiplexed channels (psgpu_fwdtree_search_session_dev).  on != 0: every following call with
+ * n_utt == 1 continues where the previous such call ended -- the object then behaves as one ps_decoder_t fed through
+ * psgpu_decode_first_pass_feat (the front end's and the feature module's own carry-over -- noise tracker, live CMN -- is
+ * the caller's: the ps_search_t binding takes its feature vectors from the reference's acmod).  Calling it again (on or
+ * off) forgets the state: the next utterance is a new decoder's first.  Calls with n_utt != 1 neither use nor change it. */
+int psgpu_decode_session(psgpu_decode_t *d, int32_t on);
+/* The session's state on the host, for a caller whose decoder also runs passes elsewhere (the reference's own second pass
+ * re-scores the utterance and evaluates the single-phone channels again: what the next utterance inherits is then what
+ * THAT pass left).  set: seed_cw [n_chain][topn] = the lists in slot n_fast_hist - 1 of the scorer's history ring (NULL: a
+ * reset scorer), mpx_ssid [n_mpx][n_emit] (NULL: freshly initialised channels); get: what the last session utterance left
+ * (*seed_valid = 0: no frame of it wrote that slot -- the lists given before still stand). */
+int psgpu_decode_session_set(psgpu_decode_t *d, const uint8_t *seed_cw, const int32_t *mpx_ssid, void *stream);
+int psgpu_decode_session_get(psgpu_decode_t *d, uint8_t *seed_cw, int32_t *seed_valid, int32_t *mpx_ssid, void *stream);
 /* pcm_dev: the samples of n_utt utterances back to back, resident on the device; samp_off [n_utt + 1]
  * HOST array of sample offsets.  Asynchronous on `stream`; one call at a time per object.  Results stay on
  * the device (psgpu_decode_view) until fetched. */

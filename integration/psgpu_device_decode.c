@@ -590,6 +590,64 @@ feat_ring_index(acmod_t *acmod, int frame_idx)
     return feat_idx;
 }
 
+/* ---- a decoder session through the ps_search_t binding.  The reference decoder's own structures stay the single holder
+ * of what an utterance inherits from the one before -- the per-state ssids of the multiplexed permanent channels (hmm_clear
+ * keeps them, hmm.c:181-196) and the scorer's history slot n_fast_hist - 1 (it seeds frame 0, ptm_mgau.c:425-441): they are
+ * handed to the device pipeline before its pass and written back after it, so that whatever else runs in between on the
+ * host (the reference's second pass evaluates the single-phone channels and re-scores the utterance) is carried too. */
+static int
+session_push(psgpu_device_decode_t *d, ngram_search_t *ngs)
+{
+    int ne = hmm_n_emit_state(&ngs->root_chan[0].hmm), R = ngs->n_root_chan, n1 = ngs->n_1ph_words, i, k, rc = 0;
+    int H = d->ps->pl_window + 2, n = d->n_chain * d->topn;
+    int32 *mpx = ckd_calloc((size_t)(R + n1) * ne + 1, 4), *cw = ckd_calloc(n + 1, 4);
+    uint8 *seed = ckd_calloc(n + 1, 1);
+    for (i = 0; i < R; ++i)
+        for (k = 0; k < ne; ++k) mpx[(size_t)i * ne + k] = hmm_mpx_ssid(&ngs->root_chan[i].hmm, k);
+    for (i = 0; i < n1; ++i) {
+        hmm_t *h = &((root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]])->hmm;
+        for (k = 0; k < ne; ++k) mpx[(size_t)(R + i) * ne + k] = hmm_is_mpx(h) ? hmm_mpx_ssid(h, k) : hmm_nonmpx_ssid(h);
+    }
+    if (psgpu_mgau_get_history(ps_search_acmod(ngs)->mgau, H - 1, cw) == 0) {
+        for (i = 0; i < n; ++i) seed[i] = (uint8)cw[i];
+        if (psgpu_decode_session_set(d->dec, seed, mpx, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) rc = -1;
+    }
+    else if (psgpu_decode_session_set(d->dec, NULL, mpx, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) rc = -1;   /* (not the PTM shim) */
+    if (rc < 0) E_ERROR("psgpu device search: %s\n", psgpu_last_error());
+    ckd_free(mpx); ckd_free(cw); ckd_free(seed);
+    return rc;
+}
+
+static int
+session_pull(psgpu_device_decode_t *d, ngram_search_t *ngs)
+{
+    int ne = hmm_n_emit_state(&ngs->root_chan[0].hmm), R = ngs->n_root_chan, n1 = ngs->n_1ph_words, i, k, rc = 0;
+    int H = d->ps->pl_window + 2, n = d->n_chain * d->topn;
+    int32 *mpx = ckd_calloc((size_t)(R + n1) * ne + 1, 4), *cw = ckd_calloc(n + 1, 4), valid = 0;
+    uint8 *seed = ckd_calloc(n + 1, 1);
+    if (psgpu_decode_session_get(d->dec, seed, &valid, mpx, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+        E_ERROR("psgpu device search: %s\n", psgpu_last_error());
+        rc = -1;
+    }
+    else {
+        for (i = 0; i < R; ++i)
+            for (k = 0; k < ne; ++k) ngs->root_chan[i].hmm.senid[k] = (uint16)mpx[(size_t)i * ne + k];
+        for (i = 0; i < n1; ++i) {
+            hmm_t *h = &((root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]])->hmm;
+            if (hmm_is_mpx(h))
+                for (k = 0; k < ne; ++k) h->senid[k] = (uint16)mpx[(size_t)(R + i) * ne + k];
+        }
+        if (valid) {
+            for (i = 0; i < n; ++i) cw[i] = seed[i];
+            if (psgpu_mgau_seed_history(ps_search_acmod(ngs)->mgau, H - 1, cw) < 0) {
+                /* (a scorer other than the PTM shim keeps its own history) */
+            }
+        }
+    }
+    ckd_free(mpx); ckd_free(cw); ckd_free(seed);
+    return rc;
+}
+
 static int
 dev_search_start(ps_search_t *search)
 {
@@ -639,10 +697,12 @@ dev_search_finish(ps_search_t *search)
     if (d->n_feat > 0) {
         if (refresh(d) < 0) return -1;
         off[0] = 0; off[1] = d->n_feat;
+        if (session_push(d, ngs) < 0) return -1;
         if (psgpu_decode_first_pass_feat(d->dec, d->h_feat, off, 1, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
             E_ERROR("psgpu device search: %s\n", psgpu_last_error());
             return -1;
         }
+        if (session_pull(d, ngs) < 0) return -1;
         if (fetch_summary(d, 1) < 0) return -1;
         if (d->h_res[2] > 0 && (nfr = fetch_and_inject(d, 0)) < 0) return -1;
     }
@@ -729,6 +789,10 @@ psgpu_device_search_attach(psgpu_device_decode_t *d)
     if (ngs->fwdflat && d->ff) {
         E_ERROR("psgpu device search: with PSGPU_DEVICE_SECOND_PASS=1 use psgpu_device_decode_utt (the vtable binding runs the "
                 "reference's own second pass)\n");
+        return -1;
+    }
+    if (psgpu_decode_session(d->dec, 1) != PSGPU_OK) {        /* one decoder, one utterance after another: see session_push */
+        E_ERROR("psgpu device search: %s\n", psgpu_last_error());
         return -1;
     }
     d->orig_vt = s->vt; d->vt = *s->vt;

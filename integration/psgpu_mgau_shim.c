@@ -100,10 +100,6 @@ upload_model(psgpu_mgau_t *g)
     uint8 *mixw;
     int f, d, rc;
 
-    if (s->mixw_cb) {
-        E_ERROR("psgpu: 4-bit clustered sendumps are not supported on the device\n");
-        return -1;
-    }
     if (la->width != 1) {
         E_ERROR("psgpu: 8-bit log-add table expected (width %d)\n", la->width);
         return -1;
@@ -111,8 +107,24 @@ upload_model(psgpu_mgau_t *g)
     /* mixw[f][d] rows may live in an mmap of sendump: gather them */
     mixw = ckd_malloc(rows * (size_t)s->n_sen);
     for (r = 0, f = 0; f < gd->n_feat; ++f)
-        for (d = 0; d < gd->n_density; ++d, ++r)
-            memcpy(mixw + r * (size_t)s->n_sen, s->mixw[f][d], (size_t)s->n_sen);
+        for (d = 0; d < gd->n_density; ++d, ++r) {
+            if (s->mixw_cb) {
+                /* a clustered sendump (read_sendump, ptm_mgau.c:457-654): a row is (n_sen + 1) / 2 bytes of two
+                 * 4-bit cluster indices.  The weight the reference uses for senone `sen` (ptm_mgau.c:375-379) is
+                 *     dcw = row[sen / 2];  dcw = (dcw & 1) ? dcw >> 4 : dcw & 0x0f;  mixw_cb[dcw]
+                 * -- the nibble is chosen by the low bit of the BYTE, not of the senone, so both senones of a byte get
+                 * the same weight.  That is a per-(row, senone) constant: it is expanded here, quirk included, into the
+                 * one-byte-per-senone table the device kernels read. */
+                int32 sen;
+                for (sen = 0; sen < s->n_sen; ++sen) {
+                    int dcw = s->mixw[f][d][sen / 2];
+                    dcw = (dcw & 1) ? dcw >> 4 : dcw & 0x0f;
+                    mixw[r * (size_t)s->n_sen + sen] = s->mixw_cb[dcw];
+                }
+            }
+            else
+                memcpy(mixw + r * (size_t)s->n_sen, s->mixw[f][d], (size_t)s->n_sen);
+        }
     if (g->model)
         psgpu_ptm_model_free(g->model);
     g->model = NULL;
@@ -533,6 +545,22 @@ psgpu_mgau_seed_history(ps_mgau_t *ps, int slot, const int32 *cw)
     g->la_c0 = g->la_cn = 0; g->la_expect = -1;
     psgpu_ptm_state_lookahead(g->state, NULL, 0, 0);           /* drop a stale look-ahead cache */
     rc = psgpu_ptm_state_set_topn(g->state, slot, cw, sc, NULL);
+    ckd_free(sc);
+    return rc == PSGPU_OK ? 0 : -1;
+}
+
+/* the codewords of history slot `slot` as the wrapped PTM scorer holds them now ([n_mgau * n_feat][topn]) */
+int
+psgpu_mgau_get_history(ps_mgau_t *ps, int slot, int32 *cw)
+{
+    psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
+    int32 *sc;
+    int rc, n;
+    if (ps == NULL || ps->vt != &psgpu_mgau_funcs || cw == NULL || slot < 0 || slot >= g->cpu->n_fast_hist)
+        return -1;
+    n = g->cpu->g->n_mgau * g->cpu->g->n_feat * g->cpu->max_topn;
+    sc = ckd_calloc(n, sizeof *sc);
+    rc = psgpu_ptm_state_get_topn(g->state, slot, cw, sc, NULL);
     ckd_free(sc);
     return rc == PSGPU_OK ? 0 : -1;
 }

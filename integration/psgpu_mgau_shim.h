@@ -27,6 +27,8 @@ int psgpu_mgau_reset(ps_mgau_t *mgau);
 
 /* history slot `slot` of a wrapped PTM scorer := the codeword lists cw [n_chain][topn] (see psgpu_mgau_shim.c) */
 int psgpu_mgau_seed_history(ps_mgau_t *mgau, int slot, const int32 *cw);
+/* ... and reads them (the lists that will seed the next utterance's first frame are slot n_fast_hist - 1's) */
+int psgpu_mgau_get_history(ps_mgau_t *ps, int slot, int32 *cw);
 
 /* Hooks for a device-side search component (integration/psgpu_phone_loop_shim.c): score what
  * lies ahead of `frame` now and return the device rows; account for a fresh frame_eval call

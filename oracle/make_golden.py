@@ -76,11 +76,11 @@ def adversarial_feats(t, n, rng):
     return x.reshape(n, n_feat * fl)
 
 
-def ptm_case(name, feats, seglen, carry, dup=0, full_topn=False, sample=16):
+def ptm_case(name, feats, seglen, carry, dup=0, full_topn=False, sample=16, model=None, more=None):
     with tempfile.NamedTemporaryFile(suffix=".f32", delete=False) as fh:
         feats.astype(np.float32).tofile(fh)
         fpath = fh.name
-    d = ref_dump("ptm", fpath, seglen, carry, dup)
+    d = ref_dump("ptm", fpath, seglen, carry, dup, model=model)
     os.unlink(fpath)
     T = feats.shape[0]
     idx = np.unique(np.linspace(0, T - 1, sample).astype(np.int64))
@@ -94,9 +94,56 @@ def ptm_case(name, feats, seglen, carry, dup=0, full_topn=False, sample=16):
                topn_norm_sample=d["topn_norm"][idx])
     if full_topn:
         out["topn_cw"] = d["topn_cw"]; out["topn_raw"] = d["topn_raw"]
+    if more:
+        out.update(more)
     np.savez_compressed(os.path.join(GOLD, "ptm_%s.npz" % name), **out)
     print("ptm_%s: T=%d" % (name, T))
     return d
+
+
+def write_clustered_sendump(path, mixw8, n_clust=16):
+    """A sendump with 4-bit clustered mixture weights in the layout read_sendump (ptm_mgau.c:457-654) expects: sixteen
+    cluster values, then per (stream, density) a row of (n_sen + 1) / 2 bytes, the even senone's cluster index in the low
+    nibble.  The clusters are sixteen quantiles of the 8-bit weights."""
+    import struct
+    n_feat, n_den, n_sen = mixw8.shape
+    cb = np.unique(np.quantile(mixw8.ravel(), np.linspace(0, 1, n_clust)).astype(np.int64))
+    while cb.size < n_clust:                        # (ties between quantiles: fill with unused values)
+        cb = np.unique(np.concatenate([cb, [int(cb.max()) + 1 if cb.max() < 255 else int(cb.min()) - 1]]))
+    cb = np.sort(cb)[:n_clust].astype(np.uint8)
+    idx = np.abs(mixw8[..., None].astype(np.int32) - cb.astype(np.int32)).argmin(axis=-1).astype(np.uint8)
+    if n_sen & 1:
+        idx = np.concatenate([idx, np.zeros((n_feat, n_den, 1), np.uint8)], axis=2)
+    packed = (idx[..., 0::2] | (idx[..., 1::2] << 4)).astype(np.uint8)
+
+    def lstr(txt):
+        b = txt.encode() + b"\0"
+        return struct.pack("<i", len(b)) + b
+    with open(path, "wb") as fh:
+        fh.write(lstr("V6 Senone Probs, Smoothed, Normalized"))
+        fh.write(lstr("(HMM file format)"))
+        for h in ("feature_count %d" % n_feat, "mixture_count %d" % n_den, "model_count %d" % n_sen,
+                  "cluster_count %d" % n_clust, "cluster_bits 4", "logbase 1.0001", "mixw_shift 10"):
+            fh.write(lstr(h))
+        fh.write(struct.pack("<i", 0))
+        fh.write(cb.tobytes())
+        fh.write(packed.tobytes())
+    return cb, packed
+
+
+def ptm_4bit():
+    """PTM scoring from a 4-bit clustered sendump (ptm_mgau.c:375-379, with its nibble selection by the low bit of the
+    BYTE): the en-us model with its sendump re-quantised.  The golden carries the packed weights and the cluster values."""
+    t = np.load(os.path.join(GOLD, "en_us_ptm_tables.npz"))
+    gof = ref_dump("feats", RAW)["feat"]
+    d = tempfile.mkdtemp()
+    for f in os.listdir(MODEL):
+        if f != "sendump":
+            os.symlink(os.path.join(MODEL, f), os.path.join(d, f))
+    cb, packed = write_clustered_sendump(os.path.join(d, "sendump"), t["mixw"])
+    tt = ref_dump("tables", model=d)
+    assert int(tt["mixw_is_4bit"][0]) == 1 and np.array_equal(tt["mixw"], packed) and np.array_equal(tt["mixw_cb"], cb)
+    ptm_case("4bit_goforward", gof[:120], 120, 0, sample=24, model=d, more=dict(mixw4=packed, mixw_cb=cb))
 
 
 def senlog_case(name, nrep, extra=(), inp=None, **kw):
@@ -273,6 +320,27 @@ def fwdtree_only():
         np.savez_compressed(os.path.join(GOLD, "fwdtree_trace_%s.npz" % name), **tr)
         print("fwdtree", name, "steps", int(d["n_steps"][0]), "bp", d["bp"].shape[0])
 
+
+
+def fwdtree_session():
+    """the SECOND utterance of a session (REFDUMP_WARMUP: the decoder decodes another utterance first): the permanent
+    multiplexed channels start with the per-state ssids the first one left (hmm_clear keeps them, hmm.c:181-196) --
+    `mpx_init` -- which changes the senones the search lists and so every score's normaliser"""
+    base = ("fwdflat", "no", "bestpath", "no")
+    for name, warm, audio in (("goforward_after_numbers", "numbers.raw", "goforward.raw"),
+                              ("numbers_after_something", "something.raw", "numbers.raw")):
+        os.environ["REFDUMP_WARMUP"] = os.path.join(REF, "data", warm)
+        try:
+            d = ref_dump("fwdtree", os.path.join(REF, "data", audio), extra=base)
+        finally:
+            del os.environ["REFDUMP_WARMUP"]
+        tr = {k: v for k, v in d.items() if k not in FT_STATIC}
+        tr["static"] = np.frombuffer(b"en_us_turtle", np.uint8)
+        np.savez_compressed(os.path.join(GOLD, "fwdtree_trace_%s.npz" % name), **tr)
+        fresh = np.load(os.path.join(GOLD, "fwdtree_trace_%s.npz" % audio.split(".")[0]))
+        print("fwdtree session", name, "bp", d["bp"].shape[0], "mpx_init non-BAD beyond state 0:",
+              int((d["mpx_init"][:, 1:] != 0xffff).sum()), "| same table as the fresh decode:", np.array_equal(fresh["bp"], d["bp"]),
+              "same scores handed:", np.array_equal(fresh["step_scr"], d["step_scr"]) if fresh["step_scr"].shape == d["step_scr"].shape else False)
 
 
 FF_STATIC = ["pron_off", "pron_ci", "pron_ssid", "ci_ssid", "lm_known"]
@@ -459,7 +527,20 @@ def fwdtree_medium_only():
     print("static", os.path.getsize(os.path.join(GOLD, "fwdtree_static_%s.npz" % static)))
 
 
+def hmm_syn_case(n_emit, n_hmm, n_steps, seed):
+    """a synthetic context with n_emit emitting states (ref_dump hmmsyn): 1, 2 and 4 reach hmm_vit_eval_anytopo"""
+    with tempfile.NamedTemporaryFile(suffix=".psgb", delete=False) as fh:
+        out = fh.name
+    subprocess.check_call([os.path.join(REF, "ref_dump"), "hmmsyn", out, str(n_emit), str(n_hmm), str(n_steps), str(seed)])
+    d = read_psgb(out)
+    os.unlink(out)
+    np.savez_compressed(os.path.join(GOLD, "hmm_syn_%dst.npz" % n_emit), **d)
+    print("hmm_syn_%dst: n_hmm=%d steps=%d" % (n_emit, n_hmm, n_steps))
+
+
 def hmm_only():
+    for ne, seed in ((4, 41), (2, 42), (1, 43)):
+        hmm_syn_case(ne, 768, 10, seed)
     # 3-state (en-us) and 5-state (tidigits) topologies, mpx and non-mpx
     hmm_case("en_us_3st", MODEL, LM, DIC, 1536, 12, 20260922)
     tdm = os.path.join(REF, "model", "tidigits")
@@ -472,6 +553,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "hmm":
         os.makedirs(GOLD, exist_ok=True)
         hmm_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "session":
+        fwdtree_session()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ptm4":
+        ptm_4bit()
     elif len(sys.argv) > 1 and sys.argv[1] == "semi":
         semi_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ms":

@@ -1044,9 +1044,60 @@ vit5_mpx(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
 #undef SEN
 }
 
-/* hmm_vit_eval (hmm.c:786-805).  Only the hard-wired 3- and 5-state
- * topologies are restated; no bundled model reaches hmm_vit_eval_anytopo
- * (SURVEY section 4). */
+/* hmm_vit_eval_anytopo (hmm.c:710-784): any number of emitting states up to
+ * HMM_MAX_NSTATE (5), any upper-triangular transition matrix.  The reference
+ * reaches it for 1, 2 and 4 emitting states.  Unlike the hard-wired forms it
+ * (a) clamps only the INCOMING state + senone sums of states 1.. (state 0's is
+ * left as is), (b) never clamps the new scores, (c) leaves a state's history
+ * (and, multiplexed, its ssid) alone when its self loop wins -- `bestfrom`
+ * stays -1 -- or when nothing reaches it. */
+static int32_t
+vit_any(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
+{
+    const int ne = h->n_emit_state;
+    const uint8_t *tp = ctx->tp + (size_t)h->tmatid * ne * (ne + 1);
+    int32_t st[5], scr, newscr, bestscr;
+    int to, from, bestfrom;
+#define TP(i, j) (-(int32_t)tp[(i) * (ne + 1) + (j)])
+    /* hmm_senscr (hmm.h:207-209): WORST_SCORE for a state without a senone */
+    for (from = 0; from < ne; ++from) {
+        int32_t sen;
+        if (h->mpx) {
+            const uint16_t ssid = h->senid[from];
+            sen = ssid == PSO_BAD_SSID ? W : -(int32_t)ctx->senscore[ctx->sseq[(size_t)ssid * ne + from]];
+        }
+        else
+            sen = h->senid[from] == PSO_BAD_SSID ? W : -(int32_t)ctx->senscore[h->senid[from]];
+        st[from] = h->score[from] + sen;
+        if (from > 0 && st[from] < W) st[from] = W;
+    }
+    /* the non-emitting final state: no self transition */
+    to = ne;
+    scr = W;
+    bestfrom = -1;
+    for (from = to - 1; from >= 0; --from)
+        if (TP(from, to) > -PSO_TMAT_WORST && (newscr = st[from] + TP(from, to)) > scr) { scr = newscr; bestfrom = from; }
+    h->out_score = scr;
+    if (bestfrom >= 0) h->out_history = h->history[bestfrom];
+    bestscr = scr;
+    for (to = ne - 1; to >= 0; --to) {
+        scr = TP(to, to) > -PSO_TMAT_WORST ? st[to] + TP(to, to) : W;
+        bestfrom = -1;
+        for (from = to - 1; from >= 0; --from)
+            if (TP(from, to) > -PSO_TMAT_WORST && (newscr = st[from] + TP(from, to)) > scr) { scr = newscr; bestfrom = from; }
+        h->score[to] = scr;
+        if (bestfrom >= 0) {
+            h->history[to] = h->history[bestfrom];
+            if (h->mpx) h->senid[to] = h->senid[bestfrom];
+        }
+        if (bestscr < scr) bestscr = scr;
+    }
+    h->bestscore = bestscr;
+    return bestscr;
+#undef TP
+}
+
+/* hmm_vit_eval (hmm.c:786-805) */
 int32_t
 pso_hmm_vit_eval(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
 {
@@ -1054,7 +1105,7 @@ pso_hmm_vit_eval(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
         return h->mpx ? vit3_mpx(ctx, h) : vit3(ctx, h);
     if (h->n_emit_state == 5)
         return h->mpx ? vit5_mpx(ctx, h) : vit5(ctx, h);
-    return W;
+    return vit_any(ctx, h);
 }
 
 /* ====================================================================== */

@@ -298,6 +298,28 @@ void pso_ft_start(pso_ft_t *s)
     h_enter(&s->w1[i], 0, NO_BP, 0);
 }
 
+/* A decoder session's carry-over into a NEW oracle object: the per-state ssids the permanent multiplexed channels (roots,
+ * then single-phone words; [R + n1][n_emit]) hold when the utterance starts -- hmm_clear (hmm.c:181-196) does not reset
+ * them.  (An oracle object that is re-started for the next utterance carries them by itself, as the reference does.)
+ * Call after pso_ft_start. */
+void pso_ft_set_mpx_ssids(pso_ft_t *s, const int32_t *ssid)
+{
+    int i, k;
+    for (i = 0; i < s->R; ++i)
+        for (k = 0; k < s->n_emit; ++k) s->node[i].senid[k] = (uint16_t)ssid[(size_t)i * s->n_emit + k];
+    for (i = 0; i < s->n1; ++i)
+        if (s->w1[i].mpx)
+            for (k = 0; k < s->n_emit; ++k) s->w1[i].senid[k] = (uint16_t)ssid[(size_t)(s->R + i) * s->n_emit + k];
+}
+void pso_ft_get_mpx_ssids(const pso_ft_t *s, int32_t *ssid)
+{
+    int i, k;
+    for (i = 0; i < s->R; ++i)
+        for (k = 0; k < s->n_emit; ++k) ssid[(size_t)i * s->n_emit + k] = s->node[i].senid[k];
+    for (i = 0; i < s->n1; ++i)
+        for (k = 0; k < s->n_emit; ++k) ssid[(size_t)(s->R + i) * s->n_emit + k] = s->w1[i].senid[k];
+}
+
 /* acmod_activate_hmm, acmod.c:1179-1221 */
 static void activate(pso_ft_t *s, const pso_hmm_t *h)
 {

@@ -34,6 +34,10 @@ typedef struct pso_ft_s pso_ft_t;
 pso_ft_t *pso_ft_new(const pso_ft_tables_t *t);     /* the tables must outlive the object */
 void pso_ft_free(pso_ft_t *s);
 void pso_ft_start(pso_ft_t *s);
+/* a session's carry-over: the per-state ssids of the permanent multiplexed channels, [R + n_1ph][n_emit] (roots, then
+ * single-phone words).  set: into a new object, after pso_ft_start; get: as they stand now */
+void pso_ft_set_mpx_ssids(pso_ft_t *s, const int32_t *ssid);
+void pso_ft_get_mpx_ssids(const pso_ft_t *s, int32_t *ssid);
 /* language scores from a trie model (ps_oracle_lm.h) instead of the dense table, which may then be NULL */
 struct pso_lm_s;
 void pso_ft_set_lm(pso_ft_t *s, const struct pso_lm_s *lm);

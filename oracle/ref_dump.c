@@ -639,14 +639,10 @@ hmm_pack(const hmm_t *h, int32 *o)
 }
 
 static int
-cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
+hmm_run(int n_emit, int n_tmat, uint8 ***tp, int n_sseq, uint16 **sseq, int n_sen, int n_hmm, int n_steps, int seed)
 {
-    bin_mdef_t *mdef = ps->acmod->mdef;
-    tmat_t *tmat = ps->acmod->tmat;
-    int n_emit = bin_mdef_n_emit_state(mdef), n_sseq = bin_mdef_n_sseq(mdef);
-    int n_sen = bin_mdef_n_sen(mdef), n_tmat = tmat->n_tmat;
     int16 *senscr = calloc(n_sen, sizeof(int16));
-    hmm_context_t *ctx = hmm_context_init(n_emit, tmat->tp, senscr, mdef->sseq);
+    hmm_context_t *ctx = hmm_context_init(n_emit, tp, senscr, sseq);
     hmm_t *h = calloc(n_hmm, sizeof(hmm_t));
     int32 *before = malloc(sizeof(int32) * (size_t)n_steps * n_hmm * HF);
     int32 *after = malloc(sizeof(int32) * (size_t)n_steps * n_hmm * HF);
@@ -659,9 +655,9 @@ cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
 
     g_rng = (uint32_t)seed;
     for (i = 0; i < n_tmat; ++i) for (a = 0; a < n_emit; ++a) for (b = 0; b <= n_emit; ++b)
-        tpflat[((size_t)i * n_emit + a) * (n_emit + 1) + b] = tmat->tp[i][a][b];
+        tpflat[((size_t)i * n_emit + a) * (n_emit + 1) + b] = tp[i][a][b];
     for (i = 0; i < n_sseq; ++i) for (a = 0; a < n_emit; ++a)
-        sseqflat[(size_t)i * n_emit + a] = mdef->sseq[i][a];
+        sseqflat[(size_t)i * n_emit + a] = sseq[i][a];
     for (i = 0; i < n_hmm; ++i) {
         mpx[i] = (uint8)(rnd() & 1);
         hmm_init(ctx, &h[i], mpx[i], rnd() % n_sseq, rnd() % n_tmat);
@@ -683,7 +679,7 @@ cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
                     h[i].score[st] = WORST_SCORE + (int32)(rnd() % 3000) - 200;
             if (r % 41 == 0)
                 hmm_clear(&h[i]);
-            if (mpx[i] && r % 7 == 0) {          /* mpx: states carry their own ssids */
+            if (mpx[i] && r % 7 == 0 && n_emit > 1) {          /* mpx: states carry their own ssids */
                 st = 1 + rnd() % (n_emit - 1);
                 h[i].senid[st] = (rnd() % 5 == 0) ? 0xffff : (uint16)(rnd() % n_sseq);
             }
@@ -707,6 +703,38 @@ cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
     put3("after", 'i', n_steps, n_hmm, HF, after);
     put2("ret", 'i', n_steps, n_hmm, ret);
     return 0;
+}
+
+static int
+cmd_hmm(ps_decoder_t *ps, int n_hmm, int n_steps, int seed)
+{
+    bin_mdef_t *mdef = ps->acmod->mdef;
+    tmat_t *tmat = ps->acmod->tmat;
+    return hmm_run(bin_mdef_n_emit_state(mdef), tmat->n_tmat, tmat->tp, bin_mdef_n_sseq(mdef), mdef->sseq,
+                   bin_mdef_n_sen(mdef), n_hmm, n_steps, seed);
+}
+
+/* hmmsyn: the same drive over a SYNTHETIC context with n_emit emitting states (1..5; no bundled model has other than
+ * 3): random upper-triangular transition matrices with missing arcs (255 = TMAT_WORST_SCORE's magnitude) and skips,
+ * random senone sequences.  n_emit other than 3 and 5 reaches hmm_vit_eval_anytopo (hmm.c:710-784). */
+static int
+cmd_hmmsyn(int n_emit, int n_hmm, int n_steps, int seed)
+{
+    const int n_tmat = 11, n_sseq = 61, n_sen = 400;
+    uint8 ***tp = (uint8 ***)ckd_calloc_3d(n_tmat, n_emit, n_emit + 1, sizeof(uint8));
+    uint16 **sseq = (uint16 **)ckd_calloc_2d(n_sseq, n_emit, sizeof(uint16));
+    int i, a, b;
+    g_rng = (uint32_t)seed * 2654435761u + 12345u;
+    for (i = 0; i < n_tmat; ++i)
+        for (a = 0; a < n_emit; ++a)
+            for (b = 0; b <= n_emit; ++b) {
+                uint32_t r = rnd();
+                tp[i][a][b] = (b < a || r % 4 == 0) ? 255 : (uint8)(1 + (r >> 3) % 140);
+            }
+    for (i = 0; i < n_sseq; ++i)
+        for (a = 0; a < n_emit; ++a)
+            sseq[i][a] = (uint16)(rnd() % n_sen);
+    return hmm_run(n_emit, n_tmat, tp, n_sseq, sseq, n_sen, n_hmm, n_steps, seed);
 }
 
 /* ------------------------------------------------------------------ */
@@ -1174,6 +1202,23 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath, int flat)
         free(lm);
     }
 traced:
+    /* REFDUMP_WARMUP=<raw>: the decoder first decodes that utterance, so that the traced one is the SECOND of a session.
+     * What the permanent channels carry over -- hmm_clear (hmm.c:181-196) resets scores and histories, not the per-state
+     * ssids of the multiplexed roots and single-phone words -- is dumped as they stand when the traced utterance starts. */
+    if (getenv("REFDUMP_WARMUP")) {
+        int n1 = ngs->n_1ph_words;
+        int32 *st = calloc((size_t)(R + n1) * n_emit + 1, 4);
+        run_utt(ps, getenv("REFDUMP_WARMUP"));
+        for (i = 0; i < R; ++i)
+            for (k = 0; k < n_emit; ++k) st[(size_t)i * n_emit + k] = hmm_mpx_ssid(&ngs->root_chan[i].hmm, k);
+        for (i = 0; i < n1; ++i) {
+            root_chan_t *r = (root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]];
+            for (k = 0; k < n_emit; ++k)
+                st[(size_t)(R + i) * n_emit + k] = hmm_is_mpx(&r->hmm) ? hmm_mpx_ssid(&r->hmm, k) : hmm_nonmpx_ssid(&r->hmm);
+        }
+        put2("mpx_init", 'i', R + n1, n_emit, st);
+        free(st);
+    }
     /* ---- the decode, traced */
     ft_ps = ps;
     ft_orig = ps->search->vt; ft_vt = *ft_orig; ft_vt.step = ft_step; if (flat) ft_vt.finish = ff_finish; ps->search->vt = &ft_vt;
@@ -1339,6 +1384,9 @@ main(int argc, char **argv)
         set = ngram_model_set_init(NULL, &m, &name, NULL, 1);
         ngram_model_apply_weights(set, (float32)atof(argv[7]), (float32)atof(argv[8]));
         rc = cmd_lm(set, argv[6]);
+    } else if (!strcmp(cmd, "hmmsyn") && argc > 6) {
+        /* ref_dump hmmsyn out.psgb n_emit n_hmm n_steps seed  (no model) */
+        rc = cmd_hmmsyn(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     } else if (!strcmp(cmd, "hmm") && xa > 8) {
         rc = cmd_hmm(make_decoder(modeldir, lm, dict, nextra, extra), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]));
     } else if (!strcmp(cmd, "decode") && xa > 6) {

@@ -26,6 +26,12 @@ struct psgpu_decode_s {
     int16_t *d_rows = nullptr;
     int32_t *d_bp = nullptr, *d_bss = nullptr, *d_idx = nullptr, *d_step = nullptr, *d_res = nullptr, *d_hyp = nullptr, *d_hn = nullptr,
             *d_w1 = nullptr;
+    // a decoder session (psgpu_decode_session): what utterance k + 1 of ONE reference decoder inherits from utterance k --
+    // the scorer's last top-N lists (the seeds of the next first frame, ptm_mgau.c) and the per-state ssids of the permanent
+    // multiplexed channels (hmm_clear keeps them)
+    bool session = false, sess_started = false, seed_valid = false;
+    uint8_t *d_seed = nullptr;
+    int32_t *d_mpx = nullptr;
     // the last call
     int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
     std::vector<int32_t> frame_off;
@@ -90,8 +96,58 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
+    DFREE(d->d_seed); DFREE(d->d_mpx);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     delete d;
+}
+
+int psgpu_decode_session(psgpu_decode_t *d, int32_t on)
+{
+    PSGPU_REQUIRE(d, "psgpu_decode_session: NULL argument");
+    d->session = on != 0;
+    d->sess_started = false; d->seed_valid = false;
+    return PSGPU_OK;
+}
+
+static int dec_session_buffers(psgpu_decode_s *d)
+{
+    int rc;
+    if (!d->d_seed && ((rc = dec_alloc((void **)&d->d_seed, (size_t)d->n_chain * d->topn))
+                       || (rc = dec_alloc((void **)&d->d_mpx, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))))
+        return rc;
+    return PSGPU_OK;
+}
+
+int psgpu_decode_session_set(psgpu_decode_t *d, const uint8_t *seed_cw, const int32_t *mpx_ssid, void *stream)
+{
+    PSGPU_REQUIRE(d && d->session, "psgpu_decode_session_set: not in session mode");
+    int rc = dec_session_buffers(d);
+    if (rc != PSGPU_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (seed_cw) {
+        PSGPU_HIP(hipMemcpyAsync(d->d_seed, seed_cw, (size_t)d->n_chain * d->topn, hipMemcpyHostToDevice, st));
+        d->seed_valid = true;
+    }
+    else d->seed_valid = false;
+    if (mpx_ssid) {
+        PSGPU_HIP(hipMemcpyAsync(d->d_mpx, mpx_ssid, 4 * (size_t)psgpu_fwdtree_n_mpx_channels(d->cfg.ft) * d->n_emit, hipMemcpyHostToDevice, st));
+        d->sess_started = true;
+    }
+    else d->sess_started = false;
+    PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_session_get(psgpu_decode_t *d, uint8_t *seed_cw, int32_t *seed_valid, int32_t *mpx_ssid, void *stream)
+{
+    PSGPU_REQUIRE(d && d->session && d->sess_started, "psgpu_decode_session_get: no session utterance decoded yet");
+    hipStream_t st = (hipStream_t)stream;
+    if (seed_valid) *seed_valid = d->seed_valid ? 1 : 0;
+    if (seed_cw && d->seed_valid) PSGPU_HIP(hipMemcpyAsync(seed_cw, d->d_seed, (size_t)d->n_chain * d->topn, hipMemcpyDeviceToHost, st));
+    if (mpx_ssid)
+        PSGPU_HIP(hipMemcpyAsync(mpx_ssid, d->d_mpx, 4 * (size_t)psgpu_fwdtree_n_mpx_channels(d->cfg.ft) * d->n_emit, hipMemcpyDeviceToHost, st));
+    PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
 }
 
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model)
@@ -147,19 +203,38 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
 static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t mf, hipStream_t st)
 {
     int rc;
+    // session: one utterance per call, chained to the call before
+    const bool sess = d->session && n_utt == 1;
+    if (sess && (rc = dec_session_buffers(d))) return rc;
+    const bool chained = sess && d->sess_started;
     dec_mark(d, 2, st);
-    if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, nullptr, nullptr, d->d_tsc, d->d_tcw,
-                                        d->d_rows, d->d_best, PSGPU_PTM_RAW_SCORES, st)))
+    if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, chained && d->seed_valid ? d->d_seed : nullptr,
+                                        nullptr, d->d_tsc, d->d_tcw, d->d_rows, d->d_best, PSGPU_PTM_RAW_SCORES, st)))
         return rc;
+    if (sess) {
+        // what seeds the next utterance's first frame: ptm_mgau_frame_eval copies frame 0's initial lists from slot
+        // n_fast_hist - 1 of its history ring (ptm_mgau.c:425-441), H = n_fast_hist = pl_window + 2 (:865); that slot was last
+        // written by the last frame ts with ts % H == H - 1 -- not by the last frame.  Shorter utterances leave it alone.
+        const int H = d->cfg.pl_window + 2, T = (int)total;
+        int ts = T - 1;
+        while (ts >= 0 && ts % H != H - 1) --ts;
+        if (ts >= 0) {
+            PSGPU_HIP(hipMemcpy2DAsync(d->d_seed, (size_t)d->topn, d->d_tcw + (size_t)ts * d->topn, (size_t)T * d->topn, (size_t)d->topn,
+                                       (size_t)d->n_chain, hipMemcpyDeviceToDevice, st));
+            d->seed_valid = true;
+        }
+    }
     dec_mark(d, 3, st);
     if ((rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
                                        nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st)))
         return rc;
     dec_mark(d, 4, st);
     // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
-    if ((rc = psgpu_fwdtree_search_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
-                                       d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1, st)))
+    if ((rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
+                                               d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
+                                               chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st)))
         return rc;
+    if (sess) d->sess_started = true;
     dec_mark(d, 5, st);
     rc = psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp, d->d_idx, d->d_res, n_utt, (int32_t)mf, d->bp_cap, d->max_words, d->d_hyp,
                                      d->d_hn, st);

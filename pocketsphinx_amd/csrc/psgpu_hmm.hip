@@ -114,8 +114,10 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
             const int16_t *ss = senscr + (size_t)utt * senscr_stride;
             if (NE == 3)
                 best = mpx ? vit3_mpx(h, tp, ss, sseq) : vit3(h, tp, ss);
-            else
+            else if (NE == 5)
                 best = mpx ? vit5_mpx(h, tp, ss, sseq) : vit5(h, tp, ss);
+            else
+                best = vit_any<NE>(h, tp, ss, sseq, mpx);        // 1, 2, 4 states: hmm_vit_eval_anytopo
             // one 64-byte line out
             q0 = make_int4(h.score[0], h.score[1], h.score[2], h.score[3]);
             q1 = make_int4(h.score[4], h.history[0], h.history[1], h.history[2]);
@@ -358,9 +360,7 @@ int psgpu_hmm_ctx_create(psgpu_hmm_ctx_t **out, int32_t n_emit_state, int32_t n_
                          const uint8_t *tp, int32_t n_sseq, const uint16_t *sseq, int32_t n_sen)
 {
     PSGPU_REQUIRE(out && tp && sseq, "psgpu_hmm_ctx_create: NULL argument");
-    PSGPU_REQUIRE(n_emit_state == 3 || n_emit_state == 5,
-                  "n_emit_state %d: the hard-wired 3- and 5-state topologies are supported "
-                  "(hmm_vit_eval_anytopo, hmm.c:709-784, is reached by no bundled model)", n_emit_state);
+    PSGPU_REQUIRE(n_emit_state >= 1 && n_emit_state <= 5, "n_emit_state %d outside 1..5 (HMM_MAX_NSTATE, hmm.h)", n_emit_state);
     PSGPU_REQUIRE(n_tmat > 0 && n_tmat < 32768 && n_sseq > 0 && n_sseq < 65535 && n_sen > 0,
                   "bad table sizes (n_tmat %d, n_sseq %d, n_sen %d)", n_tmat, n_sseq, n_sen);
     int rc = psgpu_check_device();
@@ -425,16 +425,19 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
     int blocks = (n_active + kHmmThreads - 1) / kHmmThreads;
     if (blocks > 2048) blocks = 2048;
     const int32_t tpb = c->n_tmat * c->n_emit * (c->n_emit + 1);
-    if (c->n_emit == 3)
-        hipLaunchKernelGGL((hmm_vit_kernel<3>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
-                           recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
-                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,
-                           c->launch_done_count, c->launch_done_word, c->launch_seq);
-    else
-        hipLaunchKernelGGL((hmm_vit_kernel<5>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,
-                           recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,
-                           (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,
-                           c->launch_done_count, c->launch_done_word, c->launch_seq);
+#define HMM_LAUNCH(NE)                                                                                                 \
+    hipLaunchKernelGGL((hmm_vit_kernel<NE>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,                   \
+                       recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,                   \
+                       (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,                                \
+                       c->launch_done_count, c->launch_done_word, c->launch_seq)
+    switch (c->n_emit) {
+    case 1: HMM_LAUNCH(1); break;
+    case 2: HMM_LAUNCH(2); break;
+    case 3: HMM_LAUNCH(3); break;
+    case 4: HMM_LAUNCH(4); break;
+    default: HMM_LAUNCH(5); break;
+    }
+#undef HMM_LAUNCH
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
@@ -448,6 +451,7 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
                              int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream)
 {
     PSGPU_REQUIRE(c && pp && n_utt >= 0, "psgpu_phone_loop_run_dev: bad argument");
+    PSGPU_REQUIRE(c->n_emit == 3 || c->n_emit == 5, "phone loop: %d emitting states (3 or 5 are built)", c->n_emit);
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE(ssid_dev && tmatid_dev && raw_dev && utt_off_dev && penalties_dev, "psgpu_phone_loop_run_dev: NULL device buffer");
     PSGPU_REQUIRE(pp->n_phones >= 1 && pp->n_phones <= 64, "n_phones %d outside 1..64", pp->n_phones);

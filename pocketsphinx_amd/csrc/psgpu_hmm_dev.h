@@ -265,3 +265,53 @@ __device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const
 // ---------------------------------------------------------------------------
 // kernel: one lane per active HMM
 // ---------------------------------------------------------------------------
+
+// ---- any topology (hmm.c:710-784) -------------------------------------------
+// hmm_vit_eval_anytopo: what hmm_vit_eval (hmm.c:786-805) runs for anything but 3 or 5 emitting states, i.e. 1, 2 or 4
+// (HMM_MAX_NSTATE is 5).  Any upper-triangular transition matrix.  Differences from the hard-wired forms, all kept:
+// only the incoming sums of states 1.. are clamped at WORST_SCORE (state 0's is not); new scores are not clamped; a state
+// whose self loop wins (or that nothing reaches) keeps its history and, multiplexed, its ssid.
+template <int NE, typename S>
+__device__ __forceinline__ int32_t vit_any(HmmRegs &h, const uint8_t *tp, const S &ss, const uint16_t *sseq, bool mpx)
+{
+#define TP(i, j) (-(int32_t)tp[(i) * (NE + 1) + (j)])
+    int32_t st[NE];
+#pragma unroll
+    for (int from = 0; from < NE; ++from) {
+        int32_t sen;                                    // hmm_senscr (hmm.h:207-209)
+        if (h.senid[from] == kBadSsid) sen = kW;
+        else sen = -(int32_t)ss[mpx ? sseq[(size_t)h.senid[from] * NE + from] : h.senid[from]];
+        st[from] = h.score[from] + sen;
+        if (from > 0 && st[from] < kW) st[from] = kW;
+    }
+    int32_t scr = kW, bestscr;
+    int bestfrom = -1;
+#pragma unroll
+    for (int from = NE - 1; from >= 0; --from) {        // the final state: no self transition
+        const int32_t t = TP(from, NE);
+        if (t > -kTmatWorst && st[from] + t > scr) { scr = st[from] + t; bestfrom = from; }
+    }
+    h.out_score = scr;
+#pragma unroll
+    for (int from = 0; from < NE; ++from) if (bestfrom == from) h.out_history = h.history[from];
+    bestscr = scr;
+#pragma unroll
+    for (int to = NE - 1; to >= 0; --to) {
+        scr = TP(to, to) > -kTmatWorst ? st[to] + TP(to, to) : kW;
+        bestfrom = -1;
+#pragma unroll
+        for (int from = to - 1; from >= 0; --from) {
+            const int32_t t = TP(from, to);
+            if (t > -kTmatWorst && st[from] + t > scr) { scr = st[from] + t; bestfrom = from; }
+        }
+        h.score[to] = scr;
+        // (states below `to` still hold their old history / ssid: the sweep goes downwards)
+#pragma unroll
+        for (int from = 0; from < NE; ++from)
+            if (from < to && bestfrom == from) { h.history[to] = h.history[from]; if (mpx) h.senid[to] = h.senid[from]; }
+        if (bestscr < scr) bestscr = scr;
+    }
+    h.bestscore = bestscr;
+    return bestscr;
+#undef TP
+}

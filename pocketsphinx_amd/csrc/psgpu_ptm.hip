@@ -249,6 +249,8 @@ __device__ __forceinline__ int32_t med3_i32(int32_t a, int32_t b, int32_t c)
     return r;
 }
 
+typedef float ptm_f2 __attribute__((ext_vector_type(2)));
+
 template <int LEN, int FPL>                     // FPL = frames per lane
 __global__ __launch_bounds__(256, 8)
 void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_frames,
@@ -288,23 +290,46 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
     int32_t k0[FPL], k1[FPL], k2[FPL], k3[FPL], k4[FPL];
 #pragma unroll
     for (int q = 0; q < FPL; ++q) k0[q] = k1[q] = k2[q] = k3[q] = k4[q] = kMaxNegInt32;
+    auto insert = [&](int q, float d, int cw) {
+        const float c = __builtin_amdgcn_fmed3f(d, (float)kKeyLo, (float)kKeyHi);
+        const int32_t k = ((int32_t)c << 7) | (127 - cw);
+        // insertion into the sorted five: new_i = med3(old_{i-1}, old_i, k), all five from the
+        // OLD values -- one max and four v_med3_i32, independent of each other
+        const int32_t n4 = med3_i32(k3[q], k4[q], k), n3 = med3_i32(k2[q], k3[q], k),
+                      n2 = med3_i32(k1[q], k2[q], k), n1 = med3_i32(k0[q], k1[q], k);
+        k0[q] = max(k0[q], k); k1[q] = n1; k2[q] = n2; k3[q] = n3; k4[q] = n4;
+    };
 #pragma unroll 2
     for (int cw = 0; cw < 128; ++cw) {
         const float *m = mean + cw * LEN, *v = var + cw * LEN;
         const float dt = det[cw];
+        if (FPL % 2 == 0) {
+            // two frames per lane as the halves of packed single-precision operations (v_pk_add_f32 / v_pk_mul_f32: both
+            // halves rounded as the scalar operations are, the parameters broadcast from SGPRs): the distance is 4 VALU
+            // operations per dimension, and this kernel runs at the VALU issue rate
 #pragma unroll
-        for (int q = 0; q < FPL; ++q) {
-            float d = dt;
+            for (int q = 0; q < FPL; q += 2) {
+                ptm_f2 d = { dt, dt };
 #pragma unroll
-            for (int j = 0; j < LEN; ++j)
-                d = gau_step(d, x[q][j], m[j], v[j]);
-            const float c = __builtin_amdgcn_fmed3f(d, (float)kKeyLo, (float)kKeyHi);
-            const int32_t k = ((int32_t)c << 7) | (127 - cw);
-            // insertion into the sorted five: new_i = med3(old_{i-1}, old_i, k), all five from the
-            // OLD values -- one max and four v_med3_i32, independent of each other
-            const int32_t n4 = med3_i32(k3[q], k4[q], k), n3 = med3_i32(k2[q], k3[q], k),
-                          n2 = med3_i32(k1[q], k2[q], k), n1 = med3_i32(k0[q], k1[q], k);
-            k0[q] = max(k0[q], k); k1[q] = n1; k2[q] = n2; k3[q] = n3; k4[q] = n4;
+                for (int j = 0; j < LEN; ++j) {
+                    const ptm_f2 xx = { x[q][j], x[q + 1][j] };
+                    const ptm_f2 diff = xx - (ptm_f2){ m[j], m[j] };
+                    const ptm_f2 sq = diff * diff;
+                    const ptm_f2 c = sq * (ptm_f2){ v[j], v[j] };
+                    d = d - c;
+                }
+                insert(q, d.x, cw); insert(q + 1, d.y, cw);
+            }
+        }
+        else {
+#pragma unroll
+            for (int q = 0; q < FPL; ++q) {
+                float d = dt;
+#pragma unroll
+                for (int j = 0; j < LEN; ++j)
+                    d = gau_step(d, x[q][j], m[j], v[j]);
+                insert(q, d, cw);
+            }
         }
     }
 #pragma unroll
@@ -825,7 +850,8 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         if (ws->count_dirty)                 // normally the senone kernel of the previous call zeroed it
             PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
         ws->count_dirty = 1;
-        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 1; }();
+        // two frames per lane: the packed single-precision form of the distance (PSGPU_LANE_FPL=1: one frame, scalar form)
+        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 2; }();
         const long long n_tiles = ((long long)total_frames + 64 * fpl - 1) / (64 * fpl);
         const long long lw = n_tiles * m->n_chain;
         if (m->timing) hipEventRecord(m->ev[0], st);

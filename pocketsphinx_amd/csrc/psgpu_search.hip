@@ -85,6 +85,8 @@ struct FtDev {
 
 struct FtBufs {
     int32_t *slab, *bp, *bss, *idx, *step, *res, *w1_out;
+    const int32_t *mpx_in;               // session state: per utterance [(R + n1)][n_emit] per-state ssids of the multiplexed channels, or NULL
+    int32_t *mpx_out;
     long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][32] cycles per phase (tools/build_prof_lib.py)
     int32_t bp_cap, bss_cap, max_frames;
 };
@@ -617,6 +619,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[i] = penalties[(size_t)pen_frame(0) * n_ci + i];
     }
     __syncthreads();
+    // a session's second and later utterances: the multiplexed permanent channels (roots, single-phone words) start with the
+    // per-state ssids the previous utterance left -- hmm_clear (hmm.c:181-196) resets scores and histories only, and a
+    // state's ssid decides which senone the search lists for it
+    if (bf.mpx_in) {
+        const int32_t *const mi = psgpu_as_global(bf.mpx_in) + (size_t)blockIdx.x * (R + n1) * NE;
+        for (int i = tid; i < (R + n1) * NE; i += NT) {
+            const int q = i / NE, c = q < R ? q : W1 + (q - R);
+            if (q < R || w1_mpx[q - R]) tv.at(c, F::SENID + i % NE) = mi[i];
+        }
+    }
     if (tid == 0) ch_enter<NE>(tv, W1 + w1_of_word[p.startwid], 0, -1, 0);
     __syncthreads();
 
@@ -1309,6 +1321,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     }
     // what the second pass inherits besides the tables: the permanent single-phone channels keep their per-state ssids
     // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)
+    if (bf.mpx_out) {
+        int32_t *const mo = psgpu_as_global(bf.mpx_out) + (size_t)blockIdx.x * (R + n1) * NE;
+        for (int i = tid; i < (R + n1) * NE; i += NT) {
+            const int q = i / NE;
+            mo[i] = tv.at(q < R ? q : W1 + (q - R), F::SENID + i % NE);
+        }
+    }
     if (bf.w1_out) {
         int32_t *const w1o = psgpu_as_global(bf.w1_out);
         for (int i = tid; i < n1 * NE; i += NT)
@@ -1541,6 +1560,20 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
                              int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
                              int32_t pl_window, int32_t *w1_ssid_out_dev, void *stream)
 {
+    return psgpu_fwdtree_search_session_dev(m, senscr_dev, scr_stride, penalties_dev, utt_off_dev, n_utt, max_frames, bp_cap, bss_cap,
+                                            bp_dev, bss_dev, idx_dev, step_dev, result_dev, raw_scores, pl_window, w1_ssid_out_dev,
+                                            nullptr, nullptr, stream);
+}
+
+int32_t psgpu_fwdtree_n_mpx_channels(const psgpu_fwdtree_t *m) { return m ? m->d.R + m->d.n1 : 0; }
+
+int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
+                                     const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                     int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                                     int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
+                                     int32_t pl_window, int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev,
+                                     int32_t *mpx_ssid_out_dev, void *stream)
+{
     PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0, "psgpu_fwdtree_search_dev: bad argument");
     PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
                   m->d.n_sen, kFtMaxSen);
@@ -1561,6 +1594,7 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
     FtBufs bf;
     bf.slab = m->slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
     bf.w1_out = w1_ssid_out_dev;
+    bf.mpx_in = mpx_ssid_in_dev; bf.mpx_out = mpx_ssid_out_dev;
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
     PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));

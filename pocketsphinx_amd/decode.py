@@ -86,6 +86,11 @@ class DecodePipeline:
         capi.check(capi.lib().psgpu_decode_last_stage_ms(self.h, ms), "psgpu_decode_last_stage_ms")
         return dict(zip(("front_end", "features", "scorer", "phone_loop", "search", "backtrace"), [float(v) for v in ms]))
 
+    def session(self, on=True):
+        """psgpu_decode_session: on -- every following one-utterance call continues the decoder session (the scorer's seeding
+        history slot, the multiplexed permanent channels' per-state ssids); calling it again forgets the state"""
+        capi.check(capi.lib().psgpu_decode_session(self.h, int(bool(on))), "psgpu_decode_session")
+
     def run_dev(self, pcm_dev, samp_off, stream=None):
         """pcm_dev: torch int16 tensor on the device (utterances back to back), samp_off: int64 numpy [n_utt + 1].
         Asynchronous on `stream` (default: torch's current stream)."""

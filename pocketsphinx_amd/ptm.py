@@ -19,12 +19,24 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def expand_clustered_mixw(mixw4, mixw_cb, n_sen):
+    """The one-byte-per-senone weights of a clustered sendump, as ptm_mgau_senone_eval looks them up (ptm_mgau.c:375-379):
+        dcw = row[sen / 2];  dcw = (dcw & 1) ? dcw >> 4 : dcw & 0x0f;  weight = mixw_cb[dcw]
+    The nibble is chosen by the low bit of the BYTE (not of the senone): both senones of a byte get the same weight.  A
+    per-(stream, density, senone) constant, expanded once; integration/psgpu_mgau_shim.c does the same from ptm_mgau_t."""
+    rows = np.ascontiguousarray(mixw4, np.uint8)
+    dcw = np.where(rows & 1, rows >> 4, rows & 0x0f)
+    w = np.ascontiguousarray(mixw_cb, np.uint8)[dcw]            # [n_feat][n_density][(n_sen + 1) / 2]
+    return np.ascontiguousarray(np.repeat(w, 2, axis=-1)[..., :n_sen])
+
+
 class PtmModel:
     def __init__(self, tables, topn=None, ds_ratio=None):
         L = capi.lib()
         t = tables
-        if "mixw_cb" in t or int(np.asarray(t.get("mixw_is_4bit", [0])).ravel()[0]):
-            raise capi.PsgpuError("4-bit clustered sendumps are not supported by libpsgpu")
+        if "mixw_cb" in t:
+            t = dict(t)
+            t["mixw"] = expand_clustered_mixw(t["mixw"], t["mixw_cb"], int(t["n_sen"][0]))
         self.n_mgau = int(t["n_mgau"][0]); self.n_feat = int(t["n_feat"][0])
         self.n_density = int(t["n_density"][0]); self.n_sen = int(t["n_sen"][0])
         self.topn = int(topn if topn is not None else t["max_topn"][0])

@@ -68,8 +68,11 @@ class FwdtreeSearch:
                    "psgpu_fwdtree_backtrace_dev")
         return hyp.cpu().numpy(), hn.cpu().numpy()
 
-    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None):
-        """senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back (numpy arrays, or
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None,
+               mpx_in=None, mpx_out=None):
+        """mpx_in: [n][n_mpx][n_emit] int32 per-state ssids the permanent multiplexed channels start with (a session's carry-over,
+        psgpu_fwdtree_search_session_dev) or None = a fresh decoder; mpx_out: a dict that receives {"mpx": the ssids they end with}.
+        senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back (numpy arrays, or
         torch tensors already on the device).  raw_scores: un-normalised rows + phone-loop output, see psgpu.h.
         handover: a dict that receives the device buffers a second pass takes over (FwdflatSearch.search(bp1=...)).
         Returns a list of dicts (bp [n][10], bscore_stack, bp_table_idx, step [frames][4], status) per utterance."""
@@ -94,12 +97,20 @@ class FwdtreeSearch:
         if handover is not None:
             w1 = torch.zeros((n, int(self._keep["par"][6]), int(self._keep["par"][1])), dtype=torch.int32, device=dev)
             handover.update(bp=bp, result=res, w1_ssid=w1, idx=idx, bp_cap=bp_cap, max_frames=mf)
-        capi.check(capi.lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap,
-                                                       bss_cap, p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)),
-                                                       int(pl_window), p(w1) if w1 is not None else None,
-                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   "psgpu_fwdtree_search_dev")
+        n_mpx = int(capi.lib().psgpu_fwdtree_n_mpx_channels(self.h)); ne = int(self._keep["par"][1])
+        d_mi = d_mo = None
+        if mpx_in is not None:
+            d_mi = torch.from_numpy(np.ascontiguousarray(mpx_in, np.int32).reshape(n, n_mpx, ne)).to(dev)
+        if mpx_out is not None:
+            d_mo = torch.zeros((n, n_mpx, ne), dtype=torch.int32, device=dev)
+        capi.check(capi.lib().psgpu_fwdtree_search_session_dev(
+            self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
+            int(bool(raw_scores)), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
+            p(d_mo) if d_mo is not None else None, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            "psgpu_fwdtree_search_session_dev")
         torch.cuda.current_stream().synchronize()       # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel
+        if mpx_out is not None:
+            mpx_out["mpx"] = d_mo.cpu().numpy()
         out = []
         if n == 0:
             return out

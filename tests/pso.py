@@ -164,6 +164,41 @@ def row_hash(a):
     return h
 
 
+def clustered_tables(tables, g):
+    """the en-us tables with the 4-bit clustered mixture weights of a ptm_4bit_* golden"""
+    t = dict(tables)
+    t["mixw"] = np.ascontiguousarray(g["mixw4"], np.uint8)
+    t["mixw_cb"] = np.ascontiguousarray(g["mixw_cb"], np.uint8)
+    t["mixw_is_4bit"] = np.array([1], np.int32)
+    return t
+
+
+def write_clustered_model_dir(dst, src_model, g):
+    """a copy (symlinks) of an acoustic model directory whose sendump holds the 4-bit clustered weights of a
+    ptm_4bit_* golden, in the layout read_sendump (ptm_mgau.c:457-654) reads"""
+    import struct
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src_model):
+        if f != "sendump":
+            os.symlink(os.path.join(src_model, f), os.path.join(dst, f))
+    packed, cb = np.ascontiguousarray(g["mixw4"], np.uint8), np.ascontiguousarray(g["mixw_cb"], np.uint8)
+    n_feat, n_den, _ = packed.shape
+
+    def lstr(txt):
+        b = txt.encode() + b"\0"
+        return struct.pack("<i", len(b)) + b
+    with open(os.path.join(dst, "sendump"), "wb") as fh:
+        fh.write(lstr("V6 Senone Probs, Smoothed, Normalized"))
+        fh.write(lstr("(HMM file format)"))
+        for h in ("feature_count %d" % n_feat, "mixture_count %d" % n_den, "model_count %d" % int(g["senscr_sample"].shape[1]),
+                  "cluster_count %d" % cb.size, "cluster_bits 4", "logbase 1.0001", "mixw_shift 10"):
+            fh.write(lstr(h))
+        fh.write(struct.pack("<i", 0))
+        fh.write(cb.tobytes())
+        fh.write(packed.tobytes())
+    return dst
+
+
 HMM_FIELDS = 19   # score[5] history[5] out_score out_history senid[5] bestscore tmatid (ref_dump.c hmm_pack)
 
 
@@ -405,6 +440,17 @@ class OracleFwdtree:
 
     def start(self):
         lib().pso_ft_start(self.h)
+
+    def set_mpx_ssids(self, ssid):
+        a = np.ascontiguousarray(ssid, np.int32)
+        lib().pso_ft_set_mpx_ssids.argtypes = [C.c_void_p, C.c_void_p]
+        lib().pso_ft_set_mpx_ssids(self.h, _p(a))
+
+    def get_mpx_ssids(self, shape):
+        a = np.zeros(shape, np.int32)
+        lib().pso_ft_get_mpx_ssids.argtypes = [C.c_void_p, C.c_void_p]
+        lib().pso_ft_get_mpx_ssids(self.h, _p(a))
+        return a
 
     def active_list(self, frame):
         n = lib().pso_ft_active_list(self.h, int(frame), _p(self._buf))

@@ -104,8 +104,10 @@ class SimFwdtreeSearch:
             lib().psgpu_fwdtree_free(self.h)
             self.h = C.c_void_p()
 
-    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None):
-        """handover: a dict that receives the buffers a second pass takes over (bp [n][10][cap], result [n][8], w1_ssid)"""
+    def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None,
+               mpx_in=None, mpx_out=None):
+        """handover: a dict that receives the buffers a second pass takes over (bp [n][10][cap], result [n][8], w1_ssid);
+        mpx_in / mpx_out: the session carry-over, as FwdtreeSearch.search"""
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
         n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
         d_s = np.ascontiguousarray(senscr, np.int16); d_p = np.ascontiguousarray(penalties, np.int32)
@@ -117,10 +119,17 @@ class SimFwdtreeSearch:
         if handover is not None:
             w1 = np.zeros((n, self.n1, self.n_emit), np.int32)
             handover.update(bp=bp, result=res, w1_ssid=w1, bp_cap=bp_cap)
-        check(lib().psgpu_fwdtree_search_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
-                                             p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window),
-                                             p(w1) if w1 is not None else None, None),
-              "psgpu_fwdtree_search_dev")
+        lib().psgpu_fwdtree_n_mpx_channels.argtypes = [C.c_void_p]
+        n_mpx = int(lib().psgpu_fwdtree_n_mpx_channels(self.h))
+        mi = None if mpx_in is None else np.ascontiguousarray(mpx_in, np.int32).reshape(n, n_mpx, self.n_emit)
+        mo = None if mpx_out is None else np.zeros((n, n_mpx, self.n_emit), np.int32)
+        check(lib().psgpu_fwdtree_search_session_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
+                                                     p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window),
+                                                     p(w1) if w1 is not None else None, p(mi) if mi is not None else None,
+                                                     p(mo) if mo is not None else None, None),
+              "psgpu_fwdtree_search_session_dev")
+        if mpx_out is not None:
+            mpx_out["mpx"] = mo
         self.last = dict(bp=bp, idx=idx, res=res, mf=mf, bp_cap=bp_cap)
         out = []
         for u in range(n):

@@ -60,6 +60,32 @@ def test_pipeline_tables_equal_the_reference_decoders(tables):
     p.close()
 
 
+def test_pipeline_session_second_utterance_equals_the_reference_decoders(tables):
+    """session mode (psgpu_decode_session): numbers.raw then goforward.raw through ONE pipeline object, one utterance per
+    call.  The reference's decoder, having decoded numbers.raw first, produces other tables for goforward.raw than a new
+    decoder does (golden goforward_after_numbers, oracle/make_golden.py session: the multiplexed permanent channels' per-state
+    ssids and the scorer's seeding lists carry over); so must the pipeline -- and without session mode it must not."""
+    clips = _load("speech_clips.npz")
+    g_new, g_sess = _load("fwdtree_trace_goforward.npz"), _load("fwdtree_trace_goforward_after_numbers.npz")
+    assert not np.array_equal(g_new["bp"], g_sess["bp"]) if g_new["bp"].shape == g_sess["bp"].shape else True
+    p = _pipeline(tables)
+
+    def one(name, g):
+        p.run([clips[name]])
+        _, _, res = p.fetch()
+        r = p.tables(0, res)
+        r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+        return r
+    p.session(True)
+    _check(one("numbers", _load("fwdtree_trace_numbers.npz")), _load("fwdtree_trace_numbers.npz"), "first of the session")
+    _check(one("goforward", g_sess), g_sess, "second of the session")
+    p.session(True)                                    # a new session: the first utterance is a new decoder's again
+    _check(one("goforward", g_new), g_new, "first of a new session")
+    p.session(False)
+    _check(one("goforward", g_new), g_new, "no session")
+    p.close()
+
+
 @pytest.mark.parametrize("seconds,ids", [(30.0, (0, 3, 511)), (60.0, (7,))])
 def test_pipeline_equals_the_reference_on_synthetic_utterances(tables, tmp_path, seconds, ids):
     """BASELINE configs[4] / configs[2] material: the benchmark's synthetic utterances, decoded by the compiled reference

@@ -93,6 +93,20 @@ def test_dropin_decode_identical(case, tmp_path):
         assert r["hyp_gpu"] == "go forward ten meters"
 
 
+@pytest.mark.gpu
+def test_dropin_clustered_4bit_sendump(tmp_path):
+    """an acoustic model whose sendump is 4-bit clustered (read_sendump, ptm_mgau.c:457-654): the shim expands the
+    weights as ptm_mgau_senone_eval looks them up (:375-379, nibble chosen by the low bit of the byte) -- every
+    frame_eval call's scores, hypothesis and segmentation equal the CPU scorer's on the same model"""
+    import numpy as np
+    g = np.load(os.path.join(pso.GOLDEN_DIR, "ptm_4bit_goforward.npz"))
+    model = pso.write_clustered_model_dir(str(tmp_path / "en-us-4bit"), MODEL, g)
+    r = run("goforward.raw", 1, model=model)
+    assert r["mgau"] == "ptm-psgpu" and r["device_calls"] == r["calls_gpu"] > 0, r
+    assert r["calls_cpu"] == r["calls_gpu"] and r["mismatching_calls"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["ok"] and r["rc"] == 0, r
+
+
 FULL_CASES = {
     # name: (raw, nrep, extra) -- decoder B runs GMM scoring AND every hmm_vit_eval loop on the device
     "default_3pass_x2": ("goforward.raw", 2, ()),
@@ -480,6 +494,22 @@ def test_dropin_device_search_vtable(raw, nrep, extra, lm, dic):
     r = run(raw, nrep, "psgpu_device_vtable", "yes", *extra, lm=lm, dic=dic)
     assert r["ok"] and r["rc"] == 0, r
     assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert r["n_seg"] > 0 and r["device_search_frames"] > 0, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [("fwdflat", "no", "bestpath", "no"), ()])
+def test_dropin_device_search_vtable_session(extra, tmp_path):
+    """one decoder, four different utterances one after another through the device ps_searchfuncs_t: what an utterance
+    inherits from the one before -- the per-state ssids of the multiplexed permanent channels (hmm_clear keeps them), the
+    scorer's history slot that seeds frame 0 -- goes through the device pass and back into the reference's structures
+    (integration/psgpu_device_decode.c session_push / session_pull), with and without the reference's own second and third
+    pass in between.  Every utterance's hypothesis, score and segmentation equal the CPU decoder's, which carries the same."""
+    ctl = tmp_path / "session.ctl"
+    ctl.write_text("numbers\ngoforward\nsomething\nnumbers\n")
+    r = run("@%s:%s:raw" % (ctl, DATA), 1, "psgpu_device_vtable", "yes", *extra)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["n_utts"] == 4 and r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
     assert r["n_seg"] > 0 and r["device_search_frames"] > 0, r
 
 

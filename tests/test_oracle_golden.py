@@ -66,6 +66,26 @@ def test_ptm_oracle_matches_reference(tables, case):
         assert np.array_equal(raw, g["topn_raw"])
 
 
+def test_ptm_oracle_clustered_4bit_sendump(tables):
+    """ptm_mgau.c:375-379 on a 4-bit clustered sendump (the en-us weights re-quantised by oracle/make_golden.py ptm4 and
+    scored by the unmodified reference), nibble quirk included; and the expansion the device model is built from
+    (pocketsphinx_amd.ptm.expand_clustered_mixw) gives the same scores through the plain 8-bit path."""
+    from pocketsphinx_amd.ptm import expand_clustered_mixw
+    g = _load("ptm_4bit_goforward.npz")
+    t4 = pso.clustered_tables(tables, g)
+    scr, cw, raw = run_case(pso.OraclePTM(t4), g)
+    idx = g["sample_idx"]
+    assert np.array_equal(cw[idx], g["topn_cw_sample"])
+    assert np.array_equal(scr[idx], g["senscr_sample"])
+    assert np.array_equal(pso.row_hash(scr), g["senscr_hash"])
+    t8 = dict(tables)
+    t8["mixw"] = expand_clustered_mixw(g["mixw4"], g["mixw_cb"], int(tables["n_sen"][0]))
+    scr8, _, _ = run_case(pso.OraclePTM(t8), g)
+    assert np.array_equal(scr8, scr)
+    # the quirk: both senones of a byte get the same weight
+    assert np.array_equal(t8["mixw"][..., 0:-1:2], t8["mixw"][..., 1::2])
+
+
 def test_history_dependence_is_real(tables):
     """a stateless top-N differs from the reference's stateful one
     somewhere (otherwise the carry fixtures pin nothing)."""
@@ -119,12 +139,14 @@ def test_flags2list_bridges_gaps():
     assert list(d[:4]) == [0, 3, 255, 42]
 
 
-@pytest.mark.parametrize("case", ["en_us_3st", "tidigits_5st"])
+@pytest.mark.parametrize("case", ["en_us_3st", "tidigits_5st", "syn_4st", "syn_2st", "syn_1st"])
 def test_hmm_oracle_matches_reference(case):
     """pso_hmm_vit_eval vs the reference's hmm_vit_eval (hmm.c:786-805) on the
     state dumps of oracle/ref_dump.c `hmm`: 3-state (en-us) and 5-state
     (tidigits) topologies, multiplex and not, incl. WORST_SCORE clamps,
-    BAD_SSID states and saturated senone scores."""
+    BAD_SSID states and saturated senone scores; `hmmsyn`: synthetic contexts
+    with 4, 2 and 1 emitting states, which the reference evaluates with
+    hmm_vit_eval_anytopo (hmm.c:710-784)."""
     g = _load("hmm_%s.npz" % case)
     for t in range(g["before"].shape[0]):
         after, ret = pso.hmm_step_oracle(g, t)

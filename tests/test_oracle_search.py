@@ -58,6 +58,49 @@ def test_fwdtree_oracle_matches_reference(case, parallel):
     assert np.array_equal(o.bp_table_idx(nfr), g["bp_table_idx"])
 
 
+def _replay(o, g, check_lists=True):
+    off, act, scr = g["step_act_off"], g["step_act"], g["step_scr"]
+    for i in range(int(g["n_steps"][0])):
+        fr = int(g["step_frame"][i])
+        a0, a1 = int(off[i]), int(off[i + 1])
+        if check_lists and not np.array_equal(o.active_list(fr), act[a0:a1]):
+            return "frame %d: active senone list" % fr
+        o.step(fr, act[a0:a1], scr[a0:a1], int(g["step_rest"][i]), g["step_pen"][i])
+    nfr = int(g["n_frame"][0])
+    o.finish(nfr)
+    if not (np.array_equal(o.bp_table(), g["bp"]) and np.array_equal(o.bscore_stack(), g["bscore_stack"])):
+        return "tables"
+    return None
+
+
+@pytest.mark.parametrize("case,first", [("goforward_after_numbers", "numbers"), ("numbers_after_something", None)])
+def test_fwdtree_oracle_second_utterance_of_a_session(case, first):
+    """The reference's decoder decoded another utterance first (oracle/make_golden.py session): its multiplexed permanent
+    channels start with the per-state ssids that utterance left (hmm_clear, hmm.c:181-196, keeps them; `mpx_init` in the
+    golden), which changes the senones listed per frame.  A new oracle object given those ssids reproduces the trace; a new
+    one without them does not; one that decoded the first utterance itself carries them without being told."""
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    o = pso.OracleFwdtree(st, g["par"])
+    o.start()
+    o.set_mpx_ssids(g["mpx_init"])
+    assert _replay(o, g) is None
+    o2 = pso.OracleFwdtree(st, g["par"])
+    o2.start()
+    assert _replay(o2, g) is not None          # a fresh decoder lists other senones
+    if first:
+        g1 = _load("fwdtree_trace_%s.npz" % first)
+        o3 = pso.OracleFwdtree(st, g["par"])
+        o3.start()
+        assert _replay(o3, g1) is None
+        mpx = np.asarray(st["w1_mpx"]) != 0
+        R = int(g["par"][4])
+        got, want = o3.get_mpx_ssids(g["mpx_init"].shape), g["mpx_init"]
+        assert np.array_equal(got[:R], want[:R]) and np.array_equal(got[R:][mpx], want[R:][mpx])
+        o3.start()
+        assert _replay(o3, g) is None
+
+
 def make_big_trace(out_dir):
     """`ref_dump fwdtree` of the compiled reference on the large-vocabulary task (too large to commit, ~10 s to make);
     None when oracle/_ref is not built"""

@@ -42,6 +42,24 @@ def test_golden_fresh_state(tables, gpu_model, case):
     assert np.array_equal(pso.row_hash(r["senscr"]), g["senscr_hash"])
 
 
+def test_clustered_4bit_sendump(tables):
+    """a 4-bit clustered sendump (read_sendump, ptm_mgau.c:457-654; the weight look-up with its nibble selection by
+    the low bit of the BYTE, :375-379): the device model is built from the expanded weights"""
+    import pocketsphinx_amd as P
+    g = _load("ptm_4bit_goforward.npz")
+    t4 = pso.clustered_tables(tables, g)
+    m = P.PtmModel(t4)
+    T = g["feat"].shape[0]
+    r = P.PtmMgau(m).score_utts(g["feat"], [T])
+    idx = g["sample_idx"]
+    assert np.array_equal(r["senscr"][idx], g["senscr_sample"])
+    assert np.array_equal(pso.row_hash(r["senscr"]), g["senscr_hash"])
+    # and not what the plain 8-bit model gives
+    r8 = P.PtmMgau(P.PtmModel(tables)).score_utts(g["feat"], [T])
+    assert not np.array_equal(r8["senscr"], r["senscr"])
+    m.close()
+
+
 def test_golden_carry_over(tables, gpu_model):
     """the second utterance is seeded with the first one's final
     top-N codewords (seed_cw in/out of the C ABI)."""
@@ -182,12 +200,8 @@ def test_two_host_threads_score_concurrently_on_one_model(tables):
     import torch
     import pocketsphinx_amd as P
     from pocketsphinx_amd import capi
-    g = _golden("ptm_dup_ties") if "_golden" in globals() else None
-    z = np.load(os.path.join(pso.GOLDEN_DIR, "ptm_dup_ties.npz"))
-    t2 = dict(tables)
-    for k in ("mean", "var", "det"):
-        if k in z.files:
-            t2[k] = z[k]
+    z = _load("ptm_dup_ties.npz")
+    t2 = dup_tables(tables)
     feats = np.ascontiguousarray(z["feat"], np.float32)
     o = pso.OraclePTM(t2)
     n = feats.shape[0]

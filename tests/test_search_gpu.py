@@ -51,6 +51,29 @@ def test_fwdtree_kernel_matches_reference(case):
     s.close()
 
 
+def test_fwdtree_kernel_second_utterance_of_a_session():
+    """psgpu_fwdtree_search_session_dev on the device: as tests/test_search_hostsim.py's session test (the reference's
+    decoder had decoded numbers.raw before goforward.raw; raw-score mode, the kernel lists the senones itself)"""
+    import pocketsphinx_amd as P
+    from test_search_hostsim import _raw_rows
+    g = _load("fwdtree_trace_goforward_after_numbers.npz")
+    g1 = _load("fwdtree_trace_numbers.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    s = P.FwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    raw = _raw_rows(g, rows)
+    _check(s.search(raw, pen, [rows.shape[0]], raw_scores=True, pl_window=0, mpx_in=g["mpx_init"][None])[0], g, "session")
+    rows1, pen1 = _inputs(g1, s.n_sen)
+    out = {}
+    _check(s.search(_raw_rows(g1, rows1), pen1, [rows1.shape[0]], raw_scores=True, pl_window=0, mpx_out=out)[0], g1, "first")
+    R = int(g["par"][4]); mpx = np.asarray(st["w1_mpx"]) != 0
+    assert np.array_equal(out["mpx"][0][:R], g["mpx_init"][:R]) and np.array_equal(out["mpx"][0][R:][mpx], g["mpx_init"][R:][mpx])
+    both = s.search(np.concatenate([raw, raw]), np.concatenate([pen, pen]), [rows.shape[0]] * 2, raw_scores=True, pl_window=0,
+                    mpx_in=np.stack([g["mpx_init"], out["mpx"][0]]))
+    _check(both[0], g, "batch 0"); _check(both[1], g, "batch 1")
+    s.close()
+
+
 def test_fwdtree_kernel_batch_of_utterances():
     """Several utterances in one launch (one workgroup each): every one equals its own golden."""
     import pocketsphinx_amd as P

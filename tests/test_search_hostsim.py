@@ -108,6 +108,46 @@ def test_simulated_device_trie_equals_reference_look_ups(name):
     lm.close()
 
 
+def _raw_rows(g, rows, seed=5):
+    """the reference's normalised scores plus an arbitrary per-frame offset in the listed senones, garbage elsewhere"""
+    rng = np.random.default_rng(seed)
+    off, act = g["step_act_off"], g["step_act"]
+    raw = rng.integers(-30000, 30000, rows.shape).astype(np.int16)
+    for i in range(rows.shape[0]):
+        a = act[off[i]:off[i + 1]]
+        raw[i, a] = (rows[i, a].astype(np.int32) + int(rng.integers(-2000, 2000))).astype(np.int16)
+    return raw
+
+
+@pytest.mark.parametrize("layout", ["slab", "lds"])
+def test_search_kernel_source_second_utterance_of_a_session(layout):
+    """psgpu_fwdtree_search_session_dev: the reference's decoder had decoded numbers.raw before goforward.raw (golden
+    goforward_after_numbers; oracle/make_golden.py session).  In raw-score mode the kernel lists the senones itself, so it
+    must start from the per-state ssids the first utterance left in the multiplexed permanent channels: given the golden's
+    `mpx_init` it reproduces the trace, without it it does not; and the ssids the kernel itself ends numbers.raw with are
+    those the reference's decoder had."""
+    g = _load("fwdtree_trace_goforward_after_numbers.npz")
+    g1 = _load("fwdtree_trace_numbers.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    with _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    raw = _raw_rows(g, rows)
+    _check(s.search(raw, pen, [rows.shape[0]], raw_scores=True, pl_window=0, mpx_in=g["mpx_init"][None])[0], g, "session")
+    fresh = s.search(raw, pen, [rows.shape[0]], raw_scores=True, pl_window=0)[0]
+    assert fresh["bp"].shape != g["bp"].shape or not np.array_equal(fresh["bp"], g["bp"])
+    rows1, pen1 = _inputs(g1, s.n_sen)
+    out = {}
+    _check(s.search(_raw_rows(g1, rows1), pen1, [rows1.shape[0]], raw_scores=True, pl_window=0, mpx_out=out)[0], g1, "first")
+    R = int(g["par"][4]); mpx = np.asarray(st["w1_mpx"]) != 0
+    assert np.array_equal(out["mpx"][0][:R], g["mpx_init"][:R]) and np.array_equal(out["mpx"][0][R:][mpx], g["mpx_init"][R:][mpx])
+    # two utterances of one call are independent: each starts from its own input state
+    both = s.search(np.concatenate([raw, raw]), np.concatenate([pen, pen]), [rows.shape[0]] * 2, raw_scores=True, pl_window=0,
+                    mpx_in=np.stack([g["mpx_init"], out["mpx"][0]]))
+    _check(both[0], g, "batch 0"); _check(both[1], g, "batch 1")
+    s.close()
+
+
 @pytest.mark.parametrize("layout", ["slab", "lds"])
 @pytest.mark.parametrize("case", ["goforward", "numbers", "medium_goforward"])
 def test_search_kernel_source_building_its_own_active_lists(case, layout):
