@@ -189,6 +189,12 @@ int32_t psgpu_fe_out_dim(const psgpu_fe_t *fe);
  * frame of fe_end_utt (always present when n_samples > 0) */
 int64_t psgpu_fe_n_frames(const psgpu_fe_t *fe, int64_t n_samples);
 
+/* The front end's only libm call is log(mel spectrum + 1e-4) (fe_sigproc.c:1215-1228), double precision; everything else on
+ * the path is +, -, *, / in the reference's order and so bit-identical by construction.  out_dev[i] = log(x_dev[i]) as the
+ * device computes it there -- for tests/test_fe_gpu.py, which holds it against the host's libm over the mel spectrum's
+ * value range (2^24 samples and every value of the goldens). */
+int psgpu_fe_log_dev(const double *x_dev, int64_t n, double *out_dev, void *stream);
+
 /* pcm_dev: samples of n_utt utterances back to back; samp_off [n_utt + 1] HOST array of
  * sample offsets.  cep_dev [total_frames][out_dim]; frame_off_dev [n_utt + 1] receives the
  * frame offsets (the utt_off_dev of psgpu_feat_1s_c_d_dd_dev / psgpu_ptm_score_batch_dev),
@@ -656,10 +662,13 @@ int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
  * decodes utterances one after another carries state from each into the next: the PTM scorer's top-N lists (the first
  * frame of utterance k + 1 is seeded with the last lists of utterance k) and the per-state ssids of the
  * search's permanent multiplexed channels (psgpu_fwdtree_search_session_dev).  on != 0: every following call with
- * n_utt == 1 continues where the previous such call ended -- the object then behaves as one ps_decoder_t fed through
- * psgpu_decode_first_pass_feat (the front end's and the feature module's own carry-over -- noise tracker, live CMN -- is
- * the caller's: the ps_search_t binding takes its feature vectors from the reference's acmod).  Calling it again (on or
- * off) forgets the state: the next utterance is a new decoder's first.  Calls with n_utt != 1 neither use nor change it. */
+ * n_utt == 1 continues where the previous such call ended -- the object then behaves as one ps_decoder_t between two
+ * ps_start_stream calls.  From PCM (psgpu_decode_first_pass[_dev]) the front end's noise tracker is carried as well
+ * (noise_stats_t lives until ps_start_stream: fe_start_utt, fe_interface.c:318-326, does not reset it; the bundled
+ * models' -cmn batch carries nothing); from feature vectors (psgpu_decode_first_pass_feat) what the front end and the
+ * feature module carry is the caller's -- the ps_search_t binding takes its vectors from the reference's acmod.  Calling
+ * it again (on or off) forgets the state: the next utterance is a new decoder's first.  Calls with n_utt != 1 neither
+ * use nor change it. */
 int psgpu_decode_session(psgpu_decode_t *d, int32_t on);
 /* The session's state on the host, for a caller whose decoder also runs passes elsewhere (the reference's own second pass
  * re-scores the utterance and evaluates the single-phone channels again: what the next utterance inherits is then what
@@ -756,6 +765,24 @@ typedef struct psgpu_ptm_view_s {
     int32_t featlen[16], featoff[16];
 } psgpu_ptm_view_t;
 int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out);
+
+/* The lexicon-tree search scoring its own senones.  The reference's first pass asks the scorer for the senones of its
+ * active channels only -- some 400 of en-us's 5126 per frame (ptm_mgau_frame_eval with the search's active list,
+ * ptm_mgau.c:408-454) -- and so does this entry: instead of score rows it takes what the batched scorer's FIRST step
+ * leaves, the top-N lists of every (codebook, stream) chain and frame (psgpu_ptm_score_batch_dev's topn_score_dev /
+ * topn_cw_dev, chain-major, computed with senscr_dev = NULL), and evaluates ptm_mgau_codebook_norm (:265-295) and
+ * ptm_mgau_senone_eval (:326-403) for the listed senones inside the kernel, frame by frame (csrc/psgpu_sen_dev.h).  The
+ * full rows -- 10 KB per frame written by the senone kernel and read back -- never exist.  Everything else as
+ * psgpu_fwdtree_search_session_dev with raw_scores = 1 (the frame's normaliser is the minimum over the listed senones,
+ * bridging entries included; penalties_dev from psgpu_phone_loop_run_lists_dev).  Needs the LDS layout and a scorer of
+ * 3 streams x top-4 with at most 128 chains: psgpu_fwdtree_can_score_lists says whether this model pair qualifies. */
+int32_t psgpu_fwdtree_can_score_lists(const psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v);
+int psgpu_fwdtree_search_lists_dev(psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v, const int32_t *topn_score_dev,
+                                   const uint8_t *topn_cw_dev, int32_t total_frames,
+                                   const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                   int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                                   int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t pl_window,
+                                   int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev, int32_t *mpx_ssid_out_dev, void *stream);
 int psgpu_fwdflat_search_feats_dev(psgpu_fwdflat_t *m, const psgpu_ptm_view_t *ptm, const float *feats_dev,
                                    const int32_t *topn_seed_dev, const int32_t *utt_off_dev, int32_t n_utt,
                                    int32_t max_frames, int32_t bp1_cap, const int32_t *bp1_dev,

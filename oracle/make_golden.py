@@ -143,7 +143,7 @@ def ptm_4bit():
     cb, packed = write_clustered_sendump(os.path.join(d, "sendump"), t["mixw"])
     tt = ref_dump("tables", model=d)
     assert int(tt["mixw_is_4bit"][0]) == 1 and np.array_equal(tt["mixw"], packed) and np.array_equal(tt["mixw_cb"], cb)
-    ptm_case("4bit_goforward", gof[:120], 120, 0, sample=24, model=d, more=dict(mixw4=packed, mixw_cb=cb))
+    ptm_case("4bit_goforward", gof, gof.shape[0], 0, sample=24, model=d, more=dict(mixw4=packed, mixw_cb=cb))
 
 
 def senlog_case(name, nrep, extra=(), inp=None, **kw):

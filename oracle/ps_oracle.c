@@ -1108,6 +1108,15 @@ pso_hmm_vit_eval(const pso_hmm_ctx_t *ctx, pso_hmm_t *h)
     return vit_any(ctx, h);
 }
 
+/* the host's libm log over an array: what the reference's fe_mel_cep calls per mel channel (fe_sigproc.c:1215-1228).
+ * (numpy's log is its own vector routine, not libm: tests that pin the device's log call this.) */
+void
+pso_libm_log(const double *x, int64_t n, double *out)
+{
+    int64_t i;
+    for (i = 0; i < n; ++i) out[i] = log(x[i]);
+}
+
 /* ====================================================================== */
 /* MFCC front end                                                         */
 /* ====================================================================== */

@@ -179,6 +179,9 @@ int pso_fe_n_frames(const pso_fe_t *fe, long n);
 int pso_fe_process_utt(const pso_fe_t *fe, const int16_t *pcm, long n, float *cep,
                        double *noise, int32_t *undefined);
 
+/* libm's log over an array (the front end's one transcendental) */
+void pso_libm_log(const double *x, int64_t n, double *out);
+
 /* ---------------- shared helpers ---------------- */
 
 /* acmod_flags2list (acmod.c:1223-1275): bit flags -> uint8 delta list.

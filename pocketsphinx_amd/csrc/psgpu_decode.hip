@@ -29,9 +29,11 @@ struct psgpu_decode_s {
     // a decoder session (psgpu_decode_session): what utterance k + 1 of ONE reference decoder inherits from utterance k --
     // the scorer's last top-N lists (the seeds of the next first frame, ptm_mgau.c) and the per-state ssids of the permanent
     // multiplexed channels (hmm_clear keeps them)
-    bool session = false, sess_started = false, seed_valid = false;
+    bool session = false, sess_started = false, seed_valid = false, fe_fresh = true;
     uint8_t *d_seed = nullptr;
     int32_t *d_mpx = nullptr;
+    double *d_noise = nullptr;           // the front end's noise tracker (noise_stats_t: kept until ps_start_stream, not reset per utterance)
+    int32_t *d_undef = nullptr;
     // the last call
     int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
     std::vector<int32_t> frame_off;
@@ -96,7 +98,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
-    DFREE(d->d_seed); DFREE(d->d_mpx);
+    DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_noise); DFREE(d->d_undef);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     delete d;
 }
@@ -105,16 +107,20 @@ int psgpu_decode_session(psgpu_decode_t *d, int32_t on)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_session: NULL argument");
     d->session = on != 0;
-    d->sess_started = false; d->seed_valid = false;
+    d->sess_started = false; d->seed_valid = false; d->fe_fresh = true;
     return PSGPU_OK;
 }
 
 static int dec_session_buffers(psgpu_decode_s *d)
 {
     int rc;
-    if (!d->d_seed && ((rc = dec_alloc((void **)&d->d_seed, (size_t)d->n_chain * d->topn))
-                       || (rc = dec_alloc((void **)&d->d_mpx, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))))
-        return rc;
+    if (!d->d_seed) {
+        if ((rc = dec_alloc((void **)&d->d_seed, (size_t)d->n_chain * d->topn))
+            || (rc = dec_alloc((void **)&d->d_mpx, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))
+            || (rc = dec_alloc((void **)&d->d_noise, 8 * 4 * 64)) || (rc = dec_alloc((void **)&d->d_undef, 4)))
+            return rc;
+        d->fe_fresh = true;
+    }
     return PSGPU_OK;
 }
 
@@ -262,7 +268,20 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     d->ev_valid = false;
     dec_mark(d, 0, st);
-    if ((rc = psgpu_fe_process_utts_dev(d->cfg.fe, pcm_dev, samp_off, n_utt, nullptr, nullptr, d->d_cep, d->d_off, d->frame_off.data(), st)))
+    // session: the noise tracker of the reference's front end lives until ps_start_stream (fe_start_utt, fe_interface.c:318-326,
+    // does not reset it): utterance k + 1's spectra are cleaned with what utterance k left
+    const bool sess = d->session && n_utt == 1;
+    if (sess) {
+        if ((rc = dec_session_buffers(d))) return rc;
+        if (d->fe_fresh) {
+            const int32_t one = 1;                           // "undefined": initialise from the first frame (fe_reset_noisestats)
+            PSGPU_HIP(hipMemcpyAsync(d->d_undef, &one, 4, hipMemcpyHostToDevice, st));
+            PSGPU_HIP(hipStreamSynchronize(st));
+            d->fe_fresh = false;
+        }
+    }
+    if ((rc = psgpu_fe_process_utts_dev(d->cfg.fe, pcm_dev, samp_off, n_utt, sess ? d->d_noise : nullptr, sess ? d->d_undef : nullptr,
+                                        d->d_cep, d->d_off, d->frame_off.data(), st)))
         return rc;
     dec_mark(d, 1, st);
     if (total == 0) {                                   // nothing but empty utterances: empty results

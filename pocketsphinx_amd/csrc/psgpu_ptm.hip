@@ -484,14 +484,6 @@ __device__ __forceinline__ int32_t logadd8_lds(const uint8_t *s_la, int32_t x, i
     return lo - (int32_t)s_la[d];
 }
 
-// |a - b| in one VALU op (v_sad_u32 with a zero accumulator)
-__device__ __forceinline__ int32_t abs_diff_u32(int32_t a, int32_t b)
-{
-    int32_t d;
-    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
 template <int ITERS, int kSenFr>                // kSenFr = frames per workgroup
 __global__ __launch_bounds__(512)
 void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
@@ -600,7 +592,9 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                                 const int32_t y = (int32_t)((w[f][k] >> (8 * b)) & 0xff) +
                                                   (int32_t)((nsc[f] >> (8 * k)) & 0xff);
                                 lo_[b][f] = min(fden[b][f], y);
-                                dd[b][f] = abs_diff_u32(fden[b][f], y);
+                                // (signed: a running sum goes below zero when a small weight meets the best codeword --
+                                //  min - T[d] with min < T[d]; an unsigned |a - b| would then index far outside the table)
+                                dd[b][f] = max(fden[b][f], y) - lo_[b][f];
                             }
 #pragma unroll
                         for (int b = 0; b < 4; ++b)

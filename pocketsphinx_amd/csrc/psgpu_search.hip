@@ -28,6 +28,7 @@
 // and run 1024 work-items per utterance.
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
+#include "psgpu_sen_dev.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -37,6 +38,8 @@ constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
 constexpr int kFtLdsWords = 15488;     // LDS layout: 60.5 KB of arrays (+ 2.4 KB fixed) per workgroup, two workgroups per CU
+constexpr int kFtListCap = 1024;       // listed senones per frame kept as a list (LDS layout, scoring from top-N lists); more: scored where found
+constexpr int kFtMaxChains = 128;      // (codebook, stream) chains whose lists the LDS layout holds
 constexpr int kFtMinEvl = 512;         // the frame's evaluation list holds at least this many entries (LDS layout)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
@@ -54,6 +57,8 @@ struct FtLay {
     int32_t cnt2, cnt3, woff;            // [n_w + 2] per-candidate / per-active-word scratch; first slot index of each active word
     int32_t ckey;                        // [n_w + 2] 64-bit (score, back-pointer) keys of the pair searches
     int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
+    int32_t l_cw, l_sc, l_la, l_list, l_norm;    // small layout, scoring from top-N lists: the frame's lists (packed codewords / scores per
+                                         // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
@@ -85,6 +90,11 @@ struct FtDev {
 
 struct FtBufs {
     int32_t *slab, *bp, *bss, *idx, *step, *res, *w1_out;
+    // scoring from the scorer's top-N lists instead of score rows (psgpu_fwdtree_search_lists_dev): tsc == NULL = rows
+    const int32_t *tsc;                  // [chain][total][4] raw scores, chain-major
+    const uint32_t *tcw;                 // [chain][total] four codewords packed
+    const uint8_t *mixw, *sen2cb, *la;   // the scorer's mixture weights [3][n_density][n_sen], senone -> codebook, 8-bit log-add table
+    int32_t ls_total, ls_chains, ls_density, ls_la_size;
     const int32_t *mpx_in;               // session state: per utterance [(R + n1)][n_emit] per-state ssids of the multiplexed channels, or NULL
     int32_t *mpx_out;
     long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][32] cycles per phase (tools/build_prof_lib.py)
@@ -545,6 +555,15 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3,
             *const woff = fb + L.woff, *const evl = fb + L.evl;
     unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
+    // scoring from the scorer's top-N lists (LDS layout only; the host sees to that)
+    const bool lists = SMALL && bf.tsc != nullptr;
+    uint32_t *const l_cw = reinterpret_cast<uint32_t *>(fb + L.l_cw), *const l_sc = reinterpret_cast<uint32_t *>(fb + L.l_sc);
+    uint8_t *const l_la = reinterpret_cast<uint8_t *>(fb + L.l_la);
+    uint16_t *const l_list = reinterpret_cast<uint16_t *>(fb + L.l_list);
+    int32_t *const l_norm = fb + L.l_norm;
+    const SenModel smod = { psgpu_as_global(bf.mixw), psgpu_as_global(bf.sen2cb), p.n_sen, bf.ls_density };
+    const int32_t *const tsc = psgpu_as_global(bf.tsc);
+    const uint32_t *const tcw = psgpu_as_global(bf.tcw);
     uint8_t *const present = reinterpret_cast<uint8_t *>(fb + L.present);
     FtTab tb;
     tb.bp = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * 10 * bf.bp_cap; tb.bss = psgpu_as_global(bf.bss) + (size_t)blockIdx.x * bf.bss_cap;
@@ -610,8 +629,45 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     constexpr int kPre = ROWL ? (kFtMaxSen / 2 + NT - 1) / NT : 1;
     const int row_dw = (p.n_sen + 1) >> 1;              // dwords per score row (the host checked the alignment)
     auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T - 1) : f); };
+    // scoring from lists: a frame's lists -- per (codebook, stream) chain four raw scores and four codewords -- travel one frame
+    // ahead in registers like the score row does, 5 words a work-item instead of 16: loaded after the evaluation, the streams'
+    // normalisers (ptm_mgau_codebook_norm, ptm_mgau.c:265-295: the maximum over the codebooks of best score >> 10) reduced per
+    // wavefront at the frame's end, packed into LDS at the top of the frame they belong to
+    int32_t ps0 = 0, ps1 = 0, ps2 = 0, ps3 = 0;
+    uint32_t pcw = 0;
+    auto lists_load = [&](int fr) {
+        if (tid < bf.ls_chains) {
+            const FtQuad q = *reinterpret_cast<const FtQuad *>(tsc + ((size_t)tid * bf.ls_total + t0 + fr) * 4);
+            ps0 = q.x; ps1 = q.y; ps2 = q.z; ps3 = q.w;
+            pcw = tcw[(size_t)tid * bf.ls_total + t0 + fr];
+        }
+    };
+    auto lists_norm = [&]() {                            // (every work-item: wavefront scans)
+        const int fs = tid % kSenStreams;
+        const int32_t v = tid < bf.ls_chains ? (ps0 >> kSenShift) : FtMax::id;
+#pragma unroll
+        for (int q = 0; q < kSenStreams; ++q) {
+            const int32_t m = ft_wave_incl<FtMax>(fs == q ? v : FtMax::id);
+            if ((tid & 63) == 63) l_norm[(tid >> 6) * kSenStreams + q] = m;
+        }
+    };
+    auto lists_pack = [&]() {
+        if (tid < bf.ls_chains) {
+            int32_t nm = FtMax::id;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) nm = max(nm, l_norm[w * kSenStreams + tid % kSenStreams]);
+            l_sc[tid] = sen_pack_scores(ps0, ps1, ps2, ps3, nm);
+            l_cw[tid] = pcw;
+        }
+    };
     if (SMALL && T > 0) {
-        if (ROWL) {
+        if (lists) {
+            const uint8_t *const la = psgpu_as_global(bf.la);
+            for (int i = tid; i < 512; i += NT) l_la[i] = i < bf.ls_la_size ? la[i] : 0;
+            lists_load(0);
+            lists_norm();
+        }
+        else if (ROWL) {
             const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
             uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
             for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
@@ -640,6 +696,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : penalties + (size_t)pen_frame(f) * n_ci;
         const int16_t *const row = ROWL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
+        if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
         if (tid == 0) { tb.idx[f] = s_sc[3]; s_nev = 0; }
         const int32_t best_in = s_sc[0];
@@ -665,7 +722,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             // raw-score mode: the senones of the listed channels are marked (compute_sen_active, :526-564) and the minimum of
             // their raw scores taken in the same pass
             int32_t mn = 0x7fffffff;
-            auto mark_sen = [&](int sen) { atomicOr(&s_bits[sen >> 5], 1u << (sen & 31)); mn = min(mn, (int32_t)row[sen]); };
+            auto mark_sen = [&](int sen) { atomicOr(&s_bits[sen >> 5], 1u << (sen & 31)); if (!lists) mn = min(mn, (int32_t)row[sen]); };
             auto mark = [&](const ChView &v, int c) {
                 const int mpx = v.at(c, F::MPX);
 #pragma unroll
@@ -673,7 +730,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     int sen = v.at(c, F::SENID + k);
                     if (mpx) { if (sen == kBadSsid) continue; sen = sseq[(size_t)sen * NE + k]; }
                     atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
-                    mn = min(mn, (int32_t)row[sen]);
+                    if (!lists) mn = min(mn, (int32_t)row[sen]);
                 }
             };
             for (int k0 = 0; k0 < n_items; k0 += NT) {
@@ -729,6 +786,41 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             //      continued by a backward walk by the first lane of a wavefront that holds a senone)
             const int nwords = (p.n_sen + 31) >> 5, lane = tid & 63;
             int32_t mn = 0x7fffffff, n_listed_sen = 0;
+            if (lists) {
+                // ---- the listed senones are scored here, from the frame's top-N lists (ptm_mgau_senone_eval, :326-403): the
+                //      bitmap is turned into a list (a prefix sum over its words' populations) so that the ~400 evaluations of a
+                //      frame -- twelve weight loads and nine table look-ups each -- spread evenly over the work-items; scores
+                //      go to the LDS row the evaluation reads, un-normalised, their minimum is the frame's normaliser
+                const int w = tid;                               // (one bitmap word per work-item: n_sen <= 32 NT)
+                const uint32_t b = w < nwords ? s_bits[w] : 0u;
+                const int hi = b ? w * 32 + 31 - __clz((int)b) : -1;
+                int prev = ft_wave_excl<FtMax>(hi);
+                auto score = [&](int sen) {
+                    const int32_t a = sen_eval_f3n4(smod, l_cw, l_sc, l_la, sen);
+                    s_row[sen] = (int16_t)a;                     // (int16 as the scorer's rows, ptm_mgau.c:398-400)
+                    mn = min(mn, a);
+                };
+                if (b) {
+                    n_listed_sen = __popc(b);
+                    if (prev < 0)
+                        for (int q = w - lane - 1; q >= 0; --q) { const uint32_t pb = s_bits[q]; if (pb) { prev = q * 32 + 31 - __clz((int)pb); break; } }
+                    const int sen = w * 32 + __ffs((int)b) - 1;
+                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; score(last); }   // bridging entries (rare)
+                }
+                if (w <= nwords) cnt[w] = w < nwords ? __popc(b) : 0;
+                ft_sync<SMALL>();
+                const int n_list = ft_block_scan<NT, SMALL>(cnt, nwords + 1, s_scan);
+                if (b) {
+                    int o = cnt[w];
+                    for (uint32_t bb = b; bb; bb &= bb - 1, ++o) {
+                        const int sen = w * 32 + __ffs((int)bb) - 1;
+                        if (o < kFtListCap) l_list[o] = (uint16_t)sen; else score(sen);      // (a frame with more: scored where found)
+                    }
+                }
+                ft_sync<SMALL>();
+                for (int i = tid; i < min(n_list, kFtListCap); i += NT) score((int)l_list[i]);
+            }
+            else
             for (int w0 = 0; w0 < nwords; w0 += NT) {
                 const int w = w0 + tid;
                 const uint32_t b = w < nwords ? s_bits[w] : 0u;
@@ -795,7 +887,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         uint32_t pre[kPre];
         int32_t pre_pen = 0;
         if (SMALL && nf < T) {
-            if (ROWL) {
+            if (lists) lists_load(nf);
+            else if (ROWL) {
                 const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + nf) * scr_stride);
 #pragma unroll
                 for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; pre[k] = i < row_dw ? FT_ROW_LOAD(g + i) : 0u; }
@@ -1300,7 +1393,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         FT_PROF(27);
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
         if (SMALL && nf < T) {                               // the next frame's score row and penalties take their place
-            if (ROWL) {
+            if (lists) lists_norm();
+            else if (ROWL) {
                 uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
 #pragma unroll
                 for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; if (i < row_dw) d[i] = pre[k]; }
@@ -1417,6 +1511,9 @@ static bool ft_layout(FtDev &d, bool small)
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
+        // scoring from top-N lists (psgpu_fwdtree_search_lists_dev)
+        L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
+        L.l_norm = take(kFtThreads / 64 * kSenStreams);
         // what is left of the pool holds the frame's evaluation list
         const int64_t left = (int64_t)kFtLdsWords - o;
         if (left < kFtMinEvl || d.n_sen > kFtMaxSen) return false;
@@ -1487,7 +1584,7 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.TOT = (int32_t)tot;
     d.CH = d.N + d.n1;
     d.n_tmat = t->n_tmat;
-    d.cnt_words = std::max(d.R + d.N + 1, 4 * d.n_w + 4);
+    d.cnt_words = std::max(std::max(d.R + d.N + 1, 4 * d.n_w + 4), kFtMaxSen / 32 + 4);     // (.. + 4: the senone bitmap's word populations)
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
     d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
     d.kid_off = ft_up(m, kid_off.data(), (size_t)d.N + 1, &rc); d.kids = ft_up(m, kids.data(), kids.size(), &rc);
@@ -1567,6 +1664,15 @@ int psgpu_fwdtree_search_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int6
 
 int32_t psgpu_fwdtree_n_mpx_channels(const psgpu_fwdtree_t *m) { return m ? m->d.R + m->d.n1 : 0; }
 
+struct FtListsArg { const int32_t *tsc; const uint32_t *tcw; const uint8_t *mixw, *sen2cb, *la; int32_t total, chains, density, la_size; };
+
+static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride, const FtListsArg *ls,
+                     const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                     int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                     int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
+                     int32_t pl_window, int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev,
+                     int32_t *mpx_ssid_out_dev, void *stream);
+
 int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride,
                                      const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
                                      int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
@@ -1574,16 +1680,53 @@ int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_d
                                      int32_t pl_window, int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev,
                                      int32_t *mpx_ssid_out_dev, void *stream)
 {
+    PSGPU_REQUIRE(senscr_dev || n_utt == 0, "psgpu_fwdtree_search_session_dev: NULL score rows");
+    return ft_search(m, senscr_dev, scr_stride, nullptr, penalties_dev, utt_off_dev, n_utt, max_frames, bp_cap, bss_cap, bp_dev, bss_dev,
+                     idx_dev, step_dev, result_dev, raw_scores, pl_window, w1_ssid_out_dev, mpx_ssid_in_dev, mpx_ssid_out_dev, stream);
+}
+
+int32_t psgpu_fwdtree_can_score_lists(const psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v)
+{
+    return (m && v && m->d.small && v->n_feat == kSenStreams && v->topn == kSenTopn && v->n_mgau * v->n_feat <= kFtMaxChains
+            && v->n_mgau * v->n_feat <= kFtThreads && v->n_sen == m->d.n_sen && v->n_sen <= kFtMaxSen && v->n_sen < 65536
+            && v->logadd8_size >= 256) ? 1 : 0;
+}
+
+int psgpu_fwdtree_search_lists_dev(psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v, const int32_t *topn_score_dev,
+                                   const uint8_t *topn_cw_dev, int32_t total_frames,
+                                   const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                   int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                                   int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t pl_window,
+                                   int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev, int32_t *mpx_ssid_out_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && v && (n_utt == 0 || (topn_score_dev && topn_cw_dev)), "psgpu_fwdtree_search_lists_dev: NULL argument");
+    PSGPU_REQUIRE(psgpu_fwdtree_can_score_lists(m, v),
+                  "psgpu_fwdtree_search_lists_dev: needs the LDS layout and a 3-stream top-4 scorer of at most %d chains (psgpu_fwdtree_can_score_lists)",
+                  kFtMaxChains);
+    PSGPU_REQUIRE(((uintptr_t)topn_score_dev & 15) == 0 && ((uintptr_t)topn_cw_dev & 3) == 0, "psgpu_fwdtree_search_lists_dev: misaligned lists");
+    const FtListsArg ls = { topn_score_dev, reinterpret_cast<const uint32_t *>(topn_cw_dev), v->mixw, v->sen2cb, v->logadd8, total_frames,
+                            v->n_mgau * v->n_feat, v->n_density, v->logadd8_size };
+    return ft_search(m, nullptr, 0, &ls, penalties_dev, utt_off_dev, n_utt, max_frames, bp_cap, bss_cap, bp_dev, bss_dev, idx_dev, step_dev,
+                     result_dev, 1, pl_window, w1_ssid_out_dev, mpx_ssid_in_dev, mpx_ssid_out_dev, stream);
+}
+
+static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_stride, const FtListsArg *ls,
+                     const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                     int32_t max_frames, int32_t bp_cap, int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev,
+                     int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
+                     int32_t pl_window, int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev,
+                     int32_t *mpx_ssid_out_dev, void *stream)
+{
     PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0, "psgpu_fwdtree_search_dev: bad argument");
     PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
                   m->d.n_sen, kFtMaxSen);
     PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdtree_search_dev: no language model (dense table or psgpu_fwdtree_set_lm)");
     if (n_utt == 0) return PSGPU_OK;
-    PSGPU_REQUIRE(senscr_dev && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
+    PSGPU_REQUIRE((senscr_dev || ls) && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdtree_search_dev: NULL device buffer");
     FtDev d = m->d;
     // the LDS layout copies score rows as dwords: rows must start on 4-byte boundaries
-    if (d.small && ((scr_stride & 1) || ((uintptr_t)senscr_dev & 3))) ft_layout(d, false);
+    if (!ls && d.small && ((scr_stride & 1) || ((uintptr_t)senscr_dev & 3))) ft_layout(d, false);
     hipStream_t st = (hipStream_t)stream;
     const size_t need = (size_t)d.per * n_utt;
     if (need > m->slab_words) {
@@ -1595,6 +1738,11 @@ int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_d
     bf.slab = m->slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
     bf.w1_out = w1_ssid_out_dev;
     bf.mpx_in = mpx_ssid_in_dev; bf.mpx_out = mpx_ssid_out_dev;
+    bf.tsc = nullptr; bf.tcw = nullptr; bf.mixw = bf.sen2cb = bf.la = nullptr; bf.ls_total = bf.ls_chains = bf.ls_density = bf.ls_la_size = 0;
+    if (ls) {
+        bf.tsc = ls->tsc; bf.tcw = ls->tcw; bf.mixw = ls->mixw; bf.sen2cb = ls->sen2cb; bf.la = ls->la;
+        bf.ls_total = ls->total; bf.ls_chains = ls->chains; bf.ls_density = ls->density; bf.ls_la_size = ls->la_size;
+    }
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
     PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));

@@ -91,3 +91,33 @@ def test_fe_rejects_what_it_cannot_reproduce():
     g["par"] = par
     with pytest.raises(P.PsgpuError):
         P.FrontEnd(g)
+
+
+def test_device_log_equals_the_hosts_libm_over_the_mel_range():
+    """The front end's one libm call, log(mel spectrum + 1e-4) in double precision (fe_sigproc.c:1215-1228), is the only
+    operation of the path that is not bit-identical by construction: the device's log and glibc's are both faithful, neither
+    is correctly rounded.  Pinned by measurement: 2^24 arguments spread log-uniformly over the value range of a mel
+    spectrum of 16-bit audio (1e-4, the floor, to 1e13), plus arguments straddling every power of two in it (where an
+    argument reduction changes branch), plus the neighbourhood of 1 -- every result equals libm's."""
+    import ctypes as C
+    import torch
+    from pocketsphinx_amd import capi
+    rng = np.random.default_rng(2026)
+    x = np.exp(rng.uniform(np.log(1e-4), np.log(1e13), 1 << 24))
+    edges = np.concatenate([np.nextafter(2.0 ** k, b) * np.ones(1) for k in range(-14, 45) for b in (0.0, np.inf)] +
+                           [2.0 ** np.arange(-14, 45)])
+    near1 = 1.0 + np.concatenate([np.linspace(-1e-3, 1e-3, 20001), rng.uniform(-0.3, 0.3, 100000)])
+    x = np.ascontiguousarray(np.concatenate([x, edges, near1, np.array([1e-4, 1.0001e-4])]), np.float64)
+    want = np.empty_like(x)
+    L = pso.lib()
+    L.pso_libm_log.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.pso_libm_log(x.ctypes.data_as(C.c_void_p), x.size, want.ctypes.data_as(C.c_void_p))
+    d_x = torch.from_numpy(x).cuda()
+    d_o = torch.empty_like(d_x)
+    capi.check(capi.lib().psgpu_fe_log_dev(C.c_void_p(d_x.data_ptr()), C.c_int64(x.size), C.c_void_p(d_o.data_ptr()), None),
+               "psgpu_fe_log_dev")
+    torch.cuda.synchronize()
+    got = d_o.cpu().numpy()
+    bad = np.nonzero(got.view(np.int64) != want.view(np.int64))[0]
+    assert bad.size == 0, "%d of %d arguments differ, first x = %r: device %r libm %r" % (
+        bad.size, x.size, x[bad[0]], got[bad[0]], want[bad[0]])

@@ -113,5 +113,5 @@ def test_empty_and_errors():
     ctx = P.HmmContext(g["tp"], g["sseq"], int(g["n_sen"][0]))
     assert ctx.vit_eval(np.zeros(0, P.HMM_REC), g["senscr"][0]) == -0x20000000
     with pytest.raises(P.PsgpuError):
-        P.HmmContext(np.zeros((2, 4, 5), np.uint8), np.zeros((3, 4), np.uint16), 10)   # 4-state: unsupported
+        P.HmmContext(np.zeros((2, 6, 7), np.uint8), np.zeros((3, 6), np.uint16), 10)   # 6 states: beyond HMM_MAX_NSTATE
     ctx.close()
