@@ -658,6 +658,11 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
 void psgpu_decode_free(psgpu_decode_t *d);
 /* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
+/* lists != 0: no score rows -- the phone loop and the search evaluate the senones they list from the scorer's top-N lists
+ * (psgpu_phone_loop_run_lists_dev, psgpu_fwdtree_search_lists_dev); the senone kernel is not run and rows_dev of the view is
+ * NULL.  Same results bit for bit; 15.7 GB less traffic and a third less scorer time on the 512 x 30 s batch, but more time in
+ * the latency-bound search: slower in total today, so rows are the default (PSGPU_DECODE_LISTS=1 changes it). */
+int psgpu_decode_score_mode(psgpu_decode_t *d, int32_t lists);
 /* Session mode.  The utterances of ONE call are decoded as by so many new reference decoders.  A reference decoder that
  * decodes utterances one after another carries state from each into the next: the PTM scorer's top-N lists (the first
  * frame of utterance k + 1 is seeded with the last lists of utterance k) and the per-state ssids of the
@@ -702,7 +707,8 @@ typedef struct psgpu_decode_view_s {
     const int32_t *frame_off_dev;
     const float *feat_dev;             /* [total][3 * cepsize] */
     const uint8_t *topn_cw_dev;        /* [n_chain][total][topn] */
-    const int16_t *rows_dev;           /* [total][n_sen] un-normalised scores */
+    const int16_t *rows_dev;           /* [total][n_sen] un-normalised scores; NULL when the search scored its own senones
+                                        * (psgpu_fwdtree_search_lists_dev: the default where the models allow it) */
     const int32_t *penalties_dev;      /* [total][n_phones] */
     int32_t *bp_dev, *bss_dev, *idx_dev, *step_dev, *result_dev, *hyp_dev, *hyp_n_dev, *w1_ssid_dev;
 } psgpu_decode_view_t;
@@ -763,6 +769,7 @@ typedef struct psgpu_ptm_view_s {
     const uint8_t *mixw, *sen2cb, *logadd8;
     int32_t n_mgau, n_feat, n_density, n_sen, veclen, topn, logadd8_size;
     int32_t featlen[16], featoff[16];
+    const uint8_t *mixw_sen;                  /* the weights senone-major: [n_sen][n_feat][n_density rounded up to 64] */
 } psgpu_ptm_view_t;
 int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out);
 
@@ -777,6 +784,13 @@ int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out);
  * bridging entries included; penalties_dev from psgpu_phone_loop_run_lists_dev).  Needs the LDS layout and a scorer of
  * 3 streams x top-4 with at most 128 chains: psgpu_fwdtree_can_score_lists says whether this model pair qualifies. */
 int32_t psgpu_fwdtree_can_score_lists(const psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v);
+/* ... and the phone loop feeding it: psgpu_phone_loop_run_dev with the all-phones-active list's senones (ci_list_dev, some 130)
+ * evaluated from the same lists instead of read from score rows */
+int psgpu_phone_loop_run_lists_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
+                                   const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                                   const psgpu_ptm_view_t *v, const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
+                                   const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                                   int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream);
 int psgpu_fwdtree_search_lists_dev(psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v, const int32_t *topn_score_dev,
                                    const uint8_t *topn_cw_dev, int32_t total_frames,
                                    const int32_t *penalties_dev, const int32_t *utt_off_dev, int32_t n_utt,

@@ -328,3 +328,92 @@ psgpu_decode_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t n[],
     b->cep = NULL; b->frame_off = NULL;
     return rc;
 }
+
+/* ---- several devices ------------------------------------------------------------------------------------------------ */
+struct psgpu_multi_s {
+    int n;
+    int *device;
+    psgpu_batch_t **b;
+};
+
+psgpu_multi_t *
+psgpu_multi_init(ps_config_t *config, const int devices[], int n_devices, int n_workers, unsigned flags)
+{
+    psgpu_multi_t *m;
+    int k;
+    if (config == NULL || devices == NULL || n_devices < 1) return NULL;
+    m = ckd_calloc(1, sizeof *m);
+    m->n = n_devices;
+    m->device = ckd_calloc(n_devices, sizeof *m->device);
+    m->b = ckd_calloc(n_devices, sizeof *m->b);
+    for (k = 0; k < n_devices; ++k) {
+        m->device[k] = devices[k];
+        if (!(flags & PSGPU_BATCH_CPU_ONLY) && psgpu_set_device(devices[k]) != PSGPU_OK) {
+            E_ERROR("psgpu_multi_init: device %d: %s\n", devices[k], psgpu_last_error());
+            psgpu_multi_free(m);
+            return NULL;
+        }
+        m->b[k] = psgpu_batch_init(config, n_workers, flags);
+        if (m->b[k] == NULL) { psgpu_multi_free(m); return NULL; }
+    }
+    return m;
+}
+
+void
+psgpu_multi_free(psgpu_multi_t *m)
+{
+    int k;
+    if (m == NULL) return;
+    for (k = 0; k < m->n; ++k)
+        if (m->b[k]) { psgpu_set_device(m->device[k]); psgpu_batch_free(m->b[k]); }
+    ckd_free(m->b); ckd_free(m->device); ckd_free(m);
+}
+
+int psgpu_multi_n_devices(const psgpu_multi_t *m) { return m ? m->n : 0; }
+
+typedef struct multi_arg_s {
+    psgpu_multi_t *m;
+    int k, b0, b1, rc;
+    const int16 *const *pcm;
+    const size_t *n;
+    psgpu_batch_result_t *out;
+} multi_arg_t;
+
+static void *
+multi_worker(void *p)
+{
+    multi_arg_t *a = p;
+    /* the device is a property of the calling thread */
+    if (psgpu_set_device(a->m->device[a->k]) != PSGPU_OK) { a->rc = -1; return NULL; }
+    a->rc = a->b1 > a->b0 ? psgpu_decode_batch(a->m->b[a->k], a->pcm + a->b0, a->n + a->b0, a->b1 - a->b0, a->out + a->b0) : 0;
+    return NULL;
+}
+
+int
+psgpu_decode_batch_multi(psgpu_multi_t *m, const int16 *const pcm[], const size_t n[], int B, psgpu_batch_result_t out[])
+{
+    multi_arg_t *a;
+    pthread_t *tid;
+    int *started, k, u = 0, rc = 0;
+    double total = 0, acc = 0;
+    if (m == NULL || B < 0 || (B > 0 && (pcm == NULL || n == NULL || out == NULL))) return -1;
+    a = ckd_calloc(m->n, sizeof *a); tid = ckd_calloc(m->n, sizeof *tid); started = ckd_calloc(m->n, sizeof *started);
+    for (k = 0; k < B; ++k) total += (double)n[k];
+    /* consecutive blocks of about equal audio length (utterance boundaries; the same split as pocketsphinx_amd/batch.py) */
+    for (k = 0; k < m->n; ++k) {
+        a[k].m = m; a[k].k = k; a[k].pcm = pcm; a[k].n = n; a[k].out = out; a[k].b0 = u;
+        if (k == m->n - 1) u = B;
+        else while (u < B && acc + (double)n[u] / 2 <= total * (k + 1) / m->n) acc += (double)n[u++];
+        a[k].b1 = u;
+    }
+    for (k = 0; k < m->n; ++k) {
+        if (pthread_create(&tid[k], NULL, multi_worker, &a[k]) != 0) { multi_worker(&a[k]); continue; }   /* (no thread: in line) */
+        started[k] = 1;
+    }
+    for (k = 0; k < m->n; ++k) {
+        if (started[k]) pthread_join(tid[k], NULL);
+        if (a[k].rc < 0) rc = -1;
+    }
+    ckd_free(a); ckd_free(tid); ckd_free(started);
+    return rc;
+}

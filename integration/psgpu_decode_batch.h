@@ -55,6 +55,19 @@ int psgpu_decode_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t 
                        psgpu_batch_result_t out[]);
 void psgpu_batch_result_clear(psgpu_batch_result_t *r);
 
+/* ---- several devices.  One psgpu_batch_t per entry of devices[] (psgpu_set_device(devices[k]) while it is built: every
+ * decoder's device objects live there; an index may appear more than once -- two batch objects then share that GPU),
+ * n_workers decoders each.  psgpu_decode_batch_multi splits the B utterances into n_devices consecutive blocks of about
+ * equal audio length, decodes every block with its device's psgpu_decode_batch on a host thread of its own, and returns
+ * the results in the callers' order: the utterances are independent (see psgpu_decode_batch), so nothing crosses devices
+ * but the PCM going out and the results coming back.  Returns 0, or -1 if any utterance failed. */
+typedef struct psgpu_multi_s psgpu_multi_t;
+psgpu_multi_t *psgpu_multi_init(ps_config_t *config, const int devices[], int n_devices, int n_workers, unsigned flags);
+void psgpu_multi_free(psgpu_multi_t *m);
+int psgpu_multi_n_devices(const psgpu_multi_t *m);
+int psgpu_decode_batch_multi(psgpu_multi_t *m, const int16 *const pcm[], const size_t n[], int B,
+                             psgpu_batch_result_t out[]);
+
 #ifdef __cplusplus
 }
 #endif

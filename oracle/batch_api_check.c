@@ -55,6 +55,13 @@ same(const psgpu_batch_result_t *a, const psgpu_batch_result_t *b)
     return 1;
 }
 
+static psgpu_multi_t *g_multi;
+static int
+run_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t n[], int B, psgpu_batch_result_t out[])
+{
+    return g_multi ? psgpu_decode_batch_multi(g_multi, pcm, n, B, out) : psgpu_decode_batch(b, pcm, n, B, out);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -99,25 +106,34 @@ main(int argc, char **argv)
     }
     t_ref = now_s() - t0;
 
-    /* 2. the batch call */
+    /* 2. the batch call (BATCH_CHECK_DEVICES="0,0": through the multi-device dispatcher, one batch object per entry) */
+    if (getenv("BATCH_CHECK_DEVICES")) {
+        int devs[16], nd = 0;
+        char *spec = strdup(getenv("BATCH_CHECK_DEVICES")), *tok;
+        for (tok = strtok(spec, ","); tok && nd < 16; tok = strtok(NULL, ",")) devs[nd++] = atoi(tok);
+        g_multi = psgpu_multi_init(make_config(argv, nx, extra), devs, nd, n_workers, flags);
+        if (!g_multi) { fprintf(stderr, "psgpu_multi_init failed\n"); return 3; }
+        dev = NULL;
+    }
+    else
     dev = psgpu_batch_init(make_config(argv, nx, extra), n_workers, flags);
-    if (!dev) { fprintf(stderr, "psgpu_batch_init failed\n"); return 3; }
-    if (psgpu_decode_batch(dev, cp, n, B, got) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }   /* warm */
+    if (!dev && !g_multi) { fprintf(stderr, "psgpu_batch_init failed\n"); return 3; }
+    if (run_batch(dev, cp, n, B, got) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }   /* warm */
     for (i = 0; i < B; ++i) psgpu_batch_result_clear(&got[i]);
     t0 = now_s();
-    if (psgpu_decode_batch(dev, cp, n, B, got) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }
+    if (run_batch(dev, cp, n, B, got) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }
     t_batch = now_s() - t0;
     if (getenv("BATCH_CHECK_TIMING_ONLY")) {
         for (i = 0; i < B; ++i) frames += got[i].n_frames;
         printf("{\"timing_only\": true, \"B\": %d, \"workers\": %d, \"flags\": %u, \"frames\": %d, \"batch_s\": %.4f, "
                "\"frames_per_s\": %.1f, \"hyp0\": \"%s\"}\n", B, n_workers, flags, frames, t_batch, frames / t_batch, got[0].hyp);
-        psgpu_batch_free(dev);
+        if (g_multi) psgpu_multi_free(g_multi); else psgpu_batch_free(dev);
         return 0;
     }
     for (i = 0; i < B; ++i) { rp[i] = cp[B - 1 - i]; rn[i] = n[B - 1 - i]; }
-    if (psgpu_decode_batch(dev, rp, rn, B, rev) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }
+    if (run_batch(dev, rp, rn, B, rev) < 0) { fprintf(stderr, "batch decode failed\n"); return 3; }
     for (i = 0; i < B; ++i)
-        if (psgpu_decode_batch(dev, &cp[i], &n[i], 1, &one[i]) < 0) { fprintf(stderr, "B=1 decode failed\n"); return 3; }
+        if (run_batch(dev, &cp[i], &n[i], 1, &one[i]) < 0) { fprintf(stderr, "B=1 decode failed\n"); return 3; }
     for (i = 0; i < B; ++i) {
         if (!same(&ref[i], &got[i]) && getenv("BATCH_CHECK_VERBOSE")) {
             int k;
@@ -139,6 +155,6 @@ main(int argc, char **argv)
     for (i = 0; i < B; ++i)
         printf("%s\"%s\"", i ? ", " : "", got[i].hyp);
     printf("]}\n");
-    psgpu_batch_free(dev);
+    if (g_multi) psgpu_multi_free(g_multi); else psgpu_batch_free(dev);
     return (bad_batch || bad_rev || bad_one) ? 1 : 0;
 }

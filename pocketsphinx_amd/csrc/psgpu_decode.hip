@@ -26,6 +26,10 @@ struct psgpu_decode_s {
     int16_t *d_rows = nullptr;
     int32_t *d_bp = nullptr, *d_bss = nullptr, *d_idx = nullptr, *d_step = nullptr, *d_res = nullptr, *d_hyp = nullptr, *d_hn = nullptr,
             *d_w1 = nullptr;
+    // scores on demand: the phone loop and the search evaluate the senones they list from the scorer's top-N lists
+    // (psgpu_phone_loop_run_lists_dev, psgpu_fwdtree_search_lists_dev); the senone kernel and its rows are left out
+    psgpu_ptm_view_t view;
+    bool lists = false, want_lists = false;
     // a decoder session (psgpu_decode_session): what utterance k + 1 of ONE reference decoder inherits from utterance k --
     // the scorer's last top-N lists (the seeds of the next first frame, ptm_mgau.c) and the per-state ssids of the permanent
     // multiplexed channels (hmm_clear keeps them)
@@ -54,6 +58,22 @@ static int dec_alloc(void **p, size_t bytes)
     *p = nullptr;
     PSGPU_HIP(hipMalloc(p, bytes ? bytes : 4));
     return PSGPU_OK;
+}
+
+// Where the senone scores come from: full rows from the senone kernel (the default), or the phone loop and the search
+// evaluating the senones they list themselves (psgpu_decode_score_mode / PSGPU_DECODE_LISTS=1).  Measured on the 512 x 30 s
+// batch (profiles/, r02): without rows the scorer stage drops from 42 to 26 ms and 15.7 GB of row traffic disappear, but the
+// search -- a latency-bound recurrence -- pays 12.6 k cycles per frame for list building and two dependent trips to the
+// weight tables, 90 -> 116 ms, and the phone loop's preparation 0.8 -> 5.9 ms: slower in total, hence not the default.
+static bool dec_can_lists(psgpu_decode_s *d)
+{
+    return psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK && psgpu_fwdtree_can_score_lists(d->cfg.ft, &d->view)
+           && d->cfg.n_ci_list <= 256;
+}
+static void dec_pick_mode(psgpu_decode_s *d)
+{
+    static const int env_lists = [] { const char *e = getenv("PSGPU_DECODE_LISTS"); return e ? atoi(e) : 0; }();
+    d->lists = (d->want_lists || env_lists) && dec_can_lists(d);
 }
 
 extern "C" {
@@ -88,6 +108,7 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg)
         return PSGPU_EHIP;
     }
     d->cfg.pl_ssid = nullptr; d->cfg.pl_tmatid = nullptr; d->cfg.ci_list = nullptr;      // (host tables are not kept)
+    dec_pick_mode(d);
     *out = d;
     return PSGPU_OK;
 }
@@ -101,6 +122,15 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_noise); DFREE(d->d_undef);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     delete d;
+}
+
+int psgpu_decode_score_mode(psgpu_decode_t *d, int32_t lists)
+{
+    PSGPU_REQUIRE(d, "psgpu_decode_score_mode: NULL argument");
+    d->want_lists = lists != 0;
+    PSGPU_REQUIRE(!lists || dec_can_lists(d), "psgpu_decode_score_mode: this model pair cannot score from lists (psgpu_fwdtree_can_score_lists)");
+    dec_pick_mode(d);
+    return PSGPU_OK;
 }
 
 int psgpu_decode_session(psgpu_decode_t *d, int32_t on)
@@ -162,6 +192,7 @@ int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model)
     PSGPU_REQUIRE(psgpu_ptm_n_sen(model) == d->n_sen && psgpu_ptm_n_chain(model) == d->n_chain && psgpu_ptm_topn(model) == d->topn,
                   "psgpu_decode_set_model: the model has another shape");
     d->cfg.model = model;
+    dec_pick_mode(d);
     return PSGPU_OK;
 }
 
@@ -173,15 +204,15 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
     const size_t bp_cap = 16 * mf + 2048, bss_cap = 320 * mf + 8192;
     bool waited = false;
     auto wait = [&]() { if (!waited) { hipStreamSynchronize(st); waited = true; } };
-    if (total > d->cap_frames) {
+    if (total > d->cap_frames || (!d->lists && !d->d_rows)) {         // (.. or the model changed to one that needs score rows)
         wait();
-        const size_t t = total + total / 8 + 64, ne = t * d->n_chain * d->topn;
+        const size_t t = std::max(total + total / 8 + 64, d->cap_frames), ne = t * d->n_chain * d->topn;
         DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_tsc); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_best); DFREE(d->d_pen);
         d->cap_frames = 0;
         int rc;
         if ((rc = dec_alloc((void **)&d->d_cep, 4 * t * d->cepsize)) || (rc = dec_alloc((void **)&d->d_feat, 4 * t * 3 * d->cepsize))
             || (rc = dec_alloc((void **)&d->d_tsc, 4 * ne)) || (rc = dec_alloc((void **)&d->d_tcw, ne))
-            || (rc = dec_alloc((void **)&d->d_rows, 2 * t * d->n_sen)) || (rc = dec_alloc((void **)&d->d_best, 4 * t))
+            || (!d->lists && (rc = dec_alloc((void **)&d->d_rows, 2 * t * d->n_sen))) || (!d->lists && (rc = dec_alloc((void **)&d->d_best, 4 * t)))
             || (rc = dec_alloc((void **)&d->d_pen, 4 * t * d->n_ci)))
             return rc;
         d->cap_frames = t;
@@ -215,7 +246,8 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
     const bool chained = sess && d->sess_started;
     dec_mark(d, 2, st);
     if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, chained && d->seed_valid ? d->d_seed : nullptr,
-                                        nullptr, d->d_tsc, d->d_tcw, d->d_rows, d->d_best, PSGPU_PTM_RAW_SCORES, st)))
+                                        nullptr, d->d_tsc, d->d_tcw, d->lists ? nullptr : d->d_rows, d->lists ? nullptr : d->d_best,
+                                        PSGPU_PTM_RAW_SCORES, st)))
         return rc;
     if (sess) {
         // what seeds the next utterance's first frame: ptm_mgau_frame_eval copies frame 0's initial lists from slot
@@ -231,15 +263,24 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
         }
     }
     dec_mark(d, 3, st);
-    if ((rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
-                                       nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st)))
-        return rc;
+    if (d->lists)
+        rc = psgpu_phone_loop_run_lists_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, &d->view, d->d_tsc,
+                                            d->d_tcw, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st);
+    else
+        rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
+                                      nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st);
+    if (rc) return rc;
     dec_mark(d, 4, st);
     // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
-    if ((rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
-                                               d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
-                                               chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st)))
-        return rc;
+    if (d->lists)
+        rc = psgpu_fwdtree_search_lists_dev(d->cfg.ft, &d->view, d->d_tsc, d->d_tcw, (int32_t)total, d->d_pen, d->d_off, n_utt, (int32_t)mf,
+                                            d->bp_cap, d->bss_cap, d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, d->cfg.pl_window, d->d_w1,
+                                            chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st);
+    else
+        rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
+                                              d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
+                                              chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st);
+    if (rc) return rc;
     if (sess) d->sess_started = true;
     dec_mark(d, 5, st);
     rc = psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp, d->d_idx, d->d_res, n_utt, (int32_t)mf, d->bp_cap, d->max_words, d->d_hyp,

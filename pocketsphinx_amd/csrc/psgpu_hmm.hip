@@ -50,6 +50,7 @@ struct psgpu_hmm_ctx_s {
 constexpr int32_t kZeroCopyMax = 2048;
 
 #include "psgpu_hmm_dev.h"
+#include "psgpu_sen_dev.h"
 
 constexpr int kHmmThreads = 256;
 constexpr int kTpLdsMax = 16384;
@@ -263,6 +264,75 @@ void phone_loop_prep_kernel(PlDev p, const uint16_t *__restrict__ sseq, const in
     for (int i = 0; i < W; ++i) o[i] = v[i];
 }
 
+// The same from the scorer's top-N lists instead of score rows (psgpu_phone_loop_run_lists_dev): the frame's lists of every
+// (codebook, stream) chain are normalised per stream (ptm_mgau_codebook_norm, ptm_mgau.c:265-295), the senones of the
+// all-phones-active list -- some 130 of 5126 -- are evaluated (ptm_mgau_senone_eval, :326-403; csrc/psgpu_sen_dev.h), the
+// rest as above.  One wavefront per frame; chains <= 128, listed senones <= 256.
+constexpr int kPlListMax = 256;
+template <int NE>
+__global__ __launch_bounds__(256)
+void phone_loop_prep_lists_kernel(PlDev p, const uint16_t *__restrict__ sseq, SenModel sm, const uint8_t *__restrict__ la, int32_t la_size,
+                                  const int32_t *__restrict__ tsc, const uint32_t *__restrict__ tcw, int32_t n_chain, int32_t total,
+                                  int16_t *__restrict__ css)
+{
+    constexpr int W = NE <= 3 ? 4 : 8;
+    __shared__ uint32_t s_cw[4][128], s_sc[4][128];
+    __shared__ int32_t s_val[4][kPlListMax];
+    __shared__ uint8_t s_la[512];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
+    const bool live = t < total;
+    for (int i = threadIdx.x; i < 512; i += 256) s_la[i] = i < la_size ? la[i] : 0;
+    // the frame's lists: chains lane and lane + 64
+    int32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    uint32_t ca = 0, cb = 0;
+    const int c1 = lane + 64;
+    if (live && lane < n_chain) {
+        const int4 q = *reinterpret_cast<const int4 *>(tsc + ((size_t)lane * total + t) * 4);
+        a0 = q.x; a1 = q.y; a2 = q.z; a3 = q.w; ca = tcw[(size_t)lane * total + t];
+    }
+    if (live && c1 < n_chain) {
+        const int4 q = *reinterpret_cast<const int4 *>(tsc + ((size_t)c1 * total + t) * 4);
+        b0 = q.x; b1 = q.y; b2 = q.z; b3 = q.w; cb = tcw[(size_t)c1 * total + t];
+    }
+    int32_t norm[kSenStreams];
+#pragma unroll
+    for (int q = 0; q < kSenStreams; ++q) {
+        int32_t v = kMaxNegInt32;
+        if (lane < n_chain && lane % kSenStreams == q) v = a0 >> kSenShift;
+        if (c1 < n_chain && c1 % kSenStreams == q) v = max(v, b0 >> kSenShift);
+        norm[q] = pl_wave_max(v);
+    }
+    if (lane < n_chain) { s_sc[wv][lane] = sen_pack_scores(a0, a1, a2, a3, norm[lane % kSenStreams]); s_cw[wv][lane] = ca; }
+    if (c1 < n_chain) { s_sc[wv][c1] = sen_pack_scores(b0, b1, b2, b3, norm[c1 % kSenStreams]); s_cw[wv][c1] = cb; }
+    __syncthreads();
+    int32_t nb = 0x7fffffff;
+    if (live)
+        for (int i = lane; i < p.n_list; i += 64) {
+            const int32_t a = sen_eval_f3n4(sm, s_cw[wv], s_sc[wv], s_la, (int)p.ci_list[i]);
+            s_val[wv][i] = a;
+            nb = min(nb, (int32_t)(int16_t)a);
+        }
+    nb = -pl_wave_max(-nb);
+    __syncthreads();
+    if (!live) return;
+    int16_t v[W];
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = 0;
+    if (lane < p.n_phones) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int sen = sseq[(size_t)p.ssid[lane] * NE + i];
+            int lo = 0, hi = p.n_list - 1;                       // the list is in ascending senone order
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)p.ci_list[mid] < sen) lo = mid + 1; else hi = mid; }
+            v[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)s_val[wv][lo] - (uint32_t)nb);
+        }
+    }
+    int16_t *o = css + ((size_t)t * 64 + lane) * W;
+#pragma unroll
+    for (int i = 0; i < W; ++i) o[i] = v[i];
+}
+
 template <int NE>
 __global__ __launch_bounds__(64)
 void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t *__restrict__ css,
@@ -444,20 +514,54 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
 
 void *psgpu_hmm_ctx_stream(psgpu_hmm_ctx_t *c) { return c ? (void *)c->stream : nullptr; }
 
+struct PlListsArg { const psgpu_ptm_view_t *v; const int32_t *tsc; const uint8_t *tcw; };
+static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
+                  const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                  const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev, const PlListsArg *ls,
+                  const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                  int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream);
+
 int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
                              const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
                              const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
                              const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
                              int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream)
 {
+    PSGPU_REQUIRE(raw_dev || n_utt == 0, "psgpu_phone_loop_run_dev: NULL score rows");
+    return pl_run(c, pp, ssid_dev, tmatid_dev, ci_list_dev, n_list, raw_dev, raw_stride, best_dev, nullptr, utt_off_dev, n_utt, total_frames,
+                  penalties_dev, pen_now_dev, state_dev, stream);
+}
+
+int psgpu_phone_loop_run_lists_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
+                                   const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                                   const psgpu_ptm_view_t *v, const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
+                                   const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                                   int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream)
+{
+    PSGPU_REQUIRE(v && (n_utt == 0 || (topn_score_dev && topn_cw_dev)), "psgpu_phone_loop_run_lists_dev: NULL argument");
+    PSGPU_REQUIRE(v->n_feat == kSenStreams && v->topn == kSenTopn && v->n_mgau * v->n_feat <= 128 && n_list >= 1 && n_list <= kPlListMax
+                  && v->logadd8_size >= 256 && v->mixw_sen,
+                  "psgpu_phone_loop_run_lists_dev: a 3-stream top-4 scorer of at most 128 chains and a list of at most %d senones", kPlListMax);
+    const PlListsArg ls = { v, topn_score_dev, topn_cw_dev };
+    return pl_run(c, pp, ssid_dev, tmatid_dev, ci_list_dev, n_list, nullptr, 0, nullptr, &ls, utt_off_dev, n_utt, total_frames,
+                  penalties_dev, pen_now_dev, state_dev, stream);
+}
+
+static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
+                  const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                  const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev, const PlListsArg *ls,
+                  const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                  int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream)
+{
     PSGPU_REQUIRE(c && pp && n_utt >= 0, "psgpu_phone_loop_run_dev: bad argument");
     PSGPU_REQUIRE(c->n_emit == 3 || c->n_emit == 5, "phone loop: %d emitting states (3 or 5 are built)", c->n_emit);
     if (n_utt == 0) return PSGPU_OK;
-    PSGPU_REQUIRE(ssid_dev && tmatid_dev && raw_dev && utt_off_dev && penalties_dev, "psgpu_phone_loop_run_dev: NULL device buffer");
+    PSGPU_REQUIRE(ssid_dev && tmatid_dev && (raw_dev || ls) && utt_off_dev && penalties_dev, "psgpu_phone_loop_run_dev: NULL device buffer");
     PSGPU_REQUIRE(pp->n_phones >= 1 && pp->n_phones <= 64, "n_phones %d outside 1..64", pp->n_phones);
     PSGPU_REQUIRE(pp->window >= 1 && pp->window <= kPlMaxWindow, "window %d outside 1..%d", pp->window, kPlMaxWindow);
     PSGPU_REQUIRE((best_dev != nullptr) != (ci_list_dev != nullptr && n_list > 0),
                   "exactly one of best_dev (compallsen) and ci_list_dev (active-list normalisation) is needed");
+    PSGPU_REQUIRE(!ls || ci_list_dev, "scoring from lists needs the all-phones-active senone list");
     PlDev p;
     p.n_phones = pp->n_phones; p.window = pp->window; p.beam = pp->beam; p.pbeam = pp->pbeam; p.pip = pp->pip;
     p.n_list = n_list; p.norm_mode = best_dev ? 2 : 1; p.weight = pp->penalty_weight;
@@ -474,13 +578,25 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
         c->pl_cap = total_frames;
     }
     const dim3 pg((total_frames + 3) / 4);
+    SenModel sm = { nullptr, nullptr, 0, 0 };
+    if (ls) { sm.mixw = ls->v->mixw_sen; sm.sen2cb = ls->v->sen2cb; sm.n_sen = ls->v->n_sen; sm.n_density = ls->v->n_density; }
     if (c->n_emit == 3) {
+        if (ls)
+            hipLaunchKernelGGL((phone_loop_prep_lists_kernel<3>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, sm, ls->v->logadd8,
+                               ls->v->logadd8_size, ls->tsc, reinterpret_cast<const uint32_t *>(ls->tcw), ls->v->n_mgau * ls->v->n_feat,
+                               total_frames, c->pl_css);
+        else
         hipLaunchKernelGGL((phone_loop_prep_kernel<3>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, raw_dev, raw_stride,
                            best_dev, total_frames, c->pl_css);
         hipLaunchKernelGGL((phone_loop_kernel<3>), dim3(n_utt), dim3(64), 0, st, p, (const uint8_t *)c->tp,
                            (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev);
     }
     else {
+        if (ls)
+            hipLaunchKernelGGL((phone_loop_prep_lists_kernel<5>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, sm, ls->v->logadd8,
+                               ls->v->logadd8_size, ls->tsc, reinterpret_cast<const uint32_t *>(ls->tcw), ls->v->n_mgau * ls->v->n_feat,
+                               total_frames, c->pl_css);
+        else
         hipLaunchKernelGGL((phone_loop_prep_kernel<5>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, raw_dev, raw_stride,
                            best_dev, total_frames, c->pl_css);
         hipLaunchKernelGGL((phone_loop_kernel<5>), dim3(n_utt), dim3(64), 0, st, p, (const uint8_t *)c->tp,

@@ -252,7 +252,7 @@ __device__ __forceinline__ int32_t med3_i32(int32_t a, int32_t b, int32_t c)
 typedef float ptm_f2 __attribute__((ext_vector_type(2)));
 
 template <int LEN, int FPL>                     // FPL = frames per lane
-__global__ __launch_bounds__(256, 8)
+__global__ __launch_bounds__(256, FPL >= 4 ? 4 : 8)
 void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_frames,
                      const int32_t *__restrict__ utt_off, int32_t n_utt,
                      uint8_t *__restrict__ seed_out,
@@ -283,6 +283,14 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
 #pragma unroll
         for (int j = 0; j < LEN; ++j) x[q][j] = xp[j];
     }
+    // frames as pairs: the halves of one packed operand live in one aligned register pair from the start
+    ptm_f2 xq[FPL / 2 > 0 ? FPL / 2 : 1][LEN];
+    if (FPL % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < FPL; q += 2)
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) xq[q / 2][j] = (ptm_f2){ x[q][j], x[q + 1][j] };
+    }
     const float *mean = p.mean + (size_t)chain * 128 * LEN;     // wave-uniform: scalar loads
     const float *var = p.var + (size_t)chain * 128 * LEN;
     const float *det = p.det + (size_t)chain * 128;
@@ -312,8 +320,7 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
                 ptm_f2 d = { dt, dt };
 #pragma unroll
                 for (int j = 0; j < LEN; ++j) {
-                    const ptm_f2 xx = { x[q][j], x[q + 1][j] };
-                    const ptm_f2 diff = xx - (ptm_f2){ m[j], m[j] };
+                    const ptm_f2 diff = xq[q / 2][j] - (ptm_f2){ m[j], m[j] };
                     const ptm_f2 sq = diff * diff;
                     const ptm_f2 c = sq * (ptm_f2){ v[j], v[j] };
                     d = d - c;
@@ -660,6 +667,22 @@ static int upload(T **dst, const T *src, size_t n)
     return PSGPU_OK;
 }
 
+// the weights once more, senone-major: [n_sen][n_feat][dens_stride], dens_stride = n_density rounded up to 64.  A kernel that
+// scores single senones (psgpu_sen_dev.h) then finds the topn x n_feat weights of a senone in n_feat cache lines instead of
+// topn x n_feat of them (in the reference's [stream][density][senone] order every weight of a senone is n_sen bytes from
+// the next)
+static int upload_by_senone(psgpu_ptm_model_t *m, const uint8_t *mixw)
+{
+    const size_t ds = ((size_t)m->n_density + 63) / 64 * 64, per = (size_t)m->n_feat * ds;
+    std::vector<uint8_t> t((size_t)m->n_sen * per, 0);
+    for (int f = 0; f < m->n_feat; ++f)
+        for (int d = 0; d < m->n_density; ++d) {
+            const uint8_t *row = mixw + ((size_t)f * m->n_density + d) * m->n_sen;
+            for (int s = 0; s < m->n_sen; ++s) t[(size_t)s * per + (size_t)f * ds + d] = row[s];
+        }
+    return upload(&m->mixw_sen, t.data(), t.size());
+}
+
 extern "C" {
 
 int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
@@ -705,6 +728,7 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
     if ((rc = upload(&m->mean, mean, npar)) || (rc = upload(&m->var, var, npar)) ||
         (rc = upload(&m->det, det, (size_t)m->n_chain * n_density)) ||
         (rc = upload(&m->mixw, mixw, (size_t)n_feat * n_density * n_sen)) ||
+        (rc = upload_by_senone(m, mixw)) ||
         (rc = upload(&m->sen2cb, sen2cb, (size_t)n_sen)) ||
         (rc = upload(&m->logadd8, logadd8, (size_t)logadd8_size))) {
         psgpu_ptm_model_free(m);
@@ -751,7 +775,7 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     if (!m) return;
     hipFree(m->mean); hipFree(m->var); hipFree(m->det);
     hipFree(m->mixw); hipFree(m->sen2cb); hipFree(m->logadd8);
-    hipFree(m->mixw_slot); hipFree(m->group_cb); hipFree(m->slot_sen);
+    hipFree(m->mixw_slot); hipFree(m->group_cb); hipFree(m->slot_sen); hipFree(m->mixw_sen);
     free(m->h_sen2cb);
     for (PtmWorkspace &w : m->ws) { hipFree(w.open_flags); hipFree(w.fix_list); }
     for (int i = 0; i < 4; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
@@ -765,7 +789,7 @@ int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out)
     PSGPU_REQUIRE(m->ds_ratio == 1, "psgpu_ptm_model_view: a model with -ds %d re-scores carried lists on most frames; not supported by the in-kernel scorer", m->ds_ratio);
     memset(out, 0, sizeof *out);
     out->mean = m->mean; out->var = m->var; out->det = m->det;
-    out->mixw = m->mixw; out->sen2cb = m->sen2cb; out->logadd8 = m->logadd8;
+    out->mixw = m->mixw; out->sen2cb = m->sen2cb; out->logadd8 = m->logadd8; out->mixw_sen = m->mixw_sen;
     out->n_mgau = m->n_mgau; out->n_feat = m->n_feat; out->n_density = m->n_density; out->n_sen = m->n_sen;
     out->veclen = m->veclen; out->topn = m->topn; out->logadd8_size = m->logadd8_size;
     for (int f = 0; f < 16; ++f) { out->featlen[f] = m->featlen[f]; out->featoff[f] = m->featoff[f]; }
@@ -849,7 +873,11 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         const long long n_tiles = ((long long)total_frames + 64 * fpl - 1) / (64 * fpl);
         const long long lw = n_tiles * m->n_chain;
         if (m->timing) hipEventRecord(m->ev[0], st);
-        if (fpl == 2)
+        if (fpl == 4)
+            hipLaunchKernelGGL((ptm_lane_kernel<13, 4>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                               topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);
+        else if (fpl == 2)
             hipLaunchKernelGGL((ptm_lane_kernel<13, 2>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
                                pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
                                topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);

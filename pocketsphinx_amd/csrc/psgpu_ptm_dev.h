@@ -28,6 +28,7 @@ struct psgpu_ptm_model_s {
     uint8_t *mixw, *sen2cb, *logadd8;
     uint8_t *h_sen2cb;            // host mirror (active list -> codebook set, ptm_mgau.c:297-321)
     uint8_t *mixw_slot;           // [n_feat][n_density][slot_stride], slot order, rows 64-byte aligned
+    uint8_t *mixw_sen;            // [n_sen][n_feat][dens_stride]: a senone's weights side by side, for kernels that score single senones
     uint8_t *group_cb;            // [n_groups] codebook of each 4-slot group
     uint16_t *slot_sen;           // [n_slots] senone id of a slot, 0xffff = pad
     int32_t slot_stride, n_groups;

@@ -1689,7 +1689,7 @@ int32_t psgpu_fwdtree_can_score_lists(const psgpu_fwdtree_t *m, const psgpu_ptm_
 {
     return (m && v && m->d.small && v->n_feat == kSenStreams && v->topn == kSenTopn && v->n_mgau * v->n_feat <= kFtMaxChains
             && v->n_mgau * v->n_feat <= kFtThreads && v->n_sen == m->d.n_sen && v->n_sen <= kFtMaxSen && v->n_sen < 65536
-            && v->logadd8_size >= 256) ? 1 : 0;
+            && v->logadd8_size >= 256 && v->mixw_sen != nullptr) ? 1 : 0;
 }
 
 int psgpu_fwdtree_search_lists_dev(psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v, const int32_t *topn_score_dev,
@@ -1704,7 +1704,7 @@ int psgpu_fwdtree_search_lists_dev(psgpu_fwdtree_t *m, const psgpu_ptm_view_t *v
                   "psgpu_fwdtree_search_lists_dev: needs the LDS layout and a 3-stream top-4 scorer of at most %d chains (psgpu_fwdtree_can_score_lists)",
                   kFtMaxChains);
     PSGPU_REQUIRE(((uintptr_t)topn_score_dev & 15) == 0 && ((uintptr_t)topn_cw_dev & 3) == 0, "psgpu_fwdtree_search_lists_dev: misaligned lists");
-    const FtListsArg ls = { topn_score_dev, reinterpret_cast<const uint32_t *>(topn_cw_dev), v->mixw, v->sen2cb, v->logadd8, total_frames,
+    const FtListsArg ls = { topn_score_dev, reinterpret_cast<const uint32_t *>(topn_cw_dev), v->mixw_sen, v->sen2cb, v->logadd8, total_frames,
                             v->n_mgau * v->n_feat, v->n_density, v->logadd8_size };
     return ft_search(m, nullptr, 0, &ls, penalties_dev, utt_off_dev, n_utt, max_frames, bp_cap, bss_cap, bp_dev, bss_dev, idx_dev, step_dev,
                      result_dev, 1, pl_window, w1_ssid_out_dev, mpx_ssid_in_dev, mpx_ssid_out_dev, stream);

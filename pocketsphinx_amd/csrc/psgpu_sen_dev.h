@@ -11,9 +11,10 @@ constexpr int32_t kSenMaxNegAscr = 96;      // MAX_NEG_ASCR, ptm_mgau.h
 constexpr int kSenShift = 10;               // SENSCR_SHIFT
 
 struct SenModel {
-    const uint8_t *mixw;                    // [stream][density][n_sen] mixture weights (one byte per senone)
+    const uint8_t *mixw;                    // [n_sen][stream][dens_stride] mixture weights, senone-major (psgpu_ptm_view_t.mixw_sen): a
+                                            // senone's twelve weights lie in three cache lines, not twelve
     const uint8_t *sen2cb;                  // [n_sen]
-    int32_t n_sen, n_density;
+    int32_t n_sen, n_density;               // n_density: dens_stride = n_density rounded up to 64
 };
 
 // (:280-291) one chain's four raw scores against its stream's normaliser: -(score >> 10 - norm), capped, packed as bytes
@@ -35,9 +36,10 @@ __device__ __forceinline__ int32_t sen_eval_f3n4(const SenModel &m, const uint32
     for (int f = 0; f < kSenStreams; ++f) {                  // all twelve weights are asked for before the first is used
         const uint32_t c4 = l_cw[cb * kSenStreams + f];
         nsc[f] = l_sc[cb * kSenStreams + f];
-        const uint8_t *row = m.mixw + (size_t)f * m.n_density * m.n_sen + sen;
+        const int ds = (m.n_density + 63) & ~63;
+        const uint8_t *row = m.mixw + ((size_t)sen * kSenStreams + f) * ds;
 #pragma unroll
-        for (int k = 0; k < kSenTopn; ++k) w[f][k] = row[(size_t)((c4 >> (8 * k)) & 0xff) * m.n_sen];
+        for (int k = 0; k < kSenTopn; ++k) w[f][k] = row[(c4 >> (8 * k)) & 0xff];
     }
     int32_t fden[kSenStreams];
 #pragma unroll

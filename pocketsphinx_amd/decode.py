@@ -86,6 +86,10 @@ class DecodePipeline:
         capi.check(capi.lib().psgpu_decode_last_stage_ms(self.h, ms), "psgpu_decode_last_stage_ms")
         return dict(zip(("front_end", "features", "scorer", "phone_loop", "search", "backtrace"), [float(v) for v in ms]))
 
+    def score_mode(self, lists):
+        """psgpu_decode_score_mode: True -- no score rows, the phone loop and the search score the senones they list"""
+        capi.check(capi.lib().psgpu_decode_score_mode(self.h, int(bool(lists))), "psgpu_decode_score_mode")
+
     def session(self, on=True):
         """psgpu_decode_session: on -- every following one-utterance call continues the decoder session (the scorer's seeding
         history slot, the multiplexed permanent channels' per-state ssids); calling it again forgets the state"""

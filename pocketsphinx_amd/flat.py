@@ -33,7 +33,7 @@ class PtmView(C.Structure):
     _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("det", C.c_void_p), ("mixw", C.c_void_p), ("sen2cb", C.c_void_p),
                 ("logadd8", C.c_void_p), ("n_mgau", C.c_int32), ("n_feat", C.c_int32), ("n_density", C.c_int32),
                 ("n_sen", C.c_int32), ("veclen", C.c_int32), ("topn", C.c_int32), ("logadd8_size", C.c_int32),
-                ("featlen", C.c_int32 * 16), ("featoff", C.c_int32 * 16)]
+                ("featlen", C.c_int32 * 16), ("featoff", C.c_int32 * 16), ("mixw_sen", C.c_void_p)]
 
 
 class FwdflatSearch:

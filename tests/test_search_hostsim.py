@@ -108,6 +108,25 @@ def test_simulated_device_trie_equals_reference_look_ups(name):
     lm.close()
 
 
+def test_search_kernel_source_scoring_its_own_senones(tables):
+    """psgpu_fwdtree_search_lists_dev: no score rows -- the kernel gets the scorer's top-N lists (the reference's, golden
+    ptm_goforward with full_topn) and evaluates ptm_mgau_codebook_norm + ptm_mgau_senone_eval for the senones it lists,
+    as the reference's first pass asks its scorer to.  The tables it produces are the reference decoder's."""
+    g = _load("fwdtree_trace_goforward.npz")
+    gp = _load("ptm_goforward.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    with _layout("lds"):
+        s = simlib.SimFwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    T = rows.shape[0]
+    assert gp["topn_cw"].shape[0] >= T
+    r = simlib.search_lists(s, tables, gp["topn_raw"][:T], gp["topn_cw"][:T], pen, [T])[0]
+    _check(r, g, "lists")
+    n_act = int(g["step_act_off"][-1])                                     # the reference's lists, bridging entries included
+    assert 0.9 * n_act < r["listed"] <= n_act
+    s.close()
+
+
 def _raw_rows(g, rows, seed=5):
     """the reference's normalised scores plus an arbitrary per-frame offset in the listed senones, garbage elsewhere"""
     rng = np.random.default_rng(seed)
