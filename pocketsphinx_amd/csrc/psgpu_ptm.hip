@@ -261,14 +261,23 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
                      int32_t *__restrict__ fix_count, int32_t *__restrict__ fix_list, int32_t fix_cap)
 {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const int n_tiles = (total_frames + 64 * FPL - 1) / (64 * FPL);
-    // consecutive waves (same workgroup) = consecutive tiles of ONE chain: they
-    // stream the same parameters through the scalar cache
-    const int chain = wave / n_tiles;
-    if (chain >= p.n_chain)
+    // A workgroup = four consecutive tiles of ONE chain (its wavefronts stream the same parameters through the scalar
+    // cache).  Which (chain, tiles) a workgroup gets decides how often the feature vectors come from HBM: with the chains
+    // outermost every chain swept all of them (PMC, r02: 30 GB read for 240 MB of features).  Now XCD x (workgroups go to
+    // the XCDs round robin) owns the x-th eighth of the tiles and walks it in blocks of kLaneSuper workgroups' tiles -- 16 k
+    // frames, 2.5 MB of features, which its 4 MB L2 keeps -- all chains of a block before the next block.
+    constexpr int kLaneSuper = 64;
+    const int n_units = (n_tiles + 3) >> 2, upx = (n_units + 7) >> 3;      // units of four tiles; units per XCD
+    const int xcd = (int)(blockIdx.x & 7), i = (int)(blockIdx.x >> 3);
+    const int sb = i / (kLaneSuper * p.n_chain), rem = i - sb * kLaneSuper * p.n_chain;
+    const int s_cur = min(kLaneSuper, upx - sb * kLaneSuper);
+    if (s_cur <= 0) return;
+    const int chain = __builtin_amdgcn_readfirstlane(rem / s_cur);
+    const int unit = xcd * upx + sb * kLaneSuper + (rem - chain * s_cur);
+    const int tile = __builtin_amdgcn_readfirstlane(unit * 4 + (int)(threadIdx.x >> 6));
+    if (chain >= p.n_chain || unit >= n_units || tile >= n_tiles)
         return;
-    const int tile = wave - chain * n_tiles;
     const int f = chain % p.n_feat;
 
     int t[FPL];
@@ -512,7 +521,14 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const int f0 = blockIdx.x * kSenFr;
+    // workgroups go to the eight XCDs round robin (MI355X_MICROARCH "Workgroup dispatch"); the lists are chain-major, so a
+    // 128-byte line of them holds eight consecutive frames of one chain: with frame = workgroup index every XCD's L2 fetched
+    // every line (PMC, r02: 38 GB read per 1.5 M frames for 4 GB of lists).  XCD x now takes the x-th eighth of the frames:
+    // consecutive frames share an L2.  (The grid is a multiple of eight; workgroups past the end leave.)
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int blk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int f0 = blk * kSenFr;
+    if (f0 >= total_frames) return;
     const int nf = min(kSenFr, total_frames - f0);
 
     if (tid < kSenFr * NF) s_norm[tid / NF][tid % NF] = kWorstScore;
@@ -646,7 +662,7 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                 const uint32_t v = s32[j];
                 const uint32_t a = ((v & 0xffff) - (uint32_t)sub) & 0xffff;     // int16 wrap as in :398-400
                 const uint32_t b = ((v >> 16) - (uint32_t)sub) & 0xffff;
-                o32[j] = a | (b << 16);
+                __builtin_nontemporal_store(a | (b << 16), &o32[j]);     // (streamed out once: must not push the weight table out of L2)
             }
         }
         else {
@@ -868,10 +884,14 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
         if (ws->count_dirty)                 // normally the senone kernel of the previous call zeroed it
             PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
         ws->count_dirty = 1;
-        // two frames per lane: the packed single-precision form of the distance (PSGPU_LANE_FPL=1: one frame, scalar form)
-        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 2; }();
+        // frames per lane.  2 and 4 use the packed single-precision form of the distance (v_pk_add_f32 / v_pk_mul_f32), half
+        // the VALU instructions per codeword-frame -- measured on the 512 x 30 s batch (r02, profiles/): 41.2 / 42.2 / 42.1 ms
+        // of scorer stage for 1 / 2 / 4, i.e. the packed operations issue at half rate here and buy nothing; 1 stays the default
+        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 1; }();
         const long long n_tiles = ((long long)total_frames + 64 * fpl - 1) / (64 * fpl);
-        const long long lw = n_tiles * m->n_chain;
+        // workgroups: eight XCD shares of ceil(units / 8) four-tile units, each for every chain (see the kernel)
+        const long long lane_units = (n_tiles + 3) / 4, lane_upx = (lane_units + 7) / 8;
+        const long long lw = 8 * lane_upx * m->n_chain * 4;
         if (m->timing) hipEventRecord(m->ev[0], st);
         if (fpl == 4)
             hipLaunchKernelGGL((ptm_lane_kernel<13, 4>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
@@ -925,7 +945,7 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
         }
         if (best_w) {
             const int kSenFr = (sen_fr == 1 || sen_fr == 4) ? sen_fr : 2;
-            const dim3 grid((total_frames + kSenFr - 1) / kSenFr), block(64 * best_w);
+            const dim3 grid((((total_frames + kSenFr - 1) / kSenFr + 7) / 8) * 8), block(64 * best_w);      // (a multiple of eight: see the kernel)
             const size_t sm = (((size_t)m->n_sen * 2 + 15) / 16) * 16 * kSenFr;
             hipStream_t st = (hipStream_t)stream;
             const PtmDev pv = dev_view(m);

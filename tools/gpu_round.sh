@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 
 if [ "${2:-}" != "skip-tests" ]; then
-  (timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25) > "$OUT/pytest_gpu.log"
+  (timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -40) > "$OUT/pytest_gpu.log"
   cat "$OUT/pytest_gpu.log"
   (timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3) > "$OUT/smoke.log"
   cat "$OUT/smoke.log"
