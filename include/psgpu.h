@@ -708,9 +708,10 @@ typedef struct psgpu_decode_view_s {
     const float *feat_dev;             /* [total][3 * cepsize] */
     const uint8_t *topn_cw_dev;        /* [n_chain][total][topn] */
     const int16_t *rows_dev;           /* [total][n_sen] un-normalised scores; NULL when the search scored its own senones
-                                        * (psgpu_fwdtree_search_lists_dev: the default where the models allow it) */
+                                        * (psgpu_decode_score_mode) */
     const int32_t *penalties_dev;      /* [total][n_phones] */
     int32_t *bp_dev, *bss_dev, *idx_dev, *step_dev, *result_dev, *hyp_dev, *hyp_n_dev, *w1_ssid_dev;
+    const int32_t *topn_score_dev;     /* [n_chain][total][topn] raw scores of the lists */
 } psgpu_decode_view_t;
 int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v);
 /* hyp_n [n_utt][4], hyp [n_utt][max_words][4], result [n_utt][8] (any may be NULL) to the host; waits for the
@@ -803,6 +804,22 @@ int psgpu_fwdflat_search_feats_dev(psgpu_fwdflat_t *m, const psgpu_ptm_view_t *p
                                    const int32_t *result1_dev, const int32_t *w1_ssid_dev, int32_t bp_cap,
                                    int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev, int32_t *idx_dev,
                                    int32_t *step_dev, int32_t *result_dev, void *stream);
+
+/* The same taking the batch scorer's lists of the same frames along (psgpu_ptm_score_batch_dev's topn_score_dev /
+ * topn_cw_dev and its open-entry flags, psgpu_ptm_batch_open_flags).  The reference's second pass re-scores the carried
+ * lists of every codebook and scans the codebooks its active senones touch (ptm_mgau_codebook_eval, ptm_mgau.c:228-254);
+ * for a touched codebook the outcome is the top-N of all its densities whatever list it started from, unless scores tie
+ * or leave the key range (the closed form) -- i.e. the first pass's list of that frame wherever its entry
+ * is not flagged open.  The kernel takes those lists and scans only open entries.  Same results. */
+int psgpu_ptm_batch_open_flags(psgpu_ptm_model_t *m, void *stream, const uint8_t **flags_dev);
+int psgpu_fwdflat_search_feats_lists_dev(psgpu_fwdflat_t *m, const psgpu_ptm_view_t *ptm, const float *feats_dev,
+                                         const int32_t *topn_seed_dev, const int32_t *topn_score_dev,
+                                         const uint8_t *topn_cw_dev, const uint8_t *open_flags_dev, int32_t total_frames,
+                                         const int32_t *utt_off_dev, int32_t n_utt,
+                                         int32_t max_frames, int32_t bp1_cap, const int32_t *bp1_dev,
+                                         const int32_t *result1_dev, const int32_t *w1_ssid_dev, int32_t bp_cap,
+                                         int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev, int32_t *idx_dev,
+                                         int32_t *step_dev, int32_t *result_dev, void *stream);
 
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).

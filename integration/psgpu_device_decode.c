@@ -457,6 +457,7 @@ second_pass_one(psgpu_device_decode_t *d, int T)
     psgpu_decode_view_t v;
     void *st = psgpu_hmm_ctx_stream(d->ctx);
     int32_t res[8];
+    const uint8_t *open_flags = NULL;
     int H = d->n_fast_hist, ts = T - 1, c, i, nb, nh, nfr;
     size_t ne = (size_t)d->n_chain * T * d->topn;
 
@@ -483,8 +484,12 @@ second_pass_one(psgpu_device_decode_t *d, int T)
         for (i = 0; i < d->topn; ++i)      /* a shorter utterance than H frames never wrote that slot: ptm_mgau_init's i-th codeword */
             d->h_seed[c * d->topn + i] = ts >= 0 ? d->h_tcw[((size_t)c * T + ts) * d->topn + i] : i;
     if (psgpu_memcpy_h2d(d->d_seed, d->h_seed, 4 * (size_t)d->n_chain * d->topn, st)
-        || psgpu_fwdflat_search_feats_dev(d->ff, &d->view, v.feat_dev, d->d_seed, v.frame_off_dev, 1, T, v.bp_cap, v.bp_dev, v.result_dev,
-                                          v.w1_ssid_dev, d->bp_cap2, d->bss_cap2, d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)
+        /* (the first pass's lists ride along: where an entry is not open, the second pass's scan of a touched codebook
+         *  arrives at exactly that list -- psgpu_fwdflat_search_feats_lists_dev) */
+        || psgpu_ptm_batch_open_flags(psgpu_mgau_ptm_model(ps_search_acmod(d->ps->search)->mgau), st, &open_flags)
+        || psgpu_fwdflat_search_feats_lists_dev(d->ff, &d->view, v.feat_dev, d->d_seed, v.topn_score_dev, v.topn_cw_dev, open_flags, T,
+                                                v.frame_off_dev, 1, T, v.bp_cap, v.bp_dev, v.result_dev,
+                                                v.w1_ssid_dev, d->bp_cap2, d->bss_cap2, d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)
         || psgpu_memcpy_d2h(res, d->d_res2, sizeof res, st) || psgpu_stream_sync(st)) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;

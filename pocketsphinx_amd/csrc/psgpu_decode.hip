@@ -413,7 +413,7 @@ int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v)
     PSGPU_REQUIRE(d && v, "psgpu_decode_view: NULL argument");
     v->n_utt = d->n_utt; v->total_frames = d->total; v->max_frames = d->max_frames; v->bp_cap = d->bp_cap; v->bss_cap = d->bss_cap;
     v->max_words = d->max_words; v->frame_off = d->frame_off.data();
-    v->frame_off_dev = d->d_off; v->feat_dev = d->d_feat; v->topn_cw_dev = d->d_tcw; v->rows_dev = d->d_rows; v->penalties_dev = d->d_pen;
+    v->frame_off_dev = d->d_off; v->feat_dev = d->d_feat; v->topn_cw_dev = d->d_tcw; v->topn_score_dev = d->d_tsc; v->rows_dev = d->d_rows; v->penalties_dev = d->d_pen;
     v->bp_dev = d->d_bp; v->bss_dev = d->d_bss; v->idx_dev = d->d_idx; v->step_dev = d->d_step; v->result_dev = d->d_res;
     v->hyp_dev = d->d_hyp; v->hyp_n_dev = d->d_hn; v->w1_ssid_dev = d->d_w1;
     return PSGPU_OK;

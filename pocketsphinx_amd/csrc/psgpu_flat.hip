@@ -38,10 +38,19 @@ constexpr int kFfMaxTopn = 8;
 // one work-item per (codebook, stream), sequential in codeword order -- the acceptance rule depends on it), the
 // per-stream normaliser over the touched codebooks only (:265-295), the listed senones (:326-403).  This is why pass-2
 // scores are not a shift of pass-1 rows: in pass 1 the phone loop keeps every codebook touched, here nothing does.
+struct alignas(16) FfQuad { int32_t x, y, z, w; };
 struct FfRaw {
     psgpu_ptm_view_t pm;
     const float *feats;                  // [total][veclen]
     const int32_t *seed;                 // [n_utt][n_chain][topn] codewords of the history slot pass-2 frame 0 starts from
+    // optional: the batch scorer's lists of the same frames (psgpu_ptm_score_batch_dev: chain-major scores / packed codewords /
+    // open flags).  Where an entry is not open its list is the top-N of ALL the chain's densities whatever the seeds were
+    // (the closed form): exactly what eval_topn + eval_cb of a touched codebook arrive at here, so the kernel
+    // takes it instead of scanning 128 densities in one work-item; open entries (ties, out of range) are scanned as before.
+    const int32_t *tsc;
+    const uint32_t *tcw;
+    const uint8_t *open;
+    int32_t total;
 };
 
 struct FfDev {
@@ -397,6 +406,15 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 const size_t base = (size_t)cb * pm.n_density * pm.veclen + (size_t)pm.n_density * pm.featoff[fs];
                 const float *xs = x + pm.featoff[fs];
                 int32_t cw[kFfMaxTopn], sc[kFfMaxTopn];
+                if (rw.tsc && topn == 4 && s_cbact[cb] && !rw.open[(size_t)ch * rw.total + t0 + f]) {
+                    const size_t o = (size_t)ch * rw.total + t0 + f;
+                    const FfQuad q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4);
+                    const uint32_t c4 = rw.tcw[o];
+                    s_lsc[ch * 4] = q.x; s_lsc[ch * 4 + 1] = q.y; s_lsc[ch * 4 + 2] = q.z; s_lsc[ch * 4 + 3] = q.w;
+                    s_lcw[ch * 4] = c4 & 0xff; s_lcw[ch * 4 + 1] = (c4 >> 8) & 0xff; s_lcw[ch * 4 + 2] = (c4 >> 16) & 0xff; s_lcw[ch * 4 + 3] = c4 >> 24;
+                    atomicMax(&s_norm[fs], q.x >> 10);       // ptm_mgau_codebook_norm (:272-279)
+                    continue;
+                }
                 for (int i = 0; i < topn; ++i) cw[i] = s_lcw[ch * topn + i];
                 for (int i = 0; i < topn; ++i) {                 // re-score, stable descending insertion with strict '>' (:71-85)
                     const int c = cw[i];
@@ -954,7 +972,33 @@ extern "C" int psgpu_fwdflat_search_feats_dev(psgpu_fwdflat_t *m, const psgpu_pt
                   ptm->n_sen, ptm->n_mgau, ptm->n_feat, ptm->topn);
     PSGPU_REQUIRE(ptm->mean && ptm->var && ptm->det && ptm->mixw && ptm->sen2cb && ptm->logadd8, "psgpu_fwdflat_search_feats_dev: NULL model table");
     FfRaw rw;
+    memset(&rw, 0, sizeof rw);
     rw.pm = *ptm; rw.feats = feats_dev; rw.seed = topn_seed_dev;
+    return ff_search(m, nullptr, 0, &rw, utt_off_dev, n_utt, max_frames, bp1_cap, bp1_dev, result1_dev, w1_ssid_dev,
+                     bp_cap, bss_cap, bp_dev, bss_dev, idx_dev, step_dev, result_dev, stream);
+}
+
+extern "C" int psgpu_fwdflat_search_feats_lists_dev(psgpu_fwdflat_t *m, const psgpu_ptm_view_t *ptm, const float *feats_dev,
+                                                    const int32_t *topn_seed_dev, const int32_t *topn_score_dev,
+                                                    const uint8_t *topn_cw_dev, const uint8_t *open_flags_dev, int32_t total_frames,
+                                                    const int32_t *utt_off_dev, int32_t n_utt,
+                                                    int32_t max_frames, int32_t bp1_cap, const int32_t *bp1_dev,
+                                                    const int32_t *result1_dev, const int32_t *w1_ssid_dev, int32_t bp_cap,
+                                                    int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev, int32_t *idx_dev,
+                                                    int32_t *step_dev, int32_t *result_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && ptm && feats_dev && topn_seed_dev && topn_score_dev && topn_cw_dev && open_flags_dev,
+                  "psgpu_fwdflat_search_feats_lists_dev: NULL argument");
+    PSGPU_REQUIRE(ptm->n_sen == m->d.n_sen && ptm->n_sen <= kFfMaxSen && ptm->n_mgau >= 1 && ptm->n_mgau <= kFfMaxCb &&
+                  ptm->n_feat >= 1 && ptm->n_feat <= 16 && ptm->topn == 4 &&
+                  (int64_t)ptm->n_mgau * ptm->n_feat * ptm->topn <= kFfMaxEnt && ptm->logadd8_size <= 256 && ptm->n_density >= ptm->topn,
+                  "psgpu_fwdflat_search_feats_lists_dev: model shape outside this version (top-4 lists)");
+    PSGPU_REQUIRE(ptm->mean && ptm->var && ptm->det && ptm->mixw && ptm->sen2cb && ptm->logadd8, "psgpu_fwdflat_search_feats_lists_dev: NULL model table");
+    PSGPU_REQUIRE(((uintptr_t)topn_score_dev & 15) == 0 && ((uintptr_t)topn_cw_dev & 3) == 0, "psgpu_fwdflat_search_feats_lists_dev: misaligned lists");
+    FfRaw rw;
+    memset(&rw, 0, sizeof rw);
+    rw.pm = *ptm; rw.feats = feats_dev; rw.seed = topn_seed_dev;
+    rw.tsc = topn_score_dev; rw.tcw = reinterpret_cast<const uint32_t *>(topn_cw_dev); rw.open = open_flags_dev; rw.total = total_frames;
     return ff_search(m, nullptr, 0, &rw, utt_off_dev, n_utt, max_frames, bp1_cap, bp1_dev, result1_dev, w1_ssid_dev,
                      bp_cap, bss_cap, bp_dev, bss_dev, idx_dev, step_dev, result_dev, stream);
 }

@@ -812,6 +812,17 @@ int psgpu_ptm_model_view(const psgpu_ptm_model_t *m, psgpu_ptm_view_t *out)
     return PSGPU_OK;
 }
 
+// the open-entry flags the last psgpu_ptm_score_batch_dev on `stream` left ([n_chain][total_frames], chain-major like the
+// lists; 1 = the list is not the seed-independent top-N: ties among the best five, or out of range)
+int psgpu_ptm_batch_open_flags(psgpu_ptm_model_t *m, void *stream, const uint8_t **flags_dev)
+{
+    PSGPU_REQUIRE(m && flags_dev, "psgpu_ptm_batch_open_flags: NULL argument");
+    PtmWorkspace *ws = ptm_workspace(m, (hipStream_t)stream, false);
+    PSGPU_REQUIRE(ws && ws->open_flags, "psgpu_ptm_batch_open_flags: no batch has been scored on this stream");
+    *flags_dev = ws->open_flags;
+    return PSGPU_OK;
+}
+
 int32_t psgpu_ptm_n_sen(const psgpu_ptm_model_t *m) { return m->n_sen; }
 int32_t psgpu_ptm_n_chain(const psgpu_ptm_model_t *m) { return m->n_chain; }
 int32_t psgpu_ptm_veclen(const psgpu_ptm_model_t *m) { return m->veclen; }

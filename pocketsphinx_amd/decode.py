@@ -28,7 +28,7 @@ class DecodeView(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_utt", "total_frames", "max_frames", "bp_cap", "bss_cap", "max_words")] + \
                [(n, C.c_void_p) for n in ("frame_off", "frame_off_dev", "feat_dev", "topn_cw_dev", "rows_dev", "penalties_dev",
                                           "bp_dev", "bss_dev", "idx_dev", "step_dev", "result_dev", "hyp_dev", "hyp_n_dev",
-                                          "w1_ssid_dev")]
+                                          "w1_ssid_dev", "topn_score_dev")]
 
 
 def ci_senone_list(sseq, pl_ssid, n_sen):

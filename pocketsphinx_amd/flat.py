@@ -61,12 +61,14 @@ class FwdflatSearch:
         except Exception:
             pass
 
-    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19, ptm=None, topn_seed=None):
+    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19, ptm=None, topn_seed=None, lists=None):
         """senscr [T][n_sen] int16 for utterances back to back (or, with ptm = a PtmModel and topn_seed
         [n_utt][n_chain][topn] codewords, the FEATURE rows [T][veclen] float32: the kernel then scores its own senones,
         psgpu_fwdflat_search_feats_dev); bp1: per utterance the first pass's back-pointer
         table [n][10] (numpy), or the `handover` dict FwdtreeSearch.search filled (device buffers as
         psgpu_fwdtree_search_dev left them); w1_ssid: per utterance [n_1ph][n_emit] or None.
+        lists = (topn_score, topn_cw): the batch scorer's chain-major device lists of the same frames (the scorer's last
+        call on the current stream; its open-entry flags are fetched here): psgpu_fwdflat_search_feats_lists_dev.
         Returns a list of dicts like FwdtreeSearch.search."""
         import torch
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -108,7 +110,14 @@ class FwdflatSearch:
         res = torch.zeros((n, 8), dtype=torch.int32, device=dev)
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None  # noqa: E731
         sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if ptm is not None:
+        if ptm is not None and lists is not None:
+            tsc, tcw = lists
+            fl = C.c_void_p()
+            capi.check(capi.lib().psgpu_ptm_batch_open_flags(ptm.h, sp, C.byref(fl)), "psgpu_ptm_batch_open_flags")
+            capi.check(capi.lib().psgpu_fwdflat_search_feats_lists_dev(self.h, C.byref(view), p(d_s), p(d_seed), p(tsc), p(tcw), fl, T, p(d_o), n,
+                                                                       mf, cap1, p(d_bp1), p(d_res1), p(d_w1), bp_cap, bss_cap, p(bp), p(bss),
+                                                                       p(idx), p(step), p(res), sp), "psgpu_fwdflat_search_feats_lists_dev")
+        elif ptm is not None:
             capi.check(capi.lib().psgpu_fwdflat_search_feats_dev(self.h, C.byref(view), p(d_s), p(d_seed), p(d_o), n, mf, cap1,
                                                                  p(d_bp1), p(d_res1), p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx),
                                                                  p(step), p(res), sp), "psgpu_fwdflat_search_feats_dev")

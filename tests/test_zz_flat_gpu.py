@@ -169,6 +169,9 @@ def impl_two_pass_chain_from_audio(name):
     s2 = P.FwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
     r2 = s2.search(d_f, [T], h, ptm=model, topn_seed=seed)[0]
     check_flat(r2, g, name)
+    # the same taking the first pass's lists where their entries are not open (the closed form) instead of scanning codebooks
+    r3 = s2.search(d_f, [T], h, ptm=model, topn_seed=seed, lists=(tsc, tcw))[0]
+    check_flat(r3, g, name + ", lists taken")
     s1.close(); s2.close(); model.close()
 
 

@@ -88,7 +88,8 @@ def main():
         r1 = s1.search(rows, pen, lens, bp_cap=4096, bss_cap=65536, raw_scores=True, pl_window=int(gt["pl_par"][5]), handover=h)
         torch.cuda.synchronize(); tb = time.perf_counter()
         seed = tcw[:, ts::Tu, :].permute(1, 0, 2).to(torch.int32).contiguous()          # [B][n_chain][topn]
-        r2 = s2.search(ft, lens, h, bp_cap=4096, bss_cap=65536, ptm=model, topn_seed=seed)
+        r2 = s2.search(ft, lens, h, bp_cap=4096, bss_cap=65536, ptm=model, topn_seed=seed,
+                       lists=None if os.environ.get("TP_NO_LISTS") else (tsc, tcw))
         torch.cuda.synchronize(); tc = time.perf_counter()
         return r1, r2, tb - ta, tc - tb
 
