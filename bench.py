@@ -210,8 +210,10 @@ def main():
     capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
     tables = _npz("en_us_ptm_tables.npz")
     gt = _npz("fwdtree_trace_goforward.npz")
-    # PSGPU_BENCH_PIPES=2: two pipeline objects on two streams, consecutive steps overlapping.  Measured (r02, profiles/):
-    # 225.5 vs 225.9 ms per step, i.e. no gain (and twice the buffers), so one pipeline is the default.
+    # PSGPU_BENCH_PIPES=2: two pipeline objects on two streams, consecutive steps overlapping.  Measured (r02,
+    # profiles/r02_variants.txt, tools/overlap_probe.py): 143.0 ms per step with one, 136-140 ms with two (the scorer
+    # kernels of step k + 1 hardly run beside the search kernel of step k), 228 ms with three -- and twice the buffers:
+    # one pipeline is the default.
     n_pipe = max(1, int(os.environ.get("PSGPU_BENCH_PIPES", "1")))
     pipes = [P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
              for _ in range(n_pipe)]

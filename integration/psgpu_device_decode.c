@@ -238,6 +238,19 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     else if (d->lm == NULL) {
         size_t nn = (size_t)n_w + 1;
         lm = ckd_calloc((size_t)n_w * nn * nn, 4);
+        /* The trie's back-off cache (lm_trie.c:775-811) starts zeroed: a full-history look-up whose model history is (0, 0)
+         * matches the zeroed key and is answered with zero back-off weights until any OTHER history has filled the cache.
+         * The table below is the cache's fixed point (what every look-up returns once it has been filled), so it is filled
+         * first, with a history of two different words (their model ids cannot both be 0).  A search never meets the initial
+         * state: its first full-history look-up has the history (w, <s>) with w != <s>. */
+        {
+            int a = -1, b = -1;
+            for (i = 0; i < n_w && b < 0; ++i)
+                if (!dict_filler_word(dict, i) && dict_basewid(dict, i) == i && ngram_model_set_known_wid(ngs->lmset, i)) {
+                    if (a < 0) a = i; else b = i;
+                }
+            if (b >= 0) { int32 nu; (void)ngram_tg_score(ngs->lmset, a, b, a, &nu); (void)ngram_tg_score(ngs->lmset, a, a, b, &nu); }
+        }
         for (i = 0; i < n_w; ++i)
             if (!dict_filler_word(dict, i) && dict_basewid(dict, i) == i)
                 for (j = -1; j < n_w; ++j)

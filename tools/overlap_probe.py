@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Probe: does running two half-batches on two streams (two model handles, each with its own
-scratch) overlap the VALU-bound top-N kernel of one with the latency-bound senone kernel of the
-other?  Prints frames/s for 1 stream x 10k frames and 2 streams x 5k frames."""
-import ctypes as C
+"""Do a batch's scorer kernels run beside another batch's search kernel?  Two pipeline objects on two streams, the benchmark's
+512 x 30 s workload: per step wall time with 1 and 2 steps in flight, with and without stage-timing events, and the
+completion order of stream B's whole step relative to stream A's search."""
 import os
 import sys
 import time
@@ -10,54 +9,43 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench  # noqa: E402
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
     import torch
     import pocketsphinx_amd as P
-    from pocketsphinx_amd import capi
-    L = capi.lib()
+    from pocketsphinx_amd import synth
+    import pso
+    from test_oracle_golden import _load
     dev = torch.device("cuda", 0)
-    t = bench.load_tables()
-    n_streams = int(os.environ.get("NS", 2))
-    T = bench.N_UTT * bench.UTT_LEN
-    feats_h = bench.synth_feats(t, T, bench.SEED)
-    for ns in (1, n_streams, 4):
-        per = T // ns
-        n_utt = bench.N_UTT // ns
-        models = [P.PtmModel(t) for _ in range(ns)]
-        streams = [torch.cuda.Stream() for _ in range(ns)]
-        bufs = []
-        for k in range(ns):
-            f = torch.from_numpy(feats_h[k * per:(k + 1) * per]).to(dev)
-            off = torch.arange(0, per + 1, bench.UTT_LEN, dtype=torch.int32, device=dev)
-            sc = torch.empty((per, models[k].n_chain, 4), dtype=torch.int32, device=dev)
-            cw = torch.empty((per, models[k].n_chain, 4), dtype=torch.uint8, device=dev)
-            out = torch.empty((per, models[k].n_sen), dtype=torch.int16, device=dev)
-            bufs.append((f, off, sc, cw, out))
+    B = int(os.environ.get("OP_B", "512")); sec = float(os.environ.get("OP_SEC", "30"))
+    gt = _load("fwdtree_trace_goforward.npz")
+    tables = _load("en_us_ptm_tables.npz")
+    mk = lambda: P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), tables, _load("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)  # noqa: E731
+    pcm_h = np.concatenate([synth.utterance(i % 64, sec) for i in range(B)])
+    n_samp = pcm_h.size // B
+    pcm = torch.from_numpy(pcm_h).to(dev)
+    soff = np.arange(B + 1, dtype=np.int64) * n_samp
+    for n_pipe, timing, prio in ((1, False, False), (2, False, False), (2, True, False), (2, False, True)):
+        pipes = [mk() for _ in range(n_pipe)]
+        streams = [torch.cuda.Stream(device=dev, priority=(-1 if (prio and k == 1) else 0)) for k in range(n_pipe)]
+        for q in pipes:
+            q.stage_timing(timing)
+        n = 8
+        for k in range(n_pipe):                       # warm
+            pipes[k].run_dev(pcm, soff, streams[k].cuda_stream); streams[k].synchronize()
         torch.cuda.synchronize()
-
-        def step():
-            for k in range(ns):
-                f, off, sc, cw, out = bufs[k]
-                capi.check(L.psgpu_ptm_score_batch_dev(models[k].h, C.c_void_p(f.data_ptr()), C.c_void_p(off.data_ptr()),
-                                                       n_utt, per, None, None, C.c_void_p(sc.data_ptr()),
-                                                       C.c_void_p(cw.data_ptr()), C.c_void_p(out.data_ptr()), None, 0,
-                                                       C.c_void_p(streams[k].cuda_stream)), "score")
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        K = 50
         t0 = time.perf_counter()
-        for _ in range(K):
-            step()
+        for k in range(n):
+            pipes[k % n_pipe].run_dev(pcm, soff, streams[k % n_pipe].cuda_stream)
+            if k >= n_pipe - 1:
+                streams[(k - (n_pipe - 1)) % n_pipe].synchronize()
         torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        print("%d stream(s) x %d frames: %.2f M frames/s (%.1f us per 10k frames)" % (ns, per, T * K / dt / 1e6, 1e6 * dt / K))
-        for m in models:
-            m.close()
+        dt = (time.perf_counter() - t0) / n
+        print("pipes %d stage_timing %s high-priority-second %s: %.1f ms per step" % (n_pipe, timing, prio, dt * 1e3), flush=True)
+        for q in pipes:
+            q.close()
 
 
 if __name__ == "__main__":
