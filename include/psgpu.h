@@ -573,6 +573,10 @@ int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_d
                                      int32_t *idx_dev, int32_t *step_dev, int32_t *result_dev, int32_t raw_scores,
                                      int32_t pl_window, int32_t *w1_ssid_out_dev, const int32_t *mpx_ssid_in_dev,
                                      int32_t *mpx_ssid_out_dev, void *stream);
+/* The NEXT psgpu_fwdtree_search_*_dev call on this handle also writes each utterance's hypothesis, as
+ * psgpu_fwdtree_backtrace_dev would (same layout): the walk over the table is the search kernel's last step, one launch
+ * less per batch.  One call's worth: the search call clears it.  (NULL, NULL, 0) withdraws it. */
+int psgpu_fwdtree_hyp_out(psgpu_fwdtree_t *m, int32_t *hyp_dev, int32_t *hyp_n_dev, int32_t max_words);
 /* ngram_search_find_exit (ngram_search.c:500-544) + the backtrace of ngram_search_bp_hyp / the segment
  * iterator (:546-581, 903-1010) for every utterance of a batch, on the tables as the search left them:
  * hyp_dev + u*max_words*4 = {word id, start frame, end frame, path score at the word's end} per word in
@@ -658,6 +662,25 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
 void psgpu_decode_free(psgpu_decode_t *d);
 /* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
+/* Two pipeline objects taking turns.  The tree search is a latency-bound recurrence -- one workgroup per utterance, most
+ * issue slots of its compute units idle -- and the stages before it are throughput-bound, so the front end and scorer of
+ * one batch run BESIDE the search of another: one object per batch in flight, each on a stream with a hardware queue of
+ * its own (psgpu_stream_create_dedicated).  The search kernel is built to leave room (168 registers a wave, ~50 KB of LDS a
+ * workgroup: two workgroups on a compute unit leave a third of its registers, six of eight wave slots per SIMD and ~60 KB
+ * of LDS), but two rules keep its placement sound, both enforced on the device by events once psgpu_decode_search_after
+ * (a, b) and (b, a) have been called: (1) two searches are never resident together -- d's search waits for the search of
+ * prev's latest call; (2) a search is dispatched onto a device that runs nothing else at that moment -- a call's first
+ * stages wait until the search of prev's latest call has been dispatched (a search kernel dispatched while other kernels
+ * hold LDS gets one workgroup per compute unit instead of two and takes twice as long, profiles/r03_overlap.txt).  The
+ * caller alternates the objects and starts a call on one only when that object's previous results have been fetched.
+ * psgpu_decode_wait_scored blocks the host until the latest call's stages before the search have finished.  prev = NULL
+ * ends the arrangement; an object must not be freed while another names it as prev. */
+int psgpu_decode_search_after(psgpu_decode_t *d, psgpu_decode_t *prev);
+int psgpu_decode_wait_scored(psgpu_decode_t *d);
+/* a stream with a hardware queue of its own (streams of one priority may share a queue, and kernels of one queue never
+ * overlap): hipExtStreamCreateWithCUMask with every compute unit enabled */
+int psgpu_stream_create_dedicated(void **stream);
+int psgpu_stream_destroy(void *stream);
 /* lists != 0: no score rows -- the phone loop and the search evaluate the senones they list from the scorer's top-N lists
  * (psgpu_phone_loop_run_lists_dev, psgpu_fwdtree_search_lists_dev); the senone kernel is not run and rows_dev of the view is
  * NULL.  Same results bit for bit; 15.7 GB less traffic and a third less scorer time on the 512 x 30 s batch, but more time in
@@ -695,7 +718,8 @@ int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const
 int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int32_t *frame_off, int32_t n_utt, void *stream);
 /* Per-stage timing of psgpu_decode_first_pass_dev / psgpu_decode_first_pass: when enabled, HIP events are recorded on
  * the launch stream between the stages; ms[6] = front end, dynamic features, scorer (its three kernels), phone loop
- * (two kernels), lexicon-tree search kernel, backtrace kernel of the latest call (waits for it). */
+ * (two kernels), lexicon-tree search kernel (the backtrace is its last step), and the time the stream waited for another
+ * object's search before it (psgpu_decode_search_after; otherwise ~0) of the latest call (waits for it). */
 int psgpu_decode_stage_timing(psgpu_decode_t *d, int32_t enable);
 int psgpu_decode_last_stage_ms(psgpu_decode_t *d, float ms[6]);
 /* what the last call left on the device (valid until the next call), for a second pass or a custom read-out:

@@ -111,6 +111,32 @@ int psgpu_stream_sync(void *stream)
     return PSGPU_OK;
 }
 
+int psgpu_stream_create_dedicated(void **stream)
+{
+    PSGPU_REQUIRE(stream != nullptr, "psgpu_stream_create_dedicated: NULL argument");
+    *stream = nullptr;
+    int rc = psgpu_check_device();
+    if (rc != PSGPU_OK) return rc;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    PSGPU_HIP(hipGetDevice(&dev));
+    PSGPU_HIP(hipGetDeviceProperties(&prop, dev));
+    const uint32_t n_words = (uint32_t)((prop.multiProcessorCount + 31) / 32);
+    uint32_t mask[64];
+    PSGPU_REQUIRE(n_words >= 1 && n_words <= 64, "psgpu_stream_create_dedicated: %d compute units", prop.multiProcessorCount);
+    for (uint32_t i = 0; i < n_words; ++i) mask[i] = 0xffffffffu;
+    hipStream_t st;
+    PSGPU_HIP(hipExtStreamCreateWithCUMask(&st, n_words, mask));
+    *stream = (void *)st;
+    return PSGPU_OK;
+}
+
+int psgpu_stream_destroy(void *stream)
+{
+    if (stream) PSGPU_HIP(hipStreamDestroy((hipStream_t)stream));
+    return PSGPU_OK;
+}
+
 int psgpu_event_create(void **ev)
 {
     hipEvent_t e;

@@ -47,6 +47,10 @@ struct psgpu_decode_s {
     bool timing = false;
     hipEvent_t ev[7] = {};
     bool ev_valid = false;
+    // psgpu_decode_search_after: this object's search waits for the search of prev's latest call
+    psgpu_decode_s *prev = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_srch = nullptr, ev_go = nullptr;
+    bool srch_recorded = false, go_recorded = false;
 };
 
 static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
@@ -121,6 +125,9 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
     DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_noise); DFREE(d->d_undef);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
+    if (d->ev_pre) hipEventDestroy(d->ev_pre);
+    if (d->ev_srch) hipEventDestroy(d->ev_srch);
+    if (d->ev_go) hipEventDestroy(d->ev_go);
     delete d;
 }
 
@@ -186,6 +193,26 @@ int psgpu_decode_session_get(psgpu_decode_t *d, uint8_t *seed_cw, int32_t *seed_
     return PSGPU_OK;
 }
 
+int psgpu_decode_search_after(psgpu_decode_t *d, psgpu_decode_t *prev)
+{
+    PSGPU_REQUIRE(d != nullptr && d != prev, "psgpu_decode_search_after: bad argument");
+    for (psgpu_decode_s *q : { d, prev })
+        if (q && !q->ev_pre) {
+            PSGPU_HIP(hipEventCreateWithFlags(&q->ev_pre, hipEventDisableTiming));
+            PSGPU_HIP(hipEventCreateWithFlags(&q->ev_srch, hipEventDisableTiming));
+            PSGPU_HIP(hipEventCreateWithFlags(&q->ev_go, hipEventDisableTiming));
+        }
+    d->prev = prev;
+    return PSGPU_OK;
+}
+
+int psgpu_decode_wait_scored(psgpu_decode_t *d)
+{
+    PSGPU_REQUIRE(d && d->ev_pre, "psgpu_decode_wait_scored: psgpu_decode_search_after first");
+    PSGPU_HIP(hipEventSynchronize(d->ev_pre));
+    return PSGPU_OK;
+}
+
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model)
 {
     PSGPU_REQUIRE(d && model, "psgpu_decode_set_model: NULL argument");
@@ -221,6 +248,7 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
         wait();
         const size_t nu = std::max(n_utt, d->cap_utt), cb = std::max(bp_cap, d->cap_bp), cs = std::max(bss_cap, d->cap_bss),
                      cm = std::max(mf, d->cap_mf);
+        psgpu_fe_offsets_dirty(d->cfg.fe);
         DFREE(d->d_off); DFREE(d->d_bp); DFREE(d->d_bss); DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn);
         DFREE(d->d_w1);
         d->cap_utt = 0;
@@ -271,6 +299,15 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
                                       nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st);
     if (rc) return rc;
     dec_mark(d, 4, st);
+    if (d->ev_pre) {
+        PSGPU_HIP(hipEventRecord(d->ev_pre, st));            // psgpu_decode_wait_scored
+        if (d->prev && d->prev->srch_recorded) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_srch, 0));
+        PSGPU_HIP(hipEventRecord(d->ev_go, st));             // "this call's search is being dispatched": the other object's next call waits for it
+        d->go_recorded = true;
+    }
+    dec_mark(d, 5, st);                                  // (4 -> 5: waiting for the other object's search, if any)
+    // the hypotheses are the search kernel's last step
+    if ((rc = psgpu_fwdtree_hyp_out(d->cfg.ft, d->d_hyp, d->d_hn, d->max_words))) return rc;
     // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
     if (d->lists)
         rc = psgpu_fwdtree_search_lists_dev(d->cfg.ft, &d->view, d->d_tsc, d->d_tcw, (int32_t)total, d->d_pen, d->d_off, n_utt, (int32_t)mf,
@@ -281,10 +318,8 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
                                               d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
                                               chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st);
     if (rc) return rc;
+    if (d->ev_srch) { PSGPU_HIP(hipEventRecord(d->ev_srch, st)); d->srch_recorded = true; }
     if (sess) d->sess_started = true;
-    dec_mark(d, 5, st);
-    rc = psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp, d->d_idx, d->d_res, n_utt, (int32_t)mf, d->bp_cap, d->max_words, d->d_hyp,
-                                     d->d_hn, st);
     dec_mark(d, 6, st);
     return rc;
 }
@@ -308,6 +343,11 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
     d->total = (int32_t)total; d->max_frames = (int32_t)mf;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     d->ev_valid = false;
+    // taking turns with another object (psgpu_decode_search_after): this call's first stages start when the other object's
+    // search has been dispatched -- onto a device that runs nothing else at that moment, so that all its workgroups are placed
+    // at once.  A search kernel dispatched while other kernels hold part of the compute units' LDS gets one workgroup per
+    // compute unit instead of two and takes twice as long (profiles/r03_overlap.txt).
+    if (d->prev && d->prev->go_recorded) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_go, 0));
     dec_mark(d, 0, st);
     // session: the noise tracker of the reference's front end lives until ps_start_stream (fe_start_utt, fe_interface.c:318-326,
     // does not reset it): utterance k + 1's spectra are cleaned with what utterance k left
@@ -357,6 +397,7 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
     d->total = (int32_t)total; d->max_frames = (int32_t)mf;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     PSGPU_HIP(hipStreamSynchronize(st));                 // frame_off / feat are the caller's: copied before returning
+    psgpu_fe_offsets_dirty(d->cfg.fe);
     PSGPU_HIP(hipMemcpyAsync(d->d_off, frame_off, 4 * ((size_t)n_utt + 1), hipMemcpyHostToDevice, st));
     if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * 3 * d->cepsize, hipMemcpyHostToDevice, st));
     PSGPU_HIP(hipStreamSynchronize(st));
@@ -404,7 +445,9 @@ int psgpu_decode_last_stage_ms(psgpu_decode_t *d, float ms[6])
     PSGPU_REQUIRE(d && ms, "psgpu_decode_last_stage_ms: NULL argument");
     PSGPU_REQUIRE(d->ev_valid, "psgpu_decode_last_stage_ms: no timed psgpu_decode_first_pass_dev call yet");
     PSGPU_HIP(hipEventSynchronize(d->ev[6]));
-    for (int i = 0; i < 6; ++i) PSGPU_HIP(hipEventElapsedTime(&ms[i], d->ev[i], d->ev[i + 1]));
+    for (int i = 0; i < 4; ++i) PSGPU_HIP(hipEventElapsedTime(&ms[i], d->ev[i], d->ev[i + 1]));
+    PSGPU_HIP(hipEventElapsedTime(&ms[4], d->ev[5], d->ev[6]));          // the search kernel (its last step is the backtrace)
+    PSGPU_HIP(hipEventElapsedTime(&ms[5], d->ev[4], d->ev[5]));          // waiting for another object's search (psgpu_decode_search_after)
     return PSGPU_OK;
 }
 

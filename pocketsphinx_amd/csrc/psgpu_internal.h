@@ -27,6 +27,10 @@ void psgpu_set_error(const char *fmt, ...);
 
 int psgpu_check_device();   // PSGPU_OK iff a gfx950 device is current
 
+// psgpu_fe_process_utts_dev skips the upload of offsets that are unchanged since its previous call; a caller that writes the
+// frame-offset buffer itself (or replaces it) says so
+void psgpu_fe_offsets_dirty(psgpu_fe_t *fe);
+
 // Reference constants (include/pocketsphinx/prim_type.h:168, hmm.h:73,84,
 // tied_mgau_common.h:60,78-82)
 constexpr int32_t kMaxNegInt32 = (int32_t)0x80000000;

@@ -37,7 +37,9 @@
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
-constexpr int kFtLdsWords = 15488;     // LDS layout: 60.5 KB of arrays (+ 2.4 KB fixed) per workgroup, two workgroups per CU
+constexpr int kFtLdsWords = 15488;     // LDS layout: at most 60.5 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
+                                       // that reads score rows leaves the last 14 KB out (FtLay::rows_total): two workgroups per CU then take ~100 of its
+                                       // 160 KB and leave the rest to the kernels of other streams that run beside the search
 constexpr int kFtListCap = 1024;       // listed senones per frame kept as a list (LDS layout, scoring from top-N lists); more: scored where found
 constexpr int kFtMaxChains = 128;      // (codebook, stream) chains whose lists the LDS layout holds
 constexpr int kFtMinEvl = 512;         // the frame's evaluation list holds at least this many entries (LDS layout)
@@ -61,7 +63,8 @@ struct FtLay {
                                          // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
-    int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
+    int32_t row, pen;                    // small layout: the frame's score row (int16; scoring from lists only) and two penalty rows
+    int32_t rows_total;                  // small layout: words of the pool a launch that reads score ROWS needs (row and l_* lie behind)
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
     int32_t tp;                          // small layout: copy of the transition matrices (bytes)
     int32_t total;
@@ -97,6 +100,8 @@ struct FtBufs {
     int32_t ls_total, ls_chains, ls_density, ls_la_size;
     const int32_t *mpx_in;               // session state: per utterance [(R + n1)][n_emit] per-state ssids of the multiplexed channels, or NULL
     int32_t *mpx_out;
+    int32_t *hyp, *hyp_n;                // the hypotheses, written by the kernel's last step (NULL: not wanted; see psgpu_fwdtree_hyp_out)
+    int32_t max_words;
     long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][32] cycles per phase (tools/build_prof_lib.py)
     int32_t bp_cap, bss_cap, max_frames;
 };
@@ -106,6 +111,8 @@ struct psgpu_fwdtree_s {
     std::vector<void *> allocs;
     int32_t *slab = nullptr;             // work slab, kept between calls (grown on demand)
     size_t slab_words = 0;
+    int32_t *hyp_out = nullptr, *hyp_n_out = nullptr;    // psgpu_fwdtree_hyp_out: for the NEXT search call only
+    int32_t hyp_max_words = 0;
 };
 
 // ---- channel records ---------------------------------------------------------------------------------------------
@@ -326,6 +333,38 @@ __device__ __forceinline__ bool ft_save_bp(const FtTab &t, const FtDict &d, int3
     return true;
 }
 
+// ngram_search_find_exit (ngram_search.c:500-544, frame_idx = -1) + the walk of ngram_search_bp_hyp / the segment iterator
+// (:546-581, 903-1010) over ONE utterance's table, by one work-item.  hyp [max_words][4] = wid, start frame, end frame, path
+// score at the word's end, in spoken order; hn [4] = number of words (may exceed max_words: then only the LAST max_words are
+// stored), path score of the exit, exit back-pointer, 0.
+__device__ __forceinline__ void ft_backtrace_one(const FtTab &tb, const int32_t *idx, int n_frame, int finish_wid, int max_words,
+                                                 int32_t *hyp, int32_t *hn)
+{
+    hn[0] = 0; hn[1] = kW; hn[2] = -1; hn[3] = 0;
+    if (n_frame == 0) return;
+    int f = n_frame - 1;
+    const int end = idx[f];
+    while (f >= 0 && idx[f] == end) --f;
+    if (f < 0) return;
+    int best = -1; int32_t best_score = kW;
+    for (int bp = idx[f]; bp < end; ++bp) {
+        const int wid = BPC(tb, B_WID, bp);
+        if (wid == finish_wid || BPC(tb, B_SCORE, bp) > best_score) { best_score = BPC(tb, B_SCORE, bp); best = bp; }
+        if (wid == finish_wid) break;
+    }
+    int n = 0;
+    for (int b = best; b != -1; b = BPC(tb, B_BP, b)) ++n;
+    hn[0] = n; hn[1] = best_score; hn[2] = best;
+    int k = n - 1;
+    const int skip = n > max_words ? n - max_words : 0;
+    for (int b = best; b != -1 && k >= skip; --k) {
+        const int prev = BPC(tb, B_BP, b);
+        int32_t *h = hyp + (size_t)(k - skip) * 4;
+        h[0] = BPC(tb, B_WID, b); h[1] = prev == -1 ? 0 : BPC(tb, B_FRAME, prev) + 1; h[2] = BPC(tb, B_FRAME, b); h[3] = BPC(tb, B_SCORE, b);
+        b = prev;
+    }
+}
+
 // Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, not for its outstanding
 // device-memory loads and stores (which __syncthreads() drains: the score-row prefetch would never survive a phase, and
 // every store would be waited for ~50 times a frame).  Where work-items exchange data through DEVICE memory (the
@@ -503,26 +542,37 @@ __device__ __forceinline__ int ft_key_bp(unsigned long long k) { return 0x7fffff
 #define FT_PROFD1(n) do { } while (0)
 #endif
 
-// measuring builds: PSGPU_FT_ROW_DIRECT reads the frame's scores straight from device memory (no copy through LDS, no
-// prefetch); PSGPU_FT_PLAIN_PREFETCH uses ordinary instead of non-temporal loads for the copy
-#ifdef PSGPU_FT_ROW_DIRECT
-constexpr bool kFtRowLds = false;
-#else
-constexpr bool kFtRowLds = true;
+// Registers.  The LDS layout's pool limits a compute unit to two workgroups, i.e. two waves per SIMD, and a compiler that
+// sees that hands the kernel the whole register file -- 251 VGPRs (allocated: 256) a wave, 2 x 256 = all 512 of a SIMD:
+// NO other wave can start on a compute unit that holds two of these workgroups, so with 512 utterances resident every kernel
+// of every other stream waits for the first utterance to finish (measured: a 256-element fill launched beside the search
+// completes 76 ms after the search started whenever it was launched, profiles/r03_overlap.txt).  The search is a
+// latency-bound recurrence that leaves most issue slots idle; the throughput-bound stages of ANOTHER batch (front end,
+// scorer) are the natural co-runners.  So the pool is dynamic LDS -- its size is not the compiler's business -- and the
+// kernel asks for the occupancy of kFtWavesPerEu waves per SIMD, i.e. at most 168 VGPRs a wave: two resident workgroups then
+// leave a third of every SIMD's registers (and six of its eight wave slots) to other kernels.
+#ifndef PSGPU_FT_WAVES
+#define PSGPU_FT_WAVES 3
 #endif
-#ifdef PSGPU_FT_PLAIN_PREFETCH
-#define FT_ROW_LOAD(p) (*(p))
+constexpr int kFtWavesPerEu = PSGPU_FT_WAVES;
+#if defined(__HIPCC__)
+extern __shared__ __attribute__((aligned(16))) int32_t ft_dyn_pool[];
+#define FT_KERNEL_ATTR(SMALL) __attribute__((amdgpu_waves_per_eu((SMALL) ? kFtWavesPerEu : 1)))
 #else
-#define FT_ROW_LOAD(p) __builtin_nontemporal_load(p)
+#define FT_KERNEL_ATTR(SMALL)
 #endif
 
-template <int NE, int NT, bool SMALL>
-__global__ __launch_bounds__(NT)
+template <int NE, int NT, bool SMALL, bool LISTS>
+__global__ __launch_bounds__(NT) FT_KERNEL_ATTR(SMALL)
 void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_stride, const int32_t *__restrict__ penalties_,
                     const int32_t *__restrict__ utt_off_, int32_t raw_mode, int32_t pl_window, FtBufs bf)
 {
     using F = ChF<NE>;
-    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 4];
+#if defined(__HIPCC__)
+    int32_t *const s_pool = ft_dyn_pool;                 // SMALL: kFtLdsWords words of dynamic LDS (the launch says so)
+#else
+    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 4];  // (the workgroup simulator)
+#endif
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
     __shared__ int32_t s_red[8];
@@ -556,7 +606,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const woff = fb + L.woff, *const evl = fb + L.evl;
     unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
     // scoring from the scorer's top-N lists (LDS layout only; the host sees to that)
-    const bool lists = SMALL && bf.tsc != nullptr;
+    constexpr bool lists = LISTS;                        // (a template parameter: the score row is LDS here and device memory otherwise,
+                                                         //  and an access whose address space is a run-time matter becomes a flat_* access)
+    static_assert(!LISTS || SMALL, "scoring from lists needs the LDS layout");
     uint32_t *const l_cw = reinterpret_cast<uint32_t *>(fb + L.l_cw), *const l_sc = reinterpret_cast<uint32_t *>(fb + L.l_sc);
     uint8_t *const l_la = reinterpret_cast<uint8_t *>(fb + L.l_la);
     uint16_t *const l_list = reinterpret_cast<uint16_t *>(fb + L.l_list);
@@ -601,7 +653,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         uint8_t *const l_tp = reinterpret_cast<uint8_t *>(fb + L.tp);
         for (int i = tid; i < p.n_tmat * NE * (NE + 1); i += NT) l_tp[i] = g_tp[i];
     }
-    int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // small layout only
+    int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // scoring from lists only
     int32_t *const s_pen = fb + L.pen;                                      // small layout only: [2][n_ci]
 
     // an utterance shorter than the look-ahead window is never searched by the reference: ps_end_utt steps the main search
@@ -624,10 +676,19 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int nwords = (p.n_sen + 31) >> 5;
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
     }
-    // the small layout reads scores and penalties from LDS: frame 0's rows now, every later frame's one frame ahead
-    constexpr bool ROWL = SMALL && kFtRowLds;           // the frame's score row is read from its LDS copy
-    constexpr int kPre = ROWL ? (kFtMaxSen / 2 + NT - 1) / NT : 1;
-    const int row_dw = (p.n_sen + 1) >> 1;              // dwords per score row (the host checked the alignment)
+    // Scores.  From rows: read where they lie, in device memory -- the search looks at ~400 of a row's 5126 scores, and a copy
+    // of the row in LDS (two of them, to receive the next while this one is read) was a third of the workgroup's LDS, which
+    // the kernels of other streams that run beside the search need more (two resident workgroups left 23 KB of a compute
+    // unit's 160 KB: ONE workgroup of the senone kernel).  The next frame's row is pulled into the L2 one frame ahead instead:
+    // one dword of each of its 128-byte lines is loaded (and never used) after this frame's evaluation, so that the reads of
+    // the next frame's marking and evaluation are L2 hits, not HBM misses, on the frame's critical path.  From lists: the
+    // frame's scores are computed into an LDS row (s_row).  Penalties: LDS in the small layout, two rows taking turns.
+    const int row_lines = (p.n_sen * 2 + 127) >> 7;     // 128-byte lines of a score row
+    uint32_t touch_acc = 0u;
+    auto row_touch = [&](int fr) {
+        const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + fr) * scr_stride);
+        for (int i = tid; i < row_lines; i += NT) touch_acc ^= g[min(i * 32, ((p.n_sen + 1) >> 1) - 1)];
+    };
     auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T - 1) : f); };
     // scoring from lists: a frame's lists -- per (codebook, stream) chain four raw scores and four codewords -- travel one frame
     // ahead in registers like the score row does, 5 words a work-item instead of 16: loaded after the evaluation, the streams'
@@ -667,11 +728,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             lists_load(0);
             lists_norm();
         }
-        else if (ROWL) {
-            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
-            uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
-            for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
-        }
         if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[i] = penalties[(size_t)pen_frame(0) * n_ci + i];
     }
     __syncthreads();
@@ -694,7 +750,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         int32_t *const awlc = fb + (cur ? L.awl1 : L.awl0), *const awln = fb + (cur ? L.awl0 : L.awl1);
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : penalties + (size_t)pen_frame(f) * n_ci;
-        const int16_t *const row = ROWL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
+        const int16_t *const row = lists ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
@@ -884,15 +940,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // small layout: the next frame's score row and penalties start their way from HBM now -- the barriers from here to
         // the language-model look-ups wait for LDS only, so the loads stay in flight across them; they are written to LDS
         // at the end of the frame (this frame's row has been read: evaluation is over)
-        uint32_t pre[kPre];
         int32_t pre_pen = 0;
         if (SMALL && nf < T) {
             if (lists) lists_load(nf);
-            else if (ROWL) {
-                const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + nf) * scr_stride);
-#pragma unroll
-                for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; pre[k] = i < row_dw ? FT_ROW_LOAD(g + i) : 0u; }
-            }
+            else row_touch(nf);
             if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
         }
         if (tid == 0) {
@@ -1394,11 +1445,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
         if (SMALL && nf < T) {                               // the next frame's score row and penalties take their place
             if (lists) lists_norm();
-            else if (ROWL) {
-                uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
-#pragma unroll
-                for (int k = 0; k < kPre; ++k) { const int i = tid + k * NT; if (i < row_dw) d[i] = pre[k]; }
-            }
             if (p.has_pl && tid < n_ci) s_pen[nxt * n_ci + tid] = pre_pen;
         }
         ft_sync<SMALL>();
@@ -1407,11 +1453,20 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #ifdef PSGPU_FT_PROFILE
     if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
+    if (touch_acc == 0x9e3779b9u && T < 0) result[7] = 1;      // (never: keeps the row-touching loads alive)
+    if (bf.hyp) __syncthreads();                                 // the table's last entries (device memory, other work-items') before the backtrace
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
         result[0] = s_sc[3]; result[1] = s_sc[4]; result[2] = s_sc[7]; result[3] = s_sc[6];
         result[4] = s_sc[0];                                     // ngs->best_score as the last frame left it
         result[5] = (int32_t)(s_evals & 0xffffffffull); result[6] = (int32_t)(s_evals >> 32); result[7] = s_nsen;
+        // the hypothesis, while the table's tail is still in this compute unit's cache: a separate backtrace launch is one more
+        // dispatch per batch, and a tiny dispatch issued beside ANOTHER stream's resident search kernel was measured stalling for
+        // that kernel's whole duration (profiles/r03_overlap.txt).  (The table was written by this workgroup; the full barrier
+        // above ordered those stores before this read.)
+        if (bf.hyp)
+            ft_backtrace_one(tb, tb.idx, s_sc[7], p.finishwid, bf.max_words, psgpu_as_global(bf.hyp) + (size_t)blockIdx.x * bf.max_words * 4,
+                             psgpu_as_global(bf.hyp_n) + (size_t)blockIdx.x * 4);
     }
     // what the second pass inherits besides the tables: the permanent single-phone channels keep their per-state ssids
     // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)
@@ -1441,32 +1496,9 @@ __global__ void fwdtree_backtrace_kernel(const int32_t *__restrict__ bp_all, con
     if (u >= n_utt) return;
     FtTab tb;
     tb.bp = const_cast<int32_t *>(bp_all) + (size_t)u * 10 * bp_cap; tb.bp_cap = bp_cap;
-    const int32_t *idx = idx_all + (size_t)u * (max_frames + 2);
-    int32_t *hyp = hyp_all + (size_t)u * max_words * 4, *hn = hyp_n_all + (size_t)u * 4;
-    const int n_frame = res_all[(size_t)u * 8 + 2];
-    hn[0] = 0; hn[1] = kW; hn[2] = -1; hn[3] = 0;
-    if (n_frame == 0) return;
-    int f = n_frame - 1;
-    const int end = idx[f];
-    while (f >= 0 && idx[f] == end) --f;
-    if (f < 0) return;
-    int best = -1; int32_t best_score = kW;
-    for (int bp = idx[f]; bp < end; ++bp) {
-        const int wid = BPC(tb, B_WID, bp);
-        if (wid == finish_wid || BPC(tb, B_SCORE, bp) > best_score) { best_score = BPC(tb, B_SCORE, bp); best = bp; }
-        if (wid == finish_wid) break;
-    }
-    int n = 0;
-    for (int b = best; b != -1; b = BPC(tb, B_BP, b)) ++n;
-    hn[0] = n; hn[1] = best_score; hn[2] = best;
-    int k = n - 1;
-    const int skip = n > max_words ? n - max_words : 0;
-    for (int b = best; b != -1 && k >= skip; --k) {
-        const int prev = BPC(tb, B_BP, b);
-        int32_t *h = hyp + (size_t)(k - skip) * 4;
-        h[0] = BPC(tb, B_WID, b); h[1] = prev == -1 ? 0 : BPC(tb, B_FRAME, prev) + 1; h[2] = BPC(tb, B_FRAME, b); h[3] = BPC(tb, B_SCORE, b);
-        b = prev;
-    }
+    tb.bss = nullptr; tb.idx = nullptr; tb.bss_cap = 0;
+    ft_backtrace_one(tb, idx_all + (size_t)u * (max_frames + 2), res_all[(size_t)u * 8 + 2], finish_wid, max_words,
+                     hyp_all + (size_t)u * max_words * 4, hyp_n_all + (size_t)u * 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -1507,21 +1539,27 @@ static bool ft_layout(FtDev &d, bool small)
     L.cnt2 = take(d.n_w + 2); L.cnt3 = take(d.n_w + 2); L.woff = take(d.n_w + 2); L.ckey = take(2 * ((int64_t)d.n_w + 2));
     L.present = take(((int64_t)d.TOT + 3) / 4);
     if (small) {
-        L.row = take(((int64_t)d.n_sen + 1) / 2 + 4); L.pen = take(2 * (int64_t)d.n_ci);
+        L.pen = take(2 * (int64_t)d.n_ci);
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
-        // scoring from top-N lists (psgpu_fwdtree_search_lists_dev)
-        L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
-        L.l_norm = take(kFtThreads / 64 * kSenStreams);
-        // what is left of the pool holds the frame's evaluation list
-        const int64_t left = (int64_t)kFtLdsWords - o;
+        // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the frame's
+        // score row, the lists, the log-add table, the listed senones: a launch that reads score rows asks for less LDS
+        const int64_t tail = ((int64_t)d.n_sen + 1) / 2 + 4 + 2 * (int64_t)kFtMaxChains + 512 / 4 + kFtListCap / 2 + kFtThreads / 64 * kSenStreams + 16;
+        // the frame's evaluation list takes what is left
+        const int64_t left = (int64_t)kFtLdsWords - o - tail;
         if (left < kFtMinEvl || d.n_sen > kFtMaxSen) return false;
         L.evl_cap = (int32_t)std::min<int64_t>(left & ~(int64_t)3, 8192);
+        L.evl = take(L.evl_cap);
+        L.rows_total = (int32_t)o;
+        L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
+        L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
+        L.l_norm = take(kFtThreads / 64 * kSenStreams);
     }
-    else
+    else {
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
-    L.evl = take(L.evl_cap);
+        L.evl = take(L.evl_cap);
+    }
     if (o > 0x7fffff00) return false;
     L.total = (int32_t)o;
     d.small = small ? 1 : 0;
@@ -1743,6 +1781,8 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
         bf.tsc = ls->tsc; bf.tcw = ls->tcw; bf.mixw = ls->mixw; bf.sen2cb = ls->sen2cb; bf.la = ls->la;
         bf.ls_total = ls->total; bf.ls_chains = ls->chains; bf.ls_density = ls->density; bf.ls_la_size = ls->la_size;
     }
+    bf.hyp = m->hyp_out; bf.hyp_n = m->hyp_n_out; bf.max_words = m->hyp_max_words;
+    m->hyp_out = nullptr; m->hyp_n_out = nullptr; m->hyp_max_words = 0;      // (one call's worth)
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
     PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));
@@ -1750,18 +1790,21 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
-#define FT_LAUNCH(NE, NT, SMALL)                                                                                      \
-    hipLaunchKernelGGL((fwdtree_kernel<NE, NT, SMALL>), dim3(n_utt), dim3(NT), 0, st, d, senscr_dev, scr_stride,     \
-                       penalties_dev, utt_off_dev, raw_scores, pl_window, bf)
+    const size_t pool_bytes = sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total);
+#define FT_LAUNCH(NE, NT, SMALL, LISTS)                                                                               \
+        hipLaunchKernelGGL((fwdtree_kernel<NE, NT, SMALL, LISTS>), dim3(n_utt), dim3(NT), (SMALL) ? pool_bytes : 0, st, \
+                           d, senscr_dev, scr_stride, penalties_dev, utt_off_dev, raw_scores, pl_window, bf)
     if (d.n_emit == 3) {
-        if (d.small) FT_LAUNCH(3, kFtThreads, true);
-        else if (!big) FT_LAUNCH(3, kFtThreads, false);
-        else FT_LAUNCH(3, kFtThreadsBig, false);
+        if (d.small && ls) FT_LAUNCH(3, kFtThreads, true, true);
+        else if (d.small) FT_LAUNCH(3, kFtThreads, true, false);
+        else if (!big) FT_LAUNCH(3, kFtThreads, false, false);
+        else FT_LAUNCH(3, kFtThreadsBig, false, false);
     }
     else {
-        if (d.small) FT_LAUNCH(5, kFtThreads, true);
-        else if (!big) FT_LAUNCH(5, kFtThreads, false);
-        else FT_LAUNCH(5, kFtThreadsBig, false);
+        if (d.small && ls) FT_LAUNCH(5, kFtThreads, true, true);
+        else if (d.small) FT_LAUNCH(5, kFtThreads, true, false);
+        else if (!big) FT_LAUNCH(5, kFtThreads, false, false);
+        else FT_LAUNCH(5, kFtThreadsBig, false, false);
     }
 #undef FT_LAUNCH
     PSGPU_HIP(hipGetLastError());
@@ -1798,6 +1841,13 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
         for (int i : order) fprintf(stderr, "  %2d %-48s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
     }
 #endif
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_hyp_out(psgpu_fwdtree_t *m, int32_t *hyp_dev, int32_t *hyp_n_dev, int32_t max_words)
+{
+    PSGPU_REQUIRE(m && ((hyp_dev && hyp_n_dev && max_words > 0) || (!hyp_dev && !hyp_n_dev)), "psgpu_fwdtree_hyp_out: bad argument");
+    m->hyp_out = hyp_dev; m->hyp_n_out = hyp_dev ? hyp_n_dev : nullptr; m->hyp_max_words = hyp_dev ? max_words : 0;
     return PSGPU_OK;
 }
 

@@ -78,13 +78,21 @@ class DecodePipeline:
         except Exception:
             pass
 
+    def search_after(self, prev):
+        """This object's search waits (on the device) for the search of `prev`'s latest call -- two objects taking turns, one
+        batch's front end and scorer beside the other's search: see psgpu_decode_search_after."""
+        capi.check(capi.lib().psgpu_decode_search_after(self.h, prev.h if prev is not None else None), "psgpu_decode_search_after")
+
+    def wait_scored(self):
+        capi.check(capi.lib().psgpu_decode_wait_scored(self.h), "psgpu_decode_wait_scored")
+
     def stage_timing(self, on=True):
         capi.check(capi.lib().psgpu_decode_stage_timing(self.h, int(bool(on))), "psgpu_decode_stage_timing")
 
     def last_stage_ms(self):
         ms = (C.c_float * 6)()
         capi.check(capi.lib().psgpu_decode_last_stage_ms(self.h, ms), "psgpu_decode_last_stage_ms")
-        return dict(zip(("front_end", "features", "scorer", "phone_loop", "search", "backtrace"), [float(v) for v in ms]))
+        return dict(zip(("front_end", "features", "scorer", "phone_loop", "search", "search_wait"), [float(v) for v in ms]))
 
     def score_mode(self, lists):
         """psgpu_decode_score_mode: True -- no score rows, the phone loop and the search score the senones they list"""
@@ -142,3 +150,14 @@ class DecodePipeline:
                                                         bss.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), self._stream),
                    "psgpu_decode_fetch_tables")
         return dict(bp=bp[:, :nb].T.copy(), bscore_stack=bss[:nh].copy(), bp_table_idx=idx, n_frame=nfr, status=int(res[u, 3]))
+
+
+def dedicated_stream():
+    """A raw hipStream_t with a hardware queue of its own (psgpu_stream_create_dedicated); free with free_stream."""
+    h = C.c_void_p()
+    capi.check(capi.lib().psgpu_stream_create_dedicated(C.byref(h)), "psgpu_stream_create_dedicated")
+    return h.value
+
+
+def free_stream(h):
+    capi.check(capi.lib().psgpu_stream_destroy(C.c_void_p(h)), "psgpu_stream_destroy")
