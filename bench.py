@@ -210,16 +210,20 @@ def main():
     capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
     tables = _npz("en_us_ptm_tables.npz")
     gt = _npz("fwdtree_trace_goforward.npz")
-    # PSGPU_BENCH_PIPES=2: two pipeline objects on two streams, consecutive steps overlapping.  Measured (r02,
-    # profiles/r02_variants.txt, tools/overlap_probe.py): 143.0 ms per step with one, 136-140 ms with two (the scorer
-    # kernels of step k + 1 hardly run beside the search kernel of step k), 228 ms with three -- and twice the buffers:
-    # one pipeline is the default.
-    n_pipe = max(1, int(os.environ.get("PSGPU_BENCH_PIPES", "1")))
+    # Two pipeline objects taking turns (PSGPU_BENCH_PIPES, default 2): while one batch's tree search -- a latency-bound
+    # recurrence, one workgroup per utterance -- is resident, the other batch's front end and scorer run beside it; searches
+    # are ordered by events, each pipeline on a stream with a hardware queue of its own (psgpu_decode_search_after,
+    # DESIGN.md 0).  A step is still one pass of the hot path over one batch; two are in flight.  Measured (profiles/r03_*):
+    # 145 ms per step with one object, 112 ms with two.
+    from pocketsphinx_amd import decode as pdec
+    n_pipe = max(1, int(os.environ.get("PSGPU_BENCH_PIPES", "2")))
     pipes = [P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
              for _ in range(n_pipe)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
-    for q in pipes:
+    streams = [torch.cuda.ExternalStream(pdec.dedicated_stream(), device=dev) for _ in range(n_pipe)]
+    for k, q in enumerate(pipes):
         q.stage_timing(True)
+        if n_pipe > 1:
+            q.search_after(pipes[(k - 1) % n_pipe])
     pipe = pipes[0]
     stream = torch.cuda.current_stream().cuda_stream
     sp = C.c_void_p(stream)
@@ -279,9 +283,11 @@ def main():
     if dist is not None:
         dt = pbatch.max_over_ranks(dt, device=dev)
 
-    # this rank's own results (tables' sizes, status, workload counters)
+    # this rank's own results (tables' sizes, status, workload counters); one step alone also gives the stages' times without
+    # another batch beside them
     pipe.run_dev(pcm, soff, streams[0].cuda_stream)
     hn_l, hyp_l, res_l = pipe.fetch()
+    stage_alone = pipe.last_stage_ms()
     if int((res_l[:, 3] != 0).sum()):
         raise SystemExit("bench: %d utterances ended with a full back-pointer table / score stack" % int((res_l[:, 3] != 0).sum()))
     if rank != 0:
@@ -326,6 +332,7 @@ def main():
         "xrt": round((dt / args.steps) / audio_s, 9),
         "steps_in_flight": n_pipe,
         "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
+        "stage_ms_one_step_alone": {k: round(v, 3) for k, v in stage_alone.items()},
         "workload_counts": {"hmm_evals_per_frame": round(evals / max(frames_rank, 1), 2),
                             "listed_senones_per_frame": round(senones / max(frames_rank, 1), 2),
                             "back_pointers_per_utt": round(float(res_l[:, 0].mean()), 1),
@@ -334,9 +341,11 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "fwdtree_kernel", "achieved": round(alg_bytes / search_s / 1e9, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(alg_bytes / search_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(st_mean["search"], 3),
+                     "kernel_ms_alone": round(stage_alone["search"], 3),
                      "note": "a recurrence over frames: one workgroup per utterance, bound by the latency of one frame's dependent "
                              "steps, not by bytes (DESIGN.md 4); bytes = sum over frames of 156 + 2 x listed senones + 86 x HMM "
-                             "evaluations (SURVEY 8d), counted by the kernel"},
+                             "evaluations (SURVEY 8d), counted by the kernel; kernel_ms = HIP events around the kernel in the timed "
+                             "region, i.e. with the other batch's front end and scorer running beside it"},
     }
     # ---- cpu_baseline + parity: the compiled reference on a sample of the same utterances
     if not args.no_cpu_baseline:

@@ -554,6 +554,8 @@ __device__ __forceinline__ int ft_key_bp(unsigned long long k) { return 0x7fffff
 #ifndef PSGPU_FT_WAVES
 #define PSGPU_FT_WAVES 3
 #endif
+// (s_setprio 3 for this kernel's waves -- ahead of the co-runners' at the SIMD's arbiter -- changed nothing: 112.4 vs 111.9 ms
+//  per step; what a busy device costs the search is the latency of its device-memory accesses)
 constexpr int kFtWavesPerEu = PSGPU_FT_WAVES;
 #if defined(__HIPCC__)
 extern __shared__ __attribute__((aligned(16))) int32_t ft_dyn_pool[];

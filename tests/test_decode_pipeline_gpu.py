@@ -119,3 +119,46 @@ def test_pipeline_equals_the_reference_on_synthetic_utterances(tables, tmp_path,
         assert got == want, "utterance %d: %r vs %r" % (ids[u], got[:6], want[:6])
         assert int(hn[u, 1]) == r["score"]
     p.close()
+
+
+def test_two_pipelines_taking_turns(tables):
+    """psgpu_decode_search_after: two pipeline objects on dedicated-queue streams, alternating calls -- one batch's front end
+    and scorer beside the other's search, searches ordered by events, hypotheses written by the search kernel's last step.
+    Every call's tables and hypotheses are the reference's for its recordings, whichever object ran it."""
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import decode as pdec
+    clips = _load("speech_clips.npz")
+    pipes = [_pipeline(tables), _pipeline(tables)]
+    streams = [pdec.dedicated_stream(), pdec.dedicated_stream()]
+    pipes[0].search_after(pipes[1]); pipes[1].search_after(pipes[0])
+    batches = [["goforward", "numbers"], ["numbers", "goforward", "goforward"], ["goforward"], ["numbers", "numbers"]]
+    dev_in = []
+    for names in batches:
+        pcms = [clips[n] for n in names]
+        off = np.zeros(len(pcms) + 1, np.int64); off[1:] = np.cumsum([x.size for x in pcms])
+        dev_in.append((torch.from_numpy(np.concatenate(pcms)).cuda(), off))
+    torch.cuda.synchronize()
+
+    def check(k, out):
+        hn, hyp, res = out
+        for u, n in enumerate(batches[k]):
+            g = _load("fwdtree_trace_%s.npz" % n)
+            r = pipes[k % 2].tables(u, res)
+            r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+            _check(r, g, "%s in call %d" % (n, k))
+            score, words = P.backtrace(r, int(g["par"][20]))
+            assert int(hn[u, 0]) == len(words) and int(hn[u, 1]) == score == int(g["hyp_score"][0])
+            assert [tuple(int(v) for v in hyp[u, i, :3]) for i in range(len(words))] == words
+    for k in range(len(batches)):
+        if k >= 2:
+            check(k - 2, pipes[k % 2].fetch())
+        pipes[k % 2].run_dev(dev_in[k][0], dev_in[k][1], streams[k % 2])
+    pipes[0].wait_scored()
+    for k in range(len(batches) - 2, len(batches)):
+        check(k, pipes[k % 2].fetch())
+    pipes[0].search_after(None); pipes[1].search_after(None)
+    for q in pipes:
+        q.close()
+    for s in streams:
+        pdec.free_stream(s)
