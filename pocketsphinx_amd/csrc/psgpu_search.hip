@@ -63,7 +63,7 @@ struct FtLay {
                                          // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
-    int32_t row, pen;                    // small layout: the frame's score row (int16; scoring from lists only) and two penalty rows
+    int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
     int32_t rows_total;                  // small layout: words of the pool a launch that reads score ROWS needs (row and l_* lie behind)
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
     int32_t tp;                          // small layout: copy of the transition matrices (bytes)
@@ -655,7 +655,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         uint8_t *const l_tp = reinterpret_cast<uint8_t *>(fb + L.tp);
         for (int i = tid; i < p.n_tmat * NE * (NE + 1); i += NT) l_tp[i] = g_tp[i];
     }
-    int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // scoring from lists only
+    int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // small layout only
     int32_t *const s_pen = fb + L.pen;                                      // small layout only: [2][n_ci]
 
     // an utterance shorter than the look-ahead window is never searched by the reference: ps_end_utt steps the main search
@@ -678,18 +678,24 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int nwords = (p.n_sen + 31) >> 5;
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
     }
-    // Scores.  From rows: read where they lie, in device memory -- the search looks at ~400 of a row's 5126 scores, and a copy
-    // of the row in LDS (two of them, to receive the next while this one is read) was a third of the workgroup's LDS, which
-    // the kernels of other streams that run beside the search need more (two resident workgroups left 23 KB of a compute
-    // unit's 160 KB: ONE workgroup of the senone kernel).  The next frame's row is pulled into the L2 one frame ahead instead:
-    // one dword of each of its 128-byte lines is loaded (and never used) after this frame's evaluation, so that the reads of
-    // the next frame's marking and evaluation are L2 hits, not HBM misses, on the frame's critical path.  From lists: the
-    // frame's scores are computed into an LDS row (s_row).  Penalties: LDS in the small layout, two rows taking turns.
-    const int row_lines = (p.n_sen * 2 + 127) >> 7;     // 128-byte lines of a score row
-    uint32_t touch_acc = 0u;
-    auto row_touch = [&](int fr) {
+    // Scores: the frame's row is read from LDS (s_row).  From rows: the next frame's row travels from HBM into s_row while this
+    // frame's word level runs -- issued after the evaluation, the row's last reader -- by LDS-DMA (global_load_lds_dword: no
+    // registers in between; sixteen registers a work-item held across two thirds of the frame were most of what the kernel
+    // spilled under its 168-register budget).  The loads are counted by vmcnt: waited for before the frame's last barrier.
+    // From lists: the frame's scores are computed into s_row.  Penalties: two LDS rows taking turns.
+    const int row_dw = (p.n_sen + 1) >> 1;              // dwords per score row (the host checked the alignment)
+    auto row_fetch = [&](int fr) {
         const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + fr) * scr_stride);
-        for (int i = tid; i < row_lines; i += NT) touch_acc ^= g[min(i * 32, ((p.n_sen + 1) >> 1) - 1)];
+        uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int i0 = tid & ~63; i0 < row_dw; i0 += NT) {            // (i0: the wavefront's first dword; the LDS address is base + lane * 4)
+            if (i0 + (tid & 63) < row_dw)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i0 + (tid & 63)),
+                                                 (__attribute__((address_space(3))) void *)(d + i0), 4, 0, 2);       // (aux 2: non-temporal, a row is read once)
+        }
+#else
+        for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
+#endif
     };
     auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T - 1) : f); };
     // scoring from lists: a frame's lists -- per (codebook, stream) chain four raw scores and four codewords -- travel one frame
@@ -730,6 +736,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             lists_load(0);
             lists_norm();
         }
+        else {
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
+            uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
+            for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
+        }
         if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[i] = penalties[(size_t)pen_frame(0) * n_ci + i];
     }
     __syncthreads();
@@ -752,7 +763,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         int32_t *const awlc = fb + (cur ? L.awl1 : L.awl0), *const awln = fb + (cur ? L.awl0 : L.awl1);
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : penalties + (size_t)pen_frame(f) * n_ci;
-        const int16_t *const row = lists ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
+        const int16_t *const row = SMALL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
@@ -945,7 +956,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         int32_t pre_pen = 0;
         if (SMALL && nf < T) {
             if (lists) lists_load(nf);
-            else row_touch(nf);
+            else row_fetch(nf);
             if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
         }
         if (tid == 0) {
@@ -1447,6 +1458,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
         if (SMALL && nf < T) {                               // the next frame's score row and penalties take their place
             if (lists) lists_norm();
+#if defined(__HIP_DEVICE_COMPILE__)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next row has landed in LDS (this wavefront's part)
+#endif
             if (p.has_pl && tid < n_ci) s_pen[nxt * n_ci + tid] = pre_pen;
         }
         ft_sync<SMALL>();
@@ -1455,7 +1469,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #ifdef PSGPU_FT_PROFILE
     if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
-    if (touch_acc == 0x9e3779b9u && T < 0) result[7] = 1;      // (never: keeps the row-touching loads alive)
     if (bf.hyp) __syncthreads();                                 // the table's last entries (device memory, other work-items') before the backtrace
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
@@ -1545,16 +1558,16 @@ static bool ft_layout(FtDev &d, bool small)
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
-        // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the frame's
-        // score row, the lists, the log-add table, the listed senones: a launch that reads score rows asks for less LDS
-        const int64_t tail = ((int64_t)d.n_sen + 1) / 2 + 4 + 2 * (int64_t)kFtMaxChains + 512 / 4 + kFtListCap / 2 + kFtThreads / 64 * kSenStreams + 16;
+        // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the lists, the
+        // log-add table, the listed senones: a launch that reads score rows asks for less LDS
+        L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
+        const int64_t tail = 2 * (int64_t)kFtMaxChains + 512 / 4 + kFtListCap / 2 + kFtThreads / 64 * kSenStreams + 16;
         // the frame's evaluation list takes what is left
         const int64_t left = (int64_t)kFtLdsWords - o - tail;
         if (left < kFtMinEvl || d.n_sen > kFtMaxSen) return false;
         L.evl_cap = (int32_t)std::min<int64_t>(left & ~(int64_t)3, 8192);
         L.evl = take(L.evl_cap);
         L.rows_total = (int32_t)o;
-        L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
         L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
         L.l_norm = take(kFtThreads / 64 * kSenStreams);
     }
