@@ -178,7 +178,7 @@ def child_extras(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--utts", type=int, default=B_UTT, help="utterances per GPU (default: the configs[4] share, 512)")
     ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
