@@ -196,7 +196,7 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PSGPU_BENCH_FORCE_DIST"):     # (.._FORCE_DIST: the N > 1 code path with one rank, for a one-GPU box)
         import torch.distributed as dist
         dist.init_process_group(backend="nccl")
     if not torch.cuda.is_available():
@@ -238,6 +238,8 @@ def main():
     torch.cuda.synchronize()
 
     stage = []
+    gather_stream = torch.cuda.Stream(device=dev) if dist is not None else None
+    gathered = []
 
     def launch(k):
         """one pass of the hot path over the batch: everything enqueued on the step's stream"""
@@ -249,14 +251,21 @@ def main():
         if dist is None:
             out = q.fetch()
         else:
+            # copies of the step's records (small kernels on the step's stream: the pipeline's buffers are free for its next
+            # call), then the RCCL gather on a stream of its own -- a collective's kernel launched beside a resident search may
+            # have to wait for registers, and must not hold up this pipeline's next step; its result is needed only at the end
             v = q.view()
             with torch.cuda.stream(st):
-                hn = torch.as_tensor(_DevArray(v.hyp_n_dev, (B, 4)), device=dev)
-                hy = torch.as_tensor(_DevArray(v.hyp_dev, (B, q.max_words, 4)), device=dev)
+                hn = torch.as_tensor(_DevArray(v.hyp_n_dev, (B, 4)), device=dev).clone()
+                hy = torch.as_tensor(_DevArray(v.hyp_dev, (B, q.max_words, 4)), device=dev).clone()
+                hn.record_stream(gather_stream); hy.record_stream(gather_stream)
+                copied = torch.cuda.Event(); copied.record(st)
+            with torch.cuda.stream(gather_stream):
+                gather_stream.wait_event(copied)
                 g_hn = pbatch.gather_records(hn, device=dev)
                 g_hy = pbatch.gather_records(hy, device=dev)
-                out = (g_hn.cpu().numpy(), g_hy.cpu().numpy(), None) if rank == 0 else None
-            st.synchronize()
+            gathered[:] = [(g_hn, g_hy, hn, hy)]               # (kept alive until the next step's replace them)
+            out = None
         if timed:
             stage.append(q.last_stage_ms())     # events of this step's launches (complete: the records are here)
         return out
@@ -288,6 +297,12 @@ def main():
     pipe.run_dev(pcm, soff, streams[0].cuda_stream)
     hn_l, hyp_l, res_l = pipe.fetch()
     stage_alone = pipe.last_stage_ms()
+    if dist is not None and rank == 0 and gathered:
+        # the job's records as gathered in the last timed step: rank 0's block is what rank 0 has just decoded again, and every
+        # other rank's block holds hypotheses (the same utterance lengths everywhere)
+        g_hn = gathered[0][0].cpu().numpy()
+        if g_hn.shape[0] != B * world or not np.array_equal(g_hn[:B], hn_l) or int((g_hn[:, 0] <= 0).sum()):
+            raise SystemExit("bench: the gathered hypothesis records are not the ranks' results")
     if int((res_l[:, 3] != 0).sum()):
         raise SystemExit("bench: %d utterances ended with a full back-pointer table / score stack" % int((res_l[:, 3] != 0).sum()))
     if rank != 0:
