@@ -175,7 +175,25 @@ def child_extras(out):
     child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 120)
 
 
+_JSON_FD = None
+
+
+def emit(line):
+    """the ONE line of standard output"""
+    data = (json.dumps(line) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def main():
+    # standard output carries exactly one JSON line: native libraries that print there (RCCL's version banner at
+    # init_process_group) are sent to standard error for the life of the process
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -388,7 +406,7 @@ def main():
                                       "the reference decoding the same PCM"}
             line["speedup_vs_cpu_1thread"] = round(fps / world / tot["frames_per_s"], 1)
             if bad:
-                print(json.dumps(line))
+                emit(line)
                 raise SystemExit("bench: device hypotheses differ from the reference's on utterances %r" % bad)
     # ---- extras (N = 1 only)
     extra = {}
@@ -427,7 +445,7 @@ def main():
         if not os.environ.get("PSGPU_BENCH_NO_CHILD"):
             child_extras(extra)
     line["extra"] = extra
-    print(json.dumps(line))
+    emit(line)
     if dist is not None:
         dist.destroy_process_group()
 
