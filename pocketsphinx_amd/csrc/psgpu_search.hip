@@ -663,6 +663,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0, T = (raw_mode && T_in < pl_window) ? 0 : T_in;
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
+    unsigned long long evals_run = 0ull;                 // HMM evaluations so far (ngs->st.n_hmm_eval), likewise
+    int nwc_cur = 0;                                     // right-context channels of the active words (the last of woff's prefix sums), likewise
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
     for (int c = tid; c < N; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
@@ -672,7 +674,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     for (int c = tid; c < N; c += NT) pos[c] = -1;       // pos is kept at -1 between frames
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
-        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0;
+        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0;
     }
     {
         const int nwords = (p.n_sen + 31) >> 5;
@@ -767,7 +769,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
-        if (tid == 0) { tb.idx[f] = s_sc[3]; s_nev = 0; }
+        if (tid == 0) tb.idx[f] = s_sc[3];                    // (s_nev was zeroed before the previous frame's last barrier)
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
         const int32_t bp0 = s_sc[3];                          // this frame's first back-pointer
@@ -776,10 +778,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // worked on one work-item per channel.  The channels of the active words are the segments [woff[i], woff[i + 1])
         // of one index range; an item finds its word by bisection (ft_seg_find).
         const int naw = n_awl_cur, na = n_acl_cur;
-        for (int i = tid; i < naw; i += NT) { const int w = awlc[i]; word_active[w] = 0; woff[i] = wc_off[w + 1] - wc_off[w]; }
-        if (tid == 0) woff[naw] = 0;
-        ft_sync<SMALL>();
-        const int nwc = ft_block_scan<NT, SMALL>(woff, naw + 1, s_scan);
+        // (woff -- the prefix sums of the active words' right-context counts -- and their total were made in the previous frame,
+        //  in the single-phone words' scan, as soon as this frame's word list was complete: no barrier, no scan here)
+        for (int i = tid; i < naw; i += NT) word_active[awlc[i]] = 0;
+        const int nwc = nwc_cur;
         // ---- the frame's evaluation list: every HMM instance evaluate_channels (:605-715) visits -- roots entered for this
         //      frame, the listed tree nodes, the allocated right-context channels of the active words, the single-phone
         //      words entered for this frame -- compacted into one list (order irrelevant: independent evaluations, maxima
@@ -959,23 +961,25 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             else row_fetch(nf);
             if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
         }
+        // the frame's best scores are complete in s_red behind the barrier above and stay untouched until the next frame's top:
+        // every work-item reads them there (no hand-over through work-item 0 and a second barrier); what work-item 0 records
+        // below is next read behind later barriers
+        const int32_t best_score = s_red[0];
+        evals_run += (unsigned long long)n_ev;
         if (tid == 0) {
-            s_sc[0] = s_red[0]; s_sc[1] = s_red[2];
-            s_evals += (unsigned long long)n_ev;
+            s_sc[0] = best_score; s_sc[1] = s_red[2];
+            s_evals = evals_run;
             s_sc[5] = 0;                                        // n_lastphn_cand
-            s_sc[2] = p.beam;                                   // dynamic beam (:1133-1181)
             s_nb = 0x7fffffff;
         }
-        ft_sync<SMALL>();
         FT_PROF(3);
-        const int32_t best_score = s_sc[0];
         // dynamic beam (ngram_search_fwdtree.c:1133-1181): the reference compares the utterance's CUMULATIVE evaluation count
         // with maxhmmpf, so from some frame on the histogram is consulted every frame.  It counts every root and every
         // listed node; when there are no more than maxhmmpf of them the running sum never passes it and the loop leaves
         // i == 256 -- known without building the histogram.  Otherwise: 256 bins, one prefix sum, the first bin whose
         // running sum passes maxhmmpf.
         int32_t dyn_beam = p.beam;
-        if (p.maxhmmpf != -1 && s_evals > (unsigned long long)p.maxhmmpf) {
+        if (p.maxhmmpf != -1 && evals_run > (unsigned long long)p.maxhmmpf) {
             const int32_t bw = -p.beam / 256;
             if (R + na <= p.maxhmmpf) dyn_beam = -(256 * bw);
             else {
@@ -1051,7 +1055,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         FT_PROF(5);
         for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
         for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
-        // list positions: root phase (segment per root), then one segment per list position
+        // list positions (root phase: a segment per root, then one segment per list position) and the last-phone candidates
+        // (list order, homophone chain inside) in ONE counting pass, one double prefix sum and one writing pass: the two
+        // depend on the pruning's snapshot and decisions only, not on each other
+        int32_t *const cntb = cnt + (R + N + 1);
         for (int i = tid; i < R + na; i += NT) {
             const int node = i < R ? i : aclc[i - R];
             int k = (i >= R && (o_frame[node] & 8)) ? 1 : 0;
@@ -1060,9 +1067,22 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int q = kid_off[node]; q < k1; ++q) k += (o_frame[kids[q]] & 2) ? 1 : 0;
             }
             cnt[i] = k;
+            const int32_t news = o_out[node] + p.pip;
+            int kc = 0;
+            if ((flag[node] & 1) && (p.has_pl || news > lpt))
+                for (int w = node_pw[node]; w >= 0; w = homophone[w]) kc += (news + ft_pen(d_last[w]) > lpt) ? 1 : 0;
+            cntb[i] = kc;
         }
         ft_sync<SMALL>();
-        const int32_t n_listed = ft_block_scan<NT, SMALL>(cnt, R + na, s_scan);      // exclusive prefix sum
+        int32_t n_listed;
+        {
+            int32_t tot2[2];
+            int32_t *const arr[2] = { cnt, cntb };
+            ft_block_scan_k<NT, 2, SMALL>(arr, R + na, s_scan, tot2);       // exclusive prefix sums
+            n_listed = tot2[0];
+            if (tid == 0) { s_sc[5] = tot2[1]; s_red[7] = 0; }
+        }
+        FT_PROF(6);
         for (int i = tid; i < R + na; i += NT) {
             const int node = i < R ? i : aclc[i - R];
             int o = cnt[i];
@@ -1071,31 +1091,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int k1 = kid_off[node + 1];
                 for (int q = kid_off[node]; q < k1; ++q) { const int c = kids[q]; if (o_frame[c] & 2) acln[o++] = c; }
             }
-        }
-        ft_sync<SMALL>();
-        FT_PROF(6);
-        // last-phone candidates: list order, homophone chain inside
-        for (int i = tid; i < R + na; i += NT) {
-            const int node = i < R ? i : aclc[i - R];
             const int32_t news = o_out[node] + p.pip;
-            int k = 0;
-            if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = node_pw[node]; w >= 0; w = homophone[w]) k += (news + ft_pen(d_last[w]) > lpt) ? 1 : 0;
-            cnt[i] = k;
-        }
-        ft_sync<SMALL>();
-        {
-            const int32_t n_cand_all = ft_block_scan<NT, SMALL>(cnt, R + na, s_scan);
-            if (tid == 0) { s_sc[5] = n_cand_all; s_red[7] = 0; }
-        }
-        for (int i = tid; i < R + na; i += NT) {
-            const int node = i < R ? i : aclc[i - R];
-            const int32_t news = o_out[node] + p.pip;
-            int o = cnt[i];
+            int oc = cntb[i];
             if ((flag[node] & 1) && (p.has_pl || news > lpt))
                 for (int w = node_pw[node]; w >= 0; w = homophone[w])
                     if (news + ft_pen(d_last[w]) > lpt) {
-                        cand_wid[o] = w; cand_score[o] = news - p.nwpen; cand_bp[o] = o_outh[node]; ++o;
+                        cand_wid[oc] = w; cand_score[oc] = news - p.nwpen; cand_bp[oc] = o_outh[node]; ++oc;
                     }
         }
         __syncthreads();                                     // (device memory: the evaluation's records, tb.idx[f] -- see above)
@@ -1331,13 +1332,23 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
                 f_ex[i] = ex; f_new[i] = nw; f_rc[i] = rcn;
             }
+            // the NEXT frame's active words are complete since the positions step (s_red[5] of them in awln): their right-context
+            // counts ride in the same scan, so that the next frame starts without a barrier and a scan of its own
+            const int naw_n = s_red[5], n_sc = max(n1, naw_n) + 1;
+            for (int i = n1 + 1 + tid; i < n_sc; i += NT) { f_new[i] = 0; f_rc[i] = 0; }
+            for (int i = tid; i < n_sc; i += NT) {
+                int k = 0;
+                if (i < naw_n) { const int w = awln[i]; k = wc_off[w + 1] - wc_off[w]; }
+                woff[i] = k;
+            }
             ft_sync<SMALL>();
             const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
-            int32_t tot[2];
+            int32_t tot[3];
             {
-                int32_t *const arr[2] = { f_new, f_rc };
-                ft_block_scan_k<NT, 2, SMALL>(arr, n1 + 1, s_scan, tot);
+                int32_t *const arr[3] = { f_new, f_rc, woff };
+                ft_block_scan_k<NT, 3, SMALL>(arr, n_sc, s_scan, tot);
             }
+            nwc_cur = tot[2];
             FT_PROF(20);
             for (int i = tid; i < n1; i += NT)
                 if (f_ex[i]) {
@@ -1345,7 +1356,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
                 }
             FT_PROF(21);
-            if (p.maxwpf == -1 || p.maxwpf == p.n_w) ft_sync<SMALL>(); else __syncthreads();     // (bptable_maxwpf reads the frame's entries)
+            // (bptable_maxwpf, when it applies, reads the frame's entries: a full barrier.  Otherwise nothing between here and
+            //  word_transition's barrier reads what this step wrote: the counters work-item 0 advances below were read by every
+            //  work-item before the scans' barriers)
+            if (!(p.maxwpf == -1 || p.maxwpf == p.n_w)) __syncthreads();
             if (tid == 0) { s_sc[3] = bpidx0 + tot[0]; s_sc[4] = bss0 + tot[1]; }
         }
         if (tid == 0 && !s_sc[6]) {
@@ -1453,6 +1467,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) {
             step[f * 4] = s_sc[0]; step[f * 4 + 1] = s_sc[1]; step[f * 4 + 2] = s_sc[3]; step[f * 4 + 3] = n_listed;
             ++s_sc[7];
+            s_nev = 0;                                           // the next frame's evaluation list starts empty
         }
         FT_PROF(27);
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
@@ -1637,7 +1652,7 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.TOT = (int32_t)tot;
     d.CH = d.N + d.n1;
     d.n_tmat = t->n_tmat;
-    d.cnt_words = std::max(std::max(d.R + d.N + 1, 4 * d.n_w + 4), kFtMaxSen / 32 + 4);     // (.. + 4: the senone bitmap's word populations)
+    d.cnt_words = std::max(std::max(2 * (d.R + d.N + 1), 4 * d.n_w + 4), kFtMaxSen / 32 + 4);     // (two arrays over the roots and listed nodes; .. + 4: the senone bitmap's word populations)
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
     d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
     d.kid_off = ft_up(m, kid_off.data(), (size_t)d.N + 1, &rc); d.kids = ft_up(m, kids.data(), kids.size(), &rc);

@@ -32,6 +32,8 @@ def main():
     ref = None
     for n_pipe in [int(x) for x in os.environ.get("OP_PIPES", "1,2,3").split(",")]:
         pipes = [mk() for _ in range(n_pipe)]
+        for q in pipes:
+            q.stage_timing(True)
         streams = [pdec.dedicated_stream() for _ in range(n_pipe)]
         if n_pipe > 1:
             for k in range(n_pipe):
@@ -70,7 +72,7 @@ def main():
                 ref = hn.copy()
             print("  hypotheses of the last step equal to the single-pipeline run's: %s" % bool(np.array_equal(ref, hn)))
         print("  step completions (ms): " + " ".join("%.0f" % (1e3 * t) for t in done), flush=True)
-        print("pipes %d: %.1f ms per step" % (n_pipe, dt * 1e3), flush=True)
+        print("pipes %d: %.1f ms per step; stages of the last step: %s" % (n_pipe, dt * 1e3, {k: round(v, 2) for k, v in pipes[(n - 1) % n_pipe].last_stage_ms().items()}), flush=True)
         for q in pipes:
             q.close()
         for s in streams:
