@@ -49,7 +49,7 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             if "ELb1ELb0E" in n:              # reading score rows, the pipeline's default: (next to) nothing spilled
                 assert v["Spill"] <= (0 if "ILi3E" in n else 4), (n, v)
             else:
-                assert v["Spill"] <= 16, (n, v)
+                assert v["Spill"] <= 24, (n, v)
         else:
             # slab layout, 256 work-items: at least two workgroups per CU (512 utterances = one round on 256 CUs)
             assert v["Occupancy"] >= 2 and v["Spill"] == 0, (n, v)
