@@ -663,7 +663,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0, T = (raw_mode && T_in < pl_window) ? 0 : T_in;
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
-    unsigned long long evals_run = 0ull;                 // HMM evaluations so far (ngs->st.n_hmm_eval), likewise
+    uint32_t evals_run = 0u;                             // HMM evaluations so far (ngs->st.n_hmm_eval; saturating: compared with maxhmmpf), likewise
     int nwc_cur = 0;                                     // right-context channels of the active words (the last of woff's prefix sums), likewise
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
@@ -965,10 +965,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // every work-item reads them there (no hand-over through work-item 0 and a second barrier); what work-item 0 records
         // below is next read behind later barriers
         const int32_t best_score = s_red[0];
-        evals_run += (unsigned long long)n_ev;
+        evals_run = evals_run + (uint32_t)n_ev < evals_run ? 0xffffffffu : evals_run + (uint32_t)n_ev;
         if (tid == 0) {
             s_sc[0] = best_score; s_sc[1] = s_red[2];
-            s_evals = evals_run;
+            s_evals += (unsigned long long)n_ev;
             s_sc[5] = 0;                                        // n_lastphn_cand
             s_nb = 0x7fffffff;
         }
@@ -979,7 +979,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // i == 256 -- known without building the histogram.  Otherwise: 256 bins, one prefix sum, the first bin whose
         // running sum passes maxhmmpf.
         int32_t dyn_beam = p.beam;
-        if (p.maxhmmpf != -1 && evals_run > (unsigned long long)p.maxhmmpf) {
+        if (p.maxhmmpf != -1 && evals_run > (uint32_t)p.maxhmmpf) {
             const int32_t bw = -p.beam / 256;
             if (R + na <= p.maxhmmpf) dyn_beam = -(256 * bw);
             else {
