@@ -47,7 +47,7 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             assert v["Occupancy"] >= 3 and v["VGPRs"] <= 168, (n, v)
             assert v["LDS"] <= 4 * 1024, (n, v)                               # (static part only)
             if "ELb1ELb0E" in n:              # reading score rows, the pipeline's default: (next to) nothing spilled
-                assert v["Spill"] <= (0 if "ILi3E" in n else 4), (n, v)
+                assert v["Spill"] <= 4, (n, v)
             else:
                 assert v["Spill"] <= 24, (n, v)
         else:
