@@ -690,11 +690,18 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + fr) * scr_stride);
         uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
 #if defined(__HIP_DEVICE_COMPILE__)
-        for (int i0 = tid & ~63; i0 < row_dw; i0 += NT) {            // (i0: the wavefront's first dword; the LDS address is base + lane * 4)
-            if (i0 + (tid & 63) < row_dw)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + i0 + (tid & 63)),
-                                                 (__attribute__((address_space(3))) void *)(d + i0), 4, 0, 2);       // (aux 2: non-temporal, a row is read once)
+        // sixteen bytes a lane (1 KB a wave-instruction: an LDS-DMA instruction costs the wave ~100-200 cycles of issue whatever it
+        // moves), the row's last dwords singly.  q0: the wavefront's first quad; the LDS address is base + lane * 16 (aux 2:
+        // non-temporal, a row is read once)
+        const int row_q = row_dw >> 2;
+        for (int q0 = tid & ~63; q0 < row_q; q0 += NT) {
+            if (q0 + (tid & 63) < row_q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 4 * (q0 + (tid & 63))),
+                                                 (__attribute__((address_space(3))) void *)(d + 4 * q0), 16, 0, 2);
         }
+        if (tid < 64 && 4 * row_q + tid < row_dw)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 4 * row_q + tid),
+                                             (__attribute__((address_space(3))) void *)(d + 4 * row_q), 4, 0, 2);
 #else
         for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
 #endif
