@@ -32,13 +32,14 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
-constexpr int kFtLdsWords = 15488;     // LDS layout: at most 60.5 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
-                                       // that reads score rows leaves the last 14 KB out (FtLay::rows_total): two workgroups per CU then take ~100 of its
+constexpr int kFtLdsWords = 16128;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
+                                       // that reads score rows leaves the last 3.6 KB out (FtLay::rows_total): two workgroups per CU then take ~126 of its
                                        // 160 KB and leave the rest to the kernels of other streams that run beside the search
 constexpr int kFtListCap = 1024;       // listed senones per frame kept as a list (LDS layout, scoring from top-N lists); more: scored where found
 constexpr int kFtMaxChains = 128;      // (codebook, stream) chains whose lists the LDS layout holds
@@ -605,7 +606,20 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const cand_wid = fb + L.cand_wid, *const cand_score = fb + L.cand_score, *const cand_bp = fb + L.cand_bp,
             *const o_out = fb + L.o_out, *const o_outh = fb + L.o_outh, *const pos = fb + L.pos, *const flag = fb + L.flag,
             *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3,
-            *const woff = fb + L.woff, *const evl = fb + L.evl;
+            *const woff = fb + L.woff;
+    // the frame's evaluation list: 16-bit entries in the LDS layout (channel index < 2^15, or 0x8000 | active word << 6 | right
+    // context: the host checked n_w <= 512, n_ci <= 64) so that a list of EVERY channel fits the pool -- it cannot overflow
+    using EvT = typename std::conditional<SMALL, uint16_t, int32_t>::type;
+    EvT *const evl = reinterpret_cast<EvT *>(fb + L.evl);
+    auto evl_put = [&](int at, int code) {
+        if (SMALL) evl[at] = (EvT)((code & kFtWordCh) ? (0x8000 | (((code >> 8) & 0x1ff) << 6) | (code & 63)) : code);
+        else evl[at] = (EvT)code;
+    };
+    auto evl_get = [&](int e) -> int {
+        const int v = (int)evl[e];
+        if (SMALL) return (v & 0x8000) ? (kFtWordCh | (((v >> 6) & 0x1ff) << 8) | (v & 63)) : v;
+        return v;
+    };
     unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
     // scoring from the scorer's top-N lists (LDS layout only; the host sees to that)
     constexpr bool lists = LISTS;                        // (a template parameter: the score row is LDS here and device memory otherwise,
@@ -834,7 +848,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 if (lane == 0 && m) base = atomicAdd(&s_nev, __popcll(m));
                 base = ft_lane(base, 0);
                 const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (code >= 0 && at < L.evl_cap) evl[at] = code;
+                if (code >= 0 && at < L.evl_cap) evl_put(at, code);
             }
             if (raw_mode) {
                 mn = ft_wave_incl<FtMin>(mn);                 // (lane 63: the wavefront's minimum)
@@ -848,7 +862,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         auto word_slot = [&](int code) { return wc_off[awlc[(code >> 8) & 0x3fffff]] + (code & 255); };
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
             for (int e = tid; e < n_ev; e += NT) {
-                const int c = evl[e];
+                const int c = evl_get(e);
                 if (c & kFtWordCh) ch_normalize<NE>(wv, word_slot(c), best_in); else ch_normalize<NE>(tv, c, best_in);
             }
             __syncthreads();
@@ -926,7 +940,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             FT_PROFW(0);
             FT_PROFD0();
             for (int e = tid; e < n_ev; e += NT) {
-                const int c = evl[e];
+                const int c = evl_get(e);
                 if (c & kFtWordCh) {
                     const int32_t sc = ch_eval_rec<NE>(wv.b + (size_t)word_slot(c) * F::REC, sr, tpall, sseq);
                     b_all = max(b_all, sc); b_word = max(b_word, sc);
@@ -1221,7 +1235,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             for (int i = tid; i < naw; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
             ft_sync<SMALL>();
             for (int e = tid; e < n_ev; e += NT) {
-                const int c = evl[e];
+                const int c = evl_get(e);
                 if (!(c & kFtWordCh)) continue;
                 const int i = (c >> 8) & 0x3fffff, slot = word_slot(c);
                 const FtQuad q = ch_summary<NE>(wv.b + (size_t)slot * F::REC);      // out, out history, best, frame
@@ -1585,10 +1599,11 @@ static bool ft_layout(FtDev &d, bool small)
         L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
         const int64_t tail = 2 * (int64_t)kFtMaxChains + 512 / 4 + kFtListCap / 2 + kFtThreads / 64 * kSenStreams + 16;
         // the frame's evaluation list takes what is left
-        const int64_t left = (int64_t)kFtLdsWords - o - tail;
-        if (left < kFtMinEvl || d.n_sen > kFtMaxSen) return false;
-        L.evl_cap = (int32_t)std::min<int64_t>(left & ~(int64_t)3, 8192);
-        L.evl = take(L.evl_cap);
+        // (16-bit entries; a list of every channel when that fits -- then it cannot overflow -- else what is left)
+        const int64_t left = ((int64_t)kFtLdsWords - o - tail) & ~(int64_t)3, full = (int64_t)d.R + d.N + d.n1 + d.TOT + 4;
+        if (2 * left < kFtMinEvl || d.n_sen > kFtMaxSen || d.n_w > 512 || d.n_ci > 64 || d.N + d.n1 >= 0x8000) return false;
+        L.evl_cap = (int32_t)std::min<int64_t>(2 * left, full);
+        L.evl = take((L.evl_cap + 1) / 2);
         L.rows_total = (int32_t)o;
         L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
         L.l_norm = take(kFtThreads / 64 * kSenStreams);
@@ -1828,9 +1843,21 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
     const size_t pool_bytes = sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total);
-#define FT_LAUNCH(NE, NT, SMALL, LISTS)                                                                               \
+#if defined(__HIPCC__)                    /* a pool that takes the workgroup's LDS beyond the default 64 KB (scoring from lists): say so once */
+#define FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
+        if ((SMALL) && pool_bytes + 4096 > 65536) {                                                                   \
+            static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdtree_kernel<NE, NT, SMALL, LISTS>, \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int32_t) * kFtLdsWords));    \
+            PSGPU_HIP(attr_rc);                                                                                       \
+        }
+#else
+#define FT_DYN_LDS(NE, NT, SMALL, LISTS)
+#endif
+#define FT_LAUNCH(NE, NT, SMALL, LISTS) do {                                                                          \
+        FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
         hipLaunchKernelGGL((fwdtree_kernel<NE, NT, SMALL, LISTS>), dim3(n_utt), dim3(NT), (SMALL) ? pool_bytes : 0, st, \
-                           d, senscr_dev, scr_stride, penalties_dev, utt_off_dev, raw_scores, pl_window, bf)
+                           d, senscr_dev, scr_stride, penalties_dev, utt_off_dev, raw_scores, pl_window, bf);        \
+    } while (0)
     if (d.n_emit == 3) {
         if (d.small && ls) FT_LAUNCH(3, kFtThreads, true, true);
         else if (d.small) FT_LAUNCH(3, kFtThreads, true, false);
@@ -1844,6 +1871,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
         else FT_LAUNCH(5, kFtThreadsBig, false, false);
     }
 #undef FT_LAUNCH
+#undef FT_DYN_LDS
     PSGPU_HIP(hipGetLastError());
 #ifdef PSGPU_FT_PROFILE
     {   // a profiling build: wait, average the per-phase cycle counts over the utterances, print them per frame

@@ -70,7 +70,8 @@ def main():
             hn = out[0]
             if ref is None:
                 ref = hn.copy()
-            print("  hypotheses of the last step equal to the single-pipeline run's: %s" % bool(np.array_equal(ref, hn)))
+            print("  hypotheses of the last step equal to the single-pipeline run's: %s; utterances with a non-zero status: %d"
+                  % (bool(np.array_equal(ref, hn)), int((out[2][:, 3] != 0).sum())))
         print("  step completions (ms): " + " ".join("%.0f" % (1e3 * t) for t in done), flush=True)
         print("pipes %d: %.1f ms per step; stages of the last step: %s" % (n_pipe, dt * 1e3, {k: round(v, 2) for k, v in pipes[(n - 1) % n_pipe].last_stage_ms().items()}), flush=True)
         for q in pipes:
