@@ -38,7 +38,7 @@
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
-constexpr int kFtLdsWords = 16128;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
+constexpr int kFtLdsWords = 16384;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
                                        // that reads score rows leaves the last 3.6 KB out (FtLay::rows_total): two workgroups per CU then take ~126 of its
                                        // 160 KB and leave the rest to the kernels of other streams that run beside the search
 constexpr int kFtListCap = 1024;       // listed senones per frame kept as a list (LDS layout, scoring from top-N lists); more: scored where found
@@ -67,6 +67,7 @@ struct FtLay {
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
     int32_t rows_total;                  // small layout: words of the pool a launch that reads score ROWS needs (row and l_* lie behind)
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
+    int32_t dfirst, dbase, w1w;          // small layout: copies of the words' first phone and base word id [n_w], the single-phone words' ids [n1]
     int32_t tp;                          // small layout: copy of the transition matrices (bytes)
     int32_t total;
 };
@@ -280,6 +281,24 @@ __device__ __forceinline__ int32_t ft_exit_score(const FtTab &t, const int32_t *
     if (l2 == -1) return BPC(t, B_SCORE, bp);
     const int l1 = BPC(t, B_LAST, bp);
     return t.bss[BPC(t, B_SIDX, bp) + rs_cimap[((size_t)l1 * n_ci + l2) * n_ci + rcphone]];
+}
+// The same without a branch between its loads: every address is valid whatever the entry holds (single-phone entries: the context
+// map is read at context 0 and the score stack at the table's start, then dropped), so the entry's four columns come back in ONE
+// trip to device memory, the context map in a second, the stacked score in a third -- as written above the compiler must wait for
+// last2 before it may ask for anything else, and a caller's `if (!valid) continue` in front adds another trip: a frame's pair
+// searches were chains of five to seven dependent trips.
+__device__ __forceinline__ int32_t ft_exit_score_bf(const FtTab &t, const int32_t *rs_cimap, int n_ci, int bp, int rcphone)
+{
+    const int32_t score = BPC(t, B_SCORE, bp), l2 = BPC(t, B_LAST2, bp), l1 = BPC(t, B_LAST, bp), sidx = BPC(t, B_SIDX, bp);
+    const int32_t cm = rs_cimap[((size_t)l1 * n_ci + max(l2, 0)) * n_ci + rcphone];
+    const int32_t ss = t.bss[max(sidx, 0) + max(cm, 0)];
+    return l2 == -1 ? score : ss;
+}
+// the dense language-model table's entry (p.use_trie == 0), an unconditional load
+__device__ __forceinline__ int32_t ft_lm_dense(const FtDev &p, const int32_t *lmtab, int w3, int w2, int w1)
+{
+    const size_t n1 = (size_t)p.n_w + 1;
+    return lmtab[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
 // set_real_wid, ngram_search.c:341-372
 __device__ __forceinline__ void ft_set_real_wid(const FtTab &t, const int32_t *d_filler, const int32_t *d_base, int bp)
@@ -657,6 +676,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                   *const parent = SMALL ? fb + L.parent : psgpu_as_global(p.parent), *const node_ci = SMALL ? fb + L.ci : psgpu_as_global(p.node_ci),
                   *const node_pw = SMALL ? fb + L.pw : psgpu_as_global(p.node_pw),
                   *const wc_off = SMALL ? fb + L.wc_off : psgpu_as_global(p.wc_off);
+    // the words' first phones / base ids and the single-phone words' ids: LDS copies in the small layout (the pair searches'
+    // first trip to device memory is then the back-pointer entries' alone)
+    const int32_t *const dfirst_f = SMALL ? fb + L.dfirst : d_first, *const dbase_f = SMALL ? fb + L.dbase : d_base,
+                  *const w1w_f = SMALL ? fb + L.w1w : w1_wid;
+    if (SMALL) {
+        for (int i = tid; i < p.n_w; i += NT) { fb[L.dfirst + i] = d_first[i]; fb[L.dbase + i] = d_base[i]; }
+        for (int i = tid; i < n1; i += NT) fb[L.w1w + i] = w1_wid[i];
+    }
     if (SMALL) {
         const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_k = psgpu_as_global(p.kids), *const g_p = psgpu_as_global(p.parent),
                       *const g_c = psgpu_as_global(p.node_ci), *const g_w = psgpu_as_global(p.node_pw);
@@ -1142,8 +1169,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int cb = cand_bp[i], w = cand_wid[i];
                 int need = 0, b0 = 0, sf = -1;
                 if (cb != -1) {
-                    cand_score[i] -= ft_exit_score(tb, rs_cimap, n_ci, cb, d_first[w]);
-                    const int ef = BPC(tb, B_FRAME, cb);
+                    const int ef = BPC(tb, B_FRAME, cb);                 // (one trip with the exit score's columns)
+                    cand_score[i] -= ft_exit_score_bf(tb, rs_cimap, n_ci, cb, dfirst_f[w]);
                     if (lt_sf[w] != ef + 1) { b0 = tb.idx[ef]; need = tb.idx[ef + 1] - b0; sf = ef + 1; }
                 }
                 cnt[i] = need; cnt2[i] = b0; cnt3[i] = sf;
@@ -1155,9 +1182,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             FT_PROF(29);
             for (int j = tid; j < n_pair; j += NT) {
                 const int i = ft_seg_find(cnt, n_cand, j), bp = cnt2[i] + (j - cnt[i]), w = cand_wid[i];
-                if (!BPC(tb, B_VALID, bp)) continue;
-                int32_t dscr = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
-                if (dscr > kW) dscr += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
+                // (every load of the pair before the first test: three trips to device memory -- the entry's columns; context map
+                //  and language-model entry; stacked score -- where the tests in between made seven)
+                const int32_t valid = BPC(tb, B_VALID, bp), real = BPC(tb, B_REAL, bp), preal = BPC(tb, B_PREAL, bp);
+                int32_t dscr = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, dfirst_f[w]);
+                const int32_t lmv = p.use_trie ? 0 : ft_lm_dense(p, lmtab, dbase_f[w], real, preal);
+                if (!valid) continue;
+                if (dscr > kW) dscr += p.use_trie ? ft_lm(p, lmtab, dbase_f[w], real, preal) : lmv;
                 atomicMax(&ckey[i], ft_key(dscr, bp));
             }
             ft_sync<SMALL>();
@@ -1419,19 +1450,20 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (s_sc[6]) break;
         const int bp1 = s_sc[3], nbp = bp1 - bp0;
         for (int j = tid; j < nbp * n_ci; j += NT) {
+            // (the entry's columns in one trip, context map, stacked score: three, not five)
             const int bp = bp0 + j / n_ci, rc = j % n_ci, wid = BPC(tb, B_WID, bp);
+            const int32_t sc = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, rc);
             if (rc == 0) { word_lat_idx[wid] = -1; if (wid != p.finishwid) atomicAdd(&s_red[6], 1); }
             if (wid == p.finishwid) continue;
-            const int l2 = BPC(tb, B_LAST2, bp);
-            const int32_t sc = l2 == -1 ? BPC(tb, B_SCORE, bp)
-                : tb.bss[BPC(tb, B_SIDX, bp) + rs_cimap[((size_t)BPC(tb, B_LAST, bp) * n_ci + l2) * n_ci + rc]];
             if (sc > kW) atomicMax(&brc_key[rc], ft_key(sc, bp));
         }
         for (int j = tid; j < p.n1lm * nbp; j += NT) {             // in-LM single-phone words (:1331-1388): best predecessor
-            const int i = j / nbp, bp = bp0 + j % nbp, w = w1_wid[i];
-            if (!BPC(tb, B_VALID, bp)) continue;
-            int32_t ns = ft_exit_score(tb, rs_cimap, n_ci, bp, d_first[w]);
-            if (ns != kW) ns += ft_lm(p, lmtab, d_base[w], BPC(tb, B_REAL, bp), BPC(tb, B_PREAL, bp));
+            const int i = j / nbp, bp = bp0 + j % nbp, w = w1w_f[i];
+            const int32_t valid = BPC(tb, B_VALID, bp), real = BPC(tb, B_REAL, bp), preal = BPC(tb, B_PREAL, bp);
+            int32_t ns = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, dfirst_f[w]);
+            const int32_t lmv = p.use_trie ? 0 : ft_lm_dense(p, lmtab, dbase_f[w], real, preal);
+            if (!valid) continue;
+            if (ns != kW) ns += p.use_trie ? ft_lm(p, lmtab, dbase_f[w], real, preal) : lmv;
             atomicMax(&ckey[i], ft_key(ns, bp));
         }
         FT_PROF(24);
@@ -1594,6 +1626,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
+        L.dfirst = take(d.n_w); L.dbase = take(d.n_w); L.w1w = take(d.n1);
         // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the lists, the
         // log-add table, the listed senones: a launch that reads score rows asks for less LDS
         L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
