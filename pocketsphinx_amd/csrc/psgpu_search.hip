@@ -38,7 +38,7 @@
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
-constexpr int kFtLdsWords = 16384;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
+constexpr int kFtLdsWords = 16640;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
                                        // that reads score rows leaves the last 3.6 KB out (FtLay::rows_total): two workgroups per CU then take ~126 of its
                                        // 160 KB and leave the rest to the kernels of other streams that run beside the search
 constexpr int kFtListCap = 1024;       // listed senones per frame kept as a list (LDS layout, scoring from top-N lists); more: scored where found
@@ -68,6 +68,7 @@ struct FtLay {
     int32_t rows_total;                  // small layout: words of the pool a launch that reads score ROWS needs (row and l_* lie behind)
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
     int32_t dfirst, dbase, w1w;          // small layout: copies of the words' first phone and base word id [n_w], the single-phone words' ids [n1]
+    int32_t dlast, homo, w1ci, w1ci2;    // small layout: copies of the words' last phone and homophone link [n_w], the single-phone words' phones [n1]
     int32_t tp;                          // small layout: copy of the transition matrices (bytes)
     int32_t total;
 };
@@ -679,10 +680,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // the words' first phones / base ids and the single-phone words' ids: LDS copies in the small layout (the pair searches'
     // first trip to device memory is then the back-pointer entries' alone)
     const int32_t *const dfirst_f = SMALL ? fb + L.dfirst : d_first, *const dbase_f = SMALL ? fb + L.dbase : d_base,
-                  *const w1w_f = SMALL ? fb + L.w1w : w1_wid;
+                  *const w1w_f = SMALL ? fb + L.w1w : w1_wid, *const dlast_f = SMALL ? fb + L.dlast : d_last,
+                  *const homo_f = SMALL ? fb + L.homo : homophone, *const w1ci_f = SMALL ? fb + L.w1ci : w1_ci,
+                  *const w1ci2_f = SMALL ? fb + L.w1ci2 : w1_ci2;
     if (SMALL) {
-        for (int i = tid; i < p.n_w; i += NT) { fb[L.dfirst + i] = d_first[i]; fb[L.dbase + i] = d_base[i]; }
-        for (int i = tid; i < n1; i += NT) fb[L.w1w + i] = w1_wid[i];
+        for (int i = tid; i < p.n_w; i += NT) {
+            fb[L.dfirst + i] = d_first[i]; fb[L.dbase + i] = d_base[i]; fb[L.dlast + i] = d_last[i]; fb[L.homo + i] = homophone[i];
+        }
+        for (int i = tid; i < n1; i += NT) { fb[L.w1w + i] = w1_wid[i]; fb[L.w1ci + i] = w1_ci[i]; fb[L.w1ci2 + i] = w1_ci2[i]; }
     }
     if (SMALL) {
         const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_k = psgpu_as_global(p.kids), *const g_p = psgpu_as_global(p.parent),
@@ -1118,7 +1123,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const int32_t news = o_out[node] + p.pip;
             int kc = 0;
             if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = node_pw[node]; w >= 0; w = homophone[w]) kc += (news + ft_pen(d_last[w]) > lpt) ? 1 : 0;
+                for (int w = node_pw[node]; w >= 0; w = homo_f[w]) kc += (news + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
             cntb[i] = kc;
         }
         ft_sync<SMALL>();
@@ -1142,8 +1147,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const int32_t news = o_out[node] + p.pip;
             int oc = cntb[i];
             if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = node_pw[node]; w >= 0; w = homophone[w])
-                    if (news + ft_pen(d_last[w]) > lpt) {
+                for (int w = node_pw[node]; w >= 0; w = homo_f[w])
+                    if (news + ft_pen(dlast_f[w]) > lpt) {
                         cand_wid[oc] = w; cand_score[oc] = news - p.nwpen; cand_bp[oc] = o_outh[node]; ++oc;
                     }
         }
@@ -1232,7 +1237,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (!present[slot]) {
                         // ngram_search_alloc_all_rc (ngram_search.c:583-633), then hmm_enter into the cleared channel (its frame
                         // is -1: the test below always passes): the whole record is written at once
-                        const int last = d_last[w], last2 = d_last2[w];
+                        const int last = dlast_f[w], last2 = d_last2[w];
                         ch_init_enter_rec<NE>(rec, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq, cand_score[i], cand_bp[i], nf);
                         present[slot] = 1;
                         cnt2[i] = 1;
@@ -1319,6 +1324,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int lane = tid & 63;
                 for (int e = tid >> 6; e < n_exit; e += NT / 64) {
                     const int i = ft_seg_find(w_bp, naw, e), w = awlc[i], j0 = w_bss[i], nrc = w_bss[i + 1] - j0, bpi = bpidx + e;
+                    const int32_t w_last2 = d_last2[w], w_filler = d_filler[w];      // (asked for with the channels' records, not after the merge)
                     int32_t it[4] = { kW, -1, -1, -1 };          // out score, history, its real / prev_real wid
                     if (lane < nrc) {
                         const int slot = wc_off[w] + lane;
@@ -1348,13 +1354,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         word_lat_idx[w] = bpi;
                         BPC(tb, B_WID, bpi) = w; BPC(tb, B_FRAME, bpi) = f; BPC(tb, B_BP, bpi) = P; BPC(tb, B_SCORE, bpi) = S;
                         BPC(tb, B_SIDX, bpi) = bss_head + j0; BPC(tb, B_VALID, bpi) = 1;
-                        BPC(tb, B_LAST, bpi) = d_last[w]; BPC(tb, B_LAST2, bpi) = d_last2[w];
+                        BPC(tb, B_LAST, bpi) = dlast_f[w]; BPC(tb, B_LAST2, bpi) = w_last2;
                         // set_real_wid (:341-372) from the path it was last evaluated with (real ids are >= 0: -1 = no path)
-                        if (d_filler[w]) {
-                            BPC(tb, B_REAL, bpi) = rw_real != -1 ? rw_real : d_base[w];
+                        if (w_filler) {
+                            BPC(tb, B_REAL, bpi) = rw_real != -1 ? rw_real : dbase_f[w];
                             BPC(tb, B_PREAL, bpi) = rw_real != -1 ? rw_preal : -1;
                         }
-                        else { BPC(tb, B_REAL, bpi) = d_base[w]; BPC(tb, B_PREAL, bpi) = rw_real; }
+                        else { BPC(tb, B_REAL, bpi) = dbase_f[w]; BPC(tb, B_PREAL, bpi) = rw_real; }
                     }
                 }
             }
@@ -1478,38 +1484,48 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         ft_sync<SMALL>();
         FT_PROF(25);
         if (s_red[6] > 0) {
-            for (int i = tid; i < R; i += NT) {          // tree roots (:1306-1325)
-                const int ci = node_ci[i];
-                const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
-                if (ns + ft_pen(ci) > thresh && (tv.at(i, F::FRAME) < f || ns > tv.at(i, F::SCORE))) {
-                    ch_enter<NE>(tv, i, ns, brc_path[ci], nf);
-                    tv.at(i, F::SENID) = ldiph[((size_t)ci * n_ci + node_ci2[i]) * n_ci + brc_lc[ci]];
+            // the tree roots on wavefronts 1.., the single-phone words on wavefront 0: their chains of dependent loads run side by
+            // side (three loops one after the other cost the sum of their latencies).  The single-phone words keep the reference's
+            // order within a work-item -- in-LM words, then <sil> and the noise words: a word entered by both loops must see the
+            // first's result (measured: with the two on different wavefronts `numbers` diverged at random)
+            if (tid >= 64 || NT == 64) {
+                const int t0r = NT == 64 ? tid : tid - 64, str = NT == 64 ? NT : NT - 64;
+                for (int i = t0r; i < R; i += str) {         // tree roots (:1306-1325)
+                    const int ci = node_ci[i];
+                    const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
+                    if (ns + ft_pen(ci) > thresh && (tv.at(i, F::FRAME) < f || ns > tv.at(i, F::SCORE))) {
+                        ch_enter<NE>(tv, i, ns, brc_path[ci], nf);
+                        tv.at(i, F::SENID) = ldiph[((size_t)ci * n_ci + node_ci2[i]) * n_ci + brc_lc[ci]];
+                    }
                 }
             }
-            for (int i = tid; i < p.n1lm; i += NT) {     // in-LM single-phone words (:1331-1388)
-                const int w = w1_wid[i];
-                const unsigned long long k = ckey[i];
-                const int32_t ds = ft_key_none(k) ? kMaxNegInt32 : ft_key_score(k);
-                const int dbp = ft_key_none(k) ? 0 : ft_key_bp(k);
-                lt_dscr[w] = ds; lt_bp[w] = dbp;
-                if (w == p.startwid) continue;
-                const int c = W1 + i;
-                const int32_t ns = ds + p.pip;
-                if (ns + ft_pen(w1_ci[i]) > thresh && (tv.at(c, F::FRAME) < f || ns > tv.at(c, F::SCORE))) {
-                    ch_enter<NE>(tv, c, ns, dbp, nf);
-                    tv.at(c, F::SENID) = ldiph[((size_t)w1_ci[i] * n_ci + w1_ci2[i]) * n_ci + d_last[BPC(tb, B_WID, dbp)]];
+            if (tid < 64) {
+                for (int i = tid; i < p.n1lm; i += 64) {     // in-LM single-phone words (:1331-1388)
+                    const int w = w1w_f[i];
+                    const unsigned long long kk = ckey[i];
+                    const int32_t ds = ft_key_none(kk) ? kMaxNegInt32 : ft_key_score(kk);
+                    const int dbp = ft_key_none(kk) ? 0 : ft_key_bp(kk);
+                    const int pw = BPC(tb, B_WID, dbp);      // (asked for before the tests: the frame has entries, entry 0 exists)
+                    lt_dscr[w] = ds; lt_bp[w] = dbp;
+                    if (w == p.startwid) continue;
+                    const int c = W1 + i;
+                    const int32_t ns = ds + p.pip;
+                    if (ns + ft_pen(w1ci_f[i]) > thresh && (tv.at(c, F::FRAME) < f || ns > tv.at(c, F::SCORE))) {
+                        ch_enter<NE>(tv, c, ns, dbp, nf);
+                        tv.at(c, F::SENID) = ldiph[((size_t)w1ci_f[i] * n_ci + w1ci2_f[i]) * n_ci + dlast_f[pw]];
+                    }
                 }
-            }
-            for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += NT) {    // <sil> and noise words (:1390-1426)
-                // slot filler_start - 1 stands for <sil>, which is handled whatever its place in the dictionary
-                const bool is_sil = w == p.filler_start - 1;
-                if (!is_sil && (w == p.startwid || w == p.silwid)) continue;
-                const int i = w1_of_word[is_sil ? p.silwid : w];
-                if (i < 0) continue;
-                const int c = W1 + i;
-                const int32_t ns = brc_score[p.sil_ci] + (is_sil ? p.silpen : p.fillpen) + p.pip;
-                if (ns + ft_pen(w1_ci[i]) > thresh && (tv.at(c, F::FRAME) < f || ns > tv.at(c, F::SCORE)))
-                    ch_enter<NE>(tv, c, ns, brc_path[p.sil_ci], nf);
+                for (int w = p.filler_start - 1 + tid; w <= p.filler_end; w += 64) {    // <sil> and noise words (:1390-1426)
+                    // slot filler_start - 1 stands for <sil>, which is handled whatever its place in the dictionary
+                    const bool is_sil = w == p.filler_start - 1;
+                    if (!is_sil && (w == p.startwid || w == p.silwid)) continue;
+                    const int i = w1_of_word[is_sil ? p.silwid : w];
+                    if (i < 0) continue;
+                    const int c = W1 + i;
+                    const int32_t ns = brc_score[p.sil_ci] + (is_sil ? p.silpen : p.fillpen) + p.pip;
+                    if (ns + ft_pen(w1ci_f[i]) > thresh && (tv.at(c, F::FRAME) < f || ns > tv.at(c, F::SCORE)))
+                        ch_enter<NE>(tv, c, ns, brc_path[p.sil_ci], nf);
+                }
             }
         }
         ft_sync<SMALL>();
@@ -1627,6 +1643,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
         L.dfirst = take(d.n_w); L.dbase = take(d.n_w); L.w1w = take(d.n1);
+        L.dlast = take(d.n_w); L.homo = take(d.n_w); L.w1ci = take(d.n1); L.w1ci2 = take(d.n1);
         // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the lists, the
         // log-add table, the listed senones: a launch that reads score rows asks for less LDS
         L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
