@@ -38,7 +38,7 @@
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
-constexpr int kFtLdsWords = 16640;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
+constexpr int kFtLdsWords = 16768;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
                                        // that reads score rows leaves the last 3.6 KB out (FtLay::rows_total): two workgroups per CU then take ~126 of its
                                        // 160 KB and leave the rest to the kernels of other streams that run beside the search
 constexpr int kFtListCap = 1024;       // listed senones per frame kept as a list (LDS layout, scoring from top-N lists); more: scored where found
@@ -68,6 +68,7 @@ struct FtLay {
     int32_t rows_total;                  // small layout: words of the pool a launch that reads score ROWS needs (row and l_* lie behind)
     int32_t kid_off, kids, parent, ci, pw;     // small layout: copies of the static tree tables
     int32_t dfirst, dbase, w1w;          // small layout: copies of the words' first phone and base word id [n_w], the single-phone words' ids [n1]
+    int32_t dfill;                       // small layout: copy of the words' filler flags [n_w]
     int32_t dlast, homo, w1ci, w1ci2;    // small layout: copies of the words' last phone and homophone link [n_w], the single-phone words' phones [n1]
     int32_t tp;                          // small layout: copy of the transition matrices (bytes)
     int32_t total;
@@ -682,10 +683,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int32_t *const dfirst_f = SMALL ? fb + L.dfirst : d_first, *const dbase_f = SMALL ? fb + L.dbase : d_base,
                   *const w1w_f = SMALL ? fb + L.w1w : w1_wid, *const dlast_f = SMALL ? fb + L.dlast : d_last,
                   *const homo_f = SMALL ? fb + L.homo : homophone, *const w1ci_f = SMALL ? fb + L.w1ci : w1_ci,
-                  *const w1ci2_f = SMALL ? fb + L.w1ci2 : w1_ci2;
+                  *const w1ci2_f = SMALL ? fb + L.w1ci2 : w1_ci2, *const dfill_f = SMALL ? fb + L.dfill : d_filler;
     if (SMALL) {
         for (int i = tid; i < p.n_w; i += NT) {
             fb[L.dfirst + i] = d_first[i]; fb[L.dbase + i] = d_base[i]; fb[L.dlast + i] = d_last[i]; fb[L.homo + i] = homophone[i];
+            fb[L.dfill + i] = d_filler[i];
         }
         for (int i = tid; i < n1; i += NT) { fb[L.w1w + i] = w1_wid[i]; fb[L.w1ci + i] = w1_ci[i]; fb[L.w1ci2 + i] = w1_ci2[i]; }
     }
@@ -1381,10 +1383,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         if (tv.at(c, F::OUT) > nwt) {
                             const int w = w1_wid[i];
                             ex = 1;
-                            if (word_lat_idx[w] == -1) {
-                                nw = 1;
-                                rcn = dict.d_pronlen[w] == 1 ? 0 : rs_n[d_last[w] * n_ci + d_last2[w]];
-                            }
+                            if (word_lat_idx[w] == -1) nw = 1;   // (a single-phone word has no right-context fan-out: rcn stays 0,
+                                                                  //  dict_is_single_phone = pronunciation length 1)
                         }
                     }
                 }
@@ -1411,7 +1411,23 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             for (int i = tid; i < n1; i += NT)
                 if (f_ex[i]) {
                     int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
-                    if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w1_wid[i], tv.at(W1 + i, F::OUT), tv.at(W1 + i, F::OUTH), 0)) s_sc[6] = 1;
+                    const int w = w1w_f[i];
+                    const int32_t score = tv.at(W1 + i, F::OUT), path = tv.at(W1 + i, F::OUTH);
+                    if (word_lat_idx[w] == -1 && bpi < tb.bp_cap && bsh + n_ci < tb.bss_cap) {
+                        // the new entry of a single-phone word (ngram_search_save_bp's creating branch for pronunciation length 1,
+                        // ngram_search.c:438-498): no score-stack segment, its real word ids by set_real_wid (:341-372) -- one trip
+                        // to device memory (the path's ids) where the general routine makes four
+                        const int32_t pr = path == -1 ? -1 : BPC(tb, B_REAL, path), pp = path == -1 ? -1 : BPC(tb, B_PREAL, path);
+                        word_lat_idx[w] = bpi;
+                        BPC(tb, B_WID, bpi) = w; BPC(tb, B_FRAME, bpi) = f; BPC(tb, B_BP, bpi) = path; BPC(tb, B_SCORE, bpi) = score;
+                        BPC(tb, B_SIDX, bpi) = -1; BPC(tb, B_VALID, bpi) = 1; BPC(tb, B_LAST, bpi) = dlast_f[w]; BPC(tb, B_LAST2, bpi) = -1;
+                        if (dfill_f[w]) {
+                            BPC(tb, B_REAL, bpi) = path != -1 ? pr : dbase_f[w];
+                            BPC(tb, B_PREAL, bpi) = path != -1 ? pp : -1;
+                        }
+                        else { BPC(tb, B_REAL, bpi) = dbase_f[w]; BPC(tb, B_PREAL, bpi) = path != -1 ? pr : -1; }
+                    }
+                    else if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w, score, path, 0)) s_sc[6] = 1;
                 }
             FT_PROF(21);
             // (bptable_maxwpf, when it applies, reads the frame's entries: a full barrier.  Otherwise nothing between here and
@@ -1643,7 +1659,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.wc_off = take(d.n_w + 1);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
         L.dfirst = take(d.n_w); L.dbase = take(d.n_w); L.w1w = take(d.n1);
-        L.dlast = take(d.n_w); L.homo = take(d.n_w); L.w1ci = take(d.n1); L.w1ci2 = take(d.n1);
+        L.dlast = take(d.n_w); L.homo = take(d.n_w); L.w1ci = take(d.n1); L.w1ci2 = take(d.n1); L.dfill = take(d.n_w);
         // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the lists, the
         // log-add table, the listed senones: a launch that reads score rows asks for less LDS
         L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
