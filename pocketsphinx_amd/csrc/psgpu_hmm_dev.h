@@ -79,7 +79,13 @@ template <typename S>
 __device__ __forceinline__ int32_t vit3_mpx(HmmRegs &h, const uint8_t *tp, const S &ss, const uint16_t *sseq)
 {
 #define TP(i, j) (-(int32_t)tp[(i) * 4 + (j)])
-#define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 3 + (st)]])
+    // the states' senone ids first, all three with nothing between them: one trip to the sseq table instead of three (each SEN()
+    // below sat behind the test of its state's ssid, so the compiler waited for one before it asked for the next).  A state
+    // without an ssid reads entry 0 and drops it.
+    const uint16_t sq_[3] = { sseq[(size_t)h.senid[0] * 3 + 0],
+                              sseq[(size_t)(h.senid[1] == kBadSsid ? 0 : h.senid[1]) * 3 + 1],
+                              sseq[(size_t)(h.senid[2] == kBadSsid ? 0 : h.senid[2]) * 3 + 2] };
+#define SEN(st) (-(int32_t)ss[sq_[st]])
     int32_t s3, s2, s1, s0, t0, t1, t2 = INT_MIN, best;
     if (h.senid[2] == kBadSsid) s2 = t1 = kW;
     else { s2 = h.score[2] + SEN(2); t1 = s2 + TP(2, 3); }
@@ -205,7 +211,13 @@ template <typename S>
 __device__ __forceinline__ int32_t vit5_mpx(HmmRegs &h, const uint8_t *tp, const S &ss, const uint16_t *sseq)
 {
 #define TP(i, j) (-(int32_t)tp[(i) * 6 + (j)])
-#define SEN(st) (-(int32_t)ss[sseq[(size_t)h.senid[st] * 5 + (st)]])
+    // (as in vit3_mpx: the five senone ids in one trip)
+    const uint16_t sq_[5] = { sseq[(size_t)h.senid[0] * 5 + 0],
+                              sseq[(size_t)(h.senid[1] == kBadSsid ? 0 : h.senid[1]) * 5 + 1],
+                              sseq[(size_t)(h.senid[2] == kBadSsid ? 0 : h.senid[2]) * 5 + 2],
+                              sseq[(size_t)(h.senid[3] == kBadSsid ? 0 : h.senid[3]) * 5 + 3],
+                              sseq[(size_t)(h.senid[4] == kBadSsid ? 0 : h.senid[4]) * 5 + 4] };
+#define SEN(st) (-(int32_t)ss[sq_[st]])
     int32_t s5, s4, s3, s2, s1, s0, t0, t1, t2, best;
     if (h.senid[4] == kBadSsid) s4 = t1 = kW;
     else { s4 = h.score[4] + SEN(4); t1 = s4 + TP(4, 5); }

@@ -851,13 +851,20 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             auto mark_sen = [&](int sen) { atomicOr(&s_bits[sen >> 5], 1u << (sen & 31)); if (!lists) mn = min(mn, (int32_t)row[sen]); };
             auto mark = [&](const ChView &v, int c) {
                 const int mpx = v.at(c, F::MPX);
+                int sen[NE];
+                bool ok[NE];
 #pragma unroll
-                for (int k = 0; k < NE; ++k) {
-                    int sen = v.at(c, F::SENID + k);
-                    if (mpx) { if (sen == kBadSsid) continue; sen = sseq[(size_t)sen * NE + k]; }
-                    atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
-                    if (!lists) mn = min(mn, (int32_t)row[sen]);
+                for (int k = 0; k < NE; ++k) { sen[k] = v.at(c, F::SENID + k); ok[k] = !(mpx && sen[k] == kBadSsid); }
+                if (mpx) {                                   // (the states' senone ids in ONE trip to the sseq table: a state without an ssid reads entry 0)
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) sen[k] = sseq[(size_t)(ok[k] ? sen[k] : 0) * NE + k];
                 }
+#pragma unroll
+                for (int k = 0; k < NE; ++k)
+                    if (ok[k]) {
+                        atomicOr(&s_bits[sen[k] >> 5], 1u << (sen[k] & 31));
+                        if (!lists) mn = min(mn, (int32_t)row[sen[k]]);
+                    }
             };
             for (int k0 = 0; k0 < n_items; k0 += NT) {
                 int k = k0 + tid, code = -1;
