@@ -19,6 +19,7 @@
 // Oracle: oracle/ps_oracle_flat.c (pinned to the reference); checked on the CPU through tests/hostsim.
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
+#include "psgpu_sen_dev.h"
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -103,7 +104,14 @@ struct FfOff {
 struct FfBufs {
     int32_t *slab; const int32_t *voc; int32_t *bp, *bss, *idx, *step, *res; const int32_t *w1_ssid;
     int32_t bp_cap, bss_cap, max_frames;
+    long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][16] cycles per phase (tools/build_prof_lib.py)
 };
+// per-phase cycle counts of work-item 0 (a profiling build only: -DPSGPU_FT_PROFILE; the product kernel has none of it)
+#ifdef PSGPU_FT_PROFILE
+#define FF_PROF(i) do { if (tid == 0) { const long long t_ = clock64(); s_prof[i] += t_ - s_last; s_last = t_; } } while (0)
+#else
+#define FF_PROF(i) do { } while (0)
+#endif
 
 struct psgpu_fwdflat_s {
     FfDev d;
@@ -291,12 +299,21 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ uint32_t s_bits[RAW ? kFfMaxSen / 32 : 1];
     __shared__ int32_t s_prev[RAW ? kFfMaxSen / 32 : 1];
     __shared__ int32_t s_lcw[RAW ? kFfMaxEnt : 1], s_lsc[RAW ? kFfMaxEnt : 1];   // the scorer's lists: codeword, score
-    __shared__ uint8_t s_cbact[RAW ? kFfMaxCb : 1], s_la[RAW ? 256 : 1];
+    __shared__ uint8_t s_cbact[RAW ? kFfMaxCb : 1], s_la[RAW ? 512 : 1];  // (log-add table readable up to 511: zero beyond the reference's entries)
+    // senones scored evenly over the work-items (the first pass's way, psgpu_sen_dev.h): the frame's lists packed four to a word, the
+    // listed senones as a list (prefix sum over the bitmap words' populations)
+    __shared__ uint32_t s_pcw[RAW ? kFfMaxEnt / 4 : 1], s_psc[RAW ? kFfMaxEnt / 4 : 1];
+    __shared__ int32_t s_wcnt[RAW ? kFfMaxSen / 32 + 4 : 1];
+    __shared__ uint16_t s_slist[RAW ? 1024 : 1];
     __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64];
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, -, -, length of the evaluation list
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
+#ifdef PSGPU_FT_PROFILE
+    __shared__ long long s_prof[16], s_last;
+    if (tid == 0) { for (int i = 0; i < 16; ++i) s_prof[i] = 0; s_last = clock64(); }
+#endif
     FfUtt u;
     {
         const FfOff o = offs[blockIdx.x];
@@ -350,7 +367,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     const int n_chain = RAW ? rw.pm.n_mgau * rw.pm.n_feat : 0, topn = RAW ? rw.pm.topn : 0;
     if (RAW) {
         for (int i = tid; i < n_chain * topn; i += kFfThreads) { s_lcw[i] = rw.seed[(size_t)blockIdx.x * n_chain * topn + i]; s_lsc[i] = 0; }
-        for (int i = tid; i < 256; i += kFfThreads) s_la[i] = i < rw.pm.logadd8_size ? rw.pm.logadd8[i] : 0;
+        for (int i = tid; i < 512; i += kFfThreads) s_la[i] = (i < rw.pm.logadd8_size && i < 256) ? rw.pm.logadd8[i] : 0;
     }
     __syncthreads();
 
@@ -400,6 +417,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 }
             }
             __syncthreads();
+            FF_PROF(0);
             // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain
             for (int ch = tid; ch < n_chain; ch += kFfThreads) {
                 const int cb = ch / pm.n_feat, fs = ch % pm.n_feat, len = pm.featlen[fs];
@@ -447,6 +465,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 s_lsc[i] = v > kMaxNegAscr ? kMaxNegAscr : v;
             }
             __syncthreads();
+            FF_PROF(1);
             // ---- ptm_mgau_senone_eval (:326-403) for the listed senones; the frame's scores are those minus their minimum
             int32_t mn = 0x7fffffff;
             auto senone = [&](int sen) {
@@ -467,6 +486,61 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 u.nrow32[sen] = a;
                 mn = min(mn, a);
             };
+            // The scorer's usual shape (3 streams, top-4, senone-major weights at hand): the senones spread evenly over the
+            // work-items -- a list from the bitmap by a prefix sum -- and each one's twelve weights from three cache lines
+            // (sen_eval_f3n4, the first pass's) instead of one work-item per bitmap word walking its bits, twelve scattered byte
+            // loads per senone (measured: 95 k of the frame's 254 k cycles, profiles/r03_fwdflat_phase_profile.txt).
+            const bool fast = topn == 4 && pm.n_feat == kSenStreams && pm.mixw_sen != nullptr && n_chain <= kFfMaxEnt / 4
+                              && nwords <= kFfThreads;
+            if (fast) {
+                const SenModel smod = { pm.mixw_sen, pm.sen2cb, pm.n_sen, pm.n_density };
+                for (int ch = tid; ch < n_chain; ch += kFfThreads) {
+                    s_pcw[ch] = (uint32_t)(s_lcw[ch * 4] & 0xff) | ((uint32_t)(s_lcw[ch * 4 + 1] & 0xff) << 8)
+                                | ((uint32_t)(s_lcw[ch * 4 + 2] & 0xff) << 16) | ((uint32_t)(s_lcw[ch * 4 + 3] & 0xff) << 24);
+                    s_psc[ch] = (uint32_t)(s_lsc[ch * 4] & 0xff) | ((uint32_t)(s_lsc[ch * 4 + 1] & 0xff) << 8)
+                                | ((uint32_t)(s_lsc[ch * 4 + 2] & 0xff) << 16) | ((uint32_t)(s_lsc[ch * 4 + 3] & 0xff) << 24);
+                }
+                for (int w = tid; w <= nwords; w += kFfThreads) s_wcnt[w] = w < nwords ? __popc(s_bits[w]) : 0;
+                __syncthreads();
+                auto score = [&](int sen) {
+                    const int32_t a = sen_eval_f3n4(smod, s_pcw, s_psc, s_la, sen);
+                    u.nrow32[sen] = a;
+                    mn = min(mn, a);
+                };
+                const int n_list = ff_block_scan(s_wcnt, nwords + 1, s_scan);
+                if (tid < nwords) {
+                    uint32_t b = s_bits[tid];
+                    int prev = s_prev[tid], o = s_wcnt[tid];
+                    while (b) {
+                        const int sen = tid * 32 + __ffs((int)b) - 1;
+                        b &= b - 1;
+                        for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; score(last); }   // bridging entries (rare)
+                        if (o < 1024) s_slist[o] = (uint16_t)sen; else score(sen);
+                        ++o;
+                        prev = sen;
+                    }
+                }
+                __syncthreads();
+                const int nl = min(n_list, 1024);
+                for (int i = tid; i < nl; i += kFfThreads) score((int)s_slist[i]);
+                atomicMin(&s_nb, mn);
+                __syncthreads();
+                const int32_t nb = s_nb;
+                for (int i = tid; i < nl; i += kFfThreads) {
+                    const int sen = s_slist[i];
+                    u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
+                }
+                if (n_list > 1024 && tid < nwords) {             // (a frame with more: those past the list, where they were found)
+                    uint32_t b = s_bits[tid];
+                    for (int o = s_wcnt[tid]; b; b &= b - 1, ++o)
+                        if (o >= 1024) {
+                            const int sen = tid * 32 + __ffs((int)b) - 1;
+                            u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
+                        }
+                }
+                __syncthreads();
+            }
+            else {
             for (int w = tid; w < nwords; w += kFfThreads) {
                 uint32_t b = s_bits[w];
                 int prev = s_prev[w];
@@ -490,8 +564,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 }
             }
             __syncthreads();
+            }
             row = u.nrow;
         }
+        FF_PROF(2);
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:825-838)
         if (tid == 0) u.bp_table_idx[f] = s_sc[1];
         const int32_t best_in = s_sc[0];
@@ -504,6 +580,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         __syncthreads();
         if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_sc[7] = 0; s_key = 0ull; }
         __syncthreads();
+        FF_PROF(3);
         // ---- fwdflat_eval_chan (:444-480).  A word near its end has its whole right-context fan-out (20-40 channels) active at
         //      once: the active channels are first gathered into one list (one work-item per word, order irrelevant -- the
         //      evaluations are independent and the best score is a maximum), then evaluated one work-item per channel
@@ -529,6 +606,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         __syncthreads();
         const int32_t best_score = s_sc[0];
         const int32_t thresh = best_score + p.fwdflatbeam, wordthresh = best_score + p.fwdflatwbeam;
+        FF_PROF(4);
         // ---- fwdflat_prune_chan (:482-607), one work-item per active word; exits are flagged, their back-pointer
         //      positions come from the prefix sums below (one entry per exiting word, in active-list order)
         for (int i = tid; i < na; i += kFfThreads) {
@@ -593,6 +671,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         __syncthreads();
         if (s_sc[3]) break;
 
+        FF_PROF(5);
         // ---- fwdflat_word_transition (:642-782)
         const int bp0 = u.bp_table_idx[f], bp1 = s_sc[1];
         for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
@@ -662,6 +741,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
             if (u.frame[c0] == f) ff_clear_scores(p, u, c0);
         }
+        FF_PROF(6);
         // ---- next active word list (:853-869): the vocabulary in its order (words below <s>), then <s> and above by id
         const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
         for (int i = tid; i < n_all; i += kFfThreads) {
@@ -679,7 +759,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             ++s_sc[4];
         }
         __syncthreads();
+        FF_PROF(7);
     }
+#ifdef PSGPU_FT_PROFILE
+    if (tid == 0 && bf.prof) for (int i = 0; i < 16; ++i) bf.prof[(size_t)blockIdx.x * 16 + i] = s_prof[i];
+#endif
     if (tid == 0) {
         u.bp_table_idx[s_sc[4]] = s_sc[1];                       // ngram_fwdflat_finish: mark one past the last frame
         u.result[0] = s_sc[1]; u.result[1] = s_sc[2]; u.result[2] = s_sc[4]; u.result[3] = s_sc[3]; u.result[4] = s_sc[0];
@@ -931,6 +1015,10 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     FfBufs bf;
     bf.slab = slab; bf.voc = vdev; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
     bf.w1_ssid = w1_ssid_dev; bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
+    bf.prof = nullptr;
+#ifdef PSGPU_FT_PROFILE
+    if (hipMalloc((void **)&bf.prof, sizeof(long long) * 16 * (size_t)n_utt) != hipSuccess) bf.prof = nullptr;
+#endif
     if (d.n_emit == 3 && raw)
         hipLaunchKernelGGL((fwdflat_kernel<3, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
     else if (d.n_emit == 3)
@@ -941,6 +1029,24 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         hipLaunchKernelGGL((fwdflat_kernel<5, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
+#ifdef PSGPU_FT_PROFILE
+    if (e == hipSuccess && bf.prof) {    // a profiling build: per-phase cycle counts of work-item 0, averaged over the utterances, per frame
+        static const char *const names[8] = { "senones of the active channels (bitmap, codebooks)", "top-N lists (taken / evaluated)",
+            "senone evaluation + normaliser", "mark, renormalise, reset", "evaluate (gather + hmm_vit_eval)", "prune + exits (save_bp)",
+            "word transitions + fillers + clear", "next active word list" };
+        std::vector<long long> h((size_t)16 * n_utt);
+        std::vector<int32_t> r((size_t)8 * n_utt);
+        hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost);
+        double frames = 0, tot = 0, acc[8] = {};
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 8; ++i) acc[i] += (double)h[(size_t)u * 16 + i]; }
+        for (int i = 0; i < 8; ++i) tot += acc[i];
+        fprintf(stderr, "fwdflat_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
+        for (int i = 0; i < 8; ++i)
+            fprintf(stderr, "  %d %-52s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
+    }
+    hipFree(bf.prof);
+#endif
     hipFree(slab); hipFree(vdev); hipFree(d_utts);
     PSGPU_HIP(e);
     return PSGPU_OK;
