@@ -374,6 +374,21 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = n_awl[cur];
         const int16_t *row = RAW ? nullptr : senscr + (size_t)(t0 + f) * scr_stride;
+        // ---- the frame's active channels, gathered into one list first (one work-item per word walks its chain once: order
+        //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
+        //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
+        //      profiles/r03_fwdflat_phase_profile.txt).  Nothing between here and the evaluation changes a channel's frame stamp.
+        if (tid == 0) s_sc[7] = 0;
+        __syncthreads();
+        for (int i = tid; i < na; i += kFfThreads) {
+            const int w = u.awl[cur][i];
+            int len; const int c0 = ff_root(p, u, w, len);
+            for (int k = 0; k < len; ++k)
+                if (u.frame[c0 + k] == f)                     // bit 30: the root of </s>, which does not count towards the best score
+                    u.elist[atomicAdd(&s_sc[7], 1)] = (c0 + k) | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
+        }
+        __syncthreads();
+        const int n_eval = s_sc[7];
         if (RAW) {
             const psgpu_ptm_view_t &pm = rw.pm;
             const float *x = rw.feats + (size_t)(t0 + f) * pm.veclen;
@@ -384,16 +399,12 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             if (tid < 16) s_norm[tid] = kW;
             if (tid == 0) s_nb = 0x7fffffff;
             __syncthreads();
-            for (int i = tid; i < na; i += kFfThreads) {
-                int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
-                for (int k = 0; k < len; ++k) {
-                    const int c = c0 + k;
-                    if (u.frame[c] != f) continue;
-                    for (int q = 0; q < NE; ++q) {
-                        int sen = u.senid[c * 5 + q];
-                        if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
-                        atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
-                    }
+            for (int i = tid; i < n_eval; i += kFfThreads) {
+                const int c = u.elist[i] & ~(1 << 30);
+                for (int q = 0; q < NE; ++q) {
+                    int sen = u.senid[c * 5 + q];
+                    if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
+                    atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
                 }
             }
             __syncthreads();
@@ -578,24 +589,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 for (int k = 0; k < len; ++k) if (u.frame[c0 + k] == f) ff_normalize(p, u, c0 + k, best_in);
             }
         __syncthreads();
-        if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_sc[7] = 0; s_key = 0ull; }
+        if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_key = 0ull; }
         __syncthreads();
         FF_PROF(3);
-        // ---- fwdflat_eval_chan (:444-480).  A word near its end has its whole right-context fan-out (20-40 channels) active at
-        //      once: the active channels are first gathered into one list (one work-item per word, order irrelevant -- the
-        //      evaluations are independent and the best score is a maximum), then evaluated one work-item per channel
-        //      (s_sc[7], the list length, was zeroed before the barrier above)
-        for (int i = tid; i < na; i += kFfThreads) {
-            const int w = u.awl[cur][i];
-            int len; const int c0 = ff_root(p, u, w, len);
-            for (int k = 0; k < len; ++k)
-                if (u.frame[c0 + k] == f)                     // bit 30: the root of </s>, which does not count towards the best score
-                    u.elist[atomicAdd(&s_sc[7], 1)] = (c0 + k) | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
-        }
-        __syncthreads();
+        // ---- fwdflat_eval_chan (:444-480), one work-item per channel of the list made at the top of the frame (a word near its end
+        //      has its whole right-context fan-out, 20-40 channels, active at once)
         {
             int32_t b = kW;
-            const int n_eval = s_sc[7];
             for (int i = tid; i < n_eval; i += kFfThreads) {
                 const int e = u.elist[i];
                 const int32_t sc = ff_eval<NE>(p, u, e & ~(1 << 30), row);
