@@ -45,7 +45,8 @@ sys.path.insert(0, ROOT)
 B_UTT, UTT_SECONDS = 512, 30.0
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GOPS = 78643.2         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-FMA fp32 op rate)
-N_SAMPLE = 16                    # utterances decoded by the reference for cpu_baseline + parity
+N_SAMPLE = 64                    # utterances decoded by the reference for cpu_baseline + parity
+LV_UTT, LV_CHECK, LV_STEPS = 256, 8, 2     # the large-vocabulary leg: utterances per step, utterances the reference decodes, timed steps
 
 
 def _npz(name):
@@ -73,26 +74,148 @@ def synth_pcm(first_id, n_utt, seconds):
         return np.concatenate(list(ex.map(_synth_range, jobs)))
 
 
-def reference_decode(pcm, n_samples, ids):
-    """the compiled reference on the same PCM: [(utt id, json)] + totals; None when oracle/_ref is absent"""
+def _ref_one(job):
+    exe, model, lm, dic, path, n_samples = job
+    out = subprocess.run([exe, model, lm, dic, path, str(n_samples)], capture_output=True, text=True, timeout=1800)
+    lines = [json.loads(ln) for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not lines or "total" not in lines[-1]:
+        raise RuntimeError("ref_decode_bench rc %d: %s" % (out.returncode, out.stderr[-300:]))
+    return lines[:-1], lines[-1]
+
+
+def reference_decode(pcm, n_samples, ids, lm="turtle.lm.bin", dic="turtle.dic", procs=1):
+    """the compiled reference on the same PCM: ([json per utterance, in the order of ids], totals); None when oracle/_ref is
+    absent.  procs > 1: that many reference processes side by side, each one thread decoding its share of the utterances
+    (pocketsphinx_batch's way to use a machine: one decoder per core, programs/pocketsphinx_batch.c) -- totals then carry
+    the wall time of the slowest process as well"""
     ref = os.path.join(ROOT, "oracle", "_ref")
     exe = os.path.join(ref, "ref_decode_bench")
     if not os.path.exists(exe):
         return None
-    with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as fh:
-        for i in ids:
-            pcm[i * n_samples:(i + 1) * n_samples].tofile(fh)
-        path = fh.name
+    procs = max(1, min(procs, len(ids)))
+    shares = [ids[k::procs] for k in range(procs)]
+    paths = []
     try:
-        out = subprocess.run([exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", "turtle.lm.bin"),
-                              os.path.join(ref, "data", "turtle.dic"), path, str(n_samples)], capture_output=True, text=True,
-                             timeout=900)
-        lines = [json.loads(ln) for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
-        if out.returncode != 0 or not lines or "total" not in lines[-1]:
-            raise RuntimeError("ref_decode_bench rc %d: %s" % (out.returncode, out.stderr[-300:]))
-        return lines[:-1], lines[-1]
+        for sh in shares:
+            with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as fh:
+                for i in sh:
+                    pcm[i * n_samples:(i + 1) * n_samples].tofile(fh)
+                paths.append(fh.name)
+        jobs = [(exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", lm), os.path.join(ref, "data", dic), pth, n_samples)
+                for pth in paths]
+        t0 = time.perf_counter()
+        if procs == 1:
+            outs = [_ref_one(jobs[0])]
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=procs) as ex:
+                outs = list(ex.map(_ref_one, jobs))
+        wall = time.perf_counter() - t0
     finally:
-        os.unlink(path)
+        for pth in paths:
+            os.unlink(pth)
+    by_id = {}
+    for sh, (utts, _) in zip(shares, outs):
+        for i, r in zip(sh, utts):
+            by_id[i] = r
+    frames = sum(t["frames"] for _, t in outs); cpu_s = sum(t["cpu_s"] for _, t in outs)
+    tot = {"frames": frames, "cpu_s": cpu_s, "frames_per_s": frames / cpu_s if cpu_s > 0 else 0.0,
+           "xrt": cpu_s / (frames / 100.0) if frames else 0.0, "procs": procs, "wall_s": wall,
+           "frames_per_s_all_procs": frames / wall if wall > 0 else 0.0}
+    return [by_id[i] for i in ids], tot
+
+
+def parity_of(ids, utts, hn, hyp, res):
+    """utterances whose device hypothesis (word ids, start / end frames, path score, frame count) differs from the reference's"""
+    bad = []
+    for i, r in zip(ids, utts):
+        got = [tuple(int(v) for v in hyp[i, k, :3]) for k in range(min(int(hn[i, 0]), hyp.shape[1]))]
+        want = [(s[1], s[2], s[3]) for s in r["seg"]]
+        if got != want or int(hn[i, 1]) != r["score"] or int(res[i, 2]) != r["frames"]:
+            bad.append(i)
+    return bad
+
+
+def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_utt, steps, n_check, with_cpu):
+    """The large-vocabulary decode (the stand-in for configs[2]'s absent en-us.lm.bin): the first
+    n_utt of the headline's utterances through the same device pipeline with the 134,865-word dictionary and the synthetic
+    126k-unigram LM (trie on the device) -- PCM -> hypotheses -- timed; the reference decodes n_check of them with the same LM
+    and dictionary: cpu_baseline + per-utterance parity."""
+    import torch
+    from pocketsphinx_amd import largevocab as lv
+    if not lv.available():
+        return {"skipped": "oracle/_ref (ref_dump, big.arpa, cmudict-en-us.dict) not built"}
+    t0 = time.perf_counter()
+    g = lv.tables()
+    t_tab = time.perf_counter() - t0
+    pipe = lv.pipeline(g, fe_tables, ptm_tables)
+    pipe.stage_timing(True)
+    slab = C.c_int64(); lds = C.c_int32()
+    from pocketsphinx_amd import capi
+    capi.check(capi.lib().psgpu_fwdtree_layout(pipe.search.h, C.byref(lds), C.byref(slab)), "psgpu_fwdtree_layout")
+    pcm = torch.from_numpy(pcm_all[:n_utt * n_samp]).to(dev)
+    soff = np.arange(n_utt + 1, dtype=np.int64) * n_samp
+    stream = torch.cuda.current_stream().cuda_stream
+    pipe.run_dev(pcm, soff, stream); pipe.fetch(want_hyp=False)          # warm-up (allocations, table growth if any)
+    torch.cuda.synchronize()
+    stage = []
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run_dev(pcm, soff, stream)
+        hn, hyp, res = pipe.fetch()
+        stage.append(pipe.last_stage_ms())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    n_bad_status = int((res[:, 3] != 0).sum())
+    frames = int(res[:, 2].sum())
+    evals = int(res[:, 5].astype(np.int64).sum() + (res[:, 6].astype(np.int64) << 32).sum())
+    senones = int(res[:, 7].astype(np.int64).sum())
+    alg_bytes = 156 * frames + 2 * senones + 86 * evals
+    st_mean = {k: float(np.mean([s[k] for s in stage])) for k in stage[0]}
+    search_s = st_mean["search"] * 1e-3
+    par = g["par"]
+    out = {
+        "metric": "frames/sec + xRT decode, en-us PTM 5126-senone n-gram fwdtree, 134,865-word dictionary (device first pass, PCM -> hypotheses)",
+        "value": round(frames / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt, 2), "steps": steps,
+        "xrt": round(dt / (n_utt * seconds), 7),
+        "config": {"workload": "%d utterances x %g s (the headline's first %d), en-us PTM + big.arpa (126,055 unigrams) + "
+                               "cmudict-en-us.dict (%d words, %d lexicon-tree channels), fwdtree only, trie LM on the device"
+                               % (n_utt, seconds, n_utt, int(par[3]), int(par[4] + par[5])),
+                   "utterances": n_utt, "frames_per_step": frames, "maxhmmpf": int(par[17]),
+                   "search_slab_bytes_per_utterance": int(slab.value), "lds_layout": bool(lds.value)},
+        "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
+        "workload_counts": {"hmm_evals_per_frame": round(evals / max(frames, 1), 1), "listed_senones_per_frame": round(senones / max(frames, 1), 1),
+                            "back_pointers_per_utt": round(float(res[:, 0].mean()), 1), "score_stack_per_utt": round(float(res[:, 1].mean()), 1),
+                            "words_per_hyp": round(float(hn[:, 0].mean()), 1), "table_growths": pipe.tables_grown()},
+        "roofline": {"bound": "hbm", "kernel": "fwdtree_kernel<3, 1024, false, false>", "achieved": round(alg_bytes / search_s / 1e9, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / search_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(st_mean["search"], 2),
+                     "note": "one 1024-work-item workgroup per utterance, all state in a per-utterance slab in device memory; bytes = sum over "
+                             "frames of 156 + 2 x listed senones + 86 x HMM evaluations (SURVEY 8d), counted by the kernel; kernel_ms from HIP "
+                             "events on its launch stream; PMC traffic: profiles/ (tools/gpu_call_largevocab.sh)"},
+        "tables_from_reference_init_s": round(t_tab, 1),
+    }
+    if n_bad_status:
+        out["error"] = "%d utterances ended with status != 0" % n_bad_status
+    if with_cpu:
+        ids = sorted(set(int(i) for i in np.linspace(0, n_utt - 1, min(n_check, n_utt))))
+        procs = max(1, min(len(ids), (os.cpu_count() or 2) // 2))
+        utts, tot = reference_decode(pcm_all, n_samp, ids, "big.arpa", "cmudict-en-us.dict", procs)
+        bad = parity_of(ids, utts, hn, hyp, res)
+        out["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference", "xrt": round(tot["xrt"], 5),
+                               "sample": "%d of the step's %d utterances (%d frames, %.1f s of CPU in all; %d one-thread reference processes side by "
+                                         "side, value = frames / summed CPU seconds), same LM and dictionary, -fwdflat no -bestpath no"
+                                         % (len(ids), n_utt, tot["frames"], tot["cpu_s"], tot["procs"]),
+                               "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2)"}
+        out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad,
+                         "what": "word ids, start / end frames, path score and frame count: device vs the reference on the same PCM"}
+        out["speedup_vs_cpu_1thread"] = round(frames / dt / tot["frames_per_s"], 1)
+        w = lv.words_of(g)
+        out["sample_hyp"] = " ".join(w[int(hyp[0, k, 0])] for k in range(min(int(hn[0, 0]), 12)))
+    pipe.close()
+    del pcm
+    torch.cuda.empty_cache()
+    return out
 
 
 class _DevArray:
@@ -202,6 +325,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=UTT_SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (clean per-kernel profiles)")
+    ap.add_argument("--no-large-vocab", action="store_true", help="leave the 134,865-word leg (decode_large_vocab) out")
+    ap.add_argument("--large-vocab-utts", type=int, default=LV_UTT)
+    ap.add_argument("--workload", choices=("headline", "large"), default="headline",
+                    help="large: ONLY the large-vocabulary leg, printed as the line (for profiling that kernel alone)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,6 +355,16 @@ def main():
     capi.check(L.psgpu_set_device(local_rank), "psgpu_set_device")
     tables = _npz("en_us_ptm_tables.npz")
     gt = _npz("fwdtree_trace_goforward.npz")
+    if args.workload == "large":
+        if world != 1:
+            raise SystemExit("bench.py --workload large is a one-GPU measurement")
+        nlv = min(args.large_vocab_utts, B)
+        lvl = large_vocab_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables, nlv, max(args.steps, 1),
+                              LV_CHECK, not args.no_cpu_baseline)
+        lvl.update({"n_gpus": 1, "warmup": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32 (Gaussian distances) + int32 (log-domain scores, Viterbi)", "data": "synthetic (as the headline)"})
+        emit(lvl)
+        return
     # Two pipeline objects taking turns (PSGPU_BENCH_PIPES, default 2): while one batch's tree search -- a latency-bound
     # recurrence, one workgroup per utterance -- is resident, the other batch's front end and scorer run beside it; searches
     # are ordered by events, each pipeline on a stream with a hardware queue of its own (psgpu_decode_search_after,
@@ -383,24 +520,24 @@ def main():
     # ---- cpu_baseline + parity: the compiled reference on a sample of the same utterances
     if not args.no_cpu_baseline:
         ids = sorted(set(int(i) for i in np.linspace(0, B - 1, min(N_SAMPLE, B))))
-        ref = reference_decode(pcm_all, n_samp, ids)
+        n_proc = max(1, min(len(ids), (os.cpu_count() or 2) // 2))
+        ref = reference_decode(pcm_all, n_samp, ids, procs=n_proc)
         if ref is None:
             line["cpu_baseline"] = None
             line["parity"] = {"checked": 0, "note": "oracle/_ref/ref_decode_bench not built: parity unchecked in this run"}
         else:
             utts, tot = ref
-            bad = []
-            for i, r in zip(ids, utts):
-                got = [tuple(int(v) for v in hyp_l[i, k, :3]) for k in range(int(hn_l[i, 0]))]
-                want = [(s[1], s[2], s[3]) for s in r["seg"]]
-                if got != want or int(hn_l[i, 1]) != r["score"] or int(res_l[i, 2]) != r["frames"]:
-                    bad.append(i)
+            bad = parity_of(ids, utts, hn_l, hyp_l, res_l)
             line["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference",
-                                    "xrt": tot["xrt"],
-                                    "sample": "%d of the step's %d utterances (%d frames, %.1f s of CPU): ps_start_utt / "
-                                              "ps_process_raw(full_utt) / ps_end_utt per utterance, -fwdflat no -bestpath no"
-                                              % (len(ids), B, tot["frames"], tot["cpu_s"]),
-                                    "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2), one thread"}
+                                    "xrt": round(tot["xrt"], 6),
+                                    "sample": "%d of the step's %d utterances (%d frames, %.1f s of CPU in all): ps_start_utt / "
+                                              "ps_process_raw(full_utt) / ps_end_utt per utterance, -fwdflat no -bestpath no; value = frames / "
+                                              "summed CPU seconds of one-thread decoders" % (len(ids), B, tot["frames"], tot["cpu_s"]),
+                                    "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2), one thread",
+                                    "all_cores": {"value": round(tot["frames_per_s_all_procs"], 1), "unit": "frames/s", "cores": tot["procs"],
+                                                  "host_cpus": os.cpu_count(), "wall_s": round(tot["wall_s"], 2),
+                                                  "what": "%d reference processes side by side, one decoder thread each (pocketsphinx_batch's way to "
+                                                          "use a machine), frames / wall time of the slowest" % tot["procs"]}}
             line["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad,
                               "what": "word ids, start / end frames, path score and frame count of each sampled utterance: device vs "
                                       "the reference decoding the same PCM"}
@@ -415,6 +552,12 @@ def main():
             q.close()
         del pcm
         torch.cuda.empty_cache()
+        if not args.no_large_vocab:
+            try:
+                line["decode_large_vocab"] = large_vocab_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,
+                                                             min(args.large_vocab_utts, B), LV_STEPS, LV_CHECK, not args.no_cpu_baseline)
+            except Exception as e:
+                line["decode_large_vocab"] = {"error": str(e)[-400:]}
         try:
             # configs[2]: one 60 s utterance
             p1 = P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), tables, _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)

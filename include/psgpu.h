@@ -741,6 +741,17 @@ int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v);
 /* hyp_n [n_utt][4], hyp [n_utt][max_words][4], result [n_utt][8] (any may be NULL) to the host; waits for the
  * stream.  This is the only transfer a caller that wants word sequences needs. */
 int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int32_t *result, void *stream);
+/* Capacities of the per-utterance back-pointer table and right-context score stack: entries per frame of the call's
+ * longest utterance (+ a constant); 0 keeps the current value.  Defaults 16 and 320 (a 100-word task writes 4-6 and 30-80
+ * per frame; the 134,865-word task 30 and 800).  The reference grows both tables on demand (ngram_search_save_bp,
+ * ngram_search.c:449-463, :468-480) and so never ends an utterance for lack of room.  auto_grow != 0 (the default) gives
+ * the same behaviour here: when psgpu_decode_fetch_hyps finds an utterance that ended with status 1 (table full) it
+ * doubles both allowances, allocates larger tables and repeats the SEARCH stage of that call on the scores still in the
+ * object's buffers (the stages before it are not repeated), as often as needed; the larger allowance is kept for later
+ * calls.  psgpu_decode_tables_grown = how many times that has happened since the object was created.  auto_grow = 0: an
+ * utterance whose table fills up keeps status 1 and its hypothesis is that of the frames searched so far. */
+int psgpu_decode_table_capacity(psgpu_decode_t *d, int32_t bp_per_frame, int32_t bss_per_frame, int32_t auto_grow);
+int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
  * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array. */
 int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp,

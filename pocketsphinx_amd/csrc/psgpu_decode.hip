@@ -38,6 +38,11 @@ struct psgpu_decode_s {
     int32_t *d_mpx = nullptr;
     double *d_noise = nullptr;           // the front end's noise tracker (noise_stats_t: kept until ps_start_stream, not reset per utterance)
     int32_t *d_undef = nullptr;
+    // table capacities per utterance = per-frame allowance x frames of the longest utterance + a constant
+    // (psgpu_decode_table_capacity); grown on demand when the search reports a full table (psgpu_decode_fetch_hyps)
+    int32_t bp_pf = 16, bss_pf = 320, auto_grow = 1, n_grown = 0;
+    int32_t *d_mpx_in = nullptr;          // session: the state the latest search STARTED from (a repeated search needs it again)
+    bool last_chained = false, last_sess = false, searched = false;
     // the last call
     int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
     std::vector<int32_t> frame_off;
@@ -123,7 +128,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
-    DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_noise); DFREE(d->d_undef);
+    DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
@@ -154,6 +159,7 @@ static int dec_session_buffers(psgpu_decode_s *d)
     if (!d->d_seed) {
         if ((rc = dec_alloc((void **)&d->d_seed, (size_t)d->n_chain * d->topn))
             || (rc = dec_alloc((void **)&d->d_mpx, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))
+            || (rc = dec_alloc((void **)&d->d_mpx_in, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))
             || (rc = dec_alloc((void **)&d->d_noise, 8 * 4 * 64)) || (rc = dec_alloc((void **)&d->d_undef, 4)))
             return rc;
         d->fe_fresh = true;
@@ -227,8 +233,10 @@ int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model)
 static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hipStream_t st)
 {
     // table capacities follow the longest utterance: the bundled recordings write 4-6 back-pointers and 30-80 score-stack
-    // entries per frame (tests/golden/fwdtree_trace_*); a full table ends the utterance with status 1
-    const size_t bp_cap = 16 * mf + 2048, bss_cap = 320 * mf + 8192;
+    // entries per frame with a 100-word vocabulary (tests/golden/fwdtree_trace_*), 30 and 800 with 134,865 words (the
+    // benchmark's synthetic utterances); a full table ends the utterance with status 1, and psgpu_decode_fetch_hyps then
+    // repeats the search with larger tables (the reference doubles its tables on demand, ngram_search.c:449-463)
+    const size_t bp_cap = (size_t)d->bp_pf * mf + 2048, bss_cap = (size_t)d->bss_pf * mf + 8192;
     bool waited = false;
     auto wait = [&]() { if (!waited) { hipStreamSynchronize(st); waited = true; } };
     if (total > d->cap_frames || (!d->lists && !d->d_rows)) {         // (.. or the model changed to one that needs score rows)
@@ -262,6 +270,26 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
         d->cap_utt = nu; d->cap_bp = cb; d->cap_bss = cs; d->cap_mf = cm;
     }
     return PSGPU_OK;
+}
+
+// the tree search (+ backtrace) of the latest call's utterances on the scores / penalties in the object's buffers
+static int dec_search(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t mf, hipStream_t st)
+{
+    int rc;
+    const bool chained = d->last_chained, sess = d->last_sess;
+    // the hypotheses are the search kernel's last step
+    if ((rc = psgpu_fwdtree_hyp_out(d->cfg.ft, d->d_hyp, d->d_hn, d->max_words))) return rc;
+    // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
+    if (d->lists)
+        rc = psgpu_fwdtree_search_lists_dev(d->cfg.ft, &d->view, d->d_tsc, d->d_tcw, (int32_t)total, d->d_pen, d->d_off, n_utt, (int32_t)mf,
+                                            d->bp_cap, d->bss_cap, d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, d->cfg.pl_window, d->d_w1,
+                                            chained ? d->d_mpx_in : nullptr, sess ? d->d_mpx : nullptr, st);
+    else
+        rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
+                                              d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
+                                              chained ? d->d_mpx_in : nullptr, sess ? d->d_mpx : nullptr, st);
+    if (rc == PSGPU_OK) d->searched = true;
+    return rc;
 }
 
 // scores -> phone loop -> tree search -> backtrace on the features in d_feat / the frame offsets in d_off
@@ -306,17 +334,11 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
         d->go_recorded = true;
     }
     dec_mark(d, 5, st);                                  // (4 -> 5: waiting for the other object's search, if any)
-    // the hypotheses are the search kernel's last step
-    if ((rc = psgpu_fwdtree_hyp_out(d->cfg.ft, d->d_hyp, d->d_hn, d->max_words))) return rc;
-    // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
-    if (d->lists)
-        rc = psgpu_fwdtree_search_lists_dev(d->cfg.ft, &d->view, d->d_tsc, d->d_tcw, (int32_t)total, d->d_pen, d->d_off, n_utt, (int32_t)mf,
-                                            d->bp_cap, d->bss_cap, d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, d->cfg.pl_window, d->d_w1,
-                                            chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st);
-    else
-        rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
-                                              d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
-                                              chained ? d->d_mpx : nullptr, sess ? d->d_mpx : nullptr, st);
+    if (sess && chained)                                 // (what this search starts from: a repeated search starts from it again)
+        PSGPU_HIP(hipMemcpyAsync(d->d_mpx_in, d->d_mpx, 4 * (size_t)psgpu_fwdtree_n_mpx_channels(d->cfg.ft) * d->n_emit,
+                                 hipMemcpyDeviceToDevice, st));
+    d->last_chained = chained; d->last_sess = sess;
+    rc = dec_search(d, n_utt, total, mf, st);
     if (rc) return rc;
     if (d->ev_srch) { PSGPU_HIP(hipEventRecord(d->ev_srch, st)); d->srch_recorded = true; }
     if (sess) d->sess_started = true;
@@ -328,7 +350,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm_dev && samp_off)), "psgpu_decode_first_pass_dev: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    d->n_utt = n_utt; d->total = 0; d->max_frames = 0;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false;
     d->frame_off.assign((size_t)n_utt + 1, 0);
     if (n_utt == 0) return PSGPU_OK;
     size_t total = 0, mf = 0;
@@ -382,7 +404,7 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (feat && frame_off)), "psgpu_decode_first_pass_feat: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    d->n_utt = n_utt; d->total = 0; d->max_frames = 0;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false;
     d->frame_off.assign(frame_off, frame_off + (n_utt ? n_utt + 1 : 0));
     if (n_utt == 0) { d->frame_off.assign(1, 0); return PSGPU_OK; }
     PSGPU_REQUIRE(frame_off[0] == 0, "psgpu_decode_first_pass_feat: frame offsets start at 0");
@@ -462,11 +484,66 @@ int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v)
     return PSGPU_OK;
 }
 
+int psgpu_decode_table_capacity(psgpu_decode_t *d, int32_t bp_per_frame, int32_t bss_per_frame, int32_t auto_grow)
+{
+    PSGPU_REQUIRE(d && bp_per_frame >= 0 && bss_per_frame >= 0, "psgpu_decode_table_capacity: bad argument");
+    if (bp_per_frame > 0) d->bp_pf = bp_per_frame;
+    if (bss_per_frame > 0) d->bss_pf = bss_per_frame;
+    d->auto_grow = auto_grow != 0;
+    return PSGPU_OK;
+}
+
+int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d) { return d ? d->n_grown : 0; }
+
+// An utterance whose back-pointer table or score stack filled up ended with status 1.  The reference never ends that way:
+// it doubles the table (ngram_search.c:449-463, :468-480).  Here: double both allowances, allocate new tables, search the
+// call's utterances again on the scores and penalties still in the object's buffers -- until no utterance reports a full
+// table, the device has no room for larger ones, or the allowance has grown 64-fold.  The larger allowance stays (later calls
+// start with it), so a workload pays this once.  Returns PSGPU_OK with `res` holding the final result records.
+static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t> &res, hipStream_t st)
+{
+    const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
+    for (int round = 0; round < 6; ++round) {
+        bool full = false;
+        for (size_t u = 0; u < nu && !full; ++u) full = res[u * 8 + 3] == 1;
+        if (!full) return PSGPU_OK;
+        const size_t cb = (size_t)2 * d->bp_pf * mf + 2048, cs = (size_t)2 * d->bss_pf * mf + 8192;
+        size_t free_b = 0, total_b = 0;
+        if (cb > 0x7ffffff0u / 10 || cs > 0x7ffffff0u || hipMemGetInfo(&free_b, &total_b) != hipSuccess
+            || 4 * d->cap_utt * (10 * cb + cs) + ((size_t)256 << 20) > free_b + 4 * d->cap_utt * (10 * d->cap_bp + d->cap_bss))
+            return PSGPU_OK;                              // no room: the status stays as reported
+        DFREE(d->d_bp); DFREE(d->d_bss);
+        d->cap_bp = d->cap_bss = 0;
+        int rc;
+        if ((rc = dec_alloc((void **)&d->d_bp, 4 * d->cap_utt * 10 * cb)) || (rc = dec_alloc((void **)&d->d_bss, 4 * d->cap_utt * cs))) {
+            d->cap_utt = 0;                               // (the next call allocates everything anew)
+            return rc;
+        }
+        d->bp_pf *= 2; d->bss_pf *= 2; d->cap_bp = cb; d->cap_bss = cs;
+        d->bp_cap = (int32_t)cb; d->bss_cap = (int32_t)cs;
+        ++d->n_grown;
+        if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;
+        if (d->ev_srch) PSGPU_HIP(hipEventRecord(d->ev_srch, st));
+        PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+    }
+    return PSGPU_OK;
+}
+
 int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int32_t *result, void *stream)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_fetch_hyps: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     const size_t nu = (size_t)d->n_utt;
+    if (nu && d->auto_grow && d->searched) {
+        std::vector<int32_t> res(nu * 8);
+        PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+        int rc = dec_repeat_with_larger_tables(d, res, st);
+        if (rc != PSGPU_OK) return rc;
+        if (result) memcpy(result, res.data(), 4 * nu * 8);
+        result = nullptr;
+    }
     if (nu) {
         if (hyp_n) PSGPU_HIP(hipMemcpyAsync(hyp_n, d->d_hn, 4 * nu * 4, hipMemcpyDeviceToHost, st));
         if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));

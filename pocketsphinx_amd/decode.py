@@ -98,6 +98,15 @@ class DecodePipeline:
         """psgpu_decode_score_mode: True -- no score rows, the phone loop and the search score the senones they list"""
         capi.check(capi.lib().psgpu_decode_score_mode(self.h, int(bool(lists))), "psgpu_decode_score_mode")
 
+    def table_capacity(self, bp_per_frame=0, bss_per_frame=0, auto_grow=True):
+        """psgpu_decode_table_capacity: back-pointer / score-stack entries per frame of the longest utterance (0: keep);
+        auto_grow: a full table makes fetch() repeat the search with doubled tables, as the reference grows its own"""
+        capi.check(capi.lib().psgpu_decode_table_capacity(self.h, int(bp_per_frame), int(bss_per_frame), int(bool(auto_grow))),
+                   "psgpu_decode_table_capacity")
+
+    def tables_grown(self):
+        return int(capi.lib().psgpu_decode_tables_grown(self.h))
+
     def session(self, on=True):
         """psgpu_decode_session: on -- every following one-utterance call continues the decoder session (the scorer's seeding
         history slot, the multiplexed permanent channels' per-state ssids); calling it again forgets the state"""
