@@ -498,16 +498,16 @@ int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d) { return d ? d->n_gro
 // An utterance whose back-pointer table or score stack filled up ended with status 1.  The reference never ends that way:
 // it doubles the table (ngram_search.c:449-463, :468-480).  Here: double both allowances, allocate new tables, search the
 // call's utterances again on the scores and penalties still in the object's buffers -- until no utterance reports a full
-// table, the device has no room for larger ones, or the allowance has grown 64-fold.  The larger allowance stays (later calls
+// table, the device has no room for larger ones, or the tables have doubled twelve times.  The larger allowance stays (later calls
 // start with it), so a workload pays this once.  Returns PSGPU_OK with `res` holding the final result records.
 static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t> &res, hipStream_t st)
 {
     const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
-    for (int round = 0; round < 6; ++round) {
+    for (int round = 0; round < 12; ++round) {
         bool full = false;
         for (size_t u = 0; u < nu && !full; ++u) full = res[u * 8 + 3] == 1;
         if (!full) return PSGPU_OK;
-        const size_t cb = (size_t)2 * d->bp_pf * mf + 2048, cs = (size_t)2 * d->bss_pf * mf + 8192;
+        const size_t cb = 2 * d->cap_bp, cs = 2 * d->cap_bss;
         size_t free_b = 0, total_b = 0;
         if (cb > 0x7ffffff0u / 10 || cs > 0x7ffffff0u || hipMemGetInfo(&free_b, &total_b) != hipSuccess
             || 4 * d->cap_utt * (10 * cb + cs) + ((size_t)256 << 20) > free_b + 4 * d->cap_utt * (10 * d->cap_bp + d->cap_bss))
@@ -519,7 +519,11 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
             d->cap_utt = 0;                               // (the next call allocates everything anew)
             return rc;
         }
-        d->bp_pf *= 2; d->bss_pf *= 2; d->cap_bp = cb; d->cap_bss = cs;
+        d->cap_bp = cb; d->cap_bss = cs;
+        if (mf) {                                         // (later calls start with this allowance)
+            d->bp_pf = std::max<int32_t>(d->bp_pf, (int32_t)std::min<size_t>((cb + mf - 1) / mf, 1 << 20));
+            d->bss_pf = std::max<int32_t>(d->bss_pf, (int32_t)std::min<size_t>((cs + mf - 1) / mf, 1 << 24));
+        }
         d->bp_cap = (int32_t)cb; d->bss_cap = (int32_t)cs;
         ++d->n_grown;
         if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;

@@ -35,6 +35,13 @@
 #include <type_traits>
 #include <vector>
 
+#if !defined(__HIPCC__)
+// the workgroup simulator's build (tests/hostsim) checks the two facts about the active list that the slab layouts' pruning
+// relies on instead of reading them (see there), on every node of every frame of every golden it runs
+#define PSGPU_FT_CHECK_LISTS 1
+#include <cstdio>
+#endif
+
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
@@ -79,6 +86,7 @@ struct FtDev {
     int32_t beam, pbeam, lpbeam, lponlybeam, wbeam, pip, nwpen, silpen, fillpen, maxhmmpf, maxwpf;
     int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci, has_pl;
     const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_pw, *parent, *kid_off, *kids;
+    const int32_t *kids_ci;              // kids with the child's ci phone in the top byte (slab layouts: child | ci << 24)
     const int32_t *homophone, *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx, *w1_of_word;
     const int32_t *d_pronlen, *d_first, *d_last, *d_last2, *d_base, *d_filler;
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
@@ -133,6 +141,18 @@ template <int NE> struct ChF {
     static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
 struct alignas(16) FtQuad { int32_t x, y, z, w; };
+// Slab layouts (tree state in device memory): a tree channel's record is followed, IN THE SAME 128-byte line for 3-state
+// models, by what the pruning step needs to know about the node -- so that everything a work-item asks about a node
+// comes back in one trip to device memory instead of one per array (five snapshot arrays + five static tables, each
+// access its own cache line):
+//   QA  {out score, out history, flag | (list position + 1) << 1, frame stamp}   what a CHILD's decision reads of its parent
+//   QB  {flag | (list position + 1) << 1, frame, score[0], frame stamp}          what a decision reads of the node itself
+//   QC  {ci phone, parent, first child (index into kids), number of children}    static, written once per utterance
+//   QD  {penultimate-phone word, its last phone, its homophone link, 0}          static
+// QA / QB are the pruning snapshot of a root or listed node, valid when their stamp is the current frame.
+template <int NE> struct TrF {
+    static constexpr int QA = ChF<NE>::REC, QB = QA + 4, QC = QA + 8, QD = QA + 12, REC = QA + 16;
+};
 struct ChView {
     int32_t *b;
     int cst, fst;
@@ -595,7 +615,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #if defined(__HIPCC__)
     int32_t *const s_pool = ft_dyn_pool;                 // SMALL: kFtLdsWords words of dynamic LDS (the launch says so)
 #else
-    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 4];  // (the workgroup simulator)
+    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 16 * NT + 16];     // (the workgroup simulator)
 #endif
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
@@ -606,6 +626,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     __shared__ unsigned long long s_evals;
     __shared__ int32_t s_nsen;           // listed senones, summed over the frames (raw-score mode)
     __shared__ int32_t s_nev;            // length of the frame's evaluation list
+    // slab layouts: the pruning step works on chunks of kPrIC roots / listed nodes ("items") whose snapshot lies in LDS (the
+    // dynamic pool, kPrArrays arrays of kPrIC words), so that the (item, child) pairs of a chunk find their item by a bisection
+    // in LDS and read the parent's side of a decision -- and, for an item's own entry, the node's side -- from LDS
+    constexpr int kPrIC = SMALL ? 1 : 2 * NT;
+    int32_t *const s_it_node = s_pool, *const s_it_out = s_pool + kPrIC, *const s_it_outh = s_pool + 2 * kPrIC,
+            *const s_it_fp = s_pool + 3 * kPrIC, *const s_it_k0 = s_pool + 4 * kPrIC, *const s_it_par = s_pool + 5 * kPrIC,
+            *const s_it_sc0 = s_pool + 6 * kPrIC, *const s_it_poff = s_pool + 7 * kPrIC;       // (poff: kPrIC + 1 entries)
+    __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
     __shared__ long long s_prof[48], s_last, s_lastw[4], s_d0;
@@ -620,7 +648,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int32_t *const utt_off = psgpu_as_global(utt_off_);
     int32_t *const gs = psgpu_as_global(bf.slab) + (size_t)blockIdx.x * p.per;
     int32_t *const fb = SMALL ? s_pool : gs + p.g_fast;
-    const ChView tv = { fb + L.rec, SMALL ? 1 : F::REC, SMALL ? p.CH : 1 };       // tree nodes [0, N), single-phone words [N, N + n1)
+    constexpr int TREC = SMALL ? F::REC : TrF<NE>::REC;                            // slab layouts: record + pruning snapshot + the node's static data
+    const ChView tv = { fb + L.rec, SMALL ? 1 : TREC, SMALL ? p.CH : 1 };         // tree nodes [0, N), single-phone words [N, N + n1)
     const ChView wv = { gs + p.g_wrec, F::REC, 1 };                               // last-phone slots [0, TOT)
     int32_t *const word_active = fb + L.word_active, *const word_lat_idx = fb + L.word_lat_idx, *const lt_sf = fb + L.lt_sf,
             *const lt_dscr = fb + L.lt_dscr, *const lt_bp = fb + L.lt_bp, *const cand_mark = fb + L.cand_mark,
@@ -672,6 +701,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                   *const lmtab = psgpu_as_global(p.lm);
     const uint8_t *const tpall = SMALL ? reinterpret_cast<const uint8_t *>(fb + L.tp) : psgpu_as_global(p.tp);
     const uint16_t *const sseq = psgpu_as_global(p.sseq);
+    const int32_t *const kids_ci = psgpu_as_global(p.kids_ci);
     const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
     // the tree's structure: LDS copies in the small layout
     const int32_t *const kid_off = SMALL ? fb + L.kid_off : psgpu_as_global(p.kid_off), *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids),
@@ -719,7 +749,21 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
     for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
     for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
-    for (int c = tid; c < N; c += NT) pos[c] = -1;       // pos is kept at -1 between frames
+    if (SMALL) { for (int c = tid; c < N; c += NT) pos[c] = -1; }      // pos is kept at -1 between frames
+    else {
+        // slab layouts: the snapshot quads start unstamped, the node's static data is copied beside its state (TrF)
+        using T = TrF<NE>;
+        const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_p = psgpu_as_global(p.parent), *const g_c = psgpu_as_global(p.node_ci),
+                      *const g_w = psgpu_as_global(p.node_pw);
+        for (int c = tid; c < N; c += NT) {
+            int32_t *const r = tv.b + (size_t)c * TREC;
+            const int pw = g_w[c], k0 = g_ko[c];
+            *reinterpret_cast<FtQuad *>(r + T::QA) = FtQuad{ kW, -1, 0, -1 };
+            *reinterpret_cast<FtQuad *>(r + T::QB) = FtQuad{ 0, -1, kW, -1 };
+            *reinterpret_cast<FtQuad *>(r + T::QC) = FtQuad{ g_c[c], g_p[c], k0, g_ko[c + 1] - k0 };
+            *reinterpret_cast<FtQuad *>(r + T::QD) = FtQuad{ pw, pw >= 0 ? d_last[pw] : 0, pw >= 0 ? homophone[pw] : -1, 0 };
+        }
+    }
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
         s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0;
@@ -819,7 +863,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         int32_t *const aclc = fb + (cur ? L.acl1 : L.acl0), *const acln = fb + (cur ? L.acl0 : L.acl1);
         int32_t *const awlc = fb + (cur ? L.awl1 : L.awl0), *const awln = fb + (cur ? L.awl0 : L.awl1);
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
-        const int32_t *const pp = SMALL ? s_pen + cur * n_ci : penalties + (size_t)pen_frame(f) * n_ci;
+        // (slab layouts: the frame's penalty row is copied to LDS here -- its last readers, the previous frame's word
+        //  transitions, are behind a barrier; its first reader, the pruning, is behind the barriers below)
+        if (!SMALL && p.has_pl && tid < n_ci) s_penb[tid] = penalties[(size_t)pen_frame(f) * n_ci + tid];
+        const int32_t *const pp = SMALL ? s_pen + cur * n_ci : s_penb;
         const int16_t *const row = SMALL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
@@ -987,7 +1034,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     b_all = max(b_all, sc); b_word = max(b_word, sc);
                 }
                 else {
-                    const int32_t sc = SMALL ? ch_eval<NE>(tv, c, sr, tpall, sseq) : ch_eval_rec<NE>(tv.b + (size_t)c * F::REC, sr, tpall, sseq);
+                    const int32_t sc = SMALL ? ch_eval<NE>(tv, c, sr, tpall, sseq) : ch_eval_rec<NE>(tv.b + (size_t)c * TREC, sr, tpall, sseq);
                     if (c < W1) b_all = max(b_all, sc);
                     else if (w1_wid[c - W1] != p.finishwid) { b_all = max(b_all, sc); b_word = max(b_word, sc); }   // (:688-694: </s> never sets the best score)
                 }
@@ -1069,97 +1116,362 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int32_t thresh = best_score + dyn_beam;
         const int32_t npt = best_score + p.pbeam, lpt = best_score + p.lpbeam;
 
-        // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation.  Work proportional to the active
-        //      channels (oracle prune_tree_list): the items are the roots, the listed nodes and their children.  Reads of
-        //      another node's state go to the snapshot (o_out, o_outh, flag, pos) of a root or listed node, writes to the
-        //      item's own channel and decision word, so the items are independent.
-        for (int q = tid; q < na; q += NT) pos[aclc[q]] = q;
-        for (int i = tid; i < R + na; i += NT) {
-            const int node = i < R ? i : aclc[i - R];
-            const bool active = i < R ? tv.at(node, F::FRAME) >= f : true;
-            o_out[node] = tv.at(node, F::OUT); o_outh[node] = tv.at(node, F::OUTH);
-            flag[node] = (active && tv.at(node, F::BEST) > thresh) ? 1 : 0;
-        }
-        ft_sync<SMALL>();
-        FT_PROF(4);
-        auto decide = [&](int c) {
-            const int P = parent[c], pc = pos[c];
-            const bool in_acl = pc >= 0, par_active = P < R || pos[P] >= 0;
-            const int32_t news = (par_active ? o_out[P] : kW) + p.pip;
-            const bool parent_can = par_active && (flag[P] & 1) && (p.has_pl || news > npt)
-                                    && (news + ft_pen(node_ci[c]) > npt);
-            const bool parent_first = P < R || !in_acl || pos[P] < pc;
-            const bool retc = in_acl && (flag[c] & 1);
-            bool fire;
-            if (!in_acl || parent_first) fire = parent_can && (tv.at(c, F::FRAME) < f || news > tv.at(c, F::SCORE));
-            else if (retc)               fire = parent_can && news > tv.at(c, F::SCORE);
-            else                         fire = parent_can;
-            const bool entered_first = fire && parent_first;
-            const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
-            if (in_acl && !retc && !entered_first) ch_clear<NE>(tv, c);
-            if (retc) tv.at(c, F::FRAME) = nf;
-            if (fire) ch_enter<NE>(tv, c, news, o_outh[P], nf);
-            o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
-        };
-        for (int i = tid; i < R + na; i += NT) {
-            const int node = i < R ? i : aclc[i - R];
-            // a node that is not retained enters none of its children: their (stale) decision words are not
-            // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
-            const int k0 = kid_off[node], nk = (flag[node] & 1) ? kid_off[node + 1] - k0 : 0;
-            for (int q = i >= R ? -1 : 0; q < nk; ++q) {         // q = -1: the listed node itself, then its unlisted children
-                const int c = q < 0 ? node : kids[k0 + q];
-                if (q >= 0 && pos[c] >= 0) continue;
-                decide(c);
-            }
-        }
-        FT_PROF(28);
-        ft_sync<SMALL>();
-        FT_PROF(5);
-        for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
-        for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
-        // list positions (root phase: a segment per root, then one segment per list position) and the last-phone candidates
-        // (list order, homophone chain inside) in ONE counting pass, one double prefix sum and one writing pass: the two
-        // depend on the pruning's snapshot and decisions only, not on each other
-        int32_t *const cntb = cnt + (R + N + 1);
-        for (int i = tid; i < R + na; i += NT) {
-            const int node = i < R ? i : aclc[i - R];
-            int k = (i >= R && (o_frame[node] & 8)) ? 1 : 0;
-            if (flag[node] & 1) {
-                const int k1 = kid_off[node + 1];
-                for (int q = kid_off[node]; q < k1; ++q) k += (o_frame[kids[q]] & 2) ? 1 : 0;
-            }
-            cnt[i] = k;
-            const int32_t news = o_out[node] + p.pip;
-            int kc = 0;
-            if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = node_pw[node]; w >= 0; w = homo_f[w]) kc += (news + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
-            cntb[i] = kc;
-        }
-        ft_sync<SMALL>();
         int32_t n_listed;
+        if constexpr (!SMALL) {
+        // ---- prune_root_chan + prune_nonroot_chan (:722-877) + the last-phone candidates (:824-870), slab layouts.
+        //      The same order-free formulation as below (oracle prune_tree_list: items = the roots and the listed nodes; a
+        //      decision reads the snapshot of the node and of its parent and writes the node's own channel), arranged for
+        //      state that lives in DEVICE memory, where a frame costs (dependent trips to memory) x (work-items' loop
+        //      iterations), not instructions:
+        //        * everything a decision reads of a node is in the node's own 128-byte line (TrF: snapshot quads + static
+        //          data beside the channel record): one trip per node, not one per array;
+        //        * one work-item per (item, child) PAIR -- a pair's decision is a pure function of the two snapshots, so a
+        //          child that is itself listed is decided twice, by its own item (which writes) and by its parent's pair (which
+        //          only needs the outcome for the next list) -- no second walk over the children, no barrier in between;
+        //        * a work-item takes four pairs at a time and asks for all their lines before it looks at any;
+        //        * positions in the next active list = prefix sums over the pairs' outcomes in pair order (= list order:
+        //          an item's own entry, then its entered children in sibling order), in registers + LDS;
+        //        * the frame's penalty row, the chunk's items (their snapshot, children range, parent) in LDS.
+        //      (phase profile of the 134,865-word task before: 1.87 M cycles a frame, 75 % of them in these steps: every
+        //       access of a per-node array was a trip to HBM, made one after the other inside loops over the children)
         {
-            int32_t tot2[2];
-            int32_t *const arr[2] = { cnt, cntb };
-            ft_block_scan_k<NT, 2, SMALL>(arr, R + na, s_scan, tot2);       // exclusive prefix sums
-            n_listed = tot2[0];
-            if (tid == 0) { s_sc[5] = tot2[1]; s_red[7] = 0; }
-        }
-        FT_PROF(6);
-        for (int i = tid; i < R + na; i += NT) {
-            const int node = i < R ? i : aclc[i - R];
-            int o = cnt[i];
-            if (i >= R && (o_frame[node] & 8)) acln[o++] = node;
-            if (flag[node] & 1) {
-                const int k1 = kid_off[node + 1];
-                for (int q = kid_off[node]; q < k1; ++q) { const int c = kids[q]; if (o_frame[c] & 2) acln[o++] = c; }
-            }
-            const int32_t news = o_out[node] + p.pip;
-            int oc = cntb[i];
-            if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                for (int w = node_pw[node]; w >= 0; w = homo_f[w])
-                    if (news + ft_pen(dlast_f[w]) > lpt) {
-                        cand_wid[oc] = w; cand_score[oc] = news - p.nwpen; cand_bp[oc] = o_outh[node]; ++oc;
+            using T = TrF<NE>;
+            const int n_item = R + na;
+            // What a work-group pays for here is the NUMBER of scattered accesses it makes -- a compute unit's address path
+            // takes about one work-item's request per cycle, whatever its width -- more than the trips' latency: so few, wide
+            // requests, none that a fact about the lists answers:
+            //   a node that is NOT in the active list has been cleared when it left it (or was never entered): its frame is
+            //   below f and its scores are WORST_SCORE, so "frame < f || news > score" is true without looking;
+            //   a node that IS in the list was entered or retained for this frame: its frame is f.
+            // -- pass 1: snapshot of every item, into its own line.  Four items a work-item at a time.
+            for (int i0 = 0; i0 < n_item; i0 += 4 * NT) {
+                int node[4]; FtQuad qs[4]; int32_t sc0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * NT + tid; node[u] = i < R ? i : (i < n_item ? aclc[i - R] : -1); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (node[u] >= 0) {
+                        const int32_t *const r = tv.b + (size_t)node[u] * TREC;
+                        qs[u] = *reinterpret_cast<const FtQuad *>(r + F::OUT);      // out, out history, best, frame
+                        sc0[u] = r[F::SCORE];
                     }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * NT + tid;
+                    if (node[u] < 0) continue;
+                    int32_t *const r = tv.b + (size_t)node[u] * TREC;
+                    const bool active = i < R ? qs[u].w >= f : true;
+                    const int32_t fp = ((active && qs[u].z > thresh) ? 1 : 0) | (i < R ? 0 : ((i - R + 1) << 1));
+                    *reinterpret_cast<FtQuad *>(r + T::QA) = FtQuad{ qs[u].x, qs[u].y, fp, f };
+                    *reinterpret_cast<FtQuad *>(r + T::QB) = FtQuad{ fp, f, sc0[u], 0 };
+                    if (i < R && (fp & 1)) r[F::FRAME] = nf;              // a retained root stays (no decision reads a root's frame)
+#ifdef PSGPU_FT_CHECK_LISTS
+                    if (i >= R && qs[u].w != f) { printf("listed node %d has frame %d in frame %d\n", node[u], qs[u].w, f); abort(); }
+#endif
+                }
+            }
+            __syncthreads();                                     // (device memory is exchanged: the snapshots)
+            FT_PROF(4);
+            int carry_l = 0, carry_c = 0;                        // entries of the next active list / candidates so far (uniform)
+            for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
+                // -- the chunk's items, two consecutive ones a work-item: snapshot, children range, parent -> LDS; pairs and
+                //    candidates counted
+                int32_t np[2], kc[2], c_w[2], c_news[2], c_outh[2], c_homo[2], c_dl[2];
+                {
+                    int node[2]; FtQuad qa[2], qc[2]; int32_t s0[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { const int i = c0 + 2 * tid + u; node[u] = i < R ? i : (i < n_item ? aclc[i - R] : -1); }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        qa[u] = FtQuad{ kW, -1, 0, -1 }; qc[u] = FtQuad{ 0, 0, 0, 0 }; s0[u] = kW;
+                        if (node[u] >= 0) {
+                            const int32_t *const r = tv.b + (size_t)node[u] * TREC;
+                            qa[u] = *reinterpret_cast<const FtQuad *>(r + T::QA); qc[u] = *reinterpret_cast<const FtQuad *>(r + T::QC);
+                            s0[u] = r[T::QB + 2];
+                        }
+                    }
+                    FtQuad qd[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int li = 2 * tid + u, i = c0 + li;
+                        const bool fl = node[u] >= 0 && (qa[u].z & 1);
+                        np[u] = node[u] >= 0 ? (i >= R ? 1 : 0) + (fl ? qc[u].w : 0) : 0;
+                        s_it_node[li] = node[u]; s_it_out[li] = qa[u].x; s_it_outh[li] = qa[u].y; s_it_fp[li] = qa[u].z;
+                        s_it_k0[li] = qc[u].z; s_it_par[li] = qc[u].y | (qc[u].x << 24); s_it_sc0[li] = s0[u];
+                        // last-phone candidates of the item (:824-870): the words whose penultimate phone this node is, the
+                        // homophone chain in order; the first word's last phone and link lie in the node's line -- asked for
+                        // only by the items that can have candidates
+                        const int32_t news = qa[u].x + p.pip;
+                        c_news[u] = news; c_outh[u] = qa[u].y;
+                        qd[u] = FtQuad{ -1, 0, -1, 0 };
+                        if (fl && (p.has_pl || news > lpt)) qd[u] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)node[u] * TREC + T::QD);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        kc[u] = 0; c_w[u] = qd[u].x; c_homo[u] = qd[u].z; c_dl[u] = qd[u].y;
+                        if (qd[u].x >= 0) {
+                            kc[u] = (c_news[u] + ft_pen(qd[u].y) > lpt) ? 1 : 0;
+                            for (int w = qd[u].z; w >= 0; w = homo_f[w]) kc[u] += (c_news[u] + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
+                        }
+                    }
+                }
+                FT_PROF(28);
+                // exclusive prefix sums over the chunk's items, in item order (two consecutive items a work-item)
+                int32_t n_pair, n_cd;
+                {
+                    const int lane = tid & 63, wv_ = tid >> 6;
+                    const int32_t sp = np[0] + np[1], sk = kc[0] + kc[1];
+                    const int32_t ip = ft_wave_incl<FtAdd>(sp), ik = ft_wave_incl<FtAdd>(sk);
+                    if (lane == 63) { s_scan[wv_] = ip; s_scan[NT / 64 + wv_] = ik; }
+                    ft_sync<true>();
+                    int32_t bp_ = 0, bk_ = 0; n_pair = 0; n_cd = 0;
+#pragma unroll
+                    for (int w = 0; w < NT / 64; ++w) {
+                        const int32_t a_ = s_scan[w], b_ = s_scan[NT / 64 + w];
+                        n_pair += a_; n_cd += b_;
+                        if (w < wv_) { bp_ += a_; bk_ += b_; }
+                    }
+                    const int32_t op = bp_ + ip - sp, ok_ = bk_ + ik - sk;
+                    s_it_poff[2 * tid] = op; s_it_poff[2 * tid + 1] = op + np[0];
+                    if (tid == NT - 1) s_it_poff[kPrIC] = n_pair;
+                    // the candidates, in item order then chain order
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        int oc = carry_c + ok_ + (u ? kc[0] : 0);
+                        if (kc[u] > 0) {
+                            for (int w = c_w[u], first = 1; w >= 0; first = 0) {
+                                const int lastp = first ? c_dl[u] : dlast_f[w];
+                                if (c_news[u] + ft_pen(lastp) > lpt) { cand_wid[oc] = w; cand_score[oc] = c_news[u] - p.nwpen; cand_bp[oc] = c_outh[u]; ++oc; }
+                                w = first ? c_homo[u] : homo_f[w];
+                            }
+                        }
+                    }
+                    ft_sync<true>();                                 // (the chunk's LDS arrays are complete; s_scan is free again)
+                }
+                carry_c += n_cd;
+                FT_PROF(5);
+                // -- the chunk's (item, child) pairs, four consecutive ones a work-item: the item's own entry first (listed
+                //    nodes), then its children in sibling order (retained items only)
+                for (int p0 = 0; p0 < n_pair; p0 += 4 * NT) {
+                    int li[4], q[4], c[4], cci[4]; bool val[4];
+                    const int jb = p0 + 4 * tid;
+                    {
+                        int l0 = jb < n_pair ? ft_seg_find(s_it_poff, kPrIC, jb) : 0;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int j = jb + v;
+                            val[v] = j < n_pair;
+                            // (the next pair's item: this one, its successor, or -- behind a run of items without pairs, e.g. idle
+                            //  roots -- found by a bisection of its own; poff[kPrIC] = n_pair > j ends every search)
+                            if (val[v] && s_it_poff[l0 + 1] <= j) { ++l0; if (s_it_poff[l0 + 1] <= j) l0 = ft_seg_find(s_it_poff, kPrIC, j); }
+                            li[v] = l0;
+                            const int self = (c0 + l0 >= R) ? 1 : 0;
+                            q[v] = val[v] ? j - s_it_poff[l0] - self : 0;
+                        }
+                    }
+                    FT_PROF(1);
+                    // a child's id and phone (static, shared by every utterance: the table stays in the L2)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        c[v] = -1; cci[v] = 0;
+                        if (val[v]) {
+                            if (q[v] < 0) { c[v] = s_it_node[li[v]]; cci[v] = (uint32_t)s_it_par[li[v]] >> 24; }
+                            else { const uint32_t kc_ = (uint32_t)kids_ci[s_it_k0[li[v]] + q[v]]; c[v] = (int)(kc_ & 0xffffffu); cci[v] = (int)(kc_ >> 24); }
+                        }
+                    }
+                    // a child's side of the snapshot from its line; for an item's own entry, the PARENT's side from the parent's
+                    FtQuad qx[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        qx[v] = FtQuad{ 0, -1, kW, 0 };
+                        if (val[v]) {
+                            if (q[v] < 0) qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)(s_it_par[li[v]] & 0xffffff) * TREC + T::QA);
+                            else qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)c[v] * TREC + T::QB);
+                        }
+                    }
+                    int32_t bit[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        bit[v] = 0;
+                        if (!val[v]) continue;
+                        const bool self = q[v] < 0;
+                        const int P = self ? (s_it_par[li[v]] & 0xffffff) : s_it_node[li[v]];
+                        // the parent's side: a root, or a node listed in this frame (stamp)
+                        const bool p_root = P < R;
+                        const int32_t p_fp = self ? qx[v].z : s_it_fp[li[v]];
+                        const bool p_active = p_root || !self || qx[v].w == f;
+                        const int32_t p_out = self ? qx[v].x : s_it_out[li[v]], p_outh = self ? qx[v].y : s_it_outh[li[v]];
+                        const int p_pos = (p_fp >> 1) - 1;
+                        // the node's side: listed in this frame (stamp)?  then its score as the snapshot took it
+                        const int32_t c_fp = self ? s_it_fp[li[v]] : qx[v].x;
+                        const bool in_acl = self || (qx[v].y == f && (c_fp >> 1) != 0);
+                        const int c_pos = (c_fp >> 1) - 1;
+                        const bool retc = in_acl && (c_fp & 1);
+                        const int32_t c_score = self ? s_it_sc0[li[v]] : qx[v].z;
+                        const int32_t news = (p_active ? p_out : kW) + p.pip;
+                        const bool parent_can = p_active && (p_fp & 1) && (p.has_pl || news > npt) && (news + ft_pen(cci[v]) > npt);
+                        const bool parent_first = p_root || !in_acl || p_pos < c_pos;
+                        bool fire;                                   // (frame < f: exactly the nodes that are not listed, see above)
+                        if (!in_acl) fire = parent_can;
+                        else if (parent_first || retc) fire = parent_can && news > c_score;
+                        else fire = parent_can;
+                        const bool entered_first = fire && parent_first;
+                        const bool listed = fire && (p_root || !(in_acl && !parent_first && retc));
+#ifdef PSGPU_FT_CHECK_LISTS
+                        if (!in_acl && tv.at(c[v], F::FRAME) >= f) { printf("unlisted node %d has frame %d in frame %d\n", c[v], tv.at(c[v], F::FRAME), f); abort(); }
+#endif
+                        // The frame stamp of a TREE node is read by nobody in these layouts (membership is the list itself): it
+                        // is not kept up to date on the device (the simulator's build keeps it, for its checks).
+                        if (self) {                                  // the node's own entry: its channel is written here
+                            int32_t *const r = tv.b + (size_t)c[v] * TREC;
+                            static_assert(F::HIST == NE && F::OUT % 4 == 0, "record layout");
+                            if (!retc && !entered_first) {           // hmm_clear [+ hmm_enter]: four requests instead of ten
+                                if (NE == 3) {
+                                    *reinterpret_cast<FtQuad *>(r) = FtQuad{ fire ? news : kW, kW, kW, fire ? p_outh : -1 };
+                                    r[F::HIST + 1] = -1; r[F::HIST + 2] = -1;
+                                }
+                                else {
+#pragma unroll
+                                    for (int k = 0; k < NE; ++k) { r[F::SCORE + k] = kW; r[F::HIST + k] = -1; }
+                                    if (fire) { r[F::SCORE] = news; r[F::HIST] = p_outh; }
+                                }
+                                *reinterpret_cast<FtQuad *>(r + F::OUT) = FtQuad{ kW, -1, kW, fire ? nf : -1 };
+                            }
+                            else if (fire) { r[F::SCORE] = news; r[F::HIST] = p_outh; }
+#ifdef PSGPU_FT_CHECK_LISTS
+                            if (retc || fire) r[F::FRAME] = nf;
+#endif
+                            bit[v] = (retc && !entered_first) ? 1 : 0;
+                        }
+                        else {
+                            if (!in_acl && fire) {                   // (a listed child is written by its own entry; an unlisted one was
+                                int32_t *const r = tv.b + (size_t)c[v] * TREC;     //  cleared when it left the list: its first quad is known)
+                                if (NE == 3) *reinterpret_cast<FtQuad *>(r) = FtQuad{ news, kW, kW, p_outh };
+                                else { r[F::SCORE] = news; r[F::HIST] = p_outh; }
+#ifdef PSGPU_FT_CHECK_LISTS
+                                r[F::FRAME] = nf;
+#endif
+                            }
+                            bit[v] = listed ? 1 : 0;
+                        }
+                    }
+                    FT_PROF(13);
+                    // positions in the next active list: pair order
+                    {
+                        const int lane = tid & 63, wv_ = tid >> 6;
+                        const int32_t sb = bit[0] + bit[1] + bit[2] + bit[3];
+                        const int32_t ib = ft_wave_incl<FtAdd>(sb);
+                        if (lane == 63) s_scan[wv_] = ib;
+                        FT_PROF(22);
+                        ft_sync<true>();
+                        FT_PROF(31);
+                        int32_t base = 0, tot = 0;
+#pragma unroll
+                        for (int w = 0; w < NT / 64; ++w) { const int32_t a_ = s_scan[w]; tot += a_; if (w < wv_) base += a_; }
+                        int o = carry_l + base + ib - sb;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) if (bit[v]) acln[o++] = c[v];
+                        carry_l += tot;
+                        ft_sync<true>();                             // (s_scan; the chunk's LDS arrays before the next chunk overwrites them)
+                    }
+                }
+                FT_PROF(6);
+            }
+            n_listed = carry_l;
+            if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; }
+        }
+        } else {
+            // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation.  Work proportional to the active
+            //      channels (oracle prune_tree_list): the items are the roots, the listed nodes and their children.  Reads of
+            //      another node's state go to the snapshot (o_out, o_outh, flag, pos) of a root or listed node, writes to the
+            //      item's own channel and decision word, so the items are independent.
+            for (int q = tid; q < na; q += NT) pos[aclc[q]] = q;
+            for (int i = tid; i < R + na; i += NT) {
+                const int node = i < R ? i : aclc[i - R];
+                const bool active = i < R ? tv.at(node, F::FRAME) >= f : true;
+                o_out[node] = tv.at(node, F::OUT); o_outh[node] = tv.at(node, F::OUTH);
+                flag[node] = (active && tv.at(node, F::BEST) > thresh) ? 1 : 0;
+            }
+            ft_sync<SMALL>();
+            FT_PROF(4);
+            auto decide = [&](int c) {
+                const int P = parent[c], pc = pos[c];
+                const bool in_acl = pc >= 0, par_active = P < R || pos[P] >= 0;
+                const int32_t news = (par_active ? o_out[P] : kW) + p.pip;
+                const bool parent_can = par_active && (flag[P] & 1) && (p.has_pl || news > npt)
+                                        && (news + ft_pen(node_ci[c]) > npt);
+                const bool parent_first = P < R || !in_acl || pos[P] < pc;
+                const bool retc = in_acl && (flag[c] & 1);
+                bool fire;
+                if (!in_acl || parent_first) fire = parent_can && (tv.at(c, F::FRAME) < f || news > tv.at(c, F::SCORE));
+                else if (retc)               fire = parent_can && news > tv.at(c, F::SCORE);
+                else                         fire = parent_can;
+                const bool entered_first = fire && parent_first;
+                const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
+                if (in_acl && !retc && !entered_first) ch_clear<NE>(tv, c);
+                if (retc) tv.at(c, F::FRAME) = nf;
+                if (fire) ch_enter<NE>(tv, c, news, o_outh[P], nf);
+                o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
+            };
+            for (int i = tid; i < R + na; i += NT) {
+                const int node = i < R ? i : aclc[i - R];
+                // a node that is not retained enters none of its children: their (stale) decision words are not
+                // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
+                const int k0 = kid_off[node], nk = (flag[node] & 1) ? kid_off[node + 1] - k0 : 0;
+                for (int q = i >= R ? -1 : 0; q < nk; ++q) {         // q = -1: the listed node itself, then its unlisted children
+                    const int c = q < 0 ? node : kids[k0 + q];
+                    if (q >= 0 && pos[c] >= 0) continue;
+                    decide(c);
+                }
+            }
+            FT_PROF(28);
+            ft_sync<SMALL>();
+            FT_PROF(5);
+            for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
+            for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
+            // list positions (root phase: a segment per root, then one segment per list position) and the last-phone candidates
+            // (list order, homophone chain inside) in ONE counting pass, one double prefix sum and one writing pass: the two
+            // depend on the pruning's snapshot and decisions only, not on each other
+            int32_t *const cntb = cnt + (R + N + 1);
+            for (int i = tid; i < R + na; i += NT) {
+                const int node = i < R ? i : aclc[i - R];
+                int k = (i >= R && (o_frame[node] & 8)) ? 1 : 0;
+                if (flag[node] & 1) {
+                    const int k1 = kid_off[node + 1];
+                    for (int q = kid_off[node]; q < k1; ++q) k += (o_frame[kids[q]] & 2) ? 1 : 0;
+                }
+                cnt[i] = k;
+                const int32_t news = o_out[node] + p.pip;
+                int kc = 0;
+                if ((flag[node] & 1) && (p.has_pl || news > lpt))
+                    for (int w = node_pw[node]; w >= 0; w = homo_f[w]) kc += (news + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
+                cntb[i] = kc;
+            }
+            ft_sync<SMALL>();
+            {
+                int32_t tot2[2];
+                int32_t *const arr[2] = { cnt, cntb };
+                ft_block_scan_k<NT, 2, SMALL>(arr, R + na, s_scan, tot2);       // exclusive prefix sums
+                n_listed = tot2[0];
+                if (tid == 0) { s_sc[5] = tot2[1]; s_red[7] = 0; }
+            }
+            FT_PROF(6);
+            for (int i = tid; i < R + na; i += NT) {
+                const int node = i < R ? i : aclc[i - R];
+                int o = cnt[i];
+                if (i >= R && (o_frame[node] & 8)) acln[o++] = node;
+                if (flag[node] & 1) {
+                    const int k1 = kid_off[node + 1];
+                    for (int q = kid_off[node]; q < k1; ++q) { const int c = kids[q]; if (o_frame[c] & 2) acln[o++] = c; }
+                }
+                const int32_t news = o_out[node] + p.pip;
+                int oc = cntb[i];
+                if ((flag[node] & 1) && (p.has_pl || news > lpt))
+                    for (int w = node_pw[node]; w >= 0; w = homo_f[w])
+                        if (news + ft_pen(dlast_f[w]) > lpt) {
+                            cand_wid[oc] = w; cand_score[oc] = news - p.nwpen; cand_bp[oc] = o_outh[node]; ++oc;
+                        }
+            }
         }
         __syncthreads();                                     // (device memory: the evaluation's records, tb.idx[f] -- see above)
         FT_PROF(7);
@@ -1315,8 +1627,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     awln[nawl0 + w_k[i]] = w; word_active[w] = 1;
                 }
             if (tid == 0) {
+                // (a full table: status 1, the frame's exits are not written and the counts stay what the tables hold)
                 if (bpidx + n_exit + n1 >= tb.bp_cap || bss_head + n_bss + n_ci >= tb.bss_cap) s_sc[6] = 1;
-                s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; s_red[5] = nawl0 + n_app;
+                else { s_sc[3] = bpidx + n_exit; s_sc[4] = bss_head + n_bss; }
+                s_red[5] = nawl0 + n_app;
             }
             ft_sync<SMALL>();
             FT_PROF(12);
@@ -1651,7 +1965,7 @@ static bool ft_layout(FtDev &d, bool small)
     auto take = [&](int64_t n) { const int64_t r = o; o += (n + 3) & ~(int64_t)3; return (int32_t)r; };
     FtLay &L = d.lay;
     memset(&L, 0, sizeof L);
-    L.rec = take((int64_t)d.CH * (small ? words : rec));
+    L.rec = take((int64_t)d.CH * (small ? words : rec + 16));           // (slab: TrF<NE>::REC words a channel)
     L.acl0 = take(d.N); L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
     L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
     L.cand_mark = take(d.n_w);
@@ -1751,6 +2065,12 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
     d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
     d.kid_off = ft_up(m, kid_off.data(), (size_t)d.N + 1, &rc); d.kids = ft_up(m, kids.data(), kids.size(), &rc);
+    {
+        if (d.N >= (1 << 24) || d.n_ci > 128) { psgpu_set_error("fwdtree: %d tree nodes (at most 2^24 - 1)", d.N); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
+        std::vector<int32_t> kc(kids.size(), 0);
+        for (int k = 0; k < d.M; ++k) kc[k] = (int32_t)((uint32_t)kids[k] | ((uint32_t)t->node_ci[kids[k]] << 24));
+        d.kids_ci = ft_up(m, kc.data(), kc.size(), &rc);
+    }
     d.node_pw = ft_up(m, t->node_penult_wid, d.N, &rc); d.parent = ft_up(m, parent.data(), d.N, &rc);
     d.homophone = ft_up(m, t->homophone_set, d.n_w, &rc);
     d.w1_wid = ft_up(m, t->w1_wid, d.n1, &rc); d.w1_ci = ft_up(m, t->w1_ci, d.n1, &rc); d.w1_ci2 = ft_up(m, t->w1_ci2, d.n1, &rc);
@@ -1915,12 +2235,14 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
-    const size_t pool_bytes = sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total);
+    const size_t pool_bytes = d.small ? sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total)
+                                      : sizeof(int32_t) * (size_t)(16 * (big ? kFtThreadsBig : kFtThreads) + 16);      // (slab: the pruning's item arrays)
 #if defined(__HIPCC__)                    /* a pool that takes the workgroup's LDS beyond the default 64 KB (scoring from lists): say so once */
 #define FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
-        if ((SMALL) && pool_bytes + 4096 > 65536) {                                                                   \
+        if (pool_bytes + 4096 > 65536) {                                                                              \
             static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdtree_kernel<NE, NT, SMALL, LISTS>, \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int32_t) * kFtLdsWords));    \
+                              hipFuncAttributeMaxDynamicSharedMemorySize,                                            \
+                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * (16 * (NT) + 16)));          \
             PSGPU_HIP(attr_rc);                                                                                       \
         }
 #else
@@ -1928,7 +2250,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
 #endif
 #define FT_LAUNCH(NE, NT, SMALL, LISTS) do {                                                                          \
         FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
-        hipLaunchKernelGGL((fwdtree_kernel<NE, NT, SMALL, LISTS>), dim3(n_utt), dim3(NT), (SMALL) ? pool_bytes : 0, st, \
+        hipLaunchKernelGGL((fwdtree_kernel<NE, NT, SMALL, LISTS>), dim3(n_utt), dim3(NT), pool_bytes, st,                \
                            d, senscr_dev, scr_stride, penalties_dev, utt_off_dev, raw_scores, pl_window, bf);        \
     } while (0)
     if (d.n_emit == 3) {
@@ -1949,12 +2271,12 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
 #ifdef PSGPU_FT_PROFILE
     {   // a profiling build: wait, average the per-phase cycle counts over the utterances, print them per frame
         // (an interval ends at its marker: "x: to barrier" = work-item 0's own work, the next interval = its wait at the barrier + the rest)
-        static const char *const names[32] = { "top: lists, senone marks", "-", "normaliser", "evaluate: after barrier (prefetch issue, beam)", "prune: snapshot", "prune: decide, barrier",
-            "next active list", "last-phone candidates", "predecessor search: decode + max", "entering", "active words", "prune_word_chan",
-            "positions (scans)", "-", "exits", "single-phone: barrier + counters", "word_transition: pairs, barrier", "frame end: row to LDS",
-            "evaluate: loop", "evaluate: barrier", "single-phone: flags + scan", "single-phone: save", "-", "word_transition: init + barrier",
-            "word_transition: pair loops", "word_transition: decode keys", "word_transition: enter", "deactivate + step", "prune: decide loop",
-            "predecessor search: exit scores + scan", "predecessor search: pairs", "-" };
+        static const char *const names[32] = { "top: lists, senone marks", "slab pairs: bisection", "normaliser", "evaluate: after barrier (prefetch issue, beam)", "prune: snapshot", "prune: decide, barrier | slab: chunk scans + candidates",
+            "next active list | slab: pairs", "last-phone candidates", "predecessor search: decode + max", "entering", "active words", "prune_word_chan",
+            "positions (scans)", "slab pairs: loads + decisions", "exits", "single-phone: barrier + counters", "word_transition: pairs, barrier", "frame end: row to LDS",
+            "evaluate: loop", "evaluate: barrier", "single-phone: flags + scan", "single-phone: save", "slab pairs: compaction", "word_transition: init + barrier",
+            "word_transition: pair loops", "word_transition: decode keys", "word_transition: enter", "deactivate + step", "prune: decide loop | slab: chunk items",
+            "predecessor search: exit scores + scan", "predecessor search: pairs", "slab pairs: barrier" };
         std::vector<long long> h((size_t)48 * n_utt);
         std::vector<int32_t> r((size_t)8 * n_utt);
         PSGPU_HIP(hipStreamSynchronize(st));
@@ -1965,7 +2287,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
         for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 32; ++i) acc[i] += (double)h[(size_t)u * 48 + i]; }
         for (int i = 0; i < 32; ++i) tot += acc[i];
         fprintf(stderr, "fwdtree_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
-        static const int order[] = { 0, 2, 18, 19, 3, 4, 28, 5, 6, 7, 29, 30, 8, 9, 10, 11, 12, 14, 20, 21, 15, 23, 24, 16, 25, 26, 27, 17 };
+        static const int order[] = { 0, 2, 18, 19, 3, 4, 28, 5, 1, 13, 22, 31, 6, 7, 29, 30, 8, 9, 10, 11, 12, 14, 20, 21, 15, 23, 24, 16, 25, 26, 27, 17 };
         for (int w = 1; w < 4; ++w) {
             double a1 = 0, a2 = 0;
             for (int u = 0; u < n_utt; ++u) { a1 += (double)h[(size_t)u * 48 + 32 + 4 * w + 1]; a2 += (double)h[(size_t)u * 48 + 32 + 4 * w + 2]; }
