@@ -333,6 +333,8 @@ int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, co
                                int32_t n_utt, int32_t total_frames, int16_t *senscr_dev, void *stream);
 int psgpu_semi_score_batch(psgpu_semi_model_t *m, const float *feats, const int32_t *utt_off, int32_t n_utt,
                            int16_t *senscr);
+int32_t psgpu_semi_n_sen(const psgpu_semi_model_t *m);
+int32_t psgpu_semi_veclen(const psgpu_semi_model_t *m);    /* sum of featlen */
 int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, int32_t *score,
                               int32_t *n_used);
 int psgpu_semi_state_set_topn(psgpu_semi_state_t *s, int32_t slot, const int32_t *cw,
@@ -402,6 +404,15 @@ int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_
                              int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev,
                              void *stream);
 int psgpu_ms_batch_check(psgpu_ms_model_t *m, void *stream);
+/* The same, stopping after senone_eval's own int16 store (ms_mgau.c:219, :255: `senscr[s] = senone_eval(...)`): the rows a
+ * device search normalises itself over ITS list -- best = the minimum over the listed senones, score - best clamped to
+ * int16 (:226-234, :269-277), psgpu_fwdtree_search_dev raw_scores = 1 / psgpu_phone_loop_run_dev with a senone list. */
+int psgpu_ms_score_batch_raw_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
+                                 int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev, void *stream);
+/* whether the batch entries need the list buffers (anything but a fully continuous model), their entries per frame
+ * (n_mgau * n_feat * topn) */
+int32_t psgpu_ms_batch_needs_lists(const psgpu_ms_model_t *m);
+int32_t psgpu_ms_list_entries_per_frame(const psgpu_ms_model_t *m);
 /* host-buffer convenience wrapper (allocates, copies, runs, checks, copies back) */
 int psgpu_ms_score_batch(psgpu_ms_model_t *m, const float *feats, int32_t total_frames, int16_t *senscr);
 
@@ -540,6 +551,10 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m);
  * was full), best_score of the last frame (ngs->best_score), HMM evaluations of the utterance (low, high
  * word), listed senones summed over its frames (raw_scores mode)}.  Asynchronous on `stream`; the work
  * slab belongs to the handle, so one search at a time per handle.
+ * raw_scores = 3: as 1, but the rows are final scores -- a scorer that does not normalise over the call's list
+ * (s2_semi_mgau_frame_eval): the lists are still built (the result's counters), nothing is subtracted.  With 1 the
+ * difference score - minimum is clamped to int16, as ms_cont_mgau_frame_eval stores it (ms_mgau.c:269-277; PTM's
+ * differences never leave the range).
  * raw_scores = 1: senscr_dev holds the scorer's UN-normalised rows (PSGPU_PTM_RAW_SCORES) and
  * penalties_dev the phone loop's output per phone-loop frame (psgpu_phone_loop_run_dev): the kernel
  * then builds each frame's active senone list itself (compute_sen_active + acmod_flags2list,
@@ -657,7 +672,18 @@ typedef struct psgpu_decode_config_s {
     int32_t n_ci_list;                 /*   phone is active, bridging entries included (psgpu_phone_loop_run_dev) */
     int32_t pl_window;                 /* ps->pl_window: frames the phone loop runs ahead of the search (>= 1) */
     int32_t max_words;                 /* hypothesis records per utterance (0: 512) */
+    /* The scorer.  PSGPU_SCORER_PTM (0): `model`.  Otherwise `model` is NULL and `scorer` is a psgpu_semi_model_t *
+     * (PSGPU_SCORER_SEMI: s2_semi_mgau_frame_eval, s2_semi_mgau.c:837-883 -- its scores are final, neither the phone loop nor the
+     * search subtracts anything) or a psgpu_ms_model_t * (PSGPU_SCORER_MS: ms_cont_mgau_frame_eval, ms_mgau.c:192-282 -- rows of
+     * senone_eval values, normalised over each call's own list with the int16 clamp of :269-277), the two scorers acmod_init_am
+     * (acmod.c:62-130) falls back to / is sent to by -senmgau.  Both are stateless across utterances in this pipeline: every
+     * utterance is scored as by a new decoder; psgpu_decode_session and psgpu_decode_score_mode need the PTM scorer. */
+    int32_t scorer_kind;
+    void *scorer;
 } psgpu_decode_config_t;
+#define PSGPU_SCORER_PTM 0
+#define PSGPU_SCORER_SEMI 1
+#define PSGPU_SCORER_MS 2
 int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
 void psgpu_decode_free(psgpu_decode_t *d);
 /* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */

@@ -17,6 +17,8 @@ struct psgpu_decode_s {
     uint16_t *d_ssid = nullptr, *d_ci = nullptr;
     int16_t *d_tmatid = nullptr;
     int32_t n_sen = 0, n_chain = 0, topn = 0, cepsize = 0, n_ci = 0, n1 = 0, n_emit = 0, max_words = 0;
+    int32_t kind = PSGPU_SCORER_PTM, veclen = 0, raw_flag = 1;      // the scorer (psgpu_decode_config_t.scorer_kind); what the search is told about its rows
+    int32_t *d_ms_id = nullptr; float *d_ms_dist = nullptr;         // the ms scorer's top-N lists (shapes that need them)
     // work buffers, grown on demand
     size_t cap_samples = 0, cap_frames = 0, cap_utt = 0, cap_bp = 0, cap_bss = 0, cap_mf = 0;
     int16_t *d_pcm = nullptr;
@@ -76,7 +78,7 @@ static int dec_alloc(void **p, size_t bytes)
 // weight tables, 90 -> 116 ms, and the phone loop's preparation 0.8 -> 5.9 ms: slower in total, hence not the default.
 static bool dec_can_lists(psgpu_decode_s *d)
 {
-    return psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK && psgpu_fwdtree_can_score_lists(d->cfg.ft, &d->view)
+    return d->kind == PSGPU_SCORER_PTM && psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK && psgpu_fwdtree_can_score_lists(d->cfg.ft, &d->view)
            && d->cfg.n_ci_list <= 256;
 }
 static void dec_pick_mode(psgpu_decode_s *d)
@@ -89,7 +91,10 @@ extern "C" {
 
 int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg)
 {
-    PSGPU_REQUIRE(out && cfg && cfg->fe && cfg->model && cfg->ctx && cfg->ft, "psgpu_decode_create: NULL argument");
+    PSGPU_REQUIRE(out && cfg && cfg->ctx && cfg->ft, "psgpu_decode_create: NULL argument");
+    PSGPU_REQUIRE(cfg->scorer_kind == PSGPU_SCORER_PTM ? cfg->model != nullptr
+                  : ((cfg->scorer_kind == PSGPU_SCORER_SEMI || cfg->scorer_kind == PSGPU_SCORER_MS) && cfg->scorer != nullptr),
+                  "psgpu_decode_create: no scorer (model for PSGPU_SCORER_PTM, scorer for PSGPU_SCORER_SEMI / _MS)");
     PSGPU_REQUIRE(cfg->pl_ssid && cfg->pl_tmatid && cfg->ci_list && cfg->n_ci_list > 0 && cfg->pl.n_phones >= 1 && cfg->pl.n_phones <= 64
                   && cfg->pl_window >= 1, "psgpu_decode_create: the pipeline needs the phone-loop look-ahead (tables, pl_window >= 1)");
     *out = nullptr;
@@ -97,13 +102,24 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg)
     if (rc != PSGPU_OK) return rc;
     psgpu_decode_s *d = new psgpu_decode_s();
     d->cfg = *cfg;
-    d->n_sen = psgpu_ptm_n_sen(cfg->model); d->n_chain = psgpu_ptm_n_chain(cfg->model); d->topn = psgpu_ptm_topn(cfg->model);
-    d->cepsize = psgpu_fe_out_dim(cfg->fe); d->n_ci = cfg->pl.n_phones;
+    d->kind = cfg->scorer_kind;
+    if (d->kind == PSGPU_SCORER_PTM) {
+        d->n_sen = psgpu_ptm_n_sen(cfg->model); d->n_chain = psgpu_ptm_n_chain(cfg->model); d->topn = psgpu_ptm_topn(cfg->model);
+        d->veclen = psgpu_ptm_veclen(cfg->model); d->raw_flag = 1;
+    }
+    else if (d->kind == PSGPU_SCORER_SEMI) {
+        d->n_sen = psgpu_semi_n_sen((const psgpu_semi_model_t *)cfg->scorer); d->veclen = psgpu_semi_veclen((const psgpu_semi_model_t *)cfg->scorer);
+        d->raw_flag = 3;                                 // final scores: nothing is subtracted (s2_semi_mgau.c:837-883)
+    }
+    else {
+        d->n_sen = psgpu_ms_n_sen((const psgpu_ms_model_t *)cfg->scorer); d->veclen = psgpu_ms_veclen((const psgpu_ms_model_t *)cfg->scorer);
+        d->raw_flag = 1;                                 // senone_eval values: score - min over the call's list, clamped (ms_mgau.c:258-277)
+    }
+    d->cepsize = cfg->fe ? psgpu_fe_out_dim(cfg->fe) : 0; d->n_ci = cfg->pl.n_phones;
     d->n_emit = psgpu_hmm_n_emit_state(cfg->ctx); d->n1 = psgpu_fwdtree_n_single_phone_words(cfg->ft);
     d->max_words = cfg->max_words > 0 ? cfg->max_words : 512;
-    if (psgpu_ptm_veclen(cfg->model) != 3 * d->cepsize) {
-        psgpu_set_error("psgpu_decode_create: the scorer takes %d-dimensional vectors, 1s_c_d_dd of %d cepstra gives %d",
-                        psgpu_ptm_veclen(cfg->model), d->cepsize, 3 * d->cepsize);
+    if (d->n_sen <= 0 || d->veclen <= 0) {
+        psgpu_set_error("psgpu_decode_create: the scorer reports %d senones, %d-dimensional vectors", d->n_sen, d->veclen);
         delete d;
         return PSGPU_EINVAL;
     }
@@ -128,7 +144,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
-    DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef);
+    DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
@@ -148,6 +164,7 @@ int psgpu_decode_score_mode(psgpu_decode_t *d, int32_t lists)
 int psgpu_decode_session(psgpu_decode_t *d, int32_t on)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_session: NULL argument");
+    PSGPU_REQUIRE(!on || d->kind == PSGPU_SCORER_PTM, "psgpu_decode_session: sessions are carried for the PTM scorer only");
     d->session = on != 0;
     d->sess_started = false; d->seed_valid = false; d->fe_fresh = true;
     return PSGPU_OK;
@@ -222,6 +239,7 @@ int psgpu_decode_wait_scored(psgpu_decode_t *d)
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model)
 {
     PSGPU_REQUIRE(d && model, "psgpu_decode_set_model: NULL argument");
+    PSGPU_REQUIRE(d->kind == PSGPU_SCORER_PTM, "psgpu_decode_set_model: the pipeline was created with another scorer");
     PSGPU_REQUIRE(psgpu_ptm_n_sen(model) == d->n_sen && psgpu_ptm_n_chain(model) == d->n_chain && psgpu_ptm_topn(model) == d->topn,
                   "psgpu_decode_set_model: the model has another shape");
     d->cfg.model = model;
@@ -243,12 +261,16 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
         wait();
         const size_t t = std::max(total + total / 8 + 64, d->cap_frames), ne = t * d->n_chain * d->topn;
         DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_tsc); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_best); DFREE(d->d_pen);
+        DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
         d->cap_frames = 0;
         int rc;
-        if ((rc = dec_alloc((void **)&d->d_cep, 4 * t * d->cepsize)) || (rc = dec_alloc((void **)&d->d_feat, 4 * t * 3 * d->cepsize))
+        const size_t ms_ent = (d->kind == PSGPU_SCORER_MS && psgpu_ms_batch_needs_lists((const psgpu_ms_model_t *)d->cfg.scorer))
+                              ? t * (size_t)psgpu_ms_list_entries_per_frame((const psgpu_ms_model_t *)d->cfg.scorer) : 0;
+        if ((rc = dec_alloc((void **)&d->d_cep, 4 * t * d->cepsize)) || (rc = dec_alloc((void **)&d->d_feat, 4 * t * d->veclen))
             || (rc = dec_alloc((void **)&d->d_tsc, 4 * ne)) || (rc = dec_alloc((void **)&d->d_tcw, ne))
-            || (!d->lists && (rc = dec_alloc((void **)&d->d_rows, 2 * t * d->n_sen))) || (!d->lists && (rc = dec_alloc((void **)&d->d_best, 4 * t)))
-            || (rc = dec_alloc((void **)&d->d_pen, 4 * t * d->n_ci)))
+            || (!d->lists && (rc = dec_alloc((void **)&d->d_rows, 2 * t * d->n_sen + 64))) || (!d->lists && (rc = dec_alloc((void **)&d->d_best, 4 * t)))
+            || (rc = dec_alloc((void **)&d->d_pen, 4 * t * d->n_ci))
+            || (ms_ent && ((rc = dec_alloc((void **)&d->d_ms_id, 4 * ms_ent)) || (rc = dec_alloc((void **)&d->d_ms_dist, 4 * ms_ent)))))
             return rc;
         d->cap_frames = t;
     }
@@ -256,7 +278,7 @@ static int dec_grow(psgpu_decode_s *d, size_t n_utt, size_t total, size_t mf, hi
         wait();
         const size_t nu = std::max(n_utt, d->cap_utt), cb = std::max(bp_cap, d->cap_bp), cs = std::max(bss_cap, d->cap_bss),
                      cm = std::max(mf, d->cap_mf);
-        psgpu_fe_offsets_dirty(d->cfg.fe);
+        if (d->cfg.fe) psgpu_fe_offsets_dirty(d->cfg.fe);
         DFREE(d->d_off); DFREE(d->d_bp); DFREE(d->d_bss); DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn);
         DFREE(d->d_w1);
         d->cap_utt = 0;
@@ -286,7 +308,7 @@ static int dec_search(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t mf,
                                             chained ? d->d_mpx_in : nullptr, sess ? d->d_mpx : nullptr, st);
     else
         rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_rows, d->n_sen, d->d_pen, d->d_off, n_utt, (int32_t)mf, d->bp_cap, d->bss_cap,
-                                              d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, 1, d->cfg.pl_window, d->d_w1,
+                                              d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, d->raw_flag, d->cfg.pl_window, d->d_w1,
                                               chained ? d->d_mpx_in : nullptr, sess ? d->d_mpx : nullptr, st);
     if (rc == PSGPU_OK) d->searched = true;
     return rc;
@@ -301,10 +323,15 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
     if (sess && (rc = dec_session_buffers(d))) return rc;
     const bool chained = sess && d->sess_started;
     dec_mark(d, 2, st);
-    if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, chained && d->seed_valid ? d->d_seed : nullptr,
-                                        nullptr, d->d_tsc, d->d_tcw, d->lists ? nullptr : d->d_rows, d->lists ? nullptr : d->d_best,
-                                        PSGPU_PTM_RAW_SCORES, st)))
-        return rc;
+    if (d->kind == PSGPU_SCORER_PTM)
+        rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, chained && d->seed_valid ? d->d_seed : nullptr,
+                                       nullptr, d->d_tsc, d->d_tcw, d->lists ? nullptr : d->d_rows, d->lists ? nullptr : d->d_best,
+                                       PSGPU_PTM_RAW_SCORES, st);
+    else if (d->kind == PSGPU_SCORER_SEMI)               // every utterance from a new scorer's lists, frames numbered from 0
+        rc = psgpu_semi_score_batch_dev((psgpu_semi_model_t *)d->cfg.scorer, d->d_feat, d->d_off, n_utt, (int32_t)total, d->d_rows, st);
+    else                                                 // no time dependence: frames of all utterances back to back
+        rc = psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st);
+    if (rc) return rc;
     if (sess) {
         // what seeds the next utterance's first frame: ptm_mgau_frame_eval copies frame 0's initial lists from slot
         // n_fast_hist - 1 of its history ring (ptm_mgau.c:425-441), H = n_fast_hist = pl_window + 2 (:865); that slot was last
@@ -323,7 +350,8 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
         rc = psgpu_phone_loop_run_lists_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, &d->view, d->d_tsc,
                                             d->d_tcw, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st);
     else
-        rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->d_ci, d->cfg.n_ci_list, d->d_rows, d->n_sen,
+        rc = psgpu_phone_loop_run_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->raw_flag == 3 ? nullptr : d->d_ci,
+                                      d->raw_flag == 3 ? 0 : d->cfg.n_ci_list, d->d_rows, d->n_sen,
                                       nullptr, d->d_off, n_utt, (int32_t)total, d->d_pen, nullptr, nullptr, st);
     if (rc) return rc;
     dec_mark(d, 4, st);
@@ -349,6 +377,9 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
 int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, void *stream)
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm_dev && samp_off)), "psgpu_decode_first_pass_dev: bad argument");
+    PSGPU_REQUIRE(d->cfg.fe && d->veclen == 3 * d->cepsize,
+                  "psgpu_decode_first_pass_dev: from PCM the pipeline computes 1s_c_d_dd vectors of %d cepstra; the scorer takes %d-dimensional "
+                  "vectors (other feature types: psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
     hipStream_t st = (hipStream_t)stream;
     d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false;
     d->frame_off.assign((size_t)n_utt + 1, 0);
@@ -419,9 +450,9 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
     d->total = (int32_t)total; d->max_frames = (int32_t)mf;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     PSGPU_HIP(hipStreamSynchronize(st));                 // frame_off / feat are the caller's: copied before returning
-    psgpu_fe_offsets_dirty(d->cfg.fe);
+    if (d->cfg.fe) psgpu_fe_offsets_dirty(d->cfg.fe);
     PSGPU_HIP(hipMemcpyAsync(d->d_off, frame_off, 4 * ((size_t)n_utt + 1), hipMemcpyHostToDevice, st));
-    if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * 3 * d->cepsize, hipMemcpyHostToDevice, st));
+    if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * d->veclen, hipMemcpyHostToDevice, st));
     PSGPU_HIP(hipStreamSynchronize(st));
     if (total == 0) {
         PSGPU_HIP(hipMemsetAsync(d->d_res, 0, 4 * (size_t)n_utt * 8, st));
@@ -539,6 +570,12 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
     PSGPU_REQUIRE(d, "psgpu_decode_fetch_hyps: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     const size_t nu = (size_t)d->n_utt;
+    if (nu && d->kind == PSGPU_SCORER_MS && d->searched) {
+        // (a frame with fewer than topn densities above WORST_DIST: the reference then keeps stale list ids, ms_gauden.c:438-440,
+        //  which the batched kernels do not reproduce -- reported, not hidden)
+        int rc = psgpu_ms_batch_check((psgpu_ms_model_t *)d->cfg.scorer, st);
+        if (rc != PSGPU_OK) return rc;
+    }
     if (nu && d->auto_grow && d->searched) {
         std::vector<int32_t> res(nu * 8);
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));

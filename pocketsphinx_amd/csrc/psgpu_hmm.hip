@@ -246,6 +246,7 @@ void phone_loop_prep_kernel(PlDev p, const uint16_t *__restrict__ sseq, const in
     const int16_t *row = raw + (size_t)t * raw_stride;
     int32_t nb;
     if (p.norm_mode == 2) nb = best_all[t];
+    else if (p.norm_mode == 0) nb = 0;                   // final scores (a scorer without a per-call normaliser: s2_semi_mgau)
     else {
         nb = 0x7fffffff;
         for (int i = lane; i < p.n_list; i += 64) nb = min(nb, (int32_t)row[p.ci_list[i]]);
@@ -257,7 +258,10 @@ void phone_loop_prep_kernel(PlDev p, const uint16_t *__restrict__ sseq, const in
     if (lane < p.n_phones) {
 #pragma unroll
         for (int i = 0; i < NE; ++i)
-            v[i] = (int16_t)(uint16_t)((uint32_t)(int32_t)row[sseq[(size_t)p.ssid[lane] * NE + i]] - (uint32_t)nb);
+        {   // (int16 difference: PTM's never leaves the range, the ms scorer clamps it, ms_mgau.c:269-277)
+            const int32_t x = (int32_t)((uint32_t)(int32_t)row[sseq[(size_t)p.ssid[lane] * NE + i]] - (uint32_t)nb);
+            v[i] = (int16_t)(x > 32767 ? 32767 : (x < -32768 ? -32768 : x));
+        }
     }
     int16_t *o = css + ((size_t)t * 64 + lane) * W;
 #pragma unroll
@@ -559,12 +563,12 @@ static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const
     PSGPU_REQUIRE(ssid_dev && tmatid_dev && (raw_dev || ls) && utt_off_dev && penalties_dev, "psgpu_phone_loop_run_dev: NULL device buffer");
     PSGPU_REQUIRE(pp->n_phones >= 1 && pp->n_phones <= 64, "n_phones %d outside 1..64", pp->n_phones);
     PSGPU_REQUIRE(pp->window >= 1 && pp->window <= kPlMaxWindow, "window %d outside 1..%d", pp->window, kPlMaxWindow);
-    PSGPU_REQUIRE((best_dev != nullptr) != (ci_list_dev != nullptr && n_list > 0),
-                  "exactly one of best_dev (compallsen) and ci_list_dev (active-list normalisation) is needed");
+    PSGPU_REQUIRE(!(best_dev != nullptr && ci_list_dev != nullptr && n_list > 0),
+                  "at most one of best_dev (compallsen) and ci_list_dev (active-list normalisation); neither: the rows are final scores");
     PSGPU_REQUIRE(!ls || ci_list_dev, "scoring from lists needs the all-phones-active senone list");
     PlDev p;
     p.n_phones = pp->n_phones; p.window = pp->window; p.beam = pp->beam; p.pbeam = pp->pbeam; p.pip = pp->pip;
-    p.n_list = n_list; p.norm_mode = best_dev ? 2 : 1; p.weight = pp->penalty_weight;
+    p.n_list = n_list; p.norm_mode = best_dev ? 2 : ((ci_list_dev && n_list > 0) ? 1 : 0); p.weight = pp->penalty_weight;
     p.ssid = ssid_dev; p.tmatid = tmatid_dev; p.ci_list = ci_list_dev;
     // (NULL is the default stream, as for every other entry point.  It used to select the context's own non-blocking stream:
     //  a caller that ran the scorer before and the search after this call on the default stream then raced with it.)

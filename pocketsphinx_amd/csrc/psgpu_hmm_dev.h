@@ -22,8 +22,14 @@ struct HmmRegs {
 struct SenRowNorm {
     const int16_t *row;
     int32_t nb;
+    // score - normaliser as the scorers store it: ptm_mgau_senone_eval subtracts in int16 (ptm_mgau.c:398-400; its sums are below
+    // 2^11, nothing wraps), ms_cont_mgau_frame_eval clamps the difference of two int16 values to int16 (ms_mgau.c:226-234, :269-277)
+    // -- one expression serves both: the clamp never acts on a PTM score
     __device__ __forceinline__ int16_t operator[](int s) const
-    { return (int16_t)(uint16_t)((uint32_t)(int32_t)row[s] - (uint32_t)nb); }
+    {
+        const int32_t x = (int32_t)((uint32_t)(int32_t)row[s] - (uint32_t)nb);
+        return (int16_t)(x > 32767 ? 32767 : (x < -32768 ? -32768 : x));
+    }
 };
 
 // ---- 3-state, non-multiplex (hmm.c:529-607) --------------------------------

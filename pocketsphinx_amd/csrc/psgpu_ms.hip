@@ -978,6 +978,19 @@ int psgpu_ms_score_batch_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_
     return ms_batch(m, feats_dev, total_frames, list_id_dev, list_dist_dev, senscr_dev, stream, false);
 }
 
+int psgpu_ms_score_batch_raw_dev(psgpu_ms_model_t *m, const float *feats_dev, int32_t total_frames,
+                                 int32_t *list_id_dev, float *list_dist_dev, int16_t *senscr_dev, void *stream)
+{
+    return ms_batch(m, feats_dev, total_frames, list_id_dev, list_dist_dev, senscr_dev, stream, true);
+}
+
+int32_t psgpu_ms_batch_needs_lists(const psgpu_ms_model_t *m)
+{
+    static const int no_cont = [] { const char *e = getenv("PSGPU_MS_NO_FUSED"); return e ? atoi(e) : 0; }();
+    return (m && m->cont && !no_cont && (m->d.featlen[0] == 13 || m->d.featlen[0] == 39)) ? 0 : 1;
+}
+int32_t psgpu_ms_list_entries_per_frame(const psgpu_ms_model_t *m) { return m ? m->d.n_mgau * m->d.n_feat * m->d.topn : 0; }
+
 int psgpu_ms_batch_check(psgpu_ms_model_t *m, void *stream)
 {
     PSGPU_REQUIRE(m != nullptr, "psgpu_ms_batch_check: NULL model");

@@ -1017,7 +1017,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (lane == 63 && n_listed_sen) atomicAdd(&s_nsen, n_listed_sen);
             if (lane == 63 && mn != 0x7fffffff) atomicMin(&s_nb, mn);
             ft_sync<SMALL>();
-            nb = s_nb;
+            nb = (raw_mode & 2) ? 0 : s_nb;              // (bit 1: the rows are final scores -- a scorer that does not normalise over the list)
             FT_PROF(2);
         }
         // ---- evaluate_channels (:605-715): s_red[0] every channel, [2] word level (ngs->last_phone_best_score: the

@@ -487,6 +487,9 @@ int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
     return PSGPU_OK;
 }
 
+int32_t psgpu_semi_n_sen(const psgpu_semi_model_t *m) { return m ? m->d.n_sen : 0; }
+int32_t psgpu_semi_veclen(const psgpu_semi_model_t *m) { return m ? m->veclen : 0; }
+
 int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, const int32_t *utt_off_dev,
                                int32_t n_utt, int32_t total_frames, int16_t *senscr_dev, void *stream)
 {

@@ -21,7 +21,10 @@ class _PlPar(C.Structure):
 class _Config(C.Structure):
     _fields_ = [("fe", C.c_void_p), ("model", C.c_void_p), ("ctx", C.c_void_p), ("ft", C.c_void_p), ("pl", _PlPar),
                 ("pl_ssid", C.c_void_p), ("pl_tmatid", C.c_void_p), ("ci_list", C.c_void_p), ("n_ci_list", C.c_int32),
-                ("pl_window", C.c_int32), ("max_words", C.c_int32)]
+                ("pl_window", C.c_int32), ("max_words", C.c_int32), ("scorer_kind", C.c_int32), ("scorer", C.c_void_p)]
+
+
+SCORER_PTM, SCORER_SEMI, SCORER_MS = 0, 1, 2
 
 
 class DecodeView(C.Structure):
@@ -49,19 +52,37 @@ class DecodePipeline:
     loop's parameters as `ref_dump fwdtree` writes them (pl_par = n_phones, window, beam, pbeam, pip, pl_window;
     pl_weight; pl_ssid; pl_tmat); lm: an NGramTrieLM or None (dense table in `static`)."""
 
-    def __init__(self, fe_tables, ptm_tables, static, par, trace, lm=None, max_words=512):
-        self.fe = FrontEnd(fe_tables)
-        self.model = PtmModel(ptm_tables)
+    def __init__(self, fe_tables, ptm_tables, static, par, trace, lm=None, max_words=512, scorer=None):
+        """scorer: None -- the PTM scorer built from ptm_tables; or a SemiMgau / MsMgau object (then ptm_tables is not used):
+        the scorers acmod_init_am falls back to / is sent to by -senmgau (reference src/acmod.c:62-130).  fe_tables None: no
+        front end -- feature vectors come from the caller (run_feat), e.g. the s2_4x vectors of a semi-continuous model."""
+        from .ms import MsMgau
+        from .semi import SemiMgau
+        self.fe = FrontEnd(fe_tables) if fe_tables is not None else None
+        self.scorer = scorer
+        if scorer is None:
+            self.model = PtmModel(ptm_tables)
+            kind, sh, n_sen = SCORER_PTM, None, self.model.n_sen
+        elif isinstance(scorer, SemiMgau):
+            self.model = None
+            kind, sh, n_sen = SCORER_SEMI, scorer.m, scorer.n_sen
+        elif isinstance(scorer, MsMgau):
+            self.model = None
+            kind, sh, n_sen = SCORER_MS, scorer.h, scorer.n_sen
+        else:
+            raise TypeError("scorer: None, a SemiMgau or an MsMgau")
+        self.n_sen = n_sen
+        self.veclen = scorer.veclen if scorer is not None else None
         self.search = FwdtreeSearch(static, par, lm=lm)
-        self.ctx = HmmContext(static["tp"], static["sseq"], self.model.n_sen)
+        self.ctx = HmmContext(static["tp"], static["sseq"], n_sen)
         self.max_words = int(max_words)
         pl = [int(v) for v in trace["pl_par"]]
         ssid = np.ascontiguousarray(trace["pl_ssid"], np.uint16)
         tmat = np.ascontiguousarray(trace["pl_tmat"], np.int16)
-        cil = ci_senone_list(static["sseq"], trace["pl_ssid"], self.model.n_sen)
-        cfg = _Config(self.fe.h, self.model.h, self.ctx.h, self.search.h,
+        cil = ci_senone_list(static["sseq"], trace["pl_ssid"], n_sen)
+        cfg = _Config(self.fe.h if self.fe is not None else None, self.model.h if self.model is not None else None, self.ctx.h, self.search.h,
                       _PlPar(pl[0], pl[1], pl[2], pl[3], pl[4], float(trace["pl_weight"][0])),
-                      ssid.ctypes.data, tmat.ctypes.data, cil.ctypes.data, int(cil.size), pl[5], self.max_words)
+                      ssid.ctypes.data, tmat.ctypes.data, cil.ctypes.data, int(cil.size), pl[5], self.max_words, kind, sh)
         self.h = C.c_void_p()
         capi.check(capi.lib().psgpu_decode_create(C.byref(self.h), C.byref(cfg)), "psgpu_decode_create")
         self.n_utt = 0
@@ -70,7 +91,11 @@ class DecodePipeline:
         if getattr(self, "h", None):
             capi.lib().psgpu_decode_free(self.h)
             self.h = None
-            self.search.close(); self.ctx.close(); self.model.close(); self.fe.close()
+            self.search.close(); self.ctx.close()
+            if self.model is not None:
+                self.model.close()
+            if self.fe is not None:
+                self.fe.close()
 
     def __del__(self):
         try:
@@ -134,6 +159,19 @@ class DecodePipeline:
         st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
         self.n_utt = n
         capi.check(capi.lib().psgpu_decode_first_pass(self.h, ptrs, lens, n, st), "psgpu_decode_first_pass")
+        self._stream = st
+
+    def run_feat(self, feats, utt_lens, stream=None):
+        """psgpu_decode_first_pass_feat: feature vectors from the host, [total][veclen] float32 as feat_s2mfc2feat_live leaves
+        them in acmod->feat_buf, utterances back to back (utt_lens frames each)"""
+        import torch
+        feats = np.ascontiguousarray(feats, np.float32)
+        off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(np.asarray(utt_lens, np.int64))
+        assert feats.ndim == 2 and feats.shape[0] == int(off[-1])
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        self.n_utt = len(utt_lens)
+        capi.check(capi.lib().psgpu_decode_first_pass_feat(self.h, feats.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p),
+                                                           self.n_utt, st), "psgpu_decode_first_pass_feat")
         self._stream = st
 
     def fetch(self, want_hyp=True):
