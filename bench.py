@@ -75,15 +75,16 @@ def synth_pcm(first_id, n_utt, seconds):
 
 
 def _ref_one(job):
-    exe, model, lm, dic, path, n_samples = job
-    out = subprocess.run([exe, model, lm, dic, path, str(n_samples)], capture_output=True, text=True, timeout=1800)
+    exe, model, lm, dic, path, n_samples, extra = job
+    out = subprocess.run([exe, model, lm, dic, path, str(n_samples)] + (["--"] + list(extra) if extra else []), capture_output=True,
+                         text=True, timeout=1800)
     lines = [json.loads(ln) for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     if out.returncode != 0 or not lines or "total" not in lines[-1]:
         raise RuntimeError("ref_decode_bench rc %d: %s" % (out.returncode, out.stderr[-300:]))
     return lines[:-1], lines[-1]
 
 
-def reference_decode(pcm, n_samples, ids, lm="turtle.lm.bin", dic="turtle.dic", procs=1):
+def reference_decode(pcm, n_samples, ids, lm="turtle.lm.bin", dic="turtle.dic", procs=1, model="en-us", extra=()):
     """the compiled reference on the same PCM: ([json per utterance, in the order of ids], totals); None when oracle/_ref is
     absent.  procs > 1: that many reference processes side by side, each one thread decoding its share of the utterances
     (pocketsphinx_batch's way to use a machine: one decoder per core, programs/pocketsphinx_batch.c) -- totals then carry
@@ -101,7 +102,7 @@ def reference_decode(pcm, n_samples, ids, lm="turtle.lm.bin", dic="turtle.dic", 
                 for i in sh:
                     pcm[i * n_samples:(i + 1) * n_samples].tofile(fh)
                 paths.append(fh.name)
-        jobs = [(exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", lm), os.path.join(ref, "data", dic), pth, n_samples)
+        jobs = [(exe, os.path.join(ref, "model", model), os.path.join(ref, "data", lm), os.path.join(ref, "data", dic), pth, n_samples, extra)
                 for pth in paths]
         t0 = time.perf_counter()
         if procs == 1:
@@ -213,6 +214,50 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
         w = lv.words_of(g)
         out["sample_hyp"] = " ".join(w[int(hyp[0, k, 0])] for k in range(min(int(hn[0, 0]), 12)))
     pipe.close()
+    del pcm
+    torch.cuda.empty_cache()
+    return out
+
+
+def ms_scorer_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, static, gt, n_utt, steps, n_check, with_cpu):
+    """BASELINE configs[3]'s per-GPU material: a batch of 64 utterances decoded with the multi-stream scorer (en-us through
+    ms_cont_mgau_frame_eval, the reference's -senmgau route: 42 codebooks x 3 streams x 128 densities, top-4 by full scan,
+    16-bit log-add) -- PCM -> hypotheses through the same device pipeline; the reference decodes n_check of them with that scorer"""
+    import torch
+    ms = P.MsMgau(_npz("ms_en_us_tables.npz"))
+    pipe = P.DecodePipeline(fe_tables, None, static, gt["par"], gt, scorer=ms)
+    pipe.stage_timing(True)
+    pcm = torch.from_numpy(pcm_all[:n_utt * n_samp]).to(dev)
+    soff = np.arange(n_utt + 1, dtype=np.int64) * n_samp
+    stream = torch.cuda.current_stream().cuda_stream
+    pipe.run_dev(pcm, soff, stream); pipe.fetch(want_hyp=False)
+    torch.cuda.synchronize()
+    stage = []
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run_dev(pcm, soff, stream)
+        hn, hyp, res = pipe.fetch()
+        stage.append(pipe.last_stage_ms())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / steps
+    frames = int(res[:, 2].sum())
+    st_mean = {k: float(np.mean([s_[k] for s_ in stage])) for k in stage[0]}
+    out = {"frames_per_s": round(frames / dt, 1), "ms_per_step": round(1e3 * dt, 2), "utterances": n_utt, "frames": frames,
+           "xrt": round(dt / (n_utt * seconds), 8), "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
+           "status_nonzero": int((res[:, 3] != 0).sum()),
+           "what": "configs[3]: %d utterances x %g s, en-us through the ms scorer (-senmgau .ptm.) + turtle LM, fwdtree only, PCM -> "
+                   "hypotheses on one MI355X (the per-GPU share of the 8-way shard; utterances shard as in the headline)" % (n_utt, seconds)}
+    if with_cpu:
+        ids = sorted(set(int(i) for i in np.linspace(0, n_utt - 1, min(n_check, n_utt))))
+        ref = reference_decode(pcm_all, n_samp, ids, procs=min(len(ids), max(1, (os.cpu_count() or 2) // 2)), model="en-us-ms",
+                               extra=("senmgau", ".ptm."))
+        if ref is not None:
+            utts, tot = ref
+            bad = parity_of(ids, utts, hn, hyp, res)
+            out["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                   "sample": "%d utterances, %.1f s of CPU in all, -senmgau .ptm. -fwdflat no -bestpath no" % (len(ids), tot["cpu_s"])}
+            out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad}
+    pipe.close(); ms = None
     del pcm
     torch.cuda.empty_cache()
     return out
@@ -552,6 +597,11 @@ def main():
             q.close()
         del pcm
         torch.cuda.empty_cache()
+        try:
+            line["decode_ms_scorer"] = ms_scorer_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"),
+                                                     _npz("fwdtree_static_en_us_turtle.npz"), gt, min(64, B), 2, 4, not args.no_cpu_baseline)
+        except Exception as e:
+            line["decode_ms_scorer"] = {"error": str(e)[-400:]}
         if not args.no_large_vocab:
             try:
                 line["decode_large_vocab"] = large_vocab_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,

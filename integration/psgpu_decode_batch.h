@@ -19,8 +19,10 @@ extern "C" {
 #define PSGPU_BATCH_DEVICE_FIRST_PASS 16u /* the WHOLE first pass of the batch on the device in one launch set: front end,
                                           * features, scores, phone loop, lexicon-tree search (psgpu_device_decode.h); the
                                           * workers only read the results out (ps_get_hyp / ps_seg_iter on the injected
-                                          * tables; with -fwdflat yes / -bestpath yes the reference's later passes run on
-                                          * them on the worker's host thread) */
+                                          * tables; with -bestpath yes the reference's lattice pass runs on them on the
+                                          * worker's host thread).  Needs -fwdflat no: psgpu_batch_init refuses the flag
+                                          * otherwise (the reference's second pass wants the utterance's feature vectors in
+                                          * acmod; behind ps_decode_raw -- psgpu_device_search_attach -- it has them) */
 
 typedef struct psgpu_batch_seg_s {
     char *word;

@@ -35,6 +35,7 @@
 #include "ngram_search_fwdflat.h"
 #include "phone_loop_search.h"
 #include "dict2pid.h"
+#include <stddef.h>
 #include "lm/ngram_model.h"
 #include "fe/fe_internal.h"
 
@@ -74,18 +75,20 @@ struct psgpu_device_decode_s {
 #define FREE_DEV(p) do { psgpu_free(p); (p) = NULL; } while (0)
 #define FREE_HOST(p) do { ckd_free(p); (p) = NULL; } while (0)
 
-/* one attachment per decoder: the vtable functions find it through this (the reference has no user pointer in
- * ps_search_t; decoders are few) */
-#define MAX_ATTACHED 64
-static psgpu_device_decode_t *g_attached[MAX_ATTACHED];
-
+/* The vtable functions find their attachment through the vtable itself: the function table a bound search points to
+ * (search->vt) is a member of the attachment (vt for the n-gram search, pl_vt for the phone loop), so its address gives the
+ * object -- no registry, no limit on the number of decoders, nothing shared between threads that use different decoders (the
+ * reference has no user pointer in ps_search_t). */
+static int dev_search_step(ps_search_t *search, int frame_idx);
+static int dev_phone_loop_step(ps_search_t *search, int frame_idx);
 static psgpu_device_decode_t *
 find_attached(ps_search_t *search)
 {
-    int i;
-    for (i = 0; i < MAX_ATTACHED; ++i)
-        if (g_attached[i] && (g_attached[i]->ps->search == search || g_attached[i]->ps->phone_loop == search))
-            return g_attached[i];
+    if (search == NULL || search->vt == NULL) return NULL;
+    if (search->vt->step == dev_search_step)
+        return (psgpu_device_decode_t *)((char *)search->vt - offsetof(psgpu_device_decode_t, vt));
+    if (search->vt->step == dev_phone_loop_step)
+        return (psgpu_device_decode_t *)((char *)search->vt - offsetof(psgpu_device_decode_t, pl_vt));
     return NULL;
 }
 
@@ -342,17 +345,14 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         psgpu_device_decode_detach(d);
         return NULL;
     }
-    for (i = 0; i < MAX_ATTACHED; ++i) if (g_attached[i] == NULL) { g_attached[i] = d; break; }
     return d;
 }
 
 void
 psgpu_device_decode_detach(psgpu_device_decode_t *d)
 {
-    int i;
     if (!d) return;
     psgpu_device_search_detach(d);
-    for (i = 0; i < MAX_ATTACHED; ++i) if (g_attached[i] == d) g_attached[i] = NULL;
     psgpu_decode_free(d->dec);
     psgpu_fwdflat_free(d->ff); FREE_DEV(d->d_seed); FREE_DEV(d->d_bp2); FREE_DEV(d->d_bss2); FREE_DEV(d->d_idx2); FREE_DEV(d->d_step2);
     FREE_DEV(d->d_res2); FREE_HOST(d->h_seed); FREE_HOST(d->h_tcw);

@@ -83,12 +83,21 @@ class DecodePipeline:
         cfg = _Config(self.fe.h if self.fe is not None else None, self.model.h if self.model is not None else None, self.ctx.h, self.search.h,
                       _PlPar(pl[0], pl[1], pl[2], pl[3], pl[4], float(trace["pl_weight"][0])),
                       ssid.ctypes.data, tmat.ctypes.data, cil.ctypes.data, int(cil.size), pl[5], self.max_words, kind, sh)
+        self._prev, self._next = None, []
         self.h = C.c_void_p()
         capi.check(capi.lib().psgpu_decode_create(C.byref(self.h), C.byref(cfg)), "psgpu_decode_create")
         self.n_utt = 0
 
     def close(self):
         if getattr(self, "h", None):
+            for q in list(getattr(self, "_next", [])):       # objects whose searches wait for this one's: unlinked first
+                if getattr(q, "h", None):
+                    capi.lib().psgpu_decode_search_after(q.h, None)
+                q._prev = None
+            self._next = []
+            if getattr(self, "_prev", None) is not None and self in self._prev._next:
+                self._prev._next.remove(self)
+            self._prev = None
             capi.lib().psgpu_decode_free(self.h)
             self.h = None
             self.search.close(); self.ctx.close()
@@ -107,6 +116,13 @@ class DecodePipeline:
         """This object's search waits (on the device) for the search of `prev`'s latest call -- two objects taking turns, one
         batch's front end and scorer beside the other's search: see psgpu_decode_search_after."""
         capi.check(capi.lib().psgpu_decode_search_after(self.h, prev.h if prev is not None else None), "psgpu_decode_search_after")
+        # (the C object keeps a bare pointer to prev: hold it here so that it cannot be collected first, and let go of
+        #  whoever waits on this object when it closes)
+        if getattr(self, "_prev", None) is not None and self in self._prev._next:
+            self._prev._next.remove(self)
+        self._prev = prev
+        if prev is not None:
+            prev._next.append(self)
 
     def wait_scored(self):
         capi.check(capi.lib().psgpu_decode_wait_scored(self.h), "psgpu_decode_wait_scored")
