@@ -492,6 +492,43 @@ def main():
     if dist is not None:
         dt = pbatch.max_over_ranks(dt, device=dev)
 
+    # ---- the same steps with the batch's PCM coming from HOST memory each step (the boundary handing over host buffers): a
+    #      pinned host buffer, two device buffers taking turns, the copy of step k + 1 on a stream of its own beside step k
+    pcie = None
+    if dist is None and rank == 0 and not os.environ.get("PSGPU_BENCH_NO_PCIE"):
+        try:
+            pinned = torch.from_numpy(pcm_all[:B * n_samp]).pin_memory()
+            bufs = [pcm, torch.empty_like(pcm)]
+            cstream = torch.cuda.Stream(device=dev)
+            evs = [torch.cuda.Event() for _ in bufs]
+
+            def launch_h(k):
+                with torch.cuda.stream(cstream):
+                    bufs[k % 2].copy_(pinned, non_blocking=True)
+                    evs[k % 2].record(cstream)
+                streams[k % n_pipe].wait_event(evs[k % 2])
+                pipes[k % n_pipe].run_dev(bufs[k % 2], soff, streams[k % n_pipe].cuda_stream)
+
+            def run_h(n):
+                for k in range(n):
+                    launch_h(k)
+                    if k >= n_pipe - 1:
+                        finish(k - (n_pipe - 1), False)
+                for k in range(max(n - (n_pipe - 1), 0), n):
+                    finish(k, False)
+            run_h(2)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            run_h(args.steps)
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - th) / args.steps
+            pcie = {"ms_per_step": round(1e3 * dth, 3), "h2d_bytes_per_step": int(B * n_samp * 2),
+                    "what": "every step's PCM copied from pinned host memory (hipMemcpyAsync on a copy stream, double-buffered) before "
+                            "its front end: the rate a caller holding host buffers sees"}
+            del bufs, pinned
+        except Exception as e:
+            pcie = {"error": str(e)[-200:]}
+
     # this rank's own results (tables' sizes, status, workload counters); one step alone also gives the stages' times without
     # another batch beside them
     pipe.run_dev(pcm, soff, streams[0].cuda_stream)
@@ -545,6 +582,8 @@ def main():
                    "frames_per_step_per_gpu": frames_rank, "lm": "turtle.lm.bin (115 dictionary words)",
                    "parallelism": "utt-shard x%d (rank 0 scatters PCM, gathers hypothesis records)" % world},
         "xrt": round((dt / args.steps) / audio_s, 9),
+        "pcie_inclusive": None if pcie is None else dict(pcie, **({"value": round(frames_step / (pcie["ms_per_step"] * 1e-3), 1), "unit": "frames/s"}
+                                                                  if "ms_per_step" in pcie else {})),
         "steps_in_flight": n_pipe,
         "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
         "stage_ms_one_step_alone": {k: round(v, 3) for k, v in stage_alone.items()},
@@ -560,7 +599,9 @@ def main():
                      "note": "a recurrence over frames: one workgroup per utterance, bound by the latency of one frame's dependent "
                              "steps, not by bytes (DESIGN.md 4); bytes = sum over frames of 156 + 2 x listed senones + 86 x HMM "
                              "evaluations (SURVEY 8d), counted by the kernel; kernel_ms = HIP events around the kernel in the timed "
-                             "region, i.e. with the other batch's front end and scorer running beside it"},
+                             "region, i.e. with the other batch's front end and scorer running beside it; traffic = HBM bytes per launch of "
+                             "this workload from the newest COMMITTED PMC profile (profiles/*_pmc_traffic.json, FETCH_SIZE x 2 + WRITE_SIZE): "
+                             "a constant of the repository, not a measurement of this run"},
     }
     # ---- cpu_baseline + parity: the compiled reference on a sample of the same utterances
     if not args.no_cpu_baseline:

@@ -596,6 +596,12 @@ __device__ __forceinline__ int ft_key_bp(unsigned long long k) { return 0x7fffff
 #ifndef PSGPU_FT_WAVES
 #define PSGPU_FT_WAVES 3
 #endif
+// PSGPU_FT_ROWS_DEVICE = 1: a launch that reads score ROWS (LDS layout) reads them where the scorer left them, in device
+// memory, instead of copying each frame's row into LDS one frame ahead: 10 KB less LDS per workgroup (en-us: 5126 x 2 bytes)
+#ifndef PSGPU_FT_ROWS_DEVICE
+#define PSGPU_FT_ROWS_DEVICE 0
+#endif
+constexpr bool kFtRowsDevice = PSGPU_FT_ROWS_DEVICE != 0;
 // (s_setprio 3 for this kernel's waves -- ahead of the co-runners' at the SIMD's arbiter -- changed nothing: 112.4 vs 111.9 ms
 //  per step; what a busy device costs the search is the latency of its device-memory accesses)
 constexpr int kFtWavesPerEu = PSGPU_FT_WAVES;
@@ -837,7 +843,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             lists_load(0);
             lists_norm();
         }
-        else {
+        else if (!kFtRowsDevice) {
             const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
             uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
             for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
@@ -867,7 +873,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //  transitions, are behind a barrier; its first reader, the pruning, is behind the barriers below)
         if (!SMALL && p.has_pl && tid < n_ci) s_penb[tid] = penalties[(size_t)pen_frame(f) * n_ci + tid];
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : s_penb;
-        const int16_t *const row = SMALL ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
+        constexpr bool ROW_LDS = SMALL && (LISTS || !kFtRowsDevice);          // the frame's row is in LDS
+        const int16_t *const row = ROW_LDS ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
@@ -1067,7 +1074,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         int32_t pre_pen = 0;
         if (SMALL && nf < T) {
             if (lists) lists_load(nf);
-            else row_fetch(nf);
+            else if (!kFtRowsDevice) row_fetch(nf);
             if (p.has_pl && tid < n_ci) pre_pen = penalties[(size_t)pen_frame(nf) * n_ci + tid];
         }
         // the frame's best scores are complete in s_red behind the barrier above and stay untouched until the next frame's top:
@@ -1880,7 +1887,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (SMALL && nf < T) {                               // the next frame's score row and penalties take their place
             if (lists) lists_norm();
 #if defined(__HIP_DEVICE_COMPILE__)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next row has landed in LDS (this wavefront's part)
+            else if (!kFtRowsDevice) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next row has landed in LDS (this wavefront's part)
 #endif
             if (p.has_pl && tid < n_ci) s_pen[nxt * n_ci + tid] = pre_pen;
         }
@@ -1970,7 +1977,7 @@ static bool ft_layout(FtDev &d, bool small)
     L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
     L.cand_mark = take(d.n_w);
     L.cand_wid = take(d.n_w + 1); L.cand_score = take(d.n_w + 1); L.cand_bp = take(d.n_w + 1);
-    L.o_out = take(d.N); L.o_outh = take(d.N); L.pos = take(d.N); L.flag = take(d.N); L.o_frame = take(d.N);
+    if (small) { L.o_out = take(d.N); L.o_outh = take(d.N); L.pos = take(d.N); L.flag = take(d.N); L.o_frame = take(d.N); }   // (the slab layouts keep the snapshot in the nodes' records)
     L.cnt = take(d.cnt_words);
     L.cnt2 = take(d.n_w + 2); L.cnt3 = take(d.n_w + 2); L.woff = take(d.n_w + 2); L.ckey = take(2 * ((int64_t)d.n_w + 2));
     L.present = take(((int64_t)d.TOT + 3) / 4);
@@ -1983,8 +1990,9 @@ static bool ft_layout(FtDev &d, bool small)
         L.dlast = take(d.n_w); L.homo = take(d.n_w); L.w1ci = take(d.n1); L.w1ci2 = take(d.n1); L.dfill = take(d.n_w);
         // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the lists, the
         // log-add table, the listed senones: a launch that reads score rows asks for less LDS
-        L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
-        const int64_t tail = 2 * (int64_t)kFtMaxChains + 512 / 4 + kFtListCap / 2 + kFtThreads / 64 * kSenStreams + 16;
+        if (!kFtRowsDevice) L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
+        const int64_t tail = 2 * (int64_t)kFtMaxChains + 512 / 4 + kFtListCap / 2 + kFtThreads / 64 * kSenStreams + 16
+                             + (kFtRowsDevice ? ((int64_t)d.n_sen + 1) / 2 + 8 : 0);
         // the frame's evaluation list takes what is left
         // (16-bit entries; a list of every channel when that fits -- then it cannot overflow -- else what is left)
         const int64_t left = ((int64_t)kFtLdsWords - o - tail) & ~(int64_t)3, full = (int64_t)d.R + d.N + d.n1 + d.TOT + 4;
@@ -1992,6 +2000,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.evl_cap = (int32_t)std::min<int64_t>(2 * left, full);
         L.evl = take((L.evl_cap + 1) / 2);
         L.rows_total = (int32_t)o;
+        if (kFtRowsDevice) L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);     // (scoring from lists computes the frame's scores into it)
         L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
         L.l_norm = take(kFtThreads / 64 * kSenStreams);
     }

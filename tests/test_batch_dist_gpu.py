@@ -76,3 +76,25 @@ def test_two_ranks_on_one_gpu_decode_their_blocks():
         seg = [(int(a), int(b)) for a, b in g["seg"][:, :2]]
         assert int(cnt[u, 0]) == len(seg) and int(cnt[u, 1]) == int(g["hyp_score"][0]), (u, n)
         assert [(int(r[1]), int(r[2])) for r in rec[u, :len(seg)]] == seg, (u, n)
+
+
+def test_bench_rccl_code_path_with_one_rank(tmp_path):
+    """bench.py's N > 1 code path -- init_process_group("nccl") (= RCCL), the PCM scatter before the timed region, the per-step
+    gather of the hypothesis records on a stream of its own, the MAX over ranks of the time -- run with ONE rank on this
+    one-GPU box (PSGPU_BENCH_FORCE_DIST), small workload, the reference's parity check on: it must produce the bench line"""
+    import json
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSGPU_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--utts", "8", "--seconds", "5",
+                          "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and j["config"]["utterances_per_gpu"] == 8
+    if j.get("cpu_baseline"):
+        assert j["parity"]["identical"] == j["parity"]["checked"] == 8

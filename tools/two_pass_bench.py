@@ -100,14 +100,41 @@ def main():
     dt = time.perf_counter() - t0
     fin = int(gt["par"][20])
     w0 = [w for w, _, _ in P.backtrace(r2[0], fin)[1]]
-    same = sum([w for w, _, _ in P.backtrace(r2[u], fin)[1]] == w0 for u in range(0, B, 17))
+    # parity of the sampled utterances: the compiled reference decodes the SAME PCM with both passes (-fwdflat yes -bestpath no,
+    # a new decoder's state per utterance) -- words, frame boundaries and path score of the second pass's hypothesis
+    ids = list(range(0, B, 17))
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_bench")
+    parity = {"checked": 0, "note": "oracle/_ref/ref_decode_bench not built"}
+    if os.path.exists(ref_exe):
+        import subprocess
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".raw", delete=False) as fh:
+            for u in ids:
+                pcm_h[u * ns:(u + 1) * ns].tofile(fh)
+            path = fh.name
+        try:
+            ref = os.path.join(ROOT, "oracle", "_ref")
+            o = subprocess.run([ref_exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", "turtle.lm.bin"),
+                                os.path.join(ref, "data", "turtle.dic"), path, str(ns), "--", "fwdflat", "yes", "bestpath", "no"],
+                               capture_output=True, text=True, timeout=300)
+            lines = [json.loads(ln) for ln in o.stdout.strip().splitlines() if ln.startswith("{")][:-1]
+        finally:
+            os.unlink(path)
+        bad = []
+        for u, r in zip(ids, lines):
+            score, words = P.backtrace(r2[u], fin)
+            if words != [(s_[1], s_[2], s_[3]) for s_ in r["seg"]] or score != r["score"]:
+                bad.append(u)
+        parity = {"checked": len(lines), "identical": len(lines) - len(bad), "mismatching_utterances": bad,
+                  "what": "second-pass hypothesis (word ids, start / end frames, path score) of every sampled utterance vs the reference's "
+                          "two-pass decode of the same PCM"}
     out.update(utterances=B, frames=Tn, audio_s=round(B * ns / 16000.0, 1), seconds=round(dt, 5), frames_per_s=round(Tn / dt, 1),
                xrt=round(dt / (B * ns / 16000.0), 8), first_pass_call_s=round(d1, 5), second_pass_call_s=round(d2, 5),
                second_pass_frames_per_s=round(Tn / d2, 1),
                status_nonzero=int(sum(r["status"] != 0 for r in r1) + sum(r["status"] != 0 for r in r2)),
                utt0_first_pass_table_is_reference=bool(np.array_equal(r1[0]["bp"], gf["bp1"])),
                utt0_second_pass_table_is_reference=bool(r2[0]["bp"].shape == gf["bp"].shape and np.array_equal(r2[0]["bp"], gf["bp"])),
-               sampled_hyps_equal_first="%d/%d" % (same, len(range(0, B, 17))), words_in_hyp=len(w0),
+               parity=parity, words_in_hyp=len(w0),
                what="PCM -> MFCC -> features -> PTM scores -> phone loop -> lexicon-tree search -> flat-lexicon search scoring its own "
                     "senones; call times include the Python wrappers' result read-back and, for the second pass, the host-side "
                     "vocabulary build from the first pass's table")
