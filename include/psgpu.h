@@ -647,6 +647,12 @@ void psgpu_lm_free(psgpu_lm_t *lm);
  * w2 / w1 may be -1 (no history, as the search passes it); n_used_dev may be NULL. */
 int psgpu_lm_tg_score_dev(const psgpu_lm_t *lm, const int32_t *w3_dev, const int32_t *w2_dev, const int32_t *w1_dev,
                           int64_t n, int32_t *score_dev, int32_t *n_used_dev, void *stream);
+/* For the NEXT search call on this handle only: step through all but the last `lag` frames of every utterance, with the
+ * penalties of all its frames available -- an utterance IN PROGRESS, as ps_search_forward (pocketsphinx.c:1173-1197) leaves
+ * the phone loop (at frame n) and the n-gram search (at frame n - pl_window) between two ps_process_raw calls.  The tables
+ * are then what the reference's search holds at that moment (ps_get_hyp in mid-utterance reads them).  0: the whole
+ * utterance (the default).  Like psgpu_fwdtree_hyp_out this is per-call state of the handle: one caller at a time. */
+int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag);
 /* Makes the tree search look its language scores up in `lm` (which must outlive it) instead of
  * the dense table of psgpu_fwdtree_tables_t.lm (which may then be NULL at create). */
 int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
@@ -777,6 +783,9 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
  * calls.  psgpu_decode_tables_grown = how many times that has happened since the object was created.  auto_grow = 0: an
  * utterance whose table fills up keeps status 1 and its hypothesis is that of the frames searched so far. */
 int psgpu_decode_table_capacity(psgpu_decode_t *d, int32_t bp_per_frame, int32_t bss_per_frame, int32_t auto_grow);
+/* the next psgpu_decode_first_pass* call only: psgpu_fwdtree_search_lag for its search (every stage before it runs over all
+ * frames) -- partial results of an utterance in progress */
+int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag);
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
  * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array. */

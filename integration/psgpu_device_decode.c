@@ -64,6 +64,7 @@ struct psgpu_device_decode_s {
     ps_searchfuncs_t vt, pl_vt;
     ps_searchfuncs_t *orig_vt, *orig_pl_vt;
     float *h_feat; int n_feat, cap_feat;
+    int pl_frames, n_partial;          /* frames the phone loop has been stepped through; n_feat of the latest partial read-out */
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
     psgpu_ptm_view_t view;
@@ -671,7 +672,7 @@ dev_search_start(ps_search_t *search)
 {
     psgpu_device_decode_t *d = find_attached(search);
     if (d == NULL) return -1;
-    d->n_feat = 0;
+    d->n_feat = 0; d->pl_frames = 0; d->n_partial = -1;
     return d->orig_vt->start(search);          /* ngram_search_start: tables, timers, <s> entered (ngram_search_fwdtree.c:469-520) */
 }
 
@@ -788,12 +789,73 @@ dev_search_finish(ps_search_t *search)
     return 0;
 }
 
-/* the look-ahead search of the host has nothing to do: the device pipeline runs its own (psgpu_phone_loop_run_dev) */
+/* the look-ahead search of the host has nothing to do: the device pipeline runs its own (psgpu_phone_loop_run_dev); how far
+ * it has been stepped is what a partial read-out needs (the frames ahead of the n-gram search are still in acmod's ring) */
 static int
 dev_phone_loop_step(ps_search_t *search, int frame_idx)
 {
-    (void)search; (void)frame_idx;
+    psgpu_device_decode_t *d = find_attached(search);
+    if (d && frame_idx + 1 > d->pl_frames) d->pl_frames = frame_idx + 1;
     return 1;
+}
+
+/* Results in mid-utterance (ps_get_hyp / ps_seg_iter between ps_process_raw calls, pocketsphinx.c:1372, ngram_search.c:845):
+ * the reference's search has stepped through n_feat frames by now and its phone loop through up to pl_window more; the same
+ * state on the device is the first pass over the frames seen so far with the search stopped n frames short
+ * (psgpu_decode_search_lag), from the session state the utterance started with; its tables go where the reference's
+ * read-out looks.  The utterance's final pass (dev_search_finish) starts over from the same session state. */
+static int
+partial_refresh(psgpu_device_decode_t *d, ngram_search_t *ngs)
+{
+    acmod_t *acmod = ps_search_acmod(ngs);
+    int T = d->pl_frames > d->n_feat ? d->pl_frames : d->n_feat, t, s;
+    int32_t off[2];
+    float *feat;
+    if (d->n_feat == 0 || d->n_partial == d->n_feat) return 0;
+    feat = ckd_calloc((size_t)T * d->veclen + 1, sizeof(float));
+    memcpy(feat, d->h_feat, (size_t)d->n_feat * d->veclen * sizeof(float));
+    for (t = d->n_feat; t < T; ++t) {                    /* the look-ahead frames: still in the ring */
+        int fi = feat_ring_index(acmod, t);
+        float *dst = feat + (size_t)t * d->veclen;
+        if (fi < 0) { T = t; break; }
+        for (s = 0; s < feat_dimension1(acmod->fcb); ++s) {
+            memcpy(dst, acmod->feat_buf[fi][s], feat_dimension2(acmod->fcb, s) * sizeof(float));
+            dst += feat_dimension2(acmod->fcb, s);
+        }
+    }
+    off[0] = 0; off[1] = T;
+    if (refresh(d) < 0 || session_push(d, ngs) < 0
+        || psgpu_decode_search_lag(d->dec, T - d->n_feat) != PSGPU_OK
+        || psgpu_decode_first_pass_feat(d->dec, feat, off, 1, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+        E_ERROR("psgpu device search (partial result): %s\n", psgpu_last_error());
+        ckd_free(feat);
+        return -1;
+    }
+    ckd_free(feat);
+    if (fetch_summary(d, 1) < 0) return -1;
+    if (d->h_res[2] > 0 && fetch_and_inject(d, 0) < 0) return -1;
+    d->n_partial = d->n_feat;
+    return 0;
+}
+
+static char const *
+dev_search_hyp(ps_search_t *search, int32 *out_score)
+{
+    psgpu_device_decode_t *d = find_attached(search);
+    ngram_search_t *ngs = (ngram_search_t *)search;
+    if (d == NULL) return NULL;
+    if (!ngs->done && partial_refresh(d, ngs) < 0) return NULL;
+    return d->orig_vt->hyp(search, out_score);
+}
+
+static ps_seg_t *
+dev_search_seg_iter(ps_search_t *search)
+{
+    psgpu_device_decode_t *d = find_attached(search);
+    ngram_search_t *ngs = (ngram_search_t *)search;
+    if (d == NULL) return NULL;
+    if (!ngs->done && partial_refresh(d, ngs) < 0) return NULL;
+    return d->orig_vt->seg_iter(search);
 }
 
 int
@@ -815,7 +877,8 @@ psgpu_device_search_attach(psgpu_device_decode_t *d)
     }
     d->orig_vt = s->vt; d->vt = *s->vt;
     d->vt.start = dev_search_start; d->vt.step = dev_search_step; d->vt.finish = dev_search_finish;
-    s->vt = &d->vt;                              /* reinit / free / lattice / hyp / prob / seg_iter stay the reference's */
+    d->vt.hyp = dev_search_hyp; d->vt.seg_iter = dev_search_seg_iter;     /* (the reference's, behind a mid-utterance refresh) */
+    s->vt = &d->vt;                              /* reinit / free / lattice / prob stay the reference's */
     if (pl) {
         d->orig_pl_vt = pl->vt; d->pl_vt = *pl->vt;
         d->pl_vt.step = dev_phone_loop_step;

@@ -110,7 +110,7 @@ make_decoder(const char *modeldir, const char *lm, const char *dict, int argc, c
         const char *k = argv[i];
         if (k[0] == '-') ++k;
         if (!strcmp(k, "mllr_after") || !strcmp(k, "psgpu_mgau") || !strcmp(k, "psgpu_search")
-            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop") || !strcmp(k, "psgpu_device_search") || !strcmp(k, "psgpu_device_vtable"))
+            || !strcmp(k, "align_text") || !strcmp(k, "psgpu_fe") || !strcmp(k, "psgpu_phone_loop") || !strcmp(k, "psgpu_device_search") || !strcmp(k, "psgpu_device_vtable") || !strcmp(k, "chunked"))
             continue;                                  /* handled by main() */
         if (ps_config_set_str(config, k, argv[i + 1]) == NULL) {
             fprintf(stderr, "bad config %s=%s\n", k, argv[i + 1]); exit(2);
@@ -126,7 +126,11 @@ typedef struct result_s {
     int32 score;
     char seg[65536];               /* "word sf ef ascr lscr lback\n" ... */
     int n_frames;
+    char partial[65536];           /* "chunked N": "hyp|score;" after every ps_process_raw call of the utterance */
+    int n_partial;
 } result_t;
+
+static int g_chunk;                /* "chunked N": the utterance arrives N samples at a time, ps_get_hyp after each piece */
 
 static double
 now_s(void)
@@ -202,7 +206,22 @@ decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, re
         goto results;
     }
     ps_start_utt(ps);
-    if (mfcs)
+    res->partial[0] = 0; res->n_partial = 0;
+    if (g_chunk > 0 && pcm && !dev_fe) {
+        /* live decoding (ps_process_raw without full_utt, pocketsphinx.c:1220-1257): results in mid-utterance */
+        size_t at = 0, po = 0;
+        while (at < n) {
+            size_t k = n - at < (size_t)g_chunk ? n - at : (size_t)g_chunk;
+            int32 sc = 0;
+            const char *h;
+            ps_process_raw(ps, pcm + at, k, FALSE, FALSE);
+            at += k;
+            h = ps_get_hyp(ps, &sc);
+            if (po + 512 < sizeof res->partial) po += snprintf(res->partial + po, sizeof res->partial - po, "%s|%d;", h ? h : "", sc);
+            ++res->n_partial;
+        }
+    }
+    else if (mfcs)
         ps_process_cep(ps, mfcs, nfr, FALSE, TRUE);
     else if (dev_fe) {
         if (psgpu_process_raw_full(ps, g_fe, pcm, n) < 0) { fprintf(stderr, "device front end failed\n"); exit(3); }
@@ -234,7 +253,7 @@ main(int argc, char **argv)
     enum { MAX_IN = 512 };
     char *in_id[MAX_IN], *in_path[MAX_IN];
     int n_in = 0, n_res, u, total_frames = 0;
-    int nrep, r, i, ok = 1, bad_calls = 0, first_bad = -1, hyp_equal = 1, seg_equal = 1;
+    int nrep, r, i, ok = 1, bad_calls = 0, first_bad = -1, hyp_equal = 1, seg_equal = 1, partial_equal = 1, n_partial = 0;
     double t_cpu = 0, t_gpu = 0, t0;
     int use_mgau = 1;
 #ifdef PSGPU_SEARCH_HOOKS
@@ -290,6 +309,7 @@ main(int argc, char **argv)
         /* "psgpu_device_vtable yes": decoder B's n-gram search gets the device ps_searchfuncs_t (psgpu_device_search_attach)
          * and is then driven by the UNMODIFIED public calls below (ps_start_utt / ps_process_raw / ps_end_utt) */
         if (!strcmp(argv[i], "psgpu_device_vtable")) use_dv = use_dd = !strcmp(argv[i + 1], "yes");
+        if (!strcmp(argv[i], "chunked")) g_chunk = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "psgpu_fe") && !strcmp(argv[i + 1], "yes")) {
             g_fe = psgpu_fe_wrap(gpu->acmod->fe);
             if (!g_fe) { fprintf(stderr, "psgpu_fe_wrap failed\n"); return 3; }
@@ -365,6 +385,8 @@ main(int argc, char **argv)
             if (use_dv) { g_dd_frames += ((ngram_search_t *)gpu->search)->n_frame; }
             if (strcmp(ra[k].hyp, rb[k].hyp) || ra[k].score != rb[k].score) hyp_equal = 0;
             if (strcmp(ra[k].seg, rb[k].seg)) seg_equal = 0;
+            if (strcmp(ra[k].partial, rb[k].partial) || ra[k].n_partial != rb[k].n_partial) partial_equal = 0;
+            n_partial += ra[k].n_partial;
             total_frames += ra[k].n_frames;
             if (mfcs) ckd_free_2d(mfcs);
             free(pcm);
@@ -388,7 +410,7 @@ main(int argc, char **argv)
                 if (first_bad < 0) first_bad = i;
                 ++bad_calls;
             }
-    if (bad_calls || !hyp_equal || !seg_equal) ok = 0;
+    if (bad_calls || !hyp_equal || !seg_equal || !partial_equal) ok = 0;
 #ifdef PSGPU_SEARCH_HOOKS
     psgpu_search_stats(gpu, &hmm_batches, &hmm_evals);
     psgpu_search_detach(gpu);
@@ -408,7 +430,8 @@ main(int argc, char **argv)
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
                "\"cache_served\": %ld, \"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
                "\"total_frames\": %d, \"device_fe\": %s, \"pl_steps\": %d, \"pl_mismatch\": %d, \"pl_device_steps\": %ld, "
-               "\"pl_host_steps\": %ld, \"device_search_frames\": %ld, \"utts\": [",
+               "\"pl_host_steps\": %ld, \"device_search_frames\": %ld, \"partial_results\": %d, \"partial_equal\": %s, "
+               "\"last_partial_cpu\": \"%.200s\", \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
                hyp_equal ? "true" : "false", seg_equal ? "true" : "false",
@@ -416,7 +439,8 @@ main(int argc, char **argv)
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
                use_mgau ? psgpu_mgau_n_cache_served(gpu->acmod->mgau) : 0L,
                use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames, g_fe ? "true" : "false",
-               g_pln[0], pl_bad, pl_dev, pl_host, g_dd_frames);
+               g_pln[0], pl_bad, pl_dev, pl_host, g_dd_frames, n_partial, partial_equal ? "true" : "false",
+               ra[n_res - 1].n_partial ? (strrchr(ra[n_res - 1].partial, ';') ? ra[n_res - 1].partial + (strlen(ra[n_res - 1].partial) > 180 ? strlen(ra[n_res - 1].partial) - 180 : 0) : "") : "");
         for (u = 0; u < n_res; ++u)
             printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",
                    in_id[u % n_in], rb[u].hyp, rb[u].score);

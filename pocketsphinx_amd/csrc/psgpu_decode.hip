@@ -45,6 +45,7 @@ struct psgpu_decode_s {
     int32_t bp_pf = 16, bss_pf = 320, auto_grow = 1, n_grown = 0;
     int32_t *d_mpx_in = nullptr;          // session: the state the latest search STARTED from (a repeated search needs it again)
     bool last_chained = false, last_sess = false, searched = false;
+    int32_t lag_next = 0, last_lag = 0;   // psgpu_decode_search_lag: for the next call / what the latest call's search was given
     // the last call
     int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
     std::vector<int32_t> frame_off;
@@ -301,6 +302,7 @@ static int dec_search(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t mf,
     const bool chained = d->last_chained, sess = d->last_sess;
     // the hypotheses are the search kernel's last step
     if ((rc = psgpu_fwdtree_hyp_out(d->cfg.ft, d->d_hyp, d->d_hn, d->max_words))) return rc;
+    if ((rc = psgpu_fwdtree_search_lag(d->cfg.ft, d->last_lag))) return rc;
     // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
     if (d->lists)
         rc = psgpu_fwdtree_search_lists_dev(d->cfg.ft, &d->view, d->d_tsc, d->d_tcw, (int32_t)total, d->d_pen, d->d_off, n_utt, (int32_t)mf,
@@ -366,6 +368,7 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
         PSGPU_HIP(hipMemcpyAsync(d->d_mpx_in, d->d_mpx, 4 * (size_t)psgpu_fwdtree_n_mpx_channels(d->cfg.ft) * d->n_emit,
                                  hipMemcpyDeviceToDevice, st));
     d->last_chained = chained; d->last_sess = sess;
+    d->last_lag = d->lag_next; d->lag_next = 0;
     rc = dec_search(d, n_utt, total, mf, st);
     if (rc) return rc;
     if (d->ev_srch) { PSGPU_HIP(hipEventRecord(d->ev_srch, st)); d->srch_recorded = true; }
@@ -512,6 +515,13 @@ int psgpu_decode_view(const psgpu_decode_t *d, psgpu_decode_view_t *v)
     v->frame_off_dev = d->d_off; v->feat_dev = d->d_feat; v->topn_cw_dev = d->d_tcw; v->topn_score_dev = d->d_tsc; v->rows_dev = d->d_rows; v->penalties_dev = d->d_pen;
     v->bp_dev = d->d_bp; v->bss_dev = d->d_bss; v->idx_dev = d->d_idx; v->step_dev = d->d_step; v->result_dev = d->d_res;
     v->hyp_dev = d->d_hyp; v->hyp_n_dev = d->d_hn; v->w1_ssid_dev = d->d_w1;
+    return PSGPU_OK;
+}
+
+int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag)
+{
+    PSGPU_REQUIRE(d && lag >= 0, "psgpu_decode_search_lag: bad argument");
+    d->lag_next = lag;
     return PSGPU_OK;
 }
 

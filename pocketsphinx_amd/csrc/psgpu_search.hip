@@ -116,6 +116,7 @@ struct FtBufs {
     int32_t max_words;
     long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][32] cycles per phase (tools/build_prof_lib.py)
     int32_t bp_cap, bss_cap, max_frames;
+    int32_t lag;                         // search all but the last `lag` frames of every utterance (psgpu_fwdtree_search_lag); 0: all
 };
 
 struct psgpu_fwdtree_s {
@@ -125,6 +126,7 @@ struct psgpu_fwdtree_s {
     size_t slab_words = 0;
     int32_t *hyp_out = nullptr, *hyp_n_out = nullptr;    // psgpu_fwdtree_hyp_out: for the NEXT search call only
     int32_t hyp_max_words = 0;
+    int32_t lag_next = 0;                // psgpu_fwdtree_search_lag: for the NEXT search call only
 };
 
 // ---- channel records ---------------------------------------------------------------------------------------------
@@ -744,7 +746,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 
     // an utterance shorter than the look-ahead window is never searched by the reference: ps_end_utt steps the main search
     // over the last pl_window frames only `if (output_frame >= pl_window)` (pocketsphinx.c:1329-1333)
-    const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0, T = (raw_mode && T_in < pl_window) ? 0 : T_in;
+    // (bf.lag > 0: an utterance in progress -- the phone loop has seen T_in frames, the search steps through the first
+    //  T_in - lag of them, as ps_search_forward leaves the two between calls, pocketsphinx.c:1173-1197)
+    const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0,
+              T = bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in);
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
     uint32_t evals_run = 0u;                             // HMM evaluations so far (ngs->st.n_hmm_eval; saturating: compared with maxhmmpf), likewise
@@ -804,7 +809,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
 #endif
     };
-    auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T - 1) : f); };
+    auto pen_frame = [&](int f) { return t0 + (raw_mode ? min(f + pl_window, T_in - 1) : f); };
     // scoring from lists: a frame's lists -- per (codebook, stream) chain four raw scores and four codewords -- travel one frame
     // ahead in registers like the score row does, 5 words a work-item instead of 16: loaded after the evaluation, the streams'
     // normalisers (ptm_mgau_codebook_norm, ptm_mgau.c:265-295: the maximum over the codebooks of best score >> 10) reduced per
@@ -2237,6 +2242,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     }
     bf.hyp = m->hyp_out; bf.hyp_n = m->hyp_n_out; bf.max_words = m->hyp_max_words;
     m->hyp_out = nullptr; m->hyp_n_out = nullptr; m->hyp_max_words = 0;      // (one call's worth)
+    bf.lag = m->lag_next; m->lag_next = 0;
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
     PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));
@@ -2310,6 +2316,13 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
         for (int i : order) fprintf(stderr, "  %2d %-48s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
     }
 #endif
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag)
+{
+    PSGPU_REQUIRE(m && lag >= 0, "psgpu_fwdtree_search_lag: bad argument");
+    m->lag_next = lag;
     return PSGPU_OK;
 }
 

@@ -501,6 +501,26 @@ def test_dropin_device_search_vtable(raw, nrep, extra, lm, dic):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("raw,chunk,extra", [
+    ("goforward.raw", 4096, ("fwdflat", "no", "bestpath", "no")),
+    ("numbers.raw", 2048, ("fwdflat", "no", "bestpath", "no")),
+    ("goforward.raw", 8000, ()),                         # the reference's later passes at the end, partial results before
+])
+def test_dropin_device_search_partial_results(raw, chunk, extra):
+    """live decoding through the device ps_searchfuncs_t: the utterance arrives `chunk` samples at a time
+    (ps_process_raw without full_utt, reference src/pocketsphinx.c:1220-1257) and ps_get_hyp is asked after every piece, as
+    a live application does (:1372, ngram_search_hyp, src/ngram_search.c:845).  The reference's search has then stepped
+    through output_frame - pl_window frames; the binding decodes the frames seen so far with the search stopped as far short
+    of the phone loop (psgpu_decode_search_lag) and injects that table.  EVERY partial hypothesis and score equals the CPU
+    decoder's, and so does the final result."""
+    r = run(raw, 1, "psgpu_device_vtable", "yes", "chunked", str(chunk), *extra)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["partial_equal"] and r["partial_results"] >= 5, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert any(part.split("|")[0].strip() for part in r["last_partial_cpu"].split(";") if "|" in part), r    # (words before the end)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [("fwdflat", "no", "bestpath", "no"), ()])
 def test_dropin_device_search_vtable_session(extra, tmp_path):
     """one decoder, four different utterances one after another through the device ps_searchfuncs_t: what an utterance
