@@ -683,7 +683,9 @@ typedef struct psgpu_decode_config_s {
      * search subtracts anything) or a psgpu_ms_model_t * (PSGPU_SCORER_MS: ms_cont_mgau_frame_eval, ms_mgau.c:192-282 -- rows of
      * senone_eval values, normalised over each call's own list with the int16 clamp of :269-277), the two scorers acmod_init_am
      * (acmod.c:62-130) falls back to / is sent to by -senmgau.  Both are stateless across utterances in this pipeline: every
-     * utterance is scored as by a new decoder; psgpu_decode_session and psgpu_decode_score_mode need the PTM scorer. */
+     * utterance is scored as by a new decoder.  psgpu_decode_score_mode needs the PTM scorer; psgpu_decode_session works with
+     * the ms scorer too (it has no history of its own: the search's carry-over is what a session then holds) and is refused
+     * for the semi-continuous one. */
     int32_t scorer_kind;
     void *scorer;
 } psgpu_decode_config_t;
@@ -694,6 +696,8 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
 void psgpu_decode_free(psgpu_decode_t *d);
 /* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
+/* the same for a pipeline created with PSGPU_SCORER_SEMI / PSGPU_SCORER_MS: the new handle of that kind, same shape */
+int psgpu_decode_set_scorer(psgpu_decode_t *d, void *scorer);
 /* Two pipeline objects taking turns.  The tree search is a latency-bound recurrence -- one workgroup per utterance, most
  * issue slots of its compute units idle -- and the stages before it are throughput-bound, so the front end and scorer of
  * one batch run BESIDE the search of another: one object per batch in flight, each on a stream with a hardware queue of

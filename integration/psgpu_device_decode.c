@@ -20,8 +20,9 @@
  * (flattened: roots, then depth-first), single-phone word channels, dictionary and dict2pid
  * tables, beams and penalties, the phone loop's HMMs and beams, and the language model -- the
  * model's own trie when it is one trie model without classes (psgpu_lm_tables.c), else, for small
- * vocabularies, every ngram_tg_score in a dense table.  Requires the n-gram search with -fwdtree
- * yes, the PTM scorer (psgpu_mgau_attach first), the 1s_c_d_dd feature type with batch CMN,
+ * vocabularies, every ngram_tg_score in a dense table.  The scorer is whichever psgpu scorer the decoder carries: PTM or
+ * multi-stream ("ms": any -senmgau model, models without a sendump).  Requires the n-gram search with -fwdtree
+ * yes, a psgpu scorer (psgpu_mgau_attach first), the 1s_c_d_dd feature type with batch CMN,
  * -compallsen no and the phone-loop look-ahead (pl_window > 0). */
 #include <stdlib.h>
 #include <string.h>
@@ -132,6 +133,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     psgpu_fwdtree_tables_t t;
     psgpu_decode_config_t cfg;
     psgpu_ptm_model_t *model;
+    struct psgpu_ms_model_s *msmodel;
     chan_t **nodes;
     node_ref_t *refs;
     int n_ci, n_emit, n_w, R, M, N, n1, i, j, k, w, n_tmat, n_sseq, lm_ok, want_ff;
@@ -156,11 +158,17 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         return NULL;
     }
     model = psgpu_mgau_ptm_model(acmod->mgau);
-    if (model == NULL) { E_ERROR("psgpu device decode: attach the psgpu PTM scorer first\n"); return NULL; }
+    msmodel = model ? NULL : psgpu_mgau_ms_model(acmod->mgau);
+    if (model == NULL && msmodel == NULL) {
+        E_ERROR("psgpu device decode: attach the psgpu scorer first (psgpu_mgau_attach: PTM or multi-stream model; the semi-continuous "
+                "scorer's history is not carried through the device pipeline)\n");
+        return NULL;
+    }
+    if (msmodel && want_ff) { E_ERROR("psgpu device decode: the device second pass scores from the PTM scorer's lists\n"); return NULL; }
     d = ckd_calloc(1, sizeof *d);
     d->ps = ps;
     d->n_ci = n_ci; d->n_sen = bin_mdef_n_sen(mdef);
-    d->n_chain = psgpu_ptm_n_chain(model); d->topn = psgpu_ptm_topn(model);
+    d->n_chain = model ? psgpu_ptm_n_chain(model) : 0; d->topn = model ? psgpu_ptm_topn(model) : 0;     /* (ms: no lists to carry) */
     d->cepsize = feat_cepsize(acmod->fcb); d->veclen = 3 * d->cepsize;
     d->n_words_at_attach = n_w; d->lmset_at_attach = ngs->lmset;
     /* ---- the search tables (cf. oracle/ref_dump.c cmd_fwdtree, which writes the same arrays to a file) */
@@ -326,6 +334,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         }
         memset(&cfg, 0, sizeof cfg);
         cfg.fe = d->fe; cfg.model = model; cfg.ctx = d->ctx; cfg.ft = d->ft;
+        if (model == NULL) { cfg.scorer_kind = PSGPU_SCORER_MS; cfg.scorer = msmodel; }
         cfg.pl.n_phones = pls->n_phones; cfg.pl.window = pls->window; cfg.pl.beam = pls->beam; cfg.pl.pbeam = pls->pbeam;
         cfg.pl.pip = pls->pip; cfg.pl.penalty_weight = pls->penalty_weight;
         cfg.pl_ssid = ps_ssid; cfg.pl_tmatid = ps_tm; cfg.ci_list = cil; cfg.n_ci_list = nl; cfg.pl_window = ps->pl_window;
@@ -369,13 +378,15 @@ refresh(psgpu_device_decode_t *d)
 {
     ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
     psgpu_ptm_model_t *model = psgpu_mgau_ptm_model(d->ps->acmod->mgau);
-    if (model == NULL) { E_ERROR("psgpu device decode: the psgpu PTM scorer is no longer attached\n"); return -1; }
+    struct psgpu_ms_model_s *msmodel = model ? NULL : psgpu_mgau_ms_model(d->ps->acmod->mgau);
+    if (model == NULL && msmodel == NULL) { E_ERROR("psgpu device decode: the psgpu scorer is no longer attached\n"); return -1; }
     if (dict_size(ps_search_dict(ngs)) != d->n_words_at_attach || ngs->lmset != d->lmset_at_attach) {
         E_ERROR("psgpu device decode: the dictionary or the language model changed after attach (ps_add_word / ps_set_lm): "
                 "detach and attach again\n");
         return -1;
     }
-    if (psgpu_decode_set_model(d->dec, model) != PSGPU_OK || (d->ff && psgpu_ptm_model_view(model, &d->view) != PSGPU_OK)) {
+    if ((model ? psgpu_decode_set_model(d->dec, model) : psgpu_decode_set_scorer(d->dec, msmodel)) != PSGPU_OK
+        || (d->ff && psgpu_ptm_model_view(model, &d->view) != PSGPU_OK)) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
@@ -748,7 +759,7 @@ dev_search_finish(ps_search_t *search)
         /* ... and the scorer's history: pass 2's first frame re-scores the lists pass 1 left in slot n_fast_hist - 1
          * (ptm_mgau.c:425-441), i.e. those of the last frame ts with ts % H == H - 1; the batch scorer has them
          * (chain-major [n_chain][T][topn]) */
-        {
+        if (d->n_chain > 0) {
             int H = d->ps->pl_window + 2, T = v.total_frames, ts = T - 1, c;
             size_t ne_all = (size_t)d->n_chain * T * d->topn;
             while (ts >= 0 && ts % H != H - 1) --ts;

@@ -593,6 +593,14 @@ psgpu_mgau_ptm_model(ps_mgau_t *ps)
     return ((psgpu_mgau_t *)ps)->model;
 }
 
+struct psgpu_ms_model_s *
+psgpu_mgau_ms_model(ps_mgau_t *ps)
+{
+    if (ps == NULL || ps->vt != &psgpu_ms_funcs)
+        return NULL;
+    return ((psgpu_mgau_t *)ps)->mmodel;
+}
+
 /* For a search component that consumes scores on the device (psgpu_phone_loop_shim.c):
  * announce what lies ahead of `frame` now, have it scored, and hand out the device rows. */
 int

@@ -165,7 +165,9 @@ int psgpu_decode_score_mode(psgpu_decode_t *d, int32_t lists)
 int psgpu_decode_session(psgpu_decode_t *d, int32_t on)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_session: NULL argument");
-    PSGPU_REQUIRE(!on || d->kind == PSGPU_SCORER_PTM, "psgpu_decode_session: sessions are carried for the PTM scorer only");
+    PSGPU_REQUIRE(!on || d->kind != PSGPU_SCORER_SEMI,
+                  "psgpu_decode_session: the semi-continuous scorer's top-N history is not carried between calls (the PTM scorer's is; "
+                  "the ms scorer has none)");
     d->session = on != 0;
     d->sess_started = false; d->seed_valid = false; d->fe_fresh = true;
     return PSGPU_OK;
@@ -234,6 +236,20 @@ int psgpu_decode_wait_scored(psgpu_decode_t *d)
 {
     PSGPU_REQUIRE(d && d->ev_pre, "psgpu_decode_wait_scored: psgpu_decode_search_after first");
     PSGPU_HIP(hipEventSynchronize(d->ev_pre));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_set_scorer(psgpu_decode_t *d, void *scorer)
+{
+    PSGPU_REQUIRE(d && scorer, "psgpu_decode_set_scorer: NULL argument");
+    PSGPU_REQUIRE(d->kind != PSGPU_SCORER_PTM, "psgpu_decode_set_scorer: the pipeline holds a PTM scorer (psgpu_decode_set_model)");
+    const int32_t ns = d->kind == PSGPU_SCORER_SEMI ? psgpu_semi_n_sen((const psgpu_semi_model_t *)scorer) : psgpu_ms_n_sen((const psgpu_ms_model_t *)scorer);
+    const int32_t vl = d->kind == PSGPU_SCORER_SEMI ? psgpu_semi_veclen((const psgpu_semi_model_t *)scorer) : psgpu_ms_veclen((const psgpu_ms_model_t *)scorer);
+    PSGPU_REQUIRE(ns == d->n_sen && vl == d->veclen, "psgpu_decode_set_scorer: the model has another shape");
+    if (scorer != d->cfg.scorer && d->kind == PSGPU_SCORER_MS) {          // (list buffers follow the model's top-N)
+        DFREE(d->d_ms_id); DFREE(d->d_ms_dist); d->cap_frames = 0;
+    }
+    d->cfg.scorer = scorer;
     return PSGPU_OK;
 }
 
@@ -334,7 +350,7 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
     else                                                 // no time dependence: frames of all utterances back to back
         rc = psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st);
     if (rc) return rc;
-    if (sess) {
+    if (sess && d->kind == PSGPU_SCORER_PTM) {
         // what seeds the next utterance's first frame: ptm_mgau_frame_eval copies frame 0's initial lists from slot
         // n_fast_hist - 1 of its history ring (ptm_mgau.c:425-441), H = n_fast_hist = pl_window + 2 (:865); that slot was last
         // written by the last frame ts with ts % H == H - 1 -- not by the last frame.  Shorter utterances leave it alone.

@@ -217,6 +217,28 @@ def test_ms_dropin_decode_identical(name, kw, extra):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,extra", [
+    ("an4", MS_KW_AN4, ()),                                               # + the reference's second and third pass
+    ("an4_first_pass", MS_KW_AN4, ("fwdflat", "no", "bestpath", "no")),
+    ("en_us_ms", MS_KW_ENUS, ("senmgau", ".ptm.", "fwdflat", "no", "bestpath", "no")),
+    ("en_us_ms_live", MS_KW_ENUS, ("senmgau", ".ptm.", "fwdflat", "no", "bestpath", "no", "chunked", "6000")),
+])
+def test_ms_dropin_device_search_vtable(name, kw, extra):
+    """BASELINE configs[3] behind ps_decode_raw: a decoder whose scorer is the multi-stream one (ms_cont_mgau_frame_eval,
+    reference src/ms_mgau.c:192-282 -- acmod_init_am's route for -senmgau and for models without a sendump, src/acmod.c:62-130)
+    with the device ps_searchfuncs_t bound: psgpu_device_search_attach takes the ms model out of the psgpu scorer and the
+    first pass -- ms scores, phone loop, lexicon-tree search -- runs on the MI355X, twice in a row (the second utterance
+    inherits the search's session state), the reference's own later passes on the injected table where configured.
+    Hypothesis, score and every segment equal the CPU decoder's; with `chunked` every partial hypothesis too."""
+    r = run("goforward.raw", 2, "psgpu_device_vtable", "yes", *extra, **kw)
+    assert r["ok"] and r["rc"] == 0, {k: v for k, v in r.items() if k != "utts"}
+    assert r["mgau"] == "ms-psgpu" and r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"]
+    assert r["device_search_frames"] > 0 and r["n_seg"] > 0
+    if "chunked" in extra:
+        assert r["partial_equal"] and r["partial_results"] >= 5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [(), ("fwdflat", "no", "bestpath", "no")])
 def test_large_vocabulary_dropin(extra):
     """126,052-word vocabulary (every base word of cmudict-en-us.dict, synthetic

@@ -73,8 +73,7 @@ def test_pipeline_with_the_ms_scorer_en_us(tmp_path):
     hn, hyp, res = p.fetch()
     for u, r in enumerate(refs):
         _same(u, r, hn, hyp, res, "en-us-ms utterance %d" % u)
-    with pytest.raises(P.PsgpuError):
-        p.session(True)                                   # (sessions are carried for the PTM scorer only: refused, not ignored)
+    p.session(True); p.session(False)                     # (the ms scorer has no history: a session carries the search's state only)
     p.close()
 
 
@@ -138,4 +137,6 @@ def test_pipeline_with_the_semi_continuous_scorer_tidigits(tmp_path):
         assert int(hn[u, 1]) == int(g["hyp_score"][0]), names[u]
     with pytest.raises(P.PsgpuError):
         p.run([np.zeros(16000, np.int16)])                # (from PCM this pipeline has no front end / another feature type: refused)
+    with pytest.raises(P.PsgpuError):
+        p.session(True)                                   # (this scorer's top-N history is not carried: refused, not ignored)
     p.close()
