@@ -69,6 +69,8 @@ struct FtLay {
     int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
     int32_t l_cw, l_sc, l_la, l_list, l_norm;    // small layout, scoring from top-N lists: the frame's lists (packed codewords / scores per
                                          // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
+    int32_t itb;                         // slab layouts: [R + N][4] per item (root / list position) out, out history, best, score[0] as the evaluation left them
+    int32_t act;                         // slab layouts: [2 N][3] the pruning's channel updates of the frame (node | kind << 28, score, history)
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
@@ -87,6 +89,11 @@ struct FtDev {
     int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci, has_pl;
     const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_pw, *parent, *kid_off, *kids;
     const int32_t *kids_ci;              // kids with the child's ci phone in the top byte (slab layouts: child | ci << 24)
+    // slab layouts: what the pruning and the senone marking ask about a node, as quads (one request each), shared by all
+    // utterances (8 MB at 248 k nodes: L2 / MALL resident):
+    const int32_t *node_q1;              // [N][4] parent | ci << 24, first child (index into kids), number of children, kids_ci[first child] or -1
+    const int32_t *node_q2;              // [N][4] penultimate-phone word, its last phone, its homophone link, 0
+    const int32_t *node_sen;             // [N][4 or 8] the node's senone ids (sseq[node_ssid]): states 0..n_emit-1, then 0
     const int32_t *homophone, *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx, *w1_of_word;
     const int32_t *d_pronlen, *d_first, *d_last, *d_last2, *d_base, *d_filler;
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
@@ -143,18 +150,16 @@ template <int NE> struct ChF {
     static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
 struct alignas(16) FtQuad { int32_t x, y, z, w; };
-// Slab layouts (tree state in device memory): a tree channel's record is followed, IN THE SAME 128-byte line for 3-state
-// models, by what the pruning step needs to know about the node -- so that everything a work-item asks about a node
-// comes back in one trip to device memory instead of one per array (five snapshot arrays + five static tables, each
-// access its own cache line):
-//   QA  {out score, out history, flag | (list position + 1) << 1, frame stamp}   what a CHILD's decision reads of its parent
-//   QB  {flag | (list position + 1) << 1, frame, score[0], frame stamp}          what a decision reads of the node itself
-//   QC  {ci phone, parent, first child (index into kids), number of children}    static, written once per utterance
-//   QD  {penultimate-phone word, its last phone, its homophone link, 0}          static
-// QA / QB are the pruning snapshot of a root or listed node, valid when their stamp is the current frame.
-template <int NE> struct TrF {
-    static constexpr int QA = ChF<NE>::REC, QB = QA + 4, QC = QA + 8, QD = QA + 12, REC = QA + 16;
-};
+// Slab layouts (tree state in device memory).  What a work-group pays there is the number of cache lines it touches per
+// frame, so a tree channel is ONE 64-byte record and everything else the pruning needs is either static and shared by all
+// utterances (FtDev::node_q1 / node_q2 / node_sen: the node's parent, phone, children, penultimate word, senones) or
+// written by the evaluation while it holds the record anyway:
+//   * the record's FRAME word of a non-root tree node holds its position + 1 in the CURRENT active list (the evaluation
+//     writes it; the pruning's clear resets it; <= 0: not listed) -- nobody reads a tree node's frame stamp in these layouts;
+//   * FtLay::itb holds, per root / list position, {out, out history, best, score[0]} as the evaluation left them: the
+//     pruning's item phase reads them in order (coalesced) instead of visiting every node's record again.
+// A decision reads the live record of the other node (child or parent); that is sound because the channel updates a frame's
+// decisions ask for are collected (FtLay::act) and applied after ALL of them have been taken.
 struct ChView {
     int32_t *b;
     int cst, fst;
@@ -277,6 +282,45 @@ __device__ __forceinline__ int32_t ch_eval_rec(int32_t *rec, const S &row, const
 #pragma unroll
         for (int i = 0; i < NE; ++i) rec[F::SENID + i] = h.senid[i];
     }
+    return b;
+}
+// The same for a TREE channel of the slab layouts: a non-root node's FRAME word receives `posword` (its position + 1 in the
+// active list: see the layouts' note above), and the four words the pruning's item phase wants come back in `item`
+template <int NE, typename S>
+__device__ __forceinline__ int32_t ch_eval_tree(int32_t *rec, const S &row, const uint8_t *tpall, const uint16_t *sseq, bool set_pos,
+                                                int32_t posword, FtQuad &item)
+{
+    using F = ChF<NE>;
+    constexpr int NQ = (F::WORDS + 3) / 4, NW = F::SENID / 4;
+    int32_t w[4 * NQ];
+    const FtQuad *src = reinterpret_cast<const FtQuad *>(rec);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) { const FtQuad q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    HmmRegs h;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        h.score[i] = i < NE ? w[F::SCORE + i] : kW;
+        h.history[i] = i < NE ? w[F::HIST + i] : -1;
+        h.senid[i] = i < NE ? (uint16_t)w[F::SENID + i] : 0;
+    }
+    h.out_score = w[F::OUT]; h.out_history = w[F::OUTH]; h.bestscore = w[F::BEST];
+    const uint8_t *tp = tpall + (size_t)w[F::TMAT] * NE * (NE + 1);
+    const int mpx = w[F::MPX];
+    int32_t b;
+    if (NE == 3) b = mpx ? vit3_mpx(h, tp, row, sseq) : vit3(h, tp, row);
+    else         b = mpx ? vit5_mpx(h, tp, row, sseq) : vit5(h, tp, row);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { w[F::SCORE + i] = h.score[i]; w[F::HIST + i] = h.history[i]; }
+    w[F::OUT] = h.out_score; w[F::OUTH] = h.out_history; w[F::BEST] = h.bestscore;
+    if (set_pos) w[F::FRAME] = posword;
+    FtQuad *dst = reinterpret_cast<FtQuad *>(rec);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) dst[k] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+    if (mpx) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) rec[F::SENID + i] = h.senid[i];
+    }
+    item = FtQuad{ h.out_score, h.out_history, h.bestscore, h.score[0] };
     return b;
 }
 // [OUT, OUTH, BEST, FRAME] of a record in device memory
@@ -623,7 +667,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #if defined(__HIPCC__)
     int32_t *const s_pool = ft_dyn_pool;                 // SMALL: kFtLdsWords words of dynamic LDS (the launch says so)
 #else
-    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 16 * NT + 16];     // (the workgroup simulator)
+    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 18 * NT + 16];     // (the workgroup simulator)
 #endif
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
@@ -640,7 +684,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     constexpr int kPrIC = SMALL ? 1 : 2 * NT;
     int32_t *const s_it_node = s_pool, *const s_it_out = s_pool + kPrIC, *const s_it_outh = s_pool + 2 * kPrIC,
             *const s_it_fp = s_pool + 3 * kPrIC, *const s_it_k0 = s_pool + 4 * kPrIC, *const s_it_par = s_pool + 5 * kPrIC,
-            *const s_it_sc0 = s_pool + 6 * kPrIC, *const s_it_poff = s_pool + 7 * kPrIC;       // (poff: kPrIC + 1 entries)
+            *const s_it_sc0 = s_pool + 6 * kPrIC, *const s_it_kid0 = s_pool + 7 * kPrIC,
+            *const s_it_poff = s_pool + 8 * kPrIC;                                            // (poff: kPrIC + 1 entries)
+    __shared__ int32_t s_nroot;          // slab layouts: roots evaluated in the frame
     __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
@@ -656,7 +702,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int32_t *const utt_off = psgpu_as_global(utt_off_);
     int32_t *const gs = psgpu_as_global(bf.slab) + (size_t)blockIdx.x * p.per;
     int32_t *const fb = SMALL ? s_pool : gs + p.g_fast;
-    constexpr int TREC = SMALL ? F::REC : TrF<NE>::REC;                            // slab layouts: record + pruning snapshot + the node's static data
+    constexpr int TREC = F::REC;
     const ChView tv = { fb + L.rec, SMALL ? 1 : TREC, SMALL ? p.CH : 1 };         // tree nodes [0, N), single-phone words [N, N + n1)
     const ChView wv = { gs + p.g_wrec, F::REC, 1 };                               // last-phone slots [0, TOT)
     int32_t *const word_active = fb + L.word_active, *const word_lat_idx = fb + L.word_lat_idx, *const lt_sf = fb + L.lt_sf,
@@ -710,6 +756,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const uint8_t *const tpall = SMALL ? reinterpret_cast<const uint8_t *>(fb + L.tp) : psgpu_as_global(p.tp);
     const uint16_t *const sseq = psgpu_as_global(p.sseq);
     const int32_t *const kids_ci = psgpu_as_global(p.kids_ci);
+    const FtQuad *const node_q1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q1)),
+                 *const node_q2 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q2));
+    const int32_t *const node_sen = psgpu_as_global(p.node_sen);
+    FtQuad *const itb = reinterpret_cast<FtQuad *>(fb + L.itb);        // slab layouts only
+    int32_t *const actl = fb + L.act;                                  // slab layouts only
     const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
     // the tree's structure: LDS copies in the small layout
     const int32_t *const kid_off = SMALL ? fb + L.kid_off : psgpu_as_global(p.kid_off), *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids),
@@ -761,23 +812,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
     for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
     if (SMALL) { for (int c = tid; c < N; c += NT) pos[c] = -1; }      // pos is kept at -1 between frames
-    else {
-        // slab layouts: the snapshot quads start unstamped, the node's static data is copied beside its state (TrF)
-        using T = TrF<NE>;
-        const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_p = psgpu_as_global(p.parent), *const g_c = psgpu_as_global(p.node_ci),
-                      *const g_w = psgpu_as_global(p.node_pw);
-        for (int c = tid; c < N; c += NT) {
-            int32_t *const r = tv.b + (size_t)c * TREC;
-            const int pw = g_w[c], k0 = g_ko[c];
-            *reinterpret_cast<FtQuad *>(r + T::QA) = FtQuad{ kW, -1, 0, -1 };
-            *reinterpret_cast<FtQuad *>(r + T::QB) = FtQuad{ 0, -1, kW, -1 };
-            *reinterpret_cast<FtQuad *>(r + T::QC) = FtQuad{ g_c[c], g_p[c], k0, g_ko[c + 1] - k0 };
-            *reinterpret_cast<FtQuad *>(r + T::QD) = FtQuad{ pw, pw >= 0 ? d_last[pw] : 0, pw >= 0 ? homophone[pw] : -1, 0 };
-        }
-    }
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
-        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0;
+        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0; s_nroot = 0;
     }
     {
         const int nwords = (p.n_sen + 31) >> 5;
@@ -925,11 +962,34 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         if (!lists) mn = min(mn, (int32_t)row[sen[k]]);
                     }
             };
-            for (int k0 = 0; k0 < n_items; k0 += NT) {
+            // slab layouts: the tree's items (roots, listed nodes) are not copied into the evaluation list -- the evaluation
+            // walks them in item order -- and a listed node's senones come from the static table (a root's depend on its
+            // left context: its record)
+            const int Rq = SMALL ? R : 0, naq = SMALL ? na : 0;
+            if (!SMALL) {
+                int n_act_root = 0;
+                for (int i0 = 0; i0 < R + na; i0 += NT) {
+                    const int i = i0 + tid;
+                    bool act_root = false;
+                    if (i < R) {
+                        act_root = tv.at(i, F::FRAME) == f;
+                        if (act_root && raw_mode) mark(tv, i);
+                    }
+                    else if (i < R + na && raw_mode) {
+                        const int node = aclc[i - R];
+                        const FtQuad a = *reinterpret_cast<const FtQuad *>(node_sen + (size_t)node * (NE <= 3 ? 4 : 8));
+                        mark_sen(a.x); mark_sen(a.y); mark_sen(a.z);
+                        if (NE == 5) { mark_sen(a.w); mark_sen(node_sen[(size_t)node * 8 + 4]); }
+                    }
+                    if (i0 < R) n_act_root += __popcll(__ballot(act_root));
+                }
+                if (lane == 0 && n_act_root) atomicAdd(&s_nroot, n_act_root);
+            }
+            for (int k0 = 0; k0 < n_items - (R - Rq) - (na - naq); k0 += NT) {
                 int k = k0 + tid, code = -1;
-                if (k < R) { if (tv.at(k, F::FRAME) == f) code = k; }
-                else if ((k -= R) < na) code = aclc[k];
-                else if ((k -= na) < n1) { if (tv.at(W1 + k, F::FRAME) == f) code = W1 + k; }
+                if (k < Rq) { if (tv.at(k, F::FRAME) == f) code = k; }
+                else if ((k -= Rq) < naq) code = aclc[k];
+                else if ((k -= naq) < n1) { if (tv.at(W1 + k, F::FRAME) == f) code = W1 + k; }
                 else if ((k -= n1) < nwc) {
                     const int i = ft_seg_find(woff, naw, k), r = k - woff[i], slot = wc_off[awlc[i]] + r;
                     if (present[slot]) {
@@ -956,15 +1016,21 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
         }
         ft_sync<SMALL>();
-        const int n_ev = s_nev;
-        if (n_ev > L.evl_cap) { if (tid == 0) s_sc[6] = 2; ft_sync<SMALL>(); break; }      // status 2: the LDS layout's list is full
+        const int n_evl = s_nev;                             // entries of the evaluation list (slab layouts: the word level's)
+        const int n_ev = n_evl + (SMALL ? 0 : s_nroot + na); // HMM instances evaluated this frame
+        if (n_evl > L.evl_cap) { if (tid == 0) s_sc[6] = 2; ft_sync<SMALL>(); break; }      // status 2: the LDS layout's list is full
         FT_PROF(0);
         auto word_slot = [&](int code) { return wc_off[awlc[(code >> 8) & 0x3fffff]] + (code & 255); };
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
-            for (int e = tid; e < n_ev; e += NT) {
+            for (int e = tid; e < n_evl; e += NT) {
                 const int c = evl_get(e);
                 if (c & kFtWordCh) ch_normalize<NE>(wv, word_slot(c), best_in); else ch_normalize<NE>(tv, c, best_in);
             }
+            if (!SMALL)
+                for (int i = tid; i < R + na; i += NT) {
+                    const int node = i < R ? i : aclc[i - R];
+                    if (i >= R || tv.at(node, F::FRAME) == f) ch_normalize<NE>(tv, node, best_in);
+                }
             __syncthreads();
         }
         int32_t nb = 0;
@@ -1039,7 +1105,23 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             int32_t b_all = kW, b_word = kW;
             FT_PROFW(0);
             FT_PROFD0();
-            for (int e = tid; e < n_ev; e += NT) {
+            if (!SMALL) {
+                // the tree's items in item order: the record comes in and goes out once; the evaluation leaves, for the pruning,
+                // the node's list position in its record and {out, out history, best, score[0]} in the item's compact slot
+                // (an idle root's slot says so in its last word; a root's says 1 there: no decision reads a root's score)
+                for (int i = tid; i < R + na; i += NT) {
+                    const int node = i < R ? i : aclc[i - R];
+                    int32_t *const rec = tv.b + (size_t)node * TREC;
+                    FtQuad it = FtQuad{ kW, -1, kW, 0 };
+                    if (i >= R || rec[F::FRAME] == f) {
+                        const int32_t sc = ch_eval_tree<NE>(rec, sr, tpall, sseq, i >= R, i - R + 1, it);
+                        b_all = max(b_all, sc);
+                        if (i < R) it.w = 1;
+                    }
+                    itb[i] = it;
+                }
+            }
+            for (int e = tid; e < n_evl; e += NT) {
                 const int c = evl_get(e);
                 if (c & kFtWordCh) {
                     const int32_t sc = ch_eval_rec<NE>(wv.b + (size_t)word_slot(c) * F::REC, sr, tpall, sseq);
@@ -1109,7 +1191,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 ft_sync<true>();
                 for (int i = tid; i < R + na; i += NT) {
                     const int c = i < R ? i : aclc[i - R];
-                    int32_t b = (best_score - tv.at(c, F::BEST)) / bw;
+                    int32_t b = (best_score - (SMALL ? tv.at(c, F::BEST) : itb[i].z)) / bw;
                     if (b >= 256) b = 255;
                     atomicAdd(&s_bins[b], 1);
                 }
@@ -1132,91 +1214,61 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if constexpr (!SMALL) {
         // ---- prune_root_chan + prune_nonroot_chan (:722-877) + the last-phone candidates (:824-870), slab layouts.
         //      The same order-free formulation as below (oracle prune_tree_list: items = the roots and the listed nodes; a
-        //      decision reads the snapshot of the node and of its parent and writes the node's own channel), arranged for
-        //      state that lives in DEVICE memory, where a frame costs (dependent trips to memory) x (work-items' loop
-        //      iterations), not instructions:
-        //        * everything a decision reads of a node is in the node's own 128-byte line (TrF: snapshot quads + static
-        //          data beside the channel record): one trip per node, not one per array;
-        //        * one work-item per (item, child) PAIR -- a pair's decision is a pure function of the two snapshots, so a
-        //          child that is itself listed is decided twice, by its own item (which writes) and by its parent's pair (which
-        //          only needs the outcome for the next list) -- no second walk over the children, no barrier in between;
-        //        * a work-item takes four pairs at a time and asks for all their lines before it looks at any;
-        //        * positions in the next active list = prefix sums over the pairs' outcomes in pair order (= list order:
-        //          an item's own entry, then its entered children in sibling order), in registers + LDS;
-        //        * the frame's penalty row, the chunk's items (their snapshot, children range, parent) in LDS.
-        //      (phase profile of the 134,865-word task before: 1.87 M cycles a frame, 75 % of them in these steps: every
-        //       access of a per-node array was a trip to HBM, made one after the other inside loops over the children)
+        //      decision is a function of the node's and its parent's state as the evaluation left them), arranged for
+        //      state that lives in DEVICE memory, where a frame costs the cache lines it touches and the instructions that
+        //      ask for them, not arithmetic:
+        //        * the items' side comes from the compact slots the evaluation filled (read in order) and from static
+        //          quads shared by all utterances; a node's record is touched only as some decision's OTHER node;
+        //        * one work-item per (item, child) PAIR, four consecutive pairs at a time with their loads asked for
+        //          together; a child that is itself listed is decided twice -- by its own item (whose outcome counts) and
+        //          by its parent's pair (which needs it for the next list);
+        //        * decisions only READ channels: what they ask to be done to a channel goes to a list and is applied when
+        //          every decision of the frame has been taken (so no snapshot of the channels is needed);
+        //        * positions in the next active list = prefix sums over the pairs' outcomes in pair order (= list order);
+        //        * the frame's penalty row and the chunk's items in LDS.
+        //      Facts the decisions rely on instead of reading them (checked on every node by the simulator's build):
+        //        a node that is NOT in the active list has been cleared when it left it (or was never entered): its frame is
+        //        below f and its scores are WORST_SCORE, so "frame < f || news > score" is true without looking, and its
+        //        first quad after an entry is known; a node that IS in the list was entered or retained for this frame.
+        //      (134,865-word task, phase profile: 1.87 M cycles a frame with the per-node loops of the formulation below,
+        //       1.0 M with pairs on a per-node snapshot line)
         {
-            using T = TrF<NE>;
             const int n_item = R + na;
-            // What a work-group pays for here is the NUMBER of scattered accesses it makes -- a compute unit's address path
-            // takes about one work-item's request per cycle, whatever its width -- more than the trips' latency: so few, wide
-            // requests, none that a fact about the lists answers:
-            //   a node that is NOT in the active list has been cleared when it left it (or was never entered): its frame is
-            //   below f and its scores are WORST_SCORE, so "frame < f || news > score" is true without looking;
-            //   a node that IS in the list was entered or retained for this frame: its frame is f.
-            // -- pass 1: snapshot of every item, into its own line.  Four items a work-item at a time.
-            for (int i0 = 0; i0 < n_item; i0 += 4 * NT) {
-                int node[4]; FtQuad qs[4]; int32_t sc0[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + u * NT + tid; node[u] = i < R ? i : (i < n_item ? aclc[i - R] : -1); }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (node[u] >= 0) {
-                        const int32_t *const r = tv.b + (size_t)node[u] * TREC;
-                        qs[u] = *reinterpret_cast<const FtQuad *>(r + F::OUT);      // out, out history, best, frame
-                        sc0[u] = r[F::SCORE];
-                    }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * NT + tid;
-                    if (node[u] < 0) continue;
-                    int32_t *const r = tv.b + (size_t)node[u] * TREC;
-                    const bool active = i < R ? qs[u].w >= f : true;
-                    const int32_t fp = ((active && qs[u].z > thresh) ? 1 : 0) | (i < R ? 0 : ((i - R + 1) << 1));
-                    *reinterpret_cast<FtQuad *>(r + T::QA) = FtQuad{ qs[u].x, qs[u].y, fp, f };
-                    *reinterpret_cast<FtQuad *>(r + T::QB) = FtQuad{ fp, f, sc0[u], 0 };
-                    if (i < R && (fp & 1)) r[F::FRAME] = nf;              // a retained root stays (no decision reads a root's frame)
-#ifdef PSGPU_FT_CHECK_LISTS
-                    if (i >= R && qs[u].w != f) { printf("listed node %d has frame %d in frame %d\n", node[u], qs[u].w, f); abort(); }
-#endif
-                }
-            }
-            __syncthreads();                                     // (device memory is exchanged: the snapshots)
-            FT_PROF(4);
-            int carry_l = 0, carry_c = 0;                        // entries of the next active list / candidates so far (uniform)
+            int carry_l = 0, carry_c = 0, carry_a = 0;           // next list's entries / candidates / channel updates so far (uniform)
             for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
-                // -- the chunk's items, two consecutive ones a work-item: snapshot, children range, parent -> LDS; pairs and
-                //    candidates counted
+                // -- the chunk's items, two consecutive ones a work-item -> LDS; pairs and candidates counted
                 int32_t np[2], kc[2], c_w[2], c_news[2], c_outh[2], c_homo[2], c_dl[2];
                 {
-                    int node[2]; FtQuad qa[2], qc[2]; int32_t s0[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) { const int i = c0 + 2 * tid + u; node[u] = i < R ? i : (i < n_item ? aclc[i - R] : -1); }
+                    int node[2]; FtQuad it[2], q1[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        qa[u] = FtQuad{ kW, -1, 0, -1 }; qc[u] = FtQuad{ 0, 0, 0, 0 }; s0[u] = kW;
-                        if (node[u] >= 0) {
-                            const int32_t *const r = tv.b + (size_t)node[u] * TREC;
-                            qa[u] = *reinterpret_cast<const FtQuad *>(r + T::QA); qc[u] = *reinterpret_cast<const FtQuad *>(r + T::QC);
-                            s0[u] = r[T::QB + 2];
-                        }
+                        const int i = c0 + 2 * tid + u;
+                        node[u] = i < R ? i : (i < n_item ? aclc[i - R] : -1);
+                        it[u] = FtQuad{ kW, -1, kW, 0 };
+                        if (i < n_item) it[u] = itb[i];
                     }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { q1[u] = FtQuad{ 0, 0, 0, -1 }; if (node[u] >= 0) q1[u] = node_q1[node[u]]; }
                     FtQuad qd[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int li = 2 * tid + u, i = c0 + li;
-                        const bool fl = node[u] >= 0 && (qa[u].z & 1);
-                        np[u] = node[u] >= 0 ? (i >= R ? 1 : 0) + (fl ? qc[u].w : 0) : 0;
-                        s_it_node[li] = node[u]; s_it_out[li] = qa[u].x; s_it_outh[li] = qa[u].y; s_it_fp[li] = qa[u].z;
-                        s_it_k0[li] = qc[u].z; s_it_par[li] = qc[u].y | (qc[u].x << 24); s_it_sc0[li] = s0[u];
+                        const bool active = i < R ? it[u].w != 0 : node[u] >= 0;
+                        const bool fl = active && it[u].z > thresh;
+                        const int32_t fp = (fl ? 1 : 0) | (i < R || node[u] < 0 ? 0 : ((i - R + 1) << 1));
+                        np[u] = node[u] >= 0 ? (i >= R ? 1 : 0) + (fl ? q1[u].z : 0) : 0;
+                        s_it_node[li] = node[u]; s_it_out[li] = it[u].x; s_it_outh[li] = it[u].y; s_it_fp[li] = fp;
+                        s_it_k0[li] = q1[u].y; s_it_par[li] = q1[u].x; s_it_sc0[li] = it[u].w; s_it_kid0[li] = q1[u].w;
+                        if (i < R && fl) tv.at(node[u], F::FRAME) = nf;     // a retained root stays (no decision reads this stamp before it is >= f)
                         // last-phone candidates of the item (:824-870): the words whose penultimate phone this node is, the
-                        // homophone chain in order; the first word's last phone and link lie in the node's line -- asked for
-                        // only by the items that can have candidates
-                        const int32_t news = qa[u].x + p.pip;
-                        c_news[u] = news; c_outh[u] = qa[u].y;
+                        // homophone chain in order; the first word, its last phone and link come as one static quad
+                        const int32_t news = it[u].x + p.pip;
+                        c_news[u] = news; c_outh[u] = it[u].y;
                         qd[u] = FtQuad{ -1, 0, -1, 0 };
-                        if (fl && (p.has_pl || news > lpt)) qd[u] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)node[u] * TREC + T::QD);
+                        if (fl && (p.has_pl || news > lpt)) qd[u] = node_q2[node[u]];
+#ifdef PSGPU_FT_CHECK_LISTS
+                        if (i >= R && node[u] >= 0 && tv.at(node[u], F::FRAME) != i - R + 1) { printf("listed node %d carries position %d at %d\n", node[u], tv.at(node[u], F::FRAME), i - R); abort(); }
+#endif
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -1282,46 +1334,54 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         }
                     }
                     FT_PROF(1);
-                    // a child's id and phone (static, shared by every utterance: the table stays in the L2)
+                    // a child's id and phone: the item's first child came with the item; the others from the static table
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         c[v] = -1; cci[v] = 0;
                         if (val[v]) {
                             if (q[v] < 0) { c[v] = s_it_node[li[v]]; cci[v] = (uint32_t)s_it_par[li[v]] >> 24; }
-                            else { const uint32_t kc_ = (uint32_t)kids_ci[s_it_k0[li[v]] + q[v]]; c[v] = (int)(kc_ & 0xffffffu); cci[v] = (int)(kc_ >> 24); }
+                            else {
+                                const uint32_t kc_ = q[v] == 0 ? (uint32_t)s_it_kid0[li[v]] : (uint32_t)kids_ci[s_it_k0[li[v]] + q[v]];
+                                c[v] = (int)(kc_ & 0xffffffu); cci[v] = (int)(kc_ >> 24);
+                            }
                         }
                     }
-                    // a child's side of the snapshot from its line; for an item's own entry, the PARENT's side from the parent's
-                    FtQuad qx[4];
+                    // the OTHER node's record: a child's {out, out history, best, position} -- for an item's own entry the
+                    // PARENT's (a root's last word is its frame stamp); a listed child's score[0] in a second request
+                    FtQuad qx[4]; int32_t csc[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        qx[v] = FtQuad{ 0, -1, kW, 0 };
+                        qx[v] = FtQuad{ kW, -1, kW, -1 };
                         if (val[v]) {
-                            if (q[v] < 0) qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)(s_it_par[li[v]] & 0xffffff) * TREC + T::QA);
-                            else qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)c[v] * TREC + T::QB);
+                            const int o_ = q[v] < 0 ? (s_it_par[li[v]] & 0xffffff) : c[v];
+                            qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)o_ * TREC + F::OUT);
                         }
                     }
-                    int32_t bit[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        bit[v] = 0;
+                        csc[v] = kW;
+                        if (val[v] && q[v] >= 0 && qx[v].w > 0) csc[v] = tv.b[(size_t)c[v] * TREC + F::SCORE];
+                    }
+                    int32_t bit[4], act[4], a_news[4], a_outh[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        bit[v] = 0; act[v] = 0; a_news[v] = 0; a_outh[v] = -1;
                         if (!val[v]) continue;
                         const bool self = q[v] < 0;
                         const int P = self ? (s_it_par[li[v]] & 0xffffff) : s_it_node[li[v]];
-                        // the parent's side: a root, or a node listed in this frame (stamp)
+                        // the parent's side: a root (active: its stamp is this frame's or the next's), or a node with a list position
                         const bool p_root = P < R;
-                        const int32_t p_fp = self ? qx[v].z : s_it_fp[li[v]];
-                        const bool p_active = p_root || !self || qx[v].w == f;
+                        const bool p_active = !self || (p_root ? qx[v].w >= f : qx[v].w > 0);
+                        const int p_pos = self ? (p_root ? -1 : qx[v].w - 1) : (s_it_fp[li[v]] >> 1) - 1;
+                        const bool p_flag = self ? (p_active && qx[v].z > thresh) : (s_it_fp[li[v]] & 1);
                         const int32_t p_out = self ? qx[v].x : s_it_out[li[v]], p_outh = self ? qx[v].y : s_it_outh[li[v]];
-                        const int p_pos = (p_fp >> 1) - 1;
-                        // the node's side: listed in this frame (stamp)?  then its score as the snapshot took it
-                        const int32_t c_fp = self ? s_it_fp[li[v]] : qx[v].x;
-                        const bool in_acl = self || (qx[v].y == f && (c_fp >> 1) != 0);
-                        const int c_pos = (c_fp >> 1) - 1;
-                        const bool retc = in_acl && (c_fp & 1);
-                        const int32_t c_score = self ? s_it_sc0[li[v]] : qx[v].z;
+                        // the node's side
+                        const bool in_acl = self || qx[v].w > 0;
+                        const int c_pos = self ? (s_it_fp[li[v]] >> 1) - 1 : qx[v].w - 1;
+                        const bool retc = self ? (s_it_fp[li[v]] & 1) : (in_acl && qx[v].z > thresh);
+                        const int32_t c_score = self ? s_it_sc0[li[v]] : csc[v];
                         const int32_t news = (p_active ? p_out : kW) + p.pip;
-                        const bool parent_can = p_active && (p_fp & 1) && (p.has_pl || news > npt) && (news + ft_pen(cci[v]) > npt);
+                        const bool parent_can = p_active && p_flag && (p.has_pl || news > npt) && (news + ft_pen(cci[v]) > npt);
                         const bool parent_first = p_root || !in_acl || p_pos < c_pos;
                         bool fire;                                   // (frame < f: exactly the nodes that are not listed, see above)
                         if (!in_acl) fire = parent_can;
@@ -1329,61 +1389,45 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         else fire = parent_can;
                         const bool entered_first = fire && parent_first;
                         const bool listed = fire && (p_root || !(in_acl && !parent_first && retc));
-#ifdef PSGPU_FT_CHECK_LISTS
-                        if (!in_acl && tv.at(c[v], F::FRAME) >= f) { printf("unlisted node %d has frame %d in frame %d\n", c[v], tv.at(c[v], F::FRAME), f); abort(); }
-#endif
-                        // The frame stamp of a TREE node is read by nobody in these layouts (membership is the list itself): it
-                        // is not kept up to date on the device (the simulator's build keeps it, for its checks).
-                        if (self) {                                  // the node's own entry: its channel is written here
-                            int32_t *const r = tv.b + (size_t)c[v] * TREC;
-                            static_assert(F::HIST == NE && F::OUT % 4 == 0, "record layout");
-                            if (!retc && !entered_first) {           // hmm_clear [+ hmm_enter]: four requests instead of ten
-                                if (NE == 3) {
-                                    *reinterpret_cast<FtQuad *>(r) = FtQuad{ fire ? news : kW, kW, kW, fire ? p_outh : -1 };
-                                    r[F::HIST + 1] = -1; r[F::HIST + 2] = -1;
-                                }
-                                else {
-#pragma unroll
-                                    for (int k = 0; k < NE; ++k) { r[F::SCORE + k] = kW; r[F::HIST + k] = -1; }
-                                    if (fire) { r[F::SCORE] = news; r[F::HIST] = p_outh; }
-                                }
-                                *reinterpret_cast<FtQuad *>(r + F::OUT) = FtQuad{ kW, -1, kW, fire ? nf : -1 };
-                            }
-                            else if (fire) { r[F::SCORE] = news; r[F::HIST] = p_outh; }
-#ifdef PSGPU_FT_CHECK_LISTS
-                            if (retc || fire) r[F::FRAME] = nf;
-#endif
+                        // what the decision does to the node's channel: 1 = entered (an unlisted node: cleared when it left the list,
+                        // so its whole first quad is known), 2 = entered (a listed node: score[0] and history[0]), 3 = cleared,
+                        // 4 = cleared, then entered
+                        a_news[v] = news; a_outh[v] = p_outh;
+                        if (self) {
+                            const bool clr = !retc && !entered_first;
+                            act[v] = clr ? (fire ? 4 : 3) : (fire ? 2 : 0);
                             bit[v] = (retc && !entered_first) ? 1 : 0;
                         }
                         else {
-                            if (!in_acl && fire) {                   // (a listed child is written by its own entry; an unlisted one was
-                                int32_t *const r = tv.b + (size_t)c[v] * TREC;     //  cleared when it left the list: its first quad is known)
-                                if (NE == 3) *reinterpret_cast<FtQuad *>(r) = FtQuad{ news, kW, kW, p_outh };
-                                else { r[F::SCORE] = news; r[F::HIST] = p_outh; }
-#ifdef PSGPU_FT_CHECK_LISTS
-                                r[F::FRAME] = nf;
-#endif
-                            }
+                            act[v] = (!in_acl && fire) ? 1 : 0;       // (a listed child is written by its own entry)
                             bit[v] = listed ? 1 : 0;
                         }
                     }
                     FT_PROF(13);
-                    // positions in the next active list: pair order
+                    // positions in the next active list and in the frame's list of channel updates: pair order
                     {
                         const int lane = tid & 63, wv_ = tid >> 6;
                         const int32_t sb = bit[0] + bit[1] + bit[2] + bit[3];
-                        const int32_t ib = ft_wave_incl<FtAdd>(sb);
-                        if (lane == 63) s_scan[wv_] = ib;
+                        const int32_t sa = (act[0] != 0) + (act[1] != 0) + (act[2] != 0) + (act[3] != 0);
+                        const int32_t ib = ft_wave_incl<FtAdd>(sb), ia = ft_wave_incl<FtAdd>(sa);
+                        if (lane == 63) { s_scan[wv_] = ib; s_scan[NT / 64 + wv_] = ia; }
                         FT_PROF(22);
                         ft_sync<true>();
                         FT_PROF(31);
-                        int32_t base = 0, tot = 0;
+                        int32_t base = 0, tot = 0, base_a = 0, tot_a = 0;
 #pragma unroll
-                        for (int w = 0; w < NT / 64; ++w) { const int32_t a_ = s_scan[w]; tot += a_; if (w < wv_) base += a_; }
-                        int o = carry_l + base + ib - sb;
+                        for (int w = 0; w < NT / 64; ++w) {
+                            const int32_t a_ = s_scan[w], b_ = s_scan[NT / 64 + w];
+                            tot += a_; tot_a += b_;
+                            if (w < wv_) { base += a_; base_a += b_; }
+                        }
+                        int o = carry_l + base + ib - sb, oa = carry_a + base_a + ia - sa;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) if (bit[v]) acln[o++] = c[v];
-                        carry_l += tot;
+                        for (int v = 0; v < 4; ++v) {
+                            if (bit[v]) acln[o++] = c[v];
+                            if (act[v]) { actl[3 * oa] = c[v] | (act[v] << 28); actl[3 * oa + 1] = a_news[v]; actl[3 * oa + 2] = a_outh[v]; ++oa; }
+                        }
+                        carry_l += tot; carry_a += tot_a;
                         ft_sync<true>();                             // (s_scan; the chunk's LDS arrays before the next chunk overwrites them)
                     }
                 }
@@ -1391,6 +1435,29 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             n_listed = carry_l;
             if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; }
+            __syncthreads();                                     // (device memory: every decision has been taken; the list of updates is complete)
+            // -- the channel updates
+            for (int e = tid; e < carry_a; e += NT) {
+                const int32_t code = actl[3 * e], news = actl[3 * e + 1], outh = actl[3 * e + 2];
+                const int kind = (int)((uint32_t)code >> 28);
+                int32_t *const r = tv.b + (size_t)(code & 0xffffff) * TREC;
+                static_assert(F::HIST == NE && F::OUT % 4 == 0, "record layout");
+                if (kind >= 3) {                                 // hmm_clear; the position word with it: the node leaves the list
+                    if (NE == 3) { r[F::HIST + 1] = -1; r[F::HIST + 2] = -1; }
+                    else {
+#pragma unroll
+                        for (int k = 1; k < NE; ++k) { r[F::SCORE + k] = kW; r[F::HIST + k] = -1; }
+                    }
+                    *reinterpret_cast<FtQuad *>(r + F::OUT) = FtQuad{ kW, -1, kW, -1 };
+                }
+                if (NE == 3 && kind != 2) {                      // the first quad is known: score[0..2], history[0]
+                    const bool ent = kind != 3;
+                    *reinterpret_cast<FtQuad *>(r) = FtQuad{ ent ? news : kW, kW, kW, ent ? outh : -1 };
+                }
+                else if (kind != 3) { r[F::SCORE] = news; r[F::HIST] = outh; }
+                else { r[F::SCORE] = kW; r[F::HIST] = -1; }
+            }
+            FT_PROF(4);
         }
         } else {
             // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation.  Work proportional to the active
@@ -1603,7 +1670,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             int32_t *const w_k = cnt, *const w_exit = cnt + wst, *const w_bp = cnt + 2 * wst, *const w_bss = cnt + 3 * wst;
             for (int i = tid; i < naw; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
             ft_sync<SMALL>();
-            for (int e = tid; e < n_ev; e += NT) {
+            for (int e = tid; e < n_evl; e += NT) {
                 const int c = evl_get(e);
                 if (!(c & kFtWordCh)) continue;
                 const int i = (c >> 8) & 0x3fffff, slot = word_slot(c);
@@ -1885,7 +1952,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) {
             step[f * 4] = s_sc[0]; step[f * 4 + 1] = s_sc[1]; step[f * 4 + 2] = s_sc[3]; step[f * 4 + 3] = n_listed;
             ++s_sc[7];
-            s_nev = 0;                                           // the next frame's evaluation list starts empty
+            s_nev = 0; s_nroot = 0;                              // the next frame's evaluation list starts empty
         }
         FT_PROF(27);
         n_acl_cur = n_listed; n_awl_cur = n_awl_nxt;
@@ -1977,7 +2044,7 @@ static bool ft_layout(FtDev &d, bool small)
     auto take = [&](int64_t n) { const int64_t r = o; o += (n + 3) & ~(int64_t)3; return (int32_t)r; };
     FtLay &L = d.lay;
     memset(&L, 0, sizeof L);
-    L.rec = take((int64_t)d.CH * (small ? words : rec + 16));           // (slab: TrF<NE>::REC words a channel)
+    L.rec = take((int64_t)d.CH * (small ? words : rec));
     L.acl0 = take(d.N); L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
     L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
     L.cand_mark = take(d.n_w);
@@ -2010,6 +2077,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.l_norm = take(kFtThreads / 64 * kSenStreams);
     }
     else {
+        L.itb = take(4 * ((int64_t)d.R + d.N)); L.act = take(3 * 2 * (int64_t)d.N + 16);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
         L.evl = take(L.evl_cap);
     }
@@ -2084,6 +2152,17 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
         std::vector<int32_t> kc(kids.size(), 0);
         for (int k = 0; k < d.M; ++k) kc[k] = (int32_t)((uint32_t)kids[k] | ((uint32_t)t->node_ci[kids[k]] << 24));
         d.kids_ci = ft_up(m, kc.data(), kc.size(), &rc);
+        const int nsq = d.n_emit <= 3 ? 4 : 8;
+        std::vector<int32_t> q1((size_t)d.N * 4, 0), q2((size_t)d.N * 4, 0), qs((size_t)d.N * nsq, 0);
+        for (int c = 0; c < d.N; ++c) {
+            const int k0 = kid_off[c], nk = kid_off[c + 1] - k0, pw = t->node_penult_wid[c];
+            q1[(size_t)c * 4] = (int32_t)((uint32_t)(parent[c] < 0 ? 0 : parent[c]) | ((uint32_t)t->node_ci[c] << 24));
+            q1[(size_t)c * 4 + 1] = k0; q1[(size_t)c * 4 + 2] = nk; q1[(size_t)c * 4 + 3] = nk > 0 ? kc[k0] : -1;
+            q2[(size_t)c * 4] = pw; q2[(size_t)c * 4 + 1] = pw >= 0 ? t->dict_last[pw] : 0; q2[(size_t)c * 4 + 2] = pw >= 0 ? t->homophone_set[pw] : -1;
+            for (int k = 0; k < d.n_emit; ++k) qs[(size_t)c * nsq + k] = t->sseq[(size_t)t->node_ssid[c] * d.n_emit + k];
+        }
+        d.node_q1 = ft_up(m, q1.data(), q1.size(), &rc); d.node_q2 = ft_up(m, q2.data(), q2.size(), &rc);
+        d.node_sen = ft_up(m, qs.data(), qs.size(), &rc);
     }
     d.node_pw = ft_up(m, t->node_penult_wid, d.N, &rc); d.parent = ft_up(m, parent.data(), d.N, &rc);
     d.homophone = ft_up(m, t->homophone_set, d.n_w, &rc);
@@ -2251,13 +2330,13 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
     const size_t pool_bytes = d.small ? sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total)
-                                      : sizeof(int32_t) * (size_t)(16 * (big ? kFtThreadsBig : kFtThreads) + 16);      // (slab: the pruning's item arrays)
+                                      : sizeof(int32_t) * (size_t)(18 * (big ? kFtThreadsBig : kFtThreads) + 16);      // (slab: the pruning's item arrays)
 #if defined(__HIPCC__)                    /* a pool that takes the workgroup's LDS beyond the default 64 KB (scoring from lists): say so once */
 #define FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
         if (pool_bytes + 4096 > 65536) {                                                                              \
             static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdtree_kernel<NE, NT, SMALL, LISTS>, \
                               hipFuncAttributeMaxDynamicSharedMemorySize,                                            \
-                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * (16 * (NT) + 16)));          \
+                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * (18 * (NT) + 16)));          \
             PSGPU_HIP(attr_rc);                                                                                       \
         }
 #else
