@@ -53,6 +53,8 @@ constexpr int kFtMaxChains = 128;      // (codebook, stream) chains whose lists 
 constexpr int kFtMinEvl = 512;         // the frame's evaluation list holds at least this many entries (LDS layout)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
+constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (32 KB)
+constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS
 constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
 
 // word offsets of the per-utterance arrays the tree level works on ("fast" arrays: LDS in the small layout, the
@@ -70,7 +72,7 @@ struct FtLay {
     int32_t l_cw, l_sc, l_la, l_list, l_norm;    // small layout, scoring from top-N lists: the frame's lists (packed codewords / scores per
                                          // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
     int32_t itb;                         // slab layouts: [R + N][4] per item (root / list position) out, out history, best, score[0] as the evaluation left them
-    int32_t act;                         // slab layouts: [2 N][3] the pruning's channel updates of the frame (node | kind << 28, score, history)
+    int32_t act;                         // slab layouts: [2 N][4] the pruning's channel updates of the frame (node | kind << 28, score, history, 0)
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
@@ -688,6 +690,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const s_it_poff = s_pool + 8 * kPrIC;                                            // (poff: kPrIC + 1 entries)
     __shared__ int32_t s_nroot;          // slab layouts: roots evaluated in the frame
     __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
+    // slab layouts: the frame's score row and the transition matrices in LDS too -- a channel's evaluation then asks device memory
+    // for its record only (the eight transition bytes and three senone scores of a 3-state HMM were eleven requests of their own)
+    __shared__ __attribute__((aligned(16))) int16_t s_rowb[SMALL ? 2 : kFtSlabSen];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tpb[SMALL ? 4 : kFtSlabTp];
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
     __shared__ long long s_prof[48], s_last, s_lastw[4], s_d0;
@@ -753,7 +759,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                   *const d_filler = psgpu_as_global(p.d_filler), *const rs_n = psgpu_as_global(p.rs_n), *const rs_ssid = psgpu_as_global(p.rs_ssid),
                   *const rs_cimap = psgpu_as_global(p.rs_cimap), *const ldiph = psgpu_as_global(p.ldiph), *const ci_tmat = psgpu_as_global(p.ci_tmat),
                   *const lmtab = psgpu_as_global(p.lm);
-    const uint8_t *const tpall = SMALL ? reinterpret_cast<const uint8_t *>(fb + L.tp) : psgpu_as_global(p.tp);
+    const uint8_t *const tpall = SMALL ? reinterpret_cast<const uint8_t *>(fb + L.tp) : s_tpb;
+    if (!SMALL) {
+        const uint8_t *const g_tp = psgpu_as_global(p.tp);
+        for (int i = tid; i < p.n_tmat * NE * (NE + 1); i += NT) s_tpb[i] = g_tp[i];
+    }
     const uint16_t *const sseq = psgpu_as_global(p.sseq);
     const int32_t *const kids_ci = psgpu_as_global(p.kids_ci);
     const FtQuad *const node_q1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q1)),
@@ -915,8 +925,21 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //  transitions, are behind a barrier; its first reader, the pruning, is behind the barriers below)
         if (!SMALL && p.has_pl && tid < n_ci) s_penb[tid] = penalties[(size_t)pen_frame(f) * n_ci + tid];
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : s_penb;
-        constexpr bool ROW_LDS = SMALL && (LISTS || !kFtRowsDevice);          // the frame's row is in LDS
-        const int16_t *const row = ROW_LDS ? s_row : senscr + (size_t)(t0 + f) * scr_stride;
+        constexpr bool ROW_LDS = SMALL && (LISTS || !kFtRowsDevice);          // the frame's row is in LDS (slab layouts: s_rowb, copied below)
+        constexpr bool kSlabRowLds = true;                   // (the slab layouts' row in LDS: +3 % on the 134,865-word task)
+        const int16_t *const row = ROW_LDS ? s_row : ((SMALL || !kSlabRowLds) ? senscr + (size_t)(t0 + f) * scr_stride : s_rowb);
+        if (!SMALL && kSlabRowLds) {
+            // (its last readers, the previous frame's evaluation, are behind barriers; its first readers -- the senone marks
+            //  below read the row for the normaliser -- are behind the barrier that follows)
+            const int16_t *const g = senscr + (size_t)(t0 + f) * scr_stride;
+            if (((scr_stride & 1) == 0) && (((uintptr_t)senscr & 3) == 0)) {
+                const uint32_t *g32 = reinterpret_cast<const uint32_t *>(g);
+                uint32_t *d32 = reinterpret_cast<uint32_t *>(s_rowb);
+                for (int i = tid; i < (p.n_sen + 1) >> 1; i += NT) d32[i] = g32[i];
+            }
+            else for (int i = tid; i < p.n_sen; i += NT) s_rowb[i] = g[i];
+            ft_sync<true>();
+        }
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
@@ -1319,14 +1342,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int p0 = 0; p0 < n_pair; p0 += 4 * NT) {
                     int li[4], q[4], c[4], cci[4]; bool val[4];
                     const int jb = p0 + 4 * tid;
+                    // (which item a pair belongs to: a bisection of the chunk's offsets in LDS.  Having the items' work-items write a
+                    //  descriptor per pair instead costs a barrier more per round: measured 5 % slower on the 134,865-word task.)
                     {
                         int l0 = jb < n_pair ? ft_seg_find(s_it_poff, kPrIC, jb) : 0;
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int j = jb + v;
                             val[v] = j < n_pair;
-                            // (the next pair's item: this one, its successor, or -- behind a run of items without pairs, e.g. idle
-                            //  roots -- found by a bisection of its own; poff[kPrIC] = n_pair > j ends every search)
                             if (val[v] && s_it_poff[l0 + 1] <= j) { ++l0; if (s_it_poff[l0 + 1] <= j) l0 = ft_seg_find(s_it_poff, kPrIC, j); }
                             li[v] = l0;
                             const int self = (c0 + l0 >= R) ? 1 : 0;
@@ -1425,7 +1448,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             if (bit[v]) acln[o++] = c[v];
-                            if (act[v]) { actl[3 * oa] = c[v] | (act[v] << 28); actl[3 * oa + 1] = a_news[v]; actl[3 * oa + 2] = a_outh[v]; ++oa; }
+                            if (act[v]) { reinterpret_cast<FtQuad *>(actl)[oa] = FtQuad{ c[v] | (act[v] << 28), a_news[v], a_outh[v], 0 }; ++oa; }
                         }
                         carry_l += tot; carry_a += tot_a;
                         ft_sync<true>();                             // (s_scan; the chunk's LDS arrays before the next chunk overwrites them)
@@ -1438,7 +1461,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             __syncthreads();                                     // (device memory: every decision has been taken; the list of updates is complete)
             // -- the channel updates
             for (int e = tid; e < carry_a; e += NT) {
-                const int32_t code = actl[3 * e], news = actl[3 * e + 1], outh = actl[3 * e + 2];
+                const FtQuad au = reinterpret_cast<const FtQuad *>(actl)[e];
+                const int32_t code = au.x, news = au.y, outh = au.z;
                 const int kind = (int)((uint32_t)code >> 28);
                 int32_t *const r = tv.b + (size_t)(code & 0xffffff) * TREC;
                 static_assert(F::HIST == NE && F::OUT % 4 == 0, "record layout");
@@ -2077,7 +2101,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.l_norm = take(kFtThreads / 64 * kSenStreams);
     }
     else {
-        L.itb = take(4 * ((int64_t)d.R + d.N)); L.act = take(3 * 2 * (int64_t)d.N + 16);
+        L.itb = take(4 * ((int64_t)d.R + d.N)); L.act = take(4 * 2 * (int64_t)d.N + 16);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
         L.evl = take(L.evl_cap);
     }
@@ -2297,6 +2321,9 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
                   m->d.n_sen, kFtMaxSen);
     PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdtree_search_dev: no language model (dense table or psgpu_fwdtree_set_lm)");
+    PSGPU_REQUIRE(m->d.n_sen <= kFtSlabSen && m->d.n_tmat * m->d.n_emit * (m->d.n_emit + 1) <= kFtSlabTp,
+                  "fwdtree: %d senones / %d transition matrices (the search keeps a frame's row of at most %d scores and %d bytes of "
+                  "matrices in LDS)", m->d.n_sen, m->d.n_tmat, kFtSlabSen, kFtSlabTp);
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE((senscr_dev || ls) && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdtree_search_dev: NULL device buffer");
