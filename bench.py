@@ -175,6 +175,16 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
     st_mean = {k: float(np.mean([s[k] for s in stage])) for k in stage[0]}
     search_s = st_mean["search"] * 1e-3
     par = g["par"]
+    traffic = None
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*largevocab*_pmc_traffic.json")), reverse=True):
+        try:       # the newest committed PMC pass of THIS leg at THIS batch size (tools/gpu_call_lvpmc.sh)
+            jt = json.load(open(tpath))
+            if jt.get("_workload", {}).get("leg") == "decode_large_vocab" and jt["_workload"].get("utterances") == n_utt \
+                    and jt["_workload"].get("seconds") == seconds and jt.get("fwdtree_kernel", {}).get("hbm_bytes_per_launch"):
+                traffic = round(jt["fwdtree_kernel"]["hbm_bytes_per_launch"])
+                break
+        except Exception:
+            continue
     out = {
         "metric": "frames/sec + xRT decode, en-us PTM 5126-senone n-gram fwdtree, 134,865-word dictionary (device first pass, PCM -> hypotheses)",
         "value": round(frames / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt, 2), "steps": steps,
@@ -189,11 +199,14 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
                             "back_pointers_per_utt": round(float(res[:, 0].mean()), 1), "score_stack_per_utt": round(float(res[:, 1].mean()), 1),
                             "words_per_hyp": round(float(hn[:, 0].mean()), 1), "table_growths": pipe.tables_grown()},
         "roofline": {"bound": "hbm", "kernel": "fwdtree_kernel<3, 1024, false, false>", "achieved": round(alg_bytes / search_s / 1e9, 2),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / search_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg_bytes / search_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(st_mean["search"], 2),
                      "note": "one 1024-work-item workgroup per utterance, all state in a per-utterance slab in device memory; bytes = sum over "
                              "frames of 156 + 2 x listed senones + 86 x HMM evaluations (SURVEY 8d), counted by the kernel; kernel_ms from HIP "
-                             "events on its launch stream; PMC traffic: profiles/ (tools/gpu_call_largevocab.sh)"},
+                             "events on its launch stream; traffic = L2-miss bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) of the newest "
+                             "COMMITTED PMC pass of this leg at this batch size (profiles/*largevocab*_pmc_traffic.json, "
+                             "tools/gpu_call_lvpmc.sh): a constant of the repository, not a measurement of this run; traffic / "
+                             "kernel time = the rate the memory system actually sustains"},
         "tables_from_reference_init_s": round(t_tab, 1),
     }
     if n_bad_status:
@@ -563,7 +576,7 @@ def main():
         try:       # the newest committed PMC pass OF THIS WORKLOAD (tools/prof_collect.py records what it profiled)
             j = json.load(open(tpath))
             k = j.get("fwdtree_kernel")
-            if k and j.get("_workload", {}).get("utterances") == B and j["_workload"].get("seconds") == args.seconds \
+            if k and not j.get("_workload", {}).get("leg") and j.get("_workload", {}).get("utterances") == B and j["_workload"].get("seconds") == args.seconds \
                     and k.get("hbm_bytes_per_launch"):
                 traffic = round(k["hbm_bytes_per_launch"])
                 break
