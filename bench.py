@@ -497,8 +497,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     run_steps(args.steps, True)
     torch.cuda.synchronize()
+    host_cpu_s = time.process_time() - c0                # this rank's host CPU inside the timed region (all its threads)
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -598,6 +600,10 @@ def main():
         "pcie_inclusive": None if pcie is None else dict(pcie, **({"value": round(frames_step / (pcie["ms_per_step"] * 1e-3), 1), "unit": "frames/s"}
                                                                   if "ms_per_step" in pcie else {})),
         "steps_in_flight": n_pipe,
+        "host": {"cpu_ms_per_step_per_rank": round(1e3 * host_cpu_s / args.steps, 3), "host_cpus": os.cpu_count(),
+                 "what": "host CPU time of one rank inside the timed region (launches, the fetch of the hypothesis records, the gather at N > "
+                         "1), per step: what a node's host cores must supply per GPU -- the host-side ceiling of SURVEY 8e is "
+                         "host_cpus / (N x this / ms_per_step) ranks"},
         "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
         "stage_ms_one_step_alone": {k: round(v, 3) for k, v in stage_alone.items()},
         "workload_counts": {"hmm_evals_per_frame": round(evals / max(frames_rank, 1), 2),
