@@ -590,7 +590,11 @@ int psgpu_fwdtree_search_session_dev(psgpu_fwdtree_t *m, const int16_t *senscr_d
                                      int32_t *mpx_ssid_out_dev, void *stream);
 /* The NEXT psgpu_fwdtree_search_*_dev call on this handle also writes each utterance's hypothesis, as
  * psgpu_fwdtree_backtrace_dev would (same layout): the walk over the table is the search kernel's last step, one launch
- * less per batch.  One call's worth: the search call clears it.  (NULL, NULL, 0) withdraws it. */
+ * less per batch.  One call's worth: the search call clears it.  (NULL, NULL, 0) withdraws it.
+ * EXCLUSIVE USE: a psgpu_fwdtree_t carries per-call state -- this hand-over, psgpu_fwdtree_search_lag's, and the one work
+ * slab its searches run in (grown on demand after synchronising the caller's stream only) -- so ONE caller, stream and
+ * search at a time per handle: give every pipeline object / host thread a handle of its own (the tables are a few MB; the
+ * Python mirror and integration/ create one per DecodePipeline / attachment). */
 int psgpu_fwdtree_hyp_out(psgpu_fwdtree_t *m, int32_t *hyp_dev, int32_t *hyp_n_dev, int32_t max_words);
 /* ngram_search_find_exit (ngram_search.c:500-544) + the backtrace of ngram_search_bp_hyp / the segment
  * iterator (:546-581, 903-1010) for every utterance of a batch, on the tables as the search left them:
@@ -710,7 +714,8 @@ int psgpu_decode_set_scorer(psgpu_decode_t *d, void *scorer);
  * hold LDS gets one workgroup per compute unit instead of two and takes twice as long, profiles/r03_overlap.txt).  The
  * caller alternates the objects and starts a call on one only when that object's previous results have been fetched.
  * psgpu_decode_wait_scored blocks the host until the latest call's stages before the search have finished.  prev = NULL
- * ends the arrangement; an object must not be freed while another names it as prev. */
+ * ends the arrangement; an object must not be freed while another names it as prev (psgpu_decode_search_after(x, NULL) first:
+ * the successor keeps a bare pointer; pocketsphinx_amd/decode.py does this in close()). */
 int psgpu_decode_search_after(psgpu_decode_t *d, psgpu_decode_t *prev);
 int psgpu_decode_wait_scored(psgpu_decode_t *d);
 /* a stream with a hardware queue of its own (streams of one priority may share a queue, and kernels of one queue never
