@@ -105,7 +105,7 @@ class FwdtreeSearch:
             d_mo = torch.zeros((n, n_mpx, ne), dtype=torch.int32, device=dev)
         capi.check(capi.lib().psgpu_fwdtree_search_session_dev(
             self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
-            int(bool(raw_scores)), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
+            int(raw_scores), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
             p(d_mo) if d_mo is not None else None, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
             "psgpu_fwdtree_search_session_dev")
         torch.cuda.current_stream().synchronize()       # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel

@@ -124,7 +124,7 @@ class SimFwdtreeSearch:
         mi = None if mpx_in is None else np.ascontiguousarray(mpx_in, np.int32).reshape(n, n_mpx, self.n_emit)
         mo = None if mpx_out is None else np.zeros((n, n_mpx, self.n_emit), np.int32)
         check(lib().psgpu_fwdtree_search_session_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
-                                                     p(bp), p(bss), p(idx), p(step), p(res), int(bool(raw_scores)), int(pl_window),
+                                                     p(bp), p(bss), p(idx), p(step), p(res), int(raw_scores), int(pl_window),
                                                      p(w1) if w1 is not None else None, p(mi) if mi is not None else None,
                                                      p(mo) if mo is not None else None, None),
               "psgpu_fwdtree_search_session_dev")

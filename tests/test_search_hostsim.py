@@ -205,3 +205,60 @@ def test_search_kernel_source_full_cmudict_own_active_lists(big_trace):  # noqa:
         raw[i, a] = (rows[i, a].astype(np.int32) + 777 - 5 * (i % 50)).astype(np.int16)
     _check(s.search(raw, pen, [rows.shape[0]], raw_scores=True, pl_window=0)[0], g, "cmudict raw")
     s.close(); lm.close()
+
+
+@pytest.mark.parametrize("layout", ["slab", "lds"])
+@pytest.mark.parametrize("lag", [1, 7, 10 ** 6])
+def test_search_kernel_source_stopping_short_of_the_last_frames(layout, lag):
+    """psgpu_fwdtree_search_lag: an utterance in progress (ps_search_forward, pocketsphinx.c:1173-1197 -- the n-gram search runs
+    behind the frames scored so far).  The tables are append-only and the golden trace records where each frame's entries
+    begin, so the search stopped `lag` frames early must hold exactly the golden's first bp_table_idx[T - lag] back-pointers and
+    the score-stack entries those own; a lag past the utterance's length searches nothing; and the request is one call's worth."""
+    g = _load("fwdtree_trace_goforward.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    with _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    T = rows.shape[0]
+    L = simlib.lib()
+    L.psgpu_fwdtree_search_lag.argtypes = [simlib.C.c_void_p, simlib.C.c_int32]
+    simlib.check(L.psgpu_fwdtree_search_lag(s.h, lag), "psgpu_fwdtree_search_lag")
+    r = s.search(rows, pen, [T])[0]
+    n = max(T - lag, 0)
+    assert r["status"] == 0 and r["n_frame"] == n
+    nbp = int(g["bp_table_idx"][n]) if n else 0
+    assert r["bp"].shape[0] == nbp and np.array_equal(r["bp"], g["bp"][:nbp])
+    assert np.array_equal(r["bp_table_idx"], g["bp_table_idx"][:n + 1])
+    later = g["bp"][nbp:, 5]                              # (column 5: s_idx, the first stack entry a back-pointer owns; -1 for
+    later = later[later >= 0]                             # single-phone words, which own none: ngram_search.c:476-480)
+    nbss = int(later[0]) if later.size else g["bscore_stack"].size
+    assert np.array_equal(r["bscore_stack"], g["bscore_stack"][:nbss if nbp else 0])
+    assert np.array_equal(r["step"][:n, :3], np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)[:n])
+    _check(s.search(rows, pen, [T])[0], g, "the call after")
+    s.close()
+
+
+@pytest.mark.parametrize("layout", ["slab", "lds"])
+def test_search_kernel_source_final_scores_mode(layout):
+    """raw_scores = 3 (psgpu.h): the kernel builds each frame's active senone list but the rows are FINAL scores -- a scorer that
+    does not normalise over that list (s2_semi_mgau_frame_eval, src/s2_semi_mgau.c:837-883: the tidigits trace).  The golden's
+    rows go in unchanged where the search asks, garbage everywhere else; with raw_scores = 1 the same input must NOT give the
+    trace (the listed senones' minimum is not 0 for this scorer), which is what separates the two modes."""
+    g = _load("fwdtree_trace_man_ah_2934za.npz")
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    with _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    off, act = g["step_act_off"], g["step_act"]
+    raw = np.random.default_rng(11).integers(-30000, 30000, rows.shape).astype(np.int16)
+    mins = []
+    for i in range(rows.shape[0]):
+        a = act[off[i]:off[i + 1]]
+        raw[i, a] = rows[i, a]
+        mins.append(int(rows[i, a].min()) if a.size else 0)
+    assert any(m != 0 for m in mins)
+    with _order("rev"):
+        _check(s.search(raw, pen, [rows.shape[0]], raw_scores=3, pl_window=0)[0], g, "final scores")
+    other = s.search(raw, pen, [rows.shape[0]], raw_scores=1, pl_window=0)[0]
+    assert other["bp"].shape != g["bp"].shape or not np.array_equal(other["bp"], g["bp"])
+    s.close()
