@@ -24,12 +24,22 @@
 #include <cstring>
 #include <vector>
 
+// Builds for the workgroup simulator (tests/hostsim: g++, no __HIPCC__) keep, beside the lazily maintained top-N lists of the
+// scoring mode, the lists as the reference maintains them -- every chain re-scored and re-ordered in every frame -- and stop
+// where a replayed list differs from them.  The product has none of this.
+#if !defined(__HIPCC__)
+#define PSGPU_FF_CHECK_LAZY 1
+#include <cstdio>
+#endif
+
 constexpr int kFfThreads = 256;
 constexpr int kFfMaxCi = 64;
 constexpr int kFfMaxSen = 8192;        // senones (LDS bitmap of the frame's active list, scoring mode)
 constexpr int kFfMaxEnt = 1024;        // (codebook, stream) chains x top-N entries held in LDS (en-us PTM: 126 x 4)
 constexpr int kFfMaxCb = 256;          // codebooks
 constexpr int kFfMaxTopn = 8;
+constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
+constexpr int kFfChanMask = (1 << 29) - 1, kFfClearBit = 1 << 29;   // FfUtt::elist entries
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
 // each frame's senone scores itself, as ptm_mgau_frame_eval does when the second pass calls it (ptm_mgau.c:408-454 with
@@ -77,7 +87,8 @@ struct FfUtt {
     int32_t *out, *outh, *best, *frame;  // [C]
     int32_t *senid;                      // [C][5]
     int32_t *tmat, *mpx, *rcid, *xflag;  // [C]
-    int32_t *elist;                      // [C] the frame's active channels (evaluation work list)
+    int32_t *elist;                      // [C] the frame's active channels (evaluation work list; bit 30: </s>'s root, bit 29: see the pruning)
+    int32_t *einfo;                      // [C] per entry of elist: position of the channel's word in the active word list << 10 | position in its chain
     int32_t *wchain, *wlen;              // [n_w] chain offset (channel index) or -1, chain length
     int32_t *word_active, *word_lat_idx; // [n_w] (word_active: frame stamp)
     int32_t *awl[2];                     // [awl_cap]
@@ -91,7 +102,7 @@ struct FfUtt {
 // What the kernel is actually handed per utterance: the same fields as offsets (in int32 units) from buffers that are
 // kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
 // wait counters); pointers formed from a kernel argument are global.
-#define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(wchain) \
+#define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(einfo) X(wchain) \
     X(wlen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
 #define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf)
 struct FfOff {
@@ -307,6 +318,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ uint16_t s_slist[RAW ? 1024 : 1];
     __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64];
+#ifdef PSGPU_FF_CHECK_LAZY
+    __shared__ int32_t s_shadow[RAW ? kFfMaxEnt : 1];
+#endif
+    __shared__ int32_t s_lk[RAW ? kFfMaxEnt / 4 : 1];    // per chain: the last frame after which s_lcw holds its list (-1: the seed)
+    __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, -, -, length of the evaluation list
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
@@ -367,6 +383,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     const int n_chain = RAW ? rw.pm.n_mgau * rw.pm.n_feat : 0, topn = RAW ? rw.pm.topn : 0;
     if (RAW) {
         for (int i = tid; i < n_chain * topn; i += kFfThreads) { s_lcw[i] = rw.seed[(size_t)blockIdx.x * n_chain * topn + i]; s_lsc[i] = 0; }
+        for (int i = tid; i < n_chain && i < kFfMaxEnt / 4; i += kFfThreads) s_lk[i] = -1;
+#ifdef PSGPU_FF_CHECK_LAZY
+        for (int i = tid; i < n_chain * topn; i += kFfThreads) s_shadow[i] = s_lcw[i];
+#endif
         for (int i = tid; i < 512; i += kFfThreads) s_la[i] = (i < rw.pm.logadd8_size && i < 256) ? rw.pm.logadd8[i] : 0;
     }
     __syncthreads();
@@ -378,14 +398,18 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
         //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
         //      profiles/r03_fwdflat_phase_profile.txt).  Nothing between here and the evaluation changes a channel's frame stamp.
-        if (tid == 0) s_sc[7] = 0;
+        if (tid == 0) { s_sc[7] = 0; s_nfan = 0; }
         __syncthreads();
-        for (int i = tid; i < na; i += kFfThreads) {
+        for (int i = tid >> 4; i < na; i += kFfThreads / 16) {          // sixteen work-items a word: its chain's stamps read side by side
             const int w = u.awl[cur][i];
             int len; const int c0 = ff_root(p, u, w, len);
-            for (int k = 0; k < len; ++k)
-                if (u.frame[c0 + k] == f)                     // bit 30: the root of </s>, which does not count towards the best score
-                    u.elist[atomicAdd(&s_sc[7], 1)] = (c0 + k) | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
+            if ((tid & 15) == 0) { u.cnt_a[i] = 0; u.cnt_b[i] = 0; }     // (the pruning's exit flags, see there)
+            for (int k = tid & 15; k < len; k += 16)
+                if (u.frame[c0 + k] == f) {                   // bit 30: the root of </s>, which does not count towards the best score
+                    const int pos = atomicAdd(&s_sc[7], 1);
+                    u.elist[pos] = (c0 + k) | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
+                    u.einfo[pos] = (i << 10) | k;
+                }
         }
         __syncthreads();
         const int n_eval = s_sc[7];
@@ -400,7 +424,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             if (tid == 0) s_nb = 0x7fffffff;
             __syncthreads();
             for (int i = tid; i < n_eval; i += kFfThreads) {
-                const int c = u.elist[i] & ~(1 << 30);
+                const int c = u.elist[i] & kFfChanMask;
                 for (int q = 0; q < NE; ++q) {
                     int sen = u.senid[c * 5 + q];
                     if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
@@ -429,29 +453,78 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             }
             __syncthreads();
             FF_PROF(0);
-            // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain
+            // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain.
+            //      With the batch scorer's lists at hand (`lazy`) a chain costs nothing in most frames: a touched codebook's list is
+            //      the batch scorer's where that entry is closed (whatever was carried in), and an UNTOUCHED codebook's eval_topn only
+            //      re-scores and re-orders the carried codewords -- state that nothing reads until the chain is next scanned with
+            //      an open entry (ties: rare).  Then the re-orderings since the chain's last known list (s_lk) are replayed: a frame
+            //      whose four re-scored values are pairwise distinct leaves them in descending order whatever the order before, so
+            //      the replay starts at the latest such frame (almost always the one before this).
+            const bool lazy = rw.tsc && topn == 4;
             for (int ch = tid; ch < n_chain; ch += kFfThreads) {
                 const int cb = ch / pm.n_feat, fs = ch % pm.n_feat, len = pm.featlen[fs];
                 const size_t base = (size_t)cb * pm.n_density * pm.veclen + (size_t)pm.n_density * pm.featoff[fs];
                 const float *xs = x + pm.featoff[fs];
                 int32_t cw[kFfMaxTopn], sc[kFfMaxTopn];
-                if (rw.tsc && topn == 4 && s_cbact[cb] && !rw.open[(size_t)ch * rw.total + t0 + f]) {
+#ifdef PSGPU_FF_CHECK_LAZY
+                auto shadow_rescore = [&]() {                    // eval_topn's re-ordering of the reference's carried list
+                    int32_t c4[kFfMaxTopn], s4[kFfMaxTopn];
+                    for (int i = 0; i < topn; ++i) {
+                        const int c = s_shadow[ch * topn + i];
+                        const int32_t v = ff_dist_to_int(ff_density(pm, xs, base, ch, c, len));
+                        int j = i;
+                        for (; j > 0 && v > s4[j - 1]; --j) { s4[j] = s4[j - 1]; c4[j] = c4[j - 1]; }
+                        s4[j] = v; c4[j] = c;
+                    }
+                    for (int i = 0; i < topn; ++i) s_shadow[ch * topn + i] = c4[i];
+                };
+                if (lazy && !s_cbact[cb]) shadow_rescore();
+#endif
+                if (lazy && !s_cbact[cb]) continue;
+                if (lazy && !rw.open[(size_t)ch * rw.total + t0 + f]) {
                     const size_t o = (size_t)ch * rw.total + t0 + f;
                     const FfQuad q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4);
                     const uint32_t c4 = rw.tcw[o];
                     s_lsc[ch * 4] = q.x; s_lsc[ch * 4 + 1] = q.y; s_lsc[ch * 4 + 2] = q.z; s_lsc[ch * 4 + 3] = q.w;
                     s_lcw[ch * 4] = c4 & 0xff; s_lcw[ch * 4 + 1] = (c4 >> 8) & 0xff; s_lcw[ch * 4 + 2] = (c4 >> 16) & 0xff; s_lcw[ch * 4 + 3] = c4 >> 24;
+                    s_lk[ch] = f;
+#ifdef PSGPU_FF_CHECK_LAZY
+                    for (int i = 0; i < 4; ++i) s_shadow[ch * 4 + i] = s_lcw[ch * 4 + i];
+#endif
                     atomicMax(&s_norm[fs], q.x >> 10);       // ptm_mgau_codebook_norm (:272-279)
                     continue;
                 }
                 for (int i = 0; i < topn; ++i) cw[i] = s_lcw[ch * topn + i];
-                for (int i = 0; i < topn; ++i) {                 // re-score, stable descending insertion with strict '>' (:71-85)
-                    const int c = cw[i];
-                    const int32_t v = ff_dist_to_int(ff_density(pm, xs, base, ch, c, len));
-                    int j = i;
-                    for (; j > 0 && v > sc[j - 1]; --j) { sc[j] = sc[j - 1]; cw[j] = cw[j - 1]; }
-                    sc[j] = v; cw[j] = c;
+                auto rescore = [&](const float *xg) {            // re-score, stable descending insertion with strict '>' (:71-85)
+                    for (int i = 0; i < topn; ++i) {
+                        const int c = cw[i];
+                        const int32_t v = ff_dist_to_int(ff_density(pm, xg, base, ch, c, len));
+                        int j = i;
+                        for (; j > 0 && v > sc[j - 1]; --j) { sc[j] = sc[j - 1]; cw[j] = cw[j - 1]; }
+                        sc[j] = v; cw[j] = c;
+                    }
+                };
+                if (lazy) {
+                    int g = f - 1;
+                    for (; g > s_lk[ch]; --g) {
+                        rescore(rw.feats + (size_t)(t0 + g) * pm.veclen + pm.featoff[fs]);
+                        if (sc[0] != sc[1] && sc[1] != sc[2] && sc[2] != sc[3]) break;     // (sorted: neighbours suffice)
+                    }
+                    if (g <= s_lk[ch]) {                         // no such frame: every re-ordering since the known list, in order
+                        for (int i = 0; i < topn; ++i) cw[i] = s_lcw[ch * topn + i];
+                        g = s_lk[ch];
+                    }
+                    for (++g; g < f; ++g) rescore(rw.feats + (size_t)(t0 + g) * pm.veclen + pm.featoff[fs]);
+                    s_lk[ch] = f;
+#ifdef PSGPU_FF_CHECK_LAZY
+                    for (int i = 0; i < topn; ++i)
+                        if (cw[i] != s_shadow[ch * topn + i]) {
+                            printf("fwdflat: chain %d frame %d: replayed list entry %d is codeword %d, the reference carries %d\n", ch, f, i, cw[i], s_shadow[ch * topn + i]);
+                            abort();
+                        }
+#endif
                 }
+                rescore(xs);
                 if (s_cbact[cb])
                     for (int c = 0; c < pm.n_density; ++c) {     // codewords in index order against the moving threshold (:151-226)
                         const float th = (float)sc[topn - 1];
@@ -466,6 +539,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         sc[q] = v; cw[q] = c;
                     }
                 for (int i = 0; i < topn; ++i) { s_lcw[ch * topn + i] = cw[i]; s_lsc[ch * topn + i] = sc[i]; }
+#ifdef PSGPU_FF_CHECK_LAZY
+                for (int i = 0; i < topn; ++i) s_shadow[ch * topn + i] = cw[i];
+#endif
                 if (s_cbact[cb]) atomicMax(&s_norm[fs], sc[0] >> 10);        // ptm_mgau_codebook_norm (:272-279)
             }
             __syncthreads();
@@ -598,7 +674,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             int32_t b = kW;
             for (int i = tid; i < n_eval; i += kFfThreads) {
                 const int e = u.elist[i];
-                const int32_t sc = ff_eval<NE>(p, u, e & ~(1 << 30), row);
+                const int32_t sc = ff_eval<NE>(p, u, e & kFfChanMask, row);
                 if (!(e & (1 << 30))) b = max(b, sc);
             }
             if (b > kW) atomicMax(&s_sc[0], b);
@@ -607,44 +683,46 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         const int32_t best_score = s_sc[0];
         const int32_t thresh = best_score + p.fwdflatbeam, wordthresh = best_score + p.fwdflatwbeam;
         FF_PROF(4);
-        // ---- fwdflat_prune_chan (:482-607), one work-item per active word; exits are flagged, their back-pointer
-        //      positions come from the prefix sums below (one entry per exiting word, in active-list order)
-        for (int i = tid; i < na; i += kFfThreads) {
-            const int w = u.awl[cur][i];
-            int len; const int c0 = ff_root(p, u, w, len);
-            int ex = 0, act = 0;
-            if (u.frame[c0] == f && u.best[c0] > thresh) {
-                int32_t newscore = u.out[c0];
-                u.frame[c0] = nf; act = 1;
-                if (len > 1) {
+        // ---- fwdflat_prune_chan (:482-607), one work-item per ACTIVE CHANNEL (the list made at the top of the frame).  The reference
+        //      walks a word's chain front to back; what a channel decides depends on its own evaluation alone (best / out score),
+        //      and its entry state (score[0], history[0]) is written by its one predecessor in the chain only, so the channels of
+        //      a chain can be decided side by side: (1) retain / exit / hand on to the successor(s) -- the fan-out of a word's
+        //      last-but-one phone into its right-context channels is queued and (2) spread over a wavefront's work-items;
+        //      (3) a channel that neither survived nor was entered is cleared (the walk's "else if frame != nf").  A channel that
+        //      was not active is never looked at: it was cleared when it left the list, its best score is WORST_SCORE.
+        for (int e = tid; e < n_eval; e += kFfThreads) {
+            const int c = u.elist[e] & kFfChanMask, inf = u.einfo[e], i = inf >> 10, k = inf & 1023;
+            if (u.best[c] > thresh) {
+                const int w = u.awl[cur][i];
+                int len; const int c0 = ff_root(p, u, w, len);
+                int32_t newscore = u.out[c];
+                u.frame[c] = nf; u.word_active[w] = nf;
+                if (k == 0 ? len > 1 : u.rcid[c] < 0) {
                     newscore += p.pip;
                     if (newscore > thresh) {
-                        if (u.rcid[c0 + 1] >= 0) for (int j = 1; j < len; ++j) ff_enter_if_better(u, c0 + j, newscore, u.outh[c0], f);
-                        else ff_enter_if_better(u, c0 + 1, newscore, u.outh[c0], f);
-                    }
-                }
-                else if (newscore > wordthresh) { u.xflag[c0] = 1; ex = 1; }
-            }
-            for (int k = 1; k < len; ++k) {
-                const int c = c0 + k;
-                if (u.frame[c] < f) continue;
-                if (u.best[c] > thresh) {
-                    int32_t newscore = u.out[c];
-                    u.frame[c] = nf; act = 1;
-                    if (u.rcid[c] < 0) {
-                        newscore += p.pip;
-                        if (newscore > thresh) {
-                            if (u.rcid[c + 1] >= 0) for (int j = k + 1; j < len; ++j) ff_enter_if_better(u, c0 + j, newscore, u.outh[c], f);
-                            else ff_enter_if_better(u, c + 1, newscore, u.outh[c], f);
+                        const int32_t hist = u.outh[c];
+                        if (u.rcid[c + 1] >= 0 && len - (k + 1) > 1) {
+                            const int q = atomicAdd(&s_nfan, 1);
+                            if (q < kFfMaxFan) { s_fan[q][0] = c + 1; s_fan[q][1] = len - (k + 1); s_fan[q][2] = newscore; s_fan[q][3] = hist; }
+                            else for (int j = k + 1; j < len; ++j) ff_enter_if_better(u, c0 + j, newscore, hist, f);
                         }
+                        else ff_enter_if_better(u, c + 1, newscore, hist, f);
                     }
-                    else if (newscore > wordthresh) { u.xflag[c] = 1; ex = 1; }
                 }
-                else if (u.frame[c] != nf) ff_clear_scores(p, u, c);
+                else if (newscore > wordthresh) {
+                    u.xflag[c] = 1; u.cnt_a[i] = 1;
+                    u.cnt_b[i] = p.d_pronlen[w] > 1 ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+                }
             }
-            if (act) u.word_active[w] = nf;
-            u.cnt_a[i] = ex;
-            u.cnt_b[i] = (ex && p.d_pronlen[w] > 1) ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+            else if (k > 0) u.elist[e] |= kFfClearBit;
+        }
+        __syncthreads();
+        for (int q = tid >> 6, nq = min(s_nfan, kFfMaxFan); q < nq; q += kFfThreads / 64)
+            for (int j = tid & 63; j < s_fan[q][1]; j += 64) ff_enter_if_better(u, s_fan[q][0] + j, s_fan[q][2], s_fan[q][3], f);
+        __syncthreads();
+        for (int e = tid; e < n_eval; e += kFfThreads) {
+            const int v = u.elist[e];
+            if ((v & kFfClearBit) && u.frame[v & kFfChanMask] != nf) ff_clear_scores(p, u, v & kFfChanMask);
         }
         __syncthreads();
         {
@@ -964,7 +1042,10 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         const int32_t *cu = cols.data() + (size_t)u * max_nb;
         ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
         const size_t C = (size_t)d.n1 + voc[u].n_chan, nwd = voc[u].wid.size(), cap = nwd + n_tail + 1;
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 5) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
+        for (size_t k = 0; k < nwd; ++k)
+            PSGPU_REQUIRE(voc[u].len[k] < 1024, "psgpu_fwdflat_search: a word chain of %d channels (FfUtt::einfo holds 10 bits)", voc[u].len[k]);
+        PSGPU_REQUIRE(cap < (1u << 21), "psgpu_fwdflat_search: %zu active words (FfUtt::einfo holds 21 bits)", cap);
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
     }
@@ -988,7 +1069,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         int32_t *q = slab + slab_off[i];
         auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
         u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
-        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C);
+        u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C); u.einfo = take(C);
         u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
         u.awl[0] = take(cap); u.awl[1] = take(cap);
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);

@@ -202,8 +202,10 @@ class SimFwdflatSearch:
             lib().psgpu_fwdflat_free(self.h)
             self.h = C.c_void_p()
 
-    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19, ptm_tables=None, topn_seed=None):
+    def search(self, senscr, utt_lens, bp1, w1_ssid=None, bp_cap=16384, bss_cap=1 << 19, ptm_tables=None, topn_seed=None, lists=None):
         """bp1: per utterance the first pass's table [n][10], or the `handover` dict of SimFwdtreeSearch.search.
+        lists: (topn_score [n_chain][T][4] int32, topn_cw [n_chain][T][4] uint8, open [n_chain][T] uint8) -- the batch scorer's
+        lists of the same frames (psgpu_fwdflat_search_feats_lists_dev).
         ptm_tables (a tests/golden/*_ptm_tables.npz) + topn_seed: senscr holds the FEATURE rows and the kernel scores
         its own senones (psgpu_fwdflat_search_feats_dev)."""
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
@@ -239,7 +241,16 @@ class SimFwdflatSearch:
         bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
         idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
         p = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None  # noqa: E731
-        if view is not None:
+        if view is not None and lists is not None:
+            l_sc = np.ascontiguousarray(lists[0], np.int32); l_cw = np.ascontiguousarray(lists[1], np.uint8)
+            l_op = np.ascontiguousarray(lists[2], np.uint8)
+            nch = view.n_mgau * view.n_feat
+            assert l_sc.shape == (nch, int(off[-1]), 4) and l_cw.shape == l_sc.shape and l_op.shape == l_sc.shape[:2]
+            check(lib().psgpu_fwdflat_search_feats_lists_dev(self.h, C.byref(view), p(d_s), p(d_seed), p(l_sc), p(l_cw), p(l_op), int(off[-1]),
+                                                             p(off), n, mf, cap1, p(h_bp1), p(h_res1), p(d_w1), bp_cap, bss_cap, p(bp),
+                                                             p(bss), p(idx), p(step), p(res), None),
+                  "psgpu_fwdflat_search_feats_lists_dev")
+        elif view is not None:
             check(lib().psgpu_fwdflat_search_feats_dev(self.h, C.byref(view), p(d_s), p(d_seed), p(off), n, mf, cap1, p(h_bp1), p(h_res1),
                                                        p(d_w1), bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res), None),
                   "psgpu_fwdflat_search_feats_dev")

@@ -153,3 +153,56 @@ def test_two_passes_chained_full_cmudict_vocabulary(big_flat_trace):
     s2 = simlib.SimFwdflatSearch(g, g, g["par"], g["flat_par"], g["flat_lwf"], lm=lm)
     check_flat(s2.search(flat_rows(g, s2.n_sen), [int(g["flat_n_steps"][0])], h)[0], g, "cmudict chained")
     s1.close(); s2.close(); lm.close()
+
+
+def _all_density_lists(t, feats):
+    """what the batch scorer hands over (psgpu_ptm_score_batch_dev): per (codebook, stream) chain and frame the four best of ALL
+    128 densities -- fp32 distances with the reference's one-rounding-per-operation order (ptm_mgau.c:102-128), truncated,
+    descending, the lower codeword first among equals -- and the `open` flag where that is not certainly the reference's list
+    (a tie among the best five, a score at the clamp)"""
+    n_cb, n_feat, n_den = int(t["n_mgau"][0]), int(t["n_feat"][0]), int(t["n_density"][0])
+    fl = [int(v) for v in t["featlen"]]; veclen = sum(fl); T = feats.shape[0]
+    mean = np.asarray(t["mean"], np.float32).reshape(n_cb, veclen * n_den); var = np.asarray(t["var"], np.float32).reshape(n_cb, veclen * n_den)
+    det = np.asarray(t["det"], np.float32)
+    sc = np.zeros((n_cb * n_feat, T, 4), np.int32); cw = np.zeros((n_cb * n_feat, T, 4), np.uint8); op = np.zeros((n_cb * n_feat, T), np.uint8)
+    x = np.asarray(feats, np.float32)
+    for cb in range(n_cb):
+        for fs in range(n_feat):
+            o = n_den * sum(fl[:fs]); ln = fl[fs]
+            m = mean[cb, o:o + n_den * ln].reshape(n_den, ln); v = var[cb, o:o + n_den * ln].reshape(n_den, ln)
+            xs = x[:, sum(fl[:fs]):sum(fl[:fs]) + ln]
+            d = np.broadcast_to(det[cb, fs][None, :], (T, n_den)).astype(np.float32)
+            for j in range(ln):
+                diff = (xs[:, j][:, None] - m[:, j][None, :]).astype(np.float32)
+                d = (d - ((diff * diff).astype(np.float32) * v[:, j][None, :]).astype(np.float32)).astype(np.float32)
+            s = np.clip(np.trunc(d.astype(np.float64)), -(1 << 24), (1 << 24) - 1).astype(np.int64)
+            key = (s << 7) | (127 - np.arange(n_den))[None, :]
+            best = np.sort(key, axis=1)[:, ::-1][:, :5]
+            b = best >> 7
+            ch = cb * n_feat + fs
+            sc[ch] = b[:, :4]; cw[ch] = (127 - (best[:, :4] & 127)).astype(np.uint8)
+            op[ch] = ((np.diff(b, axis=1) == 0).any(axis=1) | (b[:, 0] >= (1 << 24) - 1) | (b[:, 3] <= -(1 << 24))).astype(np.uint8)
+    return sc, cw, op
+
+
+@pytest.mark.parametrize("extra_open", [0.0, 0.02, 0.5])
+@pytest.mark.parametrize("case", ["goforward", "something_efwid2_sfwin8"])
+def test_flat_kernel_source_taking_the_batch_scorers_lists(case, extra_open):
+    """psgpu_fwdflat_search_feats_lists_dev: a touched codebook's list is taken from the batch scorer where its entry is closed, an
+    untouched codebook's chain is left alone, and an OPEN entry of a touched codebook is scanned with the reference's sequential
+    procedure -- on the list the reference would carry at that point, which the kernel has to replay (the re-orderings of the
+    untouched frames in between).  Marking MORE entries open than the ties require is always allowed (they are then scanned
+    exactly), and makes that replay the common case instead of a once-an-utterance one: the tables must not change."""
+    import pso
+    t = pso.load_tables()
+    g, st, fst = load_flat(case)
+    feats = g["flat_feat"]
+    sc, cw, op = _all_density_lists(t, feats)
+    if extra_open:
+        op = op | (np.random.default_rng(17).random(op.shape) < extra_open).astype(np.uint8)
+    with _order("rev"):
+        s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+        r = s.search(feats, [feats.shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=t, topn_seed=g["flat_ptm_seed"],
+                     lists=(sc, cw, op))[0]
+        check_flat(r, g, "%s (extra open %s)" % (case, extra_open))
+        s.close()
