@@ -22,6 +22,7 @@
 #include "psgpu_sen_dev.h"
 #include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 // Builds for the workgroup simulator (tests/hostsim: g++, no __HIPCC__) keep, beside the lazily maintained top-N lists of the
@@ -30,6 +31,10 @@
 #if !defined(__HIPCC__)
 #define PSGPU_FF_CHECK_LAZY 1
 #include <cstdio>
+extern "C" { int psgpu_sim_ff_exit_cap = 256; }      // (tests shrink it to drive the frames through the other path)
+#define FF_EXIT_CAP psgpu_sim_ff_exit_cap
+#else
+#define FF_EXIT_CAP kFfMaxExit
 #endif
 
 constexpr int kFfThreads = 256;
@@ -40,6 +45,7 @@ constexpr int kFfMaxCb = 256;          // codebooks
 constexpr int kFfMaxTopn = 8;
 constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
 constexpr int kFfChanMask = (1 << 29) - 1, kFfClearBit = 1 << 29;   // FfUtt::elist entries
+constexpr int kFfMaxExit = 256;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
 // each frame's senone scores itself, as ptm_mgau_frame_eval does when the second pass calls it (ptm_mgau.c:408-454 with
@@ -308,20 +314,21 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     const int32_t *__restrict__ utt_off, FfRaw rw)
 {
     __shared__ uint32_t s_bits[RAW ? kFfMaxSen / 32 : 1];
-    __shared__ int32_t s_prev[RAW ? kFfMaxSen / 32 : 1];
     __shared__ int32_t s_lcw[RAW ? kFfMaxEnt : 1], s_lsc[RAW ? kFfMaxEnt : 1];   // the scorer's lists: codeword, score
     __shared__ uint8_t s_cbact[RAW ? kFfMaxCb : 1], s_la[RAW ? 512 : 1];  // (log-add table readable up to 511: zero beyond the reference's entries)
     // senones scored evenly over the work-items (the first pass's way, psgpu_sen_dev.h): the frame's lists packed four to a word, the
     // listed senones as a list (prefix sum over the bitmap words' populations)
     __shared__ uint32_t s_pcw[RAW ? kFfMaxEnt / 4 : 1], s_psc[RAW ? kFfMaxEnt / 4 : 1];
-    __shared__ int32_t s_wcnt[RAW ? kFfMaxSen / 32 + 4 : 1];
-    __shared__ uint16_t s_slist[RAW ? 1024 : 1];
+    __shared__ uint16_t s_slist[RAW ? kFfMaxSen : 1];            // the frame's listed senones in the order they were first marked
+    __shared__ int32_t s_nl;
     __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64];
 #ifdef PSGPU_FF_CHECK_LAZY
     __shared__ int32_t s_shadow[RAW ? kFfMaxEnt : 1];
 #endif
     __shared__ int32_t s_lk[RAW ? kFfMaxEnt / 4 : 1];    // per chain: the last frame after which s_lcw holds its list (-1: the seed)
+    __shared__ int32_t s_ex[kFfMaxExit][8], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
+    __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset
     __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, -, -, length of the evaluation list
     __shared__ unsigned long long s_key;
@@ -398,17 +405,32 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
         //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
         //      profiles/r03_fwdflat_phase_profile.txt).  Nothing between here and the evaluation changes a channel's frame stamp.
-        if (tid == 0) { s_sc[7] = 0; s_nfan = 0; }
+        if (tid == 0) { s_sc[7] = 0; s_nfan = 0; s_nex = 0; s_tot[0] = 0; s_tot[1] = 0; s_nl = 0; s_nb = 0x7fffffff; }
+        if (RAW) {
+            for (int i = tid; i < (rw.pm.n_sen + 31) >> 5; i += kFfThreads) s_bits[i] = 0u;
+            for (int i = tid; i < rw.pm.n_mgau; i += kFfThreads) s_cbact[i] = 0;
+            if (tid < 16) s_norm[tid] = kW;
+        }
         __syncthreads();
         for (int i = tid >> 4; i < na; i += kFfThreads / 16) {          // sixteen work-items a word: its chain's stamps read side by side
             const int w = u.awl[cur][i];
             int len; const int c0 = ff_root(p, u, w, len);
-            if ((tid & 15) == 0) { u.cnt_a[i] = 0; u.cnt_b[i] = 0; }     // (the pruning's exit flags, see there)
             for (int k = tid & 15; k < len; k += 16)
                 if (u.frame[c0 + k] == f) {                   // bit 30: the root of </s>, which does not count towards the best score
-                    const int pos = atomicAdd(&s_sc[7], 1);
-                    u.elist[pos] = (c0 + k) | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
+                    const int c = c0 + k, pos = atomicAdd(&s_sc[7], 1);
+                    u.elist[pos] = c | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
                     u.einfo[pos] = (i << 10) | k;
+                    if (RAW) {
+                        // compute_fwdflat_sen_active (:416-442): the channel's senones into the frame's bitmap, and -- the first time
+                        // a senone is marked -- into the list the evaluation below goes over (its order does not matter there)
+                        const bool mpx = u.mpx[c] != 0;
+                        for (int q = 0; q < NE; ++q) {
+                            int sen = u.senid[c * 5 + q];
+                            if (mpx) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
+                            const uint32_t bit = 1u << (sen & 31);
+                            if (!(atomicOr(&s_bits[sen >> 5], bit) & bit)) s_slist[atomicAdd(&s_nl, 1)] = (uint16_t)sen;
+                        }
+                    }
                 }
         }
         __syncthreads();
@@ -417,40 +439,23 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const psgpu_ptm_view_t &pm = rw.pm;
             const float *x = rw.feats + (size_t)(t0 + f) * pm.veclen;
             const int nwords = (pm.n_sen + 31) >> 5;
-            // ---- compute_fwdflat_sen_active (:416-442): senones of the channels that are active in this frame
-            for (int i = tid; i < nwords; i += kFfThreads) s_bits[i] = 0u;
-            for (int i = tid; i < pm.n_mgau; i += kFfThreads) s_cbact[i] = 0;
-            if (tid < 16) s_norm[tid] = kW;
-            if (tid == 0) s_nb = 0x7fffffff;
-            __syncthreads();
-            for (int i = tid; i < n_eval; i += kFfThreads) {
-                const int c = u.elist[i] & kFfChanMask;
-                for (int q = 0; q < NE; ++q) {
-                    int sen = u.senid[c * 5 + q];
-                    if (u.mpx[c]) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
-                    atomicOr(&s_bits[sen >> 5], 1u << (sen & 31));
-                }
-            }
-            __syncthreads();
+            const int n_l0 = s_nl;
             {   // s_prev[w] = the highest senone listed in the words before w: where acmod_flags2list's bridging entries go
                 static_assert(kFfMaxSen / 32 <= kFfThreads, "one bitmap word per work-item");
                 const uint32_t bw = tid < nwords ? s_bits[tid] : 0u;
                 const int32_t pv = ff_block_excl_max(bw ? tid * 32 + 31 - __clz((int)bw) : -1, s_scan);
-                if (tid < nwords) s_prev[tid] = pv;
-            }
-            __syncthreads();
-            // every listed senone (bridging entries included) touches its codebook: ptm_mgau_calc_cb_active (:297-321)
-            for (int w = tid; w < nwords; w += kFfThreads) {
-                uint32_t b = s_bits[w];
-                int prev = s_prev[w];
-                while (b) {
-                    const int sen = w * 32 + __ffs((int)b) - 1;
-                    b &= b - 1;
-                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; s_cbact[pm.sen2cb[last]] = 1; }
-                    s_cbact[pm.sen2cb[sen]] = 1;
-                    prev = sen;
+                // every listed senone (bridging entries included) touches its codebook: ptm_mgau_calc_cb_active (:297-321).  Only the
+                // first senone of a bitmap word can be more than 255 past its predecessor; the entries in between are listed too
+                if (bw) {
+                    const int sen = tid * 32 + __ffs((int)bw) - 1;
+                    for (int last = pv < 0 ? 0 : pv; sen - last > 255;) {
+                        last += 255;
+                        s_cbact[pm.sen2cb[last]] = 1;
+                        s_slist[atomicAdd(&s_nl, 1)] = (uint16_t)last;
+                    }
                 }
             }
+            for (int i = tid; i < n_l0; i += kFfThreads) s_cbact[pm.sen2cb[s_slist[i]]] = 1;
             __syncthreads();
             FF_PROF(0);
             // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain.
@@ -545,15 +550,25 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 if (s_cbact[cb]) atomicMax(&s_norm[fs], sc[0] >> 10);        // ptm_mgau_codebook_norm (:272-279)
             }
             __syncthreads();
-            for (int i = tid; i < n_chain * topn; i += kFfThreads) {          // (:280-291), touched codebooks only
-                const int ch = i / topn;
+            // The scorer's usual shape (3 streams, top-4, senone-major weights at hand): each listed senone's twelve weights from three
+            // cache lines (sen_eval_f3n4, the first pass's), the lists packed four to a word
+            const bool fast = topn == 4 && pm.n_feat == kSenStreams && pm.mixw_sen != nullptr && n_chain <= kFfMaxEnt / 4;
+            for (int ch = tid; ch < n_chain; ch += kFfThreads) {              // (:280-291), touched codebooks only
                 if (!s_cbact[ch / pm.n_feat]) continue;
-                const int32_t v = s_norm[ch % pm.n_feat] - (s_lsc[i] >> 10);
-                s_lsc[i] = v > kMaxNegAscr ? kMaxNegAscr : v;
+                const int32_t nm = s_norm[ch % pm.n_feat];
+                uint32_t pc = 0, ps = 0;
+                for (int k = 0; k < topn; ++k) {
+                    int32_t v = nm - (s_lsc[ch * topn + k] >> 10);
+                    v = v > kMaxNegAscr ? kMaxNegAscr : v;
+                    s_lsc[ch * topn + k] = v;
+                    if (k < 4) { pc |= (uint32_t)(s_lcw[ch * topn + k] & 0xff) << (8 * k); ps |= (uint32_t)(v & 0xff) << (8 * k); }
+                }
+                if (fast) { s_pcw[ch] = pc; s_psc[ch] = ps; }
             }
             __syncthreads();
             FF_PROF(1);
             // ---- ptm_mgau_senone_eval (:326-403) for the listed senones; the frame's scores are those minus their minimum
+            const int n_l = s_nl;
             int32_t mn = 0x7fffffff;
             auto senone = [&](int sen) {
                 const int cb = pm.sen2cb[sen];
@@ -570,88 +585,49 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     }
                     a += fden;
                 }
-                u.nrow32[sen] = a;
-                mn = min(mn, a);
+                return a;
             };
-            // The scorer's usual shape (3 streams, top-4, senone-major weights at hand): the senones spread evenly over the
-            // work-items -- a list from the bitmap by a prefix sum -- and each one's twelve weights from three cache lines
-            // (sen_eval_f3n4, the first pass's) instead of one work-item per bitmap word walking its bits, twelve scattered byte
-            // loads per senone (measured: 95 k of the frame's 254 k cycles, profiles/r03_fwdflat_phase_profile.txt).
-            const bool fast = topn == 4 && pm.n_feat == kSenStreams && pm.mixw_sen != nullptr && n_chain <= kFfMaxEnt / 4
-                              && nwords <= kFfThreads;
-            if (fast) {
+            auto wg_min = [&](int32_t v) {                       // the list's minimum to s_nb
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+                if ((tid & 63) == 0) atomicMin(&s_nb, v);
+            };
+            if (n_l <= 4 * kFfThreads) {                         // (every frame in practice: a senone's value waits in a register)
                 const SenModel smod = { pm.mixw_sen, pm.sen2cb, pm.n_sen, pm.n_density };
-                for (int ch = tid; ch < n_chain; ch += kFfThreads) {
-                    s_pcw[ch] = (uint32_t)(s_lcw[ch * 4] & 0xff) | ((uint32_t)(s_lcw[ch * 4 + 1] & 0xff) << 8)
-                                | ((uint32_t)(s_lcw[ch * 4 + 2] & 0xff) << 16) | ((uint32_t)(s_lcw[ch * 4 + 3] & 0xff) << 24);
-                    s_psc[ch] = (uint32_t)(s_lsc[ch * 4] & 0xff) | ((uint32_t)(s_lsc[ch * 4 + 1] & 0xff) << 8)
-                                | ((uint32_t)(s_lsc[ch * 4 + 2] & 0xff) << 16) | ((uint32_t)(s_lsc[ch * 4 + 3] & 0xff) << 24);
+                int32_t av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + j * kFfThreads;
+                    av[j] = 0x7fffffff;
+                    if (i < n_l) av[j] = fast ? sen_eval_f3n4(smod, s_pcw, s_psc, s_la, (int)s_slist[i]) : senone((int)s_slist[i]);
+                    mn = min(mn, av[j]);
                 }
-                for (int w = tid; w <= nwords; w += kFfThreads) s_wcnt[w] = w < nwords ? __popc(s_bits[w]) : 0;
-                __syncthreads();
-                auto score = [&](int sen) {
-                    const int32_t a = sen_eval_f3n4(smod, s_pcw, s_psc, s_la, sen);
-                    u.nrow32[sen] = a;
-                    mn = min(mn, a);
-                };
-                const int n_list = ff_block_scan(s_wcnt, nwords + 1, s_scan);
-                if (tid < nwords) {
-                    uint32_t b = s_bits[tid];
-                    int prev = s_prev[tid], o = s_wcnt[tid];
-                    while (b) {
-                        const int sen = tid * 32 + __ffs((int)b) - 1;
-                        b &= b - 1;
-                        for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; score(last); }   // bridging entries (rare)
-                        if (o < 1024) s_slist[o] = (uint16_t)sen; else score(sen);
-                        ++o;
-                        prev = sen;
-                    }
-                }
-                __syncthreads();
-                const int nl = min(n_list, 1024);
-                for (int i = tid; i < nl; i += kFfThreads) score((int)s_slist[i]);
-                atomicMin(&s_nb, mn);
+                wg_min(mn);
                 __syncthreads();
                 const int32_t nb = s_nb;
-                for (int i = tid; i < nl; i += kFfThreads) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = tid + j * kFfThreads;
+                    if (i < n_l) u.nrow[s_slist[i]] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)av[j] - (uint32_t)nb);
+                }
+            }
+            else {
+                const SenModel smod = { pm.mixw_sen, pm.sen2cb, pm.n_sen, pm.n_density };
+                for (int i = tid; i < n_l; i += kFfThreads) {
+                    const int sen = s_slist[i];
+                    const int32_t a = fast ? sen_eval_f3n4(smod, s_pcw, s_psc, s_la, sen) : senone(sen);
+                    u.nrow32[sen] = a;
+                    mn = min(mn, a);
+                }
+                wg_min(mn);
+                __syncthreads();
+                const int32_t nb = s_nb;
+                for (int i = tid; i < n_l; i += kFfThreads) {
                     const int sen = s_slist[i];
                     u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
                 }
-                if (n_list > 1024 && tid < nwords) {             // (a frame with more: those past the list, where they were found)
-                    uint32_t b = s_bits[tid];
-                    for (int o = s_wcnt[tid]; b; b &= b - 1, ++o)
-                        if (o >= 1024) {
-                            const int sen = tid * 32 + __ffs((int)b) - 1;
-                            u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
-                        }
-                }
-                __syncthreads();
-            }
-            else {
-            for (int w = tid; w < nwords; w += kFfThreads) {
-                uint32_t b = s_bits[w];
-                int prev = s_prev[w];
-                while (b) {
-                    const int sen = w * 32 + __ffs((int)b) - 1;
-                    b &= b - 1;
-                    for (int last = prev < 0 ? 0 : prev; sen - last > 255;) { last += 255; senone(last); }
-                    senone(sen);
-                    prev = sen;
-                }
-            }
-            atomicMin(&s_nb, mn);
-            __syncthreads();
-            const int32_t nb = s_nb;
-            for (int w = tid; w < nwords; w += kFfThreads) {
-                uint32_t b = s_bits[w];
-                while (b) {
-                    const int sen = w * 32 + __ffs((int)b) - 1;
-                    b &= b - 1;
-                    u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
-                }
             }
             __syncthreads();
-            }
             row = u.nrow;
         }
         FF_PROF(2);
@@ -709,9 +685,14 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         else ff_enter_if_better(u, c + 1, newscore, hist, f);
                     }
                 }
-                else if (newscore > wordthresh) {
-                    u.xflag[c] = 1; u.cnt_a[i] = 1;
-                    u.cnt_b[i] = p.d_pronlen[w] > 1 ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+                else if (newscore > wordthresh) {            // a word exit: queued, see below
+                    const int q = atomicAdd(&s_nex, 1);
+                    if (q < FF_EXIT_CAP) {
+                        int32_t *x = s_ex[q];
+                        x[0] = inf; x[1] = c; x[2] = newscore; x[3] = u.outh[c];
+                        x[4] = p.d_pronlen[w] > 1 ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+                        x[5] = k == 0 ? 0 : u.rcid[c];
+                    }
                 }
             }
             else if (k > 0) u.elist[e] |= kFfClearBit;
@@ -725,26 +706,97 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             if ((v & kFfClearBit) && u.frame[v & kFfChanMask] != nf) ff_clear_scores(p, u, v & kFfChanMask);
         }
         __syncthreads();
-        {
+        // ---- the exits' back-pointers (ngram_search_save_bp as fwdflat_prune_chan calls it, :528-540, :588-600): one entry per
+        //      exiting WORD in active-list order, its right-context exits applied in chain order (the first creates the entry, a later
+        //      one with a strictly better score takes it over, each leaves its score in its slot of the word's stack block).  The
+        //      queue is sorted by (word's list position, chain position) by counting; a word's first exit learns how many words
+        //      and stack entries precede it from the sorted queue and then walks its group -- everything but the table itself in LDS.
+        if (s_nex <= FF_EXIT_CAP) {
             const int32_t bpidx = s_sc[1], bss_head = s_sc[2];
+            const int n_ex = s_nex;
+            for (int e = tid; e < n_ex; e += kFfThreads) {
+                const int32_t key = s_ex[e][0];
+                int r = 0;
+                for (int j = 0; j < n_ex; ++j) r += s_ex[j][0] < key;
+                s_ord[r] = (uint16_t)e;
+            }
+            __syncthreads();
+            for (int r = tid; r < n_ex; r += kFfThreads) {
+                int32_t *x = s_ex[s_ord[r]];
+                const int i = x[0] >> 10;
+                if (r > 0 && (s_ex[s_ord[r - 1]][0] >> 10) == i) { x[6] = -1; continue; }
+                int ord = 0, off = 0, pi = -1;
+                for (int j = 0; j < r; ++j) {
+                    const int32_t *y = s_ex[s_ord[j]];
+                    if ((y[0] >> 10) != pi) { ++ord; off += y[4]; pi = y[0] >> 10; }
+                }
+                x[6] = ord; x[7] = off;
+                atomicAdd(&s_tot[0], 1); atomicAdd(&s_tot[1], x[4]);
+            }
+            __syncthreads();
+            const int32_t n_exit = s_tot[0], n_bss = s_tot[1];
+            const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
+            if (!full)
+                for (int r = tid; r < n_ex; r += kFfThreads) {
+                    const int32_t *x = s_ex[s_ord[r]];
+                    if (x[6] < 0) continue;
+                    const int i = x[0] >> 10, w = u.awl[cur][i];
+                    const int32_t bpi = bpidx + x[6], bsh = bss_head + x[7];
+                    ff_save_bp(p, u, bpi, bsh, f, w, x[2], x[3], x[5]);          // (word_lat_idx[w] is -1: a new entry)
+                    int32_t cs = x[2], cp = x[3];
+                    bool dirty = false;
+                    for (int r2 = r + 1; r2 < n_ex; ++r2) {                      // the update branch of save_bp (ngram_search.c:405-437)
+                        const int32_t *y = s_ex[s_ord[r2]];
+                        if ((y[0] >> 10) != i) break;
+                        if (cs < y[2]) {
+                            if (cp != y[3]) {
+                                const int32_t b0 = cp == -1 ? -1 : FBP(u, F_PREAL, cp), b1 = cp == -1 ? -1 : FBP(u, F_REAL, cp);
+                                const int32_t n0 = y[3] == -1 ? -1 : FBP(u, F_PREAL, y[3]), n1 = y[3] == -1 ? -1 : FBP(u, F_REAL, y[3]);
+                                if (b0 != n0 || b1 != n1) ff_set_real_wid(p, u, bpi);      // with the old bp still in place, as the reference
+                                FBP(u, F_BP, bpi) = y[3];
+                                cp = y[3];
+                            }
+                            cs = y[2]; dirty = true;
+                        }
+                        u.bss[bsh + y[5]] = y[2];
+                    }
+                    if (dirty) FBP(u, F_SCORE, bpi) = cs;
+                }
+            __syncthreads();
+            if (tid == 0) { if (full) s_sc[3] = 1; else { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; } }   // (full: nothing was written)
+        }
+        else {
+            // more exits than the queue holds: through flags in the slab, one work-item per exiting word walking its chain
+            const int32_t bpidx = s_sc[1], bss_head = s_sc[2];
+            for (int i = tid; i < na; i += kFfThreads) { u.cnt_a[i] = 0; u.cnt_b[i] = 0; }
+            __syncthreads();
+            for (int e = tid; e < n_eval; e += kFfThreads) {                      // the exit test again (what failed it was cleared above)
+                const int c = u.elist[e] & kFfChanMask, inf = u.einfo[e], i = inf >> 10, k = inf & 1023;
+                if (!(u.best[c] > thresh && u.out[c] > wordthresh)) continue;
+                const int w = u.awl[cur][i];
+                int len; ff_root(p, u, w, len);
+                if (k == 0 ? len > 1 : u.rcid[c] < 0) continue;
+                u.xflag[c] = 1; u.cnt_a[i] = 1;
+                u.cnt_b[i] = p.d_pronlen[w] > 1 ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
+            }
+            __syncthreads();
             const int32_t n_exit = ff_block_scan(u.cnt_a, na, s_scan);
             const int32_t n_bss = ff_block_scan(u.cnt_b, na, s_scan);
             const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
-            if (!full)
-                for (int i = tid; i < na; i += kFfThreads) {
-                    if ((i + 1 < na ? u.cnt_a[i + 1] : n_exit) == u.cnt_a[i]) continue;
-                    const int w = u.awl[cur][i];
-                    int len; const int c0 = ff_root(p, u, w, len);
-                    const int32_t bpi = bpidx + u.cnt_a[i], bsh = bss_head + u.cnt_b[i];
-                    for (int k = 0; k < len; ++k) {
-                        const int c = c0 + k;
-                        if (!u.xflag[c]) continue;
-                        u.xflag[c] = 0;
-                        ff_save_bp(p, u, bpi, bsh, f, w, u.out[c], u.outh[c], k == 0 ? 0 : u.rcid[c]);
-                    }
+            for (int i = tid; i < na; i += kFfThreads) {
+                if ((i + 1 < na ? u.cnt_a[i + 1] : n_exit) == u.cnt_a[i]) continue;
+                const int w = u.awl[cur][i];
+                int len; const int c0 = ff_root(p, u, w, len);
+                const int32_t bpi = bpidx + u.cnt_a[i], bsh = bss_head + u.cnt_b[i];
+                for (int k = 0; k < len; ++k) {
+                    const int c = c0 + k;
+                    if (!u.xflag[c]) continue;
+                    u.xflag[c] = 0;
+                    if (!full) ff_save_bp(p, u, bpi, bsh, f, w, u.out[c], u.outh[c], k == 0 ? 0 : u.rcid[c]);
                 }
+            }
             __syncthreads();
-            if (tid == 0) { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; if (full) s_sc[3] = 1; }
+            if (tid == 0) { if (full) s_sc[3] = 1; else { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; } }   // (full: nothing was written)
         }
         __syncthreads();
         if (s_sc[3]) break;
@@ -1008,6 +1060,11 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
 {
     PSGPU_REQUIRE(m && n_utt >= 0 && max_frames >= 0 && bp_cap > 0 && bss_cap > 0 && bp1_cap > 0, "psgpu_fwdflat_search: bad argument");
     PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdflat_search: no language model (dense table or psgpu_fwdflat_set_lm)");
+#ifdef PSGPU_FT_PROFILE
+    double t_host[6]; int n_th = 0;
+    auto stamp = [&]() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); if (n_th < 6) t_host[n_th++] = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    stamp();
+#endif
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE((senscr_dev || raw) && utt_off_dev && bp1_dev && result1_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdflat_search: NULL device buffer");
@@ -1033,6 +1090,9 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
                                        sizeof(int32_t) * max_nb, n_utt, hipMemcpyDeviceToHost, st));
     }
     PSGPU_HIP(hipStreamSynchronize(st));
+#ifdef PSGPU_FT_PROFILE
+    stamp();
+#endif
     // ---- vocabulary + chain layout per utterance, slab sizes
     std::vector<FfVocab> voc(n_utt);
     std::vector<size_t> slab_off(n_utt + 1, 0), voc_off(n_utt + 1, 0);
@@ -1049,6 +1109,9 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
     }
+#ifdef PSGPU_FT_PROFILE
+    stamp();
+#endif
     int32_t *slab = nullptr, *vdev = nullptr;
     FfOff *d_utts = nullptr;
     PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * slab_off[n_utt]));
@@ -1090,6 +1153,9 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     if (e == hipSuccess) e = hipMemcpyAsync(d_utts, ho.data(), sizeof(FfOff) * n_utt, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the host vectors are about to go out of scope
     if (e != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); PSGPU_HIP(e); }
+#ifdef PSGPU_FT_PROFILE
+    stamp();
+#endif
     FfRaw rw;
     memset(&rw, 0, sizeof rw);
     if (raw) rw = *raw;
@@ -1111,6 +1177,9 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
 #ifdef PSGPU_FT_PROFILE
+    stamp();
+    fprintf(stderr, "fwdflat host: first-pass columns to the host %.2f ms, vocabularies %.2f ms, allocations + tables to the device %.2f ms, kernel %.2f ms\n",
+            t_host[1] - t_host[0], t_host[2] - t_host[1], t_host[3] - t_host[2], t_host[4] - t_host[3]);
     if (e == hipSuccess && bf.prof) {    // a profiling build: per-phase cycle counts of work-item 0, averaged over the utterances, per frame
         static const char *const names[8] = { "senones of the active channels (bitmap, codebooks)", "top-N lists (taken / evaluated)",
             "senone evaluation + normaliser", "mark, renormalise, reset", "evaluate (gather + hmm_vit_eval)", "prune + exits (save_bp)",

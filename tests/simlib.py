@@ -223,6 +223,11 @@ class SimFwdflatSearch:
                            int(t["max_topn"][0]), int(k["logadd8"].size))
             for i, v in enumerate(fl):
                 view.featlen[i] = v; view.featoff[i] = sum(fl[:i])
+            if lists is not None:                        # the weights senone-major as well (psgpu_ptm_view_t.mixw_sen), as the product's model has them
+                nd = int(t["n_density"][0]); ds = (nd + 63) & ~63
+                k["mixw_sen"] = np.zeros((int(t["n_sen"][0]), int(t["n_feat"][0]), ds), np.uint8)
+                k["mixw_sen"][:, :, :nd] = np.transpose(k["mixw"].reshape(int(t["n_feat"][0]), nd, int(t["n_sen"][0])), (2, 0, 1))
+                view.mixw_sen = k["mixw_sen"].ctypes.data
             d_s = np.ascontiguousarray(senscr, np.float32)
             d_seed = np.ascontiguousarray(topn_seed, np.int32)
             assert d_s.shape == (int(off[-1]), view.veclen) and d_seed.size == n * view.n_mgau * view.n_feat * view.topn

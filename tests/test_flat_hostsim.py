@@ -206,3 +206,23 @@ def test_flat_kernel_source_taking_the_batch_scorers_lists(case, extra_open):
                      lists=(sc, cw, op))[0]
         check_flat(r, g, "%s (extra open %s)" % (case, extra_open))
         s.close()
+
+
+@pytest.mark.parametrize("case", ["goforward", "something_efwid2_sfwin8"])
+def test_flat_kernel_source_more_exits_than_the_queue_holds(case):
+    """a frame's word exits are queued in LDS (kFfMaxExit); a frame with more goes through flags in the slab instead.  The
+    simulator's build reads the queue's capacity from a variable: with room for ONE exit nearly every frame that has exits takes
+    the other path, and the tables must be the same."""
+    import ctypes
+    g, st, fst = load_flat(case)
+    cap = ctypes.c_int.in_dll(simlib.lib(), "psgpu_sim_ff_exit_cap")
+    old = cap.value
+    try:
+        cap.value = 1
+        with _order("rev"):
+            s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+            r = s.search(flat_rows(g, s.n_sen), [int(g["flat_n_steps"][0])], [g["bp1"]], [g["flat_w1_ssid"]])[0]
+            check_flat(r, g, case)
+            s.close()
+    finally:
+        cap.value = old
