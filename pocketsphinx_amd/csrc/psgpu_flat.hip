@@ -33,8 +33,14 @@
 #include <cstdio>
 extern "C" { int psgpu_sim_ff_exit_cap = 256; }      // (tests shrink it to drive the frames through the other path)
 #define FF_EXIT_CAP psgpu_sim_ff_exit_cap
+extern "C" { int psgpu_sim_ff_el_cap = 384; }
+#define FF_EL_CAP psgpu_sim_ff_el_cap
+extern "C" { int psgpu_sim_ff_awl_regs = 1024; }
+#define FF_AWL_REGS psgpu_sim_ff_awl_regs
 #else
 #define FF_EXIT_CAP kFfMaxExit
+#define FF_EL_CAP kFfMaxEl
+#define FF_AWL_REGS (4 * kFfThreads)
 #endif
 
 constexpr int kFfThreads = 256;
@@ -45,6 +51,7 @@ constexpr int kFfMaxCb = 256;          // codebooks
 constexpr int kFfMaxTopn = 8;
 constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
 constexpr int kFfChanMask = (1 << 29) - 1, kFfClearBit = 1 << 29;   // FfUtt::elist entries
+constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel list held in LDS (the rest in the slab)
 constexpr int kFfMaxExit = 256;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
@@ -95,9 +102,9 @@ struct FfUtt {
     int32_t *tmat, *mpx, *rcid, *xflag;  // [C]
     int32_t *elist;                      // [C] the frame's active channels (evaluation work list; bit 30: </s>'s root, bit 29: see the pruning)
     int32_t *einfo;                      // [C] per entry of elist: position of the channel's word in the active word list << 10 | position in its chain
-    int32_t *wchain, *wlen;              // [n_w] chain offset (channel index) or -1, chain length
+    int32_t *wchain, *wlen, *wrcs;       // [n_w] chain offset (channel index) or -1, chain length, right-context channels (0: single phone)
     int32_t *word_active, *word_lat_idx; // [n_w] (word_active: frame stamp)
-    int32_t *awl[2];                     // [awl_cap]
+    int32_t *awl[2];                     // [awl_cap][3] the active words: word, first channel, channels | right contexts << 10 | single phone << 20
     int32_t *cnt_a, *cnt_b, *cnt_c;      // [max(awl_cap, nwd + fillers) + 1] scan scratch
     int32_t *bp, *bss, *bp_table_idx, *step, *result;
     const int32_t *w1_ssid_in;           // [n1][n_emit] or NULL
@@ -109,7 +116,7 @@ struct FfUtt {
 // kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
 // wait counters); pointers formed from a kernel argument are global.
 #define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(einfo) X(wchain) \
-    X(wlen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
+    X(wlen) X(wrcs) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
 #define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf)
 struct FfOff {
 #define X(f) int64_t f;
@@ -248,6 +255,26 @@ __device__ void ff_save_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_
     ff_set_real_wid(p, u, bpidx);
 }
 
+// ... when the word has no entry in this frame yet (the branch at ngram_search.c:438-497), with what the caller already holds: the
+// word's right-context count and whether it is a single phone.  Every load below is independent of the others.
+__device__ __forceinline__ void ff_new_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score,
+                                          int32_t path, int rc, int rcsize, bool single)
+{
+    const int32_t last = p.d_last[w], last2 = single ? -1 : p.d_last2[w], base = p.d_base[w], filler = p.d_filler[w];
+    const int32_t preal = path != -1 ? FBP(u, F_REAL, path) : -1, ppreal = path != -1 ? FBP(u, F_PREAL, path) : -1;
+    u.word_lat_idx[w] = bpidx;
+    FBP(u, F_WID, bpidx) = w; FBP(u, F_FRAME, bpidx) = frame; FBP(u, F_BP, bpidx) = path; FBP(u, F_SCORE, bpidx) = score;
+    FBP(u, F_SIDX, bpidx) = single ? -1 : bss_head; FBP(u, F_VALID, bpidx) = 1;
+    FBP(u, F_LAST, bpidx) = last; FBP(u, F_LAST2, bpidx) = last2;
+    if (!single) {
+        for (int i = 0; i < rcsize; ++i) u.bss[bss_head + i] = kW;
+        if (rcsize) u.bss[bss_head + rc] = score;
+    }
+    // set_real_wid (ngram_search.c:341-372)
+    if (filler) { FBP(u, F_REAL, bpidx) = path != -1 ? preal : base; FBP(u, F_PREAL, bpidx) = path != -1 ? ppreal : -1; }
+    else { FBP(u, F_REAL, bpidx) = base; FBP(u, F_PREAL, bpidx) = preal; }
+}
+
 // exclusive prefix sum of a[0..n) in place by the whole workgroup; returns the total.  Ends with a barrier.
 __device__ __forceinline__ int32_t ff_block_scan(int32_t *a, int n, int32_t *tmp)
 {
@@ -308,13 +335,37 @@ __device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
     return excl;
 }
 
+// exclusive prefix sum of one value per work-item; total = the workgroup's sum.  One barrier inside (tmp must not be in use before
+// the caller's previous barrier, nor be written again before its next).
+__device__ __forceinline__ int32_t ff_block_excl_sum(int32_t v, int32_t *tmp, int32_t &total)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    int32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) tmp[tid >> 6] = incl;
+    __syncthreads();
+    int32_t base = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < kFfThreads / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
+    return base + incl - v;
+}
+// an active word list entry: word, first channel, channels | right-context count << 10 | single phone << 20
+__device__ __forceinline__ void ff_awl_put(const FfDev &p, const FfUtt &u, int32_t *awl, int pos, int w)
+{
+    int len; const int c0 = ff_root(p, u, w, len);
+    awl[pos * 3] = w; awl[pos * 3 + 1] = c0; awl[pos * 3 + 2] = len | (u.wrcs[w] << 10) | ((u.wchain[w] < 0 ? 1 : 0) << 20);
+}
+
 template <int NE, bool RAW>
 __global__ __launch_bounds__(kFfThreads)
 void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const int16_t *__restrict__ senscr, int64_t scr_stride,
                     const int32_t *__restrict__ utt_off, FfRaw rw)
 {
     __shared__ uint32_t s_bits[RAW ? kFfMaxSen / 32 : 1];
-    __shared__ int32_t s_lcw[RAW ? kFfMaxEnt : 1], s_lsc[RAW ? kFfMaxEnt : 1];   // the scorer's lists: codeword, score
+    __shared__ uint8_t s_lcw[RAW ? kFfMaxEnt : 1];                // the scorer's lists: codeword,
+    __shared__ int32_t s_lsc[RAW ? kFfMaxEnt : 1];                //   score
+    __shared__ uint8_t s_s2cb[RAW ? kFfMaxSen : 1];               // the model's senone -> codebook map
     __shared__ uint8_t s_cbact[RAW ? kFfMaxCb : 1], s_la[RAW ? 512 : 1];  // (log-add table readable up to 511: zero beyond the reference's entries)
     // senones scored evenly over the work-items (the first pass's way, psgpu_sen_dev.h): the frame's lists packed four to a word, the
     // listed senones as a list (prefix sum over the bitmap words' populations)
@@ -327,6 +378,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ int32_t s_shadow[RAW ? kFfMaxEnt : 1];
 #endif
     __shared__ int32_t s_lk[RAW ? kFfMaxEnt / 4 : 1];    // per chain: the last frame after which s_lcw holds its list (-1: the seed)
+    __shared__ int32_t s_el[kFfMaxEl][4];                        // the active-channel list: channel | flags, word's list position << 10 | chain
+                                                                 //   position, word, channels after it | word's right-context count << 10 | single-phone << 20
     __shared__ int32_t s_ex[kFfMaxExit][8], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
     __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset
     __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
@@ -365,14 +418,14 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (u.w1_ssid_in && p.w1_mpx[i])        // what the first pass left in the permanent channels (hmm_clear keeps the ssids)
             for (int k = 0; k < p.n_emit; ++k) u.senid[i * 5 + k] = u.w1_ssid_in[i * p.n_emit + k];
     }
-    for (int w = tid; w < p.n_w; w += kFfThreads) { u.wchain[w] = -1; u.wlen[w] = 0; u.word_active[w] = -1; u.word_lat_idx[w] = -1; }
+    for (int w = tid; w < p.n_w; w += kFfThreads) { u.wchain[w] = -1; u.wlen[w] = 0; u.wrcs[w] = 0; u.word_active[w] = -1; u.word_lat_idx[w] = -1; }
     __syncthreads();
     for (int k = tid; k < u.nwd; k += kFfThreads) {
         const int w = u.wl_wid[k], c0 = u.wl_chain[k];
         if (c0 < 0) continue;
         const int len = p.d_pronlen[w], last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
         int c = c0;
-        u.wchain[w] = c0; u.wlen[w] = u.wl_len[k];
+        u.wchain[w] = c0; u.wlen[w] = u.wl_len[k]; u.wrcs[w] = nrc;
         ff_init(p, u, c++, 1, p.ci_ssid[p.d_first[w]], p.ci_tmat[p.d_first[w]], -1);
         for (int q = 1; q < len - 1; ++q) {
             const int o = p.pron_off[w] + q;
@@ -384,7 +437,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = 0; s_sc[3] = 0; s_sc[4] = 0;
         ff_enter(u, p.w1_of_word[p.startwid], 0, -1, 0);
-        u.awl[0][0] = p.startwid;
+        ff_awl_put(p, u, u.awl[0], 0, p.startwid);
     }
     n_awl[0] = 1;
     const int n_chain = RAW ? rw.pm.n_mgau * rw.pm.n_feat : 0, topn = RAW ? rw.pm.topn : 0;
@@ -395,6 +448,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         for (int i = tid; i < n_chain * topn; i += kFfThreads) s_shadow[i] = s_lcw[i];
 #endif
         for (int i = tid; i < 512; i += kFfThreads) s_la[i] = (i < rw.pm.logadd8_size && i < 256) ? rw.pm.logadd8[i] : 0;
+        for (int i = tid; i < rw.pm.n_sen; i += kFfThreads) s_s2cb[i] = rw.pm.sen2cb[i];
     }
     __syncthreads();
 
@@ -413,28 +467,48 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         }
         __syncthreads();
         for (int i = tid >> 4; i < na; i += kFfThreads / 16) {          // sixteen work-items a word: its chain's stamps read side by side
-            const int w = u.awl[cur][i];
-            int len; const int c0 = ff_root(p, u, w, len);
-            for (int k = tid & 15; k < len; k += 16)
-                if (u.frame[c0 + k] == f) {                   // bit 30: the root of </s>, which does not count towards the best score
-                    const int c = c0 + k, pos = atomicAdd(&s_sc[7], 1);
-                    u.elist[pos] = c | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
-                    u.einfo[pos] = (i << 10) | k;
+            const int w = u.awl[cur][i * 3], c0 = u.awl[cur][i * 3 + 1], wx = u.awl[cur][i * 3 + 2], len = wx & 1023;
+            for (int k = tid & 15; k < len; k += 16) {
+                const int c = c0 + k;
+                // (the stamp and what an active channel needs next asked for together: one trip to memory instead of two)
+                const int32_t stamp = u.frame[c];
+                int32_t sid[NE];
+                bool mpx = false;
+                if (RAW) {
+                    mpx = u.mpx[c] != 0;
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) sid[q] = u.senid[c * 5 + q];
+                }
+                if (stamp == f) {                             // bit 30: the root of </s>, which does not count towards the best score
+                    const int pos = atomicAdd(&s_sc[7], 1);
+                    const int cf = c | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
+                    if (pos < FF_EL_CAP) {
+                        int32_t *x = s_el[pos];
+                        x[0] = cf; x[1] = (i << 10) | k; x[2] = w; x[3] = (len - k - 1) | (wx & ~1023);
+                    }
+                    else { u.elist[pos] = cf; u.einfo[pos] = (i << 10) | k; }
                     if (RAW) {
                         // compute_fwdflat_sen_active (:416-442): the channel's senones into the frame's bitmap, and -- the first time
                         // a senone is marked -- into the list the evaluation below goes over (its order does not matter there)
-                        const bool mpx = u.mpx[c] != 0;
+#pragma unroll
                         for (int q = 0; q < NE; ++q) {
-                            int sen = u.senid[c * 5 + q];
+                            int sen = sid[q];
                             if (mpx) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
                             const uint32_t bit = 1u << (sen & 31);
                             if (!(atomicOr(&s_bits[sen >> 5], bit) & bit)) s_slist[atomicAdd(&s_nl, 1)] = (uint16_t)sen;
                         }
                     }
                 }
+            }
         }
         __syncthreads();
         const int n_eval = s_sc[7];
+        struct FfEnt { int32_t c, inf, w, aux; };
+        auto ent = [&](int e) -> FfEnt {
+            if (e < FF_EL_CAP) { const int32_t *x = s_el[e]; return { x[0], x[1], x[2], x[3] }; }
+            const int32_t inf = u.einfo[e], w = u.awl[cur][(inf >> 10) * 3], wx = u.awl[cur][(inf >> 10) * 3 + 2];
+            return { u.elist[e], inf, w, ((wx & 1023) - (inf & 1023) - 1) | (wx & ~1023) };
+        };
         if (RAW) {
             const psgpu_ptm_view_t &pm = rw.pm;
             const float *x = rw.feats + (size_t)(t0 + f) * pm.veclen;
@@ -450,12 +524,12 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     const int sen = tid * 32 + __ffs((int)bw) - 1;
                     for (int last = pv < 0 ? 0 : pv; sen - last > 255;) {
                         last += 255;
-                        s_cbact[pm.sen2cb[last]] = 1;
+                        s_cbact[s_s2cb[last]] = 1;
                         s_slist[atomicAdd(&s_nl, 1)] = (uint16_t)last;
                     }
                 }
             }
-            for (int i = tid; i < n_l0; i += kFfThreads) s_cbact[pm.sen2cb[s_slist[i]]] = 1;
+            for (int i = tid; i < n_l0; i += kFfThreads) s_cbact[s_s2cb[s_slist[i]]] = 1;
             __syncthreads();
             FF_PROF(0);
             // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain.
@@ -486,10 +560,16 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 if (lazy && !s_cbact[cb]) shadow_rescore();
 #endif
                 if (lazy && !s_cbact[cb]) continue;
-                if (lazy && !rw.open[(size_t)ch * rw.total + t0 + f]) {
-                    const size_t o = (size_t)ch * rw.total + t0 + f;
-                    const FfQuad q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4);
-                    const uint32_t c4 = rw.tcw[o];
+                const size_t o = (size_t)ch * rw.total + t0 + f;
+                FfQuad q = { 0, 0, 0, 0 };
+                uint32_t c4 = 0;
+                bool closed = false;
+                if (lazy) {                                      // (asked for together: one trip to memory)
+                    q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4);
+                    c4 = rw.tcw[o];
+                    closed = !rw.open[o];
+                }
+                if (closed) {
                     s_lsc[ch * 4] = q.x; s_lsc[ch * 4 + 1] = q.y; s_lsc[ch * 4 + 2] = q.z; s_lsc[ch * 4 + 3] = q.w;
                     s_lcw[ch * 4] = c4 & 0xff; s_lcw[ch * 4 + 1] = (c4 >> 8) & 0xff; s_lcw[ch * 4 + 2] = (c4 >> 16) & 0xff; s_lcw[ch * 4 + 3] = c4 >> 24;
                     s_lk[ch] = f;
@@ -571,7 +651,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const int n_l = s_nl;
             int32_t mn = 0x7fffffff;
             auto senone = [&](int sen) {
-                const int cb = pm.sen2cb[sen];
+                const int cb = s_s2cb[sen];
                 int32_t a = 0;
                 for (int fs = 0; fs < pm.n_feat; ++fs) {
                     const int li = (cb * pm.n_feat + fs) * topn;
@@ -599,7 +679,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 for (int j = 0; j < 4; ++j) {
                     const int i = tid + j * kFfThreads;
                     av[j] = 0x7fffffff;
-                    if (i < n_l) av[j] = fast ? sen_eval_f3n4(smod, s_pcw, s_psc, s_la, (int)s_slist[i]) : senone((int)s_slist[i]);
+                    if (i < n_l) av[j] = fast ? sen_eval_f3n4_cb(smod, s_pcw, s_psc, s_la, (int)s_slist[i], s_s2cb[s_slist[i]]) : senone((int)s_slist[i]);
                     mn = min(mn, av[j]);
                 }
                 wg_min(mn);
@@ -615,7 +695,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 const SenModel smod = { pm.mixw_sen, pm.sen2cb, pm.n_sen, pm.n_density };
                 for (int i = tid; i < n_l; i += kFfThreads) {
                     const int sen = s_slist[i];
-                    const int32_t a = fast ? sen_eval_f3n4(smod, s_pcw, s_psc, s_la, sen) : senone(sen);
+                    const int32_t a = fast ? sen_eval_f3n4_cb(smod, s_pcw, s_psc, s_la, sen, s_s2cb[sen]) : senone(sen);
                     u.nrow32[sen] = a;
                     mn = min(mn, a);
                 }
@@ -637,7 +717,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (best_in == kW || best_in < kW) break;
         if (best_in + 2 * p.beam < kW)                       // fwdflat_renormalize_scores (:784-810)
             for (int i = tid; i < na; i += kFfThreads) {
-                int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
+                const int c0 = u.awl[cur][i * 3 + 1], len = u.awl[cur][i * 3 + 2] & 1023;
                 for (int k = 0; k < len; ++k) if (u.frame[c0 + k] == f) ff_normalize(p, u, c0 + k, best_in);
             }
         __syncthreads();
@@ -649,7 +729,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         {
             int32_t b = kW;
             for (int i = tid; i < n_eval; i += kFfThreads) {
-                const int e = u.elist[i];
+                const int e = i < FF_EL_CAP ? s_el[i][0] : u.elist[i];
                 const int32_t sc = ff_eval<NE>(p, u, e & kFfChanMask, row);
                 if (!(e & (1 << 30))) b = max(b, sc);
             }
@@ -667,20 +747,19 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      (3) a channel that neither survived nor was entered is cleared (the walk's "else if frame != nf").  A channel that
         //      was not active is never looked at: it was cleared when it left the list, its best score is WORST_SCORE.
         for (int e = tid; e < n_eval; e += kFfThreads) {
-            const int c = u.elist[e] & kFfChanMask, inf = u.einfo[e], i = inf >> 10, k = inf & 1023;
-            if (u.best[c] > thresh) {
-                const int w = u.awl[cur][i];
-                int len; const int c0 = ff_root(p, u, w, len);
-                int32_t newscore = u.out[c];
+            const FfEnt en = ent(e);
+            const int c = en.c & kFfChanMask, k = en.inf & 1023, rem = en.aux & 1023, w = en.w;
+            const int32_t best = u.best[c], out = u.out[c], hist = u.outh[c], rc = u.rcid[c], rc1 = rem > 0 ? u.rcid[c + 1] : -1;
+            if (best > thresh) {
+                int32_t newscore = out;
                 u.frame[c] = nf; u.word_active[w] = nf;
-                if (k == 0 ? len > 1 : u.rcid[c] < 0) {
+                if (k == 0 ? rem > 0 : rc < 0) {
                     newscore += p.pip;
                     if (newscore > thresh) {
-                        const int32_t hist = u.outh[c];
-                        if (u.rcid[c + 1] >= 0 && len - (k + 1) > 1) {
+                        if (rc1 >= 0 && rem > 1) {
                             const int q = atomicAdd(&s_nfan, 1);
-                            if (q < kFfMaxFan) { s_fan[q][0] = c + 1; s_fan[q][1] = len - (k + 1); s_fan[q][2] = newscore; s_fan[q][3] = hist; }
-                            else for (int j = k + 1; j < len; ++j) ff_enter_if_better(u, c0 + j, newscore, hist, f);
+                            if (q < kFfMaxFan) { s_fan[q][0] = c + 1; s_fan[q][1] = rem; s_fan[q][2] = newscore; s_fan[q][3] = hist; }
+                            else for (int j = 1; j <= rem; ++j) ff_enter_if_better(u, c + j, newscore, hist, f);
                         }
                         else ff_enter_if_better(u, c + 1, newscore, hist, f);
                     }
@@ -689,20 +768,20 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     const int q = atomicAdd(&s_nex, 1);
                     if (q < FF_EXIT_CAP) {
                         int32_t *x = s_ex[q];
-                        x[0] = inf; x[1] = c; x[2] = newscore; x[3] = u.outh[c];
-                        x[4] = p.d_pronlen[w] > 1 ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
-                        x[5] = k == 0 ? 0 : u.rcid[c];
+                        x[0] = en.inf; x[1] = w | ((en.aux >> 20) << 30); x[2] = newscore; x[3] = hist;
+                        x[4] = (en.aux >> 10) & 1023;
+                        x[5] = k == 0 ? 0 : rc;
                     }
                 }
             }
-            else if (k > 0) u.elist[e] |= kFfClearBit;
+            else if (k > 0) { if (e < FF_EL_CAP) s_el[e][0] = en.c | kFfClearBit; else u.elist[e] = en.c | kFfClearBit; }
         }
         __syncthreads();
         for (int q = tid >> 6, nq = min(s_nfan, kFfMaxFan); q < nq; q += kFfThreads / 64)
             for (int j = tid & 63; j < s_fan[q][1]; j += 64) ff_enter_if_better(u, s_fan[q][0] + j, s_fan[q][2], s_fan[q][3], f);
         __syncthreads();
         for (int e = tid; e < n_eval; e += kFfThreads) {
-            const int v = u.elist[e];
+            const int v = e < FF_EL_CAP ? s_el[e][0] : u.elist[e];
             if ((v & kFfClearBit) && u.frame[v & kFfChanMask] != nf) ff_clear_scores(p, u, v & kFfChanMask);
         }
         __syncthreads();
@@ -740,9 +819,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 for (int r = tid; r < n_ex; r += kFfThreads) {
                     const int32_t *x = s_ex[s_ord[r]];
                     if (x[6] < 0) continue;
-                    const int i = x[0] >> 10, w = u.awl[cur][i];
+                    const int i = x[0] >> 10, w = x[1] & 0x3fffffff;
                     const int32_t bpi = bpidx + x[6], bsh = bss_head + x[7];
-                    ff_save_bp(p, u, bpi, bsh, f, w, x[2], x[3], x[5]);          // (word_lat_idx[w] is -1: a new entry)
+                    ff_new_bp(p, u, bpi, bsh, f, w, x[2], x[3], x[5], x[4], (x[1] >> 30) != 0);   // (word_lat_idx[w] is -1: a new entry)
                     int32_t cs = x[2], cp = x[3];
                     bool dirty = false;
                     for (int r2 = r + 1; r2 < n_ex; ++r2) {                      // the update branch of save_bp (ngram_search.c:405-437)
@@ -771,11 +850,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             for (int i = tid; i < na; i += kFfThreads) { u.cnt_a[i] = 0; u.cnt_b[i] = 0; }
             __syncthreads();
             for (int e = tid; e < n_eval; e += kFfThreads) {                      // the exit test again (what failed it was cleared above)
-                const int c = u.elist[e] & kFfChanMask, inf = u.einfo[e], i = inf >> 10, k = inf & 1023;
+                const FfEnt en = ent(e);
+                const int c = en.c & kFfChanMask, i = en.inf >> 10, k = en.inf & 1023, w = en.w;
                 if (!(u.best[c] > thresh && u.out[c] > wordthresh)) continue;
-                const int w = u.awl[cur][i];
-                int len; ff_root(p, u, w, len);
-                if (k == 0 ? len > 1 : u.rcid[c] < 0) continue;
+                if (k == 0 ? (en.aux & 1023) > 0 : u.rcid[c] < 0) continue;
                 u.xflag[c] = 1; u.cnt_a[i] = 1;
                 u.cnt_b[i] = p.d_pronlen[w] > 1 ? p.rs_n[p.d_last[w] * p.n_ci + p.d_last2[w]] : 0;
             }
@@ -785,8 +863,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
             for (int i = tid; i < na; i += kFfThreads) {
                 if ((i + 1 < na ? u.cnt_a[i + 1] : n_exit) == u.cnt_a[i]) continue;
-                const int w = u.awl[cur][i];
-                int len; const int c0 = ff_root(p, u, w, len);
+                const int w = u.awl[cur][i * 3], c0 = u.awl[cur][i * 3 + 1], len = u.awl[cur][i * 3 + 2] & 1023;
                 const int32_t bpi = bpidx + u.cnt_a[i], bsh = bss_head + u.cnt_b[i];
                 for (int k = 0; k < len; ++k) {
                     const int c = c0 + k;
@@ -815,8 +892,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             if (sil > kW)
                 atomicMax(&s_key, ((unsigned long long)(uint32_t)(sil - kW) << 32) | (uint32_t)(0x7fffffff - b));
         }
-        // successors: the vocabulary words that start within the window of this frame (get_expand_wordlist :609-640)
-        {
+        // successors: the vocabulary words that start within the window of this frame (get_expand_wordlist :609-640); a frame without
+        // exits has none, and no way into <sil> or the noise words either
+        if (bp1 > bp0) {
             int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
             if (sf0 < 0) sf0 = 0;
             if (ef0 > u.n_frame) ef0 = u.n_frame;
@@ -847,7 +925,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             }
         }
         __syncthreads();
-        {
+        if (bp1 > bp0) {
             // <sil> and the noise words (:755-769)
             const unsigned long long key = s_key;
             const int32_t silscore = key ? (int32_t)(uint32_t)(key >> 32) + kW : kW;
@@ -868,21 +946,44 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         __syncthreads();
         // initial channels of words that stayed inactive (:771-781)
         for (int i = tid; i < na; i += kFfThreads) {
-            int len; const int c0 = ff_root(p, u, u.awl[cur][i], len);
+            const int c0 = u.awl[cur][i * 3 + 1];
             if (u.frame[c0] == f) ff_clear_scores(p, u, c0);
         }
         FF_PROF(6);
         // ---- next active word list (:853-869): the vocabulary in its order (words below <s>), then <s> and above by id
         const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
-        for (int i = tid; i < n_all; i += kFfThreads) {
-            const int w = i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd);
-            u.cnt_c[i] = (u.word_active[w] == nf && (i < u.nwd ? w < p.startwid : true)) ? 1 : 0;
+        int32_t n_next;
+        if (n_all <= FF_AWL_REGS) {                          // four consecutive candidates a work-item, their places by one prefix sum
+            int wq[4], c0q[4], axq[4], fl = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid * 4 + j;
+                wq[j] = i < u.nwd ? u.wl_wid[i < u.nwd ? i : 0] : p.startwid + (i - u.nwd);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                    // (everything an entry holds asked for with the stamp: nothing to fetch after the sum)
+                const int i = tid * 4 + j, w = i < n_all ? wq[j] : p.startwid;
+                const int32_t stamp = u.word_active[w], ch = u.wchain[w], ln = u.wlen[w], rcs = u.wrcs[w], w1 = p.w1_of_word[w];
+                if (i < n_all && stamp == nf && (i < u.nwd ? w < p.startwid : true)) fl |= 1 << j;
+                c0q[j] = ch >= 0 ? ch : w1;
+                axq[j] = (ch >= 0 ? ln : 1) | (rcs << 10) | ((ch < 0 ? 1 : 0) << 20);
+            }
+            int pos = ff_block_excl_sum(__popc(fl), s_scan, n_next);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (fl & (1 << j)) { int32_t *a = u.awl[nxt] + 3 * pos++; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j]; }
         }
-        __syncthreads();
-        const int32_t n_next = ff_block_scan(u.cnt_c, n_all, s_scan);
-        for (int i = tid; i < n_all; i += kFfThreads)
-            if ((i + 1 < n_all ? u.cnt_c[i + 1] : n_next) != u.cnt_c[i])
-                u.awl[nxt][u.cnt_c[i]] = i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd);
+        else {
+            for (int i = tid; i < n_all; i += kFfThreads) {
+                const int w = i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd);
+                u.cnt_c[i] = (u.word_active[w] == nf && (i < u.nwd ? w < p.startwid : true)) ? 1 : 0;
+            }
+            __syncthreads();
+            n_next = ff_block_scan(u.cnt_c, n_all, s_scan);
+            for (int i = tid; i < n_all; i += kFfThreads)
+                if ((i + 1 < n_all ? u.cnt_c[i + 1] : n_next) != u.cnt_c[i])
+                    ff_awl_put(p, u, u.awl[nxt], u.cnt_c[i], i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd));
+        }
         n_awl[nxt] = n_next;
         if (tid == 0) {
             u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = 0; u.step[f * 4 + 2] = s_sc[1]; u.step[f * 4 + 3] = n_next;
@@ -1105,7 +1206,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         for (size_t k = 0; k < nwd; ++k)
             PSGPU_REQUIRE(voc[u].len[k] < 1024, "psgpu_fwdflat_search: a word chain of %d channels (FfUtt::einfo holds 10 bits)", voc[u].len[k]);
         PSGPU_REQUIRE(cap < (1u << 21), "psgpu_fwdflat_search: %zu active words (FfUtt::einfo holds 21 bits)", cap);
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 4 * (size_t)d.n_w + 2 * cap + 3 * (cap + 1) + 16
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + 6 * cap + 3 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
     }
@@ -1133,8 +1234,8 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
         u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
         u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C); u.einfo = take(C);
-        u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
-        u.awl[0] = take(cap); u.awl[1] = take(cap);
+        u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.wrcs = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
+        u.awl[0] = take(3 * cap); u.awl[1] = take(3 * cap);
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
         u.nrow32 = raw ? take(d.n_sen) : nullptr;
         u.nrow = raw ? reinterpret_cast<int16_t *>(take((size_t)d.n_sen / 2 + 1)) : nullptr;

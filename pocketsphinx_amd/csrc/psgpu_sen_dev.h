@@ -28,9 +28,9 @@ __device__ __forceinline__ uint32_t sen_pack_scores(int32_t s0, int32_t s1, int3
 // (:326-403) one senone: the sum over the streams of the log-sum over the top-N codewords of (weight + score).  l_cw / l_sc:
 // the frame's lists per chain, packed four to a word (LDS); la: the 8-bit log-add table, readable up to index 511 (zero
 // beyond the reference's 256 entries -- fast_logmath_add, tied_mgau_common.h:106-125, min(x, y) - T[|x - y|]).
-__device__ __forceinline__ int32_t sen_eval_f3n4(const SenModel &m, const uint32_t *l_cw, const uint32_t *l_sc, const uint8_t *la, int sen)
+// (_cb: the senone's codebook given by the caller, who has the map closer than device memory)
+__device__ __forceinline__ int32_t sen_eval_f3n4_cb(const SenModel &m, const uint32_t *l_cw, const uint32_t *l_sc, const uint8_t *la, int sen, int cb)
 {
-    const int cb = m.sen2cb[sen];
     uint32_t w[kSenStreams][kSenTopn], nsc[kSenStreams];
 #pragma unroll
     for (int f = 0; f < kSenStreams; ++f) {                  // all twelve weights are asked for before the first is used
@@ -57,4 +57,8 @@ __device__ __forceinline__ int32_t sen_eval_f3n4(const SenModel &m, const uint32
         for (int f = 0; f < kSenStreams; ++f) fden[f] = lo[f] - (int32_t)la[dd[f]];
     }
     return fden[0] + fden[1] + fden[2];
+}
+__device__ __forceinline__ int32_t sen_eval_f3n4(const SenModel &m, const uint32_t *l_cw, const uint32_t *l_sc, const uint8_t *la, int sen)
+{
+    return sen_eval_f3n4_cb(m, l_cw, l_sc, la, sen, m.sen2cb[sen]);
 }

@@ -208,21 +208,30 @@ def test_flat_kernel_source_taking_the_batch_scorers_lists(case, extra_open):
         s.close()
 
 
+@pytest.mark.parametrize("knob", ["psgpu_sim_ff_exit_cap:1", "psgpu_sim_ff_el_cap:3", "psgpu_sim_ff_awl_regs:0"])
 @pytest.mark.parametrize("case", ["goforward", "something_efwid2_sfwin8"])
-def test_flat_kernel_source_more_exits_than_the_queue_holds(case):
-    """a frame's word exits are queued in LDS (kFfMaxExit); a frame with more goes through flags in the slab instead.  The
-    simulator's build reads the queue's capacity from a variable: with room for ONE exit nearly every frame that has exits takes
-    the other path, and the tables must be the same."""
+def test_flat_kernel_source_more_than_the_lds_queues_hold(case, knob):
+    """a frame's word exits (kFfMaxExit) and its active-channel list (kFfMaxEl) are held in LDS; what does not fit goes through
+    the slab -- flags per channel for the exits of such a frame, the list's tail in the slab's arrays.  The simulator's build
+    reads both capacities from variables: with room for ONE exit / THREE list entries nearly every frame takes the other
+    paths (third knob: the next active word list by a scan through the slab, as vocabularies beyond 1024 words get it), scoring its own senones from the batch scorer's lists or given the scores, and the tables must be the same."""
     import ctypes
+    import pso
     g, st, fst = load_flat(case)
-    cap = ctypes.c_int.in_dll(simlib.lib(), "psgpu_sim_ff_exit_cap")
+    name, val = knob.split(":")
+    cap = ctypes.c_int.in_dll(simlib.lib(), name)
     old = cap.value
     try:
-        cap.value = 1
+        cap.value = int(val)
         with _order("rev"):
             s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
             r = s.search(flat_rows(g, s.n_sen), [int(g["flat_n_steps"][0])], [g["bp1"]], [g["flat_w1_ssid"]])[0]
             check_flat(r, g, case)
+            t = pso.load_tables()
+            feats = g["flat_feat"]
+            r = s.search(feats, [feats.shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=t, topn_seed=g["flat_ptm_seed"],
+                         lists=_all_density_lists(t, feats))[0]
+            check_flat(r, g, case + " (scoring)")
             s.close()
     finally:
         cap.value = old
