@@ -31,7 +31,7 @@
 #if !defined(__HIPCC__)
 #define PSGPU_FF_CHECK_LAZY 1
 #include <cstdio>
-extern "C" { int psgpu_sim_ff_exit_cap = 256; }      // (tests shrink it to drive the frames through the other path)
+extern "C" { int psgpu_sim_ff_exit_cap = 160; }      // (tests shrink it to drive the frames through the other path)
 #define FF_EXIT_CAP psgpu_sim_ff_exit_cap
 extern "C" { int psgpu_sim_ff_el_cap = 384; }
 #define FF_EL_CAP psgpu_sim_ff_el_cap
@@ -50,9 +50,9 @@ constexpr int kFfMaxEnt = 1024;        // (codebook, stream) chains x top-N entr
 constexpr int kFfMaxCb = 256;          // codebooks
 constexpr int kFfMaxTopn = 8;
 constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
-constexpr int kFfChanMask = (1 << 29) - 1, kFfClearBit = 1 << 29;   // FfUtt::elist entries
+constexpr int kFfChanMask = (1 << 28) - 1, kFfClearBit = 1 << 29, kFfEnteredBit = 1 << 28;   // FfUtt::elist entries
 constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel list held in LDS (the rest in the slab)
-constexpr int kFfMaxExit = 256;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
+constexpr int kFfMaxExit = 160;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
 // each frame's senone scores itself, as ptm_mgau_frame_eval does when the second pass calls it (ptm_mgau.c:408-454 with
@@ -182,7 +182,7 @@ __device__ __forceinline__ void ff_normalize(const FfDev &p, FfUtt &u, int c, in
 }
 
 template <int NE>
-__device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, const int16_t *row)
+__device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, const int16_t *row, int32_t &out_score, int32_t &out_hist, int32_t &score0)
 {
     HmmRegs h;
 #pragma unroll
@@ -199,6 +199,7 @@ __device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, cons
 #pragma unroll
     for (int i = 0; i < NE; ++i) { u.score[c * 5 + i] = h.score[i]; u.hist[c * 5 + i] = h.history[i]; u.senid[c * 5 + i] = h.senid[i]; }
     u.out[c] = h.out_score; u.outh[c] = h.out_history; u.best[c] = h.bestscore;
+    out_score = h.out_score; out_hist = h.out_history; score0 = h.score[0];
     return b;
 }
 
@@ -255,13 +256,12 @@ __device__ void ff_save_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_
     ff_set_real_wid(p, u, bpidx);
 }
 
-// ... when the word has no entry in this frame yet (the branch at ngram_search.c:438-497), with what the caller already holds: the
-// word's right-context count and whether it is a single phone.  Every load below is independent of the others.
-__device__ __forceinline__ void ff_new_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score,
-                                          int32_t path, int rc, int rcsize, bool single)
+// ... when the word has no entry in this frame yet (the branch at ngram_search.c:438-497; set_real_wid :341-372), with everything
+// it reads handed in by the caller (the pruning asked for it when it queued the exit): stores only.
+__device__ __forceinline__ void ff_new_bp(FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score, int32_t path, int rc,
+                                          int rcsize, bool single, int32_t last, int32_t last2, int32_t base, bool filler,
+                                          int32_t path_real, int32_t path_preal)
 {
-    const int32_t last = p.d_last[w], last2 = single ? -1 : p.d_last2[w], base = p.d_base[w], filler = p.d_filler[w];
-    const int32_t preal = path != -1 ? FBP(u, F_REAL, path) : -1, ppreal = path != -1 ? FBP(u, F_PREAL, path) : -1;
     u.word_lat_idx[w] = bpidx;
     FBP(u, F_WID, bpidx) = w; FBP(u, F_FRAME, bpidx) = frame; FBP(u, F_BP, bpidx) = path; FBP(u, F_SCORE, bpidx) = score;
     FBP(u, F_SIDX, bpidx) = single ? -1 : bss_head; FBP(u, F_VALID, bpidx) = 1;
@@ -270,9 +270,8 @@ __device__ __forceinline__ void ff_new_bp(const FfDev &p, FfUtt &u, int32_t bpid
         for (int i = 0; i < rcsize; ++i) u.bss[bss_head + i] = kW;
         if (rcsize) u.bss[bss_head + rc] = score;
     }
-    // set_real_wid (ngram_search.c:341-372)
-    if (filler) { FBP(u, F_REAL, bpidx) = path != -1 ? preal : base; FBP(u, F_PREAL, bpidx) = path != -1 ? ppreal : -1; }
-    else { FBP(u, F_REAL, bpidx) = base; FBP(u, F_PREAL, bpidx) = preal; }
+    if (filler) { FBP(u, F_REAL, bpidx) = path != -1 ? path_real : base; FBP(u, F_PREAL, bpidx) = path != -1 ? path_preal : -1; }
+    else { FBP(u, F_REAL, bpidx) = base; FBP(u, F_PREAL, bpidx) = path_real; }
 }
 
 // exclusive prefix sum of a[0..n) in place by the whole workgroup; returns the total.  Ends with a barrier.
@@ -377,11 +376,14 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #ifdef PSGPU_FF_CHECK_LAZY
     __shared__ int32_t s_shadow[RAW ? kFfMaxEnt : 1];
 #endif
+    __shared__ uint16_t s_openq[RAW ? kFfMaxEnt / 4 : 1];        // touched chains whose entry of this frame is open: scanned a wavefront each
+    __shared__ int32_t s_nopen;
     __shared__ int32_t s_lk[RAW ? kFfMaxEnt / 4 : 1];    // per chain: the last frame after which s_lcw holds its list (-1: the seed)
     __shared__ int32_t s_el[kFfMaxEl][4];                        // the active-channel list: channel | flags, word's list position << 10 | chain
                                                                  //   position, word, channels after it | word's right-context count << 10 | single-phone << 20
-    __shared__ int32_t s_ex[kFfMaxExit][8], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
-    __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset
+    __shared__ int32_t s_ex[kFfMaxExit][13], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
+    __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset,
+                                                                 //   the word's last / last-but-one phone, base word | filler << 30, the history's two real words
     __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, -, -, length of the evaluation list
     __shared__ unsigned long long s_key;
@@ -452,6 +454,23 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     }
     __syncthreads();
 
+    // the next active word list's candidates, four consecutive ones a work-item (vocabularies up to 4 x 256 words): static
+    const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
+    int wq[4] = { 0, 0, 0, 0 }, c0q[4] = { 0, 0, 0, 0 }, axq[4] = { 0, 0, 0, 0 };
+    if (n_all <= FF_AWL_REGS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid * 4 + j;
+            const int w = i < u.nwd ? u.wl_wid[i] : (i < n_all ? p.startwid + (i - u.nwd) : p.startwid);
+            const int32_t ch = u.wchain[w], ln = u.wlen[w], rcs = u.wrcs[w], w1 = p.w1_of_word[w];
+            wq[j] = w; c0q[j] = ch >= 0 ? ch : w1;
+            axq[j] = (ch >= 0 ? ln : 1) | (rcs << 10) | ((ch < 0 ? 1 : 0) << 20);
+        }
+    }
+    FfQuad pre_q = { 0, 0, 0, 0 };
+    uint32_t pre_c4 = 0;
+    bool pre_closed = false;
+    const bool ahead = RAW && rw.tsc && topn == 4 && n_chain <= kFfThreads;
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = n_awl[cur];
         const int16_t *row = RAW ? nullptr : senscr + (size_t)(t0 + f) * scr_stride;
@@ -459,7 +478,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
         //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
         //      profiles/r03_fwdflat_phase_profile.txt).  Nothing between here and the evaluation changes a channel's frame stamp.
-        if (tid == 0) { s_sc[7] = 0; s_nfan = 0; s_nex = 0; s_tot[0] = 0; s_tot[1] = 0; s_nl = 0; s_nb = 0x7fffffff; }
+        if (tid == 0) { s_sc[7] = 0; s_nfan = 0; s_nex = 0; s_tot[0] = 0; s_tot[1] = 0; s_nl = 0; s_nb = 0x7fffffff; s_nopen = 0; }
+        if (ahead && tid < n_chain) {
+            const size_t o = (size_t)tid * rw.total + t0 + f;
+            pre_q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); pre_c4 = rw.tcw[o]; pre_closed = !rw.open[o];
+        }
         if (RAW) {
             for (int i = tid; i < (rw.pm.n_sen + 31) >> 5; i += kFfThreads) s_bits[i] = 0u;
             for (int i = tid; i < rw.pm.n_mgau; i += kFfThreads) s_cbact[i] = 0;
@@ -502,6 +525,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             }
         }
         __syncthreads();
+        FF_PROF(8);
         const int n_eval = s_sc[7];
         struct FfEnt { int32_t c, inf, w, aux; };
         auto ent = [&](int e) -> FfEnt {
@@ -559,16 +583,17 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 };
                 if (lazy && !s_cbact[cb]) shadow_rescore();
 #endif
-                if (lazy && !s_cbact[cb]) continue;
-                const size_t o = (size_t)ch * rw.total + t0 + f;
-                FfQuad q = { 0, 0, 0, 0 };
-                uint32_t c4 = 0;
-                bool closed = false;
-                if (lazy) {                                      // (asked for together: one trip to memory)
-                    q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4);
-                    c4 = rw.tcw[o];
-                    closed = !rw.open[o];
+                // the batch scorer's entry of this chain and frame: asked for at the top of the frame (`ahead`: one chain per work-item,
+                // its registers hold it), where the trip to memory -- these lines are read once, no cache has them -- runs beside the
+                // active list's instead of after it
+                FfQuad q = pre_q;
+                uint32_t c4 = pre_c4;
+                bool closed = pre_closed;
+                if (lazy && !ahead) {
+                    const size_t o = (size_t)ch * rw.total + t0 + f;
+                    q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); c4 = rw.tcw[o]; closed = !rw.open[o];
                 }
+                if (lazy && !s_cbact[cb]) continue;
                 if (closed) {
                     s_lsc[ch * 4] = q.x; s_lsc[ch * 4 + 1] = q.y; s_lsc[ch * 4 + 2] = q.z; s_lsc[ch * 4 + 3] = q.w;
                     s_lcw[ch * 4] = c4 & 0xff; s_lcw[ch * 4 + 1] = (c4 >> 8) & 0xff; s_lcw[ch * 4 + 2] = (c4 >> 16) & 0xff; s_lcw[ch * 4 + 3] = c4 >> 24;
@@ -579,6 +604,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     atomicMax(&s_norm[fs], q.x >> 10);       // ptm_mgau_codebook_norm (:272-279)
                     continue;
                 }
+                if (lazy && pm.n_density == 128) { s_openq[atomicAdd(&s_nopen, 1)] = (uint16_t)ch; continue; }     // (a wavefront's job, below)
                 for (int i = 0; i < topn; ++i) cw[i] = s_lcw[ch * topn + i];
                 auto rescore = [&](const float *xg) {            // re-score, stable descending insertion with strict '>' (:71-85)
                     for (int i = 0; i < topn; ++i) {
@@ -630,6 +656,90 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 if (s_cbact[cb]) atomicMax(&s_norm[fs], sc[0] >> 10);        // ptm_mgau_codebook_norm (:272-279)
             }
             __syncthreads();
+            if (s_nopen) {
+                // An open entry of a touched codebook: the reference's own procedure on the list it would carry here -- the re-orderings
+                // since the chain's last known list replayed (see above), then eval_topn + eval_cb of this frame (ptm_mgau.c:71-226) -- by
+                // one WAVEFRONT: the chain's 128 densities two a work-item, the list wave-uniform, the scan in codeword order by ballots
+                // (psgpu_ptm_dev.h exact_frame_step's way).  In one work-item this was 5 k cycles of the average frame.
+                const int lane = tid & 63;
+                for (int qi = tid >> 6; qi < s_nopen; qi += kFfThreads / 64) {
+                    const int ch = s_openq[qi], cb = ch / pm.n_feat, fs = ch % pm.n_feat, len = pm.featlen[fs];
+                    const size_t base = (size_t)cb * pm.n_density * pm.veclen + (size_t)pm.n_density * pm.featoff[fs];
+                    int32_t cw[4], sc[4];
+                    float d0 = 0.0f, d1 = 0.0f;
+                    auto dens = [&](int g) {
+                        const float *xg = rw.feats + (size_t)(t0 + g) * pm.veclen + pm.featoff[fs];
+                        d0 = ff_density(pm, xg, base, ch, lane, len); d1 = ff_density(pm, xg, base, ch, lane + 64, len);
+                    };
+                    auto value = [&](int c) { return c < 64 ? __shfl(d0, c) : __shfl(d1, c - 64); };
+                    auto rescore = [&]() {                       // (:71-85)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int c = cw[i];
+                            const int32_t v = ff_dist_to_int(value(c));
+                            sc[i] = v; cw[i] = c;
+#pragma unroll
+                            for (int j = i; j > 0; --j)
+                                if (sc[j] > sc[j - 1]) {
+                                    const int32_t ts = sc[j]; sc[j] = sc[j - 1]; sc[j - 1] = ts;
+                                    const int32_t tc = cw[j]; cw[j] = cw[j - 1]; cw[j - 1] = tc;
+                                }
+                        }
+                    };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cw[i] = s_lcw[ch * 4 + i];
+                    const int lk = s_lk[ch];
+                    int g = f - 1;
+                    for (; g > lk; --g) {
+                        dens(g); rescore();
+                        if (sc[0] != sc[1] && sc[1] != sc[2] && sc[2] != sc[3]) break;
+                    }
+                    if (g <= lk) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cw[i] = s_lcw[ch * 4 + i];
+                        g = lk;
+                    }
+                    for (++g; g < f; ++g) { dens(g); rescore(); }
+#ifdef PSGPU_FF_CHECK_LAZY
+                    for (int i = 0; i < 4; ++i)
+                        if (cw[i] != s_shadow[ch * 4 + i]) {
+                            fprintf(stderr, "fwdflat: chain %d frame %d: replayed list entry %d is codeword %d, the reference carries %d\n", ch, f, i, cw[i], s_shadow[ch * 4 + i]);
+                            abort();
+                        }
+#endif
+                    dens(f); rescore();
+                    for (int pos = 0;;) {                        // (:151-226) codewords from `pos` on in index order against the moving threshold
+                        const float th = (float)sc[3];
+                        bool in0 = false, in1 = false;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { in0 |= cw[i] == lane; in1 |= cw[i] == lane + 64; }
+                        unsigned long long b0 = __ballot(d0 >= th && !in0), b1 = __ballot(d1 >= th && !in1);
+                        if (pos >= 64) { b0 = 0; b1 = pos >= 128 ? 0ull : (b1 & (~0ull << (pos - 64))); }
+                        else b0 &= ~0ull << pos;
+                        if ((b0 | b1) == 0) break;
+                        const int c = b0 ? __ffsll(b0) - 1 : 64 + __ffsll(b1) - 1;
+                        const int32_t v = ff_dist_to_int(value(c));
+                        int q = 3;                               // ahead of equal scores, the old worst drops (:140-149)
+#pragma unroll
+                        for (int k = 3; k > 0; --k)
+                            if (q == k && v >= sc[k - 1]) { sc[k] = sc[k - 1]; cw[k] = cw[k - 1]; q = k - 1; }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (q == k) { sc[k] = v; cw[k] = c; }
+                        pos = c + 1;
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { s_lcw[ch * 4 + i] = cw[i]; s_lsc[ch * 4 + i] = sc[i]; }
+#ifdef PSGPU_FF_CHECK_LAZY
+                        for (int i = 0; i < 4; ++i) s_shadow[ch * 4 + i] = cw[i];
+#endif
+                        s_lk[ch] = f;
+                        atomicMax(&s_norm[fs], sc[0] >> 10);
+                    }
+                }
+                __syncthreads();
+            }
+            FF_PROF(9);
             // The scorer's usual shape (3 streams, top-4, senone-major weights at hand): each listed senone's twelve weights from three
             // cache lines (sen_eval_f3n4, the first pass's), the lists packed four to a word
             const bool fast = topn == 4 && pm.n_feat == kSenStreams && pm.mixw_sen != nullptr && n_chain <= kFfMaxEnt / 4;
@@ -724,13 +834,22 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_key = 0ull; }
         __syncthreads();
         FF_PROF(3);
+        int32_t k_best = kW, k_out = kW, k_outh = -1, k_rc = -1, k_rc1 = -1, k_nfr = 0, k_s0 = kW;     // the first entry a work-item evaluates
         // ---- fwdflat_eval_chan (:444-480), one work-item per channel of the list made at the top of the frame (a word near its end
         //      has its whole right-context fan-out, 20-40 channels, active at once)
         {
             int32_t b = kW;
             for (int i = tid; i < n_eval; i += kFfThreads) {
                 const int e = i < FF_EL_CAP ? s_el[i][0] : u.elist[i];
-                const int32_t sc = ff_eval<NE>(p, u, e & kFfChanMask, row);
+                const int c = e & kFfChanMask;
+                if (i < kFfThreads && i < FF_EL_CAP) {       // (what the pruning of this entry reads besides: asked for with the state)
+                    const int rem = s_el[i][3] & 1023;
+                    k_rc = u.rcid[c]; k_rc1 = rem > 0 ? u.rcid[c + 1] : -1;
+                    k_nfr = rem > 0 ? u.frame[c + 1] : 0;   // (not its score[0]: the successor's own evaluation is changing it)
+                }
+                int32_t o_s, o_h, o_0;
+                const int32_t sc = ff_eval<NE>(p, u, c, row, o_s, o_h, o_0);
+                if (i < kFfThreads) { k_best = sc; k_out = o_s; k_outh = o_h; k_s0 = o_0; }
                 if (!(e & (1 << 30))) b = max(b, sc);
             }
             if (b > kW) atomicMax(&s_sc[0], b);
@@ -749,7 +868,12 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         for (int e = tid; e < n_eval; e += kFfThreads) {
             const FfEnt en = ent(e);
             const int c = en.c & kFfChanMask, k = en.inf & 1023, rem = en.aux & 1023, w = en.w;
-            const int32_t best = u.best[c], out = u.out[c], hist = u.outh[c], rc = u.rcid[c], rc1 = rem > 0 ? u.rcid[c + 1] : -1;
+            // (the successor's entry state with the rest: its stamp is f or f + 1 whoever writes it meanwhile, its score[0] is written by
+            // this work-item alone; the entry a work-item evaluated first is still in its registers)
+            const bool kept = e < kFfThreads && e < FF_EL_CAP;
+            const int32_t best = kept ? k_best : u.best[c], out = kept ? k_out : u.out[c], hist = kept ? k_outh : u.outh[c];
+            const int32_t rc = kept ? k_rc : u.rcid[c], rc1 = kept ? k_rc1 : (rem > 0 ? u.rcid[c + 1] : -1);
+            const int32_t nfr = kept ? k_nfr : (rem > 0 ? u.frame[c + 1] : 0), nsc = rem > 0 ? u.score[(c + 1) * 5] : 0;
             if (best > thresh) {
                 int32_t newscore = out;
                 u.frame[c] = nf; u.word_active[w] = nf;
@@ -761,7 +885,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                             if (q < kFfMaxFan) { s_fan[q][0] = c + 1; s_fan[q][1] = rem; s_fan[q][2] = newscore; s_fan[q][3] = hist; }
                             else for (int j = 1; j <= rem; ++j) ff_enter_if_better(u, c + j, newscore, hist, f);
                         }
-                        else ff_enter_if_better(u, c + 1, newscore, hist, f);
+                        else if (nfr < f || newscore > nsc) ff_enter(u, c + 1, newscore, hist, nf);
                     }
                 }
                 else if (newscore > wordthresh) {            // a word exit: queued, see below
@@ -771,20 +895,45 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         x[0] = en.inf; x[1] = w | ((en.aux >> 20) << 30); x[2] = newscore; x[3] = hist;
                         x[4] = (en.aux >> 10) & 1023;
                         x[5] = k == 0 ? 0 : rc;
+                        x[8] = p.d_last[w]; x[9] = (en.aux >> 20) ? -1 : p.d_last2[w]; x[10] = p.d_base[w] | (p.d_filler[w] ? (1 << 30) : 0);
+                        x[11] = hist != -1 ? FBP(u, F_REAL, hist) : -1; x[12] = hist != -1 ? FBP(u, F_PREAL, hist) : -1;
                     }
                 }
             }
-            else if (k > 0) { if (e < FF_EL_CAP) s_el[e][0] = en.c | kFfClearBit; else u.elist[e] = en.c | kFfClearBit; }
+            else if (k > 0) {
+                // the walk's "else if (frame != nf) clear": did its predecessor in the chain enter it?  For the entry a work-item
+                // evaluated itself (its state-0 score as the evaluation left it is in a register) the predecessor's decision is taken
+                // here a second time from the same values -- no look at the stamp after a barrier; for the others the stamp decides
+                int v = en.c | kFfClearBit | kFfEnteredBit;                     // (both: look at the stamp)
+                if (kept) {
+                    const int rcs = (en.aux >> 10) & 1023;
+                    const int pred = rc < 0 ? c - 1 : c - k + (k + rem - rcs);
+                    const int32_t pb = u.best[pred], po = u.out[pred] + p.pip;
+                    const bool entered = pb > thresh && pb > kW && po > thresh && po > k_s0;
+                    v = en.c | (entered ? kFfEnteredBit : kFfClearBit);
+                }
+                if (e < FF_EL_CAP) s_el[e][0] = v; else u.elist[e] = v;
+            }
         }
         __syncthreads();
+        FF_PROF(10);
         for (int q = tid >> 6, nq = min(s_nfan, kFfMaxFan); q < nq; q += kFfThreads / 64)
             for (int j = tid & 63; j < s_fan[q][1]; j += 64) ff_enter_if_better(u, s_fan[q][0] + j, s_fan[q][2], s_fan[q][3], f);
         __syncthreads();
         for (int e = tid; e < n_eval; e += kFfThreads) {
             const int v = e < FF_EL_CAP ? s_el[e][0] : u.elist[e];
-            if ((v & kFfClearBit) && u.frame[v & kFfChanMask] != nf) ff_clear_scores(p, u, v & kFfChanMask);
+            const int both = kFfClearBit | kFfEnteredBit;
+            if ((v & both) == both) { if (u.frame[v & kFfChanMask] != nf) ff_clear_scores(p, u, v & kFfChanMask); continue; }
+#ifdef PSGPU_FF_CHECK_LAZY
+            if ((v & both) && ((v & kFfEnteredBit) != 0) != (u.frame[v & kFfChanMask] == nf)) {
+                fprintf(stderr, "fwdflat: frame %d channel %d: the predecessor's decision taken twice differs (%x, stamp %d)\n", f, v & kFfChanMask, (unsigned)v, u.frame[v & kFfChanMask]);
+                abort();
+            }
+#endif
+            if (v & kFfClearBit) ff_clear_scores(p, u, v & kFfChanMask);
         }
         __syncthreads();
+        FF_PROF(11);
         // ---- the exits' back-pointers (ngram_search_save_bp as fwdflat_prune_chan calls it, :528-540, :588-600): one entry per
         //      exiting WORD in active-list order, its right-context exits applied in chain order (the first creates the entry, a later
         //      one with a strictly better score takes it over, each leaves its score in its slot of the word's stack block).  The
@@ -821,7 +970,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     if (x[6] < 0) continue;
                     const int i = x[0] >> 10, w = x[1] & 0x3fffffff;
                     const int32_t bpi = bpidx + x[6], bsh = bss_head + x[7];
-                    ff_new_bp(p, u, bpi, bsh, f, w, x[2], x[3], x[5], x[4], (x[1] >> 30) != 0);   // (word_lat_idx[w] is -1: a new entry)
+                    ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], x[5], x[4], (x[1] >> 30) != 0, x[8], x[9], x[10] & 0x3fffffff, (x[10] >> 30) != 0, x[11], x[12]);
                     int32_t cs = x[2], cp = x[3];
                     bool dirty = false;
                     for (int r2 = r + 1; r2 < n_ex; ++r2) {                      // the update branch of save_bp (ngram_search.c:405-437)
@@ -925,6 +1074,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             }
         }
         __syncthreads();
+        FF_PROF(12);
         if (bp1 > bp0) {
             // <sil> and the noise words (:755-769)
             const unsigned long long key = s_key;
@@ -951,22 +1101,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         }
         FF_PROF(6);
         // ---- next active word list (:853-869): the vocabulary in its order (words below <s>), then <s> and above by id
-        const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
         int32_t n_next;
         if (n_all <= FF_AWL_REGS) {                          // four consecutive candidates a work-item, their places by one prefix sum
-            int wq[4], c0q[4], axq[4], fl = 0;
+            int fl = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {                    // (a candidate's word, first channel and lengths never change: registers)
                 const int i = tid * 4 + j;
-                wq[j] = i < u.nwd ? u.wl_wid[i < u.nwd ? i : 0] : p.startwid + (i - u.nwd);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {                    // (everything an entry holds asked for with the stamp: nothing to fetch after the sum)
-                const int i = tid * 4 + j, w = i < n_all ? wq[j] : p.startwid;
-                const int32_t stamp = u.word_active[w], ch = u.wchain[w], ln = u.wlen[w], rcs = u.wrcs[w], w1 = p.w1_of_word[w];
-                if (i < n_all && stamp == nf && (i < u.nwd ? w < p.startwid : true)) fl |= 1 << j;
-                c0q[j] = ch >= 0 ? ch : w1;
-                axq[j] = (ch >= 0 ? ln : 1) | (rcs << 10) | ((ch < 0 ? 1 : 0) << 20);
+                if (i < n_all && u.word_active[wq[j]] == nf && (i < u.nwd ? wq[j] < p.startwid : true)) fl |= 1 << j;
             }
             int pos = ff_block_excl_sum(__popc(fl), s_scan, n_next);
 #pragma unroll
@@ -1282,19 +1423,20 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     fprintf(stderr, "fwdflat host: first-pass columns to the host %.2f ms, vocabularies %.2f ms, allocations + tables to the device %.2f ms, kernel %.2f ms\n",
             t_host[1] - t_host[0], t_host[2] - t_host[1], t_host[3] - t_host[2], t_host[4] - t_host[3]);
     if (e == hipSuccess && bf.prof) {    // a profiling build: per-phase cycle counts of work-item 0, averaged over the utterances, per frame
-        static const char *const names[8] = { "senones of the active channels (bitmap, codebooks)", "top-N lists (taken / evaluated)",
-            "senone evaluation + normaliser", "mark, renormalise, reset", "evaluate (gather + hmm_vit_eval)", "prune + exits (save_bp)",
-            "word transitions + fillers + clear", "next active word list" };
+        static const char *const names[13] = { "rest of: senones of the active channels (bitmap, codebooks)", "rest of: top-N lists (normalise, pack)",
+            "senone evaluation + normaliser", "mark, renormalise, reset", "evaluate (gather + hmm_vit_eval)", "rest of: prune + exits (the exits' back-pointers)",
+            "rest of: word transitions (fillers, clear)", "next active word list", "active channels gathered + senones marked", "top-N lists taken / evaluated",
+            "prune: decisions", "prune: fan-outs + clears", "word transitions: exits scanned, successors entered" };
         std::vector<long long> h((size_t)16 * n_utt);
         std::vector<int32_t> r((size_t)8 * n_utt);
         hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
         hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost);
-        double frames = 0, tot = 0, acc[8] = {};
-        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 8; ++i) acc[i] += (double)h[(size_t)u * 16 + i]; }
-        for (int i = 0; i < 8; ++i) tot += acc[i];
+        double frames = 0, tot = 0, acc[13] = {};
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 13; ++i) acc[i] += (double)h[(size_t)u * 16 + i]; }
+        for (int i = 0; i < 13; ++i) tot += acc[i];
         fprintf(stderr, "fwdflat_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
-        for (int i = 0; i < 8; ++i)
-            fprintf(stderr, "  %d %-52s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
+        for (int i = 0; i < 13; ++i)
+            fprintf(stderr, "  %2d %-60s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
     }
     hipFree(bf.prof);
 #endif
