@@ -52,6 +52,7 @@ constexpr int kFfMaxTopn = 8;
 constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
 constexpr int kFfChanMask = (1 << 28) - 1, kFfClearBit = 1 << 29, kFfEnteredBit = 1 << 28;   // FfUtt::elist entries
 constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel list held in LDS (the rest in the slab)
+constexpr int kFfMaxTp = 2048;         // bytes of transition matrices held in LDS (more: read from device memory)
 constexpr int kFfMaxExit = 160;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
@@ -88,6 +89,7 @@ struct FfDev {
     const int32_t *pron_off, *pron_ci, *pron_ssid, *ci_ssid;
     const uint8_t *tp;
     const uint16_t *sseq;
+    int32_t tp_bytes;
     int32_t use_trie;
     LmDev trie;
 };
@@ -182,7 +184,7 @@ __device__ __forceinline__ void ff_normalize(const FfDev &p, FfUtt &u, int c, in
 }
 
 template <int NE>
-__device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, const int16_t *row, int32_t &out_score, int32_t &out_hist, int32_t &score0)
+__device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, const int16_t *row, const uint8_t *tp_all, int32_t &out_score, int32_t &out_hist, int32_t &score0)
 {
     HmmRegs h;
 #pragma unroll
@@ -192,7 +194,7 @@ __device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, cons
         h.senid[i] = i < NE ? (uint16_t)u.senid[c * 5 + i] : 0;
     }
     h.out_score = u.out[c]; h.out_history = u.outh[c]; h.bestscore = u.best[c];
-    const uint8_t *tp = p.tp + (size_t)u.tmat[c] * NE * (NE + 1);
+    const uint8_t *tp = tp_all + (size_t)u.tmat[c] * NE * (NE + 1);
     int32_t b;
     if (NE == 3) b = u.mpx[c] ? vit3_mpx(h, tp, row, p.sseq) : vit3(h, tp, row);
     else         b = u.mpx[c] ? vit5_mpx(h, tp, row, p.sseq) : vit5(h, tp, row);
@@ -257,19 +259,16 @@ __device__ void ff_save_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_
 }
 
 // ... when the word has no entry in this frame yet (the branch at ngram_search.c:438-497; set_real_wid :341-372), with everything
-// it reads handed in by the caller (the pruning asked for it when it queued the exit): stores only.
-__device__ __forceinline__ void ff_new_bp(FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score, int32_t path, int rc,
-                                          int rcsize, bool single, int32_t last, int32_t last2, int32_t base, bool filler,
+// it reads handed in by the caller (the pruning asked for it when it queued the exit): stores only.  (The word's block of the score
+// stack is the caller's.)
+__device__ __forceinline__ void ff_new_bp(FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score, int32_t path,
+                                          bool single, int32_t last, int32_t last2, int32_t base, bool filler,
                                           int32_t path_real, int32_t path_preal)
 {
     u.word_lat_idx[w] = bpidx;
     FBP(u, F_WID, bpidx) = w; FBP(u, F_FRAME, bpidx) = frame; FBP(u, F_BP, bpidx) = path; FBP(u, F_SCORE, bpidx) = score;
     FBP(u, F_SIDX, bpidx) = single ? -1 : bss_head; FBP(u, F_VALID, bpidx) = 1;
     FBP(u, F_LAST, bpidx) = last; FBP(u, F_LAST2, bpidx) = last2;
-    if (!single) {
-        for (int i = 0; i < rcsize; ++i) u.bss[bss_head + i] = kW;
-        if (rcsize) u.bss[bss_head + rc] = score;
-    }
     if (filler) { FBP(u, F_REAL, bpidx) = path != -1 ? path_real : base; FBP(u, F_PREAL, bpidx) = path != -1 ? path_preal : -1; }
     else { FBP(u, F_REAL, bpidx) = base; FBP(u, F_PREAL, bpidx) = path_real; }
 }
@@ -356,6 +355,10 @@ __device__ __forceinline__ void ff_awl_put(const FfDev &p, const FfUtt &u, int32
     awl[pos * 3] = w; awl[pos * 3 + 1] = c0; awl[pos * 3 + 2] = len | (u.wrcs[w] << 10) | ((u.wchain[w] < 0 ? 1 : 0) << 20);
 }
 
+#if defined(__HIPCC__)
+extern __shared__ __attribute__((aligned(16))) unsigned char ff_dyn_lds[];
+#endif
+
 template <int NE, bool RAW>
 __global__ __launch_bounds__(kFfThreads)
 void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const int16_t *__restrict__ senscr, int64_t scr_stride,
@@ -385,6 +388,12 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset,
                                                                  //   the word's last / last-but-one phone, base word | filler << 30, the history's two real words
     __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
+    __shared__ uint8_t s_tp[kFfMaxTp];                           // the model's transition matrices
+#if defined(__HIPCC__)
+    int16_t *const s_row = reinterpret_cast<int16_t *>(ff_dyn_lds);           // (scoring mode) the frame's senone scores [n_sen]: dynamic LDS
+#else
+    __shared__ int16_t s_row[RAW ? kFfMaxSen : 1];                               // (the workgroup simulator)
+#endif
     __shared__ int32_t s_sc[8];          // best_score, bpidx, bss_head, status, n_frame done, -, -, length of the evaluation list
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
@@ -436,6 +445,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         for (int r = 0; r < nrc; ++r)
             ff_init(p, u, c++, 0, p.rs_ssid[((size_t)last * p.n_ci + last2) * p.n_ci + r], p.ci_tmat[last], r);
     }
+    const bool tp_lds = p.tp_bytes <= kFfMaxTp;
+    if (tp_lds) for (int i = tid; i < p.tp_bytes; i += kFfThreads) s_tp[i] = p.tp[i];
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = 0; s_sc[3] = 0; s_sc[4] = 0;
         ff_enter(u, p.w1_of_word[p.startwid], 0, -1, 0);
@@ -473,7 +484,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     const bool ahead = RAW && rw.tsc && topn == 4 && n_chain <= kFfThreads;
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = n_awl[cur];
-        const int16_t *row = RAW ? nullptr : senscr + (size_t)(t0 + f) * scr_stride;
+        const int16_t *const row_dev = RAW ? nullptr : senscr + (size_t)(t0 + f) * scr_stride;
         // ---- the frame's active channels, gathered into one list first (one work-item per word walks its chain once: order
         //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
         //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
@@ -798,7 +809,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = tid + j * kFfThreads;
-                    if (i < n_l) u.nrow[s_slist[i]] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)av[j] - (uint32_t)nb);
+                    if (i < n_l) s_row[s_slist[i]] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)av[j] - (uint32_t)nb);
                 }
             }
             else {
@@ -814,15 +825,15 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 const int32_t nb = s_nb;
                 for (int i = tid; i < n_l; i += kFfThreads) {
                     const int sen = s_slist[i];
-                    u.nrow[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
+                    s_row[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
                 }
             }
             __syncthreads();
-            row = u.nrow;
         }
         FF_PROF(2);
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:825-838)
-        if (tid == 0) u.bp_table_idx[f] = s_sc[1];
+        const int32_t bp_first = s_sc[1];                    // (the frame's first back-pointer: written for the host, kept for the word transitions)
+        if (tid == 0) u.bp_table_idx[f] = bp_first;
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
         if (best_in + 2 * p.beam < kW)                       // fwdflat_renormalize_scores (:784-810)
@@ -839,6 +850,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      has its whole right-context fan-out, 20-40 channels, active at once)
         {
             int32_t b = kW;
+            // (one instantiation per pairing of score row and transition matrices: LDS / device memory -- the address space is the
+            // compiler's to infer from the argument)
+            auto eval_all = [&](const int16_t *row, const uint8_t *tp_all) {
             for (int i = tid; i < n_eval; i += kFfThreads) {
                 const int e = i < FF_EL_CAP ? s_el[i][0] : u.elist[i];
                 const int c = e & kFfChanMask;
@@ -848,10 +862,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     k_nfr = rem > 0 ? u.frame[c + 1] : 0;   // (not its score[0]: the successor's own evaluation is changing it)
                 }
                 int32_t o_s, o_h, o_0;
-                const int32_t sc = ff_eval<NE>(p, u, c, row, o_s, o_h, o_0);
+                const int32_t sc = ff_eval<NE>(p, u, c, row, tp_all, o_s, o_h, o_0);
                 if (i < kFfThreads) { k_best = sc; k_out = o_s; k_outh = o_h; k_s0 = o_0; }
                 if (!(e & (1 << 30))) b = max(b, sc);
             }
+            };
+            if (RAW) { if (tp_lds) eval_all(s_row, s_tp); else eval_all(s_row, p.tp); }
+            else { if (tp_lds) eval_all(row_dev, s_tp); else eval_all(row_dev, p.tp); }
             if (b > kW) atomicMax(&s_sc[0], b);
         }
         __syncthreads();
@@ -939,43 +956,43 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      one with a strictly better score takes it over, each leaves its score in its slot of the word's stack block).  The
         //      queue is sorted by (word's list position, chain position) by counting; a word's first exit learns how many words
         //      and stack entries precede it from the sorted queue and then walks its group -- everything but the table itself in LDS.
-        if (s_nex <= FF_EXIT_CAP) {
+        if (s_nex == 0) { }                                  // (a frame without exits: nothing to write, no barrier to meet)
+        else if (s_nex <= FF_EXIT_CAP) {
+            static_assert(kFfMaxExit <= kFfThreads, "one queued exit per work-item");
             const int32_t bpidx = s_sc[1], bss_head = s_sc[2];
             const int n_ex = s_nex;
-            for (int e = tid; e < n_ex; e += kFfThreads) {
-                const int32_t key = s_ex[e][0];
+            if (tid < n_ex) {
+                const int32_t key = s_ex[tid][0];
                 int r = 0;
                 for (int j = 0; j < n_ex; ++j) r += s_ex[j][0] < key;
-                s_ord[r] = (uint16_t)e;
+                s_ord[r] = (uint16_t)tid;
             }
             __syncthreads();
-            for (int r = tid; r < n_ex; r += kFfThreads) {
-                int32_t *x = s_ex[s_ord[r]];
-                const int i = x[0] >> 10;
-                if (r > 0 && (s_ex[s_ord[r - 1]][0] >> 10) == i) { x[6] = -1; continue; }
-                int ord = 0, off = 0, pi = -1;
-                for (int j = 0; j < r; ++j) {
-                    const int32_t *y = s_ex[s_ord[j]];
-                    if ((y[0] >> 10) != pi) { ++ord; off += y[4]; pi = y[0] >> 10; }
-                }
-                x[6] = ord; x[7] = off;
-                atomicAdd(&s_tot[0], 1); atomicAdd(&s_tot[1], x[4]);
-            }
-            __syncthreads();
-            const int32_t n_exit = s_tot[0], n_bss = s_tot[1];
+            // sorted position r = tid: a word's first exit (`head`) counts one entry and the word's stack block; one prefix sum gives
+            // every exit the number of entries and stack slots before its word
+            const int32_t *x = s_ex[tid < n_ex ? s_ord[tid] : 0];
+            const int i = x[0] >> 10;
+            const bool mine = tid < n_ex, head = mine && (tid == 0 || (s_ex[s_ord[tid - 1]][0] >> 10) != i);
+            int32_t total;
+            const int32_t before = ff_block_excl_sum(head ? ((x[4] << 10) | 1) : 0, s_scan, total);
+            const int32_t n_exit = total & 1023, n_bss = total >> 10;
             const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
-            if (!full)
-                for (int r = tid; r < n_ex; r += kFfThreads) {
-                    const int32_t *x = s_ex[s_ord[r]];
-                    if (x[6] < 0) continue;
-                    const int i = x[0] >> 10, w = x[1] & 0x3fffffff;
-                    const int32_t bpi = bpidx + x[6], bsh = bss_head + x[7];
-                    ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], x[5], x[4], (x[1] >> 30) != 0, x[8], x[9], x[10] & 0x3fffffff, (x[10] >> 30) != 0, x[11], x[12]);
+            if (tid == 0) { if (full) s_sc[3] = 1; else { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; } }   // (full: nothing is written)
+            if (mine && !full) {
+                const bool single = (x[1] >> 30) != 0;
+                const int32_t bsh = bss_head + (before >> 10) - (head ? 0 : x[4]);
+                if (!single && x[4]) u.bss[bsh + x[5]] = x[2];               // its score in its slot of the word's stack block
+                if (head) {
+                    const int w = x[1] & 0x3fffffff;
+                    const int32_t bpi = bpidx + (before & 1023);
+                    ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], single, x[8], x[9], x[10] & 0x3fffffff, (x[10] >> 30) != 0, x[11], x[12]);
                     int32_t cs = x[2], cp = x[3];
                     bool dirty = false;
-                    for (int r2 = r + 1; r2 < n_ex; ++r2) {                      // the update branch of save_bp (ngram_search.c:405-437)
+                    unsigned long long have = 1ull << x[5];
+                    for (int r2 = tid + 1; r2 < n_ex; ++r2) {                    // the update branch of save_bp (ngram_search.c:405-437)
                         const int32_t *y = s_ex[s_ord[r2]];
                         if ((y[0] >> 10) != i) break;
+                        have |= 1ull << y[5];
                         if (cs < y[2]) {
                             if (cp != y[3]) {
                                 const int32_t b0 = cp == -1 ? -1 : FBP(u, F_PREAL, cp), b1 = cp == -1 ? -1 : FBP(u, F_REAL, cp);
@@ -986,12 +1003,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                             }
                             cs = y[2]; dirty = true;
                         }
-                        u.bss[bsh + y[5]] = y[2];
                     }
                     if (dirty) FBP(u, F_SCORE, bpi) = cs;
+                    if (!single)
+                        for (int q = 0; q < x[4]; ++q) if (!((have >> q) & 1)) u.bss[bsh + q] = kW;      // the contexts nothing exited into
                 }
+            }
             __syncthreads();
-            if (tid == 0) { if (full) s_sc[3] = 1; else { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; } }   // (full: nothing was written)
         }
         else {
             // more exits than the queue holds: through flags in the slab, one work-item per exiting word walking its chain
@@ -1029,7 +1047,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 
         FF_PROF(5);
         // ---- fwdflat_word_transition (:642-782)
-        const int bp0 = u.bp_table_idx[f], bp1 = s_sc[1];
+        const int bp0 = bp_first, bp1 = s_sc[1];
         for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
             const int wid = FBP(u, F_WID, b);
             u.word_lat_idx[wid] = -1;
@@ -1208,6 +1226,7 @@ int psgpu_fwdflat_create(psgpu_fwdflat_t **out, const psgpu_fwdflat_tables_t *t)
     d.pron_off = ff_up(m, t->pron_off, (size_t)d.n_w + 1, &rc); d.pron_ci = ff_up(m, t->pron_ci, n_pron, &rc);
     d.pron_ssid = ff_up(m, t->pron_ssid, n_pron, &rc); d.ci_ssid = ff_up(m, t->ci_ssid, d.n_ci, &rc);
     d.tp = ff_up(m, ft->tp, (size_t)ft->n_tmat * d.n_emit * (d.n_emit + 1), &rc);
+    d.tp_bytes = (int32_t)((size_t)ft->n_tmat * d.n_emit * (d.n_emit + 1));
     d.sseq = ff_up(m, ft->sseq, (size_t)ft->n_sseq * d.n_emit, &rc);
     m->h_pronlen.assign(ft->dict_pronlen, ft->dict_pronlen + d.n_w);
     m->h_last.assign(ft->dict_last, ft->dict_last + d.n_w); m->h_last2.assign(ft->dict_last2, ft->dict_last2 + d.n_w);
@@ -1408,14 +1427,31 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
 #ifdef PSGPU_FT_PROFILE
     if (hipMalloc((void **)&bf.prof, sizeof(long long) * 16 * (size_t)n_utt) != hipSuccess) bf.prof = nullptr;
 #endif
-    if (d.n_emit == 3 && raw)
-        hipLaunchKernelGGL((fwdflat_kernel<3, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
+    // scoring mode: the frame's senone scores live in LDS ([n_sen] int16, dynamic) beside ~53 KB of static arrays
+    const size_t dyn = raw ? (((size_t)d.n_sen * 2 + 15) & ~(size_t)15) : 0;
+#if defined(__HIPCC__)
+#define FF_DYN_LDS(NE)                                                                                                     \
+    if (dyn + 56 * 1024 > 65536) {                                                                                         \
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdflat_kernel<NE, true>,                      \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, kFfMaxSen * 2);  \
+        PSGPU_HIP(attr_rc);                                                                                                \
+    }
+#else
+#define FF_DYN_LDS(NE)
+#endif
+    if (d.n_emit == 3 && raw) {
+        FF_DYN_LDS(3)
+        hipLaunchKernelGGL((fwdflat_kernel<3, true>), dim3(n_utt), dim3(kFfThreads), dyn, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
+    }
     else if (d.n_emit == 3)
         hipLaunchKernelGGL((fwdflat_kernel<3, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
-    else if (raw)
-        hipLaunchKernelGGL((fwdflat_kernel<5, true>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
+    else if (raw) {
+        FF_DYN_LDS(5)
+        hipLaunchKernelGGL((fwdflat_kernel<5, true>), dim3(n_utt), dim3(kFfThreads), dyn, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
+    }
     else
         hipLaunchKernelGGL((fwdflat_kernel<5, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
+#undef FF_DYN_LDS
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
 #ifdef PSGPU_FT_PROFILE
