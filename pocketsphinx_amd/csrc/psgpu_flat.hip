@@ -35,12 +35,12 @@ extern "C" { int psgpu_sim_ff_exit_cap = 160; }      // (tests shrink it to driv
 #define FF_EXIT_CAP psgpu_sim_ff_exit_cap
 extern "C" { int psgpu_sim_ff_el_cap = 384; }
 #define FF_EL_CAP psgpu_sim_ff_el_cap
-extern "C" { int psgpu_sim_ff_awl_regs = 1024; }
+extern "C" { int psgpu_sim_ff_awl_regs = 512; }
 #define FF_AWL_REGS psgpu_sim_ff_awl_regs
 #else
 #define FF_EXIT_CAP kFfMaxExit
 #define FF_EL_CAP kFfMaxEl
-#define FF_AWL_REGS (4 * kFfThreads)
+#define FF_AWL_REGS (kFfRegRows * kFfThreads)
 #endif
 
 constexpr int kFfThreads = 256;
@@ -52,6 +52,7 @@ constexpr int kFfMaxTopn = 8;
 constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
 constexpr int kFfChanMask = (1 << 28) - 1, kFfClearBit = 1 << 29, kFfEnteredBit = 1 << 28;   // FfUtt::elist entries
 constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel list held in LDS (the rest in the slab)
+constexpr int kFfRegRows = 2;           // vocabularies up to kFfRegRows x 256 words (+ fillers) keep their static records in registers
 constexpr int kFfMaxTp = 2048;         // bytes of transition matrices held in LDS (more: read from device memory)
 constexpr int kFfMaxExit = 160;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
@@ -360,7 +361,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ff_dyn_lds[];
 #endif
 
 template <int NE, bool RAW>
-__global__ __launch_bounds__(kFfThreads)
+__global__ __launch_bounds__(kFfThreads, 2)            // (two workgroups a compute unit: 256 registers a work-item)
 void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const int16_t *__restrict__ senscr, int64_t scr_stride,
                     const int32_t *__restrict__ utt_off, FfRaw rw)
 {
@@ -375,7 +376,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ uint16_t s_slist[RAW ? kFfMaxSen : 1];            // the frame's listed senones in the order they were first marked
     __shared__ int32_t s_nl;
     __shared__ int32_t s_norm[16], s_nb;
-    __shared__ int32_t s_scan[kFfThreads / 64];
+    __shared__ int32_t s_scan[kFfThreads / 64], s_scan2[kFfThreads / 64];
 #ifdef PSGPU_FF_CHECK_LAZY
     __shared__ int32_t s_shadow[RAW ? kFfMaxEnt : 1];
 #endif
@@ -385,6 +386,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ int32_t s_el[kFfMaxEl][4];                        // the active-channel list: channel | flags, word's list position << 10 | chain
                                                                  //   position, word, channels after it | word's right-context count << 10 | single-phone << 20
     __shared__ int32_t s_ex[kFfMaxExit][13], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
+    __shared__ int32_t s_nbp[kFfMaxExit][8];                     // the frame's new back-pointers: word, last / last-but-one phone, score, sorted
+                                                                 //   position of the word's first exit, real word ids (two), -
     __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset,
                                                                  //   the word's last / last-but-one phone, base word | filler << 30, the history's two real words
     __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
@@ -465,17 +468,22 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     }
     __syncthreads();
 
-    // the next active word list's candidates, four consecutive ones a work-item (vocabularies up to 4 x 256 words): static
+    // the next active word list's candidates, candidate tid + 256 j in slot j (vocabularies up to kFfRegRows x 256 words): static
     const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
-    int wq[4] = { 0, 0, 0, 0 }, c0q[4] = { 0, 0, 0, 0 }, axq[4] = { 0, 0, 0, 0 };
+    int wq[kFfRegRows] = {}, c0q[kFfRegRows] = {}, axq[kFfRegRows] = {};
+    int fq[kFfRegRows] = {}, bq[kFfRegRows] = {}, o0q[kFfRegRows] = {}, o1q[kFfRegRows] = {};      // (vocabulary words: first phone | second << 8, base word, start-frame nodes)
     if (n_all <= FF_AWL_REGS) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid * 4 + j;
+        for (int j = 0; j < kFfRegRows; ++j) {
+            const int i = tid + j * kFfThreads;
             const int w = i < u.nwd ? u.wl_wid[i] : (i < n_all ? p.startwid + (i - u.nwd) : p.startwid);
             const int32_t ch = u.wchain[w], ln = u.wlen[w], rcs = u.wrcs[w], w1 = p.w1_of_word[w];
             wq[j] = w; c0q[j] = ch >= 0 ? ch : w1;
             axq[j] = (ch >= 0 ? ln : 1) | (rcs << 10) | ((ch < 0 ? 1 : 0) << 20);
+            if (i < u.nwd) {
+                const int ci2 = u.wl_chain[i] >= 0 ? p.pron_ci[p.pron_off[w] + 1] : p.w1_ci2[w1];
+                fq[j] = p.d_first[w] | (ci2 << 8); bq[j] = p.d_base[w]; o0q[j] = u.wl_node_off[i]; o1q[j] = u.wl_node_off[i + 1];
+            }
         }
     }
     FfQuad pre_q = { 0, 0, 0, 0 };
@@ -956,6 +964,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      one with a strictly better score takes it over, each leaves its score in its slot of the word's stack block).  The
         //      queue is sorted by (word's list position, chain position) by counting; a word's first exit learns how many words
         //      and stack entries precede it from the sorted queue and then walks its group -- everything but the table itself in LDS.
+        const int n_exq = s_nex;
         if (s_nex == 0) { }                                  // (a frame without exits: nothing to write, no barrier to meet)
         else if (s_nex <= FF_EXIT_CAP) {
             static_assert(kFfMaxExit <= kFfThreads, "one queued exit per work-item");
@@ -987,7 +996,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     const int32_t bpi = bpidx + (before & 1023);
                     ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], single, x[8], x[9], x[10] & 0x3fffffff, (x[10] >> 30) != 0, x[11], x[12]);
                     int32_t cs = x[2], cp = x[3];
-                    bool dirty = false;
+                    bool dirty = false, requirk = false;
                     unsigned long long have = 1ull << x[5];
                     for (int r2 = tid + 1; r2 < n_ex; ++r2) {                    // the update branch of save_bp (ngram_search.c:405-437)
                         const int32_t *y = s_ex[s_ord[r2]];
@@ -997,7 +1006,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                             if (cp != y[3]) {
                                 const int32_t b0 = cp == -1 ? -1 : FBP(u, F_PREAL, cp), b1 = cp == -1 ? -1 : FBP(u, F_REAL, cp);
                                 const int32_t n0 = y[3] == -1 ? -1 : FBP(u, F_PREAL, y[3]), n1 = y[3] == -1 ? -1 : FBP(u, F_REAL, y[3]);
-                                if (b0 != n0 || b1 != n1) ff_set_real_wid(p, u, bpi);      // with the old bp still in place, as the reference
+                                if (b0 != n0 || b1 != n1) { ff_set_real_wid(p, u, bpi); requirk = true; }      // with the old bp still in place, as the reference
                                 FBP(u, F_BP, bpi) = y[3];
                                 cp = y[3];
                             }
@@ -1005,6 +1014,15 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         }
                     }
                     if (dirty) FBP(u, F_SCORE, bpi) = cs;
+                    {   // what the word transitions below read of this entry
+                        int32_t *nb = s_nbp[before & 1023];
+                        const bool filler = (x[10] >> 30) != 0;
+                        const int32_t base = x[10] & 0x3fffffff;
+                        nb[0] = w; nb[1] = x[8]; nb[2] = x[9]; nb[3] = cs; nb[4] = tid;
+                        if (requirk) { nb[5] = FBP(u, F_REAL, bpi); nb[6] = FBP(u, F_PREAL, bpi); }
+                        else if (filler) { nb[5] = x[3] != -1 ? x[11] : base; nb[6] = x[3] != -1 ? x[12] : -1; }
+                        else { nb[5] = base; nb[6] = x[11]; }
+                    }
                     if (!single)
                         for (int q = 0; q < x[4]; ++q) if (!((have >> q) & 1)) u.bss[bsh + q] = kW;      // the contexts nothing exited into
                 }
@@ -1048,6 +1066,62 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         FF_PROF(5);
         // ---- fwdflat_word_transition (:642-782)
         const int bp0 = bp_first, bp1 = s_sc[1];
+        if (n_exq <= FF_EXIT_CAP && n_all <= FF_AWL_REGS) {
+            // The frame's new entries as the exits' phase left them in LDS (s_nbp; their right contexts' scores are the queue's), the
+            // vocabulary words' static data in registers: what is left to fetch is the right-context map, the language score and
+            // the start-frame nodes.
+            const int n_new = bp1 - bp0;
+            auto exit_score = [&](const int32_t *r, int slot) {      // bscore_stack[s_idx + slot] of a new entry: the exit into that context
+                const int i = s_ex[s_ord[r[4]]][0] >> 10;
+                for (int r2 = r[4]; r2 < n_exq; ++r2) {
+                    const int32_t *y = s_ex[s_ord[r2]];
+                    if ((y[0] >> 10) != i) break;
+                    if (y[5] == slot) return y[2];
+                }
+                return kW;
+            };
+            if (tid < n_new) {
+                const int32_t *r = s_nbp[tid];
+                u.word_lat_idx[r[0]] = -1;
+                if (r[0] != p.finishwid) {
+                    const int32_t sil = r[2] == -1 ? r[3] : exit_score(r, p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + p.sil_ci]);
+                    if (sil > kW)      // best exit into silence, the earliest on ties (:745-753): key = (score, -index)
+                        atomicMax(&s_key, ((unsigned long long)(uint32_t)(sil - kW) << 32) | (uint32_t)(0x7fffffff - (bp0 + tid)));
+                }
+            }
+            if (n_new > 0) {
+                int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
+                if (sf0 < 0) sf0 = 0;
+                if (ef0 > u.n_frame) ef0 = u.n_frame;
+#pragma unroll
+                for (int j = 0; j < kFfRegRows; ++j) {
+                    if (tid + j * kFfThreads >= u.nwd) continue;
+                    bool in = false;
+                    for (int q = o0q[j]; q < o1q[j] && !in; ++q) { const int sf = u.node_sf[q]; in = sf >= sf0 && sf < ef0; }
+                    if (!in) continue;
+                    const int w = wq[j], c0 = c0q[j], first = fq[j] & 0xff, ci2 = fq[j] >> 8;
+                    int32_t cur_fr = u.frame[c0], cur_sc = u.score[c0 * 5];
+                    int win = -1, win_l1 = 0;
+                    for (int t = 0; t < n_new; ++t) {          // exits in order: the first best one wins, as in the reference
+                        const int32_t *r = s_nbp[t];
+                        if (r[0] == p.finishwid) continue;
+                        int32_t newscore = r[2] == -1 ? r[3] : exit_score(r, p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + first]);
+                        if (newscore == kW) continue;
+                        // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
+                        const float prod = __fmul_rn(p.lwf, (float)ff_lm(p, bq[j], r[5], r[6]));
+                        newscore = (int32_t)__fadd_rn((float)newscore, prod);
+                        newscore += p.pip;
+                        if (newscore > thresh && (cur_fr < f || newscore > cur_sc)) { cur_fr = nf; cur_sc = newscore; win = t; win_l1 = r[1]; }
+                    }
+                    if (win >= 0) {
+                        ff_enter(u, c0, cur_sc, bp0 + win, nf);
+                        u.senid[c0 * 5] = p.ldiph[((size_t)first * p.n_ci + ci2) * p.n_ci + win_l1];
+                        u.word_active[w] = nf;
+                    }
+                }
+            }
+        }
+        else {
         for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
             const int wid = FBP(u, F_WID, b);
             u.word_lat_idx[wid] = -1;
@@ -1091,6 +1165,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 }
             }
         }
+        }
         __syncthreads();
         FF_PROF(12);
         if (bp1 > bp0) {
@@ -1120,17 +1195,18 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         FF_PROF(6);
         // ---- next active word list (:853-869): the vocabulary in its order (words below <s>), then <s> and above by id
         int32_t n_next;
-        if (n_all <= FF_AWL_REGS) {                          // four consecutive candidates a work-item, their places by one prefix sum
-            int fl = 0;
+        if (n_all <= FF_AWL_REGS) {                          // a row of 256 candidates at a time, their places by a prefix sum (one row, usually)
+            n_next = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                    // (a candidate's word, first channel and lengths never change: registers)
-                const int i = tid * 4 + j;
-                if (i < n_all && u.word_active[wq[j]] == nf && (i < u.nwd ? wq[j] < p.startwid : true)) fl |= 1 << j;
+            for (int j = 0; j < kFfRegRows; ++j) {                    // (a candidate's word, first channel and lengths never change: registers)
+                if (j * kFfThreads >= n_all) break;
+                const int i = tid + j * kFfThreads;
+                const bool on = i < n_all && u.word_active[wq[j]] == nf && (i < u.nwd ? wq[j] < p.startwid : true);
+                int32_t row_total;
+                const int pos = n_next + ff_block_excl_sum(on ? 1 : 0, (j & 1) ? s_scan2 : s_scan, row_total);
+                if (on) { int32_t *a = u.awl[nxt] + 3 * pos; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j]; }
+                n_next += row_total;
             }
-            int pos = ff_block_excl_sum(__popc(fl), s_scan, n_next);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (fl & (1 << j)) { int32_t *a = u.awl[nxt] + 3 * pos++; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j]; }
         }
         else {
             for (int i = tid; i < n_all; i += kFfThreads) {
