@@ -388,6 +388,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ int32_t s_ex[kFfMaxExit][13], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
     __shared__ int32_t s_nbp[kFfMaxExit][8];                     // the frame's new back-pointers: word, last / last-but-one phone, score, sorted
                                                                  //   position of the word's first exit, real word ids (two), -
+    __shared__ FfQuad s_srt[kFfMaxExit + 4];                      // the queue in sorted order, what a walk over a word's exits reads: word's list
+                                                                 //   position, score, history, rc slot -- one 16-byte read an exit
     __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset,
                                                                  //   the word's last / last-but-one phone, base word | filler << 30, the history's two real words
     __shared__ int32_t s_fan[kFfMaxFan][4], s_nfan;      // the pruning's queued fan-outs: first target, count, score, history
@@ -981,6 +983,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             // every exit the number of entries and stack slots before its word
             const int32_t *x = s_ex[tid < n_ex ? s_ord[tid] : 0];
             const int i = x[0] >> 10;
+            if (tid < n_ex + 4 && tid < kFfMaxExit + 4) s_srt[tid] = tid < n_ex ? FfQuad{ i, x[2], x[3], x[5] } : FfQuad{ -1, 0, 0, 0 };
             const bool mine = tid < n_ex, head = mine && (tid == 0 || (s_ex[s_ord[tid - 1]][0] >> 10) != i);
             int32_t total;
             const int32_t before = ff_block_excl_sum(head ? ((x[4] << 10) | 1) : 0, s_scan, total);
@@ -998,20 +1001,27 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     int32_t cs = x[2], cp = x[3];
                     bool dirty = false, requirk = false;
                     unsigned long long have = 1ull << x[5];
-                    for (int r2 = tid + 1; r2 < n_ex; ++r2) {                    // the update branch of save_bp (ngram_search.c:405-437)
-                        const int32_t *y = s_ex[s_ord[r2]];
-                        if ((y[0] >> 10) != i) break;
-                        have |= 1ull << y[5];
-                        if (cs < y[2]) {
-                            if (cp != y[3]) {
-                                const int32_t b0 = cp == -1 ? -1 : FBP(u, F_PREAL, cp), b1 = cp == -1 ? -1 : FBP(u, F_REAL, cp);
-                                const int32_t n0 = y[3] == -1 ? -1 : FBP(u, F_PREAL, y[3]), n1 = y[3] == -1 ? -1 : FBP(u, F_REAL, y[3]);
-                                if (b0 != n0 || b1 != n1) { ff_set_real_wid(p, u, bpi); requirk = true; }      // with the old bp still in place, as the reference
-                                FBP(u, F_BP, bpi) = y[3];
-                                cp = y[3];
+                    for (int r2 = tid + 1; r2 < n_ex; r2 += 4) {                 // the update branch of save_bp (ngram_search.c:405-437),
+                        const FfQuad y4[4] = { s_srt[r2], s_srt[r2 + 1], s_srt[r2 + 2], s_srt[r2 + 3] };    // four exits read at a time
+                        bool more = true;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const FfQuad y = y4[t];
+                            more = more && y.x == i;                             // (the sentinels after the queue's end belong to no word)
+                            if (!more) continue;
+                            have |= 1ull << y.w;
+                            if (cs < y.y) {
+                                if (cp != y.z) {
+                                    const int32_t b0 = cp == -1 ? -1 : FBP(u, F_PREAL, cp), b1 = cp == -1 ? -1 : FBP(u, F_REAL, cp);
+                                    const int32_t n0 = y.z == -1 ? -1 : FBP(u, F_PREAL, y.z), n1 = y.z == -1 ? -1 : FBP(u, F_REAL, y.z);
+                                    if (b0 != n0 || b1 != n1) { ff_set_real_wid(p, u, bpi); requirk = true; }      // with the old bp still in place, as the reference
+                                    FBP(u, F_BP, bpi) = y.z;
+                                    cp = y.z;
+                                }
+                                cs = y.y; dirty = true;
                             }
-                            cs = y[2]; dirty = true;
                         }
+                        if (!more) break;
                     }
                     if (dirty) FBP(u, F_SCORE, bpi) = cs;
                     {   // what the word transitions below read of this entry
@@ -1072,11 +1082,14 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             // the start-frame nodes.
             const int n_new = bp1 - bp0;
             auto exit_score = [&](const int32_t *r, int slot) {      // bscore_stack[s_idx + slot] of a new entry: the exit into that context
-                const int i = s_ex[s_ord[r[4]]][0] >> 10;
-                for (int r2 = r[4]; r2 < n_exq; ++r2) {
-                    const int32_t *y = s_ex[s_ord[r2]];
-                    if ((y[0] >> 10) != i) break;
-                    if (y[5] == slot) return y[2];
+                const int i = s_srt[r[4]].x;
+                for (int r2 = r[4]; r2 < n_exq; r2 += 4) {
+                    const FfQuad y4[4] = { s_srt[r2], s_srt[r2 + 1], s_srt[r2 + 2], s_srt[r2 + 3] };
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (y4[t].x != i) return kW;
+                        if (y4[t].w == slot) return y4[t].y;
+                    }
                 }
                 return kW;
             };
