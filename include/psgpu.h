@@ -611,6 +611,12 @@ int32_t psgpu_fwdtree_n_single_phone_words(const psgpu_fwdtree_t *m);
  * the handle keeps per utterance of a batch.  Either pointer may be NULL.  (PSGPU_FWDTREE_LAYOUT=slab in the
  * environment at create forces the device-memory layout: the parity tests run both.) */
 int psgpu_fwdtree_layout(const psgpu_fwdtree_t *m, int32_t *lds_layout, int64_t *slab_bytes_per_utt);
+/* From the next search call on this handle uses the slab layout (all state in device memory, an evaluation list that holds every
+ * channel) whatever psgpu_fwdtree_create chose: what a caller does about status 2 -- the LDS layout's evaluation list, sized by
+ * what its 64 KB pool has left, was too short for some frame of this workload.  psgpu_decode_fetch_hyps does it by itself
+ * (psgpu_decode_table_capacity's auto_grow) and repeats the call's search.  Scoring from top-N lists needs the LDS layout
+ * (psgpu_fwdtree_can_score_lists answers 0 afterwards).  0, or PSGPU_EINVAL when the slab would exceed 8 GB per utterance. */
+int psgpu_fwdtree_use_slab_layout(psgpu_fwdtree_t *m);
 
 
 /* ---- the trigram language model on the device -----------------------

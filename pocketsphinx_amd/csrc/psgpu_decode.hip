@@ -552,6 +552,7 @@ int psgpu_decode_table_capacity(psgpu_decode_t *d, int32_t bp_per_frame, int32_t
 
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d) { return d ? d->n_grown : 0; }
 
+// (Status 2, the LDS layout's evaluation list: see the first lines of the function.)
 // An utterance whose back-pointer table or score stack filled up ended with status 1.  The reference never ends that way:
 // it doubles the table (ngram_search.c:449-463, :468-480).  Here: double both allowances, allocate new tables, search the
 // call's utterances again on the scores and penalties still in the object's buffers -- until no utterance reports a full
@@ -560,6 +561,20 @@ int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d) { return d ? d->n_gro
 static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t> &res, hipStream_t st)
 {
     const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
+    {   // status 2: the LDS layout's evaluation list (what its pool had left) filled up in some frame.  The slab layout's list holds
+        // every channel: the search is switched to it -- for good, this workload needs it -- and the call's search stage repeated.
+        bool list_full = false;
+        for (size_t u = 0; u < nu && !list_full; ++u) list_full = res[u * 8 + 3] == 2;
+        if (list_full && !d->lists) {
+            int rc;
+            if ((rc = psgpu_fwdtree_use_slab_layout(d->cfg.ft))) return rc;
+            ++d->n_grown;
+            if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;
+            if (d->ev_srch) PSGPU_HIP(hipEventRecord(d->ev_srch, st));
+            PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+            PSGPU_HIP(hipStreamSynchronize(st));
+        }
+    }
     for (int round = 0; round < 12; ++round) {
         bool full = false;
         for (size_t u = 0; u < nu && !full; ++u) full = res[u * 8 + 3] == 1;

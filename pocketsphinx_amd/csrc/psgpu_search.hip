@@ -2101,6 +2101,8 @@ static bool ft_layout(FtDev &d, bool small)
         const int64_t left = ((int64_t)kFtLdsWords - o - tail) & ~(int64_t)3, full = (int64_t)d.R + d.N + d.n1 + d.TOT + 4;
         if (2 * left < kFtMinEvl || d.n_sen > kFtMaxSen || d.n_w > 512 || d.n_ci > 64 || d.N + d.n1 >= 0x8000) return false;
         L.evl_cap = (int32_t)std::min<int64_t>(2 * left, full);
+        if (const char *cap = getenv("PSGPU_FWDTREE_EVL_CAP"))   // (a test's knob: a list that small fills up, status 2)
+            L.evl_cap = (int32_t)std::max<int64_t>(64, std::min<int64_t>(L.evl_cap, atoll(cap)));
         L.evl = take((L.evl_cap + 1) / 2);
         L.rows_total = (int32_t)o;
         if (kFtRowsDevice) L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);     // (scoring from lists computes the frame's scores into it)
@@ -2235,6 +2237,21 @@ int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm)
 }
 
 int32_t psgpu_fwdtree_n_single_phone_words(const psgpu_fwdtree_t *m) { return m ? m->d.n1 : 0; }
+
+int psgpu_fwdtree_use_slab_layout(psgpu_fwdtree_t *m)
+{
+    PSGPU_REQUIRE(m, "psgpu_fwdtree_use_slab_layout: NULL argument");
+    if (!m->d.small) return PSGPU_OK;
+    // (the layout is a table of offsets and the choice of kernel: the model's tables on the device stay as they are; the work slab
+    //  is sized by the next search call)
+    if (!ft_layout(m->d, false)) {
+        const bool back = ft_layout(m->d, true);
+        (void)back;
+        psgpu_set_error("fwdtree: the search's per-utterance arrays exceed 8 GB in the slab layout");
+        return PSGPU_EINVAL;
+    }
+    return PSGPU_OK;
+}
 
 int psgpu_fwdtree_layout(const psgpu_fwdtree_t *m, int32_t *lds_layout, int64_t *slab_bytes_per_utt)
 {

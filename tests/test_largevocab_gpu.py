@@ -143,3 +143,37 @@ def test_pipeline_equals_the_reference_on_32_of_the_benchmarks_utterances(tables
         for u, r in enumerate(refs):
             _same(u, r, hn, hyp, res, "utterance %d (lists %s)" % (ids[u], lists))
     p.close()
+
+
+def test_a_full_evaluation_list_is_reported_and_recovered_from(tables, tmp_path, monkeypatch):
+    """status 2: the LDS layout's evaluation list (sized by what the workgroup's LDS pool has left) is too short for a frame.
+    With a list of 64 entries (PSGPU_FWDTREE_EVL_CAP, read when the search is created; the task evaluates ~240 channels a
+    frame) and growth off every utterance ends early with status 2; with growth on fetch() switches the search to the slab layout
+    (psgpu_fwdtree_use_slab_layout: a list that holds every channel), repeats the search, and the result is the reference's"""
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import synth
+    gt = _load("fwdtree_trace_goforward.npz")
+    pcms = [synth.utterance(i, 6.0) for i in (2, 4, 6)]
+    refs = _reference(tmp_path, pcms, "turtle.lm.bin", "turtle.dic")
+    monkeypatch.setenv("PSGPU_FWDTREE_EVL_CAP", "64")
+    p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), tables, _load("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+    monkeypatch.delenv("PSGPU_FWDTREE_EVL_CAP")
+    assert p.search.lds_layout()
+    p.score_mode(False)
+    p.table_capacity(0, 0, False)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    assert all(int(res[u, 3]) == 2 and int(res[u, 2]) < refs[u]["frames"] for u in range(3)), res[:, :4]
+    p.table_capacity(0, 0, True)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    assert not p.search.lds_layout() and p.tables_grown() >= 1
+    for u, r in enumerate(refs):
+        _same(u, r, hn, hyp, res, "utterance %d in the slab layout" % u)
+    p.run(pcms)                                           # (and it stays there: no repeat this time)
+    n = p.tables_grown()
+    hn, hyp, res = p.fetch()
+    assert p.tables_grown() == n
+    for u, r in enumerate(refs):
+        _same(u, r, hn, hyp, res, "utterance %d, second call" % u)
+    p.close()
