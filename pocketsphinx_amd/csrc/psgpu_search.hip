@@ -45,6 +45,7 @@
 constexpr int kFtThreads = 256;        // work-items per utterance
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
+constexpr int kFtMaxBitWords = 8192;   // slab layouts: a bitmap of the listed tree nodes in LDS for trees up to 32 x this many nodes
 constexpr int kFtLdsWords = 16768;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
                                        // that reads score rows leaves the last 3.6 KB out (FtLay::rows_total): two workgroups per CU then take ~126 of its
                                        // 160 KB and leave the rest to the kernels of other streams that run beside the search
@@ -103,6 +104,7 @@ struct FtDev {
     const uint16_t *sseq;
     int32_t n_tmat;
     int32_t small;                       // the fast arrays fit the LDS pool
+    int32_t lb_words;                    // slab layouts: words of the listed-nodes bitmap in LDS (0: none, the tree is too large)
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
     int32_t cnt_words;
     FtLay lay;
@@ -669,7 +671,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #if defined(__HIPCC__)
     int32_t *const s_pool = ft_dyn_pool;                 // SMALL: kFtLdsWords words of dynamic LDS (the launch says so)
 #else
-    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 18 * NT + 16];     // (the workgroup simulator)
+    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 18 * NT + 16 + kFtMaxBitWords];     // (the workgroup simulator)
 #endif
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
@@ -688,6 +690,15 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const s_it_fp = s_pool + 3 * kPrIC, *const s_it_k0 = s_pool + 4 * kPrIC, *const s_it_par = s_pool + 5 * kPrIC,
             *const s_it_sc0 = s_pool + 6 * kPrIC, *const s_it_kid0 = s_pool + 7 * kPrIC,
             *const s_it_poff = s_pool + 8 * kPrIC;                                            // (poff: kPrIC + 1 entries)
+    // ... and, when the tree is small enough for it (p.lb_words != 0), a bitmap of the nodes in the frame's active list: a pair
+    // whose other node is NOT listed knows that node's state without asking for its record (cleared when it left the list) --
+    // two thirds of the pairs of the 134,865-word task, a cache line and a vector-memory request each
+    uint32_t *const s_lb = reinterpret_cast<uint32_t *>(s_pool + 9 * kPrIC + 16);
+#ifdef PSGPU_FT_NO_LISTED_BITMAP            /* (an A/B build: every pair asks for its other node's record) */
+    const bool use_lb = false;
+#else
+    const bool use_lb = !SMALL && p.lb_words != 0;
+#endif
     __shared__ int32_t s_nroot;          // slab layouts: roots evaluated in the frame
     __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
     // slab layouts: the frame's score row and the transition matrices in LDS too -- a channel's evaluation then asks device memory
@@ -829,6 +840,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     {
         const int nwords = (p.n_sen + 31) >> 5;
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
+        if (use_lb) for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;
     }
     // Scores: the frame's row is read from LDS (s_row).  From rows: the next frame's row travels from HBM into s_row while this
     // frame's word level runs -- issued after the evaluation, the row's last reader -- by LDS-DMA (global_load_lds_dword: no
@@ -998,11 +1010,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         act_root = tv.at(i, F::FRAME) == f;
                         if (act_root && raw_mode) mark(tv, i);
                     }
-                    else if (i < R + na && raw_mode) {
+                    else if (i < R + na && (raw_mode || use_lb)) {
                         const int node = aclc[i - R];
-                        const FtQuad a = *reinterpret_cast<const FtQuad *>(node_sen + (size_t)node * (NE <= 3 ? 4 : 8));
-                        mark_sen(a.x); mark_sen(a.y); mark_sen(a.z);
-                        if (NE == 5) { mark_sen(a.w); mark_sen(node_sen[(size_t)node * 8 + 4]); }
+                        if (use_lb) atomicOr(&s_lb[node >> 5], 1u << (node & 31));       // (zero since the end of the last frame's pruning)
+                        if (raw_mode) {
+                            const FtQuad a = *reinterpret_cast<const FtQuad *>(node_sen + (size_t)node * (NE <= 3 ? 4 : 8));
+                            mark_sen(a.x); mark_sen(a.y); mark_sen(a.z);
+                            if (NE == 5) { mark_sen(a.w); mark_sen(node_sen[(size_t)node * 8 + 4]); }
+                        }
                     }
                     if (i0 < R) n_act_root += __popcll(__ballot(act_root));
                 }
@@ -1384,7 +1399,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         qx[v] = FtQuad{ kW, -1, kW, -1 };
                         if (val[v]) {
                             const int o_ = q[v] < 0 ? (s_it_par[li[v]] & 0xffffff) : c[v];
-                            qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)o_ * TREC + F::OUT);
+                            // (a node that is not listed: {WORST_SCORE, -, WORST_SCORE, no position} -- what the initialiser says)
+                            const bool ask = !use_lb || o_ < R || ((s_lb[o_ >> 5] >> (o_ & 31)) & 1u);
+#ifdef PSGPU_FT_CHECK_LISTS
+                            if (!ask && tv.at(o_, F::FRAME) > 0) { printf("node %d carries position %d but its bit is clear (frame %d)\n", o_, tv.at(o_, F::FRAME), f); abort(); }
+                            if (ask && use_lb && o_ >= R && tv.at(o_, F::FRAME) <= 0) { printf("node %d: bit set, no position (frame %d)\n", o_, f); abort(); }
+#endif
+                            if (ask) qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)o_ * TREC + F::OUT);
                         }
                     }
 #pragma unroll
@@ -1466,6 +1487,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             n_listed = carry_l;
             if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; }
             __syncthreads();                                     // (device memory: every decision has been taken; the list of updates is complete)
+            if (use_lb) for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;       // (the next frame's list sets its own bits)
             // -- the channel updates
             for (int e = tid; e < carry_a; e += NT) {
                 const FtQuad au = reinterpret_cast<const FtQuad *>(actl)[e];
@@ -2084,6 +2106,7 @@ static bool ft_layout(FtDev &d, bool small)
     L.cnt = take(d.cnt_words);
     L.cnt2 = take(d.n_w + 2); L.cnt3 = take(d.n_w + 2); L.woff = take(d.n_w + 2); L.ckey = take(2 * ((int64_t)d.n_w + 2));
     L.present = take(((int64_t)d.TOT + 3) / 4);
+    d.lb_words = 0;
     if (small) {
         L.pen = take(2 * (int64_t)d.n_ci);
         L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
@@ -2111,6 +2134,7 @@ static bool ft_layout(FtDev &d, bool small)
     }
     else {
         L.itb = take(4 * ((int64_t)d.R + d.N)); L.act = take(4 * 2 * (int64_t)d.N + 16);
+        d.lb_words = ((int64_t)d.R + d.N + 31) / 32 <= kFtMaxBitWords ? (int32_t)(((int64_t)d.R + d.N + 31) / 32) : 0;
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
         L.evl = take(L.evl_cap);
     }
@@ -2381,13 +2405,13 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
     const size_t pool_bytes = d.small ? sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total)
-                                      : sizeof(int32_t) * (size_t)(18 * (big ? kFtThreadsBig : kFtThreads) + 16);      // (slab: the pruning's item arrays)
+                                      : sizeof(int32_t) * (size_t)(18 * (big ? kFtThreadsBig : kFtThreads) + 16 + d.lb_words);      // (slab: the pruning's item arrays, the listed-nodes bitmap)
 #if defined(__HIPCC__)                    /* a pool that takes the workgroup's LDS beyond the default 64 KB (scoring from lists): say so once */
 #define FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
         if (pool_bytes + 4096 > 65536) {                                                                              \
             static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdtree_kernel<NE, NT, SMALL, LISTS>, \
                               hipFuncAttributeMaxDynamicSharedMemorySize,                                            \
-                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * (18 * (NT) + 16)));          \
+                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * (18 * (NT) + 16 + kFtMaxBitWords)));          \
             PSGPU_HIP(attr_rc);                                                                                       \
         }
 #else
