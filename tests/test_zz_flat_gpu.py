@@ -217,3 +217,24 @@ def impl_full_cmudict(tmp):
     model = P.PtmModel(pso.load_tables())
     check_flat(s.search(g["flat_feat"], [nfr], [g["bp1"]], [g["flat_w1_ssid"]], ptm=model, topn_seed=g["flat_ptm_seed"][None])[0], g, "cmudict, scoring")
     s.close(); model.close()
+
+
+def test_two_passes_on_different_synthetic_utterances_equal_the_reference():
+    """both passes on the device for a batch of DIFFERENT utterances (the benchmark's generator, 6 s each; the second pass scoring
+    its own senones with the batch scorer's lists at hand: entries taken, chains left alone, open entries scanned by a
+    wavefront), every utterance against the reference's two-pass decode (-fwdflat yes -bestpath no) of the same PCM: words,
+    frames, path score of the second pass's hypothesis.  (tools/two_pass_bench.py, the bench's two-pass extra, with its sample = all.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    import pso
+    if not os.path.exists(os.path.join(pso.REF_DIR, "ref_decode_bench")):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TP_B="24", TP_SYNTH="6.0", TP_CHECK_EVERY="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "two_pass_bench.py")], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["status_nonzero"] == 0
+    assert j["parity"]["checked"] == 24 and j["parity"]["identical"] == 24, j["parity"]
