@@ -354,6 +354,11 @@ def child_extras(out):
         # the full cmudict task (134,865 words): single-thread reference ~1.2 k frames/s on this decode (profiles/r01i_*)
         child("search_only_cmudict", [sb], {"SB_CASE": "cmudict", "SB_BATCHES": "1,32,256", "SB_REPS": "1"}, 200)
     child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 120)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
+        # configs[2]'s shape: ONE 60 s utterance, en-us PTM + the large LM / dictionary (en-us.lm.bin is not in the repository: big.arpa
+        # + cmudict stand in), fwdtree AND fwdflat on the device, the reference's two-pass decode of the same PCM beside it
+        child("decode_two_pass_large_vocab_60s", [os.path.join(ROOT, "tools", "two_pass_bench.py")],
+              {"TP_TASK": "big", "TP_SYNTH": "60", "TP_B": "1", "TP_CHECK_EVERY": "1"}, 200)
 
 
 _JSON_FD = None

@@ -99,6 +99,8 @@ struct FfDev {
 struct FfUtt {
     int32_t nwd, n_chan, n_frame, awl_cap;
     const int32_t *wl_wid, *wl_chain, *wl_len, *wl_node_off, *node_sf;     // [nwd] (+1), [n nodes]: vocabulary, host-built
+    const int32_t *fr_off, *fr_words;    // the same nodes by start frame: [n_frame + 2] offsets into [n nodes] vocabulary positions
+    int32_t *wseen;                      // [nwd + 1] frame stamp: the word was taken as a successor in that frame already
     int32_t *score, *hist;               // [C][5]
     int32_t *out, *outh, *best, *frame;  // [C]
     int32_t *senid;                      // [C][5]
@@ -119,8 +121,8 @@ struct FfUtt {
 // kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
 // wait counters); pointers formed from a kernel argument are global.
 #define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(einfo) X(wchain) \
-    X(wlen) X(wrcs) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
-#define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf)
+    X(wlen) X(wrcs) X(wseen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
+#define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf) X(fr_off) X(fr_words)
 struct FfOff {
 #define X(f) int64_t f;
     FF_SLAB_FIELDS(X) FF_VOC_FIELDS(X)
@@ -434,6 +436,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (u.w1_ssid_in && p.w1_mpx[i])        // what the first pass left in the permanent channels (hmm_clear keeps the ssids)
             for (int k = 0; k < p.n_emit; ++k) u.senid[i * 5 + k] = u.w1_ssid_in[i * p.n_emit + k];
     }
+    for (int k = tid; k <= u.nwd; k += kFfThreads) u.wseen[k] = -1;
     for (int w = tid; w < p.n_w; w += kFfThreads) { u.wchain[w] = -1; u.wlen[w] = 0; u.wrcs[w] = 0; u.word_active[w] = -1; u.word_lat_idx[w] = -1; }
     __syncthreads();
     for (int k = tid; k < u.nwd; k += kFfThreads) {
@@ -1152,10 +1155,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
             if (sf0 < 0) sf0 = 0;
             if (ef0 > u.n_frame) ef0 = u.n_frame;
-            for (int k = tid; k < u.nwd; k += kFfThreads) {
-                bool in = false;
-                for (int q = u.wl_node_off[k]; q < u.wl_node_off[k + 1] && !in; ++q) in = u.node_sf[q] >= sf0 && u.node_sf[q] < ef0;
-                if (!in) continue;
+            // (the window's nodes are a contiguous slice of the nodes-by-start-frame list; a word with two nodes in it is taken once)
+            for (int q = (ef0 > sf0 ? u.fr_off[sf0] : 0) + tid, q1 = ef0 > sf0 ? u.fr_off[ef0] : 0; q < q1; q += kFfThreads) {
+                const int k = u.fr_words[q];
+                if (atomicExch(&u.wseen[k], nf) == nf) continue;
                 const int w = u.wl_wid[k];
                 int len; const int c0 = ff_root(p, u, w, len);
                 const int first = p.d_first[w], base = p.d_base[w];
@@ -1350,7 +1353,7 @@ void psgpu_fwdflat_free(psgpu_fwdflat_t *m)
 // build_fwdflat_wordlist (:223-300) for one utterance from the first pass's back-pointer columns (frame, wid, bp):
 // one node per (start frame, word), new nodes at the head of their start frame's list, nodes with too few end points
 // (and </s> not ending in the last frame) dropped, the vocabulary in order of first appearance walking the frames.
-struct FfVocab { std::vector<int32_t> wid, chain, len, node_off, node_sf; int32_t n_chan = 0; };
+struct FfVocab { std::vector<int32_t> wid, chain, len, node_off, node_sf, fr_off, fr_words; int32_t n_chan = 0; };
 
 static void ff_build_vocab(const psgpu_fwdflat_s *m, const int32_t *fr, const int32_t *wid, const int32_t *bpc, int nb,
                            int n_frame, int32_t chan_base, FfVocab &v)
@@ -1399,6 +1402,15 @@ static void ff_build_vocab(const psgpu_fwdflat_s *m, const int32_t *fr, const in
         v.node_off.push_back((int32_t)v.node_sf.size());
     }
     v.n_chan = c - chan_base;
+    // the nodes by start frame (a counting sort): the successors of a frame's exits are the words with a node in its window
+    v.fr_off.assign((size_t)n_frame + 2, 0);
+    for (size_t k = 0; k < sfs.size(); ++k) for (int sf : sfs[k]) ++v.fr_off[(size_t)sf + 1];
+    for (int f = 0; f <= n_frame; ++f) v.fr_off[(size_t)f + 1] += v.fr_off[f];
+    v.fr_words.assign(v.node_sf.size(), 0);
+    {
+        std::vector<int32_t> at(v.fr_off.begin(), v.fr_off.end() - 1);
+        for (size_t k = 0; k < sfs.size(); ++k) for (int sf : sfs[k]) v.fr_words[at[sf]++] = (int32_t)k;
+    }
 }
 
 // raw == NULL: the frames' scores are given (senscr_dev); else the kernel scores its own senones from raw->feats
@@ -1455,9 +1467,9 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         for (size_t k = 0; k < nwd; ++k)
             PSGPU_REQUIRE(voc[u].len[k] < 1024, "psgpu_fwdflat_search: a word chain of %d channels (FfUtt::einfo holds 10 bits)", voc[u].len[k]);
         PSGPU_REQUIRE(cap < (1u << 21), "psgpu_fwdflat_search: %zu active words (FfUtt::einfo holds 21 bits)", cap);
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + 6 * cap + 3 * (cap + 1) + 16
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + (nwd + 1) + 6 * cap + 3 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
-        voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + voc[u].node_sf.size() + 4;
+        voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + 2 * voc[u].node_sf.size() + (size_t)nfr + 2 + 4;
     }
 #ifdef PSGPU_FT_PROFILE
     stamp();
@@ -1479,11 +1491,12 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         u.nwd = (int32_t)nwd; u.n_chan = v.n_chan; u.n_frame = res1[(size_t)i * 8 + 2]; u.awl_cap = (int32_t)cap;
         u.wl_wid = put(v.wid, nwd); u.wl_chain = put(v.chain, nwd); u.wl_len = put(v.len, nwd);
         u.wl_node_off = put(v.node_off, nwd + 1); u.node_sf = put(v.node_sf, v.node_sf.size());
+        u.fr_off = put(v.fr_off, v.fr_off.size()); u.fr_words = put(v.fr_words, v.fr_words.size());
         int32_t *q = slab + slab_off[i];
         auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
         u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
         u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C); u.einfo = take(C);
-        u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.wrcs = take(d.n_w); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
+        u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.wrcs = take(d.n_w); u.wseen = take(nwd + 1); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
         u.awl[0] = take(3 * cap); u.awl[1] = take(3 * cap);
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
         u.nrow32 = raw ? take(d.n_sen) : nullptr;

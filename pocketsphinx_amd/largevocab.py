@@ -27,17 +27,19 @@ def available():
     return all(os.path.exists(p) for p in (os.path.join(REF, "ref_dump"), LM, DICT, os.path.join(REF, "model", "en-us", "mdef")))
 
 
-def tables(out_dir=None):
+def tables(out_dir=None, two_pass=False):
     """dict of the task's tables (numpy arrays): the `ref_dump fwdtree` record of a decoder initialised with big.arpa +
-    cmudict-en-us.dict, -fwdflat no -bestpath no (it also holds that decoder's trace of goforward.raw: a golden)"""
+    cmudict-en-us.dict, -fwdflat no -bestpath no (it also holds that decoder's trace of goforward.raw: a golden).
+    two_pass: the `ref_dump fwdflat` record of a -fwdflat yes decoder instead -- the same tables plus what the flat-lexicon
+    second pass adds (pronunciations, its beams, the language-weight ratio) and the two-pass trace of goforward.raw."""
     if not available():
         raise RuntimeError("the large-vocabulary task needs oracle/_ref (ref_dump + staged model, big.arpa, cmudict): make -C oracle ref")
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from psgb import read_psgb
     tmp = out_dir or tempfile.mkdtemp(prefix="psgpu_big_")
     out = os.path.join(tmp, "big.psgb")
-    subprocess.check_call([os.path.join(REF, "ref_dump"), "fwdtree", out, os.path.join(REF, "model", "en-us"), LM, DICT,
-                           os.path.join(REF, "data", "goforward.raw"), "--", "fwdflat", "no", "bestpath", "no"],
+    subprocess.check_call([os.path.join(REF, "ref_dump"), "fwdflat" if two_pass else "fwdtree", out, os.path.join(REF, "model", "en-us"), LM, DICT,
+                           os.path.join(REF, "data", "goforward.raw"), "--", "fwdflat", "yes" if two_pass else "no", "bestpath", "no"],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
     g = read_psgb(out)
     if out_dir is None:

@@ -177,3 +177,18 @@ def test_a_full_evaluation_list_is_reported_and_recovered_from(tables, tmp_path,
     for u, r in enumerate(refs):
         _same(u, r, hn, hyp, res, "utterance %d, second call" % u)
     p.close()
+
+
+def test_both_passes_at_large_vocabulary_equal_the_reference(big_task):
+    """BASELINE configs[2]'s shape (fwdtree + fwdflat, large LM and dictionary): two different 12 s synthetic utterances, both
+    search passes on the device at 134,865 words -- the flat-lexicon pass on a vocabulary of several hundred words per
+    utterance, trie language scores, scoring its own senones -- against the reference's two-pass decode of the same PCM
+    (-fwdflat yes -bestpath no): words, frames, path score.  (tools/two_pass_bench.py with TP_TASK=big.)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TP_TASK="big", TP_B="2", TP_SYNTH="12", TP_CHECK_EVERY="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "two_pass_bench.py")], capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["status_nonzero"] == 0
+    assert j["parity"]["checked"] == 2 and j["parity"]["identical"] == 2, j["parity"]

@@ -22,8 +22,16 @@ def main():
     from pocketsphinx_amd import capi
     G = os.path.join(ROOT, "tests", "golden")
     ld = lambda n: (lambda z: {k: z[k] for k in z.files})(np.load(os.path.join(G, n)))  # noqa: E731
-    gm, gt, st = ld("mfcc_en_us_goforward.npz"), ld("fwdtree_trace_goforward.npz"), ld("fwdtree_static_en_us_turtle.npz")
-    gf, fst, t = ld("fwdflat_trace_goforward.npz"), ld("fwdflat_static_en_us_turtle.npz"), ld("en_us_ptm_tables.npz")
+    gm, t = ld("mfcc_en_us_goforward.npz"), ld("en_us_ptm_tables.npz")
+    big = os.environ.get("TP_TASK") == "big"              # the 134,865-word task (big.arpa + cmudict, trie LM on the device): configs[2]'s shape
+    lm = None
+    if big:
+        from pocketsphinx_amd import largevocab as lv
+        gt = st = gf = fst = lv.tables(two_pass=True)
+        lm = P.NGramTrieLM(gt)
+    else:
+        gt, st = ld("fwdtree_trace_goforward.npz"), ld("fwdtree_static_en_us_turtle.npz")
+        gf, fst = ld("fwdflat_trace_goforward.npz"), ld("fwdflat_static_en_us_turtle.npz")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     L = capi.lib()
@@ -32,8 +40,8 @@ def main():
     B = int(os.environ.get("TP_B", "256"))
     model = P.PtmModel(t)
     fe = P.FrontEnd(gm)
-    s1 = P.FwdtreeSearch(st, gt["par"])
-    s2 = P.FwdflatSearch(st, fst, gf["par"], gf["flat_par"], gf["flat_lwf"])
+    s1 = P.FwdtreeSearch(st, gt["par"], lm=lm)
+    s2 = P.FwdflatSearch(st, fst, gf["par"], gf["flat_par"], gf["flat_lwf"], lm=lm)
     ctx = P.HmmContext(st["tp"], st["sseq"], model.n_sen)
     pcm1 = gm["pcm"].astype(np.float32)
     rng = np.random.default_rng(3)
@@ -80,7 +88,7 @@ def main():
     H = int(t["n_fast_hist"][0])
     ts = max(x for x in range(Tu) if x % H == H - 1)
     lens = [Tu] * B
-    bp_cap, bss_cap = max(4096, 24 * Tu + 2048), max(65536, 640 * Tu + 8192)     # (per-utterance table capacities of both passes)
+    bp_cap, bss_cap = max(4096, (64 if big else 24) * Tu + 2048), max(65536, (1600 if big else 640) * Tu + 8192)     # (per-utterance table capacities of both passes)
     out = {}
 
     def two_pass():
@@ -106,6 +114,7 @@ def main():
     dt = time.perf_counter() - t0
     fin = int(gt["par"][20])
     w0 = [w for w, _, _ in P.backtrace(r2[0], fin)[1]]
+    out["task"] = "134,865 words (big.arpa + cmudict-en-us.dict, trie LM)" if big else "115 words (turtle)"
     # parity of the sampled utterances: the compiled reference decodes the SAME PCM with both passes (-fwdflat yes -bestpath no,
     # a new decoder's state per utterance) -- words, frame boundaries and path score of the second pass's hypothesis
     ids = list(range(0, B, int(os.environ.get("TP_CHECK_EVERY", "17"))))
@@ -120,9 +129,12 @@ def main():
             path = fh.name
         try:
             ref = os.path.join(ROOT, "oracle", "_ref")
-            o = subprocess.run([ref_exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", "turtle.lm.bin"),
-                                os.path.join(ref, "data", "turtle.dic"), path, str(ns), "--", "fwdflat", "yes", "bestpath", "no"],
-                               capture_output=True, text=True, timeout=300)
+            o = subprocess.run([ref_exe, os.path.join(ref, "model", "en-us"), os.path.join(ref, "data", "big.arpa" if big else "turtle.lm.bin"),
+                                os.path.join(ref, "data", "cmudict-en-us.dict" if big else "turtle.dic"), path, str(ns), "--", "fwdflat", "yes",
+                                "bestpath", "no"], capture_output=True, text=True, timeout=1800)
+            tot = json.loads(o.stdout.strip().splitlines()[-1])
+            out["reference"] = {"frames_per_s": tot.get("frames_per_s"), "cpu_s": tot.get("cpu_s"), "what": "the compiled reference, one thread, "
+                                "-fwdflat yes -bestpath no, on the sampled utterances (its own timing line)"}
             lines = [json.loads(ln) for ln in o.stdout.strip().splitlines() if ln.startswith("{")][:-1]
         finally:
             os.unlink(path)
