@@ -1225,15 +1225,27 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             }
         }
         else {
-            for (int i = tid; i < n_all; i += kFfThreads) {
-                const int w = i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd);
-                u.cnt_c[i] = (u.word_active[w] == nf && (i < u.nwd ? w < p.startwid : true)) ? 1 : 0;
+            // larger vocabularies: eight consecutive candidates a work-item per round (their words, then their stamps, asked for
+            // together), places by a prefix sum over the round's counts
+            n_next = 0;
+            for (int base = 0, round = 0; base < n_all; base += 8 * kFfThreads, ++round) {
+                int wv[8], fl = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = base + tid * 8 + j;
+                    wv[j] = i < u.nwd ? u.wl_wid[i] : p.startwid + (i < n_all ? i - u.nwd : 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = base + tid * 8 + j;
+                    if (i < n_all && u.word_active[wv[j]] == nf && (i < u.nwd ? wv[j] < p.startwid : true)) fl |= 1 << j;
+                }
+                int32_t round_total;
+                int pos = n_next + ff_block_excl_sum(__popc(fl), (round & 1) ? s_scan2 : s_scan, round_total);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (fl & (1 << j)) ff_awl_put(p, u, u.awl[nxt], pos++, wv[j]);
+                n_next += round_total;
             }
-            __syncthreads();
-            n_next = ff_block_scan(u.cnt_c, n_all, s_scan);
-            for (int i = tid; i < n_all; i += kFfThreads)
-                if ((i + 1 < n_all ? u.cnt_c[i + 1] : n_next) != u.cnt_c[i])
-                    ff_awl_put(p, u, u.awl[nxt], u.cnt_c[i], i < u.nwd ? u.wl_wid[i] : p.startwid + (i - u.nwd));
         }
         n_awl[nxt] = n_next;
         if (tid == 0) {
