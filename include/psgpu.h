@@ -906,6 +906,17 @@ int psgpu_fwdflat_search_feats_lists_dev(psgpu_fwdflat_t *m, const psgpu_ptm_vie
                                          int32_t bss_cap, int32_t *bp_dev, int32_t *bss_dev, int32_t *idx_dev,
                                          int32_t *step_dev, int32_t *result_dev, void *stream);
 
+/* The flat-lexicon second pass (ngram_fwdflat_search, src/ngram_search_fwdflat.c) as a stage of the pipeline object: after
+ * psgpu_decode_first_pass* it runs psgpu_fwdflat_search_feats_lists_dev on what that call left in the object's buffers -- the
+ * first pass's tables and permanent channels' ssids, the call's feature rows, the batch scorer's lists with their open flags,
+ * each utterance's seeding lists (slot n_fast_hist - 1 of the scorer's history) -- into second-pass tables of its own, and
+ * replaces the call's hypotheses by this pass's: psgpu_decode_fetch_hyps / psgpu_decode_fetch_tables then return the SECOND
+ * pass's hypotheses, result records and tables (the first pass's stay where psgpu_decode_view shows them).  Full tables
+ * grow as psgpu_decode_table_capacity says, for either pass.  PTM scorer only (the pass scores its own senones from that
+ * scorer's model); synchronous (the pass's vocabulary is built on the host from the first pass's table).  `flat` must have been
+ * created from the same dictionary / LM as the pipeline's search. */
+int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *flat, void *stream);
+
 /* Host-buffer form used by the search-side shim: n records in, the same n
  * records updated in place, *best = max(WORST_SCORE, returned best scores).
  * senscr is the frame's n_sen int16 scores.  Synchronous. */

@@ -44,6 +44,11 @@ struct psgpu_decode_s {
     // (psgpu_decode_table_capacity); grown on demand when the search reports a full table (psgpu_decode_fetch_hyps)
     int32_t bp_pf = 16, bss_pf = 320, auto_grow = 1, n_grown = 0;
     int32_t *d_mpx_in = nullptr;          // session: the state the latest search STARTED from (a repeated search needs it again)
+    // psgpu_decode_second_pass: the flat-lexicon pass's tables (the first pass's capacities), its seeds, whether the latest call ran it
+    int32_t *d_bp2 = nullptr, *d_bss2 = nullptr, *d_idx2 = nullptr, *d_step2 = nullptr, *d_res2 = nullptr, *d_seed2 = nullptr;
+    size_t cap2_utt = 0, cap2_bp = 0, cap2_bss = 0, cap2_mf = 0;
+    int32_t bp_cap2 = 0, bss_cap2 = 0;
+    bool pass2 = false;
     bool last_chained = false, last_sess = false, searched = false;
     int32_t lag_next = 0, last_lag = 0;   // psgpu_decode_search_lag: for the next call / what the latest call's search was given
     // the last call
@@ -86,6 +91,21 @@ static void dec_pick_mode(psgpu_decode_s *d)
 {
     static const int env_lists = [] { const char *e = getenv("PSGPU_DECODE_LISTS"); return e ? atoi(e) : 0; }();
     d->lists = (d->want_lists || env_lists) && dec_can_lists(d);
+}
+
+// The codeword lists the second pass's frame 0 starts from, per utterance: slot n_fast_hist - 1 of the scorer's history ring as the
+// first pass left it (ptm_mgau.c:425-441) = the lists of the utterance's last frame t with t % H == H - 1, H = n_fast_hist; an
+// utterance shorter than H frames never wrote that slot: a new scorer's lists, codeword = rank (:790-793).
+__global__ void dec_pass2_seed_kernel(const uint8_t *__restrict__ tcw, const int32_t *__restrict__ off, int32_t total, int32_t n_chain,
+                                      int32_t topn, int32_t H, int32_t *__restrict__ seed)
+{
+    const int u = blockIdx.x, t0 = off[u], T = off[u + 1] - t0;
+    int ts = T - 1;
+    while (ts >= 0 && ts % H != H - 1) --ts;
+    for (int i = threadIdx.x; i < n_chain * topn; i += blockDim.x) {
+        const int ch = i / topn, k = i - ch * topn;
+        seed[(size_t)u * n_chain * topn + i] = ts >= 0 ? (int32_t)tcw[((size_t)ch * total + t0 + ts) * topn + k] : k;
+    }
 }
 
 extern "C" {
@@ -145,6 +165,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
+    DFREE(d->d_bp2); DFREE(d->d_bss2); DFREE(d->d_idx2); DFREE(d->d_step2); DFREE(d->d_res2); DFREE(d->d_seed2);
     DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
@@ -400,7 +421,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
                   "psgpu_decode_first_pass_dev: from PCM the pipeline computes 1s_c_d_dd vectors of %d cepstra; the scorer takes %d-dimensional "
                   "vectors (other feature types: psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
     hipStream_t st = (hipStream_t)stream;
-    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false;
     d->frame_off.assign((size_t)n_utt + 1, 0);
     if (n_utt == 0) return PSGPU_OK;
     size_t total = 0, mf = 0;
@@ -454,7 +475,7 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (feat && frame_off)), "psgpu_decode_first_pass_feat: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false;
     d->frame_off.assign(frame_off, frame_off + (n_utt ? n_utt + 1 : 0));
     if (n_utt == 0) { d->frame_off.assign(1, 0); return PSGPU_OK; }
     PSGPU_REQUIRE(frame_off[0] == 0, "psgpu_decode_first_pass_feat: frame offsets start at 0");
@@ -617,7 +638,7 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
         int rc = psgpu_ms_batch_check((psgpu_ms_model_t *)d->cfg.scorer, st);
         if (rc != PSGPU_OK) return rc;
     }
-    if (nu && d->auto_grow && d->searched) {
+    if (nu && d->auto_grow && d->searched && !d->pass2) {
         std::vector<int32_t> res(nu * 8);
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
         PSGPU_HIP(hipStreamSynchronize(st));
@@ -629,23 +650,91 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
     if (nu) {
         if (hyp_n) PSGPU_HIP(hipMemcpyAsync(hyp_n, d->d_hn, 4 * nu * 4, hipMemcpyDeviceToHost, st));
         if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
-        if (result) PSGPU_HIP(hipMemcpyAsync(result, d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        if (result) PSGPU_HIP(hipMemcpyAsync(result, d->pass2 ? d->d_res2 : d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
     }
     PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *stream)
+{
+    PSGPU_REQUIRE(d && ff, "psgpu_decode_second_pass: NULL argument");
+    PSGPU_REQUIRE(d->searched, "psgpu_decode_second_pass: no first pass in this object (psgpu_decode_first_pass* comes first)");
+    PSGPU_REQUIRE(d->kind == PSGPU_SCORER_PTM, "psgpu_decode_second_pass: the device second pass scores from the PTM scorer's lists");
+    PSGPU_REQUIRE(psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK, "psgpu_decode_second_pass: no view of the PTM model");
+    PSGPU_REQUIRE(d->last_lag == 0, "psgpu_decode_second_pass: the first pass stopped short of the utterances' ends (psgpu_decode_search_lag)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
+    d->pass2 = false;
+    if (nu == 0) { d->pass2 = true; return PSGPU_OK; }
+    int rc;
+    {   // the first pass's tables complete (a full table: larger ones and the search again, as psgpu_decode_fetch_hyps would)
+        std::vector<int32_t> res(nu * 8);
+        PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+        if (d->auto_grow && (rc = dec_repeat_with_larger_tables(d, res, st))) return rc;
+        for (size_t u = 0; u < nu; ++u)
+            PSGPU_REQUIRE(res[u * 8 + 3] == 0, "psgpu_decode_second_pass: utterance %zu's first pass ended with status %d", u, res[u * 8 + 3]);
+    }
+    size_t cb = d->cap_bp, cs = d->cap_bss;              // the second pass's tables start at the first pass's capacities
+    for (int round = 0;; ++round) {
+        if (nu > d->cap2_utt || cb > d->cap2_bp || cs > d->cap2_bss || mf > d->cap2_mf) {
+            DFREE(d->d_bp2); DFREE(d->d_bss2); DFREE(d->d_idx2); DFREE(d->d_step2); DFREE(d->d_res2); DFREE(d->d_seed2);
+            d->cap2_utt = d->cap2_bp = d->cap2_bss = d->cap2_mf = 0;
+            const size_t cu = std::max(nu, d->cap_utt), cm = std::max(mf, d->cap_mf);
+            if ((rc = dec_alloc((void **)&d->d_bp2, 4 * cu * 10 * cb)) || (rc = dec_alloc((void **)&d->d_bss2, 4 * cu * cs))
+                || (rc = dec_alloc((void **)&d->d_idx2, 4 * cu * (cm + 2))) || (rc = dec_alloc((void **)&d->d_step2, 4 * cu * std::max<size_t>(cm, 1) * 4))
+                || (rc = dec_alloc((void **)&d->d_res2, 4 * cu * 8))
+                || (rc = dec_alloc((void **)&d->d_seed2, 4 * cu * (size_t)d->n_chain * d->topn)))
+                return rc;
+            d->cap2_utt = cu; d->cap2_bp = cb; d->cap2_bss = cs; d->cap2_mf = cm;
+        }
+        d->bp_cap2 = (int32_t)d->cap2_bp; d->bss_cap2 = (int32_t)d->cap2_bss;
+        hipLaunchKernelGGL(dec_pass2_seed_kernel, dim3((unsigned)nu), dim3(128), 0, st, d->d_tcw, d->d_off, d->total, d->n_chain, d->topn,
+                           d->cfg.pl_window + 2, d->d_seed2);
+        PSGPU_HIP(hipGetLastError());
+        const uint8_t *open_flags = nullptr;
+        if ((rc = psgpu_ptm_batch_open_flags(d->cfg.model, st, &open_flags))) return rc;
+        if ((rc = psgpu_fwdflat_search_feats_lists_dev(ff, &d->view, d->d_feat, d->d_seed2, d->d_tsc, d->d_tcw, open_flags, d->total, d->d_off,
+                                                       d->n_utt, d->max_frames, d->bp_cap, d->d_bp, d->d_res, d->d_w1, d->bp_cap2, d->bss_cap2,
+                                                       d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)))
+            return rc;
+        std::vector<int32_t> res2(nu * 8);
+        PSGPU_HIP(hipMemcpyAsync(res2.data(), d->d_res2, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+        bool full = false;
+        for (size_t u = 0; u < nu && !full; ++u) full = res2[u * 8 + 3] == 1;
+        if (!full || !d->auto_grow || round >= 12) break;
+        cb = 2 * d->cap2_bp; cs = 2 * d->cap2_bss;          // (the reference grows these tables on demand as well)
+        size_t free_b = 0, total_b = 0;
+        if (cb > 0x7ffffff0u / 10 || cs > 0x7ffffff0u || hipMemGetInfo(&free_b, &total_b) != hipSuccess
+            || 4 * d->cap2_utt * (10 * cb + cs) + ((size_t)256 << 20) > free_b + 4 * d->cap2_utt * (10 * d->cap2_bp + d->cap2_bss))
+            break;
+        ++d->n_grown;
+    }
+    // the hypotheses of this pass in the place of the first's (ngram_search_find_exit + backtrace on the second pass's table)
+    if ((rc = psgpu_fwdtree_backtrace_dev(d->cfg.ft, d->d_bp2, d->d_idx2, d->d_res2, d->n_utt, d->max_frames, d->bp_cap2, d->max_words,
+                                          d->d_hyp, d->d_hn, st)))
+        return rc;
+    d->pass2 = true;
     return PSGPU_OK;
 }
 
 int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp, int32_t *bss,
                               int32_t *idx, void *stream)
 {
-    PSGPU_REQUIRE(d && u >= 0 && u < d->n_utt && n_bp >= 0 && n_bp <= d->bp_cap && n_bss >= 0 && n_bss <= d->bss_cap
-                  && n_idx >= 0 && n_idx <= d->max_frames + 2, "psgpu_decode_fetch_tables: bad argument");
+    PSGPU_REQUIRE(d && u >= 0 && u < d->n_utt, "psgpu_decode_fetch_tables: bad argument");
+    // (after psgpu_decode_second_pass: that pass's tables, as psgpu_decode_fetch_hyps returns its hypotheses and result records)
+    const int32_t bcap = d->pass2 ? d->bp_cap2 : d->bp_cap, scap = d->pass2 ? d->bss_cap2 : d->bss_cap;
+    const int32_t *const t_bp = d->pass2 ? d->d_bp2 : d->d_bp, *const t_bss = d->pass2 ? d->d_bss2 : d->d_bss, *const t_idx = d->pass2 ? d->d_idx2 : d->d_idx;
+    PSGPU_REQUIRE(n_bp >= 0 && n_bp <= bcap && n_bss >= 0 && n_bss <= scap && n_idx >= 0 && n_idx <= d->max_frames + 2,
+                  "psgpu_decode_fetch_tables: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (bp && n_bp)       // ten columns, bp_cap apart on the device, n_bp apart on the host
-        PSGPU_HIP(hipMemcpy2DAsync(bp, 4 * (size_t)n_bp, d->d_bp + (size_t)u * 10 * d->bp_cap, 4 * (size_t)d->bp_cap, 4 * (size_t)n_bp, 10,
+        PSGPU_HIP(hipMemcpy2DAsync(bp, 4 * (size_t)n_bp, t_bp + (size_t)u * 10 * bcap, 4 * (size_t)bcap, 4 * (size_t)n_bp, 10,
                                    hipMemcpyDeviceToHost, st));
-    if (bss && n_bss) PSGPU_HIP(hipMemcpyAsync(bss, d->d_bss + (size_t)u * d->bss_cap, 4 * (size_t)n_bss, hipMemcpyDeviceToHost, st));
-    if (idx && n_idx) PSGPU_HIP(hipMemcpyAsync(idx, d->d_idx + (size_t)u * (d->max_frames + 2), 4 * (size_t)n_idx, hipMemcpyDeviceToHost, st));
+    if (bss && n_bss) PSGPU_HIP(hipMemcpyAsync(bss, t_bss + (size_t)u * scap, 4 * (size_t)n_bss, hipMemcpyDeviceToHost, st));
+    if (idx && n_idx) PSGPU_HIP(hipMemcpyAsync(idx, t_idx + (size_t)u * (d->max_frames + 2), 4 * (size_t)n_idx, hipMemcpyDeviceToHost, st));
     PSGPU_HIP(hipStreamSynchronize(st));
     return PSGPU_OK;
 }

@@ -200,6 +200,11 @@ class DecodePipeline:
                                                       res.ctypes.data_as(C.c_void_p), self._stream), "psgpu_decode_fetch_hyps")
         return hn, hyp, res
 
+    def second_pass(self, flat):
+        """psgpu_decode_second_pass: the flat-lexicon second pass (a FwdflatSearch built from the same tables) on what the latest
+        run* left in the object; fetch() / tables() then return the second pass's hypotheses, result records and tables"""
+        capi.check(capi.lib().psgpu_decode_second_pass(self.h, flat.h, self._stream), "psgpu_decode_second_pass")
+
     def view(self):
         v = DecodeView()
         capi.check(capi.lib().psgpu_decode_view(self.h, C.byref(v)), "psgpu_decode_view")

@@ -238,3 +238,59 @@ def test_two_passes_on_different_synthetic_utterances_equal_the_reference():
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["status_nonzero"] == 0
     assert j["parity"]["checked"] == 24 and j["parity"]["identical"] == 24, j["parity"]
+
+
+def test_pipeline_object_runs_both_passes(tmp_path):
+    """psgpu_decode_second_pass: PCM -> first pass -> second pass inside ONE pipeline object (the C ABI's batch entry), 20
+    different synthetic utterances of 6 s against the reference's two-pass decode of the same PCM; the first pass's tables stay
+    readable through the view; a second call on the same object (other utterances, tables re-used) as well; tiny tables grow."""
+    import json
+    import os
+    import subprocess
+    import pso
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import synth
+    from test_oracle_golden import _load
+    exe = os.path.join(pso.REF_DIR, "ref_decode_bench")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    gt, st = _load("fwdtree_trace_goforward.npz"), _load("fwdtree_static_en_us_turtle.npz")
+    gf, fst = _load("fwdflat_trace_goforward.npz"), _load("fwdflat_static_en_us_turtle.npz")
+    p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), pso.load_tables(), st, gt["par"], gt)
+    flat = P.FwdflatSearch(st, fst, gf["par"], gf["flat_par"], gf["flat_lwf"])
+    data = os.path.join(pso.REF_DIR, "data")
+
+    def reference(pcms):
+        raw = tmp_path / ("utts%d.raw" % len(os.listdir(str(tmp_path))))
+        np.concatenate(pcms).tofile(raw)
+        o = subprocess.run([exe, os.path.join(pso.REF_DIR, "model", "en-us"), os.path.join(data, "turtle.lm.bin"), os.path.join(data, "turtle.dic"),
+                            str(raw), str(pcms[0].size), "--", "fwdflat", "yes", "bestpath", "no"], capture_output=True, text=True, timeout=900)
+        assert o.returncode == 0, o.stderr[-2000:]
+        return [json.loads(ln) for ln in o.stdout.strip().splitlines() if ln.startswith("{")][:-1]
+
+    def check(ids, seconds):
+        pcms = [synth.utterance(i, seconds) for i in ids]
+        refs = reference(pcms)
+        p.run(pcms)
+        hn1, hyp1, res1 = p.fetch()                       # (the first pass's, before the second runs)
+        p.second_pass(flat)
+        hn, hyp, res = p.fetch()
+        for u, r in enumerate(refs):
+            assert int(res[u, 3]) == 0 and int(res[u, 2]) == r["frames"], (ids[u], res[u])
+            got = [tuple(int(v) for v in hyp[u, i, :3]) for i in range(int(hn[u, 0]))]
+            assert got == [(s_[1], s_[2], s_[3]) for s_ in r["seg"]], ids[u]
+            assert int(hn[u, 1]) == r["score"], ids[u]
+            assert int(res[u, 0]) == r["n_bp"], (ids[u], res[u], r["n_bp"])       # (the reference's table is the last pass's)
+        t2 = p.tables(0, res)
+        assert t2["bp"].shape[0] == int(res[0, 0]) and t2["status"] == 0
+        return hn1, hn
+
+    hn1, hn = check(list(range(20)), 6.0)
+    assert any(int(hn1[u, 1]) != int(hn[u, 1]) for u in range(20))       # (the two passes' path scores differ: it did run)
+    check([31, 7], 9.0)
+    p.close()
+    p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), pso.load_tables(), st, gt["par"], gt)
+    p.table_capacity(1, 1, True)                          # a new object whose tables are too small for either pass: both grow
+    check([3, 4, 5], 6.0)
+    assert p.tables_grown() >= 2
+    flat.close(); p.close()
