@@ -276,6 +276,52 @@ def ms_scorer_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, static, gt, n_utt
     return out
 
 
+def two_pass_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, static, gt, n_utt, steps, n_check, with_cpu):
+    """the reference's DEFAULT search configuration (-fwdflat yes; -bestpath no here) at the headline's scale: both search passes on
+    the device inside one pipeline object (psgpu_decode_second_pass), PCM -> the second pass's hypotheses; the reference decodes
+    n_check of the utterances with both passes"""
+    import torch
+    gf, fst = _npz("fwdflat_trace_goforward.npz"), _npz("fwdflat_static_en_us_turtle.npz")
+    pipe = P.DecodePipeline(fe_tables, ptm_tables, static, gt["par"], gt)
+    flat = P.FwdflatSearch(static, fst, gf["par"], gf["flat_par"], gf["flat_lwf"])
+    pcm = torch.from_numpy(pcm_all[:n_utt * n_samp]).to(dev)
+    soff = np.arange(n_utt + 1, dtype=np.int64) * n_samp
+    stream = torch.cuda.current_stream().cuda_stream
+    pipe.run_dev(pcm, soff, stream); pipe.second_pass(flat); pipe.fetch(want_hyp=False)
+    torch.cuda.synchronize()
+    t_first = t_second = 0.0
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        ta = time.perf_counter()
+        pipe.run_dev(pcm, soff, stream)
+        torch.cuda.synchronize(); tb = time.perf_counter()
+        pipe.second_pass(flat)
+        hn, hyp, res = pipe.fetch()
+        tc = time.perf_counter()
+        t_first += tb - ta; t_second += tc - tb
+    dt = (time.perf_counter() - t1) / steps
+    frames = int(res[:, 2].sum())
+    out = {"frames_per_s": round(frames / dt, 1), "ms_per_step": round(1e3 * dt, 2), "utterances": n_utt, "frames": frames,
+           "xrt": round(dt / (n_utt * seconds), 8), "first_pass_ms": round(1e3 * t_first / steps, 2),
+           "second_pass_ms": round(1e3 * t_second / steps, 2), "status_nonzero": int((res[:, 3] != 0).sum()),
+           "what": "%d utterances x %g s, en-us PTM + turtle LM, fwdtree AND fwdflat on the device in one pipeline object (one batch at a "
+                   "time: no overlap of batches as in the headline), PCM -> the second pass's hypotheses; second_pass_ms includes the host's "
+                   "vocabulary build from the first pass's tables and the fetch" % (n_utt, seconds)}
+    if with_cpu:
+        ids = sorted(set(int(i) for i in np.linspace(0, n_utt - 1, min(n_check, n_utt))))
+        ref = reference_decode(pcm_all, n_samp, ids, procs=min(len(ids), max(1, (os.cpu_count() or 2) // 2)), extra=("fwdflat", "yes", "bestpath", "no"))
+        if ref is not None:
+            utts, tot = ref
+            bad = parity_of(ids, utts, hn, hyp, res)
+            out["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                   "sample": "%d utterances, %.1f s of CPU in all, -fwdflat yes -bestpath no" % (len(ids), tot["cpu_s"])}
+            out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad}
+    flat.close(); pipe.close()
+    del pcm
+    torch.cuda.empty_cache()
+    return out
+
+
 class _DevArray:
     """a device buffer of the library as a zero-copy torch tensor (torch.as_tensor on __cuda_array_interface__)"""
 
@@ -667,6 +713,11 @@ def main():
                                                      _npz("fwdtree_static_en_us_turtle.npz"), gt, min(64, B), 2, 4, not args.no_cpu_baseline)
         except Exception as e:
             line["decode_ms_scorer"] = {"error": str(e)[-400:]}
+        try:
+            line["decode_two_pass"] = two_pass_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,
+                                                   _npz("fwdtree_static_en_us_turtle.npz"), gt, B, 2, 4, not args.no_cpu_baseline)
+        except Exception as e:
+            line["decode_two_pass"] = {"error": str(e)[-400:]}
         if not args.no_large_vocab:
             try:
                 line["decode_large_vocab"] = large_vocab_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstring>
 #include <ctime>
+#include <thread>
 #include <vector>
 
 // Builds for the workgroup simulator (tests/hostsim: g++, no __HIPCC__) keep, beside the lazily maintained top-N lists of the
@@ -388,8 +389,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ int32_t s_el[kFfMaxEl][4];                        // the active-channel list: channel | flags, word's list position << 10 | chain
                                                                  //   position, word, channels after it | word's right-context count << 10 | single-phone << 20
     __shared__ int32_t s_ex[kFfMaxExit][13], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
-    __shared__ int32_t s_nbp[kFfMaxExit][8];                     // the frame's new back-pointers: word, last / last-but-one phone, score, sorted
-                                                                 //   position of the word's first exit, real word ids (two), -
+    __shared__ int32_t s_nbp[kFfMaxExit][10];                     // the frame's new back-pointers: word, last / last-but-one phone, score, sorted
+                                                                 //   position of the word's first exit, real word ids (two), which right contexts it exited into (64 bits)
     __shared__ FfQuad s_srt[kFfMaxExit + 4];                      // the queue in sorted order, what a walk over a word's exits reads: word's list
                                                                  //   position, score, history, rc slot -- one 16-byte read an exit
     __shared__ uint16_t s_ord[kFfMaxExit];                       //   score, history, right-context count of the word, rc slot, ordinal, stack offset,
@@ -970,6 +971,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      queue is sorted by (word's list position, chain position) by counting; a word's first exit learns how many words
         //      and stack entries precede it from the sorted queue and then walks its group -- everything but the table itself in LDS.
         const int n_exq = s_nex;
+#ifdef PSGPU_FT_PROFILE
+        if (tid == 0) { s_prof[13] += n_exq > FF_EXIT_CAP ? 1 : 0; s_prof[14] += n_exq; s_prof[15] += n_exq > 256 ? 1 : 0; }
+#endif
         if (s_nex == 0) { }                                  // (a frame without exits: nothing to write, no barrier to meet)
         else if (s_nex <= FF_EXIT_CAP) {
             static_assert(kFfMaxExit <= kFfThreads, "one queued exit per work-item");
@@ -1035,6 +1039,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         if (requirk) { nb[5] = FBP(u, F_REAL, bpi); nb[6] = FBP(u, F_PREAL, bpi); }
                         else if (filler) { nb[5] = x[3] != -1 ? x[11] : base; nb[6] = x[3] != -1 ? x[12] : -1; }
                         else { nb[5] = base; nb[6] = x[11]; }
+                        nb[7] = (int32_t)(uint32_t)have; nb[8] = (int32_t)(uint32_t)(have >> 32);
                     }
                     if (!single)
                         for (int q = 0; q < x[4]; ++q) if (!((have >> q) & 1)) u.bss[bsh + q] = kW;      // the contexts nothing exited into
@@ -1085,16 +1090,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             // the start-frame nodes.
             const int n_new = bp1 - bp0;
             auto exit_score = [&](const int32_t *r, int slot) {      // bscore_stack[s_idx + slot] of a new entry: the exit into that context
-                const int i = s_srt[r[4]].x;
-                for (int r2 = r[4]; r2 < n_exq; r2 += 4) {
-                    const FfQuad y4[4] = { s_srt[r2], s_srt[r2 + 1], s_srt[r2 + 2], s_srt[r2 + 3] };
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (y4[t].x != i) return kW;
-                        if (y4[t].w == slot) return y4[t].y;
-                    }
-                }
-                return kW;
+                // (a word's exits are queued in chain order = right-context order: the slot's place among them is a population count)
+                const unsigned long long have = (unsigned long long)(uint32_t)r[7] | ((unsigned long long)(uint32_t)r[8] << 32);
+                if (!((have >> slot) & 1ull)) return kW;
+                return s_srt[r[4] + __popcll(have & ((1ull << slot) - 1ull))].y;
             };
             if (tid < n_new) {
                 const int32_t *r = s_nbp[tid];
@@ -1118,16 +1117,31 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     const int w = wq[j], c0 = c0q[j], first = fq[j] & 0xff, ci2 = fq[j] >> 8;
                     int32_t cur_fr = u.frame[c0], cur_sc = u.score[c0 * 5];
                     int win = -1, win_l1 = 0;
-                    for (int t = 0; t < n_new; ++t) {          // exits in order: the first best one wins, as in the reference
-                        const int32_t *r = s_nbp[t];
-                        if (r[0] == p.finishwid) continue;
-                        int32_t newscore = r[2] == -1 ? r[3] : exit_score(r, p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + first]);
-                        if (newscore == kW) continue;
-                        // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
-                        const float prod = __fmul_rn(p.lwf, (float)ff_lm(p, bq[j], r[5], r[6]));
-                        newscore = (int32_t)__fadd_rn((float)newscore, prod);
-                        newscore += p.pip;
-                        if (newscore > thresh && (cur_fr < f || newscore > cur_sc)) { cur_fr = nf; cur_sc = newscore; win = t; win_l1 = r[1]; }
+                    for (int t0 = 0; t0 < n_new; t0 += 4) {    // exits in order: the first best one wins, as in the reference --
+                        int32_t slot[4], lmv[4];               // four at a time, their context slots and language scores asked for together
+                        bool ok[4];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int32_t *r = s_nbp[min(t0 + v, n_new - 1)];
+                            ok[v] = t0 + v < n_new && r[0] != p.finishwid;
+                            slot[v] = -1; lmv[v] = 0;
+                            if (ok[v]) {
+                                if (r[2] != -1) slot[v] = p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + first];
+                                lmv[v] = ff_lm(p, bq[j], r[5], r[6]);
+                            }
+                        }
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            if (!ok[v]) continue;
+                            const int32_t *r = s_nbp[t0 + v];
+                            int32_t newscore = r[2] == -1 ? r[3] : exit_score(r, slot[v]);
+                            if (newscore == kW) continue;
+                            // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
+                            const float prod = __fmul_rn(p.lwf, (float)lmv[v]);
+                            newscore = (int32_t)__fadd_rn((float)newscore, prod);
+                            newscore += p.pip;
+                            if (newscore > thresh && (cur_fr < f || newscore > cur_sc)) { cur_fr = nf; cur_sc = newscore; win = t0 + v; win_l1 = r[1]; }
+                        }
                     }
                     if (win >= 0) {
                         ff_enter(u, c0, cur_sc, bp0 + win, nf);
@@ -1471,10 +1485,25 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     std::vector<FfVocab> voc(n_utt);
     std::vector<size_t> slab_off(n_utt + 1, 0), voc_off(n_utt + 1, 0);
     const int n_tail = d.n_w - d.startwid;
+    {   // the utterances' vocabularies are independent of each other: host threads (30 s of audio on the small task: 18 k first-pass
+        // entries and ~170 us an utterance; 512 of them one after another were a quarter of the call)
+        const int n_thr = (int)std::max(1u, std::min({ std::thread::hardware_concurrency(), 16u, (unsigned)((n_utt + 15) / 16) }));
+        auto work = [&](int t) {
+            for (int u = t; u < n_utt; u += n_thr) {
+                const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
+                const int32_t *cu = cols.data() + (size_t)u * max_nb;
+                ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
+            }
+        };
+        if (n_thr <= 1) work(0);
+        else {
+            std::vector<std::thread> thr;
+            for (int t = 0; t < n_thr; ++t) thr.emplace_back(work, t);
+            for (auto &t : thr) t.join();
+        }
+    }
     for (int u = 0; u < n_utt; ++u) {
-        const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
-        const int32_t *cu = cols.data() + (size_t)u * max_nb;
-        ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
+        const int nfr = res1[(size_t)u * 8 + 2];
         const size_t C = (size_t)d.n1 + voc[u].n_chan, nwd = voc[u].wid.size(), cap = nwd + n_tail + 1;
         for (size_t k = 0; k < nwd; ++k)
             PSGPU_REQUIRE(voc[u].len[k] < 1024, "psgpu_fwdflat_search: a word chain of %d channels (FfUtt::einfo holds 10 bits)", voc[u].len[k]);
@@ -1585,6 +1614,11 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 13; ++i) acc[i] += (double)h[(size_t)u * 16 + i]; }
         for (int i = 0; i < 13; ++i) tot += acc[i];
         fprintf(stderr, "fwdflat_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
+        {
+            double ov = 0, ne = 0, o256 = 0;
+            for (int u = 0; u < n_utt; ++u) { ov += (double)h[(size_t)u * 16 + 13]; ne += (double)h[(size_t)u * 16 + 14]; o256 += (double)h[(size_t)u * 16 + 15]; }
+            fprintf(stderr, "  exits queued per frame %.1f; frames whose exits exceed the LDS queue: %.1f %% (more than 256: %.1f %%)\n", ne / (frames > 0 ? frames : 1), 100.0 * ov / (frames > 0 ? frames : 1), 100.0 * o256 / (frames > 0 ? frames : 1));
+        }
         for (int i = 0; i < 13; ++i)
             fprintf(stderr, "  %2d %-60s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
     }
