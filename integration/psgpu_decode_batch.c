@@ -223,12 +223,13 @@ psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
     if ((flags & PSGPU_BATCH_DEVICE_FIRST_PASS) && !(flags & PSGPU_BATCH_CPU_ONLY)) {
         /* the pipeline reads the search tables out of worker 0's decoder; results are injected into that decoder one
          * utterance at a time (the read-out is a table walk: one host thread is plenty) */
-        if (ps_config_bool(ps_get_config(b->ps[0]), "fwdflat")) {
-            /* (refused here, at initialisation, not at the first decode: the batch entry injects pass 1's table and lets the
-             *  reference's read-out / -bestpath run on it; its second pass needs the utterance's feature vectors in acmod,
-             *  which this path -- front end on the device -- never fills) */
-            E_ERROR("PSGPU_BATCH_DEVICE_FIRST_PASS runs the first pass only: configure -fwdflat no (-bestpath yes is served from the "
-                    "injected table), or bind the device search behind ps_decode_raw (psgpu_device_search_attach), which runs the "
+        if (ps_config_bool(ps_get_config(b->ps[0]), "fwdflat")
+            && !(getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS")))) {
+            /* (refused here, at initialisation, not at the first decode: the reference's own second pass wants the utterance's
+             *  feature vectors in acmod, which this path -- front end on the device -- never fills; with the device second pass
+             *  both passes of the batch run on the device and the second pass's tables are injected) */
+            E_ERROR("PSGPU_BATCH_DEVICE_FIRST_PASS with -fwdflat yes needs PSGPU_DEVICE_SECOND_PASS=1 (both passes on the device), or "
+                    "-fwdflat no, or the device search bound behind ps_decode_raw (psgpu_device_search_attach), which runs the "
                     "reference's second pass after the device's first\n");
             goto fail;
         }

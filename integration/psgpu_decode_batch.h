@@ -20,9 +20,12 @@ extern "C" {
                                           * features, scores, phone loop, lexicon-tree search (psgpu_device_decode.h); the
                                           * workers only read the results out (ps_get_hyp / ps_seg_iter on the injected
                                           * tables; with -bestpath yes the reference's lattice pass runs on them on the
-                                          * worker's host thread).  Needs -fwdflat no: psgpu_batch_init refuses the flag
-                                          * otherwise (the reference's second pass wants the utterance's feature vectors in
-                                          * acmod; behind ps_decode_raw -- psgpu_device_search_attach -- it has them) */
+                                          * worker's host thread).  With -fwdflat yes the environment must say
+                                          * PSGPU_DEVICE_SECOND_PASS=1: the flat-lexicon pass of the batch then runs on the device
+                                          * too (psgpu_decode_second_pass) and ITS tables are injected; otherwise
+                                          * psgpu_batch_init refuses the flag (the reference's own second pass wants the
+                                          * utterance's feature vectors in acmod; behind ps_decode_raw --
+                                          * psgpu_device_search_attach -- it has them) */
 
 typedef struct psgpu_batch_seg_s {
     char *word;

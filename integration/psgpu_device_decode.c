@@ -471,68 +471,18 @@ fetch_and_inject(psgpu_device_decode_t *d, int u)
     return nfr;
 }
 
-/* ---- the second pass on the device (one utterance): the flat-lexicon search over the first pass's device-resident
- *      table, scoring its own senones from the feature rows; its scorer state starts from the lists pass 1 left in
- *      history slot n_fast_hist - 1 (ptm_mgau.c:425-441), i.e. the batch scorer's lists (chain-major
- *      [n_chain][T][topn]) of the last frame ts with ts % H == H - 1 */
+/* ---- the second pass on the device: psgpu_decode_second_pass -- the flat-lexicon search over the first pass's device-resident
+ *      tables for every utterance of the latest call, scoring its own senones from the call's feature rows, seeded from the lists
+ *      pass 1 left in the scorer's history slot n_fast_hist - 1 (ptm_mgau.c:425-441); the pipeline's fetch entry points then return
+ *      the second pass's records and tables */
 static int
-second_pass_one(psgpu_device_decode_t *d, int T)
+second_pass_batch(psgpu_device_decode_t *d)
 {
-    ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
-    psgpu_decode_view_t v;
-    void *st = psgpu_hmm_ctx_stream(d->ctx);
-    int32_t res[8];
-    const uint8_t *open_flags = NULL;
-    int H = d->n_fast_hist, ts = T - 1, c, i, nb, nh, nfr;
-    size_t ne = (size_t)d->n_chain * T * d->topn;
-
-    if (psgpu_decode_view(d->dec, &v) != PSGPU_OK || v.n_utt != 1) return -1;
-    if (T > d->cap_t2 || v.bp_cap > d->bp_cap2 || v.bss_cap > d->bss_cap2) {
-        size_t t = (size_t)T + T / 2 + 64;
-        FREE_DEV(d->d_bp2); FREE_DEV(d->d_bss2); FREE_DEV(d->d_idx2); FREE_DEV(d->d_step2); FREE_DEV(d->d_res2);
-        d->cap_t2 = 0;
-        if (psgpu_malloc((void **)&d->d_bp2, 4 * (size_t)10 * v.bp_cap) || psgpu_malloc((void **)&d->d_bss2, 4 * (size_t)v.bss_cap)
-            || psgpu_malloc((void **)&d->d_idx2, 4 * (t + 2)) || psgpu_malloc((void **)&d->d_step2, 4 * t * 4)
-            || psgpu_malloc((void **)&d->d_res2, 32)) {
-            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-            return -1;
-        }
-        d->cap_t2 = (int)t; d->bp_cap2 = v.bp_cap; d->bss_cap2 = v.bss_cap;
-    }
-    if (ne > d->cap_tcw) { FREE_HOST(d->h_tcw); d->cap_tcw = ne + ne / 2 + 64; d->h_tcw = ckd_calloc(d->cap_tcw, 1); }
-    while (ts >= 0 && ts % H != H - 1) --ts;
-    if (psgpu_memcpy_d2h(d->h_tcw, v.topn_cw_dev, ne, st) || psgpu_stream_sync(st)) {
+    if (psgpu_decode_second_pass(d->dec, d->ff, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
-    for (c = 0; c < d->n_chain; ++c)
-        for (i = 0; i < d->topn; ++i)      /* a shorter utterance than H frames never wrote that slot: ptm_mgau_init's i-th codeword */
-            d->h_seed[c * d->topn + i] = ts >= 0 ? d->h_tcw[((size_t)c * T + ts) * d->topn + i] : i;
-    if (psgpu_memcpy_h2d(d->d_seed, d->h_seed, 4 * (size_t)d->n_chain * d->topn, st)
-        /* (the first pass's lists ride along: where an entry is not open, the second pass's scan of a touched codebook
-         *  arrives at exactly that list -- psgpu_fwdflat_search_feats_lists_dev) */
-        || psgpu_ptm_batch_open_flags(psgpu_mgau_ptm_model(ps_search_acmod(d->ps->search)->mgau), st, &open_flags)
-        || psgpu_fwdflat_search_feats_lists_dev(d->ff, &d->view, v.feat_dev, d->d_seed, v.topn_score_dev, v.topn_cw_dev, open_flags, T,
-                                                v.frame_off_dev, 1, T, v.bp_cap, v.bp_dev, v.result_dev,
-                                                v.w1_ssid_dev, d->bp_cap2, d->bss_cap2, d->d_bp2, d->d_bss2, d->d_idx2, d->d_step2, d->d_res2, st)
-        || psgpu_memcpy_d2h(res, d->d_res2, sizeof res, st) || psgpu_stream_sync(st)) {
-        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-        return -1;
-    }
-    if (res[3]) { E_ERROR("psgpu device decode: second pass: back-pointer table or score stack full\n"); return -1; }
-    nb = res[0]; nh = res[1]; nfr = res[2];
-    if ((size_t)nb * 10 > d->cap_bp) { FREE_HOST(d->h_bp); d->cap_bp = (size_t)nb * 15 + 640; d->h_bp = ckd_calloc(d->cap_bp, 4); }
-    if ((size_t)nh > d->cap_bss) { FREE_HOST(d->h_bss); d->cap_bss = (size_t)nh + nh / 2 + 64; d->h_bss = ckd_calloc(d->cap_bss, 4); }
-    if ((size_t)nfr + 1 > d->cap_idx) { FREE_HOST(d->h_idx); d->cap_idx = (size_t)nfr + nfr / 2 + 64; d->h_idx = ckd_calloc(d->cap_idx, 4); }
-    for (i = 0; i < 10 && nb; ++i)
-        if (psgpu_memcpy_d2h(d->h_bp + (size_t)i * nb, d->d_bp2 + (size_t)i * d->bp_cap2, 4 * (size_t)nb, st)) return -1;
-    if ((nh && psgpu_memcpy_d2h(d->h_bss, d->d_bss2, 4 * (size_t)nh, st)) || psgpu_memcpy_d2h(d->h_idx, d->d_idx2, 4 * ((size_t)nfr + 1), st)
-        || psgpu_stream_sync(st)) {
-        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-        return -1;
-    }
-    inject(ngs, d->n_ci, d->h_bp, nb, d->h_bss, nh, d->h_idx, nfr, res[4]);
-    return nfr;
+    return 0;
 }
 
 int
@@ -560,8 +510,8 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
     if (fetch_summary(d, 1) < 0) return -1;
     if (d->h_res[3]) { E_ERROR("psgpu device decode: back-pointer table or score stack full\n"); return -1; }
     if (d->h_res[2] == 0) return 0;
-    if (d->ff) nfr = second_pass_one(d, d->h_res[2]);
-    else nfr = fetch_and_inject(d, 0);
+    if (d->ff && (second_pass_batch(d) < 0 || fetch_summary(d, 1) < 0)) return -1;
+    nfr = fetch_and_inject(d, 0);
     return nfr;
 }
 
@@ -569,10 +519,9 @@ int
 psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[], const size_t n[], int B)
 {
     if (d == NULL || B < 0 || (B > 0 && (!pcm || !n))) return -1;
-    if (d->ff) { E_ERROR("psgpu device decode: the device second pass takes one utterance per call (psgpu_device_decode_utt)\n"); return -1; }
-    if (((ngram_search_t *)d->ps->search)->fwdflat) {
-        E_ERROR("psgpu device decode: the batch entry runs pass 1 (-fwdflat no; -bestpath yes searches the injected table per "
-                "utterance); for the reference's second pass use psgpu_device_search_attach + ps_decode_raw\n");
+    if (((ngram_search_t *)d->ps->search)->fwdflat && !d->ff) {
+        E_ERROR("psgpu device decode: -fwdflat yes needs the device second pass (PSGPU_DEVICE_SECOND_PASS=1 at attach: both passes of "
+                "the batch then run on the device), or -fwdflat no\n");
         return -1;
     }
     if (refresh(d) < 0) return -1;
@@ -581,6 +530,7 @@ psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[]
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
+    if (d->ff && B > 0 && second_pass_batch(d) < 0) return -1;       /* (-fwdflat yes: the tables injected below are the second pass's) */
     return fetch_summary(d, B);
 }
 

@@ -577,6 +577,34 @@ def test_decode_batch_api_device_first_pass(workers, extra, reps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workers,extra,reps", [
+    (1, ("fwdflat", "yes", "bestpath", "no"), 1),
+    (2, (), 4),                                            # the reference's defaults: its lattice pass on the host over the injected table
+])
+def test_decode_batch_api_device_both_passes(workers, extra, reps, monkeypatch):
+    """PSGPU_BATCH_DEVICE_FIRST_PASS with -fwdflat yes and PSGPU_DEVICE_SECOND_PASS=1: BOTH search passes of the whole batch on the
+    device (psgpu_decode_first_pass + psgpu_decode_second_pass), the second pass's tables injected into the worker's decoder,
+    ps_get_hyp / ps_seg_iter (and -bestpath yes) the reference's own.  Every result equals a fresh unmodified CPU decoder's."""
+    monkeypatch.setenv("PSGPU_DEVICE_SECOND_PASS", "1")
+    r = _batch_api(workers, 16, FILES * reps, *extra)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["B"] == len(FILES) * reps and r["mismatch_batch"] == r["mismatch_reversed"] == r["mismatch_single"] == 0
+    assert r["hyps"][0] == "go forward ten meters"
+
+
+@pytest.mark.gpu
+def test_decode_batch_api_device_first_pass_refuses_the_second_pass_on_the_host():
+    """without PSGPU_DEVICE_SECOND_PASS the combination is refused at psgpu_batch_init (exit code 3 of the harness: the reference's
+    own second pass would find no feature vectors in acmod), not at the first decode"""
+    binary = os.path.join(REF, "batch_api_check")
+    env = {k: v for k, v in os.environ.items() if k != "PSGPU_DEVICE_SECOND_PASS"}
+    p = subprocess.run([binary, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"), "1", "16",
+                        os.path.join(DATA, "goforward.raw"), "--", "fwdflat", "yes", "bestpath", "no"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 3, (p.returncode, p.stdout, p.stderr[-500:])
+
+
+@pytest.mark.gpu
 def test_dropin_device_first_pass_refuses_other_setups():
     """attach fails loudly (exit code 3 of the harness) when the decoder is not a pass-1-only n-gram setup."""
     argv = [BIN, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"),
