@@ -216,7 +216,7 @@ __device__ __forceinline__ int32_t ff_lm(const FfDev &p, int w3, int w2, int w1)
     return p.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
 // set_real_wid, ngram_search.c:341-372
-__device__ void ff_set_real_wid(const FfDev &p, FfUtt &u, int bp)
+__device__ __forceinline__ void ff_set_real_wid(const FfDev &p, FfUtt &u, int bp)
 {
     const int prev = FBP(u, F_BP, bp), wid = FBP(u, F_WID, bp);
     if (p.d_filler[wid]) {
@@ -229,7 +229,7 @@ __device__ void ff_set_real_wid(const FfDev &p, FfUtt &u, int bp)
     }
 }
 // ngram_search_save_bp, ngram_search.c:376-498, with the position of a new entry (bpidx, bss_head) given by the caller
-__device__ void ff_save_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score,
+__device__ __forceinline__ void ff_save_bp(const FfDev &p, FfUtt &u, int32_t bpidx, int32_t bss_head, int frame, int w, int32_t score,
                            int32_t path, int rc)
 {
     const int bp = u.word_lat_idx[w];
@@ -866,7 +866,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             int32_t b = kW;
             // (one instantiation per pairing of score row and transition matrices: LDS / device memory -- the address space is the
             // compiler's to infer from the argument)
-            auto eval_all = [&](const int16_t *row, const uint8_t *tp_all) {
+            auto eval_all = [&](const int16_t *row, const uint8_t *tp_all) __attribute__((always_inline)) {
             for (int i = tid; i < n_eval; i += kFfThreads) {
                 const int e = i < FF_EL_CAP ? s_el[i][0] : u.elist[i];
                 const int c = e & kFfChanMask;
