@@ -406,7 +406,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
-    __shared__ long long s_prof[16], s_last;
+    __shared__ long long s_prof[16], s_last, s_t5;
+    __shared__ int s_over;
     if (tid == 0) { for (int i = 0; i < 16; ++i) s_prof[i] = 0; s_last = clock64(); }
 #endif
     FfUtt u;
@@ -972,7 +973,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      and stack entries precede it from the sorted queue and then walks its group -- everything but the table itself in LDS.
         const int n_exq = s_nex;
 #ifdef PSGPU_FT_PROFILE
-        if (tid == 0) { s_prof[13] += n_exq > FF_EXIT_CAP ? 1 : 0; s_prof[14] += n_exq; s_prof[15] += n_exq > 256 ? 1 : 0; }
+        if (tid == 0) { s_prof[13] += n_exq > FF_EXIT_CAP ? 1 : 0; s_prof[14] += n_exq; s_over = n_exq > FF_EXIT_CAP; s_t5 = clock64(); }
 #endif
         if (s_nex == 0) { }                                  // (a frame without exits: nothing to write, no barrier to meet)
         else if (s_nex <= FF_EXIT_CAP) {
@@ -1268,6 +1269,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         }
         __syncthreads();
         FF_PROF(7);
+#ifdef PSGPU_FT_PROFILE
+        if (tid == 0 && s_over) s_prof[15] += clock64() - s_t5;      // cycles from the pruning's decisions to the frame's end, frames whose exits overflow the queue
+#endif
     }
 #ifdef PSGPU_FT_PROFILE
     if (tid == 0 && bf.prof) for (int i = 0; i < 16; ++i) bf.prof[(size_t)blockIdx.x * 16 + i] = s_prof[i];
@@ -1617,7 +1621,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         {
             double ov = 0, ne = 0, o256 = 0;
             for (int u = 0; u < n_utt; ++u) { ov += (double)h[(size_t)u * 16 + 13]; ne += (double)h[(size_t)u * 16 + 14]; o256 += (double)h[(size_t)u * 16 + 15]; }
-            fprintf(stderr, "  exits queued per frame %.1f; frames whose exits exceed the LDS queue: %.1f %% (more than 256: %.1f %%)\n", ne / (frames > 0 ? frames : 1), 100.0 * ov / (frames > 0 ? frames : 1), 100.0 * o256 / (frames > 0 ? frames : 1));
+            fprintf(stderr, "  exits queued per frame %.1f; frames whose exits exceed the LDS queue: %.1f %%, cycles from their decisions to their end: %.0f each\n", ne / (frames > 0 ? frames : 1), 100.0 * ov / (frames > 0 ? frames : 1), o256 / (ov > 0 ? ov : 1));
         }
         for (int i = 0; i < 13; ++i)
             fprintf(stderr, "  %2d %-60s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
