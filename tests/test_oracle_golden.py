@@ -262,3 +262,48 @@ def test_fe_plus_dynfeat_oracle_reproduces_decoder_features():
     L.pso_dynfeat_1s_c_d_dd.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.pso_dynfeat_1s_c_d_dd(cep.ctypes.data, cep.shape[0], cep.shape[1], out.ctypes.data)
     assert out.tobytes() == np.ascontiguousarray(_load("ptm_goforward.npz")["feat"], np.float32).tobytes()
+
+
+def test_dither_sequence_is_one_mersenne_twister_stream(tmp_path):
+    """-dither yes (fe_sigproc.c:868-870, :898-901): every sample a frame reads in gets (s3_rand_int31() % 4 == 0) added in int16
+    arithmetic -- s3_rand_int31 = MT19937's genrand_int32() >> 1, seeded once by fe_init_dither(-seed) with init_genrand(seed &
+    0xffffffff) -- the stream running on from one utterance to the next.  A full frame reads frame_size (the first) or frame_shift
+    NEW samples; the tail frame of fe_end_utt (fe_interface.c:529-546) reads the whole overflow buffer -- the last frame_size -
+    frame_shift samples over again, from the UNdithered copies kept there, plus what was left -- and draws for all of them anew.
+    Pinned here: the oracle front end on PCM dithered that way (numpy's legacy MT19937 seeding is init_genrand) equals the compiled
+    reference's cepstra of three runs over one fe_t, for -seed 17 and the default -1.  The device front end draws the same stream
+    (csrc/psgpu_fe.hip FeRand; tests/test_fe_gpu.py)."""
+    import os
+    import subprocess
+    import sys
+    exe = os.path.join(pso.REF_DIR, "ref_dump")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    from psgb import read_psgb
+    for seed in (17, -1):
+        out = os.path.join(str(tmp_path), "d%d.psgb" % (seed & 0xff))
+        subprocess.check_call([exe, "mfcc", out, os.path.join(pso.REF_DIR, "model", "an4_ci_cont"), "-", "-", os.path.join(pso.REF_DIR, "data", "goforward.raw"),
+                               "3", "--", "dither", "yes", "seed", str(seed), "remove_noise", "no"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL, timeout=300)
+        g = read_psgb(out)
+        rs = np.random.RandomState(seed & 0xffffffff)
+        fe = pso.OracleFe(g)
+        pcm = np.ascontiguousarray(g["pcm"], np.int16)
+        fs, sh = int(g["par"][0]), int(g["par"][1])
+        n_full = 1 + (pcm.size - fs) // sh
+        n_reg, tail0 = fs + (n_full - 1) * sh, n_full * sh
+
+        def draws(n):
+            raw = rs.randint(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)             # genrand_int32
+            return (((raw >> 1) & 3) == 0).astype(np.int32)
+        for key in ("cep", "cep1", "cep2"):
+            reg = pcm.astype(np.int32)
+            reg[:n_reg] += draws(n_reg)
+            tail = reg.copy()
+            tail[tail0:] = pcm[tail0:].astype(np.int32) + draws(pcm.size - tail0)
+            got = fe.process(reg.astype(np.int16))                                             # (wraps like the int16 +=)
+            got[-1] = fe.process(tail.astype(np.int16))[-1]
+            ref = np.ascontiguousarray(g[key], np.float32)
+            assert got.shape == ref.shape and got.shape[0] == n_full + 1
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (seed, key)
