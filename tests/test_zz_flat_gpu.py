@@ -288,6 +288,9 @@ def test_pipeline_object_runs_both_passes(tmp_path):
     hn1, hn = check(list(range(20)), 6.0)
     assert any(int(hn1[u, 1]) != int(hn[u, 1]) for u in range(20))       # (the two passes' path scores differ: it did run)
     check([31, 7], 9.0)
+    p.score_mode(True)                                    # (the first pass scoring from lists: no score rows in the object at all)
+    check([40, 41, 42], 6.0)
+    p.score_mode(False)
     p.close()
     p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), pso.load_tables(), st, gt["par"], gt)
     p.table_capacity(1, 1, True)                          # a new object whose tables are too small for either pass: both grow
