@@ -35,6 +35,27 @@ check_flat(s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["f
                     topn_seed=g["flat_ptm_seed"], **caps(g))[0], g, "numbers")
 print("flat search scoring its own senones clean")
 
+# the second pass with the batch scorer's lists at hand (lazy lists, open entries by a wavefront) and with its LDS queues cut
+# down to almost nothing (every frame through the slab fall-backs)
+import ctypes  # noqa: E402
+from test_flat_hostsim import _all_density_lists  # noqa: E402
+t = pso.load_tables()
+g, st, fst = load_flat("goforward")
+lists = _all_density_lists(t, g["flat_feat"])
+lists = (lists[0], lists[1], lists[2] | (__import__("numpy").random.default_rng(3).random(lists[2].shape) < 0.3).astype("uint8"))
+s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
+check_flat(s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=t, topn_seed=g["flat_ptm_seed"],
+                    lists=lists, **caps(g))[0], g, "goforward, lists")
+print("flat search taking the batch scorer's lists clean")
+for name, val in (("psgpu_sim_ff_exit_cap", 1), ("psgpu_sim_ff_el_cap", 3), ("psgpu_sim_ff_awl_regs", 0)):
+    knob = ctypes.c_int.in_dll(simlib.lib(), name)
+    old = knob.value
+    knob.value = val
+    check_flat(s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=t, topn_seed=g["flat_ptm_seed"],
+                        lists=lists, **caps(g))[0], g, "goforward, lists, %s" % name)
+    knob.value = old
+    print("flat search with", name, "=", val, "clean")
+
 # tables too small: the kernels must stop with status 1 and stay inside the buffers
 g = _load("fwdtree_trace_numbers.npz")
 st = _load("fwdtree_static_en_us_turtle.npz")
