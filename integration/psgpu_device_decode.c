@@ -69,8 +69,7 @@ struct psgpu_device_decode_s {
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
     psgpu_ptm_view_t view;
-    int n_fast_hist, n1, n_emit, cap_t2, bp_cap2, bss_cap2;
-    int32_t *d_seed, *d_bp2, *d_bss2, *d_idx2, *d_step2, *d_res2, *h_seed;
+    int n_fast_hist, n1, n_emit;
     uint8_t *h_tcw; size_t cap_tcw;
 };
 
@@ -306,8 +305,6 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         if (i == PSGPU_OK && d->lm) i = psgpu_fwdflat_set_lm(d->ff, d->lm);
         d->n_fast_hist = ps->pl_window + 2;               /* ptm_mgau.c:884 */
         d->n1 = ngs->n_1ph_words; d->n_emit = n_emit;
-        if (i == PSGPU_OK && psgpu_malloc((void **)&d->d_seed, 4 * (size_t)d->n_chain * d->topn + 4)) i = PSGPU_ENOMEM;
-        d->h_seed = ckd_calloc((size_t)d->n_chain * d->topn + 1, 4);
         ckd_free(off); ckd_free(pci); ckd_free(pss); ckd_free(cis); ckd_free(known);
     }
     if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, n_tmat, tp, n_sseq, sq, d->n_sen);
@@ -364,8 +361,7 @@ psgpu_device_decode_detach(psgpu_device_decode_t *d)
     if (!d) return;
     psgpu_device_search_detach(d);
     psgpu_decode_free(d->dec);
-    psgpu_fwdflat_free(d->ff); FREE_DEV(d->d_seed); FREE_DEV(d->d_bp2); FREE_DEV(d->d_bss2); FREE_DEV(d->d_idx2); FREE_DEV(d->d_step2);
-    FREE_DEV(d->d_res2); FREE_HOST(d->h_seed); FREE_HOST(d->h_tcw);
+    psgpu_fwdflat_free(d->ff); FREE_HOST(d->h_tcw);
     psgpu_fwdtree_free(d->ft); psgpu_lm_free(d->lm); psgpu_hmm_ctx_free(d->ctx); psgpu_fe_free(d->fe);
     FREE_HOST(d->h_res); FREE_HOST(d->h_hn); FREE_HOST(d->h_bp); FREE_HOST(d->h_bss); FREE_HOST(d->h_idx); FREE_HOST(d->h_feat);
     ckd_free(d);

@@ -111,7 +111,7 @@ struct FfUtt {
     int32_t *wchain, *wlen, *wrcs;       // [n_w] chain offset (channel index) or -1, chain length, right-context channels (0: single phone)
     int32_t *word_active, *word_lat_idx; // [n_w] (word_active: frame stamp)
     int32_t *awl[2];                     // [awl_cap][3] the active words: word, first channel, channels | right contexts << 10 | single phone << 20
-    int32_t *cnt_a, *cnt_b, *cnt_c;      // [max(awl_cap, nwd + fillers) + 1] scan scratch
+    int32_t *cnt_a, *cnt_b;              // [awl_cap + 1] scan scratch of the exits' slab path
     int32_t *bp, *bss, *bp_table_idx, *step, *result;
     const int32_t *w1_ssid_in;           // [n1][n_emit] or NULL
     int16_t *nrow; int32_t *nrow32;      // [n_sen] the frame's scores (scoring mode)
@@ -122,7 +122,7 @@ struct FfUtt {
 // kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
 // wait counters); pointers formed from a kernel argument are global.
 #define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(einfo) X(wchain) \
-    X(wlen) X(wrcs) X(wseen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b) X(cnt_c)
+    X(wlen) X(wrcs) X(wseen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b)
 #define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf) X(fr_off) X(fr_words)
 struct FfOff {
 #define X(f) int64_t f;
@@ -1512,7 +1512,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         for (size_t k = 0; k < nwd; ++k)
             PSGPU_REQUIRE(voc[u].len[k] < 1024, "psgpu_fwdflat_search: a word chain of %d channels (FfUtt::einfo holds 10 bits)", voc[u].len[k]);
         PSGPU_REQUIRE(cap < (1u << 21), "psgpu_fwdflat_search: %zu active words (FfUtt::einfo holds 21 bits)", cap);
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + (nwd + 1) + 6 * cap + 3 * (cap + 1) + 16
+        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + (nwd + 1) + 6 * cap + 2 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + 2 * voc[u].node_sf.size() + (size_t)nfr + 2 + 4;
     }
@@ -1543,7 +1543,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C); u.einfo = take(C);
         u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.wrcs = take(d.n_w); u.wseen = take(nwd + 1); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
         u.awl[0] = take(3 * cap); u.awl[1] = take(3 * cap);
-        u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1); u.cnt_c = take(cap + 1);
+        u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1);
         u.nrow32 = raw ? take(d.n_sen) : nullptr;
         u.nrow = raw ? reinterpret_cast<int16_t *>(take((size_t)d.n_sen / 2 + 1)) : nullptr;
         FfOff &o = ho[i];
