@@ -16,9 +16,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not installed")
 
 
-def usage(src, tmp_path):
-    p = subprocess.run([HIPCC] + FLAGS + ["-fPIC", "-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "x.o"),
-                        os.path.join(ROOT, "pocketsphinx_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
+def usage(src, tmp_path, asm=None):
+    """resource usage of every kernel of `src` (the compiler's remarks); asm: also leave the device assembly at that path -- ONE
+    compilation serves both (the files take ~20 s each)"""
+    out_args = ["--cuda-device-only", "-S", "-o", str(asm)] if asm else ["-fPIC", "-c", "-o", str(tmp_path / "x.o")]
+    p = subprocess.run([HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + out_args +
+                       [os.path.join(ROOT, "pocketsphinx_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     out, cur = {}, None
     for line in p.stderr.splitlines():
@@ -33,7 +36,8 @@ def usage(src, tmp_path):
 
 
 def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
-    u = usage("psgpu_search.hip", tmp_path)
+    s = tmp_path / "search.s"
+    u = usage("psgpu_search.hip", tmp_path, asm=s)
     k = {n: v for n, v in u.items() if "fwdtree_kernel" in n}
     assert len(k) == 8, sorted(k)             # {3, 5 states} x {LDS layout reading rows, LDS layout scoring from lists, slab with 256 work-items, slab with 1024}
     for n, v in k.items():
@@ -58,10 +62,6 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
         assert v["LDS"] <= 64 * 1024, (n, v)
     # every pointer of the kernel is either derived from its LDS pool or declared global (psgpu_as_global): no access may be
     # left generic (flat_*: waits on both memory counters), and the 256-work-item forms keep nothing in scratch memory
-    s = tmp_path / "search.s"
-    p = subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-S", "-o", str(s), os.path.join(ROOT, "pocketsphinx_amd", "csrc", "psgpu_search.hip")],
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-2000:]
     txt = s.read_text()
     names = re.findall(r"\n(_Z14fwdtree_kernel\w+):", txt)
     assert len(names) == 8
@@ -75,7 +75,8 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
 
 
 def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):
-    u = usage("psgpu_flat.hip", tmp_path)
+    s = tmp_path / "flat.s"
+    u = usage("psgpu_flat.hip", tmp_path, asm=s)
     k = {n: v for n, v in u.items() if "fwdflat_kernel" in n}
     assert len(k) == 4, sorted(k)
     for n, v in k.items():
@@ -83,10 +84,6 @@ def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):
         # static records and the batch scorer's list entry of the frame in registers -- 200+ VGPRs -- and ~54 KB + the score row in LDS)
         assert v["Occupancy"] >= 2 and v["Spill"] == 0, (n, v)
     # the per-utterance state is addressed from kernel-argument buffers: its accesses must be provably global
-    s = tmp_path / "flat.s"
-    p = subprocess.run([HIPCC] + FLAGS + ["--cuda-device-only", "-S", "-o", str(s), os.path.join(ROOT, "pocketsphinx_amd", "csrc", "psgpu_flat.hip")],
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-2000:]
     txt = s.read_text()
     for n in re.findall(r"\n(_Z14fwdflat_kernel\w+):", txt):
         body = txt[txt.index("\n" + n + ":"):txt.index(".Lfunc_end", txt.index("\n" + n + ":"))]
