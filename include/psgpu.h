@@ -809,7 +809,8 @@ int psgpu_decode_table_capacity(psgpu_decode_t *d, int32_t bp_per_frame, int32_t
 int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag);
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
- * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array. */
+ * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array.  After
+ * psgpu_decode_second_pass: the second pass's tables (with the result records psgpu_decode_fetch_hyps returns then). */
 int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp,
                               int32_t *bss, int32_t *idx, void *stream);
 
