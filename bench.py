@@ -674,6 +674,8 @@ def main():
                              "a constant of the repository, not a measurement of this run"},
     }
     # ---- cpu_baseline + parity: the compiled reference on a sample of the same utterances
+    if world > 1:
+        line["cpu_baseline"] = None                      # (the reference leg runs at N = 1 only: BENCH, not SCALE)
     if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: the scaling runs time the device path alone)
         ids = sorted(set(int(i) for i in np.linspace(0, B - 1, min(N_SAMPLE, B))))
         n_proc = max(1, min(len(ids), (os.cpu_count() or 2) // 2))
