@@ -46,7 +46,10 @@ B_UTT, UTT_SECONDS = 512, 30.0
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_GOPS = 78643.2         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (non-FMA fp32 op rate)
 N_SAMPLE = 64                    # utterances decoded by the reference for cpu_baseline + parity
-LV_UTT, LV_CHECK, LV_STEPS = 256, 8, 2     # the large-vocabulary leg: utterances per step, utterances the reference decodes, timed steps
+LEG_CHECK = 32                   # ... on the other decode legs (two passes, multi-stream scorer, large vocabulary)
+# the compiled reference (test infrastructure): what this file does with it is time it (cpu_baseline) and compare with it (parity)
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+LV_UTT, LV_CHECK, LV_STEPS = 256, 32, 2    # the large-vocabulary leg: utterances per step, utterances the reference decodes, timed steps
 
 
 def _npz(name):
@@ -89,7 +92,7 @@ def reference_decode(pcm, n_samples, ids, lm="turtle.lm.bin", dic="turtle.dic", 
     absent.  procs > 1: that many reference processes side by side, each one thread decoding its share of the utterances
     (pocketsphinx_batch's way to use a machine: one decoder per core, programs/pocketsphinx_batch.c) -- totals then carry
     the wall time of the slowest process as well"""
-    ref = os.path.join(ROOT, "oracle", "_ref")
+    ref = REF_DIR
     exe = os.path.join(ref, "ref_decode_bench")
     if not os.path.exists(exe):
         return None
@@ -137,17 +140,18 @@ def parity_of(ids, utts, hn, hyp, res):
     return bad
 
 
-def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_utt, steps, n_check, with_cpu):
+def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_utt, steps, n_check, with_cpu, table_dir=None):
     """The large-vocabulary decode (the stand-in for configs[2]'s absent en-us.lm.bin): the first
     n_utt of the headline's utterances through the same device pipeline with the 134,865-word dictionary and the synthetic
     126k-unigram LM (trie on the device) -- PCM -> hypotheses -- timed; the reference decodes n_check of them with the same LM
     and dictionary: cpu_baseline + per-utterance parity."""
     import torch
     from pocketsphinx_amd import largevocab as lv
-    if not lv.available():
-        return {"skipped": "oracle/_ref (ref_dump, big.arpa, cmudict-en-us.dict) not built"}
+    tpath = lv.table_path(directory=table_dir)
+    if not lv.available(tpath):
+        return {"skipped": "table file %s not found (integration/psgpu_export_tables; `make -C integration tables`, or --tables DIR)" % tpath}
     t0 = time.perf_counter()
-    g = lv.tables()
+    g = lv.tables(tpath)
     t_tab = time.perf_counter() - t0
     pipe = lv.pipeline(g, fe_tables, ptm_tables)
     pipe.stage_timing(True)
@@ -176,9 +180,9 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
     search_s = st_mean["search"] * 1e-3
     par = g["par"]
     traffic = None
-    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*largevocab*_pmc_traffic.json")), reverse=True):
+    for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*largevocab*_pmc_traffic.json")), reverse=True):
         try:       # the newest committed PMC pass of THIS leg at THIS batch size (tools/gpu_call_lvpmc.sh)
-            jt = json.load(open(tpath))
+            jt = json.load(open(ppath))
             if jt.get("_workload", {}).get("leg") == "decode_large_vocab" and jt["_workload"].get("utterances") == n_utt \
                     and jt["_workload"].get("seconds") == seconds and jt.get("fwdtree_kernel", {}).get("hbm_bytes_per_launch"):
                 traffic = round(jt["fwdtree_kernel"]["hbm_bytes_per_launch"])
@@ -207,7 +211,7 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
                              "COMMITTED PMC pass of this leg at this batch size (profiles/*largevocab*_pmc_traffic.json, "
                              "tools/gpu_call_lvpmc.sh): a constant of the repository, not a measurement of this run; traffic / "
                              "kernel time = the rate the memory system actually sustains"},
-        "tables_from_reference_init_s": round(t_tab, 1),
+        "table_file": os.path.relpath(tpath, ROOT), "table_file_read_s": round(t_tab, 2),
     }
     if n_bad_status:
         out["error"] = "%d utterances ended with status != 0" % n_bad_status
@@ -396,11 +400,13 @@ def child_extras(out):
     sb = os.path.join(ROOT, "tools", "search_bench.py")
     child("search_only_turtle", [sb], {"SB_CASE": "goforward", "SB_BATCHES": "512,1024", "SB_REPS": "2"}, 100)
     child("search_only_medium", [sb], {"SB_CASE": "medium_goforward", "SB_BATCHES": "512", "SB_REPS": "2"}, 100)
-    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
-        # the full cmudict task (134,865 words): single-thread reference ~1.2 k frames/s on this decode (profiles/r01i_*)
+    if os.path.exists(os.path.join(REF_DIR, "ref_dump")):
+        # the full cmudict task (134,865 words) on replicas of a recorded reference trace (its scores are the input, its tables the
+        # check): single-thread reference ~1.2 k frames/s on this decode (profiles/r01i_*)
         child("search_only_cmudict", [sb], {"SB_CASE": "cmudict", "SB_BATCHES": "1,32,256", "SB_REPS": "1"}, 200)
     child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 120)
-    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_dump")):
+    from pocketsphinx_amd import largevocab as lv
+    if lv.available(lv.table_path(directory=os.environ.get("PSGPU_TABLE_DIR"))):
         # configs[2]'s shape: ONE 60 s utterance, en-us PTM + the large LM / dictionary (en-us.lm.bin is not in the repository: big.arpa
         # + cmudict stand in), fwdtree AND fwdflat on the device, the reference's two-pass decode of the same PCM beside it
         child("decode_two_pass_large_vocab_60s", [os.path.join(ROOT, "tools", "two_pass_bench.py")],
@@ -436,9 +442,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (clean per-kernel profiles)")
     ap.add_argument("--no-large-vocab", action="store_true", help="leave the 134,865-word leg (decode_large_vocab) out")
     ap.add_argument("--large-vocab-utts", type=int, default=LV_UTT)
+    ap.add_argument("--tables", default=None, help="directory of table files written by integration/psgpu_export_tables (default: "
+                                                   "$PSGPU_TABLE_DIR, else integration/_tables): the large-vocabulary task's tables")
     ap.add_argument("--workload", choices=("headline", "large"), default="headline",
                     help="large: ONLY the large-vocabulary leg, printed as the line (for profiling that kernel alone)")
     args = ap.parse_args()
+    if args.tables:
+        os.environ["PSGPU_TABLE_DIR"] = os.path.abspath(args.tables)      # (the child-process extras read it too)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -469,7 +479,7 @@ def main():
             raise SystemExit("bench.py --workload large is a one-GPU measurement")
         nlv = min(args.large_vocab_utts, B)
         lvl = large_vocab_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables, nlv, max(args.steps, 1),
-                              LV_CHECK, not args.no_cpu_baseline)
+                              LV_CHECK, not args.no_cpu_baseline, args.tables)
         lvl.update({"n_gpus": 1, "warmup": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                     "dtype": "f32 (Gaussian distances) + int32 (log-domain scores, Viterbi)", "data": "synthetic (as the headline)"})
         emit(lvl)
@@ -712,18 +722,18 @@ def main():
         torch.cuda.empty_cache()
         try:
             line["decode_ms_scorer"] = ms_scorer_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"),
-                                                     _npz("fwdtree_static_en_us_turtle.npz"), gt, min(64, B), 2, 4, not args.no_cpu_baseline)
+                                                     _npz("fwdtree_static_en_us_turtle.npz"), gt, min(64, B), 2, LEG_CHECK, not args.no_cpu_baseline)
         except Exception as e:
             line["decode_ms_scorer"] = {"error": str(e)[-400:]}
         try:
             line["decode_two_pass"] = two_pass_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,
-                                                   _npz("fwdtree_static_en_us_turtle.npz"), gt, B, 2, 4, not args.no_cpu_baseline)
+                                                   _npz("fwdtree_static_en_us_turtle.npz"), gt, B, 2, LEG_CHECK, not args.no_cpu_baseline)
         except Exception as e:
             line["decode_two_pass"] = {"error": str(e)[-400:]}
         if not args.no_large_vocab:
             try:
                 line["decode_large_vocab"] = large_vocab_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,
-                                                             min(args.large_vocab_utts, B), LV_STEPS, LV_CHECK, not args.no_cpu_baseline)
+                                                             min(args.large_vocab_utts, B), LV_STEPS, LV_CHECK, not args.no_cpu_baseline, args.tables)
             except Exception as e:
                 line["decode_large_vocab"] = {"error": str(e)[-400:]}
         try:

@@ -44,6 +44,7 @@
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
 #include "psgpu_lm_tables.h"
+#include "psgpu_search_tables.h"
 #include "psgpu_device_decode.h"
 
 struct psgpu_device_decode_s {
@@ -93,32 +94,6 @@ find_attached(ps_search_t *search)
     return NULL;
 }
 
-static int
-number_nodes(chan_t *first, chan_t **nodes, int n)
-{
-    chan_t *h;
-    for (h = first; h; h = h->alt) { nodes[n++] = h; n = number_nodes(h->next, nodes, n); }
-    return n;
-}
-/* index of a tree channel in the flattened numbering: the pointers are sorted once (the tree of a large
- * dictionary has a quarter of a million channels) */
-typedef struct { chan_t *h; int idx; } node_ref_t;
-static int
-node_ref_cmp(const void *a, const void *b)
-{
-    const chan_t *x = ((const node_ref_t *)a)->h, *y = ((const node_ref_t *)b)->h;
-    return x < y ? -1 : x > y;
-}
-static int
-node_index(node_ref_t *refs, int n, chan_t *h, int base)
-{
-    node_ref_t key, *r;
-    if (h == NULL) return -1;
-    key.h = h; key.idx = 0;
-    r = bsearch(&key, refs, n, sizeof *refs, node_ref_cmp);
-    return r ? base + r->idx : -1;
-}
-
 psgpu_device_decode_t *
 psgpu_device_decode_attach(ps_decoder_t *ps)
 {
@@ -126,20 +101,14 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     ngram_search_t *ngs;
     acmod_t *acmod;
     bin_mdef_t *mdef;
-    dict_t *dict;
-    dict2pid_t *d2p;
     phone_loop_search_t *pls;
+    psgpu_search_tables_t *st;
     psgpu_fwdtree_tables_t t;
     psgpu_decode_config_t cfg;
     psgpu_ptm_model_t *model;
     struct psgpu_ms_model_s *msmodel;
-    chan_t **nodes;
-    node_ref_t *refs;
-    int n_ci, n_emit, n_w, R, M, N, n1, i, j, k, w, n_tmat, n_sseq, lm_ok, want_ff;
-    int32 par[32];
-    int32 *ci, *ci2, *ssid, *tm, *child, *sib, *pw, *sw, *sci, *sci2, *sss, *stm, *smpx;
-    int32 *pl, *p0, *pz, *py, *bw, *fl, *rn, *rs, *rm, *ld, *ptm, *lm;
-    uint8 *tp; uint16 *sq;
+    int n_ci, n_emit, n_w, i, j, k, lm_ok, want_ff;
+    int32 *lm;
     psgpu_fe_shim_t *fes;
     psgpu_lm_tables_t lt;
 
@@ -148,8 +117,8 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     ngs = (ngram_search_t *)ps->search;
     if (!ngs->fwdtree) { E_ERROR("psgpu device decode: needs -fwdtree yes (pass 1 is what runs on the device)\n"); return NULL; }
     want_ff = ngs->fwdflat && getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS"));
-    acmod = ps->acmod; mdef = acmod->mdef; dict = ps_search_dict(ngs); d2p = ps_search_dict2pid(ngs);
-    n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(dict);
+    acmod = ps->acmod; mdef = acmod->mdef;
+    n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(ps_search_dict(ngs));
     if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->compallsen || acmod->fcb->cmn != CMN_BATCH
         || acmod->fcb->agc != AGC_NONE || acmod->fcb->varnorm) {
         E_ERROR("psgpu device decode: needs the 1s_c_d_dd feature type with -cmn batch, no AGC / variance normalisation / LDA, "
@@ -170,69 +139,9 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     d->n_chain = model ? psgpu_ptm_n_chain(model) : 0; d->topn = model ? psgpu_ptm_topn(model) : 0;     /* (ms: no lists to carry) */
     d->cepsize = feat_cepsize(acmod->fcb); d->veclen = 3 * d->cepsize;
     d->n_words_at_attach = n_w; d->lmset_at_attach = ngs->lmset;
-    /* ---- the search tables (cf. oracle/ref_dump.c cmd_fwdtree, which writes the same arrays to a file) */
-    R = ngs->n_root_chan;
-    nodes = ckd_calloc(ngs->n_nonroot_chan + 16, sizeof *nodes);
-    for (M = 0, i = 0; i < R; ++i) M = number_nodes(ngs->root_chan[i].next, nodes, M);
-    N = R + M; n1 = ngs->n_1ph_words;
-    refs = ckd_calloc(M + 1, sizeof *refs);
-    for (i = 0; i < M; ++i) { refs[i].h = nodes[i]; refs[i].idx = i; }
-    qsort(refs, M, sizeof *refs, node_ref_cmp);
-    ci = ckd_calloc(N, 4); ci2 = ckd_calloc(N, 4); ssid = ckd_calloc(N, 4); tm = ckd_calloc(N, 4); child = ckd_calloc(N, 4);
-    sib = ckd_calloc(N, 4); pw = ckd_calloc(N, 4);
-    for (i = 0; i < R; ++i) {
-        root_chan_t *r = &ngs->root_chan[i];
-        ci[i] = r->ciphone; ci2[i] = r->ci2phone; ssid[i] = hmm_mpx_ssid(&r->hmm, 0); tm[i] = r->hmm.tmatid;
-        child[i] = node_index(refs, M, r->next, R); sib[i] = -1; pw[i] = r->penult_phn_wid;
-    }
-    for (i = 0; i < M; ++i) {
-        chan_t *h = nodes[i];
-        ci[R + i] = h->ciphone; ci2[R + i] = -1; ssid[R + i] = hmm_nonmpx_ssid(&h->hmm); tm[R + i] = h->hmm.tmatid;
-        child[R + i] = node_index(refs, M, h->next, R); sib[R + i] = node_index(refs, M, h->alt, R);
-        pw[R + i] = h->info.penult_phn_wid;
-    }
-    ckd_free(refs);
-    sw = ckd_calloc(n1 + 1, 4); sci = ckd_calloc(n1 + 1, 4); sci2 = ckd_calloc(n1 + 1, 4); sss = ckd_calloc(n1 + 1, 4);
-    stm = ckd_calloc(n1 + 1, 4); smpx = ckd_calloc(n1 + 1, 4);
-    for (i = 0; i < n1; ++i) {
-        root_chan_t *r = (root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]];
-        sw[i] = ngs->single_phone_wid[i]; sci[i] = r->ciphone; sci2[i] = r->ci2phone; smpx[i] = hmm_is_mpx(&r->hmm);
-        sss[i] = smpx[i] ? hmm_mpx_ssid(&r->hmm, 0) : hmm_nonmpx_ssid(&r->hmm);
-        stm[i] = r->hmm.tmatid;
-    }
-    pl = ckd_calloc(n_w, 4); p0 = ckd_calloc(n_w, 4); pz = ckd_calloc(n_w, 4); py = ckd_calloc(n_w, 4); bw = ckd_calloc(n_w, 4);
-    fl = ckd_calloc(n_w, 4);
-    for (w = 0; w < n_w; ++w) {
-        pl[w] = dict_pronlen(dict, w); p0[w] = dict_first_phone(dict, w); pz[w] = dict_last_phone(dict, w);
-        py[w] = pl[w] > 1 ? dict_second_last_phone(dict, w) : -1; bw[w] = dict_basewid(dict, w); fl[w] = dict_filler_word(dict, w);
-    }
-    rn = ckd_calloc((size_t)n_ci * n_ci, 4); rs = ckd_calloc((size_t)n_ci * n_ci * n_ci, 4);
-    rm = ckd_calloc((size_t)n_ci * n_ci * n_ci, 4); ld = ckd_calloc((size_t)n_ci * n_ci * n_ci, 4);
-    for (i = 0; i < n_ci; ++i)
-        for (j = 0; j < n_ci; ++j) {
-            xwdssid_t *x = dict2pid_rssid(d2p, i, j);
-            rn[i * n_ci + j] = x->n_ssid;
-            for (k = 0; k < n_ci; ++k) {
-                rs[((size_t)i * n_ci + j) * n_ci + k] = (x->ssid && k < x->n_ssid) ? x->ssid[k] : -1;
-                rm[((size_t)i * n_ci + j) * n_ci + k] = x->cimap ? x->cimap[k] : -1;
-                ld[((size_t)i * n_ci + j) * n_ci + k] = d2p->ldiph_lc[i][j][k];
-            }
-        }
-    n_tmat = acmod->tmat->n_tmat; n_sseq = bin_mdef_n_sseq(mdef);
-    tp = ckd_calloc((size_t)n_tmat * n_emit * (n_emit + 1), 1);
-    sq = ckd_calloc((size_t)n_sseq * n_emit, 2);
-    ptm = ckd_calloc(n_ci, 4);
-    for (i = 0; i < n_tmat; ++i) for (j = 0; j < n_emit; ++j) for (k = 0; k <= n_emit; ++k)
-        tp[((size_t)i * n_emit + j) * (n_emit + 1) + k] = acmod->tmat->tp[i][j][k];
-    for (i = 0; i < n_sseq; ++i) for (j = 0; j < n_emit; ++j) sq[(size_t)i * n_emit + j] = mdef->sseq[i][j];
-    for (i = 0; i < n_ci; ++i) ptm[i] = bin_mdef_pid2tmatid(mdef, i);
-    memset(par, 0, sizeof par);
-    par[0] = n_ci; par[1] = n_emit; par[2] = d->n_sen; par[3] = n_w; par[4] = R; par[5] = M; par[6] = n1;
-    par[7] = ngs->n_1ph_LMwords; par[8] = ngs->beam; par[9] = ngs->pbeam; par[10] = ngs->lpbeam; par[11] = ngs->lponlybeam;
-    par[12] = ngs->wbeam; par[13] = ngs->pip; par[14] = ngs->nwpen; par[15] = ngs->silpen; par[16] = ngs->fillpen;
-    par[17] = ngs->maxhmmpf; par[18] = ngs->maxwpf; par[19] = dict_startwid(dict); par[20] = dict_finishwid(dict);
-    par[21] = dict_silwid(dict); par[22] = dict_filler_start(dict); par[23] = dict_filler_end(dict); par[24] = mdef->sil;
-    par[25] = ps_search_lookahead(ngs) != NULL; par[26] = acmod->compallsen;
+    /* ---- the search tables: the one flattener (psgpu_search_tables.c), which psgpu_export_tables.c writes to a file */
+    st = psgpu_search_tables_collect(ps, want_ff);
+    if (st == NULL) { ckd_free(d); return NULL; }
     /* language scores: the model's own trie on the device when it is one trie model without classes
      * (psgpu_lm_tables.c), else -- small vocabularies only -- every ngram_tg_score in a dense table */
     lm = NULL;
@@ -246,68 +155,25 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     lm_ok = d->lm != NULL || n_w <= 400;
     if (!lm_ok)
         E_ERROR("psgpu device decode: %d words and no trie model -- the dense LM table is for small vocabularies\n", n_w);
-    else if (d->lm == NULL) {
-        size_t nn = (size_t)n_w + 1;
-        lm = ckd_calloc((size_t)n_w * nn * nn, 4);
-        /* The trie's back-off cache (lm_trie.c:775-811) starts zeroed: a full-history look-up whose model history is (0, 0)
-         * matches the zeroed key and is answered with zero back-off weights until any OTHER history has filled the cache.
-         * The table below is the cache's fixed point (what every look-up returns once it has been filled), so it is filled
-         * first, with a history of two different words (their model ids cannot both be 0).  A search never meets the initial
-         * state: its first full-history look-up has the history (w, <s>) with w != <s>. */
-        {
-            int a = -1, b = -1;
-            for (i = 0; i < n_w && b < 0; ++i)
-                if (!dict_filler_word(dict, i) && dict_basewid(dict, i) == i && ngram_model_set_known_wid(ngs->lmset, i)) {
-                    if (a < 0) a = i; else b = i;
-                }
-            if (b >= 0) { int32 nu; (void)ngram_tg_score(ngs->lmset, a, b, a, &nu); (void)ngram_tg_score(ngs->lmset, a, a, b, &nu); }
-        }
-        for (i = 0; i < n_w; ++i)
-            if (!dict_filler_word(dict, i) && dict_basewid(dict, i) == i)
-                for (j = -1; j < n_w; ++j)
-                    for (k = -1; k < n_w; ++k) {
-                        int32 nu;
-                        lm[((size_t)i * nn + (j + 1)) * nn + (k + 1)] = ngram_tg_score(ngs->lmset, i, j, k, &nu) >> SENSCR_SHIFT;
-                    }
-    }
-    memset(&t, 0, sizeof t);
-    t.par = par; t.node_ci = ci; t.node_ci2 = ci2; t.node_ssid = ssid; t.node_tmat = tm; t.node_child = child; t.node_sib = sib;
-    t.node_penult_wid = pw; t.homophone_set = ngs->homophone_set; t.w1_wid = sw; t.w1_ci = sci; t.w1_ci2 = sci2; t.w1_ssid = sss;
-    t.w1_tmat = stm; t.w1_mpx = smpx; t.dict_pronlen = pl; t.dict_first = p0; t.dict_last = pz; t.dict_last2 = py;
-    t.dict_basewid = bw; t.dict_filler = fl; t.rssid_n = rn; t.rssid_ssid = rs; t.rssid_cimap = rm; t.ldiph_lc = ld;
-    t.tp = tp; t.sseq = sq; t.ci_tmat = ptm; t.lm = lm; t.n_tmat = n_tmat; t.n_sseq = n_sseq;
+    else if (d->lm == NULL)
+        lm = psgpu_search_tables_dense_lm(ps, 1);        /* (the back-off cache's fixed point: see there) */
+    psgpu_search_tables_view(st, &t, NULL);
+    t.lm = lm;
     i = lm_ok ? psgpu_fwdtree_create(&d->ft, &t) : PSGPU_EINVAL;
     if (i == PSGPU_OK && d->lm) i = psgpu_fwdtree_set_lm(d->ft, d->lm);
     if (i == PSGPU_OK && want_ff) {
-        /* ---- what the second pass adds (cf. oracle/ref_dump.c cmd_fwdtree(.., flat = 1)): pronunciations as word-internal
-         *      ssids, the CI phones' ssids, which words the language model knows, its beams and windows */
+        /* ---- what the second pass adds: pronunciations as word-internal ssids, the CI phones' ssids, which words the
+         *      language model knows, its beams and windows (psgpu_search_tables.c) */
         psgpu_fwdflat_tables_t t2;
-        int64_t tot = 0, o = 0;
-        int32 *off = ckd_calloc(n_w + 1, 4), *pci, *pss, *cis = ckd_calloc(n_ci, 4), *known = ckd_calloc(n_w, 4);
-        for (w = 0; w < n_w; ++w) tot += dict_pronlen(dict, w);
-        pci = ckd_calloc(tot + 1, 4); pss = ckd_calloc(tot + 1, 4);
-        for (w = 0; w < n_w; ++w) {
-            int len = dict_pronlen(dict, w);
-            off[w] = (int32)o;
-            for (k = 0; k < len; ++k, ++o) {
-                pci[o] = dict_pron(dict, w, k);
-                pss[o] = (k >= 1 && k < len - 1) ? dict2pid_internal(d2p, w, k) : -1;
-            }
-            known[w] = ngram_model_set_known_wid(ngs->lmset, dict_basewid(dict, w)) ? 1 : 0;
-        }
-        off[n_w] = (int32)o;
-        for (j = 0; j < n_ci; ++j) cis[j] = bin_mdef_pid2ssid(mdef, j);
-        memset(&t2, 0, sizeof t2);
-        t2.ft = &t; t2.pron_off = off; t2.pron_ci = pci; t2.pron_ssid = pss; t2.ci_ssid = cis; t2.lm_known = known;
-        t2.fwdflatbeam = ngs->fwdflatbeam; t2.fwdflatwbeam = ngs->fwdflatwbeam; t2.min_ef_width = ngs->min_ef_width;
-        t2.max_sf_win = ngs->max_sf_win; t2.lwf = ngs->fwdflat_fwdtree_lw_ratio;
+        psgpu_fwdtree_tables_t tv;
+        psgpu_search_tables_view(st, &tv, &t2);
+        t2.ft = &t;
         i = psgpu_fwdflat_create(&d->ff, &t2);
         if (i == PSGPU_OK && d->lm) i = psgpu_fwdflat_set_lm(d->ff, d->lm);
         d->n_fast_hist = ps->pl_window + 2;               /* ptm_mgau.c:884 */
         d->n1 = ngs->n_1ph_words; d->n_emit = n_emit;
-        ckd_free(off); ckd_free(pci); ckd_free(pss); ckd_free(cis); ckd_free(known);
     }
-    if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, n_tmat, tp, n_sseq, sq, d->n_sen);
+    if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, st->n_tmat, st->tp, st->n_sseq, st->sseq, d->n_sen);
     if (i == PSGPU_OK) {
         fes = psgpu_fe_wrap(acmod->fe);
         if (fes) d->fe = psgpu_fe_shim_release(fes); else i = PSGPU_EINVAL;
@@ -343,10 +209,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         E_ERROR("psgpu device decode: needs the phone-loop look-ahead (pl_window > 0, <= 64 CI phones)\n");
         i = PSGPU_EINVAL;
     }
-    ckd_free(nodes); ckd_free(ci); ckd_free(ci2); ckd_free(ssid); ckd_free(tm); ckd_free(child); ckd_free(sib); ckd_free(pw);
-    ckd_free(sw); ckd_free(sci); ckd_free(sci2); ckd_free(sss); ckd_free(stm); ckd_free(smpx);
-    ckd_free(pl); ckd_free(p0); ckd_free(pz); ckd_free(py); ckd_free(bw); ckd_free(fl); ckd_free(rn); ckd_free(rs); ckd_free(rm);
-    ckd_free(ld); ckd_free(tp); ckd_free(sq); ckd_free(ptm); ckd_free(lm);
+    psgpu_search_tables_free(st); ckd_free(lm);
     if (i != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         psgpu_device_decode_detach(d);

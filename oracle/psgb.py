@@ -1,29 +1,10 @@
-"""Reader for the "PSGB1" container written by oracle/ref_dump.c.
+"""Reader for the "PSGB1" container written by oracle/ref_dump.c: the product's own reader (the format is the table file's,
+integration/psgpu_table_file.h).
 
 TEST INFRASTRUCTURE: used only by the golden-fixture generator and tests.
 """
-import struct
-import numpy as np
+import os
+import sys
 
-_DT = {ord('f'): np.float32, ord('i'): np.int32, ord('h'): np.int16,
-       ord('B'): np.uint8, ord('H'): np.uint16, ord('q'): np.int64,
-       ord('d'): np.float64}
-
-
-def read_psgb(path):
-    out = {}
-    with open(path, 'rb') as fh:
-        buf = fh.read()
-    assert buf[:6] == b'PSGB1\n', 'not a PSGB1 file'
-    o = 6
-    while o < len(buf):
-        (nl,) = struct.unpack_from('<I', buf, o); o += 4
-        name = buf[o:o + nl].decode(); o += nl
-        dt, nd = struct.unpack_from('<II', buf, o); o += 8
-        dims = struct.unpack_from('<%dq' % nd, buf, o); o += 8 * nd
-        dtype = np.dtype(_DT[dt])
-        n = int(np.prod(dims)) if nd else 1
-        arr = np.frombuffer(buf, dtype=dtype, count=n, offset=o).reshape(dims).copy()
-        o += n * dtype.itemsize
-        out[name] = arr
-    return out
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pocketsphinx_amd.tablefile import read_psgb  # noqa: E402,F401

@@ -37,6 +37,9 @@
 #include "tmat.h"
 #include "bin_mdef.h"
 #include "hmm.h"
+#include "lm/ngram_model_set.h"
+#include "psgpu_lm_tables.h"
+#include "psgpu_search_tables.h"
 
 /* ------------------------------------------------------------------ */
 static FILE *g_out;
@@ -73,6 +76,9 @@ static void put3(const char *name, char dt, int64_t a, int64_t b, int64_t c, con
 static void put4(const char *name, char dt, int64_t a, int64_t b, int64_t c, int64_t e, const void *d)
 { int64_t dims[4] = {a, b, c, e}; psgb_put(name, dt, 4, dims, d); }
 static void puti(const char *name, int32_t v) { put1(name, 'i', 1, &v); }
+/* psgpu_table_emit_fn (integration/psgpu_search_tables.h) onto this file's writer */
+static void emit_put(void *ctx, const char *name, char dt, int nd, const int64_t *dims, const void *data)
+{ (void)ctx; psgb_put(name, dt, nd, dims, data); }
 
 /* ------------------------------------------------------------------ */
 static ps_decoder_t *
@@ -922,25 +928,6 @@ ft_step(ps_search_t *search, int frame_idx)
     return rv;
 }
 
-/* depth-first numbering of the non-root tree nodes */
-static int
-ft_number(chan_t *first, chan_t **nodes, int n)
-{
-    chan_t *h;
-    for (h = first; h; h = h->alt) {
-        nodes[n++] = h;
-        n = ft_number(h->next, nodes, n);
-    }
-    return n;
-}
-static int ft_index(chan_t **nodes, int n, chan_t *h, int base)
-{
-    int i;
-    if (h == NULL) return -1;
-    for (i = 0; i < n; ++i) if (nodes[i] == h) return base + i;
-    return -2;
-}
-
 /* ---- fwdflat (`fwdflat` command): the second pass (ngram_search_fwdflat.c) runs inside the search's finish();
  * the wrapper snapshots what pass 1 left (back-pointer table, score stack, the multiplex ssids of the permanent
  * single-phone channels: hmm_clear does not reset them), the scorer hook records the scores each pass-2 frame was
@@ -1055,133 +1042,21 @@ cmd_fwdtree(ps_decoder_t *ps, const char *rawpath, int flat)
     acmod_t *acmod = ps->acmod;
     bin_mdef_t *mdef = acmod->mdef;
     dict_t *dict = ps_search_dict(ngs);
-    dict2pid_t *d2p = ps_search_dict2pid(ngs);
     int n_ci = bin_mdef_n_ciphone(mdef), n_emit = bin_mdef_n_emit_state(mdef), n_w = dict_size(dict);
-    int R = ngs->n_root_chan, M, i, j, k, w;
-    chan_t **nodes;
-    int32 par[32];
+    int R = ngs->n_root_chan, i, j, k;
 
     if (strcmp(ps_search_type(ps->search), PS_SEARCH_TYPE_NGRAM) || !ngs->fwdtree || (!ngs->fwdflat) != !flat || ngs->bestpath) {
         fprintf(stderr, "fwdtree dump needs an n-gram search with -fwdflat no -bestpath no, fwdflat dump one with -fwdflat yes -bestpath no\n");
         return 2;
     }
     ff_on = flat;
-    /* ---- the tree */
-    nodes = calloc(ngs->n_nonroot_chan + 16, sizeof *nodes);
-    for (M = 0, i = 0; i < R; ++i) M = ft_number(ngs->root_chan[i].next, nodes, M);
+    /* ---- the static tables: the product's own flattener (integration/psgpu_search_tables.c -- the code behind
+     *      psgpu_device_search_attach and psgpu_export_tables), under the names the goldens have always used */
     {
-        int N = R + M;
-        int32 *ci = calloc(N, 4), *ci2 = calloc(N, 4), *ssid = calloc(N, 4), *tm = calloc(N, 4), *child = calloc(N, 4),
-              *sib = calloc(N, 4), *pw = calloc(N, 4);
-        for (i = 0; i < R; ++i) {
-            root_chan_t *r = &ngs->root_chan[i];
-            ci[i] = r->ciphone; ci2[i] = r->ci2phone; ssid[i] = hmm_mpx_ssid(&r->hmm, 0); tm[i] = r->hmm.tmatid;
-            child[i] = ft_index(nodes, M, r->next, R); sib[i] = -1; pw[i] = r->penult_phn_wid;
-        }
-        for (i = 0; i < M; ++i) {
-            chan_t *h = nodes[i];
-            ci[R + i] = h->ciphone; ci2[R + i] = -1; ssid[R + i] = hmm_nonmpx_ssid(&h->hmm); tm[R + i] = h->hmm.tmatid;
-            child[R + i] = ft_index(nodes, M, h->next, R); sib[R + i] = ft_index(nodes, M, h->alt, R);
-            pw[R + i] = h->info.penult_phn_wid;
-        }
-        put1("node_ci", 'i', N, ci); put1("node_ci2", 'i', N, ci2); put1("node_ssid", 'i', N, ssid);
-        put1("node_tmat", 'i', N, tm); put1("node_child", 'i', N, child); put1("node_sib", 'i', N, sib);
-        put1("node_penult_wid", 'i', N, pw);
-    }
-    put1("homophone_set", 'i', n_w, ngs->homophone_set);
-    {   /* single-phone words (permanent channels) */
-        int n1 = ngs->n_1ph_words;
-        int32 *sw = calloc(n1 + 1, 4), *sci = calloc(n1 + 1, 4), *sci2 = calloc(n1 + 1, 4), *sss = calloc(n1 + 1, 4),
-              *stm = calloc(n1 + 1, 4), *smpx = calloc(n1 + 1, 4);
-        for (i = 0; i < n1; ++i) {
-            root_chan_t *r = (root_chan_t *)ngs->word_chan[ngs->single_phone_wid[i]];
-            sw[i] = ngs->single_phone_wid[i]; sci[i] = r->ciphone; sci2[i] = r->ci2phone;
-            smpx[i] = hmm_is_mpx(&r->hmm);
-            sss[i] = smpx[i] ? hmm_mpx_ssid(&r->hmm, 0) : hmm_nonmpx_ssid(&r->hmm);
-            stm[i] = r->hmm.tmatid;
-        }
-        put1("w1_wid", 'i', n1, sw); put1("w1_ci", 'i', n1, sci); put1("w1_ci2", 'i', n1, sci2);
-        put1("w1_ssid", 'i', n1, sss); put1("w1_tmat", 'i', n1, stm); put1("w1_mpx", 'i', n1, smpx);
-    }
-    {   /* dictionary */
-        int32 *pl = calloc(n_w, 4), *p0 = calloc(n_w, 4), *pz = calloc(n_w, 4), *py = calloc(n_w, 4), *bw = calloc(n_w, 4),
-              *fl = calloc(n_w, 4), *real = calloc(n_w, 4);
-        for (w = 0; w < n_w; ++w) {
-            pl[w] = dict_pronlen(dict, w); p0[w] = dict_first_phone(dict, w); pz[w] = dict_last_phone(dict, w);
-            py[w] = pl[w] > 1 ? dict_second_last_phone(dict, w) : -1; bw[w] = dict_basewid(dict, w);
-            fl[w] = dict_filler_word(dict, w); real[w] = dict_real_word(dict, w);
-        }
-        put1("dict_pronlen", 'i', n_w, pl); put1("dict_first", 'i', n_w, p0); put1("dict_last", 'i', n_w, pz);
-        put1("dict_last2", 'i', n_w, py); put1("dict_basewid", 'i', n_w, bw); put1("dict_filler", 'i', n_w, fl);
-        put1("dict_real", 'i', n_w, real);
-    }
-    {   /* dict2pid: right-context tables for every (last phone, second-last phone), root entry ssids */
-        int32 *rn = calloc((size_t)n_ci * n_ci, 4), *rs = calloc((size_t)n_ci * n_ci * n_ci, 4), *rm = calloc((size_t)n_ci * n_ci * n_ci, 4);
-        int32 *ld = calloc((size_t)n_ci * n_ci * n_ci, 4);
-        for (i = 0; i < n_ci; ++i)
-            for (j = 0; j < n_ci; ++j) {
-                xwdssid_t *x = dict2pid_rssid(d2p, i, j);
-                rn[i * n_ci + j] = x->n_ssid;
-                for (k = 0; k < n_ci; ++k) {
-                    rs[((size_t)i * n_ci + j) * n_ci + k] = (x->ssid && k < x->n_ssid) ? x->ssid[k] : -1;
-                    rm[((size_t)i * n_ci + j) * n_ci + k] = x->cimap ? x->cimap[k] : -1;
-                    ld[((size_t)i * n_ci + j) * n_ci + k] = d2p->ldiph_lc[i][j][k];
-                }
-            }
-        put2("rssid_n", 'i', n_ci, n_ci, rn); put3("rssid_ssid", 'i', n_ci, n_ci, n_ci, rs);
-        put3("rssid_cimap", 'i', n_ci, n_ci, n_ci, rm); put3("ldiph_lc", 'i', n_ci, n_ci, n_ci, ld);
-    }
-    {   /* HMM topology */
-        int n_tmat = acmod->tmat->n_tmat, n_sseq = bin_mdef_n_sseq(mdef), a, b;
-        uint8 *tp = calloc((size_t)n_tmat * n_emit * (n_emit + 1), 1);
-        uint16 *sq = calloc((size_t)n_sseq * n_emit, 2);
-        int32 *ptm = calloc(n_ci, 4);
-        for (i = 0; i < n_tmat; ++i) for (a = 0; a < n_emit; ++a) for (b = 0; b <= n_emit; ++b)
-            tp[((size_t)i * n_emit + a) * (n_emit + 1) + b] = acmod->tmat->tp[i][a][b];
-        for (i = 0; i < n_sseq; ++i) for (a = 0; a < n_emit; ++a) sq[(size_t)i * n_emit + a] = mdef->sseq[i][a];
-        for (i = 0; i < n_ci; ++i) ptm[i] = bin_mdef_pid2tmatid(mdef, i);
-        put3("tp", 'B', n_tmat, n_emit, n_emit + 1, tp); put2("sseq", 'H', n_sseq, n_emit, sq);
-        put1("ci_tmat", 'i', n_ci, ptm);
-    }
-    memset(par, 0, sizeof par);
-    par[0] = n_ci; par[1] = n_emit; par[2] = bin_mdef_n_sen(mdef); par[3] = n_w; par[4] = R; par[5] = M;
-    par[6] = ngs->n_1ph_words; par[7] = ngs->n_1ph_LMwords; par[8] = ngs->beam; par[9] = ngs->pbeam; par[10] = ngs->lpbeam;
-    par[11] = ngs->lponlybeam; par[12] = ngs->wbeam; par[13] = ngs->pip; par[14] = ngs->nwpen; par[15] = ngs->silpen;
-    par[16] = ngs->fillpen; par[17] = ngs->maxhmmpf; par[18] = ngs->maxwpf; par[19] = dict_startwid(dict);
-    par[20] = dict_finishwid(dict); par[21] = dict_silwid(dict); par[22] = dict_filler_start(dict);
-    par[23] = dict_filler_end(dict); par[24] = mdef->sil; par[25] = ps_search_lookahead(ngs) != NULL;
-    par[26] = acmod->compallsen;
-    put1("par", 'i', 32, par);
-    if (flat) {   /* what the second pass adds: pronunciations as word-internal ssids, CI ssids, LM membership, its beams */
-        int64_t tot = 0, o = 0;
-        int32 *off = calloc(n_w + 1, 4), *pci, *pss, *cis = calloc(n_ci, 4), *known = calloc(n_w, 4), fpar[16];
-        float lwf = ngs->fwdflat_fwdtree_lw_ratio;
-        for (w = 0; w < n_w; ++w) tot += dict_pronlen(dict, w);
-        pci = calloc(tot + 1, 4); pss = calloc(tot + 1, 4);
-        for (w = 0; w < n_w; ++w) {
-            int len = dict_pronlen(dict, w);
-            off[w] = (int32)o;
-            for (k = 0; k < len; ++k, ++o) {
-                pci[o] = dict_pron(dict, w, k);
-                pss[o] = (k >= 1 && k < len - 1) ? dict2pid_internal(d2p, w, k) : -1;
-            }
-            known[w] = ngram_model_set_known_wid(ngs->lmset, dict_basewid(dict, w)) ? 1 : 0;
-        }
-        off[n_w] = (int32)o;
-        for (i = 0; i < n_ci; ++i) cis[i] = bin_mdef_pid2ssid(mdef, i);
-        put1("pron_off", 'i', n_w + 1, off); put1("pron_ci", 'i', tot, pci); put1("pron_ssid", 'i', tot, pss);
-        put1("ci_ssid", 'i', n_ci, cis); put1("lm_known", 'i', n_w, known);
-        memset(fpar, 0, sizeof fpar);
-        fpar[0] = ngs->fwdflatbeam; fpar[1] = ngs->fwdflatwbeam; fpar[2] = ngs->min_ef_width; fpar[3] = ngs->max_sf_win;
-        put1("flat_par", 'i', 16, fpar); put1("flat_lwf", 'f', 1, &lwf);
-    }
-    if (ps->phone_loop) {   /* the phone-loop search feeding the look-ahead penalties (phone_loop_search.h:75-94) */
-        phone_loop_search_t *pls = (phone_loop_search_t *)ps->phone_loop;
-        int32 pp[8] = { pls->n_phones, pls->window, pls->beam, pls->pbeam, pls->pip, ps->pl_window, 0, 0 };
-        int32 *ss = calloc(pls->n_phones, 4), *tm = calloc(pls->n_phones, 4);
-        for (i = 0; i < pls->n_phones; ++i) { ss[i] = hmm_nonmpx_ssid(&pls->hmms[i]); tm[i] = pls->hmms[i].tmatid; }
-        put1("pl_par", 'i', 8, pp); put1("pl_weight", 'd', 1, &pls->penalty_weight);
-        put1("pl_ssid", 'i', pls->n_phones, ss); put1("pl_tmat", 'i', pls->n_phones, tm);
+        psgpu_search_tables_t *st = psgpu_search_tables_collect(ps, flat);
+        if (!st) return 2;
+        psgpu_search_tables_emit(st, emit_put, NULL);
+        psgpu_search_tables_free(st);
     }
     {   /* the language model over dictionary word ids */
         size_t n1 = (size_t)n_w + 1;
@@ -1268,36 +1143,13 @@ traced:
 
 /* ---- language model: the trie's tables + the reference's answers to a list of
  * (w3, w2, w1) queries in the word ids of the model SET (= dictionary word ids inside a decoder) */
-#include "lm/ngram_model_set.h"
-#include "psgpu_lm_tables.h"
 static int
 cmd_lm(ngram_model_t *lmset, const char *qfile)
 {
     psgpu_lm_tables_t t;
-    uint32_t lev[PSGPU_LM_MAX_LEVELS * 7];
-    int l, w;
-    size_t nb = 0;
-    char *words;
+    int w;
+    if (psgpu_lm_tables_emit(lmset, emit_put, NULL) < 0) return 2;
     if (psgpu_lm_tables_read(lmset, &t) < 0) return 2;
-    puti("order", t.order); puti("n_unigrams", t.n_unigrams); puti("n_words", t.n_words);
-    put2("unigrams", 'i', t.n_unigrams + 1, 3, t.unigrams);
-    put1("ngram_mem", 'B', (int64_t)t.ngram_mem_size, t.ngram_mem ? (const void *)t.ngram_mem : (const void *)"");
-    for (l = 0; l < t.order - 1; ++l) {
-        lev[7 * l] = t.level_offset[l]; lev[7 * l + 1] = t.total_bits[l]; lev[7 * l + 2] = t.word_bits[l];
-        lev[7 * l + 3] = t.word_mask[l]; lev[7 * l + 4] = t.max_vocab[l]; lev[7 * l + 5] = t.next_bits[l];
-        lev[7 * l + 6] = t.next_mask[l];
-    }
-    put2("levels", 'i', t.order - 1, 7, lev);
-    if (t.order > 1) put2("quant", 'f', 2 * (t.order - 2) + 1, 65536, t.quant);
-    put1("lw", 'f', 1, &t.lw); puti("log_wip", t.log_wip); puti("log_zero", t.log_zero);
-    put1("widmap", 'i', t.n_words, t.widmap);
-    for (w = 0; w < t.n_words; ++w) nb += strlen(ngram_word(lmset, w)) + 1;
-    words = ckd_calloc(nb + 1, 1);
-    for (w = 0, nb = 0; w < t.n_words; ++w) {
-        const char *s = ngram_word(lmset, w);
-        memcpy(words + nb, s, strlen(s)); nb += strlen(s); words[nb++] = '\n';
-    }
-    put1("words", 'B', (int64_t)nb, words);
     if (qfile && strcmp(qfile, "-")) {
         FILE *fp = fopen(qfile, "rb");
         long n; int32 *q, *sc, *nu, i, a = -1, b = -1;

@@ -50,6 +50,7 @@ struct psgpu_decode_s {
     int32_t bp_cap2 = 0, bss_cap2 = 0;
     bool pass2 = false;
     bool last_chained = false, last_sess = false, searched = false;
+    bool first_called = false;          // a psgpu_decode_first_pass* call has been made (searched: ... and a search kernel ran in it)
     int32_t lag_next = 0, last_lag = 0;   // psgpu_decode_search_lag: for the next call / what the latest call's search was given
     // the last call
     int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
@@ -421,7 +422,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
                   "psgpu_decode_first_pass_dev: from PCM the pipeline computes 1s_c_d_dd vectors of %d cepstra; the scorer takes %d-dimensional "
                   "vectors (other feature types: psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
     hipStream_t st = (hipStream_t)stream;
-    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
     d->frame_off.assign((size_t)n_utt + 1, 0);
     if (n_utt == 0) return PSGPU_OK;
     size_t total = 0, mf = 0;
@@ -475,7 +476,7 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (feat && frame_off)), "psgpu_decode_first_pass_feat: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false;
+    d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
     d->frame_off.assign(frame_off, frame_off + (n_utt ? n_utt + 1 : 0));
     if (n_utt == 0) { d->frame_off.assign(1, 0); return PSGPU_OK; }
     PSGPU_REQUIRE(frame_off[0] == 0, "psgpu_decode_first_pass_feat: frame offsets start at 0");
@@ -659,14 +660,17 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
 int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *stream)
 {
     PSGPU_REQUIRE(d && ff, "psgpu_decode_second_pass: NULL argument");
-    PSGPU_REQUIRE(d->searched, "psgpu_decode_second_pass: no first pass in this object (psgpu_decode_first_pass* comes first)");
+    PSGPU_REQUIRE(d->first_called, "psgpu_decode_second_pass: no first pass in this object (psgpu_decode_first_pass* comes first)");
+    // a call of nothing but empty (or too short) utterances, or of none: the first pass launched no search and left empty result
+    // records; the second pass of nothing is nothing -- those records stand (as the first-pass-only path returns them)
+    if (d->n_utt == 0 || d->total == 0) { d->pass2 = false; return PSGPU_OK; }
+    PSGPU_REQUIRE(d->searched, "psgpu_decode_second_pass: the first pass of this call did not complete");
     PSGPU_REQUIRE(d->kind == PSGPU_SCORER_PTM, "psgpu_decode_second_pass: the device second pass scores from the PTM scorer's lists");
     PSGPU_REQUIRE(psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK, "psgpu_decode_second_pass: no view of the PTM model");
     PSGPU_REQUIRE(d->last_lag == 0, "psgpu_decode_second_pass: the first pass stopped short of the utterances' ends (psgpu_decode_search_lag)");
     hipStream_t st = (hipStream_t)stream;
     const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
     d->pass2 = false;
-    if (nu == 0) { d->pass2 = true; return PSGPU_OK; }
     int rc;
     {   // the first pass's tables complete (a full table: larger ones and the search again, as psgpu_decode_fetch_hyps would)
         std::vector<int32_t> res(nu * 8);

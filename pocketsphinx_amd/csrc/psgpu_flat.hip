@@ -21,6 +21,7 @@
 #include "psgpu_lm_dev.h"
 #include "psgpu_sen_dev.h"
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <ctime>
 #include <thread>
@@ -1492,12 +1493,15 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     {   // the utterances' vocabularies are independent of each other: host threads (30 s of audio on the small task: 18 k first-pass
         // entries and ~170 us an utterance; 512 of them one after another were a quarter of the call)
         const int n_thr = (int)std::max(1u, std::min({ std::thread::hardware_concurrency(), 16u, (unsigned)((n_utt + 15) / 16) }));
+        std::atomic<int> failed{0};                      // (an exception must not leave a worker: std::terminate would take the host process)
         auto work = [&](int t) {
-            for (int u = t; u < n_utt; u += n_thr) {
-                const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
-                const int32_t *cu = cols.data() + (size_t)u * max_nb;
-                ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
-            }
+            try {
+                for (int u = t; u < n_utt; u += n_thr) {
+                    const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
+                    const int32_t *cu = cols.data() + (size_t)u * max_nb;
+                    ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
+                }
+            } catch (...) { failed.store(1); }
         };
         if (n_thr <= 1) work(0);
         else {
@@ -1505,6 +1509,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
             for (int t = 0; t < n_thr; ++t) thr.emplace_back(work, t);
             for (auto &t : thr) t.join();
         }
+        if (failed.load()) { psgpu_set_error("psgpu_fwdflat_search: out of host memory building the utterances' vocabularies"); return PSGPU_ENOMEM; }
     }
     for (int u = 0; u < n_utt; ++u) {
         const int nfr = res1[(size_t)u * 8 + 2];
@@ -1581,6 +1586,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     if (dyn + 56 * 1024 > 65536) {                                                                                         \
         static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdflat_kernel<NE, true>,                      \
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, kFfMaxSen * 2);  \
+        if (attr_rc != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); }                                      \
         PSGPU_HIP(attr_rc);                                                                                                \
     }
 #else

@@ -2372,15 +2372,17 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     PSGPU_REQUIRE(!raw_scores || (m->d.n_sen <= kFtMaxSen && pl_window >= 0), "raw-score mode: n_sen %d > %d or negative pl_window",
                   m->d.n_sen, kFtMaxSen);
     PSGPU_REQUIRE(m->d.lm || m->d.use_trie, "psgpu_fwdtree_search_dev: no language model (dense table or psgpu_fwdtree_set_lm)");
-    PSGPU_REQUIRE(m->d.n_sen <= kFtSlabSen && m->d.n_tmat * m->d.n_emit * (m->d.n_emit + 1) <= kFtSlabTp,
-                  "fwdtree: %d senones / %d transition matrices (the search keeps a frame's row of at most %d scores and %d bytes of "
-                  "matrices in LDS)", m->d.n_sen, m->d.n_tmat, kFtSlabSen, kFtSlabTp);
     if (n_utt == 0) return PSGPU_OK;
     PSGPU_REQUIRE((senscr_dev || ls) && penalties_dev && utt_off_dev && bp_dev && bss_dev && idx_dev && step_dev && result_dev,
                   "psgpu_fwdtree_search_dev: NULL device buffer");
     FtDev d = m->d;
     // the LDS layout copies score rows as dwords: rows must start on 4-byte boundaries
     if (!ls && d.small && ((scr_stride & 1) || ((uintptr_t)senscr_dev & 3))) ft_layout(d, false);
+    // the slab layouts keep a frame's score row and the transition matrices in fixed LDS arrays (the LDS layout sizes its pool from
+    // the model: ft_layout refused it at create if it did not fit)
+    PSGPU_REQUIRE(d.small || (d.n_sen <= kFtSlabSen && d.n_tmat * d.n_emit * (d.n_emit + 1) <= kFtSlabTp),
+                  "fwdtree (slab layout): %d senones / %d transition matrices (the kernel keeps a frame's row of at most %d scores and %d "
+                  "bytes of matrices in LDS)", d.n_sen, d.n_tmat, kFtSlabSen, kFtSlabTp);
     hipStream_t st = (hipStream_t)stream;
     const size_t need = (size_t)d.per * n_utt;
     if (need > m->slab_words) {

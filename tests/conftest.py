@@ -53,5 +53,5 @@ def make_big_flat_trace(out_dir):
 def big_flat_trace(tmp_path_factory):
     g = make_big_flat_trace(tmp_path_factory.mktemp("bigflat"))
     if g is None:
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     return g

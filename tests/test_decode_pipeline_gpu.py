@@ -98,7 +98,7 @@ def test_pipeline_equals_the_reference_on_synthetic_utterances(tables, tmp_path,
     on the host and by the pipeline on the device: same words (dictionary ids), same frame boundaries, same path score"""
     ref = os.path.join(pso.REF_DIR, "ref_decode_bench")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     from pocketsphinx_amd import synth
     pcms = [synth.utterance(i, seconds) for i in ids]
     raw = tmp_path / "utts.raw"

@@ -96,7 +96,7 @@ def test_fe_dither_draws_the_references_sequence(tmp_path):
     import pocketsphinx_amd as P
     exe = os.path.join(pso.REF_DIR, "ref_dump")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     sys.path.insert(0, os.path.join(os.path.dirname(pso.__file__), "..", "oracle"))
     from psgb import read_psgb
     plain = _load("mfcc_en_us_goforward.npz")
@@ -119,7 +119,13 @@ def test_fe_dither_draws_the_references_sequence(tmp_path):
         for r in range(3):
             _same(cep[fo[r]:fo[r + 1]], want[r])
         fe.close()
-    assert want[0].shape == plain["cep"].shape or True
+        # the dither bits were applied: same shape as the undithered cepstra of the same recording, other values
+        assert want[0].shape[1] == plain["cep"].shape[1]
+    und = os.path.join(str(tmp_path), "undithered.psgb")
+    subprocess.check_call([exe, "mfcc", und, os.path.join(pso.REF_DIR, "model", "an4_ci_cont"), "-", "-", os.path.join(pso.REF_DIR, "data", "goforward.raw"),
+                           "1", "--", "dither", "no", "remove_noise", "no"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    gu = read_psgb(und)
+    assert gu["cep"].shape == want[0].shape and not np.array_equal(gu["cep"], want[0])
 
 
 def test_device_log_equals_the_hosts_libm_over_the_mel_range():

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def _reference(tmp_path, pcms, lm, dic, extra=()):
     ref = os.path.join(pso.REF_DIR, "ref_decode_bench")
     if not os.path.exists(ref):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     raw = tmp_path / "utts.raw"
     np.concatenate(pcms).tofile(raw)
     data = os.path.join(pso.REF_DIR, "data")
@@ -42,13 +42,30 @@ def _same(u, r, hn, hyp, res, what):
 
 @pytest.fixture(scope="module")
 def big_task():
+    """the task's tables as the product gets them: the table file integration/psgpu_export_tables wrote"""
     from pocketsphinx_amd import largevocab as lv
     if not lv.available():
-        pytest.skip("oracle/_ref (ref_dump + big.arpa + cmudict-en-us.dict) not built")
+        pytest.fail("table file %s not found: `make -C integration tables` (part of __graft_entry__.build())" % lv.table_path())
     return lv.tables()
 
 
-def test_large_vocabulary_pipeline_equals_the_reference_on_30s_utterances(tables, big_task, tmp_path):
+@pytest.fixture(scope="module")
+def big_golden(tmp_path_factory):
+    """the checker's side: `ref_dump fwdtree` of the compiled reference on the same task -- its trace of goforward.raw and, as a
+    cross-check of the export tool, the same static tables written by the test harness"""
+    from pocketsphinx_amd.tablefile import read_psgb
+    ref = pso.REF_DIR
+    need = [os.path.join(ref, "ref_dump"), os.path.join(ref, "data", "big.arpa"), os.path.join(ref, "data", "cmudict-en-us.dict")]
+    if not all(os.path.exists(p) for p in need):
+        pytest.fail("oracle/_ref (ref_dump + big.arpa + cmudict-en-us.dict) not built: run __graft_entry__.build() where /root/reference is present")
+    out = str(tmp_path_factory.mktemp("big") / "big.psgb")
+    subprocess.check_call([need[0], "fwdtree", out, os.path.join(ref, "model", "en-us"), need[1], need[2],
+                           os.path.join(ref, "data", "goforward.raw"), "--", "fwdflat", "no", "bestpath", "no"],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    return read_psgb(out)
+
+
+def test_large_vocabulary_pipeline_equals_the_reference_on_30s_utterances(tables, big_task, big_golden, tmp_path):
     """three DIFFERENT 30 s synthetic utterances (the benchmark's generator) at 134,865 words, PCM -> hypotheses on the device:
     ~9 k HMM evaluations and ~30 new back-pointers per frame, 75-90 k back-pointers and 2-2.4 M score-stack entries per
     utterance -- everything the reference's decode of the same PCM gives, incl. the table sizes"""
@@ -69,9 +86,13 @@ def test_large_vocabulary_pipeline_equals_the_reference_on_30s_utterances(tables
     p.run([clips["goforward"]])
     hn1, hyp1, res1 = p.fetch()
     tab = p.tables(0, res1)
-    assert np.array_equal(tab["bp"], big_task["bp"]) and np.array_equal(tab["bscore_stack"], big_task["bscore_stack"])
-    assert int(hn1[0, 1]) == int(big_task["hyp_score"][0])
+    assert np.array_equal(tab["bp"], big_golden["bp"]) and np.array_equal(tab["bscore_stack"], big_golden["bscore_stack"])
+    assert int(hn1[0, 1]) == int(big_golden["hyp_score"][0])
     p.close()
+    # the table file against the harness's dump of the same decoder configuration: every static array identical
+    for k in ("par", "node_ci", "node_child", "node_sib", "node_penult_wid", "homophone_set", "w1_wid", "dict_last", "dict_basewid",
+              "rssid_ssid", "rssid_cimap", "ldiph_lc", "tp", "sseq", "unigrams", "ngram_mem", "levels", "quant", "widmap"):
+        assert np.array_equal(big_task[k], big_golden[k]), k
 
 
 def test_large_vocabulary_tables_grow_on_demand(tables, big_task, tmp_path):

@@ -22,7 +22,7 @@ REF = pso.REF_DIR
 
 def _need_ref():
     if not os.path.exists(os.path.join(REF, "ref_dump")) or not os.path.exists(os.path.join(REF, "ref_decode_bench")):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
 
 
 def _ref_dump(tmp_path, cmd, model, lm, dic, args, extra=()):

@@ -201,7 +201,7 @@ def test_fwdflat_kernel_full_cmudict_vocabulary(tmp_path):
     import os
     import pso
     if not os.path.exists(os.path.join(pso.REF_DIR, "ref_dump")):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     run_isolated(ME, "impl_full_cmudict", str(tmp_path), timeout=1500)
 
 
@@ -230,7 +230,7 @@ def test_two_passes_on_different_synthetic_utterances_equal_the_reference():
     import sys
     import pso
     if not os.path.exists(os.path.join(pso.REF_DIR, "ref_decode_bench")):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TP_B="24", TP_SYNTH="6.0", TP_CHECK_EVERY="1")
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "two_pass_bench.py")], capture_output=True, text=True, timeout=900, env=env)
@@ -253,7 +253,7 @@ def test_pipeline_object_runs_both_passes(tmp_path):
     from test_oracle_golden import _load
     exe = os.path.join(pso.REF_DIR, "ref_decode_bench")
     if not os.path.exists(exe):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     gt, st = _load("fwdtree_trace_goforward.npz"), _load("fwdtree_static_en_us_turtle.npz")
     gf, fst = _load("fwdflat_trace_goforward.npz"), _load("fwdflat_static_en_us_turtle.npz")
     p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), pso.load_tables(), st, gt["par"], gt)
@@ -296,4 +296,12 @@ def test_pipeline_object_runs_both_passes(tmp_path):
     p.table_capacity(1, 1, True)                          # a new object whose tables are too small for either pass: both grow
     check([3, 4, 5], 6.0)
     assert p.tables_grown() >= 2
+    # a batch of nothing but empty / sub-frame utterances: the first pass launches no search, the second pass of nothing is
+    # nothing -- empty result records, not "no first pass" (the first-pass-only path returns the same)
+    p.run([np.zeros(0, np.int16), np.zeros(100, np.int16)])
+    p.second_pass(flat)
+    hn, hyp, res = p.fetch()
+    assert not res.any() and not hn[:, 0].any()
+    # ... and the object still decodes afterwards
+    check([8], 6.0)
     flat.close(); p.close()

@@ -75,7 +75,7 @@ def test_fwdtree_kernel_full_cmudict_vocabulary(tmp_path):
     """134,865 words, 248 k tree channels, ~8 k active channels per frame: 1024 work-items per utterance"""
     import pso
     if not os.path.exists(os.path.join(pso.REF_DIR, "ref_dump")):
-        pytest.skip("oracle/_ref (compiled reference + staged data) not built")
+        pytest.fail("oracle/_ref (compiled reference + staged data) not built: run __graft_entry__.build() where /root/reference is present")
     run_isolated(ME, "impl_full_cmudict", str(tmp_path), timeout=1200)
 
 

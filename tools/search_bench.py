@@ -22,8 +22,7 @@ def main():
         # the full-vocabulary task (134,865 words): trace made on the spot by the compiled reference (oracle/_ref)
         import subprocess
         import tempfile
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        from psgb import read_psgb
+        from pocketsphinx_amd.tablefile import read_psgb
         ref = os.path.join(ROOT, "oracle", "_ref")
         out = os.path.join(tempfile.mkdtemp(), "big.psgb")
         subprocess.check_call([os.path.join(ref, "ref_dump"), "fwdtree", out, os.path.join(ref, "model", "en-us"),
