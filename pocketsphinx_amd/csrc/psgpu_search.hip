@@ -42,7 +42,10 @@
 #include <cstdio>
 #endif
 
-constexpr int kFtThreads = 256;        // work-items per utterance
+#ifndef PSGPU_FT_THREADS
+#define PSGPU_FT_THREADS 256
+#endif
+constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS layout and the medium slab layout)
 constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
 constexpr int kFtMaxBitWords = 8192;   // slab layouts: a bitmap of the listed tree nodes in LDS for trees up to 32 x this many nodes

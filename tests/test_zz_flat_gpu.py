@@ -296,9 +296,10 @@ def test_pipeline_object_runs_both_passes(tmp_path):
     p.table_capacity(1, 1, True)                          # a new object whose tables are too small for either pass: both grow
     check([3, 4, 5], 6.0)
     assert p.tables_grown() >= 2
-    # a batch of nothing but empty / sub-frame utterances: the first pass launches no search, the second pass of nothing is
-    # nothing -- empty result records, not "no first pass" (the first-pass-only path returns the same)
-    p.run([np.zeros(0, np.int16), np.zeros(100, np.int16)])
+    # a batch of nothing but empty utterances: the first pass launches no search, the second pass of nothing is nothing --
+    # empty result records, not "no first pass" (the first-pass-only path returns the same).  (A 100-sample utterance is NOT
+    # empty: fe_end_utt flushes its overflow buffer as one frame, which both passes then search.)
+    p.run([np.zeros(0, np.int16), np.zeros(0, np.int16)])
     p.second_pass(flat)
     hn, hyp, res = p.fetch()
     assert not res.any() and not hn[:, 0].any()
