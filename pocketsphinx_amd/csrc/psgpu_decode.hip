@@ -397,7 +397,10 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
     dec_mark(d, 4, st);
     if (d->ev_pre) {
         PSGPU_HIP(hipEventRecord(d->ev_pre, st));            // psgpu_decode_wait_scored
-        if (d->prev && d->prev->srch_recorded) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_srch, 0));
+        // (PSGPU_DECODE_SEARCH_OVERLAP=1: searches of the two objects may be resident together -- a measuring knob for builds of
+        //  the search kernel that leave room for a third workgroup per compute unit)
+        static const int overlap = [] { const char *e = getenv("PSGPU_DECODE_SEARCH_OVERLAP"); return e ? atoi(e) : 0; }();
+        if (!overlap && d->prev && d->prev->srch_recorded) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_srch, 0));
         PSGPU_HIP(hipEventRecord(d->ev_go, st));             // "this call's search is being dispatched": the other object's next call waits for it
         d->go_recorded = true;
     }

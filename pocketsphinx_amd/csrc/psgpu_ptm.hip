@@ -500,7 +500,12 @@ __device__ __forceinline__ int32_t logadd8_lds(const uint8_t *s_la, int32_t x, i
     return lo - (int32_t)s_la[d];
 }
 
-template <int ITERS, int kSenFr>                // kSenFr = frames per workgroup
+// SAD = true: the chain runs on values biased by kSadBias (the scores' bytes carry it), so that every intermediate is >= 0 and
+// |x - y| is ONE unsigned instruction (v_sad_u32) instead of max - min; the host selects it when the model's log-add table
+// keeps the running sums above -kSadBias (3 x its largest entry <= kSadBias; en-us: 3 x 7).  The staged row and the block
+// minimum carry 3 x kSadBias, taken off with the normaliser in the row's last pass.
+constexpr int32_t kSadBias = 64;
+template <int ITERS, int kSenFr, bool SAD>      // kSenFr = frames per workgroup
 __global__ __launch_bounds__(512)
 void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                             const uint32_t *__restrict__ topn_cw,
@@ -563,7 +568,8 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                 const int32_t b = min(kMaxNegAscr, -((sc[fr].y >> kSenscrShift) - norm));
                 const int32_t c = min(kMaxNegAscr, -((sc[fr].z >> kSenscrShift) - norm));
                 const int32_t d = min(kMaxNegAscr, -((sc[fr].w >> kSenscrShift) - norm));
-                s_sc32[fr][i] = (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+                s_sc32[fr][i] = ((uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24))
+                                + (SAD ? 0x01010101u * (uint32_t)kSadBias : 0u);       // (<= 96 + 64 a byte)
                 s_cw32[fr][i] = cw[fr];
             }
         }
@@ -588,11 +594,19 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                     for (int f = 0; f < NF; ++f) {
                         const uint32_t c4 = s_cw32[fr][cb * NF + f];
                         nsc[f] = s_sc32[fr][cb * NF + f];
+                        // (offsets as 24-bit multiply-adds -- v_mad_u32_u24, full rate -- on a 32-bit offset from the table's base:
+                        //  written as row * stride in 64 bits the compiler emits v_mad_u64_u32, a quarter-rate instruction, twelve
+                        //  times per group; the host checked that the table is smaller than 2^24 bytes)
+                        const uint32_t base = __umul24((uint32_t)f * (uint32_t)p.n_density, (uint32_t)p.slot_stride) + slot;
 #pragma unroll
                         for (int k = 0; k < N; ++k) {
-                            const uint32_t row = (uint32_t)f * p.n_density + ((c4 >> (8 * k)) & 0xff);
-                            w[f][k] = *reinterpret_cast<const uint32_t *>(
-                                p.mixw_slot + (size_t)(row * (uint32_t)p.slot_stride + slot));
+                            uint32_t off;
+#if defined(__HIP_DEVICE_COMPILE__)
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(off) : "v"(__builtin_amdgcn_ubfe(c4, 8 * k, 8)), "s"((uint32_t)p.slot_stride), "v"(base));
+#else
+                            off = ((c4 >> (8 * k)) & 0xff) * (uint32_t)p.slot_stride + base;
+#endif
+                            w[f][k] = *reinterpret_cast<const uint32_t *>(p.mixw_slot + off);
                         }
                     }
                     const uint2 sen2 = *reinterpret_cast<const uint2 *>(p.slot_sen + slot);   // 4 x uint16
@@ -616,7 +630,12 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                                                   (int32_t)((nsc[f] >> (8 * k)) & 0xff);
                                 lo_[b][f] = min(fden[b][f], y);
                                 // (signed: a running sum goes below zero when a small weight meets the best codeword --
-                                //  min - T[d] with min < T[d]; an unsigned |a - b| would then index far outside the table)
+                                //  min - T[d] with min < T[d]; an unsigned |a - b| would then index far outside the table.
+                                //  The biased form keeps every value >= 0: one v_sad_u32)
+#if defined(__HIP_DEVICE_COMPILE__)
+                                if (SAD) asm("v_sad_u32 %0, %1, %2, 0" : "=v"(dd[b][f]) : "v"(fden[b][f]), "v"(y));
+                                else
+#endif
                                 dd[b][f] = max(fden[b][f], y) - lo_[b][f];
                             }
 #pragma unroll
@@ -650,9 +669,9 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
     __syncthreads();
     for (int fr = 0; fr < nf; ++fr) {
         const int frame = f0 + fr;
-        const int32_t best = s_best[fr];
+        const int32_t best = s_best[fr] - (SAD ? 3 * kSadBias : 0);
         if (best_out && tid == 0) best_out[frame] = best;
-        const int32_t sub = (flags & PSGPU_PTM_RAW_SCORES) ? 0 : best;
+        const int32_t sub = ((flags & PSGPU_PTM_RAW_SCORES) ? 0 : best) + (SAD ? 3 * kSadBias : 0);
         int16_t *orow = senscr + (size_t)frame * p.n_sen;
         const int16_t *srow = s_out + fr * out_stride;
         if ((p.n_sen & 1) == 0) {                   // rows stay 4-byte aligned
@@ -751,6 +770,8 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
         return rc;
     }
     m->logadd8_size = logadd8_size;
+    m->la_max = 0;
+    for (int i = 0; i < logadd8_size; ++i) m->la_max = std::max<int32_t>(m->la_max, logadd8[i]);
     m->h_sen2cb = (uint8_t *)malloc((size_t)n_sen);
     memcpy(m->h_sen2cb, sen2cb, (size_t)n_sen);
     {
@@ -770,6 +791,7 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
         const size_t n_slots = slot_sen.size();
         m->slot_stride = (int32_t)(((n_slots + 63) / 64) * 64);
         const size_t rows = (size_t)n_feat * n_density;
+        if (rows * (size_t)m->slot_stride >= (1u << 24)) m->fast_shape = 0;      // (the fast senone kernel's 24-bit table offsets)
         std::vector<uint8_t> ms(rows * m->slot_stride, 255);
         for (size_t r = 0; r < rows; ++r)
             for (size_t sl = 0; sl < n_slots; ++sl)
@@ -963,19 +985,24 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
             const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(topn_cw_dev);
             PtmWorkspace *ws = ptm_workspace(m, st, false);
             int32_t *zw = (ws && ws->fix_list) ? ws->fix_list + ws->flags_cap : nullptr;
-#define PSGPU_SEN_CASE(I) case I:                                                                              \
-                if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1>), grid, block, sm, st, pv,        \
+#define PSGPU_SEN_CASE_(I, SAD) \
+                if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1, SAD>), grid, block, sm, st, pv,   \
                                        topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
-                else if (kSenFr == 4) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 4>), grid, block, sm, st, pv,   \
+                else if (kSenFr == 4) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 4, SAD>), grid, block, sm, st, pv, \
                                        topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
-                else hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 2>), grid, block, sm, st, pv,                    \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
-                break;
+                else hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 2, SAD>), grid, block, sm, st, pv,               \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);
+#define PSGPU_SEN_CASE(I) case I: if (sad) { PSGPU_SEN_CASE_(I, true) } else { PSGPU_SEN_CASE_(I, false) } break;
+            // the biased form of the log-add chain (v_sad_u32): when 3 x the table's largest entry <= the bias
+            // (PSGPU_SENONE_SAD=0: the signed form, for A/B runs and the tests of that path)
+            static const int use_sad = [] { const char *e = getenv("PSGPU_SENONE_SAD"); return e ? atoi(e) : 1; }();
+            const bool sad = use_sad && 3 * m->la_max <= kSadBias;
             switch (iters) {
                 PSGPU_SEN_CASE(1) PSGPU_SEN_CASE(2) PSGPU_SEN_CASE(3) PSGPU_SEN_CASE(4)
                 PSGPU_SEN_CASE(5) PSGPU_SEN_CASE(6) PSGPU_SEN_CASE(7) default: PSGPU_SEN_CASE(8)
             }
 #undef PSGPU_SEN_CASE
+#undef PSGPU_SEN_CASE_
             PSGPU_HIP(hipGetLastError());
             if (zw) ws->count_dirty = 0;
             return PSGPU_OK;

@@ -33,6 +33,7 @@ struct psgpu_ptm_model_s {
     uint16_t *slot_sen;           // [n_slots] senone id of a slot, 0xffff = pad
     int32_t slot_stride, n_groups;
     int32_t logadd8_size;
+    int32_t la_max;               // largest entry of the log-add table (bounds of the senone kernel's biased form)
     std::mutex ws_mu;             // guards the list below (not the workspaces: those belong to their stream)
     std::list<PtmWorkspace> ws;
     hipEvent_t ev[4];             // optional per-kernel timing: lane | fix-up | (gap) | senone (one timed caller at a time)

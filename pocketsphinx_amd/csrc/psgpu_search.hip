@@ -46,7 +46,10 @@
 #define PSGPU_FT_THREADS 256
 #endif
 constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS layout and the medium slab layout)
-constexpr int kFtThreadsBig = 1024;    // ... on trees beyond kFtBigNodes
+#ifndef PSGPU_FT_THREADS_BIG
+#define PSGPU_FT_THREADS_BIG 1024
+#endif
+constexpr int kFtThreadsBig = PSGPU_FT_THREADS_BIG;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
 constexpr int kFtMaxBitWords = 8192;   // slab layouts: a bitmap of the listed tree nodes in LDS for trees up to 32 x this many nodes
 constexpr int kFtLdsWords = 16768;     // LDS layout: at most 63 KB of arrays (dynamic LDS, + 2.4 KB fixed) per workgroup when scoring from lists; a launch
