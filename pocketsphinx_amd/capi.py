@@ -10,6 +10,13 @@ LIB_PATH = os.environ.get("PSGPU_LIB_PATH") or os.path.join(PKG_DIR, "libpsgpu.s
 CSRC = os.path.join(PKG_DIR, "csrc")
 SOURCES = ["psgpu_core.hip", "psgpu_ptm.hip", "psgpu_ptm_frame.hip", "psgpu_hmm.hip", "psgpu_semi.hip", "psgpu_ms.hip", "psgpu_feat.hip", "psgpu_fe.hip", "psgpu_search.hip", "psgpu_lm.hip", "psgpu_flat.hip", "psgpu_decode.hip"]
 
+# per-source flags (after the common ones).  The tree search is ONE kernel of ~9,000 instructions whose frame loop is a chain of
+# dependent steps: its speed follows the number of scalar values the compiler keeps alive (what does not fit the scalar registers is
+# spilled to vector-register lanes and read back with v_readlane at every use) and the size of the loop.  -O3's unrolling of its
+# `for (i = tid; i < n; i += NT)` loops -- nearly all of which run once -- buys nothing and costs both: measured on the 512 x 279-frame
+# search (round 4), -O3 6.04 ms, -O3 -fno-unroll-loops 5.47, -O1 5.42, -Os 5.20, -Oz 6.65.
+FILE_FLAGS = {"psgpu_search.hip": ["-Os"]}
+
 # every symbol include/psgpu.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "psgpu_version", "psgpu_last_error", "psgpu_device_count", "psgpu_set_device",
@@ -69,7 +76,7 @@ def build_library(force=False, extra_flags=(), lib_path=None, build_dir=None):
     def compile_one(src):
         obj = os.path.join(bdir, os.path.basename(src) + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
-            subprocess.check_call([hipcc] + flags + ["-c", src, "-o", obj])
+            subprocess.check_call([hipcc] + flags + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
         return obj
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, srcs))

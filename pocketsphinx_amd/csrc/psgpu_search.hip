@@ -30,6 +30,7 @@
 #include "psgpu_lm_dev.h"
 #include "psgpu_sen_dev.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -72,6 +73,10 @@ struct FtLay {
     int32_t word_active, word_lat_idx, lt_sf, lt_dscr, lt_bp, cand_mark;    // [n_w]
     int32_t cand_wid, cand_score, cand_bp;                                  // [n_w + 1]
     int32_t o_out, o_outh, pos, flag, o_frame;                              // [N] pruning snapshot / decisions
+    int32_t node_blk, word_blk;          // small layout: the interleaved per-node and per-word arrays (FtCol; the fields above that name their
+                                         // columns are unused there)
+    int32_t xfr, xfr_cap;                // small layout: the frame's exits [xfr_cap][n_ci + 3] = {word, real word id, previous real word id, score per
+                                         // right context phone}, in the evaluation list's words (idle after prune_word_chan)
     int32_t cnt;                         // [cnt_words] scan scratch
     int32_t cnt2, cnt3, woff;            // [n_w + 2] per-candidate / per-active-word scratch; first slot index of each active word
     int32_t ckey;                        // [n_w + 2] 64-bit (score, back-pointer) keys of the pair searches
@@ -103,6 +108,8 @@ struct FtDev {
     const int32_t *node_q1;              // [N][4] parent | ci << 24, first child (index into kids), number of children, kids_ci[first child] or -1
     const int32_t *node_q2;              // [N][4] penultimate-phone word, its last phone, its homophone link, 0
     const int32_t *node_sen;             // [N][4 or 8] the node's senone ids (sseq[node_ssid]): states 0..n_emit-1, then 0
+    const int32_t *slot_sen;             // [TOT][4 or 8] a right-context channel's senone ids (what ngram_search_alloc_all_rc gives it: sseq of
+                                         // the rssid of its word's last two phones), then 0, its transition matrix in the last word
     const int32_t *homophone, *w1_wid, *w1_ci, *w1_ci2, *w1_ssid, *w1_tmat, *w1_mpx, *w1_of_word;
     const int32_t *d_pronlen, *d_first, *d_last, *d_last2, *d_base, *d_filler;
     const int32_t *rs_n, *rs_ssid, *rs_cimap, *ldiph, *ci_tmat, *lm, *wc_off;
@@ -122,6 +129,9 @@ struct FtDev {
 
 struct FtBufs {
     int32_t *slab, *bp, *bss, *idx, *step, *res, *w1_out;
+    int32_t *bpa;                        // [n_utt][bp_cap][kBpRow] the back-pointer tables while the search runs (FtTab); bp: the caller's columns
+    int32_t *bssx;                       // LDS layout: [n_utt][bp_cap][n_ci] an exit's score for every right context phone (the score stack read through
+                                         // the context map once, when the entry is written: see the kernel's exits step), or NULL
     // scoring from the scorer's top-N lists instead of score rows (psgpu_fwdtree_search_lists_dev): tsc == NULL = rows
     const int32_t *tsc;                  // [chain][total][4] raw scores, chain-major
     const uint32_t *tcw;                 // [chain][total] four codewords packed
@@ -141,6 +151,10 @@ struct psgpu_fwdtree_s {
     std::vector<void *> allocs;
     int32_t *slab = nullptr;             // work slab, kept between calls (grown on demand)
     size_t slab_words = 0;
+    int32_t *bssx = nullptr;             // LDS layout: the exits' scores by right context phone (FtBufs::bssx), likewise
+    size_t bssx_words = 0;
+    int32_t *bpa = nullptr;              // the tables as entries while a search runs (FtBufs::bpa), likewise
+    size_t bpa_words = 0;
     int32_t *hyp_out = nullptr, *hyp_n_out = nullptr;    // psgpu_fwdtree_hyp_out: for the NEXT search call only
     int32_t hyp_max_words = 0;
     int32_t lag_next = 0;                // psgpu_fwdtree_search_lag: for the NEXT search call only
@@ -160,6 +174,22 @@ template <int NE> struct ChF {
     static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
 struct alignas(16) FtQuad { int32_t x, y, z, w; };
+// One column of a block of interleaved arrays (LDS layout: AOS, element i at word i * K of the column's base) or a plain array
+// (slab layouts).  Why interleave: this kernel's speed follows the number of scalar values it keeps alive -- the compiler gives
+// every array's base a scalar register, spills what does not fit into vector-register lanes and reads it back with v_readlane
+// wherever it is used (1,600 such reads in the LDS layout's kernel; a build with the LDS offsets as compile-time constants ran
+// 6 % faster).  The columns of a block share ONE base; a column's offset is an immediate of the LDS instruction.  K is odd: work-items
+// on consecutive elements hit different banks.
+template <bool AOS, int K, typename T = int32_t>
+struct FtCol {
+    T *b;
+    __device__ __forceinline__ T &operator[](int i) const { return AOS ? b[i * K] : b[i]; }
+};
+// the blocks' columns: per tree node / list position (N + 1 rows) and per dictionary word (n_w + 2 rows)
+enum { NC_ACL0, NC_ACL1, NC_POS, NC_OOUT, NC_OOUTH, NC_FLAG, NC_OFRAME, NC_KIDOFF, NC_PARENT, NC_CI, NC_PW, kFtNodeCols };
+enum { WC_AWL0, WC_AWL1, WC_ACTIVE, WC_LATIDX, WC_LTSF, WC_LTDSCR, WC_LTBP, WC_CMARK, WC_CWID, WC_CSCORE, WC_CBP, WC_WCOFF, WC_DFIRST, WC_DBASE,
+       WC_DLAST, WC_HOMO, WC_DFILL, kFtWordCols };
+static_assert(kFtNodeCols % 2 == 1 && kFtWordCols % 2 == 1, "odd strides");
 // Slab layouts (tree state in device memory).  What a work-group pays there is the number of cache lines it touches per
 // frame, so a tree channel is ONE 64-byte record and everything else the pruning needs is either static and shared by all
 // utterances (FtDev::node_q1 / node_q2 / node_sen: the node's parent, phone, children, penultimate word, senones) or
@@ -212,6 +242,28 @@ __device__ __forceinline__ void ch_init_enter_rec(int32_t *rec, int ssid, int tm
 #pragma unroll
     for (int i = 0; i < NE; ++i) { w[F::SCORE + i] = kW; w[F::HIST + i] = -1; w[F::SENID + i] = sseq[(size_t)ssid * NE + i]; }
     w[F::OUT] = kW; w[F::OUTH] = -1; w[F::BEST] = kW; w[F::MPX] = 0; w[F::TMAT] = tmatid;
+    w[F::SCORE] = score; w[F::HIST] = hist; w[F::FRAME] = frame;
+    FtQuad *dst = reinterpret_cast<FtQuad *>(rec);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) dst[k] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+}
+// the same with the channel's senone ids and transition matrix given (FtDev::slot_sen: one static quad or two instead of the chain
+// last two phones -> rssid -> sseq, three dependent trips to device memory)
+template <int NE>
+__device__ __forceinline__ void ch_init_enter_rec_s(int32_t *rec, const int32_t *slot_sen, int32_t score, int32_t hist, int frame)
+{
+    using F = ChF<NE>;
+    constexpr int NQ = (F::WORDS + 3) / 4, NS = NE <= 3 ? 4 : 8;
+    int32_t sq[NS];
+    const FtQuad *src = reinterpret_cast<const FtQuad *>(slot_sen);
+#pragma unroll
+    for (int k = 0; k < NS / 4; ++k) { const FtQuad q = src[k]; sq[4 * k] = q.x; sq[4 * k + 1] = q.y; sq[4 * k + 2] = q.z; sq[4 * k + 3] = q.w; }
+    int32_t w[4 * NQ];
+#pragma unroll
+    for (int i = 0; i < 4 * NQ; ++i) w[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { w[F::SCORE + i] = kW; w[F::HIST + i] = -1; w[F::SENID + i] = sq[i]; }
+    w[F::OUT] = kW; w[F::OUTH] = -1; w[F::BEST] = kW; w[F::MPX] = 0; w[F::TMAT] = sq[NS - 1];
     w[F::SCORE] = score; w[F::HIST] = hist; w[F::FRAME] = frame;
     FtQuad *dst = reinterpret_cast<FtQuad *>(rec);
 #pragma unroll
@@ -338,12 +390,17 @@ template <int NE>
 __device__ __forceinline__ FtQuad ch_summary(const int32_t *rec) { return *reinterpret_cast<const FtQuad *>(rec + ChF<NE>::OUT); }
 
 // ---- the back-pointer table ------------------------------------------------------------------------------------------
+// While a search runs its table is an array of ENTRIES, sixteen words (one 64-byte line) each: everything a step asks about an
+// entry -- frame, score, last phones; validity and real word ids -- comes in one line and through one base pointer, a column's offset
+// being an immediate of the load (in the reference's column arrays, bptbl_t, ngram_search.h:112-124, an entry's fields are ten
+// lines behind ten base pointers).  The kernel's last step copies the entries into the caller's columns (ft_table_out).
+constexpr int kBpRow = 16;
 struct FtTab {
-    int32_t *bp, *bss, *idx;
+    int32_t *bp, *bss, *idx;             // bp: [bp_cap][kBpRow]
     int32_t bp_cap, bss_cap;
 };
-#define BPC(t, col, i) ((t).bp[(size_t)(col) * (t).bp_cap + (i)])
-enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2 };
+#define BPC(t, col, i) ((t).bp[(size_t)(i) * kBpRow + (col)])
+enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2, kBpCols };
 
 __device__ __forceinline__ int32_t ft_lm(const FtDev &p, const int32_t *lmtab, int w3, int w2, int w1)
 {
@@ -372,6 +429,15 @@ __device__ __forceinline__ int32_t ft_exit_score_bf(const FtTab &t, const int32_
     const int32_t ss = t.bss[max(sidx, 0) + max(cm, 0)];
     return l2 == -1 ? score : ss;
 }
+// The same through the table of the exits' scores by right context phone (FtBufs::bssx, LDS layout): the entry's columns and its
+// score for `rcphone` in ONE trip -- the context map was applied when the entry was written.  Single-phone entries (last2 == -1)
+// have no row: what is read there is dropped.
+__device__ __forceinline__ int32_t ft_exit_score_x(const FtTab &t, const int32_t *bssx, int n_ci, int bp, int rcphone)
+{
+    const int32_t score = BPC(t, B_SCORE, bp), l2 = BPC(t, B_LAST2, bp);
+    const int32_t xs = bssx[(size_t)bp * n_ci + rcphone];
+    return l2 == -1 ? score : xs;
+}
 // the dense language-model table's entry (p.use_trie == 0), an unconditional load
 __device__ __forceinline__ int32_t ft_lm_dense(const FtDev &p, const int32_t *lmtab, int w3, int w2, int w1)
 {
@@ -394,7 +460,8 @@ __device__ __forceinline__ void ft_set_real_wid(const FtTab &t, const int32_t *d
 // the static per-word tables save_bp reads
 struct FtDict { const int32_t *d_pronlen, *d_last, *d_last2, *d_base, *d_filler, *rs_n; int n_ci; };
 // ngram_search_save_bp, ngram_search.c:376-498 (single thread).  Returns false when a table is full.
-__device__ __forceinline__ bool ft_save_bp(const FtTab &t, const FtDict &d, int32_t *word_lat_idx, int32_t &bpidx, int32_t &bss_head,
+template <typename WL>
+__device__ __forceinline__ bool ft_save_bp(const FtTab &t, const FtDict &d, const WL &word_lat_idx, int32_t &bpidx, int32_t &bss_head,
                                            int frame, int w, int32_t score, int32_t path, int rc)
 {
     const int bp = word_lat_idx[w];
@@ -435,9 +502,15 @@ __device__ __forceinline__ bool ft_save_bp(const FtTab &t, const FtDict &d, int3
 // (:546-581, 903-1010) over ONE utterance's table, by one work-item.  hyp [max_words][4] = wid, start frame, end frame, path
 // score at the word's end, in spoken order; hn [4] = number of words (may exceed max_words: then only the LAST max_words are
 // stored), path score of the exit, exit back-pointer, 0.
-__device__ __forceinline__ void ft_backtrace_one(const FtTab &tb, const int32_t *idx, int n_frame, int finish_wid, int max_words,
+// (TB: a table whose fields BPX(tb, col, i) reads -- the kernel's entries or the caller's columns)
+struct FtTabCols { const int32_t *bp; int32_t bp_cap; };
+__device__ __forceinline__ int32_t ft_tab_get(const FtTab &t, int col, int i) { return BPC(t, col, i); }
+__device__ __forceinline__ int32_t ft_tab_get(const FtTabCols &t, int col, int i) { return t.bp[(size_t)col * t.bp_cap + i]; }
+template <typename TB>
+__device__ __forceinline__ void ft_backtrace_one(const TB &tb, const int32_t *idx, int n_frame, int finish_wid, int max_words,
                                                  int32_t *hyp, int32_t *hn)
 {
+#define BPX(t, col, i) ft_tab_get(t, col, i)
     hn[0] = 0; hn[1] = kW; hn[2] = -1; hn[3] = 0;
     if (n_frame == 0) return;
     int f = n_frame - 1;
@@ -446,21 +519,22 @@ __device__ __forceinline__ void ft_backtrace_one(const FtTab &tb, const int32_t 
     if (f < 0) return;
     int best = -1; int32_t best_score = kW;
     for (int bp = idx[f]; bp < end; ++bp) {
-        const int wid = BPC(tb, B_WID, bp);
-        if (wid == finish_wid || BPC(tb, B_SCORE, bp) > best_score) { best_score = BPC(tb, B_SCORE, bp); best = bp; }
+        const int wid = BPX(tb, B_WID, bp);
+        if (wid == finish_wid || BPX(tb, B_SCORE, bp) > best_score) { best_score = BPX(tb, B_SCORE, bp); best = bp; }
         if (wid == finish_wid) break;
     }
     int n = 0;
-    for (int b = best; b != -1; b = BPC(tb, B_BP, b)) ++n;
+    for (int b = best; b != -1; b = BPX(tb, B_BP, b)) ++n;
     hn[0] = n; hn[1] = best_score; hn[2] = best;
     int k = n - 1;
     const int skip = n > max_words ? n - max_words : 0;
     for (int b = best; b != -1 && k >= skip; --k) {
-        const int prev = BPC(tb, B_BP, b);
+        const int prev = BPX(tb, B_BP, b);
         int32_t *h = hyp + (size_t)(k - skip) * 4;
-        h[0] = BPC(tb, B_WID, b); h[1] = prev == -1 ? 0 : BPC(tb, B_FRAME, prev) + 1; h[2] = BPC(tb, B_FRAME, b); h[3] = BPC(tb, B_SCORE, b);
+        h[0] = BPX(tb, B_WID, b); h[1] = prev == -1 ? 0 : BPX(tb, B_FRAME, prev) + 1; h[2] = BPX(tb, B_FRAME, b); h[3] = BPX(tb, B_SCORE, b);
         b = prev;
     }
+#undef BPX
 }
 
 // Workgroup barrier for data exchanged through LDS only: waits for this wave's LDS operations, not for its outstanding
@@ -717,7 +791,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     if (tid == 0) { for (int i = 0; i < 48; ++i) s_prof[i] = 0; s_last = clock64(); }
 #endif
     const int N = p.N, R = p.R, n1 = p.n1, n_ci = p.n_ci;
+#ifdef PSGPU_FT_FIXLAY                     /* (a measuring build: the LDS layout of ONE task as compile-time constants) */
+    static constexpr FtLay kFixLay = PSGPU_FT_FIXLAY;
+    const FtLay &L = SMALL ? kFixLay : p.lay;
+#else
     const FtLay &L = p.lay;
+#endif
 
     // ---- pointers.  Everything the host handed over is global memory (psgpu_as_global: see psgpu_internal.h).
     const int16_t *const senscr = psgpu_as_global(senscr_);
@@ -726,14 +805,26 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     int32_t *const gs = psgpu_as_global(bf.slab) + (size_t)blockIdx.x * p.per;
     int32_t *const fb = SMALL ? s_pool : gs + p.g_fast;
     constexpr int TREC = F::REC;
-    const ChView tv = { fb + L.rec, SMALL ? 1 : TREC, SMALL ? p.CH : 1 };         // tree nodes [0, N), single-phone words [N, N + n1)
+    // (LDS layout: records of F::WORDS = 3 NE + 6 words side by side -- an odd stride, so consecutive channels still hit different
+    //  banks, and a field's offset is an immediate of the LDS instruction instead of field x channels held in a scalar register: this
+    //  kernel's speed follows the number of scalar values it keeps alive)
+    const ChView tv = { fb + L.rec, SMALL ? F::WORDS : TREC, 1 };                 // tree nodes [0, N), single-phone words [N, N + n1)
     const ChView wv = { gs + p.g_wrec, F::REC, 1 };                               // last-phone slots [0, TOT)
-    int32_t *const word_active = fb + L.word_active, *const word_lat_idx = fb + L.word_lat_idx, *const lt_sf = fb + L.lt_sf,
-            *const lt_dscr = fb + L.lt_dscr, *const lt_bp = fb + L.lt_bp, *const cand_mark = fb + L.cand_mark,
-            *const cand_wid = fb + L.cand_wid, *const cand_score = fb + L.cand_score, *const cand_bp = fb + L.cand_bp,
-            *const o_out = fb + L.o_out, *const o_outh = fb + L.o_outh, *const pos = fb + L.pos, *const flag = fb + L.flag,
-            *const o_frame = fb + L.o_frame, *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3,
-            *const woff = fb + L.woff;
+    // (LDS layout: columns of the two interleaved blocks, see FtCol; slab layouts: arrays of the utterance's slab)
+    int32_t *const nodeA = fb + L.node_blk, *const wordA = fb + L.word_blk;
+    using NCol = FtCol<SMALL, kFtNodeCols>;
+    using WCol = FtCol<SMALL, kFtWordCols>;
+    using NColC = FtCol<SMALL, kFtNodeCols, const int32_t>;
+    using WColC = FtCol<SMALL, kFtWordCols, const int32_t>;
+    const WCol word_active = { SMALL ? wordA + WC_ACTIVE : fb + L.word_active }, word_lat_idx = { SMALL ? wordA + WC_LATIDX : fb + L.word_lat_idx },
+               lt_sf = { SMALL ? wordA + WC_LTSF : fb + L.lt_sf }, lt_dscr = { SMALL ? wordA + WC_LTDSCR : fb + L.lt_dscr },
+               lt_bp = { SMALL ? wordA + WC_LTBP : fb + L.lt_bp }, cand_mark = { SMALL ? wordA + WC_CMARK : fb + L.cand_mark },
+               cand_wid = { SMALL ? wordA + WC_CWID : fb + L.cand_wid }, cand_score = { SMALL ? wordA + WC_CSCORE : fb + L.cand_score },
+               cand_bp = { SMALL ? wordA + WC_CBP : fb + L.cand_bp };
+    const NCol o_out = { SMALL ? nodeA + NC_OOUT : fb + L.o_out }, o_outh = { SMALL ? nodeA + NC_OOUTH : fb + L.o_outh },
+               pos = { SMALL ? nodeA + NC_POS : fb + L.pos }, flag = { SMALL ? nodeA + NC_FLAG : fb + L.flag },
+               o_frame = { SMALL ? nodeA + NC_OFRAME : fb + L.o_frame };
+    int32_t *const cnt = fb + L.cnt, *const cnt2 = fb + L.cnt2, *const cnt3 = fb + L.cnt3, *const woff = fb + L.woff;
     // the frame's evaluation list: 16-bit entries in the LDS layout (channel index < 2^15, or 0x8000 | active word << 6 | right
     // context: the host checked n_w <= 512, n_ci <= 64) so that a list of EVERY channel fits the pool -- it cannot overflow
     using EvT = typename std::conditional<SMALL, uint16_t, int32_t>::type;
@@ -761,7 +852,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const uint32_t *const tcw = psgpu_as_global(bf.tcw);
     uint8_t *const present = reinterpret_cast<uint8_t *>(fb + L.present);
     FtTab tb;
-    tb.bp = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * 10 * bf.bp_cap; tb.bss = psgpu_as_global(bf.bss) + (size_t)blockIdx.x * bf.bss_cap;
+    tb.bp = psgpu_as_global(bf.bpa) + (size_t)blockIdx.x * bf.bp_cap * kBpRow; tb.bss = psgpu_as_global(bf.bss) + (size_t)blockIdx.x * bf.bss_cap;
     tb.idx = psgpu_as_global(bf.idx) + (size_t)blockIdx.x * (bf.max_frames + 2);
     tb.bp_cap = bf.bp_cap; tb.bss_cap = bf.bss_cap;
     int32_t *const step = psgpu_as_global(bf.step) + (size_t)blockIdx.x * bf.max_frames * 4;
@@ -786,39 +877,47 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const FtQuad *const node_q1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q1)),
                  *const node_q2 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q2));
     const int32_t *const node_sen = psgpu_as_global(p.node_sen);
+    const int32_t *const slot_sen = psgpu_as_global(p.slot_sen);
     FtQuad *const itb = reinterpret_cast<FtQuad *>(fb + L.itb);        // slab layouts only
     int32_t *const actl = fb + L.act;                                  // slab layouts only
     const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
     // the tree's structure: LDS copies in the small layout
-    const int32_t *const kid_off = SMALL ? fb + L.kid_off : psgpu_as_global(p.kid_off), *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids),
-                  *const parent = SMALL ? fb + L.parent : psgpu_as_global(p.parent), *const node_ci = SMALL ? fb + L.ci : psgpu_as_global(p.node_ci),
-                  *const node_pw = SMALL ? fb + L.pw : psgpu_as_global(p.node_pw),
-                  *const wc_off = SMALL ? fb + L.wc_off : psgpu_as_global(p.wc_off);
+    const int32_t *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids);
+    const NColC kid_off = { SMALL ? nodeA + NC_KIDOFF : psgpu_as_global(p.kid_off) }, parent = { SMALL ? nodeA + NC_PARENT : psgpu_as_global(p.parent) },
+                node_ci = { SMALL ? nodeA + NC_CI : psgpu_as_global(p.node_ci) }, node_pw = { SMALL ? nodeA + NC_PW : psgpu_as_global(p.node_pw) };
+    const WColC wc_off = { SMALL ? wordA + WC_WCOFF : psgpu_as_global(p.wc_off) };
     // the words' first phones / base ids and the single-phone words' ids: LDS copies in the small layout (the pair searches'
     // first trip to device memory is then the back-pointer entries' alone)
-    const int32_t *const dfirst_f = SMALL ? fb + L.dfirst : d_first, *const dbase_f = SMALL ? fb + L.dbase : d_base,
-                  *const w1w_f = SMALL ? fb + L.w1w : w1_wid, *const dlast_f = SMALL ? fb + L.dlast : d_last,
-                  *const homo_f = SMALL ? fb + L.homo : homophone, *const w1ci_f = SMALL ? fb + L.w1ci : w1_ci,
-                  *const w1ci2_f = SMALL ? fb + L.w1ci2 : w1_ci2, *const dfill_f = SMALL ? fb + L.dfill : d_filler;
+    const WColC dfirst_f = { SMALL ? wordA + WC_DFIRST : d_first }, dbase_f = { SMALL ? wordA + WC_DBASE : d_base },
+                dlast_f = { SMALL ? wordA + WC_DLAST : d_last }, homo_f = { SMALL ? wordA + WC_HOMO : homophone },
+                dfill_f = { SMALL ? wordA + WC_DFILL : d_filler };
+    const int32_t *const w1w_f = SMALL ? fb + L.w1w : w1_wid, *const w1ci_f = SMALL ? fb + L.w1ci : w1_ci, *const w1ci2_f = SMALL ? fb + L.w1ci2 : w1_ci2;
     if (SMALL) {
         for (int i = tid; i < p.n_w; i += NT) {
-            fb[L.dfirst + i] = d_first[i]; fb[L.dbase + i] = d_base[i]; fb[L.dlast + i] = d_last[i]; fb[L.homo + i] = homophone[i];
-            fb[L.dfill + i] = d_filler[i];
+            int32_t *const r = wordA + i * kFtWordCols;
+            r[WC_DFIRST] = d_first[i]; r[WC_DBASE] = d_base[i]; r[WC_DLAST] = d_last[i]; r[WC_HOMO] = homophone[i]; r[WC_DFILL] = d_filler[i];
         }
         for (int i = tid; i < n1; i += NT) { fb[L.w1w + i] = w1_wid[i]; fb[L.w1ci + i] = w1_ci[i]; fb[L.w1ci2 + i] = w1_ci2[i]; }
     }
     if (SMALL) {
         const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_k = psgpu_as_global(p.kids), *const g_p = psgpu_as_global(p.parent),
                       *const g_c = psgpu_as_global(p.node_ci), *const g_w = psgpu_as_global(p.node_pw);
-        for (int i = tid; i <= N; i += NT) fb[L.kid_off + i] = g_ko[i];
+        for (int i = tid; i <= N; i += NT) nodeA[i * kFtNodeCols + NC_KIDOFF] = g_ko[i];
         for (int i = tid; i < p.M; i += NT) fb[L.kids + i] = g_k[i];
-        for (int i = tid; i < N; i += NT) { fb[L.parent + i] = g_p[i]; fb[L.ci + i] = g_c[i]; fb[L.pw + i] = g_w[i]; }
+        for (int i = tid; i < N; i += NT) { int32_t *const r = nodeA + i * kFtNodeCols; r[NC_PARENT] = g_p[i]; r[NC_CI] = g_c[i]; r[NC_PW] = g_w[i]; }
         const int32_t *const g_o = psgpu_as_global(p.wc_off);
-        for (int i = tid; i <= p.n_w; i += NT) fb[L.wc_off + i] = g_o[i];
+        for (int i = tid; i <= p.n_w; i += NT) wordA[i * kFtWordCols + WC_WCOFF] = g_o[i];
         const uint8_t *const g_tp = psgpu_as_global(p.tp);
         uint8_t *const l_tp = reinterpret_cast<uint8_t *>(fb + L.tp);
         for (int i = tid; i < p.n_tmat * NE * (NE + 1); i += NT) l_tp[i] = g_tp[i];
     }
+    // small layout: the frame's exits in LDS (in the evaluation list's words, idle after prune_word_chan) and every exit's score by
+    // right context phone in device memory -- see the exits step
+    constexpr int32_t kXSingle = 0x40000000;                             // xfr word 0: a single-phone word's entry (one score, word 3)
+    int32_t *const xfr = fb + L.xfr;
+    const int xst = n_ci + 3, xcap = SMALL ? L.xfr_cap : 0;
+    int32_t *const bssx = (SMALL && bf.bssx) ? psgpu_as_global(bf.bssx) + (size_t)blockIdx.x * bf.bp_cap * n_ci : nullptr;
+    __shared__ int32_t s_xbad;                                           // an entry of the frame is not in xfr as the word transitions expect it
     int16_t *const s_row = reinterpret_cast<int16_t *>(fb + L.row);       // small layout only
     int32_t *const s_pen = fb + L.pen;                                      // small layout only: [2][n_ci]
 
@@ -936,8 +1035,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1;
-        int32_t *const aclc = fb + (cur ? L.acl1 : L.acl0), *const acln = fb + (cur ? L.acl0 : L.acl1);
-        int32_t *const awlc = fb + (cur ? L.awl1 : L.awl0), *const awln = fb + (cur ? L.awl0 : L.awl1);
+        const NCol aclc = { SMALL ? nodeA + (cur ? NC_ACL1 : NC_ACL0) : fb + (cur ? L.acl1 : L.acl0) },
+                   acln = { SMALL ? nodeA + (cur ? NC_ACL0 : NC_ACL1) : fb + (cur ? L.acl0 : L.acl1) };
+        const WCol awlc = { SMALL ? wordA + (cur ? WC_AWL1 : WC_AWL0) : fb + (cur ? L.awl1 : L.awl0) },
+                   awln = { SMALL ? wordA + (cur ? WC_AWL0 : WC_AWL1) : fb + (cur ? L.awl0 : L.awl1) };
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
         // (slab layouts: the frame's penalty row is copied to LDS here -- its last readers, the previous frame's word
         //  transitions, are behind a barrier; its first reader, the pruning, is behind the barriers below)
@@ -961,7 +1062,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         auto ft_pen = [&](int ci) { return p.has_pl ? pp[ci] : 0; };
         if (lists) lists_pack();                             // this frame's lists (read after the next barrier)
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:1467-1480)
-        if (tid == 0) tb.idx[f] = s_sc[3];                    // (s_nev was zeroed before the previous frame's last barrier)
+        if (tid == 0) { tb.idx[f] = s_sc[3]; s_xbad = 0; }     // (s_nev was zeroed before the previous frame's last barrier)
         const int32_t best_in = s_sc[0];
         if (best_in == kW || best_in < kW) break;
         const int32_t bp0 = s_sc[3];                          // this frame's first back-pointer
@@ -1174,7 +1275,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 else {
                     const int32_t sc = SMALL ? ch_eval<NE>(tv, c, sr, tpall, sseq) : ch_eval_rec<NE>(tv.b + (size_t)c * TREC, sr, tpall, sseq);
                     if (c < W1) b_all = max(b_all, sc);
-                    else if (w1_wid[c - W1] != p.finishwid) { b_all = max(b_all, sc); b_word = max(b_word, sc); }   // (:688-694: </s> never sets the best score)
+                    else if (w1w_f[c - W1] != p.finishwid) { b_all = max(b_all, sc); b_word = max(b_word, sc); }   // (:688-694: </s> never sets the best score)
                 }
             }
             FT_PROF(18);
@@ -1625,19 +1726,17 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //      cache keyed by start frame.  Should two candidates ever share a word, the reference's loops are run as
         //      written by one thread.
         const int n_cand = s_sc[5];
-        for (int i = tid; i < n_cand; i += NT)               // O(1) per candidate: the frame stamp of the word
-            if (atomicExch(&cand_mark[cand_wid[i]], f) == f) s_red[7] = 1;
-        ft_sync<SMALL>();
-        // (two candidates naming one word would need two paths to that word in the tree: create_search_channels builds
-        //  one per dictionary entry.  The reference's loops would cope; here it ends the utterance with status 3.)
-        if (s_red[7] != 0) { if (tid == 0) s_sc[6] = 3; ft_sync<SMALL>(); break; }
         {
             for (int i = tid; i < n_cand; i += NT) {
                 const int cb = cand_bp[i], w = cand_wid[i];
+                // O(1) per candidate: the frame stamp of the word.  (Two candidates naming one word would need two paths to that word
+                // in the tree: create_search_channels builds one per dictionary entry.  The reference's loops would cope; here it ends
+                // the utterance with status 3 -- looked at behind this step's barrier, nothing in between is kept.)
+                if (atomicExch(&cand_mark[w], f) == f) s_red[7] = 1;
                 int need = 0, b0 = 0, sf = -1;
                 if (cb != -1) {
                     const int ef = BPC(tb, B_FRAME, cb);                 // (one trip with the exit score's columns)
-                    cand_score[i] -= ft_exit_score_bf(tb, rs_cimap, n_ci, cb, dfirst_f[w]);
+                    cand_score[i] -= bssx ? ft_exit_score_x(tb, bssx, n_ci, cb, dfirst_f[w]) : ft_exit_score_bf(tb, rs_cimap, n_ci, cb, dfirst_f[w]);
                     if (lt_sf[w] != ef + 1) { b0 = tb.idx[ef]; need = tb.idx[ef + 1] - b0; sf = ef + 1; }
                 }
                 cnt[i] = need; cnt2[i] = b0; cnt3[i] = sf;
@@ -1645,6 +1744,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             if (tid == 0) cnt[n_cand] = 0;
             ft_sync<SMALL>();
+            if (s_red[7] != 0) { if (tid == 0) s_sc[6] = 3; ft_sync<SMALL>(); break; }
             const int n_pair = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
             FT_PROF(29);
             for (int j = tid; j < n_pair; j += NT) {
@@ -1652,7 +1752,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 // (every load of the pair before the first test: three trips to device memory -- the entry's columns; context map
                 //  and language-model entry; stacked score -- where the tests in between made seven)
                 const int32_t valid = BPC(tb, B_VALID, bp), real = BPC(tb, B_REAL, bp), preal = BPC(tb, B_PREAL, bp);
-                int32_t dscr = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, dfirst_f[w]);
+                int32_t dscr = bssx ? ft_exit_score_x(tb, bssx, n_ci, bp, dfirst_f[w]) : ft_exit_score_bf(tb, rs_cimap, n_ci, bp, dfirst_f[w]);
                 const int32_t lmv = p.use_trie ? 0 : ft_lm_dense(p, lmtab, dbase_f[w], real, preal);
                 if (!valid) continue;
                 if (dscr > kW) dscr += p.use_trie ? ft_lm(p, lmtab, dbase_f[w], real, preal) : lmv;
@@ -1699,8 +1799,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (!present[slot]) {
                         // ngram_search_alloc_all_rc (ngram_search.c:583-633), then hmm_enter into the cleared channel (its frame
                         // is -1: the test below always passes): the whole record is written at once
-                        const int last = dlast_f[w], last2 = d_last2[w];
-                        ch_init_enter_rec<NE>(rec, rs_ssid[((size_t)last * n_ci + last2) * n_ci + r], ci_tmat[last], sseq, cand_score[i], cand_bp[i], nf);
+                        ch_init_enter_rec_s<NE>(rec, slot_sen + (size_t)slot * (NE <= 3 ? 4 : 8), cand_score[i], cand_bp[i], nf);
                         present[slot] = 1;
                         cnt2[i] = 1;
                     }
@@ -1789,6 +1888,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int e = tid >> 6; e < n_exit; e += NT / 64) {
                     const int i = ft_seg_find(w_bp, naw, e), w = awlc[i], j0 = w_bss[i], nrc = w_bss[i + 1] - j0, bpi = bpidx + e;
                     const int32_t w_last2 = d_last2[w], w_filler = d_filler[w];      // (asked for with the channels' records, not after the merge)
+                    // small layout: the row of the context map that ngram_search_exit_score (ngram_search.c:653-674) would read for this
+                    // entry later, right context phone by right context phone -- read ONCE, now, beside the channels' records
+                    int32_t cmrow = 0;
+                    if (SMALL && lane < n_ci) cmrow = rs_cimap[((size_t)dlast_f[w] * n_ci + w_last2) * n_ci + lane];
                     int32_t it[4] = { kW, -1, -1, -1 };          // out score, history, its real / prev_real wid
                     if (lane < nrc) {
                         const int slot = wc_off[w] + lane;
@@ -1814,6 +1917,21 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (dm) src = 63 - __clzll((long long)(m & ((1ull << (63 - __clzll((long long)dm))) - 1ull)));
                     const int32_t S = ft_lane(it[0], last), P = ft_lane(it[1], last);
                     const int32_t rw_real = ft_lane(it[2], src), rw_preal = ft_lane(it[3], src);
+                    if (SMALL) {
+                        // the entry's exit score for every right context phone (= its score-stack segment seen through the context map):
+                        // to device memory for the predecessor searches of later frames, to LDS for this frame's word transitions
+                        const int32_t xs = __shfl(it[0], cmrow);
+                        if (lane < n_ci) {
+                            if (bssx) bssx[(size_t)bpi * n_ci + lane] = xs;
+                            if (bpi - bp0 < xcap) xfr[(bpi - bp0) * xst + 3 + lane] = xs;
+                        }
+                        if (lane == 0 && bpi - bp0 < xcap) {
+                            int32_t *const x = xfr + (bpi - bp0) * xst;
+                            x[0] = w;
+                            x[1] = w_filler ? (rw_real != -1 ? rw_real : dbase_f[w]) : dbase_f[w];
+                            x[2] = w_filler ? (rw_real != -1 ? rw_preal : -1) : rw_real;
+                        }
+                    }
                     if (lane == 0) {
                         word_lat_idx[w] = bpi;
                         BPC(tb, B_WID, bpi) = w; BPC(tb, B_FRAME, bpi) = f; BPC(tb, B_BP, bpi) = P; BPC(tb, B_SCORE, bpi) = S;
@@ -1843,7 +1961,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (tv.at(c, F::FRAME) >= f && tv.at(c, F::BEST) > lpth) {
                         tv.at(c, F::FRAME) = nf;
                         if (tv.at(c, F::OUT) > nwt) {
-                            const int w = w1_wid[i];
+                            const int w = w1w_f[i];
                             ex = 1;
                             if (word_lat_idx[w] == -1) nw = 1;   // (a single-phone word has no right-context fan-out: rcn stays 0,
                                                                   //  dict_is_single_phone = pronunciation length 1)
@@ -1888,8 +2006,18 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                             BPC(tb, B_PREAL, bpi) = path != -1 ? pp : -1;
                         }
                         else { BPC(tb, B_REAL, bpi) = dbase_f[w]; BPC(tb, B_PREAL, bpi) = path != -1 ? pr : -1; }
+                        if (SMALL && bpi - bp0 < xcap) {
+                            int32_t *const x = xfr + (bpi - bp0) * xst;
+                            x[0] = w | kXSingle;
+                            x[1] = dfill_f[w] ? (path != -1 ? pr : dbase_f[w]) : dbase_f[w];
+                            x[2] = dfill_f[w] ? (path != -1 ? pp : -1) : (path != -1 ? pr : -1);
+                            x[3] = score;
+                        }
                     }
-                    else if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w, score, path, 0)) s_sc[6] = 1;
+                    else {
+                        if (SMALL) s_xbad = 1;                   // (the general routine: this frame's word transitions read the table itself)
+                        if (!ft_save_bp(tb, dict, word_lat_idx, bpi, bsh, f, w, score, path, 0)) s_sc[6] = 1;
+                    }
                 }
             FT_PROF(21);
             // (bptable_maxwpf, when it applies, reads the frame's entries: a full barrier.  Otherwise nothing between here and
@@ -1933,18 +2061,36 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         FT_PROF(23);
         if (s_sc[6]) break;
         const int bp1 = s_sc[3], nbp = bp1 - bp0;
+        // small layout: the frame's entries are in LDS (xfr: word, real word ids, score per right context phone) when there are no
+        // more than it holds, every one was written by the two fast paths above and bptable_maxwpf does not apply (it clears
+        // `valid` flags): the pair searches below then go to device memory for the language model only
+        const bool use_x = SMALL && nbp <= xcap && !s_xbad && (p.maxwpf == -1 || p.maxwpf == p.n_w);
         for (int j = tid; j < nbp * n_ci; j += NT) {
             // (the entry's columns in one trip, context map, stacked score: three, not five)
-            const int bp = bp0 + j / n_ci, rc = j % n_ci, wid = BPC(tb, B_WID, bp);
-            const int32_t sc = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, rc);
+            const int bp = bp0 + j / n_ci, rc = j % n_ci;
+            int wid; int32_t sc;
+            if (use_x) {
+                const int32_t *const x = xfr + (j / n_ci) * xst;
+                const int32_t x0 = x[0];
+                wid = x0 & 0xffffff; sc = (x0 & kXSingle) ? x[3] : x[3 + rc];
+            }
+            else { wid = BPC(tb, B_WID, bp); sc = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, rc); }
             if (rc == 0) { word_lat_idx[wid] = -1; if (wid != p.finishwid) atomicAdd(&s_red[6], 1); }
             if (wid == p.finishwid) continue;
             if (sc > kW) atomicMax(&brc_key[rc], ft_key(sc, bp));
         }
         for (int j = tid; j < p.n1lm * nbp; j += NT) {             // in-LM single-phone words (:1331-1388): best predecessor
             const int i = j / nbp, bp = bp0 + j % nbp, w = w1w_f[i];
-            const int32_t valid = BPC(tb, B_VALID, bp), real = BPC(tb, B_REAL, bp), preal = BPC(tb, B_PREAL, bp);
-            int32_t ns = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, dfirst_f[w]);
+            int32_t valid, real, preal, ns;
+            if (use_x) {
+                const int32_t *const x = xfr + (j % nbp) * xst;
+                const int32_t x0 = x[0];
+                valid = 1; real = x[1]; preal = x[2]; ns = (x0 & kXSingle) ? x[3] : x[3 + dfirst_f[w]];
+            }
+            else {
+                valid = BPC(tb, B_VALID, bp); real = BPC(tb, B_REAL, bp); preal = BPC(tb, B_PREAL, bp);
+                ns = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, dfirst_f[w]);
+            }
             const int32_t lmv = p.use_trie ? 0 : ft_lm_dense(p, lmtab, dbase_f[w], real, preal);
             if (!valid) continue;
             if (ns != kW) ns += p.use_trie ? ft_lm(p, lmtab, dbase_f[w], real, preal) : lmv;
@@ -1957,7 +2103,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const unsigned long long k = brc_key[rc];
             const bool none = ft_key_none(k);
             const int path = none ? 0 : ft_key_bp(k);
-            brc_score[rc] = none ? kW : ft_key_score(k); brc_path[rc] = path; brc_lc[rc] = none ? 0 : BPC(tb, B_LAST, path);
+            brc_score[rc] = none ? kW : ft_key_score(k); brc_path[rc] = path;
+            // (an entry's last phone is its word's: ngram_search_save_bp, ngram_search.c:461)
+            brc_lc[rc] = none ? 0 : (use_x ? dlast_f[xfr[(path - bp0) * xst] & 0xffffff] : BPC(tb, B_LAST, path));
         }
         ft_sync<SMALL>();
         FT_PROF(25);
@@ -1983,7 +2131,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     const unsigned long long kk = ckey[i];
                     const int32_t ds = ft_key_none(kk) ? kMaxNegInt32 : ft_key_score(kk);
                     const int dbp = ft_key_none(kk) ? 0 : ft_key_bp(kk);
-                    const int pw = BPC(tb, B_WID, dbp);      // (asked for before the tests: the frame has entries, entry 0 exists)
+                    // (asked for before the tests: the frame has entries, entry 0 exists)
+                    const int pw = (use_x && !ft_key_none(kk)) ? (xfr[(dbp - bp0) * xst] & 0xffffff) : BPC(tb, B_WID, dbp);
                     lt_dscr[w] = ds; lt_bp[w] = dbp;
                     if (w == p.startwid) continue;
                     const int c = W1 + i;
@@ -2031,7 +2180,18 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #ifdef PSGPU_FT_PROFILE
     if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
-    if (bf.hyp) __syncthreads();                                 // the table's last entries (device memory, other work-items') before the backtrace
+    __syncthreads();                                             // the table's last entries (device memory, other work-items') before the copy and the backtrace
+    {   // the table in the caller's columns (bptbl_t, ngram_search.h:112-124): ft_table_out
+        int32_t *const out = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * kBpCols * bf.bp_cap;
+        const int n_bp = s_sc[3];
+        for (int j = tid; j < n_bp * 4; j += NT) {               // (a quad of an entry per work-item)
+            const int i = j >> 2, q = j & 3;
+            if (q == 3) continue;                                // (words 12-15: unused)
+            const FtQuad v = *reinterpret_cast<const FtQuad *>(tb.bp + (size_t)i * kBpRow + 4 * q);
+            out[(size_t)(4 * q) * bf.bp_cap + i] = v.x; out[(size_t)(4 * q + 1) * bf.bp_cap + i] = v.y;
+            if (q < 2) { out[(size_t)(4 * q + 2) * bf.bp_cap + i] = v.z; out[(size_t)(4 * q + 3) * bf.bp_cap + i] = v.w; }
+        }
+    }
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
         result[0] = s_sc[3]; result[1] = s_sc[4]; result[2] = s_sc[7]; result[3] = s_sc[6];
@@ -2071,9 +2231,7 @@ __global__ void fwdtree_backtrace_kernel(const int32_t *__restrict__ bp_all, con
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_utt) return;
-    FtTab tb;
-    tb.bp = const_cast<int32_t *>(bp_all) + (size_t)u * 10 * bp_cap; tb.bp_cap = bp_cap;
-    tb.bss = nullptr; tb.idx = nullptr; tb.bss_cap = 0;
+    const FtTabCols tb = { bp_all + (size_t)u * kBpCols * bp_cap, bp_cap };
     ft_backtrace_one(tb, idx_all + (size_t)u * (max_frames + 2), res_all[(size_t)u * 8 + 2], finish_wid, max_words,
                      hyp_all + (size_t)u * max_words * 4, hyp_n_all + (size_t)u * 4);
 }
@@ -2107,22 +2265,25 @@ static bool ft_layout(FtDev &d, bool small)
     FtLay &L = d.lay;
     memset(&L, 0, sizeof L);
     L.rec = take((int64_t)d.CH * (small ? words : rec));
-    L.acl0 = take(d.N); L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
-    L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
-    L.cand_mark = take(d.n_w);
-    L.cand_wid = take(d.n_w + 1); L.cand_score = take(d.n_w + 1); L.cand_bp = take(d.n_w + 1);
-    if (small) { L.o_out = take(d.N); L.o_outh = take(d.N); L.pos = take(d.N); L.flag = take(d.N); L.o_frame = take(d.N); }   // (the slab layouts keep the snapshot in the nodes' records)
+    if (small) {                         // the interleaved blocks (FtCol): the per-node and per-word arrays as columns
+        L.node_blk = take(((int64_t)d.N + 1) * kFtNodeCols); L.word_blk = take(((int64_t)d.n_w + 2) * kFtWordCols);
+    }
+    else {
+        L.acl0 = take(d.N); L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
+        L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
+        L.cand_mark = take(d.n_w);
+        L.cand_wid = take(d.n_w + 1); L.cand_score = take(d.n_w + 1); L.cand_bp = take(d.n_w + 1);
+    }
+    // (the pruning's snapshot: columns of the node block in the LDS layout; the slab layouts keep it in the nodes' records)
     L.cnt = take(d.cnt_words);
     L.cnt2 = take(d.n_w + 2); L.cnt3 = take(d.n_w + 2); L.woff = take(d.n_w + 2); L.ckey = take(2 * ((int64_t)d.n_w + 2));
     L.present = take(((int64_t)d.TOT + 3) / 4);
     d.lb_words = 0;
     if (small) {
         L.pen = take(2 * (int64_t)d.n_ci);
-        L.kid_off = take(d.N + 1); L.kids = take(d.M); L.parent = take(d.N); L.ci = take(d.N); L.pw = take(d.N);
-        L.wc_off = take(d.n_w + 1);
+        L.kids = take(d.M);
         L.tp = take(((int64_t)d.n_tmat * ne * (ne + 1) + 3) / 4);
-        L.dfirst = take(d.n_w); L.dbase = take(d.n_w); L.w1w = take(d.n1);
-        L.dlast = take(d.n_w); L.homo = take(d.n_w); L.w1ci = take(d.n1); L.w1ci2 = take(d.n1); L.dfill = take(d.n_w);
+        L.w1w = take(d.n1); L.w1ci = take(d.n1); L.w1ci2 = take(d.n1);
         // what only scoring from top-N lists (psgpu_fwdtree_search_lists_dev) needs lies at the pool's end -- the lists, the
         // log-add table, the listed senones: a launch that reads score rows asks for less LDS
         if (!kFtRowsDevice) L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);
@@ -2136,6 +2297,9 @@ static bool ft_layout(FtDev &d, bool small)
         if (const char *cap = getenv("PSGPU_FWDTREE_EVL_CAP"))   // (a test's knob: a list that small fills up, status 2)
             L.evl_cap = (int32_t)std::max<int64_t>(64, std::min<int64_t>(L.evl_cap, atoll(cap)));
         L.evl = take((L.evl_cap + 1) / 2);
+        // the frame's exits for the word transitions lie in the evaluation list's words: the list's last reader of a frame is
+        // prune_word_chan, the exits are written after it and read until the frame's end
+        L.xfr = L.evl; L.xfr_cap = ((L.evl_cap + 1) / 2) / (d.n_ci + 3);
         L.rows_total = (int32_t)o;
         if (kFtRowsDevice) L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);     // (scoring from lists computes the frame's scores into it)
         L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);
@@ -2229,6 +2393,19 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
         }
         d.node_q1 = ft_up(m, q1.data(), q1.size(), &rc); d.node_q2 = ft_up(m, q2.data(), q2.size(), &rc);
         d.node_sen = ft_up(m, qs.data(), qs.size(), &rc);
+        // ... and what ngram_search_alloc_all_rc (ngram_search.c:583-633) gives a word's right-context channels, per slot
+        std::vector<int32_t> ss((size_t)std::max<int64_t>(tot, 1) * nsq, 0);
+        for (int w = 0; w < d.n_w; ++w) {
+            if (t->dict_pronlen[w] <= 1) continue;
+            const int last = t->dict_last[w], last2 = t->dict_last2[w], n = t->rssid_n[last * d.n_ci + last2];
+            for (int r = 0; r < n; ++r) {
+                const int ssid = t->rssid_ssid[((size_t)last * d.n_ci + last2) * d.n_ci + r];
+                int32_t *q = ss.data() + ((size_t)wc_off[w] + r) * nsq;
+                for (int k = 0; k < d.n_emit; ++k) q[k] = t->sseq[(size_t)ssid * d.n_emit + k];
+                q[nsq - 1] = t->ci_tmat[last];
+            }
+        }
+        d.slot_sen = ft_up(m, ss.data(), ss.size(), &rc);
     }
     d.node_pw = ft_up(m, t->node_penult_wid, d.N, &rc); d.parent = ft_up(m, parent.data(), d.N, &rc);
     d.homophone = ft_up(m, t->homophone_set, d.n_w, &rc);
@@ -2251,6 +2428,12 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     const char *force = getenv("PSGPU_FWDTREE_LAYOUT");
     if ((force && !strcmp(force, "slab")) || !ft_layout(d, true)) {
         if (!ft_layout(d, false)) { psgpu_set_error("fwdtree: the search's per-utterance arrays exceed 8 GB"); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
+    }
+    if (getenv("PSGPU_FT_DUMP_LAYOUT")) {                 // (a measuring aid: the layout as an initialiser list)
+        const int32_t *w = reinterpret_cast<const int32_t *>(&d.lay);
+        fprintf(stderr, "FtLay {");
+        for (size_t i = 0; i < sizeof(FtLay) / 4; ++i) fprintf(stderr, "%s%d", i ? "," : "", w[i]);
+        fprintf(stderr, "}\n");
     }
     *out = m;
     return PSGPU_OK;
@@ -2299,6 +2482,8 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
     if (!m) return;
     for (void *p : m->allocs) hipFree(p);
     hipFree(m->slab);
+    hipFree(m->bssx);
+    hipFree(m->bpa);
     delete m;
 }
 
@@ -2396,7 +2581,22 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
         PSGPU_HIP(hipMalloc((void **)&m->slab, sizeof(int32_t) * need));
         m->slab_words = need;
     }
+    // LDS layout: the exits' scores by right context phone, one row of n_ci per back-pointer
+    const size_t need_x = d.small ? (size_t)n_utt * (size_t)bp_cap * (size_t)d.n_ci : 0;
+    if (need_x > m->bssx_words) {
+        if (m->bssx) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->bssx); m->bssx = nullptr; m->bssx_words = 0; }
+        PSGPU_HIP(hipMalloc((void **)&m->bssx, sizeof(int32_t) * need_x));
+        m->bssx_words = need_x;
+    }
+    const size_t need_a = (size_t)n_utt * (size_t)bp_cap * kBpRow;
+    if (need_a > m->bpa_words) {
+        if (m->bpa) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->bpa); m->bpa = nullptr; m->bpa_words = 0; }
+        PSGPU_HIP(hipMalloc((void **)&m->bpa, sizeof(int32_t) * need_a));
+        m->bpa_words = need_a;
+    }
     FtBufs bf;
+    bf.bpa = m->bpa;
+    bf.bssx = d.small ? m->bssx : nullptr;
     bf.slab = m->slab; bf.bp = bp_dev; bf.bss = bss_dev; bf.idx = idx_dev; bf.step = step_dev; bf.res = result_dev;
     bf.w1_out = w1_ssid_out_dev;
     bf.mpx_in = mpx_ssid_in_dev; bf.mpx_out = mpx_ssid_out_dev;

@@ -20,7 +20,8 @@ def usage(src, tmp_path, asm=None):
     """resource usage of every kernel of `src` (the compiler's remarks); asm: also leave the device assembly at that path -- ONE
     compilation serves both (the files take ~20 s each)"""
     out_args = ["--cuda-device-only", "-S", "-o", str(asm)] if asm else ["-fPIC", "-c", "-o", str(tmp_path / "x.o")]
-    p = subprocess.run([HIPCC] + FLAGS + ["-Rpass-analysis=kernel-resource-usage"] + out_args +
+    from pocketsphinx_amd.capi import FILE_FLAGS         # (the product build's per-source flags: the tree search is built -Os)
+    p = subprocess.run([HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage"] + out_args +
                        [os.path.join(ROOT, "pocketsphinx_amd", "csrc", src)], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     out, cur = {}, None
@@ -53,7 +54,8 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             if "ELb1ELb0E" in n:              # reading score rows, the pipeline's default: (next to) nothing spilled
                 # (round 2: 0 / 3 spilled registers for 3- / 5-state models; round 3 -- the slab layouts' code in the same template,
                 #  the scorers' clamp, the search lag -- 2 / 5; same-box A/B of the 3-state kernel: 5.40 vs 5.37 ms)
-                assert v["Spill"] <= 6, (n, v)
+                # round 4 (-Os, arrays interleaved into two blocks: far fewer scalar values alive): none
+                assert v["Spill"] == 0, (n, v)
             else:
                 assert v["Spill"] <= 24, (n, v)
         else:
@@ -72,6 +74,11 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             assert len(re.findall(r"\bscratch_(load|store)", body)) == 0, n
         if "ELb1ELb" in n:      # tree-level state in LDS: most accesses are ds_*
             assert len(re.findall(r"\bds_(read|write|load|store)", body)) > 500, n
+        if "ELb1ELb0E" in n:
+            # scalar values spilled to vector-register lanes come back through v_readlane_b32 wherever they are used, and the
+            # kernel's time follows their number (round 4, same box: 2,491 -> 6.04 ms per 512 x 279 frames, 1,607 -> 5.20,
+            # 1,138 -> 4.83): a change that lets it grow again shows here before it shows on a GPU
+            assert len(re.findall(r"\bv_readlane_b32", body)) <= 1150, (n, len(re.findall(r"\bv_readlane_b32", body)))
 
 
 def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):
