@@ -400,7 +400,10 @@ struct FtTab {
     int32_t bp_cap, bss_cap;
 };
 #define BPC(t, col, i) ((t).bp[(size_t)(i) * kBpRow + (col)])
-enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2, kBpCols };
+enum { B_FRAME, B_VALID, B_WID, B_BP, B_SCORE, B_SIDX, B_REAL, B_PREAL, B_LAST, B_LAST2, kBpCols,
+       // words of an entry that are not columns of the caller's table: the first entry of its frame and of the next frame (what the
+       // predecessor search wants of the frame index, bp_table_idx, without a trip of its own)
+       B_F0 = kBpCols, B_F1 };
 
 __device__ __forceinline__ int32_t ft_lm(const FtDev &p, const int32_t *lmtab, int w3, int w2, int w1)
 {
@@ -1737,7 +1740,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 if (cb != -1) {
                     const int ef = BPC(tb, B_FRAME, cb);                 // (one trip with the exit score's columns)
                     cand_score[i] -= bssx ? ft_exit_score_x(tb, bssx, n_ci, cb, dfirst_f[w]) : ft_exit_score_bf(tb, rs_cimap, n_ci, cb, dfirst_f[w]);
-                    if (lt_sf[w] != ef + 1) { b0 = tb.idx[ef]; need = tb.idx[ef + 1] - b0; sf = ef + 1; }
+                    // (the frame's entries [bp_table_idx[ef], bp_table_idx[ef + 1]): the entry carries both, same cache line)
+                    const int32_t e0 = BPC(tb, B_F0, cb), e1 = BPC(tb, B_F1, cb);
+                    if (lt_sf[w] != ef + 1) { b0 = e0; need = e1 - b0; sf = ef + 1; }
                 }
                 cnt[i] = need; cnt2[i] = b0; cnt3[i] = sf;
                 ckey[i] = ft_key_floor(kW);
@@ -2075,7 +2080,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 wid = x0 & 0xffffff; sc = (x0 & kXSingle) ? x[3] : x[3 + rc];
             }
             else { wid = BPC(tb, B_WID, bp); sc = ft_exit_score_bf(tb, rs_cimap, n_ci, bp, rc); }
-            if (rc == 0) { word_lat_idx[wid] = -1; if (wid != p.finishwid) atomicAdd(&s_red[6], 1); }
+            if (rc == 0) {
+                word_lat_idx[wid] = -1; if (wid != p.finishwid) atomicAdd(&s_red[6], 1);
+                BPC(tb, B_F0, bp) = bp0; BPC(tb, B_F1, bp) = bp1;      // (the frame is complete: see the predecessor search)
+            }
             if (wid == p.finishwid) continue;
             if (sc > kW) atomicMax(&brc_key[rc], ft_key(sc, bp));
         }
