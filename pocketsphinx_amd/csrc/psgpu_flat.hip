@@ -431,7 +431,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         u.bp_cap = bf.bp_cap; u.bss_cap = bf.bss_cap;
     }
     const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
-    int n_awl[2] = {0, 0};
+    int n_awl0 = 0, n_awl1 = 0;           // (two scalars, and the lists through selected pointers below: an array or a struct member indexed by
+                                          //  a run-time value sends the whole FfUtt to scratch memory -- 344 bytes a lane, a trip to memory per use)
 
     // ---- build_fwdflat_chan (:305-368) on the host-made layout, ngram_fwdflat_start (:370-414)
     for (int i = tid; i < p.n1; i += kFfThreads) {
@@ -463,7 +464,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         ff_enter(u, p.w1_of_word[p.startwid], 0, -1, 0);
         ff_awl_put(p, u, u.awl[0], 0, p.startwid);
     }
-    n_awl[0] = 1;
+    n_awl0 = 1;
     const int n_chain = RAW ? rw.pm.n_mgau * rw.pm.n_feat : 0, topn = RAW ? rw.pm.topn : 0;
     if (RAW) {
         for (int i = tid; i < n_chain * topn; i += kFfThreads) { s_lcw[i] = rw.seed[(size_t)blockIdx.x * n_chain * topn + i]; s_lsc[i] = 0; }
@@ -499,7 +500,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     bool pre_closed = false;
     const bool ahead = RAW && rw.tsc && topn == 4 && n_chain <= kFfThreads;
     for (int f = 0; f < T; ++f) {
-        const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = n_awl[cur];
+        const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = cur ? n_awl1 : n_awl0;
+        int32_t *const awl_c = cur ? u.awl[1] : u.awl[0], *const awl_n = cur ? u.awl[0] : u.awl[1];
         const int16_t *const row_dev = RAW ? nullptr : senscr + (size_t)(t0 + f) * scr_stride;
         // ---- the frame's active channels, gathered into one list first (one work-item per word walks its chain once: order
         //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
@@ -517,7 +519,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         }
         __syncthreads();
         for (int i = tid >> 4; i < na; i += kFfThreads / 16) {          // sixteen work-items a word: its chain's stamps read side by side
-            const int w = u.awl[cur][i * 3], c0 = u.awl[cur][i * 3 + 1], wx = u.awl[cur][i * 3 + 2], len = wx & 1023;
+            const int w = awl_c[i * 3], c0 = awl_c[i * 3 + 1], wx = awl_c[i * 3 + 2], len = wx & 1023;
             for (int k = tid & 15; k < len; k += 16) {
                 const int c = c0 + k;
                 // (the stamp and what an active channel needs next asked for together: one trip to memory instead of two)
@@ -557,7 +559,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         struct FfEnt { int32_t c, inf, w, aux; };
         auto ent = [&](int e) -> FfEnt {
             if (e < FF_EL_CAP) { const int32_t *x = s_el[e]; return { x[0], x[1], x[2], x[3] }; }
-            const int32_t inf = u.einfo[e], w = u.awl[cur][(inf >> 10) * 3], wx = u.awl[cur][(inf >> 10) * 3 + 2];
+            const int32_t inf = u.einfo[e], w = awl_c[(inf >> 10) * 3], wx = awl_c[(inf >> 10) * 3 + 2];
             return { u.elist[e], inf, w, ((wx & 1023) - (inf & 1023) - 1) | (wx & ~1023) };
         };
         if (RAW) {
@@ -854,7 +856,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (best_in == kW || best_in < kW) break;
         if (best_in + 2 * p.beam < kW)                       // fwdflat_renormalize_scores (:784-810)
             for (int i = tid; i < na; i += kFfThreads) {
-                const int c0 = u.awl[cur][i * 3 + 1], len = u.awl[cur][i * 3 + 2] & 1023;
+                const int c0 = awl_c[i * 3 + 1], len = awl_c[i * 3 + 2] & 1023;
                 for (int k = 0; k < len; ++k) if (u.frame[c0 + k] == f) ff_normalize(p, u, c0 + k, best_in);
             }
         __syncthreads();
@@ -1068,7 +1070,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
             for (int i = tid; i < na; i += kFfThreads) {
                 if ((i + 1 < na ? u.cnt_a[i + 1] : n_exit) == u.cnt_a[i]) continue;
-                const int w = u.awl[cur][i * 3], c0 = u.awl[cur][i * 3 + 1], len = u.awl[cur][i * 3 + 2] & 1023;
+                const int w = awl_c[i * 3], c0 = awl_c[i * 3 + 1], len = awl_c[i * 3 + 2] & 1023;
                 const int32_t bpi = bpidx + u.cnt_a[i], bsh = bss_head + u.cnt_b[i];
                 for (int k = 0; k < len; ++k) {
                     const int c = c0 + k;
@@ -1221,7 +1223,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         __syncthreads();
         // initial channels of words that stayed inactive (:771-781)
         for (int i = tid; i < na; i += kFfThreads) {
-            const int c0 = u.awl[cur][i * 3 + 1];
+            const int c0 = awl_c[i * 3 + 1];
             if (u.frame[c0] == f) ff_clear_scores(p, u, c0);
         }
         FF_PROF(6);
@@ -1236,7 +1238,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 const bool on = i < n_all && u.word_active[wq[j]] == nf && (i < u.nwd ? wq[j] < p.startwid : true);
                 int32_t row_total;
                 const int pos = n_next + ff_block_excl_sum(on ? 1 : 0, (j & 1) ? s_scan2 : s_scan, row_total);
-                if (on) { int32_t *a = u.awl[nxt] + 3 * pos; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j]; }
+                if (on) { int32_t *a = awl_n + 3 * pos; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j]; }
                 n_next += row_total;
             }
         }
@@ -1259,11 +1261,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 int32_t round_total;
                 int pos = n_next + ff_block_excl_sum(__popc(fl), (round & 1) ? s_scan2 : s_scan, round_total);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (fl & (1 << j)) ff_awl_put(p, u, u.awl[nxt], pos++, wv[j]);
+                for (int j = 0; j < 8; ++j) if (fl & (1 << j)) ff_awl_put(p, u, awl_n, pos++, wv[j]);
                 n_next += round_total;
             }
         }
-        n_awl[nxt] = n_next;
+        if (nxt) n_awl1 = n_next; else n_awl0 = n_next;
         if (tid == 0) {
             u.step[f * 4] = s_sc[0]; u.step[f * 4 + 1] = 0; u.step[f * 4 + 2] = s_sc[1]; u.step[f * 4 + 3] = n_next;
             ++s_sc[4];
