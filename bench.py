@@ -373,6 +373,30 @@ def scorer_extra(P, capi, L, dev, sp, tables):
                         "note": "VALU-bound by construction; fp32-VALU fraction of the distance work = %.4f"
                                 % (fpf * T / (lane * 1e-3) / 1e9 / VALU_PEAK_GOPS)},
            "what": "configs[1]: en-us PTM senone-score-only, 10,000 synthetic frames = 40 utterances x 250, compallsen, topn 4"}
+    # cpu_baseline + parity: the unmodified reference's ptm_mgau_frame_eval(compallsen) on the same feature vectors, one thread
+    # (oracle/_ref/ref_score_bench: the loop around the scorer's vtable entry, acmod.c:1076-1133), every one of its int16 scores
+    # against the device's
+    exe = os.path.join(REF_DIR, "ref_score_bench")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as td:
+            fpath, spath = os.path.join(td, "feats.f32"), os.path.join(td, "scores.i16")
+            feats_h.tofile(fpath)
+            r = subprocess.run([exe, os.path.join(REF_DIR, "model", "en-us"), fpath, str(utt_len), spath], capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines and os.path.exists(spath):
+                j = json.loads(lines[-1])
+                want = np.fromfile(spath, np.int16).reshape(T, model.n_sen)
+                got = scr.cpu().numpy()
+                bad = int((want != got).any(axis=1).sum())
+                out["cpu_baseline"] = {"value": round(j["frames_per_s"], 1), "unit": "frames/s", "cores": 1, "kind": "reference",
+                                       "sample": "all %d frames of the step (%.1f s of CPU)" % (j["frames"], j["seconds"]),
+                                       "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2): ptm_mgau_frame_eval, compallsen, "
+                                               "fresh top-N history per utterance"}
+                out["parity"] = {"frames_checked": T, "senones": int(model.n_sen), "frames_with_a_differing_score": bad,
+                                 "what": "every int16 senone score of every frame: device vs the reference (bit-exact = 0 differing)"}
+                out["speedup_vs_cpu_1thread"] = round(out["frames_per_s"] / j["frames_per_s"], 1)
+            else:
+                out["cpu_baseline"] = {"error": (r.stderr or r.stdout)[-300:]}
     return out, model, feats_h
 
 
@@ -381,7 +405,7 @@ def child_extras(out):
     t_children = time.perf_counter()
 
     def child(key, argv, env, limit):
-        left = 240.0 - (time.perf_counter() - t_children)        # all children together: four minutes at most
+        left = 360.0 - (time.perf_counter() - t_children)        # all children together: six minutes at most
         if left < 20.0:
             out[key] = {"skipped": "time budget of the child-process extras used up"}
             return
@@ -405,6 +429,7 @@ def child_extras(out):
         # check): single-thread reference ~1.2 k frames/s on this decode (profiles/r01i_*)
         child("search_only_cmudict", [sb], {"SB_CASE": "cmudict", "SB_BATCHES": "1,32,256", "SB_REPS": "1"}, 200)
     child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 120)
+    child("decode_three_pass", [os.path.join(ROOT, "tools", "three_pass_bench.py")], {}, 200)
     from pocketsphinx_amd import largevocab as lv
     if lv.available(lv.table_path(directory=os.environ.get("PSGPU_TABLE_DIR"))):
         # configs[2]'s shape: ONE 60 s utterance, en-us PTM + the large LM / dictionary (en-us.lm.bin is not in the repository: big.arpa
