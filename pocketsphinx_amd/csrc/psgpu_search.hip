@@ -2308,6 +2308,8 @@ static bool ft_layout(FtDev &d, bool small)
         // the frame's exits for the word transitions lie in the evaluation list's words: the list's last reader of a frame is
         // prune_word_chan, the exits are written after it and read until the frame's end
         L.xfr = L.evl; L.xfr_cap = ((L.evl_cap + 1) / 2) / (d.n_ci + 3);
+        if (const char *cap = getenv("PSGPU_FWDTREE_XFR_CAP"))   // (a test's knob: frames with more exits take the table's path)
+            L.xfr_cap = (int32_t)std::max<int64_t>(0, std::min<int64_t>(L.xfr_cap, atoll(cap)));
         L.rows_total = (int32_t)o;
         if (kFtRowsDevice) L.row = take(((int64_t)d.n_sen + 1) / 2 + 4);     // (scoring from lists computes the frame's scores into it)
         L.l_cw = take(kFtMaxChains); L.l_sc = take(kFtMaxChains); L.l_la = take(512 / 4); L.l_list = take(kFtListCap / 2);

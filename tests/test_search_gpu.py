@@ -51,6 +51,21 @@ def test_fwdtree_kernel_matches_reference(case):
     s.close()
 
 
+@pytest.mark.parametrize("cap", ["0", "2"])
+@pytest.mark.parametrize("case", ["goforward", "numbers"])
+def test_fwdtree_kernel_word_transitions_from_the_table(case, cap, monkeypatch):
+    """the LDS layout's fall-back on frames with more exits than its LDS copy holds (PSGPU_FWDTREE_XFR_CAP, read when the search
+    is created): the word transitions read the back-pointer table itself -- same tables"""
+    import pocketsphinx_amd as P
+    monkeypatch.setenv("PSGPU_FWDTREE_XFR_CAP", cap)
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    s = P.FwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    _check(s.search(rows, pen, [rows.shape[0]])[0], g, "%s, xfr cap %s" % (case, cap))
+    s.close()
+
+
 def test_fwdtree_kernel_second_utterance_of_a_session():
     """psgpu_fwdtree_search_session_dev on the device: as tests/test_search_hostsim.py's session test (the reference's
     decoder had decoded numbers.raw before goforward.raw; raw-score mode, the kernel lists the senones itself)"""

@@ -70,6 +70,16 @@ def test_search_kernel_source_with_the_trie_lm(case, layout):
     _run(case, "rev", trie=True, layout=layout)
 
 
+@pytest.mark.parametrize("cap", ["0", "1", "3"])
+@pytest.mark.parametrize("case", ["goforward", "numbers", "man_ah_2934za"])
+def test_search_kernel_source_word_transitions_from_the_table(case, cap):
+    """The LDS layout keeps a frame's exits in LDS for the word transitions (FtLay::xfr) and falls back to the back-pointer table
+    itself on frames with more exits than that holds.  PSGPU_FWDTREE_XFR_CAP caps it at 0 / 1 / 3 entries: every frame, most
+    frames, some frames take the table's path -- the tables must not change."""
+    with _env("PSGPU_FWDTREE_XFR_CAP", cap):
+        _run(case, "rev", layout="lds")
+
+
 def test_search_kernel_source_batch_of_utterances():
     """several workgroups in one launch: every utterance equals its own golden"""
     names = ["goforward", "numbers", "goforward"]

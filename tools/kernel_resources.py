@@ -9,6 +9,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pocketsphinx_amd.capi import FILE_FLAGS  # noqa: E402  (the product build's per-source flags: the tree search is built -Os)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-w", "-I" + os.path.join(ROOT, "include"),
          "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o", "/dev/null"]
 KEYS = [("VGPRs", r"\s+VGPRs: (\d+)"), ("AGPRs", r"AGPRs: (\d+)"), ("SGPRs", r"TotalSGPRs: (\d+)"), ("spillV", r"VGPRs Spill: (\d+)"),
@@ -18,12 +20,12 @@ KEYS = [("VGPRs", r"\s+VGPRs: (\d+)"), ("AGPRs", r"AGPRs: (\d+)"), ("SGPRs", r"T
 
 def main():
     tag = sys.argv[1]
-    lines = ["# hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage, every kernel of "
-             "pocketsphinx_amd/csrc (tools/kernel_resources.py %s)" % tag,
+    lines = ["# hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage (+ the product build's per-source "
+             "flags: %s), every kernel of pocketsphinx_amd/csrc (tools/kernel_resources.py %s)" % (FILE_FLAGS, tag),
              "# (static LDS only: fwdtree_kernel's LDS layout adds 60.8 KB of dynamic LDS reading rows / 65.4 KB scoring from lists, the slab layouts "
              "18 x work-items x 4 B + 64 + the listed-nodes bitmap; fwdflat_kernel's scoring form 4 x n_sen bytes: score row and listed senones)"]
     for src in sorted(glob.glob(os.path.join(ROOT, "pocketsphinx_amd", "csrc", "*.hip"))):
-        p = subprocess.run(["hipcc"] + FLAGS + [src], capture_output=True, text=True, timeout=1800)
+        p = subprocess.run(["hipcc"] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + [src], capture_output=True, text=True, timeout=1800)
         cur = None
         rows = {}
         for ln in p.stderr.splitlines():
