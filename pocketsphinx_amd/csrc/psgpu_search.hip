@@ -635,6 +635,26 @@ __device__ __forceinline__ int32_t ft_block_scan(int32_t *a, int n, int32_t *tmp
     return total;
 }
 
+// Exclusive prefix sums over the workgroup's work-items of K values each (in tid order), results in registers, totals to every
+// work-item: ONE barrier.  tmp: K * NT / 64 words of LDS that nobody touches until the NEXT barrier after the call.
+template <int NT, int K, bool LDS>
+__device__ __forceinline__ void ft_scan_tid(int32_t (&v)[K], int32_t *tmp, int32_t (&total)[K])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t incl[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { incl[k] = ft_wave_incl<FtAdd>(v[k]); if (lane == 63) tmp[k * (NT / 64) + wv] = incl[k]; }
+    ft_sync<LDS>();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int32_t base = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { const int32_t t = tmp[k * (NT / 64) + w]; tot += t; if (w < wv) base += t; }
+        total[k] = tot;
+        v[k] = base + incl[k] - v[k];
+    }
+}
+
 // K exclusive prefix sums at once (same barriers as one)
 template <int NT, int K, bool LDS>
 __device__ __forceinline__ void ft_block_scan_k(int32_t *const (&a)[K], int n, int32_t *tmp, int32_t (&total)[K])
@@ -759,7 +779,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
     __shared__ int32_t s_red[8];
-    __shared__ int32_t s_scan[3 * NT / 64];
+    __shared__ int32_t s_scan[6 * NT / 64];
     __shared__ int32_t s_bins[320];      // histogram of the maxhmmpf beam; word_transition: 64 keys (64-bit) + 3 x 64 decoded
     __shared__ int32_t s_sc[8];          // best_score, lpbest, dynamic_beam, bpidx, bss_head, n_cand, status, n_frame
     __shared__ unsigned long long s_evals;
@@ -1626,10 +1646,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             FT_PROF(4);
         }
         } else {
-            // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation.  Work proportional to the active
-            //      channels (oracle prune_tree_list): the items are the roots, the listed nodes and their children.  Reads of
-            //      another node's state go to the snapshot (o_out, o_outh, flag, pos) of a root or listed node, writes to the
-            //      item's own channel and decision word, so the items are independent.
+            // ---- prune_root_chan + prune_nonroot_chan (:722-877), order-free formulation, one work-item per tree NODE.  The items
+            //      are the roots and the listed nodes (oracle prune_tree_list); a decision is a function of the node's state and its
+            //      parent's as the evaluation left them.  Reads of another node's state go to the snapshot (o_out, o_outh, flag, pos)
+            //      of a root or listed node, writes to the node's own channel and decision word.  No work-item walks a node's
+            //      children (those walks -- three of them, their lengths uneven -- were a quarter of a frame): the children array
+            //      (CSR) is gone through position by position, a child's place among its listed siblings is a difference of one
+            //      prefix sum over that array, an item's place in the next list a prefix sum over the items.
+            int32_t *const Sarr = cnt, *const ibase = cnt + (R + N + 1);         // [M + 1], [R + na]
             for (int q = tid; q < na; q += NT) pos[aclc[q]] = q;
             for (int i = tid; i < R + na; i += NT) {
                 const int node = i < R ? i : aclc[i - R];
@@ -1639,86 +1663,96 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             ft_sync<SMALL>();
             FT_PROF(4);
-            auto decide = [&](int c) {
-                const int P = parent[c], pc = pos[c];
-                const bool in_acl = pc >= 0, par_active = P < R || pos[P] >= 0;
-                const int32_t news = (par_active ? o_out[P] : kW) + p.pip;
-                const bool parent_can = par_active && (flag[P] & 1) && (p.has_pl || news > npt)
-                                        && (news + ft_pen(node_ci[c]) > npt);
-                const bool parent_first = P < R || !in_acl || pos[P] < pc;
-                const bool retc = in_acl && (flag[c] & 1);
-                bool fire;
-                if (!in_acl || parent_first) fire = parent_can && (tv.at(c, F::FRAME) < f || news > tv.at(c, F::SCORE));
-                else if (retc)               fire = parent_can && news > tv.at(c, F::SCORE);
-                else                         fire = parent_can;
-                const bool entered_first = fire && parent_first;
-                const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
-                if (in_acl && !retc && !entered_first) ch_clear<NE>(tv, c);
-                if (retc) tv.at(c, F::FRAME) = nf;
-                if (fire) ch_enter<NE>(tv, c, news, o_outh[P], nf);
-                o_frame[c] = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
-            };
-            for (int i = tid; i < R + na; i += NT) {
-                const int node = i < R ? i : aclc[i - R];
-                // a node that is not retained enters none of its children: their (stale) decision words are not
-                // looked at below either, so they need no visit -- on a large tree most roots are idle most of the time
-                const int k0 = kid_off[node], nk = (flag[node] & 1) ? kid_off[node + 1] - k0 : 0;
-                for (int q = i >= R ? -1 : 0; q < nk; ++q) {         // q = -1: the listed node itself, then its unlisted children
-                    const int c = q < 0 ? node : kids[k0 + q];
-                    if (q >= 0 && pos[c] >= 0) continue;
-                    decide(c);
+            {
+                // -- the decisions, child by child of the children array; listed children counted by a running prefix sum
+                int32_t carry = 0;
+                for (int j0 = 0, rnd = 0; j0 < p.M; j0 += NT, ++rnd) {
+                    const int j = j0 + tid;
+                    int32_t b2[1] = { 0 };
+                    if (j < p.M) {
+                        const int c = kids[j], P = parent[c], pc = pos[c];
+                        const int pp = P < R ? 0 : pos[P];
+                        const bool in_acl = pc >= 0, par_active = P < R || pp >= 0;
+                        const int pflag = par_active ? (flag[P] & 1) : 0;
+                        int32_t dec = 0;
+                        if (in_acl || pflag) {               // (a node that is not listed under a parent that is not retained: nothing happens to it)
+                            const int32_t news = (par_active ? o_out[P] : kW) + p.pip;
+                            const bool parent_can = par_active && pflag && (p.has_pl || news > npt) && (news + ft_pen(node_ci[c]) > npt);
+                            const bool parent_first = P < R || !in_acl || pp < pc;
+                            const bool retc = in_acl && (flag[c] & 1);
+                            bool fire;
+                            if (!in_acl || parent_first) fire = parent_can && (tv.at(c, F::FRAME) < f || news > tv.at(c, F::SCORE));
+                            else if (retc)               fire = parent_can && news > tv.at(c, F::SCORE);
+                            else                         fire = parent_can;
+                            const bool entered_first = fire && parent_first;
+                            const bool listed = fire && (P < R || !(in_acl && !parent_first && retc));
+                            if (in_acl && !retc && !entered_first) ch_clear<NE>(tv, c);
+                            if (retc) tv.at(c, F::FRAME) = nf;
+                            if (fire) ch_enter<NE>(tv, c, news, o_outh[P], nf);
+                            dec = (fire ? (listed ? 2 : 4) : 0) | ((retc && !entered_first) ? 8 : 0);
+                        }
+                        o_frame[c] = dec;
+                        b2[0] = (dec & 2) ? 1 : 0;
+                    }
+                    int32_t tot[1];
+                    ft_scan_tid<NT, 1, SMALL>(b2, s_scan + (rnd & 1) * (NT / 64), tot);
+                    if (j < p.M) Sarr[j] = carry + b2[0];
+                    carry += tot[0];
                 }
+                if (tid == 0) Sarr[p.M] = carry;
             }
             FT_PROF(28);
             ft_sync<SMALL>();
             FT_PROF(5);
-            for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1;                 // (nothing below reads pos or a root's frame
-            for (int i = tid; i < R; i += NT) if (flag[i] & 1) tv.at(i, F::FRAME) = nf;   //  before the next barrier)
-            // list positions (root phase: a segment per root, then one segment per list position) and the last-phone candidates
-            // (list order, homophone chain inside) in ONE counting pass, one double prefix sum and one writing pass: the two
-            // depend on the pruning's snapshot and decisions only, not on each other
-            int32_t *const cntb = cnt + (R + N + 1);
-            for (int i = tid; i < R + na; i += NT) {
-                const int node = i < R ? i : aclc[i - R];
-                int k = (i >= R && (o_frame[node] & 8)) ? 1 : 0;
-                if (flag[node] & 1) {
-                    const int k1 = kid_off[node + 1];
-                    for (int q = kid_off[node]; q < k1; ++q) k += (o_frame[kids[q]] & 2) ? 1 : 0;
+            {
+                // -- the items in list order: place in the next list (itself when it stays, then its listed children) and the
+                //    last-phone candidates (list order, homophone chain inside), two prefix sums over the items in one pass
+                int32_t carry_l = 0, carry_c = 0;
+                for (int i0 = 0, rnd = 0; i0 < R + na; i0 += NT, ++rnd) {
+                    const int i = i0 + tid;
+                    int32_t v[2] = { 0, 0 };
+                    int node = 0; bool self = false, fl = false; int32_t news = 0;
+                    if (i < R + na) {
+                        node = i < R ? i : aclc[i - R];
+                        fl = (flag[node] & 1) != 0;
+                        self = i >= R && (o_frame[node] & 8);
+                        v[0] = (self ? 1 : 0) + Sarr[kid_off[node + 1]] - Sarr[kid_off[node]];
+                        news = o_out[node] + p.pip;
+                        if (fl && (p.has_pl || news > lpt))
+                            for (int w = node_pw[node]; w >= 0; w = homo_f[w]) v[1] += (news + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
+                        if (i < R && fl) tv.at(i, F::FRAME) = nf;          // a retained root stays
+                    }
+                    int32_t tot[2];
+                    ft_scan_tid<NT, 2, SMALL>(v, s_scan + 2 * (NT / 64) + (rnd & 1) * 2 * (NT / 64), tot);
+                    if (i < R + na) {
+                        const int32_t o = carry_l + v[0];
+                        ibase[i] = o + (self ? 1 : 0);                    // where its listed children start
+                        if (self) acln[o] = node;
+                        int oc = carry_c + v[1];
+                        if (fl && (p.has_pl || news > lpt))
+                            for (int w = node_pw[node]; w >= 0; w = homo_f[w])
+                                if (news + ft_pen(dlast_f[w]) > lpt) {
+                                    cand_wid[oc] = w; cand_score[oc] = news - p.nwpen; cand_bp[oc] = o_outh[node]; ++oc;
+                                }
+                    }
+                    carry_l += tot[0]; carry_c += tot[1];
                 }
-                cnt[i] = k;
-                const int32_t news = o_out[node] + p.pip;
-                int kc = 0;
-                if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                    for (int w = node_pw[node]; w >= 0; w = homo_f[w]) kc += (news + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
-                cntb[i] = kc;
+                n_listed = carry_l;
+                if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; }
             }
             ft_sync<SMALL>();
-            {
-                int32_t tot2[2];
-                int32_t *const arr[2] = { cnt, cntb };
-                ft_block_scan_k<NT, 2, SMALL>(arr, R + na, s_scan, tot2);       // exclusive prefix sums
-                n_listed = tot2[0];
-                if (tid == 0) { s_sc[5] = tot2[1]; s_red[7] = 0; }
-            }
             FT_PROF(6);
-            for (int i = tid; i < R + na; i += NT) {
-                const int node = i < R ? i : aclc[i - R];
-                int o = cnt[i];
-                if (i >= R && (o_frame[node] & 8)) acln[o++] = node;
-                if (flag[node] & 1) {
-                    const int k1 = kid_off[node + 1];
-                    for (int q = kid_off[node]; q < k1; ++q) { const int c = kids[q]; if (o_frame[c] & 2) acln[o++] = c; }
+            // -- the listed children to their places
+            for (int j = tid; j < p.M; j += NT) {
+                const int c = kids[j];
+                if (o_frame[c] & 2) {
+                    const int P = parent[c];
+                    acln[ibase[P < R ? P : R + pos[P]] + Sarr[j] - Sarr[kid_off[P]]] = c;
                 }
-                const int32_t news = o_out[node] + p.pip;
-                int oc = cntb[i];
-                if ((flag[node] & 1) && (p.has_pl || news > lpt))
-                    for (int w = node_pw[node]; w >= 0; w = homo_f[w])
-                        if (news + ft_pen(dlast_f[w]) > lpt) {
-                            cand_wid[oc] = w; cand_score[oc] = news - p.nwpen; cand_bp[oc] = o_outh[node]; ++oc;
-                        }
             }
         }
         __syncthreads();                                     // (device memory: the evaluation's records, tb.idx[f] -- see above)
+        if (SMALL) { for (int q = tid; q < na; q += NT) pos[aclc[q]] = -1; }     // (pos is read by nobody until the next frame's pruning sets it)
         FT_PROF(7);
 
         // ---- word level: last_phone_transition (:884-1035).  Candidates of one frame name distinct words (a word has
