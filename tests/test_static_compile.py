@@ -77,8 +77,9 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
         if "ELb1ELb0E" in n:
             # scalar values spilled to vector-register lanes come back through v_readlane_b32 wherever they are used, and the
             # kernel's time follows their number (round 4, same box: 2,491 -> 6.04 ms per 512 x 279 frames, 1,607 -> 5.20,
-            # 1,138 -> 4.83): a change that lets it grow again shows here before it shows on a GPU
-            assert len(re.findall(r"\bv_readlane_b32", body)) <= 1150, (n, len(re.findall(r"\bv_readlane_b32", body)))
+            # 1,138 -> 4.83; the node-per-work-item pruning: 1,315 -> 4.55): a change that lets it grow again shows here before it
+            # shows on a GPU
+            assert len(re.findall(r"\bv_readlane_b32", body)) <= 1400, (n, len(re.findall(r"\bv_readlane_b32", body)))
 
 
 def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):
