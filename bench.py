@@ -540,9 +540,17 @@ def main():
     gather_stream = torch.cuda.Stream(device=dev) if dist is not None else None
     gathered = []
 
+    fe_ahead = n_pipe == 2 and not os.environ.get("PSGPU_BENCH_NO_FE_AHEAD")
+
     def launch(k):
-        """one pass of the hot path over the batch: everything enqueued on the step's stream"""
+        """one pass of the hot path over the batch: everything enqueued on the step's stream.  (Two objects: the front end of the
+        OTHER object's next step first, on that object's own stream -- it runs beside this step's scorer instead of at the start
+        of its own step, where the resident search holds most of the LDS it wants: psgpu_decode_front_end_ahead.  It is part of
+        step k + 1's work, inside the timed region for every step but the first, whose front end runs in the step itself.)"""
+        if fe_ahead and k + 1 < launch.n:
+            pipes[(k + 1) % n_pipe].front_end_ahead(pcm, soff)
         pipes[k % n_pipe].run_dev(pcm, soff, streams[k % n_pipe].cuda_stream)
+    launch.n = 0
 
     def finish(k, timed):
         """the step's hypothesis records on the host (rank 0: of every rank)"""
@@ -570,6 +578,7 @@ def main():
         return out
 
     def run_steps(n, timed):
+        launch.n = n
         for k in range(n):
             launch(k)
             if k >= n_pipe - 1:

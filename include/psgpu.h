@@ -763,6 +763,17 @@ int psgpu_decode_session_get(psgpu_decode_t *d, uint8_t *seed_cw, int32_t *seed_
  * the device (psgpu_decode_view) until fetched. */
 int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt,
                                 void *stream);
+/* The NEXT call's front end and dynamic features, ahead of that call, on a stream of the object's own: for a caller that decodes
+ * batch after batch with two objects taking turns (psgpu_decode_search_after) and has the next batch's samples on the device
+ * already.  Issued while this object's latest search is still running and BEFORE the other object's next call, it runs beside
+ * that call's scorer (whose top-N kernel uses no LDS) instead of at the start of this object's next call, where the spectrum kernel -- 4 KB of LDS a wavefront -- finds most
+ * of every compute unit's LDS held by the resident search.  The next psgpu_decode_first_pass_dev with exactly this pcm_dev /
+ * samp_off skips its front end.  Only for an input of the latest call's shape (same n_utt and samp_off: nothing is re-allocated
+ * and the frame offsets the resident search reads stay what they are); otherwise, and for a session's single utterances, it does
+ * nothing.  *started (may be NULL): 1 when the front end was issued.  A second pass that reads the features
+ * (psgpu_decode_second_pass) must have been issued before.  Replaces nothing in the reference: scheduling of fe_process_frames +
+ * feat_s2mfc2feat (fe_interface.c:345-560, feat.c:1310) for the batch entry. */
+int psgpu_decode_front_end_ahead(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, int32_t *started);
 /* the same from host buffers: pcm[u][0..n[u]) are staged and copied to the device first */
 int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const size_t n[], int32_t n_utt, void *stream);
 /* entering after the front end: feat [total][3 * cepsize] HOST feature vectors as feat_s2mfc2feat_live leaves them

@@ -65,6 +65,16 @@ struct psgpu_decode_s {
     psgpu_decode_s *prev = nullptr;
     hipEvent_t ev_pre = nullptr, ev_srch = nullptr, ev_go = nullptr;
     bool srch_recorded = false, go_recorded = false;
+    // psgpu_decode_front_end_ahead: the NEXT call's front end + features, run on a stream of this object's own while its latest
+    // call's search is still resident -- beside the other object's scorer, whose top-N kernel uses no LDS (the spectrum kernel,
+    // 4 KB of LDS a wave, gets 8 waves on a compute unit that holds two searches: run at a call's start it is 19 ms of the
+    // stages' critical path against 6.4 alone)
+    hipStream_t fe_stream = nullptr;
+    hipEvent_t ev_fe = nullptr;                          // front end ahead done
+    bool fe_ahead = false;                               // ev_fe pending for the next call
+    std::vector<int64_t> fe_soff;                        // the sample offsets the front end ahead was run for
+    std::vector<int64_t> last_soff;                      // the latest psgpu_decode_first_pass_dev call's sample offsets
+    const int16_t *fe_pcm = nullptr;
 };
 
 static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
@@ -172,6 +182,8 @@ void psgpu_decode_free(psgpu_decode_t *d)
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
     if (d->ev_go) hipEventDestroy(d->ev_go);
+    if (d->ev_fe) hipEventDestroy(d->ev_fe);
+    if (d->fe_stream) hipStreamDestroy(d->fe_stream);
     delete d;
 }
 
@@ -249,6 +261,7 @@ int psgpu_decode_search_after(psgpu_decode_t *d, psgpu_decode_t *prev)
             PSGPU_HIP(hipEventCreateWithFlags(&q->ev_pre, hipEventDisableTiming));
             PSGPU_HIP(hipEventCreateWithFlags(&q->ev_srch, hipEventDisableTiming));
             PSGPU_HIP(hipEventCreateWithFlags(&q->ev_go, hipEventDisableTiming));
+            PSGPU_HIP(hipEventCreateWithFlags(&q->ev_fe, hipEventDisableTiming));
         }
     d->prev = prev;
     return PSGPU_OK;
@@ -401,6 +414,9 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
         //  the search kernel that leave room for a third workgroup per compute unit)
         static const int overlap = [] { const char *e = getenv("PSGPU_DECODE_SEARCH_OVERLAP"); return e ? atoi(e) : 0; }();
         if (!overlap && d->prev && d->prev->srch_recorded) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_srch, 0));
+        // (... and for the other object's front end ahead, if one is on its way: the search is dispatched onto a device whose LDS
+        //  nobody else holds)
+        if (d->prev && d->prev->fe_ahead) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_fe, 0));
         PSGPU_HIP(hipEventRecord(d->ev_go, st));             // "this call's search is being dispatched": the other object's next call waits for it
         d->go_recorded = true;
     }
@@ -440,12 +456,29 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
     d->total = (int32_t)total; d->max_frames = (int32_t)mf;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     d->ev_valid = false;
+    d->last_soff.assign(samp_off, samp_off + n_utt + 1);
+    {   // the frame offsets on the host (the front end's call fills them too; a front end run ahead has gone before)
+        int32_t acc = 0;
+        for (int u = 0; u < n_utt; ++u) { d->frame_off[u] = acc; acc += (int32_t)psgpu_fe_n_frames(d->cfg.fe, samp_off[u + 1] - samp_off[u]); }
+        d->frame_off[n_utt] = acc;
+    }
     // taking turns with another object (psgpu_decode_search_after): this call's first stages start when the other object's
     // search has been dispatched -- onto a device that runs nothing else at that moment, so that all its workgroups are placed
     // at once.  A search kernel dispatched while other kernels hold part of the compute units' LDS gets one workgroup per
     // compute unit instead of two and takes twice as long (profiles/r03_overlap.txt).
     if (d->prev && d->prev->go_recorded) PSGPU_HIP(hipStreamWaitEvent(st, d->prev->ev_go, 0));
     dec_mark(d, 0, st);
+    // the front end of exactly this input has been run ahead (psgpu_decode_front_end_ahead): cepstra, features and offsets are
+    // in the object's buffers (or on their way: the event)
+    const bool ahead = d->fe_ahead && d->fe_pcm == pcm_dev && d->fe_soff.size() == (size_t)n_utt + 1
+                       && memcmp(d->fe_soff.data(), samp_off, sizeof(int64_t) * ((size_t)n_utt + 1)) == 0 && !(d->session && n_utt == 1);
+    if (d->fe_ahead) { PSGPU_HIP(hipStreamWaitEvent(st, d->ev_fe, 0)); d->fe_ahead = false; }      // (used or not: nothing of it may still be running)
+    if (ahead && total > 0) {
+        dec_mark(d, 1, st);
+        if ((rc = dec_from_feat(d, n_utt, total, mf, st))) return rc;
+        d->ev_valid = d->timing;
+        return PSGPU_OK;
+    }
     // session: the noise tracker of the reference's front end lives until ps_start_stream (fe_start_utt, fe_interface.c:318-326,
     // does not reset it): utterance k + 1's spectra are cleaned with what utterance k left
     const bool sess = d->session && n_utt == 1;
@@ -504,6 +537,38 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
         return PSGPU_OK;
     }
     return dec_from_feat(d, n_utt, total, mf, st);
+}
+
+// The next call's front end, ahead of the call: see psgpu_decode_s::fe_stream.  Runs only for an input of the latest call's shape
+// (same utterance count and sample offsets: the buffers fit, and the frame offsets the resident search still reads do not change) --
+// otherwise it does nothing and the call runs its own front end, as it does for a session's single utterances.
+int psgpu_decode_front_end_ahead(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, int32_t *started)
+{
+    PSGPU_REQUIRE(d && pcm_dev && samp_off && n_utt > 0, "psgpu_decode_front_end_ahead: bad argument");
+    if (started) *started = 0;
+    if (!d->cfg.fe || !d->prev || !d->ev_fe || d->fe_ahead || (d->session && n_utt == 1) || d->n_utt != n_utt || d->total <= 0
+        || d->last_soff.size() != (size_t)n_utt + 1 || memcmp(d->last_soff.data(), samp_off, sizeof(int64_t) * ((size_t)n_utt + 1)) != 0)
+        return PSGPU_OK;
+    if (!d->fe_stream) {
+        void *s = nullptr;
+        int rc = psgpu_stream_create_dedicated(&s);
+        if (rc != PSGPU_OK) return rc;
+        d->fe_stream = (hipStream_t)s;
+    }
+    hipStream_t fs = d->fe_stream;
+    // after this object's latest search has been dispatched (its scorer and phone loop, which read the features, are over; the
+    // search was placed on a device whose LDS nobody else held).  The caller issues this BEFORE the other object's next call: that
+    // call's search dispatch then waits for this front end (dec_from_feat), and its scorer -- whose top-N kernel uses no LDS -- is
+    // what runs beside it
+    if (d->go_recorded) PSGPU_HIP(hipStreamWaitEvent(fs, d->ev_go, 0));
+    std::vector<int32_t> fo((size_t)n_utt + 1);
+    int rc = psgpu_fe_process_utts_dev(d->cfg.fe, pcm_dev, samp_off, n_utt, nullptr, nullptr, d->d_cep, d->d_off, fo.data(), fs);
+    if (rc) return rc;
+    if ((rc = psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, n_utt, d->cepsize, d->d_feat, fs))) return rc;
+    PSGPU_HIP(hipEventRecord(d->ev_fe, fs));
+    d->fe_ahead = true; d->fe_pcm = pcm_dev; d->fe_soff.assign(samp_off, samp_off + n_utt + 1);
+    if (started) *started = 1;
+    return PSGPU_OK;
 }
 
 int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const size_t n[], int32_t n_utt, void *stream)

@@ -1851,12 +1851,22 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             __syncthreads();                                     // (device memory is exchanged here)
             FT_PROF(9);
             {                                            // stable compaction by a prefix sum
-                const int32_t nawl = ft_block_scan<NT, SMALL>(cnt2, n_cand, s_scan);
-                for (int i = tid; i < n_cand; i += NT)
-                    if ((i + 1 < n_cand ? cnt2[i + 1] : nawl) != cnt2[i]) {
-                        const int w = cand_wid[i];
-                        awln[cnt2[i]] = w; word_active[w] = 1;
-                    }
+                int32_t nawl;
+                if (n_cand <= NT) {                          // (one candidate a work-item: its flag and place in registers, one barrier)
+                    int32_t v[1] = { tid < n_cand ? cnt2[tid] : 0 }, t1[1];
+                    const int32_t mine = v[0];
+                    ft_scan_tid<NT, 1, SMALL>(v, s_scan, t1);
+                    nawl = t1[0];
+                    if (mine) { const int w = cand_wid[tid]; awln[v[0]] = w; word_active[w] = 1; }
+                }
+                else {
+                    nawl = ft_block_scan<NT, SMALL>(cnt2, n_cand, s_scan);
+                    for (int i = tid; i < n_cand; i += NT)
+                        if ((i + 1 < n_cand ? cnt2[i + 1] : nawl) != cnt2[i]) {
+                            const int w = cand_wid[i];
+                            awln[cnt2[i]] = w; word_active[w] = 1;
+                        }
+                }
                 if (tid == 0) s_red[5] = nawl;
             }
             ft_sync<SMALL>();
@@ -1993,6 +2003,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
             const int wst = p.n_w + 1;                            // n1 <= n_w
             int32_t *const f_ex = cnt, *const f_new = cnt + wst, *const f_rc = cnt + 2 * wst;
+            // (when the single-phone words and the next frame's active words are no more than the work-items -- nearly always -- each
+            //  work-item keeps its word's flags and gets its prefix sums in registers, ft_scan_tid: no arrays, one barrier)
+            const int naw_n0 = s_red[5];
+            const bool one_each = max(n1, naw_n0) + 1 <= NT;
+            int my_ex = 0, my_new = 0, my_rc = 0;
             for (int i = tid; i <= n1; i += NT) {
                 int ex = 0, nw = 0, rcn = 0;
                 if (i < n1) {
@@ -2007,29 +2022,37 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         }
                     }
                 }
-                f_ex[i] = ex; f_new[i] = nw; f_rc[i] = rcn;
+                if (one_each) { my_ex = ex; my_new = nw; my_rc = rcn; }
+                else { f_ex[i] = ex; f_new[i] = nw; f_rc[i] = rcn; }
             }
             // the NEXT frame's active words are complete since the positions step (s_red[5] of them in awln): their right-context
             // counts ride in the same scan, so that the next frame starts without a barrier and a scan of its own
-            const int naw_n = s_red[5], n_sc = max(n1, naw_n) + 1;
-            for (int i = n1 + 1 + tid; i < n_sc; i += NT) { f_new[i] = 0; f_rc[i] = 0; }
-            for (int i = tid; i < n_sc; i += NT) {
-                int k = 0;
-                if (i < naw_n) { const int w = awln[i]; k = wc_off[w + 1] - wc_off[w]; }
-                woff[i] = k;
-            }
-            ft_sync<SMALL>();
+            const int naw_n = naw_n0, n_sc = max(n1, naw_n) + 1;
             const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
             int32_t tot[3];
-            {
+            if (one_each) {
+                int32_t v[3] = { my_new, my_rc, 0 };
+                if (tid < naw_n) { const int w = awln[tid]; v[2] = wc_off[w + 1] - wc_off[w]; }
+                ft_scan_tid<NT, 3, SMALL>(v, s_scan, tot);
+                if (tid < n_sc) woff[tid] = v[2];                // (read by the next frame's list building, behind barriers)
+                my_new = v[0]; my_rc = v[1];
+            }
+            else {
+                for (int i = n1 + 1 + tid; i < n_sc; i += NT) { f_new[i] = 0; f_rc[i] = 0; }
+                for (int i = tid; i < n_sc; i += NT) {
+                    int k = 0;
+                    if (i < naw_n) { const int w = awln[i]; k = wc_off[w + 1] - wc_off[w]; }
+                    woff[i] = k;
+                }
+                ft_sync<SMALL>();
                 int32_t *const arr[3] = { f_new, f_rc, woff };
                 ft_block_scan_k<NT, 3, SMALL>(arr, n_sc, s_scan, tot);
             }
             nwc_cur = tot[2];
             FT_PROF(20);
             for (int i = tid; i < n1; i += NT)
-                if (f_ex[i]) {
-                    int32_t bpi = bpidx0 + f_new[i], bsh = bss0 + f_rc[i];
+                if (one_each ? my_ex : f_ex[i]) {
+                    int32_t bpi = bpidx0 + (one_each ? my_new : f_new[i]), bsh = bss0 + (one_each ? my_rc : f_rc[i]);
                     const int w = w1w_f[i];
                     const int32_t score = tv.at(W1 + i, F::OUT), path = tv.at(W1 + i, F::OUTH);
                     if (word_lat_idx[w] == -1 && bpi < tb.bp_cap && bsh + n_ci < tb.bss_cap) {

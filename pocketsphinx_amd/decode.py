@@ -165,6 +165,17 @@ class DecodePipeline:
                                                           self.n_utt, st), "psgpu_decode_first_pass_dev")
         self._stream = st
 
+    def front_end_ahead(self, pcm_dev, samp_off):
+        """psgpu_decode_front_end_ahead: the NEXT call's front end on the object's own stream, while its latest search is still
+        running (two objects taking turns: search_after).  The next run_dev with the same pcm_dev / samp_off skips its front end.
+        Returns whether it was issued (only for an input of the latest call's shape)."""
+        samp_off = np.ascontiguousarray(samp_off, np.int64)
+        self._keep_ahead = (pcm_dev, samp_off)
+        started = C.c_int32(0)
+        capi.check(capi.lib().psgpu_decode_front_end_ahead(self.h, C.c_void_p(pcm_dev.data_ptr()), samp_off.ctypes.data_as(C.c_void_p),
+                                                           int(samp_off.size - 1), C.byref(started)), "psgpu_decode_front_end_ahead")
+        return bool(started.value)
+
     def run(self, pcms, stream=None):
         """pcms: list of int16 numpy arrays (host)."""
         import torch

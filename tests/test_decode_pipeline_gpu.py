@@ -162,3 +162,55 @@ def test_two_pipelines_taking_turns(tables):
         q.close()
     for s in streams:
         pdec.free_stream(s)
+
+
+def test_two_pipelines_front_end_ahead(tables):
+    """psgpu_decode_front_end_ahead: with two objects taking turns, the front end of an object's NEXT call is issued on the object's
+    own stream while its latest search is still resident (before the other object's call); the call then skips its front end.
+    Same batches every time (the entry only runs for an input of the latest call's shape): every call's tables are the
+    reference's, whether its front end ran ahead (calls 2..) or inside the call (calls 0, 1), and a call with ANOTHER input after an
+    ahead run does its own front end."""
+    import torch
+    from pocketsphinx_amd import decode as pdec
+    clips = _load("speech_clips.npz")
+    pipes = [_pipeline(tables), _pipeline(tables)]
+    streams = [pdec.dedicated_stream(), pdec.dedicated_stream()]
+    pipes[0].search_after(pipes[1]); pipes[1].search_after(pipes[0])
+    names = ["goforward", "numbers", "goforward"]
+    pcms = [clips[n] for n in names]
+    off = np.zeros(len(pcms) + 1, np.int64); off[1:] = np.cumsum([x.size for x in pcms])
+    x = torch.from_numpy(np.concatenate(pcms)).cuda()
+    o_names = [names[1], names[0], names[2]]                             # (another input: other offsets)
+    o_pcms = [clips[n] for n in o_names]
+    other = torch.from_numpy(np.concatenate(o_pcms)).cuda()
+    off_o = np.zeros(len(pcms) + 1, np.int64); off_o[1:] = np.cumsum([p.size for p in o_pcms])
+    torch.cuda.synchronize()
+
+    def check(k, out, order):
+        hn, hyp, res = out
+        for u, n in enumerate(order):
+            g = _load("fwdtree_trace_%s.npz" % n)
+            r = pipes[k % 2].tables(u, res)
+            r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+            _check(r, g, "%s in call %d" % (n, k))
+    started = []
+    K = 7
+    for k in range(K):
+        if k >= 2:
+            check(k - 2, pipes[k % 2].fetch(), names)
+        if k + 1 < K:
+            started.append(pipes[(k + 1) % 2].front_end_ahead(x, off))
+        pipes[k % 2].run_dev(x, off, streams[k % 2])
+    assert started == [False] + [True] * (K - 2), started          # (object 1 has no call before its first)
+    for k in range(K - 2, K):
+        check(k, pipes[k % 2].fetch(), names)
+    # an ahead run that the next call does not use (another input of the same shape... and of another shape)
+    assert pipes[0].front_end_ahead(x, off)
+    pipes[0].run_dev(other, off_o, streams[0])
+    check(0, pipes[0].fetch(), o_names)
+    assert not pipes[0].front_end_ahead(x, off)                      # (the latest call had other offsets)
+    pipes[0].search_after(None); pipes[1].search_after(None)
+    for q in pipes:
+        q.close()
+    for s in streams:
+        pdec.free_stream(s)
