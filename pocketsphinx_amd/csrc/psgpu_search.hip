@@ -283,6 +283,20 @@ __device__ __forceinline__ void ch_normalize(const ChView &v, int c, int32_t nor
     for (int i = 0; i < NE; ++i) if (v.at(c, F::SCORE + i) > kW) v.at(c, F::SCORE + i) -= norm;
     if (v.at(c, F::OUT) > kW) v.at(c, F::OUT) -= norm;
 }
+// A 3-state model's transition matrix (12 bytes, 4-byte aligned: the tables are LDS copies that start on a word) as three word
+// reads instead of the eight byte reads the Viterbi step would make of it
+template <int NE>
+__device__ __forceinline__ const uint8_t *ft_tp_row(const uint8_t *tpall, int tmat, uint8_t (&buf)[NE * (NE + 1)])
+{
+    if (NE == 3) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(tpall + (size_t)tmat * 12);
+        const uint32_t a = q[0], b = q[1], c = q[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { buf[k] = (uint8_t)(a >> (8 * k)); buf[4 + k] = (uint8_t)(b >> (8 * k)); buf[8 + k] = (uint8_t)(c >> (8 * k)); }
+        return buf;
+    }
+    return tpall + (size_t)tmat * NE * (NE + 1);
+}
 // hmm_vit_eval on channel c with the frame's scores
 template <int NE, typename S>
 __device__ __forceinline__ int32_t ch_eval(const ChView &v, int c, const S &row, const uint8_t *tpall, const uint16_t *sseq)
@@ -296,7 +310,8 @@ __device__ __forceinline__ int32_t ch_eval(const ChView &v, int c, const S &row,
         h.senid[i] = i < NE ? (uint16_t)v.at(c, F::SENID + i) : 0;
     }
     h.out_score = v.at(c, F::OUT); h.out_history = v.at(c, F::OUTH); h.bestscore = v.at(c, F::BEST);
-    const uint8_t *tp = tpall + (size_t)v.at(c, F::TMAT) * NE * (NE + 1);
+    uint8_t tpb[NE * (NE + 1)];
+    const uint8_t *tp = ft_tp_row<NE>(tpall, v.at(c, F::TMAT), tpb);
     const int mpx = v.at(c, F::MPX);
     int32_t b;
     if (NE == 3) b = mpx ? vit3_mpx(h, tp, row, sseq) : vit3(h, tp, row);
@@ -329,7 +344,8 @@ __device__ __forceinline__ int32_t ch_eval_rec(int32_t *rec, const S &row, const
         h.senid[i] = i < NE ? (uint16_t)w[F::SENID + i] : 0;
     }
     h.out_score = w[F::OUT]; h.out_history = w[F::OUTH]; h.bestscore = w[F::BEST];
-    const uint8_t *tp = tpall + (size_t)w[F::TMAT] * NE * (NE + 1);
+    uint8_t tpb[NE * (NE + 1)];
+    const uint8_t *tp = ft_tp_row<NE>(tpall, w[F::TMAT], tpb);
     const int mpx = w[F::MPX];
     int32_t b;
     if (NE == 3) b = mpx ? vit3_mpx(h, tp, row, sseq) : vit3(h, tp, row);
@@ -366,7 +382,8 @@ __device__ __forceinline__ int32_t ch_eval_tree(int32_t *rec, const S &row, cons
         h.senid[i] = i < NE ? (uint16_t)w[F::SENID + i] : 0;
     }
     h.out_score = w[F::OUT]; h.out_history = w[F::OUTH]; h.bestscore = w[F::BEST];
-    const uint8_t *tp = tpall + (size_t)w[F::TMAT] * NE * (NE + 1);
+    uint8_t tpb[NE * (NE + 1)];
+    const uint8_t *tp = ft_tp_row<NE>(tpall, w[F::TMAT], tpb);
     const int mpx = w[F::MPX];
     int32_t b;
     if (NE == 3) b = mpx ? vit3_mpx(h, tp, row, sseq) : vit3(h, tp, row);
