@@ -53,7 +53,7 @@ constexpr int32_t kZeroCopyMax = 2048;
 #include "psgpu_sen_dev.h"
 
 constexpr int kHmmThreads = 256;
-constexpr int kTpLdsMax = 16384;
+constexpr int kTpLdsMax = 4096;      // (transition matrices of up to this many bytes sit in LDS: en-us 504, a 5-state model of 136 matrices)
 
 // fold a wave's running maximum into best[utt] (one atomic per wave per flush)
 __device__ __forceinline__ void flush_best(int32_t *best_out, int utt, int32_t m)
@@ -63,7 +63,8 @@ __device__ __forceinline__ void flush_best(int32_t *best_out, int utt, int32_t m
     if ((threadIdx.x & 63) == 0 && m != kMaxNegInt32) atomicMax(&best_out[utt], m);
 }
 
-template <int NE>
+typedef int hmm_v4i __attribute__((ext_vector_type(4)));
+template <int NE, bool STREAM>      // STREAM: a dense list beyond the caches' reach, read and written around them
 __global__ __launch_bounds__(kHmmThreads)
 void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restrict__ active,
                     int32_t n_active, const uint16_t *__restrict__ utt_of_hmm,
@@ -74,6 +75,12 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_tp[kTpLdsMax];
     __shared__ int32_t s_wbest[kHmmThreads / 64], s_wutt[kHmmThreads / 64];
+    // dense lists (active == NULL: records base .. base + 63 of a wavefront lie side by side): the records travel through LDS, 1 KB
+    // contiguous per wave-instruction (sixteen full lines) instead of sixteen bytes of each of 64 lines four times over -- the
+    // kernel's time was the address processing of those accesses (bench.py extra.hmm_vit_kernel).  Quad q of record r sits at
+    // quad slot 4 r + ((q + (r >> 1)) & 3): a record's work-item then reads its four quads without bank conflicts beyond the
+    // eight-lane groups a 128-bit LDS read is served in.
+    __shared__ int4 s_stage[kHmmThreads / 64][256];
     const bool tp_in_lds = tp_bytes <= kTpLdsMax;
     if (tp_in_lds) {
         for (int i = threadIdx.x * 4; i < tp_bytes; i += kHmmThreads * 4) {
@@ -89,16 +96,35 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
     int32_t acc = kMaxNegInt32;
     int acc_utt = -1;
     const int stride = gridDim.x * kHmmThreads;
+    constexpr bool stream_list = STREAM;
     for (int base = blockIdx.x * kHmmThreads; base < n_active; base += stride) {
         const int i = base + threadIdx.x;
         const bool live = i < n_active;
         int32_t best = kMaxNegInt32;
         int utt = 0;
+        const int lane = threadIdx.x & 63;
+        const bool dense = !active && (base + (int)(threadIdx.x & ~63u) + 64 <= n_active);      // (wave-uniform: a full wavefront of consecutive records)
+        int4 *const stg = s_stage[threadIdx.x >> 6];
+        if (dense) {
+            const int4 *gp = reinterpret_cast<const int4 *>(recs + (i - lane));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pq = k * 64 + lane, r = pq >> 2, q = pq & 3;
+                // (a list beyond the caches' reach -- 2^20 records, 64 MB -- is streamed: neither its reads nor its writes are worth a line there)
+                if (stream_list) *reinterpret_cast<hmm_v4i *>(&stg[4 * r + ((q + (r >> 1)) & 3)]) = __builtin_nontemporal_load(reinterpret_cast<const hmm_v4i *>(&gp[pq]));
+                else stg[4 * r + ((q + (r >> 1)) & 3)] = gp[pq];
+            }
+        }
         if (live) {
             const int idx = active ? active[i] : i;
             // one 64-byte line in
             const int4 *rp = reinterpret_cast<const int4 *>(recs + idx);
-            int4 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+            int4 q0, q1, q2, q3;
+            if (dense) {
+                const int sw = lane >> 1;
+                q0 = stg[4 * lane + (sw & 3)]; q1 = stg[4 * lane + ((1 + sw) & 3)]; q2 = stg[4 * lane + ((2 + sw) & 3)]; q3 = stg[4 * lane + ((3 + sw) & 3)];
+            }
+            else { q0 = rp[0]; q1 = rp[1]; q2 = rp[2]; q3 = rp[3]; }
             utt = utt_of_hmm ? utt_of_hmm[idx] : 0;
             HmmRegs h;
             h.score[0] = q0.x; h.score[1] = q0.y; h.score[2] = q0.z; h.score[3] = q0.w;
@@ -126,8 +152,23 @@ void hmm_vit_kernel(psgpu_hmm_rec_t *__restrict__ recs, const int32_t *__restric
             q3 = make_int4(h.bestscore, (int32_t)((uint32_t)h.senid[0] | ((uint32_t)h.senid[1] << 16)),
                            (int32_t)((uint32_t)h.senid[2] | ((uint32_t)h.senid[3] << 16)),
                            (int32_t)((uint32_t)h.senid[4] | (tm << 16)));
-            int4 *wp = reinterpret_cast<int4 *>(recs + idx);
-            wp[0] = q0; wp[1] = q1; wp[2] = q2; wp[3] = q3;
+            if (dense) {
+                const int sw = lane >> 1;
+                stg[4 * lane + (sw & 3)] = q0; stg[4 * lane + ((1 + sw) & 3)] = q1; stg[4 * lane + ((2 + sw) & 3)] = q2; stg[4 * lane + ((3 + sw) & 3)] = q3;
+            }
+            else {
+                int4 *wp = reinterpret_cast<int4 *>(recs + idx);
+                wp[0] = q0; wp[1] = q1; wp[2] = q2; wp[3] = q3;
+            }
+        }
+        if (dense) {
+            int4 *gp = reinterpret_cast<int4 *>(recs + (i - lane));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int slot = k * 64 + lane, r = slot >> 2, q = ((slot & 3) - (r >> 1)) & 3;
+                if (stream_list) __builtin_nontemporal_store(*reinterpret_cast<const hmm_v4i *>(&stg[slot]), reinterpret_cast<hmm_v4i *>(&gp[4 * r + q]));
+                else gp[4 * r + q] = stg[slot];
+            }
         }
         if (best_out) {
             const unsigned long long lv = __ballot(live);
@@ -497,13 +538,17 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
     if (n_active == 0) return PSGPU_OK;
     // persistent grid: at most 8 workgroups of 4 waves per CU on 256 CUs
     int blocks = (n_active + kHmmThreads - 1) / kHmmThreads;
-    if (blocks > 2048) blocks = 2048;
+    // (persistent workgroups: as many as stay resident together -- 20.5 KB of LDS each, seven on a compute unit of 256)
+    static const int max_blocks = [] { const char *e = getenv("PSGPU_HMM_BLOCKS"); return e ? atoi(e) : 1792; }();
+    if (blocks > max_blocks) blocks = max_blocks;
     const int32_t tpb = c->n_tmat * c->n_emit * (c->n_emit + 1);
-#define HMM_LAUNCH(NE)                                                                                                 \
-    hipLaunchKernelGGL((hmm_vit_kernel<NE>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,                   \
+#define HMM_LAUNCH_(NE, STREAM)                                                                                        \
+    hipLaunchKernelGGL((hmm_vit_kernel<NE, STREAM>), dim3(blocks), dim3(kHmmThreads), 0, (hipStream_t)stream,           \
                        recs_dev, active_idx_dev, n_active, utt_of_hmm_dev, senscr_dev, senscr_stride,                   \
                        (const uint8_t *)c->tp, tpb, (const uint16_t *)c->sseq, best_dev,                                \
                        c->launch_done_count, c->launch_done_word, c->launch_seq)
+    // (a dense list of more than 2^20 records -- 64 MB -- is streamed around the caches)
+#define HMM_LAUNCH(NE) do { if (!active_idx_dev && n_active > (1 << 20)) HMM_LAUNCH_(NE, true); else HMM_LAUNCH_(NE, false); } while (0)
     switch (c->n_emit) {
     case 1: HMM_LAUNCH(1); break;
     case 2: HMM_LAUNCH(2); break;
@@ -512,6 +557,7 @@ int psgpu_hmm_vit_eval_dev(psgpu_hmm_ctx_t *c, psgpu_hmm_rec_t *recs_dev,
     default: HMM_LAUNCH(5); break;
     }
 #undef HMM_LAUNCH
+#undef HMM_LAUNCH_
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }
