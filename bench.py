@@ -236,12 +236,15 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
     return out
 
 
-def ms_scorer_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, static, gt, n_utt, steps, n_check, with_cpu):
+def ms_scorer_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, static, gt, n_utt, steps, n_check, with_cpu, cont_tables=None):
     """BASELINE configs[3]'s per-GPU material: a batch of 64 utterances decoded with the multi-stream scorer (en-us through
     ms_cont_mgau_frame_eval, the reference's -senmgau route: 42 codebooks x 3 streams x 128 densities, top-4 by full scan,
-    16-bit log-add) -- PCM -> hypotheses through the same device pipeline; the reference decodes n_check of them with that scorer"""
+    16-bit log-add) -- PCM -> hypotheses through the same device pipeline; the reference decodes n_check of them with that scorer.
+    cont_tables: the leg with a CONTINUOUS-density model instead (configs[3] as written): the scorer's tables of the staged
+    5126 x 16 x 39 model as integration/psgpu_export_tables wrote them (the same lexicon tree: en-us's mdef), the reference
+    decoding with that model directory"""
     import torch
-    ms = P.MsMgau(_npz("ms_en_us_tables.npz"))
+    ms = P.MsMgau(cont_tables if cont_tables is not None else _npz("ms_en_us_tables.npz"))
     pipe = P.DecodePipeline(fe_tables, None, static, gt["par"], gt, scorer=ms)
     pipe.stage_timing(True)
     pcm = torch.from_numpy(pcm_all[:n_utt * n_samp]).to(dev)
@@ -262,17 +265,23 @@ def ms_scorer_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, static, gt, n_utt
     out = {"frames_per_s": round(frames / dt, 1), "ms_per_step": round(1e3 * dt, 2), "utterances": n_utt, "frames": frames,
            "xrt": round(dt / (n_utt * seconds), 8), "stage_ms": {k: round(v, 3) for k, v in st_mean.items()},
            "status_nonzero": int((res[:, 3] != 0).sum()),
-           "what": "configs[3]: %d utterances x %g s, en-us through the ms scorer (-senmgau .ptm.) + turtle LM, fwdtree only, PCM -> "
+           "what": ("configs[3]: %d utterances x %g s, a continuous-density model of en-us size (5126 senones x 16 densities x 39 dimensions, "
+                    "one codebook a senone: ms_gauden + ms_senone with .cont. mixtures; synthetic parameters cut from en-us, "
+                    "oracle/stage_cont_model.py) + turtle LM, fwdtree only, PCM -> hypotheses on one MI355X" % (n_utt, seconds))
+                   if cont_tables is not None else
+                   "configs[3]: %d utterances x %g s, en-us through the ms scorer (-senmgau .ptm.) + turtle LM, fwdtree only, PCM -> "
                    "hypotheses on one MI355X (the per-GPU share of the 8-way shard; utterances shard as in the headline)" % (n_utt, seconds)}
     if with_cpu:
         ids = sorted(set(int(i) for i in np.linspace(0, n_utt - 1, min(n_check, n_utt))))
-        ref = reference_decode(pcm_all, n_samp, ids, procs=min(len(ids), max(1, (os.cpu_count() or 2) // 2)), model="en-us-ms",
-                               extra=("senmgau", ".ptm."))
+        ref = reference_decode(pcm_all, n_samp, ids, procs=min(len(ids), max(1, (os.cpu_count() or 2) // 2)),
+                               model="en-us-cont" if cont_tables is not None else "en-us-ms",
+                               extra=() if cont_tables is not None else ("senmgau", ".ptm."))
         if ref is not None:
             utts, tot = ref
             bad = parity_of(ids, utts, hn, hyp, res)
             out["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference",
-                                   "sample": "%d utterances, %.1f s of CPU in all, -senmgau .ptm. -fwdflat no -bestpath no" % (len(ids), tot["cpu_s"])}
+                                   "sample": "%d utterances, %.1f s of CPU in all, %s-fwdflat no -bestpath no" % (
+                                       len(ids), tot["cpu_s"], "" if cont_tables is not None else "-senmgau .ptm. ")}
             out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad}
     pipe.close(); ms = None
     del pcm
@@ -759,6 +768,23 @@ def main():
                                                      _npz("fwdtree_static_en_us_turtle.npz"), gt, min(64, B), 2, LEG_CHECK, not args.no_cpu_baseline)
         except Exception as e:
             line["decode_ms_scorer"] = {"error": str(e)[-400:]}
+        try:
+            # configs[3] as written: the continuous-density model through the same pipeline (tables: integration/_tables, exported
+            # from a decoder the reference initialised with the staged model)
+            from pocketsphinx_amd.tablefile import read_psgb
+            tdir = os.environ.get("PSGPU_TABLE_DIR") or os.path.join(ROOT, "integration", "_tables")
+            cpath = os.path.join(tdir, "en_us_cont_turtle.psgb")
+            if os.path.exists(cpath):
+                cg = read_psgb(cpath)
+                ct = {k[3:]: v for k, v in cg.items() if k.startswith("ms_")}
+                ct["sen2mgau"] = ct["sen2mgau"].astype(np.uint32)
+                line["decode_ms_continuous"] = ms_scorer_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"),
+                                                             _npz("fwdtree_static_en_us_turtle.npz"), gt, min(64, B), 2, LEG_CHECK,
+                                                             not args.no_cpu_baseline, cont_tables=ct)
+            else:
+                line["decode_ms_continuous"] = {"skipped": "%s not built (make -C integration tables)" % cpath}
+        except Exception as e:
+            line["decode_ms_continuous"] = {"error": str(e)[-400:]}
         try:
             line["decode_two_pass"] = two_pass_leg(P, pcm_all, n_samp, args.seconds, dev, _npz("mfcc_en_us_goforward.npz"), tables,
                                                    _npz("fwdtree_static_en_us_turtle.npz"), gt, B, 2, LEG_CHECK, not args.no_cpu_baseline)

@@ -77,6 +77,35 @@ def test_pipeline_with_the_ms_scorer_en_us(tmp_path):
     p.close()
 
 
+def test_pipeline_with_a_continuous_model_of_en_us_size(tmp_path):
+    """BASELINE configs[3] as written: a continuous-density model at scale -- 5126 senones x 16 densities x 39 dimensions, one
+    codebook a senone (`.cont.` mixtures; staged by oracle/stage_cont_model.py from en-us's own parameters, the scorer's tables
+    exported by integration/psgpu_export_tables from a decoder the reference initialised with it) -- PCM -> hypotheses through the
+    device pipeline (the fused continuous kernel of csrc/psgpu_ms.hip), against the reference decoding the same PCM with that
+    model directory"""
+    _need_ref()
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import synth
+    from pocketsphinx_amd.tablefile import read_psgb
+    path = os.path.join(os.path.dirname(pso.__file__), "..", "integration", "_tables", "en_us_cont_turtle.psgb")
+    if not os.path.exists(path) or not os.path.exists(os.path.join(REF, "model", "en-us-cont", "means")):
+        pytest.fail("integration/_tables/en_us_cont_turtle.psgb / oracle/_ref/model/en-us-cont not built (__graft_entry__.build())")
+    cg = read_psgb(path)
+    ct = {k[3:]: v for k, v in cg.items() if k.startswith("ms_")}
+    ct["sen2mgau"] = ct["sen2mgau"].astype(np.uint32)
+    assert int(ct["n_mgau"][0]) == int(ct["n_sen"][0]) == 5126 and int(ct["n_density"][0]) == 16 and int(ct["featlen"][0]) == 39
+    pcms = [synth.utterance(i, 6.0) for i in (2, 4, 9, 11)]
+    refs = _ref_decode(tmp_path, "en-us-cont", pcms, ())
+    gt = _load("fwdtree_trace_goforward.npz")
+    ms = P.MsMgau(ct)
+    p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), None, _load("fwdtree_static_en_us_turtle.npz"), gt["par"], gt, scorer=ms)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    for u, r in enumerate(refs):
+        _same(u, r, hn, hyp, res, "en-us-cont utterance %d" % u)
+    p.close()
+
+
 def test_pipeline_with_the_ms_scorer_an4_continuous(tmp_path):
     """an4_ci_cont (the reference's test_mllr model: 102 codebooks x 1 density x 39 dims, senone i owns codebook i; 40 mel
     filters, other band edges; CI phones only, so part of the dictionary is dropped): every table of this configuration read
