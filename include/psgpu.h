@@ -714,6 +714,11 @@ void psgpu_decode_free(psgpu_decode_t *d);
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);
 /* the same for a pipeline created with PSGPU_SCORER_SEMI / PSGPU_SCORER_MS: the new handle of that kind, same shape */
 int psgpu_decode_set_scorer(psgpu_decode_t *d, void *scorer);
+/* -compallsen yes (acmod.c:1098-1128): every senone is scored and the rows are normalised over ALL of them (the scorers' compallsen
+ * branches, ptm_mgau.c:393-400, ms_mgau.c:213-236) instead of over what the phone loop / the search list; both then take the rows as
+ * final scores.  PTM and multi-stream scorers; not together with psgpu_decode_score_mode(lists) or psgpu_decode_second_pass (the
+ * device second pass scores and normalises its own lists). */
+int psgpu_decode_compallsen(psgpu_decode_t *d, int32_t on);
 /* Two pipeline objects taking turns.  The tree search is a latency-bound recurrence -- one workgroup per utterance, most
  * issue slots of its compute units idle -- and the stages before it are throughput-bound, so the front end and scorer of
  * one batch run BESIDE the search of another: one object per batch in flight, each on a stream with a hardware queue of

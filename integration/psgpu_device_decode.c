@@ -23,7 +23,7 @@
  * vocabularies, every ngram_tg_score in a dense table.  The scorer is whichever psgpu scorer the decoder carries: PTM or
  * multi-stream ("ms": any -senmgau model, models without a sendump).  Requires the n-gram search with -fwdtree
  * yes, a psgpu scorer (psgpu_mgau_attach first), the 1s_c_d_dd feature type with batch CMN,
- * -compallsen no and the phone-loop look-ahead (pl_window > 0). */
+ * the phone-loop look-ahead (pl_window > 0); -compallsen yes is served (psgpu_decode_compallsen). */
 #include <stdlib.h>
 #include <string.h>
 
@@ -119,10 +119,13 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     want_ff = ngs->fwdflat && getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS"));
     acmod = ps->acmod; mdef = acmod->mdef;
     n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(ps_search_dict(ngs));
-    if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->compallsen || acmod->fcb->cmn != CMN_BATCH
+    if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->fcb->cmn != CMN_BATCH
         || acmod->fcb->agc != AGC_NONE || acmod->fcb->varnorm) {
-        E_ERROR("psgpu device decode: needs the 1s_c_d_dd feature type with -cmn batch, no AGC / variance normalisation / LDA, "
-                "and -compallsen no\n");
+        E_ERROR("psgpu device decode: needs the 1s_c_d_dd feature type with -cmn batch, no AGC / variance normalisation / LDA\n");
+        return NULL;
+    }
+    if (acmod->compallsen && want_ff) {
+        E_ERROR("psgpu device decode: the device second pass normalises over its own senone lists (-compallsen no)\n");
         return NULL;
     }
     model = psgpu_mgau_ptm_model(acmod->mgau);
@@ -203,6 +206,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         cfg.pl_ssid = ps_ssid; cfg.pl_tmatid = ps_tm; cfg.ci_list = cil; cfg.n_ci_list = nl; cfg.pl_window = ps->pl_window;
         cfg.max_words = 0;
         i = psgpu_decode_create(&d->dec, &cfg);
+        if (i == PSGPU_OK && acmod->compallsen) i = psgpu_decode_compallsen(d->dec, 1);      /* -compallsen yes: rows over all senones */
         ckd_free(ps_ssid); ckd_free(cil); ckd_free(ps_tm); ckd_free(flags);
     }
     else if (i == PSGPU_OK) {

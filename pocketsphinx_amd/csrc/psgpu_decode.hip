@@ -32,6 +32,7 @@ struct psgpu_decode_s {
     // (psgpu_phone_loop_run_lists_dev, psgpu_fwdtree_search_lists_dev); the senone kernel and its rows are left out
     psgpu_ptm_view_t view;
     bool lists = false, want_lists = false;
+    bool compall = false;                // psgpu_decode_compallsen: every senone scored and normalised over all of them (-compallsen yes)
     // a decoder session (psgpu_decode_session): what utterance k + 1 of ONE reference decoder inherits from utterance k --
     // the scorer's last top-N lists (the seeds of the next first frame, ptm_mgau.c) and the per-state ssids of the permanent
     // multiplexed channels (hmm_clear keeps them)
@@ -101,7 +102,7 @@ static bool dec_can_lists(psgpu_decode_s *d)
 static void dec_pick_mode(psgpu_decode_s *d)
 {
     static const int env_lists = [] { const char *e = getenv("PSGPU_DECODE_LISTS"); return e ? atoi(e) : 0; }();
-    d->lists = (d->want_lists || env_lists) && dec_can_lists(d);
+    d->lists = (d->want_lists || env_lists) && !d->compall && dec_can_lists(d);
 }
 
 // The codeword lists the second pass's frame 0 starts from, per utterance: slot n_fast_hist - 1 of the scorer's history ring as the
@@ -274,6 +275,19 @@ int psgpu_decode_wait_scored(psgpu_decode_t *d)
     return PSGPU_OK;
 }
 
+// -compallsen yes: acmod_score has the scorer evaluate EVERY senone and normalise over all of them (acmod.c:1098-1128, the scorers'
+// compallsen branches: ptm_mgau.c:393-400 over the whole array, ms_mgau.c:213-236), whatever the searches list; the phone loop and the
+// search then take the rows as final scores (the mode the semi-continuous scorer always has).
+int psgpu_decode_compallsen(psgpu_decode_t *d, int32_t on)
+{
+    PSGPU_REQUIRE(d && d->kind != PSGPU_SCORER_SEMI, "psgpu_decode_compallsen: NULL argument, or the semi-continuous scorer (its scores are final anyway)");
+    PSGPU_REQUIRE(!(on && d->want_lists), "psgpu_decode_compallsen: scoring from lists (psgpu_decode_score_mode) evaluates the listed senones only");
+    d->compall = on != 0;
+    d->raw_flag = on ? 3 : 1;
+    dec_pick_mode(d);
+    return PSGPU_OK;
+}
+
 int psgpu_decode_set_scorer(psgpu_decode_t *d, void *scorer)
 {
     PSGPU_REQUIRE(d && scorer, "psgpu_decode_set_scorer: NULL argument");
@@ -379,11 +393,12 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
     if (d->kind == PSGPU_SCORER_PTM)
         rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, chained && d->seed_valid ? d->d_seed : nullptr,
                                        nullptr, d->d_tsc, d->d_tcw, d->lists ? nullptr : d->d_rows, d->lists ? nullptr : d->d_best,
-                                       PSGPU_PTM_RAW_SCORES, st);
+                                       d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st);
     else if (d->kind == PSGPU_SCORER_SEMI)               // every utterance from a new scorer's lists, frames numbered from 0
         rc = psgpu_semi_score_batch_dev((psgpu_semi_model_t *)d->cfg.scorer, d->d_feat, d->d_off, n_utt, (int32_t)total, d->d_rows, st);
     else                                                 // no time dependence: frames of all utterances back to back
-        rc = psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st);
+        rc = d->compall ? psgpu_ms_score_batch_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st)
+                        : psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st);
     if (rc) return rc;
     if (sess && d->kind == PSGPU_SCORER_PTM) {
         // what seeds the next utterance's first frame: ptm_mgau_frame_eval copies frame 0's initial lists from slot
@@ -734,6 +749,7 @@ int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *strea
     if (d->n_utt == 0 || d->total == 0) { d->pass2 = false; return PSGPU_OK; }
     PSGPU_REQUIRE(d->searched, "psgpu_decode_second_pass: the first pass of this call did not complete");
     PSGPU_REQUIRE(d->kind == PSGPU_SCORER_PTM, "psgpu_decode_second_pass: the device second pass scores from the PTM scorer's lists");
+    PSGPU_REQUIRE(!d->compall, "psgpu_decode_second_pass: the device second pass normalises over its own senone lists (-compallsen no)");
     PSGPU_REQUIRE(psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK, "psgpu_decode_second_pass: no view of the PTM model");
     PSGPU_REQUIRE(d->last_lag == 0, "psgpu_decode_second_pass: the first pass stopped short of the utterances' ends (psgpu_decode_search_lag)");
     hipStream_t st = (hipStream_t)stream;

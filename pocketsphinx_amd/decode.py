@@ -165,6 +165,10 @@ class DecodePipeline:
                                                           self.n_utt, st), "psgpu_decode_first_pass_dev")
         self._stream = st
 
+    def compallsen(self, on=True):
+        """psgpu_decode_compallsen: -compallsen yes -- rows normalised over all senones, taken as final by the phone loop and the search"""
+        capi.check(capi.lib().psgpu_decode_compallsen(self.h, int(bool(on))), "psgpu_decode_compallsen")
+
     def front_end_ahead(self, pcm_dev, samp_off):
         """psgpu_decode_front_end_ahead: the NEXT call's front end on the object's own stream, while its latest search is still
         running (two objects taking turns: search_after).  The next run_dev with the same pcm_dev / samp_off skips its front end.

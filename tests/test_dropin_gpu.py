@@ -477,6 +477,9 @@ def test_dropin_device_phone_loop_resumes_on_host(break_at, monkeypatch):
     ("numbers.raw", 1, (), "turtle.lm.bin", "turtle.dic", None),
     ("something.raw", 1, ("pl_window", "2", "pl_weight", "1.5"), "turtle.lm.bin", "turtle.dic", None),
     ("goforward.raw", 1, ("maxhmmpf", "100", "maxwpf", "5"), "turtle.lm.bin", "turtle.dic", None),   # histogram + word pruning
+    # -compallsen yes: every senone scored, rows normalised over all of them (psgpu_decode_compallsen)
+    ("goforward.raw", 1, ("compallsen", "yes"), "turtle.lm.bin", "turtle.dic", None),
+    ("numbers.raw", 1, ("compallsen", "yes", "bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
     # pass 3 on the host over the injected table: ngram_search_lattice + ps_lattice_bestpath (SURVEY f-2)
     ("goforward.raw", 1, ("bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
     ("numbers.raw", 1, ("bestpath", "yes"), "turtle.lm.bin", "turtle.dic", None),
