@@ -107,6 +107,43 @@ def test_active_list_multi_utt_dev():
     ctx.close()
 
 
+@pytest.mark.parametrize("n_rep", [1, 3000])
+def test_dense_list_dev(n_rep):
+    """Device entry point with a DENSE list (active == NULL): full wavefronts of consecutive records travel through LDS (1 KB a
+    wave-instruction, quads swizzled) and, past 2^20 records, around the caches (the streaming instantiation: n_rep = 3000 tiles
+    the golden's records to ~1.3 M); the tail that does not fill a wavefront takes the record-by-record path.  Every record equals
+    the reference's hmm_vit_eval of the golden's step."""
+    import torch
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import capi
+    g = _load("hmm_en_us_3st.npz")
+    n_sen = int(g["n_sen"][0])
+    ctx = P.HmmContext(g["tp"], g["sseq"], n_sen)
+    n0 = g["before"].shape[1]
+    recs0 = to_recs(P, g["before"][0], g["mpx"])
+    want0 = to_recs(P, g["after"][0], g["mpx"]); want0["bestscore"] = g["ret"][0]
+    n = n0 * n_rep - 17                                           # (not a multiple of 64: a tail)
+    recs = np.tile(recs0, n_rep)[:n]; want = np.tile(want0, n_rep)[:n]
+    if n_rep > 1:
+        assert n > (1 << 20)
+    dev = torch.device("cuda", 0)
+    d_recs = torch.from_numpy(recs.view(np.uint8).reshape(n, 64).copy()).to(dev)
+    d_scr = torch.from_numpy(np.ascontiguousarray(g["senscr"][0])).to(dev)
+    d_best = torch.full((1,), -0x20000000, dtype=torch.int32, device=dev)
+    L = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(L.psgpu_hmm_vit_eval_dev(ctx.h, C.c_void_p(d_recs.data_ptr()), None, n, None, C.c_void_p(d_scr.data_ptr()), n_sen,
+                                        C.c_void_p(d_best.data_ptr()), st), "hmm_vit_eval_dev")
+    torch.cuda.synchronize()
+    got = d_recs.cpu().numpy().reshape(-1).view(P.HMM_REC)
+    for f in ("score", "history", "senid"):
+        assert np.array_equal(got[f][:, :3], want[f][:, :3]), f
+    for f in ("out_score", "out_history", "bestscore", "tmatid_mpx"):
+        assert np.array_equal(got[f], want[f]), f
+    assert int(d_best.item()) == max(int(g["ret"][0].max()), -0x20000000)
+    ctx.close()
+
+
 def test_empty_and_errors():
     import pocketsphinx_amd as P
     g = _load("hmm_en_us_3st.npz")
