@@ -512,6 +512,18 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
                              const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
                              const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
                              int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream);
+/* An utterance IN PROGRESS: phone_loop_search_step is called once per frame and keeps its HMMs, its penalty ring (pen_buf,
+ * pen_buf_ptr) and its best score between ps_process_raw calls (phone_loop_search.c:302-340).  As psgpu_phone_loop_run_dev for
+ * the frames of ONE call (raw_dev / best_dev / penalties_dev hold this call's frames only: utt_off_dev [n_utt + 1] counts them),
+ * with the utterances' state read from (resume != 0) and written to carry_dev [n_utt][psgpu_phone_loop_carry_words()] int32:
+ * resume = 0 starts every utterance afresh (phone_loop_search_start).  The penalties of a sequence of calls are those of one
+ * call over all the frames.  A call without frames for an utterance leaves its state alone. */
+int32_t psgpu_phone_loop_carry_words(void);
+int psgpu_phone_loop_run_carry_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *p, const uint16_t *ssid_dev,
+                                   const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                                   const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
+                                   const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                                   int32_t *penalties_dev, int32_t *carry_dev, int32_t resume, void *stream);
 /* the context's own (non-blocking) stream: a stream a binding can run one decoder's chain of calls on without
  * serialising with other decoders; usable with psgpu_memcpy_* / psgpu_stream_sync.  (`stream` = NULL in the call
  * above is the default stream, as everywhere.) */
@@ -669,6 +681,18 @@ int psgpu_lm_tg_score_dev(const psgpu_lm_t *lm, const int32_t *w3_dev, const int
  * are then what the reference's search holds at that moment (ps_get_hyp in mid-utterance reads them).  0: the whole
  * utterance (the default).  Like psgpu_fwdtree_hyp_out this is per-call state of the handle: one caller at a time. */
 int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag);
+/* For the NEXT search call on this handle only: a search that keeps its state between calls, as the reference's does between
+ * two ps_search_forward rounds (ngram_fwdtree_search is called once per frame and everything it works on stays in the
+ * ngram_search_t, ngram_search_fwdtree.c:1454-1495; pocketsphinx.c:1173-1197).  mode = PSGPU_SEARCH_KEEP: when the call stops
+ * (at the lag, or at the utterances' ends) the state it stopped in is saved in the handle; PSGPU_SEARCH_RESUME: the call starts
+ * from the state the handle's PREVIOUS search call saved -- frames already searched are not searched again -- and must be made
+ * for the same utterances with the same table buffers and capacities, score rows and penalties of ALL frames so far (frames
+ * numbered from the utterance's start: utt_off_dev [n_utt + 1] with more frames than before), the same raw_scores / pl_window;
+ * PSGPU_SEARCH_KEEP | PSGPU_SEARCH_RESUME: both (a call in the middle of a live utterance).  The tables after every call are
+ * the ones one call over the same frames would have written.  LDS layout only (psgpu_fwdtree_layout): PSGPU_EINVAL otherwise. */
+#define PSGPU_SEARCH_KEEP 1
+#define PSGPU_SEARCH_RESUME 2
+int psgpu_fwdtree_search_resume(psgpu_fwdtree_t *m, int32_t mode);
 /* Makes the tree search look its language scores up in `lm` (which must outlive it) instead of
  * the dense table of psgpu_fwdtree_tables_t.lm (which may then be NULL at create). */
 int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
@@ -823,6 +847,25 @@ int psgpu_decode_table_capacity(psgpu_decode_t *d, int32_t bp_per_frame, int32_t
 /* the next psgpu_decode_first_pass* call only: psgpu_fwdtree_search_lag for its search (every stage before it runs over all
  * frames) -- partial results of an utterance in progress */
 int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag);
+/* ---- one utterance IN PROGRESS (the device side of ps_process_raw called chunk by chunk, pocketsphinx.c:1173-1197, 1243-1282):
+ * every stage goes on where the previous step's frames ended, so a live decode costs O(T) whatever the number of steps.
+ *   psgpu_decode_live_begin   a new utterance of at most max_frames frames (session mode: psgpu_decode_session; what the utterance
+ *                             inherits is what psgpu_decode_session_set / the previous utterance left).  Buffers for max_frames frames
+ *                             are allocated here; a live utterance that outgrows them is begun again with a larger capacity and its
+ *                             frames fed again (amortised O(T) when the capacity doubles).
+ *   psgpu_decode_live_step    n_new more feature frames (host, [n_new][veclen] as for psgpu_decode_first_pass_feat): the scorer runs
+ *                             on them from the previous frame's top-N lists (ptm_mgau.c:425-441), the phone loop steps through them
+ *                             (psgpu_phone_loop_run_carry_dev), and the tree search goes on from the frame it stopped at up to `lag`
+ *                             frames short of the frames scored so far (psgpu_fwdtree_search_resume; lag = 0: to the utterance's
+ *                             end -- the utterance's last step).  After every step psgpu_decode_view / _fetch_hyps / _fetch_tables
+ *                             return what ONE psgpu_decode_first_pass_feat call over the frames so far with psgpu_decode_search_lag(lag)
+ *                             would have: the reference's tables at that moment.  n_new may be 0 (another lag).  A model whose
+ *                             search takes the slab layout is searched from the utterance's first frame at every step instead.
+ *   psgpu_decode_live_frames_searched   frames the search kernel has stepped through since live_begin, summed over the steps: the
+ *                             utterance's frames searched so far when every frame was searched once. */
+int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream);
+int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, int32_t lag, void *stream);
+int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d);
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
  * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array.  After

@@ -67,6 +67,11 @@ struct psgpu_device_decode_s {
     ps_searchfuncs_t *orig_vt, *orig_pl_vt;
     float *h_feat; int n_feat, cap_feat;
     int pl_frames, n_partial;          /* frames the phone loop has been stepped through; n_feat of the latest partial read-out */
+    /* the utterance in progress as a LIVE utterance of the device pipeline (psgpu_decode_live_begin / _step): begun by the first
+     * read-out in mid-utterance; live_fed frames handed over so far; live_cap the capacity it was begun with; live_off: the pipeline
+     * refused (then every read-out decodes the prefix again, as before) */
+    int live_on, live_fed, live_cap, live_off;
+    long live_steps, live_restarts;
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
     psgpu_ptm_view_t view;
@@ -83,6 +88,7 @@ struct psgpu_device_decode_s {
  * reference has no user pointer in ps_search_t). */
 static int dev_search_step(ps_search_t *search, int frame_idx);
 static int dev_phone_loop_step(ps_search_t *search, int frame_idx);
+static int live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final);
 static psgpu_device_decode_t *
 find_attached(ps_search_t *search)
 {
@@ -497,6 +503,7 @@ dev_search_start(ps_search_t *search)
     psgpu_device_decode_t *d = find_attached(search);
     if (d == NULL) return -1;
     d->n_feat = 0; d->pl_frames = 0; d->n_partial = -1;
+    d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0;
     return d->orig_vt->start(search);          /* ngram_search_start: tables, timers, <s> entered (ngram_search_fwdtree.c:469-520) */
 }
 
@@ -532,18 +539,24 @@ dev_search_finish(ps_search_t *search)
     psgpu_device_decode_t *d = find_attached(search);
     ngram_search_t *ngs = (ngram_search_t *)search;
     int32_t off[2];
-    int nfr = 0;
+    int nfr = 0, live = 0;
     if (d == NULL) return -1;
     /* the reference's end-of-pass housekeeping on its own (idle) channels and timers; its mark of "one past the last
      * frame" is overwritten by the injected marks below */
     ngram_fwdtree_finish(ngs);
     if (d->n_feat > 0) {
+        if (d->live_on) {                                /* the utterance's remaining frames, the search to its end (lag 0) */
+            if (live_advance(d, ngs, d->n_feat, 1) <= 0) return -1;
+            live = 1;
+        }
+        else {
         if (refresh(d) < 0) return -1;
         off[0] = 0; off[1] = d->n_feat;
         if (session_push(d, ngs) < 0) return -1;
         if (psgpu_decode_first_pass_feat(d->dec, d->h_feat, off, 1, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
             E_ERROR("psgpu device search: %s\n", psgpu_last_error());
             return -1;
+        }
         }
         if (session_pull(d, ngs) < 0) return -1;
         if (fetch_summary(d, 1) < 0) return -1;
@@ -572,7 +585,7 @@ dev_search_finish(ps_search_t *search)
         /* ... and the scorer's history: pass 2's first frame re-scores the lists pass 1 left in slot n_fast_hist - 1
          * (ptm_mgau.c:425-441), i.e. those of the last frame ts with ts % H == H - 1; the batch scorer has them
          * (chain-major [n_chain][T][topn]) */
-        if (d->n_chain > 0) {
+        if (d->n_chain > 0 && !live) {                  /* (a live utterance: session_pull above has handed exactly these lists over) */
             int H = d->ps->pl_window + 2, T = v.total_frames, ts = T - 1, c;
             size_t ne_all = (size_t)d->n_chain * T * d->topn;
             while (ts >= 0 && ts % H != H - 1) --ts;
@@ -623,6 +636,62 @@ dev_phone_loop_step(ps_search_t *search, int frame_idx)
     return 1;
 }
 
+/* frame t of the utterance in progress: kept by dev_search_step, or -- the look-ahead frames the phone loop has seen and the
+ * n-gram search has not -- still in acmod's ring */
+static int
+copy_frame(psgpu_device_decode_t *d, acmod_t *acmod, int t, float *dst)
+{
+    int fi, s;
+    if (t < d->n_feat) { memcpy(dst, d->h_feat + (size_t)t * d->veclen, d->veclen * sizeof(float)); return 0; }
+    if ((fi = feat_ring_index(acmod, t)) < 0) return -1;
+    for (s = 0; s < feat_dimension1(acmod->fcb); ++s) {
+        memcpy(dst, acmod->feat_buf[fi][s], feat_dimension2(acmod->fcb, s) * sizeof(float));
+        dst += feat_dimension2(acmod->fcb, s);
+    }
+    return 0;
+}
+
+/* The utterance in progress as a live utterance of the pipeline: the frames the pipeline has not seen yet -- up to frame T -- are
+ * handed over and its search goes on to the frame the reference's has reached from where it stopped (`final`: to the utterance's end; the reference's does, ngram_search_fwdtree.c:1454-1495;
+ * nothing is decoded twice).  Begun at the first call (with the session state the utterance started from); begun AGAIN with twice
+ * the capacity, and all frames so far, when the utterance outgrows it.  Returns 1 when the pipeline's tables are the utterance's
+ * at this moment, 0 when the pipeline does not do live utterances for this decoder (the caller decodes the prefix), -1 on error. */
+static int
+live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final)
+{
+    acmod_t *acmod = ps_search_acmod(ngs);
+    void *st = psgpu_hmm_ctx_stream(d->ctx);
+    float *feat;
+    int t, from;
+    if (d->live_off) return 0;
+    if (!d->live_on || T > d->live_cap) {
+        int cap = d->live_on ? 2 * d->live_cap : 3000;            /* (30 s; doubles) */
+        while (cap < T) cap *= 2;
+        if (refresh(d) < 0) return -1;
+        if (!d->live_on && session_push(d, ngs) < 0) return -1;  /* (a restart begins from the same session state: the pipeline kept it) */
+        if (d->live_on) ++d->live_restarts;
+        if (psgpu_decode_live_begin(d->dec, cap, st) != PSGPU_OK) {
+            E_INFO("psgpu device search: no live utterance on the device (%s); results in mid-utterance decode the frames so far\n", psgpu_last_error());
+            d->live_off = 1; d->live_on = 0;
+            return 0;
+        }
+        d->live_on = 1; d->live_cap = cap; d->live_fed = 0;
+    }
+    from = d->live_fed;
+    feat = ckd_calloc((size_t)(T - from) * d->veclen + 1, sizeof(float));
+    for (t = from; t < T; ++t)
+        if (copy_frame(d, acmod, t, feat + (size_t)(t - from) * d->veclen) < 0) { T = t; break; }
+    /* (mid-utterance: the n-gram search has been stepped through n_feat frames, the phone loop through T) */
+    if (psgpu_decode_live_step(d->dec, feat, T - from, final ? 0 : (T > d->n_feat ? T - d->n_feat : 0), st) != PSGPU_OK) {
+        E_ERROR("psgpu device search (live utterance): %s\n", psgpu_last_error());
+        ckd_free(feat);
+        return -1;
+    }
+    ckd_free(feat);
+    d->live_fed = T; ++d->live_steps;
+    return 1;
+}
+
 /* Results in mid-utterance (ps_get_hyp / ps_seg_iter between ps_process_raw calls, pocketsphinx.c:1372, ngram_search.c:845):
  * the reference's search has stepped through n_feat frames by now and its phone loop through up to pl_window more; the same
  * state on the device is the first pass over the frames seen so far with the search stopped n frames short
@@ -636,6 +705,12 @@ partial_refresh(psgpu_device_decode_t *d, ngram_search_t *ngs)
     int32_t off[2];
     float *feat;
     if (d->n_feat == 0 || d->n_partial == d->n_feat) return 0;
+    if ((t = live_advance(d, ngs, T, 0)) != 0) {
+        if (t < 0 || fetch_summary(d, 1) < 0) return -1;
+        if (d->h_res[2] > 0 && fetch_and_inject(d, 0) < 0) return -1;
+        d->n_partial = d->n_feat;
+        return 0;
+    }
     feat = ckd_calloc((size_t)T * d->veclen + 1, sizeof(float));
     memcpy(feat, d->h_feat, (size_t)d->n_feat * d->veclen * sizeof(float));
     for (t = d->n_feat; t < T; ++t) {                    /* the look-ahead frames: still in the ring */
@@ -680,6 +755,14 @@ dev_search_seg_iter(ps_search_t *search)
     if (d == NULL) return NULL;
     if (!ngs->done && partial_refresh(d, ngs) < 0) return NULL;
     return d->orig_vt->seg_iter(search);
+}
+
+void
+psgpu_device_search_live_stats(psgpu_device_decode_t *d, long *frames_searched, long *steps, long *restarts)
+{
+    if (frames_searched) *frames_searched = d ? (long)psgpu_decode_live_frames_searched(d->dec) : 0;
+    if (steps) *steps = d ? d->live_steps : 0;
+    if (restarts) *restarts = d ? d->live_restarts : 0;
 }
 
 int

@@ -29,6 +29,13 @@ void psgpu_device_decode_detach(psgpu_device_decode_t *d);
  * passes run on the injected table.  0 on success. */
 int psgpu_device_search_attach(psgpu_device_decode_t *d);
 void psgpu_device_search_detach(psgpu_device_decode_t *d);
+/* Results in mid-utterance (ps_get_hyp / ps_seg_iter between ps_process_raw calls): the utterance in progress is a LIVE utterance
+ * of the device pipeline (psgpu_decode_live_begin / _step) -- every read-out hands the frames the device has not seen yet over and
+ * the device search goes on from where it stopped, as the reference's does between ps_search_forward rounds
+ * (ngram_search_fwdtree.c:1454-1495), so a live decode costs O(T).  Since the utterance's start: frames the device search kernel
+ * has stepped through (= the frames searched so far when each was searched once), live steps, and times the utterance outgrew the
+ * capacity it was begun with and was begun again (3,000 frames at first, doubling). */
+void psgpu_device_search_live_stats(psgpu_device_decode_t *d, long *frames_searched, long *steps, long *restarts);
 
 /* = ps_start_utt; ps_process_raw(pcm, n, FALSE, TRUE); ps_end_utt -- with front end, features, senone
  * scores, phone loop and lexicon-tree search on the device; afterwards the decoder's back-pointer

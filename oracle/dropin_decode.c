@@ -191,6 +191,7 @@ static int pl_record_b(ps_search_t *s, int f) { return pl_record(1, s, f); }
 
 static psgpu_device_decode_t *g_dd;   /* "psgpu_device_search yes": decoder B's whole first pass runs on the device */
 static long g_dd_frames;
+static long g_live_frames, g_live_steps, g_live_restarts, g_live_utt_frames;   /* psgpu_device_search_live_stats, summed over the utterances read out in mid-utterance */
 static psgpu_fe_shim_t *g_fe;      /* "psgpu_fe yes": decoder B's cepstra come from the device */
 
 static void
@@ -382,7 +383,12 @@ main(int argc, char **argv)
                 mfcs = read_mfc(path, ps_config_int(ps_get_config(cpu), "ceplen"), &nfr);
             }
             g_rec = &rc_gpu; t0 = now_s(); decode(gpu, pcm, n, mfcs, nfr, &rb[k], (g_dd && !use_dv) ? 2 : (g_fe != NULL)); t_gpu += now_s() - t0;
-            if (use_dv) { g_dd_frames += ((ngram_search_t *)gpu->search)->n_frame; }
+            if (use_dv) {
+                long fs = 0, st = 0, rs = 0;
+                g_dd_frames += ((ngram_search_t *)gpu->search)->n_frame;
+                psgpu_device_search_live_stats(g_dd, &fs, &st, &rs);
+                if (st > 0) { g_live_frames += fs; g_live_steps += st; g_live_restarts += rs; g_live_utt_frames += ((ngram_search_t *)gpu->search)->n_frame; }
+            }
             if (strcmp(ra[k].hyp, rb[k].hyp) || ra[k].score != rb[k].score) hyp_equal = 0;
             if (strcmp(ra[k].seg, rb[k].seg)) seg_equal = 0;
             if (strcmp(ra[k].partial, rb[k].partial) || ra[k].n_partial != rb[k].n_partial) partial_equal = 0;
@@ -430,7 +436,7 @@ main(int argc, char **argv)
                "\"decode_s_cpu\": %.4f, \"decode_s_gpu\": %.4f, \"mgau\": \"%s\", "
                "\"cache_served\": %ld, \"search_hooks\": %s, \"hmm_batches\": %ld, \"hmm_evals\": %ld, \"n_utts\": %d, "
                "\"total_frames\": %d, \"device_fe\": %s, \"pl_steps\": %d, \"pl_mismatch\": %d, \"pl_device_steps\": %ld, "
-               "\"pl_host_steps\": %ld, \"device_search_frames\": %ld, \"partial_results\": %d, \"partial_equal\": %s, "
+               "\"pl_host_steps\": %ld, \"device_search_frames\": %ld, \"partial_results\": %d, \"partial_equal\": %s, \"live_frames_searched\": %ld, \"live_utt_frames\": %ld, \"live_steps\": %ld, \"live_restarts\": %ld, "
                "\"last_partial_cpu\": \"%.200s\", \"utts\": [",
                ok ? "true" : "false", nrep, ra[0].n_frames, rc_cpu.n, rc_gpu.n,
                use_mgau ? (int)psgpu_mgau_n_calls(gpu->acmod->mgau) : 0, bad_calls, first_bad,
@@ -439,7 +445,7 @@ main(int argc, char **argv)
                n_seg, t_cpu, t_gpu, gpu->acmod->mgau->vt->name,
                use_mgau ? psgpu_mgau_n_cache_served(gpu->acmod->mgau) : 0L,
                use_search ? "true" : "false", hmm_batches, hmm_evals, n_res, total_frames, g_fe ? "true" : "false",
-               g_pln[0], pl_bad, pl_dev, pl_host, g_dd_frames, n_partial, partial_equal ? "true" : "false",
+               g_pln[0], pl_bad, pl_dev, pl_host, g_dd_frames, n_partial, partial_equal ? "true" : "false", g_live_frames, g_live_utt_frames, g_live_steps, g_live_restarts,
                ra[n_res - 1].n_partial ? (strrchr(ra[n_res - 1].partial, ';') ? ra[n_res - 1].partial + (strlen(ra[n_res - 1].partial) > 180 ? strlen(ra[n_res - 1].partial) - 180 : 0) : "") : "");
         for (u = 0; u < n_res; ++u)
             printf("%s{\"id\": \"%s\", \"hyp\": \"%s\", \"score\": %d}", u ? ", " : "",

@@ -76,6 +76,15 @@ struct psgpu_decode_s {
     std::vector<int64_t> fe_soff;                        // the sample offsets the front end ahead was run for
     std::vector<int64_t> last_soff;                      // the latest psgpu_decode_first_pass_dev call's sample offsets
     const int16_t *fe_pcm = nullptr;
+    // psgpu_decode_live_begin / _step: ONE utterance in progress, every stage going on where the previous step's frames ended --
+    // the scorer's lists seeded from the last frame's (d_lseed, taking turns), the phone loop's state (d_pl_carry), the search's
+    // (psgpu_fwdtree_search_resume); rows, penalties and tables of the utterance so far stay in the object's buffers
+    bool live = false, live_ok = false, live_chained = false, live_mpx_copied = false;
+    int32_t live_cap = 0, live_T = 0, live_S = 0, live_mode_next = 0;
+    int64_t live_searched = 0;
+    uint8_t *d_lseed[2] = { nullptr, nullptr };
+    int32_t lseed_cur = 0;
+    int32_t *d_pl_carry = nullptr, *d_off1 = nullptr;
 };
 
 static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
@@ -102,7 +111,7 @@ static bool dec_can_lists(psgpu_decode_s *d)
 static void dec_pick_mode(psgpu_decode_s *d)
 {
     static const int env_lists = [] { const char *e = getenv("PSGPU_DECODE_LISTS"); return e ? atoi(e) : 0; }();
-    d->lists = (d->want_lists || env_lists) && !d->compall && dec_can_lists(d);
+    d->lists = (d->want_lists || env_lists) && !d->compall && !d->live && dec_can_lists(d);      // (a live utterance keeps score rows)
 }
 
 // The codeword lists the second pass's frame 0 starts from, per utterance: slot n_fast_hist - 1 of the scorer's history ring as the
@@ -179,6 +188,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
     DFREE(d->d_bp2); DFREE(d->d_bss2); DFREE(d->d_idx2); DFREE(d->d_step2); DFREE(d->d_res2); DFREE(d->d_seed2);
     DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
+    DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_pl_carry); DFREE(d->d_off1);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
@@ -368,6 +378,8 @@ static int dec_search(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t mf,
     // the hypotheses are the search kernel's last step
     if ((rc = psgpu_fwdtree_hyp_out(d->cfg.ft, d->d_hyp, d->d_hn, d->max_words))) return rc;
     if ((rc = psgpu_fwdtree_search_lag(d->cfg.ft, d->last_lag))) return rc;
+    if ((rc = psgpu_fwdtree_search_resume(d->cfg.ft, d->live_mode_next))) return rc;
+    d->live_mode_next = 0;
     // (the idx rows are per utterance max_frames + 2 wide: the stride of this call, not of the allocation)
     if (d->lists)
         rc = psgpu_fwdtree_search_lists_dev(d->cfg.ft, &d->view, d->d_tsc, d->d_tcw, (int32_t)total, d->d_pen, d->d_off, n_utt, (int32_t)mf,
@@ -457,6 +469,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
                   "vectors (other feature types: psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
     hipStream_t st = (hipStream_t)stream;
     d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
+    d->live = false;
     d->frame_off.assign((size_t)n_utt + 1, 0);
     if (n_utt == 0) return PSGPU_OK;
     size_t total = 0, mf = 0;
@@ -528,6 +541,7 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (feat && frame_off)), "psgpu_decode_first_pass_feat: bad argument");
     hipStream_t st = (hipStream_t)stream;
     d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
+    d->live = false;
     d->frame_off.assign(frame_off, frame_off + (n_utt ? n_utt + 1 : 0));
     if (n_utt == 0) { d->frame_off.assign(1, 0); return PSGPU_OK; }
     PSGPU_REQUIRE(frame_off[0] == 0, "psgpu_decode_first_pass_feat: frame offsets start at 0");
@@ -607,6 +621,120 @@ int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const
     return psgpu_decode_first_pass_dev(d, d->d_pcm, d->soff.data(), n_utt, st);
 }
 
+// ---- an utterance in progress ----------------------------------------------------------------------------------------------------
+// the search's resume mode: the LDS layout keeps its state; a model that takes the slab layout is searched from the utterance's start
+// at every step (0)
+static int dec_live_mode(psgpu_decode_s *d, bool resume)
+{
+    int32_t lds = 0;
+    if (psgpu_fwdtree_layout(d->cfg.ft, &lds, nullptr) != PSGPU_OK || !lds || (d->n_sen & 1)) return 0;      // (odd rows: the search copies rows as dwords in the LDS layout only)
+    return PSGPU_SEARCH_KEEP | (resume ? PSGPU_SEARCH_RESUME : 0);
+}
+
+int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream)
+{
+    PSGPU_REQUIRE(d && max_frames > 0, "psgpu_decode_live_begin: bad argument");
+    PSGPU_REQUIRE(d->session, "psgpu_decode_live_begin: a live utterance is one decoder's (psgpu_decode_session first)");
+    PSGPU_REQUIRE(!d->want_lists, "psgpu_decode_live_begin: a live utterance keeps its score rows (not with psgpu_decode_score_mode lists)");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    d->lists = false;                                    // (PSGPU_DECODE_LISTS: not for a live utterance; the next batch call picks its mode again)
+    if ((rc = dec_session_buffers(d))) return rc;
+    if ((rc = dec_grow(d, 1, (size_t)max_frames, (size_t)max_frames, st))) return rc;
+    if (!d->d_pl_carry) {
+        if ((rc = dec_alloc((void **)&d->d_lseed[0], (size_t)std::max(1, d->n_chain * d->topn)))
+            || (rc = dec_alloc((void **)&d->d_lseed[1], (size_t)std::max(1, d->n_chain * d->topn)))
+            || (rc = dec_alloc((void **)&d->d_off1, 8)) || (rc = dec_alloc((void **)&d->d_pl_carry, 4 * (size_t)psgpu_phone_loop_carry_words())))
+            return rc;
+    }
+    d->live = true; d->live_ok = false; d->live_cap = max_frames; d->live_T = 0; d->live_S = 0; d->live_searched = 0; d->live_mode_next = 0;
+    d->live_chained = d->sess_started; d->live_mpx_copied = false; d->lseed_cur = 0;
+    d->n_utt = 1; d->total = 0; d->max_frames = max_frames; d->searched = false; d->pass2 = false; d->first_called = true;
+    d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
+    d->frame_off.assign(2, 0);
+    d->ev_valid = false;
+    if (d->cfg.fe) psgpu_fe_offsets_dirty(d->cfg.fe);
+    PSGPU_HIP(hipMemsetAsync(d->d_res, 0, 4 * 8, st));
+    PSGPU_HIP(hipMemsetAsync(d->d_hn, 0, 4 * 4, st));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, int32_t lag, void *stream)
+{
+    PSGPU_REQUIRE(d && d->live, "psgpu_decode_live_step: no live utterance (psgpu_decode_live_begin)");
+    PSGPU_REQUIRE(n_new >= 0 && lag >= 0 && (n_new == 0 || feat), "psgpu_decode_live_step: bad argument");
+    PSGPU_REQUIRE(d->live_T + n_new <= d->live_cap, "psgpu_decode_live_step: %d frames exceed the live utterance's capacity of %d "
+                  "(psgpu_decode_live_begin with a larger one, then the utterance's frames again)", d->live_T + n_new, d->live_cap);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const int t0 = d->live_T;
+    if (n_new > 0) {
+        const int32_t off1[2] = { 0, n_new };
+        PSGPU_HIP(hipMemcpyAsync(d->d_off1, off1, 8, hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipMemcpyAsync(d->d_feat + (size_t)t0 * d->veclen, feat, 4 * (size_t)n_new * d->veclen, hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipStreamSynchronize(st));             // (feat and off1 are the caller's / this frame's)
+        const float *const f = d->d_feat + (size_t)t0 * d->veclen;
+        int16_t *const rows = d->d_rows + (size_t)t0 * d->n_sen;
+        if (d->kind == PSGPU_SCORER_PTM) {
+            // this step's first frame starts from the lists of the frame before (ptm_mgau_frame_eval copies them, ptm_mgau.c:425-441):
+            // the previous step's carry-out; the utterance's first frame from the session's seed, as in dec_from_feat
+            const uint8_t *const seed_in = t0 > 0 ? d->d_lseed[d->lseed_cur] : ((d->live_chained && d->seed_valid) ? d->d_seed : nullptr);
+            uint8_t *const seed_out = d->d_lseed[d->lseed_cur ^ 1];
+            if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, f, d->d_off1, 1, n_new, seed_in, seed_out, d->d_tsc, d->d_tcw, rows, d->d_best + t0,
+                                                d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st)))
+                return rc;
+            d->lseed_cur ^= 1;
+            // the next utterance's seed: the lists of the last frame ts of the utterance so far with ts % H == H - 1 (dec_from_feat)
+            const int H = d->cfg.pl_window + 2;
+            int ts = t0 + n_new - 1;
+            while (ts >= t0 && ts % H != H - 1) --ts;
+            if (ts >= t0) {
+                PSGPU_HIP(hipMemcpy2DAsync(d->d_seed, (size_t)d->topn, d->d_tcw + (size_t)(ts - t0) * d->topn, (size_t)n_new * d->topn, (size_t)d->topn,
+                                           (size_t)d->n_chain, hipMemcpyDeviceToDevice, st));
+                d->seed_valid = true;
+            }
+        }
+        else if (d->kind == PSGPU_SCORER_MS)
+            rc = d->compall ? psgpu_ms_score_batch_dev((psgpu_ms_model_t *)d->cfg.scorer, f, n_new, d->d_ms_id, d->d_ms_dist, rows, st)
+                            : psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, f, n_new, d->d_ms_id, d->d_ms_dist, rows, st);
+        else {
+            psgpu_set_error("psgpu_decode_live_step: the semi-continuous scorer's history is not carried between calls");
+            return PSGPU_EINVAL;
+        }
+        if (rc) return rc;
+        if ((rc = psgpu_phone_loop_run_carry_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->raw_flag == 3 ? nullptr : d->d_ci,
+                                                 d->raw_flag == 3 ? 0 : d->cfg.n_ci_list, rows, d->n_sen, nullptr, d->d_off1, 1, n_new,
+                                                 d->d_pen + (size_t)t0 * d->n_ci, d->d_pl_carry, t0 > 0, st)))
+            return rc;
+        d->live_T += n_new;
+    }
+    const int T = d->live_T;
+    d->total = T; d->frame_off[1] = T; d->searched = false; d->pass2 = false;
+    if (T == 0) return PSGPU_OK;                         // (nothing yet: the empty records of live_begin stand)
+    {
+        const int32_t off[2] = { 0, T };
+        PSGPU_HIP(hipMemcpyAsync(d->d_off, off, 8, hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+    }
+    if (d->live_chained && !d->live_mpx_copied) {        // (what this utterance's search starts from: a repeated search starts from it again)
+        PSGPU_HIP(hipMemcpyAsync(d->d_mpx_in, d->d_mpx, 4 * (size_t)psgpu_fwdtree_n_mpx_channels(d->cfg.ft) * d->n_emit, hipMemcpyDeviceToDevice, st));
+        d->live_mpx_copied = true;
+    }
+    // the search: up to `lag` frames short of the frames scored (the whole utterance when lag = 0, unless it is shorter than the
+    // look-ahead window: see the kernel), from where the previous step's search stopped
+    const int S = lag > 0 ? std::max(T - lag, 0) : (T < d->cfg.pl_window ? 0 : T);
+    const int mode = dec_live_mode(d, d->live_ok && d->live_S <= S);
+    d->live_mode_next = mode;
+    d->live_searched += S - ((mode & PSGPU_SEARCH_RESUME) ? d->live_S : 0);
+    d->last_chained = d->live_chained; d->last_sess = true; d->last_lag = lag; d->lag_next = 0;
+    if ((rc = dec_search(d, 1, (size_t)T, (size_t)d->live_cap, st))) { d->live_ok = false; return rc; }
+    d->live_S = S; d->live_ok = (mode & PSGPU_SEARCH_KEEP) != 0;
+    d->sess_started = true;
+    return PSGPU_OK;
+}
+
+int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d) { return d ? d->live_searched : 0; }
+
 int psgpu_decode_stage_timing(psgpu_decode_t *d, int32_t enable)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_stage_timing: NULL argument");
@@ -663,9 +791,13 @@ int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d) { return d ? d->n_gro
 // call's utterances again on the scores and penalties still in the object's buffers -- until no utterance reports a full
 // table, the device has no room for larger ones, or the tables have doubled twelve times.  The larger allowance stays (later calls
 // start with it), so a workload pays this once.  Returns PSGPU_OK with `res` holding the final result records.
+static int dec_live_mode(psgpu_decode_s *d, bool resume);
+
 static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t> &res, hipStream_t st)
 {
     const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
+    // (a live utterance: the repeated search starts at the utterance's first frame again and keeps its state for the next step)
+    auto live_again = [&]() { if (d->live) { d->live_mode_next = dec_live_mode(d, false); d->live_ok = d->live_mode_next != 0; d->live_searched += d->live_S; } };
     {   // status 2: the LDS layout's evaluation list (what its pool had left) filled up in some frame.  The slab layout's list holds
         // every channel: the search is switched to it -- for good, this workload needs it -- and the call's search stage repeated.
         bool list_full = false;
@@ -674,6 +806,7 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
             int rc;
             if ((rc = psgpu_fwdtree_use_slab_layout(d->cfg.ft))) return rc;
             ++d->n_grown;
+            live_again();
             if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;
             if (d->ev_srch) PSGPU_HIP(hipEventRecord(d->ev_srch, st));
             PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
@@ -703,6 +836,7 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
         }
         d->bp_cap = (int32_t)cb; d->bss_cap = (int32_t)cs;
         ++d->n_grown;
+        live_again();
         if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;
         if (d->ev_srch) PSGPU_HIP(hipEventRecord(d->ev_srch, st));
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));

@@ -245,6 +245,7 @@ struct PlDev {
 };
 
 constexpr int kPlMaxWindow = 32;
+constexpr int kPlCarryWords = 64 * 8 + kPlMaxWindow * 64 + 8;     // psgpu_phone_loop_run_carry_dev: an utterance's state between calls
 
 // DPP wave maximum (same sequence as psgpu_ptm_dev.h): ~20 cycles instead of six
 // dependent ds_bpermute round trips -- the search below is one wave marching through
@@ -382,7 +383,7 @@ template <int NE>
 __global__ __launch_bounds__(64)
 void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t *__restrict__ css,
                        const int32_t *__restrict__ utt_off, int32_t *__restrict__ penalties,
-                       int32_t *__restrict__ pen_now, int32_t *__restrict__ state)
+                       int32_t *__restrict__ pen_now, int32_t *__restrict__ state, int32_t *__restrict__ carry_all, int32_t resume)
 {
     constexpr int W = NE <= 3 ? 4 : 8;
     constexpr int kAhead = 4;                                     // frames fetched ahead of the one being searched
@@ -406,6 +407,19 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
     for (int w = 0; w < p.window; ++w) s_ring[w][lane] = 0;       // memset(pen_buf, 0) (:177-178)
     int ptr = 0;
     int32_t best_score = 0;                                       // pls->best_score (:180)
+    // psgpu_phone_loop_run_carry_dev: the utterance goes on where the previous call's frames ended -- the phones' HMMs, the
+    // penalty ring and its position, the best score; `frame` counts from the utterance's start, so this call's frames are
+    // numbered from `base` = the frames of the calls before
+    int32_t *const carry = carry_all ? carry_all + (size_t)u * kPlCarryWords : nullptr;
+    int base = 0;
+    if (carry && resume) {
+        const int32_t *const cs = carry + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) h.score[i] = cs[i];
+        h.out_score = cs[5]; h.bestscore = cs[6]; frame = cs[7];
+        for (int w = 0; w < p.window; ++w) s_ring[w][lane] = carry[64 * 8 + w * 64 + lane];
+        ptr = carry[64 * 8 + kPlMaxWindow * 64]; best_score = carry[64 * 8 + kPlMaxWindow * 64 + 1]; base = carry[64 * 8 + kPlMaxWindow * 64 + 2];
+    }
     // a small register queue of upcoming frames' scores: the march never waits for memory
     typedef int16_t vec_t __attribute__((ext_vector_type(W)));
     const vec_t *in = reinterpret_cast<const vec_t *>(css) + (size_t)t0 * 64 + lane;
@@ -427,7 +441,8 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
         }
         // evaluate_hmms (:201-221)
         int32_t sc = kW;
-        const bool act = on && frame >= t;
+        const int ta = base + t;                                  // the frame's number in its utterance
+        const bool act = on && frame >= ta;
         if (act) sc = (NE == 3) ? vit3(h, tpl, ss) : vit5(h, tpl, ss);
         const int32_t bs = pl_wave_max(act ? max(sc, kW) : kW);
         best_score = bs;
@@ -443,7 +458,7 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
         }
         // prune_hmms (:247-266)
         if (act) {
-            if (h.bestscore > bs + p.beam) frame = t + 1;
+            if (h.bestscore > bs + p.beam) frame = ta + 1;
             else {                                                // hmm_clear_scores
 #pragma unroll
                 for (int i = 0; i < NE; ++i) h.score[i] = kW;
@@ -451,11 +466,11 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
             }
         }
         // phone_transition (:268-300): every phone is entered by the best exiting phone
-        const int32_t np = (on && frame == t + 1) ? h.out_score + p.pip : kMaxNegInt32;
-        const bool exits = on && frame == t + 1 && np > bs + p.pbeam;
+        const int32_t np = (on && frame == ta + 1) ? h.out_score + p.pip : kMaxNegInt32;
+        const bool exits = on && frame == ta + 1 && np > bs + p.pbeam;
         const int32_t m = pl_wave_max(exits ? np : kMaxNegInt32);
         if (m != kMaxNegInt32 && on) {
-            if (frame < t || m > h.score[0]) { h.score[0] = m; frame = t + 1; }
+            if (frame < ta || m > h.score[0]) { h.score[0] = m; frame = ta + 1; }
         }
         if (on && state) {
             int32_t *st = state + ((size_t)(t0 + t) * p.n_phones + lane) * 8;
@@ -463,6 +478,14 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
             for (int i = 0; i < NE; ++i) st[i] = h.score[i];
             st[5] = h.out_score; st[6] = h.bestscore; st[7] = frame;
         }
+    }
+    if (carry) {
+        int32_t *const cs = carry + lane * 8;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) cs[i] = h.score[i];
+        cs[5] = h.out_score; cs[6] = h.bestscore; cs[7] = frame;
+        for (int w = 0; w < p.window; ++w) carry[64 * 8 + w * 64 + lane] = s_ring[w][lane];
+        if (lane == 0) { carry[64 * 8 + kPlMaxWindow * 64] = ptr; carry[64 * 8 + kPlMaxWindow * 64 + 1] = best_score; carry[64 * 8 + kPlMaxWindow * 64 + 2] = base + T; }
     }
 }
 
@@ -569,7 +592,7 @@ static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const
                   const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
                   const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev, const PlListsArg *ls,
                   const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
-                  int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream);
+                  int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream, int32_t *carry_dev = nullptr, int32_t resume = 0);
 
 int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
                              const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
@@ -580,6 +603,19 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
     PSGPU_REQUIRE(raw_dev || n_utt == 0, "psgpu_phone_loop_run_dev: NULL score rows");
     return pl_run(c, pp, ssid_dev, tmatid_dev, ci_list_dev, n_list, raw_dev, raw_stride, best_dev, nullptr, utt_off_dev, n_utt, total_frames,
                   penalties_dev, pen_now_dev, state_dev, stream);
+}
+
+int32_t psgpu_phone_loop_carry_words(void) { return kPlCarryWords; }
+
+int psgpu_phone_loop_run_carry_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
+                                   const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
+                                   const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
+                                   const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                                   int32_t *penalties_dev, int32_t *carry_dev, int32_t resume, void *stream)
+{
+    PSGPU_REQUIRE((raw_dev && carry_dev) || n_utt == 0, "psgpu_phone_loop_run_carry_dev: NULL score rows / carry buffer");
+    return pl_run(c, pp, ssid_dev, tmatid_dev, ci_list_dev, n_list, raw_dev, raw_stride, best_dev, nullptr, utt_off_dev, n_utt, total_frames,
+                  penalties_dev, nullptr, nullptr, stream, carry_dev, resume != 0);
 }
 
 int psgpu_phone_loop_run_lists_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
@@ -601,7 +637,7 @@ static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const
                   const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
                   const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev, const PlListsArg *ls,
                   const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
-                  int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream)
+                  int32_t *penalties_dev, int32_t *pen_now_dev, int32_t *state_dev, void *stream, int32_t *carry_dev, int32_t resume)
 {
     PSGPU_REQUIRE(c && pp && n_utt >= 0, "psgpu_phone_loop_run_dev: bad argument");
     PSGPU_REQUIRE(c->n_emit == 3 || c->n_emit == 5, "phone loop: %d emitting states (3 or 5 are built)", c->n_emit);
@@ -639,7 +675,7 @@ static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const
         hipLaunchKernelGGL((phone_loop_prep_kernel<3>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, raw_dev, raw_stride,
                            best_dev, total_frames, c->pl_css);
         hipLaunchKernelGGL((phone_loop_kernel<3>), dim3(n_utt), dim3(64), 0, st, p, (const uint8_t *)c->tp,
-                           (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev);
+                           (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev, carry_dev, resume);
     }
     else {
         if (ls)
@@ -650,7 +686,7 @@ static int pl_run(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const
         hipLaunchKernelGGL((phone_loop_prep_kernel<5>), pg, dim3(256), 0, st, p, (const uint16_t *)c->sseq, raw_dev, raw_stride,
                            best_dev, total_frames, c->pl_css);
         hipLaunchKernelGGL((phone_loop_kernel<5>), dim3(n_utt), dim3(64), 0, st, p, (const uint8_t *)c->tp,
-                           (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev);
+                           (const int16_t *)c->pl_css, utt_off_dev, penalties_dev, pen_now_dev, state_dev, carry_dev, resume);
     }
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;

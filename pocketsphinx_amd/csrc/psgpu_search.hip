@@ -63,6 +63,7 @@ constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
 constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (32 KB)
 constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS
+constexpr int kFtLiveHdr = 32;         // FtBufs::live: words ahead of the pool's copy
 constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
 
 // word offsets of the per-utterance arrays the tree level works on ("fast" arrays: LDS in the small layout, the
@@ -144,6 +145,12 @@ struct FtBufs {
     long long *prof;                     // PSGPU_FT_PROFILE builds: [n_utt][32] cycles per phase (tools/build_prof_lib.py)
     int32_t bp_cap, bss_cap, max_frames;
     int32_t lag;                         // search all but the last `lag` frames of every utterance (psgpu_fwdtree_search_lag); 0: all
+    // a search that goes on where the handle's previous call stopped (psgpu_fwdtree_search_resume; LDS layout): per utterance
+    // kFtLiveHdr words {frames searched, the frame loop's carried registers, the counters} + the LDS pool as the last frame left it.
+    // The tables, the score stack, the frame marks, bpa / bssx and the last-phone channels' slab are the caller's / the handle's and
+    // stay where they are between the calls
+    int32_t *live;
+    int32_t live_mode;                   // bit 0: save the state when the call stops; bit 1: start from the saved state
 };
 
 struct psgpu_fwdtree_s {
@@ -158,6 +165,13 @@ struct psgpu_fwdtree_s {
     int32_t *hyp_out = nullptr, *hyp_n_out = nullptr;    // psgpu_fwdtree_hyp_out: for the NEXT search call only
     int32_t hyp_max_words = 0;
     int32_t lag_next = 0;                // psgpu_fwdtree_search_lag: for the NEXT search call only
+    // psgpu_fwdtree_search_resume
+    int32_t live_next = 0;               // the NEXT search call's FtBufs::live_mode
+    int32_t *live = nullptr;             // FtBufs::live, kept between calls
+    size_t live_words = 0;
+    bool live_valid = false;             // the latest search call saved its state ...
+    int32_t live_n_utt = 0, live_bp_cap = 0, live_bss_cap = 0, live_max_frames = 0, live_raw = 0, live_window = 0;    // ... for these
+    int32_t *live_bp = nullptr, *live_bss = nullptr, *live_idx = nullptr, *live_step = nullptr;
 };
 
 // ---- channel records ---------------------------------------------------------------------------------------------
@@ -968,6 +982,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0,
               T = bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in);
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
+    // psgpu_fwdtree_search_resume: the utterance's saved state; f0 = the frames searched by the calls before
+    int32_t *const live = (SMALL && bf.live) ? psgpu_as_global(bf.live) + (size_t)blockIdx.x * (kFtLiveHdr + L.rows_total) : nullptr;
+    const bool resumed = live != nullptr && (bf.live_mode & 2) != 0;
+    const int f0 = resumed ? live[0] : 0;
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
     uint32_t evals_run = 0u;                             // HMM evaluations so far (ngs->st.n_hmm_eval; saturating: compared with maxhmmpf), likewise
     int nwc_cur = 0;                                     // right-context channels of the active words (the last of woff's prefix sums), likewise
@@ -986,6 +1004,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int nwords = (p.n_sen + 31) >> 5;
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
         if (use_lb) for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;
+    }
+    if (SMALL && resumed) {
+        // the pool as the previous call's last frame left it (the static tables' copies with it), the counters, the frame loop's
+        // carried registers; the senone bitmap and the normaliser are reset at every frame's end and are as the lines above left them
+        __syncthreads();
+        for (int i = tid; i < L.rows_total; i += NT) s_pool[i] = live[kFtLiveHdr + i];
+        if (tid < 8) s_sc[tid] = live[8 + tid];
+        if (tid == 0) { s_evals = (unsigned long long)(uint32_t)live[5] | ((unsigned long long)(uint32_t)live[6] << 32); s_nsen = live[7]; }
+        n_acl_cur = live[1]; n_awl_cur = live[2]; evals_run = (uint32_t)live[3]; nwc_cur = live[4];
+        __syncthreads();
     }
     // Scores: the frame's row is read from LDS (s_row).  From rows: the next frame's row travels from HBM into s_row while this
     // frame's word level runs -- issued after the evaluation, the row's last reader -- by LDS-DMA (global_load_lds_dword: no
@@ -1045,35 +1073,35 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             l_cw[tid] = pcw;
         }
     };
-    if (SMALL && T > 0) {
+    if (SMALL && f0 < T) {                                // the first frame's scores and penalties (f0 & 1: the penalty rows take turns)
         if (lists) {
             const uint8_t *const la = psgpu_as_global(bf.la);
             for (int i = tid; i < 512; i += NT) l_la[i] = i < bf.ls_la_size ? la[i] : 0;
-            lists_load(0);
+            lists_load(f0);
             lists_norm();
         }
         else if (!kFtRowsDevice) {
-            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)t0 * scr_stride);
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(senscr + (size_t)(t0 + f0) * scr_stride);
             uint32_t *d = reinterpret_cast<uint32_t *>(s_row);
             for (int i = tid; i < row_dw; i += NT) d[i] = g[i];
         }
-        if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[i] = penalties[(size_t)pen_frame(0) * n_ci + i];
+        if (p.has_pl) for (int i = tid; i < n_ci; i += NT) s_pen[(f0 & 1) * n_ci + i] = penalties[(size_t)pen_frame(f0) * n_ci + i];
     }
     __syncthreads();
     // a session's second and later utterances: the multiplexed permanent channels (roots, single-phone words) start with the
     // per-state ssids the previous utterance left -- hmm_clear (hmm.c:181-196) resets scores and histories only, and a
     // state's ssid decides which senone the search lists for it
-    if (bf.mpx_in) {
+    if (bf.mpx_in && !resumed) {
         const int32_t *const mi = psgpu_as_global(bf.mpx_in) + (size_t)blockIdx.x * (R + n1) * NE;
         for (int i = tid; i < (R + n1) * NE; i += NT) {
             const int q = i / NE, c = q < R ? q : W1 + (q - R);
             if (q < R || w1_mpx[q - R]) tv.at(c, F::SENID + i % NE) = mi[i];
         }
     }
-    if (tid == 0) ch_enter<NE>(tv, W1 + w1_of_word[p.startwid], 0, -1, 0);
+    if (tid == 0 && !resumed) ch_enter<NE>(tv, W1 + w1_of_word[p.startwid], 0, -1, 0);
     __syncthreads();
 
-    for (int f = 0; f < T; ++f) {
+    for (int f = f0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1;
         const NCol aclc = { SMALL ? nodeA + (cur ? NC_ACL1 : NC_ACL0) : fb + (cur ? L.acl1 : L.acl0) },
                    acln = { SMALL ? nodeA + (cur ? NC_ACL0 : NC_ACL1) : fb + (cur ? L.acl0 : L.acl1) };
@@ -2263,6 +2291,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
     __syncthreads();                                             // the table's last entries (device memory, other work-items') before the copy and the backtrace
+    if (SMALL && live && (bf.live_mode & 1)) {                   // psgpu_fwdtree_search_resume: what the next call starts from
+        for (int i = tid; i < L.rows_total; i += NT) live[kFtLiveHdr + i] = s_pool[i];
+        if (tid < 8) live[8 + tid] = s_sc[tid];
+        if (tid == 0) {
+            live[0] = s_sc[7]; live[1] = n_acl_cur; live[2] = n_awl_cur; live[3] = (int32_t)evals_run; live[4] = nwc_cur;
+            live[5] = (int32_t)(s_evals & 0xffffffffull); live[6] = (int32_t)(s_evals >> 32); live[7] = s_nsen;
+        }
+    }
     {   // the table in the caller's columns (bptbl_t, ngram_search.h:112-124): ft_table_out
         int32_t *const out = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * kBpCols * bf.bp_cap;
         const int n_bp = s_sc[3];
@@ -2568,6 +2604,7 @@ void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
     hipFree(m->slab);
     hipFree(m->bssx);
     hipFree(m->bpa);
+    hipFree(m->live);
     delete m;
 }
 
@@ -2692,6 +2729,31 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     bf.hyp = m->hyp_out; bf.hyp_n = m->hyp_n_out; bf.max_words = m->hyp_max_words;
     m->hyp_out = nullptr; m->hyp_n_out = nullptr; m->hyp_max_words = 0;      // (one call's worth)
     bf.lag = m->lag_next; m->lag_next = 0;
+    // psgpu_fwdtree_search_resume (one call's worth, like the lag)
+    bf.live = nullptr; bf.live_mode = m->live_next; m->live_next = 0;
+    if (bf.live_mode) {
+        PSGPU_REQUIRE(d.small, "psgpu_fwdtree_search_resume: the search's state is saved from the LDS layout only (this model, or these "
+                      "score rows, take the slab layout: search the utterance from its start instead)");
+        if (bf.live_mode & 2)
+            PSGPU_REQUIRE(m->live_valid && m->live_n_utt == n_utt && m->live_bp_cap == bp_cap && m->live_bss_cap == bss_cap
+                          && m->live_max_frames == max_frames && m->live_raw == raw_scores && m->live_window == pl_window && m->live_bp == bp_dev
+                          && m->live_bss == bss_dev && m->live_idx == idx_dev && m->live_step == step_dev,
+                          "psgpu_fwdtree_search_resume: nothing to resume -- the handle's previous search call must have kept its state "
+                          "(mode bit 0) for the same utterances, table capacities and table buffers");
+        const size_t need_l = (size_t)n_utt * (size_t)(kFtLiveHdr + d.lay.rows_total);
+        if (need_l > m->live_words) {
+            PSGPU_REQUIRE(!(bf.live_mode & 2), "psgpu_fwdtree_search_resume: the saved state does not fit its buffer");
+            if (m->live) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->live); m->live = nullptr; m->live_words = 0; }
+            PSGPU_HIP(hipMalloc((void **)&m->live, sizeof(int32_t) * need_l));
+            m->live_words = need_l;
+        }
+        bf.live = m->live;
+    }
+    m->live_valid = (bf.live_mode & 1) != 0;
+    if (m->live_valid) {
+        m->live_n_utt = n_utt; m->live_bp_cap = bp_cap; m->live_bss_cap = bss_cap; m->live_max_frames = max_frames; m->live_raw = raw_scores;
+        m->live_window = pl_window; m->live_bp = bp_dev; m->live_bss = bss_dev; m->live_idx = idx_dev; m->live_step = step_dev;
+    }
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
     PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));
@@ -2772,6 +2834,14 @@ int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag)
 {
     PSGPU_REQUIRE(m && lag >= 0, "psgpu_fwdtree_search_lag: bad argument");
     m->lag_next = lag;
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_search_resume(psgpu_fwdtree_t *m, int32_t mode)
+{
+    PSGPU_REQUIRE(m && mode >= 0 && mode <= 3, "psgpu_fwdtree_search_resume: bad argument");
+    PSGPU_REQUIRE(!mode || m->d.small, "psgpu_fwdtree_search_resume: the search's state is saved from the LDS layout only (psgpu_fwdtree_layout)");
+    m->live_next = mode;
     return PSGPU_OK;
 }
 

@@ -205,6 +205,31 @@ class DecodePipeline:
                                                            self.n_utt, st), "psgpu_decode_first_pass_feat")
         self._stream = st
 
+    def search_lag(self, lag):
+        """psgpu_decode_search_lag: the next run*'s search stops `lag` frames short of every utterance's end"""
+        capi.check(capi.lib().psgpu_decode_search_lag(self.h, int(lag)), "psgpu_decode_search_lag")
+
+    def live_begin(self, max_frames, stream=None):
+        """psgpu_decode_live_begin: one utterance in progress (session mode), at most max_frames frames"""
+        import torch
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        self.n_utt = 1
+        self._stream = st
+        capi.check(capi.lib().psgpu_decode_live_begin(self.h, int(max_frames), st), "psgpu_decode_live_begin")
+
+    def live_step(self, feats, lag):
+        """psgpu_decode_live_step: feats [n_new][veclen] float32 more frames (may be empty); the search goes on up to `lag` frames
+        short of the frames so far (0: to the utterance's end).  fetch() / tables() as after a run_feat of the frames so far."""
+        feats = np.ascontiguousarray(feats, np.float32)
+        n = int(feats.shape[0]) if feats.ndim == 2 else 0
+        capi.check(capi.lib().psgpu_decode_live_step(self.h, feats.ctypes.data_as(C.c_void_p) if n else None, n, int(lag), self._stream),
+                   "psgpu_decode_live_step")
+
+    def live_frames_searched(self):
+        f = capi.lib().psgpu_decode_live_frames_searched
+        f.restype = C.c_int64
+        return int(f(self.h))
+
     def fetch(self, want_hyp=True):
         """(hyp_n [n][4], hyp [n][max_words][4] or None, result [n][8]) on the host; waits for the pipeline."""
         n = self.n_utt

@@ -69,7 +69,7 @@ class FwdtreeSearch:
         return hyp.cpu().numpy(), hn.cpu().numpy()
 
     def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None,
-               mpx_in=None, mpx_out=None):
+               mpx_in=None, mpx_out=None, cuts=None, lag=0):
         """mpx_in: [n][n_mpx][n_emit] int32 per-state ssids the permanent multiplexed channels start with (a session's carry-over,
         psgpu_fwdtree_search_session_dev) or None = a fresh decoder; mpx_out: a dict that receives {"mpx": the ssids they end with}.
         senscr [T][n_sen] int16 and penalties [T][n_ci] int32 for utterances back to back (numpy arrays, or
@@ -103,12 +103,23 @@ class FwdtreeSearch:
             d_mi = torch.from_numpy(np.ascontiguousarray(mpx_in, np.int32).reshape(n, n_mpx, ne)).to(dev)
         if mpx_out is not None:
             d_mo = torch.zeros((n, n_mpx, ne), dtype=torch.int32, device=dev)
-        capi.check(capi.lib().psgpu_fwdtree_search_session_dev(
-            self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(d_o), n, mf, bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
-            int(raw_scores), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
-            p(d_mo) if d_mo is not None else None, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-            "psgpu_fwdtree_search_session_dev")
-        torch.cuda.current_stream().synchronize()       # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel
+        # cuts: ONE utterance searched in several calls (psgpu_fwdtree_search_resume): up to each cut's frame count minus `lag`, then
+        # to the end -- same buffers, same tables as one call; self.searched receives the frames searched after every call
+        calls = [(d_o, 0, 0)] if cuts is None else \
+            [(torch.tensor([0, int(c)], dtype=torch.int32, device=dev), lag, (1 if i == 0 else 3)) for i, c in enumerate(cuts)] + [(d_o, 0, 2)]
+        self.searched = []
+        for o, lg, mode in calls:
+            if cuts is not None:
+                capi.check(capi.lib().psgpu_fwdtree_search_lag(self.h, int(lg)), "psgpu_fwdtree_search_lag")
+                capi.check(capi.lib().psgpu_fwdtree_search_resume(self.h, mode), "psgpu_fwdtree_search_resume")
+            capi.check(capi.lib().psgpu_fwdtree_search_session_dev(
+                self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(o), n, mf, bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
+                int(raw_scores), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
+                p(d_mo) if d_mo is not None else None, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                "psgpu_fwdtree_search_session_dev")
+            torch.cuda.current_stream().synchronize()   # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel
+            if cuts is not None:
+                self.searched.append(int(res[0, 2].item()))
         if mpx_out is not None:
             mpx_out["mpx"] = d_mo.cpu().numpy()
         out = []

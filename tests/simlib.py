@@ -98,6 +98,7 @@ class SimFwdtreeSearch:
         if lm is not None:
             check(lib().psgpu_fwdtree_set_lm(self.h, lm.h), "psgpu_fwdtree_set_lm")
         self.n_sen = int(par[2]); self.n_ci = int(par[0]); self.n1 = int(par[6]); self.n_emit = int(par[1])
+        self.searched = []
 
     def close(self):
         if self.h:
@@ -105,7 +106,7 @@ class SimFwdtreeSearch:
             self.h = C.c_void_p()
 
     def search(self, senscr, penalties, utt_lens, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0, handover=None,
-               mpx_in=None, mpx_out=None):
+               mpx_in=None, mpx_out=None, cuts=None, lag=0):
         """handover: a dict that receives the buffers a second pass takes over (bp [n][10][cap], result [n][8], w1_ssid);
         mpx_in / mpx_out: the session carry-over, as FwdtreeSearch.search"""
         off = np.zeros(len(utt_lens) + 1, np.int32); off[1:] = np.cumsum(utt_lens)
@@ -123,11 +124,21 @@ class SimFwdtreeSearch:
         n_mpx = int(lib().psgpu_fwdtree_n_mpx_channels(self.h))
         mi = None if mpx_in is None else np.ascontiguousarray(mpx_in, np.int32).reshape(n, n_mpx, self.n_emit)
         mo = None if mpx_out is None else np.zeros((n, n_mpx, self.n_emit), np.int32)
-        check(lib().psgpu_fwdtree_search_session_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(off), n, mf, bp_cap, bss_cap,
-                                                     p(bp), p(bss), p(idx), p(step), p(res), int(raw_scores), int(pl_window),
-                                                     p(w1) if w1 is not None else None, p(mi) if mi is not None else None,
-                                                     p(mo) if mo is not None else None, None),
-              "psgpu_fwdtree_search_session_dev")
+        # cuts: one utterance searched in several calls (psgpu_fwdtree_search_resume) -- up to each cut's frame count minus `lag`, then
+        # to the end: same buffers, same tables
+        calls = [(off, 0, 0)] if cuts is None else \
+            [(np.array([0, c], np.int32), lag, (1 if i == 0 else 3)) for i, c in enumerate(cuts)] + [(off, 0, 2)]
+        for o, lg, mode in calls:
+            if cuts is not None:
+                check(lib().psgpu_fwdtree_search_lag(self.h, int(lg)), "psgpu_fwdtree_search_lag")
+                check(lib().psgpu_fwdtree_search_resume(self.h, mode), "psgpu_fwdtree_search_resume")
+            check(lib().psgpu_fwdtree_search_session_dev(self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(o), n, mf, bp_cap, bss_cap,
+                                                         p(bp), p(bss), p(idx), p(step), p(res), int(raw_scores), int(pl_window),
+                                                         p(w1) if w1 is not None else None, p(mi) if mi is not None else None,
+                                                         p(mo) if mo is not None else None, None),
+                  "psgpu_fwdtree_search_session_dev")
+            if cuts is not None:
+                self.searched.append(int(res[0, 2]))
         if mpx_out is not None:
             mpx_out["mpx"] = mo
         self.last = dict(bp=bp, idx=idx, res=res, mf=mf, bp_cap=bp_cap)

@@ -214,3 +214,108 @@ def test_two_pipelines_front_end_ahead(tables):
         q.close()
     for s in streams:
         pdec.free_stream(s)
+
+
+def _session_feats(tables):
+    """the feature vectors of numbers.raw and then goforward.raw as ONE decoder's front end computes them (the noise tracker of the
+    first utterance goes on in the second, fe_interface.c:318-326): read back from a session of the pipeline fed with PCM"""
+    import ctypes as C
+    from pocketsphinx_amd import capi
+    clips = _load("speech_clips.npz")
+    p = _pipeline(tables)
+    p.session(True)
+    out = []
+    for name in ("numbers", "goforward"):
+        p.run([clips[name]])
+        p.fetch()
+        v = p.view()
+        f = np.empty((v.total_frames, 39), np.float32)
+        capi.check(capi.lib().psgpu_memcpy_d2h(f.ctypes.data_as(C.c_void_p), C.c_void_p(v.feat_dev), f.nbytes, p._stream), "d2h")
+        capi.check(capi.lib().psgpu_stream_sync(p._stream), "sync")
+        out.append(f)
+    p.close()
+    return out
+
+
+@pytest.mark.parametrize("cuts", [[12, 13, 14, 60, 61, 140, 200], [8, 100], [250]])
+def test_live_utterance_in_steps(tables, cuts):
+    """psgpu_decode_live_begin / _step: numbers.raw, then goforward.raw fed in steps, through ONE session.  After every step the tables
+    are those of one psgpu_decode_first_pass_feat call over the frames so far with the search stopped `lag` frames short (the
+    reference's tables at that moment: ps_search_forward, pocketsphinx.c:1173-1197); after the last step (lag 0) the reference
+    decoder's own for the second utterance of that session; and the search kernel has stepped through every frame ONCE."""
+    p = _pipeline(tables)
+    g1, g = _load("fwdtree_trace_numbers.npz"), _load("fwdtree_trace_goforward_after_numbers.npz")
+    f1, f2 = _session_feats(tables)
+    T = f2.shape[0]
+    lag = int(g["pl_par"][5])                              # pl_window: what ps_search_forward keeps between the two searches
+    assert T == int(g["n_frame"][0]) and lag >= 1
+
+    def tab(gold=None):
+        _, _, res = p.fetch()
+        r = p.tables(0, res)
+        if gold is not None:
+            r["step"] = np.stack([gold["step_best"], gold["step_lpbest"], gold["step_bpidx"]], axis=1)
+        return r, res
+
+    def first():
+        p.session(True)
+        p.run_feat(f1, [f1.shape[0]])
+        _check(tab(g1)[0], g1, "first of the session")
+    # what one call over the first c frames leaves, the search `lag` short: a session begun again for every cut
+    want = []
+    for c in cuts:
+        first()
+        p.search_lag(lag)
+        p.run_feat(f2[:c], [c])
+        want.append(tab()[0])
+    # the same utterance live
+    first()
+    p.live_begin(T + 50)
+    assert p.live_frames_searched() == 0
+    prev = 0
+    for c, w in zip(cuts, want):
+        p.live_step(f2[prev:c], lag)
+        r, res = tab()
+        assert r["n_frame"] == max(c - lag, 0) == w["n_frame"] and int(res[0, 3]) == 0
+        for k in ("bp", "bscore_stack", "bp_table_idx"):
+            assert np.array_equal(r[k], w[k]), "%s after %d frames" % (k, c)
+        assert p.live_frames_searched() == max(c - lag, 0)
+        prev = c
+    p.live_step(f2[prev:prev], lag)                        # (a step without frames: nothing moves)
+    assert p.live_frames_searched() == max(prev - lag, 0)
+    p.live_step(f2[prev:], 0)
+    hn, _, res = p.fetch()
+    _check(tab(g)[0], g, "the live utterance's end")
+    assert int(hn[0, 1]) == int(g["hyp_score"][0])
+    assert p.live_frames_searched() == T                   # every frame once
+    # the session goes on from a live utterance as from any other: numbers.raw after goforward.raw after numbers.raw
+    with pytest.raises(Exception):
+        p.live_step(np.zeros((60, f2.shape[1]), np.float32), 0)     # (beyond the capacity given at live_begin: refused)
+    p.close()
+
+
+def test_live_utterance_hands_the_session_on(tables):
+    """the utterance after a live one inherits what it would from a one-call utterance (the scorer's seed slot, the multiplexed
+    channels' ssids): numbers.raw live in uneven steps, then goforward.raw in one call = the session golden"""
+    p = _pipeline(tables)
+    g1, g = _load("fwdtree_trace_numbers.npz"), _load("fwdtree_trace_goforward_after_numbers.npz")
+    f1, f2 = _session_feats(tables)
+    lag = int(g["pl_par"][5])
+    p.session(True)
+    p.live_begin(f1.shape[0])
+    prev = 0
+    for c in (5, 37, 38, 150, f1.shape[0] - 1):
+        p.live_step(f1[prev:c], lag)
+        prev = c
+    p.live_step(f1[prev:], 0)
+    _, _, res = p.fetch()
+    r = p.tables(0, res)
+    r["step"] = np.stack([g1["step_best"], g1["step_lpbest"], g1["step_bpidx"]], axis=1)
+    _check(r, g1, "live first utterance")
+    assert p.live_frames_searched() == f1.shape[0]
+    p.run_feat(f2, [f2.shape[0]])
+    _, _, res = p.fetch()
+    r = p.tables(0, res)
+    r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+    _check(r, g, "second of the session, after a live first")
+    p.close()

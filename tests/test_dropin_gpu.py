@@ -535,13 +535,17 @@ def test_dropin_device_search_partial_results(raw, chunk, extra):
     """live decoding through the device ps_searchfuncs_t: the utterance arrives `chunk` samples at a time
     (ps_process_raw without full_utt, reference src/pocketsphinx.c:1220-1257) and ps_get_hyp is asked after every piece, as
     a live application does (:1372, ngram_search_hyp, src/ngram_search.c:845).  The reference's search has then stepped
-    through output_frame - pl_window frames; the binding decodes the frames seen so far with the search stopped as far short
-    of the phone loop (psgpu_decode_search_lag) and injects that table.  EVERY partial hypothesis and score equals the CPU
-    decoder's, and so does the final result."""
+    through output_frame - pl_window frames; the binding hands the device pipeline the frames it has not seen yet, the device
+    search goes on from where it stopped to as far short of the phone loop (psgpu_decode_live_step), and that table is injected.
+    EVERY partial hypothesis and score equals the CPU decoder's, and so does the final result."""
     r = run(raw, 1, "psgpu_device_vtable", "yes", "chunked", str(chunk), *extra)
     assert r["ok"] and r["rc"] == 0, r
     assert r["partial_equal"] and r["partial_results"] >= 5, r
     assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    # the utterance ran as a live utterance of the device pipeline: a step per read-out that found new frames plus the last one,
+    # and the device search stepped through every frame ONCE (not through the prefix again at every read-out)
+    assert r["live_steps"] >= 5 and r["live_restarts"] == 0, r
+    assert r["live_frames_searched"] == r["live_utt_frames"] > 0, r
     assert any(part.split("|")[0].strip() for part in r["last_partial_cpu"].split(";") if "|" in part), r    # (words before the end)
 
 

@@ -182,3 +182,35 @@ def test_device_decode_chain_audio_to_backpointers(name, tables):
     assert score == int(g["hyp_score"][0])
     assert [(sf, ef) for _, sf, ef in words] == [(int(a), int(b)) for a, b in g["seg"][:, :2]]
     s.close(); ctx.close(); model.close(); fe.close()
+
+
+@pytest.mark.parametrize("case,cuts,lag", [("goforward", [1, 2, 40, 41, 150], 0), ("goforward", [30, 100, 200], 7), ("numbers", [97], 3),
+                                           ("man_ah_2934za", [10, 11, 60], 2)])
+def test_fwdtree_kernel_resumed_between_calls(case, cuts, lag):
+    """psgpu_fwdtree_search_resume on the device: as tests/test_search_hostsim.py's test of the same name -- one utterance in several
+    calls, every frame searched once, the golden's tables at the end"""
+    import pocketsphinx_amd as P
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    s = P.FwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    T = rows.shape[0]
+    _check(s.search(rows, pen, [T], cuts=cuts, lag=lag)[0], g, "%s resumed at %r" % (case, cuts))
+    assert s.searched == [max(c - lag, 0) for c in cuts] + [T]
+    _check(s.search(rows, pen, [T])[0], g, "the call after")
+    s.close()
+
+
+def test_fwdtree_kernel_resumed_session_raw_scores():
+    """... in raw-score mode with the look-ahead's window (the pipeline's mode) and a session's inherited channel state"""
+    import pocketsphinx_amd as P
+    from test_search_hostsim import _raw_rows
+    g = _load("fwdtree_trace_goforward_after_numbers.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    s = P.FwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    raw = _raw_rows(g, rows)
+    T = rows.shape[0]
+    _check(s.search(raw, pen, [T], raw_scores=True, pl_window=0, mpx_in=g["mpx_init"][None], cuts=[3, 50, 51, 199], lag=4)[0], g, "session, resumed")
+    assert s.searched == [0, 46, 47, 195, T]
+    s.close()
