@@ -872,6 +872,12 @@ int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
  * psgpu_decode_second_pass: the second pass's tables (with the result records psgpu_decode_fetch_hyps returns then). */
 int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp,
                               int32_t *bss, int32_t *idx, void *stream);
+/* ... entries [bp0, bp0 + n_bp) of the table (bp [10][n_bp]), [bss0, bss0 + n_bss) of the score stack, [idx0, idx0 + n_idx) of the
+ * frame marks: while an utterance is in progress (psgpu_decode_live_step) the tables only grow -- entries of frames already searched do
+ * not change (ngram_search_save_bp updates an entry within its frame only, ngram_search.c:358-443) -- so a caller that holds an
+ * earlier read-out asks for the rest. */
+int psgpu_decode_fetch_tables_range(psgpu_decode_t *d, int32_t u, int32_t bp0, int32_t n_bp, int32_t bss0, int32_t n_bss, int32_t idx0,
+                                    int32_t n_idx, int32_t *bp, int32_t *bss, int32_t *idx, void *stream);
 
 /* ---- flat-lexicon second pass of whole utterances, first version ----------
  * Replaces ngram_fwdflat_start + ngram_fwdflat_search per frame + ngram_fwdflat_finish

@@ -71,7 +71,8 @@ struct psgpu_device_decode_s {
      * read-out in mid-utterance; live_fed frames handed over so far; live_cap the capacity it was begun with; live_off: the pipeline
      * refused (then every read-out decodes the prefix again, as before) */
     int live_on, live_fed, live_cap, live_off;
-    long live_steps, live_restarts;
+    int inj_nb, inj_nh, inj_nfr;       /* what the latest read-out of the live utterance put into the decoder's tables */
+    long live_steps, live_restarts, live_frames_before;    /* (live_frames_before: searched before the latest restart) */
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
     psgpu_ptm_view_t view;
@@ -296,10 +297,13 @@ grow_frames(ngram_search_t *ngs, int need)
 
 /* ---- tables in the reference's layout (ngram_search.h:112-124, ngram_search.c:301-339, 445-497).
  *      bp [10][nb] column-major, bss [nh], idx [nfr + 1] on the host. */
+/* (b0 / h0 / f0: the decoder already holds entries [0, b0) of the table, [0, h0) of the stack and the marks of frames [0, f0) from an
+ *  earlier read-out of the same utterance -- the tables only grow while it is in progress; bp / bss / idx hold the rest) */
 static void
-inject(ngram_search_t *ngs, int n_ci, const int32_t *bp, int nb, const int32_t *bss, int nh, const int32_t *idx, int nfr, int32 best_score)
+inject(ngram_search_t *ngs, int n_ci, const int32_t *bp, int b0, int nb, const int32_t *bss, int h0, int nh, const int32_t *idx, int f0, int nfr,
+       int32 best_score)
 {
-    int i;
+    int i, nn = nb - b0;
     if (nb > ngs->bp_table_size) {
         ngs->bp_table_size = nb + nb / 2;
         ngs->bp_table = ckd_realloc(ngs->bp_table, ngs->bp_table_size * sizeof(*ngs->bp_table));
@@ -309,35 +313,43 @@ inject(ngram_search_t *ngs, int n_ci, const int32_t *bp, int nb, const int32_t *
         ngs->bscore_stack = ckd_realloc(ngs->bscore_stack, ngs->bscore_stack_size * sizeof(*ngs->bscore_stack));
     }
     grow_frames(ngs, nfr + 1);
-    for (i = 0; i < nb; ++i) {
-        bptbl_t *e = &ngs->bp_table[i];
-#define COL(c) bp[(size_t)(c) * nb + i]
+    for (i = 0; i < nn; ++i) {
+        bptbl_t *e = &ngs->bp_table[b0 + i];
+#define COL(c) bp[(size_t)(c) * nn + i]
         e->frame = COL(0); e->valid = (uint8)COL(1); e->refcnt = 0; e->wid = COL(2); e->bp = COL(3); e->score = COL(4);
         e->s_idx = COL(5); e->real_wid = COL(6); e->prev_real_wid = COL(7); e->last_phone = (int16)COL(8); e->last2_phone = (int16)COL(9);
 #undef COL
     }
-    memcpy(ngs->bscore_stack, bss, sizeof(int32) * nh);
-    memcpy(ngs->bp_table_idx, idx, sizeof(int32) * (nfr + 1));
+    memcpy(ngs->bscore_stack + h0, bss, sizeof(int32) * (nh - h0));
+    memcpy(ngs->bp_table_idx + f0, idx, sizeof(int32) * (nfr + 1 - f0));
     ngs->bpidx = nb; ngs->bss_head = nh; ngs->n_frame = nfr;
     ngs->best_score = best_score;    /* ngram_search_lattice (ngram_search.c:1226) refuses an utterance whose best score is WORST_SCORE */
 }
 
 static int
-fetch_and_inject(psgpu_device_decode_t *d, int u)
+fetch_and_inject_from(psgpu_device_decode_t *d, int u, int b0, int h0, int f0)
 {
     ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
     const int32_t *res = d->h_res + (size_t)u * 8;
     int nb = res[0], nh = res[1], nfr = res[2];
     if (res[3]) { E_ERROR("psgpu device decode: utterance %d: back-pointer table or score stack full\n", u); return -1; }
+    if (b0 > nb || h0 > nh || f0 > nfr) b0 = h0 = f0 = 0;
     if ((size_t)nb * 10 > d->cap_bp) { FREE_HOST(d->h_bp); d->cap_bp = (size_t)nb * 15 + 640; d->h_bp = ckd_calloc(d->cap_bp, 4); }
     if ((size_t)nh > d->cap_bss) { FREE_HOST(d->h_bss); d->cap_bss = (size_t)nh + nh / 2 + 64; d->h_bss = ckd_calloc(d->cap_bss, 4); }
     if ((size_t)nfr + 1 > d->cap_idx) { FREE_HOST(d->h_idx); d->cap_idx = (size_t)nfr + nfr / 2 + 64; d->h_idx = ckd_calloc(d->cap_idx, 4); }
-    if (psgpu_decode_fetch_tables(d->dec, u, nb, nh, nfr + 1, d->h_bp, d->h_bss, d->h_idx, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+    if (psgpu_decode_fetch_tables_range(d->dec, u, b0, nb - b0, h0, nh - h0, f0, nfr + 1 - f0, d->h_bp, d->h_bss, d->h_idx,
+                                        psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
-    inject(ngs, d->n_ci, d->h_bp, nb, d->h_bss, nh, d->h_idx, nfr, res[4]);
+    inject(ngs, d->n_ci, d->h_bp, b0, nb, d->h_bss, h0, nh, d->h_idx, f0, nfr, res[4]);
     return nfr;
+}
+
+static int
+fetch_and_inject(psgpu_device_decode_t *d, int u)
+{
+    return fetch_and_inject_from(d, u, 0, 0, 0);
 }
 
 /* ---- the second pass on the device: psgpu_decode_second_pass -- the flat-lexicon search over the first pass's device-resident
@@ -503,7 +515,8 @@ dev_search_start(ps_search_t *search)
     psgpu_device_decode_t *d = find_attached(search);
     if (d == NULL) return -1;
     d->n_feat = 0; d->pl_frames = 0; d->n_partial = -1;
-    d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0;
+    d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0; d->live_frames_before = 0;
+    d->inj_nb = d->inj_nh = d->inj_nfr = 0;
     return d->orig_vt->start(search);          /* ngram_search_start: tables, timers, <s> entered (ngram_search_fwdtree.c:469-520) */
 }
 
@@ -560,7 +573,7 @@ dev_search_finish(ps_search_t *search)
         }
         if (session_pull(d, ngs) < 0) return -1;
         if (fetch_summary(d, 1) < 0) return -1;
-        if (d->h_res[2] > 0 && (nfr = fetch_and_inject(d, 0)) < 0) return -1;
+        if (d->h_res[2] > 0 && (nfr = live ? fetch_and_inject_from(d, 0, d->inj_nb, d->inj_nh, d->inj_nfr) : fetch_and_inject(d, 0)) < 0) return -1;
     }
     ngs->n_tot_frame += nfr;
     if (ngs->fwdflat && nfr > 0) {
@@ -669,7 +682,7 @@ live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final)
         while (cap < T) cap *= 2;
         if (refresh(d) < 0) return -1;
         if (!d->live_on && session_push(d, ngs) < 0) return -1;  /* (a restart begins from the same session state: the pipeline kept it) */
-        if (d->live_on) ++d->live_restarts;
+        if (d->live_on) { ++d->live_restarts; d->live_frames_before += (long)psgpu_decode_live_frames_searched(d->dec); }
         if (psgpu_decode_live_begin(d->dec, cap, st) != PSGPU_OK) {
             E_INFO("psgpu device search: no live utterance on the device (%s); results in mid-utterance decode the frames so far\n", psgpu_last_error());
             d->live_off = 1; d->live_on = 0;
@@ -707,7 +720,11 @@ partial_refresh(psgpu_device_decode_t *d, ngram_search_t *ngs)
     if (d->n_feat == 0 || d->n_partial == d->n_feat) return 0;
     if ((t = live_advance(d, ngs, T, 0)) != 0) {
         if (t < 0 || fetch_summary(d, 1) < 0) return -1;
-        if (d->h_res[2] > 0 && fetch_and_inject(d, 0) < 0) return -1;
+        /* (what the previous read-out of this utterance injected is still in the decoder: the rest) */
+        if (d->h_res[2] > 0) {
+            if (fetch_and_inject_from(d, 0, d->inj_nb, d->inj_nh, d->inj_nfr) < 0) return -1;
+            d->inj_nb = d->h_res[0]; d->inj_nh = d->h_res[1]; d->inj_nfr = d->h_res[2];
+        }
         d->n_partial = d->n_feat;
         return 0;
     }
@@ -760,7 +777,7 @@ dev_search_seg_iter(ps_search_t *search)
 void
 psgpu_device_search_live_stats(psgpu_device_decode_t *d, long *frames_searched, long *steps, long *restarts)
 {
-    if (frames_searched) *frames_searched = d ? (long)psgpu_decode_live_frames_searched(d->dec) : 0;
+    if (frames_searched) *frames_searched = d ? d->live_frames_before + (d->live_on ? (long)psgpu_decode_live_frames_searched(d->dec) : 0) : 0;
     if (steps) *steps = d ? d->live_steps : 0;
     if (restarts) *restarts = d ? d->live_restarts : 0;
 }

@@ -669,10 +669,11 @@ int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, 
     int rc;
     const int t0 = d->live_T;
     if (n_new > 0) {
-        const int32_t off1[2] = { 0, n_new };
+        const int32_t off1[2] = { 0, n_new }, off[2] = { 0, t0 + n_new };
         PSGPU_HIP(hipMemcpyAsync(d->d_off1, off1, 8, hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipMemcpyAsync(d->d_off, off, 8, hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipMemcpyAsync(d->d_feat + (size_t)t0 * d->veclen, feat, 4 * (size_t)n_new * d->veclen, hipMemcpyHostToDevice, st));
-        PSGPU_HIP(hipStreamSynchronize(st));             // (feat and off1 are the caller's / this frame's)
+        PSGPU_HIP(hipStreamSynchronize(st));             // (feat and the offsets are the caller's / this frame's)
         const float *const f = d->d_feat + (size_t)t0 * d->veclen;
         int16_t *const rows = d->d_rows + (size_t)t0 * d->n_sen;
         if (d->kind == PSGPU_SCORER_PTM) {
@@ -711,11 +712,6 @@ int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, 
     const int T = d->live_T;
     d->total = T; d->frame_off[1] = T; d->searched = false; d->pass2 = false;
     if (T == 0) return PSGPU_OK;                         // (nothing yet: the empty records of live_begin stand)
-    {
-        const int32_t off[2] = { 0, T };
-        PSGPU_HIP(hipMemcpyAsync(d->d_off, off, 8, hipMemcpyHostToDevice, st));
-        PSGPU_HIP(hipStreamSynchronize(st));
-    }
     if (d->live_chained && !d->live_mpx_copied) {        // (what this utterance's search starts from: a repeated search starts from it again)
         PSGPU_HIP(hipMemcpyAsync(d->d_mpx_in, d->d_mpx, 4 * (size_t)psgpu_fwdtree_n_mpx_channels(d->cfg.ft) * d->n_emit, hipMemcpyDeviceToDevice, st));
         d->live_mpx_copied = true;
@@ -859,7 +855,16 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
     if (nu && d->auto_grow && d->searched && !d->pass2) {
         std::vector<int32_t> res(nu * 8);
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        // (the usual case -- no table was full -- in one wait: the hypotheses travel with the result records)
+        if (hyp_n) PSGPU_HIP(hipMemcpyAsync(hyp_n, d->d_hn, 4 * nu * 4, hipMemcpyDeviceToHost, st));
+        if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
         PSGPU_HIP(hipStreamSynchronize(st));
+        bool again = false;
+        for (size_t u = 0; u < nu && !again; ++u) again = res[u * 8 + 3] != 0;
+        if (!again) {
+            if (result) memcpy(result, res.data(), 4 * nu * 8);
+            return PSGPU_OK;
+        }
         int rc = dec_repeat_with_larger_tables(d, res, st);
         if (rc != PSGPU_OK) return rc;
         if (result) memcpy(result, res.data(), 4 * nu * 8);
@@ -945,18 +950,27 @@ int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *strea
 int psgpu_decode_fetch_tables(psgpu_decode_t *d, int32_t u, int32_t n_bp, int32_t n_bss, int32_t n_idx, int32_t *bp, int32_t *bss,
                               int32_t *idx, void *stream)
 {
-    PSGPU_REQUIRE(d && u >= 0 && u < d->n_utt, "psgpu_decode_fetch_tables: bad argument");
+    return psgpu_decode_fetch_tables_range(d, u, 0, n_bp, 0, n_bss, 0, n_idx, bp, bss, idx, stream);
+}
+
+// entries [bp0, bp0 + n_bp) of the table (ten columns, n_bp apart on the host), [bss0, bss0 + n_bss) of the score stack,
+// [idx0, idx0 + n_idx) of the frame marks: the tables only grow while an utterance is in progress (psgpu_decode_live_step), a caller
+// that holds what an earlier read-out returned asks for the rest
+int psgpu_decode_fetch_tables_range(psgpu_decode_t *d, int32_t u, int32_t bp0, int32_t n_bp, int32_t bss0, int32_t n_bss, int32_t idx0,
+                                    int32_t n_idx, int32_t *bp, int32_t *bss, int32_t *idx, void *stream)
+{
+    PSGPU_REQUIRE(d && u >= 0 && u < d->n_utt && bp0 >= 0 && bss0 >= 0 && idx0 >= 0, "psgpu_decode_fetch_tables: bad argument");
     // (after psgpu_decode_second_pass: that pass's tables, as psgpu_decode_fetch_hyps returns its hypotheses and result records)
     const int32_t bcap = d->pass2 ? d->bp_cap2 : d->bp_cap, scap = d->pass2 ? d->bss_cap2 : d->bss_cap;
     const int32_t *const t_bp = d->pass2 ? d->d_bp2 : d->d_bp, *const t_bss = d->pass2 ? d->d_bss2 : d->d_bss, *const t_idx = d->pass2 ? d->d_idx2 : d->d_idx;
-    PSGPU_REQUIRE(n_bp >= 0 && n_bp <= bcap && n_bss >= 0 && n_bss <= scap && n_idx >= 0 && n_idx <= d->max_frames + 2,
+    PSGPU_REQUIRE(n_bp >= 0 && bp0 + n_bp <= bcap && n_bss >= 0 && bss0 + n_bss <= scap && n_idx >= 0 && idx0 + n_idx <= d->max_frames + 2,
                   "psgpu_decode_fetch_tables: bad argument");
     hipStream_t st = (hipStream_t)stream;
     if (bp && n_bp)       // ten columns, bp_cap apart on the device, n_bp apart on the host
-        PSGPU_HIP(hipMemcpy2DAsync(bp, 4 * (size_t)n_bp, t_bp + (size_t)u * 10 * bcap, 4 * (size_t)bcap, 4 * (size_t)n_bp, 10,
+        PSGPU_HIP(hipMemcpy2DAsync(bp, 4 * (size_t)n_bp, t_bp + (size_t)u * 10 * bcap + bp0, 4 * (size_t)bcap, 4 * (size_t)n_bp, 10,
                                    hipMemcpyDeviceToHost, st));
-    if (bss && n_bss) PSGPU_HIP(hipMemcpyAsync(bss, t_bss + (size_t)u * scap, 4 * (size_t)n_bss, hipMemcpyDeviceToHost, st));
-    if (idx && n_idx) PSGPU_HIP(hipMemcpyAsync(idx, t_idx + (size_t)u * (d->max_frames + 2), 4 * (size_t)n_idx, hipMemcpyDeviceToHost, st));
+    if (bss && n_bss) PSGPU_HIP(hipMemcpyAsync(bss, t_bss + (size_t)u * scap + bss0, 4 * (size_t)n_bss, hipMemcpyDeviceToHost, st));
+    if (idx && n_idx) PSGPU_HIP(hipMemcpyAsync(idx, t_idx + (size_t)u * (d->max_frames + 2) + idx0, 4 * (size_t)n_idx, hipMemcpyDeviceToHost, st));
     PSGPU_HIP(hipStreamSynchronize(st));
     return PSGPU_OK;
 }

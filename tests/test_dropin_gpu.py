@@ -634,3 +634,30 @@ def test_decode_batch_api_multi_device_dispatcher(flags, extra, reps):
     assert r["ok"] and r["rc"] == 0, r
     assert r["B"] == len(FILES) * reps and r["mismatch_batch"] == r["mismatch_reversed"] == r["mismatch_single"] == 0
     assert r["hyps"][0] == "go forward ten meters"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seconds,chunk,restarts", [(30.0, 4000, 0), (42.0, 16000, 1)])
+def test_dropin_live_decode_of_a_long_utterance(tmp_path, seconds, chunk, restarts):
+    """a synthetic 30 s utterance through the device ps_searchfuncs_t in 250 ms pieces with ps_get_hyp after every piece (120 read-outs)
+    -- the device search steps through each of its ~3,000 frames ONCE, every partial result and the final one equal the CPU decoder's;
+    and the same decode costs about what the one-call decode of the utterance does (both include the reference's own front end on
+    the host): the ratio is printed, DESIGN.md quotes it.  42 s: the live utterance outgrows the capacity it was begun with
+    (3,000 frames) once, is begun again with twice that and catches up -- frames searched = the utterance's + the prefix searched
+    before the restart."""
+    from pocketsphinx_amd import synth
+    raw = tmp_path / "long.raw"
+    synth.utterance(5, seconds).tofile(str(raw))
+    x = ("fwdflat", "no", "bestpath", "no")
+    live = run(str(raw), 2, "psgpu_device_vtable", "yes", "chunked", str(chunk), *x)
+    assert live["ok"] and live["rc"] == 0 and live["partial_equal"] and live["hyp_equal"] and live["seg_equal"], live
+    assert live["partial_results"] >= 2 * int(seconds * 16000 / chunk) and live["live_restarts"] == 2 * restarts, live
+    if restarts == 0:
+        assert live["live_frames_searched"] == live["live_utt_frames"] >= 2 * (live["n_frames"] - 1), live
+    else:
+        assert live["live_utt_frames"] < live["live_frames_searched"] <= 2 * live["live_utt_frames"], live
+    once = run(str(raw), 2, "psgpu_device_vtable", "yes", *x)
+    assert once["ok"] and once["hyp_equal"], once        # (its words differ from the live decode's: batch instead of live cepstral mean normalisation)
+    print("live decode of %.0f s in %d-sample pieces: %.3f s; in one call: %.3f s; ratio %.2f (CPU decoder live: %.3f s)"
+          % (seconds, chunk, live["decode_s_gpu"], once["decode_s_gpu"], live["decode_s_gpu"] / once["decode_s_gpu"], live["decode_s_cpu"]))
+    assert live["decode_s_gpu"] < 2.0 * once["decode_s_gpu"], (live["decode_s_gpu"], once["decode_s_gpu"])
