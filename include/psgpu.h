@@ -689,7 +689,9 @@ int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag);
  * for the same utterances with the same table buffers and capacities, score rows and penalties of ALL frames so far (frames
  * numbered from the utterance's start: utt_off_dev [n_utt + 1] with more frames than before), the same raw_scores / pl_window;
  * PSGPU_SEARCH_KEEP | PSGPU_SEARCH_RESUME: both (a call in the middle of a live utterance).  The tables after every call are
- * the ones one call over the same frames would have written.  LDS layout only (psgpu_fwdtree_layout): PSGPU_EINVAL otherwise. */
+ * the ones one call over the same frames would have written.  What is saved: the LDS layout's pool (~120 KB an utterance) and
+ * the frame loop's counters; the slab layouts' state already lies in the handle's slab, which -- like the handle's other buffers --
+ * must not be used by another search call in between (any search call without PSGPU_SEARCH_RESUME starts afresh). */
 #define PSGPU_SEARCH_KEEP 1
 #define PSGPU_SEARCH_RESUME 2
 int psgpu_fwdtree_search_resume(psgpu_fwdtree_t *m, int32_t mode);
@@ -859,8 +861,7 @@ int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag);
  *                             frames short of the frames scored so far (psgpu_fwdtree_search_resume; lag = 0: to the utterance's
  *                             end -- the utterance's last step).  After every step psgpu_decode_view / _fetch_hyps / _fetch_tables
  *                             return what ONE psgpu_decode_first_pass_feat call over the frames so far with psgpu_decode_search_lag(lag)
- *                             would have: the reference's tables at that moment.  n_new may be 0 (another lag).  A model whose
- *                             search takes the slab layout is searched from the utterance's first frame at every step instead.
+ *                             would have: the reference's tables at that moment.  n_new may be 0 (another lag).
  *   psgpu_decode_live_frames_searched   frames the search kernel has stepped through since live_begin, summed over the steps: the
  *                             utterance's frames searched so far when every frame was searched once. */
 int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream);

@@ -622,12 +622,10 @@ int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const
 }
 
 // ---- an utterance in progress ----------------------------------------------------------------------------------------------------
-// the search's resume mode: the LDS layout keeps its state; a model that takes the slab layout is searched from the utterance's start
-// at every step (0)
+// the search's resume mode of a live utterance's step
 static int dec_live_mode(psgpu_decode_s *d, bool resume)
 {
-    int32_t lds = 0;
-    if (psgpu_fwdtree_layout(d->cfg.ft, &lds, nullptr) != PSGPU_OK || !lds || (d->n_sen & 1)) return 0;      // (odd rows: the search copies rows as dwords in the LDS layout only)
+    (void)d;
     return PSGPU_SEARCH_KEEP | (resume ? PSGPU_SEARCH_RESUME : 0);
 }
 

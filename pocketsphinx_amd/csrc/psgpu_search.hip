@@ -170,7 +170,7 @@ struct psgpu_fwdtree_s {
     int32_t *live = nullptr;             // FtBufs::live, kept between calls
     size_t live_words = 0;
     bool live_valid = false;             // the latest search call saved its state ...
-    int32_t live_n_utt = 0, live_bp_cap = 0, live_bss_cap = 0, live_max_frames = 0, live_raw = 0, live_window = 0;    // ... for these
+    int32_t live_small = 0, live_n_utt = 0, live_bp_cap = 0, live_bss_cap = 0, live_max_frames = 0, live_raw = 0, live_window = 0;    // ... for these
     int32_t *live_bp = nullptr, *live_bss = nullptr, *live_idx = nullptr, *live_step = nullptr;
 };
 
@@ -983,7 +983,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
               T = bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in);
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
     // psgpu_fwdtree_search_resume: the utterance's saved state; f0 = the frames searched by the calls before
-    int32_t *const live = (SMALL && bf.live) ? psgpu_as_global(bf.live) + (size_t)blockIdx.x * (kFtLiveHdr + L.rows_total) : nullptr;
+    // (slab layouts: everything the frames share is in the utterance's slab -- which stays where it is between the calls -- but the
+    //  counters and the carried registers)
+    int32_t *const live = bf.live ? psgpu_as_global(bf.live) + (size_t)blockIdx.x * (kFtLiveHdr + (SMALL ? L.rows_total : 0)) : nullptr;
     const bool resumed = live != nullptr && (bf.live_mode & 2) != 0;
     const int f0 = resumed ? live[0] : 0;
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
@@ -991,11 +993,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     int nwc_cur = 0;                                     // right-context channels of the active words (the last of woff's prefix sums), likewise
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
-    for (int c = tid; c < N; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
-    for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
-    for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
-    for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
-    if (SMALL) { for (int c = tid; c < N; c += NT) pos[c] = -1; }      // pos is kept at -1 between frames
+    if (!resumed) {
+        for (int c = tid; c < N; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
+        for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
+        for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
+        for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
+        if (SMALL) { for (int c = tid; c < N; c += NT) pos[c] = -1; }      // pos is kept at -1 between frames
+    }
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
         s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0; s_nroot = 0;
@@ -1005,11 +1009,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
         if (use_lb) for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;
     }
-    if (SMALL && resumed) {
+    if (resumed) {
         // the pool as the previous call's last frame left it (the static tables' copies with it), the counters, the frame loop's
-        // carried registers; the senone bitmap and the normaliser are reset at every frame's end and are as the lines above left them
+        // carried registers; the senone bitmap, the listed-nodes bitmap and the normaliser are reset at every frame's end and are as
+        // the lines above left them
         __syncthreads();
-        for (int i = tid; i < L.rows_total; i += NT) s_pool[i] = live[kFtLiveHdr + i];
+        if (SMALL) for (int i = tid; i < L.rows_total; i += NT) s_pool[i] = live[kFtLiveHdr + i];
         if (tid < 8) s_sc[tid] = live[8 + tid];
         if (tid == 0) { s_evals = (unsigned long long)(uint32_t)live[5] | ((unsigned long long)(uint32_t)live[6] << 32); s_nsen = live[7]; }
         n_acl_cur = live[1]; n_awl_cur = live[2]; evals_run = (uint32_t)live[3]; nwc_cur = live[4];
@@ -2291,8 +2296,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
     __syncthreads();                                             // the table's last entries (device memory, other work-items') before the copy and the backtrace
-    if (SMALL && live && (bf.live_mode & 1)) {                   // psgpu_fwdtree_search_resume: what the next call starts from
-        for (int i = tid; i < L.rows_total; i += NT) live[kFtLiveHdr + i] = s_pool[i];
+    if (live && (bf.live_mode & 1)) {                            // psgpu_fwdtree_search_resume: what the next call starts from
+        if (SMALL) for (int i = tid; i < L.rows_total; i += NT) live[kFtLiveHdr + i] = s_pool[i];
         if (tid < 8) live[8 + tid] = s_sc[tid];
         if (tid == 0) {
             live[0] = s_sc[7]; live[1] = n_acl_cur; live[2] = n_awl_cur; live[3] = (int32_t)evals_run; live[4] = nwc_cur;
@@ -2699,6 +2704,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     const size_t need = (size_t)d.per * n_utt;
     if (need > m->slab_words) {
         if (m->slab) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->slab); m->slab = nullptr; m->slab_words = 0; }
+        m->live_valid = false;                           // (a saved search's channels lay there)
         PSGPU_HIP(hipMalloc((void **)&m->slab, sizeof(int32_t) * need));
         m->slab_words = need;
     }
@@ -2706,12 +2712,14 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     const size_t need_x = d.small ? (size_t)n_utt * (size_t)bp_cap * (size_t)d.n_ci : 0;
     if (need_x > m->bssx_words) {
         if (m->bssx) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->bssx); m->bssx = nullptr; m->bssx_words = 0; }
+        m->live_valid = false;
         PSGPU_HIP(hipMalloc((void **)&m->bssx, sizeof(int32_t) * need_x));
         m->bssx_words = need_x;
     }
     const size_t need_a = (size_t)n_utt * (size_t)bp_cap * kBpRow;
     if (need_a > m->bpa_words) {
         if (m->bpa) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->bpa); m->bpa = nullptr; m->bpa_words = 0; }
+        m->live_valid = false;
         PSGPU_HIP(hipMalloc((void **)&m->bpa, sizeof(int32_t) * need_a));
         m->bpa_words = need_a;
     }
@@ -2732,15 +2740,13 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     // psgpu_fwdtree_search_resume (one call's worth, like the lag)
     bf.live = nullptr; bf.live_mode = m->live_next; m->live_next = 0;
     if (bf.live_mode) {
-        PSGPU_REQUIRE(d.small, "psgpu_fwdtree_search_resume: the search's state is saved from the LDS layout only (this model, or these "
-                      "score rows, take the slab layout: search the utterance from its start instead)");
         if (bf.live_mode & 2)
             PSGPU_REQUIRE(m->live_valid && m->live_n_utt == n_utt && m->live_bp_cap == bp_cap && m->live_bss_cap == bss_cap
-                          && m->live_max_frames == max_frames && m->live_raw == raw_scores && m->live_window == pl_window && m->live_bp == bp_dev
+                          && m->live_small == d.small && m->live_max_frames == max_frames && m->live_raw == raw_scores && m->live_window == pl_window && m->live_bp == bp_dev
                           && m->live_bss == bss_dev && m->live_idx == idx_dev && m->live_step == step_dev,
                           "psgpu_fwdtree_search_resume: nothing to resume -- the handle's previous search call must have kept its state "
                           "(mode bit 0) for the same utterances, table capacities and table buffers");
-        const size_t need_l = (size_t)n_utt * (size_t)(kFtLiveHdr + d.lay.rows_total);
+        const size_t need_l = (size_t)n_utt * (size_t)(kFtLiveHdr + (d.small ? d.lay.rows_total : 0));
         if (need_l > m->live_words) {
             PSGPU_REQUIRE(!(bf.live_mode & 2), "psgpu_fwdtree_search_resume: the saved state does not fit its buffer");
             if (m->live) { PSGPU_HIP(hipStreamSynchronize(st)); hipFree(m->live); m->live = nullptr; m->live_words = 0; }
@@ -2751,7 +2757,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     }
     m->live_valid = (bf.live_mode & 1) != 0;
     if (m->live_valid) {
-        m->live_n_utt = n_utt; m->live_bp_cap = bp_cap; m->live_bss_cap = bss_cap; m->live_max_frames = max_frames; m->live_raw = raw_scores;
+        m->live_small = d.small; m->live_n_utt = n_utt; m->live_bp_cap = bp_cap; m->live_bss_cap = bss_cap; m->live_max_frames = max_frames; m->live_raw = raw_scores;
         m->live_window = pl_window; m->live_bp = bp_dev; m->live_bss = bss_dev; m->live_idx = idx_dev; m->live_step = step_dev;
     }
     bf.prof = nullptr;
@@ -2840,7 +2846,6 @@ int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag)
 int psgpu_fwdtree_search_resume(psgpu_fwdtree_t *m, int32_t mode)
 {
     PSGPU_REQUIRE(m && mode >= 0 && mode <= 3, "psgpu_fwdtree_search_resume: bad argument");
-    PSGPU_REQUIRE(!mode || m->d.small, "psgpu_fwdtree_search_resume: the search's state is saved from the LDS layout only (psgpu_fwdtree_layout)");
     m->live_next = mode;
     return PSGPU_OK;
 }

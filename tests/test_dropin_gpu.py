@@ -526,19 +526,22 @@ def test_dropin_device_search_vtable(raw, nrep, extra, lm, dic):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("raw,chunk,extra", [
-    ("goforward.raw", 4096, ("fwdflat", "no", "bestpath", "no")),
-    ("numbers.raw", 2048, ("fwdflat", "no", "bestpath", "no")),
-    ("goforward.raw", 8000, ()),                         # the reference's later passes at the end, partial results before
+@pytest.mark.parametrize("raw,chunk,extra,lm,dic", [
+    ("goforward.raw", 4096, ("fwdflat", "no", "bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
+    ("numbers.raw", 2048, ("fwdflat", "no", "bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
+    ("goforward.raw", 8000, (), "turtle.lm.bin", "turtle.dic"),      # the reference's later passes at the end, partial results before
+    ("numbers.raw", 4000, ("fwdflat", "no", "bestpath", "no"), "medium.arpa", "medium.dic"),
+    # the full cmudict vocabulary: the search's slab layout, 1024 work-items, resumed at every read-out
+    ("goforward.raw", 4096, ("fwdflat", "no", "bestpath", "no"), "big.arpa", "cmudict-en-us.dict"),
 ])
-def test_dropin_device_search_partial_results(raw, chunk, extra):
+def test_dropin_device_search_partial_results(raw, chunk, extra, lm, dic):
     """live decoding through the device ps_searchfuncs_t: the utterance arrives `chunk` samples at a time
     (ps_process_raw without full_utt, reference src/pocketsphinx.c:1220-1257) and ps_get_hyp is asked after every piece, as
     a live application does (:1372, ngram_search_hyp, src/ngram_search.c:845).  The reference's search has then stepped
     through output_frame - pl_window frames; the binding hands the device pipeline the frames it has not seen yet, the device
     search goes on from where it stopped to as far short of the phone loop (psgpu_decode_live_step), and that table is injected.
     EVERY partial hypothesis and score equals the CPU decoder's, and so does the final result."""
-    r = run(raw, 1, "psgpu_device_vtable", "yes", "chunked", str(chunk), *extra)
+    r = run(raw, 1, "psgpu_device_vtable", "yes", "chunked", str(chunk), *extra, lm=lm, dic=dic)
     assert r["ok"] and r["rc"] == 0, r
     assert r["partial_equal"] and r["partial_results"] >= 5, r
     assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r

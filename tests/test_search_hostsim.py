@@ -248,18 +248,21 @@ def test_search_kernel_source_stopping_short_of_the_last_frames(layout, lag):
     s.close()
 
 
-@pytest.mark.parametrize("order", ["fwd", "rev"])
+@pytest.mark.parametrize("layout,order", [("lds", "fwd"), ("lds", "rev"), ("slab", "rev")])
 @pytest.mark.parametrize("case,cuts,lag", [("goforward", [1, 2, 40, 41, 150], 0), ("goforward", [30, 100, 200], 7),
-                                           ("numbers", [97], 3), ("man_ah_2934za", [10, 11, 60], 2)])
-def test_search_kernel_source_resumed_between_calls(case, cuts, lag, order):
+                                           ("numbers", [97], 3), ("man_ah_2934za", [10, 11, 60], 2),
+                                           ("goforward_maxhmmpf60_maxwpf3", [50, 51, 170], 5), ("medium_numbers_maxwpf8", [33, 120], 4)])
+def test_search_kernel_source_resumed_between_calls(case, cuts, lag, layout, order):
     """psgpu_fwdtree_search_resume: one utterance searched in several calls, each going on where the one before stopped (the LDS
-    pool, the counters and the frame loop's carried registers saved and restored; the reference's search keeps its state between
+    pool, the counters and the frame loop's carried registers saved and restored -- the slab layouts' state stays in the slab; the
+    reference's search keeps its state between
     ps_search_forward rounds, ngram_search_fwdtree.c:1454-1495).  Every frame is searched once -- the frames searched after each
     call are the cut minus the lag -- and the tables at the end are the golden's, as from one call."""
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
-    with _order(order), _layout("lds"):
-        s = simlib.SimFwdtreeSearch(st, g["par"])
+    lm = simlib.SimLm(st) if "lm" not in st else None       # (the medium task: language scores from the device trie)
+    with _order(order), _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm)
         rows, pen = _inputs(g, s.n_sen)
         T = rows.shape[0]
         _check(s.search(rows, pen, [T], cuts=cuts, lag=lag)[0], g, "%s resumed at %r" % (case, cuts))
@@ -271,16 +274,6 @@ def test_search_kernel_source_resumed_between_calls(case, cuts, lag, order):
         with pytest.raises(RuntimeError, match="nothing to resume"):
             s.search(rows, pen, [T])
         s.close()
-
-
-def test_search_resume_needs_the_lds_layout():
-    g = _load("fwdtree_trace_goforward.npz")
-    st = _load("fwdtree_static_en_us_turtle.npz")
-    with _layout("slab"):
-        s = simlib.SimFwdtreeSearch(st, g["par"])
-    assert simlib.lib().psgpu_fwdtree_search_resume(s.h, 1) != 0
-    assert simlib.lib().psgpu_fwdtree_search_resume(s.h, 0) == 0
-    s.close()
 
 
 @pytest.mark.parametrize("layout", ["slab", "lds"])

@@ -39,6 +39,10 @@ def impl_matches_reference(case, layout):
         assert s.lds_layout(), "the bundled small-vocabulary tasks are expected to fit the LDS pool"
     rows, pen = _inputs(g, s.n_sen)
     _check(s.search(rows, pen, [rows.shape[0]])[0], g, case)
+    # ... and in three calls (psgpu_fwdtree_search_resume: the LDS layout's pool saved and restored, the slab layouts' state in place)
+    T = rows.shape[0]
+    _check(s.search(rows, pen, [T], cuts=[T // 3, T // 3 + 1, 2 * T // 3], lag=3)[0], g, case + ", resumed")
+    assert s.searched == [T // 3 - 3, T // 3 - 2, 2 * T // 3 - 3, T]
     s.close()
 
 
@@ -87,4 +91,7 @@ def impl_full_cmudict(tmp):
     rows, pen = _inputs(g, s.n_sen)
     _check(s.search(rows, pen, [rows.shape[0]])[0], g, "cmudict")
     _check(s.search(np.concatenate([rows, rows]), np.concatenate([pen, pen]), [rows.shape[0]] * 2)[1], g, "cmudict x2")
+    T = rows.shape[0]                                     # (1024 work-items an utterance, resumed twice)
+    _check(s.search(rows, pen, [T], cuts=[T // 2, T // 2 + 9], lag=4)[0], g, "cmudict, resumed")
+    assert s.searched == [T // 2 - 4, T // 2 + 5, T]
     s.close()
