@@ -172,6 +172,9 @@ struct psgpu_fwdtree_s {
     bool live_valid = false;             // the latest search call saved its state ...
     int32_t live_small = 0, live_n_utt = 0, live_bp_cap = 0, live_bss_cap = 0, live_max_frames = 0, live_raw = 0, live_window = 0;    // ... for these
     int32_t *live_bp = nullptr, *live_bss = nullptr, *live_idx = nullptr, *live_step = nullptr;
+#ifdef PSGPU_FT_PROFILE
+    long long *prof_buf = nullptr; const int32_t *prof_res = nullptr; int32_t prof_n_utt = 0; hipEvent_t prof_ev = nullptr;
+#endif
 };
 
 // ---- channel records ---------------------------------------------------------------------------------------------
@@ -2447,6 +2450,48 @@ static bool ft_layout(FtDev &d, bool small)
     return true;
 }
 
+#ifdef PSGPU_FT_PROFILE
+// a profiling build: the per-phase cycle counts of the handle's PREVIOUS search, averaged over its utterances, per frame -- printed when
+// the handle is used next (or freed), so that the launch itself does not wait and searches of other handles run beside it as they do in
+// the product build
+// (an interval ends at its marker: "x: to barrier" = work-item 0's own work, the next interval = its wait at the barrier + the rest)
+static void ft_prof_report(psgpu_fwdtree_s *m)
+{
+    if (!m->prof_buf) return;
+    hipEventSynchronize(m->prof_ev);
+    const int n_utt = m->prof_n_utt;
+    {
+        static const char *const names[32] = { "top: lists, senone marks", "slab pairs: bisection", "normaliser", "evaluate: after barrier (prefetch issue, beam)", "prune: snapshot", "prune: decide, barrier | slab: chunk scans + candidates",
+            "next active list | slab: pairs", "last-phone candidates", "predecessor search: decode + max", "entering", "active words", "prune_word_chan",
+            "positions (scans)", "slab pairs: loads + decisions", "exits", "single-phone: barrier + counters", "word_transition: pairs, barrier", "frame end: row to LDS",
+            "evaluate: loop", "evaluate: barrier", "single-phone: flags + scan", "single-phone: save", "slab pairs: compaction", "word_transition: init + barrier",
+            "word_transition: pair loops", "word_transition: decode keys", "word_transition: enter", "deactivate + step", "prune: decide loop | slab: chunk items",
+            "predecessor search: exit scores + scan", "predecessor search: pairs", "slab pairs: barrier" };
+        std::vector<long long> h((size_t)48 * n_utt);
+        std::vector<int32_t> r((size_t)8 * n_utt);
+        hipMemcpy(h.data(), m->prof_buf, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+        hipMemcpy(r.data(), m->prof_res, 4 * r.size(), hipMemcpyDeviceToHost);
+        hipFree(m->prof_buf); m->prof_buf = nullptr;
+        double frames = 0, tot = 0, acc[32] = {};
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 32; ++i) acc[i] += (double)h[(size_t)u * 48 + i]; }
+        for (int i = 0; i < 32; ++i) tot += acc[i];
+        fprintf(stderr, "fwdtree_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
+        static const int order[] = { 0, 2, 18, 19, 3, 4, 28, 5, 1, 13, 22, 31, 6, 7, 29, 30, 8, 9, 10, 11, 12, 14, 20, 21, 15, 23, 24, 16, 25, 26, 27, 17 };
+        for (int w = 1; w < 4; ++w) {
+            double a1 = 0, a2 = 0;
+            for (int u = 0; u < n_utt; ++u) { a1 += (double)h[(size_t)u * 48 + 32 + 4 * w + 1]; a2 += (double)h[(size_t)u * 48 + 32 + 4 * w + 2]; }
+            fprintf(stderr, "  wavefront %d: evaluate loop %9.0f, its barrier %9.0f cycles/frame\n", w, a1 / (frames > 0 ? frames : 1), a2 / (frames > 0 ? frames : 1));
+        }
+        {
+            double n16 = 0, c16 = 0, mx = 0, e16 = 0;
+            for (int u = 0; u < n_utt; ++u) { n16 += (double)h[(size_t)u * 48 + 44]; c16 += (double)h[(size_t)u * 48 + 45]; mx = std::max(mx, (double)h[(size_t)u * 48 + 46]); e16 += (double)h[(size_t)u * 48 + 47]; }
+            fprintf(stderr, "  evaluation over 16k cycles: %.0f of %.0f frames, %.0f cycles and %.1f evaluations each on average; longest %.0f\n", n16, frames, c16 / (n16 > 0 ? n16 : 1), e16 / (n16 > 0 ? n16 : 1), mx);
+        }
+        for (int i : order) fprintf(stderr, "  %2d %-48s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
+    }
+}
+#endif
+
 extern "C" {
 
 int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
@@ -2602,9 +2647,15 @@ int psgpu_fwdtree_layout(const psgpu_fwdtree_t *m, int32_t *lds_layout, int64_t 
     return PSGPU_OK;
 }
 
+#ifdef PSGPU_FT_PROFILE
+static void ft_prof_report(psgpu_fwdtree_s *m);
+#endif
 void psgpu_fwdtree_free(psgpu_fwdtree_t *m)
 {
     if (!m) return;
+#ifdef PSGPU_FT_PROFILE
+    ft_prof_report(m);
+#endif
     for (void *p : m->allocs) hipFree(p);
     hipFree(m->slab);
     hipFree(m->bssx);
@@ -2762,6 +2813,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     }
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
+    ft_prof_report(m);
     PSGPU_HIP(hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt));
 #endif
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
@@ -2801,37 +2853,9 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
 #undef FT_DYN_LDS
     PSGPU_HIP(hipGetLastError());
 #ifdef PSGPU_FT_PROFILE
-    {   // a profiling build: wait, average the per-phase cycle counts over the utterances, print them per frame
-        // (an interval ends at its marker: "x: to barrier" = work-item 0's own work, the next interval = its wait at the barrier + the rest)
-        static const char *const names[32] = { "top: lists, senone marks", "slab pairs: bisection", "normaliser", "evaluate: after barrier (prefetch issue, beam)", "prune: snapshot", "prune: decide, barrier | slab: chunk scans + candidates",
-            "next active list | slab: pairs", "last-phone candidates", "predecessor search: decode + max", "entering", "active words", "prune_word_chan",
-            "positions (scans)", "slab pairs: loads + decisions", "exits", "single-phone: barrier + counters", "word_transition: pairs, barrier", "frame end: row to LDS",
-            "evaluate: loop", "evaluate: barrier", "single-phone: flags + scan", "single-phone: save", "slab pairs: compaction", "word_transition: init + barrier",
-            "word_transition: pair loops", "word_transition: decode keys", "word_transition: enter", "deactivate + step", "prune: decide loop | slab: chunk items",
-            "predecessor search: exit scores + scan", "predecessor search: pairs", "slab pairs: barrier" };
-        std::vector<long long> h((size_t)48 * n_utt);
-        std::vector<int32_t> r((size_t)8 * n_utt);
-        PSGPU_HIP(hipStreamSynchronize(st));
-        PSGPU_HIP(hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-        PSGPU_HIP(hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost));
-        hipFree(bf.prof);
-        double frames = 0, tot = 0, acc[32] = {};
-        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 32; ++i) acc[i] += (double)h[(size_t)u * 48 + i]; }
-        for (int i = 0; i < 32; ++i) tot += acc[i];
-        fprintf(stderr, "fwdtree_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
-        static const int order[] = { 0, 2, 18, 19, 3, 4, 28, 5, 1, 13, 22, 31, 6, 7, 29, 30, 8, 9, 10, 11, 12, 14, 20, 21, 15, 23, 24, 16, 25, 26, 27, 17 };
-        for (int w = 1; w < 4; ++w) {
-            double a1 = 0, a2 = 0;
-            for (int u = 0; u < n_utt; ++u) { a1 += (double)h[(size_t)u * 48 + 32 + 4 * w + 1]; a2 += (double)h[(size_t)u * 48 + 32 + 4 * w + 2]; }
-            fprintf(stderr, "  wavefront %d: evaluate loop %9.0f, its barrier %9.0f cycles/frame\n", w, a1 / (frames > 0 ? frames : 1), a2 / (frames > 0 ? frames : 1));
-        }
-        {
-            double n16 = 0, c16 = 0, mx = 0, e16 = 0;
-            for (int u = 0; u < n_utt; ++u) { n16 += (double)h[(size_t)u * 48 + 44]; c16 += (double)h[(size_t)u * 48 + 45]; mx = std::max(mx, (double)h[(size_t)u * 48 + 46]); e16 += (double)h[(size_t)u * 48 + 47]; }
-            fprintf(stderr, "  evaluation over 16k cycles: %.0f of %.0f frames, %.0f cycles and %.1f evaluations each on average; longest %.0f\n", n16, frames, c16 / (n16 > 0 ? n16 : 1), e16 / (n16 > 0 ? n16 : 1), mx);
-        }
-        for (int i : order) fprintf(stderr, "  %2d %-48s %9.0f cycles/frame  %5.1f %%\n", i, names[i], acc[i] / (frames > 0 ? frames : 1), 100.0 * acc[i] / (tot > 0 ? tot : 1));
-    }
+    m->prof_buf = bf.prof; m->prof_res = result_dev; m->prof_n_utt = n_utt;
+    if (!m->prof_ev) hipEventCreateWithFlags(&m->prof_ev, hipEventDisableTiming);
+    hipEventRecord(m->prof_ev, st);
 #endif
     return PSGPU_OK;
 }
