@@ -519,6 +519,8 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
  * resume = 0 starts every utterance afresh (phone_loop_search_start).  The penalties of a sequence of calls are those of one
  * call over all the frames.  A call without frames for an utterance leaves its state alone. */
 int32_t psgpu_phone_loop_carry_words(void);
+/* utterance u of a carry buffer starts afresh at the next call although resume != 0 (the other utterances go on) */
+int psgpu_phone_loop_carry_restart(int32_t *carry_dev, int32_t u, void *stream);
 int psgpu_phone_loop_run_carry_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *p, const uint16_t *ssid_dev,
                                    const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,
                                    const int16_t *raw_dev, int64_t raw_stride, const int32_t *best_dev,
@@ -695,6 +697,14 @@ int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag);
 #define PSGPU_SEARCH_KEEP 1
 #define PSGPU_SEARCH_RESUME 2
 int psgpu_fwdtree_search_resume(psgpu_fwdtree_t *m, int32_t mode);
+/* For the NEXT search call only: utterances in progress that grow at their own pace.  ext_dev [n_utt][2] int32 = {frames scored
+ * so far, frame the search goes on to (<= the former)} per utterance replaces the back-to-back reading of utt_off_dev and the
+ * call's one lag; utt_off_dev [u] alone then places utterance u's score rows and penalties: frame f's at row utt_off_dev[u] + f.
+ * Only the frames from the one the search resumes at are read, so a caller that keeps just those passes a start before its
+ * buffer (a negative offset).  NULL: off.   psgpu_fwdtree_search_restart: utterance u of the handle's saved searches starts
+ * afresh at the next PSGPU_SEARCH_RESUME call (ngram_fwdtree_start for it alone), the others go on. */
+int psgpu_fwdtree_search_streams(psgpu_fwdtree_t *m, const int32_t *ext_dev);
+int psgpu_fwdtree_search_restart(psgpu_fwdtree_t *m, int32_t u, void *stream);
 /* Makes the tree search look its language scores up in `lm` (which must outlive it) instead of
  * the dense table of psgpu_fwdtree_tables_t.lm (which may then be NULL at create). */
 int psgpu_fwdtree_set_lm(psgpu_fwdtree_t *m, const psgpu_lm_t *lm);
@@ -867,6 +877,25 @@ int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag);
 int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream);
 int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, int32_t lag, void *stream);
 int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d);
+/* ---- MANY utterances in progress: a batch of live decoders (the serving shape of ps_process_raw called chunk by chunk on many
+ * decoders at once).  Every stream is a new decoder's utterance, grows at its own pace, and costs what its frames cost:
+ *   psgpu_decode_streams_begin    n_streams streams of at most max_frames frames an utterance, at most max_step_frames new frames a
+ *                                 stream a step (buffers are sized from these).  The search runs pl_window frames behind the frames
+ *                                 scored, as ps_search_forward keeps it, and to the utterance's end in the step that says it is the last.
+ *   psgpu_decode_streams_step     feat: the streams' new feature frames (host, [sum n_new][veclen], stream after stream); n_new [n_streams]
+ *                                 (host; 0: nothing for that stream this step); final_flags [n_streams] (host, or NULL: none): nonzero =
+ *                                 the stream's utterance ends with these frames.  One launch set for all streams: batch scorer (every
+ *                                 stream's lists seeded from its previous frame's), phone loop (psgpu_phone_loop_run_carry_dev), a copy
+ *                                 kernel that keeps the score rows and penalties the searches have not reached yet, the tree search of all
+ *                                 streams going on where each stopped (psgpu_fwdtree_search_resume / _streams).  Afterwards
+ *                                 psgpu_decode_fetch_hyps / _fetch_tables return every stream's result record, hypothesis and tables as
+ *                                 they stand -- for a stream in mid-utterance what ps_get_hyp would read at that point.  Tables do not
+ *                                 grow here (psgpu_decode_table_capacity before _begin): a full one ends its stream with status 1.
+ *   psgpu_decode_streams_restart  stream u's next frames begin a new utterance (a new decoder: no session state is inherited).
+ * psgpu_decode_live_frames_searched counts the frames the search stepped through, summed over the streams. */
+int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max_frames, int32_t max_step_frames, void *stream);
+int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_t *n_new, const uint8_t *final_flags, void *stream);
+int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream);
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
  * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array.  After

@@ -85,6 +85,21 @@ struct psgpu_decode_s {
     uint8_t *d_lseed[2] = { nullptr, nullptr };
     int32_t lseed_cur = 0;
     int32_t *d_pl_carry = nullptr, *d_off1 = nullptr;
+    // psgpu_decode_streams_*: MANY utterances in progress, each growing at its own pace (a batch of live decoders).  Per stream the
+    // frames fed (ls_T), searched (ls_S); the score rows and penalties of the frames not yet searched live in a WINDOW buffer (two,
+    // taking turns: a step copies what the search has not reached yet and appends the step's new rows), ls_wbase / ls_woff = the
+    // stream's first frame in it and its row there
+    bool streams = false, ls_first = true;
+    int32_t ls_n = 0, ls_cap = 0, ls_step = 0, ls_lag = 0, ls_cur = 0, ls_wcur = 0;
+    int64_t ls_searched = 0;
+    std::vector<int32_t> ls_T, ls_S, ls_wbase, ls_woff, ls_h;
+    std::vector<uint8_t> ls_fresh;
+    int16_t *d_win[2] = { nullptr, nullptr };
+    int32_t *d_wpen[2] = { nullptr, nullptr };
+    size_t win_rows = 0;
+    int32_t *d_ls = nullptr;             // the step's small tables: chunk offsets [n + 1], row starts [n + 1], {scored, search to} [n][2], window map [n][5]
+    uint8_t *d_sseed[2] = { nullptr, nullptr };
+    int32_t *d_splc = nullptr;
 };
 
 static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
@@ -127,6 +142,36 @@ __global__ void dec_pass2_seed_kernel(const uint8_t *__restrict__ tcw, const int
         const int ch = i / topn, k = i - ch * topn;
         seed[(size_t)u * n_chain * topn + i] = ts >= 0 ? (int32_t)tcw[((size_t)ch * total + t0 + ts) * topn + k] : k;
     }
+}
+
+// psgpu_decode_streams_step: the new window of every stream = the rows (and penalties) of its old window the search has not reached
+// yet + the step's new rows.  map [n][5] = {first row to keep in the old window, rows kept, first row in the step's buffer, new rows,
+// first row in the new window}; one workgroup per (stream, row); dwords (n_sen is even in this mode).
+__global__ __launch_bounds__(256)
+void dec_window_kernel(const int32_t *__restrict__ map, int32_t n_streams, int32_t max_rows, int32_t row_dw, int32_t n_ci,
+                       const uint32_t *__restrict__ win_old, const uint32_t *__restrict__ chunk, uint32_t *__restrict__ win_new,
+                       const int32_t *__restrict__ pen_old, const int32_t *__restrict__ pen_chunk, int32_t *__restrict__ pen_new)
+{
+    const int u = blockIdx.x / max_rows, r = blockIdx.x % max_rows;
+    const int32_t *const m = map + 5 * u;
+    const int keep = m[1], nn = m[3];
+    if (r >= keep + nn) return;
+    const size_t src = r < keep ? (size_t)(m[0] + r) : (size_t)(m[2] + r - keep), dst = (size_t)(m[4] + r);
+    const uint32_t *const s = (r < keep ? win_old : chunk) + src * row_dw;
+    uint32_t *const o = win_new + dst * row_dw;
+    for (int i = threadIdx.x; i < row_dw; i += 256) o[i] = s[i];
+    const int32_t *const ps = (r < keep ? pen_old : pen_chunk) + src * n_ci;
+    if ((int)threadIdx.x < n_ci) pen_new[dst * n_ci + threadIdx.x] = ps[threadIdx.x];
+}
+
+// ... and the scorer's carried lists of the streams that had no frames in the step: the batch scorer writes a carry-out for utterances
+// with frames only
+__global__ void dec_seed_keep_kernel(const int32_t *__restrict__ off1, int32_t n_streams, int32_t per, const uint8_t *__restrict__ in,
+                                     uint8_t *__restrict__ out)
+{
+    const int u = blockIdx.x;
+    if (off1[u + 1] != off1[u]) return;
+    for (int i = threadIdx.x; i < per; i += blockDim.x) out[(size_t)u * per + i] = in[(size_t)u * per + i];
 }
 
 extern "C" {
@@ -189,6 +234,8 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_bp2); DFREE(d->d_bss2); DFREE(d->d_idx2); DFREE(d->d_step2); DFREE(d->d_res2); DFREE(d->d_seed2);
     DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
     DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_pl_carry); DFREE(d->d_off1);
+    DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
+    DFREE(d->d_splc);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
@@ -469,7 +516,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
                   "vectors (other feature types: psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
     hipStream_t st = (hipStream_t)stream;
     d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
-    d->live = false;
+    d->live = false; d->streams = false;
     d->frame_off.assign((size_t)n_utt + 1, 0);
     if (n_utt == 0) return PSGPU_OK;
     size_t total = 0, mf = 0;
@@ -541,7 +588,7 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (feat && frame_off)), "psgpu_decode_first_pass_feat: bad argument");
     hipStream_t st = (hipStream_t)stream;
     d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
-    d->live = false;
+    d->live = false; d->streams = false;
     d->frame_off.assign(frame_off, frame_off + (n_utt ? n_utt + 1 : 0));
     if (n_utt == 0) { d->frame_off.assign(1, 0); return PSGPU_OK; }
     PSGPU_REQUIRE(frame_off[0] == 0, "psgpu_decode_first_pass_feat: frame offsets start at 0");
@@ -645,6 +692,7 @@ int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream)
             || (rc = dec_alloc((void **)&d->d_off1, 8)) || (rc = dec_alloc((void **)&d->d_pl_carry, 4 * (size_t)psgpu_phone_loop_carry_words())))
             return rc;
     }
+    d->streams = false;
     d->live = true; d->live_ok = false; d->live_cap = max_frames; d->live_T = 0; d->live_S = 0; d->live_searched = 0; d->live_mode_next = 0;
     d->live_chained = d->sess_started; d->live_mpx_copied = false; d->lseed_cur = 0;
     d->n_utt = 1; d->total = 0; d->max_frames = max_frames; d->searched = false; d->pass2 = false; d->first_called = true;
@@ -659,7 +707,7 @@ int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream)
 
 int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, int32_t lag, void *stream)
 {
-    PSGPU_REQUIRE(d && d->live, "psgpu_decode_live_step: no live utterance (psgpu_decode_live_begin)");
+    PSGPU_REQUIRE(d && d->live && !d->streams, "psgpu_decode_live_step: no live utterance (psgpu_decode_live_begin)");
     PSGPU_REQUIRE(n_new >= 0 && lag >= 0 && (n_new == 0 || feat), "psgpu_decode_live_step: bad argument");
     PSGPU_REQUIRE(d->live_T + n_new <= d->live_cap, "psgpu_decode_live_step: %d frames exceed the live utterance's capacity of %d "
                   "(psgpu_decode_live_begin with a larger one, then the utterance's frames again)", d->live_T + n_new, d->live_cap);
@@ -727,7 +775,155 @@ int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, 
     return PSGPU_OK;
 }
 
-int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d) { return d ? d->live_searched : 0; }
+int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d) { return d ? (d->streams ? d->ls_searched : d->live_searched) : 0; }
+
+// ---- many utterances in progress ---------------------------------------------------------------------------------------------------
+int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max_frames, int32_t max_step_frames, void *stream)
+{
+    PSGPU_REQUIRE(d && n_streams > 0 && max_frames > 0 && max_step_frames > 0, "psgpu_decode_streams_begin: bad argument");
+    PSGPU_REQUIRE(d->kind != PSGPU_SCORER_SEMI, "psgpu_decode_streams_begin: the semi-continuous scorer's history is not carried between calls");
+    PSGPU_REQUIRE(!d->want_lists && (d->n_sen & 1) == 0, "psgpu_decode_streams_begin: streams keep score rows (an even number of senones; not with "
+                  "psgpu_decode_score_mode lists)");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    d->lists = false; d->live = true;                    // (score rows; dec_pick_mode keeps them while the streams are in progress)
+    const size_t step_total = (size_t)n_streams * max_step_frames;
+    if ((rc = dec_grow(d, (size_t)n_streams, step_total, (size_t)max_frames, st))) return rc;
+    PSGPU_HIP(hipStreamSynchronize(st));
+    const int lag = d->cfg.pl_window;
+    const size_t wrows = (size_t)n_streams * ((size_t)max_step_frames + lag + 1), per = (size_t)std::max(1, d->n_chain * d->topn);
+    if (wrows > d->win_rows || n_streams > d->ls_n) {
+        DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
+        DFREE(d->d_splc);
+        d->win_rows = 0;
+        for (int k = 0; k < 2; ++k)
+            if ((rc = dec_alloc((void **)&d->d_win[k], 2 * wrows * d->n_sen + 64)) || (rc = dec_alloc((void **)&d->d_wpen[k], 4 * wrows * d->n_ci))
+                || (rc = dec_alloc((void **)&d->d_sseed[k], (size_t)n_streams * per)))
+                return rc;
+        if ((rc = dec_alloc((void **)&d->d_ls, 4 * (size_t)(10 * n_streams + 8)))
+            || (rc = dec_alloc((void **)&d->d_splc, 4 * (size_t)n_streams * psgpu_phone_loop_carry_words())))
+            return rc;
+        d->win_rows = wrows;
+    }
+    PSGPU_HIP(hipMemsetAsync(d->d_splc, 0, 4 * (size_t)n_streams * psgpu_phone_loop_carry_words(), st));
+    {   // a new scorer's lists: codeword = rank (ptm_mgau.c:790-793)
+        std::vector<uint8_t> seed((size_t)n_streams * per);
+        for (size_t i = 0; i < seed.size(); ++i) seed[i] = (uint8_t)(d->topn > 0 ? (i % per) % d->topn : 0);
+        PSGPU_HIP(hipMemcpyAsync(d->d_sseed[0], seed.data(), seed.size(), hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+    }
+    d->streams = true; d->ls_first = true; d->ls_n = n_streams; d->ls_cap = max_frames; d->ls_step = max_step_frames; d->ls_lag = lag; d->ls_cur = 0; d->ls_wcur = 0;
+    d->ls_searched = 0;
+    d->ls_T.assign(n_streams, 0); d->ls_S.assign(n_streams, 0); d->ls_wbase.assign(n_streams, 0); d->ls_woff.assign(n_streams, 0);
+    d->ls_fresh.assign(n_streams, 0);
+    d->n_utt = n_streams; d->total = 0; d->max_frames = max_frames; d->searched = false; d->pass2 = false; d->first_called = true;
+    d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
+    d->frame_off.assign((size_t)n_streams + 1, 0);
+    d->ev_valid = false;
+    if (d->cfg.fe) psgpu_fe_offsets_dirty(d->cfg.fe);
+    PSGPU_HIP(hipMemsetAsync(d->d_res, 0, 4 * (size_t)n_streams * 8, st));
+    PSGPU_HIP(hipMemsetAsync(d->d_hn, 0, 4 * (size_t)n_streams * 4, st));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream)
+{
+    PSGPU_REQUIRE(d && d->streams && u >= 0 && u < d->ls_n, "psgpu_decode_streams_restart: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    d->ls_T[u] = 0; d->ls_S[u] = 0; d->ls_wbase[u] = 0; d->ls_woff[u] = 0; d->ls_fresh[u] = 1;
+    if (!d->ls_first && (rc = psgpu_fwdtree_search_restart(d->cfg.ft, u, st))) return rc;
+    if ((rc = psgpu_phone_loop_carry_restart(d->d_splc, u, st))) return rc;
+    const size_t per = (size_t)std::max(1, d->n_chain * d->topn);
+    std::vector<uint8_t> seed(per);
+    for (size_t i = 0; i < per; ++i) seed[i] = (uint8_t)(d->topn > 0 ? i % d->topn : 0);
+    PSGPU_HIP(hipMemcpyAsync(d->d_sseed[d->ls_cur] + (size_t)u * per, seed.data(), per, hipMemcpyHostToDevice, st));
+    PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
+}
+
+int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_t *n_new, const uint8_t *final_flags, void *stream)
+{
+    PSGPU_REQUIRE(d && d->streams && n_new, "psgpu_decode_streams_step: no streams (psgpu_decode_streams_begin) / NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = d->ls_n, lag = d->ls_lag;
+    int rc;
+    // the step's tables
+    std::vector<int32_t> &h = d->ls_h;
+    h.assign((size_t)10 * n + 8, 0);
+    int32_t *const off1 = h.data(), *const uoff = off1 + n + 1, *const ext = uoff + n + 1, *const map = ext + 2 * n;
+    size_t total = 0, wtot = 0;
+    int64_t searched = 0;
+    for (int u = 0; u < n; ++u) {
+        PSGPU_REQUIRE(n_new[u] >= 0 && n_new[u] <= d->ls_step && d->ls_T[u] + n_new[u] <= d->ls_cap,
+                      "psgpu_decode_streams_step: stream %d: %d new frames (at most %d a step, %d an utterance)", u, n_new[u], d->ls_step, d->ls_cap);
+        const int T0 = d->ls_T[u], S0 = d->ls_S[u], T = T0 + n_new[u], keep = T0 - S0;
+        const bool fin = final_flags && final_flags[u];
+        const int S = fin ? (T < d->cfg.pl_window ? S0 : T) : std::max(T - lag, S0);
+        off1[u] = (int32_t)total; total += (size_t)n_new[u];
+        map[5 * u] = d->ls_woff[u] + (S0 - d->ls_wbase[u]); map[5 * u + 1] = keep; map[5 * u + 2] = off1[u]; map[5 * u + 3] = n_new[u];
+        map[5 * u + 4] = (int32_t)wtot;
+        uoff[u] = (int32_t)wtot - S0;                    // frame f's row: (uoff + f) -- the window starts at frame S0
+        ext[2 * u] = T; ext[2 * u + 1] = S;
+        searched += S - S0;
+        wtot += (size_t)keep + n_new[u];
+    }
+    off1[n] = (int32_t)total; uoff[n] = 0;
+    PSGPU_REQUIRE(wtot <= d->win_rows, "psgpu_decode_streams_step: %zu rows exceed the window buffer (%zu)", wtot, d->win_rows);
+    PSGPU_REQUIRE(total == 0 || feat, "psgpu_decode_streams_step: NULL features");
+    PSGPU_HIP(hipMemcpyAsync(d->d_ls, h.data(), 4 * h.size(), hipMemcpyHostToDevice, st));
+    if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * d->veclen, hipMemcpyHostToDevice, st));
+    PSGPU_HIP(hipStreamSynchronize(st));                 // (feat is the caller's)
+    const int32_t *const d_off1 = d->d_ls, *const d_uoff = d->d_ls + n + 1, *const d_ext = d_uoff + n + 1, *const d_map = d_ext + 2 * n;
+    const size_t per = (size_t)std::max(1, d->n_chain * d->topn);
+    if (total) {
+        if (d->kind == PSGPU_SCORER_PTM) {
+            const uint8_t *const seed_in = d->d_sseed[d->ls_cur];
+            uint8_t *const seed_out = d->d_sseed[d->ls_cur ^ 1];
+            if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d_off1, n, (int32_t)total, seed_in, seed_out, d->d_tsc, d->d_tcw, d->d_rows,
+                                                d->d_best, d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st)))
+                return rc;
+            hipLaunchKernelGGL(dec_seed_keep_kernel, dim3((unsigned)n), dim3(64), 0, st, d_off1, n, (int32_t)per, seed_in, seed_out);
+            PSGPU_HIP(hipGetLastError());
+            d->ls_cur ^= 1;
+        }
+        else
+            rc = d->compall ? psgpu_ms_score_batch_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st)
+                            : psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st);
+        if (rc) return rc;
+        if ((rc = psgpu_phone_loop_run_carry_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->raw_flag == 3 ? nullptr : d->d_ci,
+                                                 d->raw_flag == 3 ? 0 : d->cfg.n_ci_list, d->d_rows, d->n_sen, nullptr, d_off1, n, (int32_t)total,
+                                                 d->d_pen, d->d_splc, 1, st)))
+            return rc;
+    }
+    // the windows: what the search has not reached yet + the step's rows, into the other window buffer
+    const int wo = d->ls_wcur, wn = wo ^ 1;
+    const int32_t max_rows = d->ls_step + lag + 1;
+    hipLaunchKernelGGL(dec_window_kernel, dim3((unsigned)((size_t)n * max_rows)), dim3(256), 0, st, d_map, n, max_rows, d->n_sen / 2, d->n_ci,
+                       reinterpret_cast<const uint32_t *>(d->d_win[wo]), reinterpret_cast<const uint32_t *>(d->d_rows),
+                       reinterpret_cast<uint32_t *>(d->d_win[wn]), d->d_wpen[wo], d->d_pen, d->d_wpen[wn]);
+    PSGPU_HIP(hipGetLastError());
+    d->ls_wcur = wn;
+    // the searches go on (a stream that starts afresh: its saved state was invalidated by psgpu_decode_streams_restart)
+    if ((rc = psgpu_fwdtree_hyp_out(d->cfg.ft, d->d_hyp, d->d_hn, d->max_words))) return rc;
+    if ((rc = psgpu_fwdtree_search_lag(d->cfg.ft, 0))) return rc;
+    if ((rc = psgpu_fwdtree_search_streams(d->cfg.ft, d_ext))) return rc;
+    if ((rc = psgpu_fwdtree_search_resume(d->cfg.ft, PSGPU_SEARCH_KEEP | (d->ls_first ? 0 : PSGPU_SEARCH_RESUME)))) return rc;
+    if ((rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_win[wn], d->n_sen, d->d_wpen[wn], d_uoff, n, d->ls_cap, d->bp_cap, d->bss_cap,
+                                               d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, d->raw_flag, d->cfg.pl_window, d->d_w1,
+                                               nullptr, nullptr, st)))
+        return rc;
+    d->ls_first = false; d->searched = true; d->pass2 = false; d->last_lag = 0; d->last_chained = false; d->last_sess = false;
+    d->ls_searched += searched;
+    size_t acc = 0;
+    for (int u = 0; u < n; ++u) {
+        d->ls_wbase[u] = d->ls_S[u]; d->ls_woff[u] = map[5 * u + 4];
+        d->ls_T[u] = ext[2 * u]; d->ls_S[u] = ext[2 * u + 1]; d->ls_fresh[u] = 0;
+        d->frame_off[u] = (int32_t)acc; acc += (size_t)d->ls_T[u];
+    }
+    d->frame_off[n] = (int32_t)acc; d->total = (int32_t)std::min<size_t>(acc, 0x7fffffff);
+    return PSGPU_OK;
+}
 
 int psgpu_decode_stage_timing(psgpu_decode_t *d, int32_t enable)
 {
@@ -850,7 +1046,8 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
         int rc = psgpu_ms_batch_check((psgpu_ms_model_t *)d->cfg.scorer, st);
         if (rc != PSGPU_OK) return rc;
     }
-    if (nu && d->auto_grow && d->searched && !d->pass2) {
+    // (streams: a full table ends its stream with status 1 -- the rows of frames already searched are gone, the search cannot be repeated)
+    if (nu && d->auto_grow && d->searched && !d->pass2 && !d->streams) {
         std::vector<int32_t> res(nu * 8);
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
         // (the usual case -- no table was full -- in one wait: the hypotheses travel with the result records)

@@ -245,6 +245,7 @@ struct PlDev {
 };
 
 constexpr int kPlMaxWindow = 32;
+constexpr int kPlCarryMagic = 0x5ea4c4ed;
 constexpr int kPlCarryWords = 64 * 8 + kPlMaxWindow * 64 + 8;     // psgpu_phone_loop_run_carry_dev: an utterance's state between calls
 
 // DPP wave maximum (same sequence as psgpu_ptm_dev.h): ~20 cycles instead of six
@@ -412,7 +413,8 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
     // numbered from `base` = the frames of the calls before
     int32_t *const carry = carry_all ? carry_all + (size_t)u * kPlCarryWords : nullptr;
     int base = 0;
-    if (carry && resume) {
+    // (its last word but four: the block holds a state -- zeroed by the caller for an utterance that starts afresh among resumed ones)
+    if (carry && resume && carry[64 * 8 + kPlMaxWindow * 64 + 3] == kPlCarryMagic) {
         const int32_t *const cs = carry + lane * 8;
 #pragma unroll
         for (int i = 0; i < NE; ++i) h.score[i] = cs[i];
@@ -485,7 +487,7 @@ void phone_loop_kernel(PlDev p, const uint8_t *__restrict__ tp_g, const int16_t 
         for (int i = 0; i < NE; ++i) cs[i] = h.score[i];
         cs[5] = h.out_score; cs[6] = h.bestscore; cs[7] = frame;
         for (int w = 0; w < p.window; ++w) carry[64 * 8 + w * 64 + lane] = s_ring[w][lane];
-        if (lane == 0) { carry[64 * 8 + kPlMaxWindow * 64] = ptr; carry[64 * 8 + kPlMaxWindow * 64 + 1] = best_score; carry[64 * 8 + kPlMaxWindow * 64 + 2] = base + T; }
+        if (lane == 0) { carry[64 * 8 + kPlMaxWindow * 64] = ptr; carry[64 * 8 + kPlMaxWindow * 64 + 1] = best_score; carry[64 * 8 + kPlMaxWindow * 64 + 2] = base + T; carry[64 * 8 + kPlMaxWindow * 64 + 3] = kPlCarryMagic; }
     }
 }
 
@@ -606,6 +608,13 @@ int psgpu_phone_loop_run_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t
 }
 
 int32_t psgpu_phone_loop_carry_words(void) { return kPlCarryWords; }
+
+int psgpu_phone_loop_carry_restart(int32_t *carry_dev, int32_t u, void *stream)
+{
+    PSGPU_REQUIRE(carry_dev && u >= 0, "psgpu_phone_loop_carry_restart: bad argument");
+    PSGPU_HIP(hipMemsetAsync(carry_dev + (size_t)u * kPlCarryWords + 64 * 8 + kPlMaxWindow * 64 + 3, 0, sizeof(int32_t), (hipStream_t)stream));
+    return PSGPU_OK;
+}
 
 int psgpu_phone_loop_run_carry_dev(psgpu_hmm_ctx_t *c, const psgpu_phone_loop_params_t *pp, const uint16_t *ssid_dev,
                                    const int16_t *tmatid_dev, const uint16_t *ci_list_dev, int32_t n_list,

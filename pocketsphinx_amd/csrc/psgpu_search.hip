@@ -63,6 +63,7 @@ constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
 constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (32 KB)
 constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS
+constexpr int kFtLiveMagic = 0x5ea4c4ed;
 constexpr int kFtLiveHdr = 32;         // FtBufs::live: words ahead of the pool's copy
 constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
 
@@ -151,6 +152,10 @@ struct FtBufs {
     // stay where they are between the calls
     int32_t *live;
     int32_t live_mode;                   // bit 0: save the state when the call stops; bit 1: start from the saved state
+    // psgpu_fwdtree_search_streams: per utterance {frames scored so far, frame the search goes on to} instead of back-to-back offsets
+    // and one lag: utterances in progress that grow at their own pace; utt_off [u] alone places the utterance's rows (row of frame f
+    // at (utt_off[u] + f) * stride: a caller that keeps only the frames not yet searched passes a start before its buffer)
+    const int32_t *ext;
 };
 
 struct psgpu_fwdtree_s {
@@ -166,6 +171,7 @@ struct psgpu_fwdtree_s {
     int32_t hyp_max_words = 0;
     int32_t lag_next = 0;                // psgpu_fwdtree_search_lag: for the NEXT search call only
     // psgpu_fwdtree_search_resume
+    const int32_t *ext_next = nullptr;   // psgpu_fwdtree_search_streams: the NEXT search call's FtBufs::ext
     int32_t live_next = 0;               // the NEXT search call's FtBufs::live_mode
     int32_t *live = nullptr;             // FtBufs::live, kept between calls
     size_t live_words = 0;
@@ -982,14 +988,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // over the last pl_window frames only `if (output_frame >= pl_window)` (pocketsphinx.c:1329-1333)
     // (bf.lag > 0: an utterance in progress -- the phone loop has seen T_in frames, the search steps through the first
     //  T_in - lag of them, as ps_search_forward leaves the two between calls, pocketsphinx.c:1173-1197)
-    const int t0 = utt_off[blockIdx.x], T_in = utt_off[blockIdx.x + 1] - t0,
-              T = bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in);
+    const int32_t *const ext = bf.ext ? psgpu_as_global(bf.ext) + 2 * (size_t)blockIdx.x : nullptr;
+    const int t0 = utt_off[blockIdx.x], T_in = ext ? ext[0] : utt_off[blockIdx.x + 1] - t0,
+              T = ext ? min(ext[1], T_in) : (bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in));
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
     // psgpu_fwdtree_search_resume: the utterance's saved state; f0 = the frames searched by the calls before
     // (slab layouts: everything the frames share is in the utterance's slab -- which stays where it is between the calls -- but the
     //  counters and the carried registers)
     int32_t *const live = bf.live ? psgpu_as_global(bf.live) + (size_t)blockIdx.x * (kFtLiveHdr + (SMALL ? L.rows_total : 0)) : nullptr;
-    const bool resumed = live != nullptr && (bf.live_mode & 2) != 0;
+    // (word 16: the block holds a saved search -- zeroed by the caller for an utterance that starts afresh among resumed ones)
+    const bool resumed = live != nullptr && (bf.live_mode & 2) != 0 && live[16] == kFtLiveMagic;
     const int f0 = resumed ? live[0] : 0;
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
     uint32_t evals_run = 0u;                             // HMM evaluations so far (ngs->st.n_hmm_eval; saturating: compared with maxhmmpf), likewise
@@ -1081,7 +1089,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             l_cw[tid] = pcw;
         }
     };
-    if (SMALL && f0 < T) {                                // the first frame's scores and penalties (f0 & 1: the penalty rows take turns)
+    // (a resumed search that has failed -- its best score at the floor -- stops at its first frame below and reads nothing)
+    if (SMALL && f0 < T && !(resumed && live[8] <= kW)) {   // the first frame's scores and penalties (f0 & 1: the penalty rows take turns)
         if (lists) {
             const uint8_t *const la = psgpu_as_global(bf.la);
             for (int i = tid; i < 512; i += NT) l_la[i] = i < bf.ls_la_size ? la[i] : 0;
@@ -1118,12 +1127,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // raw mode: the phone loop runs pl_window frames ahead and stops at the last frame
         // (slab layouts: the frame's penalty row is copied to LDS here -- its last readers, the previous frame's word
         //  transitions, are behind a barrier; its first reader, the pruning, is behind the barriers below)
-        if (!SMALL && p.has_pl && tid < n_ci) s_penb[tid] = penalties[(size_t)pen_frame(f) * n_ci + tid];
+        if (!SMALL && p.has_pl && tid < n_ci && s_sc[0] > kW) s_penb[tid] = penalties[(size_t)pen_frame(f) * n_ci + tid];
         const int32_t *const pp = SMALL ? s_pen + cur * n_ci : s_penb;
         constexpr bool ROW_LDS = SMALL && (LISTS || !kFtRowsDevice);          // the frame's row is in LDS (slab layouts: s_rowb, copied below)
         constexpr bool kSlabRowLds = true;                   // (the slab layouts' row in LDS: +3 % on the 134,865-word task)
         const int16_t *const row = ROW_LDS ? s_row : ((SMALL || !kSlabRowLds) ? senscr + (size_t)(t0 + f) * scr_stride : s_rowb);
-        if (!SMALL && kSlabRowLds) {
+        if (!SMALL && kSlabRowLds && s_sc[0] > kW) {          // (a search that has failed stops below and reads no row)
             // (its last readers, the previous frame's evaluation, are behind barriers; its first readers -- the senone marks
             //  below read the row for the normaliser -- are behind the barrier that follows)
             const int16_t *const g = senscr + (size_t)(t0 + f) * scr_stride;
@@ -2305,6 +2314,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) {
             live[0] = s_sc[7]; live[1] = n_acl_cur; live[2] = n_awl_cur; live[3] = (int32_t)evals_run; live[4] = nwc_cur;
             live[5] = (int32_t)(s_evals & 0xffffffffull); live[6] = (int32_t)(s_evals >> 32); live[7] = s_nsen;
+            live[16] = kFtLiveMagic;
         }
     }
     {   // the table in the caller's columns (bptbl_t, ngram_search.h:112-124): ft_table_out
@@ -2789,6 +2799,7 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     m->hyp_out = nullptr; m->hyp_n_out = nullptr; m->hyp_max_words = 0;      // (one call's worth)
     bf.lag = m->lag_next; m->lag_next = 0;
     // psgpu_fwdtree_search_resume (one call's worth, like the lag)
+    bf.ext = m->ext_next; m->ext_next = nullptr;
     bf.live = nullptr; bf.live_mode = m->live_next; m->live_next = 0;
     if (bf.live_mode) {
         if (bf.live_mode & 2)
@@ -2864,6 +2875,21 @@ int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag)
 {
     PSGPU_REQUIRE(m && lag >= 0, "psgpu_fwdtree_search_lag: bad argument");
     m->lag_next = lag;
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_search_streams(psgpu_fwdtree_t *m, const int32_t *ext_dev)
+{
+    PSGPU_REQUIRE(m, "psgpu_fwdtree_search_streams: NULL argument");
+    m->ext_next = ext_dev;
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_search_restart(psgpu_fwdtree_t *m, int32_t u, void *stream)
+{
+    PSGPU_REQUIRE(m && m->live_valid && u >= 0 && u < m->live_n_utt, "psgpu_fwdtree_search_restart: no saved search for that utterance");
+    const size_t per = (size_t)(kFtLiveHdr + (m->live_small ? m->d.lay.rows_total : 0));
+    PSGPU_HIP(hipMemsetAsync(m->live + (size_t)u * per + 16, 0, sizeof(int32_t), (hipStream_t)stream));
     return PSGPU_OK;
 }
 

@@ -225,6 +225,31 @@ class DecodePipeline:
         capi.check(capi.lib().psgpu_decode_live_step(self.h, feats.ctypes.data_as(C.c_void_p) if n else None, n, int(lag), self._stream),
                    "psgpu_decode_live_step")
 
+    def streams_begin(self, n_streams, max_frames, max_step_frames, stream=None):
+        """psgpu_decode_streams_begin: n_streams utterances in progress at once (new decoders), each growing at its own pace"""
+        import torch
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        self.n_utt = int(n_streams)
+        self._stream = st
+        capi.check(capi.lib().psgpu_decode_streams_begin(self.h, int(n_streams), int(max_frames), int(max_step_frames), st),
+                   "psgpu_decode_streams_begin")
+
+    def streams_step(self, feats, final=None):
+        """psgpu_decode_streams_step: feats = one [n_new][veclen] float32 array per stream (empty: nothing this step); final = per stream
+        whether its utterance ends with these frames.  fetch() / tables() afterwards: every stream's results as they stand."""
+        n = self.n_utt
+        assert len(feats) == n
+        cnt = np.array([int(f.shape[0]) if f is not None and f.ndim == 2 else 0 for f in feats], np.int32)
+        parts = [np.ascontiguousarray(f, np.float32) for f, c in zip(feats, cnt) if c]
+        allf = np.concatenate(parts) if parts else np.zeros((0, 1), np.float32)
+        fin = np.zeros(n, np.uint8) if final is None else np.array([1 if x else 0 for x in final], np.uint8)
+        capi.check(capi.lib().psgpu_decode_streams_step(self.h, allf.ctypes.data_as(C.c_void_p) if parts else None,
+                                                        cnt.ctypes.data_as(C.c_void_p), fin.ctypes.data_as(C.c_void_p), self._stream),
+                   "psgpu_decode_streams_step")
+
+    def streams_restart(self, u):
+        capi.check(capi.lib().psgpu_decode_streams_restart(self.h, int(u), self._stream), "psgpu_decode_streams_restart")
+
     def live_frames_searched(self):
         f = capi.lib().psgpu_decode_live_frames_searched
         f.restype = C.c_int64

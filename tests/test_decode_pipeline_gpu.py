@@ -319,3 +319,86 @@ def test_live_utterance_hands_the_session_on(tables):
     r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
     _check(r, g, "second of the session, after a live first")
     p.close()
+
+
+def _fresh_feats(name):
+    """the recording's 1s_c_d_dd feature vectors as a NEW decoder computes them (device front end + features: bit-exact with the
+    reference's, tests/test_fe_gpu.py / test_feat_gpu.py)"""
+    import pocketsphinx_amd as P
+    clips = _load("speech_clips.npz")
+    fe = P.FrontEnd(_load("mfcc_en_us_goforward.npz"))
+    cep, _ = fe.process_utts([clips[name]])
+    fe.close()
+    return P.dynfeat_1s_c_d_dd(cep, [cep.shape[0]])
+
+
+def test_streams_many_utterances_in_progress(tables):
+    """psgpu_decode_streams_*: four streams -- a batch of live decoders -- fed at different paces (7-frame pieces, 40-frame pieces, one
+    that starts late, one shorter than the look-ahead window that is never searched), one launch set a step.  In mid-utterance every
+    stream's search stands pl_window frames behind its frames, as ps_search_forward keeps it; when a stream's utterance ends its tables
+    are the reference decoder's for that recording; a stream restarted with another recording decodes that one; and the searches stepped
+    through every frame once."""
+    import pocketsphinx_amd as P
+    p = _pipeline(tables)
+    gs = {n: _load("fwdtree_trace_%s.npz" % n) for n in ("goforward", "numbers")}
+    fs = {n: _fresh_feats(n) for n in gs}
+    W = int(gs["goforward"]["pl_par"][5])
+    vl = fs["goforward"].shape[1]
+    names = ["goforward", "numbers", "goforward", None]
+    piece = [7, 40, 23, 0]
+    start = [0, 0, 6, 0]                                   # the step a stream's first frames come in
+    p.streams_begin(4, 420, 40)
+    pos = [0, 0, 0, 0]; done = [False] * 4
+    short = fs["numbers"][:W - 1]                          # stream 3: W - 1 frames in the first step, final in the second
+    total = 0
+    for step in range(200):
+        feats, fin = [], []
+        for u in range(4):
+            if u == 3:
+                feats.append(short if step == 0 else np.zeros((0, vl), np.float32)); fin.append(step == 1)
+                continue
+            f = fs[names[u]]
+            k = 0 if (step < start[u] or done[u]) else min(piece[u] + (step % 3 if u == 0 else 0), f.shape[0] - pos[u])
+            feats.append(f[pos[u]:pos[u] + k]); pos[u] += k
+            fin.append(k > 0 and pos[u] == f.shape[0])
+        p.streams_step(feats, fin)
+        hn, hyp, res = p.fetch()
+        assert not res[:, 3].any(), res
+        for u in range(3):
+            T = fs[names[u]].shape[0]
+            if fin[u]:
+                done[u] = True
+                g = gs[names[u]]
+                r = p.tables(u, res)
+                r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+                _check(r, g, "stream %d (%s) at its end, step %d" % (u, names[u], step))
+                assert int(hn[u, 1]) == int(g["hyp_score"][0])
+                total += T
+            elif not done[u]:
+                assert int(res[u, 2]) == max(pos[u] - W, 0), (u, step, res[u], pos[u])
+                if pos[u] > W:                             # the tables of a stream in mid-utterance: the golden's up to that frame
+                    g = gs[names[u]]; n = pos[u] - W
+                    r = p.tables(u, res)
+                    assert np.array_equal(r["bp_table_idx"][:n], g["bp_table_idx"][:n]) and np.array_equal(r["bp"], g["bp"][:r["bp"].shape[0]])
+        if step >= 1:
+            assert int(res[3, 2]) == 0 and int(hn[3, 0]) == 0          # (shorter than the look-ahead window: never searched)
+        if all(done[:3]):
+            break
+    assert all(done[:3])
+    assert p.live_frames_searched() == total
+    # stream 1 again, with the other recording; the others idle
+    p.streams_restart(1)
+    f, g = fs["goforward"], gs["goforward"]
+    at = 0
+    while at < f.shape[0]:
+        k = min(33, f.shape[0] - at)
+        p.streams_step([None, f[at:at + k], None, None], [False, at + k == f.shape[0], False, False])
+        at += k
+    hn, hyp, res = p.fetch()
+    r = p.tables(1, res)
+    r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+    _check(r, g, "stream 1 restarted")
+    r0 = p.tables(0, res)                                  # (an idle stream keeps its results)
+    assert np.array_equal(r0["bp"], g["bp"])
+    assert p.live_frames_searched() == total + f.shape[0]
+    p.close()
