@@ -439,6 +439,9 @@ def child_extras(out):
         child("search_only_cmudict", [sb], {"SB_CASE": "cmudict", "SB_BATCHES": "1,32,256", "SB_REPS": "1"}, 200)
     child("device_decode_two_pass", [os.path.join(ROOT, "tools", "two_pass_bench.py")], {"TP_B": "256"}, 120)
     child("decode_three_pass", [os.path.join(ROOT, "tools", "three_pass_bench.py")], {}, 200)
+    # a batch of live decoders: the headline's 512 utterances IN PROGRESS at once, 100 ms of audio a stream a step (psgpu_decode_streams_*):
+    # frames/s over all streams and the time of a step = a piece's arrival to every stream's updated hypothesis on the host
+    child("live_streams", [os.path.join(ROOT, "tools", "streams_bench.py")], {"LS_STREAMS": "512", "LS_SEC": "30", "LS_CHUNK": "10"}, 120)
     from pocketsphinx_amd import largevocab as lv
     if lv.available(lv.table_path(directory=os.environ.get("PSGPU_TABLE_DIR"))):
         # configs[2]'s shape: ONE 60 s utterance, en-us PTM + the large LM / dictionary (en-us.lm.bin is not in the repository: big.arpa
