@@ -875,6 +875,10 @@ int psgpu_decode_search_lag(psgpu_decode_t *d, int32_t lag);
  *   psgpu_decode_live_frames_searched   frames the search kernel has stepped through since live_begin, summed over the steps: the
  *                             utterance's frames searched so far when every frame was searched once. */
 int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream);
+/* the live utterance outgrew its capacity: it begins again with room for max_frames frames, from the session state it began with the
+ * first time (which the steps so far have moved on); the caller feeds its frames again from the first one.
+ * psgpu_decode_live_frames_searched keeps counting. */
+int psgpu_decode_live_restart(psgpu_decode_t *d, int32_t max_frames, void *stream);
 int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, int32_t lag, void *stream);
 int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d);
 /* ---- MANY utterances in progress: a batch of live decoders (the serving shape of ps_process_raw called chunk by chunk on many

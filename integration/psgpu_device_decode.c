@@ -72,7 +72,7 @@ struct psgpu_device_decode_s {
      * refused (then every read-out decodes the prefix again, as before) */
     int live_on, live_fed, live_cap, live_off;
     int inj_nb, inj_nh, inj_nfr;       /* what the latest read-out of the live utterance put into the decoder's tables */
-    long live_steps, live_restarts, live_frames_before;    /* (live_frames_before: searched before the latest restart) */
+    long live_steps, live_restarts;
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
     psgpu_ptm_view_t view;
@@ -515,7 +515,7 @@ dev_search_start(ps_search_t *search)
     psgpu_device_decode_t *d = find_attached(search);
     if (d == NULL) return -1;
     d->n_feat = 0; d->pl_frames = 0; d->n_partial = -1;
-    d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0; d->live_frames_before = 0;
+    d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0;
     d->inj_nb = d->inj_nh = d->inj_nfr = 0;
     return d->orig_vt->start(search);          /* ngram_search_start: tables, timers, <s> entered (ngram_search_fwdtree.c:469-520) */
 }
@@ -682,8 +682,8 @@ live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final)
         while (cap < T) cap *= 2;
         if (refresh(d) < 0) return -1;
         if (!d->live_on && session_push(d, ngs) < 0) return -1;  /* (a restart begins from the same session state: the pipeline kept it) */
-        if (d->live_on) { ++d->live_restarts; d->live_frames_before += (long)psgpu_decode_live_frames_searched(d->dec); }
-        if (psgpu_decode_live_begin(d->dec, cap, st) != PSGPU_OK) {
+        if (d->live_on) ++d->live_restarts;
+        if ((d->live_on ? psgpu_decode_live_restart(d->dec, cap, st) : psgpu_decode_live_begin(d->dec, cap, st)) != PSGPU_OK) {
             E_INFO("psgpu device search: no live utterance on the device (%s); results in mid-utterance decode the frames so far\n", psgpu_last_error());
             d->live_off = 1; d->live_on = 0;
             return 0;
@@ -777,7 +777,7 @@ dev_search_seg_iter(ps_search_t *search)
 void
 psgpu_device_search_live_stats(psgpu_device_decode_t *d, long *frames_searched, long *steps, long *restarts)
 {
-    if (frames_searched) *frames_searched = d ? d->live_frames_before + (d->live_on ? (long)psgpu_decode_live_frames_searched(d->dec) : 0) : 0;
+    if (frames_searched) *frames_searched = d ? (long)psgpu_decode_live_frames_searched(d->dec) : 0;
     if (steps) *steps = d ? d->live_steps : 0;
     if (restarts) *restarts = d ? d->live_restarts : 0;
 }

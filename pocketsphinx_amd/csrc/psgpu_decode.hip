@@ -83,6 +83,8 @@ struct psgpu_decode_s {
     int32_t live_cap = 0, live_T = 0, live_S = 0, live_mode_next = 0;
     int64_t live_searched = 0;
     uint8_t *d_lseed[2] = { nullptr, nullptr };
+    uint8_t *d_seed0 = nullptr;          // the session's seed as the live utterance found it (psgpu_decode_live_restart puts it back)
+    bool seed0_valid = false;
     int32_t lseed_cur = 0;
     int32_t *d_pl_carry = nullptr, *d_off1 = nullptr;
     // psgpu_decode_streams_*: MANY utterances in progress, each growing at its own pace (a batch of live decoders).  Per stream the
@@ -233,7 +235,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
     DFREE(d->d_bp2); DFREE(d->d_bss2); DFREE(d->d_idx2); DFREE(d->d_step2); DFREE(d->d_res2); DFREE(d->d_seed2);
     DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
-    DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_pl_carry); DFREE(d->d_off1);
+    DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_seed0); DFREE(d->d_pl_carry); DFREE(d->d_off1);
     DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
     DFREE(d->d_splc);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
@@ -676,25 +678,52 @@ static int dec_live_mode(psgpu_decode_s *d, bool resume)
     return PSGPU_SEARCH_KEEP | (resume ? PSGPU_SEARCH_RESUME : 0);
 }
 
+static int dec_live_begin(psgpu_decode_s *d, int32_t max_frames, bool again, hipStream_t st);
+
 int psgpu_decode_live_begin(psgpu_decode_t *d, int32_t max_frames, void *stream)
+{
+    return dec_live_begin(d, max_frames, false, (hipStream_t)stream);
+}
+
+// The utterance in progress begins AGAIN -- with room for max_frames frames; the caller feeds its frames from the first one -- from the
+// session state it began with the first time: the seed lists and the multiplexed channels' ssids, both of which the steps so far have
+// moved on (the seed slot follows the frames scored, the ssids are written back by every search).
+int psgpu_decode_live_restart(psgpu_decode_t *d, int32_t max_frames, void *stream)
+{
+    PSGPU_REQUIRE(d && d->live && !d->streams, "psgpu_decode_live_restart: no live utterance (psgpu_decode_live_begin)");
+    return dec_live_begin(d, max_frames, true, (hipStream_t)stream);
+}
+
+static int dec_live_begin(psgpu_decode_s *d, int32_t max_frames, bool again, hipStream_t st)
 {
     PSGPU_REQUIRE(d && max_frames > 0, "psgpu_decode_live_begin: bad argument");
     PSGPU_REQUIRE(d->session, "psgpu_decode_live_begin: a live utterance is one decoder's (psgpu_decode_session first)");
     PSGPU_REQUIRE(!d->want_lists, "psgpu_decode_live_begin: a live utterance keeps its score rows (not with psgpu_decode_score_mode lists)");
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     d->lists = false;                                    // (PSGPU_DECODE_LISTS: not for a live utterance; the next batch call picks its mode again)
     if ((rc = dec_session_buffers(d))) return rc;
     if ((rc = dec_grow(d, 1, (size_t)max_frames, (size_t)max_frames, st))) return rc;
     if (!d->d_pl_carry) {
-        if ((rc = dec_alloc((void **)&d->d_lseed[0], (size_t)std::max(1, d->n_chain * d->topn)))
+        if ((rc = dec_alloc((void **)&d->d_seed0, (size_t)std::max(1, d->n_chain * d->topn)))
+            || (rc = dec_alloc((void **)&d->d_lseed[0], (size_t)std::max(1, d->n_chain * d->topn)))
             || (rc = dec_alloc((void **)&d->d_lseed[1], (size_t)std::max(1, d->n_chain * d->topn)))
             || (rc = dec_alloc((void **)&d->d_off1, 8)) || (rc = dec_alloc((void **)&d->d_pl_carry, 4 * (size_t)psgpu_phone_loop_carry_words())))
             return rc;
     }
     d->streams = false;
-    d->live = true; d->live_ok = false; d->live_cap = max_frames; d->live_T = 0; d->live_S = 0; d->live_searched = 0; d->live_mode_next = 0;
-    d->live_chained = d->sess_started; d->live_mpx_copied = false; d->lseed_cur = 0;
+    const size_t seed_bytes = (size_t)std::max(1, d->n_chain * d->topn);
+    if (!again) {
+        d->live_chained = d->sess_started; d->live_mpx_copied = false; d->live_searched = 0;
+        d->seed0_valid = d->seed_valid;
+        if (d->seed_valid) PSGPU_HIP(hipMemcpyAsync(d->d_seed0, d->d_seed, seed_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    else {
+        // (live_chained, and d_mpx_in once the first search has copied it, still hold what the utterance began from)
+        d->seed_valid = d->seed0_valid;
+        if (d->seed0_valid) PSGPU_HIP(hipMemcpyAsync(d->d_seed, d->d_seed0, seed_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    d->live = true; d->live_ok = false; d->live_cap = max_frames; d->live_T = 0; d->live_S = 0; d->live_mode_next = 0;
+    d->lseed_cur = 0;
     d->n_utt = 1; d->total = 0; d->max_frames = max_frames; d->searched = false; d->pass2 = false; d->first_called = true;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     d->frame_off.assign(2, 0);

@@ -217,6 +217,10 @@ class DecodePipeline:
         self._stream = st
         capi.check(capi.lib().psgpu_decode_live_begin(self.h, int(max_frames), st), "psgpu_decode_live_begin")
 
+    def live_restart(self, max_frames):
+        """psgpu_decode_live_restart: the live utterance begins again with a larger capacity (its frames are fed again)"""
+        capi.check(capi.lib().psgpu_decode_live_restart(self.h, int(max_frames), self._stream), "psgpu_decode_live_restart")
+
     def live_step(self, feats, lag):
         """psgpu_decode_live_step: feats [n_new][veclen] float32 more frames (may be empty); the search goes on up to `lag` frames
         short of the frames so far (0: to the utterance's end).  fetch() / tables() as after a run_feat of the frames so far."""

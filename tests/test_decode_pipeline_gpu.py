@@ -402,3 +402,28 @@ def test_streams_many_utterances_in_progress(tables):
     assert np.array_equal(r0["bp"], g["bp"])
     assert p.live_frames_searched() == total + f.shape[0]
     p.close()
+
+
+def test_live_utterance_begun_again_with_more_room(tables):
+    """psgpu_decode_live_restart: the second utterance of a session outgrows the capacity it was begun with after 90 frames -- by then the
+    session's seed slot and the multiplexed channels' ssids have moved on with the utterance -- and is begun again with more room, its
+    frames fed from the first: it must start from the state the utterance BEGAN with (the reference decoder's tables for the second
+    utterance of that session, which differ from a new decoder's)."""
+    p = _pipeline(tables)
+    g1, g = _load("fwdtree_trace_numbers.npz"), _load("fwdtree_trace_goforward_after_numbers.npz")
+    f1, f2 = _session_feats(tables)
+    lag = int(g["pl_par"][5])
+    p.session(True)
+    p.run_feat(f1, [f1.shape[0]]); p.fetch()
+    p.live_begin(100)
+    p.live_step(f2[:40], lag); p.live_step(f2[40:90], lag)
+    with pytest.raises(Exception):
+        p.live_step(f2[90:140], lag)                       # (does not fit)
+    p.live_restart(400)
+    p.live_step(f2[:150], lag); p.live_step(f2[150:], 0)
+    _, _, res = p.fetch()
+    r = p.tables(0, res)
+    r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+    _check(r, g, "begun again")
+    assert p.live_frames_searched() == (90 - lag) + f2.shape[0]
+    p.close()
