@@ -339,6 +339,20 @@ int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, co
                                int32_t n_utt, int32_t total_frames, int16_t *senscr_dev, void *stream);
 int psgpu_semi_score_batch(psgpu_semi_model_t *m, const float *feats, const int32_t *utt_off, int32_t n_utt,
                            int16_t *senscr);
+/* ... with the top-N lists carried across calls, as s2_semi_mgau_frame_eval carries them from frame to frame and from an utterance's
+ * last frames to the next one's first (its ring topn_hist[n_topn_hist], n_topn_hist = pl_window + 2, s2_semi_mgau.c:853-860, :1301-1322):
+ *  seed_in_dev  [n_utt][n_feat][topn] uint8 codewords every utterance's first frame starts from (NULL: a new scorer's, codeword = rank)
+ *  seed_out_dev the lists of every utterance's last frame (the next call's seed_in when the utterance goes on; untouched for an
+ *               utterance without frames; NULL: not wanted)
+ *  slot_out_dev the lists of every utterance's last frame ts with (frame_base + ts) % n_hist == n_hist - 1 -- ring slot n_hist - 1,
+ *               which seeds the NEXT utterance's first frame; untouched when there is no such frame (NULL: not wanted)
+ *  frame_base_dev [n_utt] int32 frames of each utterance scored by earlier calls (frame numbers go on from there: the ring's
+ *               slots, the down-sampling rule -ds; NULL: 0).  The three list buffers must be distinct. */
+int psgpu_semi_score_batch_carry_dev(psgpu_semi_model_t *m, const float *feats_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                     int32_t total_frames, const uint8_t *seed_in_dev, uint8_t *seed_out_dev, uint8_t *slot_out_dev,
+                                     int32_t n_hist, const int32_t *frame_base_dev, int16_t *senscr_dev, void *stream);
+int32_t psgpu_semi_n_feat(const psgpu_semi_model_t *m);
+int32_t psgpu_semi_topn(const psgpu_semi_model_t *m);
 int32_t psgpu_semi_n_sen(const psgpu_semi_model_t *m);
 int32_t psgpu_semi_veclen(const psgpu_semi_model_t *m);    /* sum of featlen */
 int psgpu_semi_state_get_topn(psgpu_semi_state_t *s, int32_t slot, int32_t *cw, int32_t *score,

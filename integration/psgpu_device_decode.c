@@ -66,6 +66,7 @@ struct psgpu_device_decode_s {
     ps_searchfuncs_t vt, pl_vt;
     ps_searchfuncs_t *orig_vt, *orig_pl_vt;
     float *h_feat; int n_feat, cap_feat;
+    int pcm_ok;                        /* the feature configuration the device computes from PCM (1s_c_d_dd, batch CMN): the PCM entries work */
     int pl_frames, n_partial;          /* frames the phone loop has been stepped through; n_feat of the latest partial read-out */
     /* the utterance in progress as a LIVE utterance of the device pipeline (psgpu_decode_live_begin / _step): begun by the first
      * read-out in mid-utterance; live_fed frames handed over so far; live_cap the capacity it was begun with; live_off: the pipeline
@@ -114,6 +115,8 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     psgpu_decode_config_t cfg;
     psgpu_ptm_model_t *model;
     struct psgpu_ms_model_s *msmodel;
+    struct psgpu_semi_model_s *smodel;
+    int pcm_ok;
     int n_ci, n_emit, n_w, i, j, k, lm_ok, want_ff;
     int32 *lm;
     psgpu_fe_shim_t *fes;
@@ -126,28 +129,31 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     want_ff = ngs->fwdflat && getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS"));
     acmod = ps->acmod; mdef = acmod->mdef;
     n_ci = bin_mdef_n_ciphone(mdef); n_emit = bin_mdef_n_emit_state(mdef); n_w = dict_size(ps_search_dict(ngs));
-    if (strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->fcb->cmn != CMN_BATCH
-        || acmod->fcb->agc != AGC_NONE || acmod->fcb->varnorm) {
-        E_ERROR("psgpu device decode: needs the 1s_c_d_dd feature type with -cmn batch, no AGC / variance normalisation / LDA\n");
-        return NULL;
-    }
+    /* from PCM the device computes 1s_c_d_dd vectors with batch CMN (psgpu_fe, psgpu_feat); any other feature configuration is served
+     * through the ps_search_t binding alone, which takes the feature vectors the decoder's own acmod computes */
+    pcm_ok = !(strcmp(feat_name(acmod->fcb), "1s_c_d_dd") || acmod->fcb->lda || acmod->fcb->cmn != CMN_BATCH
+               || acmod->fcb->agc != AGC_NONE || acmod->fcb->varnorm);
     if (acmod->compallsen && want_ff) {
         E_ERROR("psgpu device decode: the device second pass normalises over its own senone lists (-compallsen no)\n");
         return NULL;
     }
     model = psgpu_mgau_ptm_model(acmod->mgau);
     msmodel = model ? NULL : psgpu_mgau_ms_model(acmod->mgau);
-    if (model == NULL && msmodel == NULL) {
-        E_ERROR("psgpu device decode: attach the psgpu scorer first (psgpu_mgau_attach: PTM or multi-stream model; the semi-continuous "
-                "scorer's history is not carried through the device pipeline)\n");
+    smodel = (model || msmodel) ? NULL : psgpu_mgau_semi_model(acmod->mgau);
+    if (model == NULL && msmodel == NULL && smodel == NULL) {
+        E_ERROR("psgpu device decode: attach the psgpu scorer first (psgpu_mgau_attach)\n");
         return NULL;
     }
-    if (msmodel && want_ff) { E_ERROR("psgpu device decode: the device second pass scores from the PTM scorer's lists\n"); return NULL; }
+    if (!model && want_ff) { E_ERROR("psgpu device decode: the device second pass scores from the PTM scorer's lists\n"); return NULL; }
     d = ckd_calloc(1, sizeof *d);
     d->ps = ps;
     d->n_ci = n_ci; d->n_sen = bin_mdef_n_sen(mdef);
-    d->n_chain = model ? psgpu_ptm_n_chain(model) : 0; d->topn = model ? psgpu_ptm_topn(model) : 0;     /* (ms: no lists to carry) */
-    d->cepsize = feat_cepsize(acmod->fcb); d->veclen = 3 * d->cepsize;
+    d->pcm_ok = pcm_ok;
+    /* the lists a session carries: per (codebook, stream) chain for PTM, per stream for s2_semi; ms: none */
+    d->n_chain = model ? psgpu_ptm_n_chain(model) : (smodel ? psgpu_semi_n_feat(smodel) : 0);
+    d->topn = model ? psgpu_ptm_topn(model) : (smodel ? psgpu_semi_topn(smodel) : 0);
+    d->cepsize = feat_cepsize(acmod->fcb);
+    for (d->veclen = 0, j = 0; j < feat_dimension1(acmod->fcb); ++j) d->veclen += feat_dimension2(acmod->fcb, j);
     d->n_words_at_attach = n_w; d->lmset_at_attach = ngs->lmset;
     /* ---- the search tables: the one flattener (psgpu_search_tables.c), which psgpu_export_tables.c writes to a file */
     st = psgpu_search_tables_collect(ps, want_ff);
@@ -184,7 +190,7 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         d->n1 = ngs->n_1ph_words; d->n_emit = n_emit;
     }
     if (i == PSGPU_OK) i = psgpu_hmm_ctx_create(&d->ctx, n_emit, st->n_tmat, st->tp, st->n_sseq, st->sseq, d->n_sen);
-    if (i == PSGPU_OK) {
+    if (i == PSGPU_OK && pcm_ok) {
         fes = psgpu_fe_wrap(acmod->fe);
         if (fes) d->fe = psgpu_fe_shim_release(fes); else i = PSGPU_EINVAL;
     }
@@ -207,13 +213,14 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
         }
         memset(&cfg, 0, sizeof cfg);
         cfg.fe = d->fe; cfg.model = model; cfg.ctx = d->ctx; cfg.ft = d->ft;
-        if (model == NULL) { cfg.scorer_kind = PSGPU_SCORER_MS; cfg.scorer = msmodel; }
+        if (msmodel) { cfg.scorer_kind = PSGPU_SCORER_MS; cfg.scorer = msmodel; }
+        else if (smodel) { cfg.scorer_kind = PSGPU_SCORER_SEMI; cfg.scorer = smodel; }
         cfg.pl.n_phones = pls->n_phones; cfg.pl.window = pls->window; cfg.pl.beam = pls->beam; cfg.pl.pbeam = pls->pbeam;
         cfg.pl.pip = pls->pip; cfg.pl.penalty_weight = pls->penalty_weight;
         cfg.pl_ssid = ps_ssid; cfg.pl_tmatid = ps_tm; cfg.ci_list = cil; cfg.n_ci_list = nl; cfg.pl_window = ps->pl_window;
         cfg.max_words = 0;
         i = psgpu_decode_create(&d->dec, &cfg);
-        if (i == PSGPU_OK && acmod->compallsen) i = psgpu_decode_compallsen(d->dec, 1);      /* -compallsen yes: rows over all senones */
+        if (i == PSGPU_OK && acmod->compallsen && !smodel) i = psgpu_decode_compallsen(d->dec, 1);      /* -compallsen yes: rows over all senones (s2_semi's are final anyway) */
         ckd_free(ps_ssid); ckd_free(cil); ckd_free(ps_tm); ckd_free(flags);
     }
     else if (i == PSGPU_OK) {
@@ -249,13 +256,14 @@ refresh(psgpu_device_decode_t *d)
     ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
     psgpu_ptm_model_t *model = psgpu_mgau_ptm_model(d->ps->acmod->mgau);
     struct psgpu_ms_model_s *msmodel = model ? NULL : psgpu_mgau_ms_model(d->ps->acmod->mgau);
-    if (model == NULL && msmodel == NULL) { E_ERROR("psgpu device decode: the psgpu scorer is no longer attached\n"); return -1; }
+    struct psgpu_semi_model_s *smodel = (model || msmodel) ? NULL : psgpu_mgau_semi_model(d->ps->acmod->mgau);
+    if (model == NULL && msmodel == NULL && smodel == NULL) { E_ERROR("psgpu device decode: the psgpu scorer is no longer attached\n"); return -1; }
     if (dict_size(ps_search_dict(ngs)) != d->n_words_at_attach || ngs->lmset != d->lmset_at_attach) {
         E_ERROR("psgpu device decode: the dictionary or the language model changed after attach (ps_add_word / ps_set_lm): "
                 "detach and attach again\n");
         return -1;
     }
-    if ((model ? psgpu_decode_set_model(d->dec, model) : psgpu_decode_set_scorer(d->dec, msmodel)) != PSGPU_OK
+    if ((model ? psgpu_decode_set_model(d->dec, model) : psgpu_decode_set_scorer(d->dec, msmodel ? (void *)msmodel : (void *)smodel)) != PSGPU_OK
         || (d->ff && psgpu_ptm_model_view(model, &d->view) != PSGPU_OK)) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
@@ -379,6 +387,7 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
                 "psgpu_device_search_attach + ps_decode_raw: the reference's second pass then runs on the host)\n");
         return -1;
     }
+    if (!d->pcm_ok) { E_ERROR("psgpu device decode: from PCM the device computes 1s_c_d_dd vectors with -cmn batch, no AGC / variance normalisation / LDA (psgpu_device_search_attach serves the others)\n"); return -1; }
     if (refresh(d) < 0) return -1;
     /* the reference's own start / end-of-utterance housekeeping, without any frame going through its search */
     if (ps_start_utt(ps) < 0) return -1;
@@ -400,6 +409,7 @@ int
 psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[], const size_t n[], int B)
 {
     if (d == NULL || B < 0 || (B > 0 && (!pcm || !n))) return -1;
+    if (!d->pcm_ok) { E_ERROR("psgpu device decode: from PCM the device computes 1s_c_d_dd vectors with -cmn batch, no AGC / variance normalisation / LDA (psgpu_device_search_attach serves the others)\n"); return -1; }
     if (((ngram_search_t *)d->ps->search)->fwdflat && !d->ff) {
         E_ERROR("psgpu device decode: -fwdflat yes needs the device second pass (PSGPU_DEVICE_SECOND_PASS=1 at attach: both passes of "
                 "the batch then run on the device), or -fwdflat no\n");

@@ -538,6 +538,17 @@ psgpu_mgau_seed_history(ps_mgau_t *ps, int slot, const int32 *cw)
     psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
     int32 *sc;
     int rc, n;
+    if (ps != NULL && ps->vt == &psgpu_semi_funcs && cw != NULL && slot >= 0 && slot < g->cpu_semi->n_topn_hist) {
+        /* the semi-continuous scorer's ring (topn_hist, s2_semi_mgau.c:853-860): the codewords a later frame starts from; their
+         * scores are re-derived by mgau_dist, the slot's own count (topn_hist_n) is read by nobody after its frame */
+        int32 *nu;
+        n = g->cpu_semi->g->n_feat * g->cpu_semi->max_topn;
+        sc = ckd_calloc(n, sizeof *sc); nu = ckd_calloc(g->cpu_semi->g->n_feat, sizeof *nu);
+        for (rc = 0; rc < g->cpu_semi->g->n_feat; ++rc) nu[rc] = g->cpu_semi->max_topn;
+        rc = psgpu_semi_state_set_topn(g->sstate, slot, cw, sc, nu);
+        ckd_free(sc); ckd_free(nu);
+        return rc == PSGPU_OK ? 0 : -1;
+    }
     if (ps == NULL || ps->vt != &psgpu_mgau_funcs || cw == NULL || slot < 0 || slot >= g->cpu->n_fast_hist)
         return -1;
     n = g->cpu->g->n_mgau * g->cpu->g->n_feat * g->cpu->max_topn;
@@ -556,6 +567,8 @@ psgpu_mgau_get_history(ps_mgau_t *ps, int slot, int32 *cw)
     psgpu_mgau_t *g = (psgpu_mgau_t *)ps;
     int32 *sc;
     int rc, n;
+    if (ps != NULL && ps->vt == &psgpu_semi_funcs && cw != NULL && slot >= 0 && slot < g->cpu_semi->n_topn_hist)
+        return psgpu_semi_state_get_topn(g->sstate, slot, cw, NULL, NULL) == PSGPU_OK ? 0 : -1;      /* [n_feat][topn] */
     if (ps == NULL || ps->vt != &psgpu_mgau_funcs || cw == NULL || slot < 0 || slot >= g->cpu->n_fast_hist)
         return -1;
     n = g->cpu->g->n_mgau * g->cpu->g->n_feat * g->cpu->max_topn;
@@ -591,6 +604,14 @@ psgpu_mgau_ptm_model(ps_mgau_t *ps)
     if (ps == NULL || ps->vt != &psgpu_mgau_funcs)
         return NULL;
     return ((psgpu_mgau_t *)ps)->model;
+}
+
+struct psgpu_semi_model_s *
+psgpu_mgau_semi_model(ps_mgau_t *ps)
+{
+    if (ps == NULL || ps->vt != &psgpu_semi_funcs)
+        return NULL;
+    return ((psgpu_mgau_t *)ps)->smodel;
 }
 
 struct psgpu_ms_model_s *

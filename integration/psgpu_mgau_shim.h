@@ -39,6 +39,8 @@ int psgpu_mgau_prefetch(ps_mgau_t *mgau, int frame, const int16_t **raw_dev, con
 int psgpu_mgau_mark_fresh(ps_mgau_t *mgau, int frame);
 /* the device model behind a wrapped PTM scorer, or NULL */
 struct psgpu_ptm_model_s *psgpu_mgau_ptm_model(ps_mgau_t *mgau);
+/* the device model behind a wrapped semi-continuous ("s2_semi") scorer, or NULL */
+struct psgpu_semi_model_s *psgpu_mgau_semi_model(ps_mgau_t *mgau);
 /* the device model behind a wrapped multi-stream ("ms") scorer, or NULL */
 struct psgpu_ms_model_s *psgpu_mgau_ms_model(ps_mgau_t *mgau);
 

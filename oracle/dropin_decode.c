@@ -222,6 +222,20 @@ decode(ps_decoder_t *ps, const int16 *pcm, size_t n, float32 **mfcs, int nfr, re
             ++res->n_partial;
         }
     }
+    else if (mfcs && g_chunk > 0 && !dev_fe) {
+        /* ... from cepstra: g_chunk FRAMES a piece (ps_process_cep without full_utt), a read-out after each */
+        int at = 0; size_t po = 0;
+        while (at < nfr) {
+            int k = nfr - at < g_chunk ? nfr - at : g_chunk;
+            int32 sc = 0;
+            const char *h;
+            ps_process_cep(ps, mfcs + at, k, FALSE, FALSE);
+            at += k;
+            h = ps_get_hyp(ps, &sc);
+            if (po + 512 < sizeof res->partial) po += snprintf(res->partial + po, sizeof res->partial - po, "%s|%d;", h ? h : "", sc);
+            ++res->n_partial;
+        }
+    }
     else if (mfcs)
         ps_process_cep(ps, mfcs, nfr, FALSE, TRUE);
     else if (dev_fe) {

@@ -38,6 +38,7 @@ struct psgpu_decode_s {
     // multiplexed channels (hmm_clear keeps them)
     bool session = false, sess_started = false, seed_valid = false, fe_fresh = true;
     uint8_t *d_seed = nullptr;
+    uint8_t *d_seed_tmp = nullptr;       // the semi-continuous scorer's slot carry-out of a call (copied to d_seed when the call wrote it)
     int32_t *d_mpx = nullptr;
     double *d_noise = nullptr;           // the front end's noise tracker (noise_stats_t: kept until ps_start_stream, not reset per utterance)
     int32_t *d_undef = nullptr;
@@ -199,6 +200,8 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg)
     else if (d->kind == PSGPU_SCORER_SEMI) {
         d->n_sen = psgpu_semi_n_sen((const psgpu_semi_model_t *)cfg->scorer); d->veclen = psgpu_semi_veclen((const psgpu_semi_model_t *)cfg->scorer);
         d->raw_flag = 3;                                 // final scores: nothing is subtracted (s2_semi_mgau.c:837-883)
+        // (its carried lists: one per stream -- the sizes the seed buffers follow)
+        d->n_chain = psgpu_semi_n_feat((const psgpu_semi_model_t *)cfg->scorer); d->topn = psgpu_semi_topn((const psgpu_semi_model_t *)cfg->scorer);
     }
     else {
         d->n_sen = psgpu_ms_n_sen((const psgpu_ms_model_t *)cfg->scorer); d->veclen = psgpu_ms_veclen((const psgpu_ms_model_t *)cfg->scorer);
@@ -234,7 +237,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
     DFREE(d->d_bp2); DFREE(d->d_bss2); DFREE(d->d_idx2); DFREE(d->d_step2); DFREE(d->d_res2); DFREE(d->d_seed2);
-    DFREE(d->d_seed); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
+    DFREE(d->d_seed); DFREE(d->d_seed_tmp); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
     DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_seed0); DFREE(d->d_pl_carry); DFREE(d->d_off1);
     DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
     DFREE(d->d_splc);
@@ -259,9 +262,6 @@ int psgpu_decode_score_mode(psgpu_decode_t *d, int32_t lists)
 int psgpu_decode_session(psgpu_decode_t *d, int32_t on)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_session: NULL argument");
-    PSGPU_REQUIRE(!on || d->kind != PSGPU_SCORER_SEMI,
-                  "psgpu_decode_session: the semi-continuous scorer's top-N history is not carried between calls (the PTM scorer's is; "
-                  "the ms scorer has none)");
     d->session = on != 0;
     d->sess_started = false; d->seed_valid = false; d->fe_fresh = true;
     return PSGPU_OK;
@@ -271,7 +271,7 @@ static int dec_session_buffers(psgpu_decode_s *d)
 {
     int rc;
     if (!d->d_seed) {
-        if ((rc = dec_alloc((void **)&d->d_seed, (size_t)d->n_chain * d->topn))
+        if ((rc = dec_alloc((void **)&d->d_seed, (size_t)d->n_chain * d->topn)) || (rc = dec_alloc((void **)&d->d_seed_tmp, (size_t)d->n_chain * d->topn))
             || (rc = dec_alloc((void **)&d->d_mpx, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))
             || (rc = dec_alloc((void **)&d->d_mpx_in, 4 * (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit))
             || (rc = dec_alloc((void **)&d->d_noise, 8 * 4 * 64)) || (rc = dec_alloc((void **)&d->d_undef, 4)))
@@ -455,8 +455,18 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
         rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d->d_off, n_utt, (int32_t)total, chained && d->seed_valid ? d->d_seed : nullptr,
                                        nullptr, d->d_tsc, d->d_tcw, d->lists ? nullptr : d->d_rows, d->lists ? nullptr : d->d_best,
                                        d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st);
-    else if (d->kind == PSGPU_SCORER_SEMI)               // every utterance from a new scorer's lists, frames numbered from 0
-        rc = psgpu_semi_score_batch_dev((psgpu_semi_model_t *)d->cfg.scorer, d->d_feat, d->d_off, n_utt, (int32_t)total, d->d_rows, st);
+    else if (d->kind == PSGPU_SCORER_SEMI) {
+        // every utterance from a new scorer's lists, frames numbered from 0 -- a session's next utterance from ring slot n_hist - 1 as
+        // the one before left it, like the PTM scorer's (s2_semi_mgau.c:853-860; n_topn_hist = pl_window + 2, :1301)
+        const int H = d->cfg.pl_window + 2;
+        rc = psgpu_semi_score_batch_carry_dev((psgpu_semi_model_t *)d->cfg.scorer, d->d_feat, d->d_off, n_utt, (int32_t)total,
+                                              chained && d->seed_valid ? d->d_seed : nullptr, nullptr, sess ? d->d_seed_tmp : nullptr, H, nullptr,
+                                              d->d_rows, st);
+        if (rc == PSGPU_OK && sess && (int)total >= H) {  // (a frame ts with ts % H == H - 1 exists: the slot was written)
+            PSGPU_HIP(hipMemcpyAsync(d->d_seed, d->d_seed_tmp, (size_t)d->n_chain * d->topn, hipMemcpyDeviceToDevice, st));
+            d->seed_valid = true;
+        }
+    }
     else                                                 // no time dependence: frames of all utterances back to back
         rc = d->compall ? psgpu_ms_score_batch_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st)
                         : psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, d->d_feat, (int32_t)total, d->d_ms_id, d->d_ms_dist, d->d_rows, st);
@@ -707,7 +717,7 @@ static int dec_live_begin(psgpu_decode_s *d, int32_t max_frames, bool again, hip
         if ((rc = dec_alloc((void **)&d->d_seed0, (size_t)std::max(1, d->n_chain * d->topn)))
             || (rc = dec_alloc((void **)&d->d_lseed[0], (size_t)std::max(1, d->n_chain * d->topn)))
             || (rc = dec_alloc((void **)&d->d_lseed[1], (size_t)std::max(1, d->n_chain * d->topn)))
-            || (rc = dec_alloc((void **)&d->d_off1, 8)) || (rc = dec_alloc((void **)&d->d_pl_carry, 4 * (size_t)psgpu_phone_loop_carry_words())))
+            || (rc = dec_alloc((void **)&d->d_off1, 16)) || (rc = dec_alloc((void **)&d->d_pl_carry, 4 * (size_t)psgpu_phone_loop_carry_words())))
             return rc;
     }
     d->streams = false;
@@ -744,8 +754,8 @@ int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, 
     int rc;
     const int t0 = d->live_T;
     if (n_new > 0) {
-        const int32_t off1[2] = { 0, n_new }, off[2] = { 0, t0 + n_new };
-        PSGPU_HIP(hipMemcpyAsync(d->d_off1, off1, 8, hipMemcpyHostToDevice, st));
+        const int32_t off1[3] = { 0, n_new, t0 }, off[2] = { 0, t0 + n_new };
+        PSGPU_HIP(hipMemcpyAsync(d->d_off1, off1, 12, hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipMemcpyAsync(d->d_off, off, 8, hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipMemcpyAsync(d->d_feat + (size_t)t0 * d->veclen, feat, 4 * (size_t)n_new * d->veclen, hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipStreamSynchronize(st));             // (feat and the offsets are the caller's / this frame's)
@@ -774,8 +784,19 @@ int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, 
             rc = d->compall ? psgpu_ms_score_batch_dev((psgpu_ms_model_t *)d->cfg.scorer, f, n_new, d->d_ms_id, d->d_ms_dist, rows, st)
                             : psgpu_ms_score_batch_raw_dev((psgpu_ms_model_t *)d->cfg.scorer, f, n_new, d->d_ms_id, d->d_ms_dist, rows, st);
         else {
-            psgpu_set_error("psgpu_decode_live_step: the semi-continuous scorer's history is not carried between calls");
-            return PSGPU_EINVAL;
+            // the semi-continuous scorer: as the PTM scorer above, the frames numbered from t0 (d_off1[2])
+            const int H = d->cfg.pl_window + 2;
+            const uint8_t *const seed_in = t0 > 0 ? d->d_lseed[d->lseed_cur] : ((d->live_chained && d->seed_valid) ? d->d_seed : nullptr);
+            if ((rc = psgpu_semi_score_batch_carry_dev((psgpu_semi_model_t *)d->cfg.scorer, f, d->d_off1, 1, n_new, seed_in, d->d_lseed[d->lseed_cur ^ 1],
+                                                       d->d_seed_tmp, H, d->d_off1 + 2, rows, st)))
+                return rc;
+            d->lseed_cur ^= 1;
+            int ts = t0 + n_new - 1;
+            while (ts >= t0 && ts % H != H - 1) --ts;
+            if (ts >= t0) {
+                PSGPU_HIP(hipMemcpyAsync(d->d_seed, d->d_seed_tmp, (size_t)d->n_chain * d->topn, hipMemcpyDeviceToDevice, st));
+                d->seed_valid = true;
+            }
         }
         if (rc) return rc;
         if ((rc = psgpu_phone_loop_run_carry_dev(d->cfg.ctx, &d->cfg.pl, d->d_ssid, d->d_tmatid, d->raw_flag == 3 ? nullptr : d->d_ci,
@@ -810,7 +831,6 @@ int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d) { return d ? 
 int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max_frames, int32_t max_step_frames, void *stream)
 {
     PSGPU_REQUIRE(d && n_streams > 0 && max_frames > 0 && max_step_frames > 0, "psgpu_decode_streams_begin: bad argument");
-    PSGPU_REQUIRE(d->kind != PSGPU_SCORER_SEMI, "psgpu_decode_streams_begin: the semi-continuous scorer's history is not carried between calls");
     PSGPU_REQUIRE(!d->want_lists && (d->n_sen & 1) == 0, "psgpu_decode_streams_begin: streams keep score rows (an even number of senones; not with "
                   "psgpu_decode_score_mode lists)");
     hipStream_t st = (hipStream_t)stream;
@@ -829,7 +849,7 @@ int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max
             if ((rc = dec_alloc((void **)&d->d_win[k], 2 * wrows * d->n_sen + 64)) || (rc = dec_alloc((void **)&d->d_wpen[k], 4 * wrows * d->n_ci))
                 || (rc = dec_alloc((void **)&d->d_sseed[k], (size_t)n_streams * per)))
                 return rc;
-        if ((rc = dec_alloc((void **)&d->d_ls, 4 * (size_t)(10 * n_streams + 8)))
+        if ((rc = dec_alloc((void **)&d->d_ls, 4 * (size_t)(11 * n_streams + 8)))
             || (rc = dec_alloc((void **)&d->d_splc, 4 * (size_t)n_streams * psgpu_phone_loop_carry_words())))
             return rc;
         d->win_rows = wrows;
@@ -879,8 +899,8 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
     int rc;
     // the step's tables
     std::vector<int32_t> &h = d->ls_h;
-    h.assign((size_t)10 * n + 8, 0);
-    int32_t *const off1 = h.data(), *const uoff = off1 + n + 1, *const ext = uoff + n + 1, *const map = ext + 2 * n;
+    h.assign((size_t)11 * n + 8, 0);
+    int32_t *const off1 = h.data(), *const uoff = off1 + n + 1, *const ext = uoff + n + 1, *const map = ext + 2 * n, *const fbase = map + 5 * n;
     size_t total = 0, wtot = 0;
     int64_t searched = 0;
     for (int u = 0; u < n; ++u) {
@@ -890,6 +910,7 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
         const bool fin = final_flags && final_flags[u];
         const int S = fin ? (T < d->cfg.pl_window ? S0 : T) : std::max(T - lag, S0);
         off1[u] = (int32_t)total; total += (size_t)n_new[u];
+        fbase[u] = T0;
         map[5 * u] = d->ls_woff[u] + (S0 - d->ls_wbase[u]); map[5 * u + 1] = keep; map[5 * u + 2] = off1[u]; map[5 * u + 3] = n_new[u];
         map[5 * u + 4] = (int32_t)wtot;
         uoff[u] = (int32_t)wtot - S0;                    // frame f's row: (uoff + f) -- the window starts at frame S0
@@ -903,15 +924,20 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
     PSGPU_HIP(hipMemcpyAsync(d->d_ls, h.data(), 4 * h.size(), hipMemcpyHostToDevice, st));
     if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * d->veclen, hipMemcpyHostToDevice, st));
     PSGPU_HIP(hipStreamSynchronize(st));                 // (feat is the caller's)
-    const int32_t *const d_off1 = d->d_ls, *const d_uoff = d->d_ls + n + 1, *const d_ext = d_uoff + n + 1, *const d_map = d_ext + 2 * n;
+    const int32_t *const d_off1 = d->d_ls, *const d_uoff = d->d_ls + n + 1, *const d_ext = d_uoff + n + 1, *const d_map = d_ext + 2 * n,
+                  *const d_fbase = d_map + 5 * n;
     const size_t per = (size_t)std::max(1, d->n_chain * d->topn);
     if (total) {
-        if (d->kind == PSGPU_SCORER_PTM) {
+        if (d->kind == PSGPU_SCORER_PTM || d->kind == PSGPU_SCORER_SEMI) {
             const uint8_t *const seed_in = d->d_sseed[d->ls_cur];
             uint8_t *const seed_out = d->d_sseed[d->ls_cur ^ 1];
-            if ((rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d_off1, n, (int32_t)total, seed_in, seed_out, d->d_tsc, d->d_tcw, d->d_rows,
-                                                d->d_best, d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st)))
-                return rc;
+            if (d->kind == PSGPU_SCORER_PTM)
+                rc = psgpu_ptm_score_batch_dev(d->cfg.model, d->d_feat, d_off1, n, (int32_t)total, seed_in, seed_out, d->d_tsc, d->d_tcw, d->d_rows,
+                                               d->d_best, d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st);
+            else
+                rc = psgpu_semi_score_batch_carry_dev((psgpu_semi_model_t *)d->cfg.scorer, d->d_feat, d_off1, n, (int32_t)total, seed_in, seed_out,
+                                                      nullptr, d->cfg.pl_window + 2, d_fbase, d->d_rows, st);
+            if (rc) return rc;
             hipLaunchKernelGGL(dec_seed_keep_kernel, dim3((unsigned)n), dim3(64), 0, st, d_off1, n, (int32_t)per, seed_in, seed_out);
             PSGPU_HIP(hipGetLastError());
             d->ls_cur ^= 1;

@@ -194,7 +194,9 @@ template <int N>
 __global__ __launch_bounds__(256)
 void semi_chain_kernel(SemiDev p, const float *__restrict__ feats, int32_t veclen,
                        const int32_t *__restrict__ utt_off, int32_t n_utt,
-                       uint8_t *__restrict__ l_cw, int32_t *__restrict__ l_sc, uint8_t *__restrict__ l_n)
+                       uint8_t *__restrict__ l_cw, int32_t *__restrict__ l_sc, uint8_t *__restrict__ l_n,
+                       const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out, uint8_t *__restrict__ slot_out,
+                       int32_t n_hist, const int32_t *__restrict__ frame_base)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -205,8 +207,13 @@ void semi_chain_kernel(SemiDev p, const float *__restrict__ feats, int32_t vecle
     const float *mean = p.mean + p.foff[f], *var = p.var + p.foff[f];
     const float *det = p.det + (size_t)f * p.n_density;
     TopN<N> L;
+    // psgpu_semi_score_batch_carry_dev: the utterance goes on (or a session's next one begins) from carried codeword lists -- the
+    // previous frame's, which s2_semi_mgau_frame_eval copies before mgau_dist (s2_semi_mgau.c:853-860); scores are re-derived -- and its
+    // frames count from `base` for the down-sampling rule and the history slot
+    const size_t so = ((size_t)u * p.n_feat + f) * N;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { L.cw[i] = i; L.sc[i] = kMaxNegInt32; }
+    for (int i = 0; i < N; ++i) { L.cw[i] = seed_in ? (int32_t)seed_in[so + i] : i; L.sc[i] = kMaxNegInt32; }
+    const int base = frame_base ? frame_base[u] : 0;
     float dt[kSemiK];
 #pragma unroll
     for (int k = 0; k < kSemiK; ++k) dt[k] = det[min(k * 64 + lane, p.n_density - 1)];
@@ -226,7 +233,19 @@ void semi_chain_kernel(SemiDev p, const float *__restrict__ feats, int32_t vecle
         }
 #pragma unroll
         for (int i = 0; i < N; ++i) L.sc[i] = kMaxNegInt32;             // carried codewords, scores re-derived
-        generic_frame_step<N, true>(L, d, dp, lane, p.n_density, (t % p.ds_ratio) == 0);
+        generic_frame_step<N, true>(L, d, dp, lane, p.n_density, ((base + t) % p.ds_ratio) == 0);
+        if (lane == 0) {
+            // what later frames start from: the utterance's last lists (the next call's first frame), and slot n_hist - 1 of the
+            // reference's ring (the next utterance's first frame, :855-858) = the lists of the last frame ts with ts % n_hist == n_hist - 1
+            if (seed_out && t == T - 1) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) seed_out[so + i] = (uint8_t)L.cw[i];
+            }
+            if (slot_out && (base + t) % n_hist == n_hist - 1) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) slot_out[so + i] = (uint8_t)L.cw[i];
+            }
+        }
         // mgau_norm (:185-203)
         const int32_t norm = L.sc[0] >> kSenscrShift;
         int cnt = N;
@@ -490,10 +509,22 @@ int psgpu_semi_frame_eval(psgpu_semi_state_t *s, int16_t *senscr,
 int32_t psgpu_semi_n_sen(const psgpu_semi_model_t *m) { return m ? m->d.n_sen : 0; }
 int32_t psgpu_semi_veclen(const psgpu_semi_model_t *m) { return m ? m->veclen : 0; }
 
+int32_t psgpu_semi_n_feat(const psgpu_semi_model_t *m) { return m ? m->d.n_feat : 0; }
+int32_t psgpu_semi_topn(const psgpu_semi_model_t *m) { return m ? m->d.topn : 0; }
+
 int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, const int32_t *utt_off_dev,
                                int32_t n_utt, int32_t total_frames, int16_t *senscr_dev, void *stream)
 {
-    PSGPU_REQUIRE(m && n_utt >= 0 && total_frames >= 0, "psgpu_semi_score_batch_dev: bad argument");
+    return psgpu_semi_score_batch_carry_dev(m, feats_dev, utt_off_dev, n_utt, total_frames, nullptr, nullptr, nullptr, 1, nullptr, senscr_dev, stream);
+}
+
+int psgpu_semi_score_batch_carry_dev(psgpu_semi_model_t *m, const float *feats_dev, const int32_t *utt_off_dev, int32_t n_utt,
+                                     int32_t total_frames, const uint8_t *seed_in_dev, uint8_t *seed_out_dev, uint8_t *slot_out_dev,
+                                     int32_t n_hist, const int32_t *frame_base_dev, int16_t *senscr_dev, void *stream)
+{
+    PSGPU_REQUIRE(m && n_utt >= 0 && total_frames >= 0 && n_hist >= 1, "psgpu_semi_score_batch_dev: bad argument");
+    PSGPU_REQUIRE(!seed_in_dev || (seed_in_dev != seed_out_dev && seed_in_dev != slot_out_dev),
+                  "psgpu_semi_score_batch_carry_dev: the lists carried in must not be the buffer of a carry-out");
     if (n_utt == 0 || total_frames == 0) return PSGPU_OK;
     PSGPU_REQUIRE(feats_dev && utt_off_dev && senscr_dev, "psgpu_semi_score_batch_dev: NULL device buffer");
     const SemiDev &d = m->d;
@@ -510,7 +541,8 @@ int psgpu_semi_score_batch_dev(psgpu_semi_model_t *m, const float *feats_dev, co
     const int waves = n_utt * d.n_feat;
 #define PSGPU_SEMI_B(NN) case NN:                                                                                     \
         hipLaunchKernelGGL((semi_chain_kernel<NN>), dim3((waves + 3) / 4), dim3(256), 0, st, d, feats_dev, m->veclen, \
-                           utt_off_dev, n_utt, m->b_cw, m->b_sc, m->b_n);                                             \
+                           utt_off_dev, n_utt, m->b_cw, m->b_sc, m->b_n, seed_in_dev, seed_out_dev, slot_out_dev, n_hist,     \
+                           frame_base_dev);                                                                           \
         hipLaunchKernelGGL((semi_senone_batch_kernel<NN>), dim3(total_frames), dim3(256), 0, st, d,                   \
                            (const uint8_t *)m->b_cw, (const int32_t *)m->b_sc, (const uint8_t *)m->b_n, senscr_dev);  \
         break;

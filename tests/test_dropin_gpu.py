@@ -664,3 +664,32 @@ def test_dropin_live_decode_of_a_long_utterance(tmp_path, seconds, chunk, restar
     print("live decode of %.0f s in %d-sample pieces: %.3f s; in one call: %.3f s; ratio %.2f (CPU decoder live: %.3f s)"
           % (seconds, chunk, live["decode_s_gpu"], once["decode_s_gpu"], live["decode_s_gpu"] / once["decode_s_gpu"], live["decode_s_cpu"]))
     assert live["decode_s_gpu"] < 2.0 * once["decode_s_gpu"], (live["decode_s_gpu"], once["decode_s_gpu"])
+
+
+@pytest.mark.gpu
+def test_dropin_device_search_semi_continuous_session():
+    """the semi-continuous scorer (tidigits: s2_semi, 4 streams x 256 densities, 4-bit weights, s2_4x feature vectors, 5-state HMMs) behind
+    the device ps_searchfuncs_t: the 31 utterances of the reference's regression list through ONE decoder, one after another -- the
+    scorer's ring slot that seeds an utterance's first frame (s2_semi_mgau.c:853-860) and the multiplexed channels' ssids go through the
+    device pass and back (psgpu_semi_score_batch_carry_dev, session_push / session_pull).  The feature vectors are the decoder's own
+    acmod's (the binding's PCM entries serve 1s_c_d_dd only).  Every hypothesis, score and segmentation equals the CPU decoder's."""
+    r = run("@%s:%s" % (os.path.join(TD, "tidigits.ctl"), TD), 1, "psgpu_device_vtable", "yes", "fwdflat", "no", "bestpath", "no", **TD_KW)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["n_utts"] >= 30 and r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert r["device_search_frames"] > 0, r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [("fwdflat", "no", "bestpath", "no"), ()])
+def test_dropin_device_search_semi_continuous_partial_results(extra, tmp_path):
+    """... and in mid-utterance: three tidigits utterances through one decoder, 7 cepstral frames a piece (ps_process_cep without
+    full_utt) with ps_get_hyp after every piece -- live utterances of the pipeline with the semi-continuous scorer carried from step to
+    step; every partial and final result equals the CPU decoder's, each frame is searched once.  (Pieces longer than acmod's feature
+    ring -- 14 frames here -- make the REFERENCE's own live decode from cepstra fail in acmod_score, "outside queue": not used.)"""
+    names = [ln.strip() for ln in open(os.path.join(TD, "tidigits.ctl")) if ln.strip()][:3]
+    ctl = tmp_path / "three.ctl"
+    ctl.write_text("\n".join(names) + "\n")
+    r = run("@%s:%s" % (ctl, TD), 1, "psgpu_device_vtable", "yes", "chunked", "7", *extra, **TD_KW)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["partial_equal"] and r["partial_results"] >= 9 and r["hyp_equal"] and r["seg_equal"], r
+    assert r["live_frames_searched"] == r["live_utt_frames"] > 0 and r["live_restarts"] == 0, r

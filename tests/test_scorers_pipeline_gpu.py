@@ -166,6 +166,50 @@ def test_pipeline_with_the_semi_continuous_scorer_tidigits(tmp_path):
         assert int(hn[u, 1]) == int(g["hyp_score"][0]), names[u]
     with pytest.raises(P.PsgpuError):
         p.run([np.zeros(16000, np.int16)])                # (from PCM this pipeline has no front end / another feature type: refused)
-    with pytest.raises(P.PsgpuError):
-        p.session(True)                                   # (this scorer's top-N history is not carried: refused, not ignored)
+    # a session with this scorer: the first utterance of a new session is a new decoder's (its ring starts from codeword = rank)
+    p.session(True)
+    p.run_feat(feats[3], [feats[3].shape[0]])
+    hn, hyp, res = p.fetch()
+    tab = p.tables(0, res)
+    assert np.array_equal(tab["bp"], golds[3]["bp"]) and int(hn[0, 1]) == int(golds[3]["hyp_score"][0])
+    p.close()
+
+
+def test_streams_with_the_semi_continuous_scorer_tidigits(tmp_path):
+    """a batch of live decoders with the semi-continuous scorer: eight tidigits utterances as eight streams, fed 11-23 frames a step
+    (psgpu_decode_streams_step: the scorer's lists carried per stream by psgpu_semi_score_batch_carry_dev, frames numbered on from
+    where each stream stands); every stream's final tables equal the reference's decode of that file by a new decoder"""
+    _need_ref()
+    import pocketsphinx_amd as P
+    tdir = os.path.join(REF, "data", "tidigits")
+    lm, dic = os.path.join(tdir, "tidigits.lm.bin"), os.path.join(tdir, "tidigits.dic")
+    names = [ln.strip() for ln in open(os.path.join(tdir, "tidigits.ctl")) if ln.strip()][:8]
+    feats, golds = [], []
+    for n in names:
+        mfc = os.path.join(tdir, n + ".mfc")
+        feats.append(_ref_dump(tmp_path, "dynfeat", "tidigits", lm, dic, [mfc])["feat"])
+        golds.append(_ref_dump(tmp_path, "fwdtree", "tidigits", lm, dic, [mfc], ("fwdflat", "no", "bestpath", "no")))
+    g0 = golds[0]
+    semi = P.SemiMgau(_load("semi_tidigits_tables.npz"))
+    p = P.DecodePipeline(None, None, g0, g0["par"], g0, scorer=semi)
+    n = len(names)
+    p.streams_begin(n, max(f.shape[0] for f in feats) + 8, 24)
+    pos = [0] * n; done = [False] * n
+    for step in range(200):
+        fs, fin = [], []
+        for u in range(n):
+            k = 0 if done[u] else min(11 + (step + 3 * u) % 13, feats[u].shape[0] - pos[u])
+            fs.append(feats[u][pos[u]:pos[u] + k]); pos[u] += k
+            fin.append(k > 0 and pos[u] == feats[u].shape[0])
+        p.streams_step(fs, fin)
+        hn, hyp, res = p.fetch()
+        for u in range(n):
+            if fin[u]:
+                done[u] = True
+                tab = p.tables(u, res)
+                assert int(res[u, 3]) == 0 and np.array_equal(tab["bp"], golds[u]["bp"]), (names[u], step)
+                assert np.array_equal(tab["bscore_stack"], golds[u]["bscore_stack"]) and int(hn[u, 1]) == int(golds[u]["hyp_score"][0]), names[u]
+        if all(done):
+            break
+    assert all(done) and p.live_frames_searched() == sum(f.shape[0] for f in feats)
     p.close()
