@@ -24,6 +24,19 @@ for case, mode in [("goforward", "slab"), ("goforward", "lds"), ("goforward_maxh
     rows, pen = _inputs(g, s.n_sen)
     _check(s.search(rows, pen, [rows.shape[0]], handover={}, **caps(g))[0], g, case)
     print("tree search", case, "mode", mode, "clean")
+# the search resumed between calls (the state saved and restored), and on a window of rows (frames already searched dropped: a
+# read of one is out of bounds here)
+for case, mode in [("goforward", "lds"), ("goforward", "slab"), ("man_ah_2934za", "lds")]:
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    os.environ["PSGPU_FWDTREE_LAYOUT"] = mode
+    s = simlib.SimFwdtreeSearch(st, g["par"])
+    rows, pen = _inputs(g, s.n_sen)
+    T = rows.shape[0]
+    _check(s.search(rows, pen, [T], cuts=[7, 8, T // 2], lag=4, **caps(g))[0], g, case)
+    r, _ = simlib.search_windows(s, rows, pen, [9, 10, T // 2, T], 4, **caps(g))
+    _check(r, g, case)
+    print("tree search resumed / on windows", case, "mode", mode, "clean")
 for case in ["goforward", "man_ah_2934za", "medium_numbers"]:
     g, st, fst = load_flat(case)
     s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"], lm=simlib.SimLm(fst) if "lm" not in st else None)

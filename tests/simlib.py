@@ -150,6 +150,35 @@ class SimFwdtreeSearch:
         return out
 
 
+def search_windows(s, senscr, penalties, cuts, lag, bp_cap=16384, bss_cap=1 << 19, raw_scores=False, pl_window=0):
+    """ONE utterance as a live stream keeps it (psgpu_fwdtree_search_streams + _resume): every call is handed a buffer that holds ONLY
+    the score rows and penalties from the frame its search resumes at -- the rows of frames already searched are gone -- placed by a
+    start BEFORE the buffer (utt_off = -first frame kept), and {frames scored, frame to search to}.  cuts: frames scored at each call
+    (the last = all); the search runs `lag` behind them and to the end in the last call.  Returns the result dict and the frames
+    searched after every call.  (Under AddressSanitizer a read of a dropped row is a report.)"""
+    T = int(cuts[-1])
+    d_s = np.ascontiguousarray(senscr, np.int16); d_p = np.ascontiguousarray(penalties, np.int32)
+    bp = np.zeros((1, 10, bp_cap), np.int32); bss = np.zeros((1, bss_cap), np.int32)
+    idx = np.zeros((1, T + 2), np.int32); step = np.zeros((1, max(T, 1), 4), np.int32); res = np.zeros((1, 8), np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    S = 0; searched = []
+    for k, c in enumerate(cuts):
+        last = k == len(cuts) - 1
+        to = c if last else max(c - lag, S)
+        win_s = np.ascontiguousarray(d_s[S:c]); win_p = np.ascontiguousarray(d_p[S:c])       # what a stream still holds
+        off = np.array([-S, 0], np.int32); ext = np.array([c, to], np.int32)
+        check(lib().psgpu_fwdtree_search_streams(s.h, p(ext)), "psgpu_fwdtree_search_streams")
+        check(lib().psgpu_fwdtree_search_resume(s.h, 1 if k == 0 else 3), "psgpu_fwdtree_search_resume")
+        check(lib().psgpu_fwdtree_search_session_dev(s.h, p(win_s), C.c_int64(s.n_sen), p(win_p), p(off), 1, T, bp_cap, bss_cap,
+                                                     p(bp), p(bss), p(idx), p(step), p(res), int(raw_scores), int(pl_window), None, None, None, None),
+              "psgpu_fwdtree_search_session_dev")
+        S = to
+        searched.append(int(res[0, 2]))
+    nb, nh, nfr, status = [int(v) for v in res[0, :4]]
+    return dict(bp=bp[0, :, :nb].T.copy(), bscore_stack=bss[0, :nh].copy(), bp_table_idx=idx[0, :nfr + 1].copy(), step=step[0, :nfr].copy(),
+                n_frame=nfr, status=status), searched
+
+
 class PtmView(C.Structure):
     """psgpu_ptm_view_t"""
     _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("det", C.c_void_p), ("mixw", C.c_void_p), ("sen2cb", C.c_void_p),

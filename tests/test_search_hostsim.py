@@ -276,6 +276,24 @@ def test_search_kernel_source_resumed_between_calls(case, cuts, lag, layout, ord
         s.close()
 
 
+@pytest.mark.parametrize("layout", ["lds", "slab"])
+@pytest.mark.parametrize("case,cuts,lag", [("goforward", [9, 10, 47, 120, 121, 200], 5), ("numbers", [60, 61, 150], 8)])
+def test_search_kernel_source_on_a_window_of_rows(case, cuts, lag, layout):
+    """psgpu_fwdtree_search_streams: a live stream keeps only the score rows and penalties its search has not reached yet; every call gets
+    that window, placed by a start before the buffer, and per-utterance {frames scored, frame to search to}.  The tables at the end
+    are the golden's."""
+    g = _load("fwdtree_trace_%s.npz" % case)
+    st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+    with _order("rev"), _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, g["par"])
+        rows, pen = _inputs(g, s.n_sen)
+        T = rows.shape[0]
+        r, searched = simlib.search_windows(s, rows, pen, cuts + [T], lag)
+        _check(r, g, "%s in windows" % case)
+        assert searched == [max(c - lag, 0) for c in cuts] + [T]
+        s.close()
+
+
 @pytest.mark.parametrize("layout", ["slab", "lds"])
 def test_search_kernel_source_final_scores_mode(layout):
     """raw_scores = 3 (psgpu.h): the kernel builds each frame's active senone list but the rows are FINAL scores -- a scorer that
