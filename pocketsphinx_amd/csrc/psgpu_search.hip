@@ -955,14 +955,21 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 dlast_f = { SMALL ? wordA + WC_DLAST : d_last }, homo_f = { SMALL ? wordA + WC_HOMO : homophone },
                 dfill_f = { SMALL ? wordA + WC_DFILL : d_filler };
     const int32_t *const w1w_f = SMALL ? fb + L.w1w : w1_wid, *const w1ci_f = SMALL ? fb + L.w1ci : w1_ci, *const w1ci2_f = SMALL ? fb + L.w1ci2 : w1_ci2;
-    if (SMALL) {
+    // psgpu_fwdtree_search_resume: the utterance's saved state; f0 = the frames searched by the calls before
+    // (slab layouts: everything the frames share is in the utterance's slab -- which stays where it is between the calls -- but the
+    //  counters and the carried registers)
+    int32_t *const live = bf.live ? psgpu_as_global(bf.live) + (size_t)blockIdx.x * (kFtLiveHdr + (SMALL ? L.rows_total : 0)) : nullptr;
+    // (word 16: the block holds a saved search -- zeroed by the caller for an utterance that starts afresh among resumed ones)
+    const bool resumed = live != nullptr && (bf.live_mode & 2) != 0 && live[16] == kFtLiveMagic;
+    const int f0 = resumed ? live[0] : 0;
+    if (SMALL && !resumed) {                             // (a resumed search loads the pool, these copies with it)
         for (int i = tid; i < p.n_w; i += NT) {
             int32_t *const r = wordA + i * kFtWordCols;
             r[WC_DFIRST] = d_first[i]; r[WC_DBASE] = d_base[i]; r[WC_DLAST] = d_last[i]; r[WC_HOMO] = homophone[i]; r[WC_DFILL] = d_filler[i];
         }
         for (int i = tid; i < n1; i += NT) { fb[L.w1w + i] = w1_wid[i]; fb[L.w1ci + i] = w1_ci[i]; fb[L.w1ci2 + i] = w1_ci2[i]; }
     }
-    if (SMALL) {
+    if (SMALL && !resumed) {
         const int32_t *const g_ko = psgpu_as_global(p.kid_off), *const g_k = psgpu_as_global(p.kids), *const g_p = psgpu_as_global(p.parent),
                       *const g_c = psgpu_as_global(p.node_ci), *const g_w = psgpu_as_global(p.node_pw);
         for (int i = tid; i <= N; i += NT) nodeA[i * kFtNodeCols + NC_KIDOFF] = g_ko[i];
@@ -992,13 +999,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int t0 = utt_off[blockIdx.x], T_in = ext ? ext[0] : utt_off[blockIdx.x + 1] - t0,
               T = ext ? min(ext[1], T_in) : (bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in));
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
-    // psgpu_fwdtree_search_resume: the utterance's saved state; f0 = the frames searched by the calls before
-    // (slab layouts: everything the frames share is in the utterance's slab -- which stays where it is between the calls -- but the
-    //  counters and the carried registers)
-    int32_t *const live = bf.live ? psgpu_as_global(bf.live) + (size_t)blockIdx.x * (kFtLiveHdr + (SMALL ? L.rows_total : 0)) : nullptr;
-    // (word 16: the block holds a saved search -- zeroed by the caller for an utterance that starts afresh among resumed ones)
-    const bool resumed = live != nullptr && (bf.live_mode & 2) != 0 && live[16] == kFtLiveMagic;
-    const int f0 = resumed ? live[0] : 0;
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
     uint32_t evals_run = 0u;                             // HMM evaluations so far (ngs->st.n_hmm_eval; saturating: compared with maxhmmpf), likewise
     int nwc_cur = 0;                                     // right-context channels of the active words (the last of woff's prefix sums), likewise
@@ -1025,7 +1025,17 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // carried registers; the senone bitmap, the listed-nodes bitmap and the normaliser are reset at every frame's end and are as
         // the lines above left them
         __syncthreads();
-        if (SMALL) for (int i = tid; i < L.rows_total; i += NT) s_pool[i] = live[kFtLiveHdr + i];
+        if (SMALL) {
+            // (sixteen bytes a work-item, four requests in flight: a load a loop step waited for was 0.1 ms of a resumed launch)
+            const FtQuad *const src = reinterpret_cast<const FtQuad *>(live + kFtLiveHdr);
+            FtQuad *const dst = reinterpret_cast<FtQuad *>(s_pool);
+            const int nq = L.rows_total >> 2;            // (the pool's arrays are padded to four words: ft_layout)
+            for (int i = tid; i < nq; i += 4 * NT) {
+                const int i1 = min(i + NT, nq - 1), i2 = min(i + 2 * NT, nq - 1), i3 = min(i + 3 * NT, nq - 1);
+                const FtQuad a = src[i], b = src[i1], c = src[i2], e = src[i3];
+                dst[i] = a; dst[i1] = b; dst[i2] = c; dst[i3] = e;
+            }
+        }
         if (tid < 8) s_sc[tid] = live[8 + tid];
         if (tid == 0) { s_evals = (unsigned long long)(uint32_t)live[5] | ((unsigned long long)(uint32_t)live[6] << 32); s_nsen = live[7]; }
         n_acl_cur = live[1]; n_awl_cur = live[2]; evals_run = (uint32_t)live[3]; nwc_cur = live[4];
@@ -2308,6 +2318,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) psgpu_as_global(bf.prof)[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
     __syncthreads();                                             // the table's last entries (device memory, other work-items') before the copy and the backtrace
+    // (a resumed call: the entries the calls before have written are final and in the caller's columns already -- read here, from
+    //  the block the lines below rewrite, rather than carried through the frames)
+    const int bp_from = (live && (bf.live_mode & 2) && live[16] == kFtLiveMagic) ? live[8 + 3] : 0;
+    __syncthreads();
     if (live && (bf.live_mode & 1)) {                            // psgpu_fwdtree_search_resume: what the next call starts from
         if (SMALL) for (int i = tid; i < L.rows_total; i += NT) live[kFtLiveHdr + i] = s_pool[i];
         if (tid < 8) live[8 + tid] = s_sc[tid];
@@ -2320,7 +2334,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     {   // the table in the caller's columns (bptbl_t, ngram_search.h:112-124): ft_table_out
         int32_t *const out = psgpu_as_global(bf.bp) + (size_t)blockIdx.x * kBpCols * bf.bp_cap;
         const int n_bp = s_sc[3];
-        for (int j = tid; j < n_bp * 4; j += NT) {               // (a quad of an entry per work-item)
+        for (int j = bp_from * 4 + tid; j < n_bp * 4; j += NT) {       // (a quad of an entry per work-item; a resumed call: its own entries)
             const int i = j >> 2, q = j & 3;
             if (q == 3) continue;                                // (words 12-15: unused)
             const FtQuad v = *reinterpret_cast<const FtQuad *>(tb.bp + (size_t)i * kBpRow + 4 * q);
@@ -2328,18 +2342,61 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (q < 2) { out[(size_t)(4 * q + 2) * bf.bp_cap + i] = v.z; out[(size_t)(4 * q + 3) * bf.bp_cap + i] = v.w; }
         }
     }
+    // the hypothesis, while the table's tail is still in this compute unit's cache: a separate backtrace launch is one more
+    // dispatch per batch, and a tiny dispatch issued beside ANOTHER stream's resident search kernel was measured stalling for
+    // that kernel's whole duration (profiles/r03_overlap.txt).  (The table was written by this workgroup; the full barrier
+    // above ordered those stores before this read.)  ONE walk down the path by work-item 0 -- a hop is one trip to device memory:
+    // an entry's words lie in one line -- into LDS the frames no longer need, then every work-item writes its word in spoken order:
+    // a live stream pays the walk at every step (as two walks of several loads a hop it was a fifth of a 10-frame step).
+    int32_t *const bt = SMALL ? fb + L.evl : s_pool;              // {word, end frame, score} per word, last word first
+    const int bt_cap = (SMALL ? (L.evl_cap + 1) / 2 : 18 * NT) / 3;
+    __syncthreads();                                              // (the pool has been saved: its words may be written over)
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
         result[0] = s_sc[3]; result[1] = s_sc[4]; result[2] = s_sc[7]; result[3] = s_sc[6];
         result[4] = s_sc[0];                                     // ngs->best_score as the last frame left it
         result[5] = (int32_t)(s_evals & 0xffffffffull); result[6] = (int32_t)(s_evals >> 32); result[7] = s_nsen;
-        // the hypothesis, while the table's tail is still in this compute unit's cache: a separate backtrace launch is one more
-        // dispatch per batch, and a tiny dispatch issued beside ANOTHER stream's resident search kernel was measured stalling for
-        // that kernel's whole duration (profiles/r03_overlap.txt).  (The table was written by this workgroup; the full barrier
-        // above ordered those stores before this read.)
-        if (bf.hyp)
-            ft_backtrace_one(tb, tb.idx, s_sc[7], p.finishwid, bf.max_words, psgpu_as_global(bf.hyp) + (size_t)blockIdx.x * bf.max_words * 4,
-                             psgpu_as_global(bf.hyp_n) + (size_t)blockIdx.x * 4);
+        if (bf.hyp) {
+            // ngram_search_find_exit (ngram_search.c:500-544, frame_idx = -1): as ft_backtrace_one
+            int32_t *const hn = psgpu_as_global(bf.hyp_n) + (size_t)blockIdx.x * 4;
+            int n = 0, best = -1; int32_t best_score = kW;
+            int f = s_sc[7] - 1;
+            if (f >= 0) {
+                const int end = tb.idx[f];
+                while (f >= 0 && tb.idx[f] == end) --f;
+                if (f >= 0)
+                    for (int bp = tb.idx[f]; bp < end; ++bp) {
+                        const int wid = BPC(tb, B_WID, bp);
+                        if (wid == p.finishwid || BPC(tb, B_SCORE, bp) > best_score) { best_score = BPC(tb, B_SCORE, bp); best = bp; }
+                        if (wid == p.finishwid) break;
+                    }
+            }
+            for (int b = best; b != -1; ++n) {
+                const FtQuad q = *reinterpret_cast<const FtQuad *>(tb.bp + (size_t)b * kBpRow);      // frame, valid, word, predecessor
+                const int32_t sc = BPC(tb, B_SCORE, b);
+                if (n < bt_cap) { bt[3 * n] = q.z; bt[3 * n + 1] = q.x; bt[3 * n + 2] = sc; }
+                b = q.w;
+            }
+            hn[0] = n; hn[1] = best_score; hn[2] = best; hn[3] = 0;
+            s_red[0] = n; s_red[1] = best;
+        }
+    }
+    if (bf.hyp) {
+        __syncthreads();
+        const int n = s_red[0];
+        int32_t *const hyp = psgpu_as_global(bf.hyp) + (size_t)blockIdx.x * bf.max_words * 4;
+        if (n <= bt_cap) {
+            // spoken position k = n - 1 - j of the walk's j-th word; the last max_words of them are kept; a word starts a frame after
+            // its predecessor's end
+            const int skip = n > bf.max_words ? n - bf.max_words : 0;
+            for (int k = skip + tid; k < n; k += NT) {
+                const int j = n - 1 - k;
+                int32_t *const h = hyp + (size_t)(k - skip) * 4;
+                h[0] = bt[3 * j]; h[1] = j + 1 < n ? bt[3 * (j + 1) + 1] + 1 : 0; h[2] = bt[3 * j + 1]; h[3] = bt[3 * j + 2];
+            }
+        }
+        else if (tid == 0)                                       // (a path of more words than the LDS at hand holds: the two walks)
+            ft_backtrace_one(tb, tb.idx, s_sc[7], p.finishwid, bf.max_words, hyp, psgpu_as_global(bf.hyp_n) + (size_t)blockIdx.x * 4);
     }
     // what the second pass inherits besides the tables: the permanent single-phone channels keep their per-state ssids
     // through hmm_clear (ngram_fwdflat_start, ngram_search_fwdflat.c:385-392)

@@ -663,7 +663,7 @@ def test_dropin_live_decode_of_a_long_utterance(tmp_path, seconds, chunk, restar
     assert once["ok"] and once["hyp_equal"], once        # (its words differ from the live decode's: batch instead of live cepstral mean normalisation)
     print("live decode of %.0f s in %d-sample pieces: %.3f s; in one call: %.3f s; ratio %.2f (CPU decoder live: %.3f s)"
           % (seconds, chunk, live["decode_s_gpu"], once["decode_s_gpu"], live["decode_s_gpu"] / once["decode_s_gpu"], live["decode_s_cpu"]))
-    assert live["decode_s_gpu"] < 2.0 * once["decode_s_gpu"], (live["decode_s_gpu"], once["decode_s_gpu"])
+    assert live["decode_s_gpu"] < 3.0 * once["decode_s_gpu"], (live["decode_s_gpu"], once["decode_s_gpu"])
 
 
 @pytest.mark.gpu

@@ -79,7 +79,9 @@ def test_tree_search_kernels_register_budget_and_address_classes(tmp_path):
             # kernel's time follows their number (round 4, same box: 2,491 -> 6.04 ms per 512 x 279 frames, 1,607 -> 5.20,
             # 1,138 -> 4.83; the node-per-work-item pruning: 1,315 -> 4.55): a change that lets it grow again shows here before it
             # shows on a GPU
-            assert len(re.findall(r"\bv_readlane_b32", body)) <= 1400, (n, len(re.findall(r"\bv_readlane_b32", body)))
+            # (the count includes the code around the frame loop -- the resumed search's loading and saving of its state --
+            #  which the 5-state form pays with ~90 more: 3-state 1,321 -> 4.51 ms, unchanged by that code)
+            assert len(re.findall(r"\bv_readlane_b32", body)) <= (1400 if "ILi3E" in n else 1500), (n, len(re.findall(r"\bv_readlane_b32", body)))
 
 
 def test_flat_search_kernels_register_budget_and_address_classes(tmp_path):
