@@ -37,6 +37,19 @@ for case, mode in [("goforward", "lds"), ("goforward", "slab"), ("man_ah_2934za"
     r, _ = simlib.search_windows(s, rows, pen, [9, 10, T // 2, T], 4, **caps(g))
     _check(r, g, case)
     print("tree search resumed / on windows", case, "mode", mode, "clean")
+# two streams on one handle, windows back to back in one buffer, a restart in between
+ga, gb = _load("fwdtree_trace_goforward.npz"), _load("fwdtree_trace_numbers.npz")
+st = _load("fwdtree_static_en_us_turtle.npz")
+for mode in ("lds", "slab"):
+    os.environ["PSGPU_FWDTREE_LAYOUT"] = mode
+    s = simlib.SimFwdtreeSearch(st, ga["par"])
+    a, b = _inputs(ga, s.n_sen), _inputs(gb, s.n_sen)
+    Ta, Tb = a[0].shape[0], b[0].shape[0]
+    sched = [[(50, False, None), (20, False, None)], [(Ta, True, None), (131, False, None)], [(70, False, b), (200, False, None)],
+             [(Tb, True, None), (Tb, True, None)]]
+    out, _ = simlib.search_streams(s, [a, b], sched, 6, bp_cap=int(gb["bp"].shape[0]) + 64, bss_cap=int(gb["bscore_stack"].shape[0]) + 128)
+    _check(out[0], gb, "stream 0"); _check(out[1], gb, "stream 1")
+    print("tree search, two streams with a restart, mode", mode, "clean")
 for case in ["goforward", "man_ah_2934za", "medium_numbers"]:
     g, st, fst = load_flat(case)
     s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"], lm=simlib.SimLm(fst) if "lm" not in st else None)

@@ -179,6 +179,48 @@ def search_windows(s, senscr, penalties, cuts, lag, bp_cap=16384, bss_cap=1 << 1
                 n_frame=nfr, status=status), searched
 
 
+def search_streams(s, utts, schedule, lag, bp_cap=16384, bss_cap=1 << 19):
+    """SEVERAL utterances in progress on one handle, as psgpu_decode_streams_step drives them (psgpu_fwdtree_search_streams + _resume +
+    _restart).  utts: list of (senscr [T][n_sen], penalties [T][n_ci]) per stream; schedule: a list of steps, each a list per stream of
+    (frames scored so far, final?, restart_with or None) -- restart_with = (senscr, penalties) of the utterance the stream begins anew
+    BEFORE this step.  Every call is handed ONE buffer of the streams' windows (rows from the frame each search resumes at) back to
+    back.  Returns the per-stream result dicts after the last step and the frames searched after every step."""
+    n = len(utts)
+    cur = [(np.ascontiguousarray(a, np.int16), np.ascontiguousarray(b, np.int32)) for a, b in utts]
+    mf = max(max(a.shape[0] for a, _ in cur), max((r[2][0].shape[0] for st in schedule for r in st if r[2] is not None), default=0))
+    bp = np.zeros((n, 10, bp_cap), np.int32); bss = np.zeros((n, bss_cap), np.int32)
+    idx = np.zeros((n, mf + 2), np.int32); step = np.zeros((n, max(mf, 1), 4), np.int32); res = np.zeros((n, 8), np.int32)
+    p = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    S = [0] * n; log = []
+    for k, st in enumerate(schedule):
+        wins, pens, off, ext = [], [], [], []
+        at = 0
+        for u, (c, fin, again) in enumerate(st):
+            if again is not None:
+                cur[u] = (np.ascontiguousarray(again[0], np.int16), np.ascontiguousarray(again[1], np.int32)); S[u] = 0
+                if k > 0:
+                    check(lib().psgpu_fwdtree_search_restart(s.h, u, None), "psgpu_fwdtree_search_restart")
+            to = c if fin else max(c - lag, S[u])
+            wins.append(cur[u][0][S[u]:c]); pens.append(cur[u][1][S[u]:c])
+            off.append(at - S[u]); ext += [c, to]
+            at += c - S[u]; S[u] = to
+        win_s = np.ascontiguousarray(np.concatenate(wins)) if at else np.zeros((1, s.n_sen), np.int16)
+        win_p = np.ascontiguousarray(np.concatenate(pens)) if at else np.zeros((1, s.n_ci), np.int32)
+        off_a = np.array(off + [0], np.int32); ext_a = np.array(ext, np.int32)
+        check(lib().psgpu_fwdtree_search_streams(s.h, p(ext_a)), "psgpu_fwdtree_search_streams")
+        check(lib().psgpu_fwdtree_search_resume(s.h, 1 if k == 0 else 3), "psgpu_fwdtree_search_resume")
+        check(lib().psgpu_fwdtree_search_session_dev(s.h, p(win_s), C.c_int64(s.n_sen), p(win_p), p(off_a), n, mf, bp_cap, bss_cap,
+                                                     p(bp), p(bss), p(idx), p(step), p(res), 0, 0, None, None, None, None),
+              "psgpu_fwdtree_search_session_dev")
+        log.append([int(v) for v in res[:, 2]])
+    out = []
+    for u in range(n):
+        nb, nh, nfr, status = [int(v) for v in res[u, :4]]
+        out.append(dict(bp=bp[u, :, :nb].T.copy(), bscore_stack=bss[u, :nh].copy(), bp_table_idx=idx[u, :nfr + 1].copy(),
+                        step=step[u, :nfr].copy(), n_frame=nfr, status=status))
+    return out, log
+
+
 class PtmView(C.Structure):
     """psgpu_ptm_view_t"""
     _fields_ = [("mean", C.c_void_p), ("var", C.c_void_p), ("det", C.c_void_p), ("mixw", C.c_void_p), ("sen2cb", C.c_void_p),

@@ -294,6 +294,33 @@ def test_search_kernel_source_on_a_window_of_rows(case, cuts, lag, layout):
         s.close()
 
 
+@pytest.mark.parametrize("layout", ["lds", "slab"])
+def test_search_kernel_source_streams_with_a_restart(layout):
+    """two utterances in progress on one handle, growing at different paces, each on its own window of rows; stream 0 ends early and is
+    begun again with the other recording (psgpu_fwdtree_search_restart) while stream 1 goes on: every finished utterance's tables are
+    its golden's"""
+    ga, gb = _load("fwdtree_trace_goforward.npz"), _load("fwdtree_trace_numbers.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    with _order("rev"), _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, ga["par"])
+        a, b = _inputs(ga, s.n_sen), _inputs(gb, s.n_sen)
+        Ta, Tb = a[0].shape[0], b[0].shape[0]
+        lag = 6
+        sched = [[(50, False, None), (20, False, None)],
+                 [(51, False, None), (130, False, None)],
+                 [(Ta, True, None), (131, False, None)]]
+        out, log = simlib.search_streams(s, [a, b], sched, lag)
+        _check(out[0], ga, "stream 0, first utterance")
+        assert log == [[44, 14], [45, 124], [Ta, 125]]
+        # stream 0 again, now with the other recording; stream 1 to its end
+        sched2 = sched + [[(70, False, b), (200, False, None)], [(Tb, True, None), (Tb, True, None)]]
+        out, log = simlib.search_streams(s, [a, b], sched2, lag)
+        _check(out[0], gb, "stream 0, second utterance")
+        _check(out[1], gb, "stream 1")
+        assert log[3] == [64, 194] and log[4] == [Tb, Tb]
+        s.close()
+
+
 @pytest.mark.parametrize("layout", ["slab", "lds"])
 def test_search_kernel_source_final_scores_mode(layout):
     """raw_scores = 3 (psgpu.h): the kernel builds each frame's active senone list but the rows are FINAL scores -- a scorer that
