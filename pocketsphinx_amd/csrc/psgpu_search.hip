@@ -814,7 +814,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #if defined(__HIPCC__)
     int32_t *const s_pool = ft_dyn_pool;                 // SMALL: kFtLdsWords words of dynamic LDS (the launch says so)
 #else
-    __shared__ int32_t s_pool[SMALL ? kFtLdsWords : 18 * NT + 16 + kFtMaxBitWords];     // (the workgroup simulator)
+    __shared__ __attribute__((aligned(16))) int32_t s_pool[SMALL ? kFtLdsWords : 18 * NT + 16 + kFtMaxBitWords];     // (the workgroup simulator)
 #endif
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
