@@ -52,18 +52,46 @@ def main():
     steps = (T + chunk - 1) // chunk
     pieces = [np.ascontiguousarray(feat[:, k * chunk:min((k + 1) * chunk, T)].reshape(-1, vl)) for k in range(steps)]
     cnts = [np.full(n, min((k + 1) * chunk, T) - k * chunk, np.int32) for k in range(steps)]
-    p.streams_begin(n, T + 8, chunk)
-    lat = []
-    fin0 = np.zeros(n, np.uint8); fin1 = np.ones(n, np.uint8)
-    t0 = time.perf_counter()
-    for k in range(steps):
-        ta = time.perf_counter()
-        capi.check(L.psgpu_decode_streams_step(p.h, pieces[k].ctypes.data_as(C.c_void_p), cnts[k].ctypes.data_as(C.c_void_p),
-                                               (fin1 if k == steps - 1 else fin0).ctypes.data_as(C.c_void_p), p._stream), "step")
-        if fetch or k == steps - 1:
-            hn, hyp, res = p.fetch()
-        lat.append(time.perf_counter() - ta)
-    dt = time.perf_counter() - t0
+    n_obj = int(os.environ.get("LS_OBJECTS", "1"))
+    if n_obj == 2:
+        # the streams split over TWO pipeline objects on streams of their own: one half's kernels run while the host fetches the other
+        # half's hypotheses and hands over its next pieces
+        from pocketsphinx_amd import decode as pdec
+        h = n // 2
+        q = P.DecodePipeline(_npz("mfcc_en_us_goforward.npz"), _npz("en_us_ptm_tables.npz"), _npz("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+        objs = [(p, 0, h, pdec.dedicated_stream()), (q, h, n, pdec.dedicated_stream())]
+        for o, a, b, st in objs:
+            o.streams_begin(b - a, T + 8, chunk, stream=st)
+        pcs = [[np.ascontiguousarray(feat[a:b, k * chunk:min((k + 1) * chunk, T)].reshape(-1, vl)) for k in range(steps)] for _, a, b, _ in objs]
+        fin0 = np.zeros(n, np.uint8); fin1 = np.ones(n, np.uint8)
+        lat = []; outs = [None, None]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ta = time.perf_counter()
+            for i, (o, a, b, st) in enumerate(objs):
+                capi.check(L.psgpu_decode_streams_step(o.h, pcs[i][k].ctypes.data_as(C.c_void_p), cnts[k][a:b].ctypes.data_as(C.c_void_p),
+                                                       (fin1 if k == steps - 1 else fin0)[a:b].ctypes.data_as(C.c_void_p), o._stream), "step")
+            for i, (o, a, b, st) in enumerate(objs):
+                outs[i] = o.fetch()
+            lat.append(time.perf_counter() - ta)
+        dt = time.perf_counter() - t0
+        hn = np.concatenate([outs[0][0], outs[1][0]]); hyp = np.concatenate([outs[0][1], outs[1][1]]); res = np.concatenate([outs[0][2], outs[1][2]])
+        searched = p.live_frames_searched() + q.live_frames_searched()
+        q.close()
+    else:
+        p.streams_begin(n, T + 8, chunk)
+        lat = []
+        fin0 = np.zeros(n, np.uint8); fin1 = np.ones(n, np.uint8)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ta = time.perf_counter()
+            capi.check(L.psgpu_decode_streams_step(p.h, pieces[k].ctypes.data_as(C.c_void_p), cnts[k].ctypes.data_as(C.c_void_p),
+                                                   (fin1 if k == steps - 1 else fin0).ctypes.data_as(C.c_void_p), p._stream), "step")
+            if fetch or k == steps - 1:
+                hn, hyp, res = p.fetch()
+            lat.append(time.perf_counter() - ta)
+        dt = time.perf_counter() - t0
+        searched = p.live_frames_searched()
     same = bool(np.array_equal(hn, hn0) and np.array_equal(res[:, :5], res0[:, :5])
                 and all(np.array_equal(hyp[u, :hn[u, 0]], hyp0[u, :hn0[u, 0]]) for u in range(n)))
     first_ms, last_ms = 1e3 * lat[0], 1e3 * lat[-1]
@@ -73,7 +101,7 @@ def main():
            "ms_per_step": round(1e3 * dt / steps, 4), "step_ms_median": round(1e3 * float(np.median(lat)), 4),
            "step_ms_p99": round(1e3 * float(lat[int(0.99 * (len(lat) - 1))]), 4),
            "first_step_ms": round(first_ms, 3), "last_step_ms": round(last_ms, 3), "audio_ms_per_step": 10.0 * chunk, "xrt": round(dt / (n * sec), 8),
-           "hypotheses_fetched_every_step": fetch, "frames_searched": p.live_frames_searched(), "frames": n * T,
+           "hypotheses_fetched_every_step": fetch, "pipeline_objects": n_obj, "frames_searched": searched, "frames": n * T,
            "one_call_over_the_same_features_s": round(min(t_once), 4), "one_call_frames_per_s": round(n * T / min(t_once), 1),
            "final_hypotheses_equal_the_one_call_decode": same, "status_nonzero": int((res[:, 3] != 0).sum()),
            "what": "psgpu_decode_streams_step per piece: H2D of the pieces' features, batch scorer, phone loop, window copy, all streams' "
