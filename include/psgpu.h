@@ -711,9 +711,10 @@ int psgpu_fwdtree_search_lag(psgpu_fwdtree_t *m, int32_t lag);
 #define PSGPU_SEARCH_KEEP 1
 #define PSGPU_SEARCH_RESUME 2
 int psgpu_fwdtree_search_resume(psgpu_fwdtree_t *m, int32_t mode);
-/* For the NEXT search call only: utterances in progress that grow at their own pace.  ext_dev [n_utt][2] int32 = {frames scored
- * so far, frame the search goes on to (<= the former)} per utterance replaces the back-to-back reading of utt_off_dev and the
- * call's one lag; utt_off_dev [u] alone then places utterance u's score rows and penalties: frame f's at row utt_off_dev[u] + f.
+/* For the NEXT search call only: utterances in progress that grow at their own pace.  ext_dev [n_utt][3] int32 = {frames scored
+ * so far, frame the search goes on to (<= the former), nonzero: an utterance that STARTS in this call takes its multiplexed
+ * channels' ssids from mpx_ssid_in_dev -- a decoder's next utterance -- zero: it starts as a new decoder's} per utterance
+ * replaces the back-to-back reading of utt_off_dev and the call's one lag; utt_off_dev [u] alone then places utterance u's score rows and penalties: frame f's at row utt_off_dev[u] + f.
  * Only the frames from the one the search resumes at are read, so a caller that keeps just those passes a start before its
  * buffer (a negative offset).  NULL: off.   psgpu_fwdtree_search_restart: utterance u of the handle's saved searches starts
  * afresh at the next PSGPU_SEARCH_RESUME call (ngram_fwdtree_start for it alone), the others go on. */
@@ -909,11 +910,16 @@ int64_t psgpu_decode_live_frames_searched(const psgpu_decode_t *d);
  *                                 psgpu_decode_fetch_hyps / _fetch_tables return every stream's result record, hypothesis and tables as
  *                                 they stand -- for a stream in mid-utterance what ps_get_hyp would read at that point.  Tables do not
  *                                 grow here (psgpu_decode_table_capacity before _begin): a full one ends its stream with status 1.
- *   psgpu_decode_streams_restart  stream u's next frames begin a new utterance (a new decoder: no session state is inherited).
+ *   psgpu_decode_streams_restart  stream u's next frames begin a new utterance of a NEW decoder (nothing inherited);
+ *   psgpu_decode_streams_next_utt the same decoder's next utterance (below).
  * psgpu_decode_live_frames_searched counts the frames the search stepped through, summed over the streams. */
 int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max_frames, int32_t max_step_frames, void *stream);
 int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_t *n_new, const uint8_t *final_flags, void *stream);
 int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream);
+/* stream u's decoder goes on to its NEXT utterance (ps_start_utt after ps_end_utt on one decoder): like _restart, but the utterance
+ * inherits what a decoder's does -- the scorer's ring slot that seeds its first frame and the multiplexed channels' per-state ssids
+ * (psgpu_decode_session's carry-over, kept per stream).  The stream's previous utterance must have had its final step. */
+int psgpu_decode_streams_next_utt(psgpu_decode_t *d, int32_t u, void *stream);
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
  * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array.  After

@@ -103,6 +103,12 @@ struct psgpu_decode_s {
     int32_t *d_ls = nullptr;             // the step's small tables: chunk offsets [n + 1], row starts [n + 1], {scored, search to} [n][2], window map [n][5]
     uint8_t *d_sseed[2] = { nullptr, nullptr };
     int32_t *d_splc = nullptr;
+    // what a stream's NEXT utterance inherits (psgpu_decode_streams_next_utt): ring slot n_hist - 1 of its scorer as the frames so far
+    // left it (d_sslot, per stream; ls_slot: written since the stream's decoder was new), the multiplexed channels' ssids its latest
+    // search ended with (d_smpx_out) -> what its next utterance starts from (d_smpx_in; ls_mpx: the stream's utterance takes them)
+    uint8_t *d_sslot = nullptr;
+    int32_t *d_smpx_in = nullptr, *d_smpx_out = nullptr;
+    std::vector<uint8_t> ls_slot, ls_mpx;
 };
 
 static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
@@ -165,6 +171,22 @@ void dec_window_kernel(const int32_t *__restrict__ map, int32_t n_streams, int32
     for (int i = threadIdx.x; i < row_dw; i += 256) o[i] = s[i];
     const int32_t *const ps = (r < keep ? pen_old : pen_chunk) + src * n_ci;
     if ((int)threadIdx.x < n_ci) pen_new[dst * n_ci + threadIdx.x] = ps[threadIdx.x];
+}
+
+// ... ring slot n_hist - 1 of every stream's (PTM) scorer: the lists of the step's last frame ts with ts % H == H - 1, if it has one
+// (tcw: the step's lists, chain-major [n_chain][total][topn]; base: the stream's frames before the step)
+__global__ void dec_slot_kernel(const uint8_t *__restrict__ tcw, const int32_t *__restrict__ off1, const int32_t *__restrict__ base, int32_t total,
+                                int32_t n_chain, int32_t topn, int32_t H, uint8_t *__restrict__ slot)
+{
+    const int u = blockIdx.x, n = off1[u + 1] - off1[u], t0 = base[u];
+    int ts = t0 + n - 1;
+    while (ts >= t0 && ts % H != H - 1) --ts;
+    if (ts < t0) return;
+    const size_t at = (size_t)off1[u] + (ts - t0);
+    for (int i = threadIdx.x; i < n_chain * topn; i += blockDim.x) {
+        const int ch = i / topn, k = i - ch * topn;
+        slot[(size_t)u * n_chain * topn + i] = tcw[((size_t)ch * total + at) * topn + k];
+    }
 }
 
 // ... and the scorer's carried lists of the streams that had no frames in the step: the batch scorer writes a carry-out for utterances
@@ -240,7 +262,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_seed); DFREE(d->d_seed_tmp); DFREE(d->d_mpx); DFREE(d->d_mpx_in); DFREE(d->d_noise); DFREE(d->d_undef); DFREE(d->d_ms_id); DFREE(d->d_ms_dist);
     DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_seed0); DFREE(d->d_pl_carry); DFREE(d->d_off1);
     DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
-    DFREE(d->d_splc);
+    DFREE(d->d_splc); DFREE(d->d_sslot); DFREE(d->d_smpx_in); DFREE(d->d_smpx_out);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
@@ -843,14 +865,18 @@ int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max
     const size_t wrows = (size_t)n_streams * ((size_t)max_step_frames + lag + 1), per = (size_t)std::max(1, d->n_chain * d->topn);
     if (wrows > d->win_rows || n_streams > d->ls_n) {
         DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
-        DFREE(d->d_splc);
+        DFREE(d->d_splc); DFREE(d->d_sslot); DFREE(d->d_smpx_in); DFREE(d->d_smpx_out);
         d->win_rows = 0;
         for (int k = 0; k < 2; ++k)
             if ((rc = dec_alloc((void **)&d->d_win[k], 2 * wrows * d->n_sen + 64)) || (rc = dec_alloc((void **)&d->d_wpen[k], 4 * wrows * d->n_ci))
                 || (rc = dec_alloc((void **)&d->d_sseed[k], (size_t)n_streams * per)))
                 return rc;
-        if ((rc = dec_alloc((void **)&d->d_ls, 4 * (size_t)(11 * n_streams + 8)))
-            || (rc = dec_alloc((void **)&d->d_splc, 4 * (size_t)n_streams * psgpu_phone_loop_carry_words())))
+        DFREE(d->d_sslot); DFREE(d->d_smpx_in); DFREE(d->d_smpx_out);
+        const size_t mpxw = (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit;
+        if ((rc = dec_alloc((void **)&d->d_ls, 4 * (size_t)(12 * n_streams + 8)))
+            || (rc = dec_alloc((void **)&d->d_splc, 4 * (size_t)n_streams * psgpu_phone_loop_carry_words()))
+            || (rc = dec_alloc((void **)&d->d_sslot, (size_t)n_streams * per))
+            || (rc = dec_alloc((void **)&d->d_smpx_in, 4 * (size_t)n_streams * mpxw)) || (rc = dec_alloc((void **)&d->d_smpx_out, 4 * (size_t)n_streams * mpxw)))
             return rc;
         d->win_rows = wrows;
     }
@@ -864,7 +890,7 @@ int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max
     d->streams = true; d->ls_first = true; d->ls_n = n_streams; d->ls_cap = max_frames; d->ls_step = max_step_frames; d->ls_lag = lag; d->ls_cur = 0; d->ls_wcur = 0;
     d->ls_searched = 0;
     d->ls_T.assign(n_streams, 0); d->ls_S.assign(n_streams, 0); d->ls_wbase.assign(n_streams, 0); d->ls_woff.assign(n_streams, 0);
-    d->ls_fresh.assign(n_streams, 0);
+    d->ls_fresh.assign(n_streams, 0); d->ls_slot.assign(n_streams, 0); d->ls_mpx.assign(n_streams, 0);
     d->n_utt = n_streams; d->total = 0; d->max_frames = max_frames; d->searched = false; d->pass2 = false; d->first_called = true;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     d->frame_off.assign((size_t)n_streams + 1, 0);
@@ -881,6 +907,7 @@ int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream)
     hipStream_t st = (hipStream_t)stream;
     int rc;
     d->ls_T[u] = 0; d->ls_S[u] = 0; d->ls_wbase[u] = 0; d->ls_woff[u] = 0; d->ls_fresh[u] = 1;
+    d->ls_slot[u] = 0; d->ls_mpx[u] = 0;                  // (a new decoder: nothing inherited)
     if (!d->ls_first && (rc = psgpu_fwdtree_search_restart(d->cfg.ft, u, st))) return rc;
     if ((rc = psgpu_phone_loop_carry_restart(d->d_splc, u, st))) return rc;
     const size_t per = (size_t)std::max(1, d->n_chain * d->topn);
@@ -888,6 +915,23 @@ int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream)
     for (size_t i = 0; i < per; ++i) seed[i] = (uint8_t)(d->topn > 0 ? i % d->topn : 0);
     PSGPU_HIP(hipMemcpyAsync(d->d_sseed[d->ls_cur] + (size_t)u * per, seed.data(), per, hipMemcpyHostToDevice, st));
     PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
+}
+
+// Stream u's decoder goes on to its NEXT utterance: what ps_start_utt leaves in place (the scorer's ring slot that seeds the first
+// frame, the multiplexed channels' ssids -- psgpu_decode_session's carry-over, per stream), everything else afresh.
+int psgpu_decode_streams_next_utt(psgpu_decode_t *d, int32_t u, void *stream)
+{
+    PSGPU_REQUIRE(d && d->streams && u >= 0 && u < d->ls_n, "psgpu_decode_streams_next_utt: bad argument");
+    PSGPU_REQUIRE(!d->ls_first, "psgpu_decode_streams_next_utt: the stream has had no utterance yet");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const size_t per = (size_t)std::max(1, d->n_chain * d->topn), mpxw = (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit;
+    const uint8_t slot = d->ls_slot[u];
+    if ((rc = psgpu_decode_streams_restart(d, u, stream))) return rc;       // (search, phone loop, window; the lists: a new scorer's)
+    d->ls_slot[u] = slot; d->ls_mpx[u] = 1;
+    PSGPU_HIP(hipMemcpyAsync(d->d_smpx_in + (size_t)u * mpxw, d->d_smpx_out + (size_t)u * mpxw, 4 * mpxw, hipMemcpyDeviceToDevice, st));
+    if (slot) PSGPU_HIP(hipMemcpyAsync(d->d_sseed[d->ls_cur] + (size_t)u * per, d->d_sslot + (size_t)u * per, per, hipMemcpyDeviceToDevice, st));
     return PSGPU_OK;
 }
 
@@ -899,8 +943,8 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
     int rc;
     // the step's tables
     std::vector<int32_t> &h = d->ls_h;
-    h.assign((size_t)11 * n + 8, 0);
-    int32_t *const off1 = h.data(), *const uoff = off1 + n + 1, *const ext = uoff + n + 1, *const map = ext + 2 * n, *const fbase = map + 5 * n;
+    h.assign((size_t)12 * n + 8, 0);
+    int32_t *const off1 = h.data(), *const uoff = off1 + n + 1, *const ext = uoff + n + 1, *const map = ext + 3 * n, *const fbase = map + 5 * n;
     size_t total = 0, wtot = 0;
     int64_t searched = 0;
     for (int u = 0; u < n; ++u) {
@@ -914,7 +958,7 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
         map[5 * u] = d->ls_woff[u] + (S0 - d->ls_wbase[u]); map[5 * u + 1] = keep; map[5 * u + 2] = off1[u]; map[5 * u + 3] = n_new[u];
         map[5 * u + 4] = (int32_t)wtot;
         uoff[u] = (int32_t)wtot - S0;                    // frame f's row: (uoff + f) -- the window starts at frame S0
-        ext[2 * u] = T; ext[2 * u + 1] = S;
+        ext[3 * u] = T; ext[3 * u + 1] = S; ext[3 * u + 2] = d->ls_mpx[u];
         searched += S - S0;
         wtot += (size_t)keep + n_new[u];
     }
@@ -924,7 +968,7 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
     PSGPU_HIP(hipMemcpyAsync(d->d_ls, h.data(), 4 * h.size(), hipMemcpyHostToDevice, st));
     if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * d->veclen, hipMemcpyHostToDevice, st));
     PSGPU_HIP(hipStreamSynchronize(st));                 // (feat is the caller's)
-    const int32_t *const d_off1 = d->d_ls, *const d_uoff = d->d_ls + n + 1, *const d_ext = d_uoff + n + 1, *const d_map = d_ext + 2 * n,
+    const int32_t *const d_off1 = d->d_ls, *const d_uoff = d->d_ls + n + 1, *const d_ext = d_uoff + n + 1, *const d_map = d_ext + 3 * n,
                   *const d_fbase = d_map + 5 * n;
     const size_t per = (size_t)std::max(1, d->n_chain * d->topn);
     if (total) {
@@ -936,8 +980,19 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
                                                d->d_best, d->compall ? 0u : PSGPU_PTM_RAW_SCORES, st);
             else
                 rc = psgpu_semi_score_batch_carry_dev((psgpu_semi_model_t *)d->cfg.scorer, d->d_feat, d_off1, n, (int32_t)total, seed_in, seed_out,
-                                                      nullptr, d->cfg.pl_window + 2, d_fbase, d->d_rows, st);
+                                                      d->d_sslot, d->cfg.pl_window + 2, d_fbase, d->d_rows, st);
             if (rc) return rc;
+            if (d->kind == PSGPU_SCORER_PTM) {
+                hipLaunchKernelGGL(dec_slot_kernel, dim3((unsigned)n), dim3(64), 0, st, d->d_tcw, d_off1, d_fbase, (int32_t)total, d->n_chain, d->topn,
+                                   d->cfg.pl_window + 2, d->d_sslot);
+                PSGPU_HIP(hipGetLastError());
+            }
+            for (int u = 0; u < n; ++u) {                // (the ring slot was written if the step held a frame ts with ts % H == H - 1)
+                const int H = d->cfg.pl_window + 2, a = d->ls_T[u];
+                int ts = a + n_new[u] - 1;
+                while (ts >= a && ts % H != H - 1) --ts;
+                if (ts >= a) d->ls_slot[u] = 1;
+            }
             hipLaunchKernelGGL(dec_seed_keep_kernel, dim3((unsigned)n), dim3(64), 0, st, d_off1, n, (int32_t)per, seed_in, seed_out);
             PSGPU_HIP(hipGetLastError());
             d->ls_cur ^= 1;
@@ -966,14 +1021,14 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
     if ((rc = psgpu_fwdtree_search_resume(d->cfg.ft, PSGPU_SEARCH_KEEP | (d->ls_first ? 0 : PSGPU_SEARCH_RESUME)))) return rc;
     if ((rc = psgpu_fwdtree_search_session_dev(d->cfg.ft, d->d_win[wn], d->n_sen, d->d_wpen[wn], d_uoff, n, d->ls_cap, d->bp_cap, d->bss_cap,
                                                d->d_bp, d->d_bss, d->d_idx, d->d_step, d->d_res, d->raw_flag, d->cfg.pl_window, d->d_w1,
-                                               nullptr, nullptr, st)))
+                                               d->d_smpx_in, d->d_smpx_out, st)))
         return rc;
     d->ls_first = false; d->searched = true; d->pass2 = false; d->last_lag = 0; d->last_chained = false; d->last_sess = false;
     d->ls_searched += searched;
     size_t acc = 0;
     for (int u = 0; u < n; ++u) {
         d->ls_wbase[u] = d->ls_S[u]; d->ls_woff[u] = map[5 * u + 4];
-        d->ls_T[u] = ext[2 * u]; d->ls_S[u] = ext[2 * u + 1]; d->ls_fresh[u] = 0;
+        d->ls_T[u] = ext[3 * u]; d->ls_S[u] = ext[3 * u + 1]; d->ls_fresh[u] = 0;
         d->frame_off[u] = (int32_t)acc; acc += (size_t)d->ls_T[u];
     }
     d->frame_off[n] = (int32_t)acc; d->total = (int32_t)std::min<size_t>(acc, 0x7fffffff);

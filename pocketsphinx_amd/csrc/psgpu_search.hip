@@ -152,8 +152,9 @@ struct FtBufs {
     // stay where they are between the calls
     int32_t *live;
     int32_t live_mode;                   // bit 0: save the state when the call stops; bit 1: start from the saved state
-    // psgpu_fwdtree_search_streams: per utterance {frames scored so far, frame the search goes on to} instead of back-to-back offsets
-    // and one lag: utterances in progress that grow at their own pace; utt_off [u] alone places the utterance's rows (row of frame f
+    // psgpu_fwdtree_search_streams: per utterance {frames scored so far, frame the search goes on to, whether an utterance that STARTS
+    // in this call takes its multiplexed channels' ssids from mpx_in (a decoder's next utterance) or keeps a new decoder's} instead of
+    // back-to-back offsets and one lag: utterances in progress that grow at their own pace; utt_off [u] alone places the utterance's rows (row of frame f
     // at (utt_off[u] + f) * stride: a caller that keeps only the frames not yet searched passes a start before its buffer)
     const int32_t *ext;
 };
@@ -995,7 +996,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // over the last pl_window frames only `if (output_frame >= pl_window)` (pocketsphinx.c:1329-1333)
     // (bf.lag > 0: an utterance in progress -- the phone loop has seen T_in frames, the search steps through the first
     //  T_in - lag of them, as ps_search_forward leaves the two between calls, pocketsphinx.c:1173-1197)
-    const int32_t *const ext = bf.ext ? psgpu_as_global(bf.ext) + 2 * (size_t)blockIdx.x : nullptr;
+    const int32_t *const ext = bf.ext ? psgpu_as_global(bf.ext) + 3 * (size_t)blockIdx.x : nullptr;
     const int t0 = utt_off[blockIdx.x], T_in = ext ? ext[0] : utt_off[blockIdx.x + 1] - t0,
               T = ext ? min(ext[1], T_in) : (bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in));
     const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
@@ -1118,7 +1119,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // a session's second and later utterances: the multiplexed permanent channels (roots, single-phone words) start with the
     // per-state ssids the previous utterance left -- hmm_clear (hmm.c:181-196) resets scores and histories only, and a
     // state's ssid decides which senone the search lists for it
-    if (bf.mpx_in && !resumed) {
+    if (bf.mpx_in && !resumed && (!ext || ext[2])) {
         const int32_t *const mi = psgpu_as_global(bf.mpx_in) + (size_t)blockIdx.x * (R + n1) * NE;
         for (int i = tid; i < (R + n1) * NE; i += NT) {
             const int q = i / NE, c = q < R ? q : W1 + (q - R);

@@ -254,6 +254,10 @@ class DecodePipeline:
     def streams_restart(self, u):
         capi.check(capi.lib().psgpu_decode_streams_restart(self.h, int(u), self._stream), "psgpu_decode_streams_restart")
 
+    def streams_next_utt(self, u):
+        """psgpu_decode_streams_next_utt: stream u's decoder goes on to its next utterance (the session's carry-over, per stream)"""
+        capi.check(capi.lib().psgpu_decode_streams_next_utt(self.h, int(u), self._stream), "psgpu_decode_streams_next_utt")
+
     def live_frames_searched(self):
         f = capi.lib().psgpu_decode_live_frames_searched
         f.restype = C.c_int64

@@ -166,7 +166,7 @@ def search_windows(s, senscr, penalties, cuts, lag, bp_cap=16384, bss_cap=1 << 1
         last = k == len(cuts) - 1
         to = c if last else max(c - lag, S)
         win_s = np.ascontiguousarray(d_s[S:c]); win_p = np.ascontiguousarray(d_p[S:c])       # what a stream still holds
-        off = np.array([-S, 0], np.int32); ext = np.array([c, to], np.int32)
+        off = np.array([-S, 0], np.int32); ext = np.array([c, to, 0], np.int32)
         check(lib().psgpu_fwdtree_search_streams(s.h, p(ext)), "psgpu_fwdtree_search_streams")
         check(lib().psgpu_fwdtree_search_resume(s.h, 1 if k == 0 else 3), "psgpu_fwdtree_search_resume")
         check(lib().psgpu_fwdtree_search_session_dev(s.h, p(win_s), C.c_int64(s.n_sen), p(win_p), p(off), 1, T, bp_cap, bss_cap,
@@ -202,7 +202,7 @@ def search_streams(s, utts, schedule, lag, bp_cap=16384, bss_cap=1 << 19):
                     check(lib().psgpu_fwdtree_search_restart(s.h, u, None), "psgpu_fwdtree_search_restart")
             to = c if fin else max(c - lag, S[u])
             wins.append(cur[u][0][S[u]:c]); pens.append(cur[u][1][S[u]:c])
-            off.append(at - S[u]); ext += [c, to]
+            off.append(at - S[u]); ext += [c, to, 0]
             at += c - S[u]; S[u] = to
         win_s = np.ascontiguousarray(np.concatenate(wins)) if at else np.zeros((1, s.n_sen), np.int16)
         win_p = np.ascontiguousarray(np.concatenate(pens)) if at else np.zeros((1, s.n_ci), np.int32)

@@ -427,3 +427,41 @@ def test_live_utterance_begun_again_with_more_room(tables):
     _check(r, g, "begun again")
     assert p.live_frames_searched() == (90 - lag) + f2.shape[0]
     p.close()
+
+
+def test_streams_next_utterance_of_a_decoder(tables):
+    """psgpu_decode_streams_next_utt: stream 0 is ONE decoder's session -- numbers.raw, then goforward.raw, whose tables must be the
+    reference decoder's for the second utterance of that session (the scorer's ring slot and the multiplexed channels' ssids inherited:
+    other tables than a new decoder's); stream 1 beside it decodes goforward.raw as a new decoder, restarted (not continued) in between,
+    and must give the new decoder's tables both times."""
+    p = _pipeline(tables)
+    g1, g2, gn = _load("fwdtree_trace_numbers.npz"), _load("fwdtree_trace_goforward_after_numbers.npz"), _load("fwdtree_trace_goforward.npz")
+    f1, f2 = _session_feats(tables)                        # (numbers, then goforward as the same decoder's front end computes it)
+    fn = _fresh_feats("goforward")
+    assert not np.array_equal(g2["bp"], gn["bp"]) if g2["bp"].shape == gn["bp"].shape else True
+
+    def check(u, g, what):
+        hn, hyp, res = p.fetch()
+        r = p.tables(u, res)
+        r["step"] = np.stack([g["step_best"], g["step_lpbest"], g["step_bpidx"]], axis=1)
+        _check(r, g, what)
+        assert int(hn[u, 1]) == int(g["hyp_score"][0])
+    p.streams_begin(2, 420, 64)
+
+    def feed(fa, fb, pa, pb):
+        ia = ib = 0
+        while ia < fa.shape[0] or ib < fb.shape[0]:
+            ka, kb = min(pa, fa.shape[0] - ia), min(pb, fb.shape[0] - ib)
+            p.streams_step([fa[ia:ia + ka], fb[ib:ib + kb]], [ka > 0 and ia + ka == fa.shape[0], kb > 0 and ib + kb == fb.shape[0]])
+            if ka > 0 and ia + ka == fa.shape[0]:
+                yield 0
+            if kb > 0 and ib + kb == fb.shape[0]:
+                yield 1
+            ia += ka; ib += kb
+    for u in feed(f1, fn, 37, 50):
+        check(u, g1 if u == 0 else gn, "first utterances, stream %d" % u)
+    p.streams_next_utt(0)                                  # the same decoder goes on
+    p.streams_restart(1)                                   # a new decoder
+    for u in feed(f2, fn, 29, 64):
+        check(u, g2 if u == 0 else gn, "second utterances, stream %d" % u)
+    p.close()
