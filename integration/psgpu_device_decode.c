@@ -73,6 +73,11 @@ struct psgpu_device_decode_s {
      * refused (then every read-out decodes the prefix again, as before) */
     int live_on, live_fed, live_cap, live_off;
     int inj_nb, inj_nh, inj_nfr;       /* what the latest read-out of the live utterance put into the decoder's tables */
+    /* a member of a group of live decoders (psgpu_live_group_create): stream gidx of the group's pipeline; g_fed frames of the
+     * utterance in progress handed over; g_final: its ps_end_utt is in progress (1) / its last frames are on the device (2);
+     * g_utts utterances finished */
+    struct psgpu_live_group_s *grp;
+    int gidx, g_fed, g_final, g_utts;
     long live_steps, live_restarts;
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
@@ -80,6 +85,18 @@ struct psgpu_device_decode_s {
     int n_fast_hist, n1, n_emit;
     uint8_t *h_tcw; size_t cap_tcw;
 };
+
+/* N decoders, ONE pipeline in streams mode (psgpu_decode_streams_*): see psgpu_live_group_create */
+struct psgpu_live_group_s {
+    int n, cap, step_cap;
+    psgpu_device_decode_t **m;
+    psgpu_decode_t *dec;               /* member 0's pipeline object */
+    void *st;
+    float *feat; int32_t *n_new; uint8_t *fin;
+    int32_t *h_res, *h_hn;             /* [n][8], [n][4]: every stream's result record after the latest step */
+    long steps;
+};
+static int group_step(struct psgpu_live_group_s *g);
 
 #define FREE_DEV(p) do { psgpu_free(p); (p) = NULL; } while (0)
 #define FREE_HOST(p) do { ckd_free(p); (p) = NULL; } while (0)
@@ -338,15 +355,17 @@ static int
 fetch_and_inject_from(psgpu_device_decode_t *d, int u, int b0, int h0, int f0)
 {
     ngram_search_t *ngs = (ngram_search_t *)d->ps->search;
-    const int32_t *res = d->h_res + (size_t)u * 8;
+    psgpu_decode_t *dec = d->grp ? d->grp->dec : d->dec;         /* (a group's member: stream gidx of the group's pipeline) */
+    const int32_t *res = d->grp ? d->grp->h_res + (size_t)d->gidx * 8 : d->h_res + (size_t)u * 8;
     int nb = res[0], nh = res[1], nfr = res[2];
+    if (d->grp) u = d->gidx;
     if (res[3]) { E_ERROR("psgpu device decode: utterance %d: back-pointer table or score stack full\n", u); return -1; }
     if (b0 > nb || h0 > nh || f0 > nfr) b0 = h0 = f0 = 0;
     if ((size_t)nb * 10 > d->cap_bp) { FREE_HOST(d->h_bp); d->cap_bp = (size_t)nb * 15 + 640; d->h_bp = ckd_calloc(d->cap_bp, 4); }
     if ((size_t)nh > d->cap_bss) { FREE_HOST(d->h_bss); d->cap_bss = (size_t)nh + nh / 2 + 64; d->h_bss = ckd_calloc(d->cap_bss, 4); }
     if ((size_t)nfr + 1 > d->cap_idx) { FREE_HOST(d->h_idx); d->cap_idx = (size_t)nfr + nfr / 2 + 64; d->h_idx = ckd_calloc(d->cap_idx, 4); }
-    if (psgpu_decode_fetch_tables_range(d->dec, u, b0, nb - b0, h0, nh - h0, f0, nfr + 1 - f0, d->h_bp, d->h_bss, d->h_idx,
-                                        psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
+    if (psgpu_decode_fetch_tables_range(dec, u, b0, nb - b0, h0, nh - h0, f0, nfr + 1 - f0, d->h_bp, d->h_bss, d->h_idx,
+                                        d->grp ? d->grp->st : psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
@@ -525,6 +544,13 @@ dev_search_start(ps_search_t *search)
     psgpu_device_decode_t *d = find_attached(search);
     if (d == NULL) return -1;
     d->n_feat = 0; d->pl_frames = 0; d->n_partial = -1;
+    if (d->grp) {                                        /* the decoder's next utterance on its stream of the group's pipeline */
+        d->g_fed = 0; d->g_final = 0;
+        if (d->g_utts > 0 && psgpu_decode_streams_next_utt(d->grp->dec, d->gidx, d->grp->st) != PSGPU_OK) {
+            E_ERROR("psgpu live group: %s\n", psgpu_last_error());
+            return -1;
+        }
+    }
     d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0;
     d->inj_nb = d->inj_nh = d->inj_nfr = 0;
     return d->orig_vt->start(search);          /* ngram_search_start: tables, timers, <s> entered (ngram_search_fwdtree.c:469-520) */
@@ -567,6 +593,16 @@ dev_search_finish(ps_search_t *search)
     /* the reference's end-of-pass housekeeping on its own (idle) channels and timers; its mark of "one past the last
      * frame" is overwritten by the injected marks below */
     ngram_fwdtree_finish(ngs);
+    if (d->n_feat > 0 && d->grp) {
+        /* a group's member: its remaining frames go with the other members' pending ones, its search to the utterance's end */
+        d->g_final = 1;
+        if (group_step(d->grp) < 0) return -1;
+        if (d->grp->h_res[(size_t)d->gidx * 8 + 2] > 0 && (nfr = fetch_and_inject_from(d, 0, d->inj_nb, d->inj_nh, d->inj_nfr)) < 0) return -1;
+        ++d->g_utts;
+        ngs->n_tot_frame += nfr;
+        ngs->done = TRUE;
+        return 0;
+    }
     if (d->n_feat > 0) {
         if (d->live_on) {                                /* the utterance's remaining frames, the search to its end (lag 0) */
             if (live_advance(d, ngs, d->n_feat, 1) <= 0) return -1;
@@ -727,6 +763,18 @@ partial_refresh(psgpu_device_decode_t *d, ngram_search_t *ngs)
     int T = d->pl_frames > d->n_feat ? d->pl_frames : d->n_feat, t, s;
     int32_t off[2];
     float *feat;
+    if (d->grp) {
+        /* a group's member: one step of the group's pipeline if this decoder has frames the device has not seen (the other members'
+         * pending frames go with them), then what its tables have grown by */
+        const int32_t *res = d->grp->h_res + (size_t)d->gidx * 8;
+        if (d->n_feat == 0) return 0;
+        if (T > d->g_fed && group_step(d->grp) < 0) return -1;
+        if (res[2] > 0) {
+            if (fetch_and_inject_from(d, 0, d->inj_nb, d->inj_nh, d->inj_nfr) < 0) return -1;
+            d->inj_nb = res[0]; d->inj_nh = res[1]; d->inj_nfr = res[2];
+        }
+        return 0;
+    }
     if (d->n_feat == 0 || d->n_partial == d->n_feat) return 0;
     if ((t = live_advance(d, ngs, T, 0)) != 0) {
         if (t < 0 || fetch_summary(d, 1) < 0) return -1;
@@ -782,6 +830,109 @@ dev_search_seg_iter(ps_search_t *search)
     if (d == NULL) return NULL;
     if (!ngs->done && partial_refresh(d, ngs) < 0) return NULL;
     return d->orig_vt->seg_iter(search);
+}
+
+/* ---- a group of live decoders -------------------------------------------------------------------------------------------------
+ * N decoders whose n-gram searches are bound to the device (psgpu_device_search_attach each), ONE pipeline object in streams mode
+ * (member 0's; psgpu_decode_streams_*): a step hands over every member's frames the device has not seen -- the search's own and the
+ * phone loop's look-ahead, as live_advance does for one decoder -- in one launch set; every member's hyp / seg_iter then read its
+ * tables as they stand.  A member's ps_end_utt ends its stream's utterance, its next ps_start_utt goes on as the same decoder
+ * (psgpu_decode_streams_next_utt).  -fwdflat no (the reference's second pass reads host state the group does not keep up to date). */
+static int
+group_step(struct psgpu_live_group_s *g)
+{
+    int again;
+    do {
+        size_t at = 0;
+        int u;
+        again = 0;
+        for (u = 0; u < g->n; ++u) {
+            psgpu_device_decode_t *d = g->m[u];
+            acmod_t *acmod = ps_search_acmod(d->ps->search);
+            int T = d->g_final ? d->n_feat : (d->pl_frames > d->n_feat ? d->pl_frames : d->n_feat);
+            int k = T - d->g_fed, t, whole = 1;
+            if (d->g_final == 2 || k < 0) k = 0;
+            if (k > g->step_cap) { k = g->step_cap; again = 1; whole = 0; }
+            for (t = 0; t < k; ++t)
+                if (copy_frame(d, acmod, d->g_fed + t, g->feat + (at + t) * d->veclen) < 0) { k = t; whole = 0; break; }
+            g->n_new[u] = k;
+            g->fin[u] = (uint8_t)(d->g_final == 1 && whole);
+            at += (size_t)k;
+        }
+        if (psgpu_decode_streams_step(g->dec, g->feat, g->n_new, g->fin, g->st) != PSGPU_OK) {
+            E_ERROR("psgpu live group: %s\n", psgpu_last_error());
+            return -1;
+        }
+        for (u = 0; u < g->n; ++u) {
+            g->m[u]->g_fed += g->n_new[u];
+            if (g->fin[u]) g->m[u]->g_final = 2;
+        }
+    } while (again);
+    if (psgpu_decode_fetch_hyps(g->dec, g->h_hn, NULL, g->h_res, g->st) != PSGPU_OK) {
+        E_ERROR("psgpu live group: %s\n", psgpu_last_error());
+        return -1;
+    }
+    ++g->steps;
+    return 0;
+}
+
+int
+psgpu_live_group_step(struct psgpu_live_group_s *g)
+{
+    return g ? group_step(g) : -1;
+}
+
+struct psgpu_live_group_s *
+psgpu_live_group_create(psgpu_device_decode_t *const *members, int n, int max_frames, int max_step_frames)
+{
+    struct psgpu_live_group_s *g;
+    int u;
+    if (members == NULL || n < 1 || max_frames < 1 || max_step_frames < 1) return NULL;
+    for (u = 0; u < n; ++u) {
+        psgpu_device_decode_t *d = members[u];
+        if (d == NULL || d->orig_vt == NULL || d->grp || d->veclen != members[0]->veclen || d->n_sen != members[0]->n_sen) {
+            E_ERROR("psgpu live group: member %d is not a decoder bound with psgpu_device_search_attach, is in a group already, or has another model\n", u);
+            return NULL;
+        }
+        if (((ngram_search_t *)d->ps->search)->fwdflat) {
+            E_ERROR("psgpu live group: -fwdflat no (member %d)\n", u);
+            return NULL;
+        }
+    }
+    g = ckd_calloc(1, sizeof *g);
+    g->n = n; g->cap = max_frames; g->step_cap = max_step_frames;
+    g->m = ckd_calloc(n, sizeof *g->m);
+    g->dec = members[0]->dec; g->st = psgpu_hmm_ctx_stream(members[0]->ctx);
+    g->feat = ckd_calloc((size_t)n * max_step_frames * members[0]->veclen + 1, sizeof(float));
+    g->n_new = ckd_calloc(n, sizeof *g->n_new); g->fin = ckd_calloc(n, 1);
+    g->h_res = ckd_calloc((size_t)n * 8, 4); g->h_hn = ckd_calloc((size_t)n * 4, 4);
+    if (refresh(members[0]) < 0 || psgpu_decode_streams_begin(g->dec, n, max_frames, max_step_frames, g->st) != PSGPU_OK) {
+        E_ERROR("psgpu live group: %s\n", psgpu_last_error());
+        ckd_free(g->m); ckd_free(g->feat); ckd_free(g->n_new); ckd_free(g->fin); ckd_free(g->h_res); ckd_free(g->h_hn); ckd_free(g);
+        return NULL;
+    }
+    for (u = 0; u < n; ++u) {
+        g->m[u] = members[u];
+        members[u]->grp = g; members[u]->gidx = u; members[u]->g_fed = 0; members[u]->g_final = 0; members[u]->g_utts = 0;
+    }
+    return g;
+}
+
+void
+psgpu_live_group_free(struct psgpu_live_group_s *g)
+{
+    int u;
+    if (g == NULL) return;
+    for (u = 0; u < g->n; ++u) if (g->m[u]) g->m[u]->grp = NULL;
+    ckd_free(g->m); ckd_free(g->feat); ckd_free(g->n_new); ckd_free(g->fin); ckd_free(g->h_res); ckd_free(g->h_hn);
+    ckd_free(g);
+}
+
+long
+psgpu_live_group_stats(struct psgpu_live_group_s *g, long *steps)
+{
+    if (steps) *steps = g ? g->steps : 0;
+    return g ? (long)psgpu_decode_live_frames_searched(g->dec) : 0;
 }
 
 void

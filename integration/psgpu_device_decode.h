@@ -37,6 +37,20 @@ void psgpu_device_search_detach(psgpu_device_decode_t *d);
  * capacity it was begun with and was begun again (3,000 frames at first, doubling). */
 void psgpu_device_search_live_stats(psgpu_device_decode_t *d, long *frames_searched, long *steps, long *restarts);
 
+/* ---- a group of live decoders: N decoders (each: psgpu_mgau_attach, psgpu_device_decode_attach, psgpu_device_search_attach; the same
+ * model, dictionary and LM; -fwdflat no), ONE device pipeline in streams mode (psgpu_decode_streams_*, member 0's object).  The
+ * application drives every decoder with the UNMODIFIED calls -- ps_start_utt, ps_process_raw(..., FALSE, FALSE) as its audio arrives,
+ * ps_get_hyp / ps_seg_iter, ps_end_utt -- and calls psgpu_live_group_step after a round of ps_process_raw calls: one launch set hands
+ * over every member's new frames (at most max_step_frames a member a launch set: more are handed over in several) and lets all
+ * searches go on; the members' read-outs then return what the CPU decoder would at that point.  (A read-out of a member that has
+ * frames the device has not seen, and a member's ps_end_utt, step the group themselves.)  max_frames: the longest utterance. */
+typedef struct psgpu_live_group_s psgpu_live_group_t;
+psgpu_live_group_t *psgpu_live_group_create(psgpu_device_decode_t *const *members, int n, int max_frames, int max_step_frames);
+int psgpu_live_group_step(psgpu_live_group_t *g);
+void psgpu_live_group_free(psgpu_live_group_t *g);
+/* frames the device searches have stepped through since the group was created (returned) and launch sets so far */
+long psgpu_live_group_stats(psgpu_live_group_t *g, long *steps);
+
 /* = ps_start_utt; ps_process_raw(pcm, n, FALSE, TRUE); ps_end_utt -- with front end, features, senone
  * scores, phone loop and lexicon-tree search on the device; afterwards the decoder's back-pointer
  * table, score stack and frame marks hold the result in the reference's layout, so ps_get_hyp(),

@@ -693,3 +693,23 @@ def test_dropin_device_search_semi_continuous_partial_results(extra, tmp_path):
     assert r["ok"] and r["rc"] == 0, r
     assert r["partial_equal"] and r["partial_results"] >= 9 and r["hyp_equal"] and r["seg_equal"], r
     assert r["live_frames_searched"] == r["live_utt_frames"] > 0 and r["live_restarts"] == 0, r
+
+
+@pytest.mark.gpu
+def test_dropin_group_of_live_decoders():
+    """psgpu_live_group_create: THREE reference decoders, their n-gram searches bound to the device, ONE device pipeline in streams mode
+    (integration/psgpu_device_decode.c group_step; checker oracle/streams_decode.c).  Every decoder is driven by the unmodified calls --
+    ps_start_utt, ps_process_raw in pieces of its own size, ps_get_hyp after every round, ps_end_utt, the next utterance on the same
+    decoder -- beside a CPU decoder fed the same pieces: every partial hypothesis and score, every final hypothesis, score and
+    segmentation are equal (a stream's second utterance inherits what a decoder's does), and the device searched each frame once."""
+    exe = os.path.join(REF, "streams_decode")
+    if not os.path.exists(exe):
+        pytest.fail("oracle/_ref/streams_decode is missing: run __graft_entry__.build() where /root/reference is present")
+    argv = [exe, MODEL, os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "turtle.dic"), DATA, "3",
+            "goforward,numbers;numbers,something;something,goforward,numbers", "2048,4096,3000", "fwdflat", "no", "bestpath", "no"]
+    p = subprocess.run(argv, capture_output=True, text=True, timeout=600)
+    assert p.stdout.strip(), "no output (rc %d): %s" % (p.returncode, p.stderr[-2000:])
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["ok"] and p.returncode == 0, r
+    assert r["partial_results"] >= 30 and r["partial_mismatches"] == 0 and r["final_results"] == 7 and r["final_mismatches"] == 0, r
+    assert r["frames_searched"] == r["frames"] > 0, r
