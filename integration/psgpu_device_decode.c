@@ -77,7 +77,7 @@ struct psgpu_device_decode_s {
      * utterance in progress handed over; g_final: its ps_end_utt is in progress (1) / its last frames are on the device (2);
      * g_utts utterances finished */
     struct psgpu_live_group_s *grp;
-    int gidx, g_fed, g_final, g_utts;
+    int gidx, g_fed, g_final, g_utts, g_dirty, g_done;
     long live_steps, live_restarts;
     /* the second pass on the device as well (PSGPU_DEVICE_SECOND_PASS=1 with -fwdflat yes) */
     psgpu_fwdflat_t *ff;
@@ -546,10 +546,16 @@ dev_search_start(ps_search_t *search)
     d->n_feat = 0; d->pl_frames = 0; d->n_partial = -1;
     if (d->grp) {                                        /* the decoder's next utterance on its stream of the group's pipeline */
         d->g_fed = 0; d->g_final = 0;
-        if (d->g_utts > 0 && psgpu_decode_streams_next_utt(d->grp->dec, d->gidx, d->grp->st) != PSGPU_OK) {
+        /* (g_dirty: the stream has been fed frames since it was begun / last moved on -- also by another member's group_step
+         *  taking this member's look-ahead frames along; g_done: that utterance was searched to its end, the next one inherits
+         *  from it -- otherwise the stream starts its utterance over from what it began with) */
+        if (d->g_dirty
+            && (d->g_done ? psgpu_decode_streams_next_utt(d->grp->dec, d->gidx, d->grp->st)
+                          : psgpu_decode_streams_restart(d->grp->dec, d->gidx, d->grp->st)) != PSGPU_OK) {
             E_ERROR("psgpu live group: %s\n", psgpu_last_error());
             return -1;
         }
+        d->g_dirty = 0; d->g_done = 0;
     }
     d->live_on = 0; d->live_fed = 0; d->live_steps = 0; d->live_restarts = 0;
     d->inj_nb = d->inj_nh = d->inj_nfr = 0;
@@ -579,6 +585,7 @@ dev_search_step(ps_search_t *search, int frame_idx)
         dst += feat_dimension2(acmod->fcb, s);
     }
     ++d->n_feat;
+    grow_frames((ngram_search_t *)search, d->n_feat + 1);       /* what the reference's per-frame ngram_search_mark_bptable keeps true */
     return 1;
 }
 
@@ -591,7 +598,13 @@ dev_search_finish(ps_search_t *search)
     int nfr = 0, live = 0;
     if (d == NULL) return -1;
     /* the reference's end-of-pass housekeeping on its own (idle) channels and timers; its mark of "one past the last
-     * frame" is overwritten by the injected marks below */
+     * frame" is overwritten by the injected marks below.  ngram_fwdtree_finish marks frame output_frame
+     * (ngram_search_fwdtree.c:1505-1507) and ngram_search_mark_bptable doubles the frame marks only ONCE
+     * (ngram_search.c:326-338) because the reference's own search calls it every frame; this binding searches nothing on
+     * the host, so the marks are grown to the utterance's length here first (dev_search_step grows them as frames arrive
+     * too: the reference's per-frame guarantee) */
+    grow_frames(ngs, ps_search_acmod(ngs)->output_frame + 1);
+    if (d->n_feat + 1 > ps_search_acmod(ngs)->output_frame + 1) grow_frames(ngs, d->n_feat + 1);
     ngram_fwdtree_finish(ngs);
     if (d->n_feat > 0 && d->grp) {
         /* a group's member: its remaining frames go with the other members' pending ones, its search to the utterance's end */
@@ -721,7 +734,7 @@ live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final)
     acmod_t *acmod = ps_search_acmod(ngs);
     void *st = psgpu_hmm_ctx_stream(d->ctx);
     float *feat;
-    int t, from;
+    int t, from, lag;
     if (d->live_off) return 0;
     if (!d->live_on || T > d->live_cap) {
         int cap = d->live_on ? 2 * d->live_cap : 3000;            /* (30 s; doubles) */
@@ -740,8 +753,12 @@ live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final)
     feat = ckd_calloc((size_t)(T - from) * d->veclen + 1, sizeof(float));
     for (t = from; t < T; ++t)
         if (copy_frame(d, acmod, t, feat + (size_t)(t - from) * d->veclen) < 0) { T = t; break; }
-    /* (mid-utterance: the n-gram search has been stepped through n_feat frames, the phone loop through T) */
-    if (psgpu_decode_live_step(d->dec, feat, T - from, final ? 0 : (T > d->n_feat ? T - d->n_feat : 0), st) != PSGPU_OK) {
+    /* (mid-utterance: the n-gram search has been stepped through n_feat frames, the phone loop through T -- pl_window frames
+     *  more (pocketsphinx.c:1173-1197).  Should look-ahead frames be missing (copy_frame failed above), the device search stays
+     *  pl_window frames behind what it was given rather than searching frames with clamped look-ahead penalties) */
+    lag = final ? 0 : (T > d->n_feat ? T - d->n_feat : 0);
+    if (lag > 0 && lag < d->ps->pl_window) lag = d->ps->pl_window;
+    if (psgpu_decode_live_step(d->dec, feat, T - from, lag, st) != PSGPU_OK) {
         E_ERROR("psgpu device search (live utterance): %s\n", psgpu_last_error());
         ckd_free(feat);
         return -1;
@@ -865,7 +882,8 @@ group_step(struct psgpu_live_group_s *g)
         }
         for (u = 0; u < g->n; ++u) {
             g->m[u]->g_fed += g->n_new[u];
-            if (g->fin[u]) g->m[u]->g_final = 2;
+            if (g->n_new[u] > 0) g->m[u]->g_dirty = 1;
+            if (g->fin[u]) { g->m[u]->g_final = 2; g->m[u]->g_done = 1; }
         }
     } while (again);
     if (psgpu_decode_fetch_hyps(g->dec, g->h_hn, NULL, g->h_res, g->st) != PSGPU_OK) {
@@ -913,7 +931,7 @@ psgpu_live_group_create(psgpu_device_decode_t *const *members, int n, int max_fr
     }
     for (u = 0; u < n; ++u) {
         g->m[u] = members[u];
-        members[u]->grp = g; members[u]->gidx = u; members[u]->g_fed = 0; members[u]->g_final = 0; members[u]->g_utts = 0;
+        members[u]->grp = g; members[u]->gidx = u; members[u]->g_fed = 0; members[u]->g_final = 0; members[u]->g_utts = 0; members[u]->g_dirty = 0; members[u]->g_done = 0;
     }
     return g;
 }

@@ -542,6 +542,15 @@ static int dec_from_feat(psgpu_decode_s *d, int32_t n_utt, size_t total, size_t 
     return rc;
 }
 
+// A front end run ahead (psgpu_decode_front_end_ahead) writes d_cep / d_feat / d_off on its own stream: every entry point that
+// writes or re-reads those buffers first orders its stream after it and forgets it (psgpu_decode_first_pass_dev uses its result
+// when the input is the one it was run for).
+static int dec_settle_fe_ahead(psgpu_decode_s *d, hipStream_t st)
+{
+    if (d->fe_ahead) { PSGPU_HIP(hipStreamWaitEvent(st, d->ev_fe, 0)); d->fe_ahead = false; }
+    return PSGPU_OK;
+}
+
 int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, void *stream)
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm_dev && samp_off)), "psgpu_decode_first_pass_dev: bad argument");
@@ -581,7 +590,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
     // in the object's buffers (or on their way: the event)
     const bool ahead = d->fe_ahead && d->fe_pcm == pcm_dev && d->fe_soff.size() == (size_t)n_utt + 1
                        && memcmp(d->fe_soff.data(), samp_off, sizeof(int64_t) * ((size_t)n_utt + 1)) == 0 && !(d->session && n_utt == 1);
-    if (d->fe_ahead) { PSGPU_HIP(hipStreamWaitEvent(st, d->ev_fe, 0)); d->fe_ahead = false; }      // (used or not: nothing of it may still be running)
+    if ((rc = dec_settle_fe_ahead(d, st))) return rc;                    // (used or not: nothing of it may still be running)
     if (ahead && total > 0) {
         dec_mark(d, 1, st);
         if ((rc = dec_from_feat(d, n_utt, total, mf, st))) return rc;
@@ -632,8 +641,9 @@ int psgpu_decode_first_pass_feat(psgpu_decode_t *d, const float *feat, const int
         mf = std::max(mf, (size_t)(frame_off[u + 1] - frame_off[u]));
     }
     const size_t total = (size_t)frame_off[n_utt];
-    int rc = dec_grow(d, (size_t)n_utt, total ? total : 1, mf, st);
+    int rc = dec_settle_fe_ahead(d, st);
     if (rc != PSGPU_OK) return rc;
+    if ((rc = dec_grow(d, (size_t)n_utt, total ? total : 1, mf, st)) != PSGPU_OK) return rc;
     d->total = (int32_t)total; d->max_frames = (int32_t)mf;
     d->bp_cap = (int32_t)d->cap_bp; d->bss_cap = (int32_t)d->cap_bss;
     PSGPU_HIP(hipStreamSynchronize(st));                 // frame_off / feat are the caller's: copied before returning
@@ -733,6 +743,7 @@ static int dec_live_begin(psgpu_decode_s *d, int32_t max_frames, bool again, hip
     PSGPU_REQUIRE(!d->want_lists, "psgpu_decode_live_begin: a live utterance keeps its score rows (not with psgpu_decode_score_mode lists)");
     int rc;
     d->lists = false;                                    // (PSGPU_DECODE_LISTS: not for a live utterance; the next batch call picks its mode again)
+    if ((rc = dec_settle_fe_ahead(d, st))) return rc;
     if ((rc = dec_session_buffers(d))) return rc;
     if ((rc = dec_grow(d, 1, (size_t)max_frames, (size_t)max_frames, st))) return rc;
     if (!d->d_pl_carry) {
@@ -770,6 +781,11 @@ int psgpu_decode_live_step(psgpu_decode_t *d, const float *feat, int32_t n_new, 
 {
     PSGPU_REQUIRE(d && d->live && !d->streams, "psgpu_decode_live_step: no live utterance (psgpu_decode_live_begin)");
     PSGPU_REQUIRE(n_new >= 0 && lag >= 0 && (n_new == 0 || feat), "psgpu_decode_live_step: bad argument");
+    // (a frame is searched with the look-ahead penalties of frame f + pl_window, phone_loop_search.c:302-340 / ngram_search_fwdtree.c:1453-1495:
+    //  a search that stops fewer than pl_window frames short of the frames scored would take a clamped, wrong one for its last frames, and a
+    //  resumed step never goes back to them)
+    PSGPU_REQUIRE(lag == 0 || lag >= d->cfg.pl_window, "psgpu_decode_live_step: lag %d: 0 (the utterance's last step) or at least the look-ahead "
+                  "window (%d frames)", lag, d->cfg.pl_window);
     PSGPU_REQUIRE(d->live_T + n_new <= d->live_cap, "psgpu_decode_live_step: %d frames exceed the live utterance's capacity of %d "
                   "(psgpu_decode_live_begin with a larger one, then the utterance's frames again)", d->live_T + n_new, d->live_cap);
     hipStream_t st = (hipStream_t)stream;
@@ -858,6 +874,7 @@ int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max
     hipStream_t st = (hipStream_t)stream;
     int rc;
     d->lists = false; d->live = true;                    // (score rows; dec_pick_mode keeps them while the streams are in progress)
+    if ((rc = dec_settle_fe_ahead(d, st))) return rc;
     const size_t step_total = (size_t)n_streams * max_step_frames;
     if ((rc = dec_grow(d, (size_t)n_streams, step_total, (size_t)max_frames, st))) return rc;
     PSGPU_HIP(hipStreamSynchronize(st));
@@ -1196,6 +1213,10 @@ int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *strea
     PSGPU_REQUIRE(!d->compall, "psgpu_decode_second_pass: the device second pass normalises over its own senone lists (-compallsen no)");
     PSGPU_REQUIRE(psgpu_ptm_model_view(d->cfg.model, &d->view) == PSGPU_OK, "psgpu_decode_second_pass: no view of the PTM model");
     PSGPU_REQUIRE(d->last_lag == 0, "psgpu_decode_second_pass: the first pass stopped short of the utterances' ends (psgpu_decode_search_lag)");
+    // (the second pass re-reads the call's feature rows and frame offsets; a front end run ahead into them has replaced them with the
+    //  NEXT call's -- psgpu_decode_front_end_ahead comes after this call's second pass, which returns with its search finished)
+    PSGPU_REQUIRE(!d->fe_ahead, "psgpu_decode_second_pass: the next call's front end has been run ahead into this object's feature rows "
+                  "(psgpu_decode_front_end_ahead comes after the second pass)");
     hipStream_t st = (hipStream_t)stream;
     const size_t nu = (size_t)d->n_utt, mf = (size_t)d->max_frames;
     d->pass2 = false;

@@ -526,6 +526,26 @@ def test_dropin_device_search_vtable(raw, nrep, extra, lm, dic):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [("fwdflat", "no", "bestpath", "no"), ()])
+@pytest.mark.parametrize("what", ["librivox-0870.raw", 30.0, 60.0])
+def test_dropin_device_search_vtable_long_utterances_in_one_call(what, extra, tmp_path):
+    """one-call ps_decode_raw-style decodes of utterances LONGER than the 256 frame marks the reference allocates and doubles once
+    per call of ngram_search_mark_bptable (ngram_search.c:184, 324-340): librivox-0870 (710 frames), 30 s and 60 s synthetic
+    (3,000 / 6,000 frames), two utterances through one decoder (nrep 2), first pass only and with the reference's own later
+    passes over the injected tables.  (Round 4 shipped a heap overflow here: dev_search_finish called ngram_fwdtree_finish before
+    the binding had grown bp_table_idx.  tests/test_zz_asan_gpu.py runs the same path under AddressSanitizer.)"""
+    if isinstance(what, float):
+        from pocketsphinx_amd import synth
+        raw = tmp_path / "long.raw"
+        synth.utterance(11, what).tofile(str(raw))
+        what = str(raw)
+    r = run(what, 2, "psgpu_device_vtable", "yes", *extra)
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert r["n_frames"] > 512 and r["device_search_frames"] >= 2 * (r["n_frames"] - 1), r
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("raw,chunk,extra,lm,dic", [
     ("goforward.raw", 4096, ("fwdflat", "no", "bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
     ("numbers.raw", 2048, ("fwdflat", "no", "bestpath", "no"), "turtle.lm.bin", "turtle.dic"),
