@@ -345,8 +345,8 @@ inject(ngram_search_t *ngs, int n_ci, const int32_t *bp, int b0, int nb, const i
         e->s_idx = COL(5); e->real_wid = COL(6); e->prev_real_wid = COL(7); e->last_phone = (int16)COL(8); e->last2_phone = (int16)COL(9);
 #undef COL
     }
-    memcpy(ngs->bscore_stack + h0, bss, sizeof(int32) * (nh - h0));
-    memcpy(ngs->bp_table_idx + f0, idx, sizeof(int32) * (nfr + 1 - f0));
+    if (nh > h0) memcpy(ngs->bscore_stack + h0, bss, sizeof(int32) * (nh - h0));          /* (nothing new: bss may be NULL) */
+    if (nfr + 1 > f0) memcpy(ngs->bp_table_idx + f0, idx, sizeof(int32) * (nfr + 1 - f0));
     ngs->bpidx = nb; ngs->bss_head = nh; ngs->n_frame = nfr;
     ngs->best_score = best_score;    /* ngram_search_lattice (ngram_search.c:1226) refuses an utterance whose best score is WORST_SCORE */
 }
