@@ -533,8 +533,11 @@ def main():
     streams = [torch.cuda.ExternalStream(pdec.dedicated_stream(), device=dev) for _ in range(n_pipe)]
     for k, q in enumerate(pipes):
         q.stage_timing(True)
+        if q.model is not None:                          # the scorer's kernels by HIP events of their own (psgpu_ptm_kernel_timing)
+            capi.check(L.psgpu_ptm_kernel_timing(q.model.h, 1), "psgpu_ptm_kernel_timing")
         if n_pipe > 1:
             q.search_after(pipes[(k - 1) % n_pipe])
+    scorer_ms = []                                       # per timed step: (top-N kernel, exact fix-up kernel) in ms
     pipe = pipes[0]
     stream = torch.cuda.current_stream().cuda_stream
     sp = C.c_void_p(stream)
@@ -587,6 +590,10 @@ def main():
             out = None
         if timed:
             stage.append(q.last_stage_ms())     # events of this step's launches (complete: the records are here)
+            if q.model is not None:
+                ms3 = (C.c_float * 3)()
+                capi.check(L.psgpu_ptm_last_kernel_ms(q.model.h, ms3), "psgpu_ptm_last_kernel_ms")
+                scorer_ms.append((float(ms3[0]), float(ms3[1])))
         return out
 
     def run_steps(n, timed):
@@ -729,6 +736,20 @@ def main():
                              "this workload from the newest COMMITTED PMC profile (profiles/*_pmc_traffic.json, FETCH_SIZE x 2 + WRITE_SIZE): "
                              "a constant of the repository, not a measurement of this run"},
     }
+    # the scorer's roofline beside the search's (VALU-fp32 bound, not HBM, not MFMA): 838,656 fp32 operations a frame
+    # (16,128 densities x 13 dimensions x {sub, mul, mul, sub}) over the top-N kernel's own time in the timed region (HIP events
+    # around the launch on its stream: with the other batch's search resident beside it)
+    if scorer_ms:
+        lane_ms = float(np.mean([a for a, _ in scorer_ms])); fix_ms = float(np.mean([b for _, b in scorer_ms]))
+        gops = 838656.0 * frames_rank / (lane_ms * 1e-3) / 1e9
+        line["roofline"]["scorer"] = {
+            "bound": "valu_fp32", "kernel": "ptm_lane_kernel", "kernel_ms": round(lane_ms, 3), "fixup_kernel_ms": round(fix_ms, 3),
+            "achieved": round(gops / 1e3, 2), "peak": round(2 * VALU_PEAK_GOPS / 1e3, 1), "unit": "TFLOP/s",
+            "frac": round(gops / (2 * VALU_PEAK_GOPS), 4), "frac_of_no_fma_rate": round(gops / VALU_PEAK_GOPS, 4),
+                        "note": "fp32 vector operations per frame (SURVEY 8d) / the kernel's time by HIP events in the timed region (beside the other "
+                    "batch's search); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz x 2 (an FMA counted twice); the bit-exact distance "
+                    "(ptm_mgau.c:102-128: sub, mul, mul, sub in fp32, no contraction) cannot use FMA: frac_of_no_fma_rate is the bound "
+                    "it can reach"}
     # ---- cpu_baseline + parity: the compiled reference on a sample of the same utterances
     if world > 1:
         line["cpu_baseline"] = None                      # (the reference leg runs at N = 1 only: BENCH, not SCALE)
@@ -829,6 +850,29 @@ def main():
         if not os.environ.get("PSGPU_BENCH_NO_CHILD"):
             child_extras(extra)
     line["extra"] = extra
+    # the other legs where the driver keeps them (it stores `roofline` whole and only the NAMES of other top-level keys): value,
+    # roofline fraction, traffic against algorithmic bytes, CPU baseline and parity of each leg that ran
+    legs = {}
+    for name in ("decode_large_vocab", "decode_two_pass", "decode_ms_scorer", "decode_ms_continuous"):
+        lg = line.get(name)
+        if not isinstance(lg, dict) or "value" not in lg:
+            if isinstance(lg, dict) and ("error" in lg or "skipped" in lg):
+                legs[name] = {k: lg[k] for k in ("error", "skipped") if k in lg}
+            continue
+        rf, par_, cb = lg.get("roofline") or {}, lg.get("parity") or {}, lg.get("cpu_baseline") or {}
+        legs[name] = {"value": lg["value"], "unit": lg.get("unit"), "ms_per_step": lg.get("ms_per_step"),
+                      "workload": (lg.get("config") or {}).get("workload"),
+                      "roofline_frac": rf.get("frac"), "achieved_GBps": rf.get("achieved"), "kernel": rf.get("kernel"), "kernel_ms": rf.get("kernel_ms"),
+                      "traffic": rf.get("traffic"), "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
+                      "traffic_over_algorithmic": (round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 2)
+                                                   if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch") else None),
+                      "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None,
+                      "parity": ("%d/%d identical" % (par_.get("identical", 0), par_.get("checked", 0))) if par_ else None}
+        for k in ("first_pass_ms", "second_pass_ms"):
+            if k in lg:
+                legs[name][k] = lg[k]
+    if legs:
+        line["roofline"]["legs"] = legs
     emit(line)
     if dist is not None:
         dist.destroy_process_group()

@@ -1030,10 +1030,15 @@ int psgpu_ptm_kernel_timing(psgpu_ptm_model_t *m, int32_t enable)
 int psgpu_ptm_last_kernel_ms(psgpu_ptm_model_t *m, float *ms3)
 {
     PSGPU_REQUIRE(m && ms3 && m->timing, "psgpu_ptm_last_kernel_ms: timing is not enabled");
-    PSGPU_HIP(hipEventSynchronize(m->ev[3]));
+    // (a caller of psgpu_ptm_topn_dev alone -- the decode pipeline scoring from lists -- records no senone kernel: 0 then)
+    PSGPU_HIP(hipEventSynchronize(m->ev[2]));
     PSGPU_HIP(hipEventElapsedTime(&ms3[0], m->ev[0], m->ev[1]));    // main top-N kernel
     PSGPU_HIP(hipEventElapsedTime(&ms3[1], m->ev[1], m->ev[2]));    // exact fix-up launch
-    PSGPU_HIP(hipEventElapsedTime(&ms3[2], m->ev[2], m->ev[3]));    // senone kernel
+    ms3[2] = 0.0f;
+    if (m->sen_timed) {
+        PSGPU_HIP(hipEventSynchronize(m->ev[3]));
+        PSGPU_HIP(hipEventElapsedTime(&ms3[2], m->ev[2], m->ev[3]));    // senone kernel
+    }
     return PSGPU_OK;
 }
 
@@ -1050,7 +1055,7 @@ int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
     if (rc != PSGPU_OK || senscr_dev == nullptr) return rc;
     rc = psgpu_ptm_senone_dev(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev,
                               best_dev, flags, stream);
-    if (rc == PSGPU_OK && m->timing) hipEventRecord(m->ev[3], (hipStream_t)stream);
+    if (rc == PSGPU_OK && m->timing) { hipEventRecord(m->ev[3], (hipStream_t)stream); m->sen_timed = true; }
     return rc;
 }
 

@@ -38,6 +38,7 @@ struct psgpu_ptm_model_s {
     std::list<PtmWorkspace> ws;
     hipEvent_t ev[4];             // optional per-kernel timing: lane | fix-up | (gap) | senone (one timed caller at a time)
     int timing;
+    bool sen_timed = false;       // ev[3] has been recorded (psgpu_ptm_score_batch_dev ran with timing on)
 };
 
 // the workspace of `st` (created on first use; list nodes never move)
