@@ -61,8 +61,11 @@ constexpr int kFtMaxChains = 128;      // (codebook, stream) chains whose lists 
 constexpr int kFtMinEvl = 512;         // the frame's evaluation list holds at least this many entries (LDS layout)
 constexpr int kFtMaxCi = 64;
 constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list, raw-score mode)
-constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (32 KB)
-constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS
+constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (at most 32 KB of the pool)
+constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS (likewise)
+constexpr int kFtSlabPoolWords = 39808;    // slab layouts: words of dynamic LDS a workgroup may ask for (155.5 of a compute unit's 160 KB; ~3.5 KB are static)
+constexpr int kFtMaxListed = 65535;    // slab layouts: tree channels listed in one frame (their records are kept compact, in list order: FtLay::cq;
+                                       // list positions are 16-bit in the rank -> position table); more: status 4
 constexpr int kFtLiveMagic = 0x5ea4c4ed;
 constexpr int kFtLiveHdr = 32;         // FtBufs::live: words ahead of the pool's copy
 constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
@@ -85,8 +88,15 @@ struct FtLay {
     int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
     int32_t l_cw, l_sc, l_la, l_list, l_norm;    // small layout, scoring from top-N lists: the frame's lists (packed codewords / scores per
                                          // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
-    int32_t itb;                         // slab layouts: [R + N][4] per item (root / list position) out, out history, best, score[0] as the evaluation left them
-    int32_t act;                         // slab layouts: [2 N][4] the pruning's channel updates of the frame (node | kind << 28, score, history, 0)
+    int32_t itb;                         // slab layouts: [R][4] per root: out, out history, best, 1 = evaluated this frame, as the evaluation left them
+    // slab layouts: the listed tree nodes' channels, COMPACT and in list order (see the kernel's note "compact channels"):
+    int32_t cq;                          // [2][ND + 2][ccap][4] two buffers taking turns by frame parity; per buffer ND arrays of quads with the channel's
+                                         // scores, histories, out score, out history (ND = 2 for 3 states, 3 for 5) and two with what is static per node
+    int32_t csum;                        // [ccap][4] per list position: out, out history, best, score[0] as the evaluation left them
+    int32_t cdec;                        // [ccap][4] per list position: the node's own decision {place in the next list or -1, kind, entering score, history}
+    int32_t cdst;                        // [ccap] per list position: the place in the next list its PARENT's pair gave the node, or -1 (reset when read)
+    int32_t cperm;                       // [ccap] uint16: rank among the listed nodes by node id -> list position, when the frame's list outgrows the LDS table
+    int32_t ccap;                        // listed nodes a frame may hold: min(N - R, kFtMaxListed)
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
@@ -107,7 +117,10 @@ struct FtDev {
     const int32_t *kids_ci;              // kids with the child's ci phone in the top byte (slab layouts: child | ci << 24)
     // slab layouts: what the pruning and the senone marking ask about a node, as quads (one request each), shared by all
     // utterances (8 MB at 248 k nodes: L2 / MALL resident):
-    const int32_t *node_q1;              // [N][4] parent | ci << 24, first child (index into kids), number of children, kids_ci[first child] or -1
+    const int32_t *node_q1;              // [N][4] parent | ci << 24, first child (index into kids), number of children | (a word's penultimate node) << 16,
+                                         // kids_ci[first child] or -1
+    const int32_t *node_st1;             // [N][4] the node's senone ids and transition matrix as a compact channel carries them: 16 bits each (3 states:
+                                         // s0 | s1 << 16, s2 | tmat << 16, 0; 5 states: s0 | s1 << 16, s2 | s3 << 16, s4 | tmat << 16), then kids_ci[first child]
     const int32_t *node_q2;              // [N][4] penultimate-phone word, its last phone, its homophone link, 0
     const int32_t *node_sen;             // [N][4 or 8] the node's senone ids (sseq[node_ssid]): states 0..n_emit-1, then 0
     const int32_t *slot_sen;             // [TOT][4 or 8] a right-context channel's senone ids (what ngram_search_alloc_all_rc gives it: sseq of
@@ -119,7 +132,10 @@ struct FtDev {
     const uint16_t *sseq;
     int32_t n_tmat;
     int32_t small;                       // the fast arrays fit the LDS pool
-    int32_t lb_words;                    // slab layouts: words of the listed-nodes bitmap in LDS (0: none, the tree is too large)
+    int32_t lb_words;                    // slab layouts: words of the listed-nodes bitmap in LDS
+    // slab layouts: the dynamic LDS pool behind the pruning's item arrays (word offsets; set per launch, ft_slab_pool): the bitmap, its
+    // words' prefix populations (uint16), the frame's score row, the transition matrices, the rank -> list position table (uint16)
+    int32_t lds_lb, lds_pre, lds_row, lds_tp, lds_perm, lds_perm_cap, lds_words;
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
     int32_t cnt_words;
     FtLay lay;
@@ -815,7 +831,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
 #if defined(__HIPCC__)
     int32_t *const s_pool = ft_dyn_pool;                 // SMALL: kFtLdsWords words of dynamic LDS (the launch says so)
 #else
-    __shared__ __attribute__((aligned(16))) int32_t s_pool[SMALL ? kFtLdsWords : 18 * NT + 16 + kFtMaxBitWords];     // (the workgroup simulator)
+    __shared__ __attribute__((aligned(16))) int32_t s_pool[SMALL ? kFtLdsWords : kFtSlabPoolWords];     // (the workgroup simulator)
 #endif
     __shared__ uint32_t s_bits[kFtMaxSen / 32];
     __shared__ int32_t s_nb;
@@ -834,21 +850,20 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             *const s_it_fp = s_pool + 3 * kPrIC, *const s_it_k0 = s_pool + 4 * kPrIC, *const s_it_par = s_pool + 5 * kPrIC,
             *const s_it_sc0 = s_pool + 6 * kPrIC, *const s_it_kid0 = s_pool + 7 * kPrIC,
             *const s_it_poff = s_pool + 8 * kPrIC;                                            // (poff: kPrIC + 1 entries)
-    // ... and, when the tree is small enough for it (p.lb_words != 0), a bitmap of the nodes in the frame's active list: a pair
-    // whose other node is NOT listed knows that node's state without asking for its record (cleared when it left the list) --
-    // two thirds of the pairs of the 134,865-word task, a cache line and a vector-memory request each
-    uint32_t *const s_lb = reinterpret_cast<uint32_t *>(s_pool + 9 * kPrIC + 16);
-#ifdef PSGPU_FT_NO_LISTED_BITMAP            /* (an A/B build: every pair asks for its other node's record) */
-    const bool use_lb = false;
-#else
-    const bool use_lb = !SMALL && p.lb_words != 0;
-#endif
+    // ... and the index of the frame's active list (slab layouts; behind the item arrays, ft_slab_pool): a bitmap of the listed nodes,
+    // the populations of the bitmap words before each word (so that a node's RANK among the listed nodes is two LDS reads and a
+    // population count) and the table rank -> position in the list.  A pair whose other node is NOT listed knows that node's state
+    // without asking (it was cleared when it left the list) -- two thirds of the pairs of the 134,865-word task; one whose other node
+    // IS listed finds that node's compact record by its position.
+    uint32_t *const s_lb = reinterpret_cast<uint32_t *>(s_pool + (SMALL ? 0 : p.lds_lb));
+    uint16_t *const s_pre = reinterpret_cast<uint16_t *>(s_pool + (SMALL ? 0 : p.lds_pre));
+    uint16_t *const s_perm = reinterpret_cast<uint16_t *>(s_pool + (SMALL ? 0 : p.lds_perm));
     __shared__ int32_t s_nroot;          // slab layouts: roots evaluated in the frame
     __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
-    // slab layouts: the frame's score row and the transition matrices in LDS too -- a channel's evaluation then asks device memory
-    // for its record only (the eight transition bytes and three senone scores of a 3-state HMM were eleven requests of their own)
-    __shared__ __attribute__((aligned(16))) int16_t s_rowb[SMALL ? 2 : kFtSlabSen];
-    __shared__ __attribute__((aligned(16))) uint8_t s_tpb[SMALL ? 4 : kFtSlabTp];
+    // slab layouts: the frame's score row and the transition matrices in LDS too (the pool) -- a channel's evaluation then asks device
+    // memory for its record only (the eight transition bytes and three senone scores of a 3-state HMM were eleven requests of their own)
+    int16_t *const s_rowb = reinterpret_cast<int16_t *>(s_pool + (SMALL ? 0 : p.lds_row));
+    uint8_t *const s_tpb = reinterpret_cast<uint8_t *>(s_pool + (SMALL ? 0 : p.lds_tp));
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
     __shared__ long long s_prof[48], s_last, s_lastw[4], s_d0;
@@ -942,8 +957,26 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                  *const node_q2 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q2));
     const int32_t *const node_sen = psgpu_as_global(p.node_sen);
     const int32_t *const slot_sen = psgpu_as_global(p.slot_sen);
-    FtQuad *const itb = reinterpret_cast<FtQuad *>(fb + L.itb);        // slab layouts only
-    int32_t *const actl = fb + L.act;                                  // slab layouts only
+    FtQuad *const itb = reinterpret_cast<FtQuad *>(fb + L.itb);        // slab layouts only: [R]
+    // ---- compact channels (slab layouts).  A tree node's channel exists while the node is listed: its record lives at the node's
+    //      POSITION in the frame's active list, in arrays of quads (one array per quad of the record: sixty-four work-items on
+    //      consecutive positions read 1 KB in a row), two buffers taking turns -- the evaluation rewrites the frame's buffer in place,
+    //      the pruning writes the next frame's: a retained node's record is copied to its new position, a newly entered node's is made
+    //      from the static tables (and carries its static side -- parent, children, senones -- from then on: the evaluation and the
+    //      pruning of a listed node ask the static tables nothing).  Per buffer: ND quads {score[0..NE), history[0..NE), out score, out
+    //      history}, then {node, parent | ci << 24, first child's index, children | penultimate << 16} and {senones and transition
+    //      matrix, 16 bits each, ..., first child | its ci << 24}.  What a frame costs in device memory is then mostly streams; the
+    //      random accesses left are a decision's look at its OTHER node (by rank -> position, see s_lb) and the static rows of the
+    //      nodes that ENTER the list.
+    constexpr int ND = NE == 3 ? 2 : 3;
+    const int ccap = SMALL ? 1 : L.ccap;
+    FtQuad *const cq = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cq));
+    FtQuad *const csum = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.csum)), *const cdec = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cdec));
+    int32_t *const cdst = fb + (SMALL ? 0 : L.cdst);
+    uint16_t *const g_perm = reinterpret_cast<uint16_t *>(fb + (SMALL ? 0 : L.cperm));
+    auto cbuf = [&](int b, int k) { return cq + (size_t)(b * (ND + 2) + k) * ccap; };      // array k of buffer b
+    const FtQuad *const node_st1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_st1));
+    bool perm_lds = true;                                              // the current list's rank -> position table is the LDS one (uniform)
     const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
     // the tree's structure: LDS copies in the small layout
     const int32_t *const kids = SMALL ? fb + L.kids : psgpu_as_global(p.kids);
@@ -999,14 +1032,15 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int32_t *const ext = bf.ext ? psgpu_as_global(bf.ext) + 3 * (size_t)blockIdx.x : nullptr;
     const int t0 = utt_off[blockIdx.x], T_in = ext ? ext[0] : utt_off[blockIdx.x + 1] - t0,
               T = ext ? min(ext[1], T_in) : (bf.lag > 0 ? max(T_in - bf.lag, 0) : ((raw_mode && T_in < pl_window) ? 0 : T_in));
-    const int W1 = N;                                    // single-phone word i is channel W1 + i of tv
+    const int W1 = SMALL ? N : R;                        // single-phone word i is channel W1 + i of tv (slab layouts: tv holds the roots and these)
     int n_acl_cur = 0, n_awl_cur = 0;                    // list lengths: uniform copies (every thread tracks them identically)
     uint32_t evals_run = 0u;                             // HMM evaluations so far (ngs->st.n_hmm_eval; saturating: compared with maxhmmpf), likewise
     int nwc_cur = 0;                                     // right-context channels of the active words (the last of woff's prefix sums), likewise
 
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
     if (!resumed) {
-        for (int c = tid; c < N; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
+        for (int c = tid; c < W1; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
+        if (!SMALL) { for (int i = tid; i < ccap; i += NT) cdst[i] = -1; }
         for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
         for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
         for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
@@ -1019,8 +1053,28 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     {
         const int nwords = (p.n_sen + 31) >> 5;
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
-        if (use_lb) for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;
+        if (!SMALL) { for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u; }
     }
+    // slab layouts: the index of an active list -- bitmap of its nodes, the populations of the bitmap words before each word, rank ->
+    // position -- from the list itself (node ids in list order).  Called by every work-item with the bitmap all zero; ends without a
+    // barrier (the table's first readers are a frame's pruning pairs, behind many)
+    auto build_index = [&](const int32_t *list, int n) {
+        for (int o = tid; o < n; o += NT) { const int c = list[o]; atomicOr(&s_lb[c >> 5], 1u << (c & 31)); }
+        __syncthreads();
+        const int nwl = p.lb_words, K = (nwl + NT - 1) / NT, b = min(nwl, tid * K), e = min(nwl, b + K);     // K consecutive words a work-item
+        int32_t v[1] = { 0 }, tot[1];
+        for (int w = b; w < e; ++w) v[0] += __popc(s_lb[w]);
+        ft_scan_tid<NT, 1, true>(v, s_scan, tot);
+        int32_t run = v[0];
+        for (int w = b; w < e; ++w) { s_pre[w] = (uint16_t)run; run += __popc(s_lb[w]); }
+        __syncthreads();
+        perm_lds = n <= p.lds_perm_cap;                  // (a frame that lists more than the LDS table holds keeps the table in the slab)
+        for (int o = tid; o < n; o += NT) {
+            const int c = list[o];
+            const int r = (int)s_pre[c >> 5] + __popc(s_lb[c >> 5] & ((1u << (c & 31)) - 1u));
+            if (perm_lds) s_perm[r] = (uint16_t)o; else g_perm[r] = (uint16_t)o;
+        }
+    };
     if (resumed) {
         // the pool as the previous call's last frame left it (the static tables' copies with it), the counters, the frame loop's
         // carried registers; the senone bitmap, the listed-nodes bitmap and the normaliser are reset at every frame's end and are as
@@ -1041,6 +1095,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) { s_evals = (unsigned long long)(uint32_t)live[5] | ((unsigned long long)(uint32_t)live[6] << 32); s_nsen = live[7]; }
         n_acl_cur = live[1]; n_awl_cur = live[2]; evals_run = (uint32_t)live[3]; nwc_cur = live[4];
         __syncthreads();
+        if (!SMALL) {                                    // (the compact channels are in the slab, where the last frame left them; their index is LDS)
+            build_index(fb + ((f0 & 1) ? L.acl1 : L.acl0), n_acl_cur);
+            __syncthreads();
+        }
     }
     // Scores: the frame's row is read from LDS (s_row).  From rows: the next frame's row travels from HBM into s_row while this
     // frame's word level runs -- issued after the evaluation, the row's last reader -- by LDS-DMA (global_load_lds_dword: no
@@ -1213,14 +1271,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         act_root = tv.at(i, F::FRAME) == f;
                         if (act_root && raw_mode) mark(tv, i);
                     }
-                    else if (i < R + na && (raw_mode || use_lb)) {
-                        const int node = aclc[i - R];
-                        if (use_lb) atomicOr(&s_lb[node >> 5], 1u << (node & 31));       // (zero since the end of the last frame's pruning)
-                        if (raw_mode) {
-                            const FtQuad a = *reinterpret_cast<const FtQuad *>(node_sen + (size_t)node * (NE <= 3 ? 4 : 8));
-                            mark_sen(a.x); mark_sen(a.y); mark_sen(a.z);
-                            if (NE == 5) { mark_sen(a.w); mark_sen(node_sen[(size_t)node * 8 + 4]); }
-                        }
+                    else if (i < R + na && raw_mode) {
+                        const FtQuad a = cbuf(cur, ND + 1)[i - R];          // the channel carries its senones, 16 bits each
+                        mark_sen(a.x & 0xffff); mark_sen((int)((uint32_t)a.x >> 16)); mark_sen(a.y & 0xffff);
+                        if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(a.z & 0xffff); }
                     }
                     if (i0 < R) n_act_root += __popcll(__ballot(act_root));
                 }
@@ -1267,11 +1321,19 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int c = evl_get(e);
                 if (c & kFtWordCh) ch_normalize<NE>(wv, word_slot(c), best_in); else ch_normalize<NE>(tv, c, best_in);
             }
-            if (!SMALL)
-                for (int i = tid; i < R + na; i += NT) {
-                    const int node = i < R ? i : aclc[i - R];
-                    if (i >= R || tv.at(node, F::FRAME) == f) ch_normalize<NE>(tv, node, best_in);
+            if (!SMALL) {
+                for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_normalize<NE>(tv, i, best_in);
+                for (int j = tid; j < na; j += NT) {         // hmm_normalize on the compact channels: the scores and the out score
+                    int32_t w[4 * ND];
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) { const FtQuad q = cbuf(cur, k)[j]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) if (w[k] > kW) w[k] -= best_in;
+                    if (w[2 * NE] > kW) w[2 * NE] -= best_in;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
                 }
+            }
             __syncthreads();
         }
         int32_t nb = 0;
@@ -1350,16 +1412,40 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 // the tree's items in item order: the record comes in and goes out once; the evaluation leaves, for the pruning,
                 // the node's list position in its record and {out, out history, best, score[0]} in the item's compact slot
                 // (an idle root's slot says so in its last word; a root's says 1 there: no decision reads a root's score)
-                for (int i = tid; i < R + na; i += NT) {
-                    const int node = i < R ? i : aclc[i - R];
-                    int32_t *const rec = tv.b + (size_t)node * TREC;
+                for (int i = tid; i < R; i += NT) {
+                    int32_t *const rec = tv.b + (size_t)i * TREC;
                     FtQuad it = FtQuad{ kW, -1, kW, 0 };
-                    if (i >= R || rec[F::FRAME] == f) {
-                        const int32_t sc = ch_eval_tree<NE>(rec, sr, tpall, sseq, i >= R, i - R + 1, it);
+                    if (rec[F::FRAME] == f) {
+                        const int32_t sc = ch_eval_tree<NE>(rec, sr, tpall, sseq, false, 0, it);
                         b_all = max(b_all, sc);
-                        if (i < R) it.w = 1;
+                        it.w = 1;
                     }
                     itb[i] = it;
+                }
+                // the listed nodes' compact channels, position by position: ND + 1 quads in, ND + 1 out, every one in a row with its
+                // neighbours'; never multiplexed (the senones are the channel's own)
+                for (int j = tid; j < na; j += NT) {
+                    int32_t w[4 * ND];
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) { const FtQuad q = cbuf(cur, k)[j]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+                    const FtQuad sq = cbuf(cur, ND + 1)[j];
+                    HmmRegs h;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { h.score[k] = k < NE ? w[k] : kW; h.history[k] = k < NE ? w[NE + k] : -1; h.senid[k] = 0; }
+                    h.senid[0] = (uint16_t)(sq.x & 0xffff); h.senid[1] = (uint16_t)((uint32_t)sq.x >> 16); h.senid[2] = (uint16_t)(sq.y & 0xffff);
+                    int tm = (int)((uint32_t)sq.y >> 16);
+                    if (NE == 5) { h.senid[3] = (uint16_t)((uint32_t)sq.y >> 16); h.senid[4] = (uint16_t)(sq.z & 0xffff); tm = (int)((uint32_t)sq.z >> 16); }
+                    h.out_score = w[2 * NE]; h.out_history = w[2 * NE + 1]; h.bestscore = kW;
+                    uint8_t tpb[NE * (NE + 1)];
+                    const uint8_t *tp = ft_tp_row<NE>(tpall, tm, tpb);
+                    const int32_t sc = NE == 3 ? vit3(h, tp, sr) : vit5(h, tp, sr);
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) { w[k] = h.score[k]; w[NE + k] = h.history[k]; }
+                    w[2 * NE] = h.out_score; w[2 * NE + 1] = h.out_history;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+                    csum[j] = FtQuad{ h.out_score, h.out_history, h.bestscore, h.score[0] };
+                    b_all = max(b_all, sc);
                 }
             }
             for (int e = tid; e < n_evl; e += NT) {
@@ -1432,7 +1518,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 ft_sync<true>();
                 for (int i = tid; i < R + na; i += NT) {
                     const int c = i < R ? i : aclc[i - R];
-                    int32_t b = (best_score - (SMALL ? tv.at(c, F::BEST) : itb[i].z)) / bw;
+                    int32_t b = (best_score - (SMALL ? tv.at(c, F::BEST) : (i < R ? itb[i].z : csum[i - R].z))) / bw;
                     if (b >= 256) b = 255;
                     atomicAdd(&s_bins[b], 1);
                 }
@@ -1458,39 +1544,49 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //      decision is a function of the node's and its parent's state as the evaluation left them), arranged for
         //      state that lives in DEVICE memory, where a frame costs the cache lines it touches and the instructions that
         //      ask for them, not arithmetic:
-        //        * the items' side comes from the compact slots the evaluation filled (read in order) and from static
-        //          quads shared by all utterances; a node's record is touched only as some decision's OTHER node;
+        //        * an item's side comes from arrays indexed by its POSITION (the evaluation's summary and the static quads its
+        //          compact channel carries), read in order; a root's from its compact slot and the static quads;
         //        * one work-item per (item, child) PAIR, four consecutive pairs at a time with their loads asked for
         //          together; a child that is itself listed is decided twice -- by its own item (whose outcome counts) and
         //          by its parent's pair (which needs it for the next list);
-        //        * decisions only READ channels: what they ask to be done to a channel goes to a list and is applied when
-        //          every decision of the frame has been taken (so no snapshot of the channels is needed);
+        //        * a pair's OTHER node, if listed, is found through the list's index (bitmap, rank, position: LDS) and read from
+        //          the summary array; if not listed its state is known without asking;
+        //        * decisions only READ channels: a node's own decision goes to cdec [position], the place its parent's pair
+        //          gives it to cdst [position], and the next frame's channels are written when every decision of the frame has
+        //          been taken -- a node that stays is copied from its position in this frame's buffer to its position in the
+        //          next, a node that enters the list gets a channel made from the static tables right where it is decided;
         //        * positions in the next active list = prefix sums over the pairs' outcomes in pair order (= list order);
         //        * the frame's penalty row and the chunk's items in LDS.
-        //      Facts the decisions rely on instead of reading them (checked on every node by the simulator's build):
-        //        a node that is NOT in the active list has been cleared when it left it (or was never entered): its frame is
-        //        below f and its scores are WORST_SCORE, so "frame < f || news > score" is true without looking, and its
-        //        first quad after an entry is known; a node that IS in the list was entered or retained for this frame.
-        //      (134,865-word task, phase profile: 1.87 M cycles a frame with the per-node loops of the formulation below,
-        //       1.0 M with pairs on a per-node snapshot line)
+        //      Facts the decisions rely on instead of reading them:
+        //        a node that is NOT in the active list has no channel (the reference's was cleared when it left the list, or never
+        //        entered): its frame is below f and its scores are WORST_SCORE, so "frame < f || news > score" is true without
+        //        looking; a node that IS in the list was entered or retained for this frame.
         {
             const int n_item = R + na;
-            int carry_l = 0, carry_c = 0, carry_a = 0;           // next list's entries / candidates / channel updates so far (uniform)
+            int carry_l = 0, carry_c = 0;                        // next list's entries / candidates so far (uniform)
+            const FtQuad *const cs0 = cbuf(cur, ND), *const cs1 = cbuf(cur, ND + 1);
+            FtQuad *const ns0 = cbuf(nxt, ND), *const ns1 = cbuf(nxt, ND + 1);
+            bool over = false;                                   // the next list outgrows the compact buffers (uniform)
             for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
                 // -- the chunk's items, two consecutive ones a work-item -> LDS; pairs and candidates counted
                 int32_t np[2], kc[2], c_w[2], c_news[2], c_outh[2], c_homo[2], c_dl[2];
                 {
                     int node[2]; FtQuad it[2], q1[2];
+                    bool hpw[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int i = c0 + 2 * tid + u;
-                        node[u] = i < R ? i : (i < n_item ? aclc[i - R] : -1);
-                        it[u] = FtQuad{ kW, -1, kW, 0 };
-                        if (i < n_item) it[u] = itb[i];
+                        node[u] = -1; it[u] = FtQuad{ kW, -1, kW, 0 }; q1[u] = FtQuad{ 0, 0, 0, -1 };
+                        if (i < R) { node[u] = i; it[u] = itb[i]; q1[u] = node_q1[i]; }
+                        else if (i < n_item) {
+                            const FtQuad a = cs0[i - R];         // node, parent | ci << 24, first child's index, children | penultimate << 16
+                            it[u] = csum[i - R];
+                            node[u] = a.x; q1[u] = FtQuad{ a.y, a.z, a.w, cs1[i - R].w };
+                        }
+                        hpw[u] = ((uint32_t)q1[u].z >> 16) != 0u;
+                        q1[u].z &= 0xffff;
                     }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) { q1[u] = FtQuad{ 0, 0, 0, -1 }; if (node[u] >= 0) q1[u] = node_q1[node[u]]; }
-                    FtQuad qd[2];       // (asking for the second static quad with the first, before the slot says it is needed: measured, 1 % slower)
+                    FtQuad qd[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int li = 2 * tid + u, i = c0 + li;
@@ -1506,10 +1602,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         const int32_t news = it[u].x + p.pip;
                         c_news[u] = news; c_outh[u] = it[u].y;
                         qd[u] = FtQuad{ -1, 0, -1, 0 };
-                        if (fl && (p.has_pl || news > lpt)) qd[u] = node_q2[node[u]];
-#ifdef PSGPU_FT_CHECK_LISTS
-                        if (i >= R && node[u] >= 0 && tv.at(node[u], F::FRAME) != i - R + 1) { printf("listed node %d carries position %d at %d\n", node[u], tv.at(node[u], F::FRAME), i - R); abort(); }
-#endif
+                        if (fl && hpw[u] && (p.has_pl || news > lpt)) qd[u] = node_q2[node[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -1560,8 +1653,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int p0 = 0; p0 < n_pair; p0 += 4 * NT) {
                     int li[4], q[4], c[4], cci[4]; bool val[4];
                     const int jb = p0 + 4 * tid;
-                    // (which item a pair belongs to: a bisection of the chunk's offsets in LDS.  Having the items' work-items write a
-                    //  descriptor per pair instead costs a barrier more per round: measured 5 % slower on the 134,865-word task.)
+                    // (which item a pair belongs to: a bisection of the chunk's offsets in LDS)
                     {
                         int l0 = jb < n_pair ? ft_seg_find(s_it_poff, kPrIC, jb) : 0;
 #pragma unroll
@@ -1594,8 +1686,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                             }
                         }
                     }
-                    // the OTHER node's record: a child's {out, out history, best, position} -- for an item's own entry the
-                    // PARENT's (a root's last word is its frame stamp); a listed child's score[0] in a second request
+                    // the OTHER node: a child's {out, out history, best, position + 1} and score[0] -- for an item's own entry the
+                    // PARENT's.  A root's come from its record (its last word is its frame stamp); a listed node's from the summary
+                    // array at its position (bitmap -> rank -> position: LDS); a node that is not listed has nothing to say
                     FtQuad qx[4]; int32_t csc[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -1603,26 +1696,26 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         csc[v] = kW;
                         if (val[v]) {
                             const int o_ = q[v] < 0 ? (s_it_par[li[v]] & 0xffffff) : c[v];
-                            // (a node that is not listed: {WORST_SCORE, -, WORST_SCORE, no position} -- what the initialiser says)
-                            const bool ask = !use_lb || o_ < R || ((s_lb[o_ >> 5] >> (o_ & 31)) & 1u);
+                            if (o_ < R) qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)o_ * TREC + F::OUT);
+                            else {
+                                const uint32_t wb = s_lb[o_ >> 5];
+                                if ((wb >> (o_ & 31)) & 1u) {
+                                    const int r = (int)s_pre[o_ >> 5] + __popc(wb & ((1u << (o_ & 31)) - 1u));
+                                    const int ps = perm_lds ? (int)s_perm[r] : (int)g_perm[r];
 #ifdef PSGPU_FT_CHECK_LISTS
-                            if (!ask && tv.at(o_, F::FRAME) > 0) { printf("node %d carries position %d but its bit is clear (frame %d)\n", o_, tv.at(o_, F::FRAME), f); abort(); }
-                            if (ask && use_lb && o_ >= R && tv.at(o_, F::FRAME) <= 0) { printf("node %d: bit set, no position (frame %d)\n", o_, f); abort(); }
+                                    if (ps >= na || aclc[ps] != o_) { printf("frame %d: node %d -> rank %d -> position %d holds node %d (%d listed)\n", f, o_, r, ps, ps < na ? aclc[ps] : -1, na); abort(); }
 #endif
-                            if (ask) qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)o_ * TREC + F::OUT);
-                            // (with the bitmap a listed child is known before its record arrives: its score[0] in the same trip)
-                            if (ask && use_lb && q[v] >= 0) csc[v] = tv.b[(size_t)c[v] * TREC + F::SCORE];
+                                    const FtQuad sm = csum[ps];
+                                    qx[v] = FtQuad{ sm.x, sm.y, sm.z, ps + 1 };
+                                    csc[v] = sm.w;
+                                }
+                            }
                         }
                     }
-                    if (!use_lb) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v)
-                            if (val[v] && q[v] >= 0 && qx[v].w > 0) csc[v] = tv.b[(size_t)c[v] * TREC + F::SCORE];
-                    }
-                    int32_t bit[4], act[4], a_news[4], a_outh[4];
+                    int32_t bit[4], act[4], a_news[4], a_outh[4], c_at[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        bit[v] = 0; act[v] = 0; a_news[v] = 0; a_outh[v] = -1;
+                        bit[v] = 0; act[v] = 0; a_news[v] = 0; a_outh[v] = -1; c_at[v] = -1;
                         if (!val[v]) continue;
                         const bool self = q[v] < 0;
                         const int P = self ? (s_it_par[li[v]] & 0xffffff) : s_it_node[li[v]];
@@ -1646,9 +1739,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         else fire = parent_can;
                         const bool entered_first = fire && parent_first;
                         const bool listed = fire && (p_root || !(in_acl && !parent_first && retc));
-                        // what the decision does to the node's channel: 1 = entered (an unlisted node: cleared when it left the list,
-                        // so its whole first quad is known), 2 = entered (a listed node: score[0] and history[0]), 3 = cleared,
-                        // 4 = cleared, then entered
+                        // what the decision does to the node's channel: 1 = entered (an unlisted node: a new channel), 2 = entered (a
+                        // listed node: score[0] and history[0]), 3 = cleared (it leaves the list), 4 = cleared, then entered
                         a_news[v] = news; a_outh[v] = p_outh;
                         if (self) {
                             const bool clr = !retc && !entered_first;
@@ -1656,66 +1748,96 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                             bit[v] = (retc && !entered_first) ? 1 : 0;
                         }
                         else {
-                            act[v] = (!in_acl && fire) ? 1 : 0;       // (a listed child is written by its own entry)
+                            act[v] = (!in_acl && fire) ? 1 : 0;       // (a listed child's channel is its own entry's business)
                             bit[v] = listed ? 1 : 0;
+                            if (in_acl && listed) c_at[v] = c_pos;    // ... but its place in the next list is this pair's
                         }
                     }
                     FT_PROF(13);
-                    // positions in the next active list and in the frame's list of channel updates: pair order
+                    // the static side of the channels this round makes (asked for before the barrier below)
+                    FtQuad e0[4], e1[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        e0[v] = FtQuad{ 0, 0, 0, 0 }; e1[v] = FtQuad{ 0, 0, 0, -1 };
+                        if (act[v] == 1) { e0[v] = node_q1[c[v]]; e1[v] = node_st1[c[v]]; }
+                    }
+                    // positions in the next active list: pair order
                     {
                         const int lane = tid & 63, wv_ = tid >> 6;
                         const int32_t sb = bit[0] + bit[1] + bit[2] + bit[3];
-                        const int32_t sa = (act[0] != 0) + (act[1] != 0) + (act[2] != 0) + (act[3] != 0);
-                        const int32_t ib = ft_wave_incl<FtAdd>(sb), ia = ft_wave_incl<FtAdd>(sa);
-                        if (lane == 63) { s_scan[wv_] = ib; s_scan[NT / 64 + wv_] = ia; }
+                        const int32_t ib = ft_wave_incl<FtAdd>(sb);
+                        if (lane == 63) s_scan[wv_] = ib;
                         FT_PROF(22);
                         ft_sync<true>();
                         FT_PROF(31);
-                        int32_t base = 0, tot = 0, base_a = 0, tot_a = 0;
+                        int32_t base = 0, tot = 0;
 #pragma unroll
                         for (int w = 0; w < NT / 64; ++w) {
-                            const int32_t a_ = s_scan[w], b_ = s_scan[NT / 64 + w];
-                            tot += a_; tot_a += b_;
-                            if (w < wv_) { base += a_; base_a += b_; }
+                            const int32_t a_ = s_scan[w];
+                            tot += a_;
+                            if (w < wv_) base += a_;
                         }
-                        int o = carry_l + base + ib - sb, oa = carry_a + base_a + ia - sa;
+                        int o = carry_l + base + ib - sb;
+                        if (carry_l + tot > ccap) over = true;       // (uniform: every work-item sees the same totals)
+                        if (!over) {
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            if (bit[v]) acln[o++] = c[v];
-                            if (act[v]) { reinterpret_cast<FtQuad *>(actl)[oa] = FtQuad{ c[v] | (act[v] << 28), a_news[v], a_outh[v], 0 }; ++oa; }
+                            for (int v = 0; v < 4; ++v) {
+                                if (!val[v]) continue;
+                                const int at = bit[v] ? o : -1;
+                                if (bit[v]) { acln[o] = c[v]; ++o; }
+                                if (q[v] < 0) cdec[c0 + li[v] - R] = FtQuad{ at, act[v], a_news[v], a_outh[v] };
+                                else if (c_at[v] >= 0) cdst[c_at[v]] = at;
+                                else if (act[v] == 1) {
+                                    // a new channel, entered (hmm_enter into a cleared channel): node, parent | ci, children as the static
+                                    // quad has them; scores and histories at their floor but state 0
+                                    int32_t w[4 * ND];
+#pragma unroll
+                                    for (int k = 0; k < 4 * ND; ++k) w[k] = (k < NE || k == 2 * NE) ? kW : -1;
+                                    w[0] = a_news[v]; w[NE] = a_outh[v];
+#pragma unroll
+                                    for (int k = 0; k < 4 * ND; ++k) if (k > 2 * NE + 1) w[k] = 0;
+#pragma unroll
+                                    for (int k = 0; k < ND; ++k) cbuf(nxt, k)[at] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+                                    ns0[at] = FtQuad{ c[v], e0[v].x, e0[v].y, e0[v].z };
+                                    ns1[at] = e1[v];
+                                }
+                            }
                         }
-                        carry_l += tot; carry_a += tot_a;
+                        carry_l += tot;
                         ft_sync<true>();                             // (s_scan; the chunk's LDS arrays before the next chunk overwrites them)
                     }
                 }
                 FT_PROF(6);
             }
             n_listed = carry_l;
-            if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; }
-            __syncthreads();                                     // (device memory: every decision has been taken; the list of updates is complete)
-            if (use_lb) for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;       // (the next frame's list sets its own bits)
-            // -- the channel updates
-            for (int e = tid; e < carry_a; e += NT) {
-                const FtQuad au = reinterpret_cast<const FtQuad *>(actl)[e];
-                const int32_t code = au.x, news = au.y, outh = au.z;
-                const int kind = (int)((uint32_t)code >> 28);
-                int32_t *const r = tv.b + (size_t)(code & 0xffffff) * TREC;
-                static_assert(F::HIST == NE && F::OUT % 4 == 0, "record layout");
-                if (kind >= 3) {                                 // hmm_clear; the position word with it: the node leaves the list
-                    if (NE == 3) { r[F::HIST + 1] = -1; r[F::HIST + 2] = -1; }
-                    else {
+            if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; if (over) s_sc[6] = 4; }     // status 4: more than ccap tree channels listed in a frame
+            __syncthreads();                                     // (device memory: every decision has been taken: cdec, cdst, the new channels)
+            if (over) break;
+            for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;       // (this frame's index has been read for the last time)
+            // -- the channels of the nodes that stay, from their positions in this frame's buffer to their positions in the next
+            for (int j = tid; j < na; j += NT) {
+                const FtQuad d = cdec[j];
+                const int32_t h = cdst[j];
+                if (h >= 0) cdst[j] = -1;
+                const int at = d.x >= 0 ? d.x : h;
+                if (at < 0) continue;                            // (cleared: the node leaves the list, its channel ends here)
+                int32_t w[4 * ND];
+                if (d.y == 4) {                                  // cleared, then entered: a new channel's scores
 #pragma unroll
-                        for (int k = 1; k < NE; ++k) { r[F::SCORE + k] = kW; r[F::HIST + k] = -1; }
-                    }
-                    *reinterpret_cast<FtQuad *>(r + F::OUT) = FtQuad{ kW, -1, kW, -1 };
+                    for (int k = 0; k < 4 * ND; ++k) w[k] = (k < NE || k == 2 * NE) ? kW : (k <= 2 * NE + 1 ? -1 : 0);
+                    w[0] = d.z; w[NE] = d.w;
                 }
-                if (NE == 3 && kind != 2) {                      // the first quad is known: score[0..2], history[0]
-                    const bool ent = kind != 3;
-                    *reinterpret_cast<FtQuad *>(r) = FtQuad{ ent ? news : kW, kW, kW, ent ? outh : -1 };
+                else {
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) { const FtQuad q_ = cbuf(cur, k)[j]; w[4 * k] = q_.x; w[4 * k + 1] = q_.y; w[4 * k + 2] = q_.z; w[4 * k + 3] = q_.w; }
+                    if (d.y == 2) { w[0] = d.z; w[NE] = d.w; }   // hmm_enter
                 }
-                else if (kind != 3) { r[F::SCORE] = news; r[F::HIST] = outh; }
-                else { r[F::SCORE] = kW; r[F::HIST] = -1; }
+#pragma unroll
+                for (int k = 0; k < ND; ++k) cbuf(nxt, k)[at] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+                ns0[at] = cs0[j]; ns1[at] = cs1[j];
             }
+            __syncthreads();                                     // (the bitmap is clear)
+            build_index(acln.b, n_listed);
             FT_PROF(4);
         }
         } else {
@@ -2458,7 +2580,8 @@ static bool ft_layout(FtDev &d, bool small)
     auto take = [&](int64_t n) { const int64_t r = o; o += (n + 3) & ~(int64_t)3; return (int32_t)r; };
     FtLay &L = d.lay;
     memset(&L, 0, sizeof L);
-    L.rec = take((int64_t)d.CH * (small ? words : rec));
+    // (slab layouts: records of the roots and the single-phone words only -- the other tree nodes' channels exist while they are listed, compact)
+    L.rec = take(small ? (int64_t)d.CH * words : ((int64_t)d.R + d.n1) * rec);
     if (small) {                         // the interleaved blocks (FtCol): the per-node and per-word arrays as columns
         L.node_blk = take(((int64_t)d.N + 1) * kFtNodeCols); L.word_blk = take(((int64_t)d.n_w + 2) * kFtWordCols);
     }
@@ -2502,8 +2625,13 @@ static bool ft_layout(FtDev &d, bool small)
         L.l_norm = take(kFtThreads / 64 * kSenStreams);
     }
     else {
-        L.itb = take(4 * ((int64_t)d.R + d.N)); L.act = take(4 * 2 * (int64_t)d.N + 16);
-        d.lb_words = ((int64_t)d.R + d.N + 31) / 32 <= kFtMaxBitWords ? (int32_t)(((int64_t)d.R + d.N + 31) / 32) : 0;
+        L.itb = take(4 * (int64_t)d.R);
+        const int nd = ne == 3 ? 2 : 3;
+        L.ccap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, kFtMaxListed));
+        L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cdec = take(4 * (int64_t)L.ccap);
+        L.cdst = take(L.ccap); L.cperm = take(((int64_t)L.ccap + 1) / 2);
+        if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords) return false;     // (the listed-nodes bitmap lives in LDS)
+        d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
         L.evl = take(L.evl_cap);
     }
@@ -2516,6 +2644,26 @@ static bool ft_layout(FtDev &d, bool small)
     d.g_fast = small ? 0 : gtake(o);
     d.per = g;
     return true;
+}
+
+// slab layouts: the dynamic LDS pool of a launch with `nt` work-items an utterance -- the pruning's item arrays (9 arrays of 2 nt words
+// + 16), the listed-nodes bitmap, its words' prefix populations (uint16), the frame's score row, the transition matrices, and in what
+// is left of kFtSlabPoolWords the rank -> list position table (uint16 entries; a frame that lists more keeps the table in the slab)
+static void ft_slab_pool(FtDev &d, int nt)
+{
+    int32_t o = 9 * 2 * nt + 16;
+    auto take = [&](int32_t n) { const int32_t r = o; o += (n + 3) & ~3; return r; };
+    d.lds_lb = take(d.lb_words);
+    d.lds_pre = take(d.lb_words / 2 + 2);
+    d.lds_row = take((d.n_sen + 1) / 2 + 4);
+    d.lds_tp = take((d.n_tmat * d.n_emit * (d.n_emit + 1) + 3) / 4);
+    d.lds_perm = o;
+    const int32_t left = std::max(0, kFtSlabPoolWords - o) & ~3;
+    d.lds_perm_cap = (int32_t)std::min<int64_t>(2 * (int64_t)left, ((int64_t)d.lay.ccap + 7) & ~(int64_t)7);
+    if (const char *cap = getenv("PSGPU_FWDTREE_PERM_CAP"))     // (a test's knob: frames that list more take the table in the slab)
+        d.lds_perm_cap = (int32_t)std::max<int64_t>(0, std::min<int64_t>(d.lds_perm_cap, atoll(cap) & ~7ll));
+    o += d.lds_perm_cap / 2;
+    d.lds_words = (o + 3) & ~3;
 }
 
 #ifdef PSGPU_FT_PROFILE
@@ -2621,16 +2769,32 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
         for (int k = 0; k < d.M; ++k) kc[k] = (int32_t)((uint32_t)kids[k] | ((uint32_t)t->node_ci[kids[k]] << 24));
         d.kids_ci = ft_up(m, kc.data(), kc.size(), &rc);
         const int nsq = d.n_emit <= 3 ? 4 : 8;
-        std::vector<int32_t> q1((size_t)d.N * 4, 0), q2((size_t)d.N * 4, 0), qs((size_t)d.N * nsq, 0);
+        std::vector<int32_t> q1((size_t)d.N * 4, 0), q2((size_t)d.N * 4, 0), qs((size_t)d.N * nsq, 0), st1((size_t)d.N * 4, 0);
+        for (int c = 0; c < d.N; ++c)
+            if (kid_off[c + 1] - kid_off[c] > 0xffff || t->node_tmat[c] > 0xffff || t->node_tmat[c] < 0) {
+                psgpu_set_error("fwdtree: node %d has %d children / transition matrix %d (16-bit fields)", c, kid_off[c + 1] - kid_off[c], t->node_tmat[c]);
+                psgpu_fwdtree_free(m);
+                return PSGPU_EINVAL;
+            }
         for (int c = 0; c < d.N; ++c) {
             const int k0 = kid_off[c], nk = kid_off[c + 1] - k0, pw = t->node_penult_wid[c];
             q1[(size_t)c * 4] = (int32_t)((uint32_t)(parent[c] < 0 ? 0 : parent[c]) | ((uint32_t)t->node_ci[c] << 24));
-            q1[(size_t)c * 4 + 1] = k0; q1[(size_t)c * 4 + 2] = nk; q1[(size_t)c * 4 + 3] = nk > 0 ? kc[k0] : -1;
+            q1[(size_t)c * 4 + 1] = k0; q1[(size_t)c * 4 + 2] = nk | ((pw >= 0 ? 1 : 0) << 16); q1[(size_t)c * 4 + 3] = nk > 0 ? kc[k0] : -1;
+            {
+                uint32_t pk[3] = { 0, 0, 0 };
+                for (int k = 0; k <= d.n_emit; ++k) {       // (the states' senones, then the transition matrix: 16 bits each)
+                    const uint32_t v = k < d.n_emit ? (uint32_t)t->sseq[(size_t)t->node_ssid[c] * d.n_emit + k] : (uint32_t)t->node_tmat[c];
+                    pk[k >> 1] |= (v & 0xffffu) << (16 * (k & 1));
+                }
+                st1[(size_t)c * 4] = (int32_t)pk[0]; st1[(size_t)c * 4 + 1] = (int32_t)pk[1]; st1[(size_t)c * 4 + 2] = (int32_t)pk[2];
+                st1[(size_t)c * 4 + 3] = nk > 0 ? kc[k0] : -1;
+            }
             q2[(size_t)c * 4] = pw; q2[(size_t)c * 4 + 1] = pw >= 0 ? t->dict_last[pw] : 0; q2[(size_t)c * 4 + 2] = pw >= 0 ? t->homophone_set[pw] : -1;
             for (int k = 0; k < d.n_emit; ++k) qs[(size_t)c * nsq + k] = t->sseq[(size_t)t->node_ssid[c] * d.n_emit + k];
         }
         d.node_q1 = ft_up(m, q1.data(), q1.size(), &rc); d.node_q2 = ft_up(m, q2.data(), q2.size(), &rc);
         d.node_sen = ft_up(m, qs.data(), qs.size(), &rc);
+        d.node_st1 = ft_up(m, st1.data(), st1.size(), &rc);
         // ... and what ngram_search_alloc_all_rc (ngram_search.c:583-633) gives a word's right-context channels, per slot
         std::vector<int32_t> ss((size_t)std::max<int64_t>(tot, 1) * nsq, 0);
         for (int w = 0; w < d.n_w; ++w) {
@@ -2665,7 +2829,12 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     // parity tests run both)
     const char *force = getenv("PSGPU_FWDTREE_LAYOUT");
     if ((force && !strcmp(force, "slab")) || !ft_layout(d, true)) {
-        if (!ft_layout(d, false)) { psgpu_set_error("fwdtree: the search's per-utterance arrays exceed 8 GB"); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
+        if (!ft_layout(d, false)) {
+            psgpu_set_error("fwdtree: %d tree nodes (the slab layouts keep a bitmap of at most %d nodes in LDS), or per-utterance arrays beyond 8 GB",
+                            d.N, 32 * kFtMaxBitWords);
+            psgpu_fwdtree_free(m);
+            return PSGPU_EINVAL;
+        }
     }
     if (getenv("PSGPU_FT_DUMP_LAYOUT")) {                 // (a measuring aid: the layout as an initialiser list)
         const int32_t *w = reinterpret_cast<const int32_t *>(&d.lay);
@@ -2888,14 +3057,17 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     // ~10^4 active channels per frame on a large tree: 16 waves per utterance
     const bool big = d.N + d.R > kFtBigNodes || d.n_w > 1024;
-    const size_t pool_bytes = d.small ? sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total)
-                                      : sizeof(int32_t) * (size_t)(18 * (big ? kFtThreadsBig : kFtThreads) + 16 + d.lb_words);      // (slab: the pruning's item arrays, the listed-nodes bitmap)
+    if (!d.small) {
+        ft_slab_pool(d, big ? kFtThreadsBig : kFtThreads);
+        PSGPU_REQUIRE(d.lds_words <= kFtSlabPoolWords, "fwdtree (slab layout): the kernel's LDS arrays take %d words (at most %d)", d.lds_words, kFtSlabPoolWords);
+    }
+    const size_t pool_bytes = d.small ? sizeof(int32_t) * (size_t)(ls ? d.lay.total : d.lay.rows_total) : sizeof(int32_t) * (size_t)d.lds_words;
 #if defined(__HIPCC__)                    /* a pool that takes the workgroup's LDS beyond the default 64 KB (scoring from lists): say so once */
 #define FT_DYN_LDS(NE, NT, SMALL, LISTS)                                                                              \
         if (pool_bytes + 4096 > 65536) {                                                                              \
             static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdtree_kernel<NE, NT, SMALL, LISTS>, \
                               hipFuncAttributeMaxDynamicSharedMemorySize,                                            \
-                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * (18 * (NT) + 16 + kFtMaxBitWords)));          \
+                              (int)((SMALL) ? sizeof(int32_t) * kFtLdsWords : sizeof(int32_t) * kFtSlabPoolWords));          \
             PSGPU_HIP(attr_rc);                                                                                       \
         }
 #else

@@ -107,6 +107,22 @@ def test_search_kernel_source_full_cmudict_vocabulary(big_trace, order):  # noqa
     lm.close()
 
 
+@pytest.mark.parametrize("cap", ["0", "64"])
+def test_search_kernel_source_rank_table_in_the_slab(big_trace, cap):  # noqa: F811
+    """slab layouts: the listed nodes' index (bitmap -> rank -> position).  The rank -> position table is LDS while the frame's list fits
+    what the pool has left and lies in the utterance's slab otherwise: PSGPU_FWDTREE_PERM_CAP cuts the LDS table down so that every frame
+    (0) / every frame with more than 64 listed nodes takes the slab's -- on the full cmudict task and on a small one."""
+    with _env("PSGPU_FWDTREE_PERM_CAP", cap):
+        g = big_trace
+        lm = simlib.SimLm(g)
+        s = simlib.SimFwdtreeSearch(g, g["par"], lm=lm)
+        rows, pen = _inputs(g, s.n_sen)
+        _check(s.search(rows, pen, [rows.shape[0]])[0], g, "cmudict (perm cap %s)" % cap)
+        s.close(); lm.close()
+        _run("goforward", "rev", layout="slab")
+        _run("man_ah_2934za", "fwd", layout="slab")             # (5-state HMMs)
+
+
 @pytest.mark.parametrize("name", LM_CASES)
 def test_simulated_device_trie_equals_reference_look_ups(name):
     """psgpu_lm_dev.h through the simulator against the reference's recorded look-ups"""
