@@ -64,8 +64,7 @@ constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list
 constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (at most 32 KB of the pool)
 constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS (likewise)
 constexpr int kFtSlabPoolWords = 39808;    // slab layouts: words of dynamic LDS a workgroup may ask for (155.5 of a compute unit's 160 KB; ~3.5 KB are static)
-constexpr int kFtMaxListed = 65535;    // slab layouts: tree channels listed in one frame (their records are kept compact, in list order: FtLay::cq;
-                                       // list positions are 16-bit in the rank -> position table); more: status 4
+constexpr int kFtLbBlock = 1024;       // slab layouts: words of the listed-nodes bitmap per block of 16-bit prefix populations (32,768 nodes: a count fits)
 constexpr int kFtLiveMagic = 0x5ea4c4ed;
 constexpr int kFtLiveHdr = 32;         // FtBufs::live: words ahead of the pool's copy
 constexpr int kFtWordCh = 0x40000000;  // evaluation-list entries that name a right-context channel
@@ -95,8 +94,9 @@ struct FtLay {
     int32_t csum;                        // [ccap][4] per list position: out, out history, best, score[0] as the evaluation left them
     int32_t cdec;                        // [ccap][4] per list position: the node's own decision {place in the next list or -1, kind, entering score, history}
     int32_t cdst;                        // [ccap] per list position: the place in the next list its PARENT's pair gave the node, or -1 (reset when read)
-    int32_t cperm;                       // [ccap] uint16: rank among the listed nodes by node id -> list position, when the frame's list outgrows the LDS table
-    int32_t ccap;                        // listed nodes a frame may hold: min(N - R, kFtMaxListed)
+    int32_t cnew;                        // [ccap][2] per position of the NEXT list: entering score and history of a node that enters the list
+    int32_t cperm;                       // [ccap] rank among the listed nodes by node id -> list position, when the frame's list outgrows the LDS table
+    int32_t ccap;                        // listed nodes a frame may hold: N - R, every node but the roots
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
     int32_t wc_off;                      // small layout: copy of the words' first right-context slot
     int32_t row, pen;                    // small layout: the frame's score row (int16) and two penalty rows
@@ -114,11 +114,11 @@ struct FtDev {
     int32_t beam, pbeam, lpbeam, lponlybeam, wbeam, pip, nwpen, silpen, fillpen, maxhmmpf, maxwpf;
     int32_t startwid, finishwid, silwid, filler_start, filler_end, sil_ci, has_pl;
     const int32_t *node_ci, *node_ci2, *node_ssid, *node_tmat, *node_pw, *parent, *kid_off, *kids;
-    const int32_t *kids_ci;              // kids with the child's ci phone in the top byte (slab layouts: child | ci << 24)
+    const int32_t *kids_ci;              // slab layouts: per node its children (child | ci << 24), then its penultimate-phone words (word | last phone << 24)
     // slab layouts: what the pruning and the senone marking ask about a node, as quads (one request each), shared by all
     // utterances (8 MB at 248 k nodes: L2 / MALL resident):
-    const int32_t *node_q1;              // [N][4] parent | ci << 24, first child (index into kids), number of children | (a word's penultimate node) << 16,
-                                         // kids_ci[first child] or -1
+    const int32_t *node_q1;              // [N][4] parent | ci << 24, the node's first entry in kids_ci, children | penultimate-phone words << 16, that first
+                                         // entry or -1
     const int32_t *node_st1;             // [N][4] the node's senone ids and transition matrix as a compact channel carries them: 16 bits each (3 states:
                                          // s0 | s1 << 16, s2 | tmat << 16, 0; 5 states: s0 | s1 << 16, s2 | s3 << 16, s4 | tmat << 16), then kids_ci[first child]
     const int32_t *node_q2;              // [N][4] penultimate-phone word, its last phone, its homophone link, 0
@@ -214,6 +214,8 @@ template <int NE> struct ChF {
     static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
 struct alignas(16) FtQuad { int32_t x, y, z, w; };
+struct alignas(8) FtPair { int32_t x, y; };
+constexpr int32_t kFtNewCh = (int32_t)0x80000000;     // slab layouts, next active list while it is made: the node enters the list (its channel is still to be made)
 // One column of a block of interleaved arrays (LDS layout: AOS, element i at word i * K of the column's base) or a plain array
 // (slab layouts).  Why interleave: this kernel's speed follows the number of scalar values it keeps alive -- the compiler gives
 // every array's base a scalar register, spills what does not fit into vector-register lanes and reads it back with v_readlane
@@ -858,6 +860,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     uint32_t *const s_lb = reinterpret_cast<uint32_t *>(s_pool + (SMALL ? 0 : p.lds_lb));
     uint16_t *const s_pre = reinterpret_cast<uint16_t *>(s_pool + (SMALL ? 0 : p.lds_pre));
     uint16_t *const s_perm = reinterpret_cast<uint16_t *>(s_pool + (SMALL ? 0 : p.lds_perm));
+    __shared__ int32_t s_sup[kFtMaxBitWords / kFtLbBlock];       // listed nodes before each block of kFtLbBlock bitmap words (s_pre counts from the block's start)
     __shared__ int32_t s_nroot;          // slab layouts: roots evaluated in the frame
     __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
     // slab layouts: the frame's score row and the transition matrices in LDS too (the pool) -- a channel's evaluation then asks device
@@ -973,7 +976,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     FtQuad *const cq = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cq));
     FtQuad *const csum = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.csum)), *const cdec = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cdec));
     int32_t *const cdst = fb + (SMALL ? 0 : L.cdst);
-    uint16_t *const g_perm = reinterpret_cast<uint16_t *>(fb + (SMALL ? 0 : L.cperm));
+    int32_t *const g_perm = fb + (SMALL ? 0 : L.cperm);
     auto cbuf = [&](int b, int k) { return cq + (size_t)(b * (ND + 2) + k) * ccap; };      // array k of buffer b
     const FtQuad *const node_st1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_st1));
     bool perm_lds = true;                                              // the current list's rank -> position table is the LDS one (uniform)
@@ -1061,20 +1064,39 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     auto build_index = [&](const int32_t *list, int n) {
         for (int o = tid; o < n; o += NT) { const int c = list[o]; atomicOr(&s_lb[c >> 5], 1u << (c & 31)); }
         __syncthreads();
-        const int nwl = p.lb_words, K = (nwl + NT - 1) / NT, b = min(nwl, tid * K), e = min(nwl, b + K);     // K consecutive words a work-item
+        // K consecutive words a work-item, K a power of two: a work-item's words lie in one block of kFtLbBlock
+        const int nwl = p.lb_words;
+        int K = 1;
+        while (K * NT < nwl) K *= 2;
+        const int b = min(nwl, tid * K), e = min(nwl, b + K);
         int32_t v[1] = { 0 }, tot[1];
         for (int w = b; w < e; ++w) v[0] += __popc(s_lb[w]);
         ft_scan_tid<NT, 1, true>(v, s_scan, tot);
-        int32_t run = v[0];
-        for (int w = b; w < e; ++w) { s_pre[w] = (uint16_t)run; run += __popc(s_lb[w]); }
+        if (b < nwl && (b & (kFtLbBlock - 1)) == 0) s_sup[b / kFtLbBlock] = v[0];
+        ft_sync<true>();
+        if (b < nwl) {
+            int32_t run = v[0] - s_sup[b / kFtLbBlock];
+            for (int w = b; w < e; ++w) { s_pre[w] = (uint16_t)run; run += __popc(s_lb[w]); }
+        }
         __syncthreads();
         perm_lds = n <= p.lds_perm_cap;                  // (a frame that lists more than the LDS table holds keeps the table in the slab)
         for (int o = tid; o < n; o += NT) {
             const int c = list[o];
-            const int r = (int)s_pre[c >> 5] + __popc(s_lb[c >> 5] & ((1u << (c & 31)) - 1u));
-            if (perm_lds) s_perm[r] = (uint16_t)o; else g_perm[r] = (uint16_t)o;
+            const int r = s_sup[c >> 15] + (int)s_pre[c >> 5] + __popc(s_lb[c >> 5] & ((1u << (c & 31)) - 1u));
+            if (perm_lds) s_perm[r] = (uint16_t)o; else g_perm[r] = o;
         }
+#ifdef PSGPU_FT_CHECK_LISTS
+        __syncthreads();
+        for (int o = tid; o < n; o += NT) {
+            const int c = list[o];
+            const int r = c < 0 ? -1 : s_sup[c >> 15] + (int)s_pre[c >> 5] + __popc(s_lb[c >> 5] & ((1u << (c & 31)) - 1u));
+            const int ps = r < 0 ? -1 : (perm_lds ? (int)s_perm[r] : g_perm[r]);
+            if (ps != o) { printf("index of %d listed nodes: position %d holds node %d, whose rank %d leads to position %d\n", n, o, c, r, ps); abort(); }
+        }
+        __syncthreads();
+#endif
     };
+    static_assert(kFtLbBlock == 1024, "a bitmap word's block is node >> 15");
     if (resumed) {
         // the pool as the previous call's last frame left it (the static tables' copies with it), the counters, the frame loop's
         // carried registers; the senone bitmap, the listed-nodes bitmap and the normaliser are reset at every frame's end and are as
@@ -1424,28 +1446,38 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
                 // the listed nodes' compact channels, position by position: ND + 1 quads in, ND + 1 out, every one in a row with its
                 // neighbours'; never multiplexed (the senones are the channel's own)
-                for (int j = tid; j < na; j += NT) {
-                    int32_t w[4 * ND];
+                // (two positions a work-item at a time: their loads are asked for together)
+                for (int j0 = tid; j0 < na; j0 += 2 * NT) {
+                    int32_t w[2][4 * ND]; FtQuad sq[2];
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) { const FtQuad q = cbuf(cur, k)[j]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
-                    const FtQuad sq = cbuf(cur, ND + 1)[j];
+                    for (int u = 0; u < 2; ++u) {
+                        const int j = min(j0 + u * NT, na - 1);
+#pragma unroll
+                        for (int k = 0; k < ND; ++k) { const FtQuad q = cbuf(cur, k)[j]; w[u][4 * k] = q.x; w[u][4 * k + 1] = q.y; w[u][4 * k + 2] = q.z; w[u][4 * k + 3] = q.w; }
+                        sq[u] = cbuf(cur, ND + 1)[j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                    const int j = j0 + u * NT;
+                    if (j >= na) continue;
                     HmmRegs h;
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) { h.score[k] = k < NE ? w[k] : kW; h.history[k] = k < NE ? w[NE + k] : -1; h.senid[k] = 0; }
-                    h.senid[0] = (uint16_t)(sq.x & 0xffff); h.senid[1] = (uint16_t)((uint32_t)sq.x >> 16); h.senid[2] = (uint16_t)(sq.y & 0xffff);
-                    int tm = (int)((uint32_t)sq.y >> 16);
-                    if (NE == 5) { h.senid[3] = (uint16_t)((uint32_t)sq.y >> 16); h.senid[4] = (uint16_t)(sq.z & 0xffff); tm = (int)((uint32_t)sq.z >> 16); }
-                    h.out_score = w[2 * NE]; h.out_history = w[2 * NE + 1]; h.bestscore = kW;
+                    for (int k = 0; k < 5; ++k) { h.score[k] = k < NE ? w[u][k] : kW; h.history[k] = k < NE ? w[u][NE + k] : -1; h.senid[k] = 0; }
+                    h.senid[0] = (uint16_t)(sq[u].x & 0xffff); h.senid[1] = (uint16_t)((uint32_t)sq[u].x >> 16); h.senid[2] = (uint16_t)(sq[u].y & 0xffff);
+                    int tm = (int)((uint32_t)sq[u].y >> 16);
+                    if (NE == 5) { h.senid[3] = (uint16_t)((uint32_t)sq[u].y >> 16); h.senid[4] = (uint16_t)(sq[u].z & 0xffff); tm = (int)((uint32_t)sq[u].z >> 16); }
+                    h.out_score = w[u][2 * NE]; h.out_history = w[u][2 * NE + 1]; h.bestscore = kW;
                     uint8_t tpb[NE * (NE + 1)];
                     const uint8_t *tp = ft_tp_row<NE>(tpall, tm, tpb);
                     const int32_t sc = NE == 3 ? vit3(h, tp, sr) : vit5(h, tp, sr);
 #pragma unroll
-                    for (int k = 0; k < NE; ++k) { w[k] = h.score[k]; w[NE + k] = h.history[k]; }
-                    w[2 * NE] = h.out_score; w[2 * NE + 1] = h.out_history;
+                    for (int k = 0; k < NE; ++k) { w[u][k] = h.score[k]; w[u][NE + k] = h.history[k]; }
+                    w[u][2 * NE] = h.out_score; w[u][2 * NE + 1] = h.out_history;
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+                    for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[u][4 * k], w[u][4 * k + 1], w[u][4 * k + 2], w[u][4 * k + 3] };
                     csum[j] = FtQuad{ h.out_score, h.out_history, h.bestscore, h.score[0] };
                     b_all = max(b_all, sc);
+                    }
                 }
             }
             for (int e = tid; e < n_evl; e += NT) {
@@ -1564,92 +1596,65 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         {
             const int n_item = R + na;
             int carry_l = 0, carry_c = 0;                        // next list's entries / candidates so far (uniform)
+            FtPair *const cnew = reinterpret_cast<FtPair *>(fb + L.cnew);
             const FtQuad *const cs0 = cbuf(cur, ND), *const cs1 = cbuf(cur, ND + 1);
             FtQuad *const ns0 = cbuf(nxt, ND), *const ns1 = cbuf(nxt, ND + 1);
             bool over = false;                                   // the next list outgrows the compact buffers (uniform)
             for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
-                // -- the chunk's items, two consecutive ones a work-item -> LDS; pairs and candidates counted
-                int32_t np[2], kc[2], c_w[2], c_news[2], c_outh[2], c_homo[2], c_dl[2];
+                // -- the chunk's items, two consecutive ones a work-item -> LDS; their pairs counted: the item's own entry (listed nodes),
+                //    its children (retained items), the words whose penultimate phone it is (retained items whose out score can reach the
+                //    last-phone beam, :824-870)
+                int32_t np[2];
                 {
                     int node[2]; FtQuad it[2], q1[2];
-                    bool hpw[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int i = c0 + 2 * tid + u;
                         node[u] = -1; it[u] = FtQuad{ kW, -1, kW, 0 }; q1[u] = FtQuad{ 0, 0, 0, -1 };
                         if (i < R) { node[u] = i; it[u] = itb[i]; q1[u] = node_q1[i]; }
                         else if (i < n_item) {
-                            const FtQuad a = cs0[i - R];         // node, parent | ci << 24, first child's index, children | penultimate << 16
+                            const FtQuad a = cs0[i - R];         // node, parent | ci << 24, first entry's index, children | words << 16
                             it[u] = csum[i - R];
                             node[u] = a.x; q1[u] = FtQuad{ a.y, a.z, a.w, cs1[i - R].w };
                         }
-                        hpw[u] = ((uint32_t)q1[u].z >> 16) != 0u;
-                        q1[u].z &= 0xffff;
                     }
-                    FtQuad qd[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int li = 2 * tid + u, i = c0 + li;
                         const bool active = i < R ? it[u].w != 0 : node[u] >= 0;
                         const bool fl = active && it[u].z > thresh;
-                        const int32_t fp = (fl ? 1 : 0) | (i < R || node[u] < 0 ? 0 : ((i - R + 1) << 1));
-                        np[u] = node[u] >= 0 ? (i >= R ? 1 : 0) + (fl ? q1[u].z : 0) : 0;
-                        s_it_node[li] = node[u]; s_it_out[li] = it[u].x; s_it_outh[li] = it[u].y; s_it_fp[li] = fp;
+                        const int nk = fl ? (q1[u].z & 0xffff) : 0, nw = (int)((uint32_t)q1[u].z >> 16);
+                        const bool cand = fl && nw > 0 && (p.has_pl || it[u].x + p.pip > lpt);
+                        np[u] = node[u] >= 0 ? (i >= R ? 1 : 0) + nk + (cand ? nw : 0) : 0;
+                        s_it_node[li] = node[u]; s_it_out[li] = it[u].x; s_it_outh[li] = it[u].y; s_it_fp[li] = (fl ? 1 : 0) | (nk << 1);
                         s_it_k0[li] = q1[u].y; s_it_par[li] = q1[u].x; s_it_sc0[li] = it[u].w; s_it_kid0[li] = q1[u].w;
                         if (i < R && fl) tv.at(node[u], F::FRAME) = nf;     // a retained root stays (no decision reads this stamp before it is >= f)
-                        // last-phone candidates of the item (:824-870): the words whose penultimate phone this node is, the
-                        // homophone chain in order; the first word, its last phone and link come as one static quad
-                        const int32_t news = it[u].x + p.pip;
-                        c_news[u] = news; c_outh[u] = it[u].y;
-                        qd[u] = FtQuad{ -1, 0, -1, 0 };
-                        if (fl && hpw[u] && (p.has_pl || news > lpt)) qd[u] = node_q2[node[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        kc[u] = 0; c_w[u] = qd[u].x; c_homo[u] = qd[u].z; c_dl[u] = qd[u].y;
-                        if (qd[u].x >= 0) {
-                            kc[u] = (c_news[u] + ft_pen(qd[u].y) > lpt) ? 1 : 0;
-                            for (int w = qd[u].z; w >= 0; w = homo_f[w]) kc[u] += (c_news[u] + ft_pen(dlast_f[w]) > lpt) ? 1 : 0;
-                        }
                     }
                 }
                 FT_PROF(28);
                 // exclusive prefix sums over the chunk's items, in item order (two consecutive items a work-item)
-                int32_t n_pair, n_cd;
+                int32_t n_pair;
                 {
                     const int lane = tid & 63, wv_ = tid >> 6;
-                    const int32_t sp = np[0] + np[1], sk = kc[0] + kc[1];
-                    const int32_t ip = ft_wave_incl<FtAdd>(sp), ik = ft_wave_incl<FtAdd>(sk);
-                    if (lane == 63) { s_scan[wv_] = ip; s_scan[NT / 64 + wv_] = ik; }
+                    const int32_t sp = np[0] + np[1];
+                    const int32_t ip = ft_wave_incl<FtAdd>(sp);
+                    if (lane == 63) s_scan[wv_] = ip;
                     ft_sync<true>();
-                    int32_t bp_ = 0, bk_ = 0; n_pair = 0; n_cd = 0;
+                    int32_t bp_ = 0; n_pair = 0;
 #pragma unroll
                     for (int w = 0; w < NT / 64; ++w) {
-                        const int32_t a_ = s_scan[w], b_ = s_scan[NT / 64 + w];
-                        n_pair += a_; n_cd += b_;
-                        if (w < wv_) { bp_ += a_; bk_ += b_; }
+                        const int32_t a_ = s_scan[w];
+                        n_pair += a_;
+                        if (w < wv_) bp_ += a_;
                     }
-                    const int32_t op = bp_ + ip - sp, ok_ = bk_ + ik - sk;
+                    const int32_t op = bp_ + ip - sp;
                     s_it_poff[2 * tid] = op; s_it_poff[2 * tid + 1] = op + np[0];
                     if (tid == NT - 1) s_it_poff[kPrIC] = n_pair;
-                    // the candidates, in item order then chain order
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        int oc = carry_c + ok_ + (u ? kc[0] : 0);
-                        if (kc[u] > 0) {
-                            for (int w = c_w[u], first = 1; w >= 0; first = 0) {
-                                const int lastp = first ? c_dl[u] : dlast_f[w];
-                                if (c_news[u] + ft_pen(lastp) > lpt) { cand_wid[oc] = w; cand_score[oc] = c_news[u] - p.nwpen; cand_bp[oc] = c_outh[u]; ++oc; }
-                                w = first ? c_homo[u] : homo_f[w];
-                            }
-                        }
-                    }
                     ft_sync<true>();                                 // (the chunk's LDS arrays are complete; s_scan is free again)
                 }
-                carry_c += n_cd;
                 FT_PROF(5);
-                // -- the chunk's (item, child) pairs, four consecutive ones a work-item: the item's own entry first (listed
-                //    nodes), then its children in sibling order (retained items only)
+                // -- the chunk's pairs, four consecutive ones a work-item: the item's own entry first (listed nodes), then its children
+                //    in sibling order, then its penultimate-phone words in chain order
                 for (int p0 = 0; p0 < n_pair; p0 += 4 * NT) {
                     int li[4], q[4], c[4], cci[4]; bool val[4];
                     const int jb = p0 + 4 * tid;
@@ -1667,7 +1672,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         }
                     }
                     FT_PROF(1);
-                    // a child's id and phone: the item's first child came with the item; the others from the static table
+                    // a child's id and phone (a word's id and last phone): the item's first entry came with the item; the others from the
+                    // static table
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         c[v] = -1; cci[v] = 0;
@@ -1694,16 +1700,22 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     for (int v = 0; v < 4; ++v) {
                         qx[v] = FtQuad{ kW, -1, kW, -1 };
                         csc[v] = kW;
-                        if (val[v]) {
+                        if (val[v] && q[v] < (s_it_fp[li[v]] >> 1)) {     // (a word's pair looks at nothing)
                             const int o_ = q[v] < 0 ? (s_it_par[li[v]] & 0xffffff) : c[v];
                             if (o_ < R) qx[v] = *reinterpret_cast<const FtQuad *>(tv.b + (size_t)o_ * TREC + F::OUT);
                             else {
                                 const uint32_t wb = s_lb[o_ >> 5];
                                 if ((wb >> (o_ & 31)) & 1u) {
-                                    const int r = (int)s_pre[o_ >> 5] + __popc(wb & ((1u << (o_ & 31)) - 1u));
-                                    const int ps = perm_lds ? (int)s_perm[r] : (int)g_perm[r];
+                                    const int r = s_sup[o_ >> 15] + (int)s_pre[o_ >> 5] + __popc(wb & ((1u << (o_ & 31)) - 1u));
+                                    const int ps = perm_lds ? (int)s_perm[r] : g_perm[r];
 #ifdef PSGPU_FT_CHECK_LISTS
-                                    if (ps >= na || aclc[ps] != o_) { printf("frame %d: node %d -> rank %d -> position %d holds node %d (%d listed)\n", f, o_, r, ps, ps < na ? aclc[ps] : -1, na); abort(); }
+                                    if (ps >= na || aclc[ps] != o_) {
+                                        int where = -1, nb = 0;
+                                        for (int z = 0; z < na; ++z) if (aclc[z] == o_) where = z;
+                                        for (int z = 0; z < p.lb_words; ++z) nb += __popc(s_lb[z]);
+                                        printf("frame %d: node %d -> rank %d -> position %d holds node %d (%d listed; the node is at %d; %d bits set; pair q %d of item %d node %d, perm_lds %d)\n", f, o_, r, ps, ps < na ? aclc[ps] : -1, na, where, nb, q[v], c0 + li[v], s_it_node[li[v]], (int)perm_lds);
+                                        abort();
+                                    }
 #endif
                                     const FtQuad sm = csum[ps];
                                     qx[v] = FtQuad{ sm.x, sm.y, sm.z, ps + 1 };
@@ -1712,22 +1724,29 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                             }
                         }
                     }
-                    int32_t bit[4], act[4], a_news[4], a_outh[4], c_at[4];
+                    int32_t bit[4], cbit[4], act[4], a_news[4], a_outh[4], c_at[4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        bit[v] = 0; act[v] = 0; a_news[v] = 0; a_outh[v] = -1; c_at[v] = -1;
+                        bit[v] = 0; cbit[v] = 0; act[v] = 0; a_news[v] = 0; a_outh[v] = -1; c_at[v] = -1;
                         if (!val[v]) continue;
                         const bool self = q[v] < 0;
+                        const int my_pos = c0 + li[v] - R;           // the item's position in the active list (a listed node's)
+                        if (!self && q[v] >= (s_it_fp[li[v]] >> 1)) {
+                            // a last-phone candidate (:824-870): {word, score without the word insertion penalty, history}
+                            a_news[v] = s_it_out[li[v]] + p.pip; a_outh[v] = s_it_outh[li[v]];
+                            cbit[v] = (a_news[v] + ft_pen(cci[v]) > lpt) ? 1 : 0;
+                            continue;
+                        }
                         const int P = self ? (s_it_par[li[v]] & 0xffffff) : s_it_node[li[v]];
                         // the parent's side: a root (active: its stamp is this frame's or the next's), or a node with a list position
                         const bool p_root = P < R;
                         const bool p_active = !self || (p_root ? qx[v].w >= f : qx[v].w > 0);
-                        const int p_pos = self ? (p_root ? -1 : qx[v].w - 1) : (s_it_fp[li[v]] >> 1) - 1;
+                        const int p_pos = self ? (p_root ? -1 : qx[v].w - 1) : my_pos;
                         const bool p_flag = self ? (p_active && qx[v].z > thresh) : (s_it_fp[li[v]] & 1);
                         const int32_t p_out = self ? qx[v].x : s_it_out[li[v]], p_outh = self ? qx[v].y : s_it_outh[li[v]];
                         // the node's side
                         const bool in_acl = self || qx[v].w > 0;
-                        const int c_pos = self ? (s_it_fp[li[v]] >> 1) - 1 : qx[v].w - 1;
+                        const int c_pos = self ? my_pos : qx[v].w - 1;
                         const bool retc = self ? (s_it_fp[li[v]] & 1) : (in_acl && qx[v].z > thresh);
                         const int32_t c_score = self ? s_it_sc0[li[v]] : csc[v];
                         const int32_t news = (p_active ? p_out : kW) + p.pip;
@@ -1754,56 +1773,38 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         }
                     }
                     FT_PROF(13);
-                    // the static side of the channels this round makes (asked for before the barrier below)
-                    FtQuad e0[4], e1[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        e0[v] = FtQuad{ 0, 0, 0, 0 }; e1[v] = FtQuad{ 0, 0, 0, -1 };
-                        if (act[v] == 1) { e0[v] = node_q1[c[v]]; e1[v] = node_st1[c[v]]; }
-                    }
-                    // positions in the next active list: pair order
+                    // positions in the next active list and in the candidate list: pair order
                     {
                         const int lane = tid & 63, wv_ = tid >> 6;
-                        const int32_t sb = bit[0] + bit[1] + bit[2] + bit[3];
-                        const int32_t ib = ft_wave_incl<FtAdd>(sb);
-                        if (lane == 63) s_scan[wv_] = ib;
+                        const int32_t sb = bit[0] + bit[1] + bit[2] + bit[3], sc_ = cbit[0] + cbit[1] + cbit[2] + cbit[3];
+                        const int32_t ib = ft_wave_incl<FtAdd>(sb), ic = ft_wave_incl<FtAdd>(sc_);
+                        if (lane == 63) { s_scan[wv_] = ib; s_scan[NT / 64 + wv_] = ic; }
                         FT_PROF(22);
                         ft_sync<true>();
                         FT_PROF(31);
-                        int32_t base = 0, tot = 0;
+                        int32_t base = 0, tot = 0, base_c = 0, tot_c = 0;
 #pragma unroll
                         for (int w = 0; w < NT / 64; ++w) {
-                            const int32_t a_ = s_scan[w];
-                            tot += a_;
-                            if (w < wv_) base += a_;
+                            const int32_t a_ = s_scan[w], b_ = s_scan[NT / 64 + w];
+                            tot += a_; tot_c += b_;
+                            if (w < wv_) { base += a_; base_c += b_; }
                         }
-                        int o = carry_l + base + ib - sb;
+                        int o = carry_l + base + ib - sb, oc = carry_c + base_c + ic - sc_;
                         if (carry_l + tot > ccap) over = true;       // (uniform: every work-item sees the same totals)
                         if (!over) {
 #pragma unroll
                             for (int v = 0; v < 4; ++v) {
                                 if (!val[v]) continue;
+                                if (cbit[v]) { cand_wid[oc] = c[v]; cand_score[oc] = a_news[v] - p.nwpen; cand_bp[oc] = a_outh[v]; ++oc; }
                                 const int at = bit[v] ? o : -1;
-                                if (bit[v]) { acln[o] = c[v]; ++o; }
+                                // (a node that enters the list: marked in the list, its channel made when the decisions are over)
+                                if (bit[v]) { acln[o] = act[v] == 1 ? (c[v] | kFtNewCh) : c[v]; ++o; }
                                 if (q[v] < 0) cdec[c0 + li[v] - R] = FtQuad{ at, act[v], a_news[v], a_outh[v] };
                                 else if (c_at[v] >= 0) cdst[c_at[v]] = at;
-                                else if (act[v] == 1) {
-                                    // a new channel, entered (hmm_enter into a cleared channel): node, parent | ci, children as the static
-                                    // quad has them; scores and histories at their floor but state 0
-                                    int32_t w[4 * ND];
-#pragma unroll
-                                    for (int k = 0; k < 4 * ND; ++k) w[k] = (k < NE || k == 2 * NE) ? kW : -1;
-                                    w[0] = a_news[v]; w[NE] = a_outh[v];
-#pragma unroll
-                                    for (int k = 0; k < 4 * ND; ++k) if (k > 2 * NE + 1) w[k] = 0;
-#pragma unroll
-                                    for (int k = 0; k < ND; ++k) cbuf(nxt, k)[at] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
-                                    ns0[at] = FtQuad{ c[v], e0[v].x, e0[v].y, e0[v].z };
-                                    ns1[at] = e1[v];
-                                }
+                                else if (act[v] == 1) cnew[at] = FtPair{ a_news[v], a_outh[v] };
                             }
                         }
-                        carry_l += tot;
+                        carry_l += tot; carry_c += tot_c;
                         ft_sync<true>();                             // (s_scan; the chunk's LDS arrays before the next chunk overwrites them)
                     }
                 }
@@ -1815,26 +1816,58 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             if (over) break;
             for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;       // (this frame's index has been read for the last time)
             // -- the channels of the nodes that stay, from their positions in this frame's buffer to their positions in the next
-            for (int j = tid; j < na; j += NT) {
-                const FtQuad d = cdec[j];
-                const int32_t h = cdst[j];
-                if (h >= 0) cdst[j] = -1;
-                const int at = d.x >= 0 ? d.x : h;
-                if (at < 0) continue;                            // (cleared: the node leaves the list, its channel ends here)
-                int32_t w[4 * ND];
-                if (d.y == 4) {                                  // cleared, then entered: a new channel's scores
+            //    (two positions a work-item at a time: their loads are asked for together)
+            for (int j0 = tid; j0 < na; j0 += 2 * NT) {
+                FtQuad d[2]; int32_t h[2], at[2]; int32_t w[2][4 * ND]; FtQuad s0[2], s1[2];
 #pragma unroll
-                    for (int k = 0; k < 4 * ND; ++k) w[k] = (k < NE || k == 2 * NE) ? kW : (k <= 2 * NE + 1 ? -1 : 0);
-                    w[0] = d.z; w[NE] = d.w;
-                }
-                else {
+                for (int u = 0; u < 2; ++u) {
+                    const int j = min(j0 + u * NT, na - 1);
+                    d[u] = cdec[j]; h[u] = cdst[j]; s0[u] = cs0[j]; s1[u] = cs1[j];
 #pragma unroll
-                    for (int k = 0; k < ND; ++k) { const FtQuad q_ = cbuf(cur, k)[j]; w[4 * k] = q_.x; w[4 * k + 1] = q_.y; w[4 * k + 2] = q_.z; w[4 * k + 3] = q_.w; }
-                    if (d.y == 2) { w[0] = d.z; w[NE] = d.w; }   // hmm_enter
+                    for (int k = 0; k < ND; ++k) { const FtQuad q_ = cbuf(cur, k)[j]; w[u][4 * k] = q_.x; w[u][4 * k + 1] = q_.y; w[u][4 * k + 2] = q_.z; w[u][4 * k + 3] = q_.w; }
                 }
 #pragma unroll
-                for (int k = 0; k < ND; ++k) cbuf(nxt, k)[at] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
-                ns0[at] = cs0[j]; ns1[at] = cs1[j];
+                for (int u = 0; u < 2; ++u) {
+                    const int j = j0 + u * NT;
+                    if (j >= na) continue;
+                    if (h[u] >= 0) cdst[j] = -1;
+                    at[u] = d[u].x >= 0 ? d[u].x : h[u];
+                    if (at[u] < 0) continue;                     // (cleared: the node leaves the list, its channel ends here)
+                    if (d[u].y == 4) {                           // cleared, then entered: a new channel's scores
+#pragma unroll
+                        for (int k = 0; k < 4 * ND; ++k) w[u][k] = (k < NE || k == 2 * NE) ? kW : -1;
+                    }
+                    if (d[u].y == 4 || d[u].y == 2) { w[u][0] = d[u].z; w[u][NE] = d[u].w; }       // hmm_enter
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) cbuf(nxt, k)[at[u]] = FtQuad{ w[u][4 * k], w[u][4 * k + 1], w[u][4 * k + 2], w[u][4 * k + 3] };
+                    ns0[at[u]] = s0[u]; ns1[at[u]] = s1[u];
+                }
+            }
+            // -- the channels of the nodes that enter the list (hmm_enter into a cleared channel): scores and histories at their floor
+            //    but state 0's, the static side from the tables
+            for (int o0 = tid; o0 < n_listed; o0 += 2 * NT) {
+                int32_t a[2]; FtPair pl[2]; FtQuad e0[2], e1[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { const int o = o0 + u * NT; a[u] = o < n_listed ? acln[o] : 0; }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    pl[u] = FtPair{ 0, 0 }; e0[u] = FtQuad{ 0, 0, 0, 0 }; e1[u] = e0[u];
+                    if (a[u] & kFtNewCh) { const int c_ = a[u] & ~kFtNewCh; pl[u] = cnew[o0 + u * NT]; e0[u] = node_q1[c_]; e1[u] = node_st1[c_]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (!(a[u] & kFtNewCh)) continue;
+                    const int o = o0 + u * NT, c_ = a[u] & ~kFtNewCh;
+                    acln[o] = c_;
+                    int32_t w[4 * ND];
+#pragma unroll
+                    for (int k = 0; k < 4 * ND; ++k) w[k] = (k < NE || k == 2 * NE) ? kW : -1;
+                    w[0] = pl[u].x; w[NE] = pl[u].y;
+#pragma unroll
+                    for (int k = 0; k < ND; ++k) cbuf(nxt, k)[o] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
+                    ns0[o] = FtQuad{ c_, e0[u].x, e0[u].y, e0[u].z };
+                    ns1[o] = e1[u];
+                }
             }
             __syncthreads();                                     // (the bitmap is clear)
             build_index(acln.b, n_listed);
@@ -2627,9 +2660,9 @@ static bool ft_layout(FtDev &d, bool small)
     else {
         L.itb = take(4 * (int64_t)d.R);
         const int nd = ne == 3 ? 2 : 3;
-        L.ccap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, kFtMaxListed));
+        L.ccap = (int32_t)std::max<int64_t>(1, (int64_t)d.N - d.R);
         L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cdec = take(4 * (int64_t)L.ccap);
-        L.cdst = take(L.ccap); L.cperm = take(((int64_t)L.ccap + 1) / 2);
+        L.cdst = take(L.ccap); L.cperm = take(L.ccap); L.cnew = take(2 * (int64_t)L.ccap);
         if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords) return false;     // (the listed-nodes bitmap lives in LDS)
         d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
@@ -2659,7 +2692,7 @@ static void ft_slab_pool(FtDev &d, int nt)
     d.lds_tp = take((d.n_tmat * d.n_emit * (d.n_emit + 1) + 3) / 4);
     d.lds_perm = o;
     const int32_t left = std::max(0, kFtSlabPoolWords - o) & ~3;
-    d.lds_perm_cap = (int32_t)std::min<int64_t>(2 * (int64_t)left, ((int64_t)d.lay.ccap + 7) & ~(int64_t)7);
+    d.lds_perm_cap = (int32_t)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)left, 65528), ((int64_t)d.lay.ccap + 7) & ~(int64_t)7);     // (16-bit positions)
     if (const char *cap = getenv("PSGPU_FWDTREE_PERM_CAP"))     // (a test's knob: frames that list more take the table in the slab)
         d.lds_perm_cap = (int32_t)std::max<int64_t>(0, std::min<int64_t>(d.lds_perm_cap, atoll(cap) & ~7ll));
     o += d.lds_perm_cap / 2;
@@ -2765,8 +2798,24 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.kid_off = ft_up(m, kid_off.data(), (size_t)d.N + 1, &rc); d.kids = ft_up(m, kids.data(), kids.size(), &rc);
     {
         if (d.N >= (1 << 24) || d.n_ci > 128) { psgpu_set_error("fwdtree: %d tree nodes (at most 2^24 - 1)", d.N); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
-        std::vector<int32_t> kc(kids.size(), 0);
-        for (int k = 0; k < d.M; ++k) kc[k] = (int32_t)((uint32_t)kids[k] | ((uint32_t)t->node_ci[kids[k]] << 24));
+        // per node, side by side: its children (child | ci << 24, sibling order), then the words whose penultimate phone it is (word |
+        // last phone << 24, the homophone chain in order: the last-phone candidates of ngram_search_fwdtree.c:824-870) -- the pruning
+        // works on (item, entry) pairs, one work-item each, and a walk along the chain would be a loop of dependent loads
+        if (d.n_w >= (1 << 24)) { psgpu_set_error("fwdtree: %d dictionary words (at most 2^24 - 1)", d.n_w); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
+        std::vector<int32_t> kc, xoff((size_t)d.N + 1, 0), xnw(d.N, 0);
+        kc.reserve(kids.size() + (size_t)d.n_w);
+        for (int c = 0; c < d.N; ++c) {
+            xoff[c] = (int32_t)kc.size();
+            for (int k = kid_off[c]; k < kid_off[c + 1]; ++k) kc.push_back((int32_t)((uint32_t)kids[k] | ((uint32_t)t->node_ci[kids[k]] << 24)));
+            int guard = 0;
+            for (int w = t->node_penult_wid[c]; w >= 0 && guard <= d.n_w; w = t->homophone_set[w], ++guard) {
+                kc.push_back((int32_t)((uint32_t)w | ((uint32_t)t->dict_last[w] << 24)));
+                ++xnw[c];
+            }
+            if (guard > d.n_w || xnw[c] > 0xffff) { psgpu_set_error("fwdtree: node %d: a chain of %d penultimate-phone words", c, xnw[c]); psgpu_fwdtree_free(m); return PSGPU_EINVAL; }
+        }
+        xoff[d.N] = (int32_t)kc.size();
+        if (kc.empty()) kc.push_back(0);
         d.kids_ci = ft_up(m, kc.data(), kc.size(), &rc);
         const int nsq = d.n_emit <= 3 ? 4 : 8;
         std::vector<int32_t> q1((size_t)d.N * 4, 0), q2((size_t)d.N * 4, 0), qs((size_t)d.N * nsq, 0), st1((size_t)d.N * 4, 0);
@@ -2779,7 +2828,8 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
         for (int c = 0; c < d.N; ++c) {
             const int k0 = kid_off[c], nk = kid_off[c + 1] - k0, pw = t->node_penult_wid[c];
             q1[(size_t)c * 4] = (int32_t)((uint32_t)(parent[c] < 0 ? 0 : parent[c]) | ((uint32_t)t->node_ci[c] << 24));
-            q1[(size_t)c * 4 + 1] = k0; q1[(size_t)c * 4 + 2] = nk | ((pw >= 0 ? 1 : 0) << 16); q1[(size_t)c * 4 + 3] = nk > 0 ? kc[k0] : -1;
+            const int x0 = xoff[c], nx = xoff[c + 1] - x0;
+            q1[(size_t)c * 4 + 1] = x0; q1[(size_t)c * 4 + 2] = nk | (xnw[c] << 16); q1[(size_t)c * 4 + 3] = nx > 0 ? kc[x0] : -1;
             {
                 uint32_t pk[3] = { 0, 0, 0 };
                 for (int k = 0; k <= d.n_emit; ++k) {       // (the states' senones, then the transition matrix: 16 bits each)
@@ -2787,7 +2837,7 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
                     pk[k >> 1] |= (v & 0xffffu) << (16 * (k & 1));
                 }
                 st1[(size_t)c * 4] = (int32_t)pk[0]; st1[(size_t)c * 4 + 1] = (int32_t)pk[1]; st1[(size_t)c * 4 + 2] = (int32_t)pk[2];
-                st1[(size_t)c * 4 + 3] = nk > 0 ? kc[k0] : -1;
+                st1[(size_t)c * 4 + 3] = nx > 0 ? kc[x0] : -1;
             }
             q2[(size_t)c * 4] = pw; q2[(size_t)c * 4 + 1] = pw >= 0 ? t->dict_last[pw] : 0; q2[(size_t)c * 4 + 2] = pw >= 0 ? t->homophone_set[pw] : -1;
             for (int k = 0; k < d.n_emit; ++k) qs[(size_t)c * nsq + k] = t->sseq[(size_t)t->node_ssid[c] * d.n_emit + k];
