@@ -50,6 +50,10 @@ constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS 
 #ifndef PSGPU_FT_THREADS_BIG
 #define PSGPU_FT_THREADS_BIG 1024
 #endif
+#ifndef PSGPU_FT_PAIRS
+#define PSGPU_FT_PAIRS 4
+#endif
+constexpr int kFtPairs = PSGPU_FT_PAIRS;       // slab layouts: consecutive pairs of the pruning a work-item decides at a time
 constexpr int kFtThreadsBig = PSGPU_FT_THREADS_BIG;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
 constexpr int kFtMaxBitWords = 8192;   // slab layouts: a bitmap of the listed tree nodes in LDS for trees up to 32 x this many nodes
@@ -92,9 +96,8 @@ struct FtLay {
     int32_t cq;                          // [2][ND + 2][ccap][4] two buffers taking turns by frame parity; per buffer ND arrays of quads with the channel's
                                          // scores, histories, out score, out history (ND = 2 for 3 states, 3 for 5) and two with what is static per node
     int32_t csum;                        // [ccap][4] per list position: out, out history, best, score[0] as the evaluation left them
-    int32_t cdec;                        // [ccap][4] per list position: the node's own decision {place in the next list or -1, kind, entering score, history}
-    int32_t cdst;                        // [ccap] per list position: the place in the next list its PARENT's pair gave the node, or -1 (reset when read)
-    int32_t cnew;                        // [ccap][2] per position of the NEXT list: entering score and history of a node that enters the list
+    int32_t cxfer;                       // [2][ccap][4] per list position (two lists taking turns like the buffers): where the node's channel comes from -- its
+                                         // position in the frame before's list, or -1: a new channel -- and {what the pruning did to it, entering score, history}
     int32_t cperm;                       // [ccap] rank among the listed nodes by node id -> list position, when the frame's list outgrows the LDS table
     int32_t ccap;                        // listed nodes a frame may hold: N - R, every node but the roots
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
@@ -214,8 +217,6 @@ template <int NE> struct ChF {
     static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
 struct alignas(16) FtQuad { int32_t x, y, z, w; };
-struct alignas(8) FtPair { int32_t x, y; };
-constexpr int32_t kFtNewCh = (int32_t)0x80000000;     // slab layouts, next active list while it is made: the node enters the list (its channel is still to be made)
 // One column of a block of interleaved arrays (LDS layout: AOS, element i at word i * K of the column's base) or a plain array
 // (slab layouts).  Why interleave: this kernel's speed follows the number of scalar values it keeps alive -- the compiler gives
 // every array's base a scalar register, spills what does not fit into vector-register lanes and reads it back with v_readlane
@@ -963,19 +964,21 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     FtQuad *const itb = reinterpret_cast<FtQuad *>(fb + L.itb);        // slab layouts only: [R]
     // ---- compact channels (slab layouts).  A tree node's channel exists while the node is listed: its record lives at the node's
     //      POSITION in the frame's active list, in arrays of quads (one array per quad of the record: sixty-four work-items on
-    //      consecutive positions read 1 KB in a row), two buffers taking turns -- the evaluation rewrites the frame's buffer in place,
-    //      the pruning writes the next frame's: a retained node's record is copied to its new position, a newly entered node's is made
-    //      from the static tables (and carries its static side -- parent, children, senones -- from then on: the evaluation and the
-    //      pruning of a listed node ask the static tables nothing).  Per buffer: ND quads {score[0..NE), history[0..NE), out score, out
-    //      history}, then {node, parent | ci << 24, first child's index, children | penultimate << 16} and {senones and transition
-    //      matrix, 16 bits each, ..., first child | its ci << 24}.  What a frame costs in device memory is then mostly streams; the
-    //      random accesses left are a decision's look at its OTHER node (by rank -> position, see s_lb) and the static rows of the
-    //      nodes that ENTER the list.
+    //      consecutive positions read 1 KB in a row), two buffers taking turns.  The pruning moves no channel: it writes, per place
+    //      of the next list, the node and where its channel comes from (cxfer: its position in this frame's list, or "new", and the
+    //      entering score and history if it was entered); the next frame makes the channels at their new places as it goes -- its
+    //      first pass fetches the static side (from the old place or, for a new channel, from the static tables: parent, children,
+    //      senones: the evaluation and the pruning of a listed node ask the static tables nothing), its evaluation fetches the scores
+    //      and histories from the old place (old places rise with the new ones: the requests of neighbouring work-items fall into
+    //      the same lines), evaluates and writes.  Per buffer: ND quads {score[0..NE), history[0..NE), out score, out history}, then
+    //      {node, parent | ci << 24, first entry's index, children | penultimate-phone words << 16} and {senones and transition
+    //      matrix, 16 bits each, ..., first entry}.  What a frame costs in device memory is then mostly streams; the random accesses
+    //      left are a decision's look at its OTHER node (by rank -> position, see s_lb) and the static rows of the nodes that ENTER
+    //      the list.
     constexpr int ND = NE == 3 ? 2 : 3;
     const int ccap = SMALL ? 1 : L.ccap;
     FtQuad *const cq = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cq));
-    FtQuad *const csum = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.csum)), *const cdec = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cdec));
-    int32_t *const cdst = fb + (SMALL ? 0 : L.cdst);
+    FtQuad *const csum = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.csum)), *const cxf = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cxfer));
     int32_t *const g_perm = fb + (SMALL ? 0 : L.cperm);
     auto cbuf = [&](int b, int k) { return cq + (size_t)(b * (ND + 2) + k) * ccap; };      // array k of buffer b
     const FtQuad *const node_st1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_st1));
@@ -1043,7 +1046,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // ---- hmm_init of every permanent channel, ngram_fwdtree_start (:469-520)
     if (!resumed) {
         for (int c = tid; c < W1; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
-        if (!SMALL) { for (int i = tid; i < ccap; i += NT) cdst[i] = -1; }
         for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
         for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
         for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
@@ -1293,10 +1295,17 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         act_root = tv.at(i, F::FRAME) == f;
                         if (act_root && raw_mode) mark(tv, i);
                     }
-                    else if (i < R + na && raw_mode) {
-                        const FtQuad a = cbuf(cur, ND + 1)[i - R];          // the channel carries its senones, 16 bits each
-                        mark_sen(a.x & 0xffff); mark_sen((int)((uint32_t)a.x >> 16)); mark_sen(a.y & 0xffff);
-                        if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(a.z & 0xffff); }
+                    else if (i < R + na) {
+                        // the static side of the channel at this place: from its old place, or (a new channel) from the static tables
+                        const int src = cxf[(size_t)cur * ccap + (i - R)].x;
+                        FtQuad s0, a;
+                        if (src >= 0) { s0 = cbuf(nxt, ND)[src]; a = cbuf(nxt, ND + 1)[src]; }
+                        else { const int node = aclc[i - R]; const FtQuad e0 = node_q1[node]; a = node_st1[node]; s0 = FtQuad{ node, e0.x, e0.y, e0.z }; }
+                        cbuf(cur, ND)[i - R] = s0; cbuf(cur, ND + 1)[i - R] = a;
+                        if (raw_mode) {                                  // the channel carries its senones, 16 bits each
+                            mark_sen(a.x & 0xffff); mark_sen((int)((uint32_t)a.x >> 16)); mark_sen(a.y & 0xffff);
+                            if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(a.z & 0xffff); }
+                        }
                     }
                     if (i0 < R) n_act_root += __popcll(__ballot(act_root));
                 }
@@ -1345,16 +1354,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             if (!SMALL) {
                 for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_normalize<NE>(tv, i, best_in);
-                for (int j = tid; j < na; j += NT) {         // hmm_normalize on the compact channels: the scores and the out score
-                    int32_t w[4 * ND];
-#pragma unroll
-                    for (int k = 0; k < ND; ++k) { const FtQuad q = cbuf(cur, k)[j]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
-#pragma unroll
-                    for (int k = 0; k < NE; ++k) if (w[k] > kW) w[k] -= best_in;
-                    if (w[2 * NE] > kW) w[2 * NE] -= best_in;
-#pragma unroll
-                    for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
-                }
+                // (the listed nodes' channels are made by this frame's evaluation: it normalises them as it does)
             }
             __syncthreads();
         }
@@ -1446,15 +1446,34 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
                 // the listed nodes' compact channels, position by position: ND + 1 quads in, ND + 1 out, every one in a row with its
                 // neighbours'; never multiplexed (the senones are the channel's own)
-                // (two positions a work-item at a time: their loads are asked for together)
+                // (two positions a work-item at a time: their loads are asked for together.)  The channel is made here: scores and
+                // histories from its old place, with the entering score of the pruning that entered it -- or a cleared channel's, entered
+                // (hmm_enter into a cleared channel) -- and, in a frame that renormalises (:566-603), less the normaliser
+                const bool renorm = best_in + 2 * p.beam < kW;
+                const FtQuad *const xf = cxf + (size_t)cur * ccap;
                 for (int j0 = tid; j0 < na; j0 += 2 * NT) {
-                    int32_t w[2][4 * ND]; FtQuad sq[2];
+                    int32_t w[2][4 * ND]; FtQuad sq[2], x[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { x[u] = xf[min(j0 + u * NT, na - 1)]; sq[u] = cbuf(cur, ND + 1)[min(j0 + u * NT, na - 1)]; }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int j = min(j0 + u * NT, na - 1);
+                        const bool old_ = x[u].x >= 0 && x[u].y != 4;
 #pragma unroll
-                        for (int k = 0; k < ND; ++k) { const FtQuad q = cbuf(cur, k)[j]; w[u][4 * k] = q.x; w[u][4 * k + 1] = q.y; w[u][4 * k + 2] = q.z; w[u][4 * k + 3] = q.w; }
-                        sq[u] = cbuf(cur, ND + 1)[j];
+                        for (int k = 0; k < ND; ++k) {
+                            FtQuad q = FtQuad{ 0, 0, 0, 0 };
+                            if (old_) q = cbuf(nxt, k)[x[u].x];
+                            w[u][4 * k] = q.x; w[u][4 * k + 1] = q.y; w[u][4 * k + 2] = q.z; w[u][4 * k + 3] = q.w;
+                        }
+                        if (!old_) {
+#pragma unroll
+                            for (int k = 0; k < 4 * ND; ++k) w[u][k] = (k < NE || k == 2 * NE) ? kW : -1;
+                        }
+                        if (x[u].y != 0) { w[u][0] = x[u].z; w[u][NE] = x[u].w; }          // hmm_enter
+                        if (renorm) {
+#pragma unroll
+                            for (int k = 0; k < NE; ++k) if (w[u][k] > kW) w[u][k] -= best_in;
+                            if (w[u][2 * NE] > kW) w[u][2 * NE] -= best_in;
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
@@ -1583,10 +1602,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //          by its parent's pair (which needs it for the next list);
         //        * a pair's OTHER node, if listed, is found through the list's index (bitmap, rank, position: LDS) and read from
         //          the summary array; if not listed its state is known without asking;
-        //        * decisions only READ channels: a node's own decision goes to cdec [position], the place its parent's pair
-        //          gives it to cdst [position], and the next frame's channels are written when every decision of the frame has
-        //          been taken -- a node that stays is copied from its position in this frame's buffer to its position in the
-        //          next, a node that enters the list gets a channel made from the static tables right where it is decided;
+        //        * decisions only READ channels: the pair that gives a node its place in the next list writes where the node's channel
+        //          comes from and what happens to it (cxfer), and the next frame makes it there;
         //        * positions in the next active list = prefix sums over the pairs' outcomes in pair order (= list order);
         //        * the frame's penalty row and the chunk's items in LDS.
         //      Facts the decisions rely on instead of reading them:
@@ -1595,10 +1612,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //        looking; a node that IS in the list was entered or retained for this frame.
         {
             const int n_item = R + na;
+            constexpr int KP = kFtPairs;
             int carry_l = 0, carry_c = 0;                        // next list's entries / candidates so far (uniform)
-            FtPair *const cnew = reinterpret_cast<FtPair *>(fb + L.cnew);
             const FtQuad *const cs0 = cbuf(cur, ND), *const cs1 = cbuf(cur, ND + 1);
-            FtQuad *const ns0 = cbuf(nxt, ND), *const ns1 = cbuf(nxt, ND + 1);
+            FtQuad *const xfer = cxf + (size_t)nxt * ccap;     // the next list's
             bool over = false;                                   // the next list outgrows the compact buffers (uniform)
             for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
                 // -- the chunk's items, two consecutive ones a work-item -> LDS; their pairs counted: the item's own entry (listed nodes),
@@ -1655,14 +1672,14 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 FT_PROF(5);
                 // -- the chunk's pairs, four consecutive ones a work-item: the item's own entry first (listed nodes), then its children
                 //    in sibling order, then its penultimate-phone words in chain order
-                for (int p0 = 0; p0 < n_pair; p0 += 4 * NT) {
-                    int li[4], q[4], c[4], cci[4]; bool val[4];
-                    const int jb = p0 + 4 * tid;
+                for (int p0 = 0; p0 < n_pair; p0 += KP * NT) {
+                    int li[KP], q[KP], c[KP], cci[KP]; bool val[KP];
+                    const int jb = p0 + KP * tid;
                     // (which item a pair belongs to: a bisection of the chunk's offsets in LDS)
                     {
                         int l0 = jb < n_pair ? ft_seg_find(s_it_poff, kPrIC, jb) : 0;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
+                        for (int v = 0; v < KP; ++v) {
                             const int j = jb + v;
                             val[v] = j < n_pair;
                             if (val[v] && s_it_poff[l0 + 1] <= j) { ++l0; if (s_it_poff[l0 + 1] <= j) l0 = ft_seg_find(s_it_poff, kPrIC, j); }
@@ -1675,7 +1692,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     // a child's id and phone (a word's id and last phone): the item's first entry came with the item; the others from the
                     // static table
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < KP; ++v) {
                         c[v] = -1; cci[v] = 0;
                         if (val[v]) {
                             if (q[v] < 0) { c[v] = s_it_node[li[v]]; cci[v] = (uint32_t)s_it_par[li[v]] >> 24; }
@@ -1695,9 +1712,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     // the OTHER node: a child's {out, out history, best, position + 1} and score[0] -- for an item's own entry the
                     // PARENT's.  A root's come from its record (its last word is its frame stamp); a listed node's from the summary
                     // array at its position (bitmap -> rank -> position: LDS); a node that is not listed has nothing to say
-                    FtQuad qx[4]; int32_t csc[4];
+                    FtQuad qx[KP]; int32_t csc[KP];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < KP; ++v) {
                         qx[v] = FtQuad{ kW, -1, kW, -1 };
                         csc[v] = kW;
                         if (val[v] && q[v] < (s_it_fp[li[v]] >> 1)) {     // (a word's pair looks at nothing)
@@ -1724,9 +1741,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                             }
                         }
                     }
-                    int32_t bit[4], cbit[4], act[4], a_news[4], a_outh[4], c_at[4];
+                    int32_t bit[KP], cbit[KP], act[KP], a_news[KP], a_outh[KP], c_at[KP];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
+                    for (int v = 0; v < KP; ++v) {
                         bit[v] = 0; cbit[v] = 0; act[v] = 0; a_news[v] = 0; a_outh[v] = -1; c_at[v] = -1;
                         if (!val[v]) continue;
                         const bool self = q[v] < 0;
@@ -1758,25 +1775,31 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         else fire = parent_can;
                         const bool entered_first = fire && parent_first;
                         const bool listed = fire && (p_root || !(in_acl && !parent_first && retc));
-                        // what the decision does to the node's channel: 1 = entered (an unlisted node: a new channel), 2 = entered (a
-                        // listed node: score[0] and history[0]), 3 = cleared (it leaves the list), 4 = cleared, then entered
+                        // what the decision does to the channel of a node it lists: 0 = kept, 1 = a new channel, entered (an unlisted node),
+                        // 2 = entered (a listed node: score[0] and history[0]), 4 = cleared, then entered; a node nobody lists was cleared
                         a_news[v] = news; a_outh[v] = p_outh;
+                        // (a listed node is decided twice with the same inputs and the same outcome: by its own entry and by its
+                        //  parent's pair; whichever of the two gives the node its place in the next list also says what becomes of its
+                        //  channel)
+                        const bool clr = in_acl && !retc && !entered_first;
                         if (self) {
-                            const bool clr = !retc && !entered_first;
-                            act[v] = clr ? (fire ? 4 : 3) : (fire ? 2 : 0);
+                            act[v] = fire ? 2 : 0;
                             bit[v] = (retc && !entered_first) ? 1 : 0;
+                            c_at[v] = my_pos;
                         }
                         else {
-                            act[v] = (!in_acl && fire) ? 1 : 0;       // (a listed child's channel is its own entry's business)
+                            act[v] = !in_acl ? 1 : (clr ? 4 : 2);
                             bit[v] = listed ? 1 : 0;
-                            if (in_acl && listed) c_at[v] = c_pos;    // ... but its place in the next list is this pair's
+                            c_at[v] = in_acl ? c_pos : -1;
                         }
                     }
                     FT_PROF(13);
                     // positions in the next active list and in the candidate list: pair order
                     {
                         const int lane = tid & 63, wv_ = tid >> 6;
-                        const int32_t sb = bit[0] + bit[1] + bit[2] + bit[3], sc_ = cbit[0] + cbit[1] + cbit[2] + cbit[3];
+                        int32_t sb = 0, sc_ = 0;
+#pragma unroll
+                        for (int v = 0; v < KP; ++v) { sb += bit[v]; sc_ += cbit[v]; }
                         const int32_t ib = ft_wave_incl<FtAdd>(sb), ic = ft_wave_incl<FtAdd>(sc_);
                         if (lane == 63) { s_scan[wv_] = ib; s_scan[NT / 64 + wv_] = ic; }
                         FT_PROF(22);
@@ -1793,15 +1816,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         if (carry_l + tot > ccap) over = true;       // (uniform: every work-item sees the same totals)
                         if (!over) {
 #pragma unroll
-                            for (int v = 0; v < 4; ++v) {
+                            for (int v = 0; v < KP; ++v) {
                                 if (!val[v]) continue;
                                 if (cbit[v]) { cand_wid[oc] = c[v]; cand_score[oc] = a_news[v] - p.nwpen; cand_bp[oc] = a_outh[v]; ++oc; }
-                                const int at = bit[v] ? o : -1;
-                                // (a node that enters the list: marked in the list, its channel made when the decisions are over)
-                                if (bit[v]) { acln[o] = act[v] == 1 ? (c[v] | kFtNewCh) : c[v]; ++o; }
-                                if (q[v] < 0) cdec[c0 + li[v] - R] = FtQuad{ at, act[v], a_news[v], a_outh[v] };
-                                else if (c_at[v] >= 0) cdst[c_at[v]] = at;
-                                else if (act[v] == 1) cnew[at] = FtPair{ a_news[v], a_outh[v] };
+                                // a node of the next list: its place, and where its channel comes from -- its position in this frame's list
+                                // (or -1: a new channel) and what the decision does to it; the next frame's evaluation makes the channel
+                                if (bit[v]) { acln[o] = c[v]; xfer[o] = FtQuad{ c_at[v], act[v], a_news[v], a_outh[v] }; ++o; }
                             }
                         }
                         carry_l += tot; carry_c += tot_c;
@@ -1812,63 +1832,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             n_listed = carry_l;
             if (tid == 0) { s_sc[5] = carry_c; s_red[7] = 0; if (over) s_sc[6] = 4; }     // status 4: more than ccap tree channels listed in a frame
-            __syncthreads();                                     // (device memory: every decision has been taken: cdec, cdst, the new channels)
+            __syncthreads();                                     // (device memory: every decision has been taken; the next list and its cxfer are complete)
             if (over) break;
             for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;       // (this frame's index has been read for the last time)
-            // -- the channels of the nodes that stay, from their positions in this frame's buffer to their positions in the next
-            //    (two positions a work-item at a time: their loads are asked for together)
-            for (int j0 = tid; j0 < na; j0 += 2 * NT) {
-                FtQuad d[2]; int32_t h[2], at[2]; int32_t w[2][4 * ND]; FtQuad s0[2], s1[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int j = min(j0 + u * NT, na - 1);
-                    d[u] = cdec[j]; h[u] = cdst[j]; s0[u] = cs0[j]; s1[u] = cs1[j];
-#pragma unroll
-                    for (int k = 0; k < ND; ++k) { const FtQuad q_ = cbuf(cur, k)[j]; w[u][4 * k] = q_.x; w[u][4 * k + 1] = q_.y; w[u][4 * k + 2] = q_.z; w[u][4 * k + 3] = q_.w; }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int j = j0 + u * NT;
-                    if (j >= na) continue;
-                    if (h[u] >= 0) cdst[j] = -1;
-                    at[u] = d[u].x >= 0 ? d[u].x : h[u];
-                    if (at[u] < 0) continue;                     // (cleared: the node leaves the list, its channel ends here)
-                    if (d[u].y == 4) {                           // cleared, then entered: a new channel's scores
-#pragma unroll
-                        for (int k = 0; k < 4 * ND; ++k) w[u][k] = (k < NE || k == 2 * NE) ? kW : -1;
-                    }
-                    if (d[u].y == 4 || d[u].y == 2) { w[u][0] = d[u].z; w[u][NE] = d[u].w; }       // hmm_enter
-#pragma unroll
-                    for (int k = 0; k < ND; ++k) cbuf(nxt, k)[at[u]] = FtQuad{ w[u][4 * k], w[u][4 * k + 1], w[u][4 * k + 2], w[u][4 * k + 3] };
-                    ns0[at[u]] = s0[u]; ns1[at[u]] = s1[u];
-                }
-            }
-            // -- the channels of the nodes that enter the list (hmm_enter into a cleared channel): scores and histories at their floor
-            //    but state 0's, the static side from the tables
-            for (int o0 = tid; o0 < n_listed; o0 += 2 * NT) {
-                int32_t a[2]; FtPair pl[2]; FtQuad e0[2], e1[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { const int o = o0 + u * NT; a[u] = o < n_listed ? acln[o] : 0; }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    pl[u] = FtPair{ 0, 0 }; e0[u] = FtQuad{ 0, 0, 0, 0 }; e1[u] = e0[u];
-                    if (a[u] & kFtNewCh) { const int c_ = a[u] & ~kFtNewCh; pl[u] = cnew[o0 + u * NT]; e0[u] = node_q1[c_]; e1[u] = node_st1[c_]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (!(a[u] & kFtNewCh)) continue;
-                    const int o = o0 + u * NT, c_ = a[u] & ~kFtNewCh;
-                    acln[o] = c_;
-                    int32_t w[4 * ND];
-#pragma unroll
-                    for (int k = 0; k < 4 * ND; ++k) w[k] = (k < NE || k == 2 * NE) ? kW : -1;
-                    w[0] = pl[u].x; w[NE] = pl[u].y;
-#pragma unroll
-                    for (int k = 0; k < ND; ++k) cbuf(nxt, k)[o] = FtQuad{ w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3] };
-                    ns0[o] = FtQuad{ c_, e0[u].x, e0[u].y, e0[u].z };
-                    ns1[o] = e1[u];
-                }
-            }
             __syncthreads();                                     // (the bitmap is clear)
             build_index(acln.b, n_listed);
             FT_PROF(4);
@@ -2661,8 +2627,8 @@ static bool ft_layout(FtDev &d, bool small)
         L.itb = take(4 * (int64_t)d.R);
         const int nd = ne == 3 ? 2 : 3;
         L.ccap = (int32_t)std::max<int64_t>(1, (int64_t)d.N - d.R);
-        L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cdec = take(4 * (int64_t)L.ccap);
-        L.cdst = take(L.ccap); L.cperm = take(L.ccap); L.cnew = take(2 * (int64_t)L.ccap);
+        L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cxfer = take(2 * 4 * (int64_t)L.ccap);
+        L.cperm = take(L.ccap);
         if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords) return false;     // (the listed-nodes bitmap lives in LDS)
         d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
