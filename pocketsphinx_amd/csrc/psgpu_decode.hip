@@ -1130,10 +1130,26 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
             PSGPU_HIP(hipStreamSynchronize(st));
         }
     }
+    for (int pass = 0; pass < 8; ++pass) {               // (a search that goes further with larger tables may meet the other limit)
+    for (int round = 0; round < 16; ++round) {
+        // status 4 / 5: a frame listed more tree nodes than the slab layouts' compact channels hold / needed more blocks of the
+        // right-context channels' pool than there are: the capacity is doubled (psgpu_fwdtree_grow) -- for good -- and the search repeated
+        int32_t grow = 0;
+        for (size_t u = 0; u < nu && !grow; ++u) if (res[u * 8 + 3] == 4 || res[u * 8 + 3] == 5) grow = res[u * 8 + 3];
+        if (!grow) break;
+        int rc;
+        if ((rc = psgpu_fwdtree_grow(d->cfg.ft, grow))) return PSGPU_OK;       // (nothing left to grow: the status stays as reported)
+        ++d->n_grown;
+        live_again();
+        if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;
+        if (d->ev_srch) PSGPU_HIP(hipEventRecord(d->ev_srch, st));
+        PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+    }
     for (int round = 0; round < 12; ++round) {
         bool full = false;
         for (size_t u = 0; u < nu && !full; ++u) full = res[u * 8 + 3] == 1;
-        if (!full) return PSGPU_OK;
+        if (!full) break;
         const size_t cb = 2 * d->cap_bp, cs = 2 * d->cap_bss;
         size_t free_b = 0, total_b = 0;
         if (cb > 0x7ffffff0u / 10 || cs > 0x7ffffff0u || hipMemGetInfo(&free_b, &total_b) != hipSuccess
@@ -1158,6 +1174,10 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
         if (d->ev_srch) PSGPU_HIP(hipEventRecord(d->ev_srch, st));
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
         PSGPU_HIP(hipStreamSynchronize(st));
+    }
+    bool more = false;
+    for (size_t u = 0; u < nu && !more; ++u) more = res[u * 8 + 3] == 1 || res[u * 8 + 3] == 4 || res[u * 8 + 3] == 5;
+    if (!more) break;
     }
     return PSGPU_OK;
 }

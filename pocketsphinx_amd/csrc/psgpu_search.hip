@@ -68,6 +68,7 @@ constexpr int kFtMaxSen = 8192;        // senones (LDS bitmap of the active list
 constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row the workgroup copies into LDS (at most 32 KB of the pool)
 constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS (likewise)
 constexpr int kFtSlabPoolWords = 39808;    // slab layouts: words of dynamic LDS a workgroup may ask for (155.5 of a compute unit's 160 KB; ~3.5 KB are static)
+constexpr int kFtRcBlk = 64;           // slab layouts: right-context channels in a block of the pool (a word's fan-out: at most n_ci <= 64 of them)
 constexpr int kFtLbBlock = 1024;       // slab layouts: words of the listed-nodes bitmap per block of 16-bit prefix populations (32,768 nodes: a count fits)
 constexpr int kFtLiveMagic = 0x5ea4c4ed;
 constexpr int kFtLiveHdr = 32;         // FtBufs::live: words ahead of the pool's copy
@@ -88,7 +89,9 @@ struct FtLay {
     int32_t cnt;                         // [cnt_words] scan scratch
     int32_t cnt2, cnt3, woff;            // [n_w + 2] per-candidate / per-active-word scratch; first slot index of each active word
     int32_t ckey;                        // [n_w + 2] 64-bit (score, back-pointer) keys of the pair searches
-    int32_t present;                     // [TOT] bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc)
+    int32_t present;                     // bytes: right-context channel allocated (ngram_search_alloc_all_rc / _free_all_rc); LDS layout: [TOT], a
+                                         // word's slots side by side; slab layouts: [rc_blocks][kFtRcBlk], by pool block
+    int32_t wblk, rcfree;                // slab layouts: [n_w] the pool block that holds the word's right-context channels, or -1; [rc_blocks] free blocks
     int32_t l_cw, l_sc, l_la, l_list, l_norm;    // small layout, scoring from top-N lists: the frame's lists (packed codewords / scores per
                                          // chain), log-add table (512 bytes), listed senones (uint16), per-wavefront stream maxima
     int32_t itb;                         // slab layouts: [R][4] per root: out, out history, best, 1 = evaluated this frame, as the evaluation left them
@@ -141,6 +144,9 @@ struct FtDev {
     int32_t lds_lb, lds_pre, lds_row, lds_tp, lds_perm, lds_perm_cap, lds_words;
     int32_t use_trie;                    // language scores from the trie (psgpu_fwdtree_set_lm) instead of the dense table
     int32_t cnt_words;
+    // slab layouts, capacities that grow on demand (psgpu_fwdtree_grow): tree nodes a frame may list (status 4 when a frame wants
+    // more), blocks of the right-context channels' pool (status 5 when a frame needs one and none is free)
+    int32_t listed_cap, rc_blocks;
     FtLay lay;
     // always in the utterance's slab (int32 units from its start): last-phone channel records; `fast`: the FtLay arrays
     // when they are not in LDS
@@ -934,6 +940,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int32_t *const tsc = psgpu_as_global(bf.tsc);
     const uint32_t *const tcw = psgpu_as_global(bf.tcw);
     uint8_t *const present = reinterpret_cast<uint8_t *>(fb + L.present);
+    // slab layouts: the right-context channels come from a pool of blocks of kFtRcBlk records (and `present` bytes) -- a word gets a block
+    // when its first channel is allocated (ngram_search_alloc_all_rc, ngram_search.c:583-633) and gives it back when it leaves the active
+    // word list with no channel left (ngram_search_free_all_rc, :635-652); channel r of word w is record wblk[w] * kFtRcBlk + r.  (The LDS
+    // layout's vocabularies are small: every (word, right context) keeps its own slot, wc_off[w] + r.)
+    int32_t *const wblk = fb + (SMALL ? 0 : L.wblk), *const rcfree = fb + (SMALL ? 0 : L.rcfree);
+    __shared__ int32_t s_nfree;                          // free blocks (the first s_nfree entries of rcfree)
     FtTab tb;
     tb.bp = psgpu_as_global(bf.bpa) + (size_t)blockIdx.x * bf.bp_cap * kBpRow; tb.bss = psgpu_as_global(bf.bss) + (size_t)blockIdx.x * bf.bss_cap;
     tb.idx = psgpu_as_global(bf.idx) + (size_t)blockIdx.x * (bf.max_frames + 2);
@@ -989,6 +1001,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const NColC kid_off = { SMALL ? nodeA + NC_KIDOFF : psgpu_as_global(p.kid_off) }, parent = { SMALL ? nodeA + NC_PARENT : psgpu_as_global(p.parent) },
                 node_ci = { SMALL ? nodeA + NC_CI : psgpu_as_global(p.node_ci) }, node_pw = { SMALL ? nodeA + NC_PW : psgpu_as_global(p.node_pw) };
     const WColC wc_off = { SMALL ? wordA + WC_WCOFF : psgpu_as_global(p.wc_off) };
+    auto pslot = [&](int w, int r) { return SMALL ? wc_off[w] + r : wblk[w] * kFtRcBlk + r; };
     // the words' first phones / base ids and the single-phone words' ids: LDS copies in the small layout (the pair searches'
     // first trip to device memory is then the back-pointer entries' alone)
     const WColC dfirst_f = { SMALL ? wordA + WC_DFIRST : d_first }, dbase_f = { SMALL ? wordA + WC_DBASE : d_base },
@@ -1047,13 +1060,18 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     if (!resumed) {
         for (int c = tid; c < W1; c += NT) ch_init<NE>(tv, c, c < R, node_ssid[c], node_tmat[c], sseq);
         for (int i = tid; i < n1; i += NT) ch_init<NE>(tv, W1 + i, w1_mpx[i], w1_ssid[i], w1_tmat[i], sseq);
-        for (int i = tid; i < p.TOT; i += NT) present[i] = 0;
+        if (SMALL) { for (int i = tid; i < p.TOT; i += NT) present[i] = 0; }
+        else {
+            for (int i = tid; i < p.rc_blocks * (kFtRcBlk / 4); i += NT) reinterpret_cast<int32_t *>(present)[i] = 0;
+            for (int i = tid; i < p.rc_blocks; i += NT) rcfree[i] = i;
+            for (int w = tid; w < p.n_w; w += NT) wblk[w] = -1;
+        }
         for (int w = tid; w < p.n_w; w += NT) { word_lat_idx[w] = -1; lt_sf[w] = -1; word_active[w] = 0; cand_mark[w] = -1; }
         if (SMALL) { for (int c = tid; c < N; c += NT) pos[c] = -1; }      // pos is kept at -1 between frames
     }
     if (tid == 0) {
         s_sc[0] = 0; s_sc[1] = 0; s_sc[2] = p.beam; s_sc[3] = 0; s_sc[4] = 0; s_sc[5] = 0; s_sc[6] = 0; s_sc[7] = 0;
-        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0; s_nroot = 0;
+        s_evals = 0ull; s_nb = 0x7fffffff; s_nsen = 0; s_nev = 0; s_nroot = 0; s_nfree = SMALL ? 0 : p.rc_blocks;
     }
     {
         const int nwords = (p.n_sen + 31) >> 5;
@@ -1116,7 +1134,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
         }
         if (tid < 8) s_sc[tid] = live[8 + tid];
-        if (tid == 0) { s_evals = (unsigned long long)(uint32_t)live[5] | ((unsigned long long)(uint32_t)live[6] << 32); s_nsen = live[7]; }
+        if (tid == 0) { s_evals = (unsigned long long)(uint32_t)live[5] | ((unsigned long long)(uint32_t)live[6] << 32); s_nsen = live[7]; s_nfree = live[17]; }
         n_acl_cur = live[1]; n_awl_cur = live[2]; evals_run = (uint32_t)live[3]; nwc_cur = live[4];
         __syncthreads();
         if (!SMALL) {                                    // (the compact channels are in the slab, where the last frame left them; their index is LDS)
@@ -1317,7 +1335,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 else if ((k -= Rq) < naq) code = aclc[k];
                 else if ((k -= naq) < n1) { if (tv.at(W1 + k, F::FRAME) == f) code = W1 + k; }
                 else if ((k -= n1) < nwc) {
-                    const int i = ft_seg_find(woff, naw, k), r = k - woff[i], slot = wc_off[awlc[i]] + r;
+                    const int i = ft_seg_find(woff, naw, k), r = k - woff[i], slot = pslot(awlc[i], r);
                     if (present[slot]) {
                         code = kFtWordCh | (i << 8) | r;
                         if (raw_mode) {                          // (never multiplexed: the senone ids are the record's last quad(s))
@@ -1346,7 +1364,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         const int n_ev = n_evl + (SMALL ? 0 : s_nroot + na); // HMM instances evaluated this frame
         if (n_evl > L.evl_cap) { if (tid == 0) s_sc[6] = 2; ft_sync<SMALL>(); break; }      // status 2: the LDS layout's list is full
         FT_PROF(0);
-        auto word_slot = [&](int code) { return wc_off[awlc[(code >> 8) & 0x3fffff]] + (code & 255); };
+        auto word_slot = [&](int code) { return pslot(awlc[(code >> 8) & 0x3fffff], code & 255); };
         if (best_in + 2 * p.beam < kW) {                      // renormalize_scores (:566-603)
             for (int e = tid; e < n_evl; e += NT) {
                 const int c = evl_get(e);
@@ -2022,17 +2040,25 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     const int w = cand_wid[i];
                     cnt[i] = cand_score[i] > cthresh ? wc_off[w + 1] - wc_off[w] : 0;
                     cnt2[i] = 0;                                // "entered a channel"
+                    if (!SMALL && cnt[i] > 0 && wblk[w] < 0) {
+                        // the word's block of the pool (a frame's candidates name distinct words): one that no word holds -- which one
+                        // is nobody's business.  None left: status 5, the frame is not finished
+                        const int at = atomicAdd(&s_nfree, -1) - 1;
+                        if (at < 0) s_red[7] = 2;
+                        wblk[w] = at < 0 ? 0 : rcfree[at];
+                    }
                 }
                 if (tid == 0) cnt[n_cand] = 0;
                 ft_sync<SMALL>();
                 const int n_ent = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
                 for (int j = tid; j < n_ent; j += NT) {
-                    const int i = ft_seg_find(cnt, n_cand, j), w = cand_wid[i], r = j - cnt[i], slot = wc_off[w] + r;
+                    const int i = ft_seg_find(cnt, n_cand, j), w = cand_wid[i], r = j - cnt[i], slot = pslot(w, r);
                     int32_t *const rec = wv.b + (size_t)slot * F::REC;
+                    if (s_red[7] == 2) continue;                 // (the pool ran out: see above)
                     if (!present[slot]) {
                         // ngram_search_alloc_all_rc (ngram_search.c:583-633), then hmm_enter into the cleared channel (its frame
                         // is -1: the test below always passes): the whole record is written at once
-                        ch_init_enter_rec_s<NE>(rec, slot_sen + (size_t)slot * (NE <= 3 ? 4 : 8), cand_score[i], cand_bp[i], nf);
+                        ch_init_enter_rec_s<NE>(rec, slot_sen + ((size_t)wc_off[w] + r) * (NE <= 3 ? 4 : 8), cand_score[i], cand_bp[i], nf);
                         present[slot] = 1;
                         cnt2[i] = 1;
                     }
@@ -2043,6 +2069,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 }
             }
             __syncthreads();                                     // (device memory is exchanged here)
+            if (!SMALL && s_red[7] == 2) { if (tid == 0) s_sc[6] = 5; __syncthreads(); break; }     // status 5: the right-context channels' pool is full
             FT_PROF(9);
             {                                            // stable compaction by a prefix sum
                 int32_t nawl;
@@ -2093,6 +2120,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int w = i < naw ? awlc[i] : 0;
                 const int k = i < naw ? w_k[i] : 0, ex = i < naw ? w_exit[i] : 0;
                 w_k[i] = (k > 0 && !word_active[w]) ? 1 : 0;
+                if (!SMALL && i < naw && k == 0 && !word_active[w]) {
+                    // the word leaves the active list with no channel left (every `present` byte of its block is clear): the block
+                    // goes back to the pool (pushes only in this step, pops only in the entering step: barriers between)
+                    const int blk = wblk[w];
+                    wblk[w] = -1;
+                    rcfree[atomicAdd(&s_nfree, 1)] = blk;
+                }
                 w_bp[i] = ex ? 1 : 0;
                 w_bss[i] = ex ? wc_off[w + 1] - wc_off[w] : 0;     // = rssid n_ssid of the word's last two phones
             }
@@ -2137,7 +2171,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     if (SMALL && lane < n_ci) cmrow = rs_cimap[((size_t)dlast_f[w] * n_ci + w_last2) * n_ci + lane];
                     int32_t it[4] = { kW, -1, -1, -1 };          // out score, history, its real / prev_real wid
                     if (lane < nrc) {
-                        const int slot = wc_off[w] + lane;
+                        const int slot = pslot(w, lane);
                         const FtQuad q = ch_summary<NE>(wv.b + (size_t)slot * F::REC);      // out, out history, best, frame
                         if (present[slot] && q.z > lpth && q.x > nwt) {     // (best > lpth: prune_word_chan has stamped it)
                             const int32_t path = q.y;
@@ -2450,7 +2484,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (tid == 0) {
             live[0] = s_sc[7]; live[1] = n_acl_cur; live[2] = n_awl_cur; live[3] = (int32_t)evals_run; live[4] = nwc_cur;
             live[5] = (int32_t)(s_evals & 0xffffffffull); live[6] = (int32_t)(s_evals >> 32); live[7] = s_nsen;
-            live[16] = kFtLiveMagic;
+            live[16] = kFtLiveMagic; live[17] = s_nfree;
         }
     }
     {   // the table in the caller's columns (bptbl_t, ngram_search.h:112-124): ft_table_out
@@ -2593,7 +2627,8 @@ static bool ft_layout(FtDev &d, bool small)
     // (the pruning's snapshot: columns of the node block in the LDS layout; the slab layouts keep it in the nodes' records)
     L.cnt = take(d.cnt_words);
     L.cnt2 = take(d.n_w + 2); L.cnt3 = take(d.n_w + 2); L.woff = take(d.n_w + 2); L.ckey = take(2 * ((int64_t)d.n_w + 2));
-    L.present = take(((int64_t)d.TOT + 3) / 4);
+    L.present = take(small ? ((int64_t)d.TOT + 3) / 4 : (int64_t)d.rc_blocks * kFtRcBlk / 4);
+    if (!small) { L.wblk = take(d.n_w); L.rcfree = take(d.rc_blocks); }
     d.lb_words = 0;
     if (small) {
         L.pen = take(2 * (int64_t)d.n_ci);
@@ -2626,12 +2661,12 @@ static bool ft_layout(FtDev &d, bool small)
     else {
         L.itb = take(4 * (int64_t)d.R);
         const int nd = ne == 3 ? 2 : 3;
-        L.ccap = (int32_t)std::max<int64_t>(1, (int64_t)d.N - d.R);
+        L.ccap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, d.listed_cap));
         L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cxfer = take(2 * 4 * (int64_t)L.ccap);
         L.cperm = take(L.ccap);
         if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords) return false;     // (the listed-nodes bitmap lives in LDS)
         d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
-        L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.R + d.N + d.n1 + d.TOT + 64, 0x7ffffff0);
+        L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.n1 + (int64_t)d.rc_blocks * kFtRcBlk + 64, 0x7ffffff0);      // (the word level's: single-phone words, pool channels)
         L.evl = take(L.evl_cap);
     }
     if (o > 0x7fffff00) return false;
@@ -2639,7 +2674,7 @@ static bool ft_layout(FtDev &d, bool small)
     d.small = small ? 1 : 0;
     int64_t g = 0;
     auto gtake = [&](int64_t n) { const int64_t r = g; g += (n + 31) & ~(int64_t)31; return r; };       // 128-byte lines
-    d.g_wrec = gtake((int64_t)d.TOT * rec);
+    d.g_wrec = gtake(small ? (int64_t)d.TOT * rec : (int64_t)d.rc_blocks * kFtRcBlk * rec);
     d.g_fast = small ? 0 : gtake(o);
     d.per = g;
     return true;
@@ -2758,6 +2793,11 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
     d.TOT = (int32_t)tot;
     d.CH = d.N + d.n1;
     d.n_tmat = t->n_tmat;
+    {   // (PSGPU_FWDTREE_LISTED_CAP / PSGPU_FWDTREE_RC_BLOCKS: tests' knobs -- capacities that small fill up, status 4 / 5)
+        const char *lc = getenv("PSGPU_FWDTREE_LISTED_CAP"), *rb = getenv("PSGPU_FWDTREE_RC_BLOCKS");
+        d.listed_cap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, lc ? atoll(lc) : 65536));
+        d.rc_blocks = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.n_w, rb ? atoll(rb) : 2048));
+    }
     d.cnt_words = std::max(std::max(2 * (d.R + d.N + 1), 4 * d.n_w + 4), kFtMaxSen / 32 + 4);     // (two arrays over the roots and listed nodes; .. + 4: the senone bitmap's word populations)
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
     d.node_ssid = ft_up(m, t->node_ssid, d.N, &rc); d.node_tmat = ft_up(m, t->node_tmat, d.N, &rc);
@@ -2889,6 +2929,31 @@ int psgpu_fwdtree_use_slab_layout(psgpu_fwdtree_t *m)
         psgpu_set_error("fwdtree: the search's per-utterance arrays exceed 8 GB in the slab layout");
         return PSGPU_EINVAL;
     }
+    return PSGPU_OK;
+}
+
+int psgpu_fwdtree_grow(psgpu_fwdtree_t *m, int32_t status)
+{
+    PSGPU_REQUIRE(m && (status == 4 || status == 5), "psgpu_fwdtree_grow: status 4 (listed tree nodes) or 5 (right-context channel pool)");
+    FtDev &d = m->d;
+    PSGPU_REQUIRE(!d.small, "psgpu_fwdtree_grow: the LDS layout has neither capacity");
+    const int32_t old_l = d.listed_cap, old_r = d.rc_blocks;
+    if (status == 4) {
+        PSGPU_REQUIRE((int64_t)d.listed_cap < (int64_t)d.N - d.R, "psgpu_fwdtree_grow: the compact channels hold every tree node already");
+        d.listed_cap = (int32_t)std::min<int64_t>((int64_t)d.N - d.R, 2 * (int64_t)d.listed_cap);
+    }
+    else {
+        PSGPU_REQUIRE(d.rc_blocks < d.n_w, "psgpu_fwdtree_grow: the pool holds a block per word already");
+        d.rc_blocks = (int32_t)std::min<int64_t>(d.n_w, 2 * (int64_t)d.rc_blocks);
+    }
+    if (!ft_layout(d, false)) {
+        d.listed_cap = old_l; d.rc_blocks = old_r;
+        const bool back = ft_layout(d, false);
+        (void)back;
+        psgpu_set_error("psgpu_fwdtree_grow: the search's per-utterance arrays would exceed 8 GB");
+        return PSGPU_EINVAL;
+    }
+    m->live_valid = false;                               // (a saved search's arrays lay where the old layout put them)
     return PSGPU_OK;
 }
 

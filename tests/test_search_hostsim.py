@@ -123,6 +123,37 @@ def test_search_kernel_source_rank_table_in_the_slab(big_trace, cap):  # noqa: F
         _run("man_ah_2934za", "fwd", layout="slab")             # (5-state HMMs)
 
 
+@pytest.mark.parametrize("case,knob,status,start", [("goforward", "PSGPU_FWDTREE_LISTED_CAP", 4, "16"), ("goforward", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"),
+                                               ("man_ah_2934za", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"), ("cmudict", "PSGPU_FWDTREE_RC_BLOCKS", 5, "8"),
+                                               ("cmudict", "PSGPU_FWDTREE_LISTED_CAP", 4, "4096")])
+def test_search_kernel_source_capacities_grow_on_demand(case, knob, status, start, big_trace):  # noqa: F811
+    """slab layouts: the compact channels' capacity (tree nodes a frame may list) and the pool of the right-context channels' blocks start
+    small and grow on demand -- a frame that needs more ends the utterance with status 4 / 5, psgpu_fwdtree_grow doubles the capacity and the
+    search is repeated (what psgpu_decode_fetch_hyps does by itself): the final tables are the reference's, and the first run did report the
+    status (the knobs make the capacities that small)."""
+    if case == "cmudict":
+        g = big_trace; st = g; lm = simlib.SimLm(g)
+    else:
+        g = _load("fwdtree_trace_%s.npz" % case)
+        st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
+        lm = None if "lm" in st else simlib.SimLm(st)
+    with _layout("slab"), _env(knob, start):
+        s = simlib.SimFwdtreeSearch(st, g["par"], lm=lm)
+    rows, pen = _inputs(g, s.n_sen)
+    seen = []
+    for _ in range(20):
+        r = s.search(rows, pen, [rows.shape[0]])[0]
+        seen.append(r["status"])
+        if r["status"] not in (4, 5):
+            break
+        simlib.check(simlib.lib().psgpu_fwdtree_grow(s.h, r["status"]), "psgpu_fwdtree_grow")
+    assert seen[0] == status and seen[-1] == 0 and set(seen[:-1]) == {status}, seen
+    _check(r, g, "%s after %d growths" % (case, len(seen) - 1))
+    s.close()
+    if lm is not None:
+        lm.close()
+
+
 @pytest.mark.parametrize("name", LM_CASES)
 def test_simulated_device_trie_equals_reference_look_ups(name):
     """psgpu_lm_dev.h through the simulator against the reference's recorded look-ups"""
