@@ -108,18 +108,29 @@ class FwdtreeSearch:
         calls = [(d_o, 0, 0)] if cuts is None else \
             [(torch.tensor([0, int(c)], dtype=torch.int32, device=dev), lag, (1 if i == 0 else 3)) for i, c in enumerate(cuts)] + [(d_o, 0, 2)]
         self.searched = []
-        for o, lg, mode in calls:
-            if cuts is not None:
-                capi.check(capi.lib().psgpu_fwdtree_search_lag(self.h, int(lg)), "psgpu_fwdtree_search_lag")
-                capi.check(capi.lib().psgpu_fwdtree_search_resume(self.h, mode), "psgpu_fwdtree_search_resume")
-            capi.check(capi.lib().psgpu_fwdtree_search_session_dev(
-                self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(o), n, mf, bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
-                int(raw_scores), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
-                p(d_mo) if d_mo is not None else None, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                "psgpu_fwdtree_search_session_dev")
-            torch.cuda.current_stream().synchronize()   # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel
-            if cuts is not None:
-                self.searched.append(int(res[0, 2].item()))
+        self.grown = []
+        for attempt in range(40 if cuts is None else 1):
+          for o, lg, mode in calls:
+              if cuts is not None:
+                  capi.check(capi.lib().psgpu_fwdtree_search_lag(self.h, int(lg)), "psgpu_fwdtree_search_lag")
+                  capi.check(capi.lib().psgpu_fwdtree_search_resume(self.h, mode), "psgpu_fwdtree_search_resume")
+              capi.check(capi.lib().psgpu_fwdtree_search_session_dev(
+                  self.h, p(d_s), C.c_int64(self.n_sen), p(d_p), p(o), n, mf, bp_cap, bss_cap, p(bp), p(bss), p(idx), p(step), p(res),
+                  int(raw_scores), int(pl_window), p(w1) if w1 is not None else None, p(d_mi) if d_mi is not None else None,
+                  p(d_mo) if d_mo is not None else None, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                  "psgpu_fwdtree_search_session_dev")
+              torch.cuda.current_stream().synchronize()   # the entry is asynchronous; d_s / d_p / d_o must outlive the kernel
+              if cuts is not None:
+                  self.searched.append(int(res[0, 2].item()))
+          # status 4 / 5 (slab layouts): a frame listed more tree nodes than the compact channels hold / needed more blocks of the
+          # right-context channels' pool than there are -- the capacity is doubled (psgpu_fwdtree_grow) and the search repeated, as
+          # psgpu_decode_fetch_hyps does for the pipeline
+          st = res[:, 3].cpu().numpy() if n else np.zeros(0, np.int32)
+          need = [int(v) for v in st if int(v) in (4, 5)]
+          if not need or cuts is not None:
+              break
+          capi.check(capi.lib().psgpu_fwdtree_grow(self.h, need[0]), "psgpu_fwdtree_grow")
+          self.grown.append(need[0])
         if mpx_out is not None:
             mpx_out["mpx"] = d_mo.cpu().numpy()
         out = []

@@ -166,6 +166,42 @@ def test_pipeline_equals_the_reference_on_32_of_the_benchmarks_utterances(tables
     p.close()
 
 
+@pytest.mark.parametrize("knob,value,status", [("PSGPU_FWDTREE_LISTED_CAP", "64", 4), ("PSGPU_FWDTREE_RC_BLOCKS", "4", 5)])
+def test_slab_layout_capacities_are_reported_and_grown(tables, tmp_path, monkeypatch, knob, value, status):
+    """status 4 / 5 (slab layouts): the compact channels hold the tree nodes ONE frame lists, the right-context channels come from a pool of
+    blocks; both start small and grow on demand.  With the capacity cut down (the knob is read when the search is created) and growth off
+    the utterances end early with that status; with growth on fetch() doubles the capacity (psgpu_fwdtree_grow) until the search gets
+    through, and the result is the reference's -- and the capacity stays: the next call does not repeat."""
+    import pocketsphinx_amd as P
+    from pocketsphinx_amd import synth
+    gt = _load("fwdtree_trace_goforward.npz")
+    pcms = [synth.utterance(i, 6.0) for i in (2, 4, 6)]
+    refs = _reference(tmp_path, pcms, "turtle.lm.bin", "turtle.dic")
+    monkeypatch.setenv("PSGPU_FWDTREE_LAYOUT", "slab")
+    monkeypatch.setenv(knob, value)
+    p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), tables, _load("fwdtree_static_en_us_turtle.npz"), gt["par"], gt)
+    monkeypatch.delenv(knob); monkeypatch.delenv("PSGPU_FWDTREE_LAYOUT")
+    assert not p.search.lds_layout()
+    p.score_mode(False)
+    p.table_capacity(0, 0, False)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    assert all(int(res[u, 3]) == status and int(res[u, 2]) < refs[u]["frames"] for u in range(3)), res[:, :4]
+    p.table_capacity(0, 0, True)
+    p.run(pcms)
+    hn, hyp, res = p.fetch()
+    assert p.tables_grown() >= 1
+    for u, r in enumerate(refs):
+        _same(u, r, hn, hyp, res, "utterance %d after growing" % u)
+    p.run(pcms)
+    n = p.tables_grown()
+    hn, hyp, res = p.fetch()
+    assert p.tables_grown() == n
+    for u, r in enumerate(refs):
+        _same(u, r, hn, hyp, res, "utterance %d, second call" % u)
+    p.close()
+
+
 def test_a_full_evaluation_list_is_reported_and_recovered_from(tables, tmp_path, monkeypatch):
     """status 2: the LDS layout's evaluation list (sized by what the workgroup's LDS pool has left) is too short for a frame.
     With a list of 64 entries (PSGPU_FWDTREE_EVL_CAP, read when the search is created; the task evaluates ~240 channels a
