@@ -1270,7 +1270,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // (woff -- the prefix sums of the active words' right-context counts -- and their total were made in the previous frame,
         //  in the single-phone words' scan, as soon as this frame's word list was complete: no barrier, no scan here)
         for (int i = tid; i < naw; i += NT) word_active[awlc[i]] = 0;
-        const int nwc = nwc_cur;
+        // (slab layouts: a block of the pool per active word, kFtRcBlk places each -- sixty-four consecutive work-items look at one word's
+        //  block, no search for the word a channel belongs to)
+        const int nwc = SMALL ? nwc_cur : naw * kFtRcBlk;
         // ---- the frame's evaluation list: every HMM instance evaluate_channels (:605-715) visits -- roots entered for this
         //      frame, the listed tree nodes, the allocated right-context channels of the active words, the single-phone
         //      words entered for this frame -- compacted into one list (order irrelevant: independent evaluations, maxima
@@ -1335,8 +1337,15 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 else if ((k -= Rq) < naq) code = aclc[k];
                 else if ((k -= naq) < n1) { if (tv.at(W1 + k, F::FRAME) == f) code = W1 + k; }
                 else if ((k -= n1) < nwc) {
-                    const int i = ft_seg_find(woff, naw, k), r = k - woff[i], slot = pslot(awlc[i], r);
-                    if (present[slot]) {
+                    int i, r, slot; bool there;
+                    if (SMALL) { i = ft_seg_find(woff, naw, k); r = k - woff[i]; slot = pslot(awlc[i], r); there = present[slot] != 0; }
+                    else {
+                        i = k / kFtRcBlk; r = k % kFtRcBlk;
+                        const int w = awlc[i];
+                        slot = pslot(w, r);
+                        there = r < wc_off[w + 1] - wc_off[w] && present[slot] != 0;
+                    }
+                    if (there) {
                         code = kFtWordCh | (i << 8) | r;
                         if (raw_mode) {                          // (never multiplexed: the senone ids are the record's last quad(s))
                             const FtQuad *q = reinterpret_cast<const FtQuad *>(wv.b + (size_t)slot * F::REC + F::SENID);
@@ -1975,6 +1984,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //      cache keyed by start frame.  Should two candidates ever share a word, the reference's loops are run as
         //      written by one thread.
         const int n_cand = s_sc[5];
+        // slab layouts: the word level's per-candidate / per-active-word scratch arrays in LDS -- in the pruning's item arrays, idle until
+        // the next frame's pruning -- when this frame's counts fit (else the slab's): their prefix sums, the searches in them and the
+        // survivor counts (atomics) are then LDS operations
+        constexpr int kWL = SMALL ? 1 : (9 * kPrIC) / 6;
+        const bool wl_lds = !SMALL && naw + n_cand + n1 + 8 <= kWL;
+        int32_t *const cntf = wl_lds ? s_pool : cnt, *const cnt2f = wl_lds ? s_pool + 4 * kWL : cnt2, *const cnt3f = wl_lds ? s_pool + 5 * kWL : cnt3;
+        const int wstf = wl_lds ? kWL : p.n_w + 1;
         {
             for (int i = tid; i < n_cand; i += NT) {
                 const int cb = cand_bp[i], w = cand_wid[i];
@@ -1990,16 +2006,16 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     const int32_t e0 = BPC(tb, B_F0, cb), e1 = BPC(tb, B_F1, cb);
                     if (lt_sf[w] != ef + 1) { b0 = e0; need = e1 - b0; sf = ef + 1; }
                 }
-                cnt[i] = need; cnt2[i] = b0; cnt3[i] = sf;
+                cntf[i] = need; cnt2f[i] = b0; cnt3f[i] = sf;
                 ckey[i] = ft_key_floor(kW);
             }
-            if (tid == 0) cnt[n_cand] = 0;
+            if (tid == 0) cntf[n_cand] = 0;
             ft_sync<SMALL>();
             if (s_red[7] != 0) { if (tid == 0) s_sc[6] = 3; ft_sync<SMALL>(); break; }
-            const int n_pair = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
+            const int n_pair = ft_block_scan<NT, SMALL>(cntf, n_cand + 1, s_scan);
             FT_PROF(29);
             for (int j = tid; j < n_pair; j += NT) {
-                const int i = ft_seg_find(cnt, n_cand, j), bp = cnt2[i] + (j - cnt[i]), w = cand_wid[i];
+                const int i = ft_seg_find(cntf, n_cand, j), bp = cnt2f[i] + (j - cntf[i]), w = cand_wid[i];
                 // (every load of the pair before the first test: three trips to device memory -- the entry's columns; context map
                 //  and language-model entry; stacked score -- where the tests in between made seven)
                 const int32_t valid = BPC(tb, B_VALID, bp), real = BPC(tb, B_REAL, bp), preal = BPC(tb, B_PREAL, bp);
@@ -2014,11 +2030,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             int32_t bestscore = kW;
             for (int i = tid; i < n_cand; i += NT) {
                 const int w = cand_wid[i];
-                if (cnt3[i] >= 0) {                          // searched: best = WORST_SCORE keeps the old back-pointer
+                if (cnt3f[i] >= 0) {                          // searched: best = WORST_SCORE keeps the old back-pointer
                     const unsigned long long k = ckey[i];
                     if (ft_key_none(k)) lt_dscr[w] = kW;
                     else { lt_dscr[w] = ft_key_score(k); lt_bp[w] = ft_key_bp(k); }
-                    lt_sf[w] = cnt3[i];
+                    lt_sf[w] = cnt3f[i];
                 }
                 const int32_t score = cand_score[i] + lt_dscr[w];
                 cand_score[i] = score;
@@ -2038,9 +2054,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             {
                 for (int i = tid; i < n_cand; i += NT) {
                     const int w = cand_wid[i];
-                    cnt[i] = cand_score[i] > cthresh ? wc_off[w + 1] - wc_off[w] : 0;
-                    cnt2[i] = 0;                                // "entered a channel"
-                    if (!SMALL && cnt[i] > 0 && wblk[w] < 0) {
+                    cntf[i] = cand_score[i] > cthresh ? wc_off[w + 1] - wc_off[w] : 0;
+                    cnt2f[i] = 0;                                // "entered a channel"
+                    if (!SMALL && cntf[i] > 0 && wblk[w] < 0) {
                         // the word's block of the pool (a frame's candidates name distinct words): one that no word holds -- which one
                         // is nobody's business.  None left: status 5, the frame is not finished
                         const int at = atomicAdd(&s_nfree, -1) - 1;
@@ -2048,11 +2064,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         wblk[w] = at < 0 ? 0 : rcfree[at];
                     }
                 }
-                if (tid == 0) cnt[n_cand] = 0;
+                if (tid == 0) cntf[n_cand] = 0;
                 ft_sync<SMALL>();
-                const int n_ent = ft_block_scan<NT, SMALL>(cnt, n_cand + 1, s_scan);
+                const int n_ent = ft_block_scan<NT, SMALL>(cntf, n_cand + 1, s_scan);
                 for (int j = tid; j < n_ent; j += NT) {
-                    const int i = ft_seg_find(cnt, n_cand, j), w = cand_wid[i], r = j - cnt[i], slot = pslot(w, r);
+                    const int i = ft_seg_find(cntf, n_cand, j), w = cand_wid[i], r = j - cntf[i], slot = pslot(w, r);
                     int32_t *const rec = wv.b + (size_t)slot * F::REC;
                     if (s_red[7] == 2) continue;                 // (the pool ran out: see above)
                     if (!present[slot]) {
@@ -2060,11 +2076,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         // is -1: the test below always passes): the whole record is written at once
                         ch_init_enter_rec_s<NE>(rec, slot_sen + ((size_t)wc_off[w] + r) * (NE <= 3 ? 4 : 8), cand_score[i], cand_bp[i], nf);
                         present[slot] = 1;
-                        cnt2[i] = 1;
+                        cnt2f[i] = 1;
                     }
                     else if (rec[F::FRAME] < f || cand_score[i] > rec[F::SCORE]) {
                         ch_enter<NE>(wv, slot, cand_score[i], cand_bp[i], nf);
-                        cnt2[i] = 1;
+                        cnt2f[i] = 1;
                     }
                 }
             }
@@ -2074,18 +2090,18 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             {                                            // stable compaction by a prefix sum
                 int32_t nawl;
                 if (n_cand <= NT) {                          // (one candidate a work-item: its flag and place in registers, one barrier)
-                    int32_t v[1] = { tid < n_cand ? cnt2[tid] : 0 }, t1[1];
+                    int32_t v[1] = { tid < n_cand ? cnt2f[tid] : 0 }, t1[1];
                     const int32_t mine = v[0];
                     ft_scan_tid<NT, 1, SMALL>(v, s_scan, t1);
                     nawl = t1[0];
                     if (mine) { const int w = cand_wid[tid]; awln[v[0]] = w; word_active[w] = 1; }
                 }
                 else {
-                    nawl = ft_block_scan<NT, SMALL>(cnt2, n_cand, s_scan);
+                    nawl = ft_block_scan<NT, SMALL>(cnt2f, n_cand, s_scan);
                     for (int i = tid; i < n_cand; i += NT)
-                        if ((i + 1 < n_cand ? cnt2[i + 1] : nawl) != cnt2[i]) {
+                        if ((i + 1 < n_cand ? cnt2f[i + 1] : nawl) != cnt2f[i]) {
                             const int w = cand_wid[i];
-                            awln[cnt2[i]] = w; word_active[w] = 1;
+                            awln[cnt2f[i]] = w; word_active[w] = 1;
                         }
                 }
                 if (tid == 0) s_red[5] = nawl;
@@ -2097,8 +2113,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             //      this frame's candidates have just allocated were entered for the next frame and have no score yet: the
             //      reference's walk neither counts nor frees them), survivors counted per word by atomics
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            const int wst = p.n_w + 1;                            // naw <= n_w
-            int32_t *const w_k = cnt, *const w_exit = cnt + wst, *const w_bp = cnt + 2 * wst, *const w_bss = cnt + 3 * wst;
+            const int wst = wstf;                                 // naw <= n_w
+            int32_t *const w_k = cntf, *const w_exit = cntf + wst, *const w_bp = cntf + 2 * wst, *const w_bss = cntf + 3 * wst;
             for (int i = tid; i < naw; i += NT) { w_k[i] = 0; w_exit[i] = 0; }
             ft_sync<SMALL>();
             for (int e = tid; e < n_evl; e += NT) {
@@ -2229,8 +2245,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         if (!s_sc[6]) {
             // single-phone words (:1100-1127), one work-item per word; back-pointer positions in list order by prefix sums
             const int32_t nwt = s_sc[1] + p.wbeam, lpth = s_sc[1] + p.lponlybeam;
-            const int wst = p.n_w + 1;                            // n1 <= n_w
-            int32_t *const f_ex = cnt, *const f_new = cnt + wst, *const f_rc = cnt + 2 * wst;
+            const int wst = wstf;                                 // n1 <= n_w
+            int32_t *const f_ex = cntf, *const f_new = cntf + wst, *const f_rc = cntf + 2 * wst;
             // (when the single-phone words and the next frame's active words are no more than the work-items -- nearly always -- each
             //  work-item keeps its word's flags and gets its prefix sums in registers, ft_scan_tid: no arrays, one barrier)
             const int naw_n0 = s_red[5];
