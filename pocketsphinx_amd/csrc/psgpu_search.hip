@@ -53,6 +53,13 @@ constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS 
 #ifndef PSGPU_FT_PAIRS
 #define PSGPU_FT_PAIRS 4
 #endif
+#ifndef PSGPU_FT_IPT
+#define PSGPU_FT_IPT 2
+#endif
+constexpr int kFtIpt = PSGPU_FT_IPT;           // slab layouts: consecutive items (roots / listed nodes) of a pruning chunk a work-item takes to LDS
+#ifndef PSGPU_FT_POOL_WORDS_BIG
+#define PSGPU_FT_POOL_WORDS_BIG 39808
+#endif
 constexpr int kFtPairs = PSGPU_FT_PAIRS;       // slab layouts: consecutive pairs of the pruning a work-item decides at a time
 constexpr int kFtThreadsBig = PSGPU_FT_THREADS_BIG;    // ... on trees beyond kFtBigNodes
 constexpr int kFtBigNodes = 4096;
@@ -826,7 +833,10 @@ constexpr bool kFtRowsDevice = PSGPU_FT_ROWS_DEVICE != 0;
 constexpr int kFtWavesPerEu = PSGPU_FT_WAVES;
 #if defined(__HIPCC__)
 extern __shared__ __attribute__((aligned(16))) int32_t ft_dyn_pool[];
-#define FT_KERNEL_ATTR(SMALL) __attribute__((amdgpu_waves_per_eu((SMALL) ? kFtWavesPerEu : 1)))
+#ifndef PSGPU_FT_WAVES_BIG
+#define PSGPU_FT_WAVES_BIG 1
+#endif
+#define FT_KERNEL_ATTR(SMALL) __attribute__((amdgpu_waves_per_eu((SMALL) ? kFtWavesPerEu : (NT == kFtThreadsBig ? PSGPU_FT_WAVES_BIG : 1))))
 #else
 #define FT_KERNEL_ATTR(SMALL)
 #endif
@@ -854,7 +864,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // slab layouts: the pruning step works on chunks of kPrIC roots / listed nodes ("items") whose snapshot lies in LDS (the
     // dynamic pool, kPrArrays arrays of kPrIC words), so that the (item, child) pairs of a chunk find their item by a bisection
     // in LDS and read the parent's side of a decision -- and, for an item's own entry, the node's side -- from LDS
-    constexpr int kPrIC = SMALL ? 1 : 2 * NT;
+    constexpr int kPrIC = SMALL ? 1 : kFtIpt * NT;
     int32_t *const s_it_node = s_pool, *const s_it_out = s_pool + kPrIC, *const s_it_outh = s_pool + 2 * kPrIC,
             *const s_it_fp = s_pool + 3 * kPrIC, *const s_it_k0 = s_pool + 4 * kPrIC, *const s_it_par = s_pool + 5 * kPrIC,
             *const s_it_sc0 = s_pool + 6 * kPrIC, *const s_it_kid0 = s_pool + 7 * kPrIC,
@@ -1648,12 +1658,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 // -- the chunk's items, two consecutive ones a work-item -> LDS; their pairs counted: the item's own entry (listed nodes),
                 //    its children (retained items), the words whose penultimate phone it is (retained items whose out score can reach the
                 //    last-phone beam, :824-870)
-                int32_t np[2];
+                int32_t np[kFtIpt];
                 {
-                    int node[2]; FtQuad it[2], q1[2];
+                    int node[kFtIpt]; FtQuad it[kFtIpt], q1[kFtIpt];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int i = c0 + 2 * tid + u;
+                    for (int u = 0; u < kFtIpt; ++u) {
+                        const int i = c0 + kFtIpt * tid + u;
                         node[u] = -1; it[u] = FtQuad{ kW, -1, kW, 0 }; q1[u] = FtQuad{ 0, 0, 0, -1 };
                         if (i < R) { node[u] = i; it[u] = itb[i]; q1[u] = node_q1[i]; }
                         else if (i < n_item) {
@@ -1663,8 +1673,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int li = 2 * tid + u, i = c0 + li;
+                    for (int u = 0; u < kFtIpt; ++u) {
+                        const int li = kFtIpt * tid + u, i = c0 + li;
                         const bool active = i < R ? it[u].w != 0 : node[u] >= 0;
                         const bool fl = active && it[u].z > thresh;
                         const int nk = fl ? (q1[u].z & 0xffff) : 0, nw = (int)((uint32_t)q1[u].z >> 16);
@@ -1680,7 +1690,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 int32_t n_pair;
                 {
                     const int lane = tid & 63, wv_ = tid >> 6;
-                    const int32_t sp = np[0] + np[1];
+                    int32_t sp = 0;
+#pragma unroll
+                    for (int u = 0; u < kFtIpt; ++u) sp += np[u];
                     const int32_t ip = ft_wave_incl<FtAdd>(sp);
                     if (lane == 63) s_scan[wv_] = ip;
                     ft_sync<true>();
@@ -1692,7 +1704,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         if (w < wv_) bp_ += a_;
                     }
                     const int32_t op = bp_ + ip - sp;
-                    s_it_poff[2 * tid] = op; s_it_poff[2 * tid + 1] = op + np[0];
+                    { int32_t o_ = op;
+#pragma unroll
+                      for (int u = 0; u < kFtIpt; ++u) { s_it_poff[kFtIpt * tid + u] = o_; o_ += np[u]; } }
                     if (tid == NT - 1) s_it_poff[kPrIC] = n_pair;
                     ft_sync<true>();                                 // (the chunk's LDS arrays are complete; s_scan is free again)
                 }
@@ -2521,7 +2535,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // an entry's words lie in one line -- into LDS the frames no longer need, then every work-item writes its word in spoken order:
     // a live stream pays the walk at every step (as two walks of several loads a hop it was a fifth of a 10-frame step).
     int32_t *const bt = SMALL ? fb + L.evl : s_pool;              // {word, end frame, score} per word, last word first
-    const int bt_cap = (SMALL ? (L.evl_cap + 1) / 2 : 18 * NT) / 3;
+    const int bt_cap = (SMALL ? (L.evl_cap + 1) / 2 : 9 * kPrIC) / 3;
     __syncthreads();                                              // (the pool has been saved: its words may be written over)
     if (tid == 0) {
         tb.idx[s_sc[7]] = s_sc[3];                               // ngram_fwdtree_finish: mark one past the last frame
@@ -2701,14 +2715,16 @@ static bool ft_layout(FtDev &d, bool small)
 // is left of kFtSlabPoolWords the rank -> list position table (uint16 entries; a frame that lists more keeps the table in the slab)
 static void ft_slab_pool(FtDev &d, int nt)
 {
-    int32_t o = 9 * 2 * nt + 16;
+    int32_t o = 9 * kFtIpt * nt + 16;
     auto take = [&](int32_t n) { const int32_t r = o; o += (n + 3) & ~3; return r; };
     d.lds_lb = take(d.lb_words);
     d.lds_pre = take(d.lb_words / 2 + 2);
     d.lds_row = take((d.n_sen + 1) / 2 + 4);
     d.lds_tp = take((d.n_tmat * d.n_emit * (d.n_emit + 1) + 3) / 4);
     d.lds_perm = o;
-    const int32_t left = std::max(0, kFtSlabPoolWords - o) & ~3;
+    // (PSGPU_FT_POOL_WORDS_BIG: an A/B build's knob -- a pool of half a compute unit's LDS lets two workgroups of a large tree share one)
+    const int32_t budget = nt == kFtThreadsBig ? std::min(kFtSlabPoolWords, PSGPU_FT_POOL_WORDS_BIG) : kFtSlabPoolWords;
+    const int32_t left = std::max(0, budget - o) & ~3;
     d.lds_perm_cap = (int32_t)std::min<int64_t>(std::min<int64_t>(2 * (int64_t)left, 65528), ((int64_t)d.lay.ccap + 7) & ~(int64_t)7);     // (16-bit positions)
     if (const char *cap = getenv("PSGPU_FWDTREE_PERM_CAP"))     // (a test's knob: frames that list more take the table in the slab)
         d.lds_perm_cap = (int32_t)std::max<int64_t>(0, std::min<int64_t>(d.lds_perm_cap, atoll(cap) & ~7ll));
