@@ -72,6 +72,7 @@ struct psgpu_decode_s {
     // 4 KB of LDS a wave, gets 8 waves on a compute unit that holds two searches: run at a call's start it is 19 ms of the
     // stages' critical path against 6.4 alone)
     hipStream_t fe_stream = nullptr;
+    hipEvent_t ev_wait = nullptr;                        // a blocking event: the host thread SLEEPS on it where a batch call's results are fetched (dec_wait)
     hipEvent_t ev_fe = nullptr;                          // front end ahead done
     bool fe_ahead = false;                               // ev_fe pending for the next call
     std::vector<int64_t> fe_soff;                        // the sample offsets the front end ahead was run for
@@ -268,6 +269,7 @@ void psgpu_decode_free(psgpu_decode_t *d)
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
     if (d->ev_go) hipEventDestroy(d->ev_go);
     if (d->ev_fe) hipEventDestroy(d->ev_fe);
+    if (d->ev_wait) hipEventDestroy(d->ev_wait);
     if (d->fe_stream) hipStreamDestroy(d->fe_stream);
     delete d;
 }
@@ -1182,6 +1184,21 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
     return PSGPU_OK;
 }
 
+// The host's wait for a batch call's results.  hipStreamSynchronize spins: a host thread waiting 70 ms for the search of 512 x 30 s burns
+// a core doing so (bench.py's host.cpu_ms_per_step_per_rank: 1.7 cores busy per GPU in round 4, the fetch's and torch's own
+// synchronize) -- with eight ranks a node's cores are not scarce, but a waiting thread has no business running.  A call of
+// some size waits on a blocking event instead (the thread sleeps until the interrupt, ~20-50 us late); small calls and the live /
+// streams steps, where that lateness is a tenth of the step, keep the spin.  PSGPU_SPIN_WAIT=1: always spin.
+static int dec_wait(psgpu_decode_s *d, hipStream_t st)
+{
+    static const int spin = [] { const char *e = getenv("PSGPU_SPIN_WAIT"); return e ? atoi(e) : 0; }();
+    if (spin || d->live || d->streams || d->total < 100000) { PSGPU_HIP(hipStreamSynchronize(st)); return PSGPU_OK; }
+    if (!d->ev_wait) PSGPU_HIP(hipEventCreateWithFlags(&d->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+    PSGPU_HIP(hipEventRecord(d->ev_wait, st));
+    PSGPU_HIP(hipEventSynchronize(d->ev_wait));
+    return PSGPU_OK;
+}
+
 int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int32_t *result, void *stream)
 {
     PSGPU_REQUIRE(d, "psgpu_decode_fetch_hyps: NULL argument");
@@ -1200,7 +1217,7 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
         // (the usual case -- no table was full -- in one wait: the hypotheses travel with the result records)
         if (hyp_n) PSGPU_HIP(hipMemcpyAsync(hyp_n, d->d_hn, 4 * nu * 4, hipMemcpyDeviceToHost, st));
         if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
-        PSGPU_HIP(hipStreamSynchronize(st));
+        { const int wrc = dec_wait(d, st); if (wrc != PSGPU_OK) return wrc; }
         bool again = false;
         for (size_t u = 0; u < nu && !again; ++u) again = res[u * 8 + 3] != 0;
         if (!again) {
@@ -1217,8 +1234,7 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
         if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
         if (result) PSGPU_HIP(hipMemcpyAsync(result, d->pass2 ? d->d_res2 : d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
     }
-    PSGPU_HIP(hipStreamSynchronize(st));
-    return PSGPU_OK;
+    return dec_wait(d, st);
 }
 
 int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *stream)

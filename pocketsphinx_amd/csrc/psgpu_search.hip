@@ -106,8 +106,9 @@ struct FtLay {
     int32_t cq;                          // [2][ND + 2][ccap][4] two buffers taking turns by frame parity; per buffer ND arrays of quads with the channel's
                                          // scores, histories, out score, out history (ND = 2 for 3 states, 3 for 5) and two with what is static per node
     int32_t csum;                        // [ccap][4] per list position: out, out history, best, score[0] as the evaluation left them
-    int32_t cxfer;                       // [2][ccap][4] per list position (two lists taking turns like the buffers): where the node's channel comes from -- its
-                                         // position in the frame before's list, or -1: a new channel -- and {what the pruning did to it, entering score, history}
+    int32_t cxfer;                       // [2][ccap] per list position (two lists taking turns like the buffers): where the node's channel comes from -- (its
+                                         // position in the frame before's list + 1, or 0: a new channel) | what the pruning did to it << 28
+    int32_t cxpl;                        // [2][ccap][2] ... and, if the pruning entered it, the entering score and history
     int32_t cperm;                       // [ccap] rank among the listed nodes by node id -> list position, when the frame's list outgrows the LDS table
     int32_t ccap;                        // listed nodes a frame may hold: N - R, every node but the roots
     int32_t evl, evl_cap;                // [evl_cap] the frame's evaluation list (small layout: what the pool has left)
@@ -230,6 +231,7 @@ template <int NE> struct ChF {
     static_assert(OUT % 4 == 0 && SENID % 4 == 0 && REC % 4 == 0 && WORDS <= REC, "quads");
 };
 struct alignas(16) FtQuad { int32_t x, y, z, w; };
+struct alignas(8) FtPair { int32_t x, y; };
 // One column of a block of interleaved arrays (LDS layout: AOS, element i at word i * K of the column's base) or a plain array
 // (slab layouts).  Why interleave: this kernel's speed follows the number of scalar values it keeps alive -- the compiler gives
 // every array's base a scalar register, spills what does not fit into vector-register lanes and reads it back with v_readlane
@@ -1000,7 +1002,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     constexpr int ND = NE == 3 ? 2 : 3;
     const int ccap = SMALL ? 1 : L.ccap;
     FtQuad *const cq = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cq));
-    FtQuad *const csum = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.csum)), *const cxf = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.cxfer));
+    FtQuad *const csum = reinterpret_cast<FtQuad *>(fb + (SMALL ? 0 : L.csum));
+    int32_t *const cxf = fb + (SMALL ? 0 : L.cxfer);
+    FtPair *const cxp = reinterpret_cast<FtPair *>(fb + (SMALL ? 0 : L.cxpl));
     int32_t *const g_perm = fb + (SMALL ? 0 : L.cperm);
     auto cbuf = [&](int b, int k) { return cq + (size_t)(b * (ND + 2) + k) * ccap; };      // array k of buffer b
     const FtQuad *const node_st1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_st1));
@@ -1325,13 +1329,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         act_root = tv.at(i, F::FRAME) == f;
                         if (act_root && raw_mode) mark(tv, i);
                     }
-                    else if (i < R + na) {
-                        // the static side of the channel at this place: from its old place, or (a new channel) from the static tables
-                        const int src = cxf[(size_t)cur * ccap + (i - R)].x;
-                        FtQuad s0, a;
-                        if (src >= 0) { s0 = cbuf(nxt, ND)[src]; a = cbuf(nxt, ND + 1)[src]; }
-                        else { const int node = aclc[i - R]; const FtQuad e0 = node_q1[node]; a = node_st1[node]; s0 = FtQuad{ node, e0.x, e0.y, e0.z }; }
-                        cbuf(cur, ND)[i - R] = s0; cbuf(cur, ND + 1)[i - R] = a;
+                    else if (i < R + na && raw_mode) {
+                        // the channel's senones: at its old place's static side, or (a new channel) in the static tables
+                        const int src = (cxf[(size_t)cur * ccap + (i - R)] & 0x0fffffff) - 1;
+                        FtQuad a = FtQuad{ 0, 0, 0, 0 };
+                        if (raw_mode) a = src >= 0 ? cbuf(nxt, ND + 1)[src] : node_st1[aclc[i - R]];
                         if (raw_mode) {                                  // the channel carries its senones, 16 bits each
                             mark_sen(a.x & 0xffff); mark_sen((int)((uint32_t)a.x >> 16)); mark_sen(a.y & 0xffff);
                             if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(a.z & 0xffff); }
@@ -1487,25 +1489,32 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 // histories from its old place, with the entering score of the pruning that entered it -- or a cleared channel's, entered
                 // (hmm_enter into a cleared channel) -- and, in a frame that renormalises (:566-603), less the normaliser
                 const bool renorm = best_in + 2 * p.beam < kW;
-                const FtQuad *const xf = cxf + (size_t)cur * ccap;
+                const int32_t *const xf = cxf + (size_t)cur * ccap;
+                const FtPair *const xp = cxp + (size_t)cur * ccap;
                 for (int j0 = tid; j0 < na; j0 += 2 * NT) {
-                    int32_t w[2][4 * ND]; FtQuad sq[2], x[2];
+                    int32_t w[2][4 * ND]; FtQuad sq[2], s0[2]; int32_t x[2], nd_[2]; FtPair pl[2];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { x[u] = xf[min(j0 + u * NT, na - 1)]; sq[u] = cbuf(cur, ND + 1)[min(j0 + u * NT, na - 1)]; }
+                    for (int u = 0; u < 2; ++u) { const int j = min(j0 + u * NT, na - 1); x[u] = xf[j]; nd_[u] = aclc[j]; }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const bool old_ = x[u].x >= 0 && x[u].y != 4;
+                        const int src = (x[u] & 0x0fffffff) - 1, kind = (int)((uint32_t)x[u] >> 28);
+                        const bool old_ = src >= 0 && kind != 4;
+                        // the static side: from the old place, or (a new channel) from the static tables
+                        if (src >= 0) { s0[u] = cbuf(nxt, ND)[src]; sq[u] = cbuf(nxt, ND + 1)[src]; }
+                        else { const FtQuad e0 = node_q1[nd_[u]]; sq[u] = node_st1[nd_[u]]; s0[u] = FtQuad{ nd_[u], e0.x, e0.y, e0.z }; }
+                        pl[u] = FtPair{ 0, 0 };
+                        if (kind != 0) pl[u] = xp[min(j0 + u * NT, na - 1)];
 #pragma unroll
                         for (int k = 0; k < ND; ++k) {
                             FtQuad q = FtQuad{ 0, 0, 0, 0 };
-                            if (old_) q = cbuf(nxt, k)[x[u].x];
+                            if (old_) q = cbuf(nxt, k)[src];
                             w[u][4 * k] = q.x; w[u][4 * k + 1] = q.y; w[u][4 * k + 2] = q.z; w[u][4 * k + 3] = q.w;
                         }
                         if (!old_) {
 #pragma unroll
                             for (int k = 0; k < 4 * ND; ++k) w[u][k] = (k < NE || k == 2 * NE) ? kW : -1;
                         }
-                        if (x[u].y != 0) { w[u][0] = x[u].z; w[u][NE] = x[u].w; }          // hmm_enter
+                        if (kind != 0) { w[u][0] = pl[u].x; w[u][NE] = pl[u].y; }          // hmm_enter
                         if (renorm) {
 #pragma unroll
                             for (int k = 0; k < NE; ++k) if (w[u][k] > kW) w[u][k] -= best_in;
@@ -1531,6 +1540,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     w[u][2 * NE] = h.out_score; w[u][2 * NE + 1] = h.out_history;
 #pragma unroll
                     for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[u][4 * k], w[u][4 * k + 1], w[u][4 * k + 2], w[u][4 * k + 3] };
+                    cbuf(cur, ND)[j] = s0[u]; cbuf(cur, ND + 1)[j] = sq[u];
                     csum[j] = FtQuad{ h.out_score, h.out_history, h.bestscore, h.score[0] };
                     b_all = max(b_all, sc);
                     }
@@ -1652,7 +1662,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             constexpr int KP = kFtPairs;
             int carry_l = 0, carry_c = 0;                        // next list's entries / candidates so far (uniform)
             const FtQuad *const cs0 = cbuf(cur, ND), *const cs1 = cbuf(cur, ND + 1);
-            FtQuad *const xfer = cxf + (size_t)nxt * ccap;     // the next list's
+            int32_t *const xfer = cxf + (size_t)nxt * ccap;    // the next list's
+            FtPair *const xfpl = cxp + (size_t)nxt * ccap;
             bool over = false;                                   // the next list outgrows the compact buffers (uniform)
             for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
                 // -- the chunk's items, two consecutive ones a work-item -> LDS; their pairs counted: the item's own entry (listed nodes),
@@ -1862,7 +1873,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                                 if (cbit[v]) { cand_wid[oc] = c[v]; cand_score[oc] = a_news[v] - p.nwpen; cand_bp[oc] = a_outh[v]; ++oc; }
                                 // a node of the next list: its place, and where its channel comes from -- its position in this frame's list
                                 // (or -1: a new channel) and what the decision does to it; the next frame's evaluation makes the channel
-                                if (bit[v]) { acln[o] = c[v]; xfer[o] = FtQuad{ c_at[v], act[v], a_news[v], a_outh[v] }; ++o; }
+                                if (bit[v]) {
+                                    acln[o] = c[v]; xfer[o] = (c_at[v] + 1) | (act[v] << 28);
+                                    if (act[v]) xfpl[o] = FtPair{ a_news[v], a_outh[v] };
+                                    ++o;
+                                }
                             }
                         }
                         carry_l += tot; carry_c += tot_c;
@@ -2692,7 +2707,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.itb = take(4 * (int64_t)d.R);
         const int nd = ne == 3 ? 2 : 3;
         L.ccap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, d.listed_cap));
-        L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cxfer = take(2 * 4 * (int64_t)L.ccap);
+        L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cxfer = take(2 * (int64_t)L.ccap); L.cxpl = take(2 * 2 * (int64_t)L.ccap);
         L.cperm = take(L.ccap);
         if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords) return false;     // (the listed-nodes bitmap lives in LDS)
         d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
