@@ -596,25 +596,51 @@ def main():
                 scorer_ms.append((float(ms3[0]), float(ms3[1])))
         return out
 
+    host_split = {"launch_wall": 0.0, "launch_cpu": 0.0, "finish_wall": 0.0, "finish_cpu": 0.0}
+
+    def timed_call(key, fn, *a):
+        w0, c0_ = time.perf_counter(), time.thread_time()
+        r = fn(*a)
+        host_split[key + "_wall"] += time.perf_counter() - w0; host_split[key + "_cpu"] += time.thread_time() - c0_
+        return r
+
     def run_steps(n, timed):
         launch.n = n
         for k in range(n):
-            launch(k)
+            timed_call("launch", launch, k)
             if k >= n_pipe - 1:
-                finish(k - (n_pipe - 1), timed)
+                timed_call("finish", finish, k - (n_pipe - 1), timed)
         for k in range(max(n - (n_pipe - 1), 0), n):
-            finish(k, timed)
+            timed_call("finish", finish, k, timed)
 
     run_steps(args.warmup, False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    def thread_cpu():
+        """CPU seconds (user + system) of every thread of this process, by thread id, with the thread's name"""
+        out = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        for t in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/stat" % t).read()
+                name = f[f.index("(") + 1:f.rindex(")")]
+                v = f[f.rindex(")") + 2:].split()
+                out[int(t)] = (name, (int(v[11]) + int(v[12])) / tick)
+            except Exception:
+                pass
+        return out
+    for k_ in host_split:
+        host_split[k_] = 0.0
     t0 = time.perf_counter()
     c0 = time.process_time()
+    th0 = thread_cpu()
     run_steps(args.steps, True)
     torch.cuda.synchronize()
     host_cpu_s = time.process_time() - c0                # this rank's host CPU inside the timed region (all its threads)
+    th1 = thread_cpu()
+    host_threads = sorted(((n, round(1e3 * (c - th0.get(t, (n, 0.0))[1]) / args.steps, 2)) for t, (n, c) in th1.items()), key=lambda x: -x[1])[:5]
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -715,6 +741,9 @@ def main():
                                                                   if "ms_per_step" in pcie else {})),
         "steps_in_flight": n_pipe,
         "host": {"cpu_ms_per_step_per_rank": round(1e3 * host_cpu_s / args.steps, 3), "host_cpus": os.cpu_count(),
+                 "busiest_threads_ms_per_step": [{"thread": n, "cpu_ms_per_step": c} for n, c in host_threads],
+                 "main_thread_ms_per_step": {k_: round(1e3 * v_ / args.steps, 2) for k_, v_ in host_split.items()},
+                 "ranks_the_host_cores_carry": int(os.cpu_count() / max(host_cpu_s / max(dt, 1e-9), 1e-9)),
                  "what": "host CPU time of one rank inside the timed region (launches, the fetch of the hypothesis records, the gather at N > "
                          "1), per step: what a node's host cores must supply per GPU -- the host-side ceiling of SURVEY 8e is "
                          "host_cpus / (N x this / ms_per_step) ranks"},

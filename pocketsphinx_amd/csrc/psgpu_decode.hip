@@ -10,6 +10,7 @@
 // a dump) run the same code.
 #include "psgpu_internal.h"
 #include <cstring>
+#include <time.h>
 #include <vector>
 
 struct psgpu_decode_s {
@@ -1187,15 +1188,24 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
 // The host's wait for a batch call's results.  hipStreamSynchronize spins: a host thread waiting 70 ms for the search of 512 x 30 s burns
 // a core doing so (bench.py's host.cpu_ms_per_step_per_rank: 1.7 cores busy per GPU in round 4, the fetch's and torch's own
 // synchronize) -- with eight ranks a node's cores are not scarce, but a waiting thread has no business running.  A call of
-// some size waits on a blocking event instead (the thread sleeps until the interrupt, ~20-50 us late); small calls and the live /
+// some size polls an event between 0.1 ms sleeps instead; small calls and the live /
 // streams steps, where that lateness is a tenth of the step, keep the spin.  PSGPU_SPIN_WAIT=1: always spin.
 static int dec_wait(psgpu_decode_s *d, hipStream_t st)
 {
     static const int spin = [] { const char *e = getenv("PSGPU_SPIN_WAIT"); return e ? atoi(e) : 0; }();
     if (spin || d->live || d->streams || d->total < 100000) { PSGPU_HIP(hipStreamSynchronize(st)); return PSGPU_OK; }
-    if (!d->ev_wait) PSGPU_HIP(hipEventCreateWithFlags(&d->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+    // (hipEventSynchronize on an event created with hipEventBlockingSync was measured spinning all the same in this runtime -- the
+    //  waiting thread at 100 % of a core, profiles/round5_host_cpu.txt: the event is polled between short sleeps instead, at most
+    //  0.1 ms late)
+    if (!d->ev_wait) PSGPU_HIP(hipEventCreateWithFlags(&d->ev_wait, hipEventDisableTiming));
     PSGPU_HIP(hipEventRecord(d->ev_wait, st));
-    PSGPU_HIP(hipEventSynchronize(d->ev_wait));
+    for (;;) {
+        const hipError_t q = hipEventQuery(d->ev_wait);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) PSGPU_HIP(q);
+        const struct timespec ts = { 0, 100000 };
+        nanosleep(&ts, nullptr);
+    }
     return PSGPU_OK;
 }
 
@@ -1211,13 +1221,16 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
         if (rc != PSGPU_OK) return rc;
     }
     // (streams: a full table ends its stream with status 1 -- the rows of frames already searched are gone, the search cannot be repeated)
+    // (the wait comes FIRST: a copy into pageable host memory -- the caller's arrays -- makes the runtime wait for the stream inside
+    //  hipMemcpyAsync, spinning)
+    if (nu) { const int wrc = dec_wait(d, st); if (wrc != PSGPU_OK) return wrc; }
     if (nu && d->auto_grow && d->searched && !d->pass2 && !d->streams) {
         std::vector<int32_t> res(nu * 8);
         PSGPU_HIP(hipMemcpyAsync(res.data(), d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
         // (the usual case -- no table was full -- in one wait: the hypotheses travel with the result records)
         if (hyp_n) PSGPU_HIP(hipMemcpyAsync(hyp_n, d->d_hn, 4 * nu * 4, hipMemcpyDeviceToHost, st));
         if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
-        { const int wrc = dec_wait(d, st); if (wrc != PSGPU_OK) return wrc; }
+        PSGPU_HIP(hipStreamSynchronize(st));             // (the copies alone: the stream's work is over)
         bool again = false;
         for (size_t u = 0; u < nu && !again; ++u) again = res[u * 8 + 3] != 0;
         if (!again) {
@@ -1234,7 +1247,8 @@ int psgpu_decode_fetch_hyps(psgpu_decode_t *d, int32_t *hyp_n, int32_t *hyp, int
         if (hyp) PSGPU_HIP(hipMemcpyAsync(hyp, d->d_hyp, 4 * nu * d->max_words * 4, hipMemcpyDeviceToHost, st));
         if (result) PSGPU_HIP(hipMemcpyAsync(result, d->pass2 ? d->d_res2 : d->d_res, 4 * nu * 8, hipMemcpyDeviceToHost, st));
     }
-    return dec_wait(d, st);
+    PSGPU_HIP(hipStreamSynchronize(st));
+    return PSGPU_OK;
 }
 
 int psgpu_decode_second_pass(psgpu_decode_t *d, psgpu_fwdflat_t *ff, void *stream)
