@@ -655,7 +655,9 @@ int psgpu_fwdtree_use_slab_layout(psgpu_fwdtree_t *m);
  * are kept compact, in list order; 65,536 at create) and the blocks of the pool the words' right-context channels come from (one block
  * per word with a live last phone, ngram_search_alloc_all_rc / ngram_search_free_all_rc, ngram_search.c:583-652; 2,048 at create).  A
  * search that needs more ends the utterance with status 4 / 5 (result word 3); psgpu_fwdtree_grow(m, that status) doubles the capacity
- * for the handle's later calls (up to every node / a block per dictionary word), and the caller repeats the search --
+ * for the handle's later calls (up to every node / a block per dictionary word), and the caller repeats the search.  Status 6: a
+ * frame's candidate / active-word counts outgrew the LDS arrays the word level works in; psgpu_fwdtree_grow(m, 6) moves them to the
+ * slab for good --
  * psgpu_decode_fetch_hyps does both by itself (psgpu_decode_table_capacity's auto_grow).  0, or PSGPU_EINVAL (LDS layout; nothing left
  * to grow; arrays beyond 8 GB per utterance). */
 int psgpu_fwdtree_grow(psgpu_fwdtree_t *m, int32_t status);

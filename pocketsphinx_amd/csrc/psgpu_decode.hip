@@ -1138,7 +1138,7 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
         // status 4 / 5: a frame listed more tree nodes than the slab layouts' compact channels hold / needed more blocks of the
         // right-context channels' pool than there are: the capacity is doubled (psgpu_fwdtree_grow) -- for good -- and the search repeated
         int32_t grow = 0;
-        for (size_t u = 0; u < nu && !grow; ++u) if (res[u * 8 + 3] == 4 || res[u * 8 + 3] == 5) grow = res[u * 8 + 3];
+        for (size_t u = 0; u < nu && !grow; ++u) if (res[u * 8 + 3] >= 4 && res[u * 8 + 3] <= 6) grow = res[u * 8 + 3];
         if (!grow) break;
         int rc;
         if ((rc = psgpu_fwdtree_grow(d->cfg.ft, grow))) return PSGPU_OK;       // (nothing left to grow: the status stays as reported)
@@ -1179,7 +1179,7 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
         PSGPU_HIP(hipStreamSynchronize(st));
     }
     bool more = false;
-    for (size_t u = 0; u < nu && !more; ++u) more = res[u * 8 + 3] == 1 || res[u * 8 + 3] == 4 || res[u * 8 + 3] == 5;
+    for (size_t u = 0; u < nu && !more; ++u) more = res[u * 8 + 3] == 1 || (res[u * 8 + 3] >= 4 && res[u * 8 + 3] <= 6);
     if (!more) break;
     }
     return PSGPU_OK;

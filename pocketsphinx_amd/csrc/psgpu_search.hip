@@ -155,6 +155,8 @@ struct FtDev {
     // slab layouts, capacities that grow on demand (psgpu_fwdtree_grow): tree nodes a frame may list (status 4 when a frame wants
     // more), blocks of the right-context channels' pool (status 5 when a frame needs one and none is free)
     int32_t listed_cap, rc_blocks;
+    int32_t wl_global;                   // slab layouts: the word level's scratch arrays in the slab (a frame's counts outgrew the LDS arrays: status 6)
+    int32_t wl_cap;                      // ... the LDS arrays' capacity in words, if less than what the pool gives (PSGPU_FWDTREE_WL_CAP: a test's knob)
     FtLay lay;
     // always in the utterance's slab (int32 units from its start): last-phone channel records; `fast`: the FtLay arrays
     // when they are not in LDS
@@ -941,9 +943,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     };
     unsigned long long *const ckey = reinterpret_cast<unsigned long long *>(fb + L.ckey);
     // scoring from the scorer's top-N lists (LDS layout only; the host sees to that)
-    constexpr bool lists = LISTS;                        // (a template parameter: the score row is LDS here and device memory otherwise,
+    constexpr bool lists = LISTS && SMALL;               // (a template parameter: the score row is LDS here and device memory otherwise,
                                                          //  and an access whose address space is a run-time matter becomes a flat_* access)
-    static_assert(!LISTS || SMALL, "scoring from lists needs the LDS layout");
+    // slab layouts: the same parameter says where the word level's scratch arrays live -- LDS (the pruning's item arrays, idle during the
+    // word level) or the slab: a compile-time matter for the same reason.  A frame whose counts do not fit the LDS arrays ends the
+    // utterance with status 6; psgpu_fwdtree_grow(m, 6) switches the handle to the slab's arrays for good
+    constexpr bool WLDS = LISTS && !SMALL;
     uint32_t *const l_cw = reinterpret_cast<uint32_t *>(fb + L.l_cw), *const l_sc = reinterpret_cast<uint32_t *>(fb + L.l_sc);
     uint8_t *const l_la = reinterpret_cast<uint8_t *>(fb + L.l_la);
     uint16_t *const l_list = reinterpret_cast<uint16_t *>(fb + L.l_list);
@@ -2014,12 +2019,15 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         //      written by one thread.
         const int n_cand = s_sc[5];
         // slab layouts: the word level's per-candidate / per-active-word scratch arrays in LDS -- in the pruning's item arrays, idle until
-        // the next frame's pruning -- when this frame's counts fit (else the slab's): their prefix sums, the searches in them and the
-        // survivor counts (atomics) are then LDS operations
-        constexpr int kWL = SMALL ? 1 : (9 * kPrIC) / 6;
-        const bool wl_lds = !SMALL && naw + n_cand + n1 + 8 <= kWL;
-        int32_t *const cntf = wl_lds ? s_pool : cnt, *const cnt2f = wl_lds ? s_pool + 4 * kWL : cnt2, *const cnt3f = wl_lds ? s_pool + 5 * kWL : cnt3;
-        const int wstf = wl_lds ? kWL : p.n_w + 1;
+        // the next frame's pruning -- while the frames' counts fit (WLDS; else the slab's, another instantiation): their prefix sums, the
+        // searches in them and the survivor counts (atomics) are then LDS operations
+        // (LDS: [cnt: the candidates' counts, later four arrays over the active words / three over the single-phone words][cnt2][cnt3],
+        //  the last two over the candidates)
+        constexpr bool wl_lds = WLDS;
+        const int wstf = wl_lds ? max(naw, n1) + 2 : p.n_w + 1;
+        const int wl_a = max(n_cand + 1, 4 * wstf);
+        if (WLDS && wl_a + 2 * (n_cand + 1) > min(9 * kPrIC, p.wl_cap)) { if (tid == 0) s_sc[6] = 6; ft_sync<SMALL>(); break; }     // status 6
+        int32_t *const cntf = wl_lds ? s_pool : cnt, *const cnt2f = wl_lds ? s_pool + wl_a : cnt2, *const cnt3f = wl_lds ? s_pool + wl_a + n_cand + 1 : cnt3;
         {
             for (int i = tid; i < n_cand; i += NT) {
                 const int cb = cand_bp[i], w = cand_wid[i];
@@ -2279,7 +2287,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             // (when the single-phone words and the next frame's active words are no more than the work-items -- nearly always -- each
             //  work-item keeps its word's flags and gets its prefix sums in registers, ft_scan_tid: no arrays, one barrier)
             const int naw_n0 = s_red[5];
-            const bool one_each = max(n1, naw_n0) + 1 <= NT;
+            const bool one_each = (SMALL ? max(n1, naw_n0) : n1) + 1 <= NT;       // (slab layouts: no woff -- a block of the pool per active word)
             int my_ex = 0, my_new = 0, my_rc = 0;
             for (int i = tid; i <= n1; i += NT) {
                 int ex = 0, nw = 0, rcn = 0;
@@ -2300,26 +2308,35 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             }
             // the NEXT frame's active words are complete since the positions step (s_red[5] of them in awln): their right-context
             // counts ride in the same scan, so that the next frame starts without a barrier and a scan of its own
-            const int naw_n = naw_n0, n_sc = max(n1, naw_n) + 1;
+            const int naw_n = naw_n0, n_sc = (SMALL ? max(n1, naw_n) : n1) + 1;
             const int32_t bpidx0 = s_sc[3], bss0 = s_sc[4];
             int32_t tot[3];
             if (one_each) {
                 int32_t v[3] = { my_new, my_rc, 0 };
-                if (tid < naw_n) { const int w = awln[tid]; v[2] = wc_off[w + 1] - wc_off[w]; }
+                if (SMALL && tid < naw_n) { const int w = awln[tid]; v[2] = wc_off[w + 1] - wc_off[w]; }
                 ft_scan_tid<NT, 3, SMALL>(v, s_scan, tot);
-                if (tid < n_sc) woff[tid] = v[2];                // (read by the next frame's list building, behind barriers)
+                if (SMALL && tid < n_sc) woff[tid] = v[2];       // (read by the next frame's list building, behind barriers)
                 my_new = v[0]; my_rc = v[1];
             }
             else {
                 for (int i = n1 + 1 + tid; i < n_sc; i += NT) { f_new[i] = 0; f_rc[i] = 0; }
+                if (SMALL)
                 for (int i = tid; i < n_sc; i += NT) {
                     int k = 0;
                     if (i < naw_n) { const int w = awln[i]; k = wc_off[w + 1] - wc_off[w]; }
                     woff[i] = k;
                 }
                 ft_sync<SMALL>();
-                int32_t *const arr[3] = { f_new, f_rc, woff };
-                ft_block_scan_k<NT, 3, SMALL>(arr, n_sc, s_scan, tot);
+                if (SMALL) {
+                    int32_t *const arr[3] = { f_new, f_rc, woff };
+                    ft_block_scan_k<NT, 3, SMALL>(arr, n_sc, s_scan, tot);
+                }
+                else {                                       // (the slab layouts' evaluation lists need no woff: a block per active word)
+                    int32_t *const arr[2] = { f_new, f_rc };
+                    int32_t t2[2];
+                    ft_block_scan_k<NT, 2, SMALL>(arr, n_sc, s_scan, t2);
+                    tot[0] = t2[0]; tot[1] = t2[1]; tot[2] = 0;
+                }
             }
             nwc_cur = tot[2];
             FT_PROF(20);
@@ -2844,6 +2861,9 @@ int psgpu_fwdtree_create(psgpu_fwdtree_t **out, const psgpu_fwdtree_tables_t *t)
         const char *lc = getenv("PSGPU_FWDTREE_LISTED_CAP"), *rb = getenv("PSGPU_FWDTREE_RC_BLOCKS");
         d.listed_cap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, lc ? atoll(lc) : 65536));
         d.rc_blocks = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.n_w, rb ? atoll(rb) : 2048));
+        const char *wc = getenv("PSGPU_FWDTREE_WL_CAP");
+        d.wl_cap = wc ? (int32_t)std::max<int64_t>(0, atoll(wc)) : 0x7fffffff;
+        d.wl_global = 0;
     }
     d.cnt_words = std::max(std::max(2 * (d.R + d.N + 1), 4 * d.n_w + 4), kFtMaxSen / 32 + 4);     // (two arrays over the roots and listed nodes; .. + 4: the senone bitmap's word populations)
     d.node_ci = ft_up(m, t->node_ci, d.N, &rc); d.node_ci2 = ft_up(m, t->node_ci2, d.N, &rc);
@@ -2981,9 +3001,15 @@ int psgpu_fwdtree_use_slab_layout(psgpu_fwdtree_t *m)
 
 int psgpu_fwdtree_grow(psgpu_fwdtree_t *m, int32_t status)
 {
-    PSGPU_REQUIRE(m && (status == 4 || status == 5), "psgpu_fwdtree_grow: status 4 (listed tree nodes) or 5 (right-context channel pool)");
+    PSGPU_REQUIRE(m && (status == 4 || status == 5 || status == 6),
+                  "psgpu_fwdtree_grow: status 4 (listed tree nodes), 5 (right-context channel pool) or 6 (the word level's LDS arrays)");
     FtDev &d = m->d;
-    PSGPU_REQUIRE(!d.small, "psgpu_fwdtree_grow: the LDS layout has neither capacity");
+    PSGPU_REQUIRE(!d.small, "psgpu_fwdtree_grow: the LDS layout has none of these capacities");
+    if (status == 6) {
+        PSGPU_REQUIRE(!d.wl_global, "psgpu_fwdtree_grow: the word level's arrays are in the slab already");
+        d.wl_global = 1; m->live_valid = false;
+        return PSGPU_OK;
+    }
     const int32_t old_l = d.listed_cap, old_r = d.rc_blocks;
     if (status == 4) {
         PSGPU_REQUIRE((int64_t)d.listed_cap < (int64_t)d.N - d.R, "psgpu_fwdtree_grow: the compact channels hold every tree node already");
@@ -3209,13 +3235,17 @@ static int ft_search(psgpu_fwdtree_t *m, const int16_t *senscr_dev, int64_t scr_
     if (d.n_emit == 3) {
         if (d.small && ls) FT_LAUNCH(3, kFtThreads, true, true);
         else if (d.small) FT_LAUNCH(3, kFtThreads, true, false);
+        else if (!big && !d.wl_global) FT_LAUNCH(3, kFtThreads, false, true);
         else if (!big) FT_LAUNCH(3, kFtThreads, false, false);
+        else if (!d.wl_global) FT_LAUNCH(3, kFtThreadsBig, false, true);
         else FT_LAUNCH(3, kFtThreadsBig, false, false);
     }
     else {
         if (d.small && ls) FT_LAUNCH(5, kFtThreads, true, true);
         else if (d.small) FT_LAUNCH(5, kFtThreads, true, false);
+        else if (!big && !d.wl_global) FT_LAUNCH(5, kFtThreads, false, true);
         else if (!big) FT_LAUNCH(5, kFtThreads, false, false);
+        else if (!d.wl_global) FT_LAUNCH(5, kFtThreadsBig, false, true);
         else FT_LAUNCH(5, kFtThreadsBig, false, false);
     }
 #undef FT_LAUNCH

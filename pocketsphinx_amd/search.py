@@ -126,7 +126,7 @@ class FwdtreeSearch:
           # right-context channels' pool than there are -- the capacity is doubled (psgpu_fwdtree_grow) and the search repeated, as
           # psgpu_decode_fetch_hyps does for the pipeline
           st = res[:, 3].cpu().numpy() if n else np.zeros(0, np.int32)
-          need = [int(v) for v in st if int(v) in (4, 5)]
+          need = [int(v) for v in st if int(v) in (4, 5, 6)]
           if not need or cuts is not None:
               break
           capi.check(capi.lib().psgpu_fwdtree_grow(self.h, need[0]), "psgpu_fwdtree_grow")

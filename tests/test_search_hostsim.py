@@ -125,11 +125,12 @@ def test_search_kernel_source_rank_table_in_the_slab(big_trace, cap):  # noqa: F
 
 @pytest.mark.parametrize("case,knob,status,start", [("goforward", "PSGPU_FWDTREE_LISTED_CAP", 4, "16"), ("goforward", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"),
                                                ("man_ah_2934za", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"), ("cmudict", "PSGPU_FWDTREE_RC_BLOCKS", 5, "8"),
-                                               ("cmudict", "PSGPU_FWDTREE_LISTED_CAP", 4, "4096")])
+                                               ("cmudict", "PSGPU_FWDTREE_LISTED_CAP", 4, "4096"), ("goforward", "PSGPU_FWDTREE_WL_CAP", 6, "16"),
+                                               ("cmudict", "PSGPU_FWDTREE_WL_CAP", 6, "64")])
 def test_search_kernel_source_capacities_grow_on_demand(case, knob, status, start, big_trace):  # noqa: F811
     """slab layouts: the compact channels' capacity (tree nodes a frame may list) and the pool of the right-context channels' blocks start
     small and grow on demand -- a frame that needs more ends the utterance with status 4 / 5, psgpu_fwdtree_grow doubles the capacity and the
-    search is repeated (what psgpu_decode_fetch_hyps does by itself): the final tables are the reference's, and the first run did report the
+    search is repeated (status 6: the word level's scratch arrays leave LDS for the slab) (what psgpu_decode_fetch_hyps does by itself): the final tables are the reference's, and the first run did report the
     status (the knobs make the capacities that small)."""
     if case == "cmudict":
         g = big_trace; st = g; lm = simlib.SimLm(g)
@@ -144,7 +145,7 @@ def test_search_kernel_source_capacities_grow_on_demand(case, knob, status, star
     for _ in range(20):
         r = s.search(rows, pen, [rows.shape[0]])[0]
         seen.append(r["status"])
-        if r["status"] not in (4, 5):
+        if r["status"] not in (4, 5, 6):
             break
         simlib.check(simlib.lib().psgpu_fwdtree_grow(s.h, r["status"]), "psgpu_fwdtree_grow")
     assert seen[0] == status and seen[-1] == 0 and set(seen[:-1]) == {status}, seen
