@@ -2021,13 +2021,13 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         // slab layouts: the word level's per-candidate / per-active-word scratch arrays in LDS -- in the pruning's item arrays, idle until
         // the next frame's pruning -- while the frames' counts fit (WLDS; else the slab's, another instantiation): their prefix sums, the
         // searches in them and the survivor counts (atomics) are then LDS operations
-        // (LDS: [cnt: the candidates' counts, later four arrays over the active words / three over the single-phone words][cnt2][cnt3],
-        //  the last two over the candidates)
+        // (LDS: `cnt` -- the candidates' counts and their prefix sums, later four arrays over the active words / three over the
+        //  single-phone words: the arrays that are searched and counted into; the two plain per-candidate arrays stay in the slab)
         constexpr bool wl_lds = WLDS;
         const int wstf = wl_lds ? max(naw, n1) + 2 : p.n_w + 1;
         const int wl_a = max(n_cand + 1, 4 * wstf);
-        if (WLDS && wl_a + 2 * (n_cand + 1) > min(9 * kPrIC, p.wl_cap)) { if (tid == 0) s_sc[6] = 6; ft_sync<SMALL>(); break; }     // status 6
-        int32_t *const cntf = wl_lds ? s_pool : cnt, *const cnt2f = wl_lds ? s_pool + wl_a : cnt2, *const cnt3f = wl_lds ? s_pool + wl_a + n_cand + 1 : cnt3;
+        if (WLDS && wl_a > min(9 * kPrIC, p.wl_cap)) { if (tid == 0) s_sc[6] = 6; ft_sync<SMALL>(); break; }     // status 6
+        int32_t *const cntf = wl_lds ? s_pool : cnt, *const cnt2f = cnt2, *const cnt3f = cnt3;
         {
             for (int i = tid; i < n_cand; i += NT) {
                 const int cb = cand_bp[i], w = cand_wid[i];
