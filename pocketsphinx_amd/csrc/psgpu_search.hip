@@ -1000,8 +1000,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     //      senones: the evaluation and the pruning of a listed node ask the static tables nothing), its evaluation fetches the scores
     //      and histories from the old place (old places rise with the new ones: the requests of neighbouring work-items fall into
     //      the same lines), evaluates and writes.  Per buffer: ND quads {score[0..NE), history[0..NE), out score, out history}, then
-    //      {node, parent | ci << 24, first entry's index, children | penultimate-phone words << 16} and {senones and transition
-    //      matrix, 16 bits each, ..., first entry}.  What a frame costs in device memory is then mostly streams; the random accesses
+    //      {first entry, parent | ci << 24, first entry's index, children | penultimate-phone words << 16} (the pruning's side) and
+    //      {senones and transition matrix, 16 bits each, ...} (the evaluation's; the node itself is the list's entry).  What a frame costs in device memory is then mostly streams; the random accesses
     //      left are a decision's look at its OTHER node (by rank -> position, see s_lb) and the static rows of the nodes that ENTER
     //      the list.
     constexpr int ND = NE == 3 ? 2 : 3;
@@ -1506,7 +1506,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         const bool old_ = src >= 0 && kind != 4;
                         // the static side: from the old place, or (a new channel) from the static tables
                         if (src >= 0) { s0[u] = cbuf(nxt, ND)[src]; sq[u] = cbuf(nxt, ND + 1)[src]; }
-                        else { const FtQuad e0 = node_q1[nd_[u]]; sq[u] = node_st1[nd_[u]]; s0[u] = FtQuad{ nd_[u], e0.x, e0.y, e0.z }; }
+                        else { const FtQuad e0 = node_q1[nd_[u]]; sq[u] = node_st1[nd_[u]]; s0[u] = FtQuad{ e0.w, e0.x, e0.y, e0.z }; }
                         pl[u] = FtPair{ 0, 0 };
                         if (kind != 0) pl[u] = xp[min(j0 + u * NT, na - 1)];
 #pragma unroll
@@ -1666,7 +1666,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const int n_item = R + na;
             constexpr int KP = kFtPairs;
             int carry_l = 0, carry_c = 0;                        // next list's entries / candidates so far (uniform)
-            const FtQuad *const cs0 = cbuf(cur, ND), *const cs1 = cbuf(cur, ND + 1);
+            const FtQuad *const cs0 = cbuf(cur, ND);
             int32_t *const xfer = cxf + (size_t)nxt * ccap;    // the next list's
             FtPair *const xfpl = cxp + (size_t)nxt * ccap;
             bool over = false;                                   // the next list outgrows the compact buffers (uniform)
@@ -1683,9 +1683,9 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         node[u] = -1; it[u] = FtQuad{ kW, -1, kW, 0 }; q1[u] = FtQuad{ 0, 0, 0, -1 };
                         if (i < R) { node[u] = i; it[u] = itb[i]; q1[u] = node_q1[i]; }
                         else if (i < n_item) {
-                            const FtQuad a = cs0[i - R];         // node, parent | ci << 24, first entry's index, children | words << 16
+                            const FtQuad a = cs0[i - R];         // first entry, parent | ci << 24, first entry's index, children | words << 16
                             it[u] = csum[i - R];
-                            node[u] = a.x; q1[u] = FtQuad{ a.y, a.z, a.w, cs1[i - R].w };
+                            node[u] = aclc[i - R]; q1[u] = FtQuad{ a.y, a.z, a.w, a.x };
                         }
                     }
 #pragma unroll
