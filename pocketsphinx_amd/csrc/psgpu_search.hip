@@ -1012,6 +1012,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     FtPair *const cxp = reinterpret_cast<FtPair *>(fb + (SMALL ? 0 : L.cxpl));
     int32_t *const g_perm = fb + (SMALL ? 0 : L.cperm);
     auto cbuf = [&](int b, int k) { return cq + (size_t)(b * (ND + 2) + k) * ccap; };      // array k of buffer b
+    // (the evaluation's static side -- senones and transition matrix -- is 8 bytes a channel for 3-state models: its array holds pairs)
+    using FtSen = typename std::conditional<NE == 3, FtPair, FtQuad>::type;
+    auto csen = [&](int b) { return reinterpret_cast<FtSen *>(cq + (size_t)(b * (ND + 2) + ND + 1) * ccap); };
+    auto sen_of = [&](const FtQuad &q) { FtSen r; r.x = q.x; r.y = q.y; if constexpr (NE != 3) { r.z = q.z; r.w = q.w; } return r; };
+    auto sen_z = [&](const FtSen &q) { if constexpr (NE != 3) return q.z; else return 0; };
     const FtQuad *const node_st1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_st1));
     bool perm_lds = true;                                              // the current list's rank -> position table is the LDS one (uniform)
     const FtDict dict = { psgpu_as_global(p.d_pronlen), d_last, d_last2, d_base, d_filler, rs_n, n_ci };
@@ -1337,11 +1342,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     else if (i < R + na && raw_mode) {
                         // the channel's senones: at its old place's static side, or (a new channel) in the static tables
                         const int src = (cxf[(size_t)cur * ccap + (i - R)] & 0x0fffffff) - 1;
-                        FtQuad a = FtQuad{ 0, 0, 0, 0 };
-                        if (raw_mode) a = src >= 0 ? cbuf(nxt, ND + 1)[src] : node_st1[aclc[i - R]];
+                        FtSen a = sen_of(FtQuad{ 0, 0, 0, 0 });
+                        if (raw_mode) { if (src >= 0) a = csen(nxt)[src]; else a = sen_of(node_st1[aclc[i - R]]); }
                         if (raw_mode) {                                  // the channel carries its senones, 16 bits each
                             mark_sen(a.x & 0xffff); mark_sen((int)((uint32_t)a.x >> 16)); mark_sen(a.y & 0xffff);
-                            if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(a.z & 0xffff); }
+                            if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(sen_z(a) & 0xffff); }
                         }
                     }
                     if (i0 < R) n_act_root += __popcll(__ballot(act_root));
@@ -1497,7 +1502,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const int32_t *const xf = cxf + (size_t)cur * ccap;
                 const FtPair *const xp = cxp + (size_t)cur * ccap;
                 for (int j0 = tid; j0 < na; j0 += 2 * NT) {
-                    int32_t w[2][4 * ND]; FtQuad sq[2], s0[2]; int32_t x[2], nd_[2]; FtPair pl[2];
+                    int32_t w[2][4 * ND]; FtSen sq[2]; FtQuad s0[2]; int32_t x[2], nd_[2]; FtPair pl[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) { const int j = min(j0 + u * NT, na - 1); x[u] = xf[j]; nd_[u] = aclc[j]; }
 #pragma unroll
@@ -1505,8 +1510,8 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         const int src = (x[u] & 0x0fffffff) - 1, kind = (int)((uint32_t)x[u] >> 28);
                         const bool old_ = src >= 0 && kind != 4;
                         // the static side: from the old place, or (a new channel) from the static tables
-                        if (src >= 0) { s0[u] = cbuf(nxt, ND)[src]; sq[u] = cbuf(nxt, ND + 1)[src]; }
-                        else { const FtQuad e0 = node_q1[nd_[u]]; sq[u] = node_st1[nd_[u]]; s0[u] = FtQuad{ e0.w, e0.x, e0.y, e0.z }; }
+                        if (src >= 0) { s0[u] = cbuf(nxt, ND)[src]; sq[u] = csen(nxt)[src]; }
+                        else { const FtQuad e0 = node_q1[nd_[u]]; sq[u] = sen_of(node_st1[nd_[u]]); s0[u] = FtQuad{ e0.w, e0.x, e0.y, e0.z }; }
                         pl[u] = FtPair{ 0, 0 };
                         if (kind != 0) pl[u] = xp[min(j0 + u * NT, na - 1)];
 #pragma unroll
@@ -1535,7 +1540,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     for (int k = 0; k < 5; ++k) { h.score[k] = k < NE ? w[u][k] : kW; h.history[k] = k < NE ? w[u][NE + k] : -1; h.senid[k] = 0; }
                     h.senid[0] = (uint16_t)(sq[u].x & 0xffff); h.senid[1] = (uint16_t)((uint32_t)sq[u].x >> 16); h.senid[2] = (uint16_t)(sq[u].y & 0xffff);
                     int tm = (int)((uint32_t)sq[u].y >> 16);
-                    if (NE == 5) { h.senid[3] = (uint16_t)((uint32_t)sq[u].y >> 16); h.senid[4] = (uint16_t)(sq[u].z & 0xffff); tm = (int)((uint32_t)sq[u].z >> 16); }
+                    if (NE == 5) { h.senid[3] = (uint16_t)((uint32_t)sq[u].y >> 16); h.senid[4] = (uint16_t)(sen_z(sq[u]) & 0xffff); tm = (int)((uint32_t)sen_z(sq[u]) >> 16); }
                     h.out_score = w[u][2 * NE]; h.out_history = w[u][2 * NE + 1]; h.bestscore = kW;
                     uint8_t tpb[NE * (NE + 1)];
                     const uint8_t *tp = ft_tp_row<NE>(tpall, tm, tpb);
@@ -1545,7 +1550,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     w[u][2 * NE] = h.out_score; w[u][2 * NE + 1] = h.out_history;
 #pragma unroll
                     for (int k = 0; k < ND; ++k) cbuf(cur, k)[j] = FtQuad{ w[u][4 * k], w[u][4 * k + 1], w[u][4 * k + 2], w[u][4 * k + 3] };
-                    cbuf(cur, ND)[j] = s0[u]; cbuf(cur, ND + 1)[j] = sq[u];
+                    cbuf(cur, ND)[j] = s0[u]; csen(cur)[j] = sq[u];
                     csum[j] = FtQuad{ h.out_score, h.out_history, h.bestscore, h.score[0] };
                     b_all = max(b_all, sc);
                     }
