@@ -76,6 +76,7 @@ constexpr int kFtSlabSen = 16384;      // slab layouts: senones whose frame row 
 constexpr int kFtSlabTp = 4096;        // slab layouts: bytes of transition matrices kept in LDS (likewise)
 constexpr int kFtSlabPoolWords = 39808;    // slab layouts: words of dynamic LDS a workgroup may ask for (155.5 of a compute unit's 160 KB; ~3.5 KB are static)
 constexpr int kFtRcBlk = 64;           // slab layouts: right-context channels in a block of the pool (a word's fan-out: at most n_ci <= 64 of them)
+constexpr int kFtMaxRootWords = 128;   // slab layouts: roots <= 32 x this (n_ci <= 64: at most 4,096 (first, second phone) pairs)
 constexpr int kFtLbBlock = 1024;       // slab layouts: words of the listed-nodes bitmap per block of 16-bit prefix populations (32,768 nodes: a count fits)
 constexpr int kFtLiveMagic = 0x5ea4c4ed;
 constexpr int kFtLiveHdr = 32;         // FtBufs::live: words ahead of the pool's copy
@@ -883,6 +884,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     uint16_t *const s_perm = reinterpret_cast<uint16_t *>(s_pool + (SMALL ? 0 : p.lds_perm));
     __shared__ int32_t s_sup[kFtMaxBitWords / kFtLbBlock];       // listed nodes before each block of kFtLbBlock bitmap words (s_pre counts from the block's start)
     __shared__ int32_t s_nroot;          // slab layouts: roots evaluated in the frame
+    // slab layouts: which roots are entered for this frame / already stamped for the next (two bitmaps taking turns): the frame's
+    // passes over the roots ask these instead of every root's record (a 64-byte line each, several times a frame)
+    __shared__ uint32_t s_rb[2][SMALL ? 1 : kFtMaxRootWords];
+    auto rb_get = [&](int which, int i) { return (s_rb[which][i >> 5] >> (i & 31)) & 1u; };
+    auto rb_set = [&](int which, int i) { atomicOr(&s_rb[which][i >> 5], 1u << (i & 31)); };
     __shared__ int32_t s_penb[SMALL ? 1 : kFtMaxCi];     // slab layouts: the frame's phone-loop penalties
     // slab layouts: the frame's score row and the transition matrices in LDS too (the pool) -- a channel's evaluation then asks device
     // memory for its record only (the eight transition bytes and three senone scores of a 3-state HMM were eleven requests of their own)
@@ -1100,7 +1106,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     {
         const int nwords = (p.n_sen + 31) >> 5;
         for (int i = tid; i < nwords; i += NT) s_bits[i] = 0u;
-        if (!SMALL) { for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u; }
+        if (!SMALL) {
+            for (int i = tid; i < p.lb_words; i += NT) s_lb[i] = 0u;
+            for (int i = tid; i < 2 * kFtMaxRootWords; i += NT) s_rb[i / kFtMaxRootWords][i % kFtMaxRootWords] = 0u;
+        }
     }
     // slab layouts: the index of an active list -- bitmap of its nodes, the populations of the bitmap words before each word, rank ->
     // position -- from the list itself (node ids in list order).  Called by every work-item with the bitmap all zero; ends without a
@@ -1163,6 +1172,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         __syncthreads();
         if (!SMALL) {                                    // (the compact channels are in the slab, where the last frame left them; their index is LDS)
             build_index(fb + ((f0 & 1) ? L.acl1 : L.acl0), n_acl_cur);
+            for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f0) rb_set(f0 & 1, i);
             __syncthreads();
         }
     }
@@ -1336,7 +1346,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     const int i = i0 + tid;
                     bool act_root = false;
                     if (i < R) {
-                        act_root = tv.at(i, F::FRAME) == f;
+                        act_root = rb_get(cur, i) != 0u;
                         if (act_root && raw_mode) mark(tv, i);
                     }
                     else if (i < R + na && raw_mode) {
@@ -1402,7 +1412,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 if (c & kFtWordCh) ch_normalize<NE>(wv, word_slot(c), best_in); else ch_normalize<NE>(tv, c, best_in);
             }
             if (!SMALL) {
-                for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_normalize<NE>(tv, i, best_in);
+                for (int i = tid; i < R; i += NT) if (rb_get(cur, i)) ch_normalize<NE>(tv, i, best_in);
                 // (the listed nodes' channels are made by this frame's evaluation: it normalises them as it does)
             }
             __syncthreads();
@@ -1486,7 +1496,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int i = tid; i < R; i += NT) {
                     int32_t *const rec = tv.b + (size_t)i * TREC;
                     FtQuad it = FtQuad{ kW, -1, kW, 0 };
-                    if (rec[F::FRAME] == f) {
+                    if (rb_get(cur, i)) {
                         const int32_t sc = ch_eval_tree<NE>(rec, sr, tpall, sseq, false, 0, it);
                         b_all = max(b_all, sc);
                         it.w = 1;
@@ -1703,7 +1713,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         np[u] = node[u] >= 0 ? (i >= R ? 1 : 0) + nk + (cand ? nw : 0) : 0;
                         s_it_node[li] = node[u]; s_it_out[li] = it[u].x; s_it_outh[li] = it[u].y; s_it_fp[li] = (fl ? 1 : 0) | (nk << 1);
                         s_it_k0[li] = q1[u].y; s_it_par[li] = q1[u].x; s_it_sc0[li] = it[u].w; s_it_kid0[li] = q1[u].w;
-                        if (i < R && fl) tv.at(node[u], F::FRAME) = nf;     // a retained root stays (no decision reads this stamp before it is >= f)
+                        if (i < R && fl) { tv.at(node[u], F::FRAME) = nf; rb_set(nxt, i); }     // a retained root stays (no decision reads this stamp before it is >= f)
                     }
                 }
                 FT_PROF(28);
@@ -2479,7 +2489,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 for (int i = t0r; i < R; i += str) {         // tree roots (:1306-1325)
                     const int ci = node_ci[i];
                     const int32_t ns = brc_score[ci] + p.nwpen + p.pip;
-                    if (ns + ft_pen(ci) > thresh && (tv.at(i, F::FRAME) < f || ns > tv.at(i, F::SCORE))) {
+                    // (slab layouts: a root that is neither entered for this frame nor stamped for the next has a frame below f)
+                    if (ns + ft_pen(ci) > thresh
+                        && (SMALL ? (tv.at(i, F::FRAME) < f || ns > tv.at(i, F::SCORE)) : ((!rb_get(cur, i) && !rb_get(nxt, i)) || ns > tv.at(i, F::SCORE)))) {
+                        if (!SMALL) rb_set(nxt, i);
                         ch_enter<NE>(tv, i, ns, brc_path[ci], nf);
                         tv.at(i, F::SENID) = ldiph[((size_t)ci * n_ci + node_ci2[i]) * n_ci + brc_lc[ci]];
                     }
@@ -2518,7 +2531,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         ft_sync<SMALL>();
         FT_PROF(26);
         // ---- deactivate_channels (:1429-1450)
-        for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_clear<NE>(tv, i);
+        if (SMALL) { for (int i = tid; i < R; i += NT) if (tv.at(i, F::FRAME) == f) ch_clear<NE>(tv, i); }
+        else {
+            for (int i = tid; i < R; i += NT) if (rb_get(cur, i) && !rb_get(nxt, i)) ch_clear<NE>(tv, i);
+            __syncthreads();
+            for (int i = tid; i < kFtMaxRootWords; i += NT) s_rb[cur][i] = 0u;     // (the frame after next's "stamped" bits)
+        }
         for (int i = tid; i < n1; i += NT) if (tv.at(W1 + i, F::FRAME) == f) ch_clear<NE>(tv, W1 + i);
         if (tid == 0) {
             step[f * 4] = s_sc[0]; step[f * 4 + 1] = s_sc[1]; step[f * 4 + 2] = s_sc[3]; step[f * 4 + 3] = n_listed;
@@ -2731,7 +2749,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.ccap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, d.listed_cap));
         L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cxfer = take(2 * (int64_t)L.ccap); L.cxpl = take(2 * 2 * (int64_t)L.ccap);
         L.cperm = take(L.ccap);
-        if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords) return false;     // (the listed-nodes bitmap lives in LDS)
+        if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords || d.R > 32 * kFtMaxRootWords) return false;     // (the listed-nodes bitmap and the roots' live in LDS)
         d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.n1 + (int64_t)d.rc_blocks * kFtRcBlk + 64, 0x7ffffff0);      // (the word level's: single-phone words, pool channels)
         L.evl = take(L.evl_cap);
