@@ -884,6 +884,8 @@ def main():
     legs = {}
     for name in ("decode_large_vocab", "decode_two_pass", "decode_ms_scorer", "decode_ms_continuous"):
         lg = line.get(name)
+        if isinstance(lg, dict) and "value" not in lg and "frames_per_s" in lg:      # (the legs that predate the line's field names)
+            lg = dict(lg, value=lg["frames_per_s"], unit="frames/s", config={"workload": lg.get("what")})
         if not isinstance(lg, dict) or "value" not in lg:
             if isinstance(lg, dict) and ("error" in lg or "skipped" in lg):
                 legs[name] = {k: lg[k] for k in ("error", "skipped") if k in lg}
