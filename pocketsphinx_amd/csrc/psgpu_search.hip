@@ -2704,7 +2704,7 @@ static bool ft_layout(FtDev &d, bool small)
         L.node_blk = take(((int64_t)d.N + 1) * kFtNodeCols); L.word_blk = take(((int64_t)d.n_w + 2) * kFtWordCols);
     }
     else {
-        L.acl0 = take(d.N); L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
+        o = (o + 31) & ~(int64_t)31; L.acl0 = take(d.N); o = (o + 31) & ~(int64_t)31; L.acl1 = take(d.N); L.awl0 = take(d.n_w); L.awl1 = take(d.n_w);
         L.word_active = take(d.n_w); L.word_lat_idx = take(d.n_w); L.lt_sf = take(d.n_w); L.lt_dscr = take(d.n_w); L.lt_bp = take(d.n_w);
         L.cand_mark = take(d.n_w);
         L.cand_wid = take(d.n_w + 1); L.cand_score = take(d.n_w + 1); L.cand_bp = take(d.n_w + 1);
@@ -2747,8 +2747,12 @@ static bool ft_layout(FtDev &d, bool small)
         L.itb = take(4 * (int64_t)d.R);
         const int nd = ne == 3 ? 2 : 3;
         L.ccap = (int32_t)std::max<int64_t>(1, std::min<int64_t>((int64_t)d.N - d.R, d.listed_cap));
-        L.cq = take(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take(4 * (int64_t)L.ccap); L.cxfer = take(2 * (int64_t)L.ccap); L.cxpl = take(2 * 2 * (int64_t)L.ccap);
-        L.cperm = take(L.ccap);
+        // (the streamed arrays start on 128-byte lines -- a wavefront's 1 KB request then touches eight of them, not nine -- and so does each
+        //  of the arrays inside: the capacity is a multiple of 32 places)
+        L.ccap = (L.ccap + 31) & ~31;
+        auto take_line = [&](int64_t n) { o = (o + 31) & ~(int64_t)31; return take(n); };
+        L.cq = take_line(2 * (int64_t)(nd + 2) * L.ccap * 4); L.csum = take_line(4 * (int64_t)L.ccap); L.cxfer = take_line(2 * (int64_t)L.ccap);
+        L.cxpl = take_line(2 * 2 * (int64_t)L.ccap); L.cperm = take_line(L.ccap);
         if (((int64_t)d.N + 31) / 32 > kFtMaxBitWords || d.R > 32 * kFtMaxRootWords) return false;     // (the listed-nodes bitmap and the roots' live in LDS)
         d.lb_words = (int32_t)(((int64_t)d.N + 31) / 32);
         L.evl_cap = (int32_t)std::min<int64_t>((int64_t)d.n1 + (int64_t)d.rc_blocks * kFtRcBlk + 64, 0x7ffffff0);      // (the word level's: single-phone words, pool channels)
