@@ -56,6 +56,10 @@ constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS 
 #ifndef PSGPU_FT_IPT
 #define PSGPU_FT_IPT 2
 #endif
+#ifndef PSGPU_FT_EVAL_UNROLL
+#define PSGPU_FT_EVAL_UNROLL 2
+#endif
+constexpr int kFtEvalUnroll = PSGPU_FT_EVAL_UNROLL;    // slab layouts: positions of the active list a work-item evaluates at a time (their loads asked for together)
 constexpr int kFtIpt = PSGPU_FT_IPT;           // slab layouts: consecutive items (roots / listed nodes) of a pruning chunk a work-item takes to LDS
 #ifndef PSGPU_FT_POOL_WORDS_BIG
 #define PSGPU_FT_POOL_WORDS_BIG 39808
@@ -1511,12 +1515,12 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                 const bool renorm = best_in + 2 * p.beam < kW;
                 const int32_t *const xf = cxf + (size_t)cur * ccap;
                 const FtPair *const xp = cxp + (size_t)cur * ccap;
-                for (int j0 = tid; j0 < na; j0 += 2 * NT) {
-                    int32_t w[2][4 * ND]; FtSen sq[2]; FtQuad s0[2]; int32_t x[2], nd_[2]; FtPair pl[2];
+                for (int j0 = tid; j0 < na; j0 += kFtEvalUnroll * NT) {
+                    int32_t w[kFtEvalUnroll][4 * ND]; FtSen sq[kFtEvalUnroll]; FtQuad s0[kFtEvalUnroll]; int32_t x[kFtEvalUnroll], nd_[kFtEvalUnroll]; FtPair pl[kFtEvalUnroll];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) { const int j = min(j0 + u * NT, na - 1); x[u] = xf[j]; nd_[u] = aclc[j]; }
+                    for (int u = 0; u < kFtEvalUnroll; ++u) { const int j = min(j0 + u * NT, na - 1); x[u] = xf[j]; nd_[u] = aclc[j]; }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < kFtEvalUnroll; ++u) {
                         const int src = (x[u] & 0x0fffffff) - 1, kind = (int)((uint32_t)x[u] >> 28);
                         const bool old_ = src >= 0 && kind != 4;
                         // the static side: from the old place, or (a new channel) from the static tables
@@ -1542,7 +1546,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < kFtEvalUnroll; ++u) {
                     const int j = j0 + u * NT;
                     if (j >= na) continue;
                     HmmRegs h;
