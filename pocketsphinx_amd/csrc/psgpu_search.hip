@@ -1119,12 +1119,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     // position -- from the list itself (node ids in list order).  Called by every work-item with the bitmap all zero; ends without a
     // barrier (the table's first readers are a frame's pruning pairs, behind many)
     auto build_index = [&](const int32_t *list, int n) {
-        // (the list is read ONCE when it is no longer than kKeep entries a work-item: their nodes wait in registers for the ranks)
-        constexpr int kKeep = 12;
-        int32_t mine[kKeep];
-#pragma unroll
-        for (int k = 0; k < kKeep; ++k) { const int o = tid + k * NT; mine[k] = o < n ? list[o] : -1; if (mine[k] >= 0) atomicOr(&s_lb[mine[k] >> 5], 1u << (mine[k] & 31)); }
-        for (int o = tid + kKeep * NT; o < n; o += NT) { const int c = list[o]; atomicOr(&s_lb[c >> 5], 1u << (c & 31)); }
+        for (int o = tid; o < n; o += NT) { const int c = list[o]; atomicOr(&s_lb[c >> 5], 1u << (c & 31)); }
         __syncthreads();
         // K consecutive words a work-item, K a power of two: a work-item's words lie in one block of kFtLbBlock
         const int nwl = p.lb_words;
@@ -1142,14 +1137,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
         }
         __syncthreads();
         perm_lds = n <= p.lds_perm_cap;                  // (a frame that lists more than the LDS table holds keeps the table in the slab)
-#pragma unroll
-        for (int k = 0; k < kKeep; ++k) {
-            const int c = mine[k], o = tid + k * NT;
-            if (c < 0) continue;
-            const int r = s_sup[c >> 15] + (int)s_pre[c >> 5] + __popc(s_lb[c >> 5] & ((1u << (c & 31)) - 1u));
-            if (perm_lds) s_perm[r] = (uint16_t)o; else g_perm[r] = o;
-        }
-        for (int o = tid + kKeep * NT; o < n; o += NT) {
+        for (int o = tid; o < n; o += NT) {
             const int c = list[o];
             const int r = s_sup[c >> 15] + (int)s_pre[c >> 5] + __popc(s_lb[c >> 5] & ((1u << (c & 31)) - 1u));
             if (perm_lds) s_perm[r] = (uint16_t)o; else g_perm[r] = o;
