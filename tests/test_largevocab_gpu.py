@@ -166,10 +166,11 @@ def test_pipeline_equals_the_reference_on_32_of_the_benchmarks_utterances(tables
     p.close()
 
 
-@pytest.mark.parametrize("knob,value,status", [("PSGPU_FWDTREE_LISTED_CAP", "64", 4), ("PSGPU_FWDTREE_RC_BLOCKS", "4", 5)])
+@pytest.mark.parametrize("knob,value,status", [("PSGPU_FWDTREE_LISTED_CAP", "64", 4), ("PSGPU_FWDTREE_RC_BLOCKS", "4", 5), ("PSGPU_FWDTREE_WL_CAP", "16", 6)])
 def test_slab_layout_capacities_are_reported_and_grown(tables, tmp_path, monkeypatch, knob, value, status):
     """status 4 / 5 (slab layouts): the compact channels hold the tree nodes ONE frame lists, the right-context channels come from a pool of
-    blocks; both start small and grow on demand.  With the capacity cut down (the knob is read when the search is created) and growth off
+    blocks; both start small and grow on demand; the word level's searched array lives in LDS until a frame outgrows it (status 6: the
+    slab from then on).  With the capacity cut down (the knob is read when the search is created) and growth off
     the utterances end early with that status; with growth on fetch() doubles the capacity (psgpu_fwdtree_grow) until the search gets
     through, and the result is the reference's -- and the capacity stays: the next call does not repeat."""
     import pocketsphinx_amd as P
