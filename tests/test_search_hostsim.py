@@ -124,7 +124,7 @@ def test_search_kernel_source_rank_table_in_the_slab(big_trace, cap):  # noqa: F
 
 
 @pytest.mark.parametrize("case,knob,status,start", [("goforward", "PSGPU_FWDTREE_LISTED_CAP", 4, "16"), ("goforward", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"),
-                                               ("man_ah_2934za", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"), ("cmudict", "PSGPU_FWDTREE_RC_BLOCKS", 5, "8"),
+                                               ("man_ah_2934za", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"), ("cmudict", "PSGPU_FWDTREE_RC_BLOCKS", 5, "64"),
                                                ("cmudict", "PSGPU_FWDTREE_LISTED_CAP", 4, "4096"), ("goforward", "PSGPU_FWDTREE_WL_CAP", 6, "16"),
                                                ("cmudict", "PSGPU_FWDTREE_WL_CAP", 6, "64")])
 def test_search_kernel_source_capacities_grow_on_demand(case, knob, status, start, big_trace):  # noqa: F811
