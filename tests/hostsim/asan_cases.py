@@ -16,7 +16,8 @@ def caps(g):
     return dict(bp_cap=int(g["bp"].shape[0]) + 64, bss_cap=int(g["bscore_stack"].shape[0]) + 128)
 
 
-for case, mode in [("goforward", "slab"), ("goforward", "lds"), ("goforward_maxhmmpf60_maxwpf3", "lds"), ("man_ah_2934za", "lds"), ("medium_numbers_maxwpf8", "lds")]:
+for case, mode in [("goforward", "slab"), ("goforward", "lds"), ("goforward_maxhmmpf60_maxwpf3", "lds"), ("man_ah_2934za", "lds"), ("medium_numbers_maxwpf8", "lds"),
+                   ("goforward_maxhmmpf60_maxwpf3", "slab"), ("man_ah_2934za", "slab"), ("medium_numbers_maxwpf8", "slab")]:
     g = _load("fwdtree_trace_%s.npz" % case)
     st = _load("fwdtree_static_%s.npz" % bytes(g["static"]).decode())
     os.environ["PSGPU_FWDTREE_LAYOUT"] = mode
