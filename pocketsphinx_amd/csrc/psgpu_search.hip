@@ -24,8 +24,9 @@
 // (structure of arrays: consecutive channels in consecutive banks), the pruning snapshot, the active lists, the per-word
 // tables, the children lists of the tree (CSR), the frame's score row (copied in one frame ahead) -- and only the
 // right-context fan-out of the words' last phones, the back-pointer table and the language model stay in global memory.
-// Larger trees keep the same arrays in a per-utterance slab in global memory (same source lines, other base pointers)
-// and run 1024 work-items per utterance.
+// Larger trees ("slab layouts") keep the word level's arrays in a per-utterance slab in global memory (same source lines, other
+// base pointers), the tree level's state as compact channels in list order behind an index in LDS (round 5), and run 1024
+// work-items per utterance.
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
 #include "psgpu_sen_dev.h"
@@ -255,16 +256,13 @@ enum { NC_ACL0, NC_ACL1, NC_POS, NC_OOUT, NC_OOUTH, NC_FLAG, NC_OFRAME, NC_KIDOF
 enum { WC_AWL0, WC_AWL1, WC_ACTIVE, WC_LATIDX, WC_LTSF, WC_LTDSCR, WC_LTBP, WC_CMARK, WC_CWID, WC_CSCORE, WC_CBP, WC_WCOFF, WC_DFIRST, WC_DBASE,
        WC_DLAST, WC_HOMO, WC_DFILL, kFtWordCols };
 static_assert(kFtNodeCols % 2 == 1 && kFtWordCols % 2 == 1, "odd strides");
-// Slab layouts (tree state in device memory).  What a work-group pays there is the number of cache lines it touches per
-// frame, so a tree channel is ONE 64-byte record and everything else the pruning needs is either static and shared by all
-// utterances (FtDev::node_q1 / node_q2 / node_sen: the node's parent, phone, children, penultimate word, senones) or
-// written by the evaluation while it holds the record anyway:
-//   * the record's FRAME word of a non-root tree node holds its position + 1 in the CURRENT active list (the evaluation
-//     writes it; the pruning's clear resets it; <= 0: not listed) -- nobody reads a tree node's frame stamp in these layouts;
-//   * FtLay::itb holds, per root / list position, {out, out history, best, score[0]} as the evaluation left them: the
-//     pruning's item phase reads them in order (coalesced) instead of visiting every node's record again.
-// A decision reads the live record of the other node (child or parent); that is sound because the channel updates a frame's
-// decisions ask for are collected (FtLay::act) and applied after ALL of them have been taken.
+// Slab layouts (tree state in device memory).  What a workgroup pays there is the bytes and cache lines it touches per frame
+// (at 256 utterances of the 134,865-word task the kernel is bound by the memory system): the roots and the single-phone words
+// keep 64-byte records (ChF); every other tree node's channel exists while the node is listed, COMPACT, at the node's position
+// in the frame's active list (see "compact channels" in the kernel), and the right-context channels come from a pool of blocks.
+// What the pruning needs about a node is either carried by its compact channel or static and shared by all utterances
+// (FtDev::node_q1 / node_st1 / kids_ci), and FtLay::itb holds, per root, {out, out history, best, evaluated} as the evaluation
+// left them.  A decision only reads; its outcome is written for the place it gives in the next list (FtLay::cxfer).
 struct ChView {
     int32_t *b;
     int cst, fst;
@@ -998,7 +996,6 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
     const int32_t *const kids_ci = psgpu_as_global(p.kids_ci);
     const FtQuad *const node_q1 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q1)),
                  *const node_q2 = reinterpret_cast<const FtQuad *>(psgpu_as_global(p.node_q2));
-    const int32_t *const node_sen = psgpu_as_global(p.node_sen);
     const int32_t *const slot_sen = psgpu_as_global(p.slot_sen);
     FtQuad *const itb = reinterpret_cast<FtQuad *>(fb + L.itb);        // slab layouts only: [R]
     // ---- compact channels (slab layouts).  A tree node's channel exists while the node is listed: its record lives at the node's
