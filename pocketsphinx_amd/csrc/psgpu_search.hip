@@ -57,6 +57,14 @@ constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS 
 #ifndef PSGPU_FT_IPT
 #define PSGPU_FT_IPT 2
 #endif
+#ifndef PSGPU_FT_CHUNK_START
+#define PSGPU_FT_CHUNK_START (1 << 30)
+#endif
+#ifndef PSGPU_FT_CHUNK_ADAPT
+#define PSGPU_FT_CHUNK_ADAPT 0
+#endif
+constexpr int kFtChunkStart = PSGPU_FT_CHUNK_START;    // slab layouts: items of a frame's first pruning chunk (at most what the LDS arrays hold)
+constexpr bool kFtChunkAdapt = PSGPU_FT_CHUNK_ADAPT != 0;      // ... and the later chunks sized so that their pairs fill one round
 #ifndef PSGPU_FT_EVAL_UNROLL
 #define PSGPU_FT_EVAL_UNROLL 2
 #endif
@@ -1686,7 +1694,11 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             int32_t *const xfer = cxf + (size_t)nxt * ccap;    // the next list's
             FtPair *const xfpl = cxp + (size_t)nxt * ccap;
             bool over = false;                                   // the next list outgrows the compact buffers (uniform)
-            for (int c0 = 0; c0 < n_item; c0 += kPrIC) {
+            // (a chunk takes as many items as fill ONE round of pairs -- KP pairs a work-item -- judged from the chunk before: a second round
+            //  with a fifth of its places taken costs what a full one does)
+            int nci = kFtChunkStart < kPrIC ? kFtChunkStart : kPrIC;
+            for (int c0 = 0, nci_used = 0; c0 < n_item; c0 += nci_used) {
+                nci_used = nci;
                 // -- the chunk's items, two consecutive ones a work-item -> LDS; their pairs counted: the item's own entry (listed nodes),
                 //    its children (retained items), the words whose penultimate phone it is (retained items whose out score can reach the
                 //    last-phone beam, :824-870)
@@ -1695,7 +1707,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     int node[kFtIpt]; FtQuad it[kFtIpt], q1[kFtIpt];
 #pragma unroll
                     for (int u = 0; u < kFtIpt; ++u) {
-                        const int i = c0 + kFtIpt * tid + u;
+                        const int i = kFtIpt * tid + u < nci_used ? c0 + kFtIpt * tid + u : n_item;      // (beyond the chunk: no item)
                         node[u] = -1; it[u] = FtQuad{ kW, -1, kW, 0 }; q1[u] = FtQuad{ 0, 0, 0, -1 };
                         if (i < R) { node[u] = i; it[u] = itb[i]; q1[u] = node_q1[i]; }
                         else if (i < n_item) {
@@ -1706,7 +1718,7 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                     }
 #pragma unroll
                     for (int u = 0; u < kFtIpt; ++u) {
-                        const int li = kFtIpt * tid + u, i = c0 + li;
+                        const int li = kFtIpt * tid + u, i = li < nci_used ? c0 + li : n_item;
                         const bool active = i < R ? it[u].w != 0 : node[u] >= 0;
                         const bool fl = active && it[u].z > thresh;
                         const int nk = fl ? (q1[u].z & 0xffff) : 0, nw = (int)((uint32_t)q1[u].z >> 16);
@@ -1741,6 +1753,10 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
                       for (int u = 0; u < kFtIpt; ++u) { s_it_poff[kFtIpt * tid + u] = o_; o_ += np[u]; } }
                     if (tid == NT - 1) s_it_poff[kPrIC] = n_pair;
                     ft_sync<true>();                                 // (the chunk's LDS arrays are complete; s_scan is free again)
+                }
+                if (kFtChunkAdapt) {
+                    const long long want = (long long)KP * NT * nci_used / (n_pair > 0 ? n_pair : 1);
+                    nci = (int)(want > kPrIC ? kPrIC : (want < 4 * 64 ? 4 * 64 : want)) & ~1;
                 }
                 FT_PROF(5);
                 // -- the chunk's pairs, four consecutive ones a work-item: the item's own entry first (listed nodes), then its children
