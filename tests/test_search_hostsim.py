@@ -107,11 +107,11 @@ def test_search_kernel_source_full_cmudict_vocabulary(big_trace, order):  # noqa
     lm.close()
 
 
-@pytest.mark.parametrize("cap", ["0", "64"])
+@pytest.mark.parametrize("cap", ["0"])
 def test_search_kernel_source_rank_table_in_the_slab(big_trace, cap):  # noqa: F811
     """slab layouts: the listed nodes' index (bitmap -> rank -> position).  The rank -> position table is LDS while the frame's list fits
     what the pool has left and lies in the utterance's slab otherwise: PSGPU_FWDTREE_PERM_CAP cuts the LDS table down so that every frame
-    (0) / every frame with more than 64 listed nodes takes the slab's -- on the full cmudict task and on a small one."""
+    takes the slab's -- on the full cmudict task and on small ones."""
     with _env("PSGPU_FWDTREE_PERM_CAP", cap):
         g = big_trace
         lm = simlib.SimLm(g)
@@ -124,9 +124,8 @@ def test_search_kernel_source_rank_table_in_the_slab(big_trace, cap):  # noqa: F
 
 
 @pytest.mark.parametrize("case,knob,status,start", [("goforward", "PSGPU_FWDTREE_LISTED_CAP", 4, "16"), ("goforward", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"),
-                                               ("man_ah_2934za", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"), ("cmudict", "PSGPU_FWDTREE_RC_BLOCKS", 5, "64"),
-                                               ("cmudict", "PSGPU_FWDTREE_LISTED_CAP", 4, "4096"), ("goforward", "PSGPU_FWDTREE_WL_CAP", 6, "16"),
-                                               ("cmudict", "PSGPU_FWDTREE_WL_CAP", 6, "64")])
+                                               ("man_ah_2934za", "PSGPU_FWDTREE_RC_BLOCKS", 5, "1"), ("cmudict", "PSGPU_FWDTREE_RC_BLOCKS", 5, "256"),
+                                               ("cmudict", "PSGPU_FWDTREE_LISTED_CAP", 4, "4096"), ("goforward", "PSGPU_FWDTREE_WL_CAP", 6, "16")])
 def test_search_kernel_source_capacities_grow_on_demand(case, knob, status, start, big_trace):  # noqa: F811
     """slab layouts: the compact channels' capacity (tree nodes a frame may list) and the pool of the right-context channels' blocks start
     small and grow on demand -- a frame that needs more ends the utterance with status 4 / 5, psgpu_fwdtree_grow doubles the capacity and the
