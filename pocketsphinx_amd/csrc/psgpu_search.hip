@@ -65,6 +65,10 @@ constexpr int kFtThreads = PSGPU_FT_THREADS;   // work-items per utterance (LDS 
 #endif
 constexpr int kFtChunkStart = PSGPU_FT_CHUNK_START;    // slab layouts: items of a frame's first pruning chunk (at most what the LDS arrays hold)
 constexpr bool kFtChunkAdapt = PSGPU_FT_CHUNK_ADAPT != 0;      // ... and the later chunks sized so that their pairs fill one round
+#ifndef PSGPU_FT_TOP_UNROLL
+#define PSGPU_FT_TOP_UNROLL 4
+#endif
+constexpr int kFtTopUnroll = PSGPU_FT_TOP_UNROLL;      // slab layouts: positions of the active list a work-item marks the senones of at a time
 #ifndef PSGPU_FT_EVAL_UNROLL
 #define PSGPU_FT_EVAL_UNROLL 2
 #endif
@@ -1351,24 +1355,35 @@ void fwdtree_kernel(FtDev p, const int16_t *__restrict__ senscr_, int64_t scr_st
             const int Rq = SMALL ? R : 0, naq = SMALL ? na : 0;
             if (!SMALL) {
                 int n_act_root = 0;
-                for (int i0 = 0; i0 < R + na; i0 += NT) {
+                for (int i0 = 0; i0 < R; i0 += NT) {
                     const int i = i0 + tid;
-                    bool act_root = false;
-                    if (i < R) {
-                        act_root = rb_get(cur, i) != 0u;
-                        if (act_root && raw_mode) mark(tv, i);
-                    }
-                    else if (i < R + na && raw_mode) {
-                        // the channel's senones: at its old place's static side, or (a new channel) in the static tables
-                        const int src = (cxf[(size_t)cur * ccap + (i - R)] & 0x0fffffff) - 1;
-                        FtSen a = sen_of(FtQuad{ 0, 0, 0, 0 });
-                        if (raw_mode) { if (src >= 0) a = csen(nxt)[src]; else a = sen_of(node_st1[aclc[i - R]]); }
-                        if (raw_mode) {                                  // the channel carries its senones, 16 bits each
-                            mark_sen(a.x & 0xffff); mark_sen((int)((uint32_t)a.x >> 16)); mark_sen(a.y & 0xffff);
-                            if (NE == 5) { mark_sen((int)((uint32_t)a.y >> 16)); mark_sen(sen_z(a) & 0xffff); }
+                    const bool act_root = i < R && rb_get(cur, i) != 0u;
+                    if (act_root && raw_mode) mark(tv, i);
+                    n_act_root += __popcll(__ballot(act_root));
+                }
+                if (raw_mode) {
+                    // the listed nodes' senones: at the old place's static side, or (a new channel) in the static tables -- kFtTopUnroll
+                    // positions a work-item at a time: the transfer words first, then the gathers they name, then the marks
+                    const int32_t *const xf = cxf + (size_t)cur * ccap;
+                    for (int j0 = tid; j0 < na; j0 += kFtTopUnroll * NT) {
+                        int32_t xs[kFtTopUnroll], nd_[kFtTopUnroll]; FtSen a[kFtTopUnroll];
+#pragma unroll
+                        for (int u = 0; u < kFtTopUnroll; ++u) { const int j = j0 + u * NT; xs[u] = j < na ? xf[j] : 1; nd_[u] = 0; }
+#pragma unroll
+                        for (int u = 0; u < kFtTopUnroll; ++u) { const int j = j0 + u * NT; if (j < na && (xs[u] & 0x0fffffff) == 0) nd_[u] = aclc[j]; }
+#pragma unroll
+                        for (int u = 0; u < kFtTopUnroll; ++u) {
+                            const int src = (xs[u] & 0x0fffffff) - 1;
+                            a[u] = sen_of(FtQuad{ 0, 0, 0, 0 });
+                            if (j0 + u * NT < na) { if (src >= 0) a[u] = csen(nxt)[src]; else a[u] = sen_of(node_st1[nd_[u]]); }
+                        }
+#pragma unroll
+                        for (int u = 0; u < kFtTopUnroll; ++u) {
+                            if (j0 + u * NT >= na) continue;
+                            mark_sen(a[u].x & 0xffff); mark_sen((int)((uint32_t)a[u].x >> 16)); mark_sen(a[u].y & 0xffff);
+                            if (NE == 5) { mark_sen((int)((uint32_t)a[u].y >> 16)); mark_sen(sen_z(a[u]) & 0xffff); }
                         }
                     }
-                    if (i0 < R) n_act_root += __popcll(__ballot(act_root));
                 }
                 if (lane == 0 && n_act_root) atomicAdd(&s_nroot, n_act_root);
             }
