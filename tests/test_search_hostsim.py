@@ -154,6 +154,45 @@ def test_search_kernel_source_capacities_grow_on_demand(case, knob, status, star
         lm.close()
 
 
+@pytest.mark.parametrize("layout", ["slab", "lds"])
+def test_search_kernel_source_renormalises_as_the_oracle_does(layout):
+    """renormalize_scores (ngram_search_fwdtree.c:566-603, 1473-1480) runs when best_score + 2 beam falls below WORST_SCORE -- with the
+    beams a configuration can name that is an hour into an utterance, so no reference dump holds it.  Here the beam is made wide enough
+    (a parameter no configuration reaches) that it happens every few dozen frames of goforward: the kernel's tables against the oracle's
+    (oracle/ps_oracle_search.c, whose renormalisation restates the reference's lines; the oracle is pinned to the reference on every dump
+    without one).  The slab layouts normalise a listed node's channel where the frame's evaluation makes it."""
+    import pso
+    g = _load("fwdtree_trace_goforward.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    par = g["par"].copy()
+    par[8] = -268434956                                   # beam: best + 2 beam < WORST_SCORE (-2^29) once best < -1,000
+    o = pso.OracleFwdtree(st, par)
+    o.start()
+    off, act, scr = g["step_act_off"], g["step_act"], g["step_scr"]
+    n = int(g["n_steps"][0])
+    best = []
+    for i in range(n):
+        a0, a1 = int(off[i]), int(off[i + 1])
+        o.step(int(g["step_frame"][i]), act[a0:a1], scr[a0:a1], 2000, g["step_pen"][i])      # (senones the dump did not list: a plain high cost)
+        best.append((o.best_score(), o.last_phone_best_score(), o.bpidx()))
+    nfr = int(g["n_frame"][0])
+    o.finish(nfr)
+    jumps = sum(1 for i in range(1, n) if best[i][0] - best[i - 1][0] > 500)
+    assert jumps >= 3, jumps                                # (a renormalised frame's best score rises by what was taken out)
+    with _layout(layout):
+        s = simlib.SimFwdtreeSearch(st, par)
+        rows, pen = _inputs(g, s.n_sen)
+        for i in range(n):
+            listed = np.zeros(s.n_sen, bool); listed[act[int(off[i]):int(off[i + 1])]] = True
+            rows[i, ~listed] = 2000
+        r = s.search(rows, pen, [rows.shape[0]], bp_cap=1 << 16, bss_cap=1 << 21)[0]
+        s.close()
+    assert r["status"] == 0
+    assert [tuple(int(v) for v in row[:3]) for row in r["step"][:n]] == best
+    assert np.array_equal(r["bp"], o.bp_table()) and np.array_equal(r["bscore_stack"], o.bscore_stack())
+    assert np.array_equal(r["bp_table_idx"], o.bp_table_idx(nfr))
+
+
 @pytest.mark.parametrize("name", LM_CASES)
 def test_simulated_device_trie_equals_reference_look_ups(name):
     """psgpu_lm_dev.h through the simulator against the reference's recorded look-ups"""

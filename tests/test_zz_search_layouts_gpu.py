@@ -95,3 +95,43 @@ def impl_full_cmudict(tmp):
     _check(s.search(rows, pen, [T], cuts=[T // 2, T // 2 + 9], lag=4)[0], g, "cmudict, resumed")
     assert s.searched == [T // 2 - 4, T // 2 + 5, T]
     s.close()
+
+
+@pytest.mark.parametrize("layout", ["slab", "lds"])
+def test_fwdtree_kernel_renormalises_as_the_oracle_does(layout):
+    """renormalize_scores (ngram_search_fwdtree.c:566-603): unreachable with beams a configuration can name before an hour of audio, so
+    held against the oracle with a beam that wide (tests/test_search_hostsim.py has the same case on the simulator)"""
+    run_isolated(ME, "impl_renormalises", layout)
+
+
+def impl_renormalises(layout):
+    os.environ["PSGPU_FWDTREE_LAYOUT"] = layout
+    import pocketsphinx_amd as P
+    import pso
+    g = _load("fwdtree_trace_goforward.npz")
+    st = _load("fwdtree_static_en_us_turtle.npz")
+    par = g["par"].copy()
+    par[8] = -268434956                                   # beam: best + 2 beam < WORST_SCORE (-2^29) once best < -1,000
+    o = pso.OracleFwdtree(st, par)
+    o.start()
+    off, act, scr = g["step_act_off"], g["step_act"], g["step_scr"]
+    n = int(g["n_steps"][0])
+    best = []
+    for i in range(n):
+        a0, a1 = int(off[i]), int(off[i + 1])
+        o.step(int(g["step_frame"][i]), act[a0:a1], scr[a0:a1], 2000, g["step_pen"][i])
+        best.append((o.best_score(), o.last_phone_best_score(), o.bpidx()))
+    nfr = int(g["n_frame"][0])
+    o.finish(nfr)
+    assert sum(1 for i in range(1, n) if best[i][0] - best[i - 1][0] > 500) >= 3
+    s = P.FwdtreeSearch(st, par)
+    rows, pen = _inputs(g, s.n_sen)
+    for i in range(n):
+        listed = np.zeros(s.n_sen, bool); listed[act[int(off[i]):int(off[i + 1])]] = True
+        rows[i, ~listed] = 2000
+    r = s.search(rows, pen, [rows.shape[0]], bp_cap=1 << 16, bss_cap=1 << 21)[0]
+    s.close()
+    assert r["status"] == 0
+    assert [tuple(int(v) for v in row[:3]) for row in r["step"][:n]] == best
+    assert np.array_equal(r["bp"], o.bp_table()) and np.array_equal(r["bscore_stack"], o.bscore_stack())
+    assert np.array_equal(r["bp_table_idx"], o.bp_table_idx(nfr))
