@@ -49,6 +49,16 @@ N_SAMPLE = 64                    # utterances decoded by the reference for cpu_b
 LEG_CHECK = 32                   # ... on the other decode legs (two passes, multi-stream scorer, large vocabulary)
 # the compiled reference (test infrastructure): what this file does with it is time it (cpu_baseline) and compare with it (parity)
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+# ... and the same reference built with upstream's Release flags (-O3 -DNDEBUG: `make -C oracle release`): what cpu_baseline times
+REF_REL = os.path.join(REF_DIR, "release")
+
+
+def ref_exe(name):
+    """(path, flags) of a timing program of the compiled reference: the Release-flag build when it is there"""
+    rel = os.path.join(REF_REL, name)
+    if os.path.exists(rel):
+        return rel, "gcc -O3 -DNDEBUG (upstream's Release flags)"
+    return os.path.join(REF_DIR, name), "gcc -O2"
 LV_UTT, LV_CHECK, LV_STEPS = 256, 32, 2    # the large-vocabulary leg: utterances per step, utterances the reference decodes, timed steps
 
 
@@ -93,7 +103,7 @@ def reference_decode(pcm, n_samples, ids, lm="turtle.lm.bin", dic="turtle.dic", 
     (pocketsphinx_batch's way to use a machine: one decoder per core, programs/pocketsphinx_batch.c) -- totals then carry
     the wall time of the slowest process as well"""
     ref = REF_DIR
-    exe = os.path.join(ref, "ref_decode_bench")
+    exe = ref_exe("ref_decode_bench")[0]
     if not os.path.exists(exe):
         return None
     procs = max(1, min(procs, len(ids)))
@@ -224,7 +234,7 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
                                "sample": "%d of the step's %d utterances (%d frames, %.1f s of CPU in all; %d one-thread reference processes side by "
                                          "side, value = frames / summed CPU seconds), same LM and dictionary, -fwdflat no -bestpath no"
                                          % (len(ids), n_utt, tot["frames"], tot["cpu_s"], tot["procs"]),
-                               "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2)"}
+                               "what": "unmodified reference (%s)" % ref_exe("ref_decode_bench")[1]}
         out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad,
                          "what": "word ids, start / end frames, path score and frame count: device vs the reference on the same PCM"}
         out["speedup_vs_cpu_1thread"] = round(frames / dt / tot["frames_per_s"], 1)
@@ -385,7 +395,7 @@ def scorer_extra(P, capi, L, dev, sp, tables):
     # cpu_baseline + parity: the unmodified reference's ptm_mgau_frame_eval(compallsen) on the same feature vectors, one thread
     # (oracle/_ref/ref_score_bench: the loop around the scorer's vtable entry, acmod.c:1076-1133), every one of its int16 scores
     # against the device's
-    exe = os.path.join(REF_DIR, "ref_score_bench")
+    exe, exe_flags = ref_exe("ref_score_bench")
     if os.path.exists(exe):
         with tempfile.TemporaryDirectory() as td:
             fpath, spath = os.path.join(td, "feats.f32"), os.path.join(td, "scores.i16")
@@ -399,7 +409,7 @@ def scorer_extra(P, capi, L, dev, sp, tables):
                 bad = int((want != got).any(axis=1).sum())
                 out["cpu_baseline"] = {"value": round(j["frames_per_s"], 1), "unit": "frames/s", "cores": 1, "kind": "reference",
                                        "sample": "all %d frames of the step (%.1f s of CPU)" % (j["frames"], j["seconds"]),
-                                       "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2): ptm_mgau_frame_eval, compallsen, "
+                                       "what": "unmodified reference (" + exe_flags + "): ptm_mgau_frame_eval, compallsen, "
                                                "fresh top-N history per utterance"}
                 out["parity"] = {"frames_checked": T, "senones": int(model.n_sen), "frames_with_a_differing_score": bad,
                                  "what": "every int16 senone score of every frame: device vs the reference (bit-exact = 0 differing)"}
@@ -453,6 +463,111 @@ def child_extras(out):
 _JSON_FD = None
 
 
+def sq_issue(kernel_key):
+    """issue-slot fraction of a search kernel from the newest COMMITTED SQ-counter pass (profiles/*_sq_issue.json, written by
+    tools/prof_collect.py --sq): wave-instructions issued / (SQ_BUSY_CYCLES x 4 SIMDs a compute unit's sequencer feeds) -- how
+    busy the instruction streams are while the kernel holds its compute units.  A constant of the repository like `traffic`."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_issue.json")), reverse=True):
+        try:
+            k = json.load(open(path)).get(kernel_key)
+            if k and k.get("issue_frac") is not None:
+                return k
+        except Exception:
+            continue
+    return None
+
+
+def flatten_for_driver(line):
+    """the driver's record keeps `roofline`'s SCALAR keys (nested objects are dropped, BENCH_r05): the scorer's and the
+    large-vocabulary leg's figures once more as scalars beside the headline kernel's"""
+    rf = line["roofline"]
+    sc = rf.get("scorer") or {}
+    if sc:
+        rf["scorer_valu_frac"] = sc.get("frac_of_no_fma_rate")
+        rf["scorer_tflops"] = sc.get("achieved")
+        rf["scorer_kernel_ms"] = sc.get("kernel_ms")
+    st, sa = line.get("stage_ms") or {}, line.get("stage_ms_one_step_alone") or {}
+    for k in ("front_end", "scorer", "search"):
+        if k in st:
+            rf["stage_%s_ms_beside" % k] = st[k]
+        if k in sa:
+            rf["stage_%s_ms_alone" % k] = sa[k]
+    if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch"):
+        rf["traffic_over_algorithmic"] = round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
+    iq = sq_issue("fwdtree_kernel_headline")
+    if iq:
+        rf["issue_frac"] = iq["issue_frac"]
+        rf["lds_wait_frac"] = iq.get("lds_wait_frac")
+    lv = line.get("decode_large_vocab")
+    if isinstance(lv, dict) and "value" in lv:
+        lr, lp, lc = lv.get("roofline") or {}, lv.get("parity") or {}, lv.get("cpu_baseline") or {}
+        rf["lv_value"] = lv["value"]
+        rf["lv_ms_per_step"] = lv.get("ms_per_step")
+        rf["lv_utterances"] = (lv.get("config") or {}).get("utterances")
+        rf["lv_kernel_ms"] = lr.get("kernel_ms")
+        rf["lv_frac"] = lr.get("frac")
+        rf["lv_achieved"] = lr.get("achieved")
+        rf["lv_traffic"] = lr.get("traffic")
+        rf["lv_algorithmic_bytes"] = lr.get("algorithmic_bytes_per_launch")
+        rf["lv_traffic_over_algorithmic"] = (round(lr["traffic"] / lr["algorithmic_bytes_per_launch"], 3)
+                                             if lr.get("traffic") and lr.get("algorithmic_bytes_per_launch") else None)
+        rf["lv_parity_identical"] = lp.get("identical")
+        rf["lv_parity_checked"] = lp.get("checked")
+        rf["lv_cpu_baseline"] = lc.get("value")
+        iq = sq_issue("fwdtree_kernel_large_vocab")
+        if iq:
+            rf["lv_issue_frac"] = iq["issue_frac"]
+    elif isinstance(lv, dict):
+        rf["lv_value"] = None
+        rf["lv_error"] = str(lv.get("error") or lv.get("skipped"))[:120]
+    tp = line.get("decode_two_pass")
+    if isinstance(tp, dict) and "first_pass_ms" in tp:
+        rf["two_pass_first_ms"], rf["two_pass_second_ms"] = tp["first_pass_ms"], tp["second_pass_ms"]
+        rf["two_pass_value"] = tp.get("frames_per_s")
+        pp = tp.get("parity") or {}
+        rf["two_pass_parity_identical"], rf["two_pass_parity_checked"] = pp.get("identical"), pp.get("checked")
+    for key, pre in (("decode_ms_scorer", "ms"), ("decode_ms_continuous", "cont")):
+        lg = line.get(key)
+        if isinstance(lg, dict) and "frames_per_s" in lg:
+            rf[pre + "_value"] = lg["frames_per_s"]
+            pp = lg.get("parity") or {}
+            rf[pre + "_parity_identical"], rf[pre + "_parity_checked"] = pp.get("identical"), pp.get("checked")
+    ex = line.get("extra") or {}
+    s60 = ex.get("decode_two_pass_large_vocab_60s")
+    if isinstance(s60, dict):
+        for k in ("seconds", "first_pass_call_s", "second_pass_call_s", "xrt"):
+            if isinstance(s60.get(k), (int, float)):
+                rf["lv60_" + k] = s60[k]
+        if isinstance(s60.get("reference"), dict):
+            rf["lv60_cpu_seconds"] = s60["reference"].get("cpu_s")
+        if isinstance(s60.get("parity"), dict):
+            rf["lv60_parity_identical"], rf["lv60_parity_checked"] = s60["parity"].get("identical"), s60["parity"].get("checked")
+    for key, pre in (("search_only_turtle", "so_turtle"), ("search_only_cmudict", "so_cmudict")):
+        so = ex.get(key)
+        if isinstance(so, dict):
+            for k, v in so.items():
+                if isinstance(v, (int, float)) and not isinstance(v, bool):
+                    rf["%s_%s" % (pre, k)] = v
+    par = line.get("parity") or {}
+    if par:
+        rf["parity_identical"], rf["parity_checked"] = par.get("identical"), par.get("checked")
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict) and isinstance(cb.get("all_cores"), dict):
+        cb["all_cores_value"], cb["all_cores_n"] = cb["all_cores"].get("value"), cb["all_cores"].get("cores")
+
+
+def self_launch_argv(n_gpus, argv, port=None):
+    """the command line that runs this file as n_gpus ranks on this node: one process per GPU under torch.distributed.run,
+    rendezvous on 127.0.0.1 (the container's host name may not resolve)"""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_gpus,
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def emit(line):
     """the ONE line of standard output"""
     data = (json.dumps(line) + "\n").encode()
@@ -487,21 +602,41 @@ def main():
     if args.tables:
         os.environ["PSGPU_TABLE_DIR"] = os.path.abspath(args.tables)      # (the child-process extras read it too)
 
+    # --gpus N is the number of ranks of the job.  Launched by torch.distributed.run (the driver's form for N > 1) the
+    # environment carries it and the two must agree; launched plainly with N > 1 (`python bench.py --gpus 8`) this process
+    # becomes the launcher of N ranks, one per GPU over RCCL (self_launch_argv) -- the reference's batch driver is one
+    # process walking a control file (programs/pocketsphinx_batch.c:877-899); here the control file's utterances shard.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.stdout.flush()
+        os.dup2(_JSON_FD, 1)                              # (the ranks print the line themselves)
+        argv = self_launch_argv(args.gpus, sys.argv[1:])
+        sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks: %s\n" % (args.gpus, args.gpus, " ".join(argv)))
+        if os.environ.get("PSGPU_BENCH_LAUNCH_DRYRUN"):   # (tests/test_bench_launch.py: the command line, not the job)
+            emit({"launch": argv})
+            return
+        os.execv(argv[0], argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): the line's n_gpus would not be what "
+                         "was asked for" % (args.gpus, world))
     B, n_samp = args.utts, int(round(args.seconds * 16000))
 
     # rank 0 owns the PCM of the whole job (synthesised before torch / HIP start: the pool forks)
     pcm_all = synth_pcm(0, B * world, args.seconds) if rank == 0 else None
 
     import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s): one rank per GPU, no sharing" % (world, torch.cuda.device_count()))
     dist = None
     if world > 1 or os.environ.get("PSGPU_BENCH_FORCE_DIST"):     # (.._FORCE_DIST: the N > 1 code path with one rank, for a one-GPU box)
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:                       # (.._FORCE_DIST without a launcher: a one-rank group of its own)
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(self_launch_argv(1, [])[9]), "RANK": "0", "WORLD_SIZE": "1"})
         dist.init_process_group(backend="nccl")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -797,7 +932,8 @@ def main():
                                     "sample": "%d of the step's %d utterances (%d frames, %.1f s of CPU in all): ps_start_utt / "
                                               "ps_process_raw(full_utt) / ps_end_utt per utterance, -fwdflat no -bestpath no; value = frames / "
                                               "summed CPU seconds of one-thread decoders" % (len(ids), B, tot["frames"], tot["cpu_s"]),
-                                    "what": "unmodified reference (oracle/_ref/libpocketsphinx.so, gcc -O2), one thread",
+                                    "what": "unmodified reference (%s), one thread" % ref_exe("ref_decode_bench")[1],
+                                    "build": ref_exe("ref_decode_bench")[1],
                                     "all_cores": {"value": round(tot["frames_per_s_all_procs"], 1), "unit": "frames/s", "cores": tot["procs"],
                                                   "host_cpus": os.cpu_count(), "wall_s": round(tot["wall_s"], 2),
                                                   "what": "%d reference processes side by side, one decoder thread each (pocketsphinx_batch's way to "
@@ -904,6 +1040,7 @@ def main():
                 legs[name][k] = lg[k]
     if legs:
         line["roofline"]["legs"] = legs
+    flatten_for_driver(line)
     emit(line)
     if dist is not None:
         dist.destroy_process_group()

@@ -36,6 +36,27 @@ extern "C" {
 #define PSGPU_MAX_TOPN  8
 
 /* ---- library / device ------------------------------------------------ */
+/* The ABI's version: major << 16 | minor.  A binding compiled against this header checks
+ * `psgpu_abi_version() >> 16 == PSGPU_ABI_VERSION >> 16` (entry points are only ever added within a major version; the
+ * minor counts the additions) and asks psgpu_capabilities() for what the loaded library serves before it relies on an
+ * optional part -- the reference has the same two-step in its own plugin loading: a name in the vtable, then the calls
+ * (acmod.h:98-116). */
+#define PSGPU_ABI_VERSION  ((1 << 16) | 6)
+#define PSGPU_CAP_PTM                 (1ull << 0)   /* psgpu_ptm_* (ptm_mgau.c) */
+#define PSGPU_CAP_SEMI                (1ull << 1)   /* psgpu_semi_* (s2_semi_mgau.c) */
+#define PSGPU_CAP_MS                  (1ull << 2)   /* psgpu_ms_* (ms_mgau.c, ms_gauden.c, ms_senone.c) */
+#define PSGPU_CAP_HMM                 (1ull << 3)   /* psgpu_hmm_* (hmm.c) */
+#define PSGPU_CAP_FE                  (1ull << 4)   /* psgpu_fe_*, psgpu_feat_* (fe/, feat/) */
+#define PSGPU_CAP_FWDTREE             (1ull << 5)   /* psgpu_fwdtree_* (ngram_search_fwdtree.c) */
+#define PSGPU_CAP_FWDFLAT             (1ull << 6)   /* psgpu_fwdflat_* (ngram_search_fwdflat.c) */
+#define PSGPU_CAP_TRIE_LM             (1ull << 7)   /* psgpu_lm_* (lm/lm_trie.c) */
+#define PSGPU_CAP_DECODE              (1ull << 8)   /* psgpu_decode_* pipeline objects */
+#define PSGPU_CAP_STREAMS             (1ull << 9)   /* psgpu_decode_streams_* / live steps from feature vectors */
+#define PSGPU_CAP_PTM_BATCH_ANY_SHAPE (1ull << 10)  /* psgpu_ptm_score_batch_dev for every shape psgpu_ptm_frame_eval serves */
+#define PSGPU_CAP_STREAMS_PCM         (1ull << 11)  /* streams fed with PCM (per-stream front-end state + live CMN on the device) */
+#define PSGPU_CAP_FWDTREE_SPLIT       (1ull << 12)  /* one utterance's tree search on several workgroups */
+int32_t psgpu_abi_version(void);
+uint64_t psgpu_capabilities(void);
 const char *psgpu_version(void);
 const char *psgpu_last_error(void);          /* thread-local message */
 int psgpu_device_count(void);                /* >=0, or PSGPU_ENODEV */
@@ -661,6 +682,12 @@ int psgpu_fwdtree_use_slab_layout(psgpu_fwdtree_t *m);
  * psgpu_decode_fetch_hyps does both by itself (psgpu_decode_table_capacity's auto_grow).  0, or PSGPU_EINVAL (LDS layout; nothing left
  * to grow; arrays beyond 8 GB per utterance). */
 int psgpu_fwdtree_grow(psgpu_fwdtree_t *m, int32_t status);
+/* All three capacities at their ends at once (a channel place per tree node, a pool block per dictionary word, the word level's
+ * arrays in the slab): no search on this handle can end with status 4 / 5 / 6 afterwards.  What a caller does whose searches cannot
+ * be repeated -- psgpu_decode_streams_begin does it by itself: a stream's score rows are gone once searched, so a capacity met
+ * in the middle of an utterance could not be raised and the utterance searched again as psgpu_decode_fetch_hyps does for batch
+ * calls.  A no-op for the LDS layout.  0, or PSGPU_EINVAL (arrays beyond 8 GB per utterance; the capacities stay as they were). */
+int psgpu_fwdtree_full_capacity(psgpu_fwdtree_t *m);
 
 
 /* ---- the trigram language model on the device -----------------------

@@ -351,6 +351,21 @@ inject(ngram_search_t *ngs, int n_ci, const int32_t *bp, int b0, int nb, const i
     ngs->best_score = best_score;    /* ngram_search_lattice (ngram_search.c:1226) refuses an utterance whose best score is WORST_SCORE */
 }
 
+/* result word 3 of a search (include/psgpu.h: psgpu_fwdtree_search_dev, psgpu_fwdtree_grow) in words */
+static const char *
+status_text(int status)
+{
+    switch (status) {
+    case 1: return "status 1: back-pointer table or score stack full (psgpu_decode_table_capacity)";
+    case 2: return "status 2: the LDS layout's evaluation list was too short for a frame (psgpu_fwdtree_use_slab_layout)";
+    case 3: return "status 3: two last-phone candidates of one frame name the same word (a lexicon tree with two paths to one dictionary entry)";
+    case 4: return "status 4: a frame listed more tree nodes than the compact channels hold (psgpu_fwdtree_grow)";
+    case 5: return "status 5: the right-context channels' pool ran out of blocks (psgpu_fwdtree_grow)";
+    case 6: return "status 6: the word level's counts outgrew its LDS arrays (psgpu_fwdtree_grow)";
+    default: return "the search ended with an unknown status";
+    }
+}
+
 static int
 fetch_and_inject_from(psgpu_device_decode_t *d, int u, int b0, int h0, int f0)
 {
@@ -359,7 +374,7 @@ fetch_and_inject_from(psgpu_device_decode_t *d, int u, int b0, int h0, int f0)
     const int32_t *res = d->grp ? d->grp->h_res + (size_t)d->gidx * 8 : d->h_res + (size_t)u * 8;
     int nb = res[0], nh = res[1], nfr = res[2];
     if (d->grp) u = d->gidx;
-    if (res[3]) { E_ERROR("psgpu device decode: utterance %d: back-pointer table or score stack full\n", u); return -1; }
+    if (res[3]) { E_ERROR("psgpu device decode: utterance %d: %s\n", u, status_text(res[3])); return -1; }
     if (b0 > nb || h0 > nh || f0 > nfr) b0 = h0 = f0 = 0;
     if ((size_t)nb * 10 > d->cap_bp) { FREE_HOST(d->h_bp); d->cap_bp = (size_t)nb * 15 + 640; d->h_bp = ckd_calloc(d->cap_bp, 4); }
     if ((size_t)nh > d->cap_bss) { FREE_HOST(d->h_bss); d->cap_bss = (size_t)nh + nh / 2 + 64; d->h_bss = ckd_calloc(d->cap_bss, 4); }
@@ -417,7 +432,7 @@ psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n_sam
         return -1;
     }
     if (fetch_summary(d, 1) < 0) return -1;
-    if (d->h_res[3]) { E_ERROR("psgpu device decode: back-pointer table or score stack full\n"); return -1; }
+    if (d->h_res[3]) { E_ERROR("psgpu device decode: %s\n", status_text(d->h_res[3])); return -1; }
     if (d->h_res[2] == 0) return 0;
     if (d->ff && (second_pass_batch(d) < 0 || fetch_summary(d, 1) < 0)) return -1;
     nfr = fetch_and_inject(d, 0);
@@ -757,7 +772,9 @@ live_advance(psgpu_device_decode_t *d, ngram_search_t *ngs, int T, int final)
      *  more (pocketsphinx.c:1173-1197).  Should look-ahead frames be missing (copy_frame failed above), the device search stays
      *  pl_window frames behind what it was given rather than searching frames with clamped look-ahead penalties) */
     lag = final ? 0 : (T > d->n_feat ? T - d->n_feat : 0);
-    if (lag > 0 && lag < d->ps->pl_window) lag = d->ps->pl_window;
+    /* (a step that is not the utterance's last never searches closer than pl_window frames to what it was given -- also when
+     *  copy_frame took frames away and T fell to n_feat or below: the search portion of the step is then empty) */
+    if (!final && lag < d->ps->pl_window) lag = d->ps->pl_window;
     if (psgpu_decode_live_step(d->dec, feat, T - from, lag, st) != PSGPU_OK) {
         E_ERROR("psgpu device search (live utterance): %s\n", psgpu_last_error());
         ckd_free(feat);

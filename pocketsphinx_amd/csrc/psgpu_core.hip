@@ -12,6 +12,8 @@ void psgpu_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+void psgpu_clear_error() { g_err[0] = 0; }
+
 int psgpu_check_device()
 {
     int n = 0;
@@ -40,7 +42,13 @@ int psgpu_check_device()
 
 extern "C" {
 
-const char *psgpu_version(void) { return "psgpu 0.3 (gfx950): ptm, s2_semi, ms scorers + hmm_vit_eval"; }
+const char *psgpu_version(void) { return "psgpu 0.6 (gfx950): ptm, s2_semi, ms scorers + hmm_vit_eval + fwdtree / fwdflat searches"; }
+int32_t psgpu_abi_version(void) { return PSGPU_ABI_VERSION; }
+uint64_t psgpu_capabilities(void)
+{
+    return PSGPU_CAP_PTM | PSGPU_CAP_SEMI | PSGPU_CAP_MS | PSGPU_CAP_HMM | PSGPU_CAP_FE | PSGPU_CAP_FWDTREE | PSGPU_CAP_FWDFLAT
+         | PSGPU_CAP_TRIE_LM | PSGPU_CAP_DECODE | PSGPU_CAP_STREAMS;      // (only what this build serves)
+}
 const char *psgpu_last_error(void) { return g_err; }
 
 int psgpu_device_count(void)

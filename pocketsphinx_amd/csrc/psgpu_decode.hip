@@ -878,6 +878,9 @@ int psgpu_decode_streams_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max
     int rc;
     d->lists = false; d->live = true;                    // (score rows; dec_pick_mode keeps them while the streams are in progress)
     if ((rc = dec_settle_fe_ahead(d, st))) return rc;
+    // a stream's search cannot be repeated with larger arrays (its rows are gone once searched): the slab layouts' capacities at their
+    // ends from the start, so that no stream ends with status 4 / 5 / 6
+    if ((rc = psgpu_fwdtree_full_capacity(d->cfg.ft))) return rc;
     const size_t step_total = (size_t)n_streams * max_step_frames;
     if ((rc = dec_grow(d, (size_t)n_streams, step_total, (size_t)max_frames, st))) return rc;
     PSGPU_HIP(hipStreamSynchronize(st));
@@ -1133,15 +1136,22 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
             PSGPU_HIP(hipStreamSynchronize(st));
         }
     }
+    bool no_more_capacity = false;
     for (int pass = 0; pass < 8; ++pass) {               // (a search that goes further with larger tables may meet the other limit)
-    for (int round = 0; round < 16; ++round) {
+    for (int round = 0; round < 16 && !no_more_capacity; ++round) {
         // status 4 / 5: a frame listed more tree nodes than the slab layouts' compact channels hold / needed more blocks of the
         // right-context channels' pool than there are: the capacity is doubled (psgpu_fwdtree_grow) -- for good -- and the search repeated
         int32_t grow = 0;
         for (size_t u = 0; u < nu && !grow; ++u) if (res[u * 8 + 3] >= 4 && res[u * 8 + 3] <= 6) grow = res[u * 8 + 3];
         if (!grow) break;
         int rc;
-        if ((rc = psgpu_fwdtree_grow(d->cfg.ft, grow))) return PSGPU_OK;       // (nothing left to grow: the status stays as reported)
+        if ((rc = psgpu_fwdtree_grow(d->cfg.ft, grow))) {
+            // nothing left to grow: that status stays as reported (the call succeeds: the error string is not this call's); the
+            // other utterances' full tables are still doubled below, once
+            psgpu_clear_error();
+            no_more_capacity = true;
+            break;
+        }
         ++d->n_grown;
         live_again();
         if ((rc = dec_search(d, d->n_utt, (size_t)d->total, mf, st))) return rc;
@@ -1179,7 +1189,7 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
         PSGPU_HIP(hipStreamSynchronize(st));
     }
     bool more = false;
-    for (size_t u = 0; u < nu && !more; ++u) more = res[u * 8 + 3] == 1 || (res[u * 8 + 3] >= 4 && res[u * 8 + 3] <= 6);
+    for (size_t u = 0; u < nu && !more; ++u) more = res[u * 8 + 3] == 1 || (!no_more_capacity && res[u * 8 + 3] >= 4 && res[u * 8 + 3] <= 6);
     if (!more) break;
     }
     return PSGPU_OK;

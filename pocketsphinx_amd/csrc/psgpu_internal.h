@@ -7,6 +7,7 @@
 #include "psgpu.h"
 
 void psgpu_set_error(const char *fmt, ...);
+void psgpu_clear_error();
 
 #define PSGPU_HIP(call)                                                       \
     do {                                                                      \

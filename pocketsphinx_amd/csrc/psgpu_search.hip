@@ -3089,6 +3089,26 @@ int psgpu_fwdtree_grow(psgpu_fwdtree_t *m, int32_t status)
     return PSGPU_OK;
 }
 
+int psgpu_fwdtree_full_capacity(psgpu_fwdtree_t *m)
+{
+    PSGPU_REQUIRE(m, "psgpu_fwdtree_full_capacity: NULL argument");
+    FtDev &d = m->d;
+    if (d.small) return PSGPU_OK;                        // (the LDS layout has none of these capacities)
+    const int32_t old_l = d.listed_cap, old_r = d.rc_blocks, old_w = d.wl_global;
+    d.listed_cap = (int32_t)std::max<int64_t>(1, (int64_t)d.N - d.R);
+    d.rc_blocks = std::max<int32_t>(1, d.n_w);
+    d.wl_global = 1;
+    if (!ft_layout(d, false)) {
+        d.listed_cap = old_l; d.rc_blocks = old_r; d.wl_global = old_w;
+        const bool back = ft_layout(d, false);
+        (void)back;
+        psgpu_set_error("psgpu_fwdtree_full_capacity: the search's per-utterance arrays would exceed 8 GB");
+        return PSGPU_EINVAL;
+    }
+    if (d.listed_cap != old_l || d.rc_blocks != old_r || d.wl_global != old_w) m->live_valid = false;
+    return PSGPU_OK;
+}
+
 int psgpu_fwdtree_layout(const psgpu_fwdtree_t *m, int32_t *lds_layout, int64_t *slab_bytes_per_utt)
 {
     PSGPU_REQUIRE(m, "psgpu_fwdtree_layout: NULL argument");

@@ -109,7 +109,7 @@ class FwdtreeSearch:
             [(torch.tensor([0, int(c)], dtype=torch.int32, device=dev), lag, (1 if i == 0 else 3)) for i, c in enumerate(cuts)] + [(d_o, 0, 2)]
         self.searched = []
         self.grown = []
-        for attempt in range(40 if cuts is None else 1):
+        for attempt in range(40):
           for o, lg, mode in calls:
               if cuts is not None:
                   capi.check(capi.lib().psgpu_fwdtree_search_lag(self.h, int(lg)), "psgpu_fwdtree_search_lag")
@@ -125,12 +125,17 @@ class FwdtreeSearch:
           # status 4 / 5 (slab layouts): a frame listed more tree nodes than the compact channels hold / needed more blocks of the
           # right-context channels' pool than there are -- the capacity is doubled (psgpu_fwdtree_grow) and the search repeated, as
           # psgpu_decode_fetch_hyps does for the pipeline
+          # (a search in several calls -- cuts -- that meets a capacity starts over from its first cut with the larger arrays;
+          #  nothing left to grow: the status stays in the result records, as the pipeline leaves it)
           st = res[:, 3].cpu().numpy() if n else np.zeros(0, np.int32)
           need = [int(v) for v in st if int(v) in (4, 5, 6)]
-          if not need or cuts is not None:
+          if not need:
               break
-          capi.check(capi.lib().psgpu_fwdtree_grow(self.h, need[0]), "psgpu_fwdtree_grow")
+          if capi.lib().psgpu_fwdtree_grow(self.h, need[0]) != 0:
+              break
           self.grown.append(need[0])
+          if cuts is not None:
+              self.searched = []
         if mpx_out is not None:
             mpx_out["mpx"] = d_mo.cpu().numpy()
         out = []

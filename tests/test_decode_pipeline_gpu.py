@@ -404,6 +404,40 @@ def test_streams_many_utterances_in_progress(tables):
     p.close()
 
 
+def test_streams_in_the_slab_layout_never_meet_a_capacity(tables, monkeypatch):
+    """A stream's search cannot be repeated with larger arrays (its rows are gone once searched): psgpu_decode_streams_begin puts
+    the slab layouts' capacities -- listed tree nodes, right-context pool blocks, the word level's LDS arrays -- at their ends
+    (psgpu_fwdtree_full_capacity).  With capacities cut to where a batch call ends with status 4 / 5 / 6 (tests/test_largevocab_gpu.py),
+    two streams decode their recordings to the reference's tables."""
+    monkeypatch.setenv("PSGPU_FWDTREE_LAYOUT", "slab")
+    monkeypatch.setenv("PSGPU_FWDTREE_LISTED_CAP", "64"); monkeypatch.setenv("PSGPU_FWDTREE_RC_BLOCKS", "4"); monkeypatch.setenv("PSGPU_FWDTREE_WL_CAP", "16")
+    p = _pipeline(tables)
+    for k in ("PSGPU_FWDTREE_LAYOUT", "PSGPU_FWDTREE_LISTED_CAP", "PSGPU_FWDTREE_RC_BLOCKS", "PSGPU_FWDTREE_WL_CAP"):
+        monkeypatch.delenv(k)
+    assert not p.search.lds_layout()
+    gs = [_load("fwdtree_trace_goforward.npz"), _load("fwdtree_trace_numbers.npz")]
+    fs = [_fresh_feats("goforward"), _fresh_feats("numbers")]
+    p.streams_begin(2, 420, 40)
+    pos = [0, 0]
+    for step in range(100):
+        feats, fin = [], []
+        for u in range(2):
+            k = min(31 + 6 * u, fs[u].shape[0] - pos[u])
+            feats.append(fs[u][pos[u]:pos[u] + k]); pos[u] += k
+            fin.append(k > 0 and pos[u] == fs[u].shape[0])
+        p.streams_step(feats, fin)
+        hn, hyp, res = p.fetch()
+        assert not res[:, 3].any(), res[:, :4]
+        for u in range(2):
+            if fin[u]:
+                r = p.tables(u, res)
+                r["step"] = np.stack([gs[u]["step_best"], gs[u]["step_lpbest"], gs[u]["step_bpidx"]], axis=1)
+                _check(r, gs[u], "stream %d at its end" % u)
+        if all(pos[u] == fs[u].shape[0] for u in range(2)):
+            break
+    p.close()
+
+
 def test_live_utterance_begun_again_with_more_room(tables):
     """psgpu_decode_live_restart: the second utterance of a session outgrows the capacity it was begun with after 90 frames -- by then the
     session's seed slot and the multiplexed channels' ssids have moved on with the utterance -- and is begun again with more room, its

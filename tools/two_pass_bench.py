@@ -119,7 +119,9 @@ def main():
     # parity of the sampled utterances: the compiled reference decodes the SAME PCM with both passes (-fwdflat yes -bestpath no,
     # a new decoder's state per utterance) -- words, frame boundaries and path score of the second pass's hypothesis
     ids = list(range(0, B, int(os.environ.get("TP_CHECK_EVERY", "17"))))
-    ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_bench")
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "release", "ref_decode_bench")        # (upstream's Release flags: `make -C oracle release`)
+    if not os.path.exists(ref_exe):
+        ref_exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_bench")
     parity = {"checked": 0, "note": "oracle/_ref/ref_decode_bench not built"}
     if os.path.exists(ref_exe):
         import subprocess
