@@ -556,14 +556,18 @@ def flatten_for_driver(line):
         cb["all_cores_value"], cb["all_cores_n"] = cb["all_cores"].get("value"), cb["all_cores"].get("cores")
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch_argv(n_gpus, argv, port=None):
     """the command line that runs this file as n_gpus ranks on this node: one process per GPU under torch.distributed.run,
     rendezvous on 127.0.0.1 (the container's host name may not resolve)"""
     if port is None:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
+        port = free_port()
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_gpus,
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
@@ -635,7 +639,7 @@ def main():
     if world > 1 or os.environ.get("PSGPU_BENCH_FORCE_DIST"):     # (.._FORCE_DIST: the N > 1 code path with one rank, for a one-GPU box)
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:                       # (.._FORCE_DIST without a launcher: a one-rank group of its own)
-            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(self_launch_argv(1, [])[9]), "RANK": "0", "WORLD_SIZE": "1"})
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()), "RANK": "0", "WORLD_SIZE": "1"})
         dist.init_process_group(backend="nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

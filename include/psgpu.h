@@ -83,9 +83,11 @@ int psgpu_stream_sync(void *stream);
  *   logadd8   the uint8 table of logmath_init(base, SENSCR_SHIFT, 1)
  *             (ptm_mgau.c:817-825, util/logmath.c:62-162), logadd8_size >= 256
  * The tables are copied to the current device.  Accepted shapes: n_density <= 256,
- * topn 1..8, stream lengths summing to <= 64.  The batched entry below is
- * specialised for 128 densities / top-4 / 13-dim streams (en-us) and rejects other
- * shapes loudly; psgpu_ptm_frame_eval serves every accepted shape. */
+ * topn 1..8, stream lengths summing to <= 64 -- by psgpu_ptm_frame_eval and by the
+ * batched entries below alike (PSGPU_CAP_PTM_BATCH_ANY_SHAPE).  128 densities / top-4 /
+ * 13-dim streams (en-us) run the specialised kernels (frames on lanes, closed-form top-N
+ * with an exact fix-up); every other shape runs the exact sequential procedure, one
+ * wavefront per (utterance, chain) (ptm_batch_topn_generic). */
 typedef struct psgpu_ptm_model_s psgpu_ptm_model_t;
 
 int psgpu_ptm_model_create(psgpu_ptm_model_t **out,

@@ -322,6 +322,22 @@ def fwdtree_only():
 
 
 
+def fwdtree_topn_only():
+    """The first pass with the scorer's other knobs (-topn 2; -topn 6 -ds 2: ptm_mgau.c:804-896, config_macro.h:384): what the search
+    PRODUCED -- back-pointer table, score stack, frame marks, hypothesis -- without the trace it consumed (the inputs are
+    goforward.raw and the knobs): the device pipeline decodes the same PCM with a scorer of that shape."""
+    base = ("fwdflat", "no", "bestpath", "no")
+    keep = ["par", "hyp", "hyp_score", "seg", "seg_words", "bp", "bscore_stack", "bp_table_idx", "n_frame", "step_best", "step_lpbest", "step_bpidx"]
+    for name, extra in (("goforward_topn2", ("topn", "2")), ("goforward_topn6_ds2", ("topn", "6", "ds", "2")), ("numbers_topn1", ("topn", "1")),
+                        ("numbers_topn8_ds3", ("topn", "8", "ds", "3"))):
+        d = ref_dump("fwdtree", os.path.join(REF, "data", name.split("_")[0] + ".raw"), extra=base + extra)
+        tr = {k: d[k] for k in keep}
+        tr["knobs"] = np.array(extra)
+        np.savez_compressed(os.path.join(GOLD, "fwdtree_result_%s.npz" % name), **tr)
+        print("fwdtree result", name, "bp", d["bp"].shape[0], "hyp", bytes(d["hyp"]).decode(), int(d["hyp_score"][0]),
+              os.path.getsize(os.path.join(GOLD, "fwdtree_result_%s.npz" % name)))
+
+
 def fwdtree_session():
     """the SECOND utterance of a session (REFDUMP_WARMUP: the decoder decodes another utterance first): the permanent
     multiplexed channels start with the per-state ssids the first one left (hmm_clear keeps them, hmm.c:181-196) --
@@ -573,6 +589,8 @@ if __name__ == "__main__":
         mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":
         dynfeat_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree_topn":
+        fwdtree_topn_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ptm_topn":
         ptm_topn_only()
     else:

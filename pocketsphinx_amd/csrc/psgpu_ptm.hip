@@ -228,6 +228,74 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
 }
 
 // ---------------------------------------------------------------------------
+// kernel 1c: any shape (n_density <= 256, top-N 1..8, any stream lengths, any ds_ratio): the batched form of
+// ptm_frame_topn_generic (psgpu_ptm_frame.hip).
+//
+// One wavefront = one (utterance, chain): the utterance's frames in order, the list state wave-uniform, carried from
+// frame to frame as ptm_mgau_frame_eval carries it (ptm_mgau.c:435-441) -- the exact sequential procedure of eval_topn +
+// eval_cb (generic_frame_step, psgpu_ptm_dev.h), no closed form, hence nothing to repair afterwards.  Codewords on lanes, four
+// a lane (k * 64 + lane); the frame's feature values are wave-uniform (scalar loads); a codeword's parameters come from
+// the L1 / L2-resident tables every frame (a chain's are at most 256 x len x 8 bytes).  Parallelism = utterances x chains
+// (a persistent grid walks them): a batch has plenty, one utterance has n_mgau x n_feat wavefronts.  Lists leave chain-major,
+// [chain][frame][N], the layout every consumer of the batched lists reads (N = 4: the same bytes as the packed word).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(256)
+void ptm_batch_topn_generic(PtmDev p, const float *__restrict__ feats, const int32_t *__restrict__ utt_off, int32_t n_utt,
+                            int32_t total_frames, const uint8_t *__restrict__ seed_in, uint8_t *__restrict__ seed_out,
+                            int32_t *__restrict__ topn_score, uint8_t *__restrict__ topn_cw)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int n_waves = (int)(gridDim.x * (blockDim.x >> 6));
+    const long long n_work = (long long)n_utt * p.n_chain;
+    for (long long w = wave; w < n_work; w += n_waves) {
+        const int u = (int)(w / p.n_chain), chain = (int)(w - (long long)u * p.n_chain);
+        const int ubeg = utt_off[u], uend = utt_off[u + 1];
+        if (uend <= ubeg) continue;                       // (an empty utterance: its seed stays as the caller left it)
+        const int cb = chain / p.n_feat, f = chain - cb * p.n_feat;
+        const int len = p.featlen[f];
+        // packed [mgau][feat][density][featlen[f]] (ms_gauden.c:211-221)
+        const size_t base = (size_t)cb * p.n_density * p.veclen + (size_t)p.n_density * p.featoff[f];
+        const float *mp[kGenK], *vp[kGenK];
+        float dt[kGenK];
+#pragma unroll
+        for (int k = 0; k < kGenK; ++k) {
+            const int cw = min(k * 64 + lane, p.n_density - 1);
+            mp[k] = p.mean + base + (size_t)cw * len; vp[k] = p.var + base + (size_t)cw * len;
+            dt[k] = p.det[(size_t)chain * p.n_density + cw];
+        }
+        TopN<N> L;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {       // ptm_mgau.c:790-793 for a fresh decoder, else the carried codewords
+            L.cw[i] = seed_in ? (int32_t)seed_in[((size_t)u * p.n_chain + chain) * N + i] : i;
+            L.sc[i] = kMaxNegInt32;
+        }
+        for (int t = ubeg; t < uend; ++t) {
+            const float *x = feats + (size_t)t * p.veclen + p.featoff[f];      // wave-uniform: scalar loads
+            float d[kGenK];
+#pragma unroll
+            for (int k = 0; k < kGenK; ++k) d[k] = dt[k];
+            for (int j = 0; j < len; ++j) {
+                const float xj = x[j];
+#pragma unroll
+                for (int k = 0; k < kGenK; ++k) d[k] = gau_step(d[k], xj, mp[k][j], vp[k][j]);
+            }
+            generic_frame_step<N, false>(L, d, d, lane, p.n_density, ((t - ubeg) % p.ds_ratio) == 0);
+            if (lane == 0) {
+                const size_t o = ((size_t)chain * total_frames + t) * N;
+#pragma unroll
+                for (int i = 0; i < N; ++i) { topn_score[o + i] = L.sc[i]; topn_cw[o + i] = (uint8_t)L.cw[i]; }
+            }
+        }
+        if (seed_out && lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) seed_out[((size_t)u * p.n_chain + chain) * N + i] = (uint8_t)L.cw[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // kernel 1b: frames on lanes (ds_ratio == 1).
 //
 // One wavefront = one chain x 64 consecutive frames, one frame per lane.  The
@@ -858,11 +926,25 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
     PSGPU_REQUIRE(m && feats_dev && utt_off_dev && topn_score_dev && topn_cw_dev,
                   "psgpu_ptm_topn_dev: NULL argument");
     PSGPU_REQUIRE(n_utt >= 0 && total_frames >= 0, "negative sizes");
-    PSGPU_REQUIRE(m->fast_shape, "the batched entry handles 128-density / top-4 / 13-dim PTM models; this one "
-                  "(n_density %d, topn %d) is served by psgpu_ptm_frame_eval", m->n_density, m->topn);
     PSGPU_REQUIRE(seed_in_dev == nullptr || seed_in_dev != seed_out_dev,
                   "seed_in and seed_out must not alias (chunks read seeds while others write carry-outs)");
     if (n_utt == 0 || total_frames == 0) return PSGPU_OK;
+    if (!m->fast_shape) {
+        // every other shape psgpu_ptm_frame_eval serves (topn 1..8 -- a user's knob, config_macro.h:384 --, up to 256 densities,
+        // any stream lengths, any -ds): the exact sequential procedure, one wavefront per (utterance, chain)
+        hipStream_t st = (hipStream_t)stream;
+        const PtmDev pv = dev_view(m);
+        const long long waves = (long long)n_utt * m->n_chain;
+        const unsigned grid = (unsigned)std::min<long long>((waves + 3) / 4, 256LL * 8);
+        if (m->timing) { hipEventRecord(m->ev[0], st); }
+#define PSGPU_GEN(NN) case NN: hipLaunchKernelGGL((ptm_batch_topn_generic<NN>), dim3(grid), dim3(256), 0, st, pv, feats_dev, utt_off_dev, n_utt, \
+                                                  total_frames, seed_in_dev, seed_out_dev, topn_score_dev, topn_cw_dev); break;
+        switch (m->topn) { PSGPU_GEN(1) PSGPU_GEN(2) PSGPU_GEN(3) PSGPU_GEN(4) PSGPU_GEN(5) PSGPU_GEN(6) PSGPU_GEN(7) default: PSGPU_GEN(8) }
+#undef PSGPU_GEN
+        if (m->timing) { hipEventRecord(m->ev[1], st); hipEventRecord(m->ev[2], st); }
+        PSGPU_HIP(hipGetLastError());
+        return PSGPU_OK;
+    }
     // chunk length: enough wavefronts to fill 256 CUs x 32 waves a few times
     // over, but long enough to amortise the parameter load and the one-frame
     // warm-up of every chunk.
@@ -959,10 +1041,9 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
 {
     PSGPU_REQUIRE(m && topn_score_dev && topn_cw_dev && senscr_dev,
                   "psgpu_ptm_senone_dev: NULL argument");
-    PSGPU_REQUIRE(m->fast_shape, "the batched entry handles 128-density / top-4 / 13-dim PTM models");
     if (total_frames <= 0) return PSGPU_OK;
     static const int force_generic = [] { const char *e = getenv("PSGPU_SENONE_GENERIC"); return e ? atoi(e) : 0; }();
-    if (!force_generic && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 256 && m->n_sen < 0xffff) {
+    if (!force_generic && m->fast_shape && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 256 && m->n_sen < 0xffff) {
         // block = 4..8 waves: pick the width that wastes the fewest lanes
         int best_w = 0, iters = 0;
         double best_eff = 0;
@@ -1008,12 +1089,19 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
             return PSGPU_OK;
         }
     }
+    // any shape (and the fast shape on request): one workgroup per frame, lists [chain][frame][topn]
     const int out_bytes = ((m->n_sen * 2 + 15) / 16) * 16;
-    const int list_bytes = ((m->n_chain * 4 + 15) / 16) * 16;
+    const int list_bytes = ((m->n_chain * m->topn + 15) / 16) * 16;
     const size_t smem = (size_t)out_bytes + 2 * list_bytes + 256 + 16 * 4 + 8 * 4;
-    hipLaunchKernelGGL((ptm_senone_kernel<4>), dim3(total_frames), dim3(kSenThreads), smem,
-                       (hipStream_t)stream, dev_view(m), topn_score_dev, topn_cw_dev,
-                       senscr_dev, best_dev, flags, total_frames);
+    PSGPU_REQUIRE(smem <= 160 * 1024, "psgpu_ptm_senone_dev: %zu bytes of LDS for a frame's score row and lists exceed a compute unit's", smem);
+#define PSGPU_SEN_GEN(NN) case NN: {                                                                                                        \
+        if (smem > 64 * 1024)                                                                                                              \
+            PSGPU_HIP(hipFuncSetAttribute((const void *)ptm_senone_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));    \
+        hipLaunchKernelGGL((ptm_senone_kernel<NN>), dim3(total_frames), dim3(kSenThreads), smem, (hipStream_t)stream, dev_view(m),          \
+                           topn_score_dev, topn_cw_dev, senscr_dev, best_dev, flags, total_frames); } break;
+    switch (m->topn) { PSGPU_SEN_GEN(1) PSGPU_SEN_GEN(2) PSGPU_SEN_GEN(3) PSGPU_SEN_GEN(4) PSGPU_SEN_GEN(5) PSGPU_SEN_GEN(6) PSGPU_SEN_GEN(7)
+                       default: PSGPU_SEN_GEN(8) }
+#undef PSGPU_SEN_GEN
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
 }

@@ -65,6 +65,33 @@ def test_pipeline_tables_equal_the_reference_decoders(tables, lists):
     p.close()
 
 
+@pytest.mark.parametrize("case", ["goforward_topn2", "goforward_topn6_ds2", "numbers_topn1", "numbers_topn8_ds3"])
+def test_pipeline_with_other_topn_and_ds_equals_the_reference_decoders(tables, case):
+    """-topn / -ds other than the model's defaults (ptm_mgau.c:804-896): the pipeline's scorer stage goes through the any-shape
+    batched kernels (ptm_batch_topn_generic, ptm_senone_kernel<N>) and the search reads their score rows; the first pass's tables and
+    hypothesis are the reference decoder's with the same knobs (oracle/make_golden.py fwdtree_topn), twice in one batch beside an
+    utterance shorter than the look-ahead window"""
+    import pocketsphinx_amd as P
+    g = _load("fwdtree_result_%s.npz" % case)
+    knobs = dict(zip(g["knobs"][0::2], g["knobs"][1::2]))
+    t2 = dict(tables); t2["max_topn"] = np.array([int(knobs["topn"])], np.int32); t2["ds_ratio"] = np.array([int(knobs.get("ds", 1))], np.int32)
+    gt = dict(_load("fwdtree_trace_goforward.npz")); gt["par"] = g["par"]
+    p = P.DecodePipeline(_load("mfcc_en_us_goforward.npz"), t2, _load("fwdtree_static_en_us_turtle.npz"), g["par"], gt)
+    clip = _load("speech_clips.npz")[case.split("_")[0]]
+    p.run([clip, clip[:700], clip])
+    hn, hyp, res = p.fetch()
+    assert int(res[1, 2]) == 0 and int(hn[1, 0]) == 0
+    for u in (0, 2):
+        r = p.tables(u, res)
+        assert r["status"] == 0 and r["n_frame"] == int(g["n_frame"][0])
+        assert r["bp"].shape == g["bp"].shape and np.array_equal(r["bp"], g["bp"]), "utterance %d: back-pointer table" % u
+        assert np.array_equal(r["bscore_stack"], g["bscore_stack"]) and np.array_equal(r["bp_table_idx"], g["bp_table_idx"])
+        score, words = P.backtrace(r, int(g["par"][20]))
+        assert int(hn[u, 1]) == score == int(g["hyp_score"][0])
+        assert [(int(a), int(b)) for a, b in g["seg"][:, :2]] == [(sf, ef) for _, sf, ef in words]
+    p.close()
+
+
 def test_pipeline_session_second_utterance_equals_the_reference_decoders(tables):
     """session mode (psgpu_decode_session): numbers.raw then goforward.raw through ONE pipeline object, one utterance per
     call.  The reference's decoder, having decoded numbers.raw first, produces other tables for goforward.raw than a new

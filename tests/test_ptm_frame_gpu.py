@@ -45,8 +45,16 @@ def test_senlog_replay_gpu(tables, gpu_model, case):
     assert np.array_equal(scr[g["sample_idx"]], g["call_scr_sample"])
     st.close()
     if own is not None:
-        with pytest.raises(P.PsgpuError):        # the batched entry is specialised and says so
-            P.PtmMgau(own).score_utts(g["call_feat"][:4], [4])
+        # the batched entry serves the shape too (round 6: ptm_batch_topn_generic): the utterance's frames in order -- the first call of
+        # every frame of this decode is the phone loop's, all codebooks active -- against the pinned oracle with the same knobs
+        fr = g["call_frame"]
+        first = np.array([np.nonzero(fr == t)[0][0] for t in range(int(fr.max()) + 1)])
+        feats = g["call_feat"][first]
+        r = P.PtmMgau(own).score_utts(feats, [feats.shape[0]])
+        o = pso.OraclePTM(tables, topn=int(pr.get("topn", 4)), ds_ratio=int(pr.get("ds", 1)))
+        scr_o, cw_o, raw_o = o.score_utt(feats, reset_hist=True)
+        assert np.array_equal(r["senscr"], scr_o)
+        assert np.array_equal(r["topn_cw"].reshape(cw_o.shape), cw_o) and np.array_equal(r["topn_score"].reshape(raw_o.shape), raw_o)
         own.close()
 
 
