@@ -253,6 +253,28 @@ int psgpu_feat_1s_c_d_dd_dev(const float *cep_dev, const int32_t *utt_off_dev, i
 int psgpu_feat_1s_c_d_dd(const float *cep, const int32_t *utt_off, int32_t n_utt, int32_t cepsize,
                          float *feat);
 
+/* ---- the same two stages for live decoders: audio and cepstra arrive in pieces ---------------------------------
+ * psgpu_fe_stream_step_dev: fe_process_frames on a piece of audio per stream (fe_interface.c:352-512; + fe_end_utt, :514-533,
+ * when a stream's utterance ends): work_dev holds, per stream u, the samples its earlier steps left unframed followed by the new
+ * ones at work_dev[samp[2u]] (samp[2u + 1] of them) with the pre-emphasis prior in the slot before; n_frames[u] frames are made of
+ * them (full frames at multiples of frame_shift; a last frame shorter than frame_size is zero-padded); the noise tracker's state
+ * per stream goes on in noise_dev [n][4][n_filt] / undefined_dev [n] as in psgpu_fe_process_utts_dev.  Cepstra back to back in
+ * cep_dev, their offsets in frame_off_dev [n + 1].  No dither.
+ * psgpu_feat_live_step_dev: feat_s2mfc2feat_live piece by piece (feat.c:1310-1420) with cmn_live's running mean (cmn_live.c:65-150) for
+ * "1s_c_d_dd": per stream a list of ops (n cepstra, flags: 1 beginutt, 2 endutt, 4 feat_update_stats only) = the calls the
+ * reference's acmod makes (ops_dev [..][2], op_off_dev [n + 1]); state_dev [n][psgpu_feat_live_state_words(cepsize)] carries mean, sum,
+ * frame count and the feature window between steps (psgpu_feat_live_state_init: a new decoder's, the mean from -cmninit); the
+ * feature frames the ops release go to feat_dev at row feat_off_dev[u].  Bit-exact against the reference's chunked
+ * acmod_process_raw (oracle/ref_dump.c livefeat).  psgpu_decode_streams_step_pcm drives both. */
+int psgpu_fe_stream_step_dev(psgpu_fe_t *fe, const int16_t *work_dev, const int64_t *samp, const int32_t *n_frames, int32_t n_streams,
+                             double *noise_dev, int32_t *undefined_dev, float *cep_dev, int32_t *frame_off_dev, void *stream);
+int32_t psgpu_fe_frame_size(const psgpu_fe_t *fe);
+int32_t psgpu_fe_frame_shift(const psgpu_fe_t *fe);
+int32_t psgpu_feat_live_state_words(int32_t cepsize);
+int psgpu_feat_live_state_init(float *state_host, int32_t cepsize, const float *cmninit, int32_t n_init);
+int psgpu_feat_live_step_dev(const float *cep_dev, const int32_t *cep_off_dev, const int32_t *ops_dev, const int32_t *op_off_dev,
+                             const int32_t *feat_off_dev, int32_t n_streams, int32_t cepsize, float *state_dev, float *feat_dev, void *stream);
+
 /* ---- per-call scoring state: the ps_mgau_t::frame_eval replacement -------
  * One object per decoder.  Replaces the mutable part of ptm_mgau_t
  * (ptm_mgau.h:68-97): the history ring hist[n_fast_hist] of top-N lists and
@@ -959,6 +981,27 @@ int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream);
  * inherits what a decoder's does -- the scorer's ring slot that seeds its first frame and the multiplexed channels' per-state ssids
  * (psgpu_decode_session's carry-over, kept per stream).  The stream's previous utterance must have had its final step. */
 int psgpu_decode_streams_next_utt(psgpu_decode_t *d, int32_t u, void *stream);
+/* The streams fed with AUDIO (PSGPU_CAP_STREAMS_PCM): a batch of live decoders from ps_process_raw(full_utt = FALSE) on
+ * (pocketsphinx.c:1210-1246).  _pcm_begin = psgpu_decode_streams_begin + per stream a new decoder's front half: the front end's
+ * overflow samples and pre-emphasis prior, its noise tracker, the live cepstral mean (cmninit [n_cmninit]: -cmninit, config_macro.h:510,
+ * "40,3,-1" by default) and the feature window, all on the device; grow_feat = the reference decoder's acmod_set_grow (TRUE with
+ * -fwdflat yes, ngram_search.c:147): it decides how the reference cuts a call's cepstra into pieces -- and whether an utterance's last
+ * cepstra can be dropped at the feature buffer's end (acmod.c:718-723).  _step_pcm: pcm = the step's samples, stream after stream
+ * (n_samples [n] of them), one ps_process_raw call per stream with a non-zero count; final_flags[u]: + ps_end_utt.  The host walks the
+ * reference's buffer counters for the step (which frames, which pieces, how many feature frames: integer bookkeeping); the
+ * arithmetic runs on the device and the step's feature frames go straight into psgpu_decode_streams_step's stages.  n_new_out [n]
+ * (or NULL) receives the feature frames each stream gained.  A stream's next utterance: psgpu_decode_streams_next_utt (noise tracker,
+ * mean and window go on, as fe_start_utt / acmod_start_utt leave them) or _restart (a new decoder). */
+/* The reference's counters for ONE utterance from its start, host only (no device): chunks [n_chunks] = the sample counts of the
+ * ps_process_raw calls, final_ = ps_end_utt after them.  ops_out [ops_cap][2] (or NULL) receives the feat_s2mfc2feat_live calls as
+ * (cepstra, flags: 1 beginutt, 2 endutt, 4 statistics only); *n_cepstra the frames the front end made, *n_feat_frames the feature frames
+ * the searches received. */
+int psgpu_live_pieces(int32_t frame_size, int32_t frame_shift, int32_t window, int32_t pl_window, int32_t grow_feat, const int64_t *chunks,
+                      int32_t n_chunks, int32_t final_, int32_t *ops_out, int32_t ops_cap, int32_t *n_ops, int32_t *n_cepstra, int32_t *n_feat_frames);
+int psgpu_decode_streams_pcm_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max_frames, int32_t max_step_frames, const float *cmninit,
+                                   int32_t n_cmninit, int32_t grow_feat, void *stream);
+int psgpu_decode_streams_step_pcm(psgpu_decode_t *d, const int16_t *pcm, const int64_t *n_samples, const uint8_t *final_flags, int32_t *n_new_out,
+                                  void *stream);
 int32_t psgpu_decode_tables_grown(const psgpu_decode_t *d);
 /* utterance u's tables to the host, cut to the sizes `result` reported: bp [10][n_bp] (column-major: ten columns of
  * n_bp), bss [n_bss], idx [n_idx]; waits for the stream.  What a binding needs to fill a bptbl_t array.  After

@@ -338,6 +338,30 @@ def fwdtree_topn_only():
               os.path.getsize(os.path.join(GOLD, "fwdtree_result_%s.npz" % name)))
 
 
+LIVE_CASES = [("goforward", 2, [1600]), ("goforward", 3, [317]), ("numbers", 3, [800, 2400]), ("goforward", 2, [100, 5000, 333, 1601, 409, 411, 160]),
+              ("numbers", 2, [570]), ("goforward", 2, [410, 160, 160, 250]), ("numbers", 2, [16000])]
+
+
+def livefeat_only():
+    """What a LIVE decoder's acoustic front half hands its searches (ref_dump livefeat: chunked acmod_process_raw -- overflow samples,
+    cepstrum buffer pieces, cmn_live, the feature window -- over successive utterances of one decoder), for lists of chunk sizes,
+    with the growing feature buffer of -fwdflat yes and without: the hash of every feature frame, the frame counts per
+    utterance, the running mean after each, and the first case's frames in full."""
+    out = {}
+    for gi, grow in enumerate(("yes", "no")):
+        for ci, (name, nutt, chunks) in enumerate(LIVE_CASES):
+            d = ref_dump("livefeat", os.path.join(REF, "data", name + ".raw"), nutt, ",".join(str(c) for c in chunks), extra=("fwdflat", grow))
+            k = "g%d_c%d_" % (gi, ci)
+            out[k + "hash"] = row_hash(d["feat"]); out[k + "utt_frames"] = d["utt_frames"]; out[k + "mean"] = d["cmn_mean_after"]
+            out[k + "chunks"] = np.array(chunks, np.int32); out[k + "nutt"] = np.array([nutt], np.int32)
+            out[k + "clip"] = np.frombuffer(name.encode(), np.uint8)
+            if ci == 0:
+                out[k + "feat"] = d["feat"]
+            print("livefeat", grow, name, chunks, list(d["utt_frames"]))
+    np.savez_compressed(os.path.join(GOLD, "livefeat_en_us.npz"), **out)
+    print(os.path.getsize(os.path.join(GOLD, "livefeat_en_us.npz")))
+
+
 def fwdtree_session():
     """the SECOND utterance of a session (REFDUMP_WARMUP: the decoder decodes another utterance first): the permanent
     multiplexed channels start with the per-state ssids the first one left (hmm_clear keeps them, hmm.c:181-196) --
@@ -589,6 +613,8 @@ if __name__ == "__main__":
         mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":
         dynfeat_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "livefeat":
+        livefeat_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree_topn":
         fwdtree_topn_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "ptm_topn":

@@ -97,8 +97,27 @@ main(int argc, char **argv)
         ps_seg_t *seg;
         double t0, dt;
         int first = 1;
-        reset_decoder(ps);
+        /* REFDEC_CHUNKS="1600,317,...": the utterance through ps_process_raw(full_utt = FALSE) in pieces of these sizes (the list
+         * repeats) -- a live decoder: running cepstral mean, feature frames three cepstra behind (pocketsphinx.c:1210-1246).
+         * REFDEC_SESSION=1: the decoder is NOT put back between the utterances (its noise tracker, cepstral mean and feature window go on). */
+        const char *chunks = getenv("REFDEC_CHUNKS");
+        if (!(getenv("REFDEC_SESSION") && u > 0)) reset_decoder(ps);
         t0 = cpu_s();
+        if (chunks && *chunks) {
+            int32 csz[64]; int nc = 0, k = 0; size_t at = 0;
+            char *cp = strdup(chunks), *tok;
+            for (tok = strtok(cp, ","); tok && nc < 64; tok = strtok(NULL, ",")) csz[nc++] = atoi(tok);
+            free(cp);
+            if (nc == 0 || ps_start_utt(ps) < 0) return 3;
+            while (at < per) {
+                size_t take = per - at < (size_t)csz[k % nc] ? per - at : (size_t)csz[k % nc];
+                ++k;
+                if (ps_process_raw(ps, pcm + u * per + at, take, FALSE, FALSE) < 0) return 3;
+                at += take;
+            }
+            if (ps_end_utt(ps) < 0) return 3;
+        }
+        else
         if (ps_start_utt(ps) < 0 || ps_process_raw(ps, pcm + u * per, per, FALSE, TRUE) < 0 || ps_end_utt(ps) < 0) {
             fprintf(stderr, "decode of utterance %zu failed\n", u);
             return 3;

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <unistd.h>
 
 #include <pocketsphinx.h>
 #include "pocketsphinx_internal.h"
@@ -1172,6 +1173,84 @@ cmd_lm(ngram_model_t *lmset, const char *qfile)
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* livefeat: what the decoder's acoustic front half hands its searches when ps_process_raw is fed a recording in CHUNKS
+ * (full_utt = FALSE: pocketsphinx.c:1210-1246; acmod_process_raw / acmod_process_mfcbuf / acmod_process_cep, acmod.c:565-762;
+ * fe_process_frames with its overflow buffer, fe_interface.c:352-512; feat_s2mfc2feat_live with cmn_live, feat.c:1300-1420,
+ * cmn_live.c:86-194): the chunk sizes come from a list that repeats; every feature frame is taken out of the acmod's feature
+ * buffer as ps_search_forward would consume it (acmod_advance after each).  `nutt` utterances back to back on ONE decoder
+ * after ps_start_stream: the noise tracker and the running cepstral mean carry over from one to the next.
+ * Output: feat [total][dim], utt_frames [nutt], the cepstral mean after each utterance, the chunk list. */
+static int
+cmd_livefeat(ps_decoder_t *ps, const char *rawpath, int nutt, const char *chunks)
+{
+    acmod_t *acmod = ps->acmod;
+    size_t n; int16 *pcm = read_pcm(rawpath, &n);
+    int dim = feat_dimension(acmod->fcb), ceplen = feat_cepsize(acmod->fcb);
+    int32 csz[64]; int nc = 0, u, k = 0;
+    float *out = NULL; size_t no = 0, cap = 0;
+    int32 *uf = ckd_calloc(nutt, sizeof(int32));
+    float *means = ckd_calloc((size_t)nutt * ceplen, sizeof(float));
+    char *cp = ckd_salloc(chunks), *tok;
+    for (tok = strtok(cp, ","); tok && nc < 64; tok = strtok(NULL, ",")) csz[nc++] = atoi(tok);
+    if (nc == 0) return 2;
+    ps_start_stream(ps);
+    for (u = 0; u < nutt; ++u) {
+        int16 const *p = pcm; size_t left = n;
+        int fr0 = (int)no;
+        FILE *mfh = tmpfile();
+        acmod_start_utt(acmod);
+        acmod_set_mfcfh(acmod, mfh);                  /* (the cepstra as acmod_process_cep receives them, before cmn_live) */
+        for (;;) {
+            size_t take = left < (size_t)csz[k % nc] ? left : (size_t)csz[k % nc];
+            int16 const *q = p; size_t m = take;
+            ++k;
+            /* ps_process_raw's loop (pocketsphinx.c:1228-1243) with the searches replaced by the read-out of their input */
+            while (m) {
+                if (acmod_process_raw(acmod, &q, &m, FALSE) < 0) return 2;
+                while (acmod->n_feat_frame > 0) {
+                    int inptr = acmod->feat_outidx;
+                    if (no + 1 > cap) { cap = cap ? 2 * cap : 4096; out = realloc(out, sizeof(float) * cap * dim); }
+                    memcpy(out + no * dim, acmod->feat_buf[inptr][0], sizeof(float) * dim);
+                    ++no;
+                    acmod_advance(acmod);
+                }
+            }
+            p += take; left -= take;
+            if (left == 0) break;
+        }
+        /* ps_end_utt (pocketsphinx.c:1313-1333): acmod_end_utt, then the searches drain what it released */
+        {
+            FILE *keep = fdopen(dup(fileno(mfh)), "rb");      /* (acmod_end_utt closes its handle) */
+            long sz; float *cb; char nm[32];
+            acmod_end_utt(acmod);
+            fseek(keep, 0, SEEK_END); sz = ftell(keep); fseek(keep, 4, SEEK_SET);
+            cb = malloc(sz > 4 ? sz - 4 : 4);
+            if (sz > 4 && fread(cb, 1, sz - 4, keep) != (size_t)(sz - 4)) return 2;
+            fclose(keep);
+            { long z; for (z = 0; z < (sz - 4) / 4; ++z) { uint32_t *w = (uint32_t *)cb + z; *w = __builtin_bswap32(*w); } }   /* (acmod_log_mfc writes big-endian) */
+            snprintf(nm, sizeof nm, "cep%d", u);
+            put2(nm, 'f', (sz - 4) / 4 / ceplen, ceplen, cb);
+            free(cb);
+        }
+        while (acmod->n_feat_frame > 0) {
+            int inptr = acmod->feat_outidx;
+            if (no + 1 > cap) { cap = cap ? 2 * cap : 4096; out = realloc(out, sizeof(float) * cap * dim); }
+            memcpy(out + no * dim, acmod->feat_buf[inptr][0], sizeof(float) * dim);
+            ++no;
+            acmod_advance(acmod);
+        }
+        uf[u] = (int32)no - fr0;
+        memcpy(means + (size_t)u * ceplen, acmod->fcb->cmn_struct->cmn_mean, sizeof(float) * ceplen);
+    }
+    puti("dim", dim); puti("n_utt", nutt); puti("n_samples", (int32_t)n);
+    put1("chunks", 'i', nc, csz);
+    put1("utt_frames", 'i', nutt, uf);
+    put2("cmn_mean_after", 'f', nutt, ceplen, means);
+    put2("feat", 'f', (int64_t)no, dim, out);
+    return 0;
+}
+
 int
 main(int argc, char **argv)
 {
@@ -1206,6 +1285,8 @@ main(int argc, char **argv)
         rc = cmd_senlog(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]));
     } else if (!strcmp(cmd, "dynfeat") && xa > 6) {
         rc = cmd_dynfeat(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+    } else if (!strcmp(cmd, "livefeat") && xa > 8) {
+        rc = cmd_livefeat(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]), argv[8]);
     } else if (!strcmp(cmd, "mfcc") && xa > 7) {
         rc = cmd_mfcc(make_decoder(modeldir, lm, dict, nextra, extra)->acmod->fe, argv[6], atoi(argv[7]));
     } else if (!strcmp(cmd, "mfcc_cfg") && xa > 7) {

@@ -9,9 +9,144 @@
 // (integration/psgpu_device_decode.c: tables read out of a live decoder) and a table-driven caller (bench.py: tables from
 // a dump) run the same code.
 #include "psgpu_internal.h"
+#include <algorithm>
 #include <cstring>
 #include <time.h>
 #include <vector>
+
+// ---- what the reference's acmod does with a live decoder's audio, as counters ------------------------------------------------------
+// ps_process_raw(full_utt = FALSE) (pocketsphinx.c:1210-1246) hands its samples to acmod_process_raw in a loop; that runs the front
+// end into a circular buffer of 2 x window + 1 cepstra (fe_process_frames with its overflow buffer, fe_interface.c:352-512), turns the
+// buffer's content into feature frames piece by piece (acmod_process_mfcbuf / acmod_process_cep, acmod.c:565-762, each piece one
+// feat_s2mfc2feat_live call -- one cmn_live call: the running mean moves only between pieces) and the searches consume every feature
+// frame before the next round (ps_search_forward).  Which frames the front end makes in a call, how the cepstra fall into pieces, and
+// how many feature frames each piece releases is integer bookkeeping on the sample counts alone: LiveSim walks the reference's
+// counters, statement by statement, and lists the pieces; the kernels (psgpu_fe_stream_step_dev, feat_live_kernel) do the arithmetic.
+// Two of the reference's oddities come with the counters and are reproduced: a decoder without a growing feature buffer (-fwdflat
+// no: acmod_set_grow, ngram_search.c:147) that meets the buffer's end at an utterance's end drops the utterance's last cepstra
+// (acmod.c:718-723, "FIXME"), and an utterance whose first call brings less than a frame of audio starts without the replication of
+// its first frame (feat.c:1360) -- its first feature frames see the previous utterance's last cepstra in the window.
+// (oracle/ref_dump.c `livefeat` dumps what the reference hands its searches for a list of chunk sizes; tests/test_streams_pcm_gpu.py.)
+struct LiveSim {
+    int fs = 410, sh = 160, win = 3, MA = 7, FA = 12, FA0 = 12;
+    bool grow = false;
+    int ov = 0;                                           // fe_t.num_overflow_samps
+    int state = 0, n_mfc = 0, outidx = 0, n_feat = 0, feat_outidx = 0, nbuf = 0;      // acmod_t / feat_t counters (state: 1 started, 2 processing, 3 ended)
+    std::vector<int32_t> *ops = nullptr;                  // (n, flags) pairs: flags 1 begin, 2 end, 4 statistics only
+    int made = 0, feats = 0;
+    void setup(int frame_size, int frame_shift, int window, int pl_window, bool grow_feat)
+    {
+        fs = frame_size; sh = frame_shift; win = window; MA = 2 * win + 1; FA0 = FA = MA + pl_window; grow = grow_feat;
+        if (grow && FA < 128) FA0 = FA = 128;
+    }
+    void start() { ov = 0; state = 1; n_mfc = 0; outidx = 0; n_feat = 0; feat_outidx = 0; }      // fe_start_utt + acmod_start_utt (acmod.c:407-421)
+    int fe_run(long long &n_samps, int room)              // fe_process_frames_int16 (fe_interface.c:352-512): frames made
+    {
+        if (n_samps + ov < fs) { if (n_samps > 0) { ov += (int)n_samps; n_samps = 0; } return 0; }
+        if (room < 1) return 0;
+        long long consumed = 0;
+        long long fc = 1 + (n_samps + ov - fs) / sh;
+        if (fc > room) fc = room;
+        if (ov) { const int off = fs - ov; consumed += off; n_samps -= off; ov -= sh; }
+        else { consumed += fs; n_samps -= fs; }
+        for (long long i = 1; i < fc; ++i) { consumed += sh; n_samps -= sh; if (ov > 0) ov -= sh; }
+        if (ov <= 0) {
+            long long nov = n_samps < sh ? n_samps : sh;
+            ov = fs - sh;
+            if (ov > consumed) ov = (int)consumed;
+            ov += (int)nov;
+            if (ov > 0) { consumed += nov; n_samps -= nov; }
+        }
+        else {
+            long long nov = consumed + n_samps;
+            if (nov > fs - ov) nov = fs - ov;
+            ov += (int)nov;
+            if (nov > consumed) { nov -= consumed; consumed += nov; n_samps -= nov; }
+        }
+        return (int)fc;
+    }
+    int live(int ncep, bool begin, bool end)              // feat_s2mfc2feat_live's counters (feat.c:1310-1420; never near LIVEBUFBLOCKSIZE here)
+    {
+        if (begin) nbuf = 0;
+        int nb = nbuf + ncep + (end ? win : 0);
+        ops->push_back(ncep); ops->push_back((begin ? 1 : 0) | (end ? 2 : 0));
+        const int nfeat = nb - win;
+        if (nfeat <= 0) { nbuf = nb; return 0; }
+        nbuf = nb - nfeat;
+        feats += nfeat;
+        return nfeat;
+    }
+    int process_cep(int n_frames)                         // acmod_process_cep (acmod.c:671-762)
+    {
+        const int orig = n_frames;
+        int ncep = n_frames, nfeat = n_frames;
+        if (state == 3) nfeat += win; else if (state == 1) nfeat -= win;
+        if (nfeat > FA - n_feat) {
+            if (grow || state == 3) FA = FA + nfeat;
+            else ncep -= (nfeat - (FA - n_feat));
+        }
+        int inptr;
+        if (grow) { inptr = feat_outidx + n_feat; while (inptr + nfeat >= FA) FA *= 2; }
+        else inptr = (feat_outidx + n_feat) % FA;
+        if (inptr + nfeat > FA && state == 3) return 0;   // "we can't split the last frame drop properly": the cepstra stay behind
+        if (inptr + nfeat > FA) {
+            const int ncep1 = FA - inptr;
+            const int nf = live(ncep1, state == 1, false);
+            n_feat += nf; inptr = (inptr + nf) % FA;
+            n_frames -= ncep1; ncep -= ncep1;
+        }
+        n_feat += live(ncep, state == 1, state == 3);
+        n_frames -= ncep;
+        if (state == 1) state = 2;
+        return orig - n_frames;
+    }
+    void process_mfcbuf()                                 // acmod_process_mfcbuf (acmod.c:565-599)
+    {
+        int ncep = n_mfc;
+        if (outidx + ncep > MA) {
+            int ncep1 = MA - outidx;
+            const int saved = state;
+            if (state == 3) state = 2;
+            ncep1 = process_cep(ncep1);
+            ncep -= ncep1; n_mfc -= ncep1; outidx = (outidx + ncep1) % MA;
+            state = saved;
+        }
+        ncep = process_cep(ncep);
+        n_mfc -= ncep; outidx = (outidx + ncep) % MA;
+    }
+    void drain() { feat_outidx += n_feat; if (!grow) feat_outidx %= FA; n_feat = 0; }      // ps_search_forward: every feature frame consumed
+    void process_raw(long long n_samps)                   // one ps_process_raw call (acmod_process_raw, acmod.c:601-668, in its loop)
+    {
+        while (n_samps) {
+            int room = MA - n_mfc, inptr = (outidx + n_mfc) % MA;
+            bool done = false;
+            while (inptr + room > MA) {
+                const int f = fe_run(n_samps, MA - inptr);
+                made += f; n_mfc += f; room -= f; inptr = (inptr + f) % MA;
+                if (f == 0) { done = true; break; }
+            }
+            if (!done) { const int f = fe_run(n_samps, room); made += f; n_mfc += f; }
+            process_mfcbuf();
+            drain();
+        }
+    }
+    int end()                                             // acmod_end_utt (acmod.c:423-467); returns the tail frame's samples (0: none)
+    {
+        state = 3;
+        int tail = 0;
+        if (n_mfc < MA) {
+            if (ov > 0) { tail = ov; ++made; ++n_mfc; process_mfcbuf(); }
+            else { ops->push_back(0); ops->push_back(4); }
+            ov = 0;
+        }
+        else { ops->push_back(0); ops->push_back(4); }
+        drain();
+        return tail;
+    }
+};
+
+struct psgpu_decode_s;
+static int dec_pcm_stream_reset(psgpu_decode_s *d, int u, bool new_decoder, hipStream_t st);
 
 struct psgpu_decode_s {
     psgpu_decode_config_t cfg;
@@ -111,6 +246,19 @@ struct psgpu_decode_s {
     uint8_t *d_sslot = nullptr;
     int32_t *d_smpx_in = nullptr, *d_smpx_out = nullptr;
     std::vector<uint8_t> ls_slot, ls_mpx;
+    // psgpu_decode_streams_pcm_begin / _step_pcm: the streams fed with AUDIO -- per stream the front end's unframed samples with the
+    // pre-emphasis prior in front (d_pcarry [n][pc_slots]), its noise tracker (d_pnoise, d_pundef), the live cepstral mean and the feature
+    // window (d_pfeat: psgpu_feat_live_state_words each), and on the host the reference's buffer counters (LiveSim)
+    bool pcm_streams = false;
+    int32_t pc_slots = 0, pc_fs = 0, pc_sh = 0;
+    std::vector<LiveSim> pc_sim;
+    std::vector<int32_t> pc_ncarry, pc_ops, pc_h;
+    std::vector<float> pc_init;                          // a new decoder's feature state (cmninit)
+    int16_t *d_pcarry = nullptr, *d_pwork = nullptr, *d_ppcm = nullptr;
+    double *d_pnoise = nullptr;
+    int32_t *d_pundef = nullptr, *d_pdesc = nullptr, *d_pops = nullptr, *d_pfoff = nullptr;
+    float *d_pfeat = nullptr, *d_pcep = nullptr;
+    size_t pc_work_cap = 0, pc_pcm_cap = 0, pc_ops_cap = 0, pc_cep_cap = 0;
 };
 
 static void dec_mark(psgpu_decode_s *d, int i, hipStream_t st) { if (d->timing) hipEventRecord(d->ev[i], st); }
@@ -265,6 +413,8 @@ void psgpu_decode_free(psgpu_decode_t *d)
     DFREE(d->d_lseed[0]); DFREE(d->d_lseed[1]); DFREE(d->d_seed0); DFREE(d->d_pl_carry); DFREE(d->d_off1);
     DFREE(d->d_win[0]); DFREE(d->d_win[1]); DFREE(d->d_wpen[0]); DFREE(d->d_wpen[1]); DFREE(d->d_ls); DFREE(d->d_sseed[0]); DFREE(d->d_sseed[1]);
     DFREE(d->d_splc); DFREE(d->d_sslot); DFREE(d->d_smpx_in); DFREE(d->d_smpx_out);
+    DFREE(d->d_pcarry); DFREE(d->d_pwork); DFREE(d->d_ppcm); DFREE(d->d_pnoise); DFREE(d->d_pundef); DFREE(d->d_pdesc); DFREE(d->d_pops);
+    DFREE(d->d_pfoff); DFREE(d->d_pfeat); DFREE(d->d_pcep);
     for (int i = 0; i < 7; ++i) if (d->ev[i]) hipEventDestroy(d->ev[i]);
     if (d->ev_pre) hipEventDestroy(d->ev_pre);
     if (d->ev_srch) hipEventDestroy(d->ev_srch);
@@ -931,6 +1081,7 @@ int psgpu_decode_streams_restart(psgpu_decode_t *d, int32_t u, void *stream)
     int rc;
     d->ls_T[u] = 0; d->ls_S[u] = 0; d->ls_wbase[u] = 0; d->ls_woff[u] = 0; d->ls_fresh[u] = 1;
     d->ls_slot[u] = 0; d->ls_mpx[u] = 0;                  // (a new decoder: nothing inherited)
+    if (d->pcm_streams && (rc = dec_pcm_stream_reset(d, u, true, st))) return rc;
     if (!d->ls_first && (rc = psgpu_fwdtree_search_restart(d->cfg.ft, u, st))) return rc;
     if ((rc = psgpu_phone_loop_carry_restart(d->d_splc, u, st))) return rc;
     const size_t per = (size_t)std::max(1, d->n_chain * d->topn);
@@ -951,16 +1102,42 @@ int psgpu_decode_streams_next_utt(psgpu_decode_t *d, int32_t u, void *stream)
     int rc;
     const size_t per = (size_t)std::max(1, d->n_chain * d->topn), mpxw = (size_t)std::max(1, psgpu_fwdtree_n_mpx_channels(d->cfg.ft)) * d->n_emit;
     const uint8_t slot = d->ls_slot[u];
+    std::vector<float> fstate;
+    LiveSim keep;
+    int32_t undef = 0;
+    if (d->pcm_streams) {
+        // (the decoder's front half goes on: noise tracker, running cepstral mean and the feature ring stay -- fe_start_utt /
+        //  acmod_start_utt reset the overflow buffer, the prior and the buffers' counters only)
+        fstate.resize(d->pc_init.size());
+        PSGPU_HIP(hipMemcpyAsync(fstate.data(), d->d_pfeat + (size_t)u * fstate.size(), 4 * fstate.size(), hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipMemcpyAsync(&undef, d->d_pundef + u, 4, hipMemcpyDeviceToHost, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+        keep = d->pc_sim[u];
+    }
     if ((rc = psgpu_decode_streams_restart(d, u, stream))) return rc;       // (search, phone loop, window; the lists: a new scorer's)
+    if (d->pcm_streams) {
+        d->pc_sim[u].nbuf = keep.nbuf; d->pc_sim[u].FA = keep.FA;
+        PSGPU_HIP(hipMemcpyAsync(d->d_pfeat + (size_t)u * fstate.size(), fstate.data(), 4 * fstate.size(), hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipMemcpyAsync(d->d_pundef + u, &undef, 4, hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+    }
     d->ls_slot[u] = slot; d->ls_mpx[u] = 1;
     PSGPU_HIP(hipMemcpyAsync(d->d_smpx_in + (size_t)u * mpxw, d->d_smpx_out + (size_t)u * mpxw, 4 * mpxw, hipMemcpyDeviceToDevice, st));
     if (slot) PSGPU_HIP(hipMemcpyAsync(d->d_sseed[d->ls_cur] + (size_t)u * per, d->d_sslot + (size_t)u * per, per, hipMemcpyDeviceToDevice, st));
     return PSGPU_OK;
 }
 
+static int dec_streams_step_core(psgpu_decode_t *d, const float *feat, bool feat_on_device, const int32_t *n_new, const uint8_t *final_flags, void *stream);
+
 int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_t *n_new, const uint8_t *final_flags, void *stream)
 {
     PSGPU_REQUIRE(d && d->streams && n_new, "psgpu_decode_streams_step: no streams (psgpu_decode_streams_begin) / NULL argument");
+    PSGPU_REQUIRE(!d->pcm_streams, "psgpu_decode_streams_step: these streams are fed with audio (psgpu_decode_streams_step_pcm)");
+    return dec_streams_step_core(d, feat, false, n_new, final_flags, stream);
+}
+
+static int dec_streams_step_core(psgpu_decode_t *d, const float *feat, bool feat_on_device, const int32_t *n_new, const uint8_t *final_flags, void *stream)
+{
     hipStream_t st = (hipStream_t)stream;
     const int n = d->ls_n, lag = d->ls_lag;
     int rc;
@@ -987,9 +1164,9 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
     }
     off1[n] = (int32_t)total; uoff[n] = 0;
     PSGPU_REQUIRE(wtot <= d->win_rows, "psgpu_decode_streams_step: %zu rows exceed the window buffer (%zu)", wtot, d->win_rows);
-    PSGPU_REQUIRE(total == 0 || feat, "psgpu_decode_streams_step: NULL features");
+    PSGPU_REQUIRE(total == 0 || feat || feat_on_device, "psgpu_decode_streams_step: NULL features");
     PSGPU_HIP(hipMemcpyAsync(d->d_ls, h.data(), 4 * h.size(), hipMemcpyHostToDevice, st));
-    if (total) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * d->veclen, hipMemcpyHostToDevice, st));
+    if (total && !feat_on_device) PSGPU_HIP(hipMemcpyAsync(d->d_feat, feat, 4 * total * d->veclen, hipMemcpyHostToDevice, st));
     PSGPU_HIP(hipStreamSynchronize(st));                 // (feat is the caller's)
     const int32_t *const d_off1 = d->d_ls, *const d_uoff = d->d_ls + n + 1, *const d_ext = d_uoff + n + 1, *const d_map = d_ext + 3 * n,
                   *const d_fbase = d_map + 5 * n;
@@ -1055,6 +1232,177 @@ int psgpu_decode_streams_step(psgpu_decode_t *d, const float *feat, const int32_
         d->frame_off[u] = (int32_t)acc; acc += (size_t)d->ls_T[u];
     }
     d->frame_off[n] = (int32_t)acc; d->total = (int32_t)std::min<size_t>(acc, 0x7fffffff);
+    return PSGPU_OK;
+}
+
+// ---- the streams fed with audio ----------------------------------------------------------------------------------------------------
+// assemble: work = per stream [prior | carried samples | the step's new samples]; desc [n][4] = {prior slot's index in work, carried, the new
+// samples' offset in the step's buffer, new}
+__global__ __launch_bounds__(256)
+void dec_pcm_assemble_kernel(const int32_t *__restrict__ desc, const int16_t *__restrict__ carry, int32_t slots, const int16_t *__restrict__ pcm,
+                             int16_t *__restrict__ work)
+{
+    const int u = blockIdx.y;
+    const int32_t w0 = desc[4 * u], nc = desc[4 * u + 1], p0 = desc[4 * u + 2], nn = desc[4 * u + 3];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 1 + nc + nn; i += gridDim.x * 256)
+        work[w0 + i] = i <= nc ? carry[(size_t)u * slots + i] : pcm[p0 + (i - 1 - nc)];
+}
+// ... and what the step leaves unframed goes back: desc2 [n][3] = {prior slot's index in work, samples framed away, samples left}; an
+// utterance that ended leaves nothing and a zero prior (fe_start_utt, fe_interface.c:321-331)
+__global__ __launch_bounds__(256)
+void dec_pcm_carry_kernel(const int32_t *__restrict__ desc2, const int16_t *__restrict__ work, int32_t slots, int16_t *__restrict__ carry)
+{
+    const int u = blockIdx.x;
+    const int32_t w0 = desc2[3 * u], q = desc2[3 * u + 1], keep = desc2[3 * u + 2];
+    for (int i = threadIdx.x; i < 1 + (keep > 0 ? keep : 0); i += 256)
+        carry[(size_t)u * slots + i] = keep < 0 ? (int16_t)0 : work[w0 + q + i];
+}
+
+static int dec_pcm_stream_reset(psgpu_decode_s *d, int u, bool new_decoder, hipStream_t st)
+{
+    d->pc_sim[u].start();
+    d->pc_ncarry[u] = 0;
+    PSGPU_HIP(hipMemsetAsync(d->d_pcarry + (size_t)u * d->pc_slots, 0, 2, st));             // (the prior)
+    if (new_decoder) {                                   // ps_start_stream + a new decoder's feat_t / cmn_t
+        const int one = 1;
+        d->pc_sim[u].nbuf = 0; d->pc_sim[u].FA = d->pc_sim[u].FA0;
+        PSGPU_HIP(hipMemcpyAsync(d->d_pundef + u, &one, 4, hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipMemcpyAsync(d->d_pfeat + (size_t)u * d->pc_init.size(), d->pc_init.data(), 4 * d->pc_init.size(), hipMemcpyHostToDevice, st));
+        PSGPU_HIP(hipStreamSynchronize(st));
+    }
+    return PSGPU_OK;
+}
+
+int psgpu_decode_streams_pcm_begin(psgpu_decode_t *d, int32_t n_streams, int32_t max_frames, int32_t max_step_frames, const float *cmninit,
+                                   int32_t n_cmninit, int32_t grow_feat, void *stream)
+{
+    PSGPU_REQUIRE(d && d->cfg.fe, "psgpu_decode_streams_pcm_begin: the pipeline has no front end");
+    PSGPU_REQUIRE(d->veclen == 3 * d->cepsize, "psgpu_decode_streams_pcm_begin: the live feature computation is 1s_c_d_dd's (feat.c:579-622)");
+    int rc;
+    if ((rc = psgpu_decode_streams_begin(d, n_streams, max_frames, max_step_frames, stream))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    d->pc_fs = psgpu_fe_frame_size(d->cfg.fe); d->pc_sh = psgpu_fe_frame_shift(d->cfg.fe);
+    d->pc_slots = d->pc_fs + 8;
+    const int words = psgpu_feat_live_state_words(d->cepsize);
+    d->pc_init.assign((size_t)words, 0.0f);
+    if ((rc = psgpu_feat_live_state_init(d->pc_init.data(), d->cepsize, cmninit, n_cmninit))) return rc;
+    DFREE(d->d_pcarry); DFREE(d->d_pnoise); DFREE(d->d_pundef); DFREE(d->d_pdesc); DFREE(d->d_pfoff); DFREE(d->d_pfeat);
+    const int n_filt = 64;                               // (the noise tracker's state: at most 64 mel channels, psgpu_fe_create)
+    if ((rc = dec_alloc((void **)&d->d_pcarry, 2 * (size_t)n_streams * d->pc_slots)) || (rc = dec_alloc((void **)&d->d_pnoise, 8 * (size_t)n_streams * 4 * n_filt))
+        || (rc = dec_alloc((void **)&d->d_pundef, 4 * (size_t)n_streams)) || (rc = dec_alloc((void **)&d->d_pdesc, 4 * (size_t)n_streams * 16))
+        || (rc = dec_alloc((void **)&d->d_pfoff, 4 * ((size_t)n_streams + 1) * 4)) || (rc = dec_alloc((void **)&d->d_pfeat, 4 * (size_t)n_streams * words)))
+        return rc;
+    d->pc_sim.assign((size_t)n_streams, LiveSim());
+    d->pc_ncarry.assign((size_t)n_streams, 0);
+    d->pcm_streams = true;
+    for (int u = 0; u < n_streams; ++u) {
+        d->pc_sim[u].setup(d->pc_fs, d->pc_sh, 3, d->cfg.pl_window, grow_feat != 0);
+        d->pc_sim[u].ops = &d->pc_ops;
+        if ((rc = dec_pcm_stream_reset(d, u, true, st))) return rc;
+    }
+    return PSGPU_OK;
+}
+
+int psgpu_decode_streams_step_pcm(psgpu_decode_t *d, const int16_t *pcm, const int64_t *n_samples, const uint8_t *final_flags, int32_t *n_new_out,
+                                  void *stream)
+{
+    PSGPU_REQUIRE(d && d->streams && d->pcm_streams && n_samples, "psgpu_decode_streams_step_pcm: no audio streams (psgpu_decode_streams_pcm_begin) / NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = d->ls_n;
+    int rc;
+    // the reference's counters for the step: frames the front end makes, the pieces, the feature frames they release
+    std::vector<int32_t> &h = d->pc_h;
+    h.assign((size_t)n * 12 + 8, 0);
+    int32_t *const desc = h.data(), *const desc2 = desc + 4 * n, *const nfr = desc2 + 3 * n, *const op_off = nfr + n, *const n_new = op_off + n + 1;
+    std::vector<int64_t> samp(2 * (size_t)n);
+    d->pc_ops.clear();
+    int64_t work = 0, pcm_total = 0, cep_total = 0, feat_total = 0;
+    std::vector<int32_t> foff((size_t)n + 1, 0);
+    for (int u = 0; u < n; ++u) {
+        PSGPU_REQUIRE(n_samples[u] >= 0 && n_samples[u] < ((int64_t)1 << 30), "psgpu_decode_streams_step_pcm: stream %d: %lld samples", u, (long long)n_samples[u]);
+        LiveSim &sim = d->pc_sim[u];
+        const bool fin = final_flags && final_flags[u];
+        PSGPU_REQUIRE(sim.state != 3 || (n_samples[u] == 0 && !fin), "psgpu_decode_streams_step_pcm: stream %d's utterance has ended (psgpu_decode_streams_next_utt / "
+                      "_restart begins the next)", u);
+        sim.made = 0; sim.feats = 0;
+        op_off[u] = (int32_t)(d->pc_ops.size() / 2);
+        const int nc = d->pc_ncarry[u];
+        if (sim.state != 3) {
+            if (n_samples[u] > 0) sim.process_raw(n_samples[u]);
+            int tail = 0;
+            if (fin) tail = sim.end();
+            const int64_t avail = nc + n_samples[u];
+            const int full = sim.made - (tail ? 1 : 0);
+            const int64_t left = avail - (int64_t)full * d->pc_sh;
+            // (an utterance's end without fe_end_utt -- acmod_end_utt with a full cepstrum buffer, acmod.c:428 -- leaves the samples to fe_start_utt)
+            const int64_t expect = fin ? (tail ? tail : left) : sim.ov;
+            PSGPU_REQUIRE(left >= 0 && left == expect && left < d->pc_slots - 1, "psgpu_decode_streams_step_pcm: stream %d: the sample counters "
+                          "disagree (%lld left, %lld in the overflow buffer)", u, (long long)left, (long long)expect);
+            desc2[3 * u + 1] = full * d->pc_sh; desc2[3 * u + 2] = fin ? -1 : (int32_t)left;
+            d->pc_ncarry[u] = fin ? 0 : (int32_t)left;
+        }
+        else { desc2[3 * u + 1] = 0; desc2[3 * u + 2] = nc; }
+        desc[4 * u] = (int32_t)work; desc[4 * u + 1] = nc; desc[4 * u + 2] = (int32_t)pcm_total; desc[4 * u + 3] = (int32_t)n_samples[u];
+        desc2[3 * u] = (int32_t)work;
+        samp[2 * u] = work + 1; samp[2 * u + 1] = nc + n_samples[u];
+        work += 1 + nc + n_samples[u]; pcm_total += n_samples[u];
+        PSGPU_REQUIRE(work < ((int64_t)1 << 31), "psgpu_decode_streams_step_pcm: more than 2^31 samples in a step");
+        nfr[u] = sim.made; cep_total += sim.made;
+        n_new[u] = sim.feats; foff[u] = (int32_t)feat_total; feat_total += sim.feats;
+        PSGPU_REQUIRE(sim.feats <= d->ls_step, "psgpu_decode_streams_step_pcm: stream %d: %d feature frames in one step (at most %d: psgpu_decode_streams_pcm_begin)",
+                      u, sim.feats, d->ls_step);
+    }
+    op_off[n] = (int32_t)(d->pc_ops.size() / 2); foff[n] = (int32_t)feat_total;
+    if (n_new_out) memcpy(n_new_out, n_new, 4 * (size_t)n);
+    PSGPU_REQUIRE(pcm_total == 0 || pcm, "psgpu_decode_streams_step_pcm: NULL audio");
+    // buffers
+    if ((size_t)work > d->pc_work_cap || !d->d_pwork) { DFREE(d->d_pwork); d->pc_work_cap = 0; if ((rc = dec_alloc((void **)&d->d_pwork, 2 * ((size_t)work + work / 2 + 64)))) return rc; d->pc_work_cap = (size_t)work + work / 2 + 64; }
+    if ((size_t)pcm_total > d->pc_pcm_cap || !d->d_ppcm) { DFREE(d->d_ppcm); d->pc_pcm_cap = 0; if ((rc = dec_alloc((void **)&d->d_ppcm, 2 * ((size_t)pcm_total + pcm_total / 2 + 64)))) return rc; d->pc_pcm_cap = (size_t)pcm_total + pcm_total / 2 + 64; }
+    if (d->pc_ops.size() + 2 > d->pc_ops_cap || !d->d_pops) { DFREE(d->d_pops); d->pc_ops_cap = 0; if ((rc = dec_alloc((void **)&d->d_pops, 4 * (2 * d->pc_ops.size() + 64)))) return rc; d->pc_ops_cap = 2 * d->pc_ops.size() + 64; }
+    if ((size_t)cep_total > d->pc_cep_cap || !d->d_pcep) { DFREE(d->d_pcep); d->pc_cep_cap = 0; if ((rc = dec_alloc((void **)&d->d_pcep, 4 * ((size_t)cep_total * 2 + 64) * d->cepsize))) return rc; d->pc_cep_cap = (size_t)cep_total * 2 + 64; }
+    PSGPU_HIP(hipMemcpyAsync(d->d_pdesc, h.data(), 4 * (size_t)(7 * n), hipMemcpyHostToDevice, st));
+    if (pcm_total) PSGPU_HIP(hipMemcpyAsync(d->d_ppcm, pcm, 2 * (size_t)pcm_total, hipMemcpyHostToDevice, st));
+    if (!d->pc_ops.empty()) PSGPU_HIP(hipMemcpyAsync(d->d_pops, d->pc_ops.data(), 4 * d->pc_ops.size(), hipMemcpyHostToDevice, st));
+    // op offsets [n + 1], feature offsets [n + 1] (the cepstra's offsets come from the front end: d_pfoff[0 .. n])
+    int32_t *const d_opoff = d->d_pfoff + (n + 1), *const d_featoff = d_opoff + (n + 1);
+    PSGPU_HIP(hipMemcpyAsync(d_opoff, op_off, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    PSGPU_HIP(hipMemcpyAsync(d_featoff, foff.data(), 4 * ((size_t)n + 1), hipMemcpyHostToDevice, st));
+    PSGPU_HIP(hipStreamSynchronize(st));                 // (pcm, the vectors: the caller's / this call's)
+    {
+        const int64_t most = d->pc_slots + (pcm_total > 0 ? *std::max_element(n_samples, n_samples + n) : 0);
+        hipLaunchKernelGGL(dec_pcm_assemble_kernel, dim3((unsigned)std::min<int64_t>((most + 255) / 256, 64), (unsigned)n), dim3(256), 0, st, d->d_pdesc, d->d_pcarry,
+                           d->pc_slots, d->d_ppcm, d->d_pwork);
+        PSGPU_HIP(hipGetLastError());
+    }
+    if ((rc = psgpu_fe_stream_step_dev(d->cfg.fe, d->d_pwork, samp.data(), nfr, n, d->d_pnoise, d->d_pundef, d->d_pcep, d->d_pfoff, st))) return rc;
+    hipLaunchKernelGGL(dec_pcm_carry_kernel, dim3((unsigned)n), dim3(256), 0, st, d->d_pdesc + 4 * n, d->d_pwork, d->pc_slots, d->d_pcarry);
+    PSGPU_HIP(hipGetLastError());
+    // (the feature rows of the step go where psgpu_decode_streams_step puts the caller's: room for ls_step rows a stream, psgpu_decode_streams_begin)
+    if ((rc = psgpu_feat_live_step_dev(d->d_pcep, d->d_pfoff, d->d_pops, d_opoff, d_featoff, n, d->cepsize, d->d_pfeat, d->d_feat, st))) return rc;
+    return dec_streams_step_core(d, nullptr, true, n_new, final_flags, stream);
+}
+
+// the counters alone, for one utterance from its start: a host-only entry (no device is touched) -- a binding that wants to know what a
+// live reference decoder does with a sequence of ps_process_raw calls (and the tests of LiveSim against the reference's dumps)
+int psgpu_live_pieces(int32_t frame_size, int32_t frame_shift, int32_t window, int32_t pl_window, int32_t grow_feat, const int64_t *chunks,
+                      int32_t n_chunks, int32_t final_, int32_t *ops_out, int32_t ops_cap, int32_t *n_ops, int32_t *n_cepstra, int32_t *n_feat_frames)
+{
+    PSGPU_REQUIRE(frame_size > 0 && frame_shift > 0 && frame_shift <= frame_size && window >= 0 && pl_window >= 0 && n_chunks >= 0 && (n_chunks == 0 || chunks),
+                  "psgpu_live_pieces: bad argument");
+    LiveSim sim;
+    std::vector<int32_t> ops;
+    sim.setup(frame_size, frame_shift, window, pl_window, grow_feat != 0);
+    sim.ops = &ops;
+    sim.start();
+    for (int k = 0; k < n_chunks; ++k) { PSGPU_REQUIRE(chunks[k] >= 0, "psgpu_live_pieces: negative chunk"); if (chunks[k]) sim.process_raw(chunks[k]); }
+    if (final_) sim.end();
+    if (n_ops) *n_ops = (int32_t)(ops.size() / 2);
+    if (n_cepstra) *n_cepstra = sim.made;
+    if (n_feat_frames) *n_feat_frames = sim.feats;
+    if (ops_out) {
+        PSGPU_REQUIRE((size_t)ops_cap * 2 >= ops.size(), "psgpu_live_pieces: %zu ops, room for %d", ops.size() / 2, ops_cap);
+        memcpy(ops_out, ops.data(), 4 * ops.size());
+    }
     return PSGPU_OK;
 }
 

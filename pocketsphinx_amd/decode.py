@@ -251,6 +251,33 @@ class DecodePipeline:
                                                         cnt.ctypes.data_as(C.c_void_p), fin.ctypes.data_as(C.c_void_p), self._stream),
                    "psgpu_decode_streams_step")
 
+    def streams_pcm_begin(self, n_streams, max_frames, max_step_frames, cmninit=(40.0, 3.0, -1.0), grow_feat=True, stream=None):
+        """psgpu_decode_streams_pcm_begin: the streams fed with audio -- a batch of live decoders from ps_process_raw(full_utt = FALSE) on.
+        cmninit: the reference's -cmninit (its default); grow_feat: the reference decoder's acmod_set_grow (-fwdflat yes)."""
+        import torch
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        self.n_utt = int(n_streams)
+        self._stream = st
+        ci = np.ascontiguousarray(cmninit, np.float32)
+        capi.check(capi.lib().psgpu_decode_streams_pcm_begin(self.h, int(n_streams), int(max_frames), int(max_step_frames),
+                                                             ci.ctypes.data_as(C.c_void_p), int(ci.size), int(bool(grow_feat)), st),
+                   "psgpu_decode_streams_pcm_begin")
+
+    def streams_step_pcm(self, pcms, final=None):
+        """psgpu_decode_streams_step_pcm: pcms = one int16 array per stream (None / empty: nothing this step) -- one ps_process_raw call
+        each; final = per stream whether its utterance ends (ps_end_utt).  Returns the feature frames every stream gained."""
+        n = self.n_utt
+        assert len(pcms) == n
+        cnt = np.array([int(x.size) if x is not None else 0 for x in pcms], np.int64)
+        parts = [np.ascontiguousarray(x, np.int16).reshape(-1) for x, c in zip(pcms, cnt) if c]
+        allp = np.concatenate(parts) if parts else np.zeros(1, np.int16)
+        fin = np.zeros(n, np.uint8) if final is None else np.array([1 if x else 0 for x in final], np.uint8)
+        gained = np.zeros(n, np.int32)
+        capi.check(capi.lib().psgpu_decode_streams_step_pcm(self.h, allp.ctypes.data_as(C.c_void_p) if parts else None,
+                                                            cnt.ctypes.data_as(C.c_void_p), fin.ctypes.data_as(C.c_void_p),
+                                                            gained.ctypes.data_as(C.c_void_p), self._stream), "psgpu_decode_streams_step_pcm")
+        return gained
+
     def streams_restart(self, u):
         capi.check(capi.lib().psgpu_decode_streams_restart(self.h, int(u), self._stream), "psgpu_decode_streams_restart")
 
