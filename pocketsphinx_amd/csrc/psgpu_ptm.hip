@@ -171,8 +171,9 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
                       int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw,
                       const uint8_t *__restrict__ open_flags,
                       const int32_t *__restrict__ fix_count, const int32_t *__restrict__ fix_list,
-                      int32_t fix_thr)
+                      int32_t fix_thr, int32_t fr0, int32_t fr_n)
 {
+    // (fr0, fr_n: the frames [fr0, fr0 + fr_n) this launch is responsible for -- a batch scored in ranges, psgpu_ptm_score_batch_dev)
     static_assert(N == 4, "codeword lists are published as one packed uint32");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(
@@ -197,12 +198,12 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
         // Many open entries (e.g. a model with duplicated codewords): chunked
         // form -- open_flags[chain][frame] != 0 marks the frames whose list is
         // not the plain top-4; every chunk that holds one is marched again.
-        const int n_chunks = (total_frames + chunk - 1) / chunk;
+        const int n_chunks = (fr_n + chunk - 1) / chunk;
         for (int w = wave; w < n_chunks * n_chain; w += n_waves) {
             const int g = w / n_chain;
             const int chain = w - g * n_chain;
-            const int fbeg = g * chunk;
-            const int fend = min(total_frames, fbeg + chunk);
+            const int fbeg = fr0 + g * chunk;
+            const int fend = min(fr0 + fr_n, fbeg + chunk);
             bool any = false;
             for (int t0 = fbeg; t0 < fend; t0 += 64) {
                 const int tt = t0 + lane;
@@ -215,13 +216,13 @@ void ptm_chain_kernel(PtmDev p, const float *__restrict__ feats,
         return;
     }
 
-    const int n_chunks = (total_frames + chunk - 1) / chunk;
+    const int n_chunks = (fr_n + chunk - 1) / chunk;
     if (wave >= n_chunks * n_chain)
         return;
     const int g = wave / n_chain;
     const int chain = wave - g * n_chain;
-    const int fbeg = g * chunk;
-    const int fend = min(total_frames, fbeg + chunk);
+    const int fbeg = fr0 + g * chunk;
+    const int fend = min(fr0 + fr_n, fbeg + chunk);
 
     chain_chunk<LEN, N>(p, feats, utt_off, n_utt, chain, fbeg, fend, total_frames, seed_in, seed_out,
                         topn_score, topn_cw, lane);
@@ -326,10 +327,11 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
                      uint8_t *__restrict__ seed_out,
                      int32_t *__restrict__ topn_score, uint32_t *__restrict__ topn_cw,
                      uint8_t *__restrict__ open_flags,
-                     int32_t *__restrict__ fix_count, int32_t *__restrict__ fix_list, int32_t fix_cap)
+                     int32_t *__restrict__ fix_count, int32_t *__restrict__ fix_list, int32_t fix_cap, int32_t fr0, int32_t fr_n)
 {
+    // (this launch: the frames [fr0, fr0 + fr_n) of the batch; the lists' layout is the whole batch's)
     const int lane = threadIdx.x & 63;
-    const int n_tiles = (total_frames + 64 * FPL - 1) / (64 * FPL);
+    const int n_tiles = (fr_n + 64 * FPL - 1) / (64 * FPL);
     // A workgroup = four consecutive tiles of ONE chain (its wavefronts stream the same parameters through the scalar
     // cache).  Which (chain, tiles) a workgroup gets decides how often the feature vectors come from HBM: with the chains
     // outermost every chain swept all of them (PMC, r02: 30 GB read for 240 MB of features).  Now XCD x (workgroups go to
@@ -353,9 +355,9 @@ void ptm_lane_kernel(PtmDev p, const float *__restrict__ feats, int32_t total_fr
     float x[FPL][LEN];
 #pragma unroll
     for (int q = 0; q < FPL; ++q) {
-        t[q] = (tile * FPL + q) * 64 + lane;
-        valid[q] = t[q] < total_frames;
-        const int tl = valid[q] ? t[q] : total_frames - 1;
+        t[q] = fr0 + (tile * FPL + q) * 64 + lane;
+        valid[q] = t[q] < fr0 + fr_n;
+        const int tl = valid[q] ? t[q] : fr0 + fr_n - 1;
         const float *xp = feats + (size_t)tl * p.veclen + f * LEN;
 #pragma unroll
         for (int j = 0; j < LEN; ++j) x[q][j] = xp[j];
@@ -573,12 +575,17 @@ __device__ __forceinline__ int32_t logadd8_lds(const uint8_t *s_la, int32_t x, i
 // keeps the running sums above -kSadBias (3 x its largest entry <= kSadBias; en-us: 3 x 7).  The staged row and the block
 // minimum carry 3 x kSadBias, taken off with the normaliser in the row's last pass.
 constexpr int32_t kSadBias = 64;
-template <int ITERS, int kSenFr, bool SAD>      // kSenFr = frames per workgroup
+// DIRECT = true (un-normalised rows wanted, an even number of senones): a lane's scores go from its registers straight to the row in
+// device memory -- the slot layout puts even senones on even slots (psgpu_ptm_model_create), so two consecutive senones of a lane
+// are one aligned 32-bit store -- and the 10 KB of LDS that stage a frame's row for the normaliser's subtraction are not asked
+// for: beside a resident search kernel that leaves a compute unit 34 KB of LDS, the staged form gets two workgroups there, this one
+// as many as there are wave slots.
+template <int ITERS, int kSenFr, bool SAD, bool DIRECT = false>      // kSenFr = frames per workgroup
 __global__ __launch_bounds__(512)
 void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                             const uint32_t *__restrict__ topn_cw,
                             int16_t *__restrict__ senscr, int32_t *__restrict__ best_out,
-                            uint32_t flags, int32_t total_frames, int32_t *__restrict__ zero_word)
+                            uint32_t flags, int32_t total_frames, int32_t *__restrict__ zero_word, int32_t fr0, int32_t fr_n)
 {
     constexpr int N = 4, NF = 3, MAXC = 256;
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0)
@@ -600,9 +607,9 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
     // consecutive frames share an L2.  (The grid is a multiple of eight; workgroups past the end leave.)
     const int per_xcd = (int)gridDim.x >> 3;
     const int blk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int f0 = blk * kSenFr;
-    if (f0 >= total_frames) return;
-    const int nf = min(kSenFr, total_frames - f0);
+    const int f0 = fr0 + blk * kSenFr;
+    if (f0 >= fr0 + fr_n) return;
+    const int nf = min(kSenFr, fr0 + fr_n - f0);
 
     if (tid < kSenFr * NF) s_norm[tid / NF][tid % NF] = kWorstScore;
     if (tid < kSenFr) s_best[tid] = 0x7fffffff;
@@ -651,6 +658,7 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
         mybest[fr] = 0x7fffffff;
         if (fr < nf) {
             int16_t *orow_s = s_out + fr * out_stride;
+            int16_t *orow_d = senscr + (size_t)(f0 + fr) * p.n_sen;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int g = tid + it * nthr;
@@ -712,6 +720,25 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                             for (int f = 0; f < NF; ++f)
                                 fden[b][f] = lo_[b][f] - (int32_t)s_la[dd[b][f]];   // fast_logmath_add (tied_mgau_common.h:106-125)
                     }
+                    if (DIRECT) {
+                        int32_t a4[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) a4[b] = fden[b][0] + fden[b][1] + fden[b][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t pr = h ? sen2.y : sen2.x, s0 = pr & 0xffff, s1 = pr >> 16;
+                            const int32_t v0 = a4[2 * h] - (SAD ? 3 * kSadBias : 0), v1 = a4[2 * h + 1] - (SAD ? 3 * kSadBias : 0);
+                            if (s0 != 0xffff) mybest[fr] = min(mybest[fr], a4[2 * h]);
+                            if (s1 != 0xffff) mybest[fr] = min(mybest[fr], a4[2 * h + 1]);
+                            if (s0 != 0xffff && s1 == s0 + 1 && !(s0 & 1))
+                                __builtin_nontemporal_store(((uint32_t)v0 & 0xffffu) | ((uint32_t)v1 << 16), reinterpret_cast<uint32_t *>(orow_d) + (s0 >> 1));
+                            else {
+                                if (s0 != 0xffff) orow_d[s0] = (int16_t)v0;
+                                if (s1 != 0xffff) orow_d[s1] = (int16_t)v1;
+                            }
+                        }
+                    }
+                    else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         const int32_t ascore = fden[b][0] + fden[b][1] + fden[b][2];
@@ -720,6 +747,7 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
                             orow_s[sen] = (int16_t)ascore;
                             mybest[fr] = min(mybest[fr], ascore);
                         }
+                    }
                     }
                 }
             }
@@ -739,6 +767,7 @@ void ptm_senone_kernel_f3n4(PtmDev p, const int32_t *__restrict__ topn_score,
         const int frame = f0 + fr;
         const int32_t best = s_best[fr] - (SAD ? 3 * kSadBias : 0);
         if (best_out && tid == 0) best_out[frame] = best;
+        if (DIRECT) continue;                       // (the rows are out already)
         const int32_t sub = ((flags & PSGPU_PTM_RAW_SCORES) ? 0 : best) + (SAD ? 3 * kSadBias : 0);
         int16_t *orow = senscr + (size_t)frame * p.n_sen;
         const int16_t *srow = s_out + fr * out_stride;
@@ -849,11 +878,23 @@ int psgpu_ptm_model_create(psgpu_ptm_model_t **out,
         for (int i = 0; i < n_sen; ++i) by_cb[sen2cb[i]].push_back(i);
         std::vector<uint16_t> slot_sen;
         std::vector<uint8_t> group_cb;
-        for (int cb = 0; cb < 256; ++cb) {
-            if (by_cb[cb].empty()) continue;
-            for (int i : by_cb[cb]) slot_sen.push_back((uint16_t)i);
-            while (slot_sen.size() % 4) slot_sen.push_back(0xffff);
-            while (group_cb.size() < slot_sen.size() / 4) group_cb.push_back((uint8_t)cb);
+        // (a senone sits on a slot of its own parity -- a pad where the parities part, i.e. where a codebook's senone ids jump: en-us's
+        //  are its three CI senones and one range of CD senones -- so that the direct-store form of the fast senone kernel writes two
+        //  consecutive senones of a lane as one aligned 32-bit word; a model whose ids would need pads on more than a quarter of
+        //  the slots keeps the plain layout: the kernel checks each pair and falls back to 16-bit stores)
+        for (int pass = 0; pass < 2; ++pass) {
+            slot_sen.clear(); group_cb.clear();
+            size_t pads = 0;
+            for (int cb = 0; cb < 256; ++cb) {
+                if (by_cb[cb].empty()) continue;
+                for (int i : by_cb[cb]) {
+                    if (pass == 0 && ((slot_sen.size() ^ (size_t)i) & 1)) { slot_sen.push_back(0xffff); ++pads; }
+                    slot_sen.push_back((uint16_t)i);
+                }
+                while (slot_sen.size() % 4) slot_sen.push_back(0xffff);
+                while (group_cb.size() < slot_sen.size() / 4) group_cb.push_back((uint8_t)cb);
+            }
+            if (pass == 0 && 4 * pads <= slot_sen.size()) break;
         }
         m->n_groups = (int32_t)group_cb.size();
         const size_t n_slots = slot_sen.size();
@@ -883,7 +924,10 @@ void psgpu_ptm_model_free(psgpu_ptm_model_t *m)
     hipFree(m->mixw); hipFree(m->sen2cb); hipFree(m->logadd8);
     hipFree(m->mixw_slot); hipFree(m->group_cb); hipFree(m->slot_sen); hipFree(m->mixw_sen);
     free(m->h_sen2cb);
-    for (PtmWorkspace &w : m->ws) { hipFree(w.open_flags); hipFree(w.fix_list); }
+    for (PtmWorkspace &w : m->ws) {
+        hipFree(w.open_flags); hipFree(w.fix_list);
+        if (w.aux) { hipStreamSynchronize(w.aux); hipStreamDestroy(w.aux); for (hipEvent_t e : w.ev) if (e) hipEventDestroy(e); }
+    }
     for (int i = 0; i < 4; ++i) if (m->ev[i]) hipEventDestroy(m->ev[i]);
     delete m;
 }
@@ -918,6 +962,131 @@ int32_t psgpu_ptm_n_chain(const psgpu_ptm_model_t *m) { return m->n_chain; }
 int32_t psgpu_ptm_veclen(const psgpu_ptm_model_t *m) { return m->veclen; }
 int32_t psgpu_ptm_topn(const psgpu_ptm_model_t *m) { return m->topn; }
 
+constexpr int kPtmMaxRanges = 16;
+
+// The top-N pass of the frames [fr0, fr0 + fr_n) of a batch on `st` (lists in the whole batch's layout): the frames-on-lanes kernel
+// and the exact fix-up behind it, with range r's share of the workspace's open-entry list and its counter; or the chain kernel alone
+// (-ds > 1, PSGPU_NO_LANE_KERNEL); any other shape: the exact sequential procedure per (utterance, chain), whole batch only.
+static int ptm_topn_range(psgpu_ptm_model_t *m, const float *feats_dev, const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                          const uint8_t *seed_in_dev, uint8_t *seed_out_dev, int32_t *topn_score_dev, uint8_t *topn_cw_dev,
+                          PtmWorkspace *ws, int r, int32_t fr0, int32_t fr_n, bool lane_path, bool mark, hipStream_t st)
+{
+    // (mark: the model's timing event between the main pass and the fix-up is recorded in this range)
+    static const int forced = [] { const char *e = getenv("PSGPU_CHUNK"); return e ? atoi(e) : 0; }();
+    int chunk = forced;
+    if (chunk <= 0) {
+        // chunk length: enough wavefronts to fill 256 CUs x 32 waves a few times over, but long enough to amortise the parameter
+        // load and the one-frame warm-up of every chunk
+        const long long target_waves = 4LL * 256 * 32;
+        long long c = ((long long)fr_n * m->n_chain + target_waves - 1) / target_waves;
+        chunk = (int)(c < 32 ? 32 : (c > 512 ? 512 : c));
+    }
+    if (lane_path) {
+        // chunk length of the CHUNKED fix-up form (only used when many entries are open)
+        static const int fix_chunk = [] { const char *e = getenv("PSGPU_FIX_CHUNK"); return e ? atoi(e) : 32; }();
+        chunk = fix_chunk > 0 ? fix_chunk : 32;
+    }
+    const long long n_chunks = ((long long)fr_n + chunk - 1) / chunk;
+    const long long waves = n_chunks * m->n_chain;
+    const int blocks = (int)((waves + 3) / 4);
+    static const int occ = [] { const char *e = getenv("PSGPU_CHAIN_OCC"); return e ? atoi(e) : 8; }();
+    const PtmDev pv = dev_view(m);
+    uint32_t *cw32 = reinterpret_cast<uint32_t *>(topn_cw_dev);
+#define PSGPU_CHAIN(GRID, FLAGS, CNT, LST, THR)                                                          \
+    do {                                                                                                 \
+        if (occ >= 8)                                                                                    \
+            hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 8>), dim3(GRID), dim3(256), 0, st, pv, feats_dev, \
+                               utt_off_dev, n_utt, total_frames, chunk, seed_in_dev, seed_out_dev,       \
+                               topn_score_dev, cw32, FLAGS, CNT, LST, THR, fr0, fr_n);                   \
+        else                                                                                             \
+            hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 7>), dim3(GRID), dim3(256), 0, st, pv, feats_dev, \
+                               utt_off_dev, n_utt, total_frames, chunk, seed_in_dev, seed_out_dev,       \
+                               topn_score_dev, cw32, FLAGS, CNT, LST, THR, fr0, fr_n);                   \
+    } while (0)
+    if (lane_path) {
+        // frames-on-lanes main pass, then the two fix-up forms (exactly one of them does work)
+        const size_t need = (size_t)fr_n * m->n_chain;
+        int32_t *fix_count = ws->fix_list + ws->flags_cap + r;       // the counters lie behind the list
+        int32_t *fix_list = ws->fix_list + (size_t)fr0 * m->n_chain;
+        const int32_t fix_thr = (int32_t)(need / 64);
+        static const int fix_grid = [] { const char *e = getenv("PSGPU_FIX_GRID"); return e ? atoi(e) : 512; }();
+        // frames per lane.  2 and 4 use the packed single-precision form of the distance (v_pk_add_f32 / v_pk_mul_f32), half
+        // the VALU instructions per codeword-frame -- measured on the 512 x 30 s batch (r02, profiles/): 41.2 / 42.2 / 42.1 ms
+        // of scorer stage for 1 / 2 / 4, i.e. the packed operations issue at half rate here and buy nothing; 1 stays the default
+        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 1; }();
+        const long long n_tiles = ((long long)fr_n + 64 * fpl - 1) / (64 * fpl);
+        // workgroups: eight XCD shares of ceil(units / 8) four-tile units, each for every chain (see the kernel)
+        const long long lane_units = (n_tiles + 3) / 4, lane_upx = (lane_units + 7) / 8;
+        const long long lw = 8 * lane_upx * m->n_chain * 4;
+        if (fpl == 4)
+            hipLaunchKernelGGL((ptm_lane_kernel<13, 4>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                               topn_score_dev, cw32, ws->open_flags, fix_count, fix_list, (int32_t)need, fr0, fr_n);
+        else if (fpl == 2)
+            hipLaunchKernelGGL((ptm_lane_kernel<13, 2>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                               topn_score_dev, cw32, ws->open_flags, fix_count, fix_list, (int32_t)need, fr0, fr_n);
+        else
+            hipLaunchKernelGGL((ptm_lane_kernel<13, 1>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
+                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
+                               topn_score_dev, cw32, ws->open_flags, fix_count, fix_list, (int32_t)need, fr0, fr_n);
+        PSGPU_HIP(hipGetLastError());
+        if (m->timing && mark) hipEventRecord(m->ev[1], st);
+        PSGPU_CHAIN(fix_grid, (const uint8_t *)ws->open_flags, (const int32_t *)fix_count, (const int32_t *)fix_list, fix_thr);
+    }
+    else {
+        if (m->timing && mark) hipEventRecord(m->ev[1], st);
+        PSGPU_CHAIN(blocks, (const uint8_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
+    }
+#undef PSGPU_CHAIN
+    PSGPU_HIP(hipGetLastError());
+    return PSGPU_OK;
+}
+
+// the workspace's open-entry flags, list and counters for a batch of `total_frames` (the lane path); counters zeroed if a call before
+// left them dirty (normally the senone kernel of the previous call zeroed them)
+static int ptm_ws_prepare(psgpu_ptm_model_t *m, PtmWorkspace *ws, int32_t total_frames, hipStream_t st)
+{
+    const size_t need = (size_t)total_frames * m->n_chain;
+    if (need > ws->flags_cap) {                                      // (two host threads scoring on one model use two streams, hence two workspaces)
+        PSGPU_HIP(hipStreamSynchronize(st));
+        if (ws->aux) PSGPU_HIP(hipStreamSynchronize(ws->aux));
+        hipFree(ws->open_flags); hipFree(ws->fix_list);
+        ws->open_flags = nullptr; ws->fix_list = nullptr; ws->flags_cap = 0;
+        PSGPU_HIP(hipMalloc((void **)&ws->open_flags, need));
+        PSGPU_HIP(hipMalloc((void **)&ws->fix_list, (need + kPtmMaxRanges) * sizeof(int32_t)));
+        ws->flags_cap = need;
+        ws->count_dirty = 1;
+    }
+    if (ws->count_dirty) PSGPU_HIP(hipMemsetAsync(ws->fix_list + ws->flags_cap, 0, sizeof(int32_t) * kPtmMaxRanges, st));
+    ws->count_dirty = 1;
+    return PSGPU_OK;
+}
+
+static bool ptm_lane_path(const psgpu_ptm_model_t *m)
+{
+    static const int no_lane = [] { const char *e = getenv("PSGPU_NO_LANE_KERNEL"); return e ? atoi(e) : 0; }();
+    return m->fast_shape && m->ds_ratio == 1 && !no_lane;
+}
+
+static int ptm_topn_generic(psgpu_ptm_model_t *m, const float *feats_dev, const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
+                            const uint8_t *seed_in_dev, uint8_t *seed_out_dev, int32_t *topn_score_dev, uint8_t *topn_cw_dev, hipStream_t st)
+{
+    // every other shape psgpu_ptm_frame_eval serves (topn 1..8 -- a user's knob, config_macro.h:384 --, up to 256 densities,
+    // any stream lengths, any -ds): the exact sequential procedure, one wavefront per (utterance, chain)
+    const PtmDev pv = dev_view(m);
+    const long long waves = (long long)n_utt * m->n_chain;
+    const unsigned grid = (unsigned)std::min<long long>((waves + 3) / 4, 256LL * 8);
+    if (m->timing) { hipEventRecord(m->ev[0], st); }
+#define PSGPU_GEN(NN) case NN: hipLaunchKernelGGL((ptm_batch_topn_generic<NN>), dim3(grid), dim3(256), 0, st, pv, feats_dev, utt_off_dev, n_utt, \
+                                                  total_frames, seed_in_dev, seed_out_dev, topn_score_dev, topn_cw_dev); break;
+    switch (m->topn) { PSGPU_GEN(1) PSGPU_GEN(2) PSGPU_GEN(3) PSGPU_GEN(4) PSGPU_GEN(5) PSGPU_GEN(6) PSGPU_GEN(7) default: PSGPU_GEN(8) }
+#undef PSGPU_GEN
+    if (m->timing) { hipEventRecord(m->ev[1], st); hipEventRecord(m->ev[2], st); }
+    PSGPU_HIP(hipGetLastError());
+    return PSGPU_OK;
+}
+
 int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
                        const int32_t *utt_off_dev, int32_t n_utt, int32_t total_frames,
                        const uint8_t *seed_in_dev, uint8_t *seed_out_dev,
@@ -929,120 +1098,29 @@ int psgpu_ptm_topn_dev(psgpu_ptm_model_t *m, const float *feats_dev,
     PSGPU_REQUIRE(seed_in_dev == nullptr || seed_in_dev != seed_out_dev,
                   "seed_in and seed_out must not alias (chunks read seeds while others write carry-outs)");
     if (n_utt == 0 || total_frames == 0) return PSGPU_OK;
-    if (!m->fast_shape) {
-        // every other shape psgpu_ptm_frame_eval serves (topn 1..8 -- a user's knob, config_macro.h:384 --, up to 256 densities,
-        // any stream lengths, any -ds): the exact sequential procedure, one wavefront per (utterance, chain)
-        hipStream_t st = (hipStream_t)stream;
-        const PtmDev pv = dev_view(m);
-        const long long waves = (long long)n_utt * m->n_chain;
-        const unsigned grid = (unsigned)std::min<long long>((waves + 3) / 4, 256LL * 8);
-        if (m->timing) { hipEventRecord(m->ev[0], st); }
-#define PSGPU_GEN(NN) case NN: hipLaunchKernelGGL((ptm_batch_topn_generic<NN>), dim3(grid), dim3(256), 0, st, pv, feats_dev, utt_off_dev, n_utt, \
-                                                  total_frames, seed_in_dev, seed_out_dev, topn_score_dev, topn_cw_dev); break;
-        switch (m->topn) { PSGPU_GEN(1) PSGPU_GEN(2) PSGPU_GEN(3) PSGPU_GEN(4) PSGPU_GEN(5) PSGPU_GEN(6) PSGPU_GEN(7) default: PSGPU_GEN(8) }
-#undef PSGPU_GEN
-        if (m->timing) { hipEventRecord(m->ev[1], st); hipEventRecord(m->ev[2], st); }
-        PSGPU_HIP(hipGetLastError());
-        return PSGPU_OK;
-    }
-    // chunk length: enough wavefronts to fill 256 CUs x 32 waves a few times
-    // over, but long enough to amortise the parameter load and the one-frame
-    // warm-up of every chunk.
-    static const int forced = [] { const char *e = getenv("PSGPU_CHUNK"); return e ? atoi(e) : 0; }();
-    int chunk = forced;
-    if (chunk <= 0) {
-        const long long target_waves = 4LL * 256 * 32;
-        long long c = ((long long)total_frames * m->n_chain + target_waves - 1) / target_waves;
-        chunk = (int)(c < 32 ? 32 : (c > 512 ? 512 : c));
-    }
-    static const int no_lane = [] { const char *e = getenv("PSGPU_NO_LANE_KERNEL"); return e ? atoi(e) : 0; }();
-    const bool lane_path = (m->ds_ratio == 1 && !no_lane);
-    if (lane_path) {
-        // chunk length of the CHUNKED fix-up form (only used when many entries are open)
-        static const int fix_chunk = [] { const char *e = getenv("PSGPU_FIX_CHUNK"); return e ? atoi(e) : 32; }();
-        chunk = fix_chunk > 0 ? fix_chunk : 32;
-    }
-    const long long n_chunks = ((long long)total_frames + chunk - 1) / chunk;
-    const long long waves = n_chunks * m->n_chain;
-    const int blocks = (int)((waves + 3) / 4);
-    static const int occ = [] { const char *e = getenv("PSGPU_CHAIN_OCC"); return e ? atoi(e) : 8; }();
-    const PtmDev pv = dev_view(m);
-    uint32_t *cw32 = reinterpret_cast<uint32_t *>(topn_cw_dev);
     hipStream_t st = (hipStream_t)stream;
-#define PSGPU_CHAIN(GRID, FLAGS, CNT, LST, THR)                                                          \
-    do {                                                                                                 \
-        if (occ >= 8)                                                                                    \
-            hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 8>), dim3(GRID), dim3(256), 0, st, pv, feats_dev, \
-                               utt_off_dev, n_utt, total_frames, chunk, seed_in_dev, seed_out_dev,       \
-                               topn_score_dev, cw32, FLAGS, CNT, LST, THR);                              \
-        else                                                                                             \
-            hipLaunchKernelGGL((ptm_chain_kernel<13, 4, 7>), dim3(GRID), dim3(256), 0, st, pv, feats_dev, \
-                               utt_off_dev, n_utt, total_frames, chunk, seed_in_dev, seed_out_dev,       \
-                               topn_score_dev, cw32, FLAGS, CNT, LST, THR);                              \
-    } while (0)
+    if (!m->fast_shape)
+        return ptm_topn_generic(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev, seed_out_dev, topn_score_dev, topn_cw_dev, st);
+    const bool lane_path = ptm_lane_path(m);
+    PtmWorkspace *ws = nullptr;
     if (lane_path) {
-        // frames-on-lanes main pass, then the two fix-up forms (exactly one of them does work)
-        const size_t need = (size_t)total_frames * m->n_chain;
-        PtmWorkspace *ws = ptm_workspace(m, st, true);               // this stream's scratch (two host threads scoring on one
-        if (need > ws->flags_cap) {                                  //  model use two streams, hence two workspaces)
-            PSGPU_HIP(hipStreamSynchronize(st));
-            hipFree(ws->open_flags); hipFree(ws->fix_list);
-            ws->open_flags = nullptr; ws->fix_list = nullptr; ws->flags_cap = 0;
-            PSGPU_HIP(hipMalloc((void **)&ws->open_flags, need));
-            PSGPU_HIP(hipMalloc((void **)&ws->fix_list, (need + 1) * sizeof(int32_t)));
-            ws->flags_cap = need;
-            ws->count_dirty = 1;
-        }
-        int32_t *fix_count = ws->fix_list + ws->flags_cap;          // last slot of the list buffer
-        const int32_t fix_thr = (int32_t)(need / 64);
-        static const int fix_grid = [] { const char *e = getenv("PSGPU_FIX_GRID"); return e ? atoi(e) : 512; }();
-        if (ws->count_dirty)                 // normally the senone kernel of the previous call zeroed it
-            PSGPU_HIP(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st));
-        ws->count_dirty = 1;
-        // frames per lane.  2 and 4 use the packed single-precision form of the distance (v_pk_add_f32 / v_pk_mul_f32), half
-        // the VALU instructions per codeword-frame -- measured on the 512 x 30 s batch (r02, profiles/): 41.2 / 42.2 / 42.1 ms
-        // of scorer stage for 1 / 2 / 4, i.e. the packed operations issue at half rate here and buy nothing; 1 stays the default
-        static const int fpl = [] { const char *e = getenv("PSGPU_LANE_FPL"); return e ? atoi(e) : 1; }();
-        const long long n_tiles = ((long long)total_frames + 64 * fpl - 1) / (64 * fpl);
-        // workgroups: eight XCD shares of ceil(units / 8) four-tile units, each for every chain (see the kernel)
-        const long long lane_units = (n_tiles + 3) / 4, lane_upx = (lane_units + 7) / 8;
-        const long long lw = 8 * lane_upx * m->n_chain * 4;
-        if (m->timing) hipEventRecord(m->ev[0], st);
-        if (fpl == 4)
-            hipLaunchKernelGGL((ptm_lane_kernel<13, 4>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
-                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
-                               topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);
-        else if (fpl == 2)
-            hipLaunchKernelGGL((ptm_lane_kernel<13, 2>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
-                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
-                               topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);
-        else
-            hipLaunchKernelGGL((ptm_lane_kernel<13, 1>), dim3((unsigned)((lw + 3) / 4)), dim3(256), 0, st,
-                               pv, feats_dev, total_frames, utt_off_dev, n_utt, seed_out_dev,
-                               topn_score_dev, cw32, ws->open_flags, fix_count, ws->fix_list, (int32_t)need);
-        PSGPU_HIP(hipGetLastError());
-        if (m->timing) hipEventRecord(m->ev[1], st);
-        PSGPU_CHAIN(fix_grid, (const uint8_t *)ws->open_flags, (const int32_t *)fix_count, (const int32_t *)ws->fix_list, fix_thr);
+        ws = ptm_workspace(m, st, true);
+        int rc = ptm_ws_prepare(m, ws, total_frames, st);
+        if (rc) return rc;
     }
-    else {
-        if (m->timing) { hipEventRecord(m->ev[0], st); hipEventRecord(m->ev[1], st); }
-        PSGPU_CHAIN(blocks, (const uint8_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, 0);
-    }
-#undef PSGPU_CHAIN
+    if (m->timing) hipEventRecord(m->ev[0], st);
+    int rc = ptm_topn_range(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev, seed_out_dev, topn_score_dev, topn_cw_dev, ws, 0, 0,
+                            total_frames, lane_path, true, st);
     if (m->timing) hipEventRecord(m->ev[2], st);
-    PSGPU_HIP(hipGetLastError());
-    return PSGPU_OK;
+    return rc;
 }
 
-int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
-                         const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
-                         int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,
-                         void *stream)
+// the senone pass of the frames [fr0, fr0 + fr_n); zw: the open-entry counter this launch zeroes for the next call (or NULL)
+static int ptm_senone_range(psgpu_ptm_model_t *m, int32_t total_frames, const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
+                            int16_t *senscr_dev, int32_t *best_dev, uint32_t flags, int32_t *zw, int32_t fr0, int32_t fr_n, hipStream_t st, bool *used_fast)
 {
-    PSGPU_REQUIRE(m && topn_score_dev && topn_cw_dev && senscr_dev,
-                  "psgpu_ptm_senone_dev: NULL argument");
-    if (total_frames <= 0) return PSGPU_OK;
     static const int force_generic = [] { const char *e = getenv("PSGPU_SENONE_GENERIC"); return e ? atoi(e) : 0; }();
+    *used_fast = false;
     if (!force_generic && m->fast_shape && m->n_feat == 3 && m->topn == 4 && m->n_chain <= 256 && m->n_sen < 0xffff) {
         // block = 4..8 waves: pick the width that wastes the fewest lanes
         int best_w = 0, iters = 0;
@@ -1059,20 +1137,26 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
         }
         if (best_w) {
             const int kSenFr = (sen_fr == 1 || sen_fr == 4) ? sen_fr : 2;
-            const dim3 grid((((total_frames + kSenFr - 1) / kSenFr + 7) / 8) * 8), block(64 * best_w);      // (a multiple of eight: see the kernel)
-            const size_t sm = (((size_t)m->n_sen * 2 + 15) / 16) * 16 * kSenFr;
-            hipStream_t st = (hipStream_t)stream;
+            const dim3 grid((((fr_n + kSenFr - 1) / kSenFr + 7) / 8) * 8), block(64 * best_w);      // (a multiple of eight: see the kernel)
+            // (PSGPU_SENONE_DIRECT=1: measured on the 512 x 30 s batch, two batches in flight, profiles/round6_scorer_ab.txt -- the scorer
+            //  stage beside the other batch's search 63.4 -> 57.5 ms, alone 37.8 -> 39.8 (narrower stores), but the search beside it
+            //  71.3 -> 73.0 ms and a step 77.7 -> 79.5: the step IS the search's time beside the stages, and a senone kernel that gets
+            //  three times the wavefronts onto a compute unit disturbs the search's trips to device memory more.  The staged form
+            //  stays the default; the direct form is for a scorer that runs alone beside LDS-hungry work.)
+            static const int want_direct = [] { const char *e = getenv("PSGPU_SENONE_DIRECT"); return e ? atoi(e) : 0; }();
+            const bool direct = want_direct && (flags & PSGPU_PTM_RAW_SCORES) && (m->n_sen & 1) == 0 && ((uintptr_t)senscr_dev & 3) == 0 && kSenFr == 1;
+            const size_t sm = direct ? 0 : (((size_t)m->n_sen * 2 + 15) / 16) * 16 * kSenFr;
             const PtmDev pv = dev_view(m);
             const uint32_t *cw32 = reinterpret_cast<const uint32_t *>(topn_cw_dev);
-            PtmWorkspace *ws = ptm_workspace(m, st, false);
-            int32_t *zw = (ws && ws->fix_list) ? ws->fix_list + ws->flags_cap : nullptr;
 #define PSGPU_SEN_CASE_(I, SAD) \
-                if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1, SAD>), grid, block, sm, st, pv,   \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
+                if (direct) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1, SAD, true>), grid, block, sm, st, pv,   \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw, fr0, fr_n); \
+                else if (kSenFr == 1) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 1, SAD>), grid, block, sm, st, pv,   \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw, fr0, fr_n); \
                 else if (kSenFr == 4) hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 4, SAD>), grid, block, sm, st, pv, \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);       \
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw, fr0, fr_n); \
                 else hipLaunchKernelGGL((ptm_senone_kernel_f3n4<I, 2, SAD>), grid, block, sm, st, pv,               \
-                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw);
+                                       topn_score_dev, cw32, senscr_dev, best_dev, flags, total_frames, zw, fr0, fr_n);
 #define PSGPU_SEN_CASE(I) case I: if (sad) { PSGPU_SEN_CASE_(I, true) } else { PSGPU_SEN_CASE_(I, false) } break;
             // the biased form of the log-add chain (v_sad_u32): when 3 x the table's largest entry <= the bias
             // (PSGPU_SENONE_SAD=0: the signed form, for A/B runs and the tests of that path)
@@ -1085,10 +1169,11 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
 #undef PSGPU_SEN_CASE
 #undef PSGPU_SEN_CASE_
             PSGPU_HIP(hipGetLastError());
-            if (zw) ws->count_dirty = 0;
+            *used_fast = true;
             return PSGPU_OK;
         }
     }
+    PSGPU_REQUIRE(fr0 == 0 && fr_n == total_frames, "psgpu_ptm_senone_dev: the any-shape senone kernel takes whole batches");
     // any shape (and the fast shape on request): one workgroup per frame, lists [chain][frame][topn]
     const int out_bytes = ((m->n_sen * 2 + 15) / 16) * 16;
     const int list_bytes = ((m->n_chain * m->topn + 15) / 16) * 16;
@@ -1097,13 +1182,30 @@ int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
 #define PSGPU_SEN_GEN(NN) case NN: {                                                                                                        \
         if (smem > 64 * 1024)                                                                                                              \
             PSGPU_HIP(hipFuncSetAttribute((const void *)ptm_senone_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));    \
-        hipLaunchKernelGGL((ptm_senone_kernel<NN>), dim3(total_frames), dim3(kSenThreads), smem, (hipStream_t)stream, dev_view(m),          \
+        hipLaunchKernelGGL((ptm_senone_kernel<NN>), dim3(total_frames), dim3(kSenThreads), smem, st, dev_view(m),                           \
                            topn_score_dev, topn_cw_dev, senscr_dev, best_dev, flags, total_frames); } break;
     switch (m->topn) { PSGPU_SEN_GEN(1) PSGPU_SEN_GEN(2) PSGPU_SEN_GEN(3) PSGPU_SEN_GEN(4) PSGPU_SEN_GEN(5) PSGPU_SEN_GEN(6) PSGPU_SEN_GEN(7)
                        default: PSGPU_SEN_GEN(8) }
 #undef PSGPU_SEN_GEN
     PSGPU_HIP(hipGetLastError());
     return PSGPU_OK;
+}
+
+int psgpu_ptm_senone_dev(psgpu_ptm_model_t *m, int32_t total_frames,
+                         const int32_t *topn_score_dev, const uint8_t *topn_cw_dev,
+                         int16_t *senscr_dev, int32_t *best_dev, uint32_t flags,
+                         void *stream)
+{
+    PSGPU_REQUIRE(m && topn_score_dev && topn_cw_dev && senscr_dev,
+                  "psgpu_ptm_senone_dev: NULL argument");
+    if (total_frames <= 0) return PSGPU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    PtmWorkspace *ws = ptm_workspace(m, st, false);
+    int32_t *zw = (ws && ws->fix_list) ? ws->fix_list + ws->flags_cap : nullptr;       // (the whole-batch top-N pass used counter 0)
+    bool fast = false;
+    const int rc = ptm_senone_range(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev, best_dev, flags, zw, 0, total_frames, st, &fast);
+    if (rc == PSGPU_OK && fast && zw) ws->count_dirty = 0;
+    return rc;
 }
 
 int psgpu_ptm_kernel_timing(psgpu_ptm_model_t *m, int32_t enable)
@@ -1130,6 +1232,11 @@ int psgpu_ptm_last_kernel_ms(psgpu_ptm_model_t *m, float *ms3)
     return PSGPU_OK;
 }
 
+// The whole scorer for a batch.  Large batches of the specialised shape go in RANGES of frames: range r's top-N pass on the caller's
+// stream while the senone pass of range r - 1 runs on a stream of the workspace's own -- the first is bound by the vector ALU and uses
+// no LDS, the second by the latency of its table look-ups and (beside a resident search kernel) by the LDS its staged row takes:
+// side by side they fill each other's gaps (bench.py stage_ms.scorer).  The caller's stream waits for the last senone
+// pass before the call returns control of it; results and layouts are those of one pass over the whole batch.
 int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
                               const float *feats_dev, const int32_t *utt_off_dev,
                               int32_t n_utt, int32_t total_frames,
@@ -1138,13 +1245,59 @@ int psgpu_ptm_score_batch_dev(psgpu_ptm_model_t *m,
                               int16_t *senscr_dev, int32_t *best_dev,
                               uint32_t flags, void *stream)
 {
-    int rc = psgpu_ptm_topn_dev(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev,
-                                seed_out_dev, topn_score_dev, topn_cw_dev, stream);
-    if (rc != PSGPU_OK || senscr_dev == nullptr) return rc;
-    rc = psgpu_ptm_senone_dev(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev,
-                              best_dev, flags, stream);
-    if (rc == PSGPU_OK && m->timing) { hipEventRecord(m->ev[3], (hipStream_t)stream); m->sen_timed = true; }
-    return rc;
+    static const int n_ranges_env = [] { const char *e = getenv("PSGPU_PTM_RANGES"); return e ? atoi(e) : 0; }();
+    hipStream_t st = (hipStream_t)stream;
+    int R = 1;
+    if (m && senscr_dev && n_utt > 0 && ptm_lane_path(m) && m->n_feat == 3 && m->n_chain <= 256 && m->n_sen < 0xffff) {
+        // (measured on the 512 x 30 s batch, profiles/round6_scorer_ranges.txt: 1 / 4 / 6 / 8 ranges give 63.8 / 65.4 / 65.7 / 65.3 ms of
+        //  scorer stage beside the other batch's search and 38.0 / 37.8 / 38.2 / 38.0 ms alone -- the two passes do not fill each
+        //  other's gaps, both want the vector ALU; one range stays the default, PSGPU_PTM_RANGES is the A/B knob)
+        R = n_ranges_env > 0 ? n_ranges_env : 1;
+        R = std::min(R, kPtmMaxRanges);
+        while (R > 1 && total_frames / R < 4096) --R;
+    }
+    if (R <= 1) {
+        int rc = psgpu_ptm_topn_dev(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev,
+                                    seed_out_dev, topn_score_dev, topn_cw_dev, stream);
+        if (rc != PSGPU_OK || senscr_dev == nullptr) return rc;
+        rc = psgpu_ptm_senone_dev(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev,
+                                  best_dev, flags, stream);
+        if (rc == PSGPU_OK && m->timing) { hipEventRecord(m->ev[3], st); m->sen_timed = true; }
+        return rc;
+    }
+    PSGPU_REQUIRE(feats_dev && utt_off_dev && topn_score_dev && topn_cw_dev, "psgpu_ptm_score_batch_dev: NULL argument");
+    PSGPU_REQUIRE(seed_in_dev == nullptr || seed_in_dev != seed_out_dev, "seed_in and seed_out must not alias");
+    PtmWorkspace *ws = ptm_workspace(m, st, true);
+    int rc = ptm_ws_prepare(m, ws, total_frames, st);
+    if (rc) return rc;
+    if (!ws->aux) {
+        PSGPU_HIP(hipStreamCreateWithFlags(&ws->aux, hipStreamNonBlocking));
+        for (int i = 0; i <= kPtmMaxRanges; ++i) PSGPU_HIP(hipEventCreateWithFlags(&ws->ev[i], hipEventDisableTiming));
+    }
+    // ranges of whole 256-frame units (a top-N workgroup's four tiles)
+    const int32_t per = (int32_t)((((int64_t)total_frames + R - 1) / R + 255) / 256 * 256);
+    if (m->timing) hipEventRecord(m->ev[0], st);
+    int r = 0;
+    bool all_fast = true;
+    for (int32_t fr0 = 0; fr0 < total_frames; fr0 += per, ++r) {
+        const int32_t fr_n = std::min(per, total_frames - fr0);
+        if ((rc = ptm_topn_range(m, feats_dev, utt_off_dev, n_utt, total_frames, seed_in_dev, seed_out_dev, topn_score_dev, topn_cw_dev, ws, r,
+                                 fr0, fr_n, true, fr0 + per >= total_frames, st)))
+            return rc;
+        PSGPU_HIP(hipEventRecord(ws->ev[r], st));
+        PSGPU_HIP(hipStreamWaitEvent(ws->aux, ws->ev[r], 0));
+        bool fast = false;
+        if ((rc = ptm_senone_range(m, total_frames, topn_score_dev, topn_cw_dev, senscr_dev, best_dev, flags, ws->fix_list + ws->flags_cap + r, fr0, fr_n,
+                                   ws->aux, &fast)))
+            return rc;
+        all_fast = all_fast && fast;
+    }
+    if (m->timing) hipEventRecord(m->ev[2], st);         // (the top-N passes' end; the senone passes go on beside)
+    PSGPU_HIP(hipEventRecord(ws->ev[kPtmMaxRanges], ws->aux));
+    PSGPU_HIP(hipStreamWaitEvent(st, ws->ev[kPtmMaxRanges], 0));
+    if (all_fast) ws->count_dirty = 0;
+    if (m->timing) { hipEventRecord(m->ev[3], st); m->sen_timed = true; }
+    return PSGPU_OK;
 }
 
 int psgpu_ptm_score_batch(psgpu_ptm_model_t *m,

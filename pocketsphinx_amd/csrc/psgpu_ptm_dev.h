@@ -14,7 +14,9 @@ struct PtmWorkspace {
     uint8_t *open_flags;          // [n_chain][frames]: entries the lane kernel left to the fix-up
     int32_t *fix_list;            // [frames * n_chain] open entries + 1 counter word
     size_t flags_cap;
-    int count_dirty;              // the open-entry counter must be zeroed before the next lane pass
+    int count_dirty;              // the open-entry counters must be zeroed before the next lane pass
+    hipStream_t aux;              // a batch scored in ranges: the senone passes' stream, and the events that order the two
+    hipEvent_t ev[17];
 };
 
 struct psgpu_ptm_model_s {
@@ -47,7 +49,7 @@ static inline PtmWorkspace *ptm_workspace(psgpu_ptm_model_t *m, hipStream_t st, 
     std::lock_guard<std::mutex> lock(m->ws_mu);
     for (PtmWorkspace &w : m->ws) if (w.stream == st) return &w;
     if (!create) return nullptr;
-    m->ws.push_back(PtmWorkspace{st, nullptr, nullptr, 0, 1});
+    m->ws.push_back(PtmWorkspace{st, nullptr, nullptr, 0, 1, nullptr, {}});
     return &m->ws.back();
 }
 
