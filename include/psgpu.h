@@ -55,6 +55,7 @@ extern "C" {
 #define PSGPU_CAP_PTM_BATCH_ANY_SHAPE (1ull << 10)  /* psgpu_ptm_score_batch_dev for every shape psgpu_ptm_frame_eval serves */
 #define PSGPU_CAP_STREAMS_PCM         (1ull << 11)  /* streams fed with PCM (per-stream front-end state + live CMN on the device) */
 #define PSGPU_CAP_FWDTREE_SPLIT       (1ull << 12)  /* one utterance's tree search on several workgroups */
+#define PSGPU_CAP_FEAT_TYPES          (1ull << 13)  /* psgpu_feat_create: every feature type of feat_init, -lda, -svspec, varnorm, agc max */
 int32_t psgpu_abi_version(void);
 uint64_t psgpu_capabilities(void);
 const char *psgpu_version(void);
@@ -252,6 +253,23 @@ int psgpu_feat_1s_c_d_dd_dev(const float *cep_dev, const int32_t *utt_off_dev, i
                              int32_t cepsize, float *feat_dev, void *stream);
 int psgpu_feat_1s_c_d_dd(const float *cep, const int32_t *utt_off, int32_t n_utt, int32_t cepsize,
                          float *feat);
+
+/* ---- every feature type of feat_init (feat.c:704-915) for whole utterances: s2_4x, s3_1x39 / 1s_12c_12d_3p_12dd, 1s_c_d_dd,
+ * 1s_c_d_ld_dd, cep_dcep / 1s_c_d, cep / 1s_c, 1s_3c / 1s_4c and the generic "%d,%d,...[:window]", with cmn() (cmn: 0 none, 1 batch --
+ * the reference's "current" / "batch"; varnorm: unit variance, cmn.c:203-231), agc_max (agc: 0 none, 1 max; agc.c:110-127), the
+ * transform of -lda (lda [lda_out][lda_in] as feat_read_lda keeps it, lda.c:63-159) and the subvector projection of -svspec (subvec
+ * [n_subvec]: the components in the specification's order, feat.c:333-352).  psgpu_feat_compute_dev: cep_dev [total][cepsize] of
+ * n_utt utterances back to back (utt_off_dev [n_utt + 1]) -> feat_dev [total][psgpu_feat_out_dim].  Bit-exact against
+ * feat_s2mfc2feat_live(begin = end = TRUE).  (PSGPU_CAP_FEAT_TYPES.) */
+typedef struct psgpu_feat_s psgpu_feat_t;
+int psgpu_feat_create(psgpu_feat_t **out, const char *type, int32_t cepsize, int32_t cmn, int32_t varnorm, int32_t agc, const float *lda,
+                      int32_t lda_out, int32_t lda_in, const int32_t *subvec, int32_t n_subvec);
+void psgpu_feat_free(psgpu_feat_t *f);
+int32_t psgpu_feat_out_dim(const psgpu_feat_t *f);
+int32_t psgpu_feat_cepsize(const psgpu_feat_t *f);
+int32_t psgpu_feat_window(const psgpu_feat_t *f);
+int psgpu_feat_compute_dev(const psgpu_feat_t *f, const float *cep_dev, const int32_t *utt_off_dev, int32_t n_utt, float *feat_dev, void *stream);
+int psgpu_feat_compute(const psgpu_feat_t *f, const float *cep, const int32_t *utt_off, int32_t n_utt, float *feat);
 
 /* ---- the same two stages for live decoders: audio and cepstra arrive in pieces ---------------------------------
  * psgpu_fe_stream_step_dev: fe_process_frames on a piece of audio per stream (fe_interface.c:352-512; + fe_end_utt, :514-533,
@@ -821,6 +839,10 @@ typedef struct psgpu_decode_config_s {
 #define PSGPU_SCORER_SEMI 1
 #define PSGPU_SCORER_MS 2
 int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg);
+/* From PCM the pipeline computes en-us's feature type (1s_c_d_dd, batch CMN) unless another is installed here: any type of
+ * psgpu_feat_create whose cepstrum size is the front end's and whose output is the scorer's vector (the semi-continuous models'
+ * s2_4x, a model trained with -lda ...).  NULL: back to the default.  The handle stays the caller's. */
+int psgpu_decode_set_feat(psgpu_decode_t *d, const psgpu_feat_t *feat);
 void psgpu_decode_free(psgpu_decode_t *d);
 /* after the scorer's tables were re-uploaded (MLLR): the new model handle, same shape */
 int psgpu_decode_set_model(psgpu_decode_t *d, psgpu_ptm_model_t *model);

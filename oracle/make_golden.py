@@ -338,6 +338,33 @@ def fwdtree_topn_only():
               os.path.getsize(os.path.join(GOLD, "fwdtree_result_%s.npz" % name)))
 
 
+FEAT_CASES = [("s2_4x", "batch", 0, "none", 0, "-"), ("s3_1x39", "batch", 1, "max", 0, "-"), ("1s_c_d_dd", "batch", 0, "none", 29, "0-9/10-19/20-28"),
+              ("1s_c_d_ld_dd", "none", 0, "none", 0, "-"), ("1s_c_d", "batch", 1, "none", 0, "-"), ("1s_c", "none", 0, "max", 0, "-"),
+              ("1s_3c", "batch", 0, "none", 40, "-"), ("5,8:2", "batch", 0, "none", 0, "-"), ("1s_c_d_dd", "batch", 0, "none", 0, "0-12/13-25/26-38"),
+              ("1s_4c", "none", 0, "none", 0, "-"), ("1s_12c_12d_3p_12dd", "batch", 0, "max", 20, "3,1,0,19/5-8")]
+
+
+def feat_types_only():
+    """feat_s2mfc2feat_live(begin = end = TRUE) for every feature type feat_init knows, with batch CMN / unit variance / agc max, a
+    linear transform and subvector specifications (ref_dump dynfeat_cfg): the cepstra once, per case the settings, the transform
+    and the feature frames."""
+    out = {}
+    for ci, (typ, cmn, vn, agc, ldadim, sv) in enumerate(FEAT_CASES):
+        d = ref_dump("dynfeat_cfg", os.path.join(REF, "data", "goforward.mfc"), typ, cmn, vn, agc, ldadim, sv, model="-", lm="-", dic="-")
+        k = "c%d_" % ci
+        out["cep"] = d["cep"]
+        out[k + "feat"] = d["feat"]
+        out[k + "cfg"] = np.array([typ, cmn, str(vn), agc, str(ldadim), sv])
+        if "lda" in d:
+            out[k + "lda"] = d["lda"]
+        if "subvec" in d:
+            out[k + "subvec"] = d["subvec"]
+        print("feat", typ, cmn, vn, agc, ldadim, sv, d["feat"].shape, int(d["window"][0]))
+    out["n_cases"] = np.array([len(FEAT_CASES)], np.int32)
+    np.savez_compressed(os.path.join(GOLD, "feat_types.npz"), **out)
+    print(os.path.getsize(os.path.join(GOLD, "feat_types.npz")))
+
+
 LIVE_CASES = [("goforward", 2, [1600]), ("goforward", 3, [317]), ("numbers", 3, [800, 2400]), ("goforward", 2, [100, 5000, 333, 1601, 409, 411, 160]),
               ("numbers", 2, [570]), ("goforward", 2, [410, 160, 160, 250]), ("numbers", 2, [16000])]
 
@@ -613,6 +640,8 @@ if __name__ == "__main__":
         mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":
         dynfeat_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "feat_types":
+        feat_types_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "livefeat":
         livefeat_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "fwdtree_topn":

@@ -1174,6 +1174,69 @@ cmd_lm(ngram_model_t *lmset, const char *qfile)
 }
 
 /* ------------------------------------------------------------------ */
+/* dynfeat_cfg: feat_s2mfc2feat_live(begin = end = TRUE) of a feat_t built by feat_init from a type name and normalisation settings
+ * (feat.c:704-915) -- every feature type, batch CMN with or without unit variance, agc max -- optionally with a linear transform
+ * (feat_lda_transform, lda.c:140-159: a matrix of this program's own, pseudo-random, in the place feat_read_lda leaves one) and a
+ * subvector specification (feat_set_subvecs / feat_subvec_project).  Cepstra: a Sphinx .mfc file.
+ * args: MFC TYPE CMN VARNORM AGC LDADIM(0: none) SVSPEC(-: none) */
+static int
+cmd_dynfeat_cfg(const char *mfcpath, const char *type, const char *cmn, int varnorm, const char *agc, int ldadim, const char *svspec)
+{
+    FILE *fp = fopen(mfcpath, "rb");
+    long flen; int32 nmfc; int nfr, i, swap = 0, nout, ceplen = 13, dim, k;
+    float32 **mfcs, *copy, *flat;
+    mfcc_t ***feat;
+    feat_t *fcb;
+    if (!fp) { perror(mfcpath); return 2; }
+    fseek(fp, 0, SEEK_END); flen = ftell(fp); fseek(fp, 0, SEEK_SET);
+    if (fread(&nmfc, 4, 1, fp) != 1) return 2;
+    if (nmfc != flen / 4 - 1) { nmfc = (int32)__builtin_bswap32((uint32_t)nmfc); swap = 1; }
+    nfr = nmfc / ceplen;
+    mfcs = (float32 **)ckd_calloc_2d(nfr, ceplen, sizeof(float32));
+    if (fread(mfcs[0], 4, (size_t)nfr * ceplen, fp) != (size_t)nfr * ceplen) return 2;
+    fclose(fp);
+    if (swap)
+        for (i = 0; i < nfr * ceplen; ++i) { uint32_t *u = (uint32_t *)&mfcs[0][i]; *u = __builtin_bswap32(*u); }
+    copy = malloc(sizeof(float) * (size_t)nfr * ceplen);
+    memcpy(copy, mfcs[0], sizeof(float) * (size_t)nfr * ceplen);
+    fcb = feat_init(type, cmn_type_from_str(cmn), varnorm, agc_type_from_str(agc), 0, ceplen);
+    if (!fcb) return 2;
+    if (ldadim > 0) {
+        const int in = (int)fcb->stream_len[0];
+        if (fcb->n_stream != 1 || ldadim > in) { fprintf(stderr, "a transform needs one stream and at most its dimension\n"); return 2; }
+        fcb->lda = (mfcc_t ***)ckd_calloc_3d(1, ldadim, in, sizeof(mfcc_t));
+        fcb->n_lda = 1; fcb->out_dim = ldadim;
+        g_rng = 12345u;
+        for (i = 0; i < ldadim; ++i) for (k = 0; k < in; ++k) fcb->lda[0][i][k] = ((float)(rnd() & 0xffff) / 32768.0f - 1.0f) * 0.5f;
+        put2("lda", 'f', ldadim, in, fcb->lda[0][0]);
+    }
+    if (strcmp(svspec, "-")) {
+        int32 **sv = parse_subvecs(svspec), **p_, *d, n = 0, *lst;
+        if (!sv || feat_set_subvecs(fcb, sv) < 0) return 2;
+        for (p_ = sv; *p_; ++p_) for (d = *p_; *d != -1; ++d) ++n;
+        lst = ckd_calloc(n + 1, sizeof(int32));
+        for (n = 0, p_ = sv; *p_; ++p_) for (d = *p_; *d != -1; ++d) lst[n++] = *d;
+        put1("subvec", 'i', n, lst);
+    }
+    feat = feat_array_alloc(fcb, nfr);
+    nout = nfr;
+    nout = feat_s2mfc2feat_live(fcb, mfcs, &nout, TRUE, TRUE, feat);
+    /* the frames' vectors as the scorers read them: streams / subvectors side by side */
+    /* (contiguous from feat[i][0]: feat_array_alloc lays a frame's streams side by side, the transform and the projection write their
+     *  results to its start -- out_dim / sv_dim values, lda.c:156, feat.c:350) */
+    dim = 0;
+    if (fcb->sv_dim) dim = fcb->sv_dim;
+    else if (fcb->lda) dim = fcb->out_dim;
+    else for (i = 0; i < fcb->n_stream; ++i) dim += fcb->stream_len[i];
+    flat = malloc(sizeof(float) * (size_t)nout * dim);
+    for (i = 0; i < nout; ++i) memcpy(flat + (size_t)i * dim, feat[i][0], sizeof(float) * dim);
+    puti("cepsize", ceplen); puti("n_out", nout); puti("dim", dim); puti("window", feat_window_size(fcb));
+    put2("cep", 'f', nfr, ceplen, copy);
+    put2("feat", 'f', nout, dim, flat);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
 /* livefeat: what the decoder's acoustic front half hands its searches when ps_process_raw is fed a recording in CHUNKS
  * (full_utt = FALSE: pocketsphinx.c:1210-1246; acmod_process_raw / acmod_process_mfcbuf / acmod_process_cep, acmod.c:565-762;
  * fe_process_frames with its overflow buffer, fe_interface.c:352-512; feat_s2mfc2feat_live with cmn_live, feat.c:1300-1420,
@@ -1285,6 +1348,8 @@ main(int argc, char **argv)
         rc = cmd_senlog(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]));
     } else if (!strcmp(cmd, "dynfeat") && xa > 6) {
         rc = cmd_dynfeat(make_decoder(modeldir, lm, dict, nextra, extra), argv[6]);
+    } else if (!strcmp(cmd, "dynfeat_cfg") && xa > 12) {
+        rc = cmd_dynfeat_cfg(argv[6], argv[7], argv[8], atoi(argv[9]), argv[10], atoi(argv[11]), argv[12]);
     } else if (!strcmp(cmd, "livefeat") && xa > 8) {
         rc = cmd_livefeat(make_decoder(modeldir, lm, dict, nextra, extra), argv[6], atoi(argv[7]), argv[8]);
     } else if (!strcmp(cmd, "mfcc") && xa > 7) {

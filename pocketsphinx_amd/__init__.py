@@ -14,7 +14,7 @@ from .ptm import PtmModel, PtmMgau, PtmState  # noqa: F401
 from .hmm import HmmContext, HMM_REC  # noqa: F401
 from .semi import SemiMgau  # noqa: F401
 from .ms import MsMgau  # noqa: F401
-from .feat import dynfeat_1s_c_d_dd  # noqa: F401
+from .feat import dynfeat_1s_c_d_dd, FeatType  # noqa: F401
 from .fe import FrontEnd  # noqa: F401
 from .search import FwdtreeSearch, backtrace  # noqa: F401
 from .lm import NGramTrieLM  # noqa: F401

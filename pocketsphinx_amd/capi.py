@@ -39,7 +39,7 @@ SYMBOLS = [
     "psgpu_fe_process_utts_dev", "psgpu_fe_process_utts",
     "psgpu_hmm_ctx_create", "psgpu_hmm_ctx_free", "psgpu_hmm_n_emit_state",
     "psgpu_hmm_vit_eval_dev", "psgpu_hmm_vit_eval", "psgpu_phone_loop_run_dev", "psgpu_phone_loop_run_lists_dev", "psgpu_hmm_ctx_stream",
-    "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_search_session_dev", "psgpu_fwdtree_search_lists_dev", "psgpu_fwdtree_can_score_lists", "psgpu_fwdtree_n_mpx_channels", "psgpu_fwdtree_set_lm", "psgpu_fwdtree_backtrace_dev", "psgpu_fwdtree_layout", "psgpu_fwdtree_use_slab_layout", "psgpu_fwdtree_grow", "psgpu_fwdtree_full_capacity", "psgpu_fwdtree_n_single_phone_words", "psgpu_abi_version", "psgpu_capabilities", "psgpu_fe_stream_step_dev", "psgpu_fe_frame_size", "psgpu_fe_frame_shift", "psgpu_feat_live_state_words", "psgpu_feat_live_state_init", "psgpu_feat_live_step_dev", "psgpu_decode_streams_pcm_begin", "psgpu_decode_streams_step_pcm", "psgpu_live_pieces",
+    "psgpu_fwdtree_create", "psgpu_fwdtree_free", "psgpu_fwdtree_search_dev", "psgpu_fwdtree_search_session_dev", "psgpu_fwdtree_search_lists_dev", "psgpu_fwdtree_can_score_lists", "psgpu_fwdtree_n_mpx_channels", "psgpu_fwdtree_set_lm", "psgpu_fwdtree_backtrace_dev", "psgpu_fwdtree_layout", "psgpu_fwdtree_use_slab_layout", "psgpu_fwdtree_grow", "psgpu_fwdtree_full_capacity", "psgpu_fwdtree_n_single_phone_words", "psgpu_abi_version", "psgpu_capabilities", "psgpu_fe_stream_step_dev", "psgpu_fe_frame_size", "psgpu_fe_frame_shift", "psgpu_feat_live_state_words", "psgpu_feat_live_state_init", "psgpu_feat_live_step_dev", "psgpu_decode_streams_pcm_begin", "psgpu_decode_streams_step_pcm", "psgpu_live_pieces", "psgpu_feat_create", "psgpu_feat_free", "psgpu_feat_out_dim", "psgpu_feat_cepsize", "psgpu_feat_window", "psgpu_feat_compute_dev", "psgpu_feat_compute", "psgpu_decode_set_feat",
     "psgpu_decode_create", "psgpu_decode_free", "psgpu_decode_set_model", "psgpu_decode_score_mode", "psgpu_decode_session", "psgpu_decode_session_set", "psgpu_decode_session_get", "psgpu_decode_first_pass_dev", "psgpu_decode_front_end_ahead", "psgpu_decode_first_pass", "psgpu_decode_first_pass_feat",
     "psgpu_decode_view", "psgpu_decode_fetch_hyps", "psgpu_decode_fetch_tables", "psgpu_decode_fetch_tables_range", "psgpu_decode_stage_timing", "psgpu_decode_last_stage_ms", "psgpu_decode_search_after", "psgpu_decode_wait_scored", "psgpu_stream_create_dedicated", "psgpu_stream_destroy", "psgpu_fwdtree_hyp_out", "psgpu_decode_table_capacity", "psgpu_decode_second_pass", "psgpu_decode_tables_grown", "psgpu_decode_search_lag", "psgpu_fwdtree_search_lag", "psgpu_fwdtree_search_resume", "psgpu_fwdtree_search_streams", "psgpu_fwdtree_search_restart", "psgpu_phone_loop_carry_restart", "psgpu_decode_live_begin", "psgpu_decode_live_restart", "psgpu_decode_streams_begin", "psgpu_decode_streams_step", "psgpu_decode_streams_restart", "psgpu_decode_streams_next_utt", "psgpu_decode_live_step", "psgpu_decode_live_frames_searched", "psgpu_phone_loop_run_carry_dev", "psgpu_phone_loop_carry_words", "psgpu_decode_set_scorer", "psgpu_decode_compallsen", "psgpu_ms_score_batch_raw_dev", "psgpu_ms_batch_needs_lists", "psgpu_ms_list_entries_per_frame", "psgpu_semi_n_sen", "psgpu_semi_score_batch_carry_dev", "psgpu_semi_n_feat", "psgpu_semi_topn", "psgpu_semi_veclen",
     "psgpu_fwdflat_create", "psgpu_fwdflat_free", "psgpu_fwdflat_set_lm", "psgpu_fwdflat_search_dev", "psgpu_fwdflat_search_feats_dev", "psgpu_fwdflat_search_feats_lists_dev", "psgpu_ptm_batch_open_flags", "psgpu_ptm_model_view",

@@ -249,6 +249,7 @@ struct psgpu_decode_s {
     // psgpu_decode_streams_pcm_begin / _step_pcm: the streams fed with AUDIO -- per stream the front end's unframed samples with the
     // pre-emphasis prior in front (d_pcarry [n][pc_slots]), its noise tracker (d_pnoise, d_pundef), the live cepstral mean and the feature
     // window (d_pfeat: psgpu_feat_live_state_words each), and on the host the reference's buffer counters (LiveSim)
+    const psgpu_feat_t *feat = nullptr;  // psgpu_decode_set_feat: the feature type computed from the front end's cepstra (NULL: 1s_c_d_dd, batch CMN)
     bool pcm_streams = false;
     int32_t pc_slots = 0, pc_fs = 0, pc_sh = 0;
     std::vector<LiveSim> pc_sim;
@@ -704,12 +705,29 @@ static int dec_settle_fe_ahead(psgpu_decode_s *d, hipStream_t st)
     return PSGPU_OK;
 }
 
+// cepstra -> the scorer's feature vectors: the type psgpu_decode_set_feat installed, else en-us's 1s_c_d_dd with batch CMN
+static int dec_features(psgpu_decode_s *d, int32_t n_utt, hipStream_t st)
+{
+    if (d->feat) return psgpu_feat_compute_dev(d->feat, d->d_cep, d->d_off, n_utt, d->d_feat, st);
+    return psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, n_utt, d->cepsize, d->d_feat, st);
+}
+
+int psgpu_decode_set_feat(psgpu_decode_t *d, const psgpu_feat_t *feat)
+{
+    PSGPU_REQUIRE(d, "psgpu_decode_set_feat: NULL argument");
+    PSGPU_REQUIRE(!feat || (d->cfg.fe && psgpu_feat_cepsize(feat) == d->cepsize && psgpu_feat_out_dim(feat) == d->veclen),
+                  "psgpu_decode_set_feat: the feature type takes %d cepstra and makes %d-dimensional vectors; the front end makes %d, the scorer takes %d",
+                  feat ? psgpu_feat_cepsize(feat) : 0, feat ? psgpu_feat_out_dim(feat) : 0, d->cepsize, d->veclen);
+    d->feat = feat;
+    return PSGPU_OK;
+}
+
 int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const int64_t *samp_off, int32_t n_utt, void *stream)
 {
     PSGPU_REQUIRE(d && n_utt >= 0 && (n_utt == 0 || (pcm_dev && samp_off)), "psgpu_decode_first_pass_dev: bad argument");
-    PSGPU_REQUIRE(d->cfg.fe && d->veclen == 3 * d->cepsize,
+    PSGPU_REQUIRE(d->cfg.fe && (d->feat || d->veclen == 3 * d->cepsize),
                   "psgpu_decode_first_pass_dev: from PCM the pipeline computes 1s_c_d_dd vectors of %d cepstra; the scorer takes %d-dimensional "
-                  "vectors (other feature types: psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
+                  "vectors (other feature types: psgpu_decode_set_feat, or psgpu_decode_first_pass_feat)", d->cepsize, d->veclen);
     hipStream_t st = (hipStream_t)stream;
     d->n_utt = n_utt; d->total = 0; d->max_frames = 0; d->searched = false; d->pass2 = false; d->first_called = true;
     d->live = false; d->streams = false;
@@ -771,7 +789,7 @@ int psgpu_decode_first_pass_dev(psgpu_decode_t *d, const int16_t *pcm_dev, const
         PSGPU_HIP(hipMemsetAsync(d->d_hn, 0, 4 * (size_t)n_utt * 4, st));
         return PSGPU_OK;
     }
-    if ((rc = psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, n_utt, d->cepsize, d->d_feat, st))) return rc;
+    if ((rc = dec_features(d, n_utt, st))) return rc;
     if ((rc = dec_from_feat(d, n_utt, total, mf, st))) return rc;
     d->ev_valid = d->timing;
     return PSGPU_OK;
@@ -837,7 +855,7 @@ int psgpu_decode_front_end_ahead(psgpu_decode_t *d, const int16_t *pcm_dev, cons
     std::vector<int32_t> fo((size_t)n_utt + 1);
     int rc = psgpu_fe_process_utts_dev(d->cfg.fe, pcm_dev, samp_off, n_utt, nullptr, nullptr, d->d_cep, d->d_off, fo.data(), fs);
     if (rc) return rc;
-    if ((rc = psgpu_feat_1s_c_d_dd_dev(d->d_cep, d->d_off, n_utt, d->cepsize, d->d_feat, fs))) return rc;
+    if ((rc = dec_features(d, n_utt, fs))) return rc;
     PSGPU_HIP(hipEventRecord(d->ev_fe, fs));
     d->fe_ahead = true; d->fe_pcm = pcm_dev; d->fe_soff.assign(samp_off, samp_off + n_utt + 1);
     if (started) *started = 1;

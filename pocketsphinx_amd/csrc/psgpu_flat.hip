@@ -56,7 +56,10 @@ constexpr int kFfChanMask = (1 << 28) - 1, kFfClearBit = 1 << 29, kFfEnteredBit 
 constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel list held in LDS (the rest in the slab)
 constexpr int kFfRegRows = 2;           // vocabularies up to kFfRegRows x 256 words (+ fillers) keep their static records in registers
 constexpr int kFfMaxTp = 2048;         // bytes of transition matrices held in LDS (more: read from device memory)
-constexpr int kFfMaxExit = 160;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
+#ifndef PSGPU_FF_MAX_EXIT
+#define PSGPU_FF_MAX_EXIT 160
+#endif
+constexpr int kFfMaxExit = PSGPU_FF_MAX_EXIT;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
 // each frame's senone scores itself, as ptm_mgau_frame_eval does when the second pass calls it (ptm_mgau.c:408-454 with

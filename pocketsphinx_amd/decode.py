@@ -112,6 +112,12 @@ class DecodePipeline:
         except Exception:
             pass
 
+    def set_feat(self, feat):
+        """psgpu_decode_set_feat: the feature type (a FeatType, or None for en-us's 1s_c_d_dd) the pipeline computes from its front end's
+        cepstra: the semi-continuous models' s2_4x, a model with -lda ..."""
+        self._feat = feat                                  # (the C object keeps a bare pointer)
+        capi.check(capi.lib().psgpu_decode_set_feat(self.h, feat.h if feat is not None else None), "psgpu_decode_set_feat")
+
     def search_after(self, prev):
         """This object's search waits (on the device) for the search of `prev`'s latest call -- two objects taking turns, one
         batch's front end and scorer beside the other's search: see psgpu_decode_search_after."""

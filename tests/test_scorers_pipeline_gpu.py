@@ -175,6 +175,38 @@ def test_pipeline_with_the_semi_continuous_scorer_tidigits(tmp_path):
     p.close()
 
 
+def test_pipeline_from_audio_with_the_semi_continuous_scorer_tidigits(tmp_path):
+    """the same model from AUDIO: the pipeline's front end with tidigits's parameters (20 filters to 4 kHz, DC removal, DITHER -- the
+    model's feat.params insist on it; -seed 17 on both sides, the reference would seed it from the clock) and the s2_4x feature type
+    installed (psgpu_decode_set_feat) -- PCM -> MFCC -> s2_4x -> s2_semi scores -> phone loop -> tree search on the device, against the
+    reference decoding the same file.  (The dither's generator goes on from utterance to utterance: the batch's FIRST utterance is the
+    one a new decoder's first decode equals.)"""
+    _need_ref()
+    import pocketsphinx_amd as P
+    tdir = os.path.join(REF, "data", "tidigits")
+    lm, dic = os.path.join(tdir, "tidigits.lm.bin"), os.path.join(tdir, "tidigits.dic")
+    raw = os.path.join(tdir, "dhd.2934z.raw")
+    knobs = ("seed", "17", "fwdflat", "no", "bestpath", "no")
+    fe_t = _ref_dump(tmp_path, "mfcc", "tidigits", lm, dic, [raw, 1], knobs)
+    assert int(fe_t["par"][13]) == 1 and int(fe_t["dither_seed"][0]) == 17
+    g = _ref_dump(tmp_path, "fwdtree", "tidigits", lm, dic, [raw], knobs)
+    pcm = np.fromfile(raw, np.int16)
+    semi = P.SemiMgau(_load("semi_tidigits_tables.npz"))
+    p = P.DecodePipeline(fe_t, None, g, g["par"], g, scorer=semi)
+    with pytest.raises(P.PsgpuError):
+        p.run([pcm])                                       # (1s_c_d_dd vectors are not what this scorer takes)
+    ft = P.FeatType("s2_4x", cmn="current")
+    p.set_feat(ft)
+    p.run([pcm, pcm[:12000], pcm])
+    hn, hyp, res = p.fetch()
+    assert not res[:, 3].any()
+    tab = p.tables(0, res)
+    assert np.array_equal(tab["bp"], g["bp"]) and np.array_equal(tab["bscore_stack"], g["bscore_stack"])
+    assert int(hn[0, 1]) == int(g["hyp_score"][0])
+    assert int(hn[1, 0]) > 0 and int(res[2, 2]) == int(res[0, 2])
+    p.close(); ft.close()
+
+
 def test_streams_with_the_semi_continuous_scorer_tidigits(tmp_path):
     """a batch of live decoders with the semi-continuous scorer: eight tidigits utterances as eight streams, fed 11-23 frames a step
     (psgpu_decode_streams_step: the scorer's lists carried per stream by psgpu_semi_score_batch_carry_dev, frames numbered on from
