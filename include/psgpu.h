@@ -55,6 +55,7 @@ extern "C" {
 #define PSGPU_CAP_PTM_BATCH_ANY_SHAPE (1ull << 10)  /* psgpu_ptm_score_batch_dev for every shape psgpu_ptm_frame_eval serves */
 #define PSGPU_CAP_STREAMS_PCM         (1ull << 11)  /* streams fed with PCM (per-stream front-end state + live CMN on the device) */
 #define PSGPU_CAP_FWDTREE_SPLIT       (1ull << 12)  /* one utterance's tree search on several workgroups */
+#define PSGPU_CAP_LM_SETS             (1ull << 14)  /* class words in a trie model; psgpu_lm_create_interp: an interpolated model set */
 #define PSGPU_CAP_FEAT_TYPES          (1ull << 13)  /* psgpu_feat_create: every feature type of feat_init, -lda, -svspec, varnorm, agc max */
 int32_t psgpu_abi_version(void);
 uint64_t psgpu_capabilities(void);
@@ -763,9 +764,22 @@ typedef struct psgpu_lm_tables_s {
     float lw;
     int32_t log_wip, log_zero;
     const int32_t *widmap;
+    /* word classes (ngram_model_add_class / -lmctl class definitions; ngram_ng_score, lm/ngram_model.c:388-417): for a class word
+     * widmap holds its class's TAG word (-1 when ngram_class_prob does not find it in the class: the look-up is log_zero), class_weight
+     * [n_words] its in-class weight (0 for plain words; NULL: no classes), histmap [n_words] (or NULL: widmap) what the word is as a
+     * history word -- the tag word whatever the weight.  (Zero-initialise the struct: older callers leave these NULL.) */
+    const int32_t *class_weight, *histmap;
 } psgpu_lm_tables_t;
 int psgpu_lm_create(psgpu_lm_t **out, const psgpu_lm_tables_t *t);
 void psgpu_lm_free(psgpu_lm_t *lm);
+/* A model SET looked up without a current model (ngram_model_set_score with cur == -1, lm/ngram_model_set.c:685-727: after reading an
+ * -lmctl file without -lmname, or ngram_model_set_interp): the log-sum over the members of lweights[i] + member i's look-up, through
+ * the set's logmath table (addtab [addtab_size] of `width` 1 / 2 / 4 bytes = logadd_t.table, util/logmath.c:401-446; add_zero =
+ * logmath_get_zero).  members [n_members]: handles of psgpu_lm_create, each with ITS widmap from the set's word ids; they stay the
+ * caller's and must outlive the set handle.  A set with a current model needs none of this: the look-up is that member's.
+ * (PSGPU_CAP_LM_SETS.) */
+int psgpu_lm_create_interp(psgpu_lm_t **out, const psgpu_lm_t *const *members, const int32_t *lweights, int32_t n_members, const void *addtab,
+                           int32_t width, int32_t addtab_size, int32_t add_zero, int32_t log_zero);
 /* n independent look-ups: score_dev[i] = ngram_tg_score(lmset, w3[i], w2[i], w1[i], &n_used[i]);
  * w2 / w1 may be -1 (no history, as the search passes it); n_used_dev may be NULL. */
 int psgpu_lm_tg_score_dev(const psgpu_lm_t *lm, const int32_t *w3_dev, const int32_t *w2_dev, const int32_t *w1_dev,

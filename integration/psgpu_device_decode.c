@@ -43,6 +43,7 @@
 #include "psgpu.h"
 #include "psgpu_mgau_shim.h"
 #include "psgpu_fe_shim.h"
+#include "lm/ngram_model_set.h"
 #include "psgpu_lm_tables.h"
 #include "psgpu_search_tables.h"
 #include "psgpu_device_decode.h"
@@ -51,6 +52,8 @@ struct psgpu_device_decode_s {
     ps_decoder_t *ps;
     psgpu_fwdtree_t *ft;
     psgpu_lm_t *lm;                    /* the trie on the device (NULL: dense table inside ft) */
+    psgpu_lm_t *lm_members[16];        /* an interpolated model set: its members' tries (lm: psgpu_lm_create_interp over them) */
+    int n_lm_members;
     psgpu_hmm_ctx_t *ctx;
     psgpu_fe_t *fe;
     psgpu_decode_t *dec;               /* the pipeline (borrows the four above and the attached scorer's model) */
@@ -178,12 +181,34 @@ psgpu_device_decode_attach(ps_decoder_t *ps)
     /* language scores: the model's own trie on the device when it is one trie model without classes
      * (psgpu_lm_tables.c), else -- small vocabularies only -- every ngram_tg_score in a dense table */
     lm = NULL;
-    if (psgpu_lm_tables_read(ngs->lmset, &lt) == 0) {
-        if (psgpu_lm_create(&d->lm, &lt) != PSGPU_OK) {
-            E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
-            d->lm = NULL;
+    if (((ngram_model_set_t *)ngs->lmset)->cur >= 0) {
+        /* the set's current model (one model, or -lmname / ps_activate_search's choice among an -lmctl file's), word classes included */
+        if (psgpu_lm_tables_read(ngs->lmset, &lt) == 0) {
+            if (psgpu_lm_create(&d->lm, &lt) != PSGPU_OK) {
+                E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+                d->lm = NULL;
+            }
+            psgpu_lm_tables_release(&lt);
         }
-        psgpu_lm_tables_release(&lt);
+    }
+    else {
+        /* no current model: the set interpolates its members (ngram_model_set.c:697-714) -- every member's trie on the device, the
+         * log-sum over them through the set's log-add table (psgpu_lm_create_interp) */
+        psgpu_lm_set_info_t info;
+        if (psgpu_lm_set_read(ngs->lmset, &info) == 0 && info.n_models <= 16) {
+            int m, ok = 1;
+            for (m = 0; m < info.n_models && ok; ++m) {
+                ok = psgpu_lm_tables_read_member(ngs->lmset, m, &lt) == 0 && psgpu_lm_create(&d->lm_members[m], &lt) == PSGPU_OK;
+                if (ok) ++d->n_lm_members;
+                psgpu_lm_tables_release(&lt);
+            }
+            if (ok && psgpu_lm_create_interp(&d->lm, (const psgpu_lm_t *const *)d->lm_members, info.lweights, info.n_models, info.addtab,
+                                             info.addtab_width, info.addtab_size, info.add_zero, info.log_zero) != PSGPU_OK) {
+                E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+                d->lm = NULL;
+            }
+            psgpu_lm_set_release(&info);
+        }
     }
     lm_ok = d->lm != NULL || n_w <= 400;
     if (!lm_ok)
@@ -261,6 +286,7 @@ psgpu_device_decode_detach(psgpu_device_decode_t *d)
     psgpu_decode_free(d->dec);
     psgpu_fwdflat_free(d->ff); FREE_HOST(d->h_tcw);
     psgpu_fwdtree_free(d->ft); psgpu_lm_free(d->lm); psgpu_hmm_ctx_free(d->ctx); psgpu_fe_free(d->fe);
+    { int m_; for (m_ = 0; m_ < d->n_lm_members; ++m_) psgpu_lm_free(d->lm_members[m_]); d->n_lm_members = 0; }
     FREE_HOST(d->h_res); FREE_HOST(d->h_hn); FREE_HOST(d->h_bp); FREE_HOST(d->h_bss); FREE_HOST(d->h_idx); FREE_HOST(d->h_feat);
     ckd_free(d);
 }

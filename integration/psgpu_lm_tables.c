@@ -15,6 +15,7 @@
 #include "lm/ngram_model_trie.h"
 #include "lm/lm_trie.h"
 #include "lm/lm_trie_quant.h"
+#include <pocketsphinx/logmath.h>
 
 #include "psgpu_lm_tables.h"
 
@@ -22,20 +23,60 @@ int
 psgpu_lm_tables_read(ngram_model_t *lmset, psgpu_lm_tables_t *t)
 {
     ngram_model_set_t *set = (ngram_model_set_t *)lmset;
+    /* the set's CURRENT model (ngram_model_set_select / -lmname; a set of one has it selected): what ngram_model_set_score delegates
+     * to (ngram_model_set.c:715-726).  A set without one interpolates its members: psgpu_lm_tables_read_member for each +
+     * psgpu_lm_set_read + psgpu_lm_create_interp. */
+    memset(t, 0, sizeof *t);
+    if (lmset == NULL || set->cur < 0) {
+        E_ERROR("psgpu lm: the model set has no current model (an interpolated set: psgpu_lm_tables_read_member / psgpu_lm_set_read)\n");
+        return -1;
+    }
+    return psgpu_lm_tables_read_member(lmset, set->cur, t);
+}
+
+int
+psgpu_lm_set_read(ngram_model_t *lmset, psgpu_lm_set_info_t *info)
+{
+    ngram_model_set_t *set = (ngram_model_set_t *)lmset;
+    logmath_t *lmath = lmset->lmath;
+    memset(info, 0, sizeof *info);
+    info->n_models = set->n_models; info->cur = set->cur; info->lweights = set->lweights;
+    info->log_zero = lmset->log_zero; info->add_zero = logmath_get_zero(lmath);
+    {
+        /* logadd_t is private to logmath.c: the table is read through logmath_add itself -- for 0 <= d < size, with 0 and -d both
+         * above the zero, it returns 0 + table[d] (logmath.c:417-443) */
+        uint32 size = 0, width = 0, shift = 0, d;
+        uint32_t *tab;
+        if (logmath_get_table_shape(lmath, &size, &width, &shift) < 0 || size == 0 || shift != 0
+            || (int64_t)info->add_zero >= -(int64_t)size) {
+            E_ERROR("psgpu lm: the set's log-add goes through a table of shift 0 (logmath_add, logmath.c:401-446)\n");
+            return -1;
+        }
+        tab = ckd_calloc(size, sizeof *tab);
+        for (d = 0; d < size; ++d) tab[d] = (uint32_t)logmath_add(lmath, 0, -(int)d);
+        info->addtab = tab; info->addtab_width = 4; info->addtab_size = (int32_t)size;
+    }
+    return 0;
+}
+
+int
+psgpu_lm_tables_read_member(ngram_model_t *lmset, int member, psgpu_lm_tables_t *t)
+{
+    ngram_model_set_t *set = (ngram_model_set_t *)lmset;
     ngram_model_t *base;
     lm_trie_t *trie;
     int order, l, n_lev, w;
     float *q;
-    int32_t *map;
+    int32_t *map, *hmap = NULL, *cwt = NULL;
 
     memset(t, 0, sizeof *t);
-    if (lmset == NULL || set->n_models != 1 || set->cur != 0) {
-        E_ERROR("psgpu lm: the model set must hold exactly one, selected, model\n");
+    if (lmset == NULL || member < 0 || member >= set->n_models) {
+        E_ERROR("psgpu lm: no such member of the model set\n");
         return -1;
     }
-    base = set->lms[0];
-    if (base->funcs == lmset->funcs || base->n_classes != 0 || base->n < 1 || base->n > PSGPU_LM_MAX_LEVELS + 1) {
-        E_ERROR("psgpu lm: needs a trie model without word classes, order <= %d\n", PSGPU_LM_MAX_LEVELS + 1);
+    base = set->lms[member];
+    if (base->funcs == lmset->funcs || base->n < 1 || base->n > PSGPU_LM_MAX_LEVELS + 1) {
+        E_ERROR("psgpu lm: needs a trie model of order <= %d\n", PSGPU_LM_MAX_LEVELS + 1);
         return -1;
     }
     trie = ((ngram_model_trie_t *)base)->trie;
@@ -71,15 +112,41 @@ psgpu_lm_tables_read(ngram_model_t *lmset, psgpu_lm_tables_t *t)
         t->quant = q;
     }
     map = ckd_calloc(lmset->n_words > 0 ? lmset->n_words : 1, sizeof *map);
-    for (w = 0; w < lmset->n_words; ++w) map[w] = set->widmap[w][0];
-    t->widmap = map;
+    if (base->n_classes > 0) {
+        hmap = ckd_calloc(lmset->n_words > 0 ? lmset->n_words : 1, sizeof *hmap);
+        cwt = ckd_calloc(lmset->n_words > 0 ? lmset->n_words : 1, sizeof *cwt);
+    }
+    for (w = 0; w < lmset->n_words; ++w) {
+        int32 mw = set->widmap[w][member];
+        /* ngram_ng_score's "declassify" (ngram_model.c:396-412), done here once per word: a class word is its class's tag word, its
+         * in-class weight is added to a look-up FOR it, and a word ngram_class_prob does not find makes the look-up log_zero */
+        if (mw != NGRAM_INVALID_WID && NGRAM_IS_CLASSWID(mw)) {
+            ngram_class_t *cls = base->classes[NGRAM_CLASSID(mw)];
+            int32 cw = ngram_class_prob(cls, mw);
+            hmap[w] = cls->tag_wid;
+            map[w] = cw == 1 ? -1 : cls->tag_wid;
+            cwt[w] = cw == 1 ? 0 : cw;
+        }
+        else {
+            map[w] = mw;
+            if (hmap) hmap[w] = mw;
+        }
+    }
+    t->widmap = map; t->histmap = hmap; t->class_weight = cwt;
     t->lw = base->lw; t->log_wip = base->log_wip; t->log_zero = base->log_zero;
     return 0;
 }
 
 void
+psgpu_lm_set_release(psgpu_lm_set_info_t *info)
+{
+    ckd_free((void *)info->addtab);
+    memset(info, 0, sizeof *info);
+}
+
+void
 psgpu_lm_tables_release(psgpu_lm_tables_t *t)
 {
-    ckd_free((void *)t->quant); ckd_free((void *)t->widmap);
+    ckd_free((void *)t->quant); ckd_free((void *)t->widmap); ckd_free((void *)t->histmap); ckd_free((void *)t->class_weight);
     memset(t, 0, sizeof *t);
 }

@@ -338,6 +338,73 @@ def fwdtree_topn_only():
               os.path.getsize(os.path.join(GOLD, "fwdtree_result_%s.npz" % name)))
 
 
+def _arpa_ngrams(path, limit):
+    """word tuples of the 2- and 3-gram sections of an ARPA file (plain or .gz)"""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    out, sec = [], 0
+    with op(path, "rt", errors="replace") as fh:
+        for ln in fh:
+            ln = ln.strip()
+            if ln.startswith("\\") and ln.endswith("-grams:"):
+                sec = int(ln[1:ln.index("-")]); continue
+            if sec in (2, 3) and ln and not ln.startswith("\\"):
+                f = ln.split()
+                if len(f) >= 1 + sec:
+                    out.append(tuple(f[1:1 + sec]))
+    rng = np.random.default_rng(5)
+    if len(out) > limit:
+        out = [out[i] for i in sorted(rng.choice(len(out), limit, replace=False))]
+    return out
+
+
+def lm_set_only():
+    """A model SET from the reference's own -lmctl fixture (test/unit/test_ngram/100.lmctl: three models, two word classes defined in
+    100.probdef), looked up with one member selected and interpolated (ref_dump lm_set): the members' tables, the set's weights and
+    log-add table, queries -- n-grams the members hold + random triples -- and ngram_tg_score's answers."""
+    ngdir = "/root/reference/test/unit/test_ngram"
+    lmctl = os.path.join(ngdir, "100.lmctl")
+    d0 = ref_dump("lm_set", lmctl, "interp", 0, 6.5, 0.65, model="-", lm="-", dic="-")
+    words = bytes(d0["words"]).decode().split("\n")[:-1]
+    wid = {w: i for i, w in enumerate(words)}
+    grams = []
+    for f in ("turtle.lm", "100.lm.gz", "102.lm.gz"):
+        grams += _arpa_ngrams(os.path.join(ngdir, f), 700)
+    qs = []
+    rng = np.random.default_rng(9)
+    for g_ in grams:
+        ids = [wid.get(w, wid.get(w.lower(), -2)) for w in g_]
+        if min(ids) < 0:
+            continue
+        qs.append((ids[-1], ids[-2], ids[-3] if len(ids) > 2 else -1))
+    cls = [i for i, w in enumerate(words) if ":" in w]              # the class words: as the word looked up and as history
+    for c in cls:
+        for _ in range(12):
+            a, b = int(rng.integers(0, len(words))), int(rng.integers(0, len(words)))
+            qs += [(c, a, b), (a, c, b), (a, b, c), (c, -1, -1), (a, c, -1)]
+    for _ in range(600):
+        a, b, c = (int(v) for v in rng.integers(0, len(words), 3))
+        qs.append((a, b if rng.random() > 0.15 else -1, c if rng.random() > 0.3 else -1))
+    qs = [(a, b, (c if b >= 0 else -1)) for a, b, c in qs]
+    q = np.array(qs, np.int32)
+    with tempfile.NamedTemporaryFile(suffix=".q", delete=False) as fh:
+        q.tofile(fh); qpath = fh.name
+    out = {}
+    for mi, mode in enumerate(("select:100", "select:102", "select:turtle", "interp", "interp:0.5,0.3,0.2")):
+        d = ref_dump("lm_set", lmctl, mode, q.shape[0], 6.5, 0.65, qpath, model="-", lm="-", dic="-")
+        assert np.array_equal(d["queries"], q)
+        if mi == 0:
+            for k, v in d.items():
+                if k.startswith("m") and k[1].isdigit() or k in ("n_models", "n_words", "addtab", "add_zero", "set_log_zero", "words", "queries"):
+                    out[k] = v
+        out["mode%d" % mi] = np.frombuffer(mode.encode(), np.uint8)
+        out["cur%d" % mi] = d["cur"]; out["lweights%d" % mi] = d["lweights"]; out["scores%d" % mi] = d["scores"]; out["n_used%d" % mi] = d["n_used"]
+        print("lm_set", mode, "queries", q.shape[0], "n_used", np.unique(d["n_used"], return_counts=True), "log_zero answers", int((d["scores"] <= d["set_log_zero"][0]).sum()))
+    os.unlink(qpath)
+    np.savez_compressed(os.path.join(GOLD, "lm_set_100.npz"), **out)
+    print(os.path.getsize(os.path.join(GOLD, "lm_set_100.npz")))
+
+
 FEAT_CASES = [("s2_4x", "batch", 0, "none", 0, "-"), ("s3_1x39", "batch", 1, "max", 0, "-"), ("1s_c_d_dd", "batch", 0, "none", 29, "0-9/10-19/20-28"),
               ("1s_c_d_ld_dd", "none", 0, "none", 0, "-"), ("1s_c_d", "batch", 1, "none", 0, "-"), ("1s_c", "none", 0, "max", 0, "-"),
               ("1s_3c", "batch", 0, "none", 40, "-"), ("5,8:2", "batch", 0, "none", 0, "-"), ("1s_c_d_dd", "batch", 0, "none", 0, "0-12/13-25/26-38"),
@@ -640,6 +707,8 @@ if __name__ == "__main__":
         mfcc_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "dynfeat":
         dynfeat_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lm_set":
+        lm_set_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "feat_types":
         feat_types_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "livefeat":

@@ -1314,6 +1314,93 @@ cmd_livefeat(ps_decoder_t *ps, const char *rawpath, int nutt, const char *chunks
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* lm_set: a model SET read from an -lmctl file (ngram_model_set_read, lm/ngram_model_set.c:185-330: several models over a merged word
+ * list, word classes from class-definition files), looked up as the n-gram search looks its model up (ngram_tg_score on the set) --
+ * with one member selected (MODE = select:NAME) or interpolated (MODE = interp, or interp:w0,w1,...; ngram_model_set_score,
+ * :685-727).  Written: every member's tables (class words resolved, psgpu_lm_tables_read_member), the set's weights and log-add
+ * table, N pseudo-random queries over the set's words (a third with one or both history words absent) and their scores. */
+static int
+cmd_lm_set(const char *lmctl, const char *mode, int nq, float lw, float wip, const char *qfile)
+{
+    logmath_t *lmath = logmath_init(1.0001, 0, 1);        /* (the decoder's: a table, shift 0 -- acmod.c:245) */
+    ngram_model_t *set = ngram_model_set_read(NULL, lmctl, lmath);
+    ngram_model_set_t *s_;
+    psgpu_lm_set_info_t info;
+    int i, m;
+    int32 *q, *sc, *nu;
+    if (!set) { fprintf(stderr, "cannot read %s\n", lmctl); return 2; }
+    s_ = (ngram_model_set_t *)set;
+    ngram_model_apply_weights(set, lw, wip);
+    if (!strncmp(mode, "select:", 7)) { if (!ngram_model_set_select(set, mode + 7)) return 2; }
+    else if (!strcmp(mode, "interp")) { if (!ngram_model_set_interp(set, NULL, NULL)) return 2; }
+    else if (!strncmp(mode, "interp:", 7)) {
+        float32 w[16]; const char *names[16]; int n = 0; char *cp = ckd_salloc(mode + 7), *tok;
+        for (tok = strtok(cp, ","); tok && n < 16; tok = strtok(NULL, ",")) w[n++] = (float32)atof(tok);
+        if (n != s_->n_models) return 2;
+        for (i = 0; i < n; ++i) names[i] = s_->names[i];
+        if (!ngram_model_set_interp(set, names, w)) return 2;
+    }
+    else return 2;
+    if (psgpu_lm_set_read(set, &info) < 0) return 2;
+    puti("n_models", info.n_models); puti("cur", info.cur); puti("set_log_zero", info.log_zero); puti("add_zero", info.add_zero);
+    put1("lweights", 'i', info.n_models, info.lweights);
+    put1("addtab", 'i', info.addtab_size, info.addtab);
+    puti("n_words", set->n_words);
+    for (m = 0; m < info.n_models; ++m) {
+        psgpu_lm_tables_t t;
+        uint32_t lev[PSGPU_LM_MAX_LEVELS * 7];
+        char nm[48];
+        int32_t v; int l;
+        if (psgpu_lm_tables_read_member(set, m, &t) < 0) return 2;
+#define NM(x) (snprintf(nm, sizeof nm, "m%d_%s", m, x), nm)
+        v = t.order; put1(NM("order"), 'i', 1, &v); v = t.n_unigrams; put1(NM("n_unigrams"), 'i', 1, &v); v = t.n_words; put1(NM("n_words"), 'i', 1, &v);
+        put2(NM("unigrams"), 'i', t.n_unigrams + 1, 3, t.unigrams);
+        put1(NM("ngram_mem"), 'B', (int64_t)t.ngram_mem_size, t.ngram_mem ? (const void *)t.ngram_mem : (const void *)"");
+        for (l = 0; l < t.order - 1; ++l) {
+            lev[7 * l] = t.level_offset[l]; lev[7 * l + 1] = t.total_bits[l]; lev[7 * l + 2] = t.word_bits[l];
+            lev[7 * l + 3] = t.word_mask[l]; lev[7 * l + 4] = t.max_vocab[l]; lev[7 * l + 5] = t.next_bits[l]; lev[7 * l + 6] = t.next_mask[l];
+        }
+        put2(NM("levels"), 'i', t.order - 1, 7, lev);
+        if (t.order > 1) put2(NM("quant"), 'f', 2 * (t.order - 2) + 1, 65536, t.quant);
+        put1(NM("lw"), 'f', 1, &t.lw); v = t.log_wip; put1(NM("log_wip"), 'i', 1, &v); v = t.log_zero; put1(NM("log_zero"), 'i', 1, &v);
+        put1(NM("widmap"), 'i', t.n_words, t.widmap);
+        if (t.class_weight) { put1(NM("class_weight"), 'i', t.n_words, t.class_weight); put1(NM("histmap"), 'i', t.n_words, t.histmap); }
+#undef NM
+        psgpu_lm_tables_release(&t);
+    }
+    q = ckd_calloc(3 * (size_t)nq + 1, 4); sc = ckd_calloc(nq + 1, 4); nu = ckd_calloc(nq + 1, 4);
+    g_rng = 777u;
+    for (i = 0; i < nq; ++i) {
+        q[3 * i] = (int32)(rnd() % (uint32_t)set->n_words);
+        q[3 * i + 1] = (rnd() % 6 == 0) ? -1 : (int32)(rnd() % (uint32_t)set->n_words);
+        q[3 * i + 2] = (q[3 * i + 1] < 0 || rnd() % 5 == 0) ? -1 : (int32)(rnd() % (uint32_t)set->n_words);
+    }
+    /* QFILE: int32 triples (w3, w2, w1) in the set's word ids replace the pseudo-random ones (oracle/make_golden.py writes n-grams the
+     * members hold, from their text files: the trie's middle and longest levels are reached, not only the back-off to unigrams) */
+    if (qfile && strcmp(qfile, "-")) {
+        FILE *fp = fopen(qfile, "rb");
+        long n;
+        if (!fp) { perror(qfile); return 2; }
+        fseek(fp, 0, SEEK_END); n = ftell(fp) / 12; fseek(fp, 0, SEEK_SET);
+        if (n > nq) n = nq;
+        if (fread(q, 12, n, fp) != (size_t)n) return 2;
+        fclose(fp);
+        for (i = 0; i < 3 * (int)n; ++i) if (q[i] >= set->n_words || q[i] < -1 || (i % 3 == 0 && q[i] < 0)) return 2;
+    }
+    {   /* the set's words, newline-separated */
+        size_t nb = 0; char *words; int w;
+        for (w = 0; w < set->n_words; ++w) nb += strlen(ngram_word(set, w)) + 1;
+        words = ckd_calloc(nb + 1, 1);
+        for (w = 0, nb = 0; w < set->n_words; ++w) { const char *x = ngram_word(set, w); memcpy(words + nb, x, strlen(x)); nb += strlen(x); words[nb++] = '\n'; }
+        put1("words", 'B', (int64_t)nb, words);
+    }
+    for (i = 0; i < nq; ++i) sc[i] = ngram_tg_score(set, q[3 * i], q[3 * i + 1], q[3 * i + 2], &nu[i]);
+    put2("queries", 'i', nq, 3, q); put1("scores", 'i', nq, sc); put1("n_used", 'i', nq, nu);
+    psgpu_lm_set_release(&info);
+    return 0;
+}
+
 int
 main(int argc, char **argv)
 {
@@ -1383,6 +1470,9 @@ main(int argc, char **argv)
         set = ngram_model_set_init(NULL, &m, &name, NULL, 1);
         ngram_model_apply_weights(set, (float32)atof(argv[7]), (float32)atof(argv[8]));
         rc = cmd_lm(set, argv[6]);
+    } else if (!strcmp(cmd, "lm_set") && xa > 10) {
+        /* ref_dump lm_set OUT - - - LMCTL MODE N_QUERIES LW WIP [QFILE] */
+        rc = cmd_lm_set(argv[6], argv[7], atoi(argv[8]), (float)atof(argv[9]), (float)atof(argv[10]), xa > 11 ? argv[11] : NULL);
     } else if (!strcmp(cmd, "hmmsyn") && argc > 6) {
         /* ref_dump hmmsyn out.psgb n_emit n_hmm n_steps seed  (no model) */
         rc = cmd_hmmsyn(atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));

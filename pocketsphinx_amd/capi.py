@@ -43,7 +43,7 @@ SYMBOLS = [
     "psgpu_decode_create", "psgpu_decode_free", "psgpu_decode_set_model", "psgpu_decode_score_mode", "psgpu_decode_session", "psgpu_decode_session_set", "psgpu_decode_session_get", "psgpu_decode_first_pass_dev", "psgpu_decode_front_end_ahead", "psgpu_decode_first_pass", "psgpu_decode_first_pass_feat",
     "psgpu_decode_view", "psgpu_decode_fetch_hyps", "psgpu_decode_fetch_tables", "psgpu_decode_fetch_tables_range", "psgpu_decode_stage_timing", "psgpu_decode_last_stage_ms", "psgpu_decode_search_after", "psgpu_decode_wait_scored", "psgpu_stream_create_dedicated", "psgpu_stream_destroy", "psgpu_fwdtree_hyp_out", "psgpu_decode_table_capacity", "psgpu_decode_second_pass", "psgpu_decode_tables_grown", "psgpu_decode_search_lag", "psgpu_fwdtree_search_lag", "psgpu_fwdtree_search_resume", "psgpu_fwdtree_search_streams", "psgpu_fwdtree_search_restart", "psgpu_phone_loop_carry_restart", "psgpu_decode_live_begin", "psgpu_decode_live_restart", "psgpu_decode_streams_begin", "psgpu_decode_streams_step", "psgpu_decode_streams_restart", "psgpu_decode_streams_next_utt", "psgpu_decode_live_step", "psgpu_decode_live_frames_searched", "psgpu_phone_loop_run_carry_dev", "psgpu_phone_loop_carry_words", "psgpu_decode_set_scorer", "psgpu_decode_compallsen", "psgpu_ms_score_batch_raw_dev", "psgpu_ms_batch_needs_lists", "psgpu_ms_list_entries_per_frame", "psgpu_semi_n_sen", "psgpu_semi_score_batch_carry_dev", "psgpu_semi_n_feat", "psgpu_semi_topn", "psgpu_semi_veclen",
     "psgpu_fwdflat_create", "psgpu_fwdflat_free", "psgpu_fwdflat_set_lm", "psgpu_fwdflat_search_dev", "psgpu_fwdflat_search_feats_dev", "psgpu_fwdflat_search_feats_lists_dev", "psgpu_ptm_batch_open_flags", "psgpu_ptm_model_view",
-    "psgpu_lm_create", "psgpu_lm_free", "psgpu_lm_tg_score_dev",
+    "psgpu_lm_create", "psgpu_lm_create_interp", "psgpu_lm_free", "psgpu_lm_tg_score_dev",
 ]
 
 

@@ -47,7 +47,7 @@ int32_t psgpu_abi_version(void) { return PSGPU_ABI_VERSION; }
 uint64_t psgpu_capabilities(void)
 {
     return PSGPU_CAP_PTM | PSGPU_CAP_SEMI | PSGPU_CAP_MS | PSGPU_CAP_HMM | PSGPU_CAP_FE | PSGPU_CAP_FWDTREE | PSGPU_CAP_FWDFLAT
-         | PSGPU_CAP_TRIE_LM | PSGPU_CAP_DECODE | PSGPU_CAP_STREAMS | PSGPU_CAP_PTM_BATCH_ANY_SHAPE | PSGPU_CAP_STREAMS_PCM | PSGPU_CAP_FEAT_TYPES;      // (only what this build serves)
+         | PSGPU_CAP_TRIE_LM | PSGPU_CAP_DECODE | PSGPU_CAP_STREAMS | PSGPU_CAP_PTM_BATCH_ANY_SHAPE | PSGPU_CAP_STREAMS_PCM | PSGPU_CAP_FEAT_TYPES | PSGPU_CAP_LM_SETS;      // (only what this build serves)
 }
 const char *psgpu_last_error(void) { return g_err; }
 

@@ -1,6 +1,7 @@
 // psgpu_lm.hip -- the trigram language model on the device: table upload and the
 // batch look-up entry point.  The look-up itself is psgpu_lm_dev.h.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -40,7 +41,7 @@ extern "C" int psgpu_lm_create(psgpu_lm_t **out, const psgpu_lm_tables_t *t)
         if (t->word_bits[l] > 25 || t->next_bits[l] > 25 || t->level_offset[l] > t->ngram_mem_size)
             return psgpu_fail(PSGPU_EINVAL, "psgpu_lm_create: a level's bit layout is outside what bitarr_read_int25 can read");
     for (int32_t w = 0; w < t->n_words; ++w)
-        if (t->widmap[w] < -1 || t->widmap[w] >= t->n_unigrams)
+        if (t->widmap[w] < -1 || t->widmap[w] >= t->n_unigrams || (t->histmap && (t->histmap[w] < -1 || t->histmap[w] >= t->n_unigrams)))
             return psgpu_fail(PSGPU_EINVAL, "psgpu_lm_create: widmap entry outside the model's unigrams");
     {
         const int dev = psgpu_check_device();
@@ -54,12 +55,48 @@ extern "C" int psgpu_lm_create(psgpu_lm_t **out, const psgpu_lm_tables_t *t)
     d.mem = (const uint8_t *)lm_up(m, t->ngram_mem, t->order > 1 ? (size_t)t->ngram_mem_size : 0, 16, &rc);
     d.quant = (const float *)lm_up(m, t->quant, t->order > 1 ? (size_t)(2 * (t->order - 2) + 1) * 65536 * 4 : 0, 0, &rc);
     d.widmap = (const int32_t *)lm_up(m, t->widmap, 4 * (size_t)t->n_words, 0, &rc);
+    d.cwt = t->class_weight ? (const int32_t *)lm_up(m, t->class_weight, 4 * (size_t)t->n_words, 0, &rc) : nullptr;
+    d.histmap = t->histmap ? (const int32_t *)lm_up(m, t->histmap, 4 * (size_t)t->n_words, 0, &rc) : nullptr;
+    d.n_set = 0; d.set = nullptr; d.set_lw = nullptr; d.addtab = nullptr; d.addtab_n = 0; d.add_zero = 0;
     for (int l = 0; l < t->order - 1; ++l) {
         d.lev[l].off = t->level_offset[l]; d.lev[l].total_bits = t->total_bits[l]; d.lev[l].word_bits = t->word_bits[l];
         d.lev[l].word_mask = t->word_mask[l]; d.lev[l].max_vocab = t->max_vocab[l]; d.lev[l].next_bits = t->next_bits[l];
         d.lev[l].next_mask = t->next_mask[l];
     }
     d.lw = t->lw; d.log_wip = t->log_wip; d.log_zero = t->log_zero;
+    if (rc == PSGPU_OK) m->d_dev = (LmDev *)const_cast<void *>(lm_up(m, &d, sizeof d, 0, &rc));
+    if (rc != PSGPU_OK) { psgpu_lm_free(m); return rc; }
+    *out = m;
+    return PSGPU_OK;
+}
+
+extern "C" int psgpu_lm_create_interp(psgpu_lm_t **out, const psgpu_lm_t *const *members, const int32_t *lweights, int32_t n_members,
+                                      const void *addtab, int32_t width, int32_t addtab_size, int32_t add_zero, int32_t log_zero)
+{
+    if (!out || !members || !lweights || n_members < 1 || n_members > 64) return psgpu_fail(PSGPU_EINVAL, "psgpu_lm_create_interp: 1..64 members");
+    if (addtab_size < 0 || (addtab_size > 0 && (!addtab || (width != 1 && width != 2 && width != 4))))
+        return psgpu_fail(PSGPU_EINVAL, "psgpu_lm_create_interp: the log-add table is [size] of 1, 2 or 4 bytes");
+    int order = 0;
+    for (int i = 0; i < n_members; ++i) {
+        if (!members[i] || members[i]->d.n_set || members[i]->d.n_words != members[0]->d.n_words)
+            return psgpu_fail(PSGPU_EINVAL, "psgpu_lm_create_interp: members are plain models over one word list");
+        order = std::max(order, members[i]->d.order);
+    }
+    psgpu_lm_s *m = new psgpu_lm_s();
+    int rc = PSGPU_OK;
+    std::vector<LmDev> mem((size_t)n_members);
+    for (int i = 0; i < n_members; ++i) mem[i] = members[i]->d;
+    std::vector<uint32_t> tab((size_t)std::max(addtab_size, 1), 0u);
+    for (int i = 0; i < addtab_size; ++i)
+        tab[i] = width == 1 ? ((const uint8_t *)addtab)[i] : width == 2 ? ((const uint16_t *)addtab)[i] : ((const uint32_t *)addtab)[i];
+    LmDev &d = m->d;
+    memset(&d, 0, sizeof d);
+    d.order = order; d.n_words = members[0]->d.n_words; d.n_unigrams = 0; d.log_zero = log_zero; d.lw = 1.0f;
+    d.n_set = n_members;
+    d.set = (const LmDev *)lm_up(m, mem.data(), sizeof(LmDev) * mem.size(), 0, &rc);
+    d.set_lw = (const int32_t *)lm_up(m, lweights, 4 * (size_t)n_members, 0, &rc);
+    d.addtab = (const uint32_t *)lm_up(m, tab.data(), 4 * tab.size(), 0, &rc);
+    d.addtab_n = addtab_size; d.add_zero = add_zero;
     if (rc == PSGPU_OK) m->d_dev = (LmDev *)const_cast<void *>(lm_up(m, &d, sizeof d, 0, &rc));
     if (rc != PSGPU_OK) { psgpu_lm_free(m); return rc; }
     *out = m;

@@ -26,6 +26,17 @@ struct LmDev {
     float lw;
     int32_t log_wip, log_zero;
     const int32_t *widmap;    // [n_words]
+    // word classes (ngram_ng_score's "declassify", lm/ngram_model.c:388-417): a class word scores as its class's tag word plus its
+    // in-class weight; as a history word it IS the tag word.  widmap carries the tag word's id for it (-1 when ngram_class_prob does not
+    // find it: log_zero), histmap (or NULL: widmap) what it is as history, cwt (or NULL) the weight
+    const int32_t *histmap, *cwt;
+    // a model SET without a current model (ngram_model_set_score, lm/ngram_model_set.c:685-727): the look-up is the log-sum over the
+    // members of lweights[i] + member i's look-up, through the set's own log-add table (logmath_add, util/logmath.c:401-446)
+    int32_t n_set;
+    const LmDev *set;         // [n_set] members (device memory)
+    const int32_t *set_lw;    // [n_set]
+    const uint32_t *addtab;   // logadd_t.table widened to 32 bits
+    int32_t addtab_n, add_zero;
 };
 
 struct LmRange { uint32_t begin, end; };
@@ -163,15 +174,15 @@ __device__ inline float lm_hist_score(const LmDev &m, int32_t wid, const int32_t
 
 // ngram_tg_score(lmset, w3, w2, w1, &n_used) with dictionary word ids; w2 / w1 may be -1.  (lm_tg_score_call below is the
 // out-of-line form for kernels with several call sites.)
-__device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, int32_t w1, int &n_used)
+__device__ inline int32_t lm_tg_score_one(const LmDev &m, int32_t w3, int32_t w2, int32_t w1, int &n_used)
 {
     int32_t hist[2];
     int n_hist = min(2, m.order - 1);                       // ngram_model_set.c:693
     const int32_t wid = psgpu_as_global(m.widmap)[w3];
-    hist[0] = w2 < 0 ? -1 : psgpu_as_global(m.widmap)[w2];
-    hist[1] = w1 < 0 ? -1 : psgpu_as_global(m.widmap)[w1];
-    n_used = 0;
-    if (wid == -1) return m.log_zero;                       // ngram_model.c:394
+    const int32_t *const hm = m.histmap ? psgpu_as_global(m.histmap) : psgpu_as_global(m.widmap);
+    hist[0] = w2 < 0 ? -1 : hm[w2];
+    hist[1] = w1 < 0 ? -1 : hm[w1];
+    if (wid == -1) return m.log_zero;                       // ngram_model.c:394 (n_used stays what it was: a set's next member may leave the one before's)
     for (int i = 0; i < n_hist; ++i) if (hist[i] < 0) { n_hist = i; break; }    // ngram_model_trie.c:724-731
     float s;
     if (n_hist < m.order - 1) {                             // lm_trie.c:813-828, :733-742
@@ -181,7 +192,26 @@ __device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, in
     else
         s = lm_hist_score(m, wid, hist, n_hist, n_used);
     const int32_t raw = (int32_t)s;
-    return (int32_t)__fadd_rn(__fmul_rn((float)raw, m.lw), (float)m.log_wip);    // weight_score, ngram_model_trie.c:710
+    const int32_t ws = (int32_t)__fadd_rn(__fmul_rn((float)raw, m.lw), (float)m.log_wip);    // weight_score, ngram_model_trie.c:710
+    return m.cwt ? ws + psgpu_as_global(m.cwt)[w3] : ws;    // "multiply by unigram in-class weight", ngram_model.c:415-416
+}
+// logmath_add (util/logmath.c:401-446) with the set's table
+__device__ __forceinline__ int32_t lm_logadd(const LmDev &m, int32_t x, int32_t y)
+{
+    if (x <= m.add_zero) return y;
+    if (y <= m.add_zero) return x;
+    const int32_t r = x > y ? x : y, d = (int32_t)((uint32_t)r - (uint32_t)(x > y ? y : x));
+    if (d < 0 || d >= m.addtab_n) return r;
+    return r + (int32_t)psgpu_as_global(m.addtab)[d];
+}
+__device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, int32_t w1, int &n_used)
+{
+    n_used = 0;
+    if (m.n_set <= 0) return lm_tg_score_one(m, w3, w2, w1, n_used);
+    int32_t score = m.log_zero;                             // ngram_model_set.c:697-714
+    for (int i = 0; i < m.n_set; ++i)
+        score = lm_logadd(m, score, psgpu_as_global(m.set_lw)[i] + lm_tg_score_one(psgpu_as_global(m.set)[i], w3, w2, w1, n_used));
+    return score;
 }
 
 // Out of line, the descriptor read from device memory: ONE copy of the trie walk (~1,400 instructions) per kernel however

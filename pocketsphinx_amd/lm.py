@@ -18,7 +18,7 @@ class _LmTables(C.Structure):
                 ("max_vocab", C.c_uint32 * MAX_LEVELS), ("next_bits", C.c_uint32 * MAX_LEVELS),
                 ("next_mask", C.c_uint32 * MAX_LEVELS),
                 ("quant", C.c_void_p), ("lw", C.c_float), ("log_wip", C.c_int32), ("log_zero", C.c_int32),
-                ("widmap", C.c_void_p)]
+                ("widmap", C.c_void_p), ("class_weight", C.c_void_p), ("histmap", C.c_void_p)]
 
 
 class NGramTrieLM:
@@ -46,6 +46,10 @@ class NGramTrieLM:
         t.log_wip = int(np.asarray(g["log_wip"]).ravel()[0]) if log_wip is None else int(log_wip)
         t.log_zero = int(np.asarray(g["log_zero"]).ravel()[0])
         t.widmap = self._keep["widmap"].ctypes.data
+        if "class_weight" in g and g["class_weight"] is not None:      # word classes: psgpu_lm_tables_t.class_weight / .histmap
+            self._keep["class_weight"] = np.ascontiguousarray(g["class_weight"], np.int32)
+            self._keep["histmap"] = np.ascontiguousarray(g["histmap"], np.int32)
+            t.class_weight = self._keep["class_weight"].ctypes.data; t.histmap = self._keep["histmap"].ctypes.data
         self.n_words = t.n_words; self.order = order
         self.h = C.c_void_p()
         capi.check(capi.lib().psgpu_lm_create(C.byref(self.h), C.byref(t)), "psgpu_lm_create")
@@ -78,3 +82,24 @@ class NGramTrieLM:
         if torch.is_tensor(queries):
             return sc, nu
         return sc.cpu().numpy(), nu.cpu().numpy()
+
+
+class NGramSetLM(NGramTrieLM):
+    """A model set looked up WITHOUT a current model (ngram_model_set_score with cur == -1, reference src/lm/ngram_model_set.c:685-727):
+    the log-sum of lweights[i] + member i's look-up through the set's log-add table.  members: NGramTrieLM objects over the set's word
+    ids (they stay alive with this object); addtab: logadd_t.table as integers; add_zero: logmath_get_zero; log_zero: the set's."""
+
+    def __init__(self, members, lweights, addtab, add_zero, log_zero):
+        self.members = list(members)
+        hs = (C.c_void_p * len(self.members))(*[m.h for m in self.members])
+        lw = np.ascontiguousarray(lweights, np.int32)
+        tab = np.ascontiguousarray(addtab, np.uint32)
+        self.n_words = self.members[0].n_words; self.order = max(m.order for m in self.members)
+        self.h = C.c_void_p()
+        capi.check(self._lib().psgpu_lm_create_interp(C.byref(self.h), hs, lw.ctypes.data_as(C.c_void_p), len(self.members),
+                                                      tab.ctypes.data_as(C.c_void_p), 4, int(tab.size), int(add_zero), int(log_zero)),
+                   "psgpu_lm_create_interp")
+
+    @staticmethod
+    def _lib():
+        return capi.lib()

@@ -526,6 +526,26 @@ def test_dropin_device_search_vtable(raw, nrep, extra, lm, dic):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lmname", ["turtle", "medium"])
+def test_dropin_device_search_with_a_model_set_and_a_word_class(lmname, tmp_path):
+    """-lmctl (ngram_model_set_read, lm/ngram_model_set.c:185-330): two models over the medium dictionary -- the turtle LM with a word
+    class defined on one of its words (forward -> the class "forward" = {forward:forward 0.7, ahead:forward 0.3}) and the medium LM --
+    decoded with each member selected by -lmname (ps_init insists on one, pocketsphinx.c:400; the class member: class words resolved
+    on the device's word map, psgpu_lm_tables_read_member.  A set WITHOUT a current model -- ngram_model_set_interp through the API --
+    is tests/test_lm_set.py's: look-ups against the reference's, and a search with a set handle).
+    Decoder B's first pass on the device (the ps_searchfuncs_t binding), the reference's lattice pass on its tables: hypothesis, path
+    score and every segment equal the CPU decoder's."""
+    ctl = tmp_path / "set.lmctl"
+    (tmp_path / "cls.probdef").write_text("LMCLASS forward\nforward:forward 0.7\nahead:forward 0.3\nEND forward\n")
+    ctl.write_text("{ %s }\n%s turtle { forward }\n%s medium\n" % (tmp_path / "cls.probdef", os.path.join(DATA, "turtle.lm.bin"), os.path.join(DATA, "medium.arpa")))
+    extra = ("lmctl", str(ctl), "fwdflat", "no", "bestpath", "yes", "lmname", lmname)
+    r = run("goforward.raw", 1, "psgpu_device_vtable", "yes", *extra, lm="-", dic="medium.dic")
+    assert r["ok"] and r["rc"] == 0, r
+    assert r["hyp_equal"] and r["seg_equal"] and r["score_cpu"] == r["score_gpu"], r
+    assert r["n_seg"] > 0 and r["device_search_frames"] > 0, r
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [("fwdflat", "no", "bestpath", "no"), ()])
 @pytest.mark.parametrize("what", ["librivox-0870.raw", 30.0, 60.0])
 def test_dropin_device_search_vtable_long_utterances_in_one_call(what, extra, tmp_path):
