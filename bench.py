@@ -2,8 +2,9 @@
 """bench.py -- decode throughput of the device first pass on MI355X (BASELINE.json metric: frames/sec + xRT decode,
 en-us PTM, n-gram fwdtree).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  For N > 1 it is
-launched by torch.distributed.run, one rank per GPU.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  N is the number of ranks, one per
+GPU over RCCL: under a launcher (torch.distributed.run, the driver's form for N > 1) WORLD_SIZE must equal it; started plainly with
+N > 1 the process becomes that launcher itself (self_launch_argv); a node with fewer GPUs than ranks fails loudly.
 
 Workload (BASELINE.json configs[4], the per-GPU share): 512 utterances x 30 s of synthetic 16 kHz PCM (the bundled
 recordings tiled with random gains and pauses over a noise floor, pocketsphinx_amd/synth.py; utterance id = seed),
@@ -59,7 +60,7 @@ def ref_exe(name):
     if os.path.exists(rel):
         return rel, "gcc -O3 -DNDEBUG (upstream's Release flags)"
     return os.path.join(REF_DIR, name), "gcc -O2"
-LV_UTT, LV_CHECK, LV_STEPS = 256, 32, 2    # the large-vocabulary leg: utterances per step, utterances the reference decodes, timed steps
+LV_UTT, LV_CHECK, LV_STEPS = 256, 64, 2    # the large-vocabulary leg: utterances per step, utterances the reference decodes, timed steps
 
 
 def _npz(name):
@@ -464,9 +465,10 @@ _JSON_FD = None
 
 
 def sq_issue(kernel_key):
-    """issue-slot fraction of a search kernel from the newest COMMITTED SQ-counter pass (profiles/*_sq_issue.json, written by
-    tools/prof_collect.py --sq): wave-instructions issued / (SQ_BUSY_CYCLES x 4 SIMDs a compute unit's sequencer feeds) -- how
-    busy the instruction streams are while the kernel holds its compute units.  A constant of the repository like `traffic`."""
+    """how busy a search kernel's resident wavefronts are, from the newest COMMITTED SQ-counter pass (profiles/*_sq_issue.json, written by
+    tools/gpu_call_r6sq.sh): issue_frac = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (the share of a resident wavefront's cycles with an
+    instruction in flight), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES.  What bounds these kernels is the chain of dependent steps of a
+    frame, not bytes: these two say how far from a busy instruction stream that leaves them.  A constant of the repository like `traffic`."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_issue.json")), reverse=True):
         try:
             k = json.load(open(path)).get(kernel_key)
@@ -497,7 +499,9 @@ def flatten_for_driver(line):
     iq = sq_issue("fwdtree_kernel_headline")
     if iq:
         rf["issue_frac"] = iq["issue_frac"]
-        rf["lds_wait_frac"] = iq.get("lds_wait_frac")
+        rf["wait_frac"] = iq.get("wait_frac")
+    if rf.get("kernel_ms") and rf.get("kernel_ms_alone"):
+        rf["alone_over_beside"] = round(rf["kernel_ms_alone"] / rf["kernel_ms"], 4)
     lv = line.get("decode_large_vocab")
     if isinstance(lv, dict) and "value" in lv:
         lr, lp, lc = lv.get("roofline") or {}, lv.get("parity") or {}, lv.get("cpu_baseline") or {}
@@ -517,6 +521,7 @@ def flatten_for_driver(line):
         iq = sq_issue("fwdtree_kernel_large_vocab")
         if iq:
             rf["lv_issue_frac"] = iq["issue_frac"]
+            rf["lv_wait_frac"] = iq.get("wait_frac")
     elif isinstance(lv, dict):
         rf["lv_value"] = None
         rf["lv_error"] = str(lv.get("error") or lv.get("skipped"))[:120]
