@@ -215,7 +215,7 @@ __device__ __forceinline__ int32_t ff_eval(const FfDev &p, FfUtt &u, int c, cons
 
 __device__ __forceinline__ int32_t ff_lm(const FfDev &p, int w3, int w2, int w1)      // ngram_tg_score(...) >> SENSCR_SHIFT
 {
-    if (p.use_trie) { int nu; return lm_tg_score(p.trie, w3, w2, w1, nu) >> 10; }
+    if (p.use_trie) { int nu = 0; return lm_tg_score_one(p.trie, w3, w2, w1, nu) >> 10; }     // (one model: psgpu_fwdflat_set_lm refuses an interpolated set)
     const size_t n1 = (size_t)p.n_w + 1;
     return p.lm[((size_t)w3 * n1 + (size_t)(w2 + 1)) * n1 + (size_t)(w1 + 1)];
 }
@@ -1372,6 +1372,9 @@ int psgpu_fwdflat_set_lm(psgpu_fwdflat_t *m, const psgpu_lm_t *lm)
     PSGPU_REQUIRE(m && lm, "psgpu_fwdflat_set_lm: NULL argument");
     const LmDev *d = psgpu_lm_dev(lm);
     PSGPU_REQUIRE(d->n_words == m->d.n_w, "psgpu_fwdflat_set_lm: the model maps %d dictionary words, the search has %d", d->n_words, m->d.n_w);
+    // (the first pass reaches its model through one out-of-line look-up, the second inlines it into a kernel that has no registers to
+    //  spare for a call: an interpolated set -- ngram_model_set_interp, reachable through the API only -- stays with the first pass)
+    PSGPU_REQUIRE(d->n_set == 0, "psgpu_fwdflat_set_lm: the second pass on the device takes one model (a set's current member), not an interpolated set");
     m->d.trie = *d;
     m->d.use_trie = 1;
     return PSGPU_OK;

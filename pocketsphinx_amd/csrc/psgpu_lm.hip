@@ -56,7 +56,7 @@ extern "C" int psgpu_lm_create(psgpu_lm_t **out, const psgpu_lm_tables_t *t)
     d.quant = (const float *)lm_up(m, t->quant, t->order > 1 ? (size_t)(2 * (t->order - 2) + 1) * 65536 * 4 : 0, 0, &rc);
     d.widmap = (const int32_t *)lm_up(m, t->widmap, 4 * (size_t)t->n_words, 0, &rc);
     d.cwt = t->class_weight ? (const int32_t *)lm_up(m, t->class_weight, 4 * (size_t)t->n_words, 0, &rc) : nullptr;
-    d.histmap = t->histmap ? (const int32_t *)lm_up(m, t->histmap, 4 * (size_t)t->n_words, 0, &rc) : nullptr;
+    d.histmap = t->histmap ? (const int32_t *)lm_up(m, t->histmap, 4 * (size_t)t->n_words, 0, &rc) : d.widmap;
     d.n_set = 0; d.set = nullptr; d.set_lw = nullptr; d.addtab = nullptr; d.addtab_n = 0; d.add_zero = 0;
     for (int l = 0; l < t->order - 1; ++l) {
         d.lev[l].off = t->level_offset[l]; d.lev[l].total_bits = t->total_bits[l]; d.lev[l].word_bits = t->word_bits[l];

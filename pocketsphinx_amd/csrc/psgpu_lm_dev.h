@@ -28,7 +28,7 @@ struct LmDev {
     const int32_t *widmap;    // [n_words]
     // word classes (ngram_ng_score's "declassify", lm/ngram_model.c:388-417): a class word scores as its class's tag word plus its
     // in-class weight; as a history word it IS the tag word.  widmap carries the tag word's id for it (-1 when ngram_class_prob does not
-    // find it: log_zero), histmap (or NULL: widmap) what it is as history, cwt (or NULL) the weight
+    // find it: log_zero), histmap (= widmap without classes) what it is as history, cwt (or NULL) the weight
     const int32_t *histmap, *cwt;
     // a model SET without a current model (ngram_model_set_score, lm/ngram_model_set.c:685-727): the look-up is the log-sum over the
     // members of lweights[i] + member i's look-up, through the set's own log-add table (logmath_add, util/logmath.c:401-446)
@@ -179,7 +179,8 @@ __device__ inline int32_t lm_tg_score_one(const LmDev &m, int32_t w3, int32_t w2
     int32_t hist[2];
     int n_hist = min(2, m.order - 1);                       // ngram_model_set.c:693
     const int32_t wid = psgpu_as_global(m.widmap)[w3];
-    const int32_t *const hm = m.histmap ? psgpu_as_global(m.histmap) : psgpu_as_global(m.widmap);
+    const int32_t *const hm = psgpu_as_global(m.histmap);     // (never NULL on the device: psgpu_lm_create points it at widmap -- a choice
+                                                               //  between two pointers here would make every access through it generic)
     hist[0] = w2 < 0 ? -1 : hm[w2];
     hist[1] = w1 < 0 ? -1 : hm[w1];
     if (wid == -1) return m.log_zero;                       // ngram_model.c:394 (n_used stays what it was: a set's next member may leave the one before's)
@@ -195,23 +196,29 @@ __device__ inline int32_t lm_tg_score_one(const LmDev &m, int32_t w3, int32_t w2
     const int32_t ws = (int32_t)__fadd_rn(__fmul_rn((float)raw, m.lw), (float)m.log_wip);    // weight_score, ngram_model_trie.c:710
     return m.cwt ? ws + psgpu_as_global(m.cwt)[w3] : ws;    // "multiply by unigram in-class weight", ngram_model.c:415-416
 }
-// logmath_add (util/logmath.c:401-446) with the set's table
-__device__ __forceinline__ int32_t lm_logadd(const LmDev &m, int32_t x, int32_t y)
+// A set without a current model (ngram_model_set.c:697-714): out of line and on its own -- the members' descriptors live in device
+// memory, the caller's may be a kernel argument: one inlined body serving both would reach every table through a pointer of unknown
+// address space (flat loads, which wait on both memory counters; tests/test_static_compile.py counts them)
+static __device__ __attribute__((noinline, unused)) int32_t lm_set_score(const LmDev *set_dev, const int32_t *set_lw, int32_t n_set, const uint32_t *addtab,
+                                                                         int32_t addtab_n, int32_t add_zero, int32_t log_zero, int32_t w3, int32_t w2,
+                                                                         int32_t w1, int &n_used)
 {
-    if (x <= m.add_zero) return y;
-    if (y <= m.add_zero) return x;
-    const int32_t r = x > y ? x : y, d = (int32_t)((uint32_t)r - (uint32_t)(x > y ? y : x));
-    if (d < 0 || d >= m.addtab_n) return r;
-    return r + (int32_t)psgpu_as_global(m.addtab)[d];
+    int32_t score = log_zero;
+    for (int i = 0; i < n_set; ++i) {
+        const int32_t y = psgpu_as_global(set_lw)[i] + lm_tg_score_one(psgpu_as_global(set_dev)[i], w3, w2, w1, n_used);
+        // logmath_add (util/logmath.c:401-446) with the set's table
+        if (score <= add_zero) { score = y; continue; }
+        if (y <= add_zero) continue;
+        const int32_t r = score > y ? score : y, d = (int32_t)((uint32_t)r - (uint32_t)(score > y ? y : score));
+        score = (d < 0 || d >= addtab_n) ? r : r + (int32_t)psgpu_as_global(addtab)[d];
+    }
+    return score;
 }
 __device__ inline int32_t lm_tg_score(const LmDev &m, int32_t w3, int32_t w2, int32_t w1, int &n_used)
 {
     n_used = 0;
-    if (m.n_set <= 0) return lm_tg_score_one(m, w3, w2, w1, n_used);
-    int32_t score = m.log_zero;                             // ngram_model_set.c:697-714
-    for (int i = 0; i < m.n_set; ++i)
-        score = lm_logadd(m, score, psgpu_as_global(m.set_lw)[i] + lm_tg_score_one(psgpu_as_global(m.set)[i], w3, w2, w1, n_used));
-    return score;
+    if (m.n_set > 0) return lm_set_score(m.set, m.set_lw, m.n_set, m.addtab, m.addtab_n, m.add_zero, m.log_zero, w3, w2, w1, n_used);
+    return lm_tg_score_one(m, w3, w2, w1, n_used);
 }
 
 // Out of line, the descriptor read from device memory: ONE copy of the trie walk (~1,400 instructions) per kernel however
