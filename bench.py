@@ -453,6 +453,9 @@ def child_extras(out):
     # a batch of live decoders: the headline's 512 utterances IN PROGRESS at once, 100 ms of audio a stream a step (psgpu_decode_streams_*):
     # frames/s over all streams and the time of a step = a piece's arrival to every stream's updated hypothesis on the host
     child("live_streams", [os.path.join(ROOT, "tools", "streams_bench.py")], {"LS_STREAMS": "512", "LS_SEC": "30", "LS_CHUNK": "10"}, 120)
+    # ... and the same batch of live decoders fed AUDIO (psgpu_decode_streams_step_pcm: front end, live cepstral mean and feature window per
+    # stream on the device)
+    child("live_streams_from_audio", [os.path.join(ROOT, "tools", "streams_bench.py")], {"LS_STREAMS": "512", "LS_SEC": "30", "LS_CHUNK": "10", "LS_PCM": "1"}, 120)
     from pocketsphinx_amd import largevocab as lv
     if lv.available(lv.table_path(directory=os.environ.get("PSGPU_TABLE_DIR"))):
         # configs[2]'s shape: ONE 60 s utterance, en-us PTM + the large LM / dictionary (en-us.lm.bin is not in the repository: big.arpa
@@ -547,6 +550,10 @@ def flatten_for_driver(line):
             rf["lv60_cpu_seconds"] = s60["reference"].get("cpu_s")
         if isinstance(s60.get("parity"), dict):
             rf["lv60_parity_identical"], rf["lv60_parity_checked"] = s60["parity"].get("identical"), s60["parity"].get("checked")
+    for key, pre in (("live_streams", "live"), ("live_streams_from_audio", "live_pcm")):
+        ls = ex.get(key)
+        if isinstance(ls, dict) and "value" in ls:
+            rf[pre + "_value"], rf[pre + "_ms_per_step"], rf[pre + "_step_ms_p99"] = ls["value"], ls.get("ms_per_step"), ls.get("step_ms_p99")
     for key, pre in (("search_only_turtle", "so_turtle"), ("search_only_cmudict", "so_cmudict")):
         so = ex.get(key)
         if isinstance(so, dict):

@@ -53,6 +53,42 @@ def main():
     pieces = [np.ascontiguousarray(feat[:, k * chunk:min((k + 1) * chunk, T)].reshape(-1, vl)) for k in range(steps)]
     cnts = [np.full(n, min((k + 1) * chunk, T) - k * chunk, np.int32) for k in range(steps)]
     n_obj = int(os.environ.get("LS_OBJECTS", "1"))
+    if os.environ.get("LS_PCM"):
+        # the streams fed with AUDIO (psgpu_decode_streams_step_pcm): chunk x 160 samples a stream a step -- one ps_process_raw call per live
+        # decoder -- front end, live cepstral mean and feature window per stream on the device (no hypothesis to compare with: a live
+        # decoder's features are not a whole-utterance decoder's; parity is tests/test_streams_pcm_gpu.py's)
+        ns = pcm_h.size // n
+        per = chunk * 160
+        steps = (ns + per - 1) // per
+        pcs = [np.ascontiguousarray(pcm_h.reshape(n, ns)[:, k * per:min((k + 1) * per, ns)].reshape(-1)) for k in range(steps)]
+        cnt64 = [np.full(n, min((k + 1) * per, ns) - k * per, np.int64) for k in range(steps)]
+        p.streams_pcm_begin(n, T + 8, chunk + 8, grow_feat=False)
+        lat = []
+        fin0 = np.zeros(n, np.uint8); fin1 = np.ones(n, np.uint8)
+        gained = np.zeros(n, np.int32)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ta = time.perf_counter()
+            capi.check(L.psgpu_decode_streams_step_pcm(p.h, pcs[k].ctypes.data_as(C.c_void_p), cnt64[k].ctypes.data_as(C.c_void_p),
+                                                       (fin1 if k == steps - 1 else fin0).ctypes.data_as(C.c_void_p), gained.ctypes.data_as(C.c_void_p),
+                                                       p._stream), "step_pcm")
+            if fetch or k == steps - 1:
+                hn, hyp, res = p.fetch()
+            lat.append(time.perf_counter() - ta)
+        dt = time.perf_counter() - t0
+        frames = int(res[:, 2].sum())
+        first_ms, last_ms = 1e3 * lat[0], 1e3 * lat[-1]
+        lat = np.sort(np.array(lat[1:]))
+        print(json.dumps({"metric": "frames/s over all streams, live FROM AUDIO: %d streams fed %d samples a step" % (n, per), "value": round(frames / dt, 1),
+                          "unit": "frames/s", "streams": n, "seconds_per_utterance": sec, "samples_per_step_per_stream": per, "steps": steps,
+                          "ms_per_step": round(1e3 * dt / steps, 4), "step_ms_median": round(1e3 * float(np.median(lat)), 4),
+                          "step_ms_p99": round(1e3 * float(lat[int(0.99 * (len(lat) - 1))]), 4), "first_step_ms": round(first_ms, 3),
+                          "last_step_ms": round(last_ms, 3), "audio_ms_per_step": 10.0 * chunk, "xrt": round(dt / (n * sec), 8),
+                          "frames_searched": frames, "status_nonzero": int((res[:, 3] != 0).sum()), "words_per_hyp": round(float(hn[:, 0].mean()), 1),
+                          "what": "psgpu_decode_streams_step_pcm per piece: the reference's buffer counters walked on the host, H2D of the audio, front end + "
+                                  "cmn_live + feature window per stream, batch scorer, phone loop, all streams' searches resumed, hypotheses to the host"}))
+        p.close()
+        return
     if n_obj == 2:
         # the streams split over TWO pipeline objects on streams of their own: one half's kernels run while the host fetches the other
         # half's hypotheses and hands over its next pieces
