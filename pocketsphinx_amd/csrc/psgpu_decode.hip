@@ -34,6 +34,7 @@ struct LiveSim {
     int state = 0, n_mfc = 0, outidx = 0, n_feat = 0, feat_outidx = 0, nbuf = 0;      // acmod_t / feat_t counters (state: 1 started, 2 processing, 3 ended)
     std::vector<int32_t> *ops = nullptr;                  // (n, flags) pairs: flags 1 begin, 2 end, 4 statistics only
     int made = 0, feats = 0;
+    bool live_seen = false;                               // a piece has gone through feat_cmn: the decoder's cmn type is CMN_LIVE from then on (feat.c:922-924)
     void setup(int frame_size, int frame_shift, int window, int pl_window, bool grow_feat)
     {
         fs = frame_size; sh = frame_shift; win = window; MA = 2 * win + 1; FA0 = FA = MA + pl_window; grow = grow_feat;
@@ -69,6 +70,7 @@ struct LiveSim {
     {
         if (begin) nbuf = 0;
         int nb = nbuf + ncep + (end ? win : 0);
+        live_seen = true;
         ops->push_back(ncep); ops->push_back((begin ? 1 : 0) | (end ? 2 : 0));
         const int nfeat = nb - win;
         if (nfeat <= 0) { nbuf = nb; return 0; }
@@ -114,6 +116,9 @@ struct LiveSim {
         ncep = process_cep(ncep);
         n_mfc -= ncep; outidx = (outidx + ncep) % MA;
     }
+    // feat_update_stats (feat.c:1422-1431): cmn_live_update -- if the decoder's cmn type has become CMN_LIVE, i.e. once a piece has gone
+    // through feat_cmn outside a whole-utterance call; a decoder that has seen no live audio yet leaves its mean alone
+    void stats_only() { if (live_seen) { ops->push_back(0); ops->push_back(4); } }
     void drain() { feat_outidx += n_feat; if (!grow) feat_outidx %= FA; n_feat = 0; }      // ps_search_forward: every feature frame consumed
     void process_raw(long long n_samps)                   // one ps_process_raw call (acmod_process_raw, acmod.c:601-668, in its loop)
     {
@@ -136,10 +141,10 @@ struct LiveSim {
         int tail = 0;
         if (n_mfc < MA) {
             if (ov > 0) { tail = ov; ++made; ++n_mfc; process_mfcbuf(); }
-            else { ops->push_back(0); ops->push_back(4); }
+            else stats_only();
             ov = 0;
         }
-        else { ops->push_back(0); ops->push_back(4); }
+        else stats_only();
         drain();
         return tail;
     }
@@ -1134,7 +1139,7 @@ int psgpu_decode_streams_next_utt(psgpu_decode_t *d, int32_t u, void *stream)
     }
     if ((rc = psgpu_decode_streams_restart(d, u, stream))) return rc;       // (search, phone loop, window; the lists: a new scorer's)
     if (d->pcm_streams) {
-        d->pc_sim[u].nbuf = keep.nbuf; d->pc_sim[u].FA = keep.FA;
+        d->pc_sim[u].nbuf = keep.nbuf; d->pc_sim[u].FA = keep.FA; d->pc_sim[u].live_seen = keep.live_seen;
         PSGPU_HIP(hipMemcpyAsync(d->d_pfeat + (size_t)u * fstate.size(), fstate.data(), 4 * fstate.size(), hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipMemcpyAsync(d->d_pundef + u, &undef, 4, hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipStreamSynchronize(st));
@@ -1283,7 +1288,7 @@ static int dec_pcm_stream_reset(psgpu_decode_s *d, int u, bool new_decoder, hipS
     PSGPU_HIP(hipMemsetAsync(d->d_pcarry + (size_t)u * d->pc_slots, 0, 2, st));             // (the prior)
     if (new_decoder) {                                   // ps_start_stream + a new decoder's feat_t / cmn_t
         const int one = 1;
-        d->pc_sim[u].nbuf = 0; d->pc_sim[u].FA = d->pc_sim[u].FA0;
+        d->pc_sim[u].nbuf = 0; d->pc_sim[u].FA = d->pc_sim[u].FA0; d->pc_sim[u].live_seen = false;
         PSGPU_HIP(hipMemcpyAsync(d->d_pundef + u, &one, 4, hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipMemcpyAsync(d->d_pfeat + (size_t)u * d->pc_init.size(), d->pc_init.data(), 4 * d->pc_init.size(), hipMemcpyHostToDevice, st));
         PSGPU_HIP(hipStreamSynchronize(st));
