@@ -151,6 +151,33 @@ def parity_of(ids, utts, hn, hyp, res):
     return bad
 
 
+def parity_of_the_rest(pcm, n_samples, n_utt, ids, hn, hyp, res, **kw):
+    """parity beyond the timed sample: the reference decodes EVERY utterance of the step that `ids` left out, on half the host's cores
+    (no timing: cpu_baseline stays the sample's) -- only where the host has the cores to do it in seconds (>= 32; PSGPU_BENCH_FULL_PARITY=0/1
+    overrides).  -> (utterances checked, ids that differ, wall seconds), or None"""
+    want = os.environ.get("PSGPU_BENCH_FULL_PARITY")
+    if want == "0" or (want is None and (os.cpu_count() or 1) < 32):
+        return None
+    rest = [i for i in range(n_utt) if i not in set(ids)]
+    if not rest:
+        return 0, [], 0.0
+    ref = reference_decode(pcm, n_samples, rest, procs=max(1, (os.cpu_count() or 2) // 2), **kw)
+    if ref is None:
+        return None
+    return len(rest), parity_of(rest, ref[0], hn, hyp, res), ref[1]["wall_s"]
+
+
+def widen_parity(par, rest):
+    if rest is None:
+        return par
+    n, bad, wall = rest
+    par["sample_checked"] = par["checked"]
+    par["checked"] += n; par["identical"] += n - len(bad); par["mismatching_utterances"] = list(par["mismatching_utterances"]) + bad
+    par["rest_wall_s"] = round(wall, 1)
+    par["note"] = "every utterance of the step: the timed sample, then the others decoded by reference processes on half the host's cores"
+    return par
+
+
 def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_utt, steps, n_check, with_cpu, table_dir=None):
     """The large-vocabulary decode (the stand-in for configs[2]'s absent en-us.lm.bin): the first
     n_utt of the headline's utterances through the same device pipeline with the 134,865-word dictionary and the synthetic
@@ -238,6 +265,7 @@ def large_vocab_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, n_u
                                "what": "unmodified reference (%s)" % ref_exe("ref_decode_bench")[1]}
         out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad,
                          "what": "word ids, start / end frames, path score and frame count: device vs the reference on the same PCM"}
+        widen_parity(out["parity"], parity_of_the_rest(pcm_all, n_samp, n_utt, ids, hn, hyp, res, lm="big.arpa", dic="cmudict-en-us.dict"))
         out["speedup_vs_cpu_1thread"] = round(frames / dt / tot["frames_per_s"], 1)
         w = lv.words_of(g)
         out["sample_hyp"] = " ".join(w[int(hyp[0, k, 0])] for k in range(min(int(hn[0, 0]), 12)))
@@ -340,6 +368,7 @@ def two_pass_leg(P, pcm_all, n_samp, seconds, dev, fe_tables, ptm_tables, static
             out["cpu_baseline"] = {"value": round(tot["frames_per_s"], 2), "unit": "frames/s", "cores": 1, "kind": "reference",
                                    "sample": "%d utterances, %.1f s of CPU in all, -fwdflat yes -bestpath no" % (len(ids), tot["cpu_s"])}
             out["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad}
+            widen_parity(out["parity"], parity_of_the_rest(pcm_all, n_samp, n_utt, ids, hn, hyp, res, extra=("fwdflat", "yes", "bestpath", "no")))
     flat.close(); pipe.close()
     del pcm
     torch.cuda.empty_cache()
@@ -957,6 +986,8 @@ def main():
             line["parity"] = {"checked": len(ids), "identical": len(ids) - len(bad), "mismatching_utterances": bad,
                               "what": "word ids, start / end frames, path score and frame count of each sampled utterance: device vs "
                                       "the reference decoding the same PCM"}
+            widen_parity(line["parity"], parity_of_the_rest(pcm_all, n_samp, B, ids, hn_l, hyp_l, res_l))
+            bad = line["parity"]["mismatching_utterances"]
             line["speedup_vs_cpu_1thread"] = round(fps / world / tot["frames_per_s"], 1)
             if bad:
                 emit(line)

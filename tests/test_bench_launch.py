@@ -99,3 +99,18 @@ def test_the_distributed_path_with_one_rank_costs_nothing():
         if abs(ratio - 1.0) <= 0.03:
             break
     assert abs(best - 1.0) <= 0.03, "forced-dist / plain = %.3f" % best
+
+
+def test_parity_over_the_whole_step_bookkeeping(monkeypatch):
+    """the in-bench parity beyond the timed sample: off on a small host, and the sample's record widened by
+    the others' outcome"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("psgpu_bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    monkeypatch.setenv("PSGPU_BENCH_FULL_PARITY", "0")
+    assert b.parity_of_the_rest(None, 0, 8, [0, 3], None, None, None) is None
+    par = {"checked": 2, "identical": 2, "mismatching_utterances": []}
+    assert b.widen_parity(par, None) is par and par["checked"] == 2
+    b.widen_parity(par, (6, [5], 1.23))
+    assert par["checked"] == 8 and par["identical"] == 7 and par["mismatching_utterances"] == [5] and par["sample_checked"] == 2
