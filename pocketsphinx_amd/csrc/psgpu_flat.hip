@@ -151,7 +151,25 @@ struct psgpu_fwdflat_s {
     FfDev d;
     std::vector<void *> allocs;
     std::vector<int32_t> h_pronlen, h_last, h_last2, h_rs_n, h_known;   // host copies for the vocabulary build
+    // a search call's working buffers, kept from call to call and only ever grown (a batch call of 512 x 30 s: 50 MB of slab, 110 MB of
+    // first-pass columns on the host; allocating, freeing and copying through pageable memory each call cost more than the copies):
+    // device [0] slab, [1] vocabularies, [2] descriptors; pinned host [3] first-pass columns, [4] vocabularies, [5] descriptors
+    void *work[6] = {};
+    size_t work_bytes[6] = {};
 };
+// the buffer k of at least `bytes` bytes (its contents are not kept when it grows)
+static int ff_work(psgpu_fwdflat_s *m, int k, size_t bytes, void **out)
+{
+    if (bytes > m->work_bytes[k]) {
+        if (m->work[k]) { if (k < 3) hipFree(m->work[k]); else hipHostFree(m->work[k]); }
+        m->work[k] = nullptr; m->work_bytes[k] = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        PSGPU_HIP(k < 3 ? hipMalloc(&m->work[k], want) : hipHostMalloc(&m->work[k], want, hipHostMallocDefault));
+        m->work_bytes[k] = want;
+    }
+    *out = m->work[k];
+    return PSGPU_OK;
+}
 
 #define FBP(u, col, i) ((u).bp[(size_t)(col) * (u).bp_cap + (i)])
 enum { F_FRAME, F_VALID, F_WID, F_BP, F_SCORE, F_SIDX, F_REAL, F_PREAL, F_LAST, F_LAST2 };
@@ -1384,6 +1402,7 @@ void psgpu_fwdflat_free(psgpu_fwdflat_t *m)
 {
     if (!m) return;
     for (void *p : m->allocs) hipFree(p);
+    for (int k = 0; k < 6; ++k) if (m->work[k]) { if (k < 3) hipFree(m->work[k]); else hipHostFree(m->work[k]); }
     delete m;
 }
 
@@ -1482,11 +1501,13 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         PSGPU_REQUIRE(nb >= 0 && nb <= bp1_cap, "psgpu_fwdflat_search: utterance %d: %d first-pass back-pointers, capacity %d", u, nb, bp1_cap);
         max_nb = std::max(max_nb, nb);
     }
-    std::vector<int32_t> cols((size_t)3 * n_utt * max_nb);
+    int rcw;
+    int32_t *cols = nullptr;
+    if ((rcw = ff_work(m, 3, sizeof(int32_t) * (size_t)3 * n_utt * max_nb, (void **)&cols))) return rcw;
     {
         static const int kCol[3] = {F_FRAME, F_WID, F_BP};
         for (int k = 0; k < 3; ++k)
-            PSGPU_HIP(hipMemcpy2DAsync(cols.data() + (size_t)k * n_utt * max_nb, sizeof(int32_t) * max_nb,
+            PSGPU_HIP(hipMemcpy2DAsync(cols + (size_t)k * n_utt * max_nb, sizeof(int32_t) * max_nb,
                                        bp1_dev + (size_t)kCol[k] * bp1_cap, sizeof(int32_t) * 10 * bp1_cap,
                                        sizeof(int32_t) * max_nb, n_utt, hipMemcpyDeviceToHost, st));
     }
@@ -1506,7 +1527,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
             try {
                 for (int u = t; u < n_utt; u += n_thr) {
                     const int nb = res1[(size_t)u * 8], nfr = res1[(size_t)u * 8 + 2];
-                    const int32_t *cu = cols.data() + (size_t)u * max_nb;
+                    const int32_t *cu = cols + (size_t)u * max_nb;
                     ff_build_vocab(m, cu, cu + (size_t)n_utt * max_nb, cu + (size_t)2 * n_utt * max_nb, nb, nfr, d.n1, voc[u]);
                 }
             } catch (...) { failed.store(1); }
@@ -1532,19 +1553,19 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
 #ifdef PSGPU_FT_PROFILE
     stamp();
 #endif
-    int32_t *slab = nullptr, *vdev = nullptr;
-    FfOff *d_utts = nullptr;
-    PSGPU_HIP(hipMalloc((void **)&slab, sizeof(int32_t) * slab_off[n_utt]));
-    hipError_t e = hipMalloc((void **)&vdev, sizeof(int32_t) * voc_off[n_utt]);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_utts, sizeof(FfOff) * n_utt);
-    std::vector<int32_t> vhost(voc_off[n_utt]);
-    std::vector<FfOff> ho(n_utt);
-    for (int i = 0; i < n_utt && e == hipSuccess; ++i) {
+    int32_t *slab = nullptr, *vdev = nullptr, *vhost = nullptr;
+    FfOff *d_utts = nullptr, *ho = nullptr;
+    if ((rcw = ff_work(m, 0, sizeof(int32_t) * slab_off[n_utt], (void **)&slab)) || (rcw = ff_work(m, 1, sizeof(int32_t) * voc_off[n_utt], (void **)&vdev))
+        || (rcw = ff_work(m, 2, sizeof(FfOff) * n_utt, (void **)&d_utts)) || (rcw = ff_work(m, 4, sizeof(int32_t) * voc_off[n_utt], (void **)&vhost))
+        || (rcw = ff_work(m, 5, sizeof(FfOff) * n_utt, (void **)&ho)))
+        return rcw;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n_utt; ++i) {
         FfUtt u;
         memset(&u, 0, sizeof u);
         const FfVocab &v = voc[i];
         const size_t nwd = v.wid.size(), C = (size_t)d.n1 + v.n_chan, cap = nwd + n_tail + 1;
-        int32_t *vh = vhost.data() + voc_off[i], *vd = vdev + voc_off[i];
+        int32_t *vh = vhost + voc_off[i], *vd = vdev + voc_off[i];
         auto put = [&](const std::vector<int32_t> &a, size_t n) { const int32_t *r = vd; if (n) memcpy(vh, a.data(), sizeof(int32_t) * n); vh += n; vd += n; return r; };
         u.nwd = (int32_t)nwd; u.n_chan = v.n_chan; u.n_frame = res1[(size_t)i * 8 + 2]; u.awl_cap = (int32_t)cap;
         u.wl_wid = put(v.wid, nwd); u.wl_chain = put(v.chain, nwd); u.wl_len = put(v.len, nwd);
@@ -1570,10 +1591,8 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         o.nrow32 = raw ? u.nrow32 - slab : -1; o.nrow = raw ? reinterpret_cast<int32_t *>(u.nrow) - slab : -1;
         o.nwd = u.nwd; o.n_chan = u.n_chan; o.n_frame = u.n_frame; o.awl_cap = u.awl_cap;
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(vdev, vhost.data(), sizeof(int32_t) * vhost.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_utts, ho.data(), sizeof(FfOff) * n_utt, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);          // the host vectors are about to go out of scope
-    if (e != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); PSGPU_HIP(e); }
+    PSGPU_HIP(hipMemcpyAsync(vdev, vhost, sizeof(int32_t) * voc_off[n_utt], hipMemcpyHostToDevice, st));
+    PSGPU_HIP(hipMemcpyAsync(d_utts, ho, sizeof(FfOff) * n_utt, hipMemcpyHostToDevice, st));
 #ifdef PSGPU_FT_PROFILE
     stamp();
 #endif
@@ -1594,7 +1613,6 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     if (dyn + 56 * 1024 > 65536) {                                                                                         \
         static const hipError_t attr_rc = hipFuncSetAttribute((const void *)fwdflat_kernel<NE, true>,                      \
                                                               hipFuncAttributeMaxDynamicSharedMemorySize, kFfMaxSen * 2);  \
-        if (attr_rc != hipSuccess) { hipFree(slab); hipFree(vdev); hipFree(d_utts); }                                      \
         PSGPU_HIP(attr_rc);                                                                                                \
     }
 #else
@@ -1614,7 +1632,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         hipLaunchKernelGGL((fwdflat_kernel<5, false>), dim3(n_utt), dim3(kFfThreads), 0, st, d, d_utts, bf, senscr_dev, scr_stride, utt_off_dev, rw);
 #undef FF_DYN_LDS
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);          // the slab is freed below: this entry is synchronous
+    if (e == hipSuccess) e = hipStreamSynchronize(st);          // (this entry is synchronous: the pinned staging buffers are the next call's)
 #ifdef PSGPU_FT_PROFILE
     stamp();
     fprintf(stderr, "fwdflat host: first-pass columns to the host %.2f ms, vocabularies %.2f ms, allocations + tables to the device %.2f ms, kernel %.2f ms\n",
@@ -1642,7 +1660,6 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     }
     hipFree(bf.prof);
 #endif
-    hipFree(slab); hipFree(vdev); hipFree(d_utts);
     PSGPU_HIP(e);
     return PSGPU_OK;
 }

@@ -11,4 +11,4 @@ timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -T -f csv -d "$OUT/pmc_fet
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -T -f csv -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/pmc_write.log" 2>&1
 cd - > /dev/null
 find "$OUT" -name '*_kernel_trace.csv' -size +8M -delete
-python tools/prof_collect.py "$OUT" "$TAG" $N 30.0 2>&1 | grep -A9 '"fwdtree_kernel"'
+python tools/prof_collect.py "$OUT" "$TAG" $N 30.0 decode_large_vocab 2>&1 | grep -A9 '"fwdtree_kernel"'

@@ -51,7 +51,9 @@ def main():
     os.makedirs(prof, exist_ok=True)
 
     # ---- kernel stats
-    lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1",
+    cmd = ("bench.py --workload large --steps 1 --no-cpu-baseline --utts N --large-vocab-utts N (tools/gpu_call_lvpmc.sh)" if len(sys.argv) >= 6
+           else "bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1")
+    lines = ["# rocprofv3 --kernel-trace --stats -- python " + cmd,
              "# (durations in microseconds)",
              "%-8s %-14s %-12s %-8s %-10s %-10s %s" % ("calls", "total_us", "avg_us", "pct", "min_us", "max_us", "kernel")]
     stats = {}
@@ -119,6 +121,10 @@ def main():
     if len(sys.argv) >= 5:
         res["_workload"] = {"utterances": int(sys.argv[3]), "seconds": float(sys.argv[4]),
                             "command": "bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1"}
+        if len(sys.argv) >= 6:                               # a leg's own pass (tools/gpu_call_lvpmc.sh): bench.py matches on the leg's name
+            res["_workload"]["leg"] = sys.argv[5]
+            res["_workload"]["command"] = ("bench.py --workload large --steps 1 --no-cpu-baseline --utts N --large-vocab-utts N "
+                                           "(N = utterances; tools/gpu_call_lvpmc.sh)")
     res["_note"] = ("FETCH_SIZE/WRITE_SIZE are reported by rocprofv3 in KB; read bytes doubled per "
                     "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated")
     json.dump(res, open(os.path.join(prof, "%s_pmc_traffic.json" % tag), "w"), indent=1, sort_keys=True)
