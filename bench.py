@@ -638,6 +638,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only (clean per-kernel profiles)")
     ap.add_argument("--no-large-vocab", action="store_true", help="leave the 134,865-word leg (decode_large_vocab) out")
+    ap.add_argument("--scatter", action="store_true", help="N > 1: rank 0 synthesises the whole job's audio and scatters it over RCCL "
+                    "(default: every rank synthesises its own share)")
     ap.add_argument("--large-vocab-utts", type=int, default=LV_UTT)
     ap.add_argument("--tables", default=None, help="directory of table files written by integration/psgpu_export_tables (default: "
                                                    "$PSGPU_TABLE_DIR, else integration/_tables): the large-vocabulary task's tables")
@@ -668,8 +670,14 @@ def main():
                          "was asked for" % (args.gpus, world))
     B, n_samp = args.utts, int(round(args.seconds * 16000))
 
-    # rank 0 owns the PCM of the whole job (synthesised before torch / HIP start: the pool forks)
-    pcm_all = synth_pcm(0, B * world, args.seconds) if rank == 0 else None
+    # the job's PCM (synthesised before torch / HIP start: the pool forks).  Every rank makes the utterances of ITS share (utterance id =
+    # seed: the same bytes wherever they are made; the ranks' pools work side by side, so the set-up of an N-rank run costs what one
+    # rank's does).  --scatter: rank 0 owns the whole job's audio, as one reader of a control file would, and scatters it over RCCL
+    # (pocketsphinx_amd.batch.scatter_pcm; N - 1 sends of 491 MB one after another, outside the timed region either way)
+    if args.scatter and world > 1:
+        pcm_all = synth_pcm(0, B * world, args.seconds) if rank == 0 else None
+    else:
+        pcm_all = synth_pcm(rank * B, B, args.seconds)
 
     import torch
     if not torch.cuda.is_available():
@@ -724,7 +732,7 @@ def main():
 
     # ---- inputs resident in HBM: this rank's 512 utterances (scattered from rank 0 over RCCL when N > 1)
     pcm = torch.empty(B * n_samp, dtype=torch.int16, device=dev)
-    if dist is None:
+    if dist is None or not args.scatter:
         pcm.copy_(torch.from_numpy(pcm_all))
     else:
         pbatch.scatter_pcm(pcm, pcm_all, B * n_samp, device=dev)

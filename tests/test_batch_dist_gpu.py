@@ -90,7 +90,7 @@ def test_bench_rccl_code_path_with_one_rank(tmp_path):
     env = dict(os.environ, PSGPU_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--utts", "8", "--seconds", "5",
-                          "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+                          "--no-extras", "--scatter"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-500:]
