@@ -39,10 +39,16 @@ extern "C" { int psgpu_sim_ff_el_cap = 384; }
 #define FF_EL_CAP psgpu_sim_ff_el_cap
 extern "C" { int psgpu_sim_ff_awl_regs = 512; }
 #define FF_AWL_REGS psgpu_sim_ff_awl_regs
+extern "C" { int psgpu_sim_ff_pair_rows = 160; }     // new entries of a frame the word transitions take as (word, entry) pairs
+#define FF_PAIR_ROWS psgpu_sim_ff_pair_rows
+extern "C" { int psgpu_sim_ff_slice_chunk = 256; }   // ... and words of the frame's window a chunk of those pairs takes (<= kFfThreads)
+#define FF_SL_CHUNK psgpu_sim_ff_slice_chunk
 #else
 #define FF_EXIT_CAP kFfMaxExit
 #define FF_EL_CAP kFfMaxEl
 #define FF_AWL_REGS (kFfRegRows * kFfThreads)
+#define FF_PAIR_ROWS kFfMaxExit
+#define FF_SL_CHUNK kFfThreads
 #endif
 
 constexpr int kFfThreads = 256;
@@ -97,6 +103,7 @@ struct FfDev {
     const uint16_t *sseq;
     int32_t tp_bytes;
     int32_t use_trie;
+    int32_t fill_known;                  // a filler word is a word of the language model (it can be in an utterance's vocabulary)
     LmDev trie;
 };
 
@@ -106,6 +113,7 @@ struct FfUtt {
     const int32_t *wl_wid, *wl_chain, *wl_len, *wl_node_off, *node_sf;     // [nwd] (+1), [n nodes]: vocabulary, host-built
     const int32_t *fr_off, *fr_words;    // the same nodes by start frame: [n_frame + 2] offsets into [n nodes] vocabulary positions
     int32_t *wseen;                      // [nwd + 1] frame stamp: the word was taken as a successor in that frame already
+    int32_t *wstat;                      // [nwd + 1][4] a vocabulary word's static side for the word transitions: word, first channel, first phone | second << 8, base word
     int32_t *score, *hist;               // [C][5]
     int32_t *out, *outh, *best, *frame;  // [C]
     int32_t *senid;                      // [C][5]
@@ -125,7 +133,7 @@ struct FfUtt {
 // What the kernel is actually handed per utterance: the same fields as offsets (in int32 units) from buffers that are
 // kernel arguments.  Pointers loaded from memory are generic to the compiler (every access a flat_load / flat_store, both
 // wait counters); pointers formed from a kernel argument are global.
-#define FF_SLAB_FIELDS(X) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(einfo) X(wchain) \
+#define FF_SLAB_FIELDS(X) X(wstat) X(score) X(hist) X(out) X(outh) X(best) X(frame) X(senid) X(tmat) X(mpx) X(rcid) X(xflag) X(elist) X(einfo) X(wchain) \
     X(wlen) X(wrcs) X(wseen) X(word_active) X(word_lat_idx) X(cnt_a) X(cnt_b)
 #define FF_VOC_FIELDS(X) X(wl_wid) X(wl_chain) X(wl_len) X(wl_node_off) X(node_sf) X(fr_off) X(fr_words)
 struct FfOff {
@@ -398,7 +406,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     // senones scored evenly over the work-items (the first pass's way, psgpu_sen_dev.h): the frame's lists packed four to a word, the
     // listed senones as a list (prefix sum over the bitmap words' populations)
     __shared__ uint32_t s_pcw[RAW ? kFfMaxEnt / 4 : 1], s_psc[RAW ? kFfMaxEnt / 4 : 1];
-    __shared__ uint16_t s_slist[RAW ? kFfMaxSen : 1];            // the frame's listed senones in the order they were first marked
+    __shared__ __attribute__((aligned(16))) uint16_t s_slist[RAW ? kFfMaxSen : 1];   // the frame's listed senones in the order they were first marked
+    // the word transitions' rows (a chunk of the window's words: first phone or -1, base word, best pair's key): the listed senones' place --
+    // that list is dead once the frame's senones are scored -- or, when the scores are given, an array of their own
+    __shared__ __attribute__((aligned(16))) int32_t s_wt_own[RAW ? 4 : 4 * kFfThreads];
+    static_assert(!RAW || kFfMaxSen * 2 >= 16 * kFfThreads, "the rows fit the listed senones' array");
+    int32_t *const s_wfirst = RAW ? reinterpret_cast<int32_t *>(s_slist) : s_wt_own, *const s_wbase = s_wfirst + kFfThreads;
+    unsigned long long *const s_wkey = reinterpret_cast<unsigned long long *>(s_wfirst + 2 * kFfThreads);
     __shared__ int32_t s_nl;
     __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64], s_scan2[kFfThreads / 64];
@@ -428,9 +442,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
-    __shared__ long long s_prof[16], s_last, s_t5;
+    __shared__ long long s_prof[32], s_last, s_t5;
     __shared__ int s_over;
-    if (tid == 0) { for (int i = 0; i < 16; ++i) s_prof[i] = 0; s_last = clock64(); }
+    if (tid == 0) { for (int i = 0; i < 32; ++i) s_prof[i] = 0; s_last = clock64(); }
 #endif
     FfUtt u;
     {
@@ -466,6 +480,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __syncthreads();
     for (int k = tid; k < u.nwd; k += kFfThreads) {
         const int w = u.wl_wid[k], c0 = u.wl_chain[k];
+        {
+            const int w1 = p.w1_of_word[w];
+            const int ci2 = c0 >= 0 ? p.pron_ci[p.pron_off[w] + 1] : p.w1_ci2[w1];
+            *reinterpret_cast<FfQuad *>(u.wstat + 4 * (size_t)k) = FfQuad{ w, c0 >= 0 ? c0 : w1, p.d_first[w] | (ci2 << 8), p.d_base[w] };
+        }
         if (c0 < 0) continue;
         const int len = p.d_pronlen[w], last = p.d_last[w], last2 = p.d_last2[w], nrc = p.rs_n[last * p.n_ci + last2];
         int c = c0;
@@ -501,7 +520,6 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     // the next active word list's candidates, candidate tid + 256 j in slot j (vocabularies up to kFfRegRows x 256 words): static
     const int n_tail = p.n_w - p.startwid, n_all = u.nwd + n_tail;
     int wq[kFfRegRows] = {}, c0q[kFfRegRows] = {}, axq[kFfRegRows] = {};
-    int fq[kFfRegRows] = {}, bq[kFfRegRows] = {}, o0q[kFfRegRows] = {}, o1q[kFfRegRows] = {};      // (vocabulary words: first phone | second << 8, base word, start-frame nodes)
     if (n_all <= FF_AWL_REGS) {
 #pragma unroll
         for (int j = 0; j < kFfRegRows; ++j) {
@@ -510,10 +528,6 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const int32_t ch = u.wchain[w], ln = u.wlen[w], rcs = u.wrcs[w], w1 = p.w1_of_word[w];
             wq[j] = w; c0q[j] = ch >= 0 ? ch : w1;
             axq[j] = (ch >= 0 ? ln : 1) | (rcs << 10) | ((ch < 0 ? 1 : 0) << 20);
-            if (i < u.nwd) {
-                const int ci2 = u.wl_chain[i] >= 0 ? p.pron_ci[p.pron_off[w] + 1] : p.w1_ci2[w1];
-                fq[j] = p.d_first[w] | (ci2 << 8); bq[j] = p.d_base[w]; o0q[j] = u.wl_node_off[i]; o1q[j] = u.wl_node_off[i + 1];
-            }
         }
     }
     FfQuad pre_q = { 0, 0, 0, 0 };
@@ -529,6 +543,15 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
         //      profiles/r03_fwdflat_phase_profile.txt).  Nothing between here and the evaluation changes a channel's frame stamp.
         if (tid == 0) { s_sc[7] = 0; s_nfan = 0; s_nex = 0; s_tot[0] = 0; s_tot[1] = 0; s_nl = 0; s_nb = 0x7fffffff; s_nopen = 0; }
+        // the word transitions' successors (below): the window's slice of the nodes-by-start-frame list depends on f alone -- its bounds are
+        // asked for here, its words after the next barrier, their static quads after the one after that: nothing waits for them
+        int sl_q0 = 0, sl_n = 0;
+        {
+            int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
+            if (sf0 < 0) sf0 = 0;
+            if (ef0 > u.n_frame) ef0 = u.n_frame;
+            if (ef0 > sf0) { sl_q0 = u.fr_off[sf0]; sl_n = u.fr_off[ef0] - sl_q0; }
+        }
         if (ahead && tid < n_chain) {
             const size_t o = (size_t)tid * rw.total + t0 + f;
             pre_q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); pre_c4 = rw.tcw[o]; pre_closed = !rw.open[o];
@@ -576,6 +599,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         }
         __syncthreads();
         FF_PROF(8);
+        const int sl_k = tid < sl_n && tid < FF_SL_CHUNK ? u.fr_words[sl_q0 + tid] : -1;
         const int n_eval = s_sc[7];
         struct FfEnt { int32_t c, inf, w, aux; };
         auto ent = [&](int e) -> FfEnt {
@@ -881,6 +905,12 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 for (int k = 0; k < len; ++k) if (u.frame[c0 + k] == f) ff_normalize(p, u, c0 + k, best_in);
             }
         __syncthreads();
+        FfQuad sl_w = { 0, 0, 0, 0 };
+        bool sl_on = false;
+        if (sl_k >= 0) {                                      // (a word with two nodes in the window is taken once)
+            sl_on = atomicExch(&u.wseen[sl_k], nf) != nf;
+            sl_w = *reinterpret_cast<const FfQuad *>(u.wstat + 4 * (size_t)sl_k);
+        }
         if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_key = 0ull; }
         __syncthreads();
         FF_PROF(3);
@@ -1107,121 +1137,136 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (s_sc[3]) break;
 
         FF_PROF(5);
-        // ---- fwdflat_word_transition (:642-782)
+        // ---- fwdflat_word_transition (:642-782).  The successors of a frame's exits are the vocabulary words with a node in the frame's
+        //      window: a contiguous slice of the nodes-by-start-frame list (get_expand_wordlist :609-640), taken one work-item an entry and
+        //      asked for at the top of the frame -- the slice, its words (a word with two nodes in the window is taken once: wseen) and
+        //      their static quads are in registers by now.  The work is one work-item per (word, new entry) PAIR: its right-context slot and
+        //      language score asked for together, the best pair of a word kept as one 64-bit maximum in LDS -- "the first best exit wins"
+        //      (:700-720: a later exit replaces an earlier one only with a strictly better score) is the earliest index among the highest
+        //      scores --, then the word's one work-item enters it.  <sil>'s best exit (:745-753) is one more row of pairs.  A frame's new
+        //      entries are read from LDS as the exits' phase left them; a frame whose exits overflowed the queue loads their rows from the
+        //      table first and finds exit scores in the score stack.
         const int bp0 = bp_first, bp1 = s_sc[1];
-        if (n_exq <= FF_EXIT_CAP && n_all <= FF_AWL_REGS) {
-            // The frame's new entries as the exits' phase left them in LDS (s_nbp; their right contexts' scores are the queue's), the
-            // vocabulary words' static data in registers: what is left to fetch is the right-context map, the language score and
-            // the start-frame nodes.
-            const int n_new = bp1 - bp0;
+        const int n_new = bp1 - bp0;
+        if (n_new > 0) {
+            const bool lds_exits = n_exq <= FF_EXIT_CAP, by_pairs = n_new <= FF_PAIR_ROWS;
             auto exit_score = [&](const int32_t *r, int slot) {      // bscore_stack[s_idx + slot] of a new entry: the exit into that context
+                if (!lds_exits) return u.bss[r[4] + slot];
                 // (a word's exits are queued in chain order = right-context order: the slot's place among them is a population count)
                 const unsigned long long have = (unsigned long long)(uint32_t)r[7] | ((unsigned long long)(uint32_t)r[8] << 32);
                 if (!((have >> slot) & 1ull)) return kW;
                 return s_srt[r[4] + __popcll(have & ((1ull << slot) - 1ull))].y;
             };
-            if (tid < n_new) {
-                const int32_t *r = s_nbp[tid];
-                u.word_lat_idx[r[0]] = -1;
-                if (r[0] != p.finishwid) {
-                    const int32_t sil = r[2] == -1 ? r[3] : exit_score(r, p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + p.sil_ci]);
-                    if (sil > kW)      // best exit into silence, the earliest on ties (:745-753): key = (score, -index)
-                        atomicMax(&s_key, ((unsigned long long)(uint32_t)(sil - kW) << 32) | (uint32_t)(0x7fffffff - (bp0 + tid)));
+            if (by_pairs) {
+                if (!lds_exits && tid < n_new) {              // the rows from the table: word, last / last-but-one phone, score, stack offset, real words
+                    const int b = bp0 + tid;
+                    int32_t *r = s_nbp[tid];
+                    r[0] = FBP(u, F_WID, b); r[1] = FBP(u, F_LAST, b); r[2] = FBP(u, F_LAST2, b); r[3] = FBP(u, F_SCORE, b);
+                    r[4] = FBP(u, F_SIDX, b); r[5] = FBP(u, F_REAL, b); r[6] = FBP(u, F_PREAL, b);
                 }
+                if (tid < n_new) u.word_lat_idx[s_nbp[tid][0]] = -1;
             }
-            if (n_new > 0) {
-                int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
-                if (sf0 < 0) sf0 = 0;
-                if (ef0 > u.n_frame) ef0 = u.n_frame;
-#pragma unroll
-                for (int j = 0; j < kFfRegRows; ++j) {
-                    if (tid + j * kFfThreads >= u.nwd) continue;
-                    bool in = false;
-                    for (int q = o0q[j]; q < o1q[j] && !in; ++q) { const int sf = u.node_sf[q]; in = sf >= sf0 && sf < ef0; }
-                    if (!in) continue;
-                    const int w = wq[j], c0 = c0q[j], first = fq[j] & 0xff, ci2 = fq[j] >> 8;
-                    int32_t cur_fr = u.frame[c0], cur_sc = u.score[c0 * 5];
-                    int win = -1, win_l1 = 0;
-                    for (int t0 = 0; t0 < n_new; t0 += 4) {    // exits in order: the first best one wins, as in the reference --
-                        int32_t slot[4], lmv[4];               // four at a time, their context slots and language scores asked for together
-                        bool ok[4];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int32_t *r = s_nbp[min(t0 + v, n_new - 1)];
-                            ok[v] = t0 + v < n_new && r[0] != p.finishwid;
-                            slot[v] = -1; lmv[v] = 0;
-                            if (ok[v]) {
-                                if (r[2] != -1) slot[v] = p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + first];
-                                lmv[v] = ff_lm(p, bq[j], r[5], r[6]);
-                            }
-                        }
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            if (!ok[v]) continue;
-                            const int32_t *r = s_nbp[t0 + v];
-                            int32_t newscore = r[2] == -1 ? r[3] : exit_score(r, slot[v]);
-                            if (newscore == kW) continue;
-                            // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
-                            const float prod = __fmul_rn(p.lwf, (float)lmv[v]);
-                            newscore = (int32_t)__fadd_rn((float)newscore, prod);
-                            newscore += p.pip;
-                            if (newscore > thresh && (cur_fr < f || newscore > cur_sc)) { cur_fr = nf; cur_sc = newscore; win = t0 + v; win_l1 = r[1]; }
-                        }
-                    }
-                    if (win >= 0) {
-                        ff_enter(u, c0, cur_sc, bp0 + win, nf);
-                        u.senid[c0 * 5] = p.ldiph[((size_t)first * p.n_ci + ci2) * p.n_ci + win_l1];
-                        u.word_active[w] = nf;
-                    }
-                }
-            }
-        }
-        else {
-        for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
-            const int wid = FBP(u, F_WID, b);
-            u.word_lat_idx[wid] = -1;
-            if (wid == p.finishwid) continue;
-            const int l2 = FBP(u, F_LAST2, b), l1 = FBP(u, F_LAST, b);
-            const int32_t sil = l2 == -1 ? FBP(u, F_SCORE, b)
-                : u.bss[FBP(u, F_SIDX, b) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + p.sil_ci]];
-            // best exit into silence, the earliest on ties (:745-753): key = (score, -index)
-            if (sil > kW)
-                atomicMax(&s_key, ((unsigned long long)(uint32_t)(sil - kW) << 32) | (uint32_t)(0x7fffffff - b));
-        }
-        // successors: the vocabulary words that start within the window of this frame (get_expand_wordlist :609-640); a frame without
-        // exits has none, and no way into <sil> or the noise words either
-        if (bp1 > bp0) {
-            int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
-            if (sf0 < 0) sf0 = 0;
-            if (ef0 > u.n_frame) ef0 = u.n_frame;
-            // (the window's nodes are a contiguous slice of the nodes-by-start-frame list; a word with two nodes in it is taken once)
-            for (int q = (ef0 > sf0 ? u.fr_off[sf0] : 0) + tid, q1 = ef0 > sf0 ? u.fr_off[ef0] : 0; q < q1; q += kFfThreads) {
-                const int k = u.fr_words[q];
-                if (atomicExch(&u.wseen[k], nf) == nf) continue;
-                const int w = u.wl_wid[k];
-                int len; const int c0 = ff_root(p, u, w, len);
-                const int first = p.d_first[w], base = p.d_base[w];
-                const int ci2 = u.wl_chain[k] >= 0 ? p.pron_ci[p.pron_off[w] + 1] : p.w1_ci2[p.w1_of_word[w]];
-                for (int b = bp0; b < bp1; ++b) {              // exits in order: the first best one wins, as in the reference
-                    if (FBP(u, F_WID, b) == p.finishwid) continue;
+            else {
+                for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
+                    const int wid = FBP(u, F_WID, b);
+                    u.word_lat_idx[wid] = -1;
+                    if (wid == p.finishwid) continue;
                     const int l2 = FBP(u, F_LAST2, b), l1 = FBP(u, F_LAST, b);
-                    int32_t newscore = l2 == -1 ? FBP(u, F_SCORE, b)
-                        : u.bss[FBP(u, F_SIDX, b) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + first]];
-                    if (newscore == kW) continue;
-                    // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
-                    const float prod = __fmul_rn(p.lwf, (float)ff_lm(p, base, FBP(u, F_REAL, b), FBP(u, F_PREAL, b)));
-                    newscore = (int32_t)__fadd_rn((float)newscore, prod);
-                    newscore += p.pip;
-                    if (newscore > thresh && (u.frame[c0] < f || newscore > u.score[c0 * 5])) {
-                        ff_enter(u, c0, newscore, b, nf);
-                        u.senid[c0 * 5] = p.ldiph[((size_t)first * p.n_ci + ci2) * p.n_ci + l1];
-                        u.word_active[w] = nf;
+                    const int32_t sil = l2 == -1 ? FBP(u, F_SCORE, b)
+                        : u.bss[FBP(u, F_SIDX, b) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + p.sil_ci]];
+                    // best exit into silence, the earliest on ties (:745-753): key = (score, -index)
+                    if (sil > kW)
+                        atomicMax(&s_key, ((unsigned long long)(uint32_t)(sil - kW) << 32) | (uint32_t)(0x7fffffff - b));
+                }
+            }
+            for (int cb = 0; cb == 0 || cb < sl_n; cb += FF_SL_CHUNK) {
+                // this chunk's slice entries, one a work-item (the first chunk's were asked for at the top of the frame)
+                FfQuad wq4 = sl_w;
+                bool on = sl_on;
+                if (cb > 0) {
+                    on = false;
+                    if (cb + tid < sl_n && tid < FF_SL_CHUNK) {
+                        const int k = u.fr_words[sl_q0 + cb + tid];
+                        on = atomicExch(&u.wseen[k], nf) != nf;
+                        wq4 = *reinterpret_cast<const FfQuad *>(u.wstat + 4 * (size_t)k);
+                    }
+                }
+                const int n_act = min(sl_n - cb, FF_SL_CHUNK);
+                const int c0 = wq4.y, first = wq4.z & 0xff, ci2 = wq4.z >> 8;
+                int32_t cur_fr = 0, cur_sc = 0;
+                if (on) { cur_fr = u.frame[c0]; cur_sc = u.score[c0 * 5]; }
+                if (by_pairs) {
+                    s_wfirst[tid] = on ? first : -1; s_wbase[tid] = wq4.w; s_wkey[tid] = 0ull;
+                    __syncthreads();
+                    const int n_row = n_act + (cb == 0 ? 1 : 0);                     // (the first chunk: one more row, <sil>'s)
+                    for (int pr = tid, n_pair = n_row * n_new; pr < n_pair; pr += kFfThreads) {
+                        const int t = pr / n_new, e = pr - t * n_new;
+                        const int32_t *r = s_nbp[e];
+                        const bool sil = t == n_act;
+                        const int fi = sil ? p.sil_ci : s_wfirst[t];
+                        if (r[0] == p.finishwid || fi < 0) continue;
+                        int32_t slot = 0, lmv = 0;
+                        if (r[2] != -1) slot = p.rs_cimap[((size_t)r[1] * p.n_ci + r[2]) * p.n_ci + fi];
+                        if (!sil) lmv = ff_lm(p, s_wbase[t], r[5], r[6]);
+                        int32_t newscore = r[2] == -1 ? r[3] : exit_score(r, slot);
+                        if (sil) {       // best exit into silence, the earliest on ties (:745-753): key = (score, -index)
+                            if (newscore > kW)
+                                atomicMax(&s_key, ((unsigned long long)(uint32_t)(newscore - kW) << 32) | (uint32_t)(0x7fffffff - (bp0 + e)));
+                            continue;
+                        }
+                        if (newscore == kW) continue;
+                        // "newscore += lwf * (ngram_tg_score(...) >> SENSCR_SHIFT)": float product and sum, truncated (:700-706)
+                        const float prod = __fmul_rn(p.lwf, (float)lmv);
+                        newscore = (int32_t)__fadd_rn((float)newscore, prod);
+                        newscore += p.pip;
+                        if (newscore > thresh)
+                            atomicMax(&s_wkey[t], ((unsigned long long)((uint32_t)newscore ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - e));
+                    }
+                    __syncthreads();
+                    if (on) {
+                        const unsigned long long key = s_wkey[tid];
+                        const int32_t sc = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+                        const int win = 0x7fffffff - (int)(uint32_t)key;
+                        if (key && (cur_fr < f || sc > cur_sc)) {
+                            ff_enter(u, c0, sc, bp0 + win, nf);
+                            u.senid[c0 * 5] = p.ldiph[((size_t)first * p.n_ci + ci2) * p.n_ci + s_nbp[win][1]];
+                            u.word_active[wq4.x] = nf;
+                        }
+                    }
+                    if (cb + FF_SL_CHUNK < sl_n) __syncthreads();                    // (the next chunk overwrites the rows)
+                }
+                else if (on) {
+                    // more new entries than rows: the word's work-item goes through the table, exits in order
+                    for (int b = bp0; b < bp1; ++b) {
+                        if (FBP(u, F_WID, b) == p.finishwid) continue;
+                        const int l2 = FBP(u, F_LAST2, b), l1 = FBP(u, F_LAST, b);
+                        int32_t newscore = l2 == -1 ? FBP(u, F_SCORE, b)
+                            : u.bss[FBP(u, F_SIDX, b) + p.rs_cimap[((size_t)l1 * p.n_ci + l2) * p.n_ci + first]];
+                        if (newscore == kW) continue;
+                        const float prod = __fmul_rn(p.lwf, (float)ff_lm(p, wq4.w, FBP(u, F_REAL, b), FBP(u, F_PREAL, b)));
+                        newscore = (int32_t)__fadd_rn((float)newscore, prod);
+                        newscore += p.pip;
+                        if (newscore > thresh && (cur_fr < f || newscore > cur_sc)) {
+                            cur_fr = nf; cur_sc = newscore;
+                            ff_enter(u, c0, newscore, b, nf);
+                            u.senid[c0 * 5] = p.ldiph[((size_t)first * p.n_ci + ci2) * p.n_ci + l1];
+                            u.word_active[wq4.x] = nf;
+                        }
                     }
                 }
             }
+            if (!by_pairs) __syncthreads();                  // (<sil>'s key is complete)
         }
+#ifdef PSGPU_FT_PROFILE
+        if (tid == 0) {      // the word transitions' shape: [16] frames with new entries, [17] their entries, [18] slice entries, [19] (word, entry) pairs,
+            const long long t_ = clock64();   // [20] / [21] this phase's cycles in frames whose exits fit / overflow the queue, [22] the per-utterance maximum of entries
+            if (n_new > 0) { s_prof[16] += 1; s_prof[17] += n_new; s_prof[18] += sl_n; s_prof[19] += (long long)n_new * sl_n; }
+            s_prof[s_over ? 21 : 20] += t_ - s_last;
+            if (n_new > s_prof[22]) s_prof[22] = n_new;
         }
-        __syncthreads();
+#endif
+        // (a filler word that is a word of the language model can have been entered as a successor: the fillers' test must see it)
+        if (p.fill_known) __syncthreads();
         FF_PROF(12);
         if (bp1 > bp0) {
             // <sil> and the noise words (:755-769)
@@ -1298,7 +1343,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #endif
     }
 #ifdef PSGPU_FT_PROFILE
-    if (tid == 0 && bf.prof) for (int i = 0; i < 16; ++i) bf.prof[(size_t)blockIdx.x * 16 + i] = s_prof[i];
+    if (tid == 0 && bf.prof) for (int i = 0; i < 32; ++i) bf.prof[(size_t)blockIdx.x * 32 + i] = s_prof[i];
 #endif
     if (tid == 0) {
         u.bp_table_idx[s_sc[4]] = s_sc[1];                       // ngram_fwdflat_finish: mark one past the last frame
@@ -1378,6 +1423,9 @@ int psgpu_fwdflat_create(psgpu_fwdflat_t **out, const psgpu_fwdflat_tables_t *t)
     m->h_last.assign(ft->dict_last, ft->dict_last + d.n_w); m->h_last2.assign(ft->dict_last2, ft->dict_last2 + d.n_w);
     m->h_rs_n.assign(ft->rssid_n, ft->rssid_n + (size_t)d.n_ci * d.n_ci);
     m->h_known.assign(t->lm_known, t->lm_known + d.n_w);
+    d.fill_known = 0;                    // (a filler word the language model knows can be a successor AND be entered as a filler in one frame: order matters then)
+    for (int w = 0; w < d.n_w; ++w)
+        if (m->h_known[w] && (w == d.silwid || (w >= d.filler_start && w <= d.filler_end))) d.fill_known = 1;
     if (rc != PSGPU_OK) { psgpu_fwdflat_free(m); return rc; }
     *out = m;
     return PSGPU_OK;
@@ -1546,8 +1594,9 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         for (size_t k = 0; k < nwd; ++k)
             PSGPU_REQUIRE(voc[u].len[k] < 1024, "psgpu_fwdflat_search: a word chain of %d channels (FfUtt::einfo holds 10 bits)", voc[u].len[k]);
         PSGPU_REQUIRE(cap < (1u << 21), "psgpu_fwdflat_search: %zu active words (FfUtt::einfo holds 21 bits)", cap);
-        slab_off[u + 1] = slab_off[u] + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + (nwd + 1) + 6 * cap + 2 * (cap + 1) + 16
+        slab_off[u + 1] = slab_off[u] + 4 * (nwd + 1) + C * (5 + 5 + 4 + 5 + 6) + 5 * (size_t)d.n_w + (nwd + 1) + 6 * cap + 2 * (cap + 1) + 16
                         + (raw ? (size_t)d.n_sen + (size_t)d.n_sen / 2 + 2 : 0);
+        slab_off[u + 1] = (slab_off[u + 1] + 3) & ~(size_t)3;        // (an utterance's slab begins with its quads: 16-byte aligned)
         voc_off[u + 1] = voc_off[u] + 3 * nwd + (nwd + 1) + 2 * voc[u].node_sf.size() + (size_t)nfr + 2 + 4;
     }
 #ifdef PSGPU_FT_PROFILE
@@ -1573,6 +1622,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         u.fr_off = put(v.fr_off, v.fr_off.size()); u.fr_words = put(v.fr_words, v.fr_words.size());
         int32_t *q = slab + slab_off[i];
         auto take = [&](size_t n) { int32_t *r = q; q += n; return r; };
+        u.wstat = take(4 * (nwd + 1));
         u.score = take(C * 5); u.hist = take(C * 5); u.out = take(C); u.outh = take(C); u.best = take(C); u.frame = take(C);
         u.senid = take(C * 5); u.tmat = take(C); u.mpx = take(C); u.rcid = take(C); u.xflag = take(C); u.elist = take(C); u.einfo = take(C);
         u.wchain = take(d.n_w); u.wlen = take(d.n_w); u.wrcs = take(d.n_w); u.wseen = take(nwd + 1); u.word_active = take(d.n_w); u.word_lat_idx = take(d.n_w);
@@ -1604,7 +1654,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     bf.w1_ssid = w1_ssid_dev; bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
-    if (hipMalloc((void **)&bf.prof, sizeof(long long) * 16 * (size_t)n_utt) != hipSuccess) bf.prof = nullptr;
+    if (hipMalloc((void **)&bf.prof, sizeof(long long) * 32 * (size_t)n_utt) != hipSuccess) bf.prof = nullptr;
 #endif
     // scoring mode: the frame's senone scores live in LDS ([n_sen] int16, dynamic) beside ~53 KB of static arrays
     const size_t dyn = raw ? (((size_t)d.n_sen * 2 + 15) & ~(size_t)15) : 0;
@@ -1642,17 +1692,30 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
             "senone evaluation + normaliser", "mark, renormalise, reset", "evaluate (gather + hmm_vit_eval)", "rest of: prune + exits (the exits' back-pointers)",
             "rest of: word transitions (fillers, clear)", "next active word list", "active channels gathered + senones marked", "top-N lists taken / evaluated",
             "prune: decisions", "prune: fan-outs + clears", "word transitions: exits scanned, successors entered" };
-        std::vector<long long> h((size_t)16 * n_utt);
+        std::vector<long long> h((size_t)32 * n_utt);
         std::vector<int32_t> r((size_t)8 * n_utt);
         hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
         hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost);
         double frames = 0, tot = 0, acc[13] = {};
-        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 13; ++i) acc[i] += (double)h[(size_t)u * 16 + i]; }
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 13; ++i) acc[i] += (double)h[(size_t)u * 32 + i]; }
         for (int i = 0; i < 13; ++i) tot += acc[i];
         fprintf(stderr, "fwdflat_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
         {
+            double a[8] = {}, mx = 0, slow = 0, sum = 0;
+            for (int u = 0; u < n_utt; ++u) {
+                for (int i = 0; i < 7; ++i) a[i] += (double)h[(size_t)u * 32 + 16 + i];
+                mx = std::max(mx, (double)h[(size_t)u * 32 + 22]);
+                double t = 0; for (int i = 0; i < 13; ++i) t += (double)h[(size_t)u * 32 + i];
+                slow = std::max(slow, t); sum += t;
+            }
+            fprintf(stderr, "  word transitions: %.1f %% of the frames have new entries: %.1f entries, %.1f words in the window, %.0f pairs each; most entries in a frame %.0f; "
+                    "phase cycles per frame: %.0f in frames whose exits fit the queue, %.0f in those that overflow\n", 100.0 * a[0] / frames, a[1] / std::max(a[0], 1.0),
+                    a[2] / std::max(a[0], 1.0), a[3] / std::max(a[0], 1.0), mx, a[4] / frames, a[5] / frames);
+            fprintf(stderr, "  slowest utterance: %.0f cycles = %.2f x the mean\n", slow, slow / (sum / n_utt));
+        }
+        {
             double ov = 0, ne = 0, o256 = 0;
-            for (int u = 0; u < n_utt; ++u) { ov += (double)h[(size_t)u * 16 + 13]; ne += (double)h[(size_t)u * 16 + 14]; o256 += (double)h[(size_t)u * 16 + 15]; }
+            for (int u = 0; u < n_utt; ++u) { ov += (double)h[(size_t)u * 32 + 13]; ne += (double)h[(size_t)u * 32 + 14]; o256 += (double)h[(size_t)u * 32 + 15]; }
             fprintf(stderr, "  exits queued per frame %.1f; frames whose exits exceed the LDS queue: %.1f %%, cycles from their decisions to their end: %.0f each\n", ne / (frames > 0 ? frames : 1), 100.0 * ov / (frames > 0 ? frames : 1), o256 / (ov > 0 ? ov : 1));
         }
         for (int i = 0; i < 13; ++i)
