@@ -33,13 +33,13 @@
 #if !defined(__HIPCC__)
 #define PSGPU_FF_CHECK_LAZY 1
 #include <cstdio>
-extern "C" { int psgpu_sim_ff_exit_cap = 160; }      // (tests shrink it to drive the frames through the other path)
+extern "C" { int psgpu_sim_ff_exit_cap = 256; }      // (tests shrink it to drive the frames through the other path)
 #define FF_EXIT_CAP psgpu_sim_ff_exit_cap
 extern "C" { int psgpu_sim_ff_el_cap = 384; }
 #define FF_EL_CAP psgpu_sim_ff_el_cap
 extern "C" { int psgpu_sim_ff_awl_regs = 512; }
 #define FF_AWL_REGS psgpu_sim_ff_awl_regs
-extern "C" { int psgpu_sim_ff_pair_rows = 160; }     // new entries of a frame the word transitions take as (word, entry) pairs
+extern "C" { int psgpu_sim_ff_pair_rows = 96; }     // new entries of a frame the word transitions take as (word, entry) pairs
 #define FF_PAIR_ROWS psgpu_sim_ff_pair_rows
 extern "C" { int psgpu_sim_ff_slice_chunk = 256; }   // ... and words of the frame's window a chunk of those pairs takes (<= kFfThreads)
 #define FF_SL_CHUNK psgpu_sim_ff_slice_chunk
@@ -47,7 +47,7 @@ extern "C" { int psgpu_sim_ff_slice_chunk = 256; }   // ... and words of the fra
 #define FF_EXIT_CAP kFfMaxExit
 #define FF_EL_CAP kFfMaxEl
 #define FF_AWL_REGS (kFfRegRows * kFfThreads)
-#define FF_PAIR_ROWS kFfMaxExit
+#define FF_PAIR_ROWS kFfNewRows
 #define FF_SL_CHUNK kFfThreads
 #endif
 
@@ -63,9 +63,10 @@ constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel 
 constexpr int kFfRegRows = 2;           // vocabularies up to kFfRegRows x 256 words (+ fillers) keep their static records in registers
 constexpr int kFfMaxTp = 2048;         // bytes of transition matrices held in LDS (more: read from device memory)
 #ifndef PSGPU_FF_MAX_EXIT
-#define PSGPU_FF_MAX_EXIT 160
+#define PSGPU_FF_MAX_EXIT 256
 #endif
-constexpr int kFfMaxExit = PSGPU_FF_MAX_EXIT;        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
+constexpr int kFfMaxExit = PSGPU_FF_MAX_EXIT;
+constexpr int kFfNewRows = 96;          // new entries (exiting WORDS) of a frame whose rows the word transitions find in LDS (30 s of speech, 115 words: at most 33)        // word exits of a frame queued in LDS (more: the frame's exits through the slab's flags)
 
 // Scoring mode (psgpu_fwdflat_search_feats_dev): the kernel is handed the feature rows and the PTM model and produces
 // each frame's senone scores itself, as ptm_mgau_frame_eval does when the second pass calls it (ptm_mgau.c:408-454 with
@@ -151,7 +152,9 @@ struct FfBufs {
 // per-phase cycle counts of work-item 0 (a profiling build only: -DPSGPU_FT_PROFILE; the product kernel has none of it)
 #ifdef PSGPU_FT_PROFILE
 #define FF_PROF(i) do { if (tid == 0) { const long long t_ = clock64(); s_prof[i] += t_ - s_last; s_last = t_; } } while (0)
+#define FF_PROFS(i) do { if (tid == 0) s_prof[i] += clock64() - s_last; } while (0)      /* since the last FF_PROF, without moving it */
 #else
+#define FF_PROFS(i) do { } while (0)
 #define FF_PROF(i) do { } while (0)
 #endif
 
@@ -299,7 +302,8 @@ __device__ __forceinline__ void ff_new_bp(FfUtt &u, int32_t bpidx, int32_t bss_h
                                           bool single, int32_t last, int32_t last2, int32_t base, bool filler,
                                           int32_t path_real, int32_t path_preal)
 {
-    u.word_lat_idx[w] = bpidx;
+    // (word_lat_idx -- "the word's entry of this frame" -- is the slab path's (ff_save_bp): here a word's exits are found side by side in
+    //  the sorted queue, and the array stays -1 throughout)
     FBP(u, F_WID, bpidx) = w; FBP(u, F_FRAME, bpidx) = frame; FBP(u, F_BP, bpidx) = path; FBP(u, F_SCORE, bpidx) = score;
     FBP(u, F_SIDX, bpidx) = single ? -1 : bss_head; FBP(u, F_VALID, bpidx) = 1;
     FBP(u, F_LAST, bpidx) = last; FBP(u, F_LAST2, bpidx) = last2;
@@ -351,6 +355,19 @@ __device__ __forceinline__ float ff_density(const psgpu_ptm_view_t &pm, const fl
     }
     return d;
 }
+// A workgroup barrier for phases that exchange data through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and
+// the fence waits for EVERY outstanding access of the wavefront -- the stores to the slab and the tables that nothing in the next
+// phase reads, loads asked for ahead of need: a trip to device memory per barrier, ~27 barriers a frame.  This one waits for the LDS
+// counter alone.  Where work-items hand each other data through DEVICE memory (a channel's state after the evaluation, the pruning's
+// and the transitions' entries, the active word list) the kernel keeps __syncthreads(): the comments at those barriers say what crosses.
+__device__ __forceinline__ void ff_sync_lds()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 // out[t] = max of v over work-items 0 .. t - 1 (-1 for work-item 0).  Ends with a barrier.
 __device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
 {
@@ -361,9 +378,9 @@ __device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
     if (lane == 63) tmp[tid >> 6] = incl;
     int32_t excl = __shfl_up(incl, 1);
     if (lane == 0) excl = -1;
-    __syncthreads();
+    ff_sync_lds();
     for (int w = 0; w < (tid >> 6); ++w) excl = max(excl, tmp[w]);
-    __syncthreads();
+    ff_sync_lds();
     return excl;
 }
 
@@ -376,7 +393,7 @@ __device__ __forceinline__ int32_t ff_block_excl_sum(int32_t v, int32_t *tmp, in
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
     if (lane == 63) tmp[tid >> 6] = incl;
-    __syncthreads();
+    ff_sync_lds();
     int32_t base = 0; total = 0;
 #pragma unroll
     for (int w = 0; w < kFfThreads / 64; ++w) { const int32_t t = tmp[w]; total += t; if (w < (tid >> 6)) base += t; }
@@ -424,8 +441,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ int32_t s_lk[RAW ? kFfMaxEnt / 4 : 1];    // per chain: the last frame after which s_lcw holds its list (-1: the seed)
     __shared__ int32_t s_el[kFfMaxEl][4];                        // the active-channel list: channel | flags, word's list position << 10 | chain
                                                                  //   position, word, channels after it | word's right-context count << 10 | single-phone << 20
-    __shared__ int32_t s_ex[kFfMaxExit][13], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
-    __shared__ int32_t s_nbp[kFfMaxExit][10];                     // the frame's new back-pointers: word, last / last-but-one phone, score, sorted
+    __shared__ int32_t s_ex[kFfMaxExit][11], s_nex, s_tot[2];     // the frame's word exits: (word's list position << 10 | chain position), channel,
+    __shared__ int32_t s_nbp[kFfNewRows][10];                     // the frame's new back-pointers: word, last / last-but-one phone, score, sorted
                                                                  //   position of the word's first exit, real word ids (two), which right contexts it exited into (64 bits)
     __shared__ FfQuad s_srt[kFfMaxExit + 4];                      // the queue in sorted order, what a walk over a word's exits reads: word's list
                                                                  //   position, score, history, rc slot -- one 16-byte read an exit
@@ -442,9 +459,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ unsigned long long s_key;
     const int tid = threadIdx.x;
 #ifdef PSGPU_FT_PROFILE
-    __shared__ long long s_prof[32], s_last, s_t5;
+    __shared__ long long s_prof[48], s_last, s_t5;
+    __shared__ int s_pscan;
     __shared__ int s_over;
-    if (tid == 0) { for (int i = 0; i < 32; ++i) s_prof[i] = 0; s_last = clock64(); }
+    if (tid == 0) { for (int i = 0; i < 48; ++i) s_prof[i] = 0; s_last = clock64(); s_pscan = 0; }
 #endif
     FfUtt u;
     {
@@ -532,8 +550,17 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     }
     FfQuad pre_q = { 0, 0, 0, 0 };
     uint32_t pre_c4 = 0;
-    bool pre_closed = false;
+    uint8_t pre_open = 0;
     const bool ahead = RAW && rw.tsc && topn == 4 && n_chain <= kFfThreads;
+    int sl_b0 = 0, sl_b1 = 0;                 // the window's slice of the nodes-by-start-frame list, of the frame about to begin
+    auto slice_bounds = [&](int fr) {
+        int sf0 = fr - p.max_sf_win, ef0 = fr + p.max_sf_win;
+        if (sf0 < 0) sf0 = 0;
+        if (ef0 > u.n_frame) ef0 = u.n_frame;
+        sl_b0 = 0; sl_b1 = 0;
+        if (ef0 > sf0) { sl_b0 = u.fr_off[sf0]; sl_b1 = u.fr_off[ef0]; }
+    };
+    slice_bounds(0);
     for (int f = 0; f < T; ++f) {
         const int cur = f & 1, nxt = cur ^ 1, nf = f + 1, na = cur ? n_awl1 : n_awl0;
         int32_t *const awl_c = cur ? u.awl[1] : u.awl[0], *const awl_n = cur ? u.awl[0] : u.awl[1];
@@ -542,29 +569,35 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      irrelevant): the senone marking below and fwdflat_eval_chan both go over it one work-item per CHANNEL -- the marking
         //      used to walk every active word's chain a second time, one work-item per word (11 % of the frame,
         //      profiles/r03_fwdflat_phase_profile.txt).  Nothing between here and the evaluation changes a channel's frame stamp.
+        FF_PROFS(40);
         if (tid == 0) { s_sc[7] = 0; s_nfan = 0; s_nex = 0; s_tot[0] = 0; s_tot[1] = 0; s_nl = 0; s_nb = 0x7fffffff; s_nopen = 0; }
-        // the word transitions' successors (below): the window's slice of the nodes-by-start-frame list depends on f alone -- its bounds are
-        // asked for here, its words after the next barrier, their static quads after the one after that: nothing waits for them
-        int sl_q0 = 0, sl_n = 0;
-        {
-            int sf0 = f - p.max_sf_win, ef0 = f + p.max_sf_win;
-            if (sf0 < 0) sf0 = 0;
-            if (ef0 > u.n_frame) ef0 = u.n_frame;
-            if (ef0 > sf0) { sl_q0 = u.fr_off[sf0]; sl_n = u.fr_off[ef0] - sl_q0; }
-        }
-        if (ahead && tid < n_chain) {
-            const size_t o = (size_t)tid * rw.total + t0 + f;
-            pre_q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); pre_c4 = rw.tcw[o]; pre_closed = !rw.open[o];
-        }
+        FF_PROFS(41);
+        // the word transitions' successors (below): the window's slice of the nodes-by-start-frame list depends on f alone -- its bounds were
+        // asked for a frame ahead, its words are after the next barrier, their static quads after the one after that: nothing waits for them
+        const int sl_q0 = sl_b0, sl_n = sl_b1 - sl_b0;      // (this frame's bounds were asked for during the frame before)
+#if defined(PSGPU_FT_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" :: "s"(sl_n));
+#endif
+        FF_PROFS(42);
         if (RAW) {
             for (int i = tid; i < (rw.pm.n_sen + 31) >> 5; i += kFfThreads) s_bits[i] = 0u;
             for (int i = tid; i < rw.pm.n_mgau; i += kFfThreads) s_cbact[i] = 0;
             if (tid < 16) s_norm[tid] = kW;
         }
-        __syncthreads();
+        FF_PROFS(43);
+        ff_sync_lds();
+        FF_PROFS(32);
         for (int i = tid >> 4; i < na; i += kFfThreads / 16) {          // sixteen work-items a word: its chain's stamps read side by side
             const int w = awl_c[i * 3], c0 = awl_c[i * 3 + 1], wx = awl_c[i * 3 + 2], len = wx & 1023;
+#ifdef PSGPU_FT_PROFILE
+            if ((tid & 15) == 0) atomicAdd(&s_pscan, len);
+            if (i == 0) FF_PROFS(33);
+#endif
             for (int k = tid & 15; k < len; k += 16) {
+#ifdef PSGPU_FT_PROFILE
+                long long tk_a = 0, tk_b = 0;
+                if (tid == 0) tk_a = clock64();
+#endif
                 const int c = c0 + k;
                 // (the stamp and what an active channel needs next asked for together: one trip to memory instead of two)
                 const int32_t stamp = u.frame[c];
@@ -575,6 +608,20 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #pragma unroll
                     for (int q = 0; q < NE; ++q) sid[q] = u.senid[c * 5 + q];
                 }
+#ifdef PSGPU_FT_PROFILE
+                if (i == 0 && k == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    { int m_ = mpx, s0_ = RAW ? sid[0] : 0; asm volatile("" :: "v"(stamp), "v"(s0_), "v"(m_)); }
+#endif
+                    FF_PROFS(34);
+                }
+                if (tid == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    { int m_ = mpx, s0_ = RAW ? sid[0] : 0, s2_ = RAW ? sid[NE - 1] : 0; asm volatile("" :: "v"(stamp), "v"(s0_), "v"(m_), "v"(s2_)); }
+#endif
+                    tk_b = clock64(); s_prof[36] += tk_b - tk_a; s_prof[38] += 1;
+                }
+#endif
                 if (stamp == f) {                             // bit 30: the root of </s>, which does not count towards the best score
                     const int pos = atomicAdd(&s_sc[7], 1);
                     const int cf = c | ((k == 0 && w == p.finishwid) ? (1 << 30) : 0);
@@ -586,20 +633,39 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     if (RAW) {
                         // compute_fwdflat_sen_active (:416-442): the channel's senones into the frame's bitmap, and -- the first time
                         // a senone is marked -- into the list the evaluation below goes over (its order does not matter there)
+                        if (mpx) {                            // (a multiplexed channel's states through their senone sequences: asked for together)
+#pragma unroll
+                            for (int q = 0; q < NE; ++q) sid[q] = sid[q] == kBadSsid ? -1 : (int32_t)p.sseq[(size_t)sid[q] * NE + q];
+                        }
 #pragma unroll
                         for (int q = 0; q < NE; ++q) {
-                            int sen = sid[q];
-                            if (mpx) { if (sen == kBadSsid) continue; sen = p.sseq[(size_t)sen * NE + q]; }
+                            const int sen = sid[q];
+                            if (sen < 0) continue;
                             const uint32_t bit = 1u << (sen & 31);
                             if (!(atomicOr(&s_bits[sen >> 5], bit) & bit)) s_slist[atomicAdd(&s_nl, 1)] = (uint16_t)sen;
                         }
                     }
                 }
+#ifdef PSGPU_FT_PROFILE
+                if (tid == 0) s_prof[37] += clock64() - tk_b;
+#endif
             }
         }
-        __syncthreads();
+        FF_PROFS(35);
+        ff_sync_lds();
+#ifdef PSGPU_FT_PROFILE
+        if (tid == 0) { s_prof[27] += na; s_prof[28] += s_pscan; s_prof[29] += s_sc[7]; s_pscan = 0; }
+#endif
         FF_PROF(8);
         const int sl_k = tid < sl_n && tid < FF_SL_CHUNK ? u.fr_words[sl_q0 + tid] : -1;
+        slice_bounds(nf);
+        // the batch scorer's entry of this frame for the work-item's chain (`ahead`): asked for here, behind the gather's last load (loads
+        // come back in order: asked for at the top of the frame, these lines -- read once, no cache has them -- made the gather's first
+        // wait a trip to HBM) and ahead of a phase that asks device memory nothing
+        if (ahead && tid < n_chain) {
+            const size_t o = (size_t)tid * rw.total + t0 + f;
+            pre_q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); pre_c4 = rw.tcw[o]; pre_open = rw.open[o];
+        }
         const int n_eval = s_sc[7];
         struct FfEnt { int32_t c, inf, w, aux; };
         auto ent = [&](int e) -> FfEnt {
@@ -612,9 +678,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const float *x = rw.feats + (size_t)(t0 + f) * pm.veclen;
             const int nwords = (pm.n_sen + 31) >> 5;
             const int n_l0 = s_nl;
-            {   // s_prev[w] = the highest senone listed in the words before w: where acmod_flags2list's bridging entries go
+            {
                 static_assert(kFfMaxSen / 32 <= kFfThreads, "one bitmap word per work-item");
                 const uint32_t bw = tid < nwords ? s_bits[tid] : 0u;
+                // s_prev[w] = the highest senone listed in the words before w: where acmod_flags2list's bridging entries go
                 const int32_t pv = ff_block_excl_max(bw ? tid * 32 + 31 - __clz((int)bw) : -1, s_scan);
                 // every listed senone (bridging entries included) touches its codebook: ptm_mgau_calc_cb_active (:297-321).  Only the
                 // first senone of a bitmap word can be more than 255 past its predecessor; the entries in between are listed too
@@ -628,7 +695,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 }
             }
             for (int i = tid; i < n_l0; i += kFfThreads) s_cbact[s_s2cb[s_slist[i]]] = 1;
-            __syncthreads();
+            ff_sync_lds();
             FF_PROF(0);
             // ---- eval_topn for every chain, eval_cb for the touched codebooks' chains; one work-item per chain.
             //      With the batch scorer's lists at hand (`lazy`) a chain costs nothing in most frames: a touched codebook's list is
@@ -662,7 +729,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 // active list's instead of after it
                 FfQuad q = pre_q;
                 uint32_t c4 = pre_c4;
-                bool closed = pre_closed;
+                bool closed = ahead && !pre_open;
                 if (lazy && !ahead) {
                     const size_t o = (size_t)ch * rw.total + t0 + f;
                     q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); c4 = rw.tcw[o]; closed = !rw.open[o];
@@ -729,7 +796,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #endif
                 if (s_cbact[cb]) atomicMax(&s_norm[fs], sc[0] >> 10);        // ptm_mgau_codebook_norm (:272-279)
             }
-            __syncthreads();
+            ff_sync_lds();
             if (s_nopen) {
                 // An open entry of a touched codebook: the reference's own procedure on the list it would carry here -- the re-orderings
                 // since the chain's last known list replayed (see above), then eval_topn + eval_cb of this frame (ptm_mgau.c:71-226) -- by
@@ -811,7 +878,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         atomicMax(&s_norm[fs], sc[0] >> 10);
                     }
                 }
-                __syncthreads();
+                ff_sync_lds();
             }
             FF_PROF(9);
             // The scorer's usual shape (3 streams, top-4, senone-major weights at hand): each listed senone's twelve weights from three
@@ -829,7 +896,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 }
                 if (fast) { s_pcw[ch] = pc; s_psc[ch] = ps; }
             }
-            __syncthreads();
+            ff_sync_lds();
             FF_PROF(1);
             // ---- ptm_mgau_senone_eval (:326-403) for the listed senones; the frame's scores are those minus their minimum
             const int n_l = s_nl;
@@ -867,7 +934,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     mn = min(mn, av[j]);
                 }
                 wg_min(mn);
-                __syncthreads();
+                ff_sync_lds();
                 const int32_t nb = s_nb;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -884,14 +951,14 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     mn = min(mn, a);
                 }
                 wg_min(mn);
-                __syncthreads();
+                ff_sync_lds();
                 const int32_t nb = s_nb;
                 for (int i = tid; i < n_l; i += kFfThreads) {
                     const int sen = s_slist[i];
                     s_row[sen] = (int16_t)(uint16_t)((uint32_t)(int32_t)(int16_t)u.nrow32[sen] - (uint32_t)nb);
                 }
             }
-            __syncthreads();
+            ff_sync_lds();
         }
         FF_PROF(2);
         // ---- ngram_search_mark_bptable, failure test, renormalisation (:825-838)
@@ -904,7 +971,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 const int c0 = awl_c[i * 3 + 1], len = awl_c[i * 3 + 2] & 1023;
                 for (int k = 0; k < len; ++k) if (u.frame[c0 + k] == f) ff_normalize(p, u, c0 + k, best_in);
             }
-        __syncthreads();
+        // (a full barrier where work-items exchanged through device memory since the last one: renormalised channels, the part of the
+        //  active-channel list that did not fit LDS)
+        if (best_in + 2 * p.beam < kW || n_eval > FF_EL_CAP) __syncthreads(); else ff_sync_lds();
         FfQuad sl_w = { 0, 0, 0, 0 };
         bool sl_on = false;
         if (sl_k >= 0) {                                      // (a word with two nodes in the window is taken once)
@@ -912,7 +981,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             sl_w = *reinterpret_cast<const FfQuad *>(u.wstat + 4 * (size_t)sl_k);
         }
         if (tid == 0) { s_sc[0] = kW; s_sc[5] = kW; s_sc[6] = 0; s_key = 0ull; }
-        __syncthreads();
+        ff_sync_lds();
         FF_PROF(3);
         int32_t k_best = kW, k_out = kW, k_outh = -1, k_rc = -1, k_rc1 = -1, k_nfr = 0, k_s0 = kW;     // the first entry a work-item evaluates
         // ---- fwdflat_eval_chan (:444-480), one work-item per channel of the list made at the top of the frame (a word near its end
@@ -981,8 +1050,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         x[0] = en.inf; x[1] = w | ((en.aux >> 20) << 30); x[2] = newscore; x[3] = hist;
                         x[4] = (en.aux >> 10) & 1023;
                         x[5] = k == 0 ? 0 : rc;
-                        x[8] = p.d_last[w]; x[9] = (en.aux >> 20) ? -1 : p.d_last2[w]; x[10] = p.d_base[w] | (p.d_filler[w] ? (1 << 30) : 0);
-                        x[11] = hist != -1 ? FBP(u, F_REAL, hist) : -1; x[12] = hist != -1 ? FBP(u, F_PREAL, hist) : -1;
+                        x[6] = p.d_last[w]; x[7] = (en.aux >> 20) ? -1 : p.d_last2[w]; x[8] = p.d_base[w] | (p.d_filler[w] ? (1 << 30) : 0);
+                        x[9] = hist != -1 ? FBP(u, F_REAL, hist) : -1; x[10] = hist != -1 ? FBP(u, F_PREAL, hist) : -1;
                     }
                 }
             }
@@ -1005,7 +1074,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         FF_PROF(10);
         for (int q = tid >> 6, nq = min(s_nfan, kFfMaxFan); q < nq; q += kFfThreads / 64)
             for (int j = tid & 63; j < s_fan[q][1]; j += 64) ff_enter_if_better(u, s_fan[q][0] + j, s_fan[q][2], s_fan[q][3], f);
-        __syncthreads();
+        // (the clears below look at a stamp -- which a fan-out or a predecessor may just have written -- only for entries beyond a
+        //  work-item's first; the others decide from registers)
+        if (n_eval > kFfThreads || n_eval > FF_EL_CAP) __syncthreads(); else ff_sync_lds();
         for (int e = tid; e < n_eval; e += kFfThreads) {
             const int v = e < FF_EL_CAP ? s_el[e][0] : u.elist[e];
             const int both = kFfClearBit | kFfEnteredBit;
@@ -1018,7 +1089,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #endif
             if (v & kFfClearBit) ff_clear_scores(p, u, v & kFfChanMask);
         }
-        __syncthreads();
+        ff_sync_lds();
         FF_PROF(11);
         // ---- the exits' back-pointers (ngram_search_save_bp as fwdflat_prune_chan calls it, :528-540, :588-600): one entry per
         //      exiting WORD in active-list order, its right-context exits applied in chain order (the first creates the entry, a later
@@ -1027,7 +1098,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         //      and stack entries precede it from the sorted queue and then walks its group -- everything but the table itself in LDS.
         const int n_exq = s_nex;
 #ifdef PSGPU_FT_PROFILE
-        if (tid == 0) { s_prof[13] += n_exq > FF_EXIT_CAP ? 1 : 0; s_prof[14] += n_exq; s_over = n_exq > FF_EXIT_CAP; s_t5 = clock64(); }
+        if (tid == 0) { s_prof[13] += n_exq > FF_EXIT_CAP ? 1 : 0; s_prof[14] += n_exq; s_over = n_exq > FF_EXIT_CAP; s_t5 = clock64();
+                        s_prof[23] += n_exq > 192; s_prof[24] += n_exq > 224; s_prof[25] += n_exq > 256; s_prof[26] += n_exq > 320; }
 #endif
         if (s_nex == 0) { }                                  // (a frame without exits: nothing to write, no barrier to meet)
         else if (s_nex <= FF_EXIT_CAP) {
@@ -1040,12 +1112,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 for (int j = 0; j < n_ex; ++j) r += s_ex[j][0] < key;
                 s_ord[r] = (uint16_t)tid;
             }
-            __syncthreads();
+            ff_sync_lds();
             // sorted position r = tid: a word's first exit (`head`) counts one entry and the word's stack block; one prefix sum gives
             // every exit the number of entries and stack slots before its word
             const int32_t *x = s_ex[tid < n_ex ? s_ord[tid] : 0];
             const int i = x[0] >> 10;
-            if (tid < n_ex + 4 && tid < kFfMaxExit + 4) s_srt[tid] = tid < n_ex ? FfQuad{ i, x[2], x[3], x[5] } : FfQuad{ -1, 0, 0, 0 };
+            if (tid < n_ex) s_srt[tid] = FfQuad{ i, x[2], x[3], x[5] };
+            if (tid < 4) s_srt[n_ex + tid] = FfQuad{ -1, 0, 0, 0 };            // (sentinels: a walk reads four exits at a time)
             const bool mine = tid < n_ex, head = mine && (tid == 0 || (s_ex[s_ord[tid - 1]][0] >> 10) != i);
             int32_t total;
             const int32_t before = ff_block_excl_sum(head ? ((x[4] << 10) | 1) : 0, s_scan, total);
@@ -1059,7 +1132,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 if (head) {
                     const int w = x[1] & 0x3fffffff;
                     const int32_t bpi = bpidx + (before & 1023);
-                    ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], single, x[8], x[9], x[10] & 0x3fffffff, (x[10] >> 30) != 0, x[11], x[12]);
+                    ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], single, x[6], x[7], x[8] & 0x3fffffff, (x[8] >> 30) != 0, x[9], x[10]);
                     int32_t cs = x[2], cp = x[3];
                     bool dirty = false, requirk = false;
                     unsigned long long have = 1ull << x[5];
@@ -1086,21 +1159,21 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         if (!more) break;
                     }
                     if (dirty) FBP(u, F_SCORE, bpi) = cs;
-                    {   // what the word transitions below read of this entry
+                    if ((before & 1023) < FF_PAIR_ROWS) {   // what the word transitions below read of this entry (a frame with more new entries than rows reads the table)
                         int32_t *nb = s_nbp[before & 1023];
-                        const bool filler = (x[10] >> 30) != 0;
-                        const int32_t base = x[10] & 0x3fffffff;
-                        nb[0] = w; nb[1] = x[8]; nb[2] = x[9]; nb[3] = cs; nb[4] = tid;
+                        const bool filler = (x[8] >> 30) != 0;
+                        const int32_t base = x[8] & 0x3fffffff;
+                        nb[0] = w; nb[1] = x[6]; nb[2] = x[7]; nb[3] = cs; nb[4] = tid;
                         if (requirk) { nb[5] = FBP(u, F_REAL, bpi); nb[6] = FBP(u, F_PREAL, bpi); }
-                        else if (filler) { nb[5] = x[3] != -1 ? x[11] : base; nb[6] = x[3] != -1 ? x[12] : -1; }
-                        else { nb[5] = base; nb[6] = x[11]; }
+                        else if (filler) { nb[5] = x[3] != -1 ? x[9] : base; nb[6] = x[3] != -1 ? x[10] : -1; }
+                        else { nb[5] = base; nb[6] = x[9]; }
                         nb[7] = (int32_t)(uint32_t)have; nb[8] = (int32_t)(uint32_t)(have >> 32);
                     }
                     if (!single)
                         for (int q = 0; q < x[4]; ++q) if (!((have >> q) & 1)) u.bss[bsh + q] = kW;      // the contexts nothing exited into
                 }
             }
-            __syncthreads();
+            ff_sync_lds();
         }
         else {
             // more exits than the queue holds: through flags in the slab, one work-item per exiting word walking its chain
@@ -1133,7 +1206,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             __syncthreads();
             if (tid == 0) { if (full) s_sc[3] = 1; else { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; } }   // (full: nothing was written)
         }
-        __syncthreads();
+        ff_sync_lds();
         if (s_sc[3]) break;
 
         FF_PROF(5);
@@ -1164,9 +1237,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     r[0] = FBP(u, F_WID, b); r[1] = FBP(u, F_LAST, b); r[2] = FBP(u, F_LAST2, b); r[3] = FBP(u, F_SCORE, b);
                     r[4] = FBP(u, F_SIDX, b); r[5] = FBP(u, F_REAL, b); r[6] = FBP(u, F_PREAL, b);
                 }
-                if (tid < n_new) u.word_lat_idx[s_nbp[tid][0]] = -1;
+                if (!lds_exits && tid < n_new) u.word_lat_idx[s_nbp[tid][0]] = -1;      // (the slab path's exits set it)
             }
             else {
+                __syncthreads();                             // (the new entries are read from the table: what the exits' phase wrote must be there)
                 for (int b = bp0 + tid; b < bp1; b += kFfThreads) {
                     const int wid = FBP(u, F_WID, b);
                     u.word_lat_idx[wid] = -1;
@@ -1197,7 +1271,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 if (on) { cur_fr = u.frame[c0]; cur_sc = u.score[c0 * 5]; }
                 if (by_pairs) {
                     s_wfirst[tid] = on ? first : -1; s_wbase[tid] = wq4.w; s_wkey[tid] = 0ull;
-                    __syncthreads();
+                    ff_sync_lds();
                     const int n_row = n_act + (cb == 0 ? 1 : 0);                     // (the first chunk: one more row, <sil>'s)
                     for (int pr = tid, n_pair = n_row * n_new; pr < n_pair; pr += kFfThreads) {
                         const int t = pr / n_new, e = pr - t * n_new;
@@ -1222,7 +1296,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         if (newscore > thresh)
                             atomicMax(&s_wkey[t], ((unsigned long long)((uint32_t)newscore ^ 0x80000000u) << 32) | (uint32_t)(0x7fffffff - e));
                     }
-                    __syncthreads();
+                    ff_sync_lds();
                     if (on) {
                         const unsigned long long key = s_wkey[tid];
                         const int32_t sc = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
@@ -1233,7 +1307,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                             u.word_active[wq4.x] = nf;
                         }
                     }
-                    if (cb + FF_SL_CHUNK < sl_n) __syncthreads();                    // (the next chunk overwrites the rows)
+                    if (cb + FF_SL_CHUNK < sl_n) ff_sync_lds();                    // (the next chunk overwrites the rows)
                 }
                 else if (on) {
                     // more new entries than rows: the word's work-item goes through the table, exits in order
@@ -1255,7 +1329,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     }
                 }
             }
-            if (!by_pairs) __syncthreads();                  // (<sil>'s key is complete)
+            if (!by_pairs) ff_sync_lds();                  // (<sil>'s key is complete)
         }
 #ifdef PSGPU_FT_PROFILE
         if (tid == 0) {      // the word transitions' shape: [16] frames with new entries, [17] their entries, [18] slice entries, [19] (word, entry) pairs,
@@ -1343,7 +1417,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #endif
     }
 #ifdef PSGPU_FT_PROFILE
-    if (tid == 0 && bf.prof) for (int i = 0; i < 32; ++i) bf.prof[(size_t)blockIdx.x * 32 + i] = s_prof[i];
+    if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) bf.prof[(size_t)blockIdx.x * 48 + i] = s_prof[i];
 #endif
     if (tid == 0) {
         u.bp_table_idx[s_sc[4]] = s_sc[1];                       // ngram_fwdflat_finish: mark one past the last frame
@@ -1654,7 +1728,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     bf.w1_ssid = w1_ssid_dev; bf.bp_cap = bp_cap; bf.bss_cap = bss_cap; bf.max_frames = max_frames;
     bf.prof = nullptr;
 #ifdef PSGPU_FT_PROFILE
-    if (hipMalloc((void **)&bf.prof, sizeof(long long) * 32 * (size_t)n_utt) != hipSuccess) bf.prof = nullptr;
+    if (hipMalloc((void **)&bf.prof, sizeof(long long) * 48 * (size_t)n_utt) != hipSuccess) bf.prof = nullptr;
 #endif
     // scoring mode: the frame's senone scores live in LDS ([n_sen] int16, dynamic) beside ~53 KB of static arrays
     const size_t dyn = raw ? (((size_t)d.n_sen * 2 + 15) & ~(size_t)15) : 0;
@@ -1692,30 +1766,51 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
             "senone evaluation + normaliser", "mark, renormalise, reset", "evaluate (gather + hmm_vit_eval)", "rest of: prune + exits (the exits' back-pointers)",
             "rest of: word transitions (fillers, clear)", "next active word list", "active channels gathered + senones marked", "top-N lists taken / evaluated",
             "prune: decisions", "prune: fan-outs + clears", "word transitions: exits scanned, successors entered" };
-        std::vector<long long> h((size_t)32 * n_utt);
+        std::vector<long long> h((size_t)48 * n_utt);
         std::vector<int32_t> r((size_t)8 * n_utt);
         hipMemcpy(h.data(), bf.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
         hipMemcpy(r.data(), result_dev, 4 * r.size(), hipMemcpyDeviceToHost);
         double frames = 0, tot = 0, acc[13] = {};
-        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 13; ++i) acc[i] += (double)h[(size_t)u * 32 + i]; }
+        for (int u = 0; u < n_utt; ++u) { frames += r[(size_t)u * 8 + 2]; for (int i = 0; i < 13; ++i) acc[i] += (double)h[(size_t)u * 48 + i]; }
         for (int i = 0; i < 13; ++i) tot += acc[i];
         fprintf(stderr, "fwdflat_kernel profile: %d utterances, %.0f frames, %.0f cycles per frame (work-item 0)\n", n_utt, frames, tot / (frames > 0 ? frames : 1));
         {
             double a[8] = {}, mx = 0, slow = 0, sum = 0;
             for (int u = 0; u < n_utt; ++u) {
-                for (int i = 0; i < 7; ++i) a[i] += (double)h[(size_t)u * 32 + 16 + i];
-                mx = std::max(mx, (double)h[(size_t)u * 32 + 22]);
-                double t = 0; for (int i = 0; i < 13; ++i) t += (double)h[(size_t)u * 32 + i];
+                for (int i = 0; i < 7; ++i) a[i] += (double)h[(size_t)u * 48 + 16 + i];
+                mx = std::max(mx, (double)h[(size_t)u * 48 + 22]);
+                double t = 0; for (int i = 0; i < 13; ++i) t += (double)h[(size_t)u * 48 + i];
                 slow = std::max(slow, t); sum += t;
             }
             fprintf(stderr, "  word transitions: %.1f %% of the frames have new entries: %.1f entries, %.1f words in the window, %.0f pairs each; most entries in a frame %.0f; "
                     "phase cycles per frame: %.0f in frames whose exits fit the queue, %.0f in those that overflow\n", 100.0 * a[0] / frames, a[1] / std::max(a[0], 1.0),
                     a[2] / std::max(a[0], 1.0), a[3] / std::max(a[0], 1.0), mx, a[4] / frames, a[5] / frames);
             fprintf(stderr, "  slowest utterance: %.0f cycles = %.2f x the mean\n", slow, slow / (sum / n_utt));
+            double g3[3] = {}, ex[4] = {}, sub[4] = {};
+            for (int u = 0; u < n_utt; ++u) {
+                for (int i = 0; i < 3; ++i) g3[i] += (double)h[(size_t)u * 48 + 27 + i];
+                for (int i = 0; i < 4; ++i) { ex[i] += (double)h[(size_t)u * 48 + 23 + i]; sub[i] += (double)h[(size_t)u * 48 + 32 + i]; }
+            }
+            fprintf(stderr, "  per frame: %.1f active words, %.1f channels in their chains, %.1f of them active\n", g3[0] / frames, g3[1] / frames, g3[2] / frames);
+            fprintf(stderr, "  frames with more than 192 / 224 / 256 / 320 exits: %.2f / %.2f / %.2f / %.2f %%\n", 100 * ex[0] / frames, 100 * ex[1] / frames, 100 * ex[2] / frames, 100 * ex[3] / frames);
+            {
+                double z[3] = {};
+                for (int u = 0; u < n_utt; ++u) for (int i = 0; i < 3; ++i) z[i] += (double)h[(size_t)u * 48 + 36 + i];
+                fprintf(stderr, "  the gather, work-item 0: %.2f passes over sixteen channels a frame, %.0f cycles a pass until its loads are there, %.0f cycles a pass after\n",
+                        z[2] / frames, z[0] / std::max(z[2], 1.0), z[1] / std::max(z[2], 1.0));
+            }
+            {
+                double z[4] = {};
+                for (int u = 0; u < n_utt; ++u) for (int i = 0; i < 4; ++i) z[i] += (double)h[(size_t)u * 48 + 40 + i];
+                fprintf(stderr, "  the frame's top, cycles since the last frame's end: loop head %.0f, counters reset %.0f, slice bounds there %.0f, before the barrier %.0f\n",
+                        z[0] / frames, z[1] / frames, z[2] / frames, z[3] / frames);
+            }
+            fprintf(stderr, "  the gather, cycles since the frame's start (wavefront 0): top barrier passed %.0f, first list entry there %.0f, first stamp there %.0f, loop left %.0f\n",
+                    sub[0] / frames, sub[1] / frames, sub[2] / frames, sub[3] / frames);
         }
         {
             double ov = 0, ne = 0, o256 = 0;
-            for (int u = 0; u < n_utt; ++u) { ov += (double)h[(size_t)u * 32 + 13]; ne += (double)h[(size_t)u * 32 + 14]; o256 += (double)h[(size_t)u * 32 + 15]; }
+            for (int u = 0; u < n_utt; ++u) { ov += (double)h[(size_t)u * 48 + 13]; ne += (double)h[(size_t)u * 48 + 14]; o256 += (double)h[(size_t)u * 48 + 15]; }
             fprintf(stderr, "  exits queued per frame %.1f; frames whose exits exceed the LDS queue: %.1f %%, cycles from their decisions to their end: %.0f each\n", ne / (frames > 0 ? frames : 1), 100.0 * ov / (frames > 0 ? frames : 1), o256 / (ov > 0 ? ov : 1));
         }
         for (int i = 0; i < 13; ++i)
