@@ -20,6 +20,7 @@
 #include "psgpu_hmm_dev.h"
 #include "psgpu_lm_dev.h"
 #include "psgpu_sen_dev.h"
+#include "psgpu_wave_dev.h"
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -319,9 +320,7 @@ __device__ __forceinline__ int32_t ff_block_scan(int32_t *a, int n, int32_t *tmp
     const int b = min(n, tid * per), e = min(n, b + per);
     int32_t sum = 0;
     for (int i = b; i < e; ++i) sum += a[i];
-    int32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+    const int32_t incl = ft_wave_incl<FtAdd>(sum);
     if (lane == 63) tmp[tid >> 6] = incl;
     __syncthreads();
     int32_t base = 0, total = 0;
@@ -372,12 +371,12 @@ __device__ __forceinline__ void ff_sync_lds()
 __device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    int32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl = max(incl, o); }
+    // (data-parallel-primitive moves, not shuffles -- six vector operations instead of six trips through the LDS crossbar: psgpu_wave_dev.h;
+    //  the values are >= -1, FtMax's identity stands for "none")
+    const int32_t incl = ft_wave_incl<FtMax>(v);
     if (lane == 63) tmp[tid >> 6] = incl;
-    int32_t excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = -1;
+    int32_t excl = ft_wave_excl<FtMax>(v);
+    if (lane == 0 || excl < -1) excl = -1;
     ff_sync_lds();
     for (int w = 0; w < (tid >> 6); ++w) excl = max(excl, tmp[w]);
     ff_sync_lds();
@@ -389,9 +388,7 @@ __device__ __forceinline__ int32_t ff_block_excl_max(int32_t v, int32_t *tmp)
 __device__ __forceinline__ int32_t ff_block_excl_sum(int32_t v, int32_t *tmp, int32_t &total)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    int32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const int32_t incl = ft_wave_incl<FtAdd>(v);
     if (lane == 63) tmp[tid >> 6] = incl;
     ff_sync_lds();
     int32_t base = 0; total = 0;
@@ -558,7 +555,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         if (sf0 < 0) sf0 = 0;
         if (ef0 > u.n_frame) ef0 = u.n_frame;
         sl_b0 = 0; sl_b1 = 0;
-        if (ef0 > sf0) { sl_b0 = u.fr_off[sf0]; sl_b1 = u.fr_off[ef0]; }
+        // (through the vector path -- the index is the same in every work-item, which the compiler cannot see: a scalar load would make
+        //  the next LDS wait, which shares its counter, a trip to memory)
+        if (ef0 > sf0) { sl_b0 = u.fr_off[sf0 + (tid >> 12)]; sl_b1 = u.fr_off[ef0 + (tid >> 12)]; }
     };
     slice_bounds(0);
     for (int f = 0; f < T; ++f) {
@@ -594,10 +593,6 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             if (i == 0) FF_PROFS(33);
 #endif
             for (int k = tid & 15; k < len; k += 16) {
-#ifdef PSGPU_FT_PROFILE
-                long long tk_a = 0, tk_b = 0;
-                if (tid == 0) tk_a = clock64();
-#endif
                 const int c = c0 + k;
                 // (the stamp and what an active channel needs next asked for together: one trip to memory instead of two)
                 const int32_t stamp = u.frame[c];
@@ -614,12 +609,6 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     { int m_ = mpx, s0_ = RAW ? sid[0] : 0; asm volatile("" :: "v"(stamp), "v"(s0_), "v"(m_)); }
 #endif
                     FF_PROFS(34);
-                }
-                if (tid == 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    { int m_ = mpx, s0_ = RAW ? sid[0] : 0, s2_ = RAW ? sid[NE - 1] : 0; asm volatile("" :: "v"(stamp), "v"(s0_), "v"(m_), "v"(s2_)); }
-#endif
-                    tk_b = clock64(); s_prof[36] += tk_b - tk_a; s_prof[38] += 1;
                 }
 #endif
                 if (stamp == f) {                             // bit 30: the root of </s>, which does not count towards the best score
@@ -646,9 +635,6 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         }
                     }
                 }
-#ifdef PSGPU_FT_PROFILE
-                if (tid == 0) s_prof[37] += clock64() - tk_b;
-#endif
             }
         }
         FF_PROFS(35);
@@ -666,6 +652,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const size_t o = (size_t)tid * rw.total + t0 + f;
             pre_q = *reinterpret_cast<const FfQuad *>(rw.tsc + o * 4); pre_c4 = rw.tcw[o]; pre_open = rw.open[o];
         }
+
         const int n_eval = s_sc[7];
         struct FfEnt { int32_t c, inf, w, aux; };
         auto ent = [&](int e) -> FfEnt {
@@ -919,9 +906,8 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 return a;
             };
             auto wg_min = [&](int32_t v) {                       // the list's minimum to s_nb
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-                if ((tid & 63) == 0) atomicMin(&s_nb, v);
+                v = ft_wave_incl<FtMin>(v);
+                if ((tid & 63) == 63) atomicMin(&s_nb, v);
             };
             if (n_l <= 4 * kFfThreads) {                         // (every frame in practice: a senone's value waits in a register)
                 const SenModel smod = { pm.mixw_sen, pm.sen2cb, pm.n_sen, pm.n_density };
@@ -1793,12 +1779,6 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
             }
             fprintf(stderr, "  per frame: %.1f active words, %.1f channels in their chains, %.1f of them active\n", g3[0] / frames, g3[1] / frames, g3[2] / frames);
             fprintf(stderr, "  frames with more than 192 / 224 / 256 / 320 exits: %.2f / %.2f / %.2f / %.2f %%\n", 100 * ex[0] / frames, 100 * ex[1] / frames, 100 * ex[2] / frames, 100 * ex[3] / frames);
-            {
-                double z[3] = {};
-                for (int u = 0; u < n_utt; ++u) for (int i = 0; i < 3; ++i) z[i] += (double)h[(size_t)u * 48 + 36 + i];
-                fprintf(stderr, "  the gather, work-item 0: %.2f passes over sixteen channels a frame, %.0f cycles a pass until its loads are there, %.0f cycles a pass after\n",
-                        z[2] / frames, z[0] / std::max(z[2], 1.0), z[1] / std::max(z[2], 1.0));
-            }
             {
                 double z[4] = {};
                 for (int u = 0; u < n_utt; ++u) for (int i = 0; i < 4; ++i) z[i] += (double)h[(size_t)u * 48 + 40 + i];
