@@ -61,6 +61,7 @@ constexpr int kFfMaxTopn = 8;
 constexpr int kFfMaxFan = 128;         // fan-outs into right-context channels queued per frame (more: done in place)
 constexpr int kFfChanMask = (1 << 28) - 1, kFfClearBit = 1 << 29, kFfEnteredBit = 1 << 28;   // FfUtt::elist entries
 constexpr int kFfMaxEl = 384;          // entries of the frame's active-channel list held in LDS (the rest in the slab)
+constexpr int kFfAwlLds = 256;         // active words whose list entries the next frame's gather finds in LDS
 constexpr int kFfRegRows = 2;           // vocabularies up to kFfRegRows x 256 words (+ fillers) keep their static records in registers
 constexpr int kFfMaxTp = 2048;         // bytes of transition matrices held in LDS (more: read from device memory)
 #ifndef PSGPU_FF_MAX_EXIT
@@ -545,6 +546,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             axq[j] = (ch >= 0 ? ln : 1) | (rcs << 10) | ((ch < 0 ? 1 : 0) << 20);
         }
     }
+    // the active word list as the frame before wrote it, for the gather at the top of the frame: in the place of the new entries' rows, dead
+    // between the word transitions and the next frame's exits
+    static_assert(kFfNewRows * 10 >= 3 * kFfAwlLds, "the active word list's LDS copy fits the new entries' rows");
+    int32_t *const s_awl = &s_nbp[0][0];
+    bool awl_lds = false;
     FfQuad pre_q = { 0, 0, 0, 0 };
     uint32_t pre_c4 = 0;
     uint8_t pre_open = 0;
@@ -587,7 +593,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         ff_sync_lds();
         FF_PROFS(32);
         for (int i = tid >> 4; i < na; i += kFfThreads / 16) {          // sixteen work-items a word: its chain's stamps read side by side
-            const int w = awl_c[i * 3], c0 = awl_c[i * 3 + 1], wx = awl_c[i * 3 + 2], len = wx & 1023;
+            int w, c0, wx;
+            if (awl_lds) { w = s_awl[i * 3]; c0 = s_awl[i * 3 + 1]; wx = s_awl[i * 3 + 2]; }
+            else { w = awl_c[i * 3]; c0 = awl_c[i * 3 + 1]; wx = awl_c[i * 3 + 2]; }
+            const int len = wx & 1023;
 #ifdef PSGPU_FT_PROFILE
             if ((tid & 15) == 0) atomicAdd(&s_pscan, len);
             if (i == 0) FF_PROFS(33);
@@ -1092,12 +1101,22 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             static_assert(kFfMaxExit <= kFfThreads, "one queued exit per work-item");
             const int32_t bpidx = s_sc[1], bss_head = s_sc[2];
             const int n_ex = s_nex;
-            if (tid < n_ex) {
-                const int32_t key = s_ex[tid][0];
-                int r = 0;
-                for (int j = 0; j < n_ex; ++j) r += s_ex[j][0] < key;
-                s_ord[r] = (uint16_t)tid;
+            {   // ranks by counting, over the keys laid side by side first (the sorted queue's place, not yet in use): four keys a read, eight in flight
+                int32_t *const keys = reinterpret_cast<int32_t *>(s_srt);
+                if (tid < n_ex) keys[tid] = s_ex[tid][0];
+                if (tid < 8) keys[n_ex + tid] = 0x7fffffff;
+                ff_sync_lds();
+                if (tid < n_ex) {
+                    const int32_t key = keys[tid];
+                    int r = 0;
+                    for (int j = 0; j < n_ex; j += 8) {
+                        const FfQuad a = *reinterpret_cast<const FfQuad *>(keys + j), b = *reinterpret_cast<const FfQuad *>(keys + j + 4);
+                        r += (a.x < key) + (a.y < key) + (a.z < key) + (a.w < key) + (b.x < key) + (b.y < key) + (b.z < key) + (b.w < key);
+                    }
+                    s_ord[r] = (uint16_t)tid;
+                }
             }
+            FF_PROFS(36);
             ff_sync_lds();
             // sorted position r = tid: a word's first exit (`head`) counts one entry and the word's stack block; one prefix sum gives
             // every exit the number of entries and stack slots before its word
@@ -1109,17 +1128,26 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             int32_t total;
             const int32_t before = ff_block_excl_sum(head ? ((x[4] << 10) | 1) : 0, s_scan, total);
             const int32_t n_exit = total & 1023, n_bss = total >> 10;
+            FF_PROFS(37);
             const bool full = bpidx + n_exit >= u.bp_cap || bss_head + n_bss + p.n_ci >= u.bss_cap;
             if (tid == 0) { if (full) s_sc[3] = 1; else { s_sc[1] = bpidx + n_exit; s_sc[2] = bss_head + n_bss; } }   // (full: nothing is written)
             if (mine && !full) {
                 const bool single = (x[1] >> 30) != 0;
                 const int32_t bsh = bss_head + (before >> 10) - (head ? 0 : x[4]);
-                if (!single && x[4]) u.bss[bsh + x[5]] = x[2];               // its score in its slot of the word's stack block
+                if (!single && x[4]) {
+                    u.bss[bsh + x[5]] = x[2];                               // its score in its slot of the word's stack block
+                    // the contexts nothing exited into (ngram_search.c:468-475 fills the block before the first score goes in): a word's exits
+                    // are queued in context order, each takes the slots between its predecessor's and its own, the last one the rest -- not
+                    // one work-item a word over all of them
+                    for (int q = head ? 0 : s_srt[tid - 1].w + 1; q < x[5]; ++q) u.bss[bsh + q] = kW;
+                    if (s_srt[tid + 1].x != i) for (int q = x[5] + 1; q < x[4]; ++q) u.bss[bsh + q] = kW;
+                }
                 if (head) {
                     const int w = x[1] & 0x3fffffff;
                     const int32_t bpi = bpidx + (before & 1023);
                     ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], single, x[6], x[7], x[8] & 0x3fffffff, (x[8] >> 30) != 0, x[9], x[10]);
                     int32_t cs = x[2], cp = x[3];
+                    int32_t cp_real = x[9], cp_preal = x[10];          // the real words of the entry's history (asked for when the exit was queued)
                     bool dirty = false, requirk = false;
                     unsigned long long have = 1ull << x[5];
                     for (int r2 = tid + 1; r2 < n_ex; r2 += 4) {                 // the update branch of save_bp (ngram_search.c:405-437),
@@ -1133,11 +1161,12 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                             have |= 1ull << y.w;
                             if (cs < y.y) {
                                 if (cp != y.z) {
-                                    const int32_t b0 = cp == -1 ? -1 : FBP(u, F_PREAL, cp), b1 = cp == -1 ? -1 : FBP(u, F_REAL, cp);
-                                    const int32_t n0 = y.z == -1 ? -1 : FBP(u, F_PREAL, y.z), n1 = y.z == -1 ? -1 : FBP(u, F_REAL, y.z);
-                                    if (b0 != n0 || b1 != n1) { ff_set_real_wid(p, u, bpi); requirk = true; }      // with the old bp still in place, as the reference
+                                    // (the two histories' real words: every exit's came with it into the queue -- no trip to the table)
+                                    const int32_t *xe = s_ex[s_ord[r2 + t]];
+                                    const int32_t n1 = xe[9], n0 = xe[10];
+                                    if (cp_preal != n0 || cp_real != n1) { ff_set_real_wid(p, u, bpi); requirk = true; }      // with the old bp still in place, as the reference
                                     FBP(u, F_BP, bpi) = y.z;
-                                    cp = y.z;
+                                    cp = y.z; cp_real = n1; cp_preal = n0;
                                 }
                                 cs = y.y; dirty = true;
                             }
@@ -1155,11 +1184,11 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                         else { nb[5] = base; nb[6] = x[9]; }
                         nb[7] = (int32_t)(uint32_t)have; nb[8] = (int32_t)(uint32_t)(have >> 32);
                     }
-                    if (!single)
-                        for (int q = 0; q < x[4]; ++q) if (!((have >> q) & 1)) u.bss[bsh + q] = kW;      // the contexts nothing exited into
                 }
             }
+            FF_PROFS(38);
             ff_sync_lds();
+            FF_PROFS(39);
         }
         else {
             // more exits than the queue holds: through flags in the slab, one work-item per exiting word walking its chain
@@ -1364,9 +1393,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 const bool on = i < n_all && u.word_active[wq[j]] == nf && (i < u.nwd ? wq[j] < p.startwid : true);
                 int32_t row_total;
                 const int pos = n_next + ff_block_excl_sum(on ? 1 : 0, (j & 1) ? s_scan2 : s_scan, row_total);
-                if (on) { int32_t *a = awl_n + 3 * pos; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j]; }
+                if (on) {
+                    int32_t *a = awl_n + 3 * pos; a[0] = wq[j]; a[1] = c0q[j]; a[2] = axq[j];
+                    if (pos < kFfAwlLds) { s_awl[pos * 3] = wq[j]; s_awl[pos * 3 + 1] = c0q[j]; s_awl[pos * 3 + 2] = axq[j]; }
+                }
                 n_next += row_total;
             }
+            awl_lds = n_next <= kFfAwlLds;
         }
         else {
             // larger vocabularies: eight consecutive candidates a work-item per round (their words, then their stamps, asked for
@@ -1390,6 +1423,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                 for (int j = 0; j < 8; ++j) if (fl & (1 << j)) ff_awl_put(p, u, awl_n, pos++, wv[j]);
                 n_next += round_total;
             }
+            awl_lds = false;
         }
         if (nxt) n_awl1 = n_next; else n_awl0 = n_next;
         if (tid == 0) {
@@ -1783,6 +1817,12 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
                 double z[4] = {};
                 for (int u = 0; u < n_utt; ++u) for (int i = 0; i < 4; ++i) z[i] += (double)h[(size_t)u * 48 + 40 + i];
                 fprintf(stderr, "  the frame's top, cycles since the last frame's end: loop head %.0f, counters reset %.0f, slice bounds there %.0f, before the barrier %.0f\n",
+                        z[0] / frames, z[1] / frames, z[2] / frames, z[3] / frames);
+            }
+            {
+                double z[4] = {};
+                for (int u = 0; u < n_utt; ++u) for (int i = 0; i < 4; ++i) z[i] += (double)h[(size_t)u * 48 + 36 + i];
+                fprintf(stderr, "  the exits' phase (LDS queue), cycles since the pruning's end, per frame: ranks %.0f, places %.0f, entries written (work-item 0) %.0f, barrier passed %.0f\n",
                         z[0] / frames, z[1] / frames, z[2] / frames, z[3] / frames);
             }
             fprintf(stderr, "  the gather, cycles since the frame's start (wavefront 0): top barrier passed %.0f, first list entry there %.0f, first stamp there %.0f, loop left %.0f\n",
