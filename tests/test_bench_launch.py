@@ -88,9 +88,10 @@ def test_gpus_more_than_the_node_has_fails_loudly():
 @pytest.mark.gpu
 def test_the_distributed_path_with_one_rank_costs_nothing():
     """the N > 1 code path (RCCL scatter before the timed region, copy + gather of the hypothesis records inside it) with one
-    rank against the plain run of the same workload: within 3 %"""
+    rank against the plain run of the same workload: within 3 % (the best of up to five pairs: six-step runs on a shared
+    box scatter by a few per cent)"""
     best = None
-    for _ in range(3):
+    for _ in range(5):
         plain = _line({}, "--gpus", "1")
         forced = _line({"PSGPU_BENCH_FORCE_DIST": "1"}, "--gpus", "1")
         assert plain["n_gpus"] == forced["n_gpus"] == 1
