@@ -1663,7 +1663,7 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
     const int n_tail = d.n_w - d.startwid;
     {   // the utterances' vocabularies are independent of each other: host threads (30 s of audio on the small task: 18 k first-pass
         // entries and ~170 us an utterance; 512 of them one after another were a quarter of the call)
-        const int n_thr = (int)std::max(1u, std::min({ std::thread::hardware_concurrency(), 16u, (unsigned)((n_utt + 15) / 16) }));
+        const int n_thr = (int)std::max(1u, std::min({ std::thread::hardware_concurrency(), 32u, (unsigned)((n_utt + 15) / 16) }));
         std::atomic<int> failed{0};                      // (an exception must not leave a worker: std::terminate would take the host process)
         auto work = [&](int t) {
             try {
