@@ -44,12 +44,15 @@ extern "C" { int psgpu_sim_ff_pair_rows = 96; }     // new entries of a frame th
 #define FF_PAIR_ROWS psgpu_sim_ff_pair_rows
 extern "C" { int psgpu_sim_ff_slice_chunk = 256; }   // ... and words of the frame's window a chunk of those pairs takes (<= kFfThreads)
 #define FF_SL_CHUNK psgpu_sim_ff_slice_chunk
+extern "C" { int psgpu_sim_ff_force_walk = 0; }      // every exiting word's entry by the walk over its exits (the path of words whose exits' histories differ)
+#define FF_FORCE_WALK psgpu_sim_ff_force_walk
 #else
 #define FF_EXIT_CAP kFfMaxExit
 #define FF_EL_CAP kFfMaxEl
 #define FF_AWL_REGS (kFfRegRows * kFfThreads)
 #define FF_PAIR_ROWS kFfNewRows
 #define FF_SL_CHUNK kFfThreads
+#define FF_FORCE_WALK 0
 #endif
 
 constexpr int kFfThreads = 256;
@@ -424,10 +427,16 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     __shared__ __attribute__((aligned(16))) uint16_t s_slist[RAW ? kFfMaxSen : 1];   // the frame's listed senones in the order they were first marked
     // the word transitions' rows (a chunk of the window's words: first phone or -1, base word, best pair's key): the listed senones' place --
     // that list is dead once the frame's senones are scored -- or, when the scores are given, an array of their own
-    __shared__ __attribute__((aligned(16))) int32_t s_wt_own[RAW ? 4 : 4 * kFfThreads];
-    static_assert(!RAW || kFfMaxSen * 2 >= 16 * kFfThreads, "the rows fit the listed senones' array");
+    __shared__ __attribute__((aligned(16))) int32_t s_wt_own[RAW ? 4 : 5 * kFfThreads];
+    static_assert(!RAW || kFfMaxSen * 2 >= 20 * kFfThreads, "the rows fit the listed senones' array");
     int32_t *const s_wfirst = RAW ? reinterpret_cast<int32_t *>(s_slist) : s_wt_own, *const s_wbase = s_wfirst + kFfThreads;
     unsigned long long *const s_wkey = reinterpret_cast<unsigned long long *>(s_wfirst + 2 * kFfThreads);
+    static_assert(kFfMaxExit <= kFfThreads, "a group of exits per work-item at most");
+    // the exits' phase uses the same place: per exiting word (a group of the sorted queue) its best exit's key, the contexts exited into, and
+    // whether its exits' histories name different real words
+    unsigned long long *const s_gkey = reinterpret_cast<unsigned long long *>(s_wfirst);
+    uint32_t *const s_ghave = reinterpret_cast<uint32_t *>(s_wfirst + 2 * kFfThreads);
+    int32_t *const s_gdiff = s_wfirst + 4 * kFfThreads;
     __shared__ int32_t s_nl;
     __shared__ int32_t s_norm[16], s_nb;
     __shared__ int32_t s_scan[kFfThreads / 64], s_scan2[kFfThreads / 64];
@@ -1103,7 +1112,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             const int n_ex = s_nex;
             {   // ranks by counting, over the keys laid side by side first (the sorted queue's place, not yet in use): four keys a read, eight in flight
                 int32_t *const keys = reinterpret_cast<int32_t *>(s_srt);
-                if (tid < n_ex) keys[tid] = s_ex[tid][0];
+                if (tid < n_ex) { keys[tid] = s_ex[tid][0]; s_gkey[tid] = 0ull; s_ghave[2 * tid] = 0u; s_ghave[2 * tid + 1] = 0u; s_gdiff[tid] = 0; }
                 if (tid < 8) keys[n_ex + tid] = 0x7fffffff;
                 ff_sync_lds();
                 if (tid < n_ex) {
@@ -1142,15 +1151,39 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
                     for (int q = head ? 0 : s_srt[tid - 1].w + 1; q < x[5]; ++q) u.bss[bsh + q] = kW;
                     if (s_srt[tid + 1].x != i) for (int q = x[5] + 1; q < x[4]; ++q) u.bss[bsh + q] = kW;
                 }
+                // the word's entry takes the best of its exits, the first among equals (the update branch of save_bp, ngram_search.c:405-437:
+                // a later exit takes the entry over with a strictly better score): every exit offers its key to the word's maximum and its
+                // context to the word's set -- a walk by the word's first exit over all of them is only needed where it has side effects,
+                // i.e. where two of the exits' histories name different real words (set_real_wid with the old back-pointer in place)
+                const int g = (before & 1023) - (head ? 0 : 1);
+                atomicMax(&s_gkey[g], ((unsigned long long)((uint32_t)x[2] ^ 0x80000000u) << 32) | (uint32_t)(0xffffffffu - (uint32_t)tid));
+                atomicOr(&s_ghave[2 * g + (x[5] >> 5)], 1u << (x[5] & 31));
+                if (!head) { const int32_t *pe = s_ex[s_ord[tid - 1]]; if (pe[9] != x[9] || pe[10] != x[10]) s_gdiff[g] = 1; }
                 if (head) {
                     const int w = x[1] & 0x3fffffff;
-                    const int32_t bpi = bpidx + (before & 1023);
-                    ff_new_bp(u, bpi, bsh, f, w, x[2], x[3], single, x[6], x[7], x[8] & 0x3fffffff, (x[8] >> 30) != 0, x[9], x[10]);
+                    ff_new_bp(u, bpidx + g, bsh, f, w, x[2], x[3], single, x[6], x[7], x[8] & 0x3fffffff, (x[8] >> 30) != 0, x[9], x[10]);
+                }
+            }
+            ff_sync_lds();
+            if (mine && !full) {
+                if (head) {
+                    const int w = x[1] & 0x3fffffff, g = before & 1023;
+                    const int32_t bpi = bpidx + g;
                     int32_t cs = x[2], cp = x[3];
                     int32_t cp_real = x[9], cp_preal = x[10];          // the real words of the entry's history (asked for when the exit was queued)
                     bool dirty = false, requirk = false;
                     unsigned long long have = 1ull << x[5];
-                    for (int r2 = tid + 1; r2 < n_ex; r2 += 4) {                 // the update branch of save_bp (ngram_search.c:405-437),
+                    if (!s_gdiff[g] && !FF_FORCE_WALK) {
+                        const unsigned long long key = s_gkey[g];
+                        const int wpos = (int)(0xffffffffu - (uint32_t)key);
+                        have = (unsigned long long)s_ghave[2 * g] | ((unsigned long long)s_ghave[2 * g + 1] << 32);
+                        if (wpos != tid) {
+                            cs = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); cp = s_srt[wpos].z; dirty = true;
+                            if (cp != x[3]) FBP(u, F_BP, bpi) = cp;
+                        }
+                    }
+                    else
+                    for (int r2 = tid + 1; r2 < n_ex; r2 += 4) {                 // the walk, in the queue's order
                         const FfQuad y4[4] = { s_srt[r2], s_srt[r2 + 1], s_srt[r2 + 2], s_srt[r2 + 3] };    // four exits read at a time
                         bool more = true;
 #pragma unroll

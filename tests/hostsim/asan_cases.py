@@ -74,7 +74,7 @@ s = simlib.SimFwdflatSearch(st, fst, g["par"], g["flat_par"], g["flat_lwf"])
 check_flat(s.search(g["flat_feat"], [g["flat_feat"].shape[0]], [g["bp1"]], [g["flat_w1_ssid"]], ptm_tables=t, topn_seed=g["flat_ptm_seed"],
                     lists=lists, **caps(g))[0], g, "goforward, lists")
 print("flat search taking the batch scorer's lists clean")
-for name, val in (("psgpu_sim_ff_exit_cap", 1), ("psgpu_sim_ff_el_cap", 3), ("psgpu_sim_ff_awl_regs", 0), ("psgpu_sim_ff_pair_rows", 1), ("psgpu_sim_ff_slice_chunk", 2)):
+for name, val in (("psgpu_sim_ff_exit_cap", 1), ("psgpu_sim_ff_el_cap", 3), ("psgpu_sim_ff_awl_regs", 0), ("psgpu_sim_ff_pair_rows", 1), ("psgpu_sim_ff_slice_chunk", 2), ("psgpu_sim_ff_force_walk", 1)):
     knob = ctypes.c_int.in_dll(simlib.lib(), name)
     old = knob.value
     knob.value = val

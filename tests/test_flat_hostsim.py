@@ -209,7 +209,7 @@ def test_flat_kernel_source_taking_the_batch_scorers_lists(case, extra_open):
 
 
 @pytest.mark.parametrize("knob", ["psgpu_sim_ff_exit_cap:1", "psgpu_sim_ff_el_cap:3", "psgpu_sim_ff_awl_regs:0", "psgpu_sim_ff_pair_rows:0",
-                                  "psgpu_sim_ff_pair_rows:2", "psgpu_sim_ff_slice_chunk:3"])
+                                  "psgpu_sim_ff_pair_rows:2", "psgpu_sim_ff_slice_chunk:3", "psgpu_sim_ff_force_walk:1"])
 @pytest.mark.parametrize("case", ["goforward", "something_efwid2_sfwin8"])
 def test_flat_kernel_source_more_than_the_lds_queues_hold(case, knob):
     """a frame's word exits (kFfMaxExit) and its active-channel list (kFfMaxEl) are held in LDS; what does not fit goes through
@@ -217,7 +217,7 @@ def test_flat_kernel_source_more_than_the_lds_queues_hold(case, knob):
     reads both capacities from variables: with room for ONE exit / THREE list entries nearly every frame takes the other
     paths (third knob: the next active word list by a scan through the slab, as vocabularies beyond 1024 words get it; fourth: the word
     transitions of a frame with more new entries than the LDS rows hold -- none / two -- go through the table, exits in order; fifth:
-    the window's words three a chunk), scoring its own senones from the batch scorer's lists or given the scores, and the tables must be the same."""
+    the window's words three a chunk; sixth: every exiting word's entry by the walk over its exits instead of the exits' maximum), scoring its own senones from the batch scorer's lists or given the scores, and the tables must be the same."""
     import ctypes
     import pso
     g, st, fst = load_flat(case)
