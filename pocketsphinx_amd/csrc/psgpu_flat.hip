@@ -1409,11 +1409,14 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             }
         }
         __syncthreads();
-        // initial channels of words that stayed inactive (:771-781)
-        for (int i = tid; i < na; i += kFfThreads) {
-            const int c0 = awl_c[i * 3 + 1];
-            if (u.frame[c0] == f) ff_clear_scores(p, u, c0);
-        }
+        // initial channels of words that stayed inactive (:771-781): a root still stamped with this frame was evaluated and neither kept
+        // nor entered.  With the candidates' records in registers the pass below asks for the stamp beside the word's (a root stamped f
+        // belongs to a word of this frame's list, and every such word is a candidate); otherwise over the list
+        if (n_all > FF_AWL_REGS)
+            for (int i = tid; i < na; i += kFfThreads) {
+                const int c0 = awl_c[i * 3 + 1];
+                if (u.frame[c0] == f) ff_clear_scores(p, u, c0);
+            }
         FF_PROF(6);
         // ---- next active word list (:853-869): the vocabulary in its order (words below <s>), then <s> and above by id
         int32_t n_next;
@@ -1423,7 +1426,9 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
             for (int j = 0; j < kFfRegRows; ++j) {                    // (a candidate's word, first channel and lengths never change: registers)
                 if (j * kFfThreads >= n_all) break;
                 const int i = tid + j * kFfThreads;
-                const bool on = i < n_all && u.word_active[wq[j]] == nf && (i < u.nwd ? wq[j] < p.startwid : true);
+                const int32_t wa = u.word_active[wq[j]], rfr = i < n_all && c0q[j] >= 0 ? u.frame[c0q[j]] : -1;
+                if (rfr == f) ff_clear_scores(p, u, c0q[j]);
+                const bool on = i < n_all && wa == nf && (i < u.nwd ? wq[j] < p.startwid : true);
                 int32_t row_total;
                 const int pos = n_next + ff_block_excl_sum(on ? 1 : 0, (j & 1) ? s_scan2 : s_scan, row_total);
                 if (on) {
