@@ -10,6 +10,8 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <time.h>
 
 #include <pocketsphinx.h>
 #include "pocketsphinx_internal.h"
@@ -37,6 +39,9 @@ struct psgpu_batch_s {
     ps_decoder_t **ps;
     psgpu_fe_t *fe;                /* batch front end (tables of worker 0's fe_t) */
     psgpu_device_decode_t *dd;     /* PSGPU_BATCH_DEVICE_FIRST_PASS: the device pipeline, bound to worker 0's decoder */
+    void *rd_stream;               /* ... ONE stream for the workers' table fetches (made at the first call: making a stream costs ~18 ms, and
+                                    *     every further stream alive in the process slows the pipeline's own launches and waits) */
+    psgpu_dd_stage_t *rd_stage;    /* ... and their staging buffers */
     int out_dim;
     /* one call's work */
     const int16 *const *pcm;
@@ -187,6 +192,35 @@ worker(void *arg)
     return NULL;
 }
 
+/* PSGPU_BATCH_DEVICE_FIRST_PASS: the batch's searches ran on the device in one launch set; what is left per utterance is the
+ * reference's own read-out -- the tables injected into a decoder, ps_get_hyp / ps_seg_iter on them, with -bestpath yes the lattice
+ * and its best path (ngram_search.c:782, ps_lattice.c:1216: ~15 ms of host work for 30 s of audio) -- independent of one another:
+ * every worker reads utterances out into ITS decoder (staging buffers and a stream of its own) */
+static void *
+readout_worker(void *arg)
+{
+    worker_arg_t *a = arg;
+    psgpu_batch_t *b = a->b;
+    psgpu_dd_stage_t *st = &b->rd_stage[a->w];
+    void *stream = b->rd_stream;
+    if (b->device >= 0) psgpu_set_device(b->device);
+    for (;;) {
+        int u = __atomic_fetch_add(&b->next, 1, __ATOMIC_RELAXED), nfr;
+        psgpu_batch_result_t *r;
+        if (u >= b->B) break;
+        r = &b->out[u];
+        memset(r, 0, sizeof *r);
+        if ((nfr = psgpu_device_decode_batch_select_into(b->dd, u, b->ps[a->w], st, stream)) < 0) {
+            r->hyp = dup_str("");
+            __atomic_store_n(&b->failed, 1, __ATOMIC_RELAXED);
+            continue;
+        }
+        r->n_frames = psgpu_device_decode_batch_n_frames(b->dd, u) + 1;           /* ps_get_n_frames: output_frame + 1 */
+        collect(b->ps[a->w], r);
+    }
+    return NULL;
+}
+
 psgpu_batch_t *
 psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
 {
@@ -204,6 +238,7 @@ psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
     b->n_workers = n_workers; b->flags = flags;
     b->device = (flags & PSGPU_BATCH_CPU_ONLY) ? -1 : psgpu_get_device();
     b->ps = calloc(n_workers, sizeof *b->ps);
+    b->rd_stage = calloc(n_workers, sizeof *b->rd_stage);
     for (w = 0; w < n_workers; ++w) {
         b->ps[w] = ps_init(config);                        /* ps_init retains the config */
         if (b->ps[w] == NULL) goto fail;
@@ -221,8 +256,8 @@ psgpu_batch_init(ps_config_t *config, int n_workers, unsigned flags)
         }
     }
     if ((flags & PSGPU_BATCH_DEVICE_FIRST_PASS) && !(flags & PSGPU_BATCH_CPU_ONLY)) {
-        /* the pipeline reads the search tables out of worker 0's decoder; results are injected into that decoder one
-         * utterance at a time (the read-out is a table walk: one host thread is plenty) */
+        /* the pipeline reads the search tables out of worker 0's decoder; a call's results are injected into the workers' decoders,
+         * every worker reading utterances out side by side (readout_worker) */
         if (ps_config_bool(ps_get_config(b->ps[0]), "fwdflat")
             && !(getenv("PSGPU_DEVICE_SECOND_PASS") && atoi(getenv("PSGPU_DEVICE_SECOND_PASS")))) {
             /* (refused here, at initialisation, not at the first decode: the reference's own second pass wants the utterance's
@@ -263,6 +298,9 @@ psgpu_batch_free(psgpu_batch_t *b)
         psgpu_phone_loop_detach(b->ps[w]);
         ps_free(b->ps[w]);
     }
+    for (w = 0; w < b->n_workers; ++w) if (b->rd_stage) psgpu_dd_stage_release(&b->rd_stage[w]);
+    if (b->rd_stream) psgpu_stream_destroy(b->rd_stream);
+    free(b->rd_stage);
     psgpu_fe_free(b->fe);
     free(b->ps);
     free(b);
@@ -283,7 +321,32 @@ psgpu_decode_batch(psgpu_batch_t *b, const int16 *const pcm[], const size_t n[],
     if (b->dd) {
         /* the whole first pass of the batch in one launch set; then the reference's own read-out per utterance */
         int u;
+        struct timespec ts0, ts1, ts2;
+        clock_gettime(CLOCK_MONOTONIC, &ts0);
         if (psgpu_device_decode_batch_run(b->dd, pcm, n, B) < 0) return -1;
+        clock_gettime(CLOCK_MONOTONIC, &ts1);
+        nw = b->n_workers < B ? b->n_workers : B;
+        if (nw > 1) {                                      /* the read-outs side by side, one decoder a worker */
+            if (b->rd_stream == NULL && psgpu_stream_create_dedicated(&b->rd_stream) != PSGPU_OK) b->rd_stream = NULL;   /* (none: the default stream) */
+            tid = calloc(nw, sizeof *tid);
+            started = calloc(nw, sizeof *started);
+            args = calloc(nw, sizeof *args);
+            for (w = 0; w < nw; ++w) {
+                args[w].b = b; args[w].w = w;
+                if (w == nw - 1) readout_worker(&args[w]);  /* the caller's thread is the last worker */
+                else if (pthread_create(&tid[w], NULL, readout_worker, &args[w]) == 0) started[w] = 1;
+                else readout_worker(&args[w]);
+            }
+            for (w = 0; w + 1 < nw; ++w) if (started[w]) pthread_join(tid[w], NULL);
+            free(started); free(tid); free(args);
+            if (getenv("PSGPU_BATCH_TIMING")) {            /* (where a call's time goes: stderr) */
+                clock_gettime(CLOCK_MONOTONIC, &ts2);
+                fprintf(stderr, "psgpu_decode_batch: %d utterances: device passes %.1f ms, read-outs on %d threads %.1f ms\n", B,
+                        1e3 * (ts1.tv_sec - ts0.tv_sec) + 1e-6 * (ts1.tv_nsec - ts0.tv_nsec), nw,
+                        1e3 * (ts2.tv_sec - ts1.tv_sec) + 1e-6 * (ts2.tv_nsec - ts1.tv_nsec));
+            }
+            return b->failed ? -1 : 0;
+        }
         for (u = 0; u < B; ++u) {
             psgpu_batch_result_t *r = &out[u];
             int nfr;

@@ -26,6 +26,7 @@
  * the phone-loop look-ahead (pl_window > 0); -compallsen yes is served (psgpu_decode_compallsen). */
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <pocketsphinx.h>
 #include "pocketsphinx_internal.h"
@@ -475,14 +476,28 @@ psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[]
                 "the batch then run on the device), or -fwdflat no\n");
         return -1;
     }
+    {
+    struct timespec t0, t1, t2, t3;
+    int rc;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     if (refresh(d) < 0) return -1;
     d->B = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     if (psgpu_decode_first_pass(d->dec, pcm, n, B, psgpu_hmm_ctx_stream(d->ctx)) != PSGPU_OK) {
         E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
         return -1;
     }
+    if (getenv("PSGPU_BATCH_TIMING")) psgpu_stream_sync(psgpu_hmm_ctx_stream(d->ctx));
+    clock_gettime(CLOCK_MONOTONIC, &t2);
     if (d->ff && B > 0 && second_pass_batch(d) < 0) return -1;       /* (-fwdflat yes: the tables injected below are the second pass's) */
-    return fetch_summary(d, B);
+    rc = fetch_summary(d, B);
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    if (getenv("PSGPU_BATCH_TIMING"))
+        fprintf(stderr, "psgpu_device_decode_batch_run: refresh %.1f ms, first pass %.1f ms, second pass + summary %.1f ms\n",
+                1e3 * (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_nsec - t0.tv_nsec), 1e3 * (t2.tv_sec - t1.tv_sec) + 1e-6 * (t2.tv_nsec - t1.tv_nsec),
+                1e3 * (t3.tv_sec - t2.tv_sec) + 1e-6 * (t3.tv_nsec - t2.tv_nsec));
+    return rc;
+    }
 }
 
 int
@@ -496,6 +511,43 @@ psgpu_device_decode_batch_select(psgpu_device_decode_t *d, int u)
     if (ps_end_utt(ps) < 0) return -1;
     if (d->h_res[(size_t)u * 8 + 2] == 0) return 0;
     return fetch_and_inject(d, u);
+}
+
+/* the same read-out into ANOTHER decoder of the same configuration -- a worker's, on the worker's thread: utterance u's tables of
+ * the latest psgpu_device_decode_batch_run fetched into the caller's staging buffers (grown as needed) over the caller's stream and
+ * injected into `ps`'s search; the attached decoder d->ps is not touched (the batch's read-outs run side by side: the lattice and
+ * best path of -bestpath yes are the host's share of an utterance, ngram_search.c:782, ps_lattice.c:1216) */
+int
+psgpu_device_decode_batch_select_into(psgpu_device_decode_t *d, int u, ps_decoder_t *ps, psgpu_dd_stage_t *st, void *stream)
+{
+    ngram_search_t *ngs;
+    const int32_t *res;
+    int nb, nh, nfr;
+    if (d == NULL || ps == NULL || st == NULL || u < 0 || u >= d->B) return -1;
+    if (ps_start_utt(ps) < 0) return -1;
+    if (ps_end_utt(ps) < 0) return -1;
+    res = d->h_res + (size_t)u * 8;
+    nb = res[0]; nh = res[1]; nfr = res[2];
+    if (nfr == 0) return 0;
+    if (res[3]) { E_ERROR("psgpu device decode: utterance %d: %s\n", u, status_text(res[3])); return -1; }
+    ngs = (ngram_search_t *)ps->search;
+    if ((size_t)nb * 10 > st->cap_bp) { ckd_free(st->bp); st->cap_bp = (size_t)nb * 15 + 640; st->bp = ckd_calloc(st->cap_bp, 4); }
+    if ((size_t)nh > st->cap_bss) { ckd_free(st->bss); st->cap_bss = (size_t)nh + nh / 2 + 64; st->bss = ckd_calloc(st->cap_bss, 4); }
+    if ((size_t)nfr + 1 > st->cap_idx) { ckd_free(st->idx); st->cap_idx = (size_t)nfr + nfr / 2 + 64; st->idx = ckd_calloc(st->cap_idx, 4); }
+    if (psgpu_decode_fetch_tables_range(d->dec, u, 0, nb, 0, nh, 0, nfr + 1, st->bp, st->bss, st->idx, stream) != PSGPU_OK) {
+        E_ERROR("psgpu device decode: %s\n", psgpu_last_error());
+        return -1;
+    }
+    inject(ngs, d->n_ci, st->bp, 0, nb, st->bss, 0, nh, st->idx, 0, nfr, res[4]);
+    return nfr;
+}
+
+void
+psgpu_dd_stage_release(psgpu_dd_stage_t *st)
+{
+    if (!st) return;
+    ckd_free(st->bp); ckd_free(st->bss); ckd_free(st->idx);
+    memset(st, 0, sizeof *st);
 }
 
 int

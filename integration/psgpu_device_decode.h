@@ -65,6 +65,12 @@ int psgpu_device_decode_utt(psgpu_device_decode_t *d, int16 const *pcm, size_t n
  * or on the order.  _run returns 0 or -1; _select the number of frames searched, or -1. */
 int psgpu_device_decode_batch_run(psgpu_device_decode_t *d, const int16 *const pcm[], const size_t n[], int B);
 int psgpu_device_decode_batch_select(psgpu_device_decode_t *d, int u);
+/* ... into another decoder of the same configuration, on the caller's thread (psgpu_decode_batch's workers: the read-outs of a batch --
+ * with -bestpath yes each one builds a lattice and searches it -- side by side).  st: the caller's staging buffers (zero-initialised,
+ * grown as needed, psgpu_dd_stage_release); stream: the caller's (NULL: the default stream) */
+typedef struct psgpu_dd_stage_s { int32_t *bp, *bss, *idx; size_t cap_bp, cap_bss, cap_idx; } psgpu_dd_stage_t;
+int psgpu_device_decode_batch_select_into(psgpu_device_decode_t *d, int u, ps_decoder_t *ps, psgpu_dd_stage_t *st, void *stream);
+void psgpu_dd_stage_release(psgpu_dd_stage_t *st);
 /* frames the front end produced for utterance u of the last run */
 int psgpu_device_decode_batch_n_frames(psgpu_device_decode_t *d, int u);
 

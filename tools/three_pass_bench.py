@@ -29,6 +29,8 @@ def run(files, workers, timing_only, extra_env=None):
     argv = [os.path.join(REF, "batch_api_check"), os.path.join(REF, "model", "en-us"), os.path.join(REF, "data", "turtle.lm.bin"),
             os.path.join(REF, "data", "turtle.dic"), str(workers), "16"] + files + ["--", "fwdflat", "yes", "bestpath", "yes"]
     p = subprocess.run(argv, capture_output=True, text=True, timeout=900, env=env)
+    if os.environ.get("PSGPU_BATCH_TIMING"):              # (the binding's own account of a call, integration/psgpu_decode_batch.c)
+        sys.stderr.write("".join(ln + "\n" for ln in p.stderr.splitlines() if ln.startswith("psgpu_")))
     lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
     if not lines:
         raise RuntimeError("batch_api_check rc %d: %s" % (p.returncode, (p.stderr or p.stdout)[-400:]))
@@ -38,7 +40,7 @@ def run(files, workers, timing_only, extra_env=None):
 def main():
     from pocketsphinx_amd import synth
     B = int(os.environ.get("TP3_B", "128")); seconds = float(os.environ.get("TP3_SECONDS", "30")); n_check = int(os.environ.get("TP3_CHECK", "32"))
-    workers = int(os.environ.get("TP3_WORKERS", str(max(1, min(64, (os.cpu_count() or 2) // 2)))))
+    workers = int(os.environ.get("TP3_WORKERS", str(max(1, min(32, (os.cpu_count() or 2) // 2)))))
     if not os.path.exists(os.path.join(REF, "batch_api_check")):
         print(json.dumps({"skipped": "oracle/_ref/batch_api_check not built"}))
         return
