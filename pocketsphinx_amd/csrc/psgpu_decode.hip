@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstring>
 #include <time.h>
+#include <thread>
 #include <vector>
 
 // ---- what the reference's acmod does with a live decoder's audio, as counters ------------------------------------------------------
@@ -199,7 +200,7 @@ struct psgpu_decode_s {
     int32_t n_utt = 0, total = 0, max_frames = 0, bp_cap = 0, bss_cap = 0;
     std::vector<int32_t> frame_off;
     std::vector<int64_t> soff;
-    std::vector<int16_t> stage;
+    int16_t *stage = nullptr; size_t cap_stage = 0;      // pinned: the batch's audio back to back on its way to the device (grow-only)
     // optional per-stage timing: events on the launch stream around front end | features | scorer | phone loop | search | backtrace
     bool timing = false;
     hipEvent_t ev[7] = {};
@@ -411,6 +412,7 @@ int psgpu_decode_create(psgpu_decode_t **out, const psgpu_decode_config_t *cfg)
 void psgpu_decode_free(psgpu_decode_t *d)
 {
     if (!d) return;
+    if (d->stage) hipHostFree(d->stage);
     DFREE(d->d_ssid); DFREE(d->d_ci); DFREE(d->d_tmatid); DFREE(d->d_pcm); DFREE(d->d_cep); DFREE(d->d_feat); DFREE(d->d_off);
     DFREE(d->d_tsc); DFREE(d->d_best); DFREE(d->d_pen); DFREE(d->d_tcw); DFREE(d->d_rows); DFREE(d->d_bp); DFREE(d->d_bss);
     DFREE(d->d_idx); DFREE(d->d_step); DFREE(d->d_res); DFREE(d->d_hyp); DFREE(d->d_hn); DFREE(d->d_w1);
@@ -882,9 +884,24 @@ int psgpu_decode_first_pass(psgpu_decode_t *d, const int16_t *const pcm[], const
         d->cap_samples = ns + ns / 8 + 64;
     }
     PSGPU_HIP(hipStreamSynchronize(st));                 // the staging buffer of the previous call may still be in flight
-    d->stage.resize(ns ? ns : 1);
-    for (int u = 0; u < n_utt; ++u) if (n[u]) memcpy(d->stage.data() + d->soff[u], pcm[u], 2 * n[u]);
-    if (ns) PSGPU_HIP(hipMemcpyAsync(d->d_pcm, d->stage.data(), 2 * ns, hipMemcpyHostToDevice, st));
+    if (ns > d->cap_stage) {                             // (pinned staging: through pageable memory the copy of 512 x 30 s -- 491 MB -- took longer than the search)
+        if (d->stage) hipHostFree(d->stage);
+        d->stage = nullptr; d->cap_stage = 0;
+        PSGPU_HIP(hipHostMalloc((void **)&d->stage, 2 * (ns + ns / 8 + 64), hipHostMallocDefault));
+        d->cap_stage = ns + ns / 8 + 64;
+    }
+    {   // the utterances side by side into the staging buffer: a few host threads (one memcpy stream moves ~10 GB/s)
+        const int n_thr = (int)std::max(1u, std::min({ std::thread::hardware_concurrency(), 8u, (unsigned)(ns >> 23) }));
+        auto work = [&](int t) { for (int u = t; u < n_utt; u += n_thr) if (n[u]) memcpy(d->stage + d->soff[u], pcm[u], 2 * n[u]); };
+        if (n_thr <= 1) work(0);
+        else {
+            std::vector<std::thread> thr;
+            for (int t = 1; t < n_thr; ++t) thr.emplace_back(work, t);
+            work(0);
+            for (auto &t : thr) t.join();
+        }
+    }
+    if (ns) PSGPU_HIP(hipMemcpyAsync(d->d_pcm, d->stage, 2 * ns, hipMemcpyHostToDevice, st));
     return psgpu_decode_first_pass_dev(d, d->d_pcm, d->soff.data(), n_utt, st);
 }
 
