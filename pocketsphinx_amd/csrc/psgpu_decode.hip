@@ -1587,11 +1587,14 @@ static int dec_repeat_with_larger_tables(psgpu_decode_s *d, std::vector<int32_t>
 // a core doing so (bench.py's host.cpu_ms_per_step_per_rank: 1.7 cores busy per GPU in round 4, the fetch's and torch's own
 // synchronize) -- with eight ranks a node's cores are not scarce, but a waiting thread has no business running.  A call of
 // some size polls an event between 0.1 ms sleeps instead; small calls and the live /
-// streams steps, where that lateness is a tenth of the step, keep the spin.  PSGPU_SPIN_WAIT=1: always spin.
+// streams steps, where that lateness is a tenth of the step, keep the spin.  PSGPU_SPIN_WAIT=1: always spin; PSGPU_POLL_WAIT_US: always poll.
 static int dec_wait(psgpu_decode_s *d, hipStream_t st)
 {
     static const int spin = [] { const char *e = getenv("PSGPU_SPIN_WAIT"); return e ? atoi(e) : 0; }();
-    if (spin || d->live || d->streams || d->total < 100000) { PSGPU_HIP(hipStreamSynchronize(st)); return PSGPU_OK; }
+    // PSGPU_POLL_WAIT_US=n: EVERY wait -- the live / streams steps' too -- polls between sleeps of n microseconds (a host that serves many
+    // decoders per core trades up to n us of a step's latency for the core: 512 streams at 100 ms of audio a step take 0.9 ms a step)
+    static const long poll_ns = [] { const char *e = getenv("PSGPU_POLL_WAIT_US"); return e ? 1000L * atol(e) : 0L; }();
+    if (spin || (poll_ns <= 0 && (d->live || d->streams || d->total < 100000))) { PSGPU_HIP(hipStreamSynchronize(st)); return PSGPU_OK; }
     // (hipEventSynchronize on an event created with hipEventBlockingSync was measured spinning all the same in this runtime -- the
     //  waiting thread at 100 % of a core, profiles/round5_host_cpu.txt: the event is polled between short sleeps instead, at most
     //  0.1 ms late)
@@ -1601,7 +1604,7 @@ static int dec_wait(psgpu_decode_s *d, hipStream_t st)
         const hipError_t q = hipEventQuery(d->ev_wait);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) PSGPU_HIP(q);
-        const struct timespec ts = { 0, 100000 };
+        const struct timespec ts = { 0, poll_ns > 0 ? (poll_ns < 999999999L ? poll_ns : 999999999L) : 100000L };
         nanosleep(&ts, nullptr);
     }
     return PSGPU_OK;
