@@ -526,3 +526,18 @@ def test_streams_next_utterance_of_a_decoder(tables):
     for u in feed(f2, fn, 29, 64):
         check(u, g2 if u == 0 else gn, "second utterances, stream %d" % u)
     p.close()
+
+
+@pytest.mark.gpu
+def test_streams_with_every_wait_polling():
+    """PSGPU_POLL_WAIT_US: the live / streams steps' waits poll an event between short sleeps instead of spinning (a deployment's choice,
+    read once per process: a child process) -- the streams' final hypotheses still equal the one-call decode of the same utterances"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSGPU_POLL_WAIT_US="30", LS_STREAMS="24", LS_SEC="3", LS_CHUNK="7", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "streams_bench.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert j["final_hypotheses_equal_the_one_call_decode"] is True and j["status_nonzero"] == 0 and j["frames_searched"] == j["frames"]
