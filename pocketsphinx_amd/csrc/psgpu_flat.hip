@@ -148,6 +148,7 @@ struct FfOff {
 #undef X
     int64_t awl0, awl1, nrow32, nrow;    // nrow32 / nrow: -1 when the scores are given
     int32_t nwd, n_chan, n_frame, awl_cap;
+    int32_t utt, pad_;                   // the utterance this workgroup searches (the launch order is the host's: see ff_search)
 };
 struct FfBufs {
     int32_t *slab; const int32_t *voc; int32_t *bp, *bss, *idx, *step, *res; const int32_t *w1_ssid;
@@ -472,8 +473,10 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     if (tid == 0) { for (int i = 0; i < 48; ++i) s_prof[i] = 0; s_last = clock64(); s_pscan = 0; }
 #endif
     FfUtt u;
+    int ub;                               // the utterance of this workgroup
     {
         const FfOff o = offs[blockIdx.x];
+        ub = o.utt;
 #define X(f) u.f = bf.slab + o.f;
         FF_SLAB_FIELDS(X)
 #undef X
@@ -484,13 +487,13 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
         u.nrow32 = RAW ? bf.slab + o.nrow32 : nullptr;
         u.nrow = RAW ? reinterpret_cast<int16_t *>(bf.slab + o.nrow) : nullptr;
         u.nwd = o.nwd; u.n_chan = o.n_chan; u.n_frame = o.n_frame; u.awl_cap = o.awl_cap;
-        u.bp = bf.bp + (size_t)blockIdx.x * 10 * bf.bp_cap; u.bss = bf.bss + (size_t)blockIdx.x * bf.bss_cap;
-        u.bp_table_idx = bf.idx + (size_t)blockIdx.x * (bf.max_frames + 2); u.step = bf.step + (size_t)blockIdx.x * bf.max_frames * 4;
-        u.result = bf.res + (size_t)blockIdx.x * 8;
-        u.w1_ssid_in = bf.w1_ssid ? bf.w1_ssid + (size_t)blockIdx.x * p.n1 * p.n_emit : nullptr;
+        u.bp = bf.bp + (size_t)ub * 10 * bf.bp_cap; u.bss = bf.bss + (size_t)ub * bf.bss_cap;
+        u.bp_table_idx = bf.idx + (size_t)ub * (bf.max_frames + 2); u.step = bf.step + (size_t)ub * bf.max_frames * 4;
+        u.result = bf.res + (size_t)ub * 8;
+        u.w1_ssid_in = bf.w1_ssid ? bf.w1_ssid + (size_t)ub * p.n1 * p.n_emit : nullptr;
         u.bp_cap = bf.bp_cap; u.bss_cap = bf.bss_cap;
     }
-    const int t0 = utt_off[blockIdx.x], T = utt_off[blockIdx.x + 1] - t0;
+    const int t0 = utt_off[ub], T = utt_off[ub + 1] - t0;
     int n_awl0 = 0, n_awl1 = 0;           // (two scalars, and the lists through selected pointers below: an array or a struct member indexed by
                                           //  a run-time value sends the whole FfUtt to scratch memory -- 344 bytes a lane, a trip to memory per use)
 
@@ -532,7 +535,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
     n_awl0 = 1;
     const int n_chain = RAW ? rw.pm.n_mgau * rw.pm.n_feat : 0, topn = RAW ? rw.pm.topn : 0;
     if (RAW) {
-        for (int i = tid; i < n_chain * topn; i += kFfThreads) { s_lcw[i] = rw.seed[(size_t)blockIdx.x * n_chain * topn + i]; s_lsc[i] = 0; }
+        for (int i = tid; i < n_chain * topn; i += kFfThreads) { s_lcw[i] = rw.seed[(size_t)ub * n_chain * topn + i]; s_lsc[i] = 0; }
         for (int i = tid; i < n_chain && i < kFfMaxEnt / 4; i += kFfThreads) s_lk[i] = -1;
 #ifdef PSGPU_FF_CHECK_LAZY
         for (int i = tid; i < n_chain * topn; i += kFfThreads) s_shadow[i] = s_lcw[i];
@@ -1475,7 +1478,7 @@ void fwdflat_kernel(FfDev p, const FfOff *__restrict__ offs, FfBufs bf, const in
 #endif
     }
 #ifdef PSGPU_FT_PROFILE
-    if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) bf.prof[(size_t)blockIdx.x * 48 + i] = s_prof[i];
+    if (tid == 0 && bf.prof) for (int i = 0; i < 48; ++i) bf.prof[(size_t)ub * 48 + i] = s_prof[i];
 #endif
     if (tid == 0) {
         u.bp_table_idx[s_sc[4]] = s_sc[1];                       // ngram_fwdflat_finish: mark one past the last frame
@@ -1741,7 +1744,28 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         || (rcw = ff_work(m, 5, sizeof(FfOff) * n_utt, (void **)&ho)))
         return rcw;
     hipError_t e = hipSuccess;
-    for (int i = 0; i < n_utt; ++i) {
+    // The launch order.  The launch ends with its slowest utterance, and an utterance runs a quarter faster once the workgroup it shares
+    // a compute unit with has finished (77 k -> 60 k cycles a frame): the utterances with the most first-pass entries -- the larger
+    // vocabularies, the busier frames -- go first, one a compute unit while there are compute units, and the second round pairs them with
+    // the smallest ones (workgroups are handed out in index order, a free compute unit before a second workgroup on a busy one).
+    // PSGPU_FF_ORDER=0: the caller's order.
+    std::vector<int> order(n_utt);
+    for (int i = 0; i < n_utt; ++i) order[i] = i;
+    {
+        static const int want = [] { const char *e = getenv("PSGPU_FF_ORDER"); return e ? atoi(e) : 1; }();
+        int n_cu = 0;
+        if (want && n_utt > 2 && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && n_cu > 0 && n_utt > n_cu) {
+            std::vector<int> by(n_utt);
+            for (int i = 0; i < n_utt; ++i) by[i] = i;
+            std::stable_sort(by.begin(), by.end(), [&](int a, int b) { return res1[(size_t)a * 8] > res1[(size_t)b * 8]; });   // most entries first
+            // round 0: the n_cu largest, descending; the rest ascending, so that position n_cu + k (the second workgroup of the k-th compute
+            // unit) is the k-th smallest
+            for (int k = 0; k < n_cu; ++k) order[k] = by[k];
+            for (int k = n_cu; k < n_utt; ++k) order[k] = by[n_utt - 1 - (k - n_cu)];
+        }
+    }
+    for (int slot = 0; slot < n_utt; ++slot) {
+        const int i = order[slot];
         FfUtt u;
         memset(&u, 0, sizeof u);
         const FfVocab &v = voc[i];
@@ -1762,7 +1786,8 @@ static int ff_search(psgpu_fwdflat_t *m, const int16_t *senscr_dev, int64_t scr_
         u.cnt_a = take(cap + 1); u.cnt_b = take(cap + 1);
         u.nrow32 = raw ? take(d.n_sen) : nullptr;
         u.nrow = raw ? reinterpret_cast<int16_t *>(take((size_t)d.n_sen / 2 + 1)) : nullptr;
-        FfOff &o = ho[i];
+        FfOff &o = ho[slot];
+        o.utt = i; o.pad_ = 0;
 #define X(f) o.f = u.f - slab;
         FF_SLAB_FIELDS(X)
 #undef X
