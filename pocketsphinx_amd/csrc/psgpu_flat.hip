@@ -1,4 +1,4 @@
-// psgpu_flat.hip -- the flat-lexicon second pass on gfx950, first version: whole
+// psgpu_flat.hip -- the flat-lexicon second pass on gfx950: whole
 // utterances, one workgroup per utterance, every frame inside the kernel.
 //
 // Replaces ngram_fwdflat_start + ngram_fwdflat_search x T + ngram_fwdflat_finish (reference
@@ -9,12 +9,15 @@
 // with the float-weighted language score (:700-706), silence / filler entry, the next active word list.
 // Output: back-pointer table, score stack and frame marks in the reference's columns, as the first pass's kernel.
 //
-// Parallelism in this version: utterances across workgroups; inside a frame one work-item per active word
-// (a chain is short and its pruning is sequential along the chain by construction: a phone entered this frame
-// is looked at later in the same walk), one per vocabulary word for the word transitions (each loops over the
-// frame's exits in order, so "first best wins" is kept), workgroup prefix sums for back-pointer positions and the
-// next active word list (vocabulary order, then fillers: ngram_search_fwdflat.c:853-869).  The utterance's
-// vocabulary and chain layout are built on the host from the first pass's table (a few hundred entries) --
+// Parallelism: utterances across workgroups (two a compute unit; the host orders the launch so that the largest share a compute unit
+// with the smallest).  Inside a frame: the active channels gathered sixteen work-items a word; one work-item per
+// active CHANNEL for the evaluation and for the pruning's decision (a channel's entry state is written by its one predecessor only);
+// word exits queued in LDS, ranked by counting, a word's entry = the maximum of its exits' keys (the walk in queue order only where
+// their histories name different real words); word transitions one work-item per (word of the frame's window, new entry) PAIR, the
+// best pair of a word one 64-bit maximum ("the first best exit wins" = the earliest index among the highest scores); workgroup prefix
+// sums for back-pointer positions and the next active word list (vocabulary order, then fillers: ngram_search_fwdflat.c:853-869).
+// Barriers between phases that exchange through LDS only wait for the LDS counter (ff_sync_lds); where device memory crosses, a full
+// one.  The utterance's vocabulary and chain layout are built on the host from the first pass's table (host threads) --
 // build_fwdflat_wordlist's list surgery is sequential; an on-device build can replace it behind the same entry.
 // Oracle: oracle/ps_oracle_flat.c (pinned to the reference); checked on the CPU through tests/hostsim.
 #include "psgpu_hmm_dev.h"
